@@ -1,0 +1,716 @@
+"""ORACLE (test infrastructure only -- never imported by the product path).
+
+Dense primal-dual interior-point solve of the mpc_local_planner NLP.
+
+The reference hands its NLP to Ipopt (src/controller.cpp:388-421, UPSTREAM, not
+vendored, version unpinned).  This file restates Ipopt's *published* algorithm
+(Waechter & Biegler, Math. Prog. 106(1), 2006: log-barrier, primal-dual Newton
+on the perturbed KKT system, fraction-to-boundary rule, monotone
+Fiacco-McCormick barrier update, Hessian regularisation by a multiple of the
+identity) in a reduced form -- l1-merit backtracking instead of the filter, an
+inertia-free curvature test (Chiang & Zavala 2016) instead of inertia from the
+factorisation, no restoration phase -- with DENSE linear algebra (numpy.linalg)
+on the full KKT matrix.  The HIP product solves the same Newton systems with a
+stage-structured Riccati sweep; agreement of the two is the parity test.
+
+PARITY UNPINNED: no Ipopt here and no golden outputs in the reference; the
+solution is cross-checked against scipy (SLSQP / trust-constr) on the
+reference-form NLP of oracle/se2_nlp.py, and by KKT residuals.
+
+"Solver form" of the rows (same feasible set / same primal KKT points as the
+reference form, rows rescaled by positive factors):
+  equality   c_k = dt * F_k - [x_{k+1}-x_k, wrap(th_{k+1}-th_k)]  (= +dt * reference defect,
+             include/.../fd_collocation_se2.h:54-69)
+  rate rows  (u_k-u_{k-1}) - du_ub*dtp <= 0,  du_lb*dtp - (u_k-u_{k-1}) <= 0
+             (= dtp * reference rows, src/optimal_control/stage_inequality_se2.cpp:207-221;
+              dtp = dt for k>=1, the controller period for k=0, rows dropped for k=0 if dtp==0)
+  clearance  d_min - dist <= 0 (unchanged)
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import se2_nlp as R
+
+
+# --------------------------------------------------------------------------
+# model derivatives w.r.t. q = (theta, v, w)   (w = 2nd input)
+# --------------------------------------------------------------------------
+
+def model_derivs(model, p, th, v, w):
+    """Returns f (3,), G (3,3) = df_i/dq_j, H (3,3,3) = d2 f_i / dq_j dq_l."""
+    f = np.zeros(3)
+    G = np.zeros((3, 3))
+    H = np.zeros((3, 3, 3))
+    if model == R.MODEL_KINEMATIC_BICYCLE:
+        lr, lf = p[0], p[1]
+        kap = lr / (lf + lr)
+        t = math.tan(w)
+        tp = 1.0 + t * t
+        tpp = 2.0 * t * tp
+        den = 1.0 + kap * kap * t * t
+        beta = math.atan(kap * t)
+        bp = kap * tp / den
+        bpp = kap * (tpp * den - tp * 2.0 * kap * kap * t * tp) / (den * den)
+        c, s = math.cos(th + beta), math.sin(th + beta)
+        sb, cb = math.sin(beta), math.cos(beta)
+        f[:] = [v * c, v * s, v * sb / lr]
+        # f0 = v cos(th+beta)
+        G[0] = [-v * s, c, -v * s * bp]
+        G[1] = [v * c, s, v * c * bp]
+        G[2] = [0.0, sb / lr, v * cb * bp / lr]
+        H[0, 0, 0] = -v * c; H[0, 0, 1] = H[0, 1, 0] = -s
+        H[0, 0, 2] = H[0, 2, 0] = -v * c * bp
+        H[0, 1, 2] = H[0, 2, 1] = -s * bp
+        H[0, 2, 2] = -v * c * bp * bp - v * s * bpp
+        H[1, 0, 0] = -v * s; H[1, 0, 1] = H[1, 1, 0] = c
+        H[1, 0, 2] = H[1, 2, 0] = -v * s * bp
+        H[1, 1, 2] = H[1, 2, 1] = c * bp
+        H[1, 2, 2] = -v * s * bp * bp + v * c * bpp
+        H[2, 1, 2] = H[2, 2, 1] = cb * bp / lr
+        H[2, 2, 2] = v * (-sb * bp * bp + cb * bpp) / lr
+        return f, G, H
+    c, s = math.cos(th), math.sin(th)
+    f[0], f[1] = v * c, v * s
+    G[0, 0], G[0, 1] = -v * s, c
+    G[1, 0], G[1, 1] = v * c, s
+    H[0, 0, 0] = -v * c; H[0, 0, 1] = H[0, 1, 0] = -s
+    H[1, 0, 0] = -v * s; H[1, 0, 1] = H[1, 1, 0] = c
+    if model == R.MODEL_UNICYCLE:
+        f[2] = w
+        G[2, 2] = 1.0
+    elif model == R.MODEL_SIMPLE_CAR:
+        L = p[0]
+        t = math.tan(w)
+        tp = 1.0 + t * t
+        f[2] = v * t / L
+        G[2, 1] = t / L
+        G[2, 2] = v * tp / L
+        H[2, 1, 2] = H[2, 2, 1] = tp / L
+        H[2, 2, 2] = v * 2.0 * t * tp / L
+    elif model == R.MODEL_SIMPLE_CAR_FRONT:
+        L = p[0]
+        f[2] = v * math.sin(w) / L
+        G[2, 1] = math.sin(w) / L
+        G[2, 2] = v * math.cos(w) / L
+        H[2, 1, 2] = H[2, 2, 1] = math.cos(w) / L
+        H[2, 2, 2] = -v * math.sin(w) / L
+    else:
+        raise ValueError("model")
+    return f, G, H
+
+
+# --------------------------------------------------------------------------
+# point-footprint distance derivatives (analytic); other footprints: numeric
+# --------------------------------------------------------------------------
+
+def _closest_point_on_obstacle(pt, ob: R.Obstacle):
+    """closest point of the obstacle boundary/body to pt, and whether pt is inside (polygon)."""
+    v = np.asarray(ob.vertices, float)
+    if ob.kind in (R.OBST_POINT, R.OBST_CIRCLE) or len(v) == 1:
+        return v[0], False
+    if ob.kind == R.OBST_LINE or len(v) == 2:
+        segs = [(v[0], v[1])]
+        inside = False
+    else:
+        inside = R._point_in_polygon(pt, v)
+        segs = [(v[i], v[(i + 1) % len(v)]) for i in range(len(v))]
+    best, bd = None, float("inf")
+    for a, b in segs:
+        ab = b - a
+        sq = float(ab @ ab)
+        t = 0.0 if sq == 0 else min(1.0, max(0.0, float((pt - a) @ ab) / sq))
+        q = a + t * ab
+        d = float(np.linalg.norm(pt - q))
+        if d < bd:
+            bd, best = d, (q, t, ab)
+    return best, inside
+
+
+def clearance_row(cfg: R.OcpConfig, xk, ob: R.Obstacle, want_hess=True):
+    """value, gradient (3,), Hessian (3,3) of  d_min - dist(footprint(x_k), ob).
+    Point footprint: analytic.  Others: central differences (like corbo's edges)."""
+    if cfg.footprint_kind in (R.FOOTPRINT_POINT, R.FOOTPRINT_CIRCLE):
+        pt = np.asarray(xk[:2], float)
+        off = cfg.footprint_params[0] if cfg.footprint_kind == R.FOOTPRINT_CIRCLE else 0.0
+        cp, inside = _closest_point_on_obstacle(pt, ob)
+        g = np.zeros(3)
+        Hm = np.zeros((3, 3))
+        if inside:
+            return cfg.min_obstacle_dist + off, g, Hm
+        if isinstance(cp, tuple):
+            q, t, ab = cp
+            interior = 0.0 < t < 1.0
+        else:
+            q, interior = cp, False
+        dvec = pt - q
+        d = float(np.linalg.norm(dvec))
+        rad = ob.radius if ob.kind == R.OBST_CIRCLE else 0.0
+        val = cfg.min_obstacle_dist - (d - rad - off)
+        if d > 0:
+            nrm = dvec / d
+            g[:2] = -nrm
+            if not interior:
+                Hm[:2, :2] = -(np.eye(2) - np.outer(nrm, nrm)) / d
+        return val, g, Hm
+    # numeric (line / two-circle footprints)
+    def fun(x):
+        return cfg.min_obstacle_dist - R.footprint_distance(cfg.footprint_kind, cfg.footprint_params, x, ob)
+    h = 1e-6
+    x = np.asarray(xk, float)
+    val = fun(x)
+    g = np.zeros(3)
+    for i in range(3):
+        e = np.zeros(3); e[i] = h
+        g[i] = (fun(x + e) - fun(x - e)) / (2 * h)
+    Hm = np.zeros((3, 3))
+    if want_hess:
+        h2 = 1e-4
+        for i in range(3):
+            for j in range(i, 3):
+                ei = np.zeros(3); ei[i] = h2
+                ej = np.zeros(3); ej[j] = h2
+                Hm[i, j] = Hm[j, i] = (fun(x + ei + ej) - fun(x + ei - ej) - fun(x - ei + ej) + fun(x - ei - ej)) / (4 * h2 * h2)
+    return val, g, Hm
+
+
+# --------------------------------------------------------------------------
+# solver-form NLP with analytic first/second derivatives (forward differences)
+# --------------------------------------------------------------------------
+class SolverNlp:
+    """Variables kept as full arrays X (n,3), U (n-1,2), dt; the free ones are
+    indexed into a flat vector: [x_1 .. x_{n-2}, xf(free comps), u_0 .. u_{n-2}, dt(if free)]."""
+
+    def __init__(self, cfg: R.OcpConfig, inp: R.CycleInputs, relevant=None):
+        if cfg.collocation != R.COLLOC_FORWARD:
+            raise NotImplementedError("analytic solver form: forward differences only")
+        self.cfg, self.inp = cfg, inp
+        n = self.n = cfg.n
+        self.relevant = relevant if relevant is not None else [[] for _ in range(n)]
+        # index maps
+        self.ix = -np.ones((n, 3), int)
+        p = 0
+        for k in range(1, n - 1):
+            self.ix[k] = [p, p + 1, p + 2]
+            p += 3
+        for i in range(3):
+            if not cfg.xf_fixed[i]:
+                self.ix[n - 1, i] = p
+                p += 1
+        self.iu = np.zeros((n - 1, 2), int)
+        for k in range(n - 1):
+            self.iu[k] = [p, p + 1]
+            p += 2
+        self.idt = -1
+        if cfg.dt_free:
+            self.idt = p
+            p += 1
+        self.nv = p
+        self.theta_idx = [self.ix[k, 2] for k in range(n) if self.ix[k, 2] >= 0]
+        # bounds
+        self.lb = np.full(p, -R.INF)
+        self.ub = np.full(p, R.INF)
+        for k in range(n - 1):
+            self.lb[self.iu[k]] = cfg.u_lb
+            self.ub[self.iu[k]] = cfg.u_ub
+        if cfg.dt_free:
+            self.lb[self.idt], self.ub[self.idt] = cfg.dt_lb, cfg.dt_ub
+        # rate rows: list of (k, i, sign) with sign=+1 for upper row, -1 for lower row
+        self.rate_rows = []
+        ks = list(range(n))          # k = n-1 is the final row against u_ref = 0
+        for k in ks:
+            if k == 0 and inp.dt_prev == 0:
+                continue
+            for i in range(2):
+                if cfg.du_lb[i] > -R.INF:
+                    self.rate_rows.append((k, i, -1))
+            for i in range(2):
+                if cfg.du_ub[i] < R.INF:
+                    self.rate_rows.append((k, i, +1))
+        self.obst_rows = [(k, j) for k in range(1, n - 1) for j in self.relevant[k]]
+        self.mg = len(self.rate_rows) + len(self.obst_rows)
+        self.mc = 3 * (n - 1)
+
+    # ---- packing -----------------------------------------------------
+    def to_vec(self, t: R.Trajectory):
+        v = np.zeros(self.nv)
+        m = self.ix >= 0
+        v[self.ix[m]] = t.x[m]
+        v[self.iu.ravel()] = t.u.ravel()
+        if self.idt >= 0:
+            v[self.idt] = t.dt
+        return v
+
+    def to_traj(self, v) -> R.Trajectory:
+        n = self.n
+        x = np.zeros((n, 3))
+        x[0] = self.inp.x0
+        x[n - 1] = self.inp.xf
+        m = self.ix >= 0
+        x[m] = v[self.ix[m]]
+        u = v[self.iu.ravel()].reshape(n - 1, 2)
+        dt = v[self.idt] if self.idt >= 0 else self.cfg.dt_ref
+        return R.Trajectory(x, u, float(dt))
+
+    def retract(self, v, dv):
+        out = v + dv
+        out[self.theta_idx] = R.normalize_theta(out[self.theta_idx])
+        return out
+
+    # ---- evaluation --------------------------------------------------
+    def eval(self, v, lam=None, y=None, want_hess=False):
+        """returns dict(f, gf, c, Jc, g, Jg[, W])."""
+        cfg = self.cfg
+        n = self.n
+        t = self.to_traj(v)
+        X, U, dt = t.x, t.u, t.dt
+        nv = self.nv
+        gf = np.zeros(nv)
+        W = np.zeros((nv, nv)) if want_hess else None
+        xf = np.asarray(self.inp.xf, float)
+        # objective
+        if cfg.objective == R.OBJ_MIN_TIME:
+            f = (n - 1) * dt
+            if self.idt >= 0:
+                gf[self.idt] = n - 1
+        else:
+            f = 0.0
+            for k in range(n - 1):
+                xd = X[k] - xf
+                xd[2] = R.normalize_theta(xd[2])
+                sc = float(xd @ (cfg.Q * xd) + U[k] @ (cfg.R * U[k]))
+                w8 = dt if cfg.integral_form else 1.0
+                f += sc * w8
+                for i in range(3):
+                    if self.ix[k, i] >= 0:
+                        gf[self.ix[k, i]] += 2 * cfg.Q[i] * xd[i] * w8
+                        if want_hess:
+                            W[self.ix[k, i], self.ix[k, i]] += 2 * cfg.Q[i] * w8
+                            if cfg.integral_form and self.idt >= 0:
+                                W[self.ix[k, i], self.idt] += 2 * cfg.Q[i] * xd[i]
+                                W[self.idt, self.ix[k, i]] += 2 * cfg.Q[i] * xd[i]
+                for i in range(2):
+                    gf[self.iu[k, i]] += 2 * cfg.R[i] * U[k, i] * w8
+                    if want_hess:
+                        W[self.iu[k, i], self.iu[k, i]] += 2 * cfg.R[i] * w8
+                        if cfg.integral_form and self.idt >= 0:
+                            W[self.iu[k, i], self.idt] += 2 * cfg.R[i] * U[k, i]
+                            W[self.idt, self.iu[k, i]] += 2 * cfg.R[i] * U[k, i]
+                if cfg.integral_form and self.idt >= 0:
+                    gf[self.idt] += sc
+            if cfg.Qf is not None:
+                xd = X[n - 1] - xf
+                xd[2] = R.normalize_theta(xd[2])
+                for i in range(3):
+                    if self.ix[n - 1, i] >= 0:
+                        f += cfg.Qf[i] * xd[i] ** 2
+                        gf[self.ix[n - 1, i]] += 2 * cfg.Qf[i] * xd[i]
+                        if want_hess:
+                            W[self.ix[n - 1, i], self.ix[n - 1, i]] += 2 * cfg.Qf[i]
+        # equalities
+        c = np.zeros(self.mc)
+        Jc = np.zeros((self.mc, nv))
+        for k in range(n - 1):
+            fk, G, Hk = model_derivs(cfg.model, cfg.model_params, X[k, 2], U[k, 0], U[k, 1])
+            r = slice(3 * k, 3 * k + 3)
+            d = X[k + 1] - X[k]
+            d[2] = R.normalize_theta(d[2])
+            c[r] = dt * fk - d
+            qidx = [self.ix[k, 2], self.iu[k, 0], self.iu[k, 1]]
+            for a in range(3):
+                row = 3 * k + a
+                if self.ix[k, a] >= 0:
+                    Jc[row, self.ix[k, a]] += 1.0
+                if self.ix[k + 1, a] >= 0:
+                    Jc[row, self.ix[k + 1, a]] -= 1.0
+                for j, qi in enumerate(qidx):
+                    if qi >= 0:
+                        Jc[row, qi] += dt * G[a, j]
+                if self.idt >= 0:
+                    Jc[row, self.idt] += fk[a]
+            if want_hess and lam is not None:
+                lk = lam[r]
+                Hq = dt * np.einsum("a,ajl->jl", lk, Hk)
+                gq = lk @ G       # d/dq of lam^T f  -> cross term with dt
+                for j, qj in enumerate(qidx):
+                    if qj < 0:
+                        continue
+                    for l, ql in enumerate(qidx):
+                        if ql >= 0:
+                            W[qj, ql] += Hq[j, l]
+                    if self.idt >= 0:
+                        W[qj, self.idt] += gq[j]
+                        W[self.idt, qj] += gq[j]
+        # inequalities
+        g = np.zeros(self.mg)
+        Jg = np.zeros((self.mg, nv))
+        r = 0
+        for (k, i, sg) in self.rate_rows:
+            uk = U[k, i] if k < n - 1 else 0.0
+            up = U[k - 1, i] if k > 0 else self.inp.u_prev[i]
+            dtp = dt if k > 0 else self.inp.dt_prev
+            lim = cfg.du_ub[i] if sg > 0 else cfg.du_lb[i]
+            g[r] = sg * ((uk - up) - lim * dtp)
+            if k < n - 1:
+                Jg[r, self.iu[k, i]] += sg
+            if k > 0:
+                Jg[r, self.iu[k - 1, i]] -= sg
+                if self.idt >= 0:
+                    Jg[r, self.idt] -= sg * lim
+            r += 1
+        for (k, j) in self.obst_rows:
+            val, gr, Hm = clearance_row(cfg, X[k], self.inp.obstacles[j], want_hess)
+            g[r] = val
+            Jg[r, self.ix[k]] = gr
+            if want_hess and y is not None:
+                W[np.ix_(self.ix[k], self.ix[k])] += y[r] * Hm
+            r += 1
+        out = dict(f=f, gf=gf, c=c, Jc=Jc, g=g, Jg=Jg)
+        if want_hess:
+            out["W"] = W
+        return out
+
+
+# --------------------------------------------------------------------------
+# interior-point method
+# --------------------------------------------------------------------------
+@dataclass
+class IpmOptions:
+    tol: float = 1e-8
+    max_iter: int = 200
+    mu_init: float = 0.1
+    kappa_eps: float = 10.0
+    kappa_mu: float = 0.2
+    theta_mu: float = 1.5
+    tau_min: float = 0.99
+    bound_push: float = 1e-2
+    slack_push: float = 1e-2
+    eta_armijo: float = 1e-4
+    rho_frac: float = 0.1
+    delta_first: float = 1e-4
+    delta_min: float = 1e-20
+    delta_max: float = 1e20
+    kappa_plus: float = 8.0
+    kappa_plus_first: float = 100.0
+    kappa_minus: float = 1.0 / 3.0
+    curv_kappa: float = 1e-10
+    s_max: float = 100.0
+    max_ls: int = 30
+    delta_c: float = 1e-8
+    init_controls: bool = True
+    globalization: str = "filter"
+    filter_cap: int = 16
+    mu_strategy: str = "monotone"
+    kappa_c: float = 0.25
+    verbose: bool = False
+
+
+@dataclass
+class IpmResult:
+    traj: R.Trajectory
+    status: int          # 0 converged, 1 max-iter, 2 line-search failure, 3 linear-solve failure
+    iters: int
+    kkt_error: float
+    objective: float
+    lam: np.ndarray
+    y: np.ndarray
+    history: list
+
+
+def controls_from_states(cfg: R.OcpConfig, init: R.Trajectory) -> R.Trajectory:
+    """Solver-side preprocessing of the reference's cold start (u = 0,
+    ...grid_base_se2.cpp:218-224): u = 0 is a point where the car-like models lose
+    rank (v = 0 => no steering authority), so when ALL controls are zero the solver
+    seeds them from the state guess: v_k = forward-difference speed projected on the
+    heading, w_k from the heading rate, both clipped to the box."""
+    if np.any(init.u != 0.0):
+        return init
+    t = init.copy()
+    n = t.x.shape[0]
+    for k in range(n - 1):
+        d = t.x[k + 1] - t.x[k]
+        dth = float(R.normalize_theta(d[2]))
+        th = t.x[k, 2]
+        v = (d[0] * math.cos(th) + d[1] * math.sin(th)) / t.dt
+        v = min(max(v, cfg.u_lb[0]), cfg.u_ub[0])
+        rate = dth / t.dt
+        if cfg.model == R.MODEL_UNICYCLE:
+            w = rate
+        else:
+            vv = v if abs(v) > 1e-3 else (1e-3 if v >= 0 else -1e-3)
+            if cfg.model == R.MODEL_SIMPLE_CAR:
+                w = math.atan(cfg.model_params[0] * rate / vv)
+            elif cfg.model == R.MODEL_SIMPLE_CAR_FRONT:
+                w = math.asin(min(1.0, max(-1.0, cfg.model_params[0] * rate / vv)))
+            else:
+                lr, lf = cfg.model_params
+                sb = min(1.0, max(-1.0, lr * rate / vv))
+                w = math.atan(math.tan(math.asin(sb)) * (lf + lr) / lr)
+        w = min(max(w, cfg.u_lb[1]), cfg.u_ub[1])
+        t.u[k] = [v, w]
+    return t
+
+
+def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=None,
+          opt: Optional[IpmOptions] = None) -> IpmResult:
+    opt = opt or IpmOptions()
+    nlp = SolverNlp(cfg, inp, relevant)
+    nv, mc, mg = nlp.nv, nlp.mc, nlp.mg
+    lb, ub = nlp.lb, nlp.ub
+    hasL = lb > -R.INF
+    hasU = ub < R.INF
+
+    if opt.init_controls:
+        init = controls_from_states(cfg, init)
+    v = nlp.to_vec(init)
+    # push into the interior of the box (Ipopt bound_push / bound_frac, sec. 3.6)
+    for i in range(nv):
+        if hasL[i] and hasU[i]:
+            pl = min(opt.bound_push * max(1.0, abs(lb[i])), opt.bound_push * (ub[i] - lb[i]))
+            pu = min(opt.bound_push * max(1.0, abs(ub[i])), opt.bound_push * (ub[i] - lb[i]))
+            v[i] = min(max(v[i], lb[i] + pl), ub[i] - pu)
+    mu = opt.mu_init
+    ev = nlp.eval(v)
+    s = np.maximum(-ev["g"], opt.slack_push)
+    y = mu / s
+    lam = np.zeros(mc)
+    piL = np.where(hasL, mu / np.maximum(v - lb, 1e-300), 0.0)
+    piU = np.where(hasU, mu / np.maximum(ub - v, 1e-300), 0.0)
+    delta_last = 0.0
+    rho = 0.0
+    nfix_term = sum(cfg.xf_fixed)
+    theta0 = None
+    filt = []
+    nrest = 0
+    history = []
+    status = 1
+    it = 0
+
+    def kkt_err(ev, v, s, lam, y, piL, piU, mu_t):
+        rd = ev["gf"] + ev["Jc"].T @ lam + ev["Jg"].T @ y - piL + piU
+        rp = max(np.abs(ev["c"]).max(initial=0.0), np.abs(ev["g"] + s).max(initial=0.0))
+        comp = 0.0
+        if mg:
+            comp = max(comp, np.abs(s * y - mu_t).max())
+        if hasL.any():
+            comp = max(comp, np.abs((v - lb)[hasL] * piL[hasL] - mu_t).max())
+        if hasU.any():
+            comp = max(comp, np.abs((ub - v)[hasU] * piU[hasU] - mu_t).max())
+        nm = mc + mg + hasL.sum() + hasU.sum()
+        sd = max(opt.s_max, (np.abs(lam).sum() + np.abs(y).sum() + piL.sum() + piU.sum()) / max(nm, 1)) / opt.s_max
+        nz = mg + hasL.sum() + hasU.sum()
+        sc = max(opt.s_max, (np.abs(y).sum() + piL.sum() + piU.sum()) / max(nz, 1)) / opt.s_max
+        return max(np.abs(rd).max() / sd, rp, comp / sc)
+
+    def barrier_obj(f, v, s, mu):
+        val = f
+        if mg:
+            val -= mu * np.log(s).sum()
+        val -= mu * np.log((v - lb)[hasL]).sum()
+        val -= mu * np.log((ub - v)[hasU]).sum()
+        return val
+
+    while it < opt.max_iter:
+        ev = nlp.eval(v, lam, y, want_hess=True)
+        e0 = kkt_err(ev, v, s, lam, y, piL, piU, 0.0)
+        if e0 <= opt.tol:
+            status = 0
+            break
+        # barrier update
+        if opt.mu_strategy == "monotone":
+            while True:
+                emu = kkt_err(ev, v, s, lam, y, piL, piU, mu)
+                if emu <= opt.kappa_eps * mu and mu > opt.tol / 10.0:
+                    mu = max(opt.tol / 10.0, min(opt.kappa_mu * mu, mu ** opt.theta_mu))
+                    rho = 0.0
+                    filt.clear()
+                else:
+                    break
+        else:
+            # LOQO rule (Vanderbei & Shanno 1999), as in Ipopt's mu_oracle=loqo
+            comp = []
+            if mg:
+                comp.append(s * y)
+            comp.append(((v - lb) * piL)[hasL])
+            comp.append(((ub - v) * piU)[hasU])
+            comp = np.concatenate(comp)
+            avg = comp.mean()
+            xi = comp.min() / avg
+            sig = 0.1 * min(0.05 * (1 - xi) / xi, 2.0) ** 3
+            mu_new = min(max(sig * avg, opt.tol / 10.0), 1e3)
+            if mu_new != mu:
+                mu = mu_new
+                rho = 0.0
+                filt.clear()
+        tau = max(opt.tau_min, 1.0 - mu)
+        W, Jc, Jg, c, g, gf = ev["W"], ev["Jc"], ev["Jg"], ev["c"], ev["g"], ev["gf"]
+        dL = np.where(hasL, v - lb, 1.0)
+        dU = np.where(hasU, ub - v, 1.0)
+        SigZ = np.where(hasL, piL / dL, 0.0) + np.where(hasU, piU / dU, 0.0)
+        SigS = y / s
+        # gradient of the barrier function wrt z (no multipliers of c, g)
+        gphi = gf - np.where(hasL, mu / dL, 0.0) + np.where(hasU, mu / dU, 0.0)
+        rg = g + s
+        # condensed rhs: y+ = mu/s + SigS*(g+s) + SigS*Jg dz
+        ybar = mu / s + SigS * rg
+        Hc = W + np.diag(SigZ) + Jg.T @ (SigS[:, None] * Jg)
+        rhs1 = -(gphi + Jg.T @ ybar)
+        rhs = np.concatenate([rhs1, -c])
+        # regularisation loop with inertia-free curvature test
+        delta = 0.0
+        ok = False
+        ntry = 0
+        while True:
+            K = np.zeros((nv + mc, nv + mc))
+            K[:nv, :nv] = Hc + delta * np.eye(nv)
+            K[:nv, nv:] = Jc.T
+            K[nv:, :nv] = Jc
+            if opt.delta_c > 0 and nfix_term:
+                dc = opt.delta_c * mu ** opt.kappa_c
+                for a in range(3):
+                    if cfg.xf_fixed[a]:
+                        K[nv + mc - 3 + a, nv + mc - 3 + a] = -dc
+            try:
+                sol = np.linalg.solve(K, rhs)
+                good = np.all(np.isfinite(sol))
+            except np.linalg.LinAlgError:
+                good = False
+            if good:
+                dz = sol[:nv]
+                curv = dz @ ((Hc + delta * np.eye(nv)) @ dz)
+                if curv >= opt.curv_kappa * (dz @ dz):
+                    ok = True
+                    break
+            # increase delta
+            if delta == 0.0:
+                delta = opt.delta_first if delta_last == 0.0 else max(opt.delta_min, opt.kappa_minus * delta_last)
+            else:
+                delta *= opt.kappa_plus_first if delta_last == 0.0 else opt.kappa_plus
+            ntry += 1
+            if delta > opt.delta_max or ntry > 40:
+                break
+        if not ok:
+            status = 3
+            break
+        if delta > 0:
+            delta_last = delta
+        lam_new = sol[nv:]
+        ds = -rg - Jg @ dz
+        y_new = ybar + SigS * (Jg @ dz)
+        dy = y_new - y
+        dpiL = np.where(hasL, mu / dL - piL - (piL / dL) * dz, 0.0)
+        dpiU = np.where(hasU, mu / dU - piU + (piU / dU) * dz, 0.0)
+
+        # fraction to the boundary
+        def max_step(val, dval, tau):
+            neg = dval < 0
+            if not neg.any():
+                return 1.0
+            return min(1.0, float((-tau * val[neg] / dval[neg]).min()))
+        a_p = 1.0
+        if hasL.any():
+            a_p = min(a_p, max_step(dL[hasL], dz[hasL], tau))
+        if hasU.any():
+            a_p = min(a_p, max_step(dU[hasU], -dz[hasU], tau))
+        if mg:
+            a_p = min(a_p, max_step(s, ds, tau))
+        a_d = 1.0
+        if mg:
+            a_d = min(a_d, max_step(y, dy, tau))
+        if hasL.any():
+            a_d = min(a_d, max_step(piL[hasL], dpiL[hasL], tau))
+        if hasU.any():
+            a_d = min(a_d, max_step(piU[hasU], dpiU[hasU], tau))
+
+        theta = np.abs(c).sum() + np.abs(rg).sum()
+        dphi = gphi @ dz - (mu / s) @ ds if mg else gphi @ dz
+        phi_cur = barrier_obj(ev["f"], v, s, mu)
+        if theta0 is None:
+            theta0 = theta
+            theta_max = 1e4 * max(1.0, theta0)
+            theta_min = 1e-4 * max(1.0, theta0)
+        alpha = a_p
+        accepted = False
+        if opt.globalization == "merit":
+            curv_full = dz @ (Hc @ dz) + delta * (dz @ dz)
+            if theta > 0:
+                sigma = 1.0 if curv_full > 0 else 0.0
+                rho_trial = (dphi + 0.5 * sigma * curv_full) / ((1.0 - opt.rho_frac) * theta)
+                if rho < rho_trial:
+                    rho = rho_trial + 1.0
+            phi0 = phi_cur + rho * theta
+            D = dphi - rho * theta
+            for ls in range(opt.max_ls):
+                vt = nlp.retract(v, alpha * dz)
+                st = s + alpha * ds
+                evt = nlp.eval(vt)
+                tht = np.abs(evt["c"]).sum() + np.abs(evt["g"] + st).sum()
+                phit = barrier_obj(evt["f"], vt, st, mu) + rho * tht
+                if np.isfinite(phit) and phit <= phi0 + opt.eta_armijo * alpha * D:
+                    accepted = True
+                    break
+                alpha *= 0.5
+        else:
+            # Ipopt filter line search (Waechter & Biegler 2006, Alg. A, steps A-5.*), no SOC / restoration
+            g_th, g_ph, s_ph, s_th, eta_ph, dlt = 1e-5, 1e-5, 2.3, 1.1, 1e-8, 1.0
+            for ls in range(opt.max_ls):
+                vt = nlp.retract(v, alpha * dz)
+                st = s + alpha * ds
+                evt = nlp.eval(vt)
+                tht = np.abs(evt["c"]).sum() + np.abs(evt["g"] + st).sum()
+                phit = barrier_obj(evt["f"], vt, st, mu)
+                ok_t = np.isfinite(phit) and tht <= theta_max
+                if ok_t:
+                    for (fth, fph) in filt:
+                        if not (tht < fth or phit < fph):
+                            ok_t = False
+                            break
+                switching = dphi < 0 and alpha * (-dphi) ** s_ph > dlt * theta ** s_th
+                armijo = phit <= phi_cur + eta_ph * alpha * dphi
+                if ok_t:
+                    if theta <= theta_min and switching:
+                        if armijo:
+                            accepted = True
+                    else:
+                        if tht <= (1 - g_th) * theta or phit <= phi_cur - g_ph * theta:
+                            accepted = True
+                if accepted:
+                    if not (switching and armijo):
+                        filt.append(((1 - g_th) * theta, phi_cur - g_ph * theta))
+                        if len(filt) > opt.filter_cap:
+                            filt.pop(0)
+                    break
+                alpha *= 0.5
+            if not accepted:
+                # no restoration phase: clear the filter and take the shortest trial step
+                filt.clear()
+                nrest += 1
+        if not accepted:
+            if alpha * np.abs(dz).max() < 1e-14:
+                status = 2
+                break
+        v, s = vt, st
+        lam = lam + alpha * (lam_new - lam)
+        y = y + a_d * dy
+        piL = piL + a_d * dpiL
+        piU = piU + a_d * dpiU
+        # keep bound multipliers in the Ipopt safeguard band (eq. 16)
+        kS = 1e10
+        if mg:
+            y = np.minimum(np.maximum(y, mu / (kS * s)), kS * mu / s)
+        dLn = np.where(hasL, v - lb, 1.0)
+        dUn = np.where(hasU, ub - v, 1.0)
+        piL = np.where(hasL, np.minimum(np.maximum(piL, mu / (kS * dLn)), kS * mu / dLn), 0.0)
+        piU = np.where(hasU, np.minimum(np.maximum(piU, mu / (kS * dUn)), kS * mu / dUn), 0.0)
+        it += 1
+        history.append(dict(it=it, mu=mu, e0=e0, theta=theta, alpha=alpha, a_d=a_d, delta=delta, rho=rho, ls=ls, f=ev["f"]))
+        if opt.verbose:
+            print(f"{it:3d} f={ev['f']:.6f} e0={e0:.2e} mu={mu:.1e} th={theta:.2e} a={alpha:.3f} ad={a_d:.3f} dl={delta:.1e} ls={ls} rho={rho:.2e}")
+
+    ev = nlp.eval(v, lam, y)
+    e0 = kkt_err(ev, v, s, lam, y, piL, piU, 0.0)
+    return IpmResult(nlp.to_traj(v), status, it, e0, ev["f"], lam, y, history)

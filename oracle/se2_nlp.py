@@ -1,0 +1,733 @@
+"""ORACLE (test infrastructure only -- never imported by the product path).
+
+numpy restatement of the NLP that rst-tu-dortmund/mpc_local_planner hands to its
+solver every control cycle, in the REFERENCE's own form (row definitions, signs,
+variable order).  Every function cites the reference file:line it follows
+(paths relative to /root/reference/mpc_local_planner/).
+
+PARITY UNPINNED: the reference ships no tests / golden outputs and its solver
+stack (control_box_rst, Ipopt, MUMPS, teb_local_planner) is not vendored, so
+this restatement cannot be checked against reference outputs in this container.
+It is pinned only against the reference *sources* (formulas) and against
+independent solvers (scipy) on the same NLP.
+
+Conventions
+-----------
+state  x = [x, y, theta]           (include/.../systems/base_robot_se2.h:57)
+control u = [v, omega|phi]         (2 inputs for every model)
+grid   n points, n-1 intervals, ONE global dt
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+INF = 1e30  # stand-in for corbo::CORBO_INF_DBL
+
+# --------------------------------------------------------------------------
+# math utils                                   include/.../utils/math_utils.h
+# --------------------------------------------------------------------------
+
+def normalize_theta(theta):
+    """math_utils.h:81-91 -- wrap to [-pi, pi)."""
+    theta = np.asarray(theta, dtype=float)
+    out = theta.copy()
+    mask = ~((theta >= -math.pi) & (theta < math.pi))
+    if np.any(mask):
+        t = theta[mask]
+        mult = np.floor(t / (2.0 * math.pi))
+        t = t - mult * 2.0 * math.pi
+        t = np.where(t >= math.pi, t - 2.0 * math.pi, t)
+        t = np.where(t < -math.pi, t + 2.0 * math.pi, t)
+        out[mask] = t
+    return out if out.ndim else float(out)
+
+
+def interpolate_angle(a1, a2, factor):
+    """math_utils.h:100-103."""
+    return normalize_theta(a1 + factor * normalize_theta(a2 - a1))
+
+
+def cross2d(v1, v2):
+    """math_utils.h:71-74."""
+    return v1[0] * v2[1] - v2[0] * v1[1]
+
+
+# --------------------------------------------------------------------------
+# robot models                                  include/.../systems/*.h
+# --------------------------------------------------------------------------
+MODEL_UNICYCLE = 0
+MODEL_SIMPLE_CAR = 1
+MODEL_SIMPLE_CAR_FRONT = 2
+MODEL_KINEMATIC_BICYCLE = 3
+
+
+def dynamics(model: int, p: Sequence[float], x, u):
+    """Continuous-time f(x,u).
+
+    unicycle            unicycle_robot.h:59-68        f = [v cos th, v sin th, w]
+    simple_car          simple_car.h:68-77            f = [v cos th, v sin th, v tan(phi)/L]
+    simple_car (front)  simple_car.h:131-141          f = [v cos th, v sin th, v sin(phi)/L]
+    kinematic bicycle   kinematic_bicycle_model.h:65-77
+    p = (L,) for the car models, (lr, lf) for the bicycle.
+    Vectorised over leading axes of x (.., 3) / u (.., 2).
+    """
+    x = np.asarray(x, float)
+    u = np.asarray(u, float)
+    th = x[..., 2]
+    v = u[..., 0]
+    f = np.empty(np.broadcast(x[..., 0], v).shape + (3,))
+    if model == MODEL_UNICYCLE:
+        f[..., 0] = v * np.cos(th)
+        f[..., 1] = v * np.sin(th)
+        f[..., 2] = u[..., 1]
+    elif model == MODEL_SIMPLE_CAR:
+        f[..., 0] = v * np.cos(th)
+        f[..., 1] = v * np.sin(th)
+        f[..., 2] = v * np.tan(u[..., 1]) / p[0]
+    elif model == MODEL_SIMPLE_CAR_FRONT:
+        f[..., 0] = v * np.cos(th)
+        f[..., 1] = v * np.sin(th)
+        f[..., 2] = v * np.sin(u[..., 1]) / p[0]
+    elif model == MODEL_KINEMATIC_BICYCLE:
+        lr, lf = p[0], p[1]
+        beta = np.arctan(lr / (lf + lr) * np.tan(u[..., 1]))
+        f[..., 0] = v * np.cos(th + beta)
+        f[..., 1] = v * np.sin(th + beta)
+        f[..., 2] = v * np.sin(beta) / lr
+    else:
+        raise ValueError("unknown model")
+    return f
+
+
+# --------------------------------------------------------------------------
+# collocation                     include/.../optimal_control/fd_collocation_se2.h
+# --------------------------------------------------------------------------
+COLLOC_FORWARD = 0
+COLLOC_MIDPOINT = 1
+COLLOC_CRANK_NICOLSON = 2
+
+
+def collocation_defect(method: int, model: int, p, x1, u1, x2, dt):
+    """Equality rows of one FDCollocationEdge (x1,u1,x2,dt) -> 3.
+
+    forward          fd_collocation_se2.h:54-69
+    midpoint         fd_collocation_se2.h:91-108
+    crank-nicolson   fd_collocation_se2.h:130-147
+    """
+    x1 = np.asarray(x1, float)
+    x2 = np.asarray(x2, float)
+    quot = np.empty(np.broadcast(x1, x2).shape)
+    quot[..., :2] = (x2[..., :2] - x1[..., :2]) / np.asarray(dt)[..., None] if np.ndim(dt) else (x2[..., :2] - x1[..., :2]) / dt
+    quot[..., 2] = normalize_theta(x2[..., 2] - x1[..., 2]) / dt
+    if method == COLLOC_FORWARD:
+        return dynamics(model, p, x1, u1) - quot
+    if method == COLLOC_MIDPOINT:
+        mid = 0.5 * (x1 + x2)
+        mid[..., 2] = interpolate_angle(x1[..., 2], x2[..., 2], 0.5)
+        return dynamics(model, p, mid, u1) - quot
+    if method == COLLOC_CRANK_NICOLSON:
+        f1 = dynamics(model, p, x1, u1)
+        f2 = dynamics(model, p, x2, u1)
+        # error = f2; error -= quot - 0.5*(f1+error)   (fd_collocation_se2.h:139-141)
+        return f2 - (quot - 0.5 * (f1 + f2))
+    raise ValueError("unknown collocation method")
+
+
+# --------------------------------------------------------------------------
+# footprint <-> obstacle distances (teb_local_planner semantics, UPSTREAM;
+# call sites src/optimal_control/stage_inequality_se2.cpp:109,173,187)
+# --------------------------------------------------------------------------
+OBST_POINT = 0
+OBST_CIRCLE = 1
+OBST_LINE = 2
+OBST_POLYGON = 3
+
+FOOTPRINT_POINT = 0
+FOOTPRINT_CIRCLE = 1
+FOOTPRINT_LINE = 2
+FOOTPRINT_TWO_CIRCLES = 3
+
+
+@dataclass
+class Obstacle:
+    kind: int
+    vertices: np.ndarray            # (V,2): 1 for point/circle, 2 for line, V for polygon
+    radius: float = 0.0
+    velocity: Optional[np.ndarray] = None   # centroid velocity (dynamic obstacles)
+
+    def centroid(self) -> np.ndarray:
+        """teb Obstacle::getCentroid (used at stage_inequality_se2.cpp:121).
+        point/circle: the point; line: midpoint; polygon: area centroid
+        (vertex mean for degenerate polygons)."""
+        v = np.asarray(self.vertices, float)
+        if self.kind in (OBST_POINT, OBST_CIRCLE):
+            return v[0]
+        if self.kind == OBST_LINE:
+            return 0.5 * (v[0] + v[1])
+        if len(v) < 3:
+            return v.mean(axis=0)
+        x, y = v[:, 0], v[:, 1]
+        xn, yn = np.roll(x, -1), np.roll(y, -1)
+        cr = x * yn - xn * y
+        a = 0.5 * cr.sum()
+        if abs(a) < 1e-12:
+            return v.mean(axis=0)
+        return np.array([((x + xn) * cr).sum(), ((y + yn) * cr).sum()]) / (6.0 * a)
+
+
+def _dist_point_segment(pt, a, b):
+    ab = b - a
+    sq = float(ab @ ab)
+    if sq == 0.0:
+        return float(np.linalg.norm(pt - a))
+    t = float((pt - a) @ ab) / sq
+    t = min(1.0, max(0.0, t))
+    return float(np.linalg.norm(pt - (a + t * ab)))
+
+
+def _segments_intersect(a, b, c, d):
+    def orient(p, q, r):
+        return (q[0] - p[0]) * (r[1] - p[1]) - (q[1] - p[1]) * (r[0] - p[0])
+    o1, o2, o3, o4 = orient(a, b, c), orient(a, b, d), orient(c, d, a), orient(c, d, b)
+    return (o1 * o2 < 0) and (o3 * o4 < 0)
+
+
+def _dist_segment_segment(a, b, c, d):
+    if _segments_intersect(a, b, c, d):
+        return 0.0
+    return min(_dist_point_segment(a, c, d), _dist_point_segment(b, c, d),
+               _dist_point_segment(c, a, b), _dist_point_segment(d, a, b))
+
+
+def _point_in_polygon(pt, verts):
+    inside = False
+    n = len(verts)
+    j = n - 1
+    for i in range(n):
+        xi, yi = verts[i]
+        xj, yj = verts[j]
+        if ((yi > pt[1]) != (yj > pt[1])) and (pt[0] < (xj - xi) * (pt[1] - yi) / (yj - yi) + xi):
+            inside = not inside
+        j = i
+    return inside
+
+
+def _dist_point_obstacle(pt, ob: Obstacle):
+    v = np.asarray(ob.vertices, float)
+    if ob.kind == OBST_POINT:
+        return float(np.linalg.norm(pt - v[0]))
+    if ob.kind == OBST_CIRCLE:
+        return float(np.linalg.norm(pt - v[0])) - ob.radius
+    if ob.kind == OBST_LINE:
+        return _dist_point_segment(pt, v[0], v[1])
+    # polygon: 0 inside, else min over closed edge loop
+    if len(v) == 1:
+        return float(np.linalg.norm(pt - v[0]))
+    if len(v) == 2:
+        return _dist_point_segment(pt, v[0], v[1])
+    if _point_in_polygon(pt, v):
+        return 0.0
+    return min(_dist_point_segment(pt, v[i], v[(i + 1) % len(v)]) for i in range(len(v)))
+
+
+def _dist_segment_obstacle(a, b, ob: Obstacle):
+    v = np.asarray(ob.vertices, float)
+    if ob.kind == OBST_POINT:
+        return _dist_point_segment(v[0], a, b)
+    if ob.kind == OBST_CIRCLE:
+        return _dist_point_segment(v[0], a, b) - ob.radius
+    if ob.kind == OBST_LINE:
+        return _dist_segment_segment(a, b, v[0], v[1])
+    if len(v) == 1:
+        return _dist_point_segment(v[0], a, b)
+    if len(v) == 2:
+        return _dist_segment_segment(a, b, v[0], v[1])
+    if _point_in_polygon(a, v) or _point_in_polygon(b, v):
+        return 0.0
+    return min(_dist_segment_segment(a, b, v[i], v[(i + 1) % len(v)]) for i in range(len(v)))
+
+
+def footprint_distance(fp_kind: int, fp_params: Sequence[float], pose, ob: Obstacle, t: float = 0.0):
+    """teb RobotFootprintModel::calculateDistance / estimateSpatioTemporalDistance
+    (UPSTREAM semantics): unsigned minimum Euclidean distance between the footprint
+    placed at `pose` and the obstacle (moved by t*velocity for the dynamic variant).
+
+    point       fp_params = ()
+    circle      fp_params = (radius,)
+    line        fp_params = (sx, sy, ex, ey) in the robot frame
+    two circles fp_params = (front_offset, front_radius, rear_offset, rear_radius)
+    """
+    if t != 0.0 and ob.velocity is not None:
+        ob = Obstacle(ob.kind, np.asarray(ob.vertices, float) + t * np.asarray(ob.velocity, float), ob.radius, ob.velocity)
+    pos = np.asarray(pose[:2], float)
+    th = float(pose[2])
+    c, s = math.cos(th), math.sin(th)
+    if fp_kind == FOOTPRINT_POINT:
+        return _dist_point_obstacle(pos, ob)
+    if fp_kind == FOOTPRINT_CIRCLE:
+        return _dist_point_obstacle(pos, ob) - fp_params[0]
+    if fp_kind == FOOTPRINT_LINE:
+        sx, sy, ex, ey = fp_params
+        a = pos + np.array([c * sx - s * sy, s * sx + c * sy])
+        b = pos + np.array([c * ex - s * ey, s * ex + c * ey])
+        return _dist_segment_obstacle(a, b, ob)
+    if fp_kind == FOOTPRINT_TWO_CIRCLES:
+        fo, fr, ro, rr = fp_params
+        d = np.array([c, s])
+        return min(_dist_point_obstacle(pos + fo * d, ob) - fr, _dist_point_obstacle(pos - ro * d, ob) - rr)
+    raise ValueError("unknown footprint")
+
+
+# --------------------------------------------------------------------------
+# OCP description = the parameter set of src/controller.cpp:225-805
+# --------------------------------------------------------------------------
+OBJ_MIN_TIME = 0
+OBJ_QUADRATIC = 1
+
+
+@dataclass
+class OcpConfig:
+    model: int = MODEL_UNICYCLE
+    model_params: Tuple[float, ...] = (0.5,)
+    n: int = 20                                   # grid/grid_size_ref  (controller.cpp:274)
+    dt_ref: float = 0.3                           # grid/dt_ref         (controller.cpp:278)
+    dt_free: bool = True                          # grid/variable_grid/enable (:236)
+    dt_lb: float = 0.0                            # :242
+    dt_ub: float = 10.0                           # :244
+    xf_fixed: Tuple[bool, bool, bool] = (True, True, True)   # :282
+    collocation: int = COLLOC_FORWARD             # :298
+    objective: int = OBJ_MIN_TIME                 # :551
+    Q: np.ndarray = field(default_factory=lambda: np.zeros(3))     # diagonal state weights
+    R: np.ndarray = field(default_factory=lambda: np.zeros(2))     # diagonal control weights
+    integral_form: bool = False
+    Qf: Optional[np.ndarray] = None               # terminal_cost quadratic (diag) or None
+    u_lb: np.ndarray = field(default_factory=lambda: np.array([-0.2, -0.3]))
+    u_ub: np.ndarray = field(default_factory=lambda: np.array([0.4, 0.3]))
+    du_lb: np.ndarray = field(default_factory=lambda: np.array([-INF, -INF]))
+    du_ub: np.ndarray = field(default_factory=lambda: np.array([INF, INF]))
+    # collision avoidance (controller.cpp:717-729)
+    min_obstacle_dist: float = 0.5
+    force_inclusion_dist: float = 0.5
+    cutoff_dist: float = 2.0
+    enable_dynamic_obstacles: bool = False
+    footprint_kind: int = FOOTPRINT_POINT
+    footprint_params: Tuple[float, ...] = ()
+
+
+def config_carlike_min_time(n: int = 50) -> OcpConfig:
+    """BASELINE.json config 2 / ex cfg/carlike/mpc_local_planner_params.yaml:7-16,46-65."""
+    return OcpConfig(model=MODEL_SIMPLE_CAR, model_params=(0.4,), n=n, dt_ref=0.3, dt_free=True,
+                     dt_lb=0.0, dt_ub=10.0, xf_fixed=(True, True, True), objective=OBJ_MIN_TIME,
+                     u_lb=np.array([-0.2, -1.4]), u_ub=np.array([0.4, 1.4]),
+                     du_lb=np.array([-0.5, -0.5]), du_ub=np.array([0.5, 0.5]))
+
+
+def config_unicycle_quadratic(n: int = 20) -> OcpConfig:
+    """BASELINE.json config 1 / ex cfg/diff_drive/mpc_local_planner_params_quadratic_form.yaml."""
+    return OcpConfig(model=MODEL_UNICYCLE, model_params=(), n=n, dt_ref=0.3, dt_free=False,
+                     xf_fixed=(False, False, False), objective=OBJ_QUADRATIC,
+                     Q=np.array([2.0, 2.0, 0.25]), R=np.array([0.1, 0.05]), Qf=np.array([10.0, 10.0, 0.5]),
+                     u_lb=np.array([-0.2, -0.3]), u_ub=np.array([0.4, 0.3]),
+                     du_lb=np.array([-0.2, -0.2]), du_ub=np.array([0.2, 0.2]),
+                     min_obstacle_dist=0.2, force_inclusion_dist=0.5, cutoff_dist=2.5)
+
+
+def config_bicycle_min_time(n: int = 120) -> OcpConfig:
+    """BASELINE.json config 5; lr=lf=1.0 defaults of controller.cpp:366-369."""
+    return OcpConfig(model=MODEL_KINEMATIC_BICYCLE, model_params=(1.0, 1.0), n=n, dt_ref=0.3, dt_free=True,
+                     xf_fixed=(True, True, True), objective=OBJ_MIN_TIME,
+                     u_lb=np.array([-0.2, -1.5]), u_ub=np.array([0.4, 1.5]),
+                     du_lb=np.array([-0.5, -0.5]), du_ub=np.array([0.5, 0.5]))
+
+
+# --------------------------------------------------------------------------
+# trajectory container = the grid's vertex set
+#   (include/.../full_discretization_grid_base_se2.h:208-218)
+# --------------------------------------------------------------------------
+@dataclass
+class Trajectory:
+    x: np.ndarray      # (n,3)  x[0] fixed start, x[n-1] = xf vertex
+    u: np.ndarray      # (n-1,2)
+    dt: float
+
+    def copy(self):
+        return Trajectory(self.x.copy(), self.u.copy(), float(self.dt))
+
+
+def initial_state_trajectory_two_pose(x0, xf, n_ref: int, dt_ref: float):
+    """Controller::generateInitialStateTrajectory for a 2-pose plan
+    (src/controller.cpp:807-857): time series {0: x0, tf_ref: xf}."""
+    tf = (n_ref - 1) * dt_ref
+    return np.array([0.0, tf]), np.stack([np.asarray(x0, float), np.asarray(xf, float)])
+
+
+def time_series_se2_interpolate(times, values, t, tol=1e-6):
+    """TimeSeriesSE2::getValuesInterpolate, linear (src/utils/time_series_se2.cpp:34-111)."""
+    idx = None
+    for i, tv in enumerate(times):
+        if tv >= t:
+            idx = i
+            break
+    if idx is None:            # ZeroOrderHold extrapolation is what corbo uses for references
+        return values[-1].copy()
+    if abs(t - times[idx]) < tol:
+        return values[idx].copy()
+    if idx < 1:
+        return values[0].copy()
+    frac = (t - times[idx - 1]) / (times[idx] - times[idx - 1])
+    out = values[idx - 1] + frac * (values[idx] - values[idx - 1])
+    out[2] = interpolate_angle(values[idx - 1][2], values[idx][2], frac)
+    return out
+
+
+def initialize_sequences_xinit(cfg: OcpConfig, x0, xf, ts_times, ts_values) -> Trajectory:
+    """FullDiscretizationGridBaseSE2::initializeSequences (xinit overload),
+    src/optimal_control/full_discretization_grid_base_se2.cpp:192-239:
+    x_0 exact, x_k = xinit(k*dt_ref) k=1..n-2, xf, u_k = uref = 0, dt = dt_ref."""
+    n = cfg.n
+    x = np.zeros((n, 3))
+    x[0] = x0
+    for k in range(1, n - 1):
+        x[k] = time_series_se2_interpolate(ts_times, ts_values, k * cfg.dt_ref)
+    x[n - 1] = xf
+    return Trajectory(x, np.zeros((n - 1, 2)), cfg.dt_ref)
+
+
+def initialize_sequences_straight_line(cfg: OcpConfig, x0, xf) -> Trajectory:
+    """initializeSequences (static reference, no xinit), ...grid_base_se2.cpp:136-190."""
+    n = cfg.n
+    x0 = np.asarray(x0, float)
+    xf = np.asarray(xf, float)
+    d = xf - x0
+    dist = float(np.linalg.norm(d))
+    if dist != 0:
+        d = d / dist
+    step = dist / (n - 1)
+    orient = math.atan2(d[1], d[0])
+    if d[0] * math.cos(x0[2]) + d[1] * math.sin(x0[2]) < 0:
+        orient = float(normalize_theta(orient + math.pi))
+    x = np.zeros((n, 3))
+    for k in range(n - 1):
+        x[k] = x0 + k * step * d
+        if k > 0:
+            x[k, 2] = orient
+    x[n - 1] = xf
+    return Trajectory(x, np.zeros((n - 1, 2)), cfg.dt_ref)
+
+
+def cold_start(cfg: OcpConfig, x0, xf) -> Trajectory:
+    """What Controller::step does on an empty grid with a 2-pose plan
+    (src/controller.cpp:159-172 -> a2 + a5 of SURVEY.md 8a)."""
+    t, v = initial_state_trajectory_two_pose(x0, xf, cfg.n, cfg.dt_ref)
+    return initialize_sequences_xinit(cfg, x0, xf, t, v)
+
+
+def find_nearest_state(traj: Trajectory, x0) -> int:
+    """...grid_base_se2.cpp:304-339."""
+    n = traj.x.shape[0]
+    first = float(np.linalg.norm(np.asarray(x0) - traj.x[0]))
+    if abs(first) < 1e-12:
+        return 0
+    look = min((n - 1) - 1, 20)
+    best, cache = 0, first
+    for i in range(1, look + 1):
+        d = float(np.linalg.norm(np.asarray(x0) - traj.x[i]))
+        if d < cache:
+            cache, best = d, i
+        else:
+            break
+    return best
+
+
+def warm_start_shifting(traj: Trajectory, x0) -> Trajectory:
+    """...grid_base_se2.cpp:241-302 (fixed grid only)."""
+    t = traj.copy()
+    n = t.x.shape[0]
+    ns = find_nearest_state(t, x0)
+    if ns <= 0 or ns > n - 2:
+        return t
+    X, U = t.x, t.u           # X[n-1] is xf
+    for i in range(n - ns):
+        idx = i + ns
+        if idx == n - 1:
+            X[i] = X[n - 1]
+        else:
+            X[i] = X[idx]
+            U[i] = U[idx]
+    idx = n - ns
+    for i in range(ns):
+        X[idx] = X[idx - 2] + 2.0 * (X[idx - 1] - X[idx - 2])
+        X[idx, 2] = interpolate_angle(X[idx - 2, 2], X[idx - 1, 2], 2.0)
+        U[idx - 1] = U[idx - 2]
+        idx += 1
+    return t
+
+
+def new_run_overwrite(cfg: OcpConfig, traj: Trajectory, x0, xf) -> Trajectory:
+    """...grid_base_se2.cpp:101-110: overwrite start, refresh fixed goal components."""
+    t = traj.copy()
+    t.x[0] = x0
+    for i in range(3):
+        if cfg.xf_fixed[i]:
+            t.x[-1, i] = xf[i]
+    return t
+
+
+def resample_trajectory(traj: Trajectory, n_new: int) -> Trajectory:
+    """FullDiscretizationGridBaseSE2::resampleTrajectory, ...grid_base_se2.cpp:440-524."""
+    n = traj.x.shape[0]
+    if n == n_new:
+        return traj.copy()
+    x_old, dt_old = traj.x, traj.dt
+    u_old = np.vstack([traj.u, traj.u[-1:]])       # duplicate last (getStateAndControlTimeSeries :604-613)
+    dt_new = dt_old * (n - 1) / (n_new - 1)
+    x = np.zeros((n_new, 3))
+    u = np.zeros((n_new - 1, 2))
+    x[0] = x_old[0]
+    u[0] = u_old[0]
+    idx_old = 1
+    for idx_new in range(1, n_new - 1):
+        t_new = dt_new * idx_new
+        while t_new > idx_old * dt_old and idx_old < n:
+            idx_old += 1
+        t_old_p1 = idx_old * dt_old
+        xp = x_old[idx_old - 1]
+        xc = x_old[idx_old] if idx_old < n - 1 else x_old[n - 1]
+        fr = (t_new - (t_old_p1 - dt_old)) / dt_old
+        x[idx_new] = xp + fr * (xc - xp)
+        x[idx_new, 2] = interpolate_angle(xp[2], xc[2], fr)
+        u[idx_new] = u_old[idx_old - 1]
+    x[n_new - 1] = x_old[n - 1]
+    return Trajectory(x, u, dt_new)
+
+
+def adapt_grid_single_step(cfg: OcpConfig, traj: Trajectory, n_min=2, n_max=50, hyst=0.1) -> Trajectory:
+    """adaptGridTimeBasedSingleStep, src/optimal_control/finite_differences_variable_grid_se2.cpp:99-121."""
+    n = traj.x.shape[0]
+    if traj.dt > cfg.dt_ref * (1.0 + hyst) and n < n_max:
+        return resample_trajectory(traj, n + 1)
+    if traj.dt < cfg.dt_ref * (1.0 - hyst) and n > n_min:
+        return resample_trajectory(traj, n - 1)
+    return traj.copy()
+
+
+def time_series_output(traj: Trajectory):
+    """getStateAndControlTimeSeries, ...grid_base_se2.cpp:579-615:
+    times k*dt, states x_0..x_{n-2},xf, controls u_0..u_{n-2} + duplicate of the last."""
+    n = traj.x.shape[0]
+    t = np.arange(n) * traj.dt
+    return t, traj.x.copy(), np.vstack([traj.u, traj.u[-1:]])
+
+
+# --------------------------------------------------------------------------
+# obstacle association            src/optimal_control/stage_inequality_se2.cpp:50-162
+# --------------------------------------------------------------------------
+
+def associate_obstacles(cfg: OcpConfig, traj: Trajectory, obstacles: List[Obstacle]):
+    """Returns (relevant[k] -> list of obstacle indices, relevant_dyn[k]) for k=0..n-1
+    (k=0 stays empty; k=n-1 is computed but never used by createEdges)."""
+    n = traj.x.shape[0]
+    rel = [[] for _ in range(n)]
+    rel_dyn = [[] for _ in range(n)]
+    for k in range(1, n):
+        pose = traj.x[k]
+        orient = np.array([math.cos(pose[2]), math.sin(pose[2])])
+        lmin = rmin = float("inf")
+        lidx = ridx = None
+        for j, ob in enumerate(obstacles):
+            if cfg.enable_dynamic_obstacles and ob.velocity is not None and np.any(np.asarray(ob.velocity) != 0):
+                rel_dyn[k].append(j)
+                continue
+            d = footprint_distance(cfg.footprint_kind, cfg.footprint_params, pose, ob)
+            if d < cfg.force_inclusion_dist:
+                rel[k].append(j)
+                continue
+            if d > cfg.cutoff_dist:
+                continue
+            if cross2d(orient, ob.centroid()) > 0:      # centroid as an ABSOLUTE vector (:121)
+                if d < lmin:
+                    lmin, lidx = d, j
+            else:
+                if d < rmin:
+                    rmin, ridx = d, j
+        if lidx is not None:
+            rel[k].append(lidx)
+        if ridx is not None:
+            rel[k].append(ridx)
+    return rel, rel_dyn
+
+
+# --------------------------------------------------------------------------
+# the NLP in the reference's form
+# --------------------------------------------------------------------------
+@dataclass
+class CycleInputs:
+    """What crosses Controller::step for one instance."""
+    x0: np.ndarray
+    xf: np.ndarray
+    u_prev: np.ndarray = field(default_factory=lambda: np.zeros(2))
+    dt_prev: float = 0.0
+    obstacles: List[Obstacle] = field(default_factory=list)
+
+
+class ReferenceNlp:
+    """f, c(=0), g(<=0), bounds of one solve, built exactly as
+    FiniteDifferencesGridSE2::createEdges lays them out
+    (src/optimal_control/finite_differences_grid_se2.cpp:36-154).
+
+    Decision vector order = computeActiveVertices
+    (...grid_base_se2.cpp:564-577): u0, x1, u1, ..., x_{n-2}, u_{n-2}, [xf free comps], [dt].
+    """
+
+    def __init__(self, cfg: OcpConfig, inp: CycleInputs, relevant=None, relevant_dyn=None):
+        self.cfg = cfg
+        self.inp = inp
+        n = cfg.n
+        self.n = n
+        self.free_xf = [i for i in range(3) if not cfg.xf_fixed[i]]
+        self.nz = 2 + 5 * (n - 2) + len(self.free_xf) + (1 if cfg.dt_free else 0)
+        self.relevant = relevant if relevant is not None else [[] for _ in range(n)]
+        self.relevant_dyn = relevant_dyn if relevant_dyn is not None else [[] for _ in range(n)]
+        self.du_lb_finite = [i for i in range(2) if cfg.du_lb[i] > -INF]
+        self.du_ub_finite = [i for i in range(2) if cfg.du_ub[i] < INF]
+
+    # ---- packing -----------------------------------------------------
+    def pack(self, t: Trajectory) -> np.ndarray:
+        n = self.n
+        z = [t.u[0]]
+        for k in range(1, n - 1):
+            z.append(t.x[k])
+            z.append(t.u[k])
+        if self.free_xf:
+            z.append(t.x[n - 1, self.free_xf])
+        if self.cfg.dt_free:
+            z.append([t.dt])
+        return np.concatenate(z)
+
+    def unpack(self, z: np.ndarray) -> Trajectory:
+        n = self.n
+        x = np.zeros((n, 3))
+        u = np.zeros((n - 1, 2))
+        x[0] = self.inp.x0
+        x[n - 1] = self.inp.xf
+        u[0] = z[0:2]
+        p = 2
+        for k in range(1, n - 1):
+            x[k] = z[p:p + 3]
+            u[k] = z[p + 3:p + 5]
+            p += 5
+        for i in self.free_xf:
+            x[n - 1, i] = z[p]
+            p += 1
+        dt = float(z[p]) if self.cfg.dt_free else self.cfg.dt_ref
+        return Trajectory(x, u, dt)
+
+    def plus(self, z: np.ndarray, dz: np.ndarray) -> np.ndarray:
+        """Vertex retraction: VectorVertexSE2::plus wraps index 2
+        (include/.../vector_vertex_se2.h:79-96, partially fixed :240-251)."""
+        out = z + dz
+        n = self.n
+        p = 2
+        for k in range(1, n - 1):
+            out[p + 2] = normalize_theta(out[p + 2])
+            p += 5
+        for i in self.free_xf:
+            if i == 2:
+                out[p] = normalize_theta(out[p])
+            p += 1
+        return out
+
+    def bounds(self):
+        lb = np.full(self.nz, -INF)
+        ub = np.full(self.nz, INF)
+        cfg = self.cfg
+        lb[0:2], ub[0:2] = cfg.u_lb, cfg.u_ub
+        p = 2
+        for k in range(1, self.n - 1):
+            lb[p + 3:p + 5], ub[p + 3:p + 5] = cfg.u_lb, cfg.u_ub
+            p += 5
+        p += len(self.free_xf)
+        if cfg.dt_free:
+            lb[p], ub[p] = cfg.dt_lb, cfg.dt_ub
+        return lb, ub
+
+    # ---- objective ---------------------------------------------------
+    def objective(self, z: np.ndarray) -> float:
+        cfg = self.cfg
+        t = self.unpack(z)
+        n = self.n
+        if cfg.objective == OBJ_MIN_TIME:
+            # corbo::MinimumTime on a single-dt grid == (n-1)*dt; in-repo twin
+            # src/optimal_control/min_time_via_points_cost.cpp:52-56,120-124
+            return (n - 1) * t.dt
+        J = 0.0
+        xf = np.asarray(self.inp.xf, float)
+        for k in range(n - 1):
+            xd = t.x[k] - xf                       # StaticReference(xf), src/controller.cpp:169
+            xd[2] = normalize_theta(xd[2])         # quadratic_cost_se2.cpp:36-37
+            stage = float(xd @ (cfg.Q * xd) + t.u[k] @ (cfg.R * t.u[k]))
+            J += stage * (t.dt if cfg.integral_form else 1.0)   # left sum, finite_differences_grid_se2.cpp:70-74
+        if cfg.Qf is not None and self.free_xf:
+            xd = t.x[n - 1] - xf                   # final_state_conditions_se2.cpp:30-52
+            xd[2] = normalize_theta(xd[2])
+            J += float(xd @ (cfg.Qf * xd))
+        return J
+
+    # ---- equalities --------------------------------------------------
+    def equalities(self, z: np.ndarray) -> np.ndarray:
+        cfg = self.cfg
+        t = self.unpack(z)
+        return collocation_defect(cfg.collocation, cfg.model, cfg.model_params,
+                                  t.x[:-1], t.u, t.x[1:], t.dt).reshape(-1)
+
+    # ---- inequalities (<= 0) -----------------------------------------
+    def _rate_rows(self, uk, up, dtp):
+        """computeNonIntegralControlDeviationTerm, stage_inequality_se2.cpp:191-222
+        (lower block first, then upper block)."""
+        cfg = self.cfg
+        lo = [cfg.du_lb[i] - (uk[i] - up[i]) / dtp for i in self.du_lb_finite]
+        hi = [(uk[i] - up[i]) / dtp - cfg.du_ub[i] for i in self.du_ub_finite]
+        return lo + hi
+
+    def inequalities(self, z: np.ndarray) -> np.ndarray:
+        cfg = self.cfg
+        t = self.unpack(z)
+        n = self.n
+        rows: List[float] = []
+        nrate = len(self.du_lb_finite) + len(self.du_ub_finite)
+        for k in range(n - 1):
+            # clearance rows on x_k (k>=1; x_0 is fixed so corbo drops the edge)
+            if k >= 1:
+                for j in self.relevant[k]:
+                    rows.append(cfg.min_obstacle_dist - footprint_distance(
+                        cfg.footprint_kind, cfg.footprint_params, t.x[k], self.inp.obstacles[j]))
+                for j in self.relevant_dyn[k]:
+                    rows.append(cfg.min_obstacle_dist - footprint_distance(
+                        cfg.footprint_kind, cfg.footprint_params, t.x[k], self.inp.obstacles[j], k * t.dt))
+            if nrate:
+                if k == 0:
+                    if self.inp.dt_prev == 0:
+                        rows += [0.0] * nrate              # :197-201
+                    else:
+                        rows += self._rate_rows(t.u[0], self.inp.u_prev, self.inp.dt_prev)
+                else:
+                    rows += self._rate_rows(t.u[k], t.u[k - 1], t.dt)   # dt_prev == dt (createEdges :50-51)
+        if nrate:
+            # getFinalControlDeviationEdges(n, u_ref(=0), u_{n-2}, dt): finite_differences_grid_se2.cpp:150
+            rows += self._rate_rows(np.zeros(2), t.u[n - 2], t.dt)
+        return np.asarray(rows, float)
+
+    # ---- numeric derivatives the way corbo's edges do (central differences
+    #      through plus(); SURVEY 2.1 HyperGraphOptimizationProblemEdgeBased) ----
+    def numeric_jacobian(self, fun, z: np.ndarray, delta: float = 1e-6) -> np.ndarray:
+        f0 = np.atleast_1d(fun(z))
+        J = np.zeros((f0.size, z.size))
+        for i in range(z.size):
+            e = np.zeros(z.size)
+            e[i] = delta
+            J[:, i] = (np.atleast_1d(fun(self.plus(z, e))) - np.atleast_1d(fun(self.plus(z, -e)))) / (2 * delta)
+        return J
