@@ -1,0 +1,146 @@
+/*
+ * mpc_hip.h -- C ABI of the MI355X-native batched receding-horizon NLP solve.
+ *
+ * This is the drop-in boundary for ONE hot path of rst-tu-dortmund/mpc_local_planner:
+ * the NLP solve that Controller::step() triggers every control cycle
+ * (reference: mpc_local_planner/src/controller.cpp:111-179 -> :172
+ *  corbo::PredictiveController::step -> StructuredOptimalControlProblem::compute
+ *  -> SolverIpopt::solve; grid/edges: src/optimal_control/finite_differences_grid_se2.cpp:36-154).
+ *
+ * Plain C, plain pointers and sizes, no C++/torch types.  All functions return 0 on
+ * success or a negative MPC_E* code; nothing throws across the ABI.  A solver handle
+ * is thread-compatible (one handle per thread / per GPU), exactly like the reference's
+ * Controller, which is not re-entrant (include/mpc_local_planner/controller.h:118-142).
+ *
+ * Array layouts at the ABI are instance-major ("AoS", what a caller holding B
+ * independent planners naturally has):
+ *   x0[B][3], xf[B][3], u_prev[B][2], dt_prev[B]
+ *   x_init / x_out [B][n][3]   states  x_0 .. x_{n-2}, xf   (getStateAndControlTimeSeries,
+ *   u_init / u_out [B][n][2]   controls u_0 .. u_{n-2} + duplicate of the last
+ *                              (src/optimal_control/full_discretization_grid_base_se2.cpp:579-615)
+ *   dt_init / dt_out [B]
+ *   status[B], iters[B]
+ * Inside the solver everything is re-laid out instance-minor (SoA) for coalesced HBM access.
+ */
+#ifndef MPC_HIP_H_
+#define MPC_HIP_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- enums (values shared with oracle/se2_nlp.py) ------------------------------------ */
+enum mpc_model {                      /* include/mpc_local_planner/systems/ */
+    MPC_MODEL_UNICYCLE = 0,           /* unicycle_robot.h:59-68 */
+    MPC_MODEL_SIMPLE_CAR = 1,         /* simple_car.h:68-77 (rear wheel) */
+    MPC_MODEL_SIMPLE_CAR_FRONT = 2,   /* simple_car.h:131-141 */
+    MPC_MODEL_KINEMATIC_BICYCLE = 3   /* kinematic_bicycle_model.h:65-77 */
+};
+enum mpc_collocation {                /* include/.../optimal_control/fd_collocation_se2.h */
+    MPC_COLLOC_FORWARD = 0            /* :54-69 (the default, src/controller.cpp:298) */
+};
+enum mpc_objective {                  /* src/controller.cpp:551-640 */
+    MPC_OBJ_MIN_TIME = 0,
+    MPC_OBJ_QUADRATIC = 1
+};
+enum mpc_precision { MPC_FP64 = 0, MPC_FP32 = 1 };
+
+enum mpc_status {                     /* per-instance result; 0 == what corbo reports as Converged */
+    MPC_CONVERGED = 0,
+    MPC_MAX_ITER = 1,
+    MPC_LINESEARCH_FAILED = 2,
+    MPC_LINSOLVE_FAILED = 3,
+    MPC_NUMERICAL_ERROR = 4
+};
+
+enum mpc_error {
+    MPC_OK = 0,
+    MPC_EINVAL = -1,                  /* bad argument / unsupported configuration */
+    MPC_ENODEV = -2,                  /* no usable HIP device */
+    MPC_ENOMEM = -3,
+    MPC_EHIP = -4,                    /* a HIP runtime call failed (see mpc_last_error) */
+    MPC_EBATCH = -5                   /* B exceeds the capacity given to mpc_create */
+};
+
+/* ---- configuration = the parameter set read in src/controller.cpp:225-805 -------------- */
+typedef struct mpc_config {
+    int32_t model;                    /* robot/type                       (:346) */
+    double  model_params[4];          /* wheelbase | (lr, lf)             (:355,:366-369) */
+    int32_t n;                        /* grid/grid_size_ref               (:274) */
+    double  dt_ref;                   /* grid/dt_ref                      (:278) */
+    int32_t dt_free;                  /* grid/variable_grid/enable        (:236) */
+    double  dt_lb, dt_ub;             /* .../min_dt, max_dt               (:242,:244) */
+    int32_t xf_fixed[3];              /* grid/xf_fixed                    (:282) */
+    int32_t collocation;              /* grid/collocation_method          (:298) */
+    int32_t objective;                /* planning/objective/type          (:551) */
+    double  Q[3], R[2];               /* quadratic_form weights (diag)    (:561-592) */
+    int32_t integral_form;            /* .../integral_form                (:594) */
+    int32_t has_Qf;                   /* planning/terminal_cost/type == quadratic (:645) */
+    double  Qf[3];                    /* final_state_weights (diag)       (:652-668) */
+    double  u_lb[2], u_ub[2];         /* control box                      (:511,:527,:543) */
+    double  du_lb[2], du_ub[2];       /* control-rate box; +-1e30 = inf   (:756-797) */
+    /* solver (replaces solver/ipopt/..., :388-421) */
+    int32_t max_iter;                 /* iterations                       (:391) */
+    double  tol;                      /* ipopt_numeric_options/tol */
+    double  mu_init;                  /* barrier start (0 -> default 0.1) */
+    int32_t precision;                /* MPC_FP64 | MPC_FP32 */
+    int32_t reserved[8];
+} mpc_config;
+
+typedef struct mpc_solver mpc_solver;     /* opaque */
+
+/* Fill *cfg with the in-code defaults of src/controller.cpp (unicycle, n=20, dt_ref=.3,
+ * variable grid, min-time, xf fixed, no rate limits, 100 iterations). */
+void mpc_config_defaults(mpc_config* cfg);
+
+/* Create a solver for one (model, objective, n, flags) tuple on HIP device `device`
+ * with room for `max_batch` instances.  Fails with MPC_ENODEV when no GPU is present:
+ * there is NO CPU fallback.  Replaces Controller::configure (include/.../controller.h:61-62). */
+int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_solver** out);
+
+/* Drop the warm start kept inside the handle.  Replaces Controller::reset (controller.h:104). */
+int mpc_reset(mpc_solver* s);
+
+void mpc_destroy(mpc_solver* s);
+
+/* One control cycle for B independent planner instances -- the batched equivalent of
+ * Controller::step (include/.../controller.h:63-67; src/controller.cpp:111-179).
+ * HOST pointers; the call copies in, solves, copies out and returns when done.
+ *   x_init/u_init/dt_init : nullable.  NULL -> cold start built on the device exactly as the
+ *       reference does for a 2-pose plan (src/controller.cpp:807-857 +
+ *       full_discretization_grid_base_se2.cpp:192-239: linear x0->xf, shortest-arc theta, u=0,
+ *       dt=dt_ref).  Non-NULL -> used as the vertex values (warm start), with x_0 := x0 and the
+ *       fixed goal components := xf (full_discretization_grid_base_se2.cpp:101-110).
+ *   status/iters : nullable. */
+int mpc_solve_batch(mpc_solver* s, int32_t B,
+                    const double* x0, const double* xf, const double* u_prev, const double* dt_prev,
+                    const double* x_init, const double* u_init, const double* dt_init,
+                    double* x_out, double* u_out, double* dt_out,
+                    int32_t* status, int32_t* iters);
+
+/* Same contract with DEVICE pointers (HBM-resident inputs/outputs), asynchronous on the
+ * solver's stream; pair with mpc_synchronize.  This is what bench.py times. */
+int mpc_solve_batch_device(mpc_solver* s, int32_t B,
+                           const double* d_x0, const double* d_xf, const double* d_u_prev, const double* d_dt_prev,
+                           const double* d_x_init, const double* d_u_init, const double* d_dt_init,
+                           double* d_x_out, double* d_u_out, double* d_dt_out,
+                           int32_t* d_status, int32_t* d_iters);
+
+int mpc_synchronize(mpc_solver* s);
+
+/* Duration (ms) of the solve kernel of the most recent mpc_solve_batch* call, measured with
+ * HIP events on the solver's own stream (call after mpc_synchronize). */
+int mpc_last_kernel_ms(mpc_solver* s, float* ms);
+
+/* Human-readable text of the last HIP/runtime error on this thread ("" if none). */
+const char* mpc_last_error(void);
+
+/* Library/ABI version: major*10000 + minor*100 + patch. */
+int32_t mpc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MPC_HIP_H_ */

@@ -1,0 +1,10 @@
+"""mpc_local_planner_amd -- MI355X-native batched receding-horizon NLP solve behind the
+Controller::step() surface of rst-tu-dortmund/mpc_local_planner.
+
+Only the hot path lives here: csrc/ (HIP kernels + the C ABI of include/mpc_hip.h) and the
+host-side mirror of the reference's controller interface.  See DESIGN.md.
+"""
+from ._abi import (MpcConfig, make_config, config_carlike_min_time, config_unicycle_quadratic,  # noqa: F401
+                   config_bicycle_min_time, STATUS_NAMES)
+from .solver import BatchSolver, BatchResult, MpcError  # noqa: F401
+from . import workloads  # noqa: F401

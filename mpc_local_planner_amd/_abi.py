@@ -1,0 +1,115 @@
+"""ctypes mirror of include/mpc_hip.h (struct mpc_config and the enum values).
+
+Pure data definitions -- shared by the product binding (mpc_local_planner_amd/_lib.py)
+and by tests.  No solver code here.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+MODEL_UNICYCLE = 0
+MODEL_SIMPLE_CAR = 1
+MODEL_SIMPLE_CAR_FRONT = 2
+MODEL_KINEMATIC_BICYCLE = 3
+
+COLLOC_FORWARD = 0
+
+OBJ_MIN_TIME = 0
+OBJ_QUADRATIC = 1
+
+FP64 = 0
+FP32 = 1
+
+STATUS_NAMES = {0: "converged", 1: "max_iter", 2: "linesearch_failed", 3: "linsolve_failed", 4: "numerical_error"}
+
+MPC_OK = 0
+MPC_EINVAL = -1
+MPC_ENODEV = -2
+MPC_ENOMEM = -3
+MPC_EHIP = -4
+MPC_EBATCH = -5
+
+INF = 1e30
+
+
+class MpcConfig(C.Structure):
+    """struct mpc_config (include/mpc_hip.h); field-for-field."""
+    _fields_ = [
+        ("model", C.c_int32),
+        ("model_params", C.c_double * 4),
+        ("n", C.c_int32),
+        ("dt_ref", C.c_double),
+        ("dt_free", C.c_int32),
+        ("dt_lb", C.c_double),
+        ("dt_ub", C.c_double),
+        ("xf_fixed", C.c_int32 * 3),
+        ("collocation", C.c_int32),
+        ("objective", C.c_int32),
+        ("Q", C.c_double * 3),
+        ("R", C.c_double * 2),
+        ("integral_form", C.c_int32),
+        ("has_Qf", C.c_int32),
+        ("Qf", C.c_double * 3),
+        ("u_lb", C.c_double * 2),
+        ("u_ub", C.c_double * 2),
+        ("du_lb", C.c_double * 2),
+        ("du_ub", C.c_double * 2),
+        ("max_iter", C.c_int32),
+        ("tol", C.c_double),
+        ("mu_init", C.c_double),
+        ("precision", C.c_int32),
+        ("reserved", C.c_int32 * 8),
+    ]
+
+
+def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3, dt_free=True, dt_lb=0.0, dt_ub=10.0,
+                xf_fixed=(True, True, True), objective=OBJ_MIN_TIME, Q=(0, 0, 0), R=(0, 0), integral_form=False, Qf=None,
+                u_lb=(-0.2, -0.3), u_ub=(0.4, 0.3), du_lb=(-INF, -INF), du_ub=(INF, INF), max_iter=100, tol=1e-8,
+                mu_init=0.1, precision=FP64) -> MpcConfig:
+    c = MpcConfig()
+    c.model = model
+    mp = list(model_params) + [0.0] * 4
+    for i in range(4):
+        c.model_params[i] = mp[i]
+    c.n = n
+    c.dt_ref = dt_ref
+    c.dt_free = int(bool(dt_free))
+    c.dt_lb, c.dt_ub = dt_lb, dt_ub
+    for i in range(3):
+        c.xf_fixed[i] = int(bool(xf_fixed[i]))
+        c.Q[i] = Q[i]
+        c.Qf[i] = Qf[i] if Qf is not None else 0.0
+    c.collocation = COLLOC_FORWARD
+    c.objective = objective
+    c.integral_form = int(bool(integral_form))
+    c.has_Qf = int(Qf is not None)
+    for j in range(2):
+        c.R[j] = R[j]
+        c.u_lb[j], c.u_ub[j] = u_lb[j], u_ub[j]
+        c.du_lb[j], c.du_ub[j] = du_lb[j], du_ub[j]
+    c.max_iter = max_iter
+    c.tol = tol
+    c.mu_init = mu_init
+    c.precision = precision
+    return c
+
+
+def config_carlike_min_time(n=50, **kw) -> MpcConfig:
+    """BASELINE.json config 2: mpc_local_planner_examples/cfg/carlike/mpc_local_planner_params.yaml:7-16,46-65."""
+    return make_config(model=MODEL_SIMPLE_CAR, model_params=(0.4,), n=n, dt_ref=0.3, dt_free=True, dt_lb=0.0, dt_ub=10.0,
+                       xf_fixed=(True, True, True), objective=OBJ_MIN_TIME, u_lb=(-0.2, -1.4), u_ub=(0.4, 1.4),
+                       du_lb=(-0.5, -0.5), du_ub=(0.5, 0.5), **kw)
+
+
+def config_unicycle_quadratic(n=20, **kw) -> MpcConfig:
+    """BASELINE.json config 1: .../cfg/diff_drive/mpc_local_planner_params_quadratic_form.yaml:7-14,33-41,53-61."""
+    return make_config(model=MODEL_UNICYCLE, model_params=(0.0,), n=n, dt_ref=0.3, dt_free=False,
+                       xf_fixed=(False, False, False), objective=OBJ_QUADRATIC, Q=(2.0, 2.0, 0.25), R=(0.1, 0.05),
+                       Qf=(10.0, 10.0, 0.5), u_lb=(-0.2, -0.3), u_ub=(0.4, 0.3), du_lb=(-0.2, -0.2), du_ub=(0.2, 0.2), **kw)
+
+
+def config_bicycle_min_time(n=120, **kw) -> MpcConfig:
+    """BASELINE.json config 5; lr = lf = 1.0 (src/controller.cpp:366-369)."""
+    return make_config(model=MODEL_KINEMATIC_BICYCLE, model_params=(1.0, 1.0), n=n, dt_ref=0.3, dt_free=True,
+                       xf_fixed=(True, True, True), objective=OBJ_MIN_TIME, u_lb=(-0.2, -1.5), u_ub=(0.4, 1.5),
+                       du_lb=(-0.5, -0.5), du_ub=(0.5, 0.5), **kw)

@@ -1,0 +1,94 @@
+"""Loader / builder for the C-ABI library (include/mpc_hip.h -> csrc/libmpc_hip.so).
+
+The library is built IN-TREE with hipcc for gfx950; there is no CPU fallback: if the
+shared object is missing or no HIP device is usable, callers get an exception.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+from ._abi import MpcConfig
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIB_PATH = os.path.join(CSRC, "libmpc_hip.so")
+SOURCES = ["mpc_capi.hip"]
+HEADERS = ["mpc_core.hpp", "mpc_problem.hpp", os.path.join("..", "..", "include", "mpc_hip.h")]
+
+EXPORTS = [
+    "mpc_config_defaults", "mpc_create", "mpc_reset", "mpc_destroy", "mpc_solve_batch",
+    "mpc_solve_batch_device", "mpc_synchronize", "mpc_last_kernel_ms", "mpc_last_error", "mpc_version",
+]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if cand and os.path.exists(cand):
+            return cand
+    raise RuntimeError("hipcc not found (needed to build the gfx950 library)")
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB_PATH):
+        return True
+    t = os.path.getmtime(LIB_PATH)
+    for f in SOURCES + HEADERS:
+        p = os.path.join(CSRC, f)
+        if os.path.exists(p) and os.path.getmtime(p) > t:
+            return True
+    return False
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 -> csrc/libmpc_hip.so (cross-compiles without a GPU)."""
+    if not force and not needs_build():
+        return LIB_PATH
+    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
+    cmd += [os.path.join(CSRC, s) for s in SOURCES]
+    cmd += ["-o", LIB_PATH]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True, cwd=CSRC)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen the C-ABI library and declare the prototypes of include/mpc_hip.h."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    dp = C.c_void_p   # raw addresses: host numpy buffers or device pointers
+    lib.mpc_config_defaults.argtypes = [C.POINTER(MpcConfig)]
+    lib.mpc_config_defaults.restype = None
+    lib.mpc_create.argtypes = [C.POINTER(MpcConfig), C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.mpc_create.restype = C.c_int
+    lib.mpc_reset.argtypes = [C.c_void_p]
+    lib.mpc_reset.restype = C.c_int
+    lib.mpc_destroy.argtypes = [C.c_void_p]
+    lib.mpc_destroy.restype = None
+    sig = [C.c_void_p, C.c_int32] + [dp] * 12
+    lib.mpc_solve_batch.argtypes = sig
+    lib.mpc_solve_batch.restype = C.c_int
+    lib.mpc_solve_batch_device.argtypes = sig
+    lib.mpc_solve_batch_device.restype = C.c_int
+    lib.mpc_synchronize.argtypes = [C.c_void_p]
+    lib.mpc_synchronize.restype = C.c_int
+    lib.mpc_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]
+    lib.mpc_last_kernel_ms.restype = C.c_int
+    lib.mpc_last_error.argtypes = []
+    lib.mpc_last_error.restype = C.c_char_p
+    lib.mpc_version.argtypes = []
+    lib.mpc_version.restype = C.c_int32
+    _lib = lib
+    return lib

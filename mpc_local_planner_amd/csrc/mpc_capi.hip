@@ -1,0 +1,288 @@
+// mpc_capi.hip -- HIP kernels + the C ABI declared in include/mpc_hip.h.
+// gfx950 only.  There is no CPU path in this library: mpc_create fails with MPC_ENODEV
+// when no HIP device is usable.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+
+#include "../../include/mpc_hip.h"
+#include "mpc_core.hpp"
+#include "mpc_problem.hpp"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+void set_err(const char* what, hipError_t e) {
+    snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+}
+void set_err(const char* what) { snprintf(g_err, sizeof(g_err), "%s", what); }
+
+#define HIP_TRY(call)                                     \
+    do {                                                  \
+        hipError_t e_ = (call);                           \
+        if (e_ != hipSuccess) { set_err(#call, e_); return MPC_EHIP; } \
+    } while (0)
+
+constexpr int kLanes = 64;   // one wavefront per workgroup: instances spread over as many CUs as possible
+
+// One lane = one planner instance.  Inputs/outputs are instance-major (ABI layout); the iterate,
+// duals and Riccati gains live in the instance-minor workspace `ws`.
+template <typename T, int MODEL>
+__global__ __launch_bounds__(kLanes) void mpc_ipm_solve_kernel(
+    mpc::Problem<T> P, mpc::Layout L, T* __restrict__ ws, long stride, int B,
+    const double* __restrict__ x0, const double* __restrict__ xf, const double* __restrict__ u_prev,
+    const double* __restrict__ dt_prev, const double* __restrict__ x_init, const double* __restrict__ u_init,
+    const double* __restrict__ dt_init, double* __restrict__ x_out, double* __restrict__ u_out,
+    double* __restrict__ dt_out, int32_t* __restrict__ status, int32_t* __restrict__ iters) {
+    const int inst = blockIdx.x * kLanes + threadIdx.x;
+    if (inst >= B) return;
+    const int n = L.n;
+    mpc::Mem<T> M{ws + inst, stride};
+    mpc::Ipm<T, MODEL> S(P, L, M);
+    for (int i = 0; i < 3; ++i) { S.x0[i] = T(x0[3 * inst + i]); S.xf[i] = T(xf[3 * inst + i]); }
+    S.x0[2] = mpc::normalize_theta(S.x0[2]);
+    S.xf[2] = mpc::normalize_theta(S.xf[2]);
+    S.uprev[0] = u_prev ? T(u_prev[2 * inst]) : T(0);
+    S.uprev[1] = u_prev ? T(u_prev[2 * inst + 1]) : T(0);
+    S.dtprev = dt_prev ? T(dt_prev[inst]) : T(0);
+    if (x_init && u_init && dt_init) {
+        const double* xi = x_init + (long)inst * n * 3;
+        const double* ui = u_init + (long)inst * n * 2;
+        for (int k = 0; k < n; ++k)
+            for (int i = 0; i < 3; ++i) M.st(L.X + 3 * k + i, T(xi[3 * k + i]));
+        for (int k = 0; k < n - 1; ++k)
+            for (int j = 0; j < 2; ++j) M.st(L.U + 2 * k + j, T(ui[2 * k + j]));
+        M.st(L.D, T(dt_init[inst]));
+    } else {
+        S.cold_start();
+    }
+    mpc::SolveStats<T> st = S.solve();
+    // getStateAndControlTimeSeries: states x_0..x_{n-2},xf ; controls + duplicate of the last
+    double* xo = x_out + (long)inst * n * 3;
+    double* uo = u_out + (long)inst * n * 2;
+    for (int k = 0; k < n; ++k)
+        for (int i = 0; i < 3; ++i) xo[3 * k + i] = double(M.ld(L.X + 3 * k + i));
+    for (int k = 0; k < n; ++k) {
+        const int ks = k < n - 1 ? k : n - 2;
+        for (int j = 0; j < 2; ++j) uo[2 * k + j] = double(M.ld(L.U + 2 * ks + j));
+    }
+    dt_out[inst] = double(M.ld(L.D));
+    if (status) status[inst] = st.status;
+    if (iters) iters[inst] = st.iters;
+}
+
+}  // namespace
+
+struct mpc_solver {
+    mpc_config cfg;
+    mpc::Problem<double> P64;
+    mpc::Problem<float> P32;
+    mpc::Layout L;
+    int device;
+    int max_batch;
+    long stride;
+    hipStream_t stream;
+    hipEvent_t ev0, ev1;
+    void* ws;
+    // staging for the host-pointer entry point
+    double *d_x0, *d_xf, *d_up, *d_dtp, *d_xi, *d_ui, *d_dti, *d_xo, *d_uo, *d_dto;
+    int32_t *d_status, *d_iters;
+    bool timed;
+};
+
+extern "C" {
+
+void mpc_config_defaults(mpc_config* c) {
+    if (!c) return;
+    memset(c, 0, sizeof(*c));
+    c->model = MPC_MODEL_UNICYCLE;       // src/controller.cpp:346
+    c->model_params[0] = 0.5;            // :355
+    c->model_params[1] = 1.0;
+    c->n = 20;                           // :274
+    c->dt_ref = 0.3;                     // :278
+    c->dt_free = 1;                      // :236
+    c->dt_lb = 0.0;                      // :242
+    c->dt_ub = 10.0;                     // :244
+    c->xf_fixed[0] = c->xf_fixed[1] = c->xf_fixed[2] = 1;   // :282
+    c->collocation = MPC_COLLOC_FORWARD; // :298
+    c->objective = MPC_OBJ_MIN_TIME;     // :551
+    c->u_lb[0] = -0.2; c->u_ub[0] = 0.4; // :497-511
+    c->u_lb[1] = -0.3; c->u_ub[1] = 0.3;
+    for (int j = 0; j < 2; ++j) { c->du_lb[j] = -1e30; c->du_ub[j] = 1e30; }   // :756-770 (0 => inf)
+    c->max_iter = 100;                   // :391
+    c->tol = 1e-8;
+    c->mu_init = 0.1;
+    c->precision = MPC_FP64;
+}
+
+const char* mpc_last_error(void) { return g_err; }
+int32_t mpc_version(void) { return 100; }
+
+int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_solver** out) {
+    g_err[0] = 0;
+    if (!cfg || !out || max_batch <= 0) { set_err("mpc_create: bad argument"); return MPC_EINVAL; }
+    *out = nullptr;
+    if (cfg->n < 3 || cfg->n > 4096) { set_err("mpc_create: n out of range [3,4096]"); return MPC_EINVAL; }
+    if (cfg->model < 0 || cfg->model > 3) { set_err("mpc_create: unknown model"); return MPC_EINVAL; }
+    if (cfg->collocation != MPC_COLLOC_FORWARD) { set_err("mpc_create: only forward_differences collocation is implemented"); return MPC_EINVAL; }
+    if (cfg->objective != MPC_OBJ_MIN_TIME && cfg->objective != MPC_OBJ_QUADRATIC) { set_err("mpc_create: unknown objective"); return MPC_EINVAL; }
+    if (cfg->objective == MPC_OBJ_MIN_TIME && !cfg->dt_free) { set_err("mpc_create: minimum_time needs a variable grid (dt_free)"); return MPC_EINVAL; }
+    if (!(cfg->dt_ref > 0)) { set_err("mpc_create: dt_ref must be > 0"); return MPC_EINVAL; }
+    for (int j = 0; j < 2; ++j)
+        if (!(cfg->u_lb[j] < cfg->u_ub[j])) { set_err("mpc_create: control box must be finite and non-empty"); return MPC_EINVAL; }
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0) {
+        set_err("mpc_create: no HIP device available (this library has no CPU fallback)");
+        return MPC_ENODEV;
+    }
+    if (device < 0 || device >= ndev) { set_err("mpc_create: device index out of range"); return MPC_ENODEV; }
+    HIP_TRY(hipSetDevice(device));
+    mpc_solver* s = new (std::nothrow) mpc_solver;
+    if (!s) return MPC_ENOMEM;
+    memset(s, 0, sizeof(*s));
+    s->cfg = *cfg;
+    mpc::fill_problem<double>(*cfg, s->P64);
+    mpc::fill_problem<float>(*cfg, s->P32);
+    s->L = mpc::Layout::make(cfg->n);
+    s->device = device;
+    s->max_batch = max_batch;
+    s->stride = ((long)max_batch + kLanes - 1) / kLanes * kLanes;
+    const size_t tsz = cfg->precision == MPC_FP32 ? 4 : 8;
+    const size_t n = cfg->n;
+    hipError_t er = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
+    if (er == hipSuccess) er = hipEventCreate(&s->ev0);
+    if (er == hipSuccess) er = hipEventCreate(&s->ev1);
+    if (er == hipSuccess) er = hipMalloc(&s->ws, (size_t)s->L.total * s->stride * tsz);
+    const size_t Bm = max_batch;
+    if (er == hipSuccess) er = hipMalloc((void**)&s->d_x0, Bm * 3 * 8);
+    if (er == hipSuccess) er = hipMalloc((void**)&s->d_xf, Bm * 3 * 8);
+    if (er == hipSuccess) er = hipMalloc((void**)&s->d_up, Bm * 2 * 8);
+    if (er == hipSuccess) er = hipMalloc((void**)&s->d_dtp, Bm * 8);
+    if (er == hipSuccess) er = hipMalloc((void**)&s->d_xi, Bm * n * 3 * 8);
+    if (er == hipSuccess) er = hipMalloc((void**)&s->d_ui, Bm * n * 2 * 8);
+    if (er == hipSuccess) er = hipMalloc((void**)&s->d_dti, Bm * 8);
+    if (er == hipSuccess) er = hipMalloc((void**)&s->d_xo, Bm * n * 3 * 8);
+    if (er == hipSuccess) er = hipMalloc((void**)&s->d_uo, Bm * n * 2 * 8);
+    if (er == hipSuccess) er = hipMalloc((void**)&s->d_dto, Bm * 8);
+    if (er == hipSuccess) er = hipMalloc((void**)&s->d_status, Bm * 4);
+    if (er == hipSuccess) er = hipMalloc((void**)&s->d_iters, Bm * 4);
+    if (er != hipSuccess) {
+        set_err("mpc_create: allocation", er);
+        mpc_destroy(s);
+        return er == hipErrorOutOfMemory ? MPC_ENOMEM : MPC_EHIP;
+    }
+    *out = s;
+    return MPC_OK;
+}
+
+int mpc_reset(mpc_solver* s) { return s ? MPC_OK : MPC_EINVAL; }
+
+void mpc_destroy(mpc_solver* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    void* bufs[] = {s->ws, s->d_x0, s->d_xf, s->d_up, s->d_dtp, s->d_xi, s->d_ui, s->d_dti, s->d_xo, s->d_uo, s->d_dto, s->d_status, s->d_iters};
+    for (void* b : bufs) if (b) (void)hipFree(b);
+    if (s->ev0) (void)hipEventDestroy(s->ev0);
+    if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->stream) (void)hipStreamDestroy(s->stream);
+    delete s;
+}
+
+}  // extern "C"
+
+template <typename T, int MODEL>
+static void launch_model(mpc_solver* s, const mpc::Problem<T>& P, int B, const double* x0, const double* xf, const double* up,
+                         const double* dtp, const double* xi, const double* ui, const double* dti, double* xo, double* uo,
+                         double* dto, int32_t* st, int32_t* it) {
+    dim3 grid((B + kLanes - 1) / kLanes), block(kLanes);
+    hipLaunchKernelGGL((mpc_ipm_solve_kernel<T, MODEL>), grid, block, 0, s->stream, P, s->L, (T*)s->ws, s->stride, B, x0, xf, up,
+                       dtp, xi, ui, dti, xo, uo, dto, st, it);
+}
+
+template <typename T>
+static void launch_prec(mpc_solver* s, const mpc::Problem<T>& P, int B, const double* x0, const double* xf, const double* up,
+                        const double* dtp, const double* xi, const double* ui, const double* dti, double* xo, double* uo,
+                        double* dto, int32_t* st, int32_t* it) {
+    switch (s->cfg.model) {
+        case MPC_MODEL_UNICYCLE: launch_model<T, mpc::MODEL_UNICYCLE>(s, P, B, x0, xf, up, dtp, xi, ui, dti, xo, uo, dto, st, it); break;
+        case MPC_MODEL_SIMPLE_CAR: launch_model<T, mpc::MODEL_SIMPLE_CAR>(s, P, B, x0, xf, up, dtp, xi, ui, dti, xo, uo, dto, st, it); break;
+        case MPC_MODEL_SIMPLE_CAR_FRONT: launch_model<T, mpc::MODEL_SIMPLE_CAR_FRONT>(s, P, B, x0, xf, up, dtp, xi, ui, dti, xo, uo, dto, st, it); break;
+        default: launch_model<T, mpc::MODEL_KINEMATIC_BICYCLE>(s, P, B, x0, xf, up, dtp, xi, ui, dti, xo, uo, dto, st, it); break;
+    }
+}
+
+extern "C" {
+
+int mpc_solve_batch_device(mpc_solver* s, int32_t B, const double* d_x0, const double* d_xf, const double* d_u_prev,
+                           const double* d_dt_prev, const double* d_x_init, const double* d_u_init, const double* d_dt_init,
+                           double* d_x_out, double* d_u_out, double* d_dt_out, int32_t* d_status, int32_t* d_iters) {
+    g_err[0] = 0;
+    if (!s || !d_x0 || !d_xf || !d_x_out || !d_u_out || !d_dt_out) { set_err("mpc_solve_batch_device: null argument"); return MPC_EINVAL; }
+    if (B <= 0) return MPC_OK;
+    if (B > s->max_batch) { set_err("mpc_solve_batch_device: B exceeds max_batch"); return MPC_EBATCH; }
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipEventRecord(s->ev0, s->stream));
+    if (s->cfg.precision == MPC_FP32)
+        launch_prec<float>(s, s->P32, B, d_x0, d_xf, d_u_prev, d_dt_prev, d_x_init, d_u_init, d_dt_init, d_x_out, d_u_out, d_dt_out, d_status, d_iters);
+    else
+        launch_prec<double>(s, s->P64, B, d_x0, d_xf, d_u_prev, d_dt_prev, d_x_init, d_u_init, d_dt_init, d_x_out, d_u_out, d_dt_out, d_status, d_iters);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(s->ev1, s->stream));
+    s->timed = true;
+    return MPC_OK;
+}
+
+int mpc_synchronize(mpc_solver* s) {
+    if (!s) return MPC_EINVAL;
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return MPC_OK;
+}
+
+int mpc_last_kernel_ms(mpc_solver* s, float* ms) {
+    if (!s || !ms) return MPC_EINVAL;
+    if (!s->timed) { *ms = 0.f; return MPC_OK; }
+    HIP_TRY(hipEventSynchronize(s->ev1));
+    HIP_TRY(hipEventElapsedTime(ms, s->ev0, s->ev1));
+    return MPC_OK;
+}
+
+int mpc_solve_batch(mpc_solver* s, int32_t B, const double* x0, const double* xf, const double* u_prev, const double* dt_prev,
+                    const double* x_init, const double* u_init, const double* dt_init, double* x_out, double* u_out,
+                    double* dt_out, int32_t* status, int32_t* iters) {
+    g_err[0] = 0;
+    if (!s || !x0 || !xf || !x_out || !u_out || !dt_out) { set_err("mpc_solve_batch: null argument"); return MPC_EINVAL; }
+    if (B <= 0) return MPC_OK;
+    if (B > s->max_batch) { set_err("mpc_solve_batch: B exceeds max_batch"); return MPC_EBATCH; }
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t n = s->cfg.n, b = B;
+    hipStream_t q = s->stream;
+    HIP_TRY(hipMemcpyAsync(s->d_x0, x0, b * 3 * 8, hipMemcpyHostToDevice, q));
+    HIP_TRY(hipMemcpyAsync(s->d_xf, xf, b * 3 * 8, hipMemcpyHostToDevice, q));
+    if (u_prev) HIP_TRY(hipMemcpyAsync(s->d_up, u_prev, b * 2 * 8, hipMemcpyHostToDevice, q));
+    if (dt_prev) HIP_TRY(hipMemcpyAsync(s->d_dtp, dt_prev, b * 8, hipMemcpyHostToDevice, q));
+    const bool warm = x_init && u_init && dt_init;
+    if (warm) {
+        HIP_TRY(hipMemcpyAsync(s->d_xi, x_init, b * n * 3 * 8, hipMemcpyHostToDevice, q));
+        HIP_TRY(hipMemcpyAsync(s->d_ui, u_init, b * n * 2 * 8, hipMemcpyHostToDevice, q));
+        HIP_TRY(hipMemcpyAsync(s->d_dti, dt_init, b * 8, hipMemcpyHostToDevice, q));
+    }
+    int rc = mpc_solve_batch_device(s, B, s->d_x0, s->d_xf, u_prev ? s->d_up : nullptr, dt_prev ? s->d_dtp : nullptr,
+                                    warm ? s->d_xi : nullptr, warm ? s->d_ui : nullptr, warm ? s->d_dti : nullptr, s->d_xo,
+                                    s->d_uo, s->d_dto, s->d_status, s->d_iters);
+    if (rc != MPC_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(x_out, s->d_xo, b * n * 3 * 8, hipMemcpyDeviceToHost, q));
+    HIP_TRY(hipMemcpyAsync(u_out, s->d_uo, b * n * 2 * 8, hipMemcpyDeviceToHost, q));
+    HIP_TRY(hipMemcpyAsync(dt_out, s->d_dto, b * 8, hipMemcpyDeviceToHost, q));
+    if (status) HIP_TRY(hipMemcpyAsync(status, s->d_status, b * 4, hipMemcpyDeviceToHost, q));
+    if (iters) HIP_TRY(hipMemcpyAsync(iters, s->d_iters, b * 4, hipMemcpyDeviceToHost, q));
+    HIP_TRY(hipStreamSynchronize(q));
+    return MPC_OK;
+}
+
+}  // extern "C"

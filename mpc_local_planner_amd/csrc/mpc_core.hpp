@@ -1,0 +1,1126 @@
+// mpc_core.hpp -- per-instance interior-point solve of the mpc_local_planner NLP with a
+// stage-structured (Riccati) KKT factor/solve.  One GPU lane owns one planner instance;
+// all per-instance arrays live in an instance-minor (SoA) workspace so that the 64 lanes of a
+// wavefront touch 64 consecutive words for every (field, stage, component) they load/store.
+//
+// What is solved (reference files under /root/reference/mpc_local_planner/):
+//   variables   x_1..x_{n-1} (SE2), u_0..u_{n-2}, dt       src/optimal_control/full_discretization_grid_base_se2.cpp:564-577
+//   equality    forward-difference collocation              include/.../optimal_control/fd_collocation_se2.h:54-69
+//   dynamics    unicycle / simple car / bicycle             include/.../systems/*.h
+//   objective   (n-1)*dt  |  quadratic form + terminal      src/controller.cpp:551-668, src/optimal_control/quadratic_cost_se2.cpp:31-52
+//   rows <= 0   control-rate rows, control/dt boxes         src/optimal_control/stage_inequality_se2.cpp:191-222, src/controller.cpp:511-543
+//   retraction  theta <- wrap(theta + dtheta)               include/.../optimal_control/vector_vertex_se2.h:79-96
+// Rows are used in "solver form" (positive rescalings of the reference rows, same KKT points):
+//   c_k = x_k + dt f(x_k,u_k) - x_{k+1}   (= dt * reference defect),  rate rows multiplied by dt_prev.
+//
+// Linear algebra: the Newton system of the barrier problem is an LQ problem over the augmented
+// stage state xi_k = (x_k, u_{k-1}, dt) in R^6 with control u_k in R^2.  The terminal equality
+// (fixed goal components) is carried through the backward sweep as 3 extra right-hand sides
+// (Bryson-Ho sweep method); dt is a state whose initial value is free.  No pivoting across
+// stages, no sparse solver, O(n) work and O(n) storage per instance.
+#pragma once
+#include <cmath>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define MPC_HD __host__ __device__ __forceinline__
+#else
+#define MPC_HD inline
+#endif
+
+namespace mpc {
+
+constexpr int MODEL_UNICYCLE = 0;
+constexpr int MODEL_SIMPLE_CAR = 1;
+constexpr int MODEL_SIMPLE_CAR_FRONT = 2;
+constexpr int MODEL_KINEMATIC_BICYCLE = 3;
+constexpr int OBJ_MIN_TIME = 0;
+constexpr int OBJ_QUADRATIC = 1;
+
+constexpr int ST_CONVERGED = 0;
+constexpr int ST_MAX_ITER = 1;
+constexpr int ST_LINESEARCH = 2;
+constexpr int ST_LINSOLVE = 3;
+constexpr int ST_NUMERICAL = 4;
+
+// Problem description in device-friendly form (passed by value as a kernel argument).
+template <typename T>
+struct Problem {
+    int model;
+    int n;               // grid points
+    int dt_free;
+    int xf_fixed[3];
+    int objective;
+    int integral_form;
+    int has_Qf;
+    int rate_on[4];      // slots: lo0, lo1, hi0, hi1 (finite du bound?)
+    int max_iter;
+    T p0, p1;            // model params: L | (lr, lf)
+    T dt_ref, dt_lb, dt_ub;
+    T Q[3], R[2], Qf[3];
+    T u_lb[2], u_ub[2];
+    T rate_lim[4];       // du_lb0, du_lb1, du_ub0, du_ub1
+    // algorithm constants (Waechter & Biegler 2006 names)
+    T tol, mu_init, kappa_eps, kappa_mu, theta_mu, tau_min, bound_push, slack_push;
+    T eta_armijo, rho_frac, delta_first, delta_min, delta_max, kappa_plus, kappa_plus_first, kappa_minus;
+    T curv_kappa, s_max, delta_c, kappa_c;
+    int max_ls;
+};
+
+// Workspace layout: slot index -> word offset = slot * stride + instance.
+struct Layout {
+    int n;
+    int X, U, D, XT, UT, DT, LAM, LAMN, SR, YR, PL, PU, PD, DX, DU, DD, GAIN, CC, TRIG, total;
+    MPC_HD static Layout make(int n) {
+        Layout L;
+        L.n = n;
+        int o = 0;
+        L.X = o;    o += 3 * n;
+        L.U = o;    o += 2 * (n - 1);
+        L.D = o;    o += 1;
+        L.XT = o;   o += 3 * n;
+        L.UT = o;   o += 2 * (n - 1);
+        L.DT = o;   o += 1;
+        L.LAM = o;  o += 3 * (n - 1);
+        L.LAMN = o; o += 3 * (n - 1);
+        L.SR = o;   o += 4 * n;
+        L.YR = o;   o += 4 * n;
+        L.PL = o;   o += 2 * (n - 1);
+        L.PU = o;   o += 2 * (n - 1);
+        L.PD = o;   o += 2;
+        L.DX = o;   o += 3 * n;
+        L.DU = o;   o += 2 * (n - 1);
+        L.DD = o;   o += 1;
+        L.GAIN = o; o += 50 * (n - 1);   // K(12) kappa(2) Knu(6) | Px(18) px(3) Sx(9)
+        L.CC = o;   o += 3 * (n - 1);
+        L.TRIG = o; o += 4 * (n - 1);
+        L.total = o;
+        return L;
+    }
+};
+
+template <typename T>
+struct Mem {
+    T* base;
+    long stride;
+    MPC_HD T ld(int slot) const { return base[(long)slot * stride]; }
+    MPC_HD void st(int slot, T v) const { base[(long)slot * stride] = v; }
+};
+
+template <typename T> MPC_HD T t_abs(T a) { return a < T(0) ? -a : a; }
+template <typename T> MPC_HD T t_max(T a, T b) { return a > b ? a : b; }
+template <typename T> MPC_HD T t_min(T a, T b) { return a < b ? a : b; }
+MPC_HD double t_floor(double a) { return ::floor(a); }
+MPC_HD float t_floor(float a) { return ::floorf(a); }
+MPC_HD double t_log(double a) { return ::log(a); }
+MPC_HD float t_log(float a) { return ::logf(a); }
+MPC_HD double t_pow(double a, double b) { return ::pow(a, b); }
+MPC_HD float t_pow(float a, float b) { return ::powf(a, b); }
+MPC_HD double t_atan(double a) { return ::atan(a); }
+MPC_HD float t_atan(float a) { return ::atanf(a); }
+MPC_HD double t_asin(double a) { return ::asin(a); }
+MPC_HD float t_asin(float a) { return ::asinf(a); }
+MPC_HD double t_tan(double a) { return ::tan(a); }
+MPC_HD float t_tan(float a) { return ::tanf(a); }
+MPC_HD void t_sincos(double a, double* s, double* c) { ::sincos(a, s, c); }
+MPC_HD void t_sincos(float a, float* s, float* c) { ::sincosf(a, s, c); }
+template <typename T> MPC_HD bool t_finite(T a) { return (a - a) == T(0); }   // false for NaN and +-inf
+
+// include/mpc_local_planner/utils/math_utils.h:81-91
+template <typename T>
+MPC_HD T normalize_theta(T th) {
+    const T pi = T(3.14159265358979323846);
+    if (th >= -pi && th < pi) return th;
+    T m = t_floor(th / (T(2) * pi));
+    th = th - m * T(2) * pi;
+    if (th >= pi) th -= T(2) * pi;
+    if (th < -pi) th += T(2) * pi;
+    return th;
+}
+
+// sum of logs as log of a running product (exponent kept separately so it never under/overflows)
+template <typename T>
+struct LogAcc {
+    T m;
+    T acc;
+    MPC_HD LogAcc() : m(T(1)), acc(T(0)) {}
+    MPC_HD void mul(T a) {
+        m *= a;
+        if (m < T(1e-30) || m > T(1e30)) { acc += t_log(m); m = T(1); }
+    }
+    MPC_HD T value() const { return acc + t_log(m); }
+};
+
+// Model functions: f, G = df/d(theta,v,w), and the lambda-contracted second derivative.
+template <typename T>
+struct ModelEval {
+    T f[3];
+    T G[3][3];
+};
+
+// trig cache per stage: t0 = sin, t1 = cos (of theta, or theta+beta), t2 = tan(w)|sin(w)|sin(beta), t3 = model extra
+template <typename T, int MODEL>
+MPC_HD void model_trig(const Problem<T>& P, T th, T w, T tr[4]) {
+    if (MODEL == MODEL_KINEMATIC_BICYCLE) {
+        const T kap = P.p0 / (P.p1 + P.p0);
+        T t = t_tan(w);
+        T beta = t_atan(kap * t);
+        t_sincos(th + beta, &tr[0], &tr[1]);
+        tr[2] = t;
+        tr[3] = beta;
+    } else {
+        t_sincos(th, &tr[0], &tr[1]);
+        if (MODEL == MODEL_SIMPLE_CAR) { tr[2] = t_tan(w); tr[3] = T(0); }
+        else if (MODEL == MODEL_SIMPLE_CAR_FRONT) { t_sincos(w, &tr[2], &tr[3]); }
+        else { tr[2] = T(0); tr[3] = T(0); }
+    }
+}
+
+template <typename T, int MODEL>
+MPC_HD void model_f(const Problem<T>& P, const T tr[4], T v, T w, T f[3]) {
+    f[0] = v * tr[1];
+    f[1] = v * tr[0];
+    if (MODEL == MODEL_UNICYCLE) f[2] = w;
+    else if (MODEL == MODEL_SIMPLE_CAR) f[2] = v * tr[2] / P.p0;
+    else if (MODEL == MODEL_SIMPLE_CAR_FRONT) f[2] = v * tr[2] / P.p0;
+    else { T sb, cb; t_sincos(tr[3], &sb, &cb); f[2] = v * sb / P.p0; }
+}
+
+// G[a][j] = d f_a / d q_j, q = (theta, v, w);  Hq = sum_a lam_a d2 f_a / dq dq (symmetric 3x3)
+template <typename T, int MODEL>
+MPC_HD void model_derivs(const Problem<T>& P, const T tr[4], T v, T w, const T lam[3], T f[3], T G[3][3], T Hq[3][3]) {
+    const T s = tr[0], c = tr[1];
+    for (int a = 0; a < 3; ++a) for (int j = 0; j < 3; ++j) { G[a][j] = T(0); Hq[a][j] = T(0); }
+    if (MODEL == MODEL_KINEMATIC_BICYCLE) {
+        const T lr = P.p0, lf = P.p1;
+        const T kap = lr / (lf + lr);
+        const T t = tr[2];
+        const T tp = T(1) + t * t;
+        const T tpp = T(2) * t * tp;
+        const T den = T(1) + kap * kap * t * t;
+        const T bp = kap * tp / den;
+        const T bpp = kap * (tpp * den - tp * T(2) * kap * kap * t * tp) / (den * den);
+        T sb, cb;
+        t_sincos(tr[3], &sb, &cb);
+        f[0] = v * c; f[1] = v * s; f[2] = v * sb / lr;
+        G[0][0] = -v * s; G[0][1] = c; G[0][2] = -v * s * bp;
+        G[1][0] = v * c;  G[1][1] = s; G[1][2] = v * c * bp;
+        G[2][1] = sb / lr; G[2][2] = v * cb * bp / lr;
+        const T l0 = lam[0], l1 = lam[1], l2 = lam[2];
+        Hq[0][0] = l0 * (-v * c) + l1 * (-v * s);
+        Hq[0][1] = l0 * (-s) + l1 * c;
+        Hq[0][2] = l0 * (-v * c * bp) + l1 * (-v * s * bp);
+        Hq[1][2] = l0 * (-s * bp) + l1 * (c * bp) + l2 * (cb * bp / lr);
+        Hq[2][2] = l0 * (-v * c * bp * bp - v * s * bpp) + l1 * (-v * s * bp * bp + v * c * bpp)
+                 + l2 * (v * (-sb * bp * bp + cb * bpp) / lr);
+    } else {
+        f[0] = v * c; f[1] = v * s;
+        G[0][0] = -v * s; G[0][1] = c;
+        G[1][0] = v * c;  G[1][1] = s;
+        Hq[0][0] = lam[0] * (-v * c) + lam[1] * (-v * s);
+        Hq[0][1] = lam[0] * (-s) + lam[1] * c;
+        if (MODEL == MODEL_UNICYCLE) {
+            f[2] = w;
+            G[2][2] = T(1);
+        } else if (MODEL == MODEL_SIMPLE_CAR) {
+            const T t = tr[2], tp = T(1) + t * t, iL = T(1) / P.p0;
+            f[2] = v * t * iL;
+            G[2][1] = t * iL;
+            G[2][2] = v * tp * iL;
+            Hq[1][2] = lam[2] * tp * iL;
+            Hq[2][2] = lam[2] * v * T(2) * t * tp * iL;
+        } else {  // front-wheel car: tr[2] = sin w, tr[3] = cos w
+            const T iL = T(1) / P.p0;
+            f[2] = v * tr[2] * iL;
+            G[2][1] = tr[2] * iL;
+            G[2][2] = v * tr[3] * iL;
+            Hq[1][2] = lam[2] * tr[3] * iL;
+            Hq[2][2] = -lam[2] * v * tr[2] * iL;
+        }
+    }
+    Hq[1][0] = Hq[0][1]; Hq[2][0] = Hq[0][2]; Hq[2][1] = Hq[1][2];
+}
+
+// rate-row slot helpers: q in 0..3 -> component j, sign sg
+MPC_HD int slot_comp(int q) { return q & 1; }
+template <typename T> MPC_HD T slot_sign(int q) { return q < 2 ? T(-1) : T(1); }
+
+template <typename T>
+struct SolveStats {
+    int status;
+    int iters;
+    T kkt_error;
+    T objective;
+};
+
+template <typename T, int MODEL>
+struct Ipm {
+    const Problem<T>& P;
+    const Layout& L;
+    Mem<T> M;
+    // per-instance inputs
+    T x0[3], xf[3], uprev[2], dtprev;
+    // scalar state
+    T mu, rho, delta_last;
+    int nfix;
+    bool row0_on;
+
+    MPC_HD Ipm(const Problem<T>& p, const Layout& l, Mem<T> m) : P(p), L(l), M(m) {}
+
+    // ---------------------------------------------------------------- accessors
+    MPC_HD T X(int base, int k, int i) const { return M.ld(base + 3 * k + i); }
+    MPC_HD T U(int base, int k, int j) const { return M.ld(base + 2 * k + j); }
+
+    MPC_HD bool row_on(int r, int q) const { return P.rate_on[q] && (r > 0 || row0_on); }
+
+    // value of rate row r, slot q at the given controls / dt      (solver form, <= 0 feasible)
+    MPC_HD T rate_g(int r, int q, T ur, T um, T d) const {
+        const T sg = slot_sign<T>(q);
+        const T dtp = r > 0 ? d : dtprev;
+        return sg * ((ur - um) - P.rate_lim[q] * dtp);
+    }
+
+    // ---------------------------------------------------------------- initial point
+    MPC_HD void cold_start() {
+        // Controller::generateInitialStateTrajectory + initializeSequences(xinit) for a 2-pose plan:
+        // src/controller.cpp:807-857, full_discretization_grid_base_se2.cpp:192-239
+        const int n = L.n;
+        const T dth = normalize_theta(xf[2] - x0[2]);
+        for (int k = 0; k < n; ++k) {
+            T fr = T(k) / T(n - 1);
+            T xk[3];
+            if (k == 0) { xk[0] = x0[0]; xk[1] = x0[1]; xk[2] = x0[2]; }
+            else if (k == n - 1) { xk[0] = xf[0]; xk[1] = xf[1]; xk[2] = xf[2]; }
+            else {
+                xk[0] = x0[0] + fr * (xf[0] - x0[0]);
+                xk[1] = x0[1] + fr * (xf[1] - x0[1]);
+                xk[2] = normalize_theta(x0[2] + fr * dth);
+            }
+            for (int i = 0; i < 3; ++i) M.st(L.X + 3 * k + i, xk[i]);
+        }
+        for (int k = 0; k < n - 1; ++k) { M.st(L.U + 2 * k, T(0)); M.st(L.U + 2 * k + 1, T(0)); }
+        M.st(L.D, P.dt_ref);
+    }
+
+    MPC_HD void seed_controls_if_zero() {
+        const int n = L.n;
+        bool any = false;
+        for (int k = 0; k < n - 1; ++k) any = any || (U(L.U, k, 0) != T(0)) || (U(L.U, k, 1) != T(0));
+        if (any) return;
+        const T d = M.ld(L.D);
+        for (int k = 0; k < n - 1; ++k) {
+            T dx = X(L.X, k + 1, 0) - X(L.X, k, 0);
+            T dy = X(L.X, k + 1, 1) - X(L.X, k, 1);
+            T dth = normalize_theta(X(L.X, k + 1, 2) - X(L.X, k, 2));
+            T th = X(L.X, k, 2);
+            T s, c;
+            t_sincos(th, &s, &c);
+            T v = (dx * c + dy * s) / d;
+            v = t_min(t_max(v, P.u_lb[0]), P.u_ub[0]);
+            T rate = dth / d;
+            T w;
+            if (MODEL == MODEL_UNICYCLE) w = rate;
+            else {
+                T vv = t_abs(v) > T(1e-3) ? v : (v >= T(0) ? T(1e-3) : T(-1e-3));
+                if (MODEL == MODEL_SIMPLE_CAR) w = t_atan(P.p0 * rate / vv);
+                else if (MODEL == MODEL_SIMPLE_CAR_FRONT) w = t_asin(t_min(T(1), t_max(T(-1), P.p0 * rate / vv)));
+                else {
+                    T sb = t_min(T(1), t_max(T(-1), P.p0 * rate / vv));
+                    w = t_atan(t_tan(t_asin(sb)) * (P.p1 + P.p0) / P.p0);
+                }
+            }
+            w = t_min(t_max(w, P.u_lb[1]), P.u_ub[1]);
+            M.st(L.U + 2 * k, v);
+            M.st(L.U + 2 * k + 1, w);
+        }
+    }
+
+    MPC_HD T push_interior(T v, T lb, T ub) const {
+        T pl = t_min(P.bound_push * t_max(T(1), t_abs(lb)), P.bound_push * (ub - lb));
+        T pu = t_min(P.bound_push * t_max(T(1), t_abs(ub)), P.bound_push * (ub - lb));
+        return t_min(t_max(v, lb + pl), ub - pu);
+    }
+
+    // ---------------------------------------------------------------- trig / residual cache at (XB,UB,DB)
+    // writes trig and c_k for every interval; returns sum |c| and objective f
+    MPC_HD void eval_point(int XB, int UB, int DB, int TRB, int CB, T& theta_c, T& fobj, T& cinf) const {
+        const int n = L.n;
+        const T d = M.ld(DB);
+        theta_c = T(0);
+        cinf = T(0);
+        fobj = (P.objective == OBJ_MIN_TIME) ? T(n - 1) * d : T(0);
+        T xk[3] = {X(XB, 0, 0), X(XB, 0, 1), X(XB, 0, 2)};
+        for (int k = 0; k < n - 1; ++k) {
+            T v = U(UB, k, 0), w = U(UB, k, 1);
+            T tr[4], f[3];
+            model_trig<T, MODEL>(P, xk[2], w, tr);
+            model_f<T, MODEL>(P, tr, v, w, f);
+            T xn[3] = {X(XB, k + 1, 0), X(XB, k + 1, 1), X(XB, k + 1, 2)};
+            T c0 = d * f[0] - (xn[0] - xk[0]);
+            T c1 = d * f[1] - (xn[1] - xk[1]);
+            T c2 = d * f[2] - normalize_theta(xn[2] - xk[2]);
+            for (int i = 0; i < 4; ++i) M.st(TRB + 4 * k + i, tr[i]);
+            M.st(CB + 3 * k, c0); M.st(CB + 3 * k + 1, c1); M.st(CB + 3 * k + 2, c2);
+            theta_c += t_abs(c0) + t_abs(c1) + t_abs(c2);
+            cinf = t_max(cinf, t_max(t_abs(c0), t_max(t_abs(c1), t_abs(c2))));
+            if (P.objective == OBJ_QUADRATIC) {
+                T xd0 = xk[0] - xf[0], xd1 = xk[1] - xf[1], xd2 = normalize_theta(xk[2] - xf[2]);
+                T sc = P.Q[0] * xd0 * xd0 + P.Q[1] * xd1 * xd1 + P.Q[2] * xd2 * xd2 + P.R[0] * v * v + P.R[1] * w * w;
+                fobj += P.integral_form ? sc * d : sc;
+            }
+            xk[0] = xn[0]; xk[1] = xn[1]; xk[2] = xn[2];
+        }
+        if (P.objective == OBJ_QUADRATIC && P.has_Qf) {
+            T xd[3] = {xk[0] - xf[0], xk[1] - xf[1], normalize_theta(xk[2] - xf[2])};
+            for (int i = 0; i < 3; ++i) if (!P.xf_fixed[i]) fobj += P.Qf[i] * xd[i] * xd[i];
+        }
+    }
+
+    // barrier terms and inequality residuals at (UB,DB) with slacks scaled implicitly:
+    // for the (linear) rate rows  g(z+a dz) + (s + a ds) = (1-a)(g+s), so only log terms need the trial slacks.
+    MPC_HD T barrier_logs(int UB, int DB, T alpha, bool trial) const {
+        // returns  sum log(s) + sum log(u-lb) + sum log(ub-u) + logs of dt bounds  at the current (alpha=0)
+        // or trial point; trial slacks s + alpha*ds are recomputed from the stored step.
+        const int n = L.n;
+        LogAcc<T> acc;
+        const T d = M.ld(DB);
+        for (int k = 0; k < n - 1; ++k) {
+            for (int j = 0; j < 2; ++j) {
+                T u = U(UB, k, j);
+                acc.mul(u - P.u_lb[j]);
+                acc.mul(P.u_ub[j] - u);
+            }
+        }
+        if (P.dt_free) { acc.mul(d - P.dt_lb); acc.mul(P.dt_ub - d); }
+        for (int r = 0; r < n; ++r) {
+            for (int q = 0; q < 4; ++q) {
+                if (!row_on(r, q)) continue;
+                T s = M.ld(L.SR + 4 * r + q);
+                if (trial) s += alpha * row_ds(r, q);
+                acc.mul(s);
+            }
+        }
+        return acc.value();
+    }
+
+    // J_g dz for rate row r, slot q, from the stored step
+    MPC_HD T row_jdz(int r, int q) const {
+        const int n = L.n;
+        const int j = slot_comp(q);
+        const T sg = slot_sign<T>(q);
+        T dur = r < n - 1 ? M.ld(L.DU + 2 * r + j) : T(0);
+        T dum = r > 0 ? M.ld(L.DU + 2 * (r - 1) + j) : T(0);
+        T dd = r > 0 ? M.ld(L.DD) : T(0);
+        return sg * ((dur - dum) - P.rate_lim[q] * dd);
+    }
+    MPC_HD T row_val(int r, int q) const {
+        const int n = L.n;
+        const int j = slot_comp(q);
+        T ur = r < n - 1 ? U(L.U, r, j) : T(0);
+        T um = r > 0 ? U(L.U, r - 1, j) : uprev[j];
+        return rate_g(r, q, ur, um, M.ld(L.D));
+    }
+    MPC_HD T row_ds(int r, int q) const {
+        T s = M.ld(L.SR + 4 * r + q);
+        return -(row_val(r, q) + s) - row_jdz(r, q);
+    }
+
+    // ---------------------------------------------------------------- KKT error pass
+    struct Err {
+        T rd, rp, cmin, cmax, sum_mult, sum_bmult;
+        int n_mult, n_bmult;
+        T theta;   // l1 constraint violation
+    };
+
+    MPC_HD Err kkt_pass() const {
+        const int n = L.n;
+        Err e;
+        e.rd = T(0); e.rp = T(0); e.cmin = T(1e30); e.cmax = T(0); e.sum_mult = T(0); e.sum_bmult = T(0);
+        e.n_mult = 0; e.n_bmult = 0; e.theta = T(0);
+        const T d = M.ld(L.D);
+        T rd_d = (P.objective == OBJ_MIN_TIME) ? T(n - 1) : T(0);
+        T lam_prev[3] = {T(0), T(0), T(0)};
+        for (int k = 0; k < n - 1; ++k) {
+            T lam[3] = {M.ld(L.LAM + 3 * k), M.ld(L.LAM + 3 * k + 1), M.ld(L.LAM + 3 * k + 2)};
+            T tr[4] = {M.ld(L.TRIG + 4 * k), M.ld(L.TRIG + 4 * k + 1), M.ld(L.TRIG + 4 * k + 2), M.ld(L.TRIG + 4 * k + 3)};
+            T v = U(L.U, k, 0), w = U(L.U, k, 1);
+            T f[3], G[3][3], Hq[3][3];
+            model_derivs<T, MODEL>(P, tr, v, w, lam, f, G, Hq);
+            T gq[3];
+            for (int j = 0; j < 3; ++j) gq[j] = lam[0] * G[0][j] + lam[1] * G[1][j] + lam[2] * G[2][j];
+            for (int i = 0; i < 3; ++i) {
+                T ci = M.ld(L.CC + 3 * k + i);
+                e.rp = t_max(e.rp, t_abs(ci));
+                e.theta += t_abs(ci);
+                e.sum_mult += t_abs(lam[i]);
+            }
+            e.n_mult += 3;
+            rd_d += lam[0] * f[0] + lam[1] * f[1] + lam[2] * f[2];
+            // quadratic objective gradient pieces
+            T gx[3] = {T(0), T(0), T(0)}, gu[2] = {T(0), T(0)};
+            if (P.objective == OBJ_QUADRATIC) {
+                T w8 = P.integral_form ? d : T(1);
+                T xd[3] = {X(L.X, k, 0) - xf[0], X(L.X, k, 1) - xf[1], normalize_theta(X(L.X, k, 2) - xf[2])};
+                for (int i = 0; i < 3; ++i) gx[i] = T(2) * P.Q[i] * xd[i] * w8;
+                gu[0] = T(2) * P.R[0] * v * w8; gu[1] = T(2) * P.R[1] * w * w8;
+                if (P.integral_form)
+                    rd_d += P.Q[0] * xd[0] * xd[0] + P.Q[1] * xd[1] * xd[1] + P.Q[2] * xd[2] * xd[2] + P.R[0] * v * v + P.R[1] * w * w;
+            }
+            // x_k stationarity (k >= 1)
+            if (k >= 1) {
+                T r0 = gx[0] + lam[0] - lam_prev[0];
+                T r1 = gx[1] + lam[1] - lam_prev[1];
+                T r2 = gx[2] + lam[2] + d * gq[0] - lam_prev[2];
+                e.rd = t_max(e.rd, t_max(t_abs(r0), t_max(t_abs(r1), t_abs(r2))));
+            }
+            // u_k stationarity
+            for (int j = 0; j < 2; ++j) {
+                T u = j == 0 ? v : w;
+                T pl = M.ld(L.PL + 2 * k + j), pu = M.ld(L.PU + 2 * k + j);
+                T r = gu[j] + d * gq[1 + j] - pl + pu;
+                for (int q = j; q < 4; q += 2) {
+                    const T sg = slot_sign<T>(q);
+                    if (row_on(k, q)) r += sg * M.ld(L.YR + 4 * k + q);
+                    if (row_on(k + 1, q)) r -= sg * M.ld(L.YR + 4 * (k + 1) + q);
+                }
+                e.rd = t_max(e.rd, t_abs(r));
+                T cl = (u - P.u_lb[j]) * pl, cu = (P.u_ub[j] - u) * pu;
+                e.cmin = t_min(e.cmin, t_min(cl, cu));
+                e.cmax = t_max(e.cmax, t_max(cl, cu));
+                e.sum_bmult += pl + pu;
+                e.n_bmult += 2;
+            }
+            lam_prev[0] = lam[0]; lam_prev[1] = lam[1]; lam_prev[2] = lam[2];
+        }
+        // free terminal components
+        for (int i = 0; i < 3; ++i) {
+            if (!P.xf_fixed[i]) {
+                T g = T(0);
+                if (P.objective == OBJ_QUADRATIC && P.has_Qf) {
+                    T xd = X(L.X, n - 1, i) - xf[i];
+                    if (i == 2) xd = normalize_theta(xd);
+                    g = T(2) * P.Qf[i] * xd;
+                }
+                e.rd = t_max(e.rd, t_abs(g - lam_prev[i]));
+            }
+        }
+        // rate rows
+        for (int r = 0; r < n; ++r) {
+            for (int q = 0; q < 4; ++q) {
+                if (!row_on(r, q)) continue;
+                T s = M.ld(L.SR + 4 * r + q), y = M.ld(L.YR + 4 * r + q);
+                T res = row_val(r, q) + s;
+                e.rp = t_max(e.rp, t_abs(res));
+                e.theta += t_abs(res);
+                e.cmin = t_min(e.cmin, s * y);
+                e.cmax = t_max(e.cmax, s * y);
+                e.sum_bmult += y;
+                e.n_bmult += 1;
+                if (r > 0) rd_d -= slot_sign<T>(q) * P.rate_lim[q] * y;
+            }
+        }
+        if (P.dt_free) {
+            T pl = M.ld(L.PD), pu = M.ld(L.PD + 1);
+            rd_d += -pl + pu;
+            e.rd = t_max(e.rd, t_abs(rd_d));
+            T cl = (d - P.dt_lb) * pl, cu = (P.dt_ub - d) * pu;
+            e.cmin = t_min(e.cmin, t_min(cl, cu));
+            e.cmax = t_max(e.cmax, t_max(cl, cu));
+            e.sum_bmult += pl + pu;
+            e.n_bmult += 2;
+        }
+        e.sum_mult += e.sum_bmult;
+        e.n_mult += e.n_bmult;
+        return e;
+    }
+
+    MPC_HD T err_value(const Err& e, T mu_t) const {
+        T sd = t_max(P.s_max, e.sum_mult / T(e.n_mult > 0 ? e.n_mult : 1)) / P.s_max;
+        T sc = t_max(P.s_max, e.sum_bmult / T(e.n_bmult > 0 ? e.n_bmult : 1)) / P.s_max;
+        T comp = e.n_bmult > 0 ? t_max(e.cmax - mu_t, mu_t - e.cmin) : T(0);
+        return t_max(e.rd / sd, t_max(e.rp, comp / sc));
+    }
+
+    // ---------------------------------------------------------------- backward Riccati sweep
+    // returns false if a stage pivot is (numerically) singular
+    MPC_HD bool backward(T delta, T dc, T& dd_out, T nu_out[3]) const {
+        const int n = L.n;
+        const T d = M.ld(L.D);
+        T Pm[6][6], pv[6], S[6][3], W[3][3], om[3];
+        for (int a = 0; a < 6; ++a) { pv[a] = T(0); for (int b = 0; b < 6; ++b) Pm[a][b] = T(0); for (int b = 0; b < 3; ++b) S[a][b] = T(0); }
+        for (int a = 0; a < 3; ++a) { om[a] = T(0); for (int b = 0; b < 3; ++b) W[a][b] = T(0); }
+        // ---- terminal stage: xi = (x_{n-1}, u_{n-2}, dt)
+        for (int i = 0; i < 3; ++i) {
+            if (P.xf_fixed[i]) { S[i][i] = T(1); W[i][i] = -dc; }
+            else {
+                Pm[i][i] = delta;
+                if (P.objective == OBJ_QUADRATIC && P.has_Qf) {
+                    T xd = X(L.X, n - 1, i) - xf[i];
+                    if (i == 2) xd = normalize_theta(xd);
+                    Pm[i][i] += T(2) * P.Qf[i];
+                    pv[i] = T(2) * P.Qf[i] * xd;
+                }
+            }
+        }
+        for (int q = 0; q < 4; ++q) {
+            const int r = n - 1;
+            if (!row_on(r, q)) continue;
+            const int j = slot_comp(q);
+            const T sg = slot_sign<T>(q), lim = P.rate_lim[q];
+            T s = M.ld(L.SR + 4 * r + q), y = M.ld(L.YR + 4 * r + q);
+            T sig = y / s;
+            T ybar = mu / s + sig * (row_val(r, q) + s);
+            // a over (up_j, d) = (-sg, -sg*lim)
+            Pm[3 + j][3 + j] += sig;
+            Pm[3 + j][5] += sig * lim; Pm[5][3 + j] += sig * lim;
+            Pm[5][5] += sig * lim * lim;
+            pv[3 + j] += -sg * ybar;
+            pv[5] += -sg * lim * ybar;
+        }
+        // ---- stages n-2 .. 0
+        for (int k = n - 2; k >= 0; --k) {
+            T lam[3] = {M.ld(L.LAM + 3 * k), M.ld(L.LAM + 3 * k + 1), M.ld(L.LAM + 3 * k + 2)};
+            T tr[4] = {M.ld(L.TRIG + 4 * k), M.ld(L.TRIG + 4 * k + 1), M.ld(L.TRIG + 4 * k + 2), M.ld(L.TRIG + 4 * k + 3)};
+            T ck[3] = {M.ld(L.CC + 3 * k), M.ld(L.CC + 3 * k + 1), M.ld(L.CC + 3 * k + 2)};
+            T v = U(L.U, k, 0), w = U(L.U, k, 1);
+            T f[3], G[3][3], Hq[3][3];
+            model_derivs<T, MODEL>(P, tr, v, w, lam, f, G, Hq);
+            // store next-stage value rows needed for lambda_k in the forward sweep
+            {
+                const int gb = L.GAIN + 50 * k + 20;
+                for (int a = 0; a < 3; ++a) for (int b = 0; b < 6; ++b) M.st(gb + 6 * a + b, Pm[a][b]);
+                for (int a = 0; a < 3; ++a) M.st(gb + 18 + a, pv[a]);
+                for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) M.st(gb + 21 + 3 * a + b, S[a][b]);
+            }
+            // ptilde = p+ + P+[:,0:3] c ;  omega += S+[0:3,:]^T c
+            T pt[6];
+            for (int a = 0; a < 6; ++a) pt[a] = pv[a] + Pm[a][0] * ck[0] + Pm[a][1] * ck[1] + Pm[a][2] * ck[2];
+            for (int b = 0; b < 3; ++b) om[b] += S[0][b] * ck[0] + S[1][b] * ck[1] + S[2][b] * ck[2];
+            // Gx = [Ax | f] (3x4), Ax = I + d * G[:,0] e_theta^T ; Bx = d * G[:,1:3]
+            T Gx[3][4], Bx[3][2];
+            for (int a = 0; a < 3; ++a) {
+                Gx[a][0] = a == 0 ? T(1) : T(0);
+                Gx[a][1] = a == 1 ? T(1) : T(0);
+                Gx[a][2] = (a == 2 ? T(1) : T(0)) + d * G[a][0];
+                Gx[a][3] = f[a];
+                Bx[a][0] = d * G[a][1];
+                Bx[a][1] = d * G[a][2];
+            }
+            // Z = P+ G (6x4), Y = P+ Gam (6x2)
+            T Z[6][4], Y[6][2];
+            for (int a = 0; a < 6; ++a) {
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    T z = Pm[a][0] * Gx[0][c4] + Pm[a][1] * Gx[1][c4] + Pm[a][2] * Gx[2][c4];
+                    if (c4 == 3) z += Pm[a][5];
+                    Z[a][c4] = z;
+                }
+                for (int c2 = 0; c2 < 2; ++c2)
+                    Y[a][c2] = Pm[a][0] * Bx[0][c2] + Pm[a][1] * Bx[1][c2] + Pm[a][2] * Bx[2][c2] + Pm[a][3 + c2];
+            }
+            // Qt (6x6) over (x, up, d); index map of the 4 active columns: 0,1,2,5
+            const int im[4] = {0, 1, 2, 5};
+            T Qt[6][6], Mt[2][6], Rt[2][2], qt[6], rt[2], Sx[6][3], Su[2][3];
+            for (int a = 0; a < 6; ++a) { qt[a] = T(0); for (int b = 0; b < 6; ++b) Qt[a][b] = T(0); for (int b = 0; b < 3; ++b) Sx[a][b] = T(0); }
+            for (int a = 0; a < 2; ++a) for (int b = 0; b < 6; ++b) Mt[a][b] = T(0);
+            for (int r4 = 0; r4 < 4; ++r4) {
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    T z = Gx[0][r4] * Z[0][c4] + Gx[1][r4] * Z[1][c4] + Gx[2][r4] * Z[2][c4];
+                    if (r4 == 3) z += Z[5][c4];
+                    Qt[im[r4]][im[c4]] = z;
+                }
+                T g = Gx[0][r4] * pt[0] + Gx[1][r4] * pt[1] + Gx[2][r4] * pt[2];
+                if (r4 == 3) g += pt[5];
+                qt[im[r4]] = g;
+                for (int b = 0; b < 3; ++b) {
+                    T sgs = Gx[0][r4] * S[0][b] + Gx[1][r4] * S[1][b] + Gx[2][r4] * S[2][b];
+                    if (r4 == 3) sgs += S[5][b];
+                    Sx[im[r4]][b] = sgs;
+                }
+            }
+            for (int a = 0; a < 2; ++a) {
+                for (int c4 = 0; c4 < 4; ++c4)
+                    Mt[a][im[c4]] = Bx[0][a] * Z[0][c4] + Bx[1][a] * Z[1][c4] + Bx[2][a] * Z[2][c4] + Z[3 + a][c4];
+                for (int b = 0; b < 2; ++b)
+                    Rt[a][b] = Bx[0][a] * Y[0][b] + Bx[1][a] * Y[1][b] + Bx[2][a] * Y[2][b] + Y[3 + a][b];
+                rt[a] = Bx[0][a] * pt[0] + Bx[1][a] * pt[1] + Bx[2][a] * pt[2] + pt[3 + a];
+                for (int b = 0; b < 3; ++b)
+                    Su[a][b] = Bx[0][a] * S[0][b] + Bx[1][a] * S[1][b] + Bx[2][a] * S[2][b] + S[3 + a][b];
+            }
+            // ---- add the stage cost (Lagrangian curvature + condensed barrier terms)
+            // (i) curvature of lam^T (d f)
+            Qt[2][2] += d * Hq[0][0];
+            Mt[0][2] += d * Hq[0][1]; Mt[1][2] += d * Hq[0][2];
+            Rt[0][0] += d * Hq[1][1]; Rt[0][1] += d * Hq[1][2]; Rt[1][0] += d * Hq[1][2]; Rt[1][1] += d * Hq[2][2];
+            {
+                T gq0 = lam[0] * G[0][0] + lam[1] * G[1][0] + lam[2] * G[2][0];
+                T gq1 = lam[0] * G[0][1] + lam[1] * G[1][1] + lam[2] * G[2][1];
+                T gq2 = lam[0] * G[0][2] + lam[1] * G[1][2] + lam[2] * G[2][2];
+                Qt[2][5] += gq0; Qt[5][2] += gq0;
+                Mt[0][5] += gq1; Mt[1][5] += gq2;
+            }
+            // (ii) objective
+            if (P.objective == OBJ_QUADRATIC) {
+                T w8 = P.integral_form ? d : T(1);
+                T xd[3] = {X(L.X, k, 0) - xf[0], X(L.X, k, 1) - xf[1], normalize_theta(X(L.X, k, 2) - xf[2])};
+                T uu[2] = {v, w};
+                T sc = T(0);
+                for (int i = 0; i < 3; ++i) {
+                    Qt[i][i] += T(2) * P.Q[i] * w8;
+                    qt[i] += T(2) * P.Q[i] * xd[i] * w8;
+                    sc += P.Q[i] * xd[i] * xd[i];
+                    if (P.integral_form) { Qt[i][5] += T(2) * P.Q[i] * xd[i]; Qt[5][i] += T(2) * P.Q[i] * xd[i]; }
+                }
+                for (int j = 0; j < 2; ++j) {
+                    Rt[j][j] += T(2) * P.R[j] * w8;
+                    rt[j] += T(2) * P.R[j] * uu[j] * w8;
+                    sc += P.R[j] * uu[j] * uu[j];
+                    if (P.integral_form) Mt[j][5] += T(2) * P.R[j] * uu[j];
+                }
+                if (P.integral_form) qt[5] += sc;
+            } else if (k == 0) {
+                qt[5] += T(n - 1);
+            }
+            // (iii) control box
+            for (int j = 0; j < 2; ++j) {
+                T u = j == 0 ? v : w;
+                T dl = u - P.u_lb[j], du = P.u_ub[j] - u;
+                T pl = M.ld(L.PL + 2 * k + j), pu = M.ld(L.PU + 2 * k + j);
+                Rt[j][j] += pl / dl + pu / du + delta;
+                rt[j] += -mu / dl + mu / du;
+            }
+            // dt box + regularisation of dt (once, at stage 0)
+            if (k == 0 && P.dt_free) {
+                T dl = d - P.dt_lb, du = P.dt_ub - d;
+                Qt[5][5] += M.ld(L.PD) / dl + M.ld(L.PD + 1) / du + delta;
+                qt[5] += -mu / dl + mu / du;
+            }
+            // (vii) regularisation of x_k
+            if (k >= 1) { Qt[0][0] += delta; Qt[1][1] += delta; Qt[2][2] += delta; }
+            // (iv) rate rows of stage k
+            for (int q = 0; q < 4; ++q) {
+                if (!row_on(k, q)) continue;
+                const int j = slot_comp(q);
+                const T sg = slot_sign<T>(q);
+                const T lim = k > 0 ? P.rate_lim[q] : T(0);   // k = 0: dt_prev is a constant
+                T s = M.ld(L.SR + 4 * k + q), y = M.ld(L.YR + 4 * k + q);
+                T sig = y / s;
+                T um = k > 0 ? U(L.U, k - 1, j) : uprev[j];
+                T ur = j == 0 ? v : w;
+                T ybar = mu / s + sig * (rate_g(k, q, ur, um, d) + s);
+                // a over (u_j, up_j, d) = (sg, -sg, -sg*lim)
+                Rt[j][j] += sig;
+                Mt[j][3 + j] += -sig;
+                Mt[j][5] += -sig * lim;
+                Qt[3 + j][3 + j] += sig;
+                Qt[3 + j][5] += sig * lim; Qt[5][3 + j] += sig * lim;
+                Qt[5][5] += sig * lim * lim;
+                rt[j] += sg * ybar;
+                qt[3 + j] += -sg * ybar;
+                qt[5] += -sg * lim * ybar;
+            }
+            // ---- eliminate u_k
+            T det = Rt[0][0] * Rt[1][1] - Rt[0][1] * Rt[1][0];
+            T scale = t_abs(Rt[0][0] * Rt[1][1]) + t_abs(Rt[0][1] * Rt[1][0]);
+            if (!(t_abs(det) > T(1e-14) * scale) || !t_finite(det)) return false;
+            T id = T(1) / det;
+            T Ri[2][2] = {{Rt[1][1] * id, -Rt[0][1] * id}, {-Rt[1][0] * id, Rt[0][0] * id}};
+            T K[2][6], kap[2], Kn[2][3];
+            for (int a = 0; a < 2; ++a) {
+                for (int b = 0; b < 6; ++b) K[a][b] = Ri[a][0] * Mt[0][b] + Ri[a][1] * Mt[1][b];
+                kap[a] = Ri[a][0] * rt[0] + Ri[a][1] * rt[1];
+                for (int b = 0; b < 3; ++b) Kn[a][b] = Ri[a][0] * Su[0][b] + Ri[a][1] * Su[1][b];
+            }
+            {
+                const int gb = L.GAIN + 50 * k;
+                for (int a = 0; a < 2; ++a) for (int b = 0; b < 6; ++b) M.st(gb + 6 * a + b, K[a][b]);
+                M.st(gb + 12, kap[0]); M.st(gb + 13, kap[1]);
+                for (int a = 0; a < 2; ++a) for (int b = 0; b < 3; ++b) M.st(gb + 14 + 3 * a + b, Kn[a][b]);
+            }
+            for (int a = 0; a < 6; ++a) {
+                for (int b = 0; b < 6; ++b) Pm[a][b] = Qt[a][b] - (Mt[0][a] * K[0][b] + Mt[1][a] * K[1][b]);
+                pv[a] = qt[a] - (Mt[0][a] * kap[0] + Mt[1][a] * kap[1]);
+                for (int b = 0; b < 3; ++b) S[a][b] = Sx[a][b] - (Mt[0][a] * Kn[0][b] + Mt[1][a] * Kn[1][b]);
+            }
+            for (int a = 0; a < 3; ++a) {
+                for (int b = 0; b < 3; ++b) W[a][b] -= Su[0][a] * Kn[0][b] + Su[1][a] * Kn[1][b];
+                om[a] -= Su[0][a] * kap[0] + Su[1][a] * kap[1];
+            }
+            // symmetrise P (round-off hygiene)
+            for (int a = 0; a < 6; ++a) for (int b = a + 1; b < 6; ++b) { T m = T(0.5) * (Pm[a][b] + Pm[b][a]); Pm[a][b] = m; Pm[b][a] = m; }
+        }
+        // ---- stage 0: only d (if free) and nu are unknown
+        T A4[4][5];
+        for (int a = 0; a < 4; ++a) for (int b = 0; b < 5; ++b) A4[a][b] = T(0);
+        if (P.dt_free) {
+            A4[0][0] = Pm[5][5];
+            for (int b = 0; b < 3; ++b) { A4[0][1 + b] = P.xf_fixed[b] ? S[5][b] : T(0); }
+            A4[0][4] = -pv[5];
+        } else { A4[0][0] = T(1); }
+        for (int a = 0; a < 3; ++a) {
+            if (P.xf_fixed[a]) {
+                A4[1 + a][0] = P.dt_free ? S[5][a] : T(0);
+                for (int b = 0; b < 3; ++b) A4[1 + a][1 + b] = P.xf_fixed[b] ? W[a][b] : T(0);
+                A4[1 + a][4] = -om[a];
+            } else { A4[1 + a][1 + a] = T(1); }
+        }
+        // Gaussian elimination with partial pivoting (4x4)
+        for (int c = 0; c < 4; ++c) {
+            int piv = c; T best = t_abs(A4[c][c]);
+            for (int r = c + 1; r < 4; ++r) if (t_abs(A4[r][c]) > best) { best = t_abs(A4[r][c]); piv = r; }
+            if (!(best > T(0)) || !t_finite(best)) return false;
+            if (piv != c) for (int b = 0; b < 5; ++b) { T t = A4[c][b]; A4[c][b] = A4[piv][b]; A4[piv][b] = t; }
+            T ip = T(1) / A4[c][c];
+            for (int r = c + 1; r < 4; ++r) {
+                T m = A4[r][c] * ip;
+                for (int b = c; b < 5; ++b) A4[r][b] -= m * A4[c][b];
+            }
+        }
+        T sol[4];
+        for (int c = 3; c >= 0; --c) {
+            T a = A4[c][4];
+            for (int b = c + 1; b < 4; ++b) a -= A4[c][b] * sol[b];
+            sol[c] = a / A4[c][c];
+        }
+        dd_out = sol[0];
+        nu_out[0] = sol[1]; nu_out[1] = sol[2]; nu_out[2] = sol[3];
+        return t_finite(sol[0]) && t_finite(sol[1]) && t_finite(sol[2]) && t_finite(sol[3]);
+    }
+
+    // ---------------------------------------------------------------- forward sweep
+    struct Fwd {
+        T hdz, clam, dz2, dphi, a_p, a_d, dzmax, nunu;
+        bool finite;
+    };
+
+    MPC_HD void ftb(T val, T dval, T tau, T& alpha) const {
+        if (dval < T(0)) { T a = -tau * val / dval; if (a < alpha) alpha = a; }
+    }
+
+    MPC_HD Fwd forward(T dd, const T nu[3], T tau, T dc) const {
+        const int n = L.n;
+        Fwd o;
+        o.hdz = T(0); o.clam = T(0); o.dz2 = T(0); o.dphi = T(0); o.a_p = T(1); o.a_d = T(1); o.dzmax = T(0); o.finite = true;
+        o.nunu = T(0);
+        for (int i = 0; i < 3; ++i) if (P.xf_fixed[i]) o.nunu += nu[i] * nu[i];
+        const T d = M.ld(L.D);
+        T xi[6] = {T(0), T(0), T(0), T(0), T(0), dd};
+        M.st(L.DD, dd);
+        for (int i = 0; i < 3; ++i) M.st(L.DX + i, T(0));
+        if (P.dt_free) {
+            T dl = d - P.dt_lb, du = P.dt_ub - d;
+            T pl = M.ld(L.PD), pu = M.ld(L.PD + 1);
+            T gb = -mu / dl + mu / du;
+            o.hdz += gb * dd; o.dphi += gb * dd;
+            ftb(dl, dd, tau, o.a_p); ftb(du, -dd, tau, o.a_p);
+            ftb(pl, mu / dl - pl - (pl / dl) * dd, tau, o.a_d);
+            ftb(pu, mu / du - pu + (pu / du) * dd, tau, o.a_d);
+            o.dz2 += dd * dd;
+            o.dzmax = t_max(o.dzmax, t_abs(dd));
+        }
+        if (P.objective == OBJ_MIN_TIME) { o.hdz += T(n - 1) * dd; o.dphi += T(n - 1) * dd; }
+        for (int k = 0; k < n - 1; ++k) {
+            const int gb = L.GAIN + 50 * k;
+            T du_[2];
+            for (int a = 0; a < 2; ++a) {
+                T acc = M.ld(gb + 12 + a);
+                for (int b = 0; b < 6; ++b) acc += M.ld(gb + 6 * a + b) * xi[b];
+                for (int b = 0; b < 3; ++b) acc += M.ld(gb + 14 + 3 * a + b) * nu[b];
+                du_[a] = -acc;
+            }
+            T tr[4] = {M.ld(L.TRIG + 4 * k), M.ld(L.TRIG + 4 * k + 1), M.ld(L.TRIG + 4 * k + 2), M.ld(L.TRIG + 4 * k + 3)};
+            T v = U(L.U, k, 0), w = U(L.U, k, 1);
+            T lz[3] = {T(0), T(0), T(0)};
+            T f[3], G[3][3], Hq[3][3];
+            model_derivs<T, MODEL>(P, tr, v, w, lz, f, G, Hq);
+            T ck[3] = {M.ld(L.CC + 3 * k), M.ld(L.CC + 3 * k + 1), M.ld(L.CC + 3 * k + 2)};
+            // objective / barrier gradient contributions of (x_k, u_k)
+            T uu[2] = {v, w};
+            if (P.objective == OBJ_QUADRATIC) {
+                T w8 = P.integral_form ? d : T(1);
+                T xd[3] = {X(L.X, k, 0) - xf[0], X(L.X, k, 1) - xf[1], normalize_theta(X(L.X, k, 2) - xf[2])};
+                T sc = T(0), g = T(0);
+                for (int i = 0; i < 3; ++i) { g += T(2) * P.Q[i] * xd[i] * w8 * xi[i]; sc += P.Q[i] * xd[i] * xd[i]; }
+                for (int j = 0; j < 2; ++j) { g += T(2) * P.R[j] * uu[j] * w8 * du_[j]; sc += P.R[j] * uu[j] * uu[j]; }
+                if (P.integral_form) g += sc * dd;
+                o.hdz += g; o.dphi += g;
+            }
+            for (int j = 0; j < 2; ++j) {
+                T dl = uu[j] - P.u_lb[j], du = P.u_ub[j] - uu[j];
+                T pl = M.ld(L.PL + 2 * k + j), pu = M.ld(L.PU + 2 * k + j);
+                T gbar = -mu / dl + mu / du;
+                o.hdz += gbar * du_[j]; o.dphi += gbar * du_[j];
+                ftb(dl, du_[j], tau, o.a_p); ftb(du, -du_[j], tau, o.a_p);
+                ftb(pl, mu / dl - pl - (pl / dl) * du_[j], tau, o.a_d);
+                ftb(pu, mu / du - pu + (pu / du) * du_[j], tau, o.a_d);
+                o.dz2 += du_[j] * du_[j];
+                o.dzmax = t_max(o.dzmax, t_abs(du_[j]));
+                M.st(L.DU + 2 * k + j, du_[j]);
+            }
+            // rate rows of stage k: J dz = sg*((du_j - dup_j) - lim*dd[k>0])
+            for (int q = 0; q < 4; ++q) {
+                if (!row_on(k, q)) continue;
+                const int j = slot_comp(q);
+                const T sg = slot_sign<T>(q);
+                T jdz = sg * ((du_[j] - xi[3 + j]) - (k > 0 ? P.rate_lim[q] * dd : T(0)));
+                T s = M.ld(L.SR + 4 * k + q), y = M.ld(L.YR + 4 * k + q);
+                T um = k > 0 ? U(L.U, k - 1, j) : uprev[j];
+                T res = rate_g(k, q, uu[j], um, d) + s;
+                T sig = y / s;
+                T ybar = mu / s + sig * res;
+                T ds = -res - jdz;
+                T dy = ybar + sig * jdz - y;
+                o.hdz += ybar * jdz;
+                o.dphi -= (mu / s) * ds;
+                ftb(s, ds, tau, o.a_p);
+                ftb(y, dy, tau, o.a_d);
+            }
+            // next state
+            T xn[6];
+            for (int a = 0; a < 3; ++a)
+                xn[a] = xi[a] + d * G[a][0] * xi[2] + d * (G[a][1] * du_[0] + G[a][2] * du_[1]) + f[a] * dd + ck[a];
+            xn[3] = du_[0]; xn[4] = du_[1]; xn[5] = dd;
+            // lambda_k = Px xi+ + px + Sx nu
+            for (int a = 0; a < 3; ++a) {
+                T acc = M.ld(gb + 20 + 18 + a);
+                for (int b = 0; b < 6; ++b) acc += M.ld(gb + 20 + 6 * a + b) * xn[b];
+                for (int b = 0; b < 3; ++b) acc += M.ld(gb + 20 + 21 + 3 * a + b) * nu[b];
+                M.st(L.LAMN + 3 * k + a, acc);
+                o.clam += ck[a] * acc;
+                if (!t_finite(acc)) o.finite = false;
+            }
+            for (int a = 0; a < 6; ++a) xi[a] = xn[a];
+            for (int a = 0; a < 3; ++a) {
+                M.st(L.DX + 3 * (k + 1) + a, xi[a]);
+                if (k + 1 < n - 1 || !P.xf_fixed[a]) { o.dz2 += xi[a] * xi[a]; o.dzmax = t_max(o.dzmax, t_abs(xi[a])); }
+            }
+        }
+        // terminal: Qf gradient, final rate rows
+        if (P.objective == OBJ_QUADRATIC && P.has_Qf) {
+            for (int i = 0; i < 3; ++i) if (!P.xf_fixed[i]) {
+                T xd = X(L.X, n - 1, i) - xf[i];
+                if (i == 2) xd = normalize_theta(xd);
+                T g = T(2) * P.Qf[i] * xd * xi[i];
+                o.hdz += g; o.dphi += g;
+            }
+        }
+        for (int q = 0; q < 4; ++q) {
+            const int r = n - 1;
+            if (!row_on(r, q)) continue;
+            const int j = slot_comp(q);
+            const T sg = slot_sign<T>(q);
+            T jdz = sg * ((T(0) - xi[3 + j]) - P.rate_lim[q] * dd);
+            T s = M.ld(L.SR + 4 * r + q), y = M.ld(L.YR + 4 * r + q);
+            T res = row_val(r, q) + s;
+            T sig = y / s;
+            T ybar = mu / s + sig * res;
+            T ds = -res - jdz;
+            T dy = ybar + sig * jdz - y;
+            o.hdz += ybar * jdz;
+            o.dphi -= (mu / s) * ds;
+            ftb(s, ds, tau, o.a_p);
+            ftb(y, dy, tau, o.a_d);
+        }
+        if (!t_finite(o.hdz) || !t_finite(o.dz2)) o.finite = false;
+        return o;
+    }
+
+    // ---------------------------------------------------------------- trial point
+    MPC_HD void make_trial(T alpha) const {
+        const int n = L.n;
+        for (int k = 0; k < n; ++k) {
+            for (int i = 0; i < 3; ++i) {
+                T x = X(L.X, k, i);
+                if (k > 0 && (k < n - 1 || !P.xf_fixed[i])) {
+                    x += alpha * M.ld(L.DX + 3 * k + i);
+                    if (i == 2) x = normalize_theta(x);
+                }
+                M.st(L.XT + 3 * k + i, x);
+            }
+        }
+        for (int k = 0; k < n - 1; ++k)
+            for (int j = 0; j < 2; ++j) M.st(L.UT + 2 * k + j, U(L.U, k, j) + alpha * M.ld(L.DU + 2 * k + j));
+        M.st(L.DT, M.ld(L.D) + (P.dt_free ? alpha * M.ld(L.DD) : T(0)));
+    }
+
+    // ---------------------------------------------------------------- accept: duals, slacks, copy trial -> current
+    MPC_HD void accept(T alpha, T a_d) const {
+        const int n = L.n;
+        const T kS = T(1e10);
+        const T d_old = M.ld(L.D);
+        // slacks and inequality multipliers first (they need the OLD point through row_val)
+        for (int r = 0; r < n; ++r) {
+            for (int q = 0; q < 4; ++q) {
+                if (!row_on(r, q)) continue;
+                T s = M.ld(L.SR + 4 * r + q), y = M.ld(L.YR + 4 * r + q);
+                T res = row_val(r, q) + s;
+                T jdz = row_jdz(r, q);
+                T sig = y / s;
+                T ds = -res - jdz;
+                T dy = mu / s + sig * res + sig * jdz - y;
+                T sn = s + alpha * ds;
+                T yn = y + a_d * dy;
+                yn = t_min(t_max(yn, mu / (kS * sn)), kS * mu / sn);
+                M.st(L.SR + 4 * r + q, sn);
+                M.st(L.YR + 4 * r + q, yn);
+            }
+        }
+        for (int k = 0; k < n - 1; ++k) {
+            for (int j = 0; j < 2; ++j) {
+                T u = U(L.U, k, j), du_ = M.ld(L.DU + 2 * k + j);
+                T dl = u - P.u_lb[j], du = P.u_ub[j] - u;
+                T pl = M.ld(L.PL + 2 * k + j), pu = M.ld(L.PU + 2 * k + j);
+                T pln = pl + a_d * (mu / dl - pl - (pl / dl) * du_);
+                T pun = pu + a_d * (mu / du - pu + (pu / du) * du_);
+                T un = U(L.UT, k, j);
+                T dln = un - P.u_lb[j], dun = P.u_ub[j] - un;
+                pln = t_min(t_max(pln, mu / (kS * dln)), kS * mu / dln);
+                pun = t_min(t_max(pun, mu / (kS * dun)), kS * mu / dun);
+                M.st(L.PL + 2 * k + j, pln);
+                M.st(L.PU + 2 * k + j, pun);
+                M.st(L.U + 2 * k + j, un);
+            }
+            for (int i = 0; i < 3; ++i) {
+                T lo = M.ld(L.LAM + 3 * k + i);
+                M.st(L.LAM + 3 * k + i, lo + alpha * (M.ld(L.LAMN + 3 * k + i) - lo));
+            }
+        }
+        if (P.dt_free) {
+            T dd = M.ld(L.DD);
+            T dl = d_old - P.dt_lb, du = P.dt_ub - d_old;
+            T pl = M.ld(L.PD), pu = M.ld(L.PD + 1);
+            T pln = pl + a_d * (mu / dl - pl - (pl / dl) * dd);
+            T pun = pu + a_d * (mu / du - pu + (pu / du) * dd);
+            T dn = M.ld(L.DT);
+            T dln = dn - P.dt_lb, dun = P.dt_ub - dn;
+            pln = t_min(t_max(pln, mu / (kS * dln)), kS * mu / dln);
+            pun = t_min(t_max(pun, mu / (kS * dun)), kS * mu / dun);
+            M.st(L.PD, pln); M.st(L.PD + 1, pun);
+        }
+        M.st(L.D, M.ld(L.DT));
+        for (int k = 0; k < n; ++k) for (int i = 0; i < 3; ++i) M.st(L.X + 3 * k + i, M.ld(L.XT + 3 * k + i));
+    }
+
+    // ---------------------------------------------------------------- driver
+    // Expects X/U/D filled with the initial vertex values (or call cold_start() first).
+    MPC_HD SolveStats<T> solve() {
+        const int n = L.n;
+        SolveStats<T> out;
+        nfix = P.xf_fixed[0] + P.xf_fixed[1] + P.xf_fixed[2];
+        row0_on = dtprev != T(0);
+        // x_0 := measured state, fixed goal components := xf   (full_discretization_grid_base_se2.cpp:101-110)
+        for (int i = 0; i < 3; ++i) {
+            M.st(L.X + i, x0[i]);
+            if (P.xf_fixed[i]) M.st(L.X + 3 * (n - 1) + i, xf[i]);
+        }
+        seed_controls_if_zero();
+        for (int k = 0; k < n - 1; ++k)
+            for (int j = 0; j < 2; ++j) M.st(L.U + 2 * k + j, push_interior(U(L.U, k, j), P.u_lb[j], P.u_ub[j]));
+        if (P.dt_free) M.st(L.D, push_interior(M.ld(L.D), P.dt_lb, P.dt_ub));
+        else M.st(L.D, P.dt_ref);
+        mu = P.mu_init;
+        rho = T(0);
+        delta_last = T(0);
+        // duals / slacks
+        for (int r = 0; r < n; ++r) {
+            for (int q = 0; q < 4; ++q) {
+                T s = T(1), y = T(0);
+                if (row_on(r, q)) { s = t_max(-row_val(r, q), P.slack_push); y = mu / s; }
+                M.st(L.SR + 4 * r + q, s);
+                M.st(L.YR + 4 * r + q, y);
+            }
+        }
+        for (int k = 0; k < n - 1; ++k) {
+            for (int j = 0; j < 2; ++j) {
+                T u = U(L.U, k, j);
+                M.st(L.PL + 2 * k + j, mu / (u - P.u_lb[j]));
+                M.st(L.PU + 2 * k + j, mu / (P.u_ub[j] - u));
+            }
+            for (int i = 0; i < 3; ++i) M.st(L.LAM + 3 * k + i, T(0));
+        }
+        if (P.dt_free) { T d = M.ld(L.D); M.st(L.PD, mu / (d - P.dt_lb)); M.st(L.PD + 1, mu / (P.dt_ub - d)); }
+        else { M.st(L.PD, T(0)); M.st(L.PD + 1, T(0)); }
+
+        T theta_c, fobj, cinf;
+        eval_point(L.X, L.U, L.D, L.TRIG, L.CC, theta_c, fobj, cinf);
+
+        int it = 0;
+        int status = ST_MAX_ITER;
+        T e0 = T(0);
+        while (true) {
+            Err er = kkt_pass();
+            e0 = err_value(er, T(0));
+            if (!t_finite(e0)) { status = ST_NUMERICAL; break; }
+            if (e0 <= P.tol) { status = ST_CONVERGED; break; }
+            if (it >= P.max_iter) { status = ST_MAX_ITER; break; }
+            // monotone barrier update (Waechter & Biegler eq. 7)
+            for (int guard = 0; guard < 50; ++guard) {
+                T emu = err_value(er, mu);
+                if (emu <= P.kappa_eps * mu && mu > P.tol / T(10)) {
+                    mu = t_max(P.tol / T(10), t_min(P.kappa_mu * mu, t_pow(mu, P.theta_mu)));
+                    rho = T(0);
+                } else break;
+            }
+            const T tau = t_max(P.tau_min, T(1) - mu);
+            const T dc = nfix > 0 ? P.delta_c * t_pow(mu, P.kappa_c) : T(0);
+            // ---- factor/solve with inertia-free regularisation
+            T delta = T(0);
+            bool ok = false;
+            Fwd fw;
+            T dd = T(0), nu[3] = {T(0), T(0), T(0)};
+            T curv = T(0);
+            for (int ntry = 0; ntry <= 40; ++ntry) {
+                bool good = backward(delta, dc, dd, nu);
+                if (good) {
+                    fw = forward(dd, nu, tau, dc);
+                    good = fw.finite;
+                    if (good) {
+                        curv = -fw.hdz + fw.clam - dc * fw.nunu;     // = dz^T (H + delta I) dz
+                        if (curv >= P.curv_kappa * fw.dz2) { ok = true; break; }
+                    }
+                }
+                if (delta == T(0)) delta = (delta_last == T(0)) ? P.delta_first : t_max(P.delta_min, P.kappa_minus * delta_last);
+                else delta *= (delta_last == T(0)) ? P.kappa_plus_first : P.kappa_plus;
+                if (delta > P.delta_max) break;
+            }
+            if (!ok) { status = ST_LINSOLVE; break; }
+            if (delta > T(0)) delta_last = delta;
+            // ---- l1 merit, backtracking
+            const T theta = er.theta;
+            if (theta > T(0)) {
+                T sigma = curv > T(0) ? T(1) : T(0);
+                T rho_trial = (fw.dphi + T(0.5) * sigma * curv) / ((T(1) - P.rho_frac) * theta);
+                if (rho < rho_trial) rho = rho_trial + T(1);
+            }
+            const T phi0 = fobj - mu * barrier_logs(L.U, L.D, T(0), false) + rho * theta;
+            const T Dm = fw.dphi - rho * theta;
+            const T theta_rows = theta - theta_c;      // linear rows: scales with (1 - alpha)
+            T alpha = fw.a_p;
+            bool accepted = false;
+            T th_t = T(0), f_t = T(0), cinf_t = T(0);
+            for (int ls = 0; ls < P.max_ls; ++ls) {
+                if (ls > 0) alpha *= T(0.5);
+                make_trial(alpha);
+                eval_point(L.XT, L.UT, L.DT, L.TRIG, L.CC, th_t, f_t, cinf_t);   // overwrites the caches of the current point
+                T tht = th_t + (T(1) - alpha) * theta_rows;
+                T phit = f_t - mu * barrier_logs(L.UT, L.DT, alpha, true) + rho * tht;
+                if (t_finite(phit) && phit <= phi0 + P.eta_armijo * alpha * Dm) { accepted = true; break; }
+            }
+            if (!accepted && alpha * fw.dzmax < T(1e-14)) {
+                // restore caches of the current point before leaving
+                eval_point(L.X, L.U, L.D, L.TRIG, L.CC, theta_c, fobj, cinf);
+                status = ST_LINESEARCH;
+                break;
+            }
+            accept(alpha, fw.a_d);
+            theta_c = th_t; fobj = f_t; cinf = cinf_t;
+            ++it;
+        }
+        out.status = status;
+        out.iters = it;
+        out.kkt_error = e0;
+        out.objective = fobj;
+        return out;
+    }
+};
+
+}  // namespace mpc

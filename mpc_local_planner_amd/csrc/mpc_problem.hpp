@@ -1,0 +1,59 @@
+// mpc_problem.hpp -- host-side translation of the ABI's mpc_config (the reference's ROS
+// parameter set, src/controller.cpp:225-805) into the device-side Problem<T> record.
+#pragma once
+#include "../../include/mpc_hip.h"
+#include "mpc_core.hpp"
+
+namespace mpc {
+
+template <typename T>
+inline void fill_problem(const mpc_config& c, mpc::Problem<T>& P) {
+    P.model = c.model;
+    P.n = c.n;
+    P.dt_free = c.dt_free ? 1 : 0;
+    for (int i = 0; i < 3; ++i) P.xf_fixed[i] = c.xf_fixed[i] ? 1 : 0;
+    P.objective = c.objective;
+    P.integral_form = c.integral_form ? 1 : 0;
+    P.has_Qf = c.has_Qf ? 1 : 0;
+    P.max_iter = c.max_iter > 0 ? c.max_iter : 100;
+    P.p0 = T(c.model_params[0]);
+    P.p1 = T(c.model_params[1]);
+    P.dt_ref = T(c.dt_ref);
+    P.dt_lb = T(c.dt_lb);
+    P.dt_ub = T(c.dt_ub);
+    for (int i = 0; i < 3; ++i) { P.Q[i] = T(c.Q[i]); P.Qf[i] = T(c.Qf[i]); }
+    for (int j = 0; j < 2; ++j) {
+        P.R[j] = T(c.R[j]);
+        P.u_lb[j] = T(c.u_lb[j]);
+        P.u_ub[j] = T(c.u_ub[j]);
+        P.rate_on[j] = c.du_lb[j] > -1e29 ? 1 : 0;
+        P.rate_on[2 + j] = c.du_ub[j] < 1e29 ? 1 : 0;
+        P.rate_lim[j] = T(P.rate_on[j] ? c.du_lb[j] : 0.0);
+        P.rate_lim[2 + j] = T(P.rate_on[2 + j] ? c.du_ub[j] : 0.0);
+    }
+    const bool f32 = sizeof(T) == 4;
+    P.tol = T(c.tol > 0 ? c.tol : (f32 ? 1e-4 : 1e-8));
+    P.mu_init = T(c.mu_init > 0 ? c.mu_init : 0.1);
+    P.kappa_eps = T(10);
+    P.kappa_mu = T(0.2);
+    P.theta_mu = T(1.5);
+    P.tau_min = T(0.99);
+    P.bound_push = T(1e-2);
+    P.slack_push = T(1e-2);
+    P.eta_armijo = T(1e-4);
+    P.rho_frac = T(0.1);
+    P.delta_first = T(1e-4);
+    P.delta_min = T(f32 ? 1e-12 : 1e-20);
+    P.delta_max = T(f32 ? 1e12 : 1e20);
+    P.kappa_plus = T(8);
+    P.kappa_plus_first = T(100);
+    P.kappa_minus = T(1.0 / 3.0);
+    P.curv_kappa = T(f32 ? 1e-7 : 1e-10);
+    P.s_max = T(100);
+    P.delta_c = T(f32 ? 1e-5 : 1e-8);
+    P.kappa_c = T(0.25);
+    P.max_ls = 30;
+}
+
+
+}  // namespace mpc

@@ -1,0 +1,120 @@
+"""BatchSolver -- thin Python host wrapper over the C ABI (include/mpc_hip.h).
+
+Mirrors the lifecycle of the reference's Controller (configure -> step ... -> reset,
+include/mpc_local_planner/controller.h:61-104) for B independent planner instances.
+All arithmetic happens in the HIP library; this file only marshals pointers.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from ._abi import MpcConfig, MPC_OK
+
+
+class MpcError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"mpc_hip error {code}: {msg}")
+        self.code = code
+
+
+@dataclass
+class BatchResult:
+    x: np.ndarray        # (B, n, 3)
+    u: np.ndarray        # (B, n, 2)  last row duplicates u_{n-2}
+    dt: np.ndarray       # (B,)
+    status: np.ndarray   # (B,) int32, 0 = converged
+    iters: np.ndarray    # (B,) int32
+
+
+def _addr(a):
+    if a is None:
+        return None
+    return C.c_void_p(a.ctypes.data)
+
+
+def _as_f64(a, shape):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    if a.shape != shape:
+        raise ValueError(f"expected shape {shape}, got {a.shape}")
+    return a
+
+
+class BatchSolver:
+    def __init__(self, cfg: MpcConfig, max_batch: int, device: int = 0):
+        self._lib = _lib.load()
+        self.cfg = cfg
+        self.n = int(cfg.n)
+        self.max_batch = int(max_batch)
+        self.device = int(device)
+        h = C.c_void_p()
+        rc = self._lib.mpc_create(C.byref(cfg), self.max_batch, self.device, C.byref(h))
+        if rc != MPC_OK:
+            raise MpcError(rc, self._lib.mpc_last_error().decode())
+        self._h = h
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.mpc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc):
+        if rc != MPC_OK:
+            raise MpcError(rc, self._lib.mpc_last_error().decode())
+
+    def reset(self):
+        self._check(self._lib.mpc_reset(self._h))
+
+    # ---- host buffers (numpy) ------------------------------------------------
+    def solve(self, x0, xf, u_prev=None, dt_prev=None, init=None) -> BatchResult:
+        """One control cycle for B instances (Controller::step, src/controller.cpp:111-179).
+        init = (x_init (B,n,3), u_init (B,n,2), dt_init (B,)) or None for the reference cold start."""
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        B = x0.shape[0]
+        n = self.n
+        x0 = _as_f64(x0, (B, 3))
+        xf = _as_f64(xf, (B, 3))
+        u_prev = _as_f64(u_prev, (B, 2))
+        dt_prev = _as_f64(dt_prev, (B,))
+        xi = ui = di = None
+        if init is not None:
+            xi, ui, di = _as_f64(init[0], (B, n, 3)), _as_f64(init[1], (B, n, 2)), _as_f64(init[2], (B,))
+        xo = np.empty((B, n, 3))
+        uo = np.empty((B, n, 2))
+        do = np.empty(B)
+        st = np.empty(B, dtype=np.int32)
+        it = np.empty(B, dtype=np.int32)
+        rc = self._lib.mpc_solve_batch(self._h, B, _addr(x0), _addr(xf), _addr(u_prev), _addr(dt_prev), _addr(xi), _addr(ui),
+                                       _addr(di), _addr(xo), _addr(uo), _addr(do), _addr(st), _addr(it))
+        self._check(rc)
+        return BatchResult(xo, uo, do, st, it)
+
+    # ---- device buffers (raw HBM addresses, e.g. torch tensors' data_ptr()) -----
+    def solve_device(self, B: int, x0: int, xf: int, u_prev: Optional[int], dt_prev: Optional[int], x_init: Optional[int],
+                     u_init: Optional[int], dt_init: Optional[int], x_out: int, u_out: int, dt_out: int,
+                     status: Optional[int], iters: Optional[int]) -> None:
+        """Asynchronous solve on the solver's stream; all arguments are device addresses (ints)."""
+        v = lambda p: C.c_void_p(p) if p else None
+        rc = self._lib.mpc_solve_batch_device(self._h, B, v(x0), v(xf), v(u_prev), v(dt_prev), v(x_init), v(u_init), v(dt_init),
+                                              v(x_out), v(u_out), v(dt_out), v(status), v(iters))
+        self._check(rc)
+
+    def synchronize(self):
+        self._check(self._lib.mpc_synchronize(self._h))
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_float(0)
+        self._check(self._lib.mpc_last_kernel_ms(self._h, C.byref(ms)))
+        return float(ms.value)

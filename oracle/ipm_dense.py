@@ -645,6 +645,8 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
             phi0 = phi_cur + rho * theta
             D = dphi - rho * theta
             for ls in range(opt.max_ls):
+                if ls > 0:
+                    alpha *= 0.5
                 vt = nlp.retract(v, alpha * dz)
                 st = s + alpha * ds
                 evt = nlp.eval(vt)
@@ -653,7 +655,6 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
                 if np.isfinite(phit) and phit <= phi0 + opt.eta_armijo * alpha * D:
                     accepted = True
                     break
-                alpha *= 0.5
         else:
             # Ipopt filter line search (Waechter & Biegler 2006, Alg. A, steps A-5.*), no SOC / restoration
             g_th, g_ph, s_ph, s_th, eta_ph, dlt = 1e-5, 1e-5, 2.3, 1.1, 1e-8, 1.0

@@ -1,0 +1,65 @@
+// DEVELOPER HARNESS (tests only; never loaded by the package or the C-ABI library).
+// Compiles the device solver core (mpc_core.hpp) for the HOST so that its logic can be
+// debugged against the oracle in a container without a GPU.  It is NOT a CPU fallback:
+// nothing in mpc_local_planner_amd/ links or loads this file.
+#include <cstring>
+#include <vector>
+
+#include "../../include/mpc_hip.h"
+#include "../../mpc_local_planner_amd/csrc/mpc_core.hpp"
+#include "../../mpc_local_planner_amd/csrc/mpc_problem.hpp"
+
+template <typename T, int MODEL>
+static void run(const mpc_config& cfg, int B, const double* x0, const double* xf, const double* up, const double* dtp,
+                const double* xi, const double* ui, const double* dti, double* xo, double* uo, double* dto, int* st, int* it,
+                double* kkt) {
+    mpc::Problem<T> P;
+    mpc::fill_problem<T>(cfg, P);
+    mpc::Layout L = mpc::Layout::make(cfg.n);
+    const int n = cfg.n;
+    std::vector<T> ws((size_t)L.total * B, T(0));
+    for (int inst = 0; inst < B; ++inst) {
+        mpc::Mem<T> M{ws.data() + inst, (long)B};
+        mpc::Ipm<T, MODEL> S(P, L, M);
+        for (int i = 0; i < 3; ++i) { S.x0[i] = T(x0[3 * inst + i]); S.xf[i] = T(xf[3 * inst + i]); }
+        S.x0[2] = mpc::normalize_theta(S.x0[2]);
+        S.xf[2] = mpc::normalize_theta(S.xf[2]);
+        S.uprev[0] = up ? T(up[2 * inst]) : T(0);
+        S.uprev[1] = up ? T(up[2 * inst + 1]) : T(0);
+        S.dtprev = dtp ? T(dtp[inst]) : T(0);
+        if (xi && ui && dti) {
+            for (int k = 0; k < n; ++k) for (int i = 0; i < 3; ++i) M.st(L.X + 3 * k + i, T(xi[(size_t)inst * n * 3 + 3 * k + i]));
+            for (int k = 0; k < n - 1; ++k) for (int j = 0; j < 2; ++j) M.st(L.U + 2 * k + j, T(ui[(size_t)inst * n * 2 + 2 * k + j]));
+            M.st(L.D, T(dti[inst]));
+        } else {
+            S.cold_start();
+        }
+        mpc::SolveStats<T> r = S.solve();
+        for (int k = 0; k < n; ++k) for (int i = 0; i < 3; ++i) xo[(size_t)inst * n * 3 + 3 * k + i] = double(M.ld(L.X + 3 * k + i));
+        for (int k = 0; k < n; ++k) { int ks = k < n - 1 ? k : n - 2; for (int j = 0; j < 2; ++j) uo[(size_t)inst * n * 2 + 2 * k + j] = double(M.ld(L.U + 2 * ks + j)); }
+        dto[inst] = double(M.ld(L.D));
+        if (st) st[inst] = r.status;
+        if (it) it[inst] = r.iters;
+        if (kkt) kkt[inst] = double(r.kkt_error);
+    }
+}
+
+template <typename T>
+static void run_prec(const mpc_config& cfg, int B, const double* x0, const double* xf, const double* up, const double* dtp,
+                     const double* xi, const double* ui, const double* dti, double* xo, double* uo, double* dto, int* st, int* it,
+                     double* kkt) {
+    switch (cfg.model) {
+        case 0: run<T, 0>(cfg, B, x0, xf, up, dtp, xi, ui, dti, xo, uo, dto, st, it, kkt); break;
+        case 1: run<T, 1>(cfg, B, x0, xf, up, dtp, xi, ui, dti, xo, uo, dto, st, it, kkt); break;
+        case 2: run<T, 2>(cfg, B, x0, xf, up, dtp, xi, ui, dti, xo, uo, dto, st, it, kkt); break;
+        default: run<T, 3>(cfg, B, x0, xf, up, dtp, xi, ui, dti, xo, uo, dto, st, it, kkt); break;
+    }
+}
+
+extern "C" int hostdbg_solve(const mpc_config* cfg, int B, const double* x0, const double* xf, const double* up, const double* dtp,
+                             const double* xi, const double* ui, const double* dti, double* xo, double* uo, double* dto, int* st,
+                             int* it, double* kkt) {
+    if (cfg->precision == MPC_FP32) run_prec<float>(*cfg, B, x0, xf, up, dtp, xi, ui, dti, xo, uo, dto, st, it, kkt);
+    else run_prec<double>(*cfg, B, x0, xf, up, dtp, xi, ui, dti, xo, uo, dto, st, it, kkt);
+    return 0;
+}
