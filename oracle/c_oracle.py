@@ -1,0 +1,85 @@
+"""ORACLE (test infrastructure only).  ctypes wrapper of oracle/mpc_oracle.c."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(_HERE, "_build", "libmpc_oracle.so")
+
+
+class OracleConfig(C.Structure):
+    _fields_ = [
+        ("model", C.c_int32), ("model_params", C.c_double * 4), ("n", C.c_int32), ("dt_ref", C.c_double),
+        ("dt_free", C.c_int32), ("dt_lb", C.c_double), ("dt_ub", C.c_double), ("xf_fixed", C.c_int32 * 3),
+        ("objective", C.c_int32), ("Q", C.c_double * 3), ("R", C.c_double * 2), ("has_Qf", C.c_int32),
+        ("Qf", C.c_double * 3), ("u_lb", C.c_double * 2), ("u_ub", C.c_double * 2), ("du_lb", C.c_double * 2),
+        ("du_ub", C.c_double * 2), ("max_iter", C.c_int32), ("tol", C.c_double), ("mu_init", C.c_double),
+    ]
+
+
+def build(force=False):
+    if force or not os.path.exists(LIB) or os.path.getmtime(LIB) < os.path.getmtime(os.path.join(_HERE, "mpc_oracle.c")):
+        subprocess.run(["make", "-C", _HERE], check=True, stdout=subprocess.DEVNULL)
+    return LIB
+
+
+_lib = None
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB):
+            build()
+        _lib = C.CDLL(LIB)
+        _lib.oracle_solve_batch.restype = C.c_int
+        _lib.oracle_num_threads.restype = C.c_int
+    return _lib
+
+
+def from_nlp_config(cfg, max_iter=100, tol=1e-8, mu_init=0.1) -> OracleConfig:
+    """oracle.se2_nlp.OcpConfig -> OracleConfig"""
+    o = OracleConfig()
+    o.model = cfg.model
+    mp = list(cfg.model_params) + [0.0] * 4
+    for i in range(4):
+        o.model_params[i] = mp[i]
+    o.n, o.dt_ref, o.dt_free, o.dt_lb, o.dt_ub = cfg.n, cfg.dt_ref, int(cfg.dt_free), cfg.dt_lb, cfg.dt_ub
+    for i in range(3):
+        o.xf_fixed[i] = int(cfg.xf_fixed[i])
+        o.Q[i] = cfg.Q[i]
+        o.Qf[i] = cfg.Qf[i] if cfg.Qf is not None else 0.0
+    o.objective = cfg.objective
+    o.has_Qf = int(cfg.Qf is not None)
+    for j in range(2):
+        o.R[j] = cfg.R[j]
+        o.u_lb[j], o.u_ub[j] = cfg.u_lb[j], cfg.u_ub[j]
+        o.du_lb[j], o.du_ub[j] = max(cfg.du_lb[j], -1e30), min(cfg.du_ub[j], 1e30)
+    o.max_iter, o.tol, o.mu_init = max_iter, tol, mu_init
+    return o
+
+
+def num_threads() -> int:
+    return int(_load().oracle_num_threads())
+
+
+def solve_batch(ocfg: OracleConfig, x0, xf, u_prev=None, dt_prev=None, init=None, nthreads=0):
+    lib = _load()
+    x0 = np.ascontiguousarray(x0, float)
+    xf = np.ascontiguousarray(xf, float)
+    B, n = x0.shape[0], ocfg.n
+    p = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+    up = np.ascontiguousarray(u_prev, float) if u_prev is not None else None
+    dp = np.ascontiguousarray(dt_prev, float) if dt_prev is not None else None
+    xi = ui = di = None
+    if init is not None:
+        xi, ui, di = (np.ascontiguousarray(a, float) for a in init)
+    xo = np.empty((B, n, 3)); uo = np.empty((B, n, 2)); do = np.empty(B)
+    st = np.empty(B, np.int32); it = np.empty(B, np.int32)
+    lib.oracle_solve_batch(C.byref(ocfg), C.c_int(B), p(x0), p(xf), p(up), p(dp), p(xi), p(ui), p(di), p(xo), p(uo), p(do), p(st), p(it),
+                           C.c_int(nthreads))
+    return xo, uo, do, st, it

@@ -1,0 +1,702 @@
+/*
+ * ORACLE (test infrastructure only -- never linked, loaded or called by the product path).
+ *
+ * Plain-C restatement of the receding-horizon NLP solve of rst-tu-dortmund/mpc_local_planner,
+ * used (a) as the fast CPU checker for the HIP path and (b) as the timed CPU baseline
+ * ("cpu_baseline.kind = port" in bench.py).  It follows oracle/ipm_dense.py line by line
+ * (which restates Ipopt's published primal-dual interior-point algorithm, the solver the
+ * reference calls at mpc_local_planner/src/controller.cpp:388-421) but replaces numpy's dense
+ * solve by a general BANDED LU with partial pivoting on the stage-interleaved KKT matrix plus a
+ * bordered (Schur) step for the global dt column -- i.e. linear algebra that shares nothing
+ * with the product's Riccati sweep.
+ *
+ * PARITY UNPINNED: the reference ships no golden outputs and Ipopt/corbo are not vendored.
+ *
+ * NLP pieces and where they come from (paths under /root/reference/mpc_local_planner/):
+ *   dynamics          include/mpc_local_planner/systems/{unicycle_robot.h:59-68,simple_car.h:68-77,131-141,
+ *                     kinematic_bicycle_model.h:65-77}
+ *   collocation       include/mpc_local_planner/optimal_control/fd_collocation_se2.h:54-69 (forward differences)
+ *   wrap              include/mpc_local_planner/utils/math_utils.h:81-91
+ *   objective         (n-1)*dt (src/optimal_control/min_time_via_points_cost.cpp:52-56,120-124) |
+ *                     quadratic form (src/optimal_control/quadratic_cost_se2.cpp:31-52) + terminal
+ *                     (src/optimal_control/final_state_conditions_se2.cpp:30-52)
+ *   rate rows         src/optimal_control/stage_inequality_se2.cpp:191-222
+ *   boxes             src/controller.cpp:511,527,543 ; dt: src/optimal_control/finite_differences_variable_grid_se2.cpp:36-40
+ *   cold start        src/controller.cpp:807-857 + src/optimal_control/full_discretization_grid_base_se2.cpp:192-239
+ *   output            src/optimal_control/full_discretization_grid_base_se2.cpp:579-615
+ * Rows are used in "solver form" (see oracle/ipm_dense.py header): c_k = dt*f - delta (= dt * reference
+ * defect), rate rows multiplied by dt_prev.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+typedef struct oracle_config {
+    int32_t model;
+    double model_params[4];
+    int32_t n;
+    double dt_ref;
+    int32_t dt_free;
+    double dt_lb, dt_ub;
+    int32_t xf_fixed[3];
+    int32_t objective;          /* 0 min-time, 1 quadratic (non-integral) */
+    double Q[3], R[2];
+    int32_t has_Qf;
+    double Qf[3];
+    double u_lb[2], u_ub[2];
+    double du_lb[2], du_ub[2];  /* +-1e30 = inf */
+    int32_t max_iter;
+    double tol;
+    double mu_init;
+} oracle_config;
+
+#define PI 3.14159265358979323846
+#define KL 8      /* half bandwidth of the stage-interleaved KKT matrix */
+#define KU 8
+#define LDAB (2 * KL + KU + 1)
+
+static double wrap(double th) {            /* math_utils.h:81-91 */
+    if (th >= -PI && th < PI) return th;
+    double m = floor(th / (2.0 * PI));
+    th = th - m * 2.0 * PI;
+    if (th >= PI) th -= 2.0 * PI;
+    if (th < -PI) th += 2.0 * PI;
+    return th;
+}
+
+/* f, G[a][j] = df_a/dq_j (q = theta, v, w), H[a][j][l] second derivatives */
+static void model_derivs(const oracle_config* c, double th, double v, double w, double f[3], double G[3][3], double H[3][3][3]) {
+    memset(G, 0, 9 * sizeof(double));
+    memset(H, 0, 27 * sizeof(double));
+    if (c->model == 3) {
+        double lr = c->model_params[0], lf = c->model_params[1];
+        double kap = lr / (lf + lr), t = tan(w), tp = 1.0 + t * t, tpp = 2.0 * t * tp;
+        double den = 1.0 + kap * kap * t * t, beta = atan(kap * t);
+        double bp = kap * tp / den, bpp = kap * (tpp * den - tp * 2.0 * kap * kap * t * tp) / (den * den);
+        double cs = cos(th + beta), sn = sin(th + beta), sb = sin(beta), cb = cos(beta);
+        f[0] = v * cs; f[1] = v * sn; f[2] = v * sb / lr;
+        G[0][0] = -v * sn; G[0][1] = cs; G[0][2] = -v * sn * bp;
+        G[1][0] = v * cs;  G[1][1] = sn; G[1][2] = v * cs * bp;
+        G[2][1] = sb / lr; G[2][2] = v * cb * bp / lr;
+        H[0][0][0] = -v * cs; H[0][0][1] = H[0][1][0] = -sn; H[0][0][2] = H[0][2][0] = -v * cs * bp;
+        H[0][1][2] = H[0][2][1] = -sn * bp; H[0][2][2] = -v * cs * bp * bp - v * sn * bpp;
+        H[1][0][0] = -v * sn; H[1][0][1] = H[1][1][0] = cs; H[1][0][2] = H[1][2][0] = -v * sn * bp;
+        H[1][1][2] = H[1][2][1] = cs * bp; H[1][2][2] = -v * sn * bp * bp + v * cs * bpp;
+        H[2][1][2] = H[2][2][1] = cb * bp / lr; H[2][2][2] = v * (-sb * bp * bp + cb * bpp) / lr;
+        return;
+    }
+    double cs = cos(th), sn = sin(th);
+    f[0] = v * cs; f[1] = v * sn;
+    G[0][0] = -v * sn; G[0][1] = cs; G[1][0] = v * cs; G[1][1] = sn;
+    H[0][0][0] = -v * cs; H[0][0][1] = H[0][1][0] = -sn;
+    H[1][0][0] = -v * sn; H[1][0][1] = H[1][1][0] = cs;
+    if (c->model == 0) { f[2] = w; G[2][2] = 1.0; }
+    else if (c->model == 1) {
+        double L = c->model_params[0], t = tan(w), tp = 1.0 + t * t;
+        f[2] = v * t / L; G[2][1] = t / L; G[2][2] = v * tp / L;
+        H[2][1][2] = H[2][2][1] = tp / L; H[2][2][2] = v * 2.0 * t * tp / L;
+    } else {
+        double L = c->model_params[0];
+        f[2] = v * sin(w) / L; G[2][1] = sin(w) / L; G[2][2] = v * cos(w) / L;
+        H[2][1][2] = H[2][2][1] = cos(w) / L; H[2][2][2] = -v * sin(w) / L;
+    }
+}
+
+/* ---------------------------------------------------------------- per-instance work area */
+typedef struct {
+    const oracle_config* c;
+    int n, N;                 /* N = 8*(n-1): banded unknowns [u_k(2) lam_k(3) x_{k+1}(3)] per interval */
+    double x0[3], xf[3], uprev[2], dtprev;
+    double *X, *U, D;         /* X n*3, U (n-1)*2 */
+    double *Xt, *Ut, Dt;
+    double *lam, *lamn;       /* (n-1)*3 */
+    double *s, *y;            /* rate rows n*4 */
+    int *ron;                 /* row active flags n*4 */
+    double *pl, *pu;          /* (n-1)*2 */
+    double pdl, pdu;
+    double *AB, *AB0;         /* band storage LDAB x N */
+    int *ipiv;
+    double *rhs, *bcol, *brow;/* rhs, border column (K part), work */
+    double *dz_u, *dz_x;      /* steps */
+    double ddt;
+    double mu, rho, delta_last;
+} work_t;
+
+static int iu(int k, int j) { return 8 * k + j; }
+static int il(int k, int a) { return 8 * k + 2 + a; }
+static int ixn(int k, int a) { return 8 * (k - 1) + 5 + a; }   /* x_k, k >= 1 */
+
+static void band_zero(work_t* w) { memset(w->AB, 0, sizeof(double) * LDAB * w->N); }
+static void band_add(work_t* w, int i, int j, double v) {
+    /* LAPACK band layout: A(i,j) at AB[kl+ku+i-j][j] */
+    w->AB[(size_t)(KL + KU + i - j) + (size_t)LDAB * j] += v;
+}
+static void sym_add(work_t* w, int i, int j, double v) { band_add(w, i, j, v); if (i != j) band_add(w, j, i, v); }
+
+/* unblocked banded LU with partial pivoting (same elimination order as LAPACK dgbtf2) */
+static int band_factor(work_t* w) {
+    const int N = w->N, kv = KU + KL;
+    double* AB = w->AB;
+    int ju = 0;
+    for (int j = 0; j < N; ++j) {
+        int km = KL < N - 1 - j ? KL : N - 1 - j;
+        int jp = 0; double best = fabs(AB[kv + (size_t)LDAB * j]);
+        for (int i = 1; i <= km; ++i) { double a = fabs(AB[kv + i + (size_t)LDAB * j]); if (a > best) { best = a; jp = i; } }
+        w->ipiv[j] = j + jp;
+        if (!(best > 0.0) || !isfinite(best)) return -1;
+        int jm = j + KU + jp; if (jm > N - 1) jm = N - 1; if (jm > ju) ju = jm;
+        if (jp != 0) for (int c2 = j; c2 <= ju; ++c2) {
+            double* a = &AB[kv + jp + j - c2 + (size_t)LDAB * c2];
+            double* b = &AB[kv + j - c2 + (size_t)LDAB * c2];
+            double t = *a; *a = *b; *b = t;
+        }
+        double piv = 1.0 / AB[kv + (size_t)LDAB * j];
+        for (int i = 1; i <= km; ++i) AB[kv + i + (size_t)LDAB * j] *= piv;
+        for (int c2 = j + 1; c2 <= ju; ++c2) {
+            double t = AB[kv + j - c2 + (size_t)LDAB * c2];
+            if (t != 0.0) for (int i = 1; i <= km; ++i) AB[kv + i + j - c2 + (size_t)LDAB * c2] -= AB[kv + i + (size_t)LDAB * j] * t;
+        }
+    }
+    return 0;
+}
+static void band_solve(const work_t* w, double* b) {
+    const int N = w->N, kv = KU + KL;
+    const double* AB = w->AB;
+    for (int j = 0; j < N; ++j) {
+        int km = KL < N - 1 - j ? KL : N - 1 - j;
+        int p = w->ipiv[j];
+        if (p != j) { double t = b[p]; b[p] = b[j]; b[j] = t; }
+        for (int i = 1; i <= km; ++i) b[j + i] -= AB[kv + i + (size_t)LDAB * j] * b[j];
+    }
+    for (int j = N - 1; j >= 0; --j) {
+        b[j] /= AB[kv + (size_t)LDAB * j];
+        int lo = j - kv; if (lo < 0) lo = 0;
+        for (int i = lo; i < j; ++i) b[i] -= AB[kv + i - j + (size_t)LDAB * j] * b[j];
+    }
+}
+
+static int row_on(const work_t* w, int r, int q) { return w->ron[4 * r + q]; }
+static double sgn(int q) { return q < 2 ? -1.0 : 1.0; }
+static double lim(const work_t* w, int q) { return q < 2 ? w->c->du_lb[q] : w->c->du_ub[q - 2]; }
+
+static double row_val_at(const work_t* w, const double* U, double D, int r, int q) {
+    int n = w->n, j = q & 1;
+    double ur = r < n - 1 ? U[2 * r + j] : 0.0;
+    double um = r > 0 ? U[2 * (r - 1) + j] : w->uprev[j];
+    double dtp = r > 0 ? D : w->dtprev;
+    return sgn(q) * ((ur - um) - lim(w, q) * dtp);
+}
+
+/* c_k, objective at a point */
+static void eval_point(const work_t* w, const double* X, const double* U, double D, double* cc, double* fobj) {
+    const oracle_config* c = w->c;
+    int n = w->n;
+    double f = c->objective == 0 ? (n - 1) * D : 0.0;
+    for (int k = 0; k < n - 1; ++k) {
+        double ff[3], G[3][3], H[3][3][3];
+        model_derivs(c, X[3 * k + 2], U[2 * k], U[2 * k + 1], ff, G, H);
+        cc[3 * k + 0] = D * ff[0] - (X[3 * (k + 1)] - X[3 * k]);
+        cc[3 * k + 1] = D * ff[1] - (X[3 * (k + 1) + 1] - X[3 * k + 1]);
+        cc[3 * k + 2] = D * ff[2] - wrap(X[3 * (k + 1) + 2] - X[3 * k + 2]);
+        if (c->objective == 1) {
+            double xd[3] = {X[3 * k] - w->xf[0], X[3 * k + 1] - w->xf[1], wrap(X[3 * k + 2] - w->xf[2])};
+            for (int i = 0; i < 3; ++i) f += c->Q[i] * xd[i] * xd[i];
+            for (int j = 0; j < 2; ++j) f += c->R[j] * U[2 * k + j] * U[2 * k + j];
+        }
+    }
+    if (c->objective == 1 && c->has_Qf) {
+        const double* xl = &X[3 * (n - 1)];
+        double xd[3] = {xl[0] - w->xf[0], xl[1] - w->xf[1], wrap(xl[2] - w->xf[2])};
+        for (int i = 0; i < 3; ++i) if (!c->xf_fixed[i]) f += c->Qf[i] * xd[i] * xd[i];
+    }
+    *fobj = f;
+}
+
+static double barrier_logs(const work_t* w, const double* U, double D, const double* s) {
+    const oracle_config* c = w->c;
+    int n = w->n;
+    double a = 0.0;
+    for (int k = 0; k < n - 1; ++k) for (int j = 0; j < 2; ++j) a += log(U[2 * k + j] - c->u_lb[j]) + log(c->u_ub[j] - U[2 * k + j]);
+    if (c->dt_free) a += log(D - c->dt_lb) + log(c->dt_ub - D);
+    for (int r = 0; r < n; ++r) for (int q = 0; q < 4; ++q) if (row_on(w, r, q)) a += log(s[4 * r + q]);
+    return a;
+}
+
+typedef struct { double rd, rp, cmin, cmax, sm, sb, theta; int nm, nb; } err_t;
+
+static void kkt_terms(const work_t* w, const double* cc, err_t* e) {
+    const oracle_config* c = w->c;
+    int n = w->n;
+    memset(e, 0, sizeof(*e));
+    e->cmin = 1e30;
+    double rdd = c->objective == 0 ? (double)(n - 1) : 0.0;
+    for (int k = 0; k < n - 1; ++k) {
+        const double* lam = &w->lam[3 * k];
+        double f[3], G[3][3], H[3][3][3];
+        double v = w->U[2 * k], om = w->U[2 * k + 1];
+        model_derivs(c, w->X[3 * k + 2], v, om, f, G, H);
+        double gq[3];
+        for (int j = 0; j < 3; ++j) gq[j] = lam[0] * G[0][j] + lam[1] * G[1][j] + lam[2] * G[2][j];
+        for (int i = 0; i < 3; ++i) { double a = fabs(cc[3 * k + i]); if (a > e->rp) e->rp = a; e->theta += a; e->sm += fabs(lam[i]); }
+        e->nm += 3;
+        rdd += lam[0] * f[0] + lam[1] * f[1] + lam[2] * f[2];
+        double gx[3] = {0, 0, 0}, gu[2] = {0, 0};
+        if (c->objective == 1) {
+            double xd[3] = {w->X[3 * k] - w->xf[0], w->X[3 * k + 1] - w->xf[1], wrap(w->X[3 * k + 2] - w->xf[2])};
+            for (int i = 0; i < 3; ++i) gx[i] = 2 * c->Q[i] * xd[i];
+            gu[0] = 2 * c->R[0] * v; gu[1] = 2 * c->R[1] * om;
+        }
+        if (k >= 1) {
+            const double* lp = &w->lam[3 * (k - 1)];
+            double r[3] = {gx[0] + lam[0] - lp[0], gx[1] + lam[1] - lp[1], gx[2] + lam[2] + w->D * gq[0] - lp[2]};
+            for (int i = 0; i < 3; ++i) if (fabs(r[i]) > e->rd) e->rd = fabs(r[i]);
+        }
+        for (int j = 0; j < 2; ++j) {
+            double u = w->U[2 * k + j], pl = w->pl[2 * k + j], pu = w->pu[2 * k + j];
+            double r = gu[j] + w->D * gq[1 + j] - pl + pu;
+            for (int q = j; q < 4; q += 2) {
+                if (row_on(w, k, q)) r += sgn(q) * w->y[4 * k + q];
+                if (row_on(w, k + 1, q)) r -= sgn(q) * w->y[4 * (k + 1) + q];
+            }
+            if (fabs(r) > e->rd) e->rd = fabs(r);
+            double cl = (u - c->u_lb[j]) * pl, cu = (c->u_ub[j] - u) * pu;
+            if (cl < e->cmin) e->cmin = cl; if (cu < e->cmin) e->cmin = cu;
+            if (cl > e->cmax) e->cmax = cl; if (cu > e->cmax) e->cmax = cu;
+            e->sb += pl + pu; e->nb += 2;
+        }
+    }
+    {
+        const double* lp = &w->lam[3 * (n - 2)];
+        for (int i = 0; i < 3; ++i) if (!c->xf_fixed[i]) {
+            double g = 0.0;
+            if (c->objective == 1 && c->has_Qf) { double xd = w->X[3 * (n - 1) + i] - w->xf[i]; if (i == 2) xd = wrap(xd); g = 2 * c->Qf[i] * xd; }
+            if (fabs(g - lp[i]) > e->rd) e->rd = fabs(g - lp[i]);
+        }
+    }
+    for (int r = 0; r < n; ++r) for (int q = 0; q < 4; ++q) if (row_on(w, r, q)) {
+        double s = w->s[4 * r + q], y = w->y[4 * r + q];
+        double res = row_val_at(w, w->U, w->D, r, q) + s;
+        if (fabs(res) > e->rp) e->rp = fabs(res);
+        e->theta += fabs(res);
+        if (s * y < e->cmin) e->cmin = s * y; if (s * y > e->cmax) e->cmax = s * y;
+        e->sb += y; e->nb += 1;
+        if (r > 0) rdd -= sgn(q) * lim(w, q) * y;
+    }
+    if (c->dt_free) {
+        rdd += -w->pdl + w->pdu;
+        if (fabs(rdd) > e->rd) e->rd = fabs(rdd);
+        double cl = (w->D - c->dt_lb) * w->pdl, cu = (c->dt_ub - w->D) * w->pdu;
+        if (cl < e->cmin) e->cmin = cl; if (cu < e->cmin) e->cmin = cu;
+        if (cl > e->cmax) e->cmax = cl; if (cu > e->cmax) e->cmax = cu;
+        e->sb += w->pdl + w->pdu; e->nb += 2;
+    }
+    e->sm += e->sb; e->nm += e->nb;
+}
+static double err_value(const err_t* e, double mu) {
+    const double smax = 100.0;
+    double sd = fmax(smax, e->sm / (e->nm > 0 ? e->nm : 1)) / smax;
+    double sc = fmax(smax, e->sb / (e->nb > 0 ? e->nb : 1)) / smax;
+    double comp = e->nb > 0 ? fmax(e->cmax - mu, mu - e->cmin) : 0.0;
+    return fmax(e->rd / sd, fmax(e->rp, comp / sc));
+}
+
+/* Assemble the condensed KKT system (banded part + dt border) and its right-hand side.
+ * Unknown order per interval k: u_k(2), lambda_k(3), x_{k+1}(3).  dt is the border unknown.
+ * hd / Hdd: gradient and Hessian entries of dt; bcol: coupling column K[:,dt]. */
+static void assemble(work_t* w, const double* cc, double delta, double dc, double* Hdd, double* hd) {
+    const oracle_config* c = w->c;
+    int n = w->n, N = w->N;
+    band_zero(w);
+    memset(w->rhs, 0, sizeof(double) * N);
+    memset(w->bcol, 0, sizeof(double) * N);
+    double D = w->D, mu = w->mu;
+    double hdd = 0.0, gd = 0.0;
+    if (c->objective == 0) gd += (double)(n - 1);
+    if (c->dt_free) {
+        double dl = D - c->dt_lb, du = c->dt_ub - D;
+        hdd += w->pdl / dl + w->pdu / du + delta;
+        gd += -mu / dl + mu / du;
+    }
+    for (int k = 0; k < n - 1; ++k) {
+        const double* lam = &w->lam[3 * k];
+        double f[3], G[3][3], H[3][3][3];
+        double v = w->U[2 * k], om = w->U[2 * k + 1];
+        model_derivs(c, w->X[3 * k + 2], v, om, f, G, H);
+        int qi[3] = {k >= 1 ? ixn(k, 2) : -1, iu(k, 0), iu(k, 1)};
+        /* collocation rows: c = x_k + D f - x_{k+1} */
+        for (int a = 0; a < 3; ++a) {
+            int row = il(k, a);
+            if (k >= 1) sym_add(w, row, ixn(k, a), 1.0);
+            if (k + 1 < n - 1 || !c->xf_fixed[a]) sym_add(w, row, ixn(k + 1, a), -1.0);
+            for (int j = 0; j < 3; ++j) if (qi[j] >= 0) sym_add(w, row, qi[j], D * G[a][j]);
+            w->bcol[row] += f[a];
+            w->rhs[row] = -cc[3 * k + a];
+        }
+        if (k == n - 2) for (int a = 0; a < 3; ++a) if (c->xf_fixed[a]) band_add(w, il(k, a), il(k, a), -dc);
+        /* Lagrangian curvature */
+        for (int j = 0; j < 3; ++j) {
+            if (qi[j] < 0) continue;
+            for (int l = j; l < 3; ++l) {
+                if (qi[l] < 0) continue;
+                double h = D * (lam[0] * H[0][j][l] + lam[1] * H[1][j][l] + lam[2] * H[2][j][l]);
+                sym_add(w, qi[j], qi[l], h);
+            }
+            w->bcol[qi[j]] += lam[0] * G[0][j] + lam[1] * G[1][j] + lam[2] * G[2][j];
+        }
+        /* objective */
+        if (c->objective == 1) {
+            double xd[3] = {w->X[3 * k] - w->xf[0], w->X[3 * k + 1] - w->xf[1], wrap(w->X[3 * k + 2] - w->xf[2])};
+            if (k >= 1) for (int i = 0; i < 3; ++i) { band_add(w, ixn(k, i), ixn(k, i), 2 * c->Q[i]); w->rhs[ixn(k, i)] -= 2 * c->Q[i] * xd[i]; }
+            for (int j = 0; j < 2; ++j) { band_add(w, iu(k, j), iu(k, j), 2 * c->R[j]); w->rhs[iu(k, j)] -= 2 * c->R[j] * w->U[2 * k + j]; }
+        }
+        /* control box + regularisation */
+        for (int j = 0; j < 2; ++j) {
+            double u = w->U[2 * k + j], dl = u - c->u_lb[j], du = c->u_ub[j] - u;
+            band_add(w, iu(k, j), iu(k, j), w->pl[2 * k + j] / dl + w->pu[2 * k + j] / du + delta);
+            w->rhs[iu(k, j)] -= -mu / dl + mu / du;
+        }
+        if (k >= 1) for (int i = 0; i < 3; ++i) band_add(w, ixn(k, i), ixn(k, i), delta);
+    }
+    /* terminal state block: free components are variables, fixed ones are pinned (dx = 0) */
+    for (int i = 0; i < 3; ++i) {
+        int id = ixn(n - 1, i);
+        if (c->xf_fixed[i]) { band_add(w, id, id, 1.0); }
+        else {
+            band_add(w, id, id, delta);
+            if (c->objective == 1 && c->has_Qf) {
+                double xd = w->X[3 * (n - 1) + i] - w->xf[i]; if (i == 2) xd = wrap(xd);
+                band_add(w, id, id, 2 * c->Qf[i]);
+                w->rhs[id] -= 2 * c->Qf[i] * xd;
+            }
+        }
+    }
+    /* rate rows, condensed: + sigma a a^T, gradient + a * ybar */
+    for (int r = 0; r < n; ++r) for (int q = 0; q < 4; ++q) if (row_on(w, r, q)) {
+        int j = q & 1;
+        double sg = sgn(q), L = lim(w, q);
+        double s = w->s[4 * r + q], y = w->y[4 * r + q], sig = y / s;
+        double res = row_val_at(w, w->U, w->D, r, q) + s;
+        double ybar = mu / s + sig * res;
+        int i1 = r < n - 1 ? iu(r, j) : -1, i2 = r > 0 ? iu(r - 1, j) : -1;
+        double ad = r > 0 ? -sg * L : 0.0;
+        if (i1 >= 0) { band_add(w, i1, i1, sig); w->rhs[i1] -= sg * ybar; w->bcol[i1] += sig * sg * ad; }
+        if (i2 >= 0) { band_add(w, i2, i2, sig); w->rhs[i2] -= -sg * ybar; w->bcol[i2] += sig * (-sg) * ad; }
+        if (i1 >= 0 && i2 >= 0) sym_add(w, i1, i2, -sig);
+        hdd += sig * ad * ad;
+        gd += ad * ybar;
+    }
+    *Hdd = hdd;
+    *hd = gd;
+}
+
+static void ftb(double val, double dval, double tau, double* alpha) { if (dval < 0) { double a = -tau * val / dval; if (a < *alpha) *alpha = a; } }
+
+static int solve_one(work_t* w, int warm) {
+    const oracle_config* c = w->c;
+    const int n = w->n, N = w->N;
+    const double tol = c->tol > 0 ? c->tol : 1e-8;
+    const int max_iter = c->max_iter > 0 ? c->max_iter : 100;
+    const double kappa_eps = 10, kappa_mu = 0.2, theta_mu = 1.5, tau_min = 0.99, bound_push = 1e-2, slack_push = 1e-2;
+    const double eta = 1e-4, rho_frac = 0.1, delta_first = 1e-4, delta_min = 1e-20, delta_max = 1e20;
+    const double kplus = 8, kplus1 = 100, kminus = 1.0 / 3.0, curv_kappa = 1e-10, delta_c = 1e-8, kappa_c = 0.25;
+    const int max_ls = 30;
+    int nfix = c->xf_fixed[0] + c->xf_fixed[1] + c->xf_fixed[2];
+    double* cc = (double*)malloc(sizeof(double) * 3 * (n - 1));
+    double* cct = (double*)malloc(sizeof(double) * 3 * (n - 1));
+    double* st = (double*)malloc(sizeof(double) * 4 * n);
+    double* ds = (double*)malloc(sizeof(double) * 4 * n);
+    double* dy = (double*)malloc(sizeof(double) * 4 * n);
+    double* y2 = (double*)malloc(sizeof(double) * N);
+    int status = 1, it = 0;
+    /* initial vertex values */
+    if (!warm) {
+        double dth = wrap(w->xf[2] - w->x0[2]);
+        for (int k = 0; k < n; ++k) {
+            double fr = (double)k / (double)(n - 1);
+            w->X[3 * k] = w->x0[0] + fr * (w->xf[0] - w->x0[0]);
+            w->X[3 * k + 1] = w->x0[1] + fr * (w->xf[1] - w->x0[1]);
+            w->X[3 * k + 2] = wrap(w->x0[2] + fr * dth);
+        }
+        for (int i = 0; i < 3; ++i) w->X[3 * (n - 1) + i] = w->xf[i];
+        memset(w->U, 0, sizeof(double) * 2 * (n - 1));
+        w->D = c->dt_ref;
+    }
+    for (int i = 0; i < 3; ++i) { w->X[i] = w->x0[i]; if (c->xf_fixed[i]) w->X[3 * (n - 1) + i] = w->xf[i]; }
+    if (!c->dt_free) w->D = c->dt_ref;
+    /* seed controls from the state guess when all are zero (see oracle/ipm_dense.py controls_from_states) */
+    {
+        int any = 0;
+        for (int i = 0; i < 2 * (n - 1); ++i) if (w->U[i] != 0.0) any = 1;
+        if (!any) for (int k = 0; k < n - 1; ++k) {
+            double dx = w->X[3 * (k + 1)] - w->X[3 * k], dyy = w->X[3 * (k + 1) + 1] - w->X[3 * k + 1];
+            double dth = wrap(w->X[3 * (k + 1) + 2] - w->X[3 * k + 2]), th = w->X[3 * k + 2];
+            double v = (dx * cos(th) + dyy * sin(th)) / w->D;
+            v = fmin(fmax(v, c->u_lb[0]), c->u_ub[0]);
+            double rate = dth / w->D, om;
+            if (c->model == 0) om = rate;
+            else {
+                double vv = fabs(v) > 1e-3 ? v : (v >= 0 ? 1e-3 : -1e-3);
+                if (c->model == 1) om = atan(c->model_params[0] * rate / vv);
+                else if (c->model == 2) om = asin(fmin(1.0, fmax(-1.0, c->model_params[0] * rate / vv)));
+                else { double sb = fmin(1.0, fmax(-1.0, c->model_params[0] * rate / vv)); om = atan(tan(asin(sb)) * (c->model_params[1] + c->model_params[0]) / c->model_params[0]); }
+            }
+            om = fmin(fmax(om, c->u_lb[1]), c->u_ub[1]);
+            w->U[2 * k] = v; w->U[2 * k + 1] = om;
+        }
+    }
+    for (int k = 0; k < n - 1; ++k) for (int j = 0; j < 2; ++j) {
+        double lb = c->u_lb[j], ub = c->u_ub[j];
+        double pl = fmin(bound_push * fmax(1.0, fabs(lb)), bound_push * (ub - lb)), pu = fmin(bound_push * fmax(1.0, fabs(ub)), bound_push * (ub - lb));
+        w->U[2 * k + j] = fmin(fmax(w->U[2 * k + j], lb + pl), ub - pu);
+    }
+    if (c->dt_free) {
+        double lb = c->dt_lb, ub = c->dt_ub;
+        double pl = fmin(bound_push * fmax(1.0, fabs(lb)), bound_push * (ub - lb)), pu = fmin(bound_push * fmax(1.0, fabs(ub)), bound_push * (ub - lb));
+        w->D = fmin(fmax(w->D, lb + pl), ub - pu);
+    }
+    w->mu = c->mu_init > 0 ? c->mu_init : 0.1;
+    w->rho = 0; w->delta_last = 0;
+    for (int r = 0; r < n; ++r) for (int q = 0; q < 4; ++q) {
+        int finite = q < 2 ? (c->du_lb[q] > -1e29) : (c->du_ub[q - 2] < 1e29);
+        w->ron[4 * r + q] = finite && (r > 0 || w->dtprev != 0.0);
+        w->s[4 * r + q] = 1.0; w->y[4 * r + q] = 0.0;
+        if (w->ron[4 * r + q]) { w->s[4 * r + q] = fmax(-row_val_at(w, w->U, w->D, r, q), slack_push); w->y[4 * r + q] = w->mu / w->s[4 * r + q]; }
+    }
+    for (int k = 0; k < n - 1; ++k) {
+        for (int j = 0; j < 2; ++j) { w->pl[2 * k + j] = w->mu / (w->U[2 * k + j] - c->u_lb[j]); w->pu[2 * k + j] = w->mu / (c->u_ub[j] - w->U[2 * k + j]); }
+        for (int i = 0; i < 3; ++i) w->lam[3 * k + i] = 0.0;
+    }
+    w->pdl = c->dt_free ? w->mu / (w->D - c->dt_lb) : 0.0;
+    w->pdu = c->dt_free ? w->mu / (c->dt_ub - w->D) : 0.0;
+    double fobj;
+    eval_point(w, w->X, w->U, w->D, cc, &fobj);
+    while (1) {
+        err_t e;
+        kkt_terms(w, cc, &e);
+        double e0 = err_value(&e, 0.0);
+        if (!isfinite(e0)) { status = 4; break; }
+        if (e0 <= tol) { status = 0; break; }
+        if (it >= max_iter) { status = 1; break; }
+        for (int g = 0; g < 50; ++g) {
+            double emu = err_value(&e, w->mu);
+            if (emu <= kappa_eps * w->mu && w->mu > tol / 10) { w->mu = fmax(tol / 10, fmin(kappa_mu * w->mu, pow(w->mu, theta_mu))); w->rho = 0; }
+            else break;
+        }
+        double mu = w->mu, tau = fmax(tau_min, 1.0 - mu);
+        double dc = nfix > 0 ? delta_c * pow(mu, kappa_c) : 0.0;
+        double delta = 0.0, Hdd, hd, curv = 0, dz2 = 0, hdz = 0, dphi = 0, a_p = 1, a_d = 1, dzmax = 0;
+        int ok = 0;
+        for (int ntry = 0; ntry <= 40; ++ntry) {
+            assemble(w, cc, delta, dc, &Hdd, &hd);
+            int good = band_factor(w) == 0;
+            if (good) {
+                /* bordered solve: [K b; b^T Hdd] [y; ddt] = [rhs; -hd] */
+                memcpy(y2, w->bcol, sizeof(double) * N);
+                band_solve(w, w->rhs);
+                double ddt = 0.0;
+                if (c->dt_free) {
+                    band_solve(w, y2);
+                    double num = -hd, den = Hdd;
+                    for (int i = 0; i < N; ++i) { num -= w->bcol[i] * w->rhs[i]; den -= w->bcol[i] * y2[i]; }
+                    ddt = num / den;
+                    if (!isfinite(ddt) || den == 0.0) good = 0;
+                    else for (int i = 0; i < N; ++i) w->rhs[i] -= y2[i] * ddt;
+                }
+                w->ddt = ddt;
+                for (int i = 0; i < N && good; ++i) if (!isfinite(w->rhs[i])) good = 0;
+            }
+            if (good) {
+                /* curvature dz^T (Hc + delta I) dz = -h^T dz + c^T lam+ - dc |lam+_term|^2, with h = -(rhs of the primal rows) */
+                double clam = 0, nunu = 0;
+                hdz = 0; dz2 = 0; dphi = 0; a_p = 1; a_d = 1; dzmax = 0;
+                /* re-assemble gradient pieces (cheap): h^T dz = gphi.dz + ybar.(Jg dz) */
+                double ddt = w->ddt;
+                if (c->dt_free) {
+                    double dl = w->D - c->dt_lb, du = c->dt_ub - w->D, gb = -mu / dl + mu / du;
+                    hdz += gb * ddt; dphi += gb * ddt; dz2 += ddt * ddt; if (fabs(ddt) > dzmax) dzmax = fabs(ddt);
+                    ftb(dl, ddt, tau, &a_p); ftb(du, -ddt, tau, &a_p);
+                    ftb(w->pdl, mu / dl - w->pdl - (w->pdl / dl) * ddt, tau, &a_d);
+                    ftb(w->pdu, mu / du - w->pdu + (w->pdu / du) * ddt, tau, &a_d);
+                }
+                if (c->objective == 0) { hdz += (n - 1) * ddt; dphi += (n - 1) * ddt; }
+                for (int k = 0; k < n - 1; ++k) {
+                    for (int j = 0; j < 2; ++j) {
+                        double du_ = w->rhs[iu(k, j)], u = w->U[2 * k + j];
+                        double dl = u - c->u_lb[j], du = c->u_ub[j] - u, pl = w->pl[2 * k + j], pu = w->pu[2 * k + j];
+                        double gb = -mu / dl + mu / du;
+                        if (c->objective == 1) gb += 2 * c->R[j] * u;
+                        hdz += gb * du_; dphi += gb * du_; dz2 += du_ * du_; if (fabs(du_) > dzmax) dzmax = fabs(du_);
+                        ftb(dl, du_, tau, &a_p); ftb(du, -du_, tau, &a_p);
+                        ftb(pl, mu / dl - pl - (pl / dl) * du_, tau, &a_d);
+                        ftb(pu, mu / du - pu + (pu / du) * du_, tau, &a_d);
+                        w->dz_u[2 * k + j] = du_;
+                    }
+                    for (int a = 0; a < 3; ++a) {
+                        double l = w->rhs[il(k, a)];
+                        w->lamn[3 * k + a] = l;
+                        clam += cc[3 * k + a] * l;
+                        if (k == n - 2 && c->xf_fixed[a]) nunu += l * l;
+                        double dx = (k + 1 < n - 1 || !c->xf_fixed[a]) ? w->rhs[ixn(k + 1, a)] : 0.0;
+                        w->dz_x[3 * (k + 1) + a] = dx;
+                        dz2 += dx * dx; if (fabs(dx) > dzmax) dzmax = fabs(dx);
+                        if (c->objective == 1) {
+                            double g = 0;
+                            if (k + 1 < n - 1) { double xd = w->X[3 * (k + 1) + a] - w->xf[a]; if (a == 2) xd = wrap(xd); g = 2 * c->Q[a] * xd; }
+                            else if (c->has_Qf && !c->xf_fixed[a]) { double xd = w->X[3 * (k + 1) + a] - w->xf[a]; if (a == 2) xd = wrap(xd); g = 2 * c->Qf[a] * xd; }
+                            hdz += g * dx; dphi += g * dx;
+                        }
+                    }
+                }
+                for (int r = 0; r < n; ++r) for (int q = 0; q < 4; ++q) if (row_on(w, r, q)) {
+                    int j = q & 1;
+                    double sg = sgn(q), L = lim(w, q);
+                    double dur = r < n - 1 ? w->dz_u[2 * r + j] : 0.0, dum = r > 0 ? w->dz_u[2 * (r - 1) + j] : 0.0;
+                    double jdz = sg * ((dur - dum) - (r > 0 ? L * ddt : 0.0));
+                    double s = w->s[4 * r + q], y = w->y[4 * r + q], sig = y / s;
+                    double res = row_val_at(w, w->U, w->D, r, q) + s, ybar = mu / s + sig * res;
+                    ds[4 * r + q] = -res - jdz;
+                    dy[4 * r + q] = ybar + sig * jdz - y;
+                    hdz += ybar * jdz;
+                    dphi -= (mu / s) * ds[4 * r + q];
+                    ftb(s, ds[4 * r + q], tau, &a_p);
+                    ftb(y, dy[4 * r + q], tau, &a_d);
+                }
+                curv = -hdz + clam - dc * nunu;
+                if (isfinite(curv) && curv >= curv_kappa * dz2) { ok = 1; break; }
+            }
+            if (delta == 0.0) delta = w->delta_last == 0.0 ? delta_first : fmax(delta_min, kminus * w->delta_last);
+            else delta *= w->delta_last == 0.0 ? kplus1 : kplus;
+            if (delta > delta_max) break;
+        }
+        if (!ok) { status = 3; break; }
+        if (delta > 0) w->delta_last = delta;
+        double theta = e.theta;
+        if (theta > 0) {
+            double sigma = curv > 0 ? 1.0 : 0.0;
+            double rt = (dphi + 0.5 * sigma * curv) / ((1.0 - rho_frac) * theta);
+            if (w->rho < rt) w->rho = rt + 1.0;
+        }
+        double phi0 = fobj - mu * barrier_logs(w, w->U, w->D, w->s) + w->rho * theta;
+        double Dm = dphi - w->rho * theta;
+        double alpha = a_p, ft = 0;
+        int accepted = 0;
+        for (int ls = 0; ls < max_ls; ++ls) {
+            if (ls > 0) alpha *= 0.5;
+            for (int k = 0; k < n; ++k) for (int i = 0; i < 3; ++i) {
+                double x = w->X[3 * k + i];
+                if (k > 0 && (k < n - 1 || !c->xf_fixed[i])) { x += alpha * w->dz_x[3 * k + i]; if (i == 2) x = wrap(x); }
+                w->Xt[3 * k + i] = x;
+            }
+            for (int i = 0; i < 2 * (n - 1); ++i) w->Ut[i] = w->U[i] + alpha * w->dz_u[i];
+            w->Dt = w->D + (c->dt_free ? alpha * w->ddt : 0.0);
+            for (int i = 0; i < 4 * n; ++i) st[i] = w->s[i] + alpha * ds[i];
+            eval_point(w, w->Xt, w->Ut, w->Dt, cct, &ft);
+            double tht = 0;
+            for (int i = 0; i < 3 * (n - 1); ++i) tht += fabs(cct[i]);
+            for (int r = 0; r < n; ++r) for (int q = 0; q < 4; ++q) if (row_on(w, r, q)) tht += fabs(row_val_at(w, w->Ut, w->Dt, r, q) + st[4 * r + q]);
+            double phit = ft - mu * barrier_logs(w, w->Ut, w->Dt, st) + w->rho * tht;
+            if (isfinite(phit) && phit <= phi0 + eta * alpha * Dm) { accepted = 1; break; }
+        }
+        if (!accepted && alpha * dzmax < 1e-14) { status = 2; break; }
+        /* accept */
+        const double kS = 1e10;
+        for (int r = 0; r < n; ++r) for (int q = 0; q < 4; ++q) if (row_on(w, r, q)) {
+            double sn = st[4 * r + q], yn = w->y[4 * r + q] + a_d * dy[4 * r + q];
+            yn = fmin(fmax(yn, mu / (kS * sn)), kS * mu / sn);
+            w->s[4 * r + q] = sn; w->y[4 * r + q] = yn;
+        }
+        for (int k = 0; k < n - 1; ++k) {
+            for (int j = 0; j < 2; ++j) {
+                double u = w->U[2 * k + j], du_ = w->dz_u[2 * k + j], dl = u - c->u_lb[j], du = c->u_ub[j] - u;
+                double pl = w->pl[2 * k + j], pu = w->pu[2 * k + j];
+                double pln = pl + a_d * (mu / dl - pl - (pl / dl) * du_), pun = pu + a_d * (mu / du - pu + (pu / du) * du_);
+                double un = w->Ut[2 * k + j], dln = un - c->u_lb[j], dun = c->u_ub[j] - un;
+                w->pl[2 * k + j] = fmin(fmax(pln, mu / (kS * dln)), kS * mu / dln);
+                w->pu[2 * k + j] = fmin(fmax(pun, mu / (kS * dun)), kS * mu / dun);
+            }
+            for (int i = 0; i < 3; ++i) w->lam[3 * k + i] += alpha * (w->lamn[3 * k + i] - w->lam[3 * k + i]);
+        }
+        if (c->dt_free) {
+            double dl = w->D - c->dt_lb, du = c->dt_ub - w->D;
+            double pln = w->pdl + a_d * (mu / dl - w->pdl - (w->pdl / dl) * w->ddt), pun = w->pdu + a_d * (mu / du - w->pdu + (w->pdu / du) * w->ddt);
+            double dln = w->Dt - c->dt_lb, dun = c->dt_ub - w->Dt;
+            w->pdl = fmin(fmax(pln, mu / (kS * dln)), kS * mu / dln);
+            w->pdu = fmin(fmax(pun, mu / (kS * dun)), kS * mu / dun);
+        }
+        memcpy(w->X, w->Xt, sizeof(double) * 3 * n);
+        memcpy(w->U, w->Ut, sizeof(double) * 2 * (n - 1));
+        w->D = w->Dt;
+        memcpy(cc, cct, sizeof(double) * 3 * (n - 1));
+        fobj = ft;
+        ++it;
+    }
+    free(cc); free(cct); free(st); free(ds); free(dy); free(y2);
+    return status * 100000 + it;
+}
+
+static work_t* work_new(const oracle_config* c) {
+    work_t* w = (work_t*)calloc(1, sizeof(work_t));
+    int n = c->n;
+    w->c = c; w->n = n; w->N = 8 * (n - 1);
+    w->X = (double*)calloc(3 * n, 8); w->U = (double*)calloc(2 * (n - 1), 8);
+    w->Xt = (double*)calloc(3 * n, 8); w->Ut = (double*)calloc(2 * (n - 1), 8);
+    w->lam = (double*)calloc(3 * (n - 1), 8); w->lamn = (double*)calloc(3 * (n - 1), 8);
+    w->s = (double*)calloc(4 * n, 8); w->y = (double*)calloc(4 * n, 8); w->ron = (int*)calloc(4 * n, sizeof(int));
+    w->pl = (double*)calloc(2 * (n - 1), 8); w->pu = (double*)calloc(2 * (n - 1), 8);
+    w->AB = (double*)calloc((size_t)LDAB * w->N, 8); w->ipiv = (int*)calloc(w->N, sizeof(int));
+    w->rhs = (double*)calloc(w->N, 8); w->bcol = (double*)calloc(w->N, 8);
+    w->dz_u = (double*)calloc(2 * (n - 1), 8); w->dz_x = (double*)calloc(3 * n, 8);
+    return w;
+}
+static void work_free(work_t* w) {
+    free(w->X); free(w->U); free(w->Xt); free(w->Ut); free(w->lam); free(w->lamn); free(w->s); free(w->y); free(w->ron);
+    free(w->pl); free(w->pu); free(w->AB); free(w->ipiv); free(w->rhs); free(w->bcol); free(w->dz_u); free(w->dz_x); free(w);
+}
+
+/* Batched entry point; same array layouts as include/mpc_hip.h.  nthreads <= 0: all cores. */
+int oracle_solve_batch(const oracle_config* c, int B, const double* x0, const double* xf, const double* u_prev,
+                       const double* dt_prev, const double* x_init, const double* u_init, const double* dt_init,
+                       double* x_out, double* u_out, double* dt_out, int32_t* status, int32_t* iters, int nthreads) {
+    const int n = c->n;
+    if (n < 3) return -1;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel
+    {
+        work_t* w = work_new(c);
+#pragma omp for schedule(dynamic, 1)
+        for (int b = 0; b < B; ++b) {
+            for (int i = 0; i < 3; ++i) { w->x0[i] = x0[3 * b + i]; w->xf[i] = xf[3 * b + i]; }
+            w->x0[2] = wrap(w->x0[2]); w->xf[2] = wrap(w->xf[2]);
+            w->uprev[0] = u_prev ? u_prev[2 * b] : 0.0; w->uprev[1] = u_prev ? u_prev[2 * b + 1] : 0.0;
+            w->dtprev = dt_prev ? dt_prev[b] : 0.0;
+            int warm = x_init && u_init && dt_init;
+            if (warm) {
+                memcpy(w->X, x_init + (size_t)b * n * 3, sizeof(double) * 3 * n);
+                for (int k = 0; k < n - 1; ++k) for (int j = 0; j < 2; ++j) w->U[2 * k + j] = u_init[(size_t)b * n * 2 + 2 * k + j];
+                w->D = dt_init[b];
+            }
+            int r = solve_one(w, warm);
+            memcpy(x_out + (size_t)b * n * 3, w->X, sizeof(double) * 3 * n);
+            for (int k = 0; k < n; ++k) { int ks = k < n - 1 ? k : n - 2; for (int j = 0; j < 2; ++j) u_out[(size_t)b * n * 2 + 2 * k + j] = w->U[2 * ks + j]; }
+            dt_out[b] = w->D;
+            if (status) status[b] = r / 100000;
+            if (iters) iters[b] = r % 100000;
+        }
+        work_free(w);
+    }
+    return 0;
+}
+
+int oracle_num_threads(void) {
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

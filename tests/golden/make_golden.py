@@ -1,0 +1,49 @@
+"""Generates tests/golden/*.npz: inputs + converged solutions of the ORACLE (numpy dense IPM),
+kept only when the independent C oracle (banded LU) lands on the same point to 1e-8.
+
+The reference publishes no golden vectors ("parity unpinned"); these
+fixtures pin OUR oracle so that later changes to it, or to the HIP path, are detected.
+Run from the repo root:  python tests/golden/make_golden.py
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import se2_nlp as R, ipm_dense as I, c_oracle as CO  # noqa: E402
+from mpc_local_planner_amd import workloads as W  # noqa: E402
+
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def make(name, cfg, inputs, keep):
+    x0, xf, up, dtp = inputs
+    oc = CO.from_nlp_config(cfg)
+    xo, uo, do, st, it = CO.solve_batch(oc, x0, xf, up, dtp)
+    sel, X, U, D, IT = [], [], [], [], []
+    for i in range(x0.shape[0]):
+        if len(sel) >= keep:
+            break
+        if st[i] != 0:
+            continue
+        inp = R.CycleInputs(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=float(dtp[i]))
+        ref = I.solve(cfg, inp, R.cold_start(cfg, x0[i], xf[i]), opt=I.IpmOptions(globalization="merit", max_iter=100))
+        if ref.status != 0:
+            continue
+        err = max(np.abs(ref.traj.x - xo[i]).max(), np.abs(ref.traj.u - uo[i, :-1]).max(), abs(ref.traj.dt - do[i]))
+        if err > 1e-8:
+            continue
+        sel.append(i); X.append(ref.traj.x); U.append(np.vstack([ref.traj.u, ref.traj.u[-1:]])); D.append(ref.traj.dt); IT.append(ref.iters)
+    sel = np.array(sel)
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), x0=x0[sel], xf=xf[sel], u_prev=up[sel], dt_prev=dtp[sel],
+                        x=np.array(X), u=np.array(U), dt=np.array(D), iters=np.array(IT))
+    print(name, "kept", len(sel), "iters", IT)
+
+
+if __name__ == "__main__":
+    make("carlike_min_time_n50", R.config_carlike_min_time(50), W.carlike_min_time_inputs(24, seed=101), keep=8)
+    make("carlike_min_time_n20", R.config_carlike_min_time(20), W.carlike_min_time_inputs(24, seed=102, goal_range=(1.0, 2.5)), keep=8)
+    make("unicycle_quadratic_n20", R.config_unicycle_quadratic(20), W.unicycle_quadratic_inputs(16, seed=103), keep=8)
+    make("bicycle_min_time_n30", R.config_bicycle_min_time(30), W.carlike_min_time_inputs(24, seed=104, goal_range=(2.0, 6.0)), keep=6)

@@ -1,0 +1,104 @@
+"""CPU test of the DEVICE solver core: mpc_core.hpp (the code the HIP kernel instantiates) is compiled
+for the host by a tests-only harness (tests/host_harness/host_solver.cpp) and compared with the oracle.
+This is a developer check of the kernel's arithmetic without a GPU -- the harness is not part of the
+package and is never loaded by it."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import se2_nlp as R
+from mpc_local_planner_amd import _abi as A
+from mpc_local_planner_amd import workloads as W
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "host_harness", "host_solver.cpp")
+OUT = os.path.join(HERE, "host_harness", "_build", "libmpc_hostdbg.so")
+GOLD = os.path.join(HERE, "golden")
+
+
+@pytest.fixture(scope="module")
+def host():
+    core = os.path.join(HERE, "..", "mpc_local_planner_amd", "csrc", "mpc_core.hpp")
+    if not os.path.exists(OUT) or os.path.getmtime(OUT) < max(os.path.getmtime(SRC), os.path.getmtime(core)):
+        os.makedirs(os.path.dirname(OUT), exist_ok=True)
+        subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", SRC, "-o", OUT], check=True)
+    return C.CDLL(OUT)
+
+
+def host_solve(lib, cfg, x0, xf, up, dtp, init=None):
+    B, n = x0.shape[0], cfg.n
+    xo = np.zeros((B, n, 3)); uo = np.zeros((B, n, 2)); do = np.zeros(B)
+    st = np.zeros(B, np.int32); it = np.zeros(B, np.int32); kkt = np.zeros(B)
+    p = lambda a: a.ctypes.data_as(C.c_void_p) if a is not None else None
+    xi = ui = di = None
+    if init is not None:
+        xi, ui, di = (np.ascontiguousarray(a, float) for a in init)
+    lib.hostdbg_solve(C.byref(cfg), C.c_int(B), p(x0), p(xf), p(up), p(dtp), p(xi), p(ui), p(di), p(xo), p(uo), p(do), p(st), p(it), p(kkt))
+    return xo, uo, do, st, it, kkt
+
+
+CASES = {
+    "carlike_min_time_n50": lambda **k: A.config_carlike_min_time(50, **k),
+    "carlike_min_time_n20": lambda **k: A.config_carlike_min_time(20, **k),
+    "unicycle_quadratic_n20": lambda **k: A.config_unicycle_quadratic(20, **k),
+    "bicycle_min_time_n30": lambda **k: A.config_bicycle_min_time(30, **k),
+}
+
+
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_device_core_on_host_reproduces_golden(host, name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    cfg = CASES[name]()
+    xo, uo, do, st, it, kkt = host_solve(host, cfg, g["x0"], g["xf"], g["u_prev"], g["dt_prev"])
+    assert (st == 0).all()
+    assert np.abs(xo - g["x"]).max() < 1e-6
+    assert np.abs(uo - g["u"]).max() < 1e-6
+    assert np.abs(do - g["dt"]).max() < 1e-8
+    assert np.abs(it - g["iters"]).max() <= 2       # Riccati sweep follows the dense solve's iterate sequence
+
+
+def test_device_core_matches_c_oracle_on_a_batch(host, c_oracle):
+    n = 30
+    cfg = A.config_carlike_min_time(n)
+    x0, xf, up, dtp = W.carlike_min_time_inputs(48, seed=11, goal_range=(1.0, 4.0))
+    a = host_solve(host, cfg, x0, xf, up, dtp)
+    oc = c_oracle.from_nlp_config(R.config_carlike_min_time(n))
+    b = c_oracle.solve_batch(oc, x0, xf, up, dtp)
+    both = (a[3] == 0) & (b[3] == 0)
+    assert both.sum() >= 40
+    err = np.maximum(np.abs(a[0] - b[0]).reshape(48, -1).max(1), np.abs(a[1] - b[1]).reshape(48, -1).max(1))
+    # same algorithm, different linear algebra: identical up to round-off unless a line-search decision flips
+    assert (err[both] < 1e-6).mean() >= 0.9
+    assert np.median(err[both]) < 1e-9
+
+
+def test_device_core_fp32_is_close_to_fp64(host):
+    n = 20
+    x0, xf, up, dtp = W.carlike_min_time_inputs(16, seed=12, goal_range=(1.0, 2.5))
+    a = host_solve(host, A.config_carlike_min_time(n), x0, xf, up, dtp)
+    b = host_solve(host, A.config_carlike_min_time(n, precision=A.FP32, tol=1e-4), x0, xf, up, dtp)
+    both = (a[3] == 0) & (b[3] == 0)
+    assert both.sum() >= 8
+    err = np.abs(a[0] - b[0]).reshape(16, -1).max(1)
+    # BASELINE.md's fp32 goal is 1e-3; the pure-fp32 path currently reaches ~3e-3 (open items)
+    assert np.median(err[both]) < 1e-2
+
+
+def test_device_core_edge_cases(host):
+    cfg = A.config_carlike_min_time(3)          # smallest grid: 2 intervals
+    x0 = np.array([[0.0, 0.0, 0.0]]); xf = np.array([[0.3, 0.0, 0.0]])
+    xo, uo, do, st, it, _ = host_solve(host, cfg, x0, xf, np.zeros((1, 2)), np.zeros(1))   # dt_prev = 0 -> no stage-0 rate rows
+    assert st[0] == 0
+    np.testing.assert_array_equal(xo[0, 0], x0[0]); np.testing.assert_array_equal(xo[0, -1], xf[0])
+    assert uo[0, 0, 0] <= 0.4 + 1e-9 and do[0] > 0
+    np.testing.assert_array_equal(uo[0, -1], uo[0, -2])      # duplicated last control (getStateAndControlTimeSeries)
+    # heading crossing +-pi
+    cfg = A.config_carlike_min_time(20)
+    x0 = np.array([[0.0, 0.0, 3.0]]); xf = np.array([[-1.5, -0.2, -3.0]])
+    xo, uo, do, st, it, _ = host_solve(host, cfg, x0, xf, np.zeros((1, 2)), np.full(1, 0.2))
+    assert st[0] == 0
+    assert np.all(xo[0, :, 2] >= -np.pi) and np.all(xo[0, :, 2] < np.pi)
+    assert np.abs(xo[0, :, 2]).min() > 2.0      # went the short way round through +-pi

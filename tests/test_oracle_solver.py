@@ -1,0 +1,133 @@
+"""CPU tests of the oracle's SOLVE: numpy dense IPM vs scipy on the reference-form NLP, the C oracle
+(banded LU) vs the numpy IPM, and both against the committed golden fixtures."""
+import os
+
+import numpy as np
+import pytest
+from scipy.optimize import minimize
+
+from oracle import se2_nlp as R
+from oracle import ipm_dense as I
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+OCFG = {
+    "carlike_min_time_n50": lambda: R.config_carlike_min_time(50),
+    "carlike_min_time_n20": lambda: R.config_carlike_min_time(20),
+    "unicycle_quadratic_n20": lambda: R.config_unicycle_quadratic(20),
+    "bicycle_min_time_n30": lambda: R.config_bicycle_min_time(30),
+}
+
+
+def _ipm(cfg, inp, **kw):
+    return I.solve(cfg, inp, R.cold_start(cfg, inp.x0, inp.xf), opt=I.IpmOptions(globalization="merit", max_iter=100, **kw))
+
+
+def _slsqp_polish(cfg, inp, traj):
+    """Independent check: SLSQP on the REFERENCE-form NLP (division by dt, reference row order)
+    started at the IPM solution must stay there (it is a KKT point of the reference's NLP)."""
+    nlp = R.ReferenceNlp(cfg, inp)
+    z0 = nlp.pack(traj)
+    lb, ub = nlp.bounds()
+    bnds = [(None if l < -1e29 else l, None if u > 1e29 else u) for l, u in zip(lb, ub)]
+    if cfg.dt_free:
+        bnds[-1] = (1e-3, cfg.dt_ub)
+    cons = [{"type": "eq", "fun": nlp.equalities}, {"type": "ineq", "fun": lambda z: -nlp.inequalities(z)}]
+    r = minimize(nlp.objective, z0, method="SLSQP", bounds=bnds, constraints=cons, options=dict(maxiter=50, ftol=1e-12))
+    return nlp, z0, r
+
+
+def test_config1_unicycle_quadratic_single_instance_matches_scipy():
+    # BASELINE.json config 1: the reference's own CPU-runnable case
+    cfg = R.config_unicycle_quadratic(20)
+    inp = R.CycleInputs(x0=np.array([0.0, 0.0, 0.0]), xf=np.array([1.0, 0.3, 0.2]), u_prev=np.zeros(2), dt_prev=0.2)
+    res = _ipm(cfg, inp)
+    assert res.status == 0 and res.kkt_error < 1e-8
+    nlp, z0, r = _slsqp_polish(cfg, inp, res.traj)
+    assert np.abs(nlp.equalities(z0)).max() < 1e-8
+    assert nlp.inequalities(z0).max() < 1e-8
+    assert np.abs(r.x - z0).max() < 1e-5
+    assert abs(r.fun - res.objective) < 1e-6 * abs(res.objective)      # barrier residue mu=tol/10
+    # also from the cold start scipy must find the same (convex-like) optimum
+    zc = nlp.pack(R.cold_start(cfg, inp.x0, inp.xf))
+    lb, ub = nlp.bounds()
+    bnds = [(None if l < -1e29 else l, None if u > 1e29 else u) for l, u in zip(lb, ub)]
+    cons = [{"type": "eq", "fun": nlp.equalities}, {"type": "ineq", "fun": lambda z: -nlp.inequalities(z)}]
+    rc = minimize(nlp.objective, zc, method="SLSQP", bounds=bnds, constraints=cons, options=dict(maxiter=300, ftol=1e-13))
+    assert abs(rc.fun - res.objective) < 1e-6 * max(1.0, abs(res.objective))
+    assert np.abs(rc.x - z0).max() < 1e-4
+
+
+def test_carlike_min_time_solution_is_kkt_point_of_reference_form():
+    cfg = R.config_carlike_min_time(20)
+    inp = R.CycleInputs(x0=np.array([0.0, 0.0, 0.2]), xf=np.array([1.5, 0.5, 0.4]), u_prev=np.array([0.1, 0.0]), dt_prev=0.2)
+    res = _ipm(cfg, inp)
+    assert res.status == 0
+    nlp, z0, r = _slsqp_polish(cfg, inp, res.traj)
+    assert np.abs(nlp.equalities(z0)).max() < 1e-7
+    assert nlp.inequalities(z0).max() < 1e-7
+    assert abs(r.fun - res.objective) < 1e-6        # SLSQP cannot improve it ...
+    assert np.abs(r.x - z0).max() < 1e-3            # ... and stays put (its finite-difference gradients limit this to ~1e-4)
+    # physically sensible: time optimal => some control saturates
+    u = res.traj.u
+    assert (np.abs(u[:, 0] - 0.4) < 1e-4).any()
+
+
+def test_first_cycle_without_previous_control_drops_rate_rows_of_stage_zero():
+    cfg = R.config_carlike_min_time(12)
+    inp = R.CycleInputs(x0=np.array([0.0, 0.0, 0.0]), xf=np.array([1.0, 0.2, 0.1]), u_prev=np.zeros(2), dt_prev=0.0)
+    res = _ipm(cfg, inp)
+    assert res.status == 0
+    # with dt_prev = 0 the first control may jump: it is at the speed limit immediately
+    assert res.traj.u[0, 0] == pytest.approx(0.4, abs=1e-5)
+
+
+@pytest.mark.parametrize("name", sorted(OCFG))
+def test_numpy_ipm_reproduces_golden(name):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    cfg = OCFG[name]()
+    for i in range(min(3, g["x0"].shape[0])):
+        inp = R.CycleInputs(x0=g["x0"][i], xf=g["xf"][i], u_prev=g["u_prev"][i], dt_prev=float(g["dt_prev"][i]))
+        res = _ipm(cfg, inp)
+        assert res.status == 0
+        assert np.abs(res.traj.x - g["x"][i]).max() < 1e-6
+        assert np.abs(res.traj.u - g["u"][i, :-1]).max() < 1e-6
+        assert abs(res.traj.dt - g["dt"][i]) < 1e-8
+
+
+@pytest.mark.parametrize("name", sorted(OCFG))
+def test_c_oracle_reproduces_golden(name, c_oracle):
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    cfg = OCFG[name]()
+    oc = c_oracle.from_nlp_config(cfg)
+    xo, uo, do, st, it = c_oracle.solve_batch(oc, g["x0"], g["xf"], g["u_prev"], g["dt_prev"])
+    assert (st == 0).all()
+    assert np.abs(xo - g["x"]).max() < 1e-6
+    assert np.abs(uo - g["u"]).max() < 1e-6
+    assert np.abs(do - g["dt"]).max() < 1e-8
+    # banded-LU and dense solves follow the same iterate sequence
+    assert np.abs(it - g["iters"]).max() <= 2
+
+
+def test_c_oracle_warm_start_and_thread_invariance(c_oracle):
+    from mpc_local_planner_amd import workloads as W
+    cfg = R.config_carlike_min_time(20)
+    oc = c_oracle.from_nlp_config(cfg)
+    x0, xf, up, dtp = W.carlike_min_time_inputs(12, seed=5, goal_range=(1.0, 2.5))
+    a = c_oracle.solve_batch(oc, x0, xf, up, dtp, nthreads=1)
+    b = c_oracle.solve_batch(oc, x0, xf, up, dtp, nthreads=4)
+    for p, q in zip(a, b):
+        np.testing.assert_array_equal(p, q)
+    ok = a[3] == 0
+    # warm-start path (vertex values handed in, x_0 / fixed goal overwritten): every converged result is a
+    # feasible trajectory of the same problem
+    w = c_oracle.solve_batch(oc, x0, xf, up, dtp, init=(a[0], a[1], a[2]))
+    okw = w[3] == 0
+    assert okw.sum() >= 6
+    for i in np.nonzero(okw)[0]:
+        inp = R.CycleInputs(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=float(dtp[i]))
+        nlp = R.ReferenceNlp(cfg, inp)
+        z = nlp.pack(R.Trajectory(w[0][i], w[1][i, :-1], float(w[2][i])))
+        assert np.abs(nlp.equalities(z)).max() < 1e-6
+        assert nlp.inequalities(z).max() < 1e-6
+        np.testing.assert_array_equal(w[0][i, 0], x0[i])
+        np.testing.assert_array_equal(w[0][i, -1], xf[i])
