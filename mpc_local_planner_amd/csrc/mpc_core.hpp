@@ -63,7 +63,7 @@ struct Problem {
     // algorithm constants (Waechter & Biegler 2006 names)
     T tol, mu_init, kappa_eps, kappa_mu, theta_mu, tau_min, bound_push, slack_push;
     T eta_armijo, rho_frac, delta_first, delta_min, delta_max, kappa_plus, kappa_plus_first, kappa_minus;
-    T curv_kappa, s_max, delta_c, kappa_c;
+    T curv_kappa, s_max, delta_c, kappa_c, ls_eps;
     int max_ls;
 };
 
@@ -1103,7 +1103,8 @@ struct Ipm {
                 eval_point(L.XT, L.UT, L.DT, L.TRIG, L.CC, th_t, f_t, cinf_t);   // overwrites the caches of the current point
                 T tht = th_t + (T(1) - alpha) * theta_rows;
                 T phit = f_t - mu * barrier_logs(L.UT, L.DT, alpha, true) + rho * tht;
-                if (t_finite(phit) && phit <= phi0 + P.eta_armijo * alpha * Dm) { accepted = true; break; }
+                // round-off relaxed Armijo test (Waechter & Biegler 2006, sec. 3.3: 10*eps_mach*|phi|)
+                if (t_finite(phit) && phit - phi0 - P.ls_eps * t_abs(phi0) <= P.eta_armijo * alpha * Dm) { accepted = true; break; }
             }
             if (!accepted && alpha * fw.dzmax < T(1e-14)) {
                 // restore caches of the current point before leaving

@@ -52,6 +52,7 @@ inline void fill_problem(const mpc_config& c, mpc::Problem<T>& P) {
     P.s_max = T(100);
     P.delta_c = T(f32 ? 1e-5 : 1e-8);
     P.kappa_c = T(0.25);
+    P.ls_eps = T(f32 ? 10 * 1.1920929e-7 : 10 * 2.220446049250313e-16);
     P.max_ls = 30;
 }
 

@@ -652,7 +652,7 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
                 evt = nlp.eval(vt)
                 tht = np.abs(evt["c"]).sum() + np.abs(evt["g"] + st).sum()
                 phit = barrier_obj(evt["f"], vt, st, mu) + rho * tht
-                if np.isfinite(phit) and phit <= phi0 + opt.eta_armijo * alpha * D:
+                if np.isfinite(phit) and phit - phi0 - 10 * 2.220446049250313e-16 * abs(phi0) <= opt.eta_armijo * alpha * D:
                     accepted = True
                     break
         else:

@@ -599,7 +599,7 @@ static int solve_one(work_t* w, int warm) {
             for (int i = 0; i < 3 * (n - 1); ++i) tht += fabs(cct[i]);
             for (int r = 0; r < n; ++r) for (int q = 0; q < 4; ++q) if (row_on(w, r, q)) tht += fabs(row_val_at(w, w->Ut, w->Dt, r, q) + st[4 * r + q]);
             double phit = ft - mu * barrier_logs(w, w->Ut, w->Dt, st) + w->rho * tht;
-            if (isfinite(phit) && phit <= phi0 + eta * alpha * Dm) { accepted = 1; break; }
+            if (isfinite(phit) && phit - phi0 - 10 * 2.220446049250313e-16 * fabs(phi0) <= eta * alpha * Dm) { accepted = 1; break; }
         }
         if (!accepted && alpha * dzmax < 1e-14) { status = 2; break; }
         /* accept */
