@@ -11,6 +11,7 @@
 #include "../../include/mpc_hip.h"
 #include "mpc_core.hpp"
 #include "mpc_problem.hpp"
+#include "mpc_wave.hpp"
 
 namespace {
 
@@ -75,6 +76,52 @@ __global__ __launch_bounds__(kLanes) void mpc_ipm_solve_kernel(
     if (iters) iters[inst] = st.iters;
 }
 
+
+// One wavefront = one planner instance; the whole working set lives in LDS (mpc_wave.hpp).
+template <typename T, int MODEL>
+__global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
+    mpc::Problem<T> P, mpc::WaveLayout L, int B,
+    const double* __restrict__ x0, const double* __restrict__ xf, const double* __restrict__ u_prev,
+    const double* __restrict__ dt_prev, const double* __restrict__ x_init, const double* __restrict__ u_init,
+    const double* __restrict__ dt_init, double* __restrict__ x_out, double* __restrict__ u_out,
+    double* __restrict__ dt_out, int32_t* __restrict__ status, int32_t* __restrict__ iters) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char mpc_smem[];
+    T* sm = reinterpret_cast<T*>(mpc_smem);
+    const int inst = blockIdx.x;
+    const int lane = threadIdx.x;
+    if (inst >= B) return;
+    const int n = L.n;
+    mpc::IpmWave<T, MODEL> S(P, L, sm, lane);
+    for (int i = 0; i < 3; ++i) { S.x0[i] = T(x0[3 * inst + i]); S.xf[i] = T(xf[3 * inst + i]); }
+    S.x0[2] = mpc::normalize_theta(S.x0[2]);
+    S.xf[2] = mpc::normalize_theta(S.xf[2]);
+    S.uprev[0] = u_prev ? T(u_prev[2 * inst]) : T(0);
+    S.uprev[1] = u_prev ? T(u_prev[2 * inst + 1]) : T(0);
+    S.dtprev = dt_prev ? T(dt_prev[inst]) : T(0);
+    if (x_init && u_init && dt_init) {
+        // coalesced read of this instance's contiguous [n][3] / [n][2] blocks
+        const double* xi = x_init + (long)inst * n * 3;
+        const double* ui = u_init + (long)inst * n * 2;
+        for (int e = lane; e < 3 * n; e += mpc::kWave) S.F(L.X, e % 3, e / 3) = T(xi[e]);
+        for (int e = lane; e < 2 * (n - 1); e += mpc::kWave) S.F(L.U, e % 2, e / 2) = T(ui[e]);
+        if (lane == 0) S.SCL(mpc::SC_D) = T(dt_init[inst]);
+    } else {
+        S.cold_start();
+    }
+    __syncthreads();
+    mpc::SolveStats<T> st = S.solve();
+    __syncthreads();
+    double* xo = x_out + (long)inst * n * 3;
+    double* uo = u_out + (long)inst * n * 2;
+    for (int e = lane; e < 3 * n; e += mpc::kWave) xo[e] = double(S.F(L.X, e % 3, e / 3));
+    for (int e = lane; e < 2 * n; e += mpc::kWave) { int k = e / 2; int ks = k < n - 1 ? k : n - 2; uo[e] = double(S.F(L.U, e % 2, ks)); }
+    if (lane == 0) {
+        dt_out[inst] = double(S.SCL(mpc::SC_D));
+        if (status) status[inst] = st.status;
+        if (iters) iters[inst] = st.iters;
+    }
+}
+
 }  // namespace
 
 struct mpc_solver {
@@ -82,6 +129,9 @@ struct mpc_solver {
     mpc::Problem<double> P64;
     mpc::Problem<float> P32;
     mpc::Layout L;
+    mpc::WaveLayout WL;
+    int use_wave;          // 1: wavefront-per-instance LDS kernel, 0: lane-per-instance kernel
+    size_t wave_lds;
     int device;
     int max_batch;
     long stride;
@@ -149,6 +199,10 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
     mpc::fill_problem<double>(*cfg, s->P64);
     mpc::fill_problem<float>(*cfg, s->P32);
     s->L = mpc::Layout::make(cfg->n);
+    s->WL = mpc::WaveLayout::make(cfg->n);
+    s->wave_lds = (size_t)s->WL.total * (cfg->precision == MPC_FP32 ? 4 : 8);
+    s->use_wave = (s->wave_lds <= 160u * 1024u && !cfg->integral_form) ? 1 : 0;
+    if (const char* ev = getenv("MPC_HIP_KERNEL")) { if (!strcmp(ev, "lane")) s->use_wave = 0; else if (!strcmp(ev, "wave") && s->wave_lds <= 160u * 1024u) s->use_wave = 1; }
     s->device = device;
     s->max_batch = max_batch;
     s->stride = ((long)max_batch + kLanes - 1) / kLanes * kLanes;
@@ -197,23 +251,33 @@ void mpc_destroy(mpc_solver* s) {
 }  // extern "C"
 
 template <typename T, int MODEL>
-static void launch_model(mpc_solver* s, const mpc::Problem<T>& P, int B, const double* x0, const double* xf, const double* up,
-                         const double* dtp, const double* xi, const double* ui, const double* dti, double* xo, double* uo,
-                         double* dto, int32_t* st, int32_t* it) {
-    dim3 grid((B + kLanes - 1) / kLanes), block(kLanes);
-    hipLaunchKernelGGL((mpc_ipm_solve_kernel<T, MODEL>), grid, block, 0, s->stream, P, s->L, (T*)s->ws, s->stride, B, x0, xf, up,
-                       dtp, xi, ui, dti, xo, uo, dto, st, it);
+static hipError_t launch_model(mpc_solver* s, const mpc::Problem<T>& P, int B, const double* x0, const double* xf, const double* up,
+                               const double* dtp, const double* xi, const double* ui, const double* dti, double* xo, double* uo,
+                               double* dto, int32_t* st, int32_t* it) {
+    if (s->use_wave) {
+        auto kern = mpc_ipm_wave_kernel<T, MODEL>;
+        if (s->wave_lds > 48u * 1024u) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->wave_lds);
+            if (e != hipSuccess) return e;
+        }
+        hipLaunchKernelGGL(kern, dim3(B), dim3(mpc::kWave), s->wave_lds, s->stream, P, s->WL, B, x0, xf, up, dtp, xi, ui, dti, xo, uo, dto, st, it);
+    } else {
+        dim3 grid((B + kLanes - 1) / kLanes), block(kLanes);
+        hipLaunchKernelGGL((mpc_ipm_solve_kernel<T, MODEL>), grid, block, 0, s->stream, P, s->L, (T*)s->ws, s->stride, B, x0, xf, up,
+                           dtp, xi, ui, dti, xo, uo, dto, st, it);
+    }
+    return hipSuccess;
 }
 
 template <typename T>
-static void launch_prec(mpc_solver* s, const mpc::Problem<T>& P, int B, const double* x0, const double* xf, const double* up,
+static hipError_t launch_prec(mpc_solver* s, const mpc::Problem<T>& P, int B, const double* x0, const double* xf, const double* up,
                         const double* dtp, const double* xi, const double* ui, const double* dti, double* xo, double* uo,
                         double* dto, int32_t* st, int32_t* it) {
     switch (s->cfg.model) {
-        case MPC_MODEL_UNICYCLE: launch_model<T, mpc::MODEL_UNICYCLE>(s, P, B, x0, xf, up, dtp, xi, ui, dti, xo, uo, dto, st, it); break;
-        case MPC_MODEL_SIMPLE_CAR: launch_model<T, mpc::MODEL_SIMPLE_CAR>(s, P, B, x0, xf, up, dtp, xi, ui, dti, xo, uo, dto, st, it); break;
-        case MPC_MODEL_SIMPLE_CAR_FRONT: launch_model<T, mpc::MODEL_SIMPLE_CAR_FRONT>(s, P, B, x0, xf, up, dtp, xi, ui, dti, xo, uo, dto, st, it); break;
-        default: launch_model<T, mpc::MODEL_KINEMATIC_BICYCLE>(s, P, B, x0, xf, up, dtp, xi, ui, dti, xo, uo, dto, st, it); break;
+        case MPC_MODEL_UNICYCLE: return launch_model<T, mpc::MODEL_UNICYCLE>(s, P, B, x0, xf, up, dtp, xi, ui, dti, xo, uo, dto, st, it);
+        case MPC_MODEL_SIMPLE_CAR: return launch_model<T, mpc::MODEL_SIMPLE_CAR>(s, P, B, x0, xf, up, dtp, xi, ui, dti, xo, uo, dto, st, it);
+        case MPC_MODEL_SIMPLE_CAR_FRONT: return launch_model<T, mpc::MODEL_SIMPLE_CAR_FRONT>(s, P, B, x0, xf, up, dtp, xi, ui, dti, xo, uo, dto, st, it);
+        default: return launch_model<T, mpc::MODEL_KINEMATIC_BICYCLE>(s, P, B, x0, xf, up, dtp, xi, ui, dti, xo, uo, dto, st, it);
     }
 }
 
@@ -228,10 +292,12 @@ int mpc_solve_batch_device(mpc_solver* s, int32_t B, const double* d_x0, const d
     if (B > s->max_batch) { set_err("mpc_solve_batch_device: B exceeds max_batch"); return MPC_EBATCH; }
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipEventRecord(s->ev0, s->stream));
+    hipError_t le;
     if (s->cfg.precision == MPC_FP32)
-        launch_prec<float>(s, s->P32, B, d_x0, d_xf, d_u_prev, d_dt_prev, d_x_init, d_u_init, d_dt_init, d_x_out, d_u_out, d_dt_out, d_status, d_iters);
+        le = launch_prec<float>(s, s->P32, B, d_x0, d_xf, d_u_prev, d_dt_prev, d_x_init, d_u_init, d_dt_init, d_x_out, d_u_out, d_dt_out, d_status, d_iters);
     else
-        launch_prec<double>(s, s->P64, B, d_x0, d_xf, d_u_prev, d_dt_prev, d_x_init, d_u_init, d_dt_init, d_x_out, d_u_out, d_dt_out, d_status, d_iters);
+        le = launch_prec<double>(s, s->P64, B, d_x0, d_xf, d_u_prev, d_dt_prev, d_x_init, d_u_init, d_dt_init, d_x_out, d_u_out, d_dt_out, d_status, d_iters);
+    HIP_TRY(le);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev1, s->stream));
     s->timed = true;

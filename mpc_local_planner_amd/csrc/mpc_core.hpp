@@ -21,6 +21,7 @@
 #pragma once
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 
 #if defined(__HIPCC__)
 #define MPC_HD __host__ __device__ __forceinline__
@@ -60,11 +61,25 @@ struct Problem {
     T Q[3], R[2], Qf[3];
     T u_lb[2], u_ub[2];
     T rate_lim[4];       // du_lb0, du_lb1, du_ub0, du_ub1
-    // algorithm constants (Waechter & Biegler 2006 names)
-    T tol, mu_init, kappa_eps, kappa_mu, theta_mu, tau_min, bound_push, slack_push;
-    T eta_armijo, rho_frac, delta_first, delta_min, delta_max, kappa_plus, kappa_plus_first, kappa_minus;
-    T curv_kappa, s_max, delta_c, kappa_c, ls_eps;
-    int max_ls;
+    T tol, mu_init;
+};
+
+// Algorithm constants (Waechter & Biegler 2006 names).  Compile-time so that they live in
+// instruction immediates instead of scalar registers.
+template <typename T> struct Algo;
+template <> struct Algo<double> {
+    static constexpr double kappa_eps = 10, kappa_mu = 0.2, theta_mu = 1.5, tau_min = 0.99, bound_push = 1e-2, slack_push = 1e-2;
+    static constexpr double eta_armijo = 1e-4, rho_frac = 0.1, delta_first = 1e-4, delta_min = 1e-20, delta_max = 1e20;
+    static constexpr double kappa_plus = 8, kappa_plus_first = 100, kappa_minus = 1.0 / 3.0;
+    static constexpr double curv_kappa = 1e-10, s_max = 100, delta_c = 1e-8, kappa_c = 0.25, ls_eps = 10 * 2.220446049250313e-16;
+    static constexpr int max_ls = 30;
+};
+template <> struct Algo<float> {
+    static constexpr float kappa_eps = 10, kappa_mu = 0.2f, theta_mu = 1.5f, tau_min = 0.99f, bound_push = 1e-2f, slack_push = 1e-2f;
+    static constexpr float eta_armijo = 1e-4f, rho_frac = 0.1f, delta_first = 1e-4f, delta_min = 1e-12f, delta_max = 1e12f;
+    static constexpr float kappa_plus = 8, kappa_plus_first = 100, kappa_minus = 1.0f / 3.0f;
+    static constexpr float curv_kappa = 1e-7f, s_max = 100, delta_c = 1e-5f, kappa_c = 0.25f, ls_eps = 10 * 1.1920929e-7f;
+    static constexpr int max_ls = 30;
 };
 
 // Workspace layout: slot index -> word offset = slot * stride + instance.
@@ -336,8 +351,8 @@ struct Ipm {
     }
 
     MPC_HD T push_interior(T v, T lb, T ub) const {
-        T pl = t_min(P.bound_push * t_max(T(1), t_abs(lb)), P.bound_push * (ub - lb));
-        T pu = t_min(P.bound_push * t_max(T(1), t_abs(ub)), P.bound_push * (ub - lb));
+        T pl = t_min(Algo<T>::bound_push * t_max(T(1), t_abs(lb)), Algo<T>::bound_push * (ub - lb));
+        T pu = t_min(Algo<T>::bound_push * t_max(T(1), t_abs(ub)), Algo<T>::bound_push * (ub - lb));
         return t_min(t_max(v, lb + pl), ub - pu);
     }
 
@@ -472,6 +487,11 @@ struct Ipm {
                 T r1 = gx[1] + lam[1] - lam_prev[1];
                 T r2 = gx[2] + lam[2] + d * gq[0] - lam_prev[2];
                 e.rd = t_max(e.rd, t_max(t_abs(r0), t_max(t_abs(r1), t_abs(r2))));
+#ifdef MPC_TRACE
+                if (MPC_TRACE_COND && mu < T(1e-8) && (t_abs(r0) > T(1e-7) || t_abs(r1) > T(1e-7) || t_abs(r2) > T(1e-7)))
+                    printf("  x-stat k=%d r=(%.3e %.3e %.3e) gx=(%.3e %.3e %.3e) lam=(%.6e %.6e %.6e) lamp=(%.6e %.6e %.6e) dgq0 %.3e\n", k, (double)r0, (double)r1, (double)r2,
+                           (double)gx[0], (double)gx[1], (double)gx[2], (double)lam[0], (double)lam[1], (double)lam[2], (double)lam_prev[0], (double)lam_prev[1], (double)lam_prev[2], (double)(d * gq[0]));
+#endif
             }
             // u_k stationarity
             for (int j = 0; j < 2; ++j) {
@@ -484,6 +504,9 @@ struct Ipm {
                     if (row_on(k + 1, q)) r -= sg * M.ld(L.YR + 4 * (k + 1) + q);
                 }
                 e.rd = t_max(e.rd, t_abs(r));
+#ifdef MPC_TRACE
+                if (MPC_TRACE_COND && mu < T(1e-8) && t_abs(r) > T(1e-7)) printf("  u-stat k=%d j=%d r=%.3e\n", k, j, (double)r);
+#endif
                 T cl = (u - P.u_lb[j]) * pl, cu = (P.u_ub[j] - u) * pu;
                 e.cmin = t_min(e.cmin, t_min(cl, cu));
                 e.cmax = t_max(e.cmax, t_max(cl, cu));
@@ -502,6 +525,9 @@ struct Ipm {
                     g = T(2) * P.Qf[i] * xd;
                 }
                 e.rd = t_max(e.rd, t_abs(g - lam_prev[i]));
+#ifdef MPC_TRACE
+                if (MPC_TRACE_COND && mu < T(1e-8) && t_abs(g - lam_prev[i]) > T(1e-7)) printf("  xf-stat i=%d g=%.9e lam=%.9e\n", i, (double)g, (double)lam_prev[i]);
+#endif
             }
         }
         // rate rows
@@ -535,8 +561,8 @@ struct Ipm {
     }
 
     MPC_HD T err_value(const Err& e, T mu_t) const {
-        T sd = t_max(P.s_max, e.sum_mult / T(e.n_mult > 0 ? e.n_mult : 1)) / P.s_max;
-        T sc = t_max(P.s_max, e.sum_bmult / T(e.n_bmult > 0 ? e.n_bmult : 1)) / P.s_max;
+        T sd = t_max(Algo<T>::s_max, e.sum_mult / T(e.n_mult > 0 ? e.n_mult : 1)) / Algo<T>::s_max;
+        T sc = t_max(Algo<T>::s_max, e.sum_bmult / T(e.n_bmult > 0 ? e.n_bmult : 1)) / Algo<T>::s_max;
         T comp = e.n_bmult > 0 ? t_max(e.cmax - mu_t, mu_t - e.cmin) : T(0);
         return t_max(e.rd / sd, t_max(e.rp, comp / sc));
     }
@@ -1024,7 +1050,7 @@ struct Ipm {
         for (int r = 0; r < n; ++r) {
             for (int q = 0; q < 4; ++q) {
                 T s = T(1), y = T(0);
-                if (row_on(r, q)) { s = t_max(-row_val(r, q), P.slack_push); y = mu / s; }
+                if (row_on(r, q)) { s = t_max(-row_val(r, q), Algo<T>::slack_push); y = mu / s; }
                 M.st(L.SR + 4 * r + q, s);
                 M.st(L.YR + 4 * r + q, y);
             }
@@ -1055,13 +1081,13 @@ struct Ipm {
             // monotone barrier update (Waechter & Biegler eq. 7)
             for (int guard = 0; guard < 50; ++guard) {
                 T emu = err_value(er, mu);
-                if (emu <= P.kappa_eps * mu && mu > P.tol / T(10)) {
-                    mu = t_max(P.tol / T(10), t_min(P.kappa_mu * mu, t_pow(mu, P.theta_mu)));
+                if (emu <= Algo<T>::kappa_eps * mu && mu > P.tol / T(10)) {
+                    mu = t_max(P.tol / T(10), t_min(Algo<T>::kappa_mu * mu, t_pow(mu, Algo<T>::theta_mu)));
                     rho = T(0);
                 } else break;
             }
-            const T tau = t_max(P.tau_min, T(1) - mu);
-            const T dc = nfix > 0 ? P.delta_c * t_pow(mu, P.kappa_c) : T(0);
+            const T tau = t_max(Algo<T>::tau_min, T(1) - mu);
+            const T dc = nfix > 0 ? Algo<T>::delta_c * t_pow(mu, Algo<T>::kappa_c) : T(0);
             // ---- factor/solve with inertia-free regularisation
             T delta = T(0);
             bool ok = false;
@@ -1075,12 +1101,12 @@ struct Ipm {
                     good = fw.finite;
                     if (good) {
                         curv = -fw.hdz + fw.clam - dc * fw.nunu;     // = dz^T (H + delta I) dz
-                        if (curv >= P.curv_kappa * fw.dz2) { ok = true; break; }
+                        if (curv >= Algo<T>::curv_kappa * fw.dz2) { ok = true; break; }
                     }
                 }
-                if (delta == T(0)) delta = (delta_last == T(0)) ? P.delta_first : t_max(P.delta_min, P.kappa_minus * delta_last);
-                else delta *= (delta_last == T(0)) ? P.kappa_plus_first : P.kappa_plus;
-                if (delta > P.delta_max) break;
+                if (delta == T(0)) delta = (delta_last == T(0)) ? Algo<T>::delta_first : t_max(Algo<T>::delta_min, Algo<T>::kappa_minus * delta_last);
+                else delta *= (delta_last == T(0)) ? Algo<T>::kappa_plus_first : Algo<T>::kappa_plus;
+                if (delta > Algo<T>::delta_max) break;
             }
             if (!ok) { status = ST_LINSOLVE; break; }
             if (delta > T(0)) delta_last = delta;
@@ -1088,7 +1114,7 @@ struct Ipm {
             const T theta = er.theta;
             if (theta > T(0)) {
                 T sigma = curv > T(0) ? T(1) : T(0);
-                T rho_trial = (fw.dphi + T(0.5) * sigma * curv) / ((T(1) - P.rho_frac) * theta);
+                T rho_trial = (fw.dphi + T(0.5) * sigma * curv) / ((T(1) - Algo<T>::rho_frac) * theta);
                 if (rho < rho_trial) rho = rho_trial + T(1);
             }
             const T phi0 = fobj - mu * barrier_logs(L.U, L.D, T(0), false) + rho * theta;
@@ -1097,14 +1123,14 @@ struct Ipm {
             T alpha = fw.a_p;
             bool accepted = false;
             T th_t = T(0), f_t = T(0), cinf_t = T(0);
-            for (int ls = 0; ls < P.max_ls; ++ls) {
+            for (int ls = 0; ls < Algo<T>::max_ls; ++ls) {
                 if (ls > 0) alpha *= T(0.5);
                 make_trial(alpha);
                 eval_point(L.XT, L.UT, L.DT, L.TRIG, L.CC, th_t, f_t, cinf_t);   // overwrites the caches of the current point
                 T tht = th_t + (T(1) - alpha) * theta_rows;
                 T phit = f_t - mu * barrier_logs(L.UT, L.DT, alpha, true) + rho * tht;
                 // round-off relaxed Armijo test (Waechter & Biegler 2006, sec. 3.3: 10*eps_mach*|phi|)
-                if (t_finite(phit) && phit - phi0 - P.ls_eps * t_abs(phi0) <= P.eta_armijo * alpha * Dm) { accepted = true; break; }
+                if (t_finite(phit) && phit - phi0 - Algo<T>::ls_eps * t_abs(phi0) <= Algo<T>::eta_armijo * alpha * Dm) { accepted = true; break; }
             }
             if (!accepted && alpha * fw.dzmax < T(1e-14)) {
                 // restore caches of the current point before leaving
@@ -1112,6 +1138,10 @@ struct Ipm {
                 status = ST_LINESEARCH;
                 break;
             }
+#ifdef MPC_TRACE
+            if (MPC_TRACE_COND) printf("it %d e0 %.3e mu %.1e theta %.3e alpha %.4f a_d %.4f delta %.1e curv %.3e dz2 %.3e dphi %.3e rho %.2e acc %d phi0 %.17g | rd %.3e rp %.3e cmin %.3e cmax %.3e sm %.3e sb %.3e nm %d nb %d\n",
+                                       it, (double)e0, (double)mu, (double)theta, (double)alpha, (double)fw.a_d, (double)delta, (double)curv, (double)fw.dz2, (double)fw.dphi, (double)rho, (int)accepted, (double)phi0, (double)er.rd, (double)er.rp, (double)er.cmin, (double)er.cmax, (double)er.sum_mult, (double)er.sum_bmult, er.n_mult, er.n_bmult);
+#endif
             accept(alpha, fw.a_d);
             theta_c = th_t; fobj = f_t; cinf = cinf_t;
             ++it;

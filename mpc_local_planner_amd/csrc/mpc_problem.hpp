@@ -34,26 +34,6 @@ inline void fill_problem(const mpc_config& c, mpc::Problem<T>& P) {
     const bool f32 = sizeof(T) == 4;
     P.tol = T(c.tol > 0 ? c.tol : (f32 ? 1e-4 : 1e-8));
     P.mu_init = T(c.mu_init > 0 ? c.mu_init : 0.1);
-    P.kappa_eps = T(10);
-    P.kappa_mu = T(0.2);
-    P.theta_mu = T(1.5);
-    P.tau_min = T(0.99);
-    P.bound_push = T(1e-2);
-    P.slack_push = T(1e-2);
-    P.eta_armijo = T(1e-4);
-    P.rho_frac = T(0.1);
-    P.delta_first = T(1e-4);
-    P.delta_min = T(f32 ? 1e-12 : 1e-20);
-    P.delta_max = T(f32 ? 1e12 : 1e20);
-    P.kappa_plus = T(8);
-    P.kappa_plus_first = T(100);
-    P.kappa_minus = T(1.0 / 3.0);
-    P.curv_kappa = T(f32 ? 1e-7 : 1e-10);
-    P.s_max = T(100);
-    P.delta_c = T(f32 ? 1e-5 : 1e-8);
-    P.kappa_c = T(0.25);
-    P.ls_eps = T(f32 ? 10 * 1.1920929e-7 : 10 * 2.220446049250313e-16);
-    P.max_ls = 30;
 }
 
 
