@@ -88,7 +88,8 @@ def main():
     cfg = m.config_carlike_min_time(n=n)
     solver = m.BatchSolver(cfg, max_batch=B, device=local_rank)
     # independent planner instances per rank: seed + rank (no scatter needed)
-    x0, xf, up, dtp = m.workloads.carlike_min_time_inputs(B, seed=m.workloads.SEED_CONFIG2 + rank)
+    from mpc_local_planner_amd import sharding
+    x0, xf, up, dtp = m.workloads.carlike_min_time_inputs(B, seed=sharding.rank_seed(m.workloads.SEED_CONFIG2, rank))
     T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
     dx0, dxf, dup, ddtp = T(x0), T(xf), T(up), T(dtp)
     xo = torch.empty((B, n, 3), dtype=torch.float64, device=dev)
@@ -122,10 +123,7 @@ def main():
         dist.barrier()
     sync()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    elapsed = sharding.max_over_ranks(elapsed, device=dev)
 
     status = st.cpu().numpy()
     iters = it.cpu().numpy()

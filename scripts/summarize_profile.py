@@ -1,0 +1,46 @@
+#!/usr/bin/env python
+"""Turn the rocprofv3 result databases under gpurun_out/prof/ into the small text summaries kept in profiles/.
+usage: python scripts/summarize_profile.py gpurun_out/prof profiles/r01_wave_kernel"""
+import glob
+import os
+import sqlite3
+import sys
+
+
+def rows(path, sql):
+    db = sqlite3.connect(path)
+    cur = db.cursor()
+    r = cur.execute(sql).fetchall()
+    cols = [d[0] for d in cur.description]
+    db.close()
+    return cols, r
+
+
+def main(src, dst):
+    os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
+    out = []
+    tr = os.path.join(src, "trace", "run_results.db")
+    if os.path.exists(tr):
+        out.append("## rocprofv3 --kernel-trace --stats  (python bench.py --steps 5 --warmup 1 --no-cpu-baseline)\n")
+        out.append("| kernel | calls | total_ns | avg_ns | % |\n|---|---|---|---|---|\n")
+        for name, calls, tot, avg, pct in rows(tr, "select name,total_calls,total_duration,average,percentage from top_kernels")[1]:
+            out.append(f"| {name.split('(')[0][-80:]} | {calls} | {tot:.0f} | {avg:.0f} | {pct:.3f} |\n")
+        c, r = rows(tr, "select name,duration,grid_x,workgroup_x,lds_size,scratch_size,vgpr_count,accum_vgpr_count,sgpr_count from kernels where name like '%mpc_ipm%'")
+        out.append("\nper-dispatch of the solve kernel (duration ns, grid, workgroup, LDS B, scratch B/lane, VGPR, AGPR, SGPR):\n\n")
+        for x in r:
+            out.append("    " + ", ".join(str(v) for v in x[1:]) + "\n")
+    for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+        db = os.path.join(d, "run_results.db")
+        if not os.path.exists(db):
+            continue
+        c, r = rows(db, "select counter_name, count(*), avg(value), min(value), max(value) from counters_collection "
+                        "where kernel_name like '%mpc_ipm%' group by counter_name")
+        out.append(f"\n## rocprofv3 --pmc ({os.path.basename(d)}) -- per dispatch of the solve kernel\n\n| counter | dispatches | mean | min | max |\n|---|---|---|---|---|\n")
+        for name, cnt, mean, mn, mx in r:
+            out.append(f"| {name} | {cnt} | {mean:.6g} | {mn:.6g} | {mx:.6g} |\n")
+    open(dst + ".md", "w").write("".join(out))
+    print("".join(out))
+
+
+if __name__ == "__main__":
+    main(sys.argv[1], sys.argv[2])
