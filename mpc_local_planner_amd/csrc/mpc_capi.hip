@@ -39,11 +39,15 @@ __global__ __launch_bounds__(kLanes) void mpc_ipm_solve_kernel(
     const double* __restrict__ dt_prev, const double* __restrict__ x_init, const double* __restrict__ u_init,
     const double* __restrict__ dt_init, double* __restrict__ x_out, double* __restrict__ u_out,
     double* __restrict__ dt_out, int32_t* __restrict__ status, int32_t* __restrict__ iters) {
+    __shared__ mpc::Problem<T> Ps;
+    __shared__ mpc::Layout Ls;
+    if (threadIdx.x == 0) { Ps = P; Ls = L; }
+    __syncthreads();
     const int inst = blockIdx.x * kLanes + threadIdx.x;
     if (inst >= B) return;
     const int n = L.n;
     mpc::Mem<T> M{ws + inst, stride};
-    mpc::Ipm<T, MODEL> S(P, L, M);
+    mpc::Ipm<T, MODEL> S(Ps, Ls, M);
     for (int i = 0; i < 3; ++i) { S.x0[i] = T(x0[3 * inst + i]); S.xf[i] = T(xf[3 * inst + i]); }
     S.x0[2] = mpc::normalize_theta(S.x0[2]);
     S.xf[2] = mpc::normalize_theta(S.xf[2]);
@@ -87,11 +91,17 @@ __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
     double* __restrict__ dt_out, int32_t* __restrict__ status, int32_t* __restrict__ iters) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mpc_smem[];
     T* sm = reinterpret_cast<T*>(mpc_smem);
+    // problem record + layout at the end of the dynamic LDS block (16-byte aligned)
+    const size_t coff = (((size_t)L.total * sizeof(T)) + 15) & ~(size_t)15;
+    mpc::Problem<T>* Ps = reinterpret_cast<mpc::Problem<T>*>(mpc_smem + coff);
+    mpc::WaveLayout* Ls = reinterpret_cast<mpc::WaveLayout*>(mpc_smem + coff + ((sizeof(mpc::Problem<T>) + 15) & ~(size_t)15));
     const int inst = blockIdx.x;
     const int lane = threadIdx.x;
     if (inst >= B) return;
+    if (lane == 0) { *Ps = P; *Ls = L; }
+    __syncthreads();
     const int n = L.n;
-    mpc::IpmWave<T, MODEL> S(P, L, sm, lane);
+    mpc::IpmWave<T, MODEL> S(*Ps, *Ls, sm, lane);
     for (int i = 0; i < 3; ++i) { S.x0[i] = T(x0[3 * inst + i]); S.xf[i] = T(xf[3 * inst + i]); }
     S.x0[2] = mpc::normalize_theta(S.x0[2]);
     S.xf[2] = mpc::normalize_theta(S.xf[2]);
@@ -172,6 +182,13 @@ void mpc_config_defaults(mpc_config* c) {
 const char* mpc_last_error(void) { return g_err; }
 int32_t mpc_version(void) { return 100; }
 
+#ifdef MPC_PROFILE
+// developer build only (-DMPC_PROFILE): per-wave phase cycle counters of the last wave-kernel launch
+int mpc_debug_profile(long long* out, int rows) {
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mpc_prof), sizeof(long long) * 14 * (size_t)rows, 0, hipMemcpyDeviceToHost);
+}
+#endif
+
 int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_solver** out) {
     g_err[0] = 0;
     if (!cfg || !out || max_batch <= 0) { set_err("mpc_create: bad argument"); return MPC_EINVAL; }
@@ -182,6 +199,7 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
     if (cfg->objective != MPC_OBJ_MIN_TIME && cfg->objective != MPC_OBJ_QUADRATIC) { set_err("mpc_create: unknown objective"); return MPC_EINVAL; }
     if (cfg->objective == MPC_OBJ_MIN_TIME && !cfg->dt_free) { set_err("mpc_create: minimum_time needs a variable grid (dt_free)"); return MPC_EINVAL; }
     if (!(cfg->dt_ref > 0)) { set_err("mpc_create: dt_ref must be > 0"); return MPC_EINVAL; }
+    if (cfg->integral_form) { set_err("mpc_create: integral_form costs are not implemented (the example configurations use the sum form)"); return MPC_EINVAL; }
     for (int j = 0; j < 2; ++j)
         if (!(cfg->u_lb[j] < cfg->u_ub[j])) { set_err("mpc_create: control box must be finite and non-empty"); return MPC_EINVAL; }
     int ndev = 0;
@@ -200,8 +218,9 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
     mpc::fill_problem<float>(*cfg, s->P32);
     s->L = mpc::Layout::make(cfg->n);
     s->WL = mpc::WaveLayout::make(cfg->n);
-    s->wave_lds = (size_t)s->WL.total * (cfg->precision == MPC_FP32 ? 4 : 8);
-    s->use_wave = (s->wave_lds <= 160u * 1024u && !cfg->integral_form) ? 1 : 0;
+    s->wave_lds = ((((size_t)s->WL.total * (cfg->precision == MPC_FP32 ? 4 : 8)) + 15) & ~(size_t)15) + 16 +
+                  ((cfg->precision == MPC_FP32 ? sizeof(mpc::Problem<float>) : sizeof(mpc::Problem<double>)) + 15 & ~(size_t)15) + sizeof(mpc::WaveLayout);
+    s->use_wave = (s->wave_lds <= 160u * 1024u) ? 1 : 0;
     if (const char* ev = getenv("MPC_HIP_KERNEL")) { if (!strcmp(ev, "lane")) s->use_wave = 0; else if (!strcmp(ev, "wave") && s->wave_lds <= 160u * 1024u) s->use_wave = 1; }
     s->device = device;
     s->max_batch = max_batch;

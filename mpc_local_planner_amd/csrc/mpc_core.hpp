@@ -256,6 +256,211 @@ MPC_HD void model_derivs(const Problem<T>& P, const T tr[4], T v, T w, const T l
     Hq[1][0] = Hq[0][1]; Hq[2][0] = Hq[0][2]; Hq[2][1] = Hq[1][2];
 }
 
+// ---------------------------------------------------------------------------------------------
+// Structured backward (Riccati) stage step, shared by both kernels.
+//
+// Value function of stage k+1 over xi+ = (x+, u_k, dt):  1/2 xi'P xi + xi'(p + S nu) + 1/2 nu'W nu + nu'om.
+// Stage map: x+ = x + a*theta + Bx u + f dt + c with a = (a0, a1, 0)  (forward differences: only the theta
+// column of df/dx is non-zero for every model), next u-state = u_k, dt+ = dt.
+// Stage cost = Lagrangian curvature of lam'(dt f) + objective + condensed barrier terms of the control box and
+// of the (linear) control-rate rows; the previous control enters only through the rate rows, so all of its
+// blocks are diagonal and never formed as dense matrices.  ~280 FMAs (the dense 6+2 version needs >600).
+template <typename T>
+struct StageRec {
+    T a0, a1;          // dt * d f_{0,1} / d theta
+    T f[3];            // f(x_k, u_k)
+    T B[3][2];         // dt * d f / d u
+    T c[3];            // collocation residual c_k
+    T h00, h01, h02, h11, h12, h22;   // dt * sum_a lam_a d2 f_a / d(theta,v,w)^2
+    T g[3];            // sum_a lam_a d f_a / d(theta,v,w)   (cross terms with dt)
+    T sz[2];           // Sigma of the control box
+    T gb[2];           // barrier (+ quadratic objective) gradient wrt u
+    T ss[2], sl[2], sll;   // rate rows: sum sigma, sum sigma*lim, sum sigma*lim^2
+    T gy[2], gyl;      // rate rows: sum sg*ybar, sum sg*lim*ybar
+    T hx[3];           // objective gradient wrt x_k
+};
+
+template <typename T>
+struct RicState {
+    T P[6][6], p[6], S[6][3], W[3][3], om[3];
+};
+
+template <typename T>
+struct StageGain {
+    T K[2][6], kap[2], Kn[2][3];
+};
+
+// q2 = 2*Q diag (0 for min-time), r2 = 2*R diag, dx = regularisation of x_k (0 at k = 0), du = regularisation of
+// u_k, add_dd / add_qd = dt-box + objective terms that live at stage 0.  Returns false on a singular pivot.
+template <typename T>
+MPC_HD bool riccati_step(RicState<T>& V, const StageRec<T>& r, const T q2[3], const T r2[2], T dx, T du, T add_dd, T add_qd,
+                         StageGain<T>& out) {
+    T (&P)[6][6] = V.P;
+    const T c0 = r.c[0], c1 = r.c[1], c2 = r.c[2];
+    T w[6];
+    for (int i = 0; i < 6; ++i) w[i] = V.p[i] + P[i][0] * c0 + P[i][1] * c1 + P[i][2] * c2;
+    for (int b = 0; b < 3; ++b) V.om[b] += V.S[0][b] * c0 + V.S[1][b] * c1 + V.S[2][b] * c2;
+    T E[3][2], e[3], Pa[3];
+    for (int i = 0; i < 3; ++i) {
+        for (int j = 0; j < 2; ++j) E[i][j] = P[i][0] * r.B[0][j] + P[i][1] * r.B[1][j] + P[i][2] * r.B[2][j] + P[i][3 + j];
+        e[i] = P[i][0] * r.f[0] + P[i][1] * r.f[1] + P[i][2] * r.f[2] + P[i][5];
+        Pa[i] = P[i][0] * r.a0 + P[i][1] * r.a1;
+    }
+    // Q~ over x (symmetric), cross x-d, d-d
+    T Q00 = P[0][0] + dx + q2[0], Q01 = P[0][1], Q11 = P[1][1] + dx + q2[1];
+    T Q02 = P[0][2] + Pa[0], Q12 = P[1][2] + Pa[1];
+    T Q22 = P[2][2] + T(2) * Pa[2] + r.a0 * Pa[0] + r.a1 * Pa[1] + dx + q2[2] + r.h00;
+    T qd0 = e[0], qd1 = e[1], qd2 = e[2] + r.a0 * e[0] + r.a1 * e[1] + r.g[0];
+    T Qdd = r.f[0] * (e[0] + P[0][5]) + r.f[1] * (e[1] + P[1][5]) + r.f[2] * (e[2] + P[2][5]) + P[5][5] + r.sll + add_dd;
+    // M~ (u rows): x columns, d column; the u_{k-1} columns are -diag(ss)
+    T Mx[2][3], Md[2];
+    for (int j = 0; j < 2; ++j) {
+        Mx[j][0] = E[0][j];
+        Mx[j][1] = E[1][j];
+        Mx[j][2] = E[2][j] + r.a0 * E[0][j] + r.a1 * E[1][j];
+        Md[j] = r.B[0][j] * e[0] + r.B[1][j] * e[1] + r.B[2][j] * e[2] + P[0][3 + j] * r.f[0] + P[1][3 + j] * r.f[1] + P[2][3 + j] * r.f[2]
+              + P[3 + j][5] + r.g[1 + j] - r.sl[j];
+    }
+    Mx[0][2] += r.h01;
+    Mx[1][2] += r.h02;
+    // R~
+    T R00 = r.B[0][0] * E[0][0] + r.B[1][0] * E[1][0] + r.B[2][0] * E[2][0] + P[0][3] * r.B[0][0] + P[1][3] * r.B[1][0] + P[2][3] * r.B[2][0]
+          + P[3][3] + r.h11 + r.sz[0] + du + r.ss[0] + r2[0];
+    T R01 = r.B[0][0] * E[0][1] + r.B[1][0] * E[1][1] + r.B[2][0] * E[2][1] + P[0][3] * r.B[0][1] + P[1][3] * r.B[1][1] + P[2][3] * r.B[2][1]
+          + P[3][4] + r.h12;
+    T R11 = r.B[0][1] * E[0][1] + r.B[1][1] * E[1][1] + r.B[2][1] * E[2][1] + P[0][4] * r.B[0][1] + P[1][4] * r.B[1][1] + P[2][4] * r.B[2][1]
+          + P[4][4] + r.h22 + r.sz[1] + du + r.ss[1] + r2[1];
+    // gradients
+    T qx0 = w[0] + r.hx[0], qx1 = w[1] + r.hx[1], qx2 = w[2] + r.a0 * w[0] + r.a1 * w[1] + r.hx[2];
+    T ru[2];
+    for (int j = 0; j < 2; ++j) ru[j] = r.B[0][j] * w[0] + r.B[1][j] * w[1] + r.B[2][j] * w[2] + w[3 + j] + r.gb[j] + r.gy[j];
+    T qdd = r.f[0] * w[0] + r.f[1] * w[1] + r.f[2] * w[2] + w[5] - r.gyl + add_qd;
+    // nu columns
+    T Sx2[3], Su[2][3], Sd[3];
+    for (int b = 0; b < 3; ++b) {
+        Sx2[b] = V.S[2][b] + r.a0 * V.S[0][b] + r.a1 * V.S[1][b];
+        for (int j = 0; j < 2; ++j) Su[j][b] = r.B[0][j] * V.S[0][b] + r.B[1][j] * V.S[1][b] + r.B[2][j] * V.S[2][b] + V.S[3 + j][b];
+        Sd[b] = r.f[0] * V.S[0][b] + r.f[1] * V.S[1][b] + r.f[2] * V.S[2][b] + V.S[5][b];
+    }
+    // eliminate u_k
+    T det = R00 * R11 - R01 * R01;
+    T scale = t_abs(R00 * R11) + R01 * R01;
+    if (!(t_abs(det) > T(1e-14) * scale) || !t_finite(det)) return false;
+    T id = T(1) / det;
+    T Ri00 = R11 * id, Ri01 = -R01 * id, Ri11 = R00 * id;
+    T (&K)[2][6] = out.K;
+    for (int i = 0; i < 3; ++i) {
+        K[0][i] = Ri00 * Mx[0][i] + Ri01 * Mx[1][i];
+        K[1][i] = Ri01 * Mx[0][i] + Ri11 * Mx[1][i];
+    }
+    K[0][3] = -Ri00 * r.ss[0]; K[0][4] = -Ri01 * r.ss[1];
+    K[1][3] = -Ri01 * r.ss[0]; K[1][4] = -Ri11 * r.ss[1];
+    K[0][5] = Ri00 * Md[0] + Ri01 * Md[1];
+    K[1][5] = Ri01 * Md[0] + Ri11 * Md[1];
+    out.kap[0] = Ri00 * ru[0] + Ri01 * ru[1];
+    out.kap[1] = Ri01 * ru[0] + Ri11 * ru[1];
+    for (int b = 0; b < 3; ++b) {
+        out.Kn[0][b] = Ri00 * Su[0][b] + Ri01 * Su[1][b];
+        out.Kn[1][b] = Ri01 * Su[0][b] + Ri11 * Su[1][b];
+    }
+    // new value function (before overwriting: S rows 0,1 are still needed -> done via temporaries above)
+    const T Qx[3][3] = {{Q00, Q01, Q02}, {Q01, Q11, Q12}, {Q02, Q12, Q22}};
+    const T qd[3] = {qd0, qd1, qd2};
+    const T qx[3] = {qx0, qx1, qx2};
+    T Sx0[3], Sx1[3];
+    for (int b = 0; b < 3; ++b) { Sx0[b] = V.S[0][b]; Sx1[b] = V.S[1][b]; }
+    for (int i = 0; i < 3; ++i) {
+        for (int l = i; l < 3; ++l) { T v = Qx[i][l] - (Mx[0][i] * K[0][l] + Mx[1][i] * K[1][l]); P[i][l] = v; P[l][i] = v; }
+        for (int l = 0; l < 2; ++l) { T v = -(Mx[0][i] * K[0][3 + l] + Mx[1][i] * K[1][3 + l]); P[i][3 + l] = v; P[3 + l][i] = v; }
+        { T v = qd[i] - (Mx[0][i] * K[0][5] + Mx[1][i] * K[1][5]); P[i][5] = v; P[5][i] = v; }
+        V.p[i] = qx[i] - (Mx[0][i] * out.kap[0] + Mx[1][i] * out.kap[1]);
+        for (int b = 0; b < 3; ++b) {
+            T sx = i == 0 ? Sx0[b] : (i == 1 ? Sx1[b] : Sx2[b]);
+            V.S[i][b] = sx - (Mx[0][i] * out.Kn[0][b] + Mx[1][i] * out.Kn[1][b]);
+        }
+    }
+    // u_{k-1} block: M~[a][up_j] = -ss_j delta_aj
+    P[3][3] = r.ss[0] + r.ss[0] * K[0][3];
+    P[3][4] = r.ss[0] * K[0][4]; P[4][3] = P[3][4];
+    P[4][4] = r.ss[1] + r.ss[1] * K[1][4];
+    P[3][5] = r.sl[0] + r.ss[0] * K[0][5]; P[5][3] = P[3][5];
+    P[4][5] = r.sl[1] + r.ss[1] * K[1][5]; P[5][4] = P[4][5];
+    P[5][5] = Qdd - (Md[0] * K[0][5] + Md[1] * K[1][5]);
+    V.p[3] = -r.gy[0] + r.ss[0] * out.kap[0];
+    V.p[4] = -r.gy[1] + r.ss[1] * out.kap[1];
+    V.p[5] = qdd - (Md[0] * out.kap[0] + Md[1] * out.kap[1]);
+    for (int b = 0; b < 3; ++b) {
+        V.S[3][b] = r.ss[0] * out.Kn[0][b];
+        V.S[4][b] = r.ss[1] * out.Kn[1][b];
+        V.S[5][b] = Sd[b] - (Md[0] * out.Kn[0][b] + Md[1] * out.Kn[1][b]);
+    }
+    for (int a = 0; a < 3; ++a) {
+        for (int b = 0; b < 3; ++b) V.W[a][b] -= Su[0][a] * out.Kn[0][b] + Su[1][a] * out.Kn[1][b];
+        V.om[a] -= Su[0][a] * out.kap[0] + Su[1][a] * out.kap[1];
+    }
+    return true;
+}
+
+// terminal value function and the final 4x4 solve, shared by both kernels
+template <typename T>
+MPC_HD void riccati_terminal(RicState<T>& V, const Problem<T>& P_, const T xd_f[3], T delta, T dc, const T ss[2], const T sl[2], T sll,
+                             const T gy[2], T gyl) {
+    for (int a = 0; a < 6; ++a) { V.p[a] = T(0); for (int b = 0; b < 6; ++b) V.P[a][b] = T(0); for (int b = 0; b < 3; ++b) V.S[a][b] = T(0); }
+    for (int a = 0; a < 3; ++a) { V.om[a] = T(0); for (int b = 0; b < 3; ++b) V.W[a][b] = T(0); }
+    for (int i = 0; i < 3; ++i) {
+        if (P_.xf_fixed[i]) { V.S[i][i] = T(1); V.W[i][i] = -dc; }
+        else {
+            V.P[i][i] = delta;
+            if (P_.objective == OBJ_QUADRATIC && P_.has_Qf) { V.P[i][i] += T(2) * P_.Qf[i]; V.p[i] = T(2) * P_.Qf[i] * xd_f[i]; }
+        }
+    }
+    for (int j = 0; j < 2; ++j) {      // final rate rows: a over (up_j, d) = (-sg, -sg*lim)
+        V.P[3 + j][3 + j] += ss[j];
+        V.P[3 + j][5] += sl[j]; V.P[5][3 + j] += sl[j];
+        V.p[3 + j] -= gy[j];
+    }
+    V.P[5][5] += sll;
+    V.p[5] -= gyl;
+}
+
+template <typename T>
+MPC_HD bool riccati_root(const RicState<T>& V, const Problem<T>& P_, T& dd_out, T nu_out[3]) {
+    T A4[4][5];
+    for (int a = 0; a < 4; ++a) for (int b = 0; b < 5; ++b) A4[a][b] = T(0);
+    if (P_.dt_free) {
+        A4[0][0] = V.P[5][5];
+        for (int b = 0; b < 3; ++b) A4[0][1 + b] = P_.xf_fixed[b] ? V.S[5][b] : T(0);
+        A4[0][4] = -V.p[5];
+    } else { A4[0][0] = T(1); }
+    for (int a = 0; a < 3; ++a) {
+        if (P_.xf_fixed[a]) {
+            A4[1 + a][0] = P_.dt_free ? V.S[5][a] : T(0);
+            for (int b = 0; b < 3; ++b) A4[1 + a][1 + b] = P_.xf_fixed[b] ? V.W[a][b] : T(0);
+            A4[1 + a][4] = -V.om[a];
+        } else { A4[1 + a][1 + a] = T(1); }
+    }
+    for (int c = 0; c < 4; ++c) {
+        int piv = c; T best = t_abs(A4[c][c]);
+        for (int r = c + 1; r < 4; ++r) if (t_abs(A4[r][c]) > best) { best = t_abs(A4[r][c]); piv = r; }
+        if (!(best > T(0)) || !t_finite(best)) return false;
+        if (piv != c) for (int b = 0; b < 5; ++b) { T t = A4[c][b]; A4[c][b] = A4[piv][b]; A4[piv][b] = t; }
+        T ip = T(1) / A4[c][c];
+        for (int r = c + 1; r < 4; ++r) {
+            T m = A4[r][c] * ip;
+            for (int b = c; b < 5; ++b) A4[r][b] -= m * A4[c][b];
+        }
+    }
+    T sol[4];
+    for (int c = 3; c >= 0; --c) {
+        T a = A4[c][4];
+        for (int b = c + 1; b < 4; ++b) a -= A4[c][b] * sol[b];
+        sol[c] = a / A4[c][c];
+    }
+    dd_out = sol[0];
+    nu_out[0] = sol[1]; nu_out[1] = sol[2]; nu_out[2] = sol[3];
+    return t_finite(sol[0]) && t_finite(sol[1]) && t_finite(sol[2]) && t_finite(sol[3]);
+}
+
 // rate-row slot helpers: q in 0..3 -> component j, sign sg
 MPC_HD int slot_comp(int q) { return q & 1; }
 template <typename T> MPC_HD T slot_sign(int q) { return q < 2 ? T(-1) : T(1); }
@@ -270,8 +475,8 @@ struct SolveStats {
 
 template <typename T, int MODEL>
 struct Ipm {
-    const Problem<T>& P;
-    const Layout& L;
+    const Problem<T>& P;     // on the GPU this refers to a copy in LDS (see the kernels): uniform values read by
+    const Layout& L;         // broadcast ds_read instead of occupying (and spilling) scalar registers
     Mem<T> M;
     // per-instance inputs
     T x0[3], xf[3], uprev[2], dtprev;
@@ -572,244 +777,80 @@ struct Ipm {
     MPC_HD bool backward(T delta, T dc, T& dd_out, T nu_out[3]) const {
         const int n = L.n;
         const T d = M.ld(L.D);
-        T Pm[6][6], pv[6], S[6][3], W[3][3], om[3];
-        for (int a = 0; a < 6; ++a) { pv[a] = T(0); for (int b = 0; b < 6; ++b) Pm[a][b] = T(0); for (int b = 0; b < 3; ++b) S[a][b] = T(0); }
-        for (int a = 0; a < 3; ++a) { om[a] = T(0); for (int b = 0; b < 3; ++b) W[a][b] = T(0); }
-        // ---- terminal stage: xi = (x_{n-1}, u_{n-2}, dt)
-        for (int i = 0; i < 3; ++i) {
-            if (P.xf_fixed[i]) { S[i][i] = T(1); W[i][i] = -dc; }
-            else {
-                Pm[i][i] = delta;
-                if (P.objective == OBJ_QUADRATIC && P.has_Qf) {
-                    T xd = X(L.X, n - 1, i) - xf[i];
-                    if (i == 2) xd = normalize_theta(xd);
-                    Pm[i][i] += T(2) * P.Qf[i];
-                    pv[i] = T(2) * P.Qf[i] * xd;
-                }
-            }
+        RicState<T> V;
+        T q2[3] = {T(0), T(0), T(0)}, r2[2] = {T(0), T(0)};
+        if (P.objective == OBJ_QUADRATIC) { for (int i = 0; i < 3; ++i) q2[i] = T(2) * P.Q[i]; for (int j = 0; j < 2; ++j) r2[j] = T(2) * P.R[j]; }
+        {   // terminal stage: xi = (x_{n-1}, u_{n-2}, dt); final rate rows against u_ref = 0
+            T xd[3] = {X(L.X, n - 1, 0) - xf[0], X(L.X, n - 1, 1) - xf[1], normalize_theta(X(L.X, n - 1, 2) - xf[2])};
+            T ss[2] = {T(0), T(0)}, sl[2] = {T(0), T(0)}, sll = T(0), gy[2] = {T(0), T(0)}, gyl = T(0);
+            rate_terms(n - 1, d, ss, sl, sll, gy, gyl);
+            riccati_terminal(V, P, xd, delta, dc, ss, sl, sll, gy, gyl);
         }
-        for (int q = 0; q < 4; ++q) {
-            const int r = n - 1;
-            if (!row_on(r, q)) continue;
-            const int j = slot_comp(q);
-            const T sg = slot_sign<T>(q), lim = P.rate_lim[q];
-            T s = M.ld(L.SR + 4 * r + q), y = M.ld(L.YR + 4 * r + q);
-            T sig = y / s;
-            T ybar = mu / s + sig * (row_val(r, q) + s);
-            // a over (up_j, d) = (-sg, -sg*lim)
-            Pm[3 + j][3 + j] += sig;
-            Pm[3 + j][5] += sig * lim; Pm[5][3 + j] += sig * lim;
-            Pm[5][5] += sig * lim * lim;
-            pv[3 + j] += -sg * ybar;
-            pv[5] += -sg * lim * ybar;
-        }
-        // ---- stages n-2 .. 0
         for (int k = n - 2; k >= 0; --k) {
             T lam[3] = {M.ld(L.LAM + 3 * k), M.ld(L.LAM + 3 * k + 1), M.ld(L.LAM + 3 * k + 2)};
             T tr[4] = {M.ld(L.TRIG + 4 * k), M.ld(L.TRIG + 4 * k + 1), M.ld(L.TRIG + 4 * k + 2), M.ld(L.TRIG + 4 * k + 3)};
-            T ck[3] = {M.ld(L.CC + 3 * k), M.ld(L.CC + 3 * k + 1), M.ld(L.CC + 3 * k + 2)};
             T v = U(L.U, k, 0), w = U(L.U, k, 1);
             T f[3], G[3][3], Hq[3][3];
             model_derivs<T, MODEL>(P, tr, v, w, lam, f, G, Hq);
-            // store next-stage value rows needed for lambda_k in the forward sweep
+            // value rows of stage k+1 needed for lambda_k in the forward sweep
             {
                 const int gb = L.GAIN + 50 * k + 20;
-                for (int a = 0; a < 3; ++a) for (int b = 0; b < 6; ++b) M.st(gb + 6 * a + b, Pm[a][b]);
-                for (int a = 0; a < 3; ++a) M.st(gb + 18 + a, pv[a]);
-                for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) M.st(gb + 21 + 3 * a + b, S[a][b]);
+                for (int a = 0; a < 3; ++a) for (int b = 0; b < 6; ++b) M.st(gb + 6 * a + b, V.P[a][b]);
+                for (int a = 0; a < 3; ++a) M.st(gb + 18 + a, V.p[a]);
+                for (int a = 0; a < 3; ++a) for (int b = 0; b < 3; ++b) M.st(gb + 21 + 3 * a + b, V.S[a][b]);
             }
-            // ptilde = p+ + P+[:,0:3] c ;  omega += S+[0:3,:]^T c
-            T pt[6];
-            for (int a = 0; a < 6; ++a) pt[a] = pv[a] + Pm[a][0] * ck[0] + Pm[a][1] * ck[1] + Pm[a][2] * ck[2];
-            for (int b = 0; b < 3; ++b) om[b] += S[0][b] * ck[0] + S[1][b] * ck[1] + S[2][b] * ck[2];
-            // Gx = [Ax | f] (3x4), Ax = I + d * G[:,0] e_theta^T ; Bx = d * G[:,1:3]
-            T Gx[3][4], Bx[3][2];
-            for (int a = 0; a < 3; ++a) {
-                Gx[a][0] = a == 0 ? T(1) : T(0);
-                Gx[a][1] = a == 1 ? T(1) : T(0);
-                Gx[a][2] = (a == 2 ? T(1) : T(0)) + d * G[a][0];
-                Gx[a][3] = f[a];
-                Bx[a][0] = d * G[a][1];
-                Bx[a][1] = d * G[a][2];
-            }
-            // Z = P+ G (6x4), Y = P+ Gam (6x2)
-            T Z[6][4], Y[6][2];
-            for (int a = 0; a < 6; ++a) {
-                for (int c4 = 0; c4 < 4; ++c4) {
-                    T z = Pm[a][0] * Gx[0][c4] + Pm[a][1] * Gx[1][c4] + Pm[a][2] * Gx[2][c4];
-                    if (c4 == 3) z += Pm[a][5];
-                    Z[a][c4] = z;
-                }
-                for (int c2 = 0; c2 < 2; ++c2)
-                    Y[a][c2] = Pm[a][0] * Bx[0][c2] + Pm[a][1] * Bx[1][c2] + Pm[a][2] * Bx[2][c2] + Pm[a][3 + c2];
-            }
-            // Qt (6x6) over (x, up, d); index map of the 4 active columns: 0,1,2,5
-            const int im[4] = {0, 1, 2, 5};
-            T Qt[6][6], Mt[2][6], Rt[2][2], qt[6], rt[2], Sx[6][3], Su[2][3];
-            for (int a = 0; a < 6; ++a) { qt[a] = T(0); for (int b = 0; b < 6; ++b) Qt[a][b] = T(0); for (int b = 0; b < 3; ++b) Sx[a][b] = T(0); }
-            for (int a = 0; a < 2; ++a) for (int b = 0; b < 6; ++b) Mt[a][b] = T(0);
-            for (int r4 = 0; r4 < 4; ++r4) {
-                for (int c4 = 0; c4 < 4; ++c4) {
-                    T z = Gx[0][r4] * Z[0][c4] + Gx[1][r4] * Z[1][c4] + Gx[2][r4] * Z[2][c4];
-                    if (r4 == 3) z += Z[5][c4];
-                    Qt[im[r4]][im[c4]] = z;
-                }
-                T g = Gx[0][r4] * pt[0] + Gx[1][r4] * pt[1] + Gx[2][r4] * pt[2];
-                if (r4 == 3) g += pt[5];
-                qt[im[r4]] = g;
-                for (int b = 0; b < 3; ++b) {
-                    T sgs = Gx[0][r4] * S[0][b] + Gx[1][r4] * S[1][b] + Gx[2][r4] * S[2][b];
-                    if (r4 == 3) sgs += S[5][b];
-                    Sx[im[r4]][b] = sgs;
-                }
-            }
-            for (int a = 0; a < 2; ++a) {
-                for (int c4 = 0; c4 < 4; ++c4)
-                    Mt[a][im[c4]] = Bx[0][a] * Z[0][c4] + Bx[1][a] * Z[1][c4] + Bx[2][a] * Z[2][c4] + Z[3 + a][c4];
-                for (int b = 0; b < 2; ++b)
-                    Rt[a][b] = Bx[0][a] * Y[0][b] + Bx[1][a] * Y[1][b] + Bx[2][a] * Y[2][b] + Y[3 + a][b];
-                rt[a] = Bx[0][a] * pt[0] + Bx[1][a] * pt[1] + Bx[2][a] * pt[2] + pt[3 + a];
-                for (int b = 0; b < 3; ++b)
-                    Su[a][b] = Bx[0][a] * S[0][b] + Bx[1][a] * S[1][b] + Bx[2][a] * S[2][b] + S[3 + a][b];
-            }
-            // ---- add the stage cost (Lagrangian curvature + condensed barrier terms)
-            // (i) curvature of lam^T (d f)
-            Qt[2][2] += d * Hq[0][0];
-            Mt[0][2] += d * Hq[0][1]; Mt[1][2] += d * Hq[0][2];
-            Rt[0][0] += d * Hq[1][1]; Rt[0][1] += d * Hq[1][2]; Rt[1][0] += d * Hq[1][2]; Rt[1][1] += d * Hq[2][2];
-            {
-                T gq0 = lam[0] * G[0][0] + lam[1] * G[1][0] + lam[2] * G[2][0];
-                T gq1 = lam[0] * G[0][1] + lam[1] * G[1][1] + lam[2] * G[2][1];
-                T gq2 = lam[0] * G[0][2] + lam[1] * G[1][2] + lam[2] * G[2][2];
-                Qt[2][5] += gq0; Qt[5][2] += gq0;
-                Mt[0][5] += gq1; Mt[1][5] += gq2;
-            }
-            // (ii) objective
-            if (P.objective == OBJ_QUADRATIC) {
-                T w8 = P.integral_form ? d : T(1);
-                T xd[3] = {X(L.X, k, 0) - xf[0], X(L.X, k, 1) - xf[1], normalize_theta(X(L.X, k, 2) - xf[2])};
-                T uu[2] = {v, w};
-                T sc = T(0);
-                for (int i = 0; i < 3; ++i) {
-                    Qt[i][i] += T(2) * P.Q[i] * w8;
-                    qt[i] += T(2) * P.Q[i] * xd[i] * w8;
-                    sc += P.Q[i] * xd[i] * xd[i];
-                    if (P.integral_form) { Qt[i][5] += T(2) * P.Q[i] * xd[i]; Qt[5][i] += T(2) * P.Q[i] * xd[i]; }
-                }
-                for (int j = 0; j < 2; ++j) {
-                    Rt[j][j] += T(2) * P.R[j] * w8;
-                    rt[j] += T(2) * P.R[j] * uu[j] * w8;
-                    sc += P.R[j] * uu[j] * uu[j];
-                    if (P.integral_form) Mt[j][5] += T(2) * P.R[j] * uu[j];
-                }
-                if (P.integral_form) qt[5] += sc;
-            } else if (k == 0) {
-                qt[5] += T(n - 1);
-            }
-            // (iii) control box
+            StageRec<T> r;
+            r.a0 = d * G[0][0]; r.a1 = d * G[1][0];
+            for (int a = 0; a < 3; ++a) { r.f[a] = f[a]; r.B[a][0] = d * G[a][1]; r.B[a][1] = d * G[a][2]; r.c[a] = M.ld(L.CC + 3 * k + a); }
+            r.h00 = d * Hq[0][0]; r.h01 = d * Hq[0][1]; r.h02 = d * Hq[0][2]; r.h11 = d * Hq[1][1]; r.h12 = d * Hq[1][2]; r.h22 = d * Hq[2][2];
+            for (int j = 0; j < 3; ++j) r.g[j] = lam[0] * G[0][j] + lam[1] * G[1][j] + lam[2] * G[2][j];
             for (int j = 0; j < 2; ++j) {
                 T u = j == 0 ? v : w;
                 T dl = u - P.u_lb[j], du = P.u_ub[j] - u;
-                T pl = M.ld(L.PL + 2 * k + j), pu = M.ld(L.PU + 2 * k + j);
-                Rt[j][j] += pl / dl + pu / du + delta;
-                rt[j] += -mu / dl + mu / du;
+                r.sz[j] = M.ld(L.PL + 2 * k + j) / dl + M.ld(L.PU + 2 * k + j) / du;
+                r.gb[j] = -mu / dl + mu / du + r2[j] * u;
             }
-            // dt box + regularisation of dt (once, at stage 0)
-            if (k == 0 && P.dt_free) {
-                T dl = d - P.dt_lb, du = P.dt_ub - d;
-                Qt[5][5] += M.ld(L.PD) / dl + M.ld(L.PD + 1) / du + delta;
-                qt[5] += -mu / dl + mu / du;
+            r.ss[0] = r.ss[1] = r.sl[0] = r.sl[1] = r.sll = r.gy[0] = r.gy[1] = r.gyl = T(0);
+            rate_terms(k, d, r.ss, r.sl, r.sll, r.gy, r.gyl);
+            for (int i = 0; i < 3; ++i) r.hx[i] = T(0);
+            if (P.objective == OBJ_QUADRATIC) {
+                T xd[3] = {X(L.X, k, 0) - xf[0], X(L.X, k, 1) - xf[1], normalize_theta(X(L.X, k, 2) - xf[2])};
+                for (int i = 0; i < 3; ++i) r.hx[i] = q2[i] * xd[i];
             }
-            // (vii) regularisation of x_k
-            if (k >= 1) { Qt[0][0] += delta; Qt[1][1] += delta; Qt[2][2] += delta; }
-            // (iv) rate rows of stage k
-            for (int q = 0; q < 4; ++q) {
-                if (!row_on(k, q)) continue;
-                const int j = slot_comp(q);
-                const T sg = slot_sign<T>(q);
-                const T lim = k > 0 ? P.rate_lim[q] : T(0);   // k = 0: dt_prev is a constant
-                T s = M.ld(L.SR + 4 * k + q), y = M.ld(L.YR + 4 * k + q);
-                T sig = y / s;
-                T um = k > 0 ? U(L.U, k - 1, j) : uprev[j];
-                T ur = j == 0 ? v : w;
-                T ybar = mu / s + sig * (rate_g(k, q, ur, um, d) + s);
-                // a over (u_j, up_j, d) = (sg, -sg, -sg*lim)
-                Rt[j][j] += sig;
-                Mt[j][3 + j] += -sig;
-                Mt[j][5] += -sig * lim;
-                Qt[3 + j][3 + j] += sig;
-                Qt[3 + j][5] += sig * lim; Qt[5][3 + j] += sig * lim;
-                Qt[5][5] += sig * lim * lim;
-                rt[j] += sg * ybar;
-                qt[3 + j] += -sg * ybar;
-                qt[5] += -sg * lim * ybar;
+            T add_dd = T(0), add_qd = T(0);
+            if (k == 0) {
+                if (P.objective == OBJ_MIN_TIME) add_qd += T(n - 1);
+                if (P.dt_free) {
+                    T dl = d - P.dt_lb, du = P.dt_ub - d;
+                    add_dd = M.ld(L.PD) / dl + M.ld(L.PD + 1) / du + delta;
+                    add_qd += -mu / dl + mu / du;
+                }
             }
-            // ---- eliminate u_k
-            T det = Rt[0][0] * Rt[1][1] - Rt[0][1] * Rt[1][0];
-            T scale = t_abs(Rt[0][0] * Rt[1][1]) + t_abs(Rt[0][1] * Rt[1][0]);
-            if (!(t_abs(det) > T(1e-14) * scale) || !t_finite(det)) return false;
-            T id = T(1) / det;
-            T Ri[2][2] = {{Rt[1][1] * id, -Rt[0][1] * id}, {-Rt[1][0] * id, Rt[0][0] * id}};
-            T K[2][6], kap[2], Kn[2][3];
-            for (int a = 0; a < 2; ++a) {
-                for (int b = 0; b < 6; ++b) K[a][b] = Ri[a][0] * Mt[0][b] + Ri[a][1] * Mt[1][b];
-                kap[a] = Ri[a][0] * rt[0] + Ri[a][1] * rt[1];
-                for (int b = 0; b < 3; ++b) Kn[a][b] = Ri[a][0] * Su[0][b] + Ri[a][1] * Su[1][b];
-            }
-            {
-                const int gb = L.GAIN + 50 * k;
-                for (int a = 0; a < 2; ++a) for (int b = 0; b < 6; ++b) M.st(gb + 6 * a + b, K[a][b]);
-                M.st(gb + 12, kap[0]); M.st(gb + 13, kap[1]);
-                for (int a = 0; a < 2; ++a) for (int b = 0; b < 3; ++b) M.st(gb + 14 + 3 * a + b, Kn[a][b]);
-            }
-            for (int a = 0; a < 6; ++a) {
-                for (int b = 0; b < 6; ++b) Pm[a][b] = Qt[a][b] - (Mt[0][a] * K[0][b] + Mt[1][a] * K[1][b]);
-                pv[a] = qt[a] - (Mt[0][a] * kap[0] + Mt[1][a] * kap[1]);
-                for (int b = 0; b < 3; ++b) S[a][b] = Sx[a][b] - (Mt[0][a] * Kn[0][b] + Mt[1][a] * Kn[1][b]);
-            }
-            for (int a = 0; a < 3; ++a) {
-                for (int b = 0; b < 3; ++b) W[a][b] -= Su[0][a] * Kn[0][b] + Su[1][a] * Kn[1][b];
-                om[a] -= Su[0][a] * kap[0] + Su[1][a] * kap[1];
-            }
-            // symmetrise P (round-off hygiene)
-            for (int a = 0; a < 6; ++a) for (int b = a + 1; b < 6; ++b) { T m = T(0.5) * (Pm[a][b] + Pm[b][a]); Pm[a][b] = m; Pm[b][a] = m; }
+            StageGain<T> g;
+            if (!riccati_step(V, r, q2, r2, k >= 1 ? delta : T(0), delta, add_dd, add_qd, g)) return false;
+            const int gb = L.GAIN + 50 * k;
+            for (int a = 0; a < 2; ++a) for (int b = 0; b < 6; ++b) M.st(gb + 6 * a + b, g.K[a][b]);
+            M.st(gb + 12, g.kap[0]); M.st(gb + 13, g.kap[1]);
+            for (int a = 0; a < 2; ++a) for (int b = 0; b < 3; ++b) M.st(gb + 14 + 3 * a + b, g.Kn[a][b]);
         }
-        // ---- stage 0: only d (if free) and nu are unknown
-        T A4[4][5];
-        for (int a = 0; a < 4; ++a) for (int b = 0; b < 5; ++b) A4[a][b] = T(0);
-        if (P.dt_free) {
-            A4[0][0] = Pm[5][5];
-            for (int b = 0; b < 3; ++b) { A4[0][1 + b] = P.xf_fixed[b] ? S[5][b] : T(0); }
-            A4[0][4] = -pv[5];
-        } else { A4[0][0] = T(1); }
-        for (int a = 0; a < 3; ++a) {
-            if (P.xf_fixed[a]) {
-                A4[1 + a][0] = P.dt_free ? S[5][a] : T(0);
-                for (int b = 0; b < 3; ++b) A4[1 + a][1 + b] = P.xf_fixed[b] ? W[a][b] : T(0);
-                A4[1 + a][4] = -om[a];
-            } else { A4[1 + a][1 + a] = T(1); }
+        return riccati_root(V, P, dd_out, nu_out);
+    }
+
+    // condensed barrier terms of the rate rows of index r (lim = 0 for r = 0: dt_prev is a constant there)
+    MPC_HD void rate_terms(int r, T d, T ss[2], T sl[2], T& sll, T gy[2], T& gyl) const {
+        const int n = L.n;
+        for (int q = 0; q < 4; ++q) {
+            if (!row_on(r, q)) continue;
+            const int j = slot_comp(q);
+            const T sg = slot_sign<T>(q), lim = r > 0 ? P.rate_lim[q] : T(0);
+            T s = M.ld(L.SR + 4 * r + q), y = M.ld(L.YR + 4 * r + q);
+            T sig = y / s;
+            T ur = r < n - 1 ? U(L.U, r, j) : T(0);
+            T um = r > 0 ? U(L.U, r - 1, j) : uprev[j];
+            T ybar = mu / s + sig * (rate_g(r, q, ur, um, d) + s);
+            ss[j] += sig; sl[j] += sig * lim; sll += sig * lim * lim;
+            gy[j] += sg * ybar; gyl += sg * lim * ybar;
         }
-        // Gaussian elimination with partial pivoting (4x4)
-        for (int c = 0; c < 4; ++c) {
-            int piv = c; T best = t_abs(A4[c][c]);
-            for (int r = c + 1; r < 4; ++r) if (t_abs(A4[r][c]) > best) { best = t_abs(A4[r][c]); piv = r; }
-            if (!(best > T(0)) || !t_finite(best)) return false;
-            if (piv != c) for (int b = 0; b < 5; ++b) { T t = A4[c][b]; A4[c][b] = A4[piv][b]; A4[piv][b] = t; }
-            T ip = T(1) / A4[c][c];
-            for (int r = c + 1; r < 4; ++r) {
-                T m = A4[r][c] * ip;
-                for (int b = c; b < 5; ++b) A4[r][b] -= m * A4[c][b];
-            }
-        }
-        T sol[4];
-        for (int c = 3; c >= 0; --c) {
-            T a = A4[c][4];
-            for (int b = c + 1; b < 4; ++b) a -= A4[c][b] * sol[b];
-            sol[c] = a / A4[c][c];
-        }
-        dd_out = sol[0];
-        nu_out[0] = sol[1]; nu_out[1] = sol[2]; nu_out[2] = sol[3];
-        return t_finite(sol[0]) && t_finite(sol[1]) && t_finite(sol[2]) && t_finite(sol[3]);
     }
 
     // ---------------------------------------------------------------- forward sweep

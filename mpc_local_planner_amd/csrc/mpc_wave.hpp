@@ -20,6 +20,10 @@
 
 #include "mpc_core.hpp"
 
+#ifdef MPC_PROFILE
+__device__ long long g_mpc_prof[4096][14];
+#endif
+
 namespace mpc {
 
 constexpr int kWave = 64;
@@ -28,7 +32,7 @@ constexpr int NGAIN = 20;  // K(2x6) kappa(2) Knu(2x3)
 
 struct WaveLayout {
     int n, NS;
-    int X, U, XT, UT, LAM, LAMN, SR, YR, PL, PU, DX, DU, CC, TRIG, GAIN, STG, SC, total;
+    int X, U, XT, UT, LAM, LAMN, SR, YR, PL, PU, DX, DU, CC, TRIG, GAIN, STG, SC, VP, ZC, total;
     __host__ __device__ static WaveLayout make(int n) {
         WaveLayout L;
         L.n = n;
@@ -43,6 +47,8 @@ struct WaveLayout {
         L.CC = take(3); L.TRIG = take(4);
         L.GAIN = take(NGAIN); L.STG = take(NSTG);
         L.SC = o; o += 8;     // scalars: D, DT, DD, PDL, PDU
+        L.VP = o; o += 36;    // value-function matrix P of the stage being eliminated (column-major), column-parallel sweep
+        L.ZC = o; o += 8;     // constants: 6 zeros, then 1.0
         L.total = o;
         return L;
     }
@@ -66,10 +72,20 @@ template <typename T> __device__ __forceinline__ T wave_max(T v) {
     return v;
 }
 
+__device__ __forceinline__ double lane_bcast(double v, int src) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, src);
+    hi = __builtin_amdgcn_readlane(hi, src);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ float lane_bcast(float v, int src) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
 template <typename T, int MODEL>
 struct IpmWave {
-    const Problem<T>& P;
-    const WaveLayout& L;
+    const Problem<T>& P;     // lives in LDS (copied once per workgroup): wave-uniform constants are fetched with
+    const WaveLayout& L;     // broadcast ds_reads instead of being pinned in (and spilled from) scalar registers
     T* sm;
     const int lane;
     T x0[3], xf[3], uprev[2], dtprev;
@@ -81,6 +97,10 @@ struct IpmWave {
 
     // ---- LDS accessors: component-major, stage-minor (conflict-free for lane == stage)
     __device__ __forceinline__ T& F(int base, int comp, int k) const { return sm[base + comp * L.NS + k]; }
+    // stage-major records (one base address + immediate offsets in the wave-uniform sweeps)
+    __device__ __forceinline__ T& G_(int i, int k) const { return sm[L.GAIN + k * NGAIN + i]; }
+    __device__ __forceinline__ T& S_(int i, int k) const { return sm[L.STG + k * NSTG + i]; }
+    __device__ __forceinline__ T& C_(int i, int k) const { return sm[L.CC + k * 3 + i]; }
     __device__ __forceinline__ T& SCL(int i) const { return sm[L.SC + i]; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
 
@@ -123,7 +143,7 @@ struct IpmWave {
             T c1 = d * f[1] - (xn[1] - xk[1]);
             T c2 = d * f[2] - normalize_theta(xn[2] - xk[2]);
             for (int i = 0; i < 4; ++i) F(L.TRIG, i, k) = tr[i];
-            F(L.CC, 0, k) = c0; F(L.CC, 1, k) = c1; F(L.CC, 2, k) = c2;
+            C_(0, k) = c0; C_(1, k) = c1; C_(2, k) = c2;
             th += t_abs(c0) + t_abs(c1) + t_abs(c2);
             if (P.objective == OBJ_QUADRATIC) {
                 T xd0 = xk[0] - xf[0], xd1 = xk[1] - xf[1], xd2 = normalize_theta(xk[2] - xf[2]);
@@ -189,14 +209,14 @@ struct IpmWave {
                 T gq[3];
                 for (int j = 0; j < 3; ++j) gq[j] = lam[0] * G[0][j] + lam[1] * G[1][j] + lam[2] * G[2][j];
                 // stage record, mu-independent part
-                F(L.STG, 0, k) = d * G[0][0]; F(L.STG, 1, k) = d * G[1][0];
-                F(L.STG, 2, k) = f[0]; F(L.STG, 3, k) = f[1]; F(L.STG, 4, k) = f[2];
-                for (int a = 0; a < 3; ++a) { F(L.STG, 5 + 2 * a, k) = d * G[a][1]; F(L.STG, 6 + 2 * a, k) = d * G[a][2]; }
-                F(L.STG, 11, k) = d * Hq[0][0]; F(L.STG, 12, k) = d * Hq[0][1]; F(L.STG, 13, k) = d * Hq[0][2];
-                F(L.STG, 14, k) = d * Hq[1][1]; F(L.STG, 15, k) = d * Hq[1][2]; F(L.STG, 16, k) = d * Hq[2][2];
-                F(L.STG, 17, k) = gq[0]; F(L.STG, 18, k) = gq[1]; F(L.STG, 19, k) = gq[2];
+                S_(0, k) = d * G[0][0]; S_(1, k) = d * G[1][0];
+                S_(2, k) = f[0]; S_(3, k) = f[1]; S_(4, k) = f[2];
+                for (int a = 0; a < 3; ++a) { S_(5 + 2 * a, k) = d * G[a][1]; S_(6 + 2 * a, k) = d * G[a][2]; }
+                S_(11, k) = d * Hq[0][0]; S_(12, k) = d * Hq[0][1]; S_(13, k) = d * Hq[0][2];
+                S_(14, k) = d * Hq[1][1]; S_(15, k) = d * Hq[1][2]; S_(16, k) = d * Hq[2][2];
+                S_(17, k) = gq[0]; S_(18, k) = gq[1]; S_(19, k) = gq[2];
                 for (int i = 0; i < 3; ++i) {
-                    T ci = F(L.CC, i, k);
+                    T ci = C_(i, k);
                     rp = t_max(rp, t_abs(ci)); th += t_abs(ci); smult += t_abs(lam[i]);
                 }
                 nm += 3;
@@ -207,7 +227,7 @@ struct IpmWave {
                     for (int i = 0; i < 3; ++i) gx[i] = T(2) * P.Q[i] * xd[i];
                     gu[0] = T(2) * P.R[0] * v; gu[1] = T(2) * P.R[1] * w;
                 }
-                F(L.STG, 32, k) = gx[0]; F(L.STG, 33, k) = gx[1]; F(L.STG, 34, k) = gx[2];
+                S_(32, k) = gx[0]; S_(33, k) = gx[1]; S_(34, k) = gx[2];
                 if (k >= 1) {
                     T r0 = gx[0] + lam[0] - F(L.LAM, 0, k - 1);
                     T r1 = gx[1] + lam[1] - F(L.LAM, 1, k - 1);
@@ -284,10 +304,10 @@ struct IpmWave {
                 for (int j = 0; j < 2; ++j) {
                     T u = F(L.U, j, k);
                     T dl = u - P.u_lb[j], du = P.u_ub[j] - u;
-                    F(L.STG, 20 + j, k) = F(L.PL, j, k) / dl + F(L.PU, j, k) / du;
+                    S_(20 + j, k) = F(L.PL, j, k) / dl + F(L.PU, j, k) / du;
                     T g = -mu / dl + mu / du;
                     if (P.objective == OBJ_QUADRATIC) g += T(2) * P.R[j] * u;
-                    F(L.STG, 22 + j, k) = g;
+                    S_(22 + j, k) = g;
                 }
             }
             T ss[2] = {T(0), T(0)}, ssl[2] = {T(0), T(0)}, sll = T(0), gy[2] = {T(0), T(0)}, gyl = T(0);
@@ -301,11 +321,11 @@ struct IpmWave {
                 ss[j] += sig; ssl[j] += sig * lim; sll += sig * lim * lim;
                 gy[j] += sg * ybar; gyl += sg * lim * ybar;
             }
-            F(L.STG, 24, k) = ss[0]; F(L.STG, 25, k) = ss[1];
-            F(L.STG, 26, k) = ssl[0]; F(L.STG, 27, k) = ssl[1];
-            F(L.STG, 28, k) = sll;
-            F(L.STG, 29, k) = gy[0]; F(L.STG, 30, k) = gy[1];
-            F(L.STG, 31, k) = gyl;
+            S_(24, k) = ss[0]; S_(25, k) = ss[1];
+            S_(26, k) = ssl[0]; S_(27, k) = ssl[1];
+            S_(28, k) = sll;
+            S_(29, k) = gy[0]; S_(30, k) = gy[1];
+            S_(31, k) = gyl;
         }
     }
 
@@ -313,180 +333,204 @@ struct IpmWave {
     __device__ bool backward(T delta, T dc, T& dd_out, T nu_out[3]) const {
         const int n = L.n;
         const T d = SCL(SC_D);
-        T Pm[6][6], pv[6], S[6][3], W[3][3], om[3];
-        for (int a = 0; a < 6; ++a) { pv[a] = T(0); for (int b = 0; b < 6; ++b) Pm[a][b] = T(0); for (int b = 0; b < 3; ++b) S[a][b] = T(0); }
-        for (int a = 0; a < 3; ++a) { om[a] = T(0); for (int b = 0; b < 3; ++b) W[a][b] = T(0); }
-        for (int i = 0; i < 3; ++i) {
-            if (P.xf_fixed[i]) { S[i][i] = T(1); W[i][i] = -dc; }
-            else {
-                Pm[i][i] = delta;
-                if (P.objective == OBJ_QUADRATIC && P.has_Qf) {
-                    T xd = F(L.X, i, n - 1) - xf[i];
-                    if (i == 2) xd = normalize_theta(xd);
-                    Pm[i][i] += T(2) * P.Qf[i];
-                    pv[i] = T(2) * P.Qf[i] * xd;
-                }
-            }
-        }
-        {   // final rate rows (record n-1): a over (up_j, d) = (-sg, -sg*lim)
+        RicState<T> V;
+        T q2[3] = {T(0), T(0), T(0)}, r2[2] = {T(0), T(0)};
+        if (P.objective == OBJ_QUADRATIC) { for (int i = 0; i < 3; ++i) q2[i] = T(2) * P.Q[i]; for (int j = 0; j < 2; ++j) r2[j] = T(2) * P.R[j]; }
+        {
             const int r = n - 1;
-            for (int j = 0; j < 2; ++j) {
-                T ssj = F(L.STG, 24 + j, r), sslj = F(L.STG, 26 + j, r);
-                Pm[3 + j][3 + j] += ssj;
-                Pm[3 + j][5] += sslj; Pm[5][3 + j] += sslj;
-                pv[3 + j] -= F(L.STG, 29 + j, r);
-            }
-            Pm[5][5] += F(L.STG, 28, r);
-            pv[5] -= F(L.STG, 31, r);
+            T xd[3] = {F(L.X, 0, r) - xf[0], F(L.X, 1, r) - xf[1], normalize_theta(F(L.X, 2, r) - xf[2])};
+            T ss[2] = {S_(24, r), S_(25, r)}, sl[2] = {S_(26, r), S_(27, r)};
+            T gy[2] = {S_(29, r), S_(30, r)};
+            riccati_terminal(V, P, xd, delta, dc, ss, sl, S_(28, r), gy, S_(31, r));
         }
         for (int k = n - 2; k >= 0; --k) {
-            T R_[NSTG];
-#pragma unroll
-            for (int i = 0; i < NSTG; ++i) R_[i] = F(L.STG, i, k);
-            T ck[3] = {F(L.CC, 0, k), F(L.CC, 1, k), F(L.CC, 2, k)};
-            T pt[6];
-            for (int a = 0; a < 6; ++a) pt[a] = pv[a] + Pm[a][0] * ck[0] + Pm[a][1] * ck[1] + Pm[a][2] * ck[2];
-            for (int b = 0; b < 3; ++b) om[b] += S[0][b] * ck[0] + S[1][b] * ck[1] + S[2][b] * ck[2];
-            T Gx[3][4], Bx[3][2];
+            StageRec<T> r;
+            r.a0 = S_(0, k); r.a1 = S_(1, k);
             for (int a = 0; a < 3; ++a) {
-                Gx[a][0] = a == 0 ? T(1) : T(0);
-                Gx[a][1] = a == 1 ? T(1) : T(0);
-                Gx[a][2] = (a == 2 ? T(1) : T(0)) + (a == 0 ? R_[0] : (a == 1 ? R_[1] : T(0)));
-                Gx[a][3] = R_[2 + a];
-                Bx[a][0] = R_[5 + 2 * a];
-                Bx[a][1] = R_[6 + 2 * a];
+                r.f[a] = S_(2 + a, k);
+                r.B[a][0] = S_(5 + 2 * a, k); r.B[a][1] = S_(6 + 2 * a, k);
+                r.c[a] = C_(a, k);
+                r.g[a] = S_(17 + a, k);
+                r.hx[a] = S_(32 + a, k);
             }
-            T Z[6][4], Y[6][2];
-            for (int a = 0; a < 6; ++a) {
-                for (int c4 = 0; c4 < 4; ++c4) {
-                    T z = Pm[a][0] * Gx[0][c4] + Pm[a][1] * Gx[1][c4] + Pm[a][2] * Gx[2][c4];
-                    if (c4 == 3) z += Pm[a][5];
-                    Z[a][c4] = z;
-                }
-                for (int c2 = 0; c2 < 2; ++c2)
-                    Y[a][c2] = Pm[a][0] * Bx[0][c2] + Pm[a][1] * Bx[1][c2] + Pm[a][2] * Bx[2][c2] + Pm[a][3 + c2];
-            }
-            const int im[4] = {0, 1, 2, 5};
-            T Qt[6][6], Mt[2][6], Rt[2][2], qt[6], rt[2], Sx[6][3], Su[2][3];
-            for (int a = 0; a < 6; ++a) { qt[a] = T(0); for (int b = 0; b < 6; ++b) Qt[a][b] = T(0); for (int b = 0; b < 3; ++b) Sx[a][b] = T(0); }
-            for (int a = 0; a < 2; ++a) for (int b = 0; b < 6; ++b) Mt[a][b] = T(0);
-            for (int r4 = 0; r4 < 4; ++r4) {
-                for (int c4 = 0; c4 < 4; ++c4) {
-                    T z = Gx[0][r4] * Z[0][c4] + Gx[1][r4] * Z[1][c4] + Gx[2][r4] * Z[2][c4];
-                    if (r4 == 3) z += Z[5][c4];
-                    Qt[im[r4]][im[c4]] = z;
-                }
-                T g = Gx[0][r4] * pt[0] + Gx[1][r4] * pt[1] + Gx[2][r4] * pt[2];
-                if (r4 == 3) g += pt[5];
-                qt[im[r4]] = g;
-                for (int b = 0; b < 3; ++b) {
-                    T sgs = Gx[0][r4] * S[0][b] + Gx[1][r4] * S[1][b] + Gx[2][r4] * S[2][b];
-                    if (r4 == 3) sgs += S[5][b];
-                    Sx[im[r4]][b] = sgs;
-                }
-            }
-            for (int a = 0; a < 2; ++a) {
-                for (int c4 = 0; c4 < 4; ++c4)
-                    Mt[a][im[c4]] = Bx[0][a] * Z[0][c4] + Bx[1][a] * Z[1][c4] + Bx[2][a] * Z[2][c4] + Z[3 + a][c4];
-                for (int b = 0; b < 2; ++b)
-                    Rt[a][b] = Bx[0][a] * Y[0][b] + Bx[1][a] * Y[1][b] + Bx[2][a] * Y[2][b] + Y[3 + a][b];
-                rt[a] = Bx[0][a] * pt[0] + Bx[1][a] * pt[1] + Bx[2][a] * pt[2] + pt[3 + a];
-                for (int b = 0; b < 3; ++b)
-                    Su[a][b] = Bx[0][a] * S[0][b] + Bx[1][a] * S[1][b] + Bx[2][a] * S[2][b] + S[3 + a][b];
-            }
-            // stage cost from the record
-            Qt[2][2] += R_[11];
-            Mt[0][2] += R_[12]; Mt[1][2] += R_[13];
-            Rt[0][0] += R_[14]; Rt[0][1] += R_[15]; Rt[1][0] += R_[15]; Rt[1][1] += R_[16];
-            Qt[2][5] += R_[17]; Qt[5][2] += R_[17];
-            Mt[0][5] += R_[18]; Mt[1][5] += R_[19];
-            if (P.objective == OBJ_QUADRATIC) {
-                for (int i = 0; i < 3; ++i) { Qt[i][i] += T(2) * P.Q[i]; qt[i] += R_[32 + i]; }
-                for (int j = 0; j < 2; ++j) Rt[j][j] += T(2) * P.R[j];
-            } else if (k == 0) {
-                qt[5] += T(n - 1);
-            }
-            for (int j = 0; j < 2; ++j) { Rt[j][j] += R_[20 + j] + delta; rt[j] += R_[22 + j]; }
-            if (k == 0 && P.dt_free) {
-                T dl = d - P.dt_lb, du = P.dt_ub - d;
-                Qt[5][5] += SCL(SC_PDL) / dl + SCL(SC_PDU) / du + delta;
-                qt[5] += -mu / dl + mu / du;
-            }
-            if (k >= 1) { Qt[0][0] += delta; Qt[1][1] += delta; Qt[2][2] += delta; }
+            r.h00 = S_(11, k); r.h01 = S_(12, k); r.h02 = S_(13, k);
+            r.h11 = S_(14, k); r.h12 = S_(15, k); r.h22 = S_(16, k);
             for (int j = 0; j < 2; ++j) {
-                const T ssj = R_[24 + j], sslj = R_[26 + j];
-                Rt[j][j] += ssj;
-                Mt[j][3 + j] -= ssj;
-                Mt[j][5] -= sslj;
-                Qt[3 + j][3 + j] += ssj;
-                Qt[3 + j][5] += sslj; Qt[5][3 + j] += sslj;
-                rt[j] += R_[29 + j];
-                qt[3 + j] -= R_[29 + j];
+                r.sz[j] = S_(20 + j, k); r.gb[j] = S_(22 + j, k);
+                r.ss[j] = S_(24 + j, k); r.sl[j] = S_(26 + j, k); r.gy[j] = S_(29 + j, k);
             }
-            Qt[5][5] += R_[28];
-            qt[5] -= R_[31];
-            // eliminate u_k
-            T det = Rt[0][0] * Rt[1][1] - Rt[0][1] * Rt[1][0];
-            T scale = t_abs(Rt[0][0] * Rt[1][1]) + t_abs(Rt[0][1] * Rt[1][0]);
-            if (!(t_abs(det) > T(1e-14) * scale) || !t_finite(det)) return false;
-            T id = T(1) / det;
-            T Ri[2][2] = {{Rt[1][1] * id, -Rt[0][1] * id}, {-Rt[1][0] * id, Rt[0][0] * id}};
-            T K[2][6], kap[2], Kn[2][3];
-            for (int a = 0; a < 2; ++a) {
-                for (int b = 0; b < 6; ++b) K[a][b] = Ri[a][0] * Mt[0][b] + Ri[a][1] * Mt[1][b];
-                kap[a] = Ri[a][0] * rt[0] + Ri[a][1] * rt[1];
-                for (int b = 0; b < 3; ++b) Kn[a][b] = Ri[a][0] * Su[0][b] + Ri[a][1] * Su[1][b];
+            r.sll = S_(28, k); r.gyl = S_(31, k);
+            T add_dd = T(0), add_qd = T(0);
+            if (k == 0) {
+                if (P.objective == OBJ_MIN_TIME) add_qd += T(n - 1);
+                if (P.dt_free) {
+                    T dl = d - P.dt_lb, du = P.dt_ub - d;
+                    add_dd = SCL(SC_PDL) / dl + SCL(SC_PDU) / du + delta;
+                    add_qd += -mu / dl + mu / du;
+                }
             }
+            StageGain<T> g;
+            if (!riccati_step(V, r, q2, r2, k >= 1 ? delta : T(0), delta, add_dd, add_qd, g)) return false;
             if (lane == 0) {
-                for (int a = 0; a < 2; ++a) for (int b = 0; b < 6; ++b) F(L.GAIN, 6 * a + b, k) = K[a][b];
-                F(L.GAIN, 12, k) = kap[0]; F(L.GAIN, 13, k) = kap[1];
-                for (int a = 0; a < 2; ++a) for (int b = 0; b < 3; ++b) F(L.GAIN, 14 + 3 * a + b, k) = Kn[a][b];
+                for (int a = 0; a < 2; ++a) for (int b = 0; b < 6; ++b) G_(6 * a + b, k) = g.K[a][b];
+                G_(12, k) = g.kap[0]; G_(13, k) = g.kap[1];
+                for (int a = 0; a < 2; ++a) for (int b = 0; b < 3; ++b) G_(14 + 3 * a + b, k) = g.Kn[a][b];
             }
-            for (int a = 0; a < 6; ++a) {
-                for (int b = 0; b < 6; ++b) Pm[a][b] = Qt[a][b] - (Mt[0][a] * K[0][b] + Mt[1][a] * K[1][b]);
-                pv[a] = qt[a] - (Mt[0][a] * kap[0] + Mt[1][a] * kap[1]);
-                for (int b = 0; b < 3; ++b) S[a][b] = Sx[a][b] - (Mt[0][a] * Kn[0][b] + Mt[1][a] * Kn[1][b]);
-            }
-            for (int a = 0; a < 3; ++a) {
-                for (int b = 0; b < 3; ++b) W[a][b] -= Su[0][a] * Kn[0][b] + Su[1][a] * Kn[1][b];
-                om[a] -= Su[0][a] * kap[0] + Su[1][a] * kap[1];
-            }
-            for (int a = 0; a < 6; ++a) for (int b = a + 1; b < 6; ++b) { T m = T(0.5) * (Pm[a][b] + Pm[b][a]); Pm[a][b] = m; Pm[b][a] = m; }
         }
-        T A4[4][5];
-        for (int a = 0; a < 4; ++a) for (int b = 0; b < 5; ++b) A4[a][b] = T(0);
-        if (P.dt_free) {
-            A4[0][0] = Pm[5][5];
-            for (int b = 0; b < 3; ++b) A4[0][1 + b] = P.xf_fixed[b] ? S[5][b] : T(0);
-            A4[0][4] = -pv[5];
-        } else { A4[0][0] = T(1); }
+        return riccati_root(V, P, dd_out, nu_out);
+    }
+
+    // ---------------------------------------------------------------- column-parallel backward Riccati sweep
+    // Lane c (0..11) owns column c of the 8 x 12 stage matrix
+    //     Hhat = [G Gam]' [ P+ (G | 0 | Gam) | p+ + P+ c~ | S+ ]  + stage cost,
+    // rows (x0,x1,x2,up0,up1,d | u0,u1), columns (x0,x1,x2,up0,up1,d, u0,u1, p, nu0,nu1,nu2).  After eliminating u_k
+    // with the 2x2 pivot (rows 6,7 of columns 6,7, broadcast with v_readlane), lane c holds column c of the new
+    // [P | p | S]; the six P columns go through a 36-word LDS buffer to every lane for the next stage.
+    // Same arithmetic as riccati_step(), ~3x fewer instructions per stage in the wave's instruction stream.
+    __device__ bool backward_cols(T delta, T dc, T& dd_out, T nu_out[3]) const {
+        const int n = L.n;
+        const T d = SCL(SC_D);
+        const int c = lane & 15;
+        const bool quad = P.objective == OBJ_QUADRATIC;
+        T q2[3] = {T(0), T(0), T(0)}, r2[2] = {T(0), T(0)};
+        if (quad) { for (int i = 0; i < 3; ++i) q2[i] = T(2) * P.Q[i]; for (int j = 0; j < 2; ++j) r2[j] = T(2) * P.R[j]; }
+        T* VP = sm + L.VP;
+        // per-lane addressing of "its" G/Gam/c column: co_m = sm[cbase + k*cstride + m*cstep]
+        int cbase = L.ZC, cstride = 0, cstep = 0;          // default: zeros
+        if (c == 2) { cbase = L.STG + 0; cstride = NSTG; cstep = 1; }          // (a0, a1, [1])
+        else if (c == 5) { cbase = L.STG + 2; cstride = NSTG; cstep = 1; }     // f
+        else if (c == 6) { cbase = L.STG + 5; cstride = NSTG; cstep = 2; }     // Bx[:,0]
+        else if (c == 7) { cbase = L.STG + 6; cstride = NSTG; cstep = 2; }     // Bx[:,1]
+        else if (c == 8) { cbase = L.CC; cstride = 3; cstep = 1; }             // c_k
+        const int psel = c == 6 ? L.VP + 18 : (c == 7 ? L.VP + 24 : (c == 5 ? L.VP + 30 : L.ZC));   // extra P+ column
+        if (lane == 0) { for (int i = 0; i < 6; ++i) sm[L.ZC + i] = T(0); sm[L.ZC + 6] = T(1); }
+        // ---- terminal value function
+        T own[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};   // lane 8: p ; lanes 9..11: S[:, b]
+        T Wc[3] = {T(0), T(0), T(0)};                        // lanes 9+b: W[:, b]
+        T om = T(0);                                         // lanes 9+a: omega[a]
+        {
+            const int r = n - 1;
+            T col[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+            const T ss0 = S_(24, r), ss1 = S_(25, r), sl0 = S_(26, r), sl1 = S_(27, r), sll = S_(28, r);
+            T xd[3] = {F(L.X, 0, r) - xf[0], F(L.X, 1, r) - xf[1], normalize_theta(F(L.X, 2, r) - xf[2])};
+            if (c < 3) { if (!P.xf_fixed[c]) col[c] = delta + ((quad && P.has_Qf) ? T(2) * P.Qf[c] : T(0)); }
+            else if (c == 3) { col[3] = ss0; col[5] = sl0; }
+            else if (c == 4) { col[4] = ss1; col[5] = sl1; }
+            else if (c == 5) { col[3] = sl0; col[4] = sl1; col[5] = sll; }
+            else if (c == 8) {
+                for (int i = 0; i < 3; ++i) if (!P.xf_fixed[i] && quad && P.has_Qf) own[i] = T(2) * P.Qf[i] * xd[i];
+                own[3] = -S_(29, r); own[4] = -S_(30, r); own[5] = -S_(31, r);
+            } else if (c >= 9 && c < 12) {
+                const int b = c - 9;
+                if (P.xf_fixed[b]) { own[b] = T(1); Wc[b] = -dc; }
+            }
+            sync();
+            if (lane < 6) { for (int i = 0; i < 6; ++i) VP[6 * lane + i] = col[i]; }
+            sync();
+        }
+        T v[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
+        for (int k = n - 2; k >= 0; --k) {
+            // one batch of uniform LDS reads (no loads inside the divergent column branches below)
+            T rec[NSTG];
+#pragma unroll
+            for (int i = 0; i < NSTG; ++i) rec[i] = S_(i, k);
+            const T a0 = rec[0], a1 = rec[1];
+            const T f0 = rec[2], f1 = rec[3], f2 = rec[4];
+            const T B00 = rec[5], B01 = rec[6], B10 = rec[7], B11 = rec[8], B20 = rec[9], B21 = rec[10];
+            // lane's column of [G | 0 | Gam | c~]
+            const int cb = cbase + k * cstride;
+            T co0 = sm[cb], co1 = sm[cb + cstep], co2 = sm[cb + 2 * cstep];
+            if (c == 0) { co0 = T(1); }
+            else if (c == 1) { co1 = T(1); }
+            else if (c == 2) { co2 = T(1); }
+            // z = P+ * column + own
+            T z[6];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) z[i] = (VP[i] * co0 + VP[6 + i] * co1) + (VP[12 + i] * co2 + sm[psel + i]) + own[i];
+            if (c >= 9) om += own[0] * C_(0, k) + own[1] * C_(1, k) + own[2] * C_(2, k);
+            // Hhat column
+            T h[8];
+            h[0] = z[0]; h[1] = z[1];
+            h[2] = z[2] + a0 * z[0] + a1 * z[1];
+            h[3] = T(0); h[4] = T(0);
+            h[5] = (f0 * z[0] + f1 * z[1]) + (f2 * z[2] + z[5]);
+            h[6] = (B00 * z[0] + B10 * z[1]) + (B20 * z[2] + z[3]);
+            h[7] = (B01 * z[0] + B11 * z[1]) + (B21 * z[2] + z[4]);
+            // stage cost column
+            const T dxr = k >= 1 ? delta : T(0);
+            if (c < 2) { h[c] += dxr + q2[c]; }
+            else if (c == 2) { h[2] += dxr + q2[2] + rec[11]; h[5] += rec[17]; h[6] += rec[12]; h[7] += rec[13]; }
+            else if (c == 3) { h[3] += rec[24]; h[5] += rec[26]; h[6] -= rec[24]; }
+            else if (c == 4) { h[4] += rec[25]; h[5] += rec[27]; h[7] -= rec[25]; }
+            else if (c == 5) {
+                T add_dd = T(0);
+                if (k == 0 && P.dt_free) add_dd = SCL(SC_PDL) / (d - P.dt_lb) + SCL(SC_PDU) / (P.dt_ub - d) + delta;
+                h[2] += rec[17]; h[3] += rec[26]; h[4] += rec[27]; h[5] += rec[28] + add_dd;
+                h[6] += rec[18] - rec[26]; h[7] += rec[19] - rec[27];
+            } else if (c == 6) {
+                h[2] += rec[12]; h[3] -= rec[24]; h[5] += rec[18] - rec[26];
+                h[6] += rec[14] + rec[20] + delta + rec[24] + r2[0]; h[7] += rec[15];
+            } else if (c == 7) {
+                h[2] += rec[13]; h[4] -= rec[25]; h[5] += rec[19] - rec[27];
+                h[6] += rec[15]; h[7] += rec[16] + rec[21] + delta + rec[25] + r2[1];
+            } else if (c == 8) {
+                T add_qd = T(0);
+                if (k == 0) {
+                    if (P.objective == OBJ_MIN_TIME) add_qd += T(n - 1);
+                    if (P.dt_free) add_qd += -mu / (d - P.dt_lb) + mu / (P.dt_ub - d);
+                }
+                h[0] += rec[32]; h[1] += rec[33]; h[2] += rec[34];
+                h[3] -= rec[29]; h[4] -= rec[30]; h[5] += add_qd - rec[31];
+                h[6] += rec[22] + rec[29]; h[7] += rec[23] + rec[30];
+            }
+            // 2x2 pivot from columns 6,7 (rows 6,7)
+            const T R00 = lane_bcast(h[6], 6), R01 = lane_bcast(h[7], 6), R11 = lane_bcast(h[7], 7);
+            const T det = R00 * R11 - R01 * R01;
+            const T scale = t_abs(R00 * R11) + R01 * R01;
+            if (!(t_abs(det) > T(1e-14) * scale) || !t_finite(det)) return false;
+            const T id = T(1) / det;
+            const T Ri00 = R11 * id, Ri01 = -R01 * id, Ri11 = R00 * id;
+            const T K0 = Ri00 * h[6] + Ri01 * h[7], K1 = Ri01 * h[6] + Ri11 * h[7];
+            // gains: lanes 0..5 -> K[:, c], lane 8 -> kappa, lanes 9..11 -> Knu[:, b]
+            if (lane < 12 && lane != 6 && lane != 7) {
+                const int g0 = lane < 6 ? lane : (lane == 8 ? 12 : 14 + (lane - 9));
+                const int g1 = lane < 6 ? 6 + lane : (lane == 8 ? 13 : 17 + (lane - 9));
+                G_(g0, k) = K0; G_(g1, k) = K1;
+            }
+            // M~' = rows 0..5 of columns 6,7
+#pragma unroll
+            for (int i = 0; i < 6; ++i) {
+                const T m0 = lane_bcast(h[i], 6), m1 = lane_bcast(h[i], 7);
+                v[i] = h[i] - (m0 * K0 + m1 * K1);
+            }
+            // W, omega (lanes 9..11): Su[j][a] = h[6+j] of lane 9+a ; kappa from lane 8
+            {
+                const T ka0 = lane_bcast(K0, 8), ka1 = lane_bcast(K1, 8);
+                if (c >= 9) om -= h[6] * ka0 + h[7] * ka1;
+                const T s60 = lane_bcast(h[6], 9), s70 = lane_bcast(h[7], 9);
+                const T s61 = lane_bcast(h[6], 10), s71 = lane_bcast(h[7], 10);
+                const T s62 = lane_bcast(h[6], 11), s72 = lane_bcast(h[7], 11);
+                if (c >= 9) {
+                    Wc[0] -= s60 * K0 + s70 * K1;
+                    Wc[1] -= s61 * K0 + s71 * K1;
+                    Wc[2] -= s62 * K0 + s72 * K1;
+                }
+            }
+            if (c >= 8) { for (int i = 0; i < 6; ++i) own[i] = v[i]; }
+            sync();
+            if (lane < 6) { for (int i = 0; i < 6; ++i) VP[6 * lane + i] = v[i]; }
+            sync();
+        }
+        // ---- root: gather P[5][5], p[5], S[5][:], W, omega
+        RicState<T> V;
+        V.P[5][5] = lane_bcast(v[5], 5);
+        V.p[5] = lane_bcast(own[5], 8);
+        V.S[5][0] = lane_bcast(own[5], 9); V.S[5][1] = lane_bcast(own[5], 10); V.S[5][2] = lane_bcast(own[5], 11);
         for (int a = 0; a < 3; ++a) {
-            if (P.xf_fixed[a]) {
-                A4[1 + a][0] = P.dt_free ? S[5][a] : T(0);
-                for (int b = 0; b < 3; ++b) A4[1 + a][1 + b] = P.xf_fixed[b] ? W[a][b] : T(0);
-                A4[1 + a][4] = -om[a];
-            } else { A4[1 + a][1 + a] = T(1); }
+            V.W[a][0] = lane_bcast(Wc[a], 9); V.W[a][1] = lane_bcast(Wc[a], 10); V.W[a][2] = lane_bcast(Wc[a], 11);
         }
-        for (int c = 0; c < 4; ++c) {
-            int piv = c; T best = t_abs(A4[c][c]);
-            for (int r = c + 1; r < 4; ++r) if (t_abs(A4[r][c]) > best) { best = t_abs(A4[r][c]); piv = r; }
-            if (!(best > T(0)) || !t_finite(best)) return false;
-            if (piv != c) for (int b = 0; b < 5; ++b) { T t = A4[c][b]; A4[c][b] = A4[piv][b]; A4[piv][b] = t; }
-            T ip = T(1) / A4[c][c];
-            for (int r = c + 1; r < 4; ++r) {
-                T m = A4[r][c] * ip;
-                for (int b = c; b < 5; ++b) A4[r][b] -= m * A4[c][b];
-            }
-        }
-        T sol[4];
-        for (int c = 3; c >= 0; --c) {
-            T a = A4[c][4];
-            for (int b = c + 1; b < 4; ++b) a -= A4[c][b] * sol[b];
-            sol[c] = a / A4[c][c];
-        }
-        dd_out = sol[0];
-        nu_out[0] = sol[1]; nu_out[1] = sol[2]; nu_out[2] = sol[3];
-        return t_finite(sol[0]) && t_finite(sol[1]) && t_finite(sol[2]) && t_finite(sol[3]);
+        V.om[0] = lane_bcast(om, 9); V.om[1] = lane_bcast(om, 10); V.om[2] = lane_bcast(om, 11);
+        return riccati_root(V, P, dd_out, nu_out);
     }
 
     // wave-uniform: state recurrence (writes DU, DX) then costate recurrence (writes LAMN)
@@ -495,17 +539,28 @@ struct IpmWave {
         T xi[6] = {T(0), T(0), T(0), T(0), T(0), dd};
         if (lane == 0) { SCL(SC_DD) = dd; F(L.DX, 0, 0) = T(0); F(L.DX, 1, 0) = T(0); F(L.DX, 2, 0) = T(0); }
         for (int k = 0; k < n - 1; ++k) {
+            // one batch of independent LDS reads, then arithmetic
+            T g[NGAIN], sr[11], ck[3];
+#pragma unroll
+            for (int i = 0; i < NGAIN; ++i) g[i] = G_(i, k);
+#pragma unroll
+            for (int i = 0; i < 11; ++i) sr[i] = S_(i, k);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) ck[i] = C_(i, k);
             T du_[2];
+#pragma unroll
             for (int a = 0; a < 2; ++a) {
-                T acc = F(L.GAIN, 12 + a, k);
-                for (int b = 0; b < 6; ++b) acc += F(L.GAIN, 6 * a + b, k) * xi[b];
-                for (int b = 0; b < 3; ++b) acc += F(L.GAIN, 14 + 3 * a + b, k) * nu[b];
-                du_[a] = -acc;
+                T acc0 = g[12 + a] + g[6 * a + 0] * xi[0] + g[6 * a + 1] * xi[1];
+                T acc1 = g[6 * a + 2] * xi[2] + g[6 * a + 3] * xi[3];
+                T acc2 = g[6 * a + 4] * xi[4] + g[6 * a + 5] * xi[5];
+                T acc3 = g[14 + 3 * a] * nu[0] + g[15 + 3 * a] * nu[1] + g[16 + 3 * a] * nu[2];
+                du_[a] = -((acc0 + acc1) + (acc2 + acc3));
             }
             T xn[3];
+#pragma unroll
             for (int a = 0; a < 3; ++a) {
-                T ax = a < 2 ? F(L.STG, a, k) : T(0);
-                xn[a] = xi[a] + ax * xi[2] + F(L.STG, 5 + 2 * a, k) * du_[0] + F(L.STG, 6 + 2 * a, k) * du_[1] + F(L.STG, 2 + a, k) * dd + F(L.CC, a, k);
+                T ax = a < 2 ? sr[a] : T(0);
+                xn[a] = (xi[a] + ax * xi[2]) + (sr[5 + 2 * a] * du_[0] + sr[6 + 2 * a] * du_[1]) + (sr[2 + a] * dd + ck[a]);
             }
             if (lane == 0) {
                 F(L.DU, 0, k) = du_[0]; F(L.DU, 1, k) = du_[1];
@@ -535,10 +590,10 @@ struct IpmWave {
             T t[3];
             for (int i = 0; i < 3; ++i) {
                 T qd = delta + (P.objective == OBJ_QUADRATIC ? T(2) * P.Q[i] : T(0));
-                t[i] = qd * dx[i] + F(L.STG, 32 + i, k);
+                t[i] = qd * dx[i] + S_(32 + i, k);
             }
-            t[2] += F(L.STG, 11, k) * dx[2] + F(L.STG, 12, k) * duv + F(L.STG, 13, k) * duw + F(L.STG, 17, k) * dd
-                  + F(L.STG, 0, k) * lp[0] + F(L.STG, 1, k) * lp[1];
+            t[2] += S_(11, k) * dx[2] + S_(12, k) * duv + S_(13, k) * duw + S_(17, k) * dd
+                  + S_(0, k) * lp[0] + S_(1, k) * lp[1];
             lp[0] += t[0]; lp[1] += t[1]; lp[2] += t[2];
             if (lane == 0) { F(L.LAMN, 0, k - 1) = lp[0]; F(L.LAMN, 1, k - 1) = lp[1]; F(L.LAMN, 2, k - 1) = lp[2]; }
         }
@@ -575,7 +630,7 @@ struct IpmWave {
                     T u = F(L.U, j, k), du_ = F(L.DU, j, k);
                     T dl = u - P.u_lb[j], du = P.u_ub[j] - u;
                     T pl = F(L.PL, j, k), pu = F(L.PU, j, k);
-                    T gbar = F(L.STG, 22 + j, k);         // barrier (+ quadratic objective) gradient wrt u
+                    T gbar = S_(22 + j, k);         // barrier (+ quadratic objective) gradient wrt u
                     hdz += gbar * du_; dphi += gbar * du_;
                     ftb(dl, du_, tau, a_p); ftb(du, -du_, tau, a_p);
                     ftb(pl, mu / dl - pl - (pl / dl) * du_, tau, a_d);
@@ -584,7 +639,7 @@ struct IpmWave {
                 }
                 for (int i = 0; i < 3; ++i) {
                     T l = F(L.LAMN, i, k);
-                    clam += F(L.CC, i, k) * l;
+                    clam += C_(i, k) * l;
                     if (!t_finite(l)) fin = false;
                 }
             }
@@ -595,7 +650,7 @@ struct IpmWave {
                         dz2 += dx * dx; dzmax = t_max(dzmax, t_abs(dx));
                         T g = T(0);
                         if (P.objective == OBJ_QUADRATIC) {
-                            if (k < n - 1) g = F(L.STG, 32 + i, k);
+                            if (k < n - 1) g = S_(32 + i, k);
                             else if (P.has_Qf) { T xd = F(L.X, i, k) - xf[i]; if (i == 2) xd = normalize_theta(xd); g = T(2) * P.Qf[i] * xd; }
                         }
                         hdz += g * dx; dphi += g * dx;
@@ -793,8 +848,17 @@ struct IpmWave {
         sync();
         int it = 0, status = ST_MAX_ITER;
         T e0 = T(0);
+#ifdef MPC_PROFILE
+        long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int nfac = 0, ntrial = 0;
+        const long long t_begin = __builtin_readcyclecounter();
+        const long long w_begin = wall_clock64();
+#define MPC_TICK(i, stmt) { long long t0_ = __builtin_readcyclecounter(); stmt; tk[i] += __builtin_readcyclecounter() - t0_; }
+#else
+#define MPC_TICK(i, stmt) { stmt; }
+#endif
         while (true) {
-            Err er = kkt_pass();
+            Err er;
+            MPC_TICK(0, er = kkt_pass());
             e0 = err_value(er, T(0));
             if (!t_finite(e0)) { status = ST_NUMERICAL; break; }
             if (e0 <= P.tol) { status = ST_CONVERGED; break; }
@@ -806,8 +870,7 @@ struct IpmWave {
                     rho = T(0);
                 } else break;
             }
-            stage_barrier_terms();
-            sync();
+            MPC_TICK(1, stage_barrier_terms(); sync());
             const T tau = t_max(Algo<T>::tau_min, T(1) - mu);
             const T dc = nfix > 0 ? Algo<T>::delta_c * t_pow(mu, Algo<T>::kappa_c) : T(0);
             T delta = T(0);
@@ -815,12 +878,18 @@ struct IpmWave {
             Fwd fw;
             T dd = T(0), nu[3] = {T(0), T(0), T(0)}, curv = T(0);
             for (int ntry = 0; ntry <= 40; ++ntry) {
-                bool good = backward(delta, dc, dd, nu);
-                sync();
+                bool good;
+                #ifdef MPC_COLUMN_SWEEP   // experimental: column-parallel sweep (correct, currently slower than the uniform one)
+                MPC_TICK(2, good = backward_cols(delta, dc, dd, nu); sync());
+#else
+                MPC_TICK(2, good = backward(delta, dc, dd, nu); sync());
+#endif
+#ifdef MPC_PROFILE
+                ++nfac;
+#endif
                 if (good) {
-                    forward_states(dd, nu, delta);
-                    sync();
-                    fw = post_pass(dd, nu, tau);
+                    MPC_TICK(3, forward_states(dd, nu, delta); sync());
+                    MPC_TICK(4, fw = post_pass(dd, nu, tau));
                     good = fw.finite;
                     if (good) {
                         curv = -fw.hdz + fw.clam - dc * fw.nunu;
@@ -839,7 +908,8 @@ struct IpmWave {
                 T rho_trial = (fw.dphi + T(0.5) * sigma * curv) / ((T(1) - Algo<T>::rho_frac) * theta);
                 if (rho < rho_trial) rho = rho_trial + T(1);
             }
-            const T phi0 = fobj - mu * barrier_logs(L.U, SCL(SC_D), T(0), false, dd) + rho * theta;
+            T phi0;
+            MPC_TICK(5, phi0 = fobj - mu * barrier_logs(L.U, SCL(SC_D), T(0), false, dd) + rho * theta);
             const T Dm = fw.dphi - rho * theta;
             const T theta_rows = theta - theta_c;
             T alpha = fw.a_p;
@@ -847,20 +917,27 @@ struct IpmWave {
             T th_t = T(0), f_t = T(0);
             for (int ls = 0; ls < Algo<T>::max_ls; ++ls) {
                 if (ls > 0) alpha *= T(0.5);
-                make_trial(alpha);
-                sync();
-                eval_point(L.XT, L.UT, SCL(SC_DT), th_t, f_t);
-                T tht = th_t + (T(1) - alpha) * theta_rows;
-                T phit = f_t - mu * barrier_logs(L.UT, SCL(SC_DT), alpha, true, dd) + rho * tht;
-                sync();
+                T phit, tht;
+                MPC_TICK(6, make_trial(alpha); sync(); eval_point(L.XT, L.UT, SCL(SC_DT), th_t, f_t);
+                         tht = th_t + (T(1) - alpha) * theta_rows;
+                         phit = f_t - mu * barrier_logs(L.UT, SCL(SC_DT), alpha, true, dd) + rho * tht; sync());
+#ifdef MPC_PROFILE
+                ++ntrial;
+#endif
                 if (t_finite(phit) && phit - phi0 - Algo<T>::ls_eps * t_abs(phi0) <= Algo<T>::eta_armijo * alpha * Dm) { accepted = true; break; }
             }
             if (!accepted && alpha * fw.dzmax < T(1e-14)) { status = ST_LINESEARCH; break; }
-            accept(alpha, fw.a_d);
-            sync();
+            MPC_TICK(7, accept(alpha, fw.a_d); sync());
             theta_c = th_t; fobj = f_t;
             ++it;
         }
+#ifdef MPC_PROFILE
+        if (lane == 0 && blockIdx.x < 4096) {
+            long long* o = g_mpc_prof[blockIdx.x];
+            o[0] = __builtin_readcyclecounter() - t_begin; o[1] = wall_clock64() - w_begin; o[2] = it; o[3] = nfac; o[4] = ntrial;
+            for (int i = 0; i < 8; ++i) o[5 + i] = tk[i];
+        }
+#endif
         out.status = status; out.iters = it; out.kkt_error = e0; out.objective = fobj;
         return out;
     }
