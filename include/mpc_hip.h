@@ -46,6 +46,7 @@ enum mpc_objective {                  /* src/controller.cpp:551-640 */
     MPC_OBJ_QUADRATIC = 1
 };
 enum mpc_precision { MPC_FP64 = 0, MPC_FP32 = 1 };
+enum mpc_footprint { MPC_FOOTPRINT_POINT = 0, MPC_FOOTPRINT_CIRCLE = 1 };
 
 enum mpc_status {                     /* per-instance result; 0 == what corbo reports as Converged */
     MPC_CONVERGED = 0,
@@ -86,8 +87,27 @@ typedef struct mpc_config {
     double  tol;                      /* ipopt_numeric_options/tol */
     double  mu_init;                  /* barrier start (0 -> default 0.1) */
     int32_t precision;                /* MPC_FP64 | MPC_FP32 */
+    /* collision avoidance (src/controller.cpp:717-729; footprint: src/mpc_local_planner_ros.cpp:890-1001) */
+    double  min_obstacle_dist;        /* collision_avoidance/min_obstacle_dist */
+    double  force_inclusion_dist;     /* .../force_inclusion_dist */
+    double  cutoff_dist;              /* .../cutoff_dist */
+    int32_t footprint_kind;           /* MPC_FOOTPRINT_POINT | MPC_FOOTPRINT_CIRCLE */
+    double  footprint_radius;         /* circular footprint radius */
+    int32_t max_obstacles;            /* O: obstacles per instance the solver is sized for (0 = none) */
+    int32_t max_vertices;             /* V: vertices per obstacle (1 point, 2 line, >=3 polygon) */
+    int32_t max_obstacle_rows;        /* clearance rows kept per grid point (forced + left + right; default 4) */
     int32_t reserved[8];
 } mpc_config;
+
+/* Obstacles of a batch (teb_local_planner ObstContainer of every instance, flattened; borrowed for the call).
+ * Point: 1 vertex; line: 2 vertices; polygon: >= 3 vertices (closed loop, any orientation); an optional radius
+ * turns a 1-vertex obstacle into a circle.  Static obstacles only (enable_dynamic_obstacles = false). */
+typedef struct mpc_obstacles {
+    const int32_t* n_obstacles;       /* [B]                 number of valid obstacles of instance b (<= O) */
+    const int32_t* n_vertices;        /* [B][O]              number of valid vertices of obstacle (b,o) (<= V) */
+    const double*  vertices;          /* [B][O][V][2] */
+    const double*  radius;            /* [B][O] or NULL */
+} mpc_obstacles;
 
 typedef struct mpc_solver mpc_solver;     /* opaque */
 
@@ -113,10 +133,15 @@ void mpc_destroy(mpc_solver* s);
  *       full_discretization_grid_base_se2.cpp:192-239: linear x0->xf, shortest-arc theta, u=0,
  *       dt=dt_ref).  Non-NULL -> used as the vertex values (warm start), with x_0 := x0 and the
  *       fixed goal components := xf (full_discretization_grid_base_se2.cpp:101-110).
+ *   obstacles : nullable.  When given, the relevant obstacles of every grid point are associated on the device
+ *       exactly as StageInequalitySE2::update does (src/optimal_control/stage_inequality_se2.cpp:50-162) on the
+ *       initial vertex values, then frozen for the solve; rows d_min - dist(footprint(x_k), obstacle) <= 0
+ *       (stage_inequality_se2.cpp:164-175) for k = 1..n-2.
  *   status/iters : nullable. */
 int mpc_solve_batch(mpc_solver* s, int32_t B,
                     const double* x0, const double* xf, const double* u_prev, const double* dt_prev,
                     const double* x_init, const double* u_init, const double* dt_init,
+                    const mpc_obstacles* obstacles /* nullable; host pointers inside */,
                     double* x_out, double* u_out, double* dt_out,
                     int32_t* status, int32_t* iters);
 
@@ -125,6 +150,7 @@ int mpc_solve_batch(mpc_solver* s, int32_t B,
 int mpc_solve_batch_device(mpc_solver* s, int32_t B,
                            const double* d_x0, const double* d_xf, const double* d_u_prev, const double* d_dt_prev,
                            const double* d_x_init, const double* d_u_init, const double* d_dt_init,
+                           const mpc_obstacles* d_obstacles /* nullable; DEVICE pointers inside */,
                            double* d_x_out, double* d_u_out, double* d_dt_out,
                            int32_t* d_status, int32_t* d_iters);
 

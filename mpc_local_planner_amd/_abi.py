@@ -58,14 +58,33 @@ class MpcConfig(C.Structure):
         ("tol", C.c_double),
         ("mu_init", C.c_double),
         ("precision", C.c_int32),
+        ("min_obstacle_dist", C.c_double),
+        ("force_inclusion_dist", C.c_double),
+        ("cutoff_dist", C.c_double),
+        ("footprint_kind", C.c_int32),
+        ("footprint_radius", C.c_double),
+        ("max_obstacles", C.c_int32),
+        ("max_vertices", C.c_int32),
+        ("max_obstacle_rows", C.c_int32),
         ("reserved", C.c_int32 * 8),
+    ]
+
+
+class MpcObstacles(C.Structure):
+    """struct mpc_obstacles (include/mpc_hip.h): raw addresses (host or device)."""
+    _fields_ = [
+        ("n_obstacles", C.c_void_p),
+        ("n_vertices", C.c_void_p),
+        ("vertices", C.c_void_p),
+        ("radius", C.c_void_p),
     ]
 
 
 def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3, dt_free=True, dt_lb=0.0, dt_ub=10.0,
                 xf_fixed=(True, True, True), objective=OBJ_MIN_TIME, Q=(0, 0, 0), R=(0, 0), integral_form=False, Qf=None,
                 u_lb=(-0.2, -0.3), u_ub=(0.4, 0.3), du_lb=(-INF, -INF), du_ub=(INF, INF), max_iter=100, tol=1e-8,
-                mu_init=0.1, precision=FP64) -> MpcConfig:
+                mu_init=0.1, precision=FP64, min_obstacle_dist=0.5, force_inclusion_dist=0.5, cutoff_dist=2.0,
+                footprint_kind=0, footprint_radius=0.0, max_obstacles=0, max_vertices=1, max_obstacle_rows=4) -> MpcConfig:
     c = MpcConfig()
     c.model = model
     mp = list(model_params) + [0.0] * 4
@@ -91,6 +110,9 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
     c.tol = tol
     c.mu_init = mu_init
     c.precision = precision
+    c.min_obstacle_dist, c.force_inclusion_dist, c.cutoff_dist = min_obstacle_dist, force_inclusion_dist, cutoff_dist
+    c.footprint_kind, c.footprint_radius = footprint_kind, footprint_radius
+    c.max_obstacles, c.max_vertices, c.max_obstacle_rows = max_obstacles, max_vertices, max_obstacle_rows
     return c
 
 
@@ -105,7 +127,8 @@ def config_unicycle_quadratic(n=20, **kw) -> MpcConfig:
     """BASELINE.json config 1: .../cfg/diff_drive/mpc_local_planner_params_quadratic_form.yaml:7-14,33-41,53-61."""
     return make_config(model=MODEL_UNICYCLE, model_params=(0.0,), n=n, dt_ref=0.3, dt_free=False,
                        xf_fixed=(False, False, False), objective=OBJ_QUADRATIC, Q=(2.0, 2.0, 0.25), R=(0.1, 0.05),
-                       Qf=(10.0, 10.0, 0.5), u_lb=(-0.2, -0.3), u_ub=(0.4, 0.3), du_lb=(-0.2, -0.2), du_ub=(0.2, 0.2), **kw)
+                       Qf=(10.0, 10.0, 0.5), u_lb=(-0.2, -0.3), u_ub=(0.4, 0.3), du_lb=(-0.2, -0.2), du_ub=(0.2, 0.2),
+                       **{**dict(min_obstacle_dist=0.2, force_inclusion_dist=0.5, cutoff_dist=2.5), **kw})
 
 
 def config_bicycle_min_time(n=120, **kw) -> MpcConfig:

@@ -77,7 +77,7 @@ def load() -> C.CDLL:
     lib.mpc_reset.restype = C.c_int
     lib.mpc_destroy.argtypes = [C.c_void_p]
     lib.mpc_destroy.restype = None
-    sig = [C.c_void_p, C.c_int32] + [dp] * 12
+    sig = [C.c_void_p, C.c_int32] + [dp] * 7 + [C.c_void_p] + [dp] * 5     # ..., const mpc_obstacles*, outputs
     lib.mpc_solve_batch.argtypes = sig
     lib.mpc_solve_batch.restype = C.c_int
     lib.mpc_solve_batch_device.argtypes = sig

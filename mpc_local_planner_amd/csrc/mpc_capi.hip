@@ -87,7 +87,7 @@ __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
     mpc::Problem<T> P, mpc::WaveLayout L, int B,
     const double* __restrict__ x0, const double* __restrict__ xf, const double* __restrict__ u_prev,
     const double* __restrict__ dt_prev, const double* __restrict__ x_init, const double* __restrict__ u_init,
-    const double* __restrict__ dt_init, double* __restrict__ x_out, double* __restrict__ u_out,
+    const double* __restrict__ dt_init, mpc_obstacles obst, double* __restrict__ x_out, double* __restrict__ u_out,
     double* __restrict__ dt_out, int32_t* __restrict__ status, int32_t* __restrict__ iters) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mpc_smem[];
     T* sm = reinterpret_cast<T*>(mpc_smem);
@@ -118,6 +118,7 @@ __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
     } else {
         S.cold_start();
     }
+    if (L.M > 0) S.load_obstacles(obst.n_obstacles, obst.n_vertices, obst.vertices, obst.radius, inst);
     __syncthreads();
     mpc::SolveStats<T> st = S.solve();
     __syncthreads();
@@ -151,6 +152,8 @@ struct mpc_solver {
     // staging for the host-pointer entry point
     double *d_x0, *d_xf, *d_up, *d_dtp, *d_xi, *d_ui, *d_dti, *d_xo, *d_uo, *d_dto;
     int32_t *d_status, *d_iters;
+    int32_t *d_ono, *d_onv;
+    double *d_ov, *d_or;
     bool timed;
 };
 
@@ -177,6 +180,13 @@ void mpc_config_defaults(mpc_config* c) {
     c->tol = 1e-8;
     c->mu_init = 0.1;
     c->precision = MPC_FP64;
+    c->min_obstacle_dist = 0.5;          // :717
+    c->force_inclusion_dist = 0.5;       // :725
+    c->cutoff_dist = 2.0;                // :727
+    c->footprint_kind = MPC_FOOTPRINT_POINT;   // src/mpc_local_planner_ros.cpp:894-898
+    c->max_obstacles = 0;
+    c->max_vertices = 1;
+    c->max_obstacle_rows = 4;
 }
 
 const char* mpc_last_error(void) { return g_err; }
@@ -199,6 +209,10 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
     if (cfg->objective != MPC_OBJ_MIN_TIME && cfg->objective != MPC_OBJ_QUADRATIC) { set_err("mpc_create: unknown objective"); return MPC_EINVAL; }
     if (cfg->objective == MPC_OBJ_MIN_TIME && !cfg->dt_free) { set_err("mpc_create: minimum_time needs a variable grid (dt_free)"); return MPC_EINVAL; }
     if (!(cfg->dt_ref > 0)) { set_err("mpc_create: dt_ref must be > 0"); return MPC_EINVAL; }
+    if (cfg->max_obstacles < 0 || cfg->max_obstacles > 256 || (cfg->max_obstacles > 0 && (cfg->max_vertices < 1 || cfg->max_vertices > 64)) || cfg->max_obstacle_rows > 16) {
+        set_err("mpc_create: obstacle capacities out of range (max_obstacles <= 256, max_vertices <= 64, max_obstacle_rows <= 16)"); return MPC_EINVAL; }
+    if (cfg->max_obstacles > 0 && cfg->footprint_kind != MPC_FOOTPRINT_POINT && cfg->footprint_kind != MPC_FOOTPRINT_CIRCLE) {
+        set_err("mpc_create: only point and circular footprints are implemented"); return MPC_EINVAL; }
     if (cfg->integral_form) { set_err("mpc_create: integral_form costs are not implemented (the example configurations use the sum form)"); return MPC_EINVAL; }
     for (int j = 0; j < 2; ++j)
         if (!(cfg->u_lb[j] < cfg->u_ub[j])) { set_err("mpc_create: control box must be finite and non-empty"); return MPC_EINVAL; }
@@ -217,10 +231,19 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
     mpc::fill_problem<double>(*cfg, s->P64);
     mpc::fill_problem<float>(*cfg, s->P32);
     s->L = mpc::Layout::make(cfg->n);
-    s->WL = mpc::WaveLayout::make(cfg->n);
+    {
+        const int O = cfg->max_obstacles > 0 ? cfg->max_obstacles : 0;
+        const int M = O > 0 ? (cfg->max_obstacle_rows > 0 ? cfg->max_obstacle_rows : 4) : 0;
+        s->WL = mpc::WaveLayout::make(cfg->n, M, O, cfg->max_vertices > 0 ? cfg->max_vertices : 1);
+    }
     s->wave_lds = ((((size_t)s->WL.total * (cfg->precision == MPC_FP32 ? 4 : 8)) + 15) & ~(size_t)15) + 16 +
                   ((cfg->precision == MPC_FP32 ? sizeof(mpc::Problem<float>) : sizeof(mpc::Problem<double>)) + 15 & ~(size_t)15) + sizeof(mpc::WaveLayout);
     s->use_wave = (s->wave_lds <= 160u * 1024u) ? 1 : 0;
+    if (cfg->max_obstacles > 0 && !s->use_wave) {
+        set_err("mpc_create: obstacles need the LDS-resident kernel; this (n, max_obstacles, max_vertices) does not fit in 160 KB of LDS");
+        delete s;
+        return MPC_EINVAL;
+    }
     if (const char* ev = getenv("MPC_HIP_KERNEL")) { if (!strcmp(ev, "lane")) s->use_wave = 0; else if (!strcmp(ev, "wave") && s->wave_lds <= 160u * 1024u) s->use_wave = 1; }
     s->device = device;
     s->max_batch = max_batch;
@@ -244,6 +267,13 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
     if (er == hipSuccess) er = hipMalloc((void**)&s->d_dto, Bm * 8);
     if (er == hipSuccess) er = hipMalloc((void**)&s->d_status, Bm * 4);
     if (er == hipSuccess) er = hipMalloc((void**)&s->d_iters, Bm * 4);
+    if (cfg->max_obstacles > 0) {
+        const size_t O = cfg->max_obstacles, V = cfg->max_vertices > 0 ? cfg->max_vertices : 1;
+        if (er == hipSuccess) er = hipMalloc((void**)&s->d_ono, Bm * 4);
+        if (er == hipSuccess) er = hipMalloc((void**)&s->d_onv, Bm * O * 4);
+        if (er == hipSuccess) er = hipMalloc((void**)&s->d_ov, Bm * O * V * 2 * 8);
+        if (er == hipSuccess) er = hipMalloc((void**)&s->d_or, Bm * O * 8);
+    }
     if (er != hipSuccess) {
         set_err("mpc_create: allocation", er);
         mpc_destroy(s);
@@ -259,7 +289,7 @@ void mpc_destroy(mpc_solver* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    void* bufs[] = {s->ws, s->d_x0, s->d_xf, s->d_up, s->d_dtp, s->d_xi, s->d_ui, s->d_dti, s->d_xo, s->d_uo, s->d_dto, s->d_status, s->d_iters};
+    void* bufs[] = {s->d_ono, s->d_onv, s->d_ov, s->d_or, s->ws, s->d_x0, s->d_xf, s->d_up, s->d_dtp, s->d_xi, s->d_ui, s->d_dti, s->d_xo, s->d_uo, s->d_dto, s->d_status, s->d_iters};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -271,7 +301,7 @@ void mpc_destroy(mpc_solver* s) {
 
 template <typename T, int MODEL>
 static hipError_t launch_model(mpc_solver* s, const mpc::Problem<T>& P, int B, const double* x0, const double* xf, const double* up,
-                               const double* dtp, const double* xi, const double* ui, const double* dti, double* xo, double* uo,
+                               const double* dtp, const double* xi, const double* ui, const double* dti, const mpc_obstacles& ob, double* xo, double* uo,
                                double* dto, int32_t* st, int32_t* it) {
     if (s->use_wave) {
         auto kern = mpc_ipm_wave_kernel<T, MODEL>;
@@ -279,7 +309,7 @@ static hipError_t launch_model(mpc_solver* s, const mpc::Problem<T>& P, int B, c
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->wave_lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kern, dim3(B), dim3(mpc::kWave), s->wave_lds, s->stream, P, s->WL, B, x0, xf, up, dtp, xi, ui, dti, xo, uo, dto, st, it);
+        hipLaunchKernelGGL(kern, dim3(B), dim3(mpc::kWave), s->wave_lds, s->stream, P, s->WL, B, x0, xf, up, dtp, xi, ui, dti, ob, xo, uo, dto, st, it);
     } else {
         dim3 grid((B + kLanes - 1) / kLanes), block(kLanes);
         hipLaunchKernelGGL((mpc_ipm_solve_kernel<T, MODEL>), grid, block, 0, s->stream, P, s->L, (T*)s->ws, s->stride, B, x0, xf, up,
@@ -290,13 +320,13 @@ static hipError_t launch_model(mpc_solver* s, const mpc::Problem<T>& P, int B, c
 
 template <typename T>
 static hipError_t launch_prec(mpc_solver* s, const mpc::Problem<T>& P, int B, const double* x0, const double* xf, const double* up,
-                        const double* dtp, const double* xi, const double* ui, const double* dti, double* xo, double* uo,
+                        const double* dtp, const double* xi, const double* ui, const double* dti, const mpc_obstacles& ob, double* xo, double* uo,
                         double* dto, int32_t* st, int32_t* it) {
     switch (s->cfg.model) {
-        case MPC_MODEL_UNICYCLE: return launch_model<T, mpc::MODEL_UNICYCLE>(s, P, B, x0, xf, up, dtp, xi, ui, dti, xo, uo, dto, st, it);
-        case MPC_MODEL_SIMPLE_CAR: return launch_model<T, mpc::MODEL_SIMPLE_CAR>(s, P, B, x0, xf, up, dtp, xi, ui, dti, xo, uo, dto, st, it);
-        case MPC_MODEL_SIMPLE_CAR_FRONT: return launch_model<T, mpc::MODEL_SIMPLE_CAR_FRONT>(s, P, B, x0, xf, up, dtp, xi, ui, dti, xo, uo, dto, st, it);
-        default: return launch_model<T, mpc::MODEL_KINEMATIC_BICYCLE>(s, P, B, x0, xf, up, dtp, xi, ui, dti, xo, uo, dto, st, it);
+        case MPC_MODEL_UNICYCLE: return launch_model<T, mpc::MODEL_UNICYCLE>(s, P, B, x0, xf, up, dtp, xi, ui, dti, ob, xo, uo, dto, st, it);
+        case MPC_MODEL_SIMPLE_CAR: return launch_model<T, mpc::MODEL_SIMPLE_CAR>(s, P, B, x0, xf, up, dtp, xi, ui, dti, ob, xo, uo, dto, st, it);
+        case MPC_MODEL_SIMPLE_CAR_FRONT: return launch_model<T, mpc::MODEL_SIMPLE_CAR_FRONT>(s, P, B, x0, xf, up, dtp, xi, ui, dti, ob, xo, uo, dto, st, it);
+        default: return launch_model<T, mpc::MODEL_KINEMATIC_BICYCLE>(s, P, B, x0, xf, up, dtp, xi, ui, dti, ob, xo, uo, dto, st, it);
     }
 }
 
@@ -304,18 +334,27 @@ extern "C" {
 
 int mpc_solve_batch_device(mpc_solver* s, int32_t B, const double* d_x0, const double* d_xf, const double* d_u_prev,
                            const double* d_dt_prev, const double* d_x_init, const double* d_u_init, const double* d_dt_init,
-                           double* d_x_out, double* d_u_out, double* d_dt_out, int32_t* d_status, int32_t* d_iters) {
+                           const mpc_obstacles* d_obstacles, double* d_x_out, double* d_u_out, double* d_dt_out, int32_t* d_status,
+                           int32_t* d_iters) {
     g_err[0] = 0;
     if (!s || !d_x0 || !d_xf || !d_x_out || !d_u_out || !d_dt_out) { set_err("mpc_solve_batch_device: null argument"); return MPC_EINVAL; }
     if (B <= 0) return MPC_OK;
     if (B > s->max_batch) { set_err("mpc_solve_batch_device: B exceeds max_batch"); return MPC_EBATCH; }
+    mpc_obstacles ob = {nullptr, nullptr, nullptr, nullptr};
+    if (s->cfg.max_obstacles > 0) {
+        if (!d_obstacles || !d_obstacles->n_obstacles || !d_obstacles->n_vertices || !d_obstacles->vertices) {
+            set_err("mpc_solve_batch_device: the solver was created with max_obstacles > 0 but no obstacles were passed");
+            return MPC_EINVAL;
+        }
+        ob = *d_obstacles;
+    }
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipEventRecord(s->ev0, s->stream));
     hipError_t le;
     if (s->cfg.precision == MPC_FP32)
-        le = launch_prec<float>(s, s->P32, B, d_x0, d_xf, d_u_prev, d_dt_prev, d_x_init, d_u_init, d_dt_init, d_x_out, d_u_out, d_dt_out, d_status, d_iters);
+        le = launch_prec<float>(s, s->P32, B, d_x0, d_xf, d_u_prev, d_dt_prev, d_x_init, d_u_init, d_dt_init, ob, d_x_out, d_u_out, d_dt_out, d_status, d_iters);
     else
-        le = launch_prec<double>(s, s->P64, B, d_x0, d_xf, d_u_prev, d_dt_prev, d_x_init, d_u_init, d_dt_init, d_x_out, d_u_out, d_dt_out, d_status, d_iters);
+        le = launch_prec<double>(s, s->P64, B, d_x0, d_xf, d_u_prev, d_dt_prev, d_x_init, d_u_init, d_dt_init, ob, d_x_out, d_u_out, d_dt_out, d_status, d_iters);
     HIP_TRY(le);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev1, s->stream));
@@ -338,8 +377,8 @@ int mpc_last_kernel_ms(mpc_solver* s, float* ms) {
 }
 
 int mpc_solve_batch(mpc_solver* s, int32_t B, const double* x0, const double* xf, const double* u_prev, const double* dt_prev,
-                    const double* x_init, const double* u_init, const double* dt_init, double* x_out, double* u_out,
-                    double* dt_out, int32_t* status, int32_t* iters) {
+                    const double* x_init, const double* u_init, const double* dt_init, const mpc_obstacles* obstacles,
+                    double* x_out, double* u_out, double* dt_out, int32_t* status, int32_t* iters) {
     g_err[0] = 0;
     if (!s || !x0 || !xf || !x_out || !u_out || !dt_out) { set_err("mpc_solve_batch: null argument"); return MPC_EINVAL; }
     if (B <= 0) return MPC_OK;
@@ -357,8 +396,21 @@ int mpc_solve_batch(mpc_solver* s, int32_t B, const double* x0, const double* xf
         HIP_TRY(hipMemcpyAsync(s->d_ui, u_init, b * n * 2 * 8, hipMemcpyHostToDevice, q));
         HIP_TRY(hipMemcpyAsync(s->d_dti, dt_init, b * 8, hipMemcpyHostToDevice, q));
     }
+    mpc_obstacles dob = {nullptr, nullptr, nullptr, nullptr};
+    if (s->cfg.max_obstacles > 0) {
+        if (!obstacles || !obstacles->n_obstacles || !obstacles->n_vertices || !obstacles->vertices) {
+            set_err("mpc_solve_batch: the solver was created with max_obstacles > 0 but no obstacles were passed");
+            return MPC_EINVAL;
+        }
+        const size_t O = s->cfg.max_obstacles, V = s->cfg.max_vertices;
+        HIP_TRY(hipMemcpyAsync(s->d_ono, obstacles->n_obstacles, b * 4, hipMemcpyHostToDevice, q));
+        HIP_TRY(hipMemcpyAsync(s->d_onv, obstacles->n_vertices, b * O * 4, hipMemcpyHostToDevice, q));
+        HIP_TRY(hipMemcpyAsync(s->d_ov, obstacles->vertices, b * O * V * 2 * 8, hipMemcpyHostToDevice, q));
+        if (obstacles->radius) HIP_TRY(hipMemcpyAsync(s->d_or, obstacles->radius, b * O * 8, hipMemcpyHostToDevice, q));
+        dob.n_obstacles = s->d_ono; dob.n_vertices = s->d_onv; dob.vertices = s->d_ov; dob.radius = obstacles->radius ? s->d_or : nullptr;
+    }
     int rc = mpc_solve_batch_device(s, B, s->d_x0, s->d_xf, u_prev ? s->d_up : nullptr, dt_prev ? s->d_dtp : nullptr,
-                                    warm ? s->d_xi : nullptr, warm ? s->d_ui : nullptr, warm ? s->d_dti : nullptr, s->d_xo,
+                                    warm ? s->d_xi : nullptr, warm ? s->d_ui : nullptr, warm ? s->d_dti : nullptr, &dob, s->d_xo,
                                     s->d_uo, s->d_dto, s->d_status, s->d_iters);
     if (rc != MPC_OK) return rc;
     HIP_TRY(hipMemcpyAsync(x_out, s->d_xo, b * n * 3 * 8, hipMemcpyDeviceToHost, q));

@@ -62,6 +62,9 @@ struct Problem {
     T u_lb[2], u_ub[2];
     T rate_lim[4];       // du_lb0, du_lb1, du_ub0, du_ub1
     T tol, mu_init;
+    // collision avoidance (wave kernel only)
+    int n_obst, n_vert, obst_rows, footprint_kind;
+    T d_min, force_incl, cutoff, fp_radius;
 };
 
 // Algorithm constants (Waechter & Biegler 2006 names).  Compile-time so that they live in
@@ -278,6 +281,8 @@ struct StageRec {
     T ss[2], sl[2], sll;   // rate rows: sum sigma, sum sigma*lim, sum sigma*lim^2
     T gy[2], gyl;      // rate rows: sum sg*ybar, sum sg*lim*ybar
     T hx[3];           // objective gradient wrt x_k
+    T oxx, oxy, oyy;   // clearance rows: sum sigma a a' + y * hess(g) on (x, y)
+    T ogx, ogy;        // clearance rows: sum a * ybar
 };
 
 template <typename T>
@@ -307,7 +312,7 @@ MPC_HD bool riccati_step(RicState<T>& V, const StageRec<T>& r, const T q2[3], co
         Pa[i] = P[i][0] * r.a0 + P[i][1] * r.a1;
     }
     // Q~ over x (symmetric), cross x-d, d-d
-    T Q00 = P[0][0] + dx + q2[0], Q01 = P[0][1], Q11 = P[1][1] + dx + q2[1];
+    T Q00 = P[0][0] + dx + q2[0] + r.oxx, Q01 = P[0][1] + r.oxy, Q11 = P[1][1] + dx + q2[1] + r.oyy;
     T Q02 = P[0][2] + Pa[0], Q12 = P[1][2] + Pa[1];
     T Q22 = P[2][2] + T(2) * Pa[2] + r.a0 * Pa[0] + r.a1 * Pa[1] + dx + q2[2] + r.h00;
     T qd0 = e[0], qd1 = e[1], qd2 = e[2] + r.a0 * e[0] + r.a1 * e[1] + r.g[0];
@@ -331,7 +336,7 @@ MPC_HD bool riccati_step(RicState<T>& V, const StageRec<T>& r, const T q2[3], co
     T R11 = r.B[0][1] * E[0][1] + r.B[1][1] * E[1][1] + r.B[2][1] * E[2][1] + P[0][4] * r.B[0][1] + P[1][4] * r.B[1][1] + P[2][4] * r.B[2][1]
           + P[4][4] + r.h22 + r.sz[1] + du + r.ss[1] + r2[1];
     // gradients
-    T qx0 = w[0] + r.hx[0], qx1 = w[1] + r.hx[1], qx2 = w[2] + r.a0 * w[0] + r.a1 * w[1] + r.hx[2];
+    T qx0 = w[0] + r.hx[0] + r.ogx, qx1 = w[1] + r.hx[1] + r.ogy, qx2 = w[2] + r.a0 * w[0] + r.a1 * w[1] + r.hx[2];
     T ru[2];
     for (int j = 0; j < 2; ++j) ru[j] = r.B[0][j] * w[0] + r.B[1][j] * w[1] + r.B[2][j] * w[2] + w[3 + j] + r.gb[j] + r.gy[j];
     T qdd = r.f[0] * w[0] + r.f[1] * w[1] + r.f[2] * w[2] + w[5] - r.gyl + add_qd;
@@ -813,6 +818,7 @@ struct Ipm {
             r.ss[0] = r.ss[1] = r.sl[0] = r.sl[1] = r.sll = r.gy[0] = r.gy[1] = r.gyl = T(0);
             rate_terms(k, d, r.ss, r.sl, r.sll, r.gy, r.gyl);
             for (int i = 0; i < 3; ++i) r.hx[i] = T(0);
+            r.oxx = r.oxy = r.oyy = r.ogx = r.ogy = T(0);
             if (P.objective == OBJ_QUADRATIC) {
                 T xd[3] = {X(L.X, k, 0) - xf[0], X(L.X, k, 1) - xf[1], normalize_theta(X(L.X, k, 2) - xf[2])};
                 for (int i = 0; i < 3; ++i) r.hx[i] = q2[i] * xd[i];

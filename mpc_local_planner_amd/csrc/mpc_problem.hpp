@@ -34,6 +34,14 @@ inline void fill_problem(const mpc_config& c, mpc::Problem<T>& P) {
     const bool f32 = sizeof(T) == 4;
     P.tol = T(c.tol > 0 ? c.tol : (f32 ? 1e-4 : 1e-8));
     P.mu_init = T(c.mu_init > 0 ? c.mu_init : 0.1);
+    P.n_obst = c.max_obstacles > 0 ? c.max_obstacles : 0;
+    P.n_vert = c.max_vertices > 0 ? c.max_vertices : 1;
+    P.obst_rows = P.n_obst > 0 ? (c.max_obstacle_rows > 0 ? c.max_obstacle_rows : 4) : 0;
+    P.footprint_kind = c.footprint_kind;
+    P.d_min = T(c.min_obstacle_dist);
+    P.force_incl = T(c.force_inclusion_dist);
+    P.cutoff = T(c.cutoff_dist);
+    P.fp_radius = T(c.footprint_kind == MPC_FOOTPRINT_CIRCLE ? c.footprint_radius : 0.0);
 }
 
 

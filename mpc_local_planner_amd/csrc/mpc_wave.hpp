@@ -27,13 +27,16 @@ __device__ long long g_mpc_prof[4096][14];
 namespace mpc {
 
 constexpr int kWave = 64;
-constexpr int NSTG = 35;   // per-stage LQ record
+constexpr int NSTG = 40;   // per-stage LQ record (35..39: clearance-row block oxx, oxy, oyy, ogx, ogy)
 constexpr int NGAIN = 20;  // K(2x6) kappa(2) Knu(2x3)
 
 struct WaveLayout {
     int n, NS;
     int X, U, XT, UT, LAM, LAMN, SR, YR, PL, PU, DX, DU, CC, TRIG, GAIN, STG, SC, VP, ZC, total;
-    __host__ __device__ static WaveLayout make(int n) {
+    int M, O, V;                                  // clearance rows per grid point, obstacles, vertices per obstacle
+    int OS, OY, OI, OG, OAX, OAY, OHK;            // per-row slack, multiplier, obstacle index, cached g, gradient, curvature
+    int GV, GNV, GR, GC;                          // obstacle geometry: vertices, vertex counts, radii, centroids
+    __host__ __device__ static WaveLayout make(int n, int M = 0, int O = 0, int V = 1) {
         WaveLayout L;
         L.n = n;
         L.NS = n;
@@ -49,6 +52,9 @@ struct WaveLayout {
         L.SC = o; o += 8;     // scalars: D, DT, DD, PDL, PDU
         L.VP = o; o += 36;    // value-function matrix P of the stage being eliminated (column-major), column-parallel sweep
         L.ZC = o; o += 8;     // constants: 6 zeros, then 1.0
+        L.M = M; L.O = O; L.V = V;
+        L.OS = take(M); L.OY = take(M); L.OI = take(M); L.OG = take(M); L.OAX = take(M); L.OAY = take(M); L.OHK = take(M);
+        L.GV = o; o += 2 * O * V; L.GNV = o; o += O; L.GR = o; o += O; L.GC = o; o += 2 * O;
         L.total = o;
         return L;
     }
@@ -127,11 +133,135 @@ struct IpmWave {
         return t_min(t_max(v, lb + pl), ub - pu);
     }
 
+    // ---------------------------------------------------------------- clearance rows
+    // distance of the point (px,py) to obstacle j (teb semantics: point / segment / polygon, 0 inside a polygon);
+    // returns dist (>= 0, obstacle radius already subtracted), unit normal from the closest point to (px,py) and
+    // hk = 1/|p-q| if the closest feature is a vertex (or a point/circle obstacle), 0 on an edge interior.
+    __device__ void obst_eval(T px, T py, int j, T& dist, T& nx, T& ny, T& hk) const {
+        const int nv = (int)sm[L.GNV + j];
+        const T* v = sm + L.GV + 2 * L.V * j;
+        T best = T(1e30), bx = T(0), by = T(0);
+        bool vert = true;
+        if (nv <= 1) { bx = v[0]; by = v[1]; T dx = px - bx, dy = py - by; best = dx * dx + dy * dy; }
+        else {
+            bool inside = false;
+            const int ne = nv == 2 ? 1 : nv;
+            for (int e = 0; e < ne; ++e) {
+                const int e2 = (e + 1) % nv;
+                const T ax = v[2 * e], ay = v[2 * e + 1], cx = v[2 * e2], cy = v[2 * e2 + 1];
+                const T abx = cx - ax, aby = cy - ay;
+                const T sq = abx * abx + aby * aby;
+                T t = sq > T(0) ? ((px - ax) * abx + (py - ay) * aby) / sq : T(0);
+                t = t_min(T(1), t_max(T(0), t));
+                const T qx = ax + t * abx, qy = ay + t * aby;
+                const T d2 = (px - qx) * (px - qx) + (py - qy) * (py - qy);
+                if (d2 < best) { best = d2; bx = qx; by = qy; vert = !(t > T(0) && t < T(1)); }
+                if (nv >= 3 && ((ay > py) != (cy > py)) && (px < (cx - ax) * (py - ay) / (cy - ay) + ax)) inside = !inside;
+            }
+            if (inside) { dist = T(0); nx = T(0); ny = T(0); hk = T(0); return; }
+        }
+        const T dd = sqrt(best);
+        if (dd > T(0)) { nx = (px - bx) / dd; ny = (py - by) / dd; hk = vert ? T(1) / dd : T(0); }
+        else { nx = T(0); ny = T(0); hk = T(0); }
+        dist = dd - sm[L.GR + j];
+    }
+
+    // copies the instance's obstacles into LDS, computes centroids (teb Obstacle::getCentroid)
+    __device__ void load_obstacles(const int32_t* n_obst, const int32_t* n_vert, const double* verts, const double* radius, int inst) {
+        const int O = L.O, V = L.V;
+        const int no = n_obst ? n_obst[inst] : 0;
+        for (int j = lane; j < O; j += kWave) {
+            int nv = j < no ? n_vert[(long)inst * O + j] : 0;
+            if (nv > V) nv = V;
+            sm[L.GNV + j] = T(nv);
+            sm[L.GR + j] = (radius && j < no) ? T(radius[(long)inst * O + j]) : T(0);
+            const double* vv = verts + ((long)inst * O + j) * V * 2;
+            T cx = T(0), cy = T(0);
+            for (int e = 0; e < V; ++e) {
+                T x = e < nv ? T(vv[2 * e]) : T(0), y = e < nv ? T(vv[2 * e + 1]) : T(0);
+                sm[L.GV + 2 * V * j + 2 * e] = x; sm[L.GV + 2 * V * j + 2 * e + 1] = y;
+            }
+            const T* v = sm + L.GV + 2 * V * j;
+            if (nv >= 3) {
+                T a = T(0), sx = T(0), sy = T(0), mx = T(0), my = T(0);
+                for (int e = 0; e < nv; ++e) {
+                    const int e2 = (e + 1) % nv;
+                    T cr = v[2 * e] * v[2 * e2 + 1] - v[2 * e2] * v[2 * e + 1];
+                    a += cr; sx += (v[2 * e] + v[2 * e2]) * cr; sy += (v[2 * e + 1] + v[2 * e2 + 1]) * cr;
+                    mx += v[2 * e]; my += v[2 * e + 1];
+                }
+                a *= T(0.5);
+                if (t_abs(a) < T(1e-12)) { cx = mx / T(nv); cy = my / T(nv); }
+                else { cx = sx / (T(6) * a); cy = sy / (T(6) * a); }
+            } else if (nv == 2) { cx = T(0.5) * (v[0] + v[2]); cy = T(0.5) * (v[1] + v[3]); }
+            else if (nv == 1) { cx = v[0]; cy = v[1]; }
+            sm[L.GC + 2 * j] = cx; sm[L.GC + 2 * j + 1] = cy;
+        }
+    }
+
+    // StageInequalitySE2::update (src/optimal_control/stage_inequality_se2.cpp:50-162): relevant obstacles of every
+    // grid point from the current vertex values; at most M rows are kept (forced ones first, then left, right).
+    __device__ void associate_obstacles() const {
+        const int n = L.n, M = L.M;
+        for (int k = lane; k < n; k += kWave) {
+            int cnt = 0;
+            for (int m = 0; m < M; ++m) F(L.OI, m, k) = T(-1);
+            if (k >= 1) {
+                const T px = F(L.X, 0, k), py = F(L.X, 1, k), th = F(L.X, 2, k);
+                T s, c;
+                t_sincos(th, &s, &c);
+                T lmin = T(1e30), rmin = T(1e30);
+                int lidx = -1, ridx = -1;
+                for (int j = 0; j < L.O; ++j) {
+                    if ((int)sm[L.GNV + j] <= 0) continue;
+                    T dist, nx, ny, hk;
+                    obst_eval(px, py, j, dist, nx, ny, hk);
+                    dist -= P.fp_radius;
+                    if (dist < P.force_incl) { if (cnt < M) { F(L.OI, cnt, k) = T(j); ++cnt; } continue; }
+                    if (dist > P.cutoff) continue;
+                    // cross2d(orientation, centroid) with the centroid as an ABSOLUTE vector (:121)
+                    if (c * sm[L.GC + 2 * j + 1] - sm[L.GC + 2 * j] * s > T(0)) { if (dist < lmin) { lmin = dist; lidx = j; } }
+                    else { if (dist < rmin) { rmin = dist; ridx = j; } }
+                }
+                if (lidx >= 0 && cnt < M) { F(L.OI, cnt, k) = T(lidx); ++cnt; }
+                if (ridx >= 0 && cnt < M) { F(L.OI, cnt, k) = T(ridx); ++cnt; }
+            }
+        }
+    }
+
+    // value / gradient / curvature cache of the clearance rows of grid point k at position (px,py); returns row count
+    __device__ __forceinline__ bool obst_row(int k, int m, T px, T py, T& g, T& ax, T& ay, T& hk) const {
+        const int j = (int)F(L.OI, m, k);
+        if (j < 0) return false;
+        T dist, nx, ny;
+        obst_eval(px, py, j, dist, nx, ny, hk);
+        g = P.d_min - (dist - P.fp_radius);
+        ax = -nx; ay = -ny;
+        return true;
+    }
+
     // ---------------------------------------------------------------- point evaluation (parallel)
     // trig cache + c_k for the point (XB, UB, d); returns wave-reduced sum|c|, objective
-    __device__ void eval_point(int XB, int UB, T d, T& theta_c, T& fobj) const {
+    __device__ void eval_point(int XB, int UB, T d, T& theta_c, T& fobj, T alpha = T(0), bool trial = false) const {
         const int n = L.n;
         T th = T(0), fo = T(0);
+        // clearance rows (non-linear): |g(x_k) + s| with the trial slack s + alpha*ds
+        if (L.M > 0) {
+            for (int k = lane; k < n - 1; k += kWave) {
+                if (k < 1) continue;
+                const T px = F(XB, 0, k), py = F(XB, 1, k);
+                for (int m = 0; m < L.M; ++m) {
+                    T g, ax, ay, hk;
+                    if (!obst_row(k, m, px, py, g, ax, ay, hk)) continue;
+                    T s = F(L.OS, m, k);
+                    if (trial) {
+                        const T jdz = F(L.OAX, m, k) * F(L.DX, 0, k) + F(L.OAY, m, k) * F(L.DX, 1, k);
+                        s += alpha * (-(F(L.OG, m, k) + s) - jdz);
+                    }
+                    th += t_abs(g + s);
+                }
+            }
+        }
         for (int k = lane; k < n - 1; k += kWave) {
             T xk[3] = {F(XB, 0, k), F(XB, 1, k), F(XB, 2, k)};
             T xn[3] = {F(XB, 0, k + 1), F(XB, 1, k + 1), F(XB, 2, k + 1)};
@@ -177,6 +307,17 @@ struct IpmWave {
                 T s = F(L.SR, q, k);
                 if (trial) s += alpha * (-(row_val(L.U, SCL(SC_D), k, q) + s) - row_jdz(k, q, dd));
                 acc.mul(s);
+            }
+            if (L.M > 0 && k >= 1 && k < n - 1) {
+                for (int m = 0; m < L.M; ++m) {
+                    if (F(L.OI, m, k) < T(0)) continue;
+                    T s = F(L.OS, m, k);
+                    if (trial) {
+                        const T jdz = F(L.OAX, m, k) * F(L.DX, 0, k) + F(L.OAY, m, k) * F(L.DX, 1, k);
+                        s += alpha * (-(F(L.OG, m, k) + s) - jdz);
+                    }
+                    acc.mul(s);
+                }
             }
         }
         if (lane == 0 && P.dt_free) { acc.mul(d - P.dt_lb); acc.mul(P.dt_ub - d); }
@@ -228,9 +369,24 @@ struct IpmWave {
                     gu[0] = T(2) * P.R[0] * v; gu[1] = T(2) * P.R[1] * w;
                 }
                 S_(32, k) = gx[0]; S_(33, k) = gx[1]; S_(34, k) = gx[2];
+                T osx = T(0), osy = T(0);
+                if (L.M > 0 && k >= 1) {
+                    const T px = F(L.X, 0, k), py = F(L.X, 1, k);
+                    for (int m = 0; m < L.M; ++m) {
+                        T g, ax, ay, hk;
+                        if (!obst_row(k, m, px, py, g, ax, ay, hk)) continue;
+                        F(L.OG, m, k) = g; F(L.OAX, m, k) = ax; F(L.OAY, m, k) = ay; F(L.OHK, m, k) = hk;
+                        const T s = F(L.OS, m, k), y = F(L.OY, m, k);
+                        const T res = g + s;
+                        rp = t_max(rp, t_abs(res)); th += t_abs(res);
+                        cmin = t_min(cmin, s * y); cmax = t_max(cmax, s * y);
+                        sb += y; nb += 1;
+                        osx += y * ax; osy += y * ay;
+                    }
+                }
                 if (k >= 1) {
-                    T r0 = gx[0] + lam[0] - F(L.LAM, 0, k - 1);
-                    T r1 = gx[1] + lam[1] - F(L.LAM, 1, k - 1);
+                    T r0 = gx[0] + osx + lam[0] - F(L.LAM, 0, k - 1);
+                    T r1 = gx[1] + osy + lam[1] - F(L.LAM, 1, k - 1);
                     T r2 = gx[2] + lam[2] + d * gq[0] - F(L.LAM, 2, k - 1);
                     rd = t_max(rd, t_max(t_abs(r0), t_max(t_abs(r1), t_abs(r2))));
                 }
@@ -321,6 +477,24 @@ struct IpmWave {
                 ss[j] += sig; ssl[j] += sig * lim; sll += sig * lim * lim;
                 gy[j] += sg * ybar; gyl += sg * lim * ybar;
             }
+            {
+                T oxx = T(0), oxy = T(0), oyy = T(0), ogx = T(0), ogy = T(0);
+                if (L.M > 0 && k >= 1 && k < n - 1) {
+                    for (int m = 0; m < L.M; ++m) {
+                        if (F(L.OI, m, k) < T(0)) continue;
+                        const T s = F(L.OS, m, k), y = F(L.OY, m, k), g = F(L.OG, m, k);
+                        const T ax = F(L.OAX, m, k), ay = F(L.OAY, m, k), hk = F(L.OHK, m, k);
+                        const T sig = y / s;
+                        const T ybar = mu / s + sig * (g + s);
+                        // hess(g) = -hk (I - a a')
+                        oxx += sig * ax * ax - y * hk * (T(1) - ax * ax);
+                        oxy += sig * ax * ay + y * hk * ax * ay;
+                        oyy += sig * ay * ay - y * hk * (T(1) - ay * ay);
+                        ogx += ax * ybar; ogy += ay * ybar;
+                    }
+                }
+                S_(35, k) = oxx; S_(36, k) = oxy; S_(37, k) = oyy; S_(38, k) = ogx; S_(39, k) = ogy;
+            }
             S_(24, k) = ss[0]; S_(25, k) = ss[1];
             S_(26, k) = ssl[0]; S_(27, k) = ssl[1];
             S_(28, k) = sll;
@@ -360,6 +534,7 @@ struct IpmWave {
                 r.ss[j] = S_(24 + j, k); r.sl[j] = S_(26 + j, k); r.gy[j] = S_(29 + j, k);
             }
             r.sll = S_(28, k); r.gyl = S_(31, k);
+            r.oxx = S_(35, k); r.oxy = S_(36, k); r.oyy = S_(37, k); r.ogx = S_(38, k); r.ogy = S_(39, k);
             T add_dd = T(0), add_qd = T(0);
             if (k == 0) {
                 if (P.objective == OBJ_MIN_TIME) add_qd += T(n - 1);
@@ -458,7 +633,8 @@ struct IpmWave {
             h[7] = (B01 * z[0] + B11 * z[1]) + (B21 * z[2] + z[4]);
             // stage cost column
             const T dxr = k >= 1 ? delta : T(0);
-            if (c < 2) { h[c] += dxr + q2[c]; }
+            if (c == 0) { h[0] += dxr + q2[0] + rec[35]; h[1] += rec[36]; }
+            else if (c == 1) { h[1] += dxr + q2[1] + rec[37]; h[0] += rec[36]; }
             else if (c == 2) { h[2] += dxr + q2[2] + rec[11]; h[5] += rec[17]; h[6] += rec[12]; h[7] += rec[13]; }
             else if (c == 3) { h[3] += rec[24]; h[5] += rec[26]; h[6] -= rec[24]; }
             else if (c == 4) { h[4] += rec[25]; h[5] += rec[27]; h[7] -= rec[25]; }
@@ -479,7 +655,7 @@ struct IpmWave {
                     if (P.objective == OBJ_MIN_TIME) add_qd += T(n - 1);
                     if (P.dt_free) add_qd += -mu / (d - P.dt_lb) + mu / (P.dt_ub - d);
                 }
-                h[0] += rec[32]; h[1] += rec[33]; h[2] += rec[34];
+                h[0] += rec[32] + rec[38]; h[1] += rec[33] + rec[39]; h[2] += rec[34];
                 h[3] -= rec[29]; h[4] -= rec[30]; h[5] += add_qd - rec[31];
                 h[6] += rec[22] + rec[29]; h[7] += rec[23] + rec[30];
             }
@@ -592,6 +768,8 @@ struct IpmWave {
                 T qd = delta + (P.objective == OBJ_QUADRATIC ? T(2) * P.Q[i] : T(0));
                 t[i] = qd * dx[i] + S_(32 + i, k);
             }
+            t[0] += S_(35, k) * dx[0] + S_(36, k) * dx[1] + S_(38, k);
+            t[1] += S_(36, k) * dx[0] + S_(37, k) * dx[1] + S_(39, k);
             t[2] += S_(11, k) * dx[2] + S_(12, k) * duv + S_(13, k) * duw + S_(17, k) * dd
                   + S_(0, k) * lp[0] + S_(1, k) * lp[1];
             lp[0] += t[0]; lp[1] += t[1]; lp[2] += t[2];
@@ -671,6 +849,22 @@ struct IpmWave {
                 ftb(s, ds, tau, a_p);
                 ftb(y, dy, tau, a_d);
             }
+            if (L.M > 0 && k >= 1 && k < n - 1) {
+                for (int m = 0; m < L.M; ++m) {
+                    if (F(L.OI, m, k) < T(0)) continue;
+                    const T jdz = F(L.OAX, m, k) * F(L.DX, 0, k) + F(L.OAY, m, k) * F(L.DX, 1, k);
+                    const T s = F(L.OS, m, k), y = F(L.OY, m, k);
+                    const T res = F(L.OG, m, k) + s;
+                    const T sig = y / s;
+                    const T ybar = mu / s + sig * res;
+                    const T ds = -res - jdz;
+                    const T dy = ybar + sig * jdz - y;
+                    hdz += ybar * jdz;
+                    dphi -= (mu / s) * ds;
+                    ftb(s, ds, tau, a_p);
+                    ftb(y, dy, tau, a_d);
+                }
+            }
         }
         Fwd o;
         o.hdz = wave_sum(hdz); o.clam = wave_sum(clam); o.dz2 = wave_sum(dz2); o.dphi = wave_sum(dphi);
@@ -716,6 +910,19 @@ struct IpmWave {
                 sn[q] = s + alpha * ds;
                 T yv = y + a_d * dy;
                 yn[q] = t_min(t_max(yv, mu / (kS * sn[q])), kS * mu / sn[q]);
+            }
+            if (L.M > 0 && k >= 1 && k < n - 1) {
+                for (int m = 0; m < L.M; ++m) {
+                    if (F(L.OI, m, k) < T(0)) continue;
+                    const T jdz = F(L.OAX, m, k) * F(L.DX, 0, k) + F(L.OAY, m, k) * F(L.DX, 1, k);
+                    const T s = F(L.OS, m, k), y = F(L.OY, m, k);
+                    const T res = F(L.OG, m, k) + s;
+                    const T sig = y / s;
+                    const T so = s + alpha * (-res - jdz);
+                    T yo = y + a_d * (mu / s + sig * res + sig * jdz - y);
+                    yo = t_min(t_max(yo, mu / (kS * so)), kS * mu / so);
+                    F(L.OS, m, k) = so; F(L.OY, m, k) = yo;
+                }
             }
             sync();      // all lanes of this chunk have read their neighbours' old controls
             for (int q = 0; q < 4; ++q) if (row_on(k, q)) { F(L.SR, q, k) = sn[q]; F(L.YR, q, k) = yn[q]; }
@@ -813,6 +1020,7 @@ struct IpmWave {
             for (int j = 0; j < 2; ++j) F(L.U, j, k) = push_interior(F(L.U, j, k), P.u_lb[j], P.u_ub[j]);
         if (lane == 0 && P.dt_free) SCL(SC_D) = push_interior(SCL(SC_D), P.dt_lb, P.dt_ub);
         sync();
+        if (L.M > 0) { associate_obstacles(); sync(); }
         mu = P.mu_init; rho = T(0); delta_last = T(0);
         const T d = SCL(SC_D);
         for (int k = lane; k < n; k += kWave) {
@@ -820,6 +1028,16 @@ struct IpmWave {
                 T s = T(1), y = T(0);
                 if (row_on(k, q)) { s = t_max(-row_val(L.U, d, k, q), Algo<T>::slack_push); y = mu / s; }
                 F(L.SR, q, k) = s; F(L.YR, q, k) = y;
+            }
+            if (L.M > 0) {
+                const T px = F(L.X, 0, k), py = F(L.X, 1, k);
+                for (int m = 0; m < L.M; ++m) {
+                    T s = T(1), y = T(0), g, ax, ay, hk;
+                    if (k >= 1 && k < n - 1) {
+                        if (obst_row(k, m, px, py, g, ax, ay, hk)) { s = t_max(-g, Algo<T>::slack_push); y = mu / s; }
+                    } else F(L.OI, m, k) = T(-1);
+                    F(L.OS, m, k) = s; F(L.OY, m, k) = y;
+                }
             }
             if (k < n - 1) {
                 for (int j = 0; j < 2; ++j) {
@@ -918,7 +1136,7 @@ struct IpmWave {
             for (int ls = 0; ls < Algo<T>::max_ls; ++ls) {
                 if (ls > 0) alpha *= T(0.5);
                 T phit, tht;
-                MPC_TICK(6, make_trial(alpha); sync(); eval_point(L.XT, L.UT, SCL(SC_DT), th_t, f_t);
+                MPC_TICK(6, make_trial(alpha); sync(); eval_point(L.XT, L.UT, SCL(SC_DT), th_t, f_t, alpha, true);
                          tht = th_t + (T(1) - alpha) * theta_rows;
                          phit = f_t - mu * barrier_logs(L.UT, SCL(SC_DT), alpha, true, dd) + rho * tht; sync());
 #ifdef MPC_PROFILE

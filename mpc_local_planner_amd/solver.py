@@ -13,7 +13,7 @@ from typing import Optional
 import numpy as np
 
 from . import _lib
-from ._abi import MpcConfig, MPC_OK
+from ._abi import MpcConfig, MpcObstacles, MPC_OK
 
 
 class MpcError(RuntimeError):
@@ -78,9 +78,11 @@ class BatchSolver:
         self._check(self._lib.mpc_reset(self._h))
 
     # ---- host buffers (numpy) ------------------------------------------------
-    def solve(self, x0, xf, u_prev=None, dt_prev=None, init=None) -> BatchResult:
+    def solve(self, x0, xf, u_prev=None, dt_prev=None, init=None, obstacles=None) -> BatchResult:
         """One control cycle for B instances (Controller::step, src/controller.cpp:111-179).
-        init = (x_init (B,n,3), u_init (B,n,2), dt_init (B,)) or None for the reference cold start."""
+        init = (x_init (B,n,3), u_init (B,n,2), dt_init (B,)) or None for the reference cold start.
+        obstacles = (n_obstacles (B,), n_vertices (B,O), vertices (B,O,V,2)[, radius (B,O)]) when the solver was
+        created with max_obstacles > 0."""
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
         B = x0.shape[0]
         n = self.n
@@ -96,19 +98,34 @@ class BatchSolver:
         do = np.empty(B)
         st = np.empty(B, dtype=np.int32)
         it = np.empty(B, dtype=np.int32)
+        ob = None
+        keep = None
+        if obstacles is not None:
+            O, V = int(self.cfg.max_obstacles), int(self.cfg.max_vertices)
+            no = np.ascontiguousarray(obstacles[0], dtype=np.int32)
+            nv = np.ascontiguousarray(obstacles[1], dtype=np.int32)
+            vv = _as_f64(obstacles[2], (B, O, V, 2))
+            rr = _as_f64(obstacles[3], (B, O)) if len(obstacles) > 3 and obstacles[3] is not None else None
+            if no.shape != (B,) or nv.shape != (B, O):
+                raise ValueError("obstacle arrays have the wrong shape")
+            keep = (no, nv, vv, rr)
+            ob = MpcObstacles(no.ctypes.data, nv.ctypes.data, vv.ctypes.data, rr.ctypes.data if rr is not None else None)
         rc = self._lib.mpc_solve_batch(self._h, B, _addr(x0), _addr(xf), _addr(u_prev), _addr(dt_prev), _addr(xi), _addr(ui),
-                                       _addr(di), _addr(xo), _addr(uo), _addr(do), _addr(st), _addr(it))
+                                       _addr(di), C.byref(ob) if ob is not None else None, _addr(xo), _addr(uo), _addr(do),
+                                       _addr(st), _addr(it))
         self._check(rc)
         return BatchResult(xo, uo, do, st, it)
 
     # ---- device buffers (raw HBM addresses, e.g. torch tensors' data_ptr()) -----
     def solve_device(self, B: int, x0: int, xf: int, u_prev: Optional[int], dt_prev: Optional[int], x_init: Optional[int],
                      u_init: Optional[int], dt_init: Optional[int], x_out: int, u_out: int, dt_out: int,
-                     status: Optional[int], iters: Optional[int]) -> None:
+                     status: Optional[int], iters: Optional[int], obstacles=None) -> None:
         """Asynchronous solve on the solver's stream; all arguments are device addresses (ints)."""
         v = lambda p: C.c_void_p(p) if p else None
+        ob = MpcObstacles(*obstacles) if obstacles is not None else None     # 4 device addresses
         rc = self._lib.mpc_solve_batch_device(self._h, B, v(x0), v(xf), v(u_prev), v(dt_prev), v(x_init), v(u_init), v(dt_init),
-                                              v(x_out), v(u_out), v(dt_out), v(status), v(iters))
+                                              C.byref(ob) if ob is not None else None, v(x_out), v(u_out), v(dt_out), v(status),
+                                              v(iters))
         self._check(rc)
 
     def synchronize(self):

@@ -45,3 +45,42 @@ def unicycle_quadratic_inputs(batch: int, seed: int = SEED_CONFIG3, goal_range=(
 def bicycle_min_time_inputs(batch: int, seed: int = SEED_CONFIG5, goal_range=(5.0, 40.0)):
     """config 5: kinematic bicycle, long horizon; goal range scaled to n=120."""
     return carlike_min_time_inputs(batch, seed, goal_range)
+
+
+def unicycle_obstacle_inputs(batch: int, seed: int = SEED_CONFIG3, n_obst: int = 16, max_vertices: int = 6, goal_range=(3.0, 10.0),
+                             clearance: float = 0.5):
+    """config 3: unicycle quadratic-form instances with `n_obst` convex polygons (4..max_vertices vertices, circum-radius
+    U[.2,.6]) placed beside the straight line from start to goal (lateral offset U[r+.3, r+1.5] either side: gaps stay wider than 2*min_obstacle_dist), at least
+    `clearance` away from x0 and xf.
+    Returns (x0, xf, u_prev, dt_prev, (n_obstacles, n_vertices, vertices))."""
+    rng = np.random.default_rng(seed)
+    th0 = rng.uniform(-np.pi, np.pi, batch)
+    r = rng.uniform(goal_range[0], goal_range[1], batch)
+    bearing = th0 + rng.uniform(-0.5, 0.5, batch)
+    yaw = bearing + rng.uniform(-0.5, 0.5, batch)
+    x0 = np.stack([np.zeros(batch), np.zeros(batch), th0], axis=1)
+    xf = np.stack([r * np.cos(bearing), r * np.sin(bearing), yaw], axis=1)
+    nv = rng.integers(4, max_vertices + 1, size=(batch, n_obst)).astype(np.int32)
+    verts = np.zeros((batch, n_obst, max_vertices, 2))
+    for b in range(batch):
+        d = xf[b, :2] - x0[b, :2]
+        L = np.linalg.norm(d)
+        e = d / L
+        nrm = np.array([-e[1], e[0]])
+        for o in range(n_obst):
+            rad = rng.uniform(0.2, 0.6)
+            # beside the straight start->goal line (the reference's initial plan is collision free): the polygon never
+            # contains a point of the initial guess (teb's distance is 0 inside a polygon => zero gradient), but it is
+            # often closer than min_obstacle_dist, so the clearance rows start violated and become active
+            for _ in range(100):
+                off = rng.choice([-1.0, 1.0]) * rng.uniform(rad + 0.3, rad + 1.5)
+                c = x0[b, :2] + rng.uniform(0.0, 1.0) * d + off * nrm
+                if np.linalg.norm(c - x0[b, :2]) > rad + clearance and np.linalg.norm(c - xf[b, :2]) > rad + clearance:
+                    break
+            k = nv[b, o]
+            ang = np.sort(rng.uniform(0, 2 * np.pi, k))
+            ang = ang[0] + np.arange(k) * 2 * np.pi / k + rng.uniform(-0.2, 0.2, k) * (2 * np.pi / k)   # convex by construction
+            verts[b, o, :k, 0] = c[0] + rad * np.cos(ang)
+            verts[b, o, :k, 1] = c[1] + rad * np.sin(ang)
+    no = np.full(batch, n_obst, dtype=np.int32)
+    return x0, xf, np.zeros((batch, 2)), np.full(batch, 0.2), (no, nv, verts)

@@ -527,7 +527,7 @@ def time_series_output(traj: Trajectory):
 # obstacle association            src/optimal_control/stage_inequality_se2.cpp:50-162
 # --------------------------------------------------------------------------
 
-def associate_obstacles(cfg: OcpConfig, traj: Trajectory, obstacles: List[Obstacle]):
+def associate_obstacles(cfg: OcpConfig, traj: Trajectory, obstacles: List[Obstacle], max_rows: Optional[int] = None):
     """Returns (relevant[k] -> list of obstacle indices, relevant_dyn[k]) for k=0..n-1
     (k=0 stays empty; k=n-1 is computed but never used by createEdges)."""
     n = traj.x.shape[0]
@@ -558,6 +558,8 @@ def associate_obstacles(cfg: OcpConfig, traj: Trajectory, obstacles: List[Obstac
             rel[k].append(lidx)
         if ridx is not None:
             rel[k].append(ridx)
+        if max_rows is not None:
+            rel[k] = rel[k][:max_rows]      # capacity of the batched solver (forced ones first, then left, right)
     return rel, rel_dyn
 
 

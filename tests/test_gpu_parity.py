@@ -195,3 +195,45 @@ def test_fp32_path_and_other_models(m, c_oracle):
     rf = sf.solve(x0[:16] * 0.3, xf[:16] * 0.3, up[:16], dtp[:16])
     assert (rf.status == 0).sum() >= 10
     sf.close()
+
+
+def test_obstacle_rows_golden_and_properties(m):
+    """Clearance rows (stage_inequality_se2.cpp:50-175): association on the device + d_min - dist <= 0 rows.
+    (i) golden fixtures of the numpy oracle (same association, same iterate sequence); (ii) on a config-3-shaped batch
+    (n=80, 16 convex polygons) every converged trajectory keeps every ASSOCIATED obstacle at >= d_min."""
+    from oracle import se2_nlp as R
+    g = np.load(os.path.join(GOLD, "unicycle_quadratic_obstacles_n30.npz"))
+    B, O, V = g["x0"].shape[0], g["vertices"].shape[1], g["vertices"].shape[2]
+    cfg = m.config_unicycle_quadratic(30, max_obstacles=O, max_vertices=V, max_obstacle_rows=int(g["max_rows"]))
+    s = m.BatchSolver(cfg, max_batch=B)
+    r = s.solve(g["x0"], g["xf"], g["u_prev"], g["dt_prev"], obstacles=(g["n_obstacles"], g["n_vertices"], g["vertices"]))
+    assert (r.status == 0).all()
+    assert np.abs(r.x - g["x"]).max() < 1e-6 and np.abs(r.u - g["u"]).max() < 1e-6
+    assert (np.abs(r.iters - g["iters"]) <= np.maximum(2, 0.1 * g["iters"])).all()
+    # obstacles are required once the solver was created for them
+    with pytest.raises(m.MpcError):
+        s.solve(g["x0"], g["xf"], g["u_prev"], g["dt_prev"])
+    s.close()
+    # config 3 shape
+    n, B, O, V, M = 80, 256, 16, 6, 4
+    x0, xf, up, dtp, (no, nv, verts) = m.workloads.unicycle_obstacle_inputs(B, n_obst=O, max_vertices=V)
+    cfg = m.config_unicycle_quadratic(n, max_obstacles=O, max_vertices=V, max_obstacle_rows=M)
+    s = m.BatchSolver(cfg, max_batch=B)
+    r = s.solve(x0, xf, up, dtp, obstacles=(no, nv, verts))
+    ok = r.status == 0
+    assert ok.mean() > 0.6
+    ocfg = R.config_unicycle_quadratic(n)
+    checked = 0
+    for i in np.nonzero(ok)[0][:24]:
+        obs = [R.Obstacle(R.OBST_POLYGON, verts[i, o, :nv[i, o]]) for o in range(no[i])]
+        rel, _ = R.associate_obstacles(ocfg, R.cold_start(ocfg, x0[i], xf[i]), obs, max_rows=M)
+        for k in range(1, n - 1):
+            for j in rel[k]:
+                assert R.footprint_distance(R.FOOTPRINT_POINT, (), r.x[i, k], obs[j]) >= cfg.min_obstacle_dist - 1e-6
+                checked += 1
+        # and the dynamics / boxes still hold
+        nlp = R.ReferenceNlp(ocfg, R.CycleInputs(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=float(dtp[i])))
+        z = nlp.pack(R.Trajectory(r.x[i], r.u[i, :-1], float(r.dt[i])))
+        assert np.abs(nlp.equalities(z)).max() < 1e-6
+    assert checked > 500
+    s.close()

@@ -131,3 +131,23 @@ def test_c_oracle_warm_start_and_thread_invariance(c_oracle):
         assert nlp.inequalities(z).max() < 1e-6
         np.testing.assert_array_equal(w[0][i, 0], x0[i])
         np.testing.assert_array_equal(w[0][i, -1], xf[i])
+
+
+def test_numpy_ipm_with_obstacle_rows_reproduces_golden_and_keeps_clearance():
+    g = np.load(os.path.join(GOLD, "unicycle_quadratic_obstacles_n30.npz"))
+    cfg = R.config_unicycle_quadratic(30)
+    M = int(g["max_rows"])
+    for i in range(2):
+        nv = g["n_vertices"][i]
+        obs = [R.Obstacle(R.OBST_POLYGON, g["vertices"][i, o, :nv[o]]) for o in range(g["n_obstacles"][i])]
+        inp = R.CycleInputs(x0=g["x0"][i], xf=g["xf"][i], u_prev=g["u_prev"][i], dt_prev=float(g["dt_prev"][i]), obstacles=obs)
+        init = R.cold_start(cfg, inp.x0, inp.xf)
+        rel, _ = R.associate_obstacles(cfg, init, obs, max_rows=M)
+        assert max(len(q) for q in rel) <= M and rel[0] == []
+        res = I.solve(cfg, inp, init, relevant=rel, opt=I.IpmOptions(globalization="merit", max_iter=100))
+        assert res.status == 0
+        assert np.abs(res.traj.x - g["x"][i]).max() < 1e-6
+        # reference-form rows: d_min - dist <= 0 for every associated obstacle
+        nlp = R.ReferenceNlp(cfg, inp, relevant=rel)
+        gz = nlp.inequalities(nlp.pack(res.traj))
+        assert gz.max() < 1e-7
