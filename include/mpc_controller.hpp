@@ -1,0 +1,206 @@
+// mpc_controller.hpp -- ROS-free C++ host facade with the shape of mpc_local_planner's Controller
+// (reference: mpc_local_planner/include/mpc_local_planner/controller.h:61-104,
+//             mpc_local_planner/src/controller.cpp:102-179, 807-857).
+//
+// Header-only; all arithmetic of the solve happens behind the C ABI (include/mpc_hip.h, libmpc_hip.so).  What lives
+// here is exactly the host logic the reference runs around PredictiveController::step:
+//   * goal -> xf, start/odometry -> x0 (state == pose for every model, base_robot_se2.h),
+//   * re-initialisation decision (every k steps / goal jumped), src/controller.cpp:152-158,
+//   * initial state trajectory from the plan (time-equidistant poses, yaw from finite differences),
+//     src/controller.cpp:807-857, sampled onto the grid with the SE2-aware linear interpolation of
+//     src/utils/time_series_se2.cpp:34-111  (full_discretization_grid_base_se2.cpp:192-239),
+//   * warm start: previous solution handed back with x_0 overwritten (variable grid: no shifting,
+//     finite_differences_variable_grid_se2.h:85),
+//   * result time series as getStateAndControlTimeSeries (full_discretization_grid_base_se2.cpp:579-615).
+// Types carry the reference's names without ROS: PoseSE2 (teb), Twist (geometry_msgs), TimeSeries (corbo).
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <string>
+#include <vector>
+
+extern "C" {
+#include "mpc_hip.h"
+}
+
+namespace mpc_local_planner_amd {
+
+struct PoseSE2 {
+    double x = 0, y = 0, theta = 0;
+};
+struct Twist {
+    double linear_x = 0, linear_y = 0, angular_z = 0;
+};
+
+// corbo::TimeSeries, reduced to what Controller::step fills: times + column-major values
+struct TimeSeries {
+    int dim = 0;
+    std::vector<double> time;
+    std::vector<double> values;   // values[dim * k + i]
+    void clear() { time.clear(); values.clear(); }
+    void add(double t, const double* v, int d) { dim = d; time.push_back(t); values.insert(values.end(), v, v + d); }
+    int size() const { return (int)time.size(); }
+    const double* at(int k) const { return &values[(size_t)dim * k]; }
+};
+
+// include/mpc_local_planner/utils/math_utils.h:81-103
+inline double normalize_theta(double th) {
+    const double pi = 3.14159265358979323846;
+    if (th >= -pi && th < pi) return th;
+    double m = std::floor(th / (2.0 * pi));
+    th = th - m * 2.0 * pi;
+    if (th >= pi) th -= 2.0 * pi;
+    if (th < -pi) th += 2.0 * pi;
+    return th;
+}
+inline double interpolate_angle(double a1, double a2, double f) { return normalize_theta(a1 + f * normalize_theta(a2 - a1)); }
+
+// TimeSeriesSE2::getValuesInterpolate, linear + zero-order-hold extrapolation (src/utils/time_series_se2.cpp:34-111)
+inline void interpolate_se2(const std::vector<double>& times, const std::vector<double>& vals, double t, double out[3], double tol = 1e-6) {
+    const int n = (int)times.size();
+    int idx = -1;
+    for (int i = 0; i < n; ++i) if (times[i] >= t) { idx = i; break; }
+    if (idx < 0) { for (int i = 0; i < 3; ++i) out[i] = vals[3 * (n - 1) + i]; return; }
+    if (std::fabs(t - times[idx]) < tol || idx < 1) { for (int i = 0; i < 3; ++i) out[i] = vals[3 * idx + i]; return; }
+    const double fr = (t - times[idx - 1]) / (times[idx] - times[idx - 1]);
+    for (int i = 0; i < 2; ++i) out[i] = vals[3 * (idx - 1) + i] + fr * (vals[3 * idx + i] - vals[3 * (idx - 1) + i]);
+    out[2] = interpolate_angle(vals[3 * (idx - 1) + 2], vals[3 * idx + 2], fr);
+}
+
+// Controller::generateInitialStateTrajectory (src/controller.cpp:807-857) followed by the sampling of
+// initializeSequences(xinit) (full_discretization_grid_base_se2.cpp:192-239): fills x_init[n][3].
+// NOTE: `backward` has no effect in the reference (the result of normalize_theta(yaw + pi) is discarded at :841).
+inline void initial_state_trajectory(const std::vector<PoseSE2>& plan, const double x0[3], const double xf[3], int n, double dt_ref,
+                                     bool estimate_orientation, double* x_init) {
+    const int np = (int)plan.size();
+    std::vector<double> times, vals;
+    times.push_back(0.0); vals.insert(vals.end(), x0, x0 + 3);
+    const double tf = (n - 1) * dt_ref;
+    const double dt_init = tf / double(np - 1);
+    double t = dt_init;
+    for (int i = 1; i < np - 1; ++i) {
+        double yaw = plan[i].theta;
+        if (estimate_orientation) yaw = std::atan2(plan[i + 1].y - plan[i].y, plan[i + 1].x - plan[i].x);
+        const double v[3] = {plan[i].x, plan[i].y, yaw};
+        times.push_back(t); vals.insert(vals.end(), v, v + 3);
+        t += dt_init;
+    }
+    times.push_back(tf); vals.insert(vals.end(), xf, xf + 3);
+    for (int i = 0; i < 3; ++i) x_init[i] = x0[i];
+    for (int k = 1; k < n - 1; ++k) interpolate_se2(times, vals, k * dt_ref, &x_init[3 * k]);
+    for (int i = 0; i < 3; ++i) x_init[3 * (n - 1) + i] = xf[i];
+}
+
+class Controller {
+ public:
+    Controller() = default;
+    Controller(const Controller&) = delete;
+    Controller& operator=(const Controller&) = delete;
+    ~Controller() { if (_h) mpc_destroy(_h); }
+
+    // replaces configure(ros::NodeHandle&, obstacles, footprint, via_points): the caller fills mpc_config from its
+    // parameter source (INTEGRATION.md lists the key -> field mapping)
+    bool configure(const mpc_config& cfg, int device = 0) {
+        if (_h) { mpc_destroy(_h); _h = nullptr; }
+        _cfg = cfg;
+        _n = cfg.n;
+        if (mpc_create(&_cfg, 1, device, &_h) != MPC_OK) { _last_error = mpc_last_error(); return false; }
+        _x.assign((size_t)3 * _n, 0.0); _u.assign((size_t)2 * _n, 0.0);
+        _xi.assign((size_t)3 * _n, 0.0); _ui.assign((size_t)2 * _n, 0.0);
+        reset();
+        return true;
+    }
+
+    // parameters of src/controller.cpp:74-84
+    void setForceReinit(int num_steps, double new_goal_dist, double new_goal_angular) {
+        _force_reinit_num_steps = num_steps; _force_reinit_new_goal_dist = new_goal_dist; _force_reinit_new_goal_angular = new_goal_angular;
+    }
+    void setInitialPlanEstimateOrientation(bool e) { _initial_plan_estimate_orientation = e; }
+
+    // ocp->setPreviousControlInput(u, dt)  (src/mpc_local_planner_ros.cpp:384)
+    void setPreviousControlInput(const double u[2], double dt) { _u_prev[0] = u[0]; _u_prev[1] = u[1]; _dt_prev = dt; }
+
+    // obstacles of the next step() calls (borrowed, like the reference's ObstContainer reference)
+    void setObstacles(const mpc_obstacles* obst) { _obst = obst; }
+
+    // Controller::step(start, goal, ...)  (src/controller.cpp:102-109)
+    bool step(const PoseSE2& start, const PoseSE2& goal, const Twist& vel, double dt, double t, TimeSeries& u_seq, TimeSeries& x_seq) {
+        std::vector<PoseSE2> plan(2);
+        plan.front() = start; plan.back() = goal;
+        return step(plan, vel, dt, t, u_seq, x_seq);
+    }
+
+    // Controller::step(initial_plan, ...)  (src/controller.cpp:111-179)
+    bool step(const std::vector<PoseSE2>& plan, const Twist& /*vel*/, double /*dt*/, double /*t*/, TimeSeries& u_seq, TimeSeries& x_seq) {
+        if (!_h) { _last_error = "Controller must be configured before invoking step()."; return false; }
+        if (plan.size() < 2) { _last_error = "Controller::step(): initial plan must contain at least two poses."; return false; }
+        const PoseSE2& start = plan.front();
+        const PoseSE2& goal = plan.back();
+        const double xf[3] = {goal.x, goal.y, goal.theta};
+        // state == pose for every model and the odometry pose overwrites any prediction (base_robot_se2.h merge)
+        const double x0[3] = {start.x, start.y, start.theta};
+        // re-initialisation decision, :152-158
+        if (_force_reinit_num_steps > 0 && _ocp_seq % _force_reinit_num_steps == 0) _grid_empty = true;
+        if (!_grid_empty) {
+            const double dx = goal.x - _last_goal.x, dy = goal.y - _last_goal.y;
+            if (std::sqrt(dx * dx + dy * dy) > _force_reinit_new_goal_dist ||
+                std::fabs(normalize_theta(goal.theta - _last_goal.theta)) > _force_reinit_new_goal_angular)
+                _grid_empty = true;
+        }
+        const double* xi = nullptr; const double* ui = nullptr; const double* di = nullptr;
+        if (_grid_empty) {
+            if (plan.size() > 2) {      // a 2-pose plan is the device-side cold start
+                initial_state_trajectory(plan, x0, xf, _n, _cfg.dt_ref, _initial_plan_estimate_orientation, _xi.data());
+                std::fill(_ui.begin(), _ui.end(), 0.0);
+                _dti = _cfg.dt_ref;
+                xi = _xi.data(); ui = _ui.data(); di = &_dti;
+            }
+        } else {
+            _xi = _x; _ui = _u; _dti = _dt_sol;      // previous solution = warm start (x_0 / fixed goal are overwritten by the solver)
+            xi = _xi.data(); ui = _ui.data(); di = &_dti;
+        }
+        int32_t status = -1, iters = 0;
+        const int rc = mpc_solve_batch(_h, 1, x0, xf, _u_prev, &_dt_prev, xi, ui, di, _obst, _x.data(), _u.data(), &_dt_sol, &status, &iters);
+        if (rc != MPC_OK) { _last_error = mpc_last_error(); return false; }
+        _last_iterations = iters;
+        _ocp_successful = status == MPC_CONVERGED;
+        x_seq.clear(); u_seq.clear();
+        for (int k = 0; k < _n; ++k) {           // getStateAndControlTimeSeries, …grid_base_se2.cpp:579-615
+            x_seq.add(k * _dt_sol, &_x[(size_t)3 * k], 3);
+            u_seq.add(k * _dt_sol, &_u[(size_t)2 * k], 2);
+        }
+        _grid_empty = false;
+        ++_ocp_seq;
+        _last_goal = goal;
+        return _ocp_successful;
+    }
+
+    // Controller::reset (src/controller.cpp:223): the next step starts from a fresh initial guess
+    void reset() { _grid_empty = true; if (_h) mpc_reset(_h); }
+
+    int lastIterations() const { return _last_iterations; }
+    double lastDt() const { return _dt_sol; }
+    const std::string& lastError() const { return _last_error; }
+
+ private:
+    mpc_solver* _h = nullptr;
+    mpc_config _cfg{};
+    int _n = 0;
+    std::vector<double> _x, _u, _xi, _ui;
+    double _dt_sol = 0, _dti = 0;
+    double _u_prev[2] = {0, 0};
+    double _dt_prev = 0;
+    const mpc_obstacles* _obst = nullptr;
+    bool _grid_empty = true;
+    bool _ocp_successful = false;
+    int _ocp_seq = 0;
+    int _last_iterations = 0;
+    PoseSE2 _last_goal;
+    int _force_reinit_num_steps = 0;                     // src/controller.cpp:78
+    double _force_reinit_new_goal_dist = 1.0;            // :74
+    double _force_reinit_new_goal_angular = 1.5707963267948966;   // :76 (0.5*pi)
+    bool _initial_plan_estimate_orientation = true;
+    std::string _last_error;
+};
+
+}  // namespace mpc_local_planner_amd

@@ -365,6 +365,26 @@ def initial_state_trajectory_two_pose(x0, xf, n_ref: int, dt_ref: float):
     return np.array([0.0, tf]), np.stack([np.asarray(x0, float), np.asarray(xf, float)])
 
 
+def generate_initial_state_trajectory(plan, x0, xf, n_ref: int, dt_ref: float, estimate_orientation: bool = True):
+    """Controller::generateInitialStateTrajectory for a P-pose plan (src/controller.cpp:807-857): samples at
+    time-equidistant instants over tf_ref = (n_ref-1)*dt_ref, intermediate yaw from the direction to the next pose
+    (:838-840).  `backward` is a no-op in the reference (:841 discards its result).  plan: (P,3) poses."""
+    plan = np.asarray(plan, float)
+    P = plan.shape[0]
+    tf = (n_ref - 1) * dt_ref
+    dt_init = tf / (P - 1)
+    times, vals = [0.0], [np.asarray(x0, float)]
+    t = dt_init
+    for i in range(1, P - 1):
+        yaw = math.atan2(plan[i + 1, 1] - plan[i, 1], plan[i + 1, 0] - plan[i, 0]) if estimate_orientation else plan[i, 2]
+        times.append(t)
+        vals.append(np.array([plan[i, 0], plan[i, 1], yaw]))
+        t += dt_init
+    times.append(tf)
+    vals.append(np.asarray(xf, float))
+    return np.array(times), np.stack(vals)
+
+
 def time_series_se2_interpolate(times, values, t, tol=1e-6):
     """TimeSeriesSE2::getValuesInterpolate, linear (src/utils/time_series_se2.cpp:34-111)."""
     idx = None

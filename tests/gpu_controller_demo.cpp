@@ -1,0 +1,60 @@
+// GPU test program (built and run by tests/test_gpu_parity.py): the scenario of the reference's stand-alone node
+// (mpc_local_planner/src/test_mpc_optim_node.cpp:59-131 + cfg/test_mpc_optim_node.yaml): unicycle, n = 20, dt_ref = .3,
+// variable grid, minimum time, xf fixed, point footprint, d_min = .5, point obstacles (-3,1), (6,2), (4,.1),
+// start (0,0,0) -> goal (5,2,0), 20 Hz.  Drives the C++ Controller facade in closed loop: step -> apply u_0 for
+// one period -> step (warm start).  Prints one line per cycle; exit code 0 iff every check holds.
+#include <cmath>
+#include <cstdio>
+
+#include "../include/mpc_controller.hpp"
+
+using namespace mpc_local_planner_amd;
+
+int main() {
+    mpc_config c;
+    mpc_config_defaults(&c);                 // unicycle, n=20, dt_ref=.3, variable grid, min-time, xf fixed
+    c.u_lb[0] = -0.2; c.u_ub[0] = 0.4;       // max_vel_x_backwards / max_vel_x
+    c.u_lb[1] = -0.3; c.u_ub[1] = 0.3;       // max_vel_theta
+    c.min_obstacle_dist = 0.5; c.force_inclusion_dist = 0.5; c.cutoff_dist = 2.5;
+    c.footprint_kind = MPC_FOOTPRINT_POINT;
+    c.max_obstacles = 3; c.max_vertices = 1; c.max_obstacle_rows = 4;
+    c.tol = 1e-6;
+    Controller ctl;
+    if (!ctl.configure(c, 0)) { std::printf("configure failed: %s\n", ctl.lastError().c_str()); return 2; }
+    const int32_t n_obst[1] = {3};
+    const int32_t n_vert[3] = {1, 1, 1};
+    const double verts[6] = {-3.0, 1.0, 6.0, 2.0, 4.0, 0.1};
+    mpc_obstacles ob = {n_obst, n_vert, verts, nullptr};
+    ctl.setObstacles(&ob);
+    PoseSE2 pose{0, 0, 0}, goal{5, 2, 0};
+    Twist vel;
+    const double period = 0.05;
+    TimeSeries x_seq, u_seq;
+    double u_prev[2] = {0, 0};
+    int failures = 0, cold_iters = 0, warm_iters = 0;
+    double t_first = 0, t_last = 0, min_clear = 1e9;
+    for (int cyc = 0; cyc < 40; ++cyc) {
+        ctl.setPreviousControlInput(u_prev, cyc == 0 ? 0.0 : period);
+        const bool ok = ctl.step(pose, goal, vel, period, cyc * period, u_seq, x_seq);
+        if (!ok) { ++failures; ctl.reset(); std::printf("cycle %d: solve failed (%d iterations)\n", cyc, ctl.lastIterations()); continue; }
+        const double T = ctl.lastDt() * (c.n - 1);
+        if (cyc == 0) { t_first = T; cold_iters = ctl.lastIterations(); } else warm_iters += ctl.lastIterations();
+        t_last = T;
+        for (int k = 1; k < c.n - 1; ++k) {
+            const double* x = x_seq.at(k);
+            for (int o = 0; o < 3; ++o) min_clear = std::fmin(min_clear, std::hypot(x[0] - verts[2 * o], x[1] - verts[2 * o + 1]));
+        }
+        const double* u0 = u_seq.at(0);
+        if (cyc % 8 == 0) std::printf("cycle %2d pose (%.3f %.3f %.3f) u0 (%.3f %.3f) T %.3f iters %d\n", cyc, pose.x, pose.y, pose.theta, u0[0], u0[1], T, ctl.lastIterations());
+        // unicycle plant, explicit Euler over one control period
+        pose.x += period * u0[0] * std::cos(pose.theta);
+        pose.y += period * u0[0] * std::sin(pose.theta);
+        pose.theta = normalize_theta(pose.theta + period * u0[1]);
+        u_prev[0] = u0[0]; u_prev[1] = u0[1];
+    }
+    std::printf("failures %d  cold-start iterations %d  mean warm iterations %.1f  T first %.3f  T last %.3f  min clearance (associated or not) %.3f\n",
+                failures, cold_iters, warm_iters / 39.0, t_first, t_last, min_clear);
+    bool good = failures <= 2 && t_last < t_first && t_first > 5.385 / 0.4 - 1e-6 && pose.x > 0.5;
+    std::printf(good ? "DEMO_OK\n" : "DEMO_FAILED\n");
+    return good ? 0 : 1;
+}

@@ -1,0 +1,10 @@
+// tests only: C entry points around the host logic of include/mpc_controller.hpp (no GPU calls)
+#include "../../include/mpc_controller.hpp"
+
+extern "C" void ctl_initial_state_trajectory(int np, const double* plan, const double* x0, const double* xf, int n, double dt_ref,
+                                             int estimate_orientation, double* x_init) {
+    std::vector<mpc_local_planner_amd::PoseSE2> p(np);
+    for (int i = 0; i < np; ++i) { p[i].x = plan[3 * i]; p[i].y = plan[3 * i + 1]; p[i].theta = plan[3 * i + 2]; }
+    mpc_local_planner_amd::initial_state_trajectory(p, x0, xf, n, dt_ref, estimate_orientation != 0, x_init);
+}
+extern "C" double ctl_interpolate_angle(double a, double b, double f) { return mpc_local_planner_amd::interpolate_angle(a, b, f); }

@@ -1,0 +1,49 @@
+"""CPU test of the C++ Controller facade's host logic (include/mpc_controller.hpp) against the oracle's restatement
+of Controller::generateInitialStateTrajectory + initializeSequences(xinit)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from oracle import se2_nlp as R
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SRC = os.path.join(HERE, "host_harness", "controller_host.cpp")
+OUT = os.path.join(HERE, "host_harness", "_build", "libctl_host.so")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    os.makedirs(os.path.dirname(OUT), exist_ok=True)
+    # the facade only needs the ABI's declarations here: link lazily, the tested functions make no library calls
+    subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wl,--unresolved-symbols=ignore-all", SRC, "-o", OUT], check=True)
+    l = C.CDLL(OUT)
+    l.ctl_interpolate_angle.restype = C.c_double
+    l.ctl_interpolate_angle.argtypes = [C.c_double] * 3
+    return l
+
+
+def test_initial_state_trajectory_matches_oracle(lib):
+    rng = np.random.default_rng(4)
+    n, dt_ref = 20, 0.3
+    for P in (2, 3, 7):
+        plan = np.cumsum(rng.uniform(0.1, 0.6, (P, 3)), axis=0)
+        plan[:, 2] = rng.uniform(-3, 3, P)
+        x0 = plan[0].copy(); xf = plan[-1].copy()
+        for est in (True, False):
+            out = np.zeros((n, 3))
+            p = lambda a: a.ctypes.data_as(C.c_void_p)
+            lib.ctl_initial_state_trajectory(C.c_int(P), p(plan), p(x0), p(xf), C.c_int(n), C.c_double(dt_ref), C.c_int(est), p(out))
+            t, v = R.generate_initial_state_trajectory(plan, x0, xf, n, dt_ref, est)
+            cfg = R.OcpConfig(n=n, dt_ref=dt_ref)
+            ref = R.initialize_sequences_xinit(cfg, x0, xf, t, v)
+            np.testing.assert_allclose(out, ref.x, atol=1e-14)
+    # 2-pose plan == the device-side cold start
+    x0 = np.array([0.0, 0.0, 3.0]); xf = np.array([1.0, 2.0, -3.0])
+    t, v = R.generate_initial_state_trajectory(np.stack([x0, xf]), x0, xf, n, dt_ref)
+    a = R.initialize_sequences_xinit(R.OcpConfig(n=n, dt_ref=dt_ref), x0, xf, t, v)
+    b = R.cold_start(R.OcpConfig(n=n, dt_ref=dt_ref), x0, xf)
+    np.testing.assert_allclose(a.x, b.x, atol=1e-15)
+    assert lib.ctl_interpolate_angle(3.0, -3.0, 0.5) == pytest.approx(float(R.interpolate_angle(3.0, -3.0, 0.5)))

@@ -237,3 +237,17 @@ def test_obstacle_rows_golden_and_properties(m):
         assert np.abs(nlp.equalities(z)).max() < 1e-6
     assert checked > 500
     s.close()
+
+
+def test_cpp_controller_facade_closed_loop(tmp_path):
+    """Builds tests/gpu_controller_demo.cpp against include/mpc_controller.hpp + libmpc_hip.so and runs the reference's
+    stand-alone scenario (src/test_mpc_optim_node.cpp) in closed loop through the C++ Controller facade."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "mpc_local_planner_amd", "csrc")
+    exe = str(tmp_path / "controller_demo")
+    subprocess.run(["g++", "-O2", "-std=c++17", os.path.join(root, "tests", "gpu_controller_demo.cpp"), "-L" + libdir, "-lmpc_hip",
+                    "-Wl,-rpath," + libdir, "-o", exe], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0 and "DEMO_OK" in r.stdout, r.stdout + r.stderr
