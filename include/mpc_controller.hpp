@@ -91,6 +91,31 @@ inline void initial_state_trajectory(const std::vector<PoseSE2>& plan, const dou
     for (int i = 0; i < 3; ++i) x_init[3 * (n - 1) + i] = xf[i];
 }
 
+// FullDiscretizationGridBaseSE2::resampleTrajectory (src/optimal_control/full_discretization_grid_base_se2.cpp:440-524):
+// linear (theta-aware) re-interpolation of the previous solution onto n_new points, controls held, dt rescaled so that
+// the horizon length is unchanged.  x/u are [n][3] / [n][2] with the duplicated last control row; in place.
+inline void resample_trajectory(std::vector<double>& x, std::vector<double>& u, double& dt, int n, int n_new, int stride_n) {
+    if (n == n_new) return;
+    std::vector<double> xo(x.begin(), x.begin() + 3 * n), uo(u.begin(), u.begin() + 2 * n);
+    const double dt_old = dt, dt_new = dt_old * double(n - 1) / double(n_new - 1);
+    int idx_old = 1;
+    for (int idx_new = 1; idx_new < n_new - 1; ++idx_new) {
+        const double t_new = dt_new * double(idx_new);
+        while (t_new > double(idx_old) * dt_old && idx_old < n) ++idx_old;
+        const double t_old_p1 = double(idx_old) * dt_old;
+        const double* xp = &xo[3 * (idx_old - 1)];
+        const double* xc = idx_old < n - 1 ? &xo[3 * idx_old] : &xo[3 * (n - 1)];
+        const double fr = (t_new - (t_old_p1 - dt_old)) / dt_old;
+        for (int i = 0; i < 2; ++i) x[3 * idx_new + i] = xp[i] + fr * (xc[i] - xp[i]);
+        x[3 * idx_new + 2] = interpolate_angle(xp[2], xc[2], fr);
+        for (int j = 0; j < 2; ++j) u[2 * idx_new + j] = uo[2 * (idx_old - 1) + j];
+    }
+    for (int i = 0; i < 3; ++i) x[3 * (n_new - 1) + i] = xo[3 * (n - 1) + i];
+    for (int j = 0; j < 2; ++j) u[2 * (n_new - 1) + j] = u[2 * (n_new - 2) + j];
+    (void)stride_n;
+    dt = dt_new;
+}
+
 class Controller {
  public:
     Controller() = default;
@@ -103,7 +128,10 @@ class Controller {
     bool configure(const mpc_config& cfg, int device = 0) {
         if (_h) { mpc_destroy(_h); _h = nullptr; }
         _cfg = cfg;
-        _n = cfg.n;
+        _n_ref = cfg.n;                                   // grid/grid_size_ref
+        _n = _grid_adapt && cfg.dt_free ? (cfg.n > _n_max ? cfg.n : _n_max) : cfg.n;   // capacity (stride) of the arrays
+        _n_cur = _n_ref;
+        _cfg.n = _n;
         if (mpc_create(&_cfg, 1, device, &_h) != MPC_OK) { _last_error = mpc_last_error(); return false; }
         _x.assign((size_t)3 * _n, 0.0); _u.assign((size_t)2 * _n, 0.0);
         _xi.assign((size_t)3 * _n, 0.0); _ui.assign((size_t)2 * _n, 0.0);
@@ -116,6 +144,12 @@ class Controller {
         _force_reinit_num_steps = num_steps; _force_reinit_new_goal_dist = new_goal_dist; _force_reinit_new_goal_angular = new_goal_angular;
     }
     void setInitialPlanEstimateOrientation(bool e) { _initial_plan_estimate_orientation = e; }
+    // grid/variable_grid/grid_adaptation/* (src/controller.cpp:248-261); call BEFORE configure().  The batched solver needs
+    // at least 3 grid points, so min_grid_size is clamped to 3 (the reference allows 2).
+    void setGridAdaptation(bool enable, int max_grid_size = 50, double dt_hyst_ratio = 0.1, int min_grid_size = 2) {
+        _grid_adapt = enable; _n_max = max_grid_size; _dt_hyst = dt_hyst_ratio; _n_min = min_grid_size < 3 ? 3 : min_grid_size;
+    }
+    int gridSize() const { return _n_cur; }
 
     // ocp->setPreviousControlInput(u, dt)  (src/mpc_local_planner_ros.cpp:384)
     void setPreviousControlInput(const double u[2], double dt) { _u_prev[0] = u[0]; _u_prev[1] = u[1]; _dt_prev = dt; }
@@ -149,15 +183,28 @@ class Controller {
         }
         const double* xi = nullptr; const double* ui = nullptr; const double* di = nullptr;
         if (_grid_empty) {
+            _n_cur = _n_ref;
             if (plan.size() > 2) {      // a 2-pose plan is the device-side cold start
-                initial_state_trajectory(plan, x0, xf, _n, _cfg.dt_ref, _initial_plan_estimate_orientation, _xi.data());
+                initial_state_trajectory(plan, x0, xf, _n_cur, _cfg.dt_ref, _initial_plan_estimate_orientation, _xi.data());
                 std::fill(_ui.begin(), _ui.end(), 0.0);
                 _dti = _cfg.dt_ref;
                 xi = _xi.data(); ui = _ui.data(); di = &_dti;
             }
         } else {
             _xi = _x; _ui = _u; _dti = _dt_sol;      // previous solution = warm start (x_0 / fixed goal are overwritten by the solver)
+            if (_grid_adapt && _cfg.dt_free) {
+                // adaptGridTimeBasedSingleStep (src/optimal_control/finite_differences_variable_grid_se2.cpp:99-121)
+                int n_new = _n_cur;
+                if (_dt_sol > _cfg.dt_ref * (1.0 + _dt_hyst) && _n_cur < _n_max) n_new = _n_cur + 1;
+                else if (_dt_sol < _cfg.dt_ref * (1.0 - _dt_hyst) && _n_cur > _n_min) n_new = _n_cur - 1;
+                if (n_new != _n_cur) { resample_trajectory(_xi, _ui, _dti, _n_cur, n_new, _n); _n_cur = n_new; }
+            }
             xi = _xi.data(); ui = _ui.data(); di = &_dti;
+        }
+        if (_n_cur != _n || _sizes_set) {
+            const int32_t ng = _n_cur;
+            if (mpc_set_grid_sizes(_h, &ng, 1) != MPC_OK) { _last_error = mpc_last_error(); return false; }
+            _sizes_set = true;
         }
         int32_t status = -1, iters = 0;
         const int rc = mpc_solve_batch(_h, 1, x0, xf, _u_prev, &_dt_prev, xi, ui, di, _obst, _x.data(), _u.data(), &_dt_sol, &status, &iters);
@@ -165,7 +212,7 @@ class Controller {
         _last_iterations = iters;
         _ocp_successful = status == MPC_CONVERGED;
         x_seq.clear(); u_seq.clear();
-        for (int k = 0; k < _n; ++k) {           // getStateAndControlTimeSeries, …grid_base_se2.cpp:579-615
+        for (int k = 0; k < _n_cur; ++k) {       // getStateAndControlTimeSeries, …grid_base_se2.cpp:579-615
             x_seq.add(k * _dt_sol, &_x[(size_t)3 * k], 3);
             u_seq.add(k * _dt_sol, &_u[(size_t)2 * k], 2);
         }
@@ -185,7 +232,10 @@ class Controller {
  private:
     mpc_solver* _h = nullptr;
     mpc_config _cfg{};
-    int _n = 0;
+    int _n = 0, _n_ref = 0, _n_cur = 0;
+    bool _grid_adapt = false, _sizes_set = false;
+    int _n_max = 50, _n_min = 3;
+    double _dt_hyst = 0.1;
     std::vector<double> _x, _u, _xi, _ui;
     double _dt_sol = 0, _dti = 0;
     double _u_prev[2] = {0, 0};

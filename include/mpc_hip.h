@@ -154,6 +154,12 @@ int mpc_solve_batch_device(mpc_solver* s, int32_t B,
                            double* d_x_out, double* d_u_out, double* d_dt_out,
                            int32_t* d_status, int32_t* d_iters);
 
+/* Per-instance grid sizes for the following mpc_solve_batch* calls (grid adaptation of the variable grid,
+ * src/optimal_control/finite_differences_variable_grid_se2.cpp:99-121): instance b uses n_grid[b] grid points
+ * (3 <= n_grid[b] <= cfg.n); the array layouts keep the stride cfg.n and only the first n_grid[b] rows of
+ * x_init/u_init/x_out/u_out are meaningful.  HOST pointer, copied; NULL restores the uniform size cfg.n. */
+int mpc_set_grid_sizes(mpc_solver* s, const int32_t* n_grid, int32_t B);
+
 int mpc_synchronize(mpc_solver* s);
 
 /* Duration (ms) of the solve kernel of the most recent mpc_solve_batch* call, measured with

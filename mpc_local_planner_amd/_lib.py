@@ -20,7 +20,7 @@ HEADERS = ["mpc_core.hpp", "mpc_problem.hpp", os.path.join("..", "..", "include"
 
 EXPORTS = [
     "mpc_config_defaults", "mpc_create", "mpc_reset", "mpc_destroy", "mpc_solve_batch",
-    "mpc_solve_batch_device", "mpc_synchronize", "mpc_last_kernel_ms", "mpc_last_error", "mpc_version",
+    "mpc_solve_batch_device", "mpc_set_grid_sizes", "mpc_synchronize", "mpc_last_kernel_ms", "mpc_last_error", "mpc_version",
 ]
 
 
@@ -82,6 +82,8 @@ def load() -> C.CDLL:
     lib.mpc_solve_batch.restype = C.c_int
     lib.mpc_solve_batch_device.argtypes = sig
     lib.mpc_solve_batch_device.restype = C.c_int
+    lib.mpc_set_grid_sizes.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
+    lib.mpc_set_grid_sizes.restype = C.c_int
     lib.mpc_synchronize.argtypes = [C.c_void_p]
     lib.mpc_synchronize.restype = C.c_int
     lib.mpc_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]

@@ -87,8 +87,8 @@ __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
     mpc::Problem<T> P, mpc::WaveLayout L, int B,
     const double* __restrict__ x0, const double* __restrict__ xf, const double* __restrict__ u_prev,
     const double* __restrict__ dt_prev, const double* __restrict__ x_init, const double* __restrict__ u_init,
-    const double* __restrict__ dt_init, mpc_obstacles obst, double* __restrict__ x_out, double* __restrict__ u_out,
-    double* __restrict__ dt_out, int32_t* __restrict__ status, int32_t* __restrict__ iters) {
+    const double* __restrict__ dt_init, mpc_obstacles obst, const int32_t* __restrict__ n_grid, double* __restrict__ x_out,
+    double* __restrict__ u_out, double* __restrict__ dt_out, int32_t* __restrict__ status, int32_t* __restrict__ iters) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mpc_smem[];
     T* sm = reinterpret_cast<T*>(mpc_smem);
     // problem record + layout at the end of the dynamic LDS block (16-byte aligned)
@@ -98,9 +98,11 @@ __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
     const int inst = blockIdx.x;
     const int lane = threadIdx.x;
     if (inst >= B) return;
-    if (lane == 0) { *Ps = P; *Ls = L; }
+    const int nmax = L.n;          // stride of the instance-major arrays
+    int n = nmax;                  // grid points of THIS instance (grid adaptation: n_i <= n_max)
+    if (n_grid) { n = n_grid[inst]; n = n < 3 ? 3 : (n > nmax ? nmax : n); }
+    if (lane == 0) { *Ps = P; *Ls = L; Ls->n = n; Ps->n = n; }
     __syncthreads();
-    const int n = L.n;
     mpc::IpmWave<T, MODEL> S(*Ps, *Ls, sm, lane);
     for (int i = 0; i < 3; ++i) { S.x0[i] = T(x0[3 * inst + i]); S.xf[i] = T(xf[3 * inst + i]); }
     S.x0[2] = mpc::normalize_theta(S.x0[2]);
@@ -110,8 +112,8 @@ __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
     S.dtprev = dt_prev ? T(dt_prev[inst]) : T(0);
     if (x_init && u_init && dt_init) {
         // coalesced read of this instance's contiguous [n][3] / [n][2] blocks
-        const double* xi = x_init + (long)inst * n * 3;
-        const double* ui = u_init + (long)inst * n * 2;
+        const double* xi = x_init + (long)inst * nmax * 3;
+        const double* ui = u_init + (long)inst * nmax * 2;
         for (int e = lane; e < 3 * n; e += mpc::kWave) S.F(L.X, e % 3, e / 3) = T(xi[e]);
         for (int e = lane; e < 2 * (n - 1); e += mpc::kWave) S.F(L.U, e % 2, e / 2) = T(ui[e]);
         if (lane == 0) S.SCL(mpc::SC_D) = T(dt_init[inst]);
@@ -122,10 +124,10 @@ __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
     __syncthreads();
     mpc::SolveStats<T> st = S.solve();
     __syncthreads();
-    double* xo = x_out + (long)inst * n * 3;
-    double* uo = u_out + (long)inst * n * 2;
-    for (int e = lane; e < 3 * n; e += mpc::kWave) xo[e] = double(S.F(L.X, e % 3, e / 3));
-    for (int e = lane; e < 2 * n; e += mpc::kWave) { int k = e / 2; int ks = k < n - 1 ? k : n - 2; uo[e] = double(S.F(L.U, e % 2, ks)); }
+    double* xo = x_out + (long)inst * nmax * 3;
+    double* uo = u_out + (long)inst * nmax * 2;
+    for (int e = lane; e < 3 * nmax; e += mpc::kWave) { int k = e / 3; int ks = k < n ? k : n - 1; xo[e] = double(S.F(L.X, e % 3, ks)); }
+    for (int e = lane; e < 2 * nmax; e += mpc::kWave) { int k = e / 2; int ks = k < n - 1 ? k : n - 2; uo[e] = double(S.F(L.U, e % 2, ks)); }
     if (lane == 0) {
         dt_out[inst] = double(S.SCL(mpc::SC_D));
         if (status) status[inst] = st.status;
@@ -152,7 +154,8 @@ struct mpc_solver {
     // staging for the host-pointer entry point
     double *d_x0, *d_xf, *d_up, *d_dtp, *d_xi, *d_ui, *d_dti, *d_xo, *d_uo, *d_dto;
     int32_t *d_status, *d_iters;
-    int32_t *d_ono, *d_onv;
+    int32_t *d_ono, *d_onv, *d_ngrid;
+    int use_ngrid;
     double *d_ov, *d_or;
     bool timed;
 };
@@ -267,6 +270,7 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
     if (er == hipSuccess) er = hipMalloc((void**)&s->d_dto, Bm * 8);
     if (er == hipSuccess) er = hipMalloc((void**)&s->d_status, Bm * 4);
     if (er == hipSuccess) er = hipMalloc((void**)&s->d_iters, Bm * 4);
+    if (er == hipSuccess) er = hipMalloc((void**)&s->d_ngrid, Bm * 4);
     if (cfg->max_obstacles > 0) {
         const size_t O = cfg->max_obstacles, V = cfg->max_vertices > 0 ? cfg->max_vertices : 1;
         if (er == hipSuccess) er = hipMalloc((void**)&s->d_ono, Bm * 4);
@@ -289,7 +293,7 @@ void mpc_destroy(mpc_solver* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    void* bufs[] = {s->d_ono, s->d_onv, s->d_ov, s->d_or, s->ws, s->d_x0, s->d_xf, s->d_up, s->d_dtp, s->d_xi, s->d_ui, s->d_dti, s->d_xo, s->d_uo, s->d_dto, s->d_status, s->d_iters};
+    void* bufs[] = {s->d_ngrid, s->d_ono, s->d_onv, s->d_ov, s->d_or, s->ws, s->d_x0, s->d_xf, s->d_up, s->d_dtp, s->d_xi, s->d_ui, s->d_dti, s->d_xo, s->d_uo, s->d_dto, s->d_status, s->d_iters};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -309,7 +313,7 @@ static hipError_t launch_model(mpc_solver* s, const mpc::Problem<T>& P, int B, c
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->wave_lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kern, dim3(B), dim3(mpc::kWave), s->wave_lds, s->stream, P, s->WL, B, x0, xf, up, dtp, xi, ui, dti, ob, xo, uo, dto, st, it);
+        hipLaunchKernelGGL(kern, dim3(B), dim3(mpc::kWave), s->wave_lds, s->stream, P, s->WL, B, x0, xf, up, dtp, xi, ui, dti, ob, s->use_ngrid ? s->d_ngrid : nullptr, xo, uo, dto, st, it);
     } else {
         dim3 grid((B + kLanes - 1) / kLanes), block(kLanes);
         hipLaunchKernelGGL((mpc_ipm_solve_kernel<T, MODEL>), grid, block, 0, s->stream, P, s->L, (T*)s->ws, s->stride, B, x0, xf, up,
@@ -359,6 +363,21 @@ int mpc_solve_batch_device(mpc_solver* s, int32_t B, const double* d_x0, const d
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev1, s->stream));
     s->timed = true;
+    return MPC_OK;
+}
+
+int mpc_set_grid_sizes(mpc_solver* s, const int32_t* n_grid, int32_t B) {
+    g_err[0] = 0;
+    if (!s) return MPC_EINVAL;
+    if (!n_grid) { s->use_ngrid = 0; return MPC_OK; }
+    if (B <= 0 || B > s->max_batch) { set_err("mpc_set_grid_sizes: B out of range"); return MPC_EBATCH; }
+    if (!s->use_wave) { set_err("mpc_set_grid_sizes: per-instance grid sizes need the LDS-resident kernel"); return MPC_EINVAL; }
+    for (int b = 0; b < B; ++b)
+        if (n_grid[b] < 3 || n_grid[b] > s->cfg.n) { set_err("mpc_set_grid_sizes: n_grid[b] must be in [3, cfg.n]"); return MPC_EINVAL; }
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipMemcpyAsync(s->d_ngrid, n_grid, (size_t)B * 4, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    s->use_ngrid = 1;
     return MPC_OK;
 }
 

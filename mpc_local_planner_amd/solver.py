@@ -128,6 +128,14 @@ class BatchSolver:
                                               v(iters))
         self._check(rc)
 
+    def set_grid_sizes(self, n_grid=None):
+        """Per-instance grid sizes n_i <= cfg.n for the following solves (grid adaptation); None = uniform cfg.n."""
+        if n_grid is None:
+            self._check(self._lib.mpc_set_grid_sizes(self._h, None, 0))
+            return
+        a = np.ascontiguousarray(n_grid, dtype=np.int32)
+        self._check(self._lib.mpc_set_grid_sizes(self._h, C.c_void_p(a.ctypes.data), int(a.shape[0])))
+
     def synchronize(self):
         self._check(self._lib.mpc_synchronize(self._h))
 

@@ -10,6 +10,44 @@
 
 using namespace mpc_local_planner_amd;
 
+// second scenario: the shipped configuration (grid adaptation on): drive to the goal; n follows dt (n+-1 per cycle)
+static int run_adaptive() {
+    mpc_config c;
+    mpc_config_defaults(&c);
+    c.u_lb[0] = -0.2; c.u_ub[0] = 0.4; c.u_lb[1] = -0.3; c.u_ub[1] = 0.3;
+    c.tol = 1e-6;
+    Controller ctl;
+    ctl.setGridAdaptation(true, 50, 0.1, 2);          // grid_adaptation: max 50, hysteresis .1, min 2 (clamped to 3)
+    if (!ctl.configure(c, 0)) { std::printf("configure failed: %s\n", ctl.lastError().c_str()); return 2; }
+    PoseSE2 pose{0, 0, 0}, goal{2.0, 1.0, 0.5};
+    Twist vel;
+    const double period = 0.1;
+    TimeSeries x_seq, u_seq;
+    double u_prev[2] = {0, 0};
+    int failures = 0, n_first = 0, n_min_seen = 1000, n_max_seen = 0, cycles = 0;
+    bool reached = false;
+    for (int cyc = 0; cyc < 400; ++cyc) {
+        const double dx = goal.x - pose.x, dy = goal.y - pose.y;
+        if (std::hypot(dx, dy) < 0.1 && std::fabs(normalize_theta(goal.theta - pose.theta)) < 0.1) { reached = true; break; }   // xy / yaw goal tolerance
+        ctl.setPreviousControlInput(u_prev, cyc == 0 ? 0.0 : period);
+        const bool ok = ctl.step(pose, goal, vel, period, cyc * period, u_seq, x_seq);
+        ++cycles;
+        if (!ok) { ++failures; ctl.reset(); u_prev[0] = u_prev[1] = 0; continue; }
+        const int n = ctl.gridSize();
+        if (cyc == 0) n_first = n;
+        n_min_seen = n < n_min_seen ? n : n_min_seen; n_max_seen = n > n_max_seen ? n : n_max_seen;
+        if (x_seq.size() != n || u_seq.size() != n) { std::printf("time series size %d != grid size %d\n", x_seq.size(), n); return 1; }
+        const double* u0 = u_seq.at(0);
+        if (cyc % 10 == 0) std::printf("adaptive cycle %3d pose (%.3f %.3f %.3f) n %2d dt %.3f iters %d\n", cyc, pose.x, pose.y, pose.theta, n, ctl.lastDt(), ctl.lastIterations());
+        pose.x += period * u0[0] * std::cos(pose.theta);
+        pose.y += period * u0[0] * std::sin(pose.theta);
+        pose.theta = normalize_theta(pose.theta + period * u0[1]);
+        u_prev[0] = u0[0]; u_prev[1] = u0[1];
+    }
+    std::printf("adaptive: reached %d after %d cycles, failures %d, n first %d min %d max %d\n", (int)reached, cycles, failures, n_first, n_min_seen, n_max_seen);
+    return (reached && failures <= 5 && n_first == 20 && n_min_seen <= 6) ? 0 : 1;
+}
+
 int main() {
     mpc_config c;
     mpc_config_defaults(&c);                 // unicycle, n=20, dt_ref=.3, variable grid, min-time, xf fixed
@@ -55,6 +93,8 @@ int main() {
     std::printf("failures %d  cold-start iterations %d  mean warm iterations %.1f  T first %.3f  T last %.3f  min clearance (associated or not) %.3f\n",
                 failures, cold_iters, warm_iters / 39.0, t_first, t_last, min_clear);
     bool good = failures <= 2 && t_last < t_first && t_first > 5.385 / 0.4 - 1e-6 && pose.x > 0.5;
+    const int ra = run_adaptive();
+    good = good && ra == 0;
     std::printf(good ? "DEMO_OK\n" : "DEMO_FAILED\n");
     return good ? 0 : 1;
 }

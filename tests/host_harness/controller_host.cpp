@@ -8,3 +8,11 @@ extern "C" void ctl_initial_state_trajectory(int np, const double* plan, const d
     mpc_local_planner_amd::initial_state_trajectory(p, x0, xf, n, dt_ref, estimate_orientation != 0, x_init);
 }
 extern "C" double ctl_interpolate_angle(double a, double b, double f) { return mpc_local_planner_amd::interpolate_angle(a, b, f); }
+
+extern "C" double ctl_resample(double* x, double* u, double dt, int n, int n_new) {
+    std::vector<double> xv(x, x + 3 * (n > n_new ? n : n_new)), uv(u, u + 2 * (n > n_new ? n : n_new));
+    mpc_local_planner_amd::resample_trajectory(xv, uv, dt, n, n_new, 0);
+    for (size_t i = 0; i < xv.size(); ++i) x[i] = xv[i];
+    for (size_t i = 0; i < uv.size(); ++i) u[i] = uv[i];
+    return dt;
+}

@@ -22,6 +22,8 @@ def lib():
     l = C.CDLL(OUT)
     l.ctl_interpolate_angle.restype = C.c_double
     l.ctl_interpolate_angle.argtypes = [C.c_double] * 3
+    l.ctl_resample.restype = C.c_double
+    l.ctl_resample.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int]
     return l
 
 
@@ -47,3 +49,19 @@ def test_initial_state_trajectory_matches_oracle(lib):
     b = R.cold_start(R.OcpConfig(n=n, dt_ref=dt_ref), x0, xf)
     np.testing.assert_allclose(a.x, b.x, atol=1e-15)
     assert lib.ctl_interpolate_angle(3.0, -3.0, 0.5) == pytest.approx(float(R.interpolate_angle(3.0, -3.0, 0.5)))
+
+
+def test_resample_matches_oracle(lib):
+    # FullDiscretizationGridBaseSE2::resampleTrajectory, src/optimal_control/full_discretization_grid_base_se2.cpp:440-524
+    rng = np.random.default_rng(9)
+    for n, n_new in ((12, 13), (12, 11), (5, 4), (20, 21)):
+        x = np.cumsum(rng.uniform(0.0, 0.3, (n, 3)), axis=0); x[:, 2] = rng.uniform(-3.1, 3.1, n)
+        u = rng.uniform(-0.2, 0.4, (n - 1, 2))
+        tr = R.resample_trajectory(R.Trajectory(x.copy(), u.copy(), 0.27), n_new)
+        cap = max(n, n_new)
+        xb = np.zeros((cap, 3)); ub = np.zeros((cap, 2))
+        xb[:n] = x; ub[:n - 1] = u; ub[n - 1] = u[-1]
+        dt_new = lib.ctl_resample(xb.ctypes.data_as(C.c_void_p), ub.ctypes.data_as(C.c_void_p), 0.27, n, n_new)
+        assert dt_new == pytest.approx(tr.dt)
+        np.testing.assert_allclose(xb[:n_new], tr.x, atol=1e-14)
+        np.testing.assert_allclose(ub[:n_new - 1], tr.u, atol=1e-14)
