@@ -489,6 +489,7 @@ struct Ipm {
     T mu, rho, delta_last;
     int nfix;
     bool row0_on;
+    bool fail0;
 
     MPC_HD Ipm(const Problem<T>& p, const Layout& l, Mem<T> m) : P(p), L(l), M(m) {}
 
@@ -1093,6 +1094,7 @@ struct Ipm {
         mu = P.mu_init;
         rho = T(0);
         delta_last = T(0);
+        fail0 = false;
         // duals / slacks
         for (int r = 0; r < n; ++r) {
             for (int q = 0; q < 4; ++q) {
@@ -1136,7 +1138,9 @@ struct Ipm {
             const T tau = t_max(Algo<T>::tau_min, T(1) - mu);
             const T dc = nfix > 0 ? Algo<T>::delta_c * t_pow(mu, Algo<T>::kappa_c) : T(0);
             // ---- factor/solve with inertia-free regularisation
-            T delta = T(0);
+            // first trial delta = 0 unless the previous iteration's delta = 0 attempt failed (then continue from the decayed value)
+            T delta = (fail0 && delta_last > T(0)) ? t_max(Algo<T>::delta_min, Algo<T>::kappa_minus * delta_last) : T(0);
+            const bool started_zero = delta == T(0);
             bool ok = false;
             Fwd fw;
             T dd = T(0), nu[3] = {T(0), T(0), T(0)};
@@ -1157,6 +1161,7 @@ struct Ipm {
             }
             if (!ok) { status = ST_LINSOLVE; break; }
             if (delta > T(0)) delta_last = delta;
+            if (started_zero) fail0 = delta > T(0);
             // ---- l1 merit, backtracking
             const T theta = er.theta;
             if (theta > T(0)) {

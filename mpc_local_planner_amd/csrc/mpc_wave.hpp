@@ -96,7 +96,7 @@ struct IpmWave {
     const int lane;
     T x0[3], xf[3], uprev[2], dtprev;
     T mu, rho, delta_last;
-    bool row0_on;
+    bool row0_on, fail0;
     int nfix;
 
     __device__ IpmWave(const Problem<T>& p, const WaveLayout& l, T* s, int ln) : P(p), L(l), sm(s), lane(ln) {}
@@ -1021,7 +1021,7 @@ struct IpmWave {
         if (lane == 0 && P.dt_free) SCL(SC_D) = push_interior(SCL(SC_D), P.dt_lb, P.dt_ub);
         sync();
         if (L.M > 0) { associate_obstacles(); sync(); }
-        mu = P.mu_init; rho = T(0); delta_last = T(0);
+        mu = P.mu_init; rho = T(0); delta_last = T(0); fail0 = false;
         const T d = SCL(SC_D);
         for (int k = lane; k < n; k += kWave) {
             for (int q = 0; q < 4; ++q) {
@@ -1091,7 +1091,8 @@ struct IpmWave {
             MPC_TICK(1, stage_barrier_terms(); sync());
             const T tau = t_max(Algo<T>::tau_min, T(1) - mu);
             const T dc = nfix > 0 ? Algo<T>::delta_c * t_pow(mu, Algo<T>::kappa_c) : T(0);
-            T delta = T(0);
+            T delta = (fail0 && delta_last > T(0)) ? t_max(Algo<T>::delta_min, Algo<T>::kappa_minus * delta_last) : T(0);
+            const bool started_zero = delta == T(0);
             bool ok = false;
             Fwd fw;
             T dd = T(0), nu[3] = {T(0), T(0), T(0)}, curv = T(0);
@@ -1120,6 +1121,7 @@ struct IpmWave {
             }
             if (!ok) { status = ST_LINSOLVE; break; }
             if (delta > T(0)) delta_last = delta;
+            if (started_zero) fail0 = delta > T(0);
             const T theta = er.theta;
             if (theta > T(0)) {
                 T sigma = curv > T(0) ? T(1) : T(0);

@@ -483,6 +483,7 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
     delta_last = 0.0
     rho = 0.0
     nfix_term = sum(cfg.xf_fixed)
+    fail0 = False
     theta0 = None
     filt = []
     nrest = 0
@@ -561,7 +562,12 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
         rhs1 = -(gphi + Jg.T @ ybar)
         rhs = np.concatenate([rhs1, -c])
         # regularisation loop with inertia-free curvature test
+        # first trial: delta = 0, unless the previous iteration's delta = 0 attempt already failed (then continue from the
+        # decayed previous regularisation; it decays by kappa_minus per iteration, so it fades out on its own)
         delta = 0.0
+        if fail0 and delta_last > 0.0:
+            delta = max(opt.delta_min, opt.kappa_minus * delta_last)
+        started_zero = delta == 0.0
         ok = False
         ntry = 0
         while True:
@@ -598,6 +604,8 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
             break
         if delta > 0:
             delta_last = delta
+        if started_zero:
+            fail0 = delta > 0
         lam_new = sol[nv:]
         ds = -rg - Jg @ dz
         y_new = ybar + SigS * (Jg @ dz)

@@ -395,6 +395,13 @@ static void assemble(work_t* w, const double* cc, double delta, double dc, doubl
 
 static void ftb(double val, double dval, double tau, double* alpha) { if (dval < 0) { double a = -tau * val / dval; if (a < *alpha) *alpha = a; } }
 
+static int g_variant = 1;          /* 1 = the algorithm (skip the delta = 0 attempt after a failed one); 0/2: experiments */
+static long g_nfac_total = 0;
+static int g_nfac_max = 0;
+void oracle_set_variant(int v) { g_variant = v; g_nfac_total = 0; g_nfac_max = 0; }
+long oracle_nfac_total(void) { return g_nfac_total; }
+int oracle_nfac_max(void) { return g_nfac_max; }
+
 static int solve_one(work_t* w, int warm) {
     const oracle_config* c = w->c;
     const int n = w->n, N = w->N;
@@ -412,6 +419,7 @@ static int solve_one(work_t* w, int warm) {
     double* dy = (double*)malloc(sizeof(double) * 4 * n);
     double* y2 = (double*)malloc(sizeof(double) * N);
     int status = 1, it = 0;
+    int nfac = 0, fail0_streak = 0;
     /* initial vertex values */
     if (!warm) {
         double dth = wrap(w->xf[2] - w->x0[2]);
@@ -490,7 +498,11 @@ static int solve_one(work_t* w, int warm) {
         double dc = nfix > 0 ? delta_c * pow(mu, kappa_c) : 0.0;
         double delta = 0.0, Hdd, hd, curv = 0, dz2 = 0, hdz = 0, dphi = 0, a_p = 1, a_d = 1, dzmax = 0;
         int ok = 0;
+        if (g_variant == 1 && fail0_streak >= 1 && w->delta_last > 0) delta = fmax(delta_min, kminus * w->delta_last);
+        if (g_variant == 2 && fail0_streak >= 2 && w->delta_last > 0) delta = fmax(delta_min, kminus * w->delta_last);
+        int started_zero = delta == 0.0;
         for (int ntry = 0; ntry <= 40; ++ntry) {
+            ++nfac;
             assemble(w, cc, delta, dc, &Hdd, &hd);
             int good = band_factor(w) == 0;
             if (good) {
@@ -574,6 +586,8 @@ static int solve_one(work_t* w, int warm) {
         }
         if (!ok) { status = 3; break; }
         if (delta > 0) w->delta_last = delta;
+        if (started_zero) fail0_streak = delta > 0 ? fail0_streak + 1 : 0;
+        else if (g_variant == 2 && (it % 4) == 3) fail0_streak = 0;   /* re-probe delta = 0 now and then */
         double theta = e.theta;
         if (theta > 0) {
             double sigma = curv > 0 ? 1.0 : 0.0;
@@ -635,6 +649,8 @@ static int solve_one(work_t* w, int warm) {
         ++it;
     }
     free(cc); free(cct); free(st); free(ds); free(dy); free(y2);
+#pragma omp critical
+    { g_nfac_total += nfac; if (nfac > g_nfac_max) g_nfac_max = nfac; }
     return status * 100000 + it;
 }
 
