@@ -268,22 +268,47 @@ MPC_HD void model_derivs(const Problem<T>& P, const T tr[4], T v, T w, const T l
 // Stage cost = Lagrangian curvature of lam'(dt f) + objective + condensed barrier terms of the control box and
 // of the (linear) control-rate rows; the previous control enters only through the rate rows, so all of its
 // blocks are diagonal and never formed as dense matrices.  ~280 FMAs (the dense 6+2 version needs >600).
+// Index of the combined stage-cost entries ("A-form"): the non-zeros of the symmetric 8x8 stage Hessian over
+// (x0,x1,x2, up0,up1, d | u0,u1) and of its gradient column, already summed over Lagrangian curvature, objective,
+// condensed control-box, rate-row and clearance-row terms -- everything except the regularisation delta and the
+// dt-box/objective terms that live at stage 0.
+enum StageAdd {
+    A00 = 0, A01, A11, A22, A25, A26, A27, A33, A35, A36, A44, A45, A47, A55, A56, A57, A66, A67, A77,   // Hessian (19)
+    A08, A18, A28, A38, A48, A58, A68, A78,                                                              // gradient (8)
+    NADD
+};
+
 template <typename T>
 struct StageRec {
     T a0, a1;          // dt * d f_{0,1} / d theta
     T f[3];            // f(x_k, u_k)
     T B[3][2];         // dt * d f / d u
     T c[3];            // collocation residual c_k
-    T h00, h01, h02, h11, h12, h22;   // dt * sum_a lam_a d2 f_a / d(theta,v,w)^2
-    T g[3];            // sum_a lam_a d f_a / d(theta,v,w)   (cross terms with dt)
-    T sz[2];           // Sigma of the control box
-    T gb[2];           // barrier (+ quadratic objective) gradient wrt u
-    T ss[2], sl[2], sll;   // rate rows: sum sigma, sum sigma*lim, sum sigma*lim^2
-    T gy[2], gyl;      // rate rows: sum sg*ybar, sum sg*lim*ybar
-    T hx[3];           // objective gradient wrt x_k
-    T oxx, oxy, oyy;   // clearance rows: sum sigma a a' + y * hess(g) on (x, y)
-    T ogx, ogy;        // clearance rows: sum a * ybar
+    T A[NADD];         // combined stage cost, see StageAdd
 };
+
+// assembles the A-form from its ingredients (used by both kernels; the raw pieces are documented at the call sites)
+template <typename T>
+struct StageParts {
+    T h00, h01, h02, h11, h12, h22;   // dt * sum_a lam_a d2 f_a / d(theta,v,w)^2
+    T g[3];                           // sum_a lam_a d f_a / d(theta,v,w)   (cross terms with dt)
+    T sz[2], gb[2];                   // control box: Sigma, barrier (+objective) gradient
+    T ss[2], sl[2], sll, gy[2], gyl;  // rate rows: sum sigma, sigma*lim, sigma*lim^2, sg*ybar, sg*lim*ybar
+    T hx[3];                          // objective gradient wrt x_k
+    T oxx, oxy, oyy, ogx, ogy;        // clearance rows
+};
+template <typename T>
+MPC_HD void assemble_adds(const StageParts<T>& s, const T q2[3], const T r2[2], T A[NADD]) {
+    A[A00] = q2[0] + s.oxx; A[A01] = s.oxy; A[A11] = q2[1] + s.oyy; A[A22] = q2[2] + s.h00;
+    A[A25] = s.g[0]; A[A26] = s.h01; A[A27] = s.h02;
+    A[A33] = s.ss[0]; A[A35] = s.sl[0]; A[A36] = -s.ss[0];
+    A[A44] = s.ss[1]; A[A45] = s.sl[1]; A[A47] = -s.ss[1];
+    A[A55] = s.sll; A[A56] = s.g[1] - s.sl[0]; A[A57] = s.g[2] - s.sl[1];
+    A[A66] = s.h11 + s.sz[0] + s.ss[0] + r2[0]; A[A67] = s.h12; A[A77] = s.h22 + s.sz[1] + s.ss[1] + r2[1];
+    A[A08] = s.hx[0] + s.ogx; A[A18] = s.hx[1] + s.ogy; A[A28] = s.hx[2];
+    A[A38] = -s.gy[0]; A[A48] = -s.gy[1]; A[A58] = -s.gyl;
+    A[A68] = s.gb[0] + s.gy[0]; A[A78] = s.gb[1] + s.gy[1];
+}
 
 template <typename T>
 struct RicState {
@@ -295,12 +320,12 @@ struct StageGain {
     T K[2][6], kap[2], Kn[2][3];
 };
 
-// q2 = 2*Q diag (0 for min-time), r2 = 2*R diag, dx = regularisation of x_k (0 at k = 0), du = regularisation of
-// u_k, add_dd / add_qd = dt-box + objective terms that live at stage 0.  Returns false on a singular pivot.
+// dx = regularisation of x_k (0 at k = 0), du = regularisation of u_k, add_dd / add_qd = dt-box + objective terms that
+// live at stage 0.  Returns false on a singular pivot.
 template <typename T>
-MPC_HD bool riccati_step(RicState<T>& V, const StageRec<T>& r, const T q2[3], const T r2[2], T dx, T du, T add_dd, T add_qd,
-                         StageGain<T>& out) {
+MPC_HD bool riccati_step(RicState<T>& V, const StageRec<T>& r, T dx, T du, T add_dd, T add_qd, StageGain<T>& out) {
     T (&P)[6][6] = V.P;
+    const T* A = r.A;
     const T c0 = r.c[0], c1 = r.c[1], c2 = r.c[2];
     T w[6];
     for (int i = 0; i < 6; ++i) w[i] = V.p[i] + P[i][0] * c0 + P[i][1] * c1 + P[i][2] * c2;
@@ -312,34 +337,35 @@ MPC_HD bool riccati_step(RicState<T>& V, const StageRec<T>& r, const T q2[3], co
         Pa[i] = P[i][0] * r.a0 + P[i][1] * r.a1;
     }
     // Q~ over x (symmetric), cross x-d, d-d
-    T Q00 = P[0][0] + dx + q2[0] + r.oxx, Q01 = P[0][1] + r.oxy, Q11 = P[1][1] + dx + q2[1] + r.oyy;
+    T Q00 = P[0][0] + dx + A[A00], Q01 = P[0][1] + A[A01], Q11 = P[1][1] + dx + A[A11];
     T Q02 = P[0][2] + Pa[0], Q12 = P[1][2] + Pa[1];
-    T Q22 = P[2][2] + T(2) * Pa[2] + r.a0 * Pa[0] + r.a1 * Pa[1] + dx + q2[2] + r.h00;
-    T qd0 = e[0], qd1 = e[1], qd2 = e[2] + r.a0 * e[0] + r.a1 * e[1] + r.g[0];
-    T Qdd = r.f[0] * (e[0] + P[0][5]) + r.f[1] * (e[1] + P[1][5]) + r.f[2] * (e[2] + P[2][5]) + P[5][5] + r.sll + add_dd;
-    // M~ (u rows): x columns, d column; the u_{k-1} columns are -diag(ss)
+    T Q22 = P[2][2] + T(2) * Pa[2] + r.a0 * Pa[0] + r.a1 * Pa[1] + dx + A[A22];
+    T qd0 = e[0], qd1 = e[1], qd2 = e[2] + r.a0 * e[0] + r.a1 * e[1] + A[A25];
+    T Qdd = r.f[0] * (e[0] + P[0][5]) + r.f[1] * (e[1] + P[1][5]) + r.f[2] * (e[2] + P[2][5]) + P[5][5] + A[A55] + add_dd;
+    // M~ (u rows): x columns, d column; the u_{k-1} columns are diag(A36, A47)
     T Mx[2][3], Md[2];
     for (int j = 0; j < 2; ++j) {
         Mx[j][0] = E[0][j];
         Mx[j][1] = E[1][j];
         Mx[j][2] = E[2][j] + r.a0 * E[0][j] + r.a1 * E[1][j];
         Md[j] = r.B[0][j] * e[0] + r.B[1][j] * e[1] + r.B[2][j] * e[2] + P[0][3 + j] * r.f[0] + P[1][3 + j] * r.f[1] + P[2][3 + j] * r.f[2]
-              + P[3 + j][5] + r.g[1 + j] - r.sl[j];
+              + P[3 + j][5] + A[A56 + j];
     }
-    Mx[0][2] += r.h01;
-    Mx[1][2] += r.h02;
+    Mx[0][2] += A[A26];
+    Mx[1][2] += A[A27];
+    const T mu0 = A[A36], mu1 = A[A47];      // M~[0][up0], M~[1][up1]
     // R~
     T R00 = r.B[0][0] * E[0][0] + r.B[1][0] * E[1][0] + r.B[2][0] * E[2][0] + P[0][3] * r.B[0][0] + P[1][3] * r.B[1][0] + P[2][3] * r.B[2][0]
-          + P[3][3] + r.h11 + r.sz[0] + du + r.ss[0] + r2[0];
+          + P[3][3] + A[A66] + du;
     T R01 = r.B[0][0] * E[0][1] + r.B[1][0] * E[1][1] + r.B[2][0] * E[2][1] + P[0][3] * r.B[0][1] + P[1][3] * r.B[1][1] + P[2][3] * r.B[2][1]
-          + P[3][4] + r.h12;
+          + P[3][4] + A[A67];
     T R11 = r.B[0][1] * E[0][1] + r.B[1][1] * E[1][1] + r.B[2][1] * E[2][1] + P[0][4] * r.B[0][1] + P[1][4] * r.B[1][1] + P[2][4] * r.B[2][1]
-          + P[4][4] + r.h22 + r.sz[1] + du + r.ss[1] + r2[1];
+          + P[4][4] + A[A77] + du;
     // gradients
-    T qx0 = w[0] + r.hx[0] + r.ogx, qx1 = w[1] + r.hx[1] + r.ogy, qx2 = w[2] + r.a0 * w[0] + r.a1 * w[1] + r.hx[2];
+    T qx0 = w[0] + A[A08], qx1 = w[1] + A[A18], qx2 = w[2] + r.a0 * w[0] + r.a1 * w[1] + A[A28];
     T ru[2];
-    for (int j = 0; j < 2; ++j) ru[j] = r.B[0][j] * w[0] + r.B[1][j] * w[1] + r.B[2][j] * w[2] + w[3 + j] + r.gb[j] + r.gy[j];
-    T qdd = r.f[0] * w[0] + r.f[1] * w[1] + r.f[2] * w[2] + w[5] - r.gyl + add_qd;
+    for (int j = 0; j < 2; ++j) ru[j] = r.B[0][j] * w[0] + r.B[1][j] * w[1] + r.B[2][j] * w[2] + w[3 + j] + A[A68 + j];
+    T qdd = r.f[0] * w[0] + r.f[1] * w[1] + r.f[2] * w[2] + w[5] + A[A58] + add_qd;
     // nu columns
     T Sx2[3], Su[2][3], Sd[3];
     for (int b = 0; b < 3; ++b) {
@@ -358,8 +384,8 @@ MPC_HD bool riccati_step(RicState<T>& V, const StageRec<T>& r, const T q2[3], co
         K[0][i] = Ri00 * Mx[0][i] + Ri01 * Mx[1][i];
         K[1][i] = Ri01 * Mx[0][i] + Ri11 * Mx[1][i];
     }
-    K[0][3] = -Ri00 * r.ss[0]; K[0][4] = -Ri01 * r.ss[1];
-    K[1][3] = -Ri01 * r.ss[0]; K[1][4] = -Ri11 * r.ss[1];
+    K[0][3] = Ri00 * mu0; K[0][4] = Ri01 * mu1;
+    K[1][3] = Ri01 * mu0; K[1][4] = Ri11 * mu1;
     K[0][5] = Ri00 * Md[0] + Ri01 * Md[1];
     K[1][5] = Ri01 * Md[0] + Ri11 * Md[1];
     out.kap[0] = Ri00 * ru[0] + Ri01 * ru[1];
@@ -368,7 +394,6 @@ MPC_HD bool riccati_step(RicState<T>& V, const StageRec<T>& r, const T q2[3], co
         out.Kn[0][b] = Ri00 * Su[0][b] + Ri01 * Su[1][b];
         out.Kn[1][b] = Ri01 * Su[0][b] + Ri11 * Su[1][b];
     }
-    // new value function (before overwriting: S rows 0,1 are still needed -> done via temporaries above)
     const T Qx[3][3] = {{Q00, Q01, Q02}, {Q01, Q11, Q12}, {Q02, Q12, Q22}};
     const T qd[3] = {qd0, qd1, qd2};
     const T qx[3] = {qx0, qx1, qx2};
@@ -384,19 +409,19 @@ MPC_HD bool riccati_step(RicState<T>& V, const StageRec<T>& r, const T q2[3], co
             V.S[i][b] = sx - (Mx[0][i] * out.Kn[0][b] + Mx[1][i] * out.Kn[1][b]);
         }
     }
-    // u_{k-1} block: M~[a][up_j] = -ss_j delta_aj
-    P[3][3] = r.ss[0] + r.ss[0] * K[0][3];
-    P[3][4] = r.ss[0] * K[0][4]; P[4][3] = P[3][4];
-    P[4][4] = r.ss[1] + r.ss[1] * K[1][4];
-    P[3][5] = r.sl[0] + r.ss[0] * K[0][5]; P[5][3] = P[3][5];
-    P[4][5] = r.sl[1] + r.ss[1] * K[1][5]; P[5][4] = P[4][5];
+    // u_{k-1} block: M~[a][up_j] = mu_j delta_aj
+    P[3][3] = A[A33] - mu0 * K[0][3];
+    P[3][4] = -mu0 * K[0][4]; P[4][3] = P[3][4];
+    P[4][4] = A[A44] - mu1 * K[1][4];
+    P[3][5] = A[A35] - mu0 * K[0][5]; P[5][3] = P[3][5];
+    P[4][5] = A[A45] - mu1 * K[1][5]; P[5][4] = P[4][5];
     P[5][5] = Qdd - (Md[0] * K[0][5] + Md[1] * K[1][5]);
-    V.p[3] = -r.gy[0] + r.ss[0] * out.kap[0];
-    V.p[4] = -r.gy[1] + r.ss[1] * out.kap[1];
+    V.p[3] = A[A38] - mu0 * out.kap[0];
+    V.p[4] = A[A48] - mu1 * out.kap[1];
     V.p[5] = qdd - (Md[0] * out.kap[0] + Md[1] * out.kap[1]);
     for (int b = 0; b < 3; ++b) {
-        V.S[3][b] = r.ss[0] * out.Kn[0][b];
-        V.S[4][b] = r.ss[1] * out.Kn[1][b];
+        V.S[3][b] = -mu0 * out.Kn[0][b];
+        V.S[4][b] = -mu1 * out.Kn[1][b];
         V.S[5][b] = Sd[b] - (Md[0] * out.Kn[0][b] + Md[1] * out.Kn[1][b]);
     }
     for (int a = 0; a < 3; ++a) {
@@ -808,22 +833,24 @@ struct Ipm {
             StageRec<T> r;
             r.a0 = d * G[0][0]; r.a1 = d * G[1][0];
             for (int a = 0; a < 3; ++a) { r.f[a] = f[a]; r.B[a][0] = d * G[a][1]; r.B[a][1] = d * G[a][2]; r.c[a] = M.ld(L.CC + 3 * k + a); }
-            r.h00 = d * Hq[0][0]; r.h01 = d * Hq[0][1]; r.h02 = d * Hq[0][2]; r.h11 = d * Hq[1][1]; r.h12 = d * Hq[1][2]; r.h22 = d * Hq[2][2];
-            for (int j = 0; j < 3; ++j) r.g[j] = lam[0] * G[0][j] + lam[1] * G[1][j] + lam[2] * G[2][j];
+            StageParts<T> sp;
+            sp.h00 = d * Hq[0][0]; sp.h01 = d * Hq[0][1]; sp.h02 = d * Hq[0][2]; sp.h11 = d * Hq[1][1]; sp.h12 = d * Hq[1][2]; sp.h22 = d * Hq[2][2];
+            for (int j = 0; j < 3; ++j) sp.g[j] = lam[0] * G[0][j] + lam[1] * G[1][j] + lam[2] * G[2][j];
             for (int j = 0; j < 2; ++j) {
                 T u = j == 0 ? v : w;
                 T dl = u - P.u_lb[j], du = P.u_ub[j] - u;
-                r.sz[j] = M.ld(L.PL + 2 * k + j) / dl + M.ld(L.PU + 2 * k + j) / du;
-                r.gb[j] = -mu / dl + mu / du + r2[j] * u;
+                sp.sz[j] = M.ld(L.PL + 2 * k + j) / dl + M.ld(L.PU + 2 * k + j) / du;
+                sp.gb[j] = -mu / dl + mu / du + r2[j] * u;
             }
-            r.ss[0] = r.ss[1] = r.sl[0] = r.sl[1] = r.sll = r.gy[0] = r.gy[1] = r.gyl = T(0);
-            rate_terms(k, d, r.ss, r.sl, r.sll, r.gy, r.gyl);
-            for (int i = 0; i < 3; ++i) r.hx[i] = T(0);
-            r.oxx = r.oxy = r.oyy = r.ogx = r.ogy = T(0);
+            sp.ss[0] = sp.ss[1] = sp.sl[0] = sp.sl[1] = sp.sll = sp.gy[0] = sp.gy[1] = sp.gyl = T(0);
+            rate_terms(k, d, sp.ss, sp.sl, sp.sll, sp.gy, sp.gyl);
+            for (int i = 0; i < 3; ++i) sp.hx[i] = T(0);
+            sp.oxx = sp.oxy = sp.oyy = sp.ogx = sp.ogy = T(0);
             if (P.objective == OBJ_QUADRATIC) {
                 T xd[3] = {X(L.X, k, 0) - xf[0], X(L.X, k, 1) - xf[1], normalize_theta(X(L.X, k, 2) - xf[2])};
-                for (int i = 0; i < 3; ++i) r.hx[i] = q2[i] * xd[i];
+                for (int i = 0; i < 3; ++i) sp.hx[i] = q2[i] * xd[i];
             }
+            assemble_adds(sp, q2, r2, r.A);
             T add_dd = T(0), add_qd = T(0);
             if (k == 0) {
                 if (P.objective == OBJ_MIN_TIME) add_qd += T(n - 1);
@@ -834,7 +861,7 @@ struct Ipm {
                 }
             }
             StageGain<T> g;
-            if (!riccati_step(V, r, q2, r2, k >= 1 ? delta : T(0), delta, add_dd, add_qd, g)) return false;
+            if (!riccati_step(V, r, k >= 1 ? delta : T(0), delta, add_dd, add_qd, g)) return false;
             const int gb = L.GAIN + 50 * k;
             for (int a = 0; a < 2; ++a) for (int b = 0; b < 6; ++b) M.st(gb + 6 * a + b, g.K[a][b]);
             M.st(gb + 12, g.kap[0]); M.st(gb + 13, g.kap[1]);

@@ -27,7 +27,12 @@ __device__ long long g_mpc_prof[4096][14];
 namespace mpc {
 
 constexpr int kWave = 64;
-constexpr int NSTG = 40;   // per-stage LQ record (35..39: clearance-row block oxx, oxy, oyy, ogx, ogy)
+// per-stage LQ record: 0,1 a0,a1 | 2..4 f | 5..10 B[a][j] at 5+2a+j | 11..37 combined stage cost A[StageAdd] |
+// 38,39 raw control-box(+objective) gradient | 40..42 raw objective gradient wrt x
+constexpr int NSTG = 43;
+constexpr int RA = 11;     // first A slot
+constexpr int RGB = 38;    // raw gb
+constexpr int RHX = 40;    // raw hx
 constexpr int NGAIN = 20;  // K(2x6) kappa(2) Knu(2x3)
 
 struct WaveLayout {
@@ -353,9 +358,10 @@ struct IpmWave {
                 S_(0, k) = d * G[0][0]; S_(1, k) = d * G[1][0];
                 S_(2, k) = f[0]; S_(3, k) = f[1]; S_(4, k) = f[2];
                 for (int a = 0; a < 3; ++a) { S_(5 + 2 * a, k) = d * G[a][1]; S_(6 + 2 * a, k) = d * G[a][2]; }
-                S_(11, k) = d * Hq[0][0]; S_(12, k) = d * Hq[0][1]; S_(13, k) = d * Hq[0][2];
-                S_(14, k) = d * Hq[1][1]; S_(15, k) = d * Hq[1][2]; S_(16, k) = d * Hq[2][2];
-                S_(17, k) = gq[0]; S_(18, k) = gq[1]; S_(19, k) = gq[2];
+                // raw (mu-independent) pieces parked in their A slots; stage_barrier_terms() turns them into the combined entries
+                S_(RA + A22, k) = d * Hq[0][0]; S_(RA + A26, k) = d * Hq[0][1]; S_(RA + A27, k) = d * Hq[0][2];
+                S_(RA + A66, k) = d * Hq[1][1]; S_(RA + A67, k) = d * Hq[1][2]; S_(RA + A77, k) = d * Hq[2][2];
+                S_(RA + A25, k) = gq[0]; S_(RA + A56, k) = gq[1]; S_(RA + A57, k) = gq[2];
                 for (int i = 0; i < 3; ++i) {
                     T ci = C_(i, k);
                     rp = t_max(rp, t_abs(ci)); th += t_abs(ci); smult += t_abs(lam[i]);
@@ -368,7 +374,7 @@ struct IpmWave {
                     for (int i = 0; i < 3; ++i) gx[i] = T(2) * P.Q[i] * xd[i];
                     gu[0] = T(2) * P.R[0] * v; gu[1] = T(2) * P.R[1] * w;
                 }
-                S_(32, k) = gx[0]; S_(33, k) = gx[1]; S_(34, k) = gx[2];
+                S_(RHX, k) = gx[0]; S_(RHX + 1, k) = gx[1]; S_(RHX + 2, k) = gx[2];
                 T osx = T(0), osy = T(0);
                 if (L.M > 0 && k >= 1) {
                     const T px = F(L.X, 0, k), py = F(L.X, 1, k);
@@ -451,22 +457,30 @@ struct IpmWave {
         return e;
     }
 
-    // parallel: mu-dependent part of the stage records (box + rate-row condensation); record n-1 = final rate rows
+    // parallel: combine the raw pieces with the mu-dependent condensed barrier terms into the A-form; record n-1 = final rate rows
     __device__ void stage_barrier_terms() const {
         const int n = L.n;
         const T d = SCL(SC_D);
+        const bool quad = P.objective == OBJ_QUADRATIC;
+        T q2[3] = {T(0), T(0), T(0)}, r2[2] = {T(0), T(0)};
+        if (quad) { for (int i = 0; i < 3; ++i) q2[i] = T(2) * P.Q[i]; for (int j = 0; j < 2; ++j) r2[j] = T(2) * P.R[j]; }
         for (int k = lane; k < n; k += kWave) {
+            StageParts<T> sp;
+            sp.h00 = S_(RA + A22, k); sp.h01 = S_(RA + A26, k); sp.h02 = S_(RA + A27, k);
+            sp.h11 = S_(RA + A66, k); sp.h12 = S_(RA + A67, k); sp.h22 = S_(RA + A77, k);
+            sp.g[0] = S_(RA + A25, k); sp.g[1] = S_(RA + A56, k); sp.g[2] = S_(RA + A57, k);
+            sp.hx[0] = S_(RHX, k); sp.hx[1] = S_(RHX + 1, k); sp.hx[2] = S_(RHX + 2, k);
+            sp.sz[0] = sp.sz[1] = sp.gb[0] = sp.gb[1] = T(0);
             if (k < n - 1) {
                 for (int j = 0; j < 2; ++j) {
                     T u = F(L.U, j, k);
                     T dl = u - P.u_lb[j], du = P.u_ub[j] - u;
-                    S_(20 + j, k) = F(L.PL, j, k) / dl + F(L.PU, j, k) / du;
-                    T g = -mu / dl + mu / du;
-                    if (P.objective == OBJ_QUADRATIC) g += T(2) * P.R[j] * u;
-                    S_(22 + j, k) = g;
+                    sp.sz[j] = F(L.PL, j, k) / dl + F(L.PU, j, k) / du;
+                    sp.gb[j] = -mu / dl + mu / du + r2[j] * u;
                 }
             }
-            T ss[2] = {T(0), T(0)}, ssl[2] = {T(0), T(0)}, sll = T(0), gy[2] = {T(0), T(0)}, gyl = T(0);
+            S_(RGB, k) = sp.gb[0]; S_(RGB + 1, k) = sp.gb[1];
+            sp.ss[0] = sp.ss[1] = sp.sl[0] = sp.sl[1] = sp.sll = sp.gy[0] = sp.gy[1] = sp.gyl = T(0);
             for (int q = 0; q < 4; ++q) {
                 if (!row_on(k, q)) continue;
                 const int j = q & 1;
@@ -474,32 +488,28 @@ struct IpmWave {
                 T s = F(L.SR, q, k), y = F(L.YR, q, k);
                 T sig = y / s;
                 T ybar = mu / s + sig * (row_val(L.U, d, k, q) + s);
-                ss[j] += sig; ssl[j] += sig * lim; sll += sig * lim * lim;
-                gy[j] += sg * ybar; gyl += sg * lim * ybar;
+                sp.ss[j] += sig; sp.sl[j] += sig * lim; sp.sll += sig * lim * lim;
+                sp.gy[j] += sg * ybar; sp.gyl += sg * lim * ybar;
             }
-            {
-                T oxx = T(0), oxy = T(0), oyy = T(0), ogx = T(0), ogy = T(0);
-                if (L.M > 0 && k >= 1 && k < n - 1) {
-                    for (int m = 0; m < L.M; ++m) {
-                        if (F(L.OI, m, k) < T(0)) continue;
-                        const T s = F(L.OS, m, k), y = F(L.OY, m, k), g = F(L.OG, m, k);
-                        const T ax = F(L.OAX, m, k), ay = F(L.OAY, m, k), hk = F(L.OHK, m, k);
-                        const T sig = y / s;
-                        const T ybar = mu / s + sig * (g + s);
-                        // hess(g) = -hk (I - a a')
-                        oxx += sig * ax * ax - y * hk * (T(1) - ax * ax);
-                        oxy += sig * ax * ay + y * hk * ax * ay;
-                        oyy += sig * ay * ay - y * hk * (T(1) - ay * ay);
-                        ogx += ax * ybar; ogy += ay * ybar;
-                    }
+            sp.oxx = sp.oxy = sp.oyy = sp.ogx = sp.ogy = T(0);
+            if (L.M > 0 && k >= 1 && k < n - 1) {
+                for (int m = 0; m < L.M; ++m) {
+                    if (F(L.OI, m, k) < T(0)) continue;
+                    const T s = F(L.OS, m, k), y = F(L.OY, m, k), g = F(L.OG, m, k);
+                    const T ax = F(L.OAX, m, k), ay = F(L.OAY, m, k), hk = F(L.OHK, m, k);
+                    const T sig = y / s;
+                    const T ybar = mu / s + sig * (g + s);
+                    // hess(g) = -hk (I - a a')
+                    sp.oxx += sig * ax * ax - y * hk * (T(1) - ax * ax);
+                    sp.oxy += sig * ax * ay + y * hk * ax * ay;
+                    sp.oyy += sig * ay * ay - y * hk * (T(1) - ay * ay);
+                    sp.ogx += ax * ybar; sp.ogy += ay * ybar;
                 }
-                S_(35, k) = oxx; S_(36, k) = oxy; S_(37, k) = oyy; S_(38, k) = ogx; S_(39, k) = ogy;
             }
-            S_(24, k) = ss[0]; S_(25, k) = ss[1];
-            S_(26, k) = ssl[0]; S_(27, k) = ssl[1];
-            S_(28, k) = sll;
-            S_(29, k) = gy[0]; S_(30, k) = gy[1];
-            S_(31, k) = gyl;
+            T A[NADD];
+            assemble_adds(sp, q2, r2, A);
+#pragma unroll
+            for (int i = 0; i < NADD; ++i) S_(RA + i, k) = A[i];
         }
     }
 
@@ -513,28 +523,21 @@ struct IpmWave {
         {
             const int r = n - 1;
             T xd[3] = {F(L.X, 0, r) - xf[0], F(L.X, 1, r) - xf[1], normalize_theta(F(L.X, 2, r) - xf[2])};
-            T ss[2] = {S_(24, r), S_(25, r)}, sl[2] = {S_(26, r), S_(27, r)};
-            T gy[2] = {S_(29, r), S_(30, r)};
-            riccati_terminal(V, P, xd, delta, dc, ss, sl, S_(28, r), gy, S_(31, r));
+            T ss[2] = {S_(RA + A33, r), S_(RA + A44, r)}, sl[2] = {S_(RA + A35, r), S_(RA + A45, r)};
+            T gy[2] = {-S_(RA + A38, r), -S_(RA + A48, r)};
+            riccati_terminal(V, P, xd, delta, dc, ss, sl, S_(RA + A55, r), gy, -S_(RA + A58, r));
         }
         for (int k = n - 2; k >= 0; --k) {
             StageRec<T> r;
             r.a0 = S_(0, k); r.a1 = S_(1, k);
+#pragma unroll
             for (int a = 0; a < 3; ++a) {
                 r.f[a] = S_(2 + a, k);
                 r.B[a][0] = S_(5 + 2 * a, k); r.B[a][1] = S_(6 + 2 * a, k);
                 r.c[a] = C_(a, k);
-                r.g[a] = S_(17 + a, k);
-                r.hx[a] = S_(32 + a, k);
             }
-            r.h00 = S_(11, k); r.h01 = S_(12, k); r.h02 = S_(13, k);
-            r.h11 = S_(14, k); r.h12 = S_(15, k); r.h22 = S_(16, k);
-            for (int j = 0; j < 2; ++j) {
-                r.sz[j] = S_(20 + j, k); r.gb[j] = S_(22 + j, k);
-                r.ss[j] = S_(24 + j, k); r.sl[j] = S_(26 + j, k); r.gy[j] = S_(29 + j, k);
-            }
-            r.sll = S_(28, k); r.gyl = S_(31, k);
-            r.oxx = S_(35, k); r.oxy = S_(36, k); r.oyy = S_(37, k); r.ogx = S_(38, k); r.ogy = S_(39, k);
+#pragma unroll
+            for (int i = 0; i < NADD; ++i) r.A[i] = S_(RA + i, k);
             T add_dd = T(0), add_qd = T(0);
             if (k == 0) {
                 if (P.objective == OBJ_MIN_TIME) add_qd += T(n - 1);
@@ -545,7 +548,7 @@ struct IpmWave {
                 }
             }
             StageGain<T> g;
-            if (!riccati_step(V, r, q2, r2, k >= 1 ? delta : T(0), delta, add_dd, add_qd, g)) return false;
+            if (!riccati_step(V, r, k >= 1 ? delta : T(0), delta, add_dd, add_qd, g)) return false;
             if (lane == 0) {
                 for (int a = 0; a < 2; ++a) for (int b = 0; b < 6; ++b) G_(6 * a + b, k) = g.K[a][b];
                 G_(12, k) = g.kap[0]; G_(13, k) = g.kap[1];
@@ -555,196 +558,62 @@ struct IpmWave {
         return riccati_root(V, P, dd_out, nu_out);
     }
 
-    // ---------------------------------------------------------------- column-parallel backward Riccati sweep
-    // Lane c (0..11) owns column c of the 8 x 12 stage matrix
-    //     Hhat = [G Gam]' [ P+ (G | 0 | Gam) | p+ + P+ c~ | S+ ]  + stage cost,
-    // rows (x0,x1,x2,up0,up1,d | u0,u1), columns (x0,x1,x2,up0,up1,d, u0,u1, p, nu0,nu1,nu2).  After eliminating u_k
-    // with the 2x2 pivot (rows 6,7 of columns 6,7, broadcast with v_readlane), lane c holds column c of the new
-    // [P | p | S]; the six P columns go through a 36-word LDS buffer to every lane for the next stage.
-    // Same arithmetic as riccati_step(), ~3x fewer instructions per stage in the wave's instruction stream.
-    __device__ bool backward_cols(T delta, T dc, T& dd_out, T nu_out[3]) const {
-        const int n = L.n;
-        const T d = SCL(SC_D);
-        const int c = lane & 15;
-        const bool quad = P.objective == OBJ_QUADRATIC;
-        T q2[3] = {T(0), T(0), T(0)}, r2[2] = {T(0), T(0)};
-        if (quad) { for (int i = 0; i < 3; ++i) q2[i] = T(2) * P.Q[i]; for (int j = 0; j < 2; ++j) r2[j] = T(2) * P.R[j]; }
-        T* VP = sm + L.VP;
-        // per-lane addressing of "its" G/Gam/c column: co_m = sm[cbase + k*cstride + m*cstep]
-        int cbase = L.ZC, cstride = 0, cstep = 0;          // default: zeros
-        if (c == 2) { cbase = L.STG + 0; cstride = NSTG; cstep = 1; }          // (a0, a1, [1])
-        else if (c == 5) { cbase = L.STG + 2; cstride = NSTG; cstep = 1; }     // f
-        else if (c == 6) { cbase = L.STG + 5; cstride = NSTG; cstep = 2; }     // Bx[:,0]
-        else if (c == 7) { cbase = L.STG + 6; cstride = NSTG; cstep = 2; }     // Bx[:,1]
-        else if (c == 8) { cbase = L.CC; cstride = 3; cstep = 1; }             // c_k
-        const int psel = c == 6 ? L.VP + 18 : (c == 7 ? L.VP + 24 : (c == 5 ? L.VP + 30 : L.ZC));   // extra P+ column
-        if (lane == 0) { for (int i = 0; i < 6; ++i) sm[L.ZC + i] = T(0); sm[L.ZC + 6] = T(1); }
-        // ---- terminal value function
-        T own[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};   // lane 8: p ; lanes 9..11: S[:, b]
-        T Wc[3] = {T(0), T(0), T(0)};                        // lanes 9+b: W[:, b]
-        T om = T(0);                                         // lanes 9+a: omega[a]
-        {
-            const int r = n - 1;
-            T col[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
-            const T ss0 = S_(24, r), ss1 = S_(25, r), sl0 = S_(26, r), sl1 = S_(27, r), sll = S_(28, r);
-            T xd[3] = {F(L.X, 0, r) - xf[0], F(L.X, 1, r) - xf[1], normalize_theta(F(L.X, 2, r) - xf[2])};
-            if (c < 3) { if (!P.xf_fixed[c]) col[c] = delta + ((quad && P.has_Qf) ? T(2) * P.Qf[c] : T(0)); }
-            else if (c == 3) { col[3] = ss0; col[5] = sl0; }
-            else if (c == 4) { col[4] = ss1; col[5] = sl1; }
-            else if (c == 5) { col[3] = sl0; col[4] = sl1; col[5] = sll; }
-            else if (c == 8) {
-                for (int i = 0; i < 3; ++i) if (!P.xf_fixed[i] && quad && P.has_Qf) own[i] = T(2) * P.Qf[i] * xd[i];
-                own[3] = -S_(29, r); own[4] = -S_(30, r); own[5] = -S_(31, r);
-            } else if (c >= 9 && c < 12) {
-                const int b = c - 9;
-                if (P.xf_fixed[b]) { own[b] = T(1); Wc[b] = -dc; }
-            }
-            sync();
-            if (lane < 6) { for (int i = 0; i < 6; ++i) VP[6 * lane + i] = col[i]; }
-            sync();
-        }
-        T v[6] = {T(0), T(0), T(0), T(0), T(0), T(0)};
-        for (int k = n - 2; k >= 0; --k) {
-            // one batch of uniform LDS reads (no loads inside the divergent column branches below)
-            T rec[NSTG];
+    // inclusive suffix sum over the lanes of the wave (lane l gets sum_{l' >= l} v[l'])
+    __device__ __forceinline__ T wave_suffix_sum(T v) const {
 #pragma unroll
-            for (int i = 0; i < NSTG; ++i) rec[i] = S_(i, k);
-            const T a0 = rec[0], a1 = rec[1];
-            const T f0 = rec[2], f1 = rec[3], f2 = rec[4];
-            const T B00 = rec[5], B01 = rec[6], B10 = rec[7], B11 = rec[8], B20 = rec[9], B21 = rec[10];
-            // lane's column of [G | 0 | Gam | c~]
-            const int cb = cbase + k * cstride;
-            T co0 = sm[cb], co1 = sm[cb + cstep], co2 = sm[cb + 2 * cstep];
-            if (c == 0) { co0 = T(1); }
-            else if (c == 1) { co1 = T(1); }
-            else if (c == 2) { co2 = T(1); }
-            // z = P+ * column + own
-            T z[6];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) z[i] = (VP[i] * co0 + VP[6 + i] * co1) + (VP[12 + i] * co2 + sm[psel + i]) + own[i];
-            if (c >= 9) om += own[0] * C_(0, k) + own[1] * C_(1, k) + own[2] * C_(2, k);
-            // Hhat column
-            T h[8];
-            h[0] = z[0]; h[1] = z[1];
-            h[2] = z[2] + a0 * z[0] + a1 * z[1];
-            h[3] = T(0); h[4] = T(0);
-            h[5] = (f0 * z[0] + f1 * z[1]) + (f2 * z[2] + z[5]);
-            h[6] = (B00 * z[0] + B10 * z[1]) + (B20 * z[2] + z[3]);
-            h[7] = (B01 * z[0] + B11 * z[1]) + (B21 * z[2] + z[4]);
-            // stage cost column
-            const T dxr = k >= 1 ? delta : T(0);
-            if (c == 0) { h[0] += dxr + q2[0] + rec[35]; h[1] += rec[36]; }
-            else if (c == 1) { h[1] += dxr + q2[1] + rec[37]; h[0] += rec[36]; }
-            else if (c == 2) { h[2] += dxr + q2[2] + rec[11]; h[5] += rec[17]; h[6] += rec[12]; h[7] += rec[13]; }
-            else if (c == 3) { h[3] += rec[24]; h[5] += rec[26]; h[6] -= rec[24]; }
-            else if (c == 4) { h[4] += rec[25]; h[5] += rec[27]; h[7] -= rec[25]; }
-            else if (c == 5) {
-                T add_dd = T(0);
-                if (k == 0 && P.dt_free) add_dd = SCL(SC_PDL) / (d - P.dt_lb) + SCL(SC_PDU) / (P.dt_ub - d) + delta;
-                h[2] += rec[17]; h[3] += rec[26]; h[4] += rec[27]; h[5] += rec[28] + add_dd;
-                h[6] += rec[18] - rec[26]; h[7] += rec[19] - rec[27];
-            } else if (c == 6) {
-                h[2] += rec[12]; h[3] -= rec[24]; h[5] += rec[18] - rec[26];
-                h[6] += rec[14] + rec[20] + delta + rec[24] + r2[0]; h[7] += rec[15];
-            } else if (c == 7) {
-                h[2] += rec[13]; h[4] -= rec[25]; h[5] += rec[19] - rec[27];
-                h[6] += rec[15]; h[7] += rec[16] + rec[21] + delta + rec[25] + r2[1];
-            } else if (c == 8) {
-                T add_qd = T(0);
-                if (k == 0) {
-                    if (P.objective == OBJ_MIN_TIME) add_qd += T(n - 1);
-                    if (P.dt_free) add_qd += -mu / (d - P.dt_lb) + mu / (P.dt_ub - d);
-                }
-                h[0] += rec[32] + rec[38]; h[1] += rec[33] + rec[39]; h[2] += rec[34];
-                h[3] -= rec[29]; h[4] -= rec[30]; h[5] += add_qd - rec[31];
-                h[6] += rec[22] + rec[29]; h[7] += rec[23] + rec[30];
-            }
-            // 2x2 pivot from columns 6,7 (rows 6,7)
-            const T R00 = lane_bcast(h[6], 6), R01 = lane_bcast(h[7], 6), R11 = lane_bcast(h[7], 7);
-            const T det = R00 * R11 - R01 * R01;
-            const T scale = t_abs(R00 * R11) + R01 * R01;
-            if (!(t_abs(det) > T(1e-14) * scale) || !t_finite(det)) return false;
-            const T id = T(1) / det;
-            const T Ri00 = R11 * id, Ri01 = -R01 * id, Ri11 = R00 * id;
-            const T K0 = Ri00 * h[6] + Ri01 * h[7], K1 = Ri01 * h[6] + Ri11 * h[7];
-            // gains: lanes 0..5 -> K[:, c], lane 8 -> kappa, lanes 9..11 -> Knu[:, b]
-            if (lane < 12 && lane != 6 && lane != 7) {
-                const int g0 = lane < 6 ? lane : (lane == 8 ? 12 : 14 + (lane - 9));
-                const int g1 = lane < 6 ? 6 + lane : (lane == 8 ? 13 : 17 + (lane - 9));
-                G_(g0, k) = K0; G_(g1, k) = K1;
-            }
-            // M~' = rows 0..5 of columns 6,7
-#pragma unroll
-            for (int i = 0; i < 6; ++i) {
-                const T m0 = lane_bcast(h[i], 6), m1 = lane_bcast(h[i], 7);
-                v[i] = h[i] - (m0 * K0 + m1 * K1);
-            }
-            // W, omega (lanes 9..11): Su[j][a] = h[6+j] of lane 9+a ; kappa from lane 8
-            {
-                const T ka0 = lane_bcast(K0, 8), ka1 = lane_bcast(K1, 8);
-                if (c >= 9) om -= h[6] * ka0 + h[7] * ka1;
-                const T s60 = lane_bcast(h[6], 9), s70 = lane_bcast(h[7], 9);
-                const T s61 = lane_bcast(h[6], 10), s71 = lane_bcast(h[7], 10);
-                const T s62 = lane_bcast(h[6], 11), s72 = lane_bcast(h[7], 11);
-                if (c >= 9) {
-                    Wc[0] -= s60 * K0 + s70 * K1;
-                    Wc[1] -= s61 * K0 + s71 * K1;
-                    Wc[2] -= s62 * K0 + s72 * K1;
-                }
-            }
-            if (c >= 8) { for (int i = 0; i < 6; ++i) own[i] = v[i]; }
-            sync();
-            if (lane < 6) { for (int i = 0; i < 6; ++i) VP[6 * lane + i] = v[i]; }
-            sync();
-        }
-        // ---- root: gather P[5][5], p[5], S[5][:], W, omega
-        RicState<T> V;
-        V.P[5][5] = lane_bcast(v[5], 5);
-        V.p[5] = lane_bcast(own[5], 8);
-        V.S[5][0] = lane_bcast(own[5], 9); V.S[5][1] = lane_bcast(own[5], 10); V.S[5][2] = lane_bcast(own[5], 11);
-        for (int a = 0; a < 3; ++a) {
-            V.W[a][0] = lane_bcast(Wc[a], 9); V.W[a][1] = lane_bcast(Wc[a], 10); V.W[a][2] = lane_bcast(Wc[a], 11);
-        }
-        V.om[0] = lane_bcast(om, 9); V.om[1] = lane_bcast(om, 10); V.om[2] = lane_bcast(om, 11);
-        return riccati_root(V, P, dd_out, nu_out);
+        for (int o = 1; o < kWave; o <<= 1) { T w2 = __shfl_down(v, o); if (lane + o < kWave) v += w2; }
+        return v;
     }
 
-    // wave-uniform: state recurrence (writes DU, DX) then costate recurrence (writes LAMN)
+    // state recurrence (wave-uniform, software-pipelined LDS reads) then multipliers by lane-parallel suffix scans
     __device__ void forward_states(T dd, const T nu[3], T delta) const {
         const int n = L.n;
-        T xi[6] = {T(0), T(0), T(0), T(0), T(0), dd};
-        if (lane == 0) { SCL(SC_DD) = dd; F(L.DX, 0, 0) = T(0); F(L.DX, 1, 0) = T(0); F(L.DX, 2, 0) = T(0); }
-        for (int k = 0; k < n - 1; ++k) {
-            // one batch of independent LDS reads, then arithmetic
-            T g[NGAIN], sr[11], ck[3];
-#pragma unroll
-            for (int i = 0; i < NGAIN; ++i) g[i] = G_(i, k);
-#pragma unroll
-            for (int i = 0; i < 11; ++i) sr[i] = S_(i, k);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) ck[i] = C_(i, k);
-            T du_[2];
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                T acc0 = g[12 + a] + g[6 * a + 0] * xi[0] + g[6 * a + 1] * xi[1];
-                T acc1 = g[6 * a + 2] * xi[2] + g[6 * a + 3] * xi[3];
-                T acc2 = g[6 * a + 4] * xi[4] + g[6 * a + 5] * xi[5];
-                T acc3 = g[14 + 3 * a] * nu[0] + g[15 + 3 * a] * nu[1] + g[16 + 3 * a] * nu[2];
-                du_[a] = -((acc0 + acc1) + (acc2 + acc3));
-            }
-            T xn[3];
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                T ax = a < 2 ? sr[a] : T(0);
-                xn[a] = (xi[a] + ax * xi[2]) + (sr[5 + 2 * a] * du_[0] + sr[6 + 2 * a] * du_[1]) + (sr[2 + a] * dd + ck[a]);
-            }
-            if (lane == 0) {
-                F(L.DU, 0, k) = du_[0]; F(L.DU, 1, k) = du_[1];
-                F(L.DX, 0, k + 1) = xn[0]; F(L.DX, 1, k + 1) = xn[1]; F(L.DX, 2, k + 1) = xn[2];
-            }
-            xi[0] = xn[0]; xi[1] = xn[1]; xi[2] = xn[2]; xi[3] = du_[0]; xi[4] = du_[1];
+        // ---- lane-parallel: fold nu and dd into the affine terms so that the serial loop only carries (x, u_prev)
+        //      kappa^ = kappa + Knu nu + K[:,5] dd  (stored over kappa),  c^ = c + f dd  (stored in LAMN, rewritten below)
+        for (int k = lane; k < n - 1; k += kWave) {
+            for (int a = 0; a < 2; ++a)
+                G_(12 + a, k) += G_(14 + 3 * a, k) * nu[0] + G_(15 + 3 * a, k) * nu[1] + G_(16 + 3 * a, k) * nu[2] + G_(6 * a + 5, k) * dd;
+            for (int i = 0; i < 3; ++i) F(L.LAMN, i, k) = C_(i, k) + S_(2 + i, k) * dd;
         }
-        // costate: lam+_{k-1} = A_x,k^T lam+_k + (H dz)_{x_k} + h_{x_k}
+        if (lane == 0) { SCL(SC_DD) = dd; F(L.DX, 0, 0) = T(0); F(L.DX, 1, 0) = T(0); F(L.DX, 2, 0) = T(0); }
+        sync();
+        // ---- serial: xi = (dx, du_prev); 23 LDS words per stage, prefetched one stage ahead
+        T xi[5] = {T(0), T(0), T(0), T(0), T(0)};
+        T cur[23];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) { cur[i] = G_(i, 0); cur[5 + i] = G_(6 + i, 0); }
+        cur[10] = G_(12, 0); cur[11] = G_(13, 0);
+        cur[12] = S_(0, 0); cur[13] = S_(1, 0);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) cur[14 + i] = S_(5 + i, 0);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) cur[20 + i] = F(L.LAMN, i, 0);
+        for (int k = 0; k < n - 1; ++k) {
+            T nxt[23];
+            const int kn = k + 1 < n - 1 ? k + 1 : k;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) { nxt[i] = G_(i, kn); nxt[5 + i] = G_(6 + i, kn); }
+            nxt[10] = G_(12, kn); nxt[11] = G_(13, kn);
+            nxt[12] = S_(0, kn); nxt[13] = S_(1, kn);
+#pragma unroll
+            for (int i = 0; i < 6; ++i) nxt[14 + i] = S_(5 + i, kn);
+#pragma unroll
+            for (int i = 0; i < 3; ++i) nxt[20 + i] = F(L.LAMN, i, kn);
+            const T du0 = -((cur[10] + cur[0] * xi[0] + cur[1] * xi[1]) + (cur[2] * xi[2] + cur[3] * xi[3] + cur[4] * xi[4]));
+            const T du1 = -((cur[11] + cur[5] * xi[0] + cur[6] * xi[1]) + (cur[7] * xi[2] + cur[8] * xi[3] + cur[9] * xi[4]));
+            const T xn0 = (xi[0] + cur[12] * xi[2]) + (cur[14] * du0 + cur[15] * du1 + cur[20]);
+            const T xn1 = (xi[1] + cur[13] * xi[2]) + (cur[16] * du0 + cur[17] * du1 + cur[21]);
+            const T xn2 = xi[2] + (cur[18] * du0 + cur[19] * du1 + cur[22]);
+            if (lane == 0) {
+                F(L.DU, 0, k) = du0; F(L.DU, 1, k) = du1;
+                F(L.DX, 0, k + 1) = xn0; F(L.DX, 1, k + 1) = xn1; F(L.DX, 2, k + 1) = xn2;
+            }
+            xi[0] = xn0; xi[1] = xn1; xi[2] = xn2; xi[3] = du0; xi[4] = du1;
+#pragma unroll
+            for (int i = 0; i < 23; ++i) cur[i] = nxt[i];
+        }
+        // ---- multipliers: lam+_{k-1} = lam+_k + t_k + e_theta (a0_k lam+_k[0] + a1_k lam+_k[1]),  k = n-2 .. 1,
+        //      lam+_{n-2} from the terminal condition.  Components 0,1 are plain suffix sums, component 2 a second one.
         T lp[3];
         for (int i = 0; i < 3; ++i) {
             if (P.xf_fixed[i]) lp[i] = nu[i];
@@ -758,23 +627,33 @@ struct IpmWave {
                 lp[i] = g;
             }
         }
-        if (lane == 0) { F(L.LAMN, 0, n - 2) = lp[0]; F(L.LAMN, 1, n - 2) = lp[1]; F(L.LAMN, 2, n - 2) = lp[2]; }
         sync();
-        for (int k = n - 2; k >= 1; --k) {
-            T dx[3] = {F(L.DX, 0, k), F(L.DX, 1, k), F(L.DX, 2, k)};
-            T duv = F(L.DU, 0, k), duw = F(L.DU, 1, k);
-            T t[3];
-            for (int i = 0; i < 3; ++i) {
-                T qd = delta + (P.objective == OBJ_QUADRATIC ? T(2) * P.Q[i] : T(0));
-                t[i] = qd * dx[i] + S_(32 + i, k);
+        T carry[3] = {T(0), T(0), T(0)};                 // sum of t_m over the chunks already processed (m larger)
+        const int last = n - 2;                          // stages m = 1 .. n-2 carry a term t_m
+        for (int base = ((last) / kWave) * kWave; base >= 0; base -= kWave) {
+            const int m = base + lane;
+            const bool act = m >= 1 && m <= last;
+            T t0 = T(0), t1 = T(0), t2 = T(0), a0 = T(0), a1 = T(0);
+            if (act) {
+                const T dx0 = F(L.DX, 0, m), dx1 = F(L.DX, 1, m), dx2 = F(L.DX, 2, m);
+                const T duv = F(L.DU, 0, m), duw = F(L.DU, 1, m);
+                t0 = delta * dx0 + S_(RA + A00, m) * dx0 + S_(RA + A01, m) * dx1 + S_(RA + A08, m);
+                t1 = delta * dx1 + S_(RA + A01, m) * dx0 + S_(RA + A11, m) * dx1 + S_(RA + A18, m);
+                t2 = delta * dx2 + S_(RA + A22, m) * dx2 + S_(RA + A26, m) * duv + S_(RA + A27, m) * duw + S_(RA + A25, m) * dd + S_(RA + A28, m);
+                a0 = S_(0, m); a1 = S_(1, m);
             }
-            t[0] += S_(35, k) * dx[0] + S_(36, k) * dx[1] + S_(38, k);
-            t[1] += S_(36, k) * dx[0] + S_(37, k) * dx[1] + S_(39, k);
-            t[2] += S_(11, k) * dx[2] + S_(12, k) * duv + S_(13, k) * duw + S_(17, k) * dd
-                  + S_(0, k) * lp[0] + S_(1, k) * lp[1];
-            lp[0] += t[0]; lp[1] += t[1]; lp[2] += t[2];
-            if (lane == 0) { F(L.LAMN, 0, k - 1) = lp[0]; F(L.LAMN, 1, k - 1) = lp[1]; F(L.LAMN, 2, k - 1) = lp[2]; }
+            const T s0 = wave_suffix_sum(t0) + carry[0];     // sum_{m' >= m} t_m'[0]
+            const T s1 = wave_suffix_sum(t1) + carry[1];
+            // lam+_m[0..1] = lp + sum_{m' >= m+1} t_m'  = lp + s - t_m
+            const T l0 = lp[0] + s0 - t0, l1 = lp[1] + s1 - t1;
+            const T t2f = act ? t2 + a0 * l0 + a1 * l1 : T(0);
+            const T s2 = wave_suffix_sum(t2f) + carry[2];
+            if (act) {       // lam+_{m-1} = lp + sum_{m' >= m} t_m'
+                F(L.LAMN, 0, m - 1) = lp[0] + s0; F(L.LAMN, 1, m - 1) = lp[1] + s1; F(L.LAMN, 2, m - 1) = lp[2] + s2;
+            }
+            carry[0] = lane_bcast(s0, 0); carry[1] = lane_bcast(s1, 0); carry[2] = lane_bcast(s2, 0);
         }
+        if (lane == 0) { F(L.LAMN, 0, last) = lp[0]; F(L.LAMN, 1, last) = lp[1]; F(L.LAMN, 2, last) = lp[2]; }
     }
 
     // ---------------------------------------------------------------- parallel post-processing of the step
@@ -808,7 +687,7 @@ struct IpmWave {
                     T u = F(L.U, j, k), du_ = F(L.DU, j, k);
                     T dl = u - P.u_lb[j], du = P.u_ub[j] - u;
                     T pl = F(L.PL, j, k), pu = F(L.PU, j, k);
-                    T gbar = S_(22 + j, k);         // barrier (+ quadratic objective) gradient wrt u
+                    T gbar = S_(RGB + j, k);         // barrier (+ quadratic objective) gradient wrt u
                     hdz += gbar * du_; dphi += gbar * du_;
                     ftb(dl, du_, tau, a_p); ftb(du, -du_, tau, a_p);
                     ftb(pl, mu / dl - pl - (pl / dl) * du_, tau, a_d);
@@ -828,7 +707,7 @@ struct IpmWave {
                         dz2 += dx * dx; dzmax = t_max(dzmax, t_abs(dx));
                         T g = T(0);
                         if (P.objective == OBJ_QUADRATIC) {
-                            if (k < n - 1) g = S_(32 + i, k);
+                            if (k < n - 1) g = S_(RHX + i, k);
                             else if (P.has_Qf) { T xd = F(L.X, i, k) - xf[i]; if (i == 2) xd = normalize_theta(xd); g = T(2) * P.Qf[i] * xd; }
                         }
                         hdz += g * dx; dphi += g * dx;
@@ -1098,11 +977,7 @@ struct IpmWave {
             T dd = T(0), nu[3] = {T(0), T(0), T(0)}, curv = T(0);
             for (int ntry = 0; ntry <= 40; ++ntry) {
                 bool good;
-                #ifdef MPC_COLUMN_SWEEP   // experimental: column-parallel sweep (correct, currently slower than the uniform one)
-                MPC_TICK(2, good = backward_cols(delta, dc, dd, nu); sync());
-#else
-                MPC_TICK(2, good = backward(delta, dc, dd, nu); sync());
-#endif
+                                MPC_TICK(2, good = backward(delta, dc, dd, nu); sync());
 #ifdef MPC_PROFILE
                 ++nfac;
 #endif
