@@ -237,7 +237,8 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
     {
         const int O = cfg->max_obstacles > 0 ? cfg->max_obstacles : 0;
         const int M = O > 0 ? (cfg->max_obstacle_rows > 0 ? cfg->max_obstacle_rows : 4) : 0;
-        s->WL = mpc::WaveLayout::make(cfg->n, M, O, cfg->max_vertices > 0 ? cfg->max_vertices : 1);
+        const int ntrig = (cfg->model == MPC_MODEL_KINEMATIC_BICYCLE || cfg->model == MPC_MODEL_SIMPLE_CAR_FRONT) ? 4 : 3;
+        s->WL = mpc::WaveLayout::make(cfg->n, M, O, cfg->max_vertices > 0 ? cfg->max_vertices : 1, ntrig);
     }
     s->wave_lds = ((((size_t)s->WL.total * (cfg->precision == MPC_FP32 ? 4 : 8)) + 15) & ~(size_t)15) + 16 +
                   ((cfg->precision == MPC_FP32 ? sizeof(mpc::Problem<float>) : sizeof(mpc::Problem<double>)) + 15 & ~(size_t)15) + sizeof(mpc::WaveLayout);

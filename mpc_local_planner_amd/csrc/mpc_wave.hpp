@@ -27,35 +27,34 @@ __device__ long long g_mpc_prof[4096][14];
 namespace mpc {
 
 constexpr int kWave = 64;
-// per-stage LQ record: 0,1 a0,a1 | 2..4 f | 5..10 B[a][j] at 5+2a+j | 11..37 combined stage cost A[StageAdd] |
-// 38,39 raw control-box(+objective) gradient | 40..42 raw objective gradient wrt x
-constexpr int NSTG = 43;
+// per-stage LQ record: 0,1 a0,a1 | 2..4 f | 5..10 B[a][j] at 5+2a+j | 11..37 combined stage cost A[StageAdd]
+constexpr int NSTG = 38;
 constexpr int RA = 11;     // first A slot
-constexpr int RGB = 38;    // raw gb
-constexpr int RHX = 40;    // raw hx
 constexpr int NGAIN = 20;  // K(2x6) kappa(2) Knu(2x3)
 
 struct WaveLayout {
     int n, NS;
-    int X, U, XT, UT, LAM, LAMN, SR, YR, PL, PU, DX, DU, CC, TRIG, GAIN, STG, SC, VP, ZC, total;
+    int NTR;                                      // trig-cache words per stage (3, or 4 for the bicycle / front-wheel car)
+    int X, U, LAM, LAMN, SR, YR, PL, PU, DX, DU, CC, TRIG, GAIN, STG, SC, VP, ZC, total;
     int M, O, V;                                  // clearance rows per grid point, obstacles, vertices per obstacle
     int OS, OY, OI, OG, OAX, OAY, OHK;            // per-row slack, multiplier, obstacle index, cached g, gradient, curvature
     int GV, GNV, GR, GC;                          // obstacle geometry: vertices, vertex counts, radii, centroids
-    __host__ __device__ static WaveLayout make(int n, int M = 0, int O = 0, int V = 1) {
+    __host__ __device__ static WaveLayout make(int n, int M = 0, int O = 0, int V = 1, int ntrig = 4) {
         WaveLayout L;
         L.n = n;
         L.NS = n;
         int o = 0;
         auto take = [&](int comps) { int b = o; o += comps * n; return b; };
-        L.X = take(3); L.U = take(2); L.XT = take(3); L.UT = take(2);
+        L.NTR = ntrig;
+        L.X = take(3); L.U = take(2);
         L.LAM = take(3); L.LAMN = take(3);
         L.SR = take(4); L.YR = take(4);
         L.PL = take(2); L.PU = take(2);
         L.DX = take(3); L.DU = take(2);
-        L.CC = take(3); L.TRIG = take(4);
+        L.CC = take(3); L.TRIG = take(ntrig);
         L.GAIN = take(NGAIN); L.STG = take(NSTG);
         L.SC = o; o += 8;     // scalars: D, DT, DD, PDL, PDU
-        L.VP = o; o += 36;    // value-function matrix P of the stage being eliminated (column-major), column-parallel sweep
+        L.VP = o; o += 264;   // matrix-sweep scratch: VM 6x12 | T1 7x12 | HM 8x12 | W 3x3 + omega 3
         L.ZC = o; o += 8;     // constants: 6 zeros, then 1.0
         L.M = M; L.O = O; L.V = V;
         L.OS = take(M); L.OY = take(M); L.OI = take(M); L.OG = take(M); L.OAX = take(M); L.OAY = take(M); L.OHK = take(M);
@@ -114,6 +113,14 @@ struct IpmWave {
     __device__ __forceinline__ T& C_(int i, int k) const { return sm[L.CC + k * 3 + i]; }
     __device__ __forceinline__ T& SCL(int i) const { return sm[L.SC + i]; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
+
+    // trial point z + alpha*dz, evaluated on the fly (no trial copy in LDS)
+    __device__ __forceinline__ T xt(int i, int k, T alpha) const {
+        T x = F(L.X, i, k);
+        if (k > 0 && (k < L.n - 1 || !P.xf_fixed[i])) { x += alpha * F(L.DX, i, k); if (i == 2) x = normalize_theta(x); }
+        return x;
+    }
+    __device__ __forceinline__ T ut(int j, int k, T alpha) const { return F(L.U, j, k) + alpha * F(L.DU, j, k); }
 
     __device__ __forceinline__ bool row_on(int r, int q) const { return P.rate_on[q] && (r > 0 || row0_on); }
 
@@ -247,14 +254,15 @@ struct IpmWave {
 
     // ---------------------------------------------------------------- point evaluation (parallel)
     // trig cache + c_k for the point (XB, UB, d); returns wave-reduced sum|c|, objective
-    __device__ void eval_point(int XB, int UB, T d, T& theta_c, T& fobj, T alpha = T(0), bool trial = false) const {
+    __device__ void eval_point(T d, T& theta_c, T& fobj, T alpha = T(0), bool trial = false) const {
         const int n = L.n;
+        const T al = trial ? alpha : T(0);
         T th = T(0), fo = T(0);
         // clearance rows (non-linear): |g(x_k) + s| with the trial slack s + alpha*ds
         if (L.M > 0) {
             for (int k = lane; k < n - 1; k += kWave) {
                 if (k < 1) continue;
-                const T px = F(XB, 0, k), py = F(XB, 1, k);
+                const T px = xt(0, k, al), py = xt(1, k, al);
                 for (int m = 0; m < L.M; ++m) {
                     T g, ax, ay, hk;
                     if (!obst_row(k, m, px, py, g, ax, ay, hk)) continue;
@@ -268,16 +276,16 @@ struct IpmWave {
             }
         }
         for (int k = lane; k < n - 1; k += kWave) {
-            T xk[3] = {F(XB, 0, k), F(XB, 1, k), F(XB, 2, k)};
-            T xn[3] = {F(XB, 0, k + 1), F(XB, 1, k + 1), F(XB, 2, k + 1)};
-            T v = F(UB, 0, k), w = F(UB, 1, k);
+            T xk[3] = {xt(0, k, al), xt(1, k, al), xt(2, k, al)};
+            T xn[3] = {xt(0, k + 1, al), xt(1, k + 1, al), xt(2, k + 1, al)};
+            T v = ut(0, k, al), w = ut(1, k, al);
             T tr[4], f[3];
             model_trig<T, MODEL>(P, xk[2], w, tr);
             model_f<T, MODEL>(P, tr, v, w, f);
             T c0 = d * f[0] - (xn[0] - xk[0]);
             T c1 = d * f[1] - (xn[1] - xk[1]);
             T c2 = d * f[2] - normalize_theta(xn[2] - xk[2]);
-            for (int i = 0; i < 4; ++i) F(L.TRIG, i, k) = tr[i];
+            for (int i = 0; i < L.NTR; ++i) F(L.TRIG, i, k) = tr[i];
             C_(0, k) = c0; C_(1, k) = c1; C_(2, k) = c2;
             th += t_abs(c0) + t_abs(c1) + t_abs(c2);
             if (P.objective == OBJ_QUADRATIC) {
@@ -289,7 +297,7 @@ struct IpmWave {
             if (P.objective == OBJ_MIN_TIME) fo += T(n - 1) * d;
             else if (P.has_Qf) {
                 for (int i = 0; i < 3; ++i) if (!P.xf_fixed[i]) {
-                    T xd = F(XB, i, n - 1) - xf[i];
+                    T xd = xt(i, n - 1, al) - xf[i];
                     if (i == 2) xd = normalize_theta(xd);
                     fo += P.Qf[i] * xd * xd;
                 }
@@ -300,12 +308,12 @@ struct IpmWave {
     }
 
     // sum of barrier logs at the current (alpha = 0) or trial point; wave-reduced
-    __device__ T barrier_logs(int UB, T d, T alpha, bool trial, T dd) const {
+    __device__ T barrier_logs(T d, T alpha, bool trial, T dd) const {
         const int n = L.n;
         LogAcc<T> acc;
         for (int k = lane; k < n; k += kWave) {
             if (k < n - 1) {
-                for (int j = 0; j < 2; ++j) { T u = F(UB, j, k); acc.mul(u - P.u_lb[j]); acc.mul(P.u_ub[j] - u); }
+                for (int j = 0; j < 2; ++j) { T u = ut(j, k, trial ? alpha : T(0)); acc.mul(u - P.u_lb[j]); acc.mul(P.u_ub[j] - u); }
             }
             for (int q = 0; q < 4; ++q) {
                 if (!row_on(k, q)) continue;
@@ -348,7 +356,7 @@ struct IpmWave {
         for (int k = lane; k < n; k += kWave) {
             if (k < n - 1) {
                 T lam[3] = {F(L.LAM, 0, k), F(L.LAM, 1, k), F(L.LAM, 2, k)};
-                T tr[4] = {F(L.TRIG, 0, k), F(L.TRIG, 1, k), F(L.TRIG, 2, k), F(L.TRIG, 3, k)};
+                T tr[4] = {F(L.TRIG, 0, k), F(L.TRIG, 1, k), F(L.TRIG, 2, k), L.NTR > 3 ? F(L.TRIG, 3, k) : T(0)};
                 T v = F(L.U, 0, k), w = F(L.U, 1, k);
                 T f[3], G[3][3], Hq[3][3];
                 model_derivs<T, MODEL>(P, tr, v, w, lam, f, G, Hq);
@@ -374,7 +382,6 @@ struct IpmWave {
                     for (int i = 0; i < 3; ++i) gx[i] = T(2) * P.Q[i] * xd[i];
                     gu[0] = T(2) * P.R[0] * v; gu[1] = T(2) * P.R[1] * w;
                 }
-                S_(RHX, k) = gx[0]; S_(RHX + 1, k) = gx[1]; S_(RHX + 2, k) = gx[2];
                 T osx = T(0), osy = T(0);
                 if (L.M > 0 && k >= 1) {
                     const T px = F(L.X, 0, k), py = F(L.X, 1, k);
@@ -469,7 +476,11 @@ struct IpmWave {
             sp.h00 = S_(RA + A22, k); sp.h01 = S_(RA + A26, k); sp.h02 = S_(RA + A27, k);
             sp.h11 = S_(RA + A66, k); sp.h12 = S_(RA + A67, k); sp.h22 = S_(RA + A77, k);
             sp.g[0] = S_(RA + A25, k); sp.g[1] = S_(RA + A56, k); sp.g[2] = S_(RA + A57, k);
-            sp.hx[0] = S_(RHX, k); sp.hx[1] = S_(RHX + 1, k); sp.hx[2] = S_(RHX + 2, k);
+            sp.hx[0] = sp.hx[1] = sp.hx[2] = T(0);
+            if (quad && k < n - 1) {
+                sp.hx[0] = q2[0] * (F(L.X, 0, k) - xf[0]); sp.hx[1] = q2[1] * (F(L.X, 1, k) - xf[1]);
+                sp.hx[2] = q2[2] * normalize_theta(F(L.X, 2, k) - xf[2]);
+            }
             sp.sz[0] = sp.sz[1] = sp.gb[0] = sp.gb[1] = T(0);
             if (k < n - 1) {
                 for (int j = 0; j < 2; ++j) {
@@ -479,7 +490,6 @@ struct IpmWave {
                     sp.gb[j] = -mu / dl + mu / du + r2[j] * u;
                 }
             }
-            S_(RGB, k) = sp.gb[0]; S_(RGB + 1, k) = sp.gb[1];
             sp.ss[0] = sp.ss[1] = sp.sl[0] = sp.sl[1] = sp.sll = sp.gy[0] = sp.gy[1] = sp.gyl = T(0);
             for (int q = 0; q < 4; ++q) {
                 if (!row_on(k, q)) continue;
@@ -555,6 +565,171 @@ struct IpmWave {
                 for (int a = 0; a < 2; ++a) for (int b = 0; b < 3; ++b) G_(14 + 3 * a + b, k) = g.Kn[a][b];
             }
         }
+        return riccati_root(V, P, dd_out, nu_out);
+    }
+
+    // ---------------------------------------------------------------- LDS-matrix backward Riccati sweep
+    // One matrix ENTRY per lane.  With V+ = [P | 0 0 | p | S] (6 x 12, LDS), every stage is three lane-parallel steps
+    // separated by an LDS hand-off (single wave: program order suffices, no s_barrier):
+    //   A:  T1 = V+[:,0:3] * Ccoef + V+[:, extra]            (6 x 10 dense columns; Ccoef = the stage's [G | Gam | c~] columns)
+    //   B:  Hhat = Ccoef' * T1[0:3,:] + T1[extra,:] + A       (dense 6 x 10 block + 12 copied u_{k-1} entries of the A-form)
+    //   C:  2x2 pivot (uniform) -> gains K, V = Hhat_xi - Hhat[:,6:8] K,  W -= Su' Knu, omega -= Su' kappa
+    // Per-lane address tables (coefficient triple, extra column/row, A slot) are fixed before the loop, so the stage
+    // body has no divergent branches.  Same arithmetic as riccati_step(), ~3x fewer cycles per stage.
+    __device__ bool backward_mat(T delta, T dc, T& dd_out, T nu_out[3]) const {
+        const int n = L.n;
+        const T d = SCL(SC_D);
+        T* VM = sm + L.VP;            // 6 x 12
+        T* T1 = VM + 72;              // 7 x 12 (row 6 stays zero)
+        T* HM = T1 + 84;              // 8 x 12
+        T* WM = HM + 96;              // W (9) + omega (3)
+        const int ZERO = L.ZC, ONE = L.ZC + 6;
+        if (lane == 0) { for (int i = 0; i < 6; ++i) sm[L.ZC + i] = T(0); sm[ONE] = T(1); }
+        for (int e = lane; e < 264; e += kWave) VM[e] = T(0);
+        sync();
+        // ---- per-lane tables
+        const int e = lane < 60 ? lane : 59;                    // lanes 60..63 duplicate entry 59 (harmless: same value written)
+        const int cd[10] = {0, 1, 2, 5, 6, 7, 8, 9, 10, 11};    // dense columns of T1 / Hhat
+        const int rd[6] = {0, 1, 2, 5, 6, 7};                   // dense rows of Hhat
+        const int cv[10] = {0, 1, 2, 3, 4, 5, 8, 9, 10, 11};    // columns of the new V
+        // coefficient triple of index t (a column of [G | Gam | c~], equally a row of its transpose):
+        //   t=0:(1,0,0) 1:(0,1,0) 2:(a0,a1,1) 5:f 6:Bx[:,0] 7:Bx[:,1] 8:c_k  else 0;   extra index: 5->5, 6->3, 7->4, >=8 -> itself, else zero column/row 6
+        auto coef_tab = [&](int t, int m, int& base, int& stride) {
+            base = ZERO; stride = 0;
+            if (t == 0) { if (m == 0) base = ONE; }
+            else if (t == 1) { if (m == 1) base = ONE; }
+            else if (t == 2) { if (m == 2) base = ONE; else { base = L.STG + m; stride = NSTG; } }
+            else if (t == 5) { base = L.STG + 2 + m; stride = NSTG; }
+            else if (t == 6) { base = L.STG + 5 + 2 * m; stride = NSTG; }
+            else if (t == 7) { base = L.STG + 6 + 2 * m; stride = NSTG; }
+            else if (t == 8) { base = L.CC + m; stride = 3; }
+        };
+        auto extra_tab = [&](int t) { return t == 5 ? 5 : (t == 6 ? 3 : (t == 7 ? 4 : (t >= 8 ? t : 6))); };
+        // step A: T1[i][c]
+        const int iA = e / 10, cA = cd[e % 10];
+        int ab0, as0, ab1, as1, ab2, as2;
+        coef_tab(cA, 0, ab0, as0); coef_tab(cA, 1, ab1, as1); coef_tab(cA, 2, ab2, as2);
+        const int vA = 12 * iA, xA = 12 * iA + extra_tab(cA), oA = 12 * iA + cA;
+        // step B: Hhat[r][c]
+        const int rB = rd[e / 10], cB = cd[e % 10];
+        int bb0, bs0, bb1, bs1, bb2, bs2;
+        coef_tab(rB, 0, bb0, bs0); coef_tab(rB, 1, bb1, bs1); coef_tab(rB, 2, bb2, bs2);
+        const int xB = 12 * (rB >= 5 ? extra_tab(rB) : 6) + cB, oB = 12 * rB + cB;
+        auto add_idx = [&](int r, int c) -> int {      // A slot of Hhat[r][c] (symmetric), -1: none
+            if (c == 8) return A08 + r;
+            if (c > 8) return -1;
+            const int a = r < c ? r : c, b = r < c ? c : r;
+            if (a == 0) return b == 0 ? A00 : (b == 1 ? A01 : -1);
+            if (a == 1) return b == 1 ? A11 : -1;
+            if (a == 2) return b == 2 ? A22 : (b == 5 ? A25 : (b == 6 ? A26 : (b == 7 ? A27 : -1)));
+            if (a == 3) return b == 3 ? A33 : (b == 5 ? A35 : (b == 6 ? A36 : -1));
+            if (a == 4) return b == 4 ? A44 : (b == 5 ? A45 : (b == 7 ? A47 : -1));
+            if (a == 5) return b == 5 ? A55 : (b == 6 ? A56 : (b == 7 ? A57 : -1));
+            if (a == 6) return b == 6 ? A66 : (b == 7 ? A67 : -1);
+            return b == 7 ? A77 : -1;
+        };
+        const int aiB = add_idx(rB, cB);
+        const int adB = aiB >= 0 ? L.STG + RA + aiB : ZERO, adS = aiB >= 0 ? NSTG : 0;
+        const int fB = (rB == cB && rB < 3) ? 1 : ((rB == cB && (rB == 6 || rB == 7)) ? 2 : ((rB == 5 && cB == 5) ? 3 : ((rB == 5 && cB == 8) ? 4 : 0)));
+        // the 12 non-zero u_{k-1} entries of the A-form, copied by lanes 0..11
+        const int upr[12] = {3, 3, 5, 3, 6, 4, 4, 5, 4, 7, 3, 4}, upc[12] = {3, 5, 3, 6, 3, 4, 5, 4, 7, 4, 8, 8};
+        const int eu = lane < 12 ? lane : 0;
+        const int uS = L.STG + RA + add_idx(upr[eu], upc[eu]), uD = 12 * upr[eu] + upc[eu];
+        // step C: V[i][c']
+        const int iC = e / 10, cC = cv[e % 10];
+        const int g0 = cC < 6 ? cC : (cC == 8 ? 12 : 14 + (cC - 9));
+        const int g1 = cC < 6 ? 6 + cC : (cC == 8 ? 13 : 17 + (cC - 9));
+        const int wa = eu / 3, wb = eu % 3;                       // lanes 0..8: W[wa][wb];  lanes 9..11: omega[eu-9]
+        // ---- terminal value function
+        if (lane == 0) {
+            const int r = n - 1;
+            for (int i = 0; i < 3; ++i) {
+                if (P.xf_fixed[i]) { VM[12 * i + 9 + i] = T(1); WM[3 * i + i] = -dc; }
+                else {
+                    T pii = delta, pi_ = T(0);
+                    if (P.objective == OBJ_QUADRATIC && P.has_Qf) {
+                        T xd = F(L.X, i, r) - xf[i];
+                        if (i == 2) xd = normalize_theta(xd);
+                        pii += T(2) * P.Qf[i]; pi_ = T(2) * P.Qf[i] * xd;
+                    }
+                    VM[12 * i + i] = pii; VM[12 * i + 8] = pi_;
+                }
+            }
+            VM[12 * 3 + 3] = S_(RA + A33, r); VM[12 * 4 + 4] = S_(RA + A44, r); VM[12 * 5 + 5] = S_(RA + A55, r);
+            VM[12 * 3 + 5] = S_(RA + A35, r); VM[12 * 5 + 3] = S_(RA + A35, r);
+            VM[12 * 4 + 5] = S_(RA + A45, r); VM[12 * 5 + 4] = S_(RA + A45, r);
+            VM[12 * 3 + 8] = S_(RA + A38, r); VM[12 * 4 + 8] = S_(RA + A48, r); VM[12 * 5 + 8] = S_(RA + A58, r);
+        }
+        sync();
+        T add_dd0 = T(0), add_qd0 = T(0);
+        if (P.objective == OBJ_MIN_TIME) add_qd0 += T(n - 1);
+        if (P.dt_free) {
+            const T dl = d - P.dt_lb, du = P.dt_ub - d;
+            add_dd0 = SCL(SC_PDL) / dl + SCL(SC_PDU) / du + delta;
+            add_qd0 += -mu / dl + mu / du;
+        }
+        for (int k = n - 2; k >= 0; --k) {
+#ifdef MPC_ASM_MARK
+            asm volatile("; MAT_LOOP_BEGIN");
+#endif
+            // ---- A
+            {
+                const T k0 = sm[ab0 + k * as0], k1 = sm[ab1 + k * as1], k2 = sm[ab2 + k * as2];
+                const T p0 = VM[vA], p1 = VM[vA + 1], p2 = VM[vA + 2], px = VM[xA];
+                T om_add = T(0);
+                if (lane < 3) om_add = VM[9 + lane] * C_(0, k) + VM[12 + 9 + lane] * C_(1, k) + VM[24 + 9 + lane] * C_(2, k);
+                T1[oA] = (p0 * k0 + p1 * k1) + (p2 * k2 + px);
+                if (lane < 3) WM[9 + lane] += om_add;
+            }
+            sync();
+            // ---- B
+            {
+                const T k0 = sm[bb0 + k * bs0], k1 = sm[bb1 + k * bs1], k2 = sm[bb2 + k * bs2];
+                const T t0 = T1[cB], t1 = T1[12 + cB], t2 = T1[24 + cB], tx = T1[xB];
+                T add = sm[adB + k * adS];
+                if (fB == 1) add += k >= 1 ? delta : T(0);
+                else if (fB == 2) add += delta;
+                else if (fB == 3) add += k == 0 ? add_dd0 : T(0);
+                else if (fB == 4) add += k == 0 ? add_qd0 : T(0);
+                HM[oB] = ((t0 * k0 + t1 * k1) + (t2 * k2 + tx)) + add;
+                if (lane < 12) HM[uD] = sm[uS + k * NSTG];
+            }
+            sync();
+            // ---- C
+            {
+                const T R00 = HM[12 * 6 + 6], R01 = HM[12 * 6 + 7], R11 = HM[12 * 7 + 7];
+                const T det = R00 * R11 - R01 * R01;
+                const T scale = t_abs(R00 * R11) + R01 * R01;
+                if (!(t_abs(det) > T(1e-14) * scale) || !t_finite(det)) return false;
+                const T id = T(1) / det;
+                const T Ri00 = R11 * id, Ri01 = -R01 * id, Ri11 = R00 * id;
+                const T h6 = HM[12 * 6 + cC], h7 = HM[12 * 7 + cC];
+                const T K0 = Ri00 * h6 + Ri01 * h7, K1 = Ri01 * h6 + Ri11 * h7;
+                const T vn = HM[12 * iC + cC] - (HM[12 * iC + 6] * K0 + HM[12 * iC + 7] * K1);
+                // W / omega: lanes 0..8 -> W[wa][wb] with Knu of column 9+wb ; lanes 9..11 -> omega[a] with kappa (column 8)
+                T wupd = T(0);
+                if (lane < 12) {
+                    const int a = lane < 9 ? wa : lane - 9, kc = lane < 9 ? 9 + wb : 8;
+                    const T q6 = HM[12 * 6 + kc], q7 = HM[12 * 7 + kc];
+                    const T kk0 = Ri00 * q6 + Ri01 * q7, kk1 = Ri01 * q6 + Ri11 * q7;
+                    wupd = HM[12 * 6 + 9 + a] * kk0 + HM[12 * 7 + 9 + a] * kk1;
+                }
+                if (lane < 60) {
+                    VM[12 * iC + cC] = vn;
+                    if (iC == 0) { G_(g0, k) = K0; G_(g1, k) = K1; }
+                }
+                if (lane < 9) WM[3 * wa + wb] -= wupd;
+                else if (lane < 12) WM[9 + (lane - 9)] -= wupd;
+            }
+            sync();
+#ifdef MPC_ASM_MARK
+            asm volatile("; MAT_LOOP_END");
+#endif
+        }
+        RicState<T> V;
+        V.P[5][5] = VM[12 * 5 + 5];
+        V.p[5] = VM[12 * 5 + 8];
+        for (int b = 0; b < 3; ++b) { V.S[5][b] = VM[12 * 5 + 9 + b]; V.om[b] = WM[9 + b]; for (int a = 0; a < 3; ++a) V.W[a][b] = WM[3 * a + b]; }
         return riccati_root(V, P, dd_out, nu_out);
     }
 
@@ -687,7 +862,7 @@ struct IpmWave {
                     T u = F(L.U, j, k), du_ = F(L.DU, j, k);
                     T dl = u - P.u_lb[j], du = P.u_ub[j] - u;
                     T pl = F(L.PL, j, k), pu = F(L.PU, j, k);
-                    T gbar = S_(RGB + j, k);         // barrier (+ quadratic objective) gradient wrt u
+                    T gbar = -mu / dl + mu / du + (P.objective == OBJ_QUADRATIC ? T(2) * P.R[j] * u : T(0));   // barrier (+ objective) gradient wrt u
                     hdz += gbar * du_; dphi += gbar * du_;
                     ftb(dl, du_, tau, a_p); ftb(du, -du_, tau, a_p);
                     ftb(pl, mu / dl - pl - (pl / dl) * du_, tau, a_d);
@@ -707,7 +882,7 @@ struct IpmWave {
                         dz2 += dx * dx; dzmax = t_max(dzmax, t_abs(dx));
                         T g = T(0);
                         if (P.objective == OBJ_QUADRATIC) {
-                            if (k < n - 1) g = S_(RHX + i, k);
+                            if (k < n - 1) { T xd = F(L.X, i, k) - xf[i]; if (i == 2) xd = normalize_theta(xd); g = T(2) * P.Q[i] * xd; }
                             else if (P.has_Qf) { T xd = F(L.X, i, k) - xf[i]; if (i == 2) xd = normalize_theta(xd); g = T(2) * P.Qf[i] * xd; }
                         }
                         hdz += g * dx; dphi += g * dx;
@@ -755,26 +930,10 @@ struct IpmWave {
     }
 
     // ---------------------------------------------------------------- trial point / acceptance (parallel)
-    __device__ void make_trial(T alpha) const {
-        const int n = L.n;
-        for (int k = lane; k < n; k += kWave) {
-            for (int i = 0; i < 3; ++i) {
-                T x = F(L.X, i, k);
-                if (k > 0 && (k < n - 1 || !P.xf_fixed[i])) {
-                    x += alpha * F(L.DX, i, k);
-                    if (i == 2) x = normalize_theta(x);
-                }
-                F(L.XT, i, k) = x;
-            }
-            if (k < n - 1) for (int j = 0; j < 2; ++j) F(L.UT, j, k) = F(L.U, j, k) + alpha * F(L.DU, j, k);
-        }
-        if (lane == 0) SCL(SC_DT) = SCL(SC_D) + (P.dt_free ? alpha * SCL(SC_DD) : T(0));
-    }
-
     __device__ void accept(T alpha, T a_d) const {
         const int n = L.n;
         const T kS = T(1e10);
-        const T d_old = SCL(SC_D), dd = SCL(SC_DD), d_new = SCL(SC_DT);
+        const T d_old = SCL(SC_D), dd = SCL(SC_DD), d_new = d_old + (P.dt_free ? alpha * dd : T(0));
         // phase 1: everything that reads the OLD point
         T sn[4], yn[4];
         for (int k = lane; k < n; k += kWave) {      // (n <= 64 + ... handled by the loop; registers reused per chunk)
@@ -812,7 +971,7 @@ struct IpmWave {
                     T pl = F(L.PL, j, k), pu = F(L.PU, j, k);
                     T pln = pl + a_d * (mu / dl - pl - (pl / dl) * du_);
                     T pun = pu + a_d * (mu / du - pu + (pu / du) * du_);
-                    T un = F(L.UT, j, k);
+                    T un = ut(j, k, alpha);
                     T dln = un - P.u_lb[j], dun = P.u_ub[j] - un;
                     F(L.PL, j, k) = t_min(t_max(pln, mu / (kS * dln)), kS * mu / dln);
                     F(L.PU, j, k) = t_min(t_max(pun, mu / (kS * dun)), kS * mu / dun);
@@ -823,7 +982,7 @@ struct IpmWave {
                     F(L.LAM, i, k) = lo + alpha * (F(L.LAMN, i, k) - lo);
                 }
             }
-            for (int i = 0; i < 3; ++i) F(L.X, i, k) = F(L.XT, i, k);
+            for (int i = 0; i < 3; ++i) F(L.X, i, k) = xt(i, k, alpha);
         }
         if (lane == 0) {
             if (P.dt_free) {
@@ -941,7 +1100,7 @@ struct IpmWave {
         row0_on = dtprev != T(0);
         init_point();
         T theta_c, fobj;
-        eval_point(L.X, L.U, SCL(SC_D), theta_c, fobj);
+        eval_point(SCL(SC_D), theta_c, fobj);
         sync();
         int it = 0, status = ST_MAX_ITER;
         T e0 = T(0);
@@ -977,7 +1136,11 @@ struct IpmWave {
             T dd = T(0), nu[3] = {T(0), T(0), T(0)}, curv = T(0);
             for (int ntry = 0; ntry <= 40; ++ntry) {
                 bool good;
-                                MPC_TICK(2, good = backward(delta, dc, dd, nu); sync());
+                #ifdef MPC_UNIFORM_SWEEP
+                MPC_TICK(2, good = backward(delta, dc, dd, nu); sync());
+#else
+                MPC_TICK(2, good = backward_mat(delta, dc, dd, nu); sync());
+#endif
 #ifdef MPC_PROFILE
                 ++nfac;
 #endif
@@ -1004,7 +1167,7 @@ struct IpmWave {
                 if (rho < rho_trial) rho = rho_trial + T(1);
             }
             T phi0;
-            MPC_TICK(5, phi0 = fobj - mu * barrier_logs(L.U, SCL(SC_D), T(0), false, dd) + rho * theta);
+            MPC_TICK(5, phi0 = fobj - mu * barrier_logs(SCL(SC_D), T(0), false, dd) + rho * theta);
             const T Dm = fw.dphi - rho * theta;
             const T theta_rows = theta - theta_c;
             T alpha = fw.a_p;
@@ -1013,9 +1176,10 @@ struct IpmWave {
             for (int ls = 0; ls < Algo<T>::max_ls; ++ls) {
                 if (ls > 0) alpha *= T(0.5);
                 T phit, tht;
-                MPC_TICK(6, make_trial(alpha); sync(); eval_point(L.XT, L.UT, SCL(SC_DT), th_t, f_t, alpha, true);
+                const T d_t = SCL(SC_D) + (P.dt_free ? alpha * SCL(SC_DD) : T(0));
+                MPC_TICK(6, eval_point(d_t, th_t, f_t, alpha, true);
                          tht = th_t + (T(1) - alpha) * theta_rows;
-                         phit = f_t - mu * barrier_logs(L.UT, SCL(SC_DT), alpha, true, dd) + rho * tht; sync());
+                         phit = f_t - mu * barrier_logs(d_t, alpha, true, dd) + rho * tht; sync());
 #ifdef MPC_PROFILE
                 ++ntrial;
 #endif
