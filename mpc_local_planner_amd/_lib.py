@@ -63,11 +63,12 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("MPC_HIP_LIB", LIB_PATH)      # developer override (e.g. an instrumented build); default: the in-tree library
+    if not os.path.exists(path):
         raise RuntimeError(
-            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     dp = C.c_void_p   # raw addresses: host numpy buffers or device pointers
     lib.mpc_config_defaults.argtypes = [C.POINTER(MpcConfig)]
     lib.mpc_config_defaults.restype = None

@@ -101,6 +101,10 @@ __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
     const int nmax = L.n;          // stride of the instance-major arrays
     int n = nmax;                  // grid points of THIS instance (grid adaptation: n_i <= n_max)
     if (n_grid) { n = n_grid[inst]; n = n < 3 ? 3 : (n > nmax ? nmax : n); }
+#ifdef MPC_POISON_LDS      // developer check: any read of an LDS word the solver did not write first turns into NaN
+    for (int e = lane; e < L.total; e += mpc::kWave) sm[e] = T(NAN);
+    __syncthreads();
+#endif
     if (lane == 0) { *Ps = P; *Ls = L; Ls->n = n; Ps->n = n; }
     __syncthreads();
     mpc::IpmWave<T, MODEL> S(*Ps, *Ls, sm, lane);

@@ -115,12 +115,17 @@ struct IpmWave {
     __device__ __forceinline__ void sync() const { __syncthreads(); }
 
     // trial point z + alpha*dz, evaluated on the fly (no trial copy in LDS)
+    // (alpha == 0 must not touch the step arrays: they are unwritten before the first factorisation, and 0 * garbage can be NaN)
     __device__ __forceinline__ T xt(int i, int k, T alpha) const {
         T x = F(L.X, i, k);
-        if (k > 0 && (k < L.n - 1 || !P.xf_fixed[i])) { x += alpha * F(L.DX, i, k); if (i == 2) x = normalize_theta(x); }
+        if (alpha != T(0) && k > 0 && (k < L.n - 1 || !P.xf_fixed[i])) { x += alpha * F(L.DX, i, k); if (i == 2) x = normalize_theta(x); }
         return x;
     }
-    __device__ __forceinline__ T ut(int j, int k, T alpha) const { return F(L.U, j, k) + alpha * F(L.DU, j, k); }
+    __device__ __forceinline__ T ut(int j, int k, T alpha) const {
+        T u = F(L.U, j, k);
+        if (alpha != T(0)) u += alpha * F(L.DU, j, k);
+        return u;
+    }
 
     __device__ __forceinline__ bool row_on(int r, int q) const { return P.rate_on[q] && (r > 0 || row0_on); }
 
@@ -570,25 +575,36 @@ struct IpmWave {
 
     // ---------------------------------------------------------------- LDS-matrix backward Riccati sweep
     // One matrix ENTRY per lane.  With V+ = [P | 0 0 | p | S] (6 x 12, LDS), every stage is three lane-parallel steps
-    // separated by an LDS hand-off (single wave: program order suffices, no s_barrier):
-    //   A:  T1 = V+[:,0:3] * Ccoef + V+[:, extra]            (6 x 10 dense columns; Ccoef = the stage's [G | Gam | c~] columns)
-    //   B:  Hhat = Ccoef' * T1[0:3,:] + T1[extra,:] + A       (dense 6 x 10 block + 12 copied u_{k-1} entries of the A-form)
-    //   C:  2x2 pivot (uniform) -> gains K, V = Hhat_xi - Hhat[:,6:8] K,  W -= Su' Knu, omega -= Su' kappa
-    // Per-lane address tables (coefficient triple, extra column/row, A slot) are fixed before the loop, so the stage
-    // body has no divergent branches.  Same arithmetic as riccati_step(), ~3x fewer cycles per stage.
+    // separated by an LDS hand-off (single wave: program order suffices):
+    //   A:  T1 = V+[:,0:3] * Ccoef + V+[:, extra]            (6 x 10 dense columns; Ccoef = the stage's [G | Gam | c~] columns;
+    //                                                          lanes 60..62 accumulate omega += S+[0:3,:]' c_k with the same formula)
+    //   B:  Hhat = Ccoef' * T1[0:3,:] + T1[extra,:] + A       (dense 6 x 10 block; the u_{k-1} rows/columns of Hhat are pure A-form
+    //                                                          entries and are read straight from the stage record in step C)
+    //   C:  2x2 pivot (uniform) -> gains K,  V = Hhat_xi - Hhat[:,6:8] K
+    // W and omega are completed after the sweep by a lane-parallel reduction over the stages (Su is parked in the LAMN/DX
+    // arrays, which are dead until the forward pass).  All per-lane operand addresses (coefficient triple, extra column/row,
+    // A slot, delta flags) are fixed before the loop: the stage body is branch-free apart from the uniform pivot test.
+    __device__ __forceinline__ T fast_rcp(double x) const {
+        double r = __builtin_amdgcn_rcp(x);
+        r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+        r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+        return r;
+    }
+    __device__ __forceinline__ T fast_rcp(float x) const { return 1.0f / x; }
+
     __device__ bool backward_mat(T delta, T dc, T& dd_out, T nu_out[3]) const {
         const int n = L.n;
         const T d = SCL(SC_D);
-        T* VM = sm + L.VP;            // 6 x 12
-        T* T1 = VM + 72;              // 7 x 12 (row 6 stays zero)
-        T* HM = T1 + 84;              // 8 x 12
-        T* WM = HM + 96;              // W (9) + omega (3)
+        const int VMo = L.VP, T1o = L.VP + 72, HMo = L.VP + 156, WMo = L.VP + 252;   // VM 6x12 | T1 7x12 (row 6 = 0) | HM 8x12 | W 9 + omega 3
+        T* VM = sm + VMo;
+        T* HM = sm + HMo;
+        T* WM = sm + WMo;
         const int ZERO = L.ZC, ONE = L.ZC + 6;
         if (lane == 0) { for (int i = 0; i < 6; ++i) sm[L.ZC + i] = T(0); sm[ONE] = T(1); }
-        for (int e = lane; e < 264; e += kWave) VM[e] = T(0);
+        for (int e2 = lane; e2 < 264; e2 += kWave) VM[e2] = T(0);
         sync();
         // ---- per-lane tables
-        const int e = lane < 60 ? lane : 59;                    // lanes 60..63 duplicate entry 59 (harmless: same value written)
+        const int e = lane < 60 ? lane : 59;
         const int cd[10] = {0, 1, 2, 5, 6, 7, 8, 9, 10, 11};    // dense columns of T1 / Hhat
         const int rd[6] = {0, 1, 2, 5, 6, 7};                   // dense rows of Hhat
         const int cv[10] = {0, 1, 2, 3, 4, 5, 8, 9, 10, 11};    // columns of the new V
@@ -605,16 +621,6 @@ struct IpmWave {
             else if (t == 8) { base = L.CC + m; stride = 3; }
         };
         auto extra_tab = [&](int t) { return t == 5 ? 5 : (t == 6 ? 3 : (t == 7 ? 4 : (t >= 8 ? t : 6))); };
-        // step A: T1[i][c]
-        const int iA = e / 10, cA = cd[e % 10];
-        int ab0, as0, ab1, as1, ab2, as2;
-        coef_tab(cA, 0, ab0, as0); coef_tab(cA, 1, ab1, as1); coef_tab(cA, 2, ab2, as2);
-        const int vA = 12 * iA, xA = 12 * iA + extra_tab(cA), oA = 12 * iA + cA;
-        // step B: Hhat[r][c]
-        const int rB = rd[e / 10], cB = cd[e % 10];
-        int bb0, bs0, bb1, bs1, bb2, bs2;
-        coef_tab(rB, 0, bb0, bs0); coef_tab(rB, 1, bb1, bs1); coef_tab(rB, 2, bb2, bs2);
-        const int xB = 12 * (rB >= 5 ? extra_tab(rB) : 6) + cB, oB = 12 * rB + cB;
         auto add_idx = [&](int r, int c) -> int {      // A slot of Hhat[r][c] (symmetric), -1: none
             if (c == 8) return A08 + r;
             if (c > 8) return -1;
@@ -628,18 +634,49 @@ struct IpmWave {
             if (a == 6) return b == 6 ? A66 : (b == 7 ? A67 : -1);
             return b == 7 ? A77 : -1;
         };
+        // step A operands: out = p0*k0 + p1*k1 + p2*k2 + px
+        int aK0, aS0, aK1, aS1, aK2, aS2, aP0, aP1, aP2, aPx, aOut;
+        if (lane < 60) {
+            const int iA = e / 10, cA = cd[e % 10];
+            coef_tab(cA, 0, aK0, aS0); coef_tab(cA, 1, aK1, aS1); coef_tab(cA, 2, aK2, aS2);
+            aP0 = VMo + 12 * iA; aP1 = aP0 + 1; aP2 = aP0 + 2;
+            aPx = VMo + 12 * iA + extra_tab(cA);
+            aOut = T1o + 12 * iA + cA;
+        } else {            // lanes 60..62: omega[b] += S+[0][b] c0 + S+[1][b] c1 + S+[2][b] c2   (lane 63 repeats b = 2 into a dummy slot)
+            const int b = lane - 60 < 3 ? lane - 60 : 2;
+            coef_tab(8, 0, aK0, aS0); coef_tab(8, 1, aK1, aS1); coef_tab(8, 2, aK2, aS2);
+            aP0 = VMo + 9 + b; aP1 = VMo + 12 + 9 + b; aP2 = VMo + 24 + 9 + b;
+            aPx = lane < 63 ? WMo + 9 + b : ZERO;
+            aOut = lane < 63 ? WMo + 9 + b : T1o + 6 * 12 + 3;     // dummy: an unused word of T1's zero row? no -> use column 3 of row 6 (never read)
+        }
+        // step B operands: out = t0*k0 + t1*k1 + t2*k2 + tx + add + flags
+        const int rB = rd[e / 10], cB = cd[e % 10];
+        int bK0, bS0, bK1, bS1, bK2, bS2;
+        coef_tab(rB, 0, bK0, bS0); coef_tab(rB, 1, bK1, bS1); coef_tab(rB, 2, bK2, bS2);
+        const int bT0 = T1o + cB, bT1 = T1o + 12 + cB, bT2 = T1o + 24 + cB;
+        const int bTx = T1o + 12 * (rB >= 5 ? extra_tab(rB) : 6) + cB, bOut = HMo + 12 * rB + cB;
         const int aiB = add_idx(rB, cB);
-        const int adB = aiB >= 0 ? L.STG + RA + aiB : ZERO, adS = aiB >= 0 ? NSTG : 0;
-        const int fB = (rB == cB && rB < 3) ? 1 : ((rB == cB && (rB == 6 || rB == 7)) ? 2 : ((rB == 5 && cB == 5) ? 3 : ((rB == 5 && cB == 8) ? 4 : 0)));
-        // the 12 non-zero u_{k-1} entries of the A-form, copied by lanes 0..11
-        const int upr[12] = {3, 3, 5, 3, 6, 4, 4, 5, 4, 7, 3, 4}, upc[12] = {3, 5, 3, 6, 3, 4, 5, 4, 7, 4, 8, 8};
-        const int eu = lane < 12 ? lane : 0;
-        const int uS = L.STG + RA + add_idx(upr[eu], upc[eu]), uD = 12 * upr[eu] + upc[eu];
-        // step C: V[i][c']
+        const int bAd = aiB >= 0 ? L.STG + RA + aiB : ZERO, bAs = aiB >= 0 ? NSTG : 0;
+        const T f1 = (rB == cB && rB < 3) ? T(1) : T(0);                    // + delta for k >= 1
+        const T f2 = (rB == cB && (rB == 6 || rB == 7)) ? T(1) : T(0);      // + delta
+        const T f3 = (rB == 5 && cB == 5) ? T(1) : T(0);                    // + dt box (stage 0)
+        const T f4 = (rB == 5 && cB == 8) ? T(1) : T(0);                    // + objective / dt-box gradient (stage 0)
+        const bool isSu = lane < 60 && rB >= 6 && cB >= 9;                  // Su[j][a] = Hhat[6+j][9+a] parked for the W/omega reduction
+        const int suO = (rB == 6 ? L.LAMN : L.DX) + (cB >= 9 ? cB - 9 : 0) * L.NS;
+        // step C operands: Hhat[r][c] lives in HM for dense (r,c), else it is a pure A-form entry of the record (or zero)
+        auto hsrc = [&](int r, int c, int& base, int& stride) {
+            const bool dr = r != 3 && r != 4, dcn = c != 3 && c != 4;
+            if (dr && dcn) { base = HMo + 12 * r + c; stride = 0; return; }
+            const int ai = add_idx(r, c);
+            if (ai >= 0) { base = L.STG + RA + ai; stride = NSTG; } else { base = ZERO; stride = 0; }
+        };
         const int iC = e / 10, cC = cv[e % 10];
+        int c6b, c6s, c7b, c7s, ccb, ccs, i6b, i6s, i7b, i7s;
+        hsrc(6, cC, c6b, c6s); hsrc(7, cC, c7b, c7s); hsrc(iC, cC, ccb, ccs); hsrc(iC, 6, i6b, i6s); hsrc(iC, 7, i7b, i7s);
+        const int cOut = VMo + 12 * iC + cC;
         const int g0 = cC < 6 ? cC : (cC == 8 ? 12 : 14 + (cC - 9));
         const int g1 = cC < 6 ? 6 + cC : (cC == 8 ? 13 : 17 + (cC - 9));
-        const int wa = eu / 3, wb = eu % 3;                       // lanes 0..8: W[wa][wb];  lanes 9..11: omega[eu-9]
+        const bool wrG = lane < 60 && iC == 0;
         // ---- terminal value function
         if (lane == 0) {
             const int r = n - 1;
@@ -674,62 +711,63 @@ struct IpmWave {
 #endif
             // ---- A
             {
-                const T k0 = sm[ab0 + k * as0], k1 = sm[ab1 + k * as1], k2 = sm[ab2 + k * as2];
-                const T p0 = VM[vA], p1 = VM[vA + 1], p2 = VM[vA + 2], px = VM[xA];
-                T om_add = T(0);
-                if (lane < 3) om_add = VM[9 + lane] * C_(0, k) + VM[12 + 9 + lane] * C_(1, k) + VM[24 + 9 + lane] * C_(2, k);
-                T1[oA] = (p0 * k0 + p1 * k1) + (p2 * k2 + px);
-                if (lane < 3) WM[9 + lane] += om_add;
+                const T k0 = sm[aK0 + k * aS0], k1 = sm[aK1 + k * aS1], k2 = sm[aK2 + k * aS2];
+                const T p0 = sm[aP0], p1 = sm[aP1], p2 = sm[aP2], px = sm[aPx];
+                sm[aOut] = (p0 * k0 + p1 * k1) + (p2 * k2 + px);
             }
             sync();
             // ---- B
             {
-                const T k0 = sm[bb0 + k * bs0], k1 = sm[bb1 + k * bs1], k2 = sm[bb2 + k * bs2];
-                const T t0 = T1[cB], t1 = T1[12 + cB], t2 = T1[24 + cB], tx = T1[xB];
-                T add = sm[adB + k * adS];
-                if (fB == 1) add += k >= 1 ? delta : T(0);
-                else if (fB == 2) add += delta;
-                else if (fB == 3) add += k == 0 ? add_dd0 : T(0);
-                else if (fB == 4) add += k == 0 ? add_qd0 : T(0);
-                HM[oB] = ((t0 * k0 + t1 * k1) + (t2 * k2 + tx)) + add;
-                if (lane < 12) HM[uD] = sm[uS + k * NSTG];
+                const T k0 = sm[bK0 + k * bS0], k1 = sm[bK1 + k * bS1], k2 = sm[bK2 + k * bS2];
+                const T t0 = sm[bT0], t1 = sm[bT1], t2 = sm[bT2], tx = sm[bTx];
+                const T add = sm[bAd + k * bAs];
+                const T dk = k >= 1 ? delta : T(0), ddk = k == 0 ? add_dd0 : T(0), qdk = k == 0 ? add_qd0 : T(0);
+                const T val = ((t0 * k0 + t1 * k1) + (t2 * k2 + tx)) + ((add + f1 * dk) + (f2 * delta + (f3 * ddk + f4 * qdk)));
+                sm[bOut] = val;
+                if (isSu) sm[suO + k] = val;
             }
             sync();
             // ---- C
             {
                 const T R00 = HM[12 * 6 + 6], R01 = HM[12 * 6 + 7], R11 = HM[12 * 7 + 7];
+                const T h6 = sm[c6b + k * c6s], h7 = sm[c7b + k * c7s], hc = sm[ccb + k * ccs], m6 = sm[i6b + k * i6s], m7 = sm[i7b + k * i7s];
                 const T det = R00 * R11 - R01 * R01;
                 const T scale = t_abs(R00 * R11) + R01 * R01;
                 if (!(t_abs(det) > T(1e-14) * scale) || !t_finite(det)) return false;
-                const T id = T(1) / det;
+                const T id = fast_rcp(det);
                 const T Ri00 = R11 * id, Ri01 = -R01 * id, Ri11 = R00 * id;
-                const T h6 = HM[12 * 6 + cC], h7 = HM[12 * 7 + cC];
                 const T K0 = Ri00 * h6 + Ri01 * h7, K1 = Ri01 * h6 + Ri11 * h7;
-                const T vn = HM[12 * iC + cC] - (HM[12 * iC + 6] * K0 + HM[12 * iC + 7] * K1);
-                // W / omega: lanes 0..8 -> W[wa][wb] with Knu of column 9+wb ; lanes 9..11 -> omega[a] with kappa (column 8)
-                T wupd = T(0);
-                if (lane < 12) {
-                    const int a = lane < 9 ? wa : lane - 9, kc = lane < 9 ? 9 + wb : 8;
-                    const T q6 = HM[12 * 6 + kc], q7 = HM[12 * 7 + kc];
-                    const T kk0 = Ri00 * q6 + Ri01 * q7, kk1 = Ri01 * q6 + Ri11 * q7;
-                    wupd = HM[12 * 6 + 9 + a] * kk0 + HM[12 * 7 + 9 + a] * kk1;
-                }
-                if (lane < 60) {
-                    VM[12 * iC + cC] = vn;
-                    if (iC == 0) { G_(g0, k) = K0; G_(g1, k) = K1; }
-                }
-                if (lane < 9) WM[3 * wa + wb] -= wupd;
-                else if (lane < 12) WM[9 + (lane - 9)] -= wupd;
+                sm[cOut] = hc - (m6 * K0 + m7 * K1);
+                if (wrG) { G_(g0, k) = K0; G_(g1, k) = K1; }
             }
             sync();
 #ifdef MPC_ASM_MARK
             asm volatile("; MAT_LOOP_END");
 #endif
         }
+        // ---- W -= sum_k Su_k' Knu_k ,  omega -= sum_k Su_k' kappa_k   (lane-parallel over the stages)
+        T wacc[9] = {T(0), T(0), T(0), T(0), T(0), T(0), T(0), T(0), T(0)}, oacc[3] = {T(0), T(0), T(0)};
+        for (int k = lane; k < n - 1; k += kWave) {
+            T su0[3], su1[3], kn0[3], kn1[3];
+            for (int a = 0; a < 3; ++a) { su0[a] = F(L.LAMN, a, k); su1[a] = F(L.DX, a, k); kn0[a] = G_(14 + a, k); kn1[a] = G_(17 + a, k); }
+            const T ka0 = G_(12, k), ka1 = G_(13, k);
+            for (int a = 0; a < 3; ++a) {
+                for (int b = 0; b < 3; ++b) wacc[3 * a + b] += su0[a] * kn0[b] + su1[a] * kn1[b];
+                oacc[a] += su0[a] * ka0 + su1[a] * ka1;
+            }
+        }
         RicState<T> V;
         V.P[5][5] = VM[12 * 5 + 5];
         V.p[5] = VM[12 * 5 + 8];
-        for (int b = 0; b < 3; ++b) { V.S[5][b] = VM[12 * 5 + 9 + b]; V.om[b] = WM[9 + b]; for (int a = 0; a < 3; ++a) V.W[a][b] = WM[3 * a + b]; }
+        for (int b = 0; b < 3; ++b) {
+            V.S[5][b] = VM[12 * 5 + 9 + b];
+            V.om[b] = WM[9 + b] - wave_sum(oacc[b]);
+        }
+        // W is symmetric: reduce the 6 unique entries
+        for (int a = 0; a < 3; ++a) for (int b = a; b < 3; ++b) {
+            const T s = WM[3 * a + b] - wave_sum(T(0.5) * (wacc[3 * a + b] + wacc[3 * b + a]));
+            V.W[a][b] = s; V.W[b][a] = s;
+        }
         return riccati_root(V, P, dd_out, nu_out);
     }
 

@@ -251,3 +251,35 @@ def test_cpp_controller_facade_closed_loop(tmp_path):
     r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     print(r.stdout)
     assert r.returncode == 0 and "DEMO_OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_no_uninitialised_lds_reads(tmp_path):
+    """Instrumented build (-DMPC_POISON_LDS fills the whole LDS working set with NaN before the solve): every golden
+    fixture must still be reproduced, i.e. the solver never consumes an LDS word it has not written (regression test
+    for a 0 * garbage = NaN bug that only showed up when a previous kernel had left NaN patterns in LDS)."""
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = str(tmp_path / "libmpc_hip_poison.so")
+    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DMPC_POISON_LDS",
+                    os.path.join(root, "mpc_local_planner_amd", "csrc", "mpc_capi.hip"), "-o", so], check=True)
+    code = """
+import sys, numpy as np
+sys.path.insert(0, %r)
+import mpc_local_planner_amd as m
+cases = {"carlike_min_time_n50": m.config_carlike_min_time(50), "unicycle_quadratic_n20": m.config_unicycle_quadratic(20),
+         "bicycle_min_time_n30": m.config_bicycle_min_time(30)}
+for name, cfg in cases.items():
+    g = np.load(%r + "/" + name + ".npz")
+    s = m.BatchSolver(cfg, max_batch=8)
+    r = s.solve(g["x0"], g["xf"], g["u_prev"], g["dt_prev"])
+    assert (r.status == 0).all() and np.abs(r.x - g["x"]).max() < 1e-6, (name, r.status, r.iters)
+g = np.load(%r + "/unicycle_quadratic_obstacles_n30.npz")
+O, V = g["vertices"].shape[1], g["vertices"].shape[2]
+s = m.BatchSolver(m.config_unicycle_quadratic(30, max_obstacles=O, max_vertices=V, max_obstacle_rows=int(g["max_rows"])), max_batch=8)
+r = s.solve(g["x0"], g["xf"], g["u_prev"], g["dt_prev"], obstacles=(g["n_obstacles"], g["n_vertices"], g["vertices"]))
+assert (r.status == 0).all() and np.abs(r.x - g["x"]).max() < 1e-6, ("obstacles", r.status)
+print("POISON_OK")
+""" % (root, GOLD, GOLD)
+    env = dict(os.environ, MPC_HIP_LIB=so)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
+    assert "POISON_OK" in r.stdout, r.stdout + r.stderr
