@@ -66,21 +66,41 @@ struct WaveLayout {
 
 enum { SC_D = 0, SC_DT = 1, SC_DD = 2, SC_PDL = 3, SC_PDU = 4 };
 
-template <typename T> __device__ __forceinline__ T wave_sum(T v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-    return v;
+// ---- wavefront reductions on the DPP path (row rotations inside each 16-lane row, then 4 v_readlane), no LDS traffic:
+//      ~25 VALU instructions per fp64 reduction instead of 12 ds_bpermute round trips.  Result is wave-uniform.
+template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
 }
-template <typename T> __device__ __forceinline__ T wave_min(T v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { T w = __shfl_xor(v, o); v = w < v ? w : v; }
-    return v;
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    int x = __float_as_int(v);
+    x = __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, false);
+    return __int_as_float(x);
 }
-template <typename T> __device__ __forceinline__ T wave_max(T v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { T w = __shfl_xor(v, o); v = w > v ? w : v; }
-    return v;
+__device__ __forceinline__ double rd_lane(double v, int src) {
+    int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
 }
+__device__ __forceinline__ float rd_lane(float v, int src) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src)); }
+
+struct OpSum { template <typename T> __device__ __forceinline__ static T f(T a, T b) { return a + b; } };
+struct OpMin { template <typename T> __device__ __forceinline__ static T f(T a, T b) { return b < a ? b : a; } };
+struct OpMax { template <typename T> __device__ __forceinline__ static T f(T a, T b) { return b > a ? b : a; } };
+
+template <typename Op, typename T> __device__ __forceinline__ T wave_reduce(T v) {
+    // row_ror:8,4,2,1 (dpp_ctrl 0x120 + n): afterwards every lane of a row holds the row's reduction
+    v = Op::f(v, dpp_mov<0x128>(v));
+    v = Op::f(v, dpp_mov<0x124>(v));
+    v = Op::f(v, dpp_mov<0x122>(v));
+    v = Op::f(v, dpp_mov<0x121>(v));
+    const T r0 = rd_lane(v, 0), r1 = rd_lane(v, 16), r2 = rd_lane(v, 32), r3 = rd_lane(v, 48);
+    return Op::f(Op::f(r0, r1), Op::f(r2, r3));
+}
+template <typename T> __device__ __forceinline__ T wave_sum(T v) { return wave_reduce<OpSum>(v); }
+template <typename T> __device__ __forceinline__ T wave_min(T v) { return wave_reduce<OpMin>(v); }
+template <typename T> __device__ __forceinline__ T wave_max(T v) { return wave_reduce<OpMax>(v); }
 
 __device__ __forceinline__ double lane_bcast(double v, int src) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -677,6 +697,7 @@ struct IpmWave {
         const int g0 = cC < 6 ? cC : (cC == 8 ? 12 : 14 + (cC - 9));
         const int g1 = cC < 6 ? 6 + cC : (cC == 8 ? 13 : 17 + (cC - 9));
         const bool wrG = lane < 60 && iC == 0;
+        const int gainB = L.GAIN;
         // ---- terminal value function
         if (lane == 0) {
             const int r = n - 1;
@@ -738,7 +759,7 @@ struct IpmWave {
                 const T Ri00 = R11 * id, Ri01 = -R01 * id, Ri11 = R00 * id;
                 const T K0 = Ri00 * h6 + Ri01 * h7, K1 = Ri01 * h6 + Ri11 * h7;
                 sm[cOut] = hc - (m6 * K0 + m7 * K1);
-                if (wrG) { G_(g0, k) = K0; G_(g1, k) = K1; }
+                if (wrG) { sm[gainB + k * NGAIN + g0] = K0; sm[gainB + k * NGAIN + g1] = K1; }
             }
             sync();
 #ifdef MPC_ASM_MARK
@@ -790,40 +811,45 @@ struct IpmWave {
         }
         if (lane == 0) { SCL(SC_DD) = dd; F(L.DX, 0, 0) = T(0); F(L.DX, 1, 0) = T(0); F(L.DX, 2, 0) = T(0); }
         sync();
-        // ---- serial: xi = (dx, du_prev); 23 LDS words per stage, prefetched one stage ahead
+        // ---- serial: xi = (dx, du_prev); 23 LDS words per stage, prefetched one stage ahead.  The layout record lives in LDS, and
+        //      the compiler must assume that the stores below may alias it, so every base offset is copied to a register first.
+        const int gB = L.GAIN, sB = L.STG, cB_ = L.LAMN, ns = L.NS, dxB = L.DX, duB = L.DU;
         T xi[5] = {T(0), T(0), T(0), T(0), T(0)};
         T cur[23];
+        auto load_stage = [&](int k, T (&o)[23]) {
+            const T* g = sm + gB + k * NGAIN;
+            const T* s = sm + sB + k * NSTG;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) { cur[i] = G_(i, 0); cur[5 + i] = G_(6 + i, 0); }
-        cur[10] = G_(12, 0); cur[11] = G_(13, 0);
-        cur[12] = S_(0, 0); cur[13] = S_(1, 0);
+            for (int i = 0; i < 5; ++i) { o[i] = g[i]; o[5 + i] = g[6 + i]; }
+            o[10] = g[12]; o[11] = g[13];
+            o[12] = s[0]; o[13] = s[1];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) cur[14 + i] = S_(5 + i, 0);
+            for (int i = 0; i < 6; ++i) o[14 + i] = s[5 + i];
 #pragma unroll
-        for (int i = 0; i < 3; ++i) cur[20 + i] = F(L.LAMN, i, 0);
+            for (int i = 0; i < 3; ++i) o[20 + i] = sm[cB_ + i * ns + k];
+        };
+        load_stage(0, cur);
         for (int k = 0; k < n - 1; ++k) {
+#ifdef MPC_ASM_MARK
+            asm volatile("; FWD_LOOP_BEGIN");
+#endif
             T nxt[23];
-            const int kn = k + 1 < n - 1 ? k + 1 : k;
-#pragma unroll
-            for (int i = 0; i < 5; ++i) { nxt[i] = G_(i, kn); nxt[5 + i] = G_(6 + i, kn); }
-            nxt[10] = G_(12, kn); nxt[11] = G_(13, kn);
-            nxt[12] = S_(0, kn); nxt[13] = S_(1, kn);
-#pragma unroll
-            for (int i = 0; i < 6; ++i) nxt[14 + i] = S_(5 + i, kn);
-#pragma unroll
-            for (int i = 0; i < 3; ++i) nxt[20 + i] = F(L.LAMN, i, kn);
+            load_stage(k + 1 < n - 1 ? k + 1 : k, nxt);
             const T du0 = -((cur[10] + cur[0] * xi[0] + cur[1] * xi[1]) + (cur[2] * xi[2] + cur[3] * xi[3] + cur[4] * xi[4]));
             const T du1 = -((cur[11] + cur[5] * xi[0] + cur[6] * xi[1]) + (cur[7] * xi[2] + cur[8] * xi[3] + cur[9] * xi[4]));
             const T xn0 = (xi[0] + cur[12] * xi[2]) + (cur[14] * du0 + cur[15] * du1 + cur[20]);
             const T xn1 = (xi[1] + cur[13] * xi[2]) + (cur[16] * du0 + cur[17] * du1 + cur[21]);
             const T xn2 = xi[2] + (cur[18] * du0 + cur[19] * du1 + cur[22]);
             if (lane == 0) {
-                F(L.DU, 0, k) = du0; F(L.DU, 1, k) = du1;
-                F(L.DX, 0, k + 1) = xn0; F(L.DX, 1, k + 1) = xn1; F(L.DX, 2, k + 1) = xn2;
+                sm[duB + k] = du0; sm[duB + ns + k] = du1;
+                sm[dxB + k + 1] = xn0; sm[dxB + ns + k + 1] = xn1; sm[dxB + 2 * ns + k + 1] = xn2;
             }
             xi[0] = xn0; xi[1] = xn1; xi[2] = xn2; xi[3] = du0; xi[4] = du1;
 #pragma unroll
             for (int i = 0; i < 23; ++i) cur[i] = nxt[i];
+#ifdef MPC_ASM_MARK
+            asm volatile("; FWD_LOOP_END");
+#endif
         }
         // ---- multipliers: lam+_{k-1} = lam+_k + t_k + e_theta (a0_k lam+_k[0] + a1_k lam+_k[1]),  k = n-2 .. 1,
         //      lam+_{n-2} from the terminal condition.  Components 0,1 are plain suffix sums, component 2 a second one.
