@@ -59,6 +59,19 @@ def cpu_baseline(n, seconds_budget=15.0):
                       f"mean {float(out[4].mean()):.1f} iterations, {dt:.2f} s wall on {cores} OpenMP threads"}
 
 
+def measured_traffic(n, B):
+    """HBM bytes per launch of the solve kernel from the rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, in bytes),
+    as recorded by scripts/summarize_profile.py for this exact workload; None when no matching record is committed."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")
+    try:
+        rec = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if rec.get("n") == n and rec.get("batch") == B and os.environ.get("MPC_HIP_KERNEL", "wave") == rec.get("kernel", "wave"):
+        return rec.get("bytes_per_launch")
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -150,8 +163,9 @@ def main():
                        "iters_p50": float(np.percentile(iters, 50)), "iters_p99": float(np.percentile(iters, 99)),
                        "iters_max": int(iters.max())},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "mpc_ipm_solve_kernel", "kernel_ms": k_ms,
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": measured_traffic(n, B),
+                         "kernel": "mpc_ipm_solve_kernel" if os.environ.get("MPC_HIP_KERNEL") == "lane" else "mpc_ipm_wave_kernel",
+                         "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "latency/FP64-issue bound by construction (SURVEY.md 8d): compulsory traffic is ~4 KB per solve",
                          "fp64_valu": {"achieved_tflops": fp64_tf, "peak_tflops": FP64_VECTOR_PEAK_TF,

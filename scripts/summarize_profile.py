@@ -38,6 +38,22 @@ def main(src, dst):
         out.append(f"\n## rocprofv3 --pmc ({os.path.basename(d)}) -- per dispatch of the solve kernel\n\n| counter | dispatches | mean | min | max |\n|---|---|---|---|---|\n")
         for name, cnt, mean, mn, mx in r:
             out.append(f"| {name} | {cnt} | {mean:.6g} | {mn:.6g} | {mx:.6g} |\n")
+    # HBM traffic record for bench.py's roofline.traffic: FETCH_SIZE/WRITE_SIZE are in KiB; FETCH_SIZE counts 64 B per 128-B
+    # request on gfx950 (MI355X_MICROARCH.md, HBM section) -> x2.  WRITE_SIZE is uncalibrated for partial (8-byte) stores.
+    vals = {}
+    for d in ("pmc_fetch", "pmc_write"):
+        db = os.path.join(src, d, "run_results.db")
+        if os.path.exists(db):
+            for name, mean in rows(db, "select counter_name, avg(value) from counters_collection where kernel_name like "
+                                       "'%mpc_ipm%' group by counter_name")[1]:
+                vals[name] = mean
+    if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+        import json
+        rec = {"kernel": "wave", "n": 50, "batch": 1024, "fetch_size_kib": vals["FETCH_SIZE"], "write_size_kib": vals["WRITE_SIZE"],
+               "bytes_per_launch": (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
+               "source": os.path.basename(dst) + ".md", "command": "python bench.py --steps 5 --warmup 1 --no-cpu-baseline"}
+        json.dump(rec, open(os.path.join(os.path.dirname(dst) or ".", "hbm_traffic.json"), "w"), indent=1)
+        out.append(f"\nHBM traffic per launch = 2 x FETCH_SIZE + WRITE_SIZE = {rec['bytes_per_launch'] / 1e6:.2f} MB\n")
     open(dst + ".md", "w").write("".join(out))
     print("".join(out))
 
