@@ -16,7 +16,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libmpc_hip.so")
 SOURCES = ["mpc_capi.hip"]
-HEADERS = ["mpc_core.hpp", "mpc_problem.hpp", os.path.join("..", "..", "include", "mpc_hip.h")]
+HEADERS = ["mpc_core.hpp", "mpc_problem.hpp", "mpc_wave.hpp", "mpc_dpp_blocks.inc", os.path.join("..", "..", "include", "mpc_hip.h")]
 
 EXPORTS = [
     "mpc_config_defaults", "mpc_create", "mpc_reset", "mpc_destroy", "mpc_solve_batch",

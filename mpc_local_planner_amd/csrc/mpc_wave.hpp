@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include "mpc_core.hpp"
+#include "mpc_dpp_blocks.inc"
 
 #ifdef MPC_PROFILE
 __device__ long long g_mpc_prof[4096][14];
@@ -28,8 +29,8 @@ namespace mpc {
 
 constexpr int kWave = 64;
 // per-stage LQ record: 0,1 a0,a1 | 2..4 f | 5..10 B[a][j] at 5+2a+j | 11..37 combined stage cost A[StageAdd]
-constexpr int NSTG = 38;
-constexpr int RA = 11;     // first A slot
+constexpr int NSTG = 39;
+constexpr int RA = 12;     // first A slot (words 0..11: a0 a1 1 | f | Bx[:,0] | Bx[:,1])
 constexpr int NGAIN = 20;  // K(2x6) kappa(2) Knu(2x3)
 
 struct WaveLayout {
@@ -54,7 +55,7 @@ struct WaveLayout {
         L.CC = take(3); L.TRIG = take(ntrig);
         L.GAIN = take(NGAIN); L.STG = take(NSTG);
         L.SC = o; o += 8;     // scalars: D, DT, DD, PDL, PDU
-        L.VP = o; o += 264;   // matrix-sweep scratch: VM 6x12 | T1 7x12 | HM 8x12 | W 3x3 + omega 3
+        L.VP = o; o += 160;   // sweep scratch: terminal V 6x12 | W 3x3 + omega 3 | dummy words | W/omega partials
         L.ZC = o; o += 8;     // constants: 6 zeros, then 1.0
         L.M = M; L.O = O; L.V = V;
         L.OS = take(M); L.OY = take(M); L.OI = take(M); L.OG = take(M); L.OAX = take(M); L.OAY = take(M); L.OHK = take(M);
@@ -133,6 +134,9 @@ struct IpmWave {
     __device__ __forceinline__ T& C_(int i, int k) const { return sm[L.CC + k * 3 + i]; }
     __device__ __forceinline__ T& SCL(int i) const { return sm[L.SC + i]; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
+    // explicit LDS pointers for the running-pointer loops (address-space inference gives up on per-lane selected pointers)
+    typedef __attribute__((address_space(3))) T LdsT;
+    __device__ __forceinline__ LdsT* lds(int word) const { return (LdsT*)sm + word; }
 
     // trial point z + alpha*dz, evaluated on the fly (no trial copy in LDS)
     // (alpha == 0 must not touch the step arrays: they are unwritten before the first factorisation, and 0 * garbage can be NaN)
@@ -388,9 +392,9 @@ struct IpmWave {
                 T gq[3];
                 for (int j = 0; j < 3; ++j) gq[j] = lam[0] * G[0][j] + lam[1] * G[1][j] + lam[2] * G[2][j];
                 // stage record, mu-independent part
-                S_(0, k) = d * G[0][0]; S_(1, k) = d * G[1][0];
-                S_(2, k) = f[0]; S_(3, k) = f[1]; S_(4, k) = f[2];
-                for (int a = 0; a < 3; ++a) { S_(5 + 2 * a, k) = d * G[a][1]; S_(6 + 2 * a, k) = d * G[a][2]; }
+                S_(0, k) = d * G[0][0]; S_(1, k) = d * G[1][0]; S_(2, k) = T(1);       // column 2 of Ghat: (a0, a1, 1)
+                S_(3, k) = f[0]; S_(4, k) = f[1]; S_(5, k) = f[2];
+                for (int a = 0; a < 3; ++a) { S_(6 + a, k) = d * G[a][1]; S_(9 + a, k) = d * G[a][2]; }   // Bx column-major
                 // raw (mu-independent) pieces parked in their A slots; stage_barrier_terms() turns them into the combined entries
                 S_(RA + A22, k) = d * Hq[0][0]; S_(RA + A26, k) = d * Hq[0][1]; S_(RA + A27, k) = d * Hq[0][2];
                 S_(RA + A66, k) = d * Hq[1][1]; S_(RA + A67, k) = d * Hq[1][2]; S_(RA + A77, k) = d * Hq[2][2];
@@ -549,61 +553,7 @@ struct IpmWave {
     }
 
     // ---------------------------------------------------------------- wave-uniform backward Riccati sweep
-    __device__ bool backward(T delta, T dc, T& dd_out, T nu_out[3]) const {
-        const int n = L.n;
-        const T d = SCL(SC_D);
-        RicState<T> V;
-        T q2[3] = {T(0), T(0), T(0)}, r2[2] = {T(0), T(0)};
-        if (P.objective == OBJ_QUADRATIC) { for (int i = 0; i < 3; ++i) q2[i] = T(2) * P.Q[i]; for (int j = 0; j < 2; ++j) r2[j] = T(2) * P.R[j]; }
-        {
-            const int r = n - 1;
-            T xd[3] = {F(L.X, 0, r) - xf[0], F(L.X, 1, r) - xf[1], normalize_theta(F(L.X, 2, r) - xf[2])};
-            T ss[2] = {S_(RA + A33, r), S_(RA + A44, r)}, sl[2] = {S_(RA + A35, r), S_(RA + A45, r)};
-            T gy[2] = {-S_(RA + A38, r), -S_(RA + A48, r)};
-            riccati_terminal(V, P, xd, delta, dc, ss, sl, S_(RA + A55, r), gy, -S_(RA + A58, r));
-        }
-        for (int k = n - 2; k >= 0; --k) {
-            StageRec<T> r;
-            r.a0 = S_(0, k); r.a1 = S_(1, k);
-#pragma unroll
-            for (int a = 0; a < 3; ++a) {
-                r.f[a] = S_(2 + a, k);
-                r.B[a][0] = S_(5 + 2 * a, k); r.B[a][1] = S_(6 + 2 * a, k);
-                r.c[a] = C_(a, k);
-            }
-#pragma unroll
-            for (int i = 0; i < NADD; ++i) r.A[i] = S_(RA + i, k);
-            T add_dd = T(0), add_qd = T(0);
-            if (k == 0) {
-                if (P.objective == OBJ_MIN_TIME) add_qd += T(n - 1);
-                if (P.dt_free) {
-                    T dl = d - P.dt_lb, du = P.dt_ub - d;
-                    add_dd = SCL(SC_PDL) / dl + SCL(SC_PDU) / du + delta;
-                    add_qd += -mu / dl + mu / du;
-                }
-            }
-            StageGain<T> g;
-            if (!riccati_step(V, r, k >= 1 ? delta : T(0), delta, add_dd, add_qd, g)) return false;
-            if (lane == 0) {
-                for (int a = 0; a < 2; ++a) for (int b = 0; b < 6; ++b) G_(6 * a + b, k) = g.K[a][b];
-                G_(12, k) = g.kap[0]; G_(13, k) = g.kap[1];
-                for (int a = 0; a < 2; ++a) for (int b = 0; b < 3; ++b) G_(14 + 3 * a + b, k) = g.Kn[a][b];
-            }
-        }
-        return riccati_root(V, P, dd_out, nu_out);
-    }
-
-    // ---------------------------------------------------------------- LDS-matrix backward Riccati sweep
-    // One matrix ENTRY per lane.  With V+ = [P | 0 0 | p | S] (6 x 12, LDS), every stage is three lane-parallel steps
-    // separated by an LDS hand-off (single wave: program order suffices):
-    //   A:  T1 = V+[:,0:3] * Ccoef + V+[:, extra]            (6 x 10 dense columns; Ccoef = the stage's [G | Gam | c~] columns;
-    //                                                          lanes 60..62 accumulate omega += S+[0:3,:]' c_k with the same formula)
-    //   B:  Hhat = Ccoef' * T1[0:3,:] + T1[extra,:] + A       (dense 6 x 10 block; the u_{k-1} rows/columns of Hhat are pure A-form
-    //                                                          entries and are read straight from the stage record in step C)
-    //   C:  2x2 pivot (uniform) -> gains K,  V = Hhat_xi - Hhat[:,6:8] K
-    // W and omega are completed after the sweep by a lane-parallel reduction over the stages (Su is parked in the LAMN/DX
-    // arrays, which are dead until the forward pass).  All per-lane operand addresses (coefficient triple, extra column/row,
-    // A slot, delta flags) are fixed before the loop: the stage body is branch-free apart from the uniform pivot test.
+    // ---------------------------------------------------------------- backward Riccati sweep
     __device__ __forceinline__ T fast_rcp(double x) const {
         double r = __builtin_amdgcn_rcp(x);
         r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
@@ -612,39 +562,45 @@ struct IpmWave {
     }
     __device__ __forceinline__ T fast_rcp(float x) const { return 1.0f / x; }
 
-    __device__ bool backward_mat(T delta, T dc, T& dd_out, T nu_out[3]) const {
+    // ---- register-resident backward sweep: lane c (0..11 of every 16-lane DPP row) owns COLUMN c of the value block
+    //      [P | . . | p | S] (6x12) and of Hhat (8x12).  Entries of other columns are fetched with the DP-ALU DPP broadcast
+    //      (v_fmac_f64_dpp ... row_newbcast:m), so a stage is ~90 fp64 VALU instructions and NO LDS hand-off; the stage
+    //      record (3 coefficients + 8 cost entries per lane) is prefetched from LDS one stage ahead.
+    //        T1 = V+ Ghat           T1[i][c] = sum_{m<3} V+[i][m] G[m][c] + V+[i][x(c)]
+    //        Hhat = Ghat' T1 + cost Hhat[r][c] = sum_{m<3} G[m][r] T1[m][c] + T1[x(r)][c] + A[r][c]
+    //        V = Hhat_xx - Hhat_xu R^-1 Hhat_ux   (R = Hhat[6:8][6:8], closed-form inverse; symmetry: Hhat[i][6] = lane i's Hhat[6][.])
+    //      Cost model on gfx950 with one wave per SIMD (scripts/ubench/issue_rate.hip): EVERY instruction, VALU or not, costs
+    //      ~4.5 cycles of issue, an LDS write->read hand-off ~115 cycles, s_nop 1 ~8 cycles: the sweep is written to minimise
+    //      the instruction count.  The DPP arithmetic lives in four inline-asm blocks per stage (mpc_dpp_blocks.inc, generated
+    //      by scripts/gen_dpp_blocks.py): the compiler cannot see a DPP operand inside inline asm and therefore does not insert
+    //      the 2 wait states of the VALU-write -> DPP-read hazard; each block opens with s_nop 1 and orders its own instructions.
+#ifdef MPC_DPP_DEBUG     // developer aid: single-instruction DPP helpers to bisect the generated blocks (each pays its own s_nop)
+#define MPC_BC_CASE(N) else if constexpr (LANE == N) { \
+        if constexpr (sizeof(T) == 8) asm("s_nop 1\n\tv_fmac_f64_dpp %0, %1, %2 row_newbcast:" #N " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(own)); \
+        else asm("s_nop 1\n\tv_fmac_f32_dpp %0, %1, %2 row_newbcast:" #N " row_mask:0xf bank_mask:0xf" : "+v"(acc) : "v"(src), "v"(own)); }
+    template <int LANE> __device__ __forceinline__ static void fmac_bc(T& acc, T src, T own) {
+        if constexpr (LANE < 0) {}
+        MPC_BC_CASE(0) MPC_BC_CASE(1) MPC_BC_CASE(2) MPC_BC_CASE(3) MPC_BC_CASE(4) MPC_BC_CASE(5)
+        MPC_BC_CASE(6) MPC_BC_CASE(7) MPC_BC_CASE(8) MPC_BC_CASE(9) MPC_BC_CASE(10) MPC_BC_CASE(11)
+    }
+#undef MPC_BC_CASE
+#endif
+    __device__ bool backward_dpp(T delta, T dc, T& dd_out, T nu_out[3]) const {
         const int n = L.n;
         const T d = SCL(SC_D);
-        const int VMo = L.VP, T1o = L.VP + 72, HMo = L.VP + 156, WMo = L.VP + 252;   // VM 6x12 | T1 7x12 (row 6 = 0) | HM 8x12 | W 9 + omega 3
+        const int VMo = L.VP, WMo = L.VP + 84;          // scratch: VM 6x12 | W 9 + omega 3 | dummy words | W/omega partials
         T* VM = sm + VMo;
-        T* HM = sm + HMo;
         T* WM = sm + WMo;
-        const int ZERO = L.ZC, ONE = L.ZC + 6;
-        if (lane == 0) { for (int i = 0; i < 6; ++i) sm[L.ZC + i] = T(0); sm[ONE] = T(1); }
-        for (int e2 = lane; e2 < 264; e2 += kWave) VM[e2] = T(0);
+        const int ZC = L.ZC;                            // constants 0 0 0 0 1 0 0 0: (0,0,0) @0, (0,1,0) @3, (1,0,0) @4
+        if (lane < 8) sm[ZC + lane] = lane == 4 ? T(1) : T(0);
+        for (int e2 = lane; e2 < 160; e2 += kWave) VM[e2] = T(0);
         sync();
-        // ---- per-lane tables
-        const int e = lane < 60 ? lane : 59;
-        const int cd[10] = {0, 1, 2, 5, 6, 7, 8, 9, 10, 11};    // dense columns of T1 / Hhat
-        const int rd[6] = {0, 1, 2, 5, 6, 7};                   // dense rows of Hhat
-        const int cv[10] = {0, 1, 2, 3, 4, 5, 8, 9, 10, 11};    // columns of the new V
-        // coefficient triple of index t (a column of [G | Gam | c~], equally a row of its transpose):
-        //   t=0:(1,0,0) 1:(0,1,0) 2:(a0,a1,1) 5:f 6:Bx[:,0] 7:Bx[:,1] 8:c_k  else 0;   extra index: 5->5, 6->3, 7->4, >=8 -> itself, else zero column/row 6
-        auto coef_tab = [&](int t, int m, int& base, int& stride) {
-            base = ZERO; stride = 0;
-            if (t == 0) { if (m == 0) base = ONE; }
-            else if (t == 1) { if (m == 1) base = ONE; }
-            else if (t == 2) { if (m == 2) base = ONE; else { base = L.STG + m; stride = NSTG; } }
-            else if (t == 5) { base = L.STG + 2 + m; stride = NSTG; }
-            else if (t == 6) { base = L.STG + 5 + 2 * m; stride = NSTG; }
-            else if (t == 7) { base = L.STG + 6 + 2 * m; stride = NSTG; }
-            else if (t == 8) { base = L.CC + m; stride = 3; }
-        };
-        auto extra_tab = [&](int t) { return t == 5 ? 5 : (t == 6 ? 3 : (t == 7 ? 4 : (t >= 8 ? t : 6))); };
-        auto add_idx = [&](int r, int c) -> int {      // A slot of Hhat[r][c] (symmetric), -1: none
-            if (c == 8) return A08 + r;
-            if (c > 8) return -1;
-            const int a = r < c ? r : c, b = r < c ? c : r;
+        const int c = lane & 15;                    // column owned by this lane (12..15 idle: they carry zeros)
+        const bool act = c < 12;
+        auto add_idx = [&](int r, int cc) -> int {      // A slot of Hhat[r][cc] (symmetric), -1: none
+            if (cc == 8) return A08 + r;
+            if (cc > 8) return -1;
+            const int a = r < cc ? r : cc, b = r < cc ? cc : r;
             if (a == 0) return b == 0 ? A00 : (b == 1 ? A01 : -1);
             if (a == 1) return b == 1 ? A11 : -1;
             if (a == 2) return b == 2 ? A22 : (b == 5 ? A25 : (b == 6 ? A26 : (b == 7 ? A27 : -1)));
@@ -654,51 +610,34 @@ struct IpmWave {
             if (a == 6) return b == 6 ? A66 : (b == 7 ? A67 : -1);
             return b == 7 ? A77 : -1;
         };
-        // step A operands: out = p0*k0 + p1*k1 + p2*k2 + px
-        int aK0, aS0, aK1, aS1, aK2, aS2, aP0, aP1, aP2, aPx, aOut;
-        if (lane < 60) {
-            const int iA = e / 10, cA = cd[e % 10];
-            coef_tab(cA, 0, aK0, aS0); coef_tab(cA, 1, aK1, aS1); coef_tab(cA, 2, aK2, aS2);
-            aP0 = VMo + 12 * iA; aP1 = aP0 + 1; aP2 = aP0 + 2;
-            aPx = VMo + 12 * iA + extra_tab(cA);
-            aOut = T1o + 12 * iA + cA;
-        } else {            // lanes 60..62: omega[b] += S+[0][b] c0 + S+[1][b] c1 + S+[2][b] c2   (lane 63 repeats b = 2 into a dummy slot)
-            const int b = lane - 60 < 3 ? lane - 60 : 2;
-            coef_tab(8, 0, aK0, aS0); coef_tab(8, 1, aK1, aS1); coef_tab(8, 2, aK2, aS2);
-            aP0 = VMo + 9 + b; aP1 = VMo + 12 + 9 + b; aP2 = VMo + 24 + 9 + b;
-            aPx = lane < 63 ? WMo + 9 + b : ZERO;
-            aOut = lane < 63 ? WMo + 9 + b : T1o + 6 * 12 + 3;     // dummy: an unused word of T1's zero row? no -> use column 3 of row 6 (never read)
+        // coefficient triple of column c: three consecutive words, running pointer (stride 0 for the constant triples)
+        int gb = ZC, gs = 0;
+        if (c == 0) gb = ZC + 4;
+        else if (c == 1) gb = ZC + 3;
+        else if (c == 2) { gb = L.STG; gs = NSTG; }
+        else if (c == 5) { gb = L.STG + 3; gs = NSTG; }
+        else if (c == 6) { gb = L.STG + 6; gs = NSTG; }
+        else if (c == 7) { gb = L.STG + 9; gs = NSTG; }
+        else if (c == 8) { gb = L.CC; gs = 3; }
+        const LdsT* gp = lds(gb + (n - 2) * gs);
+        const LdsT* ap[8];
+        int as_[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+            const int ai = act ? add_idx(r, c) : -1;
+            as_[r] = ai >= 0 ? NSTG : 0;
+            ap[r] = lds(ai >= 0 ? L.STG + RA + ai + (n - 2) * NSTG : ZC);
         }
-        // step B operands: out = t0*k0 + t1*k1 + t2*k2 + tx + add + flags
-        const int rB = rd[e / 10], cB = cd[e % 10];
-        int bK0, bS0, bK1, bS1, bK2, bS2;
-        coef_tab(rB, 0, bK0, bS0); coef_tab(rB, 1, bK1, bS1); coef_tab(rB, 2, bK2, bS2);
-        const int bT0 = T1o + cB, bT1 = T1o + 12 + cB, bT2 = T1o + 24 + cB;
-        const int bTx = T1o + 12 * (rB >= 5 ? extra_tab(rB) : 6) + cB, bOut = HMo + 12 * rB + cB;
-        const int aiB = add_idx(rB, cB);
-        const int bAd = aiB >= 0 ? L.STG + RA + aiB : ZERO, bAs = aiB >= 0 ? NSTG : 0;
-        const T f1 = (rB == cB && rB < 3) ? T(1) : T(0);                    // + delta for k >= 1
-        const T f2 = (rB == cB && (rB == 6 || rB == 7)) ? T(1) : T(0);      // + delta
-        const T f3 = (rB == 5 && cB == 5) ? T(1) : T(0);                    // + dt box (stage 0)
-        const T f4 = (rB == 5 && cB == 8) ? T(1) : T(0);                    // + objective / dt-box gradient (stage 0)
-        const bool isSu = lane < 60 && rB >= 6 && cB >= 9;                  // Su[j][a] = Hhat[6+j][9+a] parked for the W/omega reduction
-        const int suO = (rB == 6 ? L.LAMN : L.DX) + (cB >= 9 ? cB - 9 : 0) * L.NS;
-        // step C operands: Hhat[r][c] lives in HM for dense (r,c), else it is a pure A-form entry of the record (or zero)
-        auto hsrc = [&](int r, int c, int& base, int& stride) {
-            const bool dr = r != 3 && r != 4, dcn = c != 3 && c != 4;
-            if (dr && dcn) { base = HMo + 12 * r + c; stride = 0; return; }
-            const int ai = add_idx(r, c);
-            if (ai >= 0) { base = L.STG + RA + ai; stride = NSTG; } else { base = ZERO; stride = 0; }
-        };
-        const int iC = e / 10, cC = cv[e % 10];
-        int c6b, c6s, c7b, c7s, ccb, ccs, i6b, i6s, i7b, i7s;
-        hsrc(6, cC, c6b, c6s); hsrc(7, cC, c7b, c7s); hsrc(iC, cC, ccb, ccs); hsrc(iC, 6, i6b, i6s); hsrc(iC, 7, i7b, i7s);
-        const int cOut = VMo + 12 * iC + cC;
-        const int g0 = cC < 6 ? cC : (cC == 8 ? 12 : 14 + (cC - 9));
-        const int g1 = cC < 6 ? 6 + cC : (cC == 8 ? 13 : 17 + (cC - 9));
-        const bool wrG = lane < 60 && iC == 0;
-        const int gainB = L.GAIN;
-        // ---- terminal value function
+        const T ec = (c == 5 || (c >= 8 && c < 12)) ? T(1) : T(0);       // own column enters T1 (dt, p, S)
+        const T E3 = c == 6 ? T(1) : T(0), E4 = c == 7 ? T(1) : T(0);     // the u columns pick up the u_prev columns of V+
+        const T dA0 = c == 0 ? delta : T(0), dA1 = c == 1 ? delta : T(0), dA2 = c == 2 ? delta : T(0);   // x diagonal, k >= 1
+        const T dA6 = c == 6 ? delta : T(0), dA7 = c == 7 ? delta : T(0);                                 // u diagonal
+        // negated gains go to GAIN as [nK0 (cols 0..5) | nkappa0 | nKnu0 (3) | nK1 ... ] : g1 = g0 + 10; idle lanes hit a dummy pair
+        const bool wrG = lane < 12 && c != 6 && c != 7;
+        const int g0 = c < 6 ? c : (c == 8 ? 6 : 7 + (c - 9));
+        LdsT* kp = lds(wrG ? L.GAIN + g0 + (n - 2) * NGAIN : VMo + 130);
+        const int ks = wrG ? NGAIN : 0;
+        // ---- terminal value function (built by lane 0 in LDS, then picked up column-wise)
         if (lane == 0) {
             const int r = n - 1;
             for (int i = 0; i < 3; ++i) {
@@ -719,6 +658,9 @@ struct IpmWave {
             VM[12 * 3 + 8] = S_(RA + A38, r); VM[12 * 4 + 8] = S_(RA + A48, r); VM[12 * 5 + 8] = S_(RA + A58, r);
         }
         sync();
+        T V[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) V[i] = act ? VM[12 * i + c] : T(0);
         T add_dd0 = T(0), add_qd0 = T(0);
         if (P.objective == OBJ_MIN_TIME) add_qd0 += T(n - 1);
         if (P.dt_free) {
@@ -726,73 +668,104 @@ struct IpmWave {
             add_dd0 = SCL(SC_PDL) / dl + SCL(SC_PDU) / du + delta;
             add_qd0 += -mu / dl + mu / du;
         }
-        for (int k = n - 2; k >= 0; --k) {
+        const T s05 = c == 5 ? add_dd0 : (c == 8 ? add_qd0 : T(0));       // stage-0 extras of row 5
+        T om = T(0), wn[3] = {T(0), T(0), T(0)};
+        T worst = T(1);                                                   // min over the stages of |det R| - 1e-14 * scale
+        auto load_stage = [&](T (&g)[3], T (&a)[8]) {                     // reads the stage the running pointers are at, then steps them
+            g[0] = gp[0]; g[1] = gp[1]; g[2] = gp[2];
+            gp -= gs;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { a[r] = *ap[r]; ap[r] -= as_[r]; }
+        };
+        auto stage = [&](T dk0, T dk1, T dk2, T s5, T (&G)[3], T (&A)[8], T (&Gn)[3], T (&An)[8]) {
+            load_stage(Gn, An);                                           // prefetch of the next stage (k - 1)
+            // ---- T1 = V+ Ghat (own column, then the five broadcast columns) and
+            //      omega[b] += S+[0][b] c0 + S+[1][b] c1 + S+[2][b] c2  (lanes 9..11; c_k is lane 8's coefficient triple)
+            T t[6];
+#if defined(MPC_DPP_DEBUG) && (MPC_DPP_DEBUG & 1)
+            for (int i = 0; i < 6; ++i) t[i] = V[i] * ec;
+            for (int i = 0; i < 6; ++i) fmac_bc<0>(t[i], V[i], G[0]);
+            for (int i = 0; i < 6; ++i) fmac_bc<1>(t[i], V[i], G[1]);
+            for (int i = 0; i < 6; ++i) fmac_bc<2>(t[i], V[i], G[2]);
+            for (int i = 0; i < 6; ++i) fmac_bc<3>(t[i], V[i], E3);
+            for (int i = 0; i < 6; ++i) fmac_bc<4>(t[i], V[i], E4);
+            fmac_bc<8>(om, G[0], V[0]); fmac_bc<8>(om, G[1], V[1]); fmac_bc<8>(om, G[2], V[2]);
+#else
+            MPC_DPP_BLOCK_T1
+#endif
+            // ---- Hhat = Ghat' T1 + cost entries (+ regularisation on this lane's diagonal entry)
+            T h[8];
+            h[0] = (A[0] + dk0) + t[0]; h[1] = (A[1] + dk1) + t[1]; h[2] = (A[2] + dk2) + t[2];
+            h[3] = A[3]; h[4] = A[4];
+            h[5] = (A[5] + s5) + t[5];
+            h[6] = (A[6] + dA6) + t[3]; h[7] = (A[7] + dA7) + t[4];
+#if defined(MPC_DPP_DEBUG) && (MPC_DPP_DEBUG & 2)
+            fmac_bc<6>(h[6], G[0], t[0]); fmac_bc<7>(h[7], G[0], t[0]); fmac_bc<5>(h[5], G[0], t[0]); fmac_bc<2>(h[2], G[0], t[0]);
+            fmac_bc<6>(h[6], G[1], t[1]); fmac_bc<7>(h[7], G[1], t[1]); fmac_bc<5>(h[5], G[1], t[1]); fmac_bc<2>(h[2], G[1], t[1]);
+            fmac_bc<6>(h[6], G[2], t[2]); fmac_bc<7>(h[7], G[2], t[2]); fmac_bc<5>(h[5], G[2], t[2]);
+#else
+            MPC_DPP_BLOCK_H
+#endif
+            // ---- Schur complement on the control block
+            T R00, R01, R11;
+            MPC_DPP_BLOCK_R
+            const T r2 = R01 * R01;
+            const T det = R00 * R11 - r2;
+            worst = t_min(worst, t_abs(det) - T(1e-14) * (t_abs(R00 * R11) + r2));
+            const T nid = -fast_rcp(det);
+            const T nRi00 = R11 * nid, Ri01 = -(R01 * nid), nRi11 = R00 * nid;  // -R^-1 = [nRi00 Ri01; Ri01 nRi11]
+            const T nK0 = nRi00 * h[6] + Ri01 * h[7], nK1 = Ri01 * h[6] + nRi11 * h[7];
+            kp[0] = nK0; kp[10] = nK1;
+            kp -= ks;
+            // W[a][b] -= Su[:,a]' Knu[:,b] in lane 9+b, omega[a] -= Su[:,a]' kappa in lane 8 (Su[j][a] = Hhat[6+j][9+a]);
+            // V = Hhat_xx + Hhat_xu nK   (row i of Hhat[:,6:8] = lane i's Hhat[6:8][.])
+            V[0] = h[0]; V[1] = h[1]; V[2] = h[2]; V[3] = h[3]; V[4] = h[4]; V[5] = h[5];
+#if defined(MPC_DPP_DEBUG) && (MPC_DPP_DEBUG & 4)
+            fmac_bc<9>(wn[0], h[6], nK0); fmac_bc<10>(wn[1], h[6], nK0); fmac_bc<11>(wn[2], h[6], nK0);
+            fmac_bc<9>(wn[0], h[7], nK1); fmac_bc<10>(wn[1], h[7], nK1); fmac_bc<11>(wn[2], h[7], nK1);
+            fmac_bc<0>(V[0], h[6], nK0); fmac_bc<1>(V[1], h[6], nK0); fmac_bc<2>(V[2], h[6], nK0);
+            fmac_bc<3>(V[3], h[6], nK0); fmac_bc<4>(V[4], h[6], nK0); fmac_bc<5>(V[5], h[6], nK0);
+            fmac_bc<0>(V[0], h[7], nK1); fmac_bc<1>(V[1], h[7], nK1); fmac_bc<2>(V[2], h[7], nK1);
+            fmac_bc<3>(V[3], h[7], nK1); fmac_bc<4>(V[4], h[7], nK1); fmac_bc<5>(V[5], h[7], nK1);
+#else
+            MPC_DPP_BLOCK_V
+#endif
+        };
+        T Ga[3], Aa[8], Gb[3], Ab[8];
+        load_stage(Ga, Aa);
+        int k = n - 2;
+        for (; k >= 2; k -= 2) {        // stages k and k-1 (both >= 1): the two register sets swap roles, no copies
 #ifdef MPC_ASM_MARK
             asm volatile("; MAT_LOOP_BEGIN");
 #endif
-            // ---- A
-            {
-                const T k0 = sm[aK0 + k * aS0], k1 = sm[aK1 + k * aS1], k2 = sm[aK2 + k * aS2];
-                const T p0 = sm[aP0], p1 = sm[aP1], p2 = sm[aP2], px = sm[aPx];
-                sm[aOut] = (p0 * k0 + p1 * k1) + (p2 * k2 + px);
-            }
-            sync();
-            // ---- B
-            {
-                const T k0 = sm[bK0 + k * bS0], k1 = sm[bK1 + k * bS1], k2 = sm[bK2 + k * bS2];
-                const T t0 = sm[bT0], t1 = sm[bT1], t2 = sm[bT2], tx = sm[bTx];
-                const T add = sm[bAd + k * bAs];
-                const T dk = k >= 1 ? delta : T(0), ddk = k == 0 ? add_dd0 : T(0), qdk = k == 0 ? add_qd0 : T(0);
-                const T val = ((t0 * k0 + t1 * k1) + (t2 * k2 + tx)) + ((add + f1 * dk) + (f2 * delta + (f3 * ddk + f4 * qdk)));
-                sm[bOut] = val;
-                if (isSu) sm[suO + k] = val;
-            }
-            sync();
-            // ---- C
-            {
-                const T R00 = HM[12 * 6 + 6], R01 = HM[12 * 6 + 7], R11 = HM[12 * 7 + 7];
-                const T h6 = sm[c6b + k * c6s], h7 = sm[c7b + k * c7s], hc = sm[ccb + k * ccs], m6 = sm[i6b + k * i6s], m7 = sm[i7b + k * i7s];
-                const T det = R00 * R11 - R01 * R01;
-                const T scale = t_abs(R00 * R11) + R01 * R01;
-                if (!(t_abs(det) > T(1e-14) * scale) || !t_finite(det)) return false;
-                const T id = fast_rcp(det);
-                const T Ri00 = R11 * id, Ri01 = -R01 * id, Ri11 = R00 * id;
-                const T K0 = Ri00 * h6 + Ri01 * h7, K1 = Ri01 * h6 + Ri11 * h7;
-                sm[cOut] = hc - (m6 * K0 + m7 * K1);
-                if (wrG) { sm[gainB + k * NGAIN + g0] = K0; sm[gainB + k * NGAIN + g1] = K1; }
-            }
-            sync();
+            stage(dA0, dA1, dA2, T(0), Ga, Aa, Gb, Ab);
+            stage(dA0, dA1, dA2, T(0), Gb, Ab, Ga, Aa);
 #ifdef MPC_ASM_MARK
             asm volatile("; MAT_LOOP_END");
 #endif
         }
-        // ---- W -= sum_k Su_k' Knu_k ,  omega -= sum_k Su_k' kappa_k   (lane-parallel over the stages)
-        T wacc[9] = {T(0), T(0), T(0), T(0), T(0), T(0), T(0), T(0), T(0)}, oacc[3] = {T(0), T(0), T(0)};
-        for (int k = lane; k < n - 1; k += kWave) {
-            T su0[3], su1[3], kn0[3], kn1[3];
-            for (int a = 0; a < 3; ++a) { su0[a] = F(L.LAMN, a, k); su1[a] = F(L.DX, a, k); kn0[a] = G_(14 + a, k); kn1[a] = G_(17 + a, k); }
-            const T ka0 = G_(12, k), ka1 = G_(13, k);
-            for (int a = 0; a < 3; ++a) {
-                for (int b = 0; b < 3; ++b) wacc[3 * a + b] += su0[a] * kn0[b] + su1[a] * kn1[b];
-                oacc[a] += su0[a] * ka0 + su1[a] * ka1;
-            }
-        }
-        RicState<T> V;
-        V.P[5][5] = VM[12 * 5 + 5];
-        V.p[5] = VM[12 * 5 + 8];
+        if (k == 1) { stage(dA0, dA1, dA2, T(0), Ga, Aa, Gb, Ab); stage(T(0), T(0), T(0), s05, Gb, Ab, Ga, Aa); }
+        else stage(T(0), T(0), T(0), s05, Ga, Aa, Gb, Ab);
+        // row 5 of the value block, omega and the W / omega corrections go back to LDS for the root solve
+        if (lane < 12) VM[12 * 5 + c] = V[5];
+        if (lane >= 9 && lane < 12) { WM[9 + (c - 9)] += om; for (int a = 0; a < 3; ++a) VM[110 + 3 * a + (c - 9)] = wn[a]; }
+        if (lane == 8) for (int a = 0; a < 3; ++a) VM[120 + a] = wn[a];
+        sync();
+        if (!(rd_lane(worst, 0) > T(0))) return false;
+        RicState<T> Vr;
+        Vr.P[5][5] = VM[12 * 5 + 5];
+        Vr.p[5] = VM[12 * 5 + 8];
         for (int b = 0; b < 3; ++b) {
-            V.S[5][b] = VM[12 * 5 + 9 + b];
-            V.om[b] = WM[9 + b] - wave_sum(oacc[b]);
+            Vr.S[5][b] = VM[12 * 5 + 9 + b];
+            Vr.om[b] = WM[9 + b] + VM[120 + b];
         }
-        // W is symmetric: reduce the 6 unique entries
         for (int a = 0; a < 3; ++a) for (int b = a; b < 3; ++b) {
-            const T s = WM[3 * a + b] - wave_sum(T(0.5) * (wacc[3 * a + b] + wacc[3 * b + a]));
-            V.W[a][b] = s; V.W[b][a] = s;
+            const T s = WM[3 * a + b] + T(0.5) * (VM[110 + 3 * a + b] + VM[110 + 3 * b + a]);
+            Vr.W[a][b] = s; Vr.W[b][a] = s;
         }
-        return riccati_root(V, P, dd_out, nu_out);
+        return riccati_root(Vr, P, dd_out, nu_out);
     }
 
-    // inclusive suffix sum over the lanes of the wave (lane l gets sum_{l' >= l} v[l'])
     __device__ __forceinline__ T wave_suffix_sum(T v) const {
 #pragma unroll
         for (int o = 1; o < kWave; o <<= 1) { T w2 = __shfl_down(v, o); if (lane + o < kWave) v += w2; }
@@ -804,53 +777,78 @@ struct IpmWave {
         const int n = L.n;
         // ---- lane-parallel: fold nu and dd into the affine terms so that the serial loop only carries (x, u_prev)
         //      kappa^ = kappa + Knu nu + K[:,5] dd  (stored over kappa),  c^ = c + f dd  (stored in LAMN, rewritten below)
+        //      (gains are stored negated: [nK0 (6) | nkappa0 | nKnu0 (3) | nK1 (6) | nkappa1 | nKnu1 (3)])
         for (int k = lane; k < n - 1; k += kWave) {
             for (int a = 0; a < 2; ++a)
-                G_(12 + a, k) += G_(14 + 3 * a, k) * nu[0] + G_(15 + 3 * a, k) * nu[1] + G_(16 + 3 * a, k) * nu[2] + G_(6 * a + 5, k) * dd;
-            for (int i = 0; i < 3; ++i) F(L.LAMN, i, k) = C_(i, k) + S_(2 + i, k) * dd;
+                G_(10 * a + 6, k) += G_(10 * a + 7, k) * nu[0] + G_(10 * a + 8, k) * nu[1] + G_(10 * a + 9, k) * nu[2] + G_(10 * a + 5, k) * dd;
+            for (int i = 0; i < 3; ++i) F(L.LAMN, i, k) = C_(i, k) + S_(3 + i, k) * dd;
         }
         if (lane == 0) { SCL(SC_DD) = dd; F(L.DX, 0, 0) = T(0); F(L.DX, 1, 0) = T(0); F(L.DX, 2, 0) = T(0); }
+        if (lane < 8) sm[L.ZC + lane] = lane == 4 ? T(1) : T(0);
         sync();
-        // ---- serial: xi = (dx, du_prev); 23 LDS words per stage, prefetched one stage ahead.  The layout record lives in LDS, and
-        //      the compiler must assume that the stores below may alias it, so every base offset is copied to a register first.
-        const int gB = L.GAIN, sB = L.STG, cB_ = L.LAMN, ns = L.NS, dxB = L.DX, duB = L.DU;
-        T xi[5] = {T(0), T(0), T(0), T(0), T(0)};
-        T cur[23];
-        auto load_stage = [&](int k, T (&o)[23]) {
-            const T* g = sm + gB + k * NGAIN;
-            const T* s = sm + sB + k * NSTG;
+        // ---- serial recurrence, one COMPONENT per lane: lanes 0..2 carry dx_k, lanes 3,4 carry du_{k-1}; a stage is
+        //        s  = cst + sum_j q_j * xi[j]        lanes 3,4: du_k = nkappa^ + nK xi ;  lanes 0..2: dx_k[c] + a_c dx_k[2] + c^_k[c]
+        //        xn = s + b0 * s[3] + b1 * s[4]      lanes 0..2: + Bx[c][:] du_k
+        //      i.e. 7 DPP-broadcast FMAs; the 8 per-lane coefficients are prefetched one stage ahead through running pointers.
+        {
+            const int c = lane & 15;
+            const int ZC = L.ZC;
+            int qw[8], qs[8];        // word index and stride of: cst, q0..q4, b0, b1
 #pragma unroll
-            for (int i = 0; i < 5; ++i) { o[i] = g[i]; o[5 + i] = g[6 + i]; }
-            o[10] = g[12]; o[11] = g[13];
-            o[12] = s[0]; o[13] = s[1];
+            for (int j = 0; j < 8; ++j) { qw[j] = ZC; qs[j] = 0; }
+            if (c < 3) {
+                qw[0] = L.LAMN + c * L.NS; qs[0] = 1;
+                qw[1 + c] = ZC + 4;                                          // xi[c] itself
+                if (c < 2) { qw[3] = L.STG + c; qs[3] = NSTG; }              // a_c * xi[2]
+                qw[6] = L.STG + 6 + c; qs[6] = NSTG;
+                qw[7] = L.STG + 9 + c; qs[7] = NSTG;
+            } else if (c < 5) {
+                const int a = c - 3;
+                qw[0] = L.GAIN + 10 * a + 6; qs[0] = NGAIN;
 #pragma unroll
-            for (int i = 0; i < 6; ++i) o[14 + i] = s[5 + i];
-#pragma unroll
-            for (int i = 0; i < 3; ++i) o[20 + i] = sm[cB_ + i * ns + k];
-        };
-        load_stage(0, cur);
-        for (int k = 0; k < n - 1; ++k) {
-#ifdef MPC_ASM_MARK
-            asm volatile("; FWD_LOOP_BEGIN");
-#endif
-            T nxt[23];
-            load_stage(k + 1 < n - 1 ? k + 1 : k, nxt);
-            const T du0 = -((cur[10] + cur[0] * xi[0] + cur[1] * xi[1]) + (cur[2] * xi[2] + cur[3] * xi[3] + cur[4] * xi[4]));
-            const T du1 = -((cur[11] + cur[5] * xi[0] + cur[6] * xi[1]) + (cur[7] * xi[2] + cur[8] * xi[3] + cur[9] * xi[4]));
-            const T xn0 = (xi[0] + cur[12] * xi[2]) + (cur[14] * du0 + cur[15] * du1 + cur[20]);
-            const T xn1 = (xi[1] + cur[13] * xi[2]) + (cur[16] * du0 + cur[17] * du1 + cur[21]);
-            const T xn2 = xi[2] + (cur[18] * du0 + cur[19] * du1 + cur[22]);
-            if (lane == 0) {
-                sm[duB + k] = du0; sm[duB + ns + k] = du1;
-                sm[dxB + k + 1] = xn0; sm[dxB + ns + k + 1] = xn1; sm[dxB + 2 * ns + k + 1] = xn2;
+                for (int j = 0; j < 5; ++j) { qw[1 + j] = L.GAIN + 10 * a + j; qs[1 + j] = NGAIN; }
             }
-            xi[0] = xn0; xi[1] = xn1; xi[2] = xn2; xi[3] = du0; xi[4] = du1;
+            const LdsT* qp[8];
 #pragma unroll
-            for (int i = 0; i < 23; ++i) cur[i] = nxt[i];
-#ifdef MPC_ASM_MARK
-            asm volatile("; FWD_LOOP_END");
+            for (int j = 0; j < 8; ++j) qp[j] = lds(qw[j]);
+            // where the result goes: dx_{k+1}[c] / du_k[c-3]; idle lanes write a dummy word of the sweep scratch
+            LdsT* op = lds(c < 3 ? L.DX + c * L.NS + 1 : (c < 5 ? L.DU + (c - 3) * L.NS : L.VP + 130));
+            const int os = c < 5 ? 1 : 0;
+            auto load_q = [&](T (&q)[8]) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { q[j] = *qp[j]; qp[j] += qs[j]; }
+            };
+            T xi = T(0);
+            auto stage = [&](T (&q)[8], T (&qn)[8]) {
+                load_q(qn);
+                T s = q[0], s2 = T(0), xn;
+#if defined(MPC_DPP_DEBUG) && (MPC_DPP_DEBUG & 8)
+                fmac_bc<0>(s, xi, q[1]); fmac_bc<1>(s2, xi, q[2]); fmac_bc<2>(s, xi, q[3]); fmac_bc<3>(s2, xi, q[4]); fmac_bc<4>(s, xi, q[5]);
+                s += s2;
+                xn = s;
+                fmac_bc<3>(xn, s, q[6]); fmac_bc<4>(xn, s, q[7]);
+#else
+                MPC_DPP_BLOCK_FWD
 #endif
+                *op = xn; op += os;
+                xi = xn;
+            };
+            T qa[8], qb[8];
+            load_q(qa);
+            int k = 0;
+            for (; k + 1 < n - 1; k += 2) {
+#ifdef MPC_ASM_MARK
+                asm volatile("; FWD_LOOP_BEGIN");
+#endif
+                stage(qa, qb); stage(qb, qa);
+#ifdef MPC_ASM_MARK
+                asm volatile("; FWD_LOOP_END");
+#endif
+            }
+            if (k < n - 1) stage(qa, qb);
         }
+        sync();
+        const T xi[3] = {F(L.DX, 0, n - 1), F(L.DX, 1, n - 1), F(L.DX, 2, n - 1)};
         // ---- multipliers: lam+_{k-1} = lam+_k + t_k + e_theta (a0_k lam+_k[0] + a1_k lam+_k[1]),  k = n-2 .. 1,
         //      lam+_{n-2} from the terminal condition.  Components 0,1 are plain suffix sums, component 2 a second one.
         T lp[3];
@@ -1200,16 +1198,34 @@ struct IpmWave {
             T dd = T(0), nu[3] = {T(0), T(0), T(0)}, curv = T(0);
             for (int ntry = 0; ntry <= 40; ++ntry) {
                 bool good;
-                #ifdef MPC_UNIFORM_SWEEP
-                MPC_TICK(2, good = backward(delta, dc, dd, nu); sync());
-#else
-                MPC_TICK(2, good = backward_mat(delta, dc, dd, nu); sync());
-#endif
+                MPC_TICK(2, good = backward_dpp(delta, dc, dd, nu); sync());
 #ifdef MPC_PROFILE
                 ++nfac;
 #endif
+#ifdef MPC_NANCHECK      // developer aid: non-finite words per field of the LDS record after each sweep (lane 0 prints)
+                if (blockIdx.x == MPC_NANCHECK && lane == 0) {
+                    const int offs[] = {L.X, L.U, L.LAM, L.LAMN, L.SR, L.YR, L.PL, L.PU, L.DX, L.DU, L.CC, L.TRIG, L.GAIN, L.STG, L.SC, L.VP, L.ZC, L.total};
+                    const char* nm[] = {"X", "U", "LAM", "LAMN", "SR", "YR", "PL", "PU", "DX", "DU", "CC", "TRIG", "GAIN", "STG", "SC", "VP", "ZC"};
+                    printf("it %d try %d good %d delta %g dd %g mu %g |", it, ntry, (int)good, (double)delta, (double)dd, (double)mu);
+                    for (int f = 0; f < 17; ++f) {
+                        int cnt = 0, first = -1;
+                        for (int q = offs[f]; q < offs[f + 1]; ++q) if (!t_finite(sm[q])) { ++cnt; if (first < 0) first = q - offs[f]; }
+                        if (cnt) printf(" %s:%d@%d", nm[f], cnt, first);
+                    }
+                    printf("\n");
+                }
+#endif
                 if (good) {
                     MPC_TICK(3, forward_states(dd, nu, delta); sync());
+#ifdef MPC_NANCHECK
+                    if (blockIdx.x == MPC_NANCHECK) {
+                        for (int k = lane; k < L.n; k += kWave) {
+                            bool f = t_finite(F(L.DX, 0, k)) && t_finite(F(L.DX, 1, k)) && t_finite(F(L.DX, 2, k));
+                            if (k < L.n - 1) f = f && t_finite(F(L.DU, 0, k)) && t_finite(F(L.DU, 1, k)) && t_finite(F(L.LAMN, 0, k)) && t_finite(F(L.LAMN, 1, k)) && t_finite(F(L.LAMN, 2, k));
+                            if (!f) printf("it %d try %d fwd nonfinite at k %d: dx %g %g %g du %g %g lamn %g %g %g\n", it, ntry, k, (double)F(L.DX, 0, k), (double)F(L.DX, 1, k), (double)F(L.DX, 2, k), (double)F(L.DU, 0, k), (double)F(L.DU, 1, k), (double)F(L.LAMN, 0, k), (double)F(L.LAMN, 1, k), (double)F(L.LAMN, 2, k));
+                        }
+                    }
+#endif
                     MPC_TICK(4, fw = post_pass(dd, nu, tau));
                     good = fw.finite;
                     if (good) {
@@ -1250,6 +1266,10 @@ struct IpmWave {
                 if (t_finite(phit) && phit - phi0 - Algo<T>::ls_eps * t_abs(phi0) <= Algo<T>::eta_armijo * alpha * Dm) { accepted = true; break; }
             }
             if (!accepted && alpha * fw.dzmax < T(1e-14)) { status = ST_LINESEARCH; break; }
+#ifdef MPC_NANCHECK
+            if (blockIdx.x == MPC_NANCHECK && lane == 0)
+                printf("   ls: it %d f %.6f -> %.6f theta_c %.3e alpha %.4f a_p %.4f a_d %.4f rho %.3e Dm %.4e hdz %.6e clam %.6e dz2 %.6e dphi %.6e\n", it, (double)fobj, (double)f_t, (double)th_t, (double)alpha, (double)fw.a_p, (double)fw.a_d, (double)rho, (double)Dm, (double)fw.hdz, (double)fw.clam, (double)fw.dz2, (double)fw.dphi);
+#endif
             MPC_TICK(7, accept(alpha, fw.a_d); sync());
             theta_c = th_t; fobj = f_t;
             ++it;
