@@ -138,10 +138,46 @@ MPC_HD double t_atan(double a) { return ::atan(a); }
 MPC_HD float t_atan(float a) { return ::atanf(a); }
 MPC_HD double t_asin(double a) { return ::asin(a); }
 MPC_HD float t_asin(float a) { return ::asinf(a); }
-MPC_HD double t_tan(double a) { return ::tan(a); }
-MPC_HD float t_tan(float a) { return ::tanf(a); }
-MPC_HD void t_sincos(double a, double* s, double* c) { ::sincos(a, s, c); }
+// ---- fp64 sine / cosine / tangent for the arguments this solver produces (angles wrapped to [-pi, pi), steering angles
+//      inside their box): Cody-Waite reduction by pi/2 (two FMAs, exact for the quadrant counts that occur) and the classic
+//      degree-13/14 minimax kernels on [-pi/4, pi/4] (Sun fdlibm coefficients).  ~40 instructions instead of the several hundred
+//      of the general libm routine, whose extended-precision reduction dominated the line-search trials; <= 1 ulp on the
+//      reduced range (tests/host_harness checks it against libm).  Arguments beyond 1e5 or non-finite take the libm path.
+MPC_HD void sincos_reduced(double x, double* sp, double* cp) {
+    const double k = __builtin_rint(x * 6.36619772367581382433e-01);
+    double r = __builtin_fma(-k, 1.57079632673412561417e+00, x);
+    r = __builtin_fma(-k, 6.07710050650619224932e-11, r);
+    const double z = r * r;
+    double ps = __builtin_fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08);
+    ps = __builtin_fma(z, ps, 2.75573137070700676789e-06);
+    ps = __builtin_fma(z, ps, -1.98412698298579493134e-04);
+    ps = __builtin_fma(z, ps, 8.33333333332248946124e-03);
+    ps = __builtin_fma(z, ps, -1.66666666666666324348e-01);
+    const double s = __builtin_fma(z * r, ps, r);
+    double pc = __builtin_fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09);
+    pc = __builtin_fma(z, pc, -2.75573143513906633035e-07);
+    pc = __builtin_fma(z, pc, 2.48015872894767294178e-05);
+    pc = __builtin_fma(z, pc, -1.38888888888741095749e-03);
+    pc = __builtin_fma(z, pc, 4.16666666666666019037e-02);
+    const double hz = 0.5 * z, wv = 1.0 - hz;
+    const double c = wv + (((1.0 - wv) - hz) + z * z * pc);
+    const int q = (int)k & 3;
+    const double s1 = (q & 1) ? c : s, c1 = (q & 1) ? s : c;
+    *sp = (q & 2) ? -s1 : s1;
+    *cp = ((q + 1) & 2) ? -c1 : c1;
+}
+MPC_HD void t_sincos(double a, double* s, double* c) {
+    if (a > -1e5 && a < 1e5) sincos_reduced(a, s, c);
+    else ::sincos(a, s, c);
+}
 MPC_HD void t_sincos(float a, float* s, float* c) { ::sincosf(a, s, c); }
+MPC_HD double t_tan(double a) {
+    if (!(a > -1e5 && a < 1e5)) return ::tan(a);
+    double s, c;
+    sincos_reduced(a, &s, &c);
+    return s / c;
+}
+MPC_HD float t_tan(float a) { return ::tanf(a); }
 template <typename T> MPC_HD bool t_finite(T a) { return (a - a) == T(0); }   // false for NaN and +-inf
 
 // include/mpc_local_planner/utils/math_utils.h:81-91
@@ -156,17 +192,33 @@ MPC_HD T normalize_theta(T th) {
     return th;
 }
 
-// sum of logs as log of a running product (exponent kept separately so it never under/overflows)
+// sum of logs as log of a running product; the product is renormalised after every factor pair by peeling its binary
+// exponent (frexp: two cheap instructions, no branch), so it never under/overflows.  sum log = log(m) + e * ln 2.
+MPC_HD void t_frexp(double a, double* m, int* e) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    *m = __builtin_amdgcn_frexp_mant(a); *e = __builtin_amdgcn_frexp_exp(a);
+#else
+    *m = ::frexp(a, e);
+#endif
+}
+MPC_HD void t_frexp(float a, float* m, int* e) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    *m = __builtin_amdgcn_frexp_mantf(a); *e = __builtin_amdgcn_frexp_expf(a);
+#else
+    *m = ::frexpf(a, e);
+#endif
+}
 template <typename T>
 struct LogAcc {
     T m;
-    T acc;
-    MPC_HD LogAcc() : m(T(1)), acc(T(0)) {}
+    int e;
+    MPC_HD LogAcc() : m(T(1)), e(0) {}
     MPC_HD void mul(T a) {
-        m *= a;
-        if (m < T(1e-30) || m > T(1e30)) { acc += t_log(m); m = T(1); }
+        T mm; int ee;
+        t_frexp(m * a, &mm, &ee);
+        m = mm; e += ee;
     }
-    MPC_HD T value() const { return acc + t_log(m); }
+    MPC_HD T value() const { return t_log(m) + T(e) * T(0.69314718055994530942); }
 };
 
 // Model functions: f, G = df/d(theta,v,w), and the lambda-contracted second derivative.

@@ -178,7 +178,7 @@ struct IpmWave {
     // distance of the point (px,py) to obstacle j (teb semantics: point / segment / polygon, 0 inside a polygon);
     // returns dist (>= 0, obstacle radius already subtracted), unit normal from the closest point to (px,py) and
     // hk = 1/|p-q| if the closest feature is a vertex (or a point/circle obstacle), 0 on an edge interior.
-    __device__ void obst_eval(T px, T py, int j, T& dist, T& nx, T& ny, T& hk) const {
+    __device__ __forceinline__ void obst_eval(T px, T py, int j, T& dist, T& nx, T& ny, T& hk) const {
         const int nv = (int)sm[L.GNV + j];
         const T* v = sm + L.GV + 2 * L.V * j;
         T best = T(1e30), bx = T(0), by = T(0);
@@ -208,7 +208,7 @@ struct IpmWave {
     }
 
     // copies the instance's obstacles into LDS, computes centroids (teb Obstacle::getCentroid)
-    __device__ void load_obstacles(const int32_t* n_obst, const int32_t* n_vert, const double* verts, const double* radius, int inst) {
+    __device__ __forceinline__ void load_obstacles(const int32_t* n_obst, const int32_t* n_vert, const double* verts, const double* radius, int inst) {
         const int O = L.O, V = L.V;
         const int no = n_obst ? n_obst[inst] : 0;
         for (int j = lane; j < O; j += kWave) {
@@ -242,7 +242,7 @@ struct IpmWave {
 
     // StageInequalitySE2::update (src/optimal_control/stage_inequality_se2.cpp:50-162): relevant obstacles of every
     // grid point from the current vertex values; at most M rows are kept (forced ones first, then left, right).
-    __device__ void associate_obstacles() const {
+    __device__ __forceinline__ void associate_obstacles() const {
         const int n = L.n, M = L.M;
         for (int k = lane; k < n; k += kWave) {
             int cnt = 0;
@@ -283,7 +283,7 @@ struct IpmWave {
 
     // ---------------------------------------------------------------- point evaluation (parallel)
     // trig cache + c_k for the point (XB, UB, d); returns wave-reduced sum|c|, objective
-    __device__ void eval_point(T d, T& theta_c, T& fobj, T alpha = T(0), bool trial = false) const {
+    __device__ __forceinline__ void eval_point(T d, T& theta_c, T& fobj, T alpha = T(0), bool trial = false) const {
         const int n = L.n;
         const T al = trial ? alpha : T(0);
         T th = T(0), fo = T(0);
@@ -337,7 +337,7 @@ struct IpmWave {
     }
 
     // sum of barrier logs at the current (alpha = 0) or trial point; wave-reduced
-    __device__ T barrier_logs(T d, T alpha, bool trial, T dd) const {
+    __device__ __forceinline__ T barrier_logs(T d, T alpha, bool trial, T dd) const {
         const int n = L.n;
         LogAcc<T> acc;
         for (int k = lane; k < n; k += kWave) {
@@ -366,10 +366,85 @@ struct IpmWave {
         return wave_sum(acc.value());
     }
 
+    // ---------------------------------------------------------------- line-search trials, register-resident fast path
+    // (n <= 64, no clearance rows: one interval / one rate row per lane).  Everything a trial needs that does not depend on the
+    // step length is pulled into registers once per iteration; a trial is then ~300 instructions with no LDS reads.  Same
+    // arithmetic as eval_point() + barrier_logs() at (alpha, trial = true).
+    struct TrialRegs {
+        T xk[3], dxk[3], xn[3], dxn[3], u[2], du[2], s[4], ds[4];
+        T ulb[2], uub[2], dt_lb, dt_ub, Q[3], R[2], nm1;
+        bool stage, on[4], quad, dtf;
+        int k;
+    };
+    __device__ __forceinline__ bool trial_fast_ok() const { return L.M == 0 && L.n <= kWave; }
+    __device__ __forceinline__ void trial_setup(TrialRegs& r, T dd) const {
+        const int n = L.n, k = lane;
+        const T d = SCL(SC_D);
+        r.k = k; r.stage = k < n - 1;
+        r.quad = P.objective == OBJ_QUADRATIC; r.dtf = P.dt_free != 0; r.nm1 = T(n - 1);
+        r.dt_lb = P.dt_lb; r.dt_ub = P.dt_ub;
+        for (int i = 0; i < 3; ++i) {
+            r.Q[i] = P.Q[i];
+            r.xk[i] = r.dxk[i] = r.xn[i] = r.dxn[i] = T(0);
+            if (r.stage) {
+                r.xk[i] = F(L.X, i, k); r.xn[i] = F(L.X, i, k + 1);
+                if (k > 0) r.dxk[i] = F(L.DX, i, k);
+                if (k + 1 < n - 1 || !P.xf_fixed[i]) r.dxn[i] = F(L.DX, i, k + 1);
+            }
+        }
+        for (int j = 0; j < 2; ++j) {
+            r.R[j] = P.R[j]; r.ulb[j] = P.u_lb[j]; r.uub[j] = P.u_ub[j];
+            r.u[j] = r.stage ? F(L.U, j, k) : T(0); r.du[j] = r.stage ? F(L.DU, j, k) : T(0);
+        }
+        for (int q = 0; q < 4; ++q) {
+            r.on[q] = k < n && row_on(k, q);
+            r.s[q] = T(1); r.ds[q] = T(0);
+            if (r.on[q]) { const T s = F(L.SR, q, k); r.s[q] = s; r.ds[q] = -(row_val(L.U, d, k, q) + s) - row_jdz(k, q, dd); }
+        }
+    }
+    // returns wave-reduced sum|c| (th), objective (fo) and the sum of the barrier logs at z + alpha dz, dt = d
+    __device__ __forceinline__ void trial_eval(const TrialRegs& r, T alpha, T d, T& th_out, T& fo_out, T& logs_out) const {
+        T th = T(0), fo = T(0);
+        LogAcc<T> acc;
+        if (r.stage) {
+            const T x0_ = r.xk[0] + alpha * r.dxk[0], x1_ = r.xk[1] + alpha * r.dxk[1];
+            const T x2_ = r.k > 0 ? normalize_theta(r.xk[2] + alpha * r.dxk[2]) : r.xk[2];
+            const T n0 = r.xn[0] + alpha * r.dxn[0], n1 = r.xn[1] + alpha * r.dxn[1];
+            const T n2 = r.dxn[2] != T(0) ? normalize_theta(r.xn[2] + alpha * r.dxn[2]) : r.xn[2];
+            const T v = r.u[0] + alpha * r.du[0], w = r.u[1] + alpha * r.du[1];
+            T tr[4], f[3];
+            model_trig<T, MODEL>(P, x2_, w, tr);
+            model_f<T, MODEL>(P, tr, v, w, f);
+            const T c0 = d * f[0] - (n0 - x0_), c1 = d * f[1] - (n1 - x1_), c2 = d * f[2] - normalize_theta(n2 - x2_);
+            for (int i = 0; i < L.NTR; ++i) F(L.TRIG, i, r.k) = tr[i];
+            C_(0, r.k) = c0; C_(1, r.k) = c1; C_(2, r.k) = c2;
+            th = t_abs(c0) + t_abs(c1) + t_abs(c2);
+            if (r.quad) {
+                const T xd0 = x0_ - xf[0], xd1 = x1_ - xf[1], xd2 = normalize_theta(x2_ - xf[2]);
+                fo = r.Q[0] * xd0 * xd0 + r.Q[1] * xd1 * xd1 + r.Q[2] * xd2 * xd2 + r.R[0] * v * v + r.R[1] * w * w;
+            }
+            acc.mul(v - r.ulb[0]); acc.mul(r.uub[0] - v); acc.mul(w - r.ulb[1]); acc.mul(r.uub[1] - w);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc.mul(r.s[q] + alpha * r.ds[q]);      // rows that are off carry s = 1, ds = 0
+        if (lane == 0) {
+            if (!r.quad) fo += r.nm1 * d;
+            else if (P.has_Qf) {
+                for (int i = 0; i < 3; ++i) if (!P.xf_fixed[i]) {
+                    T xd = xt(i, L.n - 1, alpha) - xf[i];
+                    if (i == 2) xd = normalize_theta(xd);
+                    fo += P.Qf[i] * xd * xd;
+                }
+            }
+            if (r.dtf) { acc.mul(d - r.dt_lb); acc.mul(r.dt_ub - d); }
+        }
+        th_out = wave_sum(th); fo_out = wave_sum(fo); logs_out = wave_sum(acc.value());
+    }
+
     // ---------------------------------------------------------------- KKT error + stage records
     struct Err { T rd, rp, cmin, cmax, sum_mult, sum_bmult, theta; int n_mult, n_bmult; };
 
-    __device__ T err_value(const Err& e, T mu_t) const {
+    __device__ __forceinline__ T err_value(const Err& e, T mu_t) const {
         T sd = t_max(Algo<T>::s_max, e.sum_mult / T(e.n_mult > 0 ? e.n_mult : 1)) / Algo<T>::s_max;
         T sc = t_max(Algo<T>::s_max, e.sum_bmult / T(e.n_bmult > 0 ? e.n_bmult : 1)) / Algo<T>::s_max;
         T comp = e.n_bmult > 0 ? t_max(e.cmax - mu_t, mu_t - e.cmin) : T(0);
@@ -377,7 +452,7 @@ struct IpmWave {
     }
 
     // parallel: KKT error pieces (needs LAM of the neighbours) ; also writes the mu-independent part of STG
-    __device__ Err kkt_pass() const {
+    __device__ __forceinline__ Err kkt_pass() const {
         const int n = L.n;
         const T d = SCL(SC_D);
         T rd = T(0), rp = T(0), cmin = T(1e30), cmax = T(0), smult = T(0), sb = T(0), th = T(0), rdd = T(0);
@@ -494,7 +569,7 @@ struct IpmWave {
     }
 
     // parallel: combine the raw pieces with the mu-dependent condensed barrier terms into the A-form; record n-1 = final rate rows
-    __device__ void stage_barrier_terms() const {
+    __device__ __forceinline__ void stage_barrier_terms() const {
         const int n = L.n;
         const T d = SCL(SC_D);
         const bool quad = P.objective == OBJ_QUADRATIC;
@@ -585,7 +660,7 @@ struct IpmWave {
     }
 #undef MPC_BC_CASE
 #endif
-    __device__ bool backward_dpp(T delta, T dc, T& dd_out, T nu_out[3]) const {
+    __device__ __forceinline__ bool backward_dpp(T delta, T dc, T& dd_out, T nu_out[3]) const {
         const int n = L.n;
         const T d = SCL(SC_D);
         const int VMo = L.VP, WMo = L.VP + 84;          // scratch: VM 6x12 | W 9 + omega 3 | dummy words | W/omega partials
@@ -773,7 +848,7 @@ struct IpmWave {
     }
 
     // state recurrence (wave-uniform, software-pipelined LDS reads) then multipliers by lane-parallel suffix scans
-    __device__ void forward_states(T dd, const T nu[3], T delta) const {
+    __device__ __forceinline__ void forward_states(T dd, const T nu[3], T delta) const {
         const int n = L.n;
         // ---- lane-parallel: fold nu and dd into the affine terms so that the serial loop only carries (x, u_prev)
         //      kappa^ = kappa + Knu nu + K[:,5] dd  (stored over kappa),  c^ = c + f dd  (stored in LAMN, rewritten below)
@@ -900,7 +975,7 @@ struct IpmWave {
         if (dval < T(0)) { T a = -tau * val / dval; if (a < alpha) alpha = a; }
     }
 
-    __device__ Fwd post_pass(T dd, const T nu[3], T tau) const {
+    __device__ __forceinline__ Fwd post_pass(T dd, const T nu[3], T tau) const {
         const int n = L.n;
         const T d = SCL(SC_D);
         T hdz = T(0), clam = T(0), dz2 = T(0), dphi = T(0), a_p = T(1), a_d = T(1), dzmax = T(0);
@@ -992,7 +1067,7 @@ struct IpmWave {
     }
 
     // ---------------------------------------------------------------- trial point / acceptance (parallel)
-    __device__ void accept(T alpha, T a_d) const {
+    __device__ __forceinline__ void accept(T alpha, T a_d) const {
         const int n = L.n;
         const T kS = T(1e10);
         const T d_old = SCL(SC_D), dd = SCL(SC_DD), d_new = d_old + (P.dt_free ? alpha * dd : T(0));
@@ -1061,7 +1136,7 @@ struct IpmWave {
     }
 
     // ---------------------------------------------------------------- initial point (parallel)
-    __device__ void cold_start() const {
+    __device__ __forceinline__ void cold_start() const {
         const int n = L.n;
         const T dth = normalize_theta(xf[2] - x0[2]);
         for (int k = lane; k < n; k += kWave) {
@@ -1080,7 +1155,7 @@ struct IpmWave {
         if (lane == 0) SCL(SC_D) = P.dt_ref;
     }
 
-    __device__ void init_point() {
+    __device__ __forceinline__ void init_point() {
         const int n = L.n;
         if (lane == 0) {
             for (int i = 0; i < 3; ++i) {
@@ -1156,7 +1231,7 @@ struct IpmWave {
     }
 
     // ---------------------------------------------------------------- driver (all lanes, uniform control flow)
-    __device__ SolveStats<T> solve() {
+    __device__ __forceinline__ SolveStats<T> solve() {
         SolveStats<T> out;
         nfix = P.xf_fixed[0] + P.xf_fixed[1] + P.xf_fixed[2];
         row0_on = dtprev != T(0);
@@ -1252,14 +1327,30 @@ struct IpmWave {
             const T theta_rows = theta - theta_c;
             T alpha = fw.a_p;
             bool accepted = false;
+            const bool fast_trials = trial_fast_ok();
+            TrialRegs tregs;
+            if (fast_trials) { MPC_TICK(5, trial_setup(tregs, dd)); }
             T th_t = T(0), f_t = T(0);
             for (int ls = 0; ls < Algo<T>::max_ls; ++ls) {
                 if (ls > 0) alpha *= T(0.5);
                 T phit, tht;
                 const T d_t = SCL(SC_D) + (P.dt_free ? alpha * SCL(SC_DD) : T(0));
-                MPC_TICK(6, eval_point(d_t, th_t, f_t, alpha, true);
-                         tht = th_t + (T(1) - alpha) * theta_rows;
-                         phit = f_t - mu * barrier_logs(d_t, alpha, true, dd) + rho * tht; sync());
+#ifdef MPC_ASM_MARK
+                asm volatile("; TRIAL_BEGIN");
+#endif
+                if (fast_trials) {
+                    T lg;
+                    MPC_TICK(6, trial_eval(tregs, alpha, d_t, th_t, f_t, lg);
+                             tht = th_t + (T(1) - alpha) * theta_rows;
+                             phit = f_t - mu * lg + rho * tht; sync());
+                } else {
+                    MPC_TICK(6, eval_point(d_t, th_t, f_t, alpha, true);
+                             tht = th_t + (T(1) - alpha) * theta_rows;
+                             phit = f_t - mu * barrier_logs(d_t, alpha, true, dd) + rho * tht; sync());
+                }
+#ifdef MPC_ASM_MARK
+                asm volatile("; TRIAL_END");
+#endif
 #ifdef MPC_PROFILE
                 ++ntrial;
 #endif

@@ -63,3 +63,8 @@ extern "C" int hostdbg_solve(const mpc_config* cfg, int B, const double* x0, con
     else run_prec<double>(*cfg, B, x0, xf, up, dtp, xi, ui, dti, xo, uo, dto, st, it, kkt);
     return 0;
 }
+
+// trig kernels of the device code (mpc_core.hpp: sincos_reduced / t_tan), exposed for tests/test_host_core.py
+extern "C" void hostdbg_trig(int n, const double* x, double* s, double* c, double* t) {
+    for (int i = 0; i < n; ++i) { mpc::t_sincos(x[i], &s[i], &c[i]); t[i] = mpc::t_tan(x[i]); }
+}
