@@ -202,7 +202,7 @@ int32_t mpc_version(void) { return 100; }
 #ifdef MPC_PROFILE
 // developer build only (-DMPC_PROFILE): per-wave phase cycle counters of the last wave-kernel launch
 int mpc_debug_profile(long long* out, int rows) {
-    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mpc_prof), sizeof(long long) * 14 * (size_t)rows, 0, hipMemcpyDeviceToHost);
+    return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_mpc_prof), sizeof(long long) * 16 * (size_t)rows, 0, hipMemcpyDeviceToHost);
 }
 #endif
 

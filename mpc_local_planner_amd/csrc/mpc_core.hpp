@@ -178,7 +178,20 @@ MPC_HD double t_tan(double a) {
     return s / c;
 }
 MPC_HD float t_tan(float a) { return ::tanf(a); }
-template <typename T> MPC_HD bool t_finite(T a) { return (a - a) == T(0); }   // false for NaN and +-inf
+// false for NaN and +-inf.  (Not `(a - a) == 0`: with FMA contraction `a` = x*y turns that into fma(x, y, -(x*y)), the rounding
+// error of the product, which is not zero.)
+template <typename T> MPC_HD bool t_finite(T a) { return __builtin_isfinite(a); }
+// reciprocal: hardware seed + two Newton steps on the device (the IEEE division sequence is ~40 instructions), 1/x on the host
+MPC_HD double t_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+#else
+    return 1.0 / x;
+#endif
+}
+MPC_HD float t_rcp(float x) { return 1.0f / x; }
 
 // include/mpc_local_planner/utils/math_utils.h:81-91
 template <typename T>
@@ -521,12 +534,14 @@ MPC_HD bool riccati_root(const RicState<T>& V, const Problem<T>& P_, T& dd_out, 
             A4[1 + a][4] = -V.om[a];
         } else { A4[1 + a][1 + a] = T(1); }
     }
+    T ipiv[4];
     for (int c = 0; c < 4; ++c) {
         int piv = c; T best = t_abs(A4[c][c]);
         for (int r = c + 1; r < 4; ++r) if (t_abs(A4[r][c]) > best) { best = t_abs(A4[r][c]); piv = r; }
         if (!(best > T(0)) || !t_finite(best)) return false;
         if (piv != c) for (int b = 0; b < 5; ++b) { T t = A4[c][b]; A4[c][b] = A4[piv][b]; A4[piv][b] = t; }
-        T ip = T(1) / A4[c][c];
+        T ip = t_rcp(A4[c][c]);
+        ipiv[c] = ip;
         for (int r = c + 1; r < 4; ++r) {
             T m = A4[r][c] * ip;
             for (int b = c; b < 5; ++b) A4[r][b] -= m * A4[c][b];
@@ -536,7 +551,7 @@ MPC_HD bool riccati_root(const RicState<T>& V, const Problem<T>& P_, T& dd_out, 
     for (int c = 3; c >= 0; --c) {
         T a = A4[c][4];
         for (int b = c + 1; b < 4; ++b) a -= A4[c][b] * sol[b];
-        sol[c] = a / A4[c][c];
+        sol[c] = a * ipiv[c];
     }
     dd_out = sol[0];
     nu_out[0] = sol[1]; nu_out[1] = sol[2]; nu_out[2] = sol[3];

@@ -22,7 +22,7 @@
 #include "mpc_dpp_blocks.inc"
 
 #ifdef MPC_PROFILE
-__device__ long long g_mpc_prof[4096][14];
+__device__ long long g_mpc_prof[4096][16];
 #endif
 
 namespace mpc {
@@ -55,8 +55,8 @@ struct WaveLayout {
         L.CC = take(3); L.TRIG = take(ntrig);
         L.GAIN = take(NGAIN); L.STG = take(NSTG);
         L.SC = o; o += 8;     // scalars: D, DT, DD, PDL, PDU
-        L.VP = o; o += 160;   // sweep scratch: terminal V 6x12 | W 3x3 + omega 3 | dummy words | W/omega partials
-        L.ZC = o; o += 8;     // constants: 6 zeros, then 1.0
+        L.VP = o; o += 16;    // dummy store targets of the idle lanes in the sweeps
+        L.ZC = o; o += 8;     // constants 0 0 0 0 1 0 0 0 (coefficient triples of the constant columns)
         L.M = M; L.O = O; L.V = V;
         L.OS = take(M); L.OY = take(M); L.OI = take(M); L.OG = take(M); L.OAX = take(M); L.OAY = take(M); L.OHK = take(M);
         L.GV = o; o += 2 * O * V; L.GNV = o; o += O; L.GR = o; o += O; L.GC = o; o += 2 * O;
@@ -66,6 +66,29 @@ struct WaveLayout {
 };
 
 enum { SC_D = 0, SC_DT = 1, SC_DD = 2, SC_PDL = 3, SC_PDU = 4 };
+
+// A slot (StageAdd) of the entry (r, c) of the symmetric 8x8 stage cost block [x(3) u_prev(2) dt u(2)] and of its gradient
+// column c = 8; -1 where the block is structurally zero.  Packed per row as 12 x 5 bits (slot + 1) so that a lane looks its
+// column up with one 64-bit shift instead of a cascade of divergent branches.
+constexpr int stage_add_slot(int r, int c) {
+    if (c == 8) return A08 + r;
+    if (c > 8) return -1;
+    const int a = r < c ? r : c, b = r < c ? c : r;
+    if (a == 0) return b == 0 ? A00 : (b == 1 ? A01 : -1);
+    if (a == 1) return b == 1 ? A11 : -1;
+    if (a == 2) return b == 2 ? A22 : (b == 5 ? A25 : (b == 6 ? A26 : (b == 7 ? A27 : -1)));
+    if (a == 3) return b == 3 ? A33 : (b == 5 ? A35 : (b == 6 ? A36 : -1));
+    if (a == 4) return b == 4 ? A44 : (b == 5 ? A45 : (b == 7 ? A47 : -1));
+    if (a == 5) return b == 5 ? A55 : (b == 6 ? A56 : (b == 7 ? A57 : -1));
+    if (a == 6) return b == 6 ? A66 : (b == 7 ? A67 : -1);
+    return b == 7 ? A77 : -1;
+}
+constexpr unsigned long long stage_add_row(int r) {
+    unsigned long long v = 0;
+    for (int c = 0; c < 12; ++c) v |= (unsigned long long)(stage_add_slot(r, c) + 1) << (5 * c);
+    return v;
+}
+
 
 // ---- wavefront reductions on the DPP path (row rotations inside each 16-lane row, then 4 v_readlane), no LDS traffic:
 //      ~25 VALU instructions per fp64 reduction instead of 12 ds_bpermute round trips.  Result is wave-uniform.
@@ -122,6 +145,11 @@ struct IpmWave {
     T x0[3], xf[3], uprev[2], dtprev;
     T mu, rho, delta_last;
     bool row0_on, fail0;
+    int flags;      // bits 0..2 xf_fixed, 3 dt_free, 4 quadratic objective, 5 has_Qf, 6..9 rate_on: the problem record lives in LDS and every
+                    // P.x costs a ds_read (+ wait) that the compiler cannot hoist over LDS stores; one scalar register holds the switches
+#ifdef MPC_PROFILE
+    mutable long long prof_loop = 0, prof_setup = 0, prof_fwd_loop = 0;    // ticks inside the backward stage loop / before it / inside the forward loop
+#endif
     int nfix;
 
     __device__ IpmWave(const Problem<T>& p, const WaveLayout& l, T* s, int ln) : P(p), L(l), sm(s), lane(ln) {}
@@ -134,6 +162,11 @@ struct IpmWave {
     __device__ __forceinline__ T& C_(int i, int k) const { return sm[L.CC + k * 3 + i]; }
     __device__ __forceinline__ T& SCL(int i) const { return sm[L.SC + i]; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
+    __device__ __forceinline__ bool fx(int i) const { return (flags >> i) & 1; }
+    __device__ __forceinline__ bool dtf() const { return (flags >> 3) & 1; }
+    __device__ __forceinline__ bool quad() const { return (flags >> 4) & 1; }
+    __device__ __forceinline__ bool hasqf() const { return (flags >> 5) & 1; }
+    __device__ __forceinline__ bool ron(int q) const { return (flags >> (6 + q)) & 1; }
     // explicit LDS pointers for the running-pointer loops (address-space inference gives up on per-lane selected pointers)
     typedef __attribute__((address_space(3))) T LdsT;
     __device__ __forceinline__ LdsT* lds(int word) const { return (LdsT*)sm + word; }
@@ -142,7 +175,7 @@ struct IpmWave {
     // (alpha == 0 must not touch the step arrays: they are unwritten before the first factorisation, and 0 * garbage can be NaN)
     __device__ __forceinline__ T xt(int i, int k, T alpha) const {
         T x = F(L.X, i, k);
-        if (alpha != T(0) && k > 0 && (k < L.n - 1 || !P.xf_fixed[i])) { x += alpha * F(L.DX, i, k); if (i == 2) x = normalize_theta(x); }
+        if (alpha != T(0) && k > 0 && (k < L.n - 1 || !fx(i))) { x += alpha * F(L.DX, i, k); if (i == 2) x = normalize_theta(x); }
         return x;
     }
     __device__ __forceinline__ T ut(int j, int k, T alpha) const {
@@ -151,7 +184,7 @@ struct IpmWave {
         return u;
     }
 
-    __device__ __forceinline__ bool row_on(int r, int q) const { return P.rate_on[q] && (r > 0 || row0_on); }
+    __device__ __forceinline__ bool row_on(int r, int q) const { return ron(q) && (r > 0 || row0_on); }
 
     // rate row r, slot q at controls from base UB and dt d (solver form, <= 0 feasible)
     __device__ __forceinline__ T row_val(int UB, T d, int r, int q) const {
@@ -317,15 +350,15 @@ struct IpmWave {
             for (int i = 0; i < L.NTR; ++i) F(L.TRIG, i, k) = tr[i];
             C_(0, k) = c0; C_(1, k) = c1; C_(2, k) = c2;
             th += t_abs(c0) + t_abs(c1) + t_abs(c2);
-            if (P.objective == OBJ_QUADRATIC) {
+            if (quad()) {
                 T xd0 = xk[0] - xf[0], xd1 = xk[1] - xf[1], xd2 = normalize_theta(xk[2] - xf[2]);
                 fo += P.Q[0] * xd0 * xd0 + P.Q[1] * xd1 * xd1 + P.Q[2] * xd2 * xd2 + P.R[0] * v * v + P.R[1] * w * w;
             }
         }
         if (lane == 0) {
-            if (P.objective == OBJ_MIN_TIME) fo += T(n - 1) * d;
-            else if (P.has_Qf) {
-                for (int i = 0; i < 3; ++i) if (!P.xf_fixed[i]) {
+            if (!quad()) fo += T(n - 1) * d;
+            else if (hasqf()) {
+                for (int i = 0; i < 3; ++i) if (!fx(i)) {
                     T xd = xt(i, n - 1, al) - xf[i];
                     if (i == 2) xd = normalize_theta(xd);
                     fo += P.Qf[i] * xd * xd;
@@ -362,7 +395,7 @@ struct IpmWave {
                 }
             }
         }
-        if (lane == 0 && P.dt_free) { acc.mul(d - P.dt_lb); acc.mul(P.dt_ub - d); }
+        if (lane == 0 && dtf()) { acc.mul(d - P.dt_lb); acc.mul(P.dt_ub - d); }
         return wave_sum(acc.value());
     }
 
@@ -381,7 +414,7 @@ struct IpmWave {
         const int n = L.n, k = lane;
         const T d = SCL(SC_D);
         r.k = k; r.stage = k < n - 1;
-        r.quad = P.objective == OBJ_QUADRATIC; r.dtf = P.dt_free != 0; r.nm1 = T(n - 1);
+        r.quad = quad(); r.dtf = dtf(); r.nm1 = T(n - 1);
         r.dt_lb = P.dt_lb; r.dt_ub = P.dt_ub;
         for (int i = 0; i < 3; ++i) {
             r.Q[i] = P.Q[i];
@@ -389,7 +422,7 @@ struct IpmWave {
             if (r.stage) {
                 r.xk[i] = F(L.X, i, k); r.xn[i] = F(L.X, i, k + 1);
                 if (k > 0) r.dxk[i] = F(L.DX, i, k);
-                if (k + 1 < n - 1 || !P.xf_fixed[i]) r.dxn[i] = F(L.DX, i, k + 1);
+                if (k + 1 < n - 1 || !fx(i)) r.dxn[i] = F(L.DX, i, k + 1);
             }
         }
         for (int j = 0; j < 2; ++j) {
@@ -429,8 +462,8 @@ struct IpmWave {
         for (int q = 0; q < 4; ++q) acc.mul(r.s[q] + alpha * r.ds[q]);      // rows that are off carry s = 1, ds = 0
         if (lane == 0) {
             if (!r.quad) fo += r.nm1 * d;
-            else if (P.has_Qf) {
-                for (int i = 0; i < 3; ++i) if (!P.xf_fixed[i]) {
+            else if (hasqf()) {
+                for (int i = 0; i < 3; ++i) if (!fx(i)) {
                     T xd = xt(i, L.n - 1, alpha) - xf[i];
                     if (i == 2) xd = normalize_theta(xd);
                     fo += P.Qf[i] * xd * xd;
@@ -481,7 +514,7 @@ struct IpmWave {
                 nm += 3;
                 rdd += lam[0] * f[0] + lam[1] * f[1] + lam[2] * f[2];
                 T gx[3] = {T(0), T(0), T(0)}, gu[2] = {T(0), T(0)};
-                if (P.objective == OBJ_QUADRATIC) {
+                if (quad()) {
                     T xd[3] = {F(L.X, 0, k) - xf[0], F(L.X, 1, k) - xf[1], normalize_theta(F(L.X, 2, k) - xf[2])};
                     for (int i = 0; i < 3; ++i) gx[i] = T(2) * P.Q[i] * xd[i];
                     gu[0] = T(2) * P.R[0] * v; gu[1] = T(2) * P.R[1] * w;
@@ -522,9 +555,9 @@ struct IpmWave {
                     sb += pl + pu; nb += 2;
                 }
                 if (k == n - 2) {
-                    for (int i = 0; i < 3; ++i) if (!P.xf_fixed[i]) {
+                    for (int i = 0; i < 3; ++i) if (!fx(i)) {
                         T g = T(0);
-                        if (P.objective == OBJ_QUADRATIC && P.has_Qf) {
+                        if (quad() && hasqf()) {
                             T xd = F(L.X, i, n - 1) - xf[i];
                             if (i == 2) xd = normalize_theta(xd);
                             g = T(2) * P.Qf[i] * xd;
@@ -544,8 +577,8 @@ struct IpmWave {
             }
         }
         if (lane == 0) {
-            if (P.objective == OBJ_MIN_TIME) rdd += T(n - 1);
-            if (P.dt_free) {
+            if (!quad()) rdd += T(n - 1);
+            if (dtf()) {
                 T pl = SCL(SC_PDL), pu = SCL(SC_PDU);
                 rdd += -pl + pu;
                 T cl = (d - P.dt_lb) * pl, cu = (P.dt_ub - d) * pu;
@@ -556,7 +589,7 @@ struct IpmWave {
         Err e;
         rdd = wave_sum(rdd);
         e.rd = wave_max(rd);
-        if (P.dt_free) e.rd = t_max(e.rd, t_abs(rdd));
+        if (dtf()) e.rd = t_max(e.rd, t_abs(rdd));
         e.rp = wave_max(rp);
         e.cmin = wave_min(cmin);
         e.cmax = wave_max(cmax);
@@ -572,7 +605,7 @@ struct IpmWave {
     __device__ __forceinline__ void stage_barrier_terms() const {
         const int n = L.n;
         const T d = SCL(SC_D);
-        const bool quad = P.objective == OBJ_QUADRATIC;
+        const bool quad = this->quad();
         T q2[3] = {T(0), T(0), T(0)}, r2[2] = {T(0), T(0)};
         if (quad) { for (int i = 0; i < 3; ++i) q2[i] = T(2) * P.Q[i]; for (int j = 0; j < 2; ++j) r2[j] = T(2) * P.R[j]; }
         for (int k = lane; k < n; k += kWave) {
@@ -661,47 +694,35 @@ struct IpmWave {
 #undef MPC_BC_CASE
 #endif
     __device__ __forceinline__ bool backward_dpp(T delta, T dc, T& dd_out, T nu_out[3]) const {
+#ifdef MPC_PROFILE
+        const long long ts0 = __builtin_readcyclecounter();
+#endif
+#ifdef MPC_ASM_MARK
+        asm volatile("; BWD_SETUP_BEGIN");
+#endif
         const int n = L.n;
         const T d = SCL(SC_D);
-        const int VMo = L.VP, WMo = L.VP + 84;          // scratch: VM 6x12 | W 9 + omega 3 | dummy words | W/omega partials
-        T* VM = sm + VMo;
-        T* WM = sm + WMo;
-        const int ZC = L.ZC;                            // constants 0 0 0 0 1 0 0 0: (0,0,0) @0, (0,1,0) @3, (1,0,0) @4
-        if (lane < 8) sm[ZC + lane] = lane == 4 ? T(1) : T(0);
-        for (int e2 = lane; e2 < 160; e2 += kWave) VM[e2] = T(0);
-        sync();
+        const int ZC = L.ZC;                            // constants 0 0 0 0 1 0 0 0 (written once per solve): (0,0,0) @0, (0,1,0) @3, (1,0,0) @4
         const int c = lane & 15;                    // column owned by this lane (12..15 idle: they carry zeros)
         const bool act = c < 12;
-        auto add_idx = [&](int r, int cc) -> int {      // A slot of Hhat[r][cc] (symmetric), -1: none
-            if (cc == 8) return A08 + r;
-            if (cc > 8) return -1;
-            const int a = r < cc ? r : cc, b = r < cc ? cc : r;
-            if (a == 0) return b == 0 ? A00 : (b == 1 ? A01 : -1);
-            if (a == 1) return b == 1 ? A11 : -1;
-            if (a == 2) return b == 2 ? A22 : (b == 5 ? A25 : (b == 6 ? A26 : (b == 7 ? A27 : -1)));
-            if (a == 3) return b == 3 ? A33 : (b == 5 ? A35 : (b == 6 ? A36 : -1));
-            if (a == 4) return b == 4 ? A44 : (b == 5 ? A45 : (b == 7 ? A47 : -1));
-            if (a == 5) return b == 5 ? A55 : (b == 6 ? A56 : (b == 7 ? A57 : -1));
-            if (a == 6) return b == 6 ? A66 : (b == 7 ? A67 : -1);
-            return b == 7 ? A77 : -1;
-        };
-        // coefficient triple of column c: three consecutive words, running pointer (stride 0 for the constant triples)
-        int gb = ZC, gs = 0;
-        if (c == 0) gb = ZC + 4;
-        else if (c == 1) gb = ZC + 3;
-        else if (c == 2) { gb = L.STG; gs = NSTG; }
-        else if (c == 5) { gb = L.STG + 3; gs = NSTG; }
-        else if (c == 6) { gb = L.STG + 6; gs = NSTG; }
-        else if (c == 7) { gb = L.STG + 9; gs = NSTG; }
-        else if (c == 8) { gb = L.CC; gs = 3; }
+        // coefficient triple of column c: three consecutive words, running pointer (stride 0 for the constant triples).
+        // kind: 0 (0,0,0)  1 (1,0,0)  2 (0,1,0)  3 (a0,a1,1)  4 f  5 Bx[:,0]  6 Bx[:,1]  7 c_k   -- columns 0..11, 3 bits each
+        constexpr unsigned long long KIND = 1ull | (2ull << 3) | (3ull << 6) | (4ull << 15) | (5ull << 18) | (6ull << 21) | (7ull << 24);
+        const int kind = act ? (int)((KIND >> (3 * c)) & 7) : 0;
+        const int gb = kind < 3 ? ZC + (kind == 1 ? 4 : (kind == 2 ? 3 : 0)) : (kind < 7 ? L.STG + 3 * (kind - 3) : L.CC);
+        const int gs = kind < 3 ? 0 : (kind < 7 ? NSTG : 3);
         const LdsT* gp = lds(gb + (n - 2) * gs);
         const LdsT* ap[8];
         int as_[8];
+        constexpr unsigned long long rows[8] = {stage_add_row(0), stage_add_row(1), stage_add_row(2), stage_add_row(3),
+                                                stage_add_row(4), stage_add_row(5), stage_add_row(6), stage_add_row(7)};
+        const int sh = act ? 5 * c : 60;               // idle lanes: shift the row word out (slot -1)
+        const int abase = L.STG + RA - 1 + (n - 2) * NSTG;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
-            const int ai = act ? add_idx(r, c) : -1;
-            as_[r] = ai >= 0 ? NSTG : 0;
-            ap[r] = lds(ai >= 0 ? L.STG + RA + ai + (n - 2) * NSTG : ZC);
+            const int slot1 = (int)((rows[r] >> sh) & 31);       // slot + 1, 0 = structurally zero
+            as_[r] = slot1 ? NSTG : 0;
+            ap[r] = lds(slot1 ? abase + slot1 : ZC);
         }
         const T ec = (c == 5 || (c >= 8 && c < 12)) ? T(1) : T(0);       // own column enters T1 (dt, p, S)
         const T E3 = c == 6 ? T(1) : T(0), E4 = c == 7 ? T(1) : T(0);     // the u columns pick up the u_prev columns of V+
@@ -710,47 +731,51 @@ struct IpmWave {
         // negated gains go to GAIN as [nK0 (cols 0..5) | nkappa0 | nKnu0 (3) | nK1 ... ] : g1 = g0 + 10; idle lanes hit a dummy pair
         const bool wrG = lane < 12 && c != 6 && c != 7;
         const int g0 = c < 6 ? c : (c == 8 ? 6 : 7 + (c - 9));
-        LdsT* kp = lds(wrG ? L.GAIN + g0 + (n - 2) * NGAIN : VMo + 130);
+        LdsT* kp = lds(wrG ? L.GAIN + g0 + (n - 2) * NGAIN : L.VP);      // idle lanes: dummy pair in the scratch area
         const int ks = wrG ? NGAIN : 0;
-        // ---- terminal value function (built by lane 0 in LDS, then picked up column-wise)
-        if (lane == 0) {
-            const int r = n - 1;
-            for (int i = 0; i < 3; ++i) {
-                if (P.xf_fixed[i]) { VM[12 * i + 9 + i] = T(1); WM[3 * i + i] = -dc; }
-                else {
-                    T pii = delta, pi_ = T(0);
-                    if (P.objective == OBJ_QUADRATIC && P.has_Qf) {
-                        T xd = F(L.X, i, r) - xf[i];
-                        if (i == 2) xd = normalize_theta(xd);
-                        pii += T(2) * P.Qf[i]; pi_ = T(2) * P.Qf[i] * xd;
-                    }
-                    VM[12 * i + i] = pii; VM[12 * i + 8] = pi_;
-                }
-            }
-            VM[12 * 3 + 3] = S_(RA + A33, r); VM[12 * 4 + 4] = S_(RA + A44, r); VM[12 * 5 + 5] = S_(RA + A55, r);
-            VM[12 * 3 + 5] = S_(RA + A35, r); VM[12 * 5 + 3] = S_(RA + A35, r);
-            VM[12 * 4 + 5] = S_(RA + A45, r); VM[12 * 5 + 4] = S_(RA + A45, r);
-            VM[12 * 3 + 8] = S_(RA + A38, r); VM[12 * 4 + 8] = S_(RA + A48, r); VM[12 * 5 + 8] = S_(RA + A58, r);
-        }
-        sync();
+        // ---- terminal value function, straight into the owning lanes' registers (rows 3..5: the u_prev / dt entries of the
+        //      final rate rows = the A slots (i, c) of stage n-1 for c in {3, 4, 5, 8})
         T V[6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) V[i] = act ? VM[12 * i + c] : T(0);
+        for (int i = 0; i < 3; ++i) {
+            if (fx(i)) V[i] = c == 9 + i ? T(1) : T(0);
+            else {
+                T pii = delta, pi_ = T(0);
+                if (quad() && hasqf()) {
+                    T xd = F(L.X, i, n - 1) - xf[i];
+                    if (i == 2) xd = normalize_theta(xd);
+                    pii += T(2) * P.Qf[i]; pi_ = T(2) * P.Qf[i] * xd;
+                }
+                V[i] = c == i ? pii : (c == 8 ? pi_ : T(0));
+            }
+        }
+        {
+            const bool t3 = c == 3 || c == 5 || c == 8, t4 = c == 4 || c == 5 || c == 8, t5 = c == 3 || c == 4 || c == 5 || c == 8;
+            const T a3 = ap[3][as_[3]], a4 = ap[4][as_[4]], a5 = ap[5][as_[5]];       // one stage above the running pointers
+            V[3] = t3 ? a3 : T(0); V[4] = t4 ? a4 : T(0); V[5] = t5 ? a5 : T(0);
+        }
         T add_dd0 = T(0), add_qd0 = T(0);
-        if (P.objective == OBJ_MIN_TIME) add_qd0 += T(n - 1);
-        if (P.dt_free) {
+        if (!quad()) add_qd0 += T(n - 1);
+        if (dtf()) {
             const T dl = d - P.dt_lb, du = P.dt_ub - d;
-            add_dd0 = SCL(SC_PDL) / dl + SCL(SC_PDU) / du + delta;
-            add_qd0 += -mu / dl + mu / du;
+            const T idl = fast_rcp(dl), idu = fast_rcp(du);
+            add_dd0 = SCL(SC_PDL) * idl + SCL(SC_PDU) * idu + delta;
+            add_qd0 += mu * idu - mu * idl;
         }
         const T s05 = c == 5 ? add_dd0 : (c == 8 ? add_qd0 : T(0));       // stage-0 extras of row 5
         T om = T(0), wn[3] = {T(0), T(0), T(0)};
         T worst = T(1);                                                   // min over the stages of |det R| - 1e-14 * scale
         auto load_stage = [&](T (&g)[3], T (&a)[8]) {                     // reads the stage the running pointers are at, then steps them
+#if defined(MPC_EXP) && (MPC_EXP & 1)
+            g[0] = gp[0]; g[1] = g[0] * T(0.5); g[2] = g[0] * T(0.25);
+            for (int r = 0; r < 8; ++r) a[r] = g[0] * T(r);
+            gp -= gs;
+#else
             g[0] = gp[0]; g[1] = gp[1]; g[2] = gp[2];
             gp -= gs;
 #pragma unroll
             for (int r = 0; r < 8; ++r) { a[r] = *ap[r]; ap[r] -= as_[r]; }
+#endif
         };
         auto stage = [&](T dk0, T dk1, T dk2, T s5, T (&G)[3], T (&A)[8], T (&Gn)[3], T (&An)[8]) {
             load_stage(Gn, An);                                           // prefetch of the next stage (k - 1)
@@ -790,8 +815,10 @@ struct IpmWave {
             const T nid = -fast_rcp(det);
             const T nRi00 = R11 * nid, Ri01 = -(R01 * nid), nRi11 = R00 * nid;  // -R^-1 = [nRi00 Ri01; Ri01 nRi11]
             const T nK0 = nRi00 * h[6] + Ri01 * h[7], nK1 = Ri01 * h[6] + nRi11 * h[7];
+#if !(defined(MPC_EXP) && (MPC_EXP & 2))
             kp[0] = nK0; kp[10] = nK1;
             kp -= ks;
+#endif
             // W[a][b] -= Su[:,a]' Knu[:,b] in lane 9+b, omega[a] -= Su[:,a]' kappa in lane 8 (Su[j][a] = Hhat[6+j][9+a]);
             // V = Hhat_xx + Hhat_xu nK   (row i of Hhat[:,6:8] = lane i's Hhat[6:8][.])
             V[0] = h[0]; V[1] = h[1]; V[2] = h[2]; V[3] = h[3]; V[4] = h[4]; V[5] = h[5];
@@ -807,6 +834,10 @@ struct IpmWave {
 #endif
         };
         T Ga[3], Aa[8], Gb[3], Ab[8];
+#ifdef MPC_PROFILE
+        const long long tl0 = __builtin_readcyclecounter();
+        prof_setup += tl0 - ts0;
+#endif
         load_stage(Ga, Aa);
         int k = n - 2;
         for (; k >= 2; k -= 2) {        // stages k and k-1 (both >= 1): the two register sets swap roles, no copies
@@ -821,23 +852,38 @@ struct IpmWave {
         }
         if (k == 1) { stage(dA0, dA1, dA2, T(0), Ga, Aa, Gb, Ab); stage(T(0), T(0), T(0), s05, Gb, Ab, Ga, Aa); }
         else stage(T(0), T(0), T(0), s05, Ga, Aa, Gb, Ab);
-        // row 5 of the value block, omega and the W / omega corrections go back to LDS for the root solve
-        if (lane < 12) VM[12 * 5 + c] = V[5];
-        if (lane >= 9 && lane < 12) { WM[9 + (c - 9)] += om; for (int a = 0; a < 3; ++a) VM[110 + 3 * a + (c - 9)] = wn[a]; }
-        if (lane == 8) for (int a = 0; a < 3; ++a) VM[120 + a] = wn[a];
-        sync();
+#ifdef MPC_PROFILE
+        prof_loop += __builtin_readcyclecounter() - tl0;
+#endif
+        // row 5 of the value block, omega and the W / omega corrections are gathered with v_readlane (no LDS round trip)
         if (!(rd_lane(worst, 0) > T(0))) return false;
         RicState<T> Vr;
-        Vr.P[5][5] = VM[12 * 5 + 5];
-        Vr.p[5] = VM[12 * 5 + 8];
-        for (int b = 0; b < 3; ++b) {
-            Vr.S[5][b] = VM[12 * 5 + 9 + b];
-            Vr.om[b] = WM[9 + b] + VM[120 + b];
+        Vr.P[5][5] = rd_lane(V[5], 5);
+        Vr.p[5] = rd_lane(V[5], 8);
+        Vr.S[5][0] = rd_lane(V[5], 9); Vr.S[5][1] = rd_lane(V[5], 10); Vr.S[5][2] = rd_lane(V[5], 11);
+        Vr.om[0] = rd_lane(om, 9) + rd_lane(wn[0], 8);
+        Vr.om[1] = rd_lane(om, 10) + rd_lane(wn[1], 8);
+        Vr.om[2] = rd_lane(om, 11) + rd_lane(wn[2], 8);
+        {
+            // W[a][b] partial lives in lane 9+b as wn[a]; symmetrise; the fixed components carry -delta_c on the diagonal
+            const T w00 = rd_lane(wn[0], 9), w01 = rd_lane(wn[0], 10), w02 = rd_lane(wn[0], 11);
+            const T w10 = rd_lane(wn[1], 9), w11 = rd_lane(wn[1], 10), w12 = rd_lane(wn[1], 11);
+            const T w20 = rd_lane(wn[2], 9), w21 = rd_lane(wn[2], 10), w22 = rd_lane(wn[2], 11);
+            Vr.W[0][0] = w00 - (fx(0) ? dc : T(0)); Vr.W[1][1] = w11 - (fx(1) ? dc : T(0)); Vr.W[2][2] = w22 - (fx(2) ? dc : T(0));
+            Vr.W[0][1] = Vr.W[1][0] = T(0.5) * (w01 + w10);
+            Vr.W[0][2] = Vr.W[2][0] = T(0.5) * (w02 + w20);
+            Vr.W[1][2] = Vr.W[2][1] = T(0.5) * (w12 + w21);
         }
-        for (int a = 0; a < 3; ++a) for (int b = a; b < 3; ++b) {
-            const T s = WM[3 * a + b] + T(0.5) * (VM[110 + 3 * a + b] + VM[110 + 3 * b + a]);
-            Vr.W[a][b] = s; Vr.W[b][a] = s;
+#ifdef MPC_NANCHECK
+        {
+            const bool okr = riccati_root(Vr, P, dd_out, nu_out);
+            if (blockIdx.x == MPC_NANCHECK && lane == 0)
+                printf("  root: ok %d worst %g P55 %g p5 %g S5 %g %g %g om %g %g %g W %g %g %g %g %g %g\n", (int)okr, (double)rd_lane(worst, 0), (double)Vr.P[5][5], (double)Vr.p[5],
+                       (double)Vr.S[5][0], (double)Vr.S[5][1], (double)Vr.S[5][2], (double)Vr.om[0], (double)Vr.om[1], (double)Vr.om[2],
+                       (double)Vr.W[0][0], (double)Vr.W[0][1], (double)Vr.W[0][2], (double)Vr.W[1][1], (double)Vr.W[1][2], (double)Vr.W[2][2]);
+            return okr;
         }
+#endif
         return riccati_root(Vr, P, dd_out, nu_out);
     }
 
@@ -859,7 +905,6 @@ struct IpmWave {
             for (int i = 0; i < 3; ++i) F(L.LAMN, i, k) = C_(i, k) + S_(3 + i, k) * dd;
         }
         if (lane == 0) { SCL(SC_DD) = dd; F(L.DX, 0, 0) = T(0); F(L.DX, 1, 0) = T(0); F(L.DX, 2, 0) = T(0); }
-        if (lane < 8) sm[L.ZC + lane] = lane == 4 ? T(1) : T(0);
         sync();
         // ---- serial recurrence, one COMPONENT per lane: lanes 0..2 carry dx_k, lanes 3,4 carry du_{k-1}; a stage is
         //        s  = cst + sum_j q_j * xi[j]        lanes 3,4: du_k = nkappa^ + nK xi ;  lanes 0..2: dx_k[c] + a_c dx_k[2] + c^_k[c]
@@ -887,7 +932,7 @@ struct IpmWave {
 #pragma unroll
             for (int j = 0; j < 8; ++j) qp[j] = lds(qw[j]);
             // where the result goes: dx_{k+1}[c] / du_k[c-3]; idle lanes write a dummy word of the sweep scratch
-            LdsT* op = lds(c < 3 ? L.DX + c * L.NS + 1 : (c < 5 ? L.DU + (c - 3) * L.NS : L.VP + 130));
+            LdsT* op = lds(c < 3 ? L.DX + c * L.NS + 1 : (c < 5 ? L.DU + (c - 3) * L.NS : L.VP + 12));
             const int os = c < 5 ? 1 : 0;
             auto load_q = [&](T (&q)[8]) {
 #pragma unroll
@@ -908,6 +953,9 @@ struct IpmWave {
                 *op = xn; op += os;
                 xi = xn;
             };
+#ifdef MPC_PROFILE
+            const long long tf0 = __builtin_readcyclecounter();
+#endif
             T qa[8], qb[8];
             load_q(qa);
             int k = 0;
@@ -921,6 +969,9 @@ struct IpmWave {
 #endif
             }
             if (k < n - 1) stage(qa, qb);
+#ifdef MPC_PROFILE
+            prof_fwd_loop += __builtin_readcyclecounter() - tf0;
+#endif
         }
         sync();
         const T xi[3] = {F(L.DX, 0, n - 1), F(L.DX, 1, n - 1), F(L.DX, 2, n - 1)};
@@ -928,10 +979,10 @@ struct IpmWave {
         //      lam+_{n-2} from the terminal condition.  Components 0,1 are plain suffix sums, component 2 a second one.
         T lp[3];
         for (int i = 0; i < 3; ++i) {
-            if (P.xf_fixed[i]) lp[i] = nu[i];
+            if (fx(i)) lp[i] = nu[i];
             else {
                 T g = delta * xi[i];
-                if (P.objective == OBJ_QUADRATIC && P.has_Qf) {
+                if (quad() && hasqf()) {
                     T xd = F(L.X, i, n - 1) - xf[i];
                     if (i == 2) xd = normalize_theta(xd);
                     g += T(2) * P.Qf[i] * (xi[i] + xd);
@@ -981,7 +1032,7 @@ struct IpmWave {
         T hdz = T(0), clam = T(0), dz2 = T(0), dphi = T(0), a_p = T(1), a_d = T(1), dzmax = T(0);
         bool fin = true;
         if (lane == 0) {
-            if (P.dt_free) {
+            if (dtf()) {
                 T dl = d - P.dt_lb, du = P.dt_ub - d;
                 T pl = SCL(SC_PDL), pu = SCL(SC_PDU);
                 T gb = -mu / dl + mu / du;
@@ -991,7 +1042,7 @@ struct IpmWave {
                 ftb(pu, mu / du - pu + (pu / du) * dd, tau, a_d);
                 dz2 += dd * dd; dzmax = t_max(dzmax, t_abs(dd));
             }
-            if (P.objective == OBJ_MIN_TIME) { hdz += T(n - 1) * dd; dphi += T(n - 1) * dd; }
+            if (!quad()) { hdz += T(n - 1) * dd; dphi += T(n - 1) * dd; }
         }
         for (int k = lane; k < n; k += kWave) {
             if (k < n - 1) {
@@ -999,7 +1050,7 @@ struct IpmWave {
                     T u = F(L.U, j, k), du_ = F(L.DU, j, k);
                     T dl = u - P.u_lb[j], du = P.u_ub[j] - u;
                     T pl = F(L.PL, j, k), pu = F(L.PU, j, k);
-                    T gbar = -mu / dl + mu / du + (P.objective == OBJ_QUADRATIC ? T(2) * P.R[j] * u : T(0));   // barrier (+ objective) gradient wrt u
+                    T gbar = -mu / dl + mu / du + (quad() ? T(2) * P.R[j] * u : T(0));   // barrier (+ objective) gradient wrt u
                     hdz += gbar * du_; dphi += gbar * du_;
                     ftb(dl, du_, tau, a_p); ftb(du, -du_, tau, a_p);
                     ftb(pl, mu / dl - pl - (pl / dl) * du_, tau, a_d);
@@ -1014,13 +1065,13 @@ struct IpmWave {
             }
             if (k >= 1) {
                 for (int i = 0; i < 3; ++i) {
-                    if (k < n - 1 || !P.xf_fixed[i]) {
+                    if (k < n - 1 || !fx(i)) {
                         T dx = F(L.DX, i, k);
                         dz2 += dx * dx; dzmax = t_max(dzmax, t_abs(dx));
                         T g = T(0);
-                        if (P.objective == OBJ_QUADRATIC) {
+                        if (quad()) {
                             if (k < n - 1) { T xd = F(L.X, i, k) - xf[i]; if (i == 2) xd = normalize_theta(xd); g = T(2) * P.Q[i] * xd; }
-                            else if (P.has_Qf) { T xd = F(L.X, i, k) - xf[i]; if (i == 2) xd = normalize_theta(xd); g = T(2) * P.Qf[i] * xd; }
+                            else if (hasqf()) { T xd = F(L.X, i, k) - xf[i]; if (i == 2) xd = normalize_theta(xd); g = T(2) * P.Qf[i] * xd; }
                         }
                         hdz += g * dx; dphi += g * dx;
                     }
@@ -1061,7 +1112,7 @@ struct IpmWave {
         o.hdz = wave_sum(hdz); o.clam = wave_sum(clam); o.dz2 = wave_sum(dz2); o.dphi = wave_sum(dphi);
         o.a_p = wave_min(a_p); o.a_d = wave_min(a_d); o.dzmax = wave_max(dzmax);
         o.nunu = T(0);
-        for (int i = 0; i < 3; ++i) if (P.xf_fixed[i]) o.nunu += nu[i] * nu[i];
+        for (int i = 0; i < 3; ++i) if (fx(i)) o.nunu += nu[i] * nu[i];
         o.finite = (wave_min(fin ? T(1) : T(0)) > T(0.5)) && t_finite(o.hdz) && t_finite(o.dz2);
         return o;
     }
@@ -1070,7 +1121,7 @@ struct IpmWave {
     __device__ __forceinline__ void accept(T alpha, T a_d) const {
         const int n = L.n;
         const T kS = T(1e10);
-        const T d_old = SCL(SC_D), dd = SCL(SC_DD), d_new = d_old + (P.dt_free ? alpha * dd : T(0));
+        const T d_old = SCL(SC_D), dd = SCL(SC_DD), d_new = d_old + (dtf() ? alpha * dd : T(0));
         // phase 1: everything that reads the OLD point
         T sn[4], yn[4];
         for (int k = lane; k < n; k += kWave) {      // (n <= 64 + ... handled by the loop; registers reused per chunk)
@@ -1122,7 +1173,7 @@ struct IpmWave {
             for (int i = 0; i < 3; ++i) F(L.X, i, k) = xt(i, k, alpha);
         }
         if (lane == 0) {
-            if (P.dt_free) {
+            if (dtf()) {
                 T dl = d_old - P.dt_lb, du = P.dt_ub - d_old;
                 T pl = SCL(SC_PDL), pu = SCL(SC_PDU);
                 T pln = pl + a_d * (mu / dl - pl - (pl / dl) * dd);
@@ -1160,9 +1211,9 @@ struct IpmWave {
         if (lane == 0) {
             for (int i = 0; i < 3; ++i) {
                 F(L.X, i, 0) = x0[i];
-                if (P.xf_fixed[i]) F(L.X, i, n - 1) = xf[i];
+                if (fx(i)) F(L.X, i, n - 1) = xf[i];
             }
-            if (!P.dt_free) SCL(SC_D) = P.dt_ref;
+            if (!dtf()) SCL(SC_D) = P.dt_ref;
         }
         sync();
         // seed controls from the state guess when every control is zero
@@ -1193,7 +1244,7 @@ struct IpmWave {
         sync();
         for (int k = lane; k < n - 1; k += kWave)
             for (int j = 0; j < 2; ++j) F(L.U, j, k) = push_interior(F(L.U, j, k), P.u_lb[j], P.u_ub[j]);
-        if (lane == 0 && P.dt_free) SCL(SC_D) = push_interior(SCL(SC_D), P.dt_lb, P.dt_ub);
+        if (lane == 0 && dtf()) SCL(SC_D) = push_interior(SCL(SC_D), P.dt_lb, P.dt_ub);
         sync();
         if (L.M > 0) { associate_obstacles(); sync(); }
         mu = P.mu_init; rho = T(0); delta_last = T(0); fail0 = false;
@@ -1224,8 +1275,8 @@ struct IpmWave {
             }
         }
         if (lane == 0) {
-            SCL(SC_PDL) = P.dt_free ? mu / (d - P.dt_lb) : T(0);
-            SCL(SC_PDU) = P.dt_free ? mu / (P.dt_ub - d) : T(0);
+            SCL(SC_PDL) = dtf() ? mu / (d - P.dt_lb) : T(0);
+            SCL(SC_PDU) = dtf() ? mu / (P.dt_ub - d) : T(0);
         }
         sync();
     }
@@ -1233,8 +1284,12 @@ struct IpmWave {
     // ---------------------------------------------------------------- driver (all lanes, uniform control flow)
     __device__ __forceinline__ SolveStats<T> solve() {
         SolveStats<T> out;
-        nfix = P.xf_fixed[0] + P.xf_fixed[1] + P.xf_fixed[2];
+        flags = (P.xf_fixed[0] ? 1 : 0) | (P.xf_fixed[1] ? 2 : 0) | (P.xf_fixed[2] ? 4 : 0) | (P.dt_free ? 8 : 0) | (P.objective == OBJ_QUADRATIC ? 16 : 0) |
+                (P.has_Qf ? 32 : 0) | (P.rate_on[0] ? 64 : 0) | (P.rate_on[1] ? 128 : 0) | (P.rate_on[2] ? 256 : 0) | (P.rate_on[3] ? 512 : 0);
+        flags = __builtin_amdgcn_readfirstlane(flags);
+        nfix = (int)fx(0) + (int)fx(1) + (int)fx(2);
         row0_on = dtprev != T(0);
+        if (lane < 8) sm[L.ZC + lane] = lane == 4 ? T(1) : T(0);      // constant coefficient triples of the sweeps
         init_point();
         T theta_c, fobj;
         eval_point(SCL(SC_D), theta_c, fobj);
@@ -1281,7 +1336,7 @@ struct IpmWave {
                 if (blockIdx.x == MPC_NANCHECK && lane == 0) {
                     const int offs[] = {L.X, L.U, L.LAM, L.LAMN, L.SR, L.YR, L.PL, L.PU, L.DX, L.DU, L.CC, L.TRIG, L.GAIN, L.STG, L.SC, L.VP, L.ZC, L.total};
                     const char* nm[] = {"X", "U", "LAM", "LAMN", "SR", "YR", "PL", "PU", "DX", "DU", "CC", "TRIG", "GAIN", "STG", "SC", "VP", "ZC"};
-                    printf("it %d try %d good %d delta %g dd %g mu %g |", it, ntry, (int)good, (double)delta, (double)dd, (double)mu);
+                    printf("it %d try %d good %d delta %g dd %g nu %g %g %g mu %g |", it, ntry, (int)good, (double)delta, (double)dd, (double)nu[0], (double)nu[1], (double)nu[2], (double)mu);
                     for (int f = 0; f < 17; ++f) {
                         int cnt = 0, first = -1;
                         for (int q = offs[f]; q < offs[f + 1]; ++q) if (!t_finite(sm[q])) { ++cnt; if (first < 0) first = q - offs[f]; }
@@ -1334,7 +1389,7 @@ struct IpmWave {
             for (int ls = 0; ls < Algo<T>::max_ls; ++ls) {
                 if (ls > 0) alpha *= T(0.5);
                 T phit, tht;
-                const T d_t = SCL(SC_D) + (P.dt_free ? alpha * SCL(SC_DD) : T(0));
+                const T d_t = SCL(SC_D) + (dtf() ? alpha * SCL(SC_DD) : T(0));
 #ifdef MPC_ASM_MARK
                 asm volatile("; TRIAL_BEGIN");
 #endif
@@ -1370,6 +1425,7 @@ struct IpmWave {
             long long* o = g_mpc_prof[blockIdx.x];
             o[0] = __builtin_readcyclecounter() - t_begin; o[1] = wall_clock64() - w_begin; o[2] = it; o[3] = nfac; o[4] = ntrial;
             for (int i = 0; i < 8; ++i) o[5 + i] = tk[i];
+            o[13] = prof_loop; o[14] = prof_setup; o[15] = prof_fwd_loop;
         }
 #endif
         out.status = status; out.iters = it; out.kkt_error = e0; out.objective = fobj;

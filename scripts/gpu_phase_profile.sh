@@ -16,13 +16,13 @@ r = s.solve(x0, xf, up, dtp)
 r = s.solve(x0, xf, up, dtp)
 print("kernel ms", s.last_kernel_ms())
 lib = _lib.load()
-buf = np.zeros((B, 14), dtype=np.int64)
+buf = np.zeros((B, 16), dtype=np.int64)
 lib.mpc_debug_profile(buf.ctypes.data_as(C.c_void_p), C.c_int(B))
-names = ["ticks", "wall100MHz", "iters", "nfac", "ntrial", "kkt", "barrier_terms", "backward", "forward", "post", "logs0", "trial", "accept"]
+names = ["ticks", "wall100MHz", "iters", "nfac", "ntrial", "kkt", "barrier_terms", "backward", "forward", "post", "logs0", "trial", "accept", "bwd_loop", "bwd_setup", "fwd_loop"]
 o = np.argsort(-buf[:, 0])[:5]
 print("tick rate GHz ~", (buf[:, 0] / (buf[:, 1] / 100e6)).mean() / 1e9)
 for i in o:
-    print(i, dict(zip(names, buf[i, :13].tolist())))
-print("mean over waves:", dict(zip(names, buf[:, :13].mean(0).round(0).tolist())))
+    print(i, dict(zip(names, buf[i, :16].tolist())))
+print("mean over waves:", dict(zip(names, buf[:, :16].mean(0).round(0).tolist())))
 print("per-sweep ticks: backward", buf[:, 7].sum() / buf[:, 3].sum(), "forward", buf[:, 8].sum() / buf[:, 3].sum(), "trial", buf[:, 11].sum() / max(1, buf[:, 4].sum()))
 PY
