@@ -811,7 +811,7 @@ struct IpmWave {
             MPC_DPP_BLOCK_R
             const T r2 = R01 * R01;
             const T det = R00 * R11 - r2;
-            worst = t_min(worst, t_abs(det) - T(1e-14) * (t_abs(R00 * R11) + r2));
+            worst = t_fmin(worst, t_abs(det) - T(1e-14) * (t_abs(R00 * R11) + r2));   // a NaN determinant poisons V and is caught by the root solve
             const T nid = -fast_rcp(det);
             const T nRi00 = R11 * nid, Ri01 = -(R01 * nid), nRi11 = R00 * nid;  // -R^-1 = [nRi00 Ri01; Ri01 nRi11]
             const T nK0 = nRi00 * h[6] + Ri01 * h[7], nK1 = Ri01 * h[6] + nRi11 * h[7];
