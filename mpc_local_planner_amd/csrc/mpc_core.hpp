@@ -537,22 +537,35 @@ MPC_HD bool riccati_root(const RicState<T>& V, const Problem<T>& P_, T& dd_out, 
             A4[1 + a][4] = -V.om[a];
         } else { A4[1 + a][1 + a] = T(1); }
     }
+    // Gaussian elimination with partial pivoting, written with compile-time indices only: the pivot row is brought up by
+    // compare-and-swap selects (a run-time row index would put the 4x5 tableau into scratch memory on the GPU).
     T ipiv[4];
+    bool ok = true;
+#pragma unroll
     for (int c = 0; c < 4; ++c) {
-        int piv = c; T best = t_abs(A4[c][c]);
-        for (int r = c + 1; r < 4; ++r) if (t_abs(A4[r][c]) > best) { best = t_abs(A4[r][c]); piv = r; }
-        if (!(best > T(0)) || !t_finite(best)) return false;
-        if (piv != c) for (int b = 0; b < 5; ++b) { T t = A4[c][b]; A4[c][b] = A4[piv][b]; A4[piv][b] = t; }
-        T ip = t_rcp(A4[c][c]);
-        ipiv[c] = ip;
+#pragma unroll
         for (int r = c + 1; r < 4; ++r) {
-            T m = A4[r][c] * ip;
+            const bool sw = t_abs(A4[r][c]) > t_abs(A4[c][c]);
+#pragma unroll
+            for (int b = 0; b < 5; ++b) { const T x = A4[c][b], y = A4[r][b]; A4[c][b] = sw ? y : x; A4[r][b] = sw ? x : y; }
+        }
+        const T best = t_abs(A4[c][c]);
+        ok = ok && (best > T(0)) && t_finite(best);
+        const T ip = t_rcp(A4[c][c]);
+        ipiv[c] = ip;
+#pragma unroll
+        for (int r = c + 1; r < 4; ++r) {
+            const T m = A4[r][c] * ip;
+#pragma unroll
             for (int b = c; b < 5; ++b) A4[r][b] -= m * A4[c][b];
         }
     }
+    if (!ok) return false;
     T sol[4];
+#pragma unroll
     for (int c = 3; c >= 0; --c) {
         T a = A4[c][4];
+#pragma unroll
         for (int b = c + 1; b < 4; ++b) a -= A4[c][b] * sol[b];
         sol[c] = a * ipiv[c];
     }

@@ -24,7 +24,8 @@ def main(src, dst):
         out.append("## rocprofv3 --kernel-trace --stats  (python bench.py --steps 5 --warmup 1 --no-cpu-baseline)\n")
         out.append("| kernel | calls | total_ns | avg_ns | % |\n|---|---|---|---|---|\n")
         for name, calls, tot, avg, pct in rows(tr, "select name,total_calls,total_duration,average,percentage from top_kernels")[1]:
-            out.append(f"| {name.split('(')[0][-80:]} | {calls} | {tot:.0f} | {avg:.0f} | {pct:.3f} |\n")
+            short = name.replace("(anonymous namespace)::", "").split("(mpc::")[0][:100]
+            out.append(f"| {short} | {calls} | {tot:.0f} | {avg:.0f} | {pct:.3f} |\n")
         c, r = rows(tr, "select name,duration,grid_x,workgroup_x,lds_size,scratch_size,vgpr_count,accum_vgpr_count,sgpr_count from kernels where name like '%mpc_ipm%'")
         out.append("\nper-dispatch of the solve kernel (duration ns, grid, workgroup, LDS B, scratch B/lane, VGPR, AGPR, SGPR):\n\n")
         for x in r:
