@@ -22,7 +22,7 @@ def main(src, dst):
     tr = os.path.join(src, "trace", "run_results.db")
     if os.path.exists(tr):
         out.append("## rocprofv3 --kernel-trace --stats  (python bench.py --steps 5 --warmup 1 --no-cpu-baseline)\n")
-        out.append("| kernel | calls | total_ns | avg_ns | % |\n|---|---|---|---|---|\n")
+        out.append("| kernel | calls | total_us | avg_us | % |\n|---|---|---|---|---|\n")
         for name, calls, tot, avg, pct in rows(tr, "select name,total_calls,total_duration,average,percentage from top_kernels")[1]:
             short = name.replace("(anonymous namespace)::", "").split("(mpc::")[0][:100]
             out.append(f"| {short} | {calls} | {tot:.0f} | {avg:.0f} | {pct:.3f} |\n")
