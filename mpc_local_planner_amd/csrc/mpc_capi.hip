@@ -107,7 +107,9 @@ __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
 #endif
     if (lane == 0) { *Ps = P; *Ls = L; Ls->n = n; Ps->n = n; }
     __syncthreads();
-    mpc::IpmWave<T, MODEL> S(*Ps, *Ls, sm, lane);
+    mpc::WaveLayout Lv = L;            // from the kernel arguments: wave-uniform, lives in SGPRs
+    Lv.n = __builtin_amdgcn_readfirstlane(n);
+    mpc::IpmWave<T, MODEL> S(*Ps, Lv, sm, lane);
     for (int i = 0; i < 3; ++i) { S.x0[i] = T(x0[3 * inst + i]); S.xf[i] = T(xf[3 * inst + i]); }
     S.x0[2] = mpc::normalize_theta(S.x0[2]);
     S.xf[2] = mpc::normalize_theta(S.xf[2]);

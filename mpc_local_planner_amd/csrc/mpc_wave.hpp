@@ -139,7 +139,8 @@ __device__ __forceinline__ float lane_bcast(float v, int src) {
 template <typename T, int MODEL>
 struct IpmWave {
     const Problem<T>& P;     // lives in LDS (copied once per workgroup): wave-uniform constants are fetched with
-    const WaveLayout& L;     // broadcast ds_reads instead of being pinned in (and spilled from) scalar registers
+    const WaveLayout L;      // broadcast ds_reads instead of being pinned in (and spilled from) scalar registers; the layout
+                             // (45 small ints, used by every accessor) is held by value = in scalar registers
     T* sm;
     const int lane;
     T x0[3], xf[3], uprev[2], dtprev;
