@@ -888,10 +888,27 @@ struct IpmWave {
         return riccati_root(Vr, P, dd_out, nu_out);
     }
 
+    // inclusive suffix sum over the wave (lane i gets sum_{j >= i} v_j): Hillis-Steele inside each 16-lane row with DPP row
+    // shifts (row_shl:n = 0x100 + n, out-of-row sources read as 0), then the totals of the higher rows via v_readlane.
+    // ~27 VALU instructions and no LDS traffic (the ds_bpermute version was 12 LDS round trips).
+    template <int CTRL> __device__ __forceinline__ static double dpp_shl0(double v) {
+        int lo = __double2loint(v), hi = __double2hiint(v);
+        lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, true);
+        hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, true);
+        return __hiloint2double(hi, lo);
+    }
+    template <int CTRL> __device__ __forceinline__ static float dpp_shl0(float v) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+    }
     __device__ __forceinline__ T wave_suffix_sum(T v) const {
-#pragma unroll
-        for (int o = 1; o < kWave; o <<= 1) { T w2 = __shfl_down(v, o); if (lane + o < kWave) v += w2; }
-        return v;
+        v += dpp_shl0<0x101>(v);
+        v += dpp_shl0<0x102>(v);
+        v += dpp_shl0<0x104>(v);
+        v += dpp_shl0<0x108>(v);
+        const T r1 = rd_lane(v, 16), r2 = rd_lane(v, 32), r3 = rd_lane(v, 48);
+        const T c2 = r3, c1 = r2 + r3, c0 = r1 + c1;
+        const int row = lane >> 4;
+        return v + (row == 0 ? c0 : (row == 1 ? c1 : (row == 2 ? c2 : T(0))));
     }
 
     // state recurrence (wave-uniform, software-pipelined LDS reads) then multipliers by lane-parallel suffix scans
