@@ -623,9 +623,9 @@ struct IpmWave {
             if (k < n - 1) {
                 for (int j = 0; j < 2; ++j) {
                     T u = F(L.U, j, k);
-                    T dl = u - P.u_lb[j], du = P.u_ub[j] - u;
-                    sp.sz[j] = F(L.PL, j, k) / dl + F(L.PU, j, k) / du;
-                    sp.gb[j] = -mu / dl + mu / du + r2[j] * u;
+                    const T idl = t_rcp(u - P.u_lb[j]), idu = t_rcp(P.u_ub[j] - u);      // one reciprocal per bound, shared by all quotients
+                    sp.sz[j] = F(L.PL, j, k) * idl + F(L.PU, j, k) * idu;
+                    sp.gb[j] = mu * idu - mu * idl + r2[j] * u;
                 }
             }
             sp.ss[0] = sp.ss[1] = sp.sl[0] = sp.sl[1] = sp.sll = sp.gy[0] = sp.gy[1] = sp.gyl = T(0);
@@ -634,8 +634,9 @@ struct IpmWave {
                 const int j = q & 1;
                 const T sg = slot_sign<T>(q), lim = k > 0 ? P.rate_lim[q] : T(0);
                 T s = F(L.SR, q, k), y = F(L.YR, q, k);
-                T sig = y / s;
-                T ybar = mu / s + sig * (row_val(L.U, d, k, q) + s);
+                const T is = t_rcp(s);
+                T sig = y * is;
+                T ybar = mu * is + sig * (row_val(L.U, d, k, q) + s);
                 sp.ss[j] += sig; sp.sl[j] += sig * lim; sp.sll += sig * lim * lim;
                 sp.gy[j] += sg * ybar; sp.gyl += sg * lim * ybar;
             }
@@ -1068,11 +1069,12 @@ struct IpmWave {
                     T u = F(L.U, j, k), du_ = F(L.DU, j, k);
                     T dl = u - P.u_lb[j], du = P.u_ub[j] - u;
                     T pl = F(L.PL, j, k), pu = F(L.PU, j, k);
-                    T gbar = -mu / dl + mu / du + (quad() ? T(2) * P.R[j] * u : T(0));   // barrier (+ objective) gradient wrt u
+                    const T idl = t_rcp(dl), idu = t_rcp(du);
+                    T gbar = mu * idu - mu * idl + (quad() ? T(2) * P.R[j] * u : T(0));   // barrier (+ objective) gradient wrt u
                     hdz += gbar * du_; dphi += gbar * du_;
                     ftb(dl, du_, tau, a_p); ftb(du, -du_, tau, a_p);
-                    ftb(pl, mu / dl - pl - (pl / dl) * du_, tau, a_d);
-                    ftb(pu, mu / du - pu + (pu / du) * du_, tau, a_d);
+                    ftb(pl, mu * idl - pl - (pl * idl) * du_, tau, a_d);
+                    ftb(pu, mu * idu - pu + (pu * idu) * du_, tau, a_d);
                     dz2 += du_ * du_; dzmax = t_max(dzmax, t_abs(du_));
                 }
                 for (int i = 0; i < 3; ++i) {
@@ -1100,12 +1102,13 @@ struct IpmWave {
                 T jdz = row_jdz(k, q, dd);
                 T s = F(L.SR, q, k), y = F(L.YR, q, k);
                 T res = row_val(L.U, d, k, q) + s;
-                T sig = y / s;
-                T ybar = mu / s + sig * res;
+                const T is = t_rcp(s);
+                T sig = y * is;
+                T ybar = mu * is + sig * res;
                 T ds = -res - jdz;
                 T dy = ybar + sig * jdz - y;
                 hdz += ybar * jdz;
-                dphi -= (mu / s) * ds;
+                dphi -= (mu * is) * ds;
                 ftb(s, ds, tau, a_p);
                 ftb(y, dy, tau, a_d);
             }
@@ -1148,12 +1151,14 @@ struct IpmWave {
                 T s = F(L.SR, q, k), y = F(L.YR, q, k);
                 T res = row_val(L.U, d_old, k, q) + s;
                 T jdz = row_jdz(k, q, dd);
-                T sig = y / s;
+                const T is = t_rcp(s);
+                T sig = y * is;
                 T ds = -res - jdz;
-                T dy = mu / s + sig * res + sig * jdz - y;
+                T dy = mu * is + sig * res + sig * jdz - y;
                 sn[q] = s + alpha * ds;
                 T yv = y + a_d * dy;
-                yn[q] = t_min(t_max(yv, mu / (kS * sn[q])), kS * mu / sn[q]);
+                const T musn = mu * t_rcp(sn[q]);
+                yn[q] = t_min(t_max(yv, musn * (T(1) / kS)), kS * musn);
             }
             if (L.M > 0 && k >= 1 && k < n - 1) {
                 for (int m = 0; m < L.M; ++m) {
@@ -1175,12 +1180,13 @@ struct IpmWave {
                     T u = F(L.U, j, k), du_ = F(L.DU, j, k);
                     T dl = u - P.u_lb[j], du = P.u_ub[j] - u;
                     T pl = F(L.PL, j, k), pu = F(L.PU, j, k);
-                    T pln = pl + a_d * (mu / dl - pl - (pl / dl) * du_);
-                    T pun = pu + a_d * (mu / du - pu + (pu / du) * du_);
+                    const T idl = t_rcp(dl), idu = t_rcp(du);
+                    T pln = pl + a_d * (mu * idl - pl - (pl * idl) * du_);
+                    T pun = pu + a_d * (mu * idu - pu + (pu * idu) * du_);
                     T un = ut(j, k, alpha);
-                    T dln = un - P.u_lb[j], dun = P.u_ub[j] - un;
-                    F(L.PL, j, k) = t_min(t_max(pln, mu / (kS * dln)), kS * mu / dln);
-                    F(L.PU, j, k) = t_min(t_max(pun, mu / (kS * dun)), kS * mu / dun);
+                    const T mdl = mu * t_rcp(un - P.u_lb[j]), mdu = mu * t_rcp(P.u_ub[j] - un);
+                    F(L.PL, j, k) = t_min(t_max(pln, mdl * (T(1) / kS)), kS * mdl);
+                    F(L.PU, j, k) = t_min(t_max(pun, mdu * (T(1) / kS)), kS * mdu);
                     F(L.U, j, k) = un;
                 }
                 for (int i = 0; i < 3; ++i) {
@@ -1313,7 +1319,8 @@ struct IpmWave {
         eval_point(SCL(SC_D), theta_c, fobj);
         sync();
         int it = 0, status = ST_MAX_ITER;
-        T e0 = T(0);
+        T e0 = T(0), logs_cur = T(0);
+        bool have_logs = false;
 #ifdef MPC_PROFILE
         long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int nfac = 0, ntrial = 0;
         const long long t_begin = __builtin_readcyclecounter();
@@ -1395,7 +1402,9 @@ struct IpmWave {
                 if (rho < rho_trial) rho = rho_trial + T(1);
             }
             T phi0;
-            MPC_TICK(5, phi0 = fobj - mu * barrier_logs(SCL(SC_D), T(0), false, dd) + rho * theta);
+            // sum of the barrier logs at the current point: it is the value of the last accepted trial (same point, mu-independent)
+            if (!have_logs) { MPC_TICK(5, logs_cur = barrier_logs(SCL(SC_D), T(0), false, dd)); have_logs = true; }
+            phi0 = fobj - mu * logs_cur + rho * theta;
             const T Dm = fw.dphi - rho * theta;
             const T theta_rows = theta - theta_c;
             T alpha = fw.a_p;
@@ -1403,7 +1412,7 @@ struct IpmWave {
             const bool fast_trials = trial_fast_ok();
             TrialRegs tregs;
             if (fast_trials) { MPC_TICK(5, trial_setup(tregs, dd)); }
-            T th_t = T(0), f_t = T(0);
+            T th_t = T(0), f_t = T(0), lg_t = T(0);
             for (int ls = 0; ls < Algo<T>::max_ls; ++ls) {
                 if (ls > 0) alpha *= T(0.5);
                 T phit, tht;
@@ -1412,14 +1421,14 @@ struct IpmWave {
                 asm volatile("; TRIAL_BEGIN");
 #endif
                 if (fast_trials) {
-                    T lg;
-                    MPC_TICK(6, trial_eval(tregs, alpha, d_t, th_t, f_t, lg);
+                    MPC_TICK(6, trial_eval(tregs, alpha, d_t, th_t, f_t, lg_t);
                              tht = th_t + (T(1) - alpha) * theta_rows;
-                             phit = f_t - mu * lg + rho * tht; sync());
+                             phit = f_t - mu * lg_t + rho * tht; sync());
                 } else {
                     MPC_TICK(6, eval_point(d_t, th_t, f_t, alpha, true);
                              tht = th_t + (T(1) - alpha) * theta_rows;
-                             phit = f_t - mu * barrier_logs(d_t, alpha, true, dd) + rho * tht; sync());
+                             lg_t = barrier_logs(d_t, alpha, true, dd);
+                             phit = f_t - mu * lg_t + rho * tht; sync());
                 }
 #ifdef MPC_ASM_MARK
                 asm volatile("; TRIAL_END");
@@ -1435,7 +1444,7 @@ struct IpmWave {
                 printf("   ls: it %d f %.6f -> %.6f theta_c %.3e alpha %.4f a_p %.4f a_d %.4f rho %.3e Dm %.4e hdz %.6e clam %.6e dz2 %.6e dphi %.6e\n", it, (double)fobj, (double)f_t, (double)th_t, (double)alpha, (double)fw.a_p, (double)fw.a_d, (double)rho, (double)Dm, (double)fw.hdz, (double)fw.clam, (double)fw.dz2, (double)fw.dphi);
 #endif
             MPC_TICK(7, accept(alpha, fw.a_d); sync());
-            theta_c = th_t; fobj = f_t;
+            theta_c = th_t; fobj = f_t; logs_cur = lg_t;
             ++it;
         }
 #ifdef MPC_PROFILE
