@@ -1331,7 +1331,13 @@ struct IpmWave {
 #endif
         while (true) {
             Err er;
+#ifdef MPC_ASM_MARK
+            asm volatile("; KKT_BEGIN");
+#endif
             MPC_TICK(0, er = kkt_pass());
+#ifdef MPC_ASM_MARK
+            asm volatile("; KKT_END");
+#endif
             e0 = err_value(er, T(0));
             if (!t_finite(e0)) { status = ST_NUMERICAL; break; }
             if (e0 <= P.tol) { status = ST_CONVERGED; break; }
