@@ -3,7 +3,7 @@ kept only when the independent C oracle (banded LU) lands on the same point to 1
 
 The reference publishes no golden vectors ("parity unpinned"); these
 fixtures pin OUR oracle so that later changes to it, or to the HIP path, are detected.
-Run from the repo root:  python tests/golden/make_golden.py
+Run from the repo root:  python tests/golden/make_golden.py   (add --warm to (re)generate only the warm-start fixture)
 """
 import os
 import sys
@@ -65,9 +65,40 @@ def make_obstacles(name, n=30, B=10, O=6, V=6, M=4, keep=6):
     print(name, "kept", len(sel), "iters", IT)
 
 
-if __name__ == "__main__":
+if __name__ == "__main__" and "--warm" not in sys.argv:
     make_obstacles("unicycle_quadratic_obstacles_n30")
     make("carlike_min_time_n50", R.config_carlike_min_time(50), W.carlike_min_time_inputs(32, seed=101), keep=8)
     make("carlike_min_time_n20", R.config_carlike_min_time(20), W.carlike_min_time_inputs(32, seed=102, goal_range=(1.0, 2.5)), keep=8)
     make("unicycle_quadratic_n20", R.config_unicycle_quadratic(20), W.unicycle_quadratic_inputs(16, seed=103), keep=8)
     make("bicycle_min_time_n30", R.config_bicycle_min_time(30), W.carlike_min_time_inputs(32, seed=104, goal_range=(2.0, 6.0)), keep=6)
+
+
+def make_warm(name, n=20, keep=6):
+    """Second control cycle: the plant advances one 0.2 s period under u_0 (explicit Euler), the previous solution is the
+    initial guess with x0 overwritten (full_discretization_grid_base_se2.cpp:101-110; variable grid: no shifting)."""
+    g = np.load(os.path.join(OUT, f"carlike_min_time_n{n}.npz"))
+    cfg = R.config_carlike_min_time(n)
+    per = 0.2
+    rows = []
+    for i in range(g["x0"].shape[0]):
+        if len(rows) >= keep:
+            break
+        x0, u0 = g["x0"][i], g["u"][i, 0]
+        f = R.dynamics(cfg.model, cfg.model_params, x0, u0)
+        x1 = x0 + per * f
+        x1[2] = R.normalize_theta(x1[2])
+        prev = R.Trajectory(g["x"][i].copy(), g["u"][i, :-1].copy(), float(g["dt"][i]))
+        init = R.Trajectory(prev.x.copy(), prev.u.copy(), prev.dt)
+        init.x[0] = x1
+        inp = R.CycleInputs(x0=x1, xf=g["xf"][i], u_prev=u0, dt_prev=per)
+        ref = I.solve(cfg, inp, init, opt=I.IpmOptions(globalization="merit", max_iter=100))
+        if ref.status != 0 or ref.iters > 45:
+            continue
+        rows.append(dict(x0=x1, xf=g["xf"][i], u_prev=u0, dt_prev=per, x_init=init.x, u_init=np.vstack([init.u, init.u[-1:]]), dt_init=init.dt,
+                         x=ref.traj.x, u=np.vstack([ref.traj.u, ref.traj.u[-1:]]), dt=ref.traj.dt, iters=ref.iters))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **{k: np.array([r[k] for r in rows]) for k in rows[0]})
+    print(name, "kept", len(rows), "iters", [r["iters"] for r in rows])
+
+
+if __name__ == "__main__" and "--warm" in sys.argv:
+    make_warm("carlike_min_time_n20_warm")

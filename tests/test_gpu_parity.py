@@ -283,3 +283,37 @@ print("POISON_OK")
     env = dict(os.environ, MPC_HIP_LIB=so)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert "POISON_OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_warm_start_golden(m):
+    """Second control cycle: previous solution as the initial guess, x0 advanced by the plant (numpy-oracle fixture
+    tests/golden/carlike_min_time_n20_warm.npz, generated by make_golden.py --warm)."""
+    g = np.load(os.path.join(GOLD, "carlike_min_time_n20_warm.npz"))
+    s = m.BatchSolver(m.config_carlike_min_time(20), max_batch=g["x0"].shape[0])
+    r = s.solve(g["x0"], g["xf"], g["u_prev"], g["dt_prev"], init=(g["x_init"], g["u_init"], g["dt_init"]))
+    assert (r.status == 0).all()
+    assert np.abs(r.x - g["x"]).max() < 1e-6 and np.abs(r.u - g["u"]).max() < 1e-6 and np.abs(r.dt - g["dt"]).max() < 1e-8
+    assert (np.abs(r.iters - g["iters"]) <= 2).all()
+    s.close()
+
+
+def test_mixed_grid_sizes_in_one_batch(m):
+    """mpc_set_grid_sizes: instances with n_i = 50 and n_i = 20 grid points in ONE launch of a solver created for n = 50
+    (grid adaptation changes n between cycles, finite_differences_variable_grid_se2.cpp:99-121); each instance must land
+    on its own golden solution; rows beyond n_i of the outputs repeat the last grid point."""
+    g50 = np.load(os.path.join(GOLD, "carlike_min_time_n50.npz"))
+    g20 = np.load(os.path.join(GOLD, "carlike_min_time_n20.npz"))
+    b50, b20 = g50["x0"].shape[0], g20["x0"].shape[0]
+    cat = lambda k: np.concatenate([g50[k], g20[k]])
+    s = m.BatchSolver(m.config_carlike_min_time(50), max_batch=b50 + b20)
+    s.set_grid_sizes(np.array([50] * b50 + [20] * b20, dtype=np.int32))
+    r = s.solve(cat("x0"), cat("xf"), cat("u_prev"), cat("dt_prev"))
+    assert (r.status == 0).all()
+    assert np.abs(r.x[:b50] - g50["x"]).max() < 1e-6 and np.abs(r.dt[:b50] - g50["dt"]).max() < 1e-8
+    assert np.abs(r.x[b50:, :20] - g20["x"]).max() < 1e-6 and np.abs(r.u[b50:, :19] - g20["u"][:, :19]).max() < 1e-6
+    assert np.abs(r.dt[b50:] - g20["dt"]).max() < 1e-8
+    assert np.abs(r.x[b50:, 20:] - r.x[b50:, 19:20]).max() == 0.0
+    s.set_grid_sizes(None)
+    r2 = s.solve(g50["x0"], g50["xf"], g50["u_prev"], g50["dt_prev"])
+    assert np.abs(r2.x - g50["x"]).max() < 1e-6
+    s.close()

@@ -116,3 +116,13 @@ def test_device_trig_kernels_match_libm(host):
     assert np.abs(s - np.sin(x)).max() < 2.5e-16 and np.abs(c - np.cos(x)).max() < 2.5e-16
     w = np.abs(x) < 1.45
     assert (np.abs(t[w] - np.tan(x[w])) <= 4 * np.spacing(np.abs(np.tan(x[w])))).all()
+
+
+def test_device_core_on_host_warm_start_golden(host):
+    """second control cycle (previous solution as the guess): tests/golden/carlike_min_time_n20_warm.npz"""
+    g = np.load(os.path.join(GOLD, "carlike_min_time_n20_warm.npz"))
+    cfg = A.config_carlike_min_time(20)
+    xo, uo, do, st, it, kkt = host_solve(host, cfg, g["x0"], g["xf"], g["u_prev"], g["dt_prev"], init=(g["x_init"], g["u_init"], g["dt_init"]))
+    assert (st == 0).all()
+    assert np.abs(xo - g["x"]).max() < 1e-6 and np.abs(do - g["dt"]).max() < 1e-8
+    assert (np.abs(it - g["iters"]) <= 2).all()
