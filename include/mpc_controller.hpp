@@ -9,11 +9,12 @@
 //   * initial state trajectory from the plan (time-equidistant poses, yaw from finite differences),
 //     src/controller.cpp:807-857, sampled onto the grid with the SE2-aware linear interpolation of
 //     src/utils/time_series_se2.cpp:34-111  (full_discretization_grid_base_se2.cpp:192-239),
-//   * warm start: previous solution handed back with x_0 overwritten (variable grid: no shifting,
+//   * warm start: previous solution handed back with x_0 overwritten (fixed grid: shifted first, warm_start_shifting(); variable grid: no shifting,
 //     finite_differences_variable_grid_se2.h:85),
 //   * result time series as getStateAndControlTimeSeries (full_discretization_grid_base_se2.cpp:579-615).
 // Types carry the reference's names without ROS: PoseSE2 (teb), Twist (geometry_msgs), TimeSeries (corbo).
 #pragma once
+#include <algorithm>
 #include <cmath>
 #include <cstdint>
 #include <string>
@@ -116,6 +117,40 @@ inline void resample_trajectory(std::vector<double>& x, std::vector<double>& u, 
     dt = dt_new;
 }
 
+// findNearestState + warmStartShifting (src/optimal_control/full_discretization_grid_base_se2.cpp:241-339): moving-horizon warm
+// start of the FIXED-dt grid.  The previous solution is shifted by the index of the state nearest to the new start (search
+// stops at the first non-improving sample, look-ahead <= 20), the tail is extrapolated linearly (angles with
+// interpolate_angle(.., 2.0)) and the last control is held.  x: [n][3], u: [n][2] (row n-1 of u is the duplicated control).
+inline int find_nearest_state(const double* x, int n, const double x0[3]) {
+    auto dist = [&](int i) { const double a = x0[0] - x[3 * i], b = x0[1] - x[3 * i + 1], c = x0[2] - x[3 * i + 2]; return std::sqrt(a * a + b * b + c * c); };
+    const double first = dist(0);
+    if (std::fabs(first) < 1e-12) return 0;
+    const int look = std::min((n - 1) - 1, 20);
+    int best = 0; double cache = first;
+    for (int i = 1; i <= look; ++i) {
+        const double d = dist(i);
+        if (d < cache) { cache = d; best = i; } else break;
+    }
+    return best;
+}
+inline void warm_start_shifting(double* x, double* u, int n, const double x0[3]) {
+    const int ns = find_nearest_state(x, n, x0);
+    if (ns <= 0 || ns > n - 2) return;
+    for (int i = 0; i < n - ns; ++i) {
+        const int idx = i + ns;
+        for (int c = 0; c < 3; ++c) x[3 * i + c] = x[3 * (idx == n - 1 ? n - 1 : idx) + c];
+        if (idx != n - 1) { u[2 * i] = u[2 * idx]; u[2 * i + 1] = u[2 * idx + 1]; }
+    }
+    int idx = n - ns;
+    for (int i = 0; i < ns; ++i, ++idx) {
+        for (int c = 0; c < 2; ++c) x[3 * idx + c] = x[3 * (idx - 2) + c] + 2.0 * (x[3 * (idx - 1) + c] - x[3 * (idx - 2) + c]);
+        const double a1 = x[3 * (idx - 2) + 2], a2 = x[3 * (idx - 1) + 2];
+        x[3 * idx + 2] = normalize_theta(a1 + 2.0 * normalize_theta(a2 - a1));          // interpolate_angle(a1, a2, 2.0)
+        u[2 * (idx - 1)] = u[2 * (idx - 2)]; u[2 * (idx - 1) + 1] = u[2 * (idx - 2) + 1];
+    }
+    u[2 * (n - 1)] = u[2 * (n - 2)]; u[2 * (n - 1) + 1] = u[2 * (n - 2) + 1];               // keep the duplicated last control consistent
+}
+
 class Controller {
  public:
     Controller() = default;
@@ -149,6 +184,7 @@ class Controller {
     void setGridAdaptation(bool enable, int max_grid_size = 50, double dt_hyst_ratio = 0.1, int min_grid_size = 2) {
         _grid_adapt = enable; _n_max = max_grid_size; _dt_hyst = dt_hyst_ratio; _n_min = min_grid_size < 3 ? 3 : min_grid_size;
     }
+    void setWarmStart(bool w) { _warm_start = w; }      // grid/warm_start (src/controller.cpp:294-296)
     int gridSize() const { return _n_cur; }
 
     // ocp->setPreviousControlInput(u, dt)  (src/mpc_local_planner_ros.cpp:384)
@@ -192,6 +228,7 @@ class Controller {
             }
         } else {
             _xi = _x; _ui = _u; _dti = _dt_sol;      // previous solution = warm start (x_0 / fixed goal are overwritten by the solver)
+            if (_warm_start && !_cfg.dt_free) warm_start_shifting(_xi.data(), _ui.data(), _n_cur, x0);   // fixed grid only (…grid_base_se2.cpp:96-100)
             if (_grid_adapt && _cfg.dt_free) {
                 // adaptGridTimeBasedSingleStep (src/optimal_control/finite_differences_variable_grid_se2.cpp:99-121)
                 int n_new = _n_cur;
@@ -233,7 +270,7 @@ class Controller {
     mpc_solver* _h = nullptr;
     mpc_config _cfg{};
     int _n = 0, _n_ref = 0, _n_cur = 0;
-    bool _grid_adapt = false, _sizes_set = false;
+    bool _grid_adapt = false, _sizes_set = false, _warm_start = true;
     int _n_max = 50, _n_min = 3;
     double _dt_hyst = 0.1;
     std::vector<double> _x, _u, _xi, _ui;

@@ -16,3 +16,6 @@ extern "C" double ctl_resample(double* x, double* u, double dt, int n, int n_new
     for (size_t i = 0; i < uv.size(); ++i) u[i] = uv[i];
     return dt;
 }
+
+extern "C" int ctl_find_nearest_state(const double* x, int n, const double* x0) { return mpc_local_planner_amd::find_nearest_state(x, n, x0); }
+extern "C" void ctl_warm_start_shifting(double* x, double* u, int n, const double* x0) { mpc_local_planner_amd::warm_start_shifting(x, u, n, x0); }

@@ -65,3 +65,24 @@ def test_resample_matches_oracle(lib):
         assert dt_new == pytest.approx(tr.dt)
         np.testing.assert_allclose(xb[:n_new], tr.x, atol=1e-14)
         np.testing.assert_allclose(ub[:n_new - 1], tr.u, atol=1e-14)
+
+
+def test_warm_start_shifting_matches_oracle(lib):
+    """fixed-grid moving-horizon warm start (full_discretization_grid_base_se2.cpp:241-339) vs oracle/se2_nlp.py"""
+    rng = np.random.default_rng(9)
+    n = 20
+    for trial in range(20):
+        x = np.cumsum(rng.uniform(0.0, 0.2, (n, 3)), axis=0)
+        x[:, 2] = np.cumsum(rng.uniform(-0.5, 0.5, n))
+        x[:, 2] = (x[:, 2] + np.pi) % (2 * np.pi) - np.pi
+        u = rng.normal(size=(n - 1, 2))
+        k = int(rng.integers(0, 6))
+        x0 = x[k] + rng.normal(scale=0.01, size=3) * (trial % 3 > 0)
+        ref = R.warm_start_shifting(R.Trajectory(x.copy(), u.copy(), 0.3), x0)
+        xx = x.copy(); uu = np.vstack([u, u[-1:]]).copy()
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        x0c = np.ascontiguousarray(x0)
+        assert lib.ctl_find_nearest_state(p(xx), C.c_int(n), p(x0c)) == R.find_nearest_state(R.Trajectory(x, u, 0.3), x0)
+        lib.ctl_warm_start_shifting(p(xx), p(uu), C.c_int(n), p(x0c))
+        assert np.abs(xx - ref.x).max() < 1e-14
+        assert np.abs(uu[:-1] - ref.u).max() < 1e-14
