@@ -146,6 +146,7 @@ struct IpmWave {
     T x0[3], xf[3], uprev[2], dtprev;
     T mu, rho, delta_last;
     bool row0_on, fail0;
+    mutable int cnt_mult = -1, cnt_bmult = -1;      // number of equality / bound multipliers (cached by kkt_pass)
     int flags;      // bits 0..2 xf_fixed, 3 dt_free, 4 quadratic objective, 5 has_Qf, 6..9 rate_on: the problem record lives in LDS and every
                     // P.x costs a ds_read (+ wait) that the compiler cannot hoist over LDS stores; one scalar register holds the switches
 #ifdef MPC_PROFILE
@@ -492,6 +493,7 @@ struct IpmWave {
         T rd = T(0), rp = T(0), cmin = T(1e30), cmax = T(0), smult = T(0), sb = T(0), th = T(0), rdd = T(0);
         int nm = 0, nb = 0;
         for (int k = lane; k < n; k += kWave) {
+            T rec[20];
             if (k < n - 1) {
                 T lam[3] = {F(L.LAM, 0, k), F(L.LAM, 1, k), F(L.LAM, 2, k)};
                 T tr[4] = {F(L.TRIG, 0, k), F(L.TRIG, 1, k), F(L.TRIG, 2, k), L.NTR > 3 ? F(L.TRIG, 3, k) : T(0)};
@@ -500,14 +502,14 @@ struct IpmWave {
                 model_derivs<T, MODEL>(P, tr, v, w, lam, f, G, Hq);
                 T gq[3];
                 for (int j = 0; j < 3; ++j) gq[j] = lam[0] * G[0][j] + lam[1] * G[1][j] + lam[2] * G[2][j];
-                // stage record, mu-independent part
-                S_(0, k) = d * G[0][0]; S_(1, k) = d * G[1][0]; S_(2, k) = T(1);       // column 2 of Ghat: (a0, a1, 1)
-                S_(3, k) = f[0]; S_(4, k) = f[1]; S_(5, k) = f[2];
-                for (int a = 0; a < 3; ++a) { S_(6 + a, k) = d * G[a][1]; S_(9 + a, k) = d * G[a][2]; }   // Bx column-major
-                // raw (mu-independent) pieces parked in their A slots; stage_barrier_terms() turns them into the combined entries
-                S_(RA + A22, k) = d * Hq[0][0]; S_(RA + A26, k) = d * Hq[0][1]; S_(RA + A27, k) = d * Hq[0][2];
-                S_(RA + A66, k) = d * Hq[1][1]; S_(RA + A67, k) = d * Hq[1][2]; S_(RA + A77, k) = d * Hq[2][2];
-                S_(RA + A25, k) = gq[0]; S_(RA + A56, k) = gq[1]; S_(RA + A57, k) = gq[2];
+                // stage record, mu-independent part: kept in registers and stored at the END of the loop body -- every LDS store
+                // forces the loads that follow it in program order to be re-issued and waited for (possible aliasing)
+                rec[0] = d * G[0][0]; rec[1] = d * G[1][0];
+                rec[2] = f[0]; rec[3] = f[1]; rec[4] = f[2];
+                for (int a = 0; a < 3; ++a) { rec[5 + a] = d * G[a][1]; rec[8 + a] = d * G[a][2]; }
+                rec[11] = d * Hq[0][0]; rec[12] = d * Hq[0][1]; rec[13] = d * Hq[0][2];
+                rec[14] = d * Hq[1][1]; rec[15] = d * Hq[1][2]; rec[16] = d * Hq[2][2];
+                rec[17] = gq[0]; rec[18] = gq[1]; rec[19] = gq[2];
                 for (int i = 0; i < 3; ++i) {
                     T ci = C_(i, k);
                     rp = t_max(rp, t_abs(ci)); th += t_abs(ci); smult += t_abs(lam[i]);
@@ -576,6 +578,15 @@ struct IpmWave {
                 sb += y; nb += 1;
                 if (k > 0) rdd -= slot_sign<T>(q) * P.rate_lim[q] * y;
             }
+            if (k < n - 1) {
+                S_(0, k) = rec[0]; S_(1, k) = rec[1]; S_(2, k) = T(1);                 // column 2 of Ghat: (a0, a1, 1)
+                S_(3, k) = rec[2]; S_(4, k) = rec[3]; S_(5, k) = rec[4];
+                for (int a = 0; a < 3; ++a) { S_(6 + a, k) = rec[5 + a]; S_(9 + a, k) = rec[8 + a]; }   // Bx column-major
+                // raw (mu-independent) pieces parked in their A slots; stage_barrier_terms() turns them into the combined entries
+                S_(RA + A22, k) = rec[11]; S_(RA + A26, k) = rec[12]; S_(RA + A27, k) = rec[13];
+                S_(RA + A66, k) = rec[14]; S_(RA + A67, k) = rec[15]; S_(RA + A77, k) = rec[16];
+                S_(RA + A25, k) = rec[17]; S_(RA + A56, k) = rec[18]; S_(RA + A57, k) = rec[19];
+            }
         }
         if (lane == 0) {
             if (!quad()) rdd += T(n - 1);
@@ -597,8 +608,12 @@ struct IpmWave {
         e.sum_bmult = wave_sum(sb);
         e.sum_mult = wave_sum(smult) + e.sum_bmult;
         e.theta = wave_sum(th);
-        e.n_bmult = (int)wave_sum((T)nb);
-        e.n_mult = (int)wave_sum((T)nm) + e.n_bmult;
+        if (L.M == 0 && cnt_bmult >= 0) { e.n_bmult = cnt_bmult; e.n_mult = cnt_mult; }      // without clearance rows the counts never change
+        else {
+            e.n_bmult = (int)wave_sum((T)nb);
+            e.n_mult = (int)wave_sum((T)nm) + e.n_bmult;
+            cnt_bmult = e.n_bmult; cnt_mult = e.n_mult;
+        }
         return e;
     }
 
