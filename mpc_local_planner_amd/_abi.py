@@ -66,7 +66,8 @@ class MpcConfig(C.Structure):
         ("max_obstacles", C.c_int32),
         ("max_vertices", C.c_int32),
         ("max_obstacle_rows", C.c_int32),
-        ("reserved", C.c_int32 * 8),
+        ("mu_init_warm", C.c_double),
+        ("reserved", C.c_int32 * 6),
     ]
 
 
@@ -84,7 +85,7 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
                 xf_fixed=(True, True, True), objective=OBJ_MIN_TIME, Q=(0, 0, 0), R=(0, 0), integral_form=False, Qf=None,
                 u_lb=(-0.2, -0.3), u_ub=(0.4, 0.3), du_lb=(-INF, -INF), du_ub=(INF, INF), max_iter=100, tol=1e-8,
                 mu_init=0.1, precision=FP64, min_obstacle_dist=0.5, force_inclusion_dist=0.5, cutoff_dist=2.0,
-                footprint_kind=0, footprint_radius=0.0, max_obstacles=0, max_vertices=1, max_obstacle_rows=4) -> MpcConfig:
+                footprint_kind=0, footprint_radius=0.0, max_obstacles=0, max_vertices=1, max_obstacle_rows=4, mu_init_warm=0.0) -> MpcConfig:
     c = MpcConfig()
     c.model = model
     mp = list(model_params) + [0.0] * 4
@@ -113,6 +114,7 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
     c.min_obstacle_dist, c.force_inclusion_dist, c.cutoff_dist = min_obstacle_dist, force_inclusion_dist, cutoff_dist
     c.footprint_kind, c.footprint_radius = footprint_kind, footprint_radius
     c.max_obstacles, c.max_vertices, c.max_obstacle_rows = max_obstacles, max_vertices, max_obstacle_rows
+    c.mu_init_warm = mu_init_warm
     return c
 
 

@@ -123,6 +123,7 @@ __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
         for (int e = lane; e < 3 * n; e += mpc::kWave) S.F(L.X, e % 3, e / 3) = T(xi[e]);
         for (int e = lane; e < 2 * (n - 1); e += mpc::kWave) S.F(L.U, e % 2, e / 2) = T(ui[e]);
         if (lane == 0) S.SCL(mpc::SC_D) = T(dt_init[inst]);
+        S.warm_guess = true;
     } else {
         S.cold_start();
     }

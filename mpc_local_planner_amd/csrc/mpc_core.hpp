@@ -61,7 +61,7 @@ struct Problem {
     T Q[3], R[2], Qf[3];
     T u_lb[2], u_ub[2];
     T rate_lim[4];       // du_lb0, du_lb1, du_ub0, du_ub1
-    T tol, mu_init;
+    T tol, mu_init, mu_init_warm;
     // collision avoidance (wave kernel only)
     int n_obst, n_vert, obst_rows, footprint_kind;
     T d_min, force_incl, cutoff, fp_radius;

@@ -34,6 +34,7 @@ inline void fill_problem(const mpc_config& c, mpc::Problem<T>& P) {
     const bool f32 = sizeof(T) == 4;
     P.tol = T(c.tol > 0 ? c.tol : (f32 ? 1e-4 : 1e-8));
     P.mu_init = T(c.mu_init > 0 ? c.mu_init : 0.1);
+    P.mu_init_warm = T(c.mu_init_warm > 0 ? c.mu_init_warm : (c.mu_init > 0 ? c.mu_init : 0.1));
     P.n_obst = c.max_obstacles > 0 ? c.max_obstacles : 0;
     P.n_vert = c.max_vertices > 0 ? c.max_vertices : 1;
     P.obst_rows = P.n_obst > 0 ? (c.max_obstacle_rows > 0 ? c.max_obstacle_rows : 4) : 0;

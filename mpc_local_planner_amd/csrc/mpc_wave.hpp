@@ -146,6 +146,7 @@ struct IpmWave {
     T x0[3], xf[3], uprev[2], dtprev;
     T mu, rho, delta_last;
     bool row0_on, fail0;
+    bool warm_guess = false;     // the caller supplied an initial guess (second and later control cycles)
     mutable int cnt_mult = -1, cnt_bmult = -1;      // number of equality / bound multipliers (cached by kkt_pass)
     int flags;      // bits 0..2 xf_fixed, 3 dt_free, 4 quadratic objective, 5 has_Qf, 6..9 rate_on: the problem record lives in LDS and every
                     // P.x costs a ds_read (+ wait) that the compiler cannot hoist over LDS stores; one scalar register holds the switches
@@ -1286,7 +1287,7 @@ struct IpmWave {
         if (lane == 0 && dtf()) SCL(SC_D) = push_interior(SCL(SC_D), P.dt_lb, P.dt_ub);
         sync();
         if (L.M > 0) { associate_obstacles(); sync(); }
-        mu = P.mu_init; rho = T(0); delta_last = T(0); fail0 = false;
+        mu = warm_guess ? P.mu_init_warm : P.mu_init; rho = T(0); delta_last = T(0); fail0 = false;
         const T d = SCL(SC_D);
         for (int k = lane; k < n; k += kWave) {
             for (int q = 0; q < 4; ++q) {
