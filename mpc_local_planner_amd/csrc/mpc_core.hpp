@@ -141,6 +141,17 @@ MPC_HD double t_atan(double a) { return ::atan(a); }
 MPC_HD float t_atan(float a) { return ::atanf(a); }
 MPC_HD double t_asin(double a) { return ::asin(a); }
 MPC_HD float t_asin(float a) { return ::asinf(a); }
+// reciprocal: hardware seed + two Newton steps on the device (the IEEE division sequence is ~40 instructions), 1/x on the host
+MPC_HD double t_rcp(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+#else
+    return 1.0 / x;
+#endif
+}
+MPC_HD float t_rcp(float x) { return 1.0f / x; }
 // ---- fp64 sine / cosine / tangent for the arguments this solver produces (angles wrapped to [-pi, pi), steering angles
 //      inside their box): Cody-Waite reduction by pi/2 (two FMAs, exact for the quadrant counts that occur) and the classic
 //      degree-13/14 minimax kernels on [-pi/4, pi/4] (Sun fdlibm coefficients).  ~40 instructions instead of the several hundred
@@ -170,31 +181,26 @@ MPC_HD void sincos_reduced(double x, double* sp, double* cp) {
     *cp = ((q + 1) & 2) ? -c1 : c1;
 }
 MPC_HD void t_sincos(double a, double* s, double* c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    sincos_reduced(a, s, c);        // device callers pass wrapped angles / boxed steering angles only (no large-argument path, no branch)
+#else
     if (a > -1e5 && a < 1e5) sincos_reduced(a, s, c);
     else ::sincos(a, s, c);
+#endif
 }
 MPC_HD void t_sincos(float a, float* s, float* c) { ::sincosf(a, s, c); }
 MPC_HD double t_tan(double a) {
+#if !defined(__HIP_DEVICE_COMPILE__)
     if (!(a > -1e5 && a < 1e5)) return ::tan(a);
+#endif
     double s, c;
     sincos_reduced(a, &s, &c);
-    return s / c;
+    return s * t_rcp(c);
 }
 MPC_HD float t_tan(float a) { return ::tanf(a); }
 // false for NaN and +-inf.  (Not `(a - a) == 0`: with FMA contraction `a` = x*y turns that into fma(x, y, -(x*y)), the rounding
 // error of the product, which is not zero.)
 template <typename T> MPC_HD bool t_finite(T a) { return __builtin_isfinite(a); }
-// reciprocal: hardware seed + two Newton steps on the device (the IEEE division sequence is ~40 instructions), 1/x on the host
-MPC_HD double t_rcp(double x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    double r = __builtin_amdgcn_rcp(x);
-    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-    return __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
-#else
-    return 1.0 / x;
-#endif
-}
-MPC_HD float t_rcp(float x) { return 1.0f / x; }
 
 // include/mpc_local_planner/utils/math_utils.h:81-91
 template <typename T>
@@ -224,6 +230,22 @@ MPC_HD void t_frexp(float a, float* m, int* e) {
     *m = ::frexpf(a, e);
 #endif
 }
+// log(m) for a frexp mantissa m in [0.5, 1) (or any m in ~[0.35, 1.42]): the kernel of the classic fdlibm log --
+// f = m' - 1 with m' in [sqrt(1/2), sqrt(2)), s = f / (2 + f), log(1 + f) = f - hfsq + s (hfsq + R(s^2)) -- one reciprocal and
+// 14 FMAs instead of the general routine (exponent handling, sub-normals, special values).  Non-positive m yields NaN.
+MPC_HD double log_mantissa(double m) {
+    const bool lo = m < 0.70710678118654752440;
+    const double f = (lo ? m + m : m) - 1.0;
+    const double s = f * t_rcp(2.0 + f), z = s * s, w = z * z;
+    const double t1 = w * (3.999999999940941908e-01 + w * (2.222219843214978396e-01 + w * 1.531383769920937332e-01));
+    const double t2 = z * (6.666666666666735130e-01 + w * (2.857142874366239149e-01 + w * (1.818357216161805012e-01 + w * 1.479819860511658591e-01)));
+    const double hfsq = 0.5 * f * f;
+    const double r = f - (hfsq - s * (hfsq + (t1 + t2)));
+    const double out = lo ? r - 0.69314718055994530942 : r;
+    return m > 0.0 ? out : (m - m) / (m - m) + __builtin_nan("");
+}
+MPC_HD float log_mantissa(float m) { return t_log(m); }
+
 template <typename T>
 struct LogAcc {
     T m;
@@ -234,7 +256,7 @@ struct LogAcc {
         t_frexp(m * a, &mm, &ee);
         m = mm; e += ee;
     }
-    MPC_HD T value() const { return t_log(m) + T(e) * T(0.69314718055994530942); }
+    MPC_HD T value() const { return log_mantissa(m) + T(e) * T(0.69314718055994530942); }
 };
 
 // Model functions: f, G = df/d(theta,v,w), and the lambda-contracted second derivative.

@@ -68,3 +68,4 @@ extern "C" int hostdbg_solve(const mpc_config* cfg, int B, const double* x0, con
 extern "C" void hostdbg_trig(int n, const double* x, double* s, double* c, double* t) {
     for (int i = 0; i < n; ++i) { mpc::t_sincos(x[i], &s[i], &c[i]); t[i] = mpc::t_tan(x[i]); }
 }
+extern "C" void hostdbg_log_mantissa(int n, const double* m, double* out) { for (int i = 0; i < n; ++i) out[i] = mpc::log_mantissa(m[i]); }

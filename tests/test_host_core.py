@@ -126,3 +126,15 @@ def test_device_core_on_host_warm_start_golden(host):
     assert (st == 0).all()
     assert np.abs(xo - g["x"]).max() < 1e-6 and np.abs(do - g["dt"]).max() < 1e-8
     assert (np.abs(it - g["iters"]) <= 2).all()
+
+
+def test_log_of_frexp_mantissa_matches_libm(host):
+    """LogAcc::value() evaluates log only on a frexp mantissa in [0.5, 1): mpc_core.hpp::log_mantissa (fdlibm kernel, <= 1 ulp)."""
+    m = np.concatenate([np.linspace(0.5, 1.0, 200001)[:-1], [0.5, 0.70710678118654746, 0.7071067811865476, 0.9999999999999999]])
+    out = np.empty_like(m)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    host.hostdbg_log_mantissa(C.c_int(m.size), p(m), p(out))
+    assert np.abs(out - np.log(m)).max() < 2.3e-16
+    bad = np.array([0.0, -0.6]); o2 = np.empty_like(bad)
+    host.hostdbg_log_mantissa(C.c_int(2), p(bad), p(o2))
+    assert np.isnan(o2).all()
