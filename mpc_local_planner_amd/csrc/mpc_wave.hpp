@@ -1335,7 +1335,7 @@ struct IpmWave {
         eval_point(SCL(SC_D), theta_c, fobj);
         sync();
         int it = 0, status = ST_MAX_ITER;
-        T e0 = T(0), logs_cur = T(0);
+        T e0 = T(0), logs_cur = T(0), dc_mu = T(-1), dc_val = T(0);
         bool have_logs = false;
 #ifdef MPC_PROFILE
         long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int nfac = 0, ntrial = 0;
@@ -1367,7 +1367,8 @@ struct IpmWave {
             }
             MPC_TICK(1, stage_barrier_terms(); sync());
             const T tau = t_max(Algo<T>::tau_min, T(1) - mu);
-            const T dc = nfix > 0 ? Algo<T>::delta_c * t_pow(mu, Algo<T>::kappa_c) : T(0);
+            if (mu != dc_mu) { dc_mu = mu; dc_val = nfix > 0 ? Algo<T>::delta_c * t_pow(mu, Algo<T>::kappa_c) : T(0); }   // pow() only when mu moved
+            const T dc = dc_val;
             T delta = (fail0 && delta_last > T(0)) ? t_max(Algo<T>::delta_min, Algo<T>::kappa_minus * delta_last) : T(0);
             const bool started_zero = delta == T(0);
             bool ok = false;
