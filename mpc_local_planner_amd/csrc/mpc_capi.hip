@@ -223,7 +223,7 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         set_err("mpc_create: obstacle capacities out of range (max_obstacles <= 256, max_vertices <= 64, max_obstacle_rows <= 16)"); return MPC_EINVAL; }
     if (cfg->max_obstacles > 0 && cfg->footprint_kind != MPC_FOOTPRINT_POINT && cfg->footprint_kind != MPC_FOOTPRINT_CIRCLE) {
         set_err("mpc_create: only point and circular footprints are implemented"); return MPC_EINVAL; }
-    if (cfg->integral_form) { set_err("mpc_create: integral_form costs are not implemented (the example configurations use the sum form)"); return MPC_EINVAL; }
+    if (cfg->integral_form && cfg->dt_free) { set_err("mpc_create: integral_form costs are implemented for the fixed-dt grid only (dt_free = 0)"); return MPC_EINVAL; }
     for (int j = 0; j < 2; ++j)
         if (!(cfg->u_lb[j] < cfg->u_ub[j])) { set_err("mpc_create: control box must be finite and non-empty"); return MPC_EINVAL; }
     int ndev = 0;

@@ -13,7 +13,6 @@ inline void fill_problem(const mpc_config& c, mpc::Problem<T>& P) {
     P.dt_free = c.dt_free ? 1 : 0;
     for (int i = 0; i < 3; ++i) P.xf_fixed[i] = c.xf_fixed[i] ? 1 : 0;
     P.objective = c.objective;
-    P.integral_form = c.integral_form ? 1 : 0;
     P.has_Qf = c.has_Qf ? 1 : 0;
     P.max_iter = c.max_iter > 0 ? c.max_iter : 100;
     P.p0 = T(c.model_params[0]);
@@ -21,9 +20,14 @@ inline void fill_problem(const mpc_config& c, mpc::Problem<T>& P) {
     P.dt_ref = T(c.dt_ref);
     P.dt_lb = T(c.dt_lb);
     P.dt_ub = T(c.dt_ub);
-    for (int i = 0; i < 3; ++i) { P.Q[i] = T(c.Q[i]); P.Qf[i] = T(c.Qf[i]); }
+    // integral form on the fixed-dt grid (quadratic_cost_se2.cpp:54-83, left sum finite_differences_grid_se2.cpp:61-75): every stage
+    // term is multiplied by the constant dt, i.e. the weights are scaled; the terminal cost is not.  (dt free + integral form couples
+    // the states with dt in the Hessian and is rejected by mpc_create.)
+    const double wsc = (c.integral_form && !c.dt_free) ? c.dt_ref : 1.0;
+    P.integral_form = 0;
+    for (int i = 0; i < 3; ++i) { P.Q[i] = T(c.Q[i] * wsc); P.Qf[i] = T(c.Qf[i]); }
     for (int j = 0; j < 2; ++j) {
-        P.R[j] = T(c.R[j]);
+        P.R[j] = T(c.R[j] * wsc);
         P.u_lb[j] = T(c.u_lb[j]);
         P.u_ub[j] = T(c.u_ub[j]);
         P.rate_on[j] = c.du_lb[j] > -1e29 ? 1 : 0;

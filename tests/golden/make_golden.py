@@ -65,7 +65,7 @@ def make_obstacles(name, n=30, B=10, O=6, V=6, M=4, keep=6):
     print(name, "kept", len(sel), "iters", IT)
 
 
-if __name__ == "__main__" and "--warm" not in sys.argv:
+if __name__ == "__main__" and "--warm" not in sys.argv and "--integral" not in sys.argv:
     make_obstacles("unicycle_quadratic_obstacles_n30")
     make("carlike_min_time_n50", R.config_carlike_min_time(50), W.carlike_min_time_inputs(32, seed=101), keep=8)
     make("carlike_min_time_n20", R.config_carlike_min_time(20), W.carlike_min_time_inputs(32, seed=102, goal_range=(1.0, 2.5)), keep=8)
@@ -102,3 +102,25 @@ def make_warm(name, n=20, keep=6):
 
 if __name__ == "__main__" and "--warm" in sys.argv:
     make_warm("carlike_min_time_n20_warm")
+
+
+def make_integral(name, n=20, keep=6):
+    """quadratic INTEGRAL-form cost on the fixed-dt grid (quadratic_cost_se2.cpp:54-83 + left sum): numpy oracle only."""
+    x0, xf, up, dtp = W.unicycle_quadratic_inputs(16, seed=106)
+    cfg = R.config_unicycle_quadratic(n)
+    cfg.integral_form = True
+    rows = []
+    for i in range(x0.shape[0]):
+        if len(rows) >= keep:
+            break
+        inp = R.CycleInputs(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=float(dtp[i]))
+        ref = I.solve(cfg, inp, R.cold_start(cfg, x0[i], xf[i]), opt=I.IpmOptions(globalization="merit", max_iter=100))
+        if ref.status != 0 or ref.iters > 45:
+            continue
+        rows.append(dict(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=dtp[i], x=ref.traj.x, u=np.vstack([ref.traj.u, ref.traj.u[-1:]]), dt=ref.traj.dt, iters=ref.iters))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **{k: np.array([r[k] for r in rows]) for k in rows[0]})
+    print(name, "kept", len(rows), "iters", [r["iters"] for r in rows])
+
+
+if __name__ == "__main__" and "--integral" in sys.argv:
+    make_integral("unicycle_quadratic_integral_n20")

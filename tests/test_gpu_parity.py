@@ -317,3 +317,16 @@ def test_mixed_grid_sizes_in_one_batch(m):
     r2 = s.solve(g50["x0"], g50["xf"], g50["u_prev"], g50["dt_prev"])
     assert np.abs(r2.x - g50["x"]).max() < 1e-6
     s.close()
+
+
+def test_integral_form_fixed_grid_golden(m):
+    """quadratic INTEGRAL-form cost (quadratic_cost_se2.cpp:54-83) on the fixed-dt grid; with dt free it is rejected."""
+    g = np.load(os.path.join(GOLD, "unicycle_quadratic_integral_n20.npz"))
+    s = m.BatchSolver(m.config_unicycle_quadratic(20, integral_form=True), max_batch=g["x0"].shape[0])
+    r = s.solve(g["x0"], g["xf"], g["u_prev"], g["dt_prev"])
+    assert (r.status == 0).all()
+    assert np.abs(r.x - g["x"]).max() < 1e-6 and np.abs(r.u - g["u"]).max() < 1e-6
+    assert (np.abs(r.iters - g["iters"]) <= 2).all()
+    s.close()
+    with pytest.raises(m.MpcError):
+        m.BatchSolver(m.make_config(objective=m._abi.OBJ_QUADRATIC, Q=(1, 1, 1), R=(1, 1), integral_form=True, dt_free=True), max_batch=1)

@@ -21,8 +21,9 @@ GOLD = os.path.join(HERE, "golden")
 
 @pytest.fixture(scope="module")
 def host():
-    core = os.path.join(HERE, "..", "mpc_local_planner_amd", "csrc", "mpc_core.hpp")
-    if not os.path.exists(OUT) or os.path.getmtime(OUT) < max(os.path.getmtime(SRC), os.path.getmtime(core)):
+    csrc = os.path.join(HERE, "..", "mpc_local_planner_amd", "csrc")
+    deps = [SRC, os.path.join(csrc, "mpc_core.hpp"), os.path.join(csrc, "mpc_problem.hpp"), os.path.join(HERE, "..", "include", "mpc_hip.h")]
+    if not os.path.exists(OUT) or os.path.getmtime(OUT) < max(os.path.getmtime(d) for d in deps):
         os.makedirs(os.path.dirname(OUT), exist_ok=True)
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", SRC, "-o", OUT], check=True)
     return C.CDLL(OUT)
@@ -138,3 +139,13 @@ def test_log_of_frexp_mantissa_matches_libm(host):
     bad = np.array([0.0, -0.6]); o2 = np.empty_like(bad)
     host.hostdbg_log_mantissa(C.c_int(2), p(bad), p(o2))
     assert np.isnan(o2).all()
+
+
+def test_device_core_on_host_integral_form_golden(host):
+    """integral-form quadratic cost on the fixed-dt grid = weights scaled by dt (mpc_problem.hpp); numpy-oracle fixture"""
+    g = np.load(os.path.join(GOLD, "unicycle_quadratic_integral_n20.npz"))
+    cfg = A.config_unicycle_quadratic(20, integral_form=True)
+    xo, uo, do, st, it, kkt = host_solve(host, cfg, g["x0"], g["xf"], g["u_prev"], g["dt_prev"])
+    assert (st == 0).all()
+    assert np.abs(xo - g["x"]).max() < 1e-6 and np.abs(uo - g["u"]).max() < 1e-6
+    assert (np.abs(it - g["iters"]) <= 2).all()
