@@ -784,16 +784,10 @@ struct IpmWave {
         T om = T(0), wn[3] = {T(0), T(0), T(0)};
         T worst = T(1);                                                   // min over the stages of |det R| - 1e-14 * scale
         auto load_stage = [&](T (&g)[3], T (&a)[8]) {                     // reads the stage the running pointers are at, then steps them
-#if defined(MPC_EXP) && (MPC_EXP & 1)
-            g[0] = gp[0]; g[1] = g[0] * T(0.5); g[2] = g[0] * T(0.25);
-            for (int r = 0; r < 8; ++r) a[r] = g[0] * T(r);
-            gp -= gs;
-#else
             g[0] = gp[0]; g[1] = gp[1]; g[2] = gp[2];
             gp -= gs;
 #pragma unroll
             for (int r = 0; r < 8; ++r) { a[r] = *ap[r]; ap[r] -= as_[r]; }
-#endif
         };
         auto stage = [&](T dk0, T dk1, T dk2, T s5, T (&G)[3], T (&A)[8], T (&Gn)[3], T (&An)[8]) {
             load_stage(Gn, An);                                           // prefetch of the next stage (k - 1)
@@ -833,10 +827,8 @@ struct IpmWave {
             const T nid = -fast_rcp(det);
             const T nRi00 = R11 * nid, Ri01 = -(R01 * nid), nRi11 = R00 * nid;  // -R^-1 = [nRi00 Ri01; Ri01 nRi11]
             const T nK0 = nRi00 * h[6] + Ri01 * h[7], nK1 = Ri01 * h[6] + nRi11 * h[7];
-#if !(defined(MPC_EXP) && (MPC_EXP & 2))
             kp[0] = nK0; kp[10] = nK1;
             kp -= ks;
-#endif
             // W[a][b] -= Su[:,a]' Knu[:,b] in lane 9+b, omega[a] -= Su[:,a]' kappa in lane 8 (Su[j][a] = Hhat[6+j][9+a]);
             // V = Hhat_xx + Hhat_xu nK   (row i of Hhat[:,6:8] = lane i's Hhat[6:8][.])
             V[0] = h[0]; V[1] = h[1]; V[2] = h[2]; V[3] = h[3]; V[4] = h[4]; V[5] = h[5];
