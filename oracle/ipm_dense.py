@@ -419,6 +419,8 @@ class IpmResult:
     lam: np.ndarray
     y: np.ndarray
     history: list
+    piL: Optional[np.ndarray] = None     # multipliers of the lower / upper variable bounds (for dual_start of the next cycle)
+    piU: Optional[np.ndarray] = None
 
 
 def controls_from_states(cfg: R.OcpConfig, init: R.Trajectory) -> R.Trajectory:
@@ -456,7 +458,11 @@ def controls_from_states(cfg: R.OcpConfig, init: R.Trajectory) -> R.Trajectory:
 
 
 def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=None,
-          opt: Optional[IpmOptions] = None) -> IpmResult:
+          opt: Optional[IpmOptions] = None, dual_start: Optional[IpmResult] = None) -> IpmResult:
+    """dual_start: result of the previous control cycle of the same problem structure.  Its multipliers are carried over
+    (moving-horizon warm start of the duals): every inequality / bound multiplier is max(previous value, mu0 / slack) so
+    that no complementarity product starts below the barrier parameter; slacks are re-derived from the new point; the
+    collocation multipliers are taken as they are.  Ignored when the structure (row / variable counts) differs."""
     opt = opt or IpmOptions()
     nlp = SolverNlp(cfg, inp, relevant)
     nv, mc, mg = nlp.nv, nlp.mc, nlp.mg
@@ -480,6 +486,12 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
     lam = np.zeros(mc)
     piL = np.where(hasL, mu / np.maximum(v - lb, 1e-300), 0.0)
     piU = np.where(hasU, mu / np.maximum(ub - v, 1e-300), 0.0)
+    ds = dual_start
+    if ds is not None and ds.piL is not None and ds.lam.shape == lam.shape and ds.y.shape == y.shape and ds.piL.shape == piL.shape:
+        lam = ds.lam.copy()
+        y = np.maximum(ds.y, y)
+        piL = np.where(hasL, np.maximum(ds.piL, piL), 0.0)
+        piU = np.where(hasU, np.maximum(ds.piU, piU), 0.0)
     delta_last = 0.0
     rho = 0.0
     nfix_term = sum(cfg.xf_fixed)
@@ -722,4 +734,4 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
 
     ev = nlp.eval(v, lam, y)
     e0 = kkt_err(ev, v, s, lam, y, piL, piU, 0.0)
-    return IpmResult(nlp.to_traj(v), status, it, e0, ev["f"], lam, y, history)
+    return IpmResult(nlp.to_traj(v), status, it, e0, ev["f"], lam, y, history, piL, piU)

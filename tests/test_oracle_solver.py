@@ -151,3 +151,27 @@ def test_numpy_ipm_with_obstacle_rows_reproduces_golden_and_keeps_clearance():
         nlp = R.ReferenceNlp(cfg, inp, relevant=rel)
         gz = nlp.inequalities(nlp.pack(res.traj))
         assert gz.max() < 1e-7
+
+
+def test_dual_start_lands_on_the_same_solution():
+    """Oracle-only feature for the next step of the warm start: multipliers of the previous cycle carried
+    over as max(previous, mu0 / slack).  Second control cycle of a golden instance: same solution, not more iterations + 2."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "carlike_min_time_n20.npz"))
+    cfg = R.config_carlike_min_time(20)
+    i, per = 3, 0.2
+    inp = R.CycleInputs(x0=g["x0"][i], xf=g["xf"][i], u_prev=g["u_prev"][i], dt_prev=float(g["dt_prev"][i]))
+    r1 = I.solve(cfg, inp, R.cold_start(cfg, inp.x0, inp.xf), opt=I.IpmOptions(globalization="merit", max_iter=100))
+    assert r1.status == 0 and r1.piL is not None
+    u0 = r1.traj.u[0]
+    x1 = inp.x0 + per * R.dynamics(cfg.model, cfg.model_params, inp.x0, u0)
+    x1[2] = R.normalize_theta(x1[2])
+    init = R.Trajectory(r1.traj.x.copy(), r1.traj.u.copy(), r1.traj.dt)
+    init.x[0] = x1
+    inp2 = R.CycleInputs(x0=x1, xf=g["xf"][i], u_prev=u0, dt_prev=per)
+    opt = I.IpmOptions(globalization="merit", max_iter=100, mu_init=1e-3)
+    a = I.solve(cfg, inp2, init, opt=opt)
+    b = I.solve(cfg, inp2, init, opt=opt, dual_start=r1)
+    assert a.status == 0 and b.status == 0
+    assert np.abs(a.traj.x - b.traj.x).max() < 1e-8 and abs(a.traj.dt - b.traj.dt) < 1e-9
+    assert b.iters <= a.iters + 2
