@@ -9,10 +9,11 @@
 //   lane-parallel over the horizon (lane k <-> interval k / grid point k / rate row k):
 //       residuals + KKT error, per-stage LQ data (dynamics Jacobians, Lagrangian curvature, condensed
 //       barrier terms), step post-processing (slack/dual steps, fraction-to-boundary), line-search
-//       trial evaluation, acceptance.  Scalars are combined with wavefront reductions (DPP/bpermute).
-//   wave-uniform (every lane executes the same scalar recurrence on broadcast LDS reads, lane 0 stores):
-//       backward Riccati sweep over the augmented stage state (x_k, u_{k-1}, dt), forward state
-//       recurrence, costate (multiplier) recurrence.
+//       trial evaluation (register-resident), acceptance.  Scalars are combined with DPP wavefront reductions.
+//   serial over the horizon, parallel INSIDE a stage (registers + DP-ALU DPP broadcasts, no LDS hand-offs):
+//       backward Riccati sweep over the augmented stage state (x_k, u_{k-1}, dt): lane c owns column c of the
+//       value block and of the stage Hessian (backward_dpp); forward state recurrence: lane c owns component c
+//       of (dx, du) (forward_states); the costate (multiplier) recurrence is two wave suffix scans.
 // The arithmetic is the same as mpc_core.hpp (lane-per-instance variant); see that file for the
 // reference citations of every formula.
 #pragma once
@@ -28,10 +29,10 @@ __device__ long long g_mpc_prof[4096][16];
 namespace mpc {
 
 constexpr int kWave = 64;
-// per-stage LQ record: 0,1 a0,a1 | 2..4 f | 5..10 B[a][j] at 5+2a+j | 11..37 combined stage cost A[StageAdd]
+// per-stage LQ record: 0..2 a0 a1 1 | 3..5 f | 6..8 Bx[:,0] | 9..11 Bx[:,1] | 12..38 combined stage cost A[StageAdd]
 constexpr int NSTG = 39;
 constexpr int RA = 12;     // first A slot (words 0..11: a0 a1 1 | f | Bx[:,0] | Bx[:,1])
-constexpr int NGAIN = 20;  // K(2x6) kappa(2) Knu(2x3)
+constexpr int NGAIN = 20;  // negated gains: nK0(6) nkappa0 nKnu0(3) | nK1(6) nkappa1 nKnu1(3)
 
 struct WaveLayout {
     int n, NS;
@@ -159,7 +160,7 @@ struct IpmWave {
 
     // ---- LDS accessors: component-major, stage-minor (conflict-free for lane == stage)
     __device__ __forceinline__ T& F(int base, int comp, int k) const { return sm[base + comp * L.NS + k]; }
-    // stage-major records (one base address + immediate offsets in the wave-uniform sweeps)
+    // stage-major records
     __device__ __forceinline__ T& G_(int i, int k) const { return sm[L.GAIN + k * NGAIN + i]; }
     __device__ __forceinline__ T& S_(int i, int k) const { return sm[L.STG + k * NSTG + i]; }
     __device__ __forceinline__ T& C_(int i, int k) const { return sm[L.CC + k * 3 + i]; }
@@ -678,7 +679,7 @@ struct IpmWave {
         }
     }
 
-    // ---------------------------------------------------------------- wave-uniform backward Riccati sweep
+    // ---------------------------------------------------------------- backward Riccati sweep
     // ---------------------------------------------------------------- backward Riccati sweep
     __device__ __forceinline__ T fast_rcp(double x) const {
         double r = __builtin_amdgcn_rcp(x);
@@ -920,7 +921,7 @@ struct IpmWave {
         return v + (row == 0 ? c0 : (row == 1 ? c1 : (row == 2 ? c2 : T(0))));
     }
 
-    // state recurrence (wave-uniform, software-pipelined LDS reads) then multipliers by lane-parallel suffix scans
+    // state recurrence (one component per lane, DPP broadcasts, prefetched coefficients) then multipliers by lane-parallel suffix scans
     __device__ __forceinline__ void forward_states(T dd, const T nu[3], T delta) const {
         const int n = L.n;
         // ---- lane-parallel: fold nu and dd into the affine terms so that the serial loop only carries (x, u_prev)
