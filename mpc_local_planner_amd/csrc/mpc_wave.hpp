@@ -680,7 +680,6 @@ struct IpmWave {
     }
 
     // ---------------------------------------------------------------- backward Riccati sweep
-    // ---------------------------------------------------------------- backward Riccati sweep
     __device__ __forceinline__ T fast_rcp(double x) const {
         double r = __builtin_amdgcn_rcp(x);
         r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
