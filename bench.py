@@ -78,7 +78,7 @@ def measured_traffic(n, B):
         rec = json.load(open(path))
     except (OSError, ValueError):
         return None
-    if rec.get("n") == n and rec.get("batch") == B and os.environ.get("MPC_HIP_KERNEL", "wave") == rec.get("kernel", "wave"):
+    if rec.get("n") == n and rec.get("batch") == B:
         return rec.get("bytes_per_launch")
     return None
 
@@ -207,7 +207,7 @@ def main():
                        "iters_max": int(iters.max())},
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": measured_traffic(n, B),
-                         "kernel": "mpc_ipm_solve_kernel" if os.environ.get("MPC_HIP_KERNEL") == "lane" else "mpc_ipm_wave_kernel",
+                         "kernel": "mpc_ipm_wave_kernel",
                          "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "latency/FP64-issue bound by construction (SURVEY.md 8d): compulsory traffic is ~4 KB per solve",

@@ -28,7 +28,9 @@ void set_err(const char* what) { snprintf(g_err, sizeof(g_err), "%s", what); }
         if (e_ != hipSuccess) { set_err(#call, e_); return MPC_EHIP; } \
     } while (0)
 
-constexpr int kLanes = 64;   // one wavefront per workgroup: instances spread over as many CUs as possible
+constexpr int kLanes = 64;
+
+#ifdef MPC_ENABLE_LANE_KERNEL   // developer builds only: the lane-per-instance kernel is NOT part of the product
 
 // One lane = one planner instance.  Inputs/outputs are instance-major (ABI layout); the iterate,
 // duals and Riccati gains live in the instance-minor workspace `ws`.
@@ -80,6 +82,8 @@ __global__ __launch_bounds__(kLanes) void mpc_ipm_solve_kernel(
     if (iters) iters[inst] = st.iters;
 }
 
+
+#endif
 
 // One wavefront = one planner instance; the whole working set lives in LDS (mpc_wave.hpp).
 template <typename T, int MODEL>
@@ -250,12 +254,21 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
     s->wave_lds = ((((size_t)s->WL.total * (cfg->precision == MPC_FP32 ? 4 : 8)) + 15) & ~(size_t)15) + 16 +
                   ((cfg->precision == MPC_FP32 ? sizeof(mpc::Problem<float>) : sizeof(mpc::Problem<double>)) + 15 & ~(size_t)15) + sizeof(mpc::WaveLayout);
     s->use_wave = (s->wave_lds <= 160u * 1024u) ? 1 : 0;
+#ifdef MPC_ENABLE_LANE_KERNEL
+    if (const char* ev = getenv("MPC_HIP_KERNEL")) { if (!strcmp(ev, "lane")) s->use_wave = 0; }
     if (cfg->max_obstacles > 0 && !s->use_wave) {
         set_err("mpc_create: obstacles need the LDS-resident kernel; this (n, max_obstacles, max_vertices) does not fit in 160 KB of LDS");
         delete s;
         return MPC_EINVAL;
     }
-    if (const char* ev = getenv("MPC_HIP_KERNEL")) { if (!strcmp(ev, "lane")) s->use_wave = 0; else if (!strcmp(ev, "wave") && s->wave_lds <= 160u * 1024u) s->use_wave = 1; }
+#else
+    if (!s->use_wave) {
+        set_err("mpc_create: the working set of one instance (n, max_obstacles, max_vertices, precision) does not fit in the 160 KB of LDS "
+                "of a compute unit (about n <= 215 grid points in fp64 without obstacles)");
+        delete s;
+        return MPC_EINVAL;
+    }
+#endif
     s->device = device;
     s->max_batch = max_batch;
     s->stride = ((long)max_batch + kLanes - 1) / kLanes * kLanes;
@@ -264,7 +277,9 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
     hipError_t er = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
     if (er == hipSuccess) er = hipEventCreate(&s->ev0);
     if (er == hipSuccess) er = hipEventCreate(&s->ev1);
-    if (er == hipSuccess) er = hipMalloc(&s->ws, (size_t)s->L.total * s->stride * tsz);
+#ifdef MPC_ENABLE_LANE_KERNEL
+    if (er == hipSuccess && !s->use_wave) er = hipMalloc(&s->ws, (size_t)s->L.total * s->stride * tsz);
+#endif
     const size_t Bm = max_batch;
     if (er == hipSuccess) er = hipMalloc((void**)&s->d_x0, Bm * 3 * 8);
     if (er == hipSuccess) er = hipMalloc((void**)&s->d_xf, Bm * 3 * 8);
@@ -323,9 +338,13 @@ static hipError_t launch_model(mpc_solver* s, const mpc::Problem<T>& P, int B, c
         }
         hipLaunchKernelGGL(kern, dim3(B), dim3(mpc::kWave), s->wave_lds, s->stream, P, s->WL, B, x0, xf, up, dtp, xi, ui, dti, ob, s->use_ngrid ? s->d_ngrid : nullptr, xo, uo, dto, st, it);
     } else {
+#ifdef MPC_ENABLE_LANE_KERNEL
         dim3 grid((B + kLanes - 1) / kLanes), block(kLanes);
         hipLaunchKernelGGL((mpc_ipm_solve_kernel<T, MODEL>), grid, block, 0, s->stream, P, s->L, (T*)s->ws, s->stride, B, x0, xf, up,
                            dtp, xi, ui, dti, xo, uo, dto, st, it);
+#else
+        return hipErrorInvalidConfiguration;
+#endif
     }
     return hipSuccess;
 }

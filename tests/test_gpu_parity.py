@@ -330,3 +330,4 @@ def test_integral_form_fixed_grid_golden(m):
     s.close()
     with pytest.raises(m.MpcError):
         m.BatchSolver(m.make_config(objective=m._abi.OBJ_QUADRATIC, Q=(1, 1, 1), R=(1, 1), integral_form=True, dt_free=True), max_batch=1)
+
