@@ -65,7 +65,7 @@ def make_obstacles(name, n=30, B=10, O=6, V=6, M=4, keep=6):
     print(name, "kept", len(sel), "iters", IT)
 
 
-if __name__ == "__main__" and "--warm" not in sys.argv and "--integral" not in sys.argv:
+if __name__ == "__main__" and "--warm" not in sys.argv and "--integral" not in sys.argv and "--closed-loop" not in sys.argv:
     make_obstacles("unicycle_quadratic_obstacles_n30")
     make("carlike_min_time_n50", R.config_carlike_min_time(50), W.carlike_min_time_inputs(32, seed=101), keep=8)
     make("carlike_min_time_n20", R.config_carlike_min_time(20), W.carlike_min_time_inputs(32, seed=102, goal_range=(1.0, 2.5)), keep=8)
@@ -124,3 +124,35 @@ def make_integral(name, n=20, keep=6):
 
 if __name__ == "__main__" and "--integral" in sys.argv:
     make_integral("unicycle_quadratic_integral_n20")
+
+
+def make_closed_loop(name, n=20, cycles=40):
+    """SURVEY 8c level 3: closed loop of BASELINE config 1 (unicycle, quadratic form, fixed dt, free goal + Qf): the plant is advanced
+    one 0.2 s period with u_0 (explicit Euler), the next cycle starts from the SHIFTED previous solution (fixed grid:
+    warmStartShifting, full_discretization_grid_base_se2.cpp:241-339) with x0 overwritten.  Every cycle is stored with its inputs,
+    so the cycles can be re-solved independently (one GPU batch)."""
+    cfg = R.config_unicycle_quadratic(n)
+    per = 0.2
+    x0 = np.array([0.0, 0.0, 0.0]); xf = np.array([1.0, 0.3, 0.2]); up = np.zeros(2)
+    rows = []
+    prev = None
+    for c in range(cycles):
+        inp = R.CycleInputs(x0=x0.copy(), xf=xf, u_prev=up.copy(), dt_prev=per)
+        if prev is None:
+            init = R.cold_start(cfg, x0, xf)
+        else:
+            init = R.new_run_overwrite(cfg, R.warm_start_shifting(prev, x0), x0, xf)
+        ref = I.solve(cfg, inp, init, opt=I.IpmOptions(globalization="merit", max_iter=100))
+        assert ref.status == 0, (c, ref.status)
+        rows.append(dict(x0=x0.copy(), xf=xf.copy(), u_prev=up.copy(), dt_prev=per, x_init=init.x.copy(), u_init=np.vstack([init.u, init.u[-1:]]),
+                         dt_init=init.dt, x=ref.traj.x, u=np.vstack([ref.traj.u, ref.traj.u[-1:]]), dt=ref.traj.dt, iters=ref.iters))
+        prev = ref.traj
+        up = ref.traj.u[0].copy()
+        x0 = x0 + per * R.dynamics(cfg.model, cfg.model_params, x0, up)
+        x0[2] = R.normalize_theta(x0[2])
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **{k: np.array([r[k] for r in rows]) for k in rows[0]})
+    print(name, "cycles", len(rows), "iters", [r["iters"] for r in rows], "final pose", x0)
+
+
+if __name__ == "__main__" and "--closed-loop" in sys.argv:
+    make_closed_loop("unicycle_quadratic_closed_loop_n20")

@@ -331,3 +331,19 @@ def test_integral_form_fixed_grid_golden(m):
     with pytest.raises(m.MpcError):
         m.BatchSolver(m.make_config(objective=m._abi.OBJ_QUADRATIC, Q=(1, 1, 1), R=(1, 1), integral_form=True, dt_free=True), max_batch=1)
 
+
+
+def test_closed_loop_golden_config1(m):
+    """SURVEY 8c level 3 (closed loop): 40 control cycles of BASELINE config 1 generated by the numpy oracle (plant advanced with
+    u_0, fixed-grid shifted warm start); the cycles are independent given their stored inputs, so they form one GPU batch.
+    First cycle = cold start (its stored guess is the reference cold start), the others start from the shifted solution."""
+    g = np.load(os.path.join(GOLD, "unicycle_quadratic_closed_loop_n20.npz"))
+    B = g["x0"].shape[0]
+    s = m.BatchSolver(m.config_unicycle_quadratic(20), max_batch=B)
+    r = s.solve(g["x0"], g["xf"], g["u_prev"], g["dt_prev"], init=(g["x_init"], g["u_init"], g["dt_init"]))
+    assert (r.status == 0).all()
+    assert np.abs(r.x - g["x"]).max() < 1e-6 and np.abs(r.u - g["u"]).max() < 1e-6
+    assert (np.abs(r.iters - g["iters"]) <= 2).all()
+    # the commanded controls of the whole run (what the robot would have executed)
+    assert np.abs(r.u[:, 0] - g["u"][:, 0]).max() < 1e-7
+    s.close()

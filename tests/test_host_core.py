@@ -149,3 +149,13 @@ def test_device_core_on_host_integral_form_golden(host):
     assert (st == 0).all()
     assert np.abs(xo - g["x"]).max() < 1e-6 and np.abs(uo - g["u"]).max() < 1e-6
     assert (np.abs(it - g["iters"]) <= 2).all()
+
+
+def test_device_core_on_host_closed_loop_golden(host):
+    """SURVEY 8c level 3: 40 closed-loop cycles of config 1 (fixed-dt grid, shifted warm start), re-solved independently."""
+    g = np.load(os.path.join(GOLD, "unicycle_quadratic_closed_loop_n20.npz"))
+    cfg = A.config_unicycle_quadratic(20)
+    xo, uo, do, st, it, kkt = host_solve(host, cfg, g["x0"], g["xf"], g["u_prev"], g["dt_prev"], init=(g["x_init"], g["u_init"], g["dt_init"]))
+    assert (st == 0).all()
+    assert np.abs(xo - g["x"]).max() < 1e-6 and np.abs(uo - g["u"]).max() < 1e-6
+    assert (np.abs(it - g["iters"]) <= 2).all()
