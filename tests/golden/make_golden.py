@@ -65,7 +65,7 @@ def make_obstacles(name, n=30, B=10, O=6, V=6, M=4, keep=6):
     print(name, "kept", len(sel), "iters", IT)
 
 
-if __name__ == "__main__" and "--warm" not in sys.argv and "--integral" not in sys.argv and "--closed-loop" not in sys.argv:
+if __name__ == "__main__" and "--warm" not in sys.argv and "--integral" not in sys.argv and "--closed-loop" not in sys.argv and "--config3" not in sys.argv:
     make_obstacles("unicycle_quadratic_obstacles_n30")
     make("carlike_min_time_n50", R.config_carlike_min_time(50), W.carlike_min_time_inputs(32, seed=101), keep=8)
     make("carlike_min_time_n20", R.config_carlike_min_time(20), W.carlike_min_time_inputs(32, seed=102, goal_range=(1.0, 2.5)), keep=8)
@@ -156,3 +156,8 @@ def make_closed_loop(name, n=20, cycles=40):
 
 if __name__ == "__main__" and "--closed-loop" in sys.argv:
     make_closed_loop("unicycle_quadratic_closed_loop_n20")
+
+
+if __name__ == "__main__" and "--config3" in sys.argv:
+    # BASELINE config 3 shape: n = 80, 16 polygons, at most 4 clearance rows per grid point (numpy oracle only; ~1 s per instance)
+    make_obstacles("unicycle_quadratic_obstacles_n80", n=80, B=40, O=16, V=6, M=4, keep=24)
