@@ -1153,7 +1153,11 @@ struct IpmWave {
         const T d_old = SCL(SC_D), dd = SCL(SC_DD), d_new = d_old + (dtf() ? alpha * dd : T(0));
         // phase 1: everything that reads the OLD point
         T sn[4], yn[4];
-        for (int k = lane; k < n; k += kWave) {      // (n <= 64 + ... handled by the loop; registers reused per chunk)
+        // Chunks of 64 grid points are visited from the END of the horizon: a rate row k reads the OLD u_{k-1}, which belongs to the
+        // previous chunk when k is a multiple of 64, so that chunk must not have been overwritten yet (n > 64: configs 3 and 5).
+        for (int k = ((n - 1) / kWave) * kWave + lane; k >= 0; k -= kWave) {
+            const bool act = k < n;
+            if (act) {
             for (int q = 0; q < 4; ++q) {
                 if (!row_on(k, q)) continue;
                 T s = F(L.SR, q, k), y = F(L.YR, q, k);
@@ -1181,7 +1185,9 @@ struct IpmWave {
                     F(L.OS, m, k) = so; F(L.OY, m, k) = yo;
                 }
             }
+            }
             sync();      // all lanes of this chunk have read their neighbours' old controls
+            if (act) {
             for (int q = 0; q < 4; ++q) if (row_on(k, q)) { F(L.SR, q, k) = sn[q]; F(L.YR, q, k) = yn[q]; }
             if (k < n - 1) {
                 for (int j = 0; j < 2; ++j) {
@@ -1203,6 +1209,7 @@ struct IpmWave {
                 }
             }
             for (int i = 0; i < 3; ++i) F(L.X, i, k) = xt(i, k, alpha);
+            }
         }
         if (lane == 0) {
             if (dtf()) {
@@ -1453,6 +1460,11 @@ struct IpmWave {
 #endif
                 if (t_finite(phit) && phit - phi0 - Algo<T>::ls_eps * t_abs(phi0) <= Algo<T>::eta_armijo * alpha * Dm) { accepted = true; break; }
             }
+#ifdef MPC_NANCHECK
+            if (blockIdx.x == MPC_NANCHECK && lane == 0 && !accepted)
+                printf("   ls FAILED: it %d phi0 %.12e Dm %.6e rho %.6e mu %g theta %.6e theta_c %.6e fobj %.9f logs_cur %.9f | last alpha %g f_t %.9f th_t %.6e lg_t %.9f dzmax %g a_p %g\n",
+                       it, (double)phi0, (double)Dm, (double)rho, (double)mu, (double)theta, (double)theta_c, (double)fobj, (double)logs_cur, (double)alpha, (double)f_t, (double)th_t, (double)lg_t, (double)fw.dzmax, (double)fw.a_p);
+#endif
             if (!accepted && alpha * fw.dzmax < T(1e-14)) { status = ST_LINESEARCH; break; }
 #ifdef MPC_NANCHECK
             if (blockIdx.x == MPC_NANCHECK && lane == 0)

@@ -37,6 +37,7 @@ def _load():
             build()
         _lib = C.CDLL(LIB)
         _lib.oracle_solve_batch.restype = C.c_int
+        _lib.oracle_solve_batch_obst.restype = C.c_int
         _lib.oracle_num_threads.restype = C.c_int
     return _lib
 
@@ -67,7 +68,20 @@ def num_threads() -> int:
     return int(_load().oracle_num_threads())
 
 
-def solve_batch(ocfg: OracleConfig, x0, xf, u_prev=None, dt_prev=None, init=None, nthreads=0):
+class OracleObst(C.Structure):
+    """struct oracle_obst (oracle/mpc_oracle.c): obstacle handling of a batch, same meaning as the mpc_config fields."""
+    _fields_ = [("max_obstacles", C.c_int32), ("max_vertices", C.c_int32), ("max_rows", C.c_int32),
+                ("min_obstacle_dist", C.c_double), ("force_inclusion_dist", C.c_double), ("cutoff_dist", C.c_double),
+                ("footprint_radius", C.c_double)]
+
+
+def obst_from_nlp_config(cfg, max_obstacles: int, max_vertices: int, max_rows: int) -> OracleObst:
+    fr = cfg.footprint_params[0] if getattr(cfg, "footprint_kind", 0) == 1 and cfg.footprint_params else 0.0
+    return OracleObst(max_obstacles, max_vertices, max_rows, cfg.min_obstacle_dist, cfg.force_inclusion_dist, cfg.cutoff_dist, fr)
+
+
+def solve_batch(ocfg: OracleConfig, x0, xf, u_prev=None, dt_prev=None, init=None, nthreads=0, obstacles=None, obst: "OracleObst" = None):
+    """obstacles = (n_obstacles (B,), n_vertices (B,O), vertices (B,O,V,2)[, radius (B,O)]) together with obst (OracleObst)."""
     lib = _load()
     x0 = np.ascontiguousarray(x0, float)
     xf = np.ascontiguousarray(xf, float)
@@ -80,6 +94,15 @@ def solve_batch(ocfg: OracleConfig, x0, xf, u_prev=None, dt_prev=None, init=None
         xi, ui, di = (np.ascontiguousarray(a, float) for a in init)
     xo = np.empty((B, n, 3)); uo = np.empty((B, n, 2)); do = np.empty(B)
     st = np.empty(B, np.int32); it = np.empty(B, np.int32)
+    if obstacles is not None and obst is not None:
+        no = np.ascontiguousarray(obstacles[0], np.int32)
+        nv = np.ascontiguousarray(obstacles[1], np.int32)
+        vv = np.ascontiguousarray(obstacles[2], float)
+        rr = np.ascontiguousarray(obstacles[3], float) if len(obstacles) > 3 and obstacles[3] is not None else None
+        assert nv.shape == (B, obst.max_obstacles) and vv.shape == (B, obst.max_obstacles, obst.max_vertices, 2)
+        lib.oracle_solve_batch_obst(C.byref(ocfg), C.c_int(B), p(x0), p(xf), p(up), p(dp), p(xi), p(ui), p(di), C.byref(obst), p(no), p(nv), p(vv),
+                                    p(rr), p(xo), p(uo), p(do), p(st), p(it), C.c_int(nthreads))
+        return xo, uo, do, st, it
     lib.oracle_solve_batch(C.byref(ocfg), C.c_int(B), p(x0), p(xf), p(up), p(dp), p(xi), p(ui), p(di), p(xo), p(uo), p(do), p(st), p(it),
                            C.c_int(nthreads))
     return xo, uo, do, st, it

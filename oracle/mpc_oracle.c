@@ -106,6 +106,12 @@ static void model_derivs(const oracle_config* c, double th, double v, double w, 
     }
 }
 
+/* obstacle handling of a batch: same meaning as the fields of mpc_config (include/mpc_hip.h); point or circular footprint */
+typedef struct oracle_obst {
+    int32_t max_obstacles, max_vertices, max_rows;
+    double min_obstacle_dist, force_inclusion_dist, cutoff_dist, footprint_radius;
+} oracle_obst;
+
 /* ---------------------------------------------------------------- per-instance work area */
 typedef struct {
     const oracle_config* c;
@@ -124,6 +130,13 @@ typedef struct {
     double *dz_u, *dz_x;      /* steps */
     double ddt;
     double mu, rho, delta_last;
+    /* clearance rows (stage_inequality_se2.cpp:50-175): obstacles of this instance + per grid point up to M associated rows */
+    const struct oracle_obst* ob;
+    int n_obst; const int32_t* n_vert; const double* verts; const double* radius;
+    double* cent;             /* O*2 centroids */
+    int* oi;                  /* n*M obstacle index or -1 */
+    double *os, *oy, *ost, *ods, *ody;   /* n*M slack, multiplier, trial slack, steps */
+    double *og, *oax, *oay, *ohk;        /* n*M cached value, gradient (= -unit normal), curvature 1/|p-q| (0 on an edge interior) */
 } work_t;
 
 static int iu(int k, int j) { return 8 * k + j; }
@@ -192,6 +205,105 @@ static double row_val_at(const work_t* w, const double* U, double D, int r, int 
 }
 
 /* c_k, objective at a point */
+
+/* ---------------------------------------------------------------- clearance rows
+ * distance of (px,py) to obstacle j with the teb semantics the reference links against (point / segment / closed polygon, 0 inside
+ * a polygon; an optional radius turns a 1-vertex obstacle into a circle): dist >= 0 before the radius is subtracted, unit normal
+ * from the closest point to (px,py), hk = 1/|p-q| where the closest feature is a vertex (0 on an edge interior). */
+static int obst_M(const work_t* w) { return w->ob ? w->ob->max_rows : 0; }
+static void obst_eval(const work_t* w, double px, double py, int j, double* dist, double* nx, double* ny, double* hk) {
+    const int V = w->ob->max_vertices;
+    int nv = w->n_vert[j]; if (nv > V) nv = V;
+    const double* v = w->verts + (size_t)2 * V * j;
+    double best = 1e30, bx = 0, by = 0;
+    int vert = 1;
+    if (nv <= 1) { bx = v[0]; by = v[1]; best = (px - bx) * (px - bx) + (py - by) * (py - by); }
+    else {
+        int inside = 0;
+        const int ne = nv == 2 ? 1 : nv;
+        for (int e = 0; e < ne; ++e) {
+            const int e2 = (e + 1) % nv;
+            const double ax = v[2 * e], ay = v[2 * e + 1], cx = v[2 * e2], cy = v[2 * e2 + 1];
+            const double abx = cx - ax, aby = cy - ay, sq = abx * abx + aby * aby;
+            double t = sq > 0 ? ((px - ax) * abx + (py - ay) * aby) / sq : 0.0;
+            t = fmin(1.0, fmax(0.0, t));
+            const double qx = ax + t * abx, qy = ay + t * aby;
+            const double d2 = (px - qx) * (px - qx) + (py - qy) * (py - qy);
+            if (d2 < best) { best = d2; bx = qx; by = qy; vert = !(t > 0 && t < 1); }
+            if (nv >= 3 && ((ay > py) != (cy > py)) && (px < (cx - ax) * (py - ay) / (cy - ay) + ax)) inside = !inside;
+        }
+        if (inside) { *dist = 0; *nx = 0; *ny = 0; *hk = 0; return; }
+    }
+    const double dd = sqrt(best);
+    if (dd > 0) { *nx = (px - bx) / dd; *ny = (py - by) / dd; *hk = vert ? 1.0 / dd : 0.0; }
+    else { *nx = 0; *ny = 0; *hk = 0; }
+    *dist = dd - (w->radius ? w->radius[j] : 0.0);
+}
+static void obst_centroids(work_t* w) {
+    const int V = w->ob->max_vertices;
+    for (int j = 0; j < w->n_obst; ++j) {
+        int nv = w->n_vert[j]; if (nv > V) nv = V;
+        const double* v = w->verts + (size_t)2 * V * j;
+        double cx = 0, cy = 0;
+        if (nv >= 3) {
+            double a = 0, sx = 0, sy = 0, mx = 0, my = 0;
+            for (int e = 0; e < nv; ++e) {
+                const int e2 = (e + 1) % nv;
+                const double cr = v[2 * e] * v[2 * e2 + 1] - v[2 * e2] * v[2 * e + 1];
+                a += cr; sx += (v[2 * e] + v[2 * e2]) * cr; sy += (v[2 * e + 1] + v[2 * e2 + 1]) * cr;
+                mx += v[2 * e]; my += v[2 * e + 1];
+            }
+            a *= 0.5;
+            if (fabs(a) < 1e-12) { cx = mx / nv; cy = my / nv; } else { cx = sx / (6 * a); cy = sy / (6 * a); }
+        } else if (nv == 2) { cx = 0.5 * (v[0] + v[2]); cy = 0.5 * (v[1] + v[3]); }
+        else if (nv == 1) { cx = v[0]; cy = v[1]; }
+        w->cent[2 * j] = cx; w->cent[2 * j + 1] = cy;
+    }
+}
+/* StageInequalitySE2::update (stage_inequality_se2.cpp:50-162) on the current vertex values; forced rows first, then nearest left / right */
+static void obst_associate(work_t* w) {
+    const int n = w->n, M = obst_M(w);
+    const oracle_obst* o = w->ob;
+    for (int k = 0; k < n; ++k) {
+        for (int m = 0; m < M; ++m) w->oi[k * M + m] = -1;
+        if (k < 1) continue;
+        const double px = w->X[3 * k], py = w->X[3 * k + 1], th = w->X[3 * k + 2], co = cos(th), si = sin(th);
+        double lmin = 1e30, rmin = 1e30; int lidx = -1, ridx = -1, cnt = 0;
+        for (int j = 0; j < w->n_obst; ++j) {
+            if (w->n_vert[j] <= 0) continue;
+            double dist, nx, ny, hk;
+            obst_eval(w, px, py, j, &dist, &nx, &ny, &hk);
+            dist -= o->footprint_radius;
+            if (dist < o->force_inclusion_dist) { if (cnt < M) w->oi[k * M + cnt++] = j; continue; }
+            if (dist > o->cutoff_dist) continue;
+            if (co * w->cent[2 * j + 1] - w->cent[2 * j] * si > 0) { if (dist < lmin) { lmin = dist; lidx = j; } }   /* centroid as an ABSOLUTE vector (:121) */
+            else { if (dist < rmin) { rmin = dist; ridx = j; } }
+        }
+        if (lidx >= 0 && cnt < M) w->oi[k * M + cnt++] = lidx;
+        if (ridx >= 0 && cnt < M) w->oi[k * M + cnt++] = ridx;
+    }
+}
+/* value / gradient / curvature of row (k,m) at position (px,py); 0 if the slot is empty */
+static int obst_row(const work_t* w, int k, int m, double px, double py, double* g, double* ax, double* ay, double* hk) {
+    const int j = w->oi[k * obst_M(w) + m];
+    if (j < 0) return 0;
+    double dist, nx, ny;
+    obst_eval(w, px, py, j, &dist, &nx, &ny, hk);
+    *g = w->ob->min_obstacle_dist - (dist - w->ob->footprint_radius);
+    *ax = -nx; *ay = -ny;
+    return 1;
+}
+/* sum |g + s| over the clearance rows at the point X with slacks sl */
+static double obst_theta(const work_t* w, const double* X, const double* sl) {
+    const int n = w->n, M = obst_M(w);
+    double th = 0;
+    for (int k = 1; k < n - 1; ++k) for (int m = 0; m < M; ++m) {
+        double g, ax, ay, hk;
+        if (obst_row(w, k, m, X[3 * k], X[3 * k + 1], &g, &ax, &ay, &hk)) th += fabs(g + sl[k * M + m]);
+    }
+    return th;
+}
+
 static void eval_point(const work_t* w, const double* X, const double* U, double D, double* cc, double* fobj) {
     const oracle_config* c = w->c;
     int n = w->n;
@@ -216,13 +328,14 @@ static void eval_point(const work_t* w, const double* X, const double* U, double
     *fobj = f;
 }
 
-static double barrier_logs(const work_t* w, const double* U, double D, const double* s) {
+static double barrier_logs(const work_t* w, const double* U, double D, const double* s, const double* os) {
     const oracle_config* c = w->c;
     int n = w->n;
     double a = 0.0;
     for (int k = 0; k < n - 1; ++k) for (int j = 0; j < 2; ++j) a += log(U[2 * k + j] - c->u_lb[j]) + log(c->u_ub[j] - U[2 * k + j]);
     if (c->dt_free) a += log(D - c->dt_lb) + log(c->dt_ub - D);
     for (int r = 0; r < n; ++r) for (int q = 0; q < 4; ++q) if (row_on(w, r, q)) a += log(s[4 * r + q]);
+    for (int k = 1, M = obst_M(w); k < n - 1; ++k) for (int m = 0; m < M; ++m) if (w->oi[k * M + m] >= 0) a += log(os[k * M + m]);
     return a;
 }
 
@@ -250,9 +363,22 @@ static void kkt_terms(const work_t* w, const double* cc, err_t* e) {
             for (int i = 0; i < 3; ++i) gx[i] = 2 * c->Q[i] * xd[i];
             gu[0] = 2 * c->R[0] * v; gu[1] = 2 * c->R[1] * om;
         }
+        double osx = 0, osy = 0;
+        if (k >= 1) for (int m = 0, M = obst_M(w); m < M; ++m) {
+            double g, ax, ay, hk;
+            work_t* wm = (work_t*)w;           /* the caches are scratch */
+            if (!obst_row(w, k, m, w->X[3 * k], w->X[3 * k + 1], &g, &ax, &ay, &hk)) continue;
+            wm->og[k * M + m] = g; wm->oax[k * M + m] = ax; wm->oay[k * M + m] = ay; wm->ohk[k * M + m] = hk;
+            const double sl = w->os[k * M + m], y = w->oy[k * M + m], res = g + sl;
+            if (fabs(res) > e->rp) e->rp = fabs(res);
+            e->theta += fabs(res);
+            if (sl * y < e->cmin) e->cmin = sl * y; if (sl * y > e->cmax) e->cmax = sl * y;
+            e->sb += y; e->nb += 1;
+            osx += y * ax; osy += y * ay;
+        }
         if (k >= 1) {
             const double* lp = &w->lam[3 * (k - 1)];
-            double r[3] = {gx[0] + lam[0] - lp[0], gx[1] + lam[1] - lp[1], gx[2] + lam[2] + w->D * gq[0] - lp[2]};
+            double r[3] = {gx[0] + osx + lam[0] - lp[0], gx[1] + osy + lam[1] - lp[1], gx[2] + lam[2] + w->D * gq[0] - lp[2]};
             for (int i = 0; i < 3; ++i) if (fabs(r[i]) > e->rd) e->rd = fabs(r[i]);
         }
         for (int j = 0; j < 2; ++j) {
@@ -360,6 +486,17 @@ static void assemble(work_t* w, const double* cc, double delta, double dc, doubl
             w->rhs[iu(k, j)] -= -mu / dl + mu / du;
         }
         if (k >= 1) for (int i = 0; i < 3; ++i) band_add(w, ixn(k, i), ixn(k, i), delta);
+        /* clearance rows, condensed: + sigma a a^T + y hess(g),  hess(g) = -hk (I - a a^T);  gradient + a * ybar */
+        if (k >= 1) for (int m = 0, M = obst_M(w); m < M; ++m) {
+            if (w->oi[k * M + m] < 0) continue;
+            const double sl = w->os[k * M + m], y = w->oy[k * M + m], g = w->og[k * M + m];
+            const double ax = w->oax[k * M + m], ay = w->oay[k * M + m], hk = w->ohk[k * M + m];
+            const double sig = y / sl, ybar = mu / sl + sig * (g + sl);
+            band_add(w, ixn(k, 0), ixn(k, 0), sig * ax * ax - y * hk * (1.0 - ax * ax));
+            sym_add(w, ixn(k, 0), ixn(k, 1), sig * ax * ay + y * hk * ax * ay);
+            band_add(w, ixn(k, 1), ixn(k, 1), sig * ay * ay - y * hk * (1.0 - ay * ay));
+            w->rhs[ixn(k, 0)] -= ax * ybar; w->rhs[ixn(k, 1)] -= ay * ybar;
+        }
     }
     /* terminal state block: free components are variables, fixed ones are pinned (dx = 0) */
     for (int i = 0; i < 3; ++i) {
@@ -478,6 +615,18 @@ static int solve_one(work_t* w, int warm) {
         for (int j = 0; j < 2; ++j) { w->pl[2 * k + j] = w->mu / (w->U[2 * k + j] - c->u_lb[j]); w->pu[2 * k + j] = w->mu / (c->u_ub[j] - w->U[2 * k + j]); }
         for (int i = 0; i < 3; ++i) w->lam[3 * k + i] = 0.0;
     }
+    if (obst_M(w) > 0) {
+        const int M = obst_M(w);
+        obst_centroids(w);
+        obst_associate(w);
+        for (int k = 0; k < n; ++k) for (int m = 0; m < M; ++m) {
+            double g, ax, ay, hk;
+            w->os[k * M + m] = 1.0; w->oy[k * M + m] = 0.0; w->ods[k * M + m] = 0.0; w->ody[k * M + m] = 0.0;
+            if (k >= 1 && k < n - 1 && obst_row(w, k, m, w->X[3 * k], w->X[3 * k + 1], &g, &ax, &ay, &hk)) {
+                w->os[k * M + m] = fmax(-g, slack_push); w->oy[k * M + m] = w->mu / w->os[k * M + m];
+            } else w->oi[k * M + m] = -1;
+        }
+    }
     w->pdl = c->dt_free ? w->mu / (w->D - c->dt_lb) : 0.0;
     w->pdu = c->dt_free ? w->mu / (c->dt_ub - w->D) : 0.0;
     double fobj;
@@ -577,6 +726,18 @@ static int solve_one(work_t* w, int warm) {
                     ftb(s, ds[4 * r + q], tau, &a_p);
                     ftb(y, dy[4 * r + q], tau, &a_d);
                 }
+                for (int k = 1, M = obst_M(w); k < n - 1; ++k) for (int m = 0; m < M; ++m) {
+                    if (w->oi[k * M + m] < 0) continue;
+                    const double jdz = w->oax[k * M + m] * w->dz_x[3 * k] + w->oay[k * M + m] * w->dz_x[3 * k + 1];
+                    const double sl = w->os[k * M + m], y = w->oy[k * M + m], res = w->og[k * M + m] + sl;
+                    const double sig = y / sl, ybar = mu / sl + sig * res;
+                    w->ods[k * M + m] = -res - jdz;
+                    w->ody[k * M + m] = ybar + sig * jdz - y;
+                    hdz += ybar * jdz;
+                    dphi -= (mu / sl) * w->ods[k * M + m];
+                    ftb(sl, w->ods[k * M + m], tau, &a_p);
+                    ftb(y, w->ody[k * M + m], tau, &a_d);
+                }
                 curv = -hdz + clam - dc * nunu;
                 if (isfinite(curv) && curv >= curv_kappa * dz2) { ok = 1; break; }
             }
@@ -594,7 +755,7 @@ static int solve_one(work_t* w, int warm) {
             double rt = (dphi + 0.5 * sigma * curv) / ((1.0 - rho_frac) * theta);
             if (w->rho < rt) w->rho = rt + 1.0;
         }
-        double phi0 = fobj - mu * barrier_logs(w, w->U, w->D, w->s) + w->rho * theta;
+        double phi0 = fobj - mu * barrier_logs(w, w->U, w->D, w->s, w->os) + w->rho * theta;
         double Dm = dphi - w->rho * theta;
         double alpha = a_p, ft = 0;
         int accepted = 0;
@@ -608,11 +769,13 @@ static int solve_one(work_t* w, int warm) {
             for (int i = 0; i < 2 * (n - 1); ++i) w->Ut[i] = w->U[i] + alpha * w->dz_u[i];
             w->Dt = w->D + (c->dt_free ? alpha * w->ddt : 0.0);
             for (int i = 0; i < 4 * n; ++i) st[i] = w->s[i] + alpha * ds[i];
+            for (int i = 0, nm = n * obst_M(w); i < nm; ++i) w->ost[i] = w->oi[i] >= 0 ? w->os[i] + alpha * w->ods[i] : 1.0;
             eval_point(w, w->Xt, w->Ut, w->Dt, cct, &ft);
             double tht = 0;
             for (int i = 0; i < 3 * (n - 1); ++i) tht += fabs(cct[i]);
             for (int r = 0; r < n; ++r) for (int q = 0; q < 4; ++q) if (row_on(w, r, q)) tht += fabs(row_val_at(w, w->Ut, w->Dt, r, q) + st[4 * r + q]);
-            double phit = ft - mu * barrier_logs(w, w->Ut, w->Dt, st) + w->rho * tht;
+            if (obst_M(w) > 0) tht += obst_theta(w, w->Xt, w->ost);
+            double phit = ft - mu * barrier_logs(w, w->Ut, w->Dt, st, w->ost) + w->rho * tht;
             if (isfinite(phit) && phit - phi0 - 10 * 2.220446049250313e-16 * fabs(phi0) <= eta * alpha * Dm) { accepted = 1; break; }
         }
         if (!accepted && alpha * dzmax < 1e-14) { status = 2; break; }
@@ -622,6 +785,12 @@ static int solve_one(work_t* w, int warm) {
             double sn = st[4 * r + q], yn = w->y[4 * r + q] + a_d * dy[4 * r + q];
             yn = fmin(fmax(yn, mu / (kS * sn)), kS * mu / sn);
             w->s[4 * r + q] = sn; w->y[4 * r + q] = yn;
+        }
+        for (int k = 1, M = obst_M(w); k < n - 1; ++k) for (int m = 0; m < M; ++m) if (w->oi[k * M + m] >= 0) {
+            const double sn = w->ost[k * M + m];
+            double yn = w->oy[k * M + m] + a_d * w->ody[k * M + m];
+            yn = fmin(fmax(yn, mu / (kS * sn)), kS * mu / sn);
+            w->os[k * M + m] = sn; w->oy[k * M + m] = yn;
         }
         for (int k = 0; k < n - 1; ++k) {
             for (int j = 0; j < 2; ++j) {
@@ -668,29 +837,50 @@ static work_t* work_new(const oracle_config* c) {
     w->dz_u = (double*)calloc(2 * (n - 1), 8); w->dz_x = (double*)calloc(3 * n, 8);
     return w;
 }
+static void work_obst(work_t* w, const oracle_obst* ob) {       /* clearance-row storage (only when a batch has obstacles) */
+    const int n = w->n, M = ob->max_rows, O = ob->max_obstacles;
+    w->ob = ob;
+    w->cent = (double*)calloc((size_t)2 * O, 8);
+    w->oi = (int*)calloc((size_t)n * M, sizeof(int));
+    w->os = (double*)calloc((size_t)n * M, 8); w->oy = (double*)calloc((size_t)n * M, 8); w->ost = (double*)calloc((size_t)n * M, 8);
+    w->ods = (double*)calloc((size_t)n * M, 8); w->ody = (double*)calloc((size_t)n * M, 8);
+    w->og = (double*)calloc((size_t)n * M, 8); w->oax = (double*)calloc((size_t)n * M, 8); w->oay = (double*)calloc((size_t)n * M, 8);
+    w->ohk = (double*)calloc((size_t)n * M, 8);
+}
 static void work_free(work_t* w) {
     free(w->X); free(w->U); free(w->Xt); free(w->Ut); free(w->lam); free(w->lamn); free(w->s); free(w->y); free(w->ron);
-    free(w->pl); free(w->pu); free(w->AB); free(w->ipiv); free(w->rhs); free(w->bcol); free(w->dz_u); free(w->dz_x); free(w);
+    free(w->pl); free(w->pu); free(w->AB); free(w->ipiv); free(w->rhs); free(w->bcol); free(w->dz_u); free(w->dz_x);
+    free(w->cent); free(w->oi); free(w->os); free(w->oy); free(w->ost); free(w->ods); free(w->ody); free(w->og); free(w->oax); free(w->oay); free(w->ohk);
+    free(w);
 }
 
-/* Batched entry point; same array layouts as include/mpc_hip.h.  nthreads <= 0: all cores. */
-int oracle_solve_batch(const oracle_config* c, int B, const double* x0, const double* xf, const double* u_prev,
-                       const double* dt_prev, const double* x_init, const double* u_init, const double* dt_init,
-                       double* x_out, double* u_out, double* dt_out, int32_t* status, int32_t* iters, int nthreads) {
+/* Batched entry point; same array layouts as include/mpc_hip.h.  nthreads <= 0: all cores.
+ * Obstacles (optional, ob != NULL): n_obst[B], n_vert[B][O], verts[B][O][V][2], radius[B][O] or NULL, as struct mpc_obstacles. */
+int oracle_solve_batch_obst(const oracle_config* c, int B, const double* x0, const double* xf, const double* u_prev,
+                            const double* dt_prev, const double* x_init, const double* u_init, const double* dt_init,
+                            const oracle_obst* ob, const int32_t* n_obst, const int32_t* n_vert, const double* verts, const double* radius,
+                            double* x_out, double* u_out, double* dt_out, int32_t* status, int32_t* iters, int nthreads) {
     const int n = c->n;
     if (n < 3) return -1;
+    if (ob && (ob->max_rows <= 0 || ob->max_obstacles <= 0 || !n_obst || !n_vert || !verts)) ob = NULL;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
 #pragma omp parallel
     {
         work_t* w = work_new(c);
+        if (ob) work_obst(w, ob);
 #pragma omp for schedule(dynamic, 1)
         for (int b = 0; b < B; ++b) {
             for (int i = 0; i < 3; ++i) { w->x0[i] = x0[3 * b + i]; w->xf[i] = xf[3 * b + i]; }
             w->x0[2] = wrap(w->x0[2]); w->xf[2] = wrap(w->xf[2]);
             w->uprev[0] = u_prev ? u_prev[2 * b] : 0.0; w->uprev[1] = u_prev ? u_prev[2 * b + 1] : 0.0;
             w->dtprev = dt_prev ? dt_prev[b] : 0.0;
+            if (ob) {
+                const size_t O = ob->max_obstacles, V = ob->max_vertices;
+                w->n_obst = n_obst[b] < (int)O ? n_obst[b] : (int)O;
+                w->n_vert = n_vert + (size_t)b * O; w->verts = verts + (size_t)b * O * V * 2; w->radius = radius ? radius + (size_t)b * O : NULL;
+            }
             int warm = x_init && u_init && dt_init;
             if (warm) {
                 memcpy(w->X, x_init + (size_t)b * n * 3, sizeof(double) * 3 * n);
@@ -707,6 +897,12 @@ int oracle_solve_batch(const oracle_config* c, int B, const double* x0, const do
         work_free(w);
     }
     return 0;
+}
+int oracle_solve_batch(const oracle_config* c, int B, const double* x0, const double* xf, const double* u_prev,
+                       const double* dt_prev, const double* x_init, const double* u_init, const double* dt_init,
+                       double* x_out, double* u_out, double* dt_out, int32_t* status, int32_t* iters, int nthreads) {
+    return oracle_solve_batch_obst(c, B, x0, xf, u_prev, dt_prev, x_init, u_init, dt_init, NULL, NULL, NULL, NULL, NULL, x_out, u_out, dt_out,
+                                   status, iters, nthreads);
 }
 
 int oracle_num_threads(void) {

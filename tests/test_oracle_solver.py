@@ -175,3 +175,20 @@ def test_dual_start_lands_on_the_same_solution():
     assert a.status == 0 and b.status == 0
     assert np.abs(a.traj.x - b.traj.x).max() < 1e-8 and abs(a.traj.dt - b.traj.dt) < 1e-9
     assert b.iters <= a.iters + 2
+
+
+def test_c_oracle_clearance_rows_match_numpy_goldens():
+    """oracle/mpc_oracle.c restates the clearance rows independently of ipm_dense.py (teb distances, association, condensed rows in the
+    banded KKT): it must land on the numpy oracle's golden solutions with the same iteration counts."""
+    from oracle import c_oracle as CO
+    here = os.path.dirname(os.path.abspath(__file__))
+    for name, n in (("unicycle_quadratic_obstacles_n30", 30), ("unicycle_quadratic_obstacles_n80", 80)):
+        g = np.load(os.path.join(here, "golden", name + ".npz"))
+        cfg = R.config_unicycle_quadratic(n)
+        O, V = g["vertices"].shape[1], g["vertices"].shape[2]
+        xo, uo, do, st, it = CO.solve_batch(CO.from_nlp_config(cfg), g["x0"], g["xf"], g["u_prev"], g["dt_prev"],
+                                            obstacles=(g["n_obstacles"], g["n_vertices"], g["vertices"]),
+                                            obst=CO.obst_from_nlp_config(cfg, O, V, int(g["max_rows"])))
+        assert (st == 0).all()
+        assert np.abs(xo - g["x"]).max() < 1e-9
+        assert (it == g["iters"]).all()
