@@ -48,10 +48,12 @@ def bicycle_min_time_inputs(batch: int, seed: int = SEED_CONFIG5, goal_range=(5.
 
 
 def unicycle_obstacle_inputs(batch: int, seed: int = SEED_CONFIG3, n_obst: int = 16, max_vertices: int = 6, goal_range=(3.0, 10.0),
-                             clearance: float = 0.5):
+                             clearance: float = 0.5, lateral=(0.3, 1.5)):
     """config 3: unicycle quadratic-form instances with `n_obst` convex polygons (4..max_vertices vertices, circum-radius
-    U[.2,.6]) placed beside the straight line from start to goal (lateral offset U[r+.3, r+1.5] either side: gaps stay wider than 2*min_obstacle_dist), at least
-    `clearance` away from x0 and xf.
+    U[.2,.6]) placed beside the straight line from start to goal (lateral offset U[r+lateral[0], r+lateral[1]] either side), at least
+    `clearance` away from x0 and xf.  With the default `lateral` the corridor is wider than min_obstacle_dist (= 0.2 in config 3), so the
+    clearance rows are associated and carried through the solve but rarely bind; `lateral=(0.02, 0.6)` puts about a third of the
+    obstacles inside the clearance band, i.e. the rows start violated and are active at the solution.
     Returns (x0, xf, u_prev, dt_prev, (n_obstacles, n_vertices, vertices))."""
     rng = np.random.default_rng(seed)
     th0 = rng.uniform(-np.pi, np.pi, batch)
@@ -70,10 +72,9 @@ def unicycle_obstacle_inputs(batch: int, seed: int = SEED_CONFIG3, n_obst: int =
         for o in range(n_obst):
             rad = rng.uniform(0.2, 0.6)
             # beside the straight start->goal line (the reference's initial plan is collision free): the polygon never
-            # contains a point of the initial guess (teb's distance is 0 inside a polygon => zero gradient), but it is
-            # often closer than min_obstacle_dist, so the clearance rows start violated and become active
+            # contains a point of the initial guess (teb's distance is 0 inside a polygon => zero gradient)
             for _ in range(100):
-                off = rng.choice([-1.0, 1.0]) * rng.uniform(rad + 0.3, rad + 1.5)
+                off = rng.choice([-1.0, 1.0]) * rng.uniform(rad + lateral[0], rad + lateral[1])
                 c = x0[b, :2] + rng.uniform(0.0, 1.0) * d + off * nrm
                 if np.linalg.norm(c - x0[b, :2]) > rad + clearance and np.linalg.norm(c - xf[b, :2]) > rad + clearance:
                     break

@@ -387,3 +387,26 @@ def test_long_horizon_bicycle_vs_c_oracle(m, c_oracle):
     err = np.abs(r.x - xo).reshape(B, -1).max(1)
     assert np.median(err[both]) < 1e-8
     s.close()
+
+
+def test_active_clearance_rows_vs_c_oracle(m, c_oracle):
+    """Obstacles INSIDE the clearance band (workload lateral=(0.15, 0.8): the rows start violated and about a quarter of the instances
+    end with binding clearance constraints).  The device must converge on the same instances as the C oracle and land on the same
+    solutions; a hard workload for the interior-point method itself (~80 % converge within 100 iterations in every implementation)."""
+    from oracle import se2_nlp as R
+    n, B, O, V, M = 80, 128, 16, 6, 4
+    x0, xf, up, dtp, (no, nv, verts) = m.workloads.unicycle_obstacle_inputs(B, n_obst=O, max_vertices=V, lateral=(0.15, 0.8))
+    s = m.BatchSolver(m.config_unicycle_quadratic(n, max_obstacles=O, max_vertices=V, max_obstacle_rows=M), max_batch=B)
+    r = s.solve(x0, xf, up, dtp, obstacles=(no, nv, verts))
+    ocfg = R.config_unicycle_quadratic(n)
+    oc = c_oracle.from_nlp_config(ocfg)
+    xo, uo, do, st, it = c_oracle.solve_batch(oc, x0, xf, up, dtp, obstacles=(no, nv, verts), obst=c_oracle.obst_from_nlp_config(ocfg, O, V, M))
+    xn, _, _, stn, _ = c_oracle.solve_batch(oc, x0, xf, up, dtp)                      # the same instances without obstacles
+    both = (r.status == 0) & (st == 0)
+    assert both.sum() >= 0.6 * B and abs(int((r.status == 0).sum()) - int((st == 0).sum())) <= 0.08 * B
+    err = np.abs(r.x - xo).reshape(B, -1).max(1)
+    assert np.median(err[both]) < 1e-7 and (err[both] < 1e-4).mean() > 0.9
+    moved = both & (stn == 0) & (np.abs(xo - xn).reshape(B, -1).max(1) > 1e-3)            # instances whose solution the obstacles shape
+    assert moved.sum() >= 10
+    assert np.median(err[moved]) < 1e-6
+    s.close()
