@@ -39,7 +39,8 @@ enum mpc_model {                      /* include/mpc_local_planner/systems/ */
     MPC_MODEL_KINEMATIC_BICYCLE = 3   /* kinematic_bicycle_model.h:65-77 */
 };
 enum mpc_collocation {                /* include/.../optimal_control/fd_collocation_se2.h */
-    MPC_COLLOC_FORWARD = 0            /* :54-69 (the default, src/controller.cpp:298) */
+    MPC_COLLOC_FORWARD = 0,           /* :54-69 (the default, src/controller.cpp:298) */
+    MPC_COLLOC_MIDPOINT = 1           /* :91-108 midpoint_differences */
 };
 enum mpc_objective {                  /* src/controller.cpp:551-640 */
     MPC_OBJ_MIN_TIME = 0,

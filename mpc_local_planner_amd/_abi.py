@@ -13,6 +13,7 @@ MODEL_SIMPLE_CAR_FRONT = 2
 MODEL_KINEMATIC_BICYCLE = 3
 
 COLLOC_FORWARD = 0
+COLLOC_MIDPOINT = 1
 
 OBJ_MIN_TIME = 0
 OBJ_QUADRATIC = 1
@@ -85,7 +86,7 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
                 xf_fixed=(True, True, True), objective=OBJ_MIN_TIME, Q=(0, 0, 0), R=(0, 0), integral_form=False, Qf=None,
                 u_lb=(-0.2, -0.3), u_ub=(0.4, 0.3), du_lb=(-INF, -INF), du_ub=(INF, INF), max_iter=100, tol=1e-8,
                 mu_init=0.1, precision=FP64, min_obstacle_dist=0.5, force_inclusion_dist=0.5, cutoff_dist=2.0,
-                footprint_kind=0, footprint_radius=0.0, max_obstacles=0, max_vertices=1, max_obstacle_rows=4, mu_init_warm=0.0) -> MpcConfig:
+                footprint_kind=0, footprint_radius=0.0, max_obstacles=0, max_vertices=1, max_obstacle_rows=4, mu_init_warm=0.0, collocation=COLLOC_FORWARD) -> MpcConfig:
     c = MpcConfig()
     c.model = model
     mp = list(model_params) + [0.0] * 4
@@ -99,7 +100,7 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
         c.xf_fixed[i] = int(bool(xf_fixed[i]))
         c.Q[i] = Q[i]
         c.Qf[i] = Qf[i] if Qf is not None else 0.0
-    c.collocation = COLLOC_FORWARD
+    c.collocation = collocation
     c.objective = objective
     c.integral_form = int(bool(integral_form))
     c.has_Qf = int(Qf is not None)

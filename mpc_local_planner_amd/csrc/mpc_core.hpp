@@ -53,6 +53,7 @@ struct Problem {
     int xf_fixed[3];
     int objective;
     int integral_form;
+    int collocation;     // 0 forward differences, 1 midpoint differences (wave kernel only)
     int has_Qf;
     int rate_on[4];      // slots: lo0, lo1, hi0, hi1 (finite du bound?)
     int max_iter;
@@ -349,6 +350,84 @@ MPC_HD void model_derivs(const Problem<T>& P, const T tr[4], T v, T w, const T l
     Hq[1][0] = Hq[0][1]; Hq[2][0] = Hq[0][2]; Hq[2][1] = Hq[1][2];
 }
 
+// ---- collocation variants (include/mpc_local_planner/optimal_control/fd_collocation_se2.h) in solver form:
+//        c_k = x_k + D(theta_k, u_k, dt) - x_{k+1},  theta row wrapped
+//      forward differences  (:54-69)    D = dt f(theta_k, u_k)
+//      midpoint differences (:91-108)   D = dt f(theta_m, u_k) with theta_m = theta_k + dt f_2(u_k) / 2.  The reference takes
+//        theta_m = interpolate_angle(theta_k, theta_{k+1}, 0.5); on the constraint manifold theta_{k+1} = theta_k + dt f_2(u_k)
+//        (the heading rate f_2 of every model is independent of the pose), so both are the same point: same feasible set and
+//        KKT points, and the rows stay explicit in x_{k+1} (stage structure of the Riccati sweep).
+// model_trig_colloc fills the trig cache at the angle the row is evaluated at; stage_map turns the model derivatives at that
+// angle into the derivatives of D with respect to (theta, v, w) and dt, and of lam' D (chain rule through theta_m).
+template <typename T, int MODEL>
+MPC_HD void model_trig_colloc(const Problem<T>& P, T th, T v, T w, T d, T tr[4]) {
+    if (P.collocation == 1) {
+        T f2;
+        if (MODEL == MODEL_UNICYCLE) f2 = w;
+        else if (MODEL == MODEL_SIMPLE_CAR) f2 = v * t_tan(w) / P.p0;
+        else if (MODEL == MODEL_SIMPLE_CAR_FRONT) { T sw, cw; t_sincos(w, &sw, &cw); f2 = v * sw / P.p0; }
+        else { T sb, cb; t_sincos(t_atan(P.p0 / (P.p1 + P.p0) * t_tan(w)), &sb, &cb); f2 = v * sb / P.p0; }
+        th += T(0.5) * d * f2;
+    }
+    model_trig<T, MODEL>(P, th, w, tr);
+}
+template <typename T>
+struct StageMap {
+    T f[3];          // f at the evaluation angle (D = dt f)
+    T Jq[3][3];      // dD/d(theta, v, w)
+    T Jdt[3];        // dD/d dt
+    T Hqq[3][3];     // d2 (lam' D) / d(theta, v, w)^2
+    T Hqd[3];        // d2 (lam' D) / d(theta, v, w) d dt
+    T Hdd;           // d2 (lam' D) / d dt^2
+};
+template <typename T, int MODEL>
+MPC_HD void stage_map(const Problem<T>& P, const T tr[4], T v, T w, T d, const T lam[3], StageMap<T>& o) {
+    T G[3][3], Hq[3][3];
+    model_derivs<T, MODEL>(P, tr, v, w, lam, o.f, G, Hq);
+    T gq[3];
+    for (int j = 0; j < 3; ++j) gq[j] = lam[0] * G[0][j] + lam[1] * G[1][j] + lam[2] * G[2][j];
+    if (P.collocation != 1) {
+        for (int a = 0; a < 3; ++a) { o.Jdt[a] = o.f[a]; for (int j = 0; j < 3; ++j) o.Jq[a][j] = d * G[a][j]; }
+        for (int j = 0; j < 3; ++j) { o.Hqd[j] = gq[j]; for (int l = 0; l < 3; ++l) o.Hqq[j][l] = d * Hq[j][l]; }
+        o.Hdd = T(0);
+        return;
+    }
+    // second derivatives of the heading rate f_2 wrt (v, w): the lam = e_2 slice of the model Hessian
+    const T e2[3] = {T(0), T(0), T(1)};
+    T f_[3], G_[3][3], H2[3][3];
+    model_derivs<T, MODEL>(P, tr, v, w, e2, f_, G_, H2);
+    const T f2 = o.f[2];
+    // m = d theta_m / d(theta, v, w, dt);  mab = second derivatives (only (u,u) and (u,dt) are non-zero)
+    const T m[4] = {T(1), T(0.5) * d * G[2][1], T(0.5) * d * G[2][2], T(0.5) * f2};
+    T mab[4][4];
+    for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) mab[a][b] = T(0);
+    for (int j = 1; j < 3; ++j) {
+        for (int l = 1; l < 3; ++l) mab[j][l] = T(0.5) * d * H2[j][l];
+        mab[j][3] = mab[3][j] = T(0.5) * G[2][j];
+    }
+    // g(theta,u,dt) = f(theta_m,u): dg_a/dz = G[a][0] m_z + [z = u_j] G[a][j]
+    for (int a = 0; a < 3; ++a) {
+        T dg[4];
+        for (int z = 0; z < 4; ++z) dg[z] = G[a][0] * m[z];
+        dg[1] += G[a][1]; dg[2] += G[a][2];
+        for (int j = 0; j < 3; ++j) o.Jq[a][j] = d * dg[j];
+        o.Jdt[a] = o.f[a] + d * dg[3];
+    }
+    // L = dt phi(theta_m, u), phi = lam' f:  L_ab = [a=dt] Dphi_b + [b=dt] Dphi_a + dt D2phi_ab
+    T Dphi[4], L[4][4];
+    for (int z = 0; z < 4; ++z) Dphi[z] = gq[0] * m[z];
+    Dphi[1] += gq[1]; Dphi[2] += gq[2];
+    for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) {
+        T v2 = Hq[0][0] * m[a] * m[b] + gq[0] * mab[a][b];
+        if (a >= 1 && a <= 2) v2 += Hq[0][a] * m[b];
+        if (b >= 1 && b <= 2) v2 += Hq[0][b] * m[a];
+        if (a >= 1 && a <= 2 && b >= 1 && b <= 2) v2 += Hq[a][b];
+        L[a][b] = d * v2 + (a == 3 ? Dphi[b] : T(0)) + (b == 3 ? Dphi[a] : T(0));
+    }
+    for (int j = 0; j < 3; ++j) { o.Hqd[j] = L[j][3]; for (int l = 0; l < 3; ++l) o.Hqq[j][l] = L[j][l]; }
+    o.Hdd = L[3][3];
+}
+
 // ---------------------------------------------------------------------------------------------
 // Structured backward (Riccati) stage step, shared by both kernels.
 //
@@ -382,6 +461,7 @@ template <typename T>
 struct StageParts {
     T h00, h01, h02, h11, h12, h22;   // dt * sum_a lam_a d2 f_a / d(theta,v,w)^2
     T g[3];                           // sum_a lam_a d f_a / d(theta,v,w)   (cross terms with dt)
+    T hdd;                            // d2 (lam' D) / d dt^2 (midpoint collocation; 0 for forward differences)
     T sz[2], gb[2];                   // control box: Sigma, barrier (+objective) gradient
     T ss[2], sl[2], sll, gy[2], gyl;  // rate rows: sum sigma, sigma*lim, sigma*lim^2, sg*ybar, sg*lim*ybar
     T hx[3];                          // objective gradient wrt x_k
@@ -393,7 +473,7 @@ MPC_HD void assemble_adds(const StageParts<T>& s, const T q2[3], const T r2[2], 
     A[A25] = s.g[0]; A[A26] = s.h01; A[A27] = s.h02;
     A[A33] = s.ss[0]; A[A35] = s.sl[0]; A[A36] = -s.ss[0];
     A[A44] = s.ss[1]; A[A45] = s.sl[1]; A[A47] = -s.ss[1];
-    A[A55] = s.sll; A[A56] = s.g[1] - s.sl[0]; A[A57] = s.g[2] - s.sl[1];
+    A[A55] = s.sll + s.hdd; A[A56] = s.g[1] - s.sl[0]; A[A57] = s.g[2] - s.sl[1];
     A[A66] = s.h11 + s.sz[0] + s.ss[0] + r2[0]; A[A67] = s.h12; A[A77] = s.h22 + s.sz[1] + s.ss[1] + r2[1];
     A[A08] = s.hx[0] + s.ogx; A[A18] = s.hx[1] + s.ogy; A[A28] = s.hx[2];
     A[A38] = -s.gy[0]; A[A48] = -s.gy[1]; A[A58] = -s.gyl;
@@ -939,6 +1019,7 @@ struct Ipm {
             r.a0 = d * G[0][0]; r.a1 = d * G[1][0];
             for (int a = 0; a < 3; ++a) { r.f[a] = f[a]; r.B[a][0] = d * G[a][1]; r.B[a][1] = d * G[a][2]; r.c[a] = M.ld(L.CC + 3 * k + a); }
             StageParts<T> sp;
+            sp.hdd = T(0);
             sp.h00 = d * Hq[0][0]; sp.h01 = d * Hq[0][1]; sp.h02 = d * Hq[0][2]; sp.h11 = d * Hq[1][1]; sp.h12 = d * Hq[1][2]; sp.h22 = d * Hq[2][2];
             for (int j = 0; j < 3; ++j) sp.g[j] = lam[0] * G[0][j] + lam[1] * G[1][j] + lam[2] * G[2][j];
             for (int j = 0; j < 2; ++j) {

@@ -13,6 +13,7 @@ inline void fill_problem(const mpc_config& c, mpc::Problem<T>& P) {
     P.dt_free = c.dt_free ? 1 : 0;
     for (int i = 0; i < 3; ++i) P.xf_fixed[i] = c.xf_fixed[i] ? 1 : 0;
     P.objective = c.objective;
+    P.collocation = c.collocation;
     P.has_Qf = c.has_Qf ? 1 : 0;
     P.max_iter = c.max_iter > 0 ? c.max_iter : 100;
     P.p0 = T(c.model_params[0]);

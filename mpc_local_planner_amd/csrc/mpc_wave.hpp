@@ -346,7 +346,7 @@ struct IpmWave {
             T xn[3] = {xt(0, k + 1, al), xt(1, k + 1, al), xt(2, k + 1, al)};
             T v = ut(0, k, al), w = ut(1, k, al);
             T tr[4], f[3];
-            model_trig<T, MODEL>(P, xk[2], w, tr);
+            model_trig_colloc<T, MODEL>(P, xk[2], v, w, d, tr);
             model_f<T, MODEL>(P, tr, v, w, f);
             T c0 = d * f[0] - (xn[0] - xk[0]);
             T c1 = d * f[1] - (xn[1] - xk[1]);
@@ -450,7 +450,7 @@ struct IpmWave {
             const T n2 = r.dxn[2] != T(0) ? normalize_theta(r.xn[2] + alpha * r.dxn[2]) : r.xn[2];
             const T v = r.u[0] + alpha * r.du[0], w = r.u[1] + alpha * r.du[1];
             T tr[4], f[3];
-            model_trig<T, MODEL>(P, x2_, w, tr);
+            model_trig_colloc<T, MODEL>(P, x2_, v, w, d, tr);
             model_f<T, MODEL>(P, tr, v, w, f);
             const T c0 = d * f[0] - (n0 - x0_), c1 = d * f[1] - (n1 - x1_), c2 = d * f[2] - normalize_theta(n2 - x2_);
             for (int i = 0; i < L.NTR; ++i) F(L.TRIG, i, r.k) = tr[i];
@@ -495,29 +495,32 @@ struct IpmWave {
         T rd = T(0), rp = T(0), cmin = T(1e30), cmax = T(0), smult = T(0), sb = T(0), th = T(0), rdd = T(0);
         int nm = 0, nb = 0;
         for (int k = lane; k < n; k += kWave) {
-            T rec[20];
+            T rec[21];
             if (k < n - 1) {
                 T lam[3] = {F(L.LAM, 0, k), F(L.LAM, 1, k), F(L.LAM, 2, k)};
                 T tr[4] = {F(L.TRIG, 0, k), F(L.TRIG, 1, k), F(L.TRIG, 2, k), L.NTR > 3 ? F(L.TRIG, 3, k) : T(0)};
                 T v = F(L.U, 0, k), w = F(L.U, 1, k);
-                T f[3], G[3][3], Hq[3][3];
-                model_derivs<T, MODEL>(P, tr, v, w, lam, f, G, Hq);
-                T gq[3];
-                for (int j = 0; j < 3; ++j) gq[j] = lam[0] * G[0][j] + lam[1] * G[1][j] + lam[2] * G[2][j];
+                // derivatives of the collocation increment D(theta, u, dt) (forward or midpoint differences, mpc_core.hpp::stage_map);
+                // gJ[j] = lam' dD/dq_j is what the dual residuals need, Jdt = dD/d dt the dt column of the row
+                StageMap<T> sm_;
+                stage_map<T, MODEL>(P, tr, v, w, d, lam, sm_);
+                T gJ[3];
+                for (int j = 0; j < 3; ++j) gJ[j] = lam[0] * sm_.Jq[0][j] + lam[1] * sm_.Jq[1][j] + lam[2] * sm_.Jq[2][j];
                 // stage record, mu-independent part: kept in registers and stored at the END of the loop body -- every LDS store
                 // forces the loads that follow it in program order to be re-issued and waited for (possible aliasing)
-                rec[0] = d * G[0][0]; rec[1] = d * G[1][0];
-                rec[2] = f[0]; rec[3] = f[1]; rec[4] = f[2];
-                for (int a = 0; a < 3; ++a) { rec[5 + a] = d * G[a][1]; rec[8 + a] = d * G[a][2]; }
-                rec[11] = d * Hq[0][0]; rec[12] = d * Hq[0][1]; rec[13] = d * Hq[0][2];
-                rec[14] = d * Hq[1][1]; rec[15] = d * Hq[1][2]; rec[16] = d * Hq[2][2];
-                rec[17] = gq[0]; rec[18] = gq[1]; rec[19] = gq[2];
+                rec[0] = sm_.Jq[0][0]; rec[1] = sm_.Jq[1][0];
+                rec[2] = sm_.Jdt[0]; rec[3] = sm_.Jdt[1]; rec[4] = sm_.Jdt[2];
+                for (int a = 0; a < 3; ++a) { rec[5 + a] = sm_.Jq[a][1]; rec[8 + a] = sm_.Jq[a][2]; }
+                rec[11] = sm_.Hqq[0][0]; rec[12] = sm_.Hqq[0][1]; rec[13] = sm_.Hqq[0][2];
+                rec[14] = sm_.Hqq[1][1]; rec[15] = sm_.Hqq[1][2]; rec[16] = sm_.Hqq[2][2];
+                rec[17] = sm_.Hqd[0]; rec[18] = sm_.Hqd[1]; rec[19] = sm_.Hqd[2];
+                rec[20] = sm_.Hdd;
                 for (int i = 0; i < 3; ++i) {
                     T ci = C_(i, k);
                     rp = t_max(rp, t_abs(ci)); th += t_abs(ci); smult += t_abs(lam[i]);
                 }
                 nm += 3;
-                rdd += lam[0] * f[0] + lam[1] * f[1] + lam[2] * f[2];
+                rdd += lam[0] * sm_.Jdt[0] + lam[1] * sm_.Jdt[1] + lam[2] * sm_.Jdt[2];
                 T gx[3] = {T(0), T(0), T(0)}, gu[2] = {T(0), T(0)};
                 if (quad()) {
                     T xd[3] = {F(L.X, 0, k) - xf[0], F(L.X, 1, k) - xf[1], normalize_theta(F(L.X, 2, k) - xf[2])};
@@ -542,13 +545,13 @@ struct IpmWave {
                 if (k >= 1) {
                     T r0 = gx[0] + osx + lam[0] - F(L.LAM, 0, k - 1);
                     T r1 = gx[1] + osy + lam[1] - F(L.LAM, 1, k - 1);
-                    T r2 = gx[2] + lam[2] + d * gq[0] - F(L.LAM, 2, k - 1);
+                    T r2 = gx[2] + lam[2] + gJ[0] - F(L.LAM, 2, k - 1);
                     rd = t_max(rd, t_max(t_abs(r0), t_max(t_abs(r1), t_abs(r2))));
                 }
                 for (int j = 0; j < 2; ++j) {
                     T u = j == 0 ? v : w;
                     T pl = F(L.PL, j, k), pu = F(L.PU, j, k);
-                    T r = gu[j] + d * gq[1 + j] - pl + pu;
+                    T r = gu[j] + gJ[1 + j] - pl + pu;
                     for (int q = j; q < 4; q += 2) {
                         const T sg = slot_sign<T>(q);
                         if (row_on(k, q)) r += sg * F(L.YR, q, k);
@@ -587,7 +590,7 @@ struct IpmWave {
                 // raw (mu-independent) pieces parked in their A slots; stage_barrier_terms() turns them into the combined entries
                 S_(RA + A22, k) = rec[11]; S_(RA + A26, k) = rec[12]; S_(RA + A27, k) = rec[13];
                 S_(RA + A66, k) = rec[14]; S_(RA + A67, k) = rec[15]; S_(RA + A77, k) = rec[16];
-                S_(RA + A25, k) = rec[17]; S_(RA + A56, k) = rec[18]; S_(RA + A57, k) = rec[19];
+                S_(RA + A25, k) = rec[17]; S_(RA + A56, k) = rec[18]; S_(RA + A57, k) = rec[19]; S_(RA + A55, k) = rec[20];
             }
         }
         if (lane == 0) {
@@ -631,6 +634,7 @@ struct IpmWave {
             sp.h00 = S_(RA + A22, k); sp.h01 = S_(RA + A26, k); sp.h02 = S_(RA + A27, k);
             sp.h11 = S_(RA + A66, k); sp.h12 = S_(RA + A67, k); sp.h22 = S_(RA + A77, k);
             sp.g[0] = S_(RA + A25, k); sp.g[1] = S_(RA + A56, k); sp.g[2] = S_(RA + A57, k);
+            sp.hdd = k < n - 1 ? S_(RA + A55, k) : T(0);
             sp.hx[0] = sp.hx[1] = sp.hx[2] = T(0);
             if (quad && k < n - 1) {
                 sp.hx[0] = q2[0] * (F(L.X, 0, k) - xf[0]); sp.hx[1] = q2[1] * (F(L.X, 1, k) - xf[1]);

@@ -104,6 +104,51 @@ def model_derivs(model, p, th, v, w):
     return f, G, H
 
 
+def stage_map_derivs(cfg: R.OcpConfig, th, v, w, dt, lam=None):
+    """Increment of the collocation row in solver form:  c_k = x_k + D(theta_k, u_k, dt) - x_{k+1}  (theta row wrapped).
+      forward differences (fd_collocation_se2.h:54-69)    D = dt f(theta_k, u_k)
+      midpoint differences (fd_collocation_se2.h:91-108)  D = dt f(theta_m, u_k),  theta_m = theta_k + dt f_theta-row(u_k) / 2
+    The reference evaluates the midpoint at interpolate_angle(theta_k, theta_{k+1}, 0.5); on the constraint manifold theta_{k+1} =
+    theta_k + dt f_2(u_k) (the heading rate of every model is independent of the pose), so theta_m is the SAME point and the
+    two forms have the same feasible set and KKT points -- the solver form keeps the rows explicit in x_{k+1} (stage structure).
+    Returns val (3,), Jq (3,3) = dD/d(theta,v,w), Jdt (3,), and with lam: Hqq (3,3), Hqd (3,), Hdd of lam^T D."""
+    if cfg.collocation == R.COLLOC_FORWARD:
+        f, G, H = model_derivs(cfg.model, cfg.model_params, th, v, w)
+        out = dict(val=dt * f, Jq=dt * G, Jdt=f.copy())
+        if lam is not None:
+            out.update(Hqq=dt * np.einsum("a,ajl->jl", lam, H), Hqd=lam @ G, Hdd=0.0)
+        return out
+    if cfg.collocation != R.COLLOC_MIDPOINT:
+        raise NotImplementedError("solver form: forward and midpoint differences")
+    f0, G0, H0 = model_derivs(cfg.model, cfg.model_params, th, v, w)      # heading-rate row (independent of theta)
+    f2, f2u, f2uu = f0[2], G0[2, 1:], H0[2, 1:, 1:]
+    thm = th + 0.5 * dt * f2
+    f, G, H = model_derivs(cfg.model, cfg.model_params, thm, v, w)
+    m = np.array([1.0, 0.5 * dt * f2u[0], 0.5 * dt * f2u[1], 0.5 * f2])        # d theta_m / d(theta, v, w, dt)
+    # g(theta,u,dt) = f(theta_m, u):  dg/da = f_theta m_a + [a = u_j] f_uj
+    dg = np.outer(G[:, 0], m)
+    dg[:, 1:3] += G[:, 1:3]
+    out = dict(val=dt * f, Jq=dt * dg[:, :3], Jdt=f + dt * dg[:, 3])
+    if lam is not None:
+        gq = lam @ G                                  # phi_m, phi_v, phi_w
+        Hl = np.einsum("a,ajl->jl", lam, H)           # second derivatives of phi = lam^T f wrt (m, v, w)
+        mab = np.zeros((4, 4))
+        mab[1:3, 1:3] = 0.5 * dt * f2uu
+        mab[1:3, 3] = mab[3, 1:3] = 0.5 * f2u
+        Dphi = gq[0] * m
+        Dphi[1:3] += gq[1:3]
+        D2 = Hl[0, 0] * np.outer(m, m) + gq[0] * mab
+        for j in (1, 2):
+            D2[j, :] += Hl[0, j] * m
+            D2[:, j] += Hl[0, j] * m
+        D2[1:3, 1:3] += Hl[1:3, 1:3]
+        L = dt * D2
+        L[3, :] += Dphi
+        L[:, 3] += Dphi
+        out.update(Hqq=L[:3, :3], Hqd=L[:3, 3], Hdd=L[3, 3])
+    return out
+
+
 # --------------------------------------------------------------------------
 # point-footprint distance derivatives (analytic); other footprints: numeric
 # --------------------------------------------------------------------------
@@ -186,8 +231,8 @@ class SolverNlp:
     indexed into a flat vector: [x_1 .. x_{n-2}, xf(free comps), u_0 .. u_{n-2}, dt(if free)]."""
 
     def __init__(self, cfg: R.OcpConfig, inp: R.CycleInputs, relevant=None):
-        if cfg.collocation != R.COLLOC_FORWARD:
-            raise NotImplementedError("analytic solver form: forward differences only")
+        if cfg.collocation not in (R.COLLOC_FORWARD, R.COLLOC_MIDPOINT):
+            raise NotImplementedError("analytic solver form: forward and midpoint differences")
         self.cfg, self.inp = cfg, inp
         n = self.n = cfg.n
         self.relevant = relevant if relevant is not None else [[] for _ in range(n)]
@@ -315,11 +360,12 @@ class SolverNlp:
         c = np.zeros(self.mc)
         Jc = np.zeros((self.mc, nv))
         for k in range(n - 1):
-            fk, G, Hk = model_derivs(cfg.model, cfg.model_params, X[k, 2], U[k, 0], U[k, 1])
+            lk = lam[3 * k:3 * k + 3] if (want_hess and lam is not None) else None
+            sd = stage_map_derivs(cfg, X[k, 2], U[k, 0], U[k, 1], dt, lk)
             r = slice(3 * k, 3 * k + 3)
             d = X[k + 1] - X[k]
             d[2] = R.normalize_theta(d[2])
-            c[r] = dt * fk - d
+            c[r] = sd["val"] - d
             qidx = [self.ix[k, 2], self.iu[k, 0], self.iu[k, 1]]
             for a in range(3):
                 row = 3 * k + a
@@ -329,22 +375,21 @@ class SolverNlp:
                     Jc[row, self.ix[k + 1, a]] -= 1.0
                 for j, qi in enumerate(qidx):
                     if qi >= 0:
-                        Jc[row, qi] += dt * G[a, j]
+                        Jc[row, qi] += sd["Jq"][a, j]
                 if self.idt >= 0:
-                    Jc[row, self.idt] += fk[a]
-            if want_hess and lam is not None:
-                lk = lam[r]
-                Hq = dt * np.einsum("a,ajl->jl", lk, Hk)
-                gq = lk @ G       # d/dq of lam^T f  -> cross term with dt
+                    Jc[row, self.idt] += sd["Jdt"][a]
+            if lk is not None:
                 for j, qj in enumerate(qidx):
                     if qj < 0:
                         continue
                     for l, ql in enumerate(qidx):
                         if ql >= 0:
-                            W[qj, ql] += Hq[j, l]
+                            W[qj, ql] += sd["Hqq"][j, l]
                     if self.idt >= 0:
-                        W[qj, self.idt] += gq[j]
-                        W[self.idt, qj] += gq[j]
+                        W[qj, self.idt] += sd["Hqd"][j]
+                        W[self.idt, qj] += sd["Hqd"][j]
+                if self.idt >= 0:
+                    W[self.idt, self.idt] += sd["Hdd"]
         # inequalities
         g = np.zeros(self.mg)
         Jg = np.zeros((self.mg, nv))

@@ -65,7 +65,7 @@ def make_obstacles(name, n=30, B=10, O=6, V=6, M=4, keep=6):
     print(name, "kept", len(sel), "iters", IT)
 
 
-if __name__ == "__main__" and "--warm" not in sys.argv and "--integral" not in sys.argv and "--closed-loop" not in sys.argv and "--config3" not in sys.argv:
+if __name__ == "__main__" and "--warm" not in sys.argv and "--integral" not in sys.argv and "--closed-loop" not in sys.argv and "--config3" not in sys.argv and "--midpoint" not in sys.argv:
     make_obstacles("unicycle_quadratic_obstacles_n30")
     make("carlike_min_time_n50", R.config_carlike_min_time(50), W.carlike_min_time_inputs(32, seed=101), keep=8)
     make("carlike_min_time_n20", R.config_carlike_min_time(20), W.carlike_min_time_inputs(32, seed=102, goal_range=(1.0, 2.5)), keep=8)
@@ -161,3 +161,31 @@ if __name__ == "__main__" and "--closed-loop" in sys.argv:
 if __name__ == "__main__" and "--config3" in sys.argv:
     # BASELINE config 3 shape: n = 80, 16 polygons, at most 4 clearance rows per grid point (numpy oracle only; ~1 s per instance)
     make_obstacles("unicycle_quadratic_obstacles_n80", n=80, B=40, O=16, V=6, M=4, keep=24)
+
+
+def make_midpoint(name, cfg, inputs, keep=6):
+    """midpoint_differences collocation (fd_collocation_se2.h:91-108) in the explicit solver form of ipm_dense.stage_map_derivs;
+    every kept solution is also checked against the REFERENCE-form midpoint defect (interpolate_angle midpoint)."""
+    x0, xf, up, dtp = inputs
+    rows = []
+    for i in range(x0.shape[0]):
+        if len(rows) >= keep:
+            break
+        inp = R.CycleInputs(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=float(dtp[i]))
+        ref = I.solve(cfg, inp, R.cold_start(cfg, x0[i], xf[i]), opt=I.IpmOptions(globalization="merit", max_iter=100))
+        if ref.status != 0 or ref.iters > 45:
+            continue
+        nlp = R.ReferenceNlp(cfg, inp)
+        assert np.abs(nlp.equalities(nlp.pack(ref.traj))).max() < 1e-6
+        rows.append(dict(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=dtp[i], x=ref.traj.x, u=np.vstack([ref.traj.u, ref.traj.u[-1:]]), dt=ref.traj.dt, iters=ref.iters))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **{k: np.array([r[k] for r in rows]) for k in rows[0]})
+    print(name, "kept", len(rows), "iters", [r["iters"] for r in rows])
+
+
+if __name__ == "__main__" and "--midpoint" in sys.argv:
+    c = R.config_carlike_min_time(20); c.collocation = R.COLLOC_MIDPOINT
+    make_midpoint("carlike_min_time_midpoint_n20", c, W.carlike_min_time_inputs(32, seed=107, goal_range=(1.0, 2.5)))
+    c = R.config_unicycle_quadratic(20); c.collocation = R.COLLOC_MIDPOINT
+    make_midpoint("unicycle_quadratic_midpoint_n20", c, W.unicycle_quadratic_inputs(16, seed=108))
+    c = R.config_bicycle_min_time(30); c.collocation = R.COLLOC_MIDPOINT
+    make_midpoint("bicycle_min_time_midpoint_n30", c, W.carlike_min_time_inputs(32, seed=109, goal_range=(2.0, 6.0)), keep=4)
