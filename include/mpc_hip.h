@@ -40,7 +40,8 @@ enum mpc_model {                      /* include/mpc_local_planner/systems/ */
 };
 enum mpc_collocation {                /* include/.../optimal_control/fd_collocation_se2.h */
     MPC_COLLOC_FORWARD = 0,           /* :54-69 (the default, src/controller.cpp:298) */
-    MPC_COLLOC_MIDPOINT = 1           /* :91-108 midpoint_differences (crank_nicolson_differences :130-147 is rejected) */
+    MPC_COLLOC_MIDPOINT = 1,          /* :91-108 midpoint_differences */
+    MPC_COLLOC_CRANK_NICOLSON = 2     /* :130-147 crank_nicolson_differences, restated literally: 1.5 f(x_{k+1}) + 0.5 f(x_k) */
 };
 enum mpc_objective {                  /* src/controller.cpp:551-640 */
     MPC_OBJ_MIN_TIME = 0,

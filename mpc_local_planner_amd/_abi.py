@@ -14,6 +14,7 @@ MODEL_KINEMATIC_BICYCLE = 3
 
 COLLOC_FORWARD = 0
 COLLOC_MIDPOINT = 1
+COLLOC_CRANK_NICOLSON = 2
 
 OBJ_MIN_TIME = 0
 OBJ_QUADRATIC = 1

@@ -219,8 +219,8 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
     *out = nullptr;
     if (cfg->n < 3 || cfg->n > 4096) { set_err("mpc_create: n out of range [3,4096]"); return MPC_EINVAL; }
     if (cfg->model < 0 || cfg->model > 3) { set_err("mpc_create: unknown model"); return MPC_EINVAL; }
-    if (cfg->collocation != MPC_COLLOC_FORWARD && cfg->collocation != MPC_COLLOC_MIDPOINT) {
-        set_err("mpc_create: forward_differences and midpoint_differences collocation are implemented (not crank_nicolson_differences)"); return MPC_EINVAL; }
+    if (cfg->collocation != MPC_COLLOC_FORWARD && cfg->collocation != MPC_COLLOC_MIDPOINT && cfg->collocation != MPC_COLLOC_CRANK_NICOLSON) {
+        set_err("mpc_create: unknown collocation method"); return MPC_EINVAL; }
     if (cfg->objective != MPC_OBJ_MIN_TIME && cfg->objective != MPC_OBJ_QUADRATIC) { set_err("mpc_create: unknown objective"); return MPC_EINVAL; }
     if (cfg->objective == MPC_OBJ_MIN_TIME && !cfg->dt_free) { set_err("mpc_create: minimum_time needs a variable grid (dt_free)"); return MPC_EINVAL; }
     if (!(cfg->dt_ref > 0)) { set_err("mpc_create: dt_ref must be > 0"); return MPC_EINVAL; }
@@ -249,7 +249,8 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
     {
         const int O = cfg->max_obstacles > 0 ? cfg->max_obstacles : 0;
         const int M = O > 0 ? (cfg->max_obstacle_rows > 0 ? cfg->max_obstacle_rows : 4) : 0;
-        const int ntrig = (cfg->model == MPC_MODEL_KINEMATIC_BICYCLE || cfg->model == MPC_MODEL_SIMPLE_CAR_FRONT) ? 4 : 3;
+        const int ntrig = ((cfg->model == MPC_MODEL_KINEMATIC_BICYCLE || cfg->model == MPC_MODEL_SIMPLE_CAR_FRONT) ? 4 : 3) +
+                          (cfg->collocation == MPC_COLLOC_CRANK_NICOLSON ? 2 : 0);
         s->WL = mpc::WaveLayout::make(cfg->n, M, O, cfg->max_vertices > 0 ? cfg->max_vertices : 1, ntrig);
     }
     s->wave_lds = ((((size_t)s->WL.total * (cfg->precision == MPC_FP32 ? 4 : 8)) + 15) & ~(size_t)15) + 16 +

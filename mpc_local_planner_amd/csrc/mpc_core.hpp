@@ -53,7 +53,7 @@ struct Problem {
     int xf_fixed[3];
     int objective;
     int integral_form;
-    int collocation;     // 0 forward differences, 1 midpoint differences (wave kernel only)
+    int collocation;     // 0 forward differences, 1 midpoint differences, 2 Crank-Nicolson (wave kernel only)
     int has_Qf;
     int rate_on[4];      // slots: lo0, lo1, hi0, hi1 (finite du bound?)
     int max_iter;
@@ -351,29 +351,60 @@ MPC_HD void model_derivs(const Problem<T>& P, const T tr[4], T v, T w, const T l
 }
 
 // ---- collocation variants (include/mpc_local_planner/optimal_control/fd_collocation_se2.h) in solver form:
-//        c_k = x_k + D(theta_k, u_k, dt) - x_{k+1},  theta row wrapped
-//      forward differences  (:54-69)    D = dt f(theta_k, u_k)
-//      midpoint differences (:91-108)   D = dt f(theta_m, u_k) with theta_m = theta_k + dt f_2(u_k) / 2.  The reference takes
-//        theta_m = interpolate_angle(theta_k, theta_{k+1}, 0.5); on the constraint manifold theta_{k+1} = theta_k + dt f_2(u_k)
-//        (the heading rate f_2 of every model is independent of the pose), so both are the same point: same feasible set and
-//        KKT points, and the rows stay explicit in x_{k+1} (stage structure of the Riccati sweep).
-// model_trig_colloc fills the trig cache at the angle the row is evaluated at; stage_map turns the model derivatives at that
-// angle into the derivatives of D with respect to (theta, v, w) and dt, and of lam' D (chain rule through theta_m).
+//        c_k = x_k + D(theta_k, u_k, dt) - x_{k+1},  theta row wrapped,   D = dt sum_e wt_e f(theta_k + ce_e dt f_2(u_k), u_k)
+//      forward differences  (:54-69)    one point  (wt, ce) = (1, 0)
+//      midpoint differences (:91-108)   one point  (1, 1/2):  theta_m = theta_k + dt f_2(u_k) / 2
+//      Crank-Nicolson       (:130-147)  two points (1/2, 0), (3/2, 2): the reference's code evaluates to 1.5 f(x_{k+1}) + 0.5 f(x_k) - quot
+//        (`error` is aliased on the right-hand side, :139-141), restated literally; its heading row reads theta_{k+1} = theta_k + 2 dt f_2.
+//      The reference evaluates the dynamics at interpolate_angle(theta_k, theta_{k+1}, 0.5) resp. at theta_{k+1}; on the constraint
+//      manifold theta_{k+1} is an explicit function of (theta_k, u_k, dt) (the heading rate f_2 of every model is independent of the
+//      pose), so these are the same points: same feasible set and KKT points, and the rows stay explicit in x_{k+1} (stage structure
+//      of the Riccati sweep).
+// model_trig_colloc fills the trig cache at the angle(s) the row is evaluated at (tr: first point + steering terms, tr2: sin/cos of the
+// second point); colloc_f returns sum_e wt_e f_e (so that D = dt * that); stage_map turns the model derivatives at those angles into
+// the derivatives of D with respect to (theta, v, w) and dt, and of lam' D (chain rule through the evaluation angles).
+enum { COLLOC_FWD = 0, COLLOC_MID = 1, COLLOC_CN = 2 };
+template <typename T>
+MPC_HD int colloc_points(int method, T wt[2], T ce[2]) {
+    wt[0] = T(1); ce[0] = T(0); wt[1] = T(0); ce[1] = T(0);
+    if (method == COLLOC_MID) { ce[0] = T(0.5); return 1; }
+    if (method == COLLOC_CN) { wt[0] = T(0.5); wt[1] = T(1.5); ce[1] = T(2); return 2; }
+    return 1;
+}
 template <typename T, int MODEL>
-MPC_HD void model_trig_colloc(const Problem<T>& P, T th, T v, T w, T d, T tr[4]) {
-    if (P.collocation == 1) {
-        T f2;
-        if (MODEL == MODEL_UNICYCLE) f2 = w;
-        else if (MODEL == MODEL_SIMPLE_CAR) f2 = v * t_tan(w) / P.p0;
-        else if (MODEL == MODEL_SIMPLE_CAR_FRONT) { T sw, cw; t_sincos(w, &sw, &cw); f2 = v * sw / P.p0; }
-        else { T sb, cb; t_sincos(t_atan(P.p0 / (P.p1 + P.p0) * t_tan(w)), &sb, &cb); f2 = v * sb / P.p0; }
-        th += T(0.5) * d * f2;
+MPC_HD T model_heading_rate(const Problem<T>& P, T v, T w) {
+    if (MODEL == MODEL_UNICYCLE) return w;
+    if (MODEL == MODEL_SIMPLE_CAR) return v * t_tan(w) / P.p0;
+    if (MODEL == MODEL_SIMPLE_CAR_FRONT) { T sw, cw; t_sincos(w, &sw, &cw); return v * sw / P.p0; }
+    T sb, cb; t_sincos(t_atan(P.p0 / (P.p1 + P.p0) * t_tan(w)), &sb, &cb); return v * sb / P.p0;
+}
+template <typename T, int MODEL>
+MPC_HD void model_trig_colloc(const Problem<T>& P, T th, T v, T w, T d, T tr[4], T tr2[2]) {
+    tr2[0] = T(0); tr2[1] = T(0);
+    if (P.collocation == COLLOC_FWD) { model_trig<T, MODEL>(P, th, w, tr); return; }
+    T wt[2], ce[2];
+    const int np_ = colloc_points<T>(P.collocation, wt, ce);
+    const T f2 = model_heading_rate<T, MODEL>(P, v, w);
+    model_trig<T, MODEL>(P, th + ce[0] * d * f2, w, tr);
+    if (np_ > 1) {
+        T thb = th + ce[1] * d * f2;
+        if (MODEL == MODEL_KINEMATIC_BICYCLE) thb += tr[3];      // heading + slip angle beta
+        t_sincos(thb, &tr2[0], &tr2[1]);
     }
-    model_trig<T, MODEL>(P, th, w, tr);
+}
+template <typename T, int MODEL>
+MPC_HD void colloc_f(const Problem<T>& P, const T tr[4], const T tr2[2], T v, T w, T f[3]) {
+    model_f<T, MODEL>(P, tr, v, w, f);
+    if (P.collocation == COLLOC_CN) {
+        const T trb[4] = {tr2[0], tr2[1], tr[2], tr[3]};
+        T fb[3];
+        model_f<T, MODEL>(P, trb, v, w, fb);
+        for (int a = 0; a < 3; ++a) f[a] = T(0.5) * f[a] + T(1.5) * fb[a];
+    }
 }
 template <typename T>
 struct StageMap {
-    T f[3];          // f at the evaluation angle (D = dt f)
+    T f[3];          // sum_e wt_e f_e  (D = dt * f)
     T Jq[3][3];      // dD/d(theta, v, w)
     T Jdt[3];        // dD/d dt
     T Hqq[3][3];     // d2 (lam' D) / d(theta, v, w)^2
@@ -381,49 +412,66 @@ struct StageMap {
     T Hdd;           // d2 (lam' D) / d dt^2
 };
 template <typename T, int MODEL>
-MPC_HD void stage_map(const Problem<T>& P, const T tr[4], T v, T w, T d, const T lam[3], StageMap<T>& o) {
+MPC_HD void stage_map(const Problem<T>& P, const T tr[4], const T tr2[2], T v, T w, T d, const T lam[3], StageMap<T>& o) {
     T G[3][3], Hq[3][3];
     model_derivs<T, MODEL>(P, tr, v, w, lam, o.f, G, Hq);
-    T gq[3];
-    for (int j = 0; j < 3; ++j) gq[j] = lam[0] * G[0][j] + lam[1] * G[1][j] + lam[2] * G[2][j];
-    if (P.collocation != 1) {
+    if (P.collocation == COLLOC_FWD) {
+        T gq[3];
+        for (int j = 0; j < 3; ++j) gq[j] = lam[0] * G[0][j] + lam[1] * G[1][j] + lam[2] * G[2][j];
         for (int a = 0; a < 3; ++a) { o.Jdt[a] = o.f[a]; for (int j = 0; j < 3; ++j) o.Jq[a][j] = d * G[a][j]; }
         for (int j = 0; j < 3; ++j) { o.Hqd[j] = gq[j]; for (int l = 0; l < 3; ++l) o.Hqq[j][l] = d * Hq[j][l]; }
         o.Hdd = T(0);
         return;
     }
-    // second derivatives of the heading rate f_2 wrt (v, w): the lam = e_2 slice of the model Hessian
+    T wt[2], ce[2];
+    const int np_ = colloc_points<T>(P.collocation, wt, ce);
+    // second derivatives of the heading rate f_2 wrt (v, w): the lam = e_2 slice of the model Hessian (independent of the angle)
     const T e2[3] = {T(0), T(0), T(1)};
     T f_[3], G_[3][3], H2[3][3];
     model_derivs<T, MODEL>(P, tr, v, w, e2, f_, G_, H2);
-    const T f2 = o.f[2];
-    // m = d theta_m / d(theta, v, w, dt);  mab = second derivatives (only (u,u) and (u,dt) are non-zero)
-    const T m[4] = {T(1), T(0.5) * d * G[2][1], T(0.5) * d * G[2][2], T(0.5) * f2};
-    T mab[4][4];
-    for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) mab[a][b] = T(0);
-    for (int j = 1; j < 3; ++j) {
-        for (int l = 1; l < 3; ++l) mab[j][l] = T(0.5) * d * H2[j][l];
-        mab[j][3] = mab[3][j] = T(0.5) * G[2][j];
+    const T f2 = o.f[2], f2v = G[2][1], f2w = G[2][2];
+    T fsum[3] = {T(0), T(0), T(0)}, L[4][4];
+    for (int a = 0; a < 3; ++a) { o.Jdt[a] = T(0); for (int j = 0; j < 3; ++j) o.Jq[a][j] = T(0); }
+    for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) L[a][b] = T(0);
+    for (int e = 0; e < np_; ++e) {
+        T fe[3];
+        if (e == 1) {                                   // second evaluation angle: same steering terms, its own sin/cos
+            const T trb[4] = {tr2[0], tr2[1], tr[2], tr[3]};
+            model_derivs<T, MODEL>(P, trb, v, w, lam, fe, G, Hq);
+        } else { fe[0] = o.f[0]; fe[1] = o.f[1]; fe[2] = o.f[2]; }
+        T gq[3];
+        for (int j = 0; j < 3; ++j) gq[j] = lam[0] * G[0][j] + lam[1] * G[1][j] + lam[2] * G[2][j];
+        // m = d theta_e / d(theta, v, w, dt);  mab = its second derivatives (only (u,u) and (u,dt) are non-zero)
+        const T c_ = ce[e], we = wt[e];
+        const T m[4] = {T(1), c_ * d * f2v, c_ * d * f2w, c_ * f2};
+        T mab[4][4];
+        for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) mab[a][b] = T(0);
+        for (int j = 1; j < 3; ++j) {
+            for (int l = 1; l < 3; ++l) mab[j][l] = c_ * d * H2[j][l];
+            mab[j][3] = mab[3][j] = c_ * (j == 1 ? f2v : f2w);
+        }
+        // g(theta,u,dt) = f(theta_e,u): dg_a/dz = G[a][0] m_z + [z = u_j] G[a][j]
+        for (int a = 0; a < 3; ++a) {
+            T dg[4];
+            for (int z = 0; z < 4; ++z) dg[z] = G[a][0] * m[z];
+            dg[1] += G[a][1]; dg[2] += G[a][2];
+            for (int j = 0; j < 3; ++j) o.Jq[a][j] += we * d * dg[j];
+            o.Jdt[a] += we * (fe[a] + d * dg[3]);
+            fsum[a] += we * fe[a];
+        }
+        // L_e = dt phi(theta_e, u), phi = lam' f:  L_ab = [a=dt] Dphi_b + [b=dt] Dphi_a + dt D2phi_ab
+        T Dphi[4];
+        for (int z = 0; z < 4; ++z) Dphi[z] = gq[0] * m[z];
+        Dphi[1] += gq[1]; Dphi[2] += gq[2];
+        for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) {
+            T v2 = Hq[0][0] * m[a] * m[b] + gq[0] * mab[a][b];
+            if (a >= 1 && a <= 2) v2 += Hq[0][a] * m[b];
+            if (b >= 1 && b <= 2) v2 += Hq[0][b] * m[a];
+            if (a >= 1 && a <= 2 && b >= 1 && b <= 2) v2 += Hq[a][b];
+            L[a][b] += we * (d * v2 + (a == 3 ? Dphi[b] : T(0)) + (b == 3 ? Dphi[a] : T(0)));
+        }
     }
-    // g(theta,u,dt) = f(theta_m,u): dg_a/dz = G[a][0] m_z + [z = u_j] G[a][j]
-    for (int a = 0; a < 3; ++a) {
-        T dg[4];
-        for (int z = 0; z < 4; ++z) dg[z] = G[a][0] * m[z];
-        dg[1] += G[a][1]; dg[2] += G[a][2];
-        for (int j = 0; j < 3; ++j) o.Jq[a][j] = d * dg[j];
-        o.Jdt[a] = o.f[a] + d * dg[3];
-    }
-    // L = dt phi(theta_m, u), phi = lam' f:  L_ab = [a=dt] Dphi_b + [b=dt] Dphi_a + dt D2phi_ab
-    T Dphi[4], L[4][4];
-    for (int z = 0; z < 4; ++z) Dphi[z] = gq[0] * m[z];
-    Dphi[1] += gq[1]; Dphi[2] += gq[2];
-    for (int a = 0; a < 4; ++a) for (int b = 0; b < 4; ++b) {
-        T v2 = Hq[0][0] * m[a] * m[b] + gq[0] * mab[a][b];
-        if (a >= 1 && a <= 2) v2 += Hq[0][a] * m[b];
-        if (b >= 1 && b <= 2) v2 += Hq[0][b] * m[a];
-        if (a >= 1 && a <= 2 && b >= 1 && b <= 2) v2 += Hq[a][b];
-        L[a][b] = d * v2 + (a == 3 ? Dphi[b] : T(0)) + (b == 3 ? Dphi[a] : T(0));
-    }
+    for (int a = 0; a < 3; ++a) o.f[a] = fsum[a];
     for (int j = 0; j < 3; ++j) { o.Hqd[j] = L[j][3]; for (int l = 0; l < 3; ++l) o.Hqq[j][l] = L[j][l]; }
     o.Hdd = L[3][3];
 }

@@ -36,7 +36,7 @@ constexpr int NGAIN = 20;  // negated gains: nK0(6) nkappa0 nKnu0(3) | nK1(6) nk
 
 struct WaveLayout {
     int n, NS;
-    int NTR;                                      // trig-cache words per stage (3, or 4 for the bicycle / front-wheel car)
+    int NTR;                                      // trig-cache words per stage (3, or 4 for the bicycle / front-wheel car; +2 for Crank-Nicolson)
     int X, U, LAM, LAMN, SR, YR, PL, PU, DX, DU, CC, TRIG, GAIN, STG, SC, VP, ZC, total;
     int M, O, V;                                  // clearance rows per grid point, obstacles, vertices per obstacle
     int OS, OY, OI, OG, OAX, OAY, OHK;            // per-row slack, multiplier, obstacle index, cached g, gradient, curvature
@@ -166,6 +166,8 @@ struct IpmWave {
     __device__ __forceinline__ T& C_(int i, int k) const { return sm[L.CC + k * 3 + i]; }
     __device__ __forceinline__ T& SCL(int i) const { return sm[L.SC + i]; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
+    // trig-cache words per stage: sin, cos, steering term(s); Crank-Nicolson appends sin/cos of its second evaluation angle
+    static constexpr int NTRB = (MODEL == MODEL_KINEMATIC_BICYCLE || MODEL == MODEL_SIMPLE_CAR_FRONT) ? 4 : 3;
     __device__ __forceinline__ bool fx(int i) const { return (flags >> i) & 1; }
     __device__ __forceinline__ bool dtf() const { return (flags >> 3) & 1; }
     __device__ __forceinline__ bool quad() const { return (flags >> 4) & 1; }
@@ -345,13 +347,14 @@ struct IpmWave {
             T xk[3] = {xt(0, k, al), xt(1, k, al), xt(2, k, al)};
             T xn[3] = {xt(0, k + 1, al), xt(1, k + 1, al), xt(2, k + 1, al)};
             T v = ut(0, k, al), w = ut(1, k, al);
-            T tr[4], f[3];
-            model_trig_colloc<T, MODEL>(P, xk[2], v, w, d, tr);
-            model_f<T, MODEL>(P, tr, v, w, f);
+            T tr[4], tr2[2], f[3];
+            model_trig_colloc<T, MODEL>(P, xk[2], v, w, d, tr, tr2);
+            colloc_f<T, MODEL>(P, tr, tr2, v, w, f);
             T c0 = d * f[0] - (xn[0] - xk[0]);
             T c1 = d * f[1] - (xn[1] - xk[1]);
             T c2 = d * f[2] - normalize_theta(xn[2] - xk[2]);
-            for (int i = 0; i < L.NTR; ++i) F(L.TRIG, i, k) = tr[i];
+            for (int i = 0; i < NTRB; ++i) F(L.TRIG, i, k) = tr[i];
+            if (P.collocation == COLLOC_CN) { F(L.TRIG, NTRB, k) = tr2[0]; F(L.TRIG, NTRB + 1, k) = tr2[1]; }
             C_(0, k) = c0; C_(1, k) = c1; C_(2, k) = c2;
             th += t_abs(c0) + t_abs(c1) + t_abs(c2);
             if (quad()) {
@@ -449,11 +452,12 @@ struct IpmWave {
             const T n0 = r.xn[0] + alpha * r.dxn[0], n1 = r.xn[1] + alpha * r.dxn[1];
             const T n2 = r.dxn[2] != T(0) ? normalize_theta(r.xn[2] + alpha * r.dxn[2]) : r.xn[2];
             const T v = r.u[0] + alpha * r.du[0], w = r.u[1] + alpha * r.du[1];
-            T tr[4], f[3];
-            model_trig_colloc<T, MODEL>(P, x2_, v, w, d, tr);
-            model_f<T, MODEL>(P, tr, v, w, f);
+            T tr[4], tr2[2], f[3];
+            model_trig_colloc<T, MODEL>(P, x2_, v, w, d, tr, tr2);
+            colloc_f<T, MODEL>(P, tr, tr2, v, w, f);
             const T c0 = d * f[0] - (n0 - x0_), c1 = d * f[1] - (n1 - x1_), c2 = d * f[2] - normalize_theta(n2 - x2_);
-            for (int i = 0; i < L.NTR; ++i) F(L.TRIG, i, r.k) = tr[i];
+            for (int i = 0; i < NTRB; ++i) F(L.TRIG, i, r.k) = tr[i];
+            if (P.collocation == COLLOC_CN) { F(L.TRIG, NTRB, r.k) = tr2[0]; F(L.TRIG, NTRB + 1, r.k) = tr2[1]; }
             C_(0, r.k) = c0; C_(1, r.k) = c1; C_(2, r.k) = c2;
             th = t_abs(c0) + t_abs(c1) + t_abs(c2);
             if (r.quad) {
@@ -498,12 +502,14 @@ struct IpmWave {
             T rec[21];
             if (k < n - 1) {
                 T lam[3] = {F(L.LAM, 0, k), F(L.LAM, 1, k), F(L.LAM, 2, k)};
-                T tr[4] = {F(L.TRIG, 0, k), F(L.TRIG, 1, k), F(L.TRIG, 2, k), L.NTR > 3 ? F(L.TRIG, 3, k) : T(0)};
+                T tr[4] = {F(L.TRIG, 0, k), F(L.TRIG, 1, k), F(L.TRIG, 2, k), NTRB > 3 ? F(L.TRIG, 3, k) : T(0)};
+                T tr2[2] = {T(0), T(0)};
+                if (P.collocation == COLLOC_CN) { tr2[0] = F(L.TRIG, NTRB, k); tr2[1] = F(L.TRIG, NTRB + 1, k); }
                 T v = F(L.U, 0, k), w = F(L.U, 1, k);
                 // derivatives of the collocation increment D(theta, u, dt) (forward or midpoint differences, mpc_core.hpp::stage_map);
                 // gJ[j] = lam' dD/dq_j is what the dual residuals need, Jdt = dD/d dt the dt column of the row
                 StageMap<T> sm_;
-                stage_map<T, MODEL>(P, tr, v, w, d, lam, sm_);
+                stage_map<T, MODEL>(P, tr, tr2, v, w, d, lam, sm_);
                 T gJ[3];
                 for (int j = 0; j < 3; ++j) gJ[j] = lam[0] * sm_.Jq[0][j] + lam[1] * sm_.Jq[1][j] + lam[2] * sm_.Jq[2][j];
                 // stage record, mu-independent part: kept in registers and stored at the END of the loop body -- every LDS store

@@ -104,47 +104,60 @@ def model_derivs(model, p, th, v, w):
     return f, G, H
 
 
+def colloc_points(method):
+    """Evaluation points (weight, c) of the collocation increment D = dt sum_e weight_e f(theta_k + c_e dt f_2(u_k), u_k)."""
+    if method == R.COLLOC_FORWARD:
+        return [(1.0, 0.0)]
+    if method == R.COLLOC_MIDPOINT:
+        return [(1.0, 0.5)]
+    if method == R.COLLOC_CRANK_NICOLSON:
+        # the reference's code evaluates to 1.5 f(x_{k+1}) + 0.5 f(x_k) - quot (fd_collocation_se2.h:139-141, `error` aliased on the
+        # right-hand side); restated literally: the heading row then reads theta_{k+1} = theta_k + 2 dt f_2(u_k)
+        return [(0.5, 0.0), (1.5, 2.0)]
+    raise NotImplementedError("collocation method")
+
+
 def stage_map_derivs(cfg: R.OcpConfig, th, v, w, dt, lam=None):
     """Increment of the collocation row in solver form:  c_k = x_k + D(theta_k, u_k, dt) - x_{k+1}  (theta row wrapped).
       forward differences (fd_collocation_se2.h:54-69)    D = dt f(theta_k, u_k)
-      midpoint differences (fd_collocation_se2.h:91-108)  D = dt f(theta_m, u_k),  theta_m = theta_k + dt f_theta-row(u_k) / 2
-    The reference evaluates the midpoint at interpolate_angle(theta_k, theta_{k+1}, 0.5); on the constraint manifold theta_{k+1} =
-    theta_k + dt f_2(u_k) (the heading rate of every model is independent of the pose), so theta_m is the SAME point and the
-    two forms have the same feasible set and KKT points -- the solver form keeps the rows explicit in x_{k+1} (stage structure).
+      midpoint differences (fd_collocation_se2.h:91-108)  D = dt f(theta_m, u_k),  theta_m = theta_k + dt f_2(u_k) / 2
+      Crank-Nicolson (fd_collocation_se2.h:130-147, literal) D = dt (0.5 f(theta_k, u_k) + 1.5 f(theta_k + 2 dt f_2(u_k), u_k))
+    The reference evaluates the dynamics at interpolate_angle(theta_k, theta_{k+1}, 0.5) resp. at theta_{k+1}; on the constraint
+    manifold theta_{k+1} is an explicit function of (theta_k, u_k, dt) because the heading rate f_2 of every model is independent of
+    the pose, so these are the SAME points: same feasible set and KKT points, and the rows stay explicit in x_{k+1} (stage structure).
     Returns val (3,), Jq (3,3) = dD/d(theta,v,w), Jdt (3,), and with lam: Hqq (3,3), Hqd (3,), Hdd of lam^T D."""
-    if cfg.collocation == R.COLLOC_FORWARD:
-        f, G, H = model_derivs(cfg.model, cfg.model_params, th, v, w)
-        out = dict(val=dt * f, Jq=dt * G, Jdt=f.copy())
-        if lam is not None:
-            out.update(Hqq=dt * np.einsum("a,ajl->jl", lam, H), Hqd=lam @ G, Hdd=0.0)
-        return out
-    if cfg.collocation != R.COLLOC_MIDPOINT:
-        raise NotImplementedError("solver form: forward and midpoint differences")
+    pts = colloc_points(cfg.collocation)
     f0, G0, H0 = model_derivs(cfg.model, cfg.model_params, th, v, w)      # heading-rate row (independent of theta)
     f2, f2u, f2uu = f0[2], G0[2, 1:], H0[2, 1:, 1:]
-    thm = th + 0.5 * dt * f2
-    f, G, H = model_derivs(cfg.model, cfg.model_params, thm, v, w)
-    m = np.array([1.0, 0.5 * dt * f2u[0], 0.5 * dt * f2u[1], 0.5 * f2])        # d theta_m / d(theta, v, w, dt)
-    # g(theta,u,dt) = f(theta_m, u):  dg/da = f_theta m_a + [a = u_j] f_uj
-    dg = np.outer(G[:, 0], m)
-    dg[:, 1:3] += G[:, 1:3]
-    out = dict(val=dt * f, Jq=dt * dg[:, :3], Jdt=f + dt * dg[:, 3])
+    val = np.zeros(3); Jq = np.zeros((3, 3)); Jdt = np.zeros(3)
+    L = np.zeros((4, 4))
+    for (wt, ce) in pts:
+        f, G, H = (f0, G0, H0) if ce == 0.0 else model_derivs(cfg.model, cfg.model_params, th + ce * dt * f2, v, w)
+        m = np.array([1.0, ce * dt * f2u[0], ce * dt * f2u[1], ce * f2])        # d theta_e / d(theta, v, w, dt)
+        dg = np.outer(G[:, 0], m)                                                 # g(theta,u,dt) = f(theta_e, u)
+        dg[:, 1:3] += G[:, 1:3]
+        val += wt * dt * f
+        Jq += wt * dt * dg[:, :3]
+        Jdt += wt * (f + dt * dg[:, 3])
+        if lam is not None:
+            gq = lam @ G                                  # phi_m, phi_v, phi_w
+            Hl = np.einsum("a,ajl->jl", lam, H)           # second derivatives of phi = lam^T f wrt (theta_e, v, w)
+            mab = np.zeros((4, 4))
+            mab[1:3, 1:3] = ce * dt * f2uu
+            mab[1:3, 3] = mab[3, 1:3] = ce * f2u
+            Dphi = gq[0] * m
+            Dphi[1:3] += gq[1:3]
+            D2 = Hl[0, 0] * np.outer(m, m) + gq[0] * mab
+            for j in (1, 2):
+                D2[j, :] += Hl[0, j] * m
+                D2[:, j] += Hl[0, j] * m
+            D2[1:3, 1:3] += Hl[1:3, 1:3]
+            Le = dt * D2
+            Le[3, :] += Dphi
+            Le[:, 3] += Dphi
+            L += wt * Le
+    out = dict(val=val, Jq=Jq, Jdt=Jdt)
     if lam is not None:
-        gq = lam @ G                                  # phi_m, phi_v, phi_w
-        Hl = np.einsum("a,ajl->jl", lam, H)           # second derivatives of phi = lam^T f wrt (m, v, w)
-        mab = np.zeros((4, 4))
-        mab[1:3, 1:3] = 0.5 * dt * f2uu
-        mab[1:3, 3] = mab[3, 1:3] = 0.5 * f2u
-        Dphi = gq[0] * m
-        Dphi[1:3] += gq[1:3]
-        D2 = Hl[0, 0] * np.outer(m, m) + gq[0] * mab
-        for j in (1, 2):
-            D2[j, :] += Hl[0, j] * m
-            D2[:, j] += Hl[0, j] * m
-        D2[1:3, 1:3] += Hl[1:3, 1:3]
-        L = dt * D2
-        L[3, :] += Dphi
-        L[:, 3] += Dphi
         out.update(Hqq=L[:3, :3], Hqd=L[:3, 3], Hdd=L[3, 3])
     return out
 
@@ -231,8 +244,7 @@ class SolverNlp:
     indexed into a flat vector: [x_1 .. x_{n-2}, xf(free comps), u_0 .. u_{n-2}, dt(if free)]."""
 
     def __init__(self, cfg: R.OcpConfig, inp: R.CycleInputs, relevant=None):
-        if cfg.collocation not in (R.COLLOC_FORWARD, R.COLLOC_MIDPOINT):
-            raise NotImplementedError("analytic solver form: forward and midpoint differences")
+        colloc_points(cfg.collocation)      # raises for an unknown method
         self.cfg, self.inp = cfg, inp
         n = self.n = cfg.n
         self.relevant = relevant if relevant is not None else [[] for _ in range(n)]

@@ -65,7 +65,7 @@ def make_obstacles(name, n=30, B=10, O=6, V=6, M=4, keep=6):
     print(name, "kept", len(sel), "iters", IT)
 
 
-if __name__ == "__main__" and "--warm" not in sys.argv and "--integral" not in sys.argv and "--closed-loop" not in sys.argv and "--config3" not in sys.argv and "--midpoint" not in sys.argv:
+if __name__ == "__main__" and "--warm" not in sys.argv and "--integral" not in sys.argv and "--closed-loop" not in sys.argv and "--config3" not in sys.argv and "--midpoint" not in sys.argv and "--cn" not in sys.argv:
     make_obstacles("unicycle_quadratic_obstacles_n30")
     make("carlike_min_time_n50", R.config_carlike_min_time(50), W.carlike_min_time_inputs(32, seed=101), keep=8)
     make("carlike_min_time_n20", R.config_carlike_min_time(20), W.carlike_min_time_inputs(32, seed=102, goal_range=(1.0, 2.5)), keep=8)
@@ -189,3 +189,13 @@ if __name__ == "__main__" and "--midpoint" in sys.argv:
     make_midpoint("unicycle_quadratic_midpoint_n20", c, W.unicycle_quadratic_inputs(16, seed=108))
     c = R.config_bicycle_min_time(30); c.collocation = R.COLLOC_MIDPOINT
     make_midpoint("bicycle_min_time_midpoint_n30", c, W.carlike_min_time_inputs(32, seed=109, goal_range=(2.0, 6.0)), keep=4)
+
+
+if __name__ == "__main__" and "--cn" in sys.argv:
+    # crank_nicolson_differences, restated literally (1.5 f(x_{k+1}) + 0.5 f(x_k), fd_collocation_se2.h:139-141)
+    c = R.config_carlike_min_time(20); c.collocation = R.COLLOC_CRANK_NICOLSON
+    make_midpoint("carlike_min_time_cn_n20", c, W.carlike_min_time_inputs(32, seed=110, goal_range=(1.0, 2.5)))
+    c = R.config_bicycle_min_time(30); c.collocation = R.COLLOC_CRANK_NICOLSON
+    make_midpoint("bicycle_min_time_cn_n30", c, W.carlike_min_time_inputs(32, seed=111, goal_range=(2.0, 6.0)), keep=4)
+    c = R.config_unicycle_quadratic(20); c.collocation = R.COLLOC_CRANK_NICOLSON
+    make_midpoint("unicycle_quadratic_cn_n20", c, W.unicycle_quadratic_inputs(16, seed=112))

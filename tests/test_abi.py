@@ -71,7 +71,7 @@ def test_invalid_config_rejected(lib):
     assert lib.mpc_create(C.byref(bad), 4, 0, C.byref(h)) == MPC_EINVAL
     assert b"n out of range" in lib.mpc_last_error()
     bad = config_carlike_min_time(n=20)
-    bad.collocation = 2          # crank_nicolson_differences: not implemented (forward = 0 and midpoint = 1 are)
+    bad.collocation = 7          # unknown method (0 forward, 1 midpoint, 2 Crank-Nicolson exist)
     assert lib.mpc_create(C.byref(bad), 4, 0, C.byref(h)) == MPC_EINVAL
     bad = config_carlike_min_time(n=20)
     bad.dt_free = 0

@@ -412,24 +412,28 @@ def test_active_clearance_rows_vs_c_oracle(m, c_oracle):
     s.close()
 
 
-@pytest.mark.parametrize("name", ["carlike_min_time_midpoint_n20", "unicycle_quadratic_midpoint_n20", "bicycle_min_time_midpoint_n30"])
-def test_midpoint_collocation_golden(m, name):
-    """midpoint_differences collocation (fd_collocation_se2.h:91-108): numpy-oracle fixtures (explicit solver form; every fixture is
-    feasible in the reference-form midpoint rows, tests/golden/make_golden.py --midpoint).  Same iterate sequence on the device."""
+COLLOC_CASES = {
+    "carlike_min_time_midpoint_n20": ("carlike", 20, 1), "unicycle_quadratic_midpoint_n20": ("unicycle", 20, 1), "bicycle_min_time_midpoint_n30": ("bicycle", 30, 1),
+    "carlike_min_time_cn_n20": ("carlike", 20, 2), "unicycle_quadratic_cn_n20": ("unicycle", 20, 2), "bicycle_min_time_cn_n30": ("bicycle", 30, 2),
+}
+
+
+@pytest.mark.parametrize("name", sorted(COLLOC_CASES))
+def test_midpoint_and_crank_nicolson_collocation_golden(m, name):
+    """midpoint_differences (fd_collocation_se2.h:91-108) and crank_nicolson_differences (:130-147, restated literally) collocation:
+    numpy-oracle fixtures in the explicit solver form (tests/golden/make_golden.py --midpoint / --cn); every fixture and every device
+    result is feasible in the REFERENCE-form rows (dynamics evaluated at interpolate_angle(..) / at x_{k+1}).  Same iterate sequence."""
+    from oracle import se2_nlp as R
+    kind, n, method = COLLOC_CASES[name]
     g = np.load(os.path.join(GOLD, name + ".npz"))
-    mk = {"carlike_min_time_midpoint_n20": lambda: m.config_carlike_min_time(20, collocation=m._abi.COLLOC_MIDPOINT),
-          "unicycle_quadratic_midpoint_n20": lambda: m.config_unicycle_quadratic(20, collocation=m._abi.COLLOC_MIDPOINT),
-          "bicycle_min_time_midpoint_n30": lambda: m.config_bicycle_min_time(30, collocation=m._abi.COLLOC_MIDPOINT)}[name]
-    s = m.BatchSolver(mk(), max_batch=g["x0"].shape[0])
+    mk = {"carlike": m.config_carlike_min_time, "unicycle": m.config_unicycle_quadratic, "bicycle": m.config_bicycle_min_time}[kind]
+    s = m.BatchSolver(mk(n, collocation=method), max_batch=g["x0"].shape[0])
     r = s.solve(g["x0"], g["xf"], g["u_prev"], g["dt_prev"])
     assert (r.status == 0).all()
     assert np.abs(r.x - g["x"]).max() < 1e-6 and np.abs(r.u - g["u"]).max() < 1e-6 and np.abs(r.dt - g["dt"]).max() < 1e-8
     assert (np.abs(r.iters - g["iters"]) <= np.maximum(2, 0.1 * g["iters"])).all()
-    # the solution satisfies the reference's own midpoint rows (theta_m = interpolate_angle(theta_k, theta_{k+1}, 0.5))
-    from oracle import se2_nlp as R
-    ocfg = {"carlike_min_time_midpoint_n20": R.config_carlike_min_time(20), "unicycle_quadratic_midpoint_n20": R.config_unicycle_quadratic(20),
-            "bicycle_min_time_midpoint_n30": R.config_bicycle_min_time(30)}[name]
-    ocfg.collocation = R.COLLOC_MIDPOINT
+    ocfg = {"carlike": R.config_carlike_min_time, "unicycle": R.config_unicycle_quadratic, "bicycle": R.config_bicycle_min_time}[kind](n)
+    ocfg.collocation = method
     for i in range(g["x0"].shape[0]):
         nlp = R.ReferenceNlp(ocfg, R.CycleInputs(x0=g["x0"][i], xf=g["xf"][i], u_prev=g["u_prev"][i], dt_prev=float(g["dt_prev"][i])))
         assert np.abs(nlp.equalities(nlp.pack(R.Trajectory(r.x[i], r.u[i, :-1], float(r.dt[i]))))).max() < 1e-6
