@@ -18,6 +18,7 @@ class OracleConfig(C.Structure):
         ("objective", C.c_int32), ("Q", C.c_double * 3), ("R", C.c_double * 2), ("has_Qf", C.c_int32),
         ("Qf", C.c_double * 3), ("u_lb", C.c_double * 2), ("u_ub", C.c_double * 2), ("du_lb", C.c_double * 2),
         ("du_ub", C.c_double * 2), ("max_iter", C.c_int32), ("tol", C.c_double), ("mu_init", C.c_double),
+        ("collocation", C.c_int32),
     ]
 
 
@@ -61,6 +62,7 @@ def from_nlp_config(cfg, max_iter=100, tol=1e-8, mu_init=0.1) -> OracleConfig:
         o.u_lb[j], o.u_ub[j] = cfg.u_lb[j], cfg.u_ub[j]
         o.du_lb[j], o.du_ub[j] = max(cfg.du_lb[j], -1e30), min(cfg.du_ub[j], 1e30)
     o.max_iter, o.tol, o.mu_init = max_iter, tol, mu_init
+    o.collocation = int(getattr(cfg, "collocation", 0))
     return o
 
 

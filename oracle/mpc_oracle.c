@@ -15,7 +15,7 @@
  * NLP pieces and where they come from (paths under /root/reference/mpc_local_planner/):
  *   dynamics          include/mpc_local_planner/systems/{unicycle_robot.h:59-68,simple_car.h:68-77,131-141,
  *                     kinematic_bicycle_model.h:65-77}
- *   collocation       include/mpc_local_planner/optimal_control/fd_collocation_se2.h:54-69 (forward differences)
+ *   collocation       include/mpc_local_planner/optimal_control/fd_collocation_se2.h:54-69 (forward differences), :91-108 midpoint, :130-147 crank-nicolson (stage_map)
  *   wrap              include/mpc_local_planner/utils/math_utils.h:81-91
  *   objective         (n-1)*dt (src/optimal_control/min_time_via_points_cost.cpp:52-56,120-124) |
  *                     quadratic form (src/optimal_control/quadratic_cost_se2.cpp:31-52) + terminal
@@ -52,6 +52,7 @@ typedef struct oracle_config {
     int32_t max_iter;
     double tol;
     double mu_init;
+    int32_t collocation;        /* 0 forward, 1 midpoint, 2 crank-nicolson (literal) -- same codes as include/mpc_hip.h */
 } oracle_config;
 
 #define PI 3.14159265358979323846
@@ -103,6 +104,62 @@ static void model_derivs(const oracle_config* c, double th, double v, double w, 
         double L = c->model_params[0];
         f[2] = v * sin(w) / L; G[2][1] = sin(w) / L; G[2][2] = v * cos(w) / L;
         H[2][1][2] = H[2][2][1] = cos(w) / L; H[2][2][2] = -v * sin(w) / L;
+    }
+}
+
+/* Increment of a collocation row in solver form, c_k = x_k + Dk(theta_k, u_k, dt) - x_{k+1}, for the three finite-difference rules
+ * (fd_collocation_se2.h:54-69 forward, :91-108 midpoint, :130-147 crank-nicolson as coded: 0.5 f(x_k) + 1.5 f(x_{k+1})).  The
+ * reference evaluates f at theta_k + ce dt f_2(u_k) on the constraint manifold (f_2 = heading rate, pose independent), so
+ * Dk = dt sum_e wt_e f(theta_k + ce_e dt f_2, u_k).  q = (theta, v, w).  With lam: second derivatives of lam^T Dk. */
+typedef struct stage_map_t { double val[3], Jq[3][3], Jdt[3], Hqq[3][3], Hqd[3], Hdd; } stage_map_t;
+static void stage_map(const oracle_config* c, double th, double v, double w, double dt, const double* lam, stage_map_t* o) {
+    static const double PT[3][2][2] = {{{1.0, 0.0}, {0, 0}}, {{1.0, 0.5}, {0, 0}}, {{0.5, 0.0}, {1.5, 2.0}}};
+    const int npt = c->collocation == 2 ? 2 : 1;
+    double f0[3], G0[3][3], H0[3][3][3];
+    model_derivs(c, th, v, w, f0, G0, H0);
+    const double f2 = f0[2], f2u[2] = {G0[2][1], G0[2][2]};
+    memset(o, 0, sizeof(*o));
+    double L[4][4]; memset(L, 0, sizeof(L));
+    for (int e = 0; e < npt; ++e) {
+        const double wt = PT[c->collocation][e][0], ce = PT[c->collocation][e][1];
+        double f[3], G[3][3], H[3][3][3];
+        model_derivs(c, th + ce * dt * f2, v, w, f, G, H);
+        const double m[4] = {1.0, ce * dt * f2u[0], ce * dt * f2u[1], ce * f2};      /* d theta_e / d(theta, v, w, dt) */
+        for (int a = 0; a < 3; ++a) {
+            double dg[4];
+            for (int j = 0; j < 4; ++j) dg[j] = G[a][0] * m[j];
+            dg[1] += G[a][1]; dg[2] += G[a][2];
+            o->val[a] += wt * dt * f[a];
+            for (int j = 0; j < 3; ++j) o->Jq[a][j] += wt * dt * dg[j];
+            o->Jdt[a] += wt * (f[a] + dt * dg[3]);
+        }
+        if (!lam) continue;
+        double gq[3], Hl[3][3];
+        for (int j = 0; j < 3; ++j) {
+            gq[j] = lam[0] * G[0][j] + lam[1] * G[1][j] + lam[2] * G[2][j];
+            for (int l = 0; l < 3; ++l) Hl[j][l] = lam[0] * H[0][j][l] + lam[1] * H[1][j][l] + lam[2] * H[2][j][l];
+        }
+        double mab[4][4]; memset(mab, 0, sizeof(mab));                               /* second derivatives of theta_e */
+        for (int j = 1; j < 3; ++j) {
+            for (int l = 1; l < 3; ++l) mab[j][l] = ce * dt * H0[2][j][l];
+            mab[j][3] = mab[3][j] = ce * f2u[j - 1];
+        }
+        double Dphi[4], D2[4][4];
+        for (int j = 0; j < 4; ++j) Dphi[j] = gq[0] * m[j];
+        Dphi[1] += gq[1]; Dphi[2] += gq[2];
+        for (int j = 0; j < 4; ++j) for (int l = 0; l < 4; ++l) D2[j][l] = Hl[0][0] * m[j] * m[l] + gq[0] * mab[j][l];
+        for (int j = 1; j < 3; ++j) for (int l = 0; l < 4; ++l) { D2[j][l] += Hl[0][j] * m[l]; D2[l][j] += Hl[0][j] * m[l]; }
+        for (int j = 1; j < 3; ++j) for (int l = 1; l < 3; ++l) D2[j][l] += Hl[j][l];
+        for (int j = 0; j < 4; ++j) for (int l = 0; l < 4; ++l) {
+            double le = dt * D2[j][l];
+            if (j == 3) le += Dphi[l];
+            if (l == 3) le += Dphi[j];
+            L[j][l] += wt * le;
+        }
+    }
+    if (lam) {
+        for (int j = 0; j < 3; ++j) { for (int l = 0; l < 3; ++l) o->Hqq[j][l] = L[j][l]; o->Hqd[j] = L[j][3]; }
+        o->Hdd = L[3][3];
     }
 }
 
@@ -309,11 +366,11 @@ static void eval_point(const work_t* w, const double* X, const double* U, double
     int n = w->n;
     double f = c->objective == 0 ? (n - 1) * D : 0.0;
     for (int k = 0; k < n - 1; ++k) {
-        double ff[3], G[3][3], H[3][3][3];
-        model_derivs(c, X[3 * k + 2], U[2 * k], U[2 * k + 1], ff, G, H);
-        cc[3 * k + 0] = D * ff[0] - (X[3 * (k + 1)] - X[3 * k]);
-        cc[3 * k + 1] = D * ff[1] - (X[3 * (k + 1) + 1] - X[3 * k + 1]);
-        cc[3 * k + 2] = D * ff[2] - wrap(X[3 * (k + 1) + 2] - X[3 * k + 2]);
+        stage_map_t sm;
+        stage_map(c, X[3 * k + 2], U[2 * k], U[2 * k + 1], D, NULL, &sm);
+        cc[3 * k + 0] = sm.val[0] - (X[3 * (k + 1)] - X[3 * k]);
+        cc[3 * k + 1] = sm.val[1] - (X[3 * (k + 1) + 1] - X[3 * k + 1]);
+        cc[3 * k + 2] = sm.val[2] - wrap(X[3 * (k + 1) + 2] - X[3 * k + 2]);
         if (c->objective == 1) {
             double xd[3] = {X[3 * k] - w->xf[0], X[3 * k + 1] - w->xf[1], wrap(X[3 * k + 2] - w->xf[2])};
             for (int i = 0; i < 3; ++i) f += c->Q[i] * xd[i] * xd[i];
@@ -349,14 +406,14 @@ static void kkt_terms(const work_t* w, const double* cc, err_t* e) {
     double rdd = c->objective == 0 ? (double)(n - 1) : 0.0;
     for (int k = 0; k < n - 1; ++k) {
         const double* lam = &w->lam[3 * k];
-        double f[3], G[3][3], H[3][3][3];
         double v = w->U[2 * k], om = w->U[2 * k + 1];
-        model_derivs(c, w->X[3 * k + 2], v, om, f, G, H);
-        double gq[3];
-        for (int j = 0; j < 3; ++j) gq[j] = lam[0] * G[0][j] + lam[1] * G[1][j] + lam[2] * G[2][j];
+        stage_map_t sm;
+        stage_map(c, w->X[3 * k + 2], v, om, w->D, NULL, &sm);
+        double gq[3];              /* lam^T dDk/dq */
+        for (int j = 0; j < 3; ++j) gq[j] = lam[0] * sm.Jq[0][j] + lam[1] * sm.Jq[1][j] + lam[2] * sm.Jq[2][j];
         for (int i = 0; i < 3; ++i) { double a = fabs(cc[3 * k + i]); if (a > e->rp) e->rp = a; e->theta += a; e->sm += fabs(lam[i]); }
         e->nm += 3;
-        rdd += lam[0] * f[0] + lam[1] * f[1] + lam[2] * f[2];
+        rdd += lam[0] * sm.Jdt[0] + lam[1] * sm.Jdt[1] + lam[2] * sm.Jdt[2];
         double gx[3] = {0, 0, 0}, gu[2] = {0, 0};
         if (c->objective == 1) {
             double xd[3] = {w->X[3 * k] - w->xf[0], w->X[3 * k + 1] - w->xf[1], wrap(w->X[3 * k + 2] - w->xf[2])};
@@ -378,12 +435,12 @@ static void kkt_terms(const work_t* w, const double* cc, err_t* e) {
         }
         if (k >= 1) {
             const double* lp = &w->lam[3 * (k - 1)];
-            double r[3] = {gx[0] + osx + lam[0] - lp[0], gx[1] + osy + lam[1] - lp[1], gx[2] + lam[2] + w->D * gq[0] - lp[2]};
+            double r[3] = {gx[0] + osx + lam[0] - lp[0], gx[1] + osy + lam[1] - lp[1], gx[2] + lam[2] + gq[0] - lp[2]};
             for (int i = 0; i < 3; ++i) if (fabs(r[i]) > e->rd) e->rd = fabs(r[i]);
         }
         for (int j = 0; j < 2; ++j) {
             double u = w->U[2 * k + j], pl = w->pl[2 * k + j], pu = w->pu[2 * k + j];
-            double r = gu[j] + w->D * gq[1 + j] - pl + pu;
+            double r = gu[j] + gq[1 + j] - pl + pu;
             for (int q = j; q < 4; q += 2) {
                 if (row_on(w, k, q)) r += sgn(q) * w->y[4 * k + q];
                 if (row_on(w, k + 1, q)) r -= sgn(q) * w->y[4 * (k + 1) + q];
@@ -449,17 +506,17 @@ static void assemble(work_t* w, const double* cc, double delta, double dc, doubl
     }
     for (int k = 0; k < n - 1; ++k) {
         const double* lam = &w->lam[3 * k];
-        double f[3], G[3][3], H[3][3][3];
         double v = w->U[2 * k], om = w->U[2 * k + 1];
-        model_derivs(c, w->X[3 * k + 2], v, om, f, G, H);
+        stage_map_t sm;
+        stage_map(c, w->X[3 * k + 2], v, om, D, lam, &sm);
         int qi[3] = {k >= 1 ? ixn(k, 2) : -1, iu(k, 0), iu(k, 1)};
-        /* collocation rows: c = x_k + D f - x_{k+1} */
+        /* collocation rows: c = x_k + Dk(theta_k, u_k, dt) - x_{k+1} */
         for (int a = 0; a < 3; ++a) {
             int row = il(k, a);
             if (k >= 1) sym_add(w, row, ixn(k, a), 1.0);
             if (k + 1 < n - 1 || !c->xf_fixed[a]) sym_add(w, row, ixn(k + 1, a), -1.0);
-            for (int j = 0; j < 3; ++j) if (qi[j] >= 0) sym_add(w, row, qi[j], D * G[a][j]);
-            w->bcol[row] += f[a];
+            for (int j = 0; j < 3; ++j) if (qi[j] >= 0) sym_add(w, row, qi[j], sm.Jq[a][j]);
+            w->bcol[row] += sm.Jdt[a];
             w->rhs[row] = -cc[3 * k + a];
         }
         if (k == n - 2) for (int a = 0; a < 3; ++a) if (c->xf_fixed[a]) band_add(w, il(k, a), il(k, a), -dc);
@@ -468,11 +525,11 @@ static void assemble(work_t* w, const double* cc, double delta, double dc, doubl
             if (qi[j] < 0) continue;
             for (int l = j; l < 3; ++l) {
                 if (qi[l] < 0) continue;
-                double h = D * (lam[0] * H[0][j][l] + lam[1] * H[1][j][l] + lam[2] * H[2][j][l]);
-                sym_add(w, qi[j], qi[l], h);
+                sym_add(w, qi[j], qi[l], sm.Hqq[j][l]);
             }
-            w->bcol[qi[j]] += lam[0] * G[0][j] + lam[1] * G[1][j] + lam[2] * G[2][j];
+            w->bcol[qi[j]] += sm.Hqd[j];
         }
+        hdd += sm.Hdd;
         /* objective */
         if (c->objective == 1) {
             double xd[3] = {w->X[3 * k] - w->xf[0], w->X[3 * k + 1] - w->xf[1], wrap(w->X[3 * k + 2] - w->xf[2])};

@@ -438,3 +438,29 @@ def test_midpoint_and_crank_nicolson_collocation_golden(m, name):
         nlp = R.ReferenceNlp(ocfg, R.CycleInputs(x0=g["x0"][i], xf=g["xf"][i], u_prev=g["u_prev"][i], dt_prev=float(g["dt_prev"][i])))
         assert np.abs(nlp.equalities(nlp.pack(R.Trajectory(r.x[i], r.u[i, :-1], float(r.dt[i]))))).max() < 1e-6
     s.close()
+
+
+@pytest.mark.parametrize("method", [1, 2])
+def test_config2_midpoint_and_crank_nicolson_batch_vs_c_oracle(m, c_oracle, method):
+    """BASELINE.json config 2 (car-like min-time, n=50, B=256 of the 8d input distribution) with the other two collocation rules of
+    grid/collocation_method (src/controller.cpp:298-312) against oracle/mpc_oracle.c's stage_map restatement."""
+    import copy
+    from oracle import se2_nlp as R
+    B = 256
+    _, ocfg = _cases(m)["carlike_min_time_n50"]
+    ocfg = copy.deepcopy(ocfg)
+    ocfg.collocation = method
+    x0, xf, up, dtp = m.workloads.carlike_min_time_inputs(B)
+    s = m.BatchSolver(m.config_carlike_min_time(50, collocation=method), max_batch=B)
+    r = s.solve(x0, xf, up, dtp)
+    xo, uo, do, st, it = c_oracle.solve_batch(c_oracle.from_nlp_config(ocfg), x0, xf, up, dtp)
+    both = (r.status == 0) & (st == 0)
+    assert both.mean() > 0.8
+    assert (r.status == st).mean() > 0.93
+    err = np.maximum(np.abs(r.x - xo).reshape(B, -1).max(1), np.abs(r.u - uo).reshape(B, -1).max(1))
+    err = np.maximum(err, np.abs(r.dt - do))
+    assert (err[both] < 1e-4).mean() > 0.9
+    assert np.median(err[both]) < 1e-8
+    for i in np.nonzero(r.status == 0)[0][:32]:
+        assert _feasibility(R, ocfg, x0, xf, up, dtp, r, i) < 1e-6
+    s.close()

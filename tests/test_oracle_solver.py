@@ -192,3 +192,19 @@ def test_c_oracle_clearance_rows_match_numpy_goldens():
         assert (st == 0).all()
         assert np.abs(xo - g["x"]).max() < 1e-9
         assert (it == g["iters"]).all()
+
+
+@pytest.mark.parametrize("name,kind,n,method", [
+    ("carlike_min_time_midpoint_n20", "carlike", 20, 1), ("unicycle_quadratic_midpoint_n20", "unicycle", 20, 1),
+    ("bicycle_min_time_midpoint_n30", "bicycle", 30, 1), ("carlike_min_time_cn_n20", "carlike", 20, 2),
+    ("unicycle_quadratic_cn_n20", "unicycle", 20, 2), ("bicycle_min_time_cn_n30", "bicycle", 30, 2)])
+def test_c_oracle_midpoint_and_crank_nicolson_match_numpy_goldens(name, kind, n, method, c_oracle):
+    """oracle/mpc_oracle.c's stage_map (midpoint / literal crank-nicolson rows, chain-rule derivatives incl. the dt column and
+    d2/ddt2) against the numpy oracle's fixtures (tests/golden/make_golden.py --midpoint / --cn)."""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    cfg = {"carlike": R.config_carlike_min_time, "unicycle": R.config_unicycle_quadratic, "bicycle": R.config_bicycle_min_time}[kind](n)
+    cfg.collocation = method
+    xo, uo, do, st, it = c_oracle.solve_batch(c_oracle.from_nlp_config(cfg), g["x0"], g["xf"], g["u_prev"], g["dt_prev"])
+    assert (st == 0).all()
+    assert np.abs(xo - g["x"]).max() < 1e-6 and np.abs(uo - g["u"]).max() < 1e-6 and np.abs(do - g["dt"]).max() < 1e-8
+    assert np.abs(it - g["iters"]).max() <= 2
