@@ -100,6 +100,10 @@ typedef struct mpc_config {
     int32_t max_obstacle_rows;        /* clearance rows kept per grid point (forced + left + right; default 4) */
     double  mu_init_warm;             /* barrier start of a solve that is given an initial guess (x_init != NULL); 0 -> mu_init.
                                        * Closed-loop cycles start next to a solution: 1e-2 saves ~25 % of the iterations. */
+    int32_t terminal_ball;            /* planning/terminal_constraint/type == l2_ball (src/controller.cpp:683); the row exists only when at
+                                       * least one goal component is free (finite_differences_grid_se2.cpp:128-143) */
+    double  terminal_ball_S[3];       /* .../l2_ball/weight_matrix (diagonal)  (:686-692) */
+    double  terminal_ball_gamma;      /* .../l2_ball/radius: row  xd' S xd - gamma <= 0  (final_state_conditions_se2.cpp:54-64) */
     int32_t reserved[6];
 } mpc_config;
 

@@ -69,6 +69,9 @@ class MpcConfig(C.Structure):
         ("max_vertices", C.c_int32),
         ("max_obstacle_rows", C.c_int32),
         ("mu_init_warm", C.c_double),
+        ("terminal_ball", C.c_int32),
+        ("terminal_ball_S", C.c_double * 3),
+        ("terminal_ball_gamma", C.c_double),
         ("reserved", C.c_int32 * 6),
     ]
 
@@ -87,7 +90,8 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
                 xf_fixed=(True, True, True), objective=OBJ_MIN_TIME, Q=(0, 0, 0), R=(0, 0), integral_form=False, Qf=None,
                 u_lb=(-0.2, -0.3), u_ub=(0.4, 0.3), du_lb=(-INF, -INF), du_ub=(INF, INF), max_iter=100, tol=1e-8,
                 mu_init=0.1, precision=FP64, min_obstacle_dist=0.5, force_inclusion_dist=0.5, cutoff_dist=2.0,
-                footprint_kind=0, footprint_radius=0.0, max_obstacles=0, max_vertices=1, max_obstacle_rows=4, mu_init_warm=0.0, collocation=COLLOC_FORWARD) -> MpcConfig:
+                footprint_kind=0, footprint_radius=0.0, max_obstacles=0, max_vertices=1, max_obstacle_rows=4, mu_init_warm=0.0, collocation=COLLOC_FORWARD,
+                terminal_ball_S=None, terminal_ball_gamma=1.0) -> MpcConfig:
     c = MpcConfig()
     c.model = model
     mp = list(model_params) + [0.0] * 4
@@ -117,6 +121,10 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
     c.footprint_kind, c.footprint_radius = footprint_kind, footprint_radius
     c.max_obstacles, c.max_vertices, c.max_obstacle_rows = max_obstacles, max_vertices, max_obstacle_rows
     c.mu_init_warm = mu_init_warm
+    c.terminal_ball = int(terminal_ball_S is not None)
+    for i in range(3):
+        c.terminal_ball_S[i] = terminal_ball_S[i] if terminal_ball_S is not None else 0.0
+    c.terminal_ball_gamma = terminal_ball_gamma
     return c
 
 
@@ -129,10 +137,12 @@ def config_carlike_min_time(n=50, **kw) -> MpcConfig:
 
 def config_unicycle_quadratic(n=20, **kw) -> MpcConfig:
     """BASELINE.json config 1: .../cfg/diff_drive/mpc_local_planner_params_quadratic_form.yaml:7-14,33-41,53-61."""
-    return make_config(model=MODEL_UNICYCLE, model_params=(0.0,), n=n, dt_ref=0.3, dt_free=False,
-                       xf_fixed=(False, False, False), objective=OBJ_QUADRATIC, Q=(2.0, 2.0, 0.25), R=(0.1, 0.05),
-                       Qf=(10.0, 10.0, 0.5), u_lb=(-0.2, -0.3), u_ub=(0.4, 0.3), du_lb=(-0.2, -0.2), du_ub=(0.2, 0.2),
-                       **{**dict(min_obstacle_dist=0.2, force_inclusion_dist=0.5, cutoff_dist=2.5), **kw})
+    d = dict(model=MODEL_UNICYCLE, model_params=(0.0,), n=n, dt_ref=0.3, dt_free=False,
+             xf_fixed=(False, False, False), objective=OBJ_QUADRATIC, Q=(2.0, 2.0, 0.25), R=(0.1, 0.05),
+             Qf=(10.0, 10.0, 0.5), u_lb=(-0.2, -0.3), u_ub=(0.4, 0.3), du_lb=(-0.2, -0.2), du_ub=(0.2, 0.2),
+             min_obstacle_dist=0.2, force_inclusion_dist=0.5, cutoff_dist=2.5)
+    d.update(kw)
+    return make_config(**d)
 
 
 def config_bicycle_min_time(n=120, **kw) -> MpcConfig:

@@ -66,6 +66,9 @@ struct Problem {
     // collision avoidance (wave kernel only)
     int n_obst, n_vert, obst_rows, footprint_kind;
     T d_min, force_incl, cutoff, fp_radius;
+    // terminal l2-ball row  xd' S xd - gamma <= 0  on the free final state (wave kernel only)
+    int ball;
+    T ball_S[3], ball_gamma;
 };
 
 // Algorithm constants (Waechter & Biegler 2006 names).  Compile-time so that they live in

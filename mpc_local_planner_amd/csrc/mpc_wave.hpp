@@ -55,7 +55,7 @@ struct WaveLayout {
         L.DX = take(3); L.DU = take(2);
         L.CC = take(3); L.TRIG = take(ntrig);
         L.GAIN = take(NGAIN); L.STG = take(NSTG);
-        L.SC = o; o += 8;     // scalars: D, DT, DD, PDL, PDU
+        L.SC = o; o += 16;    // scalars: D, DT, DD, PDL, PDU | terminal-ball row: slack, multiplier, cached value and gradient
         L.VP = o; o += 16;    // dummy store targets of the idle lanes in the sweeps
         L.ZC = o; o += 8;     // constants 0 0 0 0 1 0 0 0 (coefficient triples of the constant columns)
         L.M = M; L.O = O; L.V = V;
@@ -66,7 +66,7 @@ struct WaveLayout {
     }
 };
 
-enum { SC_D = 0, SC_DT = 1, SC_DD = 2, SC_PDL = 3, SC_PDU = 4 };
+enum { SC_D = 0, SC_DT = 1, SC_DD = 2, SC_PDL = 3, SC_PDU = 4, SC_TS = 5, SC_TY = 6, SC_TG = 7, SC_TA = 8 /* 8..10 */ };
 
 // A slot (StageAdd) of the entry (r, c) of the symmetric 8x8 stage cost block [x(3) u_prev(2) dt u(2)] and of its gradient
 // column c = 8; -1 where the block is structurally zero.  Packed per row as 12 x 5 bits (slot + 1) so that a lane looks its
@@ -149,7 +149,7 @@ struct IpmWave {
     bool row0_on, fail0;
     bool warm_guess = false;     // the caller supplied an initial guess (second and later control cycles)
     mutable int cnt_mult = -1, cnt_bmult = -1;      // number of equality / bound multipliers (cached by kkt_pass)
-    int flags;      // bits 0..2 xf_fixed, 3 dt_free, 4 quadratic objective, 5 has_Qf, 6..9 rate_on: the problem record lives in LDS and every
+    int flags;      // bits 0..2 xf_fixed, 3 dt_free, 4 quadratic objective, 5 has_Qf, 6..9 rate_on, 10 terminal ball: the problem record lives in LDS and every
                     // P.x costs a ds_read (+ wait) that the compiler cannot hoist over LDS stores; one scalar register holds the switches
 #ifdef MPC_PROFILE
     mutable long long prof_loop = 0, prof_setup = 0, prof_fwd_loop = 0;    // ticks inside the backward stage loop / before it / inside the forward loop
@@ -173,6 +173,7 @@ struct IpmWave {
     __device__ __forceinline__ bool quad() const { return (flags >> 4) & 1; }
     __device__ __forceinline__ bool hasqf() const { return (flags >> 5) & 1; }
     __device__ __forceinline__ bool ron(int q) const { return (flags >> (6 + q)) & 1; }
+    __device__ __forceinline__ bool ball() const { return (flags >> 10) & 1; }
     // explicit LDS pointers for the running-pointer loops (address-space inference gives up on per-lane selected pointers)
     typedef __attribute__((address_space(3))) T LdsT;
     __device__ __forceinline__ LdsT* lds(int word) const { return (LdsT*)sm + word; }
@@ -211,6 +212,33 @@ struct IpmWave {
         T pl = t_min(Algo<T>::bound_push * t_max(T(1), t_abs(lb)), Algo<T>::bound_push * (ub - lb));
         T pu = t_min(Algo<T>::bound_push * t_max(T(1), t_abs(ub)), Algo<T>::bound_push * (ub - lb));
         return t_min(t_max(v, lb + pl), ub - pu);
+    }
+
+    // ---------------------------------------------------------------- terminal l2-ball row (TerminalBallSE2, final_state_conditions_se2.cpp:54-64)
+    // g = xd' S xd - gamma on the final state at z + alpha dz, gradient a = 2 S xd over the free components (fixed ones: xd = 0)
+    __device__ __forceinline__ T ball_eval(T alpha, T a[3]) const {
+        T g = -P.ball_gamma;
+        for (int i = 0; i < 3; ++i) {
+            a[i] = T(0);
+            if (fx(i)) continue;
+            T xd = xt(i, L.n - 1, alpha) - xf[i];
+            if (i == 2) xd = normalize_theta(xd);
+            g += P.ball_S[i] * xd * xd;
+            a[i] = T(2) * P.ball_S[i] * xd;
+        }
+        return g;
+    }
+    // a' dx_T from the gradient cached by kkt_pass
+    __device__ __forceinline__ T ball_jdz() const {
+        T j = T(0);
+        for (int i = 0; i < 3; ++i) if (!fx(i)) j += SCL(SC_TA + i) * F(L.DX, i, L.n - 1);
+        return j;
+    }
+    // slack at the trial point (linear in alpha, like every other row's slack)
+    __device__ __forceinline__ T ball_slack(T alpha, bool trial) const {
+        T s = SCL(SC_TS);
+        if (trial) s += alpha * (-(SCL(SC_TG) + s) - ball_jdz());
+        return s;
     }
 
     // ---------------------------------------------------------------- clearance rows
@@ -371,6 +399,7 @@ struct IpmWave {
                     fo += P.Qf[i] * xd * xd;
                 }
             }
+            if (ball()) { T a[3]; th += t_abs(ball_eval(al, a) + ball_slack(alpha, trial)); }
         }
         theta_c = wave_sum(th);
         fobj = wave_sum(fo);
@@ -403,6 +432,7 @@ struct IpmWave {
             }
         }
         if (lane == 0 && dtf()) { acc.mul(d - P.dt_lb); acc.mul(P.dt_ub - d); }
+        if (lane == 0 && ball()) acc.mul(ball_slack(alpha, trial));
         return wave_sum(acc.value());
     }
 
@@ -478,6 +508,7 @@ struct IpmWave {
                 }
             }
             if (r.dtf) { acc.mul(d - r.dt_lb); acc.mul(r.dt_ub - d); }
+            if (ball()) { T a[3]; const T st = ball_slack(alpha, true); th += t_abs(ball_eval(alpha, a) + st); acc.mul(st); }
         }
         th_out = wave_sum(th); fo_out = wave_sum(fo); logs_out = wave_sum(acc.value());
     }
@@ -569,6 +600,15 @@ struct IpmWave {
                     sb += pl + pu; nb += 2;
                 }
                 if (k == n - 2) {
+                    T ta[3] = {T(0), T(0), T(0)}, ty = T(0);
+                    if (ball()) {        // terminal l2-ball row: value / gradient cache for the step, residuals
+                        const T tg = ball_eval(T(0), ta), ts = SCL(SC_TS);
+                        ty = SCL(SC_TY);
+                        SCL(SC_TG) = tg; SCL(SC_TA) = ta[0]; SCL(SC_TA + 1) = ta[1]; SCL(SC_TA + 2) = ta[2];
+                        rp = t_max(rp, t_abs(tg + ts)); th += t_abs(tg + ts);
+                        cmin = t_min(cmin, ts * ty); cmax = t_max(cmax, ts * ty);
+                        sb += ty; nb += 1;
+                    }
                     for (int i = 0; i < 3; ++i) if (!fx(i)) {
                         T g = T(0);
                         if (quad() && hasqf()) {
@@ -576,7 +616,7 @@ struct IpmWave {
                             if (i == 2) xd = normalize_theta(xd);
                             g = T(2) * P.Qf[i] * xd;
                         }
-                        rd = t_max(rd, t_abs(g - lam[i]));
+                        rd = t_max(rd, t_abs(g + ty * ta[i] - lam[i]));
                     }
                 }
             }
@@ -764,6 +804,15 @@ struct IpmWave {
         // ---- terminal value function, straight into the owning lanes' registers (rows 3..5: the u_prev / dt entries of the
         //      final rate rows = the A slots (i, c) of stage n-1 for c in {3, 4, 5, 8})
         T V[6];
+        // condensed terminal l2-ball row: + sigma a a' + 2 y S on the final-state block, + a ybar on its gradient
+        T tsig = T(0), tyb = T(0), ty = T(0), ta[3] = {T(0), T(0), T(0)};
+        if (ball()) {
+            const T ts = SCL(SC_TS), tg = SCL(SC_TG);
+            ty = SCL(SC_TY);
+            tsig = ty / ts; tyb = mu / ts + tsig * (tg + ts);
+            ta[0] = SCL(SC_TA); ta[1] = SCL(SC_TA + 1); ta[2] = SCL(SC_TA + 2);
+        }
+        const T tac = c < 3 ? (c == 0 ? ta[0] : (c == 1 ? ta[1] : ta[2])) : T(0);
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             if (fx(i)) V[i] = c == 9 + i ? T(1) : T(0);
@@ -774,7 +823,9 @@ struct IpmWave {
                     if (i == 2) xd = normalize_theta(xd);
                     pii += T(2) * P.Qf[i]; pi_ = T(2) * P.Qf[i] * xd;
                 }
+                if (ball()) { pii += T(2) * ty * P.ball_S[i]; pi_ += ta[i] * tyb; }
                 V[i] = c == i ? pii : (c == 8 ? pi_ : T(0));
+                if (ball() && c < 3) V[i] += tsig * ta[i] * tac;       // a of a fixed component is 0
             }
         }
         {
@@ -1024,6 +1075,12 @@ struct IpmWave {
                     if (i == 2) xd = normalize_theta(xd);
                     g += T(2) * P.Qf[i] * (xi[i] + xd);
                 }
+                if (ball()) {
+                    const T ts = SCL(SC_TS), ty = SCL(SC_TY), sig = ty / ts;
+                    T adx = T(0);
+                    for (int j = 0; j < 3; ++j) if (!fx(j)) adx += SCL(SC_TA + j) * xi[j];
+                    g += SCL(SC_TA + i) * (sig * adx + mu / ts + sig * (SCL(SC_TG) + ts)) + T(2) * ty * P.ball_S[i] * xi[i];
+                }
                 lp[i] = g;
             }
         }
@@ -1080,6 +1137,15 @@ struct IpmWave {
                 dz2 += dd * dd; dzmax = t_max(dzmax, t_abs(dd));
             }
             if (!quad()) { hdz += T(n - 1) * dd; dphi += T(n - 1) * dd; }
+            if (ball()) {
+                const T jdz = ball_jdz(), s = SCL(SC_TS), y = SCL(SC_TY), res = SCL(SC_TG) + s;
+                const T sig = y / s, ybar = mu / s + sig * res;
+                const T ds = -res - jdz, dy = ybar + sig * jdz - y;
+                hdz += ybar * jdz;
+                dphi -= (mu / s) * ds;
+                ftb(s, ds, tau, a_p);
+                ftb(y, dy, tau, a_d);
+            }
         }
         for (int k = lane; k < n; k += kWave) {
             if (k < n - 1) {
@@ -1232,6 +1298,13 @@ struct IpmWave {
                 SCL(SC_PDU) = t_min(t_max(pun, mu / (kS * dun)), kS * mu / dun);
             }
             SCL(SC_D) = d_new;
+            if (ball()) {        // from the caches of the OLD point (value, gradient) and the step
+                const T jdz = ball_jdz(), s = SCL(SC_TS), y = SCL(SC_TY), res = SCL(SC_TG) + s, sig = y / s;
+                const T so = s + alpha * (-res - jdz);
+                T yo = y + a_d * (mu / s + sig * res + sig * jdz - y);
+                yo = t_min(t_max(yo, mu / (kS * so)), kS * mu / so);
+                SCL(SC_TS) = so; SCL(SC_TY) = yo;
+            }
         }
     }
 
@@ -1326,6 +1399,11 @@ struct IpmWave {
         if (lane == 0) {
             SCL(SC_PDL) = dtf() ? mu / (d - P.dt_lb) : T(0);
             SCL(SC_PDU) = dtf() ? mu / (P.dt_ub - d) : T(0);
+            if (ball()) {
+                T a[3];
+                const T s = t_max(-ball_eval(T(0), a), Algo<T>::slack_push);
+                SCL(SC_TS) = s; SCL(SC_TY) = mu / s;
+            }
         }
         sync();
     }
@@ -1334,7 +1412,7 @@ struct IpmWave {
     __device__ __forceinline__ SolveStats<T> solve() {
         SolveStats<T> out;
         flags = (P.xf_fixed[0] ? 1 : 0) | (P.xf_fixed[1] ? 2 : 0) | (P.xf_fixed[2] ? 4 : 0) | (P.dt_free ? 8 : 0) | (P.objective == OBJ_QUADRATIC ? 16 : 0) |
-                (P.has_Qf ? 32 : 0) | (P.rate_on[0] ? 64 : 0) | (P.rate_on[1] ? 128 : 0) | (P.rate_on[2] ? 256 : 0) | (P.rate_on[3] ? 512 : 0);
+                (P.has_Qf ? 32 : 0) | (P.rate_on[0] ? 64 : 0) | (P.rate_on[1] ? 128 : 0) | (P.rate_on[2] ? 256 : 0) | (P.rate_on[3] ? 512 : 0) | (P.ball ? 1024 : 0);
         flags = __builtin_amdgcn_readfirstlane(flags);
         nfix = (int)fx(0) + (int)fx(1) + (int)fx(2);
         row0_on = dtprev != T(0);

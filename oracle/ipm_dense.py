@@ -289,7 +289,9 @@ class SolverNlp:
                 if cfg.du_ub[i] < R.INF:
                     self.rate_rows.append((k, i, +1))
         self.obst_rows = [(k, j) for k in range(1, n - 1) for j in self.relevant[k]]
-        self.mg = len(self.rate_rows) + len(self.obst_rows)
+        # terminal l2-ball row on the free final state (final_state_conditions_se2.cpp:54-64; edge only when xf is not fixed)
+        self.ball_row = cfg.terminal_ball_S is not None and any(not f for f in cfg.xf_fixed)
+        self.mg = len(self.rate_rows) + len(self.obst_rows) + (1 if self.ball_row else 0)
         self.mc = 3 * (n - 1)
 
     # ---- packing -----------------------------------------------------
@@ -425,6 +427,17 @@ class SolverNlp:
             Jg[r, self.ix[k]] = gr
             if want_hess and y is not None:
                 W[np.ix_(self.ix[k], self.ix[k])] += y[r] * Hm
+            r += 1
+        if self.ball_row:
+            S = np.asarray(cfg.terminal_ball_S, float)
+            xd = X[n - 1] - xf
+            xd[2] = R.normalize_theta(xd[2])
+            g[r] = float(xd @ (S * xd)) - cfg.terminal_ball_gamma
+            for i in range(3):
+                if self.ix[n - 1, i] >= 0:
+                    Jg[r, self.ix[n - 1, i]] = 2 * S[i] * xd[i]
+                    if want_hess and y is not None:
+                        W[self.ix[n - 1, i], self.ix[n - 1, i]] += y[r] * 2 * S[i]
             r += 1
         out = dict(f=f, gf=gf, c=c, Jc=Jc, g=g, Jg=Jg)
         if want_hess:

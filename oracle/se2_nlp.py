@@ -305,6 +305,8 @@ class OcpConfig:
     R: np.ndarray = field(default_factory=lambda: np.zeros(2))     # diagonal control weights
     integral_form: bool = False
     Qf: Optional[np.ndarray] = None               # terminal_cost quadratic (diag) or None
+    terminal_ball_S: Optional[np.ndarray] = None  # terminal_constraint l2_ball weight_matrix (diag) or None   (controller.cpp:683-703)
+    terminal_ball_gamma: float = 1.0              # .../l2_ball/radius: the row is xd' S xd - gamma <= 0 (final_state_conditions_se2.cpp:54-64)
     u_lb: np.ndarray = field(default_factory=lambda: np.array([-0.2, -0.3]))
     u_ub: np.ndarray = field(default_factory=lambda: np.array([0.4, 0.3]))
     du_lb: np.ndarray = field(default_factory=lambda: np.array([-INF, -INF]))
@@ -738,6 +740,12 @@ class ReferenceNlp:
                         rows += self._rate_rows(t.u[0], self.inp.u_prev, self.inp.dt_prev)
                 else:
                     rows += self._rate_rows(t.u[k], t.u[k - 1], t.dt)   # dt_prev == dt (createEdges :50-51)
+        if cfg.terminal_ball_S is not None and self.free_xf:
+            # final-state constraint edge, only with an unfixed final state (finite_differences_grid_se2.cpp:128-143);
+            # TerminalBallSE2::computeNonIntegralStateTerm (final_state_conditions_se2.cpp:54-64)
+            xd = t.x[n - 1] - np.asarray(self.inp.xf, float)
+            xd[2] = normalize_theta(xd[2])
+            rows.append(float(xd @ (np.asarray(cfg.terminal_ball_S, float) * xd)) - cfg.terminal_ball_gamma)
         if nrate:
             # getFinalControlDeviationEdges(n, u_ref(=0), u_{n-2}, dt): finite_differences_grid_se2.cpp:150
             rows += self._rate_rows(np.zeros(2), t.u[n - 2], t.dt)

@@ -65,7 +65,7 @@ def make_obstacles(name, n=30, B=10, O=6, V=6, M=4, keep=6):
     print(name, "kept", len(sel), "iters", IT)
 
 
-if __name__ == "__main__" and "--warm" not in sys.argv and "--integral" not in sys.argv and "--closed-loop" not in sys.argv and "--config3" not in sys.argv and "--midpoint" not in sys.argv and "--cn" not in sys.argv:
+if __name__ == "__main__" and "--warm" not in sys.argv and "--integral" not in sys.argv and "--closed-loop" not in sys.argv and "--config3" not in sys.argv and "--midpoint" not in sys.argv and "--cn" not in sys.argv and "--ball" not in sys.argv:
     make_obstacles("unicycle_quadratic_obstacles_n30")
     make("carlike_min_time_n50", R.config_carlike_min_time(50), W.carlike_min_time_inputs(32, seed=101), keep=8)
     make("carlike_min_time_n20", R.config_carlike_min_time(20), W.carlike_min_time_inputs(32, seed=102, goal_range=(1.0, 2.5)), keep=8)
@@ -199,3 +199,47 @@ if __name__ == "__main__" and "--cn" in sys.argv:
     make_midpoint("bicycle_min_time_cn_n30", c, W.carlike_min_time_inputs(32, seed=111, goal_range=(2.0, 6.0)), keep=4)
     c = R.config_unicycle_quadratic(20); c.collocation = R.COLLOC_CRANK_NICOLSON
     make_midpoint("unicycle_quadratic_cn_n20", c, W.unicycle_quadratic_inputs(16, seed=112))
+
+
+BALL_S, BALL_GAMMA = np.array([1.0, 1.0, 0.01]), 0.02
+BALL_Q, BALL_R = np.array([0.2, 0.2, 0.02]), np.array([1.0, 0.5])
+
+
+def ball_config(n=20, with_ball=True):
+    """effort-dominated quadratic form without terminal cost: the unconstrained solution stops short of the goal, the l2-ball row
+    (radius^2-like gamma = 0.02, i.e. ~14 cm) is what brings the final state in -- active and feasible for goals within reach."""
+    cfg = R.config_unicycle_quadratic(n)
+    cfg.Q, cfg.R, cfg.Qf = BALL_Q.copy(), BALL_R.copy(), None
+    if with_ball:
+        cfg.terminal_ball_S, cfg.terminal_ball_gamma = BALL_S.copy(), BALL_GAMMA
+    return cfg
+
+
+def make_terminal_ball(name, n=20, B=16, keep=6):
+    """a18 TerminalBallSE2 (final_state_conditions_se2.cpp:54-64): unicycle, quadratic form, fixed dt, free goal, with the l2-ball row
+    xd' S xd - gamma <= 0  on the final state.  Kept: converged instances whose solution WITHOUT the row violates it (row active)."""
+    x0, xf, up, dtp = W.unicycle_quadratic_inputs(B, seed=131, goal_range=(0.8, 1.3))
+    rows = []
+    for i in range(B):
+        if len(rows) >= keep:
+            break
+        inp = R.CycleInputs(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=float(dtp[i]))
+        cfg = ball_config(n, False)
+        free = I.solve(cfg, inp, R.cold_start(cfg, x0[i], xf[i]), opt=I.IpmOptions(globalization="merit", max_iter=100))
+        xd = free.traj.x[-1] - xf[i]; xd[2] = R.normalize_theta(xd[2])
+        cfg = ball_config(n, True)
+        ref = I.solve(cfg, inp, R.cold_start(cfg, x0[i], xf[i]), opt=I.IpmOptions(globalization="merit", max_iter=100))
+        if free.status != 0 or float(xd @ (BALL_S * xd)) < 2 * BALL_GAMMA or ref.status != 0 or ref.iters > 45:
+            continue
+        nlp = R.ReferenceNlp(cfg, inp)
+        z = nlp.pack(ref.traj)
+        assert np.abs(nlp.equalities(z)).max() < 1e-7 and nlp.inequalities(z).max() < 1e-7
+        rows.append(dict(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=dtp[i], x=ref.traj.x, u=np.vstack([ref.traj.u, ref.traj.u[-1:]]), dt=ref.traj.dt,
+                         iters=ref.iters, y_ball=ref.y[-1], x_free=free.traj.x))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), S=BALL_S, gamma=BALL_GAMMA, Q=BALL_Q, R=BALL_R,
+                        **{k: np.array([r[k] for r in rows]) for k in rows[0]})
+    print(name, "kept", len(rows), "iters", [r["iters"] for r in rows], "y", [float(r["y_ball"]) for r in rows])
+
+
+if __name__ == "__main__" and "--ball" in sys.argv:
+    make_terminal_ball("unicycle_quadratic_ball_n20")

@@ -464,3 +464,31 @@ def test_config2_midpoint_and_crank_nicolson_batch_vs_c_oracle(m, c_oracle, meth
     for i in np.nonzero(r.status == 0)[0][:32]:
         assert _feasibility(R, ocfg, x0, xf, up, dtp, r, i) < 1e-6
     s.close()
+
+
+def test_terminal_ball_golden(m):
+    """a18 TerminalBallSE2 (final_state_conditions_se2.cpp:54-64, configured at src/controller.cpp:676-703): l2-ball row on the free final
+    state.  Fixture (tests/golden/make_golden.py --ball): effort-dominated quadratic form whose unconstrained solution stops short of
+    the goal, so the row is ACTIVE in every instance.  Plus: a ball that is far from binding (the reference's example radius 5) leaves
+    the config-1 goldens untouched."""
+    from oracle import se2_nlp as R
+    g = np.load(os.path.join(GOLD, "unicycle_quadratic_ball_n20.npz"))
+    B = g["x0"].shape[0]
+    cfg = m.config_unicycle_quadratic(20, Q=tuple(g["Q"]), R=tuple(g["R"]), Qf=None, terminal_ball_S=tuple(g["S"]), terminal_ball_gamma=float(g["gamma"]))
+    s = m.BatchSolver(cfg, max_batch=B)
+    r = s.solve(g["x0"], g["xf"], g["u_prev"], g["dt_prev"])
+    assert (r.status == 0).all()
+    assert np.abs(r.x - g["x"]).max() < 1e-6 and np.abs(r.u - g["u"]).max() < 1e-6
+    assert (np.abs(r.iters - g["iters"]) <= 2).all()
+    xd = r.x[:, -1] - g["xf"]
+    xd[:, 2] = R.normalize_theta(xd[:, 2])
+    val = (xd * xd * g["S"]).sum(1)
+    assert np.abs(val - float(g["gamma"])).max() < 1e-6                      # on the ball's boundary ...
+    xdf = g["x_free"][:, -1] - g["xf"]
+    assert ((xdf[:, :2] ** 2).sum(1) > 2 * float(g["gamma"])).all()         # ... which the solution without the row is far outside of
+    s.close()
+    g1 = np.load(os.path.join(GOLD, "unicycle_quadratic_n20.npz"))
+    s = m.BatchSolver(m.config_unicycle_quadratic(20, terminal_ball_S=(1.0, 1.0, 1.0), terminal_ball_gamma=5.0), max_batch=g1["x0"].shape[0])
+    r = s.solve(g1["x0"], g1["xf"], g1["u_prev"], g1["dt_prev"])
+    assert (r.status == 0).all() and np.abs(r.x - g1["x"]).max() < 1e-6 and np.abs(r.u - g1["u"]).max() < 1e-6
+    s.close()
