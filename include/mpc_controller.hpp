@@ -193,6 +193,16 @@ class Controller {
     // obstacles of the next step() calls (borrowed, like the reference's ObstContainer reference)
     void setObstacles(const mpc_obstacles* obst) { _obst = obst; }
 
+    // via-points of the next step() calls (the reference's ViaPointContainer, refilled by the planner every cycle,
+    // src/mpc_local_planner_ros.cpp:619-635); needs cfg.objective = MPC_OBJ_MIN_TIME_VIA_POINTS.  poses: n_via x (x, y, theta)
+    bool setViaPoints(const double* poses, int n_via) {
+        if (!_h || _cfg.max_via_points <= 0 || n_via > _cfg.max_via_points) return false;
+        std::vector<double> buf((size_t)_cfg.max_via_points * 3, 0.0);
+        for (int i = 0; i < 3 * n_via; ++i) buf[i] = poses[i];
+        const int32_t nv = n_via;
+        return mpc_set_via_points(_h, 1, &nv, buf.data()) == MPC_OK;
+    }
+
     // Controller::step(start, goal, ...)  (src/controller.cpp:102-109)
     bool step(const PoseSE2& start, const PoseSE2& goal, const Twist& vel, double dt, double t, TimeSeries& u_seq, TimeSeries& x_seq) {
         std::vector<PoseSE2> plan(2);

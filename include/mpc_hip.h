@@ -45,7 +45,8 @@ enum mpc_collocation {                /* include/.../optimal_control/fd_collocat
 };
 enum mpc_objective {                  /* src/controller.cpp:551-640 */
     MPC_OBJ_MIN_TIME = 0,
-    MPC_OBJ_QUADRATIC = 1
+    MPC_OBJ_QUADRATIC = 1,
+    MPC_OBJ_MIN_TIME_VIA_POINTS = 2     /* planning/objective/type minimum_time_via_points (src/controller.cpp:597-612) */
 };
 enum mpc_precision { MPC_FP64 = 0, MPC_FP32 = 1 };
 enum mpc_footprint { MPC_FOOTPRINT_POINT = 0, MPC_FOOTPRINT_CIRCLE = 1 };
@@ -104,6 +105,11 @@ typedef struct mpc_config {
                                        * least one goal component is free (finite_differences_grid_se2.cpp:128-143) */
     double  terminal_ball_S[3];       /* .../l2_ball/weight_matrix (diagonal)  (:686-692) */
     double  terminal_ball_gamma;      /* .../l2_ball/radius: row  xd' S xd - gamma <= 0  (final_state_conditions_se2.cpp:54-64) */
+    double  vp_position_weight;       /* objective/minimum_time_via_points/position_weight    (src/controller.cpp:601) */
+    double  vp_orientation_weight;    /* .../orientation_weight (:603); as coded the term is LINEAR in the heading error
+                                       * (src/optimal_control/min_time_via_points_cost.cpp:139-142) */
+    int32_t via_points_ordered;       /* .../via_points_ordered  (:605) */
+    int32_t max_via_points;           /* via-points per instance the solver is sized for (objective MIN_TIME_VIA_POINTS; <= 64) */
     int32_t reserved[6];
 } mpc_config;
 
@@ -167,6 +173,16 @@ int mpc_solve_batch_device(mpc_solver* s, int32_t B,
  * (3 <= n_grid[b] <= cfg.n); the array layouts keep the stride cfg.n and only the first n_grid[b] rows of
  * x_init/u_init/x_out/u_out are meaningful.  HOST pointer, copied; NULL restores the uniform size cfg.n. */
 int mpc_set_grid_sizes(mpc_solver* s, const int32_t* n_grid, int32_t B);
+
+/* Via-points of the minimum_time_via_points objective (the reference's borrowed ViaPointContainer,
+ * include/mpc_local_planner/optimal_control/min_time_via_points_cost.h:102, refilled by the planner between steps,
+ * src/mpc_local_planner_ros.cpp:619-635): instance b has n_via[b] (<= cfg.max_via_points) poses via[b][p] = (x, y, theta).
+ * Every solve attaches each via-point to its closest grid point of the trajectory the solve STARTS from
+ * (MinTimeViaPointsCost::update, src/optimal_control/min_time_via_points_cost.cpp:39-117; runs on the device).
+ * HOST pointers, copied; they stay in force until the next call; NULL clears them (plain minimum time). */
+int mpc_set_via_points(mpc_solver* s, int32_t B, const int32_t* n_via, const double* via /* [B][max_via_points][3] */);
+/* Same with DEVICE pointers, borrowed until the next mpc_set_via_points* call. */
+int mpc_set_via_points_device(mpc_solver* s, const int32_t* d_n_via, const double* d_via);
 
 int mpc_synchronize(mpc_solver* s);
 

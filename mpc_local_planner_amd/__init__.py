@@ -5,6 +5,6 @@ Only the hot path lives here: csrc/ (HIP kernels + the C ABI of include/mpc_hip.
 host-side mirror of the reference's controller interface.  See DESIGN.md.
 """
 from ._abi import (MpcConfig, make_config, config_carlike_min_time, config_unicycle_quadratic,  # noqa: F401
-                   config_bicycle_min_time, STATUS_NAMES)
+                   config_bicycle_min_time, STATUS_NAMES, OBJ_MIN_TIME, OBJ_QUADRATIC, OBJ_MIN_TIME_VIA_POINTS)
 from .solver import BatchSolver, BatchResult, MpcError  # noqa: F401
 from . import workloads  # noqa: F401

@@ -18,6 +18,7 @@ COLLOC_CRANK_NICOLSON = 2
 
 OBJ_MIN_TIME = 0
 OBJ_QUADRATIC = 1
+OBJ_MIN_TIME_VIA_POINTS = 2
 
 FP64 = 0
 FP32 = 1
@@ -72,6 +73,10 @@ class MpcConfig(C.Structure):
         ("terminal_ball", C.c_int32),
         ("terminal_ball_S", C.c_double * 3),
         ("terminal_ball_gamma", C.c_double),
+        ("vp_position_weight", C.c_double),
+        ("vp_orientation_weight", C.c_double),
+        ("via_points_ordered", C.c_int32),
+        ("max_via_points", C.c_int32),
         ("reserved", C.c_int32 * 6),
     ]
 
@@ -91,7 +96,8 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
                 u_lb=(-0.2, -0.3), u_ub=(0.4, 0.3), du_lb=(-INF, -INF), du_ub=(INF, INF), max_iter=100, tol=1e-8,
                 mu_init=0.1, precision=FP64, min_obstacle_dist=0.5, force_inclusion_dist=0.5, cutoff_dist=2.0,
                 footprint_kind=0, footprint_radius=0.0, max_obstacles=0, max_vertices=1, max_obstacle_rows=4, mu_init_warm=0.0, collocation=COLLOC_FORWARD,
-                terminal_ball_S=None, terminal_ball_gamma=1.0) -> MpcConfig:
+                terminal_ball_S=None, terminal_ball_gamma=1.0, vp_position_weight=1e-3, vp_orientation_weight=0.0,
+                via_points_ordered=False, max_via_points=0) -> MpcConfig:
     c = MpcConfig()
     c.model = model
     mp = list(model_params) + [0.0] * 4
@@ -125,14 +131,18 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
     for i in range(3):
         c.terminal_ball_S[i] = terminal_ball_S[i] if terminal_ball_S is not None else 0.0
     c.terminal_ball_gamma = terminal_ball_gamma
+    c.vp_position_weight, c.vp_orientation_weight = vp_position_weight, vp_orientation_weight
+    c.via_points_ordered, c.max_via_points = int(bool(via_points_ordered)), max_via_points
     return c
 
 
 def config_carlike_min_time(n=50, **kw) -> MpcConfig:
     """BASELINE.json config 2: mpc_local_planner_examples/cfg/carlike/mpc_local_planner_params.yaml:7-16,46-65."""
-    return make_config(model=MODEL_SIMPLE_CAR, model_params=(0.4,), n=n, dt_ref=0.3, dt_free=True, dt_lb=0.0, dt_ub=10.0,
-                       xf_fixed=(True, True, True), objective=OBJ_MIN_TIME, u_lb=(-0.2, -1.4), u_ub=(0.4, 1.4),
-                       du_lb=(-0.5, -0.5), du_ub=(0.5, 0.5), **kw)
+    d = dict(model=MODEL_SIMPLE_CAR, model_params=(0.4,), n=n, dt_ref=0.3, dt_free=True, dt_lb=0.0, dt_ub=10.0,
+             xf_fixed=(True, True, True), objective=OBJ_MIN_TIME, u_lb=(-0.2, -1.4), u_ub=(0.4, 1.4),
+             du_lb=(-0.5, -0.5), du_ub=(0.5, 0.5))
+    d.update(kw)
+    return make_config(**d)
 
 
 def config_unicycle_quadratic(n=20, **kw) -> MpcConfig:

@@ -86,12 +86,13 @@ __global__ __launch_bounds__(kLanes) void mpc_ipm_solve_kernel(
 #endif
 
 // One wavefront = one planner instance; the whole working set lives in LDS (mpc_wave.hpp).
-template <typename T, int MODEL>
+template <typename T, int MODEL, bool EXT>
 __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
     mpc::Problem<T> P, mpc::WaveLayout L, int B,
     const double* __restrict__ x0, const double* __restrict__ xf, const double* __restrict__ u_prev,
     const double* __restrict__ dt_prev, const double* __restrict__ x_init, const double* __restrict__ u_init,
-    const double* __restrict__ dt_init, mpc_obstacles obst, const int32_t* __restrict__ n_grid, double* __restrict__ x_out,
+    const double* __restrict__ dt_init, mpc_obstacles obst, const int32_t* __restrict__ n_grid, const int32_t* __restrict__ n_via,
+    const double* __restrict__ via, double* __restrict__ x_out,
     double* __restrict__ u_out, double* __restrict__ dt_out, int32_t* __restrict__ status, int32_t* __restrict__ iters) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mpc_smem[];
     T* sm = reinterpret_cast<T*>(mpc_smem);
@@ -113,7 +114,7 @@ __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
     __syncthreads();
     mpc::WaveLayout Lv = L;            // from the kernel arguments: wave-uniform, lives in SGPRs
     Lv.n = __builtin_amdgcn_readfirstlane(n);
-    mpc::IpmWave<T, MODEL> S(*Ps, Lv, sm, lane);
+    mpc::IpmWave<T, MODEL, EXT> S(*Ps, Lv, sm, lane);
     for (int i = 0; i < 3; ++i) { S.x0[i] = T(x0[3 * inst + i]); S.xf[i] = T(xf[3 * inst + i]); }
     S.x0[2] = mpc::normalize_theta(S.x0[2]);
     S.xf[2] = mpc::normalize_theta(S.xf[2]);
@@ -132,6 +133,7 @@ __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
         S.cold_start();
     }
     if (L.M > 0) S.load_obstacles(obst.n_obstacles, obst.n_vertices, obst.vertices, obst.radius, inst);
+    if (EXT && L.NV > 0) S.load_via_points(n_via, via, inst);
     __syncthreads();
     mpc::SolveStats<T> st = S.solve();
     __syncthreads();
@@ -166,6 +168,10 @@ struct mpc_solver {
     double *d_x0, *d_xf, *d_up, *d_dtp, *d_xi, *d_ui, *d_dti, *d_xo, *d_uo, *d_dto;
     int32_t *d_status, *d_iters;
     int32_t *d_ono, *d_onv, *d_ngrid;
+    int32_t *d_nvia;            // own copy of the via-point counts / poses (mpc_set_via_points) ...
+    double *d_via;
+    const int32_t* p_nvia;      // ... and what the kernel reads: the own copy or borrowed device pointers
+    const double* p_via;
     int use_ngrid;
     double *d_ov, *d_or;
     bool timed;
@@ -221,8 +227,10 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
     if (cfg->model < 0 || cfg->model > 3) { set_err("mpc_create: unknown model"); return MPC_EINVAL; }
     if (cfg->collocation != MPC_COLLOC_FORWARD && cfg->collocation != MPC_COLLOC_MIDPOINT && cfg->collocation != MPC_COLLOC_CRANK_NICOLSON) {
         set_err("mpc_create: unknown collocation method"); return MPC_EINVAL; }
-    if (cfg->objective != MPC_OBJ_MIN_TIME && cfg->objective != MPC_OBJ_QUADRATIC) { set_err("mpc_create: unknown objective"); return MPC_EINVAL; }
-    if (cfg->objective == MPC_OBJ_MIN_TIME && !cfg->dt_free) { set_err("mpc_create: minimum_time needs a variable grid (dt_free)"); return MPC_EINVAL; }
+    if (cfg->objective != MPC_OBJ_MIN_TIME && cfg->objective != MPC_OBJ_QUADRATIC && cfg->objective != MPC_OBJ_MIN_TIME_VIA_POINTS) { set_err("mpc_create: unknown objective"); return MPC_EINVAL; }
+    if (cfg->objective == MPC_OBJ_MIN_TIME_VIA_POINTS && (cfg->max_via_points < 1 || cfg->max_via_points > 64)) {
+        set_err("mpc_create: minimum_time_via_points needs 1 <= max_via_points <= 64"); return MPC_EINVAL; }
+    if (cfg->objective != MPC_OBJ_QUADRATIC && !cfg->dt_free) { set_err("mpc_create: minimum_time needs a variable grid (dt_free)"); return MPC_EINVAL; }
     if (!(cfg->dt_ref > 0)) { set_err("mpc_create: dt_ref must be > 0"); return MPC_EINVAL; }
     if (cfg->max_obstacles < 0 || cfg->max_obstacles > 256 || (cfg->max_obstacles > 0 && (cfg->max_vertices < 1 || cfg->max_vertices > 64)) || cfg->max_obstacle_rows > 16) {
         set_err("mpc_create: obstacle capacities out of range (max_obstacles <= 256, max_vertices <= 64, max_obstacle_rows <= 16)"); return MPC_EINVAL; }
@@ -251,7 +259,7 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         const int M = O > 0 ? (cfg->max_obstacle_rows > 0 ? cfg->max_obstacle_rows : 4) : 0;
         const int ntrig = ((cfg->model == MPC_MODEL_KINEMATIC_BICYCLE || cfg->model == MPC_MODEL_SIMPLE_CAR_FRONT) ? 4 : 3) +
                           (cfg->collocation == MPC_COLLOC_CRANK_NICOLSON ? 2 : 0);
-        s->WL = mpc::WaveLayout::make(cfg->n, M, O, cfg->max_vertices > 0 ? cfg->max_vertices : 1, ntrig);
+        s->WL = mpc::WaveLayout::make(cfg->n, M, O, cfg->max_vertices > 0 ? cfg->max_vertices : 1, ntrig, s->P64.n_via);
     }
     s->wave_lds = ((((size_t)s->WL.total * (cfg->precision == MPC_FP32 ? 4 : 8)) + 15) & ~(size_t)15) + 16 +
                   ((cfg->precision == MPC_FP32 ? sizeof(mpc::Problem<float>) : sizeof(mpc::Problem<double>)) + 15 & ~(size_t)15) + sizeof(mpc::WaveLayout);
@@ -296,6 +304,12 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
     if (er == hipSuccess) er = hipMalloc((void**)&s->d_status, Bm * 4);
     if (er == hipSuccess) er = hipMalloc((void**)&s->d_iters, Bm * 4);
     if (er == hipSuccess) er = hipMalloc((void**)&s->d_ngrid, Bm * 4);
+    if (s->P64.n_via > 0) {
+        if (er == hipSuccess) er = hipMalloc((void**)&s->d_nvia, Bm * 4);
+        if (er == hipSuccess) er = hipMalloc((void**)&s->d_via, Bm * (size_t)s->P64.n_via * 3 * 8);
+        if (er == hipSuccess) er = hipMemset(s->d_nvia, 0, Bm * 4);
+        s->p_nvia = s->d_nvia; s->p_via = s->d_via;
+    }
     if (cfg->max_obstacles > 0) {
         const size_t O = cfg->max_obstacles, V = cfg->max_vertices > 0 ? cfg->max_vertices : 1;
         if (er == hipSuccess) er = hipMalloc((void**)&s->d_ono, Bm * 4);
@@ -318,7 +332,7 @@ void mpc_destroy(mpc_solver* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    void* bufs[] = {s->d_ngrid, s->d_ono, s->d_onv, s->d_ov, s->d_or, s->ws, s->d_x0, s->d_xf, s->d_up, s->d_dtp, s->d_xi, s->d_ui, s->d_dti, s->d_xo, s->d_uo, s->d_dto, s->d_status, s->d_iters};
+    void* bufs[] = {s->d_nvia, s->d_via, s->d_ngrid, s->d_ono, s->d_onv, s->d_ov, s->d_or, s->ws, s->d_x0, s->d_xf, s->d_up, s->d_dtp, s->d_xi, s->d_ui, s->d_dti, s->d_xo, s->d_uo, s->d_dto, s->d_status, s->d_iters};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -333,12 +347,12 @@ static hipError_t launch_model(mpc_solver* s, const mpc::Problem<T>& P, int B, c
                                const double* dtp, const double* xi, const double* ui, const double* dti, const mpc_obstacles& ob, double* xo, double* uo,
                                double* dto, int32_t* st, int32_t* it) {
     if (s->use_wave) {
-        auto kern = mpc_ipm_wave_kernel<T, MODEL>;
+        auto kern = (P.ball || P.via) ? mpc_ipm_wave_kernel<T, MODEL, true> : mpc_ipm_wave_kernel<T, MODEL, false>;
         if (s->wave_lds > 48u * 1024u) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->wave_lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kern, dim3(B), dim3(mpc::kWave), s->wave_lds, s->stream, P, s->WL, B, x0, xf, up, dtp, xi, ui, dti, ob, s->use_ngrid ? s->d_ngrid : nullptr, xo, uo, dto, st, it);
+        hipLaunchKernelGGL(kern, dim3(B), dim3(mpc::kWave), s->wave_lds, s->stream, P, s->WL, B, x0, xf, up, dtp, xi, ui, dti, ob, s->use_ngrid ? s->d_ngrid : nullptr, s->p_nvia, s->p_via, xo, uo, dto, st, it);
     } else {
 #ifdef MPC_ENABLE_LANE_KERNEL
         dim3 grid((B + kLanes - 1) / kLanes), block(kLanes);
@@ -392,6 +406,35 @@ int mpc_solve_batch_device(mpc_solver* s, int32_t B, const double* d_x0, const d
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev1, s->stream));
     s->timed = true;
+    return MPC_OK;
+}
+
+int mpc_set_via_points(mpc_solver* s, int32_t B, const int32_t* n_via, const double* via) {
+    g_err[0] = 0;
+    if (!s) return MPC_EINVAL;
+    if (s->P64.n_via <= 0) { set_err("mpc_set_via_points: the solver was not created with objective MPC_OBJ_MIN_TIME_VIA_POINTS"); return MPC_EINVAL; }
+    HIP_TRY(hipSetDevice(s->device));
+    s->p_nvia = s->d_nvia; s->p_via = s->d_via;
+    if (!n_via || !via) {
+        HIP_TRY(hipMemsetAsync(s->d_nvia, 0, (size_t)s->max_batch * 4, s->stream));
+        HIP_TRY(hipStreamSynchronize(s->stream));
+        return MPC_OK;
+    }
+    if (B <= 0 || B > s->max_batch) { set_err("mpc_set_via_points: B out of range"); return MPC_EBATCH; }
+    for (int b = 0; b < B; ++b)
+        if (n_via[b] < 0 || n_via[b] > s->P64.n_via) { set_err("mpc_set_via_points: n_via[b] must be in [0, cfg.max_via_points]"); return MPC_EINVAL; }
+    HIP_TRY(hipMemcpyAsync(s->d_nvia, n_via, (size_t)B * 4, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipMemcpyAsync(s->d_via, via, (size_t)B * s->P64.n_via * 3 * 8, hipMemcpyHostToDevice, s->stream));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    return MPC_OK;
+}
+
+int mpc_set_via_points_device(mpc_solver* s, const int32_t* d_n_via, const double* d_via) {
+    g_err[0] = 0;
+    if (!s) return MPC_EINVAL;
+    if (s->P64.n_via <= 0) { set_err("mpc_set_via_points_device: the solver was not created with objective MPC_OBJ_MIN_TIME_VIA_POINTS"); return MPC_EINVAL; }
+    if (!d_n_via || !d_via) return mpc_set_via_points(s, 0, nullptr, nullptr);
+    s->p_nvia = d_n_via; s->p_via = d_via;
     return MPC_OK;
 }
 

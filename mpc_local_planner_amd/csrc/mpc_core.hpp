@@ -69,6 +69,9 @@ struct Problem {
     // terminal l2-ball row  xd' S xd - gamma <= 0  on the free final state (wave kernel only)
     int ball;
     T ball_S[3], ball_gamma;
+    // minimum_time_via_points objective (wave kernel only): objective stays OBJ_MIN_TIME, the via-point terms are switched by `via`
+    int via, n_via, vp_ordered;
+    T vp_wp, vp_wo;
 };
 
 // Algorithm constants (Waechter & Biegler 2006 names).  Compile-time so that they live in

@@ -12,7 +12,12 @@ inline void fill_problem(const mpc_config& c, mpc::Problem<T>& P) {
     P.n = c.n;
     P.dt_free = c.dt_free ? 1 : 0;
     for (int i = 0; i < 3; ++i) P.xf_fixed[i] = c.xf_fixed[i] ? 1 : 0;
-    P.objective = c.objective;
+    P.objective = c.objective == MPC_OBJ_MIN_TIME_VIA_POINTS ? MPC_OBJ_MIN_TIME : c.objective;
+    P.via = c.objective == MPC_OBJ_MIN_TIME_VIA_POINTS ? 1 : 0;
+    P.n_via = P.via ? c.max_via_points : 0;
+    P.vp_ordered = c.via_points_ordered ? 1 : 0;
+    P.vp_wp = T(c.vp_position_weight);
+    P.vp_wo = T(c.vp_orientation_weight);
     P.collocation = c.collocation;
     P.has_Qf = c.has_Qf ? 1 : 0;
     P.max_iter = c.max_iter > 0 ? c.max_iter : 100;

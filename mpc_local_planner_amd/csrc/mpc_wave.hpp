@@ -41,7 +41,8 @@ struct WaveLayout {
     int M, O, V;                                  // clearance rows per grid point, obstacles, vertices per obstacle
     int OS, OY, OI, OG, OAX, OAY, OHK;            // per-row slack, multiplier, obstacle index, cached g, gradient, curvature
     int GV, GNV, GR, GC;                          // obstacle geometry: vertices, vertex counts, radii, centroids
-    __host__ __device__ static WaveLayout make(int n, int M = 0, int O = 0, int V = 1, int ntrig = 4) {
+    int NV, VIA, VIDX;                            // via-points: capacity, poses (x, y, theta), attached grid point (-1 = skipped)
+    __host__ __device__ static WaveLayout make(int n, int M = 0, int O = 0, int V = 1, int ntrig = 4, int NV = 0) {
         WaveLayout L;
         L.n = n;
         L.NS = n;
@@ -61,6 +62,7 @@ struct WaveLayout {
         L.M = M; L.O = O; L.V = V;
         L.OS = take(M); L.OY = take(M); L.OI = take(M); L.OG = take(M); L.OAX = take(M); L.OAY = take(M); L.OHK = take(M);
         L.GV = o; o += 2 * O * V; L.GNV = o; o += O; L.GR = o; o += O; L.GC = o; o += 2 * O;
+        L.NV = NV; L.VIA = o; o += 3 * NV; L.VIDX = o; o += NV;
         L.total = o;
         return L;
     }
@@ -137,7 +139,9 @@ __device__ __forceinline__ float lane_bcast(float v, int src) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
 
-template <typename T, int MODEL>
+// EXT = false compiles the rarely used rows / objective terms (terminal l2-ball, via-points) out of the kernel: the headline
+// configurations keep their instruction count and register budget
+template <typename T, int MODEL, bool EXT = true>
 struct IpmWave {
     const Problem<T>& P;     // lives in LDS (copied once per workgroup): wave-uniform constants are fetched with
     const WaveLayout L;      // broadcast ds_reads instead of being pinned in (and spilled from) scalar registers; the layout
@@ -149,7 +153,8 @@ struct IpmWave {
     bool row0_on, fail0;
     bool warm_guess = false;     // the caller supplied an initial guess (second and later control cycles)
     mutable int cnt_mult = -1, cnt_bmult = -1;      // number of equality / bound multipliers (cached by kkt_pass)
-    int flags;      // bits 0..2 xf_fixed, 3 dt_free, 4 quadratic objective, 5 has_Qf, 6..9 rate_on, 10 terminal ball: the problem record lives in LDS and every
+    int nvia = 0;   // via-points of this instance
+    int flags;      // bits 0..2 xf_fixed, 3 dt_free, 4 quadratic objective, 5 has_Qf, 6..9 rate_on, 10 terminal ball, 11 via-points: the problem record lives in LDS and every
                     // P.x costs a ds_read (+ wait) that the compiler cannot hoist over LDS stores; one scalar register holds the switches
 #ifdef MPC_PROFILE
     mutable long long prof_loop = 0, prof_setup = 0, prof_fwd_loop = 0;    // ticks inside the backward stage loop / before it / inside the forward loop
@@ -173,7 +178,8 @@ struct IpmWave {
     __device__ __forceinline__ bool quad() const { return (flags >> 4) & 1; }
     __device__ __forceinline__ bool hasqf() const { return (flags >> 5) & 1; }
     __device__ __forceinline__ bool ron(int q) const { return (flags >> (6 + q)) & 1; }
-    __device__ __forceinline__ bool ball() const { return (flags >> 10) & 1; }
+    __device__ __forceinline__ bool ball() const { return EXT && ((flags >> 10) & 1); }
+    __device__ __forceinline__ bool via() const { return EXT && ((flags >> 11) & 1); }
     // explicit LDS pointers for the running-pointer loops (address-space inference gives up on per-lane selected pointers)
     typedef __attribute__((address_space(3))) T LdsT;
     __device__ __forceinline__ LdsT* lds(int word) const { return (LdsT*)sm + word; }
@@ -239,6 +245,63 @@ struct IpmWave {
         T s = SCL(SC_TS);
         if (trial) s += alpha * (-(SCL(SC_TG) + s) - ball_jdz());
         return s;
+    }
+
+    // ---------------------------------------------------------------- via-points (MinTimeViaPointsCost, min_time_via_points_cost.cpp)
+    __device__ __forceinline__ void load_via_points(const int32_t* n_via, const double* viap, int inst) {
+        const int NV = L.NV;
+        int nv = n_via ? n_via[inst] : 0;
+        nv = nv < 0 ? 0 : (nv > NV ? NV : nv);
+        for (int v = lane; v < NV; v += kWave) {
+            for (int i = 0; i < 3; ++i) sm[L.VIA + 3 * v + i] = v < nv ? T(viap[((long)inst * NV + v) * 3 + i]) : T(0);
+            sm[L.VIDX + v] = T(-1);
+        }
+        nvia = __builtin_amdgcn_readfirstlane(nv);
+    }
+    // MinTimeViaPointsCost::update (:39-117) with findClosestPose (full_discretization_grid_base_se2.cpp:364-388): every via-point is
+    // attached to the first closest state of the CURRENT vertex values (states start..n-2, then the final state if strictly closer);
+    // ordered mode restarts the search two states behind the previous match; a match at the goal moves to n-2, one at the start is
+    // moved to 1 (ordered) or skipped.
+    __device__ __forceinline__ void associate_via_points() const {
+        const int n = L.n;
+        int start = 0;
+        for (int v = 0; v < nvia; ++v) {
+            const T vx = sm[L.VIA + 3 * v], vy = sm[L.VIA + 3 * v + 1];
+            T best = T(3e38);
+            int bidx = 1 << 30;
+            for (int i = lane; i < n - 1; i += kWave) {
+                if (i < start) continue;
+                const T dx = vx - F(L.X, 0, i), dy = vy - F(L.X, 1, i);
+                const T dist = sqrt(dx * dx + dy * dy);
+                if (dist < best) { best = dist; bidx = i; }
+            }
+            const T dmin = wave_min(best);
+            int idx = (int)wave_min(best == dmin ? T(bidx) : T(1 << 30));
+            {
+                const T dx = vx - F(L.X, 0, n - 1), dy = vy - F(L.X, 1, n - 1);
+                if (sqrt(dx * dx + dy * dy) < dmin || idx >= n) idx = n - 1;
+            }
+            if (P.vp_ordered) start = idx + 2;
+            if (idx > n - 2) idx = n - 2;
+            if (idx < 1) idx = P.vp_ordered ? 1 : -1;
+            if (lane == 0) sm[L.VIDX + v] = T(idx);
+        }
+    }
+    // via-point terms of grid point k at (px, py, th): value, gradient, number of attached points (Hessian 2 w_p m on x and y);
+    // the orientation term is linear as coded (:139-142)
+    __device__ __forceinline__ int via_terms(int k, T px, T py, T th, T& val, T g[3]) const {
+        val = T(0); g[0] = g[1] = g[2] = T(0);
+        int m = 0;
+        const T wp = P.vp_wp, wo = P.vp_wo;
+        for (int v = 0; v < nvia; ++v) {
+            if ((int)sm[L.VIDX + v] != k) continue;
+            const T dx = px - sm[L.VIA + 3 * v], dy = py - sm[L.VIA + 3 * v + 1];
+            val += wp * (dx * dx + dy * dy);
+            g[0] += T(2) * wp * dx; g[1] += T(2) * wp * dy;
+            if (wo > T(0)) { val += wo * normalize_theta(sm[L.VIA + 3 * v + 2] - th); g[2] -= wo; }
+            ++m;
+        }
+        return m;
     }
 
     // ---------------------------------------------------------------- clearance rows
@@ -389,6 +452,7 @@ struct IpmWave {
                 T xd0 = xk[0] - xf[0], xd1 = xk[1] - xf[1], xd2 = normalize_theta(xk[2] - xf[2]);
                 fo += P.Q[0] * xd0 * xd0 + P.Q[1] * xd1 * xd1 + P.Q[2] * xd2 * xd2 + P.R[0] * v * v + P.R[1] * w * w;
             }
+            if (via()) { T vv, vg[3]; via_terms(k, xk[0], xk[1], xk[2], vv, vg); fo += vv; }
         }
         if (lane == 0) {
             if (!quad()) fo += T(n - 1) * d;
@@ -494,6 +558,7 @@ struct IpmWave {
                 const T xd0 = x0_ - xf[0], xd1 = x1_ - xf[1], xd2 = normalize_theta(x2_ - xf[2]);
                 fo = r.Q[0] * xd0 * xd0 + r.Q[1] * xd1 * xd1 + r.Q[2] * xd2 * xd2 + r.R[0] * v * v + r.R[1] * w * w;
             }
+            if (via()) { T vv, vg[3]; via_terms(r.k, x0_, x1_, x2_, vv, vg); fo += vv; }
             acc.mul(v - r.ulb[0]); acc.mul(r.uub[0] - v); acc.mul(w - r.ulb[1]); acc.mul(r.uub[1] - w);
         }
 #pragma unroll
@@ -564,6 +629,7 @@ struct IpmWave {
                     for (int i = 0; i < 3; ++i) gx[i] = T(2) * P.Q[i] * xd[i];
                     gu[0] = T(2) * P.R[0] * v; gu[1] = T(2) * P.R[1] * w;
                 }
+                if (via()) { T vv; via_terms(k, F(L.X, 0, k), F(L.X, 1, k), F(L.X, 2, k), vv, gx); }
                 T osx = T(0), osy = T(0);
                 if (L.M > 0 && k >= 1) {
                     const T px = F(L.X, 0, k), py = F(L.X, 1, k);
@@ -721,6 +787,12 @@ struct IpmWave {
                     sp.oyy += sig * ay * ay - y * hk * (T(1) - ay * ay);
                     sp.ogx += ax * ybar; sp.ogy += ay * ybar;
                 }
+            }
+            if (via() && k >= 1 && k < n - 1) {
+                T vv, vg[3];
+                const int m = via_terms(k, F(L.X, 0, k), F(L.X, 1, k), F(L.X, 2, k), vv, vg);
+                const T h = T(2) * P.vp_wp * T(m);
+                sp.oxx += h; sp.oyy += h; sp.ogx += vg[0]; sp.ogy += vg[1]; sp.hx[2] += vg[2];
             }
             T A[NADD];
             assemble_adds(sp, q2, r2, A);
@@ -1168,11 +1240,13 @@ struct IpmWave {
                 }
             }
             if (k >= 1) {
+                T vg[3] = {T(0), T(0), T(0)};
+                if (via() && k < n - 1) { T vv; via_terms(k, F(L.X, 0, k), F(L.X, 1, k), F(L.X, 2, k), vv, vg); }
                 for (int i = 0; i < 3; ++i) {
                     if (k < n - 1 || !fx(i)) {
                         T dx = F(L.DX, i, k);
                         dz2 += dx * dx; dzmax = t_max(dzmax, t_abs(dx));
-                        T g = T(0);
+                        T g = vg[i];
                         if (quad()) {
                             if (k < n - 1) { T xd = F(L.X, i, k) - xf[i]; if (i == 2) xd = normalize_theta(xd); g = T(2) * P.Q[i] * xd; }
                             else if (hasqf()) { T xd = F(L.X, i, k) - xf[i]; if (i == 2) xd = normalize_theta(xd); g = T(2) * P.Qf[i] * xd; }
@@ -1369,6 +1443,7 @@ struct IpmWave {
         if (lane == 0 && dtf()) SCL(SC_D) = push_interior(SCL(SC_D), P.dt_lb, P.dt_ub);
         sync();
         if (L.M > 0) { associate_obstacles(); sync(); }
+        if (via()) { associate_via_points(); sync(); }
         mu = warm_guess ? P.mu_init_warm : P.mu_init; rho = T(0); delta_last = T(0); fail0 = false;
         const T d = SCL(SC_D);
         for (int k = lane; k < n; k += kWave) {
@@ -1412,7 +1487,7 @@ struct IpmWave {
     __device__ __forceinline__ SolveStats<T> solve() {
         SolveStats<T> out;
         flags = (P.xf_fixed[0] ? 1 : 0) | (P.xf_fixed[1] ? 2 : 0) | (P.xf_fixed[2] ? 4 : 0) | (P.dt_free ? 8 : 0) | (P.objective == OBJ_QUADRATIC ? 16 : 0) |
-                (P.has_Qf ? 32 : 0) | (P.rate_on[0] ? 64 : 0) | (P.rate_on[1] ? 128 : 0) | (P.rate_on[2] ? 256 : 0) | (P.rate_on[3] ? 512 : 0) | (P.ball ? 1024 : 0);
+                (P.has_Qf ? 32 : 0) | (P.rate_on[0] ? 64 : 0) | (P.rate_on[1] ? 128 : 0) | (P.rate_on[2] ? 256 : 0) | (P.rate_on[3] ? 512 : 0) | (P.ball ? 1024 : 0) | (P.via ? 2048 : 0);
         flags = __builtin_amdgcn_readfirstlane(flags);
         nfix = (int)fx(0) + (int)fx(1) + (int)fx(2);
         row0_on = dtprev != T(0);

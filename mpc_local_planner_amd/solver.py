@@ -136,6 +136,17 @@ class BatchSolver:
         a = np.ascontiguousarray(n_grid, dtype=np.int32)
         self._check(self._lib.mpc_set_grid_sizes(self._h, C.c_void_p(a.ctypes.data), int(a.shape[0])))
 
+    def set_via_points(self, n_via=None, via=None):
+        """Via-points of the minimum_time_via_points objective for the following solves: n_via[B], via[B][cfg.max_via_points][3]
+        (x, y, theta); None clears them."""
+        if n_via is None:
+            self._check(self._lib.mpc_set_via_points(self._h, 0, None, None))
+            return
+        nv = np.ascontiguousarray(n_via, dtype=np.int32)
+        vp = np.ascontiguousarray(via, dtype=np.float64)
+        assert vp.shape == (nv.shape[0], self.cfg.max_via_points, 3), vp.shape
+        self._check(self._lib.mpc_set_via_points(self._h, int(nv.shape[0]), C.c_void_p(nv.ctypes.data), C.c_void_p(vp.ctypes.data)))
+
     def synchronize(self):
         self._check(self._lib.mpc_synchronize(self._h))
 

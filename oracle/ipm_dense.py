@@ -243,9 +243,10 @@ class SolverNlp:
     """Variables kept as full arrays X (n,3), U (n-1,2), dt; the free ones are
     indexed into a flat vector: [x_1 .. x_{n-2}, xf(free comps), u_0 .. u_{n-2}, dt(if free)]."""
 
-    def __init__(self, cfg: R.OcpConfig, inp: R.CycleInputs, relevant=None):
+    def __init__(self, cfg: R.OcpConfig, inp: R.CycleInputs, relevant=None, via_idx=None):
         colloc_points(cfg.collocation)      # raises for an unknown method
         self.cfg, self.inp = cfg, inp
+        self.via_idx = via_idx if via_idx is not None else []
         n = self.n = cfg.n
         self.relevant = relevant if relevant is not None else [[] for _ in range(n)]
         # index maps
@@ -332,10 +333,25 @@ class SolverNlp:
         W = np.zeros((nv, nv)) if want_hess else None
         xf = np.asarray(self.inp.xf, float)
         # objective
-        if cfg.objective == R.OBJ_MIN_TIME:
+        if cfg.objective in (R.OBJ_MIN_TIME, R.OBJ_MIN_TIME_VIA_POINTS):
             f = (n - 1) * dt
             if self.idt >= 0:
                 gf[self.idt] = n - 1
+            if cfg.objective == R.OBJ_MIN_TIME_VIA_POINTS:
+                # min_time_via_points_cost.cpp:130-145; the orientation term is linear as coded (gradient -w_o, no curvature)
+                wp, wo = cfg.vp_position_weight, cfg.vp_orientation_weight
+                for vi, k in enumerate(self.via_idx):
+                    if k < 0:
+                        continue
+                    vp = self.inp.via_points[vi]
+                    f += wp * float((vp[0] - X[k, 0]) ** 2 + (vp[1] - X[k, 1]) ** 2)
+                    for i in range(2):
+                        gf[self.ix[k, i]] += 2 * wp * (X[k, i] - vp[i])
+                        if want_hess:
+                            W[self.ix[k, i], self.ix[k, i]] += 2 * wp
+                    if wo > 0:
+                        f += wo * float(R.normalize_theta(vp[2] - X[k, 2]))
+                        gf[self.ix[k, 2]] -= wo
         else:
             f = 0.0
             for k in range(n - 1):
@@ -534,7 +550,9 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
     that no complementarity product starts below the barrier parameter; slacks are re-derived from the new point; the
     collocation multipliers are taken as they are.  Ignored when the structure (row / variable counts) differs."""
     opt = opt or IpmOptions()
-    nlp = SolverNlp(cfg, inp, relevant)
+    # via-point association from the vertex values the solve starts from (MinTimeViaPointsCost::update runs in the grid update, before the solve)
+    via_idx = R.associate_via_points(cfg, init.x, inp.via_points) if cfg.objective == R.OBJ_MIN_TIME_VIA_POINTS else None
+    nlp = SolverNlp(cfg, inp, relevant, via_idx)
     nv, mc, mg = nlp.nv, nlp.mc, nlp.mg
     lb, ub = nlp.lb, nlp.ub
     hasL = lb > -R.INF

@@ -287,6 +287,7 @@ def footprint_distance(fp_kind: int, fp_params: Sequence[float], pose, ob: Obsta
 # --------------------------------------------------------------------------
 OBJ_MIN_TIME = 0
 OBJ_QUADRATIC = 1
+OBJ_MIN_TIME_VIA_POINTS = 2    # planning/objective/type minimum_time_via_points (src/controller.cpp:597-612)
 
 
 @dataclass
@@ -305,6 +306,9 @@ class OcpConfig:
     R: np.ndarray = field(default_factory=lambda: np.zeros(2))     # diagonal control weights
     integral_form: bool = False
     Qf: Optional[np.ndarray] = None               # terminal_cost quadratic (diag) or None
+    vp_position_weight: float = 1e-3              # minimum_time_via_points/position_weight (min_time_via_points_cost.h:122)
+    vp_orientation_weight: float = 0.0            # .../orientation_weight
+    via_points_ordered: bool = False              # .../via_points_ordered
     terminal_ball_S: Optional[np.ndarray] = None  # terminal_constraint l2_ball weight_matrix (diag) or None   (controller.cpp:683-703)
     terminal_ball_gamma: float = 1.0              # .../l2_ball/radius: the row is xd' S xd - gamma <= 0 (final_state_conditions_se2.cpp:54-64)
     u_lb: np.ndarray = field(default_factory=lambda: np.array([-0.2, -0.3]))
@@ -596,6 +600,44 @@ class CycleInputs:
     u_prev: np.ndarray = field(default_factory=lambda: np.zeros(2))
     dt_prev: float = 0.0
     obstacles: List[Obstacle] = field(default_factory=list)
+    via_points: Optional[np.ndarray] = None       # (P, 3) poses x, y, theta (ViaPointContainer, borrowed by the cost)
+
+
+def find_closest_pose(x: np.ndarray, x_ref: float, y_ref: float, start_idx: int = 0) -> int:
+    """FullDiscretizationGridBaseSE2::findClosestPose (...grid_base_se2.cpp:364-388): first minimum of the euclidean distance over
+    the states start_idx .. n-2, then the final state (index n-1) if it is strictly closer."""
+    n = x.shape[0]
+    min_dist, min_idx = np.finfo(float).max, -1
+    for i in range(start_idx, n - 1):
+        d = math.sqrt((x_ref - x[i, 0]) ** 2 + (y_ref - x[i, 1]) ** 2)
+        if d < min_dist:
+            min_dist, min_idx = d, i
+    d = math.sqrt((x_ref - x[n - 1, 0]) ** 2 + (y_ref - x[n - 1, 1]) ** 2)
+    if d < min_dist:
+        min_idx = n - 1
+    return min_idx
+
+
+def associate_via_points(cfg: "OcpConfig", x: np.ndarray, via_points) -> List[int]:
+    """MinTimeViaPointsCost::update (src/optimal_control/min_time_via_points_cost.cpp:39-117): grid point every via-point is attached
+    to (-1 = skipped), from the CURRENT vertex values.  Ordered mode restarts the search two states behind the previous match."""
+    n = x.shape[0]
+    out = []
+    start = 0
+    for vp in (via_points if via_points is not None else []):
+        idx = find_closest_pose(x, float(vp[0]), float(vp[1]), start)
+        if cfg.via_points_ordered:
+            start = idx + 2                      # :83
+        if idx > n - 2:
+            idx = n - 2                          # :86
+        if idx < 1:
+            if cfg.via_points_ordered:
+                idx = 1                          # :91-92
+            else:
+                out.append(-1)                   # :95-96
+                continue
+        out.append(idx)
+    return out
 
 
 class ReferenceNlp:
@@ -607,9 +649,10 @@ class ReferenceNlp:
     (...grid_base_se2.cpp:564-577): u0, x1, u1, ..., x_{n-2}, u_{n-2}, [xf free comps], [dt].
     """
 
-    def __init__(self, cfg: OcpConfig, inp: CycleInputs, relevant=None, relevant_dyn=None):
+    def __init__(self, cfg: OcpConfig, inp: CycleInputs, relevant=None, relevant_dyn=None, via_idx=None):
         self.cfg = cfg
         self.inp = inp
+        self.via_idx = via_idx if via_idx is not None else []      # associate_via_points() of the trajectory the solve starts from
         n = cfg.n
         self.n = n
         self.free_xf = [i for i in range(3) if not cfg.xf_fixed[i]]
@@ -688,6 +731,18 @@ class ReferenceNlp:
             # corbo::MinimumTime on a single-dt grid == (n-1)*dt; in-repo twin
             # src/optimal_control/min_time_via_points_cost.cpp:52-56,120-124
             return (n - 1) * t.dt
+        if cfg.objective == OBJ_MIN_TIME_VIA_POINTS:
+            # MinTimeViaPointsCost (min_time_via_points_cost.cpp:120-145): (n-1) dt on the single-dt grid, plus per attached via-point
+            # position_weight |vp - p_k|^2 and -- as coded -- orientation_weight * normalize_theta(theta_vp - theta_k) (NOT squared)
+            J = (n - 1) * t.dt
+            for v, k in enumerate(self.via_idx):
+                if k < 0:
+                    continue
+                vp = self.inp.via_points[v]
+                J += cfg.vp_position_weight * float((vp[0] - t.x[k, 0]) ** 2 + (vp[1] - t.x[k, 1]) ** 2)
+                if cfg.vp_orientation_weight > 0:
+                    J += cfg.vp_orientation_weight * float(normalize_theta(vp[2] - t.x[k, 2]))
+            return J
         J = 0.0
         xf = np.asarray(self.inp.xf, float)
         for k in range(n - 1):

@@ -65,7 +65,7 @@ def make_obstacles(name, n=30, B=10, O=6, V=6, M=4, keep=6):
     print(name, "kept", len(sel), "iters", IT)
 
 
-if __name__ == "__main__" and "--warm" not in sys.argv and "--integral" not in sys.argv and "--closed-loop" not in sys.argv and "--config3" not in sys.argv and "--midpoint" not in sys.argv and "--cn" not in sys.argv and "--ball" not in sys.argv:
+if __name__ == "__main__" and "--warm" not in sys.argv and "--integral" not in sys.argv and "--closed-loop" not in sys.argv and "--config3" not in sys.argv and "--midpoint" not in sys.argv and "--cn" not in sys.argv and "--ball" not in sys.argv and "--via" not in sys.argv:
     make_obstacles("unicycle_quadratic_obstacles_n30")
     make("carlike_min_time_n50", R.config_carlike_min_time(50), W.carlike_min_time_inputs(32, seed=101), keep=8)
     make("carlike_min_time_n20", R.config_carlike_min_time(20), W.carlike_min_time_inputs(32, seed=102, goal_range=(1.0, 2.5)), keep=8)
@@ -243,3 +243,57 @@ def make_terminal_ball(name, n=20, B=16, keep=6):
 
 if __name__ == "__main__" and "--ball" in sys.argv:
     make_terminal_ball("unicycle_quadratic_ball_n20")
+
+
+def via_points_for(x0, xf, rng, nvp, near_start=False):
+    """via-points next to the straight line start -> goal (what the planner samples from the global plan, mpc_local_planner_ros.cpp:619-635),
+    pushed sideways by up to 0.4 m; optionally one right at the start pose (exercises the idx < 1 branch)."""
+    d = xf[:2] - x0[:2]
+    L = float(np.hypot(*d))
+    t = d / L
+    nrm = np.array([-t[1], t[0]])
+    fr = np.sort(rng.uniform(0.15, 0.85, nvp))
+    vps = [[*(x0[:2] + f * d + rng.uniform(-0.4, 0.4) * nrm), float(np.arctan2(t[1], t[0]))] for f in fr]
+    if near_start:
+        vps[0] = [x0[0] + 0.01, x0[1] - 0.01, float(x0[2])]
+    return np.array(vps)
+
+
+def make_via(name, ordered, wo, nvp, near_start, n=30, B=24, keep=6, VP=4):
+    """f3: minimum_time_via_points objective (src/optimal_control/min_time_via_points_cost.cpp), car-like model of BASELINE config 2."""
+    cfg = R.config_carlike_min_time(n)
+    cfg.objective, cfg.vp_position_weight, cfg.vp_orientation_weight, cfg.via_points_ordered = R.OBJ_MIN_TIME_VIA_POINTS, 10.5, wo, ordered
+    x0, xf, up, dtp = W.carlike_min_time_inputs(B, seed=141, goal_range=(2.0, 4.5))
+    rng = np.random.default_rng(77)
+    rows = []
+    for i in range(B):
+        vps = via_points_for(x0[i], xf[i], rng, nvp, near_start)
+        if len(rows) >= keep:
+            break
+        inp = R.CycleInputs(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=float(dtp[i]), via_points=vps)
+        init = R.cold_start(cfg, x0[i], xf[i])
+        idx = R.associate_via_points(cfg, init.x, vps)
+        ref = I.solve(cfg, inp, init, opt=I.IpmOptions(globalization="merit", max_iter=100))
+        if ref.status != 0 or ref.iters > 45:
+            continue
+        # keep only instances whose iterate path is stable under round-off: these problems are flat around the solution (a KKT error of
+        # 1e-9 leaves ~1e-5 of play in the states), so two implementations agree to 1e-6 only where a 1e-12 perturbation of the data
+        # does not move the point where the iteration stops
+        inp2 = R.CycleInputs(x0=x0[i], xf=xf[i] * (1 + 1e-12), u_prev=up[i], dt_prev=float(dtp[i]), via_points=vps * (1 - 1e-12))
+        pert = I.solve(cfg, inp2, R.cold_start(cfg, x0[i], inp2.xf), opt=I.IpmOptions(globalization="merit", max_iter=100))
+        if pert.iters != ref.iters or np.abs(pert.traj.x - ref.traj.x).max() > 1e-8 or np.abs(pert.traj.u - ref.traj.u).max() > 1e-8:
+            continue
+        nlp = R.ReferenceNlp(cfg, inp, via_idx=idx)
+        z = nlp.pack(ref.traj)
+        assert np.abs(nlp.equalities(z)).max() < 1e-7 and nlp.inequalities(z).max() < 1e-7
+        assert abs(nlp.objective(z) - ref.objective) < 1e-9 * max(1.0, abs(ref.objective))
+        via = np.zeros((VP, 3)); via[:nvp] = vps
+        rows.append(dict(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=dtp[i], n_via=nvp, via=via, idx=np.array(idx + [-1] * (VP - nvp)),
+                         x=ref.traj.x, u=np.vstack([ref.traj.u, ref.traj.u[-1:]]), dt=ref.traj.dt, iters=ref.iters, objective=ref.objective))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), ordered=ordered, wp=10.5, wo=wo, **{k: np.array([r[k] for r in rows]) for k in rows[0]})
+    print(name, "kept", len(rows), "iters", [r["iters"] for r in rows], "idx", [list(r["idx"]) for r in rows])
+
+
+if __name__ == "__main__" and "--via" in sys.argv:
+    make_via("carlike_via_points_n30", ordered=False, wo=0.0, nvp=2, near_start=False)
+    make_via("carlike_via_points_ordered_n30", ordered=True, wo=0.05, nvp=3, near_start=True)

@@ -492,3 +492,26 @@ def test_terminal_ball_golden(m):
     r = s.solve(g1["x0"], g1["xf"], g1["u_prev"], g1["dt_prev"])
     assert (r.status == 0).all() and np.abs(r.x - g1["x"]).max() < 1e-6 and np.abs(r.u - g1["u"]).max() < 1e-6
     s.close()
+
+
+@pytest.mark.parametrize("name", ["carlike_via_points_n30", "carlike_via_points_ordered_n30"])
+def test_via_points_objective_golden(m, name):
+    """minimum_time_via_points (src/optimal_control/min_time_via_points_cost.cpp:39-145): association of every via-point
+    with its closest grid point of the starting trajectory (plain and ordered mode, incl. the 'behind the start' branch), quadratic
+    attraction on the position, the orientation term linear as the reference codes it.  Fixtures: tests/golden/make_golden.py --via."""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    B, VP = g["x0"].shape[0], g["via"].shape[1]
+    cfg = m.config_carlike_min_time(30, objective=m.OBJ_MIN_TIME_VIA_POINTS, vp_position_weight=float(g["wp"]), vp_orientation_weight=float(g["wo"]),
+                                    via_points_ordered=bool(g["ordered"]), max_via_points=VP)
+    s = m.BatchSolver(cfg, max_batch=B)
+    s.set_via_points(g["n_via"], g["via"])
+    r = s.solve(g["x0"], g["xf"], g["u_prev"], g["dt_prev"])
+    assert (r.status == 0).all()
+    assert np.abs(r.x - g["x"]).max() < 1e-6 and np.abs(r.u - g["u"]).max() < 1e-6 and np.abs(r.dt - g["dt"]).max() < 1e-7
+    assert (np.abs(r.iters - g["iters"]) <= np.maximum(2, 0.1 * g["iters"])).all()
+    # cleared via-points: plain minimum time (shorter transition time than with the detours)
+    s.set_via_points(None)
+    p = s.solve(g["x0"], g["xf"], g["u_prev"], g["dt_prev"])
+    ok = p.status == 0
+    assert ok.sum() >= B - 1 and (p.dt[ok] < r.dt[ok] + 1e-9).all() and (p.dt[ok] < r.dt[ok] - 1e-4).any()
+    s.close()
