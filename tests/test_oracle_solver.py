@@ -208,3 +208,40 @@ def test_c_oracle_midpoint_and_crank_nicolson_match_numpy_goldens(name, kind, n,
     assert (st == 0).all()
     assert np.abs(xo - g["x"]).max() < 1e-6 and np.abs(uo - g["u"]).max() < 1e-6 and np.abs(do - g["dt"]).max() < 1e-8
     assert np.abs(it - g["iters"]).max() <= 2
+
+
+def test_via_point_association_rules():
+    """MinTimeViaPointsCost::update (min_time_via_points_cost.cpp:39-117) + findClosestPose (...grid_base_se2.cpp:364-388)."""
+    x = np.zeros((6, 3))
+    x[:, 0] = np.arange(6.0)                       # states on the x axis at 0..5 (the last one is the goal)
+    cfg = R.config_carlike_min_time(6)
+    cfg.objective = R.OBJ_MIN_TIME_VIA_POINTS
+    assert R.find_closest_pose(x, 2.4, 1.0) == 2 and R.find_closest_pose(x, 2.5, 0.0) == 2       # first minimum wins a tie
+    assert R.find_closest_pose(x, 9.0, 0.0) == 5 and R.find_closest_pose(x, 2.0, 0.0, start_idx=4) == 4
+    vps = np.array([[2.4, 0.5, 0.0], [-1.0, 0.0, 0.0], [7.0, 0.0, 0.0], [0.9, 0.0, 0.0]])
+    assert R.associate_via_points(cfg, x, vps) == [2, -1, 4, 1]                # behind the start: skipped; at/after the goal: n-2
+    cfg.via_points_ordered = True
+    # ordered: the search restarts two states behind the previous (unclamped) match; a match at the start moves to state 1
+    assert R.associate_via_points(cfg, x, vps) == [2, 4, 4, 4]
+    assert R.associate_via_points(cfg, x, np.array([[-1.0, 0, 0], [0.1, 0, 0], [3.2, 0, 0]])) == [1, 2, 4]
+
+
+@pytest.mark.parametrize("name", ["carlike_via_points_n30", "carlike_via_points_ordered_n30", "unicycle_quadratic_ball_n20"])
+def test_numpy_oracle_reproduces_via_point_and_terminal_ball_goldens(name):
+    """regression pin of oracle/ipm_dense.py for the fixtures of tests/golden/make_golden.py --via / --ball (first two instances)."""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    for i in range(2):
+        if "ball" in name:
+            cfg = R.config_unicycle_quadratic(20)
+            cfg.Q, cfg.R, cfg.Qf, cfg.terminal_ball_S, cfg.terminal_ball_gamma = g["Q"], g["R"], None, g["S"], float(g["gamma"])
+            inp = R.CycleInputs(x0=g["x0"][i], xf=g["xf"][i], u_prev=g["u_prev"][i], dt_prev=float(g["dt_prev"][i]))
+        else:
+            cfg = R.config_carlike_min_time(30)
+            cfg.objective, cfg.vp_position_weight, cfg.vp_orientation_weight = R.OBJ_MIN_TIME_VIA_POINTS, float(g["wp"]), float(g["wo"])
+            cfg.via_points_ordered = bool(g["ordered"])
+            vps = g["via"][i, :int(g["n_via"][i])]
+            inp = R.CycleInputs(x0=g["x0"][i], xf=g["xf"][i], u_prev=g["u_prev"][i], dt_prev=float(g["dt_prev"][i]), via_points=vps)
+            assert R.associate_via_points(cfg, R.cold_start(cfg, g["x0"][i], g["xf"][i]).x, vps) == list(g["idx"][i, :len(vps)])
+        r = I.solve(cfg, inp, R.cold_start(cfg, g["x0"][i], g["xf"][i]), opt=I.IpmOptions(globalization="merit", max_iter=100))
+        assert r.status == 0 and r.iters == g["iters"][i]
+        assert np.abs(r.traj.x - g["x"][i]).max() < 1e-9 and abs(r.traj.dt - g["dt"][i]) < 1e-10
