@@ -184,6 +184,23 @@ int mpc_set_via_points(mpc_solver* s, int32_t B, const int32_t* n_via, const dou
 /* Same with DEVICE pointers, borrowed until the next mpc_set_via_points* call. */
 int mpc_set_via_points_device(mpc_solver* s, const int32_t* d_n_via, const double* d_via);
 
+/* Costmap -> point obstacles, the step in front of the solve (MpcLocalPlannerROS::updateObstacleContainerWithCostmap,
+ * src/mpc_local_planner_ros.cpp:474-499): every LETHAL (254) cell of instance b's local costmap cost[b][my][mx]
+ * (costmap_2d layout, cell (mx,my) at index my*size_x + mx; the last row and column are not visited, as in the reference)
+ * becomes a point obstacle at origin[b] + (m + 0.5) * resolution, unless it lies behind the robot pose[b] = (x, y, theta)
+ * and farther away than behind_robot_dist (collision_avoidance/costmap_obstacles_behind_robot_dist, default 1.5).
+ * Output in the mpc_obstacles layout of THIS solver (capacity cfg.max_obstacles, vertex stride cfg.max_vertices), in the
+ * reference's container order (mx outer, my inner); dropped[b] (nullable) = cells that did not fit.  The result can be
+ * handed to mpc_solve_batch_device as is (radius = NULL); converter / custom obstacles are appended by the caller
+ * behind n_obstacles[b].  DEVICE pointers; runs on the solver's stream. */
+int mpc_costmap_to_obstacles_device(mpc_solver* s, int32_t B, const uint8_t* d_cost, int32_t size_x, int32_t size_y, double resolution,
+                                    const double* d_origin /* [B][2] */, const double* d_robot_pose /* [B][3] */, double behind_robot_dist,
+                                    int32_t* d_n_obstacles, int32_t* d_n_vertices, double* d_vertices, int32_t* d_dropped);
+/* Same with HOST pointers (staged through temporary device buffers; blocking). */
+int mpc_costmap_to_obstacles(mpc_solver* s, int32_t B, const uint8_t* cost, int32_t size_x, int32_t size_y, double resolution,
+                             const double* origin, const double* robot_pose, double behind_robot_dist,
+                             int32_t* n_obstacles, int32_t* n_vertices, double* vertices, int32_t* dropped);
+
 int mpc_synchronize(mpc_solver* s);
 
 /* Duration (ms) of the solve kernel of the most recent mpc_solve_batch* call, measured with

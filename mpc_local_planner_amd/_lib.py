@@ -16,11 +16,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libmpc_hip.so")
 SOURCES = ["mpc_capi.hip"]
-HEADERS = ["mpc_core.hpp", "mpc_problem.hpp", "mpc_wave.hpp", "mpc_dpp_blocks.inc", os.path.join("..", "..", "include", "mpc_hip.h")]
+HEADERS = ["mpc_core.hpp", "mpc_problem.hpp", "mpc_wave.hpp", "mpc_dpp_blocks.inc", "mpc_costmap.hpp", os.path.join("..", "..", "include", "mpc_hip.h")]
 
 EXPORTS = [
     "mpc_config_defaults", "mpc_create", "mpc_reset", "mpc_destroy", "mpc_solve_batch",
-    "mpc_solve_batch_device", "mpc_set_grid_sizes", "mpc_set_via_points", "mpc_set_via_points_device", "mpc_synchronize", "mpc_last_kernel_ms", "mpc_last_error", "mpc_version",
+    "mpc_solve_batch_device", "mpc_set_grid_sizes", "mpc_set_via_points", "mpc_set_via_points_device", "mpc_costmap_to_obstacles", "mpc_costmap_to_obstacles_device", "mpc_synchronize", "mpc_last_kernel_ms", "mpc_last_error", "mpc_version",
 ]
 
 
@@ -89,6 +89,11 @@ def load() -> C.CDLL:
     lib.mpc_set_via_points.restype = C.c_int
     lib.mpc_set_via_points_device.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.mpc_set_via_points_device.restype = C.c_int
+    cm = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_double, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.mpc_costmap_to_obstacles.argtypes = cm
+    lib.mpc_costmap_to_obstacles.restype = C.c_int
+    lib.mpc_costmap_to_obstacles_device.argtypes = cm
+    lib.mpc_costmap_to_obstacles_device.restype = C.c_int
     lib.mpc_synchronize.argtypes = [C.c_void_p]
     lib.mpc_synchronize.restype = C.c_int
     lib.mpc_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]

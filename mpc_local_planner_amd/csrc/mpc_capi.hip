@@ -12,6 +12,7 @@
 #include "mpc_core.hpp"
 #include "mpc_problem.hpp"
 #include "mpc_wave.hpp"
+#include "mpc_costmap.hpp"
 
 namespace {
 
@@ -232,8 +233,8 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         set_err("mpc_create: minimum_time_via_points needs 1 <= max_via_points <= 64"); return MPC_EINVAL; }
     if (cfg->objective != MPC_OBJ_QUADRATIC && !cfg->dt_free) { set_err("mpc_create: minimum_time needs a variable grid (dt_free)"); return MPC_EINVAL; }
     if (!(cfg->dt_ref > 0)) { set_err("mpc_create: dt_ref must be > 0"); return MPC_EINVAL; }
-    if (cfg->max_obstacles < 0 || cfg->max_obstacles > 256 || (cfg->max_obstacles > 0 && (cfg->max_vertices < 1 || cfg->max_vertices > 64)) || cfg->max_obstacle_rows > 16) {
-        set_err("mpc_create: obstacle capacities out of range (max_obstacles <= 256, max_vertices <= 64, max_obstacle_rows <= 16)"); return MPC_EINVAL; }
+    if (cfg->max_obstacles < 0 || cfg->max_obstacles > 4096 || (cfg->max_obstacles > 0 && (cfg->max_vertices < 1 || cfg->max_vertices > 64)) || cfg->max_obstacle_rows > 16) {
+        set_err("mpc_create: obstacle capacities out of range (max_obstacles <= 4096, max_vertices <= 64, max_obstacle_rows <= 16)"); return MPC_EINVAL; }
     if (cfg->max_obstacles > 0 && cfg->footprint_kind != MPC_FOOTPRINT_POINT && cfg->footprint_kind != MPC_FOOTPRINT_CIRCLE) {
         set_err("mpc_create: only point and circular footprints are implemented"); return MPC_EINVAL; }
     if (cfg->integral_form && cfg->dt_free) { set_err("mpc_create: integral_form costs are implemented for the fixed-dt grid only (dt_free = 0)"); return MPC_EINVAL; }
@@ -436,6 +437,61 @@ int mpc_set_via_points_device(mpc_solver* s, const int32_t* d_n_via, const doubl
     if (!d_n_via || !d_via) return mpc_set_via_points(s, 0, nullptr, nullptr);
     s->p_nvia = d_n_via; s->p_via = d_via;
     return MPC_OK;
+}
+
+int mpc_costmap_to_obstacles_device(mpc_solver* s, int32_t B, const uint8_t* d_cost, int32_t size_x, int32_t size_y, double resolution,
+                                    const double* d_origin, const double* d_robot_pose, double behind_robot_dist,
+                                    int32_t* d_n_obstacles, int32_t* d_n_vertices, double* d_vertices, int32_t* d_dropped) {
+    g_err[0] = 0;
+    if (!s || !d_cost || !d_origin || !d_robot_pose || !d_n_obstacles || !d_n_vertices || !d_vertices) { set_err("mpc_costmap_to_obstacles_device: null argument"); return MPC_EINVAL; }
+    if (s->cfg.max_obstacles <= 0) { set_err("mpc_costmap_to_obstacles_device: the solver was created with max_obstacles = 0"); return MPC_EINVAL; }
+    if (size_x < 1 || size_y < 1 || !(resolution > 0)) { set_err("mpc_costmap_to_obstacles_device: bad costmap geometry"); return MPC_EINVAL; }
+    if (B <= 0) return MPC_OK;
+    if (B > s->max_batch) { set_err("mpc_costmap_to_obstacles_device: B exceeds max_batch"); return MPC_EBATCH; }
+    HIP_TRY(hipSetDevice(s->device));
+    mpc::CostmapArgs a;
+    a.cost = d_cost; a.origin = d_origin; a.pose = d_robot_pose;
+    a.size_x = size_x; a.size_y = size_y; a.resolution = resolution; a.behind_dist = behind_robot_dist;
+    a.O = s->cfg.max_obstacles; a.V = s->cfg.max_vertices > 0 ? s->cfg.max_vertices : 1;
+    a.n_obstacles = d_n_obstacles; a.n_vertices = d_n_vertices; a.vertices = d_vertices; a.dropped = d_dropped;
+    HIP_TRY(hipEventRecord(s->ev0, s->stream));
+    hipLaunchKernelGGL(mpc::costmap_to_obstacles_kernel, dim3(B), dim3(mpc::kCostmapThreads), 0, s->stream, a);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipEventRecord(s->ev1, s->stream));
+    s->timed = true;
+    return MPC_OK;
+}
+
+int mpc_costmap_to_obstacles(mpc_solver* s, int32_t B, const uint8_t* cost, int32_t size_x, int32_t size_y, double resolution,
+                             const double* origin, const double* robot_pose, double behind_robot_dist,
+                             int32_t* n_obstacles, int32_t* n_vertices, double* vertices, int32_t* dropped) {
+    g_err[0] = 0;
+    if (!s || !cost || !origin || !robot_pose || !n_obstacles || !n_vertices || !vertices) { set_err("mpc_costmap_to_obstacles: null argument"); return MPC_EINVAL; }
+    if (B <= 0) return MPC_OK;
+    if (s->cfg.max_obstacles <= 0 || size_x < 1 || size_y < 1) { set_err("mpc_costmap_to_obstacles: bad argument"); return MPC_EINVAL; }
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t O = s->cfg.max_obstacles, V = s->cfg.max_vertices > 0 ? s->cfg.max_vertices : 1, nb = (size_t)B;
+    const size_t sz[7] = {nb * size_x * size_y, nb * 2 * 8, nb * 3 * 8, nb * 4, nb * O * 4, nb * O * V * 2 * 8, nb * 4};
+    void* d[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipError_t er = hipSuccess;
+    for (int i = 0; i < 7 && er == hipSuccess; ++i) er = hipMalloc(&d[i], sz[i]);
+    int rc = MPC_OK;
+    if (er == hipSuccess) er = hipMemcpyAsync(d[0], cost, sz[0], hipMemcpyHostToDevice, s->stream);
+    if (er == hipSuccess) er = hipMemcpyAsync(d[1], origin, sz[1], hipMemcpyHostToDevice, s->stream);
+    if (er == hipSuccess) er = hipMemcpyAsync(d[2], robot_pose, sz[2], hipMemcpyHostToDevice, s->stream);
+    if (er == hipSuccess) er = hipMemsetAsync(d[4], 0, sz[4], s->stream);
+    if (er == hipSuccess) er = hipMemsetAsync(d[5], 0, sz[5], s->stream);
+    if (er == hipSuccess)
+        rc = mpc_costmap_to_obstacles_device(s, B, (const uint8_t*)d[0], size_x, size_y, resolution, (const double*)d[1], (const double*)d[2], behind_robot_dist,
+                                             (int32_t*)d[3], (int32_t*)d[4], (double*)d[5], (int32_t*)d[6]);
+    if (er == hipSuccess && rc == MPC_OK) er = hipMemcpyAsync(n_obstacles, d[3], sz[3], hipMemcpyDeviceToHost, s->stream);
+    if (er == hipSuccess && rc == MPC_OK) er = hipMemcpyAsync(n_vertices, d[4], sz[4], hipMemcpyDeviceToHost, s->stream);
+    if (er == hipSuccess && rc == MPC_OK) er = hipMemcpyAsync(vertices, d[5], sz[5], hipMemcpyDeviceToHost, s->stream);
+    if (er == hipSuccess && rc == MPC_OK && dropped) er = hipMemcpyAsync(dropped, d[6], sz[6], hipMemcpyDeviceToHost, s->stream);
+    if (er == hipSuccess) er = hipStreamSynchronize(s->stream);
+    for (int i = 0; i < 7; ++i) if (d[i]) (void)hipFree(d[i]);
+    if (er != hipSuccess) { set_err("mpc_costmap_to_obstacles", er); return er == hipErrorOutOfMemory ? MPC_ENOMEM : MPC_EHIP; }
+    return rc;
 }
 
 int mpc_set_grid_sizes(mpc_solver* s, const int32_t* n_grid, int32_t B) {

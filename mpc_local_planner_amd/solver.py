@@ -147,6 +147,20 @@ class BatchSolver:
         assert vp.shape == (nv.shape[0], self.cfg.max_via_points, 3), vp.shape
         self._check(self._lib.mpc_set_via_points(self._h, int(nv.shape[0]), C.c_void_p(nv.ctypes.data), C.c_void_p(vp.ctypes.data)))
 
+    def costmap_to_obstacles(self, cost, resolution, origin, robot_pose, behind_robot_dist=1.5):
+        """Lethal costmap cells -> point obstacles in this solver's obstacle layout (mpc_costmap_to_obstacles).
+        cost: uint8 [B][size_y][size_x]; origin [B][2]; robot_pose [B][3].  Returns (n_obstacles[B], n_vertices[B][O], vertices[B][O][V][2], dropped[B])."""
+        cost = np.ascontiguousarray(cost, dtype=np.uint8)
+        B, sy, sx = cost.shape
+        org = np.ascontiguousarray(origin, dtype=np.float64).reshape(B, 2)
+        pose = np.ascontiguousarray(robot_pose, dtype=np.float64).reshape(B, 3)
+        O, V = self.cfg.max_obstacles, max(1, self.cfg.max_vertices)
+        no = np.zeros(B, np.int32); nv = np.zeros((B, O), np.int32); vt = np.zeros((B, O, V, 2)); dr = np.zeros(B, np.int32)
+        p = lambda a: C.c_void_p(a.ctypes.data)
+        self._check(self._lib.mpc_costmap_to_obstacles(self._h, B, p(cost), sx, sy, float(resolution), p(org), p(pose), float(behind_robot_dist),
+                                                       p(no), p(nv), p(vt), p(dr)))
+        return no, nv, vt, dr
+
     def synchronize(self):
         self._check(self._lib.mpc_synchronize(self._h))
 

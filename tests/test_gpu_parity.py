@@ -515,3 +515,52 @@ def test_via_points_objective_golden(m, name):
     ok = p.status == 0
     assert ok.sum() >= B - 1 and (p.dt[ok] < r.dt[ok] + 1e-9).all() and (p.dt[ok] < r.dt[ok] - 1e-4).any()
     s.close()
+
+
+def test_costmap_to_point_obstacles_bit_exact(m):
+    """SURVEY 8(f)-2: MpcLocalPlannerROS::updateObstacleContainerWithCostmap (src/mpc_local_planner_ros.cpp:474-499) on the device vs
+    oracle/costmap.py: same obstacles, same ORDER, bit-identical coordinates; capacity overflow is reported; edge cases: empty map,
+    lethal cells only in the last row / column (never visited), a map narrower than one slab and one wider than 256 columns."""
+    from oracle import costmap as OC
+    rng = np.random.default_rng(20260927)
+    for (sx, sy, B, dens, O) in ((60, 45, 5, 0.02, 256), (300, 70, 3, 0.004, 256), (40, 40, 2, 0.2, 64), (1, 1, 1, 1.0, 8), (2, 5, 2, 1.0, 8)):
+        pr = (1.0 - dens) * np.array([0.5, 0.2, 0.1, 0.1, 0.0, 0.1]); pr[4] = dens
+        cost = rng.choice(np.array([0, 1, 128, 253, 254, 255], np.uint8), size=(B, sy, sx), p=pr).astype(np.uint8)
+        if sx > 10:
+            cost[0] = 0
+            cost[0, -1, :] = 254; cost[0, :, -1] = 254            # instance 0: lethal only where the reference never looks
+        res = 0.05
+        origin = rng.uniform(-5, 5, (B, 2))
+        pose = np.concatenate([origin + rng.uniform(0.2, 0.8, (B, 2)) * np.array([sx, sy]) * res, rng.uniform(-np.pi, np.pi, (B, 1))], 1)
+        s = m.BatchSolver(m.config_unicycle_quadratic(20, max_obstacles=O, max_vertices=3), max_batch=B)
+        no, nv, vt, dr = s.costmap_to_obstacles(cost, res, origin, pose, behind_robot_dist=0.6)
+        for b in range(B):
+            ref = OC.costmap_to_obstacles(cost[b], res, origin[b], pose[b], 0.6)
+            k = min(len(ref), O)
+            assert no[b] == k and dr[b] == len(ref) - k
+            assert (nv[b, :k] == 1).all() and (nv[b, k:] == 0).all()
+            np.testing.assert_array_equal(vt[b, :k, 0, :], ref[:k])
+        if sx > 10:
+            assert no[0] == 0
+        s.close()
+
+
+def test_costmap_obstacles_feed_the_solve(m):
+    """costmap cells -> point obstacles -> clearance rows, all through the C ABI: the solved trajectory keeps min_obstacle_dist to every
+    lethal cell centre it was given."""
+    from oracle import costmap as OC
+    sx = sy = 80
+    res = 0.05
+    cost = np.zeros((1, sy, sx), np.uint8)
+    cost[0, 44:48, 40:42] = 254                                 # a block whose nearest cell centre is ~0.17 m beside the straight line start -> goal
+    origin = np.array([[-0.5, -2.0]])
+    x0 = np.array([[0.0, 0.0, 0.0]]); xf = np.array([[3.0, 0.1, 0.0]])
+    s = m.BatchSolver(m.config_unicycle_quadratic(40, max_obstacles=64, max_vertices=1), max_batch=1)
+    no, nv, vt, dr = s.costmap_to_obstacles(cost, res, origin, x0, behind_robot_dist=1.5)
+    assert no[0] == 8 and dr[0] == 0
+    r = s.solve(x0, xf, np.zeros((1, 2)), np.array([0.2]), obstacles=(no, nv, vt))
+    assert r.status[0] == 0
+    pts = OC.costmap_to_obstacles(cost[0], res, origin[0], x0[0])
+    d = np.sqrt(((r.x[0, 1:-1, None, :2] - pts[None]) ** 2).sum(-1))
+    assert d.min() > 0.2 - 1e-6 and d.min() < 0.2 + 1e-3        # min_obstacle_dist of the config; the block is in the way, so the row binds
+    s.close()
