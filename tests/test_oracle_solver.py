@@ -245,3 +245,17 @@ def test_numpy_oracle_reproduces_via_point_and_terminal_ball_goldens(name):
         r = I.solve(cfg, inp, R.cold_start(cfg, g["x0"][i], g["xf"][i]), opt=I.IpmOptions(globalization="merit", max_iter=100))
         assert r.status == 0 and r.iters == g["iters"][i]
         assert np.abs(r.traj.x - g["x"][i]).max() < 1e-9 and abs(r.traj.dt - g["dt"][i]) < 1e-10
+
+
+def test_costmap_oracle_order_and_filter():
+    """oracle/costmap.py against a hand-worked map (src/mpc_local_planner_ros.cpp:474-499): container order is x-index outer, y-index
+    inner; the last row / column are never visited; cells behind the robot and farther than the limit are dropped."""
+    from oracle import costmap as OC
+    cost = np.zeros((4, 5), np.uint8)                 # size_y = 4, size_x = 5
+    cost[2, 1] = 254; cost[0, 1] = 254; cost[1, 3] = 254; cost[0, 0] = 253; cost[3, 2] = 254; cost[1, 4] = 254
+    pts = OC.costmap_to_obstacles(cost, 1.0, (10.0, 20.0), (12.0, 21.0, 0.0), behind_robot_dist=100.0)
+    np.testing.assert_array_equal(pts, [[11.5, 20.5], [11.5, 22.5], [13.5, 21.5]])          # (1,0), (1,2), (3,1); row 3 and column 4 skipped
+    # robot at x = 12 heading +x: the two cells at x = 11.5 are behind it; (1,2) is 1.58 away, (1,0) 0.71
+    pts = OC.costmap_to_obstacles(cost, 1.0, (10.0, 20.0), (12.0, 21.0, 0.0), behind_robot_dist=1.0)
+    np.testing.assert_array_equal(pts, [[11.5, 20.5], [13.5, 21.5]])
+    assert OC.costmap_to_obstacles(np.full((1, 1), 254, np.uint8), 1.0, (0, 0), (0, 0, 0)).shape == (0, 2)
