@@ -19,6 +19,7 @@ class OracleConfig(C.Structure):
         ("Qf", C.c_double * 3), ("u_lb", C.c_double * 2), ("u_ub", C.c_double * 2), ("du_lb", C.c_double * 2),
         ("du_ub", C.c_double * 2), ("max_iter", C.c_int32), ("tol", C.c_double), ("mu_init", C.c_double),
         ("collocation", C.c_int32),
+        ("via", C.c_int32), ("vp_ordered", C.c_int32), ("vp_wp", C.c_double), ("vp_wo", C.c_double),
     ]
 
 
@@ -63,6 +64,9 @@ def from_nlp_config(cfg, max_iter=100, tol=1e-8, mu_init=0.1) -> OracleConfig:
         o.du_lb[j], o.du_ub[j] = max(cfg.du_lb[j], -1e30), min(cfg.du_ub[j], 1e30)
     o.max_iter, o.tol, o.mu_init = max_iter, tol, mu_init
     o.collocation = int(getattr(cfg, "collocation", 0))
+    if cfg.objective == 2:          # minimum_time_via_points = minimum time + via-point terms (set the points with set_via_points)
+        o.objective, o.via = 0, 1
+        o.vp_ordered, o.vp_wp, o.vp_wo = int(cfg.via_points_ordered), cfg.vp_position_weight, cfg.vp_orientation_weight
     return o
 
 
@@ -82,9 +86,17 @@ def obst_from_nlp_config(cfg, max_obstacles: int, max_vertices: int, max_rows: i
     return OracleObst(max_obstacles, max_vertices, max_rows, cfg.min_obstacle_dist, cfg.force_inclusion_dist, cfg.cutoff_dist, fr)
 
 
-def solve_batch(ocfg: OracleConfig, x0, xf, u_prev=None, dt_prev=None, init=None, nthreads=0, obstacles=None, obst: "OracleObst" = None):
-    """obstacles = (n_obstacles (B,), n_vertices (B,O), vertices (B,O,V,2)[, radius (B,O)]) together with obst (OracleObst)."""
+def solve_batch(ocfg: OracleConfig, x0, xf, u_prev=None, dt_prev=None, init=None, nthreads=0, obstacles=None, obst: "OracleObst" = None, via=None):
+    """obstacles = (n_obstacles (B,), n_vertices (B,O), vertices (B,O,V,2)[, radius (B,O)]) together with obst (OracleObst).
+    via = (n_via (B,), via (B,VP,3)) for a config made from objective minimum_time_via_points."""
     lib = _load()
+    if via is not None:
+        nvia = np.ascontiguousarray(via[0], np.int32); vps = np.ascontiguousarray(via[1], float)
+        lib.oracle_set_via_points(nvia.ctypes.data_as(C.c_void_p), vps.ctypes.data_as(C.c_void_p), C.c_int(vps.shape[1]))
+        try:
+            return solve_batch(ocfg, x0, xf, u_prev, dt_prev, init, nthreads, obstacles, obst)
+        finally:
+            lib.oracle_set_via_points(None, None, C.c_int(0))
     x0 = np.ascontiguousarray(x0, float)
     xf = np.ascontiguousarray(xf, float)
     B, n = x0.shape[0], ocfg.n

@@ -53,6 +53,9 @@ typedef struct oracle_config {
     double tol;
     double mu_init;
     int32_t collocation;        /* 0 forward, 1 midpoint, 2 crank-nicolson (literal) -- same codes as include/mpc_hip.h */
+    int32_t via;                /* minimum_time_via_points: objective 0 plus the via-point terms (min_time_via_points_cost.cpp:120-145) */
+    int32_t vp_ordered;
+    double vp_wp, vp_wo;
 } oracle_config;
 
 #define PI 3.14159265358979323846
@@ -194,6 +197,8 @@ typedef struct {
     int* oi;                  /* n*M obstacle index or -1 */
     double *os, *oy, *ost, *ods, *ody;   /* n*M slack, multiplier, trial slack, steps */
     double *og, *oax, *oay, *ohk;        /* n*M cached value, gradient (= -unit normal), curvature 1/|p-q| (0 on an edge interior) */
+    /* via-points of this instance (set per batch with oracle_set_via_points) and the grid point each one is attached to */
+    int nvia; const double* via; int vidx[64];
 } work_t;
 
 static int iu(int k, int j) { return 8 * k + j; }
@@ -361,6 +366,41 @@ static double obst_theta(const work_t* w, const double* X, const double* sl) {
     return th;
 }
 
+/* ---- via-points: MinTimeViaPointsCost::update (min_time_via_points_cost.cpp:39-117) + findClosestPose (...grid_base_se2.cpp:364-388) */
+static const int32_t* g_nvia = NULL; static const double* g_via = NULL; static int g_vp_cap = 0;
+void oracle_set_via_points(const int32_t* n_via, const double* via, int cap) { g_nvia = n_via; g_via = via; g_vp_cap = cap > 64 ? 64 : cap; }
+static void via_associate(work_t* w) {
+    const int n = w->n;
+    int start = 0;
+    for (int v = 0; v < w->nvia; ++v) {
+        const double vx = w->via[3 * v], vy = w->via[3 * v + 1];
+        double best = 1.7976931348623157e308; int idx = -1;
+        for (int i = start; i < n - 1; ++i) {
+            const double dx = vx - w->X[3 * i], dy = vy - w->X[3 * i + 1], d = sqrt(dx * dx + dy * dy);
+            if (d < best) { best = d; idx = i; }
+        }
+        { const double dx = vx - w->X[3 * (n - 1)], dy = vy - w->X[3 * (n - 1) + 1]; if (sqrt(dx * dx + dy * dy) < best) idx = n - 1; }
+        if (w->c->vp_ordered) start = idx + 2;
+        if (idx > n - 2) idx = n - 2;
+        if (idx < 1) idx = w->c->vp_ordered ? 1 : -1;
+        w->vidx[v] = idx;
+    }
+}
+/* value, gradient wrt (x, y, theta) and count of the via-points attached to grid point k; orientation term linear as coded (:139-142) */
+static int via_terms(const work_t* w, int k, double px, double py, double th, double* val, double g[3]) {
+    int m = 0;
+    *val = 0; g[0] = g[1] = g[2] = 0;
+    for (int v = 0; v < w->nvia; ++v) {
+        if (w->vidx[v] != k) continue;
+        const double dx = px - w->via[3 * v], dy = py - w->via[3 * v + 1];
+        *val += w->c->vp_wp * (dx * dx + dy * dy);
+        g[0] += 2 * w->c->vp_wp * dx; g[1] += 2 * w->c->vp_wp * dy;
+        if (w->c->vp_wo > 0) { *val += w->c->vp_wo * wrap(w->via[3 * v + 2] - th); g[2] -= w->c->vp_wo; }
+        ++m;
+    }
+    return m;
+}
+
 static void eval_point(const work_t* w, const double* X, const double* U, double D, double* cc, double* fobj) {
     const oracle_config* c = w->c;
     int n = w->n;
@@ -371,6 +411,7 @@ static void eval_point(const work_t* w, const double* X, const double* U, double
         cc[3 * k + 0] = sm.val[0] - (X[3 * (k + 1)] - X[3 * k]);
         cc[3 * k + 1] = sm.val[1] - (X[3 * (k + 1) + 1] - X[3 * k + 1]);
         cc[3 * k + 2] = sm.val[2] - wrap(X[3 * (k + 1) + 2] - X[3 * k + 2]);
+        if (c->via && k >= 1) { double vv, vg[3]; via_terms(w, k, X[3 * k], X[3 * k + 1], X[3 * k + 2], &vv, vg); f += vv; }
         if (c->objective == 1) {
             double xd[3] = {X[3 * k] - w->xf[0], X[3 * k + 1] - w->xf[1], wrap(X[3 * k + 2] - w->xf[2])};
             for (int i = 0; i < 3; ++i) f += c->Q[i] * xd[i] * xd[i];
@@ -420,6 +461,7 @@ static void kkt_terms(const work_t* w, const double* cc, err_t* e) {
             for (int i = 0; i < 3; ++i) gx[i] = 2 * c->Q[i] * xd[i];
             gu[0] = 2 * c->R[0] * v; gu[1] = 2 * c->R[1] * om;
         }
+        if (c->via && k >= 1) { double vv, vg[3]; via_terms(w, k, w->X[3 * k], w->X[3 * k + 1], w->X[3 * k + 2], &vv, vg); for (int i = 0; i < 3; ++i) gx[i] += vg[i]; }
         double osx = 0, osy = 0;
         if (k >= 1) for (int m = 0, M = obst_M(w); m < M; ++m) {
             double g, ax, ay, hk;
@@ -535,6 +577,12 @@ static void assemble(work_t* w, const double* cc, double delta, double dc, doubl
             double xd[3] = {w->X[3 * k] - w->xf[0], w->X[3 * k + 1] - w->xf[1], wrap(w->X[3 * k + 2] - w->xf[2])};
             if (k >= 1) for (int i = 0; i < 3; ++i) { band_add(w, ixn(k, i), ixn(k, i), 2 * c->Q[i]); w->rhs[ixn(k, i)] -= 2 * c->Q[i] * xd[i]; }
             for (int j = 0; j < 2; ++j) { band_add(w, iu(k, j), iu(k, j), 2 * c->R[j]); w->rhs[iu(k, j)] -= 2 * c->R[j] * w->U[2 * k + j]; }
+        }
+        if (c->via && k >= 1) {
+            double vv, vg[3];
+            const int m = via_terms(w, k, w->X[3 * k], w->X[3 * k + 1], w->X[3 * k + 2], &vv, vg);
+            for (int i = 0; i < 2; ++i) band_add(w, ixn(k, i), ixn(k, i), 2 * c->vp_wp * m);
+            for (int i = 0; i < 3; ++i) w->rhs[ixn(k, i)] -= vg[i];
         }
         /* control box + regularisation */
         for (int j = 0; j < 2; ++j) {
@@ -672,6 +720,7 @@ static int solve_one(work_t* w, int warm) {
         for (int j = 0; j < 2; ++j) { w->pl[2 * k + j] = w->mu / (w->U[2 * k + j] - c->u_lb[j]); w->pu[2 * k + j] = w->mu / (c->u_ub[j] - w->U[2 * k + j]); }
         for (int i = 0; i < 3; ++i) w->lam[3 * k + i] = 0.0;
     }
+    if (c->via) via_associate(w);
     if (obst_M(w) > 0) {
         const int M = obst_M(w);
         obst_centroids(w);
@@ -767,6 +816,11 @@ static int solve_one(work_t* w, int warm) {
                             else if (c->has_Qf && !c->xf_fixed[a]) { double xd = w->X[3 * (k + 1) + a] - w->xf[a]; if (a == 2) xd = wrap(xd); g = 2 * c->Qf[a] * xd; }
                             hdz += g * dx; dphi += g * dx;
                         }
+                    }
+                    if (c->via && k + 1 < n - 1) {        /* via-point gradient at grid point k+1 */
+                        double vv, vg[3];
+                        via_terms(w, k + 1, w->X[3 * (k + 1)], w->X[3 * (k + 1) + 1], w->X[3 * (k + 1) + 2], &vv, vg);
+                        for (int a = 0; a < 3; ++a) { hdz += vg[a] * w->dz_x[3 * (k + 1) + a]; dphi += vg[a] * w->dz_x[3 * (k + 1) + a]; }
                     }
                 }
                 for (int r = 0; r < n; ++r) for (int q = 0; q < 4; ++q) if (row_on(w, r, q)) {
@@ -938,6 +992,8 @@ int oracle_solve_batch_obst(const oracle_config* c, int B, const double* x0, con
                 w->n_obst = n_obst[b] < (int)O ? n_obst[b] : (int)O;
                 w->n_vert = n_vert + (size_t)b * O; w->verts = verts + (size_t)b * O * V * 2; w->radius = radius ? radius + (size_t)b * O : NULL;
             }
+            w->nvia = 0;
+            if (c->via && g_nvia && g_via) { w->nvia = g_nvia[b] < g_vp_cap ? g_nvia[b] : g_vp_cap; w->via = g_via + (size_t)b * g_vp_cap * 3; }
             int warm = x_init && u_init && dt_init;
             if (warm) {
                 memcpy(w->X, x_init + (size_t)b * n * 3, sizeof(double) * 3 * n);

@@ -564,3 +564,36 @@ def test_costmap_obstacles_feed_the_solve(m):
     d = np.sqrt(((r.x[0, 1:-1, None, :2] - pts[None]) ** 2).sum(-1))
     assert d.min() > 0.2 - 1e-6 and d.min() < 0.2 + 1e-3        # min_obstacle_dist of the config; the block is in the way, so the row binds
     s.close()
+
+
+@pytest.mark.parametrize("ordered", [False, True])
+def test_via_points_batch_vs_c_oracle(m, c_oracle, ordered):
+    """config-2 family (car-like, n=50) with 3 random via-points per instance, B=192: association (incl. skipped / clamped points) and
+    objective terms against oracle/mpc_oracle.c at batch scale."""
+    import copy
+    B, VP, n = 192, 4, 50
+    _, ocfg = _cases(m)["carlike_min_time_n50"]
+    ocfg = copy.deepcopy(ocfg)
+    ocfg.objective, ocfg.vp_position_weight, ocfg.vp_orientation_weight, ocfg.via_points_ordered = 2, 10.5, 0.0, ordered
+    x0, xf, up, dtp = m.workloads.carlike_min_time_inputs(B, seed=777)
+    rng = np.random.default_rng(778)
+    t = rng.uniform(-0.1, 1.1, (B, 3, 1))                         # a few lie before the start / behind the goal
+    if ordered:
+        t = np.sort(t, axis=1)
+    d = (xf[:, None, :2] - x0[:, None, :2])
+    nrm = np.stack([-d[..., 1], d[..., 0]], -1) / np.linalg.norm(d, axis=-1, keepdims=True)
+    via = np.zeros((B, VP, 3))
+    via[:, :3, :2] = x0[:, None, :2] + t * d + rng.uniform(-0.4, 0.4, (B, 3, 1)) * nrm
+    nvia = rng.integers(0, 4, B).astype(np.int32)                # 0..3 via-points
+    s = m.BatchSolver(m.config_carlike_min_time(n, objective=m.OBJ_MIN_TIME_VIA_POINTS, vp_position_weight=10.5, via_points_ordered=ordered,
+                                                max_via_points=VP), max_batch=B)
+    s.set_via_points(nvia, via)
+    r = s.solve(x0, xf, up, dtp)
+    xo, uo, do, st, it = c_oracle.solve_batch(c_oracle.from_nlp_config(ocfg), x0, xf, up, dtp, via=(nvia, via))
+    both = (r.status == 0) & (st == 0)
+    assert both.mean() > 0.75 and (r.status == st).mean() > 0.9
+    err = np.maximum(np.abs(r.x - xo).reshape(B, -1).max(1), np.abs(r.u - uo).reshape(B, -1).max(1))
+    # same algorithm and association; the via-point problems are flat around the solution, so a flipped line-search tie shows up as ~1e-4
+    assert np.median(err[both]) < 1e-7 and (err[both] < 1e-3).mean() > 0.9
+    assert (np.abs(r.iters - it)[both] <= 2).mean() > 0.8
+    s.close()

@@ -259,3 +259,16 @@ def test_costmap_oracle_order_and_filter():
     pts = OC.costmap_to_obstacles(cost, 1.0, (10.0, 20.0), (12.0, 21.0, 0.0), behind_robot_dist=1.0)
     np.testing.assert_array_equal(pts, [[11.5, 20.5], [13.5, 21.5]])
     assert OC.costmap_to_obstacles(np.full((1, 1), 254, np.uint8), 1.0, (0, 0), (0, 0, 0)).shape == (0, 2)
+
+
+@pytest.mark.parametrize("name", ["carlike_via_points_n30", "carlike_via_points_ordered_n30"])
+def test_c_oracle_via_points_match_numpy_goldens(name, c_oracle):
+    """oracle/mpc_oracle.c restates the via-point association and objective terms independently of ipm_dense.py."""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    cfg = R.config_carlike_min_time(30)
+    cfg.objective, cfg.vp_position_weight, cfg.vp_orientation_weight = R.OBJ_MIN_TIME_VIA_POINTS, float(g["wp"]), float(g["wo"])
+    cfg.via_points_ordered = bool(g["ordered"])
+    xo, uo, do, st, it = c_oracle.solve_batch(c_oracle.from_nlp_config(cfg), g["x0"], g["xf"], g["u_prev"], g["dt_prev"], via=(g["n_via"], g["via"]))
+    assert (st == 0).all()
+    assert np.abs(xo - g["x"]).max() < 1e-6 and np.abs(uo - g["u"]).max() < 1e-6 and np.abs(do - g["dt"]).max() < 1e-8
+    assert np.abs(it - g["iters"]).max() <= 2
