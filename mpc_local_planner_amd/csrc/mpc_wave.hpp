@@ -29,8 +29,8 @@ __device__ long long g_mpc_prof[4096][16];
 namespace mpc {
 
 constexpr int kWave = 64;
-// per-stage LQ record: 0..2 a0 a1 1 | 3..5 f | 6..8 Bx[:,0] | 9..11 Bx[:,1] | 12..38 combined stage cost A[StageAdd]
-constexpr int NSTG = 39;
+// per-stage LQ record: 0..2 a0 a1 1 | 3..5 f | 6..8 Bx[:,0] | 9..11 Bx[:,1] | 12..40 combined stage cost A[StageAdd]
+constexpr int NSTG = 41;
 constexpr int RA = 12;     // first A slot (words 0..11: a0 a1 1 | f | Bx[:,0] | Bx[:,1])
 constexpr int NGAIN = 20;  // negated gains: nK0(6) nkappa0 nKnu0(3) | nK1(6) nkappa1 nKnu1(3)
 
@@ -41,8 +41,9 @@ struct WaveLayout {
     int M, O, V;                                  // clearance rows per grid point, obstacles, vertices per obstacle
     int OS, OY, OI, OG, OAX, OAY, OHK;            // per-row slack, multiplier, obstacle index, cached g, gradient, curvature
     int GV, GNV, GR, GC;                          // obstacle geometry: vertices, vertex counts, radii, centroids
+    int OAT, OHXT, OHYT, OHTT;                    // heading parts of the clearance rows (line footprint only: MT = M, else 0 words)
     int NV, VIA, VIDX;                            // via-points: capacity, poses (x, y, theta), attached grid point (-1 = skipped)
-    __host__ __device__ static WaveLayout make(int n, int M = 0, int O = 0, int V = 1, int ntrig = 4, int NV = 0) {
+    __host__ __device__ static WaveLayout make(int n, int M = 0, int O = 0, int V = 1, int ntrig = 4, int NV = 0, int MT = 0) {
         WaveLayout L;
         L.n = n;
         L.NS = n;
@@ -63,6 +64,7 @@ struct WaveLayout {
         L.OS = take(M); L.OY = take(M); L.OI = take(M); L.OG = take(M); L.OAX = take(M); L.OAY = take(M); L.OHK = take(M);
         L.GV = o; o += 2 * O * V; L.GNV = o; o += O; L.GR = o; o += O; L.GC = o; o += 2 * O;
         L.NV = NV; L.VIA = o; o += 3 * NV; L.VIDX = o; o += NV;
+        L.OAT = take(MT); L.OHXT = take(MT); L.OHYT = take(MT); L.OHTT = take(MT);
         L.total = o;
         return L;
     }
@@ -77,8 +79,8 @@ constexpr int stage_add_slot(int r, int c) {
     if (c == 8) return A08 + r;
     if (c > 8) return -1;
     const int a = r < c ? r : c, b = r < c ? c : r;
-    if (a == 0) return b == 0 ? A00 : (b == 1 ? A01 : -1);
-    if (a == 1) return b == 1 ? A11 : -1;
+    if (a == 0) return b == 0 ? A00 : (b == 1 ? A01 : (b == 2 ? A02 : -1));
+    if (a == 1) return b == 1 ? A11 : (b == 2 ? A12 : -1);
     if (a == 2) return b == 2 ? A22 : (b == 5 ? A25 : (b == 6 ? A26 : (b == 7 ? A27 : -1)));
     if (a == 3) return b == 3 ? A33 : (b == 5 ? A35 : (b == 6 ? A36 : -1));
     if (a == 4) return b == 4 ? A44 : (b == 5 ? A45 : (b == 7 ? A47 : -1));
@@ -154,7 +156,7 @@ struct IpmWave {
     bool warm_guess = false;     // the caller supplied an initial guess (second and later control cycles)
     mutable int cnt_mult = -1, cnt_bmult = -1;      // number of equality / bound multipliers (cached by kkt_pass)
     int nvia = 0;   // via-points of this instance
-    int flags;      // bits 0..2 xf_fixed, 3 dt_free, 4 quadratic objective, 5 has_Qf, 6..9 rate_on, 10 terminal ball, 11 via-points: the problem record lives in LDS and every
+    int flags;      // bits 0..2 xf_fixed, 3 dt_free, 4 quadratic objective, 5 has_Qf, 6..9 rate_on, 10 terminal ball, 11 via-points, 12 line footprint: the problem record lives in LDS and every
                     // P.x costs a ds_read (+ wait) that the compiler cannot hoist over LDS stores; one scalar register holds the switches
 #ifdef MPC_PROFILE
     mutable long long prof_loop = 0, prof_setup = 0, prof_fwd_loop = 0;    // ticks inside the backward stage loop / before it / inside the forward loop
@@ -180,6 +182,7 @@ struct IpmWave {
     __device__ __forceinline__ bool ron(int q) const { return (flags >> (6 + q)) & 1; }
     __device__ __forceinline__ bool ball() const { return EXT && ((flags >> 10) & 1); }
     __device__ __forceinline__ bool via() const { return EXT && ((flags >> 11) & 1); }
+    __device__ __forceinline__ bool fpline() const { return EXT && ((flags >> 12) & 1); }
     // explicit LDS pointers for the running-pointer loops (address-space inference gives up on per-lane selected pointers)
     typedef __attribute__((address_space(3))) T LdsT;
     __device__ __forceinline__ LdsT* lds(int word) const { return (LdsT*)sm + word; }
@@ -386,8 +389,8 @@ struct IpmWave {
                 for (int j = 0; j < L.O; ++j) {
                     if ((int)sm[L.GNV + j] <= 0) continue;
                     T dist, nx, ny, hk;
-                    obst_eval(px, py, j, dist, nx, ny, hk);
-                    dist -= P.fp_radius;
+                    if (fpline()) { T a3[3], h3[3]; dist = line_eval(px, py, th, j, a3, hk, h3); }
+                    else { obst_eval(px, py, j, dist, nx, ny, hk); dist -= P.fp_radius; }
                     if (dist < P.force_incl) { if (cnt < M) { F(L.OI, cnt, k) = T(j); ++cnt; } continue; }
                     if (dist > P.cutoff) continue;
                     // cross2d(orientation, centroid) with the centroid as an ABSOLUTE vector (:121)
@@ -400,6 +403,34 @@ struct IpmWave {
         }
     }
 
+    // teb LineRobotFootprint::calculateDistance for a point / circular obstacle j: distance of the obstacle centre to the footprint
+    // segment, evaluated in the ROBOT frame q = R(-theta)(p_o - p) where the segment is fixed.  Returns the distance, the row gradient
+    // a = d g / d(x, y, theta) of g = d_min - dist, hk (the (x,y) block of hess g is -hk (I - a_xy a_xy'), |a_xy| = 1) and the heading
+    // parts h3 = hess g [x theta, y theta, theta theta].
+    __device__ __forceinline__ T line_eval(T px, T py, T th, int j, T a[3], T& hk, T h3[3]) const {
+        const T* v = sm + L.GV + 2 * L.V * j;
+        T s, c;
+        t_sincos(th, &s, &c);
+        const T vx = v[0] - px, vy = v[1] - py;
+        const T qx = c * vx + s * vy, qy = c * vy - s * vx;
+        const T a0 = P.fp_line[0], a1 = P.fp_line[1], abx = P.fp_line[2] - a0, aby = P.fp_line[3] - a1;
+        const T sq = abx * abx + aby * aby;
+        T t = sq > T(0) ? ((qx - a0) * abx + (qy - a1) * aby) / sq : T(0);
+        t = t_min(T(1), t_max(T(0), t));
+        const T dx = qx - (a0 + t * abx), dy = qy - (a1 + t * aby);
+        const T D = sqrt(dx * dx + dy * dy);
+        T nx = T(0), ny = T(0);
+        hk = T(0);
+        if (D > T(0)) { nx = dx / D; ny = dy / D; hk = (t > T(0) && t < T(1)) ? T(0) : T(1) / D; }
+        const T nw = nx * qy - ny * qx;                                   // n' dq/dtheta,  dq/dtheta = (qy, -qx)
+        a[0] = c * nx - s * ny; a[1] = s * nx + c * ny; a[2] = -nw;        // -(Jq' n)
+        const T hwx = hk * (qy - nx * nw), hwy = hk * (-qx - ny * nw);    // H_D dq/dtheta,  H_D = hk (I - n n')
+        h3[0] = -((s * hwy - c * hwx) + (nx * s + ny * c));
+        h3[1] = -((-s * hwx - c * hwy) + (ny * s - nx * c));
+        h3[2] = -((qy * hwx - qx * hwy) - (nx * qx + ny * qy));
+        return D - sm[L.GR + j];
+    }
+
     // value / gradient / curvature cache of the clearance rows of grid point k at position (px,py); returns row count
     __device__ __forceinline__ bool obst_row(int k, int m, T px, T py, T& g, T& ax, T& ay, T& hk) const {
         const int j = (int)F(L.OI, m, k);
@@ -409,6 +440,20 @@ struct IpmWave {
         g = P.d_min - (dist - P.fp_radius);
         ax = -nx; ay = -ny;
         return true;
+    }
+    // same for a footprint that turns with the pose (line): adds the heading gradient and the heading parts of the Hessian
+    __device__ __forceinline__ bool obst_row3(int k, int m, T px, T py, T th, T& g, T a[3], T& hk, T h3[3]) const {
+        if (!fpline()) { a[2] = T(0); h3[0] = h3[1] = h3[2] = T(0); return obst_row(k, m, px, py, g, a[0], a[1], hk); }
+        const int j = (int)F(L.OI, m, k);
+        if (j < 0) return false;
+        g = P.d_min - line_eval(px, py, th, j, a, hk, h3);
+        return true;
+    }
+    // a' dz of row (k, m) from the cached gradient
+    __device__ __forceinline__ T obst_jdz(int k, int m) const {
+        T j = F(L.OAX, m, k) * F(L.DX, 0, k) + F(L.OAY, m, k) * F(L.DX, 1, k);
+        if (fpline()) j += F(L.OAT, m, k) * F(L.DX, 2, k);
+        return j;
     }
 
     // ---------------------------------------------------------------- point evaluation (parallel)
@@ -421,15 +466,12 @@ struct IpmWave {
         if (L.M > 0) {
             for (int k = lane; k < n - 1; k += kWave) {
                 if (k < 1) continue;
-                const T px = xt(0, k, al), py = xt(1, k, al);
+                const T px = xt(0, k, al), py = xt(1, k, al), pth = fpline() ? xt(2, k, al) : T(0);
                 for (int m = 0; m < L.M; ++m) {
-                    T g, ax, ay, hk;
-                    if (!obst_row(k, m, px, py, g, ax, ay, hk)) continue;
+                    T g, a3[3], hk, h3[3];
+                    if (!obst_row3(k, m, px, py, pth, g, a3, hk, h3)) continue;
                     T s = F(L.OS, m, k);
-                    if (trial) {
-                        const T jdz = F(L.OAX, m, k) * F(L.DX, 0, k) + F(L.OAY, m, k) * F(L.DX, 1, k);
-                        s += alpha * (-(F(L.OG, m, k) + s) - jdz);
-                    }
+                    if (trial) s += alpha * (-(F(L.OG, m, k) + s) - obst_jdz(k, m));
                     th += t_abs(g + s);
                 }
             }
@@ -487,10 +529,7 @@ struct IpmWave {
                 for (int m = 0; m < L.M; ++m) {
                     if (F(L.OI, m, k) < T(0)) continue;
                     T s = F(L.OS, m, k);
-                    if (trial) {
-                        const T jdz = F(L.OAX, m, k) * F(L.DX, 0, k) + F(L.OAY, m, k) * F(L.DX, 1, k);
-                        s += alpha * (-(F(L.OG, m, k) + s) - jdz);
-                    }
+                    if (trial) s += alpha * (-(F(L.OG, m, k) + s) - obst_jdz(k, m));
                     acc.mul(s);
                 }
             }
@@ -630,25 +669,27 @@ struct IpmWave {
                     gu[0] = T(2) * P.R[0] * v; gu[1] = T(2) * P.R[1] * w;
                 }
                 if (via()) { T vv; via_terms(k, F(L.X, 0, k), F(L.X, 1, k), F(L.X, 2, k), vv, gx); }
-                T osx = T(0), osy = T(0);
+                T osx = T(0), osy = T(0), ost = T(0);
                 if (L.M > 0 && k >= 1) {
                     const T px = F(L.X, 0, k), py = F(L.X, 1, k);
                     for (int m = 0; m < L.M; ++m) {
-                        T g, ax, ay, hk;
-                        if (!obst_row(k, m, px, py, g, ax, ay, hk)) continue;
+                        T g, a3[3], hk, h3[3];
+                        if (!obst_row3(k, m, px, py, F(L.X, 2, k), g, a3, hk, h3)) continue;
+                        const T ax = a3[0], ay = a3[1];
                         F(L.OG, m, k) = g; F(L.OAX, m, k) = ax; F(L.OAY, m, k) = ay; F(L.OHK, m, k) = hk;
+                        if (fpline()) { F(L.OAT, m, k) = a3[2]; F(L.OHXT, m, k) = h3[0]; F(L.OHYT, m, k) = h3[1]; F(L.OHTT, m, k) = h3[2]; }
                         const T s = F(L.OS, m, k), y = F(L.OY, m, k);
                         const T res = g + s;
                         rp = t_max(rp, t_abs(res)); th += t_abs(res);
                         cmin = t_min(cmin, s * y); cmax = t_max(cmax, s * y);
                         sb += y; nb += 1;
-                        osx += y * ax; osy += y * ay;
+                        osx += y * ax; osy += y * ay; ost += y * a3[2];
                     }
                 }
                 if (k >= 1) {
                     T r0 = gx[0] + osx + lam[0] - F(L.LAM, 0, k - 1);
                     T r1 = gx[1] + osy + lam[1] - F(L.LAM, 1, k - 1);
-                    T r2 = gx[2] + lam[2] + gJ[0] - F(L.LAM, 2, k - 1);
+                    T r2 = gx[2] + ost + lam[2] + gJ[0] - F(L.LAM, 2, k - 1);
                     rd = t_max(rd, t_max(t_abs(r0), t_max(t_abs(r1), t_abs(r2))));
                 }
                 for (int j = 0; j < 2; ++j) {
@@ -786,6 +827,13 @@ struct IpmWave {
                     sp.oxy += sig * ax * ay + y * hk * ax * ay;
                     sp.oyy += sig * ay * ay - y * hk * (T(1) - ay * ay);
                     sp.ogx += ax * ybar; sp.ogy += ay * ybar;
+                    if (fpline()) {
+                        const T at = F(L.OAT, m, k);
+                        sp.oxt += sig * ax * at + y * F(L.OHXT, m, k);
+                        sp.oyt += sig * ay * at + y * F(L.OHYT, m, k);
+                        sp.ott += sig * at * at + y * F(L.OHTT, m, k);
+                        sp.ogt += at * ybar;
+                    }
                 }
             }
             if (via() && k >= 1 && k < n - 1) {
@@ -1169,6 +1217,10 @@ struct IpmWave {
                 t0 = delta * dx0 + S_(RA + A00, m) * dx0 + S_(RA + A01, m) * dx1 + S_(RA + A08, m);
                 t1 = delta * dx1 + S_(RA + A01, m) * dx0 + S_(RA + A11, m) * dx1 + S_(RA + A18, m);
                 t2 = delta * dx2 + S_(RA + A22, m) * dx2 + S_(RA + A26, m) * duv + S_(RA + A27, m) * duw + S_(RA + A25, m) * dd + S_(RA + A28, m);
+                if (fpline()) {        // position-heading coupling of the clearance rows
+                    const T c02 = S_(RA + A02, m), c12 = S_(RA + A12, m);
+                    t0 += c02 * dx2; t1 += c12 * dx2; t2 += c02 * dx0 + c12 * dx1;
+                }
                 a0 = S_(0, m); a1 = S_(1, m);
             }
             const T s0 = wave_suffix_sum(t0) + carry[0];     // sum_{m' >= m} t_m'[0]
@@ -1273,7 +1325,7 @@ struct IpmWave {
             if (L.M > 0 && k >= 1 && k < n - 1) {
                 for (int m = 0; m < L.M; ++m) {
                     if (F(L.OI, m, k) < T(0)) continue;
-                    const T jdz = F(L.OAX, m, k) * F(L.DX, 0, k) + F(L.OAY, m, k) * F(L.DX, 1, k);
+                    const T jdz = obst_jdz(k, m);
                     const T s = F(L.OS, m, k), y = F(L.OY, m, k);
                     const T res = F(L.OG, m, k) + s;
                     const T sig = y / s;
@@ -1325,7 +1377,7 @@ struct IpmWave {
             if (L.M > 0 && k >= 1 && k < n - 1) {
                 for (int m = 0; m < L.M; ++m) {
                     if (F(L.OI, m, k) < T(0)) continue;
-                    const T jdz = F(L.OAX, m, k) * F(L.DX, 0, k) + F(L.OAY, m, k) * F(L.DX, 1, k);
+                    const T jdz = obst_jdz(k, m);
                     const T s = F(L.OS, m, k), y = F(L.OY, m, k);
                     const T res = F(L.OG, m, k) + s;
                     const T sig = y / s;
@@ -1455,9 +1507,9 @@ struct IpmWave {
             if (L.M > 0) {
                 const T px = F(L.X, 0, k), py = F(L.X, 1, k);
                 for (int m = 0; m < L.M; ++m) {
-                    T s = T(1), y = T(0), g, ax, ay, hk;
+                    T s = T(1), y = T(0), g, a3[3], hk, h3[3];
                     if (k >= 1 && k < n - 1) {
-                        if (obst_row(k, m, px, py, g, ax, ay, hk)) { s = t_max(-g, Algo<T>::slack_push); y = mu / s; }
+                        if (obst_row3(k, m, px, py, F(L.X, 2, k), g, a3, hk, h3)) { s = t_max(-g, Algo<T>::slack_push); y = mu / s; }
                     } else F(L.OI, m, k) = T(-1);
                     F(L.OS, m, k) = s; F(L.OY, m, k) = y;
                 }
@@ -1487,7 +1539,7 @@ struct IpmWave {
     __device__ __forceinline__ SolveStats<T> solve() {
         SolveStats<T> out;
         flags = (P.xf_fixed[0] ? 1 : 0) | (P.xf_fixed[1] ? 2 : 0) | (P.xf_fixed[2] ? 4 : 0) | (P.dt_free ? 8 : 0) | (P.objective == OBJ_QUADRATIC ? 16 : 0) |
-                (P.has_Qf ? 32 : 0) | (P.rate_on[0] ? 64 : 0) | (P.rate_on[1] ? 128 : 0) | (P.rate_on[2] ? 256 : 0) | (P.rate_on[3] ? 512 : 0) | (P.ball ? 1024 : 0) | (P.via ? 2048 : 0);
+                (P.has_Qf ? 32 : 0) | (P.rate_on[0] ? 64 : 0) | (P.rate_on[1] ? 128 : 0) | (P.rate_on[2] ? 256 : 0) | (P.rate_on[3] ? 512 : 0) | (P.ball ? 1024 : 0) | (P.via ? 2048 : 0) | ((P.n_obst > 0 && P.footprint_kind == 2) ? 4096 : 0);
         flags = __builtin_amdgcn_readfirstlane(flags);
         nfix = (int)fx(0) + (int)fx(1) + (int)fx(2);
         row0_on = dtprev != T(0);

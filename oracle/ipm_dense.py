@@ -215,7 +215,34 @@ def clearance_row(cfg: R.OcpConfig, xk, ob: R.Obstacle, want_hess=True):
             if not interior:
                 Hm[:2, :2] = -(np.eye(2) - np.outer(nrm, nrm)) / d
         return val, g, Hm
-    # numeric (line / two-circle footprints)
+    if cfg.footprint_kind == R.FOOTPRINT_LINE and (ob.kind in (R.OBST_POINT, R.OBST_CIRCLE) or len(np.asarray(ob.vertices)) == 1):
+        # teb LineRobotFootprint::calculateDistance with a point / circular obstacle = distance of the obstacle centre to the footprint
+        # segment; evaluated in the ROBOT frame, q = R(-theta)(p_o - p), where the segment [a, b] is fixed: analytic chain rule
+        sx, sy, ex, ey = cfg.footprint_params
+        a = np.array([sx, sy]); ab = np.array([ex - sx, ey - sy])
+        th = float(xk[2]); c, s = math.cos(th), math.sin(th)
+        v = np.asarray(ob.vertices, float).reshape(-1, 2)[0] - np.asarray(xk[:2], float)
+        q = np.array([c * v[0] + s * v[1], -s * v[0] + c * v[1]])
+        sq = float(ab @ ab)
+        t = float((q - a) @ ab) / sq if sq > 0 else 0.0
+        t = min(1.0, max(0.0, t))
+        dvec = q - (a + t * ab)
+        d = float(np.linalg.norm(dvec))
+        rad = ob.radius if ob.kind == R.OBST_CIRCLE else 0.0
+        val = cfg.min_obstacle_dist - (d - rad)
+        g = np.zeros(3); Hm = np.zeros((3, 3))
+        if d > 0:
+            nrm = dvec / d
+            hk = 0.0 if 0.0 < t < 1.0 else 1.0 / d
+            Jq = np.array([[-c, -s, q[1]], [s, -c, -q[0]]])                 # d q / d (x, y, theta)
+            gd = Jq.T @ nrm
+            Hd = Jq.T @ (hk * (np.eye(2) - np.outer(nrm, nrm))) @ Jq
+            Hd[0, 2] += nrm[0] * s + nrm[1] * c; Hd[2, 0] = Hd[0, 2]        # n' d2q/dx dtheta
+            Hd[1, 2] += -nrm[0] * c + nrm[1] * s; Hd[2, 1] = Hd[1, 2]
+            Hd[2, 2] += -(nrm @ q)
+            g, Hm = -gd, -Hd
+        return val, g, Hm
+    # numeric (two-circle footprints, line footprint with line / polygon obstacles)
     def fun(x):
         return cfg.min_obstacle_dist - R.footprint_distance(cfg.footprint_kind, cfg.footprint_params, x, ob)
     h = 1e-6

@@ -65,7 +65,7 @@ def make_obstacles(name, n=30, B=10, O=6, V=6, M=4, keep=6):
     print(name, "kept", len(sel), "iters", IT)
 
 
-if __name__ == "__main__" and "--warm" not in sys.argv and "--integral" not in sys.argv and "--closed-loop" not in sys.argv and "--config3" not in sys.argv and "--midpoint" not in sys.argv and "--cn" not in sys.argv and "--ball" not in sys.argv and "--via" not in sys.argv:
+if __name__ == "__main__" and "--warm" not in sys.argv and "--integral" not in sys.argv and "--closed-loop" not in sys.argv and "--config3" not in sys.argv and "--midpoint" not in sys.argv and "--cn" not in sys.argv and "--ball" not in sys.argv and "--via" not in sys.argv and "--line" not in sys.argv:
     make_obstacles("unicycle_quadratic_obstacles_n30")
     make("carlike_min_time_n50", R.config_carlike_min_time(50), W.carlike_min_time_inputs(32, seed=101), keep=8)
     make("carlike_min_time_n20", R.config_carlike_min_time(20), W.carlike_min_time_inputs(32, seed=102, goal_range=(1.0, 2.5)), keep=8)
@@ -297,3 +297,47 @@ def make_via(name, ordered, wo, nvp, near_start, n=30, B=24, keep=6, VP=4):
 if __name__ == "__main__" and "--via" in sys.argv:
     make_via("carlike_via_points_n30", ordered=False, wo=0.0, nvp=2, near_start=False)
     make_via("carlike_via_points_ordered_n30", ordered=True, wo=0.05, nvp=3, near_start=True)
+
+
+LINE_FP = (0.0, 0.0, 0.4, 0.0)        # carlike example: footprint_model line_start / line_end (cfg/carlike/mpc_local_planner_params.yaml:20-23)
+
+
+def line_footprint_inputs(B, seed, n_obst=4):
+    """car-like inputs of config 2 + point obstacles beside the straight line start -> goal (what the costmap yields), 0.3 .. 0.9 m off."""
+    x0, xf, up, dtp = W.carlike_min_time_inputs(B, seed=seed, goal_range=(2.0, 4.0))
+    rng = np.random.default_rng(seed + 1)
+    d = xf[:, None, :2] - x0[:, None, :2]
+    nrm = np.stack([-d[..., 1], d[..., 0]], -1) / np.linalg.norm(d, axis=-1, keepdims=True)
+    fr = rng.uniform(0.2, 0.8, (B, n_obst, 1))
+    off = rng.uniform(0.3, 0.9, (B, n_obst, 1)) * rng.choice([-1.0, 1.0], (B, n_obst, 1))
+    pts = x0[:, None, :2] + fr * d + off * nrm
+    return x0, xf, up, dtp, pts
+
+
+def make_line_footprint(name, n=30, B=16, keep=6, M=4):
+    """a21 with the car-like example's LINE footprint (teb LineRobotFootprint) against point obstacles: clearance rows that depend on the
+    heading (gradient and Hessian couple position and heading)."""
+    cfg = R.config_carlike_min_time(n)
+    cfg.footprint_kind, cfg.footprint_params = R.FOOTPRINT_LINE, LINE_FP
+    cfg.min_obstacle_dist, cfg.force_inclusion_dist, cfg.cutoff_dist = 0.27, 0.5, 2.5
+    x0, xf, up, dtp, pts = line_footprint_inputs(B, 151)
+    rows = []
+    for i in range(B):
+        if len(rows) >= keep:
+            break
+        obs = [R.Obstacle(R.OBST_POINT, pts[i, o:o + 1]) for o in range(pts.shape[1])]
+        inp = R.CycleInputs(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=float(dtp[i]), obstacles=obs)
+        init = R.cold_start(cfg, x0[i], xf[i])
+        rel, _ = R.associate_obstacles(cfg, init, obs, max_rows=M)
+        ref = I.solve(cfg, inp, init, relevant=rel, opt=I.IpmOptions(globalization="merit", max_iter=100))
+        if ref.status != 0 or ref.iters > 60:
+            continue
+        dmin = min(R.footprint_distance(cfg.footprint_kind, cfg.footprint_params, ref.traj.x[k], ob) for k in range(1, n - 1) for ob in obs)
+        rows.append(dict(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=dtp[i], pts=pts[i], x=ref.traj.x, u=np.vstack([ref.traj.u, ref.traj.u[-1:]]),
+                         dt=ref.traj.dt, iters=ref.iters, dmin=dmin))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), line=np.array(LINE_FP), max_rows=M, **{k: np.array([r[k] for r in rows]) for k in rows[0]})
+    print(name, "kept", len(rows), "iters", [r["iters"] for r in rows], "min footprint distance", [round(float(r["dmin"]), 4) for r in rows])
+
+
+if __name__ == "__main__" and "--line" in sys.argv:
+    make_line_footprint("carlike_line_footprint_n30")

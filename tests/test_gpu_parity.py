@@ -597,3 +597,29 @@ def test_via_points_batch_vs_c_oracle(m, c_oracle, ordered):
     assert np.median(err[both]) < 1e-7 and (err[both] < 1e-3).mean() > 0.9
     assert (np.abs(r.iters - it)[both] <= 2).mean() > 0.8
     s.close()
+
+
+def test_line_footprint_golden(m):
+    """a21 with teb's LineRobotFootprint (the car-like example's footprint, cfg/carlike/mpc_local_planner_params.yaml:19-23) against point
+    obstacles: the clearance rows depend on the heading (position-heading coupling in gradient and Hessian, A-form slots A02/A12).
+    Fixture: tests/golden/make_golden.py --line (numpy oracle, analytic row derivatives checked against differences); half of the
+    instances end with a binding row."""
+    from oracle import se2_nlp as R
+    g = np.load(os.path.join(GOLD, "carlike_line_footprint_n30.npz"))
+    B, O = g["pts"].shape[0], g["pts"].shape[1]
+    cfg = m.config_carlike_min_time(30, footprint_kind=2, footprint_line=tuple(g["line"]), min_obstacle_dist=0.27, force_inclusion_dist=0.5,
+                                    cutoff_dist=2.5, max_obstacles=O, max_vertices=1, max_obstacle_rows=int(g["max_rows"]))
+    s = m.BatchSolver(cfg, max_batch=B)
+    no = np.full(B, O, np.int32); nv = np.ones((B, O), np.int32); vt = g["pts"].reshape(B, O, 1, 2)
+    r = s.solve(g["x0"], g["xf"], g["u_prev"], g["dt_prev"], obstacles=(no, nv, vt))
+    assert (r.status == 0).all()
+    err = np.maximum(np.abs(r.x - g["x"]).reshape(B, -1).max(1), np.abs(r.u - g["u"]).reshape(B, -1).max(1))
+    same = r.iters == g["iters"]
+    assert same.sum() >= B - 1 and (err[same] < 1e-6).all() and (err < 1e-5).all()      # one more / one less iteration stops ~1e-6 away
+    assert np.abs(r.dt - g["dt"]).max() < 1e-6
+    assert (np.abs(r.iters - g["iters"]) <= np.maximum(2, 0.1 * g["iters"])).all()
+    for i in range(B):                       # clearance of the FOOTPRINT (not of the reference point) in the reference's own distance function
+        obs = [R.Obstacle(R.OBST_POINT, g["pts"][i, o:o + 1]) for o in range(O)]
+        dmin = min(R.footprint_distance(R.FOOTPRINT_LINE, tuple(g["line"]), r.x[i, k], ob) for k in range(1, 29) for ob in obs)
+        assert dmin > 0.27 - 1e-6
+    s.close()
