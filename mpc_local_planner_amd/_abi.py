@@ -77,7 +77,7 @@ class MpcConfig(C.Structure):
         ("vp_orientation_weight", C.c_double),
         ("via_points_ordered", C.c_int32),
         ("max_via_points", C.c_int32),
-        ("footprint_line", C.c_double * 4),
+        ("footprint_params", C.c_double * 4),
         ("reserved", C.c_int32 * 6),
     ]
 
@@ -98,7 +98,7 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
                 mu_init=0.1, precision=FP64, min_obstacle_dist=0.5, force_inclusion_dist=0.5, cutoff_dist=2.0,
                 footprint_kind=0, footprint_radius=0.0, max_obstacles=0, max_vertices=1, max_obstacle_rows=4, mu_init_warm=0.0, collocation=COLLOC_FORWARD,
                 terminal_ball_S=None, terminal_ball_gamma=1.0, vp_position_weight=1e-3, vp_orientation_weight=0.0,
-                via_points_ordered=False, max_via_points=0, footprint_line=(0.0, 0.0, 0.0, 0.0)) -> MpcConfig:
+                via_points_ordered=False, max_via_points=0, footprint_params=(0.0, 0.0, 0.0, 0.0)) -> MpcConfig:
     c = MpcConfig()
     c.model = model
     mp = list(model_params) + [0.0] * 4
@@ -135,7 +135,7 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
     c.vp_position_weight, c.vp_orientation_weight = vp_position_weight, vp_orientation_weight
     c.via_points_ordered, c.max_via_points = int(bool(via_points_ordered)), max_via_points
     for i in range(4):
-        c.footprint_line[i] = footprint_line[i]
+        c.footprint_params[i] = footprint_params[i]
     return c
 
 

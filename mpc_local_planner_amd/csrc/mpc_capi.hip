@@ -235,9 +235,10 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
     if (!(cfg->dt_ref > 0)) { set_err("mpc_create: dt_ref must be > 0"); return MPC_EINVAL; }
     if (cfg->max_obstacles < 0 || cfg->max_obstacles > 4096 || (cfg->max_obstacles > 0 && (cfg->max_vertices < 1 || cfg->max_vertices > 64)) || cfg->max_obstacle_rows > 16) {
         set_err("mpc_create: obstacle capacities out of range (max_obstacles <= 4096, max_vertices <= 64, max_obstacle_rows <= 16)"); return MPC_EINVAL; }
-    if (cfg->max_obstacles > 0 && cfg->footprint_kind != MPC_FOOTPRINT_POINT && cfg->footprint_kind != MPC_FOOTPRINT_CIRCLE && cfg->footprint_kind != MPC_FOOTPRINT_LINE) {
-        set_err("mpc_create: only point, circular and line footprints are implemented"); return MPC_EINVAL; }
-    if (cfg->max_obstacles > 0 && cfg->footprint_kind == MPC_FOOTPRINT_LINE && cfg->max_vertices != 1) {
+    if (cfg->max_obstacles > 0 && cfg->footprint_kind != MPC_FOOTPRINT_POINT && cfg->footprint_kind != MPC_FOOTPRINT_CIRCLE && cfg->footprint_kind != MPC_FOOTPRINT_LINE &&
+        cfg->footprint_kind != MPC_FOOTPRINT_TWO_CIRCLES) {
+        set_err("mpc_create: only point, circular, line and two-circle footprints are implemented"); return MPC_EINVAL; }
+    if (cfg->max_obstacles > 0 && cfg->footprint_kind == MPC_FOOTPRINT_LINE && cfg->max_vertices > 1) {
         set_err("mpc_create: the line footprint is implemented for point and circular obstacles (max_vertices = 1)"); return MPC_EINVAL; }
     if (cfg->integral_form && cfg->dt_free) { set_err("mpc_create: integral_form costs are implemented for the fixed-dt grid only (dt_free = 0)"); return MPC_EINVAL; }
     for (int j = 0; j < 2; ++j)
@@ -263,7 +264,7 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         const int ntrig = ((cfg->model == MPC_MODEL_KINEMATIC_BICYCLE || cfg->model == MPC_MODEL_SIMPLE_CAR_FRONT) ? 4 : 3) +
                           (cfg->collocation == MPC_COLLOC_CRANK_NICOLSON ? 2 : 0);
         s->WL = mpc::WaveLayout::make(cfg->n, M, O, cfg->max_vertices > 0 ? cfg->max_vertices : 1, ntrig, s->P64.n_via,
-                                        (O > 0 && cfg->footprint_kind == MPC_FOOTPRINT_LINE) ? M : 0);
+                                        (O > 0 && (cfg->footprint_kind == MPC_FOOTPRINT_LINE || cfg->footprint_kind == MPC_FOOTPRINT_TWO_CIRCLES)) ? M : 0);
     }
     s->wave_lds = ((((size_t)s->WL.total * (cfg->precision == MPC_FP32 ? 4 : 8)) + 15) & ~(size_t)15) + 16 +
                   ((cfg->precision == MPC_FP32 ? sizeof(mpc::Problem<float>) : sizeof(mpc::Problem<double>)) + 15 & ~(size_t)15) + sizeof(mpc::WaveLayout);
@@ -351,7 +352,7 @@ static hipError_t launch_model(mpc_solver* s, const mpc::Problem<T>& P, int B, c
                                const double* dtp, const double* xi, const double* ui, const double* dti, const mpc_obstacles& ob, double* xo, double* uo,
                                double* dto, int32_t* st, int32_t* it) {
     if (s->use_wave) {
-        const bool ext = P.ball || P.via || (P.n_obst > 0 && P.footprint_kind == MPC_FOOTPRINT_LINE);
+        const bool ext = P.ball || P.via || (P.n_obst > 0 && (P.footprint_kind == MPC_FOOTPRINT_LINE || P.footprint_kind == MPC_FOOTPRINT_TWO_CIRCLES));
         auto kern = ext ? mpc_ipm_wave_kernel<T, MODEL, true> : mpc_ipm_wave_kernel<T, MODEL, false>;
         if (s->wave_lds > 48u * 1024u) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->wave_lds);

@@ -156,7 +156,7 @@ struct IpmWave {
     bool warm_guess = false;     // the caller supplied an initial guess (second and later control cycles)
     mutable int cnt_mult = -1, cnt_bmult = -1;      // number of equality / bound multipliers (cached by kkt_pass)
     int nvia = 0;   // via-points of this instance
-    int flags;      // bits 0..2 xf_fixed, 3 dt_free, 4 quadratic objective, 5 has_Qf, 6..9 rate_on, 10 terminal ball, 11 via-points, 12 line footprint: the problem record lives in LDS and every
+    int flags;      // bits 0..2 xf_fixed, 3 dt_free, 4 quadratic objective, 5 has_Qf, 6..9 rate_on, 10 terminal ball, 11 via-points, 12 footprint that turns with the pose (line, two circles): the problem record lives in LDS and every
                     // P.x costs a ds_read (+ wait) that the compiler cannot hoist over LDS stores; one scalar register holds the switches
 #ifdef MPC_PROFILE
     mutable long long prof_loop = 0, prof_setup = 0, prof_fwd_loop = 0;    // ticks inside the backward stage loop / before it / inside the forward loop
@@ -389,7 +389,7 @@ struct IpmWave {
                 for (int j = 0; j < L.O; ++j) {
                     if ((int)sm[L.GNV + j] <= 0) continue;
                     T dist, nx, ny, hk;
-                    if (fpline()) { T a3[3], h3[3]; dist = line_eval(px, py, th, j, a3, hk, h3); }
+                    if (fpline()) { T a3[3], h3[3]; dist = turn_eval(px, py, th, j, a3, hk, h3); }
                     else { obst_eval(px, py, j, dist, nx, ny, hk); dist -= P.fp_radius; }
                     if (dist < P.force_incl) { if (cnt < M) { F(L.OI, cnt, k) = T(j); ++cnt; } continue; }
                     if (dist > P.cutoff) continue;
@@ -431,6 +431,31 @@ struct IpmWave {
         return D - sm[L.GR + j];
     }
 
+    // teb TwoCirclesRobotFootprint::calculateDistance: min(dist(front centre) - r_front, dist(rear centre) - r_rear) with the centres at
+    // +front_offset / -rear_offset along the heading: the point evaluation at c(theta) = p + o (cos, sin), chain rule through theta.
+    // Same outputs as line_eval (|a_xy| = 1 again, so the (x,y) block keeps the -hk (I - a_xy a_xy') form).
+    __device__ __forceinline__ T two_eval(T px, T py, T th, int j, T a[3], T& hk, T h3[3]) const {
+        T s, c;
+        t_sincos(th, &s, &c);
+        T df, nfx, nfy, hf, dr, nrx, nry, hr;
+        obst_eval(px + P.fp_line[0] * c, py + P.fp_line[0] * s, j, df, nfx, nfy, hf);
+        obst_eval(px - P.fp_line[2] * c, py - P.fp_line[2] * s, j, dr, nrx, nry, hr);
+        df -= P.fp_line[1]; dr -= P.fp_line[3];
+        const bool rear = dr < df;                                   // std::min(front, rear): the front one wins a tie
+        const T o = rear ? -P.fp_line[2] : P.fp_line[0];
+        const T nx = rear ? nrx : nfx, ny = rear ? nry : nfy;
+        hk = rear ? hr : hf;
+        const T wx = -o * s, wy = o * c;                             // dc/dtheta
+        const T nw = nx * wx + ny * wy;
+        a[0] = -nx; a[1] = -ny; a[2] = -nw;
+        const T hvx = hk * (wx - nx * nw), hvy = hk * (wy - ny * nw);    // H_D dc/dtheta
+        h3[0] = -hvx; h3[1] = -hvy; h3[2] = -((wx * hvx + wy * hvy) - o * (nx * c + ny * s));
+        return rear ? dr : df;
+    }
+    __device__ __forceinline__ T turn_eval(T px, T py, T th, int j, T a[3], T& hk, T h3[3]) const {
+        return P.footprint_kind == 3 ? two_eval(px, py, th, j, a, hk, h3) : line_eval(px, py, th, j, a, hk, h3);
+    }
+
     // value / gradient / curvature cache of the clearance rows of grid point k at position (px,py); returns row count
     __device__ __forceinline__ bool obst_row(int k, int m, T px, T py, T& g, T& ax, T& ay, T& hk) const {
         const int j = (int)F(L.OI, m, k);
@@ -446,7 +471,7 @@ struct IpmWave {
         if (!fpline()) { a[2] = T(0); h3[0] = h3[1] = h3[2] = T(0); return obst_row(k, m, px, py, g, a[0], a[1], hk); }
         const int j = (int)F(L.OI, m, k);
         if (j < 0) return false;
-        g = P.d_min - line_eval(px, py, th, j, a, hk, h3);
+        g = P.d_min - turn_eval(px, py, th, j, a, hk, h3);
         return true;
     }
     // a' dz of row (k, m) from the cached gradient
@@ -1539,7 +1564,7 @@ struct IpmWave {
     __device__ __forceinline__ SolveStats<T> solve() {
         SolveStats<T> out;
         flags = (P.xf_fixed[0] ? 1 : 0) | (P.xf_fixed[1] ? 2 : 0) | (P.xf_fixed[2] ? 4 : 0) | (P.dt_free ? 8 : 0) | (P.objective == OBJ_QUADRATIC ? 16 : 0) |
-                (P.has_Qf ? 32 : 0) | (P.rate_on[0] ? 64 : 0) | (P.rate_on[1] ? 128 : 0) | (P.rate_on[2] ? 256 : 0) | (P.rate_on[3] ? 512 : 0) | (P.ball ? 1024 : 0) | (P.via ? 2048 : 0) | ((P.n_obst > 0 && P.footprint_kind == 2) ? 4096 : 0);
+                (P.has_Qf ? 32 : 0) | (P.rate_on[0] ? 64 : 0) | (P.rate_on[1] ? 128 : 0) | (P.rate_on[2] ? 256 : 0) | (P.rate_on[3] ? 512 : 0) | (P.ball ? 1024 : 0) | (P.via ? 2048 : 0) | ((P.n_obst > 0 && (P.footprint_kind == 2 || P.footprint_kind == 3)) ? 4096 : 0);
         flags = __builtin_amdgcn_readfirstlane(flags);
         nfix = (int)fx(0) + (int)fx(1) + (int)fx(2);
         row0_on = dtprev != T(0);

@@ -189,9 +189,47 @@ def _closest_point_on_obstacle(pt, ob: R.Obstacle):
     return best, inside
 
 
+def _point_row(pt, ob: R.Obstacle):
+    """distance of the point pt to the obstacle (teb semantics, radius subtracted), unit normal from the closest point to pt and
+    hk = 1/|pt - closest| if the closest feature is a vertex (point / circle obstacle), 0 on an edge interior or inside a polygon."""
+    cp, inside = _closest_point_on_obstacle(pt, ob)
+    if inside:
+        return 0.0, np.zeros(2), 0.0
+    if isinstance(cp, tuple):
+        q, t, ab = cp
+        interior = 0.0 < t < 1.0
+    else:
+        q, interior = cp, False
+    dvec = pt - q
+    d = float(np.linalg.norm(dvec))
+    rad = ob.radius if ob.kind == R.OBST_CIRCLE else 0.0
+    if d > 0:
+        return d - rad, dvec / d, (0.0 if interior else 1.0 / d)
+    return d - rad, np.zeros(2), 0.0
+
+
 def clearance_row(cfg: R.OcpConfig, xk, ob: R.Obstacle, want_hess=True):
     """value, gradient (3,), Hessian (3,3) of  d_min - dist(footprint(x_k), ob).
-    Point footprint: analytic.  Others: central differences (like corbo's edges)."""
+    Point / circular footprint, two-circle footprint, line footprint against point / circular obstacles: analytic.
+    Others: central differences (like corbo's edges)."""
+    if cfg.footprint_kind == R.FOOTPRINT_TWO_CIRCLES:
+        # teb TwoCirclesRobotFootprint::calculateDistance: min(dist(front centre) - r_front, dist(rear centre) - r_rear), the centres sit
+        # at +front_offset / -rear_offset along the heading: point rows at c(theta) = p + o (cos, sin), chain rule through theta
+        fo, fr, ro, rr = cfg.footprint_params
+        th = float(xk[2]); c, s = math.cos(th), math.sin(th)
+        best = None
+        for o, r in ((fo, fr), (-ro, rr)):
+            ctr = np.asarray(xk[:2], float) + o * np.array([c, s])
+            d, nrm, hk = _point_row(ctr, ob)
+            if best is None or d - r < best[0]:
+                best = (d - r, nrm, hk, o)
+        dist, nrm, hk, o = best
+        w = o * np.array([-s, c])                                         # d c / d theta
+        Jc = np.array([[1.0, 0.0, w[0]], [0.0, 1.0, w[1]]])
+        gd = Jc.T @ nrm
+        Hd = Jc.T @ (hk * (np.eye(2) - np.outer(nrm, nrm))) @ Jc
+        Hd[2, 2] += float(nrm @ (-o * np.array([c, s])))                  # n' d2c/dtheta2
+        return cfg.min_obstacle_dist - dist, -gd, -Hd
     if cfg.footprint_kind in (R.FOOTPRINT_POINT, R.FOOTPRINT_CIRCLE):
         pt = np.asarray(xk[:2], float)
         off = cfg.footprint_params[0] if cfg.footprint_kind == R.FOOTPRINT_CIRCLE else 0.0

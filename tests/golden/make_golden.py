@@ -65,7 +65,7 @@ def make_obstacles(name, n=30, B=10, O=6, V=6, M=4, keep=6):
     print(name, "kept", len(sel), "iters", IT)
 
 
-if __name__ == "__main__" and "--warm" not in sys.argv and "--integral" not in sys.argv and "--closed-loop" not in sys.argv and "--config3" not in sys.argv and "--midpoint" not in sys.argv and "--cn" not in sys.argv and "--ball" not in sys.argv and "--via" not in sys.argv and "--line" not in sys.argv:
+if __name__ == "__main__" and "--warm" not in sys.argv and "--integral" not in sys.argv and "--closed-loop" not in sys.argv and "--config3" not in sys.argv and "--midpoint" not in sys.argv and "--cn" not in sys.argv and "--ball" not in sys.argv and "--via" not in sys.argv and "--line" not in sys.argv and "--two" not in sys.argv:
     make_obstacles("unicycle_quadratic_obstacles_n30")
     make("carlike_min_time_n50", R.config_carlike_min_time(50), W.carlike_min_time_inputs(32, seed=101), keep=8)
     make("carlike_min_time_n20", R.config_carlike_min_time(20), W.carlike_min_time_inputs(32, seed=102, goal_range=(1.0, 2.5)), keep=8)
@@ -341,3 +341,33 @@ def make_line_footprint(name, n=30, B=16, keep=6, M=4):
 
 if __name__ == "__main__" and "--line" in sys.argv:
     make_line_footprint("carlike_line_footprint_n30")
+
+
+TWO_FP = (0.2, 0.15, 0.2, 0.15)       # front_offset, front_radius, rear_offset, rear_radius
+
+
+def make_two_circles(name, n=30, B=12, O=6, V=6, M=4, keep=6):
+    """a21 with teb's TwoCirclesRobotFootprint against polygon obstacles (config-3 family, lateral range tightened so that rows bind)."""
+    x0, xf, up, dtp, (no, nv, verts) = W.unicycle_obstacle_inputs(B, seed=161, n_obst=O, max_vertices=V, goal_range=(2.0, 4.0), lateral=(0.3, 0.8))
+    cfg = R.config_unicycle_quadratic(n)
+    cfg.footprint_kind, cfg.footprint_params = R.FOOTPRINT_TWO_CIRCLES, TWO_FP
+    rows = []
+    for i in range(B):
+        if len(rows) >= keep:
+            break
+        obs = [R.Obstacle(R.OBST_POLYGON, verts[i, o, :nv[i, o]]) for o in range(no[i])]
+        inp = R.CycleInputs(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=float(dtp[i]), obstacles=obs)
+        init = R.cold_start(cfg, x0[i], xf[i])
+        rel, _ = R.associate_obstacles(cfg, init, obs, max_rows=M)
+        ref = I.solve(cfg, inp, init, relevant=rel, opt=I.IpmOptions(globalization="merit", max_iter=100))
+        if ref.status != 0 or ref.iters > 60:
+            continue
+        dmin = min(R.footprint_distance(cfg.footprint_kind, cfg.footprint_params, ref.traj.x[k], ob) for k in range(1, n - 1) for ob in obs)
+        rows.append(dict(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=dtp[i], n_obstacles=no[i], n_vertices=nv[i], vertices=verts[i],
+                         x=ref.traj.x, u=np.vstack([ref.traj.u, ref.traj.u[-1:]]), dt=ref.traj.dt, iters=ref.iters, dmin=dmin))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), two=np.array(TWO_FP), max_rows=M, **{k: np.array([r[k] for r in rows]) for k in rows[0]})
+    print(name, "kept", len(rows), "iters", [r["iters"] for r in rows], "min footprint distance", [round(float(r["dmin"]), 4) for r in rows])
+
+
+if __name__ == "__main__" and "--two" in sys.argv:
+    make_two_circles("unicycle_two_circles_obstacles_n30")

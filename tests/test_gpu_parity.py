@@ -607,7 +607,7 @@ def test_line_footprint_golden(m):
     from oracle import se2_nlp as R
     g = np.load(os.path.join(GOLD, "carlike_line_footprint_n30.npz"))
     B, O = g["pts"].shape[0], g["pts"].shape[1]
-    cfg = m.config_carlike_min_time(30, footprint_kind=2, footprint_line=tuple(g["line"]), min_obstacle_dist=0.27, force_inclusion_dist=0.5,
+    cfg = m.config_carlike_min_time(30, footprint_kind=2, footprint_params=tuple(g["line"]), min_obstacle_dist=0.27, force_inclusion_dist=0.5,
                                     cutoff_dist=2.5, max_obstacles=O, max_vertices=1, max_obstacle_rows=int(g["max_rows"]))
     s = m.BatchSolver(cfg, max_batch=B)
     no = np.full(B, O, np.int32); nv = np.ones((B, O), np.int32); vt = g["pts"].reshape(B, O, 1, 2)
@@ -622,4 +622,25 @@ def test_line_footprint_golden(m):
         obs = [R.Obstacle(R.OBST_POINT, g["pts"][i, o:o + 1]) for o in range(O)]
         dmin = min(R.footprint_distance(R.FOOTPRINT_LINE, tuple(g["line"]), r.x[i, k], ob) for k in range(1, 29) for ob in obs)
         assert dmin > 0.27 - 1e-6
+    s.close()
+
+
+def test_two_circles_footprint_golden(m):
+    """a21 with teb's TwoCirclesRobotFootprint against polygon obstacles (fixture: tests/golden/make_golden.py --two; three of the six
+    instances end with a binding row); the footprint clearance is re-checked with the reference-form distance function."""
+    from oracle import se2_nlp as R
+    g = np.load(os.path.join(GOLD, "unicycle_two_circles_obstacles_n30.npz"))
+    B, O, V = g["vertices"].shape[0], g["vertices"].shape[1], g["vertices"].shape[2]
+    cfg = m.config_unicycle_quadratic(30, footprint_kind=3, footprint_params=tuple(g["two"]), max_obstacles=O, max_vertices=V, max_obstacle_rows=int(g["max_rows"]))
+    s = m.BatchSolver(cfg, max_batch=B)
+    r = s.solve(g["x0"], g["xf"], g["u_prev"], g["dt_prev"], obstacles=(g["n_obstacles"], g["n_vertices"], g["vertices"]))
+    assert (r.status == 0).all()
+    err = np.maximum(np.abs(r.x - g["x"]).reshape(B, -1).max(1), np.abs(r.u - g["u"]).reshape(B, -1).max(1))
+    same = r.iters == g["iters"]
+    assert same.sum() >= B - 2 and (err[same] < 1e-6).all() and (err < 1e-4).all()
+    assert (np.abs(r.iters - g["iters"]) <= np.maximum(2, 0.1 * g["iters"])).all()
+    for i in range(B):
+        obs = [R.Obstacle(R.OBST_POLYGON, g["vertices"][i, o, :g["n_vertices"][i, o]]) for o in range(g["n_obstacles"][i])]
+        dmin = min(R.footprint_distance(R.FOOTPRINT_TWO_CIRCLES, tuple(g["two"]), r.x[i, k], ob) for k in range(1, 29) for ob in obs)
+        assert dmin > 0.2 - 1e-6
     s.close()
