@@ -82,7 +82,7 @@ typedef struct mpc_config {
     int32_t collocation;              /* grid/collocation_method          (:298) */
     int32_t objective;                /* planning/objective/type          (:551) */
     double  Q[3], R[2];               /* quadratic_form weights (diag)    (:561-592) */
-    int32_t integral_form;            /* .../integral_form                (:594); fixed-dt grid only (dt_free = 0) */
+    int32_t integral_form;            /* .../integral_form                (:594) */
     int32_t has_Qf;                   /* planning/terminal_cost/type == quadratic (:645) */
     double  Qf[3];                    /* final_state_weights (diag)       (:652-668) */
     double  u_lb[2], u_ub[2];         /* control box                      (:511,:527,:543) */

@@ -240,7 +240,6 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         set_err("mpc_create: only point, circular, line and two-circle footprints are implemented"); return MPC_EINVAL; }
     if (cfg->max_obstacles > 0 && cfg->footprint_kind == MPC_FOOTPRINT_LINE && cfg->max_vertices > 1) {
         set_err("mpc_create: the line footprint is implemented for point and circular obstacles (max_vertices = 1)"); return MPC_EINVAL; }
-    if (cfg->integral_form && cfg->dt_free) { set_err("mpc_create: integral_form costs are implemented for the fixed-dt grid only (dt_free = 0)"); return MPC_EINVAL; }
     for (int j = 0; j < 2; ++j)
         if (!(cfg->u_lb[j] < cfg->u_ub[j])) { set_err("mpc_create: control box must be finite and non-empty"); return MPC_EINVAL; }
     int ndev = 0;
@@ -352,7 +351,7 @@ static hipError_t launch_model(mpc_solver* s, const mpc::Problem<T>& P, int B, c
                                const double* dtp, const double* xi, const double* ui, const double* dti, const mpc_obstacles& ob, double* xo, double* uo,
                                double* dto, int32_t* st, int32_t* it) {
     if (s->use_wave) {
-        const bool ext = P.ball || P.via || (P.n_obst > 0 && (P.footprint_kind == MPC_FOOTPRINT_LINE || P.footprint_kind == MPC_FOOTPRINT_TWO_CIRCLES));
+        const bool ext = P.ball || P.via || P.integral_form || (P.n_obst > 0 && (P.footprint_kind == MPC_FOOTPRINT_LINE || P.footprint_kind == MPC_FOOTPRINT_TWO_CIRCLES));
         auto kern = ext ? mpc_ipm_wave_kernel<T, MODEL, true> : mpc_ipm_wave_kernel<T, MODEL, false>;
         if (s->wave_lds > 48u * 1024u) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->wave_lds);

@@ -499,6 +499,7 @@ MPC_HD void stage_map(const Problem<T>& P, const T tr[4], const T tr2[2], T v, T
 enum StageAdd {
     A00 = 0, A01, A11, A22, A25, A26, A27, A33, A35, A36, A44, A45, A47, A55, A56, A57, A66, A67, A77,   // Hessian (19)
     A02, A12,                                                                                            // position-heading coupling (clearance rows of a line footprint)
+    A05, A15,                                                                                            // position-dt coupling (integral-form cost on the variable grid)
     A08, A18, A28, A38, A48, A58, A68, A78,                                                              // gradient (8)
     NADD
 };
@@ -523,18 +524,19 @@ struct StageParts {
     T hx[3];                          // objective gradient wrt x_k
     T oxx, oxy, oyy, ogx, ogy;        // clearance rows
     T oxt = T(0), oyt = T(0), ott = T(0), ogt = T(0);   // ... heading parts (footprints that turn with the pose)
+    T cxd[3] = {T(0), T(0), T(0)}, cud[2] = {T(0), T(0)}, gdt = T(0);   // integral-form cost with free dt: d2/dx ddt, d2/du ddt, d/ddt
 };
 template <typename T>
 MPC_HD void assemble_adds(const StageParts<T>& s, const T q2[3], const T r2[2], T A[NADD]) {
     A[A00] = q2[0] + s.oxx; A[A01] = s.oxy; A[A11] = q2[1] + s.oyy; A[A22] = q2[2] + s.h00 + s.ott;
-    A[A02] = s.oxt; A[A12] = s.oyt;
-    A[A25] = s.g[0]; A[A26] = s.h01; A[A27] = s.h02;
+    A[A02] = s.oxt; A[A12] = s.oyt; A[A05] = s.cxd[0]; A[A15] = s.cxd[1];
+    A[A25] = s.g[0] + s.cxd[2]; A[A26] = s.h01; A[A27] = s.h02;
     A[A33] = s.ss[0]; A[A35] = s.sl[0]; A[A36] = -s.ss[0];
     A[A44] = s.ss[1]; A[A45] = s.sl[1]; A[A47] = -s.ss[1];
-    A[A55] = s.sll + s.hdd; A[A56] = s.g[1] - s.sl[0]; A[A57] = s.g[2] - s.sl[1];
+    A[A55] = s.sll + s.hdd; A[A56] = s.g[1] - s.sl[0] + s.cud[0]; A[A57] = s.g[2] - s.sl[1] + s.cud[1];
     A[A66] = s.h11 + s.sz[0] + s.ss[0] + r2[0]; A[A67] = s.h12; A[A77] = s.h22 + s.sz[1] + s.ss[1] + r2[1];
     A[A08] = s.hx[0] + s.ogx; A[A18] = s.hx[1] + s.ogy; A[A28] = s.hx[2] + s.ogt;
-    A[A38] = -s.gy[0]; A[A48] = -s.gy[1]; A[A58] = -s.gyl;
+    A[A38] = -s.gy[0]; A[A48] = -s.gy[1]; A[A58] = -s.gyl + s.gdt;
     A[A68] = s.gb[0] + s.gy[0]; A[A78] = s.gb[1] + s.gy[1];
 }
 

@@ -30,7 +30,9 @@ inline void fill_problem(const mpc_config& c, mpc::Problem<T>& P) {
     // term is multiplied by the constant dt, i.e. the weights are scaled; the terminal cost is not.  (dt free + integral form couples
     // the states with dt in the Hessian and is rejected by mpc_create.)
     const double wsc = (c.integral_form && !c.dt_free) ? c.dt_ref : 1.0;
-    P.integral_form = 0;
+    // integral form on the variable grid (dt is a decision variable): the weights stay unscaled, the kernel multiplies by the current dt
+    // and carries the state-dt / control-dt coupling of the Hessian (wave kernel, A-form slots A05 A15 A25 A56 A57)
+    P.integral_form = (c.objective == MPC_OBJ_QUADRATIC && c.integral_form && c.dt_free) ? 1 : 0;
     for (int i = 0; i < 3; ++i) { P.Q[i] = T(c.Q[i] * wsc); P.Qf[i] = T(c.Qf[i]); }
     for (int j = 0; j < 2; ++j) {
         P.R[j] = T(c.R[j] * wsc);

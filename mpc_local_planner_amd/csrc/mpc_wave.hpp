@@ -29,8 +29,8 @@ __device__ long long g_mpc_prof[4096][16];
 namespace mpc {
 
 constexpr int kWave = 64;
-// per-stage LQ record: 0..2 a0 a1 1 | 3..5 f | 6..8 Bx[:,0] | 9..11 Bx[:,1] | 12..40 combined stage cost A[StageAdd]
-constexpr int NSTG = 41;
+// per-stage LQ record: 0..2 a0 a1 1 | 3..5 f | 6..8 Bx[:,0] | 9..11 Bx[:,1] | 12..42 combined stage cost A[StageAdd]
+constexpr int NSTG = 43;
 constexpr int RA = 12;     // first A slot (words 0..11: a0 a1 1 | f | Bx[:,0] | Bx[:,1])
 constexpr int NGAIN = 20;  // negated gains: nK0(6) nkappa0 nKnu0(3) | nK1(6) nkappa1 nKnu1(3)
 
@@ -79,8 +79,8 @@ constexpr int stage_add_slot(int r, int c) {
     if (c == 8) return A08 + r;
     if (c > 8) return -1;
     const int a = r < c ? r : c, b = r < c ? c : r;
-    if (a == 0) return b == 0 ? A00 : (b == 1 ? A01 : (b == 2 ? A02 : -1));
-    if (a == 1) return b == 1 ? A11 : (b == 2 ? A12 : -1);
+    if (a == 0) return b == 0 ? A00 : (b == 1 ? A01 : (b == 2 ? A02 : (b == 5 ? A05 : -1)));
+    if (a == 1) return b == 1 ? A11 : (b == 2 ? A12 : (b == 5 ? A15 : -1));
     if (a == 2) return b == 2 ? A22 : (b == 5 ? A25 : (b == 6 ? A26 : (b == 7 ? A27 : -1)));
     if (a == 3) return b == 3 ? A33 : (b == 5 ? A35 : (b == 6 ? A36 : -1));
     if (a == 4) return b == 4 ? A44 : (b == 5 ? A45 : (b == 7 ? A47 : -1));
@@ -183,6 +183,7 @@ struct IpmWave {
     __device__ __forceinline__ bool ball() const { return EXT && ((flags >> 10) & 1); }
     __device__ __forceinline__ bool via() const { return EXT && ((flags >> 11) & 1); }
     __device__ __forceinline__ bool fpline() const { return EXT && ((flags >> 12) & 1); }
+    __device__ __forceinline__ bool intf() const { return EXT && ((flags >> 13) & 1); }     // integral-form cost, dt free
     // explicit LDS pointers for the running-pointer loops (address-space inference gives up on per-lane selected pointers)
     typedef __attribute__((address_space(3))) T LdsT;
     __device__ __forceinline__ LdsT* lds(int word) const { return (LdsT*)sm + word; }
@@ -517,7 +518,7 @@ struct IpmWave {
             th += t_abs(c0) + t_abs(c1) + t_abs(c2);
             if (quad()) {
                 T xd0 = xk[0] - xf[0], xd1 = xk[1] - xf[1], xd2 = normalize_theta(xk[2] - xf[2]);
-                fo += P.Q[0] * xd0 * xd0 + P.Q[1] * xd1 * xd1 + P.Q[2] * xd2 * xd2 + P.R[0] * v * v + P.R[1] * w * w;
+                fo += (P.Q[0] * xd0 * xd0 + P.Q[1] * xd1 * xd1 + P.Q[2] * xd2 * xd2 + P.R[0] * v * v + P.R[1] * w * w) * (intf() ? d : T(1));
             }
             if (via()) { T vv, vg[3]; via_terms(k, xk[0], xk[1], xk[2], vv, vg); fo += vv; }
         }
@@ -620,7 +621,7 @@ struct IpmWave {
             th = t_abs(c0) + t_abs(c1) + t_abs(c2);
             if (r.quad) {
                 const T xd0 = x0_ - xf[0], xd1 = x1_ - xf[1], xd2 = normalize_theta(x2_ - xf[2]);
-                fo = r.Q[0] * xd0 * xd0 + r.Q[1] * xd1 * xd1 + r.Q[2] * xd2 * xd2 + r.R[0] * v * v + r.R[1] * w * w;
+                fo = (r.Q[0] * xd0 * xd0 + r.Q[1] * xd1 * xd1 + r.Q[2] * xd2 * xd2 + r.R[0] * v * v + r.R[1] * w * w) * (intf() ? d : T(1));
             }
             if (via()) { T vv, vg[3]; via_terms(r.k, x0_, x1_, x2_, vv, vg); fo += vv; }
             acc.mul(v - r.ulb[0]); acc.mul(r.uub[0] - v); acc.mul(w - r.ulb[1]); acc.mul(r.uub[1] - w);
@@ -690,8 +691,10 @@ struct IpmWave {
                 T gx[3] = {T(0), T(0), T(0)}, gu[2] = {T(0), T(0)};
                 if (quad()) {
                     T xd[3] = {F(L.X, 0, k) - xf[0], F(L.X, 1, k) - xf[1], normalize_theta(F(L.X, 2, k) - xf[2])};
-                    for (int i = 0; i < 3; ++i) gx[i] = T(2) * P.Q[i] * xd[i];
-                    gu[0] = T(2) * P.R[0] * v; gu[1] = T(2) * P.R[1] * w;
+                    const T w8 = intf() ? d : T(1);
+                    for (int i = 0; i < 3; ++i) gx[i] = T(2) * P.Q[i] * xd[i] * w8;
+                    gu[0] = T(2) * P.R[0] * v * w8; gu[1] = T(2) * P.R[1] * w * w8;
+                    if (intf()) rdd += P.Q[0] * xd[0] * xd[0] + P.Q[1] * xd[1] * xd[1] + P.Q[2] * xd[2] * xd[2] + P.R[0] * v * v + P.R[1] * w * w;
                 }
                 if (via()) { T vv; via_terms(k, F(L.X, 0, k), F(L.X, 1, k), F(L.X, 2, k), vv, gx); }
                 T osx = T(0), osy = T(0), ost = T(0);
@@ -806,7 +809,7 @@ struct IpmWave {
         const T d = SCL(SC_D);
         const bool quad = this->quad();
         T q2[3] = {T(0), T(0), T(0)}, r2[2] = {T(0), T(0)};
-        if (quad) { for (int i = 0; i < 3; ++i) q2[i] = T(2) * P.Q[i]; for (int j = 0; j < 2; ++j) r2[j] = T(2) * P.R[j]; }
+        if (quad) { const T w8 = intf() ? d : T(1); for (int i = 0; i < 3; ++i) q2[i] = T(2) * P.Q[i] * w8; for (int j = 0; j < 2; ++j) r2[j] = T(2) * P.R[j] * w8; }
         for (int k = lane; k < n; k += kWave) {
             StageParts<T> sp;
             sp.h00 = S_(RA + A22, k); sp.h01 = S_(RA + A26, k); sp.h02 = S_(RA + A27, k);
@@ -860,6 +863,14 @@ struct IpmWave {
                         sp.ogt += at * ybar;
                     }
                 }
+            }
+            if (intf() && k < n - 1) {       // d/ddt and the mixed second derivatives of  dt * (xd'Q xd + u'R u)
+                const T xd0 = F(L.X, 0, k) - xf[0], xd1 = F(L.X, 1, k) - xf[1], xd2 = normalize_theta(F(L.X, 2, k) - xf[2]);
+                const T v = F(L.U, 0, k), w = F(L.U, 1, k);
+                sp.cxd[0] = T(2) * P.Q[0] * xd0; sp.cxd[1] = T(2) * P.Q[1] * xd1; sp.cxd[2] = T(2) * P.Q[2] * xd2;
+                sp.cud[0] = T(2) * P.R[0] * v; sp.cud[1] = T(2) * P.R[1] * w;
+                sp.gdt = P.Q[0] * xd0 * xd0 + P.Q[1] * xd1 * xd1 + P.Q[2] * xd2 * xd2 + P.R[0] * v * v + P.R[1] * w * w;
+                if (k == 0) { sp.cxd[0] = sp.cxd[1] = sp.cxd[2] = T(0); }      // x_0 is not a variable
             }
             if (via() && k >= 1 && k < n - 1) {
                 T vv, vg[3];
@@ -1242,6 +1253,7 @@ struct IpmWave {
                 t0 = delta * dx0 + S_(RA + A00, m) * dx0 + S_(RA + A01, m) * dx1 + S_(RA + A08, m);
                 t1 = delta * dx1 + S_(RA + A01, m) * dx0 + S_(RA + A11, m) * dx1 + S_(RA + A18, m);
                 t2 = delta * dx2 + S_(RA + A22, m) * dx2 + S_(RA + A26, m) * duv + S_(RA + A27, m) * duw + S_(RA + A25, m) * dd + S_(RA + A28, m);
+                if (intf()) { t0 += S_(RA + A05, m) * dd; t1 += S_(RA + A15, m) * dd; }
                 if (fpline()) {        // position-heading coupling of the clearance rows
                     const T c02 = S_(RA + A02, m), c12 = S_(RA + A12, m);
                     t0 += c02 * dx2; t1 += c12 * dx2; t2 += c02 * dx0 + c12 * dx1;
@@ -1303,7 +1315,7 @@ struct IpmWave {
                     T dl = u - P.u_lb[j], du = P.u_ub[j] - u;
                     T pl = F(L.PL, j, k), pu = F(L.PU, j, k);
                     const T idl = t_rcp(dl), idu = t_rcp(du);
-                    T gbar = mu * idu - mu * idl + (quad() ? T(2) * P.R[j] * u : T(0));   // barrier (+ objective) gradient wrt u
+                    T gbar = mu * idu - mu * idl + (quad() ? T(2) * P.R[j] * u * (intf() ? d : T(1)) : T(0));   // barrier (+ objective) gradient wrt u
                     hdz += gbar * du_; dphi += gbar * du_;
                     ftb(dl, du_, tau, a_p); ftb(du, -du_, tau, a_p);
                     ftb(pl, mu * idl - pl - (pl * idl) * du_, tau, a_d);
@@ -1315,6 +1327,12 @@ struct IpmWave {
                     clam += C_(i, k) * l;
                     if (!t_finite(l)) fin = false;
                 }
+                if (intf()) {       // d/ddt of the integral-form stage cost
+                    const T xd0 = F(L.X, 0, k) - xf[0], xd1 = F(L.X, 1, k) - xf[1], xd2 = normalize_theta(F(L.X, 2, k) - xf[2]);
+                    const T v = F(L.U, 0, k), w = F(L.U, 1, k);
+                    const T sc = P.Q[0] * xd0 * xd0 + P.Q[1] * xd1 * xd1 + P.Q[2] * xd2 * xd2 + P.R[0] * v * v + P.R[1] * w * w;
+                    hdz += sc * dd; dphi += sc * dd;
+                }
             }
             if (k >= 1) {
                 T vg[3] = {T(0), T(0), T(0)};
@@ -1325,7 +1343,7 @@ struct IpmWave {
                         dz2 += dx * dx; dzmax = t_max(dzmax, t_abs(dx));
                         T g = vg[i];
                         if (quad()) {
-                            if (k < n - 1) { T xd = F(L.X, i, k) - xf[i]; if (i == 2) xd = normalize_theta(xd); g = T(2) * P.Q[i] * xd; }
+                            if (k < n - 1) { T xd = F(L.X, i, k) - xf[i]; if (i == 2) xd = normalize_theta(xd); g = T(2) * P.Q[i] * xd * (intf() ? d : T(1)); }
                             else if (hasqf()) { T xd = F(L.X, i, k) - xf[i]; if (i == 2) xd = normalize_theta(xd); g = T(2) * P.Qf[i] * xd; }
                         }
                         hdz += g * dx; dphi += g * dx;
@@ -1564,7 +1582,7 @@ struct IpmWave {
     __device__ __forceinline__ SolveStats<T> solve() {
         SolveStats<T> out;
         flags = (P.xf_fixed[0] ? 1 : 0) | (P.xf_fixed[1] ? 2 : 0) | (P.xf_fixed[2] ? 4 : 0) | (P.dt_free ? 8 : 0) | (P.objective == OBJ_QUADRATIC ? 16 : 0) |
-                (P.has_Qf ? 32 : 0) | (P.rate_on[0] ? 64 : 0) | (P.rate_on[1] ? 128 : 0) | (P.rate_on[2] ? 256 : 0) | (P.rate_on[3] ? 512 : 0) | (P.ball ? 1024 : 0) | (P.via ? 2048 : 0) | ((P.n_obst > 0 && (P.footprint_kind == 2 || P.footprint_kind == 3)) ? 4096 : 0);
+                (P.has_Qf ? 32 : 0) | (P.rate_on[0] ? 64 : 0) | (P.rate_on[1] ? 128 : 0) | (P.rate_on[2] ? 256 : 0) | (P.rate_on[3] ? 512 : 0) | (P.ball ? 1024 : 0) | (P.via ? 2048 : 0) | ((P.n_obst > 0 && (P.footprint_kind == 2 || P.footprint_kind == 3)) ? 4096 : 0) | (P.integral_form ? 8192 : 0);
         flags = __builtin_amdgcn_readfirstlane(flags);
         nfix = (int)fx(0) + (int)fx(1) + (int)fx(2);
         row0_on = dtprev != T(0);

@@ -65,7 +65,7 @@ def make_obstacles(name, n=30, B=10, O=6, V=6, M=4, keep=6):
     print(name, "kept", len(sel), "iters", IT)
 
 
-if __name__ == "__main__" and "--warm" not in sys.argv and "--integral" not in sys.argv and "--closed-loop" not in sys.argv and "--config3" not in sys.argv and "--midpoint" not in sys.argv and "--cn" not in sys.argv and "--ball" not in sys.argv and "--via" not in sys.argv and "--line" not in sys.argv and "--two" not in sys.argv:
+if __name__ == "__main__" and "--warm" not in sys.argv and "--integral" not in sys.argv and "--closed-loop" not in sys.argv and "--config3" not in sys.argv and "--midpoint" not in sys.argv and "--cn" not in sys.argv and "--ball" not in sys.argv and "--via" not in sys.argv and "--line" not in sys.argv and "--two" not in sys.argv and "--integral-free" not in sys.argv:
     make_obstacles("unicycle_quadratic_obstacles_n30")
     make("carlike_min_time_n50", R.config_carlike_min_time(50), W.carlike_min_time_inputs(32, seed=101), keep=8)
     make("carlike_min_time_n20", R.config_carlike_min_time(20), W.carlike_min_time_inputs(32, seed=102, goal_range=(1.0, 2.5)), keep=8)
@@ -371,3 +371,38 @@ def make_two_circles(name, n=30, B=12, O=6, V=6, M=4, keep=6):
 
 if __name__ == "__main__" and "--two" in sys.argv:
     make_two_circles("unicycle_two_circles_obstacles_n30")
+
+
+def integral_free_dt_config(n=20):
+    """a17 on the variable grid: quadratic integral-form cost dt * sum(xd'Q xd + u'R u) (left sum, finite_differences_grid_se2.cpp:61-75)
+    with dt free, fixed goal (free end time optimal control); effort weights raised so that dt does not run into its bounds."""
+    cfg = R.config_unicycle_quadratic(n)
+    cfg.dt_free, cfg.dt_lb, cfg.dt_ub, cfg.xf_fixed, cfg.Qf, cfg.integral_form = True, 0.01, 2.0, (True, True, True), None, True
+    cfg.R = np.array([1.0, 0.5])
+    return cfg
+
+
+def make_integral_free_dt(name, n=20, B=16, keep=6):
+    cfg = integral_free_dt_config(n)
+    x0, xf, up, dtp = W.unicycle_quadratic_inputs(B, seed=171, goal_range=(1.0, 2.0))
+    rows = []
+    for i in range(B):
+        if len(rows) >= keep:
+            break
+        inp = R.CycleInputs(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=float(dtp[i]))
+        ref = I.solve(cfg, inp, R.cold_start(cfg, x0[i], xf[i]), opt=I.IpmOptions(globalization="merit", max_iter=100))
+        inp2 = R.CycleInputs(x0=x0[i], xf=xf[i] * (1 + 1e-12), u_prev=up[i], dt_prev=float(dtp[i]))
+        pert = I.solve(cfg, inp2, R.cold_start(cfg, x0[i], inp2.xf), opt=I.IpmOptions(globalization="merit", max_iter=100))
+        if ref.status != 0 or ref.iters > 60 or pert.iters != ref.iters or np.abs(pert.traj.x - ref.traj.x).max() > 1e-8:
+            continue
+        nlp = R.ReferenceNlp(cfg, inp)
+        z = nlp.pack(ref.traj)
+        assert np.abs(nlp.equalities(z)).max() < 1e-7 and abs(nlp.objective(z) - ref.objective) < 1e-9 * max(1.0, ref.objective)
+        rows.append(dict(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=dtp[i], x=ref.traj.x, u=np.vstack([ref.traj.u, ref.traj.u[-1:]]), dt=ref.traj.dt,
+                         iters=ref.iters, objective=ref.objective))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), **{k: np.array([r[k] for r in rows]) for k in rows[0]})
+    print(name, "kept", len(rows), "iters", [r["iters"] for r in rows], "dt", [round(float(r["dt"]), 4) for r in rows])
+
+
+if __name__ == "__main__" and "--integral-free" in sys.argv:
+    make_integral_free_dt("unicycle_quadratic_integral_free_dt_n20")

@@ -329,7 +329,7 @@ def test_mixed_grid_sizes_in_one_batch(m):
 
 
 def test_integral_form_fixed_grid_golden(m):
-    """quadratic INTEGRAL-form cost (quadratic_cost_se2.cpp:54-83) on the fixed-dt grid; with dt free it is rejected."""
+    """quadratic INTEGRAL-form cost (quadratic_cost_se2.cpp:54-83) on the fixed-dt grid (weights x dt); the variable-grid case is test_integral_form_free_dt_golden."""
     g = np.load(os.path.join(GOLD, "unicycle_quadratic_integral_n20.npz"))
     s = m.BatchSolver(m.config_unicycle_quadratic(20, integral_form=True), max_batch=g["x0"].shape[0])
     r = s.solve(g["x0"], g["xf"], g["u_prev"], g["dt_prev"])
@@ -337,8 +337,6 @@ def test_integral_form_fixed_grid_golden(m):
     assert np.abs(r.x - g["x"]).max() < 1e-6 and np.abs(r.u - g["u"]).max() < 1e-6
     assert (np.abs(r.iters - g["iters"]) <= 2).all()
     s.close()
-    with pytest.raises(m.MpcError):
-        m.BatchSolver(m.make_config(objective=m._abi.OBJ_QUADRATIC, Q=(1, 1, 1), R=(1, 1), integral_form=True, dt_free=True), max_batch=1)
 
 
 
@@ -643,4 +641,21 @@ def test_two_circles_footprint_golden(m):
         obs = [R.Obstacle(R.OBST_POLYGON, g["vertices"][i, o, :g["n_vertices"][i, o]]) for o in range(g["n_obstacles"][i])]
         dmin = min(R.footprint_distance(R.FOOTPRINT_TWO_CIRCLES, tuple(g["two"]), r.x[i, k], ob) for k in range(1, 29) for ob in obs)
         assert dmin > 0.2 - 1e-6
+    s.close()
+
+
+def test_integral_form_free_dt_golden(m):
+    """a17 on the variable grid: dt * sum(xd'Q xd + u'R u) with dt a decision variable (quadratic_cost_se2.cpp:54-83, left sum
+    finite_differences_grid_se2.cpp:61-75): state-dt and control-dt coupling in the Hessian (A-form slots A05 A15 A25 A56 A57), the stage
+    costs in the dt gradient.  Fixture: tests/golden/make_golden.py --integral-free."""
+    g = np.load(os.path.join(GOLD, "unicycle_quadratic_integral_free_dt_n20.npz"))
+    B = g["x0"].shape[0]
+    cfg = m.config_unicycle_quadratic(20, dt_free=True, dt_lb=0.01, dt_ub=2.0, xf_fixed=(True, True, True), Qf=None, integral_form=True, R=(1.0, 0.5))
+    s = m.BatchSolver(cfg, max_batch=B)
+    r = s.solve(g["x0"], g["xf"], g["u_prev"], g["dt_prev"])
+    assert (r.status == 0).all()
+    err = np.maximum(np.abs(r.x - g["x"]).reshape(B, -1).max(1), np.abs(r.u - g["u"]).reshape(B, -1).max(1))
+    same = r.iters == g["iters"]
+    assert same.sum() >= B - 1 and (err[same] < 1e-6).all() and (err < 1e-4).all()
+    assert np.abs(r.dt - g["dt"]).max() < 1e-6
     s.close()
