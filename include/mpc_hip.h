@@ -112,6 +112,7 @@ typedef struct mpc_config {
                                        * (src/optimal_control/min_time_via_points_cost.cpp:139-142) */
     int32_t via_points_ordered;       /* .../via_points_ordered  (:605) */
     int32_t max_via_points;           /* via-points per instance the solver is sized for (objective MIN_TIME_VIA_POINTS; <= 64) */
+    int32_t enable_dynamic_obstacles; /* collision_avoidance/enable_dynamic_obstacles (src/controller.cpp:721); point / circular footprint */
     double  footprint_params[4];      /* MPC_FOOTPRINT_LINE: footprint_model/line_start (x, y), line_end (x, y) in the robot frame;
                                        * MPC_FOOTPRINT_TWO_CIRCLES: front_offset, front_radius, rear_offset, rear_radius (src/mpc_local_planner_ros.cpp:900-960) */
     int32_t reserved[6];
@@ -119,12 +120,15 @@ typedef struct mpc_config {
 
 /* Obstacles of a batch (teb_local_planner ObstContainer of every instance, flattened; borrowed for the call).
  * Point: 1 vertex; line: 2 vertices; polygon: >= 3 vertices (closed loop, any orientation); an optional radius
- * turns a 1-vertex obstacle into a circle.  Static obstacles only (enable_dynamic_obstacles = false). */
+ * turns a 1-vertex obstacle into a circle.  With mpc_config.enable_dynamic_obstacles an obstacle with a non-zero centroid velocity is
+ * a DYNAMIC obstacle: it is kept at every grid point and its row at grid point k is evaluated against the obstacle moved by k*dt*velocity
+ * (src/optimal_control/stage_inequality_se2.cpp:99-106,177-189). */
 typedef struct mpc_obstacles {
     const int32_t* n_obstacles;       /* [B]                 number of valid obstacles of instance b (<= O) */
     const int32_t* n_vertices;        /* [B][O]              number of valid vertices of obstacle (b,o) (<= V) */
     const double*  vertices;          /* [B][O][V][2] */
     const double*  radius;            /* [B][O] or NULL */
+    const double*  velocity;          /* [B][O][2] centroid velocities or NULL (all static) */
 } mpc_obstacles;
 
 typedef struct mpc_solver mpc_solver;     /* opaque */

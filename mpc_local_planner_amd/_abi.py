@@ -77,6 +77,7 @@ class MpcConfig(C.Structure):
         ("vp_orientation_weight", C.c_double),
         ("via_points_ordered", C.c_int32),
         ("max_via_points", C.c_int32),
+        ("enable_dynamic_obstacles", C.c_int32),
         ("footprint_params", C.c_double * 4),
         ("reserved", C.c_int32 * 6),
     ]
@@ -89,6 +90,7 @@ class MpcObstacles(C.Structure):
         ("n_vertices", C.c_void_p),
         ("vertices", C.c_void_p),
         ("radius", C.c_void_p),
+        ("velocity", C.c_void_p),
     ]
 
 
@@ -98,7 +100,8 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
                 mu_init=0.1, precision=FP64, min_obstacle_dist=0.5, force_inclusion_dist=0.5, cutoff_dist=2.0,
                 footprint_kind=0, footprint_radius=0.0, max_obstacles=0, max_vertices=1, max_obstacle_rows=4, mu_init_warm=0.0, collocation=COLLOC_FORWARD,
                 terminal_ball_S=None, terminal_ball_gamma=1.0, vp_position_weight=1e-3, vp_orientation_weight=0.0,
-                via_points_ordered=False, max_via_points=0, footprint_params=(0.0, 0.0, 0.0, 0.0)) -> MpcConfig:
+                via_points_ordered=False, max_via_points=0, footprint_params=(0.0, 0.0, 0.0, 0.0),
+                enable_dynamic_obstacles=False) -> MpcConfig:
     c = MpcConfig()
     c.model = model
     mp = list(model_params) + [0.0] * 4
@@ -136,6 +139,7 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
     c.via_points_ordered, c.max_via_points = int(bool(via_points_ordered)), max_via_points
     for i in range(4):
         c.footprint_params[i] = footprint_params[i]
+    c.enable_dynamic_obstacles = int(bool(enable_dynamic_obstacles))
     return c
 
 

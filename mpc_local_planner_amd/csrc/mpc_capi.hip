@@ -133,7 +133,7 @@ __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
     } else {
         S.cold_start();
     }
-    if (L.M > 0) S.load_obstacles(obst.n_obstacles, obst.n_vertices, obst.vertices, obst.radius, inst);
+    if (L.M > 0) S.load_obstacles(obst.n_obstacles, obst.n_vertices, obst.vertices, obst.radius, obst.velocity, inst);
     if (EXT && L.NV > 0) S.load_via_points(n_via, via, inst);
     __syncthreads();
     mpc::SolveStats<T> st = S.solve();
@@ -174,7 +174,7 @@ struct mpc_solver {
     const int32_t* p_nvia;      // ... and what the kernel reads: the own copy or borrowed device pointers
     const double* p_via;
     int use_ngrid;
-    double *d_ov, *d_or;
+    double *d_ov, *d_or, *d_ovel;
     bool timed;
 };
 
@@ -238,6 +238,8 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
     if (cfg->max_obstacles > 0 && cfg->footprint_kind != MPC_FOOTPRINT_POINT && cfg->footprint_kind != MPC_FOOTPRINT_CIRCLE && cfg->footprint_kind != MPC_FOOTPRINT_LINE &&
         cfg->footprint_kind != MPC_FOOTPRINT_TWO_CIRCLES) {
         set_err("mpc_create: only point, circular, line and two-circle footprints are implemented"); return MPC_EINVAL; }
+    if (cfg->max_obstacles > 0 && cfg->enable_dynamic_obstacles && cfg->footprint_kind != MPC_FOOTPRINT_POINT && cfg->footprint_kind != MPC_FOOTPRINT_CIRCLE) {
+        set_err("mpc_create: dynamic obstacles are implemented for the point and circular footprints"); return MPC_EINVAL; }
     if (cfg->max_obstacles > 0 && cfg->footprint_kind == MPC_FOOTPRINT_LINE && cfg->max_vertices > 1) {
         set_err("mpc_create: the line footprint is implemented for point and circular obstacles (max_vertices = 1)"); return MPC_EINVAL; }
     for (int j = 0; j < 2; ++j)
@@ -263,7 +265,8 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         const int ntrig = ((cfg->model == MPC_MODEL_KINEMATIC_BICYCLE || cfg->model == MPC_MODEL_SIMPLE_CAR_FRONT) ? 4 : 3) +
                           (cfg->collocation == MPC_COLLOC_CRANK_NICOLSON ? 2 : 0);
         s->WL = mpc::WaveLayout::make(cfg->n, M, O, cfg->max_vertices > 0 ? cfg->max_vertices : 1, ntrig, s->P64.n_via,
-                                        (O > 0 && (cfg->footprint_kind == MPC_FOOTPRINT_LINE || cfg->footprint_kind == MPC_FOOTPRINT_TWO_CIRCLES)) ? M : 0);
+                                        (O > 0 && (cfg->footprint_kind == MPC_FOOTPRINT_LINE || cfg->footprint_kind == MPC_FOOTPRINT_TWO_CIRCLES || cfg->enable_dynamic_obstacles)) ? M : 0,
+                                        (O > 0 && cfg->enable_dynamic_obstacles) ? O : 0);
     }
     s->wave_lds = ((((size_t)s->WL.total * (cfg->precision == MPC_FP32 ? 4 : 8)) + 15) & ~(size_t)15) + 16 +
                   ((cfg->precision == MPC_FP32 ? sizeof(mpc::Problem<float>) : sizeof(mpc::Problem<double>)) + 15 & ~(size_t)15) + sizeof(mpc::WaveLayout);
@@ -320,6 +323,7 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         if (er == hipSuccess) er = hipMalloc((void**)&s->d_onv, Bm * O * 4);
         if (er == hipSuccess) er = hipMalloc((void**)&s->d_ov, Bm * O * V * 2 * 8);
         if (er == hipSuccess) er = hipMalloc((void**)&s->d_or, Bm * O * 8);
+        if (er == hipSuccess && cfg->enable_dynamic_obstacles) er = hipMalloc((void**)&s->d_ovel, Bm * O * 2 * 8);
     }
     if (er != hipSuccess) {
         set_err("mpc_create: allocation", er);
@@ -336,7 +340,7 @@ void mpc_destroy(mpc_solver* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    void* bufs[] = {s->d_nvia, s->d_via, s->d_ngrid, s->d_ono, s->d_onv, s->d_ov, s->d_or, s->ws, s->d_x0, s->d_xf, s->d_up, s->d_dtp, s->d_xi, s->d_ui, s->d_dti, s->d_xo, s->d_uo, s->d_dto, s->d_status, s->d_iters};
+    void* bufs[] = {s->d_ovel, s->d_nvia, s->d_via, s->d_ngrid, s->d_ono, s->d_onv, s->d_ov, s->d_or, s->ws, s->d_x0, s->d_xf, s->d_up, s->d_dtp, s->d_xi, s->d_ui, s->d_dti, s->d_xo, s->d_uo, s->d_dto, s->d_status, s->d_iters};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -351,7 +355,7 @@ static hipError_t launch_model(mpc_solver* s, const mpc::Problem<T>& P, int B, c
                                const double* dtp, const double* xi, const double* ui, const double* dti, const mpc_obstacles& ob, double* xo, double* uo,
                                double* dto, int32_t* st, int32_t* it) {
     if (s->use_wave) {
-        const bool ext = P.ball || P.via || P.integral_form || (P.n_obst > 0 && (P.footprint_kind == MPC_FOOTPRINT_LINE || P.footprint_kind == MPC_FOOTPRINT_TWO_CIRCLES));
+        const bool ext = P.ball || P.via || P.integral_form || P.dyn_obst || (P.n_obst > 0 && (P.footprint_kind == MPC_FOOTPRINT_LINE || P.footprint_kind == MPC_FOOTPRINT_TWO_CIRCLES));
         auto kern = ext ? mpc_ipm_wave_kernel<T, MODEL, true> : mpc_ipm_wave_kernel<T, MODEL, false>;
         if (s->wave_lds > 48u * 1024u) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->wave_lds);
@@ -392,7 +396,7 @@ int mpc_solve_batch_device(mpc_solver* s, int32_t B, const double* d_x0, const d
     if (!s || !d_x0 || !d_xf || !d_x_out || !d_u_out || !d_dt_out) { set_err("mpc_solve_batch_device: null argument"); return MPC_EINVAL; }
     if (B <= 0) return MPC_OK;
     if (B > s->max_batch) { set_err("mpc_solve_batch_device: B exceeds max_batch"); return MPC_EBATCH; }
-    mpc_obstacles ob = {nullptr, nullptr, nullptr, nullptr};
+    mpc_obstacles ob = {nullptr, nullptr, nullptr, nullptr, nullptr};
     if (s->cfg.max_obstacles > 0) {
         if (!d_obstacles || !d_obstacles->n_obstacles || !d_obstacles->n_vertices || !d_obstacles->vertices) {
             set_err("mpc_solve_batch_device: the solver was created with max_obstacles > 0 but no obstacles were passed");
@@ -547,7 +551,7 @@ int mpc_solve_batch(mpc_solver* s, int32_t B, const double* x0, const double* xf
         HIP_TRY(hipMemcpyAsync(s->d_ui, u_init, b * n * 2 * 8, hipMemcpyHostToDevice, q));
         HIP_TRY(hipMemcpyAsync(s->d_dti, dt_init, b * 8, hipMemcpyHostToDevice, q));
     }
-    mpc_obstacles dob = {nullptr, nullptr, nullptr, nullptr};
+    mpc_obstacles dob = {nullptr, nullptr, nullptr, nullptr, nullptr};
     if (s->cfg.max_obstacles > 0) {
         if (!obstacles || !obstacles->n_obstacles || !obstacles->n_vertices || !obstacles->vertices) {
             set_err("mpc_solve_batch: the solver was created with max_obstacles > 0 but no obstacles were passed");
@@ -559,6 +563,10 @@ int mpc_solve_batch(mpc_solver* s, int32_t B, const double* x0, const double* xf
         HIP_TRY(hipMemcpyAsync(s->d_ov, obstacles->vertices, b * O * V * 2 * 8, hipMemcpyHostToDevice, q));
         if (obstacles->radius) HIP_TRY(hipMemcpyAsync(s->d_or, obstacles->radius, b * O * 8, hipMemcpyHostToDevice, q));
         dob.n_obstacles = s->d_ono; dob.n_vertices = s->d_onv; dob.vertices = s->d_ov; dob.radius = obstacles->radius ? s->d_or : nullptr;
+        if (obstacles->velocity && s->d_ovel) {
+            HIP_TRY(hipMemcpyAsync(s->d_ovel, obstacles->velocity, b * O * 2 * 8, hipMemcpyHostToDevice, q));
+            dob.velocity = s->d_ovel;
+        }
     }
     int rc = mpc_solve_batch_device(s, B, s->d_x0, s->d_xf, u_prev ? s->d_up : nullptr, dt_prev ? s->d_dtp : nullptr,
                                     warm ? s->d_xi : nullptr, warm ? s->d_ui : nullptr, warm ? s->d_dti : nullptr, &dob, s->d_xo,

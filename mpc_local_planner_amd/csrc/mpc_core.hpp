@@ -67,6 +67,7 @@ struct Problem {
     int n_obst, n_vert, obst_rows, footprint_kind;
     T d_min, force_incl, cutoff, fp_radius;
     T fp_line[4];        // line footprint: start, end in the robot frame
+    int dyn_obst;        // enable_dynamic_obstacles
     // terminal l2-ball row  xd' S xd - gamma <= 0  on the free final state (wave kernel only)
     int ball;
     T ball_S[3], ball_gamma;

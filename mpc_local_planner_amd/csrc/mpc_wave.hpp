@@ -41,9 +41,11 @@ struct WaveLayout {
     int M, O, V;                                  // clearance rows per grid point, obstacles, vertices per obstacle
     int OS, OY, OI, OG, OAX, OAY, OHK;            // per-row slack, multiplier, obstacle index, cached g, gradient, curvature
     int GV, GNV, GR, GC;                          // obstacle geometry: vertices, vertex counts, radii, centroids
-    int OAT, OHXT, OHYT, OHTT;                    // heading parts of the clearance rows (line footprint only: MT = M, else 0 words)
+    int OAT, OHXT, OHYT, OHTT;                    // third-variable parts of the clearance rows: heading (footprints that turn with the pose) or
+                                                  // dt (dynamic obstacles); MT = M when either is configured, else 0 words
+    int GVEL;                                     // obstacle velocities (dynamic obstacles; 2 * OD words)
     int NV, VIA, VIDX;                            // via-points: capacity, poses (x, y, theta), attached grid point (-1 = skipped)
-    __host__ __device__ static WaveLayout make(int n, int M = 0, int O = 0, int V = 1, int ntrig = 4, int NV = 0, int MT = 0) {
+    __host__ __device__ static WaveLayout make(int n, int M = 0, int O = 0, int V = 1, int ntrig = 4, int NV = 0, int MT = 0, int OD = 0) {
         WaveLayout L;
         L.n = n;
         L.NS = n;
@@ -65,6 +67,7 @@ struct WaveLayout {
         L.GV = o; o += 2 * O * V; L.GNV = o; o += O; L.GR = o; o += O; L.GC = o; o += 2 * O;
         L.NV = NV; L.VIA = o; o += 3 * NV; L.VIDX = o; o += NV;
         L.OAT = take(MT); L.OHXT = take(MT); L.OHYT = take(MT); L.OHTT = take(MT);
+        L.GVEL = o; o += 2 * OD;
         L.total = o;
         return L;
     }
@@ -156,7 +159,7 @@ struct IpmWave {
     bool warm_guess = false;     // the caller supplied an initial guess (second and later control cycles)
     mutable int cnt_mult = -1, cnt_bmult = -1;      // number of equality / bound multipliers (cached by kkt_pass)
     int nvia = 0;   // via-points of this instance
-    int flags;      // bits 0..2 xf_fixed, 3 dt_free, 4 quadratic objective, 5 has_Qf, 6..9 rate_on, 10 terminal ball, 11 via-points, 12 footprint that turns with the pose (line, two circles): the problem record lives in LDS and every
+    int flags;      // bits 0..2 xf_fixed, 3 dt_free, 4 quadratic objective, 5 has_Qf, 6..9 rate_on, 10 terminal ball, 11 via-points, 12 footprint that turns with the pose (line, two circles), 13 integral form with dt free, 14 dynamic obstacles: the problem record lives in LDS and every
                     // P.x costs a ds_read (+ wait) that the compiler cannot hoist over LDS stores; one scalar register holds the switches
 #ifdef MPC_PROFILE
     mutable long long prof_loop = 0, prof_setup = 0, prof_fwd_loop = 0;    // ticks inside the backward stage loop / before it / inside the forward loop
@@ -184,6 +187,7 @@ struct IpmWave {
     __device__ __forceinline__ bool via() const { return EXT && ((flags >> 11) & 1); }
     __device__ __forceinline__ bool fpline() const { return EXT && ((flags >> 12) & 1); }
     __device__ __forceinline__ bool intf() const { return EXT && ((flags >> 13) & 1); }     // integral-form cost, dt free
+    __device__ __forceinline__ bool dynobs() const { return EXT && ((flags >> 14) & 1); }
     // explicit LDS pointers for the running-pointer loops (address-space inference gives up on per-lane selected pointers)
     typedef __attribute__((address_space(3))) T LdsT;
     __device__ __forceinline__ LdsT* lds(int word) const { return (LdsT*)sm + word; }
@@ -342,9 +346,11 @@ struct IpmWave {
     }
 
     // copies the instance's obstacles into LDS, computes centroids (teb Obstacle::getCentroid)
-    __device__ __forceinline__ void load_obstacles(const int32_t* n_obst, const int32_t* n_vert, const double* verts, const double* radius, int inst) {
+    __device__ __forceinline__ void load_obstacles(const int32_t* n_obst, const int32_t* n_vert, const double* verts, const double* radius, const double* vel, int inst) {
         const int O = L.O, V = L.V;
         const int no = n_obst ? n_obst[inst] : 0;
+        if (EXT && P.dyn_obst)
+            for (int e = lane; e < 2 * O; e += kWave) sm[L.GVEL + e] = (vel && e / 2 < no) ? T(vel[(long)inst * O * 2 + e]) : T(0);
         for (int j = lane; j < O; j += kWave) {
             int nv = j < no ? n_vert[(long)inst * O + j] : 0;
             if (nv > V) nv = V;
@@ -387,8 +393,11 @@ struct IpmWave {
                 t_sincos(th, &s, &c);
                 T lmin = T(1e30), rmin = T(1e30);
                 int lidx = -1, ridx = -1;
+                if (dynobs())        // every dynamic obstacle is kept at every grid point (:99-106)
+                    for (int j = 0; j < L.O; ++j) if ((int)sm[L.GNV + j] > 0 && is_dynamic(j) && cnt < M) { F(L.OI, cnt, k) = T(j); ++cnt; }
                 for (int j = 0; j < L.O; ++j) {
                     if ((int)sm[L.GNV + j] <= 0) continue;
+                    if (is_dynamic(j)) continue;
                     T dist, nx, ny, hk;
                     if (fpline()) { T a3[3], h3[3]; dist = turn_eval(px, py, th, j, a3, hk, h3); }
                     else { obst_eval(px, py, j, dist, nx, ny, hk); dist -= P.fp_radius; }
@@ -467,8 +476,30 @@ struct IpmWave {
         ax = -nx; ay = -ny;
         return true;
     }
-    // same for a footprint that turns with the pose (line): adds the heading gradient and the heading parts of the Hessian
-    __device__ __forceinline__ bool obst_row3(int k, int m, T px, T py, T th, T& g, T a[3], T& hk, T h3[3]) const {
+    __device__ __forceinline__ bool is_dynamic(int j) const { return dynobs() && (sm[L.GVEL + 2 * j] != T(0) || sm[L.GVEL + 2 * j + 1] != T(0)); }
+    // dynamic obstacle j at grid point k (computeNonIntegralStateDtTerm, stage_inequality_se2.cpp:177-189): the obstacle moved by k dt v,
+    // i.e. the static evaluation at the point p - k dt v; a[2] = d g / d dt, h3 = hess g [x dt, y dt, dt dt] (chain rule, c linear in dt)
+    __device__ __forceinline__ void dyn_row(int k, int j, T px, T py, T d, T& g, T a[3], T& hk, T h3[3]) const {
+        const T kvx = T(k) * sm[L.GVEL + 2 * j], kvy = T(k) * sm[L.GVEL + 2 * j + 1];
+        T dist, nx, ny;
+        obst_eval(px - d * kvx, py - d * kvy, j, dist, nx, ny, hk);
+        g = P.d_min - (dist - P.fp_radius);
+        a[0] = -nx; a[1] = -ny;
+        const T nkv = nx * kvx + ny * kvy;
+        a[2] = nkv;                                                   // -(n . (-k v))
+        // hess dist [xy, d] = H_D (-k v), H_D = hk (I - n n');  hess g = -hess dist
+        const T hx = hk * (kvx - nx * nkv), hy = hk * (kvy - ny * nkv);
+        h3[0] = hx; h3[1] = hy; h3[2] = -(kvx * hx + kvy * hy);
+        if (!dtf()) { a[2] = T(0); h3[0] = h3[1] = h3[2] = T(0); }   // fixed grid: dt is not a variable
+    }
+    // same for a footprint that turns with the pose (line): adds the heading gradient and the heading parts of the Hessian; with dynamic
+    // obstacles the third slot carries the dt parts instead (d = dt of the evaluated point)
+    __device__ __forceinline__ bool obst_row3(int k, int m, T px, T py, T th, T& g, T a[3], T& hk, T h3[3], T d = T(0)) const {
+        if (dynobs()) {
+            const int j = (int)F(L.OI, m, k);
+            if (j < 0) return false;
+            if (is_dynamic(j)) { dyn_row(k, j, px, py, d, g, a, hk, h3); return true; }
+        }
         if (!fpline()) { a[2] = T(0); h3[0] = h3[1] = h3[2] = T(0); return obst_row(k, m, px, py, g, a[0], a[1], hk); }
         const int j = (int)F(L.OI, m, k);
         if (j < 0) return false;
@@ -479,6 +510,7 @@ struct IpmWave {
     __device__ __forceinline__ T obst_jdz(int k, int m) const {
         T j = F(L.OAX, m, k) * F(L.DX, 0, k) + F(L.OAY, m, k) * F(L.DX, 1, k);
         if (fpline()) j += F(L.OAT, m, k) * F(L.DX, 2, k);
+        if (dynobs()) j += F(L.OAT, m, k) * SCL(SC_DD);
         return j;
     }
 
@@ -495,7 +527,7 @@ struct IpmWave {
                 const T px = xt(0, k, al), py = xt(1, k, al), pth = fpline() ? xt(2, k, al) : T(0);
                 for (int m = 0; m < L.M; ++m) {
                     T g, a3[3], hk, h3[3];
-                    if (!obst_row3(k, m, px, py, pth, g, a3, hk, h3)) continue;
+                    if (!obst_row3(k, m, px, py, pth, g, a3, hk, h3, d)) continue;
                     T s = F(L.OS, m, k);
                     if (trial) s += alpha * (-(F(L.OG, m, k) + s) - obst_jdz(k, m));
                     th += t_abs(g + s);
@@ -702,16 +734,17 @@ struct IpmWave {
                     const T px = F(L.X, 0, k), py = F(L.X, 1, k);
                     for (int m = 0; m < L.M; ++m) {
                         T g, a3[3], hk, h3[3];
-                        if (!obst_row3(k, m, px, py, F(L.X, 2, k), g, a3, hk, h3)) continue;
+                        if (!obst_row3(k, m, px, py, F(L.X, 2, k), g, a3, hk, h3, d)) continue;
                         const T ax = a3[0], ay = a3[1];
                         F(L.OG, m, k) = g; F(L.OAX, m, k) = ax; F(L.OAY, m, k) = ay; F(L.OHK, m, k) = hk;
-                        if (fpline()) { F(L.OAT, m, k) = a3[2]; F(L.OHXT, m, k) = h3[0]; F(L.OHYT, m, k) = h3[1]; F(L.OHTT, m, k) = h3[2]; }
+                        if (fpline() || dynobs()) { F(L.OAT, m, k) = a3[2]; F(L.OHXT, m, k) = h3[0]; F(L.OHYT, m, k) = h3[1]; F(L.OHTT, m, k) = h3[2]; }
                         const T s = F(L.OS, m, k), y = F(L.OY, m, k);
                         const T res = g + s;
                         rp = t_max(rp, t_abs(res)); th += t_abs(res);
                         cmin = t_min(cmin, s * y); cmax = t_max(cmax, s * y);
                         sb += y; nb += 1;
-                        osx += y * ax; osy += y * ay; ost += y * a3[2];
+                        osx += y * ax; osy += y * ay;
+                        if (dynobs()) rdd += y * a3[2]; else ost += y * a3[2];
                     }
                 }
                 if (k >= 1) {
@@ -862,15 +895,21 @@ struct IpmWave {
                         sp.ott += sig * at * at + y * F(L.OHTT, m, k);
                         sp.ogt += at * ybar;
                     }
+                    if (dynobs()) {       // dt parts of the rows of dynamic obstacles (zero for the static ones)
+                        const T ad = F(L.OAT, m, k);
+                        sp.cxd[0] += sig * ax * ad + y * F(L.OHXT, m, k);
+                        sp.cxd[1] += sig * ay * ad + y * F(L.OHYT, m, k);
+                        sp.hdd += sig * ad * ad + y * F(L.OHTT, m, k);
+                        sp.gdt += ad * ybar;
+                    }
                 }
             }
             if (intf() && k < n - 1) {       // d/ddt and the mixed second derivatives of  dt * (xd'Q xd + u'R u)
                 const T xd0 = F(L.X, 0, k) - xf[0], xd1 = F(L.X, 1, k) - xf[1], xd2 = normalize_theta(F(L.X, 2, k) - xf[2]);
                 const T v = F(L.U, 0, k), w = F(L.U, 1, k);
-                sp.cxd[0] = T(2) * P.Q[0] * xd0; sp.cxd[1] = T(2) * P.Q[1] * xd1; sp.cxd[2] = T(2) * P.Q[2] * xd2;
+                if (k > 0) { sp.cxd[0] += T(2) * P.Q[0] * xd0; sp.cxd[1] += T(2) * P.Q[1] * xd1; sp.cxd[2] += T(2) * P.Q[2] * xd2; }   // x_0 is not a variable
                 sp.cud[0] = T(2) * P.R[0] * v; sp.cud[1] = T(2) * P.R[1] * w;
-                sp.gdt = P.Q[0] * xd0 * xd0 + P.Q[1] * xd1 * xd1 + P.Q[2] * xd2 * xd2 + P.R[0] * v * v + P.R[1] * w * w;
-                if (k == 0) { sp.cxd[0] = sp.cxd[1] = sp.cxd[2] = T(0); }      // x_0 is not a variable
+                sp.gdt += P.Q[0] * xd0 * xd0 + P.Q[1] * xd1 * xd1 + P.Q[2] * xd2 * xd2 + P.R[0] * v * v + P.R[1] * w * w;
             }
             if (via() && k >= 1 && k < n - 1) {
                 T vv, vg[3];
@@ -1253,7 +1292,7 @@ struct IpmWave {
                 t0 = delta * dx0 + S_(RA + A00, m) * dx0 + S_(RA + A01, m) * dx1 + S_(RA + A08, m);
                 t1 = delta * dx1 + S_(RA + A01, m) * dx0 + S_(RA + A11, m) * dx1 + S_(RA + A18, m);
                 t2 = delta * dx2 + S_(RA + A22, m) * dx2 + S_(RA + A26, m) * duv + S_(RA + A27, m) * duw + S_(RA + A25, m) * dd + S_(RA + A28, m);
-                if (intf()) { t0 += S_(RA + A05, m) * dd; t1 += S_(RA + A15, m) * dd; }
+                if (intf() || dynobs()) { t0 += S_(RA + A05, m) * dd; t1 += S_(RA + A15, m) * dd; }
                 if (fpline()) {        // position-heading coupling of the clearance rows
                     const T c02 = S_(RA + A02, m), c12 = S_(RA + A12, m);
                     t0 += c02 * dx2; t1 += c12 * dx2; t2 += c02 * dx0 + c12 * dx1;
@@ -1552,7 +1591,7 @@ struct IpmWave {
                 for (int m = 0; m < L.M; ++m) {
                     T s = T(1), y = T(0), g, a3[3], hk, h3[3];
                     if (k >= 1 && k < n - 1) {
-                        if (obst_row3(k, m, px, py, F(L.X, 2, k), g, a3, hk, h3)) { s = t_max(-g, Algo<T>::slack_push); y = mu / s; }
+                        if (obst_row3(k, m, px, py, F(L.X, 2, k), g, a3, hk, h3, d)) { s = t_max(-g, Algo<T>::slack_push); y = mu / s; }
                     } else F(L.OI, m, k) = T(-1);
                     F(L.OS, m, k) = s; F(L.OY, m, k) = y;
                 }
@@ -1582,7 +1621,7 @@ struct IpmWave {
     __device__ __forceinline__ SolveStats<T> solve() {
         SolveStats<T> out;
         flags = (P.xf_fixed[0] ? 1 : 0) | (P.xf_fixed[1] ? 2 : 0) | (P.xf_fixed[2] ? 4 : 0) | (P.dt_free ? 8 : 0) | (P.objective == OBJ_QUADRATIC ? 16 : 0) |
-                (P.has_Qf ? 32 : 0) | (P.rate_on[0] ? 64 : 0) | (P.rate_on[1] ? 128 : 0) | (P.rate_on[2] ? 256 : 0) | (P.rate_on[3] ? 512 : 0) | (P.ball ? 1024 : 0) | (P.via ? 2048 : 0) | ((P.n_obst > 0 && (P.footprint_kind == 2 || P.footprint_kind == 3)) ? 4096 : 0) | (P.integral_form ? 8192 : 0);
+                (P.has_Qf ? 32 : 0) | (P.rate_on[0] ? 64 : 0) | (P.rate_on[1] ? 128 : 0) | (P.rate_on[2] ? 256 : 0) | (P.rate_on[3] ? 512 : 0) | (P.ball ? 1024 : 0) | (P.via ? 2048 : 0) | ((P.n_obst > 0 && (P.footprint_kind == 2 || P.footprint_kind == 3)) ? 4096 : 0) | (P.integral_form ? 8192 : 0) | (P.dyn_obst ? 16384 : 0);
         flags = __builtin_amdgcn_readfirstlane(flags);
         nfix = (int)fx(0) + (int)fx(1) + (int)fx(2);
         row0_on = dtprev != T(0);

@@ -81,7 +81,7 @@ class BatchSolver:
     def solve(self, x0, xf, u_prev=None, dt_prev=None, init=None, obstacles=None) -> BatchResult:
         """One control cycle for B instances (Controller::step, src/controller.cpp:111-179).
         init = (x_init (B,n,3), u_init (B,n,2), dt_init (B,)) or None for the reference cold start.
-        obstacles = (n_obstacles (B,), n_vertices (B,O), vertices (B,O,V,2)[, radius (B,O)]) when the solver was
+        obstacles = (n_obstacles (B,), n_vertices (B,O), vertices (B,O,V,2)[, radius (B,O)[, velocity (B,O,2)]]) when the solver was
         created with max_obstacles > 0."""
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
         B = x0.shape[0]
@@ -106,10 +106,12 @@ class BatchSolver:
             nv = np.ascontiguousarray(obstacles[1], dtype=np.int32)
             vv = _as_f64(obstacles[2], (B, O, V, 2))
             rr = _as_f64(obstacles[3], (B, O)) if len(obstacles) > 3 and obstacles[3] is not None else None
+            vel = _as_f64(obstacles[4], (B, O, 2)) if len(obstacles) > 4 and obstacles[4] is not None else None
             if no.shape != (B,) or nv.shape != (B, O):
                 raise ValueError("obstacle arrays have the wrong shape")
-            keep = (no, nv, vv, rr)
-            ob = MpcObstacles(no.ctypes.data, nv.ctypes.data, vv.ctypes.data, rr.ctypes.data if rr is not None else None)
+            keep = (no, nv, vv, rr, vel)
+            ob = MpcObstacles(no.ctypes.data, nv.ctypes.data, vv.ctypes.data, rr.ctypes.data if rr is not None else None,
+                              vel.ctypes.data if vel is not None else None)
         rc = self._lib.mpc_solve_batch(self._h, B, _addr(x0), _addr(xf), _addr(u_prev), _addr(dt_prev), _addr(xi), _addr(ui),
                                        _addr(di), C.byref(ob) if ob is not None else None, _addr(xo), _addr(uo), _addr(do),
                                        _addr(st), _addr(it))
@@ -122,7 +124,7 @@ class BatchSolver:
                      status: Optional[int], iters: Optional[int], obstacles=None) -> None:
         """Asynchronous solve on the solver's stream; all arguments are device addresses (ints)."""
         v = lambda p: C.c_void_p(p) if p else None
-        ob = MpcObstacles(*obstacles) if obstacles is not None else None     # 4 device addresses
+        ob = MpcObstacles(*(tuple(obstacles) + (None,) * (5 - len(obstacles)))) if obstacles is not None else None     # up to 5 device addresses
         rc = self._lib.mpc_solve_batch_device(self._h, B, v(x0), v(xf), v(u_prev), v(dt_prev), v(x_init), v(u_init), v(dt_init),
                                               C.byref(ob) if ob is not None else None, v(x_out), v(u_out), v(dt_out), v(status),
                                               v(iters))

@@ -308,7 +308,7 @@ class SolverNlp:
     """Variables kept as full arrays X (n,3), U (n-1,2), dt; the free ones are
     indexed into a flat vector: [x_1 .. x_{n-2}, xf(free comps), u_0 .. u_{n-2}, dt(if free)]."""
 
-    def __init__(self, cfg: R.OcpConfig, inp: R.CycleInputs, relevant=None, via_idx=None):
+    def __init__(self, cfg: R.OcpConfig, inp: R.CycleInputs, relevant=None, via_idx=None, relevant_dyn=None):
         colloc_points(cfg.collocation)      # raises for an unknown method
         self.cfg, self.inp = cfg, inp
         self.via_idx = via_idx if via_idx is not None else []
@@ -355,9 +355,13 @@ class SolverNlp:
                 if cfg.du_ub[i] < R.INF:
                     self.rate_rows.append((k, i, +1))
         self.obst_rows = [(k, j) for k in range(1, n - 1) for j in self.relevant[k]]
+        # dynamic obstacles (stage_inequality_se2.cpp:99-106,177-189): a row per grid point and moving obstacle, evaluated against the
+        # obstacle predicted at t = k dt -- the row depends on dt
+        self.relevant_dyn = relevant_dyn if relevant_dyn is not None else [[] for _ in range(n)]
+        self.dyn_rows = [(k, j) for k in range(1, n - 1) for j in self.relevant_dyn[k]]
         # terminal l2-ball row on the free final state (final_state_conditions_se2.cpp:54-64; edge only when xf is not fixed)
         self.ball_row = cfg.terminal_ball_S is not None and any(not f for f in cfg.xf_fixed)
-        self.mg = len(self.rate_rows) + len(self.obst_rows) + (1 if self.ball_row else 0)
+        self.mg = len(self.rate_rows) + len(self.obst_rows) + len(self.dyn_rows) + (1 if self.ball_row else 0)
         self.mc = 3 * (n - 1)
 
     # ---- packing -----------------------------------------------------
@@ -509,6 +513,25 @@ class SolverNlp:
             if want_hess and y is not None:
                 W[np.ix_(self.ix[k], self.ix[k])] += y[r] * Hm
             r += 1
+        for (k, j) in self.dyn_rows:
+            # point / circular footprint against the obstacle moved by k dt v = the static row at the point p - k dt v (chain rule in dt)
+            ob = self.inp.obstacles[j]
+            vel = np.asarray(ob.velocity, float)
+            shifted = np.array([X[k, 0] - k * dt * vel[0], X[k, 1] - k * dt * vel[1], X[k, 2]])
+            val, gr, Hm = clearance_row(cfg, shifted, ob, want_hess)
+            g[r] = val
+            Jg[r, self.ix[k]] = gr
+            ad = float(gr[:2] @ (-k * vel))
+            if self.idt >= 0:
+                Jg[r, self.idt] = ad
+            if want_hess and y is not None:
+                W[np.ix_(self.ix[k], self.ix[k])] += y[r] * Hm
+                if self.idt >= 0:
+                    hxd = Hm[:2, :2] @ (-k * vel)
+                    W[self.ix[k][:2], self.idt] += y[r] * hxd
+                    W[self.idt, self.ix[k][:2]] += y[r] * hxd
+                    W[self.idt, self.idt] += y[r] * float((-k * vel) @ hxd)
+            r += 1
         if self.ball_row:
             S = np.asarray(cfg.terminal_ball_S, float)
             xd = X[n - 1] - xf
@@ -609,7 +632,7 @@ def controls_from_states(cfg: R.OcpConfig, init: R.Trajectory) -> R.Trajectory:
 
 
 def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=None,
-          opt: Optional[IpmOptions] = None, dual_start: Optional[IpmResult] = None) -> IpmResult:
+          opt: Optional[IpmOptions] = None, dual_start: Optional[IpmResult] = None, relevant_dyn=None) -> IpmResult:
     """dual_start: result of the previous control cycle of the same problem structure.  Its multipliers are carried over
     (moving-horizon warm start of the duals): every inequality / bound multiplier is max(previous value, mu0 / slack) so
     that no complementarity product starts below the barrier parameter; slacks are re-derived from the new point; the
@@ -617,7 +640,7 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
     opt = opt or IpmOptions()
     # via-point association from the vertex values the solve starts from (MinTimeViaPointsCost::update runs in the grid update, before the solve)
     via_idx = R.associate_via_points(cfg, init.x, inp.via_points) if cfg.objective == R.OBJ_MIN_TIME_VIA_POINTS else None
-    nlp = SolverNlp(cfg, inp, relevant, via_idx)
+    nlp = SolverNlp(cfg, inp, relevant, via_idx, relevant_dyn)
     nv, mc, mg = nlp.nv, nlp.mc, nlp.mg
     lb, ub = nlp.lb, nlp.ub
     hasL = lb > -R.INF

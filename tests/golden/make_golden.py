@@ -65,7 +65,7 @@ def make_obstacles(name, n=30, B=10, O=6, V=6, M=4, keep=6):
     print(name, "kept", len(sel), "iters", IT)
 
 
-if __name__ == "__main__" and "--warm" not in sys.argv and "--integral" not in sys.argv and "--closed-loop" not in sys.argv and "--config3" not in sys.argv and "--midpoint" not in sys.argv and "--cn" not in sys.argv and "--ball" not in sys.argv and "--via" not in sys.argv and "--line" not in sys.argv and "--two" not in sys.argv and "--integral-free" not in sys.argv:
+if __name__ == "__main__" and "--warm" not in sys.argv and "--integral" not in sys.argv and "--closed-loop" not in sys.argv and "--config3" not in sys.argv and "--midpoint" not in sys.argv and "--cn" not in sys.argv and "--ball" not in sys.argv and "--via" not in sys.argv and "--line" not in sys.argv and "--two" not in sys.argv and "--integral-free" not in sys.argv and "--dynamic" not in sys.argv:
     make_obstacles("unicycle_quadratic_obstacles_n30")
     make("carlike_min_time_n50", R.config_carlike_min_time(50), W.carlike_min_time_inputs(32, seed=101), keep=8)
     make("carlike_min_time_n20", R.config_carlike_min_time(20), W.carlike_min_time_inputs(32, seed=102, goal_range=(1.0, 2.5)), keep=8)
@@ -406,3 +406,41 @@ def make_integral_free_dt(name, n=20, B=16, keep=6):
 
 if __name__ == "__main__" and "--integral-free" in sys.argv:
     make_integral_free_dt("unicycle_quadratic_integral_free_dt_n20")
+
+
+def make_dynamic_obstacles(name, n=30, B=12, keep=6, M=4, O=3):
+    """a22: dynamic obstacles (stage_inequality_se2.cpp:99-106,177-189) in the car-like min-time problem: a circular obstacle that crosses the
+    path with constant velocity (its row at grid point k is evaluated at the predicted position for t = k dt, so the row depends on dt)
+    and a static point obstacle.  Every kept instance is re-checked in the reference-form rows (ReferenceNlp with relevant_dyn)."""
+    cfg = R.config_carlike_min_time(n)
+    cfg.enable_dynamic_obstacles, cfg.min_obstacle_dist, cfg.force_inclusion_dist, cfg.cutoff_dist = True, 0.3, 0.5, 2.5
+    x0, xf, up, dtp = W.carlike_min_time_inputs(B, seed=181, goal_range=(2.5, 4.0))
+    rows = []
+    for i in range(B):
+        if len(rows) >= keep:
+            break
+        d = xf[i, :2] - x0[i, :2]
+        t = d / np.hypot(*d)
+        nrm = np.array([-t[1], t[0]])
+        verts = np.zeros((O, 1, 2)); rad = np.zeros(O); vel = np.zeros((O, 2))
+        verts[0, 0] = x0[i, :2] + 0.5 * d + 1.0 * nrm; rad[0] = 0.15; vel[0] = -0.12 * nrm            # moving circle
+        verts[1, 0] = x0[i, :2] + 0.25 * d - 0.5 * nrm                                                # static point
+        obs = [R.Obstacle(R.OBST_CIRCLE, verts[0], radius=0.15, velocity=vel[0]), R.Obstacle(R.OBST_POINT, verts[1])]
+        inp = R.CycleInputs(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=float(dtp[i]), obstacles=obs)
+        init = R.cold_start(cfg, x0[i], xf[i])
+        rel, reld = R.associate_obstacles(cfg, init, obs, max_rows=M - 1)          # the device keeps dynamic rows first, M rows in total
+        ref = I.solve(cfg, inp, init, relevant=rel, relevant_dyn=reld, opt=I.IpmOptions(globalization="merit", max_iter=100))
+        if ref.status != 0 or ref.iters > 60:
+            continue
+        nlp = R.ReferenceNlp(cfg, inp, relevant=rel, relevant_dyn=reld)
+        z = nlp.pack(ref.traj)
+        assert np.abs(nlp.equalities(z)).max() < 1e-7 and nlp.inequalities(z).max() < 1e-7
+        dmin = min(R.footprint_distance(cfg.footprint_kind, cfg.footprint_params, ref.traj.x[k], obs[0], k * ref.traj.dt) for k in range(1, n - 1))
+        rows.append(dict(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=dtp[i], n_obstacles=2, n_vertices=np.array([1, 1, 0]), vertices=verts, radius=rad,
+                         velocity=vel, x=ref.traj.x, u=np.vstack([ref.traj.u, ref.traj.u[-1:]]), dt=ref.traj.dt, iters=ref.iters, dmin=dmin))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), max_rows=M, **{k: np.array([r[k] for r in rows]) for k in rows[0]})
+    print(name, "kept", len(rows), "iters", [r["iters"] for r in rows], "min distance to the moving obstacle", [round(float(r["dmin"]), 4) for r in rows])
+
+
+if __name__ == "__main__" and "--dynamic" in sys.argv:
+    make_dynamic_obstacles("carlike_dynamic_obstacles_n30")

@@ -62,7 +62,7 @@ int main() {
     const int32_t n_obst[1] = {3};
     const int32_t n_vert[3] = {1, 1, 1};
     const double verts[6] = {-3.0, 1.0, 6.0, 2.0, 4.0, 0.1};
-    mpc_obstacles ob = {n_obst, n_vert, verts, nullptr};
+    mpc_obstacles ob = {n_obst, n_vert, verts, nullptr, nullptr};
     ctl.setObstacles(&ob);
     PoseSE2 pose{0, 0, 0}, goal{5, 2, 0};
     Twist vel;

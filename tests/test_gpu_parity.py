@@ -659,3 +659,32 @@ def test_integral_form_free_dt_golden(m):
     assert same.sum() >= B - 1 and (err[same] < 1e-6).all() and (err < 1e-4).all()
     assert np.abs(r.dt - g["dt"]).max() < 1e-6
     s.close()
+
+
+def test_dynamic_obstacles_golden(m):
+    """a22 computeNonIntegralStateDtTerm (stage_inequality_se2.cpp:177-189) + the 'always kept' association of dynamic obstacles (:99-106):
+    a circular obstacle crossing the path with constant velocity (row at grid point k against the position predicted for t = k dt -> dt
+    enters gradient and Hessian of the row) and a static point obstacle; car-like min-time, dt free.  Fixture: make_golden.py --dynamic
+    (all instances end with the moving obstacle's row binding)."""
+    from oracle import se2_nlp as R
+    g = np.load(os.path.join(GOLD, "carlike_dynamic_obstacles_n30.npz"))
+    B, O = g["x0"].shape[0], g["vertices"].shape[1]
+    cfg = m.config_carlike_min_time(30, enable_dynamic_obstacles=True, min_obstacle_dist=0.3, force_inclusion_dist=0.5, cutoff_dist=2.5,
+                                    max_obstacles=O, max_vertices=1, max_obstacle_rows=int(g["max_rows"]))
+    s = m.BatchSolver(cfg, max_batch=B)
+    r = s.solve(g["x0"], g["xf"], g["u_prev"], g["dt_prev"], obstacles=(g["n_obstacles"], g["n_vertices"], g["vertices"], g["radius"], g["velocity"]))
+    assert (r.status == 0).all()
+    err = np.maximum(np.abs(r.x - g["x"]).reshape(B, -1).max(1), np.abs(r.u - g["u"]).reshape(B, -1).max(1))
+    same = r.iters == g["iters"]
+    assert same.sum() >= B - 1 and (err[same] < 1e-6).all() and (err < 1e-4).all()
+    assert np.abs(r.dt - g["dt"]).max() < 1e-5
+    for i in range(B):          # clearance to the MOVING obstacle along the solved trajectory, reference-form distance at t = k dt
+        ob = R.Obstacle(R.OBST_CIRCLE, g["vertices"][i, 0], radius=float(g["radius"][i, 0]), velocity=g["velocity"][i, 0])
+        dmin = min(R.footprint_distance(R.FOOTPRINT_POINT, (), r.x[i, k], ob, k * r.dt[i]) for k in range(1, 29))
+        assert abs(dmin - 0.3) < 1e-5
+    # the same obstacles frozen (velocity ignored): a different, faster trajectory
+    s2 = m.BatchSolver(m.config_carlike_min_time(30, min_obstacle_dist=0.3, force_inclusion_dist=0.5, cutoff_dist=2.5, max_obstacles=O, max_vertices=1,
+                                                 max_obstacle_rows=int(g["max_rows"])), max_batch=B)
+    q = s2.solve(g["x0"], g["xf"], g["u_prev"], g["dt_prev"], obstacles=(g["n_obstacles"], g["n_vertices"], g["vertices"], g["radius"]))
+    assert (np.abs(q.x - r.x).reshape(B, -1).max(1) > 1e-3).all()
+    s.close(); s2.close()
