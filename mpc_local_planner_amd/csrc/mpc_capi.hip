@@ -178,6 +178,13 @@ struct mpc_solver {
     bool timed;
 };
 
+// which kernel instantiation serves this solver: the one with the rarely used rows / terms / coupling slots, or the headline one
+static bool solver_ext(const mpc_solver* s) {
+    const mpc::Problem<double>& P = s->P64;
+    return P.ball || P.via || P.integral_form || P.dyn_obst ||
+           (P.n_obst > 0 && (P.footprint_kind == MPC_FOOTPRINT_LINE || P.footprint_kind == MPC_FOOTPRINT_TWO_CIRCLES));
+}
+
 extern "C" {
 
 void mpc_config_defaults(mpc_config* c) {
@@ -266,7 +273,7 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
                           (cfg->collocation == MPC_COLLOC_CRANK_NICOLSON ? 2 : 0);
         s->WL = mpc::WaveLayout::make(cfg->n, M, O, cfg->max_vertices > 0 ? cfg->max_vertices : 1, ntrig, s->P64.n_via,
                                         (O > 0 && (cfg->footprint_kind == MPC_FOOTPRINT_LINE || cfg->footprint_kind == MPC_FOOTPRINT_TWO_CIRCLES || cfg->enable_dynamic_obstacles)) ? M : 0,
-                                        (O > 0 && cfg->enable_dynamic_obstacles) ? O : 0);
+                                        (O > 0 && cfg->enable_dynamic_obstacles) ? O : 0, solver_ext(s) ? mpc::NSTG_EXT : mpc::NSTG_BASE);
     }
     s->wave_lds = ((((size_t)s->WL.total * (cfg->precision == MPC_FP32 ? 4 : 8)) + 15) & ~(size_t)15) + 16 +
                   ((cfg->precision == MPC_FP32 ? sizeof(mpc::Problem<float>) : sizeof(mpc::Problem<double>)) + 15 & ~(size_t)15) + sizeof(mpc::WaveLayout);
@@ -355,7 +362,7 @@ static hipError_t launch_model(mpc_solver* s, const mpc::Problem<T>& P, int B, c
                                const double* dtp, const double* xi, const double* ui, const double* dti, const mpc_obstacles& ob, double* xo, double* uo,
                                double* dto, int32_t* st, int32_t* it) {
     if (s->use_wave) {
-        const bool ext = P.ball || P.via || P.integral_form || P.dyn_obst || (P.n_obst > 0 && (P.footprint_kind == MPC_FOOTPRINT_LINE || P.footprint_kind == MPC_FOOTPRINT_TWO_CIRCLES));
+        const bool ext = solver_ext(s);
         auto kern = ext ? mpc_ipm_wave_kernel<T, MODEL, true> : mpc_ipm_wave_kernel<T, MODEL, false>;
         if (s->wave_lds > 48u * 1024u) {
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->wave_lds);

@@ -499,9 +499,10 @@ MPC_HD void stage_map(const Problem<T>& P, const T tr[4], const T tr2[2], T v, T
 // dt-box/objective terms that live at stage 0.
 enum StageAdd {
     A00 = 0, A01, A11, A22, A25, A26, A27, A33, A35, A36, A44, A45, A47, A55, A56, A57, A66, A67, A77,   // Hessian (19)
-    A02, A12,                                                                                            // position-heading coupling (clearance rows of a line footprint)
-    A05, A15,                                                                                            // position-dt coupling (integral-form cost on the variable grid)
     A08, A18, A28, A38, A48, A58, A68, A78,                                                              // gradient (8)
+    NADD_BASE,                                                                                           // the headline configurations stop here (27 entries)
+    A02 = NADD_BASE, A12,                                                                                // position-heading coupling (clearance rows of a footprint that turns with the pose)
+    A05, A15,                                                                                            // position-dt coupling (integral-form cost on the variable grid, dynamic obstacles)
     NADD
 };
 

@@ -29,9 +29,10 @@ __device__ long long g_mpc_prof[4096][16];
 namespace mpc {
 
 constexpr int kWave = 64;
-// per-stage LQ record: 0..2 a0 a1 1 | 3..5 f | 6..8 Bx[:,0] | 9..11 Bx[:,1] | 12..42 combined stage cost A[StageAdd]
-constexpr int NSTG = 43;
+// per-stage LQ record: 0..2 a0 a1 1 | 3..5 f | 6..8 Bx[:,0] | 9..11 Bx[:,1] | 12.. combined stage cost A[StageAdd] (27 entries, 31 with the extra coupling slots)
 constexpr int RA = 12;     // first A slot (words 0..11: a0 a1 1 | f | Bx[:,0] | Bx[:,1])
+constexpr int NSTG_EXT = RA + NADD;         // 43: record of the kernel instantiation with the extra coupling slots (A02 A12 A05 A15)
+constexpr int NSTG_BASE = RA + NADD_BASE;   // 39: record of the headline kernel (odd strides: conflict-free for lane == stage)
 constexpr int NGAIN = 20;  // negated gains: nK0(6) nkappa0 nKnu0(3) | nK1(6) nkappa1 nKnu1(3)
 
 struct WaveLayout {
@@ -45,7 +46,7 @@ struct WaveLayout {
                                                   // dt (dynamic obstacles); MT = M when either is configured, else 0 words
     int GVEL;                                     // obstacle velocities (dynamic obstacles; 2 * OD words)
     int NV, VIA, VIDX;                            // via-points: capacity, poses (x, y, theta), attached grid point (-1 = skipped)
-    __host__ __device__ static WaveLayout make(int n, int M = 0, int O = 0, int V = 1, int ntrig = 4, int NV = 0, int MT = 0, int OD = 0) {
+    __host__ __device__ static WaveLayout make(int n, int M = 0, int O = 0, int V = 1, int ntrig = 4, int NV = 0, int MT = 0, int OD = 0, int nstg = NSTG_BASE) {
         WaveLayout L;
         L.n = n;
         L.NS = n;
@@ -58,7 +59,7 @@ struct WaveLayout {
         L.PL = take(2); L.PU = take(2);
         L.DX = take(3); L.DU = take(2);
         L.CC = take(3); L.TRIG = take(ntrig);
-        L.GAIN = take(NGAIN); L.STG = take(NSTG);
+        L.GAIN = take(NGAIN); L.STG = take(nstg);
         L.SC = o; o += 16;    // scalars: D, DT, DD, PDL, PDU | terminal-ball row: slack, multiplier, cached value and gradient
         L.VP = o; o += 16;    // dummy store targets of the idle lanes in the sweeps
         L.ZC = o; o += 8;     // constants 0 0 0 0 1 0 0 0 (coefficient triples of the constant columns)
@@ -78,12 +79,12 @@ enum { SC_D = 0, SC_DT = 1, SC_DD = 2, SC_PDL = 3, SC_PDU = 4, SC_TS = 5, SC_TY 
 // A slot (StageAdd) of the entry (r, c) of the symmetric 8x8 stage cost block [x(3) u_prev(2) dt u(2)] and of its gradient
 // column c = 8; -1 where the block is structurally zero.  Packed per row as 12 x 5 bits (slot + 1) so that a lane looks its
 // column up with one 64-bit shift instead of a cascade of divergent branches.
-constexpr int stage_add_slot(int r, int c) {
+constexpr int stage_add_slot(int r, int c, bool ext) {
     if (c == 8) return A08 + r;
     if (c > 8) return -1;
     const int a = r < c ? r : c, b = r < c ? c : r;
-    if (a == 0) return b == 0 ? A00 : (b == 1 ? A01 : (b == 2 ? A02 : (b == 5 ? A05 : -1)));
-    if (a == 1) return b == 1 ? A11 : (b == 2 ? A12 : (b == 5 ? A15 : -1));
+    if (a == 0) return b == 0 ? A00 : (b == 1 ? A01 : (b == 2 && ext ? A02 : (b == 5 && ext ? A05 : -1)));
+    if (a == 1) return b == 1 ? A11 : (b == 2 && ext ? A12 : (b == 5 && ext ? A15 : -1));
     if (a == 2) return b == 2 ? A22 : (b == 5 ? A25 : (b == 6 ? A26 : (b == 7 ? A27 : -1)));
     if (a == 3) return b == 3 ? A33 : (b == 5 ? A35 : (b == 6 ? A36 : -1));
     if (a == 4) return b == 4 ? A44 : (b == 5 ? A45 : (b == 7 ? A47 : -1));
@@ -91,9 +92,9 @@ constexpr int stage_add_slot(int r, int c) {
     if (a == 6) return b == 6 ? A66 : (b == 7 ? A67 : -1);
     return b == 7 ? A77 : -1;
 }
-constexpr unsigned long long stage_add_row(int r) {
+constexpr unsigned long long stage_add_row(int r, bool ext) {
     unsigned long long v = 0;
-    for (int c = 0; c < 12; ++c) v |= (unsigned long long)(stage_add_slot(r, c) + 1) << (5 * c);
+    for (int c = 0; c < 12; ++c) v |= (unsigned long long)(stage_add_slot(r, c, ext) + 1) << (5 * c);
     return v;
 }
 
@@ -172,6 +173,8 @@ struct IpmWave {
     __device__ __forceinline__ T& F(int base, int comp, int k) const { return sm[base + comp * L.NS + k]; }
     // stage-major records
     __device__ __forceinline__ T& G_(int i, int k) const { return sm[L.GAIN + k * NGAIN + i]; }
+    static constexpr int NSTG = EXT ? NSTG_EXT : NSTG_BASE;        // words per stage record
+    static constexpr int NADDv = EXT ? (int)NADD : (int)NADD_BASE;
     __device__ __forceinline__ T& S_(int i, int k) const { return sm[L.STG + k * NSTG + i]; }
     __device__ __forceinline__ T& C_(int i, int k) const { return sm[L.CC + k * 3 + i]; }
     __device__ __forceinline__ T& SCL(int i) const { return sm[L.SC + i]; }
@@ -920,7 +923,7 @@ struct IpmWave {
             T A[NADD];
             assemble_adds(sp, q2, r2, A);
 #pragma unroll
-            for (int i = 0; i < NADD; ++i) S_(RA + i, k) = A[i];
+            for (int i = 0; i < NADDv; ++i) S_(RA + i, k) = A[i];
         }
     }
 
@@ -977,8 +980,8 @@ struct IpmWave {
         const LdsT* gp = lds(gb + (n - 2) * gs);
         const LdsT* ap[8];
         int as_[8];
-        constexpr unsigned long long rows[8] = {stage_add_row(0), stage_add_row(1), stage_add_row(2), stage_add_row(3),
-                                                stage_add_row(4), stage_add_row(5), stage_add_row(6), stage_add_row(7)};
+        constexpr unsigned long long rows[8] = {stage_add_row(0, EXT), stage_add_row(1, EXT), stage_add_row(2, EXT), stage_add_row(3, EXT),
+                                                stage_add_row(4, EXT), stage_add_row(5, EXT), stage_add_row(6, EXT), stage_add_row(7, EXT)};
         const int sh = act ? 5 * c : 60;               // idle lanes: shift the row word out (slot -1)
         const int abase = L.STG + RA - 1 + (n - 2) * NSTG;
 #pragma unroll
