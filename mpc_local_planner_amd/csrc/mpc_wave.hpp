@@ -316,7 +316,8 @@ struct IpmWave {
     }
 
     // ---------------------------------------------------------------- clearance rows
-    // distance of the point (px,py) to obstacle j (teb semantics: point / segment / polygon, 0 inside a polygon);
+    // distance of the point (px,py) to obstacle j (teb semantics: point / segment / closed polygon edge loop -- no inside test, as
+    // distance_point_to_polygon_2d);
     // returns dist (>= 0, obstacle radius already subtracted), unit normal from the closest point to (px,py) and
     // hk = 1/|p-q| if the closest feature is a vertex (or a point/circle obstacle), 0 on an edge interior.
     __device__ __forceinline__ void obst_eval(T px, T py, int j, T& dist, T& nx, T& ny, T& hk) const {
@@ -326,7 +327,6 @@ struct IpmWave {
         bool vert = true;
         if (nv <= 1) { bx = v[0]; by = v[1]; T dx = px - bx, dy = py - by; best = dx * dx + dy * dy; }
         else {
-            bool inside = false;
             const int ne = nv == 2 ? 1 : nv;
             for (int e = 0; e < ne; ++e) {
                 const int e2 = (e + 1) % nv;
@@ -338,9 +338,7 @@ struct IpmWave {
                 const T qx = ax + t * abx, qy = ay + t * aby;
                 const T d2 = (px - qx) * (px - qx) + (py - qy) * (py - qy);
                 if (d2 < best) { best = d2; bx = qx; by = qy; vert = !(t > T(0) && t < T(1)); }
-                if (nv >= 3 && ((ay > py) != (cy > py)) && (px < (cx - ax) * (py - ay) / (cy - ay) + ax)) inside = !inside;
             }
-            if (inside) { dist = T(0); nx = T(0); ny = T(0); hk = T(0); return; }
         }
         const T dd = sqrt(best);
         if (dd > T(0)) { nx = (px - bx) / dd; ny = (py - by) / dd; hk = vert ? T(1) / dd : T(0); }

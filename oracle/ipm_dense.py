@@ -175,7 +175,7 @@ def _closest_point_on_obstacle(pt, ob: R.Obstacle):
         segs = [(v[0], v[1])]
         inside = False
     else:
-        inside = R._point_in_polygon(pt, v)
+        inside = False          # teb: distance to the boundary also for a point inside the polygon (no inside test)
         segs = [(v[i], v[(i + 1) % len(v)]) for i in range(len(v))]
     best, bd = None, float("inf")
     for a, b in segs:

@@ -269,8 +269,8 @@ static double row_val_at(const work_t* w, const double* U, double D, int r, int 
 /* c_k, objective at a point */
 
 /* ---------------------------------------------------------------- clearance rows
- * distance of (px,py) to obstacle j with the teb semantics the reference links against (point / segment / closed polygon, 0 inside
- * a polygon; an optional radius turns a 1-vertex obstacle into a circle): dist >= 0 before the radius is subtracted, unit normal
+ * distance of (px,py) to obstacle j with the teb semantics the reference links against (point / segment / closed polygon edge loop, no
+ * inside test; an optional radius turns a 1-vertex obstacle into a circle): dist >= 0 before the radius is subtracted, unit normal
  * from the closest point to (px,py), hk = 1/|p-q| where the closest feature is a vertex (0 on an edge interior). */
 static int obst_M(const work_t* w) { return w->ob ? w->ob->max_rows : 0; }
 static void obst_eval(const work_t* w, double px, double py, int j, double* dist, double* nx, double* ny, double* hk) {
@@ -281,8 +281,7 @@ static void obst_eval(const work_t* w, double px, double py, int j, double* dist
     int vert = 1;
     if (nv <= 1) { bx = v[0]; by = v[1]; best = (px - bx) * (px - bx) + (py - by) * (py - by); }
     else {
-        int inside = 0;
-        const int ne = nv == 2 ? 1 : nv;
+        const int ne = nv == 2 ? 1 : nv;        /* closed edge loop, no inside test (teb distance_point_to_polygon_2d) */
         for (int e = 0; e < ne; ++e) {
             const int e2 = (e + 1) % nv;
             const double ax = v[2 * e], ay = v[2 * e + 1], cx = v[2 * e2], cy = v[2 * e2 + 1];
@@ -292,9 +291,7 @@ static void obst_eval(const work_t* w, double px, double py, int j, double* dist
             const double qx = ax + t * abx, qy = ay + t * aby;
             const double d2 = (px - qx) * (px - qx) + (py - qy) * (py - qy);
             if (d2 < best) { best = d2; bx = qx; by = qy; vert = !(t > 0 && t < 1); }
-            if (nv >= 3 && ((ay > py) != (cy > py)) && (px < (cx - ax) * (py - ay) / (cy - ay) + ax)) inside = !inside;
         }
-        if (inside) { *dist = 0; *nx = 0; *ny = 0; *hk = 0; return; }
     }
     const double dd = sqrt(best);
     if (dd > 0) { *nx = (px - bx) / dd; *ny = (py - by) / dd; *hk = vert ? 1.0 / dd : 0.0; }

@@ -224,13 +224,12 @@ def _dist_point_obstacle(pt, ob: Obstacle):
         return float(np.linalg.norm(pt - v[0])) - ob.radius
     if ob.kind == OBST_LINE:
         return _dist_point_segment(pt, v[0], v[1])
-    # polygon: 0 inside, else min over closed edge loop
+    # polygon: teb distance_point_to_polygon_2d = min over the closed edge loop (NO inside test: a point inside a polygon gets its
+    # distance to the boundary, as PolygonObstacle::getMinimumDistance returns it)
     if len(v) == 1:
         return float(np.linalg.norm(pt - v[0]))
     if len(v) == 2:
         return _dist_point_segment(pt, v[0], v[1])
-    if _point_in_polygon(pt, v):
-        return 0.0
     return min(_dist_point_segment(pt, v[i], v[(i + 1) % len(v)]) for i in range(len(v)))
 
 
