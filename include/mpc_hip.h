@@ -51,7 +51,8 @@ enum mpc_objective {                  /* src/controller.cpp:551-640 */
 enum mpc_precision { MPC_FP64 = 0, MPC_FP32 = 1 };
 enum mpc_footprint { MPC_FOOTPRINT_POINT = 0, MPC_FOOTPRINT_CIRCLE = 1,
                      MPC_FOOTPRINT_LINE = 2,        /* teb LineRobotFootprint; point and circular obstacles (what the costmap yields) */
-                     MPC_FOOTPRINT_TWO_CIRCLES = 3  /* teb TwoCirclesRobotFootprint; every obstacle kind */ };
+                     MPC_FOOTPRINT_TWO_CIRCLES = 3, /* teb TwoCirclesRobotFootprint; every obstacle kind */
+                     MPC_FOOTPRINT_POLYGON = 4      /* teb PolygonRobotFootprint; point and circular obstacles */ };
 
 enum mpc_status {                     /* per-instance result; 0 == what corbo reports as Converged */
     MPC_CONVERGED = 0,
@@ -96,7 +97,7 @@ typedef struct mpc_config {
     double  min_obstacle_dist;        /* collision_avoidance/min_obstacle_dist */
     double  force_inclusion_dist;     /* .../force_inclusion_dist */
     double  cutoff_dist;              /* .../cutoff_dist */
-    int32_t footprint_kind;           /* MPC_FOOTPRINT_POINT | _CIRCLE | _LINE | _TWO_CIRCLES */
+    int32_t footprint_kind;           /* MPC_FOOTPRINT_POINT | _CIRCLE | _LINE | _TWO_CIRCLES | _POLYGON */
     double  footprint_radius;         /* circular footprint radius */
     int32_t max_obstacles;            /* O: obstacles per instance the solver is sized for (0 = none) */
     int32_t max_vertices;             /* V: vertices per obstacle (1 point, 2 line, >=3 polygon) */
@@ -112,6 +113,8 @@ typedef struct mpc_config {
                                        * (src/optimal_control/min_time_via_points_cost.cpp:139-142) */
     int32_t via_points_ordered;       /* .../via_points_ordered  (:605) */
     int32_t max_via_points;           /* via-points per instance the solver is sized for (objective MIN_TIME_VIA_POINTS; <= 64) */
+    int32_t footprint_n_vertices;     /* MPC_FOOTPRINT_POLYGON: footprint_model/vertices (<= 16), robot frame */
+    double  footprint_vertices[32];   /* x0, y0, x1, y1, ... */
     int32_t enable_dynamic_obstacles; /* collision_avoidance/enable_dynamic_obstacles (src/controller.cpp:721); point / circular footprint */
     double  footprint_params[4];      /* MPC_FOOTPRINT_LINE: footprint_model/line_start (x, y), line_end (x, y) in the robot frame;
                                        * MPC_FOOTPRINT_TWO_CIRCLES: front_offset, front_radius, rear_offset, rear_radius (src/mpc_local_planner_ros.cpp:900-960) */

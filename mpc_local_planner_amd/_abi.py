@@ -77,6 +77,8 @@ class MpcConfig(C.Structure):
         ("vp_orientation_weight", C.c_double),
         ("via_points_ordered", C.c_int32),
         ("max_via_points", C.c_int32),
+        ("footprint_n_vertices", C.c_int32),
+        ("footprint_vertices", C.c_double * 32),
         ("enable_dynamic_obstacles", C.c_int32),
         ("footprint_params", C.c_double * 4),
         ("reserved", C.c_int32 * 6),
@@ -101,7 +103,7 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
                 footprint_kind=0, footprint_radius=0.0, max_obstacles=0, max_vertices=1, max_obstacle_rows=4, mu_init_warm=0.0, collocation=COLLOC_FORWARD,
                 terminal_ball_S=None, terminal_ball_gamma=1.0, vp_position_weight=1e-3, vp_orientation_weight=0.0,
                 via_points_ordered=False, max_via_points=0, footprint_params=(0.0, 0.0, 0.0, 0.0),
-                enable_dynamic_obstacles=False) -> MpcConfig:
+                enable_dynamic_obstacles=False, footprint_vertices=()) -> MpcConfig:
     c = MpcConfig()
     c.model = model
     mp = list(model_params) + [0.0] * 4
@@ -140,6 +142,12 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
     for i in range(4):
         c.footprint_params[i] = footprint_params[i]
     c.enable_dynamic_obstacles = int(bool(enable_dynamic_obstacles))
+    fv = []
+    for row in footprint_vertices:          # flat (x0, y0, x1, ...) or nested ((x0, y0), ...)
+        fv.extend([float(v) for v in row] if hasattr(row, "__len__") else [float(row)])
+    c.footprint_n_vertices = len(fv) // 2
+    for i, x in enumerate(fv[:32]):
+        c.footprint_vertices[i] = x
     return c
 
 

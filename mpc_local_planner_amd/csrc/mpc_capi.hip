@@ -182,7 +182,7 @@ struct mpc_solver {
 static bool solver_ext(const mpc_solver* s) {
     const mpc::Problem<double>& P = s->P64;
     return P.ball || P.via || P.integral_form || P.dyn_obst ||
-           (P.n_obst > 0 && (P.footprint_kind == MPC_FOOTPRINT_LINE || P.footprint_kind == MPC_FOOTPRINT_TWO_CIRCLES));
+           (P.n_obst > 0 && (P.footprint_kind == MPC_FOOTPRINT_LINE || P.footprint_kind == MPC_FOOTPRINT_TWO_CIRCLES || P.footprint_kind == MPC_FOOTPRINT_POLYGON));
 }
 
 extern "C" {
@@ -243,12 +243,14 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
     if (cfg->max_obstacles < 0 || cfg->max_obstacles > 4096 || (cfg->max_obstacles > 0 && (cfg->max_vertices < 1 || cfg->max_vertices > 64)) || cfg->max_obstacle_rows > 16) {
         set_err("mpc_create: obstacle capacities out of range (max_obstacles <= 4096, max_vertices <= 64, max_obstacle_rows <= 16)"); return MPC_EINVAL; }
     if (cfg->max_obstacles > 0 && cfg->footprint_kind != MPC_FOOTPRINT_POINT && cfg->footprint_kind != MPC_FOOTPRINT_CIRCLE && cfg->footprint_kind != MPC_FOOTPRINT_LINE &&
-        cfg->footprint_kind != MPC_FOOTPRINT_TWO_CIRCLES) {
-        set_err("mpc_create: only point, circular, line and two-circle footprints are implemented"); return MPC_EINVAL; }
+        cfg->footprint_kind != MPC_FOOTPRINT_TWO_CIRCLES && cfg->footprint_kind != MPC_FOOTPRINT_POLYGON) {
+        set_err("mpc_create: unknown footprint model"); return MPC_EINVAL; }
+    if (cfg->max_obstacles > 0 && cfg->footprint_kind == MPC_FOOTPRINT_POLYGON && (cfg->footprint_n_vertices < 1 || cfg->footprint_n_vertices > 16)) {
+        set_err("mpc_create: the polygon footprint needs 1..16 vertices"); return MPC_EINVAL; }
     if (cfg->max_obstacles > 0 && cfg->enable_dynamic_obstacles && cfg->footprint_kind != MPC_FOOTPRINT_POINT && cfg->footprint_kind != MPC_FOOTPRINT_CIRCLE) {
         set_err("mpc_create: dynamic obstacles are implemented for the point and circular footprints"); return MPC_EINVAL; }
-    if (cfg->max_obstacles > 0 && cfg->footprint_kind == MPC_FOOTPRINT_LINE && cfg->max_vertices > 1) {
-        set_err("mpc_create: the line footprint is implemented for point and circular obstacles (max_vertices = 1)"); return MPC_EINVAL; }
+    if (cfg->max_obstacles > 0 && (cfg->footprint_kind == MPC_FOOTPRINT_LINE || cfg->footprint_kind == MPC_FOOTPRINT_POLYGON) && cfg->max_vertices > 1) {
+        set_err("mpc_create: the line and polygon footprints are implemented for point and circular obstacles (max_vertices = 1)"); return MPC_EINVAL; }
     for (int j = 0; j < 2; ++j)
         if (!(cfg->u_lb[j] < cfg->u_ub[j])) { set_err("mpc_create: control box must be finite and non-empty"); return MPC_EINVAL; }
     int ndev = 0;
@@ -272,7 +274,8 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         const int ntrig = ((cfg->model == MPC_MODEL_KINEMATIC_BICYCLE || cfg->model == MPC_MODEL_SIMPLE_CAR_FRONT) ? 4 : 3) +
                           (cfg->collocation == MPC_COLLOC_CRANK_NICOLSON ? 2 : 0);
         s->WL = mpc::WaveLayout::make(cfg->n, M, O, cfg->max_vertices > 0 ? cfg->max_vertices : 1, ntrig, s->P64.n_via,
-                                        (O > 0 && (cfg->footprint_kind == MPC_FOOTPRINT_LINE || cfg->footprint_kind == MPC_FOOTPRINT_TWO_CIRCLES || cfg->enable_dynamic_obstacles)) ? M : 0,
+                                        (O > 0 && (cfg->footprint_kind == MPC_FOOTPRINT_LINE || cfg->footprint_kind == MPC_FOOTPRINT_TWO_CIRCLES ||
+                                                   cfg->footprint_kind == MPC_FOOTPRINT_POLYGON || cfg->enable_dynamic_obstacles)) ? M : 0,
                                         (O > 0 && cfg->enable_dynamic_obstacles) ? O : 0, solver_ext(s) ? mpc::NSTG_EXT : mpc::NSTG_BASE);
     }
     s->wave_lds = ((((size_t)s->WL.total * (cfg->precision == MPC_FP32 ? 4 : 8)) + 15) & ~(size_t)15) + 16 +

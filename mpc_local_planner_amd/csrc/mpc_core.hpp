@@ -68,6 +68,8 @@ struct Problem {
     T d_min, force_incl, cutoff, fp_radius;
     T fp_line[4];        // line footprint: start, end in the robot frame
     int dyn_obst;        // enable_dynamic_obstacles
+    int fp_nv;           // polygon footprint: vertices (robot frame)
+    T fp_poly[32];
     // terminal l2-ball row  xd' S xd - gamma <= 0  on the free final state (wave kernel only)
     int ball;
     T ball_S[3], ball_gamma;

@@ -57,6 +57,8 @@ inline void fill_problem(const mpc_config& c, mpc::Problem<T>& P) {
     P.fp_radius = T(c.footprint_kind == MPC_FOOTPRINT_CIRCLE ? c.footprint_radius : 0.0);
     for (int i = 0; i < 4; ++i) P.fp_line[i] = T(c.footprint_params[i]);
     P.dyn_obst = (c.enable_dynamic_obstacles && c.max_obstacles > 0) ? 1 : 0;
+    P.fp_nv = c.footprint_kind == MPC_FOOTPRINT_POLYGON ? (c.footprint_n_vertices < 16 ? c.footprint_n_vertices : 16) : 0;
+    for (int i = 0; i < 32; ++i) P.fp_poly[i] = T(i < 2 * P.fp_nv ? c.footprint_vertices[i] : 0.0);
     // TerminalBallSE2 (final_state_conditions_se2.cpp:54-64): the edge exists only with an unfixed final state (finite_differences_grid_se2.cpp:128-143)
     P.ball = (c.terminal_ball && !(c.xf_fixed[0] && c.xf_fixed[1] && c.xf_fixed[2])) ? 1 : 0;
     for (int i = 0; i < 3; ++i) P.ball_S[i] = T(c.terminal_ball_S[i]);

@@ -424,12 +424,25 @@ struct IpmWave {
         t_sincos(th, &s, &c);
         const T vx = v[0] - px, vy = v[1] - py;
         const T qx = c * vx + s * vy, qy = c * vy - s * vx;
-        const T a0 = P.fp_line[0], a1 = P.fp_line[1], abx = P.fp_line[2] - a0, aby = P.fp_line[3] - a1;
-        const T sq = abx * abx + aby * aby;
-        T t = sq > T(0) ? ((qx - a0) * abx + (qy - a1) * aby) / sq : T(0);
-        t = t_min(T(1), t_max(T(0), t));
-        const T dx = qx - (a0 + t * abx), dy = qy - (a1 + t * aby);
-        const T D = sqrt(dx * dx + dy * dy);
+        // closest point of the footprint: the segment (line) or the closed edge loop of the polygon (teb distance_point_to_polygon_2d:
+        // first closest edge wins, no inside test; 1 vertex = a point, 2 vertices = one edge)
+        T dx = T(0), dy = T(0), t = T(0), best = T(3e38);
+        const bool poly = P.footprint_kind == 4;
+        const int nv = poly ? P.fp_nv : 2;
+        const int ne = nv <= 2 ? 1 : nv;
+        for (int e = 0; e < ne; ++e) {
+            const int e2 = nv == 1 ? 0 : (e + 1) % nv;
+            const T a0 = poly ? P.fp_poly[2 * e] : P.fp_line[0], a1 = poly ? P.fp_poly[2 * e + 1] : P.fp_line[1];
+            const T b0 = poly ? P.fp_poly[2 * e2] : P.fp_line[2], b1 = poly ? P.fp_poly[2 * e2 + 1] : P.fp_line[3];
+            const T abx = b0 - a0, aby = b1 - a1;
+            const T sq = abx * abx + aby * aby;
+            T te = sq > T(0) ? ((qx - a0) * abx + (qy - a1) * aby) / sq : T(0);
+            te = t_min(T(1), t_max(T(0), te));
+            const T ex = qx - (a0 + te * abx), ey = qy - (a1 + te * aby);
+            const T de = sqrt(ex * ex + ey * ey);
+            if (de < best) { best = de; dx = ex; dy = ey; t = te; }
+        }
+        const T D = best;
         T nx = T(0), ny = T(0);
         hk = T(0);
         if (D > T(0)) { nx = dx / D; ny = dy / D; hk = (t > T(0) && t < T(1)) ? T(0) : T(1) / D; }
@@ -464,7 +477,7 @@ struct IpmWave {
         return rear ? dr : df;
     }
     __device__ __forceinline__ T turn_eval(T px, T py, T th, int j, T a[3], T& hk, T h3[3]) const {
-        return P.footprint_kind == 3 ? two_eval(px, py, th, j, a, hk, h3) : line_eval(px, py, th, j, a, hk, h3);
+        return P.footprint_kind == 3 ? two_eval(px, py, th, j, a, hk, h3) : line_eval(px, py, th, j, a, hk, h3);      // line_eval: line and polygon
     }
 
     // value / gradient / curvature cache of the clearance rows of grid point k at position (px,py); returns row count
@@ -1622,7 +1635,7 @@ struct IpmWave {
     __device__ __forceinline__ SolveStats<T> solve() {
         SolveStats<T> out;
         flags = (P.xf_fixed[0] ? 1 : 0) | (P.xf_fixed[1] ? 2 : 0) | (P.xf_fixed[2] ? 4 : 0) | (P.dt_free ? 8 : 0) | (P.objective == OBJ_QUADRATIC ? 16 : 0) |
-                (P.has_Qf ? 32 : 0) | (P.rate_on[0] ? 64 : 0) | (P.rate_on[1] ? 128 : 0) | (P.rate_on[2] ? 256 : 0) | (P.rate_on[3] ? 512 : 0) | (P.ball ? 1024 : 0) | (P.via ? 2048 : 0) | ((P.n_obst > 0 && (P.footprint_kind == 2 || P.footprint_kind == 3)) ? 4096 : 0) | (P.integral_form ? 8192 : 0) | (P.dyn_obst ? 16384 : 0);
+                (P.has_Qf ? 32 : 0) | (P.rate_on[0] ? 64 : 0) | (P.rate_on[1] ? 128 : 0) | (P.rate_on[2] ? 256 : 0) | (P.rate_on[3] ? 512 : 0) | (P.ball ? 1024 : 0) | (P.via ? 2048 : 0) | ((P.n_obst > 0 && (P.footprint_kind == 2 || P.footprint_kind == 3 || P.footprint_kind == 4)) ? 4096 : 0) | (P.integral_form ? 8192 : 0) | (P.dyn_obst ? 16384 : 0);
         flags = __builtin_amdgcn_readfirstlane(flags);
         nfix = (int)fx(0) + (int)fx(1) + (int)fx(2);
         row0_on = dtprev != T(0);

@@ -253,19 +253,29 @@ def clearance_row(cfg: R.OcpConfig, xk, ob: R.Obstacle, want_hess=True):
             if not interior:
                 Hm[:2, :2] = -(np.eye(2) - np.outer(nrm, nrm)) / d
         return val, g, Hm
-    if cfg.footprint_kind == R.FOOTPRINT_LINE and (ob.kind in (R.OBST_POINT, R.OBST_CIRCLE) or len(np.asarray(ob.vertices)) == 1):
-        # teb LineRobotFootprint::calculateDistance with a point / circular obstacle = distance of the obstacle centre to the footprint
-        # segment; evaluated in the ROBOT frame, q = R(-theta)(p_o - p), where the segment [a, b] is fixed: analytic chain rule
-        sx, sy, ex, ey = cfg.footprint_params
-        a = np.array([sx, sy]); ab = np.array([ex - sx, ey - sy])
+    if cfg.footprint_kind in (R.FOOTPRINT_LINE, R.FOOTPRINT_POLYGON) and (ob.kind in (R.OBST_POINT, R.OBST_CIRCLE) or len(np.asarray(ob.vertices)) == 1):
+        # teb Line / PolygonRobotFootprint::calculateDistance with a point / circular obstacle = distance of the obstacle centre to the
+        # footprint segment / closed edge loop; evaluated in the ROBOT frame, q = R(-theta)(p_o - p), where the footprint is fixed
+        fv = np.asarray(cfg.footprint_params, float).reshape(-1, 2)
+        if cfg.footprint_kind == R.FOOTPRINT_LINE or len(fv) == 2:
+            edges = [(fv[0], fv[1])]
+        elif len(fv) == 1:
+            edges = [(fv[0], fv[0])]
+        else:
+            edges = [(fv[i], fv[(i + 1) % len(fv)]) for i in range(len(fv))]
         th = float(xk[2]); c, s = math.cos(th), math.sin(th)
         v = np.asarray(ob.vertices, float).reshape(-1, 2)[0] - np.asarray(xk[:2], float)
         q = np.array([c * v[0] + s * v[1], -s * v[0] + c * v[1]])
-        sq = float(ab @ ab)
-        t = float((q - a) @ ab) / sq if sq > 0 else 0.0
-        t = min(1.0, max(0.0, t))
-        dvec = q - (a + t * ab)
-        d = float(np.linalg.norm(dvec))
+        d, dvec, t = float("inf"), None, 0.0
+        for (a, b2) in edges:                      # first closest edge wins
+            ab = b2 - a
+            sq = float(ab @ ab)
+            te = float((q - a) @ ab) / sq if sq > 0 else 0.0
+            te = min(1.0, max(0.0, te))
+            dv = q - (a + te * ab)
+            de = float(np.linalg.norm(dv))
+            if de < d:
+                d, dvec, t = de, dv, te
         rad = ob.radius if ob.kind == R.OBST_CIRCLE else 0.0
         val = cfg.min_obstacle_dist - (d - rad)
         g = np.zeros(3); Hm = np.zeros((3, 3))

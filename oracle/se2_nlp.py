@@ -150,6 +150,7 @@ FOOTPRINT_POINT = 0
 FOOTPRINT_CIRCLE = 1
 FOOTPRINT_LINE = 2
 FOOTPRINT_TWO_CIRCLES = 3
+FOOTPRINT_POLYGON = 4
 
 
 @dataclass
@@ -259,6 +260,7 @@ def footprint_distance(fp_kind: int, fp_params: Sequence[float], pose, ob: Obsta
     circle      fp_params = (radius,)
     line        fp_params = (sx, sy, ex, ey) in the robot frame
     two circles fp_params = (front_offset, front_radius, rear_offset, rear_radius)
+    polygon     fp_params = (x0, y0, x1, y1, ...) vertices in the robot frame
     """
     if t != 0.0 and ob.velocity is not None:
         ob = Obstacle(ob.kind, np.asarray(ob.vertices, float) + t * np.asarray(ob.velocity, float), ob.radius, ob.velocity)
@@ -278,6 +280,15 @@ def footprint_distance(fp_kind: int, fp_params: Sequence[float], pose, ob: Obsta
         fo, fr, ro, rr = fp_params
         d = np.array([c, s])
         return min(_dist_point_obstacle(pos + fo * d, ob) - fr, _dist_point_obstacle(pos - ro * d, ob) - rr)
+    if fp_kind == FOOTPRINT_POLYGON:
+        # teb PolygonRobotFootprint::calculateDistance: the vertices (robot frame, fp_params = x0, y0, x1, y1, ...) moved to the world frame,
+        # then obstacle->getMinimumDistance(polygon); point / circular obstacles: distance_point_to_polygon_2d (closed edge loop, no inside test)
+        vv = np.asarray(fp_params, float).reshape(-1, 2)
+        world = pos + np.stack([c * vv[:, 0] - s * vv[:, 1], s * vv[:, 0] + c * vv[:, 1]], 1)
+        if ob.kind in (OBST_POINT, OBST_CIRCLE) or len(np.asarray(ob.vertices)) == 1:
+            p = np.asarray(ob.vertices, float).reshape(-1, 2)[0]
+            return _dist_point_obstacle(p, Obstacle(OBST_POLYGON, world)) - (ob.radius if ob.kind == OBST_CIRCLE else 0.0)
+        raise NotImplementedError("polygon footprint against line / polygon obstacles")
     raise ValueError("unknown footprint")
 
 

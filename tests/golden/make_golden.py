@@ -65,7 +65,7 @@ def make_obstacles(name, n=30, B=10, O=6, V=6, M=4, keep=6):
     print(name, "kept", len(sel), "iters", IT)
 
 
-if __name__ == "__main__" and "--warm" not in sys.argv and "--integral" not in sys.argv and "--closed-loop" not in sys.argv and "--config3" not in sys.argv and "--midpoint" not in sys.argv and "--cn" not in sys.argv and "--ball" not in sys.argv and "--via" not in sys.argv and "--line" not in sys.argv and "--two" not in sys.argv and "--integral-free" not in sys.argv and "--dynamic" not in sys.argv:
+if __name__ == "__main__" and "--warm" not in sys.argv and "--integral" not in sys.argv and "--closed-loop" not in sys.argv and "--config3" not in sys.argv and "--midpoint" not in sys.argv and "--cn" not in sys.argv and "--ball" not in sys.argv and "--via" not in sys.argv and "--line" not in sys.argv and "--two" not in sys.argv and "--integral-free" not in sys.argv and "--dynamic" not in sys.argv and "--polygon" not in sys.argv:
     make_obstacles("unicycle_quadratic_obstacles_n30")
     make("carlike_min_time_n50", R.config_carlike_min_time(50), W.carlike_min_time_inputs(32, seed=101), keep=8)
     make("carlike_min_time_n20", R.config_carlike_min_time(20), W.carlike_min_time_inputs(32, seed=102, goal_range=(1.0, 2.5)), keep=8)
@@ -444,3 +444,34 @@ def make_dynamic_obstacles(name, n=30, B=12, keep=6, M=4, O=3):
 
 if __name__ == "__main__" and "--dynamic" in sys.argv:
     make_dynamic_obstacles("carlike_dynamic_obstacles_n30")
+
+
+POLY_FP = (0.25, -0.05, 0.18, -0.05, 0.18, -0.18, -0.19, -0.18, -0.25, 0.0, -0.19, 0.18, 0.18, 0.18, 0.18, 0.05, 0.25, 0.05)   # carlike yaml :28
+
+
+def make_polygon_footprint(name, n=30, B=16, keep=6, M=4):
+    """a21 with teb's PolygonRobotFootprint (vertex list of the car-like example YAML) against point obstacles."""
+    cfg = R.config_carlike_min_time(n)
+    cfg.footprint_kind, cfg.footprint_params = R.FOOTPRINT_POLYGON, POLY_FP
+    cfg.min_obstacle_dist, cfg.force_inclusion_dist, cfg.cutoff_dist = 0.15, 0.5, 2.5
+    x0, xf, up, dtp, pts = line_footprint_inputs(B, 191)
+    rows = []
+    for i in range(B):
+        if len(rows) >= keep:
+            break
+        obs = [R.Obstacle(R.OBST_POINT, pts[i, o:o + 1]) for o in range(pts.shape[1])]
+        inp = R.CycleInputs(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=float(dtp[i]), obstacles=obs)
+        init = R.cold_start(cfg, x0[i], xf[i])
+        rel, _ = R.associate_obstacles(cfg, init, obs, max_rows=M)
+        ref = I.solve(cfg, inp, init, relevant=rel, opt=I.IpmOptions(globalization="merit", max_iter=100))
+        if ref.status != 0 or ref.iters > 45:       # long runs are round-off sensitive (the device needed 88 iterations for a 58-iteration one)
+            continue
+        dmin = min(R.footprint_distance(cfg.footprint_kind, cfg.footprint_params, ref.traj.x[k], ob) for k in range(1, n - 1) for ob in obs)
+        rows.append(dict(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=dtp[i], pts=pts[i], x=ref.traj.x, u=np.vstack([ref.traj.u, ref.traj.u[-1:]]),
+                         dt=ref.traj.dt, iters=ref.iters, dmin=dmin))
+    np.savez_compressed(os.path.join(OUT, name + ".npz"), poly=np.array(POLY_FP), max_rows=M, **{k: np.array([r[k] for r in rows]) for k in rows[0]})
+    print(name, "kept", len(rows), "iters", [r["iters"] for r in rows], "min footprint distance", [round(float(r["dmin"]), 4) for r in rows])
+
+
+if __name__ == "__main__" and "--polygon" in sys.argv:
+    make_polygon_footprint("carlike_polygon_footprint_n30", keep=5)

@@ -688,3 +688,27 @@ def test_dynamic_obstacles_golden(m):
     q = s2.solve(g["x0"], g["xf"], g["u_prev"], g["dt_prev"], obstacles=(g["n_obstacles"], g["n_vertices"], g["vertices"], g["radius"]))
     assert (np.abs(q.x - r.x).reshape(B, -1).max(1) > 1e-3).all()
     s.close(); s2.close()
+
+
+def test_polygon_footprint_golden(m):
+    """a21 with teb's PolygonRobotFootprint (the vertex list of cfg/carlike/mpc_local_planner_params.yaml:28) against point obstacles: the
+    obstacle in the robot frame against the closed edge loop (first closest edge, no inside test).  Fixture: make_golden.py --polygon
+    (four of five instances end with a binding row)."""
+    from oracle import se2_nlp as R
+    g = np.load(os.path.join(GOLD, "carlike_polygon_footprint_n30.npz"))
+    B, O = g["pts"].shape[0], g["pts"].shape[1]
+    cfg = m.config_carlike_min_time(30, footprint_kind=4, footprint_vertices=tuple(g["poly"]), min_obstacle_dist=0.15, force_inclusion_dist=0.5,
+                                    cutoff_dist=2.5, max_obstacles=O, max_vertices=1, max_obstacle_rows=int(g["max_rows"]))
+    s = m.BatchSolver(cfg, max_batch=B)
+    no = np.full(B, O, np.int32); nv = np.ones((B, O), np.int32); vt = g["pts"].reshape(B, O, 1, 2)
+    r = s.solve(g["x0"], g["xf"], g["u_prev"], g["dt_prev"], obstacles=(no, nv, vt))
+    assert (r.status == 0).all()
+    err = np.maximum(np.abs(r.x - g["x"]).reshape(B, -1).max(1), np.abs(r.u - g["u"]).reshape(B, -1).max(1))
+    same = r.iters == g["iters"]
+    assert same.sum() >= B - 2 and (err[same] < 1e-6).all() and (err < 1e-4).all()
+    assert (np.abs(r.iters - g["iters"]) <= np.maximum(2, 0.1 * g["iters"])).all()
+    for i in range(B):
+        obs = [R.Obstacle(R.OBST_POINT, g["pts"][i, o:o + 1]) for o in range(O)]
+        dmin = min(R.footprint_distance(R.FOOTPRINT_POLYGON, tuple(g["poly"]), r.x[i, k], ob) for k in range(1, 29) for ob in obs)
+        assert dmin > 0.15 - 1e-6
+    s.close()
