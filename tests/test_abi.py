@@ -38,19 +38,24 @@ def test_header_functions_all_exported(lib):
 
 
 def test_config_struct_layout_matches_c(tmp_path):
-    from mpc_local_planner_amd._abi import MpcConfig
+    """every field of the ctypes mirror sits where the C compiler puts it (struct mpc_config and struct mpc_obstacles)."""
+    from mpc_local_planner_amd._abi import MpcConfig, MpcObstacles
+    fields = [f[0] for f in MpcConfig._fields_]
+    ofields = [f[0] for f in MpcObstacles._fields_]
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mpc_hip.h"\n'
-                   'int main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(mpc_config), offsetof(mpc_config,n), '
-                   'offsetof(mpc_config,Q), offsetof(mpc_config,du_ub), offsetof(mpc_config,precision));return 0;}\n')
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "mpc_hip.h"\nint main(){\n'
+                   'printf("%zu %zu\\n", sizeof(mpc_config), sizeof(mpc_obstacles));\n' +
+                   "".join('printf("%%zu\\n", offsetof(mpc_config,%s));\n' % f for f in fields) +
+                   "".join('printf("%%zu\\n", offsetof(mpc_obstacles,%s));\n' % f for f in ofields) + 'return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
-    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
-    assert int(out[0]) == C.sizeof(MpcConfig)
-    assert int(out[1]) == MpcConfig.n.offset
-    assert int(out[2]) == MpcConfig.Q.offset
-    assert int(out[3]) == MpcConfig.du_ub.offset
-    assert int(out[4]) == MpcConfig.precision.offset
+    out = [int(v) for v in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()]
+    assert out[0] == C.sizeof(MpcConfig) and out[1] == C.sizeof(MpcObstacles)
+    offs = out[2:]
+    for f, o in zip(fields, offs[:len(fields)]):
+        assert getattr(MpcConfig, f).offset == o, f
+    for f, o in zip(ofields, offs[len(fields):]):
+        assert getattr(MpcObstacles, f).offset == o, f
 
 
 def test_defaults_match_reference_in_code_defaults(lib):
