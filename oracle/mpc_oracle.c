@@ -529,6 +529,34 @@ static double err_value(const err_t* e, double mu) {
 /* Assemble the condensed KKT system (banded part + dt border) and its right-hand side.
  * Unknown order per interval k: u_k(2), lambda_k(3), x_{k+1}(3).  dt is the border unknown.
  * hd / Hdd: gradient and Hessian entries of dt; bcol: coupling column K[:,dt]. */
+static int g_variant = 1;          /* 1 = the algorithm (skip the delta = 0 attempt after a failed one); 0/2/3: experiments */
+/* EXPERIMENT (oracle_set_variant(3)): replace the stage block [Hqq Hqd; Hqd' Hdd] of lam' D by its positive semidefinite part
+ * (cyclic Jacobi on the symmetric 4x4, negative eigenvalues clipped to 0).  Not part of the algorithm the product implements. */
+static void psd_project4(stage_map_t* sm, int drop_theta) {
+    double A[4][4], V[4][4];
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) A[i][j] = sm->Hqq[i][j]; A[i][3] = A[3][i] = sm->Hqd[i]; }
+    A[3][3] = sm->Hdd;
+    if (drop_theta) for (int j = 0; j < 4; ++j) A[0][j] = A[j][0] = 0.0;
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) V[i][j] = i == j;
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        double off = 0;
+        for (int p = 0; p < 4; ++p) for (int q = p + 1; q < 4; ++q) off += A[p][q] * A[p][q];
+        if (off < 1e-30) break;
+        for (int p = 0; p < 4; ++p) for (int q = p + 1; q < 4; ++q) {
+            if (fabs(A[p][q]) < 1e-300) continue;
+            const double th = (A[q][q] - A[p][p]) / (2.0 * A[p][q]);
+            const double t = (th >= 0 ? 1.0 : -1.0) / (fabs(th) + sqrt(th * th + 1.0)), c = 1.0 / sqrt(t * t + 1.0), sn = t * c;
+            for (int k = 0; k < 4; ++k) { const double akp = A[k][p], akq = A[k][q]; A[k][p] = c * akp - sn * akq; A[k][q] = sn * akp + c * akq; }
+            for (int k = 0; k < 4; ++k) { const double apk = A[p][k], aqk = A[q][k]; A[p][k] = c * apk - sn * aqk; A[q][k] = sn * apk + c * aqk; }
+            for (int k = 0; k < 4; ++k) { const double vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - sn * vkq; V[k][q] = sn * vkp + c * vkq; }
+        }
+    }
+    double R[4][4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { double v = 0; for (int k = 0; k < 4; ++k) v += V[i][k] * (A[k][k] > 0 ? A[k][k] : 0.0) * V[j][k]; R[i][j] = v; }
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) sm->Hqq[i][j] = R[i][j]; sm->Hqd[i] = R[i][3]; }
+    sm->Hdd = R[3][3];
+}
+
 static void assemble(work_t* w, const double* cc, double delta, double dc, double* Hdd, double* hd) {
     const oracle_config* c = w->c;
     int n = w->n, N = w->N;
@@ -559,6 +587,7 @@ static void assemble(work_t* w, const double* cc, double delta, double dc, doubl
             w->rhs[row] = -cc[3 * k + a];
         }
         if (k == n - 2) for (int a = 0; a < 3; ++a) if (c->xf_fixed[a]) band_add(w, il(k, a), il(k, a), -dc);
+        if (g_variant == 3) psd_project4(&sm, qi[0] < 0);      /* experiment: stage-wise convexification of the Lagrangian curvature */
         /* Lagrangian curvature */
         for (int j = 0; j < 3; ++j) {
             if (qi[j] < 0) continue;
@@ -634,7 +663,6 @@ static void assemble(work_t* w, const double* cc, double delta, double dc, doubl
 
 static void ftb(double val, double dval, double tau, double* alpha) { if (dval < 0) { double a = -tau * val / dval; if (a < *alpha) *alpha = a; } }
 
-static int g_variant = 1;          /* 1 = the algorithm (skip the delta = 0 attempt after a failed one); 0/2: experiments */
 static long g_nfac_total = 0;
 static int g_nfac_max = 0;
 void oracle_set_variant(int v) { g_variant = v; g_nfac_total = 0; g_nfac_max = 0; }
