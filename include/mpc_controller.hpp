@@ -185,6 +185,7 @@ class Controller {
         _grid_adapt = enable; _n_max = max_grid_size; _dt_hyst = dt_hyst_ratio; _n_min = min_grid_size < 3 ? 3 : min_grid_size;
     }
     void setWarmStart(bool w) { _warm_start = w; }      // grid/warm_start (src/controller.cpp:294-296)
+    void setNumOcpIterations(int n) { _num_ocp_iterations = n < 1 ? 1 : n; }      // controller/outer_ocp_iterations (src/controller.cpp:70-72)
     int gridSize() const { return _n_cur; }
 
     // ocp->setPreviousControlInput(u, dt)  (src/mpc_local_planner_ros.cpp:384)
@@ -227,6 +228,10 @@ class Controller {
                 std::fabs(normalize_theta(goal.theta - _last_goal.theta)) > _force_reinit_new_goal_angular)
                 _grid_empty = true;
         }
+        // PredictiveController::step repeats the OCP (grid update + solve) num_ocp_iterations times per control cycle
+        // (controller/outer_ocp_iterations, src/controller.cpp:70-72); every repetition after the first starts from the solution just computed
+        int32_t status = -1, iters = 0;
+        for (int outer = 0; outer < _num_ocp_iterations; ++outer) {
         const double* xi = nullptr; const double* ui = nullptr; const double* di = nullptr;
         if (_grid_empty) {
             _n_cur = _n_ref;
@@ -253,9 +258,10 @@ class Controller {
             if (mpc_set_grid_sizes(_h, &ng, 1) != MPC_OK) { _last_error = mpc_last_error(); return false; }
             _sizes_set = true;
         }
-        int32_t status = -1, iters = 0;
         const int rc = mpc_solve_batch(_h, 1, x0, xf, _u_prev, &_dt_prev, xi, ui, di, _obst, _x.data(), _u.data(), &_dt_sol, &status, &iters);
         if (rc != MPC_OK) { _last_error = mpc_last_error(); return false; }
+        _grid_empty = false;
+        }
         _last_iterations = iters;
         _ocp_successful = status == MPC_CONVERGED;
         x_seq.clear(); u_seq.clear();
@@ -292,6 +298,7 @@ class Controller {
     bool _ocp_successful = false;
     int _ocp_seq = 0;
     int _last_iterations = 0;
+    int _num_ocp_iterations = 1;
     PoseSE2 _last_goal;
     int _force_reinit_num_steps = 0;                     // src/controller.cpp:78
     double _force_reinit_new_goal_dist = 1.0;            // :74
