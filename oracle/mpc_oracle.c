@@ -56,6 +56,7 @@ typedef struct oracle_config {
     int32_t via;                /* minimum_time_via_points: objective 0 plus the via-point terms (min_time_via_points_cost.cpp:120-145) */
     int32_t vp_ordered;
     double vp_wp, vp_wo;
+    int32_t integral;           /* quadratic objective in integral form: stage cost x dt (left sum; quadratic_cost_se2.cpp:54-83, finite_differences_grid_se2.cpp:61-75) */
 } oracle_config;
 
 #define PI 3.14159265358979323846
@@ -411,8 +412,9 @@ static void eval_point(const work_t* w, const double* X, const double* U, double
         if (c->via && k >= 1) { double vv, vg[3]; via_terms(w, k, X[3 * k], X[3 * k + 1], X[3 * k + 2], &vv, vg); f += vv; }
         if (c->objective == 1) {
             double xd[3] = {X[3 * k] - w->xf[0], X[3 * k + 1] - w->xf[1], wrap(X[3 * k + 2] - w->xf[2])};
-            for (int i = 0; i < 3; ++i) f += c->Q[i] * xd[i] * xd[i];
-            for (int j = 0; j < 2; ++j) f += c->R[j] * U[2 * k + j] * U[2 * k + j];
+            const double w8 = c->integral ? D : 1.0;
+            for (int i = 0; i < 3; ++i) f += w8 * c->Q[i] * xd[i] * xd[i];
+            for (int j = 0; j < 2; ++j) f += w8 * c->R[j] * U[2 * k + j] * U[2 * k + j];
         }
     }
     if (c->objective == 1 && c->has_Qf) {
@@ -455,8 +457,10 @@ static void kkt_terms(const work_t* w, const double* cc, err_t* e) {
         double gx[3] = {0, 0, 0}, gu[2] = {0, 0};
         if (c->objective == 1) {
             double xd[3] = {w->X[3 * k] - w->xf[0], w->X[3 * k + 1] - w->xf[1], wrap(w->X[3 * k + 2] - w->xf[2])};
-            for (int i = 0; i < 3; ++i) gx[i] = 2 * c->Q[i] * xd[i];
-            gu[0] = 2 * c->R[0] * v; gu[1] = 2 * c->R[1] * om;
+            const double w8 = c->integral ? w->D : 1.0;
+            for (int i = 0; i < 3; ++i) gx[i] = 2 * c->Q[i] * xd[i] * w8;
+            gu[0] = 2 * c->R[0] * v * w8; gu[1] = 2 * c->R[1] * om * w8;
+            if (c->integral) rdd += c->Q[0] * xd[0] * xd[0] + c->Q[1] * xd[1] * xd[1] + c->Q[2] * xd[2] * xd[2] + c->R[0] * v * v + c->R[1] * om * om;
         }
         if (c->via && k >= 1) { double vv, vg[3]; via_terms(w, k, w->X[3 * k], w->X[3 * k + 1], w->X[3 * k + 2], &vv, vg); for (int i = 0; i < 3; ++i) gx[i] += vg[i]; }
         double osx = 0, osy = 0;
@@ -601,8 +605,15 @@ static void assemble(work_t* w, const double* cc, double delta, double dc, doubl
         /* objective */
         if (c->objective == 1) {
             double xd[3] = {w->X[3 * k] - w->xf[0], w->X[3 * k + 1] - w->xf[1], wrap(w->X[3 * k + 2] - w->xf[2])};
-            if (k >= 1) for (int i = 0; i < 3; ++i) { band_add(w, ixn(k, i), ixn(k, i), 2 * c->Q[i]); w->rhs[ixn(k, i)] -= 2 * c->Q[i] * xd[i]; }
-            for (int j = 0; j < 2; ++j) { band_add(w, iu(k, j), iu(k, j), 2 * c->R[j]); w->rhs[iu(k, j)] -= 2 * c->R[j] * w->U[2 * k + j]; }
+            const double w8 = c->integral ? D : 1.0;
+            if (k >= 1) for (int i = 0; i < 3; ++i) { band_add(w, ixn(k, i), ixn(k, i), 2 * c->Q[i] * w8); w->rhs[ixn(k, i)] -= 2 * c->Q[i] * xd[i] * w8; }
+            for (int j = 0; j < 2; ++j) { band_add(w, iu(k, j), iu(k, j), 2 * c->R[j] * w8); w->rhs[iu(k, j)] -= 2 * c->R[j] * w->U[2 * k + j] * w8; }
+            if (c->integral) {       /* d/d dt and the mixed second derivatives of  dt * (xd'Q xd + u'R u) */
+                if (k >= 1) for (int i = 0; i < 3; ++i) w->bcol[ixn(k, i)] += 2 * c->Q[i] * xd[i];
+                for (int j = 0; j < 2; ++j) w->bcol[iu(k, j)] += 2 * c->R[j] * w->U[2 * k + j];
+                for (int i = 0; i < 3; ++i) gd += c->Q[i] * xd[i] * xd[i];
+                for (int j = 0; j < 2; ++j) gd += c->R[j] * w->U[2 * k + j] * w->U[2 * k + j];
+            }
         }
         if (c->via && k >= 1) {
             double vv, vg[3];
@@ -815,12 +826,18 @@ static int solve_one(work_t* w, int warm) {
                     ftb(w->pdu, mu / du - w->pdu + (w->pdu / du) * ddt, tau, &a_d);
                 }
                 if (c->objective == 0) { hdz += (n - 1) * ddt; dphi += (n - 1) * ddt; }
+                if (c->objective == 1 && c->integral) for (int k = 0; k < n - 1; ++k) {        /* d/d dt of the integral-form stage costs */
+                    double xd[3] = {w->X[3 * k] - w->xf[0], w->X[3 * k + 1] - w->xf[1], wrap(w->X[3 * k + 2] - w->xf[2])}, sc = 0;
+                    for (int i = 0; i < 3; ++i) sc += c->Q[i] * xd[i] * xd[i];
+                    for (int j = 0; j < 2; ++j) sc += c->R[j] * w->U[2 * k + j] * w->U[2 * k + j];
+                    hdz += sc * ddt; dphi += sc * ddt;
+                }
                 for (int k = 0; k < n - 1; ++k) {
                     for (int j = 0; j < 2; ++j) {
                         double du_ = w->rhs[iu(k, j)], u = w->U[2 * k + j];
                         double dl = u - c->u_lb[j], du = c->u_ub[j] - u, pl = w->pl[2 * k + j], pu = w->pu[2 * k + j];
                         double gb = -mu / dl + mu / du;
-                        if (c->objective == 1) gb += 2 * c->R[j] * u;
+                        if (c->objective == 1) gb += 2 * c->R[j] * u * (c->integral ? w->D : 1.0);
                         hdz += gb * du_; dphi += gb * du_; dz2 += du_ * du_; if (fabs(du_) > dzmax) dzmax = fabs(du_);
                         ftb(dl, du_, tau, &a_p); ftb(du, -du_, tau, &a_p);
                         ftb(pl, mu / dl - pl - (pl / dl) * du_, tau, &a_d);
@@ -837,7 +854,7 @@ static int solve_one(work_t* w, int warm) {
                         dz2 += dx * dx; if (fabs(dx) > dzmax) dzmax = fabs(dx);
                         if (c->objective == 1) {
                             double g = 0;
-                            if (k + 1 < n - 1) { double xd = w->X[3 * (k + 1) + a] - w->xf[a]; if (a == 2) xd = wrap(xd); g = 2 * c->Q[a] * xd; }
+                            if (k + 1 < n - 1) { double xd = w->X[3 * (k + 1) + a] - w->xf[a]; if (a == 2) xd = wrap(xd); g = 2 * c->Q[a] * xd * (c->integral ? w->D : 1.0); }
                             else if (c->has_Qf && !c->xf_fixed[a]) { double xd = w->X[3 * (k + 1) + a] - w->xf[a]; if (a == 2) xd = wrap(xd); g = 2 * c->Qf[a] * xd; }
                             hdz += g * dx; dphi += g * dx;
                         }

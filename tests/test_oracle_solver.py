@@ -272,3 +272,18 @@ def test_c_oracle_via_points_match_numpy_goldens(name, c_oracle):
     assert (st == 0).all()
     assert np.abs(xo - g["x"]).max() < 1e-6 and np.abs(uo - g["u"]).max() < 1e-6 and np.abs(do - g["dt"]).max() < 1e-8
     assert np.abs(it - g["iters"]).max() <= 2
+
+
+@pytest.mark.parametrize("name,free", [("unicycle_quadratic_integral_n20", False), ("unicycle_quadratic_integral_free_dt_n20", True)])
+def test_c_oracle_integral_form_matches_numpy_goldens(name, free, c_oracle):
+    """oracle/mpc_oracle.c restates the integral-form cost (fixed grid: cost x dt_ref; variable grid: dt a variable with the state-dt and
+    control-dt coupling in the dt border column) against the numpy fixtures."""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    cfg = R.config_unicycle_quadratic(20)
+    cfg.integral_form = True
+    if free:
+        cfg.dt_free, cfg.dt_lb, cfg.dt_ub, cfg.xf_fixed, cfg.Qf, cfg.R = True, 0.01, 2.0, (True, True, True), None, np.array([1.0, 0.5])
+    xo, uo, do, st, it = c_oracle.solve_batch(c_oracle.from_nlp_config(cfg), g["x0"], g["xf"], g["u_prev"], g["dt_prev"])
+    assert (st == 0).all()
+    assert np.abs(xo - g["x"]).max() < 1e-6 and np.abs(uo - g["u"]).max() < 1e-6 and np.abs(do - g["dt"]).max() < 1e-7
+    assert np.abs(it - g["iters"]).max() <= 2
