@@ -80,12 +80,25 @@ class OracleObst(C.Structure):
     """struct oracle_obst (oracle/mpc_oracle.c): obstacle handling of a batch, same meaning as the mpc_config fields."""
     _fields_ = [("max_obstacles", C.c_int32), ("max_vertices", C.c_int32), ("max_rows", C.c_int32),
                 ("min_obstacle_dist", C.c_double), ("force_inclusion_dist", C.c_double), ("cutoff_dist", C.c_double),
-                ("footprint_radius", C.c_double)]
+                ("footprint_radius", C.c_double),
+                ("footprint_kind", C.c_int32), ("footprint_params", C.c_double * 4), ("footprint_nv", C.c_int32), ("footprint_poly", C.c_double * 32),
+                ("dynamic", C.c_int32)]
 
 
 def obst_from_nlp_config(cfg, max_obstacles: int, max_vertices: int, max_rows: int) -> OracleObst:
-    fr = cfg.footprint_params[0] if getattr(cfg, "footprint_kind", 0) == 1 and cfg.footprint_params else 0.0
-    return OracleObst(max_obstacles, max_vertices, max_rows, cfg.min_obstacle_dist, cfg.force_inclusion_dist, cfg.cutoff_dist, fr)
+    kind = int(getattr(cfg, "footprint_kind", 0))
+    fr = cfg.footprint_params[0] if kind == 1 and cfg.footprint_params else 0.0
+    o = OracleObst(max_obstacles, max_vertices, max_rows, cfg.min_obstacle_dist, cfg.force_inclusion_dist, cfg.cutoff_dist, fr)
+    o.footprint_kind = kind
+    if kind in (2, 3):
+        for i in range(4):
+            o.footprint_params[i] = float(cfg.footprint_params[i])
+    if kind == 4:
+        o.footprint_nv = len(cfg.footprint_params) // 2
+        for i, v in enumerate(cfg.footprint_params[:32]):
+            o.footprint_poly[i] = float(v)
+    o.dynamic = int(bool(getattr(cfg, "enable_dynamic_obstacles", False)))
+    return o
 
 
 def solve_batch(ocfg: OracleConfig, x0, xf, u_prev=None, dt_prev=None, init=None, nthreads=0, obstacles=None, obst: "OracleObst" = None, via=None):
@@ -115,9 +128,12 @@ def solve_batch(ocfg: OracleConfig, x0, xf, u_prev=None, dt_prev=None, init=None
         nv = np.ascontiguousarray(obstacles[1], np.int32)
         vv = np.ascontiguousarray(obstacles[2], float)
         rr = np.ascontiguousarray(obstacles[3], float) if len(obstacles) > 3 and obstacles[3] is not None else None
+        vel = np.ascontiguousarray(obstacles[4], float) if len(obstacles) > 4 and obstacles[4] is not None else None
+        lib.oracle_set_obstacle_velocities(p(vel))
         assert nv.shape == (B, obst.max_obstacles) and vv.shape == (B, obst.max_obstacles, obst.max_vertices, 2)
         lib.oracle_solve_batch_obst(C.byref(ocfg), C.c_int(B), p(x0), p(xf), p(up), p(dp), p(xi), p(ui), p(di), C.byref(obst), p(no), p(nv), p(vv),
                                     p(rr), p(xo), p(uo), p(do), p(st), p(it), C.c_int(nthreads))
+        lib.oracle_set_obstacle_velocities(None)
         return xo, uo, do, st, it
     lib.oracle_solve_batch(C.byref(ocfg), C.c_int(B), p(x0), p(xf), p(up), p(dp), p(xi), p(ui), p(di), p(xo), p(uo), p(do), p(st), p(it),
                            C.c_int(nthreads))

@@ -171,6 +171,11 @@ static void stage_map(const oracle_config* c, double th, double v, double w, dou
 typedef struct oracle_obst {
     int32_t max_obstacles, max_vertices, max_rows;
     double min_obstacle_dist, force_inclusion_dist, cutoff_dist, footprint_radius;
+    int32_t footprint_kind;         /* 0 point, 1 circle, 2 line, 3 two circles, 4 polygon (as include/mpc_hip.h) */
+    double footprint_params[4];     /* line: start, end; two circles: front offset, front radius, rear offset, rear radius */
+    int32_t footprint_nv;           /* polygon footprint */
+    double footprint_poly[32];
+    int32_t dynamic;                /* enable_dynamic_obstacles: velocities set with oracle_set_obstacle_velocities */
 } oracle_obst;
 
 /* ---------------------------------------------------------------- per-instance work area */
@@ -198,6 +203,9 @@ typedef struct {
     int* oi;                  /* n*M obstacle index or -1 */
     double *os, *oy, *ost, *ods, *ody;   /* n*M slack, multiplier, trial slack, steps */
     double *og, *oax, *oay, *ohk;        /* n*M cached value, gradient (= -unit normal), curvature 1/|p-q| (0 on an edge interior) */
+    double *oat, *oh3;                   /* third-variable parts of the rows: gradient entry n*M and Hessian entries 3*n*M -- heading for the
+                                          * footprints that turn with the pose, dt for dynamic obstacles */
+    const double* vel;                   /* obstacle velocities of this instance [O][2] or NULL */
     /* via-points of this instance (set per batch with oracle_set_via_points) and the grid point each one is attached to */
     int nvia; const double* via; int vidx[64];
 } work_t;
@@ -320,6 +328,9 @@ static void obst_centroids(work_t* w) {
         w->cent[2 * j] = cx; w->cent[2 * j + 1] = cy;
     }
 }
+static int fp_turns(const work_t* w);
+static int is_dynamic(const work_t* w, int j);
+static double turn_dist(const work_t* w, double px, double py, double th, int j, double a[3], double* hk, double h3[3]);
 /* StageInequalitySE2::update (stage_inequality_se2.cpp:50-162) on the current vertex values; forced rows first, then nearest left / right */
 static void obst_associate(work_t* w) {
     const int n = w->n, M = obst_M(w);
@@ -329,11 +340,12 @@ static void obst_associate(work_t* w) {
         if (k < 1) continue;
         const double px = w->X[3 * k], py = w->X[3 * k + 1], th = w->X[3 * k + 2], co = cos(th), si = sin(th);
         double lmin = 1e30, rmin = 1e30; int lidx = -1, ridx = -1, cnt = 0;
+        for (int j = 0; j < w->n_obst; ++j) if (w->n_vert[j] > 0 && is_dynamic(w, j) && cnt < M) w->oi[k * M + cnt++] = j;   /* always kept (:99-106) */
         for (int j = 0; j < w->n_obst; ++j) {
-            if (w->n_vert[j] <= 0) continue;
+            if (w->n_vert[j] <= 0 || is_dynamic(w, j)) continue;
             double dist, nx, ny, hk;
-            obst_eval(w, px, py, j, &dist, &nx, &ny, &hk);
-            dist -= o->footprint_radius;
+            if (fp_turns(w)) { double a3[3], h3[3]; dist = turn_dist(w, px, py, th, j, a3, &hk, h3); }
+            else { obst_eval(w, px, py, j, &dist, &nx, &ny, &hk); dist -= o->footprint_radius; }
             if (dist < o->force_inclusion_dist) { if (cnt < M) w->oi[k * M + cnt++] = j; continue; }
             if (dist > o->cutoff_dist) continue;
             if (co * w->cent[2 * j + 1] - w->cent[2 * j] * si > 0) { if (dist < lmin) { lmin = dist; lidx = j; } }   /* centroid as an ABSOLUTE vector (:121) */
@@ -353,18 +365,95 @@ static int obst_row(const work_t* w, int k, int m, double px, double py, double*
     *ax = -nx; *ay = -ny;
     return 1;
 }
-/* sum |g + s| over the clearance rows at the point X with slacks sl */
-static double obst_theta(const work_t* w, const double* X, const double* sl) {
+static int fp_turns(const work_t* w) { return w->ob && w->ob->footprint_kind >= 2; }
+static int is_dynamic(const work_t* w, int j) { return j >= 0 && w->ob && w->ob->dynamic && w->vel && (w->vel[2 * j] != 0.0 || w->vel[2 * j + 1] != 0.0); }
+/* teb Line / PolygonRobotFootprint::calculateDistance for a point / circular obstacle: the obstacle centre in the robot frame,
+ * q = R(-theta)(p_o - p), against the fixed segment / closed edge loop (first closest edge, no inside test).  Returns the distance; a = gradient
+ * of the row g = d_min - dist wrt (x, y, theta), hk as in obst_eval, h3 = hess g [x theta, y theta, theta theta]. */
+static double line_eval(const work_t* w, double px, double py, double th, int j, double a[3], double* hk, double h3[3]) {
+    const oracle_obst* o = w->ob;
+    const double* v = w->verts + (size_t)2 * o->max_vertices * j;
+    const double s = sin(th), c = cos(th), vx = v[0] - px, vy = v[1] - py;
+    const double qx = c * vx + s * vy, qy = c * vy - s * vx;
+    const int poly = o->footprint_kind == 4, nv = poly ? o->footprint_nv : 2, ne = nv <= 2 ? 1 : nv;
+    double dx = 0, dy = 0, t = 0, best = 1.7976931348623157e308;
+    for (int e = 0; e < ne; ++e) {
+        const int e2 = nv == 1 ? 0 : (e + 1) % nv;
+        const double a0 = poly ? o->footprint_poly[2 * e] : o->footprint_params[0], a1 = poly ? o->footprint_poly[2 * e + 1] : o->footprint_params[1];
+        const double b0 = poly ? o->footprint_poly[2 * e2] : o->footprint_params[2], b1 = poly ? o->footprint_poly[2 * e2 + 1] : o->footprint_params[3];
+        const double abx = b0 - a0, aby = b1 - a1, sq = abx * abx + aby * aby;
+        double te = sq > 0 ? ((qx - a0) * abx + (qy - a1) * aby) / sq : 0.0;
+        te = fmin(1.0, fmax(0.0, te));
+        const double ex = qx - (a0 + te * abx), ey = qy - (a1 + te * aby), de = sqrt(ex * ex + ey * ey);
+        if (de < best) { best = de; dx = ex; dy = ey; t = te; }
+    }
+    const double D = best;
+    double nx = 0, ny = 0;
+    *hk = 0;
+    if (D > 0) { nx = dx / D; ny = dy / D; *hk = (t > 0 && t < 1) ? 0.0 : 1.0 / D; }
+    const double nw = nx * qy - ny * qx;
+    a[0] = c * nx - s * ny; a[1] = s * nx + c * ny; a[2] = -nw;
+    const double hwx = *hk * (qy - nx * nw), hwy = *hk * (-qx - ny * nw);
+    h3[0] = -((s * hwy - c * hwx) + (nx * s + ny * c));
+    h3[1] = -((-s * hwx - c * hwy) + (ny * s - nx * c));
+    h3[2] = -((qy * hwx - qx * hwy) - (nx * qx + ny * qy));
+    return D - (w->radius ? w->radius[j] : 0.0);
+}
+/* teb TwoCirclesRobotFootprint::calculateDistance: the closer of the two circles (front wins a tie), chain rule through the heading */
+static double two_eval(const work_t* w, double px, double py, double th, int j, double a[3], double* hk, double h3[3]) {
+    const double* fp = w->ob->footprint_params;
+    const double s = sin(th), c = cos(th);
+    double df, nfx, nfy, hf, dr, nrx, nry, hr;
+    obst_eval(w, px + fp[0] * c, py + fp[0] * s, j, &df, &nfx, &nfy, &hf);
+    obst_eval(w, px - fp[2] * c, py - fp[2] * s, j, &dr, &nrx, &nry, &hr);
+    df -= fp[1]; dr -= fp[3];
+    const int rear = dr < df;
+    const double o = rear ? -fp[2] : fp[0], nx = rear ? nrx : nfx, ny = rear ? nry : nfy;
+    *hk = rear ? hr : hf;
+    const double wx = -o * s, wy = o * c, nw = nx * wx + ny * wy;
+    a[0] = -nx; a[1] = -ny; a[2] = -nw;
+    const double hvx = *hk * (wx - nx * nw), hvy = *hk * (wy - ny * nw);
+    h3[0] = -hvx; h3[1] = -hvy; h3[2] = -((wx * hvx + wy * hvy) - o * (nx * c + ny * s));
+    return rear ? dr : df;
+}
+static double turn_dist(const work_t* w, double px, double py, double th, int j, double a[3], double* hk, double h3[3]) {
+    return w->ob->footprint_kind == 3 ? two_eval(w, px, py, th, j, a, hk, h3) : line_eval(w, px, py, th, j, a, hk, h3);
+}
+/* row (k,m) with its third-variable parts: heading (footprints that turn with the pose) or dt (dynamic obstacle: the obstacle moved by
+ * k D v = the static row at p - k D v, stage_inequality_se2.cpp:177-189) */
+static int obst_row3(const work_t* w, int k, int m, double px, double py, double th, double D, double* g, double a[3], double* hk, double h3[3]) {
+    const int j = w->oi[k * obst_M(w) + m];
+    if (j < 0) return 0;
+    a[2] = 0; h3[0] = h3[1] = h3[2] = 0;
+    if (is_dynamic(w, j)) {
+        const double kvx = k * w->vel[2 * j], kvy = k * w->vel[2 * j + 1];
+        double dist, nx, ny;
+        obst_eval(w, px - D * kvx, py - D * kvy, j, &dist, &nx, &ny, hk);
+        *g = w->ob->min_obstacle_dist - (dist - w->ob->footprint_radius);
+        a[0] = -nx; a[1] = -ny;
+        if (w->c->dt_free) {
+            const double nkv = nx * kvx + ny * kvy, hx = *hk * (kvx - nx * nkv), hy = *hk * (kvy - ny * nkv);
+            a[2] = nkv; h3[0] = hx; h3[1] = hy; h3[2] = -(kvx * hx + kvy * hy);
+        }
+        return 1;
+    }
+    if (fp_turns(w)) { *g = w->ob->min_obstacle_dist - turn_dist(w, px, py, th, j, a, hk, h3); return 1; }
+    return obst_row(w, k, m, px, py, g, &a[0], &a[1], hk);
+}
+/* sum |g + s| over the clearance rows at the point (X, D) with slacks sl */
+static double obst_theta(const work_t* w, const double* X, double D, const double* sl) {
     const int n = w->n, M = obst_M(w);
     double th = 0;
     for (int k = 1; k < n - 1; ++k) for (int m = 0; m < M; ++m) {
-        double g, ax, ay, hk;
-        if (obst_row(w, k, m, X[3 * k], X[3 * k + 1], &g, &ax, &ay, &hk)) th += fabs(g + sl[k * M + m]);
+        double g, a[3], hk, h3[3];
+        if (obst_row3(w, k, m, X[3 * k], X[3 * k + 1], X[3 * k + 2], D, &g, a, &hk, h3)) th += fabs(g + sl[k * M + m]);
     }
     return th;
 }
 
 /* ---- via-points: MinTimeViaPointsCost::update (min_time_via_points_cost.cpp:39-117) + findClosestPose (...grid_base_se2.cpp:364-388) */
+static const double* g_ovel = NULL;      /* obstacle velocities of the next batch [B][O][2] (dynamic obstacles) */
+void oracle_set_obstacle_velocities(const double* vel) { g_ovel = vel; }
 static const int32_t* g_nvia = NULL; static const double* g_via = NULL; static int g_vp_cap = 0;
 void oracle_set_via_points(const int32_t* n_via, const double* via, int cap) { g_nvia = n_via; g_via = via; g_vp_cap = cap > 64 ? 64 : cap; }
 static void via_associate(work_t* w) {
@@ -463,22 +552,25 @@ static void kkt_terms(const work_t* w, const double* cc, err_t* e) {
             if (c->integral) rdd += c->Q[0] * xd[0] * xd[0] + c->Q[1] * xd[1] * xd[1] + c->Q[2] * xd[2] * xd[2] + c->R[0] * v * v + c->R[1] * om * om;
         }
         if (c->via && k >= 1) { double vv, vg[3]; via_terms(w, k, w->X[3 * k], w->X[3 * k + 1], w->X[3 * k + 2], &vv, vg); for (int i = 0; i < 3; ++i) gx[i] += vg[i]; }
-        double osx = 0, osy = 0;
+        double osx = 0, osy = 0, ost = 0;
         if (k >= 1) for (int m = 0, M = obst_M(w); m < M; ++m) {
-            double g, ax, ay, hk;
+            double g, a3[3], hk, h3[3];
             work_t* wm = (work_t*)w;           /* the caches are scratch */
-            if (!obst_row(w, k, m, w->X[3 * k], w->X[3 * k + 1], &g, &ax, &ay, &hk)) continue;
+            if (!obst_row3(w, k, m, w->X[3 * k], w->X[3 * k + 1], w->X[3 * k + 2], w->D, &g, a3, &hk, h3)) continue;
+            const double ax = a3[0], ay = a3[1];
             wm->og[k * M + m] = g; wm->oax[k * M + m] = ax; wm->oay[k * M + m] = ay; wm->ohk[k * M + m] = hk;
+            wm->oat[k * M + m] = a3[2]; for (int i = 0; i < 3; ++i) wm->oh3[3 * (k * M + m) + i] = h3[i];
             const double sl = w->os[k * M + m], y = w->oy[k * M + m], res = g + sl;
             if (fabs(res) > e->rp) e->rp = fabs(res);
             e->theta += fabs(res);
             if (sl * y < e->cmin) e->cmin = sl * y; if (sl * y > e->cmax) e->cmax = sl * y;
             e->sb += y; e->nb += 1;
             osx += y * ax; osy += y * ay;
+            if (is_dynamic(w, w->oi[k * M + m])) rdd += y * a3[2]; else ost += y * a3[2];
         }
         if (k >= 1) {
             const double* lp = &w->lam[3 * (k - 1)];
-            double r[3] = {gx[0] + osx + lam[0] - lp[0], gx[1] + osy + lam[1] - lp[1], gx[2] + lam[2] + gq[0] - lp[2]};
+            double r[3] = {gx[0] + osx + lam[0] - lp[0], gx[1] + osy + lam[1] - lp[1], gx[2] + ost + lam[2] + gq[0] - lp[2]};
             for (int i = 0; i < 3; ++i) if (fabs(r[i]) > e->rd) e->rd = fabs(r[i]);
         }
         for (int j = 0; j < 2; ++j) {
@@ -638,6 +730,18 @@ static void assemble(work_t* w, const double* cc, double delta, double dc, doubl
             sym_add(w, ixn(k, 0), ixn(k, 1), sig * ax * ay + y * hk * ax * ay);
             band_add(w, ixn(k, 1), ixn(k, 1), sig * ay * ay - y * hk * (1.0 - ay * ay));
             w->rhs[ixn(k, 0)] -= ax * ybar; w->rhs[ixn(k, 1)] -= ay * ybar;
+            const double at = w->oat[k * M + m], *h3 = &w->oh3[3 * (k * M + m)];
+            if (is_dynamic(w, w->oi[k * M + m])) {          /* third variable = dt: border column, dt-dt entry, dt gradient */
+                w->bcol[ixn(k, 0)] += sig * ax * at + y * h3[0];
+                w->bcol[ixn(k, 1)] += sig * ay * at + y * h3[1];
+                hdd += sig * at * at + y * h3[2];
+                gd += at * ybar;
+            } else if (fp_turns(w)) {                       /* third variable = heading */
+                sym_add(w, ixn(k, 0), ixn(k, 2), sig * ax * at + y * h3[0]);
+                sym_add(w, ixn(k, 1), ixn(k, 2), sig * ay * at + y * h3[1]);
+                band_add(w, ixn(k, 2), ixn(k, 2), sig * at * at + y * h3[2]);
+                w->rhs[ixn(k, 2)] -= at * ybar;
+            }
         }
     }
     /* terminal state block: free components are variables, fixed ones are pinned (dx = 0) */
@@ -762,9 +866,9 @@ static int solve_one(work_t* w, int warm) {
         obst_centroids(w);
         obst_associate(w);
         for (int k = 0; k < n; ++k) for (int m = 0; m < M; ++m) {
-            double g, ax, ay, hk;
+            double g, a3[3], hk, h3[3];
             w->os[k * M + m] = 1.0; w->oy[k * M + m] = 0.0; w->ods[k * M + m] = 0.0; w->ody[k * M + m] = 0.0;
-            if (k >= 1 && k < n - 1 && obst_row(w, k, m, w->X[3 * k], w->X[3 * k + 1], &g, &ax, &ay, &hk)) {
+            if (k >= 1 && k < n - 1 && obst_row3(w, k, m, w->X[3 * k], w->X[3 * k + 1], w->X[3 * k + 2], w->D, &g, a3, &hk, h3)) {
                 w->os[k * M + m] = fmax(-g, slack_push); w->oy[k * M + m] = w->mu / w->os[k * M + m];
             } else w->oi[k * M + m] = -1;
         }
@@ -881,7 +985,8 @@ static int solve_one(work_t* w, int warm) {
                 }
                 for (int k = 1, M = obst_M(w); k < n - 1; ++k) for (int m = 0; m < M; ++m) {
                     if (w->oi[k * M + m] < 0) continue;
-                    const double jdz = w->oax[k * M + m] * w->dz_x[3 * k] + w->oay[k * M + m] * w->dz_x[3 * k + 1];
+                    const double jdz = w->oax[k * M + m] * w->dz_x[3 * k] + w->oay[k * M + m] * w->dz_x[3 * k + 1] +
+                                       w->oat[k * M + m] * (is_dynamic(w, w->oi[k * M + m]) ? ddt : w->dz_x[3 * k + 2]);
                     const double sl = w->os[k * M + m], y = w->oy[k * M + m], res = w->og[k * M + m] + sl;
                     const double sig = y / sl, ybar = mu / sl + sig * res;
                     w->ods[k * M + m] = -res - jdz;
@@ -927,7 +1032,7 @@ static int solve_one(work_t* w, int warm) {
             double tht = 0;
             for (int i = 0; i < 3 * (n - 1); ++i) tht += fabs(cct[i]);
             for (int r = 0; r < n; ++r) for (int q = 0; q < 4; ++q) if (row_on(w, r, q)) tht += fabs(row_val_at(w, w->Ut, w->Dt, r, q) + st[4 * r + q]);
-            if (obst_M(w) > 0) tht += obst_theta(w, w->Xt, w->ost);
+            if (obst_M(w) > 0) tht += obst_theta(w, w->Xt, w->Dt, w->ost);
             double phit = ft - mu * barrier_logs(w, w->Ut, w->Dt, st, w->ost) + w->rho * tht;
             if (isfinite(phit) && phit - phi0 - 10 * 2.220446049250313e-16 * fabs(phi0) <= eta * alpha * Dm) { accepted = 1; break; }
         }
@@ -999,11 +1104,12 @@ static void work_obst(work_t* w, const oracle_obst* ob) {       /* clearance-row
     w->ods = (double*)calloc((size_t)n * M, 8); w->ody = (double*)calloc((size_t)n * M, 8);
     w->og = (double*)calloc((size_t)n * M, 8); w->oax = (double*)calloc((size_t)n * M, 8); w->oay = (double*)calloc((size_t)n * M, 8);
     w->ohk = (double*)calloc((size_t)n * M, 8);
+    w->oat = (double*)calloc((size_t)n * M, 8); w->oh3 = (double*)calloc((size_t)3 * n * M, 8);
 }
 static void work_free(work_t* w) {
     free(w->X); free(w->U); free(w->Xt); free(w->Ut); free(w->lam); free(w->lamn); free(w->s); free(w->y); free(w->ron);
     free(w->pl); free(w->pu); free(w->AB); free(w->ipiv); free(w->rhs); free(w->bcol); free(w->dz_u); free(w->dz_x);
-    free(w->cent); free(w->oi); free(w->os); free(w->oy); free(w->ost); free(w->ods); free(w->ody); free(w->og); free(w->oax); free(w->oay); free(w->ohk);
+    free(w->cent); free(w->oi); free(w->os); free(w->oy); free(w->ost); free(w->ods); free(w->ody); free(w->og); free(w->oax); free(w->oay); free(w->ohk); free(w->oat); free(w->oh3);
     free(w);
 }
 
@@ -1033,6 +1139,7 @@ int oracle_solve_batch_obst(const oracle_config* c, int B, const double* x0, con
                 const size_t O = ob->max_obstacles, V = ob->max_vertices;
                 w->n_obst = n_obst[b] < (int)O ? n_obst[b] : (int)O;
                 w->n_vert = n_vert + (size_t)b * O; w->verts = verts + (size_t)b * O * V * 2; w->radius = radius ? radius + (size_t)b * O : NULL;
+                w->vel = (ob->dynamic && g_ovel) ? g_ovel + (size_t)b * O * 2 : NULL;
             }
             w->nvia = 0;
             if (c->via && g_nvia && g_via) { w->nvia = g_nvia[b] < g_vp_cap ? g_nvia[b] : g_vp_cap; w->via = g_via + (size_t)b * g_vp_cap * 3; }

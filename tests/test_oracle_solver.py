@@ -287,3 +287,38 @@ def test_c_oracle_integral_form_matches_numpy_goldens(name, free, c_oracle):
     assert (st == 0).all()
     assert np.abs(xo - g["x"]).max() < 1e-6 and np.abs(uo - g["u"]).max() < 1e-6 and np.abs(do - g["dt"]).max() < 1e-7
     assert np.abs(it - g["iters"]).max() <= 2
+
+
+def test_c_oracle_footprints_and_dynamic_obstacles_match_numpy_goldens(c_oracle):
+    """oracle/mpc_oracle.c restates the heading-dependent clearance rows (line / polygon / two-circle footprints) and the dt-dependent rows of
+    dynamic obstacles independently of ipm_dense.py: same solutions as the numpy fixtures."""
+    def check(g, cfg, obstacles, O, V, M, tol_it=2):
+        xo, uo, do, st, it = c_oracle.solve_batch(c_oracle.from_nlp_config(cfg), g["x0"], g["xf"], g["u_prev"], g["dt_prev"], obstacles=obstacles,
+                                                  obst=c_oracle.obst_from_nlp_config(cfg, O, V, M))
+        assert (st == 0).all()
+        assert np.abs(xo - g["x"]).max() < 1e-6 and np.abs(uo - g["u"]).max() < 1e-6 and np.abs(do - g["dt"]).max() < 1e-7
+        assert np.abs(it - g["iters"]).max() <= tol_it
+    # line footprint, point obstacles
+    g = np.load(os.path.join(GOLD, "carlike_line_footprint_n30.npz"))
+    B, O = g["pts"].shape[:2]
+    cfg = R.config_carlike_min_time(30)
+    cfg.footprint_kind, cfg.footprint_params = R.FOOTPRINT_LINE, tuple(g["line"])
+    cfg.min_obstacle_dist, cfg.force_inclusion_dist, cfg.cutoff_dist = 0.27, 0.5, 2.5
+    check(g, cfg, (np.full(B, O, np.int32), np.ones((B, O), np.int32), g["pts"].reshape(B, O, 1, 2)), O, 1, int(g["max_rows"]))
+    # polygon footprint, point obstacles
+    g = np.load(os.path.join(GOLD, "carlike_polygon_footprint_n30.npz"))
+    B, O = g["pts"].shape[:2]
+    cfg = R.config_carlike_min_time(30)
+    cfg.footprint_kind, cfg.footprint_params = R.FOOTPRINT_POLYGON, tuple(g["poly"])
+    cfg.min_obstacle_dist, cfg.force_inclusion_dist, cfg.cutoff_dist = 0.15, 0.5, 2.5
+    check(g, cfg, (np.full(B, O, np.int32), np.ones((B, O), np.int32), g["pts"].reshape(B, O, 1, 2)), O, 1, int(g["max_rows"]))
+    # two circles, polygon obstacles
+    g = np.load(os.path.join(GOLD, "unicycle_two_circles_obstacles_n30.npz"))
+    cfg = R.config_unicycle_quadratic(30)
+    cfg.footprint_kind, cfg.footprint_params = R.FOOTPRINT_TWO_CIRCLES, tuple(g["two"])
+    check(g, cfg, (g["n_obstacles"], g["n_vertices"], g["vertices"]), g["vertices"].shape[1], g["vertices"].shape[2], int(g["max_rows"]))
+    # dynamic obstacles (dt free)
+    g = np.load(os.path.join(GOLD, "carlike_dynamic_obstacles_n30.npz"))
+    cfg = R.config_carlike_min_time(30)
+    cfg.enable_dynamic_obstacles, cfg.min_obstacle_dist, cfg.force_inclusion_dist, cfg.cutoff_dist = True, 0.3, 0.5, 2.5
+    check(g, cfg, (g["n_obstacles"], g["n_vertices"], g["vertices"], g["radius"], g["velocity"]), g["vertices"].shape[1], 1, int(g["max_rows"]))
