@@ -20,6 +20,7 @@ class OracleConfig(C.Structure):
         ("du_ub", C.c_double * 2), ("max_iter", C.c_int32), ("tol", C.c_double), ("mu_init", C.c_double),
         ("collocation", C.c_int32),
         ("via", C.c_int32), ("vp_ordered", C.c_int32), ("vp_wp", C.c_double), ("vp_wo", C.c_double),
+        ("ball", C.c_int32), ("ball_S", C.c_double * 3), ("ball_gamma", C.c_double),
         ("integral", C.c_int32),
     ]
 
@@ -66,6 +67,10 @@ def from_nlp_config(cfg, max_iter=100, tol=1e-8, mu_init=0.1) -> OracleConfig:
     o.max_iter, o.tol, o.mu_init = max_iter, tol, mu_init
     o.collocation = int(getattr(cfg, "collocation", 0))
     o.integral = int(bool(getattr(cfg, "integral_form", False)) and cfg.objective == 1)
+    if getattr(cfg, "terminal_ball_S", None) is not None:
+        o.ball, o.ball_gamma = 1, float(cfg.terminal_ball_gamma)
+        for i in range(3):
+            o.ball_S[i] = float(cfg.terminal_ball_S[i])
     if cfg.objective == 2:          # minimum_time_via_points = minimum time + via-point terms (set the points with set_via_points)
         o.objective, o.via = 0, 1
         o.vp_ordered, o.vp_wp, o.vp_wo = int(cfg.via_points_ordered), cfg.vp_position_weight, cfg.vp_orientation_weight

@@ -56,6 +56,8 @@ typedef struct oracle_config {
     int32_t via;                /* minimum_time_via_points: objective 0 plus the via-point terms (min_time_via_points_cost.cpp:120-145) */
     int32_t vp_ordered;
     double vp_wp, vp_wo;
+    int32_t ball;               /* terminal l2-ball row xd' S xd - gamma <= 0 on the free final state (final_state_conditions_se2.cpp:54-64) */
+    double ball_S[3], ball_gamma;
     int32_t integral;           /* quadratic objective in integral form: stage cost x dt (left sum; quadratic_cost_se2.cpp:54-83, finite_differences_grid_se2.cpp:61-75) */
 } oracle_config;
 
@@ -206,6 +208,7 @@ typedef struct {
     double *oat, *oh3;                   /* third-variable parts of the rows: gradient entry n*M and Hessian entries 3*n*M -- heading for the
                                           * footprints that turn with the pose, dt for dynamic obstacles */
     const double* vel;                   /* obstacle velocities of this instance [O][2] or NULL */
+    double ts, ty, tst, tds, tdy, tg, ta[3];   /* terminal-ball row: slack, multiplier, trial slack, steps, cached value and gradient */
     /* via-points of this instance (set per batch with oracle_set_via_points) and the grid point each one is attached to */
     int nvia; const double* via; int vidx[64];
 } work_t;
@@ -514,6 +517,18 @@ static void eval_point(const work_t* w, const double* X, const double* U, double
     *fobj = f;
 }
 
+static int ball_on(const work_t* w) { return w->c->ball && !(w->c->xf_fixed[0] && w->c->xf_fixed[1] && w->c->xf_fixed[2]); }
+static double ball_eval(const work_t* w, const double* X, double a[3]) {
+    const oracle_config* c = w->c;
+    double g = -c->ball_gamma;
+    for (int i = 0; i < 3; ++i) {
+        a[i] = 0;
+        if (c->xf_fixed[i]) continue;
+        double xd = X[3 * (w->n - 1) + i] - w->xf[i]; if (i == 2) xd = wrap(xd);
+        g += c->ball_S[i] * xd * xd; a[i] = 2 * c->ball_S[i] * xd;
+    }
+    return g;
+}
 static double barrier_logs(const work_t* w, const double* U, double D, const double* s, const double* os) {
     const oracle_config* c = w->c;
     int n = w->n;
@@ -592,7 +607,17 @@ static void kkt_terms(const work_t* w, const double* cc, err_t* e) {
         for (int i = 0; i < 3; ++i) if (!c->xf_fixed[i]) {
             double g = 0.0;
             if (c->objective == 1 && c->has_Qf) { double xd = w->X[3 * (n - 1) + i] - w->xf[i]; if (i == 2) xd = wrap(xd); g = 2 * c->Qf[i] * xd; }
+            if (ball_on(w)) { double ta[3]; ball_eval(w, w->X, ta); g += w->ty * ta[i]; }
             if (fabs(g - lp[i]) > e->rd) e->rd = fabs(g - lp[i]);
+        }
+        if (ball_on(w)) {
+            work_t* wm = (work_t*)w;
+            wm->tg = ball_eval(w, w->X, wm->ta);
+            const double res = w->tg + w->ts;
+            if (fabs(res) > e->rp) e->rp = fabs(res);
+            e->theta += fabs(res);
+            if (w->ts * w->ty < e->cmin) e->cmin = w->ts * w->ty; if (w->ts * w->ty > e->cmax) e->cmax = w->ts * w->ty;
+            e->sb += w->ty; e->nb += 1;
         }
     }
     for (int r = 0; r < n; ++r) for (int q = 0; q < 4; ++q) if (row_on(w, r, q)) {
@@ -757,6 +782,15 @@ static void assemble(work_t* w, const double* cc, double delta, double dc, doubl
             }
         }
     }
+    if (ball_on(w)) {        /* condensed terminal-ball row: + sigma a a' + 2 y S, gradient + a ybar */
+        const double sig = w->ty / w->ts, ybar = mu / w->ts + sig * (w->tg + w->ts);
+        for (int i = 0; i < 3; ++i) {
+            if (c->xf_fixed[i]) continue;
+            band_add(w, ixn(n - 1, i), ixn(n - 1, i), 2 * w->ty * c->ball_S[i] + sig * w->ta[i] * w->ta[i]);
+            for (int j = i + 1; j < 3; ++j) if (!c->xf_fixed[j]) sym_add(w, ixn(n - 1, i), ixn(n - 1, j), sig * w->ta[i] * w->ta[j]);
+            w->rhs[ixn(n - 1, i)] -= w->ta[i] * ybar;
+        }
+    }
     /* rate rows, condensed: + sigma a a^T, gradient + a * ybar */
     for (int r = 0; r < n; ++r) for (int q = 0; q < 4; ++q) if (row_on(w, r, q)) {
         int j = q & 1;
@@ -873,6 +907,7 @@ static int solve_one(work_t* w, int warm) {
             } else w->oi[k * M + m] = -1;
         }
     }
+    if (ball_on(w)) { double ta[3]; w->ts = fmax(-ball_eval(w, w->X, ta), slack_push); w->ty = w->mu / w->ts; w->tds = w->tdy = 0; }
     w->pdl = c->dt_free ? w->mu / (w->D - c->dt_lb) : 0.0;
     w->pdu = c->dt_free ? w->mu / (c->dt_ub - w->D) : 0.0;
     double fobj;
@@ -996,6 +1031,16 @@ static int solve_one(work_t* w, int warm) {
                     ftb(sl, w->ods[k * M + m], tau, &a_p);
                     ftb(y, w->ody[k * M + m], tau, &a_d);
                 }
+                if (ball_on(w)) {
+                    double jdz = 0;
+                    for (int i = 0; i < 3; ++i) if (!c->xf_fixed[i]) jdz += w->ta[i] * w->dz_x[3 * (n - 1) + i];
+                    const double res = w->tg + w->ts, sig = w->ty / w->ts, ybar = mu / w->ts + sig * res;
+                    w->tds = -res - jdz; w->tdy = ybar + sig * jdz - w->ty;
+                    hdz += ybar * jdz;
+                    dphi -= (mu / w->ts) * w->tds;
+                    ftb(w->ts, w->tds, tau, &a_p);
+                    ftb(w->ty, w->tdy, tau, &a_d);
+                }
                 curv = -hdz + clam - dc * nunu;
                 if (isfinite(curv) && curv >= curv_kappa * dz2) { ok = 1; break; }
             }
@@ -1013,7 +1058,7 @@ static int solve_one(work_t* w, int warm) {
             double rt = (dphi + 0.5 * sigma * curv) / ((1.0 - rho_frac) * theta);
             if (w->rho < rt) w->rho = rt + 1.0;
         }
-        double phi0 = fobj - mu * barrier_logs(w, w->U, w->D, w->s, w->os) + w->rho * theta;
+        double phi0 = fobj - mu * (barrier_logs(w, w->U, w->D, w->s, w->os) + (ball_on(w) ? log(w->ts) : 0.0)) + w->rho * theta;
         double Dm = dphi - w->rho * theta;
         double alpha = a_p, ft = 0;
         int accepted = 0;
@@ -1033,7 +1078,9 @@ static int solve_one(work_t* w, int warm) {
             for (int i = 0; i < 3 * (n - 1); ++i) tht += fabs(cct[i]);
             for (int r = 0; r < n; ++r) for (int q = 0; q < 4; ++q) if (row_on(w, r, q)) tht += fabs(row_val_at(w, w->Ut, w->Dt, r, q) + st[4 * r + q]);
             if (obst_M(w) > 0) tht += obst_theta(w, w->Xt, w->Dt, w->ost);
-            double phit = ft - mu * barrier_logs(w, w->Ut, w->Dt, st, w->ost) + w->rho * tht;
+            double tlog = 0;
+            if (ball_on(w)) { double ta[3]; w->tst = w->ts + alpha * w->tds; tht += fabs(ball_eval(w, w->Xt, ta) + w->tst); tlog = log(w->tst); }
+            double phit = ft - mu * (barrier_logs(w, w->Ut, w->Dt, st, w->ost) + tlog) + w->rho * tht;
             if (isfinite(phit) && phit - phi0 - 10 * 2.220446049250313e-16 * fabs(phi0) <= eta * alpha * Dm) { accepted = 1; break; }
         }
         if (!accepted && alpha * dzmax < 1e-14) { status = 2; break; }
@@ -1060,6 +1107,10 @@ static int solve_one(work_t* w, int warm) {
                 w->pu[2 * k + j] = fmin(fmax(pun, mu / (kS * dun)), kS * mu / dun);
             }
             for (int i = 0; i < 3; ++i) w->lam[3 * k + i] += alpha * (w->lamn[3 * k + i] - w->lam[3 * k + i]);
+        }
+        if (ball_on(w)) {
+            double yn = w->ty + a_d * w->tdy;
+            w->ts = w->tst; w->ty = fmin(fmax(yn, mu / (kS * w->ts)), kS * mu / w->ts);
         }
         if (c->dt_free) {
             double dl = w->D - c->dt_lb, du = c->dt_ub - w->D;

@@ -322,3 +322,13 @@ def test_c_oracle_footprints_and_dynamic_obstacles_match_numpy_goldens(c_oracle)
     cfg = R.config_carlike_min_time(30)
     cfg.enable_dynamic_obstacles, cfg.min_obstacle_dist, cfg.force_inclusion_dist, cfg.cutoff_dist = True, 0.3, 0.5, 2.5
     check(g, cfg, (g["n_obstacles"], g["n_vertices"], g["vertices"], g["radius"], g["velocity"]), g["vertices"].shape[1], 1, int(g["max_rows"]))
+
+
+def test_c_oracle_terminal_ball_matches_numpy_golden(c_oracle):
+    g = np.load(os.path.join(GOLD, "unicycle_quadratic_ball_n20.npz"))
+    cfg = R.config_unicycle_quadratic(20)
+    cfg.Q, cfg.R, cfg.Qf, cfg.terminal_ball_S, cfg.terminal_ball_gamma = g["Q"], g["R"], None, g["S"], float(g["gamma"])
+    xo, uo, do, st, it = c_oracle.solve_batch(c_oracle.from_nlp_config(cfg), g["x0"], g["xf"], g["u_prev"], g["dt_prev"])
+    assert (st == 0).all()
+    assert np.abs(xo - g["x"]).max() < 1e-6 and np.abs(uo - g["u"]).max() < 1e-6
+    assert np.abs(it - g["iters"]).max() <= 2
