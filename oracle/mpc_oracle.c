@@ -20,6 +20,12 @@
  *   objective         (n-1)*dt (src/optimal_control/min_time_via_points_cost.cpp:52-56,120-124) |
  *                     quadratic form (src/optimal_control/quadratic_cost_se2.cpp:31-52) + terminal
  *                     (src/optimal_control/final_state_conditions_se2.cpp:30-52)
+ *                     via-points (src/optimal_control/min_time_via_points_cost.cpp:39-145, findClosestPose
+ *                     src/optimal_control/full_discretization_grid_base_se2.cpp:364-388) | integral form
+ *                     (src/optimal_control/quadratic_cost_se2.cpp:54-83, left sum src/optimal_control/finite_differences_grid_se2.cpp:61-75)
+ *   terminal ball     src/optimal_control/final_state_conditions_se2.cpp:54-64 (edge only with a free goal, finite_differences_grid_se2.cpp:128-143)
+ *   clearance rows    src/optimal_control/stage_inequality_se2.cpp:50-189 (association :50-162, static rows :164-175, dynamic obstacles :99-106,177-189);
+ *                     teb_local_planner distances and footprint models (point, circular, line, two circles, polygon) restated from upstream semantics
  *   rate rows         src/optimal_control/stage_inequality_se2.cpp:191-222
  *   boxes             src/controller.cpp:511,527,543 ; dt: src/optimal_control/finite_differences_variable_grid_se2.cpp:36-40
  *   cold start        src/controller.cpp:807-857 + src/optimal_control/full_discretization_grid_base_se2.cpp:192-239
