@@ -332,3 +332,68 @@ def test_c_oracle_terminal_ball_matches_numpy_golden(c_oracle):
     assert (st == 0).all()
     assert np.abs(xo - g["x"]).max() < 1e-6 and np.abs(uo - g["u"]).max() < 1e-6
     assert np.abs(it - g["iters"]).max() <= 2
+
+
+def _polish_fixture(cfg, inp, x, u, dt, **nlp_kw):
+    """SLSQP on the REFERENCE-form NLP (reference row forms, teb-style distance functions, division by dt) started at a fixture's
+    solution: the fixture must be feasible there and SLSQP must not find a better objective nearby."""
+    nlp = R.ReferenceNlp(cfg, inp, **nlp_kw)
+    z0 = nlp.pack(R.Trajectory(x, u[:-1], float(dt)))
+    lb, ub = nlp.bounds()
+    bnds = [(None if l < -1e29 else l, None if b > 1e29 else b) for l, b in zip(lb, ub)]
+    if cfg.dt_free:
+        bnds[-1] = (max(1e-3, cfg.dt_lb), cfg.dt_ub)
+    cons = [{"type": "eq", "fun": nlp.equalities}, {"type": "ineq", "fun": lambda z: -nlp.inequalities(z)}]
+    r = minimize(nlp.objective, z0, method="SLSQP", bounds=bnds, constraints=cons, options=dict(maxiter=40, ftol=1e-12))
+    assert np.abs(nlp.equalities(z0)).max() < 1e-7 and nlp.inequalities(z0).max() < 1e-7
+    f0 = nlp.objective(z0)
+    ok = np.abs(nlp.equalities(r.x)).max() < 1e-7 and nlp.inequalities(r.x).max() < 1e-7
+    assert (not ok) or r.fun > f0 - 1e-6 * max(1.0, abs(f0)), (r.fun, f0)
+    if r.status == 0:            # SLSQP agrees that this is a solution: it must not have walked away either
+        assert np.abs(r.x - z0).max() < 2e-3, np.abs(r.x - z0).max()
+    _polish_fixture.last_status = r.status
+    return f0
+
+
+def test_late_round1_fixtures_are_kkt_points_of_the_reference_form():
+    """independent pin of the fixtures behind the rows added late in round 1: via-points, terminal ball, integral form with dt free,
+    line footprint, dynamic obstacles -- first instance of each, polished with SLSQP on the reference-form NLP."""
+    g = np.load(os.path.join(GOLD, "carlike_via_points_n30.npz"))
+    cfg = R.config_carlike_min_time(30)
+    cfg.objective, cfg.vp_position_weight = R.OBJ_MIN_TIME_VIA_POINTS, float(g["wp"])
+    vps = g["via"][0, :int(g["n_via"][0])]
+    inp = R.CycleInputs(x0=g["x0"][0], xf=g["xf"][0], u_prev=g["u_prev"][0], dt_prev=float(g["dt_prev"][0]), via_points=vps)
+    f0 = _polish_fixture(cfg, inp, g["x"][0], g["u"][0], g["dt"][0], via_idx=list(g["idx"][0, :len(vps)]))
+    assert abs(f0 - float(g["objective"][0])) < 1e-9 * max(1.0, f0)
+
+    g = np.load(os.path.join(GOLD, "unicycle_quadratic_ball_n20.npz"))
+    cfg = R.config_unicycle_quadratic(20)
+    cfg.Q, cfg.R, cfg.Qf, cfg.terminal_ball_S, cfg.terminal_ball_gamma = g["Q"], g["R"], None, g["S"], float(g["gamma"])
+    inp = R.CycleInputs(x0=g["x0"][0], xf=g["xf"][0], u_prev=g["u_prev"][0], dt_prev=float(g["dt_prev"][0]))
+    _polish_fixture(cfg, inp, g["x"][0], g["u"][0], g["dt"][0])
+
+    g = np.load(os.path.join(GOLD, "unicycle_quadratic_integral_free_dt_n20.npz"))
+    cfg = R.config_unicycle_quadratic(20)
+    cfg.dt_free, cfg.dt_lb, cfg.dt_ub, cfg.xf_fixed, cfg.Qf, cfg.integral_form, cfg.R = True, 0.01, 2.0, (True, True, True), None, True, np.array([1.0, 0.5])
+    inp = R.CycleInputs(x0=g["x0"][0], xf=g["xf"][0], u_prev=g["u_prev"][0], dt_prev=float(g["dt_prev"][0]))
+    f0 = _polish_fixture(cfg, inp, g["x"][0], g["u"][0], g["dt"][0])
+    assert abs(f0 - float(g["objective"][0])) < 1e-9 * max(1.0, f0)
+
+    g = np.load(os.path.join(GOLD, "carlike_line_footprint_n30.npz"))
+    cfg = R.config_carlike_min_time(30)
+    cfg.footprint_kind, cfg.footprint_params = R.FOOTPRINT_LINE, tuple(g["line"])
+    cfg.min_obstacle_dist, cfg.force_inclusion_dist, cfg.cutoff_dist = 0.27, 0.5, 2.5
+    i = int(np.argmin(np.abs(g["dmin"] - 0.27)))                     # an instance with a binding row
+    obs = [R.Obstacle(R.OBST_POINT, g["pts"][i, o:o + 1]) for o in range(g["pts"].shape[1])]
+    inp = R.CycleInputs(x0=g["x0"][i], xf=g["xf"][i], u_prev=g["u_prev"][i], dt_prev=float(g["dt_prev"][i]), obstacles=obs)
+    rel, _ = R.associate_obstacles(cfg, R.cold_start(cfg, g["x0"][i], g["xf"][i]), obs, max_rows=int(g["max_rows"]))
+    _polish_fixture(cfg, inp, g["x"][i], g["u"][i], g["dt"][i], relevant=rel)
+
+    g = np.load(os.path.join(GOLD, "carlike_dynamic_obstacles_n30.npz"))
+    cfg = R.config_carlike_min_time(30)
+    cfg.enable_dynamic_obstacles, cfg.min_obstacle_dist, cfg.force_inclusion_dist, cfg.cutoff_dist = True, 0.3, 0.5, 2.5
+    obs = [R.Obstacle(R.OBST_CIRCLE, g["vertices"][0, 0], radius=float(g["radius"][0, 0]), velocity=g["velocity"][0, 0]),
+           R.Obstacle(R.OBST_POINT, g["vertices"][0, 1])]
+    inp = R.CycleInputs(x0=g["x0"][0], xf=g["xf"][0], u_prev=g["u_prev"][0], dt_prev=float(g["dt_prev"][0]), obstacles=obs)
+    rel, reld = R.associate_obstacles(cfg, R.cold_start(cfg, g["x0"][0], g["xf"][0]), obs, max_rows=int(g["max_rows"]) - 1)
+    _polish_fixture(cfg, inp, g["x"][0], g["u"][0], g["dt"][0], relevant=rel, relevant_dyn=reld)
