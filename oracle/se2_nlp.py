@@ -246,9 +246,17 @@ def _dist_segment_obstacle(a, b, ob: Obstacle):
         return _dist_point_segment(v[0], a, b)
     if len(v) == 2:
         return _dist_segment_segment(a, b, v[0], v[1])
-    if _point_in_polygon(a, v) or _point_in_polygon(b, v):
-        return 0.0
+    # teb distance_segment_to_polygon_2d: min over the closed edge loop of the segment-segment distance (0 where they cross; no inside test)
     return min(_dist_segment_segment(a, b, v[i], v[(i + 1) % len(v)]) for i in range(len(v)))
+
+
+def _dist_polygon_obstacle(world, ob: Obstacle):
+    """teb distance_polygon_to_polygon_2d(footprint polygon, obstacle): min over the footprint's closed edge loop of the segment-to-obstacle
+    distance (1 vertex: a point, 2 vertices: one edge)."""
+    if len(world) == 1:
+        return _dist_point_obstacle(world[0], ob)
+    ne = 1 if len(world) == 2 else len(world)
+    return min(_dist_segment_obstacle(world[i], world[(i + 1) % len(world)], ob) for i in range(ne))
 
 
 def footprint_distance(fp_kind: int, fp_params: Sequence[float], pose, ob: Obstacle, t: float = 0.0):
@@ -288,7 +296,7 @@ def footprint_distance(fp_kind: int, fp_params: Sequence[float], pose, ob: Obsta
         if ob.kind in (OBST_POINT, OBST_CIRCLE) or len(np.asarray(ob.vertices)) == 1:
             p = np.asarray(ob.vertices, float).reshape(-1, 2)[0]
             return _dist_point_obstacle(p, Obstacle(OBST_POLYGON, world)) - (ob.radius if ob.kind == OBST_CIRCLE else 0.0)
-        raise NotImplementedError("polygon footprint against line / polygon obstacles")
+        return _dist_polygon_obstacle(world, ob)
     raise ValueError("unknown footprint")
 
 

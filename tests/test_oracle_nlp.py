@@ -249,3 +249,21 @@ def test_footprint_distances_and_obstacle_association():
     assert 0 not in sum(rel, [])                 # (-3,1) is beyond the cutoff of every pose
     assert any(2 in r for r in rel)
     assert all(len(r) == 0 for r in rel_dyn)
+
+
+def test_footprint_distances_polygon_and_segment_cases():
+    """teb distance semantics for the footprint / obstacle pairs the device does not take yet (reference-form restatement only):
+    segment and polygon footprints against line and polygon obstacles -- closed edge loops, 0 where edges cross, no inside tests."""
+    sq = R.Obstacle(R.OBST_POLYGON, np.array([[1, -1], [2, -1], [2, 1], [1, 1.0]]))
+    ln = R.Obstacle(R.OBST_LINE, np.array([[0.0, 2.0], [3.0, 2.0]]))
+    line_fp = (0.0, 0.0, 0.4, 0.0)
+    assert R.footprint_distance(R.FOOTPRINT_LINE, line_fp, np.array([0, 0, 0.0]), sq) == pytest.approx(0.6)
+    assert R.footprint_distance(R.FOOTPRINT_LINE, line_fp, np.array([0.8, 0, 0.0]), sq) == 0.0                 # crosses the left edge
+    assert R.footprint_distance(R.FOOTPRINT_LINE, line_fp, np.array([1.3, 0, 0.0]), sq) == pytest.approx(0.3)  # fully inside: distance to the boundary
+    assert R.footprint_distance(R.FOOTPRINT_LINE, line_fp, np.array([0, 0, math.pi / 2]), ln) == pytest.approx(1.6)
+    tri = (0.0, 0.0, 0.5, 0.0, 0.0, 0.5)
+    assert R.footprint_distance(R.FOOTPRINT_POLYGON, tri, np.array([0, 0, 0.0]), sq) == pytest.approx(0.5)
+    assert R.footprint_distance(R.FOOTPRINT_POLYGON, tri, np.array([0, 0, 0.0]), ln) == pytest.approx(1.5)
+    assert R.footprint_distance(R.FOOTPRINT_POLYGON, tri, np.array([0.7, 0, 0.0]), sq) == 0.0
+    pt = R.Obstacle(R.OBST_POINT, np.array([[0.1, 0.1]]))
+    assert R.footprint_distance(R.FOOTPRINT_POLYGON, tri, np.array([0, 0, 0.0]), pt) == pytest.approx(0.1)      # inside the footprint: boundary distance
