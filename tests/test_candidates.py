@@ -1,0 +1,61 @@
+"""Host-side candidate initial trajectories (mpc_local_planner_amd/candidates.py): the guesses against the oracle's restatements of the
+reference's two initialisations, the winner selection, and -- with the C oracle standing in for the device behind the same solve()
+signature -- the effect on the config-2 workload.  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import se2_nlp as R
+import mpc_local_planner_amd as m
+from mpc_local_planner_amd import candidates as K
+
+
+def test_guesses_match_the_reference_initialisations():
+    x0, xf, _, _ = m.workloads.carlike_min_time_inputs(32, seed=3)
+    cfg = R.config_carlike_min_time(30)
+    xc, uc, dc = K.cold_start_guess(x0, xf, 30, cfg.dt_ref)
+    xt, ut, dt = K.travel_direction_guess(x0, xf, 30, cfg.dt_ref)
+    xr, _, _ = K.travel_direction_guess(x0, xf, 30, cfg.dt_ref, reverse=True)
+    for b in range(32):
+        np.testing.assert_allclose(xc[b], R.cold_start(cfg, x0[b], xf[b]).x, atol=1e-12)                      # a2 + a5 (2-pose plan)
+        ref = R.initialize_sequences_straight_line(cfg, x0[b], xf[b]).x                                        # a4
+        np.testing.assert_allclose(xt[b], ref, atol=1e-12)
+        np.testing.assert_allclose(np.abs(R.normalize_theta(xr[b, 1:-1, 2] - ref[1:-1, 2])), np.pi, atol=1e-12)
+        np.testing.assert_array_equal(xr[b, [0, -1]], ref[[0, -1]])
+    assert (uc == 0).all() and (ut == 0).all() and (dc == cfg.dt_ref).all() and (dt == cfg.dt_ref).all()
+
+
+def test_select_best_prefers_converged_then_shortest_time():
+    #            inst 0      1      2      3
+    status = [0, 1, 0, 1,   0, 0, 1, 1]            # candidate 0, candidate 1
+    dt = [0.5, 0.2, 0.3, 0.1,   0.4, 0.9, 0.2, 0.05]
+    np.testing.assert_array_equal(K.select_best(status, dt, 2, dt_free=True), [1, 1, 0, 0])
+    np.testing.assert_array_equal(K.select_best(status, dt, 2, dt_free=False), [0, 1, 0, 0])
+
+
+class _OracleBackedSolver:
+    """stands in for BatchSolver in this CPU test: same solve() signature and result type, the C oracle does the work"""
+    def __init__(self, ocfg, c_oracle):
+        self.ocfg, self.co, self.n = ocfg, c_oracle, ocfg.n
+        self.cfg = type("Cfg", (), {"dt_ref": ocfg.dt_ref, "dt_free": ocfg.dt_free})()
+
+    def solve(self, x0, xf, u_prev=None, dt_prev=None, init=None, obstacles=None):
+        xo, uo, do, st, it = self.co.solve_batch(self.co.from_nlp_config(self.ocfg), x0, xf, u_prev, dt_prev, init=init)
+        return m.BatchResult(xo, uo, do, st, it)
+
+
+def test_best_of_two_guesses_on_config2(c_oracle):
+    """config-2 workload (car-like minimum time, n = 50): the reference's two initialisations as candidates of every instance.  The
+    converged fraction rises from ~0.94 to > 0.99 and no instance ends with a longer transition time than from the cold start alone."""
+    B = 192
+    x0, xf, up, dtp = m.workloads.carlike_min_time_inputs(B)
+    s = _OracleBackedSolver(R.config_carlike_min_time(50), c_oracle)
+    best, win, allr = K.solve_best_of(s, x0, xf, up, dtp, guesses=("cold", "travel"))
+    single = s.solve(x0, xf, up, dtp)                                   # device-style cold start (no init)
+    same = (allr.status[:B] == 0) & (single.status == 0)
+    err = np.abs(allr.x[:B, :, :2] - single.x[:, :, :2]).reshape(B, -1).max(1)[same]
+    assert (allr.status[:B] == single.status).mean() > 0.97 and np.median(err) < 1e-7 and (err < 1e-3).mean() > 0.95   # candidate 0 IS the cold start
+    assert (best.status == 0).mean() > 0.99 > (allr.status[:B] == 0).mean()
+    ok = allr.status[:B] == 0                                          # never worse than the cold-start candidate of the same batch
+    assert (best.status[ok] == 0).all() and (best.dt[ok] <= allr.dt[:B][ok] + 1e-12).all()
+    assert (best.dt[ok] < allr.dt[:B][ok] - 1e-4).mean() > 0.1          # ... and strictly better in a good share of the instances
+    assert (win == 1).mean() > 0.1                                      # the second guess does win a share of the instances

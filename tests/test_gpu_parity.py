@@ -712,3 +712,23 @@ def test_polygon_footprint_golden(m):
         dmin = min(R.footprint_distance(R.FOOTPRINT_POLYGON, tuple(g["poly"]), r.x[i, k], ob) for k in range(1, 29) for ob in obs)
         assert dmin > 0.15 - 1e-6
     s.close()
+
+
+def test_candidate_initial_trajectories_best_of(m):
+    """north star: "batches of independent planner instances (and candidate initial trajectories)".  The reference's two initialisations
+    (2-pose-plan cold start; initializeSequences without xinit) as candidates of every config-2 instance, solved as ONE batch of 2B
+    members and reduced on the host (mpc_local_planner_amd/candidates.py; the CPU twin of this test runs the same code on the C oracle,
+    tests/test_candidates.py): more instances converge, none ends worse than its cold-start candidate."""
+    from mpc_local_planner_amd import candidates as K
+    B = 256
+    x0, xf, up, dtp = m.workloads.carlike_min_time_inputs(B)
+    s = m.BatchSolver(m.config_carlike_min_time(50), max_batch=2 * B)
+    best, win, allr = K.solve_best_of(s, x0, xf, up, dtp, guesses=("cold", "travel"))
+    cold_ok = allr.status[:B] == 0
+    assert (best.status == 0).mean() >= 0.97 and (best.status == 0).mean() >= cold_ok.mean() + 0.02
+    assert (best.status[cold_ok] == 0).all() and (best.dt[cold_ok] <= allr.dt[:B][cold_ok] + 1e-12).all()
+    single = s.solve(x0, xf, up, dtp)                                   # the device-side cold start is the same guess
+    same = cold_ok & (single.status == 0)
+    err = np.abs(allr.x[:B, :, :2] - single.x[:, :, :2]).reshape(B, -1).max(1)[same]
+    assert np.median(err) < 1e-7
+    s.close()
