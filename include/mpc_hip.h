@@ -54,6 +54,20 @@ enum mpc_footprint { MPC_FOOTPRINT_POINT = 0, MPC_FOOTPRINT_CIRCLE = 1,
                      MPC_FOOTPRINT_TWO_CIRCLES = 3, /* teb TwoCirclesRobotFootprint; every obstacle kind */
                      MPC_FOOTPRINT_POLYGON = 4      /* teb PolygonRobotFootprint; point and circular obstacles */ };
 
+/* Candidate initial trajectories of one planner instance (BASELINE north star: "batches of independent planner instances (and
+ * candidate initial trajectories)").  Every candidate is a complete solve of the same NLP from its own initial vertex values. */
+enum mpc_candidate_kind {
+    MPC_CAND_REFERENCE = 0,           /* what Controller::step builds: x_init/u_init/dt_init when given, else the 2-pose-plan cold start
+                                       * (src/controller.cpp:807-857 + full_discretization_grid_base_se2.cpp:192-239) */
+    MPC_CAND_TRAVEL = 1,              /* initializeSequences without xinit (full_discretization_grid_base_se2.cpp:136-190): straight line, heading =
+                                       * direction of travel, turned by pi when the goal lies behind the start pose */
+    MPC_CAND_TRAVEL_REVERSE = 2,      /* the same with the other driving direction (ours) */
+    MPC_CAND_BLEND = 3,               /* ours: MPC_CAND_TRAVEL with the heading blended from the start heading over the first candidate_blend
+                                       * grid points and into the goal heading over the last candidate_blend grid points */
+    MPC_CAND_BLEND_REVERSE = 4        /* ours: the same around MPC_CAND_TRAVEL_REVERSE */
+};
+#define MPC_MAX_CANDIDATES 4
+
 enum mpc_status {                     /* per-instance result; 0 == what corbo reports as Converged */
     MPC_CONVERGED = 0,
     MPC_MAX_ITER = 1,
@@ -118,6 +132,16 @@ typedef struct mpc_config {
     int32_t enable_dynamic_obstacles; /* collision_avoidance/enable_dynamic_obstacles (src/controller.cpp:721); point / circular footprint */
     double  footprint_params[4];      /* MPC_FOOTPRINT_LINE: footprint_model/line_start (x, y), line_end (x, y) in the robot frame;
                                        * MPC_FOOTPRINT_TWO_CIRCLES: front_offset, front_radius, rear_offset, rear_radius (src/mpc_local_planner_ros.cpp:900-960) */
+    /* candidate initial trajectories (0 or 1 = a single solve from MPC_CAND_REFERENCE, the reference's behaviour).  With n_candidates > 1 every
+     * instance is solved from each candidate as its own workgroup of the same launch; RULE (deterministic, timing-independent): the candidate
+     * with the LOWEST index that converges within its own iteration cap supplies the result; without any, candidate 0's last iterate and
+     * status are returned.  Candidate 0 should be MPC_CAND_REFERENCE so that every instance the reference path solves keeps that answer.
+     * Lower-priority candidates stop at their next iteration once a higher-priority one has converged (hedging: they only cost time
+     * on SIMDs that would otherwise idle while the slow instances of a batch finish). */
+    int32_t n_candidates;
+    int32_t candidate_kind[MPC_MAX_CANDIDATES];
+    int32_t candidate_max_iter[MPC_MAX_CANDIDATES];   /* iteration cap of candidate c (0 -> max_iter) */
+    int32_t candidate_blend;          /* grid points of the heading blend of MPC_CAND_BLEND* (0 -> 8) */
     int32_t reserved[6];
 } mpc_config;
 
@@ -211,6 +235,12 @@ int mpc_costmap_to_obstacles_device(mpc_solver* s, int32_t B, const uint8_t* d_c
 int mpc_costmap_to_obstacles(mpc_solver* s, int32_t B, const uint8_t* cost, int32_t size_x, int32_t size_y, double resolution,
                              const double* origin, const double* robot_pose, double behind_robot_dist,
                              int32_t* n_obstacles, int32_t* n_vertices, double* vertices, int32_t* dropped);
+
+/* Candidate bookkeeping of the most recent mpc_solve_batch* call (after mpc_synchronize): winner[b] = index of the candidate that supplied
+ * instance b's result (-1: none converged, candidate 0's last iterate was returned); iters_total[b] = interior-point iterations spent on
+ * instance b over all its candidates (iters[] of the solve call is the winner's count).  HOST pointers, either may be NULL.  With
+ * n_candidates <= 1: winner = 0 / -1 from the status, iters_total = iters. */
+int mpc_last_candidates(mpc_solver* s, int32_t B, int32_t* winner, int32_t* iters_total);
 
 int mpc_synchronize(mpc_solver* s);
 

@@ -34,6 +34,13 @@ MPC_EBATCH = -5
 
 INF = 1e30
 
+CAND_REFERENCE = 0
+CAND_TRAVEL = 1
+CAND_TRAVEL_REVERSE = 2
+CAND_BLEND = 3
+CAND_BLEND_REVERSE = 4
+MAX_CANDIDATES = 4
+
 
 class MpcConfig(C.Structure):
     """struct mpc_config (include/mpc_hip.h); field-for-field."""
@@ -81,6 +88,10 @@ class MpcConfig(C.Structure):
         ("footprint_vertices", C.c_double * 32),
         ("enable_dynamic_obstacles", C.c_int32),
         ("footprint_params", C.c_double * 4),
+        ("n_candidates", C.c_int32),
+        ("candidate_kind", C.c_int32 * 4),
+        ("candidate_max_iter", C.c_int32 * 4),
+        ("candidate_blend", C.c_int32),
         ("reserved", C.c_int32 * 6),
     ]
 
@@ -103,7 +114,7 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
                 footprint_kind=0, footprint_radius=0.0, max_obstacles=0, max_vertices=1, max_obstacle_rows=4, mu_init_warm=0.0, collocation=COLLOC_FORWARD,
                 terminal_ball_S=None, terminal_ball_gamma=1.0, vp_position_weight=1e-3, vp_orientation_weight=0.0,
                 via_points_ordered=False, max_via_points=0, footprint_params=(0.0, 0.0, 0.0, 0.0),
-                enable_dynamic_obstacles=False, footprint_vertices=()) -> MpcConfig:
+                enable_dynamic_obstacles=False, footprint_vertices=(), candidates=(), candidate_max_iter=(), candidate_blend=0) -> MpcConfig:
     c = MpcConfig()
     c.model = model
     mp = list(model_params) + [0.0] * 4
@@ -148,6 +159,12 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
     c.footprint_n_vertices = len(fv) // 2
     for i, x in enumerate(fv[:32]):
         c.footprint_vertices[i] = x
+    # candidate initial trajectories: kinds (CAND_*) in priority order, per-candidate iteration caps (0 / missing -> max_iter)
+    c.n_candidates = len(candidates)
+    for i, k in enumerate(candidates[:MAX_CANDIDATES]):
+        c.candidate_kind[i] = int(k)
+        c.candidate_max_iter[i] = int(candidate_max_iter[i]) if i < len(candidate_max_iter) else 0
+    c.candidate_blend = int(candidate_blend)
     return c
 
 

@@ -86,14 +86,33 @@ __global__ __launch_bounds__(kLanes) void mpc_ipm_solve_kernel(
 
 #endif
 
-// One wavefront = one planner instance; the whole working set lives in LDS (mpc_wave.hpp).
+// Candidate bookkeeping of a launch with n_candidates > 1 (device pointers; all NULL / 0 for a single candidate).
+//   win[b]      lowest candidate index of instance b that has converged so far (INT_MAX-like: none)
+//   exited[b]   candidates of instance b that have finished; the LAST one to finish copies the winner's record to the caller's outputs
+//   it_sum[b]   iterations spent on instance b by all its candidates
+//   rec         [C][B][5 n + 3] doubles: x (n x 3), u (n x 2), dt, status, iterations of candidate c of instance b (written by candidate 0
+//               always and by every candidate that converged)
+// win / exited / it_sum are restored to their idle values by that last workgroup, so consecutive launches need no memset.
+struct CandCtl {
+    int n_cand;
+    int* win;
+    int* exited;
+    int* it_sum;
+    double* rec;
+    int32_t* winner_out;
+    int32_t* iters_total_out;
+};
+constexpr int kWinIdle = 0x7f7f7f7f;
+
+// One wavefront = one (planner instance, candidate initial trajectory); the whole working set lives in LDS (mpc_wave.hpp).
+// Grid: n_cand * B workgroups, candidate-major, so that the hardware dispatches every instance's candidate 0 before any hedge.
 template <typename T, int MODEL, bool EXT>
 __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
     mpc::Problem<T> P, mpc::WaveLayout L, int B,
     const double* __restrict__ x0, const double* __restrict__ xf, const double* __restrict__ u_prev,
     const double* __restrict__ dt_prev, const double* __restrict__ x_init, const double* __restrict__ u_init,
     const double* __restrict__ dt_init, mpc_obstacles obst, const int32_t* __restrict__ n_grid, const int32_t* __restrict__ n_via,
-    const double* __restrict__ via, double* __restrict__ x_out,
+    const double* __restrict__ via, CandCtl cc, double* __restrict__ x_out,
     double* __restrict__ u_out, double* __restrict__ dt_out, int32_t* __restrict__ status, int32_t* __restrict__ iters) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mpc_smem[];
     T* sm = reinterpret_cast<T*>(mpc_smem);
@@ -101,51 +120,108 @@ __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
     const size_t coff = (((size_t)L.total * sizeof(T)) + 15) & ~(size_t)15;
     mpc::Problem<T>* Ps = reinterpret_cast<mpc::Problem<T>*>(mpc_smem + coff);
     mpc::WaveLayout* Ls = reinterpret_cast<mpc::WaveLayout*>(mpc_smem + coff + ((sizeof(mpc::Problem<T>) + 15) & ~(size_t)15));
-    const int inst = blockIdx.x;
+    const int NC = cc.n_cand;                        // wave-uniform kernel argument
+    const int cand = NC > 1 ? (int)blockIdx.x / B : 0;
+    const int inst = (int)blockIdx.x - cand * B;
     const int lane = threadIdx.x;
-    if (inst >= B) return;
+    if (inst >= B || cand >= (NC > 1 ? NC : 1)) return;
     const int nmax = L.n;          // stride of the instance-major arrays
     int n = nmax;                  // grid points of THIS instance (grid adaptation: n_i <= n_max)
     if (n_grid) { n = n_grid[inst]; n = n < 3 ? 3 : (n > nmax ? nmax : n); }
-#ifdef MPC_POISON_LDS      // developer check: any read of an LDS word the solver did not write first turns into NaN
-    for (int e = lane; e < L.total; e += mpc::kWave) sm[e] = T(NAN);
-    __syncthreads();
-#endif
-    if (lane == 0) { *Ps = P; *Ls = L; Ls->n = n; Ps->n = n; }
-    __syncthreads();
+    // a hedge whose instance already has a converged higher-priority candidate never starts
+    bool run = true;
+    if (NC > 1 && cand > 0) {
+        const int w = __builtin_amdgcn_readfirstlane(__hip_atomic_load(cc.win + inst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        run = !(w < cand);
+    }
+    int st_status = mpc::ST_SUPERSEDED, st_iters = 0;
     mpc::WaveLayout Lv = L;            // from the kernel arguments: wave-uniform, lives in SGPRs
     Lv.n = __builtin_amdgcn_readfirstlane(n);
-    mpc::IpmWave<T, MODEL, EXT> S(*Ps, Lv, sm, lane);
-    for (int i = 0; i < 3; ++i) { S.x0[i] = T(x0[3 * inst + i]); S.xf[i] = T(xf[3 * inst + i]); }
-    S.x0[2] = mpc::normalize_theta(S.x0[2]);
-    S.xf[2] = mpc::normalize_theta(S.xf[2]);
-    S.uprev[0] = u_prev ? T(u_prev[2 * inst]) : T(0);
-    S.uprev[1] = u_prev ? T(u_prev[2 * inst + 1]) : T(0);
-    S.dtprev = dt_prev ? T(dt_prev[inst]) : T(0);
-    if (x_init && u_init && dt_init) {
-        // coalesced read of this instance's contiguous [n][3] / [n][2] blocks
-        const double* xi = x_init + (long)inst * nmax * 3;
-        const double* ui = u_init + (long)inst * nmax * 2;
-        for (int e = lane; e < 3 * n; e += mpc::kWave) S.F(L.X, e % 3, e / 3) = T(xi[e]);
-        for (int e = lane; e < 2 * (n - 1); e += mpc::kWave) S.F(L.U, e % 2, e / 2) = T(ui[e]);
-        if (lane == 0) S.SCL(mpc::SC_D) = T(dt_init[inst]);
-        S.warm_guess = true;
-    } else {
-        S.cold_start();
+    if (run) {
+#ifdef MPC_POISON_LDS      // developer check: any read of an LDS word the solver did not write first turns into NaN
+        for (int e = lane; e < L.total; e += mpc::kWave) sm[e] = T(NAN);
+        __syncthreads();
+#endif
+        if (lane == 0) { *Ps = P; *Ls = L; Ls->n = n; Ps->n = n; }
+        __syncthreads();
+        mpc::IpmWave<T, MODEL, EXT> S(*Ps, Lv, sm, lane);
+        for (int i = 0; i < 3; ++i) { S.x0[i] = T(x0[3 * inst + i]); S.xf[i] = T(xf[3 * inst + i]); }
+        S.x0[2] = mpc::normalize_theta(S.x0[2]);
+        S.xf[2] = mpc::normalize_theta(S.xf[2]);
+        S.uprev[0] = u_prev ? T(u_prev[2 * inst]) : T(0);
+        S.uprev[1] = u_prev ? T(u_prev[2 * inst + 1]) : T(0);
+        S.dtprev = dt_prev ? T(dt_prev[inst]) : T(0);
+        const int kind = NC > 1 ? P.cand_kind[cand] : 0;
+        if (NC > 1) { S.my_cand = cand; S.iter_cap = P.cand_max_iter[cand]; S.win_ptr = cand > 0 ? cc.win + inst : nullptr; }
+        if (kind == 0 && x_init && u_init && dt_init) {
+            // coalesced read of this instance's contiguous [n][3] / [n][2] blocks
+            const double* xi = x_init + (long)inst * nmax * 3;
+            const double* ui = u_init + (long)inst * nmax * 2;
+            for (int e = lane; e < 3 * n; e += mpc::kWave) S.F(L.X, e % 3, e / 3) = T(xi[e]);
+            for (int e = lane; e < 2 * (n - 1); e += mpc::kWave) S.F(L.U, e % 2, e / 2) = T(ui[e]);
+            if (lane == 0) S.SCL(mpc::SC_D) = T(dt_init[inst]);
+            S.warm_guess = true;
+        } else if (kind == 0) {
+            S.cold_start();
+        } else {
+            S.seed_start(kind);
+        }
+        if (L.M > 0) S.load_obstacles(obst.n_obstacles, obst.n_vertices, obst.vertices, obst.radius, obst.velocity, inst);
+        if (EXT && L.NV > 0) S.load_via_points(n_via, via, inst);
+        __syncthreads();
+        mpc::SolveStats<T> st = S.solve();
+        __syncthreads();
+        st_status = st.status; st_iters = st.iters;
+        if (NC <= 1) {
+            double* xo = x_out + (long)inst * nmax * 3;
+            double* uo = u_out + (long)inst * nmax * 2;
+            for (int e = lane; e < 3 * nmax; e += mpc::kWave) { int k = e / 3; int ks = k < n ? k : n - 1; xo[e] = double(S.F(L.X, e % 3, ks)); }
+            for (int e = lane; e < 2 * nmax; e += mpc::kWave) { int k = e / 2; int ks = k < n - 1 ? k : n - 2; uo[e] = double(S.F(L.U, e % 2, ks)); }
+            if (lane == 0) {
+                dt_out[inst] = double(S.SCL(mpc::SC_D));
+                if (status) status[inst] = st.status;
+                if (iters) iters[inst] = st.iters;
+            }
+            return;
+        }
+        // candidate record: candidate 0 always (its last iterate is the fallback), the others when they converged
+        if (cand == 0 || st.status == mpc::ST_CONVERGED) {
+            double* r = cc.rec + ((long)cand * B + inst) * (5 * nmax + 3);
+            for (int e = lane; e < 3 * nmax; e += mpc::kWave) { int k = e / 3; int ks = k < n ? k : n - 1; r[e] = double(S.F(L.X, e % 3, ks)); }
+            for (int e = lane; e < 2 * nmax; e += mpc::kWave) { int k = e / 2; int ks = k < n - 1 ? k : n - 2; r[3 * nmax + e] = double(S.F(L.U, e % 2, ks)); }
+            if (lane == 0) { r[5 * nmax] = double(S.SCL(mpc::SC_D)); r[5 * nmax + 1] = double(st.status); r[5 * nmax + 2] = double(st.iters); }
+        }
     }
-    if (L.M > 0) S.load_obstacles(obst.n_obstacles, obst.n_vertices, obst.vertices, obst.radius, obst.velocity, inst);
-    if (EXT && L.NV > 0) S.load_via_points(n_via, via, inst);
+    // ---- exit protocol (n_cand > 1): publish, count, and let the last candidate of the instance deliver the result
+    __threadfence();
     __syncthreads();
-    mpc::SolveStats<T> st = S.solve();
-    __syncthreads();
+    int last = 0;
+    if (lane == 0) {
+        if (st_status == mpc::ST_CONVERGED) atomicMin(cc.win + inst, cand);
+        if (st_iters > 0) atomicAdd(cc.it_sum + inst, st_iters);
+        __threadfence();
+        last = atomicAdd(cc.exited + inst, 1) == NC - 1;
+    }
+    last = __builtin_amdgcn_readfirstlane(last);
+    if (!last) return;
+    __threadfence();
+    const int w = __builtin_amdgcn_readfirstlane(__hip_atomic_load(cc.win + inst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    const int src = w < NC ? w : 0;
+    const double* r = cc.rec + ((long)src * B + inst) * (5 * nmax + 3);
     double* xo = x_out + (long)inst * nmax * 3;
     double* uo = u_out + (long)inst * nmax * 2;
-    for (int e = lane; e < 3 * nmax; e += mpc::kWave) { int k = e / 3; int ks = k < n ? k : n - 1; xo[e] = double(S.F(L.X, e % 3, ks)); }
-    for (int e = lane; e < 2 * nmax; e += mpc::kWave) { int k = e / 2; int ks = k < n - 1 ? k : n - 2; uo[e] = double(S.F(L.U, e % 2, ks)); }
+    for (int e = lane; e < 3 * nmax; e += mpc::kWave) xo[e] = __builtin_nontemporal_load(r + e);
+    for (int e = lane; e < 2 * nmax; e += mpc::kWave) uo[e] = __builtin_nontemporal_load(r + 3 * nmax + e);
     if (lane == 0) {
-        dt_out[inst] = double(S.SCL(mpc::SC_D));
-        if (status) status[inst] = st.status;
-        if (iters) iters[inst] = st.iters;
+        dt_out[inst] = __builtin_nontemporal_load(r + 5 * nmax);
+        if (status) status[inst] = (int32_t)__builtin_nontemporal_load(r + 5 * nmax + 1);
+        if (iters) iters[inst] = (int32_t)__builtin_nontemporal_load(r + 5 * nmax + 2);
+        if (cc.winner_out) cc.winner_out[inst] = w < NC ? w : -1;
+        if (cc.iters_total_out) cc.iters_total_out[inst] = __hip_atomic_load(cc.it_sum + inst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // back to idle for the next launch
+        __hip_atomic_store(cc.win + inst, kWinIdle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(cc.it_sum + inst, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(cc.exited + inst, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -175,6 +251,12 @@ struct mpc_solver {
     const double* p_via;
     int use_ngrid;
     double *d_ov, *d_or, *d_ovel;
+    // candidate initial trajectories (n_candidates > 1): bookkeeping words, candidate records, per-instance winner / total iterations
+    int *d_cwin, *d_cexited, *d_citsum;
+    double* d_crec;
+    int32_t *d_winner, *d_iters_total;
+    int32_t* last_status;       // device pointers of the most recent solve (mpc_last_candidates without candidates)
+    int32_t* last_iters;
     bool timed;
 };
 
@@ -253,6 +335,12 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         set_err("mpc_create: the line and polygon footprints are implemented for point and circular obstacles (max_vertices = 1)"); return MPC_EINVAL; }
     for (int j = 0; j < 2; ++j)
         if (!(cfg->u_lb[j] < cfg->u_ub[j])) { set_err("mpc_create: control box must be finite and non-empty"); return MPC_EINVAL; }
+    if (cfg->n_candidates < 0 || cfg->n_candidates > MPC_MAX_CANDIDATES) { set_err("mpc_create: n_candidates must be in [0, MPC_MAX_CANDIDATES]"); return MPC_EINVAL; }
+    for (int k = 0; k < cfg->n_candidates; ++k)
+        if (cfg->candidate_kind[k] < MPC_CAND_REFERENCE || cfg->candidate_kind[k] > MPC_CAND_BLEND_REVERSE || cfg->candidate_max_iter[k] < 0) {
+            set_err("mpc_create: unknown candidate kind or negative candidate_max_iter"); return MPC_EINVAL; }
+    if (cfg->dt_free && !(cfg->dt_lb < cfg->dt_ub)) { set_err("mpc_create: dt_lb must be below dt_ub on the variable grid"); return MPC_EINVAL; }
+    if (cfg->dt_free && !(cfg->dt_ref >= cfg->dt_lb && cfg->dt_ref <= cfg->dt_ub)) { set_err("mpc_create: dt_ref must lie in [dt_lb, dt_ub] on the variable grid"); return MPC_EINVAL; }
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
     if (e != hipSuccess || ndev <= 0) {
@@ -335,6 +423,18 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         if (er == hipSuccess) er = hipMalloc((void**)&s->d_or, Bm * O * 8);
         if (er == hipSuccess && cfg->enable_dynamic_obstacles) er = hipMalloc((void**)&s->d_ovel, Bm * O * 2 * 8);
     }
+    if (s->P64.n_cand > 1) {
+        const size_t C_ = s->P64.n_cand;
+        if (er == hipSuccess) er = hipMalloc((void**)&s->d_cwin, Bm * 4);
+        if (er == hipSuccess) er = hipMalloc((void**)&s->d_cexited, Bm * 4);
+        if (er == hipSuccess) er = hipMalloc((void**)&s->d_citsum, Bm * 4);
+        if (er == hipSuccess) er = hipMalloc((void**)&s->d_crec, C_ * Bm * (5 * n + 3) * 8);
+        if (er == hipSuccess) er = hipMalloc((void**)&s->d_winner, Bm * 4);
+        if (er == hipSuccess) er = hipMalloc((void**)&s->d_iters_total, Bm * 4);
+        if (er == hipSuccess) er = hipMemset(s->d_cwin, 0x7f, Bm * 4);
+        if (er == hipSuccess) er = hipMemset(s->d_cexited, 0, Bm * 4);
+        if (er == hipSuccess) er = hipMemset(s->d_citsum, 0, Bm * 4);
+    }
     if (er != hipSuccess) {
         set_err("mpc_create: allocation", er);
         mpc_destroy(s);
@@ -344,13 +444,24 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
     return MPC_OK;
 }
 
-int mpc_reset(mpc_solver* s) { return s ? MPC_OK : MPC_EINVAL; }
+int mpc_reset(mpc_solver* s) {
+    if (!s) return MPC_EINVAL;
+    g_err[0] = 0;
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->d_cwin) {      // candidate bookkeeping back to idle (it is self-restoring unless a launch was aborted)
+        HIP_TRY(hipMemset(s->d_cwin, 0x7f, (size_t)s->max_batch * 4));
+        HIP_TRY(hipMemset(s->d_cexited, 0, (size_t)s->max_batch * 4));
+        HIP_TRY(hipMemset(s->d_citsum, 0, (size_t)s->max_batch * 4));
+    }
+    return MPC_OK;
+}
 
 void mpc_destroy(mpc_solver* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    void* bufs[] = {s->d_ovel, s->d_nvia, s->d_via, s->d_ngrid, s->d_ono, s->d_onv, s->d_ov, s->d_or, s->ws, s->d_x0, s->d_xf, s->d_up, s->d_dtp, s->d_xi, s->d_ui, s->d_dti, s->d_xo, s->d_uo, s->d_dto, s->d_status, s->d_iters};
+    void* bufs[] = {s->d_cwin, s->d_cexited, s->d_citsum, s->d_crec, s->d_winner, s->d_iters_total, s->d_ovel, s->d_nvia, s->d_via, s->d_ngrid, s->d_ono, s->d_onv, s->d_ov, s->d_or, s->ws, s->d_x0, s->d_xf, s->d_up, s->d_dtp, s->d_xi, s->d_ui, s->d_dti, s->d_xo, s->d_uo, s->d_dto, s->d_status, s->d_iters};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
@@ -371,7 +482,9 @@ static hipError_t launch_model(mpc_solver* s, const mpc::Problem<T>& P, int B, c
             hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->wave_lds);
             if (e != hipSuccess) return e;
         }
-        hipLaunchKernelGGL(kern, dim3(B), dim3(mpc::kWave), s->wave_lds, s->stream, P, s->WL, B, x0, xf, up, dtp, xi, ui, dti, ob, s->use_ngrid ? s->d_ngrid : nullptr, s->p_nvia, s->p_via, xo, uo, dto, st, it);
+        CandCtl cc = {P.n_cand, s->d_cwin, s->d_cexited, s->d_citsum, s->d_crec, s->d_winner, s->d_iters_total};
+        hipLaunchKernelGGL(kern, dim3((unsigned)B * (unsigned)(P.n_cand > 1 ? P.n_cand : 1)), dim3(mpc::kWave), s->wave_lds, s->stream, P, s->WL, B, x0, xf, up, dtp, xi, ui, dti, ob,
+                           s->use_ngrid ? s->d_ngrid : nullptr, s->p_nvia, s->p_via, cc, xo, uo, dto, st, it);
     } else {
 #ifdef MPC_ENABLE_LANE_KERNEL
         dim3 grid((B + kLanes - 1) / kLanes), block(kLanes);
@@ -425,6 +538,31 @@ int mpc_solve_batch_device(mpc_solver* s, int32_t B, const double* d_x0, const d
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipEventRecord(s->ev1, s->stream));
     s->timed = true;
+    s->last_status = d_status; s->last_iters = d_iters;
+    return MPC_OK;
+}
+
+int mpc_last_candidates(mpc_solver* s, int32_t B, int32_t* winner, int32_t* iters_total) {
+    g_err[0] = 0;
+    if (!s) return MPC_EINVAL;
+    if (B <= 0) return MPC_OK;
+    if (B > s->max_batch) { set_err("mpc_last_candidates: B exceeds max_batch"); return MPC_EBATCH; }
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->P64.n_cand > 1) {
+        if (winner) HIP_TRY(hipMemcpy(winner, s->d_winner, (size_t)B * 4, hipMemcpyDeviceToHost));
+        if (iters_total) HIP_TRY(hipMemcpy(iters_total, s->d_iters_total, (size_t)B * 4, hipMemcpyDeviceToHost));
+        return MPC_OK;
+    }
+    if (winner) {
+        if (!s->last_status) { set_err("mpc_last_candidates: the last solve kept no status array"); return MPC_EINVAL; }
+        HIP_TRY(hipMemcpy(winner, s->last_status, (size_t)B * 4, hipMemcpyDeviceToHost));
+        for (int b = 0; b < B; ++b) winner[b] = winner[b] == MPC_CONVERGED ? 0 : -1;
+    }
+    if (iters_total) {
+        if (!s->last_iters) { set_err("mpc_last_candidates: the last solve kept no iteration array"); return MPC_EINVAL; }
+        HIP_TRY(hipMemcpy(iters_total, s->last_iters, (size_t)B * 4, hipMemcpyDeviceToHost));
+    }
     return MPC_OK;
 }
 

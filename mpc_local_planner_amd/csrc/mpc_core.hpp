@@ -43,6 +43,7 @@ constexpr int ST_MAX_ITER = 1;
 constexpr int ST_LINESEARCH = 2;
 constexpr int ST_LINSOLVE = 3;
 constexpr int ST_NUMERICAL = 4;
+constexpr int ST_SUPERSEDED = 5;     // internal: a candidate stopped because a higher-priority candidate of its instance converged (never returned)
 
 // Problem description in device-friendly form (passed by value as a kernel argument).
 template <typename T>
@@ -76,6 +77,8 @@ struct Problem {
     // minimum_time_via_points objective (wave kernel only): objective stays OBJ_MIN_TIME, the via-point terms are switched by `via`
     int via, n_via, vp_ordered;
     T vp_wp, vp_wo;
+    // candidate initial trajectories (wave kernel only): kinds (mpc_candidate_kind), iteration caps, heading-blend length
+    int n_cand, cand_kind[4], cand_max_iter[4], cand_blend;
 };
 
 // Algorithm constants (Waechter & Biegler 2006 names).  Compile-time so that they live in
@@ -150,6 +153,8 @@ MPC_HD double t_pow(double a, double b) { return ::pow(a, b); }
 MPC_HD float t_pow(float a, float b) { return ::powf(a, b); }
 MPC_HD double t_atan(double a) { return ::atan(a); }
 MPC_HD float t_atan(float a) { return ::atanf(a); }
+MPC_HD double t_atan2(double y, double x) { return ::atan2(y, x); }
+MPC_HD float t_atan2(float y, float x) { return ::atan2f(y, x); }
 MPC_HD double t_asin(double a) { return ::asin(a); }
 MPC_HD float t_asin(float a) { return ::asinf(a); }
 // reciprocal: hardware seed + two Newton steps on the device (the IEEE division sequence is ~40 instructions), 1/x on the host

@@ -27,8 +27,7 @@ inline void fill_problem(const mpc_config& c, mpc::Problem<T>& P) {
     P.dt_lb = T(c.dt_lb);
     P.dt_ub = T(c.dt_ub);
     // integral form on the fixed-dt grid (quadratic_cost_se2.cpp:54-83, left sum finite_differences_grid_se2.cpp:61-75): every stage
-    // term is multiplied by the constant dt, i.e. the weights are scaled; the terminal cost is not.  (dt free + integral form couples
-    // the states with dt in the Hessian and is rejected by mpc_create.)
+    // term is multiplied by the constant dt, i.e. the weights are scaled; the terminal cost is not.  (dt free + integral form: see below.)
     const double wsc = (c.integral_form && !c.dt_free) ? c.dt_ref : 1.0;
     // integral form on the variable grid (dt is a decision variable): the weights stay unscaled, the kernel multiplies by the current dt
     // and carries the state-dt / control-dt coupling of the Hessian (wave kernel, A-form slots A05 A15 A25 A56 A57)
@@ -63,6 +62,12 @@ inline void fill_problem(const mpc_config& c, mpc::Problem<T>& P) {
     P.ball = (c.terminal_ball && !(c.xf_fixed[0] && c.xf_fixed[1] && c.xf_fixed[2])) ? 1 : 0;
     for (int i = 0; i < 3; ++i) P.ball_S[i] = T(c.terminal_ball_S[i]);
     P.ball_gamma = T(c.terminal_ball_gamma);
+    P.n_cand = c.n_candidates > 1 ? (c.n_candidates < MPC_MAX_CANDIDATES ? c.n_candidates : MPC_MAX_CANDIDATES) : 1;
+    for (int k = 0; k < 4; ++k) {
+        P.cand_kind[k] = (c.n_candidates > 1 && k < P.n_cand) ? c.candidate_kind[k] : MPC_CAND_REFERENCE;
+        P.cand_max_iter[k] = (c.n_candidates > 1 && c.candidate_max_iter[k] > 0) ? c.candidate_max_iter[k] : P.max_iter;
+    }
+    P.cand_blend = c.candidate_blend > 0 ? c.candidate_blend : 8;
 }
 
 

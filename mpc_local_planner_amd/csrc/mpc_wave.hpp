@@ -166,6 +166,10 @@ struct IpmWave {
     mutable long long prof_loop = 0, prof_setup = 0, prof_fwd_loop = 0;    // ticks inside the backward stage loop / before it / inside the forward loop
 #endif
     int nfix;
+    // candidate initial trajectories: this wave's candidate index, its iteration cap and the instance's winner word (global memory; NULL when
+    // the solver runs a single candidate).  A lower winner index than ours = a higher-priority candidate has converged: we stop.
+    int my_cand = 0, iter_cap = 0;
+    const int* win_ptr = nullptr;
 
     __device__ IpmWave(const Problem<T>& p, const WaveLayout& l, T* s, int ln) : P(p), L(l), sm(s), lane(ln) {}
 
@@ -1550,6 +1554,40 @@ struct IpmWave {
         if (lane == 0) SCL(SC_D) = P.dt_ref;
     }
 
+    // initial vertex values of candidate kind `kind` (mpc_candidate_kind; MPC_CAND_REFERENCE is cold_start() / the caller's guess):
+    // positions on the straight line as in cold_start(); heading = direction of travel, turned by pi when the goal lies behind the start
+    // pose (initializeSequences without xinit, full_discretization_grid_base_se2.cpp:136-190), + pi for the *_REVERSE kinds; the BLEND kinds
+    // turn from the start heading into that direction over the first m grid points and into the goal heading over the last m.
+    __device__ __forceinline__ void seed_start(int kind) const {
+        const int n = L.n;
+        const T ddx = xf[0] - x0[0], ddy = xf[1] - x0[1];
+        T orient = t_atan2(ddy, ddx);
+        T s0, c0;
+        t_sincos(x0[2], &s0, &c0);
+        if (ddx * c0 + ddy * s0 < T(0)) orient = normalize_theta(orient + T(3.14159265358979323846));
+        if (kind == 2 || kind == 4) orient = normalize_theta(orient + T(3.14159265358979323846));
+        const bool blend = kind >= 3;
+        int m = P.cand_blend;
+        if (m > (n - 1) / 2) m = (n - 1) / 2;
+        const T d0 = normalize_theta(orient - x0[2]), df = normalize_theta(orient - xf[2]);
+        for (int k = lane; k < n; k += kWave) {
+            const T fr = T(k) / T(n - 1);
+            T xk[3];
+            if (k == 0) { xk[0] = x0[0]; xk[1] = x0[1]; xk[2] = x0[2]; }
+            else if (k == n - 1) { xk[0] = xf[0]; xk[1] = xf[1]; xk[2] = xf[2]; }
+            else {
+                xk[0] = x0[0] + fr * ddx;
+                xk[1] = x0[1] + fr * ddy;
+                xk[2] = orient;
+                if (blend && k < m) xk[2] = normalize_theta(x0[2] + (T(k) / T(m)) * d0);
+                if (blend && n - 1 - k < m) xk[2] = normalize_theta(xf[2] + (T(n - 1 - k) / T(m)) * df);
+            }
+            for (int i = 0; i < 3; ++i) F(L.X, i, k) = xk[i];
+            if (k < n - 1) { F(L.U, 0, k) = T(0); F(L.U, 1, k) = T(0); }
+        }
+        if (lane == 0) SCL(SC_D) = P.dt_ref;
+    }
+
     __device__ __forceinline__ void init_point() {
         const int n = L.n;
         if (lane == 0) {
@@ -1639,6 +1677,7 @@ struct IpmWave {
         flags = __builtin_amdgcn_readfirstlane(flags);
         nfix = (int)fx(0) + (int)fx(1) + (int)fx(2);
         row0_on = dtprev != T(0);
+        if (iter_cap <= 0) iter_cap = P.max_iter;
         if (lane < 8) sm[L.ZC + lane] = lane == 4 ? T(1) : T(0);      // constant coefficient triples of the sweeps
         init_point();
         T theta_c, fobj;
@@ -1667,7 +1706,11 @@ struct IpmWave {
             e0 = err_value(er, T(0));
             if (!t_finite(e0)) { status = ST_NUMERICAL; break; }
             if (e0 <= P.tol) { status = ST_CONVERGED; break; }
-            if (it >= P.max_iter) { status = ST_MAX_ITER; break; }
+            if (it >= iter_cap) { status = ST_MAX_ITER; break; }
+            if (win_ptr) {      // hedged candidate: one L2 read per iteration (all lanes, same word)
+                const int w = __builtin_amdgcn_readfirstlane(__hip_atomic_load(win_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+                if (w < my_cand) { status = ST_SUPERSEDED; break; }
+            }
             for (int guard = 0; guard < 50; ++guard) {
                 T emu = err_value(er, mu);
                 if (emu <= Algo<T>::kappa_eps * mu && mu > P.tol / T(10)) {

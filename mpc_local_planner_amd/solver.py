@@ -163,6 +163,13 @@ class BatchSolver:
                                                        p(no), p(nv), p(vt), p(dr)))
         return no, nv, vt, dr
 
+    def last_candidates(self, B: int):
+        """(winner[B], iters_total[B]) of the most recent solve (mpc_last_candidates): index of the candidate initial trajectory that
+        supplied each instance's result (-1: none converged) and the iterations spent over all candidates of the instance."""
+        win = np.empty(B, np.int32); tot = np.empty(B, np.int32)
+        self._check(self._lib.mpc_last_candidates(self._h, int(B), C.c_void_p(win.ctypes.data), C.c_void_p(tot.ctypes.data)))
+        return win, tot
+
     def synchronize(self):
         self._check(self._lib.mpc_synchronize(self._h))
 

@@ -59,3 +59,47 @@ def test_best_of_two_guesses_on_config2(c_oracle):
     assert (best.status[ok] == 0).all() and (best.dt[ok] <= allr.dt[:B][ok] + 1e-12).all()
     assert (best.dt[ok] < allr.dt[:B][ok] - 1e-4).mean() > 0.1          # ... and strictly better in a good share of the instances
     assert (win == 1).mean() > 0.1                                      # the second guess does win a share of the instances
+
+
+def test_oracle_candidate_kinds_restate_the_guesses():
+    """oracle/candidates.py (what the GPU tests check the device-side candidates against) vs the reference initialisations restated in
+    oracle/se2_nlp.py and the host-side guesses of the product package."""
+    from oracle import candidates as OC
+    x0, xf, _, _ = m.workloads.carlike_min_time_inputs(48, seed=5)
+    n, cfg = 30, R.config_carlike_min_time(30)
+    for b in range(48):
+        np.testing.assert_allclose(OC.guess(OC.REFERENCE, x0[b:b + 1], xf[b:b + 1], n, cfg.dt_ref)[0][0], R.cold_start(cfg, x0[b], xf[b]).x, atol=1e-12)
+        np.testing.assert_allclose(OC.guess(OC.TRAVEL, x0[b:b + 1], xf[b:b + 1], n, cfg.dt_ref)[0][0], R.initialize_sequences_straight_line(cfg, x0[b], xf[b]).x, atol=1e-12)
+    np.testing.assert_allclose(OC.guess(OC.TRAVEL_REVERSE, x0, xf, n, 0.3)[0], K.travel_direction_guess(x0, xf, n, 0.3, reverse=True)[0], atol=1e-12)
+    # blend: start / goal poses exact, the middle of the horizon carries the travel direction, the ends turn monotonically from / into the pose headings
+    for kind, base in ((OC.BLEND, OC.TRAVEL), (OC.BLEND_REVERSE, OC.TRAVEL_REVERSE)):
+        xb = OC.guess(kind, x0, xf, n, 0.3, blend=8)[0]
+        xt = OC.guess(base, x0, xf, n, 0.3)[0]
+        np.testing.assert_array_equal(xb[:, :, :2], xt[:, :, :2])
+        np.testing.assert_array_equal(xb[:, 8:n - 8, 2], xt[:, 8:n - 8, 2])
+        d0 = OC.wrap(xt[:, 10, 2] - x0[:, 2])
+        for k in range(1, 8):
+            np.testing.assert_allclose(OC.wrap(xb[:, k, 2] - x0[:, 2]), k / 8 * d0, atol=1e-12)
+            np.testing.assert_allclose(OC.wrap(xb[:, n - 1 - k, 2] - xf[:, 2]), k / 8 * OC.wrap(xt[:, 10, 2] - xf[:, 2]), atol=1e-12)
+
+
+def test_candidate_rule_lowest_converged_index_wins():
+    from oracle import candidates as OC
+    #          inst 0  1  2  3
+    status = [[0, 1, 1, 1], [0, 0, 1, 2], [1, 0, 0, 3]]
+    np.testing.assert_array_equal(OC.apply_rule(status, 3), [0, 1, 2, -1])
+
+
+def test_candidate_rule_on_config2_with_the_c_oracle(c_oracle):
+    """the rule the device applies (reference cold start first, two blended-heading hedges, every candidate capped at 60 iterations) on the
+    config-2 workload: > 98.5 % of the instances end converged and every instance the capped reference path solves keeps that answer."""
+    from oracle import candidates as OC
+    B, n = 256, 50
+    x0, xf, up, dtp = m.workloads.carlike_min_time_inputs(B)
+    ocfg = R.config_carlike_min_time(n)
+    kinds, caps = (OC.REFERENCE, OC.BLEND, OC.BLEND_REVERSE), (60, 60, 60)
+    x, u, dt, st, it, win, low, allr = OC.solve_candidates(c_oracle, lambda cap: c_oracle.from_nlp_config(ocfg, max_iter=cap), x0, xf, up, dtp, kinds, caps, n, ocfg.dt_ref)
+    assert (st == 0).mean() > 0.985 > (allr[0][3] == 0).mean()
+    ref_ok = allr[0][3] == 0
+    assert (win[ref_ok] == 0).all() and np.array_equal(x[ref_ok], allr[0][0][ref_ok])
+    assert (it[st == 0] <= 60).all() and (win >= 1).mean() > 0.1
