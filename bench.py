@@ -1,12 +1,19 @@
 #!/usr/bin/env python
 """bench.py -- MPC control-cycle solves/sec of the car-like minimum-time NLP (n=50) on MI355X.
 
-One "step" = one pass of the hot path (a full batched NLP solve, cold start exactly as
-Controller::step does on an empty grid) over one batch of synthetic planner inputs that are
-already resident in HBM.  N=1 workload: BASELINE.json configs[1] (batch 1024 per GPU).  N>1:
-independent planner instances are sharded over the ranks (weak scaling, 1024 per GPU, rank r draws
-its inputs from seed+r); there is no data-path collective -- RCCL is used only for the barrier and
-the max-over-ranks reduction of the timing.
+One "step" = one pass of the hot path (a full batched NLP solve, cold start exactly as Controller::step does on an empty grid, with the
+candidate initial trajectories of DESIGN.md section 5.4 hedging the slow instances) over one batch of synthetic planner inputs that are
+already resident in HBM.
+
+  N = 1   workload = BASELINE.json configs[1]: 1024 instances on the GPU.  The same line carries, as extra legs measured after the
+          timed region: the warm-started cycle, configs[2] (unicycle n=80, 16 polygons, B=4096), the per-GPU shares of configs[3]
+          (car-like n=50, B=4096) and configs[4] (bicycle n=120 fp32, B=1024), and the CPU baseline.
+  N > 1   workload = BASELINE.json configs[3]: 4096 instances per GPU (32768 at N=8), rank r draws its inputs from seed+r; no data-path
+          collective inside the timed region.  After it, the per-rank results (status, dt, x -- device resident) are all-gathered over
+          RCCL so that every rank holds the whole job's answer; that exchange is timed separately and reported as `gather_ms`.
+
+`value` counts CONVERGED solves only (a Controller::step that returns false makes the planner reset and command zero,
+src/mpc_local_planner_ros.cpp:394-404); `value_all_solves` counts every instance.
 
 Contract: python bench.py --gpus N --steps K --warmup W   (torchrun for N>1) -> ONE JSON line on rank 0.
 """
@@ -24,22 +31,28 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 N_GRID = 50
-BATCH_PER_GPU = 1024
+BATCH_1GPU = 1024              # BASELINE.json configs[1]
+BATCH_PER_GPU_MULTI = 4096     # BASELINE.json configs[3]: 32768 over 8 GPUs
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_VECTOR_PEAK_TF = 78.6     # SURVEY.md 8d / AMD spec, vector fp64
+FP32_VECTOR_PEAK_TF = 157.3
+# candidate initial trajectories of the headline run (include/mpc_hip.h, enum mpc_candidate_kind): the reference cold start first, then
+# the blended-heading hedges; every candidate is capped at 60 interior-point iterations
+CAND_KINDS = (0, 3, 4)
+CAND_CAPS = (60, 60, 60)
 
 
-def algorithmic_bytes_per_solve(n: int) -> int:
-    """B_alg = 8 * (2*P(n) + 9), P(n) = 5n - 1 scalars per trajectory (read guess + write solution)
-    + x0(3) + xf(3) + u_prev(2) + dt_prev(1)."""
-    return 8 * (2 * (5 * n - 1) + 9)
+def algorithmic_bytes_per_solve(n: int, s: int = 8, obstacle_scalars: int = 0) -> int:
+    """B_alg = s * (2*P(n) + 9 + O), P(n) = 5n - 1 scalars per trajectory (read guess + write solution)
+    + x0(3) + xf(3) + u_prev(2) + dt_prev(1) + obstacle scalars."""
+    return s * (2 * (5 * n - 1) + 9 + obstacle_scalars)
 
 
 def cpu_baseline(n):
     """Times the C oracle (oracle/mpc_oracle.c, banded-LU interior point, OpenMP over instances) on a bounded
     sample of the same workload on the host cores.  Checker/baseline only: nothing here feeds the GPU path.
     The thread count is the one that gives the highest throughput in a short pilot (containers often expose more logical
-    CPUs than their CPU quota lets them run; oversubscribing costs the oracle up to 2x)."""
+    CPUs than their CPU quota lets them run; oversubscribing costs the oracle up to 2x).  Single candidate (the reference path)."""
     from oracle import c_oracle as CO, se2_nlp as R
     import mpc_local_planner_amd.workloads as W
     CO.build()
@@ -56,31 +69,100 @@ def cpu_baseline(n):
         if rate > best:
             best, cores = rate, nt
         nt //= 2
-    # ~5 s wall at the best thread count: with the long-tailed iteration counts (p50 28, max 100) a thread needs a few hundred
-    # instances before its throughput stops depending on which instances it drew; more than one GPU batch = further draws
-    # from the same distribution
-    sample2 = int(min(64 * BATCH_PER_GPU, max(pilot, best * 5.0)))
+    sample2 = int(min(64 * BATCH_1GPU, max(pilot, best * 5.0)))
     x0, xf, up, dtp = W.carlike_min_time_inputs(sample2)
     t = time.perf_counter()
     out = CO.solve_batch(oc, x0, xf, up, dtp, nthreads=cores)
     dt = time.perf_counter() - t
-    return {"value": sample2 / dt, "unit": "solves/s", "cores": cores, "kind": "port",
-            "sample": f"{sample2} instances drawn from the config-2 distribution (seed {W.SEED_CONFIG2}), cold start, tol 1e-8, "
-                      f"mean {float(out[4].mean()):.1f} iterations, {dt:.2f} s wall on {cores} OpenMP threads "
+    conv = float((out[3] == 0).mean())
+    return {"value": sample2 * conv / dt, "value_all_solves": sample2 / dt, "unit": "solves/s", "cores": cores, "kind": "port",
+            "converged_frac": conv,
+            "sample": f"{sample2} instances drawn from the config-2 distribution (seed {W.SEED_CONFIG2}), cold start, one candidate (the reference "
+                      f"path), tol 1e-8, max 100 iterations, mean {float(out[4].mean()):.1f} iterations, {dt:.2f} s wall on {cores} OpenMP threads "
                       f"(best of a pilot over {logical}, {logical}/2, ... threads; the host exposes {logical} logical CPUs)"}
 
 
-def measured_traffic(n, B):
+def measured_traffic(key):
     """HBM bytes per launch of the solve kernel from the rocprofv3 PMC passes (FETCH_SIZE x2 on gfx950 + WRITE_SIZE, in bytes),
     as recorded by scripts/summarize_profile.py for this exact workload; None when no matching record is committed."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hbm_traffic.json")
+    path = os.path.join(ROOT, "profiles", "hbm_traffic.json")
     try:
         rec = json.load(open(path))
     except (OSError, ValueError):
         return None
-    if rec.get("n") == n and rec.get("batch") == B:
-        return rec.get("bytes_per_launch")
-    return None
+    rec = rec.get(key) if isinstance(rec.get(key), dict) else (rec if rec.get("key") == key else None)
+    return rec.get("bytes_per_launch") if rec else None
+
+
+class Leg:
+    """one solver + device-resident inputs/outputs of one workload"""
+
+    def __init__(self, m, torch, dev, cfg, B, inputs, obstacles=None):
+        self.m, self.torch, self.dev, self.B, self.n = m, torch, dev, B, int(cfg.n)
+        self.solver = m.BatchSolver(cfg, max_batch=B, device=dev.index)
+        T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        self.inp = [T(a) for a in inputs]
+        n = self.n
+        self.xo = torch.empty((B, n, 3), dtype=torch.float64, device=dev)
+        self.uo = torch.empty((B, n, 2), dtype=torch.float64, device=dev)
+        self.do = torch.empty(B, dtype=torch.float64, device=dev)
+        self.st = torch.empty(B, dtype=torch.int32, device=dev)
+        self.it = torch.empty(B, dtype=torch.int32, device=dev)
+        self.ob = None
+        if obstacles is not None:
+            self.ob_t = [T(a) for a in obstacles]
+            self.ob = tuple(t.data_ptr() for t in self.ob_t)
+
+    def step(self, init=None, inp=None, st=None, it=None):
+        i = self.inp if inp is None else inp
+        xi, ui, di = (None, None, None) if init is None else (t.data_ptr() for t in init)
+        self.solver.solve_device(self.B, i[0].data_ptr(), i[1].data_ptr(), i[2].data_ptr(), i[3].data_ptr(), xi, ui, di,
+                                 self.xo.data_ptr(), self.uo.data_ptr(), self.do.data_ptr(), (st if st is not None else self.st).data_ptr(),
+                                 (it if it is not None else self.it).data_ptr(), obstacles=self.ob)
+
+    def sync(self):
+        self.solver.synchronize()
+        self.torch.cuda.synchronize()
+
+    def timed(self, steps, warmup, **kw):
+        for _ in range(warmup):
+            self.step(**kw)
+        self.sync()
+        k_ms = []
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            self.step(**kw)
+            self.solver.synchronize()          # a control cycle ends when its commands are available
+            k_ms.append(self.solver.last_kernel_ms())
+        self.sync()
+        return time.perf_counter() - t0, float(np.mean(k_ms))
+
+    def stats(self, st=None, it=None):
+        status = (self.st if st is None else st).cpu().numpy()
+        iters = (self.it if it is None else it).cpu().numpy()
+        win, tot = self.solver.last_candidates(self.B)
+        ok = status == 0
+        return {"converged_frac": float(ok.mean()), "iters_mean": float(iters.mean()), "iters_p50": float(np.percentile(iters, 50)),
+                "iters_p99": float(np.percentile(iters, 99)), "iters_max": int(iters.max()),
+                "iters_total_mean": float(tot.mean()), "winner_histogram": np.bincount(win + 1, minlength=2).tolist()}, ok
+
+    def close(self):
+        self.solver.close()
+
+
+def leg_summary(leg, steps, warmup, bytes_per_solve, flops_per_iter, peak_tf, traffic_key):
+    elapsed, k_ms = leg.timed(steps, warmup)
+    s, ok = leg.stats()
+    B = leg.B
+    bpl = bytes_per_solve * B
+    gbs = bpl / (k_ms * 1e-3) / 1e9
+    tf = B * s["iters_total_mean"] * flops_per_iter / (k_ms * 1e-3) / 1e12
+    return {"value": B * s["converged_frac"] * steps / elapsed, "value_all_solves": B * steps / elapsed, "unit": "solves/s", "batch": B,
+            "ms_per_step": elapsed / steps * 1e3, "solver": s,
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
+                         "traffic": measured_traffic(traffic_key), "kernel": "mpc_ipm_wave_kernel", "kernel_ms": k_ms,
+                         "algorithmic_bytes_per_launch": bpl,
+                         "valu": {"achieved_tflops": tf, "peak_tflops": peak_tf, "frac": tf / peak_tf, "flops_per_iteration": flops_per_iter}}}
 
 
 def main():
@@ -88,15 +170,18 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=BATCH_PER_GPU, help="instances per GPU")
+    ap.add_argument("--batch", type=int, default=0, help="instances per GPU (default: 1024 at N=1 = configs[1], 4096 at N>1 = configs[3])")
     ap.add_argument("--n", type=int, default=N_GRID)
+    ap.add_argument("--candidates", type=str, default=",".join(str(k) for k in CAND_KINDS), help="candidate kinds in priority order; '0' = the single reference solve")
+    ap.add_argument("--caps", type=str, default=",".join(str(k) for k in CAND_CAPS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-warm", action="store_true", help="skip the separately reported warm-start leg")
+    ap.add_argument("--no-legs", action="store_true", help="skip the extra legs (warm start, other configs)")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     import mpc_local_planner_amd as m
+    from mpc_local_planner_amd import sharding
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -105,122 +190,148 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    torch.zeros(1, device=dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
-    B, n = args.batch, args.n
-    cfg = m.config_carlike_min_time(n=n, mu_init_warm=1e-2)      # only solves that are given an initial guess (the warm-start leg) use it
-    solver = m.BatchSolver(cfg, max_batch=B, device=local_rank)
+    n = args.n
+    B = args.batch if args.batch > 0 else (BATCH_1GPU if world == 1 else BATCH_PER_GPU_MULTI)
+    kinds = tuple(int(k) for k in args.candidates.split(","))
+    caps = tuple(int(k) for k in args.caps.split(","))[:len(kinds)]
+    ckw = dict(candidates=kinds, candidate_max_iter=caps) if len(kinds) > 1 else {}
+    cfg = m.config_carlike_min_time(n=n, mu_init_warm=1e-2, **ckw)      # mu_init_warm: only solves that are given an initial guess (the warm-start leg)
     # independent planner instances per rank: seed + rank (no scatter needed)
-    from mpc_local_planner_amd import sharding
-    x0, xf, up, dtp = m.workloads.carlike_min_time_inputs(B, seed=sharding.rank_seed(m.workloads.SEED_CONFIG2, rank))
-    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
-    dx0, dxf, dup, ddtp = T(x0), T(xf), T(up), T(dtp)
-    xo = torch.empty((B, n, 3), dtype=torch.float64, device=dev)
-    uo = torch.empty((B, n, 2), dtype=torch.float64, device=dev)
-    do = torch.empty(B, dtype=torch.float64, device=dev)
-    st = torch.empty(B, dtype=torch.int32, device=dev)
-    it = torch.empty(B, dtype=torch.int32, device=dev)
-
-    def step():
-        solver.solve_device(B, dx0.data_ptr(), dxf.data_ptr(), dup.data_ptr(), ddtp.data_ptr(), None, None, None,
-                            xo.data_ptr(), uo.data_ptr(), do.data_ptr(), st.data_ptr(), it.data_ptr())
-
-    def sync():
-        solver.synchronize()
-        torch.cuda.synchronize()
+    leg = Leg(m, torch, dev, cfg, B, m.workloads.carlike_min_time_inputs(B, seed=sharding.rank_seed(m.workloads.SEED_CONFIG2, rank)))
 
     for _ in range(args.warmup):
-        step()
-    sync()
+        leg.step()
+    leg.sync()
     if world > 1:
         dist.barrier()
-    sync()
+    leg.sync()
     kernel_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
-        solver.synchronize()          # a control cycle ends when its commands are available
-        kernel_ms.append(solver.last_kernel_ms())
-    sync()
+        leg.step()
+        leg.solver.synchronize()          # a control cycle ends when its commands are available
+        kernel_ms.append(leg.solver.last_kernel_ms())
+    leg.sync()
     if world > 1:
         dist.barrier()
-    sync()
+    leg.sync()
     elapsed = time.perf_counter() - t0
     elapsed = sharding.max_over_ranks(elapsed, device=dev)
+    sstat, ok = leg.stats()
 
-    status = st.cpu().numpy()
-    iters = it.cpu().numpy()
+    # ---- N > 1: every rank ends with the whole job's results (RCCL all-gather of HBM-resident arrays), outside the timed region
+    gather = None
+    n_conv_total = int(ok.sum())
+    if world > 1:
+        total = B * world
+        torch.cuda.synchronize()
+        tg = time.perf_counter()
+        g_st = sharding.gather_results(leg.st, world, total)
+        g_dt = sharding.gather_results(leg.do, world, total)
+        g_x = sharding.gather_results(leg.xo, world, total)
+        torch.cuda.synchronize()
+        tg = time.perf_counter() - tg
+        lo, hi = sharding.shard_range(total, world, rank)
+        assert torch.equal(g_st[lo:hi], leg.st) and torch.equal(g_x[lo:hi], leg.xo) and g_dt.shape[0] == total
+        n_conv_total = int((g_st == 0).sum().item())
+        nbytes = (g_st.numel() * 4 + g_dt.numel() * 8 + g_x.numel() * 8)
+        gather = {"ms": tg * 1e3, "bytes_per_rank_received": nbytes, "what": "status, dt_out, x_out of all ranks (RCCL all_gather, device resident), first call "
+                  "(includes communicator warm-up); NOT part of ms_per_step"}
 
-    # ---- warm start, reported separately: the plant advances one controller period (0.2 s) with u_0, the previous
-    #      solution is the initial guess with x0 overwritten (full_discretization_grid_base_se2.cpp:101-110; variable grid: no shifting)
-    warm = None
-    if world == 1 and not args.no_warm:
-        per, Lw = 0.2, float(cfg.model_params[0])
-        u0 = uo[:, 0, :].clone()
-        x1 = dx0.clone()
-        x1[:, 0] += per * u0[:, 0] * torch.cos(dx0[:, 2]); x1[:, 1] += per * u0[:, 0] * torch.sin(dx0[:, 2])
-        x1[:, 2] = torch.remainder(dx0[:, 2] + per * u0[:, 0] * torch.tan(u0[:, 1]) / Lw + np.pi, 2 * np.pi) - np.pi
-        xi, ui, di = xo.clone(), uo.clone(), do.clone()
-        dper = torch.full((B,), per, dtype=torch.float64, device=dev)
-        st2 = torch.empty_like(st); it2 = torch.empty_like(it)
-
-        def wstep():
-            solver.solve_device(B, x1.data_ptr(), dxf.data_ptr(), u0.data_ptr(), dper.data_ptr(), xi.data_ptr(), ui.data_ptr(), di.data_ptr(),
-                                xo.data_ptr(), uo.data_ptr(), do.data_ptr(), st2.data_ptr(), it2.data_ptr())
-        for _ in range(args.warmup):
-            wstep()
-        sync()
-        tw = time.perf_counter()
-        for _ in range(args.steps):
-            wstep()
-            solver.synchronize()
-        sync()
-        tw = time.perf_counter() - tw
-        was_ok = torch.from_numpy(status == 0).to(dev)
-        s2, i2 = st2[was_ok].cpu().numpy(), it2[was_ok].cpu().numpy()
-        warm = {"value": B * args.steps / tw, "unit": "solves/s", "ms_per_step": tw / args.steps * 1e3,
-                "converged_frac_of_previously_converged": float((s2 == 0).mean()), "iters_mean": float(i2.mean()),
-                "init": "previous solution with x0 advanced one 0.2 s period under u_0; slacks and multipliers re-initialised at mu0 = mu_init_warm = 1e-2"}
+    line = None
     if rank == 0:
         total = B * world * args.steps
-        value = total / elapsed
         k_ms = float(np.mean(kernel_ms))
+        conv_frac_job = n_conv_total / (B * world)
         bytes_per_launch = algorithmic_bytes_per_solve(n) * B
         achieved_gbs = bytes_per_launch / (k_ms * 1e-3) / 1e9
-        mean_it = float(iters.mean())
         flops_per_iter = 914.0 * (n - 1)               # SURVEY.md 8d convention
-        fp64_tf = B * mean_it * flops_per_iter / (k_ms * 1e-3) / 1e12
+        fp64_tf = B * sstat["iters_total_mean"] * flops_per_iter / (k_ms * 1e-3) / 1e12
+        wl = ("BASELINE.json configs[1]: carlike (Ackermann) minimum-time MPC, n=50 grid points, batch=1024 instances on 1 MI355X" if (world == 1 and B == BATCH_1GPU and n == N_GRID) else
+              (f"BASELINE.json configs[3]: carlike minimum-time MPC, n=50, batch={B * world} sharded across {world} MI355X ({B} per GPU)" if (B == BATCH_PER_GPU_MULTI and n == N_GRID) else
+               f"carlike minimum-time MPC, n={n}, batch={B} per GPU (non-default size)"))
         line = {
             "metric": "MPC solves/sec (batched control cycles) at N=50 carlike",
-            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": total * conv_frac_job / elapsed, "value_all_solves": total / elapsed,
+            "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: carlike (Ackermann) minimum-time MPC, n=50 grid points, "
-                                   f"batch={B} instances per GPU, cold start (Controller::step on an empty grid), tol 1e-8, "
-                                   "max 100 iterations", "n": n, "batch_per_gpu": B, "global_batch": B * world,
-                       "parallelism": f"instances sharded over {world} GPU(s), no data-path collective",
+            "config": {"workload": wl + "; cold start (Controller::step on an empty grid), tol 1e-8; value counts converged solves only",
+                       "n": n, "batch_per_gpu": B, "global_batch": B * world,
+                       "candidates": {"kinds": list(kinds), "max_iter": list(caps),
+                                      "rule": "lowest-index candidate that converges within its cap supplies the result (index 0 = the reference cold start)"},
+                       "parallelism": f"instances sharded over {world} GPU(s), no data-path collective in the timed region",
                        "seed": m.workloads.SEED_CONFIG2},
-            "solver": {"converged_frac": float((status == 0).mean()), "iters_mean": mean_it,
-                       "iters_p50": float(np.percentile(iters, 50)), "iters_p99": float(np.percentile(iters, 99)),
-                       "iters_max": int(iters.max())},
+            "solver": dict(sstat, converged_frac_job=conv_frac_job),
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": measured_traffic(n, B),
+                         "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": measured_traffic(f"carlike_n{n}_B{B}_c{len(kinds)}"),
                          "kernel": "mpc_ipm_wave_kernel",
                          "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": bytes_per_launch,
                          "note": "latency/FP64-issue bound by construction (SURVEY.md 8d): compulsory traffic is ~4 KB per solve",
                          "fp64_valu": {"achieved_tflops": fp64_tf, "peak_tflops": FP64_VECTOR_PEAK_TF,
                                        "frac": fp64_tf / FP64_VECTOR_PEAK_TF,
-                                       "flops_per_iteration": flops_per_iter}},
+                                       "flops_per_iteration": flops_per_iter,
+                                       "note": "iterations of ALL candidates of an instance are counted as work"}},
         }
-        if warm is not None:
-            line["warm_start"] = warm
+        if gather is not None:
+            line["gather"] = gather
+
+    # ---- extra legs (N = 1 only; after the timed region)
+    if world == 1 and not args.no_legs:
+        legs = {}
+        # warm start, reported separately: the plant advances one controller period (0.2 s) with u_0, the previous solution is
+        # the initial guess with x0 overwritten (full_discretization_grid_base_se2.cpp:101-110; variable grid: no shifting)
+        per, Lw = 0.2, float(cfg.model_params[0])
+        dx0, dxf = leg.inp[0], leg.inp[1]
+        u0 = leg.uo[:, 0, :].clone()
+        x1 = dx0.clone()
+        x1[:, 0] += per * u0[:, 0] * torch.cos(dx0[:, 2]); x1[:, 1] += per * u0[:, 0] * torch.sin(dx0[:, 2])
+        x1[:, 2] = torch.remainder(dx0[:, 2] + per * u0[:, 0] * torch.tan(u0[:, 1]) / Lw + np.pi, 2 * np.pi) - np.pi
+        init = (leg.xo.clone(), leg.uo.clone(), leg.do.clone())
+        dper = torch.full((B,), per, dtype=torch.float64, device=dev)
+        st2 = torch.empty_like(leg.st); it2 = torch.empty_like(leg.it)
+        tw, kw_ms = leg.timed(args.steps, args.warmup, init=init, inp=[x1, dxf, u0, dper], st=st2, it=it2)
+        s2, ok2 = leg.stats(st2, it2)
+        it2n = it2.cpu().numpy()
+        legs["warm_start"] = {"value": B * float(ok2.mean()) * args.steps / tw, "value_all_solves": B * args.steps / tw, "unit": "solves/s", "ms_per_step": tw / args.steps * 1e3, "kernel_ms": kw_ms,
+                              "converged_frac": float(ok2.mean()), "converged_frac_of_previously_converged": float(ok2[ok].mean()), "iters_mean": float(it2n[ok].mean()),
+                              "iters_p99": float(np.percentile(it2n[ok], 99)),
+                              "init": "previous solution with x0 advanced one 0.2 s period under u_0 as candidate 0 (slacks and multipliers re-initialised at mu0 = mu_init_warm = 1e-2); the hedges start from their own seeds"}
+        leg.close()
+        # configs[3] share on one GPU (what every rank of the N = 8 run does)
+        l4 = Leg(m, torch, dev, cfg, BATCH_PER_GPU_MULTI, m.workloads.carlike_min_time_inputs(BATCH_PER_GPU_MULTI))
+        legs["config4_share_B4096"] = leg_summary(l4, max(2, args.steps // 2), 1, algorithmic_bytes_per_solve(n), 914.0 * (n - 1), FP64_VECTOR_PEAK_TF, f"carlike_n{n}_B4096_c{len(kinds)}")
+        l4.close()
+        # configs[2]: unicycle quadratic form, n = 80, 16 polygon obstacles, B = 4096 (single candidate: > 99.9 % converge from the cold start)
+        n3, B3, O, V, M = 80, 4096, 16, 6, 4
+        x0, xf, up, dtp, obs = m.workloads.unicycle_obstacle_inputs(B3, n_obst=O, max_vertices=V)
+        l3 = Leg(m, torch, dev, m.config_unicycle_quadratic(n3, max_obstacles=O, max_vertices=V, max_obstacle_rows=M), B3, (x0, xf, up, dtp), obstacles=obs)
+        osc = int(np.mean([(2 * obs[1][b] + 2).sum() for b in range(64)]))       # sum(2 V_j + 2) obstacle scalars per instance
+        legs["config3_unicycle_n80_16polygons_B4096"] = leg_summary(l3, max(2, args.steps // 2), 1, algorithmic_bytes_per_solve(n3, 8, osc), (18 + 342 + 418 + 100) * (n3 - 1) + 60 * 2 * (n3 - 2),
+                                                                   FP64_VECTOR_PEAK_TF, "unicycle_n80_B4096")
+        l3.close()
+        # configs[4] share: kinematic bicycle, n = 120, fp32, 1024 per GPU
+        n5, B5 = 120, 1024
+        c5 = m.config_bicycle_min_time(n5, precision=1, tol=1e-4, **(dict(candidates=kinds, candidate_max_iter=tuple(100 for _ in kinds)) if len(kinds) > 1 else {}))
+        l5 = Leg(m, torch, dev, c5, B5, m.workloads.bicycle_min_time_inputs(B5))
+        legs["config5_share_bicycle_n120_fp32_B1024"] = leg_summary(l5, max(2, args.steps // 2), 1, algorithmic_bytes_per_solve(n5, 4), (24 + 486 + 418 + 100) * (n5 - 1), FP32_VECTOR_PEAK_TF, "bicycle_n120_fp32_B1024")
+        legs["config5_share_bicycle_n120_fp32_B1024"]["dtype"] = "f32"
+        l5.close()
+        line["legs"] = legs
+        line["scaling_reference"] = {"per_gpu_value_at_4096": legs["config4_share_B4096"]["value"],
+                                     "note": "bench.py --gpus N>1 runs configs[3] (4096 instances per GPU); its per-GPU reference on one GPU is this leg, not the N=1 headline (1024 instances)"}
+    else:
+        leg.close()
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             line["cpu_baseline"] = cpu_baseline(n)
         print(json.dumps(line))
-    solver.close()
     if world > 1:
         dist.destroy_process_group()
 

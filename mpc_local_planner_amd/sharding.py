@@ -20,20 +20,27 @@ def rank_seed(seed: int, rank: int) -> int:
     return seed + rank
 
 
-def gather_results(local: np.ndarray, world: int, total: int):
-    """all_gather of a per-rank result array along axis 0 into the global array (ragged shards allowed)."""
+def gather_results(local, world: int, total: int, device=None):
+    """all_gather of a per-rank result array along axis 0 into the global array (ragged shards allowed).
+    `local` is a numpy array or a torch tensor.  A device-resident tensor is gathered where it lives (RCCL moves HBM to HBM); a numpy
+    array / CPU tensor is staged on `device` first when the process group's backend is nccl (= RCCL, which only moves device memory).
+    Returns the same kind of object it was given."""
     import torch
     import torch.distributed as dist
     if world == 1:
         return local
+    is_np = isinstance(local, np.ndarray)
+    t = torch.from_numpy(np.ascontiguousarray(local)) if is_np else local
+    if not t.is_cuda and dist.get_backend() == "nccl":
+        t = t.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
     sizes = [shard_range(total, world, r) for r in range(world)]
     maxlen = max(hi - lo for lo, hi in sizes)
-    pad = np.zeros((maxlen,) + local.shape[1:], dtype=local.dtype)
-    pad[: local.shape[0]] = local
-    t = torch.from_numpy(pad)
-    out = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(out, t)
-    return np.concatenate([o.numpy()[: hi - lo] for o, (lo, hi) in zip(out, sizes)], axis=0)
+    pad = torch.zeros((maxlen,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+    pad[: t.shape[0]] = t
+    out = [torch.empty_like(pad) for _ in range(world)]
+    dist.all_gather(out, pad)
+    full = torch.cat([o[: hi - lo] for o, (lo, hi) in zip(out, sizes)], dim=0)
+    return full.cpu().numpy() if is_np else full
 
 
 def max_over_ranks(value: float, device=None) -> float:

@@ -1,0 +1,76 @@
+"""ORACLE (test infrastructure only): is a trajectory a KKT point of the REFERENCE-FORM NLP?
+
+Used by the parity tests to classify solver results that do not coincide with the oracle's iterate sequence (a line-search tie that
+flips, another candidate initial trajectory): such a result is acceptable iff it is feasible and stationary for the NLP exactly as the
+reference poses it (oracle/se2_nlp.py::ReferenceNlp: rows of FiniteDifferencesGridSE2::createEdges, src/optimal_control/
+finite_differences_grid_se2.cpp:36-154, derivatives by central differences through the vertex retraction as corbo's edges take them).
+
+    feasibility   max(|c(z)|, g(z)^+, bound violations)
+    stationarity  min over multipliers (lambda free; nu >= 0 on the nearly active rows; pi_l, pi_u >= 0 on the nearly active bounds) of
+                  || grad f + J_c' lambda + J_g,act' nu - pi_l + pi_u ||_inf      (bounded least squares, scipy.optimize.lsq_linear)
+    complementarity  max_i multiplier_i * slack_i over those rows / bounds
+An interior-point result at barrier mu ~ 1e-9 keeps slack s = mu / y on a row with multiplier y, so "nearly active" has to be generous
+(act_tol, default 1e-1: rows left out carry barrier multipliers below ~1e-8); what keeps a far-away row from being used is the complementarity number.
+"""
+from __future__ import annotations
+
+import numpy as np
+from scipy.optimize import lsq_linear
+
+from . import se2_nlp as R
+
+
+def kkt_residuals(ocfg, x0, xf, u_prev, dt_prev, x, u, dt, act_tol: float = 1e-1, nlp_kwargs=None, inp_kwargs=None, fd_step: float = 1e-5):
+    """x (n,3), u (n,2) or (n-1,2) (a duplicated last control is dropped), dt.  Returns dict(feas, stat, objective, n_active)."""
+    inp = R.CycleInputs(x0=np.asarray(x0, float), xf=np.asarray(xf, float), u_prev=np.asarray(u_prev, float), dt_prev=float(dt_prev), **(inp_kwargs or {}))
+    nlp = R.ReferenceNlp(ocfg, inp, **(nlp_kwargs or {}))
+    n = ocfg.n
+    u = np.asarray(u, float)[: n - 1]
+    z = nlp.pack(R.Trajectory(np.asarray(x, float), u, float(dt)))
+    lb, ub = nlp.bounds()
+    c = nlp.equalities(z)
+    g = nlp.inequalities(z)
+    feas = max(float(np.abs(c).max(initial=0.0)), float(g.max(initial=0.0)), float((lb - z).max(initial=0.0)), float((z - ub).max(initial=0.0)))
+    gradf = nlp.numeric_jacobian(lambda v: np.array([nlp.objective(v)]), z, fd_step)[0]
+    Jc = nlp.numeric_jacobian(nlp.equalities, z, fd_step)
+    act = np.where(g > -act_tol)[0]
+    Jg = nlp.numeric_jacobian(nlp.inequalities, z, fd_step)[act] if act.size else np.zeros((0, z.size))
+    al = np.where(z - lb < act_tol)[0]
+    au = np.where(ub - z < act_tol)[0]
+    El = np.zeros((al.size, z.size)); El[np.arange(al.size), al] = -1.0
+    Eu = np.zeros((au.size, z.size)); Eu[np.arange(au.size), au] = 1.0
+    A = np.concatenate([Jc, Jg, El, Eu], axis=0).T            # columns = multipliers
+    slack = np.concatenate([-g[act], (z - lb)[al], (ub - z)[au]])
+    lo = np.concatenate([np.full(Jc.shape[0], -np.inf), np.zeros(slack.size)])
+    # multipliers are not unique (degenerate rows): the complementarity products enter the least-squares problem as extra rows
+    # slack_i * multiplier_i = 0, so that a row that is not active only gets the (tiny) multiplier the stationarity residual really needs
+    W = np.zeros((slack.size, lo.size)); W[np.arange(slack.size), Jc.shape[0] + np.arange(slack.size)] = np.abs(slack)
+    sol = lsq_linear(np.concatenate([A, W], axis=0), np.concatenate([-gradf, np.zeros(slack.size)]), bounds=(lo, np.full(lo.size, np.inf)),
+                     tol=1e-15, max_iter=4000, method='bvls')
+    stat = float(np.abs(A @ sol.x + gradf).max())
+    comp = float((sol.x[Jc.shape[0]:] * np.abs(slack)).max(initial=0.0))
+    return {"feas": feas, "stat": stat, "comp": comp, "objective": float(nlp.objective(z)), "n_active": int(act.size + al.size + au.size)}
+
+
+def is_kkt_point(res, feas_tol: float = 1e-6, stat_tol: float = 1e-6, comp_tol: float = 1e-6) -> bool:
+    return res["feas"] <= feas_tol and res["stat"] <= stat_tol and res["comp"] <= comp_tol
+
+
+def _one(args):
+    ocfg, x0, xf, up, dtp, x, u, dt = args
+    return kkt_residuals(ocfg, x0, xf, up, dtp, x, u, dt)
+
+
+def kkt_many(ocfg, x0, xf, u_prev, dt_prev, x, u, dt, idx, workers: int = 0):
+    """kkt_residuals for the instances `idx` of a batch, spread over worker processes (spawned: the caller may hold a GPU context)."""
+    import multiprocessing as mp
+    import os
+    idx = [int(i) for i in idx]
+    if not idx:
+        return {}
+    jobs = [(ocfg, x0[i], xf[i], u_prev[i], float(dt_prev[i]), x[i], u[i], float(dt[i])) for i in idx]
+    workers = workers or max(1, min(len(jobs), (os.cpu_count() or 2) // 2, 32))
+    if workers == 1 or len(jobs) < 3:
+        return dict(zip(idx, map(_one, jobs)))
+    with mp.get_context("spawn").Pool(workers) as pool:
+        return dict(zip(idx, pool.map(_one, jobs)))

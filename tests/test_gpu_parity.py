@@ -15,7 +15,9 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 @pytest.fixture(scope="module")
 def m():
     import torch
-    assert torch.cuda.is_available(), "these tests need the MI355X"
+    if not torch.cuda.is_available():
+        pytest.skip("these tests need the MI355X (no HIP device here)")
+    torch.zeros(1, device="cuda")          # torch's HIP runtime before the library's
     import mpc_local_planner_amd as pkg
     return pkg
 
@@ -52,6 +54,33 @@ def _feasibility(R, ocfg, x0, xf, up, dtp, res, i):
     return max(np.abs(nlp.equalities(z)).max(), nlp.inequalities(z).max(initial=0.0), (lb - z).max(), (z - ub).max())
 
 
+def _account(tag, ocfg, inputs, r, oracle_out, tol=1e-4):
+    """Parity ACCOUNTING (no thresholds on fractions): every converged device instance is either within `tol` of the C oracle's result
+    (same KKT point: 'match') or is shown to be a KKT point of the reference-form NLP on its own (oracle/kkt_check.py: feasibility,
+    stationarity and complementarity <= 1e-6; 'other_kkt': a line-search tie or a regularisation decision flipped and the iterate
+    sequences parted ways).  Prints the counts and the objective differences, asserts that nothing is left unclassified."""
+    from oracle import kkt_check as KC
+    x0, xf, up, dtp = inputs
+    xo, uo, do, st, it = oracle_out[:5]
+    B = x0.shape[0]
+    err = np.maximum(np.abs(r.x - xo).reshape(B, -1).max(1), np.abs(r.u - uo).reshape(B, -1).max(1))
+    err = np.maximum(err, np.abs(r.dt - do))
+    conv = r.status == 0
+    match = conv & (st == 0) & (err < tol)
+    rest = np.nonzero(conv & ~match)[0]
+    res = KC.kkt_many(ocfg, x0, xf, up, dtp, r.x, r.u, r.dt, rest)
+    other = [i for i in rest if KC.is_kkt_point(res[i])]
+    bad = [i for i in rest if not KC.is_kkt_point(res[i])]
+    dobj = [res[i]["objective"] - (ocfg.n - 1) * do[i] for i in other if st[i] == 0] if ocfg.objective == 0 else []
+    print(f"[{tag}] B={B}: device converged {int(conv.sum())}, oracle converged {int((st == 0).sum())}; match(<{tol:g}) {int(match.sum())} "
+          f"(median |d| {np.median(err[match]):.1e}), other_kkt {len(other)}, unclassified {len(bad)}; "
+          f"objective(device) - objective(oracle) over other_kkt with a converged oracle: n={len(dobj)}"
+          + (f", min {min(dobj):+.3e}, median {np.median(dobj):+.3e}, max {max(dobj):+.3e}" if dobj else "")
+          + f"; worst other_kkt feas/stat/comp = {max([res[i]['feas'] for i in other], default=0):.1e}/{max([res[i]['stat'] for i in other], default=0):.1e}/{max([res[i]['comp'] for i in other], default=0):.1e}")
+    assert not bad, [(int(i), res[i]) for i in bad[:5]]
+    return match, other
+
+
 def test_config2_batch_vs_c_oracle(m, c_oracle):
     """BASELINE.json config 2 (car-like min-time, n=50) on the SURVEY 8d input distribution."""
     from oracle import se2_nlp as R
@@ -69,11 +98,60 @@ def test_config2_batch_vs_c_oracle(m, c_oracle):
     err = np.maximum(err, np.abs(r.dt - do))
     # same algorithm, independent linear algebra (Riccati sweep vs banded LU): identical to round-off except where a
     # line-search/regularisation decision flips on a tie and the iterate sequences part ways
-    assert (err[both] < 1e-4).mean() > 0.9
     assert np.median(err[both]) < 1e-8
+    _account("config 2, B=256", ocfg, (x0, xf, up, dtp), r, (xo, uo, do, st, it))
     # every converged GPU result is a feasible point of the REFERENCE-form NLP (independent of any solver)
     for i in np.nonzero(r.status == 0)[0][:64]:
         assert _feasibility(R, ocfg, x0, xf, up, dtp, r, i) < 1e-6
+    s.close()
+
+
+def test_config2_full_batch_accounting(m, c_oracle):
+    """BASELINE.json config 2 at its FULL batch (B = 1024, single candidate = the reference path) against the C oracle, instance by
+    instance: match / other KKT point of the reference-form NLP / unclassified (must be 0)."""
+    B = 1024
+    cfg, ocfg = _cases(m)["carlike_min_time_n50"]
+    inputs = m.workloads.carlike_min_time_inputs(B)
+    s = m.BatchSolver(cfg, max_batch=B)
+    r = s.solve(*inputs)
+    out = c_oracle.solve_batch(c_oracle.from_nlp_config(ocfg), *inputs)
+    match, other = _account("config 2, B=1024", ocfg, inputs, r, out)
+    assert (r.status == out[3]).mean() > 0.97 and match.sum() > 0.85 * B
+    s.close()
+
+
+def test_candidates_full_batch_winners_vs_oracle_rule(m, c_oracle):
+    """Candidate initial trajectories on the device (seeds generated in the kernel, hedged workgroups, winner picked with atomics) against
+    the identical rule run on the C oracle (oracle/candidates.py), config 2 at B = 1024: converged fraction >= 0.99, winner's iterations
+    <= the cap, winners compared instance by instance; every instance whose winner or trajectory differs must still be a KKT point of
+    the reference-form NLP."""
+    from oracle import candidates as OC
+    from mpc_local_planner_amd import _abi as A
+    B, n = 1024, 50
+    kinds, caps = (A.CAND_REFERENCE, A.CAND_BLEND, A.CAND_BLEND_REVERSE), (60, 60, 60)
+    _, ocfg = _cases(m)["carlike_min_time_n50"]
+    inputs = m.workloads.carlike_min_time_inputs(B)
+    s = m.BatchSolver(m.config_carlike_min_time(n, candidates=kinds, candidate_max_iter=caps), max_batch=B)
+    r = s.solve(*inputs)
+    win, tot = s.last_candidates(B)
+    r2 = s.solve(*inputs)                                   # hedging is timing dependent, the RESULT must not be
+    win2, _ = s.last_candidates(B)
+    np.testing.assert_array_equal(r.x, r2.x); np.testing.assert_array_equal(win, win2); np.testing.assert_array_equal(r.iters, r2.iters)
+    ox, ou, od, ost, oit, owin, olow, allr = OC.solve_candidates(c_oracle, lambda cap: c_oracle.from_nlp_config(ocfg, max_iter=cap), *inputs, kinds, caps, n, ocfg.dt_ref)
+    conv = r.status == 0
+    print(f"[candidates] device converged {conv.mean():.4f} (oracle rule {np.mean(ost == 0):.4f}); winners device {np.bincount(win + 1, minlength=4).tolist()} "
+          f"oracle {np.bincount(owin + 1, minlength=4).tolist()} (index 0 = none); equal winners {np.mean(win == owin):.4f}; winner iterations p99 {np.percentile(r.iters[conv], 99):.0f}")
+    assert conv.mean() >= 0.99 and (win[conv] >= 0).all() and (win[~conv] == -1).all()
+    assert (r.iters[conv] <= np.asarray(caps)[win[conv]]).all() and (tot >= r.iters).all()
+    assert np.mean(win == owin) > 0.97
+    # the single-candidate solve IS candidate 0: where it converges within the cap it must win and supply the identical trajectory
+    s1 = m.BatchSolver(m.config_carlike_min_time(n, max_iter=caps[0]), max_batch=B)
+    r1 = s1.solve(*inputs)
+    ref_ok = r1.status == 0
+    assert (win[ref_ok] == 0).all() and np.array_equal(r.x[ref_ok], r1.x[ref_ok]) and np.array_equal(r.iters[ref_ok], r1.iters[ref_ok])
+    assert (win[~ref_ok] != 0).all()
+    s1.close()
+    _account("config 2 with candidates, B=1024", ocfg, inputs, r, (ox, ou, od, ost, oit))
     s.close()
 
 
@@ -457,8 +535,8 @@ def test_config2_midpoint_and_crank_nicolson_batch_vs_c_oracle(m, c_oracle, meth
     assert (r.status == st).mean() > 0.93
     err = np.maximum(np.abs(r.x - xo).reshape(B, -1).max(1), np.abs(r.u - uo).reshape(B, -1).max(1))
     err = np.maximum(err, np.abs(r.dt - do))
-    assert (err[both] < 1e-4).mean() > 0.9
     assert np.median(err[both]) < 1e-8
+    _account(f"config 2, collocation {method}, B=256", ocfg, (x0, xf, up, dtp), r, (xo, uo, do, st, it))
     for i in np.nonzero(r.status == 0)[0][:32]:
         assert _feasibility(R, ocfg, x0, xf, up, dtp, r, i) < 1e-6
     s.close()
