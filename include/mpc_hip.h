@@ -169,7 +169,8 @@ void mpc_config_defaults(mpc_config* cfg);
  * there is NO CPU fallback.  Replaces Controller::configure (include/.../controller.h:61-62). */
 int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_solver** out);
 
-/* Drop the warm start kept inside the handle.  Replaces Controller::reset (controller.h:104). */
+/* Replaces Controller::reset (controller.h:104): waits for the stream and returns the handle's per-instance state (candidate
+ * bookkeeping, the duals kept for warm starts) to its initial values. */
 int mpc_reset(mpc_solver* s);
 
 void mpc_destroy(mpc_solver* s);
@@ -177,7 +178,7 @@ void mpc_destroy(mpc_solver* s);
 /* One control cycle for B independent planner instances -- the batched equivalent of
  * Controller::step (include/.../controller.h:63-67; src/controller.cpp:111-179).
  * HOST pointers; the call copies in, solves, copies out and returns when done.
- *   x_init/u_init/dt_init : nullable.  NULL -> cold start built on the device exactly as the
+ *   x_init/u_init/dt_init : nullable, all three or none (a partial triple is MPC_EINVAL).  NULL -> cold start built on the device exactly as the
  *       reference does for a 2-pose plan (src/controller.cpp:807-857 +
  *       full_discretization_grid_base_se2.cpp:192-239: linear x0->xf, shortest-arc theta, u=0,
  *       dt=dt_ref).  Non-NULL -> used as the vertex values (warm start), with x_0 := x0 and the

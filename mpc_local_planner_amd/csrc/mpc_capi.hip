@@ -29,63 +29,6 @@ void set_err(const char* what) { snprintf(g_err, sizeof(g_err), "%s", what); }
         if (e_ != hipSuccess) { set_err(#call, e_); return MPC_EHIP; } \
     } while (0)
 
-constexpr int kLanes = 64;
-
-#ifdef MPC_ENABLE_LANE_KERNEL   // developer builds only: the lane-per-instance kernel is NOT part of the product
-
-// One lane = one planner instance.  Inputs/outputs are instance-major (ABI layout); the iterate,
-// duals and Riccati gains live in the instance-minor workspace `ws`.
-template <typename T, int MODEL>
-__global__ __launch_bounds__(kLanes) void mpc_ipm_solve_kernel(
-    mpc::Problem<T> P, mpc::Layout L, T* __restrict__ ws, long stride, int B,
-    const double* __restrict__ x0, const double* __restrict__ xf, const double* __restrict__ u_prev,
-    const double* __restrict__ dt_prev, const double* __restrict__ x_init, const double* __restrict__ u_init,
-    const double* __restrict__ dt_init, double* __restrict__ x_out, double* __restrict__ u_out,
-    double* __restrict__ dt_out, int32_t* __restrict__ status, int32_t* __restrict__ iters) {
-    __shared__ mpc::Problem<T> Ps;
-    __shared__ mpc::Layout Ls;
-    if (threadIdx.x == 0) { Ps = P; Ls = L; }
-    __syncthreads();
-    const int inst = blockIdx.x * kLanes + threadIdx.x;
-    if (inst >= B) return;
-    const int n = L.n;
-    mpc::Mem<T> M{ws + inst, stride};
-    mpc::Ipm<T, MODEL> S(Ps, Ls, M);
-    for (int i = 0; i < 3; ++i) { S.x0[i] = T(x0[3 * inst + i]); S.xf[i] = T(xf[3 * inst + i]); }
-    S.x0[2] = mpc::normalize_theta(S.x0[2]);
-    S.xf[2] = mpc::normalize_theta(S.xf[2]);
-    S.uprev[0] = u_prev ? T(u_prev[2 * inst]) : T(0);
-    S.uprev[1] = u_prev ? T(u_prev[2 * inst + 1]) : T(0);
-    S.dtprev = dt_prev ? T(dt_prev[inst]) : T(0);
-    if (x_init && u_init && dt_init) {
-        const double* xi = x_init + (long)inst * n * 3;
-        const double* ui = u_init + (long)inst * n * 2;
-        for (int k = 0; k < n; ++k)
-            for (int i = 0; i < 3; ++i) M.st(L.X + 3 * k + i, T(xi[3 * k + i]));
-        for (int k = 0; k < n - 1; ++k)
-            for (int j = 0; j < 2; ++j) M.st(L.U + 2 * k + j, T(ui[2 * k + j]));
-        M.st(L.D, T(dt_init[inst]));
-    } else {
-        S.cold_start();
-    }
-    mpc::SolveStats<T> st = S.solve();
-    // getStateAndControlTimeSeries: states x_0..x_{n-2},xf ; controls + duplicate of the last
-    double* xo = x_out + (long)inst * n * 3;
-    double* uo = u_out + (long)inst * n * 2;
-    for (int k = 0; k < n; ++k)
-        for (int i = 0; i < 3; ++i) xo[3 * k + i] = double(M.ld(L.X + 3 * k + i));
-    for (int k = 0; k < n; ++k) {
-        const int ks = k < n - 1 ? k : n - 2;
-        for (int j = 0; j < 2; ++j) uo[2 * k + j] = double(M.ld(L.U + 2 * ks + j));
-    }
-    dt_out[inst] = double(M.ld(L.D));
-    if (status) status[inst] = st.status;
-    if (iters) iters[inst] = st.iters;
-}
-
-
-#endif
-
 // Candidate bookkeeping of a launch with n_candidates > 1 (device pointers; all NULL / 0 for a single candidate).
 //   win[b]      lowest candidate index of instance b that has converged so far (INT_MAX-like: none)
 //   exited[b]   candidates of instance b that have finished; the LAST one to finish copies the winner's record to the caller's outputs
@@ -231,16 +174,12 @@ struct mpc_solver {
     mpc_config cfg;
     mpc::Problem<double> P64;
     mpc::Problem<float> P32;
-    mpc::Layout L;
     mpc::WaveLayout WL;
-    int use_wave;          // 1: wavefront-per-instance LDS kernel, 0: lane-per-instance kernel
     size_t wave_lds;
     int device;
     int max_batch;
-    long stride;
     hipStream_t stream;
     hipEvent_t ev0, ev1;
-    void* ws;
     // staging for the host-pointer entry point
     double *d_x0, *d_xf, *d_up, *d_dtp, *d_xi, *d_ui, *d_dti, *d_xo, *d_uo, *d_dto;
     int32_t *d_status, *d_iters;
@@ -250,6 +189,8 @@ struct mpc_solver {
     const int32_t* p_nvia;      // ... and what the kernel reads: the own copy or borrowed device pointers
     const double* p_via;
     int use_ngrid;
+    int ngrid_B, nvia_B;        // batch sizes the per-instance grid sizes / own via-point copies were set for (solves must not exceed them)
+    hipEvent_t cev0, cev1;      // costmap kernel timing (kept apart from the solve kernel's events)
     double *d_ov, *d_or, *d_ovel;
     // candidate initial trajectories (n_candidates > 1): bookkeeping words, candidate records, per-instance winner / total iterations
     int *d_cwin, *d_cexited, *d_citsum;
@@ -355,7 +296,6 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
     s->cfg = *cfg;
     mpc::fill_problem<double>(*cfg, s->P64);
     mpc::fill_problem<float>(*cfg, s->P32);
-    s->L = mpc::Layout::make(cfg->n);
     {
         const int O = cfg->max_obstacles > 0 ? cfg->max_obstacles : 0;
         const int M = O > 0 ? (cfg->max_obstacle_rows > 0 ? cfg->max_obstacle_rows : 4) : 0;
@@ -368,33 +308,20 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
     }
     s->wave_lds = ((((size_t)s->WL.total * (cfg->precision == MPC_FP32 ? 4 : 8)) + 15) & ~(size_t)15) + 16 +
                   ((cfg->precision == MPC_FP32 ? sizeof(mpc::Problem<float>) : sizeof(mpc::Problem<double>)) + 15 & ~(size_t)15) + sizeof(mpc::WaveLayout);
-    s->use_wave = (s->wave_lds <= 160u * 1024u) ? 1 : 0;
-#ifdef MPC_ENABLE_LANE_KERNEL
-    if (const char* ev = getenv("MPC_HIP_KERNEL")) { if (!strcmp(ev, "lane")) s->use_wave = 0; }
-    if (cfg->max_obstacles > 0 && !s->use_wave) {
-        set_err("mpc_create: obstacles need the LDS-resident kernel; this (n, max_obstacles, max_vertices) does not fit in 160 KB of LDS");
-        delete s;
-        return MPC_EINVAL;
-    }
-#else
-    if (!s->use_wave) {
+    if (s->wave_lds > 160u * 1024u) {
         set_err("mpc_create: the working set of one instance (n, max_obstacles, max_vertices, precision) does not fit in the 160 KB of LDS "
                 "of a compute unit (about n <= 215 grid points in fp64 without obstacles)");
         delete s;
         return MPC_EINVAL;
     }
-#endif
     s->device = device;
     s->max_batch = max_batch;
-    s->stride = ((long)max_batch + kLanes - 1) / kLanes * kLanes;
-    const size_t tsz = cfg->precision == MPC_FP32 ? 4 : 8;
     const size_t n = cfg->n;
     hipError_t er = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking);
     if (er == hipSuccess) er = hipEventCreate(&s->ev0);
     if (er == hipSuccess) er = hipEventCreate(&s->ev1);
-#ifdef MPC_ENABLE_LANE_KERNEL
-    if (er == hipSuccess && !s->use_wave) er = hipMalloc(&s->ws, (size_t)s->L.total * s->stride * tsz);
-#endif
+    if (er == hipSuccess) er = hipEventCreate(&s->cev0);
+    if (er == hipSuccess) er = hipEventCreate(&s->cev1);
     const size_t Bm = max_batch;
     if (er == hipSuccess) er = hipMalloc((void**)&s->d_x0, Bm * 3 * 8);
     if (er == hipSuccess) er = hipMalloc((void**)&s->d_xf, Bm * 3 * 8);
@@ -461,10 +388,12 @@ void mpc_destroy(mpc_solver* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    void* bufs[] = {s->d_cwin, s->d_cexited, s->d_citsum, s->d_crec, s->d_winner, s->d_iters_total, s->d_ovel, s->d_nvia, s->d_via, s->d_ngrid, s->d_ono, s->d_onv, s->d_ov, s->d_or, s->ws, s->d_x0, s->d_xf, s->d_up, s->d_dtp, s->d_xi, s->d_ui, s->d_dti, s->d_xo, s->d_uo, s->d_dto, s->d_status, s->d_iters};
+    void* bufs[] = {s->d_cwin, s->d_cexited, s->d_citsum, s->d_crec, s->d_winner, s->d_iters_total, s->d_ovel, s->d_nvia, s->d_via, s->d_ngrid, s->d_ono, s->d_onv, s->d_ov, s->d_or, s->d_x0, s->d_xf, s->d_up, s->d_dtp, s->d_xi, s->d_ui, s->d_dti, s->d_xo, s->d_uo, s->d_dto, s->d_status, s->d_iters};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
+    if (s->cev0) (void)hipEventDestroy(s->cev0);
+    if (s->cev1) (void)hipEventDestroy(s->cev1);
     if (s->stream) (void)hipStreamDestroy(s->stream);
     delete s;
 }
@@ -475,25 +404,15 @@ template <typename T, int MODEL>
 static hipError_t launch_model(mpc_solver* s, const mpc::Problem<T>& P, int B, const double* x0, const double* xf, const double* up,
                                const double* dtp, const double* xi, const double* ui, const double* dti, const mpc_obstacles& ob, double* xo, double* uo,
                                double* dto, int32_t* st, int32_t* it) {
-    if (s->use_wave) {
-        const bool ext = solver_ext(s);
-        auto kern = ext ? mpc_ipm_wave_kernel<T, MODEL, true> : mpc_ipm_wave_kernel<T, MODEL, false>;
-        if (s->wave_lds > 48u * 1024u) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->wave_lds);
-            if (e != hipSuccess) return e;
-        }
-        CandCtl cc = {P.n_cand, s->d_cwin, s->d_cexited, s->d_citsum, s->d_crec, s->d_winner, s->d_iters_total};
-        hipLaunchKernelGGL(kern, dim3((unsigned)B * (unsigned)(P.n_cand > 1 ? P.n_cand : 1)), dim3(mpc::kWave), s->wave_lds, s->stream, P, s->WL, B, x0, xf, up, dtp, xi, ui, dti, ob,
-                           s->use_ngrid ? s->d_ngrid : nullptr, s->p_nvia, s->p_via, cc, xo, uo, dto, st, it);
-    } else {
-#ifdef MPC_ENABLE_LANE_KERNEL
-        dim3 grid((B + kLanes - 1) / kLanes), block(kLanes);
-        hipLaunchKernelGGL((mpc_ipm_solve_kernel<T, MODEL>), grid, block, 0, s->stream, P, s->L, (T*)s->ws, s->stride, B, x0, xf, up,
-                           dtp, xi, ui, dti, xo, uo, dto, st, it);
-#else
-        return hipErrorInvalidConfiguration;
-#endif
+    const bool ext = solver_ext(s);
+    auto kern = ext ? mpc_ipm_wave_kernel<T, MODEL, true> : mpc_ipm_wave_kernel<T, MODEL, false>;
+    if (s->wave_lds > 48u * 1024u) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->wave_lds);
+        if (e != hipSuccess) return e;
     }
+    CandCtl cc = {P.n_cand, s->d_cwin, s->d_cexited, s->d_citsum, s->d_crec, s->d_winner, s->d_iters_total};
+    hipLaunchKernelGGL(kern, dim3((unsigned)B * (unsigned)(P.n_cand > 1 ? P.n_cand : 1)), dim3(mpc::kWave), s->wave_lds, s->stream, P, s->WL, B, x0, xf, up, dtp, xi, ui, dti, ob,
+                       s->use_ngrid ? s->d_ngrid : nullptr, s->p_nvia, s->p_via, cc, xo, uo, dto, st, it);
     return hipSuccess;
 }
 
@@ -519,6 +438,11 @@ int mpc_solve_batch_device(mpc_solver* s, int32_t B, const double* d_x0, const d
     if (!s || !d_x0 || !d_xf || !d_x_out || !d_u_out || !d_dt_out) { set_err("mpc_solve_batch_device: null argument"); return MPC_EINVAL; }
     if (B <= 0) return MPC_OK;
     if (B > s->max_batch) { set_err("mpc_solve_batch_device: B exceeds max_batch"); return MPC_EBATCH; }
+    if ((d_x_init != nullptr) != (d_u_init != nullptr) || (d_x_init != nullptr) != (d_dt_init != nullptr)) {
+        set_err("mpc_solve_batch: x_init, u_init and dt_init must be given together (all three or none)"); return MPC_EINVAL; }
+    if (s->use_ngrid && B > s->ngrid_B) { set_err("mpc_solve_batch: B exceeds the batch the per-instance grid sizes were set for (mpc_set_grid_sizes)"); return MPC_EBATCH; }
+    if (s->P64.n_via > 0 && s->p_nvia == s->d_nvia && s->nvia_B > 0 && B > s->nvia_B) {
+        set_err("mpc_solve_batch: B exceeds the batch the via-points were set for (mpc_set_via_points)"); return MPC_EBATCH; }
     mpc_obstacles ob = {nullptr, nullptr, nullptr, nullptr, nullptr};
     if (s->cfg.max_obstacles > 0) {
         if (!d_obstacles || !d_obstacles->n_obstacles || !d_obstacles->n_vertices || !d_obstacles->vertices) {
@@ -575,6 +499,7 @@ int mpc_set_via_points(mpc_solver* s, int32_t B, const int32_t* n_via, const dou
     if (!n_via || !via) {
         HIP_TRY(hipMemsetAsync(s->d_nvia, 0, (size_t)s->max_batch * 4, s->stream));
         HIP_TRY(hipStreamSynchronize(s->stream));
+        s->nvia_B = 0;             // every instance: no via-points
         return MPC_OK;
     }
     if (B <= 0 || B > s->max_batch) { set_err("mpc_set_via_points: B out of range"); return MPC_EBATCH; }
@@ -583,6 +508,7 @@ int mpc_set_via_points(mpc_solver* s, int32_t B, const int32_t* n_via, const dou
     HIP_TRY(hipMemcpyAsync(s->d_nvia, n_via, (size_t)B * 4, hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipMemcpyAsync(s->d_via, via, (size_t)B * s->P64.n_via * 3 * 8, hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
+    s->nvia_B = B;
     return MPC_OK;
 }
 
@@ -610,11 +536,10 @@ int mpc_costmap_to_obstacles_device(mpc_solver* s, int32_t B, const uint8_t* d_c
     a.size_x = size_x; a.size_y = size_y; a.resolution = resolution; a.behind_dist = behind_robot_dist;
     a.O = s->cfg.max_obstacles; a.V = s->cfg.max_vertices > 0 ? s->cfg.max_vertices : 1;
     a.n_obstacles = d_n_obstacles; a.n_vertices = d_n_vertices; a.vertices = d_vertices; a.dropped = d_dropped;
-    HIP_TRY(hipEventRecord(s->ev0, s->stream));
+    HIP_TRY(hipEventRecord(s->cev0, s->stream));
     hipLaunchKernelGGL(mpc::costmap_to_obstacles_kernel, dim3(B), dim3(mpc::kCostmapThreads), 0, s->stream, a);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipEventRecord(s->ev1, s->stream));
-    s->timed = true;
+    HIP_TRY(hipEventRecord(s->cev1, s->stream));
     return MPC_OK;
 }
 
@@ -655,13 +580,13 @@ int mpc_set_grid_sizes(mpc_solver* s, const int32_t* n_grid, int32_t B) {
     if (!s) return MPC_EINVAL;
     if (!n_grid) { s->use_ngrid = 0; return MPC_OK; }
     if (B <= 0 || B > s->max_batch) { set_err("mpc_set_grid_sizes: B out of range"); return MPC_EBATCH; }
-    if (!s->use_wave) { set_err("mpc_set_grid_sizes: per-instance grid sizes need the LDS-resident kernel"); return MPC_EINVAL; }
     for (int b = 0; b < B; ++b)
         if (n_grid[b] < 3 || n_grid[b] > s->cfg.n) { set_err("mpc_set_grid_sizes: n_grid[b] must be in [3, cfg.n]"); return MPC_EINVAL; }
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipMemcpyAsync(s->d_ngrid, n_grid, (size_t)B * 4, hipMemcpyHostToDevice, s->stream));
     HIP_TRY(hipStreamSynchronize(s->stream));
     s->use_ngrid = 1;
+    s->ngrid_B = B;
     return MPC_OK;
 }
 
@@ -686,6 +611,8 @@ int mpc_solve_batch(mpc_solver* s, int32_t B, const double* x0, const double* xf
     if (!s || !x0 || !xf || !x_out || !u_out || !dt_out) { set_err("mpc_solve_batch: null argument"); return MPC_EINVAL; }
     if (B <= 0) return MPC_OK;
     if (B > s->max_batch) { set_err("mpc_solve_batch: B exceeds max_batch"); return MPC_EBATCH; }
+    if ((x_init != nullptr) != (u_init != nullptr) || (x_init != nullptr) != (dt_init != nullptr)) {
+        set_err("mpc_solve_batch: x_init, u_init and dt_init must be given together (all three or none)"); return MPC_EINVAL; }
     HIP_TRY(hipSetDevice(s->device));
     const size_t n = s->cfg.n, b = B;
     hipStream_t q = s->stream;

@@ -7,6 +7,7 @@
 
 #include "../../include/mpc_hip.h"
 #include "../../mpc_local_planner_amd/csrc/mpc_core.hpp"
+#include "ipm_serial.hpp"
 #include "../../mpc_local_planner_amd/csrc/mpc_problem.hpp"
 
 template <typename T, int MODEL>
