@@ -181,9 +181,10 @@ struct mpc_solver {
     hipStream_t stream;
     hipEvent_t ev0, ev1;
     // staging for the host-pointer entry point
-    double *d_x0, *d_xf, *d_up, *d_dtp, *d_xi, *d_ui, *d_dti, *d_xo, *d_uo, *d_dto;
-    int32_t *d_status, *d_iters;
-    int32_t *d_ono, *d_onv, *d_ngrid;
+    // staging of the host-pointer entry point: ONE pinned host block and ONE device block each way (one H2D and one D2H per call)
+    unsigned char *h_in, *h_out, *d_in, *d_out;
+    size_t in_cap, out_cap;
+    int32_t* d_ngrid;
     int32_t *d_nvia;            // own copy of the via-point counts / poses (mpc_set_via_points) ...
     double *d_via;
     const int32_t* p_nvia;      // ... and what the kernel reads: the own copy or borrowed device pointers
@@ -191,7 +192,6 @@ struct mpc_solver {
     int use_ngrid;
     int ngrid_B, nvia_B;        // batch sizes the per-instance grid sizes / own via-point copies were set for (solves must not exceed them)
     hipEvent_t cev0, cev1;      // costmap kernel timing (kept apart from the solve kernel's events)
-    double *d_ov, *d_or, *d_ovel;
     // candidate initial trajectories (n_candidates > 1): bookkeeping words, candidate records, per-instance winner / total iterations
     int *d_cwin, *d_cexited, *d_citsum;
     double* d_crec;
@@ -323,32 +323,23 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
     if (er == hipSuccess) er = hipEventCreate(&s->cev0);
     if (er == hipSuccess) er = hipEventCreate(&s->cev1);
     const size_t Bm = max_batch;
-    if (er == hipSuccess) er = hipMalloc((void**)&s->d_x0, Bm * 3 * 8);
-    if (er == hipSuccess) er = hipMalloc((void**)&s->d_xf, Bm * 3 * 8);
-    if (er == hipSuccess) er = hipMalloc((void**)&s->d_up, Bm * 2 * 8);
-    if (er == hipSuccess) er = hipMalloc((void**)&s->d_dtp, Bm * 8);
-    if (er == hipSuccess) er = hipMalloc((void**)&s->d_xi, Bm * n * 3 * 8);
-    if (er == hipSuccess) er = hipMalloc((void**)&s->d_ui, Bm * n * 2 * 8);
-    if (er == hipSuccess) er = hipMalloc((void**)&s->d_dti, Bm * 8);
-    if (er == hipSuccess) er = hipMalloc((void**)&s->d_xo, Bm * n * 3 * 8);
-    if (er == hipSuccess) er = hipMalloc((void**)&s->d_uo, Bm * n * 2 * 8);
-    if (er == hipSuccess) er = hipMalloc((void**)&s->d_dto, Bm * 8);
-    if (er == hipSuccess) er = hipMalloc((void**)&s->d_status, Bm * 4);
-    if (er == hipSuccess) er = hipMalloc((void**)&s->d_iters, Bm * 4);
+    {
+        const size_t O = cfg->max_obstacles > 0 ? cfg->max_obstacles : 0, V = cfg->max_vertices > 0 ? cfg->max_vertices : 1;
+        // inputs: x0 xf u_prev dt_prev | x_init u_init dt_init | n_obstacles n_vertices vertices radius velocity (each piece 256-byte aligned)
+        s->in_cap = Bm * (3 + 3 + 2 + 1) * 8 + Bm * (5 * n + 1) * 8 + (O ? Bm * 4 + Bm * O * 4 + Bm * O * V * 2 * 8 + Bm * O * 8 + Bm * O * 2 * 8 : 0) + 16 * 256;
+        // outputs: x_out u_out dt_out status iters
+        s->out_cap = Bm * (5 * n + 1) * 8 + Bm * 8 + 8 * 256;
+        if (er == hipSuccess) er = hipHostMalloc((void**)&s->h_in, s->in_cap, hipHostMallocDefault);
+        if (er == hipSuccess) er = hipHostMalloc((void**)&s->h_out, s->out_cap, hipHostMallocDefault);
+        if (er == hipSuccess) er = hipMalloc((void**)&s->d_in, s->in_cap);
+        if (er == hipSuccess) er = hipMalloc((void**)&s->d_out, s->out_cap);
+    }
     if (er == hipSuccess) er = hipMalloc((void**)&s->d_ngrid, Bm * 4);
     if (s->P64.n_via > 0) {
         if (er == hipSuccess) er = hipMalloc((void**)&s->d_nvia, Bm * 4);
         if (er == hipSuccess) er = hipMalloc((void**)&s->d_via, Bm * (size_t)s->P64.n_via * 3 * 8);
         if (er == hipSuccess) er = hipMemset(s->d_nvia, 0, Bm * 4);
         s->p_nvia = s->d_nvia; s->p_via = s->d_via;
-    }
-    if (cfg->max_obstacles > 0) {
-        const size_t O = cfg->max_obstacles, V = cfg->max_vertices > 0 ? cfg->max_vertices : 1;
-        if (er == hipSuccess) er = hipMalloc((void**)&s->d_ono, Bm * 4);
-        if (er == hipSuccess) er = hipMalloc((void**)&s->d_onv, Bm * O * 4);
-        if (er == hipSuccess) er = hipMalloc((void**)&s->d_ov, Bm * O * V * 2 * 8);
-        if (er == hipSuccess) er = hipMalloc((void**)&s->d_or, Bm * O * 8);
-        if (er == hipSuccess && cfg->enable_dynamic_obstacles) er = hipMalloc((void**)&s->d_ovel, Bm * O * 2 * 8);
     }
     if (s->P64.n_cand > 1) {
         const size_t C_ = s->P64.n_cand;
@@ -388,8 +379,10 @@ void mpc_destroy(mpc_solver* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    void* bufs[] = {s->d_cwin, s->d_cexited, s->d_citsum, s->d_crec, s->d_winner, s->d_iters_total, s->d_ovel, s->d_nvia, s->d_via, s->d_ngrid, s->d_ono, s->d_onv, s->d_ov, s->d_or, s->d_x0, s->d_xf, s->d_up, s->d_dtp, s->d_xi, s->d_ui, s->d_dti, s->d_xo, s->d_uo, s->d_dto, s->d_status, s->d_iters};
+    void* bufs[] = {s->d_cwin, s->d_cexited, s->d_citsum, s->d_crec, s->d_winner, s->d_iters_total, s->d_nvia, s->d_via, s->d_ngrid, s->d_in, s->d_out};
     for (void* b : bufs) if (b) (void)hipFree(b);
+    if (s->h_in) (void)hipHostFree(s->h_in);
+    if (s->h_out) (void)hipHostFree(s->h_out);
     if (s->ev0) (void)hipEventDestroy(s->ev0);
     if (s->ev1) (void)hipEventDestroy(s->ev1);
     if (s->cev0) (void)hipEventDestroy(s->cev0);
@@ -616,43 +609,54 @@ int mpc_solve_batch(mpc_solver* s, int32_t B, const double* x0, const double* xf
     HIP_TRY(hipSetDevice(s->device));
     const size_t n = s->cfg.n, b = B;
     hipStream_t q = s->stream;
-    HIP_TRY(hipMemcpyAsync(s->d_x0, x0, b * 3 * 8, hipMemcpyHostToDevice, q));
-    HIP_TRY(hipMemcpyAsync(s->d_xf, xf, b * 3 * 8, hipMemcpyHostToDevice, q));
-    if (u_prev) HIP_TRY(hipMemcpyAsync(s->d_up, u_prev, b * 2 * 8, hipMemcpyHostToDevice, q));
-    if (dt_prev) HIP_TRY(hipMemcpyAsync(s->d_dtp, dt_prev, b * 8, hipMemcpyHostToDevice, q));
-    const bool warm = x_init && u_init && dt_init;
+    const bool warm = x_init != nullptr;
+    if (s->cfg.max_obstacles > 0 && (!obstacles || !obstacles->n_obstacles || !obstacles->n_vertices || !obstacles->vertices)) {
+        set_err("mpc_solve_batch: the solver was created with max_obstacles > 0 but no obstacles were passed");
+        return MPC_EINVAL;
+    }
+    // ---- pack every input into the pinned block (256-byte aligned pieces), ONE host-to-device copy
+    size_t off = 0;
+    auto put = [&](const void* src, size_t bytes) -> const unsigned char* {
+        const unsigned char* dptr = s->d_in + off;
+        memcpy(s->h_in + off, src, bytes);
+        off = (off + bytes + 255) & ~(size_t)255;
+        return dptr;
+    };
+    const double* dx0 = (const double*)put(x0, b * 3 * 8);
+    const double* dxf = (const double*)put(xf, b * 3 * 8);
+    const double* dup = u_prev ? (const double*)put(u_prev, b * 2 * 8) : nullptr;
+    const double* ddtp = dt_prev ? (const double*)put(dt_prev, b * 8) : nullptr;
+    const double *dxi = nullptr, *dui = nullptr, *ddti = nullptr;
     if (warm) {
-        HIP_TRY(hipMemcpyAsync(s->d_xi, x_init, b * n * 3 * 8, hipMemcpyHostToDevice, q));
-        HIP_TRY(hipMemcpyAsync(s->d_ui, u_init, b * n * 2 * 8, hipMemcpyHostToDevice, q));
-        HIP_TRY(hipMemcpyAsync(s->d_dti, dt_init, b * 8, hipMemcpyHostToDevice, q));
+        dxi = (const double*)put(x_init, b * n * 3 * 8);
+        dui = (const double*)put(u_init, b * n * 2 * 8);
+        ddti = (const double*)put(dt_init, b * 8);
     }
     mpc_obstacles dob = {nullptr, nullptr, nullptr, nullptr, nullptr};
     if (s->cfg.max_obstacles > 0) {
-        if (!obstacles || !obstacles->n_obstacles || !obstacles->n_vertices || !obstacles->vertices) {
-            set_err("mpc_solve_batch: the solver was created with max_obstacles > 0 but no obstacles were passed");
-            return MPC_EINVAL;
-        }
-        const size_t O = s->cfg.max_obstacles, V = s->cfg.max_vertices;
-        HIP_TRY(hipMemcpyAsync(s->d_ono, obstacles->n_obstacles, b * 4, hipMemcpyHostToDevice, q));
-        HIP_TRY(hipMemcpyAsync(s->d_onv, obstacles->n_vertices, b * O * 4, hipMemcpyHostToDevice, q));
-        HIP_TRY(hipMemcpyAsync(s->d_ov, obstacles->vertices, b * O * V * 2 * 8, hipMemcpyHostToDevice, q));
-        if (obstacles->radius) HIP_TRY(hipMemcpyAsync(s->d_or, obstacles->radius, b * O * 8, hipMemcpyHostToDevice, q));
-        dob.n_obstacles = s->d_ono; dob.n_vertices = s->d_onv; dob.vertices = s->d_ov; dob.radius = obstacles->radius ? s->d_or : nullptr;
-        if (obstacles->velocity && s->d_ovel) {
-            HIP_TRY(hipMemcpyAsync(s->d_ovel, obstacles->velocity, b * O * 2 * 8, hipMemcpyHostToDevice, q));
-            dob.velocity = s->d_ovel;
-        }
+        const size_t O = s->cfg.max_obstacles, V = s->cfg.max_vertices > 0 ? s->cfg.max_vertices : 1;
+        dob.n_obstacles = (const int32_t*)put(obstacles->n_obstacles, b * 4);
+        dob.n_vertices = (const int32_t*)put(obstacles->n_vertices, b * O * 4);
+        dob.vertices = (const double*)put(obstacles->vertices, b * O * V * 2 * 8);
+        if (obstacles->radius) dob.radius = (const double*)put(obstacles->radius, b * O * 8);
+        if (obstacles->velocity && s->cfg.enable_dynamic_obstacles) dob.velocity = (const double*)put(obstacles->velocity, b * O * 2 * 8);
     }
-    int rc = mpc_solve_batch_device(s, B, s->d_x0, s->d_xf, u_prev ? s->d_up : nullptr, dt_prev ? s->d_dtp : nullptr,
-                                    warm ? s->d_xi : nullptr, warm ? s->d_ui : nullptr, warm ? s->d_dti : nullptr, &dob, s->d_xo,
-                                    s->d_uo, s->d_dto, s->d_status, s->d_iters);
+    if (off > s->in_cap) { set_err("mpc_solve_batch: internal staging overflow"); return MPC_EINVAL; }
+    HIP_TRY(hipMemcpyAsync(s->d_in, s->h_in, off, hipMemcpyHostToDevice, q));
+    // ---- outputs: one device block, ONE device-to-host copy
+    size_t oo = 0;
+    auto take = [&](size_t bytes) { size_t at = oo; oo = (oo + bytes + 255) & ~(size_t)255; return at; };
+    const size_t o_x = take(b * n * 3 * 8), o_u = take(b * n * 2 * 8), o_dt = take(b * 8), o_st = take(b * 4), o_it = take(b * 4);
+    int rc = mpc_solve_batch_device(s, B, dx0, dxf, dup, ddtp, dxi, dui, ddti, &dob, (double*)(s->d_out + o_x), (double*)(s->d_out + o_u),
+                                    (double*)(s->d_out + o_dt), (int32_t*)(s->d_out + o_st), (int32_t*)(s->d_out + o_it));
     if (rc != MPC_OK) return rc;
-    HIP_TRY(hipMemcpyAsync(x_out, s->d_xo, b * n * 3 * 8, hipMemcpyDeviceToHost, q));
-    HIP_TRY(hipMemcpyAsync(u_out, s->d_uo, b * n * 2 * 8, hipMemcpyDeviceToHost, q));
-    HIP_TRY(hipMemcpyAsync(dt_out, s->d_dto, b * 8, hipMemcpyDeviceToHost, q));
-    if (status) HIP_TRY(hipMemcpyAsync(status, s->d_status, b * 4, hipMemcpyDeviceToHost, q));
-    if (iters) HIP_TRY(hipMemcpyAsync(iters, s->d_iters, b * 4, hipMemcpyDeviceToHost, q));
+    HIP_TRY(hipMemcpyAsync(s->h_out, s->d_out, oo, hipMemcpyDeviceToHost, q));
     HIP_TRY(hipStreamSynchronize(q));
+    memcpy(x_out, s->h_out + o_x, b * n * 3 * 8);
+    memcpy(u_out, s->h_out + o_u, b * n * 2 * 8);
+    memcpy(dt_out, s->h_out + o_dt, b * 8);
+    if (status) memcpy(status, s->h_out + o_st, b * 4);
+    if (iters) memcpy(iters, s->h_out + o_it, b * 4);
     return MPC_OK;
 }
 

@@ -56,19 +56,41 @@ def is_kkt_point(res, feas_tol: float = 1e-6, stat_tol: float = 1e-6, comp_tol: 
     return res["feas"] <= feas_tol and res["stat"] <= stat_tol and res["comp"] <= comp_tol
 
 
+def obstacle_list(n_obstacles, n_vertices, vertices, radius=None, velocity=None):
+    """one instance's slice of the ABI's mpc_obstacles arrays -> [se2_nlp.Obstacle]"""
+    out = []
+    for j in range(int(n_obstacles)):
+        nv = int(n_vertices[j])
+        r = float(radius[j]) if radius is not None else 0.0
+        kind = (R.OBST_CIRCLE if r > 0 else R.OBST_POINT) if nv <= 1 else (R.OBST_LINE if nv == 2 else R.OBST_POLYGON)
+        vel = np.asarray(velocity[j], float) if velocity is not None else None
+        out.append(R.Obstacle(kind, np.asarray(vertices[j][:max(nv, 1)], float), r, vel))
+    return out
+
+
 def _one(args):
-    ocfg, x0, xf, up, dtp, x, u, dt = args
-    return kkt_residuals(ocfg, x0, xf, up, dtp, x, u, dt)
+    ocfg, x0, xf, up, dtp, x, u, dt, obst, max_rows = args
+    if obst is None:
+        return kkt_residuals(ocfg, x0, xf, up, dtp, x, u, dt)
+    # clearance rows: the association is frozen on the trajectory the solve STARTS from (the cold start), as in the product
+    obs = obstacle_list(*obst)
+    rel, rel_dyn = R.associate_obstacles(ocfg, R.cold_start(ocfg, x0, xf), obs, max_rows)
+    return kkt_residuals(ocfg, x0, xf, up, dtp, x, u, dt, nlp_kwargs=dict(relevant=rel, relevant_dyn=rel_dyn), inp_kwargs=dict(obstacles=obs))
 
 
-def kkt_many(ocfg, x0, xf, u_prev, dt_prev, x, u, dt, idx, workers: int = 0):
-    """kkt_residuals for the instances `idx` of a batch, spread over worker processes (spawned: the caller may hold a GPU context)."""
+def kkt_many(ocfg, x0, xf, u_prev, dt_prev, x, u, dt, idx, workers: int = 0, obstacles=None, max_rows=None):
+    """kkt_residuals for the instances `idx` of a batch, spread over worker processes (spawned: the caller may hold a GPU context).
+    obstacles = the ABI arrays (n_obstacles (B,), n_vertices (B,O), vertices (B,O,V,2)[, radius (B,O)[, velocity (B,O,2)]])."""
     import multiprocessing as mp
     import os
     idx = [int(i) for i in idx]
     if not idx:
         return {}
-    jobs = [(ocfg, x0[i], xf[i], u_prev[i], float(dt_prev[i]), x[i], u[i], float(dt[i])) for i in idx]
+    def ob(i):
+        if obstacles is None:
+            return None
+        return tuple(None if (k >= len(obstacles) or obstacles[k] is None) else obstacles[k][i] for k in range(5))
+    jobs = [(ocfg, x0[i], xf[i], u_prev[i], float(dt_prev[i]), x[i], u[i], float(dt[i]), ob(i), max_rows) for i in idx]
     workers = workers or max(1, min(len(jobs), (os.cpu_count() or 2) // 2, 32))
     if workers == 1 or len(jobs) < 3:
         return dict(zip(idx, map(_one, jobs)))

@@ -54,31 +54,7 @@ def _feasibility(R, ocfg, x0, xf, up, dtp, res, i):
     return max(np.abs(nlp.equalities(z)).max(), nlp.inequalities(z).max(initial=0.0), (lb - z).max(), (z - ub).max())
 
 
-def _account(tag, ocfg, inputs, r, oracle_out, tol=1e-4):
-    """Parity ACCOUNTING (no thresholds on fractions): every converged device instance is either within `tol` of the C oracle's result
-    (same KKT point: 'match') or is shown to be a KKT point of the reference-form NLP on its own (oracle/kkt_check.py: feasibility,
-    stationarity and complementarity <= 1e-6; 'other_kkt': a line-search tie or a regularisation decision flipped and the iterate
-    sequences parted ways).  Prints the counts and the objective differences, asserts that nothing is left unclassified."""
-    from oracle import kkt_check as KC
-    x0, xf, up, dtp = inputs
-    xo, uo, do, st, it = oracle_out[:5]
-    B = x0.shape[0]
-    err = np.maximum(np.abs(r.x - xo).reshape(B, -1).max(1), np.abs(r.u - uo).reshape(B, -1).max(1))
-    err = np.maximum(err, np.abs(r.dt - do))
-    conv = r.status == 0
-    match = conv & (st == 0) & (err < tol)
-    rest = np.nonzero(conv & ~match)[0]
-    res = KC.kkt_many(ocfg, x0, xf, up, dtp, r.x, r.u, r.dt, rest)
-    other = [i for i in rest if KC.is_kkt_point(res[i])]
-    bad = [i for i in rest if not KC.is_kkt_point(res[i])]
-    dobj = [res[i]["objective"] - (ocfg.n - 1) * do[i] for i in other if st[i] == 0] if ocfg.objective == 0 else []
-    print(f"[{tag}] B={B}: device converged {int(conv.sum())}, oracle converged {int((st == 0).sum())}; match(<{tol:g}) {int(match.sum())} "
-          f"(median |d| {np.median(err[match]):.1e}), other_kkt {len(other)}, unclassified {len(bad)}; "
-          f"objective(device) - objective(oracle) over other_kkt with a converged oracle: n={len(dobj)}"
-          + (f", min {min(dobj):+.3e}, median {np.median(dobj):+.3e}, max {max(dobj):+.3e}" if dobj else "")
-          + f"; worst other_kkt feas/stat/comp = {max([res[i]['feas'] for i in other], default=0):.1e}/{max([res[i]['stat'] for i in other], default=0):.1e}/{max([res[i]['comp'] for i in other], default=0):.1e}")
-    assert not bad, [(int(i), res[i]) for i in bad[:5]]
-    return match, other
+from _parity import account as _account      # noqa: E402  (tests/_parity.py)
 
 
 def test_config2_batch_vs_c_oracle(m, c_oracle):
@@ -326,7 +302,7 @@ def test_obstacle_rows_golden_and_properties(m):
     s.close()
 
 
-def test_cpp_controller_facade_closed_loop(tmp_path):
+def test_cpp_controller_facade_closed_loop(m, tmp_path):
     """Builds tests/gpu_controller_demo.cpp against include/mpc_controller.hpp + libmpc_hip.so and runs the reference's
     stand-alone scenario (src/test_mpc_optim_node.cpp) in closed loop through the C++ Controller facade."""
     import subprocess
@@ -340,7 +316,7 @@ def test_cpp_controller_facade_closed_loop(tmp_path):
     assert r.returncode == 0 and "DEMO_OK" in r.stdout, r.stdout + r.stderr
 
 
-def test_no_uninitialised_lds_reads(tmp_path):
+def test_no_uninitialised_lds_reads(m, tmp_path):
     """Instrumented build (-DMPC_POISON_LDS fills the whole LDS working set with NaN before the solve): every golden
     fixture must still be reproduced, i.e. the solver never consumes an LDS word it has not written (regression test
     for a 0 * garbage = NaN bug that only showed up when a previous kernel had left NaN patterns in LDS)."""
