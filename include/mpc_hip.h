@@ -49,10 +49,10 @@ enum mpc_objective {                  /* src/controller.cpp:551-640 */
     MPC_OBJ_MIN_TIME_VIA_POINTS = 2     /* planning/objective/type minimum_time_via_points (src/controller.cpp:597-612) */
 };
 enum mpc_precision { MPC_FP64 = 0, MPC_FP32 = 1 };
-enum mpc_footprint { MPC_FOOTPRINT_POINT = 0, MPC_FOOTPRINT_CIRCLE = 1,
-                     MPC_FOOTPRINT_LINE = 2,        /* teb LineRobotFootprint; point and circular obstacles (what the costmap yields) */
-                     MPC_FOOTPRINT_TWO_CIRCLES = 3, /* teb TwoCirclesRobotFootprint; every obstacle kind */
-                     MPC_FOOTPRINT_POLYGON = 4      /* teb PolygonRobotFootprint; point and circular obstacles */ };
+enum mpc_footprint { MPC_FOOTPRINT_POINT = 0, MPC_FOOTPRINT_CIRCLE = 1,     /* every footprint works with every obstacle kind (point, circle, line, polygon), static or dynamic */
+                     MPC_FOOTPRINT_LINE = 2,        /* teb LineRobotFootprint (the car-like example's footprint) */
+                     MPC_FOOTPRINT_TWO_CIRCLES = 3, /* teb TwoCirclesRobotFootprint */
+                     MPC_FOOTPRINT_POLYGON = 4      /* teb PolygonRobotFootprint */ };
 
 /* Candidate initial trajectories of one planner instance (BASELINE north star: "batches of independent planner instances (and
  * candidate initial trajectories)").  Every candidate is a complete solve of the same NLP from its own initial vertex values. */
@@ -115,7 +115,10 @@ typedef struct mpc_config {
     double  footprint_radius;         /* circular footprint radius */
     int32_t max_obstacles;            /* O: obstacles per instance the solver is sized for (0 = none) */
     int32_t max_vertices;             /* V: vertices per obstacle (1 point, 2 line, >=3 polygon) */
-    int32_t max_obstacle_rows;        /* clearance rows kept per grid point (forced + left + right; default 4) */
+    int32_t max_obstacle_rows;        /* M: clearance rows kept per grid point (default 4, <= 16).  The reference keeps EVERY obstacle closer than
+                                       * force_inclusion_dist plus the nearest one on the left and on the right (stage_inequality_se2.cpp:99-160);
+                                       * here the kept rows are: dynamic obstacles, forced ones in container order -- the M CLOSEST of them when they do
+                                       * not all fit --, then left, right.  mpc_last_rows_dropped tells how many did not fit. */
     double  mu_init_warm;             /* barrier start of a solve that is given an initial guess (x_init != NULL); 0 -> mu_init.
                                        * Closed-loop cycles start next to a solution: 1e-2 saves ~25 % of the iterations. */
     int32_t terminal_ball;            /* planning/terminal_constraint/type == l2_ball (src/controller.cpp:683); the row exists only when at
@@ -129,7 +132,7 @@ typedef struct mpc_config {
     int32_t max_via_points;           /* via-points per instance the solver is sized for (objective MIN_TIME_VIA_POINTS; <= 64) */
     int32_t footprint_n_vertices;     /* MPC_FOOTPRINT_POLYGON: footprint_model/vertices (<= 16), robot frame */
     double  footprint_vertices[32];   /* x0, y0, x1, y1, ... */
-    int32_t enable_dynamic_obstacles; /* collision_avoidance/enable_dynamic_obstacles (src/controller.cpp:721); point / circular footprint */
+    int32_t enable_dynamic_obstacles; /* collision_avoidance/enable_dynamic_obstacles (src/controller.cpp:721) */
     double  footprint_params[4];      /* MPC_FOOTPRINT_LINE: footprint_model/line_start (x, y), line_end (x, y) in the robot frame;
                                        * MPC_FOOTPRINT_TWO_CIRCLES: front_offset, front_radius, rear_offset, rear_radius (src/mpc_local_planner_ros.cpp:900-960) */
     /* candidate initial trajectories (0 or 1 = a single solve from MPC_CAND_REFERENCE, the reference's behaviour).  With n_candidates > 1 every
@@ -236,6 +239,10 @@ int mpc_costmap_to_obstacles_device(mpc_solver* s, int32_t B, const uint8_t* d_c
 int mpc_costmap_to_obstacles(mpc_solver* s, int32_t B, const uint8_t* cost, int32_t size_x, int32_t size_y, double resolution,
                              const double* origin, const double* robot_pose, double behind_robot_dist,
                              int32_t* n_obstacles, int32_t* n_vertices, double* vertices, int32_t* dropped);
+
+/* Clearance rows that did NOT fit into max_obstacle_rows in the most recent solve, per instance (summed over the grid points k = 1..n-2;
+ * association of candidate 0).  0 everywhere = the solve saw exactly the rows the reference would have built.  HOST pointer. */
+int mpc_last_rows_dropped(mpc_solver* s, int32_t B, int32_t* rows_dropped);
 
 /* Candidate bookkeeping of the most recent mpc_solve_batch* call (after mpc_synchronize): winner[b] = index of the candidate that supplied
  * instance b's result (-1: none converged, candidate 0's last iterate was returned); iters_total[b] = interior-point iterations spent on

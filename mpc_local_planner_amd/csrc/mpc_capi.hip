@@ -44,6 +44,7 @@ struct CandCtl {
     double* rec;
     int32_t* winner_out;
     int32_t* iters_total_out;
+    int32_t* rows_dropped;     // [B] clearance rows of candidate 0 that did not fit into max_obstacle_rows (NULL without obstacles)
 };
 constexpr int kWinIdle = 0x7f7f7f7f;
 
@@ -115,6 +116,7 @@ __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
         mpc::SolveStats<T> st = S.solve();
         __syncthreads();
         st_status = st.status; st_iters = st.iters;
+        if (cc.rows_dropped && cand == 0 && lane == 0) cc.rows_dropped[inst] = S.rows_dropped;
         if (NC <= 1) {
             double* xo = x_out + (long)inst * nmax * 3;
             double* uo = u_out + (long)inst * nmax * 2;
@@ -196,6 +198,7 @@ struct mpc_solver {
     int *d_cwin, *d_cexited, *d_citsum;
     double* d_crec;
     int32_t *d_winner, *d_iters_total;
+    int32_t* d_rows_dropped;    // per instance: clearance rows that did not fit (solvers with obstacles)
     int32_t* last_status;       // device pointers of the most recent solve (mpc_last_candidates without candidates)
     int32_t* last_iters;
     bool timed;
@@ -270,10 +273,6 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         set_err("mpc_create: unknown footprint model"); return MPC_EINVAL; }
     if (cfg->max_obstacles > 0 && cfg->footprint_kind == MPC_FOOTPRINT_POLYGON && (cfg->footprint_n_vertices < 1 || cfg->footprint_n_vertices > 16)) {
         set_err("mpc_create: the polygon footprint needs 1..16 vertices"); return MPC_EINVAL; }
-    if (cfg->max_obstacles > 0 && cfg->enable_dynamic_obstacles && cfg->footprint_kind != MPC_FOOTPRINT_POINT && cfg->footprint_kind != MPC_FOOTPRINT_CIRCLE) {
-        set_err("mpc_create: dynamic obstacles are implemented for the point and circular footprints"); return MPC_EINVAL; }
-    if (cfg->max_obstacles > 0 && (cfg->footprint_kind == MPC_FOOTPRINT_LINE || cfg->footprint_kind == MPC_FOOTPRINT_POLYGON) && cfg->max_vertices > 1) {
-        set_err("mpc_create: the line and polygon footprints are implemented for point and circular obstacles (max_vertices = 1)"); return MPC_EINVAL; }
     for (int j = 0; j < 2; ++j)
         if (!(cfg->u_lb[j] < cfg->u_ub[j])) { set_err("mpc_create: control box must be finite and non-empty"); return MPC_EINVAL; }
     if (cfg->n_candidates < 0 || cfg->n_candidates > MPC_MAX_CANDIDATES) { set_err("mpc_create: n_candidates must be in [0, MPC_MAX_CANDIDATES]"); return MPC_EINVAL; }
@@ -304,7 +303,9 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         s->WL = mpc::WaveLayout::make(cfg->n, M, O, cfg->max_vertices > 0 ? cfg->max_vertices : 1, ntrig, s->P64.n_via,
                                         (O > 0 && (cfg->footprint_kind == MPC_FOOTPRINT_LINE || cfg->footprint_kind == MPC_FOOTPRINT_TWO_CIRCLES ||
                                                    cfg->footprint_kind == MPC_FOOTPRINT_POLYGON || cfg->enable_dynamic_obstacles)) ? M : 0,
-                                        (O > 0 && cfg->enable_dynamic_obstacles) ? O : 0, solver_ext(s) ? mpc::NSTG_EXT : mpc::NSTG_BASE);
+                                        (O > 0 && cfg->enable_dynamic_obstacles) ? O : 0, solver_ext(s) ? mpc::NSTG_EXT : mpc::NSTG_BASE,
+                                        (O > 0 && cfg->enable_dynamic_obstacles && (cfg->footprint_kind == MPC_FOOTPRINT_LINE || cfg->footprint_kind == MPC_FOOTPRINT_TWO_CIRCLES ||
+                                                                                     cfg->footprint_kind == MPC_FOOTPRINT_POLYGON)) ? M : 0);
     }
     s->wave_lds = ((((size_t)s->WL.total * (cfg->precision == MPC_FP32 ? 4 : 8)) + 15) & ~(size_t)15) + 16 +
                   ((cfg->precision == MPC_FP32 ? sizeof(mpc::Problem<float>) : sizeof(mpc::Problem<double>)) + 15 & ~(size_t)15) + sizeof(mpc::WaveLayout);
@@ -340,6 +341,10 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         if (er == hipSuccess) er = hipMalloc((void**)&s->d_via, Bm * (size_t)s->P64.n_via * 3 * 8);
         if (er == hipSuccess) er = hipMemset(s->d_nvia, 0, Bm * 4);
         s->p_nvia = s->d_nvia; s->p_via = s->d_via;
+    }
+    if (cfg->max_obstacles > 0) {
+        if (er == hipSuccess) er = hipMalloc((void**)&s->d_rows_dropped, Bm * 4);
+        if (er == hipSuccess) er = hipMemset(s->d_rows_dropped, 0, Bm * 4);
     }
     if (s->P64.n_cand > 1) {
         const size_t C_ = s->P64.n_cand;
@@ -379,7 +384,7 @@ void mpc_destroy(mpc_solver* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    void* bufs[] = {s->d_cwin, s->d_cexited, s->d_citsum, s->d_crec, s->d_winner, s->d_iters_total, s->d_nvia, s->d_via, s->d_ngrid, s->d_in, s->d_out};
+    void* bufs[] = {s->d_rows_dropped, s->d_cwin, s->d_cexited, s->d_citsum, s->d_crec, s->d_winner, s->d_iters_total, s->d_nvia, s->d_via, s->d_ngrid, s->d_in, s->d_out};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (s->h_in) (void)hipHostFree(s->h_in);
     if (s->h_out) (void)hipHostFree(s->h_out);
@@ -403,7 +408,7 @@ static hipError_t launch_model(mpc_solver* s, const mpc::Problem<T>& P, int B, c
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->wave_lds);
         if (e != hipSuccess) return e;
     }
-    CandCtl cc = {P.n_cand, s->d_cwin, s->d_cexited, s->d_citsum, s->d_crec, s->d_winner, s->d_iters_total};
+    CandCtl cc = {P.n_cand, s->d_cwin, s->d_cexited, s->d_citsum, s->d_crec, s->d_winner, s->d_iters_total, s->d_rows_dropped};
     hipLaunchKernelGGL(kern, dim3((unsigned)B * (unsigned)(P.n_cand > 1 ? P.n_cand : 1)), dim3(mpc::kWave), s->wave_lds, s->stream, P, s->WL, B, x0, xf, up, dtp, xi, ui, dti, ob,
                        s->use_ngrid ? s->d_ngrid : nullptr, s->p_nvia, s->p_via, cc, xo, uo, dto, st, it);
     return hipSuccess;
@@ -480,6 +485,18 @@ int mpc_last_candidates(mpc_solver* s, int32_t B, int32_t* winner, int32_t* iter
         if (!s->last_iters) { set_err("mpc_last_candidates: the last solve kept no iteration array"); return MPC_EINVAL; }
         HIP_TRY(hipMemcpy(iters_total, s->last_iters, (size_t)B * 4, hipMemcpyDeviceToHost));
     }
+    return MPC_OK;
+}
+
+int mpc_last_rows_dropped(mpc_solver* s, int32_t B, int32_t* rows_dropped) {
+    g_err[0] = 0;
+    if (!s || !rows_dropped) return MPC_EINVAL;
+    if (B <= 0) return MPC_OK;
+    if (B > s->max_batch) { set_err("mpc_last_rows_dropped: B exceeds max_batch"); return MPC_EBATCH; }
+    if (!s->d_rows_dropped) { memset(rows_dropped, 0, (size_t)B * 4); return MPC_OK; }
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipMemcpy(rows_dropped, s->d_rows_dropped, (size_t)B * 4, hipMemcpyDeviceToHost));
     return MPC_OK;
 }
 

@@ -44,9 +44,10 @@ struct WaveLayout {
     int GV, GNV, GR, GC;                          // obstacle geometry: vertices, vertex counts, radii, centroids
     int OAT, OHXT, OHYT, OHTT;                    // third-variable parts of the clearance rows: heading (footprints that turn with the pose) or
                                                   // dt (dynamic obstacles); MT = M when either is configured, else 0 words
+    int OAD, OHXD, OHYD, OHDD, OHTD;              // dt parts when BOTH apply (dynamic obstacles + a turning footprint): gradient, hess [x dt, y dt, dt dt, theta dt]
     int GVEL;                                     // obstacle velocities (dynamic obstacles; 2 * OD words)
     int NV, VIA, VIDX;                            // via-points: capacity, poses (x, y, theta), attached grid point (-1 = skipped)
-    __host__ __device__ static WaveLayout make(int n, int M = 0, int O = 0, int V = 1, int ntrig = 4, int NV = 0, int MT = 0, int OD = 0, int nstg = NSTG_BASE) {
+    __host__ __device__ static WaveLayout make(int n, int M = 0, int O = 0, int V = 1, int ntrig = 4, int NV = 0, int MT = 0, int OD = 0, int nstg = NSTG_BASE, int MD = 0) {
         WaveLayout L;
         L.n = n;
         L.NS = n;
@@ -68,6 +69,7 @@ struct WaveLayout {
         L.GV = o; o += 2 * O * V; L.GNV = o; o += O; L.GR = o; o += O; L.GC = o; o += 2 * O;
         L.NV = NV; L.VIA = o; o += 3 * NV; L.VIDX = o; o += NV;
         L.OAT = take(MT); L.OHXT = take(MT); L.OHYT = take(MT); L.OHTT = take(MT);
+        L.OAD = take(MD); L.OHXD = take(MD); L.OHYD = take(MD); L.OHDD = take(MD); L.OHTD = take(MD);
         L.GVEL = o; o += 2 * OD;
         L.total = o;
         return L;
@@ -169,6 +171,7 @@ struct IpmWave {
     // candidate initial trajectories: this wave's candidate index, its iteration cap and the instance's winner word (global memory; NULL when
     // the solver runs a single candidate).  A lower winner index than ours = a higher-priority candidate has converged: we stop.
     int my_cand = 0, iter_cap = 0;
+    int rows_dropped = 0;        // clearance rows that did not fit into max_obstacle_rows (associate_obstacles)
     const int* win_ptr = nullptr;
 
     __device__ IpmWave(const Problem<T>& p, const WaveLayout& l, T* s, int ln) : P(p), L(l), sm(s), lane(ln) {}
@@ -386,9 +389,14 @@ struct IpmWave {
     }
 
     // StageInequalitySE2::update (src/optimal_control/stage_inequality_se2.cpp:50-162): relevant obstacles of every
-    // grid point from the current vertex values; at most M rows are kept (forced ones first, then left, right).
-    __device__ __forceinline__ void associate_obstacles() const {
+    // grid point from the current vertex values.  The reference keeps EVERY obstacle closer than force_inclusion_dist plus the nearest one
+    // on the left and on the right; this record has room for M rows per grid point.  Order of the kept rows: dynamic obstacles, forced
+    // ones (container order), left, right.  When more than M rows are wanted, the forced ones that stay are the M CLOSEST (ties: lower
+    // index) -- a deviation from the reference that the caller can see: the number of rows that did not fit is returned (summed over the
+    // grid points; mpc_last_rows_dropped) so that max_obstacle_rows can be raised.
+    __device__ __forceinline__ int associate_obstacles() const {
         const int n = L.n, M = L.M;
+        int dropped = 0;
         for (int k = lane; k < n; k += kWave) {
             int cnt = 0;
             for (int m = 0; m < M; ++m) F(L.OI, m, k) = T(-1);
@@ -397,39 +405,51 @@ struct IpmWave {
                 T s, c;
                 t_sincos(th, &s, &c);
                 T lmin = T(1e30), rmin = T(1e30);
-                int lidx = -1, ridx = -1;
+                int lidx = -1, ridx = -1, wanted = 0;
                 if (dynobs())        // every dynamic obstacle is kept at every grid point (:99-106)
-                    for (int j = 0; j < L.O; ++j) if ((int)sm[L.GNV + j] > 0 && is_dynamic(j) && cnt < M) { F(L.OI, cnt, k) = T(j); ++cnt; }
+                    for (int j = 0; j < L.O; ++j) if ((int)sm[L.GNV + j] > 0 && is_dynamic(j)) { ++wanted; if (cnt < M) { F(L.OI, cnt, k) = T(j); ++cnt; } }
+                const int first_forced = cnt;
                 for (int j = 0; j < L.O; ++j) {
                     if ((int)sm[L.GNV + j] <= 0) continue;
                     if (is_dynamic(j)) continue;
                     T dist, nx, ny, hk;
                     if (fpline()) { T a3[3], h3[3]; dist = turn_eval(px, py, th, j, a3, hk, h3); }
                     else { obst_eval(px, py, j, dist, nx, ny, hk); dist -= P.fp_radius; }
-                    if (dist < P.force_incl) { if (cnt < M) { F(L.OI, cnt, k) = T(j); ++cnt; } continue; }
+                    if (dist < P.force_incl) {
+                        ++wanted;
+                        if (cnt < M) { F(L.OI, cnt, k) = T(j); F(L.OG, cnt, k) = dist; ++cnt; }       // OG doubles as the distance of a kept forced row
+                        else if (first_forced < M) {
+                            // full: the farthest forced row kept so far gives way if this obstacle is closer (the later ones keep their order)
+                            int far = first_forced;
+                            for (int m = first_forced + 1; m < M; ++m) if (F(L.OG, m, k) >= F(L.OG, far, k)) far = m;
+                            if (dist < F(L.OG, far, k)) {
+                                for (int m = far; m + 1 < M; ++m) { F(L.OI, m, k) = F(L.OI, m + 1, k); F(L.OG, m, k) = F(L.OG, m + 1, k); }
+                                F(L.OI, M - 1, k) = T(j); F(L.OG, M - 1, k) = dist;
+                            }
+                        }
+                        continue;
+                    }
                     if (dist > P.cutoff) continue;
                     // cross2d(orientation, centroid) with the centroid as an ABSOLUTE vector (:121)
                     if (c * sm[L.GC + 2 * j + 1] - sm[L.GC + 2 * j] * s > T(0)) { if (dist < lmin) { lmin = dist; lidx = j; } }
                     else { if (dist < rmin) { rmin = dist; ridx = j; } }
                 }
-                if (lidx >= 0 && cnt < M) { F(L.OI, cnt, k) = T(lidx); ++cnt; }
-                if (ridx >= 0 && cnt < M) { F(L.OI, cnt, k) = T(ridx); ++cnt; }
+                if (lidx >= 0) { ++wanted; if (cnt < M) { F(L.OI, cnt, k) = T(lidx); ++cnt; } }
+                if (ridx >= 0) { ++wanted; if (cnt < M) { F(L.OI, cnt, k) = T(ridx); ++cnt; } }
+                if (k < n - 1) dropped += wanted - cnt;       // the final state carries no rows (finite_differences_grid_se2.cpp:47-56)
             }
         }
+        return (int)wave_sum(T(dropped));
     }
 
-    // teb LineRobotFootprint::calculateDistance for a point / circular obstacle j: distance of the obstacle centre to the footprint
-    // segment, evaluated in the ROBOT frame q = R(-theta)(p_o - p) where the segment is fixed.  Returns the distance, the row gradient
-    // a = d g / d(x, y, theta) of g = d_min - dist, hk (the (x,y) block of hess g is -hk (I - a_xy a_xy'), |a_xy| = 1) and the heading
-    // parts h3 = hess g [x theta, y theta, theta theta].
-    __device__ __forceinline__ T line_eval(T px, T py, T th, int j, T a[3], T& hk, T h3[3]) const {
-        const T* v = sm + L.GV + 2 * L.V * j;
-        T s, c;
-        t_sincos(th, &s, &c);
-        const T vx = v[0] - px, vy = v[1] - py;
+    // teb Line / PolygonRobotFootprint::calculateDistance for ONE world point (vwx, vwy) (an obstacle centre or an obstacle vertex): distance
+    // of the point to the footprint segment / closed edge loop, evaluated in the ROBOT frame q = R(-theta)(v - p) where the footprint is
+    // fixed (teb distance_point_to_polygon_2d: first closest edge wins, no inside test; 1 vertex = a point, 2 vertices = one edge).
+    // Returns the distance, the row gradient a = d g / d(x, y, theta) of g = d_min - dist, hk (the (x,y) block of hess g is
+    // -hk (I - a_xy a_xy'), |a_xy| = 1) and the heading parts h3 = hess g [x theta, y theta, theta theta].
+    __device__ __forceinline__ T fp_point_eval(T px, T py, T s, T c, T vwx, T vwy, T a[3], T& hk, T h3[3]) const {
+        const T vx = vwx - px, vy = vwy - py;
         const T qx = c * vx + s * vy, qy = c * vy - s * vx;
-        // closest point of the footprint: the segment (line) or the closed edge loop of the polygon (teb distance_point_to_polygon_2d:
-        // first closest edge wins, no inside test; 1 vertex = a point, 2 vertices = one edge)
         T dx = T(0), dy = T(0), t = T(0), best = T(3e38);
         const bool poly = P.footprint_kind == 4;
         const int nv = poly ? P.fp_nv : 2;
@@ -456,7 +476,68 @@ struct IpmWave {
         h3[0] = -((s * hwy - c * hwx) + (nx * s + ny * c));
         h3[1] = -((-s * hwx - c * hwy) + (ny * s - nx * c));
         h3[2] = -((qy * hwx - qx * hwy) - (nx * qx + ny * qy));
-        return D - sm[L.GR + j];
+        return D;
+    }
+    // footprint vertex i in the robot frame (line: start, end; polygon: the vertex list)
+    __device__ __forceinline__ void fp_vertex(int i, T& ax, T& ay) const {
+        const bool poly = P.footprint_kind == 4;
+        ax = poly ? P.fp_poly[2 * i] : P.fp_line[2 * i]; ay = poly ? P.fp_poly[2 * i + 1] : P.fp_line[2 * i + 1];
+    }
+    __device__ __forceinline__ static bool seg_intersect(T ax, T ay, T bx, T by, T cx, T cy, T dx, T dy) {
+        const T o1 = (bx - ax) * (cy - ay) - (by - ay) * (cx - ax), o2 = (bx - ax) * (dy - ay) - (by - ay) * (dx - ax);
+        const T o3 = (dx - cx) * (ay - cy) - (dy - cy) * (ax - cx), o4 = (dx - cx) * (by - cy) - (dy - cy) * (bx - cx);
+        return o1 * o2 < T(0) && o3 * o4 < T(0);
+    }
+    // line / polygon footprint against obstacle j of ANY kind (teb LineRobotFootprint / PolygonRobotFootprint::calculateDistance ->
+    // Obstacle::getMinimumDistance(segment | polygon): distance_segment_to_segment_2d / distance_segment_to_polygon_2d /
+    // distance_polygon_to_polygon_2d).  All of them are the minimum over point-to-segment distances between the two closed edge loops
+    // (0 where two edges cross, no inside test), i.e. the minimum over
+    //     every obstacle vertex against the footprint edges  (fp_point_eval: the footprint moves with the pose), and
+    //     every footprint vertex c_i(theta) = p + R(theta) a_i against the obstacle edges (obst_eval, chain rule through theta).
+    // Point / circular obstacles take the first family only (their single vertex).  Same outputs as fp_point_eval.
+    __device__ __forceinline__ T line_eval(T px, T py, T th, int j, T a[3], T& hk, T h3[3]) const {
+        const T* v = sm + L.GV + 2 * L.V * j;
+        T s, c;
+        t_sincos(th, &s, &c);
+        const int nvo = (int)sm[L.GNV + j];
+        if (nvo <= 1) return fp_point_eval(px, py, s, c, v[0], v[1], a, hk, h3) - sm[L.GR + j];
+        const int F_ = P.footprint_kind == 4 ? P.fp_nv : 2;
+        T best = T(3e38);
+        for (int m = 0; m < nvo; ++m) {
+            T am[3], hm, h3m[3];
+            const T D = fp_point_eval(px, py, s, c, v[2 * m], v[2 * m + 1], am, hm, h3m);
+            if (D < best) { best = D; a[0] = am[0]; a[1] = am[1]; a[2] = am[2]; hk = hm; h3[0] = h3m[0]; h3[1] = h3m[1]; h3[2] = h3m[2]; }
+        }
+        for (int i = 0; i < F_; ++i) {
+            T ax_, ay_;
+            fp_vertex(i, ax_, ay_);
+            const T rx = c * ax_ - s * ay_, ry = s * ax_ + c * ay_;
+            T D, nx, ny, ho;
+            obst_eval(px + rx, py + ry, j, D, nx, ny, ho);
+            if (D < best) {
+                best = D;
+                const T wx = -ry, wy = rx, nw = nx * wx + ny * wy;         // w = dc/dtheta
+                a[0] = -nx; a[1] = -ny; a[2] = -nw;
+                hk = ho;
+                const T hvx = ho * (wx - nx * nw), hvy = ho * (wy - ny * nw);
+                h3[0] = -hvx; h3[1] = -hvy; h3[2] = -((wx * hvx + wy * hvy) - (nx * rx + ny * ry));
+            }
+        }
+        // crossing edges: distance 0 (and no gradient), as distance_segment_to_segment_2d returns it
+        const int nef = F_ <= 2 ? (F_ == 2 ? 1 : 0) : F_, neo = nvo == 2 ? 1 : nvo;
+        for (int e = 0; e < nef; ++e) {
+            T a0x, a0y, a1x, a1y;
+            fp_vertex(e, a0x, a0y); fp_vertex((e + 1) % F_, a1x, a1y);
+            const T Ax = px + c * a0x - s * a0y, Ay = py + s * a0x + c * a0y, Bx = px + c * a1x - s * a1y, By = py + s * a1x + c * a1y;
+            for (int o = 0; o < neo; ++o) {
+                const int o2 = (o + 1) % nvo;
+                if (seg_intersect(Ax, Ay, Bx, By, v[2 * o], v[2 * o + 1], v[2 * o2], v[2 * o2 + 1])) {
+                    a[0] = a[1] = a[2] = T(0); hk = T(0); h3[0] = h3[1] = h3[2] = T(0);
+                    return T(0);
+                }
+            }
+        }
+        return best;
     }
 
     // teb TwoCirclesRobotFootprint::calculateDistance: min(dist(front centre) - r_front, dist(rear centre) - r_rear) with the centres at
@@ -510,13 +591,29 @@ struct IpmWave {
         h3[0] = hx; h3[1] = hy; h3[2] = -(kvx * hx + kvy * hy);
         if (!dtf()) { a[2] = T(0); h3[0] = h3[1] = h3[2] = T(0); }   // fixed grid: dt is not a variable
     }
-    // same for a footprint that turns with the pose (line): adds the heading gradient and the heading parts of the Hessian; with dynamic
-    // obstacles the third slot carries the dt parts instead (d = dt of the evaluated point)
-    __device__ __forceinline__ bool obst_row3(int k, int m, T px, T py, T th, T& g, T a[3], T& hk, T h3[3], T d = T(0)) const {
+    // row (k, m) with its third-variable parts.  a[2] / h3: heading (footprints that turn with the pose) or, with a point / circular
+    // footprint, dt (dynamic obstacles; d = dt of the evaluated point).  With BOTH (a dynamic obstacle seen by a turning footprint) a[2] / h3
+    // carry the heading parts and ad / hd = (d g / d dt, hess g [x dt, y dt, dt dt, theta dt]) the dt parts: the row is the static row
+    // G(p - k dt v, theta), so with kappa = k v:  g_dt = -a_xy . kappa,  g_{p dt} = -H_xy kappa,  g_{theta dt} = -g_{p theta} . kappa,
+    // g_{dt dt} = kappa' H_xy kappa,  H_xy = -hk (I - a_xy a_xy').
+    __device__ __forceinline__ bool obst_row3(int k, int m, T px, T py, T th, T& g, T a[3], T& hk, T h3[3], T d, T& ad, T hd[4]) const {
+        ad = T(0); hd[0] = hd[1] = hd[2] = hd[3] = T(0);
         if (dynobs()) {
             const int j = (int)F(L.OI, m, k);
             if (j < 0) return false;
-            if (is_dynamic(j)) { dyn_row(k, j, px, py, d, g, a, hk, h3); return true; }
+            if (is_dynamic(j)) {
+                if (!fpline()) { dyn_row(k, j, px, py, d, g, a, hk, h3); return true; }
+                const T kx = T(k) * sm[L.GVEL + 2 * j], ky = T(k) * sm[L.GVEL + 2 * j + 1];
+                g = P.d_min - turn_eval(px - d * kx, py - d * ky, th, j, a, hk, h3);
+                if (dtf()) {
+                    const T ak = a[0] * kx + a[1] * ky;
+                    ad = -ak;
+                    hd[0] = hk * (kx - a[0] * ak); hd[1] = hk * (ky - a[1] * ak);
+                    hd[2] = -hk * (kx * kx + ky * ky - ak * ak);
+                    hd[3] = -(h3[0] * kx + h3[1] * ky);
+                }
+                return true;
+            }
         }
         if (!fpline()) { a[2] = T(0); h3[0] = h3[1] = h3[2] = T(0); return obst_row(k, m, px, py, g, a[0], a[1], hk); }
         const int j = (int)F(L.OI, m, k);
@@ -524,11 +621,17 @@ struct IpmWave {
         g = P.d_min - turn_eval(px, py, th, j, a, hk, h3);
         return true;
     }
+    __device__ __forceinline__ bool obst_row3(int k, int m, T px, T py, T th, T& g, T a[3], T& hk, T h3[3], T d = T(0)) const {
+        T ad, hd[4];
+        return obst_row3(k, m, px, py, th, g, a, hk, h3, d, ad, hd);
+    }
+    __device__ __forceinline__ bool dynturn() const { return fpline() && dynobs(); }
     // a' dz of row (k, m) from the cached gradient
     __device__ __forceinline__ T obst_jdz(int k, int m) const {
         T j = F(L.OAX, m, k) * F(L.DX, 0, k) + F(L.OAY, m, k) * F(L.DX, 1, k);
         if (fpline()) j += F(L.OAT, m, k) * F(L.DX, 2, k);
-        if (dynobs()) j += F(L.OAT, m, k) * SCL(SC_DD);
+        if (dynturn()) j += F(L.OAD, m, k) * SCL(SC_DD);
+        else if (dynobs()) j += F(L.OAT, m, k) * SCL(SC_DD);
         return j;
     }
 
@@ -751,18 +854,20 @@ struct IpmWave {
                 if (L.M > 0 && k >= 1) {
                     const T px = F(L.X, 0, k), py = F(L.X, 1, k);
                     for (int m = 0; m < L.M; ++m) {
-                        T g, a3[3], hk, h3[3];
-                        if (!obst_row3(k, m, px, py, F(L.X, 2, k), g, a3, hk, h3, d)) continue;
+                        T g, a3[3], hk, h3[3], ad, hd[4];
+                        if (!obst_row3(k, m, px, py, F(L.X, 2, k), g, a3, hk, h3, d, ad, hd)) continue;
                         const T ax = a3[0], ay = a3[1];
                         F(L.OG, m, k) = g; F(L.OAX, m, k) = ax; F(L.OAY, m, k) = ay; F(L.OHK, m, k) = hk;
                         if (fpline() || dynobs()) { F(L.OAT, m, k) = a3[2]; F(L.OHXT, m, k) = h3[0]; F(L.OHYT, m, k) = h3[1]; F(L.OHTT, m, k) = h3[2]; }
+                        if (dynturn()) { F(L.OAD, m, k) = ad; F(L.OHXD, m, k) = hd[0]; F(L.OHYD, m, k) = hd[1]; F(L.OHDD, m, k) = hd[2]; F(L.OHTD, m, k) = hd[3]; }
                         const T s = F(L.OS, m, k), y = F(L.OY, m, k);
                         const T res = g + s;
                         rp = t_max(rp, t_abs(res)); th += t_abs(res);
                         cmin = t_min(cmin, s * y); cmax = t_max(cmax, s * y);
                         sb += y; nb += 1;
                         osx += y * ax; osy += y * ay;
-                        if (dynobs()) rdd += y * a3[2]; else ost += y * a3[2];
+                        if (dynturn()) { rdd += y * ad; ost += y * a3[2]; }
+                        else if (dynobs()) rdd += y * a3[2]; else ost += y * a3[2];
                     }
                 }
                 if (k >= 1) {
@@ -913,7 +1018,14 @@ struct IpmWave {
                         sp.ott += sig * at * at + y * F(L.OHTT, m, k);
                         sp.ogt += at * ybar;
                     }
-                    if (dynobs()) {       // dt parts of the rows of dynamic obstacles (zero for the static ones)
+                    if (dynturn()) {      // dt parts next to the heading parts: x dt, y dt, theta dt, dt dt
+                        const T ad = F(L.OAD, m, k), at = F(L.OAT, m, k);
+                        sp.cxd[0] += sig * ax * ad + y * F(L.OHXD, m, k);
+                        sp.cxd[1] += sig * ay * ad + y * F(L.OHYD, m, k);
+                        sp.cxd[2] += sig * at * ad + y * F(L.OHTD, m, k);
+                        sp.hdd += sig * ad * ad + y * F(L.OHDD, m, k);
+                        sp.gdt += ad * ybar;
+                    } else if (dynobs()) {       // dt parts of the rows of dynamic obstacles (zero for the static ones)
                         const T ad = F(L.OAT, m, k);
                         sp.cxd[0] += sig * ax * ad + y * F(L.OHXT, m, k);
                         sp.cxd[1] += sig * ay * ad + y * F(L.OHYT, m, k);
@@ -1628,7 +1740,7 @@ struct IpmWave {
             for (int j = 0; j < 2; ++j) F(L.U, j, k) = push_interior(F(L.U, j, k), P.u_lb[j], P.u_ub[j]);
         if (lane == 0 && dtf()) SCL(SC_D) = push_interior(SCL(SC_D), P.dt_lb, P.dt_ub);
         sync();
-        if (L.M > 0) { associate_obstacles(); sync(); }
+        if (L.M > 0) { rows_dropped = associate_obstacles(); sync(); }
         if (via()) { associate_via_points(); sync(); }
         mu = warm_guess ? P.mu_init_warm : P.mu_init; rho = T(0); delta_last = T(0); fail0 = false;
         const T d = SCL(SC_D);

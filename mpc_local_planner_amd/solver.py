@@ -170,6 +170,12 @@ class BatchSolver:
         self._check(self._lib.mpc_last_candidates(self._h, int(B), C.c_void_p(win.ctypes.data), C.c_void_p(tot.ctypes.data)))
         return win, tot
 
+    def last_rows_dropped(self, B: int):
+        """per instance: clearance rows that did not fit into max_obstacle_rows in the most recent solve (mpc_last_rows_dropped)"""
+        out = np.zeros(B, np.int32)
+        self._check(self._lib.mpc_last_rows_dropped(self._h, int(B), C.c_void_p(out.ctypes.data)))
+        return out
+
     def synchronize(self):
         self._check(self._lib.mpc_synchronize(self._h))
 

@@ -106,15 +106,27 @@ def obst_from_nlp_config(cfg, max_obstacles: int, max_vertices: int, max_rows: i
     return o
 
 
-def solve_batch(ocfg: OracleConfig, x0, xf, u_prev=None, dt_prev=None, init=None, nthreads=0, obstacles=None, obst: "OracleObst" = None, via=None):
-    """obstacles = (n_obstacles (B,), n_vertices (B,O), vertices (B,O,V,2)[, radius (B,O)]) together with obst (OracleObst).
+def footprint_row(obst: "OracleObst", pose, vertices, radius: float = 0.0):
+    """TEST HOOK (oracle_footprint_row): distance footprint(pose) <-> one obstacle and the analytic derivatives of the row g = d_min - dist as the
+    solver uses them.  Returns (dist, a[3] = grad g, hk, h3[3] = hess g [x theta, y theta, theta theta]); hess g (x, y) = -hk (I - a_xy a_xy')."""
+    lib = _load()
+    pose = np.ascontiguousarray(pose, float)
+    v = np.zeros((max(obst.max_vertices, 1), 2)); vv = np.asarray(vertices, float).reshape(-1, 2); v[: len(vv)] = vv
+    out = np.zeros(8)
+    lib.oracle_footprint_row(C.byref(obst), pose.ctypes.data_as(C.c_void_p), C.c_int(len(vv)), v.ctypes.data_as(C.c_void_p), C.c_double(radius), out.ctypes.data_as(C.c_void_p))
+    return out[0], out[1:4].copy(), out[4], out[5:8].copy()
+
+
+def solve_batch(ocfg: OracleConfig, x0, xf, u_prev=None, dt_prev=None, init=None, nthreads=0, obstacles=None, obst: "OracleObst" = None, via=None, rows_dropped=None):
+    """rows_dropped: optional int32 array (B,) that receives the number of clearance rows that did not fit into obst.max_rows.
+    obstacles = (n_obstacles (B,), n_vertices (B,O), vertices (B,O,V,2)[, radius (B,O)]) together with obst (OracleObst).
     via = (n_via (B,), via (B,VP,3)) for a config made from objective minimum_time_via_points."""
     lib = _load()
     if via is not None:
         nvia = np.ascontiguousarray(via[0], np.int32); vps = np.ascontiguousarray(via[1], float)
         lib.oracle_set_via_points(nvia.ctypes.data_as(C.c_void_p), vps.ctypes.data_as(C.c_void_p), C.c_int(vps.shape[1]))
         try:
-            return solve_batch(ocfg, x0, xf, u_prev, dt_prev, init, nthreads, obstacles, obst)
+            return solve_batch(ocfg, x0, xf, u_prev, dt_prev, init, nthreads, obstacles, obst, rows_dropped=rows_dropped)
         finally:
             lib.oracle_set_via_points(None, None, C.c_int(0))
     x0 = np.ascontiguousarray(x0, float)
@@ -135,10 +147,12 @@ def solve_batch(ocfg: OracleConfig, x0, xf, u_prev=None, dt_prev=None, init=None
         rr = np.ascontiguousarray(obstacles[3], float) if len(obstacles) > 3 and obstacles[3] is not None else None
         vel = np.ascontiguousarray(obstacles[4], float) if len(obstacles) > 4 and obstacles[4] is not None else None
         lib.oracle_set_obstacle_velocities(p(vel))
+        lib.oracle_set_rows_dropped_out(p(rows_dropped) if rows_dropped is not None else None)
         assert nv.shape == (B, obst.max_obstacles) and vv.shape == (B, obst.max_obstacles, obst.max_vertices, 2)
         lib.oracle_solve_batch_obst(C.byref(ocfg), C.c_int(B), p(x0), p(xf), p(up), p(dp), p(xi), p(ui), p(di), C.byref(obst), p(no), p(nv), p(vv),
                                     p(rr), p(xo), p(uo), p(do), p(st), p(it), C.c_int(nthreads))
         lib.oracle_set_obstacle_velocities(None)
+        lib.oracle_set_rows_dropped_out(None)
         return xo, uo, do, st, it
     lib.oracle_solve_batch(C.byref(ocfg), C.c_int(B), p(x0), p(xf), p(up), p(dp), p(xi), p(ui), p(di), p(xo), p(uo), p(do), p(st), p(it),
                            C.c_int(nthreads))

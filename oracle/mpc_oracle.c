@@ -211,12 +211,14 @@ typedef struct {
     int* oi;                  /* n*M obstacle index or -1 */
     double *os, *oy, *ost, *ods, *ody;   /* n*M slack, multiplier, trial slack, steps */
     double *og, *oax, *oay, *ohk;        /* n*M cached value, gradient (= -unit normal), curvature 1/|p-q| (0 on an edge interior) */
+    double *oad, *ohd;                   /* dt parts (n*M, 4*n*M) of a dynamic obstacle's row when the footprint turns with the pose */
     double *oat, *oh3;                   /* third-variable parts of the rows: gradient entry n*M and Hessian entries 3*n*M -- heading for the
                                           * footprints that turn with the pose, dt for dynamic obstacles */
     const double* vel;                   /* obstacle velocities of this instance [O][2] or NULL */
     double ts, ty, tst, tds, tdy, tg, ta[3];   /* terminal-ball row: slack, multiplier, trial slack, steps, cached value and gradient */
     /* via-points of this instance (set per batch with oracle_set_via_points) and the grid point each one is attached to */
     int nvia; const double* via; int vidx[64];
+    int rows_dropped;          /* clearance rows that did not fit into max_rows (obst_associate) */
 } work_t;
 
 static int iu(int k, int j) { return 8 * k + j; }
@@ -340,29 +342,48 @@ static void obst_centroids(work_t* w) {
 static int fp_turns(const work_t* w);
 static int is_dynamic(const work_t* w, int j);
 static double turn_dist(const work_t* w, double px, double py, double th, int j, double a[3], double* hk, double h3[3]);
-/* StageInequalitySE2::update (stage_inequality_se2.cpp:50-162) on the current vertex values; forced rows first, then nearest left / right */
-static void obst_associate(work_t* w) {
+/* StageInequalitySE2::update (stage_inequality_se2.cpp:50-162) on the current vertex values.  Capacity rule of the batched solvers (M rows per
+ * grid point): dynamic obstacles, forced ones in container order -- the M closest of them when they do not all fit (ties: lower index) --,
+ * then nearest left / right.  Returns the number of rows that did not fit, summed over k = 1..n-2. */
+static int obst_associate(work_t* w) {
     const int n = w->n, M = obst_M(w);
     const oracle_obst* o = w->ob;
+    int dropped = 0;
+    double fd[64];
     for (int k = 0; k < n; ++k) {
         for (int m = 0; m < M; ++m) w->oi[k * M + m] = -1;
         if (k < 1) continue;
         const double px = w->X[3 * k], py = w->X[3 * k + 1], th = w->X[3 * k + 2], co = cos(th), si = sin(th);
-        double lmin = 1e30, rmin = 1e30; int lidx = -1, ridx = -1, cnt = 0;
-        for (int j = 0; j < w->n_obst; ++j) if (w->n_vert[j] > 0 && is_dynamic(w, j) && cnt < M) w->oi[k * M + cnt++] = j;   /* always kept (:99-106) */
+        double lmin = 1e30, rmin = 1e30; int lidx = -1, ridx = -1, cnt = 0, wanted = 0;
+        for (int j = 0; j < w->n_obst; ++j) if (w->n_vert[j] > 0 && is_dynamic(w, j)) { ++wanted; if (cnt < M) w->oi[k * M + cnt++] = j; }   /* always kept (:99-106) */
+        const int first_forced = cnt;
         for (int j = 0; j < w->n_obst; ++j) {
             if (w->n_vert[j] <= 0 || is_dynamic(w, j)) continue;
             double dist, nx, ny, hk;
             if (fp_turns(w)) { double a3[3], h3[3]; dist = turn_dist(w, px, py, th, j, a3, &hk, h3); }
             else { obst_eval(w, px, py, j, &dist, &nx, &ny, &hk); dist -= o->footprint_radius; }
-            if (dist < o->force_inclusion_dist) { if (cnt < M) w->oi[k * M + cnt++] = j; continue; }
+            if (dist < o->force_inclusion_dist) {
+                ++wanted;
+                if (cnt < M) { fd[cnt] = dist; w->oi[k * M + cnt++] = j; }
+                else if (first_forced < M) {
+                    int far = first_forced;
+                    for (int m = first_forced + 1; m < M; ++m) if (fd[m] >= fd[far]) far = m;
+                    if (dist < fd[far]) {
+                        for (int m = far; m + 1 < M; ++m) { w->oi[k * M + m] = w->oi[k * M + m + 1]; fd[m] = fd[m + 1]; }
+                        w->oi[k * M + M - 1] = j; fd[M - 1] = dist;
+                    }
+                }
+                continue;
+            }
             if (dist > o->cutoff_dist) continue;
             if (co * w->cent[2 * j + 1] - w->cent[2 * j] * si > 0) { if (dist < lmin) { lmin = dist; lidx = j; } }   /* centroid as an ABSOLUTE vector (:121) */
             else { if (dist < rmin) { rmin = dist; ridx = j; } }
         }
-        if (lidx >= 0 && cnt < M) w->oi[k * M + cnt++] = lidx;
-        if (ridx >= 0 && cnt < M) w->oi[k * M + cnt++] = ridx;
+        if (lidx >= 0) { ++wanted; if (cnt < M) w->oi[k * M + cnt++] = lidx; }
+        if (ridx >= 0) { ++wanted; if (cnt < M) w->oi[k * M + cnt++] = ridx; }
+        if (k < n - 1) dropped += wanted - cnt;
     }
+    return dropped;
 }
 /* value / gradient / curvature of row (k,m) at position (px,py); 0 if the slot is empty */
 static int obst_row(const work_t* w, int k, int m, double px, double py, double* g, double* ax, double* ay, double* hk) {
@@ -376,13 +397,12 @@ static int obst_row(const work_t* w, int k, int m, double px, double py, double*
 }
 static int fp_turns(const work_t* w) { return w->ob && w->ob->footprint_kind >= 2; }
 static int is_dynamic(const work_t* w, int j) { return j >= 0 && w->ob && w->ob->dynamic && w->vel && (w->vel[2 * j] != 0.0 || w->vel[2 * j + 1] != 0.0); }
-/* teb Line / PolygonRobotFootprint::calculateDistance for a point / circular obstacle: the obstacle centre in the robot frame,
- * q = R(-theta)(p_o - p), against the fixed segment / closed edge loop (first closest edge, no inside test).  Returns the distance; a = gradient
+/* teb Line / PolygonRobotFootprint::calculateDistance for ONE world point (an obstacle centre or vertex): the point in the robot frame,
+ * q = R(-theta)(v - p), against the fixed segment / closed edge loop (first closest edge, no inside test).  Returns the distance; a = gradient
  * of the row g = d_min - dist wrt (x, y, theta), hk as in obst_eval, h3 = hess g [x theta, y theta, theta theta]. */
-static double line_eval(const work_t* w, double px, double py, double th, int j, double a[3], double* hk, double h3[3]) {
+static double fp_point_eval(const work_t* w, double px, double py, double th, double vwx, double vwy, double a[3], double* hk, double h3[3]) {
     const oracle_obst* o = w->ob;
-    const double* v = w->verts + (size_t)2 * o->max_vertices * j;
-    const double s = sin(th), c = cos(th), vx = v[0] - px, vy = v[1] - py;
+    const double s = sin(th), c = cos(th), vx = vwx - px, vy = vwy - py;
     const double qx = c * vx + s * vy, qy = c * vy - s * vx;
     const int poly = o->footprint_kind == 4, nv = poly ? o->footprint_nv : 2, ne = nv <= 2 ? 1 : nv;
     double dx = 0, dy = 0, t = 0, best = 1.7976931348623157e308;
@@ -406,7 +426,61 @@ static double line_eval(const work_t* w, double px, double py, double th, int j,
     h3[0] = -((s * hwy - c * hwx) + (nx * s + ny * c));
     h3[1] = -((-s * hwx - c * hwy) + (ny * s - nx * c));
     h3[2] = -((qy * hwx - qx * hwy) - (nx * qx + ny * qy));
-    return D - (w->radius ? w->radius[j] : 0.0);
+    return D;
+}
+static void fp_vertex(const oracle_obst* o, int i, double* ax, double* ay) {
+    if (o->footprint_kind == 4) { *ax = o->footprint_poly[2 * i]; *ay = o->footprint_poly[2 * i + 1]; }
+    else { *ax = o->footprint_params[2 * i]; *ay = o->footprint_params[2 * i + 1]; }
+}
+static int seg_intersect(double ax, double ay, double bx, double by, double cx, double cy, double dx, double dy) {
+    const double o1 = (bx - ax) * (cy - ay) - (by - ay) * (cx - ax), o2 = (bx - ax) * (dy - ay) - (by - ay) * (dx - ax);
+    const double o3 = (dx - cx) * (ay - cy) - (dy - cy) * (ax - cx), o4 = (dx - cx) * (by - cy) - (dy - cy) * (bx - cx);
+    return o1 * o2 < 0 && o3 * o4 < 0;
+}
+/* line / polygon footprint against obstacle j of any kind (teb Obstacle::getMinimumDistance(segment | polygon): distance_segment_to_segment_2d,
+ * distance_segment_to_polygon_2d, distance_polygon_to_polygon_2d): minimum over the point-to-segment distances between the two edge loops --
+ * every obstacle vertex against the footprint edges (fp_point_eval), every footprint vertex c_i(theta) = p + R(theta) a_i against the obstacle
+ * edges (obst_eval, chain rule through theta) -- and 0 where two edges cross (no inside test). */
+static double line_eval(const work_t* w, double px, double py, double th, int j, double a[3], double* hk, double h3[3]) {
+    const oracle_obst* o = w->ob;
+    const double* v = w->verts + (size_t)2 * o->max_vertices * j;
+    int nvo = w->n_vert[j]; if (nvo > o->max_vertices) nvo = o->max_vertices;
+    if (nvo <= 1) return fp_point_eval(w, px, py, th, v[0], v[1], a, hk, h3) - (w->radius ? w->radius[j] : 0.0);
+    const int F = o->footprint_kind == 4 ? o->footprint_nv : 2;
+    const double s = sin(th), c = cos(th);
+    double best = 1.7976931348623157e308;
+    for (int m = 0; m < nvo; ++m) {
+        double am[3], hm, h3m[3];
+        const double D = fp_point_eval(w, px, py, th, v[2 * m], v[2 * m + 1], am, &hm, h3m);
+        if (D < best) { best = D; for (int i = 0; i < 3; ++i) { a[i] = am[i]; h3[i] = h3m[i]; } *hk = hm; }
+    }
+    for (int i = 0; i < F; ++i) {
+        double ax_, ay_, D, nx, ny, ho;
+        fp_vertex(o, i, &ax_, &ay_);
+        const double rx = c * ax_ - s * ay_, ry = s * ax_ + c * ay_;
+        obst_eval(w, px + rx, py + ry, j, &D, &nx, &ny, &ho);
+        if (D < best) {
+            best = D;
+            const double wx = -ry, wy = rx, nw = nx * wx + ny * wy;
+            a[0] = -nx; a[1] = -ny; a[2] = -nw; *hk = ho;
+            const double hvx = ho * (wx - nx * nw), hvy = ho * (wy - ny * nw);
+            h3[0] = -hvx; h3[1] = -hvy; h3[2] = -((wx * hvx + wy * hvy) - (nx * rx + ny * ry));
+        }
+    }
+    const int nef = F <= 2 ? (F == 2 ? 1 : 0) : F, neo = nvo == 2 ? 1 : nvo;
+    for (int e = 0; e < nef; ++e) {
+        double a0x, a0y, a1x, a1y;
+        fp_vertex(o, e, &a0x, &a0y); fp_vertex(o, (e + 1) % F, &a1x, &a1y);
+        const double Ax = px + c * a0x - s * a0y, Ay = py + s * a0x + c * a0y, Bx = px + c * a1x - s * a1y, By = py + s * a1x + c * a1y;
+        for (int q = 0; q < neo; ++q) {
+            const int q2 = (q + 1) % nvo;
+            if (seg_intersect(Ax, Ay, Bx, By, v[2 * q], v[2 * q + 1], v[2 * q2], v[2 * q2 + 1])) {
+                a[0] = a[1] = a[2] = 0; *hk = 0; h3[0] = h3[1] = h3[2] = 0;
+                return 0.0;
+            }
+        }
+    }
+    return best;
 }
 /* teb TwoCirclesRobotFootprint::calculateDistance: the closer of the two circles (front wins a tie), chain rule through the heading */
 static double two_eval(const work_t* w, double px, double py, double th, int j, double a[3], double* hk, double h3[3]) {
@@ -430,12 +504,26 @@ static double turn_dist(const work_t* w, double px, double py, double th, int j,
 }
 /* row (k,m) with its third-variable parts: heading (footprints that turn with the pose) or dt (dynamic obstacle: the obstacle moved by
  * k D v = the static row at p - k D v, stage_inequality_se2.cpp:177-189) */
-static int obst_row3(const work_t* w, int k, int m, double px, double py, double th, double D, double* g, double a[3], double* hk, double h3[3]) {
+static int obst_row3x(const work_t* w, int k, int m, double px, double py, double th, double D, double* g, double a[3], double* hk, double h3[3], double* ad, double hd[4]) {
     const int j = w->oi[k * obst_M(w) + m];
     if (j < 0) return 0;
     a[2] = 0; h3[0] = h3[1] = h3[2] = 0;
+    *ad = 0; hd[0] = hd[1] = hd[2] = hd[3] = 0;
     if (is_dynamic(w, j)) {
         const double kvx = k * w->vel[2 * j], kvy = k * w->vel[2 * j + 1];
+        if (fp_turns(w)) {
+            /* a dynamic obstacle seen by a footprint that turns with the pose: a[2] / h3 are the heading parts, ad / hd = (g_dt, hess g [x dt,
+             * y dt, dt dt, theta dt]) the dt parts of G(p - k dt v, theta) */
+            *g = w->ob->min_obstacle_dist - turn_dist(w, px - D * kvx, py - D * kvy, th, j, a, hk, h3);
+            if (w->c->dt_free) {
+                const double ak = a[0] * kvx + a[1] * kvy;
+                *ad = -ak;
+                hd[0] = *hk * (kvx - a[0] * ak); hd[1] = *hk * (kvy - a[1] * ak);
+                hd[2] = -*hk * (kvx * kvx + kvy * kvy - ak * ak);
+                hd[3] = -(h3[0] * kvx + h3[1] * kvy);
+            }
+            return 1;
+        }
         double dist, nx, ny;
         obst_eval(w, px - D * kvx, py - D * kvy, j, &dist, &nx, &ny, hk);
         *g = w->ob->min_obstacle_dist - (dist - w->ob->footprint_radius);
@@ -449,6 +537,10 @@ static int obst_row3(const work_t* w, int k, int m, double px, double py, double
     if (fp_turns(w)) { *g = w->ob->min_obstacle_dist - turn_dist(w, px, py, th, j, a, hk, h3); return 1; }
     return obst_row(w, k, m, px, py, g, &a[0], &a[1], hk);
 }
+static int obst_row3(const work_t* w, int k, int m, double px, double py, double th, double D, double* g, double a[3], double* hk, double h3[3]) {
+    double ad, hd[4];
+    return obst_row3x(w, k, m, px, py, th, D, g, a, hk, h3, &ad, hd);
+}
 /* sum |g + s| over the clearance rows at the point (X, D) with slacks sl */
 static double obst_theta(const work_t* w, const double* X, double D, const double* sl) {
     const int n = w->n, M = obst_M(w);
@@ -461,6 +553,8 @@ static double obst_theta(const work_t* w, const double* X, double D, const doubl
 }
 
 /* ---- via-points: MinTimeViaPointsCost::update (min_time_via_points_cost.cpp:39-117) + findClosestPose (...grid_base_se2.cpp:364-388) */
+static int32_t* g_dropped_out = NULL;     /* [B] rows that did not fit (next batch), or NULL */
+void oracle_set_rows_dropped_out(int32_t* out) { g_dropped_out = out; }
 static const double* g_ovel = NULL;      /* obstacle velocities of the next batch [B][O][2] (dynamic obstacles) */
 void oracle_set_obstacle_velocities(const double* vel) { g_ovel = vel; }
 static const int32_t* g_nvia = NULL; static const double* g_via = NULL; static int g_vp_cap = 0;
@@ -575,19 +669,21 @@ static void kkt_terms(const work_t* w, const double* cc, err_t* e) {
         if (c->via && k >= 1) { double vv, vg[3]; via_terms(w, k, w->X[3 * k], w->X[3 * k + 1], w->X[3 * k + 2], &vv, vg); for (int i = 0; i < 3; ++i) gx[i] += vg[i]; }
         double osx = 0, osy = 0, ost = 0;
         if (k >= 1) for (int m = 0, M = obst_M(w); m < M; ++m) {
-            double g, a3[3], hk, h3[3];
+            double g, a3[3], hk, h3[3], ad, hd[4];
             work_t* wm = (work_t*)w;           /* the caches are scratch */
-            if (!obst_row3(w, k, m, w->X[3 * k], w->X[3 * k + 1], w->X[3 * k + 2], w->D, &g, a3, &hk, h3)) continue;
+            if (!obst_row3x(w, k, m, w->X[3 * k], w->X[3 * k + 1], w->X[3 * k + 2], w->D, &g, a3, &hk, h3, &ad, hd)) continue;
             const double ax = a3[0], ay = a3[1];
             wm->og[k * M + m] = g; wm->oax[k * M + m] = ax; wm->oay[k * M + m] = ay; wm->ohk[k * M + m] = hk;
             wm->oat[k * M + m] = a3[2]; for (int i = 0; i < 3; ++i) wm->oh3[3 * (k * M + m) + i] = h3[i];
+            wm->oad[k * M + m] = ad; for (int i = 0; i < 4; ++i) wm->ohd[4 * (k * M + m) + i] = hd[i];
             const double sl = w->os[k * M + m], y = w->oy[k * M + m], res = g + sl;
             if (fabs(res) > e->rp) e->rp = fabs(res);
             e->theta += fabs(res);
             if (sl * y < e->cmin) e->cmin = sl * y; if (sl * y > e->cmax) e->cmax = sl * y;
             e->sb += y; e->nb += 1;
             osx += y * ax; osy += y * ay;
-            if (is_dynamic(w, w->oi[k * M + m])) rdd += y * a3[2]; else ost += y * a3[2];
+            if (is_dynamic(w, w->oi[k * M + m]) && fp_turns(w)) { rdd += y * ad; ost += y * a3[2]; }
+            else if (is_dynamic(w, w->oi[k * M + m])) rdd += y * a3[2]; else ost += y * a3[2];
         }
         if (k >= 1) {
             const double* lp = &w->lam[3 * (k - 1)];
@@ -762,7 +858,18 @@ static void assemble(work_t* w, const double* cc, double delta, double dc, doubl
             band_add(w, ixn(k, 1), ixn(k, 1), sig * ay * ay - y * hk * (1.0 - ay * ay));
             w->rhs[ixn(k, 0)] -= ax * ybar; w->rhs[ixn(k, 1)] -= ay * ybar;
             const double at = w->oat[k * M + m], *h3 = &w->oh3[3 * (k * M + m)];
-            if (is_dynamic(w, w->oi[k * M + m])) {          /* third variable = dt: border column, dt-dt entry, dt gradient */
+            if (is_dynamic(w, w->oi[k * M + m]) && fp_turns(w)) {     /* heading parts in the band + dt parts in the border */
+                const double ad = w->oad[k * M + m], *hd = &w->ohd[4 * (k * M + m)];
+                sym_add(w, ixn(k, 0), ixn(k, 2), sig * ax * at + y * h3[0]);
+                sym_add(w, ixn(k, 1), ixn(k, 2), sig * ay * at + y * h3[1]);
+                band_add(w, ixn(k, 2), ixn(k, 2), sig * at * at + y * h3[2]);
+                w->rhs[ixn(k, 2)] -= at * ybar;
+                w->bcol[ixn(k, 0)] += sig * ax * ad + y * hd[0];
+                w->bcol[ixn(k, 1)] += sig * ay * ad + y * hd[1];
+                w->bcol[ixn(k, 2)] += sig * at * ad + y * hd[3];
+                hdd += sig * ad * ad + y * hd[2];
+                gd += ad * ybar;
+            } else if (is_dynamic(w, w->oi[k * M + m])) {          /* third variable = dt: border column, dt-dt entry, dt gradient */
                 w->bcol[ixn(k, 0)] += sig * ax * at + y * h3[0];
                 w->bcol[ixn(k, 1)] += sig * ay * at + y * h3[1];
                 hdd += sig * at * at + y * h3[2];
@@ -904,7 +1011,7 @@ static int solve_one(work_t* w, int warm) {
     if (obst_M(w) > 0) {
         const int M = obst_M(w);
         obst_centroids(w);
-        obst_associate(w);
+        w->rows_dropped = obst_associate(w);
         for (int k = 0; k < n; ++k) for (int m = 0; m < M; ++m) {
             double g, a3[3], hk, h3[3];
             w->os[k * M + m] = 1.0; w->oy[k * M + m] = 0.0; w->ods[k * M + m] = 0.0; w->ody[k * M + m] = 0.0;
@@ -1026,8 +1133,10 @@ static int solve_one(work_t* w, int warm) {
                 }
                 for (int k = 1, M = obst_M(w); k < n - 1; ++k) for (int m = 0; m < M; ++m) {
                     if (w->oi[k * M + m] < 0) continue;
+                    const int dyn_ = is_dynamic(w, w->oi[k * M + m]);
                     const double jdz = w->oax[k * M + m] * w->dz_x[3 * k] + w->oay[k * M + m] * w->dz_x[3 * k + 1] +
-                                       w->oat[k * M + m] * (is_dynamic(w, w->oi[k * M + m]) ? ddt : w->dz_x[3 * k + 2]);
+                                       ((dyn_ && fp_turns(w)) ? w->oat[k * M + m] * w->dz_x[3 * k + 2] + w->oad[k * M + m] * ddt
+                                                              : w->oat[k * M + m] * (dyn_ ? ddt : w->dz_x[3 * k + 2]));
                     const double sl = w->os[k * M + m], y = w->oy[k * M + m], res = w->og[k * M + m] + sl;
                     const double sig = y / sl, ybar = mu / sl + sig * res;
                     w->ods[k * M + m] = -res - jdz;
@@ -1138,6 +1247,19 @@ static int solve_one(work_t* w, int warm) {
     return status * 100000 + it;
 }
 
+/* TEST HOOK: g = d_min - dist(footprint(pose), obstacle) with its analytic derivatives, as the solver uses them.
+ * out = [dist, a0, a1, a2, hk, h3[0], h3[1], h3[2]] */
+void oracle_footprint_row(const oracle_obst* ob, const double pose[3], int nv, const double* verts, double radius, double out[8]) {
+    work_t w;
+    memset(&w, 0, sizeof(w));
+    int32_t nvv = nv;
+    w.ob = ob; w.n_obst = 1; w.n_vert = &nvv; w.verts = verts; w.radius = &radius;
+    double a[3] = {0, 0, 0}, hk = 0, h3[3] = {0, 0, 0}, d;
+    if (ob->footprint_kind >= 2) d = turn_dist(&w, pose[0], pose[1], pose[2], 0, a, &hk, h3);
+    else { double nx, ny; obst_eval(&w, pose[0], pose[1], 0, &d, &nx, &ny, &hk); d -= ob->footprint_radius; a[0] = -nx; a[1] = -ny; }
+    out[0] = d; out[1] = a[0]; out[2] = a[1]; out[3] = a[2]; out[4] = hk; out[5] = h3[0]; out[6] = h3[1]; out[7] = h3[2];
+}
+
 static work_t* work_new(const oracle_config* c) {
     work_t* w = (work_t*)calloc(1, sizeof(work_t));
     int n = c->n;
@@ -1162,11 +1284,12 @@ static void work_obst(work_t* w, const oracle_obst* ob) {       /* clearance-row
     w->og = (double*)calloc((size_t)n * M, 8); w->oax = (double*)calloc((size_t)n * M, 8); w->oay = (double*)calloc((size_t)n * M, 8);
     w->ohk = (double*)calloc((size_t)n * M, 8);
     w->oat = (double*)calloc((size_t)n * M, 8); w->oh3 = (double*)calloc((size_t)3 * n * M, 8);
+    w->oad = (double*)calloc((size_t)n * M, 8); w->ohd = (double*)calloc((size_t)4 * n * M, 8);
 }
 static void work_free(work_t* w) {
     free(w->X); free(w->U); free(w->Xt); free(w->Ut); free(w->lam); free(w->lamn); free(w->s); free(w->y); free(w->ron);
     free(w->pl); free(w->pu); free(w->AB); free(w->ipiv); free(w->rhs); free(w->bcol); free(w->dz_u); free(w->dz_x);
-    free(w->cent); free(w->oi); free(w->os); free(w->oy); free(w->ost); free(w->ods); free(w->ody); free(w->og); free(w->oax); free(w->oay); free(w->ohk); free(w->oat); free(w->oh3);
+    free(w->cent); free(w->oi); free(w->os); free(w->oy); free(w->ost); free(w->ods); free(w->ody); free(w->og); free(w->oax); free(w->oay); free(w->ohk); free(w->oat); free(w->oh3); free(w->oad); free(w->ohd);
     free(w);
 }
 
@@ -1206,7 +1329,9 @@ int oracle_solve_batch_obst(const oracle_config* c, int B, const double* x0, con
                 for (int k = 0; k < n - 1; ++k) for (int j = 0; j < 2; ++j) w->U[2 * k + j] = u_init[(size_t)b * n * 2 + 2 * k + j];
                 w->D = dt_init[b];
             }
+            w->rows_dropped = 0;
             int r = solve_one(w, warm);
+            if (g_dropped_out) g_dropped_out[b] = w->rows_dropped;
             memcpy(x_out + (size_t)b * n * 3, w->X, sizeof(double) * 3 * n);
             for (int k = 0; k < n; ++k) { int ks = k < n - 1 ? k : n - 2; for (int j = 0; j < 2; ++j) u_out[(size_t)b * n * 2 + 2 * k + j] = w->U[2 * ks + j]; }
             dt_out[b] = w->D;

@@ -571,24 +571,30 @@ def time_series_output(traj: Trajectory):
 # obstacle association            src/optimal_control/stage_inequality_se2.cpp:50-162
 # --------------------------------------------------------------------------
 
-def associate_obstacles(cfg: OcpConfig, traj: Trajectory, obstacles: List[Obstacle], max_rows: Optional[int] = None):
+def associate_obstacles(cfg: OcpConfig, traj: Trajectory, obstacles: List[Obstacle], max_rows: Optional[int] = None, return_dropped: bool = False):
     """Returns (relevant[k] -> list of obstacle indices, relevant_dyn[k]) for k=0..n-1
-    (k=0 stays empty; k=n-1 is computed but never used by createEdges)."""
+    (k=0 stays empty; k=n-1 is computed but never used by createEdges).
+    max_rows = None is the reference (every obstacle closer than force_inclusion_dist + nearest left + nearest right, no cap).
+    max_rows = M restates the capacity rule of the batched solvers (mpc_wave.hpp::associate_obstacles): dynamic obstacles first, then the
+    forced ones in container order -- the M closest of them when they do not all fit (ties: lower index) --, then left, right;
+    return_dropped adds the number of rows that did not fit, summed over k = 1..n-2."""
     n = traj.x.shape[0]
     rel = [[] for _ in range(n)]
     rel_dyn = [[] for _ in range(n)]
+    dropped = 0
     for k in range(1, n):
         pose = traj.x[k]
         orient = np.array([math.cos(pose[2]), math.sin(pose[2])])
         lmin = rmin = float("inf")
         lidx = ridx = None
+        forced = []
         for j, ob in enumerate(obstacles):
             if cfg.enable_dynamic_obstacles and ob.velocity is not None and np.any(np.asarray(ob.velocity) != 0):
                 rel_dyn[k].append(j)
                 continue
             d = footprint_distance(cfg.footprint_kind, cfg.footprint_params, pose, ob)
             if d < cfg.force_inclusion_dist:
-                rel[k].append(j)
+                forced.append((d, j))
                 continue
             if d > cfg.cutoff_dist:
                 continue
@@ -598,13 +604,19 @@ def associate_obstacles(cfg: OcpConfig, traj: Trajectory, obstacles: List[Obstac
             else:
                 if d < rmin:
                     rmin, ridx = d, j
-        if lidx is not None:
-            rel[k].append(lidx)
-        if ridx is not None:
-            rel[k].append(ridx)
+        wanted = len(rel_dyn[k]) + len(forced) + (lidx is not None) + (ridx is not None)
         if max_rows is not None:
-            rel[k] = rel[k][:max_rows]      # capacity of the batched solver (forced ones first, then left, right)
-    return rel, rel_dyn
+            rel_dyn[k] = rel_dyn[k][:max_rows]
+            room = max_rows - len(rel_dyn[k])
+            if len(forced) > room:
+                forced = sorted(sorted(forced)[:room], key=lambda e: e[1])      # the closest ones, back in container order
+        rel[k] = [j for _, j in forced]
+        for idx in (lidx, ridx):
+            if idx is not None and (max_rows is None or len(rel_dyn[k]) + len(rel[k]) < max_rows):
+                rel[k].append(idx)
+        if 1 <= k < n - 1:
+            dropped += wanted - len(rel_dyn[k]) - len(rel[k])
+    return (rel, rel_dyn, dropped) if return_dropped else (rel, rel_dyn)
 
 
 # --------------------------------------------------------------------------

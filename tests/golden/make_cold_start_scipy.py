@@ -1,0 +1,81 @@
+#!/usr/bin/env python
+"""Generates tests/golden/cold_start_scipy_config{2,3}.npz: an INDEPENDENT solver (scipy SLSQP, an active-set SQP with no code in common
+with the interior-point implementations of this repository) on the REFERENCE-FORM NLP (oracle/se2_nlp.py::ReferenceNlp), started from the
+reference's cold start -- not from anybody's answer (level 2).
+
+  config 2   car-like minimum time, n = 50, the first 32 instances of the SURVEY 8d distribution
+  config 3   unicycle quadratic form, n = 80, 16 polygon obstacles, the first 32 instances of workloads.unicycle_obstacle_inputs
+             (association frozen on the cold start, max 4 rows per grid point, as the batched solvers do)
+
+Start point: the 2-pose-plan cold start (src/controller.cpp:807-857 + full_discretization_grid_base_se2.cpp:192-239) with the controls
+seeded from the state guess exactly as the interior-point solvers do (oracle/ipm_dense.py::controls_from_states; with u = 0 the car-like
+model has no steering authority and SLSQP's first QP is singular in the steering direction).
+
+Stored per instance: SLSQP's x, u, dt, objective, success flag, iterations and its max constraint violation.  tests/test_oracle_solver.py
+compares the C oracle with it on the CPU, tests/test_gpu_parity.py the device.  Runtime: ~2 min (config 2) + ~25 min (config 3) on 8 cores.
+usage: python tests/golden/make_cold_start_scipy.py [2|3] [count]"""
+import multiprocessing as mp
+import os
+import sys
+import time
+
+import numpy as np
+from scipy.optimize import minimize
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle import se2_nlp as R, ipm_dense as I, kkt_check as KC      # noqa: E402
+import mpc_local_planner_amd.workloads as W                           # noqa: E402  (numpy only)
+
+
+def solve_one(args):
+    cfgname, i, x0, xf, up, dtp, obst = args
+    t0 = time.time()
+    if cfgname == 2:
+        ocfg = R.config_carlike_min_time(50)
+        inp = R.CycleInputs(x0=x0, xf=xf, u_prev=up, dt_prev=float(dtp))
+        nlp = R.ReferenceNlp(ocfg, inp)
+    else:
+        ocfg = R.config_unicycle_quadratic(80)
+        obs = KC.obstacle_list(*obst)
+        inp = R.CycleInputs(x0=x0, xf=xf, u_prev=up, dt_prev=float(dtp), obstacles=obs)
+        rel, rel_dyn = R.associate_obstacles(ocfg, R.cold_start(ocfg, x0, xf), obs, 4)
+        nlp = R.ReferenceNlp(ocfg, inp, relevant=rel, relevant_dyn=rel_dyn)
+    start = I.controls_from_states(ocfg, R.cold_start(ocfg, x0, xf))
+    z0 = nlp.pack(start)
+    lb, ub = nlp.bounds()
+    z0 = np.minimum(np.maximum(z0, lb), ub)
+    bnds = [(None if l < -1e29 else l, None if u > 1e29 else u) for l, u in zip(lb, ub)]
+    if ocfg.dt_free:
+        bnds[-1] = (1e-3, ocfg.dt_ub)            # the reference rows divide by dt
+    cons = [{"type": "eq", "fun": nlp.equalities}, {"type": "ineq", "fun": lambda z: -nlp.inequalities(z)}]
+    r = minimize(nlp.objective, z0, method="SLSQP", bounds=bnds, constraints=cons, options=dict(maxiter=600, ftol=1e-12))
+    t = nlp.unpack(r.x)
+    viol = max(np.abs(nlp.equalities(r.x)).max(), nlp.inequalities(r.x).max(initial=0.0))
+    print(f"config {cfgname} instance {i}: success {r.success} it {r.nit} f {r.fun:.6f} viol {viol:.1e} ({time.time() - t0:.0f} s)", flush=True)
+    return t.x, t.u, t.dt, r.fun, bool(r.success), r.nit, viol
+
+
+def main():
+    which = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    K = int(sys.argv[2]) if len(sys.argv) > 2 else 32
+    if which == 2:
+        x0, xf, up, dtp = W.carlike_min_time_inputs(K)
+        jobs = [(2, i, x0[i], xf[i], up[i], dtp[i], None) for i in range(K)]
+    else:
+        x0, xf, up, dtp, (no, nv, vt) = W.unicycle_obstacle_inputs(K, n_obst=16, max_vertices=6)
+        jobs = [(3, i, x0[i], xf[i], up[i], dtp[i], (no[i], nv[i], vt[i], None, None)) for i in range(K)]
+    with mp.Pool(min(K, os.cpu_count() or 2)) as pool:
+        out = pool.map(solve_one, jobs)
+    n = 50 if which == 2 else 80
+    u = np.zeros((K, n, 2))
+    for i, o in enumerate(out):
+        u[i, :n - 1] = o[1]; u[i, n - 1] = o[1][-1]
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"cold_start_scipy_config{which}.npz"),
+                        x=np.stack([o[0] for o in out]), u=u, dt=np.array([o[2] for o in out]), objective=np.array([o[3] for o in out]),
+                        success=np.array([o[4] for o in out]), nit=np.array([o[5] for o in out]), violation=np.array([o[6] for o in out]),
+                        count=K)
+
+
+if __name__ == "__main__":
+    main()

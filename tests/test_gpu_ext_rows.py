@@ -147,3 +147,104 @@ def test_host_pointer_entry_costs_little_more_than_the_kernel(m):
     print(f"[host entry] B={B}: wall {min(walls) * 1e3:.2f} ms, kernel {np.median(kern) * 1e3:.2f} ms, ratio {ratio:.3f}")
     assert ratio <= 1.15
     s.close()
+
+
+def polygon_obstacles(x0, xf, seed, n_obst=4, V=5, lo=0.45, hi=1.1, lines=False):
+    """convex polygons (or, with lines=True, alternating 2-vertex line obstacles and polygons) beside the straight start-goal line"""
+    rng = np.random.default_rng(seed)
+    B = x0.shape[0]
+    d = xf[:, :2] - x0[:, :2]
+    nrm = np.stack([-d[:, 1], d[:, 0]], -1) / np.linalg.norm(d, axis=-1, keepdims=True)
+    nv = np.zeros((B, n_obst), np.int32); vt = np.zeros((B, n_obst, V, 2))
+    for b in range(B):
+        for o in range(n_obst):
+            rad = rng.uniform(0.12, 0.3)
+            c = x0[b, :2] + rng.uniform(0.2, 0.8) * d[b] + rng.choice([-1.0, 1.0]) * rng.uniform(rad + lo, rad + hi) * nrm[b]
+            k = 2 if (lines and o % 2 == 0) else int(rng.integers(3, V + 1))
+            ang = np.sort(rng.uniform(0, 2 * np.pi, k)) if k > 2 else rng.uniform(0, np.pi) + np.array([0.0, np.pi])
+            nv[b, o] = k
+            vt[b, o, :k, 0] = c[0] + rad * np.cos(ang); vt[b, o, :k, 1] = c[1] + rad * np.sin(ang)
+    return np.full(B, n_obst, np.int32), nv, vt
+
+
+@pytest.mark.parametrize("name,lines", [("line", False), ("line", True), ("polygon", False)])
+def test_line_and_polygon_footprints_against_line_and_polygon_obstacles(m, c_oracle, name, lines):
+    """a21, the pairing VERDICT r1 found missing: the car-like example's line footprint (cfg/carlike/mpc_local_planner_params.yaml:19-23) and
+    the polygon footprint against costmap_converter-style polygon / line obstacles (src/mpc_local_planner_ros.cpp:501-541) --
+    teb distance_segment_to_polygon_2d / distance_polygon_to_polygon_2d -- car-like n = 50, against the C oracle + KKT accounting."""
+    from oracle import se2_nlp as R
+    B, n, O, V = (128 if name == "line" else 64), 50, 4, 5
+    kind, params, dmin = FOOTPRINTS[name]
+    x0, xf, up, dtp = m.workloads.carlike_min_time_inputs(B, seed=921, goal_range=(2.0, 5.0))
+    no, nv, vt = polygon_obstacles(x0, xf, 922, O, V, lines=lines)
+    ocfg = R.config_carlike_min_time(n)
+    ocfg.footprint_kind, ocfg.footprint_params, ocfg.min_obstacle_dist, ocfg.force_inclusion_dist, ocfg.cutoff_dist = kind, params, dmin, 0.5, 2.5
+    kw = dict(footprint_kind=kind, min_obstacle_dist=dmin, force_inclusion_dist=0.5, cutoff_dist=2.5, max_obstacles=O, max_vertices=V, max_obstacle_rows=4)
+    kw.update(dict(footprint_vertices=params) if kind == 4 else dict(footprint_params=params))
+    s = m.BatchSolver(m.config_carlike_min_time(n, **kw), max_batch=B)
+    r = s.solve(x0, xf, up, dtp, obstacles=(no, nv, vt))
+    ref = c_oracle.solve_batch(c_oracle.from_nlp_config(ocfg), x0, xf, up, dtp, obstacles=(no, nv, vt), obst=c_oracle.obst_from_nlp_config(ocfg, O, V, 4))
+    both = _summary(r, ref, B)
+    # the obstacles shape a good share of the solutions (otherwise this test would say nothing about the rows)
+    free = c_oracle.solve_batch(c_oracle.from_nlp_config(R.config_carlike_min_time(n)), x0, xf, up, dtp)
+    moved = both & (free[3] == 0) & (np.abs(ref[0] - free[0]).reshape(B, -1).max(1) > 1e-3)
+    assert moved.sum() >= 0.15 * B
+    account(f"{name} footprint vs {'line+polygon' if lines else 'polygon'} obstacles, B={B}", ocfg, (x0, xf, up, dtp), r, ref, obstacles=(no, nv, vt), max_rows=4)
+    s.close()
+
+
+@pytest.mark.parametrize("name", ["line", "two_circles"])
+def test_dynamic_obstacles_with_turning_footprints(m, c_oracle, name):
+    """a22 with a footprint that turns with the pose (stage_inequality_se2.cpp:177-189 through Line / TwoCirclesRobotFootprint): rows carry heading
+    AND dt parts (x-dt, y-dt, theta-dt, dt-dt)."""
+    from oracle import se2_nlp as R
+    B, n = 128, 50
+    kind, params, dmin = FOOTPRINTS[name]
+    x0, xf, up, dtp = m.workloads.carlike_min_time_inputs(B, seed=931, goal_range=(2.0, 5.0))
+    no, nv, vt = point_obstacles(x0, xf, 932, n_obst=3, lo=0.6, hi=1.1)
+    rad = np.zeros((B, 3)); vel = np.zeros((B, 3, 2))
+    d = xf[:, :2] - x0[:, :2]
+    nrm = np.stack([-d[:, 1], d[:, 0]], -1) / np.linalg.norm(d, axis=-1, keepdims=True)
+    vt[:, 0, 0] = x0[:, :2] + 0.5 * d + 1.2 * nrm; rad[:, 0] = 0.15; vel[:, 0] = -0.12 * nrm
+    ocfg = R.config_carlike_min_time(n)
+    ocfg.footprint_kind, ocfg.footprint_params = kind, params
+    ocfg.enable_dynamic_obstacles, ocfg.min_obstacle_dist, ocfg.force_inclusion_dist, ocfg.cutoff_dist = True, dmin, 0.5, 2.5
+    s = m.BatchSolver(m.config_carlike_min_time(n, footprint_kind=kind, footprint_params=params, enable_dynamic_obstacles=True, min_obstacle_dist=dmin,
+                                                force_inclusion_dist=0.5, cutoff_dist=2.5, max_obstacles=3, max_vertices=1, max_obstacle_rows=4), max_batch=B)
+    r = s.solve(x0, xf, up, dtp, obstacles=(no, nv, vt, rad, vel))
+    ref = c_oracle.solve_batch(c_oracle.from_nlp_config(ocfg), x0, xf, up, dtp, obstacles=(no, nv, vt, rad, vel), obst=c_oracle.obst_from_nlp_config(ocfg, 3, 1, 4))
+    both = _summary(r, ref, B)
+    still = c_oracle.solve_batch(c_oracle.from_nlp_config(ocfg), x0, xf, up, dtp, obstacles=(no, nv, vt, rad, 0 * vel), obst=c_oracle.obst_from_nlp_config(ocfg, 3, 1, 4))
+    assert (both & (still[3] == 0) & (np.abs(ref[0] - still[0]).reshape(B, -1).max(1) > 1e-4)).sum() >= 5      # the motion matters
+    account(f"dynamic obstacles, {name} footprint, B={B}", ocfg, (x0, xf, up, dtp), r, ref, obstacles=(no, nv, vt, rad, vel), max_rows=4)
+    s.close()
+
+
+def test_rows_that_do_not_fit_are_counted(m, c_oracle):
+    """More obstacles inside force_inclusion_dist than max_obstacle_rows (a dense costmap): the solver keeps the closest ones and reports,
+    per instance, how many rows did not fit -- the same count as the C oracle's restatement of the rule; with enough rows the count is 0."""
+    from oracle import se2_nlp as R
+    B, n, O = 64, 30, 24
+    x0, xf, up, dtp = m.workloads.unicycle_quadratic_inputs(B, seed=941, goal_range=(1.5, 2.5))
+    rng = np.random.default_rng(942)
+    d = xf[:, None, :2] - x0[:, None, :2]
+    nrm = np.stack([-d[..., 1], d[..., 0]], -1) / np.linalg.norm(d, axis=-1, keepdims=True)
+    pts = x0[:, None, :2] + rng.uniform(0.1, 0.9, (B, O, 1)) * d + rng.uniform(0.3, 0.55, (B, O, 1)) * rng.choice([-1.0, 1.0], (B, O, 1)) * nrm
+    no = np.full(B, O, np.int32); nv = np.ones((B, O), np.int32); vt = pts.reshape(B, O, 1, 2)
+    ocfg = R.config_unicycle_quadratic(n)
+    ocfg.min_obstacle_dist, ocfg.force_inclusion_dist, ocfg.cutoff_dist = 0.2, 0.5, 2.5
+    for M, expect_drop in ((4, True), (16, False)):
+        s = m.BatchSolver(m.config_unicycle_quadratic(n, max_obstacles=O, max_vertices=1, max_obstacle_rows=M), max_batch=B)
+        r = s.solve(x0, xf, up, dtp, obstacles=(no, nv, vt))
+        dev = s.last_rows_dropped(B)
+        ora = np.zeros(B, np.int32)
+        ref = c_oracle.solve_batch(c_oracle.from_nlp_config(ocfg), x0, xf, up, dtp, obstacles=(no, nv, vt), obst=c_oracle.obst_from_nlp_config(ocfg, O, 1, M), rows_dropped=ora)
+        np.testing.assert_array_equal(dev, ora)
+        assert (dev > 0).any() == expect_drop
+        both = (r.status == 0) & (ref[3] == 0)
+        assert both.sum() >= 0.5 * B and np.median(np.abs(r.x - ref[0]).reshape(B, -1).max(1)[both]) < 1e-7
+        if not expect_drop:       # every wanted row is there: clearance holds against ALL obstacles
+            xs = r.x[both][:, 1:-1, None, :2]
+            dist = np.linalg.norm(xs - pts[both][:, None, :, :], axis=-1)
+            assert dist.min() > 0.2 - 1e-6
+        s.close()
