@@ -15,6 +15,7 @@
 // Types carry the reference's names without ROS: PoseSE2 (teb), Twist (geometry_msgs), TimeSeries (corbo).
 #pragma once
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdint>
 #include <string>
@@ -151,6 +152,30 @@ inline void warm_start_shifting(double* x, double* u, int n, const double x0[3])
     u[2 * (n - 1)] = u[2 * (n - 2)]; u[2 * (n - 1) + 1] = u[2 * (n - 2) + 1];               // keep the duplicated last control consistent
 }
 
+// mpc_local_planner_msgs/OptimalControlResult (msg/OptimalControlResult.msg:1-12) without the ROS header: the wire layout that
+// Controller::publishOptimalControlResult fills (src/controller.cpp:197-221).  states / controls are "Column Major" = corbo::TimeSeries'
+// value matrix (dim x N, column-major), i.e. sample-major: states[dim_states * k + i] -- exactly one row of the ABI's x_out / u_out.
+struct OptimalControlResult {
+    uint32_t seq = 0;                       // header.seq = _ocp_seq (:202)
+    int64_t dim_states = 0, dim_controls = 0;
+    std::vector<double> time_states, states;
+    std::vector<double> time_controls, controls;
+    bool optimal_solution_found = false;
+    double cpu_time = 0.0;                  // _statistics.step_time (:206): wall time of the last step(), seconds
+};
+// fills `msg` from the time series a step() returned (:208-218: empty series leave the arrays empty)
+inline void fill_optimal_control_result(const TimeSeries& x_seq, const TimeSeries& u_seq, bool solution_found, double cpu_time, uint32_t seq,
+                                        OptimalControlResult& msg) {
+    msg.seq = seq;
+    msg.dim_states = 3;                     // _dynamics->getStateDimension(): SE2 state for every model (systems/base_robot_se2.h)
+    msg.dim_controls = 2;                   // getInputDimension()
+    msg.optimal_solution_found = solution_found;
+    msg.cpu_time = cpu_time;
+    msg.time_states.clear(); msg.states.clear(); msg.time_controls.clear(); msg.controls.clear();
+    if (x_seq.size() > 0) { msg.time_states = x_seq.time; msg.states = x_seq.values; }
+    if (u_seq.size() > 0) { msg.time_controls = u_seq.time; msg.controls = u_seq.values; }
+}
+
 class Controller {
  public:
     Controller() = default;
@@ -213,6 +238,7 @@ class Controller {
 
     // Controller::step(initial_plan, ...)  (src/controller.cpp:111-179)
     bool step(const std::vector<PoseSE2>& plan, const Twist& /*vel*/, double /*dt*/, double /*t*/, TimeSeries& u_seq, TimeSeries& x_seq) {
+        const auto t_step0 = std::chrono::steady_clock::now();
         if (!_h) { _last_error = "Controller must be configured before invoking step()."; return false; }
         if (plan.size() < 2) { _last_error = "Controller::step(): initial plan must contain at least two poses."; return false; }
         const PoseSE2& start = plan.front();
@@ -272,7 +298,27 @@ class Controller {
         _grid_empty = false;
         ++_ocp_seq;
         _last_goal = goal;
+        _last_step_time = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_step0).count();      // _statistics.step_time (:175)
         return _ocp_successful;
+    }
+
+    // Controller::publishOptimalControlResult (src/controller.cpp:197-221) without the publisher: the message of the last step()
+    void optimalControlResult(const TimeSeries& x_seq, const TimeSeries& u_seq, OptimalControlResult& msg) const {
+        fill_optimal_control_result(x_seq, u_seq, _ocp_successful, _last_step_time, (uint32_t)_ocp_seq, msg);
+    }
+
+    // Controller::isPoseTrajectoryFeasible (src/controller.cpp:859-917) of the trajectory the last step() planned, against the local
+    // costmap (row-major cost[my * size_x + mx], origin = world position of cell (0, 0)'s lower-left corner).  footprint_spec: n_spec points
+    // (x, y) in the robot frame (costmap_2d footprint).  Conventions of footprintCost: see mpc_check_feasibility in mpc_hip.h.
+    bool isPoseTrajectoryFeasible(const uint8_t* cost, int size_x, int size_y, double resolution, const double origin[2], const double* footprint_spec,
+                                  int n_spec, double inscribed_radius, double /*circumscribed_radius*/, double min_resolution_collision_check_angular,
+                                  int look_ahead_idx) {
+        if (!_h) { _last_error = "Controller must be configured before invoking step()."; return false; }
+        if (_n_cur < 2) return false;
+        int32_t ok = 0;
+        if (mpc_check_feasibility(_h, 1, _x.data(), cost, size_x, size_y, resolution, origin, footprint_spec, n_spec, inscribed_radius,
+                                  min_resolution_collision_check_angular, look_ahead_idx, &ok) != MPC_OK) { _last_error = mpc_last_error(); return false; }
+        return ok != 0;
     }
 
     // Controller::reset (src/controller.cpp:223): the next step starts from a fresh initial guess
@@ -298,6 +344,7 @@ class Controller {
     bool _ocp_successful = false;
     int _ocp_seq = 0;
     int _last_iterations = 0;
+    double _last_step_time = 0.0;
     int _num_ocp_iterations = 1;
     PoseSE2 _last_goal;
     int _force_reinit_num_steps = 0;                     // src/controller.cpp:78

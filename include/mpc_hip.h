@@ -250,6 +250,22 @@ int mpc_last_rows_dropped(mpc_solver* s, int32_t B, int32_t* rows_dropped);
  * n_candidates <= 1: winner = 0 / -1 from the status, iters_total = iters. */
 int mpc_last_candidates(mpc_solver* s, int32_t B, int32_t* winner, int32_t* iters_total);
 
+/* Post-solve feasibility check of the planned pose trajectories against the local costmaps -- Controller::isPoseTrajectoryFeasible
+ * (src/controller.cpp:859-917; caller: src/mpc_local_planner_ros.cpp:410-421): feasible[b] = 0 iff a footprint placed at a grid point
+ * x[b][0..look_ahead_idx] -- or at a pose interpolated between two neighbours that lie farther apart than inscribed_radius or turn by more
+ * than min_resolution_collision_check_angular -- covers a LETHAL cell in the sense footprintCost(...) == -1 of
+ * base_local_planner::CostmapModel (PINNED to ROS navigation 1.17 / noetic: -1 lethal, -2 no information, -3 outside the map, the first
+ * negative code met along centre, edges in order, Bresenham cells in order decides; fewer than 3 footprint points = centre cell only, where
+ * INSCRIBED counts as lethal).  cost[b][my][mx] as in mpc_costmap_to_obstacles; x = the solver's x_out layout [B][cfg.n][3] (per-instance
+ * grid sizes of mpc_set_grid_sizes are honoured); footprint_spec = n_spec (<= 32) points (x, y) in the robot frame, HOST pointer in both
+ * variants; look_ahead_idx < 0 = the whole horizon.  circumscribed_radius of the reference's signature is unused by footprintCost. */
+int mpc_check_feasibility_device(mpc_solver* s, int32_t B, const double* d_x, const uint8_t* d_cost, int32_t size_x, int32_t size_y, double resolution,
+                                 const double* d_origin /* [B][2] */, const double* footprint_spec, int32_t n_spec, double inscribed_radius,
+                                 double min_resolution_collision_check_angular, int32_t look_ahead_idx, int32_t* d_feasible);
+int mpc_check_feasibility(mpc_solver* s, int32_t B, const double* x, const uint8_t* cost, int32_t size_x, int32_t size_y, double resolution,
+                          const double* origin, const double* footprint_spec, int32_t n_spec, double inscribed_radius,
+                          double min_resolution_collision_check_angular, int32_t look_ahead_idx, int32_t* feasible);
+
 int mpc_synchronize(mpc_solver* s);
 
 /* Duration (ms) of the solve kernel of the most recent mpc_solve_batch* call, measured with

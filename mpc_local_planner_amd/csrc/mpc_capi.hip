@@ -13,6 +13,7 @@
 #include "mpc_problem.hpp"
 #include "mpc_wave.hpp"
 #include "mpc_costmap.hpp"
+#include "mpc_feasibility.hpp"
 
 namespace {
 
@@ -582,6 +583,58 @@ int mpc_costmap_to_obstacles(mpc_solver* s, int32_t B, const uint8_t* cost, int3
     if (er == hipSuccess) er = hipStreamSynchronize(s->stream);
     for (int i = 0; i < 7; ++i) if (d[i]) (void)hipFree(d[i]);
     if (er != hipSuccess) { set_err("mpc_costmap_to_obstacles", er); return er == hipErrorOutOfMemory ? MPC_ENOMEM : MPC_EHIP; }
+    return rc;
+}
+
+int mpc_check_feasibility_device(mpc_solver* s, int32_t B, const double* d_x, const uint8_t* d_cost, int32_t size_x, int32_t size_y, double resolution,
+                                 const double* d_origin, const double* footprint_spec, int32_t n_spec, double inscribed_radius,
+                                 double min_resolution_collision_check_angular, int32_t look_ahead_idx, int32_t* d_feasible) {
+    g_err[0] = 0;
+    if (!s || !d_x || !d_cost || !d_origin || !d_feasible) { set_err("mpc_check_feasibility_device: null argument"); return MPC_EINVAL; }
+    if (size_x < 1 || size_y < 1 || !(resolution > 0) || n_spec < 0 || n_spec > mpc::kFeasMaxSpec || (n_spec > 0 && !footprint_spec) ||
+        !(inscribed_radius > 0) || !(min_resolution_collision_check_angular > 0)) {
+        set_err("mpc_check_feasibility_device: bad costmap geometry, footprint (<= 32 points) or resolution parameters"); return MPC_EINVAL; }
+    if (B <= 0) return MPC_OK;
+    if (B > s->max_batch) { set_err("mpc_check_feasibility_device: B exceeds max_batch"); return MPC_EBATCH; }
+    if (s->use_ngrid && B > s->ngrid_B) { set_err("mpc_check_feasibility_device: B exceeds the batch the per-instance grid sizes were set for"); return MPC_EBATCH; }
+    HIP_TRY(hipSetDevice(s->device));
+    mpc::FeasArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = d_x; a.n_grid = s->use_ngrid ? s->d_ngrid : nullptr; a.n_stride = s->cfg.n;
+    a.cost = d_cost; a.origin = d_origin; a.size_x = size_x; a.size_y = size_y; a.resolution = resolution;
+    a.n_spec = n_spec;
+    for (int i = 0; i < 2 * n_spec; ++i) a.spec[i] = footprint_spec[i];
+    a.inscribed_radius = inscribed_radius; a.min_res_angular = min_resolution_collision_check_angular; a.look_ahead_idx = look_ahead_idx;
+    a.feasible = d_feasible;
+    hipLaunchKernelGGL(mpc::feasibility_kernel, dim3(B), dim3(mpc::kFeasThreads), 0, s->stream, a);
+    HIP_TRY(hipGetLastError());
+    return MPC_OK;
+}
+
+int mpc_check_feasibility(mpc_solver* s, int32_t B, const double* x, const uint8_t* cost, int32_t size_x, int32_t size_y, double resolution,
+                          const double* origin, const double* footprint_spec, int32_t n_spec, double inscribed_radius,
+                          double min_resolution_collision_check_angular, int32_t look_ahead_idx, int32_t* feasible) {
+    g_err[0] = 0;
+    if (!s || !x || !cost || !origin || !feasible) { set_err("mpc_check_feasibility: null argument"); return MPC_EINVAL; }
+    if (B <= 0) return MPC_OK;
+    if (B > s->max_batch || size_x < 1 || size_y < 1) { set_err("mpc_check_feasibility: bad argument"); return MPC_EINVAL; }
+    HIP_TRY(hipSetDevice(s->device));
+    const size_t nb = B, n = s->cfg.n;
+    const size_t sz[4] = {nb * n * 3 * 8, nb * size_x * size_y, nb * 2 * 8, nb * 4};
+    void* d[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipError_t er = hipSuccess;
+    for (int i = 0; i < 4 && er == hipSuccess; ++i) er = hipMalloc(&d[i], sz[i]);
+    int rc = MPC_OK;
+    if (er == hipSuccess) er = hipMemcpyAsync(d[0], x, sz[0], hipMemcpyHostToDevice, s->stream);
+    if (er == hipSuccess) er = hipMemcpyAsync(d[1], cost, sz[1], hipMemcpyHostToDevice, s->stream);
+    if (er == hipSuccess) er = hipMemcpyAsync(d[2], origin, sz[2], hipMemcpyHostToDevice, s->stream);
+    if (er == hipSuccess)
+        rc = mpc_check_feasibility_device(s, B, (const double*)d[0], (const uint8_t*)d[1], size_x, size_y, resolution, (const double*)d[2], footprint_spec, n_spec,
+                                          inscribed_radius, min_resolution_collision_check_angular, look_ahead_idx, (int32_t*)d[3]);
+    if (er == hipSuccess && rc == MPC_OK) er = hipMemcpyAsync(feasible, d[3], sz[3], hipMemcpyDeviceToHost, s->stream);
+    if (er == hipSuccess) er = hipStreamSynchronize(s->stream);
+    for (int i = 0; i < 4; ++i) if (d[i]) (void)hipFree(d[i]);
+    if (er != hipSuccess) { set_err("mpc_check_feasibility", er); return er == hipErrorOutOfMemory ? MPC_ENOMEM : MPC_EHIP; }
     return rc;
 }
 

@@ -170,6 +170,21 @@ class BatchSolver:
         self._check(self._lib.mpc_last_candidates(self._h, int(B), C.c_void_p(win.ctypes.data), C.c_void_p(tot.ctypes.data)))
         return win, tot
 
+    def check_feasibility(self, x, cost, resolution, origin, footprint_spec, inscribed_radius, min_resolution_collision_check_angular=0.3, look_ahead_idx=-1):
+        """Controller::isPoseTrajectoryFeasible for B planned trajectories (mpc_check_feasibility): x (B, n, 3), cost uint8 (B, size_y, size_x),
+        origin (B, 2), footprint_spec (F, 2) in the robot frame.  Returns int32 (B,): 1 feasible, 0 not."""
+        x = _as_f64(x, (np.asarray(x).shape[0], self.n, 3))
+        B = x.shape[0]
+        cost = np.ascontiguousarray(cost, dtype=np.uint8)
+        _, sy, sx = cost.shape
+        org = np.ascontiguousarray(origin, dtype=np.float64).reshape(B, 2)
+        spec = np.ascontiguousarray(footprint_spec, dtype=np.float64).reshape(-1, 2)
+        out = np.zeros(B, np.int32)
+        p = lambda a: C.c_void_p(a.ctypes.data)
+        self._check(self._lib.mpc_check_feasibility(self._h, B, p(x), p(cost), sx, sy, float(resolution), p(org), p(spec), int(spec.shape[0]),
+                                                    float(inscribed_radius), float(min_resolution_collision_check_angular), int(look_ahead_idx), p(out)))
+        return out
+
     def last_rows_dropped(self, B: int):
         """per instance: clearance rows that did not fit into max_obstacle_rows in the most recent solve (mpc_last_rows_dropped)"""
         out = np.zeros(B, np.int32)

@@ -846,3 +846,14 @@ class ReferenceNlp:
             e[i] = delta
             J[:, i] = (np.atleast_1d(fun(self.plus(z, e))) - np.atleast_1d(fun(self.plus(z, -e)))) / (2 * delta)
         return J
+
+
+def optimal_control_result(x, u, dt, found: bool, cpu_time: float, seq: int):
+    """mpc_local_planner_msgs/OptimalControlResult (msg/OptimalControlResult.msg:1-12) as Controller::publishOptimalControlResult fills it
+    (src/controller.cpp:197-221) from getStateAndControlTimeSeries (...grid_base_se2.cpp:579-615): x (n,3) states, u (n,2) controls with the
+    duplicated last row; times k*dt; "Column Major" = corbo::TimeSeries' dim x N value matrix stored column-major = sample after sample."""
+    x = np.asarray(x, float); u = np.asarray(u, float)
+    n = x.shape[0]
+    t = np.arange(n) * float(dt)
+    return {"seq": int(seq), "dim_states": 3, "dim_controls": 2, "time_states": t.copy(), "states": x.reshape(-1).copy(),
+            "time_controls": t.copy(), "controls": u.reshape(-1).copy(), "optimal_solution_found": bool(found), "cpu_time": float(cpu_time)}

@@ -19,3 +19,21 @@ extern "C" double ctl_resample(double* x, double* u, double dt, int n, int n_new
 
 extern "C" int ctl_find_nearest_state(const double* x, int n, const double* x0) { return mpc_local_planner_amd::find_nearest_state(x, n, x0); }
 extern "C" void ctl_warm_start_shifting(double* x, double* u, int n, const double* x0) { mpc_local_planner_amd::warm_start_shifting(x, u, n, x0); }
+
+// OptimalControlResult wire layout (msg/OptimalControlResult.msg:1-12) filled from time series built like Controller::step does;
+// returns the flattened message: [seq, dim_states, dim_controls, found, cpu_time, n_ts, n_s, n_tc, n_c, time_states.., states.., time_controls.., controls..]
+extern "C" int ctl_optimal_control_result(int n, const double* x, const double* u, double dt, int found, double cpu_time, int seq, double* out) {
+    using namespace mpc_local_planner_amd;
+    TimeSeries xs, us;
+    for (int k = 0; k < n; ++k) { xs.add(k * dt, x + 3 * k, 3); us.add(k * dt, u + 2 * k, 2); }
+    OptimalControlResult msg;
+    fill_optimal_control_result(xs, us, found != 0, cpu_time, (uint32_t)seq, msg);
+    int o = 0;
+    out[o++] = msg.seq; out[o++] = (double)msg.dim_states; out[o++] = (double)msg.dim_controls; out[o++] = msg.optimal_solution_found ? 1 : 0; out[o++] = msg.cpu_time;
+    out[o++] = (double)msg.time_states.size(); out[o++] = (double)msg.states.size(); out[o++] = (double)msg.time_controls.size(); out[o++] = (double)msg.controls.size();
+    for (double v : msg.time_states) out[o++] = v;
+    for (double v : msg.states) out[o++] = v;
+    for (double v : msg.time_controls) out[o++] = v;
+    for (double v : msg.controls) out[o++] = v;
+    return o;
+}

@@ -86,3 +86,22 @@ def test_warm_start_shifting_matches_oracle(lib):
         lib.ctl_warm_start_shifting(p(xx), p(uu), C.c_int(n), p(x0c))
         assert np.abs(xx - ref.x).max() < 1e-14
         assert np.abs(uu[:-1] - ref.u).max() < 1e-14
+
+
+def test_optimal_control_result_wire_layout(lib):
+    """f4: the facade's OptimalControlResult against the numpy restatement of msg/OptimalControlResult.msg + src/controller.cpp:197-221, bit-exact."""
+    rng = np.random.default_rng(9)
+    n, dt = 17, 0.2371
+    x = rng.normal(size=(n, 3)); u = rng.normal(size=(n, 2)); u[-1] = u[-2]
+    out = np.zeros(9 + 2 * n + 5 * n)
+    lib.ctl_optimal_control_result.restype = C.c_int
+    cnt = lib.ctl_optimal_control_result(C.c_int(n), x.ctypes.data_as(C.c_void_p), u.ctypes.data_as(C.c_void_p), C.c_double(dt), C.c_int(1), C.c_double(0.0123), C.c_int(41),
+                                         out.ctypes.data_as(C.c_void_p))
+    ref = R.optimal_control_result(x, u, dt, True, 0.0123, 41)
+    assert cnt == out.size
+    assert out[:9].tolist() == [41, 3, 2, 1, 0.0123, n, 3 * n, n, 2 * n]
+    np.testing.assert_array_equal(out[9:9 + n], ref["time_states"])
+    np.testing.assert_array_equal(out[9 + n:9 + 4 * n], ref["states"])
+    np.testing.assert_array_equal(out[9 + 4 * n:9 + 5 * n], ref["time_controls"])
+    np.testing.assert_array_equal(out[9 + 5 * n:], ref["controls"])
+    assert ref["states"][3 * 5 + 2] == x[5, 2] and ref["controls"][2 * 7 + 1] == u[7, 1]      # sample-major ("column major" of the dim x N matrix)
