@@ -786,3 +786,25 @@ def test_candidate_initial_trajectories_best_of(m):
     err = np.abs(allr.x[:B, :, :2] - single.x[:, :, :2]).reshape(B, -1).max(1)[same]
     assert np.median(err) < 1e-7
     s.close()
+
+
+@pytest.mark.parametrize("which", [2, 3])
+def test_device_vs_independent_sqp_from_the_cold_start(m, which):
+    """SURVEY 8c level 2 on the device: scipy SLSQP on the reference-form NLP from the reference cold start (fixtures of
+    tests/golden/make_cold_start_scipy.py, 32 instances each of config 2 and config 3) against the HIP solve."""
+    from test_oracle_solver import _vs_independent_sqp
+
+    def solve(ocfg, inputs, obst):
+        if obst is None:
+            s = m.BatchSolver(m.config_carlike_min_time(50), max_batch=32)
+            r = s.solve(*inputs)
+        else:
+            s = m.BatchSolver(m.config_unicycle_quadratic(80, max_obstacles=16, max_vertices=6, max_obstacle_rows=4), max_batch=32)
+            r = s.solve(*inputs, obstacles=obst)
+        s.close()
+        return r.x, r.u, r.dt, r.status, r.iters
+    same, err, conv = _vs_independent_sqp(f"device vs SLSQP, config {which}", which, solve)
+    if which == 3:
+        assert conv.all() and same.all()
+    else:
+        assert conv.sum() >= 30 and same.sum() >= 10
