@@ -145,6 +145,13 @@ typedef struct mpc_config {
     int32_t candidate_kind[MPC_MAX_CANDIDATES];
     int32_t candidate_max_iter[MPC_MAX_CANDIDATES];   /* iteration cap of candidate c (0 -> max_iter) */
     int32_t candidate_blend;          /* grid points of the heading blend of MPC_CAND_BLEND* (0 -> 8) */
+    /* warm start of the multipliers (the reference's Ipopt keeps its multipliers between control cycles: warm_start_init_point in corbo's
+     * SolverIpopt).  With dual_warm_start != 0 the handle keeps, per instance slot b, the collocation multipliers and the multipliers of the
+     * control / dt boxes and the control-rate rows of the last CONVERGED solve; a later solve of slot b that is given an initial guess starts
+     * from them -- every inequality multiplier max(previous, mu0 / slack), slacks re-derived from the new point, mu0 = mu_init_dual -- as
+     * long as the slot's grid size is unchanged.  mpc_reset forgets them. */
+    int32_t dual_warm_start;
+    double  mu_init_dual;             /* barrier start of such a solve (0 -> 1e-3) */
     int32_t reserved[6];
 } mpc_config;
 
@@ -212,6 +219,21 @@ int mpc_solve_batch_device(mpc_solver* s, int32_t B,
  * (3 <= n_grid[b] <= cfg.n); the array layouts keep the stride cfg.n and only the first n_grid[b] rows of
  * x_init/u_init/x_out/u_out are meaningful.  HOST pointer, copied; NULL restores the uniform size cfg.n. */
 int mpc_set_grid_sizes(mpc_solver* s, const int32_t* n_grid, int32_t B);
+
+/* The grid update between two control cycles for a whole batch, on the device and in place on the previous solve's outputs
+ * (d_x / d_u / d_dt = that solve's x_out / u_out / dt_out, handed back as x_init / u_init / dt_init of the next solve), so that a batched
+ * closed loop needs no host round trip:
+ *   fixed grid (cfg.dt_free == 0): warmStartShifting + findNearestState (src/optimal_control/full_discretization_grid_base_se2.cpp:241-339)
+ *       towards the new start states d_x0_new [B][3]; multipliers kept by dual_warm_start move with the trajectory;
+ *   variable grid with adapt != 0: adaptGridTimeBasedSingleStep (src/optimal_control/finite_differences_variable_grid_se2.cpp:99-121) with
+ *       n_min (clamped to 3), n_max (clamped to cfg.n), dt_hyst_ratio, + resampleTrajectory (...grid_base_se2.cpp:440-524); the
+ *       per-instance grid sizes live in the handle (as after mpc_set_grid_sizes) and are read back with mpc_get_grid_sizes;
+ *   variable grid with adapt == 0: nothing to do (no shifting on the variable grid, finite_differences_variable_grid_se2.h:85).
+ * DEVICE pointers; runs on the solver's stream. */
+int mpc_grid_update_device(mpc_solver* s, int32_t B, const double* d_x0_new, double* d_x, double* d_u, double* d_dt,
+                           int32_t adapt, int32_t n_min, int32_t n_max, double dt_hyst_ratio);
+/* Grid sizes currently in force (HOST pointer): cfg.n everywhere unless mpc_set_grid_sizes / mpc_grid_update_device changed them. */
+int mpc_get_grid_sizes(mpc_solver* s, int32_t B, int32_t* n_grid);
 
 /* Via-points of the minimum_time_via_points objective (the reference's borrowed ViaPointContainer,
  * include/mpc_local_planner/optimal_control/min_time_via_points_cost.h:102, refilled by the planner between steps,

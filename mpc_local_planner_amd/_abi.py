@@ -92,6 +92,8 @@ class MpcConfig(C.Structure):
         ("candidate_kind", C.c_int32 * 4),
         ("candidate_max_iter", C.c_int32 * 4),
         ("candidate_blend", C.c_int32),
+        ("dual_warm_start", C.c_int32),
+        ("mu_init_dual", C.c_double),
         ("reserved", C.c_int32 * 6),
     ]
 
@@ -114,7 +116,7 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
                 footprint_kind=0, footprint_radius=0.0, max_obstacles=0, max_vertices=1, max_obstacle_rows=4, mu_init_warm=0.0, collocation=COLLOC_FORWARD,
                 terminal_ball_S=None, terminal_ball_gamma=1.0, vp_position_weight=1e-3, vp_orientation_weight=0.0,
                 via_points_ordered=False, max_via_points=0, footprint_params=(0.0, 0.0, 0.0, 0.0),
-                enable_dynamic_obstacles=False, footprint_vertices=(), candidates=(), candidate_max_iter=(), candidate_blend=0) -> MpcConfig:
+                enable_dynamic_obstacles=False, footprint_vertices=(), candidates=(), candidate_max_iter=(), candidate_blend=0, dual_warm_start=False, mu_init_dual=0.0) -> MpcConfig:
     c = MpcConfig()
     c.model = model
     mp = list(model_params) + [0.0] * 4
@@ -165,6 +167,8 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
         c.candidate_kind[i] = int(k)
         c.candidate_max_iter[i] = int(candidate_max_iter[i]) if i < len(candidate_max_iter) else 0
     c.candidate_blend = int(candidate_blend)
+    c.dual_warm_start = int(bool(dual_warm_start))
+    c.mu_init_dual = float(mu_init_dual)
     return c
 
 

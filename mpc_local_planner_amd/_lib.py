@@ -16,11 +16,11 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libmpc_hip.so")
 SOURCES = ["mpc_capi.hip"]
-HEADERS = ["mpc_core.hpp", "mpc_problem.hpp", "mpc_wave.hpp", "mpc_dpp_blocks.inc", "mpc_costmap.hpp", "mpc_feasibility.hpp", os.path.join("..", "..", "include", "mpc_hip.h")]
+HEADERS = ["mpc_core.hpp", "mpc_problem.hpp", "mpc_wave.hpp", "mpc_dpp_blocks.inc", "mpc_costmap.hpp", "mpc_feasibility.hpp", "mpc_grid_update.hpp", os.path.join("..", "..", "include", "mpc_hip.h")]
 
 EXPORTS = [
     "mpc_config_defaults", "mpc_create", "mpc_reset", "mpc_destroy", "mpc_solve_batch",
-    "mpc_solve_batch_device", "mpc_set_grid_sizes", "mpc_set_via_points", "mpc_set_via_points_device", "mpc_costmap_to_obstacles", "mpc_costmap_to_obstacles_device", "mpc_last_candidates", "mpc_last_rows_dropped", "mpc_check_feasibility", "mpc_check_feasibility_device", "mpc_synchronize", "mpc_last_kernel_ms", "mpc_last_error", "mpc_version",
+    "mpc_solve_batch_device", "mpc_set_grid_sizes", "mpc_set_via_points", "mpc_set_via_points_device", "mpc_costmap_to_obstacles", "mpc_costmap_to_obstacles_device", "mpc_last_candidates", "mpc_last_rows_dropped", "mpc_check_feasibility", "mpc_check_feasibility_device", "mpc_grid_update_device", "mpc_get_grid_sizes", "mpc_synchronize", "mpc_last_kernel_ms", "mpc_last_error", "mpc_version",
 ]
 
 
@@ -103,6 +103,10 @@ def load() -> C.CDLL:
     lib.mpc_check_feasibility.restype = C.c_int
     lib.mpc_check_feasibility_device.argtypes = fs
     lib.mpc_check_feasibility_device.restype = C.c_int
+    lib.mpc_grid_update_device.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_double]
+    lib.mpc_grid_update_device.restype = C.c_int
+    lib.mpc_get_grid_sizes.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    lib.mpc_get_grid_sizes.restype = C.c_int
     lib.mpc_synchronize.argtypes = [C.c_void_p]
     lib.mpc_synchronize.restype = C.c_int
     lib.mpc_last_kernel_ms.argtypes = [C.c_void_p, C.POINTER(C.c_float)]

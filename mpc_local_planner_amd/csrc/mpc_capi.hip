@@ -7,6 +7,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "../../include/mpc_hip.h"
 #include "mpc_core.hpp"
@@ -14,6 +15,7 @@
 #include "mpc_wave.hpp"
 #include "mpc_costmap.hpp"
 #include "mpc_feasibility.hpp"
+#include "mpc_grid_update.hpp"
 
 namespace {
 
@@ -46,6 +48,8 @@ struct CandCtl {
     int32_t* winner_out;
     int32_t* iters_total_out;
     int32_t* rows_dropped;     // [B] clearance rows of candidate 0 that did not fit into max_obstacle_rows (NULL without obstacles)
+    double* dual;              // [B][dual_words] multipliers kept between control cycles (dual_warm_start) or NULL; word 0 = grid size, 0 = nothing kept
+    int dual_words;            // doubles per instance in `dual` (and appended to every candidate record)
 };
 constexpr int kWinIdle = 0x7f7f7f7f;
 
@@ -98,6 +102,7 @@ __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
         S.dtprev = dt_prev ? T(dt_prev[inst]) : T(0);
         const int kind = NC > 1 ? P.cand_kind[cand] : 0;
         if (NC > 1) { S.my_cand = cand; S.iter_cap = P.cand_max_iter[cand]; S.win_ptr = cand > 0 ? cc.win + inst : nullptr; }
+        if (cc.dual && cand == 0) S.dual_in = cc.dual + (long)inst * cc.dual_words;
         if (kind == 0 && x_init && u_init && dt_init) {
             // coalesced read of this instance's contiguous [n][3] / [n][2] blocks
             const double* xi = x_init + (long)inst * nmax * 3;
@@ -128,14 +133,21 @@ __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
                 if (status) status[inst] = st.status;
                 if (iters) iters[inst] = st.iters;
             }
+            if (cc.dual) {
+                double* blk = cc.dual + (long)inst * cc.dual_words;
+                __syncthreads();                                   // every lane has read its share of the old block (load_duals) long ago; keep the order explicit
+                if (st.status == mpc::ST_CONVERGED) S.store_duals(blk);
+                else if (lane == 0) blk[0] = 0.0;
+            }
             return;
         }
         // candidate record: candidate 0 always (its last iterate is the fallback), the others when they converged
         if (cand == 0 || st.status == mpc::ST_CONVERGED) {
-            double* r = cc.rec + ((long)cand * B + inst) * (5 * nmax + 3);
+            double* r = cc.rec + ((long)cand * B + inst) * (5 * nmax + 3 + cc.dual_words);
             for (int e = lane; e < 3 * nmax; e += mpc::kWave) { int k = e / 3; int ks = k < n ? k : n - 1; r[e] = double(S.F(L.X, e % 3, ks)); }
             for (int e = lane; e < 2 * nmax; e += mpc::kWave) { int k = e / 2; int ks = k < n - 1 ? k : n - 2; r[3 * nmax + e] = double(S.F(L.U, e % 2, ks)); }
             if (lane == 0) { r[5 * nmax] = double(S.SCL(mpc::SC_D)); r[5 * nmax + 1] = double(st.status); r[5 * nmax + 2] = double(st.iters); }
+            if (cc.dual && st.status == mpc::ST_CONVERGED) S.store_duals(r + 5 * nmax + 3);
         }
     }
     // ---- exit protocol (n_cand > 1): publish, count, and let the last candidate of the instance deliver the result
@@ -153,11 +165,16 @@ __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
     __threadfence();
     const int w = __builtin_amdgcn_readfirstlane(__hip_atomic_load(cc.win + inst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     const int src = w < NC ? w : 0;
-    const double* r = cc.rec + ((long)src * B + inst) * (5 * nmax + 3);
+    const double* r = cc.rec + ((long)src * B + inst) * (5 * nmax + 3 + cc.dual_words);
     double* xo = x_out + (long)inst * nmax * 3;
     double* uo = u_out + (long)inst * nmax * 2;
     for (int e = lane; e < 3 * nmax; e += mpc::kWave) xo[e] = __builtin_nontemporal_load(r + e);
     for (int e = lane; e < 2 * nmax; e += mpc::kWave) uo[e] = __builtin_nontemporal_load(r + 3 * nmax + e);
+    if (cc.dual) {
+        double* blk = cc.dual + (long)inst * cc.dual_words;
+        if (w < NC) { for (int e = lane; e < cc.dual_words; e += mpc::kWave) blk[e] = __builtin_nontemporal_load(r + 5 * nmax + 3 + e); }
+        else if (lane == 0) blk[0] = 0.0;
+    }
     if (lane == 0) {
         dt_out[inst] = __builtin_nontemporal_load(r + 5 * nmax);
         if (status) status[inst] = (int32_t)__builtin_nontemporal_load(r + 5 * nmax + 1);
@@ -200,6 +217,8 @@ struct mpc_solver {
     double* d_crec;
     int32_t *d_winner, *d_iters_total;
     int32_t* d_rows_dropped;    // per instance: clearance rows that did not fit (solvers with obstacles)
+    double* d_dual;             // per instance: multipliers of the last converged solve (dual_warm_start)
+    int dual_words;
     int32_t* last_status;       // device pointers of the most recent solve (mpc_last_candidates without candidates)
     int32_t* last_iters;
     bool timed;
@@ -347,12 +366,17 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         if (er == hipSuccess) er = hipMalloc((void**)&s->d_rows_dropped, Bm * 4);
         if (er == hipSuccess) er = hipMemset(s->d_rows_dropped, 0, Bm * 4);
     }
+    if (cfg->dual_warm_start) {
+        s->dual_words = mpc::IpmWave<double, 0, false>::dual_words(s->WL.NS);
+        if (er == hipSuccess) er = hipMalloc((void**)&s->d_dual, Bm * (size_t)s->dual_words * 8);
+        if (er == hipSuccess) er = hipMemset(s->d_dual, 0, Bm * (size_t)s->dual_words * 8);
+    }
     if (s->P64.n_cand > 1) {
         const size_t C_ = s->P64.n_cand;
         if (er == hipSuccess) er = hipMalloc((void**)&s->d_cwin, Bm * 4);
         if (er == hipSuccess) er = hipMalloc((void**)&s->d_cexited, Bm * 4);
         if (er == hipSuccess) er = hipMalloc((void**)&s->d_citsum, Bm * 4);
-        if (er == hipSuccess) er = hipMalloc((void**)&s->d_crec, C_ * Bm * (5 * n + 3) * 8);
+        if (er == hipSuccess) er = hipMalloc((void**)&s->d_crec, C_ * Bm * (5 * n + 3 + (size_t)s->dual_words) * 8);
         if (er == hipSuccess) er = hipMalloc((void**)&s->d_winner, Bm * 4);
         if (er == hipSuccess) er = hipMalloc((void**)&s->d_iters_total, Bm * 4);
         if (er == hipSuccess) er = hipMemset(s->d_cwin, 0x7f, Bm * 4);
@@ -373,6 +397,7 @@ int mpc_reset(mpc_solver* s) {
     g_err[0] = 0;
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipStreamSynchronize(s->stream));
+    if (s->d_dual) HIP_TRY(hipMemset(s->d_dual, 0, (size_t)s->max_batch * s->dual_words * 8));      // forget the multipliers
     if (s->d_cwin) {      // candidate bookkeeping back to idle (it is self-restoring unless a launch was aborted)
         HIP_TRY(hipMemset(s->d_cwin, 0x7f, (size_t)s->max_batch * 4));
         HIP_TRY(hipMemset(s->d_cexited, 0, (size_t)s->max_batch * 4));
@@ -385,7 +410,7 @@ void mpc_destroy(mpc_solver* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    void* bufs[] = {s->d_rows_dropped, s->d_cwin, s->d_cexited, s->d_citsum, s->d_crec, s->d_winner, s->d_iters_total, s->d_nvia, s->d_via, s->d_ngrid, s->d_in, s->d_out};
+    void* bufs[] = {s->d_dual, s->d_rows_dropped, s->d_cwin, s->d_cexited, s->d_citsum, s->d_crec, s->d_winner, s->d_iters_total, s->d_nvia, s->d_via, s->d_ngrid, s->d_in, s->d_out};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (s->h_in) (void)hipHostFree(s->h_in);
     if (s->h_out) (void)hipHostFree(s->h_out);
@@ -409,7 +434,7 @@ static hipError_t launch_model(mpc_solver* s, const mpc::Problem<T>& P, int B, c
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->wave_lds);
         if (e != hipSuccess) return e;
     }
-    CandCtl cc = {P.n_cand, s->d_cwin, s->d_cexited, s->d_citsum, s->d_crec, s->d_winner, s->d_iters_total, s->d_rows_dropped};
+    CandCtl cc = {P.n_cand, s->d_cwin, s->d_cexited, s->d_citsum, s->d_crec, s->d_winner, s->d_iters_total, s->d_rows_dropped, s->d_dual, s->dual_words};
     hipLaunchKernelGGL(kern, dim3((unsigned)B * (unsigned)(P.n_cand > 1 ? P.n_cand : 1)), dim3(mpc::kWave), s->wave_lds, s->stream, P, s->WL, B, x0, xf, up, dtp, xi, ui, dti, ob,
                        s->use_ngrid ? s->d_ngrid : nullptr, s->p_nvia, s->p_via, cc, xo, uo, dto, st, it);
     return hipSuccess;
@@ -584,6 +609,51 @@ int mpc_costmap_to_obstacles(mpc_solver* s, int32_t B, const uint8_t* cost, int3
     for (int i = 0; i < 7; ++i) if (d[i]) (void)hipFree(d[i]);
     if (er != hipSuccess) { set_err("mpc_costmap_to_obstacles", er); return er == hipErrorOutOfMemory ? MPC_ENOMEM : MPC_EHIP; }
     return rc;
+}
+
+int mpc_grid_update_device(mpc_solver* s, int32_t B, const double* d_x0_new, double* d_x, double* d_u, double* d_dt,
+                           int32_t adapt, int32_t n_min, int32_t n_max, double dt_hyst_ratio) {
+    g_err[0] = 0;
+    if (!s || !d_x || !d_u || !d_dt) { set_err("mpc_grid_update_device: null argument"); return MPC_EINVAL; }
+    if (B <= 0) return MPC_OK;
+    if (B > s->max_batch) { set_err("mpc_grid_update_device: B exceeds max_batch"); return MPC_EBATCH; }
+    HIP_TRY(hipSetDevice(s->device));
+    mpc::GridUpdateArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x0 = d_x0_new; a.x = d_x; a.u = d_u; a.dt = d_dt; a.n_stride = s->cfg.n;
+    a.dual = s->d_dual; a.dual_words = s->dual_words; a.dual_ns = s->WL.NS;
+    if (!s->cfg.dt_free) {
+        if (!d_x0_new) { set_err("mpc_grid_update_device: the fixed grid shifts towards the new start state (d_x0_new)"); return MPC_EINVAL; }
+        a.mode = 0;
+        a.n_grid = s->use_ngrid ? s->d_ngrid : nullptr;
+    } else {
+        if (!adapt) return MPC_OK;                      // variable grid without adaptation: nothing moves (x0 is overwritten by the solve)
+        if (n_min < 3) n_min = 3;                       // the solver needs 3 grid points (the reference allows 2)
+        if (n_max > s->cfg.n) n_max = s->cfg.n;
+        if (!s->use_ngrid) {                            // first adaptation: every slot starts at the uniform size
+            HIP_TRY(hipMemsetAsync(s->d_ngrid, 0, (size_t)s->max_batch * 4, s->stream));
+            std::vector<int32_t> full((size_t)s->max_batch, s->cfg.n);
+            HIP_TRY(hipMemcpyAsync(s->d_ngrid, full.data(), full.size() * 4, hipMemcpyHostToDevice, s->stream));
+            HIP_TRY(hipStreamSynchronize(s->stream));
+            s->use_ngrid = 1; s->ngrid_B = s->max_batch;
+        }
+        a.mode = 1; a.n_grid = s->d_ngrid; a.n_min = n_min; a.n_max = n_max; a.dt_ref = s->cfg.dt_ref; a.hyst = dt_hyst_ratio;
+    }
+    hipLaunchKernelGGL(mpc::grid_update_kernel, dim3(B), dim3(64), (size_t)s->cfg.n * 5 * 8, s->stream, a);
+    HIP_TRY(hipGetLastError());
+    return MPC_OK;
+}
+
+int mpc_get_grid_sizes(mpc_solver* s, int32_t B, int32_t* n_grid) {
+    g_err[0] = 0;
+    if (!s || !n_grid) return MPC_EINVAL;
+    if (B <= 0) return MPC_OK;
+    if (B > s->max_batch) { set_err("mpc_get_grid_sizes: B exceeds max_batch"); return MPC_EBATCH; }
+    if (!s->use_ngrid) { for (int b = 0; b < B; ++b) n_grid[b] = s->cfg.n; return MPC_OK; }
+    HIP_TRY(hipSetDevice(s->device));
+    HIP_TRY(hipStreamSynchronize(s->stream));
+    HIP_TRY(hipMemcpy(n_grid, s->d_ngrid, (size_t)B * 4, hipMemcpyDeviceToHost));
+    return MPC_OK;
 }
 
 int mpc_check_feasibility_device(mpc_solver* s, int32_t B, const double* d_x, const uint8_t* d_cost, int32_t size_x, int32_t size_y, double resolution,

@@ -80,6 +80,7 @@ struct Problem {
     T vp_wp, vp_wo;
     // candidate initial trajectories (wave kernel only): kinds (mpc_candidate_kind), iteration caps, heading-blend length
     int n_cand, cand_kind[4], cand_max_iter[4], cand_blend;
+    T mu_init_dual;      // barrier start of a solve that starts from the multipliers kept in the handle (dual_warm_start)
 };
 
 // Algorithm constants (Waechter & Biegler 2006 names).  Compile-time so that they live in

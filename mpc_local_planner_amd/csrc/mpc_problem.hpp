@@ -68,6 +68,7 @@ inline void fill_problem(const mpc_config& c, mpc::Problem<T>& P) {
         P.cand_max_iter[k] = (c.n_candidates > 1 && c.candidate_max_iter[k] > 0) ? c.candidate_max_iter[k] : P.max_iter;
     }
     P.cand_blend = c.candidate_blend > 0 ? c.candidate_blend : 8;
+    P.mu_init_dual = T(c.mu_init_dual > 0 ? c.mu_init_dual : 1e-3);
 }
 
 

@@ -172,6 +172,7 @@ struct IpmWave {
     // the solver runs a single candidate).  A lower winner index than ours = a higher-priority candidate has converged: we stop.
     int my_cand = 0, iter_cap = 0;
     int rows_dropped = 0;        // clearance rows that did not fit into max_obstacle_rows (associate_obstacles)
+    const double* dual_in = nullptr;   // multipliers of this instance's last converged solve (handle state; dual_warm_start) or NULL
     const int* win_ptr = nullptr;
 
     __device__ IpmWave(const Problem<T>& p, const WaveLayout& l, T* s, int ln) : P(p), L(l), sm(s), lane(ln) {}
@@ -1700,6 +1701,35 @@ struct IpmWave {
         if (lane == 0) SCL(SC_D) = P.dt_ref;
     }
 
+    // ---- multipliers kept in the handle between control cycles (dual_warm_start).  Block layout (doubles): [0] grid size, [1] pi_dt lower,
+    //      [2] pi_dt upper, [3] terminal-ball multiplier, then the LDS word ranges LAM (3 NS), YR (4 NS), PL (2 NS), PU (2 NS) verbatim.
+    __host__ __device__ static int dual_words(int ns) { return 4 + 11 * ns; }
+    __device__ __forceinline__ void store_duals(double* blk) const {
+        const int NS = L.NS;
+        if (lane == 0) { blk[0] = double(L.n); blk[1] = double(SCL(SC_PDL)); blk[2] = double(SCL(SC_PDU)); blk[3] = ball() ? double(SCL(SC_TY)) : 0.0; }
+        for (int e = lane; e < 3 * NS; e += kWave) blk[4 + e] = double(sm[L.LAM + e]);
+        for (int e = lane; e < 4 * NS; e += kWave) blk[4 + 3 * NS + e] = double(sm[L.YR + e]);
+        for (int e = lane; e < 2 * NS; e += kWave) { blk[4 + 7 * NS + e] = double(sm[L.PL + e]); blk[4 + 9 * NS + e] = double(sm[L.PU + e]); }
+    }
+    // every inequality multiplier max(previous, mu0 / slack) (the slacks and mu0 / slack were just set by init_point), lam as it was
+    __device__ __forceinline__ void load_duals(const double* blk) const {
+        const int n = L.n, NS = L.NS;
+        for (int k = lane; k < n; k += kWave) {
+            if (k < n - 1) {
+                for (int i = 0; i < 3; ++i) F(L.LAM, i, k) = T(blk[4 + i * NS + k]);
+                for (int j = 0; j < 2; ++j) {
+                    F(L.PL, j, k) = t_max(F(L.PL, j, k), T(blk[4 + 7 * NS + j * NS + k]));
+                    F(L.PU, j, k) = t_max(F(L.PU, j, k), T(blk[4 + 9 * NS + j * NS + k]));
+                }
+            }
+            for (int q = 0; q < 4; ++q) if (row_on(k, q)) F(L.YR, q, k) = t_max(F(L.YR, q, k), T(blk[4 + 3 * NS + q * NS + k]));
+        }
+        if (lane == 0) {
+            if (dtf()) { SCL(SC_PDL) = t_max(SCL(SC_PDL), T(blk[1])); SCL(SC_PDU) = t_max(SCL(SC_PDU), T(blk[2])); }
+            if (ball()) SCL(SC_TY) = t_max(SCL(SC_TY), T(blk[3]));
+        }
+    }
+
     __device__ __forceinline__ void init_point() {
         const int n = L.n;
         if (lane == 0) {
@@ -1742,7 +1772,8 @@ struct IpmWave {
         sync();
         if (L.M > 0) { rows_dropped = associate_obstacles(); sync(); }
         if (via()) { associate_via_points(); sync(); }
-        mu = warm_guess ? P.mu_init_warm : P.mu_init; rho = T(0); delta_last = T(0); fail0 = false;
+        const bool dual_ok = dual_in != nullptr && warm_guess && (int)dual_in[0] == n;       // same grid size as the solve that left the multipliers
+        mu = dual_ok ? P.mu_init_dual : (warm_guess ? P.mu_init_warm : P.mu_init); rho = T(0); delta_last = T(0); fail0 = false;
         const T d = SCL(SC_D);
         for (int k = lane; k < n; k += kWave) {
             for (int q = 0; q < 4; ++q) {
@@ -1779,6 +1810,7 @@ struct IpmWave {
             }
         }
         sync();
+        if (dual_ok) { load_duals(dual_in); sync(); }
     }
 
     // ---------------------------------------------------------------- driver (all lanes, uniform control flow)

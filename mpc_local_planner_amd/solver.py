@@ -185,6 +185,17 @@ class BatchSolver:
                                                     float(inscribed_radius), float(min_resolution_collision_check_angular), int(look_ahead_idx), p(out)))
         return out
 
+    def grid_update_device(self, B: int, x0_new: Optional[int], x: int, u: int, dt: int, adapt: bool = False, n_min: int = 3, n_max: int = 0, dt_hyst_ratio: float = 0.1):
+        """mpc_grid_update_device: warm-start shift (fixed grid) / single-step grid adaptation + resampling (variable grid) of a whole batch, in place
+        on device arrays (addresses)."""
+        v = lambda p: C.c_void_p(p) if p else None
+        self._check(self._lib.mpc_grid_update_device(self._h, int(B), v(x0_new), v(x), v(u), v(dt), int(bool(adapt)), int(n_min), int(n_max or self.n), float(dt_hyst_ratio)))
+
+    def grid_sizes(self, B: int):
+        out = np.zeros(B, np.int32)
+        self._check(self._lib.mpc_get_grid_sizes(self._h, int(B), C.c_void_p(out.ctypes.data)))
+        return out
+
     def last_rows_dropped(self, B: int):
         """per instance: clearance rows that did not fit into max_obstacle_rows in the most recent solve (mpc_last_rows_dropped)"""
         out = np.zeros(B, np.int32)

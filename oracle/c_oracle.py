@@ -77,6 +77,13 @@ def from_nlp_config(cfg, max_iter=100, tol=1e-8, mu_init=0.1) -> OracleConfig:
     return o
 
 
+def dual_state(B: int, n: int):
+    """zeroed per-instance multiplier state for solve_batch(..., dual_state=..., dual_mu0=...) (the product's dual_warm_start)"""
+    lib = _load()
+    lib.oracle_dual_words.restype = C.c_int
+    return np.zeros((B, int(lib.oracle_dual_words(C.c_int(n)))))
+
+
 def num_threads() -> int:
     return int(_load().oracle_num_threads())
 
@@ -117,11 +124,17 @@ def footprint_row(obst: "OracleObst", pose, vertices, radius: float = 0.0):
     return out[0], out[1:4].copy(), out[4], out[5:8].copy()
 
 
-def solve_batch(ocfg: OracleConfig, x0, xf, u_prev=None, dt_prev=None, init=None, nthreads=0, obstacles=None, obst: "OracleObst" = None, via=None, rows_dropped=None):
+def solve_batch(ocfg: OracleConfig, x0, xf, u_prev=None, dt_prev=None, init=None, nthreads=0, obstacles=None, obst: "OracleObst" = None, via=None, rows_dropped=None, dual_state=None, dual_mu0=1e-3):
     """rows_dropped: optional int32 array (B,) that receives the number of clearance rows that did not fit into obst.max_rows.
     obstacles = (n_obstacles (B,), n_vertices (B,O), vertices (B,O,V,2)[, radius (B,O)]) together with obst (OracleObst).
     via = (n_via (B,), via (B,VP,3)) for a config made from objective minimum_time_via_points."""
     lib = _load()
+    if dual_state is not None:
+        lib.oracle_set_dual_state(dual_state.ctypes.data_as(C.c_void_p), C.c_int(dual_state.shape[1]), C.c_double(dual_mu0))
+        try:
+            return solve_batch(ocfg, x0, xf, u_prev, dt_prev, init, nthreads, obstacles, obst, via, rows_dropped)
+        finally:
+            lib.oracle_set_dual_state(None, C.c_int(0), C.c_double(0.0))
     if via is not None:
         nvia = np.ascontiguousarray(via[0], np.int32); vps = np.ascontiguousarray(via[1], float)
         lib.oracle_set_via_points(nvia.ctypes.data_as(C.c_void_p), vps.ctypes.data_as(C.c_void_p), C.c_int(vps.shape[1]))

@@ -219,6 +219,7 @@ typedef struct {
     /* via-points of this instance (set per batch with oracle_set_via_points) and the grid point each one is attached to */
     int nvia; const double* via; int vidx[64];
     int rows_dropped;          /* clearance rows that did not fit into max_rows (obst_associate) */
+    double* dual;              /* this instance's block of the kept multipliers or NULL */
 } work_t;
 
 static int iu(int k, int j) { return 8 * k + j; }
@@ -553,6 +554,12 @@ static double obst_theta(const work_t* w, const double* X, double D, const doubl
 }
 
 /* ---- via-points: MinTimeViaPointsCost::update (min_time_via_points_cost.cpp:39-117) + findClosestPose (...grid_base_se2.cpp:364-388) */
+/* multipliers kept between control cycles (the product's dual_warm_start): per instance [0] grid size (0 = nothing kept), [1] pi_dt lower,
+ * [2] pi_dt upper, [3] terminal-ball multiplier, lam 3(n-1), y 4n, pl 2(n-1), pu 2(n-1); a solve that is given an initial guess starts from
+ * them with every inequality multiplier max(previous, mu0 / slack) and the barrier at mu0 */
+static double* g_dual_state = NULL; static int g_dual_words = 0; static double g_dual_mu0 = 1e-3;
+void oracle_set_dual_state(double* state, int words, double mu0) { g_dual_state = state; g_dual_words = words; g_dual_mu0 = mu0 > 0 ? mu0 : 1e-3; }
+int oracle_dual_words(int n) { return 4 + 3 * (n - 1) + 4 * n + 4 * (n - 1); }
 static int32_t* g_dropped_out = NULL;     /* [B] rows that did not fit (next batch), or NULL */
 void oracle_set_rows_dropped_out(int32_t* out) { g_dropped_out = out; }
 static const double* g_ovel = NULL;      /* obstacle velocities of the next batch [B][O][2] (dynamic obstacles) */
@@ -995,7 +1002,8 @@ static int solve_one(work_t* w, int warm) {
         double pl = fmin(bound_push * fmax(1.0, fabs(lb)), bound_push * (ub - lb)), pu = fmin(bound_push * fmax(1.0, fabs(ub)), bound_push * (ub - lb));
         w->D = fmin(fmax(w->D, lb + pl), ub - pu);
     }
-    w->mu = c->mu_init > 0 ? c->mu_init : 0.1;
+    const int dual_ok = warm && w->dual && (int)w->dual[0] == n;
+    w->mu = dual_ok ? g_dual_mu0 : (c->mu_init > 0 ? c->mu_init : 0.1);
     w->rho = 0; w->delta_last = 0;
     for (int r = 0; r < n; ++r) for (int q = 0; q < 4; ++q) {
         int finite = q < 2 ? (c->du_lb[q] > -1e29) : (c->du_ub[q - 2] < 1e29);
@@ -1023,6 +1031,14 @@ static int solve_one(work_t* w, int warm) {
     if (ball_on(w)) { double ta[3]; w->ts = fmax(-ball_eval(w, w->X, ta), slack_push); w->ty = w->mu / w->ts; w->tds = w->tdy = 0; }
     w->pdl = c->dt_free ? w->mu / (w->D - c->dt_lb) : 0.0;
     w->pdu = c->dt_free ? w->mu / (c->dt_ub - w->D) : 0.0;
+    if (dual_ok) {
+        const double* b = w->dual; const double *bl = b + 4, *by = bl + 3 * (n - 1), *bpl = by + 4 * n, *bpu = bpl + 2 * (n - 1);
+        for (int i = 0; i < 3 * (n - 1); ++i) w->lam[i] = bl[i];
+        for (int i = 0; i < 4 * n; ++i) if (w->ron[i]) w->y[i] = fmax(w->y[i], by[i]);
+        for (int i = 0; i < 2 * (n - 1); ++i) { w->pl[i] = fmax(w->pl[i], bpl[i]); w->pu[i] = fmax(w->pu[i], bpu[i]); }
+        if (c->dt_free) { w->pdl = fmax(w->pdl, b[1]); w->pdu = fmax(w->pdu, b[2]); }
+        if (ball_on(w)) w->ty = fmax(w->ty, b[3]);
+    }
     double fobj;
     eval_point(w, w->X, w->U, w->D, cc, &fobj);
     while (1) {
@@ -1241,6 +1257,15 @@ static int solve_one(work_t* w, int warm) {
         fobj = ft;
         ++it;
     }
+    if (w->dual) {
+        double* b = w->dual;
+        if (status == 0) {
+            double *bl = b + 4, *by = bl + 3 * (n - 1), *bpl = by + 4 * n, *bpu = bpl + 2 * (n - 1);
+            b[0] = n; b[1] = w->pdl; b[2] = w->pdu; b[3] = ball_on(w) ? w->ty : 0.0;
+            memcpy(bl, w->lam, sizeof(double) * 3 * (n - 1)); memcpy(by, w->y, sizeof(double) * 4 * n);
+            memcpy(bpl, w->pl, sizeof(double) * 2 * (n - 1)); memcpy(bpu, w->pu, sizeof(double) * 2 * (n - 1));
+        } else b[0] = 0;
+    }
     free(cc); free(cct); free(st); free(ds); free(dy); free(y2);
 #pragma omp critical
     { g_nfac_total += nfac; if (nfac > g_nfac_max) g_nfac_max = nfac; }
@@ -1330,6 +1355,7 @@ int oracle_solve_batch_obst(const oracle_config* c, int B, const double* x0, con
                 w->D = dt_init[b];
             }
             w->rows_dropped = 0;
+            w->dual = (g_dual_state && g_dual_words >= oracle_dual_words(n)) ? g_dual_state + (size_t)b * g_dual_words : NULL;
             int r = solve_one(w, warm);
             if (g_dropped_out) g_dropped_out[b] = w->rows_dropped;
             memcpy(x_out + (size_t)b * n * 3, w->X, sizeof(double) * 3 * n);

@@ -1,0 +1,161 @@
+"""GPU tests (-m gpu) of the state the handle keeps between control cycles and of the batched closed loop: multipliers carried across
+cycles (dual_warm_start), the device-side grid update (warm-start shift on the fixed grid, single-step adaptation + resampling on the
+variable grid) and a 50-cycle closed loop of a whole batch that never leaves the device between cycles."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("these tests need the MI355X (no HIP device here)")
+    torch.zeros(1, device="cuda")
+    import mpc_local_planner_amd as pkg
+    return pkg, torch
+
+
+def _advance_carlike(x0, u0, per, L):
+    x1 = x0.copy()
+    x1[:, 0] += per * u0[:, 0] * np.cos(x0[:, 2]); x1[:, 1] += per * u0[:, 0] * np.sin(x0[:, 2])
+    x1[:, 2] = (x0[:, 2] + per * u0[:, 0] * np.tan(u0[:, 1]) / L + np.pi) % (2 * np.pi) - np.pi
+    return x1
+
+
+def test_multipliers_kept_in_the_handle_shorten_the_next_cycle(env, c_oracle):
+    """config 2, B = 1024: cycle 1 cold, the plant advances one period, cycle 2 starts from the previous solution.  With dual_warm_start the
+    second solve starts from the kept multipliers (mu0 = 1e-3): <= 16 iterations on average (20.5 without), >= 99 % of the previously
+    converged instances converge again, same results as the C oracle running the same rule, and mpc_reset forgets the multipliers."""
+    from oracle import se2_nlp as R
+    from _parity import account
+    m, torch = env
+    B, n, per = 1024, 50, 0.2
+    inputs = m.workloads.carlike_min_time_inputs(B)
+    x0, xf, up, dtp = inputs
+    ocfg = R.config_carlike_min_time(n)
+    oc = c_oracle.from_nlp_config(ocfg)
+    s = m.BatchSolver(m.config_carlike_min_time(n, dual_warm_start=True, mu_init_dual=1e-3, mu_init_warm=1e-2), max_batch=B)
+    r1 = s.solve(*inputs)
+    ds = c_oracle.dual_state(B, n)
+    o1 = c_oracle.solve_batch(oc, *inputs, dual_state=ds)
+    ok = (r1.status == 0) & (o1[3] == 0) & (np.abs(r1.x - o1[0]).reshape(B, -1).max(1) < 1e-6)          # same first cycle on both sides
+    x1 = _advance_carlike(x0, r1.u[:, 0, :], per, 0.4)
+    dper = np.full(B, per)
+    r2 = s.solve(x1, xf, r1.u[:, 0, :], dper, init=(r1.x, r1.u, r1.dt))
+    o2 = c_oracle.solve_batch(oc, x1, xf, r1.u[:, 0, :], dper, init=(r1.x, r1.u, r1.dt), dual_state=ds, dual_mu0=1e-3)
+    print(f"[dual warm start] cycle 2: iterations mean {r2.iters[ok].mean():.2f} (oracle {o2[4][ok].mean():.2f}), re-converged {np.mean(r2.status[ok] == 0):.4f}")
+    assert r2.iters[ok].mean() <= 16.5 and np.mean(r2.status[ok] == 0) >= 0.99
+    assert abs(r2.iters[ok].mean() - o2[4][ok].mean()) < 0.5
+    sub = np.nonzero(ok)[0]
+    rr = m.BatchResult(r2.x[sub], r2.u[sub], r2.dt[sub], r2.status[sub], r2.iters[sub])
+    account("dual warm start, cycle 2", ocfg, (x1[sub], xf[sub], r1.u[sub, 0, :], dper[sub]), rr, tuple(a[sub] for a in o2))
+    # mpc_reset: the same warm solve now starts from re-initialised multipliers (mu_init_warm) and needs more iterations
+    s.reset()
+    r3 = s.solve(x1, xf, r1.u[:, 0, :], dper, init=(r1.x, r1.u, r1.dt))
+    assert r3.iters[ok].mean() > r2.iters[ok].mean() + 2.0
+    s.close()
+
+
+def test_grid_update_on_the_device_is_bit_exact(env):
+    """mpc_grid_update_device against the numpy restatements (oracle/se2_nlp.py: warm_start_shifting / find_nearest_state,
+    adapt_grid_single_step / resample_trajectory), bit for bit, on solver outputs."""
+    from oracle import se2_nlp as R
+    m, torch = env
+    dev = torch.device("cuda", 0)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    rng = np.random.default_rng(961)
+    # ---- fixed grid: shift towards the new start
+    B, n = 192, 20
+    inputs = m.workloads.unicycle_quadratic_inputs(B, seed=962)
+    s = m.BatchSolver(m.config_unicycle_quadratic(n), max_batch=B)
+    r = s.solve(*inputs)
+    adv = rng.integers(0, 4, B)                                     # the robot moved 0..3 grid intervals (+ noise) along its plan
+    x0n = r.x[np.arange(B), adv] + rng.normal(0, 0.01, (B, 3))
+    dx, du, dd, d0 = T(r.x), T(r.u), T(r.dt), T(x0n)
+    s.grid_update_device(B, d0.data_ptr(), dx.data_ptr(), du.data_ptr(), dd.data_ptr())
+    s.synchronize()
+    gx, gu = dx.cpu().numpy(), du.cpu().numpy()
+    shifted = 0
+    for b in range(B):
+        t = R.warm_start_shifting(R.Trajectory(r.x[b].copy(), r.u[b, :-1].copy(), float(r.dt[b])), x0n[b])
+        np.testing.assert_array_equal(gx[b], t.x)
+        np.testing.assert_array_equal(gu[b, :-1], t.u)
+        np.testing.assert_array_equal(gu[b, -1], t.u[-1])
+        shifted += int(not np.array_equal(t.x, r.x[b]))
+    assert shifted > B // 2
+    s.close()
+    # ---- variable grid: n + 1 / n - 1 / unchanged, resampled
+    B, n = 192, 40
+    inputs = m.workloads.carlike_min_time_inputs(B, seed=963, goal_range=(1.0, 6.0))
+    ocfg = R.config_carlike_min_time(n)
+    s = m.BatchSolver(m.config_carlike_min_time(n), max_batch=B)
+    n0 = rng.integers(20, 36, B).astype(np.int32)
+    s.set_grid_sizes(n0)
+    r = s.solve(*inputs)
+    dx, du, dd = T(r.x), T(r.u), T(r.dt)
+    s.grid_update_device(B, None, dx.data_ptr(), du.data_ptr(), dd.data_ptr(), adapt=True, n_min=3, n_max=n, dt_hyst_ratio=0.1)
+    s.synchronize()
+    gx, gu, gd, gn = dx.cpu().numpy(), du.cpu().numpy(), dd.cpu().numpy(), s.grid_sizes(B)
+    changed = 0
+    for b in range(B):
+        k = int(n0[b])
+        t = R.adapt_grid_single_step(ocfg, R.Trajectory(r.x[b, :k].copy(), r.u[b, :k - 1].copy(), float(r.dt[b])), n_min=3, n_max=n, hyst=0.1)
+        kn = t.x.shape[0]
+        assert gn[b] == kn
+        np.testing.assert_array_equal(gx[b, :kn], t.x)
+        np.testing.assert_array_equal(gu[b, :kn - 1], t.u)
+        assert gd[b] == t.dt
+        changed += int(kn != k)
+    assert changed > B // 4 and (gn > n0).any() and (gn < n0).any()
+    s.close()
+
+
+def test_batched_closed_loop_50_cycles_on_the_device(env, c_oracle):
+    """SURVEY 8c level 3 for a batch: 128 unicycle planners (config 1 family, fixed grid, moving-horizon shift) run 50 control cycles; between
+    cycles only device arrays are touched (plant step with torch on the GPU, mpc_grid_update_device, the next solve reads the previous
+    outputs).  Every cycle's inputs are also given to the C oracle (same shift restated in numpy): the device must reproduce the oracle's
+    commands cycle by cycle, re-converge throughout and drive the robots to their goals."""
+    from oracle import se2_nlp as R
+    m, torch = env
+    dev = torch.device("cuda", 0)
+    B, n, per, cycles = 128, 20, 0.3, 50
+    x0, xf, up, dtp = m.workloads.unicycle_quadratic_inputs(B, seed=971, goal_range=(1.0, 2.0))
+    ocfg = R.config_unicycle_quadratic(n)
+    oc = c_oracle.from_nlp_config(ocfg)
+    s = m.BatchSolver(m.config_unicycle_quadratic(n, dual_warm_start=True), max_batch=B)
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    dx0, dxf, dup, ddtp = T(x0), T(xf), T(up), T(np.full(B, per))
+    xo = torch.empty((B, n, 3), dtype=torch.float64, device=dev); uo = torch.empty((B, n, 2), dtype=torch.float64, device=dev)
+    do = torch.empty(B, dtype=torch.float64, device=dev); st = torch.empty(B, dtype=torch.int32, device=dev); it = torch.empty(B, dtype=torch.int32, device=dev)
+    xi = torch.empty_like(xo); ui = torch.empty_like(uo); di = torch.empty_like(do)
+    worst, conv_min, iters = 0.0, 1.0, []
+    for c in range(cycles):
+        init = None if c == 0 else (xi.data_ptr(), ui.data_ptr(), di.data_ptr())
+        s.solve_device(B, dx0.data_ptr(), dxf.data_ptr(), dup.data_ptr(), ddtp.data_ptr(), *(init or (None, None, None)), xo.data_ptr(), uo.data_ptr(), do.data_ptr(), st.data_ptr(), it.data_ptr())
+        s.synchronize()
+        # checker (host copies are for the ORACLE only; the loop itself continues from the device arrays)
+        hx0, hup = dx0.cpu().numpy(), dup.cpu().numpy()
+        hinit = None if c == 0 else (xi.cpu().numpy(), ui.cpu().numpy(), di.cpu().numpy())
+        o = c_oracle.solve_batch(oc, hx0, xf, hup, np.full(B, per), init=hinit)
+        hu, hs = uo.cpu().numpy(), st.cpu().numpy()
+        both = (hs == 0) & (o[3] == 0)
+        conv_min = min(conv_min, float((hs == 0).mean()))
+        worst = max(worst, float(np.abs(hu[both, 0] - o[1][both, 0]).max()))
+        iters.append(float(it.float().mean().item()))
+        assert (hs == o[3]).mean() > 0.98
+        # plant: unicycle, one period with the first command (on the device)
+        u0 = uo[:, 0, :]
+        dx0 = torch.stack([dx0[:, 0] + per * u0[:, 0] * torch.cos(dx0[:, 2]), dx0[:, 1] + per * u0[:, 0] * torch.sin(dx0[:, 2]),
+                           torch.remainder(dx0[:, 2] + per * u0[:, 1] + np.pi, 2 * np.pi) - np.pi], 1).contiguous()
+        dup = u0.clone()
+        xi.copy_(xo); ui.copy_(uo); di.copy_(do)
+        s.grid_update_device(B, dx0.data_ptr(), xi.data_ptr(), ui.data_ptr(), di.data_ptr())
+    print(f"[closed loop] {cycles} cycles x {B} planners: worst |u0(device) - u0(oracle)| {worst:.2e}, lowest converged fraction {conv_min:.3f}, "
+          f"iterations first / later cycles {iters[0]:.1f} / {np.mean(iters[5:]):.1f}")
+    assert worst < 1e-6 and conv_min > 0.97
+    dist = torch.linalg.norm(dx0[:, :2] - dxf[:, :2], dim=1).cpu().numpy()
+    assert np.median(dist) < 0.15 and (dist < 0.4).mean() > 0.9
+    assert np.mean(iters[5:]) < iters[0]
+    s.close()
