@@ -200,7 +200,9 @@ def main():
     kinds = tuple(int(k) for k in args.candidates.split(","))
     caps = tuple(int(k) for k in args.caps.split(","))[:len(kinds)]
     ckw = dict(candidates=kinds, candidate_max_iter=caps) if len(kinds) > 1 else {}
-    cfg = m.config_carlike_min_time(n=n, mu_init_warm=1e-2, **ckw)      # mu_init_warm: only solves that are given an initial guess (the warm-start leg)
+    # mu_init_warm / dual_warm_start only act on solves that are given an initial guess (the warm-start leg): the handle keeps the multipliers of
+    # every instance's last converged solve and the next cycle starts from them at mu0 = 1e-3
+    cfg = m.config_carlike_min_time(n=n, mu_init_warm=1e-2, dual_warm_start=True, mu_init_dual=1e-3, **ckw)
     # independent planner instances per rank: seed + rank (no scatter needed)
     leg = Leg(m, torch, dev, cfg, B, m.workloads.carlike_min_time_inputs(B, seed=sharding.rank_seed(m.workloads.SEED_CONFIG2, rank)))
 
@@ -302,7 +304,8 @@ def main():
         legs["warm_start"] = {"value": B * float(ok2.mean()) * args.steps / tw, "value_all_solves": B * args.steps / tw, "unit": "solves/s", "ms_per_step": tw / args.steps * 1e3, "kernel_ms": kw_ms,
                               "converged_frac": float(ok2.mean()), "converged_frac_of_previously_converged": float(ok2[ok].mean()), "iters_mean": float(it2n[ok].mean()),
                               "iters_p99": float(np.percentile(it2n[ok], 99)),
-                              "init": "previous solution with x0 advanced one 0.2 s period under u_0 as candidate 0 (slacks and multipliers re-initialised at mu0 = mu_init_warm = 1e-2); the hedges start from their own seeds"}
+                              "init": "previous solution with x0 advanced one 0.2 s period under u_0 as candidate 0, started from the multipliers the handle kept from the cold cycle "
+                                      "(dual_warm_start: every inequality multiplier max(previous, mu0 / slack), mu0 = 1e-3); the hedges start cold from their own seeds"}
         leg.close()
         # configs[3] share on one GPU (what every rank of the N = 8 run does)
         l4 = Leg(m, torch, dev, cfg, BATCH_PER_GPU_MULTI, m.workloads.carlike_min_time_inputs(BATCH_PER_GPU_MULTI))
