@@ -48,7 +48,9 @@ enum mpc_objective {                  /* src/controller.cpp:551-640 */
     MPC_OBJ_QUADRATIC = 1,
     MPC_OBJ_MIN_TIME_VIA_POINTS = 2     /* planning/objective/type minimum_time_via_points (src/controller.cpp:597-612) */
 };
-enum mpc_precision { MPC_FP64 = 0, MPC_FP32 = 1 };
+enum mpc_precision { MPC_FP64 = 0, MPC_FP32 = 1,
+                     MPC_MIXED = 2      /* fp32 main phase (to tol 1e-4; the candidates run here) + fp64 refinement started from its iterate AND its
+                                         * multipliers (barrier 1e-5) down to cfg.tol: fp64-accurate results at roughly the fp32 residency */ };
 enum mpc_footprint { MPC_FOOTPRINT_POINT = 0, MPC_FOOTPRINT_CIRCLE = 1,     /* every footprint works with every obstacle kind (point, circle, line, polygon), static or dynamic */
                      MPC_FOOTPRINT_LINE = 2,        /* teb LineRobotFootprint (the car-like example's footprint) */
                      MPC_FOOTPRINT_TWO_CIRCLES = 3, /* teb TwoCirclesRobotFootprint */
@@ -106,7 +108,7 @@ typedef struct mpc_config {
     int32_t max_iter;                 /* iterations                       (:391) */
     double  tol;                      /* ipopt_numeric_options/tol */
     double  mu_init;                  /* barrier start (0 -> default 0.1) */
-    int32_t precision;                /* MPC_FP64 | MPC_FP32 */
+    int32_t precision;                /* MPC_FP64 | MPC_FP32 | MPC_MIXED */
     /* collision avoidance (src/controller.cpp:717-729; footprint: src/mpc_local_planner_ros.cpp:890-1001) */
     double  min_obstacle_dist;        /* collision_avoidance/min_obstacle_dist */
     double  force_inclusion_dist;     /* .../force_inclusion_dist */

@@ -22,6 +22,7 @@ OBJ_MIN_TIME_VIA_POINTS = 2
 
 FP64 = 0
 FP32 = 1
+MIXED = 2
 
 STATUS_NAMES = {0: "converged", 1: "max_iter", 2: "linesearch_failed", 3: "linsolve_failed", 4: "numerical_error"}
 

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
     const double* __restrict__ x0, const double* __restrict__ xf, const double* __restrict__ u_prev,
     const double* __restrict__ dt_prev, const double* __restrict__ x_init, const double* __restrict__ u_init,
     const double* __restrict__ dt_init, mpc_obstacles obst, const int32_t* __restrict__ n_grid, const int32_t* __restrict__ n_via,
-    const double* __restrict__ via, CandCtl cc, double* __restrict__ x_out,
+    const double* __restrict__ via, CandCtl cc, const int32_t* __restrict__ iters_add, double* __restrict__ x_out,
     double* __restrict__ u_out, double* __restrict__ dt_out, int32_t* __restrict__ status, int32_t* __restrict__ iters) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mpc_smem[];
     T* sm = reinterpret_cast<T*>(mpc_smem);
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
             if (lane == 0) {
                 dt_out[inst] = double(S.SCL(mpc::SC_D));
                 if (status) status[inst] = st.status;
-                if (iters) iters[inst] = st.iters;
+                if (iters) iters[inst] = st.iters + (iters_add ? iters_add[inst] : 0);
             }
             if (cc.dual) {
                 double* blk = cc.dual + (long)inst * cc.dual_words;
@@ -195,7 +195,9 @@ struct mpc_solver {
     mpc::Problem<double> P64;
     mpc::Problem<float> P32;
     mpc::WaveLayout WL;
-    size_t wave_lds;
+    size_t wave_lds;            // dynamic LDS of the kernel instantiation of cfg.precision (MPC_MIXED: the fp64 one, the larger)
+    size_t wave_lds32;          // MPC_MIXED: dynamic LDS of the fp32 phase
+    int32_t* d_iters1;          // MPC_MIXED: iterations of the fp32 phase
     int device;
     int max_batch;
     hipStream_t stream;
@@ -295,6 +297,9 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         set_err("mpc_create: the polygon footprint needs 1..16 vertices"); return MPC_EINVAL; }
     for (int j = 0; j < 2; ++j)
         if (!(cfg->u_lb[j] < cfg->u_ub[j])) { set_err("mpc_create: control box must be finite and non-empty"); return MPC_EINVAL; }
+    if (cfg->precision != MPC_FP64 && cfg->precision != MPC_FP32 && cfg->precision != MPC_MIXED) { set_err("mpc_create: unknown precision"); return MPC_EINVAL; }
+    if (cfg->precision == MPC_MIXED && (cfg->max_obstacles > 0 || cfg->objective == MPC_OBJ_MIN_TIME_VIA_POINTS)) {
+        set_err("mpc_create: MPC_MIXED is implemented for problems without clearance rows and via-points (their association would be redone by the refinement phase)"); return MPC_EINVAL; }
     if (cfg->n_candidates < 0 || cfg->n_candidates > MPC_MAX_CANDIDATES) { set_err("mpc_create: n_candidates must be in [0, MPC_MAX_CANDIDATES]"); return MPC_EINVAL; }
     for (int k = 0; k < cfg->n_candidates; ++k)
         if (cfg->candidate_kind[k] < MPC_CAND_REFERENCE || cfg->candidate_kind[k] > MPC_CAND_BLEND_REVERSE || cfg->candidate_max_iter[k] < 0) {
@@ -315,6 +320,12 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
     s->cfg = *cfg;
     mpc::fill_problem<double>(*cfg, s->P64);
     mpc::fill_problem<float>(*cfg, s->P32);
+    if (cfg->precision == MPC_MIXED) {
+        s->P32.tol = 1e-4f;                                  // phase 1 stops where fp32 residuals stop making sense
+        s->P64.n_cand = 1;                                   // phase 2 refines the winner
+        if (!(cfg->mu_init_dual > 0)) s->P64.mu_init_dual = 1e-5;      // phase 1 ended at a barrier of ~1e-5
+        s->P64.mu_init_warm = 1e-3;                          // instances phase 1 did not converge start phase 2 from its last iterate
+    }
     {
         const int O = cfg->max_obstacles > 0 ? cfg->max_obstacles : 0;
         const int M = O > 0 ? (cfg->max_obstacle_rows > 0 ? cfg->max_obstacle_rows : 4) : 0;
@@ -327,8 +338,9 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
                                         (O > 0 && cfg->enable_dynamic_obstacles && (cfg->footprint_kind == MPC_FOOTPRINT_LINE || cfg->footprint_kind == MPC_FOOTPRINT_TWO_CIRCLES ||
                                                                                      cfg->footprint_kind == MPC_FOOTPRINT_POLYGON)) ? M : 0);
     }
-    s->wave_lds = ((((size_t)s->WL.total * (cfg->precision == MPC_FP32 ? 4 : 8)) + 15) & ~(size_t)15) + 16 +
-                  ((cfg->precision == MPC_FP32 ? sizeof(mpc::Problem<float>) : sizeof(mpc::Problem<double>)) + 15 & ~(size_t)15) + sizeof(mpc::WaveLayout);
+    s->wave_lds32 = ((((size_t)s->WL.total * 4) + 15) & ~(size_t)15) + 16 + ((sizeof(mpc::Problem<float>) + 15) & ~(size_t)15) + sizeof(mpc::WaveLayout);
+    s->wave_lds = cfg->precision == MPC_FP32 ? s->wave_lds32
+                : ((((size_t)s->WL.total * 8) + 15) & ~(size_t)15) + 16 + ((sizeof(mpc::Problem<double>) + 15) & ~(size_t)15) + sizeof(mpc::WaveLayout);
     if (s->wave_lds > 160u * 1024u) {
         set_err("mpc_create: the working set of one instance (n, max_obstacles, max_vertices, precision) does not fit in the 160 KB of LDS "
                 "of a compute unit (about n <= 215 grid points in fp64 without obstacles)");
@@ -366,7 +378,8 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         if (er == hipSuccess) er = hipMalloc((void**)&s->d_rows_dropped, Bm * 4);
         if (er == hipSuccess) er = hipMemset(s->d_rows_dropped, 0, Bm * 4);
     }
-    if (cfg->dual_warm_start) {
+    if (cfg->precision == MPC_MIXED && er == hipSuccess) er = hipMalloc((void**)&s->d_iters1, Bm * 4);
+    if (cfg->dual_warm_start || cfg->precision == MPC_MIXED) {
         s->dual_words = mpc::IpmWave<double, 0, false>::dual_words(s->WL.NS);
         if (er == hipSuccess) er = hipMalloc((void**)&s->d_dual, Bm * (size_t)s->dual_words * 8);
         if (er == hipSuccess) er = hipMemset(s->d_dual, 0, Bm * (size_t)s->dual_words * 8);
@@ -410,7 +423,7 @@ void mpc_destroy(mpc_solver* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    void* bufs[] = {s->d_dual, s->d_rows_dropped, s->d_cwin, s->d_cexited, s->d_citsum, s->d_crec, s->d_winner, s->d_iters_total, s->d_nvia, s->d_via, s->d_ngrid, s->d_in, s->d_out};
+    void* bufs[] = {s->d_iters1, s->d_dual, s->d_rows_dropped, s->d_cwin, s->d_cexited, s->d_citsum, s->d_crec, s->d_winner, s->d_iters_total, s->d_nvia, s->d_via, s->d_ngrid, s->d_in, s->d_out};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (s->h_in) (void)hipHostFree(s->h_in);
     if (s->h_out) (void)hipHostFree(s->h_out);
@@ -430,13 +443,15 @@ static hipError_t launch_model(mpc_solver* s, const mpc::Problem<T>& P, int B, c
                                double* dto, int32_t* st, int32_t* it) {
     const bool ext = solver_ext(s);
     auto kern = ext ? mpc_ipm_wave_kernel<T, MODEL, true> : mpc_ipm_wave_kernel<T, MODEL, false>;
-    if (s->wave_lds > 48u * 1024u) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)s->wave_lds);
+    const size_t lds = sizeof(T) == 4 ? s->wave_lds32 : s->wave_lds;
+    if (lds > 48u * 1024u) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return e;
     }
+    const int32_t* iters_add = (s->cfg.precision == MPC_MIXED && sizeof(T) == 8) ? s->d_iters1 : nullptr;
     CandCtl cc = {P.n_cand, s->d_cwin, s->d_cexited, s->d_citsum, s->d_crec, s->d_winner, s->d_iters_total, s->d_rows_dropped, s->d_dual, s->dual_words};
-    hipLaunchKernelGGL(kern, dim3((unsigned)B * (unsigned)(P.n_cand > 1 ? P.n_cand : 1)), dim3(mpc::kWave), s->wave_lds, s->stream, P, s->WL, B, x0, xf, up, dtp, xi, ui, dti, ob,
-                       s->use_ngrid ? s->d_ngrid : nullptr, s->p_nvia, s->p_via, cc, xo, uo, dto, st, it);
+    hipLaunchKernelGGL(kern, dim3((unsigned)B * (unsigned)(P.n_cand > 1 ? P.n_cand : 1)), dim3(mpc::kWave), lds, s->stream, P, s->WL, B, x0, xf, up, dtp, xi, ui, dti, ob,
+                       s->use_ngrid ? s->d_ngrid : nullptr, s->p_nvia, s->p_via, cc, iters_add, xo, uo, dto, st, it);
     return hipSuccess;
 }
 
@@ -478,7 +493,12 @@ int mpc_solve_batch_device(mpc_solver* s, int32_t B, const double* d_x0, const d
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipEventRecord(s->ev0, s->stream));
     hipError_t le;
-    if (s->cfg.precision == MPC_FP32)
+    if (s->cfg.precision == MPC_MIXED) {
+        // phase 1 (fp32, candidates, tol 1e-4) leaves iterate + multipliers; phase 2 (fp64, one candidate) refines them in place
+        le = launch_prec<float>(s, s->P32, B, d_x0, d_xf, d_u_prev, d_dt_prev, d_x_init, d_u_init, d_dt_init, ob, d_x_out, d_u_out, d_dt_out, d_status, s->d_iters1);
+        if (le == hipSuccess)
+            le = launch_prec<double>(s, s->P64, B, d_x0, d_xf, d_u_prev, d_dt_prev, d_x_out, d_u_out, d_dt_out, ob, d_x_out, d_u_out, d_dt_out, d_status, d_iters);
+    } else if (s->cfg.precision == MPC_FP32)
         le = launch_prec<float>(s, s->P32, B, d_x0, d_xf, d_u_prev, d_dt_prev, d_x_init, d_u_init, d_dt_init, ob, d_x_out, d_u_out, d_dt_out, d_status, d_iters);
     else
         le = launch_prec<double>(s, s->P64, B, d_x0, d_xf, d_u_prev, d_dt_prev, d_x_init, d_u_init, d_dt_init, ob, d_x_out, d_u_out, d_dt_out, d_status, d_iters);

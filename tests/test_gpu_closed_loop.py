@@ -163,3 +163,29 @@ def test_batched_closed_loop_50_cycles_on_the_device(env, c_oracle, dual):
     assert np.median(dist) < 0.15 and (dist < 0.4).mean() > 0.9
     assert np.mean(iters[5:]) < iters[0]
     s.close()
+
+
+def test_mixed_precision_meets_the_fp64_tolerance_on_config5(env, c_oracle):
+    """BASELINE.json configs[4] shape (kinematic bicycle, variable-dt time-optimal, n = 120): MPC_MIXED = fp32 main phase (to 1e-4) + fp64
+    refinement started from its iterate and multipliers.  Against the C oracle (fp64): median trajectory difference < 1e-4, 95 % < 1e-3,
+    converged fraction within 2 points of the fp64 kernel; plain fp32 (tol 1e-4) is shown beside it."""
+    from oracle import se2_nlp as R
+    from mpc_local_planner_amd import _abi as A
+    m, torch = env
+    B, n = 256, 120
+    inputs = m.workloads.bicycle_min_time_inputs(B)
+    ref = c_oracle.solve_batch(c_oracle.from_nlp_config(R.config_bicycle_min_time(n)), *inputs)
+    out = {}
+    for tag, kw in (("fp64", dict(precision=A.FP64)), ("mixed", dict(precision=A.MIXED)), ("fp32", dict(precision=A.FP32, tol=1e-4))):
+        s = m.BatchSolver(m.config_bicycle_min_time(n, **kw), max_batch=B)
+        r = s.solve(*inputs)
+        r = s.solve(*inputs)
+        both = (r.status == 0) & (ref[3] == 0)
+        err = np.abs(r.x - ref[0]).reshape(B, -1).max(1)[both]
+        out[tag] = (float((r.status == 0).mean()), float(np.median(err)), float(np.percentile(err, 95)), s.last_kernel_ms(), float(r.iters.mean()))
+        print(f"[config 5, {tag}] converged {out[tag][0]:.3f} (oracle {np.mean(ref[3] == 0):.3f}); |x - oracle| median {out[tag][1]:.1e}, p95 {out[tag][2]:.1e}; "
+              f"kernel {out[tag][3]:.2f} ms; iterations {out[tag][4]:.1f}")
+        s.close()
+    assert out["mixed"][1] < 1e-4 and out["mixed"][2] < 1e-3
+    assert abs(out["mixed"][0] - out["fp64"][0]) <= 0.02
+    assert out["fp64"][1] < 1e-6
