@@ -336,6 +336,13 @@ def main():
         legs["config5_share_bicycle_n120_fp32_B1024"] = leg_summary(l5, max(2, args.steps // 2), 1, algorithmic_bytes_per_solve(n5, 4), (24 + 486 + 418 + 100) * (n5 - 1), FP32_VECTOR_PEAK_TF, "bicycle_n120_fp32_B1024")
         legs["config5_share_bicycle_n120_fp32_B1024"]["dtype"] = "f32"
         l5.close()
+        # the same share in MPC_MIXED: fp32 main phase + fp64 refinement (trajectories within ~1e-8 of the fp64 solve instead of ~2e-4)
+        c5m = m.config_bicycle_min_time(n5, precision=2, **(dict(candidates=kinds, candidate_max_iter=tuple(100 for _ in kinds)) if len(kinds) > 1 else {}))
+        l5m = Leg(m, torch, dev, c5m, B5, m.workloads.bicycle_min_time_inputs(B5))
+        legs["config5_share_bicycle_n120_mixed_B1024"] = leg_summary(l5m, max(2, args.steps // 2), 1, algorithmic_bytes_per_solve(n5, 8), (24 + 486 + 418 + 100) * (n5 - 1), FP32_VECTOR_PEAK_TF, "bicycle_n120_mixed_B1024")
+        legs["config5_share_bicycle_n120_mixed_B1024"]["dtype"] = "f32 main phase + f64 refinement"
+        legs["config5_share_bicycle_n120_mixed_B1024"]["roofline"]["note"] = "kernel_ms = both phases (two launches of mpc_ipm_wave_kernel); iterations of the fp64 phase are included in iters"
+        l5m.close()
         line["legs"] = legs
         line["scaling_reference"] = {"per_gpu_value_at_4096": legs["config4_share_B4096"]["value"],
                                      "note": "bench.py --gpus N>1 runs configs[3] (4096 instances per GPU); its per-GPU reference on one GPU is this leg, not the N=1 headline (1024 instances)"}
