@@ -16,12 +16,12 @@ def rows(path, sql):
     return cols, r
 
 
-def main(src, dst):
+def main(src, dst, key="carlike_n50_B1024_c4"):
     os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
     out = []
     tr = os.path.join(src, "trace", "run_results.db")
     if os.path.exists(tr):
-        out.append("## rocprofv3 --kernel-trace --stats  (python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-warm)\n")
+        out.append("## rocprofv3 --kernel-trace --stats  (python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-legs)\n")
         out.append("| kernel | calls | total_us | avg_us | % |\n|---|---|---|---|---|\n")
         for name, calls, tot, avg, pct in rows(tr, "select name,total_calls,total_duration,average,percentage from top_kernels")[1]:
             short = name.replace("(anonymous namespace)::", "").split("(mpc::")[0][:100]
@@ -50,14 +50,22 @@ def main(src, dst):
                 vals[name] = mean
     if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
         import json
-        rec = {"kernel": "wave", "n": 50, "batch": 1024, "fetch_size_kib": vals["FETCH_SIZE"], "write_size_kib": vals["WRITE_SIZE"],
+        rec = {"kernel": "mpc_ipm_wave_kernel", "key": key, "fetch_size_kib": vals["FETCH_SIZE"], "write_size_kib": vals["WRITE_SIZE"],
                "bytes_per_launch": (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
-               "source": os.path.basename(dst) + ".md", "command": "python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-warm"}
-        json.dump(rec, open(os.path.join(os.path.dirname(dst) or ".", "hbm_traffic.json"), "w"), indent=1)
+               "source": os.path.basename(dst) + ".md", "command": "python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-legs"}
+        path = os.path.join(os.path.dirname(dst) or ".", "hbm_traffic.json")
+        try:
+            allrec = json.load(open(path))
+            if not isinstance(allrec.get(key, {}), dict) or "kernel" in allrec:
+                allrec = {}
+        except (OSError, ValueError):
+            allrec = {}
+        allrec[key] = rec
+        json.dump(allrec, open(path, "w"), indent=1)
         out.append(f"\nHBM traffic per launch = 2 x FETCH_SIZE + WRITE_SIZE = {rec['bytes_per_launch'] / 1e6:.2f} MB\n")
     open(dst + ".md", "w").write("".join(out))
     print("".join(out))
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:4])
