@@ -202,9 +202,10 @@ def main():
     kinds = tuple(int(k) for k in args.candidates.split(","))
     caps = tuple(int(k) for k in args.caps.split(","))[:len(kinds)]
     ckw = dict(candidates=kinds, candidate_max_iter=caps) if len(kinds) > 1 else {}
-    # mu_init_warm / dual_warm_start only act on solves that are given an initial guess (the warm-start leg): the handle keeps the multipliers of
-    # every instance's last converged solve and the next cycle starts from them at mu0 = 1e-3
-    cfg = m.config_carlike_min_time(n=n, mu_init_warm=1e-2, dual_warm_start=True, mu_init_dual=1e-3, **ckw)
+    # the warm-start leg has its own solver: its handle keeps the multipliers of every instance's last converged solve (dual_warm_start) and the
+    # next cycle starts from them at mu0 = 1e-3; the headline solver does not write them
+    cfg = m.config_carlike_min_time(n=n, **ckw)
+    cfg_warm = m.config_carlike_min_time(n=n, mu_init_warm=1e-2, dual_warm_start=True, mu_init_dual=1e-3, **ckw)
     # independent planner instances per rank: seed + rank (no scatter needed)
     leg = Leg(m, torch, dev, cfg, B, m.workloads.carlike_min_time_inputs(B, seed=sharding.rank_seed(m.workloads.SEED_CONFIG2, rank)))
 
@@ -292,6 +293,11 @@ def main():
         # warm start, reported separately: the plant advances one controller period (0.2 s) with u_0, the previous solution is
         # the initial guess with x0 overwritten (full_discretization_grid_base_se2.cpp:101-110; variable grid: no shifting)
         per, Lw = 0.2, float(cfg.model_params[0])
+        lw = Leg(m, torch, dev, cfg_warm, B, m.workloads.carlike_min_time_inputs(B, seed=sharding.rank_seed(m.workloads.SEED_CONFIG2, rank)))
+        lw.step(); lw.sync()
+        assert torch.equal(lw.xo, leg.xo) and torch.equal(lw.st, leg.st)
+        leg.close()
+        leg = lw
         dx0, dxf = leg.inp[0], leg.inp[1]
         u0 = leg.uo[:, 0, :].clone()
         x1 = dx0.clone()

@@ -36,8 +36,8 @@ void set_err(const char* what) { snprintf(g_err, sizeof(g_err), "%s", what); }
 //   win[b]      lowest candidate index of instance b that has converged so far (INT_MAX-like: none)
 //   exited[b]   candidates of instance b that have finished; the LAST one to finish copies the winner's record to the caller's outputs
 //   it_sum[b]   iterations spent on instance b by all its candidates
-//   rec         [C][B][5 n + 3] doubles: x (n x 3), u (n x 2), dt, status, iterations of candidate c of instance b (written by candidate 0
-//               always and by every candidate that converged)
+//   rec         [C][B][5 n + 3 (+ multipliers)] doubles: x (n x 3), u (n x 2), dt, status, iterations of hedge c >= 1 of instance b, written when it
+//               converged (candidate 0 delivers straight into the caller's arrays)
 // win / exited / it_sum are restored to their idle values by that last workgroup, so consecutive launches need no memset.
 struct CandCtl {
     int n_cand;
@@ -65,10 +65,9 @@ __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
     double* __restrict__ u_out, double* __restrict__ dt_out, int32_t* __restrict__ status, int32_t* __restrict__ iters) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mpc_smem[];
     T* sm = reinterpret_cast<T*>(mpc_smem);
-    // problem record + layout at the end of the dynamic LDS block (16-byte aligned)
+    // problem record at the end of the dynamic LDS block (16-byte aligned); the layout stays in scalar registers
     const size_t coff = (((size_t)L.total * sizeof(T)) + 15) & ~(size_t)15;
     mpc::Problem<T>* Ps = reinterpret_cast<mpc::Problem<T>*>(mpc_smem + coff);
-    mpc::WaveLayout* Ls = reinterpret_cast<mpc::WaveLayout*>(mpc_smem + coff + ((sizeof(mpc::Problem<T>) + 15) & ~(size_t)15));
     const int NC = cc.n_cand;                        // wave-uniform kernel argument
     const int cand = NC > 1 ? (int)blockIdx.x / B : 0;
     const int inst = (int)blockIdx.x - cand * B;
@@ -84,14 +83,14 @@ __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
         run = !(w < cand);
     }
     int st_status = mpc::ST_SUPERSEDED, st_iters = 0;
-    mpc::WaveLayout Lv = L;            // from the kernel arguments: wave-uniform, lives in SGPRs
-    Lv.n = __builtin_amdgcn_readfirstlane(n);
     if (run) {
+        mpc::WaveLayout Lv = L;            // from the kernel arguments: wave-uniform, lives in SGPRs
+        Lv.n = __builtin_amdgcn_readfirstlane(n);
 #ifdef MPC_POISON_LDS      // developer check: any read of an LDS word the solver did not write first turns into NaN
         for (int e = lane; e < L.total; e += mpc::kWave) sm[e] = T(NAN);
         __syncthreads();
 #endif
-        if (lane == 0) { *Ps = P; *Ls = L; Ls->n = n; Ps->n = n; }
+        if (lane == 0) { *Ps = P; Ps->n = n; }
         __syncthreads();
         mpc::IpmWave<T, MODEL, EXT> S(*Ps, Lv, sm, lane);
         for (int i = 0; i < 3; ++i) { S.x0[i] = T(x0[3 * inst + i]); S.xf[i] = T(xf[3 * inst + i]); }
@@ -100,8 +99,9 @@ __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
         S.uprev[0] = u_prev ? T(u_prev[2 * inst]) : T(0);
         S.uprev[1] = u_prev ? T(u_prev[2 * inst + 1]) : T(0);
         S.dtprev = dt_prev ? T(dt_prev[inst]) : T(0);
-        const int kind = NC > 1 ? P.cand_kind[cand] : 0;
-        if (NC > 1) { S.my_cand = cand; S.iter_cap = P.cand_max_iter[cand]; S.win_ptr = cand > 0 ? cc.win + inst : nullptr; }
+        // (indexed through the LDS copy: a run-time index into the by-value kernel argument would put the arrays into scratch memory)
+        const int kind = NC > 1 ? Ps->cand_kind[cand] : 0;
+        if (NC > 1) { S.my_cand = cand; S.iter_cap = Ps->cand_max_iter[cand]; S.win_ptr = cand > 0 ? cc.win + inst : nullptr; }
         if (cc.dual && cand == 0) S.dual_in = cc.dual + (long)inst * cc.dual_words;
         if (kind == 0 && x_init && u_init && dt_init) {
             // coalesced read of this instance's contiguous [n][3] / [n][2] blocks
@@ -123,7 +123,10 @@ __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
         __syncthreads();
         st_status = st.status; st_iters = st.iters;
         if (cc.rows_dropped && cand == 0 && lane == 0) cc.rows_dropped[inst] = S.rows_dropped;
-        if (NC <= 1) {
+        if (cand == 0) {
+            // candidate 0 (the only one when NC <= 1) delivers straight into the caller's arrays: whenever it converges it IS the result (lowest
+            // index), and when no candidate converges its last iterate and status are what is returned.  Only when a hedge wins does the last
+            // workgroup of the instance overwrite this with the hedge's record (it runs after every candidate, this one included, has left).
             double* xo = x_out + (long)inst * nmax * 3;
             double* uo = u_out + (long)inst * nmax * 2;
             for (int e = lane; e < 3 * nmax; e += mpc::kWave) { int k = e / 3; int ks = k < n ? k : n - 1; xo[e] = double(S.F(L.X, e % 3, ks)); }
@@ -139,18 +142,17 @@ __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
                 if (st.status == mpc::ST_CONVERGED) S.store_duals(blk);
                 else if (lane == 0) blk[0] = 0.0;
             }
-            return;
-        }
-        // candidate record: candidate 0 always (its last iterate is the fallback), the others when they converged
-        if (cand == 0 || st.status == mpc::ST_CONVERGED) {
+            if (NC <= 1) return;
+        } else if (st.status == mpc::ST_CONVERGED) {
+            // a hedge that converged leaves its record: x (n x 3), u (n x 2), dt, status, iterations [, multipliers]
             double* r = cc.rec + ((long)cand * B + inst) * (5 * nmax + 3 + cc.dual_words);
             for (int e = lane; e < 3 * nmax; e += mpc::kWave) { int k = e / 3; int ks = k < n ? k : n - 1; r[e] = double(S.F(L.X, e % 3, ks)); }
             for (int e = lane; e < 2 * nmax; e += mpc::kWave) { int k = e / 2; int ks = k < n - 1 ? k : n - 2; r[3 * nmax + e] = double(S.F(L.U, e % 2, ks)); }
             if (lane == 0) { r[5 * nmax] = double(S.SCL(mpc::SC_D)); r[5 * nmax + 1] = double(st.status); r[5 * nmax + 2] = double(st.iters); }
-            if (cc.dual && st.status == mpc::ST_CONVERGED) S.store_duals(r + 5 * nmax + 3);
+            if (cc.dual) S.store_duals(r + 5 * nmax + 3);
         }
     }
-    // ---- exit protocol (n_cand > 1): publish, count, and let the last candidate of the instance deliver the result
+    // ---- exit protocol (n_cand > 1): publish, count, and let the last candidate of the instance deliver a hedge's result
     __threadfence();
     __syncthreads();
     int last = 0;
@@ -164,21 +166,23 @@ __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
     if (!last) return;
     __threadfence();
     const int w = __builtin_amdgcn_readfirstlane(__hip_atomic_load(cc.win + inst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    const int src = w < NC ? w : 0;
-    const double* r = cc.rec + ((long)src * B + inst) * (5 * nmax + 3 + cc.dual_words);
-    double* xo = x_out + (long)inst * nmax * 3;
-    double* uo = u_out + (long)inst * nmax * 2;
-    for (int e = lane; e < 3 * nmax; e += mpc::kWave) xo[e] = __builtin_nontemporal_load(r + e);
-    for (int e = lane; e < 2 * nmax; e += mpc::kWave) uo[e] = __builtin_nontemporal_load(r + 3 * nmax + e);
-    if (cc.dual) {
-        double* blk = cc.dual + (long)inst * cc.dual_words;
-        if (w < NC) { for (int e = lane; e < cc.dual_words; e += mpc::kWave) blk[e] = __builtin_nontemporal_load(r + 5 * nmax + 3 + e); }
-        else if (lane == 0) blk[0] = 0.0;
+    if (w > 0 && w < NC) {
+        const double* r = cc.rec + ((long)w * B + inst) * (5 * nmax + 3 + cc.dual_words);
+        double* xo = x_out + (long)inst * nmax * 3;
+        double* uo = u_out + (long)inst * nmax * 2;
+        for (int e = lane; e < 3 * nmax; e += mpc::kWave) xo[e] = __builtin_nontemporal_load(r + e);
+        for (int e = lane; e < 2 * nmax; e += mpc::kWave) uo[e] = __builtin_nontemporal_load(r + 3 * nmax + e);
+        if (cc.dual) {
+            double* blk = cc.dual + (long)inst * cc.dual_words;
+            for (int e = lane; e < cc.dual_words; e += mpc::kWave) blk[e] = __builtin_nontemporal_load(r + 5 * nmax + 3 + e);
+        }
+        if (lane == 0) {
+            dt_out[inst] = __builtin_nontemporal_load(r + 5 * nmax);
+            if (status) status[inst] = (int32_t)__builtin_nontemporal_load(r + 5 * nmax + 1);
+            if (iters) iters[inst] = (int32_t)__builtin_nontemporal_load(r + 5 * nmax + 2);
+        }
     }
     if (lane == 0) {
-        dt_out[inst] = __builtin_nontemporal_load(r + 5 * nmax);
-        if (status) status[inst] = (int32_t)__builtin_nontemporal_load(r + 5 * nmax + 1);
-        if (iters) iters[inst] = (int32_t)__builtin_nontemporal_load(r + 5 * nmax + 2);
         if (cc.winner_out) cc.winner_out[inst] = w < NC ? w : -1;
         if (cc.iters_total_out) cc.iters_total_out[inst] = __hip_atomic_load(cc.it_sum + inst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // back to idle for the next launch
@@ -459,12 +463,17 @@ template <typename T>
 static hipError_t launch_prec(mpc_solver* s, const mpc::Problem<T>& P, int B, const double* x0, const double* xf, const double* up,
                         const double* dtp, const double* xi, const double* ui, const double* dti, const mpc_obstacles& ob, double* xo, double* uo,
                         double* dto, int32_t* st, int32_t* it) {
+#ifdef MPC_DEV_ONE_MODEL       // developer builds (fast compile, asm inspection): only the car-like fp64 instantiations exist
+    if (sizeof(T) == 8) return launch_model<double, mpc::MODEL_SIMPLE_CAR>(s, s->P64, B, x0, xf, up, dtp, xi, ui, dti, ob, xo, uo, dto, st, it);
+    return hipErrorInvalidConfiguration;
+#else
     switch (s->cfg.model) {
         case MPC_MODEL_UNICYCLE: return launch_model<T, mpc::MODEL_UNICYCLE>(s, P, B, x0, xf, up, dtp, xi, ui, dti, ob, xo, uo, dto, st, it);
         case MPC_MODEL_SIMPLE_CAR: return launch_model<T, mpc::MODEL_SIMPLE_CAR>(s, P, B, x0, xf, up, dtp, xi, ui, dti, ob, xo, uo, dto, st, it);
         case MPC_MODEL_SIMPLE_CAR_FRONT: return launch_model<T, mpc::MODEL_SIMPLE_CAR_FRONT>(s, P, B, x0, xf, up, dtp, xi, ui, dti, ob, xo, uo, dto, st, it);
         default: return launch_model<T, mpc::MODEL_KINEMATIC_BICYCLE>(s, P, B, x0, xf, up, dtp, xi, ui, dti, ob, xo, uo, dto, st, it);
     }
+#endif
 }
 
 extern "C" {
