@@ -36,12 +36,13 @@ BATCH_PER_GPU_MULTI = 4096     # BASELINE.json configs[3]: 32768 over 8 GPUs
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec
 FP64_VECTOR_PEAK_TF = 78.6     # SURVEY.md 8d / AMD spec, vector fp64
 FP32_VECTOR_PEAK_TF = 157.3
-# candidate initial trajectories of the headline run (include/mpc_hip.h, enum mpc_candidate_kind): the reference cold start first, then the
-# blended-heading hedges (forward, reverse) and the reverse travel direction, with falling iteration caps (a hedge starts later, its cap bounds
-# the launch time).  Chosen with the C oracle over EIGHT seeds of the config-2 distribution (>= 99.0 % converged on each, 99.5 % on average;
-# DESIGN.md section 5.4 has the measured sweep, including the faster settings that reach 99 % on the benchmark seed only).
-CAND_KINDS = (0, 3, 4, 2)
-CAND_CAPS = (60, 60, 50, 40)
+# candidate initial trajectories of the headline run (include/mpc_hip.h, enum mpc_candidate_kind): the reference cold start first, then three
+# Hermite-curve hedges (forward with tangent scales 2 and 3, forward-then-reverse with 1.5) with falling iteration caps (a hedge starts later,
+# its cap bounds the launch time).  Chosen with the C oracle over EIGHT seeds of the config-2 distribution (>= 99.3 % converged on each, 99.45 %
+# on average; DESIGN.md section 5.4 has the measured sweep).
+CAND_KINDS = (0, 5, 5, 7)
+CAND_CAPS = (60, 45, 40, 35)
+CAND_PARAMS = (0.0, 2.0, 3.0, 1.5)
 
 
 def algorithmic_bytes_per_solve(n: int, s: int = 8, obstacle_scalars: int = 0) -> int:
@@ -176,6 +177,7 @@ def main():
     ap.add_argument("--n", type=int, default=N_GRID)
     ap.add_argument("--candidates", type=str, default=",".join(str(k) for k in CAND_KINDS), help="candidate kinds in priority order; '0' = the single reference solve")
     ap.add_argument("--caps", type=str, default=",".join(str(k) for k in CAND_CAPS))
+    ap.add_argument("--params", type=str, default=",".join(str(k) for k in CAND_PARAMS), help="per candidate: tangent scale of the Hermite kinds")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the extra legs (warm start, other configs)")
     args = ap.parse_args()
@@ -201,7 +203,8 @@ def main():
     B = args.batch if args.batch > 0 else (BATCH_1GPU if world == 1 else BATCH_PER_GPU_MULTI)
     kinds = tuple(int(k) for k in args.candidates.split(","))
     caps = tuple(int(k) for k in args.caps.split(","))[:len(kinds)]
-    ckw = dict(candidates=kinds, candidate_max_iter=caps) if len(kinds) > 1 else {}
+    pars = tuple(float(k) for k in args.params.split(","))[:len(kinds)]
+    ckw = dict(candidates=kinds, candidate_max_iter=caps, candidate_param=pars) if len(kinds) > 1 else {}
     # the warm-start leg has its own solver: its handle keeps the multipliers of every instance's last converged solve (dual_warm_start) and the
     # next cycle starts from them at mu0 = 1e-3; the headline solver does not write them
     cfg = m.config_carlike_min_time(n=n, **ckw)
@@ -268,7 +271,7 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": wl + "; cold start (Controller::step on an empty grid), tol 1e-8; value counts converged solves only",
                        "n": n, "batch_per_gpu": B, "global_batch": B * world,
-                       "candidates": {"kinds": list(kinds), "max_iter": list(caps),
+                       "candidates": {"kinds": list(kinds), "max_iter": list(caps), "param": list(pars),
                                       "rule": "lowest-index candidate that converges within its cap supplies the result (index 0 = the reference cold start)"},
                        "parallelism": f"instances sharded over {world} GPU(s), no data-path collective in the timed region",
                        "seed": m.workloads.SEED_CONFIG2},
@@ -339,13 +342,13 @@ def main():
         l3.close()
         # configs[4] share: kinematic bicycle, n = 120, fp32, 1024 per GPU
         n5, B5 = 120, 1024
-        c5 = m.config_bicycle_min_time(n5, precision=1, tol=1e-4, **(dict(candidates=kinds, candidate_max_iter=tuple(100 for _ in kinds)) if len(kinds) > 1 else {}))
+        c5 = m.config_bicycle_min_time(n5, precision=1, tol=1e-4, **(dict(candidates=kinds, candidate_max_iter=tuple(100 for _ in kinds), candidate_param=pars) if len(kinds) > 1 else {}))
         l5 = Leg(m, torch, dev, c5, B5, m.workloads.bicycle_min_time_inputs(B5))
         legs["config5_share_bicycle_n120_fp32_B1024"] = leg_summary(l5, max(2, args.steps // 2), 1, algorithmic_bytes_per_solve(n5, 4), (24 + 486 + 418 + 100) * (n5 - 1), FP32_VECTOR_PEAK_TF, "bicycle_n120_fp32_B1024")
         legs["config5_share_bicycle_n120_fp32_B1024"]["dtype"] = "f32"
         l5.close()
         # the same share in MPC_MIXED: fp32 main phase + fp64 refinement (trajectories within ~1e-8 of the fp64 solve instead of ~2e-4)
-        c5m = m.config_bicycle_min_time(n5, precision=2, **(dict(candidates=kinds, candidate_max_iter=tuple(100 for _ in kinds)) if len(kinds) > 1 else {}))
+        c5m = m.config_bicycle_min_time(n5, precision=2, **(dict(candidates=kinds, candidate_max_iter=tuple(100 for _ in kinds), candidate_param=pars) if len(kinds) > 1 else {}))
         l5m = Leg(m, torch, dev, c5m, B5, m.workloads.bicycle_min_time_inputs(B5))
         legs["config5_share_bicycle_n120_mixed_B1024"] = leg_summary(l5m, max(2, args.steps // 2), 1, algorithmic_bytes_per_solve(n5, 8), (24 + 486 + 418 + 100) * (n5 - 1), FP32_VECTOR_PEAK_TF, "bicycle_n120_mixed_B1024")
         legs["config5_share_bicycle_n120_mixed_B1024"]["dtype"] = "f32 main phase + f64 refinement"

@@ -40,6 +40,7 @@ CAND_TRAVEL = 1
 CAND_TRAVEL_REVERSE = 2
 CAND_BLEND = 3
 CAND_BLEND_REVERSE = 4
+CAND_HERMITE_FF, CAND_HERMITE_RR, CAND_HERMITE_FR, CAND_HERMITE_RF = 5, 6, 7, 8
 MAX_CANDIDATES = 4
 
 
@@ -95,6 +96,7 @@ class MpcConfig(C.Structure):
         ("candidate_blend", C.c_int32),
         ("dual_warm_start", C.c_int32),
         ("mu_init_dual", C.c_double),
+        ("candidate_param", C.c_double * 4),
         ("reserved", C.c_int32 * 6),
     ]
 
@@ -117,7 +119,7 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
                 footprint_kind=0, footprint_radius=0.0, max_obstacles=0, max_vertices=1, max_obstacle_rows=4, mu_init_warm=0.0, collocation=COLLOC_FORWARD,
                 terminal_ball_S=None, terminal_ball_gamma=1.0, vp_position_weight=1e-3, vp_orientation_weight=0.0,
                 via_points_ordered=False, max_via_points=0, footprint_params=(0.0, 0.0, 0.0, 0.0),
-                enable_dynamic_obstacles=False, footprint_vertices=(), candidates=(), candidate_max_iter=(), candidate_blend=0, dual_warm_start=False, mu_init_dual=0.0) -> MpcConfig:
+                enable_dynamic_obstacles=False, footprint_vertices=(), candidates=(), candidate_max_iter=(), candidate_blend=0, dual_warm_start=False, mu_init_dual=0.0, candidate_param=()) -> MpcConfig:
     c = MpcConfig()
     c.model = model
     mp = list(model_params) + [0.0] * 4
@@ -167,6 +169,7 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
     for i, k in enumerate(candidates[:MAX_CANDIDATES]):
         c.candidate_kind[i] = int(k)
         c.candidate_max_iter[i] = int(candidate_max_iter[i]) if i < len(candidate_max_iter) else 0
+        c.candidate_param[i] = float(candidate_param[i]) if i < len(candidate_param) else 0.0
     c.candidate_blend = int(candidate_blend)
     c.dual_warm_start = int(bool(dual_warm_start))
     c.mu_init_dual = float(mu_init_dual)

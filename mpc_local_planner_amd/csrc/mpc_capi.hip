@@ -114,7 +114,7 @@ __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
         } else if (kind == 0) {
             S.cold_start();
         } else {
-            S.seed_start(kind);
+            S.seed_start(kind, Ps->cand_param[cand]);
         }
         if (L.M > 0) S.load_obstacles(obst.n_obstacles, obst.n_vertices, obst.vertices, obst.radius, obst.velocity, inst);
         if (EXT && L.NV > 0) S.load_via_points(n_via, via, inst);
@@ -306,7 +306,7 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         set_err("mpc_create: MPC_MIXED is implemented for problems without clearance rows and via-points (their association would be redone by the refinement phase)"); return MPC_EINVAL; }
     if (cfg->n_candidates < 0 || cfg->n_candidates > MPC_MAX_CANDIDATES) { set_err("mpc_create: n_candidates must be in [0, MPC_MAX_CANDIDATES]"); return MPC_EINVAL; }
     for (int k = 0; k < cfg->n_candidates; ++k)
-        if (cfg->candidate_kind[k] < MPC_CAND_REFERENCE || cfg->candidate_kind[k] > MPC_CAND_BLEND_REVERSE || cfg->candidate_max_iter[k] < 0) {
+        if (cfg->candidate_kind[k] < MPC_CAND_REFERENCE || cfg->candidate_kind[k] > MPC_CAND_HERMITE_RF || cfg->candidate_max_iter[k] < 0) {
             set_err("mpc_create: unknown candidate kind or negative candidate_max_iter"); return MPC_EINVAL; }
     if (cfg->dt_free && !(cfg->dt_lb < cfg->dt_ub)) { set_err("mpc_create: dt_lb must be below dt_ub on the variable grid"); return MPC_EINVAL; }
     if (cfg->dt_free && !(cfg->dt_ref >= cfg->dt_lb && cfg->dt_ref <= cfg->dt_ub)) { set_err("mpc_create: dt_ref must lie in [dt_lb, dt_ub] on the variable grid"); return MPC_EINVAL; }

@@ -80,6 +80,7 @@ struct Problem {
     T vp_wp, vp_wo;
     // candidate initial trajectories (wave kernel only): kinds (mpc_candidate_kind), iteration caps, heading-blend length
     int n_cand, cand_kind[4], cand_max_iter[4], cand_blend;
+    T cand_param[4];     // tangent scale of the Hermite kinds
     T mu_init_dual;      // barrier start of a solve that starts from the multipliers kept in the handle (dual_warm_start)
 };
 

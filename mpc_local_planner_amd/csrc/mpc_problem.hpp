@@ -66,6 +66,7 @@ inline void fill_problem(const mpc_config& c, mpc::Problem<T>& P) {
     for (int k = 0; k < 4; ++k) {
         P.cand_kind[k] = (c.n_candidates > 1 && k < P.n_cand) ? c.candidate_kind[k] : MPC_CAND_REFERENCE;
         P.cand_max_iter[k] = (c.n_candidates > 1 && c.candidate_max_iter[k] > 0) ? c.candidate_max_iter[k] : P.max_iter;
+        P.cand_param[k] = T((c.n_candidates > 1 && c.candidate_param[k] > 0) ? c.candidate_param[k] : 2.0);
     }
     P.cand_blend = c.candidate_blend > 0 ? c.candidate_blend : 8;
     P.mu_init_dual = T(c.mu_init_dual > 0 ? c.mu_init_dual : 1e-3);

@@ -1671,9 +1671,40 @@ struct IpmWave {
     // positions on the straight line as in cold_start(); heading = direction of travel, turned by pi when the goal lies behind the start
     // pose (initializeSequences without xinit, full_discretization_grid_base_se2.cpp:136-190), + pi for the *_REVERSE kinds; the BLEND kinds
     // turn from the start heading into that direction over the first m grid points and into the goal heading over the last m.
-    __device__ __forceinline__ void seed_start(int kind) const {
+    // Kinds 5..8 (HERMITE_FF / _RR / _FR / _RF): positions on the cubic Hermite curve between the two poses, end tangents along the headings scaled by
+    // tscale * |goal - start| and signed by the driving direction at that end; heading = tangent direction (+ pi where the robot drives backwards:
+    // the first half of the horizon takes the start's direction, the second half the goal's).
+    __device__ __forceinline__ void seed_start(int kind, T tscale = T(2)) const {
         const int n = L.n;
         const T ddx = xf[0] - x0[0], ddy = xf[1] - x0[1];
+        if (kind >= 5) {
+            const T sg0 = (kind == 5 || kind == 7) ? T(1) : T(-1), sg1 = (kind == 5 || kind == 8) ? T(1) : T(-1);
+            const T dd = sqrt(ddx * ddx + ddy * ddy);
+            T s0_, c0_, s1_, c1_;
+            t_sincos(x0[2], &s0_, &c0_);
+            t_sincos(xf[2], &s1_, &c1_);
+            const T m0x = sg0 * tscale * dd * c0_, m0y = sg0 * tscale * dd * s0_, m1x = sg1 * tscale * dd * c1_, m1y = sg1 * tscale * dd * s1_;
+            for (int k = lane; k < n; k += kWave) {
+                const T t = T(k) / T(n - 1), t2 = t * t, t3 = t2 * t;
+                const T h00 = T(2) * t3 - T(3) * t2 + T(1), h10 = t3 - T(2) * t2 + t, h01 = T(-2) * t3 + T(3) * t2, h11 = t3 - t2;
+                const T g00 = T(6) * t2 - T(6) * t, g10 = T(3) * t2 - T(4) * t + T(1), g01 = T(-6) * t2 + T(6) * t, g11 = T(3) * t2 - T(2) * t;
+                T xk[3];
+                if (k == 0) { xk[0] = x0[0]; xk[1] = x0[1]; xk[2] = x0[2]; }
+                else if (k == n - 1) { xk[0] = xf[0]; xk[1] = xf[1]; xk[2] = xf[2]; }
+                else {
+                    xk[0] = h00 * x0[0] + h10 * m0x + h01 * xf[0] + h11 * m1x;
+                    xk[1] = h00 * x0[1] + h10 * m0y + h01 * xf[1] + h11 * m1y;
+                    const T tx = g00 * x0[0] + g10 * m0x + g01 * xf[0] + g11 * m1x, ty = g00 * x0[1] + g10 * m0y + g01 * xf[1] + g11 * m1y;
+                    T th = t_atan2(ty, tx);
+                    if ((2 * k < n - 1 ? sg0 : sg1) < T(0)) th = normalize_theta(th + T(3.14159265358979323846));
+                    xk[2] = th;
+                }
+                for (int i = 0; i < 3; ++i) F(L.X, i, k) = xk[i];
+                if (k < n - 1) { F(L.U, 0, k) = T(0); F(L.U, 1, k) = T(0); }
+            }
+            if (lane == 0) SCL(SC_D) = P.dt_ref;
+            return;
+        }
         T orient = t_atan2(ddy, ddx);
         T s0, c0;
         t_sincos(x0[2], &s0, &c0);

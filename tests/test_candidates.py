@@ -103,3 +103,43 @@ def test_candidate_rule_on_config2_with_the_c_oracle(c_oracle):
     ref_ok = allr[0][3] == 0
     assert (win[ref_ok] == 0).all() and np.array_equal(x[ref_ok], allr[0][0][ref_ok])
     assert (it[st == 0] <= 60).all() and (win >= 1).mean() > 0.1
+
+
+def test_hermite_candidates_are_smooth_curves_between_the_poses():
+    """kinds 5..8 (ours): cubic Hermite curve from the start pose to the goal pose, heading along the tangent (+ pi where the robot drives
+    backwards).  End poses exact, the curve leaves / arrives along the pose headings, forward and reverse variants mirror each other's heading."""
+    from oracle import candidates as OC
+    x0, xf, _, _ = m.workloads.carlike_min_time_inputs(64, seed=6)
+    n = 50
+    ff = OC.guess(OC.HERMITE_FF, x0, xf, n, 0.3, param=2.0)[0]
+    rr = OC.guess(OC.HERMITE_RR, x0, xf, n, 0.3, param=2.0)[0]
+    fr = OC.guess(OC.HERMITE_FR, x0, xf, n, 0.3, param=2.0)[0]
+    for g in (ff, rr, fr):
+        np.testing.assert_array_equal(g[:, 0], np.c_[x0[:, :2], OC.wrap(x0[:, 2])])
+        np.testing.assert_array_equal(g[:, -1], np.c_[xf[:, :2], OC.wrap(xf[:, 2])])
+    # forward-forward: the first step leaves along the start heading, the last one arrives along the goal heading
+    d0 = ff[:, 1, :2] - ff[:, 0, :2]; d1 = ff[:, -1, :2] - ff[:, -2, :2]
+    assert (np.abs(OC.wrap(np.arctan2(d0[:, 1], d0[:, 0]) - x0[:, 2])) < 0.15).all() and (np.abs(OC.wrap(np.arctan2(d1[:, 1], d1[:, 0]) - xf[:, 2])) < 0.15).all()
+    # the heading of the guess is the tangent direction (forward) / its opposite (reverse)
+    t = ff[:, 11, :2] - ff[:, 9, :2]
+    assert (np.abs(OC.wrap(ff[:, 10, 2] - np.arctan2(t[:, 1], t[:, 0]))) < 0.05).all()
+    t = rr[:, 11, :2] - rr[:, 9, :2]
+    assert (np.abs(OC.wrap(rr[:, 10, 2] - np.arctan2(t[:, 1], t[:, 0]) - np.pi)) < 0.05).all()
+    # forward-reverse: forward in the first half, backwards in the second
+    t = fr[:, 41, :2] - fr[:, 39, :2]
+    assert (np.abs(OC.wrap(fr[:, 40, 2] - np.arctan2(t[:, 1], t[:, 0]) - np.pi)) < 0.05).all()
+    np.testing.assert_array_equal(fr[:, :24, :2], OC.guess(OC.HERMITE_FR, x0, xf, n, 0.3, param=2.0)[0][:, :24, :2])
+
+
+def test_hermite_hedges_on_config2_with_the_c_oracle(c_oracle):
+    """bench.py's candidate set (reference cold start + three Hermite hedges, caps 60 / 45 / 40 / 35) on the config-2 workload with the C oracle:
+    >= 99 % converged, the reference path keeps every instance it solves within its cap."""
+    from oracle import candidates as OC
+    B, n = 256, 50
+    x0, xf, up, dtp = m.workloads.carlike_min_time_inputs(B)
+    ocfg = R.config_carlike_min_time(n)
+    kinds, caps, pars = (OC.REFERENCE, OC.HERMITE_FF, OC.HERMITE_FF, OC.HERMITE_FR), (60, 45, 40, 35), (0.0, 2.0, 3.0, 1.5)
+    x, u, dt, st, it, win, low, allr = OC.solve_candidates(c_oracle, lambda cap: c_oracle.from_nlp_config(ocfg, max_iter=cap), x0, xf, up, dtp, kinds, caps, n, ocfg.dt_ref, params=pars)
+    assert (st == 0).mean() >= 0.99
+    ref_ok = allr[0][3] == 0
+    assert (win[ref_ok] == 0).all() and np.array_equal(x[ref_ok], allr[0][0][ref_ok])

@@ -104,19 +104,19 @@ def test_candidates_full_batch_winners_vs_oracle_rule(m, c_oracle):
     from oracle import candidates as OC
     from mpc_local_planner_amd import _abi as A
     B, n = 1024, 50
-    kinds, caps = (A.CAND_REFERENCE, A.CAND_BLEND, A.CAND_BLEND_REVERSE), (60, 60, 60)
+    kinds, caps, pars = (A.CAND_REFERENCE, A.CAND_HERMITE_FF, A.CAND_HERMITE_FF, A.CAND_HERMITE_FR), (60, 45, 40, 35), (0.0, 2.0, 3.0, 1.5)      # bench.py's set
     _, ocfg = _cases(m)["carlike_min_time_n50"]
     inputs = m.workloads.carlike_min_time_inputs(B)
-    s = m.BatchSolver(m.config_carlike_min_time(n, candidates=kinds, candidate_max_iter=caps), max_batch=B)
+    s = m.BatchSolver(m.config_carlike_min_time(n, candidates=kinds, candidate_max_iter=caps, candidate_param=pars), max_batch=B)
     r = s.solve(*inputs)
     win, tot = s.last_candidates(B)
     r2 = s.solve(*inputs)                                   # hedging is timing dependent, the RESULT must not be
     win2, _ = s.last_candidates(B)
     np.testing.assert_array_equal(r.x, r2.x); np.testing.assert_array_equal(win, win2); np.testing.assert_array_equal(r.iters, r2.iters)
-    ox, ou, od, ost, oit, owin, olow, allr = OC.solve_candidates(c_oracle, lambda cap: c_oracle.from_nlp_config(ocfg, max_iter=cap), *inputs, kinds, caps, n, ocfg.dt_ref)
+    ox, ou, od, ost, oit, owin, olow, allr = OC.solve_candidates(c_oracle, lambda cap: c_oracle.from_nlp_config(ocfg, max_iter=cap), *inputs, kinds, caps, n, ocfg.dt_ref, params=pars)
     conv = r.status == 0
-    print(f"[candidates] device converged {conv.mean():.4f} (oracle rule {np.mean(ost == 0):.4f}); winners device {np.bincount(win + 1, minlength=4).tolist()} "
-          f"oracle {np.bincount(owin + 1, minlength=4).tolist()} (index 0 = none); equal winners {np.mean(win == owin):.4f}; winner iterations p99 {np.percentile(r.iters[conv], 99):.0f}")
+    print(f"[candidates] device converged {conv.mean():.4f} (oracle rule {np.mean(ost == 0):.4f}); winners device {np.bincount(win + 1, minlength=5).tolist()} "
+          f"oracle {np.bincount(owin + 1, minlength=5).tolist()} (index 0 = none); equal winners {np.mean(win == owin):.4f}; winner iterations p99 {np.percentile(r.iters[conv], 99):.0f}")
     assert conv.mean() >= 0.99 and (win[conv] >= 0).all() and (win[~conv] == -1).all()
     assert (r.iters[conv] <= np.asarray(caps)[win[conv]]).all() and (tot >= r.iters).all()
     assert np.mean(win == owin) > 0.97
