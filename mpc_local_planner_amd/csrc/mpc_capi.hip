@@ -388,8 +388,8 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         if (er == hipSuccess) er = hipMalloc((void**)&s->d_dual, Bm * (size_t)s->dual_words * 8);
         if (er == hipSuccess) er = hipMemset(s->d_dual, 0, Bm * (size_t)s->dual_words * 8);
     }
-    if (s->P64.n_cand > 1) {
-        const size_t C_ = s->P64.n_cand;
+    if (s->P32.n_cand > 1) {
+        const size_t C_ = s->P32.n_cand;
         if (er == hipSuccess) er = hipMalloc((void**)&s->d_cwin, Bm * 4);
         if (er == hipSuccess) er = hipMalloc((void**)&s->d_cexited, Bm * 4);
         if (er == hipSuccess) er = hipMalloc((void**)&s->d_citsum, Bm * 4);
@@ -526,7 +526,7 @@ int mpc_last_candidates(mpc_solver* s, int32_t B, int32_t* winner, int32_t* iter
     if (B > s->max_batch) { set_err("mpc_last_candidates: B exceeds max_batch"); return MPC_EBATCH; }
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipStreamSynchronize(s->stream));
-    if (s->P64.n_cand > 1) {
+    if (s->P32.n_cand > 1) {
         if (winner) HIP_TRY(hipMemcpy(winner, s->d_winner, (size_t)B * 4, hipMemcpyDeviceToHost));
         if (iters_total) HIP_TRY(hipMemcpy(iters_total, s->d_iters_total, (size_t)B * 4, hipMemcpyDeviceToHost));
         return MPC_OK;
