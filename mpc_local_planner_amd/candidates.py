@@ -1,4 +1,7 @@
-"""Candidate initial trajectories for one planner instance, solved as extra members of the same batch.
+"""Candidate initial trajectories for one planner instance, HOST-SIDE variant: the guesses go in through x_init / u_init / dt_init as extra
+members of the same batch and the winner is picked on the host.  Since round 2 the library does this on the device (mpc_config.n_candidates:
+seeds generated in the kernel, hedged workgroups, deterministic lowest-converged-index rule) -- this module stays for
+callers that bring their own guesses or want another selection rule (here: shortest transition time among the converged candidates).
 
 BASELINE.json's north star names "candidate initial trajectories" next to independent planner instances as what a batch holds.  The
 interior-point solve is local: which driving-direction reversals the solution contains is decided by the initial guess (DESIGN.md section 9,
