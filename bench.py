@@ -180,6 +180,8 @@ def main():
     ap.add_argument("--params", type=str, default=",".join(str(k) for k in CAND_PARAMS), help="per candidate: tangent scale of the Hermite kinds")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the extra legs (warm start, other configs)")
+    ap.add_argument("--force-dist", action="store_true", help="developer check on a one-GPU box: take the N > 1 code path (process group, barriers, RCCL "
+                    "all-gather of the results) with a world of one rank")
     args = ap.parse_args()
 
     import torch
@@ -195,12 +197,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     torch.zeros(1, device=dev)
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
 
     n = args.n
-    B = args.batch if args.batch > 0 else (BATCH_1GPU if world == 1 else BATCH_PER_GPU_MULTI)
+    B = args.batch if args.batch > 0 else (BATCH_PER_GPU_MULTI if multi else BATCH_1GPU)
     kinds = tuple(int(k) for k in args.candidates.split(","))
     caps = tuple(int(k) for k in args.caps.split(","))[:len(kinds)]
     pars = tuple(float(k) for k in args.params.split(","))[:len(kinds)]
@@ -215,7 +219,7 @@ def main():
     for _ in range(args.warmup):
         leg.step()
     leg.sync()
-    if world > 1:
+    if multi:
         dist.barrier()
     leg.sync()
     kernel_ms = []
@@ -225,7 +229,7 @@ def main():
         leg.solver.synchronize()          # a control cycle ends when its commands are available
         kernel_ms.append(leg.solver.last_kernel_ms())
     leg.sync()
-    if world > 1:
+    if multi:
         dist.barrier()
     leg.sync()
     elapsed = time.perf_counter() - t0
@@ -235,13 +239,13 @@ def main():
     # ---- N > 1: every rank ends with the whole job's results (RCCL all-gather of HBM-resident arrays), outside the timed region
     gather = None
     n_conv_total = int(ok.sum())
-    if world > 1:
+    if multi:
         total = B * world
         torch.cuda.synchronize()
         tg = time.perf_counter()
-        g_st = sharding.gather_results(leg.st, world, total)
-        g_dt = sharding.gather_results(leg.do, world, total)
-        g_x = sharding.gather_results(leg.xo, world, total)
+        g_st = sharding.gather_results(leg.st, world, total, force=args.force_dist)
+        g_dt = sharding.gather_results(leg.do, world, total, force=args.force_dist)
+        g_x = sharding.gather_results(leg.xo, world, total, force=args.force_dist)
         torch.cuda.synchronize()
         tg = time.perf_counter() - tg
         lo, hi = sharding.shard_range(total, world, rank)
@@ -291,7 +295,7 @@ def main():
             line["gather"] = gather
 
     # ---- extra legs (N = 1 only; after the timed region)
-    if world == 1 and not args.no_legs:
+    if not multi and not args.no_legs:
         legs = {}
         # warm start, reported separately: the plant advances one controller period (0.2 s) with u_0, the previous solution is
         # the initial guess with x0 overwritten (full_discretization_grid_base_se2.cpp:101-110; variable grid: no shifting)
@@ -359,12 +363,19 @@ def main():
                                      "note": "bench.py --gpus N>1 runs configs[3] (4096 instances per GPU); its per-GPU reference on one GPU is this leg, not the N=1 headline (1024 instances)"}
     else:
         leg.close()
-    if rank == 0:
-        if not args.no_cpu_baseline and world == 1:
-            line["cpu_baseline"] = cpu_baseline(n)
-        print(json.dumps(line))
-    if world > 1:
+    if rank == 0 and not args.no_cpu_baseline and not multi:
+        line["cpu_baseline"] = cpu_baseline(n)
+    if multi:
         dist.destroy_process_group()
+    if rank == 0:
+        # the JSON line goes out LAST: RCCL prints a version banner through C stdio, which a pipe would otherwise deliver after python's buffer
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

@@ -20,14 +20,14 @@ def rank_seed(seed: int, rank: int) -> int:
     return seed + rank
 
 
-def gather_results(local, world: int, total: int, device=None):
+def gather_results(local, world: int, total: int, device=None, force: bool = False):
     """all_gather of a per-rank result array along axis 0 into the global array (ragged shards allowed).
     `local` is a numpy array or a torch tensor.  A device-resident tensor is gathered where it lives (RCCL moves HBM to HBM); a numpy
     array / CPU tensor is staged on `device` first when the process group's backend is nccl (= RCCL, which only moves device memory).
     Returns the same kind of object it was given."""
     import torch
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not force:      # force: run the collective even in a world of one rank (developer check of the RCCL path)
         return local
     is_np = isinstance(local, np.ndarray)
     t = torch.from_numpy(np.ascontiguousarray(local)) if is_np else local
