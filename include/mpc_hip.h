@@ -76,6 +76,15 @@ enum mpc_candidate_kind {
 };
 #define MPC_MAX_CANDIDATES 4
 
+enum mpc_hessian_mode {
+    MPC_HESSIAN_EXACT = 0,            /* exact Lagrangian Hessian (analytic) + inertia-free regularisation: the default */
+    MPC_HESSIAN_CONVEXIFIED = 1       /* every stage block of the constraint curvature lam' D over (theta, v, w, dt) replaced by its positive semidefinite
+                                       * part: hardly any regularisation retries (1.03 instead of 1.2 factorisations per iteration) but linear instead of
+                                       * quadratic local convergence.  With tol = 1e-4 this is the "reference-like" setting: the car-like example runs
+                                       * Ipopt with tol 1e-4 and a limited-memory (positive definite) Hessian because the exact one "does currently not
+                                       * work well with the carlike model" (cfg/carlike/mpc_local_planner_params.yaml:91-95). */
+};
+
 enum mpc_status {                     /* per-instance result; 0 == what corbo reports as Converged */
     MPC_CONVERGED = 0,
     MPC_MAX_ITER = 1,
@@ -161,6 +170,7 @@ typedef struct mpc_config {
     int32_t dual_warm_start;
     double  mu_init_dual;             /* barrier start of such a solve (0 -> 1e-3) */
     double  candidate_param[MPC_MAX_CANDIDATES];      /* per candidate: tangent scale of the MPC_CAND_HERMITE_* kinds (0 -> 2.0) */
+    int32_t hessian_mode;             /* MPC_HESSIAN_EXACT | MPC_HESSIAN_CONVEXIFIED (solver/ipopt/ipopt_string_options/hessian_approximation, :407-418) */
     int32_t reserved[6];
 } mpc_config;
 

@@ -97,6 +97,7 @@ class MpcConfig(C.Structure):
         ("dual_warm_start", C.c_int32),
         ("mu_init_dual", C.c_double),
         ("candidate_param", C.c_double * 4),
+        ("hessian_mode", C.c_int32),
         ("reserved", C.c_int32 * 6),
     ]
 
@@ -119,7 +120,7 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
                 footprint_kind=0, footprint_radius=0.0, max_obstacles=0, max_vertices=1, max_obstacle_rows=4, mu_init_warm=0.0, collocation=COLLOC_FORWARD,
                 terminal_ball_S=None, terminal_ball_gamma=1.0, vp_position_weight=1e-3, vp_orientation_weight=0.0,
                 via_points_ordered=False, max_via_points=0, footprint_params=(0.0, 0.0, 0.0, 0.0),
-                enable_dynamic_obstacles=False, footprint_vertices=(), candidates=(), candidate_max_iter=(), candidate_blend=0, dual_warm_start=False, mu_init_dual=0.0, candidate_param=()) -> MpcConfig:
+                enable_dynamic_obstacles=False, footprint_vertices=(), candidates=(), candidate_max_iter=(), candidate_blend=0, dual_warm_start=False, mu_init_dual=0.0, candidate_param=(), hessian_mode=0) -> MpcConfig:
     c = MpcConfig()
     c.model = model
     mp = list(model_params) + [0.0] * 4
@@ -173,6 +174,7 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
     c.candidate_blend = int(candidate_blend)
     c.dual_warm_start = int(bool(dual_warm_start))
     c.mu_init_dual = float(mu_init_dual)
+    c.hessian_mode = int(hessian_mode)
     return c
 
 

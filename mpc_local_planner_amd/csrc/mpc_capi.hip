@@ -233,7 +233,7 @@ struct mpc_solver {
 // which kernel instantiation serves this solver: the one with the rarely used rows / terms / coupling slots, or the headline one
 static bool solver_ext(const mpc_solver* s) {
     const mpc::Problem<double>& P = s->P64;
-    return P.ball || P.via || P.integral_form || P.dyn_obst ||
+    return P.ball || P.via || P.integral_form || P.dyn_obst || P.hess_mode ||
            (P.n_obst > 0 && (P.footprint_kind == MPC_FOOTPRINT_LINE || P.footprint_kind == MPC_FOOTPRINT_TWO_CIRCLES || P.footprint_kind == MPC_FOOTPRINT_POLYGON));
 }
 
@@ -304,6 +304,7 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
     if (cfg->precision != MPC_FP64 && cfg->precision != MPC_FP32 && cfg->precision != MPC_MIXED) { set_err("mpc_create: unknown precision"); return MPC_EINVAL; }
     if (cfg->precision == MPC_MIXED && (cfg->max_obstacles > 0 || cfg->objective == MPC_OBJ_MIN_TIME_VIA_POINTS)) {
         set_err("mpc_create: MPC_MIXED is implemented for problems without clearance rows and via-points (their association would be redone by the refinement phase)"); return MPC_EINVAL; }
+    if (cfg->hessian_mode != MPC_HESSIAN_EXACT && cfg->hessian_mode != MPC_HESSIAN_CONVEXIFIED) { set_err("mpc_create: unknown hessian_mode"); return MPC_EINVAL; }
     if (cfg->n_candidates < 0 || cfg->n_candidates > MPC_MAX_CANDIDATES) { set_err("mpc_create: n_candidates must be in [0, MPC_MAX_CANDIDATES]"); return MPC_EINVAL; }
     for (int k = 0; k < cfg->n_candidates; ++k)
         if (cfg->candidate_kind[k] < MPC_CAND_REFERENCE || cfg->candidate_kind[k] > MPC_CAND_HERMITE_RF || cfg->candidate_max_iter[k] < 0) {

@@ -81,6 +81,7 @@ struct Problem {
     // candidate initial trajectories (wave kernel only): kinds (mpc_candidate_kind), iteration caps, heading-blend length
     int n_cand, cand_kind[4], cand_max_iter[4], cand_blend;
     T cand_param[4];     // tangent scale of the Hermite kinds
+    int hess_mode;       // 0 exact Lagrangian Hessian, 1 convexified (stage-wise positive semidefinite part; EXT kernel instantiation)
     T mu_init_dual;      // barrier start of a solve that starts from the multipliers kept in the handle (dual_warm_start)
 };
 
@@ -389,6 +390,36 @@ struct StageMap {
     T Hqd[3];        // d2 (lam' D) / d(theta, v, w) d dt
     T Hdd;           // d2 (lam' D) / d dt^2
 };
+// MPC_HESSIAN_CONVEXIFIED: the stage block [Hqq Hqd; Hqd' Hdd] of the Lagrangian curvature lam' D over (theta, v, w, dt) is replaced by its
+// positive semidefinite part (cyclic Jacobi eigen-decomposition of the 4 x 4 block, negative eigenvalues set to 0); drop_theta: the heading
+// of this stage is not a variable (stage 0), its row / column is removed first.  The C restatement used by the tests runs the same arithmetic.
+template <typename T>
+MPC_HD void psd_project4(StageMap<T>& sm, bool drop_theta) {
+    T A[4][4], V[4][4];
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) A[i][j] = sm.Hqq[i][j]; A[i][3] = A[3][i] = sm.Hqd[i]; }
+    A[3][3] = sm.Hdd;
+    if (drop_theta) for (int j = 0; j < 4; ++j) A[0][j] = A[j][0] = T(0);
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) V[i][j] = i == j ? T(1) : T(0);
+    for (int sweep = 0; sweep < 30; ++sweep) {
+        T off = T(0);
+        for (int p = 0; p < 4; ++p) for (int q = p + 1; q < 4; ++q) off += A[p][q] * A[p][q];
+        if (off < T(1e-30)) break;
+        for (int p = 0; p < 4; ++p) for (int q = p + 1; q < 4; ++q) {
+            if (!(t_abs(A[p][q]) >= T(1e-300))) continue;      // (fp32: the constant rounds to 0, exact zeros are skipped)
+            if (A[p][q] == T(0)) continue;
+            const T th = (A[q][q] - A[p][p]) / (T(2) * A[p][q]);
+            const T t = (th >= T(0) ? T(1) : T(-1)) / (t_abs(th) + sqrt(th * th + T(1))), c = T(1) / sqrt(t * t + T(1)), sn = t * c;
+            for (int k = 0; k < 4; ++k) { const T akp = A[k][p], akq = A[k][q]; A[k][p] = c * akp - sn * akq; A[k][q] = sn * akp + c * akq; }
+            for (int k = 0; k < 4; ++k) { const T apk = A[p][k], aqk = A[q][k]; A[p][k] = c * apk - sn * aqk; A[q][k] = sn * apk + c * aqk; }
+            for (int k = 0; k < 4; ++k) { const T vkp = V[k][p], vkq = V[k][q]; V[k][p] = c * vkp - sn * vkq; V[k][q] = sn * vkp + c * vkq; }
+        }
+    }
+    T R[4][4];
+    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) { T v = T(0); for (int k = 0; k < 4; ++k) v += V[i][k] * (A[k][k] > T(0) ? A[k][k] : T(0)) * V[j][k]; R[i][j] = v; }
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) sm.Hqq[i][j] = R[i][j]; sm.Hqd[i] = R[i][3]; }
+    sm.Hdd = R[3][3];
+}
+
 template <typename T, int MODEL>
 MPC_HD void stage_map(const Problem<T>& P, const T tr[4], const T tr2[2], T v, T w, T d, const T lam[3], StageMap<T>& o) {
     T G[3][3], Hq[3][3];

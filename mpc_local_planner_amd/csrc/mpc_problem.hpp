@@ -70,6 +70,7 @@ inline void fill_problem(const mpc_config& c, mpc::Problem<T>& P) {
     }
     P.cand_blend = c.candidate_blend > 0 ? c.candidate_blend : 8;
     P.mu_init_dual = T(c.mu_init_dual > 0 ? c.mu_init_dual : 1e-3);
+    P.hess_mode = c.hessian_mode == MPC_HESSIAN_CONVEXIFIED ? 1 : 0;
 }
 
 

@@ -199,6 +199,7 @@ struct IpmWave {
     __device__ __forceinline__ bool fpline() const { return EXT && ((flags >> 12) & 1); }
     __device__ __forceinline__ bool intf() const { return EXT && ((flags >> 13) & 1); }     // integral-form cost, dt free
     __device__ __forceinline__ bool dynobs() const { return EXT && ((flags >> 14) & 1); }
+    __device__ __forceinline__ bool hessm() const { return EXT && ((flags >> 15) & 1); }      // convexified Hessian
     // explicit LDS pointers for the running-pointer loops (address-space inference gives up on per-lane selected pointers)
     typedef __attribute__((address_space(3))) T LdsT;
     __device__ __forceinline__ LdsT* lds(int word) const { return (LdsT*)sm + word; }
@@ -973,6 +974,15 @@ struct IpmWave {
             sp.h11 = S_(RA + A66, k); sp.h12 = S_(RA + A67, k); sp.h22 = S_(RA + A77, k);
             sp.g[0] = S_(RA + A25, k); sp.g[1] = S_(RA + A56, k); sp.g[2] = S_(RA + A57, k);
             sp.hdd = k < n - 1 ? S_(RA + A55, k) : T(0);
+            if (EXT && hessm() && k < n - 1) {       // MPC_HESSIAN_CONVEXIFIED: positive semidefinite part of the stage's curvature block (theta, v, w, dt)
+                StageMap<T> pm;
+                pm.Hqq[0][0] = sp.h00; pm.Hqq[0][1] = pm.Hqq[1][0] = sp.h01; pm.Hqq[0][2] = pm.Hqq[2][0] = sp.h02;
+                pm.Hqq[1][1] = sp.h11; pm.Hqq[1][2] = pm.Hqq[2][1] = sp.h12; pm.Hqq[2][2] = sp.h22;
+                pm.Hqd[0] = sp.g[0]; pm.Hqd[1] = sp.g[1]; pm.Hqd[2] = sp.g[2]; pm.Hdd = sp.hdd;
+                psd_project4(pm, k == 0);
+                sp.h00 = pm.Hqq[0][0]; sp.h01 = pm.Hqq[0][1]; sp.h02 = pm.Hqq[0][2]; sp.h11 = pm.Hqq[1][1]; sp.h12 = pm.Hqq[1][2]; sp.h22 = pm.Hqq[2][2];
+                sp.g[0] = pm.Hqd[0]; sp.g[1] = pm.Hqd[1]; sp.g[2] = pm.Hqd[2]; sp.hdd = pm.Hdd;
+            }
             sp.hx[0] = sp.hx[1] = sp.hx[2] = T(0);
             if (quad && k < n - 1) {
                 sp.hx[0] = q2[0] * (F(L.X, 0, k) - xf[0]); sp.hx[1] = q2[1] * (F(L.X, 1, k) - xf[1]);
@@ -1848,7 +1858,7 @@ struct IpmWave {
     __device__ __forceinline__ SolveStats<T> solve() {
         SolveStats<T> out;
         flags = (P.xf_fixed[0] ? 1 : 0) | (P.xf_fixed[1] ? 2 : 0) | (P.xf_fixed[2] ? 4 : 0) | (P.dt_free ? 8 : 0) | (P.objective == OBJ_QUADRATIC ? 16 : 0) |
-                (P.has_Qf ? 32 : 0) | (P.rate_on[0] ? 64 : 0) | (P.rate_on[1] ? 128 : 0) | (P.rate_on[2] ? 256 : 0) | (P.rate_on[3] ? 512 : 0) | (P.ball ? 1024 : 0) | (P.via ? 2048 : 0) | ((P.n_obst > 0 && (P.footprint_kind == 2 || P.footprint_kind == 3 || P.footprint_kind == 4)) ? 4096 : 0) | (P.integral_form ? 8192 : 0) | (P.dyn_obst ? 16384 : 0);
+                (P.has_Qf ? 32 : 0) | (P.rate_on[0] ? 64 : 0) | (P.rate_on[1] ? 128 : 0) | (P.rate_on[2] ? 256 : 0) | (P.rate_on[3] ? 512 : 0) | (P.ball ? 1024 : 0) | (P.via ? 2048 : 0) | ((P.n_obst > 0 && (P.footprint_kind == 2 || P.footprint_kind == 3 || P.footprint_kind == 4)) ? 4096 : 0) | (P.integral_form ? 8192 : 0) | (P.dyn_obst ? 16384 : 0) | (P.hess_mode ? 32768 : 0);
         flags = __builtin_amdgcn_readfirstlane(flags);
         nfix = (int)fx(0) + (int)fx(1) + (int)fx(2);
         row0_on = dtprev != T(0);

@@ -22,6 +22,7 @@ class OracleConfig(C.Structure):
         ("via", C.c_int32), ("vp_ordered", C.c_int32), ("vp_wp", C.c_double), ("vp_wo", C.c_double),
         ("ball", C.c_int32), ("ball_S", C.c_double * 3), ("ball_gamma", C.c_double),
         ("integral", C.c_int32),
+        ("hessian_mode", C.c_int32),
     ]
 
 
@@ -46,7 +47,7 @@ def _load():
     return _lib
 
 
-def from_nlp_config(cfg, max_iter=100, tol=1e-8, mu_init=0.1) -> OracleConfig:
+def from_nlp_config(cfg, max_iter=100, tol=1e-8, mu_init=0.1, hessian_mode=0) -> OracleConfig:
     """oracle.se2_nlp.OcpConfig -> OracleConfig"""
     o = OracleConfig()
     o.model = cfg.model
@@ -65,6 +66,7 @@ def from_nlp_config(cfg, max_iter=100, tol=1e-8, mu_init=0.1) -> OracleConfig:
         o.u_lb[j], o.u_ub[j] = cfg.u_lb[j], cfg.u_ub[j]
         o.du_lb[j], o.du_ub[j] = max(cfg.du_lb[j], -1e30), min(cfg.du_ub[j], 1e30)
     o.max_iter, o.tol, o.mu_init = max_iter, tol, mu_init
+    o.hessian_mode = int(hessian_mode)
     o.collocation = int(getattr(cfg, "collocation", 0))
     o.integral = int(bool(getattr(cfg, "integral_form", False)) and cfg.objective == 1)
     if getattr(cfg, "terminal_ball_S", None) is not None:

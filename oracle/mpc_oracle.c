@@ -65,6 +65,8 @@ typedef struct oracle_config {
     int32_t ball;               /* terminal l2-ball row xd' S xd - gamma <= 0 on the free final state (final_state_conditions_se2.cpp:54-64) */
     double ball_S[3], ball_gamma;
     int32_t integral;           /* quadratic objective in integral form: stage cost x dt (left sum; quadratic_cost_se2.cpp:54-83, finite_differences_grid_se2.cpp:61-75) */
+    int32_t hessian_mode;       /* 0 exact Lagrangian Hessian; 1 convexified: the stage block [Hqq Hqd; Hqd' Hdd] of lam' D is replaced by its
+                                 * positive semidefinite part (the product's MPC_HESSIAN_CONVEXIFIED, the "reference-like" mode) */
 } oracle_config;
 
 #define PI 3.14159265358979323846
@@ -817,7 +819,7 @@ static void assemble(work_t* w, const double* cc, double delta, double dc, doubl
             w->rhs[row] = -cc[3 * k + a];
         }
         if (k == n - 2) for (int a = 0; a < 3; ++a) if (c->xf_fixed[a]) band_add(w, il(k, a), il(k, a), -dc);
-        if (g_variant == 3) psd_project4(&sm, qi[0] < 0);      /* experiment: stage-wise convexification of the Lagrangian curvature */
+        if (g_variant == 3 || c->hessian_mode == 1) psd_project4(&sm, qi[0] < 0);      /* stage-wise convexification of the Lagrangian curvature */
         /* Lagrangian curvature */
         for (int j = 0; j < 3; ++j) {
             if (qi[j] < 0) continue;

@@ -273,3 +273,31 @@ def test_feasibility_check_bit_exact_vs_numpy_restatement(m):
         assert 0 < ref.sum() < B          # both outcomes occur
     s.set_grid_sizes(None)
     s.close()
+
+
+def test_convexified_hessian_reference_like_mode(m, c_oracle):
+    """MPC_HESSIAN_CONVEXIFIED (+ tol 1e-4 = the "reference-like" setting: the car-like example YAML runs Ipopt with tol 1e-4 and a positive
+    definite limited-memory Hessian, cfg/carlike/mpc_local_planner_params.yaml:91-95): every stage block of the constraint curvature is
+    replaced by its positive semidefinite part.  Device vs the C oracle running the same mode (config 2, B = 256): same converged set, same
+    iterates; and -- what the mode is for -- (almost) no regularisation retries, at the price of more iterations than the exact Hessian."""
+    from oracle import se2_nlp as R
+    from mpc_local_planner_amd import _abi as A
+    B, n = 256, 50
+    inputs = m.workloads.carlike_min_time_inputs(B)
+    ocfg = R.config_carlike_min_time(n)
+    for tol in (1e-8, 1e-4):
+        s = m.BatchSolver(m.config_carlike_min_time(n, hessian_mode=1, tol=tol), max_batch=B)
+        r = s.solve(*inputs)
+        ref = c_oracle.solve_batch(c_oracle.from_nlp_config(ocfg, tol=tol, hessian_mode=1), *inputs)
+        both = (r.status == 0) & (ref[3] == 0)
+        err = np.abs(r.x - ref[0]).reshape(B, -1).max(1)
+        print(f"[convexified Hessian, tol {tol:g}] converged device {np.mean(r.status == 0):.3f} oracle {np.mean(ref[3] == 0):.3f}; iterations device {r.iters.mean():.1f} oracle {ref[4].mean():.1f}; "
+              f"median |d| {np.median(err[both]):.1e}; within 1e-4: {np.mean(err[both] < 1e-4):.3f}")
+        assert (r.status == ref[3]).mean() > 0.93 and np.median(err[both]) < (1e-7 if tol < 1e-6 else 1e-5)
+        if tol < 1e-6:
+            account(f"convexified Hessian, B={B}", ocfg, inputs, r, ref)
+        s.close()
+    se = m.BatchSolver(m.config_carlike_min_time(n), max_batch=B)
+    re = se.solve(*inputs)
+    assert r.iters.mean() < 1.6 * re.iters.mean()
+    se.close()
