@@ -358,6 +358,22 @@ def main():
         legs["config5_share_bicycle_n120_mixed_B1024"]["dtype"] = "f32 main phase + f64 refinement"
         legs["config5_share_bicycle_n120_mixed_B1024"]["roofline"]["note"] = "kernel_ms = both phases (two launches of mpc_ipm_wave_kernel); iterations of the fp64 phase are included in iters"
         l5m.close()
+        # B = 1: what ONE move_base instance pays per control cycle -- Controller::step through the host-pointer entry (PCIe and launch included),
+        # 256 different config-2 instances solved one at a time, cold start with the headline's candidates (all of them run concurrently here)
+        s1 = m.BatchSolver(cfg, max_batch=1, device=local_rank)
+        xs = m.workloads.carlike_min_time_inputs(256)
+        lat, ok1 = [], []
+        for i in range(260):
+            j = i % 256
+            t1 = time.perf_counter()
+            r1 = s1.solve(xs[0][j:j + 1], xs[1][j:j + 1], xs[2][j:j + 1], xs[3][j:j + 1])
+            if i >= 4:
+                lat.append(time.perf_counter() - t1); ok1.append(int(r1.status[0] == 0))
+        s1.close()
+        lat = np.asarray(lat) * 1e3
+        legs["single_instance_latency_B1"] = {"ms_mean": float(lat.mean()), "ms_p50": float(np.percentile(lat, 50)), "ms_p99": float(np.percentile(lat, 99)), "ms_max": float(lat.max()),
+                                              "converged_frac": float(np.mean(ok1)), "unit": "ms per Controller::step-equivalent solve (host pointers in and out)",
+                                              "note": "the reference's implied budget is 200 ms (move_base at 5 Hz) / 50 ms (test node at 20 Hz), BASELINE.md section 1"}
         line["legs"] = legs
         line["scaling_reference"] = {"per_gpu_value_at_4096": legs["config4_share_B4096"]["value"],
                                      "note": "bench.py --gpus N>1 runs configs[3] (4096 instances per GPU); its per-GPU reference on one GPU is this leg, not the N=1 headline (1024 instances)"}
