@@ -213,6 +213,13 @@ class Controller {
     void setNumOcpIterations(int n) { _num_ocp_iterations = n < 1 ? 1 : n; }      // controller/outer_ocp_iterations (src/controller.cpp:70-72)
     int gridSize() const { return _n_cur; }
 
+    // Controller::stateFeedbackCallback (src/controller.cpp:181-195) + controller/prefer_x_feedback (:82): a measured state that is younger than
+    // two controller periods replaces the odometry pose when prefer_x_feedback is set; otherwise the odometry pose overwrites the whole state
+    // (BaseRobotSE2::mergeStateFeedbackAndOdomFeedback, include/mpc_local_planner/systems/base_robot_se2.h:93-101), which also makes the
+    // prediction from the previous state sequence (:139-142) irrelevant for every model of this package.
+    void stateFeedbackCallback(const double state[3], double stamp) { _x_feedback[0] = state[0]; _x_feedback[1] = state[1]; _x_feedback[2] = state[2]; _x_feedback_time = stamp; _have_x_feedback = true; }
+    void setPreferStateFeedback(bool p) { _prefer_x_feedback = p; }
+
     // ocp->setPreviousControlInput(u, dt)  (src/mpc_local_planner_ros.cpp:384)
     void setPreviousControlInput(const double u[2], double dt) { _u_prev[0] = u[0]; _u_prev[1] = u[1]; _dt_prev = dt; }
 
@@ -237,15 +244,17 @@ class Controller {
     }
 
     // Controller::step(initial_plan, ...)  (src/controller.cpp:111-179)
-    bool step(const std::vector<PoseSE2>& plan, const Twist& /*vel*/, double /*dt*/, double /*t*/, TimeSeries& u_seq, TimeSeries& x_seq) {
+    bool step(const std::vector<PoseSE2>& plan, const Twist& /*vel*/, double dt, double t, TimeSeries& u_seq, TimeSeries& x_seq) {
         const auto t_step0 = std::chrono::steady_clock::now();
         if (!_h) { _last_error = "Controller must be configured before invoking step()."; return false; }
         if (plan.size() < 2) { _last_error = "Controller::step(): initial plan must contain at least two poses."; return false; }
         const PoseSE2& start = plan.front();
         const PoseSE2& goal = plan.back();
         const double xf[3] = {goal.x, goal.y, goal.theta};
-        // state == pose for every model and the odometry pose overwrites any prediction (base_robot_se2.h merge)
-        const double x0[3] = {start.x, start.y, start.theta};
+        // state == pose for every model; :131-149: a fresh state measurement wins only with prefer_x_feedback, else the odometry pose overwrites the state
+        const bool new_x = _have_x_feedback && (t - _x_feedback_time) < 2.0 * dt;
+        const bool use_fb = new_x && _prefer_x_feedback;
+        const double x0[3] = {use_fb ? _x_feedback[0] : start.x, use_fb ? _x_feedback[1] : start.y, use_fb ? _x_feedback[2] : start.theta};
         // re-initialisation decision, :152-158
         if (_force_reinit_num_steps > 0 && _ocp_seq % _force_reinit_num_steps == 0) _grid_empty = true;
         if (!_grid_empty) {
@@ -351,6 +360,9 @@ class Controller {
     double _force_reinit_new_goal_dist = 1.0;            // :74
     double _force_reinit_new_goal_angular = 1.5707963267948966;   // :76 (0.5*pi)
     bool _initial_plan_estimate_orientation = true;
+    double _x_feedback[3] = {0, 0, 0};
+    double _x_feedback_time = 0.0;
+    bool _have_x_feedback = false, _prefer_x_feedback = false;      // controller/prefer_x_feedback (src/controller.cpp:82)
     std::string _last_error;
 };
 

@@ -1,4 +1,4 @@
-"""ORACLE (test infrastructure only): candidate initial trajectories and the winner rule, restated on the CPU.
+"""ORACLE (test infrastructure only; parity unpinned: the reference has no recorded outputs for this path): candidate initial trajectories and the winner rule, restated on the CPU.
 
 The product generates the candidates on the device (mpc_wave.hpp::seed_start) and applies the rule with atomics inside the solve
 kernel (mpc_capi.hip, "exit protocol"); this file restates both in numpy so that tests can run the identical rule on the C oracle:

@@ -1,4 +1,4 @@
-"""ORACLE (test infrastructure only): is a trajectory a KKT point of the REFERENCE-FORM NLP?
+"""ORACLE (test infrastructure only; parity unpinned: nothing of the reference can run here): is a trajectory a KKT point of the REFERENCE-FORM NLP?
 
 Used by the parity tests to classify solver results that do not coincide with the oracle's iterate sequence (a line-search tie that
 flips, another candidate initial trajectory): such a result is acceptable iff it is feasible and stationary for the NLP exactly as the
