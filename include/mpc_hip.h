@@ -50,7 +50,7 @@ enum mpc_objective {                  /* src/controller.cpp:551-640 */
 };
 enum mpc_precision { MPC_FP64 = 0, MPC_FP32 = 1,
                      MPC_MIXED = 2      /* fp32 main phase (to tol 1e-4; the candidates run here) + fp64 refinement started from its iterate AND its
-                                         * multipliers (barrier 1e-5) down to cfg.tol: fp64-accurate results at roughly the fp32 residency */ };
+                                         * multipliers (barrier 1e-5, at most 40 iterations) down to cfg.tol: fp64-accurate results at roughly the fp32 residency */ };
 enum mpc_footprint { MPC_FOOTPRINT_POINT = 0, MPC_FOOTPRINT_CIRCLE = 1,     /* every footprint works with every obstacle kind (point, circle, line, polygon), static or dynamic */
                      MPC_FOOTPRINT_LINE = 2,        /* teb LineRobotFootprint (the car-like example's footprint) */
                      MPC_FOOTPRINT_TWO_CIRCLES = 3, /* teb TwoCirclesRobotFootprint */

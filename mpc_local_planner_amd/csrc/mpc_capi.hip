@@ -330,6 +330,7 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         s->P64.n_cand = 1;                                   // phase 2 refines the winner
         if (!(cfg->mu_init_dual > 0)) s->P64.mu_init_dual = 1e-5;      // phase 1 ended at a barrier of ~1e-5
         s->P64.mu_init_warm = 1e-3;                          // instances phase 1 did not converge start phase 2 from its last iterate
+        if (s->P64.max_iter > 40) s->P64.max_iter = 40;      // a refinement that needs more than that is a solve of its own (phase-1 failures would hold the launch for 100)
     }
     {
         const int O = cfg->max_obstacles > 0 ? cfg->max_obstacles : 0;
