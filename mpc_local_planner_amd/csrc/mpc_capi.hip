@@ -465,8 +465,8 @@ template <typename T>
 static hipError_t launch_prec(mpc_solver* s, const mpc::Problem<T>& P, int B, const double* x0, const double* xf, const double* up,
                         const double* dtp, const double* xi, const double* ui, const double* dti, const mpc_obstacles& ob, double* xo, double* uo,
                         double* dto, int32_t* st, int32_t* it) {
-#ifdef MPC_DEV_ONE_MODEL       // developer builds (fast compile, asm inspection): only the car-like fp64 instantiations exist
-    if (sizeof(T) == 8) return launch_model<double, mpc::MODEL_SIMPLE_CAR>(s, s->P64, B, x0, xf, up, dtp, xi, ui, dti, ob, xo, uo, dto, st, it);
+#ifdef MPC_DEV_ONE_MODEL       // developer builds (fast compile, asm inspection): only the fp64 instantiations of ONE model exist (-DMPC_DEV_ONE_MODEL=<model id>)
+    if (sizeof(T) == 8) return launch_model<double, MPC_DEV_ONE_MODEL>(s, s->P64, B, x0, xf, up, dtp, xi, ui, dti, ob, xo, uo, dto, st, it);
     return hipErrorInvalidConfiguration;
 #else
     switch (s->cfg.model) {
