@@ -334,3 +334,34 @@ def test_candidates_compose_with_clearance_rows(m, c_oracle):
         # rows exist only for the ASSOCIATED obstacles (nearest left / right + forced ones of the start trajectory): allow what the reference allows
         assert d > -1e-9
     s.close()
+
+
+def test_abi_guards_of_per_instance_state(m):
+    """solves must not read per-instance state (grid sizes) that was set for a smaller batch; a partial initial-guess triple is an
+    error, not a silent cold start; the costmap kernel does not disturb the solve kernel's timer."""
+    import ctypes as C
+    from mpc_local_planner_amd._abi import MPC_EBATCH, MPC_EINVAL
+    B, n = 8, 20
+    x0, xf, up, dtp = m.workloads.carlike_min_time_inputs(B, seed=3, goal_range=(1.0, 2.0))
+    s = m.BatchSolver(m.config_carlike_min_time(n), max_batch=B)
+    s.set_grid_sizes(np.full(4, 12, np.int32))
+    with pytest.raises(m.MpcError) as e:
+        s.solve(x0, xf, up, dtp)
+    assert e.value.code == MPC_EBATCH
+    r = s.solve(x0[:4], xf[:4], up[:4], dtp[:4])
+    assert r.x.shape == (4, n, 3)
+    s.set_grid_sizes(None)
+    r = s.solve(x0, xf, up, dtp)
+    xo = np.empty((B, n, 3)); uo = np.empty((B, n, 2)); do = np.empty(B)
+    p = lambda a: C.c_void_p(a.ctypes.data)
+    rc = s._lib.mpc_solve_batch(s._h, B, p(x0), p(xf), p(up), p(dtp), p(r.x), None, None, None, p(xo), p(uo), p(do), None, None)
+    assert rc == MPC_EINVAL and b"all three or none" in s._lib.mpc_last_error()
+    s.close()
+    so = m.BatchSolver(m.config_unicycle_quadratic(n, max_obstacles=8, max_vertices=1), max_batch=B)
+    xq = m.workloads.unicycle_quadratic_inputs(B, seed=4)
+    no = np.zeros(B, np.int32); nv = np.zeros((B, 8), np.int32); vt = np.zeros((B, 8, 1, 2))
+    so.solve(*xq, obstacles=(no, nv, vt))
+    t_solve = so.last_kernel_ms()
+    so.costmap_to_obstacles(np.zeros((B, 30, 30), np.uint8), 0.1, np.zeros((B, 2)), np.zeros((B, 3)))
+    assert so.last_kernel_ms() == t_solve and t_solve > 0
+    so.close()
