@@ -270,7 +270,7 @@ void mpc_config_defaults(mpc_config* c) {
 }
 
 const char* mpc_last_error(void) { return g_err; }
-int32_t mpc_version(void) { return 100; }
+int32_t mpc_version(void) { return 200; }      // 0.2.0: mpc_config grew (candidates, kept multipliers, hessian_mode), new entry points
 
 #ifdef MPC_PROFILE
 // developer build only (-DMPC_PROFILE): per-wave phase cycle counters of the last wave-kernel launch
