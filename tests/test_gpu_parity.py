@@ -325,10 +325,44 @@ def test_no_uninitialised_lds_reads(m, tmp_path):
     so = str(tmp_path / "libmpc_hip_poison.so")
     subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DMPC_POISON_LDS",
                     os.path.join(root, "mpc_local_planner_amd", "csrc", "mpc_capi.hip"), "-o", so], check=True)
+    # round-2 paths: candidates (kernel-generated seeds), kept multipliers, a turning footprint against polygons and a dynamic obstacle -- results of
+    # the normal library (this process) must be reproduced bit for bit by the poisoned build (the subprocess)
+    x0, xf, up, dtp = m.workloads.carlike_min_time_inputs(16, seed=77, goal_range=(2.0, 4.0))
+    ckw = dict(candidates=(0, 5, 3, 7), candidate_max_iter=(40, 40, 40, 40), candidate_param=(0, 2.0, 0, 1.5), dual_warm_start=True)
+    sA = m.BatchSolver(m.config_carlike_min_time(30, **ckw), max_batch=16)
+    rA = sA.solve(x0, xf, up, dtp)
+    rA2 = sA.solve(x0 + 0.01, xf, up, dtp, init=(rA.x, rA.u, rA.dt))
+    sA.close()
+    d = xf[:, :2] - x0[:, :2]
+    nrm = np.stack([-d[:, 1], d[:, 0]], -1) / np.linalg.norm(d, axis=-1, keepdims=True)
+    vt = np.zeros((16, 2, 4, 2)); nv = np.zeros((16, 2), np.int32); rad = np.zeros((16, 2)); vel = np.zeros((16, 2, 2))
+    sq = np.array([[0.2, 0.2], [-0.2, 0.2], [-0.2, -0.2], [0.2, -0.2]])
+    vt[:, 0] = (x0[:, None, :2] + 0.5 * d[:, None, :] + 0.9 * nrm[:, None, :]) + sq[None]; nv[:, 0] = 4
+    vt[:, 1, 0] = x0[:, :2] + 0.6 * d - 1.1 * nrm; nv[:, 1] = 1; rad[:, 1] = 0.1; vel[:, 1] = 0.1 * nrm
+    okw = dict(footprint_kind=2, footprint_params=(0.0, 0.0, 0.4, 0.0), min_obstacle_dist=0.25, enable_dynamic_obstacles=True, max_obstacles=2, max_vertices=4, max_obstacle_rows=4)
+    sB = m.BatchSolver(m.config_carlike_min_time(30, **okw), max_batch=16)
+    rB = sB.solve(x0, xf, up, dtp, obstacles=(np.full(16, 2, np.int32), nv, vt, rad, vel))
+    sB.close()
+    np.savez(str(tmp_path / "r2.npz"), x0=x0, xf=xf, up=up, dtp=dtp, xA=rA.x, stA=rA.status, xA2=rA2.x, itA2=rA2.iters, nv=nv, vt=vt, rad=rad, vel=vel, xB=rB.x, stB=rB.status)
     code = """
 import sys, numpy as np
 sys.path.insert(0, %r)
 import mpc_local_planner_amd as m
+R2 = %r
+if R2:
+    g = np.load(R2)
+    ckw = dict(candidates=(0, 5, 3, 7), candidate_max_iter=(40, 40, 40, 40), candidate_param=(0, 2.0, 0, 1.5), dual_warm_start=True)
+    s = m.BatchSolver(m.config_carlike_min_time(30, **ckw), max_batch=16)
+    r = s.solve(g["x0"], g["xf"], g["up"], g["dtp"])
+    assert np.array_equal(r.x, g["xA"]) and np.array_equal(r.status, g["stA"]), "candidates"
+    r2 = s.solve(g["x0"] + 0.01, g["xf"], g["up"], g["dtp"], init=(r.x, r.u, r.dt))
+    assert np.array_equal(r2.x, g["xA2"]) and np.array_equal(r2.iters, g["itA2"]), "kept multipliers"
+    s.close()
+    okw = dict(footprint_kind=2, footprint_params=(0.0, 0.0, 0.4, 0.0), min_obstacle_dist=0.25, enable_dynamic_obstacles=True, max_obstacles=2, max_vertices=4, max_obstacle_rows=4)
+    s = m.BatchSolver(m.config_carlike_min_time(30, **okw), max_batch=16)
+    r = s.solve(g["x0"], g["xf"], g["up"], g["dtp"], obstacles=(np.full(16, 2, np.int32), g["nv"], g["vt"], g["rad"], g["vel"]))
+    assert np.array_equal(r.x, g["xB"]) and np.array_equal(r.status, g["stB"]), "turning footprint + polygon + dynamic obstacle"
+    s.close()
 cases = {"carlike_min_time_n50": m.config_carlike_min_time(50), "unicycle_quadratic_n20": m.config_unicycle_quadratic(20),
          "bicycle_min_time_n30": m.config_bicycle_min_time(30)}
 for name, cfg in cases.items():
@@ -342,7 +376,7 @@ s = m.BatchSolver(m.config_unicycle_quadratic(30, max_obstacles=O, max_vertices=
 r = s.solve(g["x0"], g["xf"], g["u_prev"], g["dt_prev"], obstacles=(g["n_obstacles"], g["n_vertices"], g["vertices"]))
 assert (r.status == 0).all() and np.abs(r.x - g["x"]).max() < 1e-6, ("obstacles", r.status)
 print("POISON_OK")
-""" % (root, GOLD, GOLD)
+""" % (root, str(tmp_path / "r2.npz"), GOLD, GOLD)
     env = dict(os.environ, MPC_HIP_LIB=so)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=600)
     assert "POISON_OK" in r.stdout, r.stdout + r.stderr
