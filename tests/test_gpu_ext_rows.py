@@ -365,3 +365,23 @@ def test_abi_guards_of_per_instance_state(m):
     so.costmap_to_obstacles(np.zeros((B, 30, 30), np.uint8), 0.1, np.zeros((B, 2)), np.zeros((B, 3)))
     assert so.last_kernel_ms() == t_solve and t_solve > 0
     so.close()
+
+
+def test_candidate_results_do_not_depend_on_batch_composition_or_timing(m):
+    """Hedging is timing dependent (which hedges start, how far they get), the RESULT must not be: instances solved inside a batch of 4096 (every
+    candidate-0 workgroup is dispatched before any hedge) and the same instances solved as batches of 1024 and of 64 (hedges start at once)
+    give bit-identical trajectories, statuses, iteration counts and winners."""
+    from mpc_local_planner_amd import _abi as A
+    n, B = 50, 4096
+    x0, xf, up, dtp = m.workloads.carlike_min_time_inputs(B, seed=955)
+    s = m.BatchSolver(m.config_carlike_min_time(n, candidates=(0, 5, 5, 7), candidate_max_iter=(60, 45, 40, 35), candidate_param=(0.0, 2.0, 3.0, 1.5)), max_batch=B)
+    big = s.solve(x0, xf, up, dtp)
+    wbig, _ = s.last_candidates(B)
+    for lo, cnt in ((0, 1024), (3000, 64), (4095, 1)):
+        sl = slice(lo, lo + cnt)
+        r = s.solve(x0[sl], xf[sl], up[sl], dtp[sl])
+        w, _ = s.last_candidates(cnt)
+        np.testing.assert_array_equal(r.x, big.x[sl]); np.testing.assert_array_equal(r.u, big.u[sl]); np.testing.assert_array_equal(r.dt, big.dt[sl])
+        np.testing.assert_array_equal(r.status, big.status[sl]); np.testing.assert_array_equal(r.iters, big.iters[sl]); np.testing.assert_array_equal(w, wbig[sl])
+    assert (big.status == 0).mean() > 0.99
+    s.close()
