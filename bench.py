@@ -43,6 +43,7 @@ FP32_VECTOR_PEAK_TF = 157.3
 CAND_KINDS = (0, 5, 5, 7)
 CAND_CAPS = (60, 45, 40, 35)
 CAND_PARAMS = (0.0, 2.0, 3.0, 1.5)
+CAND5_KINDS, CAND5_CAPS, CAND5_PARAMS = (0, 1, 2, 5), (60, 50, 45, 40), (0.0, 0.0, 0.0, 2.0)      # config-5 legs (bicycle, n = 120)
 
 
 def algorithmic_bytes_per_solve(n: int, s: int = 8, obstacle_scalars: int = 0) -> int:
@@ -346,10 +347,11 @@ def main():
         l3.close()
         # configs[4] share: kinematic bicycle, n = 120, fp32, 1024 per GPU
         n5, B5 = 120, 1024
-        # the headline's candidate set with caps of 100.  (A set chosen with the fp64 C oracle for this workload -- reference, Hermite FF 1.0, blend: 100 %
-        # within 60 iterations in fp64 -- was measured WORSE in the fp32 phase: 95.3 % at caps 100, 92.2 % at caps 60, against 97.9 % for this set;
-        # the fp32 solves stall on round-off before the scaled KKT error reaches 1e-4 on these 5-40 m problems.)
-        c5kw = dict(candidates=kinds, candidate_max_iter=tuple(100 for _ in kinds), candidate_param=pars) if len(kinds) > 1 else {}
+        # candidate set chosen ON THE DEVICE in fp32 (scripts/gpu_candidate_sweep_config5.py, profiles/r02_candidate_sweep_config5.log): the reference cold
+        # start, then the reference's own no-initial-plan guess (heading = direction of travel), its reverse-driving twin and one Hermite seed.  On these
+        # 5-40 m problems the reference cold start alone converges for 72 %, this set for 99.8 % (6 draws: see the log); the headline's Hermite set at
+        # caps 100, which this leg ran before, reached 97.9 % in 20 ms.
+        c5kw = dict(candidates=CAND5_KINDS, candidate_max_iter=CAND5_CAPS, candidate_param=CAND5_PARAMS) if len(kinds) > 1 else {}
         c5 = m.config_bicycle_min_time(n5, precision=1, tol=1e-4, **c5kw)
         l5 = Leg(m, torch, dev, c5, B5, m.workloads.bicycle_min_time_inputs(B5))
         legs["config5_share_bicycle_n120_fp32_B1024"] = leg_summary(l5, max(2, args.steps // 2), 1, algorithmic_bytes_per_solve(n5, 4), (24 + 486 + 418 + 100) * (n5 - 1), FP32_VECTOR_PEAK_TF, "bicycle_n120_fp32_B1024")
