@@ -115,7 +115,8 @@ typedef struct mpc_config {
     int32_t objective;                /* planning/objective/type          (:551) */
     double  Q[3], R[2];               /* quadratic_form weights (diag)    (:561-592) */
     int32_t integral_form;            /* .../integral_form                (:594) */
-    int32_t has_Qf;                   /* planning/terminal_cost/type == quadratic (:645) */
+    int32_t has_Qf;                   /* planning/terminal_cost/type == quadratic (:645); applies with EVERY objective type, on the goal components
+                                       * that are free (the edge exists while the final state is not completely fixed, finite_differences_grid_se2.cpp:128-133) */
     double  Qf[3];                    /* final_state_weights (diag)       (:652-668) */
     double  u_lb[2], u_ub[2];         /* control box                      (:511,:527,:543) */
     double  du_lb[2], du_ub[2];       /* control-rate box; +-1e30 = inf   (:756-797) */

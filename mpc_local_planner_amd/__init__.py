@@ -8,3 +8,5 @@ from ._abi import (MpcConfig, make_config, config_carlike_min_time, config_unicy
                    config_bicycle_min_time, STATUS_NAMES, OBJ_MIN_TIME, OBJ_QUADRATIC, OBJ_MIN_TIME_VIA_POINTS)
 from .solver import BatchSolver, BatchResult, MpcError  # noqa: F401
 from . import workloads  # noqa: F401
+from . import params  # noqa: F401  (the reference's parameter set -> mpc_config)
+from .params import config_from_params, config_from_yaml  # noqa: F401

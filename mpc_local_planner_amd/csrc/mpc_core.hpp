@@ -674,7 +674,7 @@ MPC_HD void riccati_terminal(RicState<T>& V, const Problem<T>& P_, const T xd_f[
         if (P_.xf_fixed[i]) { V.S[i][i] = T(1); V.W[i][i] = -dc; }
         else {
             V.P[i][i] = delta;
-            if (P_.objective == OBJ_QUADRATIC && P_.has_Qf) { V.P[i][i] += T(2) * P_.Qf[i]; V.p[i] = T(2) * P_.Qf[i] * xd_f[i]; }
+            if (P_.has_Qf) { V.P[i][i] += T(2) * P_.Qf[i]; V.p[i] = T(2) * P_.Qf[i] * xd_f[i]; }
         }
     }
     for (int j = 0; j < 2; ++j) {      // final rate rows: a over (up_j, d) = (-sg, -sg*lim)

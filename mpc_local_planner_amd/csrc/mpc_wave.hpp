@@ -679,7 +679,7 @@ struct IpmWave {
         }
         if (lane == 0) {
             if (!quad()) fo += T(n - 1) * d;
-            else if (hasqf()) {
+            if (hasqf()) {       // the terminal cost does not depend on the stage cost's type (src/controller.cpp:641-672)
                 for (int i = 0; i < 3; ++i) if (!fx(i)) {
                     T xd = xt(i, n - 1, al) - xf[i];
                     if (i == 2) xd = normalize_theta(xd);
@@ -785,7 +785,7 @@ struct IpmWave {
         for (int q = 0; q < 4; ++q) acc.mul(r.s[q] + alpha * r.ds[q]);      // rows that are off carry s = 1, ds = 0
         if (lane == 0) {
             if (!r.quad) fo += r.nm1 * d;
-            else if (hasqf()) {
+            if (hasqf()) {
                 for (int i = 0; i < 3; ++i) if (!fx(i)) {
                     T xd = xt(i, L.n - 1, alpha) - xf[i];
                     if (i == 2) xd = normalize_theta(xd);
@@ -904,7 +904,7 @@ struct IpmWave {
                     }
                     for (int i = 0; i < 3; ++i) if (!fx(i)) {
                         T g = T(0);
-                        if (quad() && hasqf()) {
+                        if (hasqf()) {
                             T xd = F(L.X, i, n - 1) - xf[i];
                             if (i == 2) xd = normalize_theta(xd);
                             g = T(2) * P.Qf[i] * xd;
@@ -1154,7 +1154,7 @@ struct IpmWave {
             if (fx(i)) V[i] = c == 9 + i ? T(1) : T(0);
             else {
                 T pii = delta, pi_ = T(0);
-                if (quad() && hasqf()) {
+                if (hasqf()) {
                     T xd = F(L.X, i, n - 1) - xf[i];
                     if (i == 2) xd = normalize_theta(xd);
                     pii += T(2) * P.Qf[i]; pi_ = T(2) * P.Qf[i] * xd;
@@ -1406,7 +1406,7 @@ struct IpmWave {
             if (fx(i)) lp[i] = nu[i];
             else {
                 T g = delta * xi[i];
-                if (quad() && hasqf()) {
+                if (hasqf()) {
                     T xd = F(L.X, i, n - 1) - xf[i];
                     if (i == 2) xd = normalize_theta(xd);
                     g += T(2) * P.Qf[i] * (xi[i] + xd);
@@ -1522,10 +1522,8 @@ struct IpmWave {
                         T dx = F(L.DX, i, k);
                         dz2 += dx * dx; dzmax = t_max(dzmax, t_abs(dx));
                         T g = vg[i];
-                        if (quad()) {
-                            if (k < n - 1) { T xd = F(L.X, i, k) - xf[i]; if (i == 2) xd = normalize_theta(xd); g = T(2) * P.Q[i] * xd * (intf() ? d : T(1)); }
-                            else if (hasqf()) { T xd = F(L.X, i, k) - xf[i]; if (i == 2) xd = normalize_theta(xd); g = T(2) * P.Qf[i] * xd; }
-                        }
+                        if (quad() && k < n - 1) { T xd = F(L.X, i, k) - xf[i]; if (i == 2) xd = normalize_theta(xd); g = T(2) * P.Q[i] * xd * (intf() ? d : T(1)); }
+                        else if (k == n - 1 && hasqf()) { T xd = F(L.X, i, k) - xf[i]; if (i == 2) xd = normalize_theta(xd); g += T(2) * P.Qf[i] * xd; }
                         hdz += g * dx; dphi += g * dx;
                     }
                 }

@@ -1,0 +1,346 @@
+"""The reference's parameter set -> struct mpc_config.
+
+`Controller::configure` (src/controller.cpp:58-100) reads ~70 keys from the ROS parameter server (`nh.param(key, var, default)`) while it
+builds the corbo objects: configureRobotDynamics (:344-378), configureGrid (:225-342), configureSolver (:380-481), configureOcp (:483-805);
+the footprint is read by the plugin (src/mpc_local_planner_ros.cpp:890-1001).  A user of the reference owns YAML files with exactly those
+keys (mpc_local_planner_examples/cfg/**).  This module reads the same keys with the same in-code defaults, the same fix-ups (negative
+`max_vel_x_backwards` / `dec_lim_x` are flipped, a rate limit <= 0 means "none") and the same rejections, and returns
+
+    cfg    the mpc_config for mpc_create (what shapes the NLP)
+    ctrl   the options that live in the Controller facade, not in the solve (include/mpc_controller.hpp: grid adaptation, warm start,
+           outer iterations, re-initialisation thresholds, state feedback, result publishing)
+    notes  parameters that were accepted but have no effect here, or were mapped onto the nearest equivalent (one line each)
+
+A configuration the reference rejects (`configure` returns false) raises ParamError with the reference's reason; one that the reference accepts
+but this path does not implement raises ParamNotImplemented (it never falls back silently to a different NLP).
+
+    cfg, ctrl, notes = config_from_yaml("mpc_local_planner_params.yaml", max_obstacles=64, max_vertices=8)
+    solver = BatchSolver(cfg, max_batch=1024)
+
+Sizing parameters that the reference does not have (obstacle / via-point capacity of a handle, arithmetic precision, candidates, ...) are
+keyword arguments and go to make_config unchanged.
+"""
+from __future__ import annotations
+
+import math
+from typing import Any
+
+from . import _abi as A
+
+PLUGIN_NAMESPACE = "MpcLocalPlannerROS"      # move_base loads the plugin's parameters under this name (the example YAMLs' top-level key)
+FOOTPRINT_POINT, FOOTPRINT_CIRCLE, FOOTPRINT_LINE, FOOTPRINT_TWO_CIRCLES, FOOTPRINT_POLYGON = range(5)   # include/mpc_hip.h, enum mpc_footprint_kind
+HESSIAN_EXACT, HESSIAN_CONVEXIFIED = 0, 1
+
+
+class ParamError(ValueError):
+    """the reference's configure() fails on this parameter set"""
+
+
+class ParamNotImplemented(NotImplementedError):
+    """valid for the reference, not built here"""
+
+
+class _Reader:
+    """nh.param(key, var, default): nested dicts addressed by 'a/b/c'; records which keys were read"""
+
+    def __init__(self, tree: dict):
+        self.tree = tree or {}
+        self.used: set[str] = set()
+
+    def has(self, key: str) -> bool:
+        node: Any = self.tree
+        for part in key.split("/"):
+            if not isinstance(node, dict) or part not in node:
+                return False
+            node = node[part]
+        return True
+
+    def get(self, key: str, default):
+        node: Any = self.tree
+        for part in key.split("/"):
+            if not isinstance(node, dict) or part not in node:
+                return default
+            node = node[part]
+        self.used.add(key)
+        # roscpp converts between int and double parameters but not from strings; a value of the wrong kind leaves the default in place
+        if isinstance(default, bool):
+            return bool(node) if isinstance(node, (bool, int)) else default
+        if isinstance(default, int):
+            return int(node) if isinstance(node, (int, float)) and not isinstance(node, bool) else default
+        if isinstance(default, float):
+            return float(node) if isinstance(node, (int, float)) and not isinstance(node, bool) else default
+        if isinstance(default, str):
+            return node if isinstance(node, str) else default
+        return node
+
+    def unused(self, prefix: str = "") -> list[str]:
+        out = []
+
+        def walk(node, path):
+            if isinstance(node, dict) and node:
+                for k, v in node.items():
+                    walk(v, f"{path}/{k}" if path else str(k))
+            elif path not in self.used and not any(u.startswith(path + "/") or path.startswith(u + "/") for u in self.used):
+                out.append(path)
+        walk(self.tree, prefix)
+        return out
+
+
+def _weights(values, dim: int, what: str, reason: str):
+    """a weight list of length dim (diagonal) or dim*dim (full matrix, column major: Eigen's default, src/controller.cpp:565-573)"""
+    v = [float(x) for x in (values or [])]
+    if len(v) == dim:
+        return v
+    if len(v) == dim * dim:
+        m = [[v[c * dim + r] for c in range(dim)] for r in range(dim)]
+        off = max(abs(m[r][c] + m[c][r]) for r in range(dim) for c in range(dim) if r != c)    # x'Mx only sees the symmetric part
+        if off > 0.0:
+            raise ParamNotImplemented(f"{what}: a {dim} x {dim} weight matrix with off-diagonal terms (the device path takes diagonal weights)")
+        return [m[i][i] for i in range(dim)]
+    raise ParamError(reason)
+
+
+def config_from_params(params: dict, costmap_footprint=None, **sizing):
+    """params: the plugin's parameter namespace as nested dicts (what rosparam holds under /move_base/MpcLocalPlannerROS).
+    costmap_footprint: vertices [(x, y), ...] for footprint_model/type == costmap_2d (the reference asks the costmap; without one it
+    falls back to the point model, src/mpc_local_planner_ros.cpp:902-911).
+    sizing: make_config keywords the reference has no parameter for (max_obstacles, max_vertices, max_obstacle_rows, max_via_points,
+    precision, candidates, ...); they override what the parameters give."""
+    p = _Reader(params)
+    notes: list[str] = []
+    kw: dict[str, Any] = {}
+
+    # ---- configureRobotDynamics (src/controller.cpp:344-378) and the control bounds of configureOcp (:494-548)
+    robot = p.get("robot/type", "unicycle")
+    if robot == "unicycle":
+        kw["model"], kw["model_params"] = A.MODEL_UNICYCLE, (0.0,)
+        ns, second, second_default, rate_key = "robot/unicycle", "max_vel_theta", 0.3, "acc_lim_theta"
+    elif robot == "simple_car":
+        wheelbase = p.get("robot/simple_car/wheelbase", 0.5)
+        front = p.get("robot/simple_car/front_wheel_driving", False)
+        kw["model"], kw["model_params"] = (A.MODEL_SIMPLE_CAR_FRONT if front else A.MODEL_SIMPLE_CAR), (wheelbase,)
+        ns, second, second_default, rate_key = "robot/simple_car", "max_steering_angle", 1.5, "max_steering_rate"
+    elif robot == "kinematic_bicycle_vel_input":
+        lr = p.get("robot/kinematic_bicycle_vel_input/length_rear", 1.0)
+        lf = p.get("robot/kinematic_bicycle_vel_input/length_front", 1.0)
+        kw["model"], kw["model_params"] = A.MODEL_KINEMATIC_BICYCLE, (lr, lf)
+        ns, second, second_default, rate_key = "robot/kinematic_bicycle_vel_input", "max_steering_angle", 1.5, "max_steering_rate"
+    else:
+        raise ParamError(f"Unknown robot type '{robot}' specified.")                       # :373
+    vmax = p.get(f"{ns}/max_vel_x", 0.4)
+    vback = p.get(f"{ns}/max_vel_x_backwards", 0.2)
+    if vback < 0:
+        notes.append("max_vel_x_backwards must be >= 0 (sign flipped, as the reference does)")
+        vback = -vback
+    wmax = p.get(f"{ns}/{second}", second_default)
+    kw["u_lb"], kw["u_ub"] = (-vback, -wmax), (vmax, wmax)
+    # control-rate rows (:731-797): a limit <= 0 means "no row"
+    acc = p.get(f"{ns}/acc_lim_x", 0.0)
+    dec = p.get(f"{ns}/dec_lim_x", 0.0)
+    if dec < 0:
+        notes.append("dec_lim_x must be >= 0 (sign flipped, as the reference does)")
+        dec = -dec
+    rate = p.get(f"{ns}/{rate_key}", 0.0)
+    inf = A.INF
+    acc, dec, rate = (acc if acc > 0 else inf), (dec if dec > 0 else inf), (rate if rate > 0 else inf)
+    kw["du_lb"], kw["du_ub"] = (-dec, -rate), (acc, rate)
+
+    # ---- configureGrid (:225-342)
+    grid_type = p.get("grid/type", "fd_grid")
+    if grid_type != "fd_grid":
+        raise ParamError(f"Unknown grid type '{grid_type}' specified.")                      # :337
+    ctrl: dict[str, Any] = {}
+    variable = p.get("grid/variable_grid/enable", True)
+    kw["dt_free"] = variable
+    if variable:
+        kw["dt_lb"] = p.get("grid/variable_grid/min_dt", 0.0)
+        kw["dt_ub"] = p.get("grid/variable_grid/max_dt", 10.0)
+        adapt = p.get("grid/variable_grid/grid_adaptation/enable", True)
+        ctrl["grid_adaptation"] = adapt
+        if adapt:
+            ctrl["max_grid_size"] = p.get("grid/variable_grid/grid_adaptation/max_grid_size", 50)
+            ctrl["dt_hyst_ratio"] = p.get("grid/variable_grid/grid_adaptation/dt_hyst_ratio", 0.1)
+            ctrl["min_grid_size"] = p.get("grid/variable_grid/grid_adaptation/min_grid_size", 2)
+    else:
+        ctrl["grid_adaptation"] = False
+    kw["n"] = p.get("grid/grid_size_ref", 20)
+    kw["dt_ref"] = p.get("grid/dt_ref", 0.3)
+    xf_fixed = p.get("grid/xf_fixed", [True, True, True])
+    if len(xf_fixed) != 3:
+        raise ParamError(f"Array size of `xf_fixed` does not match robot state dimension(): {len(xf_fixed)} != 3")     # :285
+    kw["xf_fixed"] = tuple(bool(v) for v in xf_fixed)
+    ctrl["warm_start"] = p.get("grid/warm_start", True)
+    colloc = p.get("grid/collocation_method", "forward_differences")
+    colloc_ids = {"forward_differences": A.COLLOC_FORWARD, "midpoint_differences": A.COLLOC_MIDPOINT, "crank_nicolson_differences": A.COLLOC_CRANK_NICOLSON}
+    if colloc not in colloc_ids:
+        notes.append(f"Unknown collocation method '{colloc}' specified. Falling back to default...")      # :314: the reference goes on with forward differences
+        colloc = "forward_differences"
+    kw["collocation"] = colloc_ids[colloc]
+    integration = p.get("grid/cost_integration_method", "left_sum")
+    if integration not in ("left_sum", "trapezoidal_rule"):
+        notes.append(f"Unknown cost integration method '{integration}' specified. Falling back to default...")       # :331
+        integration = "left_sum"
+    # the grid with max_grid_size points must fit the handle: the solver is sized for the largest grid the adaptation may reach
+    ctrl["n_max"] = max(kw["n"], ctrl.get("max_grid_size", 0)) if ctrl["grid_adaptation"] else kw["n"]
+
+    # ---- configureSolver (:380-481)
+    solver = p.get("solver/type", "ipopt")
+    if solver == "lsq_lm":
+        raise ParamNotImplemented("solver/type lsq_lm: the Levenberg-Marquardt least-squares solver is outside this path (SURVEY.md section 8: out of scope)")
+    if solver != "ipopt":
+        raise ParamError(f"Unknown solver type '{solver}' specified.")                        # :477
+    kw["max_iter"] = p.get("solver/ipopt/iterations", 100)
+    if p.get("solver/ipopt/max_cpu_time", -1.0) > 0:
+        notes.append("solver/ipopt/max_cpu_time has no counterpart: a launch is bounded by max_iter (and by the candidates' iteration caps)")
+    numeric = p.get("solver/ipopt/ipopt_numeric_options", {}) or {}
+    strings = p.get("solver/ipopt/ipopt_string_options", {}) or {}
+    integers = p.get("solver/ipopt/ipopt_integer_options", {}) or {}
+    for k, v in numeric.items():
+        if k == "tol":
+            kw["tol"] = float(v)
+        elif k == "mu_init":
+            kw["mu_init"] = float(v)
+        else:
+            notes.append(f"ipopt numeric option {k} = {v}: no counterpart, ignored")
+    for k, v in strings.items():
+        if k == "hessian_approximation":
+            if v == "limited-memory":
+                kw["hessian_mode"] = HESSIAN_CONVEXIFIED
+                notes.append("hessian_approximation limited-memory -> MPC_HESSIAN_CONVEXIFIED (the positive-semidefinite part of the exact stage Hessians; "
+                             "no quasi-Newton update is built)")
+            else:
+                kw["hessian_mode"] = HESSIAN_EXACT
+        elif k == "linear_solver":
+            notes.append(f"linear_solver {v}: the KKT systems are solved by the stage-structured sweep of the kernel")
+        else:
+            notes.append(f"ipopt string option {k} = {v}: no counterpart, ignored")
+    for k, v in integers.items():
+        if k == "max_iter":
+            kw["max_iter"] = int(v)
+        else:
+            notes.append(f"ipopt integer option {k} = {v}: no counterpart, ignored")
+    if "tol" not in kw:
+        kw["tol"] = 1e-8       # Ipopt's default tol
+
+    # ---- configureOcp: objective (:551-639)
+    objective = p.get("planning/objective/type", "minimum_time")
+    if objective == "minimum_time":
+        kw["objective"] = A.OBJ_MIN_TIME
+    elif objective == "quadratic_form":
+        kw["objective"] = A.OBJ_QUADRATIC
+        Q = _weights(p.get("planning/objective/quadratic_form/state_weights", []), 3, "state_weights",
+                     "State weights dimension invalid. Must be either 3 x 1 or 3 x 3.")                       # :575
+        R = _weights(p.get("planning/objective/quadratic_form/control_weights", []), 2, "control_weights",
+                     "Control weights dimension invalid. Must be either 2 x 1 or 2 x 2.")                     # :590
+        integral = p.get("planning/objective/quadratic_form/integral_form", False)
+        hybrid = p.get("planning/objective/quadratic_form/hybrid_cost_minimum_time", False)
+        q_zero, r_zero = all(v == 0 for v in Q), all(v == 0 for v in R)
+        if hybrid and not (q_zero and not r_zero):
+            # :603-612: only the pure control cost has a hybrid variant
+            notes.append("Hybrid minimum time and quadratic form cost is currently only supported for non-zero control weights only. Falling back to quadratic form.")
+            hybrid = False
+        if hybrid:
+            raise ParamNotImplemented("planning/objective/quadratic_form/hybrid_cost_minimum_time (corbo::MinTimeQuadraticControls)")
+        if integral and integration == "trapezoidal_rule" and not q_zero:
+            raise ParamNotImplemented("grid/cost_integration_method trapezoidal_rule with an integral-form state cost (the device path integrates by the left sum)")
+        kw["Q"], kw["R"], kw["integral_form"] = tuple(Q), tuple(R), integral
+    elif objective == "minimum_time_via_points":
+        kw["objective"] = A.OBJ_MIN_TIME_VIA_POINTS
+        kw["via_points_ordered"] = p.get("planning/objective/minimum_time_via_points/via_points_ordered", False)
+        kw["vp_position_weight"] = p.get("planning/objective/minimum_time_via_points/position_weight", 1.0)
+        kw["vp_orientation_weight"] = p.get("planning/objective/minimum_time_via_points/orientation_weight", 0.0)
+        kw["max_via_points"] = 16
+    else:
+        raise ParamError(f"Unknown objective type '{objective}' specified ('planning/objective/type').")      # :636
+    # terminal cost (:641-672) and terminal constraint (:674-713)
+    tcost = p.get("planning/terminal_cost/type", "none")
+    if tcost == "quadratic":
+        kw["Qf"] = tuple(_weights(p.get("planning/terminal_cost/quadratic/final_state_weights", []), 3, "final_state_weights",
+                                  "Final state weights dimension invalid. Must be either 3 x 1 or 3 x 3."))       # :664
+    elif tcost != "none":
+        raise ParamError(f"Unknown terminal_cost type '{tcost}' specified ('planning/terminal_cost/type').")     # :670
+    tcon = p.get("planning/terminal_constraint/type", "none")
+    if tcon == "l2_ball":
+        kw["terminal_ball_S"] = tuple(_weights(p.get("planning/terminal_constraint/l2_ball/weight_matrix", []), 3, "weight_matrix",
+                                               "l2-ball weight_matrix dimensions invalid. Must be either 3 x 1 or 3 x 3."))  # :699
+        kw["terminal_ball_gamma"] = p.get("planning/terminal_constraint/l2_ball/radius", 1.0)
+    elif tcon != "none":
+        raise ParamError(f"Unknown terminal_constraint type '{tcon}' specified ('planning/terminal_constraint/type').")   # :711
+
+    # ---- collision avoidance (:715-729)
+    kw["min_obstacle_dist"] = p.get("collision_avoidance/min_obstacle_dist", 0.5)
+    kw["enable_dynamic_obstacles"] = p.get("collision_avoidance/enable_dynamic_obstacles", False)
+    kw["force_inclusion_dist"] = p.get("collision_avoidance/force_inclusion_dist", 0.5)
+    kw["cutoff_dist"] = p.get("collision_avoidance/cutoff_dist", 2.0)
+
+    # ---- footprint (src/mpc_local_planner_ros.cpp:890-1001): every malformed model falls back to the point model, as there
+    kw.update(_footprint(p, costmap_footprint, notes))
+
+    # ---- options of the Controller facade (src/controller.cpp:70-88; defaults: include/mpc_local_planner/controller.h:124-143)
+    ctrl["outer_ocp_iterations"] = p.get("controller/outer_ocp_iterations", 1)
+    ctrl["force_reinit_new_goal_dist"] = p.get("controller/force_reinit_new_goal_dist", 1.0)
+    ctrl["force_reinit_new_goal_angular"] = p.get("controller/force_reinit_new_goal_angular", 0.5 * math.pi)
+    ctrl["allow_init_with_backward_motion"] = p.get("controller/allow_init_with_backward_motion", True)
+    ctrl["force_reinit_num_steps"] = p.get("controller/force_reinit_num_steps", 0)
+    ctrl["prefer_x_feedback"] = p.get("controller/prefer_x_feedback", False)
+    ctrl["publish_ocp_results"] = p.get("controller/publish_ocp_results", False)
+    ctrl["print_cpu_time"] = p.get("controller/print_cpu_time", False)
+
+    kw.update(sizing)
+    if kw.get("max_obstacles", 0) <= 0:
+        kw.pop("max_vertices", None)
+    return A.make_config(**kw), ctrl, notes
+
+
+def _footprint(p: _Reader, costmap_footprint, notes: list[str]) -> dict:
+    point = {"footprint_kind": FOOTPRINT_POINT}
+    if not p.has("footprint_model/type"):
+        return point                                           # :894-898
+    kind = p.get("footprint_model/type", "point")
+    if kind == "costmap_2d":
+        if not costmap_footprint:
+            notes.append("footprint_model/type costmap_2d without a costmap footprint: point model (as the reference without a costmap)")
+            return point
+        return {"footprint_kind": FOOTPRINT_POLYGON, "footprint_vertices": [tuple(map(float, v)) for v in costmap_footprint]}
+    if kind == "point":
+        return point
+    if kind == "circular":
+        if not p.has("footprint_model/radius"):
+            notes.append("Footprint model 'circular' cannot be loaded: footprint_model/radius does not exist. Using point-model instead.")
+            return point
+        return {"footprint_kind": FOOTPRINT_CIRCLE, "footprint_radius": p.get("footprint_model/radius", 0.0)}
+    if kind == "line":
+        a, b = p.get("footprint_model/line_start", None), p.get("footprint_model/line_end", None)
+        if a is None or b is None or len(a) != 2 or len(b) != 2:
+            notes.append("Footprint model 'line' cannot be loaded: line_start / line_end missing or not 2D. Using point-model instead.")
+            return point
+        return {"footprint_kind": FOOTPRINT_LINE, "footprint_params": (float(a[0]), float(a[1]), float(b[0]), float(b[1]))}
+    if kind == "two_circles":
+        keys = ("front_offset", "front_radius", "rear_offset", "rear_radius")
+        if not all(p.has(f"footprint_model/{k}") for k in keys):
+            notes.append("Footprint model 'two_circles' cannot be loaded: front_offset, front_radius, rear_offset and rear_radius are needed. Using point-model instead.")
+            return point
+        return {"footprint_kind": FOOTPRINT_TWO_CIRCLES, "footprint_params": tuple(p.get(f"footprint_model/{k}", 0.0) for k in keys)}
+    if kind == "polygon":
+        v = p.get("footprint_model/vertices", None)
+        ok = isinstance(v, (list, tuple)) and len(v) >= 3 and all(isinstance(q, (list, tuple)) and len(q) == 2 for q in v)
+        if not ok:
+            # makeFootprintFromXMLRPC (:1030-1060) throws for fewer than 3 points or points that are not [x, y]
+            notes.append("Footprint model 'polygon' cannot be loaded: footprint_model/vertices must be a list of at least 3 [x, y] points. Using point-model instead.")
+            return point
+        if len(v) > 16:
+            raise ParamNotImplemented("footprint_model/vertices: more than 16 vertices (mpc_config.footprint_vertices)")
+        return {"footprint_kind": FOOTPRINT_POLYGON, "footprint_vertices": [(float(q[0]), float(q[1])) for q in v]}
+    notes.append(f"Footprint model '{kind}' unknown. Using point-model instead.")
+    return point
+
+
+def config_from_yaml(path: str, namespace: str | None = PLUGIN_NAMESPACE, costmap_footprint=None, **sizing):
+    """Reads a parameter file of the reference (the plugin's keys under `namespace`, as in mpc_local_planner_examples/cfg/**; namespace=None
+    or a file without that top-level key: the keys start at the top, as in cfg/test_mpc_optim_node.yaml)."""
+    import yaml
+    with open(path) as f:
+        tree = yaml.safe_load(f) or {}
+    if namespace and isinstance(tree.get(namespace), dict):
+        tree = tree[namespace]
+    return config_from_params(tree, costmap_footprint=costmap_footprint, **sizing)

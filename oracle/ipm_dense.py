@@ -456,15 +456,15 @@ class SolverNlp:
                             W[self.idt, self.iu[k, i]] += 2 * cfg.R[i] * U[k, i]
                 if cfg.integral_form and self.idt >= 0:
                     gf[self.idt] += sc
-            if cfg.Qf is not None:
-                xd = X[n - 1] - xf
-                xd[2] = R.normalize_theta(xd[2])
-                for i in range(3):
-                    if self.ix[n - 1, i] >= 0:
-                        f += cfg.Qf[i] * xd[i] ** 2
-                        gf[self.ix[n - 1, i]] += 2 * cfg.Qf[i] * xd[i]
-                        if want_hess:
-                            W[self.ix[n - 1, i], self.ix[n - 1, i]] += 2 * cfg.Qf[i]
+        if cfg.Qf is not None:         # terminal cost: independent of the stage cost's type (src/controller.cpp:641-672)
+            xd = X[n - 1] - xf
+            xd[2] = R.normalize_theta(xd[2])
+            for i in range(3):
+                if self.ix[n - 1, i] >= 0:
+                    f += cfg.Qf[i] * xd[i] ** 2
+                    gf[self.ix[n - 1, i]] += 2 * cfg.Qf[i] * xd[i]
+                    if want_hess:
+                        W[self.ix[n - 1, i], self.ix[n - 1, i]] += 2 * cfg.Qf[i]
         # equalities
         c = np.zeros(self.mc)
         Jc = np.zeros((self.mc, nv))

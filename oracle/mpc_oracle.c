@@ -618,7 +618,7 @@ static void eval_point(const work_t* w, const double* X, const double* U, double
             for (int j = 0; j < 2; ++j) f += w8 * c->R[j] * U[2 * k + j] * U[2 * k + j];
         }
     }
-    if (c->objective == 1 && c->has_Qf) {
+    if (c->has_Qf) {
         const double* xl = &X[3 * (n - 1)];
         double xd[3] = {xl[0] - w->xf[0], xl[1] - w->xf[1], wrap(xl[2] - w->xf[2])};
         for (int i = 0; i < 3; ++i) if (!c->xf_fixed[i]) f += c->Qf[i] * xd[i] * xd[i];
@@ -717,7 +717,7 @@ static void kkt_terms(const work_t* w, const double* cc, err_t* e) {
         const double* lp = &w->lam[3 * (n - 2)];
         for (int i = 0; i < 3; ++i) if (!c->xf_fixed[i]) {
             double g = 0.0;
-            if (c->objective == 1 && c->has_Qf) { double xd = w->X[3 * (n - 1) + i] - w->xf[i]; if (i == 2) xd = wrap(xd); g = 2 * c->Qf[i] * xd; }
+            if (c->has_Qf) { double xd = w->X[3 * (n - 1) + i] - w->xf[i]; if (i == 2) xd = wrap(xd); g = 2 * c->Qf[i] * xd; }
             if (ball_on(w)) { double ta[3]; ball_eval(w, w->X, ta); g += w->ty * ta[i]; }
             if (fabs(g - lp[i]) > e->rd) e->rd = fabs(g - lp[i]);
         }
@@ -897,7 +897,7 @@ static void assemble(work_t* w, const double* cc, double delta, double dc, doubl
         if (c->xf_fixed[i]) { band_add(w, id, id, 1.0); }
         else {
             band_add(w, id, id, delta);
-            if (c->objective == 1 && c->has_Qf) {
+            if (c->has_Qf) {
                 double xd = w->X[3 * (n - 1) + i] - w->xf[i]; if (i == 2) xd = wrap(xd);
                 band_add(w, id, id, 2 * c->Qf[i]);
                 w->rhs[id] -= 2 * c->Qf[i] * xd;
@@ -1122,10 +1122,10 @@ static int solve_one(work_t* w, int warm) {
                         double dx = (k + 1 < n - 1 || !c->xf_fixed[a]) ? w->rhs[ixn(k + 1, a)] : 0.0;
                         w->dz_x[3 * (k + 1) + a] = dx;
                         dz2 += dx * dx; if (fabs(dx) > dzmax) dzmax = fabs(dx);
-                        if (c->objective == 1) {
+                        {
                             double g = 0;
-                            if (k + 1 < n - 1) { double xd = w->X[3 * (k + 1) + a] - w->xf[a]; if (a == 2) xd = wrap(xd); g = 2 * c->Q[a] * xd * (c->integral ? w->D : 1.0); }
-                            else if (c->has_Qf && !c->xf_fixed[a]) { double xd = w->X[3 * (k + 1) + a] - w->xf[a]; if (a == 2) xd = wrap(xd); g = 2 * c->Qf[a] * xd; }
+                            if (c->objective == 1 && k + 1 < n - 1) { double xd = w->X[3 * (k + 1) + a] - w->xf[a]; if (a == 2) xd = wrap(xd); g = 2 * c->Q[a] * xd * (c->integral ? w->D : 1.0); }
+                            else if (k + 1 == n - 1 && c->has_Qf && !c->xf_fixed[a]) { double xd = w->X[3 * (k + 1) + a] - w->xf[a]; if (a == 2) xd = wrap(xd); g = 2 * c->Qf[a] * xd; }
                             hdz += g * dx; dphi += g * dx;
                         }
                     }

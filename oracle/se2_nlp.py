@@ -760,7 +760,7 @@ class ReferenceNlp:
         if cfg.objective == OBJ_MIN_TIME:
             # corbo::MinimumTime on a single-dt grid == (n-1)*dt; in-repo twin
             # src/optimal_control/min_time_via_points_cost.cpp:52-56,120-124
-            return (n - 1) * t.dt
+            return (n - 1) * t.dt + self._terminal_cost(t)
         if cfg.objective == OBJ_MIN_TIME_VIA_POINTS:
             # MinTimeViaPointsCost (min_time_via_points_cost.cpp:120-145): (n-1) dt on the single-dt grid, plus per attached via-point
             # position_weight |vp - p_k|^2 and -- as coded -- orientation_weight * normalize_theta(theta_vp - theta_k) (NOT squared)
@@ -772,7 +772,7 @@ class ReferenceNlp:
                 J += cfg.vp_position_weight * float((vp[0] - t.x[k, 0]) ** 2 + (vp[1] - t.x[k, 1]) ** 2)
                 if cfg.vp_orientation_weight > 0:
                     J += cfg.vp_orientation_weight * float(normalize_theta(vp[2] - t.x[k, 2]))
-            return J
+            return J + self._terminal_cost(t)
         J = 0.0
         xf = np.asarray(self.inp.xf, float)
         for k in range(n - 1):
@@ -780,11 +780,17 @@ class ReferenceNlp:
             xd[2] = normalize_theta(xd[2])         # quadratic_cost_se2.cpp:36-37
             stage = float(xd @ (cfg.Q * xd) + t.u[k] @ (cfg.R * t.u[k]))
             J += stage * (t.dt if cfg.integral_form else 1.0)   # left sum, finite_differences_grid_se2.cpp:70-74
-        if cfg.Qf is not None and self.free_xf:
-            xd = t.x[n - 1] - xf                   # final_state_conditions_se2.cpp:30-52
-            xd[2] = normalize_theta(xd[2])
-            J += float(xd @ (cfg.Qf * xd))
-        return J
+        return J + self._terminal_cost(t)
+
+    def _terminal_cost(self, t) -> float:
+        """planning/terminal_cost (src/controller.cpp:641-672): whatever the stage cost is; the edge exists only while the final state is not
+        completely fixed (finite_differences_grid_se2.cpp:128-133)"""
+        cfg = self.cfg
+        if cfg.Qf is None or not self.free_xf:
+            return 0.0
+        xd = t.x[cfg.n - 1] - np.asarray(self.inp.xf, float)       # final_state_conditions_se2.cpp:30-52
+        xd[2] = normalize_theta(xd[2])
+        return float(xd @ (cfg.Qf * xd))
 
     # ---- equalities --------------------------------------------------
     def equalities(self, z: np.ndarray) -> np.ndarray:

@@ -166,7 +166,7 @@ struct Ipm {
             }
             xk[0] = xn[0]; xk[1] = xn[1]; xk[2] = xn[2];
         }
-        if (P.objective == OBJ_QUADRATIC && P.has_Qf) {
+        if (P.has_Qf) {
             T xd[3] = {xk[0] - xf[0], xk[1] - xf[1], normalize_theta(xk[2] - xf[2])};
             for (int i = 0; i < 3; ++i) if (!P.xf_fixed[i]) fobj += P.Qf[i] * xd[i] * xd[i];
         }
@@ -300,7 +300,7 @@ struct Ipm {
         for (int i = 0; i < 3; ++i) {
             if (!P.xf_fixed[i]) {
                 T g = T(0);
-                if (P.objective == OBJ_QUADRATIC && P.has_Qf) {
+                if (P.has_Qf) {
                     T xd = X(L.X, n - 1, i) - xf[i];
                     if (i == 2) xd = normalize_theta(xd);
                     g = T(2) * P.Qf[i] * xd;
@@ -542,7 +542,7 @@ struct Ipm {
             }
         }
         // terminal: Qf gradient, final rate rows
-        if (P.objective == OBJ_QUADRATIC && P.has_Qf) {
+        if (P.has_Qf) {
             for (int i = 0; i < 3; ++i) if (!P.xf_fixed[i]) {
                 T xd = X(L.X, n - 1, i) - xf[i];
                 if (i == 2) xd = normalize_theta(xd);

@@ -842,3 +842,22 @@ def test_device_vs_independent_sqp_from_the_cold_start(m, which):
         assert conv.all() and same.all()
     else:
         assert conv.sum() >= 30 and same.sum() >= 10
+
+
+@pytest.mark.gpu
+def test_terminal_cost_with_minimum_time_objective_vs_c_oracle(m, c_oracle):
+    """planning/terminal_cost quadratic with planning/objective minimum_time and a free final state (src/controller.cpp:641-672,
+    finite_differences_grid_se2.cpp:128-133): device against the C oracle, accounting over B = 128."""
+    import dataclasses
+    from oracle import se2_nlp as R
+    B, n = 128, 30
+    ocfg = dataclasses.replace(R.config_carlike_min_time(n), Qf=np.array([2.0, 2.0, 2.0]), xf_fixed=(False, False, False), dt_lb=0.05)
+    cfg = m.config_carlike_min_time(n, Qf=(2.0, 2.0, 2.0), xf_fixed=(False, False, False), dt_lb=0.05)
+    inputs = m.workloads.carlike_min_time_inputs(B, seed=31, goal_range=(1.0, 4.0))
+    s = m.BatchSolver(cfg, max_batch=B)
+    r = s.solve(*inputs)
+    out = c_oracle.solve_batch(c_oracle.from_nlp_config(ocfg), *inputs)
+    match, other = _account("min-time + terminal cost, free xf", ocfg, inputs, r, out)
+    assert (r.status == 0).mean() > 0.9 and match.sum() > 0.85 * B
+    assert np.abs(r.x[:, -1] - inputs[1]).max(1)[r.status == 0].max() > 0.05      # the terminal cost is live: the final state is not the goal
+    s.close()

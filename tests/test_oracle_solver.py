@@ -482,3 +482,27 @@ def test_numpy_and_c_oracle_agree_on_unfiltered_config2_instances(c_oracle):
                 assert KC.is_kkt_point(KC.kkt_residuals(ocfg, x0[i], xf[i], up[i], dtp[i], o[0][i], o[1][i], o[2][i])), i
         hard += int(o[4][i] > 45)
     assert hard >= 3 and parted <= 2
+
+
+def test_terminal_cost_applies_to_the_minimum_time_objective_too(c_oracle):
+    """planning/terminal_cost is configured independently of planning/objective (src/controller.cpp:641-672) and its edge exists whenever the final
+    state is not completely fixed (finite_differences_grid_se2.cpp:128-133): minimum time + quadratic terminal cost + free final state.
+    numpy dense and C oracle agree, and the results are KKT points of the reference-form NLP."""
+    import dataclasses
+    import mpc_local_planner_amd.workloads as W
+    from oracle import kkt_check as KC
+    ocfg = dataclasses.replace(R.config_carlike_min_time(20), Qf=np.array([2.0, 2.0, 2.0]), xf_fixed=(False, False, False), dt_lb=0.05)
+    x0, xf, up, dtp = W.carlike_min_time_inputs(8, seed=5, goal_range=(1.0, 2.5))
+    xo, uo, do, st, it = c_oracle.solve_batch(c_oracle.from_nlp_config(ocfg), x0, xf, up, dtp)
+    assert (st == 0).all()
+    away = np.abs(xo[:, -1] - xf).max(1)
+    assert away.max() > 0.05          # the final state is free: the terminal cost trades distance to the goal against time
+    for i in range(4):
+        inp = R.CycleInputs(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=float(dtp[i]))
+        d = I.solve(ocfg, inp, R.cold_start(ocfg, x0[i], xf[i]))
+        assert d.status == 0 and np.abs(d.traj.x - xo[i]).max() < 1e-6
+        k = KC.kkt_residuals(ocfg, x0[i], xf[i], up[i], dtp[i], xo[i], uo[i], do[i])
+        assert KC.is_kkt_point(k), k
+        # and it is NOT a KKT point of the problem without the terminal cost
+        k0 = KC.kkt_residuals(dataclasses.replace(ocfg, Qf=None), x0[i], xf[i], up[i], dtp[i], xo[i], uo[i], do[i])
+        assert k0["stat"] > 1e-3
