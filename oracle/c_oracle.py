@@ -23,6 +23,8 @@ class OracleConfig(C.Structure):
         ("ball", C.c_int32), ("ball_S", C.c_double * 3), ("ball_gamma", C.c_double),
         ("integral", C.c_int32),
         ("hessian_mode", C.c_int32),
+        ("hybrid", C.c_int32), ("trapezoid", C.c_int32),
+        ("Qo", C.c_double * 3), ("Ro", C.c_double), ("Qfo", C.c_double * 3), ("So", C.c_double * 3),
     ]
 
 
@@ -55,14 +57,22 @@ def from_nlp_config(cfg, max_iter=100, tol=1e-8, mu_init=0.1, hessian_mode=0) ->
     for i in range(4):
         o.model_params[i] = mp[i]
     o.n, o.dt_ref, o.dt_free, o.dt_lb, o.dt_ub = cfg.n, cfg.dt_ref, int(cfg.dt_free), cfg.dt_lb, cfg.dt_ub
+    from . import se2_nlp as _R
+    Qm, Rm = _R.weight_matrix(cfg.Q), _R.weight_matrix(cfg.R)
+    Qfm = _R.weight_matrix(cfg.Qf) if cfg.Qf is not None else np.zeros((3, 3))
+    off = lambda m: (m[0, 1], m[0, 2], m[1, 2])
     for i in range(3):
         o.xf_fixed[i] = int(cfg.xf_fixed[i])
-        o.Q[i] = cfg.Q[i]
-        o.Qf[i] = cfg.Qf[i] if cfg.Qf is not None else 0.0
+        o.Q[i] = Qm[i, i]
+        o.Qf[i] = Qfm[i, i]
+        o.Qo[i], o.Qfo[i] = off(Qm)[i], off(Qfm)[i]
     o.objective = cfg.objective
     o.has_Qf = int(cfg.Qf is not None)
+    o.Ro = Rm[0, 1]
+    o.hybrid = int(bool(getattr(cfg, "hybrid_min_time", False)) and cfg.objective == 1)
+    o.trapezoid = int(getattr(cfg, "cost_integration", "left_sum") == "trapezoidal_rule")
     for j in range(2):
-        o.R[j] = cfg.R[j]
+        o.R[j] = Rm[j, j]
         o.u_lb[j], o.u_ub[j] = cfg.u_lb[j], cfg.u_ub[j]
         o.du_lb[j], o.du_ub[j] = max(cfg.du_lb[j], -1e30), min(cfg.du_ub[j], 1e30)
     o.max_iter, o.tol, o.mu_init = max_iter, tol, mu_init
@@ -71,8 +81,10 @@ def from_nlp_config(cfg, max_iter=100, tol=1e-8, mu_init=0.1, hessian_mode=0) ->
     o.integral = int(bool(getattr(cfg, "integral_form", False)) and cfg.objective == 1)
     if getattr(cfg, "terminal_ball_S", None) is not None:
         o.ball, o.ball_gamma = 1, float(cfg.terminal_ball_gamma)
+        Sm = _R.weight_matrix(cfg.terminal_ball_S)
         for i in range(3):
-            o.ball_S[i] = float(cfg.terminal_ball_S[i])
+            o.ball_S[i] = Sm[i, i]
+            o.So[i] = off(Sm)[i]
     if cfg.objective == 2:          # minimum_time_via_points = minimum time + via-point terms (set the points with set_via_points)
         o.objective, o.via = 0, 1
         o.vp_ordered, o.vp_wp, o.vp_wo = int(cfg.via_points_ordered), cfg.vp_position_weight, cfg.vp_orientation_weight

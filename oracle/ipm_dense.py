@@ -432,39 +432,68 @@ class SolverNlp:
                         f += wo * float(R.normalize_theta(vp[2] - X[k, 2]))
                         gf[self.ix[k, 2]] -= wo
         else:
+            # quadratic form x' Q x + u' R u per grid point (quadratic_cost_se2.cpp:31-83), Q / R diagonal or full; integral form: times dt by the
+            # left sum or the trapezoidal rule (finite_differences_grid_se2.cpp:61-75); hybrid: + (n - 1) dt (corbo::MinTimeQuadraticControls)
+            Qm, Rm = R.weight_matrix(cfg.Q), R.weight_matrix(cfg.R)
+            integral = cfg.integral_form
+            trapezoid = integral and cfg.cost_integration == "trapezoidal_rule"
             f = 0.0
-            for k in range(n - 1):
+            if cfg.hybrid_min_time:
+                f += (n - 1) * dt
+                if self.idt >= 0:
+                    gf[self.idt] += n - 1
+            # weight of the state term of grid point k (in units of dt when integral): left sum 1 for k < n-1; trapezoid 1/2 at both ends
+            for k in range(n):
+                ws = (0.5 if k in (0, n - 1) else 1.0) if trapezoid else (1.0 if k < n - 1 else 0.0)
+                if ws == 0.0:
+                    continue
                 xd = X[k] - xf
                 xd[2] = R.normalize_theta(xd[2])
-                sc = float(xd @ (cfg.Q * xd) + U[k] @ (cfg.R * U[k]))
-                w8 = dt if cfg.integral_form else 1.0
+                Qx = Qm @ xd
+                sc = float(xd @ Qx) * ws
+                w8 = dt if integral else 1.0
                 f += sc * w8
-                for i in range(3):
-                    if self.ix[k, i] >= 0:
-                        gf[self.ix[k, i]] += 2 * cfg.Q[i] * xd[i] * w8
-                        if want_hess:
-                            W[self.ix[k, i], self.ix[k, i]] += 2 * cfg.Q[i] * w8
-                            if cfg.integral_form and self.idt >= 0:
-                                W[self.ix[k, i], self.idt] += 2 * cfg.Q[i] * xd[i]
-                                W[self.idt, self.ix[k, i]] += 2 * cfg.Q[i] * xd[i]
-                for i in range(2):
-                    gf[self.iu[k, i]] += 2 * cfg.R[i] * U[k, i] * w8
-                    if want_hess:
-                        W[self.iu[k, i], self.iu[k, i]] += 2 * cfg.R[i] * w8
-                        if cfg.integral_form and self.idt >= 0:
-                            W[self.iu[k, i], self.idt] += 2 * cfg.R[i] * U[k, i]
-                            W[self.idt, self.iu[k, i]] += 2 * cfg.R[i] * U[k, i]
-                if cfg.integral_form and self.idt >= 0:
+                if integral and self.idt >= 0:
                     gf[self.idt] += sc
+                for i in range(3):
+                    if self.ix[k, i] < 0:
+                        continue
+                    gf[self.ix[k, i]] += 2 * Qx[i] * ws * w8
+                    if want_hess:
+                        for j in range(3):
+                            if self.ix[k, j] >= 0:
+                                W[self.ix[k, i], self.ix[k, j]] += 2 * Qm[i, j] * ws * w8
+                        if integral and self.idt >= 0:
+                            W[self.ix[k, i], self.idt] += 2 * Qx[i] * ws
+                            W[self.idt, self.ix[k, i]] += 2 * Qx[i] * ws
+            for k in range(n - 1):
+                Ru = Rm @ U[k]
+                sc = float(U[k] @ Ru)
+                w8 = dt if integral else 1.0
+                f += sc * w8
+                if integral and self.idt >= 0:
+                    gf[self.idt] += sc
+                for i in range(2):
+                    gf[self.iu[k, i]] += 2 * Ru[i] * w8
+                    if want_hess:
+                        for j in range(2):
+                            W[self.iu[k, i], self.iu[k, j]] += 2 * Rm[i, j] * w8
+                        if integral and self.idt >= 0:
+                            W[self.iu[k, i], self.idt] += 2 * Ru[i]
+                            W[self.idt, self.iu[k, i]] += 2 * Ru[i]
         if cfg.Qf is not None:         # terminal cost: independent of the stage cost's type (src/controller.cpp:641-672)
+            Qfm = R.weight_matrix(cfg.Qf)
             xd = X[n - 1] - xf
             xd[2] = R.normalize_theta(xd[2])
-            for i in range(3):
-                if self.ix[n - 1, i] >= 0:
-                    f += cfg.Qf[i] * xd[i] ** 2
-                    gf[self.ix[n - 1, i]] += 2 * cfg.Qf[i] * xd[i]
-                    if want_hess:
-                        W[self.ix[n - 1, i], self.ix[n - 1, i]] += 2 * cfg.Qf[i]
+            Qx = Qfm @ xd
+            free = [i for i in range(3) if self.ix[n - 1, i] >= 0]
+            if free:
+                f += float(xd @ Qx)
+            for i in free:
+                gf[self.ix[n - 1, i]] += 2 * Qx[i]
+                if want_hess:
+                    for j in free:
+                        W[self.ix[n - 1, i], self.ix[n - 1, j]] += 2 * Qfm[i, j]
         # equalities
         c = np.zeros(self.mc)
         Jc = np.zeros((self.mc, nv))
@@ -543,15 +572,18 @@ class SolverNlp:
                     W[self.idt, self.idt] += y[r] * float((-k * vel) @ hxd)
             r += 1
         if self.ball_row:
-            S = np.asarray(cfg.terminal_ball_S, float)
+            S = R.weight_matrix(cfg.terminal_ball_S)
             xd = X[n - 1] - xf
             xd[2] = R.normalize_theta(xd[2])
-            g[r] = float(xd @ (S * xd)) - cfg.terminal_ball_gamma
+            Sx = S @ xd
+            g[r] = float(xd @ Sx) - cfg.terminal_ball_gamma
             for i in range(3):
                 if self.ix[n - 1, i] >= 0:
-                    Jg[r, self.ix[n - 1, i]] = 2 * S[i] * xd[i]
+                    Jg[r, self.ix[n - 1, i]] = 2 * Sx[i]
                     if want_hess and y is not None:
-                        W[self.ix[n - 1, i], self.ix[n - 1, i]] += y[r] * 2 * S[i]
+                        for j in range(3):
+                            if self.ix[n - 1, j] >= 0:
+                                W[self.ix[n - 1, i], self.ix[n - 1, j]] += y[r] * 2 * S[i, j]
             r += 1
         out = dict(f=f, gf=gf, c=c, Jc=Jc, g=g, Jg=Jg)
         if want_hess:

@@ -67,7 +67,28 @@ typedef struct oracle_config {
     int32_t integral;           /* quadratic objective in integral form: stage cost x dt (left sum; quadratic_cost_se2.cpp:54-83, finite_differences_grid_se2.cpp:61-75) */
     int32_t hessian_mode;       /* 0 exact Lagrangian Hessian; 1 convexified: the stage block [Hqq Hqd; Hqd' Hdd] of lam' D is replaced by its
                                  * positive semidefinite part (the product's MPC_HESSIAN_CONVEXIFIED, the "reference-like" mode) */
+    int32_t hybrid;             /* quadratic_form/hybrid_cost_minimum_time: + (n-1) dt (corbo::MinTimeQuadraticControls, src/controller.cpp:616-618) */
+    int32_t trapezoid;          /* grid/cost_integration_method trapezoidal_rule (integral-form terms only; finite_differences_grid_se2.cpp:63-68):
+                                 * 0.5 dt (l(x_k, u_k) + l(x_{k+1}, u_k)) per interval */
+    double Qo[3], Ro, Qfo[3], So[3];   /* off-diagonal terms (01, 02, 12) of the symmetric parts of the full weight matrices (src/controller.cpp:565-573,
+                                        * 580-588, 656-664, 690-698); Q / R / Qf / ball_S hold the diagonals */
 } oracle_config;
+
+#define MINTIME(c) ((c)->objective == 0 || (c)->hybrid)
+/* y = W x for the symmetric 3 x 3 matrix with diagonal d and off-diagonal terms o = (01, 02, 12) */
+static inline void sym3_mul(const double d[3], const double o[3], const double x[3], double y[3]) {
+    y[0] = d[0] * x[0] + o[0] * x[1] + o[1] * x[2];
+    y[1] = o[0] * x[0] + d[1] * x[1] + o[2] * x[2];
+    y[2] = o[1] * x[0] + o[2] * x[1] + d[2] * x[2];
+}
+static inline double sym3_at(const double d[3], const double o[3], int i, int j) { return i == j ? d[i] : o[i + j - 1]; }
+/* weight of the state term of grid point k of the quadratic form (in units of dt when integral): one term per grid point 0..n-2 (sum or
+ * left sum); trapezoidal rule: every interval gives half to either end, so the two end points keep 1/2 and the final state gets a term */
+static inline double state_weight(const oracle_config* c, int n, int k) {
+    if (c->objective != 1) return 0.0;
+    if (c->integral && c->trapezoid) return (k == 0 || k == n - 1) ? 0.5 : 1.0;
+    return k < n - 1 ? 1.0 : 0.0;
+}
 
 #define PI 3.14159265358979323846
 #define KL 8      /* half bandwidth of the stage-interleaved KKT matrix */
@@ -603,7 +624,7 @@ static int via_terms(const work_t* w, int k, double px, double py, double th, do
 static void eval_point(const work_t* w, const double* X, const double* U, double D, double* cc, double* fobj) {
     const oracle_config* c = w->c;
     int n = w->n;
-    double f = c->objective == 0 ? (n - 1) * D : 0.0;
+    double f = MINTIME(c) ? (n - 1) * D : 0.0;
     for (int k = 0; k < n - 1; ++k) {
         stage_map_t sm;
         stage_map(c, X[3 * k + 2], U[2 * k], U[2 * k + 1], D, NULL, &sm);
@@ -612,16 +633,22 @@ static void eval_point(const work_t* w, const double* X, const double* U, double
         cc[3 * k + 2] = sm.val[2] - wrap(X[3 * (k + 1) + 2] - X[3 * k + 2]);
         if (c->via && k >= 1) { double vv, vg[3]; via_terms(w, k, X[3 * k], X[3 * k + 1], X[3 * k + 2], &vv, vg); f += vv; }
         if (c->objective == 1) {
-            double xd[3] = {X[3 * k] - w->xf[0], X[3 * k + 1] - w->xf[1], wrap(X[3 * k + 2] - w->xf[2])};
-            const double w8 = c->integral ? D : 1.0;
-            for (int i = 0; i < 3; ++i) f += w8 * c->Q[i] * xd[i] * xd[i];
-            for (int j = 0; j < 2; ++j) f += w8 * c->R[j] * U[2 * k + j] * U[2 * k + j];
+            const double w8 = c->integral ? D : 1.0, v = U[2 * k], om = U[2 * k + 1];
+            f += w8 * (c->R[0] * v * v + c->R[1] * om * om + 2 * c->Ro * v * om);
         }
     }
-    if (c->has_Qf) {
+    if (c->objective == 1) for (int k = 0; k < n; ++k) {
+        const double ws = state_weight(c, n, k);
+        if (ws == 0.0) continue;
+        double xd[3] = {X[3 * k] - w->xf[0], X[3 * k + 1] - w->xf[1], wrap(X[3 * k + 2] - w->xf[2])}, qx[3];
+        sym3_mul(c->Q, c->Qo, xd, qx);
+        f += (c->integral ? D : 1.0) * ws * (xd[0] * qx[0] + xd[1] * qx[1] + xd[2] * qx[2]);
+    }
+    if (c->has_Qf && !(c->xf_fixed[0] && c->xf_fixed[1] && c->xf_fixed[2])) {
         const double* xl = &X[3 * (n - 1)];
-        double xd[3] = {xl[0] - w->xf[0], xl[1] - w->xf[1], wrap(xl[2] - w->xf[2])};
-        for (int i = 0; i < 3; ++i) if (!c->xf_fixed[i]) f += c->Qf[i] * xd[i] * xd[i];
+        double xd[3] = {xl[0] - w->xf[0], xl[1] - w->xf[1], wrap(xl[2] - w->xf[2])}, qx[3];       /* a fixed component sits on the goal: xd = 0 */
+        sym3_mul(c->Qf, c->Qfo, xd, qx);
+        f += xd[0] * qx[0] + xd[1] * qx[1] + xd[2] * qx[2];
     }
     *fobj = f;
 }
@@ -629,13 +656,13 @@ static void eval_point(const work_t* w, const double* X, const double* U, double
 static int ball_on(const work_t* w) { return w->c->ball && !(w->c->xf_fixed[0] && w->c->xf_fixed[1] && w->c->xf_fixed[2]); }
 static double ball_eval(const work_t* w, const double* X, double a[3]) {
     const oracle_config* c = w->c;
-    double g = -c->ball_gamma;
+    double g = -c->ball_gamma, xd[3], sx[3];
     for (int i = 0; i < 3; ++i) {
-        a[i] = 0;
-        if (c->xf_fixed[i]) continue;
-        double xd = X[3 * (w->n - 1) + i] - w->xf[i]; if (i == 2) xd = wrap(xd);
-        g += c->ball_S[i] * xd * xd; a[i] = 2 * c->ball_S[i] * xd;
+        xd[i] = c->xf_fixed[i] ? 0.0 : X[3 * (w->n - 1) + i] - w->xf[i];
+        if (i == 2) xd[i] = wrap(xd[i]);
     }
+    sym3_mul(c->ball_S, c->So, xd, sx);
+    for (int i = 0; i < 3; ++i) { a[i] = c->xf_fixed[i] ? 0.0 : 2 * sx[i]; g += xd[i] * sx[i]; }
     return g;
 }
 static double barrier_logs(const work_t* w, const double* U, double D, const double* s, const double* os) {
@@ -656,7 +683,7 @@ static void kkt_terms(const work_t* w, const double* cc, err_t* e) {
     int n = w->n;
     memset(e, 0, sizeof(*e));
     e->cmin = 1e30;
-    double rdd = c->objective == 0 ? (double)(n - 1) : 0.0;
+    double rdd = MINTIME(c) ? (double)(n - 1) : 0.0;
     for (int k = 0; k < n - 1; ++k) {
         const double* lam = &w->lam[3 * k];
         double v = w->U[2 * k], om = w->U[2 * k + 1];
@@ -669,11 +696,12 @@ static void kkt_terms(const work_t* w, const double* cc, err_t* e) {
         rdd += lam[0] * sm.Jdt[0] + lam[1] * sm.Jdt[1] + lam[2] * sm.Jdt[2];
         double gx[3] = {0, 0, 0}, gu[2] = {0, 0};
         if (c->objective == 1) {
-            double xd[3] = {w->X[3 * k] - w->xf[0], w->X[3 * k + 1] - w->xf[1], wrap(w->X[3 * k + 2] - w->xf[2])};
-            const double w8 = c->integral ? w->D : 1.0;
-            for (int i = 0; i < 3; ++i) gx[i] = 2 * c->Q[i] * xd[i] * w8;
-            gu[0] = 2 * c->R[0] * v * w8; gu[1] = 2 * c->R[1] * om * w8;
-            if (c->integral) rdd += c->Q[0] * xd[0] * xd[0] + c->Q[1] * xd[1] * xd[1] + c->Q[2] * xd[2] * xd[2] + c->R[0] * v * v + c->R[1] * om * om;
+            double xd[3] = {w->X[3 * k] - w->xf[0], w->X[3 * k + 1] - w->xf[1], wrap(w->X[3 * k + 2] - w->xf[2])}, qx[3];
+            const double w8 = c->integral ? w->D : 1.0, ws = state_weight(c, n, k);
+            sym3_mul(c->Q, c->Qo, xd, qx);
+            for (int i = 0; i < 3; ++i) gx[i] = 2 * ws * qx[i] * w8;
+            gu[0] = 2 * (c->R[0] * v + c->Ro * om) * w8; gu[1] = 2 * (c->R[1] * om + c->Ro * v) * w8;
+            if (c->integral) rdd += ws * (xd[0] * qx[0] + xd[1] * qx[1] + xd[2] * qx[2]) + c->R[0] * v * v + c->R[1] * om * om + 2 * c->Ro * v * om;
         }
         if (c->via && k >= 1) { double vv, vg[3]; via_terms(w, k, w->X[3 * k], w->X[3 * k + 1], w->X[3 * k + 2], &vv, vg); for (int i = 0; i < 3; ++i) gx[i] += vg[i]; }
         double osx = 0, osy = 0, ost = 0;
@@ -715,9 +743,15 @@ static void kkt_terms(const work_t* w, const double* cc, err_t* e) {
     }
     {
         const double* lp = &w->lam[3 * (n - 2)];
+        double xdf[3] = {w->X[3 * (n - 1)] - w->xf[0], w->X[3 * (n - 1) + 1] - w->xf[1], wrap(w->X[3 * (n - 1) + 2] - w->xf[2])}, qfx[3], qtx[3];
+        const double wt = state_weight(c, n, n - 1);              /* trapezoidal rule: the final state carries half an interval's state cost */
+        sym3_mul(c->Qf, c->Qfo, xdf, qfx);
+        sym3_mul(c->Q, c->Qo, xdf, qtx);
+        if (wt != 0.0) rdd += wt * (xdf[0] * qtx[0] + xdf[1] * qtx[1] + xdf[2] * qtx[2]);
         for (int i = 0; i < 3; ++i) if (!c->xf_fixed[i]) {
             double g = 0.0;
-            if (c->has_Qf) { double xd = w->X[3 * (n - 1) + i] - w->xf[i]; if (i == 2) xd = wrap(xd); g = 2 * c->Qf[i] * xd; }
+            if (c->has_Qf) g = 2 * qfx[i];
+            if (wt != 0.0) g += 2 * wt * w->D * qtx[i];
             if (ball_on(w)) { double ta[3]; ball_eval(w, w->X, ta); g += w->ty * ta[i]; }
             if (fabs(g - lp[i]) > e->rd) e->rd = fabs(g - lp[i]);
         }
@@ -797,7 +831,7 @@ static void assemble(work_t* w, const double* cc, double delta, double dc, doubl
     memset(w->bcol, 0, sizeof(double) * N);
     double D = w->D, mu = w->mu;
     double hdd = 0.0, gd = 0.0;
-    if (c->objective == 0) gd += (double)(n - 1);
+    if (MINTIME(c)) gd += (double)(n - 1);
     if (c->dt_free) {
         double dl = D - c->dt_lb, du = c->dt_ub - D;
         hdd += w->pdl / dl + w->pdu / du + delta;
@@ -832,15 +866,21 @@ static void assemble(work_t* w, const double* cc, double delta, double dc, doubl
         hdd += sm.Hdd;
         /* objective */
         if (c->objective == 1) {
-            double xd[3] = {w->X[3 * k] - w->xf[0], w->X[3 * k + 1] - w->xf[1], wrap(w->X[3 * k + 2] - w->xf[2])};
-            const double w8 = c->integral ? D : 1.0;
-            if (k >= 1) for (int i = 0; i < 3; ++i) { band_add(w, ixn(k, i), ixn(k, i), 2 * c->Q[i] * w8); w->rhs[ixn(k, i)] -= 2 * c->Q[i] * xd[i] * w8; }
-            for (int j = 0; j < 2; ++j) { band_add(w, iu(k, j), iu(k, j), 2 * c->R[j] * w8); w->rhs[iu(k, j)] -= 2 * c->R[j] * w->U[2 * k + j] * w8; }
-            if (c->integral) {       /* d/d dt and the mixed second derivatives of  dt * (xd'Q xd + u'R u) */
-                if (k >= 1) for (int i = 0; i < 3; ++i) w->bcol[ixn(k, i)] += 2 * c->Q[i] * xd[i];
-                for (int j = 0; j < 2; ++j) w->bcol[iu(k, j)] += 2 * c->R[j] * w->U[2 * k + j];
-                for (int i = 0; i < 3; ++i) gd += c->Q[i] * xd[i] * xd[i];
-                for (int j = 0; j < 2; ++j) gd += c->R[j] * w->U[2 * k + j] * w->U[2 * k + j];
+            double xd[3] = {w->X[3 * k] - w->xf[0], w->X[3 * k + 1] - w->xf[1], wrap(w->X[3 * k + 2] - w->xf[2])}, qx[3];
+            const double w8 = c->integral ? D : 1.0, ws = state_weight(c, n, k), v = w->U[2 * k], om = w->U[2 * k + 1];
+            const double ru[2] = {c->R[0] * v + c->Ro * om, c->R[1] * om + c->Ro * v};
+            sym3_mul(c->Q, c->Qo, xd, qx);
+            if (k >= 1) for (int i = 0; i < 3; ++i) {
+                band_add(w, ixn(k, i), ixn(k, i), 2 * ws * c->Q[i] * w8);
+                for (int j = i + 1; j < 3; ++j) sym_add(w, ixn(k, i), ixn(k, j), 2 * ws * sym3_at(c->Q, c->Qo, i, j) * w8);
+                w->rhs[ixn(k, i)] -= 2 * ws * qx[i] * w8;
+            }
+            for (int j = 0; j < 2; ++j) { band_add(w, iu(k, j), iu(k, j), 2 * c->R[j] * w8); w->rhs[iu(k, j)] -= 2 * ru[j] * w8; }
+            sym_add(w, iu(k, 0), iu(k, 1), 2 * c->Ro * w8);
+            if (c->integral) {       /* d/d dt and the mixed second derivatives of  dt * (ws xd'Q xd + u'R u) */
+                if (k >= 1) for (int i = 0; i < 3; ++i) w->bcol[ixn(k, i)] += 2 * ws * qx[i];
+                for (int j = 0; j < 2; ++j) w->bcol[iu(k, j)] += 2 * ru[j];
+                gd += ws * (xd[0] * qx[0] + xd[1] * qx[1] + xd[2] * qx[2]) + v * ru[0] + om * ru[1];
             }
         }
         if (c->via && k >= 1) {
@@ -892,16 +932,25 @@ static void assemble(work_t* w, const double* cc, double delta, double dc, doubl
         }
     }
     /* terminal state block: free components are variables, fixed ones are pinned (dx = 0) */
-    for (int i = 0; i < 3; ++i) {
-        int id = ixn(n - 1, i);
-        if (c->xf_fixed[i]) { band_add(w, id, id, 1.0); }
-        else {
+    {
+        double xdf[3] = {w->X[3 * (n - 1)] - w->xf[0], w->X[3 * (n - 1) + 1] - w->xf[1], wrap(w->X[3 * (n - 1) + 2] - w->xf[2])}, qfx[3], qtx[3];
+        const double wt = state_weight(c, n, n - 1);              /* trapezoidal rule: wt * dt * xd' Q xd on the final state */
+        sym3_mul(c->Qf, c->Qfo, xdf, qfx);
+        sym3_mul(c->Q, c->Qo, xdf, qtx);
+        if (wt != 0.0) gd += wt * (xdf[0] * qtx[0] + xdf[1] * qtx[1] + xdf[2] * qtx[2]);
+        for (int i = 0; i < 3; ++i) {
+            int id = ixn(n - 1, i);
+            if (c->xf_fixed[i]) { band_add(w, id, id, 1.0); continue; }
             band_add(w, id, id, delta);
-            if (c->has_Qf) {
-                double xd = w->X[3 * (n - 1) + i] - w->xf[i]; if (i == 2) xd = wrap(xd);
-                band_add(w, id, id, 2 * c->Qf[i]);
-                w->rhs[id] -= 2 * c->Qf[i] * xd;
+            for (int j = i; j < 3; ++j) {
+                if (c->xf_fixed[j]) continue;
+                double h = 0.0;
+                if (c->has_Qf) h += 2 * sym3_at(c->Qf, c->Qfo, i, j);
+                if (wt != 0.0) h += 2 * wt * D * sym3_at(c->Q, c->Qo, i, j);
+                if (h != 0.0) sym_add(w, id, ixn(n - 1, j), h);
             }
+            if (c->has_Qf) w->rhs[id] -= 2 * qfx[i];
+            if (wt != 0.0) { w->rhs[id] -= 2 * wt * D * qtx[i]; w->bcol[id] += 2 * wt * qtx[i]; }
         }
     }
     if (ball_on(w)) {        /* condensed terminal-ball row: + sigma a a' + 2 y S, gradient + a ybar */
@@ -909,7 +958,7 @@ static void assemble(work_t* w, const double* cc, double delta, double dc, doubl
         for (int i = 0; i < 3; ++i) {
             if (c->xf_fixed[i]) continue;
             band_add(w, ixn(n - 1, i), ixn(n - 1, i), 2 * w->ty * c->ball_S[i] + sig * w->ta[i] * w->ta[i]);
-            for (int j = i + 1; j < 3; ++j) if (!c->xf_fixed[j]) sym_add(w, ixn(n - 1, i), ixn(n - 1, j), sig * w->ta[i] * w->ta[j]);
+            for (int j = i + 1; j < 3; ++j) if (!c->xf_fixed[j]) sym_add(w, ixn(n - 1, i), ixn(n - 1, j), 2 * w->ty * sym3_at(c->ball_S, c->So, i, j) + sig * w->ta[i] * w->ta[j]);
             w->rhs[ixn(n - 1, i)] -= w->ta[i] * ybar;
         }
     }
@@ -1095,11 +1144,12 @@ static int solve_one(work_t* w, int warm) {
                     ftb(w->pdl, mu / dl - w->pdl - (w->pdl / dl) * ddt, tau, &a_d);
                     ftb(w->pdu, mu / du - w->pdu + (w->pdu / du) * ddt, tau, &a_d);
                 }
-                if (c->objective == 0) { hdz += (n - 1) * ddt; dphi += (n - 1) * ddt; }
-                if (c->objective == 1 && c->integral) for (int k = 0; k < n - 1; ++k) {        /* d/d dt of the integral-form stage costs */
-                    double xd[3] = {w->X[3 * k] - w->xf[0], w->X[3 * k + 1] - w->xf[1], wrap(w->X[3 * k + 2] - w->xf[2])}, sc = 0;
-                    for (int i = 0; i < 3; ++i) sc += c->Q[i] * xd[i] * xd[i];
-                    for (int j = 0; j < 2; ++j) sc += c->R[j] * w->U[2 * k + j] * w->U[2 * k + j];
+                if (MINTIME(c)) { hdz += (n - 1) * ddt; dphi += (n - 1) * ddt; }
+                if (c->objective == 1 && c->integral) for (int k = 0; k < n; ++k) {        /* d/d dt of the integral-form stage costs */
+                    double xd[3] = {w->X[3 * k] - w->xf[0], w->X[3 * k + 1] - w->xf[1], wrap(w->X[3 * k + 2] - w->xf[2])}, qx[3], sc;
+                    sym3_mul(c->Q, c->Qo, xd, qx);
+                    sc = state_weight(c, n, k) * (xd[0] * qx[0] + xd[1] * qx[1] + xd[2] * qx[2]);
+                    if (k < n - 1) { const double v = w->U[2 * k], om = w->U[2 * k + 1]; sc += c->R[0] * v * v + c->R[1] * om * om + 2 * c->Ro * v * om; }
                     hdz += sc * ddt; dphi += sc * ddt;
                 }
                 for (int k = 0; k < n - 1; ++k) {
@@ -1107,7 +1157,7 @@ static int solve_one(work_t* w, int warm) {
                         double du_ = w->rhs[iu(k, j)], u = w->U[2 * k + j];
                         double dl = u - c->u_lb[j], du = c->u_ub[j] - u, pl = w->pl[2 * k + j], pu = w->pu[2 * k + j];
                         double gb = -mu / dl + mu / du;
-                        if (c->objective == 1) gb += 2 * c->R[j] * u * (c->integral ? w->D : 1.0);
+                        if (c->objective == 1) gb += 2 * (c->R[j] * u + c->Ro * w->U[2 * k + 1 - j]) * (c->integral ? w->D : 1.0);
                         hdz += gb * du_; dphi += gb * du_; dz2 += du_ * du_; if (fabs(du_) > dzmax) dzmax = fabs(du_);
                         ftb(dl, du_, tau, &a_p); ftb(du, -du_, tau, &a_p);
                         ftb(pl, mu / dl - pl - (pl / dl) * du_, tau, &a_d);
@@ -1124,8 +1174,11 @@ static int solve_one(work_t* w, int warm) {
                         dz2 += dx * dx; if (fabs(dx) > dzmax) dzmax = fabs(dx);
                         {
                             double g = 0;
-                            if (c->objective == 1 && k + 1 < n - 1) { double xd = w->X[3 * (k + 1) + a] - w->xf[a]; if (a == 2) xd = wrap(xd); g = 2 * c->Q[a] * xd * (c->integral ? w->D : 1.0); }
-                            else if (k + 1 == n - 1 && c->has_Qf && !c->xf_fixed[a]) { double xd = w->X[3 * (k + 1) + a] - w->xf[a]; if (a == 2) xd = wrap(xd); g = 2 * c->Qf[a] * xd; }
+                            const double xd[3] = {w->X[3 * (k + 1)] - w->xf[0], w->X[3 * (k + 1) + 1] - w->xf[1], wrap(w->X[3 * (k + 1) + 2] - w->xf[2])};
+                            const double ws = state_weight(c, n, k + 1);
+                            double qx[3];
+                            if (ws != 0.0) { sym3_mul(c->Q, c->Qo, xd, qx); g = 2 * ws * qx[a] * (c->integral ? w->D : 1.0); }
+                            if (k + 1 == n - 1 && c->has_Qf && !c->xf_fixed[a]) { sym3_mul(c->Qf, c->Qfo, xd, qx); g += 2 * qx[a]; }
                             hdz += g * dx; dphi += g * dx;
                         }
                     }

@@ -320,14 +320,16 @@ class OcpConfig:
     xf_fixed: Tuple[bool, bool, bool] = (True, True, True)   # :282
     collocation: int = COLLOC_FORWARD             # :298
     objective: int = OBJ_MIN_TIME                 # :551
-    Q: np.ndarray = field(default_factory=lambda: np.zeros(3))     # diagonal state weights
-    R: np.ndarray = field(default_factory=lambda: np.zeros(2))     # diagonal control weights
+    Q: np.ndarray = field(default_factory=lambda: np.zeros(3))     # state weights: (3,) diagonal or (3, 3) matrix (controller.cpp:561-576)
+    R: np.ndarray = field(default_factory=lambda: np.zeros(2))     # control weights: (2,) or (2, 2)
     integral_form: bool = False
-    Qf: Optional[np.ndarray] = None               # terminal_cost quadratic (diag) or None
+    cost_integration: str = "left_sum"            # grid/cost_integration_method: left_sum | trapezoidal_rule (integral-form terms only; controller.cpp:318-333)
+    hybrid_min_time: bool = False                 # quadratic_form/hybrid_cost_minimum_time: corbo::MinTimeQuadraticControls = minimum time + control cost (:616-618)
+    Qf: Optional[np.ndarray] = None               # terminal_cost quadratic: (3,) diagonal or (3, 3), or None
     vp_position_weight: float = 1e-3              # minimum_time_via_points/position_weight (min_time_via_points_cost.h:122)
     vp_orientation_weight: float = 0.0            # .../orientation_weight
     via_points_ordered: bool = False              # .../via_points_ordered
-    terminal_ball_S: Optional[np.ndarray] = None  # terminal_constraint l2_ball weight_matrix (diag) or None   (controller.cpp:683-703)
+    terminal_ball_S: Optional[np.ndarray] = None  # terminal_constraint l2_ball weight_matrix ((3,) diagonal or (3, 3)) or None   (controller.cpp:683-703)
     terminal_ball_gamma: float = 1.0              # .../l2_ball/radius: the row is xd' S xd - gamma <= 0 (final_state_conditions_se2.cpp:54-64)
     u_lb: np.ndarray = field(default_factory=lambda: np.array([-0.2, -0.3]))
     u_ub: np.ndarray = field(default_factory=lambda: np.array([0.4, 0.3]))
@@ -340,6 +342,12 @@ class OcpConfig:
     enable_dynamic_obstacles: bool = False
     footprint_kind: int = FOOTPRINT_POINT
     footprint_params: Tuple[float, ...] = ()
+
+
+def weight_matrix(w) -> np.ndarray:
+    """a weight given as its diagonal or as a full matrix -> the symmetric matrix the quadratic form x' W x sees"""
+    w = np.asarray(w, float)
+    return np.diag(w) if w.ndim == 1 else 0.5 * (w + w.T)
 
 
 def config_carlike_min_time(n: int = 50) -> OcpConfig:
@@ -773,13 +781,23 @@ class ReferenceNlp:
                 if cfg.vp_orientation_weight > 0:
                     J += cfg.vp_orientation_weight * float(normalize_theta(vp[2] - t.x[k, 2]))
             return J + self._terminal_cost(t)
-        J = 0.0
         xf = np.asarray(self.inp.xf, float)
-        for k in range(n - 1):
+        Qm, Rm = weight_matrix(cfg.Q), weight_matrix(cfg.R)
+
+        def state_cost(k):
             xd = t.x[k] - xf                       # StaticReference(xf), src/controller.cpp:169
             xd[2] = normalize_theta(xd[2])         # quadratic_cost_se2.cpp:36-37
-            stage = float(xd @ (cfg.Q * xd) + t.u[k] @ (cfg.R * t.u[k]))
-            J += stage * (t.dt if cfg.integral_form else 1.0)   # left sum, finite_differences_grid_se2.cpp:70-74
+            return float(xd @ Qm @ xd)
+        J = (n - 1) * t.dt if cfg.hybrid_min_time else 0.0       # corbo::MinTimeQuadraticControls: MinimumTime's dt term + the control cost
+        for k in range(n - 1):
+            ctrl = float(t.u[k] @ Rm @ t.u[k])
+            if not cfg.integral_form:
+                J += state_cost(k) + ctrl                                        # non-integral terms: one edge per grid point
+            elif cfg.cost_integration == "trapezoidal_rule":
+                # corbo::TrapezoidalIntegralCostEdge(x_k, u_k, x_{k+1}, dt): 0.5 dt (l(x_k, u_k) + l(x_{k+1}, u_k)), finite_differences_grid_se2.cpp:63-68
+                J += 0.5 * t.dt * ((state_cost(k) + ctrl) + (state_cost(k + 1) + ctrl))
+            else:
+                J += t.dt * (state_cost(k) + ctrl)                                # left sum, finite_differences_grid_se2.cpp:70-74
         return J + self._terminal_cost(t)
 
     def _terminal_cost(self, t) -> float:
@@ -790,7 +808,7 @@ class ReferenceNlp:
             return 0.0
         xd = t.x[cfg.n - 1] - np.asarray(self.inp.xf, float)       # final_state_conditions_se2.cpp:30-52
         xd[2] = normalize_theta(xd[2])
-        return float(xd @ (cfg.Qf * xd))
+        return float(xd @ weight_matrix(cfg.Qf) @ xd)
 
     # ---- equalities --------------------------------------------------
     def equalities(self, z: np.ndarray) -> np.ndarray:
@@ -836,7 +854,7 @@ class ReferenceNlp:
             # TerminalBallSE2::computeNonIntegralStateTerm (final_state_conditions_se2.cpp:54-64)
             xd = t.x[n - 1] - np.asarray(self.inp.xf, float)
             xd[2] = normalize_theta(xd[2])
-            rows.append(float(xd @ (np.asarray(cfg.terminal_ball_S, float) * xd)) - cfg.terminal_ball_gamma)
+            rows.append(float(xd @ weight_matrix(cfg.terminal_ball_S) @ xd) - cfg.terminal_ball_gamma)
         if nrate:
             # getFinalControlDeviationEdges(n, u_ref(=0), u_{n-2}, dt): finite_differences_grid_se2.cpp:150
             rows += self._rate_rows(np.zeros(2), t.u[n - 2], t.dt)

@@ -186,6 +186,57 @@ def test_solver_nlp_derivatives_vs_numeric_through_retraction():
     np.testing.assert_allclose(num(gradL), ev["W"], atol=1e-5)
 
 
+FULL_Q = np.array([[2.0, 0.3, -0.1], [0.3, 1.5, 0.2], [-0.1, 0.2, 0.4]])
+FULL_R = np.array([[0.1, 0.02], [0.02, 0.05]])
+FULL_QF = np.array([[8.0, 1.0, 0.0], [1.0, 9.0, 0.5], [0.0, 0.5, 0.6]])
+FULL_S = np.array([[1.0, 0.2, 0.0], [0.2, 1.0, 0.1], [0.0, 0.1, 0.5]])
+
+
+@pytest.mark.parametrize("case", ["full_weights", "trapezoid_free_dt", "trapezoid_fixed_dt", "hybrid", "full_weights_trapezoid_ball"])
+def test_cost_variants_objective_equals_the_reference_form_and_derivatives_match(case):
+    """full Q / R / Qf / S matrices (src/controller.cpp:561-592,652-668,686-702), trapezoidal rule for integral-form costs
+    (finite_differences_grid_se2.cpp:63-68), hybrid minimum time + control cost (src/controller.cpp:616-618): the solver NLP's objective equals
+    the reference-form objective at random points and its analytic derivatives match central differences through the retraction."""
+    import dataclasses
+    base = R.config_unicycle_quadratic(8)
+    cfg = {
+        "full_weights": dataclasses.replace(base, Q=FULL_Q, R=FULL_R, Qf=FULL_QF),
+        "trapezoid_free_dt": dataclasses.replace(base, integral_form=True, cost_integration="trapezoidal_rule", dt_free=True),
+        "trapezoid_fixed_dt": dataclasses.replace(base, integral_form=True, cost_integration="trapezoidal_rule"),
+        "hybrid": dataclasses.replace(base, Q=np.zeros(3), Qf=None, hybrid_min_time=True, dt_free=True, xf_fixed=(True, True, True)),
+        "full_weights_trapezoid_ball": dataclasses.replace(base, Q=FULL_Q, R=FULL_R, Qf=FULL_QF, integral_form=True, cost_integration="trapezoidal_rule", dt_free=True,
+                                                           terminal_ball_S=FULL_S, terminal_ball_gamma=0.3),
+    }[case]
+    inp = R.CycleInputs(x0=np.array([0, 0, 0.1]), xf=np.array([1.0, 0.3, 0.2]), u_prev=np.zeros(2), dt_prev=0.2)
+    nlp = I.SolverNlp(cfg, inp)
+    ref = R.ReferenceNlp(cfg, inp)
+    rng = np.random.default_rng(5)
+    for trial in range(3):
+        v = nlp.to_vec(R.cold_start(cfg, inp.x0, inp.xf)) + 0.05 * rng.standard_normal(nlp.nv)
+        if nlp.idt >= 0:
+            v[nlp.idt] = 0.3 + 0.1 * rng.uniform()
+        tt = nlp.to_traj(v)
+        assert abs(nlp.eval(v)["f"] - ref.objective(ref.pack(tt))) < 1e-12
+    lam = rng.standard_normal(nlp.mc)
+    y = rng.uniform(0.1, 1, nlp.mg)
+    ev = nlp.eval(v, lam, y, want_hess=True)
+
+    def num(fun, h=1e-6):
+        f0 = np.atleast_1d(fun(v))
+        J = np.zeros((f0.size, v.size))
+        for i in range(v.size):
+            e = np.zeros(v.size); e[i] = h
+            J[:, i] = (np.atleast_1d(fun(nlp.retract(v, e))) - np.atleast_1d(fun(nlp.retract(v, -e)))) / (2 * h)
+        return J
+    np.testing.assert_allclose(num(lambda a: nlp.eval(a)["f"])[0], ev["gf"], atol=1e-6)
+    np.testing.assert_allclose(num(lambda a: nlp.eval(a)["g"]), ev["Jg"], atol=1e-6)
+
+    def gradL(a):
+        e = nlp.eval(a)
+        return e["gf"] + e["Jc"].T @ lam + e["Jg"].T @ y
+    np.testing.assert_allclose(num(gradL), ev["W"], atol=2e-5)
+
+
 def test_warm_start_shift_and_nearest_state():
     # ...grid_base_se2.cpp:241-339
     x = np.stack([np.linspace(0, 1, 6), np.zeros(6), np.zeros(6)], 1)
