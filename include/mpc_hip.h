@@ -76,6 +76,8 @@ enum mpc_candidate_kind {
 };
 #define MPC_MAX_CANDIDATES 4
 
+enum mpc_cost_integration { MPC_COST_LEFT_SUM = 0, MPC_COST_TRAPEZOIDAL = 1 };
+
 enum mpc_hessian_mode {
     MPC_HESSIAN_EXACT = 0,            /* exact Lagrangian Hessian (analytic) + inertia-free regularisation: the default */
     MPC_HESSIAN_CONVEXIFIED = 1       /* every stage block of the constraint curvature lam' D over (theta, v, w, dt) replaced by its positive semidefinite
@@ -113,11 +115,11 @@ typedef struct mpc_config {
     int32_t xf_fixed[3];              /* grid/xf_fixed                    (:282) */
     int32_t collocation;              /* grid/collocation_method          (:298) */
     int32_t objective;                /* planning/objective/type          (:551) */
-    double  Q[3], R[2];               /* quadratic_form weights (diag)    (:561-592) */
+    double  Q[3], R[2];               /* quadratic_form weights: diagonals (:561-592); off-diagonal terms: Q_offdiag, R_offdiag below */
     int32_t integral_form;            /* .../integral_form                (:594) */
     int32_t has_Qf;                   /* planning/terminal_cost/type == quadratic (:645); applies with EVERY objective type, on the goal components
                                        * that are free (the edge exists while the final state is not completely fixed, finite_differences_grid_se2.cpp:128-133) */
-    double  Qf[3];                    /* final_state_weights (diag)       (:652-668) */
+    double  Qf[3];                    /* final_state_weights: diagonal    (:652-668); off-diagonal terms: Qf_offdiag */
     double  u_lb[2], u_ub[2];         /* control box                      (:511,:527,:543) */
     double  du_lb[2], du_ub[2];       /* control-rate box; +-1e30 = inf   (:756-797) */
     /* solver (replaces solver/ipopt/..., :388-421) */
@@ -141,7 +143,7 @@ typedef struct mpc_config {
                                        * Closed-loop cycles start next to a solution: 1e-2 saves ~25 % of the iterations. */
     int32_t terminal_ball;            /* planning/terminal_constraint/type == l2_ball (src/controller.cpp:683); the row exists only when at
                                        * least one goal component is free (finite_differences_grid_se2.cpp:128-143) */
-    double  terminal_ball_S[3];       /* .../l2_ball/weight_matrix (diagonal)  (:686-692) */
+    double  terminal_ball_S[3];       /* .../l2_ball/weight_matrix: diagonal  (:686-692); off-diagonal terms: terminal_ball_S_offdiag */
     double  terminal_ball_gamma;      /* .../l2_ball/radius: row  xd' S xd - gamma <= 0  (final_state_conditions_se2.cpp:54-64) */
     double  vp_position_weight;       /* objective/minimum_time_via_points/position_weight    (src/controller.cpp:601) */
     double  vp_orientation_weight;    /* .../orientation_weight (:603); as coded the term is LINEAR in the heading error
@@ -172,7 +174,20 @@ typedef struct mpc_config {
     double  mu_init_dual;             /* barrier start of such a solve (0 -> 1e-3) */
     double  candidate_param[MPC_MAX_CANDIDATES];      /* per candidate: tangent scale of the MPC_CAND_HERMITE_* kinds (0 -> 2.0) */
     int32_t hessian_mode;             /* MPC_HESSIAN_EXACT | MPC_HESSIAN_CONVEXIFIED (solver/ipopt/ipopt_string_options/hessian_approximation, :407-418) */
-    int32_t reserved[6];
+    int32_t hybrid_cost_minimum_time; /* planning/objective/quadratic_form/hybrid_cost_minimum_time (src/controller.cpp:596,616-618): with objective
+                                       * MPC_OBJ_QUADRATIC the cost is minimum time PLUS the quadratic form, (n-1) dt + sum ...  (corbo::MinTimeQuadraticControls;
+                                       * the reference only takes this branch when the state weights are zero -- the reader of mpc_params.hpp mirrors that) */
+    int32_t cost_integration;         /* grid/cost_integration_method (:318-333): MPC_COST_LEFT_SUM | MPC_COST_TRAPEZOIDAL.  Only integral-form terms are
+                                       * integrated (integral_form = 1): trapezoidal = 0.5 dt (l(x_k, u_k) + l(x_{k+1}, u_k)) per interval
+                                       * (corbo::TrapezoidalIntegralCostEdge, finite_differences_grid_se2.cpp:63-68) */
+    int32_t reserved[4];
+    /* full weight matrices (state_weights / control_weights / final_state_weights / weight_matrix given as n x n lists, column major,
+     * src/controller.cpp:565-573,580-588,656-664,690-698): Q, R, Qf, terminal_ball_S above hold the DIAGONALS, these the off-diagonal terms
+     * (0,1), (0,2), (1,2) of the symmetric parts (x' W x only sees (W + W') / 2); all zero = diagonal weights */
+    double  Q_offdiag[3];
+    double  R_offdiag;
+    double  Qf_offdiag[3];
+    double  terminal_ball_S_offdiag[3];
 } mpc_config;
 
 /* Obstacles of a batch (teb_local_planner ObstContainer of every instance, flattened; borrowed for the call).

@@ -123,17 +123,17 @@ struct ParamReport {
 };
 
 namespace detail {
-// length dim: diagonal; dim*dim: full matrix, column major (Eigen's default, src/controller.cpp:565-573); x'Mx only sees the symmetric part
-inline ParamStatus weights(const std::vector<double>& v, int dim, const char* what, const char* reason, double* out, ParamReport& rep) {
-    if ((int)v.size() == dim) { for (int i = 0; i < dim; ++i) out[i] = v[i]; return PARAMS_OK; }
+// length dim: diagonal; dim*dim: full matrix, column major (Eigen's default, src/controller.cpp:565-573); x'Mx only sees the symmetric part:
+// diag[] gets the diagonal, off[] the symmetric off-diagonal terms (0,1)[, (0,2), (1,2)]
+inline ParamStatus weights(const std::vector<double>& v, int dim, const char* reason, double* diag, double* off, ParamReport& rep) {
+    const int noff = dim == 3 ? 3 : 1;
+    for (int i = 0; i < noff; ++i) off[i] = 0.0;
+    if ((int)v.size() == dim) { for (int i = 0; i < dim; ++i) diag[i] = v[i]; return PARAMS_OK; }
     if ((int)v.size() == dim * dim) {
-        for (int r = 0; r < dim; ++r)
-            for (int c = 0; c < dim; ++c)
-                if (r != c && v[c * dim + r] + v[r * dim + c] != 0.0) {
-                    rep.error = std::string(what) + ": a weight matrix with off-diagonal terms (the device path takes diagonal weights)";
-                    return PARAMS_NOT_IMPLEMENTED;
-                }
-        for (int i = 0; i < dim; ++i) out[i] = v[i * dim + i];
+        auto at = [&](int r, int c) { return 0.5 * (v[c * dim + r] + v[r * dim + c]); };
+        for (int i = 0; i < dim; ++i) diag[i] = v[i * dim + i];
+        off[0] = at(0, 1);
+        if (dim == 3) { off[1] = at(0, 2); off[2] = at(1, 2); }
         return PARAMS_OK;
     }
     rep.error = reason;
@@ -292,20 +292,20 @@ inline ParamStatus config_from_params(const ParamSource& p, mpc_config& c, Contr
         std::vector<double> qw, rw;
         p.get("planning/objective/quadratic_form/state_weights", qw);
         p.get("planning/objective/quadratic_form/control_weights", rw);
-        ParamStatus st = detail::weights(qw, 3, "state_weights", "State weights dimension invalid. Must be either 3 x 1 or 3 x 3.", c.Q, rep);
+        ParamStatus st = detail::weights(qw, 3, "State weights dimension invalid. Must be either 3 x 1 or 3 x 3.", c.Q, c.Q_offdiag, rep);
         if (st != PARAMS_OK) return st;
-        st = detail::weights(rw, 2, "control_weights", "Control weights dimension invalid. Must be either 2 x 1 or 2 x 2.", c.R, rep);
+        st = detail::weights(rw, 2, "Control weights dimension invalid. Must be either 2 x 1 or 2 x 2.", c.R, &c.R_offdiag, rep);
         if (st != PARAMS_OK) return st;
         c.integral_form = p.param("planning/objective/quadratic_form/integral_form", false) ? 1 : 0;
         bool hybrid = p.param("planning/objective/quadratic_form/hybrid_cost_minimum_time", false);
-        const bool q_zero = c.Q[0] == 0 && c.Q[1] == 0 && c.Q[2] == 0, r_zero = c.R[0] == 0 && c.R[1] == 0;
+        const bool q_zero = c.Q[0] == 0 && c.Q[1] == 0 && c.Q[2] == 0 && c.Q_offdiag[0] == 0 && c.Q_offdiag[1] == 0 && c.Q_offdiag[2] == 0;
+        const bool r_zero = c.R[0] == 0 && c.R[1] == 0 && c.R_offdiag == 0;
         if (hybrid && !(q_zero && !r_zero)) {
             rep.notes.push_back("Hybrid minimum time and quadratic form cost is currently only supported for non-zero control weights only. Falling back to quadratic form.");
             hybrid = false;
         }
-        if (hybrid) return missing("planning/objective/quadratic_form/hybrid_cost_minimum_time (corbo::MinTimeQuadraticControls)");
-        if (c.integral_form && integration == "trapezoidal_rule" && !q_zero)
-            return missing("grid/cost_integration_method trapezoidal_rule with an integral-form state cost (the device path integrates by the left sum)");
+        c.hybrid_cost_minimum_time = hybrid ? 1 : 0;            // corbo::MinTimeQuadraticControls: (n - 1) dt + the control cost (:616-618)
+        c.cost_integration = integration == "trapezoidal_rule" ? MPC_COST_TRAPEZOIDAL : MPC_COST_LEFT_SUM;      // integral-form terms only (:318-333)
     } else if (objective == "minimum_time_via_points") {
         c.objective = MPC_OBJ_MIN_TIME_VIA_POINTS;
         c.via_points_ordered = p.param("planning/objective/minimum_time_via_points/via_points_ordered", false) ? 1 : 0;
@@ -317,7 +317,7 @@ inline ParamStatus config_from_params(const ParamSource& p, mpc_config& c, Contr
     if (tcost == "quadratic") {
         std::vector<double> w;
         p.get("planning/terminal_cost/quadratic/final_state_weights", w);
-        ParamStatus st = detail::weights(w, 3, "final_state_weights", "Final state weights dimension invalid. Must be either 3 x 1 or 3 x 3.", c.Qf, rep);
+        ParamStatus st = detail::weights(w, 3, "Final state weights dimension invalid. Must be either 3 x 1 or 3 x 3.", c.Qf, c.Qf_offdiag, rep);
         if (st != PARAMS_OK) return st;
         c.has_Qf = 1;
     } else if (tcost != "none") return reject("Unknown terminal_cost type '" + tcost + "' specified ('planning/terminal_cost/type').");
@@ -325,7 +325,7 @@ inline ParamStatus config_from_params(const ParamSource& p, mpc_config& c, Contr
     if (tcon == "l2_ball") {
         std::vector<double> w;
         p.get("planning/terminal_constraint/l2_ball/weight_matrix", w);
-        ParamStatus st = detail::weights(w, 3, "weight_matrix", "l2-ball weight_matrix dimensions invalid. Must be either 3 x 1 or 3 x 3.", c.terminal_ball_S, rep);
+        ParamStatus st = detail::weights(w, 3, "l2-ball weight_matrix dimensions invalid. Must be either 3 x 1 or 3 x 3.", c.terminal_ball_S, c.terminal_ball_S_offdiag, rep);
         if (st != PARAMS_OK) return st;
         c.terminal_ball = 1;
         c.terminal_ball_gamma = p.param("planning/terminal_constraint/l2_ball/radius", 1.0);

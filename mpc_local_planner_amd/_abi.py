@@ -35,6 +35,8 @@ MPC_EBATCH = -5
 
 INF = 1e30
 
+COST_LEFT_SUM, COST_TRAPEZOIDAL = 0, 1
+
 CAND_REFERENCE = 0
 CAND_TRAVEL = 1
 CAND_TRAVEL_REVERSE = 2
@@ -98,7 +100,13 @@ class MpcConfig(C.Structure):
         ("mu_init_dual", C.c_double),
         ("candidate_param", C.c_double * 4),
         ("hessian_mode", C.c_int32),
-        ("reserved", C.c_int32 * 6),
+        ("hybrid_cost_minimum_time", C.c_int32),
+        ("cost_integration", C.c_int32),
+        ("reserved", C.c_int32 * 4),
+        ("Q_offdiag", C.c_double * 3),
+        ("R_offdiag", C.c_double),
+        ("Qf_offdiag", C.c_double * 3),
+        ("terminal_ball_S_offdiag", C.c_double * 3),
     ]
 
 
@@ -113,6 +121,15 @@ class MpcObstacles(C.Structure):
     ]
 
 
+def _diag_offdiag(w, dim):
+    """a weight given as its diagonal or as a full dim x dim matrix -> (diagonal, off-diagonal terms (0,1)[, (0,2), (1,2)] of the symmetric part)"""
+    rows = [list(r) if hasattr(r, "__len__") else None for r in w]
+    if rows and rows[0] is not None:
+        m = [[0.5 * (float(rows[i][j]) + float(rows[j][i])) for j in range(dim)] for i in range(dim)]
+        return [m[i][i] for i in range(dim)], ([m[0][1], m[0][2], m[1][2]] if dim == 3 else [m[0][1]])
+    return [float(v) for v in w], [0.0] * (3 if dim == 3 else 1)
+
+
 def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3, dt_free=True, dt_lb=0.0, dt_ub=10.0,
                 xf_fixed=(True, True, True), objective=OBJ_MIN_TIME, Q=(0, 0, 0), R=(0, 0), integral_form=False, Qf=None,
                 u_lb=(-0.2, -0.3), u_ub=(0.4, 0.3), du_lb=(-INF, -INF), du_ub=(INF, INF), max_iter=100, tol=1e-8,
@@ -120,7 +137,9 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
                 footprint_kind=0, footprint_radius=0.0, max_obstacles=0, max_vertices=1, max_obstacle_rows=4, mu_init_warm=0.0, collocation=COLLOC_FORWARD,
                 terminal_ball_S=None, terminal_ball_gamma=1.0, vp_position_weight=1e-3, vp_orientation_weight=0.0,
                 via_points_ordered=False, max_via_points=0, footprint_params=(0.0, 0.0, 0.0, 0.0),
-                enable_dynamic_obstacles=False, footprint_vertices=(), candidates=(), candidate_max_iter=(), candidate_blend=0, dual_warm_start=False, mu_init_dual=0.0, candidate_param=(), hessian_mode=0) -> MpcConfig:
+                enable_dynamic_obstacles=False, footprint_vertices=(), candidates=(), candidate_max_iter=(), candidate_blend=0, dual_warm_start=False, mu_init_dual=0.0, candidate_param=(), hessian_mode=0,
+                hybrid_cost_minimum_time=False, cost_integration=COST_LEFT_SUM) -> MpcConfig:
+    """Q, R, Qf, terminal_ball_S: the diagonal (3 / 2 / 3 / 3 values) or the full matrix (nested 3 x 3 / 2 x 2; its symmetric part is used)."""
     c = MpcConfig()
     c.model = model
     mp = list(model_params) + [0.0] * 4
@@ -130,16 +149,20 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
     c.dt_ref = dt_ref
     c.dt_free = int(bool(dt_free))
     c.dt_lb, c.dt_ub = dt_lb, dt_ub
+    Qd, Qo = _diag_offdiag(Q, 3)
+    Qfd, Qfo = _diag_offdiag(Qf if Qf is not None else (0, 0, 0), 3)
+    Rd, Ro = _diag_offdiag(R, 2)
     for i in range(3):
         c.xf_fixed[i] = int(bool(xf_fixed[i]))
-        c.Q[i] = Q[i]
-        c.Qf[i] = Qf[i] if Qf is not None else 0.0
+        c.Q[i], c.Q_offdiag[i] = Qd[i], Qo[i]
+        c.Qf[i], c.Qf_offdiag[i] = Qfd[i], Qfo[i]
+    c.R_offdiag = Ro[0]
     c.collocation = collocation
     c.objective = objective
     c.integral_form = int(bool(integral_form))
     c.has_Qf = int(Qf is not None)
     for j in range(2):
-        c.R[j] = R[j]
+        c.R[j] = Rd[j]
         c.u_lb[j], c.u_ub[j] = u_lb[j], u_ub[j]
         c.du_lb[j], c.du_ub[j] = du_lb[j], du_ub[j]
     c.max_iter = max_iter
@@ -151,8 +174,9 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
     c.max_obstacles, c.max_vertices, c.max_obstacle_rows = max_obstacles, max_vertices, max_obstacle_rows
     c.mu_init_warm = mu_init_warm
     c.terminal_ball = int(terminal_ball_S is not None)
+    Sd, So = _diag_offdiag(terminal_ball_S if terminal_ball_S is not None else (0, 0, 0), 3)
     for i in range(3):
-        c.terminal_ball_S[i] = terminal_ball_S[i] if terminal_ball_S is not None else 0.0
+        c.terminal_ball_S[i], c.terminal_ball_S_offdiag[i] = Sd[i], So[i]
     c.terminal_ball_gamma = terminal_ball_gamma
     c.vp_position_weight, c.vp_orientation_weight = vp_position_weight, vp_orientation_weight
     c.via_points_ordered, c.max_via_points = int(bool(via_points_ordered)), max_via_points
@@ -175,6 +199,8 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
     c.dual_warm_start = int(bool(dual_warm_start))
     c.mu_init_dual = float(mu_init_dual)
     c.hessian_mode = int(hessian_mode)
+    c.hybrid_cost_minimum_time = int(bool(hybrid_cost_minimum_time))
+    c.cost_integration = int(cost_integration)
     return c
 
 

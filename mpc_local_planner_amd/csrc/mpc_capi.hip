@@ -55,7 +55,7 @@ constexpr int kWinIdle = 0x7f7f7f7f;
 
 // One wavefront = one (planner instance, candidate initial trajectory); the whole working set lives in LDS (mpc_wave.hpp).
 // Grid: n_cand * B workgroups, candidate-major, so that the hardware dispatches every instance's candidate 0 before any hedge.
-template <typename T, int MODEL, bool EXT>
+template <typename T, int MODEL, int EXT>
 __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
     mpc::Problem<T> P, mpc::WaveLayout L, int B,
     const double* __restrict__ x0, const double* __restrict__ xf, const double* __restrict__ u_prev,
@@ -233,7 +233,7 @@ struct mpc_solver {
 // which kernel instantiation serves this solver: the one with the rarely used rows / terms / coupling slots, or the headline one
 static bool solver_ext(const mpc_solver* s) {
     const mpc::Problem<double>& P = s->P64;
-    return P.ball || P.via || P.integral_form || P.dyn_obst || P.hess_mode ||
+    return P.ball || P.via || P.integral_form || P.dyn_obst || P.hess_mode || P.costx ||
            (P.n_obst > 0 && (P.footprint_kind == MPC_FOOTPRINT_LINE || P.footprint_kind == MPC_FOOTPRINT_TWO_CIRCLES || P.footprint_kind == MPC_FOOTPRINT_POLYGON));
 }
 
@@ -270,7 +270,7 @@ void mpc_config_defaults(mpc_config* c) {
 }
 
 const char* mpc_last_error(void) { return g_err; }
-int32_t mpc_version(void) { return 200; }      // 0.2.0: mpc_config grew (candidates, kept multipliers, hessian_mode), new entry points
+int32_t mpc_version(void) { return 210; }      // 0.2.0: mpc_config grew (candidates, kept multipliers, hessian_mode), new entry points; 0.2.1: cost variants (off-diagonal weights, trapezoidal rule, hybrid cost)
 
 #ifdef MPC_PROFILE
 // developer build only (-DMPC_PROFILE): per-wave phase cycle counters of the last wave-kernel launch
@@ -302,6 +302,8 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
     for (int j = 0; j < 2; ++j)
         if (!(cfg->u_lb[j] < cfg->u_ub[j])) { set_err("mpc_create: control box must be finite and non-empty"); return MPC_EINVAL; }
     if (cfg->precision != MPC_FP64 && cfg->precision != MPC_FP32 && cfg->precision != MPC_MIXED) { set_err("mpc_create: unknown precision"); return MPC_EINVAL; }
+    if (cfg->cost_integration != MPC_COST_LEFT_SUM && cfg->cost_integration != MPC_COST_TRAPEZOIDAL) { set_err("mpc_create: unknown cost_integration"); return MPC_EINVAL; }
+    if (cfg->hybrid_cost_minimum_time && cfg->objective != MPC_OBJ_QUADRATIC) { set_err("mpc_create: hybrid_cost_minimum_time belongs to the quadratic_form objective"); return MPC_EINVAL; }
     if (cfg->precision == MPC_MIXED && (cfg->max_obstacles > 0 || cfg->objective == MPC_OBJ_MIN_TIME_VIA_POINTS)) {
         set_err("mpc_create: MPC_MIXED is implemented for problems without clearance rows and via-points (their association would be redone by the refinement phase)"); return MPC_EINVAL; }
     if (cfg->hessian_mode != MPC_HESSIAN_EXACT && cfg->hessian_mode != MPC_HESSIAN_CONVEXIFIED) { set_err("mpc_create: unknown hessian_mode"); return MPC_EINVAL; }
@@ -386,7 +388,7 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
     }
     if (cfg->precision == MPC_MIXED && er == hipSuccess) er = hipMalloc((void**)&s->d_iters1, Bm * 4);
     if (cfg->dual_warm_start || cfg->precision == MPC_MIXED) {
-        s->dual_words = mpc::IpmWave<double, 0, false>::dual_words(s->WL.NS);
+        s->dual_words = mpc::IpmWave<double, 0, 0>::dual_words(s->WL.NS);
         if (er == hipSuccess) er = hipMalloc((void**)&s->d_dual, Bm * (size_t)s->dual_words * 8);
         if (er == hipSuccess) er = hipMemset(s->d_dual, 0, Bm * (size_t)s->dual_words * 8);
     }
@@ -448,7 +450,7 @@ static hipError_t launch_model(mpc_solver* s, const mpc::Problem<T>& P, int B, c
                                const double* dtp, const double* xi, const double* ui, const double* dti, const mpc_obstacles& ob, double* xo, double* uo,
                                double* dto, int32_t* st, int32_t* it) {
     const bool ext = solver_ext(s);
-    auto kern = ext ? mpc_ipm_wave_kernel<T, MODEL, true> : mpc_ipm_wave_kernel<T, MODEL, false>;
+    auto kern = !ext ? mpc_ipm_wave_kernel<T, MODEL, 0> : (s->P64.costx ? mpc_ipm_wave_kernel<T, MODEL, 2> : mpc_ipm_wave_kernel<T, MODEL, 1>);
     const size_t lds = sizeof(T) == 4 ? s->wave_lds32 : s->wave_lds;
     if (lds > 48u * 1024u) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

@@ -83,6 +83,10 @@ struct Problem {
     T cand_param[4];     // tangent scale of the Hermite kinds
     int hess_mode;       // 0 exact Lagrangian Hessian, 1 convexified (stage-wise positive semidefinite part; EXT kernel instantiation)
     T mu_init_dual;      // barrier start of a solve that starts from the multipliers kept in the handle (dual_warm_start)
+    // cost variants (EXT kernel instantiation, except `hybrid`): off-diagonal terms (01, 02, 12) of full weight matrices, trapezoidal rule for the
+    // integral-form cost on the variable grid, minimum time added to the quadratic form
+    T Qo[3], Ro, Qfo[3], So[3];
+    int trapz, hybrid, costx;      // costx: any of Qo / Ro / Qfo / So non-zero, or trapz
 };
 
 // Algorithm constants (Waechter & Biegler 2006 names).  Compile-time so that they live in

@@ -71,6 +71,27 @@ inline void fill_problem(const mpc_config& c, mpc::Problem<T>& P) {
     P.cand_blend = c.candidate_blend > 0 ? c.candidate_blend : 8;
     P.mu_init_dual = T(c.mu_init_dual > 0 ? c.mu_init_dual : 1e-3);
     P.hess_mode = c.hessian_mode == MPC_HESSIAN_CONVEXIFIED ? 1 : 0;
+    // ---- cost variants
+    const bool quad = c.objective == MPC_OBJ_QUADRATIC;
+    P.hybrid = (quad && c.hybrid_cost_minimum_time) ? 1 : 0;
+    for (int i = 0; i < 3; ++i) { P.Qo[i] = T(quad ? c.Q_offdiag[i] * wsc : 0.0); P.Qfo[i] = T(c.has_Qf ? c.Qf_offdiag[i] : 0.0); P.So[i] = T(c.terminal_ball_S_offdiag[i]); }
+    P.Ro = T(quad ? c.R_offdiag * wsc : 0.0);
+    const bool trapezoid = quad && c.integral_form && c.cost_integration == MPC_COST_TRAPEZOIDAL;
+    // trapezoidal rule (finite_differences_grid_se2.cpp:63-68): every interval gives half of its state cost to either end, so against the left
+    // sum x_0 loses half a term (a constant on the fixed grid: x_0 is not a variable) and the FINAL state gains 0.5 dt xd' Q xd.
+    // Fixed grid: that is a terminal cost with weights 0.5 dt_ref Q on top of Qf.  Variable grid: handled in the kernel (P.trapz).
+    P.trapz = (trapezoid && c.dt_free) ? 1 : 0;
+    if (trapezoid && !c.dt_free) {
+        for (int i = 0; i < 3; ++i) {
+            P.Qf[i] = T((c.has_Qf ? c.Qf[i] : 0.0) + 0.5 * c.dt_ref * c.Q[i]);
+            P.Qfo[i] = T((c.has_Qf ? c.Qf_offdiag[i] : 0.0) + 0.5 * c.dt_ref * c.Q_offdiag[i]);
+        }
+        P.has_Qf = 1;
+    } else if (!c.has_Qf) {
+        for (int i = 0; i < 3; ++i) P.Qf[i] = T(0);
+    }
+    P.costx = (P.trapz || P.Ro != T(0)) ? 1 : 0;
+    for (int i = 0; i < 3; ++i) if (P.Qo[i] != T(0) || P.Qfo[i] != T(0) || (P.ball && P.So[i] != T(0))) P.costx = 1;
 }
 
 

@@ -149,7 +149,8 @@ __device__ __forceinline__ float lane_bcast(float v, int src) {
 
 // EXT = false compiles the rarely used rows / objective terms (terminal l2-ball, via-points) out of the kernel: the headline
 // configurations keep their instruction count and register budget
-template <typename T, int MODEL, bool EXT = true>
+// EXT: 0 = headline instantiation, 1 = + the rarely used rows / terms / coupling slots, 2 = + the cost variants (off-diagonal weights, trapezoidal rule)
+template <typename T, int MODEL, int EXT = 1>
 struct IpmWave {
     const Problem<T>& P;     // lives in LDS (copied once per workgroup): wave-uniform constants are fetched with
     const WaveLayout L;      // broadcast ds_reads instead of being pinned in (and spilled from) scalar registers; the layout
@@ -193,6 +194,29 @@ struct IpmWave {
     __device__ __forceinline__ bool dtf() const { return (flags >> 3) & 1; }
     __device__ __forceinline__ bool quad() const { return (flags >> 4) & 1; }
     __device__ __forceinline__ bool hasqf() const { return (flags >> 5) & 1; }
+    // cost variants: minimum-time term in the objective (minimum-time objectives and the hybrid quadratic form); off-diagonal weights /
+    // trapezoidal rule (EXT instantiation only: everything below `costx()` is delta code on top of the diagonal left-sum arithmetic)
+    __device__ __forceinline__ bool mintime() const { return (flags >> 16) & 1; }
+    __device__ __forceinline__ bool costx() const { return EXT >= 2; }      // that instantiation is only launched for such problems (mpc_capi.hip::solver_ext)
+    // off-diagonal part of W x and of x' W x for the symmetric matrix with off-diagonal terms o = (01, 02, 12)
+    __device__ __forceinline__ void offmul(const T o[3], const T x[3], T y[3]) const {
+        y[0] = o[0] * x[1] + o[1] * x[2]; y[1] = o[0] * x[0] + o[2] * x[2]; y[2] = o[1] * x[0] + o[2] * x[1];
+    }
+    __device__ __forceinline__ T offquad(const T o[3], const T x[3]) const { return T(2) * (o[0] * x[0] * x[1] + o[1] * x[0] * x[2] + o[2] * x[1] * x[2]); }
+    __device__ __forceinline__ T fullquad(const T dg[3], const T o[3], const T x[3]) const { return dg[0] * x[0] * x[0] + dg[1] * x[1] * x[1] + dg[2] * x[2] * x[2] + offquad(o, x); }
+    // error of the final state at z + alpha dz (a fixed component sits on the goal: 0)
+    __device__ __forceinline__ void xd_final(T alpha, T xd[3]) const {
+        for (int i = 0; i < 3; ++i) { xd[i] = fx(i) ? T(0) : xt(i, L.n - 1, alpha) - xf[i]; }
+        xd[2] = normalize_theta(xd[2]);
+    }
+    // delta of the objective at the final state against the diagonal left-sum arithmetic: off-diagonal terminal cost + trapezoid term
+    __device__ __forceinline__ T final_cost_extra(T alpha, T d) const {
+        T xd[3]; xd_final(alpha, xd);
+        T f = T(0);
+        if (hasqf()) f += offquad(P.Qfo, xd);
+        if (P.trapz) f += T(0.5) * d * fullquad(P.Q, P.Qo, xd);
+        return f;
+    }
     __device__ __forceinline__ bool ron(int q) const { return (flags >> (6 + q)) & 1; }
     __device__ __forceinline__ bool ball() const { return EXT && ((flags >> 10) & 1); }
     __device__ __forceinline__ bool via() const { return EXT && ((flags >> 11) & 1); }
@@ -251,6 +275,11 @@ struct IpmWave {
             if (i == 2) xd = normalize_theta(xd);
             g += P.ball_S[i] * xd * xd;
             a[i] = T(2) * P.ball_S[i] * xd;
+        }
+        if (costx()) {
+            T xd[3], sx[3]; xd_final(alpha, xd); offmul(P.So, xd, sx);
+            g += offquad(P.So, xd);
+            for (int i = 0; i < 3; ++i) if (!fx(i)) a[i] += T(2) * sx[i];
         }
         return g;
     }
@@ -674,11 +703,17 @@ struct IpmWave {
             if (quad()) {
                 T xd0 = xk[0] - xf[0], xd1 = xk[1] - xf[1], xd2 = normalize_theta(xk[2] - xf[2]);
                 fo += (P.Q[0] * xd0 * xd0 + P.Q[1] * xd1 * xd1 + P.Q[2] * xd2 * xd2 + P.R[0] * v * v + P.R[1] * w * w) * (intf() ? d : T(1));
+                if (costx()) {
+                    const T xd[3] = {xd0, xd1, xd2};
+                    fo += (offquad(P.Qo, xd) + T(2) * P.Ro * v * w) * (intf() ? d : T(1));
+                    if (k == 0 && P.trapz) fo -= T(0.5) * d * fullquad(P.Q, P.Qo, xd);
+                }
             }
             if (via()) { T vv, vg[3]; via_terms(k, xk[0], xk[1], xk[2], vv, vg); fo += vv; }
         }
         if (lane == 0) {
-            if (!quad()) fo += T(n - 1) * d;
+            if (mintime()) fo += T(n - 1) * d;
+            if (costx()) fo += final_cost_extra(al, d);
             if (hasqf()) {       // the terminal cost does not depend on the stage cost's type (src/controller.cpp:641-672)
                 for (int i = 0; i < 3; ++i) if (!fx(i)) {
                     T xd = xt(i, n - 1, al) - xf[i];
@@ -727,15 +762,15 @@ struct IpmWave {
     struct TrialRegs {
         T xk[3], dxk[3], xn[3], dxn[3], u[2], du[2], s[4], ds[4];
         T ulb[2], uub[2], dt_lb, dt_ub, Q[3], R[2], nm1;
-        bool stage, on[4], quad, dtf;
+        bool stage, on[4], quad, mint, dtf;
         int k;
     };
-    __device__ __forceinline__ bool trial_fast_ok() const { return L.M == 0 && L.n <= kWave; }
+    __device__ __forceinline__ bool trial_fast_ok() const { return L.M == 0 && L.n <= kWave && !costx(); }
     __device__ __forceinline__ void trial_setup(TrialRegs& r, T dd) const {
         const int n = L.n, k = lane;
         const T d = SCL(SC_D);
         r.k = k; r.stage = k < n - 1;
-        r.quad = quad(); r.dtf = dtf(); r.nm1 = T(n - 1);
+        r.quad = quad(); r.mint = mintime(); r.dtf = dtf(); r.nm1 = T(n - 1);
         r.dt_lb = P.dt_lb; r.dt_ub = P.dt_ub;
         for (int i = 0; i < 3; ++i) {
             r.Q[i] = P.Q[i];
@@ -784,7 +819,7 @@ struct IpmWave {
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc.mul(r.s[q] + alpha * r.ds[q]);      // rows that are off carry s = 1, ds = 0
         if (lane == 0) {
-            if (!r.quad) fo += r.nm1 * d;
+            if (r.mint) fo += r.nm1 * d;
             if (hasqf()) {
                 for (int i = 0; i < 3; ++i) if (!fx(i)) {
                     T xd = xt(i, L.n - 1, alpha) - xf[i];
@@ -850,6 +885,13 @@ struct IpmWave {
                     for (int i = 0; i < 3; ++i) gx[i] = T(2) * P.Q[i] * xd[i] * w8;
                     gu[0] = T(2) * P.R[0] * v * w8; gu[1] = T(2) * P.R[1] * w * w8;
                     if (intf()) rdd += P.Q[0] * xd[0] * xd[0] + P.Q[1] * xd[1] * xd[1] + P.Q[2] * xd[2] * xd[2] + P.R[0] * v * v + P.R[1] * w * w;
+                    if (costx()) {
+                        T qo[3]; offmul(P.Qo, xd, qo);
+                        for (int i = 0; i < 3; ++i) gx[i] += T(2) * qo[i] * w8;
+                        gu[0] += T(2) * P.Ro * w * w8; gu[1] += T(2) * P.Ro * v * w8;
+                        if (intf()) rdd += offquad(P.Qo, xd) + T(2) * P.Ro * v * w;
+                        if (k == 0 && P.trapz) rdd -= T(0.5) * fullquad(P.Q, P.Qo, xd);
+                    }
                 }
                 if (via()) { T vv; via_terms(k, F(L.X, 0, k), F(L.X, 1, k), F(L.X, 2, k), vv, gx); }
                 T osx = T(0), osy = T(0), ost = T(0);
@@ -902,12 +944,22 @@ struct IpmWave {
                         cmin = t_min(cmin, ts * ty); cmax = t_max(cmax, ts * ty);
                         sb += ty; nb += 1;
                     }
+                    T gext[3] = {T(0), T(0), T(0)};
+                    if (costx()) {       // off-diagonal terminal cost, trapezoid term of the final state (gradient, and its share of d/d dt)
+                        T xdT[3], y3[3]; xd_final(T(0), xdT);
+                        if (hasqf()) { offmul(P.Qfo, xdT, y3); for (int i = 0; i < 3; ++i) gext[i] += T(2) * y3[i]; }
+                        if (P.trapz) {
+                            offmul(P.Qo, xdT, y3);
+                            for (int i = 0; i < 3; ++i) gext[i] += d * (P.Q[i] * xdT[i] + y3[i]);
+                            rdd += T(0.5) * fullquad(P.Q, P.Qo, xdT);
+                        }
+                    }
                     for (int i = 0; i < 3; ++i) if (!fx(i)) {
-                        T g = T(0);
+                        T g = gext[i];
                         if (hasqf()) {
                             T xd = F(L.X, i, n - 1) - xf[i];
                             if (i == 2) xd = normalize_theta(xd);
-                            g = T(2) * P.Qf[i] * xd;
+                            g += T(2) * P.Qf[i] * xd;
                         }
                         rd = t_max(rd, t_abs(g + ty * ta[i] - lam[i]));
                     }
@@ -933,7 +985,7 @@ struct IpmWave {
             }
         }
         if (lane == 0) {
-            if (!quad()) rdd += T(n - 1);
+            if (mintime()) rdd += T(n - 1);
             if (dtf()) {
                 T pl = SCL(SC_PDL), pu = SCL(SC_PDU);
                 rdd += -pl + pu;
@@ -1058,6 +1110,22 @@ struct IpmWave {
                 const T h = T(2) * P.vp_wp * T(m);
                 sp.oxx += h; sp.oyy += h; sp.ogx += vg[0]; sp.ogy += vg[1]; sp.hx[2] += vg[2];
             }
+            if (costx() && quad && k < n - 1) {       // off-diagonal weights: Hessian slots A01 A02 A12 A67, gradients, dt coupling; trapezoid: x_0's half term
+                const T w8 = intf() ? d : T(1);
+                const T xd[3] = {F(L.X, 0, k) - xf[0], F(L.X, 1, k) - xf[1], normalize_theta(F(L.X, 2, k) - xf[2])};
+                const T v = F(L.U, 0, k), w = F(L.U, 1, k);
+                T qo[3]; offmul(P.Qo, xd, qo);
+                sp.oxy += T(2) * P.Qo[0] * w8; sp.oxt += T(2) * P.Qo[1] * w8; sp.oyt += T(2) * P.Qo[2] * w8;
+                sp.h12 += T(2) * P.Ro * w8;
+                for (int i = 0; i < 3; ++i) sp.hx[i] += T(2) * qo[i] * w8;
+                sp.gb[0] += T(2) * P.Ro * w * w8; sp.gb[1] += T(2) * P.Ro * v * w8;
+                if (intf()) {
+                    if (k > 0) for (int i = 0; i < 3; ++i) sp.cxd[i] += T(2) * qo[i];
+                    sp.cud[0] += T(2) * P.Ro * w; sp.cud[1] += T(2) * P.Ro * v;
+                    sp.gdt += offquad(P.Qo, xd) + T(2) * P.Ro * v * w;
+                    if (k == 0 && P.trapz) sp.gdt -= T(0.5) * fullquad(P.Q, P.Qo, xd);
+                }
+            }
             T A[NADD];
             assemble_adds(sp, q2, r2, A);
 #pragma unroll
@@ -1149,6 +1217,9 @@ struct IpmWave {
             ta[0] = SCL(SC_TA); ta[1] = SCL(SC_TA + 1); ta[2] = SCL(SC_TA + 2);
         }
         const T tac = c < 3 ? (c == 0 ? ta[0] : (c == 1 ? ta[1] : ta[2])) : T(0);
+        // cost variants: off-diagonal terminal weights (Qf, S) and the trapezoid term 0.5 dt xd' Q xd of the final state (x-x, x-dt, gradients)
+        T xdT[3] = {T(0), T(0), T(0)}, qT[3] = {T(0), T(0), T(0)};       // qT = Q xd_T (full) when the trapezoid term exists
+        if (costx()) { xd_final(T(0), xdT); if (P.trapz) { offmul(P.Qo, xdT, qT); for (int i = 0; i < 3; ++i) qT[i] += P.Q[i] * xdT[i]; } }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
             if (fx(i)) V[i] = c == 9 + i ? T(1) : T(0);
@@ -1162,15 +1233,32 @@ struct IpmWave {
                 if (ball()) { pii += T(2) * ty * P.ball_S[i]; pi_ += ta[i] * tyb; }
                 V[i] = c == i ? pii : (c == 8 ? pi_ : T(0));
                 if (ball() && c < 3) V[i] += tsig * ta[i] * tac;       // a of a fixed component is 0
+                if (costx()) {
+                    if (c < 3 && !fx(c)) {         // Hessian entry (i, c) over the free final components
+                        const int oi = i + c - 1;  // (0,1) -> 0, (0,2) -> 1, (1,2) -> 2
+                        if (c != i) { if (hasqf()) V[i] += T(2) * P.Qfo[oi]; if (ball()) V[i] += T(2) * ty * P.So[oi]; if (P.trapz) V[i] += d * P.Qo[oi]; }
+                        else if (P.trapz) V[i] += d * P.Q[i];
+                    }
+                    if (c == 8) {
+                        T y3[3];
+                        if (hasqf()) { offmul(P.Qfo, xdT, y3); V[i] += T(2) * y3[i]; }
+                        if (P.trapz) V[i] += d * qT[i];
+                    }
+                    if (c == 5 && P.trapz) V[i] += qT[i];
+                }
             }
         }
         {
             const bool t3 = c == 3 || c == 5 || c == 8, t4 = c == 4 || c == 5 || c == 8, t5 = c == 3 || c == 4 || c == 5 || c == 8;
             const T a3 = ap[3][as_[3]], a4 = ap[4][as_[4]], a5 = ap[5][as_[5]];       // one stage above the running pointers
             V[3] = t3 ? a3 : T(0); V[4] = t4 ? a4 : T(0); V[5] = t5 ? a5 : T(0);
+            if (costx() && P.trapz) {
+                if (c < 3 && !fx(c)) V[5] += c == 0 ? qT[0] : (c == 1 ? qT[1] : qT[2]);
+                if (c == 8) V[5] += T(0.5) * (xdT[0] * qT[0] + xdT[1] * qT[1] + xdT[2] * qT[2]);
+            }
         }
         T add_dd0 = T(0), add_qd0 = T(0);
-        if (!quad()) add_qd0 += T(n - 1);
+        if (mintime()) add_qd0 += T(n - 1);
         if (dtf()) {
             const T dl = d - P.dt_lb, du = P.dt_ub - d;
             const T idl = fast_rcp(dl), idu = fast_rcp(du);
@@ -1417,6 +1505,20 @@ struct IpmWave {
                     for (int j = 0; j < 3; ++j) if (!fx(j)) adx += SCL(SC_TA + j) * xi[j];
                     g += SCL(SC_TA + i) * (sig * adx + mu / ts + sig * (SCL(SC_TG) + ts)) + T(2) * ty * P.ball_S[i] * xi[i];
                 }
+                if (costx()) {       // the rows of the terminal block that the variants add: (xi + xd) through the off-diagonal / trapezoid Hessian, dt coupling
+                    T xdT[3], z[3], y3[3];
+                    xd_final(T(0), xdT);
+                    const T xif[3] = {fx(0) ? T(0) : xi[0], fx(1) ? T(0) : xi[1], fx(2) ? T(0) : xi[2]};
+                    for (int j = 0; j < 3; ++j) z[j] = xif[j] + xdT[j];
+                    if (hasqf()) { offmul(P.Qfo, z, y3); g += T(2) * y3[i]; }
+                    if (ball()) { offmul(P.So, xif, y3); g += T(2) * SCL(SC_TY) * y3[i]; }
+                    if (P.trapz) {
+                        offmul(P.Qo, z, y3);
+                        g += SCL(SC_D) * (P.Q[i] * z[i] + y3[i]);
+                        offmul(P.Qo, xdT, y3);
+                        g += (P.Q[i] * xdT[i] + y3[i]) * SCL(SC_DD);
+                    }
+                }
                 lp[i] = g;
             }
         }
@@ -1434,7 +1536,7 @@ struct IpmWave {
                 t1 = delta * dx1 + S_(RA + A01, m) * dx0 + S_(RA + A11, m) * dx1 + S_(RA + A18, m);
                 t2 = delta * dx2 + S_(RA + A22, m) * dx2 + S_(RA + A26, m) * duv + S_(RA + A27, m) * duw + S_(RA + A25, m) * dd + S_(RA + A28, m);
                 if (intf() || dynobs()) { t0 += S_(RA + A05, m) * dd; t1 += S_(RA + A15, m) * dd; }
-                if (fpline()) {        // position-heading coupling of the clearance rows
+                if (fpline() || costx()) {        // position-heading coupling of the clearance rows / of a full state weight matrix
                     const T c02 = S_(RA + A02, m), c12 = S_(RA + A12, m);
                     t0 += c02 * dx2; t1 += c12 * dx2; t2 += c02 * dx0 + c12 * dx1;
                 }
@@ -1477,7 +1579,7 @@ struct IpmWave {
                 ftb(pu, mu / du - pu + (pu / du) * dd, tau, a_d);
                 dz2 += dd * dd; dzmax = t_max(dzmax, t_abs(dd));
             }
-            if (!quad()) { hdz += T(n - 1) * dd; dphi += T(n - 1) * dd; }
+            if (mintime()) { hdz += T(n - 1) * dd; dphi += T(n - 1) * dd; }
             if (ball()) {
                 const T jdz = ball_jdz(), s = SCL(SC_TS), y = SCL(SC_TY), res = SCL(SC_TG) + s;
                 const T sig = y / s, ybar = mu / s + sig * res;
@@ -1496,6 +1598,7 @@ struct IpmWave {
                     T pl = F(L.PL, j, k), pu = F(L.PU, j, k);
                     const T idl = t_rcp(dl), idu = t_rcp(du);
                     T gbar = mu * idu - mu * idl + (quad() ? T(2) * P.R[j] * u * (intf() ? d : T(1)) : T(0));   // barrier (+ objective) gradient wrt u
+                    if (costx() && quad()) gbar += T(2) * P.Ro * F(L.U, 1 - j, k) * (intf() ? d : T(1));
                     hdz += gbar * du_; dphi += gbar * du_;
                     ftb(dl, du_, tau, a_p); ftb(du, -du_, tau, a_p);
                     ftb(pl, mu * idl - pl - (pl * idl) * du_, tau, a_d);
@@ -1510,13 +1613,37 @@ struct IpmWave {
                 if (intf()) {       // d/ddt of the integral-form stage cost
                     const T xd0 = F(L.X, 0, k) - xf[0], xd1 = F(L.X, 1, k) - xf[1], xd2 = normalize_theta(F(L.X, 2, k) - xf[2]);
                     const T v = F(L.U, 0, k), w = F(L.U, 1, k);
-                    const T sc = P.Q[0] * xd0 * xd0 + P.Q[1] * xd1 * xd1 + P.Q[2] * xd2 * xd2 + P.R[0] * v * v + P.R[1] * w * w;
+                    T sc = P.Q[0] * xd0 * xd0 + P.Q[1] * xd1 * xd1 + P.Q[2] * xd2 * xd2 + P.R[0] * v * v + P.R[1] * w * w;
+                    if (costx()) {
+                        const T xd[3] = {xd0, xd1, xd2};
+                        sc += offquad(P.Qo, xd) + T(2) * P.Ro * v * w;
+                        if (k == 0 && P.trapz) sc -= T(0.5) * fullquad(P.Q, P.Qo, xd);
+                    }
                     hdz += sc * dd; dphi += sc * dd;
                 }
             }
             if (k >= 1) {
                 T vg[3] = {T(0), T(0), T(0)};
                 if (via() && k < n - 1) { T vv; via_terms(k, F(L.X, 0, k), F(L.X, 1, k), F(L.X, 2, k), vv, vg); }
+                T gxo[3] = {T(0), T(0), T(0)};         // cost variants: what the off-diagonal weights / the trapezoid term add to the gradient wrt x_k
+                if (costx()) {
+                    if (k < n - 1) {
+                        if (quad()) {
+                            const T xd[3] = {F(L.X, 0, k) - xf[0], F(L.X, 1, k) - xf[1], normalize_theta(F(L.X, 2, k) - xf[2])};
+                            offmul(P.Qo, xd, gxo);
+                            for (int i = 0; i < 3; ++i) gxo[i] *= T(2) * (intf() ? d : T(1));
+                        }
+                    } else {
+                        T xdT[3], y3[3]; xd_final(T(0), xdT);
+                        if (hasqf()) { offmul(P.Qfo, xdT, y3); for (int i = 0; i < 3; ++i) gxo[i] += T(2) * y3[i]; }
+                        if (P.trapz) {
+                            offmul(P.Qo, xdT, y3);
+                            for (int i = 0; i < 3; ++i) gxo[i] += d * (P.Q[i] * xdT[i] + y3[i]);
+                            const T sc = T(0.5) * fullquad(P.Q, P.Qo, xdT);
+                            hdz += sc * dd; dphi += sc * dd;
+                        }
+                    }
+                }
                 for (int i = 0; i < 3; ++i) {
                     if (k < n - 1 || !fx(i)) {
                         T dx = F(L.DX, i, k);
@@ -1524,6 +1651,7 @@ struct IpmWave {
                         T g = vg[i];
                         if (quad() && k < n - 1) { T xd = F(L.X, i, k) - xf[i]; if (i == 2) xd = normalize_theta(xd); g = T(2) * P.Q[i] * xd * (intf() ? d : T(1)); }
                         else if (k == n - 1 && hasqf()) { T xd = F(L.X, i, k) - xf[i]; if (i == 2) xd = normalize_theta(xd); g += T(2) * P.Qf[i] * xd; }
+                        g += gxo[i];
                         hdz += g * dx; dphi += g * dx;
                     }
                 }
@@ -1856,7 +1984,7 @@ struct IpmWave {
     __device__ __forceinline__ SolveStats<T> solve() {
         SolveStats<T> out;
         flags = (P.xf_fixed[0] ? 1 : 0) | (P.xf_fixed[1] ? 2 : 0) | (P.xf_fixed[2] ? 4 : 0) | (P.dt_free ? 8 : 0) | (P.objective == OBJ_QUADRATIC ? 16 : 0) |
-                (P.has_Qf ? 32 : 0) | (P.rate_on[0] ? 64 : 0) | (P.rate_on[1] ? 128 : 0) | (P.rate_on[2] ? 256 : 0) | (P.rate_on[3] ? 512 : 0) | (P.ball ? 1024 : 0) | (P.via ? 2048 : 0) | ((P.n_obst > 0 && (P.footprint_kind == 2 || P.footprint_kind == 3 || P.footprint_kind == 4)) ? 4096 : 0) | (P.integral_form ? 8192 : 0) | (P.dyn_obst ? 16384 : 0) | (P.hess_mode ? 32768 : 0);
+                (P.has_Qf ? 32 : 0) | (P.rate_on[0] ? 64 : 0) | (P.rate_on[1] ? 128 : 0) | (P.rate_on[2] ? 256 : 0) | (P.rate_on[3] ? 512 : 0) | (P.ball ? 1024 : 0) | (P.via ? 2048 : 0) | ((P.n_obst > 0 && (P.footprint_kind == 2 || P.footprint_kind == 3 || P.footprint_kind == 4)) ? 4096 : 0) | (P.integral_form ? 8192 : 0) | (P.dyn_obst ? 16384 : 0) | (P.hess_mode ? 32768 : 0) | ((P.objective != OBJ_QUADRATIC || P.hybrid) ? 65536 : 0) | (P.costx ? 131072 : 0);
         flags = __builtin_amdgcn_readfirstlane(flags);
         nfix = (int)fx(0) + (int)fx(1) + (int)fx(2);
         row0_on = dtprev != T(0);

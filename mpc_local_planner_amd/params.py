@@ -12,7 +12,8 @@ keys (mpc_local_planner_examples/cfg/**).  This module reads the same keys with 
     notes  parameters that were accepted but have no effect here, or were mapped onto the nearest equivalent (one line each)
 
 A configuration the reference rejects (`configure` returns false) raises ParamError with the reference's reason; one that the reference accepts
-but this path does not implement raises ParamNotImplemented (it never falls back silently to a different NLP).
+but this path does not implement raises ParamNotImplemented (it never falls back silently to a different NLP): today that is the
+Levenberg-Marquardt solver (`solver/type lsq_lm`) and a polygon footprint with more than 16 vertices.
 
     cfg, ctrl, notes = config_from_yaml("mpc_local_planner_params.yaml", max_obstacles=64, max_vertices=8)
     solver = BatchSolver(cfg, max_batch=1024)
@@ -86,18 +87,22 @@ class _Reader:
         return out
 
 
-def _weights(values, dim: int, what: str, reason: str):
-    """a weight list of length dim (diagonal) or dim*dim (full matrix, column major: Eigen's default, src/controller.cpp:565-573)"""
+def _weights(values, dim: int, reason: str):
+    """a weight list of length dim (diagonal) or dim*dim (full matrix, column major: Eigen's default, src/controller.cpp:565-573) -> what make_config
+    takes: the diagonal, or the matrix as nested rows (only its symmetric part enters x' W x)"""
     v = [float(x) for x in (values or [])]
     if len(v) == dim:
-        return v
+        return tuple(v)
     if len(v) == dim * dim:
         m = [[v[c * dim + r] for c in range(dim)] for r in range(dim)]
-        off = max(abs(m[r][c] + m[c][r]) for r in range(dim) for c in range(dim) if r != c)    # x'Mx only sees the symmetric part
-        if off > 0.0:
-            raise ParamNotImplemented(f"{what}: a {dim} x {dim} weight matrix with off-diagonal terms (the device path takes diagonal weights)")
-        return [m[i][i] for i in range(dim)]
+        if all(m[r][c] + m[c][r] == 0.0 for r in range(dim) for c in range(dim) if r != c):
+            return tuple(m[i][i] for i in range(dim))
+        return tuple(tuple(row) for row in m)
     raise ParamError(reason)
+
+
+def _is_zero(w) -> bool:
+    return all((all(x == 0 for x in r) if hasattr(r, "__len__") else r == 0) for r in w)
 
 
 def config_from_params(params: dict, costmap_footprint=None, **sizing):
@@ -228,22 +233,18 @@ def config_from_params(params: dict, costmap_footprint=None, **sizing):
         kw["objective"] = A.OBJ_MIN_TIME
     elif objective == "quadratic_form":
         kw["objective"] = A.OBJ_QUADRATIC
-        Q = _weights(p.get("planning/objective/quadratic_form/state_weights", []), 3, "state_weights",
-                     "State weights dimension invalid. Must be either 3 x 1 or 3 x 3.")                       # :575
-        R = _weights(p.get("planning/objective/quadratic_form/control_weights", []), 2, "control_weights",
-                     "Control weights dimension invalid. Must be either 2 x 1 or 2 x 2.")                     # :590
+        Q = _weights(p.get("planning/objective/quadratic_form/state_weights", []), 3, "State weights dimension invalid. Must be either 3 x 1 or 3 x 3.")     # :575
+        R = _weights(p.get("planning/objective/quadratic_form/control_weights", []), 2, "Control weights dimension invalid. Must be either 2 x 1 or 2 x 2.")   # :590
         integral = p.get("planning/objective/quadratic_form/integral_form", False)
         hybrid = p.get("planning/objective/quadratic_form/hybrid_cost_minimum_time", False)
-        q_zero, r_zero = all(v == 0 for v in Q), all(v == 0 for v in R)
+        q_zero, r_zero = _is_zero(Q), _is_zero(R)
         if hybrid and not (q_zero and not r_zero):
             # :603-612: only the pure control cost has a hybrid variant
             notes.append("Hybrid minimum time and quadratic form cost is currently only supported for non-zero control weights only. Falling back to quadratic form.")
             hybrid = False
-        if hybrid:
-            raise ParamNotImplemented("planning/objective/quadratic_form/hybrid_cost_minimum_time (corbo::MinTimeQuadraticControls)")
-        if integral and integration == "trapezoidal_rule" and not q_zero:
-            raise ParamNotImplemented("grid/cost_integration_method trapezoidal_rule with an integral-form state cost (the device path integrates by the left sum)")
-        kw["Q"], kw["R"], kw["integral_form"] = tuple(Q), tuple(R), integral
+        kw["Q"], kw["R"], kw["integral_form"] = Q, R, integral
+        kw["hybrid_cost_minimum_time"] = hybrid                  # corbo::MinTimeQuadraticControls: (n - 1) dt + the control cost (:616-618)
+        kw["cost_integration"] = A.COST_TRAPEZOIDAL if integration == "trapezoidal_rule" else A.COST_LEFT_SUM      # integral-form terms only (:318-333)
     elif objective == "minimum_time_via_points":
         kw["objective"] = A.OBJ_MIN_TIME_VIA_POINTS
         kw["via_points_ordered"] = p.get("planning/objective/minimum_time_via_points/via_points_ordered", False)
@@ -255,14 +256,12 @@ def config_from_params(params: dict, costmap_footprint=None, **sizing):
     # terminal cost (:641-672) and terminal constraint (:674-713)
     tcost = p.get("planning/terminal_cost/type", "none")
     if tcost == "quadratic":
-        kw["Qf"] = tuple(_weights(p.get("planning/terminal_cost/quadratic/final_state_weights", []), 3, "final_state_weights",
-                                  "Final state weights dimension invalid. Must be either 3 x 1 or 3 x 3."))       # :664
+        kw["Qf"] = _weights(p.get("planning/terminal_cost/quadratic/final_state_weights", []), 3, "Final state weights dimension invalid. Must be either 3 x 1 or 3 x 3.")   # :664
     elif tcost != "none":
         raise ParamError(f"Unknown terminal_cost type '{tcost}' specified ('planning/terminal_cost/type').")     # :670
     tcon = p.get("planning/terminal_constraint/type", "none")
     if tcon == "l2_ball":
-        kw["terminal_ball_S"] = tuple(_weights(p.get("planning/terminal_constraint/l2_ball/weight_matrix", []), 3, "weight_matrix",
-                                               "l2-ball weight_matrix dimensions invalid. Must be either 3 x 1 or 3 x 3."))  # :699
+        kw["terminal_ball_S"] = _weights(p.get("planning/terminal_constraint/l2_ball/weight_matrix", []), 3, "l2-ball weight_matrix dimensions invalid. Must be either 3 x 1 or 3 x 3.")  # :699
         kw["terminal_ball_gamma"] = p.get("planning/terminal_constraint/l2_ball/radius", 1.0)
     elif tcon != "none":
         raise ParamError(f"Unknown terminal_constraint type '{tcon}' specified ('planning/terminal_constraint/type').")   # :711

@@ -385,3 +385,35 @@ def test_candidate_results_do_not_depend_on_batch_composition_or_timing(m):
         np.testing.assert_array_equal(r.status, big.status[sl]); np.testing.assert_array_equal(r.iters, big.iters[sl]); np.testing.assert_array_equal(w, wbig[sl])
     assert (big.status == 0).mean() > 0.99
     s.close()
+
+
+DEVICE_COST_VARIANTS = {
+    # name -> make_config keywords; the oracle-side configuration of the same name is tests/test_oracle_solver.py::cost_variant
+    "full_weights": dict(Q=[[2.0, 0.3, -0.1], [0.3, 1.5, 0.2], [-0.1, 0.2, 0.4]], R=[[0.1, 0.02], [0.02, 0.05]], Qf=[[8.0, 1.0, 0.0], [1.0, 9.0, 0.5], [0.0, 0.5, 0.6]]),
+    "trapezoid_fixed_dt": dict(integral_form=True, cost_integration=1),
+    "trapezoid_free_dt": dict(integral_form=True, cost_integration=1, dt_free=True, dt_lb=0.05, dt_ub=1.0),
+    "trapezoid_xf_fixed_free_dt": dict(integral_form=True, cost_integration=1, xf_fixed=(True, True, True), dt_free=True, dt_lb=0.05, dt_ub=1.0),
+    "hybrid": dict(Q=(0, 0, 0), Qf=None, hybrid_cost_minimum_time=True, dt_free=True, xf_fixed=(True, True, True), R=(1.0, 0.5)),
+    "hybrid_integral": dict(Q=(0, 0, 0), Qf=None, hybrid_cost_minimum_time=True, dt_free=True, xf_fixed=(True, True, True), R=(1.0, 0.5), integral_form=True),
+    "all": dict(Q=[[2.0, 0.3, -0.1], [0.3, 1.5, 0.2], [-0.1, 0.2, 0.4]], R=[[0.1, 0.02], [0.02, 0.05]], Qf=[[8.0, 1.0, 0.0], [1.0, 9.0, 0.5], [0.0, 0.5, 0.6]], integral_form=True,
+                cost_integration=1, terminal_ball_S=[[1.0, 0.2, 0.0], [0.2, 1.0, 0.1], [0.0, 0.1, 0.5]], terminal_ball_gamma=0.3, dt_free=True, dt_lb=0.05, dt_ub=1.0),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", sorted(DEVICE_COST_VARIANTS))
+def test_cost_variants_vs_c_oracle(m, c_oracle, name):
+    """full Q / R / Qf / S weight matrices (src/controller.cpp:561-592,652-668,686-702), trapezoidal rule for integral-form costs
+    (finite_differences_grid_se2.cpp:63-68), hybrid minimum time + control cost (src/controller.cpp:616-618): device against the C oracle on
+    B = 128 instances of the unicycle quadratic-form workload, accounting (match / other KKT point of the reference-form NLP / unclassified = 0)."""
+    from test_oracle_solver import cost_variant
+    B, n = 128, 16
+    ocfg = cost_variant(name, n)
+    inputs = m.workloads.unicycle_quadratic_inputs(B, seed=11)
+    s = m.BatchSolver(m.config_unicycle_quadratic(n, **DEVICE_COST_VARIANTS[name]), max_batch=B)
+    r = s.solve(*inputs)
+    out = c_oracle.solve_batch(c_oracle.from_nlp_config(ocfg), *inputs)
+    match, other = account(f"cost variant {name}", ocfg, inputs, r, out)
+    assert (r.status == 0).mean() > 0.95 and match.sum() > 0.9 * B
+    assert abs(float(r.iters[match].mean()) - float(out[4][match].mean())) < 0.5          # same iterate sequences
+    s.close()

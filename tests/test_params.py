@@ -159,26 +159,31 @@ def test_what_the_reference_rejects_is_rejected():
             P.config_from_params(params)
 
 
-def test_what_is_not_built_says_so():
+def test_what_is_not_built_says_so_and_the_cost_variants_pass_through():
     qf = lambda **kw: {"planning": {"objective": {"type": "quadratic_form", "quadratic_form": kw}}}
     with pytest.raises(P.ParamNotImplemented, match="lsq_lm"):
         P.config_from_params({"solver": {"type": "lsq_lm"}})
-    with pytest.raises(P.ParamNotImplemented, match="off-diagonal"):
-        P.config_from_params(qf(state_weights=[1, 0.5, 0, 0.5, 1, 0, 0, 0, 1], control_weights=[1, 1]))
-    # an antisymmetric off-diagonal part does not change x'Qx: accepted
-    c, _, _ = P.config_from_params(qf(state_weights=[1, 0.5, 0, -0.5, 1, 0, 0, 0, 1], control_weights=[1, 1]))
-    assert list(c.Q) == [1, 1, 1]
-    with pytest.raises(P.ParamNotImplemented, match="hybrid_cost_minimum_time"):
-        P.config_from_params(qf(state_weights=[0, 0, 0], control_weights=[1, 1], hybrid_cost_minimum_time=True))
-    # the reference itself falls back to the plain quadratic form when the state weights are not zero (src/controller.cpp:603-612)
+    with pytest.raises(P.ParamNotImplemented, match="16 vertices"):
+        P.config_from_params({"footprint_model": {"type": "polygon", "vertices": [[math.cos(0.3 * i), math.sin(0.3 * i)] for i in range(20)]}})
+    # full weight matrices (column major, src/controller.cpp:565-573): the symmetric part is what x'Qx sees
+    c, _, _ = P.config_from_params(qf(state_weights=[1, 0.5, 0, 0.3, 2, 0, 0, 0.2, 3], control_weights=[1, 0.1, 0.3, 2]))
+    assert list(c.Q) == [1, 2, 3] and list(c.Q_offdiag) == [0.4, 0.0, 0.1] and list(c.R) == [1, 2] and c.R_offdiag == 0.2
+    c, _, _ = P.config_from_params(qf(state_weights=[1, 0.5, 0, -0.5, 1, 0, 0, 0, 1], control_weights=[1, 1]))       # antisymmetric off-diagonal part: no effect
+    assert list(c.Q) == [1, 1, 1] and list(c.Q_offdiag) == [0, 0, 0]
+    tc = {"planning": {"terminal_cost": {"type": "quadratic", "quadratic": {"final_state_weights": [5, 1, 0, 1, 6, 0.5, 0, 0.5, 7]}},
+                       "terminal_constraint": {"type": "l2_ball", "l2_ball": {"weight_matrix": [1, 0.2, 0, 0.2, 1, 0, 0, 0, 0.5]}}}}
+    c, _, _ = P.config_from_params(tc)
+    assert list(c.Qf) == [5, 6, 7] and list(c.Qf_offdiag) == [1, 0, 0.5] and list(c.terminal_ball_S_offdiag) == [0.2, 0, 0]
+    # hybrid cost: only with zero state weights and non-zero control weights; otherwise the reference itself falls back (src/controller.cpp:603-618)
+    c, _, notes = P.config_from_params(qf(state_weights=[0, 0, 0], control_weights=[1, 1], hybrid_cost_minimum_time=True))
+    assert c.objective == A.OBJ_QUADRATIC and c.hybrid_cost_minimum_time == 1 and not notes
     c, _, notes = P.config_from_params(qf(state_weights=[1, 1, 1], control_weights=[1, 1], hybrid_cost_minimum_time=True))
-    assert c.objective == A.OBJ_QUADRATIC and any("Falling back to quadratic form" in s for s in notes)
+    assert c.hybrid_cost_minimum_time == 0 and any("Falling back to quadratic form" in s for s in notes)
     tr = qf(state_weights=[1, 1, 1], control_weights=[1, 1], integral_form=True)
     tr["grid"] = {"cost_integration_method": "trapezoidal_rule"}
-    with pytest.raises(P.ParamNotImplemented, match="trapezoidal_rule"):
-        P.config_from_params(tr)
-    tr["planning"]["objective"]["quadratic_form"]["integral_form"] = False        # the rule only matters for integral terms
-    assert P.config_from_params(tr)[0].integral_form == 0
+    c, _, _ = P.config_from_params(tr)
+    assert c.cost_integration == A.COST_TRAPEZOIDAL and c.integral_form == 1
+    assert P.config_from_params(qf(state_weights=[1, 1, 1], control_weights=[1, 1], integral_form=True))[0].cost_integration == A.COST_LEFT_SUM
 
 
 def test_footprint_models_and_their_fallbacks():
@@ -289,8 +294,9 @@ def _cpp_config(cpp, tree, costmap_footprint=None):
 
 SCALARS = ["model", "n", "dt_ref", "dt_free", "dt_lb", "dt_ub", "collocation", "objective", "integral_form", "has_Qf", "max_iter", "tol", "mu_init", "precision",
            "min_obstacle_dist", "force_inclusion_dist", "cutoff_dist", "footprint_kind", "footprint_radius", "footprint_n_vertices", "max_obstacles", "max_vertices",
-           "max_obstacle_rows", "terminal_ball", "enable_dynamic_obstacles", "hessian_mode", "via_points_ordered", "n_candidates", "dual_warm_start"]
-ARRAYS = ["model_params", "xf_fixed", "Q", "R", "Qf", "u_lb", "u_ub", "du_lb", "du_ub", "terminal_ball_S", "footprint_params", "footprint_vertices"]
+           "max_obstacle_rows", "terminal_ball", "enable_dynamic_obstacles", "hessian_mode", "via_points_ordered", "n_candidates", "dual_warm_start", "hybrid_cost_minimum_time", "cost_integration", "R_offdiag"]
+ARRAYS = ["model_params", "xf_fixed", "Q", "R", "Qf", "u_lb", "u_ub", "du_lb", "du_ub", "terminal_ball_S", "footprint_params", "footprint_vertices", "Q_offdiag", "Qf_offdiag",
+          "terminal_ball_S_offdiag"]
 
 
 def test_cpp_reader_agrees_with_the_python_reader(cpp, tmp_path):
@@ -305,6 +311,11 @@ def test_cpp_reader_agrees_with_the_python_reader(cpp, tmp_path):
              ({"planning": {"objective": {"type": "minimum_time_via_points", "minimum_time_via_points": {"position_weight": 10.5, "via_points_ordered": True}}},
                "footprint_model": {"type": "two_circles", "front_offset": 0.2, "front_radius": 0.25, "rear_offset": 0.1, "rear_radius": 0.2},
                "solver": {"ipopt": {"iterations": 55, "ipopt_numeric_options": {"tol": 1e-5, "mu_init": 0.05, "acceptable_tol": 1e-3}, "ipopt_integer_options": {"max_iter": 70}}}}, None),
+             ({"planning": {"objective": {"type": "quadratic_form", "quadratic_form": {"state_weights": [1, 0.5, 0, 0.3, 2, 0, 0, 0.2, 3.0], "control_weights": [1, 0.1, 0.3, 2.0], "integral_form": True}},
+                            "terminal_cost": {"type": "quadratic", "quadratic": {"final_state_weights": [5, 1, 0, 1, 6, 0.5, 0, 0.5, 7.0]}},
+                            "terminal_constraint": {"type": "l2_ball", "l2_ball": {"weight_matrix": [1, 0.2, 0, 0.2, 1, 0, 0, 0, 0.5], "radius": 0.4}}},
+               "grid": {"cost_integration_method": "trapezoidal_rule", "xf_fixed": [False, False, False]}}, None),
+             ({"planning": {"objective": {"type": "quadratic_form", "quadratic_form": {"state_weights": [0.0, 0.0, 0.0], "control_weights": [1.0, 0.5], "hybrid_cost_minimum_time": True}}}}, None),
              ({"footprint_model": {"type": "costmap_2d"}}, [(0.2, 0.1), (-0.2, 0.1), (-0.2, -0.1), (0.2, -0.1)]),
              ({"footprint_model": {"type": "circular"}}, None), ({"footprint_model": {"type": "line", "line_start": [0.0, 0.0], "line_end": [0.4, 0.0]}}, None)]
     for tree, fp in cases:
@@ -329,8 +340,7 @@ def test_cpp_reader_gives_the_same_verdicts(cpp):
     rejected = [{"robot": {"type": "hovercraft"}}, {"grid": {"type": "shooting"}}, {"grid": {"xf_fixed": [True, True]}}, {"solver": {"type": "sqp"}},
                 {"planning": {"objective": {"type": "shortest_path"}}}, qf(state_weights=[1.0, 2.0], control_weights=[1.0, 1.0]),
                 {"planning": {"terminal_cost": {"type": "cubic"}}}, {"planning": {"terminal_constraint": {"type": "box"}}}]
-    missing = [{"solver": {"type": "lsq_lm"}}, qf(state_weights=[1, 0.5, 0, 0.5, 1, 0, 0, 0, 1.0], control_weights=[1.0, 1.0]),
-               qf(state_weights=[0.0, 0.0, 0.0], control_weights=[1.0, 1.0], hybrid_cost_minimum_time=True)]
+    missing = [{"solver": {"type": "lsq_lm"}}]
     for tree in rejected:
         with pytest.raises(P.ParamError) as e:
             P.config_from_params(tree)
