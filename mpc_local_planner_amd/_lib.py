@@ -15,8 +15,8 @@ from ._abi import MpcConfig
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libmpc_hip.so")
-SOURCES = ["mpc_capi.hip"]
-HEADERS = ["mpc_core.hpp", "mpc_problem.hpp", "mpc_wave.hpp", "mpc_dpp_blocks.inc", "mpc_costmap.hpp", "mpc_feasibility.hpp", "mpc_grid_update.hpp", os.path.join("..", "..", "include", "mpc_hip.h")]
+SOURCES = ["mpc_capi.hip", "mpc_solve_inst.hip"]
+HEADERS = ["mpc_solve_kernel.hpp", "mpc_core.hpp", "mpc_problem.hpp", "mpc_wave.hpp", "mpc_dpp_blocks.inc", "mpc_costmap.hpp", "mpc_feasibility.hpp", "mpc_grid_update.hpp", os.path.join("..", "..", "include", "mpc_hip.h")]
 
 EXPORTS = [
     "mpc_config_defaults", "mpc_create", "mpc_reset", "mpc_destroy", "mpc_solve_batch",
@@ -42,17 +42,34 @@ def needs_build() -> bool:
     return False
 
 
-def build(force: bool = False, verbose: bool = False) -> str:
-    """hipcc --offload-arch=gfx950 -> csrc/libmpc_hip.so (cross-compiles without a GPU)."""
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str | None = None) -> str:
+    """hipcc --offload-arch=gfx950 -> csrc/libmpc_hip.so (cross-compiles without a GPU).
+
+    Split build: the ABI + the small kernels (mpc_capi.hip) and one object per (arithmetic type, model) pair of the solve kernel
+    (mpc_solve_inst.hip, three kernel instantiations each) are compiled in parallel, then linked.  A plain
+    `hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared mpc_capi.hip -o libmpc_hip.so` gives the same library from one translation unit."""
+    if out is None and not force and not needs_build():
         return LIB_PATH
-    cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared"]
-    cmd += [os.path.join(CSRC, s) for s in SOURCES]
-    cmd += ["-o", LIB_PATH]
-    if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True, cwd=CSRC)
-    return LIB_PATH
+    from concurrent.futures import ThreadPoolExecutor
+    out = out or LIB_PATH                      # another `out` (+ extra_flags): an instrumented copy next to the product library (tests)
+    objdir = os.path.join(CSRC, "_obj") if out == LIB_PATH else out + ".obj"
+    os.makedirs(objdir, exist_ok=True)
+    base = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DMPC_SPLIT_BUILD"] + list(extra_flags)
+    jobs = [(base + ["-c", os.path.join(CSRC, "mpc_capi.hip"), "-o", os.path.join(objdir, "mpc_capi.o")])]
+    for t in ("double", "float"):
+        for model in range(4):
+            jobs.append(base + ["-DMPC_SOLVE_INST", f"-DMPC_INST_T={t}", f"-DMPC_INST_MODEL={model}", "-c", os.path.join(CSRC, "mpc_solve_inst.hip"),
+                                "-o", os.path.join(objdir, f"mpc_solve_{t}_{model}.o")])
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+    with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 2)) as pool:
+        list(pool.map(run, jobs))
+    link = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + [j[-1] for j in jobs] + ["-o", out]
+    run(link)
+    return out
 
 
 _lib = None

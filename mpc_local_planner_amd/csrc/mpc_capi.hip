@@ -13,6 +13,7 @@
 #include "mpc_core.hpp"
 #include "mpc_problem.hpp"
 #include "mpc_wave.hpp"
+#include "mpc_solve_kernel.hpp"
 #include "mpc_costmap.hpp"
 #include "mpc_feasibility.hpp"
 #include "mpc_grid_update.hpp"
@@ -31,166 +32,6 @@ void set_err(const char* what) { snprintf(g_err, sizeof(g_err), "%s", what); }
         hipError_t e_ = (call);                           \
         if (e_ != hipSuccess) { set_err(#call, e_); return MPC_EHIP; } \
     } while (0)
-
-// Candidate bookkeeping of a launch with n_candidates > 1 (device pointers; all NULL / 0 for a single candidate).
-//   win[b]      lowest candidate index of instance b that has converged so far (INT_MAX-like: none)
-//   exited[b]   candidates of instance b that have finished; the LAST one to finish copies the winner's record to the caller's outputs
-//   it_sum[b]   iterations spent on instance b by all its candidates
-//   rec         [C][B][5 n + 3 (+ multipliers)] doubles: x (n x 3), u (n x 2), dt, status, iterations of hedge c >= 1 of instance b, written when it
-//               converged (candidate 0 delivers straight into the caller's arrays)
-// win / exited / it_sum are restored to their idle values by that last workgroup, so consecutive launches need no memset.
-struct CandCtl {
-    int n_cand;
-    int* win;
-    int* exited;
-    int* it_sum;
-    double* rec;
-    int32_t* winner_out;
-    int32_t* iters_total_out;
-    int32_t* rows_dropped;     // [B] clearance rows of candidate 0 that did not fit into max_obstacle_rows (NULL without obstacles)
-    double* dual;              // [B][dual_words] multipliers kept between control cycles (dual_warm_start) or NULL; word 0 = grid size, 0 = nothing kept
-    int dual_words;            // doubles per instance in `dual` (and appended to every candidate record)
-};
-constexpr int kWinIdle = 0x7f7f7f7f;
-
-// One wavefront = one (planner instance, candidate initial trajectory); the whole working set lives in LDS (mpc_wave.hpp).
-// Grid: n_cand * B workgroups, candidate-major, so that the hardware dispatches every instance's candidate 0 before any hedge.
-template <typename T, int MODEL, int EXT>
-__global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
-    mpc::Problem<T> P, mpc::WaveLayout L, int B,
-    const double* __restrict__ x0, const double* __restrict__ xf, const double* __restrict__ u_prev,
-    const double* __restrict__ dt_prev, const double* __restrict__ x_init, const double* __restrict__ u_init,
-    const double* __restrict__ dt_init, mpc_obstacles obst, const int32_t* __restrict__ n_grid, const int32_t* __restrict__ n_via,
-    const double* __restrict__ via, CandCtl cc, const int32_t* __restrict__ iters_add, double* __restrict__ x_out,
-    double* __restrict__ u_out, double* __restrict__ dt_out, int32_t* __restrict__ status, int32_t* __restrict__ iters) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char mpc_smem[];
-    T* sm = reinterpret_cast<T*>(mpc_smem);
-    // problem record at the end of the dynamic LDS block (16-byte aligned); the layout stays in scalar registers
-    const size_t coff = (((size_t)L.total * sizeof(T)) + 15) & ~(size_t)15;
-    mpc::Problem<T>* Ps = reinterpret_cast<mpc::Problem<T>*>(mpc_smem + coff);
-    const int NC = cc.n_cand;                        // wave-uniform kernel argument
-    const int cand = NC > 1 ? (int)blockIdx.x / B : 0;
-    const int inst = (int)blockIdx.x - cand * B;
-    const int lane = threadIdx.x;
-    if (inst >= B || cand >= (NC > 1 ? NC : 1)) return;
-    const int nmax = L.n;          // stride of the instance-major arrays
-    int n = nmax;                  // grid points of THIS instance (grid adaptation: n_i <= n_max)
-    if (n_grid) { n = n_grid[inst]; n = n < 3 ? 3 : (n > nmax ? nmax : n); }
-    // a hedge whose instance already has a converged higher-priority candidate never starts
-    bool run = true;
-    if (NC > 1 && cand > 0) {
-        const int w = __builtin_amdgcn_readfirstlane(__hip_atomic_load(cc.win + inst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-        run = !(w < cand);
-    }
-    int st_status = mpc::ST_SUPERSEDED, st_iters = 0;
-    if (run) {
-        mpc::WaveLayout Lv = L;            // from the kernel arguments: wave-uniform, lives in SGPRs
-        Lv.n = __builtin_amdgcn_readfirstlane(n);
-#ifdef MPC_POISON_LDS      // developer check: any read of an LDS word the solver did not write first turns into NaN
-        for (int e = lane; e < L.total; e += mpc::kWave) sm[e] = T(NAN);
-        __syncthreads();
-#endif
-        if (lane == 0) { *Ps = P; Ps->n = n; }
-        __syncthreads();
-        mpc::IpmWave<T, MODEL, EXT> S(*Ps, Lv, sm, lane);
-        for (int i = 0; i < 3; ++i) { S.x0[i] = T(x0[3 * inst + i]); S.xf[i] = T(xf[3 * inst + i]); }
-        S.x0[2] = mpc::normalize_theta(S.x0[2]);
-        S.xf[2] = mpc::normalize_theta(S.xf[2]);
-        S.uprev[0] = u_prev ? T(u_prev[2 * inst]) : T(0);
-        S.uprev[1] = u_prev ? T(u_prev[2 * inst + 1]) : T(0);
-        S.dtprev = dt_prev ? T(dt_prev[inst]) : T(0);
-        // (indexed through the LDS copy: a run-time index into the by-value kernel argument would put the arrays into scratch memory)
-        const int kind = NC > 1 ? Ps->cand_kind[cand] : 0;
-        if (NC > 1) { S.my_cand = cand; S.iter_cap = Ps->cand_max_iter[cand]; S.win_ptr = cand > 0 ? cc.win + inst : nullptr; }
-        if (cc.dual && cand == 0) S.dual_in = cc.dual + (long)inst * cc.dual_words;
-        if (kind == 0 && x_init && u_init && dt_init) {
-            // coalesced read of this instance's contiguous [n][3] / [n][2] blocks
-            const double* xi = x_init + (long)inst * nmax * 3;
-            const double* ui = u_init + (long)inst * nmax * 2;
-            for (int e = lane; e < 3 * n; e += mpc::kWave) S.F(L.X, e % 3, e / 3) = T(xi[e]);
-            for (int e = lane; e < 2 * (n - 1); e += mpc::kWave) S.F(L.U, e % 2, e / 2) = T(ui[e]);
-            if (lane == 0) S.SCL(mpc::SC_D) = T(dt_init[inst]);
-            S.warm_guess = true;
-        } else if (kind == 0) {
-            S.cold_start();
-        } else {
-            S.seed_start(kind, Ps->cand_param[cand]);
-        }
-        if (L.M > 0) S.load_obstacles(obst.n_obstacles, obst.n_vertices, obst.vertices, obst.radius, obst.velocity, inst);
-        if (EXT && L.NV > 0) S.load_via_points(n_via, via, inst);
-        __syncthreads();
-        mpc::SolveStats<T> st = S.solve();
-        __syncthreads();
-        st_status = st.status; st_iters = st.iters;
-        if (cc.rows_dropped && cand == 0 && lane == 0) cc.rows_dropped[inst] = S.rows_dropped;
-        if (cand == 0) {
-            // candidate 0 (the only one when NC <= 1) delivers straight into the caller's arrays: whenever it converges it IS the result (lowest
-            // index), and when no candidate converges its last iterate and status are what is returned.  Only when a hedge wins does the last
-            // workgroup of the instance overwrite this with the hedge's record (it runs after every candidate, this one included, has left).
-            double* xo = x_out + (long)inst * nmax * 3;
-            double* uo = u_out + (long)inst * nmax * 2;
-            for (int e = lane; e < 3 * nmax; e += mpc::kWave) { int k = e / 3; int ks = k < n ? k : n - 1; xo[e] = double(S.F(L.X, e % 3, ks)); }
-            for (int e = lane; e < 2 * nmax; e += mpc::kWave) { int k = e / 2; int ks = k < n - 1 ? k : n - 2; uo[e] = double(S.F(L.U, e % 2, ks)); }
-            if (lane == 0) {
-                dt_out[inst] = double(S.SCL(mpc::SC_D));
-                if (status) status[inst] = st.status;
-                if (iters) iters[inst] = st.iters + (iters_add ? iters_add[inst] : 0);
-            }
-            if (cc.dual) {
-                double* blk = cc.dual + (long)inst * cc.dual_words;
-                __syncthreads();                                   // every lane has read its share of the old block (load_duals) long ago; keep the order explicit
-                if (st.status == mpc::ST_CONVERGED) S.store_duals(blk);
-                else if (lane == 0) blk[0] = 0.0;
-            }
-            if (NC <= 1) return;
-        } else if (st.status == mpc::ST_CONVERGED) {
-            // a hedge that converged leaves its record: x (n x 3), u (n x 2), dt, status, iterations [, multipliers]
-            double* r = cc.rec + ((long)cand * B + inst) * (5 * nmax + 3 + cc.dual_words);
-            for (int e = lane; e < 3 * nmax; e += mpc::kWave) { int k = e / 3; int ks = k < n ? k : n - 1; r[e] = double(S.F(L.X, e % 3, ks)); }
-            for (int e = lane; e < 2 * nmax; e += mpc::kWave) { int k = e / 2; int ks = k < n - 1 ? k : n - 2; r[3 * nmax + e] = double(S.F(L.U, e % 2, ks)); }
-            if (lane == 0) { r[5 * nmax] = double(S.SCL(mpc::SC_D)); r[5 * nmax + 1] = double(st.status); r[5 * nmax + 2] = double(st.iters); }
-            if (cc.dual) S.store_duals(r + 5 * nmax + 3);
-        }
-    }
-    // ---- exit protocol (n_cand > 1): publish, count, and let the last candidate of the instance deliver a hedge's result
-    __threadfence();
-    __syncthreads();
-    int last = 0;
-    if (lane == 0) {
-        if (st_status == mpc::ST_CONVERGED) atomicMin(cc.win + inst, cand);
-        if (st_iters > 0) atomicAdd(cc.it_sum + inst, st_iters);
-        __threadfence();
-        last = atomicAdd(cc.exited + inst, 1) == NC - 1;
-    }
-    last = __builtin_amdgcn_readfirstlane(last);
-    if (!last) return;
-    __threadfence();
-    const int w = __builtin_amdgcn_readfirstlane(__hip_atomic_load(cc.win + inst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
-    if (w > 0 && w < NC) {
-        const double* r = cc.rec + ((long)w * B + inst) * (5 * nmax + 3 + cc.dual_words);
-        double* xo = x_out + (long)inst * nmax * 3;
-        double* uo = u_out + (long)inst * nmax * 2;
-        for (int e = lane; e < 3 * nmax; e += mpc::kWave) xo[e] = __builtin_nontemporal_load(r + e);
-        for (int e = lane; e < 2 * nmax; e += mpc::kWave) uo[e] = __builtin_nontemporal_load(r + 3 * nmax + e);
-        if (cc.dual) {
-            double* blk = cc.dual + (long)inst * cc.dual_words;
-            for (int e = lane; e < cc.dual_words; e += mpc::kWave) blk[e] = __builtin_nontemporal_load(r + 5 * nmax + 3 + e);
-        }
-        if (lane == 0) {
-            dt_out[inst] = __builtin_nontemporal_load(r + 5 * nmax);
-            if (status) status[inst] = (int32_t)__builtin_nontemporal_load(r + 5 * nmax + 1);
-            if (iters) iters[inst] = (int32_t)__builtin_nontemporal_load(r + 5 * nmax + 2);
-        }
-    }
-    if (lane == 0) {
-        if (cc.winner_out) cc.winner_out[inst] = w < NC ? w : -1;
-        if (cc.iters_total_out) cc.iters_total_out[inst] = __hip_atomic_load(cc.it_sum + inst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        // back to idle for the next launch
-        __hip_atomic_store(cc.win + inst, kWinIdle, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(cc.it_sum + inst, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(cc.exited + inst, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-}
 
 }  // namespace
 
@@ -445,22 +286,23 @@ void mpc_destroy(mpc_solver* s) {
 
 }  // extern "C"
 
+// fills the launch record of mpc_solve_kernel.hpp from the handle; the kernels themselves are instantiated per (precision, model) in
+// mpc_solve_inst.hip (split build: one object each, compiled in parallel) or right here (single translation unit)
 template <typename T, int MODEL>
 static hipError_t launch_model(mpc_solver* s, const mpc::Problem<T>& P, int B, const double* x0, const double* xf, const double* up,
                                const double* dtp, const double* xi, const double* ui, const double* dti, const mpc_obstacles& ob, double* xo, double* uo,
                                double* dto, int32_t* st, int32_t* it) {
-    const bool ext = solver_ext(s);
-    auto kern = !ext ? mpc_ipm_wave_kernel<T, MODEL, 0> : (s->P64.costx ? mpc_ipm_wave_kernel<T, MODEL, 2> : mpc_ipm_wave_kernel<T, MODEL, 1>);
-    const size_t lds = sizeof(T) == 4 ? s->wave_lds32 : s->wave_lds;
-    if (lds > 48u * 1024u) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return e;
-    }
-    const int32_t* iters_add = (s->cfg.precision == MPC_MIXED && sizeof(T) == 8) ? s->d_iters1 : nullptr;
-    CandCtl cc = {P.n_cand, s->d_cwin, s->d_cexited, s->d_citsum, s->d_crec, s->d_winner, s->d_iters_total, s->d_rows_dropped, s->d_dual, s->dual_words};
-    hipLaunchKernelGGL(kern, dim3((unsigned)B * (unsigned)(P.n_cand > 1 ? P.n_cand : 1)), dim3(mpc::kWave), lds, s->stream, P, s->WL, B, x0, xf, up, dtp, xi, ui, dti, ob,
-                       s->use_ngrid ? s->d_ngrid : nullptr, s->p_nvia, s->p_via, cc, iters_add, xo, uo, dto, st, it);
-    return hipSuccess;
+    mpc::SolveLaunch a;
+    a.level = !solver_ext(s) ? 0 : (s->P64.costx ? 2 : 1);
+    a.lds = sizeof(T) == 4 ? s->wave_lds32 : s->wave_lds;
+    a.stream = s->stream;
+    a.L = s->WL; a.B = B;
+    a.x0 = x0; a.xf = xf; a.u_prev = up; a.dt_prev = dtp; a.x_init = xi; a.u_init = ui; a.dt_init = dti; a.obst = ob;
+    a.n_grid = s->use_ngrid ? s->d_ngrid : nullptr; a.n_via = s->p_nvia; a.via = s->p_via;
+    a.cc = {P.n_cand, s->d_cwin, s->d_cexited, s->d_citsum, s->d_crec, s->d_winner, s->d_iters_total, s->d_rows_dropped, s->d_dual, s->dual_words};
+    a.iters_add = (s->cfg.precision == MPC_MIXED && sizeof(T) == 8) ? s->d_iters1 : nullptr;
+    a.x_out = xo; a.u_out = uo; a.dt_out = dto; a.status = st; a.iters = it;
+    return mpc::launch_solve<T, MODEL>(a, P);
 }
 
 template <typename T>

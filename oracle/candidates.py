@@ -1,7 +1,7 @@
 """ORACLE (test infrastructure only; parity unpinned: the reference has no recorded outputs for this path): candidate initial trajectories and the winner rule, restated on the CPU.
 
 The product generates the candidates on the device (mpc_wave.hpp::seed_start) and applies the rule with atomics inside the solve
-kernel (mpc_capi.hip, "exit protocol"); this file restates both in numpy so that tests can run the identical rule on the C oracle:
+kernel (mpc_solve_kernel.hpp, "exit protocol"); this file restates both in numpy so that tests can run the identical rule on the C oracle:
 
   kinds (include/mpc_hip.h, enum mpc_candidate_kind)
     0 REFERENCE        the 2-pose-plan cold start of Controller::step (src/controller.cpp:807-857 +

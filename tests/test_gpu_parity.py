@@ -323,8 +323,8 @@ def test_no_uninitialised_lds_reads(m, tmp_path):
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     so = str(tmp_path / "libmpc_hip_poison.so")
-    subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-DMPC_POISON_LDS",
-                    os.path.join(root, "mpc_local_planner_amd", "csrc", "mpc_capi.hip"), "-o", so], check=True)
+    from mpc_local_planner_amd import _lib
+    _lib.build(extra_flags=["-DMPC_POISON_LDS"], out=so)          # the split build of the product library with one more flag (parallel: ~25 s)
     # round-2 paths: candidates (kernel-generated seeds), kept multipliers, a turning footprint against polygons and a dynamic obstacle -- results of
     # the normal library (this process) must be reproduced bit for bit by the poisoned build (the subprocess)
     x0, xf, up, dtp = m.workloads.carlike_min_time_inputs(16, seed=77, goal_range=(2.0, 4.0))
