@@ -358,16 +358,18 @@ struct IpmWave {
     // distance_point_to_polygon_2d);
     // returns dist (>= 0, obstacle radius already subtracted), unit normal from the closest point to (px,py) and
     // hk = 1/|p-q| if the closest feature is a vertex (or a point/circle obstacle), 0 on an edge interior.
-    __device__ __forceinline__ void obst_eval(T px, T py, int j, T& dist, T& nx, T& ny, T& hk) const {
+    // obst_closest: the closest point (bx, by) of obstacle j to (px, py), its squared distance, and whether the closest feature is a vertex
+    // (what the callers that compare several candidates need; roots and normals only for the winner).
+    __device__ __forceinline__ T obst_closest(T px, T py, int j, T& bx, T& by, bool& vert) const {
         const int nv = (int)sm[L.GNV + j];
         const T* v = sm + L.GV + 2 * L.V * j;
-        T best = T(1e30), bx = T(0), by = T(0);
-        bool vert = true;
+        T best = T(1e30);
+        bx = T(0); by = T(0); vert = true;
         if (nv <= 1) { bx = v[0]; by = v[1]; T dx = px - bx, dy = py - by; best = dx * dx + dy * dy; }
         else {
             const int ne = nv == 2 ? 1 : nv;
             for (int e = 0; e < ne; ++e) {
-                const int e2 = (e + 1) % nv;
+                const int e2 = e + 1 < nv ? e + 1 : 0;
                 const T ax = v[2 * e], ay = v[2 * e + 1], cx = v[2 * e2], cy = v[2 * e2 + 1];
                 const T abx = cx - ax, aby = cy - ay;
                 const T sq = abx * abx + aby * aby;
@@ -378,6 +380,12 @@ struct IpmWave {
                 if (d2 < best) { best = d2; bx = qx; by = qy; vert = !(t > T(0) && t < T(1)); }
             }
         }
+        return best;
+    }
+    __device__ __forceinline__ void obst_eval(T px, T py, int j, T& dist, T& nx, T& ny, T& hk) const {
+        T bx, by;
+        bool vert;
+        const T best = obst_closest(px, py, j, bx, by, vert);
         const T dd = sqrt(best);
         if (dd > T(0)) { nx = (px - bx) / dd; ny = (py - by) / dd; hk = vert ? T(1) / dd : T(0); }
         else { nx = T(0); ny = T(0); hk = T(0); }
@@ -478,15 +486,18 @@ struct IpmWave {
     // fixed (teb distance_point_to_polygon_2d: first closest edge wins, no inside test; 1 vertex = a point, 2 vertices = one edge).
     // Returns the distance, the row gradient a = d g / d(x, y, theta) of g = d_min - dist, hk (the (x,y) block of hess g is
     // -hk (I - a_xy a_xy'), |a_xy| = 1) and the heading parts h3 = hess g [x theta, y theta, theta theta].
-    __device__ __forceinline__ T fp_point_eval(T px, T py, T s, T c, T vwx, T vwy, T a[3], T& hk, T h3[3]) const {
+    // closest point of the footprint (robot frame) to the world point (vwx, vwy): squared distance, offset (dx, dy) from the closest point to
+    // q = R(-theta)(v - p), edge parameter t.  First closest edge wins (squared distances compared; the root is taken once by the caller).
+    __device__ __forceinline__ T fp_point_closest(T px, T py, T s, T c, T vwx, T vwy, T& qx, T& qy, T& dx, T& dy, T& t) const {
         const T vx = vwx - px, vy = vwy - py;
-        const T qx = c * vx + s * vy, qy = c * vy - s * vx;
-        T dx = T(0), dy = T(0), t = T(0), best = T(3e38);
+        qx = c * vx + s * vy; qy = c * vy - s * vx;
+        dx = T(0); dy = T(0); t = T(0);
+        T best = T(3e38);
         const bool poly = P.footprint_kind == 4;
         const int nv = poly ? P.fp_nv : 2;
         const int ne = nv <= 2 ? 1 : nv;
         for (int e = 0; e < ne; ++e) {
-            const int e2 = nv == 1 ? 0 : (e + 1) % nv;
+            const int e2 = nv == 1 ? 0 : (e + 1 < nv ? e + 1 : 0);
             const T a0 = poly ? P.fp_poly[2 * e] : P.fp_line[0], a1 = poly ? P.fp_poly[2 * e + 1] : P.fp_line[1];
             const T b0 = poly ? P.fp_poly[2 * e2] : P.fp_line[2], b1 = poly ? P.fp_poly[2 * e2 + 1] : P.fp_line[3];
             const T abx = b0 - a0, aby = b1 - a1;
@@ -494,10 +505,13 @@ struct IpmWave {
             T te = sq > T(0) ? ((qx - a0) * abx + (qy - a1) * aby) / sq : T(0);
             te = t_min(T(1), t_max(T(0), te));
             const T ex = qx - (a0 + te * abx), ey = qy - (a1 + te * aby);
-            const T de = sqrt(ex * ex + ey * ey);
-            if (de < best) { best = de; dx = ex; dy = ey; t = te; }
+            const T e2d = ex * ex + ey * ey;
+            if (e2d < best) { best = e2d; dx = ex; dy = ey; t = te; }
         }
-        const T D = best;
+        return best;
+    }
+    // row gradient a = d g / d(x, y, theta) of g = d_min - D, hk and the heading parts h3 for the closest-point data of fp_point_closest
+    __device__ __forceinline__ void fp_point_derivs(T s, T c, T qx, T qy, T dx, T dy, T t, T D, T a[3], T& hk, T h3[3]) const {
         T nx = T(0), ny = T(0);
         hk = T(0);
         if (D > T(0)) { nx = dx / D; ny = dy / D; hk = (t > T(0) && t < T(1)) ? T(0) : T(1) / D; }
@@ -507,7 +521,18 @@ struct IpmWave {
         h3[0] = -((s * hwy - c * hwx) + (nx * s + ny * c));
         h3[1] = -((-s * hwx - c * hwy) + (ny * s - nx * c));
         h3[2] = -((qy * hwx - qx * hwy) - (nx * qx + ny * qy));
+    }
+    __device__ __forceinline__ T fp_point_eval(T px, T py, T s, T c, T vwx, T vwy, T a[3], T& hk, T h3[3]) const {
+        T qx, qy, dx, dy, t;
+        const T D = sqrt(fp_point_closest(px, py, s, c, vwx, vwy, qx, qy, dx, dy, t));
+        fp_point_derivs(s, c, qx, qy, dx, dy, t, D, a, hk, h3);
         return D;
+    }
+    // sin / cos of the heading, kept per lane: the rows of one grid point (and the trials of one row) ask for the same angle again and again
+    mutable T sc_th = T(1e30), sc_s = T(0), sc_c = T(1);
+    __device__ __forceinline__ void heading_sincos(T th, T& s_, T& c_) const {
+        if (th != sc_th) { t_sincos(th, &sc_s, &sc_c); sc_th = th; }
+        s_ = sc_s; c_ = sc_c;
     }
     // footprint vertex i in the robot frame (line: start, end; polygon: the vertex list)
     __device__ __forceinline__ void fp_vertex(int i, T& ax, T& ay) const {
@@ -529,39 +554,51 @@ struct IpmWave {
     __device__ __forceinline__ T line_eval(T px, T py, T th, int j, T a[3], T& hk, T h3[3]) const {
         const T* v = sm + L.GV + 2 * L.V * j;
         T s, c;
-        t_sincos(th, &s, &c);
+        heading_sincos(th, s, c);
         const int nvo = (int)sm[L.GNV + j];
         if (nvo <= 1) return fp_point_eval(px, py, s, c, v[0], v[1], a, hk, h3) - sm[L.GR + j];
         const int F_ = P.footprint_kind == 4 ? P.fp_nv : 2;
-        T best = T(3e38);
+        // the candidates are compared by their squared distances (first minimum wins); roots and derivatives only for the winner of each family
+        T bestA = T(3e38), aqx = T(0), aqy = T(0), adx = T(0), ady = T(0), at = T(0);
         for (int m = 0; m < nvo; ++m) {
-            T am[3], hm, h3m[3];
-            const T D = fp_point_eval(px, py, s, c, v[2 * m], v[2 * m + 1], am, hm, h3m);
-            if (D < best) { best = D; a[0] = am[0]; a[1] = am[1]; a[2] = am[2]; hk = hm; h3[0] = h3m[0]; h3[1] = h3m[1]; h3[2] = h3m[2]; }
+            T qx, qy, dx, dy, t;
+            const T d2 = fp_point_closest(px, py, s, c, v[2 * m], v[2 * m + 1], qx, qy, dx, dy, t);
+            if (d2 < bestA) { bestA = d2; aqx = qx; aqy = qy; adx = dx; ady = dy; at = t; }
         }
+        T bestB = T(3e38), brx = T(0), bry = T(0), bbx = T(0), bby = T(0);
+        bool bvert = true;
         for (int i = 0; i < F_; ++i) {
-            T ax_, ay_;
+            T ax_, ay_, qbx, qby;
+            bool vert;
             fp_vertex(i, ax_, ay_);
             const T rx = c * ax_ - s * ay_, ry = s * ax_ + c * ay_;
-            T D, nx, ny, ho;
-            obst_eval(px + rx, py + ry, j, D, nx, ny, ho);
-            if (D < best) {
-                best = D;
-                const T wx = -ry, wy = rx, nw = nx * wx + ny * wy;         // w = dc/dtheta
-                a[0] = -nx; a[1] = -ny; a[2] = -nw;
-                hk = ho;
-                const T hvx = ho * (wx - nx * nw), hvy = ho * (wy - ny * nw);
-                h3[0] = -hvx; h3[1] = -hvy; h3[2] = -((wx * hvx + wy * hvy) - (nx * rx + ny * ry));
-            }
+            const T d2 = obst_closest(px + rx, py + ry, j, qbx, qby, vert);
+            if (d2 < bestB) { bestB = d2; brx = rx; bry = ry; bbx = qbx; bby = qby; bvert = vert; }
+        }
+        const T DA = sqrt(bestA), DB = sqrt(bestB) - sm[L.GR + j];
+        T best;
+        if (DB < DA) {             // a footprint vertex c_i(theta) = p + R(theta) a_i against the obstacle's edges: chain rule through theta
+            best = DB;
+            const T dd = sqrt(bestB);
+            T nx = T(0), ny = T(0), ho = T(0);
+            if (dd > T(0)) { nx = (px + brx - bbx) / dd; ny = (py + bry - bby) / dd; ho = bvert ? T(1) / dd : T(0); }
+            const T wx = -bry, wy = brx, nw = nx * wx + ny * wy;         // w = dc/dtheta
+            a[0] = -nx; a[1] = -ny; a[2] = -nw;
+            hk = ho;
+            const T hvx = ho * (wx - nx * nw), hvy = ho * (wy - ny * nw);
+            h3[0] = -hvx; h3[1] = -hvy; h3[2] = -((wx * hvx + wy * hvy) - (nx * brx + ny * bry));
+        } else {                   // an obstacle vertex against the footprint's edges
+            best = DA;
+            fp_point_derivs(s, c, aqx, aqy, adx, ady, at, DA, a, hk, h3);
         }
         // crossing edges: distance 0 (and no gradient), as distance_segment_to_segment_2d returns it
         const int nef = F_ <= 2 ? (F_ == 2 ? 1 : 0) : F_, neo = nvo == 2 ? 1 : nvo;
         for (int e = 0; e < nef; ++e) {
             T a0x, a0y, a1x, a1y;
-            fp_vertex(e, a0x, a0y); fp_vertex((e + 1) % F_, a1x, a1y);
+            fp_vertex(e, a0x, a0y); fp_vertex(e + 1 < F_ ? e + 1 : 0, a1x, a1y);
             const T Ax = px + c * a0x - s * a0y, Ay = py + s * a0x + c * a0y, Bx = px + c * a1x - s * a1y, By = py + s * a1x + c * a1y;
             for (int o = 0; o < neo; ++o) {
-                const int o2 = (o + 1) % nvo;
+                const int o2 = o + 1 < nvo ? o + 1 : 0;
                 if (seg_intersect(Ax, Ay, Bx, By, v[2 * o], v[2 * o + 1], v[2 * o2], v[2 * o2 + 1])) {
                     a[0] = a[1] = a[2] = T(0); hk = T(0); h3[0] = h3[1] = h3[2] = T(0);
                     return T(0);
@@ -576,7 +613,7 @@ struct IpmWave {
     // Same outputs as line_eval (|a_xy| = 1 again, so the (x,y) block keeps the -hk (I - a_xy a_xy') form).
     __device__ __forceinline__ T two_eval(T px, T py, T th, int j, T a[3], T& hk, T h3[3]) const {
         T s, c;
-        t_sincos(th, &s, &c);
+        heading_sincos(th, s, c);
         T df, nfx, nfy, hf, dr, nrx, nry, hr;
         obst_eval(px + P.fp_line[0] * c, py + P.fp_line[0] * s, j, df, nfx, nfy, hf);
         obst_eval(px - P.fp_line[2] * c, py - P.fp_line[2] * s, j, dr, nrx, nry, hr);
