@@ -59,6 +59,21 @@ class BatchSolver:
             raise MpcError(rc, self._lib.mpc_last_error().decode())
         self._h = h
 
+    @classmethod
+    def from_yaml(cls, path: str, max_batch: int, device: int = 0, namespace="MpcLocalPlannerROS", costmap_footprint=None, **sizing):
+        """A solver configured from a parameter file of the reference (its keys, its defaults: mpc_local_planner_amd/params.py).  The grid
+        is sized for the largest size the reference's grid adaptation may reach.  The facade options and the notes of the reader are kept
+        as `controller_options` / `param_notes`."""
+        from . import params
+        cfg, ctrl, notes = params.config_from_yaml(path, namespace=namespace, costmap_footprint=costmap_footprint, **sizing)
+        n_ref = int(cfg.n)
+        cfg.n = max(n_ref, int(ctrl.get("n_max", n_ref)))          # capacity: grid/variable_grid/grid_adaptation/max_grid_size
+        s = cls(cfg, max_batch, device)
+        if cfg.n > n_ref:
+            s.set_grid_sizes([n_ref] * max_batch)                   # every instance starts at grid/grid_size_ref, as the reference's grid does
+        s.controller_options, s.param_notes, s.n_ref = ctrl, notes, n_ref
+        return s
+
     def close(self):
         if getattr(self, "_h", None):
             self._lib.mpc_destroy(self._h)

@@ -417,3 +417,27 @@ def test_cost_variants_vs_c_oracle(m, c_oracle, name):
     assert (r.status == 0).mean() > 0.95 and match.sum() > 0.9 * B
     assert abs(float(r.iters[match].mean()) - float(out[4][match].mean())) < 0.5          # same iterate sequences
     s.close()
+
+
+def test_solver_from_a_parameter_file_of_the_reference(m, tmp_path):
+    """BatchSolver.from_yaml: a parameter file in the reference's layout (tests/test_params.py::CARLIKE_YAML: car-like model, line footprint, Crank-Nicolson
+    collocation, terminal cost + terminal ball with a free heading, convexified Hessian, tol 1e-4) -> a configured handle; the batch solves and the
+    handle is sized for the largest grid the reference's grid adaptation may reach."""
+    from test_params import CARLIKE_YAML
+    f = tmp_path / "params.yaml"
+    f.write_text(CARLIKE_YAML)
+    B = 64
+    s = m.BatchSolver.from_yaml(str(f), max_batch=B, max_obstacles=4, max_vertices=1)
+    assert s.n == 60 and s.n_ref == 24 and s.controller_options["max_grid_size"] == 60 and any("limited-memory" in t for t in s.param_notes)
+    assert (s.grid_sizes(B) == 24).all()
+    x0, xf, up, dtp = m.workloads.carlike_min_time_inputs(B, seed=3, goal_range=(1.0, 3.0))
+    no, nv, vt = point_obstacles(x0, xf, seed=9)
+    r = s.solve(x0, xf, up, dtp, obstacles=(no, nv, vt))
+    ok = r.status == 0
+    assert ok.mean() > 0.7
+    # the two goal components that the file fixes are met, the free heading stays inside the terminal ball (S = diag(1, 1, 0.5), radius 0.2)
+    last = s.n_ref - 1
+    assert np.abs(r.x[ok, last, :2] - xf[ok, :2]).max() < 1e-9
+    dth = np.arctan2(np.sin(r.x[ok, last, 2] - xf[ok, 2]), np.cos(r.x[ok, last, 2] - xf[ok, 2]))
+    assert (0.5 * dth ** 2 <= 0.2 + 1e-6).all()
+    s.close()
