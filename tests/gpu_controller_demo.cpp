@@ -7,18 +7,29 @@
 #include <cstdio>
 
 #include "../include/mpc_controller.hpp"
+#include "../include/mpc_params.hpp"
 
 using namespace mpc_local_planner_amd;
 
 // second scenario: the shipped configuration (grid adaptation on): drive to the goal; n follows dt (n+-1 per cycle)
 static int run_adaptive() {
-    mpc_config c;
-    mpc_config_defaults(&c);
-    c.u_lb[0] = -0.2; c.u_ub[0] = 0.4; c.u_lb[1] = -0.3; c.u_ub[1] = 0.3;
-    c.tol = 1e-6;
+    // configured the way the plugin does it: from the parameter set (here the keys of the diff-drive minimum-time example, held in a map
+    // instead of the ROS parameter server) through include/mpc_params.hpp
+    MapParamSource prm;
+    prm.set("robot/type", "unicycle");
+    prm.set("robot/unicycle/max_vel_x", 0.4); prm.set("robot/unicycle/max_vel_x_backwards", 0.2); prm.set("robot/unicycle/max_vel_theta", 0.3);
+    prm.set("grid/type", "fd_grid"); prm.set("grid/grid_size_ref", 20); prm.set("grid/dt_ref", 0.3);
+    prm.set("grid/xf_fixed", std::vector<bool>{true, true, true});
+    prm.set("grid/variable_grid/enable", true); prm.set("grid/variable_grid/min_dt", 0.0); prm.set("grid/variable_grid/max_dt", 10.0);
+    prm.set("grid/variable_grid/grid_adaptation/enable", true); prm.set("grid/variable_grid/grid_adaptation/max_grid_size", 50);
+    prm.set("grid/variable_grid/grid_adaptation/dt_hyst_ratio", 0.1); prm.set("grid/variable_grid/grid_adaptation/min_grid_size", 2);   // the facade clamps 2 to 3
+    prm.set("planning/objective/type", "minimum_time");
+    prm.set("solver/type", "ipopt"); prm.set("solver/ipopt/iterations", 100); prm.set("solver/ipopt/ipopt_numeric_options/tol", 1e-6);
+    prm.set("solver/ipopt/ipopt_string_options/linear_solver", "mumps");
     Controller ctl;
-    ctl.setGridAdaptation(true, 50, 0.1, 2);          // grid_adaptation: max 50, hysteresis .1, min 2 (clamped to 3)
-    if (!ctl.configure(c, 0)) { std::printf("configure failed: %s\n", ctl.lastError().c_str()); return 2; }
+    ParamReport rep;
+    if (configure_from_params(ctl, prm, rep) != PARAMS_OK) { std::printf("configure failed: %s\n", rep.error.c_str()); return 2; }
+    for (const std::string& note : rep.notes) std::printf("parameter note: %s\n", note.c_str());
     PoseSE2 pose{0, 0, 0}, goal{2.0, 1.0, 0.5};
     Twist vel;
     const double period = 0.1;
