@@ -42,6 +42,9 @@ FP32_VECTOR_PEAK_TF = 157.3
 # on average; DESIGN.md section 5.4 has the measured sweep).
 CAND_KINDS = (0, 5, 5, 7)
 CAND_CAPS = (60, 45, 40, 35)
+# at 4096 instances per GPU the launch is bound by the total work, not by its slowest instance: longer hedge caps cost nothing there and lift the converged
+# fraction (profiles/r02_candidate_sweep_B4096.log: 99.95 % instead of 99.2 % at the same 10.1 ms)
+CAND_CAPS_LARGE_BATCH = (60, 60, 50, 40)
 CAND_PARAMS = (0.0, 2.0, 3.0, 1.5)
 CAND5_KINDS, CAND5_CAPS, CAND5_PARAMS = (0, 1, 2, 5), (60, 50, 45, 40), (0.0, 0.0, 0.0, 2.0)      # config-5 legs (bicycle, n = 120)
 
@@ -177,7 +180,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="instances per GPU (default: 1024 at N=1 = configs[1], 4096 at N>1 = configs[3])")
     ap.add_argument("--n", type=int, default=N_GRID)
     ap.add_argument("--candidates", type=str, default=",".join(str(k) for k in CAND_KINDS), help="candidate kinds in priority order; '0' = the single reference solve")
-    ap.add_argument("--caps", type=str, default=",".join(str(k) for k in CAND_CAPS))
+    ap.add_argument("--caps", type=str, default="", help="per-candidate iteration caps (default: %s up to 1024 instances per GPU, %s at 4096)" % (CAND_CAPS, CAND_CAPS_LARGE_BATCH))
     ap.add_argument("--params", type=str, default=",".join(str(k) for k in CAND_PARAMS), help="per candidate: tangent scale of the Hermite kinds")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the extra legs (warm start, other configs)")
@@ -207,7 +210,7 @@ def main():
     n = args.n
     B = args.batch if args.batch > 0 else (BATCH_PER_GPU_MULTI if multi else BATCH_1GPU)
     kinds = tuple(int(k) for k in args.candidates.split(","))
-    caps = tuple(int(k) for k in args.caps.split(","))[:len(kinds)]
+    caps = (tuple(int(k) for k in args.caps.split(",")) if args.caps else (CAND_CAPS_LARGE_BATCH if B >= 4096 else CAND_CAPS))[:len(kinds)]
     pars = tuple(float(k) for k in args.params.split(","))[:len(kinds)]
     ckw = dict(candidates=kinds, candidate_max_iter=caps, candidate_param=pars) if len(kinds) > 1 else {}
     # the warm-start leg has its own solver: its handle keeps the multipliers of every instance's last converged solve (dual_warm_start) and the
@@ -334,8 +337,11 @@ def main():
                                       "(dual_warm_start: every inequality multiplier max(previous, mu0 / slack), mu0 = 1e-3); the hedges start cold from their own seeds"}
         leg.close()
         # configs[3] share on one GPU (what every rank of the N = 8 run does)
-        l4 = Leg(m, torch, dev, cfg, BATCH_PER_GPU_MULTI, m.workloads.carlike_min_time_inputs(BATCH_PER_GPU_MULTI))
+        caps4 = (tuple(int(k) for k in args.caps.split(",")) if args.caps else CAND_CAPS_LARGE_BATCH)[:len(kinds)]
+        cfg4 = m.config_carlike_min_time(n=n, candidates=kinds, candidate_max_iter=caps4, candidate_param=pars) if len(kinds) > 1 else cfg
+        l4 = Leg(m, torch, dev, cfg4, BATCH_PER_GPU_MULTI, m.workloads.carlike_min_time_inputs(BATCH_PER_GPU_MULTI))
         legs["config4_share_B4096"] = leg_summary(l4, max(2, args.steps // 2), 1, algorithmic_bytes_per_solve(n), 914.0 * (n - 1), FP64_VECTOR_PEAK_TF, f"carlike_n{n}_B4096_c{len(kinds)}")
+        legs["config4_share_B4096"]["candidate_max_iter"] = list(caps4)
         l4.close()
         # configs[2]: unicycle quadratic form, n = 80, 16 polygon obstacles, B = 4096 (single candidate: > 99.9 % converge from the cold start)
         n3, B3, O, V, M = 80, 4096, 16, 6, 4
