@@ -245,6 +245,8 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         if (er == hipSuccess) er = hipMemset(s->d_cexited, 0, Bm * 4);
         if (er == hipSuccess) er = hipMemset(s->d_citsum, 0, Bm * 4);
     }
+    // the fills above run on the null stream, the solves on the handle's own non-blocking stream: nothing orders the two, so wait here
+    if (er == hipSuccess) er = hipDeviceSynchronize();
     if (er != hipSuccess) {
         set_err("mpc_create: allocation", er);
         mpc_destroy(s);
@@ -265,6 +267,7 @@ int mpc_reset(mpc_solver* s) {
         HIP_TRY(hipMemset(s->d_cexited, 0, (size_t)s->max_batch * 4));
         HIP_TRY(hipMemset(s->d_citsum, 0, (size_t)s->max_batch * 4));
     }
+    HIP_TRY(hipDeviceSynchronize());      // null-stream fills vs the handle's non-blocking stream (see mpc_create)
     return MPC_OK;
 }
 
