@@ -549,3 +549,29 @@ def test_c_oracle_cost_variants_match_numpy_and_are_kkt_points_of_the_reference_
         import dataclasses
         xl = c_oracle.solve_batch(c_oracle.from_nlp_config(dataclasses.replace(ocfg, cost_integration="left_sum")), x0, xf, up, dtp)[0]
         assert np.abs(xl - xo).max() > 1e-3
+
+
+@pytest.mark.parametrize("name", [v for v in COST_VARIANTS if v != "trapezoid_xf_fixed_free_dt"])
+def test_cost_variants_independent_sqp_from_the_cold_start(name, c_oracle):
+    """SURVEY 8c level 2 for the cost variants: scipy's SLSQP (an active-set SQP with no code in common with the interior-point implementations), started
+    at the reference's cold start on the reference-form NLP, ends at the interior-point oracle's point (these quadratic-form problems are near-convex).
+    Not for the variant with a FIXED goal and a free dt: like the minimum-time problem it has several local optima and the two solvers settle in different
+    ones (both KKT points: test_c_oracle_cost_variants_match_numpy_and_are_kkt_points_of_the_reference_form)."""
+    from scipy.optimize import minimize
+    import mpc_local_planner_amd.workloads as W
+    ocfg = cost_variant(name, 12)
+    x0, xf, up, dtp = W.unicycle_quadratic_inputs(3, seed=11)
+    xo, uo, do, st, it = c_oracle.solve_batch(c_oracle.from_nlp_config(ocfg), x0, xf, up, dtp)
+    assert (st == 0).all()
+    for i in range(3):
+        inp = R.CycleInputs(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=float(dtp[i]))
+        nlp = R.ReferenceNlp(ocfg, inp)
+        z0 = nlp.pack(I.controls_from_states(ocfg, R.cold_start(ocfg, x0[i], xf[i])))
+        lb, ub = nlp.bounds()
+        z0 = np.minimum(np.maximum(z0, lb), ub)
+        bnds = [(None if l < -1e29 else l, None if u > 1e29 else u) for l, u in zip(lb, ub)]
+        cons = [{"type": "eq", "fun": nlp.equalities}, {"type": "ineq", "fun": lambda z: -nlp.inequalities(z)}]
+        r = minimize(nlp.objective, z0, method="SLSQP", bounds=bnds, constraints=cons, options=dict(maxiter=600, ftol=1e-13))
+        t = nlp.unpack(r.x)
+        assert np.abs(t.x - xo[i]).max() < 1e-4 and abs(t.dt - do[i]) < 1e-4, (name, i, np.abs(t.x - xo[i]).max())
+        assert abs(r.fun - nlp.objective(nlp.pack(R.Trajectory(xo[i], uo[i][:ocfg.n - 1], float(do[i]))))) < 1e-6 * max(1.0, abs(r.fun))
