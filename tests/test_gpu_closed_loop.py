@@ -194,3 +194,32 @@ def test_mixed_precision_meets_the_fp64_tolerance_on_config5(env, c_oracle):
     assert out["mixed"][1] < 1e-4 and out["mixed"][5] > 0.85
     assert out["mixed"][0] >= out["fp64"][0] - 0.02
     assert out["fp64"][1] < 1e-6
+
+
+def test_config5_candidates_vs_oracle_rule_fp64_and_mixed(env, c_oracle):
+    """BASELINE.json configs[4] shape (kinematic bicycle, n = 120) with the candidate set of its bench leg (reference cold start, travel, travel-reverse,
+    Hermite FF; caps 60/50/45/40): the identical rule on the C oracle against the device in fp64 (winners and trajectories) and in MPC_MIXED (fp32
+    main phase picks the winner, fp64 refinement), accounting for every converged device result: within 1e-4 of the oracle rule's result or a KKT point
+    of the reference-form NLP on its own; nothing unclassified."""
+    from oracle import se2_nlp as R, candidates as OC
+    from mpc_local_planner_amd import _abi as A
+    from _parity import account
+    m, torch = env
+    B, n = 128, 120
+    kinds, caps, pars = (A.CAND_REFERENCE, A.CAND_TRAVEL, A.CAND_TRAVEL_REVERSE, A.CAND_HERMITE_FF), (60, 50, 45, 40), (0.0, 0.0, 0.0, 2.0)
+    ocfg = R.config_bicycle_min_time(n)
+    inputs = m.workloads.bicycle_min_time_inputs(B)
+    ox, ou, od, ost, oit, owin, olow, allr = OC.solve_candidates(c_oracle, lambda cap: c_oracle.from_nlp_config(ocfg, max_iter=cap), *inputs, kinds, caps, n, ocfg.dt_ref, params=pars)
+    for tag, prec in (("fp64", A.FP64), ("mixed", A.MIXED)):
+        s = m.BatchSolver(m.config_bicycle_min_time(n, precision=prec, candidates=kinds, candidate_max_iter=caps, candidate_param=pars), max_batch=B)
+        r = s.solve(*inputs)
+        win, tot = s.last_candidates(B)
+        conv = r.status == 0
+        print(f"[config 5 candidates, {tag}] device converged {conv.mean():.4f} (oracle rule {np.mean(ost == 0):.4f}); winners device {np.bincount(win + 1, minlength=5).tolist()} "
+              f"oracle {np.bincount(owin + 1, minlength=5).tolist()} (index 0 = none); equal winners {np.mean(win == owin):.4f}")
+        assert conv.mean() >= 0.97
+        if tag == "fp64":
+            assert np.mean(win == owin) > 0.95
+        match, other = account(f"config 5 shape with candidates, {tag}", ocfg, inputs, r, (ox, ou, od, ost, oit))
+        assert match.sum() > (0.9 if tag == "fp64" else 0.6) * B
+        s.close()
