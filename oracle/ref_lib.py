@@ -1,0 +1,76 @@
+"""ORACLE (test infrastructure only): ctypes access to oracle/_ref/libmpc_ref.so = REFERENCE code (math_utils.h, the four robot models, the three SE(2)
+collocation rules) compiled from /root/reference by `make -C oracle ref` (oracle/ref_wrap.cpp explains what is real and what is a stand-in).
+Present only where /root/reference exists; `load()` returns None elsewhere (the GPU box): tests then use the recorded vectors of
+tests/golden/ref_models_collocation.npz."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB = os.path.join(_HERE, "_ref", "libmpc_ref.so")
+REFERENCE_INCLUDE = "/root/reference/mpc_local_planner/include"
+
+
+def build() -> bool:
+    """compiles oracle/_ref when the reference tree is present; True if the library exists afterwards"""
+    if os.path.isdir(REFERENCE_INCLUDE):
+        subprocess.run(["make", "-C", _HERE, "ref"], check=True, stdout=subprocess.DEVNULL)
+    return os.path.exists(LIB)
+
+
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None and os.path.exists(LIB):
+        lib = C.CDLL(LIB)
+        lib.ref_normalize_theta.restype = C.c_double; lib.ref_normalize_theta.argtypes = [C.c_double]
+        lib.ref_interpolate_angle.restype = C.c_double; lib.ref_interpolate_angle.argtypes = [C.c_double] * 3
+        lib.ref_average_angles.restype = C.c_double; lib.ref_average_angles.argtypes = [C.c_void_p, C.c_int]
+        lib.ref_dynamics.restype = None
+        lib.ref_dynamics.argtypes = [C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.ref_collocation.restype = None
+        lib.ref_collocation.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        _lib = lib
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def normalize_theta(th):
+    lib = load()
+    return np.array([lib.ref_normalize_theta(float(t)) for t in np.atleast_1d(th)])
+
+
+def interpolate_angle(a1, a2, f):
+    lib = load()
+    return np.array([lib.ref_interpolate_angle(float(a), float(b), float(c)) for a, b, c in zip(a1, a2, f)])
+
+
+def average_angles(angles):
+    a = np.ascontiguousarray(angles, float)
+    return load().ref_average_angles(_p(a), a.size)
+
+
+def dynamics(model: int, params, x, u):
+    x = np.ascontiguousarray(x, float); u = np.ascontiguousarray(u, float)
+    f = np.zeros_like(x)
+    p = list(params) + [0.0, 0.0]
+    load().ref_dynamics(model, p[0], p[1], x.shape[0], _p(x), _p(u), _p(f))
+    return f
+
+
+def collocation(method: int, model: int, params, x1, u1, x2, dt):
+    x1 = np.ascontiguousarray(x1, float); u1 = np.ascontiguousarray(u1, float); x2 = np.ascontiguousarray(x2, float)
+    dt = np.ascontiguousarray(np.broadcast_to(np.asarray(dt, float), (x1.shape[0],)))
+    e = np.zeros_like(x1)
+    p = list(params) + [0.0, 0.0]
+    load().ref_collocation(method, model, p[0], p[1], x1.shape[0], _p(x1), _p(u1), _p(x2), _p(dt), _p(e))
+    return e

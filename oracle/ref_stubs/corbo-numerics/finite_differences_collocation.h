@@ -1,0 +1,17 @@
+// ORACLE (test infrastructure only): the INTERFACE of corbo::FiniteDifferencesCollocationInterface as the reference's SE(2) collocation rules
+// override it (include/mpc_local_planner/optimal_control/fd_collocation_se2.h); no corbo code.
+#pragma once
+#include <corbo-systems/system_dynamics_interface.h>
+
+namespace corbo {
+class FiniteDifferencesCollocationInterface {
+ public:
+    using Ptr = std::shared_ptr<FiniteDifferencesCollocationInterface>;
+    using StateVector = Eigen::VectorXd;
+    using InputVector = Eigen::VectorXd;
+    virtual ~FiniteDifferencesCollocationInterface() = default;
+    virtual Ptr getInstance() const = 0;
+    virtual void computeEqualityConstraint(const StateVector& x1, const InputVector& u1, const StateVector& x2, double dt, const SystemDynamicsInterface& system,
+                                           Eigen::Ref<Eigen::VectorXd> error) = 0;
+};
+}  // namespace corbo

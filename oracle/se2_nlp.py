@@ -5,11 +5,16 @@ solver every control cycle, in the REFERENCE's own form (row definitions, signs,
 variable order).  Every function cites the reference file:line it follows
 (paths relative to /root/reference/mpc_local_planner/).
 
-PARITY UNPINNED: the reference ships no tests / golden outputs and its solver
-stack (control_box_rst, Ipopt, MUMPS, teb_local_planner) is not vendored, so
-this restatement cannot be checked against reference outputs in this container.
-It is pinned only against the reference *sources* (formulas) and against
-independent solvers (scipy) on the same NLP.
+PARITY: PINNED to reference code for the angle helpers, the four robot models and
+the three collocation rules (normalize_theta / interpolate_angle, dynamics,
+collocation_defect below): the reference's own headers for these compile here
+against interface stand-ins (oracle/ref_wrap.cpp, oracle/_ref), their outputs are
+recorded in tests/golden/ref_models_collocation.npz and tests/test_reference_pinned.py
+holds this file (and the kernel's core) to them.  UNPINNED for everything else: the
+reference ships no tests / golden outputs and its solver stack (control_box_rst's
+OCP assembly, Ipopt, MUMPS, teb_local_planner's distance functions) is not vendored,
+so cost assembly, inequality rows and solver iterates are pinned only against the
+reference *sources* (formulas) and against independent solvers (scipy) on the same NLP.
 
 Conventions
 -----------

@@ -70,3 +70,30 @@ extern "C" void hostdbg_trig(int n, const double* x, double* s, double* c, doubl
     for (int i = 0; i < n; ++i) { mpc::t_sincos(x[i], &s[i], &c[i]); t[i] = mpc::t_tan(x[i]); }
 }
 extern "C" void hostdbg_log_mantissa(int n, const double* m, double* out) { for (int i = 0; i < n; ++i) out[i] = mpc::log_mantissa(m[i]); }
+
+// the collocation rows as the kernel's core forms them (mpc_core.hpp: model_trig_colloc + colloc_f; mpc_wave.hpp::eval_point does exactly this):
+// c = dt * F(theta_1, u, dt) - (x_2 - x_1), heading difference wrapped.  tests/test_reference_pinned.py compares them with the compiled
+// REFERENCE collocation rules (oracle/_ref) on the heading manifold, where the two formulations coincide.
+template <int MODEL>
+static void colloc_rows(const mpc::Problem<double>& P, int count, const double* x1, const double* u, const double* x2, const double* dt, double* c) {
+    for (int i = 0; i < count; ++i) {
+        double tr[4], tr2[2], f[3];
+        const double th = x1[3 * i + 2], v = u[2 * i], w = u[2 * i + 1], d = dt[i];
+        mpc::model_trig_colloc<double, MODEL>(P, th, v, w, d, tr, tr2);
+        mpc::colloc_f<double, MODEL>(P, tr, tr2, v, w, f);
+        c[3 * i] = d * f[0] - (x2[3 * i] - x1[3 * i]);
+        c[3 * i + 1] = d * f[1] - (x2[3 * i + 1] - x1[3 * i + 1]);
+        c[3 * i + 2] = d * f[2] - mpc::normalize_theta(x2[3 * i + 2] - x1[3 * i + 2]);
+    }
+}
+extern "C" void hostdbg_colloc(const mpc_config* cfg, int count, const double* x1, const double* u, const double* x2, const double* dt, double* c) {
+    mpc::Problem<double> P;
+    mpc::fill_problem(*cfg, P);
+    switch (cfg->model) {
+        case 0: colloc_rows<0>(P, count, x1, u, x2, dt, c); break;
+        case 1: colloc_rows<1>(P, count, x1, u, x2, dt, c); break;
+        case 2: colloc_rows<2>(P, count, x1, u, x2, dt, c); break;
+        default: colloc_rows<3>(P, count, x1, u, x2, dt, c); break;
+    }
+}
+extern "C" double hostdbg_normalize_theta(double th) { return mpc::normalize_theta(th); }
