@@ -138,6 +138,26 @@ def footprint_row(obst: "OracleObst", pose, vertices, radius: float = 0.0):
     return out[0], out[1:4].copy(), out[4], out[5:8].copy()
 
 
+def associate_at(ocfg: OracleConfig, obst: "OracleObst", states, vertices, n_vertices, radius=None, velocity=None):
+    """TEST HOOK (oracle_associate_at): the solver's obstacle association on GIVEN grid states (n, 3) for one instance's obstacles (vertices (O, V, 2),
+    n_vertices (O,)).  Returns (oi (n, max_rows) obstacle indices, -1 = empty; moving obstacles first, then static ones in the reference's order, dropped)."""
+    lib = _load()
+    x = np.ascontiguousarray(states, float)
+    O, V = obst.max_obstacles, obst.max_vertices
+    nv = np.zeros(O, np.int32); vt = np.zeros((O, V, 2)); rd = np.zeros(O); ve = np.zeros((O, 2))
+    k = len(n_vertices)
+    nv[:k] = n_vertices; vt[:k, :np.asarray(vertices).shape[1]] = vertices
+    if radius is not None:
+        rd[:k] = radius
+    if velocity is not None:
+        ve[:k] = velocity
+    oi = np.full((ocfg.n, obst.max_rows), -1, np.int32)
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    lib.oracle_associate_at.restype = C.c_int
+    dropped = lib.oracle_associate_at(C.byref(ocfg), C.byref(obst), p(x), C.c_int(k), p(nv), p(vt), p(rd), p(ve), p(oi))
+    return oi, int(dropped)
+
+
 def solve_batch(ocfg: OracleConfig, x0, xf, u_prev=None, dt_prev=None, init=None, nthreads=0, obstacles=None, obst: "OracleObst" = None, via=None, rows_dropped=None, dual_state=None, dual_mu0=1e-3):
     """rows_dropped: optional int32 array (B,) that receives the number of clearance rows that did not fit into obst.max_rows.
     obstacles = (n_obstacles (B,), n_vertices (B,O), vertices (B,O,V,2)[, radius (B,O)]) together with obst (OracleObst).

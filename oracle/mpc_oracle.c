@@ -1423,6 +1423,23 @@ int oracle_solve_batch_obst(const oracle_config* c, int B, const double* x0, con
     }
     return 0;
 }
+/* TEST HOOK: the association of obst_associate() on GIVEN grid states (x [n][3]) for one instance's obstacles; oi_out [n][max_rows] obstacle indices
+ * (-1 = empty slot; moving obstacles first, then the static ones in the reference's order).  Returns the number of rows that did not fit. */
+int oracle_associate_at(const oracle_config* c, const oracle_obst* ob, const double* x, int n_obst, const int32_t* n_vert, const double* verts, const double* radius,
+                        const double* vel, int32_t* oi_out) {
+    work_t* w = work_new(c);
+    work_obst(w, ob);
+    const int n = c->n, M = obst_M(w);
+    memcpy(w->X, x, sizeof(double) * 3 * n);
+    w->n_obst = n_obst < ob->max_obstacles ? n_obst : ob->max_obstacles;
+    w->n_vert = n_vert; w->verts = verts; w->radius = radius; w->vel = ob->dynamic ? vel : NULL;
+    obst_centroids(w);
+    const int dropped = obst_associate(w);
+    for (int i = 0; i < n * M; ++i) oi_out[i] = w->oi[i];
+    work_free(w);
+    return dropped;
+}
+
 int oracle_solve_batch(const oracle_config* c, int B, const double* x0, const double* xf, const double* u_prev,
                        const double* dt_prev, const double* x_init, const double* u_init, const double* dt_init,
                        double* x_out, double* u_out, double* dt_out, int32_t* status, int32_t* iters, int nthreads) {

@@ -36,6 +36,11 @@ def load():
         lib.ref_dynamics.argtypes = [C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.ref_collocation.restype = None
         lib.ref_collocation.argtypes = [C.c_int, C.c_int, C.c_double, C.c_double, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.ref_associate.restype = C.c_int
+        lib.ref_associate.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_double, C.c_int] + [C.c_void_p] * 6
+        lib.ref_control_deviation_rows.restype = C.c_int
+        lib.ref_control_deviation_rows.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        lib.ref_corbo_inf.restype = C.c_double
         _lib = lib
     return _lib
 
@@ -74,3 +79,30 @@ def collocation(method: int, model: int, params, x1, u1, x2, dt):
     p = list(params) + [0.0, 0.0]
     load().ref_collocation(method, model, p[0], p[1], x1.shape[0], _p(x1), _p(u1), _p(x2), _p(dt), _p(e))
     return e
+
+
+def associate(states, obst_xy, obst_vel=None, dynamic=None, min_dist=0.5, force_incl=0.5, cutoff=2.0, enable_dyn=False, dt=0.1, max_out=64):
+    """StageInequalitySE2::update + the clearance rows at the states, point obstacles and the point footprint (oracle/ref_wrap_rows.cpp).
+    Returns (relevant[k] list of obstacle indices in the reference's order, relevant_dyn[k], rows[k], dyn_rows[k])."""
+    x = np.ascontiguousarray(states, float); n = x.shape[0]
+    xy = np.ascontiguousarray(obst_xy, float).reshape(-1, 2); no = xy.shape[0]
+    vel = np.ascontiguousarray(obst_vel if obst_vel is not None else np.zeros((no, 2)), float)
+    dyn = np.ascontiguousarray(dynamic if dynamic is not None else np.zeros(no), np.int32)
+    ri = np.full((n, max_out), -1, np.int32); rc = np.zeros(n, np.int32); di = np.full((n, max_out), -1, np.int32); dc = np.zeros(n, np.int32)
+    rows = np.zeros((n, max_out)); drows = np.zeros((n, max_out))
+    r = load().ref_associate(n, _p(x), no, _p(xy), _p(vel), _p(dyn), min_dist, force_incl, cutoff, int(enable_dyn), dt, max_out, _p(ri), _p(rc), _p(di), _p(dc), _p(rows), _p(drows))
+    assert r == 0, "more associated obstacles than max_out"
+    return ([ri[k, :rc[k]].tolist() for k in range(n)], [di[k, :dc[k]].tolist() for k in range(n)],
+            [rows[k, :rc[k]].copy() for k in range(n)], [drows[k, :dc[k]].copy() for k in range(n)])
+
+
+def control_deviation_rows(k, u_k, u_prev, dt_prev, du_lb, du_ub):
+    """StageInequalitySE2::computeNonIntegralControlDeviationTerm; bounds at +-corbo_inf() mean none"""
+    a = [np.ascontiguousarray(v, float) for v in (u_k, u_prev, du_lb, du_ub)]
+    out = np.zeros(4)
+    m = load().ref_control_deviation_rows(int(k), _p(a[0]), _p(a[1]), float(dt_prev), _p(a[2]), _p(a[3]), _p(out))
+    return out[:m].copy()
+
+
+def corbo_inf() -> float:
+    return load().ref_corbo_inf()

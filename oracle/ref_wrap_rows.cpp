@@ -1,0 +1,78 @@
+// ORACLE (test infrastructure only): C entry points around the reference's src/optimal_control/stage_inequality_se2.cpp, compiled from where it lies
+// under /root/reference (second translation unit of oracle/_ref/libmpc_ref.so; see oracle/ref_wrap.cpp and the notes in oracle/ref_stubs/).
+// What runs is the reference's own StageInequalitySE2::update (the obstacle association of every grid point, :50-162),
+// computeNonIntegralStateTerm / computeNonIntegralStateDtTerm (clearance rows of static / moving obstacles, :164-189) and
+// computeNonIntegralControlDeviationTerm (control-rate rows, :191-226) -- on POINT obstacles and the POINT footprint, whose distance is unambiguous
+// (teb's other shapes are not available here).
+#include <vector>
+
+#include <mpc_local_planner/optimal_control/full_discretization_grid_base_se2.h>      // the stand-in of oracle/ref_stubs (states + first dt)
+#include <mpc_local_planner/optimal_control/stage_inequality_se2.h>                   // the reference's header
+
+namespace {
+struct Grid : mpc_local_planner::FullDiscretizationGridBaseSE2 {
+    std::vector<Eigen::VectorXd> x;
+    double dt = 0.1;
+    const Eigen::VectorXd& getState(int k) const override { return x[(size_t)k]; }
+    double getFirstDt() const override { return dt; }
+};
+struct Probe : mpc_local_planner::StageInequalitySE2 {       // the association result is a protected member
+    using StageInequalitySE2::_relevant_obstacles;
+    using StageInequalitySE2::_relevant_dyn_obstacles;
+};
+}  // namespace
+
+extern "C" {
+// states [n][3]; obstacles: xy [n_obst][2], vel [n_obst][2], dynamic [n_obst].  Out, per grid point k: indices of the associated static / dynamic
+// obstacles in the reference's order (rel_idx / dyn_idx [n][max_out], counts rel_cnt / dyn_cnt [n]) and the rows evaluated at the states
+// (rows / dyn_rows [n][max_out]).  Returns 0, or -1 if some grid point has more than max_out associated obstacles.
+int ref_associate(int n, const double* states, int n_obst, const double* obst_xy, const double* obst_vel, const int* dynamic, double min_dist, double force_incl,
+                  double cutoff, int enable_dyn, double dt, int max_out, int* rel_idx, int* rel_cnt, int* dyn_idx, int* dyn_cnt, double* rows, double* dyn_rows) {
+    teb_local_planner::ObstContainer obstacles;
+    for (int j = 0; j < n_obst; ++j)
+        obstacles.push_back(std::make_shared<teb_local_planner::PointObstacle>(obst_xy[2 * j], obst_xy[2 * j + 1], obst_vel[2 * j], obst_vel[2 * j + 1], dynamic[j] != 0));
+    Grid grid;
+    grid.dt = dt;
+    for (int k = 0; k < n; ++k) { Eigen::VectorXd s(3); for (int i = 0; i < 3; ++i) s[i] = states[3 * k + i]; grid.x.push_back(s); }
+    Probe row;
+    row.setObstacleVector(obstacles);
+    row.setRobotFootprintModel(std::make_shared<teb_local_planner::PointRobotFootprint>());
+    row.setMinimumDistance(min_dist);
+    row.setObstacleFilterParameters(force_incl, cutoff);
+    row.setEnableDynamicObstacles(enable_dyn != 0);
+    corbo::ReferenceTrajectoryInterface xref, uref;
+    row.update(n, 0.0, xref, uref, nullptr, true, grid.x[0], nullptr, std::vector<double>(), &grid);
+    auto index_of = [&](const teb_local_planner::ObstaclePtr& o) { for (int j = 0; j < n_obst; ++j) if (obstacles[(size_t)j].get() == o.get()) return j; return -1; };
+    int rc = 0;
+    for (int k = 0; k < n; ++k) {
+        const auto& rel = row._relevant_obstacles[(size_t)k];
+        const auto& dyn = row._relevant_dyn_obstacles[(size_t)k];
+        rel_cnt[k] = (int)rel.size(); dyn_cnt[k] = (int)dyn.size();
+        if ((int)rel.size() > max_out || (int)dyn.size() > max_out) { rc = -1; continue; }
+        for (size_t i = 0; i < rel.size(); ++i) rel_idx[k * max_out + (int)i] = index_of(rel[i]);
+        for (size_t i = 0; i < dyn.size(); ++i) dyn_idx[k * max_out + (int)i] = index_of(dyn[i]);
+        if (!rel.empty()) { Eigen::VectorXd c((int)rel.size()); row.computeNonIntegralStateTerm(k, grid.x[(size_t)k], c); for (int i = 0; i < c.size(); ++i) rows[k * max_out + i] = c[i]; }
+        if (!dyn.empty()) { Eigen::VectorXd c((int)dyn.size()); row.computeNonIntegralStateDtTerm(k, grid.x[(size_t)k], dt, c); for (int i = 0; i < c.size(); ++i) dyn_rows[k * max_out + i] = c[i]; }
+    }
+    return rc;
+}
+
+// control-rate rows of grid point k: returns their number (finite lower bounds first, then finite upper bounds, :207-225); bounds beyond +-corbo::CORBO_INF_DBL
+// mean "none"
+int ref_control_deviation_rows(int k, const double* u_k, const double* u_prev, double dt_prev, const double* du_lb, const double* du_ub, double* out) {
+    Probe row;
+    Eigen::VectorXd lb(2), ub(2), u(2), up(2);
+    for (int i = 0; i < 2; ++i) { lb[i] = du_lb[i]; ub[i] = du_ub[i]; u[i] = u_k[i]; up[i] = u_prev[i]; }
+    row.setControlDeviationBounds(lb, ub);
+    Grid grid;
+    { Eigen::VectorXd s(3); grid.x.push_back(s); grid.x.push_back(s); }
+    corbo::ReferenceTrajectoryInterface xref, uref;
+    row.update(2, 0.0, xref, uref, nullptr, true, grid.x[0], nullptr, std::vector<double>(), &grid);      // counts the finite bounds (:150-156)
+    const int m = row.getNonIntegralControlDeviationTermDimension(k);
+    Eigen::VectorXd c(m);
+    row.computeNonIntegralControlDeviationTerm(k, u, up, dt_prev, c);
+    for (int i = 0; i < m; ++i) out[i] = c[i];
+    return m;
+}
+double ref_corbo_inf(void) { return corbo::CORBO_INF_DBL; }
+}  // extern "C"

@@ -5,16 +5,19 @@ solver every control cycle, in the REFERENCE's own form (row definitions, signs,
 variable order).  Every function cites the reference file:line it follows
 (paths relative to /root/reference/mpc_local_planner/).
 
-PARITY: PINNED to reference code for the angle helpers, the four robot models and
+PARITY: PINNED to executed reference code for the angle helpers, the four robot models,
 the three collocation rules (normalize_theta / interpolate_angle, dynamics,
-collocation_defect below): the reference's own headers for these compile here
-against interface stand-ins (oracle/ref_wrap.cpp, oracle/_ref), their outputs are
-recorded in tests/golden/ref_models_collocation.npz and tests/test_reference_pinned.py
-holds this file (and the kernel's core) to them.  UNPINNED for everything else: the
-reference ships no tests / golden outputs and its solver stack (control_box_rst's
-OCP assembly, Ipopt, MUMPS, teb_local_planner's distance functions) is not vendored,
-so cost assembly, inequality rows and solver iterates are pinned only against the
-reference *sources* (formulas) and against independent solvers (scipy) on the same NLP.
+collocation_defect below), the obstacle association (associate_obstacles, uncapped),
+the clearance rows of point obstacles (static and moving) and the control-rate rows:
+the reference's own sources for these compile here against interface stand-ins
+(oracle/ref_wrap.cpp, oracle/ref_wrap_rows.cpp -> oracle/_ref), their outputs are recorded
+in tests/golden/ref_models_collocation.npz / ref_stage_inequality.npz and
+tests/test_reference_pinned.py holds this file, the C oracle and the kernel's core to them.
+UNPINNED for everything else: the reference ships no tests / golden outputs and its
+solver stack (control_box_rst's cost / edge assembly, Ipopt, MUMPS, teb_local_planner's
+distance functions for lines, polygons and turning footprints) is not vendored, so those
+parts are pinned only against the reference *sources* (formulas) and against independent
+solvers (scipy) on the same NLP.
 
 Conventions
 -----------

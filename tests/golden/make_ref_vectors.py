@@ -48,6 +48,39 @@ def main():
             out[f"manifold_collocation_model{mid}_method{method}"] = RL.collocation(method, mid, par, x1, u, x2m, dt)
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_models_collocation.npz"), **out)
     print("written", len(out), "arrays")
+    # ---- the reference's StageInequalitySE2 (src/optimal_control/stage_inequality_se2.cpp): association of every grid point, clearance rows of static and
+    #      moving POINT obstacles for the point footprint, control-rate rows -> tests/golden/ref_stage_inequality.npz
+    rng = np.random.default_rng(20260926)
+    S, NMAX, OMAX, MOUT = 60, 24, 28, 32
+    g = dict(n=np.zeros(S, np.int32), n_obst=np.zeros(S, np.int32), states=np.zeros((S, NMAX, 3)), obst_xy=np.zeros((S, OMAX, 2)), obst_vel=np.zeros((S, OMAX, 2)),
+             dynamic=np.zeros((S, OMAX), np.int32), params=np.zeros((S, 5)), rel=np.full((S, NMAX, MOUT), -1, np.int32), rel_cnt=np.zeros((S, NMAX), np.int32),
+             dyn=np.full((S, NMAX, MOUT), -1, np.int32), dyn_cnt=np.zeros((S, NMAX), np.int32), rows=np.zeros((S, NMAX, MOUT)), dyn_rows=np.zeros((S, NMAX, MOUT)))
+    for s_ in range(S):
+        n = int(rng.integers(5, NMAX + 1)); no = int(rng.integers(1, OMAX + 1))
+        x = np.cumsum(rng.uniform(-0.3, 0.5, (n, 3)), 0); x[:, 2] = rng.uniform(-np.pi, np.pi, n)
+        xy = rng.uniform(-3, 6, (no, 2)); vel = rng.uniform(-0.3, 0.3, (no, 2)); dyn = (rng.uniform(size=no) < 0.25).astype(np.int32); vel[dyn == 0] = 0
+        dmin, fi, co, en, dtk = rng.uniform(0.1, 0.6), rng.uniform(0.2, 1.5), rng.uniform(1.5, 4.0), float(s_ % 2), rng.uniform(0.05, 0.4)
+        rel, reld, rows, drows = RL.associate(x, xy, vel, dyn, dmin, fi, co, bool(en), dt=dtk, max_out=MOUT)
+        g["n"][s_], g["n_obst"][s_] = n, no
+        g["states"][s_, :n] = x; g["obst_xy"][s_, :no] = xy; g["obst_vel"][s_, :no] = vel; g["dynamic"][s_, :no] = dyn; g["params"][s_] = (dmin, fi, co, en, dtk)
+        for k in range(n):
+            g["rel_cnt"][s_, k], g["dyn_cnt"][s_, k] = len(rel[k]), len(reld[k])
+            g["rel"][s_, k, :len(rel[k])] = rel[k]; g["dyn"][s_, k, :len(reld[k])] = reld[k]
+            g["rows"][s_, k, :len(rel[k])] = rows[k]; g["dyn_rows"][s_, k, :len(reld[k])] = drows[k]
+    K = 200
+    inf = RL.corbo_inf()
+    uk, up = rng.uniform(-1, 1, (K, 2)), rng.uniform(-1, 1, (K, 2))
+    dtp = rng.uniform(0.05, 0.5, K); dtp[::9] = 0.0                      # dt_prev == 0: the first cycle (rows of stage 0 are zeroed, :197-201)
+    kk = np.where(dtp == 0.0, 0, rng.integers(0, 10, K)).astype(np.int32)
+    lb = -rng.uniform(0.1, 1.0, (K, 2)); ub = rng.uniform(0.1, 1.0, (K, 2))
+    lb[rng.uniform(size=(K, 2)) < 0.25] = -inf; ub[rng.uniform(size=(K, 2)) < 0.25] = inf
+    cd = np.zeros((K, 4)); cdn = np.zeros(K, np.int32)
+    for i in range(K):
+        r = RL.control_deviation_rows(int(kk[i]), uk[i], up[i], float(dtp[i]), lb[i], ub[i])
+        cdn[i] = r.size; cd[i, :r.size] = r
+    g.update(rate_k=kk, rate_u=uk, rate_u_prev=up, rate_dt_prev=dtp, rate_lb=lb, rate_ub=ub, rate_rows=cd, rate_count=cdn, corbo_inf=np.array(inf))
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_stage_inequality.npz"), **g)
+    print("written stage-inequality vectors:", S, "scenes,", K, "rate-row samples")
 
 
 if __name__ == "__main__":

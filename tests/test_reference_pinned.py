@@ -103,3 +103,78 @@ def test_compiled_reference_code_directly_on_fresh_inputs():
             ref = RL.collocation(method, model, par, x1, u, x2, dt)
             ours = np.stack([R.collocation_defect(method, model, par, x1[i:i + 1], u[i:i + 1], x2[i:i + 1], dt[i])[0] for i in range(100)])
             assert np.abs(ours - ref).max() <= 1e-15 * max(1.0, np.abs(ref).max())
+
+
+# ---- StageInequalitySE2 (src/optimal_control/stage_inequality_se2.cpp, compiled from the reference): association, clearance rows, control-rate rows ---------
+S = np.load(os.path.join(HERE, "golden", "ref_stage_inequality.npz"))
+
+
+def _scene(i):
+    import dataclasses
+    n, no = int(S["n"][i]), int(S["n_obst"][i])
+    dmin, fi, co, en, dtk = S["params"][i]
+    cfg = dataclasses.replace(R.config_unicycle_quadratic(n), min_obstacle_dist=float(dmin), force_inclusion_dist=float(fi), cutoff_dist=float(co), enable_dynamic_obstacles=bool(en))
+    obs = [R.Obstacle(R.OBST_POINT, S["obst_xy"][i, j:j + 1].copy(), 0.0, S["obst_vel"][i, j].copy() if S["dynamic"][i, j] else None) for j in range(no)]
+    return cfg, R.Trajectory(S["states"][i, :n].copy(), np.zeros((n - 1, 2)), float(dtk)), obs, n
+
+
+def test_obstacle_association_reproduces_the_reference():
+    """StageInequalitySE2::update (:50-162) executed on 60 scenes of point obstacles (static and moving): every obstacle closer than force_inclusion_dist, the
+    nearest one on the left and on the right inside cutoff_dist -- `cross2d(orientation, centroid)` with the centroid as an ABSOLUTE vector (:121) --, moving
+    obstacles all kept when enabled; same obstacles in the same order at every grid point"""
+    points = 0
+    for i in range(S["n"].shape[0]):
+        cfg, traj, obs, n = _scene(i)
+        rel, rel_dyn = R.associate_obstacles(cfg, traj, obs, None)
+        for k in range(n):
+            assert rel[k] == S["rel"][i, k, :S["rel_cnt"][i, k]].tolist(), (i, k)
+            assert rel_dyn[k] == S["dyn"][i, k, :S["dyn_cnt"][i, k]].tolist(), (i, k)
+            points += 1
+    assert points > 700 and S["rel_cnt"].max() >= 4 and S["dyn_cnt"].max() >= 2
+
+
+def test_clearance_rows_reproduce_the_reference():
+    """computeNonIntegralStateTerm / computeNonIntegralStateDtTerm (:164-189): min_obstacle_dist - distance, a moving obstacle predicted k * dt ahead"""
+    worst = 0.0
+    for i in range(S["n"].shape[0]):
+        cfg, traj, obs, n = _scene(i)
+        for k in range(1, n):
+            for c, j in enumerate(S["rel"][i, k, :S["rel_cnt"][i, k]]):
+                ours = cfg.min_obstacle_dist - R.footprint_distance(cfg.footprint_kind, cfg.footprint_params, traj.x[k], obs[j])
+                worst = max(worst, abs(ours - S["rows"][i, k, c]))
+            for c, j in enumerate(S["dyn"][i, k, :S["dyn_cnt"][i, k]]):
+                ours = cfg.min_obstacle_dist - R.footprint_distance(cfg.footprint_kind, cfg.footprint_params, traj.x[k], obs[j], k * traj.dt)
+                worst = max(worst, abs(ours - S["dyn_rows"][i, k, c]))
+    assert worst < 1e-14
+
+
+def test_control_rate_rows_reproduce_the_reference():
+    """computeNonIntegralControlDeviationTerm (:191-226): finite lower bounds first, then finite upper bounds; all zero in the first cycle (k = 0, dt_prev = 0)"""
+    import dataclasses
+    inf = float(S["corbo_inf"])
+    for i in range(S["rate_k"].shape[0]):
+        lb = np.where(S["rate_lb"][i] <= -inf, -R.INF, S["rate_lb"][i]); ub = np.where(S["rate_ub"][i] >= inf, R.INF, S["rate_ub"][i])
+        cfg = dataclasses.replace(R.config_unicycle_quadratic(5), du_lb=lb, du_ub=ub)
+        inp = R.CycleInputs(x0=np.zeros(3), xf=np.ones(3), u_prev=S["rate_u_prev"][i], dt_prev=float(S["rate_dt_prev"][i]))
+        nlp = R.ReferenceNlp(cfg, inp)
+        m = int(S["rate_count"][i])
+        assert m == len(nlp.du_lb_finite) + len(nlp.du_ub_finite)
+        if S["rate_dt_prev"][i] == 0.0:
+            assert (S["rate_rows"][i, :m] == 0).all()            # ReferenceNlp.inequalities writes zeros there as well (se2_nlp.py, k == 0 branch)
+            continue
+        ours = np.array(nlp._rate_rows(S["rate_u"][i], S["rate_u_prev"][i], float(S["rate_dt_prev"][i])))
+        assert np.abs(ours - S["rate_rows"][i, :m]).max(initial=0.0) < 1e-15
+
+
+def test_c_oracle_association_reproduces_the_reference(c_oracle):
+    """the C oracle's obst_associate (the code the device mirrors line by line), with room for every row: moving obstacles first, then exactly the
+    reference's static list in the reference's order"""
+    for i in range(S["n"].shape[0]):
+        cfg, traj, obs, n = _scene(i)
+        no = len(obs)
+        ob = c_oracle.obst_from_nlp_config(cfg, max_obstacles=max(no, 1), max_vertices=1, max_rows=32)
+        oi, dropped = c_oracle.associate_at(c_oracle.from_nlp_config(cfg), ob, traj.x, S["obst_xy"][i, :no, None, :], np.ones(no, np.int32), velocity=S["obst_vel"][i, :no])
+        assert dropped == 0
+        for k in range(1, n):
+            want = S["dyn"][i, k, :S["dyn_cnt"][i, k]].tolist() + S["rel"][i, k, :S["rel_cnt"][i, k]].tolist()
+            assert [j for j in oi[k] if j >= 0] == want, (i, k)
