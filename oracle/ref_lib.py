@@ -41,6 +41,8 @@ def load():
         lib.ref_control_deviation_rows.restype = C.c_int
         lib.ref_control_deviation_rows.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         lib.ref_corbo_inf.restype = C.c_double
+        lib.ref_via_points.restype = None
+        lib.ref_via_points.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
         _lib = lib
     return _lib
 
@@ -106,3 +108,11 @@ def control_deviation_rows(k, u_k, u_prev, dt_prev, du_lb, du_ub):
 
 def corbo_inf() -> float:
     return load().ref_corbo_inf()
+
+
+def via_points(states, via, w_pos, w_orient, ordered, dt):
+    """MinTimeViaPointsCost::update + the cost terms (oracle/ref_wrap_rows.cpp::ref_via_points).  Returns (attached[n_via] grid index or -1, terms[n_via], dt term)."""
+    x = np.ascontiguousarray(states, float); v = np.ascontiguousarray(via, float).reshape(-1, 3)
+    att = np.zeros(v.shape[0], np.int32); terms = np.zeros(v.shape[0]); dtt = np.zeros(1)
+    load().ref_via_points(x.shape[0], _p(x), v.shape[0], _p(v), float(w_pos), float(w_orient), int(ordered), float(dt), _p(att), _p(terms), _p(dtt))
+    return att, terms, float(dtt[0])

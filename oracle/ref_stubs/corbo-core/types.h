@@ -8,6 +8,10 @@
 namespace corbo {
 constexpr const double CORBO_INF_DBL = 2e30;      // control_box_rst: corbo-core/types.h ("representation for infinity"); only ever compared against
 }
+// corbo-core/console.h: console messages
 #ifndef PRINT_WARNING_COND_ONCE
-#define PRINT_WARNING_COND_ONCE(cond, msg) do { } while (0)      // corbo-core/console.h: a console message
+#define PRINT_WARNING_COND_ONCE(cond, msg) do { } while (0)
+#define PRINT_WARNING(msg) do { } while (0)
+#define PRINT_DEBUG(msg) do { } while (0)
+#define PRINT_DEBUG_NAMED(msg) do { } while (0)
 #endif

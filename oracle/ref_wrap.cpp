@@ -5,6 +5,7 @@
 //   include/mpc_local_planner/systems/{unicycle_robot,simple_car,kinematic_bicycle_model}.h      the four robot models' dynamics()
 //   include/mpc_local_planner/optimal_control/fd_collocation_se2.h        forward / midpoint / Crank-Nicolson collocation rows on SE(2)
 //   src/optimal_control/stage_inequality_se2.cpp (+ its header)           obstacle association, clearance rows, control-rate rows: oracle/ref_wrap_rows.cpp
+//   src/optimal_control/min_time_via_points_cost.cpp (+ its header)       via-point association and cost terms, time term: oracle/ref_wrap_rows.cpp
 //
 // The model and collocation headers are written against Eigen and control_box_rst (corbo), neither of which is in this image; oracle/ref_stubs/
 // provides the INTERFACES they derive from and the few element-wise vector operations they use (see the notes there).  The arithmetic that

@@ -8,6 +8,7 @@
 
 #include <mpc_local_planner/optimal_control/full_discretization_grid_base_se2.h>      // the stand-in of oracle/ref_stubs (states + first dt)
 #include <mpc_local_planner/optimal_control/stage_inequality_se2.h>                   // the reference's header
+#include <mpc_local_planner/optimal_control/min_time_via_points_cost.h>               // the reference's header
 
 namespace {
 struct Grid : mpc_local_planner::FullDiscretizationGridBaseSE2 {
@@ -15,6 +16,7 @@ struct Grid : mpc_local_planner::FullDiscretizationGridBaseSE2 {
     double dt = 0.1;
     const Eigen::VectorXd& getState(int k) const override { return x[(size_t)k]; }
     double getFirstDt() const override { return dt; }
+    int getN() const override { return (int)x.size(); }
 };
 struct Probe : mpc_local_planner::StageInequalitySE2 {       // the association result is a protected member
     using StageInequalitySE2::_relevant_obstacles;
@@ -75,4 +77,38 @@ int ref_control_deviation_rows(int k, const double* u_k, const double* u_prev, d
     return m;
 }
 double ref_corbo_inf(void) { return corbo::CORBO_INF_DBL; }
+
+// MinTimeViaPointsCost (src/optimal_control/min_time_via_points_cost.cpp, compiled from the reference): update() attaches every via-point
+// (via [n_via][3]) to a grid point of the states [n][3]; out: attached[n_via] = grid index or -1 (skipped), terms[n_via] = the cost term of that via-point
+// evaluated at its grid point's state (computeNonIntegralStateTerm), *dt_term = computeNonIntegralDtTerm(0, dt)
+namespace {
+struct ViaProbe : mpc_local_planner::MinTimeViaPointsCost { using MinTimeViaPointsCost::_vp_association; };
+}
+void ref_via_points(int n, const double* states, int n_via, const double* via, double w_pos, double w_orient, int ordered, double dt, int* attached, double* terms, double* dt_term) {
+    mpc_local_planner::MinTimeViaPointsCost::ViaPointContainer vps;
+    for (int v = 0; v < n_via; ++v) vps.emplace_back(via[3 * v], via[3 * v + 1], via[3 * v + 2]);
+    Grid grid;
+    grid.dt = dt;
+    for (int k = 0; k < n; ++k) { Eigen::VectorXd s(3); for (int i = 0; i < 3; ++i) s[i] = states[3 * k + i]; grid.x.push_back(s); }
+    ViaProbe cost;
+    cost.setViaPointContainer(vps);
+    cost.setViaPointWeights(w_pos, w_orient);
+    cost.setViaPointOrderedMode(ordered != 0);
+    corbo::ReferenceTrajectoryInterface xref, uref;
+    cost.update(n, 0.0, xref, uref, nullptr, true, grid.x[0], nullptr, std::vector<double>(), &grid);
+    for (int v = 0; v < n_via; ++v) { attached[v] = -1; terms[v] = 0.0; }
+    for (int k = 0; k < n; ++k) {
+        const auto& item = cost._vp_association[(size_t)k];
+        if (item.first.empty()) continue;
+        Eigen::VectorXd c((int)item.first.size());
+        cost.computeNonIntegralStateTerm(k, grid.x[(size_t)k], c);
+        for (size_t i = 0; i < item.first.size(); ++i) {
+            const int v = (int)(item.first[i] - vps.data());
+            attached[v] = k; terms[v] = c[(int)i];
+        }
+    }
+    Eigen::VectorXd d(1);
+    cost.computeNonIntegralDtTerm(0, dt, d);
+    *dt_term = d[0];
+}
 }  // extern "C"

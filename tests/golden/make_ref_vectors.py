@@ -81,6 +81,24 @@ def main():
     g.update(rate_k=kk, rate_u=uk, rate_u_prev=up, rate_dt_prev=dtp, rate_lb=lb, rate_ub=ub, rate_rows=cd, rate_count=cdn, corbo_inf=np.array(inf))
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_stage_inequality.npz"), **g)
     print("written stage-inequality vectors:", S, "scenes,", K, "rate-row samples")
+    # ---- the reference's MinTimeViaPointsCost (src/optimal_control/min_time_via_points_cost.cpp): association of the via-points, their cost terms, the time term
+    rng = np.random.default_rng(20260927)
+    S2, NMAX2, VMAX = 120, 30, 8
+    v = dict(n=np.zeros(S2, np.int32), n_via=np.zeros(S2, np.int32), states=np.zeros((S2, NMAX2, 3)), via=np.zeros((S2, VMAX, 3)), params=np.zeros((S2, 4)),
+             attached=np.full((S2, VMAX), -2, np.int32), terms=np.zeros((S2, VMAX)), dt_term=np.zeros(S2))
+    for s_ in range(S2):
+        n = int(rng.integers(4, NMAX2 + 1)); nv = int(rng.integers(1, VMAX + 1))
+        x = np.cumsum(rng.uniform(-0.2, 0.5, (n, 3)), 0); x[:, 2] = rng.uniform(-np.pi, np.pi, n)
+        via = np.concatenate([x[rng.integers(0, n, nv), :2] + rng.uniform(-0.6, 0.6, (nv, 2)), rng.uniform(-np.pi, np.pi, (nv, 1))], 1)
+        if s_ % 5 == 0: via[0, :2] = x[0, :2] - 0.5           # behind the start: skipped, or attached to state 1 in the ordered mode
+        if s_ % 7 == 0: via[-1, :2] = x[-1, :2] + 0.3         # beyond the goal: attached to the state in front of it
+        ordered, wp, wo, dtk = float(s_ % 2), rng.uniform(0.1, 20), (0.0 if s_ % 3 else rng.uniform(0.1, 2)), rng.uniform(0.05, 0.4)
+        att, terms, dtt = RL.via_points(x, via, wp, wo, bool(ordered), dtk)
+        v["n"][s_], v["n_via"][s_] = n, nv
+        v["states"][s_, :n] = x; v["via"][s_, :nv] = via; v["params"][s_] = (wp, wo, ordered, dtk)
+        v["attached"][s_, :nv] = att; v["terms"][s_, :nv] = terms; v["dt_term"][s_] = dtt
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_via_points.npz"), **v)
+    print("written via-point vectors:", S2, "scenes")
 
 
 if __name__ == "__main__":

@@ -178,3 +178,37 @@ def test_c_oracle_association_reproduces_the_reference(c_oracle):
         for k in range(1, n):
             want = S["dyn"][i, k, :S["dyn_cnt"][i, k]].tolist() + S["rel"][i, k, :S["rel_cnt"][i, k]].tolist()
             assert [j for j in oi[k] if j >= 0] == want, (i, k)
+
+
+# ---- MinTimeViaPointsCost (src/optimal_control/min_time_via_points_cost.cpp, compiled from the reference) ---------------------------------------------------
+V = np.load(os.path.join(HERE, "golden", "ref_via_points.npz"))
+
+
+def test_via_point_association_and_terms_reproduce_the_reference():
+    """update() (:39-117): the closest grid state (first minimum; the final state only if strictly closer -- that part is findClosestPose, restated in the
+    stand-in grid), ordered mode restarting two states behind the previous match, a via-point at / beyond the goal moved to the state in front of it, one at /
+    behind the start skipped (ordered: attached to state 1).  computeNonIntegralStateTerm (:130-145): position weight x squared distance plus -- as coded --
+    the orientation weight times the wrapped heading difference, NOT squared.  computeNonIntegralDtTerm (:119-128): (n - 1) dt on the single-dt grid."""
+    import dataclasses
+    n_att = 0
+    for i in range(V["n"].shape[0]):
+        n, nv = int(V["n"][i]), int(V["n_via"][i])
+        wp, wo, ordered, dtk = V["params"][i]
+        x, via = V["states"][i, :n], V["via"][i, :nv]
+        cfg = dataclasses.replace(R.config_carlike_min_time(n), objective=R.OBJ_MIN_TIME_VIA_POINTS, via_points_ordered=bool(ordered), vp_position_weight=float(wp), vp_orientation_weight=float(wo))
+        ours = R.associate_via_points(cfg, x, via)
+        assert ours == V["attached"][i, :nv].tolist(), i
+        for v in range(nv):
+            k = ours[v]
+            if k < 0:
+                continue
+            n_att += 1
+            term = wp * ((via[v, 0] - x[k, 0]) ** 2 + (via[v, 1] - x[k, 1]) ** 2) + (wo * R.normalize_theta(via[v, 2] - x[k, 2]) if wo > 0 else 0.0)
+            assert abs(term - V["terms"][i, v]) < 1e-14
+        assert abs(V["dt_term"][i] - (n - 1) * dtk) < 1e-15
+        # the reference-form objective = time term + the attached via-points' terms
+        inp = R.CycleInputs(x0=x[0], xf=x[-1], u_prev=np.zeros(2), dt_prev=0.0, via_points=via)
+        nlp = R.ReferenceNlp(cfg, inp, via_idx=ours)
+        J = nlp.objective(nlp.pack(R.Trajectory(x.copy(), np.zeros((n - 1, 2)), float(dtk))))
+        assert abs(J - (V["dt_term"][i] + sum(V["terms"][i, v] for v in range(nv) if ours[v] >= 0))) < 1e-12
+    assert n_att > 300 and (V["attached"] == -1).sum() > 5
