@@ -300,9 +300,10 @@ class Controller {
         _last_iterations = iters;
         _ocp_successful = status == MPC_CONVERGED;
         x_seq.clear(); u_seq.clear();
-        for (int k = 0; k < _n_cur; ++k) {       // getStateAndControlTimeSeries, …grid_base_se2.cpp:579-615
-            x_seq.add(k * _dt_sol, &_x[(size_t)3 * k], 3);
-            u_seq.add(k * _dt_sol, &_u[(size_t)2 * k], 2);
+        double t_k = 0.0;                        // getStateAndControlTimeSeries, …grid_base_se2.cpp:579-615: the stamps are ACCUMULATED (t += dt), not k dt
+        for (int k = 0; k < _n_cur; ++k, t_k += _dt_sol) {
+            x_seq.add(t_k, &_x[(size_t)3 * k], 3);
+            u_seq.add(t_k, &_u[(size_t)2 * k], 2);
         }
         _grid_empty = false;
         ++_ocp_seq;

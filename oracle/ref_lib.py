@@ -43,6 +43,15 @@ def load():
         lib.ref_corbo_inf.restype = C.c_double
         lib.ref_via_points.restype = None
         lib.ref_via_points.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_double, C.c_double, C.c_int, C.c_double, C.c_void_p, C.c_void_p, C.c_void_p]
+        V = C.c_void_p; D = C.c_double; I = C.c_int
+        lib.ref_grid_cold_start.restype = None; lib.ref_grid_cold_start.argtypes = [I, D, V, V, V, V, V]
+        lib.ref_grid_find_nearest_state.restype = I; lib.ref_grid_find_nearest_state.argtypes = [I, V, V, D, V]
+        lib.ref_grid_warm_start_cycle.restype = None; lib.ref_grid_warm_start_cycle.argtypes = [I, V, V, D, V, V, V, V, V]
+        lib.ref_grid_resample.restype = I; lib.ref_grid_resample.argtypes = [I, V, V, D, I, V, V, V]
+        lib.ref_grid_adapt.restype = I; lib.ref_grid_adapt.argtypes = [I, V, V, D, D, I, I, D, V, V, V]
+        lib.ref_grid_find_closest_pose.restype = I; lib.ref_grid_find_closest_pose.argtypes = [I, V, V, D, D, D, I]
+        lib.ref_grid_time_series.restype = I; lib.ref_grid_time_series.argtypes = [I, V, V, D, V, V, V]
+        lib.ref_time_series_se2_interpolate.restype = None; lib.ref_time_series_se2_interpolate.argtypes = [I, V, V, I, I, I, V, V, V]
         _lib = lib
     return _lib
 
@@ -116,3 +125,67 @@ def via_points(states, via, w_pos, w_orient, ordered, dt):
     att = np.zeros(v.shape[0], np.int32); terms = np.zeros(v.shape[0]); dtt = np.zeros(1)
     load().ref_via_points(x.shape[0], _p(x), v.shape[0], _p(v), float(w_pos), float(w_orient), int(ordered), float(dt), _p(att), _p(terms), _p(dtt))
     return att, terms, float(dtt[0])
+
+
+# ---- the grid classes (oracle/ref_wrap_grid.cpp): x (n,3) states incl. the final one, u (n-1,2) controls, dt
+def _xu(x, u):
+    x = np.ascontiguousarray(x, float); u = np.ascontiguousarray(u, float)
+    assert x.ndim == 2 and x.shape[1] == 3 and u.shape == (x.shape[0] - 1, 2)
+    return x, u
+
+
+def grid_cold_start(n, dt_ref, x0, xf, xinit=None):
+    """update() of an EMPTY grid.  xinit None: the reference's own straight-line guess; else (n,3) samples of the initial state trajectory"""
+    x0 = np.ascontiguousarray(x0, float); xf = np.ascontiguousarray(xf, float)
+    xi = None if xinit is None else np.ascontiguousarray(xinit, float)
+    xo = np.zeros((n, 3)); uo = np.zeros((n - 1, 2))
+    load().ref_grid_cold_start(n, float(dt_ref), _p(x0), _p(xf), None if xi is None else _p(xi), _p(xo), _p(uo))
+    return xo, uo
+
+
+def grid_find_nearest_state(x, u, dt, x0_new):
+    x, u = _xu(x, u); q = np.ascontiguousarray(x0_new, float)
+    return load().ref_grid_find_nearest_state(x.shape[0], _p(x), _p(u), float(dt), _p(q))
+
+
+def grid_warm_start_cycle(x, u, dt, x0_new, xf_new, xf_fixed=(1, 1, 1)):
+    """the next cycle of a fixed grid with grid/warm_start: warmStartShifting, then x_0 := x0_new and the fixed goal components := xf_new"""
+    x, u = _xu(x, u); a = np.ascontiguousarray(x0_new, float); b = np.ascontiguousarray(xf_new, float); fx = np.ascontiguousarray(xf_fixed, np.int32)
+    xo = np.zeros_like(x); uo = np.zeros_like(u)
+    load().ref_grid_warm_start_cycle(x.shape[0], _p(x), _p(u), float(dt), _p(a), _p(b), _p(fx), _p(xo), _p(uo))
+    return xo, uo
+
+
+def grid_resample(x, u, dt, n_new):
+    x, u = _xu(x, u); cap = max(x.shape[0], n_new)
+    xo = np.zeros((cap, 3)); uo = np.zeros((cap, 2)); dto = np.zeros(1)
+    m = load().ref_grid_resample(x.shape[0], _p(x), _p(u), float(dt), int(n_new), _p(xo), _p(uo), _p(dto))
+    return xo[:m].copy(), uo[:m - 1].copy(), float(dto[0])
+
+
+def grid_adapt(x, u, dt, dt_ref, n_max, n_min, hyst):
+    x, u = _xu(x, u); cap = x.shape[0] + 1
+    xo = np.zeros((cap, 3)); uo = np.zeros((cap, 2)); dto = np.zeros(1)
+    m = load().ref_grid_adapt(x.shape[0], _p(x), _p(u), float(dt), float(dt_ref), int(n_max), int(n_min), float(hyst), _p(xo), _p(uo), _p(dto))
+    return xo[:m].copy(), uo[:m - 1].copy(), float(dto[0])
+
+
+def grid_find_closest_pose(x, x_ref, y_ref, start_idx=0):
+    x = np.ascontiguousarray(x, float); u = np.zeros((x.shape[0] - 1, 2))
+    return load().ref_grid_find_closest_pose(x.shape[0], _p(x), _p(u), 0.1, float(x_ref), float(y_ref), int(start_idx))
+
+
+def grid_time_series(x, u, dt):
+    x, u = _xu(x, u); n = x.shape[0]
+    t = np.zeros(n); xs = np.zeros((n, 3)); us = np.zeros((n, 2))
+    m = load().ref_grid_time_series(n, _p(x), _p(u), float(dt), _p(t), _p(xs), _p(us))
+    assert m == n
+    return t, xs, us
+
+
+def time_series_se2_interpolate(times, values, t, linear=True, hold=True):
+    """TimeSeriesSE2::getValuesInterpolate at every t; returns (values (len(t),3) with NaN where the call returned false, ok flags)"""
+    tm = np.ascontiguousarray(times, float); v = np.ascontiguousarray(values, float).reshape(-1, 3); t = np.ascontiguousarray(np.atleast_1d(t), float)
+    out = np.full((t.size, 3), np.nan); ok = np.zeros(t.size, np.int32)
+    load().ref_time_series_se2_interpolate(tm.size, _p(tm), _p(v), int(linear), int(hold), t.size, _p(t), _p(out), _p(ok))
+    return out, ok.astype(bool)

@@ -14,4 +14,10 @@ class FiniteDifferencesCollocationInterface {
     virtual void computeEqualityConstraint(const StateVector& x1, const InputVector& u1, const StateVector& x2, double dt, const SystemDynamicsInterface& system,
                                            Eigen::Ref<Eigen::VectorXd> error) = 0;
 };
+// named by the reference's grid header as the default rule (full_discretization_grid_base_se2.h:199); never evaluated here
+class CrankNicolsonDiffCollocation : public FiniteDifferencesCollocationInterface {
+ public:
+    Ptr getInstance() const override { return std::make_shared<CrankNicolsonDiffCollocation>(); }
+    void computeEqualityConstraint(const StateVector&, const InputVector&, const StateVector&, double, const SystemDynamicsInterface&, Eigen::Ref<Eigen::VectorXd>) override {}
+};
 }  // namespace corbo

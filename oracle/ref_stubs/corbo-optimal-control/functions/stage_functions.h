@@ -2,14 +2,9 @@
 // overrides it, and the two types that only appear in the signature of update(); no corbo code.
 #pragma once
 #include <corbo-core/reference_trajectory.h>
+#include <corbo-optimal-control/structured_ocp/discretization_grids/discretization_grid_interface.h>
 
 namespace corbo {
-class StagePreprocessor { public: using Ptr = std::shared_ptr<StagePreprocessor>; };
-class DiscretizationGridInterface {
- public:
-    virtual ~DiscretizationGridInterface() = default;
-    virtual double getFirstDt() const = 0;
-};
 class StageInequalityConstraint {
  public:
     using Ptr = std::shared_ptr<StageInequalityConstraint>;

@@ -6,19 +6,24 @@
 // (teb's other shapes are not available here).
 #include <vector>
 
-#include <mpc_local_planner/optimal_control/full_discretization_grid_base_se2.h>      // the stand-in of oracle/ref_stubs (states + first dt)
+#include "ref_wrap_common.hpp"                                                        // a reference grid object holding given states
 #include <mpc_local_planner/optimal_control/stage_inequality_se2.h>                   // the reference's header
 #include <mpc_local_planner/optimal_control/min_time_via_points_cost.h>               // the reference's header
 
 namespace {
-struct Grid : mpc_local_planner::FullDiscretizationGridBaseSE2 {
+// states only: controls zero, dt as given
+struct StateGrid {
+    Probe<mpc_local_planner::FiniteDifferencesGridSE2> g;
+    corbo::NlpFunctions nlp;
     std::vector<Eigen::VectorXd> x;
-    double dt = 0.1;
-    const Eigen::VectorXd& getState(int k) const override { return x[(size_t)k]; }
-    double getFirstDt() const override { return dt; }
-    int getN() const override { return (int)x.size(); }
+    StateGrid(int n, const double* states, double dt) {
+        std::vector<double> u((size_t)2 * (n > 1 ? n - 1 : 1), 0.0);
+        const bool fx[3] = {true, true, true};
+        fill(g, nlp, n, states, u.data(), dt, fx);
+        for (int k = 0; k < n; ++k) x.push_back(g.getState(k));
+    }
 };
-struct Probe : mpc_local_planner::StageInequalitySE2 {       // the association result is a protected member
+struct RowProbe : mpc_local_planner::StageInequalitySE2 {       // the association result is a protected member
     using StageInequalitySE2::_relevant_obstacles;
     using StageInequalitySE2::_relevant_dyn_obstacles;
 };
@@ -33,17 +38,15 @@ int ref_associate(int n, const double* states, int n_obst, const double* obst_xy
     teb_local_planner::ObstContainer obstacles;
     for (int j = 0; j < n_obst; ++j)
         obstacles.push_back(std::make_shared<teb_local_planner::PointObstacle>(obst_xy[2 * j], obst_xy[2 * j + 1], obst_vel[2 * j], obst_vel[2 * j + 1], dynamic[j] != 0));
-    Grid grid;
-    grid.dt = dt;
-    for (int k = 0; k < n; ++k) { Eigen::VectorXd s(3); for (int i = 0; i < 3; ++i) s[i] = states[3 * k + i]; grid.x.push_back(s); }
-    Probe row;
+    StateGrid grid(n, states, dt);
+    RowProbe row;
     row.setObstacleVector(obstacles);
     row.setRobotFootprintModel(std::make_shared<teb_local_planner::PointRobotFootprint>());
     row.setMinimumDistance(min_dist);
     row.setObstacleFilterParameters(force_incl, cutoff);
     row.setEnableDynamicObstacles(enable_dyn != 0);
     corbo::ReferenceTrajectoryInterface xref, uref;
-    row.update(n, 0.0, xref, uref, nullptr, true, grid.x[0], nullptr, std::vector<double>(), &grid);
+    row.update(n, 0.0, xref, uref, nullptr, true, grid.x[0], nullptr, std::vector<double>(), &grid.g);
     auto index_of = [&](const teb_local_planner::ObstaclePtr& o) { for (int j = 0; j < n_obst; ++j) if (obstacles[(size_t)j].get() == o.get()) return j; return -1; };
     int rc = 0;
     for (int k = 0; k < n; ++k) {
@@ -62,14 +65,14 @@ int ref_associate(int n, const double* states, int n_obst, const double* obst_xy
 // control-rate rows of grid point k: returns their number (finite lower bounds first, then finite upper bounds, :207-225); bounds beyond +-corbo::CORBO_INF_DBL
 // mean "none"
 int ref_control_deviation_rows(int k, const double* u_k, const double* u_prev, double dt_prev, const double* du_lb, const double* du_ub, double* out) {
-    Probe row;
+    RowProbe row;
     Eigen::VectorXd lb(2), ub(2), u(2), up(2);
     for (int i = 0; i < 2; ++i) { lb[i] = du_lb[i]; ub[i] = du_ub[i]; u[i] = u_k[i]; up[i] = u_prev[i]; }
     row.setControlDeviationBounds(lb, ub);
-    Grid grid;
-    { Eigen::VectorXd s(3); grid.x.push_back(s); grid.x.push_back(s); }
+    const double three_states[9] = {0, 0, 0, 1, 0, 0, 2, 0, 0};
+    StateGrid grid(3, three_states, 0.1);
     corbo::ReferenceTrajectoryInterface xref, uref;
-    row.update(2, 0.0, xref, uref, nullptr, true, grid.x[0], nullptr, std::vector<double>(), &grid);      // counts the finite bounds (:150-156)
+    row.update(3, 0.0, xref, uref, nullptr, true, grid.x[0], nullptr, std::vector<double>(), &grid.g);      // counts the finite bounds (:150-156)
     const int m = row.getNonIntegralControlDeviationTermDimension(k);
     Eigen::VectorXd c(m);
     row.computeNonIntegralControlDeviationTerm(k, u, up, dt_prev, c);
@@ -87,15 +90,13 @@ struct ViaProbe : mpc_local_planner::MinTimeViaPointsCost { using MinTimeViaPoin
 void ref_via_points(int n, const double* states, int n_via, const double* via, double w_pos, double w_orient, int ordered, double dt, int* attached, double* terms, double* dt_term) {
     mpc_local_planner::MinTimeViaPointsCost::ViaPointContainer vps;
     for (int v = 0; v < n_via; ++v) vps.emplace_back(via[3 * v], via[3 * v + 1], via[3 * v + 2]);
-    Grid grid;
-    grid.dt = dt;
-    for (int k = 0; k < n; ++k) { Eigen::VectorXd s(3); for (int i = 0; i < 3; ++i) s[i] = states[3 * k + i]; grid.x.push_back(s); }
+    StateGrid grid(n, states, dt);
     ViaProbe cost;
     cost.setViaPointContainer(vps);
     cost.setViaPointWeights(w_pos, w_orient);
     cost.setViaPointOrderedMode(ordered != 0);
     corbo::ReferenceTrajectoryInterface xref, uref;
-    cost.update(n, 0.0, xref, uref, nullptr, true, grid.x[0], nullptr, std::vector<double>(), &grid);
+    cost.update(n, 0.0, xref, uref, nullptr, true, grid.x[0], nullptr, std::vector<double>(), &grid.g);
     for (int v = 0; v < n_via; ++v) { attached[v] = -1; terms[v] = 0.0; }
     for (int k = 0; k < n; ++k) {
         const auto& item = cost._vp_association[(size_t)k];

@@ -8,10 +8,13 @@ variable order).  Every function cites the reference file:line it follows
 PARITY: PINNED to executed reference code for the angle helpers, the four robot models,
 the three collocation rules (normalize_theta / interpolate_angle, dynamics,
 collocation_defect below), the obstacle association (associate_obstacles, uncapped),
-the clearance rows of point obstacles (static and moving) and the control-rate rows:
+the clearance rows of point obstacles (static and moving), the control-rate rows, the
+via-point association and terms, and the grid handling (cold start, nearest state, warm-start
+shifting, resampling, single-step adaptation, closest pose, time series, TimeSeriesSE2
+interpolation -- bit for bit):
 the reference's own sources for these compile here against interface stand-ins
-(oracle/ref_wrap.cpp, oracle/ref_wrap_rows.cpp -> oracle/_ref), their outputs are recorded
-in tests/golden/ref_models_collocation.npz / ref_stage_inequality.npz and
+(oracle/ref_wrap.cpp, ref_wrap_rows.cpp, ref_wrap_grid.cpp -> oracle/_ref), their outputs are recorded
+in tests/golden/ref_models_collocation.npz / ref_stage_inequality.npz / ref_via_points.npz / ref_grid.npz and
 tests/test_reference_pinned.py holds this file, the C oracle and the kernel's core to them.
 UNPINNED for everything else: the reference ships no tests / golden outputs and its
 solver stack (control_box_rst's cost / edge assembly, Ipopt, MUMPS, teb_local_planner's
@@ -462,8 +465,8 @@ def initialize_sequences_straight_line(cfg: OcpConfig, x0, xf) -> Trajectory:
     n = cfg.n
     x0 = np.asarray(x0, float)
     xf = np.asarray(xf, float)
-    d = xf - x0
-    dist = float(np.linalg.norm(d))
+    d = xf - x0                      # all three components: the heading difference counts into `dist` (:157-158)
+    dist = math.sqrt(d[0] * d[0] + d[1] * d[1] + d[2] * d[2])
     if dist != 0:
         d = d / dist
     step = dist / (n - 1)
@@ -575,11 +578,20 @@ def adapt_grid_single_step(cfg: OcpConfig, traj: Trajectory, n_min=2, n_max=50, 
     return traj.copy()
 
 
+def time_stamps(n: int, dt: float) -> np.ndarray:
+    """the stamps of getStateAndControlTimeSeries (...grid_base_se2.cpp:592-599): t = 0; t += dt per sample -- the running sum, which differs from k*dt in the
+    last bits"""
+    t = np.zeros(n)
+    for k in range(1, n):
+        t[k] = t[k - 1] + dt
+    return t
+
+
 def time_series_output(traj: Trajectory):
     """getStateAndControlTimeSeries, ...grid_base_se2.cpp:579-615:
-    times k*dt, states x_0..x_{n-2},xf, controls u_0..u_{n-2} + duplicate of the last."""
+    accumulated time stamps (t += dt), states x_0..x_{n-2},xf, controls u_0..u_{n-2} + duplicate of the last."""
     n = traj.x.shape[0]
-    t = np.arange(n) * traj.dt
+    t = time_stamps(n, traj.dt)
     return t, traj.x.copy(), np.vstack([traj.u, traj.u[-1:]])
 
 
@@ -883,9 +895,9 @@ class ReferenceNlp:
 def optimal_control_result(x, u, dt, found: bool, cpu_time: float, seq: int):
     """mpc_local_planner_msgs/OptimalControlResult (msg/OptimalControlResult.msg:1-12) as Controller::publishOptimalControlResult fills it
     (src/controller.cpp:197-221) from getStateAndControlTimeSeries (...grid_base_se2.cpp:579-615): x (n,3) states, u (n,2) controls with the
-    duplicated last row; times k*dt; "Column Major" = corbo::TimeSeries' dim x N value matrix stored column-major = sample after sample."""
+    duplicated last row; accumulated time stamps; "Column Major" = corbo::TimeSeries' dim x N value matrix stored column-major = sample after sample."""
     x = np.asarray(x, float); u = np.asarray(u, float)
     n = x.shape[0]
-    t = np.arange(n) * float(dt)
+    t = time_stamps(n, float(dt))
     return {"seq": int(seq), "dim_states": 3, "dim_controls": 2, "time_states": t.copy(), "states": x.reshape(-1).copy(),
             "time_controls": t.copy(), "controls": u.reshape(-1).copy(), "optimal_solution_found": bool(found), "cpu_time": float(cpu_time)}

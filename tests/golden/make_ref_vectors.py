@@ -100,6 +100,87 @@ def main():
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_via_points.npz"), **v)
     print("written via-point vectors:", S2, "scenes")
 
+    # ---- the reference's grid classes (src/optimal_control/full_discretization_grid_base_se2.cpp, finite_differences_variable_grid_se2.cpp) and its
+    # TimeSeriesSE2 (src/utils/time_series_se2.cpp), oracle/ref_wrap_grid.cpp: cold start, nearest state, warm-start shifting, resampling, grid adaptation,
+    # closest pose, the time series handed back
+    rng = np.random.default_rng(20260928)
+    S3, NM = 150, 48
+    pi = np.pi
+    g = dict(n=np.zeros(S3, np.int32), x=np.zeros((S3, NM, 3)), u=np.zeros((S3, NM, 2)), dt=np.zeros(S3),
+             cold_x0=np.zeros((S3, 3)), cold_xf=np.zeros((S3, 3)), cold_dt_ref=np.zeros(S3), cold_line_x=np.zeros((S3, NM, 3)), cold_line_u=np.zeros((S3, NM, 2)),
+             cold_xinit=np.zeros((S3, NM, 3)), cold_xinit_x=np.zeros((S3, NM, 3)),
+             query=np.zeros((S3, 3)), nearest=np.zeros(S3, np.int32), goal_new=np.zeros((S3, 3)), xf_fixed=np.zeros((S3, 3), np.int32),
+             warm_x=np.zeros((S3, NM, 3)), warm_u=np.zeros((S3, NM, 2)),
+             n_new=np.zeros(S3, np.int32), resample_x=np.zeros((S3, NM, 3)), resample_u=np.zeros((S3, NM, 2)), resample_dt=np.zeros(S3),
+             adapt_par=np.zeros((S3, 4)), adapt_n=np.zeros(S3, np.int32), adapt_x=np.zeros((S3, NM, 3)), adapt_u=np.zeros((S3, NM, 2)), adapt_dt=np.zeros(S3),
+             closest_query=np.zeros((S3, 4, 3)), closest=np.zeros((S3, 4), np.int32),
+             series_t=np.zeros((S3, NM)), series_x=np.zeros((S3, NM, 3)), series_u=np.zeros((S3, NM, 2)))
+    for s_ in range(S3):
+        n = int(rng.integers(3, 41)) if s_ % 10 else (3, 4, 22, 23, 24, 40)[(s_ // 10) % 6]     # 22..24: around the look-ahead limit of findNearestState
+        x = np.cumsum(rng.uniform(-0.1, 0.4, (n, 3)), 0)
+        x[:, 2] = RL.normalize_theta(rng.uniform(-pi, pi) + np.cumsum(rng.uniform(-0.3, 0.5, n)))       # headings that cross the +-pi seam now and then
+        u = rng.normal(size=(n - 1, 2)); dt = float(rng.uniform(0.05, 0.4))
+        g["n"][s_] = n; g["x"][s_, :n] = x; g["u"][s_, :n - 1] = u; g["dt"][s_] = dt
+        # cold start: own straight line guess (goal in front / behind / at the start), and from samples of an initial state trajectory
+        x0 = x[0].copy(); xf = x[-1].copy()
+        if s_ % 4 == 1: xf[:2] = x0[:2] - rng.uniform(0.5, 2.0) * np.array([np.cos(x0[2]), np.sin(x0[2])]) + rng.normal(0, 0.1, 2)     # behind the robot
+        if s_ % 25 == 3: xf[:2] = x0[:2]                                                                                               # no distance to go
+        dt_ref = float(rng.uniform(0.05, 0.4))
+        cx, cu = RL.grid_cold_start(n, dt_ref, x0, xf)
+        g["cold_x0"][s_], g["cold_xf"][s_], g["cold_dt_ref"][s_] = x0, xf, dt_ref
+        g["cold_line_x"][s_, :n] = cx; g["cold_line_u"][s_, :n - 1] = cu
+        xinit = x + rng.normal(0, 0.05, x.shape); xinit[:, 2] = RL.normalize_theta(xinit[:, 2])
+        g["cold_xinit"][s_, :n] = xinit
+        g["cold_xinit_x"][s_, :n] = RL.grid_cold_start(n, dt_ref, x0, xf, xinit)[0]
+        # the next cycle of the fixed grid
+        j = int(rng.integers(0, min(n, 27)))
+        q = x[j] + rng.normal(0, 0.02, 3) * (s_ % 6 != 0)          # every sixth query sits exactly ON a state
+        fx = rng.integers(0, 2, 3).astype(np.int32) if s_ % 3 else np.ones(3, np.int32)
+        goal = x[-1] + rng.normal(0, 0.3, 3); goal[2] = RL.normalize_theta(goal[2])[0]
+        g["query"][s_], g["goal_new"][s_], g["xf_fixed"][s_] = q, goal, fx
+        g["nearest"][s_] = RL.grid_find_nearest_state(x, u, dt, q)
+        wx, wu = RL.grid_warm_start_cycle(x, u, dt, q, goal, fx)
+        g["warm_x"][s_, :n] = wx; g["warm_u"][s_, :n - 1] = wu
+        # resampling, adaptation of the variable grid
+        n_new = int(rng.integers(2, NM + 1)) if s_ % 5 else n + (1, -1, 0)[(s_ // 5) % 3]
+        n_new = max(n_new, 2)
+        rx, ru, rdt = RL.grid_resample(x, u, dt, n_new)
+        g["n_new"][s_] = n_new; g["resample_x"][s_, :n_new] = rx; g["resample_u"][s_, :n_new - 1] = ru; g["resample_dt"][s_] = rdt
+        hyst = (0.1, 0.05, 0.2)[s_ % 3]
+        ratio = (0.7, 0.93, 1.0, 1.07, 1.3, 1.0 + hyst, 1.0 - hyst)[s_ % 7]
+        n_max = n + (0 if s_ % 11 == 0 else int(rng.integers(1, 8))); n_min = n - (0 if s_ % 13 == 0 else int(rng.integers(1, 3))); n_min = max(n_min, 2)
+        dtr = dt / ratio
+        ax, au, adt = RL.grid_adapt(x, u, dt, dtr, n_max, n_min, hyst)
+        g["adapt_par"][s_] = (dtr, n_max, n_min, hyst); g["adapt_n"][s_] = ax.shape[0]
+        g["adapt_x"][s_, :ax.shape[0]] = ax; g["adapt_u"][s_, :ax.shape[0] - 1] = au; g["adapt_dt"][s_] = adt
+        for c in range(4):
+            k = int(rng.integers(0, n)); start = int(rng.integers(0, n + 1)) if c else 0
+            xr, yr = x[k, :2] + rng.normal(0, 0.15, 2)
+            g["closest_query"][s_, c] = (xr, yr, start)
+            g["closest"][s_, c] = RL.grid_find_closest_pose(x, xr, yr, start)
+        t, xs, us = RL.grid_time_series(x, u, dt)
+        g["series_t"][s_, :n] = t; g["series_x"][s_, :n] = xs; g["series_u"][s_, :n] = us
+    # TimeSeriesSE2::getValuesInterpolate as the initial state trajectory is sampled (Linear, ZeroOrderHold beyond the end)
+    T3, MM, QQ = 80, 12, 40
+    g["ts_m"] = np.zeros(T3, np.int32); g["ts_times"] = np.zeros((T3, MM)); g["ts_values"] = np.zeros((T3, MM, 3)); g["ts_query"] = np.zeros((T3, QQ))
+    g["ts_out"] = np.zeros((T3, QQ, 3)); g["ts_out_no_hold"] = np.zeros((T3, QQ, 3)); g["ts_ok_no_hold"] = np.zeros((T3, QQ), np.int32)
+    for s_ in range(T3):
+        m = int(rng.integers(2, MM + 1))
+        tm = np.concatenate([[0.0], np.cumsum(rng.uniform(0.05, 0.8, m - 1))])
+        vals = np.cumsum(rng.uniform(-0.3, 0.6, (m, 3)), 0); vals[:, 2] = RL.normalize_theta(rng.uniform(-pi, pi) + np.cumsum(rng.uniform(-0.8, 1.2, m)))
+        q = rng.uniform(0.0, tm[-1] * 1.15, QQ)
+        q[:m] = tm                                             # exact hits
+        q[m:m + 3] = tm[rng.integers(0, m, 3)] + (3e-7, -3e-7, 2e-6)        # inside / outside the 1e-6 tolerance
+        q[m + 3] = tm[-1] + 1.0
+        q = np.maximum(q, 0.0)
+        out, ok = RL.time_series_se2_interpolate(tm, vals, q)
+        assert ok.all()
+        out2, ok2 = RL.time_series_se2_interpolate(tm, vals, q, hold=False)
+        g["ts_m"][s_] = m; g["ts_times"][s_, :m] = tm; g["ts_values"][s_, :m] = vals; g["ts_query"][s_] = q
+        g["ts_out"][s_] = out; g["ts_out_no_hold"][s_] = np.nan_to_num(out2, nan=0.0); g["ts_ok_no_hold"][s_] = ok2
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_grid.npz"), **g)
+    print("written grid vectors:", S3, "trajectories,", T3, "time series")
+
 
 if __name__ == "__main__":
     main()

@@ -7,6 +7,9 @@ extern "C" void ctl_initial_state_trajectory(int np, const double* plan, const d
     for (int i = 0; i < np; ++i) { p[i].x = plan[3 * i]; p[i].y = plan[3 * i + 1]; p[i].theta = plan[3 * i + 2]; }
     mpc_local_planner_amd::initial_state_trajectory(p, x0, xf, n, dt_ref, estimate_orientation != 0, x_init);
 }
+extern "C" void ctl_interpolate_se2(int m, const double* times, const double* vals, double t, double* out) {
+    mpc_local_planner_amd::interpolate_se2(std::vector<double>(times, times + m), std::vector<double>(vals, vals + 3 * m), t, out);
+}
 extern "C" double ctl_interpolate_angle(double a, double b, double f) { return mpc_local_planner_amd::interpolate_angle(a, b, f); }
 
 extern "C" double ctl_resample(double* x, double* u, double dt, int n, int n_new) {
@@ -25,7 +28,8 @@ extern "C" void ctl_warm_start_shifting(double* x, double* u, int n, const doubl
 extern "C" int ctl_optimal_control_result(int n, const double* x, const double* u, double dt, int found, double cpu_time, int seq, double* out) {
     using namespace mpc_local_planner_amd;
     TimeSeries xs, us;
-    for (int k = 0; k < n; ++k) { xs.add(k * dt, x + 3 * k, 3); us.add(k * dt, u + 2 * k, 2); }
+    double t = 0.0;
+    for (int k = 0; k < n; ++k, t += dt) { xs.add(t, x + 3 * k, 3); us.add(t, u + 2 * k, 2); }
     OptimalControlResult msg;
     fill_optimal_control_result(xs, us, found != 0, cpu_time, (uint32_t)seq, msg);
     int o = 0;

@@ -185,8 +185,8 @@ V = np.load(os.path.join(HERE, "golden", "ref_via_points.npz"))
 
 
 def test_via_point_association_and_terms_reproduce_the_reference():
-    """update() (:39-117): the closest grid state (first minimum; the final state only if strictly closer -- that part is findClosestPose, restated in the
-    stand-in grid), ordered mode restarting two states behind the previous match, a via-point at / beyond the goal moved to the state in front of it, one at /
+    """update() (:39-117): the closest grid state (first minimum; the final state only if strictly closer -- findClosestPose of the reference's own grid
+    class, see the grid tests below), ordered mode restarting two states behind the previous match, a via-point at / beyond the goal moved to the state in front of it, one at /
     behind the start skipped (ordered: attached to state 1).  computeNonIntegralStateTerm (:130-145): position weight x squared distance plus -- as coded --
     the orientation weight times the wrapped heading difference, NOT squared.  computeNonIntegralDtTerm (:119-128): (n - 1) dt on the single-dt grid."""
     import dataclasses
@@ -212,3 +212,151 @@ def test_via_point_association_and_terms_reproduce_the_reference():
         J = nlp.objective(nlp.pack(R.Trajectory(x.copy(), np.zeros((n - 1, 2)), float(dtk))))
         assert abs(J - (V["dt_term"][i] + sum(V["terms"][i, v] for v in range(nv) if ours[v] >= 0))) < 1e-12
     assert n_att > 300 and (V["attached"] == -1).sum() > 5
+
+
+# ---- the grid classes and TimeSeriesSE2 (src/optimal_control/full_discretization_grid_base_se2.cpp, finite_differences_variable_grid_se2.cpp,
+# src/utils/time_series_se2.cpp), compiled and executed: oracle/ref_wrap_grid.cpp -> tests/golden/ref_grid.npz
+GR = np.load(os.path.join(HERE, "golden", "ref_grid.npz"))
+
+
+def _traj(i):
+    n = int(GR["n"][i])
+    return n, GR["x"][i, :n].copy(), GR["u"][i, :n - 1].copy(), float(GR["dt"][i])
+
+
+def test_cold_start_reproduces_the_reference_grid():
+    """update() on an empty grid (:58-134 -> initializeSequences, both overloads :136-239): the straight line with the heading of the direction of travel
+    (reversed when the goal lies behind the robot, untouched start and goal poses), and the samples of an initial state trajectory between start and goal"""
+    behind = 0
+    for i in range(GR["n"].shape[0]):
+        n = int(GR["n"][i])
+        x0, xf, dt_ref = GR["cold_x0"][i], GR["cold_xf"][i], float(GR["cold_dt_ref"][i])
+        cfg = R.OcpConfig(n=n, dt_ref=dt_ref)
+        t = R.initialize_sequences_straight_line(cfg, x0, xf)
+        assert np.array_equal(t.x, GR["cold_line_x"][i, :n]), i
+        assert np.array_equal(t.u, GR["cold_line_u"][i, :n - 1]) and t.dt == dt_ref
+        d = xf[:2] - x0[:2]
+        behind += int(d @ np.array([np.cos(x0[2]), np.sin(x0[2])]) < 0)
+        # xinit overload: the table is what DiscreteTimeReferenceTrajectory hands out at k dt_ref; equal time stamps = exact hits of the interpolation
+        xi = GR["cold_xinit"][i, :n]
+        t2 = R.initialize_sequences_xinit(cfg, x0, xf, np.arange(n) * dt_ref, xi)
+        assert np.array_equal(t2.x, GR["cold_xinit_x"][i, :n]), i
+    assert behind > 20
+
+
+def test_time_series_se2_interpolation_reproduces_the_reference():
+    """TimeSeriesSE2::getValuesInterpolate (src/utils/time_series_se2.cpp:34-111), Linear + ZeroOrderHold beyond the end: exact hits within the 1e-6 tolerance
+    return the stored sample, the heading is interpolated on the circle"""
+    for i in range(GR["ts_m"].shape[0]):
+        m = int(GR["ts_m"][i])
+        tm, vals = GR["ts_times"][i, :m], GR["ts_values"][i, :m]
+        for q, ref, ref_nh, ok_nh in zip(GR["ts_query"][i], GR["ts_out"][i], GR["ts_out_no_hold"][i], GR["ts_ok_no_hold"][i]):
+            ours = R.time_series_se2_interpolate(tm, vals, float(q))
+            assert np.array_equal(ours, ref), (i, q)
+            # NoExtrapolation: as coded (:43-46 `break` leaves the switch only) the call does NOT fail beyond the last stamp, it extends the last interval linearly
+            assert ok_nh
+            if q <= tm[-1]:
+                assert np.array_equal(ref_nh, ref)
+            elif q - tm[-1] < 1e-6:
+                assert np.array_equal(ref_nh, vals[-1])
+            else:
+                fr = (q - tm[-2]) / (tm[-1] - tm[-2])
+                lin = vals[-2] + fr * (vals[-1] - vals[-2]); lin[2] = R.interpolate_angle(vals[-2][2], vals[-1][2], fr)
+                assert np.array_equal(ref_nh, lin)
+
+
+def test_nearest_state_and_warm_start_shift_reproduce_the_reference_grid():
+    """findNearestState (:304-339: stops at the first non-improving state, looks at most 20 states ahead, never at the final state) and the next cycle of the fixed
+    grid (update(): warmStartShifting :241-302, then x_0 := measured state, fixed goal components := the goal :101-116)"""
+    shifts = set()
+    for i in range(GR["n"].shape[0]):
+        n, x, u, dt = _traj(i)
+        q, goal, fx = GR["query"][i], GR["goal_new"][i], GR["xf_fixed"][i]
+        tr = R.Trajectory(x, u, dt)
+        ns = R.find_nearest_state(tr, q)
+        assert ns == GR["nearest"][i], i
+        shifts.add(ns)
+        cfg = R.OcpConfig(n=n, dt_ref=dt, xf_fixed=tuple(bool(f) for f in fx))
+        w = R.new_run_overwrite(cfg, R.warm_start_shifting(tr, q), q, goal)
+        assert np.array_equal(w.x, GR["warm_x"][i, :n]), i
+        assert np.array_equal(w.u, GR["warm_u"][i, :n - 1]), i
+    assert 0 in shifts and 20 in shifts and max(shifts) == 20 and len(shifts) > 12
+
+
+def test_resampling_and_grid_adaptation_reproduce_the_reference_grid():
+    """resampleTrajectory (:440-524) and adaptGridTimeBasedSingleStep (finite_differences_variable_grid_se2.cpp:99-121: one state more when dt > dt_ref (1 + hyst)
+    and n < n_max, one less when dt < dt_ref (1 - hyst) and n > n_min)"""
+    grown = shrunk = kept = 0
+    for i in range(GR["n"].shape[0]):
+        n, x, u, dt = _traj(i)
+        tr = R.Trajectory(x, u, dt)
+        n_new = int(GR["n_new"][i])
+        r = R.resample_trajectory(tr, n_new)
+        assert r.x.shape[0] == n_new
+        assert np.array_equal(r.x, GR["resample_x"][i, :n_new]), i
+        assert np.array_equal(r.u, GR["resample_u"][i, :n_new - 1]), i
+        assert r.dt == GR["resample_dt"][i]
+        dtr, n_max, n_min, hyst = GR["adapt_par"][i]
+        a = R.adapt_grid_single_step(R.OcpConfig(n=n, dt_ref=float(dtr)), tr, n_min=int(n_min), n_max=int(n_max), hyst=float(hyst))
+        na = int(GR["adapt_n"][i])
+        assert a.x.shape[0] == na, i
+        assert np.array_equal(a.x, GR["adapt_x"][i, :na]) and np.array_equal(a.u, GR["adapt_u"][i, :na - 1]) and a.dt == GR["adapt_dt"][i]
+        grown += na > n; shrunk += na < n; kept += na == n
+    assert grown > 15 and shrunk > 15 and kept > 30
+
+
+def test_closest_pose_and_time_series_reproduce_the_reference_grid():
+    """findClosestPose (:364-388) and getStateAndControlTimeSeries (:579-615: the last control repeated at the final state's time stamp)"""
+    for i in range(GR["n"].shape[0]):
+        n, x, u, dt = _traj(i)
+        for (xr, yr, start), ref in zip(GR["closest_query"][i], GR["closest"][i]):
+            assert R.find_closest_pose(x, float(xr), float(yr), int(start)) == ref, i
+        t, xs, us = R.time_series_output(R.Trajectory(x, u, dt))
+        assert np.array_equal(t, GR["series_t"][i, :n]) and np.array_equal(xs, GR["series_x"][i, :n]) and np.array_equal(us, GR["series_u"][i, :n])
+        msg = R.optimal_control_result(xs, us, dt, True, 0.0, 0)
+        assert np.array_equal(msg["states"], GR["series_x"][i, :n].reshape(-1)) and np.array_equal(msg["time_controls"], GR["series_t"][i, :n])
+
+
+@pytest.fixture(scope="module")
+def facade():
+    src = os.path.join(HERE, "host_harness", "controller_host.cpp")
+    out = os.path.join(HERE, "host_harness", "_build", "libctl_host_pinned.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wl,--unresolved-symbols=ignore-all", src, "-o", out], check=True)
+    l = C.CDLL(out)
+    l.ctl_resample.restype = C.c_double
+    l.ctl_resample.argtypes = [C.c_void_p, C.c_void_p, C.c_double, C.c_int, C.c_int]
+    l.ctl_interpolate_se2.restype = None
+    l.ctl_interpolate_se2.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p]
+    return l
+
+
+def test_controller_facade_grid_logic_reproduces_the_reference_grid(facade):
+    """the shipped host logic (include/mpc_controller.hpp: find_nearest_state, warm_start_shifting, resample_trajectory, interpolate_se2) against the recorded outputs
+    of the reference's grid class; the facade keeps the controls as [n][2] with the last row repeated"""
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    for i in range(GR["n"].shape[0]):
+        n, x, u, dt = _traj(i)
+        q = np.ascontiguousarray(GR["query"][i])
+        xx = x.copy(); uu = np.ascontiguousarray(np.vstack([u, u[-1:]]))
+        assert facade.ctl_find_nearest_state(p(xx), C.c_int(n), p(q)) == GR["nearest"][i]
+        facade.ctl_warm_start_shifting(p(xx), p(uu), C.c_int(n), p(q))
+        wx = GR["warm_x"][i, :n].copy()            # the recorded cycle also overwrote the start and the fixed goal components: compare what shifting alone decides
+        assert np.array_equal(xx[1:n - 1], wx[1:n - 1]), i
+        assert np.array_equal(uu[:n - 1], GR["warm_u"][i, :n - 1]), i
+        free = GR["xf_fixed"][i] == 0
+        assert np.array_equal(xx[n - 1][free], wx[n - 1][free])
+        n_new = int(GR["n_new"][i]); cap = max(n, n_new)
+        xb = np.zeros((cap, 3)); xb[:n] = x
+        ub = np.zeros((cap, 2)); ub[:n - 1] = u; ub[n - 1] = u[-1]
+        dt_new = facade.ctl_resample(p(xb), p(ub), dt, n, n_new)
+        assert dt_new == GR["resample_dt"][i]
+        assert np.array_equal(xb[:n_new], GR["resample_x"][i, :n_new]), i
+        assert np.array_equal(ub[:n_new - 1], GR["resample_u"][i, :n_new - 1]), i
+    for i in range(GR["ts_m"].shape[0]):
+        m = int(GR["ts_m"][i])
+        tm, vals = np.ascontiguousarray(GR["ts_times"][i, :m]), np.ascontiguousarray(GR["ts_values"][i, :m])
+        out = np.zeros(3)
+        for qv, ref in zip(GR["ts_query"][i], GR["ts_out"][i]):
+            facade.ctl_interpolate_se2(m, p(tm), p(vals), float(qv), p(out))
+            assert np.array_equal(out, ref), (i, qv)
