@@ -52,6 +52,9 @@ def load():
         lib.ref_grid_find_closest_pose.restype = I; lib.ref_grid_find_closest_pose.argtypes = [I, V, V, D, D, D, I]
         lib.ref_grid_time_series.restype = I; lib.ref_grid_time_series.argtypes = [I, V, V, D, V, V, V]
         lib.ref_time_series_se2_interpolate.restype = None; lib.ref_time_series_se2_interpolate.argtypes = [I, V, V, I, I, I, V, V, V]
+        lib.ref_quadratic_cost.restype = None; lib.ref_quadratic_cost.argtypes = [I, V, V, I, I, I, I, V, V, V, V, V]
+        lib.ref_final_state_cost.restype = None; lib.ref_final_state_cost.argtypes = [V, I, I, I, V, V, V]
+        lib.ref_terminal_ball.restype = None; lib.ref_terminal_ball.argtypes = [V, D, I, I, V, V, V]
         _lib = lib
     return _lib
 
@@ -189,3 +192,30 @@ def time_series_se2_interpolate(times, values, t, linear=True, hold=True):
     out = np.full((t.size, 3), np.nan); ok = np.zeros(t.size, np.int32)
     load().ref_time_series_se2_interpolate(tm.size, _p(tm), _p(v), int(linear), int(hold), t.size, _p(t), _p(out), _p(ok))
     return out, ok.astype(bool)
+
+
+# ---- the SE(2) cost and terminal-condition classes (oracle/ref_wrap_cost.cpp)
+def quadratic_cost(Q, R, x, x_ref, u, u_ref=None, form=True, diagonal=False, integral=False, lsq=False):
+    """QuadraticFormCostSE2 (form) / QuadraticStateCostSE2 at every sample: the state term, or with integral=True the integrand l(x_k, u_k)"""
+    Q = np.ascontiguousarray(Q, float).reshape(3, 3); R = np.ascontiguousarray(R, float).reshape(2, 2)
+    x = np.ascontiguousarray(x, float); xr = np.ascontiguousarray(np.broadcast_to(np.asarray(x_ref, float), x.shape)); u = np.ascontiguousarray(u, float)
+    ur = None if u_ref is None else np.ascontiguousarray(np.broadcast_to(np.asarray(u_ref, float), u.shape))
+    out = np.zeros((x.shape[0], 3 if lsq else 1))
+    load().ref_quadratic_cost(int(form), _p(Q), _p(R), int(diagonal), int(integral), int(lsq), x.shape[0], _p(x), _p(xr), _p(u), None if ur is None else _p(ur), _p(out))
+    return out if lsq else out[:, 0]
+
+
+def final_state_cost(Qf, x, x_ref, diagonal=False, lsq=False):
+    Qf = np.ascontiguousarray(Qf, float).reshape(3, 3); x = np.ascontiguousarray(x, float).reshape(-1, 3)
+    xr = np.ascontiguousarray(np.broadcast_to(np.asarray(x_ref, float), x.shape))
+    out = np.zeros((x.shape[0], 3 if lsq else 1))
+    load().ref_final_state_cost(_p(Qf), int(diagonal), int(lsq), x.shape[0], _p(x), _p(xr), _p(out))
+    return out if lsq else out[:, 0]
+
+
+def terminal_ball(S, gamma, x, x_ref, diagonal=False):
+    S = np.ascontiguousarray(S, float).reshape(3, 3); x = np.ascontiguousarray(x, float).reshape(-1, 3)
+    xr = np.ascontiguousarray(np.broadcast_to(np.asarray(x_ref, float), x.shape))
+    out = np.zeros(x.shape[0])
+    load().ref_terminal_ball(_p(S), float(gamma), int(diagonal), x.shape[0], _p(x), _p(xr), _p(out))
+    return out

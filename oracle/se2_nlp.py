@@ -9,15 +9,16 @@ PARITY: PINNED to executed reference code for the angle helpers, the four robot 
 the three collocation rules (normalize_theta / interpolate_angle, dynamics,
 collocation_defect below), the obstacle association (associate_obstacles, uncapped),
 the clearance rows of point obstacles (static and moving), the control-rate rows, the
-via-point association and terms, and the grid handling (cold start, nearest state, warm-start
+via-point association and terms, the quadratic cost terms / final-state cost / terminal-ball row,
+and the grid handling (cold start, nearest state, warm-start
 shifting, resampling, single-step adaptation, closest pose, time series, TimeSeriesSE2
 interpolation -- bit for bit):
 the reference's own sources for these compile here against interface stand-ins
-(oracle/ref_wrap.cpp, ref_wrap_rows.cpp, ref_wrap_grid.cpp -> oracle/_ref), their outputs are recorded
-in tests/golden/ref_models_collocation.npz / ref_stage_inequality.npz / ref_via_points.npz / ref_grid.npz and
+(oracle/ref_wrap.cpp, ref_wrap_rows.cpp, ref_wrap_grid.cpp, ref_wrap_cost.cpp -> oracle/_ref), their outputs are recorded
+in tests/golden/ref_models_collocation.npz / ref_stage_inequality.npz / ref_via_points.npz / ref_grid.npz / ref_costs.npz and
 tests/test_reference_pinned.py holds this file, the C oracle and the kernel's core to them.
 UNPINNED for everything else: the reference ships no tests / golden outputs and its
-solver stack (control_box_rst's cost / edge assembly, Ipopt, MUMPS, teb_local_planner's
+solver stack (control_box_rst's edge assembly, Ipopt, MUMPS, teb_local_planner's
 distance functions for lines, polygons and turning footprints) is not vendored, so those
 parts are pinned only against the reference *sources* (formulas) and against independent
 solvers (scipy) on the same NLP.

@@ -181,6 +181,43 @@ def main():
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_grid.npz"), **g)
     print("written grid vectors:", S3, "trajectories,", T3, "time series")
 
+    # ---- the reference's cost and terminal-condition classes (src/optimal_control/quadratic_cost_se2.cpp, final_state_conditions_se2.cpp), oracle/ref_wrap_cost.cpp
+    rng = np.random.default_rng(20260929)
+    S4, NC = 100, 26
+
+    def spd(d):
+        a = rng.normal(size=(d, d))
+        return a @ a.T + np.diag(rng.uniform(0.1, 2.0, d))
+    c = dict(n=np.zeros(S4, np.int32), x=np.zeros((S4, NC, 3)), u=np.zeros((S4, NC, 2)), goal=np.zeros((S4, 3)), dt=np.zeros(S4),
+             Q=np.zeros((S4, 3, 3)), R=np.zeros((S4, 2, 2)), Qf=np.zeros((S4, 3, 3)), S=np.zeros((S4, 3, 3)), gamma=np.zeros(S4))
+    for key in ("form_state", "form_state_diag", "state_state", "state_state_diag", "form_l", "form_l_diag", "form_l_next", "form_l_next_diag", "state_l", "state_l_diag",
+                "final", "final_diag", "ball", "ball_diag"):
+        c[key] = np.zeros((S4, NC))
+    c["form_state_lsq_diag"] = np.zeros((S4, NC, 3)); c["final_lsq_diag"] = np.zeros((S4, NC, 3))
+    c["form_l_uref"] = np.zeros((S4, NC)); c["u_ref"] = np.zeros((S4, 2))
+    for s_ in range(S4):
+        n = int(rng.integers(4, NC + 1))
+        x = np.cumsum(rng.uniform(-0.2, 0.5, (n, 3)), 0); x[:, 2] = rng.uniform(-pi, pi, n)            # heading errors on both sides of the +-pi seam
+        u = rng.normal(size=(n, 2)); goal = x[-1] + rng.normal(0, 0.4, 3); goal[2] = rng.uniform(-pi, pi)
+        Q, R_, Qf, S_ = spd(3), spd(2), spd(3), spd(3)
+        c["n"][s_] = n; c["x"][s_, :n] = x; c["u"][s_, :n] = u; c["goal"][s_] = goal; c["dt"][s_] = rng.uniform(0.05, 0.4)
+        c["Q"][s_], c["R"][s_], c["Qf"][s_], c["S"][s_], c["gamma"][s_] = Q, R_, Qf, S_, rng.uniform(0.01, 1.0)
+        xn = np.vstack([x[1:], x[-1:]])                      # x_{k+1} next to u_k: the second evaluation of the trapezoidal rule
+        for dg, sfx in ((False, ""), (True, "_diag")):
+            c["form_state" + sfx][s_, :n] = RL.quadratic_cost(Q, R_, x, goal, u, form=True, diagonal=dg)
+            c["state_state" + sfx][s_, :n] = RL.quadratic_cost(Q, R_, x, goal, u, form=False, diagonal=dg)
+            c["form_l" + sfx][s_, :n] = RL.quadratic_cost(Q, R_, x, goal, u, form=True, diagonal=dg, integral=True)
+            c["form_l_next" + sfx][s_, :n] = RL.quadratic_cost(Q, R_, xn, goal, u, form=True, diagonal=dg, integral=True)
+            c["state_l" + sfx][s_, :n] = RL.quadratic_cost(Q, R_, x, goal, u, form=False, diagonal=dg, integral=True)
+            c["final" + sfx][s_, :n] = RL.final_state_cost(Qf, x, goal, diagonal=dg)
+            c["ball" + sfx][s_, :n] = RL.terminal_ball(S_, c["gamma"][s_], x, goal, diagonal=dg)
+        c["form_state_lsq_diag"][s_, :n] = RL.quadratic_cost(Q, R_, x, goal, u, form=True, diagonal=True, lsq=True)
+        c["final_lsq_diag"][s_, :n] = RL.final_state_cost(Qf, x, goal, diagonal=True, lsq=True)
+        c["u_ref"][s_] = rng.normal(size=2)
+        c["form_l_uref"][s_, :n] = RL.quadratic_cost(Q, R_, x, goal, u, u_ref=c["u_ref"][s_], form=True, integral=True)
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_costs.npz"), **c)
+    print("written cost vectors:", S4, "trajectories")
+
 
 if __name__ == "__main__":
     main()

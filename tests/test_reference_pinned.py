@@ -360,3 +360,74 @@ def test_controller_facade_grid_logic_reproduces_the_reference_grid(facade):
         for qv, ref in zip(GR["ts_query"][i], GR["ts_out"][i]):
             facade.ctl_interpolate_se2(m, p(tm), p(vals), float(qv), p(out))
             assert np.array_equal(out, ref), (i, qv)
+
+
+# ---- the cost and terminal-condition classes (src/optimal_control/quadratic_cost_se2.cpp, final_state_conditions_se2.cpp), compiled and executed:
+# oracle/ref_wrap_cost.cpp -> tests/golden/ref_costs.npz
+CO = np.load(os.path.join(HERE, "golden", "ref_costs.npz"))
+
+
+def _cost_scene(i, diagonal):
+    n = int(CO["n"][i])
+    pick = (lambda M: np.diag(M).copy()) if diagonal else (lambda M: M.copy())
+    return n, CO["x"][i, :n], CO["u"][i, :n], CO["goal"][i], float(CO["dt"][i]), pick(CO["Q"][i]), pick(CO["R"][i]), pick(CO["Qf"][i]), pick(CO["S"][i]), float(CO["gamma"][i])
+
+
+@pytest.mark.parametrize("diagonal", [False, True])
+def test_cost_terms_reproduce_the_reference(diagonal):
+    """per grid point: xd = x_k - x_ref with the heading difference wrapped (quadratic_cost_se2.cpp:36-37), then xd' Q xd (state term), xd' Q xd + u' R u (the
+    integrand of the integral form, control reference zero or not), xd' Qf xd (final_state_conditions_se2.cpp:30-52), xd' S xd - gamma (:54-64)"""
+    sfx = "_diag" if diagonal else ""
+    wrapped = 0
+    for i in range(CO["n"].shape[0]):
+        n, x, u, goal, dt, Q, Rw, Qf, S, gamma = _cost_scene(i, diagonal)
+        Qm, Rm, Qfm, Sm = (R.weight_matrix(w) for w in (Q, Rw, Qf, S))
+        for k in range(n):
+            xd = x[k] - goal
+            wrapped += abs(xd[2]) > np.pi
+            xd[2] = R.normalize_theta(xd[2])
+            st = float(xd @ Qm @ xd)
+            tol = 1e-14 * max(1.0, abs(st))
+            assert abs(st - CO["form_state" + sfx][i, k]) < tol and abs(st - CO["state_state" + sfx][i, k]) < tol
+            assert abs(st + float(u[k] @ Rm @ u[k]) - CO["form_l" + sfx][i, k]) < 4 * tol + 1e-14 * float(u[k] @ Rm @ u[k])
+            assert abs(st - CO["state_l" + sfx][i, k]) < tol                                       # QuadraticStateCostSE2: no control part
+            assert abs(float(xd @ Qfm @ xd) - CO["final" + sfx][i, k]) < 1e-14 * max(1.0, CO["final" + sfx][i, k])
+            assert abs(float(xd @ Sm @ xd) - gamma - CO["ball" + sfx][i, k]) < 1e-14 * max(1.0, abs(CO["ball" + sfx][i, k]) + gamma)
+            if not diagonal:
+                ud = u[k] - CO["u_ref"][i]
+                assert abs(st + float(ud @ Rm @ ud) - CO["form_l_uref"][i, k]) < 1e-13 * max(1.0, CO["form_l_uref"][i, k])
+            else:
+                # least-squares form (lsq solvers), diagonal weights: sqrt(Q) xd, three values per grid point whose squares sum to the quadratic form
+                assert np.allclose(CO["form_state_lsq_diag"][i, k], np.sqrt(Q) * xd, rtol=1e-15, atol=1e-15)
+                assert abs(float((CO["form_state_lsq_diag"][i, k] ** 2).sum()) - st) < 1e-13 * max(1.0, st)
+                assert np.allclose(CO["final_lsq_diag"][i, k], np.sqrt(Qf) * xd, rtol=1e-15, atol=1e-15)
+    assert wrapped > 200
+
+
+@pytest.mark.parametrize("diagonal", [False, True])
+@pytest.mark.parametrize("form", ["non_integral", "left_sum", "trapezoidal_rule"])
+def test_reference_form_objective_is_the_sum_of_the_reference_s_terms(diagonal, form):
+    """ReferenceNlp.objective against the recorded per-point terms put together the way the grid's edges do (finite_differences_grid_se2.cpp:53-126: one term per
+    grid point k < n-1, or dt l(x_k, u_k) [left sum], or 0.5 dt (l(x_k, u_k) + l(x_{k+1}, u_k)) [trapezoidal rule], plus the final-state cost at x_{n-1}), and the
+    terminal-ball row"""
+    import dataclasses
+    sfx = "_diag" if diagonal else ""
+    for i in range(CO["n"].shape[0]):
+        n, x, u, goal, dt, Q, Rw, Qf, S, gamma = _cost_scene(i, diagonal)
+        Rm = R.weight_matrix(Rw)
+        cfg = dataclasses.replace(R.config_unicycle_quadratic(n), Q=Q, R=Rw, Qf=Qf, terminal_ball_S=S, terminal_ball_gamma=gamma, xf_fixed=(False, False, False),
+                                  integral_form=form != "non_integral", cost_integration="left_sum" if form == "non_integral" else form, dt_free=False, dt_ref=dt,
+                                  du_lb=np.full(2, -R.INF), du_ub=np.full(2, R.INF))
+        nlp = R.ReferenceNlp(cfg, R.CycleInputs(x0=x[0], xf=goal))
+        z = nlp.pack(R.Trajectory(x.copy(), u[:n - 1].copy(), dt))
+        J = nlp.objective(z)
+        if form == "non_integral":
+            ref = sum(CO["form_state" + sfx][i, k] + float(u[k] @ Rm @ u[k]) for k in range(n - 1))        # the control term is corbo's base class: u' R u
+        elif form == "left_sum":
+            ref = sum(dt * CO["form_l" + sfx][i, k] for k in range(n - 1))
+        else:
+            ref = sum(0.5 * dt * (CO["form_l" + sfx][i, k] + CO["form_l_next" + sfx][i, k]) for k in range(n - 1))
+        ref += CO["final" + sfx][i, n - 1]
+        assert abs(J - ref) < 1e-12 * max(1.0, abs(ref)), (i, J, ref)
+        g = nlp.inequalities(z)
+        assert abs(g[-1] - CO["ball" + sfx][i, n - 1]) < 1e-13 * max(1.0, abs(g[-1]))
