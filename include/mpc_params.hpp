@@ -14,6 +14,7 @@
 // Python twin with the same behaviour: mpc_local_planner_amd/params.py (tests/test_params.py compares the two field by field).
 #pragma once
 
+#include <cstdlib>
 #include <cmath>
 #include <map>
 #include <string>
@@ -63,16 +64,27 @@ class MapParamSource : public ParamSource {
         auto it = _m.lower_bound(pre);
         return it != _m.end() && it->first.compare(0, pre.size(), pre) == 0;
     }
-    // roscpp converts between int and double parameters, nothing else
-    bool get(const std::string& key, bool& v) const override { auto p = find(key); if (!p) return false; if (p->kind == Value::BOOL) { v = p->b; return true; } if (p->kind == Value::INT) { v = p->i != 0; return true; } return false; }
-    bool get(const std::string& key, int& v) const override { auto p = find(key); if (!p) return false; if (p->kind == Value::INT) { v = p->i; return true; } if (p->kind == Value::DOUBLE) { v = (int)p->d; return true; } return false; }
+    // roscpp (param.cpp): a double parameter takes an int, an int parameter takes a double rounded half up, a bool parameter takes a bool only
+    bool get(const std::string& key, bool& v) const override { auto p = find(key); if (!p || p->kind != Value::BOOL) return false; v = p->b; return true; }
+    bool get(const std::string& key, int& v) const override {
+        auto p = find(key); if (!p) return false;
+        if (p->kind == Value::INT) { v = p->i; return true; }
+        if (p->kind == Value::DOUBLE) { const double d = p->d; v = (int)(std::fmod(d, 1.0) < 0.5 ? std::floor(d) : std::ceil(d)); return true; }
+        return false;
+    }
     bool get(const std::string& key, double& v) const override { auto p = find(key); if (!p) return false; if (p->kind == Value::DOUBLE) { v = p->d; return true; } if (p->kind == Value::INT) { v = p->i; return true; } return false; }
     bool get(const std::string& key, std::string& v) const override { auto p = find(key); if (!p || p->kind != Value::STRING) return false; v = p->s; return true; }
     bool get(const std::string& key, std::vector<double>& v) const override { auto p = find(key); if (!p || p->kind != Value::DOUBLES) return false; v = p->dv; return true; }
     bool get(const std::string& key, std::vector<bool>& v) const override { auto p = find(key); if (!p || p->kind != Value::BOOLS) return false; v = p->bv; return true; }
     bool get(const std::string& key, std::vector<std::vector<double>>& v) const override { auto p = find(key); if (!p || p->kind != Value::POINTS) return false; v = p->pv; return true; }
     bool get(const std::string& key, std::map<std::string, double>& v) const override {
-        return children(key, [&](const std::string& k, const Value& x) { if (x.kind == Value::DOUBLE) v[k] = x.d; else if (x.kind == Value::INT) v[k] = x.i; });
+        // a number written as text counts when it parses completely: `tol: 1e-4` is TEXT for a YAML 1.1 loader (rosparam's), and roscpp would then reject the
+        // whole map, leaving Ipopt's defaults in force; the evident intent is honoured here (config_from_params notes it)
+        return children(key, [&](const std::string& k, const Value& x) {
+            if (x.kind == Value::DOUBLE) v[k] = x.d;
+            else if (x.kind == Value::INT) v[k] = x.i;
+            else if (x.kind == Value::STRING) { char* end = nullptr; const double d = std::strtod(x.s.c_str(), &end); if (end != x.s.c_str() && *end == 0) v[k] = d; }
+        });
     }
     bool get(const std::string& key, std::map<std::string, std::string>& v) const override {
         return children(key, [&](const std::string& k, const Value& x) { if (x.kind == Value::STRING) v[k] = x.s; });
@@ -247,7 +259,11 @@ inline ParamStatus config_from_params(const ParamSource& p, mpc_config& c, Contr
     if (colloc == "forward_differences") c.collocation = MPC_COLLOC_FORWARD;
     else if (colloc == "midpoint_differences") c.collocation = MPC_COLLOC_MIDPOINT;
     else if (colloc == "crank_nicolson_differences") c.collocation = MPC_COLLOC_CRANK_NICOLSON;
-    else { rep.notes.push_back("Unknown collocation method '" + colloc + "' specified. Falling back to default..."); c.collocation = MPC_COLLOC_FORWARD; }
+    else {
+        // :314: the reference logs "Falling back to default..." and goes on with the grid's initial rule, corbo's plain Crank-Nicolson differences
+        // (full_discretization_grid_base_se2.h:206) -- a rule WITHOUT the SE(2) heading wrap that is not built here
+        return missing("Unknown collocation method '" + colloc + "' specified: the reference falls back to corbo::CrankNicolsonDiffCollocation (no SE(2) heading wrap), not built here");
+    }
     std::string integration = p.param<std::string>("grid/cost_integration_method", "left_sum");
     if (integration != "left_sum" && integration != "trapezoidal_rule") {
         rep.notes.push_back("Unknown cost integration method '" + integration + "' specified. Falling back to default..."); integration = "left_sum"; }
@@ -262,6 +278,13 @@ inline ParamStatus config_from_params(const ParamSource& p, mpc_config& c, Contr
         rep.notes.push_back("solver/ipopt/max_cpu_time has no counterpart: a launch is bounded by max_iter (and by the candidates' iteration caps)");
     std::map<std::string, double> numeric; std::map<std::string, std::string> strings; std::map<std::string, int> integers;
     p.get("solver/ipopt/ipopt_numeric_options", numeric);
+    {
+        std::map<std::string, std::string> as_text;
+        p.get("solver/ipopt/ipopt_numeric_options", as_text);
+        for (const auto& kv : as_text)
+            if (numeric.count(kv.first))
+                rep.notes.push_back("ipopt numeric option " + kv.first + " is text ('" + kv.second + "' is not a YAML 1.1 float): roscpp rejects the whole map and the reference runs with Ipopt's defaults; the value is used here");
+    }
     p.get("solver/ipopt/ipopt_string_options", strings);
     p.get("solver/ipopt/ipopt_integer_options", integers);
     c.tol = 1e-8;                                            // Ipopt's default tol

@@ -63,11 +63,14 @@ class _Reader:
                 return default
             node = node[part]
         self.used.add(key)
-        # roscpp converts between int and double parameters but not from strings; a value of the wrong kind leaves the default in place
+        # roscpp (param.cpp): a double parameter takes an int, an int parameter takes a double rounded half up, a bool parameter takes a bool only;
+        # a value of any other kind leaves the default in place
         if isinstance(default, bool):
-            return bool(node) if isinstance(node, (bool, int)) else default
+            return node if isinstance(node, bool) else default
         if isinstance(default, int):
-            return int(node) if isinstance(node, (int, float)) and not isinstance(node, bool) else default
+            if isinstance(node, float):
+                return int(math.floor(node) if math.fmod(node, 1.0) < 0.5 else math.ceil(node))
+            return node if isinstance(node, int) and not isinstance(node, bool) else default
         if isinstance(default, float):
             return float(node) if isinstance(node, (int, float)) and not isinstance(node, bool) else default
         if isinstance(default, str):
@@ -178,8 +181,10 @@ def config_from_params(params: dict, costmap_footprint=None, **sizing):
     colloc = p.get("grid/collocation_method", "forward_differences")
     colloc_ids = {"forward_differences": A.COLLOC_FORWARD, "midpoint_differences": A.COLLOC_MIDPOINT, "crank_nicolson_differences": A.COLLOC_CRANK_NICOLSON}
     if colloc not in colloc_ids:
-        notes.append(f"Unknown collocation method '{colloc}' specified. Falling back to default...")      # :314: the reference goes on with forward differences
-        colloc = "forward_differences"
+        # :314: the reference logs "Falling back to default..." and goes on with the grid's initial rule, corbo's plain Crank-Nicolson differences
+        # (full_discretization_grid_base_se2.h:206), a rule WITHOUT the SE(2) heading wrap that is not built here
+        raise ParamNotImplemented(f"Unknown collocation method '{colloc}' specified: the reference falls back to corbo::CrankNicolsonDiffCollocation "
+                                  "(no SE(2) heading wrap), not built here")
     kw["collocation"] = colloc_ids[colloc]
     integration = p.get("grid/cost_integration_method", "left_sum")
     if integration not in ("left_sum", "trapezoidal_rule"):
@@ -201,6 +206,16 @@ def config_from_params(params: dict, costmap_footprint=None, **sizing):
     strings = p.get("solver/ipopt/ipopt_string_options", {}) or {}
     integers = p.get("solver/ipopt/ipopt_integer_options", {}) or {}
     for k, v in numeric.items():
+        if isinstance(v, str):
+            # `tol: 1e-4` is TEXT for a YAML 1.1 loader (PyYAML, which rosparam uses, wants a dot in a float): roscpp then rejects the whole map
+            # (param.cpp: every element must be castable) and the reference runs with Ipopt's defaults.  The evident intent is honoured here.
+            try:
+                v = float(v)
+            except ValueError:
+                notes.append(f"ipopt numeric option {k} = {v!r}: not a number, ignored")
+                continue
+            notes.append(f"ipopt numeric option {k} is text ('{numeric[k]}' is not a YAML 1.1 float): roscpp rejects the whole map and the reference runs with "
+                         "Ipopt's defaults; the value is used here")
         if k == "tol":
             kw["tol"] = float(v)
         elif k == "mu_init":

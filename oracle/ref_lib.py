@@ -55,6 +55,22 @@ def load():
         lib.ref_quadratic_cost.restype = None; lib.ref_quadratic_cost.argtypes = [I, V, V, I, I, I, I, V, V, V, V, V]
         lib.ref_final_state_cost.restype = None; lib.ref_final_state_cost.argtypes = [V, I, I, I, V, V, V]
         lib.ref_terminal_ball.restype = None; lib.ref_terminal_ball.argtypes = [V, D, I, I, V, V, V]
+        lib.ref_ctl_create.restype = V; lib.ref_ctl_create.argtypes = [C.c_char_p, I, V, I, V, I]
+        lib.ref_ctl_destroy.restype = None; lib.ref_ctl_destroy.argtypes = [V]
+        lib.ref_ctl_probe_configure.restype = I; lib.ref_ctl_probe_configure.argtypes = [C.c_char_p, C.c_char_p, I]
+        lib.ref_ctl_configured.restype = I; lib.ref_ctl_configured.argtypes = [V]
+        lib.ref_ctl_set_solver.restype = None; lib.ref_ctl_set_solver.argtypes = [V, V]
+        lib.ref_ctl_log.restype = I; lib.ref_ctl_log.argtypes = [C.c_char_p, I]
+        lib.ref_ctl_dump.restype = I; lib.ref_ctl_dump.argtypes = [V, C.c_char_p, I]
+        lib.ref_ctl_set_previous_control.restype = None; lib.ref_ctl_set_previous_control.argtypes = [V, V, D]
+        lib.ref_ctl_state_feedback.restype = None; lib.ref_ctl_state_feedback.argtypes = [V, V, I, D]
+        lib.ref_ctl_reset.restype = None; lib.ref_ctl_reset.argtypes = [V]
+        lib.ref_ctl_step.restype = I; lib.ref_ctl_step.argtypes = [V, I, V, V, D, D, I, V, V, V, V]
+        lib.ref_ctl_step_two_poses.restype = I; lib.ref_ctl_step_two_poses.argtypes = [V, V, V, V, D, D, I, V, V, V, V]
+        lib.ref_ctl_last_guess.restype = I; lib.ref_ctl_last_guess.argtypes = [V, I, V, V, V]
+        lib.ref_ctl_counters.restype = None; lib.ref_ctl_counters.argtypes = [V, V, V]
+        lib.ref_ctl_result_msg.restype = None; lib.ref_ctl_result_msg.argtypes = [V, V, I, V, V, V, V]
+        lib.ref_ctl_feasible.restype = I; lib.ref_ctl_feasible.argtypes = [V, V, D, D, D, I, I, V, V]
         _lib = lib
     return _lib
 
@@ -219,3 +235,148 @@ def terminal_ball(S, gamma, x, x_ref, diagonal=False):
     out = np.zeros(x.shape[0])
     load().ref_terminal_ball(_p(S), float(gamma), int(diagonal), x.shape[0], _p(x), _p(xr), _p(out))
     return out
+
+
+# ---- the reference's Controller (src/controller.cpp), oracle/ref_wrap_controller.cpp
+def _scalar_tag(v):
+    if isinstance(v, bool):
+        return "b", "1" if v else "0"
+    if isinstance(v, int):
+        return "i", str(v)
+    if isinstance(v, float):
+        return "d", repr(float(v))
+    return "s", str(v)
+
+
+def flatten_params(tree, prefix=""):
+    """a nested parameter dictionary (one namespace of a ROS parameter file) -> the lines of the stand-in parameter store, typed the way a YAML loader types them"""
+    lines = []
+    for k, v in tree.items():
+        key = f"{prefix}{k}"
+        if isinstance(v, dict):
+            lines += flatten_params(v, key + "/")
+            vals = list(v.values())
+            if vals and all(isinstance(x, (int, float)) and not isinstance(x, bool) for x in vals):
+                lines.append(f"{key}\tnm\t" + ",".join(f"{a}:{'i' if isinstance(b, int) else 'd'}:{b!r}" for a, b in v.items()))
+            elif vals and all(isinstance(x, str) for x in vals):
+                lines.append(f"{key}\tsm\t" + ",".join(f"{a}:{b}" for a, b in v.items()))
+        elif isinstance(v, (list, tuple)):
+            if v and all(isinstance(x, bool) for x in v):
+                lines.append(f"{key}\tbl\t" + ",".join("1" if x else "0" for x in v))
+            elif all(isinstance(x, (int, float)) and not isinstance(x, bool) for x in v):
+                lines.append(f"{key}\tnl\t" + ",".join(("i:%d" % x) if isinstance(x, int) else ("d:%r" % float(x)) for x in v))
+        else:
+            t, val = _scalar_tag(v)
+            lines.append(f"{key}\t{t}\t{val}")
+    return lines
+
+
+def probe_configure(params):
+    """the reference's Controller::configure in a forked child: (1 | 0 | 2 = crashed, [(level, text), ...] console lines up to there)"""
+    buf = C.create_string_buffer(1 << 16)
+    r = load().ref_ctl_probe_configure("\n".join(flatten_params(params)).encode(), buf, len(buf))
+    return r, [(int(l.split("|", 1)[0]), l.split("|", 1)[1]) for l in buf.value.decode().splitlines() if "|" in l]
+
+
+_SOLVE_CB = C.CFUNCTYPE(C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double)
+_COST_CB = C.CFUNCTYPE(C.c_double, C.c_double, C.c_double, C.c_double)
+
+
+class RefController:
+    """the reference's Controller, configured from a parameter dictionary; `solver(x (n,3), u (n-1,2), dt, u_prev (2,), dt_prev) -> (x, u, dt, ok)` stands in for the NLP solver
+    and sees the grid exactly as the reference's update() left it"""
+    CAP = 256
+
+    def __init__(self, params, obstacles=(), via_points=(), estimate_orientation=True, solver=None):
+        lib = load()
+        text = "\n".join(flatten_params(params)).encode()
+        ob = np.ascontiguousarray(obstacles, float).reshape(-1, 2); vp = np.ascontiguousarray(via_points, float).reshape(-1, 3)
+        self._h = lib.ref_ctl_create(text, ob.shape[0], _p(ob), vp.shape[0], _p(vp), int(estimate_orientation))
+        self.log = self._log()
+        self.configured = bool(lib.ref_ctl_configured(self._h))
+        self.solver = solver
+        self.guesses = []
+
+        def cb(n, px, pu, pdt, pup, dtp):
+            x = np.ctypeslib.as_array(px, (n, 3)); u = np.ctypeslib.as_array(pu, (n - 1, 2))
+            self.guesses.append((x.copy(), u.copy(), float(pdt[0])))
+            if self.solver is None:
+                return 1
+            xs, us, dts, ok = self.solver(x.copy(), u.copy(), float(pdt[0]), np.array([pup[0], pup[1]]), float(dtp))
+            x[:] = xs; u[:] = us; pdt[0] = dts
+            return 1 if ok else 0
+        self._cb = _SOLVE_CB(cb)
+        lib.ref_ctl_set_solver(self._h, C.cast(self._cb, C.c_void_p))
+
+    def _log(self):
+        buf = C.create_string_buffer(1 << 16)
+        load().ref_ctl_log(buf, len(buf))
+        return [(int(l.split("|", 1)[0]), l.split("|", 1)[1]) for l in buf.value.decode().splitlines() if "|" in l]
+
+    def errors(self):
+        return [t for lv, t in self._log() if lv == 3]
+
+    def warnings(self):
+        return [t for lv, t in self._log() if lv == 2]
+
+    def dump(self):
+        buf = C.create_string_buffer(1 << 16)
+        load().ref_ctl_dump(self._h, buf, len(buf))
+        return dict(l.split("=", 1) for l in buf.value.decode().splitlines() if "=" in l)
+
+    def set_previous_control(self, u, dt):
+        a = np.ascontiguousarray(u, float)
+        load().ref_ctl_set_previous_control(self._h, _p(a), float(dt))
+
+    def state_feedback(self, state, stamp):
+        a = np.ascontiguousarray(state, float)
+        load().ref_ctl_state_feedback(self._h, _p(a), a.size, float(stamp))
+
+    def reset(self):
+        load().ref_ctl_reset(self._h)
+
+    def step(self, plan, vel=(0.0, 0.0, 0.0), dt=0.1, t=0.0, two_pose_overload=False):
+        plan = np.ascontiguousarray(plan, float).reshape(-1, 3); v = np.ascontiguousarray(vel, float)
+        to = np.zeros(self.CAP); xo = np.zeros((self.CAP, 3)); uo = np.zeros((self.CAP, 2)); n = C.c_int(0)
+        if two_pose_overload:
+            a, b = np.ascontiguousarray(plan[0]), np.ascontiguousarray(plan[-1])
+            ok = load().ref_ctl_step_two_poses(self._h, _p(a), _p(b), _p(v), float(dt), float(t), self.CAP, _p(to), _p(xo), _p(uo), C.byref(n))
+        else:
+            ok = load().ref_ctl_step(self._h, plan.shape[0], _p(plan), _p(v), float(dt), float(t), self.CAP, _p(to), _p(xo), _p(uo), C.byref(n))
+        m = n.value
+        return bool(ok), to[:m].copy(), xo[:m].copy(), uo[:m].copy()
+
+    def last_guess(self):
+        x = np.zeros((self.CAP, 3)); u = np.zeros((self.CAP, 2)); dt = np.zeros(1)
+        n = load().ref_ctl_last_guess(self._h, self.CAP, _p(x), _p(u), _p(dt))
+        return x[:n].copy(), u[:n - 1].copy(), float(dt[0])
+
+    def counters(self):
+        c = np.zeros(6, np.int64); d = np.zeros(1)
+        load().ref_ctl_counters(self._h, _p(c), _p(d))
+        return dict(ocp_seq=int(c[0]), resets=int(c[1]), computes=int(c[2]), published=int(c[3]), grid_empty=bool(c[4]), xinit_precomputes=int(c[5]), last_xinit_sample_dt=float(d[0]))
+
+    def result_msg(self):
+        head = np.zeros(9); cap = 3 * self.CAP
+        ts = np.zeros(cap); st = np.zeros(cap); tc = np.zeros(cap); ct = np.zeros(cap)
+        load().ref_ctl_result_msg(self._h, _p(head), cap, _p(ts), _p(st), _p(tc), _p(ct))
+        return {"seq": int(head[0]), "dim_states": int(head[1]), "dim_controls": int(head[2]), "optimal_solution_found": bool(head[3]), "cpu_time": float(head[4]),
+                "time_states": ts[:int(head[5])].copy(), "states": st[:int(head[6])].copy(), "time_controls": tc[:int(head[7])].copy(), "controls": ct[:int(head[8])].copy()}
+
+    def feasible(self, cost, inscribed_radius=0.0, circumscribed_radius=0.0, min_resolution_collision_check_angular=np.pi, look_ahead_idx=-1):
+        """isPoseTrajectoryFeasible on the grid's current trajectory; cost(x, y, theta) -> footprintCost (-1 = collision).  Returns (feasible, poses asked (m,3))"""
+        cb = _COST_CB(lambda x, y, th: float(cost(x, y, th)))
+        calls = np.zeros((4096, 3)); n = C.c_int(0)
+        ok = load().ref_ctl_feasible(self._h, C.cast(cb, C.c_void_p), float(inscribed_radius), float(circumscribed_radius), float(min_resolution_collision_check_angular),
+                                     int(look_ahead_idx), 4096, _p(calls), C.byref(n))
+        return bool(ok), calls[:n.value].copy()
+
+    def close(self):
+        if self._h:
+            load().ref_ctl_destroy(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -3,6 +3,7 @@
 #ifndef PRINT_ERROR_NAMED
 #define PRINT_ERROR_NAMED(msg) do { } while (0)
 #define PRINT_ERROR(msg) do { } while (0)
+#define PRINT_ERROR_COND(cond, msg) do { } while (0)
 #define PRINT_ERROR_COND_NAMED(cond, msg) do { } while (0)
 #define PRINT_WARNING_COND_NAMED(cond, msg) do { } while (0)
 #endif

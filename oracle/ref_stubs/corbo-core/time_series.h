@@ -35,6 +35,9 @@ class TimeSeries {
     void clear() { _time.clear(); _x.clear(); }
     void add(double t, const Eigen::Ref<const Eigen::VectorXd>& x) { _time.push_back(t); _x.push_back(Eigen::VectorXd(x)); _value_dim = x.size(); }
     int getTimeDimension() const { return (int)_time.size(); }
+    bool isEmpty() const { return _time.empty(); }
+    const std::vector<double>& getTime() const { return _time; }
+    std::vector<double> getValues() const { std::vector<double> v; for (const auto& c : _x) for (int i = 0; i < c.size(); ++i) v.push_back(c[i]); return v; }      // dim x N, column-major
     int getValueDimension() const { return _value_dim; }
     const Eigen::VectorXd& getValuesMap(int idx) const { return _x[(size_t)idx]; }
     ValuesMatMap getValuesMatrixView() const { return ValuesMatMap{&_x}; }

@@ -2,6 +2,7 @@
 // (include/mpc_local_planner/optimal_control/full_discretization_grid_base_se2.h) and the types in its signatures, reduced to what
 // src/optimal_control/full_discretization_grid_base_se2.cpp and finite_differences_variable_grid_se2.cpp touch.  No corbo code.
 #pragma once
+#include <functional>
 #include <corbo-core/time_series.h>
 #include <corbo-core/console.h>
 #include <corbo-core/reference_trajectory.h>
@@ -25,8 +26,12 @@ struct NlpFunctions {
         auto fill = [](Eigen::VectorXd& v, int n, double val) { if (v.size() != n) { v = Eigen::VectorXd(n); for (int i = 0; i < n; ++i) v[i] = val; } };
         fill(x_lb, x_dim, -CORBO_INF_DBL); fill(x_ub, x_dim, CORBO_INF_DBL); fill(u_lb, u_dim, -CORBO_INF_DBL); fill(u_ub, u_dim, CORBO_INF_DBL);
     }
-    bool update(int, double, ReferenceTrajectoryInterface&, ReferenceTrajectoryInterface&, ReferenceTrajectoryInterface*, bool, const Eigen::VectorXd&, const std::vector<double>&,
-                const DiscretizationGridInterface*) { return false; }
+    // the per-cycle update of the stage functions: forwarded to whoever registered (the optimal-control-problem stand-in hands it to the stage cost and the
+    // stage inequalities, i.e. the reference's obstacle and via-point association); nobody registered: nothing to do
+    std::function<bool(int, double, ReferenceTrajectoryInterface&, ReferenceTrajectoryInterface&, ReferenceTrajectoryInterface*, bool, const Eigen::VectorXd&, const std::vector<double>&,
+                       const DiscretizationGridInterface*)> on_update;
+    bool update(int n, double t, ReferenceTrajectoryInterface& xref, ReferenceTrajectoryInterface& uref, ReferenceTrajectoryInterface* sref, bool single_dt, const Eigen::VectorXd& x0,
+                const std::vector<double>& dts, const DiscretizationGridInterface* grid) { return on_update ? on_update(n, t, xref, uref, sref, single_dt, x0, dts, grid) : false; }
 };
 struct GridUpdateResult {
     bool vertices_updated = false, edges_updated = false;

@@ -1,0 +1,8 @@
+// ORACLE (test infrastructure only): the fields of geometry_msgs/Pose, PoseStamped, Point, Quaternion
+#pragma once
+namespace geometry_msgs {
+struct Point { double x = 0, y = 0, z = 0; };
+struct Quaternion { double x = 0, y = 0, z = 0, w = 1; };
+struct Pose { Point position; Quaternion orientation; };
+struct PoseStamped { Pose pose; };
+}  // namespace geometry_msgs

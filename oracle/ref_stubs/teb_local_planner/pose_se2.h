@@ -2,11 +2,20 @@
 #pragma once
 #include <Eigen/Core>
 #include <cmath>
+#include <geometry_msgs/Pose.h>
 namespace teb_local_planner {
 class PoseSE2 {
  public:
     PoseSE2() = default;
     PoseSE2(double x, double y, double theta) : _position(x, y), _theta(theta) {}
+    // teb: position from the message, theta = yaw of the quaternion; toPoseMsg writes the yaw back as a rotation about z
+    explicit PoseSE2(const geometry_msgs::Pose& p)
+        : _position(p.position.x, p.position.y),
+          _theta(std::atan2(2.0 * (p.orientation.w * p.orientation.z + p.orientation.x * p.orientation.y), 1.0 - 2.0 * (p.orientation.y * p.orientation.y + p.orientation.z * p.orientation.z))) {}
+    void toPoseMsg(geometry_msgs::Pose& p) const {
+        p.position.x = _position.x(); p.position.y = _position.y(); p.position.z = 0;
+        p.orientation.x = 0; p.orientation.y = 0; p.orientation.z = std::sin(0.5 * _theta); p.orientation.w = std::cos(0.5 * _theta);
+    }
     Eigen::Vector2d& position() { return _position; }
     const Eigen::Vector2d& position() const { return _position; }
     double& x() { return _position.x(); }
@@ -21,3 +30,13 @@ class PoseSE2 {
     double _theta = 0;
 };
 }  // namespace teb_local_planner
+namespace g2o {      // teb's pose_se2.h pulls g2o/stuff/misc.h: the angle wrap to [-pi, pi) the reference calls once (src/controller.cpp:906)
+inline double normalize_theta(double theta) {
+    if (theta >= -M_PI && theta < M_PI) return theta;
+    double multiplier = std::floor(theta / (2 * M_PI));
+    theta = theta - multiplier * 2 * M_PI;
+    if (theta >= M_PI) theta -= 2 * M_PI;
+    if (theta < -M_PI) theta += 2 * M_PI;
+    return theta;
+}
+}  // namespace g2o

@@ -218,6 +218,24 @@ def main():
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_costs.npz"), **c)
     print("written cost vectors:", S4, "trajectories")
 
+    # ---- the reference's Controller::configure (src/controller.cpp:58-100, :225-805) on the parameter dictionaries of configure_cases.py: what it built, what it
+    # logged, and whether it returned, returned false or crashed (oracle/ref_wrap_controller.cpp)
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import configure_cases
+    rec = {}
+    for name, params in configure_cases.cases().items():
+        status, log = RL.probe_configure(params)
+        entry = {"status": status, "errors": [t for lv, t in log if lv == 3], "warnings": [t for lv, t in log if lv == 2]}
+        if status == 1:
+            ctl = RL.RefController(params)
+            entry["built"] = ctl.dump()
+            ctl.close()
+        rec[name] = entry
+    with open(os.path.join(ROOT, "tests", "golden", "ref_configure.json"), "w") as f:
+        json.dump(rec, f, indent=1, sort_keys=True)
+    print("written configure records:", len(rec), "parameter sets,", sum(1 for e in rec.values() if e["status"] == 2), "of them crash the reference")
+
 
 if __name__ == "__main__":
     main()

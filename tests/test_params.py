@@ -350,3 +350,152 @@ def test_cpp_reader_gives_the_same_verdicts(cpp):
         with pytest.raises(P.ParamNotImplemented):
             P.config_from_params(tree)
         assert _cpp_config(cpp, tree)[0] == 2
+
+
+# ---- held to the REFERENCE's own Controller::configure, compiled and executed (oracle/ref_wrap_controller.cpp; tests/golden/make_ref_vectors.py ran it on every
+# parameter set of tests/golden/configure_cases.py and recorded what it built in tests/golden/ref_configure.json) -----------------------------------------------------
+import json
+import sys
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import configure_cases      # noqa: E402
+
+REF_CONFIGURE = json.load(open(os.path.join(HERE, "golden", "ref_configure.json")))
+REF_MODELS = {0: "unicycle", 1: "simple_car", 2: "simple_car_front_wheel_driving", 3: "kinematic_bicycle_vel_input"}
+REF_COLLOC = {0: "forward_differences", 1: "midpoint_differences", 2: "crank_nicolson_differences"}
+
+
+def _sym(diag, off, dim):
+    m = np.diag(np.array(list(diag)[:dim], float))
+    if dim == 3:
+        m[0, 1], m[0, 2], m[1, 2] = off
+        m[1, 0], m[2, 0], m[2, 1] = off
+    else:
+        m[0, 1] = m[1, 0] = off
+    return m
+
+
+def _nums(text):
+    return np.array([float(x) for x in text.split(",")]) if text else np.zeros(0)
+
+
+def _unbounded(v):
+    v = np.asarray(v, float)
+    return np.where(np.abs(v) >= 1e29, np.sign(v) * np.inf, v)         # "no limit": corbo's 2e30 there, 1e30 here
+
+
+def _held_to_reference(cfg, ctrl, built):
+    """every setting Controller::configure put into the objects it built, against the mpc_config / facade options made from the same parameters"""
+    def same(name, ours, ref):
+        ok = (ours == ref) if isinstance(ours, str) else np.array_equal(np.asarray(ours, float), np.asarray(ref, float))
+        assert ok, (name, ours, ref)
+    sym_of = lambda key, dim: (lambda m: 0.5 * (m + m.T))(_nums(built[key]).reshape(dim, dim))
+    same("model", REF_MODELS[cfg.model], built["model"])
+    if cfg.model in (1, 2):
+        same("wheelbase", cfg.model_params[0], float(built["wheelbase"]))
+    if cfg.model == 3:
+        same("length_rear", cfg.model_params[0], float(built["length_rear"])); same("length_front", cfg.model_params[1], float(built["length_front"]))
+    same("variable_grid", cfg.dt_free, int(built["variable_grid"]))
+    same("grid_size_ref", cfg.n, int(built["n_ref"])); same("dt_ref", cfg.dt_ref, float(built["dt_ref"])); same("warm_start", ctrl["warm_start"], int(built["warm_start"]))
+    if cfg.dt_free:
+        same("min_dt", cfg.dt_lb, float(built["dt_lb"])); same("max_dt", cfg.dt_ub, float(built["dt_ub"]))
+    same("xf_fixed", list(cfg.xf_fixed), _nums(built["xf_fixed"]))
+    same("collocation", REF_COLLOC[cfg.collocation], built["collocation"])
+    same("grid_adaptation", ctrl["grid_adaptation"], int(built.get("grid_adaptation", 0)))
+    if ctrl["grid_adaptation"]:
+        same("max_grid_size", ctrl["max_grid_size"], int(built["n_max"])); same("min_grid_size", ctrl["min_grid_size"], int(built["n_min"]))
+        same("dt_hyst_ratio", ctrl["dt_hyst_ratio"], float(built["dt_hyst_ratio"]))
+    same("iterations", cfg.max_iter, int(built.get("ipopt_integer.max_iter", built["iterations"])))
+    if "ipopt_numeric.tol" in built:
+        same("tol", cfg.tol, float(built["ipopt_numeric.tol"]))
+    same("u_lb", list(cfg.u_lb), _nums(built["u_lb"])); same("u_ub", list(cfg.u_ub), _nums(built["u_ub"]))
+    same("du_lb", _unbounded(list(cfg.du_lb)), _unbounded(_nums(built["du_lb"]))); same("du_ub", _unbounded(list(cfg.du_ub)), _unbounded(_nums(built["du_ub"])))
+    Q, Rm = _sym(cfg.Q, tuple(cfg.Q_offdiag), 3), _sym(cfg.R, cfg.R_offdiag, 2)
+    if cfg.objective == A.OBJ_MIN_TIME:
+        stage = "MinimumTime"
+    elif cfg.objective == A.OBJ_MIN_TIME_VIA_POINTS:
+        stage = "MinTimeViaPointsCost"
+    else:       # which corbo / SE(2) cost class the weights select (src/controller.cpp:598-624)
+        stage = ("MinTimeQuadraticControls" if cfg.hybrid_cost_minimum_time else "QuadraticFormCostSE2" if Q.any() and Rm.any() else "QuadraticStateCostSE2" if Q.any()
+                 else "QuadraticControlCost" if Rm.any() else "none")
+    same("stage cost", stage, built["stage_cost"])
+    if "Q" in built:
+        same("Q", Q, sym_of("Q", 3))
+    if "R" in built:
+        same("R", Rm, sym_of("R", 2))
+    if "integral_form" in built:
+        same("integral_form", cfg.integral_form, int(built["integral_form"]))
+        if cfg.integral_form:
+            same("cost_integration", "trapezoidal_rule" if cfg.cost_integration else "left_sum", built["cost_integration"])
+    if stage == "MinTimeViaPointsCost":
+        same("via_points_ordered", cfg.via_points_ordered, int(built["via_points_ordered"])); same("position_weight", cfg.vp_position_weight, float(built["vp_position_weight"]))
+        same("orientation_weight", cfg.vp_orientation_weight, float(built["vp_orientation_weight"]))
+    same("terminal cost", "QuadraticFinalStateCostSE2" if cfg.has_Qf else "none", built["final_stage_cost"])
+    if cfg.has_Qf:
+        same("Qf", _sym(cfg.Qf, tuple(cfg.Qf_offdiag), 3), sym_of("Qf", 3))
+    same("terminal constraint", "TerminalBallSE2" if cfg.terminal_ball else "none", built["final_stage_constraint"])
+    if cfg.terminal_ball:
+        same("S", _sym(cfg.terminal_ball_S, tuple(cfg.terminal_ball_S_offdiag), 3), sym_of("S", 3)); same("radius", cfg.terminal_ball_gamma, float(built["gamma"]))
+    for k in ("min_obstacle_dist", "force_inclusion_dist", "cutoff_dist"):
+        same(k, getattr(cfg, k), float(built[k]))
+    same("enable_dynamic_obstacles", cfg.enable_dynamic_obstacles, int(built["enable_dynamic_obstacles"]))
+    for k in ("outer_ocp_iterations", "force_reinit_new_goal_dist", "force_reinit_new_goal_angular", "allow_init_with_backward_motion", "force_reinit_num_steps", "prefer_x_feedback",
+              "publish_ocp_results", "print_cpu_time"):
+        same(k, ctrl[k], float(built[k]))
+    assert built["auto_update_previous_control"] == "0"         # src/controller.cpp:90: the caller hands the previous control over (setPreviousControlInput)
+
+
+NOT_BUILT = {"lsq_lm_solver", "unknown_collocation"}      # the reference configures; this path says what it lacks instead of solving a different problem
+
+
+@pytest.mark.parametrize("name", sorted(REF_CONFIGURE))
+def test_parameter_translation_reproduces_what_the_reference_s_configure_built(name):
+    """keys, in-code defaults, roscpp's type conversions, sign fix-ups, the cost class chosen from which weights vanish, column-major weight matrices, "<= 0 means no
+    rate limit", and the verdicts.  Where the reference returns false, ParamError carries its reason; where it CRASHES (every `return {}` of configureOcp ends in
+    `_ocp->initialize()` on an empty pointer, src/controller.cpp:97) ParamError carries the reason it logged just before."""
+    params, rec = configure_cases.cases()[name], REF_CONFIGURE[name]
+    if rec["status"] != 1:
+        with pytest.raises(P.ParamError) as e:
+            P.config_from_params(params)
+        assert str(e.value) == rec["errors"][0]
+        return
+    if name in NOT_BUILT:
+        with pytest.raises(P.ParamNotImplemented):
+            P.config_from_params(params)
+        return
+    cfg, ctrl, notes = P.config_from_params(params)
+    _held_to_reference(cfg, ctrl, rec["built"])
+    for w in rec["warnings"]:             # the reference's warnings reappear as notes ('"max_vel_x_backwards must be >= 0"')
+        assert any(w.strip('"').split(" must")[0] in n for n in notes), (w, notes)
+
+
+def test_reference_configure_records_cover_every_verdict():
+    st = [r["status"] for r in REF_CONFIGURE.values()]
+    assert st.count(1) >= 38 and st.count(0) >= 3 and st.count(2) >= 8
+    # `tol: 1e-4` read by a YAML 1.1 loader is text: the reference's numeric option map stays empty (no ipopt_numeric.* entry), the package honours the intent and says so
+    built = REF_CONFIGURE["carlike_numeric_option_as_text"]["built"]
+    assert not any(k.startswith("ipopt_numeric.") for k in built)
+    cfg, _, notes = P.config_from_params(configure_cases.cases()["carlike_numeric_option_as_text"])
+    assert cfg.tol == 1e-4 and any("roscpp rejects the whole map" in n for n in notes)
+    assert float(REF_CONFIGURE["carlike_numeric_options"]["built"]["ipopt_numeric.tol"]) == 1e-4
+
+
+@pytest.mark.parametrize("name", sorted(REF_CONFIGURE))
+def test_cpp_reader_on_the_reference_s_configure_cases(cpp, name):
+    """include/mpc_params.hpp gives the same verdict and the same mpc_config / facade options as the Python reader on every recorded parameter set"""
+    params, rec = configure_cases.cases()[name], REF_CONFIGURE[name]
+    st, cfg, opt, rep = _cpp_config(cpp, params)
+    if rec["status"] != 1:
+        assert st == 1 and rep.split("\n")[0] == rec["errors"][0]
+        return
+    if name in NOT_BUILT:
+        assert st == 2
+        return
+    assert st == 0, rep
+    py_cfg, py_ctrl, _ = P.config_from_params(params)
+    for field in SCALARS:
+        assert getattr(cfg, field) == getattr(py_cfg, field), field
+    for field in ARRAYS:
+        assert list(getattr(cfg, field)) == list(getattr(py_cfg, field)), field
+    for k, v in py_ctrl.items():
+        assert opt[k] == float(v), k
+    _held_to_reference(cfg, {k: opt[k] for k in py_ctrl}, rec["built"])
