@@ -72,8 +72,10 @@ inline void interpolate_se2(const std::vector<double>& times, const std::vector<
 // Controller::generateInitialStateTrajectory (src/controller.cpp:807-857) followed by the sampling of
 // initializeSequences(xinit) (full_discretization_grid_base_se2.cpp:192-239): fills x_init[n][3].
 // NOTE: `backward` has no effect in the reference (the result of normalize_theta(yaw + pi) is discarded at :841).
+// dt_sample: the spacing the trajectory is sampled at, dt_ref unless the caller reproduces the reference's re-initialisation (Controller::step below)
 inline void initial_state_trajectory(const std::vector<PoseSE2>& plan, const double x0[3], const double xf[3], int n, double dt_ref,
-                                     bool estimate_orientation, double* x_init) {
+                                     bool estimate_orientation, double* x_init, double dt_sample = -1.0) {
+    if (dt_sample <= 0.0) dt_sample = dt_ref;
     const int np = (int)plan.size();
     std::vector<double> times, vals;
     times.push_back(0.0); vals.insert(vals.end(), x0, x0 + 3);
@@ -89,7 +91,7 @@ inline void initial_state_trajectory(const std::vector<PoseSE2>& plan, const dou
     }
     times.push_back(tf); vals.insert(vals.end(), xf, xf + 3);
     for (int i = 0; i < 3; ++i) x_init[i] = x0[i];
-    for (int k = 1; k < n - 1; ++k) interpolate_se2(times, vals, k * dt_ref, &x_init[3 * k]);
+    for (int k = 1; k < n - 1; ++k) interpolate_se2(times, vals, k * dt_sample, &x_init[3 * k]);
     for (int i = 0; i < 3; ++i) x_init[3 * (n - 1) + i] = xf[i];
 }
 
@@ -211,6 +213,12 @@ class Controller {
     }
     void setWarmStart(bool w) { _warm_start = w; }      // grid/warm_start (src/controller.cpp:294-296)
     void setNumOcpIterations(int n) { _num_ocp_iterations = n < 1 ? 1 : n; }      // controller/outer_ocp_iterations (src/controller.cpp:70-72)
+    // The reference samples the initial state trajectory at the grid's CURRENT dt (full_discretization_grid_base_se2.cpp:61-65: precompute(getDt(), ...)), and
+    // clear() does not put dt back to dt_ref (:526-536).  So on the variable grid every re-initialisation AFTER a first solve (goal jump, reset(), force_reinit_num_steps)
+    // samples the plan at the LAST OPTIMISED dt while the plan's time axis still spans (n_ref - 1) dt_ref: a guess that is compressed (dt < dt_ref) or runs into the
+    // goal early (dt > dt_ref).  Seen by executing the reference's Controller (oracle/ref_wrap_controller.cpp).  true (default): reproduce it, so that re-initialised
+    // solves start where the reference's do; false: always sample at dt_ref.
+    void setReferenceReinitSampling(bool on) { _reference_reinit_sampling = on; }
     int gridSize() const { return _n_cur; }
 
     // Controller::stateFeedbackCallback (src/controller.cpp:181-195) + controller/prefer_x_feedback (:82): a measured state that is younger than
@@ -270,8 +278,9 @@ class Controller {
         const double* xi = nullptr; const double* ui = nullptr; const double* di = nullptr;
         if (_grid_empty) {
             _n_cur = _n_ref;
-            if (plan.size() > 2) {      // a 2-pose plan is the device-side cold start
-                initial_state_trajectory(plan, x0, xf, _n_cur, _cfg.dt_ref, _initial_plan_estimate_orientation, _xi.data());
+            const double dt_sample = (_reference_reinit_sampling && _have_solution && _cfg.dt_free && _dt_sol > 0.0) ? _dt_sol : _cfg.dt_ref;
+            if (plan.size() > 2 || dt_sample != _cfg.dt_ref) {      // a 2-pose plan sampled at dt_ref is the device-side cold start
+                initial_state_trajectory(plan, x0, xf, _n_cur, _cfg.dt_ref, _initial_plan_estimate_orientation, _xi.data(), dt_sample);
                 std::fill(_ui.begin(), _ui.end(), 0.0);
                 _dti = _cfg.dt_ref;
                 xi = _xi.data(); ui = _ui.data(); di = &_dti;
@@ -296,6 +305,7 @@ class Controller {
         const int rc = mpc_solve_batch(_h, 1, x0, xf, _u_prev, &_dt_prev, xi, ui, di, _obst, _x.data(), _u.data(), &_dt_sol, &status, &iters);
         if (rc != MPC_OK) { _last_error = mpc_last_error(); return false; }
         _grid_empty = false;
+        _have_solution = true;
         }
         _last_iterations = iters;
         _ocp_successful = status == MPC_CONVERGED;
@@ -314,7 +324,8 @@ class Controller {
 
     // Controller::publishOptimalControlResult (src/controller.cpp:197-221) without the publisher: the message of the last step()
     void optimalControlResult(const TimeSeries& x_seq, const TimeSeries& u_seq, OptimalControlResult& msg) const {
-        fill_optimal_control_result(x_seq, u_seq, _ocp_successful, _last_step_time, (uint32_t)_ocp_seq, msg);
+        // header.seq = _ocp_seq BEFORE step() increments it (:163 publishes, :165 ++_ocp_seq): the first step's message carries 0 (executed: tests/golden/ref_feasibility_and_result.npz)
+        fill_optimal_control_result(x_seq, u_seq, _ocp_successful, _last_step_time, (uint32_t)(_ocp_seq > 0 ? _ocp_seq - 1 : 0), msg);
     }
 
     // Controller::isPoseTrajectoryFeasible (src/controller.cpp:859-917) of the trajectory the last step() planned, against the local
@@ -351,6 +362,7 @@ class Controller {
     double _dt_prev = 0;
     const mpc_obstacles* _obst = nullptr;
     bool _grid_empty = true;
+    bool _have_solution = false, _reference_reinit_sampling = true;
     bool _ocp_successful = false;
     int _ocp_seq = 0;
     int _last_iterations = 0;

@@ -97,8 +97,13 @@ def footprint_cost(cost, resolution, origin, x, y, theta, spec):
     return worst
 
 
-def is_pose_trajectory_feasible(cost, resolution, origin, x, spec, inscribed_radius, min_resolution_collision_check_angular, look_ahead_idx=-1):
-    """cost (size_y, size_x) uint8, x (n, 3) planned states.  src/controller.cpp:859-917."""
+def is_pose_trajectory_feasible(cost, resolution, origin, x, spec, inscribed_radius, min_resolution_collision_check_angular, look_ahead_idx=-1, pose_cost=None):
+    """cost (size_y, size_x) uint8, x (n, 3) planned states.  src/controller.cpp:859-917.  pose_cost(x, y, theta): replaces the costmap lookup (the poses asked
+    and the early exit are PINNED to the executed reference with it: tests/test_reference_pinned.py)"""
+    if pose_cost is not None:
+        footprint_cost = lambda _c, _r, _o, px, py, pth, _s: pose_cost(px, py, pth)      # noqa: E731
+    else:
+        footprint_cost = globals()["footprint_cost"]
     n = x.shape[0]
     if n < 2:
         return False

@@ -12,7 +12,8 @@ the clearance rows of point obstacles (static and moving), the control-rate rows
 via-point association and terms, the quadratic cost terms / final-state cost / terminal-ball row,
 and the grid handling (cold start, nearest state, warm-start
 shifting, resampling, single-step adaptation, closest pose, time series, TimeSeriesSE2
-interpolation -- bit for bit):
+interpolation -- bit for bit).  The controller logic around it (src/controller.cpp) is executed too and
+holds the parameter readers, the C++ facade and oracle/feasibility.py (tests/test_params.py, test_reference_pinned.py):
 the reference's own sources for these compile here against interface stand-ins
 (oracle/ref_wrap.cpp, ref_wrap_rows.cpp, ref_wrap_grid.cpp, ref_wrap_cost.cpp -> oracle/_ref), their outputs are recorded
 in tests/golden/ref_models_collocation.npz / ref_stage_inequality.npz / ref_via_points.npz / ref_grid.npz / ref_costs.npz and

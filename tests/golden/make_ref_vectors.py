@@ -236,6 +236,85 @@ def main():
         json.dump(rec, f, indent=1, sort_keys=True)
     print("written configure records:", len(rec), "parameter sets,", sum(1 for e in rec.values() if e["status"] == 2), "of them crash the reference")
 
+    # ---- the reference's Controller::step in closed loop (src/controller.cpp:102-179, :807-857 + the grid's update()), a stand-in solver plugged in: what it hands to the
+    # solver and what it returns, step by step (controller_scenarios.py)
+    import controller_scenarios as CS
+    from mpc_local_planner_amd import params as PP
+    steps = {}
+    for vname, prm in CS.variants().items():
+        cfg = PP.config_from_params(prm)[0]
+        for seed in (0, 1):
+            rng = np.random.default_rng(4000 + seed)
+            state = dict(calls=0, dt_factor=1.0, free_dt=bool(cfg.dt_free), fixed=[bool(f) for f in cfg.xf_fixed], fail_at={17, 60})
+            ref = RL.RefController(prm, solver=lambda *a, st=state: CS.stand_in_solver(*a, st))
+            assert ref.configured
+            pose, goal, t, dtc, u_last = np.array([0.0, 0.0, 0.3]), np.array([3.0, 1.0, 0.5]), 0.0, 0.1, np.zeros(2)
+            K = CS.STEPS
+            r = dict(plan=np.zeros((K, 5, 3)), n_plan=np.zeros(K, np.int32), reset=np.zeros(K, np.int32), fb=np.full((K, 4), np.nan), factor=np.zeros(K), t=np.zeros(K), u_prev=np.zeros((K, 2)),
+                     ok=np.zeros(K, np.int32), n_guess=np.zeros(K, np.int32), guess_x=np.zeros((K, CS.NMAX, 3)), guess_u=np.zeros((K, CS.NMAX, 2)), guess_dt=np.zeros(K),
+                     n_out=np.zeros(K, np.int32), out_t=np.zeros((K, CS.NMAX)), out_x=np.zeros((K, CS.NMAX, 3)), out_u=np.zeros((K, CS.NMAX, 2)), xinit_sample_dt=np.zeros(K))
+            for i in range(K):
+                goal, reset, fb, factor, plan = CS.next_event(rng, pose, goal, t)
+                if reset: ref.reset()
+                if fb is not None: ref.state_feedback(fb[0], fb[1]); r["fb"][i] = (*fb[0], fb[1])
+                state["dt_factor"] = factor
+                ref.set_previous_control(u_last, dtc)
+                ok, to, xo, uo = ref.step(plan, (0.1, 0.0, 0.05), dtc, t)
+                gx, gu, gdt = ref.last_guess()
+                n, m = gx.shape[0], xo.shape[0]
+                r["plan"][i, :plan.shape[0]] = plan; r["n_plan"][i] = plan.shape[0]; r["reset"][i] = reset; r["factor"][i] = factor; r["t"][i] = t; r["u_prev"][i] = u_last
+                r["ok"][i] = ok; r["n_guess"][i] = n; r["guess_x"][i, :n] = gx; r["guess_u"][i, :n - 1] = gu; r["guess_dt"][i] = gdt
+                r["n_out"][i] = m; r["out_t"][i, :m] = to; r["out_x"][i, :m] = xo; r["out_u"][i, :m] = uo; r["xinit_sample_dt"][i] = ref.counters()["last_xinit_sample_dt"]
+                u_last = uo[0].copy(); pose = xo[1].copy(); t += dtc
+            ref.close()
+            for k_, v_ in r.items(): steps[f"{vname}/{seed}/{k_}"] = v_
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_controller_steps.npz"), **steps)
+    print("written controller step records:", len(CS.variants()), "parameter sets x 2 scripts x", CS.STEPS, "steps")
+
+    # ---- Controller::isPoseTrajectoryFeasible (src/controller.cpp:859-917): the poses it asks the costmap model about, with and without a collision on the way; and the
+    # OptimalControlResult it publishes (:197-221)
+    rng = np.random.default_rng(20260930)
+    prm = configure_cases.base_carlike()
+    prm["controller"]["publish_ocp_results"] = True; prm["controller"]["outer_ocp_iterations"] = 1
+    prm["grid"]["variable_grid"]["grid_adaptation"]["enable"] = False
+    F3, NF, CF = 40, 24, 400
+    fz = dict(n=np.zeros(F3, np.int32), x=np.zeros((F3, NF, 3)), par=np.zeros((F3, 3)), n_calls=np.zeros(F3, np.int32), calls=np.zeros((F3, CF, 3)), hit_at=np.zeros(F3, np.int32),
+              hit_feasible=np.zeros(F3, np.int32), hit_calls=np.zeros(F3, np.int32), feasible=np.zeros(F3, np.int32))
+    msg = {}
+    for s_ in range(F3):
+        n = int(rng.integers(3, NF + 1))
+        traj = np.cumsum(rng.uniform(-0.05, 0.3, (n, 3)), 0); traj[:, 2] = RL.normalize_theta(rng.uniform(-pi, pi) + np.cumsum(rng.uniform(-0.4, 0.6, n)))
+        prm["grid"]["grid_size_ref"] = n
+        holder = {}
+
+        def put(x, u, dt, up, dtp, traj=traj):
+            xs = traj.copy(); xs[0] = x[0]
+            return xs, u + 0.1, 0.2, True
+        ctl = RL.RefController(prm, solver=put)
+        ok, to, xo, uo = ctl.step(np.stack([traj[0], traj[-1]]), (0, 0, 0), 0.1, 0.0)
+        assert ok and xo.shape[0] == n
+        look = -1 if s_ % 3 else int(rng.integers(0, n + 2))
+        r_in, ang = float(rng.uniform(0.08, 0.5)), float(rng.uniform(0.1, 0.6))
+        feas, calls = ctl.feasible(lambda x, y, th: 0.0, inscribed_radius=r_in, min_resolution_collision_check_angular=ang, look_ahead_idx=look)
+        hit = int(rng.integers(0, calls.shape[0]))
+        cnt = [0]
+
+        def blocked(x, y, th, cnt=cnt, hit=hit):
+            cnt[0] += 1
+            return -1.0 if cnt[0] - 1 == hit else (-2.0 if cnt[0] % 5 == 0 else 3.0)       # -2 / -3 (unknown, outside) do not stop the check, only -1 does
+        feas2, calls2 = ctl.feasible(blocked, inscribed_radius=r_in, min_resolution_collision_check_angular=ang, look_ahead_idx=look)
+        fz["n"][s_] = n; fz["x"][s_, :n] = xo; fz["par"][s_] = (r_in, ang, look); fz["n_calls"][s_] = calls.shape[0]; fz["calls"][s_, :calls.shape[0]] = calls
+        fz["feasible"][s_] = feas; fz["hit_at"][s_] = hit; fz["hit_feasible"][s_] = feas2; fz["hit_calls"][s_] = calls2.shape[0]
+        if s_ == 0:
+            m = ctl.result_msg()
+            msg = {"msg_" + k: np.atleast_1d(np.asarray(v, float)) for k, v in m.items()}
+            ctl.step(np.stack([traj[0], traj[-1]]), (0, 0, 0), 0.1, 0.1)
+            msg["msg_seq_second_step"] = np.array([ctl.result_msg()["seq"]], float)
+            msg["msg_x"], msg["msg_u"], msg["msg_t"] = xo, uo, to
+        ctl.close()
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_feasibility_and_result.npz"), **fz, **msg)
+    print("written feasibility-check records:", F3, "trajectories; result message of step 0")
+
 
 if __name__ == "__main__":
     main()

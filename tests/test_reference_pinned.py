@@ -431,3 +431,160 @@ def test_reference_form_objective_is_the_sum_of_the_reference_s_terms(diagonal, 
         assert abs(J - ref) < 1e-12 * max(1.0, abs(ref)), (i, J, ref)
         g = nlp.inequalities(z)
         assert abs(g[-1] - CO["ball" + sfx][i, n - 1]) < 1e-13 * max(1.0, abs(g[-1]))
+
+
+# ---- Controller::step of the reference (src/controller.cpp:102-179, :807-857), executed in closed loop with a stand-in solver (oracle/ref_wrap_controller.cpp), against
+# the shipped facade (include/mpc_controller.hpp) driven through the same script with the same stand-in (tests/host_harness/facade_step_host.cpp records what the
+# facade hands to mpc_solve_batch).  Recorded: tests/golden/ref_controller_steps.npz (generator: make_ref_vectors.py + controller_scenarios.py)
+import sys
+sys.path.insert(0, os.path.join(HERE, "golden"))
+import controller_scenarios as CS      # noqa: E402
+
+STEPS_REC = np.load(os.path.join(HERE, "golden", "ref_controller_steps.npz"))
+OPT_NAMES = ["grid_adaptation", "max_grid_size", "dt_hyst_ratio", "min_grid_size", "n_max", "warm_start", "outer_ocp_iterations", "force_reinit_new_goal_dist",
+             "force_reinit_new_goal_angular", "allow_init_with_backward_motion", "force_reinit_num_steps", "prefer_x_feedback", "publish_ocp_results", "print_cpu_time"]
+_SOLVER_CB = C.CFUNCTYPE(C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_double)
+
+
+@pytest.fixture(scope="module")
+def facade_lib():
+    src = os.path.join(HERE, "host_harness", "facade_step_host.cpp")
+    out = os.path.join(HERE, "host_harness", "_build", "libfacade_step.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    # -Bsymbolic: the recorder's own mpc_* definitions must win even when the product library was loaded globally earlier in the session
+    subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wl,-Bsymbolic", src, "-o", out], check=True)
+    lib = C.CDLL(out)
+    V, D, I = C.c_void_p, C.c_double, C.c_int
+    lib.fs_create.restype = V; lib.fs_create.argtypes = [V, V, I]
+    lib.fs_destroy.argtypes = [V]; lib.fs_set_solver.argtypes = [V]; lib.fs_reset.argtypes = [V]
+    lib.fs_set_previous_control.argtypes = [V, V, D]; lib.fs_state_feedback.argtypes = [V, V, D]
+    lib.fs_step.restype = I; lib.fs_step.argtypes = [V, I, V, V, D, D, I, V, V, V, V]
+    lib.fs_last_guess.restype = I; lib.fs_last_guess.argtypes = [I, V, V, V, V]
+    lib.fs_result_msg.restype = None; lib.fs_result_msg.argtypes = [V, I] + [V] * 8
+    return lib
+
+
+class _Facade:
+    def __init__(self, lib, params, solver, reference_reinit_sampling=True):
+        from mpc_local_planner_amd import params as PP
+        self.lib = lib
+        self.cfg, ctrl, _ = PP.config_from_params(params)
+        opt = np.array([float(ctrl.get(k, 0)) for k in OPT_NAMES])
+        self.h = lib.fs_create(C.byref(self.cfg), opt.ctypes.data_as(C.c_void_p), 1)
+        assert self.h
+
+        def cb(n, px, pu, pdt, pup, dtp):
+            x = np.ctypeslib.as_array(px, (n, 3)); u = np.ctypeslib.as_array(pu, (n - 1, 2))
+            xs, us, dts, ok = solver(x.copy(), u.copy(), float(pdt[0]), np.array([pup[0], pup[1]]), float(dtp))
+            x[:] = xs; u[:] = us; pdt[0] = dts
+            return 1 if ok else 0
+        self._cb = _SOLVER_CB(cb)
+
+    def step(self, plan, u_prev, dt, t):
+        p = lambda a: a.ctypes.data_as(C.c_void_p)
+        self.lib.fs_set_solver(C.cast(self._cb, C.c_void_p))
+        up = np.ascontiguousarray(u_prev, float); self.lib.fs_set_previous_control(self.h, p(up), dt)
+        plan = np.ascontiguousarray(plan, float); vel = np.array([0.1, 0.0, 0.05])
+        to, xo, uo, n = np.zeros(256), np.zeros((256, 3)), np.zeros((256, 2)), C.c_int(0)
+        ok = self.lib.fs_step(self.h, plan.shape[0], p(plan), p(vel), dt, t, 256, p(to), p(xo), p(uo), C.byref(n))
+        gx, gu, gdt, cold = np.zeros((256, 3)), np.zeros((256, 2)), np.zeros(1), C.c_int(0)
+        m = self.lib.fs_last_guess(256, p(gx), p(gu), p(gdt), C.byref(cold))
+        return bool(ok), to[:n.value].copy(), xo[:n.value].copy(), uo[:n.value].copy(), gx[:m].copy(), gu[:m - 1].copy(), float(gdt[0])
+
+    def close(self):
+        self.lib.fs_destroy(self.h)
+
+
+@pytest.mark.parametrize("variant", sorted(CS.variants()))
+@pytest.mark.parametrize("script", [0, 1])
+def test_controller_facade_steps_like_the_reference_s_controller(facade_lib, variant, script):
+    """per control cycle: the state the cycle starts from (odometry pose, or a fresh state measurement with prefer_x_feedback), the re-initialisation decision (goal jump in
+    distance / heading, reset(), force_reinit_num_steps), the initial state trajectory from plans of 2..5 poses (intermediate headings from the direction of travel) sampled
+    as the reference samples it -- INCLUDING the stale-dt sampling of a re-initialisation after a first solve --, warm-start shifting on the fixed grid, single-step grid
+    adaptation on every outer iteration, outer_ocp_iterations, the previous control handed over, and the time series given back: vertex values handed to the solver and
+    results agree with the recorded run of the reference's Controller to 1e-12 at every one of 40 steps"""
+    prm = CS.variants()[variant]
+    key = lambda k: STEPS_REC[f"{variant}/{script}/{k}"]
+    from mpc_local_planner_amd import params as PP
+    cfg = PP.config_from_params(prm)[0]
+    state = dict(calls=0, dt_factor=1.0, free_dt=bool(cfg.dt_free), fixed=[bool(f) for f in cfg.xf_fixed], fail_at={17, 60})
+    fac = _Facade(facade_lib, prm, lambda *a: CS.stand_in_solver(*a, state))
+    reinit_with_stale_dt = 0
+    for i in range(CS.STEPS):
+        if key("reset")[i]:
+            facade_lib.fs_reset(fac.h)
+        fb = key("fb")[i]
+        if not np.isnan(fb[0]):
+            s3 = np.ascontiguousarray(fb[:3]); facade_lib.fs_state_feedback(fac.h, s3.ctypes.data_as(C.c_void_p), float(fb[3]))
+        state["dt_factor"] = float(key("factor")[i])
+        plan = key("plan")[i, :int(key("n_plan")[i])]
+        ok, to, xo, uo, gx, gu, gdt = fac.step(plan, key("u_prev")[i], 0.1, float(key("t")[i]))
+        n, m = int(key("n_guess")[i]), int(key("n_out")[i])
+        assert gx.shape[0] == n and xo.shape[0] == m, (i, gx.shape, n)
+        assert np.abs(gx - key("guess_x")[i, :n]).max() < 1e-12 and np.abs(gu - key("guess_u")[i, :n - 1]).max() < 1e-12 and abs(gdt - key("guess_dt")[i]) < 1e-15, i
+        assert ok == bool(key("ok")[i]), i
+        assert np.abs(xo - key("out_x")[i, :m]).max() < 1e-12 and np.abs(uo - key("out_u")[i, :m]).max() < 1e-12 and np.abs(to - key("out_t")[i, :m]).max() < 1e-12, i
+        reinit_with_stale_dt += int(abs(key("xinit_sample_dt")[i] - cfg.dt_ref) > 1e-6)
+    assert state["calls"] >= CS.STEPS
+    if cfg.dt_free:
+        assert reinit_with_stale_dt > 0          # the script contains re-initialisations after a solve: the reference sampled its plan at the last optimised dt
+    fac.close()
+
+
+FZ = np.load(os.path.join(HERE, "golden", "ref_feasibility_and_result.npz"))
+
+
+def test_feasibility_check_asks_about_the_same_poses_as_the_reference():
+    """Controller::isPoseTrajectoryFeasible (src/controller.cpp:859-917), executed with a recording costmap model: every grid point up to look_ahead_idx (out-of-range:
+    all), between neighbours farther apart than the inscribed radius or turning more than min_resolution_collision_check_angular the accumulated intermediate poses;
+    only an answer of -1 ends the check (-2 / -3 do not).  oracle/feasibility.py asks about the same poses in the same order and stops at the same call."""
+    from oracle import feasibility as FE
+    interpolated = 0
+    for i in range(FZ["n"].shape[0]):
+        n = int(FZ["n"][i]); x = FZ["x"][i, :n]
+        r_in, ang, look = FZ["par"][i]
+        asked = []
+        ok = FE.is_pose_trajectory_feasible(None, 0.0, None, x, None, float(r_in), float(ang), int(look), pose_cost=lambda a, b, c: asked.append((a, b, c)) or 0.0)
+        m = int(FZ["n_calls"][i])
+        assert ok == bool(FZ["feasible"][i]) and len(asked) == m, (i, len(asked), m)
+        assert np.abs(np.array(asked) - FZ["calls"][i, :m]).max() < 1e-13
+        interpolated += m - (n if look < 0 or look >= n else int(look) + 1)
+        hit, cnt = int(FZ["hit_at"][i]), [0]
+
+        def blocked(a, b, c):
+            cnt[0] += 1
+            return -1.0 if cnt[0] - 1 == hit else (-2.0 if cnt[0] % 5 == 0 else 3.0)
+        assert FE.is_pose_trajectory_feasible(None, 0.0, None, x, None, float(r_in), float(ang), int(look), pose_cost=blocked) == bool(FZ["hit_feasible"][i]) is False
+        assert cnt[0] == FZ["hit_calls"][i] == hit + 1
+    assert interpolated > 200
+
+
+def test_result_message_of_the_facade_is_the_one_the_reference_publishes(facade_lib):
+    """mpc_local_planner_msgs/OptimalControlResult as Controller::publishOptimalControlResult fills it (src/controller.cpp:197-221), taken from the stand-in publisher:
+    header.seq counts from 0 (published before ++_ocp_seq), dim_states / dim_controls, the time series sample after sample, optimal_solution_found"""
+    import copy
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import configure_cases
+    prm = configure_cases.base_carlike()
+    prm["controller"]["publish_ocp_results"] = True; prm["controller"]["outer_ocp_iterations"] = 1
+    prm["grid"]["variable_grid"]["grid_adaptation"]["enable"] = False
+    n = int(FZ["n"][0]); traj = FZ["x"][0, :n]
+    prm["grid"]["grid_size_ref"] = n
+
+    def put(x, u, dt, up, dtp):
+        xs = traj.copy(); xs[0] = x[0]
+        return xs, u + 0.1, 0.2, True
+    fac = _Facade(facade_lib, prm, put)
+    plan = np.stack([traj[0], traj[-1]])
+    for step, seq in ((0, FZ["msg_seq"][0]), (1, FZ["msg_seq_second_step"][0])):
+        ok, to, xo, uo, *_ = fac.step(plan, np.zeros(2), 0.1, 0.1 * step)
+        head = np.zeros(9); a = [np.zeros(4 * n) for _ in range(4)]
+        p = lambda v: v.ctypes.data_as(C.c_void_p)
+        facade_lib.fs_result_msg(fac.h, xo.shape[0], p(to), p(np.ascontiguousarray(xo)), p(np.ascontiguousarray(uo)), p(head), *[p(v) for v in a])
+        assert head[0] == seq == step and head[1] == FZ["msg_dim_states"][0] == 3 and head[2] == FZ["msg_dim_controls"][0] == 2 and head[3] == FZ["msg_optimal_solution_found"][0] == 1
+        if step == 0:
+            for got, name in zip(a, ("time_states", "states", "time_controls", "controls")):
+                ref = FZ["msg_" + name]
+                assert int(head[5 + ("time_states", "states", "time_controls", "controls").index(name)]) == ref.size
+                assert np.abs(got[:ref.size] - ref).max() < 1e-12, name
+    fac.close()
