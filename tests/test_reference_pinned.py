@@ -588,3 +588,31 @@ def test_result_message_of_the_facade_is_the_one_the_reference_publishes(facade_
                 assert int(head[5 + ("time_states", "states", "time_controls", "controls").index(name)]) == ref.size
                 assert np.abs(got[:ref.size] - ref).max() < 1e-12, name
     fac.close()
+
+
+@pytest.mark.skipif(not os.path.isdir(RL.REFERENCE_INCLUDE), reason="the reference tree is only present in the build container")
+def test_recorded_vectors_are_what_the_compiled_reference_gives_today():
+    """the committed fixtures against a fresh run of oracle/_ref (built from /root/reference by this test): guards against fixtures that drift from the generator"""
+    import json
+    assert RL.build()
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import configure_cases
+    rec = json.load(open(os.path.join(HERE, "golden", "ref_configure.json")))
+    for name, params in configure_cases.cases().items():
+        status, log = RL.probe_configure(params)
+        assert status == rec[name]["status"] and [t for lv, t in log if lv == 3] == rec[name]["errors"], name
+        if status == 1:
+            ctl = RL.RefController(params)
+            assert ctl.dump() == rec[name]["built"], name
+            ctl.close()
+    for i in range(0, GR["n"].shape[0], 7):
+        n, x, u, dt = _traj(i)
+        assert RL.grid_find_nearest_state(x, u, dt, GR["query"][i]) == GR["nearest"][i]
+        wx, wu = RL.grid_warm_start_cycle(x, u, dt, GR["query"][i], GR["goal_new"][i], GR["xf_fixed"][i])
+        assert np.array_equal(wx, GR["warm_x"][i, :n]) and np.array_equal(wu, GR["warm_u"][i, :n - 1])
+        rx, ru, rdt = RL.grid_resample(x, u, dt, int(GR["n_new"][i]))
+        assert np.array_equal(rx, GR["resample_x"][i, :rx.shape[0]]) and rdt == GR["resample_dt"][i]
+    for i in range(0, CO["n"].shape[0], 9):
+        n, x, u, goal, dt, Q, Rw, Qf, S_, gamma = _cost_scene(i, False)
+        assert np.array_equal(RL.quadratic_cost(Q, Rw, x, goal, u, form=True, integral=True), CO["form_l"][i, :n])
+        assert np.array_equal(RL.terminal_ball(S_, gamma, x, goal), CO["ball"][i, :n])
