@@ -154,6 +154,114 @@ inline void warm_start_shifting(double* x, double* u, int n, const double x0[3])
     u[2 * (n - 1)] = u[2 * (n - 2)]; u[2 * (n - 1) + 1] = u[2 * (n - 2) + 1];               // keep the duplicated last control consistent
 }
 
+// ---- what the reference's plugin prepares before Controller::step (src/mpc_local_planner_ros.cpp); each function is held to that source, compiled and executed
+// (oracle/ref_wrap_plugin.cpp, tests/test_reference_pinned.py)
+
+// MpcLocalPlannerROS::updateViaPointsContainer (:619-635): walking along the transformed plan, a pose becomes a via-point when it is at least min_separation away
+// (x / y) from the previously inserted one; the first pose counts as inserted but is no via-point.  min_separation <= 0: none.
+inline std::vector<PoseSE2> via_points_from_plan(const std::vector<PoseSE2>& plan, double min_separation) {
+    std::vector<PoseSE2> out;
+    if (min_separation <= 0) return out;
+    size_t prev = 0;
+    for (size_t i = 1; i < plan.size(); ++i) {
+        const double dx = plan[i].x - plan[prev].x, dy = plan[i].y - plan[prev].y;
+        if (std::sqrt(dx * dx + dy * dy) < min_separation) continue;
+        out.push_back(plan[i]);
+        prev = i;
+    }
+    return out;
+}
+
+// costmap_converter/ObstacleMsg reduced to what the plugin reads: polygon points (x, y), radius, planar velocity
+struct ObstacleMessage {
+    std::vector<double> points;      // x0, y0, x1, y1, ...   (geometry_msgs/Point32: single precision on the wire)
+    double radius = 0.0;
+    double vx = 0.0, vy = 0.0;
+};
+// The obstacles of ONE planner instance in the layout of struct mpc_obstacles (capacity = the handle's max_obstacles / max_vertices).  fromMessages restates
+// updateObstacleContainerWithCostmapConverter (:501-541; converter = true, messages already in the planning frame) and updateObstacleContainerWithCustomObstacles
+// (:543-617; converter = false, moved by the planar transform (yaw, tx, ty), a message without points is skipped): 1 point + radius > 0 = circle, 1 point = point,
+// 2 = line, more = polygon; a velocity below 1 mm/s leaves the obstacle static (teb_local_planner Obstacle::setCentroidVelocity); as in the reference the velocity of a
+// message goes to the LAST obstacle of the container (in the converter path a message without points therefore re-labels the obstacle before it).
+class ObstacleSet {
+ public:
+    ObstacleSet(int max_obstacles, int max_vertices)
+        : _O(max_obstacles), _V(max_vertices), _nv((size_t)max_obstacles, 0), _verts((size_t)max_obstacles * max_vertices * 2, 0.0), _radius((size_t)max_obstacles, 0.0),
+          _vel((size_t)max_obstacles * 2, 0.0) {}
+    void clear() { _n = 0; }
+    int size() const { return _n; }
+    // false when the capacity is exceeded (nothing is dropped silently: the caller decides)
+    bool add(const double* xy, int n_vertices, double radius = 0.0) {
+        if (_n >= _O || n_vertices > _V || n_vertices < 1) return false;
+        _nv[(size_t)_n] = n_vertices; _radius[(size_t)_n] = radius; _vel[(size_t)2 * _n] = _vel[(size_t)2 * _n + 1] = 0.0;
+        for (int i = 0; i < 2 * n_vertices; ++i) _verts[((size_t)_n * _V) * 2 + i] = xy[i];
+        ++_n;
+        return true;
+    }
+    bool fromMessages(const std::vector<ObstacleMessage>& msgs, bool converter = true, double yaw = 0.0, double tx = 0.0, double ty = 0.0, bool append = false) {
+        if (!append) clear();
+        const double c = std::cos(yaw), s = std::sin(yaw);
+        for (const ObstacleMessage& m : msgs) {
+            const int k = (int)m.points.size() / 2;
+            if (k == 0 && !converter) continue;                                   // :592-596 "Invalid custom obstacle received ... Skipping"
+            if (k > 0) {
+                std::vector<double> xy((size_t)2 * k);
+                for (int i = 0; i < k; ++i) {
+                    const double x = (double)(float)m.points[(size_t)2 * i], y = (double)(float)m.points[(size_t)2 * i + 1];
+                    xy[(size_t)2 * i] = converter ? x : tx + c * x - s * y;
+                    xy[(size_t)2 * i + 1] = converter ? y : ty + s * x + c * y;
+                }
+                if (!add(xy.data(), k, (k == 1 && m.radius > 0) ? m.radius : 0.0)) return false;
+            }
+            if (_n > 0 && std::sqrt(m.vx * m.vx + m.vy * m.vy) >= 0.001) { _vel[(size_t)2 * (_n - 1)] = m.vx; _vel[(size_t)2 * (_n - 1) + 1] = m.vy; }
+        }
+        return true;
+    }
+    // borrowed view for Controller::setObstacles / mpc_solve_batch with B = 1 (valid until the set changes)
+    const mpc_obstacles* view() {
+        _count = _n;
+        _view.n_obstacles = &_count; _view.n_vertices = _nv.data(); _view.vertices = _verts.data(); _view.radius = _radius.data(); _view.velocity = _vel.data();
+        return &_view;
+    }
+    int nVertices(int o) const { return _nv[(size_t)o]; }
+    const double* vertices(int o) const { return &_verts[((size_t)o * _V) * 2]; }
+    double radius(int o) const { return _radius[(size_t)o]; }
+    const double* velocity(int o) const { return &_vel[(size_t)2 * o]; }
+ private:
+    int _O, _V, _n = 0;
+    int32_t _count = 0;
+    std::vector<int32_t> _nv;
+    std::vector<double> _verts, _radius, _vel;
+    mpc_obstacles _view{};
+};
+
+// MpcLocalPlannerROS::estimateLocalGoalOrientation (:807-852): the local goal's heading with controller/global_plan_overwrite_orientation -- near the end of the global
+// plan the goal's own heading (rotated into the planning frame), otherwise the circular mean of the directions between up to moving_average_length successive plan poses
+// beyond the local goal.  global_plan in its own frame, (yaw, tx, ty) the planar transform plan -> planning frame, local_goal already in the planning frame.
+inline double estimate_local_goal_orientation(const std::vector<PoseSE2>& global_plan, const PoseSE2& local_goal, int current_goal_idx, double yaw, double tx, double ty,
+                                              int moving_average_length = 3) {
+    const int n = (int)global_plan.size();
+    if (current_goal_idx > n - moving_average_length - 2) {
+        if (current_goal_idx >= n - 1) return local_goal.theta;
+        const double a = yaw, b = global_plan.back().theta;                      // getYaw(rotation * orientation), both rotations about z
+        const double az = std::sin(0.5 * a), aw = std::cos(0.5 * a), bz = std::sin(0.5 * b), bw = std::cos(0.5 * b);
+        const double z = aw * bz + az * bw, w = aw * bw - az * bz;
+        return std::atan2(2.0 * w * z, 1.0 - 2.0 * z * z);
+    }
+    moving_average_length = std::min(moving_average_length, n - current_goal_idx - 1);
+    const double c = std::cos(yaw), s = std::sin(yaw);
+    double px = local_goal.x, py = local_goal.y, sx = 0.0, sy = 0.0;
+    const int end = current_goal_idx + moving_average_length;
+    for (int i = current_goal_idx; i < end; ++i) {
+        const PoseSE2& q = global_plan[(size_t)i + 1];
+        const double nx = tx + c * q.x - s * q.y, ny = ty + s * q.x + c * q.y;
+        const double a = std::atan2(ny - py, nx - px);
+        sx += std::cos(a); sy += std::sin(a);
+        if (i < end - 1) { px = nx; py = ny; }
+    }
+    return (sx == 0.0 && sy == 0.0) ? 0.0 : std::atan2(sy, sx);
+}
+
 // mpc_local_planner_msgs/OptimalControlResult (msg/OptimalControlResult.msg:1-12) without the ROS header: the wire layout that
 // Controller::publishOptimalControlResult fills (src/controller.cpp:197-221).  states / controls are "Column Major" = corbo::TimeSeries'
 // value matrix (dim x N, column-major), i.e. sample-major: states[dim_states * k + i] -- exactly one row of the ABI's x_out / u_out.

@@ -306,6 +306,10 @@ def config_from_params(params: dict, costmap_footprint=None, **sizing):
     return A.make_config(**kw), ctrl, notes
 
 
+def _is_number(v) -> bool:
+    return isinstance(v, (int, float)) and not isinstance(v, bool)
+
+
 def _footprint(p: _Reader, costmap_footprint, notes: list[str]) -> dict:
     point = {"footprint_kind": FOOTPRINT_POINT}
     if not p.has("footprint_model/type"):
@@ -322,10 +326,15 @@ def _footprint(p: _Reader, costmap_footprint, notes: list[str]) -> dict:
         if not p.has("footprint_model/radius"):
             notes.append("Footprint model 'circular' cannot be loaded: footprint_model/radius does not exist. Using point-model instead.")
             return point
-        return {"footprint_kind": FOOTPRINT_CIRCLE, "footprint_radius": p.get("footprint_model/radius", 0.0)}
+        radius = p.get("footprint_model/radius", None)
+        if not _is_number(radius):            # getParam(double) fails on anything that is not a number (:925)
+            notes.append("Footprint model 'circular' cannot be loaded: footprint_model/radius does not exist. Using point-model instead.")
+            return point
+        return {"footprint_kind": FOOTPRINT_CIRCLE, "footprint_radius": float(radius)}
     if kind == "line":
         a, b = p.get("footprint_model/line_start", None), p.get("footprint_model/line_end", None)
-        if a is None or b is None or len(a) != 2 or len(b) != 2:
+        numeric = lambda v: isinstance(v, (list, tuple)) and all(_is_number(e) for e in v)      # noqa: E731    a list with text in it reads as empty (:944-946)
+        if not numeric(a) or not numeric(b) or len(a) != 2 or len(b) != 2:
             notes.append("Footprint model 'line' cannot be loaded: line_start / line_end missing or not 2D. Using point-model instead.")
             return point
         return {"footprint_kind": FOOTPRINT_LINE, "footprint_params": (float(a[0]), float(a[1]), float(b[0]), float(b[1]))}
@@ -334,12 +343,17 @@ def _footprint(p: _Reader, costmap_footprint, notes: list[str]) -> dict:
         if not all(p.has(f"footprint_model/{k}") for k in keys):
             notes.append("Footprint model 'two_circles' cannot be loaded: front_offset, front_radius, rear_offset and rear_radius are needed. Using point-model instead.")
             return point
-        return {"footprint_kind": FOOTPRINT_TWO_CIRCLES, "footprint_params": tuple(p.get(f"footprint_model/{k}", 0.0) for k in keys)}
+        vals = [p.get(f"footprint_model/{k}", None) for k in keys]
+        if not all(_is_number(v) for v in vals):
+            # the reference only asks hasParam (:964-965) and would go on with uninitialised numbers: treated as "cannot be loaded" here
+            notes.append("Footprint model 'two_circles' cannot be loaded: front_offset, front_radius, rear_offset and rear_radius must be numbers. Using point-model instead.")
+            return point
+        return {"footprint_kind": FOOTPRINT_TWO_CIRCLES, "footprint_params": tuple(float(v) for v in vals)}
     if kind == "polygon":
         v = p.get("footprint_model/vertices", None)
-        ok = isinstance(v, (list, tuple)) and len(v) >= 3 and all(isinstance(q, (list, tuple)) and len(q) == 2 for q in v)
+        ok = isinstance(v, (list, tuple)) and len(v) >= 3 and all(isinstance(q, (list, tuple)) and len(q) == 2 and all(_is_number(e) for e in q) for q in v)
         if not ok:
-            # makeFootprintFromXMLRPC (:1030-1060) throws for fewer than 3 points or points that are not [x, y]
+            # makeFootprintFromXMLRPC / getNumberFromXMLRPC (:1046-1095) throw for fewer than 3 points, points that are not [x, y], coordinates that are not numbers
             notes.append("Footprint model 'polygon' cannot be loaded: footprint_model/vertices must be a list of at least 3 [x, y] points. Using point-model instead.")
             return point
         if len(v) > 16:

@@ -1,0 +1,115 @@
+"""What the reference's plugin prepares for a control cycle BEFORE Controller::step -- the data formats on the caller's side of the path
+(src/mpc_local_planner_ros.cpp), for a binding that feeds BatchSolver / the C ABI instead of corbo:
+
+    via_points_from_plan            updateViaPointsContainer (:619-635)
+    obstacles_from_messages         updateObstacleContainerWithCostmapConverter (:501-541) / updateObstacleContainerWithCustomObstacles (:543-617)
+    pack_obstacles                  the obstacle records -> the arrays of struct mpc_obstacles (include/mpc_hip.h) for one instance
+    estimate_local_goal_orientation estimateLocalGoalOrientation (:807-852)
+
+(the costmap -> point obstacle scan, :474-499, is the device kernel mpc_costmap_to_obstacles).  Each function is held to the reference's own source,
+compiled and executed by the test suite (tests/test_reference_pinned.py)."""
+from __future__ import annotations
+
+import math
+from typing import Iterable, Sequence
+
+import numpy as np
+
+DYNAMIC_VELOCITY_THRESHOLD = 0.001      # teb_local_planner Obstacle::setCentroidVelocity: below 1 mm/s an obstacle stays static
+
+
+def via_points_from_plan(plan, min_separation: float) -> np.ndarray:
+    """plan (n, 3) poses of the transformed global plan -> (P, 3) via-points: walking along the plan, a pose becomes a via-point when it is at least
+    min_separation away (Euclidean, x/y) from the previously inserted one -- the first pose counts as inserted but is not a via-point itself.
+    min_separation <= 0: none."""
+    plan = np.asarray(plan, float).reshape(-1, 3)
+    if min_separation <= 0:
+        return np.zeros((0, 3))
+    out, prev = [], 0
+    for i in range(1, plan.shape[0]):
+        if math.sqrt((plan[i, 0] - plan[prev, 0]) ** 2 + (plan[i, 1] - plan[prev, 1]) ** 2) < min_separation:
+            continue
+        out.append(plan[i])
+        prev = i
+    return np.array(out, float).reshape(-1, 3)
+
+
+def obstacles_from_messages(msgs: Iterable[dict], converter: bool = True, transform: Sequence[float] = (0.0, 0.0, 0.0)):
+    """costmap_converter/ObstacleMsg-like records {points: [(x, y[, z]), ...], radius: r, velocity: (vx, vy)} -> obstacle records
+    (vertices (k, 2), radius, velocity (2,)) in container order.  1 point + radius > 0: circle; 1 point: point; 2: line; more: polygon.
+    converter=True: the messages of a costmap_converter plugin, already in the planning frame.  converter=False: custom obstacles, moved into the planning
+    frame by the planar transform (yaw, tx, ty); a message without points is skipped (the reference warns).
+    A velocity below 1 mm/s leaves the obstacle static.  As in the reference, the velocity of a message goes to the LAST obstacle in the container: in the
+    converter path a message without points therefore re-labels the obstacle before it."""
+    c, s = math.cos(transform[0]), math.sin(transform[0])
+    out = []
+
+    def moved(q):
+        if converter:
+            return (float(np.float32(q[0])), float(np.float32(q[1])))            # geometry_msgs/Point32: single precision on the wire
+        x, y = float(np.float32(q[0])), float(np.float32(q[1]))
+        return (transform[1] + c * x - s * y, transform[2] + s * x + c * y)
+    for m in msgs:
+        pts = list(m.get("points", ()))
+        radius = float(m.get("radius", 0.0))
+        if len(pts) == 1 and radius > 0:
+            out.append([np.array([moved(pts[0])]), radius, np.zeros(2)])
+        elif len(pts) == 1:
+            out.append([np.array([moved(pts[0])]), 0.0, np.zeros(2)])
+        elif len(pts) == 2:
+            out.append([np.array([moved(pts[0]), moved(pts[1])]), 0.0, np.zeros(2)])
+        elif len(pts) == 0:
+            if not converter:
+                continue                                                        # :592-596 "Invalid custom obstacle received ... Skipping"
+        else:
+            out.append([np.array([moved(q) for q in pts]), 0.0, np.zeros(2)])
+        v = np.asarray(m.get("velocity", (0.0, 0.0)), float)
+        if out and math.sqrt(v[0] * v[0] + v[1] * v[1]) >= DYNAMIC_VELOCITY_THRESHOLD:
+            out[-1][2] = v.copy()
+    return [(a, r, v) for a, r, v in out]
+
+
+def pack_obstacles(records, max_obstacles: int, max_vertices: int):
+    """obstacle records of ONE instance -> (n_obstacles, n_vertices (O,), vertices (O, V, 2), radius (O,), velocity (O, 2)); raises when the handle's capacity is
+    exceeded (never drops silently)"""
+    if len(records) > max_obstacles:
+        raise ValueError(f"{len(records)} obstacles exceed max_obstacles = {max_obstacles}")
+    nv = np.zeros(max_obstacles, np.int32); vv = np.zeros((max_obstacles, max_vertices, 2)); rr = np.zeros(max_obstacles); vel = np.zeros((max_obstacles, 2))
+    for i, (verts, radius, v) in enumerate(records):
+        k = len(verts)
+        if k > max_vertices:
+            raise ValueError(f"obstacle {i} has {k} vertices, max_vertices = {max_vertices}")
+        nv[i] = k; vv[i, :k] = verts; rr[i] = radius; vel[i] = v
+    return len(records), nv, vv, rr, vel
+
+
+def _yaw_compose(a: float, b: float) -> float:
+    """yaw of the product of two rotations about z given by their yaw angles, through quaternions as tf2 does (getYaw(rotation * orientation))"""
+    az, aw, bz, bw = math.sin(0.5 * a), math.cos(0.5 * a), math.sin(0.5 * b), math.cos(0.5 * b)
+    z, w = aw * bz + az * bw, aw * bw - az * bz
+    return math.atan2(2.0 * w * z, 1.0 - 2.0 * z * z)
+
+
+def estimate_local_goal_orientation(global_plan, local_goal, current_goal_idx: int, transform: Sequence[float] = (0.0, 0.0, 0.0), moving_average_length: int = 3) -> float:
+    """heading of the local goal when controller/global_plan_overwrite_orientation is set: near the end of the global plan the goal's own heading, otherwise the
+    circular mean of the directions between up to moving_average_length successive plan poses beyond the local goal (plan poses moved into the planning frame by
+    the planar transform (yaw, tx, ty); the local goal is given in the planning frame)."""
+    plan = np.asarray(global_plan, float).reshape(-1, 3)
+    n = plan.shape[0]
+    if current_goal_idx > n - moving_average_length - 2:
+        if current_goal_idx >= n - 1:
+            return float(local_goal[2])
+        return _yaw_compose(transform[0], plan[-1, 2])
+    moving_average_length = min(moving_average_length, n - current_goal_idx - 1)
+    c, s = math.cos(transform[0]), math.sin(transform[0])
+    prev = (float(local_goal[0]), float(local_goal[1]))
+    sx = sy = 0.0
+    end = current_goal_idx + moving_average_length
+    for i in range(current_goal_idx, end):
+        q = plan[i + 1]
+        nxt = (transform[1] + c * q[0] - s * q[1], transform[2] + s * q[0] + c * q[1])
+        a = math.atan2(nxt[1] - prev[1], nxt[0] - prev[0])
+        sx += math.cos(a); sy += math.sin(a)
+        if i < end - 1:
+            prev = nxt
+    return 0.0 if (sx == 0 and sy == 0) else math.atan2(sy, sx)

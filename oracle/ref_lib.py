@@ -71,6 +71,11 @@ def load():
         lib.ref_ctl_counters.restype = None; lib.ref_ctl_counters.argtypes = [V, V, V]
         lib.ref_ctl_result_msg.restype = None; lib.ref_ctl_result_msg.argtypes = [V, V, I, V, V, V, V]
         lib.ref_ctl_feasible.restype = I; lib.ref_ctl_feasible.argtypes = [V, V, D, D, D, I, I, V, V]
+        lib.ref_plugin_costmap_obstacles.restype = I; lib.ref_plugin_costmap_obstacles.argtypes = [I, I, V, D, D, D, V, D, I, I, V]
+        lib.ref_plugin_via_points.restype = I; lib.ref_plugin_via_points.argtypes = [I, V, D, I, V]
+        lib.ref_plugin_obstacle_messages.restype = I; lib.ref_plugin_obstacle_messages.argtypes = [I, I, V, V, V, V, V, I, I, V, V]
+        lib.ref_plugin_footprint.restype = I; lib.ref_plugin_footprint.argtypes = [C.c_char_p, I, V, V, I, V, V, C.c_char_p, I]
+        lib.ref_plugin_goal_orientation.restype = D; lib.ref_plugin_goal_orientation.argtypes = [I, V, V, I, V, I]
         _lib = lib
     return _lib
 
@@ -380,3 +385,72 @@ class RefController:
             self.close()
         except Exception:
             pass
+
+
+# ---- the reference's plugin source (src/mpc_local_planner_ros.cpp), oracle/ref_wrap_plugin.cpp: the functions that prepare the solver's inputs
+def plugin_costmap_obstacles(cost, resolution, origin, robot_pose, behind_robot_dist=1.5, include=True):
+    """updateObstacleContainerWithCostmap: cost (size_y, size_x) uint8 -> (P, 2) point obstacles in container order"""
+    c = np.ascontiguousarray(cost, np.uint8); rp = np.ascontiguousarray(robot_pose, float)
+    cap = int(c.size) + 1
+    out = np.zeros((cap, 2))
+    n = load().ref_plugin_costmap_obstacles(c.shape[1], c.shape[0], _p(c), float(resolution), float(origin[0]), float(origin[1]), _p(rp), float(behind_robot_dist), int(include), cap, _p(out))
+    return out[:n].copy()
+
+
+def plugin_via_points(plan, min_separation):
+    """updateViaPointsContainer: plan (n, 3) poses -> (P, 3) via-point poses"""
+    pl = np.ascontiguousarray(plan, float).reshape(-1, 3)
+    out = np.zeros((pl.shape[0] + 1, 3))
+    n = load().ref_plugin_via_points(pl.shape[0], _p(pl), float(min_separation), out.shape[0], _p(out))
+    return out[:n].copy()
+
+
+def plugin_obstacle_messages(msgs, converter=True, transform=(0.0, 0.0, 0.0), cap_v=16):
+    """obstacle messages [{points: [(x, y, z), ...], radius, velocity: (vx, vy)}] -> [(kind 0 point | 1 circle | 2 line | 3 polygon, vertices (k,2), radius, dynamic, (vx, vy))]
+    through updateObstacleContainerWithCostmapConverter (converter) or updateObstacleContainerWithCustomObstacles (planar transform yaw, tx, ty)"""
+    npts = np.array([len(m["points"]) for m in msgs], np.int32)
+    pts = np.ascontiguousarray([q for m in msgs for q in m["points"]], float).reshape(-1, 3)
+    rad = np.array([m.get("radius", 0.0) for m in msgs], float); vel = np.ascontiguousarray([m.get("velocity", (0.0, 0.0)) for m in msgs], float).reshape(-1, 2)
+    tr = np.ascontiguousarray(transform, float)
+    cap = len(msgs) + 1
+    rec = np.zeros((cap, 6)); verts = np.zeros((cap, cap_v, 2))
+    n = load().ref_plugin_obstacle_messages(int(converter), len(msgs), _p(npts), _p(pts), _p(rad), _p(vel), _p(tr), cap, cap_v, _p(rec), _p(verts))
+    return [(int(rec[i, 0]), verts[i, :int(rec[i, 1])].copy(), float(rec[i, 2]), bool(rec[i, 3]), (float(rec[i, 4]), float(rec[i, 5]))) for i in range(n)]
+
+
+def _footprint_lines(tree):
+    lines = []
+    for k, v in (tree.get("footprint_model") or {}).items():
+        key = f"footprint_model/{k}"
+        if isinstance(v, (list, tuple)) and v and all(isinstance(q, (list, tuple)) for q in v):
+            rows = ["|".join(("i:%d" % e) if isinstance(e, int) and not isinstance(e, bool) else ("d:%r" % float(e)) if isinstance(e, float) else "s:x" for e in q) for q in v]
+            lines.append(f"{key}\tll\t" + ";".join(rows))
+        elif isinstance(v, (list, tuple)):
+            if all(isinstance(e, (int, float)) and not isinstance(e, bool) for e in v):
+                lines.append(f"{key}\tnl\t" + ",".join(("i:%d" % e) if isinstance(e, int) else ("d:%r" % float(e)) for e in v))
+        elif isinstance(v, bool):
+            lines.append(f"{key}\tb\t{int(v)}")
+        elif isinstance(v, int):
+            lines.append(f"{key}\ti\t{v}")
+        elif isinstance(v, float):
+            lines.append(f"{key}\td\t{v!r}")
+        elif isinstance(v, str):
+            lines.append(f"{key}\ts\t{v}")
+    return lines
+
+
+FOOTPRINT_KINDS = ("point", "circular", "line", "two_circles", "polygon")
+
+
+def plugin_footprint(params, costmap_footprint=None, no_costmap=False):
+    """getRobotFootprintFromParamServer: -> (kind name, args (4,), vertices (k,2), console lines [(level, text)])"""
+    cfp = np.ascontiguousarray(costmap_footprint if costmap_footprint is not None else np.zeros((0, 2)), float).reshape(-1, 2)
+    args = np.zeros(4); verts = np.zeros((64, 2)); nv = C.c_int(0); log = C.create_string_buffer(1 << 14)
+    kind = load().ref_plugin_footprint("\n".join(_footprint_lines(params)).encode(), -1 if no_costmap else cfp.shape[0], _p(cfp), _p(args), 64, _p(verts), C.byref(nv), log, len(log))
+    lines = [(int(l.split("|", 1)[0]), l.split("|", 1)[1]) for l in log.value.decode().splitlines() if "|" in l]
+    return FOOTPRINT_KINDS[kind], args, verts[:nv.value].copy(), lines
+
+
+def plugin_goal_orientation(plan, local_goal, current_goal_idx, transform=(0.0, 0.0, 0.0), moving_average_length=3):
+    pl = np.ascontiguousarray(plan, float).reshape(-1, 3); g = np.ascontiguousarray(local_goal, float); tr = np.ascontiguousarray(transform, float)
+    return load().ref_plugin_goal_orientation(pl.shape[0], _p(pl), _p(g), int(current_goal_idx), _p(tr), int(moving_average_length))

@@ -2,6 +2,7 @@
 #pragma once
 #include <Eigen/Core>
 #include <cmath>
+#include <vector>
 #include <geometry_msgs/Pose.h>
 namespace teb_local_planner {
 class PoseSE2 {
@@ -29,6 +30,8 @@ class PoseSE2 {
     Eigen::Vector2d _position;
     double _theta = 0;
 };
+// teb: misc.h
+inline double average_angles(const std::vector<double>& angles) { double x = 0, y = 0; for (double a : angles) { x += std::cos(a); y += std::sin(a); } return (x == 0 && y == 0) ? 0 : std::atan2(y, x); }
 }  // namespace teb_local_planner
 namespace g2o {      // teb's pose_se2.h pulls g2o/stuff/misc.h: the angle wrap to [-pi, pi) the reference calls once (src/controller.cpp:906)
 inline double normalize_theta(double theta) {

@@ -10,6 +10,7 @@
 //                                                                         the grid classes and the SE(2) time series: oracle/ref_wrap_grid.cpp
 //   src/optimal_control/quadratic_cost_se2.cpp, final_state_conditions_se2.cpp (+ headers)      cost terms, final-state cost, terminal ball: oracle/ref_wrap_cost.cpp
 //   src/controller.cpp (+ controller.h)                                  configure / step / isPoseTrajectoryFeasible / publishOptimalControlResult: oracle/ref_wrap_controller.cpp
+//   src/mpc_local_planner_ros.cpp (+ its header)                         costmap / message obstacles, via-points, goal heading, footprint parameters: oracle/ref_wrap_plugin.cpp
 //
 // The model and collocation headers are written against Eigen and control_box_rst (corbo), neither of which is in this image; oracle/ref_stubs/
 // provides the INTERFACES they derive from and the few element-wise vector operations they use (see the notes there).  The arithmetic that

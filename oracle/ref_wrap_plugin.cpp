@@ -1,0 +1,182 @@
+// ORACLE (test infrastructure only): the reference's plugin source src/mpc_local_planner_ros.cpp, compiled from where it lies under /root/reference (the whole translation
+// unit, against the stand-ins of oracle/ref_stubs/ for roscpp, tf2, costmap_2d, costmap_converter, pluginlib, dynamic_reconfigure, nav_core, mbf, boost) and EXECUTED for the
+// functions that prepare the solver's inputs:
+//   updateObstacleContainerWithCostmap (:474-499)            lethal costmap cells -> point obstacles
+//   updateObstacleContainerWithCostmapConverter (:501-541),
+//   updateObstacleContainerWithCustomObstacles (:543-617)    obstacle messages -> point / circle / line / polygon obstacles (+ velocities)
+//   updateViaPointsContainer (:619-635)                      via-points from the transformed plan
+//   getRobotFootprintFromParamServer (:890-1001) + makeFootprintFromXMLRPC / getNumberFromXMLRPC (:1046-1095)
+//   estimateLocalGoalOrientation (:807-852)
+// The member functions are protected / the members private: the class definition is read with those two keywords turned into `public` (this file only; the reference's
+// source file itself is compiled unchanged).  Publisher (src/utils/publisher.cpp: RViz markers) is not compiled; its members are empty functions here.
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <mutex>
+#include <sstream>
+#include <string>
+#include <vector>
+#include <Eigen/Core>
+#include <ros/ros.h>
+
+#define private public
+#define protected public
+#include <mpc_local_planner/mpc_local_planner_ros.h>
+#undef private
+#undef protected
+
+namespace mpc_local_planner {
+Publisher::Publisher(ros::NodeHandle&, RobotDynamicsInterface::Ptr, const std::string&) {}
+void Publisher::initialize(ros::NodeHandle&, RobotDynamicsInterface::Ptr, const std::string&) {}
+void Publisher::publishLocalPlan(const std::vector<geometry_msgs::PoseStamped>&) const {}
+void Publisher::publishLocalPlan(const corbo::TimeSeries&) const {}
+void Publisher::publishGlobalPlan(const std::vector<geometry_msgs::PoseStamped>&) const {}
+void Publisher::publishRobotFootprintModel(const teb_local_planner::PoseSE2&, const teb_local_planner::BaseRobotFootprintModel&, const std::string&, const std_msgs::ColorRGBA&) {}
+void Publisher::publishObstacles(const teb_local_planner::ObstContainer&) const {}
+void Publisher::publishViaPoints(const std::vector<teb_local_planner::PoseSE2>&, const std::string&) const {}
+std_msgs::ColorRGBA Publisher::toColorMsg(float a, float r, float g, float b) { std_msgs::ColorRGBA c; c.a = a; c.r = r; c.g = g; c.b = b; return c; }
+}  // namespace mpc_local_planner
+
+namespace {
+using mpc_local_planner::MpcLocalPlannerROS;
+void parse_params_plugin(const char* text, ros::ParamStore& store);
+std::vector<std::string> split(const std::string& s, char c) { std::vector<std::string> out; std::stringstream ss(s); std::string item; while (std::getline(ss, item, c)) out.push_back(item); return out; }
+// as oracle/ref_wrap_controller.cpp::parse_params, plus "ll": a list of lists "i:1|d:2.5;d:0|s:x" (footprint_model/vertices)
+void parse_params_plugin(const char* text, ros::ParamStore& store) {
+    for (const std::string& line : split(text, '\n')) {
+        const auto f = split(line, '\t');
+        if (f.size() < 2) continue;
+        const std::string val = f.size() > 2 ? f[2] : "";
+        ros::ParamValue p;
+        if (f[1] == "i") { p.kind = ros::ParamValue::Int; p.i = std::stol(val); }
+        else if (f[1] == "d") { p.kind = ros::ParamValue::Double; p.d = std::stod(val); }
+        else if (f[1] == "b") { p.kind = ros::ParamValue::Bool; p.b = val == "1"; }
+        else if (f[1] == "s") { p.kind = ros::ParamValue::String; p.s = val; }
+        else if (f[1] == "nl") { p.kind = ros::ParamValue::NumList; for (const auto& e : split(val, ',')) { p.num_is_int.push_back(e[0] == 'i'); p.nums.push_back(std::stod(e.substr(2))); } }
+        else if (f[1] == "ll") {
+            p.kind = ros::ParamValue::ListOfLists;
+            for (const auto& row : split(val, ';')) {
+                std::vector<double> r; std::vector<int> k;
+                for (const auto& e : split(row, '|')) { k.push_back(e[0] == 'i' ? 0 : e[0] == 'd' ? 1 : 2); r.push_back(e[0] == 's' ? 0.0 : std::stod(e.substr(2))); }
+                p.lists.push_back(r); p.lists_kind.push_back(k);
+            }
+        } else continue;
+        store[f[0]] = p;
+    }
+}
+// obstacles of the container -> flat records: kind (0 point, 1 circle, 2 line, 3 polygon), n_vertices, radius, dynamic, vx, vy; vertices [cap_v][2]
+int dump_obstacles(const teb_local_planner::ObstContainer& obst, int cap, int cap_v, double* rec, double* verts) {
+    int n = 0;
+    for (const auto& o : obst) {
+        if (n >= cap) break;
+        double* r = rec + 6 * n; double* v = verts + (size_t)2 * cap_v * n;
+        std::vector<Eigen::Vector2d> pts; double radius = 0; int kind = 0;
+        if (auto* s = dynamic_cast<const teb_local_planner::ShapeObstacle*>(o.get())) {
+            pts = s->vertices; radius = s->radius;
+            kind = dynamic_cast<const teb_local_planner::CircularObstacle*>(s) ? 1 : dynamic_cast<const teb_local_planner::LineObstacle*>(s) ? 2 : 3;
+        } else pts.push_back(o->getCentroid());
+        r[0] = kind; r[1] = (double)pts.size(); r[2] = radius; r[3] = o->isDynamic(); r[4] = o->getCentroidVelocity().x(); r[5] = o->getCentroidVelocity().y();
+        for (size_t i = 0; i < pts.size() && (int)i < cap_v; ++i) { v[2 * i] = pts[i].x(); v[2 * i + 1] = pts[i].y(); }
+        ++n;
+    }
+    return (int)obst.size();
+}
+costmap_converter::ObstacleArrayMsg make_msgs(int n_msgs, const int* n_points, const double* points /* [sum][3] */, const double* radius, const double* vel /* [n][2] */) {
+    costmap_converter::ObstacleArrayMsg arr;
+    arr.header.frame_id = "sensor";
+    size_t off = 0;
+    for (int i = 0; i < n_msgs; ++i) {
+        costmap_converter::ObstacleMsg m;
+        for (int j = 0; j < n_points[i]; ++j, ++off) { geometry_msgs::Point32 q; q.x = (float)points[3 * off]; q.y = (float)points[3 * off + 1]; q.z = (float)points[3 * off + 2]; m.polygon.points.push_back(q); }
+        m.radius = radius[i]; m.velocities.twist.linear.x = vel[2 * i]; m.velocities.twist.linear.y = vel[2 * i + 1];
+        arr.obstacles.push_back(m);
+    }
+    return arr;
+}
+}  // namespace
+
+extern "C" {
+// updateObstacleContainerWithCostmap: cells [size_y][size_x] row-major (getCost(mx, my) = cells[my * size_x + mx]); out_xy [cap][2]; returns the number of obstacles
+int ref_plugin_costmap_obstacles(int size_x, int size_y, const unsigned char* cells, double resolution, double origin_x, double origin_y, const double* robot_pose, double behind_robot_dist,
+                                 int include_costmap_obstacles, int cap, double* out_xy) {
+    MpcLocalPlannerROS p;
+    costmap_2d::Costmap2D cm((unsigned)size_x, (unsigned)size_y, resolution, origin_x, origin_y);
+    cm.cells.assign(cells, cells + (size_t)size_x * size_y);
+    p._costmap = &cm;
+    p._params.include_costmap_obstacles = include_costmap_obstacles != 0;
+    p._params.costmap_obstacles_behind_robot_dist = behind_robot_dist;
+    p._robot_pose = teb_local_planner::PoseSE2(robot_pose[0], robot_pose[1], robot_pose[2]);
+    p.updateObstacleContainerWithCostmap();
+    int n = 0;
+    for (const auto& o : p._obstacles) { if (n < cap) { out_xy[2 * n] = o->getCentroid().x(); out_xy[2 * n + 1] = o->getCentroid().y(); } ++n; }
+    return n;
+}
+// updateViaPointsContainer: plan [n][3] (x, y, yaw); out [cap][3]; returns the number of via-points
+int ref_plugin_via_points(int n_plan, const double* plan, double min_separation, int cap, double* out) {
+    MpcLocalPlannerROS p;
+    std::vector<geometry_msgs::PoseStamped> poses((size_t)n_plan);
+    for (int i = 0; i < n_plan; ++i) teb_local_planner::PoseSE2(plan[3 * i], plan[3 * i + 1], plan[3 * i + 2]).toPoseMsg(poses[(size_t)i].pose);
+    p._via_points.emplace_back(9.0, 9.0, 9.0);            // stale content: must be cleared
+    p.updateViaPointsContainer(poses, min_separation);
+    int n = 0;
+    for (const auto& v : p._via_points) { if (n < cap) { out[3 * n] = v.x(); out[3 * n + 1] = v.y(); out[3 * n + 2] = v.theta(); } ++n; }
+    return n;
+}
+// obstacle messages -> the container.  converter != 0: updateObstacleContainerWithCostmapConverter (no transform); else updateObstacleContainerWithCustomObstacles with the
+// planar transform (yaw, tx, ty) answered by the tf buffer.  rec [cap][6], verts [cap][cap_v][2] as dump_obstacles; returns the number of obstacles
+int ref_plugin_obstacle_messages(int converter, int n_msgs, const int* n_points, const double* points, const double* radius, const double* vel, const double* transform, int cap, int cap_v,
+                                 double* rec, double* verts) {
+    MpcLocalPlannerROS p;
+    ros::stub_log().lines.clear();
+    if (converter) {
+        auto conv = std::make_shared<costmap_converter::BaseCostmapToPolygons>();
+        conv->obstacles = std::make_shared<costmap_converter::ObstacleArrayMsg>(make_msgs(n_msgs, n_points, points, radius, vel));
+        p._costmap_converter = conv;
+        p.updateObstacleContainerWithCostmapConverter();
+    } else {
+        tf2_ros::Buffer tf;
+        tf.answer.transform.rotation.z = std::sin(0.5 * transform[0]); tf.answer.transform.rotation.w = std::cos(0.5 * transform[0]);
+        tf.answer.transform.translation.x = transform[1]; tf.answer.transform.translation.y = transform[2];
+        p._tf = &tf; p._global_frame = "odom";
+        p._custom_obstacle_msg = make_msgs(n_msgs, n_points, points, radius, vel);
+        p.updateObstacleContainerWithCustomObstacles();
+    }
+    return dump_obstacles(p._obstacles, cap, cap_v, rec, verts);
+}
+// getRobotFootprintFromParamServer: params as text (see parse_params_plugin); costmap footprint [n_cfp][2] or n_cfp < 0 for "no costmap".  kind: 0 point, 1 circular, 2 line,
+// 3 two_circles, 4 polygon; args [4]; vertices [cap][2], *n_vertices; log = the console lines ("<level>|text")
+int ref_plugin_footprint(const char* params_text, int n_cfp, const double* cfp, double* args, int cap, double* vertices, int* n_vertices, char* log, int log_cap) {
+    ros::stub_log().lines.clear();
+    ros::ParamStore store;
+    parse_params_plugin(params_text, store);
+    ros::NodeHandle nh; nh.store = &store;
+    costmap_2d::Costmap2DROS cm;
+    for (int i = 0; i < n_cfp; ++i) { geometry_msgs::Point q; q.x = cfp[2 * i]; q.y = cfp[2 * i + 1]; cm.footprint.push_back(q); }
+    auto model = MpcLocalPlannerROS::getRobotFootprintFromParamServer(nh, n_cfp >= 0 ? &cm : nullptr);
+    int kind = 0; *n_vertices = 0;
+    if (auto* r = dynamic_cast<teb_local_planner::RecordedFootprint*>(model.get())) {
+        kind = dynamic_cast<teb_local_planner::CircularRobotFootprint*>(r) ? 1 : dynamic_cast<teb_local_planner::LineRobotFootprint*>(r) ? 2
+               : dynamic_cast<teb_local_planner::TwoCirclesRobotFootprint*>(r) ? 3 : 4;
+        for (size_t i = 0; i < r->args.size() && i < 4; ++i) args[i] = r->args[i];
+        *n_vertices = (int)r->vertices.size();
+        for (size_t i = 0; i < r->vertices.size() && (int)i < cap; ++i) { vertices[2 * i] = r->vertices[i].x(); vertices[2 * i + 1] = r->vertices[i].y(); }
+    }
+    std::ostringstream o;
+    for (const auto& l : ros::stub_log().lines) o << l.first << "|" << l.second << "\n";
+    std::strncpy(log, o.str().c_str(), (size_t)log_cap - 1); log[log_cap - 1] = 0;
+    return kind;
+}
+// estimateLocalGoalOrientation: global plan [n][3] (x, y, yaw) in the plan frame, local goal pose (already transformed), index of the current goal in the plan, the planar
+// transform plan -> global (yaw, tx, ty)
+double ref_plugin_goal_orientation(int n_plan, const double* plan, const double* local_goal, int current_goal_idx, const double* transform, int moving_average_length) {
+    MpcLocalPlannerROS p;
+    std::vector<geometry_msgs::PoseStamped> poses((size_t)n_plan);
+    for (int i = 0; i < n_plan; ++i) teb_local_planner::PoseSE2(plan[3 * i], plan[3 * i + 1], plan[3 * i + 2]).toPoseMsg(poses[(size_t)i].pose);
+    geometry_msgs::PoseStamped goal; teb_local_planner::PoseSE2(local_goal[0], local_goal[1], local_goal[2]).toPoseMsg(goal.pose);
+    geometry_msgs::TransformStamped t;
+    t.transform.rotation.z = std::sin(0.5 * transform[0]); t.transform.rotation.w = std::cos(0.5 * transform[0]); t.transform.translation.x = transform[1]; t.transform.translation.y = transform[2];
+    return p.estimateLocalGoalOrientation(poses, goal, current_goal_idx, t, moving_average_length);
+}
+}  // extern "C"

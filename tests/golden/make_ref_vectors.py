@@ -315,6 +315,58 @@ def main():
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_feasibility_and_result.npz"), **fz, **msg)
     print("written feasibility-check records:", F3, "trajectories; result message of step 0")
 
+    # ---- the plugin source (src/mpc_local_planner_ros.cpp), oracle/ref_wrap_plugin.cpp: costmap -> point obstacles, obstacle messages -> obstacles, via-points from the
+    # plan, the local goal's heading, the footprint model from the parameters
+    import footprint_cases
+    rng = np.random.default_rng(20261001)
+    pl = {}
+    for s_ in range(12):
+        sy, sx = int(rng.integers(2, 40)), int(rng.integers(2, 50))
+        cost = np.where(rng.random((sy, sx)) < 0.08, 254, rng.choice([0, 1, 100, 253, 255], (sy, sx))).astype(np.uint8)
+        cost[-1, :] = 254; cost[:, -1] = 254                       # the last row and column are never visited (:481-483)
+        res, org = float(rng.uniform(0.03, 0.2)), rng.uniform(-3, 0, 2)
+        pose = np.array([org[0] + rng.uniform(0, sx * res), org[1] + rng.uniform(0, sy * res), rng.uniform(-pi, pi)])
+        behind = float(rng.choice([0.0, 0.3, 1.5]))
+        pl[f"cm{s_}_cost"] = cost; pl[f"cm{s_}_par"] = np.array([res, org[0], org[1], *pose, behind])
+        pl[f"cm{s_}_obstacles"] = RL.plugin_costmap_obstacles(cost, res, org, pose, behind)
+    pl["cm_disabled"] = RL.plugin_costmap_obstacles(np.full((4, 4), 254, np.uint8), 0.1, (0, 0), (0, 0, 0), 1.5, include=False)
+    V3, PM = 60, 24
+    pl["vp_n"] = np.zeros(V3, np.int32); pl["vp_plan"] = np.zeros((V3, PM, 3)); pl["vp_sep"] = np.zeros(V3); pl["vp_count"] = np.zeros(V3, np.int32); pl["vp_out"] = np.zeros((V3, PM, 3))
+    pl["go_par"] = np.zeros((V3, 8)); pl["go_out"] = np.zeros(V3)
+    for s_ in range(V3):
+        n = int(rng.integers(1, PM + 1))
+        plan = np.cumsum(rng.uniform(-0.1, 0.4, (n, 3)), 0); plan[:, 2] = rng.uniform(-pi, pi, n)
+        sep = float(rng.choice([-1.0, 0.0, 0.2, 0.5, 1.0]))
+        vp = RL.plugin_via_points(plan, sep)
+        pl["vp_n"][s_] = n; pl["vp_plan"][s_, :n] = plan; pl["vp_sep"][s_] = sep; pl["vp_count"][s_] = vp.shape[0]; pl["vp_out"][s_, :vp.shape[0]] = vp
+        idx, ma = int(rng.integers(0, n)), int(rng.integers(1, 5))
+        tr, goal = (rng.uniform(-3, 3), rng.uniform(-1, 1), rng.uniform(-1, 1)), rng.uniform(-2, 2, 3)
+        pl["go_par"][s_] = (idx, ma, *tr, *goal); pl["go_out"][s_] = RL.plugin_goal_orientation(plan, goal, idx, tr, ma)
+    M3, MM, PP_ = 60, 8, 6
+    pl["ms_n"] = np.zeros(M3, np.int32); pl["ms_npts"] = np.zeros((M3, MM), np.int32); pl["ms_pts"] = np.zeros((M3, MM, PP_, 3)); pl["ms_radius"] = np.zeros((M3, MM)); pl["ms_vel"] = np.zeros((M3, MM, 2))
+    pl["ms_converter"] = np.zeros(M3, np.int32); pl["ms_transform"] = np.zeros((M3, 3)); pl["ms_count"] = np.zeros(M3, np.int32)
+    pl["ms_rec"] = np.zeros((M3, MM, 6)); pl["ms_verts"] = np.zeros((M3, MM, PP_, 2))
+    for s_ in range(M3):
+        k = int(rng.integers(1, MM + 1)); msgs = []
+        for i in range(k):
+            npt = int(rng.choice([0, 1, 1, 2, 3, 5]))
+            m = {"points": [tuple(rng.uniform(-3, 3, 3)) for _ in range(npt)], "radius": float(rng.choice([0.0, 0.0, 0.3])), "velocity": tuple(rng.choice([0.0, 0.0005, 0.2], 2))}
+            msgs.append(m)
+            pl["ms_npts"][s_, i] = npt; pl["ms_pts"][s_, i, :npt] = np.array(m["points"]).reshape(-1, 3); pl["ms_radius"][s_, i] = m["radius"]; pl["ms_vel"][s_, i] = m["velocity"]
+        conv, tr = s_ % 2, (rng.uniform(-3, 3), rng.uniform(-1, 1), rng.uniform(-1, 1))
+        out = RL.plugin_obstacle_messages(msgs, bool(conv), tr, cap_v=PP_)
+        pl["ms_n"][s_] = k; pl["ms_converter"][s_] = conv; pl["ms_transform"][s_] = tr; pl["ms_count"][s_] = len(out)
+        for i, (kind, verts, radius, dyn, vel) in enumerate(out):
+            pl["ms_rec"][s_, i] = (kind, verts.shape[0], radius, dyn, *vel); pl["ms_verts"][s_, i, :verts.shape[0]] = verts
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_plugin_inputs.npz"), **pl)
+    fp = {}
+    for name, (fm, cfp, nocm) in footprint_cases.cases().items():
+        kind, args, verts, log = RL.plugin_footprint({"footprint_model": fm} if fm else {}, cfp, nocm)
+        fp[name] = {"kind": kind, "args": args.tolist(), "vertices": verts.tolist(), "complaints": [t for lv, t in log if lv >= 2]}
+    with open(os.path.join(ROOT, "tests", "golden", "ref_footprint_models.json"), "w") as f:
+        json.dump(fp, f, indent=1, sort_keys=True)
+    print("written plugin-input records: 12 costmaps,", V3, "plans,", M3, "obstacle message arrays,", len(fp), "footprint parameter sets")
+
 
 if __name__ == "__main__":
     main()

@@ -41,3 +41,40 @@ extern "C" int ctl_optimal_control_result(int n, const double* x, const double* 
     for (double v : msg.controls) out[o++] = v;
     return o;
 }
+
+// ---- the plugin-side helpers of include/mpc_controller.hpp
+extern "C" int ctl_via_points_from_plan(int n, const double* plan, double min_separation, double* out) {
+    using namespace mpc_local_planner_amd;
+    std::vector<PoseSE2> p((size_t)n);
+    for (int i = 0; i < n; ++i) { p[(size_t)i].x = plan[3 * i]; p[(size_t)i].y = plan[3 * i + 1]; p[(size_t)i].theta = plan[3 * i + 2]; }
+    const auto v = via_points_from_plan(p, min_separation);
+    for (size_t i = 0; i < v.size(); ++i) { out[3 * i] = v[i].x; out[3 * i + 1] = v[i].y; out[3 * i + 2] = v[i].theta; }
+    return (int)v.size();
+}
+extern "C" double ctl_goal_orientation(int n, const double* plan, const double* goal, int idx, const double* tr, int ma) {
+    using namespace mpc_local_planner_amd;
+    std::vector<PoseSE2> p((size_t)n);
+    for (int i = 0; i < n; ++i) { p[(size_t)i].x = plan[3 * i]; p[(size_t)i].y = plan[3 * i + 1]; p[(size_t)i].theta = plan[3 * i + 2]; }
+    PoseSE2 g; g.x = goal[0]; g.y = goal[1]; g.theta = goal[2];
+    return estimate_local_goal_orientation(p, g, idx, tr[0], tr[1], tr[2], ma);
+}
+// messages: n_points [n], points [n][max_pts][3] (z ignored), radius [n], vel [n][2] -> through ObstacleSet::fromMessages and its mpc_obstacles view:
+// rec [cap][5] = n_vertices, radius, dynamic, vx, vy; verts [cap][max_pts][2]; returns the number of obstacles, -1 when the capacity is exceeded
+extern "C" int ctl_obstacles_from_messages(int n, int max_pts, const int* n_points, const double* points, const double* radius, const double* vel, int converter, const double* tr,
+                                           int cap, double* rec, double* verts) {
+    using namespace mpc_local_planner_amd;
+    std::vector<ObstacleMessage> msgs((size_t)n);
+    for (int i = 0; i < n; ++i) {
+        for (int j = 0; j < n_points[i]; ++j) { msgs[(size_t)i].points.push_back(points[((size_t)i * max_pts + j) * 3]); msgs[(size_t)i].points.push_back(points[((size_t)i * max_pts + j) * 3 + 1]); }
+        msgs[(size_t)i].radius = radius[i]; msgs[(size_t)i].vx = vel[2 * i]; msgs[(size_t)i].vy = vel[2 * i + 1];
+    }
+    ObstacleSet set(cap, max_pts);
+    if (!set.fromMessages(msgs, converter != 0, tr[0], tr[1], tr[2])) return -1;
+    const mpc_obstacles* v = set.view();
+    for (int o = 0; o < v->n_obstacles[0]; ++o) {
+        rec[5 * o] = v->n_vertices[o]; rec[5 * o + 1] = v->radius[o]; rec[5 * o + 3] = v->velocity[2 * o]; rec[5 * o + 4] = v->velocity[2 * o + 1];
+        rec[5 * o + 2] = (rec[5 * o + 3] != 0.0 || rec[5 * o + 4] != 0.0) ? 1 : 0;
+        for (int i = 0; i < 2 * v->n_vertices[o]; ++i) verts[(size_t)o * max_pts * 2 + i] = v->vertices[(size_t)o * max_pts * 2 + i];
+    }
+    return v->n_obstacles[0];
+}

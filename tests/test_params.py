@@ -499,3 +499,43 @@ def test_cpp_reader_on_the_reference_s_configure_cases(cpp, name):
     for k, v in py_ctrl.items():
         assert opt[k] == float(v), k
     _held_to_reference(cfg, {k: opt[k] for k in py_ctrl}, rec["built"])
+
+
+# ---- footprint_model: held to getRobotFootprintFromParamServer of the reference's plugin source (src/mpc_local_planner_ros.cpp:890-1001 + makeFootprintFromXMLRPC /
+# getNumberFromXMLRPC :1046-1095), compiled and executed (oracle/ref_wrap_plugin.cpp -> tests/golden/ref_footprint_models.json)
+import footprint_cases      # noqa: E402
+
+REF_FOOTPRINTS = json.load(open(os.path.join(HERE, "golden", "ref_footprint_models.json")))
+FOOTPRINT_KIND_NAMES = {0: "point", 1: "circular", 2: "line", 3: "two_circles", 4: "polygon"}
+
+
+def _footprint_held_to_reference(cfg, rec):
+    assert FOOTPRINT_KIND_NAMES[cfg.footprint_kind] == rec["kind"]
+    if rec["kind"] == "circular":
+        assert cfg.footprint_radius == rec["args"][0]
+    if rec["kind"] in ("line", "two_circles"):
+        assert list(cfg.footprint_params) == rec["args"]
+    if rec["kind"] == "polygon":
+        k = len(rec["vertices"])
+        assert cfg.footprint_n_vertices == k
+        got = np.array(list(cfg.footprint_vertices)[:2 * k]).reshape(-1, 2)
+        assert np.abs(got - np.array(rec["vertices"])).max() < 1e-7          # the costmap footprint went through geometry_msgs/Point32 there
+
+
+@pytest.mark.parametrize("name", sorted(REF_FOOTPRINTS))
+def test_footprint_model_reproduces_what_the_reference_plugin_builds(cpp, name):
+    """every model type, ints where doubles are expected, and every fall-back to the point model: missing keys, a radius given as text, 3-D line ends, fewer than 3 polygon
+    vertices, a vertex that is not [x, y], a coordinate that is not a number, a flat list, an unknown type, costmap_2d with and without a costmap -- the Python reader and
+    the C++ reader (include/mpc_params.hpp) build what the reference builds, and complain (note) exactly where the reference complains"""
+    fm, cfp, no_costmap = footprint_cases.cases()[name]
+    rec = REF_FOOTPRINTS[name]
+    tree = {"footprint_model": fm} if fm else {}
+    cfg, _, notes = P.config_from_params(tree, costmap_footprint=None if no_costmap else cfp)
+    _footprint_held_to_reference(cfg, rec)
+    assert bool(rec["complaints"]) == bool(notes), (rec["complaints"], notes)
+    if name == "polygon_text":
+        return                 # a coordinate that is text cannot be expressed through the typed C++ parameter source
+    st, ccfg, _, rep = _cpp_config(cpp, tree, None if no_costmap else cfp)
+    assert st == 0, rep
+    _footprint_held_to_reference(ccfg, rec)
+    assert bool(rec["complaints"]) == (len([l for l in rep.split("\n") if l]) > 0), (rec["complaints"], rep)

@@ -616,3 +616,91 @@ def test_recorded_vectors_are_what_the_compiled_reference_gives_today():
         n, x, u, goal, dt, Q, Rw, Qf, S_, gamma = _cost_scene(i, False)
         assert np.array_equal(RL.quadratic_cost(Q, Rw, x, goal, u, form=True, integral=True), CO["form_l"][i, :n])
         assert np.array_equal(RL.terminal_ball(S_, gamma, x, goal), CO["ball"][i, :n])
+
+
+# ---- the reference's plugin source (src/mpc_local_planner_ros.cpp), compiled as a whole and executed for the functions that prepare the solver's inputs
+# (oracle/ref_wrap_plugin.cpp -> tests/golden/ref_plugin_inputs.npz, ref_footprint_models.json)
+PLG = np.load(os.path.join(HERE, "golden", "ref_plugin_inputs.npz"))
+
+
+def test_costmap_scan_reproduces_the_reference_plugin():
+    """updateObstacleContainerWithCostmap (:474-499): LETHAL cells only, the last row and column never visited, column-major visiting order, cell centres, the
+    behind-the-robot filter; include_costmap_obstacles = false: nothing.  oracle/costmap.py (the CPU restatement the device kernel mpc_costmap_to_obstacles is compared
+    with bit for bit in tests/test_gpu_parity.py) gives the same obstacles in the same order"""
+    from oracle import costmap as CM
+    total = 0
+    for i in range(12):
+        cost, par = PLG[f"cm{i}_cost"], PLG[f"cm{i}_par"]
+        ours = CM.costmap_to_obstacles(cost, par[0], par[1:3], par[3:6], par[6])
+        ref = PLG[f"cm{i}_obstacles"]
+        assert ours.shape == ref.shape and (ref.size == 0 or np.array_equal(ours, ref)), i
+        total += ref.shape[0]
+        assert ref.shape[0] < int((cost[:-1, :-1] == 254).sum()) + 1
+    assert total > 200 and PLG["cm_disabled"].shape[0] == 0
+
+
+def test_plan_helpers_reproduce_the_reference_plugin(host_ctl):
+    """updateViaPointsContainer (:619-635) and estimateLocalGoalOrientation (:807-852): the package's plugin_inputs.py and the C++ helpers of include/mpc_controller.hpp"""
+    from mpc_local_planner_amd import plugin_inputs as PI
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    some = 0
+    for i in range(PLG["vp_n"].shape[0]):
+        n = int(PLG["vp_n"][i]); plan = np.ascontiguousarray(PLG["vp_plan"][i, :n]); sep = float(PLG["vp_sep"][i]); m = int(PLG["vp_count"][i])
+        ref = PLG["vp_out"][i, :m]
+        ours = PI.via_points_from_plan(plan, sep)
+        assert ours.shape[0] == m and (m == 0 or (np.array_equal(ours[:, :2], ref[:, :2]) and np.abs(ours[:, 2] - ref[:, 2]).max() < 1e-15)), i      # yaw went through a quaternion there
+        out = np.zeros((n + 1, 3))
+        assert host_ctl.ctl_via_points_from_plan(n, p(plan), sep, p(out)) == m and np.array_equal(out[:m], ours)
+        some += m
+        idx, ma, yaw, tx, ty, gx, gy, gth = PLG["go_par"][i]
+        goal, tr = np.array([gx, gy, gth]), np.array([yaw, tx, ty])
+        a = PI.estimate_local_goal_orientation(plan, goal, int(idx), tr, int(ma))
+        b = host_ctl.ctl_goal_orientation(n, p(plan), p(goal), int(idx), p(tr), int(ma))
+        for got in (a, b):
+            assert abs(np.arctan2(np.sin(got - PLG["go_out"][i]), np.cos(got - PLG["go_out"][i]))) < 1e-12, i
+    assert some > 100
+
+
+def test_obstacle_messages_reproduce_the_reference_plugin(host_ctl):
+    """updateObstacleContainerWithCostmapConverter (:501-541) / updateObstacleContainerWithCustomObstacles (:543-617): kinds by the number of points and the radius, the
+    planar transform of custom obstacles, the 1 mm/s threshold below which an obstacle stays static, the velocity going to the LAST obstacle of the container,
+    messages without points.  plugin_inputs.py and the C++ ObstacleSet (through its mpc_obstacles view)"""
+    from mpc_local_planner_amd import plugin_inputs as PI
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    kinds = set()
+    for i in range(PLG["ms_n"].shape[0]):
+        k = int(PLG["ms_n"][i]); conv = bool(PLG["ms_converter"][i]); tr = np.ascontiguousarray(PLG["ms_transform"][i])
+        msgs = [{"points": [tuple(q) for q in PLG["ms_pts"][i, j, :int(PLG["ms_npts"][i, j])]], "radius": float(PLG["ms_radius"][i, j]), "velocity": tuple(PLG["ms_vel"][i, j])} for j in range(k)]
+        ours = PI.obstacles_from_messages(msgs, conv, tr)
+        m = int(PLG["ms_count"][i])
+        assert len(ours) == m, i
+        rec = np.zeros((8, 5)); verts = np.zeros((8, 6, 2))
+        npts = np.ascontiguousarray(PLG["ms_npts"][i]); pts = np.ascontiguousarray(PLG["ms_pts"][i]); rad = np.ascontiguousarray(PLG["ms_radius"][i]); vel = np.ascontiguousarray(PLG["ms_vel"][i])
+        assert host_ctl.ctl_obstacles_from_messages(k, 6, p(npts), p(pts), p(rad), p(vel), int(conv), p(tr), 8, p(rec), p(verts)) == m
+        for o, (v_, r_, vel_) in enumerate(ours):
+            kind, nv, radius, dyn, vx, vy = PLG["ms_rec"][i, o]
+            kinds.add(int(kind))
+            assert v_.shape[0] == nv == rec[o, 0] and r_ == radius == rec[o, 1]
+            assert (kind == 1) == (nv == 1 and radius > 0) and (kind == 0) == (nv == 1 and radius == 0) and (kind == 2) == (nv == 2) and (kind == 3) == (nv > 2)
+            assert np.abs(v_ - PLG["ms_verts"][i, o, :int(nv)]).max() < 1e-13 and np.abs(verts[o, :int(nv)] - PLG["ms_verts"][i, o, :int(nv)]).max() < 1e-13
+            assert bool(dyn) == bool(np.any(vel_ != 0)) == bool(rec[o, 2]) and np.array_equal(vel_ * bool(dyn), [vx * dyn, vy * dyn]) and np.array_equal(rec[o, 3:5], vel_)
+    assert kinds == {0, 1, 2, 3}
+    # pack_obstacles: the arrays of struct mpc_obstacles; capacity overflow is an error, not a silent drop
+    nobs, nv, vv, rr, vel = PI.pack_obstacles(ours, 8, 6)
+    assert nobs == len(ours) and all(nv[o] == ours[o][0].shape[0] for o in range(nobs))
+    with pytest.raises(ValueError):
+        PI.pack_obstacles(ours + ours + ours + ours + ours + ours + ours + ours + ours, 8, 6)
+
+
+@pytest.fixture(scope="module")
+def host_ctl():
+    src = os.path.join(HERE, "host_harness", "controller_host.cpp")
+    out = os.path.join(HERE, "host_harness", "_build", "libctl_host_plugin_helpers.so")
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    subprocess.run(["g++", "-O1", "-std=c++17", "-fPIC", "-shared", "-Wl,--unresolved-symbols=ignore-all", src, "-o", out], check=True)
+    l = C.CDLL(out)
+    V, D, I = C.c_void_p, C.c_double, C.c_int
+    l.ctl_via_points_from_plan.restype = I; l.ctl_via_points_from_plan.argtypes = [I, V, D, V]
+    l.ctl_goal_orientation.restype = D; l.ctl_goal_orientation.argtypes = [I, V, V, I, V, I]
+    l.ctl_obstacles_from_messages.restype = I; l.ctl_obstacles_from_messages.argtypes = [I, I, V, V, V, V, I, V, I, V, V]
+    return l
