@@ -217,6 +217,7 @@ class ObstacleSet {
         }
         return true;
     }
+    void setLastVelocity(double vx, double vy) { if (_n > 0) { _vel[(size_t)2 * (_n - 1)] = vx; _vel[(size_t)2 * (_n - 1) + 1] = vy; } }
     // borrowed view for Controller::setObstacles / mpc_solve_batch with B = 1 (valid until the set changes)
     const mpc_obstacles* view() {
         _count = _n;
@@ -454,6 +455,7 @@ class Controller {
     void reset() { _grid_empty = true; if (_h) mpc_reset(_h); }
 
     int lastIterations() const { return _last_iterations; }
+    double lastStepTime() const { return _last_step_time; }       // _statistics.step_time (src/controller.cpp:175), seconds
     double lastDt() const { return _dt_sol; }
     const std::string& lastError() const { return _last_error; }
 

@@ -379,7 +379,8 @@ inline ParamStatus config_from_params(const ParamSource& p, mpc_config& c, Contr
 // reference has no parameter for (max_obstacles, max_vertices, max_obstacle_rows, max_via_points; fields left at 0 keep their defaults).
 struct HandleCapacities { int max_obstacles = 0, max_vertices = 0, max_obstacle_rows = 0, max_via_points = 0; };
 inline ParamStatus configure_from_params(Controller& controller, const ParamSource& p, ParamReport& rep, const HandleCapacities& caps = HandleCapacities(),
-                                         int device = 0, const std::vector<std::vector<double>>* costmap_footprint = nullptr) {
+                                         int device = 0, const std::vector<std::vector<double>>* costmap_footprint = nullptr, mpc_config* cfg_out = nullptr,
+                                         ControllerOptions* options_out = nullptr) {
     mpc_config cfg;
     ControllerOptions opt;
     const ParamStatus st = config_from_params(p, cfg, opt, rep, costmap_footprint);
@@ -387,6 +388,8 @@ inline ParamStatus configure_from_params(Controller& controller, const ParamSour
     if (caps.max_obstacles > 0) { cfg.max_obstacles = caps.max_obstacles; cfg.max_vertices = caps.max_vertices > 0 ? caps.max_vertices : 1; }
     if (caps.max_obstacle_rows > 0) cfg.max_obstacle_rows = caps.max_obstacle_rows;
     if (caps.max_via_points > 0) cfg.max_via_points = caps.max_via_points;
+    if (cfg_out) *cfg_out = cfg;
+    if (options_out) *options_out = opt;
     opt.apply(controller);                       // grid adaptation etc. BEFORE configure(): it sizes the handle for the largest grid
     if (!controller.configure(cfg, device)) { rep.error = controller.lastError(); return PARAMS_REJECTED; }
     return PARAMS_OK;

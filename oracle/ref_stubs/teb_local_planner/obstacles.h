@@ -33,6 +33,7 @@ class PointObstacle : public Obstacle {
     void setCentroidVelocity(const Eigen::Vector2d& v) override { _vel = v; _dynamic = true; }
     using Obstacle::setCentroidVelocity;
     const Eigen::Vector2d& getCentroid() const override { return _pos; }
+    const Eigen::Vector2d& position() const { return _pos; }
     bool isDynamic() const override { return _dynamic; }
     const Eigen::Vector2d& getCentroidVelocity() const override { return _vel; }
  private:
@@ -47,27 +48,32 @@ class ShapeObstacle : public Obstacle {
     const Eigen::Vector2d& getCentroidVelocity() const override { return _vel; }
     void setCentroidVelocity(const Eigen::Vector2d& v) override { _vel = v; _dynamic = true; }
     using Obstacle::setCentroidVelocity;
-    std::vector<Eigen::Vector2d> vertices;
-    double radius = 0;
+    std::vector<Eigen::Vector2d> pts;
+    double radius_ = 0;
  protected:
     Eigen::Vector2d _centroid, _vel;
     bool _dynamic = false;
 };
 class CircularObstacle : public ShapeObstacle {
  public:
-    CircularObstacle(double x, double y, double r) { vertices.emplace_back(x, y); radius = r; _centroid = vertices[0]; }
-    CircularObstacle(const Eigen::Vector2d& p, double r) { vertices.push_back(p); radius = r; _centroid = p; }
+    CircularObstacle(double x, double y, double r) { pts.emplace_back(x, y); radius_ = r; _centroid = pts[0]; }
+    CircularObstacle(const Eigen::Vector2d& p, double r) { pts.push_back(p); radius_ = r; _centroid = p; }
+    const Eigen::Vector2d& position() const { return pts[0]; }
+    double radius() const { return radius_; }
 };
 class LineObstacle : public ShapeObstacle {
  public:
-    LineObstacle(double x1, double y1, double x2, double y2) { vertices.emplace_back(x1, y1); vertices.emplace_back(x2, y2); _centroid = 0.5 * (vertices[0] + vertices[1]); }
-    LineObstacle(const Eigen::Vector2d& a, const Eigen::Vector2d& b) { vertices.push_back(a); vertices.push_back(b); _centroid = 0.5 * (a + b); }
+    LineObstacle(double x1, double y1, double x2, double y2) { pts.emplace_back(x1, y1); pts.emplace_back(x2, y2); _centroid = 0.5 * (pts[0] + pts[1]); }
+    LineObstacle(const Eigen::Vector2d& a, const Eigen::Vector2d& b) { pts.push_back(a); pts.push_back(b); _centroid = 0.5 * (a + b); }
+    const Eigen::Vector2d& start() const { return pts[0]; }
+    const Eigen::Vector2d& end() const { return pts[1]; }
 };
 class PolygonObstacle : public ShapeObstacle {
  public:
-    void pushBackVertex(double x, double y) { vertices.emplace_back(x, y); }
-    void pushBackVertex(const Eigen::Vector2d& v) { vertices.push_back(v); }
+    void pushBackVertex(double x, double y) { pts.emplace_back(x, y); }
+    void pushBackVertex(const Eigen::Vector2d& v) { pts.push_back(v); }
     void finalizePolygon() { finalized = true; }
+    const Point2dContainer& vertices() const { return pts; }
     bool finalized = false;
 };
 using ObstaclePtr = std::shared_ptr<Obstacle>;          // teb: boost::shared_ptr -- same use (bool test, get(), range-for over the container)

@@ -25,41 +25,12 @@
 #include <corbo-optimal-control/functions/minimum_time.h>
 #include <corbo-optimal-control/functions/quadratic_control_cost.h>
 #include <corbo-optimization/solver/levenberg_marquardt_sparse.h>
+#include "ref_wrap_controller_access.hpp"
 
 namespace {
 using namespace mpc_local_planner;
+using namespace ref_access;
 
-// protected members, read through derived classes
-struct CtlAccess : Controller {
-    using Controller::_grid; using Controller::_dynamics; using Controller::_solver; using Controller::_structured_ocp; using Controller::_inequality_constraint;
-    using Controller::_force_reinit_new_goal_dist; using Controller::_force_reinit_new_goal_angular; using Controller::_guess_backwards_motion;
-    using Controller::_force_reinit_num_steps; using Controller::_prefer_x_feedback; using Controller::_publish_ocp_results; using Controller::_print_cpu_time;
-    using Controller::_num_ocp_iterations; using Controller::_auto_update_prev_control; using Controller::_x_seq_init; using Controller::_ocp_seq; using Controller::_robot_type;
-    using Controller::_initial_plan_estimate_orientation;
-};
-struct GridAccess : FiniteDifferencesVariableGridSE2 {
-    using FiniteDifferencesVariableGridSE2::_x_seq; using FiniteDifferencesVariableGridSE2::_u_seq; using FiniteDifferencesVariableGridSE2::_xf; using FiniteDifferencesVariableGridSE2::_dt;
-    using FiniteDifferencesVariableGridSE2::_n_ref; using FiniteDifferencesVariableGridSE2::_dt_ref; using FiniteDifferencesVariableGridSE2::_warm_start;
-    using FiniteDifferencesVariableGridSE2::_xf_fixed; using FiniteDifferencesVariableGridSE2::_dt_lb; using FiniteDifferencesVariableGridSE2::_dt_ub;
-    using FiniteDifferencesVariableGridSE2::_cost_integration; using FiniteDifferencesVariableGridSE2::_fd_eval; using FiniteDifferencesVariableGridSE2::_grid_adapt;
-    using FiniteDifferencesVariableGridSE2::_n_max; using FiniteDifferencesVariableGridSE2::_n_min; using FiniteDifferencesVariableGridSE2::_dt_hyst_ratio;
-    using FiniteDifferencesVariableGridSE2::_u_prev; using FiniteDifferencesVariableGridSE2::_u_prev_dt;
-};
-struct BaseGridAccess : FiniteDifferencesGridSE2 {
-    using FiniteDifferencesGridSE2::_x_seq; using FiniteDifferencesGridSE2::_u_seq; using FiniteDifferencesGridSE2::_xf; using FiniteDifferencesGridSE2::_dt;
-    using FiniteDifferencesGridSE2::_n_ref; using FiniteDifferencesGridSE2::_dt_ref; using FiniteDifferencesGridSE2::_warm_start; using FiniteDifferencesGridSE2::_xf_fixed;
-    using FiniteDifferencesGridSE2::_dt_lb; using FiniteDifferencesGridSE2::_dt_ub; using FiniteDifferencesGridSE2::_cost_integration; using FiniteDifferencesGridSE2::_fd_eval;
-    using FiniteDifferencesGridSE2::_u_prev; using FiniteDifferencesGridSE2::_u_prev_dt;
-};
-struct IneqAccess : StageInequalitySE2 {
-    using StageInequalitySE2::_min_obstacle_dist; using StageInequalitySE2::_obstacle_filter_force_inclusion_dist; using StageInequalitySE2::_obstacle_filter_cutoff_dist;
-    using StageInequalitySE2::_enable_dynamic_obstacles; using StageInequalitySE2::_du_lb; using StageInequalitySE2::_du_ub; using StageInequalitySE2::_relevant_obstacles;
-};
-struct ViaAccess : MinTimeViaPointsCost {
-    using MinTimeViaPointsCost::_via_points_ordered; using MinTimeViaPointsCost::_vp_position_weight; using MinTimeViaPointsCost::_vp_orientation_weight;
-};
-
-typedef int (*solve_cb)(int n, double* x, double* u, double* dt, const double* u_prev, double u_prev_dt);
 typedef double (*cost_cb)(double x, double y, double theta);
 
 struct Handle {
@@ -71,7 +42,7 @@ struct Handle {
     Controller ctl;
     bool configured = false;
     solve_cb solver = nullptr;
-    std::vector<double> guess_x, guess_u; double guess_dt = 0; int guess_n = 0;            // the grid as the last compute() handed it to the "solver"
+    GuessRecord guess;            // the grid as the last compute() handed it to the "solver"
     mpc_local_planner_msgs::OptimalControlResult last_msg; int n_published = 0;
     CtlAccess& acc() { return static_cast<CtlAccess&>(ctl); }
 };
@@ -98,19 +69,6 @@ void parse_params(const char* text, ros::ParamStore& store) {
     }
 }
 
-template <class G> void read_grid(G& g, std::vector<double>& x, std::vector<double>& u, double& dt, int& n) {
-    n = g.getN();
-    x.assign((size_t)3 * n, 0.0); u.assign((size_t)2 * (n > 1 ? n - 1 : 0), 0.0);
-    for (int k = 0; k < n; ++k) { const Eigen::VectorXd& s = g.getState(k); for (int i = 0; i < 3; ++i) x[3 * k + i] = s[i]; }
-    for (int k = 0; k < n - 1; ++k) for (int j = 0; j < 2; ++j) u[2 * k + j] = g._u_seq[(size_t)k].values()[j];
-    dt = g.getDt();
-}
-template <class G> void write_grid(G& g, const std::vector<double>& x, const std::vector<double>& u, double dt, int n) {
-    for (int k = 0; k < n - 1; ++k) for (int i = 0; i < 3; ++i) g._x_seq[(size_t)k].values()[i] = x[3 * k + i];
-    for (int i = 0; i < 3; ++i) g._xf.values()[i] = x[3 * (n - 1) + i];
-    for (int k = 0; k < n - 1; ++k) for (int j = 0; j < 2; ++j) g._u_seq[(size_t)k].values()[j] = u[2 * k + j];
-    g._dt.value() = dt;
-}
 const char* model_name(const RobotDynamicsInterface* d) {
     if (dynamic_cast<const UnicycleModel*>(d)) return "unicycle";
     if (dynamic_cast<const SimpleCarFrontWheelDrivingModel*>(d)) return "simple_car_front_wheel_driving";
@@ -135,22 +93,7 @@ void* ref_ctl_create(const char* params_text, int n_obst, const double* obst_xy,
     for (int i = 0; i < n_via; ++i) h->via_points.emplace_back(via[3 * i], via[3 * i + 1], via[3 * i + 2]);
     h->ctl.setInitialPlanEstimateOrientation(estimate_orientation != 0);
     h->configured = h->ctl.configure(h->nh, h->obstacles, h->robot_model, h->via_points);
-    if (h->configured && h->acc()._structured_ocp) {
-        h->acc()._structured_ocp->solve_hook = [h](corbo::StructuredOptimalControlProblem& ocp) {
-            bool ok = true;
-            auto run = [&](auto& g) {
-                read_grid(g, h->guess_x, h->guess_u, h->guess_dt, h->guess_n);
-                if (!h->solver) return;
-                std::vector<double> x = h->guess_x, u = h->guess_u; double dt = h->guess_dt;
-                double up[2] = {g._u_prev.values()[0], g._u_prev.values()[1]};
-                ok = h->solver(h->guess_n, x.data(), u.data(), &dt, up, g._u_prev_dt.value()) != 0;
-                write_grid(g, x, u, dt, h->guess_n);
-            };
-            if (auto* vg = dynamic_cast<FiniteDifferencesVariableGridSE2*>(ocp.grid.get())) run(static_cast<GridAccess&>(*vg));
-            else run(static_cast<BaseGridAccess&>(*dynamic_cast<FiniteDifferencesGridSE2*>(ocp.grid.get())));
-            return ok;
-        };
-    }
+    if (h->configured) install_solver(h->ctl, &h->solver, &h->guess);
     return h;
 }
 // configure() in a forked child, because several error paths of the reference do not return false but dereference an empty pointer (an unknown solver type:
@@ -318,11 +261,11 @@ int ref_ctl_step_two_poses(void* p, const double* start, const double* goal, con
 // the grid as the last compute() handed it to the solver (= the reference's initial guess / warm start): returns n; x [n][3], u [n-1][2]
 int ref_ctl_last_guess(void* p, int cap, double* x, double* u, double* dt) {
     Handle* h = static_cast<Handle*>(p);
-    const int n = h->guess_n < cap ? h->guess_n : cap;
-    for (int i = 0; i < 3 * n; ++i) x[i] = h->guess_x[(size_t)i];
-    for (int i = 0; i < 2 * (n - 1); ++i) u[i] = h->guess_u[(size_t)i];
-    *dt = h->guess_dt;
-    return h->guess_n;
+    const int n = h->guess.n < cap ? h->guess.n : cap;
+    for (int i = 0; i < 3 * n; ++i) x[i] = h->guess.x[(size_t)i];
+    for (int i = 0; i < 2 * (n - 1); ++i) u[i] = h->guess.u[(size_t)i];
+    *dt = h->guess.dt;
+    return h->guess.n;
 }
 // counters: [0] _ocp_seq, [1] grid->clear() calls through reset(), [2] compute() calls, [3] messages published, [4] grid empty now, [5] number of precompute() calls of the
 // initial state trajectory; *last_sample_dt = the dt the last of them was asked for

@@ -26,6 +26,26 @@
 #include <mpc_local_planner/mpc_local_planner_ros.h>
 #undef private
 #undef protected
+#include "ref_wrap_controller_access.hpp"
+#include "ref_wrap_plugin_run.hpp"
+
+#define PLUGIN_ENTRY(name) ref_plugin_##name
+// the stand-in solver goes into the reference's Controller (its optimal-control-problem stand-in)
+struct SolverPort {
+    ref_access::solve_cb cb = nullptr;
+    ref_access::GuessRecord guess;
+    void attach(mpc_local_planner::MpcLocalPlannerROS& p) { ref_access::install_solver(p._controller, &cb, &guess); }
+    void set(plugin_run::solve_cb c) { cb = c; }
+    void begin_cycle() { guess.n = 0; }
+    int guess_n() const { return guess.n; }
+    int last_guess(int cap, double* x, double* u, double* dt) const {
+        const int n = guess.n < cap ? guess.n : cap;
+        for (int i = 0; i < 3 * n; ++i) x[i] = guess.x[(size_t)i];
+        for (int i = 0; i < 2 * (n - 1); ++i) u[i] = guess.u[(size_t)i];
+        *dt = guess.dt;
+        return guess.n;
+    }
+};
 
 namespace mpc_local_planner {
 Publisher::Publisher(ros::NodeHandle&, RobotDynamicsInterface::Ptr, const std::string&) {}
@@ -41,31 +61,8 @@ std_msgs::ColorRGBA Publisher::toColorMsg(float a, float r, float g, float b) { 
 
 namespace {
 using mpc_local_planner::MpcLocalPlannerROS;
-void parse_params_plugin(const char* text, ros::ParamStore& store);
-std::vector<std::string> split(const std::string& s, char c) { std::vector<std::string> out; std::stringstream ss(s); std::string item; while (std::getline(ss, item, c)) out.push_back(item); return out; }
-// as oracle/ref_wrap_controller.cpp::parse_params, plus "ll": a list of lists "i:1|d:2.5;d:0|s:x" (footprint_model/vertices)
-void parse_params_plugin(const char* text, ros::ParamStore& store) {
-    for (const std::string& line : split(text, '\n')) {
-        const auto f = split(line, '\t');
-        if (f.size() < 2) continue;
-        const std::string val = f.size() > 2 ? f[2] : "";
-        ros::ParamValue p;
-        if (f[1] == "i") { p.kind = ros::ParamValue::Int; p.i = std::stol(val); }
-        else if (f[1] == "d") { p.kind = ros::ParamValue::Double; p.d = std::stod(val); }
-        else if (f[1] == "b") { p.kind = ros::ParamValue::Bool; p.b = val == "1"; }
-        else if (f[1] == "s") { p.kind = ros::ParamValue::String; p.s = val; }
-        else if (f[1] == "nl") { p.kind = ros::ParamValue::NumList; for (const auto& e : split(val, ',')) { p.num_is_int.push_back(e[0] == 'i'); p.nums.push_back(std::stod(e.substr(2))); } }
-        else if (f[1] == "ll") {
-            p.kind = ros::ParamValue::ListOfLists;
-            for (const auto& row : split(val, ';')) {
-                std::vector<double> r; std::vector<int> k;
-                for (const auto& e : split(row, '|')) { k.push_back(e[0] == 'i' ? 0 : e[0] == 'd' ? 1 : 2); r.push_back(e[0] == 's' ? 0.0 : std::stod(e.substr(2))); }
-                p.lists.push_back(r); p.lists_kind.push_back(k);
-            }
-        } else continue;
-        store[f[0]] = p;
-    }
-}
+using plugin_run::parse_params_plugin;
+using plugin_run::split;
 // obstacles of the container -> flat records: kind (0 point, 1 circle, 2 line, 3 polygon), n_vertices, radius, dynamic, vx, vy; vertices [cap_v][2]
 int dump_obstacles(const teb_local_planner::ObstContainer& obst, int cap, int cap_v, double* rec, double* verts) {
     int n = 0;
@@ -74,7 +71,7 @@ int dump_obstacles(const teb_local_planner::ObstContainer& obst, int cap, int ca
         double* r = rec + 6 * n; double* v = verts + (size_t)2 * cap_v * n;
         std::vector<Eigen::Vector2d> pts; double radius = 0; int kind = 0;
         if (auto* s = dynamic_cast<const teb_local_planner::ShapeObstacle*>(o.get())) {
-            pts = s->vertices; radius = s->radius;
+            pts = s->pts; radius = s->radius_;
             kind = dynamic_cast<const teb_local_planner::CircularObstacle*>(s) ? 1 : dynamic_cast<const teb_local_planner::LineObstacle*>(s) ? 2 : 3;
         } else pts.push_back(o->getCentroid());
         r[0] = kind; r[1] = (double)pts.size(); r[2] = radius; r[3] = o->isDynamic(); r[4] = o->getCentroidVelocity().x(); r[5] = o->getCentroidVelocity().y();
@@ -179,4 +176,6 @@ double ref_plugin_goal_orientation(int n_plan, const double* plan, const double*
     t.transform.rotation.z = std::sin(0.5 * transform[0]); t.transform.rotation.w = std::cos(0.5 * transform[0]); t.transform.translation.x = transform[1]; t.transform.translation.y = transform[2];
     return p.estimateLocalGoalOrientation(poses, goal, current_goal_idx, t, moving_average_length);
 }
+
+#include "ref_wrap_plugin_cycle.inc"
 }  // extern "C"

@@ -89,6 +89,7 @@ int fs_step(void* p, int n_plan, const double* plan, const double* vel, double d
     *n_out = xs.size();
     return ok ? 1 : 0;
 }
+void fs_forget_guess() { g_guess_n = 0; }
 int fs_last_guess(int cap, double* x, double* u, double* dt, int* cold) {
     const int n = g_guess_n < cap ? g_guess_n : cap;
     for (int i = 0; i < 3 * n; ++i) x[i] = g_guess_x[(size_t)i];

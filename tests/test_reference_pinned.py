@@ -704,3 +704,71 @@ def host_ctl():
     l.ctl_goal_orientation.restype = D; l.ctl_goal_orientation.argtypes = [I, V, V, I, V, I]
     l.ctl_obstacles_from_messages.restype = I; l.ctl_obstacles_from_messages.argtypes = [I, I, V, V, V, V, I, V, I, V, V]
     return l
+
+
+# ---- drop-in at the plugin level: the reference's plugin source src/mpc_local_planner_ros.cpp, UNCHANGED, built twice -- on the reference's own Controller
+# (oracle/ref_wrap_plugin.cpp) and on include/mpc_reference_binding.hpp (oracle/ref_wrap_plugin_on_binding.cpp: the binding takes the place of the reference's controller.h,
+# src/controller.cpp is not compiled, the C ABI is the recorder of tests/host_harness/facade_step_host.cpp) -- and run side by side
+def _plugin_variants():
+    import copy
+    import configure_cases
+    car = configure_cases.base_carlike()
+    car["controller"]["outer_ocp_iterations"] = 1
+    car["footprint_model"] = {"type": "line", "line_start": [0.0, 0.0], "line_end": [0.4, 0.0]}
+    v = {"carlike_line_footprint": car}
+    a = copy.deepcopy(car); a["controller"]["global_plan_viapoint_sep"] = 0.6; a["planning"]["objective"] = {"type": "minimum_time_via_points", "minimum_time_via_points": {"position_weight": 8.0}}
+    a["controller"]["outer_ocp_iterations"] = 2; a["footprint_model"] = {"type": "polygon", "vertices": [[0.3, 0.2], [-0.3, 0.2], [-0.3, -0.2], [0.3, -0.2]]}
+    v["via_points_polygon_footprint"] = a
+    a = copy.deepcopy(car); a["robot"] = {"type": "unicycle"}; a["grid"]["variable_grid"]["enable"] = False; a["grid"]["xf_fixed"] = [False, False, False]
+    a["planning"]["objective"] = {"type": "quadratic_form", "quadratic_form": {"state_weights": [2.0, 2.0, 0.25], "control_weights": [0.1, 0.05]}}
+    a["controller"]["global_plan_overwrite_orientation"] = False; a["collision_avoidance"]["include_costmap_obstacles"] = False; a["footprint_model"] = {"type": "circular", "radius": 0.25}
+    v["unicycle_quadratic_fixed_grid_no_costmap_obstacles"] = a
+    a = copy.deepcopy(car); a["controller"]["max_global_plan_lookahead_dist"] = 3.0; a["controller"]["global_plan_prune_distance"] = 0.5; a["collision_avoidance"]["costmap_obstacles_behind_robot_dist"] = 0.3
+    a["collision_avoidance"]["collision_check_no_poses"] = 5; a["collision_avoidance"]["collision_check_min_resolution_angular"] = 0.2; a["footprint_model"] = {"type": "point"}
+    v["long_lookahead_short_feasibility_check"] = a
+    return v
+
+
+@pytest.mark.skipif(not os.path.isdir(RL.REFERENCE_INCLUDE), reason="the reference tree is only present in the build container")
+@pytest.mark.parametrize("variant", ["carlike_line_footprint", "via_points_polygon_footprint", "unicycle_quadratic_fixed_grid_no_costmap_obstacles", "long_lookahead_short_feasibility_check"])
+def test_reference_plugin_source_runs_unchanged_on_the_binding(variant):
+    """initialize() -> setPlan() -> 40 x computeVelocityCommands() on a costmap with obstacles (a wall appears in front of the robot for four cycles: the feasibility check
+    trips, the planner resets) and one failing solve: the two builds agree at every cycle in the mbf outcome code, the velocity command, the obstacle and via-point containers,
+    the goal flag, the infeasible-plan counter, the planned trajectory and the vertex values handed to the solver"""
+    assert RL.build()
+    from mpc_local_planner_amd import params as PP
+    prm = _plugin_variants()[variant]
+    cfg = PP.config_from_params(prm)[0]
+    rng = np.random.default_rng(7)
+    cost = np.zeros((100, 120), np.uint8)
+    for _ in range(25):
+        i, j = rng.integers(5, 95), rng.integers(30, 115)
+        cost[i:i + 2, j:j + 2] = 254
+    fp = [(0.2, 0.1), (-0.2, 0.1), (-0.2, -0.1), (0.2, -0.1)]
+    mk = lambda: dict(calls=0, dt_factor=0.97, free_dt=bool(cfg.dt_free), fixed=[bool(f) for f in cfg.xf_fixed], fail_at={9})
+    sa, sb = mk(), mk()
+    A = RL.PluginRunner(prm, cost, 0.1, (-2.0, -5.0), footprint=fp, solver=lambda *a: CS.stand_in_solver(*a, sa))
+    B = RL.PluginRunner(prm, cost, 0.1, (-2.0, -5.0), footprint=fp, solver=lambda *a: CS.stand_in_solver(*a, sb), lib=RL.load_plugin_on_binding(), prefix="amd_plugin_")
+    assert A.initialized and B.initialized
+    plan = np.stack([np.linspace(0, 8, 60), 1.5 * np.sin(np.linspace(0, 3, 60)), np.zeros(60)], 1)
+    plan[:-1, 2] = np.arctan2(np.diff(plan[:, 1]), np.diff(plan[:, 0])); plan[-1, 2] = plan[-2, 2]
+    assert A.set_plan(plan) and B.set_plan(plan)
+    pose = np.array([0.0, 0.0, 0.2])
+    codes = []
+    for i in range(40):
+        if i == 20:
+            k = int((pose[0] + 0.25 + 2.0) / 0.1); cost[:, k:k + 2] = 254
+        if i == 24:
+            cost[:, :] = 0
+        a, b = A.cycle(pose, (0.1, 0.0, 0.02), cost), B.cycle(pose, (0.1, 0.0, 0.02), cost)
+        codes.append(a["code"])
+        assert a["code"] == b["code"] and np.abs(a["cmd"] - b["cmd"]).max() < 1e-12, (i, a["code"], b["code"], a["cmd"], b["cmd"])
+        assert (a["n_obstacles"], a["n_via"], a["goal_reached"], a["infeasible_in_a_row"]) == (b["n_obstacles"], b["n_via"], b["goal_reached"], b["infeasible_in_a_row"]), i
+        assert a["x_seq"].shape == b["x_seq"].shape and (a["x_seq"].size == 0 or np.abs(a["x_seq"] - b["x_seq"]).max() < 1e-12), i
+        assert a["guess_x"].shape == b["guess_x"].shape and (a["guess_x"].size == 0 or (np.abs(a["guess_x"] - b["guess_x"]).max() < 1e-12 and abs(a["guess_dt"] - b["guess_dt"]) < 1e-15)), i
+        if a["code"] == 0 and len(a["x_seq"]) > 1:
+            pose = a["x_seq"][1].copy()
+    assert codes.count(0) >= 30 and codes.count(100) >= 2                     # SUCCESS and NO_VALID_CMD (failed solve; infeasible trajectory unless the check is short-sighted)
+    if variant == "via_points_polygon_footprint":
+        assert a["n_via"] > 0
+    A.close(); B.close()
