@@ -363,6 +363,7 @@ class Controller {
     // Controller::step(initial_plan, ...)  (src/controller.cpp:111-179)
     bool step(const std::vector<PoseSE2>& plan, const Twist& /*vel*/, double dt, double t, TimeSeries& u_seq, TimeSeries& x_seq) {
         const auto t_step0 = std::chrono::steady_clock::now();
+        _last_error.clear();
         if (!_h) { _last_error = "Controller must be configured before invoking step()."; return false; }
         if (plan.size() < 2) { _last_error = "Controller::step(): initial plan must contain at least two poses."; return false; }
         const PoseSE2& start = plan.front();

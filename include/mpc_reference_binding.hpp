@@ -181,6 +181,8 @@ class Controller {
         amd::Twist tw; tw.linear_x = vel.linear.x; tw.linear_y = vel.linear.y; tw.angular_z = vel.angular.z;
         amd::TimeSeries us, xs;
         const bool ok = _amd.step(plan, tw, dt, t.toSec(), us, xs);
+        if (!ok && !_amd.lastError().empty()) ROS_ERROR_STREAM("mpc_local_planner (hip): " << _amd.lastError());
+        else if (!ok) ROS_WARN_STREAM("mpc_local_planner (hip): the solve did not converge (" << _amd.lastIterations() << " iterations)");
         _x_last = xs;
         if (x_seq) { x_seq->clear(); for (int k = 0; k < xs.size(); ++k) { Eigen::VectorXd v(3); for (int i = 0; i < 3; ++i) v[i] = xs.at(k)[i]; x_seq->add(xs.time[(size_t)k], v); } }
         if (u_seq) { u_seq->clear(); for (int k = 0; k < us.size(); ++k) { Eigen::VectorXd v(2); for (int j = 0; j < 2; ++j) v[j] = us.at(k)[j]; u_seq->add(us.time[(size_t)k], v); } }

@@ -84,6 +84,8 @@ def load():
         lib.ref_plugin_set_plan.restype = I; lib.ref_plugin_set_plan.argtypes = [V, I, V]
         lib.ref_plugin_cycle.restype = C.c_uint; lib.ref_plugin_cycle.argtypes = [V, V, V, V, V, V, I, V]
         lib.ref_plugin_last_guess.restype = I; lib.ref_plugin_last_guess.argtypes = [V, I, V, V, V]
+        lib.ref_plugin_set_custom_obstacles.restype = None; lib.ref_plugin_set_custom_obstacles.argtypes = [V, I, V, V, V, V]
+        lib.ref_plugin_container.restype = I; lib.ref_plugin_container.argtypes = [V, I, I, V, V]
         _lib = lib
     return _lib
 
@@ -508,6 +510,34 @@ class PluginRunner:
         return {"code": int(code), "cmd": cmd, "n_obstacles": int(info[0]), "n_via": int(info[1]), "goal_reached": bool(info[2]), "infeasible_in_a_row": int(info[3]),
                 "x_seq": xs[:int(info[4])].copy(), "guess_x": gx[:n].copy(), "guess_u": gu[:max(n - 1, 0)].copy(), "guess_dt": float(gdt[0])}
 
+    def log(self, min_level=2):
+        """console lines (warnings and errors by default) since the plugin was created"""
+        f = self._f("log"); f.restype = C.c_int; f.argtypes = [C.c_char_p, C.c_int]
+        buf = C.create_string_buffer(1 << 16)
+        f(buf, len(buf))
+        lines = [(int(l.split("|", 1)[0]), l.split("|", 1)[1]) for l in buf.value.decode(errors="replace").splitlines() if "|" in l]
+        return [t for lv, t in lines if lv >= min_level]
+
+    def set_custom_obstacles(self, msgs):
+        """the "obstacles" topic: [{points: [(x, y, z), ...], radius, velocity: (vx, vy)}]"""
+        npts = np.array([len(m["points"]) for m in msgs], np.int32)
+        pts = np.ascontiguousarray([q for m in msgs for q in m["points"]], float).reshape(-1, 3)
+        rad = np.array([m.get("radius", 0.0) for m in msgs], float); vel = np.ascontiguousarray([m.get("velocity", (0.0, 0.0)) for m in msgs], float).reshape(-1, 2)
+        self._f("set_custom_obstacles")(self._h, len(msgs), _p(npts), _p(pts), _p(rad), _p(vel))
+
+    def _obstacle_dump(self, name, cap=1024, cap_v=16):
+        rec = np.zeros((cap, 4)); verts = np.zeros((cap, cap_v, 2))
+        n = self._f(name)(self._h, cap, cap_v, _p(rec), _p(verts))
+        return n, [(verts[o, :int(rec[o, 0])].copy(), float(rec[o, 1]), rec[o, 2:4].copy()) for o in range(max(min(n, cap), 0))]
+
+    def container(self):
+        """the plugin's obstacle container after the last cycle: (size, [(vertices, radius, velocity)])"""
+        return self._obstacle_dump("container")
+
+    def abi_obstacles(self):
+        """(binding build only) what was handed to mpc_solve_batch in the last cycle"""
+        return self._obstacle_dump("abi_obstacles")
+
     def close(self):
         if self._h:
             self._f("destroy")(self._h); self._h = None
@@ -533,5 +563,8 @@ def load_plugin_on_binding():
         lib.amd_plugin_set_plan.restype = I; lib.amd_plugin_set_plan.argtypes = [V, I, V]
         lib.amd_plugin_cycle.restype = C.c_uint; lib.amd_plugin_cycle.argtypes = [V, V, V, V, V, V, I, V]
         lib.amd_plugin_last_guess.restype = I; lib.amd_plugin_last_guess.argtypes = [V, I, V, V, V]
+        lib.amd_plugin_set_custom_obstacles.restype = None; lib.amd_plugin_set_custom_obstacles.argtypes = [V, I, V, V, V, V]
+        lib.amd_plugin_container.restype = I; lib.amd_plugin_container.argtypes = [V, I, I, V, V]
+        lib.amd_plugin_abi_obstacles.restype = I; lib.amd_plugin_abi_obstacles.argtypes = [V, I, I, V, V]
         _binding_lib = lib
     return _binding_lib

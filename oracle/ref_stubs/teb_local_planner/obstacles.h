@@ -72,7 +72,8 @@ class PolygonObstacle : public ShapeObstacle {
  public:
     void pushBackVertex(double x, double y) { pts.emplace_back(x, y); }
     void pushBackVertex(const Eigen::Vector2d& v) { pts.push_back(v); }
-    void finalizePolygon() { finalized = true; }
+    // teb computes the AREA centroid; this stand-in takes the mean of the vertices (only used to rank obstacles by distance in the binding)
+    void finalizePolygon() { finalized = true; double x = 0, y = 0; for (const auto& q : pts) { x += q.x(); y += q.y(); } if (!pts.empty()) _centroid = Eigen::Vector2d(x / pts.size(), y / pts.size()); }
     const Point2dContainer& vertices() const { return pts; }
     bool finalized = false;
 };

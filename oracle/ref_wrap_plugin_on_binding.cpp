@@ -60,4 +60,9 @@ struct SolverPort {
 #endif
 extern "C" {
 #include "ref_wrap_plugin_cycle.inc"
+#ifndef PLUGIN_ON_HIP
+int fs_last_obstacles(int cap, int cap_v, double* rec, double* verts);
+// what the binding handed to mpc_solve_batch in the last cycle (same layout as amd_plugin_container)
+int amd_plugin_abi_obstacles(void*, int cap, int cap_v, double* rec, double* verts) { return fs_last_obstacles(cap, cap_v, rec, verts); }
+#endif
 }

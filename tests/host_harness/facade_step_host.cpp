@@ -17,6 +17,8 @@ namespace {
 solve_cb g_solver = nullptr;
 std::vector<double> g_guess_x, g_guess_u; double g_guess_dt = 0; int g_guess_n = 0, g_guess_cold = 0;
 std::string g_err;
+std::vector<double> g_obst;          // per obstacle: n_vertices, radius, vx, vy, then 2 * V vertex coordinates
+int g_obst_n = -1, g_obst_stride = 0;
 }
 
 extern "C" {
@@ -28,8 +30,18 @@ int mpc_set_grid_sizes(mpc_solver* s, const int32_t* n_grid, int32_t) { s->n_gri
 int mpc_set_via_points(mpc_solver*, int32_t, const int32_t*, const double*) { return MPC_OK; }
 int mpc_check_feasibility(mpc_solver*, int32_t, const double*, const uint8_t*, int32_t, int32_t, double, const double*, const double*, int32_t, double, double, int32_t, int32_t* ok) { *ok = 1; return MPC_OK; }
 int mpc_solve_batch(mpc_solver* s, int32_t, const double* x0, const double* xf, const double* u_prev, const double* dt_prev, const double* x_init, const double* u_init,
-                    const double* dt_init, const mpc_obstacles*, double* x_out, double* u_out, double* dt_out, int32_t* status, int32_t* iters) {
+                    const double* dt_init, const mpc_obstacles* ob, double* x_out, double* u_out, double* dt_out, int32_t* status, int32_t* iters) {
     using namespace mpc_local_planner_amd;
+    g_obst_n = -1;
+    if (ob) {
+        const int V = s->cfg.max_vertices;
+        g_obst_n = ob->n_obstacles[0]; g_obst_stride = 4 + 2 * V; g_obst.assign((size_t)g_obst_n * g_obst_stride, 0.0);
+        for (int o = 0; o < g_obst_n; ++o) {
+            double* r = &g_obst[(size_t)o * g_obst_stride];
+            r[0] = ob->n_vertices[o]; r[1] = ob->radius ? ob->radius[o] : 0.0; r[2] = ob->velocity ? ob->velocity[2 * o] : 0.0; r[3] = ob->velocity ? ob->velocity[2 * o + 1] : 0.0;
+            for (int i = 0; i < 2 * ob->n_vertices[o]; ++i) r[4 + i] = ob->vertices[(size_t)o * V * 2 + i];
+        }
+    }
     const int n = s->n_grid;
     std::vector<double> x((size_t)3 * n), u((size_t)2 * (n - 1), 0.0);
     double dt = s->cfg.dt_ref;
@@ -89,7 +101,16 @@ int fs_step(void* p, int n_plan, const double* plan, const double* vel, double d
     *n_out = xs.size();
     return ok ? 1 : 0;
 }
-void fs_forget_guess() { g_guess_n = 0; }
+void fs_forget_guess() { g_guess_n = 0; g_obst_n = -1; }
+// the obstacles of the last mpc_solve_batch: rec [cap][4] = n_vertices, radius, vx, vy; verts [cap][cap_v][2]; returns their number (-1: none were handed over)
+int fs_last_obstacles(int cap, int cap_v, double* rec, double* verts) {
+    for (int o = 0; o < g_obst_n && o < cap; ++o) {
+        const double* r = &g_obst[(size_t)o * g_obst_stride];
+        for (int i = 0; i < 4; ++i) rec[4 * o + i] = r[i];
+        for (int i = 0; i < 2 * (int)r[0] && i < 2 * cap_v; ++i) verts[(size_t)o * cap_v * 2 + i] = r[4 + i];
+    }
+    return g_obst_n;
+}
 int fs_last_guess(int cap, double* x, double* u, double* dt, int* cold) {
     const int n = g_guess_n < cap ? g_guess_n : cap;
     for (int i = 0; i < 3 * n; ++i) x[i] = g_guess_x[(size_t)i];

@@ -772,3 +772,39 @@ def test_reference_plugin_source_runs_unchanged_on_the_binding(variant):
     if variant == "via_points_polygon_footprint":
         assert a["n_via"] > 0
     A.close(); B.close()
+
+
+@pytest.mark.skipif(not os.path.isdir(RL.REFERENCE_INCLUDE), reason="the reference tree is only present in the build container")
+def test_binding_hands_the_plugins_obstacle_container_to_the_abi():
+    """costmap cells and custom obstacle messages (circle, point, line, polygon; moving ones) end up in the plugin's ObstContainer; the binding turns that container into the
+    arrays of struct mpc_obstacles every cycle: same obstacles, same order, radius and velocity kept.  With a handle that holds fewer obstacles than the container, the
+    nearest to the robot are kept (and a warning is logged)"""
+    assert RL.build()
+    import configure_cases
+    prm = configure_cases.base_carlike()
+    prm["controller"]["outer_ocp_iterations"] = 1; prm["collision_avoidance"]["enable_dynamic_obstacles"] = True
+    prm["mpc_hip"] = {"max_obstacles": 40, "max_vertices": 6}
+    cost = np.zeros((60, 80), np.uint8); cost[30:33, 40:43] = 254; cost[10:12, 60:62] = 254
+    msgs = [{"points": [(1, 1, 0)], "radius": 0.3, "velocity": (0.1, 0.0)}, {"points": [(2, -1, 0)]}, {"points": [(1, 2, 0), (2, 2, 0)], "velocity": (0.0005, 0)},
+            {"points": [(3, 1, 0), (3.5, 1, 0), (3.5, 1.5, 0), (3, 1.6, 0)], "velocity": (0, -0.2)}]
+    for cap in (40, 8):
+        prm["mpc_hip"]["max_obstacles"] = cap
+        run = RL.PluginRunner(prm, cost, 0.1, (-2.0, -3.0), footprint=[(0.2, 0.1), (-0.2, 0.1), (-0.2, -0.1)], lib=RL.load_plugin_on_binding(), prefix="amd_plugin_")
+        assert run.initialized and run.set_plan(np.linspace([0, 0, 0], [4, 0.5, 0], 30))
+        run.set_custom_obstacles(msgs)
+        pose = np.array([0.0, 0.0, 0.1])
+        assert run.cycle(pose)["code"] == 0
+        n_c, cont = run.container(); n_a, abi = run.abi_obstacles()
+        assert n_c == 17 and len(cont) == 17                                   # 13 lethal cells inside the scan (9 + 4) + 4 messages
+        if cap >= n_c:
+            assert n_a == n_c
+            for (v1, r1, vel1), (v2, r2, vel2) in zip(cont, abi):
+                assert np.array_equal(v1, v2) and r1 == r2 and np.array_equal(vel1, vel2)
+            assert [v.shape[0] for v, _, _ in abi[-4:]] == [1, 1, 2, 4] and abi[-4][1] == 0.3 and np.array_equal(abi[-4][2], [0.1, 0.0]) and np.array_equal(abi[-2][2], [0.0, 0.0])
+        else:
+            assert n_a == cap
+            dist = np.array([np.hypot(*(v.mean(0) - pose[:2])) for v, _, _ in cont])          # centroid of points / segments / these polygons' vertices
+            kept = np.sort(dist)[:cap]
+            got = np.array([np.hypot(*(v.mean(0) - pose[:2])) for v, _, _ in abi])
+            assert np.allclose(np.sort(got), kept, atol=1e-9)
+        run.close()
