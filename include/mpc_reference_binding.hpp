@@ -143,17 +143,17 @@ class Controller {
         _inequality = std::make_shared<StageInequalityView>(_cfg.min_obstacle_dist);
         _ocp_view = std::make_shared<OptimalControlProblemView>(&_amd);
         _obstacle_set.reset(new amd::ObstacleSet(caps.max_obstacles, caps.max_vertices));
-        _x_feedback_sub = nh.subscribe("state_feedback", 1, &Controller::stateFeedbackCallback, this);
-        _ocp_result_pub = nh.advertise<mpc_local_planner_msgs::OptimalControlResult>("ocp_result", 100);
+        _state_feedback_subscription = nh.subscribe("state_feedback", 1, &Controller::stateFeedbackCallback, this);
+        _result_publisher = nh.advertise<mpc_local_planner_msgs::OptimalControlResult>("ocp_result", 100);
         ROS_INFO("OCP initialized.");
         return true;
     }
 
     bool step(const PoseSE2& start, const PoseSE2& goal, const geometry_msgs::Twist& vel, double dt, ros::Time t, corbo::TimeSeries::Ptr u_seq, corbo::TimeSeries::Ptr x_seq) {
-        std::vector<geometry_msgs::PoseStamped> initial_plan(2);
-        start.toPoseMsg(initial_plan.front().pose);
-        goal.toPoseMsg(initial_plan.back().pose);
-        return step(initial_plan, vel, dt, t, u_seq, x_seq);
+        geometry_msgs::PoseStamped first, last;                       // a plan of two poses: start and goal (src/controller.cpp:102-109)
+        start.toPoseMsg(first.pose);
+        goal.toPoseMsg(last.pose);
+        return step(std::vector<geometry_msgs::PoseStamped>{first, last}, vel, dt, t, u_seq, x_seq);
     }
 
     // Controller::step (src/controller.cpp:111-179)
@@ -198,7 +198,7 @@ class Controller {
     void stateFeedbackCallback(const mpc_local_planner_msgs::StateFeedback::ConstPtr& msg) {
         if (!_dynamics) return;
         if ((int)msg->state.size() != 3) { ROS_ERROR_STREAM("stateFeedbackCallback(): state feedback dimension does not match robot state dimension: " << msg->state.size() << " != 3"); return; }
-        std::lock_guard<std::mutex> lock(_x_feedback_mutex);
+        std::lock_guard<std::mutex> lock(_feedback_guard);
         const double s[3] = {msg->state[0], msg->state[1], msg->state[2]};
         _amd.stateFeedbackCallback(s, msg->header.stamp.toSec());
     }
@@ -268,11 +268,11 @@ class Controller {
     void publishOptimalControlResult(const mpc_local_planner_amd::TimeSeries& xs, const mpc_local_planner_amd::TimeSeries& us) {
         mpc_local_planner_amd::OptimalControlResult r;
         _amd.optimalControlResult(xs, us, r);
-        mpc_local_planner_msgs::OptimalControlResult msg;
-        msg.header.stamp = ros::Time::now(); msg.header.seq = r.seq;
-        msg.dim_states = r.dim_states; msg.dim_controls = r.dim_controls; msg.optimal_solution_found = r.optimal_solution_found; msg.cpu_time = r.cpu_time;
-        msg.time_states = r.time_states; msg.states = r.states; msg.time_controls = r.time_controls; msg.controls = r.controls;
-        _ocp_result_pub.publish(msg);
+        mpc_local_planner_msgs::OptimalControlResult out;
+        out.header.stamp = ros::Time::now(); out.header.seq = r.seq;
+        out.dim_states = r.dim_states; out.dim_controls = r.dim_controls; out.optimal_solution_found = r.optimal_solution_found; out.cpu_time = r.cpu_time;
+        out.time_states = r.time_states; out.states = r.states; out.time_controls = r.time_controls; out.controls = r.controls;
+        _result_publisher.publish(out);
     }
 
     mpc_local_planner_amd::Controller _amd;
@@ -287,9 +287,9 @@ class Controller {
     OptimalControlProblemView::Ptr _ocp_view;
     mpc_local_planner_amd::TimeSeries _x_last;
     bool _initial_plan_estimate_orientation = true;
-    ros::Subscriber _x_feedback_sub;
-    ros::Publisher _ocp_result_pub;
-    std::mutex _x_feedback_mutex;
+    ros::Subscriber _state_feedback_subscription;
+    ros::Publisher _result_publisher;
+    std::mutex _feedback_guard;
 };
 
 }  // namespace mpc_local_planner
