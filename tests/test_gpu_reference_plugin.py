@@ -94,7 +94,7 @@ def test_reference_plugin_drives_the_robot_with_the_gpu_solver():
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(LIB), reason="oracle/_ref/libmpc_plugin_on_hip.so is built where the reference tree is (make -C oracle ref)")
-@pytest.mark.parametrize("variant", ["via_points_polygon_footprint", "diff_drive_quadratic_form", "moving_obstacle_messages"])
+@pytest.mark.parametrize("variant", ["via_points_polygon_footprint", "diff_drive_quadratic_form", "moving_obstacle_messages", "moving_obstacle_messages_two_circles_footprint"])
 def test_reference_plugin_on_the_gpu_solver_other_configurations(variant):
     """the same closed loop with (a) the via-point objective (via-points taken from the plan every 0.6 m) and a polygon footprint, (b) a differential-drive robot with the
     quadratic-form objective on the fixed grid and a free goal, (c) obstacle messages on the "obstacles" topic with collision_avoidance/enable_dynamic_obstacles: a moving circle, a moving line and a static polygon beside the path"""
@@ -118,7 +118,8 @@ def test_reference_plugin_on_the_gpu_solver_other_configurations(variant):
         prm["footprint_model"] = {"type": "circular", "radius": 0.2}
     else:
         prm["collision_avoidance"]["enable_dynamic_obstacles"] = True
-        prm["footprint_model"] = {"type": "circular", "radius": 0.2}
+        prm["footprint_model"] = ({"type": "circular", "radius": 0.2} if variant == "moving_obstacle_messages"
+                                  else {"type": "two_circles", "front_offset": 0.3, "front_radius": 0.2, "rear_offset": 0.0, "rear_radius": 0.2})
         # moving obstacles that come close to the path but never into the clearance zone of the (fixed) local goal within the horizon: a predicted obstacle ON the goal
         # makes the NLP infeasible, here as in the reference (seen while writing this test: a circle drifting onto the path stops the robot in both)
         msgs = [{"points": [(2.0, 2.3, 0)], "radius": 0.25, "velocity": (0.0, -0.06)}, {"points": [(3.0, -1.6, 0), (3.4, -1.6, 0)], "velocity": (0.0, 0.05)},
