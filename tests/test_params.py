@@ -539,3 +539,28 @@ def test_footprint_model_reproduces_what_the_reference_plugin_builds(cpp, name):
     assert st == 0, rep
     _footprint_held_to_reference(ccfg, rec)
     assert bool(rec["complaints"]) == (len([l for l in rep.split("\n") if l]) > 0), (rec["complaints"], rep)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/mpc_local_planner_examples/cfg"), reason="the reference tree is only present in the build container")
+def test_the_reference_s_shipped_parameter_files_against_its_own_configure(cpp):
+    """every mpc_local_planner_params*.yaml under mpc_local_planner_examples/cfg and cfg/test_mpc_optim_node.yaml: loaded with the YAML loader rosparam uses, run through the
+    REFERENCE's Controller::configure (oracle/_ref, live) and through both parameter readers of this repository"""
+    import glob
+    import yaml
+    from oracle import ref_lib as RL
+    assert RL.build()
+    files = sorted(glob.glob("/root/reference/mpc_local_planner_examples/cfg/*/mpc_local_planner_params*.yaml")) + ["/root/reference/mpc_local_planner/cfg/test_mpc_optim_node.yaml"]
+    assert len(files) >= 4
+    for path in files:
+        tree = yaml.safe_load(open(path)) or {}
+        tree = tree.get("MpcLocalPlannerROS", tree)
+        status, log = RL.probe_configure(tree)
+        assert status == 1, (path, log)
+        ctl = RL.RefController(tree)
+        built = ctl.dump()
+        ctl.close()
+        cfg, ctrl, notes = P.config_from_params(tree)
+        _held_to_reference(cfg, ctrl, built)
+        st, ccfg, opt, rep = _cpp_config(cpp, tree)
+        assert st == 0, rep
+        _held_to_reference(ccfg, {k: opt[k] for k in ctrl}, built)
