@@ -503,11 +503,11 @@ class PluginRunner:
     def cycle(self, robot_pose, robot_vel=(0.0, 0.0, 0.0), cost=None):
         rp = np.ascontiguousarray(robot_pose, float); rv = np.ascontiguousarray(robot_vel, float)
         c = None if cost is None else np.ascontiguousarray(cost, np.uint8)
-        cmd = np.zeros(3); info = np.zeros(6); xs = np.zeros((self.CAP, 3))
+        cmd = np.zeros(3); info = np.zeros(8); xs = np.zeros((self.CAP, 3))
         code = self._f("cycle")(self._h, _p(rp), _p(rv), None if c is None else _p(c), _p(cmd), _p(info), self.CAP, _p(xs))
         gx = np.zeros((self.CAP, 3)); gu = np.zeros((self.CAP, 2)); gdt = np.zeros(1)
         n = self._f("last_guess")(self._h, self.CAP, _p(gx), _p(gu), _p(gdt))
-        return {"code": int(code), "cmd": cmd, "n_obstacles": int(info[0]), "n_via": int(info[1]), "goal_reached": bool(info[2]), "infeasible_in_a_row": int(info[3]),
+        return {"code": int(code), "cmd": cmd, "n_obstacles": int(info[0]), "n_via": int(info[1]), "goal_reached": bool(info[2]), "infeasible_in_a_row": int(info[3]), "feasibility_calls": int(info[6]), "feasibility_checksum": float(info[7]),
                 "x_seq": xs[:int(info[4])].copy(), "guess_x": gx[:n].copy(), "guess_u": gu[:max(n - 1, 0)].copy(), "guess_dt": float(gdt[0])}
 
     def log(self, min_level=2):

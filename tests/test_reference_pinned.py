@@ -754,7 +754,7 @@ def test_reference_plugin_source_runs_unchanged_on_the_binding(variant):
     plan[:-1, 2] = np.arctan2(np.diff(plan[:, 1]), np.diff(plan[:, 0])); plan[-1, 2] = plan[-2, 2]
     assert A.set_plan(plan) and B.set_plan(plan)
     pose = np.array([0.0, 0.0, 0.2])
-    codes = []
+    codes, checked = [], 0
     for i in range(40):
         if i == 20:
             k = int((pose[0] + 0.25 + 2.0) / 0.1); cost[:, k:k + 2] = 254
@@ -765,9 +765,12 @@ def test_reference_plugin_source_runs_unchanged_on_the_binding(variant):
         assert a["code"] == b["code"] and np.abs(a["cmd"] - b["cmd"]).max() < 1e-12, (i, a["code"], b["code"], a["cmd"], b["cmd"])
         assert (a["n_obstacles"], a["n_via"], a["goal_reached"], a["infeasible_in_a_row"]) == (b["n_obstacles"], b["n_via"], b["goal_reached"], b["infeasible_in_a_row"]), i
         assert a["x_seq"].shape == b["x_seq"].shape and (a["x_seq"].size == 0 or np.abs(a["x_seq"] - b["x_seq"]).max() < 1e-12), i
+        assert a["feasibility_calls"] == b["feasibility_calls"] and abs(a["feasibility_checksum"] - b["feasibility_checksum"]) < 1e-9, i      # the poses the costmap model was asked about
+        checked += a["feasibility_calls"]
         assert a["guess_x"].shape == b["guess_x"].shape and (a["guess_x"].size == 0 or (np.abs(a["guess_x"] - b["guess_x"]).max() < 1e-12 and abs(a["guess_dt"] - b["guess_dt"]) < 1e-15)), i
         if a["code"] == 0 and len(a["x_seq"]) > 1:
             pose = a["x_seq"][1].copy()
+    assert checked > 200
     assert codes.count(0) >= 30 and codes.count(100) >= 2                     # SUCCESS and NO_VALID_CMD (failed solve; infeasible trajectory unless the check is short-sighted)
     if variant == "via_points_polygon_footprint":
         assert a["n_via"] > 0
