@@ -568,3 +568,26 @@ def load_plugin_on_binding():
         lib.amd_plugin_abi_obstacles.restype = I; lib.amd_plugin_abi_obstacles.argtypes = [V, I, I, V, V]
         _binding_lib = lib
     return _binding_lib
+
+
+EDGES_LIB = os.path.join(_HERE, "_ref", "libmpc_ref_edges.so")
+_edges_lib = None
+
+
+def create_edges(x, u, dt, xf_fixed=(1, 1, 1), cost_integration="left_sum", cost_integral=False, eq_integral=False, ineq_integral=False, final_cost=False, final_constraint=None):
+    """the reference's FiniteDifferencesGridSE2::createEdges (oracle/ref_wrap_edges.cpp) on a grid holding (x, u, dt): [(set, kind, k, [vertex names])] in creation order;
+    final_constraint: None, "inequality" or "equality" (a string)"""
+    global _edges_lib
+    if _edges_lib is None:
+        _edges_lib = C.CDLL(EDGES_LIB)
+        _edges_lib.ref_edges_dump.restype = C.c_int
+        _edges_lib.ref_edges_dump.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_double, C.c_void_p] + [C.c_int] * 6 + [C.c_char_p, C.c_int]
+    x, u = _xu(x, u); fx = np.ascontiguousarray(xf_fixed, np.int32)
+    buf = C.create_string_buffer(1 << 18)
+    _edges_lib.ref_edges_dump(x.shape[0], _p(x), _p(u), float(dt), _p(fx), int(cost_integration == "trapezoidal_rule"), int(cost_integral), int(eq_integral), int(ineq_integral),
+                              int(final_cost), {None: 0, "inequality": 1, "equality": 2}[final_constraint], buf, len(buf))
+    out = []
+    for line in buf.value.decode().splitlines():
+        s_, kind, k, verts = line.split("|")
+        out.append((s_, kind, int(k), verts.split(",")))
+    return out

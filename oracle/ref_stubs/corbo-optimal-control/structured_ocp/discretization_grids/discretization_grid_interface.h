@@ -2,6 +2,8 @@
 // (include/mpc_local_planner/optimal_control/full_discretization_grid_base_se2.h) and the types in its signatures, reduced to what
 // src/optimal_control/full_discretization_grid_base_se2.cpp and finite_differences_variable_grid_se2.cpp touch.  No corbo code.
 #pragma once
+#include <string>
+#include <initializer_list>
 #include <functional>
 #include <corbo-core/time_series.h>
 #include <corbo-core/console.h>
@@ -12,8 +14,32 @@
 #include <corbo-systems/system_dynamics_interface.h>
 
 namespace corbo {
-class OptimizationEdgeSet {};
-class BaseEdge {};
+// an edge as a RECORD: its kind, the grid point it belongs to and the vertices it connects (oracle/ref_wrap_edges.cpp dumps them); no evaluation
+class BaseEdge {
+ public:
+    using Ptr = std::shared_ptr<BaseEdge>;
+    virtual ~BaseEdge() = default;
+    BaseEdge() = default;
+    BaseEdge(const std::string& kind_, int k_, std::initializer_list<const VertexInterface*> v) : kind(kind_), k(k_), vertices(v) {}
+    std::string kind, note;
+    int k = -1;
+    std::vector<const VertexInterface*> vertices;
+};
+class OptimizationEdgeSet {
+ public:
+    void clear() { objective.clear(); equalities.clear(); inequalities.clear(); }
+    void addObjectiveEdge(BaseEdge::Ptr e) { objective.push_back(e); }
+    void addEqualityEdge(BaseEdge::Ptr e) { equalities.push_back(e); }
+    void addInequalityEdge(BaseEdge::Ptr e) { inequalities.push_back(e); }
+    std::vector<BaseEdge::Ptr> objective, equalities, inequalities;
+};
+// what createEdges asks a stage function for
+struct StageFunctionHandle {
+    using Ptr = std::shared_ptr<StageFunctionHandle>;
+    bool integral_terms = false, equality = false;
+    bool hasIntegralTerms(int) const { return integral_terms; }
+    bool isEqualityConstraint() const { return equality; }
+};
 class BaseMixedEdge {};
 template <class T> class Factory { public: static Factory& instance() { static Factory f; return f; } };
 class StagePreprocessor { public: using Ptr = std::shared_ptr<StagePreprocessor>; };
@@ -22,6 +48,21 @@ class DiscretizationGridInterface;
 // bounds + the per-cycle update of the stage functions (association of obstacles / via-points): a no-op here, the rows are exercised on their own
 struct NlpFunctions {
     Eigen::VectorXd x_lb, x_ub, u_lb, u_ub;
+    // ---- for createEdges (src/optimal_control/finite_differences_grid_se2.cpp): the functions it asks about, and its three requests for edges, answered with RECORDS of the
+    // vertices that were handed over (which edges corbo would really build from them -- e.g. none for a term whose vertices are all fixed -- is corbo's business)
+    StageFunctionHandle::Ptr stage_cost, stage_equalities, stage_inequalities, final_stage_constraints;
+    bool has_final_cost = false;
+    void getNonIntegralStageFunctionEdges(int k, VectorVertex& x_k, VectorVertex& u_k, ScalarVertex& dt, VectorVertex& u_prev, ScalarVertex& dt_prev, std::vector<BaseEdge::Ptr>& cost_terms,
+                                          std::vector<BaseEdge::Ptr>&, std::vector<BaseEdge::Ptr>&) {
+        cost_terms.push_back(std::make_shared<BaseEdge>("non_integral_stage_functions", k, std::initializer_list<const VertexInterface*>{&x_k, &u_k, &dt, &u_prev, &dt_prev}));
+    }
+    BaseEdge::Ptr getFinalStateCostEdge(int k, VectorVertex& xf) { return has_final_cost ? std::make_shared<BaseEdge>("final_state_cost", k, std::initializer_list<const VertexInterface*>{&xf}) : nullptr; }
+    BaseEdge::Ptr getFinalStateConstraintEdge(int k, VectorVertex& xf) {
+        return final_stage_constraints ? std::make_shared<BaseEdge>("final_state_constraint", k, std::initializer_list<const VertexInterface*>{&xf}) : nullptr;
+    }
+    void getFinalControlDeviationEdges(int n, VectorVertex& u_ref, VectorVertex& u_prev, ScalarVertex& dt, std::vector<BaseEdge::Ptr>&, std::vector<BaseEdge::Ptr>&, std::vector<BaseEdge::Ptr>& ineq_terms) {
+        ineq_terms.push_back(std::make_shared<BaseEdge>("final_control_deviation", n, std::initializer_list<const VertexInterface*>{&u_ref, &u_prev, &dt}));
+    }
     void checkAndInitializeBoundDimensions(int x_dim, int u_dim) {
         auto fill = [](Eigen::VectorXd& v, int n, double val) { if (v.size() != n) { v = Eigen::VectorXd(n); for (int i = 0; i < n; ++i) v[i] = val; } };
         fill(x_lb, x_dim, -CORBO_INF_DBL); fill(x_ub, x_dim, CORBO_INF_DBL); fill(u_lb, u_dim, -CORBO_INF_DBL); fill(u_ub, u_dim, CORBO_INF_DBL);

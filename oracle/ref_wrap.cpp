@@ -9,6 +9,7 @@
 //   src/optimal_control/full_discretization_grid_base_se2.cpp, finite_differences_variable_grid_se2.cpp (+ headers), src/utils/time_series_se2.cpp
 //                                                                         the grid classes and the SE(2) time series: oracle/ref_wrap_grid.cpp
 //   src/optimal_control/quadratic_cost_se2.cpp, final_state_conditions_se2.cpp (+ headers)      cost terms, final-state cost, terminal ball: oracle/ref_wrap_cost.cpp
+//   src/optimal_control/finite_differences_grid_se2.cpp                  createEdges with record edges (own library): oracle/ref_wrap_edges.cpp
 //   src/controller.cpp (+ controller.h)                                  configure / step / isPoseTrajectoryFeasible / publishOptimalControlResult: oracle/ref_wrap_controller.cpp
 //   src/mpc_local_planner_ros.cpp (+ its header)                         costmap / message obstacles, via-points, goal heading, footprint parameters: oracle/ref_wrap_plugin.cpp
 //

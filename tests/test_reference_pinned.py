@@ -811,3 +811,72 @@ def test_binding_hands_the_plugins_obstacle_container_to_the_abi():
             got = np.array([np.hypot(*(v.mean(0) - pose[:2])) for v, _, _ in abi])
             assert np.allclose(np.sort(got), kept, atol=1e-9)
         run.close()
+
+
+@pytest.mark.skipif(not os.path.isdir(RL.REFERENCE_INCLUDE), reason="the reference tree is only present in the build container")
+@pytest.mark.parametrize("rule", ["non_integral", "left_sum", "trapezoidal_rule"])
+@pytest.mark.parametrize("xf_fixed", [(True, True, True), (False, False, False)])
+def test_reference_form_nlp_is_the_reference_s_terms_on_the_reference_s_edge_layout(rule, xf_fixed):
+    """the reference's createEdges (src/optimal_control/finite_differences_grid_se2.cpp:36-154), compiled and executed with record edges (oracle/ref_wrap_edges.cpp), says which
+    vertices every term is built on: the previous control and ITS dt at k = 0, u_{k-1} and the grid's dt afterwards, xf as the successor of x_{n-2}, (u_ref, u_{n-2}, dt) for the
+    closing control-deviation edge, final-state edges only while xf is not fixed.  Evaluating the EXECUTED reference terms (collocation rows, rate rows, cost integrands, final
+    cost, terminal ball) on exactly those vertices reproduces oracle/se2_nlp.py::ReferenceNlp -- equalities, rate rows, terminal ball and objective"""
+    import dataclasses
+    assert RL.build()
+    rng = np.random.default_rng(5)
+    n = 7
+    x = np.cumsum(rng.uniform(-0.1, 0.4, (n, 3)), 0); x[:, 2] = rng.uniform(-np.pi, np.pi, n)
+    u = rng.normal(0, 0.3, (n - 1, 2)); dt = 0.23
+    goal = x[-1] + rng.normal(0, 0.3, 3); goal[2] = float(R.normalize_theta(goal[2]))
+    if all(xf_fixed):
+        x[-1] = goal                                   # a fixed final state sits on the goal
+    u_prev, dt_prev = rng.normal(0, 0.2, 2), 0.11
+    Q, Rw, Qf, S, gamma = np.array([2.0, 1.5, 0.3]), np.array([0.4, 0.2]), np.array([5.0, 4.0, 1.0]), np.array([1.0, 1.0, 0.2]), 0.5
+    du_lb, du_ub = np.array([-0.5, -0.6]), np.array([0.7, 0.8])
+    cfg = dataclasses.replace(R.config_unicycle_quadratic(n), Q=Q, R=Rw, Qf=Qf, terminal_ball_S=S, terminal_ball_gamma=gamma, xf_fixed=xf_fixed, integral_form=rule != "non_integral",
+                              cost_integration="left_sum" if rule == "non_integral" else rule, dt_free=False, dt_ref=dt, du_lb=du_lb, du_ub=du_ub, collocation=R.COLLOC_FORWARD)
+    nlp = R.ReferenceNlp(cfg, R.CycleInputs(x0=x[0], xf=goal, u_prev=u_prev, dt_prev=dt_prev))
+    z = nlp.pack(R.Trajectory(x.copy(), u.copy(), dt))
+    edges = RL.create_edges(x, u, dt, [int(f) for f in xf_fixed], "trapezoidal_rule" if rule == "trapezoidal_rule" else "left_sum", cost_integral=rule != "non_integral",
+                            final_cost=True, final_constraint="inequality")
+    val = {f"x{k}": x[k] for k in range(n - 1)}
+    val.update({f"u{k}": u[k] for k in range(n - 1)})
+    val.update({"xf": x[-1], "dt": dt, "u_prev": u_prev, "u_prev_dt": dt_prev, "u_ref": np.zeros(2)})
+    model_par = MODELS[cfg.model]
+    J, eq, ineq = 0.0, [], []
+    Qm, Rm = np.diag(Q), np.diag(Rw)
+    for s_, kind, k, v in edges:
+        if kind == "non_integral_stage_functions":
+            xk, uk, dtk, up, dtp = (val[name] for name in v)
+            assert (v[3], v[4]) == (("u_prev", "u_prev_dt") if k == 0 else (f"u{k - 1}", "dt")) and v[2] == "dt"
+            if rule == "non_integral":                               # state term (executed reference) + corbo's control term u' R u
+                J += RL.quadratic_cost(Qm, Rm, xk[None], goal, uk[None], form=True)[0] + float(uk @ Rm @ uk)
+            ineq += list(RL.control_deviation_rows(k, uk, up, dtp, du_lb, du_ub))
+        elif kind == "LeftSumCostEdge":
+            xk, uk, dtk = (val[name] for name in v)
+            J += dtk * RL.quadratic_cost(Qm, Rm, xk[None], goal, uk[None], form=True, integral=True)[0]
+        elif kind == "TrapezoidalIntegralCostEdge":
+            xk, uk, xn, dtk = (val[name] for name in v)
+            assert v[2] == ("xf" if k == n - 2 else f"x{k + 1}")
+            l = RL.quadratic_cost(Qm, Rm, np.stack([xk, xn]), goal, np.stack([uk, uk]), form=True, integral=True)
+            J += 0.5 * dtk * (l[0] + l[1])
+        elif kind == "FDCollocationEdge":
+            xk, uk, xn, dtk = (val[name] for name in v)
+            eq += list(RL.collocation(R.COLLOC_FORWARD, cfg.model, model_par, xk[None], uk[None], xn[None], dtk)[0])
+        elif kind == "final_state_cost":
+            J += RL.final_state_cost(np.diag(Qf), val[v[0]][None], goal)[0]
+        elif kind == "final_state_constraint":
+            ball = RL.terminal_ball(np.diag(S), gamma, val[v[0]][None], goal)[0]
+        elif kind == "final_control_deviation":
+            assert v == ["u_ref", f"u{n - 2}", "dt"]
+            closing = list(RL.control_deviation_rows(k, val[v[0]], val[v[1]], val[v[2]], du_lb, du_ub))
+    kinds = [e[1] for e in edges]
+    assert ("final_state_cost" in kinds) == ("final_state_constraint" in kinds) == (not all(xf_fixed))
+    if all(xf_fixed):
+        ours_ineq = np.array(ineq + closing)
+    else:
+        ours_ineq = np.array(ineq + [ball] + closing)                 # the oracle lists: rate rows per grid point, the terminal ball, the closing rate rows
+    assert np.abs(np.array(eq) - nlp.equalities(z)).max() < 1e-14
+    g = nlp.inequalities(z)
+    assert g.shape == ours_ineq.shape and np.abs(g - ours_ineq).max() < 1e-13
+    assert abs(J - nlp.objective(z)) < 1e-12 * max(1.0, abs(J))
