@@ -367,6 +367,68 @@ def main():
         json.dump(fp, f, indent=1, sort_keys=True)
     print("written plugin-input records: 12 costmaps,", V3, "plans,", M3, "obstacle message arrays,", len(fp), "footprint parameter sets")
 
+    # ---- plugin-level closed loop with REAL solves on the CPU: the reference's plugin + the reference's Controller (oracle/_ref), the C oracle's interior-point solve plugged
+    # in as its solver (obstacles of the cycle taken from the plugin's container).  tests/test_gpu_reference_plugin.py replays the recorded poses on the plugin-on-hip build and
+    # compares the commands and the planned trajectories.
+    from oracle import c_oracle as CO, se2_nlp as R2
+    import dataclasses
+    CO.build()
+    prm = configure_cases.base_carlike()
+    prm["footprint_model"] = {"type": "line", "line_start": [0.0, 0.0], "line_end": [0.4, 0.0]}
+    prm["controller"]["outer_ocp_iterations"] = 2
+    prm["mpc_hip"] = {"max_obstacles": 32, "max_vertices": 4}
+    cfgp = PP.config_from_params(prm)[0]
+    cost = np.zeros((100, 140), np.uint8)
+    res, org = 0.1, (-2.0, -5.0)
+    plan = np.stack([np.linspace(0, 9, 70), 1.2 * np.sin(np.linspace(0, 3, 70)), np.zeros(70)], 1)
+    plan[:-1, 2] = np.arctan2(np.diff(plan[:, 1]), np.diff(plan[:, 0])); plan[-1, 2] = plan[-2, 2]
+    for k in (18, 33, 48):
+        c_ = plan[k, :2] + np.array([0.0, 0.55 if (k // 15) % 2 else -0.55])
+        j_, i_ = int((c_[0] - org[0]) / res), int((c_[1] - org[1]) / res)
+        cost[i_:i_ + 2, j_:j_ + 2] = 254
+    fp = [(0.45, 0.15), (-0.05, 0.15), (-0.05, -0.15), (0.45, -0.15)]
+    runner = RL.PluginRunner(prm, cost, res, org, footprint=fp)
+    O_, V_ = 32, 4
+    solves = []
+
+    def oracle_solver(x, u, dt, u_prev, dt_prev):
+        n = x.shape[0]
+        ocfg = dataclasses.replace(R2.config_carlike_min_time(n), model_params=(cfgp.model_params[0],), dt_ref=cfgp.dt_ref, dt_lb=cfgp.dt_lb, dt_ub=cfgp.dt_ub,
+                                   u_lb=np.array(list(cfgp.u_lb)), u_ub=np.array(list(cfgp.u_ub)), du_lb=np.array(list(cfgp.du_lb)), du_ub=np.array(list(cfgp.du_ub)),
+                                   footprint_kind=int(cfgp.footprint_kind), footprint_params=tuple(cfgp.footprint_params), min_obstacle_dist=cfgp.min_obstacle_dist,
+                                   force_inclusion_dist=cfgp.force_inclusion_dist, cutoff_dist=cfgp.cutoff_dist)
+        count, cont = runner.container()
+        assert count <= O_
+        nv = np.zeros((1, O_), np.int32); vt = np.zeros((1, O_, V_, 2)); rad = np.zeros((1, O_)); vel = np.zeros((1, O_, 2))
+        for i, (v, r, ve) in enumerate(cont):
+            nv[0, i] = len(v); vt[0, i, :len(v)] = v; rad[0, i] = r; vel[0, i] = ve
+        ui = np.vstack([u, u[-1:]])[None]
+        xo, uo, do, st, it = CO.solve_batch(CO.from_nlp_config(ocfg, max_iter=int(cfgp.max_iter), tol=float(cfgp.tol), mu_init=float(cfgp.mu_init), hessian_mode=int(cfgp.hessian_mode)),
+                                            x[None, 0], x[None, -1], u_prev[None], np.array([dt_prev]), init=(x[None], ui, np.array([dt])),
+                                            obstacles=(np.array([count], np.int32), nv, vt, rad, vel), obst=CO.obst_from_nlp_config(ocfg, O_, V_, int(cfgp.max_obstacle_rows)))
+        solves.append((int(st[0]), int(it[0])))
+        return xo[0], uo[0, :n - 1], float(do[0]), st[0] == 0
+    runner.solver = oracle_solver
+    assert runner.initialized and runner.set_plan(plan)
+    K, NCAP = 60, 52
+    cl = dict(cost=cost, plan=plan, par=np.array([res, org[0], org[1]]), footprint=np.array(fp), pose=np.zeros((K, 3)), vel=np.zeros((K, 3)), code=np.zeros(K, np.int32), cmd=np.zeros((K, 3)),
+              n=np.zeros(K, np.int32), x_seq=np.zeros((K, NCAP, 3)), iters=np.zeros((K, 2), np.int32))
+    pose, vel = np.array([0.0, 0.0, 0.1]), np.zeros(3)
+    for i in range(K):
+        solves.clear()
+        o = runner.cycle(pose, vel)
+        m = o["x_seq"].shape[0]
+        cl["pose"][i], cl["vel"][i], cl["code"][i], cl["cmd"][i], cl["n"][i] = pose, vel, o["code"], o["cmd"], m
+        cl["x_seq"][i, :m] = o["x_seq"]; cl["iters"][i, :len(solves)] = [it for _, it in solves][:2]
+        v, phi = o["cmd"][0], o["cmd"][2]
+        pose = pose + 0.1 * np.array([v * np.cos(pose[2]), v * np.sin(pose[2]), v / 0.4 * np.tan(phi)])
+        vel = np.array([v, 0.0, phi])
+    runner.close()
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_plugin_closed_loop.npz"), **cl)
+    with open(os.path.join(ROOT, "tests", "golden", "ref_plugin_closed_loop_params.json"), "w") as f:
+        json.dump(prm, f, indent=1, sort_keys=True)
+    print("written plugin closed loop:", K, "cycles,", int((cl["code"] == 0).sum()), "SUCCESS, final pose", np.round(pose, 3), "iterations per solve (mean)", cl["iters"].mean())
+
 
 if __name__ == "__main__":
     main()
