@@ -530,6 +530,13 @@ class PluginRunner:
         n = self._f(name)(self._h, cap, cap_v, _p(rec), _p(verts))
         return n, [(verts[o, :int(rec[o, 0])].copy(), float(rec[o, 1]), rec[o, 2:4].copy()) for o in range(max(min(n, cap), 0))]
 
+    def goal_and_via_points(self):
+        """(local goal (3,), via-points (P, 3)) of the current / last cycle"""
+        f = self._f("goal_and_via_points"); f.restype = C.c_int; f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+        goal = np.zeros(3); via = np.zeros((64, 3))
+        n = f(self._h, _p(goal), 64, _p(via))
+        return goal, via[:n].copy()
+
     def container(self):
         """the plugin's obstacle container after the last cycle: (size, [(vertices, radius, velocity)])"""
         return self._obstacle_dump("container")

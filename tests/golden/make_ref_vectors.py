@@ -367,17 +367,13 @@ def main():
         json.dump(fp, f, indent=1, sort_keys=True)
     print("written plugin-input records: 12 costmaps,", V3, "plans,", M3, "obstacle message arrays,", len(fp), "footprint parameter sets")
 
-    # ---- plugin-level closed loop with REAL solves on the CPU: the reference's plugin + the reference's Controller (oracle/_ref), the C oracle's interior-point solve plugged
-    # in as its solver (obstacles of the cycle taken from the plugin's container).  tests/test_gpu_reference_plugin.py replays the recorded poses on the plugin-on-hip build and
-    # compares the commands and the planned trajectories.
-    from oracle import c_oracle as CO, se2_nlp as R2
-    import dataclasses
+    # ---- plugin-level closed loops with REAL solves on the CPU: the reference's plugin + the reference's Controller (oracle/_ref), the C oracle's interior-point solve plugged
+    # in as its solver (obstacles, goal and via-points of the cycle taken from the plugin).  tests/test_gpu_reference_plugin.py replays the recorded poses on the plugin-on-hip
+    # build and compares the commands and the planned trajectories.
+    from oracle import c_oracle as CO
+    import oracle_from_config
+    import copy
     CO.build()
-    prm = configure_cases.base_carlike()
-    prm["footprint_model"] = {"type": "line", "line_start": [0.0, 0.0], "line_end": [0.4, 0.0]}
-    prm["controller"]["outer_ocp_iterations"] = 2
-    prm["mpc_hip"] = {"max_obstacles": 32, "max_vertices": 4}
-    cfgp = PP.config_from_params(prm)[0]
     cost = np.zeros((100, 140), np.uint8)
     res, org = 0.1, (-2.0, -5.0)
     plan = np.stack([np.linspace(0, 9, 70), 1.2 * np.sin(np.linspace(0, 3, 70)), np.zeros(70)], 1)
@@ -387,48 +383,69 @@ def main():
         j_, i_ = int((c_[0] - org[0]) / res), int((c_[1] - org[1]) / res)
         cost[i_:i_ + 2, j_:j_ + 2] = 254
     fp = [(0.45, 0.15), (-0.05, 0.15), (-0.05, -0.15), (0.45, -0.15)]
-    runner = RL.PluginRunner(prm, cost, res, org, footprint=fp)
-    O_, V_ = 32, 4
-    solves = []
+    base = configure_cases.base_carlike()
+    base["controller"]["outer_ocp_iterations"] = 2
+    base["mpc_hip"] = {"max_obstacles": 32, "max_vertices": 4}
+    loops = {}
+    a_ = copy.deepcopy(base); a_["footprint_model"] = {"type": "line", "line_start": [0.0, 0.0], "line_end": [0.4, 0.0]}
+    loops["carlike_line_footprint"] = (a_, True)
+    a_ = copy.deepcopy(base); a_["controller"]["global_plan_viapoint_sep"] = 0.6
+    a_["planning"]["objective"] = {"type": "minimum_time_via_points", "minimum_time_via_points": {"position_weight": 8.0, "via_points_ordered": True}}
+    a_["footprint_model"] = {"type": "polygon", "vertices": [[0.45, 0.15], [-0.05, 0.15], [-0.05, -0.15], [0.45, -0.15]]}
+    loops["via_points_polygon_footprint"] = (a_, True)
+    a_ = copy.deepcopy(base)
+    a_["robot"] = {"type": "unicycle", "unicycle": {"max_vel_x": 0.4, "max_vel_x_backwards": 0.2, "max_vel_theta": 0.3, "acc_lim_x": 0.2, "dec_lim_x": 0.2, "acc_lim_theta": 0.2}}
+    a_["grid"]["variable_grid"]["enable"] = False; a_["grid"]["xf_fixed"] = [False, False, False]
+    a_["planning"]["objective"] = {"type": "quadratic_form", "quadratic_form": {"state_weights": [2.0, 2.0, 0.25], "control_weights": [0.1, 0.05], "integral_form": False}}
+    a_["planning"]["terminal_cost"] = {"type": "quadratic", "quadratic": {"final_state_weights": [10.0, 10.0, 0.5]}}
+    a_["controller"]["max_global_plan_lookahead_dist"] = 1.0
+    a_["footprint_model"] = {"type": "circular", "radius": 0.2}
+    loops["diff_drive_quadratic_form"] = (a_, False)
+    O_, V_, K, NCAP = 32, 4, 60, 52
+    for lname, (prm, car) in loops.items():
+        cfgp = PP.config_from_params(prm)[0]
+        runner = RL.PluginRunner(prm, cost, res, org, footprint=fp)
+        solves = []
 
-    def oracle_solver(x, u, dt, u_prev, dt_prev):
-        n = x.shape[0]
-        ocfg = dataclasses.replace(R2.config_carlike_min_time(n), model_params=(cfgp.model_params[0],), dt_ref=cfgp.dt_ref, dt_lb=cfgp.dt_lb, dt_ub=cfgp.dt_ub,
-                                   u_lb=np.array(list(cfgp.u_lb)), u_ub=np.array(list(cfgp.u_ub)), du_lb=np.array(list(cfgp.du_lb)), du_ub=np.array(list(cfgp.du_ub)),
-                                   footprint_kind=int(cfgp.footprint_kind), footprint_params=tuple(cfgp.footprint_params), min_obstacle_dist=cfgp.min_obstacle_dist,
-                                   force_inclusion_dist=cfgp.force_inclusion_dist, cutoff_dist=cfgp.cutoff_dist)
-        count, cont = runner.container()
-        assert count <= O_
-        nv = np.zeros((1, O_), np.int32); vt = np.zeros((1, O_, V_, 2)); rad = np.zeros((1, O_)); vel = np.zeros((1, O_, 2))
-        for i, (v, r, ve) in enumerate(cont):
-            nv[0, i] = len(v); vt[0, i, :len(v)] = v; rad[0, i] = r; vel[0, i] = ve
-        ui = np.vstack([u, u[-1:]])[None]
-        xo, uo, do, st, it = CO.solve_batch(CO.from_nlp_config(ocfg, max_iter=int(cfgp.max_iter), tol=float(cfgp.tol), mu_init=float(cfgp.mu_init), hessian_mode=int(cfgp.hessian_mode)),
-                                            x[None, 0], x[None, -1], u_prev[None], np.array([dt_prev]), init=(x[None], ui, np.array([dt])),
-                                            obstacles=(np.array([count], np.int32), nv, vt, rad, vel), obst=CO.obst_from_nlp_config(ocfg, O_, V_, int(cfgp.max_obstacle_rows)))
-        solves.append((int(st[0]), int(it[0])))
-        return xo[0], uo[0, :n - 1], float(do[0]), st[0] == 0
-    runner.solver = oracle_solver
-    assert runner.initialized and runner.set_plan(plan)
-    K, NCAP = 60, 52
-    cl = dict(cost=cost, plan=plan, par=np.array([res, org[0], org[1]]), footprint=np.array(fp), pose=np.zeros((K, 3)), vel=np.zeros((K, 3)), code=np.zeros(K, np.int32), cmd=np.zeros((K, 3)),
-              n=np.zeros(K, np.int32), x_seq=np.zeros((K, NCAP, 3)), iters=np.zeros((K, 2), np.int32))
-    pose, vel = np.array([0.0, 0.0, 0.1]), np.zeros(3)
-    for i in range(K):
-        solves.clear()
-        o = runner.cycle(pose, vel)
-        m = o["x_seq"].shape[0]
-        cl["pose"][i], cl["vel"][i], cl["code"][i], cl["cmd"][i], cl["n"][i] = pose, vel, o["code"], o["cmd"], m
-        cl["x_seq"][i, :m] = o["x_seq"]; cl["iters"][i, :len(solves)] = [it for _, it in solves][:2]
-        v, phi = o["cmd"][0], o["cmd"][2]
-        pose = pose + 0.1 * np.array([v * np.cos(pose[2]), v * np.sin(pose[2]), v / 0.4 * np.tan(phi)])
-        vel = np.array([v, 0.0, phi])
-    runner.close()
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_plugin_closed_loop.npz"), **cl)
-    with open(os.path.join(ROOT, "tests", "golden", "ref_plugin_closed_loop_params.json"), "w") as f:
-        json.dump(prm, f, indent=1, sort_keys=True)
-    print("written plugin closed loop:", K, "cycles,", int((cl["code"] == 0).sum()), "SUCCESS, final pose", np.round(pose, 3), "iterations per solve (mean)", cl["iters"].mean())
-
+        def oracle_solver(x, u, dt, u_prev, dt_prev, runner=runner, cfgp=cfgp, solves=solves):
+            n = x.shape[0]
+            ocfg = oracle_from_config.ocp_config(cfgp, n)
+            count, cont = runner.container()
+            goal, via = runner.goal_and_via_points()
+            assert count <= O_
+            nv = np.zeros((1, O_), np.int32); vt = np.zeros((1, O_, V_, 2)); rad = np.zeros((1, O_)); vel = np.zeros((1, O_, 2))
+            for i, (v, r, ve) in enumerate(cont):
+                nv[0, i] = len(v); vt[0, i, :len(v)] = v; rad[0, i] = r; vel[0, i] = ve
+            ui = np.vstack([u, u[-1:]])[None]
+            viap = None
+            if cfgp.objective == 2:
+                vp = np.zeros((1, 16, 3)); vp[0, :len(via)] = via
+                viap = (np.array([len(via)], np.int32), vp)
+            xo, uo, do, st, it = CO.solve_batch(CO.from_nlp_config(ocfg, max_iter=int(cfgp.max_iter), tol=float(cfgp.tol), mu_init=float(cfgp.mu_init), hessian_mode=int(cfgp.hessian_mode)),
+                                                x[None, 0], goal[None], u_prev[None], np.array([dt_prev]), init=(x[None], ui, np.array([dt])),
+                                                obstacles=(np.array([count], np.int32), nv, vt, rad, vel), obst=CO.obst_from_nlp_config(ocfg, O_, V_, int(cfgp.max_obstacle_rows)), via=viap)
+            solves.append(int(it[0]))
+            return xo[0], uo[0, :n - 1], float(do[0]), st[0] == 0
+        runner.solver = oracle_solver
+        assert runner.initialized and runner.set_plan(plan)
+        cl = dict(pose=np.zeros((K, 3)), vel=np.zeros((K, 3)), code=np.zeros(K, np.int32), cmd=np.zeros((K, 3)), n=np.zeros(K, np.int32), x_seq=np.zeros((K, NCAP, 3)), iters=np.zeros((K, 2), np.int32),
+                  n_via=np.zeros(K, np.int32))
+        pose, vel = np.array([0.0, 0.0, 0.1]), np.zeros(3)
+        for i in range(K):
+            solves.clear()
+            o = runner.cycle(pose, vel)
+            m = o["x_seq"].shape[0]
+            cl["pose"][i], cl["vel"][i], cl["code"][i], cl["cmd"][i], cl["n"][i], cl["n_via"][i] = pose, vel, o["code"], o["cmd"], m, o["n_via"]
+            cl["x_seq"][i, :m] = o["x_seq"]; cl["iters"][i, :len(solves[:2])] = solves[:2]
+            v, w = o["cmd"][0], o["cmd"][2]
+            pose = pose + 0.1 * np.array([v * np.cos(pose[2]), v * np.sin(pose[2]), (v / 0.4 * np.tan(w)) if car else w])
+            vel = np.array([v, 0.0, w])
+        runner.close()
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"ref_plugin_closed_loop_{lname}.npz"), cost=cost, plan=plan, par=np.array([res, org[0], org[1]]), footprint=np.array(fp), **cl)
+        with open(os.path.join(ROOT, "tests", "golden", f"ref_plugin_closed_loop_{lname}.json"), "w") as f:
+            json.dump(prm, f, indent=1, sort_keys=True)
+        print("written plugin closed loop", lname, ":", K, "cycles,", int((cl["code"] == 0).sum()), "SUCCESS, final pose", np.round(pose, 3), "mean iterations per solve", round(float(cl["iters"].mean()), 1),
+              "via-points", int(cl["n_via"].min()), "..", int(cl["n_via"].max()))
 
 if __name__ == "__main__":
     main()

@@ -159,15 +159,17 @@ def test_reference_plugin_on_the_gpu_solver_other_configurations(variant):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(LIB), reason="oracle/_ref/libmpc_plugin_on_hip.so is built where the reference tree is (make -C oracle ref)")
-def test_plugin_on_the_gpu_solver_reproduces_the_plugin_on_the_cpu_oracle():
-    """tests/golden/ref_plugin_closed_loop.npz: 60 control cycles of the reference's plugin WITH THE REFERENCE'S OWN Controller (oracle/_ref), the C oracle's interior-point
-    solve plugged in as its solver, recorded on the CPU (generator: tests/golden/make_ref_vectors.py).  Here the same robot poses are replayed on the plugin built on the
-    binding and the MI355X solver: the same outcome codes, the velocity commands and the planned trajectories within the north-star tolerance of 1e-4 at every cycle --
-    the reference's orchestration and the CPU restatement of the solve on one side, the binding and the GPU kernel on the other"""
+@pytest.mark.parametrize("loop", ["carlike_line_footprint", "via_points_polygon_footprint", "diff_drive_quadratic_form"])
+def test_plugin_on_the_gpu_solver_reproduces_the_plugin_on_the_cpu_oracle(loop):
+    """tests/golden/ref_plugin_closed_loop_<loop>.npz: 60 control cycles of the reference's plugin WITH THE REFERENCE'S OWN Controller (oracle/_ref), the C oracle's
+    interior-point solve plugged in as its solver, recorded on the CPU (generator: tests/golden/make_ref_vectors.py) -- car-like minimum time with a line footprint, the
+    via-point objective with a polygon footprint, differential drive with the quadratic form on the fixed grid and a free goal.  Here the same robot poses are replayed on
+    the plugin built on the binding and the MI355X solver: the same outcome codes, the velocity commands and the planned trajectories within the north-star tolerance of 1e-4
+    at every cycle -- the reference's orchestration and the CPU restatement of the solve on one side, the binding and the GPU kernel on the other"""
     import json
     from oracle import ref_lib as RL
-    rec = np.load(os.path.join(HERE, "golden", "ref_plugin_closed_loop.npz"))
-    prm = json.load(open(os.path.join(HERE, "golden", "ref_plugin_closed_loop_params.json")))
+    rec = np.load(os.path.join(HERE, "golden", f"ref_plugin_closed_loop_{loop}.npz"))
+    prm = json.load(open(os.path.join(HERE, "golden", f"ref_plugin_closed_loop_{loop}.json")))
     res, ox, oy = rec["par"]
     run = RL.PluginRunner(prm, rec["cost"], float(res), (float(ox), float(oy)), footprint=rec["footprint"], lib=_load(), prefix="hip_plugin_")
     assert run.initialized and run.set_plan(rec["plan"])
@@ -176,9 +178,9 @@ def test_plugin_on_the_gpu_solver_reproduces_the_plugin_on_the_cpu_oracle():
         o = run.cycle(rec["pose"][i], rec["vel"][i])
         assert o["code"] == rec["code"][i], (i, o["code"], run.log()[-2:])
         m = int(rec["n"][i])
-        assert o["x_seq"].shape[0] == m, (i, o["x_seq"].shape, m)
+        assert o["x_seq"].shape[0] == m and o["n_via"] == rec["n_via"][i], (i, o["x_seq"].shape, m)
         worst_cmd = max(worst_cmd, np.abs(o["cmd"] - rec["cmd"][i]).max())
         worst_x = max(worst_x, np.abs(o["x_seq"] - rec["x_seq"][i, :m]).max())
-    print(f"plugin on the GPU solver against the plugin on the CPU oracle: {rec['pose'].shape[0]} cycles, largest command difference {worst_cmd:.2e}, largest state difference {worst_x:.2e}")
+    print(f"{loop}: plugin on the GPU solver against the plugin on the CPU oracle, {rec['pose'].shape[0]} cycles: largest command difference {worst_cmd:.2e}, largest state difference {worst_x:.2e}")
     assert worst_cmd < 1e-4 and worst_x < 1e-4
     run.close()
