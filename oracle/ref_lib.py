@@ -573,6 +573,7 @@ def load_plugin_on_binding():
         lib.amd_plugin_set_custom_obstacles.restype = None; lib.amd_plugin_set_custom_obstacles.argtypes = [V, I, V, V, V, V]
         lib.amd_plugin_container.restype = I; lib.amd_plugin_container.argtypes = [V, I, I, V, V]
         lib.amd_plugin_abi_obstacles.restype = I; lib.amd_plugin_abi_obstacles.argtypes = [V, I, I, V, V]
+        lib.amd_plugin_goal_and_via_points.restype = I; lib.amd_plugin_goal_and_via_points.argtypes = [V, V, I, V]
         _binding_lib = lib
     return _binding_lib
 

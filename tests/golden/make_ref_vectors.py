@@ -371,7 +371,7 @@ def main():
     # in as its solver (obstacles, goal and via-points of the cycle taken from the plugin).  tests/test_gpu_reference_plugin.py replays the recorded poses on the plugin-on-hip
     # build and compares the commands and the planned trajectories.
     from oracle import c_oracle as CO
-    import oracle_from_config
+    import plugin_oracle_solver
     import copy
     CO.build()
     cost = np.zeros((100, 140), np.uint8)
@@ -401,31 +401,13 @@ def main():
     a_["controller"]["max_global_plan_lookahead_dist"] = 1.0
     a_["footprint_model"] = {"type": "circular", "radius": 0.2}
     loops["diff_drive_quadratic_form"] = (a_, False)
-    O_, V_, K, NCAP = 32, 4, 60, 52
+    K, NCAP = 60, 52
     for lname, (prm, car) in loops.items():
         cfgp = PP.config_from_params(prm)[0]
         runner = RL.PluginRunner(prm, cost, res, org, footprint=fp)
         solves = []
 
-        def oracle_solver(x, u, dt, u_prev, dt_prev, runner=runner, cfgp=cfgp, solves=solves):
-            n = x.shape[0]
-            ocfg = oracle_from_config.ocp_config(cfgp, n)
-            count, cont = runner.container()
-            goal, via = runner.goal_and_via_points()
-            assert count <= O_
-            nv = np.zeros((1, O_), np.int32); vt = np.zeros((1, O_, V_, 2)); rad = np.zeros((1, O_)); vel = np.zeros((1, O_, 2))
-            for i, (v, r, ve) in enumerate(cont):
-                nv[0, i] = len(v); vt[0, i, :len(v)] = v; rad[0, i] = r; vel[0, i] = ve
-            ui = np.vstack([u, u[-1:]])[None]
-            viap = None
-            if cfgp.objective == 2:
-                vp = np.zeros((1, 16, 3)); vp[0, :len(via)] = via
-                viap = (np.array([len(via)], np.int32), vp)
-            xo, uo, do, st, it = CO.solve_batch(CO.from_nlp_config(ocfg, max_iter=int(cfgp.max_iter), tol=float(cfgp.tol), mu_init=float(cfgp.mu_init), hessian_mode=int(cfgp.hessian_mode)),
-                                                x[None, 0], goal[None], u_prev[None], np.array([dt_prev]), init=(x[None], ui, np.array([dt])),
-                                                obstacles=(np.array([count], np.int32), nv, vt, rad, vel), obst=CO.obst_from_nlp_config(ocfg, O_, V_, int(cfgp.max_obstacle_rows)), via=viap)
-            solves.append(int(it[0]))
-            return xo[0], uo[0, :n - 1], float(do[0]), st[0] == 0
+        oracle_solver = plugin_oracle_solver.make(runner, cfgp, solves)
         runner.solver = oracle_solver
         assert runner.initialized and runner.set_plan(plan)
         cl = dict(pose=np.zeros((K, 3)), vel=np.zeros((K, 3)), code=np.zeros(K, np.int32), cmd=np.zeros((K, 3)), n=np.zeros(K, np.int32), x_seq=np.zeros((K, NCAP, 3)), iters=np.zeros((K, 2), np.int32),

@@ -880,3 +880,28 @@ def test_reference_form_nlp_is_the_reference_s_terms_on_the_reference_s_edge_lay
     g = nlp.inequalities(z)
     assert g.shape == ours_ineq.shape and np.abs(g - ours_ineq).max() < 1e-13
     assert abs(J - nlp.objective(z)) < 1e-12 * max(1.0, abs(J))
+
+
+@pytest.mark.skipif(not os.path.isdir(RL.REFERENCE_INCLUDE), reason="the reference tree is only present in the build container")
+@pytest.mark.parametrize("loop", ["carlike_line_footprint", "via_points_polygon_footprint", "diff_drive_quadratic_form"])
+def test_binding_reproduces_the_recorded_closed_loops_with_real_solves(loop):
+    """tests/golden/ref_plugin_closed_loop_<loop>.npz was recorded with the reference's plugin on the reference's own Controller and the C oracle's solve behind it.  The same
+    plugin source on the binding (recording C ABI, the same C oracle behind it), replaying the recorded poses: identical outcome codes, commands and planned trajectories to
+    1e-9 at each of the 60 cycles -- the CPU twin of tests/test_gpu_reference_plugin.py::test_plugin_on_the_gpu_solver_reproduces_the_plugin_on_the_cpu_oracle"""
+    import json
+    assert RL.build()
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import plugin_oracle_solver
+    from mpc_local_planner_amd import params as PP
+    rec = np.load(os.path.join(HERE, "golden", f"ref_plugin_closed_loop_{loop}.npz"))
+    prm = json.load(open(os.path.join(HERE, "golden", f"ref_plugin_closed_loop_{loop}.json")))
+    res, ox, oy = rec["par"]
+    run = RL.PluginRunner(prm, rec["cost"], float(res), (float(ox), float(oy)), footprint=rec["footprint"], lib=RL.load_plugin_on_binding(), prefix="amd_plugin_")
+    run.solver = plugin_oracle_solver.make(run, PP.config_from_params(prm)[0])
+    assert run.initialized and run.set_plan(rec["plan"])
+    for i in range(rec["pose"].shape[0]):
+        o = run.cycle(rec["pose"][i], rec["vel"][i])
+        m = int(rec["n"][i])
+        assert o["code"] == rec["code"][i] and o["x_seq"].shape[0] == m and o["n_via"] == rec["n_via"][i], i
+        assert np.abs(o["cmd"] - rec["cmd"][i]).max() < 1e-9 and np.abs(o["x_seq"] - rec["x_seq"][i, :m]).max() < 1e-9, i
+    run.close()
