@@ -456,6 +456,8 @@ class Controller {
     void reset() { _grid_empty = true; if (_h) mpc_reset(_h); }
 
     int lastIterations() const { return _last_iterations; }
+    // clearance rows of the last solve that did not fit into mpc_config.max_obstacle_rows per grid point (the reference has no cap: raise max_obstacle_rows when this is > 0)
+    int lastRowsDropped() const { int32_t d = 0; return (_h && mpc_last_rows_dropped(_h, 1, &d) == MPC_OK) ? d : 0; }
     double lastStepTime() const { return _last_step_time; }       // _statistics.step_time (src/controller.cpp:175), seconds
     double lastDt() const { return _dt_sol; }
     const std::string& lastError() const { return _last_error; }

@@ -13,8 +13,9 @@
 // Differences a maintainer should know (all reported, none silent):
 //   * footprint_model/type costmap_2d: teb's PolygonRobotFootprint has no accessor for its vertices, so the model object handed to configure() cannot be read
 //     back; call setCostmapFootprint(costmap_ros->getRobotFootprint()) before configure(), otherwise the point model is used and a warning is logged;
-//   * the handle's capacities come from two extra parameters, mpc_hip/max_obstacles (default 256) and mpc_hip/max_vertices (default 8); when a cycle has more
-//     obstacles than that, the nearest ones to the robot are kept and a warning is logged; a polygon with more vertices than max_vertices is an error (step fails);
+//   * the handle's capacities come from extra parameters, mpc_hip/max_obstacles (default 256), mpc_hip/max_vertices (default 8) and mpc_hip/max_obstacle_rows (clearance rows
+//     per grid point, default 4; the reference has no cap -- a warning says how many rows of a cycle did not fit); when a cycle has more obstacles than max_obstacles, the nearest
+//     ones to the robot are kept and a warning is logged; a polygon with more vertices than max_vertices is an error (step fails);
 //   * solver/type lsq_lm, an unknown collocation method and polygon footprints with more than 16 vertices are refused at configure() (the reference accepts them).
 #pragma once
 #include <algorithm>
@@ -123,10 +124,11 @@ class Controller {
         _obstacles = &obstacles; _via_points = &via_points;
         binding_detail::RosParamSource src(nh);
         amd::HandleCapacities caps;
-        int max_obstacles = 256, max_vertices = 8;
+        int max_obstacles = 256, max_vertices = 8, max_obstacle_rows = 0;
         nh.param("mpc_hip/max_obstacles", max_obstacles, max_obstacles);
         nh.param("mpc_hip/max_vertices", max_vertices, max_vertices);
-        caps.max_obstacles = max_obstacles; caps.max_vertices = max_vertices; caps.max_via_points = 16;
+        nh.param("mpc_hip/max_obstacle_rows", max_obstacle_rows, max_obstacle_rows);            // clearance rows per grid point; 0: the library's default (4)
+        caps.max_obstacles = max_obstacles; caps.max_vertices = max_vertices; caps.max_obstacle_rows = max_obstacle_rows; caps.max_via_points = 16;
         amd::ParamReport report;
         _amd.setInitialPlanEstimateOrientation(_initial_plan_estimate_orientation);
         std::string type; if (nh.getParam("footprint_model/type", type) && type == "costmap_2d" && _costmap_footprint.empty())
@@ -184,6 +186,8 @@ class Controller {
         if (!ok && !_amd.lastError().empty()) ROS_ERROR_STREAM("mpc_local_planner (hip): " << _amd.lastError());
         else if (!ok) ROS_WARN_STREAM("mpc_local_planner (hip): the solve did not converge (" << _amd.lastIterations() << " iterations)");
         _x_last = xs;
+        if (const int dropped = _amd.lastRowsDropped())
+            ROS_WARN_STREAM("mpc_local_planner (hip): " << dropped << " clearance rows did not fit (max_obstacle_rows per grid point); the reference keeps all of them");
         if (x_seq) { x_seq->clear(); for (int k = 0; k < xs.size(); ++k) { Eigen::VectorXd v(3); for (int i = 0; i < 3; ++i) v[i] = xs.at(k)[i]; x_seq->add(xs.time[(size_t)k], v); } }
         if (u_seq) { u_seq->clear(); for (int k = 0; k < us.size(); ++k) { Eigen::VectorXd v(2); for (int j = 0; j < 2; ++j) v[j] = us.at(k)[j]; u_seq->add(us.time[(size_t)k], v); } }
         if (_options.publish_ocp_results) publishOptimalControlResult(xs, us);

@@ -28,6 +28,7 @@ int mpc_reset(mpc_solver* s) { ++s->resets; return MPC_OK; }
 const char* mpc_last_error(void) { return g_err.c_str(); }
 int mpc_set_grid_sizes(mpc_solver* s, const int32_t* n_grid, int32_t) { s->n_grid = n_grid ? n_grid[0] : s->cfg.n; return MPC_OK; }
 int mpc_set_via_points(mpc_solver*, int32_t, const int32_t*, const double*) { return MPC_OK; }
+int mpc_last_rows_dropped(mpc_solver*, int32_t, int32_t* rows_dropped) { rows_dropped[0] = 0; return MPC_OK; }
 int mpc_check_feasibility(mpc_solver*, int32_t, const double*, const uint8_t*, int32_t, int32_t, double, const double*, const double*, int32_t, double, double, int32_t, int32_t* ok) { *ok = 1; return MPC_OK; }
 int mpc_solve_batch(mpc_solver* s, int32_t, const double* x0, const double* xf, const double* u_prev, const double* dt_prev, const double* x_init, const double* u_init,
                     const double* dt_init, const mpc_obstacles* ob, double* x_out, double* u_out, double* dt_out, int32_t* status, int32_t* iters) {
