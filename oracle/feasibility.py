@@ -14,7 +14,9 @@ base_local_planner/src/costmap_model.cpp + line_iterator.h + costmap_2d::Costmap
     (LineIterator = Bresenham, x0,y0 .. x1,y1) in order: NO_INFORMATION -> -2, LETHAL -> -1; the FIRST negative value is returned.
   worldToMap(wx, wy): false if wx < origin_x or wy < origin_y; m = (int)((w - origin) / resolution); false unless mx < size_x and my < size_y.
 (Older navigation releases return -1 for all three cases; with that convention unknown / outside cells would also make a trajectory
-infeasible.  The reference compares with -1 only.)  Parity unpinned (no tests or recorded outputs in the reference for this path).
+infeasible.  The reference compares with -1 only.)  Parity: the poses that are asked about and the early exit are PINNED to the reference's own
+isPoseTrajectoryFeasible, compiled and executed with a recording costmap model (tests/test_reference_pinned.py::test_feasibility_check_asks_about_the_same_poses_as_the_reference);
+footprintCost itself is third-party (base_local_planner) and stays restated from its published source.
 """
 import math
 

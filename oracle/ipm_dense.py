@@ -13,9 +13,10 @@ factorisation, no restoration phase -- with DENSE linear algebra (numpy.linalg)
 on the full KKT matrix.  The HIP product solves the same Newton systems with a
 stage-structured Riccati sweep; agreement of the two is the parity test.
 
-PARITY UNPINNED: no Ipopt here and no golden outputs in the reference; the
+PARITY UNPINNED for the solve: no Ipopt here and no golden outputs in the reference; the
 solution is cross-checked against scipy (SLSQP / trust-constr) on the
-reference-form NLP of oracle/se2_nlp.py, and by KKT residuals.
+reference-form NLP of oracle/se2_nlp.py, and by KKT residuals.  The NLP it solves is pinned
+to executed reference code where that was possible (header of oracle/se2_nlp.py).
 
 "Solver form" of the rows (same feasible set / same primal KKT points as the
 reference form, rows rescaled by positive factors):

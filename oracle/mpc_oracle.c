@@ -10,7 +10,10 @@
  * bordered (Schur) step for the global dt column -- i.e. linear algebra that shares nothing
  * with the product's Riccati sweep.
  *
- * PARITY UNPINNED: the reference ships no golden outputs and Ipopt/corbo are not vendored.
+ * PARITY: the reference ships no golden outputs and Ipopt/corbo are not vendored, so the SOLVE (the iterates, the point a non-convex problem converges to) is unpinned.
+ * The NLP pieces are pinned where the reference's own code could be compiled and executed (oracle/_ref): this file follows oracle/se2_nlp.py, which is held to the recorded
+ * outputs of the reference's models, collocation rules, costs, rate rows, association and via-point rules (tests/test_reference_pinned.py; the association of this file
+ * directly: test_c_oracle_association_reproduces_the_reference); teb's distance functions for lines / polygons / turning footprints are third-party and stay restated.
  *
  * NLP pieces and where they come from (paths under /root/reference/mpc_local_planner/):
  *   dynamics          include/mpc_local_planner/systems/{unicycle_robot.h:59-68,simple_car.h:68-77,131-141,
