@@ -124,6 +124,45 @@ struct ControllerOptions {
     }
 };
 
+// the parameters MpcLocalPlannerROS::initialize reads for ITSELF (src/mpc_local_planner_ros.cpp:96-125, :220; in-code defaults include/mpc_local_planner/mpc_local_planner_ros.h:369-391):
+// what a binding needs around the solve -- goal tolerances, plan pruning / look-ahead, via-point separation (via_points_from_plan), the costmap scan
+// (mpc_costmap_to_obstacles: include_costmap_obstacles, costmap_obstacles_behind_robot_dist), the feasibility check (mpc_check_feasibility: collision_check_*).
+// controller_frequency is move_base's own parameter (the control period handed to step() is its inverse, :380): read from `move_base` when given.
+struct PluginOptions {
+    double xy_goal_tolerance = 0.2, yaw_goal_tolerance = 0.1;
+    bool global_plan_overwrite_orientation = true;
+    double global_plan_prune_distance = 1.0, max_global_plan_lookahead_dist = 1.5, global_plan_viapoint_sep = -1.0;
+    std::string odom_topic = "odom";
+    bool is_footprint_dynamic = false, include_costmap_obstacles = true;
+    double costmap_obstacles_behind_robot_dist = 1.5;
+    int collision_check_no_poses = -1;
+    double collision_check_min_resolution_angular = 3.14159265358979323846;
+    std::string costmap_converter_plugin;
+    double costmap_converter_rate = 5.0;
+    bool costmap_converter_spin_thread = true;
+    double controller_frequency = 10.0;
+};
+inline PluginOptions plugin_options_from_params(const ParamSource& p, const ParamSource* move_base = nullptr) {
+    PluginOptions o;
+    o.xy_goal_tolerance = p.param("controller/xy_goal_tolerance", o.xy_goal_tolerance);
+    o.yaw_goal_tolerance = p.param("controller/yaw_goal_tolerance", o.yaw_goal_tolerance);
+    o.global_plan_overwrite_orientation = p.param("controller/global_plan_overwrite_orientation", o.global_plan_overwrite_orientation);
+    o.global_plan_prune_distance = p.param("controller/global_plan_prune_distance", o.global_plan_prune_distance);
+    o.max_global_plan_lookahead_dist = p.param("controller/max_global_plan_lookahead_dist", o.max_global_plan_lookahead_dist);
+    o.global_plan_viapoint_sep = p.param("controller/global_plan_viapoint_sep", o.global_plan_viapoint_sep);
+    o.odom_topic = p.param("odom_topic", o.odom_topic);
+    o.is_footprint_dynamic = p.param("footprint_model/is_footprint_dynamic", o.is_footprint_dynamic);
+    o.include_costmap_obstacles = p.param("collision_avoidance/include_costmap_obstacles", o.include_costmap_obstacles);
+    o.costmap_obstacles_behind_robot_dist = p.param("collision_avoidance/costmap_obstacles_behind_robot_dist", o.costmap_obstacles_behind_robot_dist);
+    o.collision_check_no_poses = p.param("collision_avoidance/collision_check_no_poses", o.collision_check_no_poses);
+    o.collision_check_min_resolution_angular = p.param("collision_avoidance/collision_check_min_resolution_angular", o.collision_check_min_resolution_angular);
+    o.costmap_converter_plugin = p.param("costmap_converter_plugin", o.costmap_converter_plugin);
+    o.costmap_converter_rate = p.param("costmap_converter_rate", o.costmap_converter_rate);
+    o.costmap_converter_spin_thread = p.param("costmap_converter_spin_thread", o.costmap_converter_spin_thread);
+    if (move_base) o.controller_frequency = move_base->param("controller_frequency", o.controller_frequency);
+    return o;
+}
+
 enum ParamStatus {
     PARAMS_OK = 0,
     PARAMS_REJECTED = 1,           // the reference's configure() returns false on this parameter set (error = its reason)

@@ -306,6 +306,32 @@ def config_from_params(params: dict, costmap_footprint=None, **sizing):
     return A.make_config(**kw), ctrl, notes
 
 
+def plugin_options_from_params(params: dict, move_base_params: dict | None = None) -> dict:
+    """The parameters that MpcLocalPlannerROS::initialize reads for ITSELF (src/mpc_local_planner_ros.cpp:96-125, :220), with the in-code defaults of
+    include/mpc_local_planner/mpc_local_planner_ros.h:369-391 -- what a binding needs around the solve: goal tolerances, plan pruning / look-ahead, via-point separation
+    (plugin_inputs.via_points_from_plan), the costmap scan (BatchSolver.costmap_to_obstacles: include_costmap_obstacles, costmap_obstacles_behind_robot_dist), the
+    feasibility check (BatchSolver.check_feasibility: collision_check_min_resolution_angular, collision_check_no_poses).  controller_frequency is move_base's own
+    parameter (the control period handed to step() is its inverse, :380): taken from move_base_params."""
+    p = _Reader(params)
+    mb = _Reader(move_base_params or {})
+    return {
+        "xy_goal_tolerance": p.get("controller/xy_goal_tolerance", 0.2), "yaw_goal_tolerance": p.get("controller/yaw_goal_tolerance", 0.1),
+        "global_plan_overwrite_orientation": p.get("controller/global_plan_overwrite_orientation", True),
+        "global_plan_prune_distance": p.get("controller/global_plan_prune_distance", 1.0),
+        "max_global_plan_lookahead_dist": p.get("controller/max_global_plan_lookahead_dist", 1.5),
+        "global_plan_viapoint_sep": p.get("controller/global_plan_viapoint_sep", -1.0),
+        "odom_topic": p.get("odom_topic", "odom"),
+        "is_footprint_dynamic": p.get("footprint_model/is_footprint_dynamic", False),
+        "include_costmap_obstacles": p.get("collision_avoidance/include_costmap_obstacles", True),
+        "costmap_obstacles_behind_robot_dist": p.get("collision_avoidance/costmap_obstacles_behind_robot_dist", 1.5),
+        "collision_check_no_poses": p.get("collision_avoidance/collision_check_no_poses", -1),
+        "collision_check_min_resolution_angular": p.get("collision_avoidance/collision_check_min_resolution_angular", math.pi),
+        "costmap_converter_plugin": p.get("costmap_converter_plugin", ""), "costmap_converter_rate": p.get("costmap_converter_rate", 5.0),
+        "costmap_converter_spin_thread": p.get("costmap_converter_spin_thread", True),
+        "controller_frequency": mb.get("controller_frequency", 10.0),
+    }
+
+
 def _is_number(v) -> bool:
     return isinstance(v, (int, float)) and not isinstance(v, bool)
 

@@ -477,12 +477,13 @@ class PluginRunner:
     computeVelocityCommands() cycle by cycle, a stand-in solver plugged in.  Entry points: prefix + create / set_solver / set_plan / cycle / last_guess / destroy"""
     CAP = 128
 
-    def __init__(self, params, cost, resolution, origin, footprint=(), solver=None, lib=None, prefix="ref_plugin_"):
+    def __init__(self, params, cost, resolution, origin, footprint=(), solver=None, lib=None, prefix="ref_plugin_", move_base_params=None):
         self._lib = lib or load()
         self._f = lambda name: getattr(self._lib, prefix + name)
         c = np.ascontiguousarray(cost, np.uint8); fp = np.ascontiguousarray(footprint, float).reshape(-1, 2)
         self._cost_shape = c.shape
-        self._h = self._f("create")("\n".join(plugin_param_lines(params)).encode(), c.shape[1], c.shape[0], _p(c), float(resolution), float(origin[0]), float(origin[1]), fp.shape[0], _p(fp))
+        lines = plugin_param_lines(params) + ["~/" + l for l in flatten_params(move_base_params or {})]           # NodeHandle("~"): move_base's own namespace
+        self._h = self._f("create")("\n".join(lines).encode(), c.shape[1], c.shape[0], _p(c), float(resolution), float(origin[0]), float(origin[1]), fp.shape[0], _p(fp))
         self.initialized = bool(self._f("initialized")(self._h))
         self.solver = solver
 
@@ -529,6 +530,20 @@ class PluginRunner:
         rec = np.zeros((cap, 4)); verts = np.zeros((cap, cap_v, 2))
         n = self._f(name)(self._h, cap, cap_v, _p(rec), _p(verts))
         return n, [(verts[o, :int(rec[o, 0])].copy(), float(rec[o, 1]), rec[o, 2:4].copy()) for o in range(max(min(n, cap), 0))]
+
+    PLUGIN_PARAMETER_NAMES = ("xy_goal_tolerance", "yaw_goal_tolerance", "global_plan_overwrite_orientation", "global_plan_prune_distance", "max_global_plan_lookahead_dist",
+                              "is_footprint_dynamic", "include_costmap_obstacles", "costmap_obstacles_behind_robot_dist", "global_plan_viapoint_sep",
+                              "collision_check_min_resolution_angular", "collision_check_no_poses", "controller_frequency", "costmap_converter_rate", "costmap_converter_spin_thread")
+
+    def parameters(self):
+        """the plugin-level parameters as initialize() read them"""
+        f = self._f("parameters"); f.restype = None; f.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int]
+        out = np.zeros(14); buf = C.create_string_buffer(1024)
+        f(self._h, _p(out), buf, len(buf))
+        d = dict(zip(self.PLUGIN_PARAMETER_NAMES, out.tolist()))
+        txt = buf.value.decode().split("\n")
+        d["odom_topic"], d["costmap_converter_plugin"] = txt[0], (txt[1] if len(txt) > 1 else "")
+        return d
 
     def goal_and_via_points(self):
         """(local goal (3,), via-points (P, 3)) of the current / last cycle"""

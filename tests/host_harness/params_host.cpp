@@ -35,3 +35,30 @@ extern "C" int ctl_config_from_params(const char* text, const char* costmap_fp, 
     report[report_cap - 1] = 0;
     return (int)st;
 }
+
+// plugin-level parameters (include/mpc_params.hpp::plugin_options_from_params): text / move_base_text as above; out [14] in the order of oracle/ref_lib.py::PLUGIN_PARAMETER_NAMES,
+// strings "odom_topic\ncostmap_converter_plugin"
+extern "C" void ctl_plugin_options(const char* text, const char* move_base_text, double* out, char* strings, int cap) {
+    using namespace mpc_local_planner_amd;
+    auto split = [](const std::string& s, char sep) { std::vector<std::string> o; std::string cur; std::istringstream is(s); while (std::getline(is, cur, sep)) o.push_back(cur); return o; };
+    auto fill = [&](const char* t, MapParamSource& src) {
+        for (auto& line : split(t, '\n')) {
+            auto f = split(line, '\t');
+            if (f.size() < 2) continue;
+            const std::string val = f.size() > 2 ? f[2] : "";
+            if (f[1] == "b") src.set(f[0], val == "1");
+            else if (f[1] == "i") src.set(f[0], std::stoi(val));
+            else if (f[1] == "d") src.set(f[0], std::stod(val));
+            else if (f[1] == "s") src.set(f[0], val);
+        }
+    };
+    MapParamSource a, b;
+    fill(text, a); fill(move_base_text, b);
+    const PluginOptions o = plugin_options_from_params(a, &b);
+    const double v[14] = {o.xy_goal_tolerance, o.yaw_goal_tolerance, (double)o.global_plan_overwrite_orientation, o.global_plan_prune_distance, o.max_global_plan_lookahead_dist,
+                          (double)o.is_footprint_dynamic, (double)o.include_costmap_obstacles, o.costmap_obstacles_behind_robot_dist, o.global_plan_viapoint_sep,
+                          o.collision_check_min_resolution_angular, (double)o.collision_check_no_poses, o.controller_frequency, o.costmap_converter_rate, (double)o.costmap_converter_spin_thread};
+    for (int i = 0; i < 14; ++i) out[i] = v[i];
+    const std::string s = o.odom_topic + "\n" + o.costmap_converter_plugin;
+    std::strncpy(strings, s.c_str(), (size_t)cap - 1); strings[cap - 1] = 0;
+}

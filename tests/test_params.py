@@ -564,3 +564,36 @@ def test_the_reference_s_shipped_parameter_files_against_its_own_configure(cpp):
         st, ccfg, opt, rep = _cpp_config(cpp, tree)
         assert st == 0, rep
         _held_to_reference(ccfg, {k: opt[k] for k in ctrl}, built)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/mpc_local_planner/src"), reason="the reference tree is only present in the build container")
+def test_plugin_level_parameters_against_the_reference_s_initialize(cpp):
+    """the parameters MpcLocalPlannerROS::initialize reads for itself (src/mpc_local_planner_ros.cpp:96-125, :220), executed (oracle/_ref, the whole plugin) on parameter sets
+    with defaults, explicit values and roscpp's conversions: plugin_options_from_params gives the same values"""
+    from oracle import ref_lib as RL
+    assert RL.build()
+    base = configure_cases.base_carlike()
+    sets = [({}, None), (base, None),
+            ({"controller": {"xy_goal_tolerance": 0.05, "yaw_goal_tolerance": 1, "global_plan_overwrite_orientation": False, "global_plan_prune_distance": 0.4,
+                             "max_global_plan_lookahead_dist": 3, "global_plan_viapoint_sep": 0.5},
+              "odom_topic": "/robot/odom", "footprint_model": {"is_footprint_dynamic": True},
+              "collision_avoidance": {"include_costmap_obstacles": False, "costmap_obstacles_behind_robot_dist": 0.7, "collision_check_no_poses": 6.6, "collision_check_min_resolution_angular": 0.3},
+              "costmap_converter_plugin": "", "costmap_converter_rate": 7, "costmap_converter_spin_thread": False}, {"controller_frequency": 20.0}),
+            ({"controller": {"global_plan_overwrite_orientation": 1, "xy_goal_tolerance": "0.3"}, "collision_avoidance": {"collision_check_no_poses": "4"}}, {"controller_frequency": 5})]
+    cost = np.zeros((10, 10), np.uint8)
+    for tree, mb in sets:
+        run = RL.PluginRunner(tree, cost, 0.1, (0.0, 0.0), footprint=[(0.2, 0.1), (-0.2, 0.1), (-0.2, -0.1)], move_base_params=mb)
+        assert run.initialized
+        ref = run.parameters()
+        run.close()
+        ours = P.plugin_options_from_params(tree, mb)
+        assert set(ours) == set(ref)
+        for k, v in ref.items():
+            assert (ours[k] == v) if isinstance(v, str) else (float(ours[k]) == v), (k, ours[k], v, tree)
+        out = np.zeros(14); strings = C.create_string_buffer(1024)
+        cpp.ctl_plugin_options.restype = None
+        cpp.ctl_plugin_options("\n".join(_flatten(tree)).encode(), "\n".join(_flatten(mb or {})).encode(), out.ctypes.data_as(C.c_void_p), strings, 1024)
+        got = dict(zip(RL.PluginRunner.PLUGIN_PARAMETER_NAMES, out.tolist()))
+        txt = strings.value.decode().split("\n")
+        got["odom_topic"], got["costmap_converter_plugin"] = txt[0], (txt[1] if len(txt) > 1 else "")
+        assert got == ref, (got, ref)
