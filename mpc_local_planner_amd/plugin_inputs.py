@@ -5,6 +5,7 @@
     obstacles_from_messages         updateObstacleContainerWithCostmapConverter (:501-541) / updateObstacleContainerWithCustomObstacles (:543-617)
     pack_obstacles                  the obstacle records -> the arrays of struct mpc_obstacles (include/mpc_hip.h) for one instance
     estimate_local_goal_orientation estimateLocalGoalOrientation (:807-852)
+    prune_global_plan / transform_global_plan   pruneGlobalPlan (:645-685) / transformGlobalPlan (:687-805)
 
 (the costmap -> point obstacle scan, :474-499, is the device kernel mpc_costmap_to_obstacles).  Each function is held to the reference's own source,
 compiled and executed by the test suite (tests/test_reference_pinned.py)."""
@@ -32,6 +33,60 @@ def via_points_from_plan(plan, min_separation: float) -> np.ndarray:
         out.append(plan[i])
         prev = i
     return np.array(out, float).reshape(-1, 3)
+
+
+def _to_global(transform, x, y, yaw):
+    c, s = math.cos(transform[0]), math.sin(transform[0])
+    return transform[1] + c * x - s * y, transform[2] + s * x + c * y, _yaw_compose(transform[0], yaw)
+
+
+def _to_plan_frame(transform, x, y):
+    c, s = math.cos(transform[0]), math.sin(transform[0])
+    dx, dy = x - transform[1], y - transform[2]
+    return c * dx + s * dy, -s * dx + c * dy
+
+
+def prune_global_plan(plan, robot_pose, transform: Sequence[float] = (0.0, 0.0, 0.0), dist_behind_robot: float = 1.0):
+    """pruneGlobalPlan (:645-685): cuts off the part of the global plan the robot has passed -- everything before the FIRST pose closer than dist_behind_robot to the robot.
+    plan (n, 3) in its own frame, robot_pose in the planning frame, transform = (yaw, tx, ty) plan frame -> planning frame.  Returns (True, plan'); with no pose that close the plan stays as it is -- and the
+    result is still True: as coded (:661-675, `erase_end` starts at begin(), not end()) the reference never reports the failure its `return false` was written for."""
+    plan = np.asarray(plan, float).reshape(-1, 3)
+    if plan.shape[0] == 0:
+        return True, plan
+    rx, ry = _to_plan_frame(transform, float(robot_pose[0]), float(robot_pose[1]))
+    for i in range(plan.shape[0]):
+        if (rx - plan[i, 0]) ** 2 + (ry - plan[i, 1]) ** 2 < dist_behind_robot * dist_behind_robot:
+            return True, plan[i:].copy()
+    return True, plan.copy()
+
+
+def transform_global_plan(plan, robot_pose, costmap_size_x: int, costmap_size_y: int, resolution: float, max_plan_length: float, transform: Sequence[float] = (0.0, 0.0, 0.0)):
+    """transformGlobalPlan (:687-805): the part of the global plan that is handed to the controller -- from the plan pose closest to the robot (searched only until the plan
+    leaves 85 % of the local costmap's half size) onwards, while the poses stay inside that radius and the length along the plan stays within max_plan_length (<= 0: no limit);
+    poses moved into the planning frame.  An empty selection yields the global goal alone.  Returns (poses (m, 3), index of the last selected pose in the global plan)."""
+    plan = np.asarray(plan, float).reshape(-1, 3)
+    n = plan.shape[0]
+    if n == 0:
+        raise ValueError("Received plan with zero length")
+    rx, ry = _to_plan_frame(transform, float(robot_pose[0]), float(robot_pose[1]))
+    thr = 0.85 * max(costmap_size_x * resolution / 2.0, costmap_size_y * resolution / 2.0)
+    sq_thr, sq_dist, i = thr * thr, 1e10, 0
+    for j in range(n):
+        d = (rx - plan[j, 0]) ** 2 + (ry - plan[j, 1]) ** 2
+        if d > sq_thr:
+            break
+        if d < sq_dist:
+            sq_dist, i = d, j
+    out, length = [], 0.0
+    while i < n and sq_dist <= sq_thr and (max_plan_length <= 0 or length <= max_plan_length):
+        out.append(_to_global(transform, *plan[i]))
+        sq_dist = (rx - plan[i, 0]) ** 2 + (ry - plan[i, 1]) ** 2
+        if i > 0 and max_plan_length > 0:
+            length += math.sqrt((plan[i, 0] - plan[i - 1, 0]) ** 2 + (plan[i, 1] - plan[i - 1, 1]) ** 2)
+        i += 1
+    if not out:
+        return np.array([_to_global(transform, *plan[-1])]), n - 1
+    return np.array(out, float), i - 1
 
 
 def obstacles_from_messages(msgs: Iterable[dict], converter: bool = True, transform: Sequence[float] = (0.0, 0.0, 0.0)):

@@ -77,6 +77,8 @@ def load():
         lib.ref_plugin_obstacle_messages.restype = I; lib.ref_plugin_obstacle_messages.argtypes = [I, I, V, V, V, V, V, I, I, V, V]
         lib.ref_plugin_footprint.restype = I; lib.ref_plugin_footprint.argtypes = [C.c_char_p, I, V, V, I, V, V, C.c_char_p, I]
         lib.ref_plugin_goal_orientation.restype = D; lib.ref_plugin_goal_orientation.argtypes = [I, V, V, I, V, I]
+        lib.ref_plugin_prune_plan.restype = I; lib.ref_plugin_prune_plan.argtypes = [I, V, V, V, D, V, V]
+        lib.ref_plugin_transform_plan.restype = I; lib.ref_plugin_transform_plan.argtypes = [I, V, V, I, I, D, D, V, V, V, V]
         lib.ref_plugin_create.restype = V; lib.ref_plugin_create.argtypes = [C.c_char_p, I, I, V, D, D, D, I, V]
         lib.ref_plugin_destroy.restype = None; lib.ref_plugin_destroy.argtypes = [V]
         lib.ref_plugin_initialized.restype = I; lib.ref_plugin_initialized.argtypes = [V]
@@ -459,6 +461,22 @@ def plugin_footprint(params, costmap_footprint=None, no_costmap=False):
     kind = load().ref_plugin_footprint("\n".join(_footprint_lines(params)).encode(), -1 if no_costmap else cfp.shape[0], _p(cfp), _p(args), 64, _p(verts), C.byref(nv), log, len(log))
     lines = [(int(l.split("|", 1)[0]), l.split("|", 1)[1]) for l in log.value.decode().splitlines() if "|" in l]
     return FOOTPRINT_KINDS[kind], args, verts[:nv.value].copy(), lines
+
+
+def plugin_prune_plan(plan, robot_pose, transform=(0.0, 0.0, 0.0), dist_behind_robot=1.0):
+    """pruneGlobalPlan: plan (n,3) in its frame, robot pose in the global frame, transform plan -> global (yaw, tx, ty) -> (ok, pruned plan)"""
+    pl = np.ascontiguousarray(plan, float).reshape(-1, 3); rp = np.ascontiguousarray(robot_pose, float); tr = np.ascontiguousarray(transform, float)
+    out = np.zeros((max(pl.shape[0], 1), 3)); n = C.c_int(0)
+    ok = load().ref_plugin_prune_plan(pl.shape[0], _p(pl), _p(rp), _p(tr), float(dist_behind_robot), _p(out), C.byref(n))
+    return bool(ok), out[:n.value].copy()
+
+
+def plugin_transform_plan(plan, robot_pose, size_x, size_y, resolution, max_plan_length, transform=(0.0, 0.0, 0.0)):
+    """transformGlobalPlan -> (ok, transformed plan (m,3) in the global frame, index of the current goal in the global plan)"""
+    pl = np.ascontiguousarray(plan, float).reshape(-1, 3); rp = np.ascontiguousarray(robot_pose, float); tr = np.ascontiguousarray(transform, float)
+    out = np.zeros((pl.shape[0] + 1, 3)); m = C.c_int(0); gi = C.c_int(0)
+    ok = load().ref_plugin_transform_plan(pl.shape[0], _p(pl), _p(rp), int(size_x), int(size_y), float(resolution), float(max_plan_length), _p(tr), _p(out), C.byref(m), C.byref(gi))
+    return bool(ok), out[:m.value].copy(), gi.value
 
 
 def plugin_goal_orientation(plan, local_goal, current_goal_idx, transform=(0.0, 0.0, 0.0), moving_average_length=3):

@@ -177,5 +177,39 @@ double ref_plugin_goal_orientation(int n_plan, const double* plan, const double*
     return p.estimateLocalGoalOrientation(poses, goal, current_goal_idx, t, moving_average_length);
 }
 
+// pruneGlobalPlan (:645-685): plan [n][3] in its own frame ("map"), the robot pose in the global frame ("odom"), the planar transform plan -> global (yaw, tx, ty);
+// out [n][3] = the pruned plan, *n_out its length; returns the function's result
+int ref_plugin_prune_plan(int n, const double* plan, const double* robot_pose, const double* transform, double dist_behind_robot, double* out, int* n_out) {
+    MpcLocalPlannerROS p;
+    tf2_ros::Buffer tf;
+    tf.answer.transform.rotation.z = std::sin(0.5 * transform[0]); tf.answer.transform.rotation.w = std::cos(0.5 * transform[0]);
+    tf.answer.transform.translation.x = transform[1]; tf.answer.transform.translation.y = transform[2];
+    std::vector<geometry_msgs::PoseStamped> poses((size_t)n);
+    for (int i = 0; i < n; ++i) { teb_local_planner::PoseSE2(plan[3 * i], plan[3 * i + 1], plan[3 * i + 2]).toPoseMsg(poses[(size_t)i].pose); poses[(size_t)i].header.frame_id = "map"; }
+    geometry_msgs::PoseStamped robot; teb_local_planner::PoseSE2(robot_pose[0], robot_pose[1], robot_pose[2]).toPoseMsg(robot.pose); robot.header.frame_id = "odom";
+    const bool ok = p.pruneGlobalPlan(tf, robot, poses, dist_behind_robot);
+    *n_out = (int)poses.size();
+    for (size_t i = 0; i < poses.size(); ++i) { teb_local_planner::PoseSE2 q(poses[i].pose); out[3 * i] = q.x(); out[3 * i + 1] = q.y(); out[3 * i + 2] = q.theta(); }
+    return ok ? 1 : 0;
+}
+// transformGlobalPlan (:687-805): as above plus the local costmap's size (cells) and resolution and max_plan_length; out [n][3] = the transformed plan (global frame),
+// *m its length, *goal_idx the index of the current goal in the global plan; returns the function's result
+int ref_plugin_transform_plan(int n, const double* plan, const double* robot_pose, int size_x, int size_y, double resolution, double max_plan_length, const double* transform, double* out,
+                              int* m, int* goal_idx) {
+    MpcLocalPlannerROS p;
+    tf2_ros::Buffer tf;
+    tf.answer.transform.rotation.z = std::sin(0.5 * transform[0]); tf.answer.transform.rotation.w = std::cos(0.5 * transform[0]);
+    tf.answer.transform.translation.x = transform[1]; tf.answer.transform.translation.y = transform[2];
+    std::vector<geometry_msgs::PoseStamped> poses((size_t)n), result;
+    for (int i = 0; i < n; ++i) { teb_local_planner::PoseSE2(plan[3 * i], plan[3 * i + 1], plan[3 * i + 2]).toPoseMsg(poses[(size_t)i].pose); poses[(size_t)i].header.frame_id = "map"; }
+    geometry_msgs::PoseStamped robot; teb_local_planner::PoseSE2(robot_pose[0], robot_pose[1], robot_pose[2]).toPoseMsg(robot.pose); robot.header.frame_id = "odom";
+    costmap_2d::Costmap2D cm((unsigned)size_x, (unsigned)size_y, resolution, 0.0, 0.0);
+    geometry_msgs::TransformStamped t;
+    *goal_idx = -1;
+    const bool ok = p.transformGlobalPlan(tf, poses, robot, cm, "odom", max_plan_length, result, goal_idx, &t);
+    *m = (int)result.size();
+    for (size_t i = 0; i < result.size(); ++i) { teb_local_planner::PoseSE2 q(result[i].pose); out[3 * i] = q.x(); out[3 * i + 1] = q.y(); out[3 * i + 2] = q.theta(); }
+    return ok ? 1 : 0;
+}
 #include "ref_wrap_plugin_cycle.inc"
 }  // extern "C"

@@ -358,6 +358,24 @@ def main():
         pl["ms_n"][s_] = k; pl["ms_converter"][s_] = conv; pl["ms_transform"][s_] = tr; pl["ms_count"][s_] = len(out)
         for i, (kind, verts, radius, dyn, vel) in enumerate(out):
             pl["ms_rec"][s_, i] = (kind, verts.shape[0], radius, dyn, *vel); pl["ms_verts"][s_, i, :verts.shape[0]] = verts
+    # pruneGlobalPlan / transformGlobalPlan
+    G3, GP = 80, 60
+    pl["gp_n"] = np.zeros(G3, np.int32); pl["gp_plan"] = np.zeros((G3, GP, 3)); pl["gp_par"] = np.zeros((G3, 11))
+    pl["gp_pruned_n"] = np.zeros(G3, np.int32); pl["gp_pruned_ok"] = np.zeros(G3, np.int32); pl["gp_pruned_first"] = np.zeros((G3, 2))
+    pl["gp_tr_n"] = np.zeros(G3, np.int32); pl["gp_tr"] = np.zeros((G3, GP + 1, 3)); pl["gp_goal_idx"] = np.zeros(G3, np.int32)
+    for s_ in range(G3):
+        n = int(rng.integers(1, GP + 1))
+        plan = np.cumsum(rng.uniform(-0.05, 0.25, (n, 3)), 0); plan[:, 2] = rng.uniform(-pi, pi, n)
+        tr = (rng.uniform(-3, 3), rng.uniform(-1, 1), rng.uniform(-1, 1)) if s_ % 2 else (0.0, 0.0, 0.0)
+        k = int(rng.integers(0, n)); c_, s2_ = np.cos(tr[0]), np.sin(tr[0])
+        pose = np.array([tr[1] + c_ * plan[k, 0] - s2_ * plan[k, 1] + rng.normal(0, 0.3), tr[2] + s2_ * plan[k, 0] + c_ * plan[k, 1] + rng.normal(0, 0.3), rng.uniform(-3, 3)])
+        d, sx, sy, res, ml = float(rng.choice([0.2, 0.5, 1.0])), int(rng.integers(20, 80)), int(rng.integers(20, 80)), float(rng.choice([0.05, 0.1])), float(rng.choice([-1, 0.5, 1.5, 3.0]))
+        ok1, pr = RL.plugin_prune_plan(plan, pose, tr, d)
+        ok2, tp, gi = RL.plugin_transform_plan(plan, pose, sx, sy, res, ml, tr)
+        assert ok2
+        pl["gp_n"][s_] = n; pl["gp_plan"][s_, :n] = plan; pl["gp_par"][s_] = (*tr, *pose, d, sx, sy, res, ml)
+        pl["gp_pruned_n"][s_] = pr.shape[0]; pl["gp_pruned_ok"][s_] = ok1; pl["gp_pruned_first"][s_] = pr[0, :2] if pr.shape[0] else 0
+        pl["gp_tr_n"][s_] = tp.shape[0]; pl["gp_tr"][s_, :tp.shape[0]] = tp; pl["gp_goal_idx"][s_] = gi
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_plugin_inputs.npz"), **pl)
     fp = {}
     for name, (fm, cfp, nocm) in footprint_cases.cases().items():

@@ -905,3 +905,23 @@ def test_binding_reproduces_the_recorded_closed_loops_with_real_solves(loop):
         assert o["code"] == rec["code"][i] and o["x_seq"].shape[0] == m and o["n_via"] == rec["n_via"][i], i
         assert np.abs(o["cmd"] - rec["cmd"][i]).max() < 1e-9 and np.abs(o["x_seq"] - rec["x_seq"][i, :m]).max() < 1e-9, i
     run.close()
+
+
+def test_plan_pruning_and_selection_reproduce_the_reference_plugin():
+    """pruneGlobalPlan (:645-685) and transformGlobalPlan (:687-805), executed with a planar tf answer: what is cut off behind the robot (and that the function reports success
+    even when no pose is close enough), where the selected part starts (closest pose inside 85 % of the costmap's half size), where it ends (radius, max_plan_length), the
+    goal index, the poses moved into the planning frame; an empty selection yields the global goal"""
+    from mpc_local_planner_amd import plugin_inputs as PI
+    cut = injected = 0
+    for i in range(PLG["gp_n"].shape[0]):
+        n = int(PLG["gp_n"][i]); plan = PLG["gp_plan"][i, :n]
+        yaw, tx, ty, px, py, pth, d, sx, sy, res, ml = PLG["gp_par"][i]
+        ok, pr = PI.prune_global_plan(plan, (px, py, pth), (yaw, tx, ty), d)
+        assert ok == bool(PLG["gp_pruned_ok"][i]) and pr.shape[0] == PLG["gp_pruned_n"][i] and (pr.shape[0] == 0 or np.array_equal(pr[0, :2], PLG["gp_pruned_first"][i])), i
+        cut += pr.shape[0] < n
+        tp, gi = PI.transform_global_plan(plan, (px, py, pth), int(sx), int(sy), res, ml, (yaw, tx, ty))
+        m = int(PLG["gp_tr_n"][i]); ref = PLG["gp_tr"][i, :m]
+        assert tp.shape[0] == m and gi == PLG["gp_goal_idx"][i], (i, tp.shape, m, gi)
+        assert np.abs(tp[:, :2] - ref[:, :2]).max() < 1e-12 and np.abs(np.arctan2(np.sin(tp[:, 2] - ref[:, 2]), np.cos(tp[:, 2] - ref[:, 2]))).max() < 1e-12
+        injected += int(m == 1 and gi == n - 1)
+    assert cut > 20 and injected >= 1
