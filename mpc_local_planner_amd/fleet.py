@@ -1,0 +1,320 @@
+"""computeVelocityCommands for a fleet: one control cycle of the reference's plugin (src/mpc_local_planner_ros.cpp:264-461) for B robots at once, every solve of the
+cycle in ONE batched launch.
+
+Per robot the cycle is the reference's: prune and select the global plan, via-points from the plan, goal check, local goal with its heading, obstacles from the costmap,
+Controller::step (re-initialisation decision, initial state trajectory or warm start, grid adaptation, outer iterations; src/controller.cpp:111-179), post-solve feasibility
+check, command from the first control.  The pieces are the ones the test suite holds to the executed reference (plugin_inputs.py, params.py, the kernels behind BatchSolver);
+this module adds the per-robot bookkeeping of the Controller (what include/mpc_controller.hpp keeps for ONE robot) for a batch, and is itself held to recorded runs of the
+reference's plugin (tests/test_fleet.py, tests/test_gpu_fleet.py).
+
+    fleet = FleetPlanner(params, batch=256)            # params: the plugin's parameter namespace (the reference's YAML layout)
+    fleet.set_plan(b, poses)                           # global plan of robot b, (n, 3)
+    out = fleet.step(robot_poses, costmaps, resolution, origins, footprint_spec)     # -> FleetResult
+
+What is not covered: tf (plans and poses are given in the planning frame), costmap_converter / custom obstacle messages (pass `extra_obstacles`), dynamic footprints.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+from . import _abi as A
+from . import params as P
+from . import plugin_inputs as PI
+
+SUCCESS, NO_VALID_CMD, INVALID_PATH, INTERNAL_ERROR = 0, 100, 103, 114      # mbf_msgs/ExePathResult codes the reference returns
+
+
+def _wrap(th: float) -> float:
+    if -math.pi <= th < math.pi:
+        return th
+    th = th - math.floor(th / (2.0 * math.pi)) * 2.0 * math.pi
+    if th >= math.pi:
+        th -= 2.0 * math.pi
+    if th < -math.pi:
+        th += 2.0 * math.pi
+    return th
+
+
+def _interp_angle(a1: float, a2: float, f: float) -> float:
+    return _wrap(a1 + f * _wrap(a2 - a1))
+
+
+def _interpolate_se2(times, vals, t, tol=1e-6):
+    """TimeSeriesSE2::getValuesInterpolate, linear with zero-order hold beyond the end (src/utils/time_series_se2.cpp:34-111)"""
+    idx = -1
+    for i, tv in enumerate(times):
+        if tv >= t:
+            idx = i
+            break
+    if idx < 0:
+        return vals[-1].copy()
+    if abs(t - times[idx]) < tol or idx < 1:
+        return vals[idx].copy()
+    fr = (t - times[idx - 1]) / (times[idx] - times[idx - 1])
+    out = vals[idx - 1] + fr * (vals[idx] - vals[idx - 1])
+    out[2] = _interp_angle(vals[idx - 1][2], vals[idx][2], fr)
+    return out
+
+
+def initial_state_trajectory(plan, x0, xf, n: int, dt_ref: float, estimate_orientation: bool, dt_sample: float):
+    """Controller::generateInitialStateTrajectory (src/controller.cpp:807-857) sampled as initializeSequences does (…grid_base_se2.cpp:192-239): (n, 3).
+    dt_sample: the spacing of the samples (dt_ref, or the last optimised dt on a re-initialisation: see Controller::setReferenceReinitSampling in the C++ facade)"""
+    npl = plan.shape[0]
+    tf = (n - 1) * dt_ref
+    dt_init = tf / float(npl - 1)
+    times, vals = [0.0], [np.asarray(x0, float)]
+    t = dt_init
+    for i in range(1, npl - 1):
+        yaw = math.atan2(plan[i + 1, 1] - plan[i, 1], plan[i + 1, 0] - plan[i, 0]) if estimate_orientation else plan[i, 2]
+        times.append(t); vals.append(np.array([plan[i, 0], plan[i, 1], yaw]))
+        t += dt_init
+    times.append(tf); vals.append(np.asarray(xf, float))
+    x = np.zeros((n, 3))
+    x[0] = x0
+    for k in range(1, n - 1):
+        x[k] = _interpolate_se2(times, vals, k * dt_sample)
+    x[n - 1] = xf
+    return x
+
+
+def warm_start_shift(x, u, x0):
+    """findNearestState + warmStartShifting (…grid_base_se2.cpp:241-339), in place; x (n, 3), u (n, 2) with the repeated last control"""
+    n = x.shape[0]
+    dist = lambda i: math.sqrt(float(((x0 - x[i]) ** 2).sum()))
+    first = dist(0)
+    ns = 0
+    if abs(first) >= 1e-12:
+        cache = first
+        for i in range(1, min(n - 2, 20) + 1):
+            d = dist(i)
+            if d < cache:
+                cache, ns = d, i
+            else:
+                break
+    if ns <= 0 or ns > n - 2:
+        return
+    for i in range(n - ns):
+        idx = i + ns
+        x[i] = x[n - 1] if idx == n - 1 else x[idx]
+        if idx != n - 1:
+            u[i] = u[idx]
+    idx = n - ns
+    for _ in range(ns):
+        x[idx, :2] = x[idx - 2, :2] + 2.0 * (x[idx - 1, :2] - x[idx - 2, :2])
+        x[idx, 2] = _interp_angle(x[idx - 2, 2], x[idx - 1, 2], 2.0)
+        u[idx - 1] = u[idx - 2]
+        idx += 1
+    u[n - 1] = u[n - 2]
+
+
+def resample(x, u, dt, n: int, n_new: int):
+    """resampleTrajectory (…grid_base_se2.cpp:440-524): first n rows of x / u -> n_new rows (same arrays must have room); returns the new dt"""
+    if n == n_new:
+        return dt
+    xo, uo = x[:n].copy(), u[:n].copy()
+    dt_new = dt * float(n - 1) / float(n_new - 1)
+    idx_old = 1
+    for idx_new in range(1, n_new - 1):
+        t_new = dt_new * idx_new
+        while t_new > idx_old * dt and idx_old < n:
+            idx_old += 1
+        xp = xo[idx_old - 1]
+        xc = xo[idx_old] if idx_old < n - 1 else xo[n - 1]
+        fr = (t_new - (idx_old * dt - dt)) / dt
+        x[idx_new, :2] = xp[:2] + fr * (xc[:2] - xp[:2])
+        x[idx_new, 2] = _interp_angle(xp[2], xc[2], fr)
+        u[idx_new] = uo[idx_old - 1]
+    x[n_new - 1] = xo[n - 1]
+    u[n_new - 1] = u[n_new - 2]
+    return dt_new
+
+
+@dataclass
+class FleetResult:
+    code: np.ndarray                 # (B,) SUCCESS | NO_VALID_CMD | INVALID_PATH | INTERNAL_ERROR
+    cmd: np.ndarray                  # (B, 3) vx, vy, omega (for the car-like models the third entry is the steering angle, as getTwistFromControl of the reference)
+    goal_reached: np.ndarray         # (B,) bool
+    n_grid: np.ndarray               # (B,) grid points of the planned trajectory (0: none)
+    x: np.ndarray                    # (B, n_max, 3) planned states (rows < n_grid valid)
+    u: np.ndarray                    # (B, n_max, 2)
+    dt: np.ndarray                   # (B,)
+    n_obstacles: np.ndarray          # (B,)
+    n_via: np.ndarray                # (B,)
+    iterations: np.ndarray = field(default_factory=lambda: np.zeros(0, np.int32))
+
+
+class FleetPlanner:
+    def __init__(self, params: dict, batch: int, move_base_params: Optional[dict] = None, costmap_footprint=None, max_obstacles: int = 64, max_vertices: int = 4,
+                 device: int = 0, solver=None, **sizing):
+        self.cfg, self.ctrl, self.notes = P.config_from_params(params, costmap_footprint=costmap_footprint, max_obstacles=max_obstacles, max_vertices=max_vertices, **sizing)
+        self.opts = P.plugin_options_from_params(params, move_base_params)
+        self.B = int(batch)
+        self.n_ref = int(self.cfg.n)
+        self.adapt = bool(self.ctrl.get("grid_adaptation")) and bool(self.cfg.dt_free)
+        self.n_max = int(self.ctrl["n_max"]) if self.adapt else self.n_ref
+        self.n_min = max(3, int(self.ctrl.get("min_grid_size", 2)))              # the batched solver needs 3 grid points
+        self.hyst = float(self.ctrl.get("dt_hyst_ratio", 0.1))
+        self.cfg.n = self.n_max
+        if solver is None:
+            from .solver import BatchSolver
+            solver = BatchSolver(self.cfg, max_batch=self.B, device=device)
+        self.solver = solver                       # anything with BatchSolver's solve / set_grid_sizes / set_via_points / costmap_to_obstacles / check_feasibility
+        B, N = self.B, self.n_max
+        self.plans: List[Optional[np.ndarray]] = [None] * B
+        self.grid_empty = np.ones(B, bool)
+        self.have_solution = np.zeros(B, bool)
+        self.n_cur = np.full(B, self.n_ref, np.int32)
+        self.x = np.zeros((B, N, 3)); self.u = np.zeros((B, N, 2)); self.dt = np.full(B, float(self.cfg.dt_ref))
+        self.last_goal = np.zeros((B, 3))
+        self.ocp_seq = np.zeros(B, np.int64)
+        self.has_u = np.zeros(B, bool)                                            # a previous control exists (the plugin hands u_seq[0] over, :384)
+        self.infeasible_in_a_row = np.zeros(B, np.int32)
+
+    def set_plan(self, b: int, plan) -> None:
+        """setPlan (:232-252): the plan is replaced, the warm start is kept"""
+        self.plans[b] = np.asarray(plan, float).reshape(-1, 3).copy()
+
+    def reset(self, b: int) -> None:
+        """Controller::reset: the next cycle of robot b starts from a fresh initial guess"""
+        self.grid_empty[b] = True
+
+    def step(self, robot_poses, costmaps, resolution: float, origins, footprint_spec, inscribed_radius: float = 0.0, extra_obstacles: Optional[Sequence] = None) -> FleetResult:
+        """One control cycle for every robot with a plan.  robot_poses (B, 3); costmaps uint8 (B, size_y, size_x) or None; origins (B, 2); footprint_spec (F, 2) the
+        costmap footprint in the robot frame (feasibility check); extra_obstacles[b]: obstacle records (vertices, radius, velocity) appended after the costmap's cells."""
+        B, cfg, o = self.B, self.cfg, self.opts
+        poses = np.asarray(robot_poses, float).reshape(B, 3)
+        res = FleetResult(code=np.full(B, INTERNAL_ERROR, np.int32), cmd=np.zeros((B, 3)), goal_reached=np.zeros(B, bool), n_grid=np.zeros(B, np.int32),
+                          x=np.zeros((B, self.n_max, 3)), u=np.zeros((B, self.n_max, 2)), dt=np.zeros(B), n_obstacles=np.zeros(B, np.int32), n_via=np.zeros(B, np.int32),
+                          iterations=np.zeros(B, np.int32))
+        size_y, size_x = (costmaps.shape[1], costmaps.shape[2]) if costmaps is not None else (0, 0)
+        active, local_plans, goals, vias = [], {}, {}, {}
+        for b in range(B):
+            plan = self.plans[b]
+            if plan is None or plan.shape[0] == 0:
+                continue                                                          # "Could not transform the global plan" (:300-305)
+            _, plan = PI.prune_global_plan(plan, poses[b], dist_behind_robot=o["global_plan_prune_distance"])
+            self.plans[b] = plan
+            tp, goal_idx = PI.transform_global_plan(plan, poses[b], size_x, size_y, resolution, o["max_global_plan_lookahead_dist"])
+            vias[b] = PI.via_points_from_plan(tp, o["global_plan_viapoint_sep"])
+            gx, gy, gth = plan[-1]
+            if math.hypot(gx - poses[b, 0], gy - poses[b, 1]) < o["xy_goal_tolerance"] and abs(_wrap(gth - poses[b, 2])) < o["yaw_goal_tolerance"]:
+                res.code[b], res.goal_reached[b] = SUCCESS, True
+                continue
+            goal = np.array(tp[-1], float)
+            if o["global_plan_overwrite_orientation"]:
+                goal[2] = PI.estimate_local_goal_orientation(plan, goal, goal_idx)
+                tp = tp.copy(); tp[-1, 2] = goal[2]
+            if tp.shape[0] == 1:
+                tp = np.vstack([tp[:1], tp])
+            tp[0] = poses[b]
+            local_plans[b], goals[b] = tp, goal
+            active.append(b)
+        if not active:
+            return res
+        act = np.array(active)
+        m = len(active)
+        # obstacles of the cycle: costmap scan for the active robots (one launch), then what the caller adds
+        obst = None
+        if cfg.max_obstacles > 0:
+            O, V = int(cfg.max_obstacles), max(1, int(cfg.max_vertices))
+            if costmaps is not None and o["include_costmap_obstacles"]:
+                no, nv, vt, _ = self.solver.costmap_to_obstacles(costmaps[act], resolution, np.asarray(origins, float).reshape(B, 2)[act], poses[act], o["costmap_obstacles_behind_robot_dist"])
+            else:
+                no, nv, vt = np.zeros(m, np.int32), np.zeros((m, O), np.int32), np.zeros((m, O, V, 2))
+            rad, vel = np.zeros((m, O)), np.zeros((m, O, 2))
+            if extra_obstacles is not None:
+                for i, b in enumerate(active):
+                    for verts, radius, v in (extra_obstacles[b] or ()):
+                        k = int(no[i])
+                        if k >= O or len(verts) > V:
+                            raise ValueError("obstacle capacity of the handle exceeded (max_obstacles / max_vertices)")
+                        nv[i, k] = len(verts); vt[i, k, :len(verts)] = verts; rad[i, k] = radius; vel[i, k] = v; no[i] = k + 1
+            obst = (no, nv, vt, rad, vel)
+            res.n_obstacles[act] = no
+        # Controller::step for every active robot: start state, re-initialisation decision, vertex values of the first solve
+        dt_ctrl = 1.0 / float(o["controller_frequency"])
+        N = self.n_max
+        xi, ui, di = np.zeros((m, N, 3)), np.zeros((m, N, 2)), np.zeros(m)
+        x0, xf, up, dtp = np.zeros((m, 3)), np.zeros((m, 3)), np.zeros((m, 2)), np.zeros(m)
+        frs = int(self.ctrl.get("force_reinit_num_steps", 0))
+        for i, b in enumerate(active):
+            goal = goals[b]
+            x0[i], xf[i] = poses[b], goal
+            if self.has_u[b]:
+                up[i], dtp[i] = self.u[b, 0], dt_ctrl
+            if frs > 0 and self.ocp_seq[b] % frs == 0:
+                self.grid_empty[b] = True
+            if not self.grid_empty[b]:
+                lg = self.last_goal[b]
+                if math.hypot(goal[0] - lg[0], goal[1] - lg[1]) > self.ctrl["force_reinit_new_goal_dist"] or abs(_wrap(goal[2] - lg[2])) > self.ctrl["force_reinit_new_goal_angular"]:
+                    self.grid_empty[b] = True
+        n_outer = max(1, int(self.ctrl.get("outer_ocp_iterations", 1)))
+        status = np.zeros(m, np.int32)
+        for outer in range(n_outer):
+            for i, b in enumerate(active):
+                if self.grid_empty[b]:
+                    self.n_cur[b] = self.n_ref
+                    dt_sample = self.dt[b] if (self.have_solution[b] and cfg.dt_free and self.dt[b] > 0) else float(cfg.dt_ref)
+                    xi[i, :self.n_ref] = initial_state_trajectory(local_plans[b], x0[i], xf[i], self.n_ref, float(cfg.dt_ref), bool(o["global_plan_overwrite_orientation"]), dt_sample)
+                    ui[i] = 0.0
+                    di[i] = float(cfg.dt_ref)
+                else:
+                    n = int(self.n_cur[b])
+                    xi[i], ui[i], di[i] = self.x[b], self.u[b], self.dt[b]
+                    if self.ctrl.get("warm_start", True) and not cfg.dt_free:
+                        warm_start_shift(xi[i, :n], ui[i, :n], x0[i])
+                    if self.adapt:
+                        n_new = n
+                        if self.dt[b] > cfg.dt_ref * (1.0 + self.hyst) and n < self.n_max:
+                            n_new = n + 1
+                        elif self.dt[b] < cfg.dt_ref * (1.0 - self.hyst) and n > self.n_min:
+                            n_new = n - 1
+                        if n_new != n:
+                            di[i] = resample(xi[i], ui[i], float(di[i]), n, n_new)
+                            self.n_cur[b] = n_new
+            self.solver.set_grid_sizes(self.n_cur[act])
+            if cfg.objective == A.OBJ_MIN_TIME_VIA_POINTS:
+                VP = int(cfg.max_via_points)
+                nvp, vp = np.zeros(m, np.int32), np.zeros((m, VP, 3))
+                for i, b in enumerate(active):
+                    k = min(len(vias[b]), VP)
+                    nvp[i] = k; vp[i, :k] = vias[b][:k]
+                self.solver.set_via_points(nvp, vp)
+            r = self.solver.solve(x0, xf, up, dtp, init=(xi, ui, di), obstacles=obst)
+            status = r.status
+            for i, b in enumerate(active):
+                self.x[b], self.u[b], self.dt[b] = r.x[i], r.u[i], r.dt[i]
+                self.grid_empty[b] = False
+                self.have_solution[b] = True
+                self.has_u[b] = True                                              # the plugin's _u_seq holds the series of the last step, converged or not
+            res.iterations[act] = r.iters
+        for i, b in enumerate(active):
+            self.ocp_seq[b] += 1
+            self.last_goal[b] = goals[b]
+            res.n_via[b] = len(vias[b])
+        # what the plugin does with the result (:386-461)
+        ok = status == 0                                                           # MPC_CONVERGED
+        feas = np.ones(m, np.int32)
+        if costmaps is not None and ok.any():
+            # the check only looks at the first n_grid states of every instance: pad the rest with the final state (no motion, no extra poses)
+            xs = self.x[act].copy()
+            for i, b in enumerate(active):
+                xs[i, self.n_cur[b]:] = xs[i, self.n_cur[b] - 1]
+            feas = self.solver.check_feasibility(xs, costmaps[act], resolution, np.asarray(origins, float).reshape(B, 2)[act], footprint_spec, inscribed_radius,
+                                                 o["collision_check_min_resolution_angular"], o["collision_check_no_poses"])
+        for i, b in enumerate(active):
+            n = int(self.n_cur[b])
+            res.n_grid[b] = n; res.x[b] = self.x[b]; res.u[b] = self.u[b]; res.dt[b] = self.dt[b]
+            if not ok[i] or not feas[i]:
+                self.grid_empty[b] = True                                         # _controller.reset()
+                self.infeasible_in_a_row[b] += 1
+                res.code[b] = NO_VALID_CMD
+                continue
+            self.infeasible_in_a_row[b] = 0
+            res.code[b] = SUCCESS
+            res.cmd[b] = (self.u[b, 0, 0], 0.0, self.u[b, 0, 1])                # getTwistFromControl: (v, 0, omega | steering angle) for every model of the package
+        return res

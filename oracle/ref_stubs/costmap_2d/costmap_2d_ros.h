@@ -33,8 +33,20 @@ class Costmap2DROS {
     geometry_msgs::PoseStamped robot_pose;
     std::vector<geometry_msgs::Point> footprint;
 };
+// costmap_2d/footprint.cpp: the smallest distance from the robot centre to an edge of the footprint polygon and the largest to a vertex (inscribed / circumscribed radius)
 inline void calculateMinAndMaxDistances(const std::vector<geometry_msgs::Point>& fp, double& min_dist, double& max_dist) {
-    min_dist = 0; max_dist = 0;
-    for (const auto& q : fp) { const double d = std::sqrt(q.x * q.x + q.y * q.y); max_dist = std::max(max_dist, d); }
+    min_dist = 1e300; max_dist = 0;
+    if (fp.size() <= 2) { min_dist = 0; return; }
+    auto to_segment = [](double ax, double ay, double bx, double by) {
+        const double dx = bx - ax, dy = by - ay, l2 = dx * dx + dy * dy;
+        double t = l2 > 0 ? -(ax * dx + ay * dy) / l2 : 0.0;
+        t = t < 0 ? 0 : (t > 1 ? 1 : t);
+        return std::sqrt((ax + t * dx) * (ax + t * dx) + (ay + t * dy) * (ay + t * dy));
+    };
+    for (size_t i = 0; i < fp.size(); ++i) {
+        const auto& a = fp[i]; const auto& b = fp[(i + 1) % fp.size()];
+        min_dist = std::min(min_dist, std::min(std::sqrt(a.x * a.x + a.y * a.y), to_segment(a.x, a.y, b.x, b.y)));
+        max_dist = std::max(max_dist, std::sqrt(a.x * a.x + a.y * a.y));
+    }
 }
 }  // namespace costmap_2d

@@ -1,0 +1,65 @@
+"""FleetPlanner (mpc_local_planner_amd/fleet.py): computeVelocityCommands for a batch of robots, held to recorded runs of the REFERENCE's plugin (the reference's plugin source +
+the reference's own Controller, the C oracle's solve plugged in: tests/golden/ref_plugin_closed_loop_*.npz, generator tests/golden/make_ref_vectors.py).  Here the solver behind the
+fleet is the CPU stand-in of tests/golden/fleet_oracle_backend.py (the same C oracle); tests/test_gpu_fleet.py runs the same script on the real BatchSolver."""
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "golden"))
+LOOPS = ["carlike_line_footprint", "via_points_polygon_footprint", "diff_drive_quadratic_form"]
+
+
+def replay(loop, make_solver, batch_layout, tol):
+    """batch_layout: for every robot of the batch the cycle at which it gets its plan (None: never).  Every robot replays the recorded poses from its own start."""
+    from mpc_local_planner_amd.fleet import FleetPlanner
+    rec = np.load(os.path.join(HERE, "golden", f"ref_plugin_closed_loop_{loop}.npz"))
+    prm = json.load(open(os.path.join(HERE, "golden", f"ref_plugin_closed_loop_{loop}.json")))
+    B = len(batch_layout)
+    fleet = FleetPlanner(prm, batch=B, max_obstacles=32, max_vertices=4, solver=None if make_solver is None else "deferred")
+    if make_solver is not None:
+        fleet.solver = make_solver(fleet.cfg, B)
+    res_, ox, oy = rec["par"]
+    K = rec["pose"].shape[0]
+    cost = np.repeat(rec["cost"][None], B, 0)
+    origins = np.tile([ox, oy], (B, 1))
+    worst_cmd = worst_x = 0.0
+    compared = 0
+    for cycle in range(K + max(s for s in batch_layout if s is not None)):
+        poses = np.zeros((B, 3))
+        for b, start in enumerate(batch_layout):
+            if start is not None and cycle == start:
+                fleet.set_plan(b, rec["plan"])
+            if start is not None and 0 <= cycle - start < K:
+                poses[b] = rec["pose"][cycle - start]
+            elif start is not None and cycle - start >= K:
+                fleet.plans[b] = None                                   # this robot is done
+        out = fleet.step(poses, cost, float(res_), origins, rec["footprint"], inscribed_radius=0.15)
+        for b, start in enumerate(batch_layout):
+            if start is None or not (0 <= cycle - start < K):
+                assert out.code[b] == 114 and out.n_grid[b] == 0          # a robot without a plan
+                continue
+            i = cycle - start
+            m = int(rec["n"][i])
+            assert out.code[b] == rec["code"][i] and out.n_grid[b] == m and out.n_via[b] == rec["n_via"][i], (loop, b, i, out.code[b], out.n_grid[b], m)
+            worst_cmd = max(worst_cmd, np.abs(out.cmd[b] - rec["cmd"][i]).max())
+            worst_x = max(worst_x, np.abs(out.x[b, :m] - rec["x_seq"][i, :m]).max())
+            compared += 1
+    assert compared == K * sum(s is not None for s in batch_layout)
+    assert worst_cmd < tol and worst_x < tol, (worst_cmd, worst_x)
+    return worst_cmd, worst_x
+
+
+def oracle_backend(cfg, B):
+    import fleet_oracle_backend
+    return fleet_oracle_backend.OracleBackend(cfg, B)
+
+
+@pytest.mark.parametrize("loop", LOOPS)
+def test_fleet_cycle_reproduces_the_recorded_runs_of_the_reference_plugin(loop):
+    """three robots in one batch -- two start at cycle 0, one five cycles later, a fourth never gets a plan -- each reproduces the recorded run of the reference's plugin
+    (outcome codes, grid sizes, via-point counts; commands and planned states to 1e-9: same C oracle behind both)"""
+    replay(loop, oracle_backend, [0, 5, 0, None], 1e-9)
