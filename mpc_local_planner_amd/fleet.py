@@ -111,23 +111,36 @@ def warm_start_shift(x, u, x0):
     u[n - 1] = u[n - 2]
 
 
+def _wrap_array(th):
+    """normalize_theta element-wise (same branches as _wrap)"""
+    th = np.asarray(th, float)
+    out = th.copy()
+    m = ~((th >= -math.pi) & (th < math.pi))
+    if m.any():
+        t = th[m] - np.floor(th[m] / (2.0 * math.pi)) * 2.0 * math.pi
+        t = np.where(t >= math.pi, t - 2.0 * math.pi, t)
+        t = np.where(t < -math.pi, t + 2.0 * math.pi, t)
+        out[m] = t
+    return out
+
+
 def resample(x, u, dt, n: int, n_new: int):
     """resampleTrajectory (…grid_base_se2.cpp:440-524): first n rows of x / u -> n_new rows (same arrays must have room); returns the new dt"""
     if n == n_new:
         return dt
     xo, uo = x[:n].copy(), u[:n].copy()
     dt_new = dt * float(n - 1) / float(n_new - 1)
-    idx_old = 1
-    for idx_new in range(1, n_new - 1):
-        t_new = dt_new * idx_new
-        while t_new > idx_old * dt and idx_old < n:
-            idx_old += 1
+    if n_new > 2:
+        t_new = dt_new * np.arange(1, n_new - 1)
+        # idx_old: the smallest k >= 1 with k dt >= t_new, n if there is none (the `while (t_new > idx_old * dt && idx_old < n)` of the reference)
+        idx_old = 1 + np.searchsorted(np.arange(1, n + 1) * dt, t_new, side="left")
+        idx_old = np.minimum(idx_old, n)
         xp = xo[idx_old - 1]
-        xc = xo[idx_old] if idx_old < n - 1 else xo[n - 1]
+        xc = xo[np.where(idx_old < n - 1, idx_old, n - 1)]
         fr = (t_new - (idx_old * dt - dt)) / dt
-        x[idx_new, :2] = xp[:2] + fr * (xc[:2] - xp[:2])
-        x[idx_new, 2] = _interp_angle(xp[2], xc[2], fr)
-        u[idx_new] = uo[idx_old - 1]
+        x[1:n_new - 1, :2] = xp[:, :2] + fr[:, None] * (xc[:, :2] - xp[:, :2])
+        x[1:n_new - 1, 2] = _wrap_array(xp[:, 2] + fr * _wrap_array(xc[:, 2] - xp[:, 2]))
+        u[1:n_new - 1] = uo[idx_old - 1]
     x[n_new - 1] = xo[n - 1]
     u[n_new - 1] = u[n_new - 2]
     return dt_new

@@ -70,23 +70,47 @@ def transform_global_plan(plan, robot_pose, costmap_size_x: int, costmap_size_y:
         raise ValueError("Received plan with zero length")
     rx, ry = _to_plan_frame(transform, float(robot_pose[0]), float(robot_pose[1]))
     thr = 0.85 * max(costmap_size_x * resolution / 2.0, costmap_size_y * resolution / 2.0)
-    sq_thr, sq_dist, i = thr * thr, 1e10, 0
-    for j in range(n):
-        d = (rx - plan[j, 0]) ** 2 + (ry - plan[j, 1]) ** 2
-        if d > sq_thr:
-            break
-        if d < sq_dist:
-            sq_dist, i = d, j
-    out, length = [], 0.0
-    while i < n and sq_dist <= sq_thr and (max_plan_length <= 0 or length <= max_plan_length):
-        out.append(_to_global(transform, *plan[i]))
-        sq_dist = (rx - plan[i, 0]) ** 2 + (ry - plan[i, 1]) ** 2
-        if i > 0 and max_plan_length > 0:
-            length += math.sqrt((plan[i, 0] - plan[i - 1, 0]) ** 2 + (plan[i, 1] - plan[i - 1, 1]) ** 2)
-        i += 1
-    if not out:
-        return np.array([_to_global(transform, *plan[-1])]), n - 1
-    return np.array(out, float), i - 1
+    sq_thr = thr * thr
+    # the loops of the reference, evaluated with array operations (a fleet calls this once per robot and cycle)
+    d2 = (rx - plan[:, 0]) ** 2 + (ry - plan[:, 1]) ** 2
+    outside = np.nonzero(d2 > sq_thr)[0]
+    stop = int(outside[0]) if outside.size else n                       # the search ends at the first pose beyond the radius (:724)
+    if stop == 0:
+        i, sq_dist = 0, 1e10
+    else:
+        i = int(np.argmin(d2[:stop]))                                   # the first of equal minima, like the strict `<` of the loop
+        sq_dist = float(d2[i])
+    if sq_dist > sq_thr:
+        return _poses_to_global(transform, plan[-1:]), n - 1            # empty selection: the global goal alone (:766-774)
+    # pose j (j >= i) is taken while the pose BEFORE it was inside the radius and the length accumulated BEFORE it is within the limit; the length counts the segment
+    # (j-1, j) of every pose taken, the one in front of pose i included when i > 0 (:760-761)
+    prev_inside = np.concatenate([[True], d2[i:n - 1] <= sq_thr])
+    if max_plan_length > 0:
+        seg = np.zeros(n - i)
+        idx = np.arange(i, n)
+        has_prev = idx > 0
+        seg[has_prev] = np.sqrt((plan[idx[has_prev], 0] - plan[idx[has_prev] - 1, 0]) ** 2 + (plan[idx[has_prev], 1] - plan[idx[has_prev] - 1, 1]) ** 2)
+        length_before = np.concatenate([[0.0], np.cumsum(seg)[:-1]])
+        take = prev_inside & (length_before <= max_plan_length)
+    else:
+        take = prev_inside
+    bad = np.nonzero(~take)[0]
+    count = int(bad[0]) if bad.size else n - i
+    return _poses_to_global(transform, plan[i:i + count]), i + count - 1
+
+
+def _poses_to_global(transform, poses):
+    poses = np.asarray(poses, float).reshape(-1, 3)
+    c, s = math.cos(transform[0]), math.sin(transform[0])
+    out = np.empty_like(poses)
+    out[:, 0] = transform[1] + c * poses[:, 0] - s * poses[:, 1]
+    out[:, 1] = transform[2] + s * poses[:, 0] + c * poses[:, 1]
+    # heading through quaternions, as tf2::doTransform composes the rotations (getYaw(rotation * orientation))
+    az, aw = math.sin(0.5 * transform[0]), math.cos(0.5 * transform[0])
+    bz, bw = np.sin(0.5 * poses[:, 2]), np.cos(0.5 * poses[:, 2])
+    z, w = aw * bz + az * bw, aw * bw - az * bz
+    out[:, 2] = np.arctan2(2.0 * w * z, 1.0 - 2.0 * z * z)
+    return out
 
 
 def obstacles_from_messages(msgs: Iterable[dict], converter: bool = True, transform: Sequence[float] = (0.0, 0.0, 0.0)):

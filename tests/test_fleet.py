@@ -63,3 +63,26 @@ def test_fleet_cycle_reproduces_the_recorded_runs_of_the_reference_plugin(loop):
     """three robots in one batch -- two start at cycle 0, one five cycles later, a fourth never gets a plan -- each reproduces the recorded run of the reference's plugin
     (outcome codes, grid sizes, via-point counts; commands and planned states to 1e-9: same C oracle behind both)"""
     replay(loop, oracle_backend, [0, 5, 0, None], 1e-9)
+
+
+def test_fleet_grid_helpers_reproduce_the_reference_grid_bit_for_bit():
+    """the per-robot grid handling inside fleet.py (resample, warm_start_shift, initial_state_trajectory / TimeSeriesSE2 interpolation) against the recorded outputs of the
+    reference's grid class and time series (tests/golden/ref_grid.npz, oracle/ref_wrap_grid.cpp)"""
+    from mpc_local_planner_amd import fleet as F
+    GR = np.load(os.path.join(HERE, "golden", "ref_grid.npz"))
+    for i in range(GR["n"].shape[0]):
+        n, nn = int(GR["n"][i]), int(GR["n_new"][i])
+        cap = max(n, nn)
+        x = np.zeros((cap, 3)); u = np.zeros((cap, 2))
+        x[:n] = GR["x"][i, :n]; u[:n - 1] = GR["u"][i, :n - 1]; u[n - 1] = u[n - 2]
+        dt = F.resample(x, u, float(GR["dt"][i]), n, nn)
+        assert dt == GR["resample_dt"][i] and np.array_equal(x[:nn], GR["resample_x"][i, :nn]) and np.array_equal(u[:nn - 1], GR["resample_u"][i, :nn - 1]), i
+        x = GR["x"][i, :n].copy(); u = np.vstack([GR["u"][i, :n - 1], GR["u"][i, n - 2:n - 1]])
+        F.warm_start_shift(x, u, GR["query"][i])
+        free = GR["xf_fixed"][i] == 0                                   # the recorded cycle also overwrote the start and the fixed goal components
+        assert np.array_equal(x[1:n - 1], GR["warm_x"][i, 1:n - 1]) and np.array_equal(u[:n - 1], GR["warm_u"][i, :n - 1]) and np.array_equal(x[n - 1][free], GR["warm_x"][i, n - 1][free]), i
+    for i in range(GR["ts_m"].shape[0]):
+        m = int(GR["ts_m"][i])
+        tm, vals = list(GR["ts_times"][i, :m]), [v.copy() for v in GR["ts_values"][i, :m]]
+        for q, ref in zip(GR["ts_query"][i], GR["ts_out"][i]):
+            assert np.array_equal(F._interpolate_se2(tm, vals, float(q)), ref), (i, q)
