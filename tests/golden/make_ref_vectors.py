@@ -419,6 +419,9 @@ def main():
     a_["controller"]["max_global_plan_lookahead_dist"] = 1.0
     a_["footprint_model"] = {"type": "circular", "radius": 0.2}
     loops["diff_drive_quadratic_form"] = (a_, False)
+    a_ = copy.deepcopy(base); a_["footprint_model"] = {"type": "point"}
+    a_["grid"]["variable_grid"]["grid_adaptation"]["min_grid_size"] = 3          # the batched solver's floor (the reference would go down to 2 grid points)
+    loops["carlike_to_the_goal"] = (a_, True)
     K, NCAP = 60, 52
     for lname, (prm, car) in loops.items():
         cfgp = PP.config_from_params(prm)[0]
@@ -427,8 +430,9 @@ def main():
 
         oracle_solver = plugin_oracle_solver.make(runner, cfgp, solves)
         runner.solver = oracle_solver
-        assert runner.initialized and runner.set_plan(plan)
-        cl = dict(pose=np.zeros((K, 3)), vel=np.zeros((K, 3)), code=np.zeros(K, np.int32), cmd=np.zeros((K, 3)), n=np.zeros(K, np.int32), x_seq=np.zeros((K, NCAP, 3)), iters=np.zeros((K, 2), np.int32),
+        the_plan = plan[:17] if lname == "carlike_to_the_goal" else plan            # a short plan: the robot arrives within the recorded cycles
+        assert runner.initialized and runner.set_plan(the_plan)
+        cl = dict(goal_reached=np.zeros(K, np.int32), pose=np.zeros((K, 3)), vel=np.zeros((K, 3)), code=np.zeros(K, np.int32), cmd=np.zeros((K, 3)), n=np.zeros(K, np.int32), x_seq=np.zeros((K, NCAP, 3)), iters=np.zeros((K, 2), np.int32),
                   n_via=np.zeros(K, np.int32))
         pose, vel = np.array([0.0, 0.0, 0.1]), np.zeros(3)
         for i in range(K):
@@ -436,16 +440,17 @@ def main():
             o = runner.cycle(pose, vel)
             m = o["x_seq"].shape[0]
             cl["pose"][i], cl["vel"][i], cl["code"][i], cl["cmd"][i], cl["n"][i], cl["n_via"][i] = pose, vel, o["code"], o["cmd"], m, o["n_via"]
+            cl["goal_reached"][i] = o["goal_reached"]
             cl["x_seq"][i, :m] = o["x_seq"]; cl["iters"][i, :len(solves[:2])] = solves[:2]
             v, w = o["cmd"][0], o["cmd"][2]
             pose = pose + 0.1 * np.array([v * np.cos(pose[2]), v * np.sin(pose[2]), (v / 0.4 * np.tan(w)) if car else w])
             vel = np.array([v, 0.0, w])
         runner.close()
-        np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"ref_plugin_closed_loop_{lname}.npz"), cost=cost, plan=plan, par=np.array([res, org[0], org[1]]), footprint=np.array(fp), **cl)
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"ref_plugin_closed_loop_{lname}.npz"), cost=cost, plan=the_plan, par=np.array([res, org[0], org[1]]), footprint=np.array(fp), **cl)
         with open(os.path.join(ROOT, "tests", "golden", f"ref_plugin_closed_loop_{lname}.json"), "w") as f:
             json.dump(prm, f, indent=1, sort_keys=True)
         print("written plugin closed loop", lname, ":", K, "cycles,", int((cl["code"] == 0).sum()), "SUCCESS, final pose", np.round(pose, 3), "mean iterations per solve", round(float(cl["iters"].mean()), 1),
-              "via-points", int(cl["n_via"].min()), "..", int(cl["n_via"].max()))
+              "via-points", int(cl["n_via"].min()), "..", int(cl["n_via"].max()), "goal reached in", int(cl["goal_reached"].sum()), "cycles, smallest grid", int(cl["n"][cl["n"] > 0].min()))
 
 if __name__ == "__main__":
     main()

@@ -11,6 +11,9 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "golden"))
 LOOPS = ["carlike_line_footprint", "via_points_polygon_footprint", "diff_drive_quadratic_form"]
+# a run towards the goal of a short plan: the grid shrinks to 4 points and a fifth of the solves fail near the goal (every failure resets the planner) -- CPU only, where the
+# solver behind the fleet is the same C oracle that was behind the recording
+LOOPS_CPU = LOOPS + ["carlike_to_the_goal"]
 
 
 def replay(loop, make_solver, batch_layout, tol):
@@ -44,7 +47,7 @@ def replay(loop, make_solver, batch_layout, tol):
                 continue
             i = cycle - start
             m = int(rec["n"][i])
-            assert out.code[b] == rec["code"][i] and out.n_grid[b] == m and out.n_via[b] == rec["n_via"][i], (loop, b, i, out.code[b], out.n_grid[b], m)
+            assert out.code[b] == rec["code"][i] and out.n_grid[b] == m and out.n_via[b] == rec["n_via"][i] and out.goal_reached[b] == bool(rec["goal_reached"][i]), (loop, b, i, out.code[b], out.n_grid[b], m)
             worst_cmd = max(worst_cmd, np.abs(out.cmd[b] - rec["cmd"][i]).max())
             worst_x = max(worst_x, np.abs(out.x[b, :m] - rec["x_seq"][i, :m]).max())
             compared += 1
@@ -58,7 +61,7 @@ def oracle_backend(cfg, B):
     return fleet_oracle_backend.OracleBackend(cfg, B)
 
 
-@pytest.mark.parametrize("loop", LOOPS)
+@pytest.mark.parametrize("loop", LOOPS_CPU)
 def test_fleet_cycle_reproduces_the_recorded_runs_of_the_reference_plugin(loop):
     """three robots in one batch -- two start at cycle 0, one five cycles later, a fourth never gets a plan -- each reproduces the recorded run of the reference's plugin
     (outcome codes, grid sizes, via-point counts; commands and planned states to 1e-9: same C oracle behind both)"""
