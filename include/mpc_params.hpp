@@ -345,6 +345,12 @@ inline ParamStatus config_from_params(const ParamSource& p, mpc_config& c, Contr
         if (kv.first == "max_iter") c.max_iter = kv.second;
         else rep.notes.push_back("ipopt integer option " + kv.first + ": no counterpart, ignored");
     }
+    if (c.hessian_mode == MPC_HESSIAN_CONVEXIFIED && c.tol < 1e-6) {
+        // with tol 1e-8 the convexified Hessian stalls in front of the goal (linear convergence); with the file's tol 1e-4 or the exact Hessian the robot arrives (measured on
+        // tests/golden/ref_plugin_closed_loop_carlike_to_the_goal.*)
+        c.hessian_mode = MPC_HESSIAN_EXACT;
+        rep.notes.push_back("hessian_approximation limited-memory with tol < 1e-6: the exact Hessian is used instead of MPC_HESSIAN_CONVEXIFIED (first-order curvature does not reach such a tolerance reliably close to the goal; the KKT points are the same)");
+    }
 
     // ---- objective (:551-639), terminal cost (:641-672), terminal constraint (:674-713)
     const std::string objective = p.param<std::string>("planning/objective/type", "minimum_time");

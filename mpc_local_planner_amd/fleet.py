@@ -213,6 +213,7 @@ class FleetPlanner:
             self.plans[b] = plan
             tp, goal_idx = PI.transform_global_plan(plan, poses[b], size_x, size_y, resolution, o["max_global_plan_lookahead_dist"])
             vias[b] = PI.via_points_from_plan(tp, o["global_plan_viapoint_sep"])
+            res.n_via[b] = len(vias[b])
             gx, gy, gth = plan[-1]
             if math.hypot(gx - poses[b, 0], gy - poses[b, 1]) < o["xy_goal_tolerance"] and abs(_wrap(gth - poses[b, 2])) < o["yaw_goal_tolerance"]:
                 res.code[b], res.goal_reached[b] = SUCCESS, True
@@ -308,7 +309,6 @@ class FleetPlanner:
         for i, b in enumerate(active):
             self.ocp_seq[b] += 1
             self.last_goal[b] = goals[b]
-            res.n_via[b] = len(vias[b])
         # what the plugin does with the result (:386-461)
         ok = status == 0                                                           # MPC_CONVERGED
         feas = np.ones(m, np.int32)
