@@ -93,3 +93,67 @@ def test_fleet_grid_helpers_reproduce_the_reference_grid_bit_for_bit():
         tm, vals = list(GR["ts_times"][i, :m]), [v.copy() for v in GR["ts_values"][i, :m]]
         for q, ref in zip(GR["ts_query"][i], GR["ts_out"][i]):
             assert np.array_equal(F._interpolate_se2(tm, vals, float(q)), ref), (i, q)
+
+
+class _EchoBackend:
+    """returns the vertex values it was given (a solve that changes nothing); records what it was handed; robots listed in `infeasible` / `failing` get that verdict"""
+    def __init__(self, cfg):
+        self.cfg, self.n = cfg, int(cfg.n)
+        self.infeasible, self.failing, self.calls = set(), set(), []
+
+    def set_grid_sizes(self, n=None):
+        self.n_grid = None if n is None else np.array(n)
+
+    def set_via_points(self, a=None, b=None):
+        self.via = (a, b)
+
+    def costmap_to_obstacles(self, cost, res, org, pose, behind=1.5):
+        B, O, V = cost.shape[0], int(self.cfg.max_obstacles), max(1, int(self.cfg.max_vertices))
+        no = np.ones(B, np.int32); nv = np.zeros((B, O), np.int32); nv[:, 0] = 1; vt = np.zeros((B, O, V, 2)); vt[:, 0, 0] = (9.0, 9.0)
+        return no, nv, vt, np.zeros(B, np.int32)
+
+    def check_feasibility(self, x, *a, **k):
+        return np.array([0 if b in self.infeasible else 1 for b in range(x.shape[0])], np.int32)
+
+    def solve(self, x0, xf, up, dtp, init=None, obstacles=None):
+        class R_:
+            pass
+        self.calls.append(dict(x0=x0.copy(), xf=xf.copy(), up=up.copy(), dtp=dtp.copy(), init=tuple(a.copy() for a in init), obstacles=None if obstacles is None else tuple(a.copy() for a in obstacles)))
+        r = R_()
+        r.x, r.u, r.dt = init[0].copy(), init[1].copy() + 0.05, init[2].copy()
+        r.status = np.array([1 if b in self.failing else 0 for b in range(x0.shape[0])], np.int32)
+        r.iters = np.ones(x0.shape[0], np.int32)
+        return r
+
+
+def test_fleet_bookkeeping_extra_obstacles_failures_and_infeasible_plans():
+    """what step() does around the solve: obstacles the caller adds go behind the costmap's cells; a failed solve or an infeasible trajectory gives NO_VALID_CMD, a zero
+    command and a fresh start next cycle (the plugin's _controller.reset()); the previous control handed to the next solve is the first control of the last series, with
+    dt = 1 / controller_frequency; a robot at its goal is not planned for"""
+    from mpc_local_planner_amd.fleet import FleetPlanner, NO_VALID_CMD, SUCCESS
+    from mpc_local_planner_amd import plugin_inputs as PI
+    prm = json.load(open(os.path.join(HERE, "golden", "ref_plugin_closed_loop_carlike_line_footprint.json")))
+    B = 4
+    fleet = FleetPlanner(prm, batch=B, max_obstacles=8, max_vertices=4, solver="deferred")
+    be = fleet.solver = _EchoBackend(fleet.cfg)
+    plan = np.stack([np.linspace(0, 6, 50), np.zeros(50), np.zeros(50)], 1)
+    for b in range(B):
+        fleet.set_plan(b, plan)
+    poses = np.tile([0.0, 0.0, 0.0], (B, 1)); poses[3] = plan[-1]            # robot 3 stands on its goal
+    cost = np.zeros((B, 60, 60), np.uint8); org = np.tile([-3.0, -3.0], (B, 1)); fp = np.array([(0.3, 0.2), (-0.3, 0.2), (-0.3, -0.2), (0.3, -0.2)])
+    extra = [PI.obstacles_from_messages([{"points": [(1.0, 1.0, 0)], "radius": 0.3, "velocity": (0.1, 0.0)}, {"points": [(2, 1, 0), (2, 2, 0), (3, 2, 0)]}]), None, None, None]
+    be.failing, be.infeasible = {1}, {2}                                       # indices within the ACTIVE robots of the call (robots 0, 1, 2)
+    out = fleet.step(poses, cost, 0.1, org, fp, inscribed_radius=0.2, extra_obstacles=extra)
+    assert out.code.tolist() == [SUCCESS, NO_VALID_CMD, NO_VALID_CMD, SUCCESS] and out.goal_reached.tolist() == [False, False, False, True]
+    assert out.cmd[0, 0] == 0.1 and not out.cmd[1:].any()                       # two outer iterations, each echo solve adds 0.05 to the controls
+    no, nv, vt, rad, vel = be.calls[0]["obstacles"]
+    assert no.tolist() == [3, 1, 1] and nv[0, :3].tolist() == [1, 1, 3] and rad[0, 1] == 0.3 and vel[0, 1].tolist() == [0.1, 0.0] and np.array_equal(vt[0, 2, :3], [(2, 1), (2, 2), (3, 2)])
+    assert len(be.calls) == 2 and (be.calls[0]["dtp"] == 0).all()            # outer_ocp_iterations 2; no previous control in the first cycle
+    assert fleet.grid_empty.tolist()[:3] == [False, True, True]
+    be.failing, be.infeasible = set(), set()
+    out = fleet.step(poses, cost, 0.1, org, fp, inscribed_radius=0.2)
+    assert out.code[:3].tolist() == [SUCCESS] * 3
+    third = be.calls[2]
+    assert np.allclose(third["dtp"], 0.1) and np.allclose(third["up"][:, 0], 0.1)          # u[0] of the last series (two echo solves added 0.05 each), dt = 1 / 10 Hz
+    # robot 0 went on from its previous solution, robots 1 and 2 started afresh (controls of a fresh initial trajectory are zero)
+    assert third["init"][1][0].any() and not third["init"][1][1].any() and not third["init"][1][2].any()
