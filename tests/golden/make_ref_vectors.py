@@ -422,10 +422,17 @@ def main():
     a_ = copy.deepcopy(base); a_["footprint_model"] = {"type": "point"}
     a_["grid"]["variable_grid"]["grid_adaptation"]["min_grid_size"] = 3          # the batched solver's floor (the reference would go down to 2 grid points)
     loops["carlike_to_the_goal"] = (a_, True)
+    a_ = copy.deepcopy(base); a_["footprint_model"] = {"type": "line", "line_start": [0.0, 0.0], "line_end": [0.4, 0.0]}
+    loops["carlike_block_close_to_the_path"] = (a_, True)            # a block 0.42 m beside the path: the clearance rows of the line footprint push the robot aside (one solve fails on the way: reset)
+    cost_close = np.zeros((100, 140), np.uint8)
+    c_ = plan[14, :2] + 0.42 * np.array([-np.sin(plan[14, 2]), np.cos(plan[14, 2])]) - 0.1
+    j_, i_ = int((c_[0] - org[0]) / res), int((c_[1] - org[1]) / res)
+    cost_close[i_:i_ + 2, j_:j_ + 2] = 254
     K, NCAP = 60, 52
     for lname, (prm, car) in loops.items():
         cfgp = PP.config_from_params(prm)[0]
-        runner = RL.PluginRunner(prm, cost, res, org, footprint=fp)
+        the_cost = cost_close if lname == "carlike_block_close_to_the_path" else cost
+        runner = RL.PluginRunner(prm, the_cost, res, org, footprint=fp)
         solves = []
 
         oracle_solver = plugin_oracle_solver.make(runner, cfgp, solves)
@@ -446,7 +453,7 @@ def main():
             pose = pose + 0.1 * np.array([v * np.cos(pose[2]), v * np.sin(pose[2]), (v / 0.4 * np.tan(w)) if car else w])
             vel = np.array([v, 0.0, w])
         runner.close()
-        np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"ref_plugin_closed_loop_{lname}.npz"), cost=cost, plan=the_plan, par=np.array([res, org[0], org[1]]), footprint=np.array(fp), **cl)
+        np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"ref_plugin_closed_loop_{lname}.npz"), cost=the_cost, plan=the_plan, par=np.array([res, org[0], org[1]]), footprint=np.array(fp), **cl)
         with open(os.path.join(ROOT, "tests", "golden", f"ref_plugin_closed_loop_{lname}.json"), "w") as f:
             json.dump(prm, f, indent=1, sort_keys=True)
         print("written plugin closed loop", lname, ":", K, "cycles,", int((cl["code"] == 0).sum()), "SUCCESS, final pose", np.round(pose, 3), "mean iterations per solve", round(float(cl["iters"].mean()), 1),

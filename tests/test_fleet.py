@@ -10,10 +10,10 @@ import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "golden"))
-LOOPS = ["carlike_line_footprint", "via_points_polygon_footprint", "diff_drive_quadratic_form"]
-# a run towards the goal of a short plan: the grid shrinks to 4 points and a fifth of the solves fail near the goal (every failure resets the planner) -- CPU only, where the
-# solver behind the fleet is the same C oracle that was behind the recording
-LOOPS_CPU = LOOPS + ["carlike_to_the_goal"]
+# the last two: a run to the goal of a short plan (the grid shrinks to 4 points, one solve fails on the way, then the goal is reported), and a block 0.42 m beside the path
+# (clearance rows at work, one failed solve): the device fails in the same cycles as the C oracle behind the recordings
+LOOPS = ["carlike_line_footprint", "via_points_polygon_footprint", "diff_drive_quadratic_form", "carlike_to_the_goal", "carlike_block_close_to_the_path"]
+LOOPS_CPU = LOOPS
 
 
 def replay(loop, make_solver, batch_layout, tol):

@@ -159,11 +159,12 @@ def test_reference_plugin_on_the_gpu_solver_other_configurations(variant):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(LIB), reason="oracle/_ref/libmpc_plugin_on_hip.so is built where the reference tree is (make -C oracle ref)")
-@pytest.mark.parametrize("loop", ["carlike_line_footprint", "via_points_polygon_footprint", "diff_drive_quadratic_form"])
+@pytest.mark.parametrize("loop", ["carlike_line_footprint", "via_points_polygon_footprint", "diff_drive_quadratic_form", "carlike_to_the_goal", "carlike_block_close_to_the_path"])
 def test_plugin_on_the_gpu_solver_reproduces_the_plugin_on_the_cpu_oracle(loop):
     """tests/golden/ref_plugin_closed_loop_<loop>.npz: 60 control cycles of the reference's plugin WITH THE REFERENCE'S OWN Controller (oracle/_ref), the C oracle's
     interior-point solve plugged in as its solver, recorded on the CPU (generator: tests/golden/make_ref_vectors.py) -- car-like minimum time with a line footprint, the
-    via-point objective with a polygon footprint, differential drive with the quadratic form on the fixed grid and a free goal.  Here the same robot poses are replayed on
+    via-point objective with a polygon footprint, differential drive with the quadratic form on the fixed grid and a free goal, a run to the goal (shrinking grid, a failed solve, goal reached), a block close to
+    the path (clearance rows at work, a failed solve).  Here the same robot poses are replayed on
     the plugin built on the binding and the MI355X solver: the same outcome codes, the velocity commands and the planned trajectories within the north-star tolerance of 1e-4
     at every cycle -- the reference's orchestration and the CPU restatement of the solve on one side, the binding and the GPU kernel on the other"""
     import json

@@ -883,7 +883,7 @@ def test_reference_form_nlp_is_the_reference_s_terms_on_the_reference_s_edge_lay
 
 
 @pytest.mark.skipif(not os.path.isdir(RL.REFERENCE_INCLUDE), reason="the reference tree is only present in the build container")
-@pytest.mark.parametrize("loop", ["carlike_line_footprint", "via_points_polygon_footprint", "diff_drive_quadratic_form", "carlike_to_the_goal"])
+@pytest.mark.parametrize("loop", ["carlike_line_footprint", "via_points_polygon_footprint", "diff_drive_quadratic_form", "carlike_to_the_goal", "carlike_block_close_to_the_path"])
 def test_binding_reproduces_the_recorded_closed_loops_with_real_solves(loop):
     """tests/golden/ref_plugin_closed_loop_<loop>.npz was recorded with the reference's plugin on the reference's own Controller and the C oracle's solve behind it.  The same
     plugin source on the binding (recording C ABI, the same C oracle behind it), replaying the recorded poses: identical outcome codes, commands and planned trajectories to
