@@ -1,9 +1,19 @@
 #!/usr/bin/env python
-"""Generates tests/golden/ref_models_collocation.npz: outputs of REFERENCE code -- include/mpc_local_planner/utils/math_utils.h, the four robot
-models of include/mpc_local_planner/systems/ and the three collocation rules of include/mpc_local_planner/optimal_control/fd_collocation_se2.h --
-compiled from /root/reference into oracle/_ref/libmpc_ref.so (`make -C oracle ref`; oracle/ref_wrap.cpp says what is real and what is an
-interface stand-in) on seeded inputs.  /root/reference does not exist on the GPU box, so the vectors are committed; this script must be run
-where the reference tree is.   usage: python tests/golden/make_ref_vectors.py"""
+"""Runs the REFERENCE's own code -- compiled from /root/reference into oracle/_ref by `make -C oracle ref` (oracle/ref_wrap*.cpp say what is real and what is an interface
+stand-in) -- on seeded inputs and records what it gives.  /root/reference does not exist on the GPU box, so the records are committed; this script must be run where the reference
+tree is (deterministic: a second run rewrites identical files).   usage: python tests/golden/make_ref_vectors.py
+
+  ref_models_collocation.npz     math_utils.h, the four robot models, the three SE(2) collocation rules
+  ref_stage_inequality.npz       StageInequalitySE2: obstacle association, clearance rows of point obstacles, control-rate rows
+  ref_via_points.npz             MinTimeViaPointsCost: association, terms, time term
+  ref_grid.npz                   the grid classes and TimeSeriesSE2: cold start, nearest state, warm-start cycle, resampling, adaptation, closest pose, time series
+  ref_costs.npz                  QuadraticFormCostSE2 / QuadraticStateCostSE2 / QuadraticFinalStateCostSE2 / TerminalBallSE2
+  ref_configure.json             Controller::configure on the parameter sets of configure_cases.py: what it built, its verdicts (returned, returned false, crashed)
+  ref_controller_steps.npz       Controller::step in closed loop with a stand-in solver (controller_scenarios.py)
+  ref_feasibility_and_result.npz isPoseTrajectoryFeasible with a recording costmap model; the published OptimalControlResult
+  ref_plugin_inputs.npz          the plugin source: costmap scan, obstacle messages, via-points, goal heading, plan pruning / selection
+  ref_footprint_models.json      getRobotFootprintFromParamServer on the parameter sets of footprint_cases.py
+  ref_plugin_closed_loop_*.npz/.json   the whole plugin with the reference's Controller, the C oracle's solve plugged in as its solver: closed loops with real solves"""
 import os
 import sys
 
