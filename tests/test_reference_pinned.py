@@ -925,3 +925,25 @@ def test_plan_pruning_and_selection_reproduce_the_reference_plugin():
         assert np.abs(tp[:, :2] - ref[:, :2]).max() < 1e-12 and np.abs(np.arctan2(np.sin(tp[:, 2] - ref[:, 2]), np.cos(tp[:, 2] - ref[:, 2]))).max() < 1e-12
         injected += int(m == 1 and gi == n - 1)
     assert cut > 20 and injected >= 1
+
+
+@pytest.mark.skipif(not os.path.isdir(RL.REFERENCE_INCLUDE), reason="the reference tree is only present in the build container")
+def test_recorded_plugin_loop_is_what_the_reference_build_gives_today():
+    """the generator's run of tests/golden/ref_plugin_closed_loop_carlike_line_footprint.npz, repeated live on the reference's plugin + the reference's Controller with the C oracle
+    behind it: bit-identical commands and trajectories (guards the committed recording against drift of the generator, the stand-ins or the oracle)"""
+    import json
+    assert RL.build()
+    sys.path.insert(0, os.path.join(HERE, "golden"))
+    import plugin_oracle_solver
+    from mpc_local_planner_amd import params as PP
+    rec = np.load(os.path.join(HERE, "golden", "ref_plugin_closed_loop_carlike_line_footprint.npz"))
+    prm = json.load(open(os.path.join(HERE, "golden", "ref_plugin_closed_loop_carlike_line_footprint.json")))
+    res, ox, oy = rec["par"]
+    run = RL.PluginRunner(prm, rec["cost"], float(res), (float(ox), float(oy)), footprint=rec["footprint"])
+    run.solver = plugin_oracle_solver.make(run, PP.config_from_params(prm)[0])
+    assert run.initialized and run.set_plan(rec["plan"])
+    for i in range(rec["pose"].shape[0]):
+        o = run.cycle(rec["pose"][i], rec["vel"][i])
+        m = int(rec["n"][i])
+        assert o["code"] == rec["code"][i] and np.array_equal(o["cmd"], rec["cmd"][i]) and np.array_equal(o["x_seq"], rec["x_seq"][i, :m]), i
+    run.close()
