@@ -172,6 +172,49 @@ inline std::vector<PoseSE2> via_points_from_plan(const std::vector<PoseSE2>& pla
     return out;
 }
 
+// MpcLocalPlannerROS::pruneGlobalPlan (:645-685): cuts off what lies behind the robot -- everything before the FIRST plan pose closer than dist_behind_robot to it.  The robot
+// pose is given in the plan's frame.  Always true, as in the reference (with no pose that close the plan stays as it is: `erase_end` starts at begin(), :661-675).
+inline bool prune_global_plan(std::vector<PoseSE2>& plan, const PoseSE2& robot_in_plan_frame, double dist_behind_robot = 1.0) {
+    const double thr = dist_behind_robot * dist_behind_robot;
+    for (size_t i = 0; i < plan.size(); ++i) {
+        const double dx = robot_in_plan_frame.x - plan[i].x, dy = robot_in_plan_frame.y - plan[i].y;
+        if (dx * dx + dy * dy < thr) { plan.erase(plan.begin(), plan.begin() + (long)i); return true; }
+    }
+    return true;
+}
+// MpcLocalPlannerROS::transformGlobalPlan (:687-805) for a plan already in the planning frame: the part handed to the controller -- from the plan pose closest to the robot
+// (searched until the plan leaves 85 % of the local costmap's half size) onwards, while the poses stay inside that radius and the length along the plan stays within
+// max_plan_length (<= 0: no limit).  An empty selection yields the global goal alone.  Returns the index of the last selected pose in the global plan.
+inline int transform_global_plan(const std::vector<PoseSE2>& plan, const PoseSE2& robot, int costmap_size_x, int costmap_size_y, double resolution, double max_plan_length,
+                                 std::vector<PoseSE2>& selected) {
+    selected.clear();
+    const int n = (int)plan.size();
+    if (n == 0) return -1;
+    double thr = std::max(costmap_size_x * resolution / 2.0, costmap_size_y * resolution / 2.0);
+    thr *= 0.85;
+    const double sq_thr = thr * thr;
+    auto sq = [&](int j) { const double dx = robot.x - plan[(size_t)j].x, dy = robot.y - plan[(size_t)j].y; return dx * dx + dy * dy; };
+    int i = 0;
+    double sq_dist = 1e10;
+    for (int j = 0; j < n; ++j) {
+        const double d = sq(j);
+        if (d > sq_thr) break;
+        if (d < sq_dist) { sq_dist = d; i = j; }
+    }
+    double length = 0.0;
+    while (i < n && sq_dist <= sq_thr && (max_plan_length <= 0 || length <= max_plan_length)) {
+        selected.push_back(plan[(size_t)i]);
+        sq_dist = sq(i);
+        if (i > 0 && max_plan_length > 0) {
+            const double dx = plan[(size_t)i].x - plan[(size_t)i - 1].x, dy = plan[(size_t)i].y - plan[(size_t)i - 1].y;
+            length += std::sqrt(dx * dx + dy * dy);
+        }
+        ++i;
+    }
+    if (selected.empty()) { selected.push_back(plan.back()); return n - 1; }
+    return i - 1;
+}
+
 // costmap_converter/ObstacleMsg reduced to what the plugin reads: polygon points (x, y), radius, planar velocity
 struct ObstacleMessage {
     std::vector<double> points;      // x0, y0, x1, y1, ...   (geometry_msgs/Point32: single precision on the wire)

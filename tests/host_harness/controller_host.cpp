@@ -78,3 +78,23 @@ extern "C" int ctl_obstacles_from_messages(int n, int max_pts, const int* n_poin
     }
     return v->n_obstacles[0];
 }
+
+extern "C" int ctl_prune_plan(int n, const double* plan, const double* robot, double dist, double* out) {
+    using namespace mpc_local_planner_amd;
+    std::vector<PoseSE2> p((size_t)n);
+    for (int i = 0; i < n; ++i) { p[(size_t)i].x = plan[3 * i]; p[(size_t)i].y = plan[3 * i + 1]; p[(size_t)i].theta = plan[3 * i + 2]; }
+    PoseSE2 r; r.x = robot[0]; r.y = robot[1]; r.theta = robot[2];
+    prune_global_plan(p, r, dist);
+    for (size_t i = 0; i < p.size(); ++i) { out[3 * i] = p[i].x; out[3 * i + 1] = p[i].y; out[3 * i + 2] = p[i].theta; }
+    return (int)p.size();
+}
+extern "C" int ctl_transform_plan(int n, const double* plan, const double* robot, int sx, int sy, double res, double max_len, double* out, int* m) {
+    using namespace mpc_local_planner_amd;
+    std::vector<PoseSE2> p((size_t)n), sel;
+    for (int i = 0; i < n; ++i) { p[(size_t)i].x = plan[3 * i]; p[(size_t)i].y = plan[3 * i + 1]; p[(size_t)i].theta = plan[3 * i + 2]; }
+    PoseSE2 r; r.x = robot[0]; r.y = robot[1]; r.theta = robot[2];
+    const int gi = transform_global_plan(p, r, sx, sy, res, max_len, sel);
+    *m = (int)sel.size();
+    for (size_t i = 0; i < sel.size(); ++i) { out[3 * i] = sel[i].x; out[3 * i + 1] = sel[i].y; out[3 * i + 2] = sel[i].theta; }
+    return gi;
+}

@@ -703,6 +703,8 @@ def host_ctl():
     l.ctl_via_points_from_plan.restype = I; l.ctl_via_points_from_plan.argtypes = [I, V, D, V]
     l.ctl_goal_orientation.restype = D; l.ctl_goal_orientation.argtypes = [I, V, V, I, V, I]
     l.ctl_obstacles_from_messages.restype = I; l.ctl_obstacles_from_messages.argtypes = [I, I, V, V, V, V, I, V, I, V, V]
+    l.ctl_prune_plan.restype = I; l.ctl_prune_plan.argtypes = [I, V, V, D, V]
+    l.ctl_transform_plan.restype = I; l.ctl_transform_plan.argtypes = [I, V, V, I, I, D, D, V, V]
     return l
 
 
@@ -907,7 +909,7 @@ def test_binding_reproduces_the_recorded_closed_loops_with_real_solves(loop):
     run.close()
 
 
-def test_plan_pruning_and_selection_reproduce_the_reference_plugin():
+def test_plan_pruning_and_selection_reproduce_the_reference_plugin(host_ctl):
     """pruneGlobalPlan (:645-685) and transformGlobalPlan (:687-805), executed with a planar tf answer: what is cut off behind the robot (and that the function reports success
     even when no pose is close enough), where the selected part starts (closest pose inside 85 % of the costmap's half size), where it ends (radius, max_plan_length), the
     goal index, the poses moved into the planning frame; an empty selection yields the global goal"""
@@ -924,6 +926,13 @@ def test_plan_pruning_and_selection_reproduce_the_reference_plugin():
         assert tp.shape[0] == m and gi == PLG["gp_goal_idx"][i], (i, tp.shape, m, gi)
         assert np.abs(tp[:, :2] - ref[:, :2]).max() < 1e-12 and np.abs(np.arctan2(np.sin(tp[:, 2] - ref[:, 2]), np.cos(tp[:, 2] - ref[:, 2]))).max() < 1e-12
         injected += int(m == 1 and gi == n - 1)
+        if yaw == 0 and tx == 0 and ty == 0:                       # the C++ helpers of include/mpc_controller.hpp take a plan that is already in the planning frame
+            p = lambda a: a.ctypes.data_as(C.c_void_p)
+            pl = np.ascontiguousarray(plan); rb = np.array([px, py, pth]); out = np.zeros((n + 1, 3)); mm = C.c_int(0)
+            k = host_ctl.ctl_prune_plan(n, p(pl), p(rb), d, p(out))
+            assert k == pr.shape[0] and np.array_equal(out[:k], pr)
+            gj = host_ctl.ctl_transform_plan(n, p(pl), p(rb), int(sx), int(sy), res, ml, p(out), C.byref(mm))
+            assert gj == gi and mm.value == m and np.array_equal(out[:m, :2], plan[gi - m + 1:gi + 1, :2] if not (m == 1 and gi == n - 1) else plan[-1:, :2])
     assert cut > 20 and injected >= 1
 
 
