@@ -537,6 +537,12 @@ class PluginRunner:
         lines = [(int(l.split("|", 1)[0]), l.split("|", 1)[1]) for l in buf.value.decode(errors="replace").splitlines() if "|" in l]
         return [t for lv, t in lines if lv >= min_level]
 
+    def state_feedback(self, state, stamp):
+        """a message on the controller's state_feedback topic; the stand-in clock stands at 0"""
+        f = self._f("state_feedback"); f.restype = None; f.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_double]
+        a = np.ascontiguousarray(state, float)
+        f(self._h, _p(a), a.size, float(stamp))
+
     def set_custom_obstacles(self, msgs):
         """the "obstacles" topic: [{points: [(x, y, z), ...], radius, velocity: (vx, vy)}]"""
         npts = np.array([len(m["points"]) for m in msgs], np.int32)

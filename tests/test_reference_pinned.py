@@ -725,6 +725,8 @@ def _plugin_variants():
     a["planning"]["objective"] = {"type": "quadratic_form", "quadratic_form": {"state_weights": [2.0, 2.0, 0.25], "control_weights": [0.1, 0.05]}}
     a["controller"]["global_plan_overwrite_orientation"] = False; a["collision_avoidance"]["include_costmap_obstacles"] = False; a["footprint_model"] = {"type": "circular", "radius": 0.25}
     v["unicycle_quadratic_fixed_grid_no_costmap_obstacles"] = a
+    a = copy.deepcopy(car); a["controller"]["prefer_x_feedback"] = True; a["controller"]["force_reinit_num_steps"] = 9
+    v["state_feedback_preferred_periodic_reinit"] = a
     a = copy.deepcopy(car); a["controller"]["max_global_plan_lookahead_dist"] = 3.0; a["controller"]["global_plan_prune_distance"] = 0.5; a["collision_avoidance"]["costmap_obstacles_behind_robot_dist"] = 0.3
     a["collision_avoidance"]["collision_check_no_poses"] = 5; a["collision_avoidance"]["collision_check_min_resolution_angular"] = 0.2; a["footprint_model"] = {"type": "point"}
     v["long_lookahead_short_feasibility_check"] = a
@@ -732,7 +734,8 @@ def _plugin_variants():
 
 
 @pytest.mark.skipif(not os.path.isdir(RL.REFERENCE_INCLUDE), reason="the reference tree is only present in the build container")
-@pytest.mark.parametrize("variant", ["carlike_line_footprint", "via_points_polygon_footprint", "unicycle_quadratic_fixed_grid_no_costmap_obstacles", "long_lookahead_short_feasibility_check"])
+@pytest.mark.parametrize("variant", ["carlike_line_footprint", "via_points_polygon_footprint", "unicycle_quadratic_fixed_grid_no_costmap_obstacles", "long_lookahead_short_feasibility_check",
+                                     "state_feedback_preferred_periodic_reinit"])
 def test_reference_plugin_source_runs_unchanged_on_the_binding(variant):
     """initialize() -> setPlan() -> 40 x computeVelocityCommands() on a costmap with obstacles (a wall appears in front of the robot for four cycles: the feasibility check
     trips, the planner resets) and one failing solve: the two builds agree at every cycle in the mbf outcome code, the velocity command, the obstacle and via-point containers,
@@ -762,8 +765,14 @@ def test_reference_plugin_source_runs_unchanged_on_the_binding(variant):
             k = int((pose[0] + 0.25 + 2.0) / 0.1); cost[:, k:k + 2] = 254
         if i == 24:
             cost[:, :] = 0
+        if variant == "state_feedback_preferred_periodic_reinit" and i % 3 == 0:        # a measured state: fresh every sixth cycle, stale every sixth
+            meas, stamp = pose + np.array([0.02, -0.01, 0.03]), (-0.05 if i % 6 == 0 else -1.0)
+            A.state_feedback(meas, stamp); B.state_feedback(meas, stamp)
+            last_meas, last_fresh = meas, stamp > -0.2                        # the stand-in clock stands at 0: a measurement stays fresh until the next message
         a, b = A.cycle(pose, (0.1, 0.0, 0.02), cost), B.cycle(pose, (0.1, 0.0, 0.02), cost)
         codes.append(a["code"])
+        if variant == "state_feedback_preferred_periodic_reinit" and a["guess_x"].size:
+            assert np.allclose(a["guess_x"][0], last_meas if last_fresh else pose, atol=1e-12), i          # the solve starts from the measured state only while it is fresh
         assert a["code"] == b["code"] and np.abs(a["cmd"] - b["cmd"]).max() < 1e-12, (i, a["code"], b["code"], a["cmd"], b["cmd"])
         assert (a["n_obstacles"], a["n_via"], a["goal_reached"], a["infeasible_in_a_row"]) == (b["n_obstacles"], b["n_via"], b["goal_reached"], b["infeasible_in_a_row"]), i
         assert a["x_seq"].shape == b["x_seq"].shape and (a["x_seq"].size == 0 or np.abs(a["x_seq"] - b["x_seq"]).max() < 1e-12), i
