@@ -13,7 +13,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB = os.path.join(_HERE, "_ref", "libmpc_ref.so")
 PLUGIN_ON_BINDING_LIB = os.path.join(_HERE, "_ref", "libmpc_plugin_on_binding.so")      # the reference's plugin source built on include/mpc_reference_binding.hpp
-REFERENCE_INCLUDE = "/root/reference/mpc_local_planner/include"
+REFERENCE_INCLUDE = os.environ.get("MPC_REFERENCE_INCLUDE", "/root/reference/mpc_local_planner/include")      # the variable exists to test the "no reference tree" behaviour
 
 
 def build() -> bool:
