@@ -22,7 +22,10 @@ int g_obst_n = -1, g_obst_stride = 0;
 }
 
 extern "C" {
-int mpc_create(const mpc_config* cfg, int32_t, int32_t, mpc_solver** out) { *out = new mpc_solver{*cfg, cfg->n}; return MPC_OK; }
+static mpc_config g_last_created;
+int mpc_create(const mpc_config* cfg, int32_t, int32_t, mpc_solver** out) { g_last_created = *cfg; *out = new mpc_solver{*cfg, cfg->n}; return MPC_OK; }
+// the configuration of the most recent mpc_create (what a binding built from its parameters)
+void fs_last_created_config(mpc_config* out) { *out = g_last_created; }
 void mpc_destroy(mpc_solver* s) { delete s; }
 int mpc_reset(mpc_solver* s) { ++s->resets; return MPC_OK; }
 const char* mpc_last_error(void) { return g_err.c_str(); }

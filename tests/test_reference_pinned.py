@@ -965,3 +965,43 @@ def test_recorded_plugin_loop_is_what_the_reference_build_gives_today():
         m = int(rec["n"][i])
         assert o["code"] == rec["code"][i] and np.array_equal(o["cmd"], rec["cmd"][i]) and np.array_equal(o["x_seq"], rec["x_seq"][i, :m]), i
     run.close()
+
+
+@pytest.mark.skipif(not os.path.isdir(RL.REFERENCE_INCLUDE), reason="the reference tree is only present in the build container")
+def test_binding_configure_builds_the_handle_the_parameter_readers_describe():
+    """mpc_local_planner::Controller of include/mpc_reference_binding.hpp, configure() on a ros::NodeHandle: the mpc_config it hands to mpc_create equals what the parameter
+    reader gives for the same parameters plus the handle capacities (mpc_hip/*); footprint_model/type costmap_2d becomes the polygon of setCostmapFootprint, or -- without
+    that call -- the point model with a warning; a parameter set the reference rejects makes configure() return false with the reference's message"""
+    assert RL.build()
+    import configure_cases
+    from mpc_local_planner_amd import params as PP, _abi as A2
+    lib = RL.load_plugin_on_binding()
+    lib.amd_binding_configure.restype = C.c_int; lib.amd_binding_configure.argtypes = [C.c_char_p, C.c_int, C.c_void_p]
+    lib.fs_last_created_config.restype = None; lib.fs_last_created_config.argtypes = [C.POINTER(A2.MpcConfig)]
+    lib.amd_plugin_log.restype = C.c_int; lib.amd_plugin_log.argtypes = [C.c_char_p, C.c_int]
+
+    def configure(tree, fp=None):
+        a = None if fp is None else np.ascontiguousarray(fp, float)
+        ok = lib.amd_binding_configure("\n".join(RL.plugin_param_lines(tree)).encode(), 0 if a is None else a.shape[0], None if a is None else a.ctypes.data_as(C.c_void_p))
+        cfg = A2.MpcConfig(); lib.fs_last_created_config(C.byref(cfg))
+        buf = C.create_string_buffer(1 << 14); lib.amd_plugin_log(buf, len(buf))
+        return bool(ok), cfg, buf.value.decode()
+    prm = configure_cases.base_carlike()
+    prm["mpc_hip"] = {"max_obstacles": 48, "max_vertices": 5, "max_obstacle_rows": 6}
+    prm["footprint_model"] = {"type": "line", "line_start": [0.0, 0.0], "line_end": [0.4, 0.0]}
+    ok, cfg, _ = configure(prm)
+    ref = PP.config_from_params(prm, max_obstacles=48, max_vertices=5, max_obstacle_rows=6, max_via_points=16)[0]
+    assert ok and (cfg.max_obstacles, cfg.max_vertices, cfg.max_obstacle_rows) == (48, 5, 6) and cfg.n == 50         # sized for the largest grid of the adaptation
+    for f in ("model", "dt_ref", "dt_free", "dt_lb", "dt_ub", "collocation", "objective", "max_iter", "tol", "hessian_mode", "min_obstacle_dist", "force_inclusion_dist", "cutoff_dist",
+              "footprint_kind", "enable_dynamic_obstacles"):
+        assert getattr(cfg, f) == getattr(ref, f), f
+    for f in ("model_params", "xf_fixed", "u_lb", "u_ub", "du_lb", "du_ub", "footprint_params"):
+        assert list(getattr(cfg, f)) == list(getattr(ref, f)), f
+    square = [(0.2, 0.1), (-0.2, 0.1), (-0.2, -0.1), (0.2, -0.1)]
+    prm["footprint_model"] = {"type": "costmap_2d"}
+    ok, cfg, log = configure(prm, square)
+    assert ok and cfg.footprint_kind == 4 and cfg.footprint_n_vertices == 4 and np.allclose(np.array(list(cfg.footprint_vertices)[:8]).reshape(4, 2), square)
+    ok, cfg, log = configure(prm)
+    assert ok and cfg.footprint_kind == 0 and "setCostmapFootprint" in log
+    ok, _, log = configure(configure_cases.cases()["unknown_objective"])
+    assert not ok and "Unknown objective type 'maximum_comfort'" in log
