@@ -623,6 +623,11 @@ class IpmOptions:
     filter_cap: int = 16
     mu_strategy: str = "monotone"
     kappa_c: float = 0.25
+    # EXPERIMENT, off by default (not in the C solver, not in the kernel): when the line search refuses
+    # every trial step (or accepts only one shorter than 1e-6 of the fraction-to-boundary step) at a point whose error is at most `acceptable_tol`, stop there with status 0 instead of taking the shortest trial
+    # step with a full multiplier step -- Ipopt's "solved to acceptable level" / tiny-step stop, which the reference counts as success.
+    acceptable_stop: bool = False
+    acceptable_tol: float = 1e-6
     verbose: bool = False
 
 
@@ -933,6 +938,10 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
             if alpha * np.abs(dz).max() < 1e-14:
                 status = 2
                 break
+        if opt.acceptable_stop and (not accepted or alpha < 1e-6 * a_p) and e0 <= opt.acceptable_tol:
+            # nothing is moved (neither the point nor the multipliers): the next iteration would compute the same step and refuse it again
+            status = 0
+            break
         v, s = vt, st
         lam = lam + alpha * (lam_new - lam)
         y = y + a_d * dy

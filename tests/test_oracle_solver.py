@@ -575,3 +575,25 @@ def test_cost_variants_independent_sqp_from_the_cold_start(name, c_oracle):
         t = nlp.unpack(r.x)
         assert np.abs(t.x - xo[i]).max() < 1e-4 and abs(t.dt - do[i]) < 1e-4, (name, i, np.abs(t.x - xo[i]).max())
         assert abs(r.fun - nlp.objective(nlp.pack(R.Trajectory(xo[i], uo[i][:ocfg.n - 1], float(do[i]))))) < 1e-6 * max(1.0, abs(r.fun))
+
+
+def test_near_goal_stall_and_the_experimental_acceptable_level_stop():
+    """a 4-point grid 0.27 m in front of the goal (a cycle of the recorded `carlike_to_the_goal` run).
+    With tol 1e-8 the solve stands at 1.2e-8 after 15 iterations, the line search refuses what follows and the solve ends at max_iter;
+    at tol 1e-6 it converges; the opt-in stop of the numpy solver (not in the C solver, not in the kernel: an experiment for the next
+    round) ends at that 15th iterate with status 0, and the three answers agree to 2e-6."""
+    cfg = R.config_carlike_min_time(4)
+    inp = R.CycleInputs(x0=np.array([1.836, 0.676, 0.366]), xf=np.array([2.087, 0.769, 0.2927]), u_prev=np.array([0.4, 0.0]), dt_prev=0.1)
+    stalled = _ipm(cfg, inp)
+    loose = _ipm(cfg, inp, tol=1e-6)
+    stopped = _ipm(cfg, inp, acceptable_stop=True)
+    assert stalled.status == 1 and stalled.iters == 100 and stalled.kkt_error < 1e-5
+    assert min(h["e0"] for h in stalled.history) < 2e-8          # it had been there
+    assert loose.status == 0 and loose.iters <= 16
+    assert stopped.status == 0 and stopped.iters <= 16 and stopped.kkt_error < 2e-8
+    for other in (stalled, loose):
+        assert np.abs(stopped.traj.x - other.traj.x).max() < 2e-6
+        assert np.abs(stopped.traj.u - other.traj.u).max() < 2e-6
+        assert abs(stopped.traj.dt - other.traj.dt) < 2e-6
+    # off by default: the goldens and the parity suites are not touched by the experiment
+    assert I.IpmOptions().acceptable_stop is False
