@@ -98,6 +98,15 @@ def dual_state(B: int, n: int):
     return np.zeros((B, int(lib.oracle_dual_words(C.c_int(n)))))
 
 
+def set_acceptable_stop(tol: float):
+    """EXPERIMENT switch of the C solver, process-wide, 0 = off (the default): stop with status 0 when the line search refuses the step at
+    a point whose error is at most `tol`.  Tests that switch it on switch it off again."""
+    lib = _load()
+    lib.oracle_set_acceptable_stop.argtypes = [C.c_double]
+    lib.oracle_set_acceptable_stop.restype = None
+    lib.oracle_set_acceptable_stop(float(tol))
+
+
 def num_threads() -> int:
     return int(_load().oracle_num_threads())
 

@@ -989,6 +989,11 @@ static void ftb(double val, double dval, double tau, double* alpha) { if (dval <
 static long g_nfac_total = 0;
 static int g_nfac_max = 0;
 void oracle_set_variant(int v) { g_variant = v; g_nfac_total = 0; g_nfac_max = 0; }
+/* EXPERIMENT, off (0) unless a test switches it on (same rule as IpmOptions.acceptable_stop of ipm_dense.py, not in the
+ * kernel): when the line search refuses every trial step, or accepts only one below 1e-6 of the fraction-to-boundary step, at a point whose error is at
+ * most this tolerance, the solve ends there with status 0 -- Ipopt's "solved to acceptable level", which the reference counts as success. */
+static double g_acceptable_tol = 0.0;
+void oracle_set_acceptable_stop(double tol) { g_acceptable_tol = tol; }
 long oracle_nfac_total(void) { return g_nfac_total; }
 int oracle_nfac_max(void) { return g_nfac_max; }
 
@@ -1273,6 +1278,7 @@ static int solve_one(work_t* w, int warm) {
             if (isfinite(phit) && phit - phi0 - 10 * 2.220446049250313e-16 * fabs(phi0) <= eta * alpha * Dm) { accepted = 1; break; }
         }
         if (!accepted && alpha * dzmax < 1e-14) { status = 2; break; }
+        if (g_acceptable_tol > 0 && (!accepted || alpha < 1e-6 * a_p) && e0 <= g_acceptable_tol) { status = 0; break; }
         /* accept */
         const double kS = 1e10;
         for (int r = 0; r < n; ++r) for (int q = 0; q < 4; ++q) if (row_on(w, r, q)) {

@@ -597,3 +597,24 @@ def test_near_goal_stall_and_the_experimental_acceptable_level_stop():
         assert abs(stopped.traj.dt - other.traj.dt) < 2e-6
     # off by default: the goldens and the parity suites are not touched by the experiment
     assert I.IpmOptions().acceptable_stop is False
+
+
+def test_near_goal_stall_in_the_c_solver_and_its_experimental_stop(c_oracle):
+    """The same instance in the C solver: max_iter by default, 15 iterations with the process-wide experiment switch, same point as numpy."""
+    cfg = R.config_carlike_min_time(4)
+    x0, xf = np.array([[1.836, 0.676, 0.366]]), np.array([[2.087, 0.769, 0.2927]])
+    up, dtp = np.array([[0.4, 0.0]]), np.array([0.1])
+    oc = c_oracle.from_nlp_config(cfg, max_iter=100, tol=1e-8)
+    ref = _ipm(cfg, R.CycleInputs(x0=x0[0], xf=xf[0], u_prev=up[0], dt_prev=0.1), acceptable_stop=True)
+    r = c_oracle.solve_batch(oc, x0, xf, up, dtp, nthreads=1)
+    assert r[3][0] == 1 and r[4][0] == 100
+    c_oracle.set_acceptable_stop(1e-6)
+    try:
+        r = c_oracle.solve_batch(oc, x0, xf, up, dtp, nthreads=1)
+    finally:
+        c_oracle.set_acceptable_stop(0.0)
+    assert r[3][0] == 0 and r[4][0] == ref.iters
+    assert np.abs(r[0][0] - ref.traj.x).max() < 1e-7 and np.abs(r[1][0][:3] - ref.traj.u).max() < 1e-7 and abs(r[2][0] - ref.traj.dt) < 1e-7
+    # and off again
+    r = c_oracle.solve_batch(oc, x0, xf, up, dtp, nthreads=1)
+    assert r[3][0] == 1
