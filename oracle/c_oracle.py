@@ -107,6 +107,15 @@ def set_acceptable_stop(tol: float):
     lib.oracle_set_acceptable_stop(float(tol))
 
 
+def set_acceptable_iter(k: int):
+    """Second experiment switch (0 = off): status 0 after `k` iterations in a row with an error of at most the tolerance given to
+    `set_acceptable_stop` (Ipopt's acceptable_iter, 15 there)."""
+    lib = _load()
+    lib.oracle_set_acceptable_iter.argtypes = [C.c_int]
+    lib.oracle_set_acceptable_iter.restype = None
+    lib.oracle_set_acceptable_iter(int(k))
+
+
 def num_threads() -> int:
     return int(_load().oracle_num_threads())
 

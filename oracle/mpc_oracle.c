@@ -994,6 +994,10 @@ void oracle_set_variant(int v) { g_variant = v; g_nfac_total = 0; g_nfac_max = 0
  * most this tolerance, the solve ends there with status 0 -- Ipopt's "solved to acceptable level", which the reference counts as success. */
 static double g_acceptable_tol = 0.0;
 void oracle_set_acceptable_stop(double tol) { g_acceptable_tol = tol; }
+/* second half of Ipopt's rule, also an experiment switch (0 = off): status 0 after this many iterations in a row with an error of at most
+ * g_acceptable_tol (Ipopt: acceptable_iter = 15) */
+static int g_acceptable_iter = 0;
+void oracle_set_acceptable_iter(int k) { g_acceptable_iter = k; }
 long oracle_nfac_total(void) { return g_nfac_total; }
 int oracle_nfac_max(void) { return g_nfac_max; }
 
@@ -1099,6 +1103,7 @@ static int solve_one(work_t* w, int warm) {
         if (ball_on(w)) w->ty = fmax(w->ty, b[3]);
     }
     double fobj;
+    int n_acceptable = 0;
     eval_point(w, w->X, w->U, w->D, cc, &fobj);
     while (1) {
         err_t e;
@@ -1106,6 +1111,10 @@ static int solve_one(work_t* w, int warm) {
         double e0 = err_value(&e, 0.0);
         if (!isfinite(e0)) { status = 4; break; }
         if (e0 <= tol) { status = 0; break; }
+        if (g_acceptable_iter > 0 && g_acceptable_tol > 0) {
+            n_acceptable = e0 <= g_acceptable_tol ? n_acceptable + 1 : 0;
+            if (n_acceptable >= g_acceptable_iter) { status = 0; break; }
+        }
         if (it >= max_iter) { status = 1; break; }
         for (int g = 0; g < 50; ++g) {
             double emu = err_value(&e, w->mu);

@@ -618,3 +618,13 @@ def test_near_goal_stall_in_the_c_solver_and_its_experimental_stop(c_oracle):
     # and off again
     r = c_oracle.solve_batch(oc, x0, xf, up, dtp, nthreads=1)
     assert r[3][0] == 1
+    # the other half of Ipopt's rule (k iterations in a row at the acceptable level) is a second switch; both on, level 1e-5, k = 15:
+    # the run ends early, by whichever rule fires first
+    c_oracle.set_acceptable_stop(1e-5)
+    c_oracle.set_acceptable_iter(15)
+    try:
+        r = c_oracle.solve_batch(oc, x0, xf, up, dtp, nthreads=1)
+    finally:
+        c_oracle.set_acceptable_stop(0.0)
+        c_oracle.set_acceptable_iter(0)
+    assert r[3][0] == 0 and r[4][0] <= 30
