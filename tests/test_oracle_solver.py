@@ -587,8 +587,11 @@ def test_near_goal_stall_and_the_experimental_acceptable_level_stop():
     stalled = _ipm(cfg, inp)
     loose = _ipm(cfg, inp, tol=1e-6)
     stopped = _ipm(cfg, inp, acceptable_stop=True)
-    assert stalled.status == 1 and stalled.iters == 100 and stalled.kkt_error < 1e-5
-    assert min(h["e0"] for h in stalled.history) < 2e-8          # it had been there
+    # the stall sits at the rounding level of the merit function: on this container's BLAS it is there (status 1 after 100 iterations); the C solver's
+    # test below, whose arithmetic does not depend on the machine, is the one that insists on it
+    assert stalled.status in (0, 1) and stalled.kkt_error < 1e-5
+    if stalled.status == 1:
+        assert stalled.iters == 100 and min(h["e0"] for h in stalled.history) < 2e-8          # it had been there
     assert loose.status == 0 and loose.iters <= 16
     assert stopped.status == 0 and stopped.iters <= 16 and stopped.kkt_error < 2e-8
     for other in (stalled, loose):
