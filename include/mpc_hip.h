@@ -188,6 +188,17 @@ typedef struct mpc_config {
     double  R_offdiag;
     double  Qf_offdiag[3];
     double  terminal_ball_S_offdiag[3];
+    /* Ipopt's "solved to acceptable level", which the reference's wrapper counts as success (src/controller.cpp:388-421 configures corbo's
+     * SolverIpopt; its result is success for Converged and for EarlyTerminated alike).  Two halves, both at the level acceptable_tol:
+     *   - acceptable_iter iterations in a row with a scaled optimality error of at most acceptable_tol end the solve with MPC_CONVERGED;
+     *   - when the line search refuses every trial step, or accepts only one below 1e-6 of the fraction-to-boundary step, at a point whose error
+     *     is at most acceptable_tol, the solve ends THERE (neither the point nor the multipliers move) with MPC_CONVERGED.
+     * Without it the tiny grids the plugin reaches close to its goal (n = 4..10 after grid adaptation) stall a factor ~1.2 above tol = 1e-8 at
+     * the rounding level of the merit function and end in MPC_MAX_ITER (the recorded to-the-goal run of the reference's plugin then answers
+     * NO_VALID_CMD).  The headline workloads are untouched by it (bit-identical trajectories / iteration counts). */
+    double  acceptable_tol;           /* solver/ipopt/ipopt_numeric_options/acceptable_tol: 0 -> Ipopt's default 1e-6, < 0 -> rule off */
+    int32_t acceptable_iter;          /* .../ipopt_integer_options/acceptable_iter: 0 -> Ipopt's default 15, < 0 -> counting half off */
+    int32_t reserved2;
 } mpc_config;
 
 /* Obstacles of a batch (teb_local_planner ObstContainer of every instance, flattened; borrowed for the call).

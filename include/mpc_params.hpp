@@ -330,6 +330,7 @@ inline ParamStatus config_from_params(const ParamSource& p, mpc_config& c, Contr
     for (const auto& kv : numeric) {
         if (kv.first == "tol") c.tol = kv.second;
         else if (kv.first == "mu_init") c.mu_init = kv.second;
+        else if (kv.first == "acceptable_tol") c.acceptable_tol = kv.second > 0 ? kv.second : -1.0;
         else rep.notes.push_back("ipopt numeric option " + kv.first + ": no counterpart, ignored");
     }
     for (const auto& kv : strings) {
@@ -343,6 +344,7 @@ inline ParamStatus config_from_params(const ParamSource& p, mpc_config& c, Contr
     }
     for (const auto& kv : integers) {
         if (kv.first == "max_iter") c.max_iter = kv.second;
+        else if (kv.first == "acceptable_iter") c.acceptable_iter = kv.second > 0 ? kv.second : -1;      // Ipopt: 0 disables the heuristic
         else rep.notes.push_back("ipopt integer option " + kv.first + ": no counterpart, ignored");
     }
     if (c.hessian_mode == MPC_HESSIAN_CONVEXIFIED && c.tol < 1e-6) {

@@ -11,4 +11,3 @@ from . import workloads  # noqa: F401
 from . import params  # noqa: F401  (the reference's parameter set -> mpc_config)
 from .params import config_from_params, config_from_yaml  # noqa: F401
 from . import plugin_inputs  # noqa: F401  (what the reference's plugin prepares around a solve: plan handling, via-points, obstacle messages)
-from .fleet import FleetPlanner, FleetResult  # noqa: F401  (the plugin's control cycle for a batch of robots)

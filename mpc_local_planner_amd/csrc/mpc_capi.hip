@@ -111,7 +111,8 @@ void mpc_config_defaults(mpc_config* c) {
 }
 
 const char* mpc_last_error(void) { return g_err; }
-int32_t mpc_version(void) { return 210; }      // 0.2.0: mpc_config grew (candidates, kept multipliers, hessian_mode), new entry points; 0.2.1: cost variants (off-diagonal weights, trapezoidal rule, hybrid cost)
+int32_t mpc_version(void) { return 300; }      // 0.3.0: mpc_config grew (acceptable_tol / acceptable_iter)
+// history: 0.2.0: mpc_config grew (candidates, kept multipliers, hessian_mode), new entry points; 0.2.1: cost variants (off-diagonal weights, trapezoidal rule, hybrid cost)
 
 #ifdef MPC_PROFILE
 // developer build only (-DMPC_PROFILE): per-wave phase cycle counters of the last wave-kernel launch
@@ -145,6 +146,8 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
     if (cfg->precision != MPC_FP64 && cfg->precision != MPC_FP32 && cfg->precision != MPC_MIXED) { set_err("mpc_create: unknown precision"); return MPC_EINVAL; }
     if (cfg->cost_integration != MPC_COST_LEFT_SUM && cfg->cost_integration != MPC_COST_TRAPEZOIDAL) { set_err("mpc_create: unknown cost_integration"); return MPC_EINVAL; }
     if (cfg->hybrid_cost_minimum_time && cfg->objective != MPC_OBJ_QUADRATIC) { set_err("mpc_create: hybrid_cost_minimum_time belongs to the quadratic_form objective"); return MPC_EINVAL; }
+    if (cfg->n_candidates == 1 && cfg->candidate_kind[0] != MPC_CAND_REFERENCE) {
+        set_err("mpc_create: a single candidate must be MPC_CAND_REFERENCE (other kinds only run as hedges next to it: n_candidates >= 2)"); return MPC_EINVAL; }
     if (cfg->precision == MPC_MIXED && (cfg->max_obstacles > 0 || cfg->objective == MPC_OBJ_MIN_TIME_VIA_POINTS)) {
         set_err("mpc_create: MPC_MIXED is implemented for problems without clearance rows and via-points (their association would be redone by the refinement phase)"); return MPC_EINVAL; }
     if (cfg->hessian_mode != MPC_HESSIAN_EXACT && cfg->hessian_mode != MPC_HESSIAN_CONVEXIFIED) { set_err("mpc_create: unknown hessian_mode"); return MPC_EINVAL; }
@@ -217,6 +220,7 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         if (er == hipSuccess) er = hipMalloc((void**)&s->d_out, s->out_cap);
     }
     if (er == hipSuccess) er = hipMalloc((void**)&s->d_ngrid, Bm * 4);
+    if (er == hipSuccess) { std::vector<int32_t> full(Bm, cfg->n); er = hipMemcpy(s->d_ngrid, full.data(), Bm * 4, hipMemcpyHostToDevice); }      // never uninitialised
     if (s->P64.n_via > 0) {
         if (er == hipSuccess) er = hipMalloc((void**)&s->d_nvia, Bm * 4);
         if (er == hipSuccess) er = hipMalloc((void**)&s->d_via, Bm * (size_t)s->P64.n_via * 3 * 8);
@@ -302,7 +306,10 @@ static hipError_t launch_model(mpc_solver* s, const mpc::Problem<T>& P, int B, c
     a.L = s->WL; a.B = B;
     a.x0 = x0; a.xf = xf; a.u_prev = up; a.dt_prev = dtp; a.x_init = xi; a.u_init = ui; a.dt_init = dti; a.obst = ob;
     a.n_grid = s->use_ngrid ? s->d_ngrid : nullptr; a.n_via = s->p_nvia; a.via = s->p_via;
-    a.cc = {P.n_cand, s->d_cwin, s->d_cexited, s->d_citsum, s->d_crec, s->d_winner, s->d_iters_total, s->d_rows_dropped, s->d_dual, s->dual_words};
+    // kept multipliers: a launch starts from them under dual_warm_start; in MPC_MIXED without it the block is only the hand-off from the fp32 phase
+    // (which leaves its multipliers) to the fp64 phase (which starts from them) -- nothing is carried from the slot's previous control cycle
+    const int dual_read = (s->cfg.dual_warm_start || (s->cfg.precision == MPC_MIXED && sizeof(T) == 8)) ? 1 : 0;
+    a.cc = {P.n_cand, s->d_cwin, s->d_cexited, s->d_citsum, s->d_crec, s->d_winner, s->d_iters_total, s->d_rows_dropped, s->d_dual, s->dual_words, dual_read};
     a.iters_add = (s->cfg.precision == MPC_MIXED && sizeof(T) == 8) ? s->d_iters1 : nullptr;
     a.x_out = xo; a.u_out = uo; a.dt_out = dto; a.status = st; a.iters = it;
     return mpc::launch_solve<T, MODEL>(a, P);
@@ -495,6 +502,7 @@ int mpc_grid_update_device(mpc_solver* s, int32_t B, const double* d_x0_new, dou
     if (!s || !d_x || !d_u || !d_dt) { set_err("mpc_grid_update_device: null argument"); return MPC_EINVAL; }
     if (B <= 0) return MPC_OK;
     if (B > s->max_batch) { set_err("mpc_grid_update_device: B exceeds max_batch"); return MPC_EBATCH; }
+    if (s->use_ngrid && B > s->ngrid_B) { set_err("mpc_grid_update_device: B exceeds the batch the per-instance grid sizes were set for (mpc_set_grid_sizes)"); return MPC_EBATCH; }
     HIP_TRY(hipSetDevice(s->device));
     mpc::GridUpdateArgs a;
     memset(&a, 0, sizeof(a));

@@ -87,6 +87,9 @@ struct Problem {
     // integral-form cost on the variable grid, minimum time added to the quadratic form
     T Qo[3], Ro, Qfo[3], So[3];
     int trapz, hybrid, costx;      // costx: any of Qo / Ro / Qfo / So non-zero, or trapz
+    // Ipopt's acceptable-level stop (mpc_config.acceptable_tol / acceptable_iter): level (0 = rule off) and iterations in a row (0 = counting half off)
+    T acc_tol;
+    int acc_iter;
 };
 
 // Algorithm constants (Waechter & Biegler 2006 names).  Compile-time so that they live in

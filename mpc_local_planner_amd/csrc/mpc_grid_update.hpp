@@ -99,14 +99,14 @@ __global__ __launch_bounds__(64) void grid_update_kernel(GridUpdateArgs a) {
             if ((int)blk[0] == n) {
                 const int NS = a.dual_ns;
                 __syncthreads();
+                // each array goes through the LDS block (the trajectory copy in it is no longer needed): any grid size the block holds, no
+                // per-lane staging buffer (a fixed `keep[4]` overflowed for n > 256, which an fp32 solver's LDS budget allows)
                 for (int comp = 0; comp < 11; ++comp) {
                     double* arr = blk + 4 + comp * NS;
-                    double keep[4];
-                    int cnt = 0;
-                    for (int k = lane; k < n; k += 64) { const int src = k + sh < n ? k + sh : n - 1; keep[cnt++] = arr[comp < 3 || comp >= 7 ? (src < n - 1 ? src : n - 2) : src]; }
+                    for (int k = lane; k < n; k += 64) gsm[k] = arr[k];
                     __syncthreads();
-                    cnt = 0;
-                    for (int k = lane; k < n; k += 64) arr[k] = keep[cnt++];
+                    const bool per_interval = comp < 3 || comp >= 7;        // lam, pl, pu live on the n - 1 intervals: the tail repeats interval n - 2
+                    for (int k = lane; k < n; k += 64) { const int src = k + sh < n ? k + sh : n - 1; arr[k] = gsm[per_interval ? (src < n - 1 ? src : n - 2) : src]; }
                     __syncthreads();
                 }
             }

@@ -90,6 +90,8 @@ inline void fill_problem(const mpc_config& c, mpc::Problem<T>& P) {
     } else if (!c.has_Qf) {
         for (int i = 0; i < 3; ++i) P.Qf[i] = T(0);
     }
+    P.acc_tol = T(c.acceptable_tol > 0 ? c.acceptable_tol : (c.acceptable_tol < 0 ? 0.0 : 1e-6));
+    P.acc_iter = c.acceptable_iter > 0 ? c.acceptable_iter : (c.acceptable_iter < 0 ? 0 : 15);
     P.costx = (P.trapz || P.Ro != T(0)) ? 1 : 0;
     for (int i = 0; i < 3; ++i) if (P.Qo[i] != T(0) || P.Qfo[i] != T(0) || (P.ball && P.So[i] != T(0))) P.costx = 1;
 }

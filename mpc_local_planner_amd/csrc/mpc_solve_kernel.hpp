@@ -29,6 +29,7 @@ struct CandCtl {
     int32_t* rows_dropped;     // [B] clearance rows of candidate 0 that did not fit into max_obstacle_rows (NULL without obstacles)
     double* dual;              // [B][dual_words] multipliers kept between control cycles (dual_warm_start) or NULL; word 0 = grid size, 0 = nothing kept
     int dual_words;            // doubles per instance in `dual` (and appended to every candidate record)
+    int dual_read;             // this launch STARTS from the kept multipliers (dual_warm_start, or the fp64 phase of MPC_MIXED); 0: it only leaves them
 };
 constexpr int kWinIdle = 0x7f7f7f7f;
 
@@ -58,7 +59,7 @@ __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
     // a hedge whose instance already has a converged higher-priority candidate never starts
     bool run = true;
     if (NC > 1 && cand > 0) {
-        const int w = __builtin_amdgcn_readfirstlane(__hip_atomic_load(cc.win + inst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const int w = __builtin_amdgcn_readfirstlane(__hip_atomic_load(cc.win + inst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));     // a hint only: decides how much of a LOSING candidate runs, never the result
         run = !(w < cand);
     }
     int st_status = mpc::ST_SUPERSEDED, st_iters = 0;
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
         // (indexed through the LDS copy: a run-time index into the by-value kernel argument would put the arrays into scratch memory)
         const int kind = NC > 1 ? Ps->cand_kind[cand] : 0;
         if (NC > 1) { S.my_cand = cand; S.iter_cap = Ps->cand_max_iter[cand]; S.win_ptr = cand > 0 ? cc.win + inst : nullptr; }
-        if (cc.dual && cand == 0) S.dual_in = cc.dual + (long)inst * cc.dual_words;
+        if (cc.dual && cc.dual_read && cand == 0) S.dual_in = cc.dual + (long)inst * cc.dual_words;
         if (kind == 0 && x_init && u_init && dt_init) {
             // coalesced read of this instance's contiguous [n][3] / [n][2] blocks
             const double* xi = x_init + (long)inst * nmax * 3;
@@ -131,34 +132,38 @@ __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
             if (cc.dual) S.store_duals(r + 5 * nmax + 3);
         }
     }
-    // ---- exit protocol (n_cand > 1): publish, count, and let the last candidate of the instance deliver a hedge's result
-    __threadfence();
+    // ---- exit protocol (n_cand > 1): publish, count, and let the last candidate of the instance deliver a hedge's result.
+    // Hand-off of a hedge's record (and of candidate 0's outputs) from the workgroup that wrote it to the workgroup that leaves last, possibly on
+    // another XCD (own L2): RELEASE by the writer -- every lane's agent-scope release fence after its own plain stores, the workgroup barrier,
+    // then lane 0's release-ordered atomics on `win` / `exited` -- and ACQUIRE by the reader -- lane 0's acquire-ordered read-modify-write of
+    // `exited` (it reads the value the last writer released), the broadcast of its result, every lane's agent-scope acquire fence, an
+    // acquire-ordered load of `win`, then ordinary loads of the record.  No relaxed load decides what is read, no non-temporal load reads it.
+    __threadfence();                                // agent-scope fence (release side), executed by EVERY lane after its own stores
     __syncthreads();
     int last = 0;
     if (lane == 0) {
-        if (st_status == mpc::ST_CONVERGED) atomicMin(cc.win + inst, cand);
-        if (st_iters > 0) atomicAdd(cc.it_sum + inst, st_iters);
-        __threadfence();
-        last = atomicAdd(cc.exited + inst, 1) == NC - 1;
+        if (st_status == mpc::ST_CONVERGED) __hip_atomic_fetch_min(cc.win + inst, cand, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (st_iters > 0) __hip_atomic_fetch_add(cc.it_sum + inst, st_iters, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = __hip_atomic_fetch_add(cc.exited + inst, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == NC - 1;
     }
     last = __builtin_amdgcn_readfirstlane(last);
     if (!last) return;
-    __threadfence();
-    const int w = __builtin_amdgcn_readfirstlane(__hip_atomic_load(cc.win + inst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    __threadfence();                                // agent-scope fence (acquire side), every lane, before any lane reads the record
+    const int w = __builtin_amdgcn_readfirstlane(__hip_atomic_load(cc.win + inst, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT));
     if (w > 0 && w < NC) {
         const double* r = cc.rec + ((long)w * B + inst) * (5 * nmax + 3 + cc.dual_words);
         double* xo = x_out + (long)inst * nmax * 3;
         double* uo = u_out + (long)inst * nmax * 2;
-        for (int e = lane; e < 3 * nmax; e += mpc::kWave) xo[e] = __builtin_nontemporal_load(r + e);
-        for (int e = lane; e < 2 * nmax; e += mpc::kWave) uo[e] = __builtin_nontemporal_load(r + 3 * nmax + e);
+        for (int e = lane; e < 3 * nmax; e += mpc::kWave) xo[e] = r[e];
+        for (int e = lane; e < 2 * nmax; e += mpc::kWave) uo[e] = r[3 * nmax + e];
         if (cc.dual) {
             double* blk = cc.dual + (long)inst * cc.dual_words;
-            for (int e = lane; e < cc.dual_words; e += mpc::kWave) blk[e] = __builtin_nontemporal_load(r + 5 * nmax + 3 + e);
+            for (int e = lane; e < cc.dual_words; e += mpc::kWave) blk[e] = r[5 * nmax + 3 + e];
         }
         if (lane == 0) {
-            dt_out[inst] = __builtin_nontemporal_load(r + 5 * nmax);
-            if (status) status[inst] = (int32_t)__builtin_nontemporal_load(r + 5 * nmax + 1);
-            if (iters) iters[inst] = (int32_t)__builtin_nontemporal_load(r + 5 * nmax + 2);
+            dt_out[inst] = r[5 * nmax];
+            if (status) status[inst] = (int32_t)r[5 * nmax + 1];
+            if (iters) iters[inst] = (int32_t)r[5 * nmax + 2] + (iters_add ? iters_add[inst] : 0);
         }
     }
     if (lane == 0) {

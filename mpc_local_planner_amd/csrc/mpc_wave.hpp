@@ -2031,7 +2031,9 @@ struct IpmWave {
         T theta_c, fobj;
         eval_point(SCL(SC_D), theta_c, fobj);
         sync();
-        int it = 0, status = ST_MAX_ITER;
+        int it = 0, status = ST_MAX_ITER, n_acc = 0;
+        const T acc_tol = P.acc_tol;
+        const int acc_it = P.acc_iter;
         T e0 = T(0), logs_cur = T(0), dc_mu = T(-1), dc_val = T(0);
         bool have_logs = false;
 #ifdef MPC_PROFILE
@@ -2054,6 +2056,9 @@ struct IpmWave {
             e0 = err_value(er, T(0));
             if (!t_finite(e0)) { status = ST_NUMERICAL; break; }
             if (e0 <= P.tol) { status = ST_CONVERGED; break; }
+            // Ipopt's acceptable-level stop, counting half: acc_iter iterations in a row at the level acc_tol (mpc_config.acceptable_tol / _iter)
+            n_acc = (acc_it > 0 && e0 <= acc_tol) ? n_acc + 1 : 0;
+            if (acc_it > 0 && n_acc >= acc_it) { status = ST_CONVERGED; break; }
             if (it >= iter_cap) { status = ST_MAX_ITER; break; }
             if (win_ptr) {      // hedged candidate: one L2 read per iteration (all lanes, same word)
                 const int w = __builtin_amdgcn_readfirstlane(__hip_atomic_load(win_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
@@ -2167,6 +2172,10 @@ struct IpmWave {
                 printf("   ls FAILED: it %d phi0 %.12e Dm %.6e rho %.6e mu %g theta %.6e theta_c %.6e fobj %.9f logs_cur %.9f | last alpha %g f_t %.9f th_t %.6e lg_t %.9f dzmax %g a_p %g\n",
                        it, (double)phi0, (double)Dm, (double)rho, (double)mu, (double)theta, (double)theta_c, (double)fobj, (double)logs_cur, (double)alpha, (double)f_t, (double)th_t, (double)lg_t, (double)fw.dzmax, (double)fw.a_p);
 #endif
+            // Ipopt's acceptable-level stop, refused-step half (tested before the line-search failure: Ipopt answers a failed line search at an
+            // acceptable point with success): every trial step refused (or only one below 1e-6 of the fraction-to-boundary step accepted) at a point
+            // at the acceptable level: the solve ends here, nothing is moved (the next iteration would compute the same step and refuse it again)
+            if (acc_tol > T(0) && (!accepted || alpha < T(1e-6) * fw.a_p) && e0 <= acc_tol) { status = ST_CONVERGED; break; }
             if (!accepted && alpha * fw.dzmax < T(1e-14)) { status = ST_LINESEARCH; break; }
 #ifdef MPC_NANCHECK
             if (blockIdx.x == MPC_NANCHECK && lane == 0)

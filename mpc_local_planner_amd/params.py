@@ -220,6 +220,8 @@ def config_from_params(params: dict, costmap_footprint=None, **sizing):
             kw["tol"] = float(v)
         elif k == "mu_init":
             kw["mu_init"] = float(v)
+        elif k == "acceptable_tol":
+            kw["acceptable_tol"] = float(v) if float(v) > 0 else -1.0
         else:
             notes.append(f"ipopt numeric option {k} = {v}: no counterpart, ignored")
     for k, v in strings.items():
@@ -237,6 +239,8 @@ def config_from_params(params: dict, costmap_footprint=None, **sizing):
     for k, v in integers.items():
         if k == "max_iter":
             kw["max_iter"] = int(v)
+        elif k == "acceptable_iter":
+            kw["acceptable_iter"] = int(v) if int(v) > 0 else -1      # Ipopt: 0 disables the heuristic
         else:
             notes.append(f"ipopt integer option {k} = {v}: no counterpart, ignored")
     if "tol" not in kw:

@@ -25,6 +25,7 @@ class OracleConfig(C.Structure):
         ("hessian_mode", C.c_int32),
         ("hybrid", C.c_int32), ("trapezoid", C.c_int32),
         ("Qo", C.c_double * 3), ("Ro", C.c_double), ("Qfo", C.c_double * 3), ("So", C.c_double * 3),
+        ("acceptable_tol", C.c_double), ("acceptable_iter", C.c_int32),
     ]
 
 
@@ -49,8 +50,9 @@ def _load():
     return _lib
 
 
-def from_nlp_config(cfg, max_iter=100, tol=1e-8, mu_init=0.1, hessian_mode=0) -> OracleConfig:
-    """oracle.se2_nlp.OcpConfig -> OracleConfig"""
+def from_nlp_config(cfg, max_iter=100, tol=1e-8, mu_init=0.1, hessian_mode=0, acceptable_tol=0.0, acceptable_iter=0) -> OracleConfig:
+    """oracle.se2_nlp.OcpConfig -> OracleConfig.  acceptable_tol / acceptable_iter: Ipopt's acceptable-level stop (0 = its defaults 1e-6 / 15,
+    negative = off), the same fields as mpc_config's."""
     o = OracleConfig()
     o.model = cfg.model
     mp = list(cfg.model_params) + [0.0] * 4
@@ -77,6 +79,7 @@ def from_nlp_config(cfg, max_iter=100, tol=1e-8, mu_init=0.1, hessian_mode=0) ->
         o.du_lb[j], o.du_ub[j] = max(cfg.du_lb[j], -1e30), min(cfg.du_ub[j], 1e30)
     o.max_iter, o.tol, o.mu_init = max_iter, tol, mu_init
     o.hessian_mode = int(hessian_mode)
+    o.acceptable_tol, o.acceptable_iter = float(acceptable_tol), int(acceptable_iter)
     o.collocation = int(getattr(cfg, "collocation", 0))
     o.integral = int(bool(getattr(cfg, "integral_form", False)) and cfg.objective == 1)
     if getattr(cfg, "terminal_ball_S", None) is not None:
@@ -96,24 +99,6 @@ def dual_state(B: int, n: int):
     lib = _load()
     lib.oracle_dual_words.restype = C.c_int
     return np.zeros((B, int(lib.oracle_dual_words(C.c_int(n)))))
-
-
-def set_acceptable_stop(tol: float):
-    """EXPERIMENT switch of the C solver, process-wide, 0 = off (the default): stop with status 0 when the line search refuses the step at
-    a point whose error is at most `tol`.  Tests that switch it on switch it off again."""
-    lib = _load()
-    lib.oracle_set_acceptable_stop.argtypes = [C.c_double]
-    lib.oracle_set_acceptable_stop.restype = None
-    lib.oracle_set_acceptable_stop(float(tol))
-
-
-def set_acceptable_iter(k: int):
-    """Second experiment switch (0 = off): status 0 after `k` iterations in a row with an error of at most the tolerance given to
-    `set_acceptable_stop` (Ipopt's acceptable_iter, 15 there)."""
-    lib = _load()
-    lib.oracle_set_acceptable_iter.argtypes = [C.c_int]
-    lib.oracle_set_acceptable_iter.restype = None
-    lib.oracle_set_acceptable_iter(int(k))
 
 
 def num_threads() -> int:

@@ -623,11 +623,14 @@ class IpmOptions:
     filter_cap: int = 16
     mu_strategy: str = "monotone"
     kappa_c: float = 0.25
-    # EXPERIMENT, off by default (not in the C solver, not in the kernel): when the line search refuses
-    # every trial step (or accepts only one shorter than 1e-6 of the fraction-to-boundary step) at a point whose error is at most `acceptable_tol`, stop there with status 0 instead of taking the shortest trial
-    # step with a full multiplier step -- Ipopt's "solved to acceptable level" / tiny-step stop, which the reference counts as success.
-    acceptable_stop: bool = False
+    # Ipopt's "solved to acceptable level", which the reference's wrapper counts as success (src/controller.cpp:388-421 configures SolverIpopt; corbo
+    # reports success for Converged and EarlyTerminated alike).  Two halves, both at the level `acceptable_tol` (Ipopt default 1e-6; <= 0 = off):
+    #   * `acceptable_iter` iterations in a row (Ipopt default 15; <= 0 = off) with an error of at most the level end the solve with status 0;
+    #   * when the line search refuses every trial step, or accepts only one shorter than 1e-6 of the fraction-to-boundary step, at a point at that
+    #     level, the solve ends THERE (neither the point nor the multipliers move) with status 0 instead of taking the shortest trial step.
+    # Same rule, same defaults in oracle/mpc_oracle.c (oracle_config.acceptable_tol / _iter) and in the kernel (mpc_config.acceptable_tol / _iter).
     acceptable_tol: float = 1e-6
+    acceptable_iter: int = 15
     verbose: bool = False
 
 
@@ -726,6 +729,7 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
     history = []
     status = 1
     it = 0
+    n_acceptable = 0
 
     def kkt_err(ev, v, s, lam, y, piL, piU, mu_t):
         rd = ev["gf"] + ev["Jc"].T @ lam + ev["Jg"].T @ y - piL + piU
@@ -757,6 +761,11 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
         if e0 <= opt.tol:
             status = 0
             break
+        if opt.acceptable_iter > 0 and opt.acceptable_tol > 0:
+            n_acceptable = n_acceptable + 1 if e0 <= opt.acceptable_tol else 0
+            if n_acceptable >= opt.acceptable_iter:
+                status = 0
+                break
         # barrier update
         if opt.mu_strategy == "monotone":
             while True:
@@ -934,14 +943,15 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
                 # no restoration phase: clear the filter and take the shortest trial step
                 filt.clear()
                 nrest += 1
+        if opt.acceptable_tol > 0 and (not accepted or alpha < 1e-6 * a_p) and e0 <= opt.acceptable_tol:
+            # nothing is moved (neither the point nor the multipliers): the next iteration would compute the same step and refuse it again.
+            # Tested before the line-search failure: Ipopt answers a failed line search at an acceptable point with success.
+            status = 0
+            break
         if not accepted:
             if alpha * np.abs(dz).max() < 1e-14:
                 status = 2
                 break
-        if opt.acceptable_stop and (not accepted or alpha < 1e-6 * a_p) and e0 <= opt.acceptable_tol:
-            # nothing is moved (neither the point nor the multipliers): the next iteration would compute the same step and refuse it again
-            status = 0
-            break
         v, s = vt, st
         lam = lam + alpha * (lam_new - lam)
         y = y + a_d * dy

@@ -75,7 +75,13 @@ typedef struct oracle_config {
                                  * 0.5 dt (l(x_k, u_k) + l(x_{k+1}, u_k)) per interval */
     double Qo[3], Ro, Qfo[3], So[3];   /* off-diagonal terms (01, 02, 12) of the symmetric parts of the full weight matrices (src/controller.cpp:565-573,
                                         * 580-588, 656-664, 690-698); Q / R / Qf / ball_S hold the diagonals */
+    double acceptable_tol;      /* Ipopt's "solved to acceptable level", which the reference's wrapper counts as success (src/controller.cpp:388-421 configures
+                                 * SolverIpopt; corbo: success iff Converged or EarlyTerminated): 0 -> Ipopt's default 1e-6, < 0 -> rule off.  Same meaning
+                                 * as mpc_config.acceptable_tol (include/mpc_hip.h) */
+    int32_t acceptable_iter;    /* iterations in a row at that level that end the solve with status 0: 0 -> Ipopt's default 15, < 0 -> off */
 } oracle_config;
+static inline double acc_tol_of(const oracle_config* c) { return c->acceptable_tol > 0 ? c->acceptable_tol : (c->acceptable_tol < 0 ? 0.0 : 1e-6); }
+static inline int acc_iter_of(const oracle_config* c) { return c->acceptable_iter > 0 ? c->acceptable_iter : (c->acceptable_iter < 0 ? 0 : 15); }
 
 #define MINTIME(c) ((c)->objective == 0 || (c)->hybrid)
 /* y = W x for the symmetric 3 x 3 matrix with diagonal d and off-diagonal terms o = (01, 02, 12) */
@@ -989,15 +995,6 @@ static void ftb(double val, double dval, double tau, double* alpha) { if (dval <
 static long g_nfac_total = 0;
 static int g_nfac_max = 0;
 void oracle_set_variant(int v) { g_variant = v; g_nfac_total = 0; g_nfac_max = 0; }
-/* EXPERIMENT, off (0) unless a test switches it on (same rule as IpmOptions.acceptable_stop of ipm_dense.py, not in the
- * kernel): when the line search refuses every trial step, or accepts only one below 1e-6 of the fraction-to-boundary step, at a point whose error is at
- * most this tolerance, the solve ends there with status 0 -- Ipopt's "solved to acceptable level", which the reference counts as success. */
-static double g_acceptable_tol = 0.0;
-void oracle_set_acceptable_stop(double tol) { g_acceptable_tol = tol; }
-/* second half of Ipopt's rule, also an experiment switch (0 = off): status 0 after this many iterations in a row with an error of at most
- * g_acceptable_tol (Ipopt: acceptable_iter = 15) */
-static int g_acceptable_iter = 0;
-void oracle_set_acceptable_iter(int k) { g_acceptable_iter = k; }
 long oracle_nfac_total(void) { return g_nfac_total; }
 int oracle_nfac_max(void) { return g_nfac_max; }
 
@@ -1104,6 +1101,8 @@ static int solve_one(work_t* w, int warm) {
     }
     double fobj;
     int n_acceptable = 0;
+    const double acc_tol = acc_tol_of(c);
+    const int acc_it = acc_iter_of(c);
     eval_point(w, w->X, w->U, w->D, cc, &fobj);
     while (1) {
         err_t e;
@@ -1111,9 +1110,10 @@ static int solve_one(work_t* w, int warm) {
         double e0 = err_value(&e, 0.0);
         if (!isfinite(e0)) { status = 4; break; }
         if (e0 <= tol) { status = 0; break; }
-        if (g_acceptable_iter > 0 && g_acceptable_tol > 0) {
-            n_acceptable = e0 <= g_acceptable_tol ? n_acceptable + 1 : 0;
-            if (n_acceptable >= g_acceptable_iter) { status = 0; break; }
+        /* Ipopt's acceptable-level stop, first half: acceptable_iter iterations in a row with an error of at most acceptable_tol */
+        if (acc_it > 0 && acc_tol > 0) {
+            n_acceptable = e0 <= acc_tol ? n_acceptable + 1 : 0;
+            if (n_acceptable >= acc_it) { status = 0; break; }
         }
         if (it >= max_iter) { status = 1; break; }
         for (int g = 0; g < 50; ++g) {
@@ -1286,8 +1286,10 @@ static int solve_one(work_t* w, int warm) {
             double phit = ft - mu * (barrier_logs(w, w->Ut, w->Dt, st, w->ost) + tlog) + w->rho * tht;
             if (isfinite(phit) && phit - phi0 - 10 * 2.220446049250313e-16 * fabs(phi0) <= eta * alpha * Dm) { accepted = 1; break; }
         }
+        /* second half (tested BEFORE the line-search failure below: Ipopt answers a failed line search at an acceptable point with success): the line search refuses every trial step, or accepts only one below 1e-6 of the fraction-to-boundary step, at a point whose
+         * error is at most acceptable_tol -> the solve ends THERE (nothing is moved) with status 0 */
+        if (acc_tol > 0 && (!accepted || alpha < 1e-6 * a_p) && e0 <= acc_tol) { status = 0; break; }
         if (!accepted && alpha * dzmax < 1e-14) { status = 2; break; }
-        if (g_acceptable_tol > 0 && (!accepted || alpha < 1e-6 * a_p) && e0 <= g_acceptable_tol) { status = 0; break; }
         /* accept */
         const double kS = 1e10;
         for (int r = 0; r < n; ++r) for (int q = 0; q < 4; ++q) if (row_on(w, r, q)) {

@@ -2,11 +2,13 @@
 import numpy as np
 
 
-def account(tag, ocfg, inputs, r, oracle_out, tol=1e-4, obstacles=None, max_rows=None, kkt_tol=1e-6):
+def account(tag, ocfg, inputs, r, oracle_out, tol=1e-4, obstacles=None, max_rows=None, kkt_tol=1e-6, min_match=0.7):
     """Every converged device instance is either within `tol` of the C oracle's result (same KKT point: 'match') or is shown to be a
     KKT point of the reference-form NLP on its own (oracle/kkt_check.py: feasibility, stationarity and complementarity <= kkt_tol;
     'other_kkt': a line-search tie or a regularisation decision flipped and the iterate sequences parted ways, or another candidate
     initial trajectory won).  Prints the counts and the objective differences, asserts that nothing is left unclassified.
+    A floor on the matching share keeps the test meaningful (a device that never agreed with the oracle but only produced KKT points would pass the
+    classification alone): of the instances that converged on BOTH sides at least `min_match` must match.
     Returns (match mask, list of other_kkt indices)."""
     from oracle import kkt_check as KC
     x0, xf, up, dtp = inputs
@@ -28,4 +30,6 @@ def account(tag, ocfg, inputs, r, oracle_out, tol=1e-4, obstacles=None, max_rows
           + (f", min {min(dobj):+.3e}, median {np.median(dobj):+.3e}, max {max(dobj):+.3e}" if dobj else "")
           + f"; worst other_kkt feas/stat/comp = {max([res[i]['feas'] for i in other], default=0):.1e}/{max([res[i]['stat'] for i in other], default=0):.1e}/{max([res[i]['comp'] for i in other], default=0):.1e}")
     assert not bad, [(int(i), res[i]) for i in bad[:5]]
+    both = int((conv & (st == 0)).sum())
+    assert both == 0 or match.sum() >= min_match * both, (tag, int(match.sum()), both, min_match)
     return match, other

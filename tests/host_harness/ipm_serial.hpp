@@ -691,7 +691,7 @@ struct Ipm {
         T theta_c, fobj, cinf;
         eval_point(L.X, L.U, L.D, L.TRIG, L.CC, theta_c, fobj, cinf);
 
-        int it = 0;
+        int it = 0, n_acc = 0;
         int status = ST_MAX_ITER;
         T e0 = T(0);
         while (true) {
@@ -699,6 +699,8 @@ struct Ipm {
             e0 = err_value(er, T(0));
             if (!t_finite(e0)) { status = ST_NUMERICAL; break; }
             if (e0 <= P.tol) { status = ST_CONVERGED; break; }
+            n_acc = (P.acc_iter > 0 && e0 <= P.acc_tol) ? n_acc + 1 : 0;       // Ipopt's acceptable-level stop (counting half), as mpc_wave.hpp
+            if (P.acc_iter > 0 && n_acc >= P.acc_iter) { status = ST_CONVERGED; break; }
             if (it >= P.max_iter) { status = ST_MAX_ITER; break; }
             // monotone barrier update (Waechter & Biegler eq. 7)
             for (int guard = 0; guard < 50; ++guard) {
@@ -756,6 +758,11 @@ struct Ipm {
                 T phit = f_t - mu * barrier_logs(L.UT, L.DT, alpha, true) + rho * tht;
                 // round-off relaxed Armijo test (Waechter & Biegler 2006, sec. 3.3: 10*eps_mach*|phi|)
                 if (t_finite(phit) && phit - phi0 - Algo<T>::ls_eps * t_abs(phi0) <= Algo<T>::eta_armijo * alpha * Dm) { accepted = true; break; }
+            }
+            if (P.acc_tol > T(0) && (!accepted || alpha < T(1e-6) * fw.a_p) && e0 <= P.acc_tol) {      // refused-step half of the acceptable-level stop
+                eval_point(L.X, L.U, L.D, L.TRIG, L.CC, theta_c, fobj, cinf);
+                status = ST_CONVERGED;
+                break;
             }
             if (!accepted && alpha * fw.dzmax < T(1e-14)) {
                 // restore caches of the current point before leaving

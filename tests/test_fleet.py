@@ -1,4 +1,4 @@
-"""FleetPlanner (mpc_local_planner_amd/fleet.py): computeVelocityCommands for a batch of robots, held to recorded runs of the REFERENCE's plugin (the reference's plugin source +
+"""FleetPlanner (examples/fleet.py): computeVelocityCommands for a batch of robots, held to recorded runs of the REFERENCE's plugin (the reference's plugin source +
 the reference's own Controller, the C oracle's solve plugged in: tests/golden/ref_plugin_closed_loop_*.npz, generator tests/golden/make_ref_vectors.py).  Here the solver behind the
 fleet is the CPU stand-in of tests/golden/fleet_oracle_backend.py (the same C oracle); tests/test_gpu_fleet.py runs the same script on the real BatchSolver."""
 import json
@@ -10,6 +10,7 @@ import pytest
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.join(HERE, "golden"))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "examples"))
 # the last two: a run to the goal of a short plan (the grid shrinks to 4 points, one solve fails on the way, then the goal is reported), and a block 0.42 m beside the path
 # (clearance rows at work, one failed solve): the device fails in the same cycles as the C oracle behind the recordings
 LOOPS = ["carlike_line_footprint", "via_points_polygon_footprint", "diff_drive_quadratic_form", "carlike_to_the_goal", "carlike_block_close_to_the_path"]
@@ -18,7 +19,7 @@ LOOPS_CPU = LOOPS
 
 def replay(loop, make_solver, batch_layout, tol):
     """batch_layout: for every robot of the batch the cycle at which it gets its plan (None: never).  Every robot replays the recorded poses from its own start."""
-    from mpc_local_planner_amd.fleet import FleetPlanner
+    from fleet import FleetPlanner      # examples/fleet.py
     rec = np.load(os.path.join(HERE, "golden", f"ref_plugin_closed_loop_{loop}.npz"))
     prm = json.load(open(os.path.join(HERE, "golden", f"ref_plugin_closed_loop_{loop}.json")))
     B = len(batch_layout)
@@ -75,7 +76,7 @@ def test_fleet_cycle_reproduces_the_recorded_runs_of_the_reference_plugin(loop):
 def test_fleet_grid_helpers_reproduce_the_reference_grid_bit_for_bit():
     """the per-robot grid handling inside fleet.py (resample, warm_start_shift, initial_state_trajectory / TimeSeriesSE2 interpolation) against the recorded outputs of the
     reference's grid class and time series (tests/golden/ref_grid.npz, oracle/ref_wrap_grid.cpp)"""
-    from mpc_local_planner_amd import fleet as F
+    import fleet as F      # examples/fleet.py
     GR = np.load(os.path.join(HERE, "golden", "ref_grid.npz"))
     for i in range(GR["n"].shape[0]):
         n, nn = int(GR["n"][i]), int(GR["n_new"][i])
@@ -130,7 +131,7 @@ def test_fleet_bookkeeping_extra_obstacles_failures_and_infeasible_plans():
     """what step() does around the solve: obstacles the caller adds go behind the costmap's cells; a failed solve or an infeasible trajectory gives NO_VALID_CMD, a zero
     command and a fresh start next cycle (the plugin's _controller.reset()); the previous control handed to the next solve is the first control of the last series, with
     dt = 1 / controller_frequency; a robot at its goal is not planned for"""
-    from mpc_local_planner_amd.fleet import FleetPlanner, NO_VALID_CMD, SUCCESS
+    from fleet import FleetPlanner, NO_VALID_CMD, SUCCESS      # examples/fleet.py
     from mpc_local_planner_amd import plugin_inputs as PI
     prm = json.load(open(os.path.join(HERE, "golden", "ref_plugin_closed_loop_carlike_line_footprint.json")))
     B = 4

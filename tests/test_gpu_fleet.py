@@ -18,7 +18,7 @@ def test_fleet_of_64_robots_in_closed_loop():
     two batched solves (outer iterations) and one feasibility-check launch for the whole fleet"""
     import json, os, time
     import numpy as np
-    from mpc_local_planner_amd.fleet import FleetPlanner
+    from fleet import FleetPlanner      # examples/fleet.py
     here = os.path.dirname(os.path.abspath(__file__))
     prm = json.load(open(os.path.join(here, "golden", "ref_plugin_closed_loop_carlike_line_footprint.json")))
     B, res = 64, 0.1

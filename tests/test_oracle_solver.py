@@ -577,16 +577,16 @@ def test_cost_variants_independent_sqp_from_the_cold_start(name, c_oracle):
         assert abs(r.fun - nlp.objective(nlp.pack(R.Trajectory(xo[i], uo[i][:ocfg.n - 1], float(do[i]))))) < 1e-6 * max(1.0, abs(r.fun))
 
 
-def test_near_goal_stall_and_the_experimental_acceptable_level_stop():
-    """a 4-point grid 0.27 m in front of the goal (a cycle of the recorded `carlike_to_the_goal` run).
-    With tol 1e-8 the solve stands at 1.2e-8 after 15 iterations, the line search refuses what follows and the solve ends at max_iter;
-    at tol 1e-6 it converges; the opt-in stop of the numpy solver (not in the C solver, not in the kernel: an experiment for the next
-    round) ends at that 15th iterate with status 0, and the three answers agree to 2e-6."""
+def test_near_goal_stall_and_the_acceptable_level_stop():
+    """A 4-point grid 0.27 m in front of the goal (a cycle of the `carlike_to_the_goal` closed loop of the reference's plugin).  With tol 1e-8 and
+    WITHOUT Ipopt's acceptable-level stop the solve stands at 1.2e-8 after 15 iterations, the line search refuses what follows and the solve ends
+    at max_iter; at tol 1e-6 it converges; with the stop (the default of all three solvers: IpmOptions.acceptable_tol / oracle_config / mpc_config)
+    it ends at that 15th iterate with status 0, and the three answers agree to 2e-6."""
     cfg = R.config_carlike_min_time(4)
     inp = R.CycleInputs(x0=np.array([1.836, 0.676, 0.366]), xf=np.array([2.087, 0.769, 0.2927]), u_prev=np.array([0.4, 0.0]), dt_prev=0.1)
-    stalled = _ipm(cfg, inp)
+    stalled = _ipm(cfg, inp, acceptable_tol=0.0)
     loose = _ipm(cfg, inp, tol=1e-6)
-    stopped = _ipm(cfg, inp, acceptable_stop=True)
+    stopped = _ipm(cfg, inp)
     # the stall sits at the rounding level of the merit function: on this container's BLAS it is there (status 1 after 100 iterations); the C solver's
     # test below, whose arithmetic does not depend on the machine, is the one that insists on it
     assert stalled.status in (0, 1) and stalled.kkt_error < 1e-5
@@ -598,36 +598,32 @@ def test_near_goal_stall_and_the_experimental_acceptable_level_stop():
         assert np.abs(stopped.traj.x - other.traj.x).max() < 2e-6
         assert np.abs(stopped.traj.u - other.traj.u).max() < 2e-6
         assert abs(stopped.traj.dt - other.traj.dt) < 2e-6
-    # off by default: the goldens and the parity suites are not touched by the experiment
-    assert I.IpmOptions().acceptable_stop is False
+    # Ipopt's defaults
+    assert I.IpmOptions().acceptable_tol == 1e-6 and I.IpmOptions().acceptable_iter == 15
 
 
-def test_near_goal_stall_in_the_c_solver_and_its_experimental_stop(c_oracle):
-    """The same instance in the C solver: max_iter by default, 15 iterations with the process-wide experiment switch, same point as numpy."""
+def test_near_goal_stall_in_the_c_solver_and_its_acceptable_level_stop(c_oracle):
+    """The same instance in the C solver: max_iter with the rule switched off (acceptable_tol < 0), 15 iterations with it (the default), same point
+    as numpy; and the headline workload is untouched by the rule: bit-identical trajectories, statuses and iteration counts on 256 cold starts."""
     cfg = R.config_carlike_min_time(4)
     x0, xf = np.array([[1.836, 0.676, 0.366]]), np.array([[2.087, 0.769, 0.2927]])
     up, dtp = np.array([[0.4, 0.0]]), np.array([0.1])
-    oc = c_oracle.from_nlp_config(cfg, max_iter=100, tol=1e-8)
-    ref = _ipm(cfg, R.CycleInputs(x0=x0[0], xf=xf[0], u_prev=up[0], dt_prev=0.1), acceptable_stop=True)
-    r = c_oracle.solve_batch(oc, x0, xf, up, dtp, nthreads=1)
+    off = c_oracle.from_nlp_config(cfg, max_iter=100, tol=1e-8, acceptable_tol=-1.0)
+    on = c_oracle.from_nlp_config(cfg, max_iter=100, tol=1e-8)
+    ref = _ipm(cfg, R.CycleInputs(x0=x0[0], xf=xf[0], u_prev=up[0], dt_prev=0.1))
+    r = c_oracle.solve_batch(off, x0, xf, up, dtp, nthreads=1)
     assert r[3][0] == 1 and r[4][0] == 100
-    c_oracle.set_acceptable_stop(1e-6)
-    try:
-        r = c_oracle.solve_batch(oc, x0, xf, up, dtp, nthreads=1)
-    finally:
-        c_oracle.set_acceptable_stop(0.0)
+    r = c_oracle.solve_batch(on, x0, xf, up, dtp, nthreads=1)
     assert r[3][0] == 0 and r[4][0] == ref.iters
     assert np.abs(r[0][0] - ref.traj.x).max() < 1e-7 and np.abs(r[1][0][:3] - ref.traj.u).max() < 1e-7 and abs(r[2][0] - ref.traj.dt) < 1e-7
-    # and off again
-    r = c_oracle.solve_batch(oc, x0, xf, up, dtp, nthreads=1)
-    assert r[3][0] == 1
-    # the other half of Ipopt's rule (k iterations in a row at the acceptable level) is a second switch; both on, level 1e-5, k = 15:
-    # the run ends early, by whichever rule fires first
-    c_oracle.set_acceptable_stop(1e-5)
-    c_oracle.set_acceptable_iter(15)
-    try:
-        r = c_oracle.solve_batch(oc, x0, xf, up, dtp, nthreads=1)
-    finally:
-        c_oracle.set_acceptable_stop(0.0)
-        c_oracle.set_acceptable_iter(0)
+    # a looser level with the counting half: the run ends early, by whichever rule fires first
+    r = c_oracle.solve_batch(c_oracle.from_nlp_config(cfg, max_iter=100, tol=1e-8, acceptable_tol=1e-5, acceptable_iter=15), x0, xf, up, dtp, nthreads=1)
     assert r[3][0] == 0 and r[4][0] <= 30
+    # headline workload (config 2): the rule changes nothing
+    from mpc_local_planner_amd import workloads as W
+    cfg2 = R.config_carlike_min_time(50)
+    w = W.carlike_min_time_inputs(256)
+    a = c_oracle.solve_batch(c_oracle.from_nlp_config(cfg2, max_iter=100, tol=1e-8, acceptable_tol=-1.0), *w)
+    b = c_oracle.solve_batch(c_oracle.from_nlp_config(cfg2, max_iter=100, tol=1e-8), *w)
+    for i in range(5):
+        assert np.array_equal(a[i], b[i])
