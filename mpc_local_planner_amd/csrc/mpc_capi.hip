@@ -171,8 +171,10 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
     s->cfg = *cfg;
     mpc::fill_problem<double>(*cfg, s->P64);
     mpc::fill_problem<float>(*cfg, s->P32);
+    if (const char* e = getenv("MPC_NO_PIT")) { if (e[0] == '1') { s->P64.pit = 0; s->P32.pit = 0; } }      // developer switch: serial sweeps only (A/B measurements)
+    if (const char* e = getenv("MPC_PIT_MU")) { s->P64.pit_mu_min = atof(e); s->P32.pit_mu_min = (float)atof(e); }      // developer switch: threshold of the partitioned sweeps
     if (cfg->precision == MPC_MIXED) {
-        s->P32.tol = 1e-4f;                                  // phase 1 stops where fp32 residuals stop making sense
+        s->P32.tol = 1e-4f; s->P32.pit_mu_min = 1e-4f;        // phase 1 stops where fp32 residuals stop making sense
         s->P64.n_cand = 1;                                   // phase 2 refines the winner
         if (!(cfg->mu_init_dual > 0)) s->P64.mu_init_dual = 1e-5;      // phase 1 ended at a barrier of ~1e-5
         s->P64.mu_init_warm = 1e-3;                          // instances phase 1 did not converge start phase 2 from its last iterate

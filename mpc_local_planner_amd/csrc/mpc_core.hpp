@@ -90,6 +90,8 @@ struct Problem {
     // Ipopt's acceptable-level stop (mpc_config.acceptable_tol / acceptable_iter): level (0 = rule off) and iterations in a row (0 = counting half off)
     T acc_tol;
     int acc_iter;
+    T pit_mu_min;        // ... while the barrier parameter is above this (the last iterations of a solve take the serial sweeps: see DESIGN.md)
+    int pit;             // partitioned (parallel-in-time) sweeps for grids of 40 points and more (1; 0 = the serial sweeps everywhere: developer switch MPC_NO_PIT)
 };
 
 // Algorithm constants (Waechter & Biegler 2006 names).  Compile-time so that they live in

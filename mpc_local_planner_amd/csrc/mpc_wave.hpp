@@ -33,12 +33,14 @@ constexpr int kWave = 64;
 constexpr int RA = 12;     // first A slot (words 0..11: a0 a1 1 | f | Bx[:,0] | Bx[:,1])
 constexpr int NSTG_EXT = RA + NADD;         // 43: record of the kernel instantiation with the extra coupling slots (A02 A12 A05 A15)
 constexpr int NSTG_BASE = RA + NADD_BASE;   // 39: record of the headline kernel (odd strides: conflict-free for lane == stage)
-constexpr int NGAIN = 20;  // negated gains: nK0(6) nkappa0 nKnu0(3) | nK1(6) nkappa1 nKnu1(3)
+constexpr int NGAIN = 24;  // negated gains: nK0(6) nkappa0 nKnu0(5) | nK1(6) nkappa1 nKnu1(5)   (5 border columns: the partitioned sweep's segments end in the
+                           // costate of (x, u_prev); the serial sweep and the last segment use the first 3 = the fixed goal components)
+constexpr int NGH = NGAIN / 2;
 
 struct WaveLayout {
     int n, NS;
     int NTR;                                      // trig-cache words per stage (3, or 4 for the bicycle / front-wheel car; +2 for Crank-Nicolson)
-    int X, U, LAM, LAMN, SR, YR, PL, PU, DX, DU, CC, TRIG, GAIN, STG, SC, VP, ZC, total;
+    int X, U, LAM, LAMN, SR, YR, PL, PU, DX, DU, CC, TRIG, GAIN, STG, SC, VP, ZC, ZI, total;
     int M, O, V;                                  // clearance rows per grid point, obstacles, vertices per obstacle
     int OS, OY, OI, OG, OAX, OAY, OHK;            // per-row slack, multiplier, obstacle index, cached g, gradient, curvature
     int GV, GNV, GR, GC;                          // obstacle geometry: vertices, vertex counts, radii, centroids
@@ -64,6 +66,7 @@ struct WaveLayout {
         L.SC = o; o += 16;    // scalars: D, DT, DD, PDL, PDU | terminal-ball row: slack, multiplier, cached value and gradient
         L.VP = o; o += 16;    // dummy store targets of the idle lanes in the sweeps
         L.ZC = o; o += 8;     // constants 0 0 0 0 1 0 0 0 (coefficient triples of the constant columns)
+        L.ZI = o; o += 12;    // constants 0 0 0 0 0 0 1 0 0 0 0 0: the unit vector e_c (6 words) starts at ZI + 6 - c, six zeros at ZI (partitioned sweep)
         L.M = M; L.O = O; L.V = V;
         L.OS = take(M); L.OY = take(M); L.OI = take(M); L.OG = take(M); L.OAX = take(M); L.OAY = take(M); L.OHK = take(M);
         L.GV = o; o += 2 * O * V; L.GNV = o; o += O; L.GR = o; o += O; L.GC = o; o += 2 * O;
@@ -1171,6 +1174,60 @@ struct IpmWave {
     }
 
     // ---------------------------------------------------------------- backward Riccati sweep
+    // terminal value function of the backward sweeps (serial and partitioned), straight into the owning lanes' registers: column c of [P | p | S];
+    // a3 / a4 / a5 = this lane's entries of the rows 3..5 of the final rate rows' record (stage n-1: the A slots (i, c) for c in {3, 4, 5, 8})
+    __device__ __forceinline__ void terminal_value(T (&V)[6], const int c, const T delta, const T d, const T a3, const T a4, const T a5) const {
+        const int n = L.n;
+        // condensed terminal l2-ball row: + sigma a a' + 2 y S on the final-state block, + a ybar on its gradient
+        T tsig = T(0), tyb = T(0), ty = T(0), ta[3] = {T(0), T(0), T(0)};
+        if (ball()) {
+            const T ts = SCL(SC_TS), tg = SCL(SC_TG);
+            ty = SCL(SC_TY);
+            tsig = ty / ts; tyb = mu / ts + tsig * (tg + ts);
+            ta[0] = SCL(SC_TA); ta[1] = SCL(SC_TA + 1); ta[2] = SCL(SC_TA + 2);
+        }
+        const T tac = c < 3 ? (c == 0 ? ta[0] : (c == 1 ? ta[1] : ta[2])) : T(0);
+        // cost variants: off-diagonal terminal weights (Qf, S) and the trapezoid term 0.5 dt xd' Q xd of the final state (x-x, x-dt, gradients)
+        T xdT[3] = {T(0), T(0), T(0)}, qT[3] = {T(0), T(0), T(0)};       // qT = Q xd_T (full) when the trapezoid term exists
+        if (costx()) { xd_final(T(0), xdT); if (P.trapz) { offmul(P.Qo, xdT, qT); for (int i = 0; i < 3; ++i) qT[i] += P.Q[i] * xdT[i]; } }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            if (fx(i)) V[i] = c == 9 + i ? T(1) : T(0);
+            else {
+                T pii = delta, pi_ = T(0);
+                if (hasqf()) {
+                    T xd = F(L.X, i, n - 1) - xf[i];
+                    if (i == 2) xd = normalize_theta(xd);
+                    pii += T(2) * P.Qf[i]; pi_ = T(2) * P.Qf[i] * xd;
+                }
+                if (ball()) { pii += T(2) * ty * P.ball_S[i]; pi_ += ta[i] * tyb; }
+                V[i] = c == i ? pii : (c == 8 ? pi_ : T(0));
+                if (ball() && c < 3) V[i] += tsig * ta[i] * tac;       // a of a fixed component is 0
+                if (costx()) {
+                    if (c < 3 && !fx(c)) {         // Hessian entry (i, c) over the free final components
+                        const int oi = i + c - 1;  // (0,1) -> 0, (0,2) -> 1, (1,2) -> 2
+                        if (c != i) { if (hasqf()) V[i] += T(2) * P.Qfo[oi]; if (ball()) V[i] += T(2) * ty * P.So[oi]; if (P.trapz) V[i] += d * P.Qo[oi]; }
+                        else if (P.trapz) V[i] += d * P.Q[i];
+                    }
+                    if (c == 8) {
+                        T y3[3];
+                        if (hasqf()) { offmul(P.Qfo, xdT, y3); V[i] += T(2) * y3[i]; }
+                        if (P.trapz) V[i] += d * qT[i];
+                    }
+                    if (c == 5 && P.trapz) V[i] += qT[i];
+                }
+            }
+        }
+        {
+            const bool t3 = c == 3 || c == 5 || c == 8, t4 = c == 4 || c == 5 || c == 8, t5 = c == 3 || c == 4 || c == 5 || c == 8;
+            V[3] = t3 ? a3 : T(0); V[4] = t4 ? a4 : T(0); V[5] = t5 ? a5 : T(0);
+            if (costx() && P.trapz) {
+                if (c < 3 && !fx(c)) V[5] += c == 0 ? qT[0] : (c == 1 ? qT[1] : qT[2]);
+                if (c == 8) V[5] += T(0.5) * (xdT[0] * qT[0] + xdT[1] * qT[1] + xdT[2] * qT[2]);
+            }
+        }
+    }
+
     __device__ __forceinline__ T fast_rcp(double x) const {
         double r = __builtin_amdgcn_rcp(x);
         r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
@@ -1237,7 +1294,7 @@ struct IpmWave {
         const T E3 = c == 6 ? T(1) : T(0), E4 = c == 7 ? T(1) : T(0);     // the u columns pick up the u_prev columns of V+
         const T dA0 = c == 0 ? delta : T(0), dA1 = c == 1 ? delta : T(0), dA2 = c == 2 ? delta : T(0);   // x diagonal, k >= 1
         const T dA6 = c == 6 ? delta : T(0), dA7 = c == 7 ? delta : T(0);                                 // u diagonal
-        // negated gains go to GAIN as [nK0 (cols 0..5) | nkappa0 | nKnu0 (3) | nK1 ... ] : g1 = g0 + 10; idle lanes hit a dummy pair
+        // negated gains go to GAIN as [nK0 (cols 0..5) | nkappa0 | nKnu0 (3 of 5) | nK1 ... ] : g1 = g0 + NGH; idle lanes hit a dummy pair
         const bool wrG = lane < 12 && c != 6 && c != 7;
         const int g0 = c < 6 ? c : (c == 8 ? 6 : 7 + (c - 9));
         LdsT* kp = lds(wrG ? L.GAIN + g0 + (n - 2) * NGAIN : L.VP);      // idle lanes: dummy pair in the scratch area
@@ -1245,55 +1302,7 @@ struct IpmWave {
         // ---- terminal value function, straight into the owning lanes' registers (rows 3..5: the u_prev / dt entries of the
         //      final rate rows = the A slots (i, c) of stage n-1 for c in {3, 4, 5, 8})
         T V[6];
-        // condensed terminal l2-ball row: + sigma a a' + 2 y S on the final-state block, + a ybar on its gradient
-        T tsig = T(0), tyb = T(0), ty = T(0), ta[3] = {T(0), T(0), T(0)};
-        if (ball()) {
-            const T ts = SCL(SC_TS), tg = SCL(SC_TG);
-            ty = SCL(SC_TY);
-            tsig = ty / ts; tyb = mu / ts + tsig * (tg + ts);
-            ta[0] = SCL(SC_TA); ta[1] = SCL(SC_TA + 1); ta[2] = SCL(SC_TA + 2);
-        }
-        const T tac = c < 3 ? (c == 0 ? ta[0] : (c == 1 ? ta[1] : ta[2])) : T(0);
-        // cost variants: off-diagonal terminal weights (Qf, S) and the trapezoid term 0.5 dt xd' Q xd of the final state (x-x, x-dt, gradients)
-        T xdT[3] = {T(0), T(0), T(0)}, qT[3] = {T(0), T(0), T(0)};       // qT = Q xd_T (full) when the trapezoid term exists
-        if (costx()) { xd_final(T(0), xdT); if (P.trapz) { offmul(P.Qo, xdT, qT); for (int i = 0; i < 3; ++i) qT[i] += P.Q[i] * xdT[i]; } }
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            if (fx(i)) V[i] = c == 9 + i ? T(1) : T(0);
-            else {
-                T pii = delta, pi_ = T(0);
-                if (hasqf()) {
-                    T xd = F(L.X, i, n - 1) - xf[i];
-                    if (i == 2) xd = normalize_theta(xd);
-                    pii += T(2) * P.Qf[i]; pi_ = T(2) * P.Qf[i] * xd;
-                }
-                if (ball()) { pii += T(2) * ty * P.ball_S[i]; pi_ += ta[i] * tyb; }
-                V[i] = c == i ? pii : (c == 8 ? pi_ : T(0));
-                if (ball() && c < 3) V[i] += tsig * ta[i] * tac;       // a of a fixed component is 0
-                if (costx()) {
-                    if (c < 3 && !fx(c)) {         // Hessian entry (i, c) over the free final components
-                        const int oi = i + c - 1;  // (0,1) -> 0, (0,2) -> 1, (1,2) -> 2
-                        if (c != i) { if (hasqf()) V[i] += T(2) * P.Qfo[oi]; if (ball()) V[i] += T(2) * ty * P.So[oi]; if (P.trapz) V[i] += d * P.Qo[oi]; }
-                        else if (P.trapz) V[i] += d * P.Q[i];
-                    }
-                    if (c == 8) {
-                        T y3[3];
-                        if (hasqf()) { offmul(P.Qfo, xdT, y3); V[i] += T(2) * y3[i]; }
-                        if (P.trapz) V[i] += d * qT[i];
-                    }
-                    if (c == 5 && P.trapz) V[i] += qT[i];
-                }
-            }
-        }
-        {
-            const bool t3 = c == 3 || c == 5 || c == 8, t4 = c == 4 || c == 5 || c == 8, t5 = c == 3 || c == 4 || c == 5 || c == 8;
-            const T a3 = ap[3][as_[3]], a4 = ap[4][as_[4]], a5 = ap[5][as_[5]];       // one stage above the running pointers
-            V[3] = t3 ? a3 : T(0); V[4] = t4 ? a4 : T(0); V[5] = t5 ? a5 : T(0);
-            if (costx() && P.trapz) {
-                if (c < 3 && !fx(c)) V[5] += c == 0 ? qT[0] : (c == 1 ? qT[1] : qT[2]);
-                if (c == 8) V[5] += T(0.5) * (xdT[0] * qT[0] + xdT[1] * qT[1] + xdT[2] * qT[2]);
-            }
-        }
+        terminal_value(V, c, delta, d, ap[3][as_[3]], ap[4][as_[4]], ap[5][as_[5]]);       // rows 3..5: one stage above the running pointers
         T add_dd0 = T(0), add_qd0 = T(0);
         if (mintime()) add_qd0 += T(n - 1);
         if (dtf()) {
@@ -1349,7 +1358,7 @@ struct IpmWave {
             const T nid = -fast_rcp(det);
             const T nRi00 = R11 * nid, Ri01 = -(R01 * nid), nRi11 = R00 * nid;  // -R^-1 = [nRi00 Ri01; Ri01 nRi11]
             const T nK0 = nRi00 * h[6] + Ri01 * h[7], nK1 = Ri01 * h[6] + nRi11 * h[7];
-            kp[0] = nK0; kp[10] = nK1;
+            kp[0] = nK0; kp[NGH] = nK1;
             kp -= ks;
             // W[a][b] -= Su[:,a]' Knu[:,b] in lane 9+b, omega[a] -= Su[:,a]' kappa in lane 8 (Su[j][a] = Hhat[6+j][9+a]);
             // V = Hhat_xx + Hhat_xu nK   (row i of Hhat[:,6:8] = lane i's Hhat[6:8][.])
@@ -1406,6 +1415,12 @@ struct IpmWave {
             Vr.W[0][2] = Vr.W[2][0] = T(0.5) * (w02 + w20);
             Vr.W[1][2] = Vr.W[2][1] = T(0.5) * (w12 + w21);
         }
+#ifdef MPC_PIT_VERBOSE
+        if (blockIdx.x == MPC_PIT_CHECK && lane == 0)
+            printf("  %s root: P55 %.10e p5 %.10e S5 %.10e %.10e %.10e om %.10e %.10e %.10e W %.10e %.10e %.10e %.10e %.10e %.10e\n", "serial", (double)Vr.P[5][5], (double)Vr.p[5],
+                   (double)Vr.S[5][0], (double)Vr.S[5][1], (double)Vr.S[5][2], (double)Vr.om[0], (double)Vr.om[1], (double)Vr.om[2],
+                   (double)Vr.W[0][0], (double)Vr.W[0][1], (double)Vr.W[0][2], (double)Vr.W[1][1], (double)Vr.W[1][2], (double)Vr.W[2][2]);
+#endif
 #ifdef MPC_NANCHECK
         {
             const bool okr = riccati_root(Vr, P, dd_out, nu_out);
@@ -1450,7 +1465,7 @@ struct IpmWave {
         //      (gains are stored negated: [nK0 (6) | nkappa0 | nKnu0 (3) | nK1 (6) | nkappa1 | nKnu1 (3)])
         for (int k = lane; k < n - 1; k += kWave) {
             for (int a = 0; a < 2; ++a)
-                G_(10 * a + 6, k) += G_(10 * a + 7, k) * nu[0] + G_(10 * a + 8, k) * nu[1] + G_(10 * a + 9, k) * nu[2] + G_(10 * a + 5, k) * dd;
+                G_(NGH * a + 6, k) += G_(NGH * a + 7, k) * nu[0] + G_(NGH * a + 8, k) * nu[1] + G_(NGH * a + 9, k) * nu[2] + G_(NGH * a + 5, k) * dd;
             for (int i = 0; i < 3; ++i) F(L.LAMN, i, k) = C_(i, k) + S_(3 + i, k) * dd;
         }
         if (lane == 0) { SCL(SC_DD) = dd; F(L.DX, 0, 0) = T(0); F(L.DX, 1, 0) = T(0); F(L.DX, 2, 0) = T(0); }
@@ -1473,9 +1488,9 @@ struct IpmWave {
                 qw[7] = L.STG + 9 + c; qs[7] = NSTG;
             } else if (c < 5) {
                 const int a = c - 3;
-                qw[0] = L.GAIN + 10 * a + 6; qs[0] = NGAIN;
+                qw[0] = L.GAIN + NGH * a + 6; qs[0] = NGAIN;
 #pragma unroll
-                for (int j = 0; j < 5; ++j) { qw[1 + j] = L.GAIN + 10 * a + j; qs[1 + j] = NGAIN; }
+                for (int j = 0; j < 5; ++j) { qw[1 + j] = L.GAIN + NGH * a + j; qs[1 + j] = NGAIN; }
             }
             const LdsT* qp[8];
 #pragma unroll
@@ -1522,6 +1537,13 @@ struct IpmWave {
             prof_fwd_loop += __builtin_readcyclecounter() - tf0;
 #endif
         }
+        multipliers(dd, nu, delta);
+    }
+
+    // multipliers of the collocation rows for ALL stages at once, from the primal step in DX / DU (lane-parallel suffix scans); the tail of both
+    // forward passes (serial and partitioned)
+    __device__ __forceinline__ void multipliers(T dd, const T nu[3], T delta) const {
+        const int n = L.n;
         sync();
         const T xi[3] = {F(L.DX, 0, n - 1), F(L.DX, 1, n - 1), F(L.DX, 2, n - 1)};
         // ---- multipliers: lam+_{k-1} = lam+_k + t_k + e_theta (a0_k lam+_k[0] + a1_k lam+_k[1]),  k = n-2 .. 1,
@@ -1591,6 +1613,375 @@ struct IpmWave {
             carry[0] = lane_bcast(s0, 0); carry[1] = lane_bcast(s1, 0); carry[2] = lane_bcast(s2, 0);
         }
         if (lane == 0) { F(L.LAMN, 0, last) = lp[0]; F(L.LAMN, 1, last) = lp[1]; F(L.LAMN, 2, last) = lp[2]; }
+        }
+
+    // ================================================================ partitioned ("parallel-in-time") sweeps
+    // The serial sweeps above use 12 of 64 lanes and repeat the same arithmetic in all four 16-lane DPP rows.  Here the four rows work on four TIME
+    // SEGMENTS of the horizon at once (tests/test_pit_math.py holds the algebra against a dense KKT solve):
+    //   backward  row s < 3 sweeps its segment [s Lm, (s+1) Lm) from the identity border (P, p, S, W, om) = (0, 0, I, 0, 0): that yields the segment's
+    //             scattering element, lam_a = P xi_a + S lam_b + p, xi_b = S' xi_a + W lam_b + om (the border multiplier is the costate at the segment's
+    //             end: five columns, lanes 9..13; the dt column, lane 14, stays e_5); row 3 sweeps the last segment from the terminal value function, after
+    //             the N mod 4 leftover stages have been swept by all rows together.  Same stage code as the serial sweep (only the V block differs).
+    //   combine   right to left, three times: element + value function at its end -> value function at its start (combine()): every row does the same
+    //             arithmetic; the element travels from its row to all rows through one LDS tile (in the step arrays, which are free during a factorisation)
+    //   root      as in the serial sweep, from the value function at stage 0
+    //   forward   boundary states / costates from the combine's maps (wave-uniform), gains folded per stage with the costate of the stage's own segment,
+    //             then every row runs the state recurrence of its segment; the leftover stages follow in row 3
+    // What the backward half leaves for the forward half, per mid-segment s: the eliminated tile [X | y | Z] (xi_{b_{s+1}} = X xi_{b_s} + y + Z nu) and the
+    // value function [P+ | p+ | S+] at the boundary b_{s+1}, rows 0..4 x 10 columns each, in LDS words that are free during a factorisation: s = 2 in
+    // LAMN, s = 1 in the trig cache (read by kkt_pass, rewritten by every line-search trial), s = 0 in DX (over the hand-off tile, dead by then).
+    __device__ __forceinline__ int pit_tile(int s) const { return s == 2 ? L.LAMN : (s == 1 ? L.TRIG : L.DX); }
+    // column slot of lane c in a saved tile whose 6 x 6 block sits in lane set A (in_a) or B: 0..5 the block, 6 = lane 8, 7..9 = lanes 9..11; -1: not stored
+    __device__ __forceinline__ static int pit_slot(int c, bool in_a) { const int q = in_a ? pos_a(c) : pos_b(c); return q >= 0 ? q : ((c >= 8 && c < 12) ? c - 2 : -1); }
+    __device__ __forceinline__ void pit_save(int ll, int base, bool in_a, const T (&M)[6]) const {
+        const int sl = pit_slot(ll & 15, in_a);
+        if (ll < 16 && sl >= 0) {
+#pragma unroll
+            for (int i = 0; i < 5; ++i) sm[base + 10 * i + sl] = M[i];
+        }
+    }
+    __device__ __forceinline__ void pit_load(int ll, int base, bool in_a, T (&M)[5]) const {
+        const int sl = pit_slot(ll & 15, in_a);
+        const int a = base + (sl >= 0 ? sl : 0);
+#pragma unroll
+        for (int i = 0; i < 5; ++i) M[i] = sm[a + 10 * i];
+    }
+    __device__ __forceinline__ bool pit_enabled() const { return P.pit != 0 && L.n >= 40; }      // the hand-off tile (192 words) lives in DX | DU (5 n words), a saved tile pair (100 words) in 3 n words
+    // lane index that the optimiser must treat as unknown HERE: keeps the per-lane address arithmetic of a phase inside the phase (hoisted out of the
+    // interior-point loop as loop invariants it would occupy registers for the whole solve)
+    __device__ __forceinline__ int local_lane() const { int l = lane; asm volatile("" : "+v"(l)); return l; }
+    __device__ __forceinline__ static int pos_a(int c) { return c < 6 ? c : -1; }                          // position of lane c in the lane set A = (0 .. 5)
+    __device__ __forceinline__ static int pos_b(int c) { return c == 6 ? 0 : (c == 7 ? 1 : (c >= 12 ? c - 10 : -1)); }   // ... in B = (6, 7, 12 .. 15)
+
+    // one combine step.  LP_A: the value function's P+ columns sit in lane set A (then the result's sit in B), else the other way round.
+    // In: Vp / Wp / omp = value function at the segment's end, the element's tile in LDS at TB.  Out: the same registers = value function at the
+    // segment's start; A = the eliminated tile (kept for the forward pass); wpiv = min |pivot| so far.
+    template <bool LP_A>
+    __device__ __forceinline__ void combine(const int TB, const int save, T (&Vp)[6], T (&Wp)[3], T& omp, T& wpiv) const {
+        const int ll = local_lane();
+        const int c = ll & 15;
+        const int pp = LP_A ? pos_a(c) : pos_b(c), px = LP_A ? pos_b(c) : pos_a(c);          // position in the value function's / the result's lane set
+        const int TW = TB + 96, TO = TB + 176;
+        const int lm = c < 6 ? c : 0;                                                        // left factors: column m in lane m
+        // base tile: S' in the result's lanes, om in lane 8, the identity in the value function's lanes, zeros elsewhere (row i = word i from the base)
+        const int bb = px >= 0 ? TB + 16 * px + 9 : (c == 8 ? TO + 9 : (pp >= 0 ? L.ZI + 6 - pp : L.ZI));
+        // the element's own P in the result's lanes, p in lane 8, zeros elsewhere (lane 15 of the sweep carries zeros)
+        const int pb = TB + (px >= 0 ? px : (c == 8 ? 8 : 15));
+        const T sig = pp >= 0 ? T(-1) : T(1);
+        const T keep = (px >= 0 || (c >= 8 && c < 12)) ? T(1) : T(0);
+        T Wt[5], WV[5], A[6];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) Wt[i] = sm[TW + 16 * i + 9 + lm];
+        MPC_DPP_BLOCK_CWV
+#pragma unroll
+        for (int i = 0; i < 5; ++i) A[i] = sm[bb + i] + sig * WV[i];
+        A[5] = sm[bb + 5];
+        T gj_pv, gj_r, gj_e, gj_na;
+        if constexpr (LP_A) { MPC_DPP_BLOCK_CGJ_A } else { MPC_DPP_BLOCK_CGJ_B }
+        T U[6], St[6], Ra[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { U[i] = Vp[i]; St[i] = sm[TB + 16 * i + 9 + lm]; Ra[i] = sm[pb + 16 * i]; }
+        if constexpr (LP_A) { MPC_DPP_BLOCK_CU_A } else { MPC_DPP_BLOCK_CU_B }
+        MPC_DPP_BLOCK_CRA
+        MPC_DPP_BLOCK_CWN
+        // for the forward pass: the value function at the segment's END (still in Vp) and the eliminated tile; every read of the hand-off tile is done
+        pit_save(ll, save + 50, LP_A, Vp);
+        pit_save(ll, save, !LP_A, A);
+#pragma unroll
+        for (int i = 0; i < 6; ++i) Vp[i] = Ra[i] * keep;
+    }
+
+#ifdef MPC_PIT_VERBOSE
+#define PIT_DBG_W(tag) if (blockIdx.x == MPC_PIT_CHECK) { const double q00 = rd_lane(Wp[0], 9), q01 = rd_lane(Wp[0], 10), q02 = rd_lane(Wp[0], 11), q10 = rd_lane(Wp[1], 9), q11 = rd_lane(Wp[1], 10), q12 = rd_lane(Wp[1], 11), q20 = rd_lane(Wp[2], 9), q22 = rd_lane(Wp[2], 11), o0 = rd_lane(omp, 9); \
+            if (lane == 0) printf("   [%s] Wp0 %.9e %.9e %.9e Wp1 %.9e %.9e %.9e Wp2 %.9e .. %.9e om0 %.9e\n", tag, q00, q01, q02, q10, q11, q12, q20, q22, o0); }
+#else
+#define PIT_DBG_W(tag)
+#endif
+    __device__ __forceinline__ bool backward_pit(T delta, T dc, T& dd_out, T nu_out[3]) const {
+        const int n = L.n, N = n - 1, Lm = N >> 2, rem = N - 4 * Lm;
+        const T d = SCL(SC_D);
+        const int ZC = L.ZC;
+        const int ll = local_lane();
+        const int c = ll & 15, row = ll >> 4;
+        // columns: 0..5 P, 6 7 the u columns of Hhat, 8 p, 9..13 border (row 3: 9..11 = the fixed goal components), 14 the dt border column, 15 idle
+        constexpr unsigned long long KIND = 1ull | (2ull << 3) | (3ull << 6) | (4ull << 15) | (5ull << 18) | (6ull << 21) | (7ull << 24);
+        const int kind = c < 12 ? (int)((KIND >> (3 * c)) & 7) : 0;
+        const int gb = kind < 3 ? ZC + (kind == 1 ? 4 : (kind == 2 ? 3 : 0)) : (kind < 7 ? L.STG + 3 * (kind - 3) : L.CC);
+        const int gs = kind < 3 ? 0 : (kind < 7 ? NSTG : 3);
+        constexpr unsigned long long rows[8] = {stage_add_row(0, EXT), stage_add_row(1, EXT), stage_add_row(2, EXT), stage_add_row(3, EXT),
+                                                stage_add_row(4, EXT), stage_add_row(5, EXT), stage_add_row(6, EXT), stage_add_row(7, EXT)};
+        const int sh = c < 12 ? 5 * c : 60;
+        int slot1[8], as_[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) { slot1[r] = (int)((rows[r] >> sh) & 31); as_[r] = slot1[r] ? NSTG : 0; }
+        const T ec = (c == 5 || (c >= 8 && c < 15)) ? T(1) : T(0);
+        const T E3 = c == 6 ? T(1) : T(0), E4 = c == 7 ? T(1) : T(0);
+        const T dA0 = c == 0 ? delta : T(0), dA1 = c == 1 ? delta : T(0), dA2 = c == 2 ? delta : T(0);
+        const T dA6 = c == 6 ? delta : T(0), dA7 = c == 7 ? delta : T(0);
+        const bool wrG = c < 14 && c != 6 && c != 7;                       // every row stores the gains of its own stages
+        const int g0 = c < 6 ? c : (c == 8 ? 6 : 7 + (c - 9));
+        const LdsT* gp;
+        const LdsT* ap[8];
+        LdsT* kp;
+        const int ks = wrG ? NGAIN : 0;
+        auto point_at = [&](int k) {                                      // running pointers at stage k (per lane)
+            gp = lds(gb + k * gs);
+#pragma unroll
+            for (int r = 0; r < 8; ++r) ap[r] = lds(slot1[r] ? L.STG + RA - 1 + slot1[r] + k * NSTG : ZC);
+            kp = lds(wrG ? L.GAIN + g0 + k * NGAIN : L.VP);
+        };
+        T V[6], wn[5] = {T(0), T(0), T(0), T(0), T(0)}, om = T(0);
+        {
+            const int kf = n - 1;                                          // record of the final rate rows
+            const T a3 = slot1[3] ? S_(RA - 1 + slot1[3], kf) : T(0), a4 = slot1[4] ? S_(RA - 1 + slot1[4], kf) : T(0), a5 = slot1[5] ? S_(RA - 1 + slot1[5], kf) : T(0);
+            terminal_value(V, c, delta, d, a3, a4, a5);
+        }
+        T add_dd0 = T(0), add_qd0 = T(0);
+        if (mintime()) add_qd0 += T(n - 1);
+        if (dtf()) {
+            const T dl = d - P.dt_lb, du = P.dt_ub - d;
+            const T idl = fast_rcp(dl), idu = fast_rcp(du);
+            add_dd0 = SCL(SC_PDL) * idl + SCL(SC_PDU) * idu + delta;
+            add_qd0 += mu * idu - mu * idl;
+        }
+        // stage 0 belongs to row 0: no regularisation on x_0 (it is fixed), the dt-box / objective terms on row 5
+        const T s05 = row == 0 ? (c == 5 ? add_dd0 : (c == 8 ? add_qd0 : T(0))) : T(0);
+        const T dL0 = row == 0 ? T(0) : dA0, dL1 = row == 0 ? T(0) : dA1, dL2 = row == 0 ? T(0) : dA2;
+        T worst = T(1);
+        auto load_stage = [&](T (&g)[3], T (&a)[8]) {
+            g[0] = gp[0]; g[1] = gp[1]; g[2] = gp[2];
+            gp -= gs;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) { a[r] = *ap[r]; ap[r] -= as_[r]; }
+        };
+        auto stage = [&](T dk0, T dk1, T dk2, T s5, T (&G)[3], T (&A)[8], T (&Gn)[3], T (&An)[8]) {
+            load_stage(Gn, An);
+            T t[6];
+            MPC_DPP_BLOCK_T1
+            T h[8];
+            h[0] = (A[0] + dk0) + t[0]; h[1] = (A[1] + dk1) + t[1]; h[2] = (A[2] + dk2) + t[2];
+            h[3] = A[3]; h[4] = A[4];
+            h[5] = (A[5] + s5) + t[5];
+            h[6] = (A[6] + dA6) + t[3]; h[7] = (A[7] + dA7) + t[4];
+            MPC_DPP_BLOCK_H
+            T R00, R01, R11;
+            MPC_DPP_BLOCK_R
+            const T r2 = R01 * R01;
+            const T det = R00 * R11 - r2;
+            worst = t_fmin(worst, t_abs(det) - T(1e-14) * (t_abs(R00 * R11) + r2));
+            const T nid = -fast_rcp(det);
+            const T nRi00 = R11 * nid, Ri01 = -(R01 * nid), nRi11 = R00 * nid;
+            const T nK0 = nRi00 * h[6] + Ri01 * h[7], nK1 = Ri01 * h[6] + nRi11 * h[7];
+            kp[0] = nK0; kp[NGH] = nK1;
+            kp -= ks;
+            V[0] = h[0]; V[1] = h[1]; V[2] = h[2]; V[3] = h[3]; V[4] = h[4]; V[5] = h[5];
+            MPC_DPP_BLOCK_V5
+        };
+        T Ga[3], Aa[8], Gb[3], Ab[8];
+#ifdef MPC_PROFILE
+        const long long tp0 = __builtin_readcyclecounter();
+#endif
+        // ---- the N mod 4 leftover stages at the end of the horizon: all rows together (k = N-1 .. 4 Lm)
+        if (rem > 0) {
+            point_at(N - 1);
+            load_stage(Ga, Aa);
+            stage(dA0, dA1, dA2, T(0), Ga, Aa, Gb, Ab);
+            if (rem > 1) stage(dA0, dA1, dA2, T(0), Gb, Ab, Ga, Aa);
+            if (rem > 2) stage(dA0, dA1, dA2, T(0), Ga, Aa, Gb, Ab);
+        }
+        // ---- rows 0..2 start their segments from the identity border
+        if (row < 3) {
+#pragma unroll
+            for (int i = 0; i < 6; ++i) V[i] = c == 9 + i ? T(1) : T(0);
+#pragma unroll
+            for (int a = 0; a < 5; ++a) wn[a] = T(0);
+            om = T(0);
+        }
+        // ---- the four segments: row s sweeps k = s Lm + Lm - 1 .. s Lm
+        point_at(row * Lm + Lm - 1);
+        load_stage(Ga, Aa);
+        int j = Lm;
+        for (; j >= 3; j -= 2) {
+            stage(dA0, dA1, dA2, T(0), Ga, Aa, Gb, Ab);
+            stage(dA0, dA1, dA2, T(0), Gb, Ab, Ga, Aa);
+        }
+        if (j == 2) { stage(dA0, dA1, dA2, T(0), Ga, Aa, Gb, Ab); stage(dL0, dL1, dL2, s05, Gb, Ab, Ga, Aa); }
+        else stage(dL0, dL1, dL2, s05, Ga, Aa, Gb, Ab);
+        {
+            const T w4 = t_fmin(t_fmin(rd_lane(worst, 0), rd_lane(worst, 16)), t_fmin(rd_lane(worst, 32), rd_lane(worst, 48)));
+            if (!(w4 > T(0))) return false;
+        }
+#ifdef MPC_PROFILE
+        const long long tp1 = __builtin_readcyclecounter();
+        prof_loop += tp1 - tp0;
+#endif
+        // ---- hand-off + combine.  Tile (words from TB): [i][lane] V rows 0..5 | [a][lane] wn rows 0..4 | [lane] om
+        const int TB = L.DX;
+        // (the sync() on either side is what makes the hand-off visible ACROSS lanes: without it the compiler treats the tile as per-thread memory and
+        // lets the other rows' loads overtake this row's stores)
+        auto put_tile = [&](int r) {
+            sync();
+            if (row == r) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) sm[TB + 16 * i + c] = V[i];
+#pragma unroll
+                for (int a = 0; a < 5; ++a) sm[TB + 96 + 16 * a + c] = wn[a];
+                sm[TB + 176 + c] = om;
+            }
+            sync();
+        };
+        T Vp[6], Wp[3], omp, wpiv = T(1);
+        put_tile(3);
+        {
+            const int cz = (c < 6 || (c >= 8 && c < 12)) ? c : 15;         // everything else reads the idle lane's zeros
+#pragma unroll
+            for (int i = 0; i < 6; ++i) Vp[i] = sm[TB + 16 * i + cz];
+#pragma unroll
+            for (int a = 0; a < 3; ++a) Wp[a] = sm[TB + 96 + 16 * a + c];
+            omp = sm[TB + 176 + c];
+        }
+        PIT_DBG_W("V3")
+        put_tile(2);
+        combine<true>(TB, pit_tile(2), Vp, Wp, omp, wpiv);
+        PIT_DBG_W("V2")
+        put_tile(1);
+        combine<false>(TB, pit_tile(1), Vp, Wp, omp, wpiv);
+        PIT_DBG_W("V1")
+        put_tile(0);
+        combine<true>(TB, pit_tile(0), Vp, Wp, omp, wpiv);
+        PIT_DBG_W("V0")
+#ifdef MPC_PROFILE
+        prof_setup += __builtin_readcyclecounter() - tp1;
+#endif
+        if (!(rd_lane(wpiv, 0) > T(1e-9))) return false;                   // a pivot of I - W P+ broke down: the caller repeats this factorisation with the serial sweep
+        // ---- root: the value function at stage 0 has its P columns in lane set B (lane 15 = column 5)
+        RicState<T> Vr;
+        Vr.P[5][5] = rd_lane(Vp[5], 15);
+        Vr.p[5] = rd_lane(Vp[5], 8);
+        Vr.S[5][0] = rd_lane(Vp[5], 9); Vr.S[5][1] = rd_lane(Vp[5], 10); Vr.S[5][2] = rd_lane(Vp[5], 11);
+        Vr.om[0] = rd_lane(omp, 9); Vr.om[1] = rd_lane(omp, 10); Vr.om[2] = rd_lane(omp, 11);
+        {
+            const T w00 = rd_lane(Wp[0], 9), w01 = rd_lane(Wp[0], 10), w02 = rd_lane(Wp[0], 11);
+            const T w10 = rd_lane(Wp[1], 9), w11 = rd_lane(Wp[1], 10), w12 = rd_lane(Wp[1], 11);
+            const T w20 = rd_lane(Wp[2], 9), w21 = rd_lane(Wp[2], 10), w22 = rd_lane(Wp[2], 11);
+            Vr.W[0][0] = w00 - (fx(0) ? dc : T(0)); Vr.W[1][1] = w11 - (fx(1) ? dc : T(0)); Vr.W[2][2] = w22 - (fx(2) ? dc : T(0));
+            Vr.W[0][1] = Vr.W[1][0] = T(0.5) * (w01 + w10);
+            Vr.W[0][2] = Vr.W[2][0] = T(0.5) * (w02 + w20);
+            Vr.W[1][2] = Vr.W[2][1] = T(0.5) * (w12 + w21);
+        }
+#ifdef MPC_PIT_VERBOSE
+        if (blockIdx.x == MPC_PIT_CHECK && lane == 0)
+            printf("  %s root: P55 %.10e p5 %.10e S5 %.10e %.10e %.10e om %.10e %.10e %.10e W %.10e %.10e %.10e %.10e %.10e %.10e\n", "pit   ", (double)Vr.P[5][5], (double)Vr.p[5],
+                   (double)Vr.S[5][0], (double)Vr.S[5][1], (double)Vr.S[5][2], (double)Vr.om[0], (double)Vr.om[1], (double)Vr.om[2],
+                   (double)Vr.W[0][0], (double)Vr.W[0][1], (double)Vr.W[0][2], (double)Vr.W[1][1], (double)Vr.W[1][2], (double)Vr.W[2][2]);
+#endif
+        return riccati_root(Vr, P, dd_out, nu_out);
+    }
+
+    __device__ __forceinline__ void forward_pit(T dd, const T nu[3], T delta) const {
+        const int n = L.n, N = n - 1, Lm = N >> 2;
+        const int ll = local_lane();
+        const int c = ll & 15, row = ll >> 4;
+        // ---- boundary states (components 0..4; component 5 is dd) and costates, wave-uniform, left to right; they go to a small table behind the s = 0 tiles:
+        //      TX + 5 s + i = state at b_{s+1}, TL + 5 s + i = costate at b_{s+1}
+        const int TX = L.DX + 100, TL = L.DX + 115;
+        {
+            T acc[5], M[5], xi[5];
+            pit_load(ll, pit_tile(0), false, M);
+            MPC_DPP_BLOCK_BX0_B
+#pragma unroll
+            for (int i = 0; i < 5; ++i) { xi[i] = acc[i]; sm[TX + i] = acc[i]; }
+            pit_load(ll, pit_tile(0) + 50, true, M);
+            MPC_DPP_BLOCK_BX_A
+#pragma unroll
+            for (int i = 0; i < 5; ++i) sm[TL + i] = acc[i];
+            pit_load(ll, pit_tile(1), true, M);
+            MPC_DPP_BLOCK_BX_A
+#pragma unroll
+            for (int i = 0; i < 5; ++i) { xi[i] = acc[i]; sm[TX + 5 + i] = acc[i]; }
+            pit_load(ll, pit_tile(1) + 50, false, M);
+            MPC_DPP_BLOCK_BX_B
+#pragma unroll
+            for (int i = 0; i < 5; ++i) sm[TL + 5 + i] = acc[i];
+            pit_load(ll, pit_tile(2), false, M);
+            MPC_DPP_BLOCK_BX_B
+#pragma unroll
+            for (int i = 0; i < 5; ++i) { xi[i] = acc[i]; sm[TX + 10 + i] = acc[i]; }
+            pit_load(ll, pit_tile(2) + 50, true, M);
+            MPC_DPP_BLOCK_BX_A
+#pragma unroll
+            for (int i = 0; i < 5; ++i) sm[TL + 10 + i] = acc[i];
+        }
+        // component c of the boundary state of this row's segment (row 0 starts at 0): read before the step arrays are written
+        const T xi_row = (c < 5 && row > 0) ? sm[TX + 5 * (row - 1) + c] : T(0);
+        // ---- lane-parallel: fold the border multiplier of the stage's own segment and dd into the affine terms (as forward_states does with nu)
+        for (int k = lane; k < n - 1; k += kWave) {
+            const int seg = (k >= Lm ? 1 : 0) + (k >= 2 * Lm ? 1 : 0) + (k >= 3 * Lm ? 1 : 0);
+            T m5[5];
+#pragma unroll
+            for (int b = 0; b < 5; ++b) m5[b] = seg < 3 ? sm[TL + 5 * seg + b] : (b < 3 ? nu[b] : T(0));
+            for (int a = 0; a < 2; ++a)
+                G_(NGH * a + 6, k) += G_(NGH * a + 7, k) * m5[0] + G_(NGH * a + 8, k) * m5[1] + G_(NGH * a + 9, k) * m5[2] + G_(NGH * a + 10, k) * m5[3] + G_(NGH * a + 11, k) * m5[4] +
+                                      G_(NGH * a + 5, k) * dd;
+            for (int i = 0; i < 3; ++i) F(L.LAMN, i, k) = C_(i, k) + S_(3 + i, k) * dd;
+        }
+        if (lane == 0) { SCL(SC_DD) = dd; F(L.DX, 0, 0) = T(0); F(L.DX, 1, 0) = T(0); F(L.DX, 2, 0) = T(0); }
+        sync();
+        // ---- the four segments at once: row s carries (dx, du_prev) through its stages, starting from its boundary state
+        {
+            const int ZC = L.ZC, k0 = row * Lm;
+            int qw[8], qs[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { qw[j] = ZC; qs[j] = 0; }
+            if (c < 3) {
+                qw[0] = L.LAMN + c * L.NS; qs[0] = 1;
+                qw[1 + c] = ZC + 4;
+                if (c < 2) { qw[3] = L.STG + c; qs[3] = NSTG; }
+                qw[6] = L.STG + 6 + c; qs[6] = NSTG;
+                qw[7] = L.STG + 9 + c; qs[7] = NSTG;
+            } else if (c < 5) {
+                const int a = c - 3;
+                qw[0] = L.GAIN + NGH * a + 6; qs[0] = NGAIN;
+#pragma unroll
+                for (int j = 0; j < 5; ++j) { qw[1 + j] = L.GAIN + NGH * a + j; qs[1 + j] = NGAIN; }
+            }
+            const LdsT* qp[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) qp[j] = lds(qw[j] + qs[j] * k0);
+            int os = c < 5 ? 1 : 0;
+            LdsT* op = lds((c < 3 ? L.DX + c * L.NS + 1 : (c < 5 ? L.DU + (c - 3) * L.NS : L.VP + 12)) + os * k0);
+            auto load_q = [&](T (&q)[8]) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) { q[j] = *qp[j]; qp[j] += qs[j]; }
+            };
+            T xi = xi_row;
+            auto stage = [&](T (&q)[8], T (&qn)[8]) {
+                load_q(qn);
+                T s = q[0], s2 = T(0), xn;
+                MPC_DPP_BLOCK_FWD
+                *op = xn; op += os;
+                xi = xn;
+            };
+            T qa[8], qb[8];
+#ifdef MPC_PROFILE
+            const long long tf0 = __builtin_readcyclecounter();
+#endif
+            load_q(qa);
+            int k = 0;
+            for (; k + 1 < Lm; k += 2) { stage(qa, qb); stage(qb, qa); }
+            if (k < Lm) { stage(qa, qb);
+#pragma unroll
+                          for (int j = 0; j < 8; ++j) qa[j] = qb[j]; }
+            // leftover stages 4 Lm .. N-1: row 3 simply goes on (its pointers are there); the other rows compute along but write to a dummy word
+            if (row < 3) { op = lds(L.VP + 12); os = 0; }
+            for (k = 4 * Lm; k < N; ++k) { stage(qa, qb);
+#pragma unroll
+                                           for (int j = 0; j < 8; ++j) qa[j] = qb[j]; }
+#ifdef MPC_PROFILE
+            prof_fwd_loop += __builtin_readcyclecounter() - tf0;
+#endif
+        }
+        multipliers(dd, nu, delta);
     }
 
     // ---------------------------------------------------------------- parallel post-processing of the step
@@ -2027,6 +2418,8 @@ struct IpmWave {
         row0_on = dtprev != T(0);
         if (iter_cap <= 0) iter_cap = P.max_iter;
         if (lane < 8) sm[L.ZC + lane] = lane == 4 ? T(1) : T(0);      // constant coefficient triples of the sweeps
+        if (lane < 12) sm[L.ZI + lane] = lane == 6 ? T(1) : T(0);     // unit vectors / zeros of the partitioned sweep's combine step
+        const bool pit = pit_enabled();
         init_point();
         T theta_c, fobj;
         eval_point(SCL(SC_D), theta_c, fobj);
@@ -2081,8 +2474,31 @@ struct IpmWave {
             Fwd fw;
             T dd = T(0), nu[3] = {T(0), T(0), T(0)}, curv = T(0);
             for (int ntry = 0; ntry <= 40; ++ntry) {
-                bool good;
-                MPC_TICK(2, good = backward_dpp(delta, dc, dd, nu); sync());
+                bool good, used_pit = false;
+#ifdef MPC_PIT_CHECK     // developer aid: both sweeps on the same factorisation; blocks below MPC_PIT_CHECK report every factorisation on which the two differ
+                if (pit && (int)blockIdx.x < MPC_PIT_CHECK) {
+                    T dd1 = T(0), nu1[3] = {T(0), T(0), T(0)}, dd2 = T(0), nu2[3] = {T(0), T(0), T(0)};
+                    const bool g1 = backward_pit(delta, dc, dd1, nu1); sync();
+                    if (g1) { forward_pit(dd1, nu1, delta); sync(); }
+                    T keepx = T(0), keepu = T(0), keepl = T(0);
+                    const int kk = lane < L.n - 1 ? lane : 0;
+                    keepx = F(L.DX, 2, kk); keepu = F(L.DU, 1, kk); keepl = F(L.LAMN, 2, kk);
+                    sync();
+                    const bool g2 = backward_dpp(delta, dc, dd2, nu2); sync();
+                    if (g2) { forward_states(dd2, nu2, delta); sync(); }
+                    const T ex = wave_max(t_abs(keepx - F(L.DX, 2, kk))), eu = wave_max(t_abs(keepu - F(L.DU, 1, kk))), el = wave_max(t_abs(keepl - F(L.LAMN, 2, kk)));
+                    const T sx = wave_max(t_abs(F(L.DX, 2, kk))), su = wave_max(t_abs(F(L.DU, 1, kk))), sl = wave_max(t_abs(F(L.LAMN, 2, kk)));
+                    if (lane == 0 && (g1 != g2 || ex > T(1e-7) * (sx + T(1e-3)) || eu > T(1e-7) * (su + T(1e-3)) || el > T(1e-7) * (sl + T(1e-3))))
+                        printf("blk %d it %d try %d delta %.2e mu %.1e: pit ok %d serial ok %d | dd %.9e vs %.9e | max diff dx %.2e (of %.2e) du %.2e (of %.2e) lam %.2e (of %.2e)\n", (int)blockIdx.x, it, ntry, (double)delta, (double)mu,
+                               (int)g1, (int)g2, (double)dd1, (double)dd2, (double)ex, (double)sx, (double)eu, (double)su, (double)el, (double)sl);
+                    sync();
+                }
+#endif
+                if (pit && mu > P.pit_mu_min) {        // partitioned sweep; a broken-down combine pivot (or a singular stage pivot) falls back to the serial sweep
+                    MPC_TICK(2, good = backward_pit(delta, dc, dd, nu); sync());
+                    used_pit = good;
+                    if (!good) { MPC_TICK(2, good = backward_dpp(delta, dc, dd, nu); sync()); }
+                } else { MPC_TICK(2, good = backward_dpp(delta, dc, dd, nu); sync()); }
 #ifdef MPC_PROFILE
                 ++nfac;
 #endif
@@ -2100,7 +2516,8 @@ struct IpmWave {
                 }
 #endif
                 if (good) {
-                    MPC_TICK(3, forward_states(dd, nu, delta); sync());
+                    if (used_pit) { MPC_TICK(3, forward_pit(dd, nu, delta); sync()); }
+                    else { MPC_TICK(3, forward_states(dd, nu, delta); sync()); }
 #ifdef MPC_NANCHECK
                     if (blockIdx.x == MPC_NANCHECK) {
                         for (int k = lane; k < L.n; k += kWave) {
