@@ -1631,18 +1631,40 @@ struct IpmWave {
     // value function [P+ | p+ | S+] at the boundary b_{s+1}, rows 0..4 x 10 columns each, in LDS words that are free during a factorisation: s = 2 in
     // LAMN, s = 1 in the trig cache (read by kkt_pass, rewritten by every line-search trial), s = 0 in DX (over the hand-off tile, dead by then).
     __device__ __forceinline__ int pit_tile(int s) const { return s == 2 ? L.LAMN : (s == 1 ? L.TRIG : L.DX); }
-    // column slot of lane c in a saved tile whose 6 x 6 block sits in lane set A (in_a) or B: 0..5 the block, 6 = lane 8, 7..9 = lanes 9..11; -1: not stored
-    __device__ __forceinline__ static int pit_slot(int c, bool in_a) { const int q = in_a ? pos_a(c) : pos_b(c); return q >= 0 ? q : ((c >= 8 && c < 12) ? c - 2 : -1); }
-    __device__ __forceinline__ void pit_save(int ll, int base, bool in_a, const T (&M)[6]) const {
-        const int sl = pit_slot(ll & 15, in_a);
-        if (ll < 16 && sl >= 0) {
+    // Per-lane constants of a combine step, branch-free integer arithmetic (computed once per factorisation for both lane-set variants).
+    // Lane sets: A = lanes 0..5, B = lanes 6, 7, 12..15; lp_a: the value function's P+ columns sit in A and the result's in B, else the other way round.
+    struct CombLane {
+        int bb;        // base tile: S' in the result's lanes, om in lane 8, the identity in the value function's lanes, zeros elsewhere (row i = word i from here)
+        int pb;        // the element's own P in the result's lanes, p in lane 8 (row i = 16 i words from here); the other lanes are masked by keep_p
+        int sx, sp;    // slot (0..9, -1 = none) of this lane in a saved tile whose block sits in the result's / the value function's lane set
+        T sig;         // -1 in the value function's lanes (M = I - W P+), +1 elsewhere
+        T keep;        // 1 in the result's lanes and in lanes 8..11
+        T keep_p;      // 1 in the result's lanes and in lane 8
+    };
+    __device__ __forceinline__ CombLane comb_lane(int c, bool lp_a, int TB) const {
+        const int in_a = c < 6 ? 1 : 0, in_b = ((c == 6) | (c == 7) | (c >= 12)) ? 1 : 0, is8 = c == 8 ? 1 : 0, is_s = ((c >= 9) & (c < 12)) ? 1 : 0;
+        const int qa = c, qb = c < 8 ? c - 6 : c - 10;                     // position inside A / B (meaningful where in_a / in_b)
+        const int in_p = lp_a ? in_a : in_b, in_x = lp_a ? in_b : in_a, pp = lp_a ? qa : qb, px = lp_a ? qb : qa;
+        CombLane r;
+        r.bb = in_x * (TB + 16 * px + 9) + is8 * (TB + 176 + 9) + in_p * (L.ZI + 6 - pp) + (1 - in_x - is8 - in_p) * L.ZI;
+        r.pb = TB + in_x * px + is8 * 8 + (1 - in_x - is8) * 15;
+        const int tail = (is8 | is_s) * (c - 2) - (1 - (is8 | is_s));     // lanes 8..11 -> slots 6..9, else -1
+        r.sx = in_x * px + (1 - in_x) * tail;
+        r.sp = in_p * pp + (1 - in_p) * tail;
+        r.sig = T(1 - 2 * in_p);
+        r.keep = T(in_x | is8 | is_s);
+        r.keep_p = T(in_x | is8);
+        return r;
+    }
+    // saved tile: rows 0..4 x 10 slots; every row of the wave holds the same data, so all of them store (same words, same values)
+    __device__ __forceinline__ void pit_save(int base, int slot, const T (&M)[6]) const {
+        if (slot >= 0) {
 #pragma unroll
-            for (int i = 0; i < 5; ++i) sm[base + 10 * i + sl] = M[i];
+            for (int i = 0; i < 5; ++i) sm[base + 10 * i + slot] = M[i];
         }
     }
-    __device__ __forceinline__ void pit_load(int ll, int base, bool in_a, T (&M)[5]) const {
-        const int sl = pit_slot(ll & 15, in_a);
-        const int a = base + (sl >= 0 ? sl : 0);
+    __device__ __forceinline__ void pit_load(int base, int slot, T (&M)[5]) const {
+        const int a = base + (slot >= 0 ? slot : 0);
 #pragma unroll
         for (int i = 0; i < 5; ++i) M[i] = sm[a + 10 * i];
     }
@@ -1650,45 +1672,34 @@ struct IpmWave {
     // lane index that the optimiser must treat as unknown HERE: keeps the per-lane address arithmetic of a phase inside the phase (hoisted out of the
     // interior-point loop as loop invariants it would occupy registers for the whole solve)
     __device__ __forceinline__ int local_lane() const { int l = lane; asm volatile("" : "+v"(l)); return l; }
-    __device__ __forceinline__ static int pos_a(int c) { return c < 6 ? c : -1; }                          // position of lane c in the lane set A = (0 .. 5)
-    __device__ __forceinline__ static int pos_b(int c) { return c == 6 ? 0 : (c == 7 ? 1 : (c >= 12 ? c - 10 : -1)); }   // ... in B = (6, 7, 12 .. 15)
-
     // one combine step.  LP_A: the value function's P+ columns sit in lane set A (then the result's sit in B), else the other way round.
     // In: Vp / Wp / omp = value function at the segment's end, the element's tile in LDS at TB.  Out: the same registers = value function at the
-    // segment's start; A = the eliminated tile (kept for the forward pass); wpiv = min |pivot| so far.
+    // segment's start; the eliminated tile and the old value function go to `save` for the forward pass; wpiv = min |pivot| so far.
     template <bool LP_A>
-    __device__ __forceinline__ void combine(const int TB, const int save, T (&Vp)[6], T (&Wp)[3], T& omp, T& wpiv) const {
-        const int ll = local_lane();
-        const int c = ll & 15;
-        const int pp = LP_A ? pos_a(c) : pos_b(c), px = LP_A ? pos_b(c) : pos_a(c);          // position in the value function's / the result's lane set
-        const int TW = TB + 96, TO = TB + 176;
-        const int lm = c < 6 ? c : 0;                                                        // left factors: column m in lane m
-        // base tile: S' in the result's lanes, om in lane 8, the identity in the value function's lanes, zeros elsewhere (row i = word i from the base)
-        const int bb = px >= 0 ? TB + 16 * px + 9 : (c == 8 ? TO + 9 : (pp >= 0 ? L.ZI + 6 - pp : L.ZI));
-        // the element's own P in the result's lanes, p in lane 8, zeros elsewhere (lane 15 of the sweep carries zeros)
-        const int pb = TB + (px >= 0 ? px : (c == 8 ? 8 : 15));
-        const T sig = pp >= 0 ? T(-1) : T(1);
-        const T keep = (px >= 0 || (c >= 8 && c < 12)) ? T(1) : T(0);
-        T Wt[5], WV[5], A[6];
+    __device__ __forceinline__ void combine(const int TB, const int save, const CombLane& cl, const int lm, T (&Vp)[6], T (&Wp)[3], T& omp, T& wpiv) const {
+        const int TW = TB + 96;
+        T Wt[5], WV[5], A[6], U[6], St[6], Ra[6];
 #pragma unroll
-        for (int i = 0; i < 5; ++i) Wt[i] = sm[TW + 16 * i + 9 + lm];
+        for (int i = 0; i < 5; ++i) Wt[i] = sm[TW + 16 * i + 9 + lm];                      // left factor W: column m in lane m
+#pragma unroll
+        for (int i = 0; i < 6; ++i) A[i] = sm[cl.bb + i];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) { St[i] = sm[TB + 16 * i + 9 + lm]; Ra[i] = sm[cl.pb + 16 * i]; }
         MPC_DPP_BLOCK_CWV
 #pragma unroll
-        for (int i = 0; i < 5; ++i) A[i] = sm[bb + i] + sig * WV[i];
-        A[5] = sm[bb + 5];
+        for (int i = 0; i < 5; ++i) A[i] += cl.sig * WV[i];
         T gj_pv, gj_r, gj_e, gj_na;
         if constexpr (LP_A) { MPC_DPP_BLOCK_CGJ_A } else { MPC_DPP_BLOCK_CGJ_B }
-        T U[6], St[6], Ra[6];
 #pragma unroll
-        for (int i = 0; i < 6; ++i) { U[i] = Vp[i]; St[i] = sm[TB + 16 * i + 9 + lm]; Ra[i] = sm[pb + 16 * i]; }
+        for (int i = 0; i < 6; ++i) { U[i] = Vp[i]; Ra[i] *= cl.keep_p; }
         if constexpr (LP_A) { MPC_DPP_BLOCK_CU_A } else { MPC_DPP_BLOCK_CU_B }
         MPC_DPP_BLOCK_CRA
         MPC_DPP_BLOCK_CWN
         // for the forward pass: the value function at the segment's END (still in Vp) and the eliminated tile; every read of the hand-off tile is done
-        pit_save(ll, save + 50, LP_A, Vp);
-        pit_save(ll, save, !LP_A, A);
+        pit_save(save + 50, cl.sp, Vp);
+        pit_save(save, cl.sx, A);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) Vp[i] = Ra[i] * keep;
+        for (int i = 0; i < 6; ++i) Vp[i] = Ra[i] * cl.keep;
     }
 
 #ifdef MPC_PIT_VERBOSE
@@ -1841,14 +1852,16 @@ struct IpmWave {
             omp = sm[TB + 176 + c];
         }
         PIT_DBG_W("V3")
+        const CombLane cla = comb_lane(c, true, TB), clb = comb_lane(c, false, TB);
+        const int lm = c < 6 ? c : 0;
         put_tile(2);
-        combine<true>(TB, pit_tile(2), Vp, Wp, omp, wpiv);
+        combine<true>(TB, pit_tile(2), cla, lm, Vp, Wp, omp, wpiv);
         PIT_DBG_W("V2")
         put_tile(1);
-        combine<false>(TB, pit_tile(1), Vp, Wp, omp, wpiv);
+        combine<false>(TB, pit_tile(1), clb, lm, Vp, Wp, omp, wpiv);
         PIT_DBG_W("V1")
         put_tile(0);
-        combine<true>(TB, pit_tile(0), Vp, Wp, omp, wpiv);
+        combine<true>(TB, pit_tile(0), cla, lm, Vp, Wp, omp, wpiv);
         PIT_DBG_W("V0")
 #ifdef MPC_PROFILE
         prof_setup += __builtin_readcyclecounter() - tp1;
@@ -1886,29 +1899,29 @@ struct IpmWave {
         //      TX + 5 s + i = state at b_{s+1}, TL + 5 s + i = costate at b_{s+1}
         const int TX = L.DX + 100, TL = L.DX + 115;
         {
-            T acc[5], M[5], xi[5];
-            pit_load(ll, pit_tile(0), false, M);
-            MPC_DPP_BLOCK_BX0_B
+            const CombLane cla = comb_lane(c, true, L.DX), clb = comb_lane(c, false, L.DX);
+            // all six tiles first (one LDS round trip), then the six products back to back
+            T XA0[5], VB0[5], XA1[5], VB1[5], XA2[5], VB2[5];
+            pit_load(pit_tile(0), cla.sx, XA0); pit_load(pit_tile(0) + 50, cla.sp, VB0);
+            pit_load(pit_tile(1), clb.sx, XA1); pit_load(pit_tile(1) + 50, clb.sp, VB1);
+            pit_load(pit_tile(2), cla.sx, XA2); pit_load(pit_tile(2) + 50, cla.sp, VB2);
+            T acc[5], xi[5];
+            { const T (&M)[5] = XA0; MPC_DPP_BLOCK_BX0_B }
 #pragma unroll
             for (int i = 0; i < 5; ++i) { xi[i] = acc[i]; sm[TX + i] = acc[i]; }
-            pit_load(ll, pit_tile(0) + 50, true, M);
-            MPC_DPP_BLOCK_BX_A
+            { const T (&M)[5] = VB0; MPC_DPP_BLOCK_BX_A }
 #pragma unroll
             for (int i = 0; i < 5; ++i) sm[TL + i] = acc[i];
-            pit_load(ll, pit_tile(1), true, M);
-            MPC_DPP_BLOCK_BX_A
+            { const T (&M)[5] = XA1; MPC_DPP_BLOCK_BX_A }
 #pragma unroll
             for (int i = 0; i < 5; ++i) { xi[i] = acc[i]; sm[TX + 5 + i] = acc[i]; }
-            pit_load(ll, pit_tile(1) + 50, false, M);
-            MPC_DPP_BLOCK_BX_B
+            { const T (&M)[5] = VB1; MPC_DPP_BLOCK_BX_B }
 #pragma unroll
             for (int i = 0; i < 5; ++i) sm[TL + 5 + i] = acc[i];
-            pit_load(ll, pit_tile(2), false, M);
-            MPC_DPP_BLOCK_BX_B
+            { const T (&M)[5] = XA2; MPC_DPP_BLOCK_BX_B }
 #pragma unroll
             for (int i = 0; i < 5; ++i) { xi[i] = acc[i]; sm[TX + 10 + i] = acc[i]; }
-            pit_load(ll, pit_tile(2) + 50, true, M);
-            MPC_DPP_BLOCK_BX_A
+            { const T (&M)[5] = VB2; MPC_DPP_BLOCK_BX_A }
 #pragma unroll
             for (int i = 0; i < 5; ++i) sm[TL + 10 + i] = acc[i];
         }
