@@ -2394,7 +2394,7 @@ struct IpmWave {
                 for (int m = 0; m < L.M; ++m) {
                     T s = T(1), y = T(0), g, a3[3], hk, h3[3];
                     if (k >= 1 && k < n - 1) {
-                        if (obst_row3(k, m, px, py, F(L.X, 2, k), g, a3, hk, h3, d)) { s = t_max(-g, Algo<T>::slack_push); y = mu / s; }
+                        if (obst_row3(k, m, px, py, F(L.X, 2, k), g, a3, hk, h3, d)) { s = t_max(-g, Algo<T>::clearance_slack_push); y = mu / s; }
                     } else F(L.OI, m, k) = T(-1);
                     F(L.OS, m, k) = s; F(L.OY, m, k) = y;
                 }

@@ -606,6 +606,7 @@ class IpmOptions:
     tau_min: float = 0.99
     bound_push: float = 1e-2
     slack_push: float = 1e-2
+    clearance_slack_push: float = 0.5      # initial slack of a clearance row (static or moving obstacle): max(-g, 0.5), see Algo<T>::clearance_slack_push in csrc/mpc_core.hpp
     eta_armijo: float = 1e-4
     rho_frac: float = 0.1
     delta_first: float = 1e-4
@@ -708,7 +709,9 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
             v[i] = min(max(v[i], lb[i] + pl), ub[i] - pu)
     mu = opt.mu_init
     ev = nlp.eval(v)
-    s = np.maximum(-ev["g"], opt.slack_push)
+    push = np.full(mg, opt.slack_push)
+    push[len(nlp.rate_rows):len(nlp.rate_rows) + len(nlp.obst_rows) + len(nlp.dyn_rows)] = opt.clearance_slack_push
+    s = np.maximum(-ev["g"], push)
     y = mu / s
     lam = np.zeros(mc)
     piL = np.where(hasL, mu / np.maximum(v - lb, 1e-300), 0.0)

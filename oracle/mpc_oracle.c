@@ -1007,6 +1007,7 @@ static int solve_one(work_t* w, int warm) {
     const double eta = 1e-4, rho_frac = 0.1, delta_first = 1e-4, delta_min = 1e-20, delta_max = 1e20;
     const double kplus = 8, kplus1 = 100, kminus = 1.0 / 3.0, curv_kappa = 1e-10, delta_c = 1e-8, kappa_c = 0.25;
     const int max_ls = 30;
+    const double clearance_slack_push = 0.5;      /* initial slack of a clearance row, max(-g, 0.5): see Algo<T>::clearance_slack_push in csrc/mpc_core.hpp */
     int nfix = c->xf_fixed[0] + c->xf_fixed[1] + c->xf_fixed[2];
     double* cc = (double*)malloc(sizeof(double) * 3 * (n - 1));
     double* cct = (double*)malloc(sizeof(double) * 3 * (n - 1));
@@ -1084,7 +1085,7 @@ static int solve_one(work_t* w, int warm) {
             double g, a3[3], hk, h3[3];
             w->os[k * M + m] = 1.0; w->oy[k * M + m] = 0.0; w->ods[k * M + m] = 0.0; w->ody[k * M + m] = 0.0;
             if (k >= 1 && k < n - 1 && obst_row3(w, k, m, w->X[3 * k], w->X[3 * k + 1], w->X[3 * k + 2], w->D, &g, a3, &hk, h3)) {
-                w->os[k * M + m] = fmax(-g, slack_push); w->oy[k * M + m] = w->mu / w->os[k * M + m];
+                w->os[k * M + m] = fmax(-g, clearance_slack_push); w->oy[k * M + m] = w->mu / w->os[k * M + m];
             } else w->oi[k * M + m] = -1;
         }
     }
