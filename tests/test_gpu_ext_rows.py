@@ -213,11 +213,24 @@ def test_dynamic_obstacles_with_turning_footprints(m, c_oracle, name):
                                                 force_inclusion_dist=0.5, cutoff_dist=2.5, max_obstacles=3, max_vertices=1, max_obstacle_rows=4), max_batch=B)
     r = s.solve(x0, xf, up, dtp, obstacles=(no, nv, vt, rad, vel))
     ref = c_oracle.solve_batch(c_oracle.from_nlp_config(ocfg), x0, xf, up, dtp, obstacles=(no, nv, vt, rad, vel), obst=c_oracle.obst_from_nlp_config(ocfg, 3, 1, 4))
-    both = _summary(r, ref, B, min_frac=0.3)      # a hard workload for the interior-point method itself (~45 % converge within 100 iterations, in every implementation)
+    both = _summary(r, ref, B, min_frac=0.45)      # a hard workload for the interior-point method from the reference guess alone (~60 % converge within 100 iterations, in every implementation)
     still = c_oracle.solve_batch(c_oracle.from_nlp_config(ocfg), x0, xf, up, dtp, obstacles=(no, nv, vt, rad, 0 * vel), obst=c_oracle.obst_from_nlp_config(ocfg, 3, 1, 4))
     assert (both & (still[3] == 0) & (np.abs(ref[0] - still[0]).reshape(B, -1).max(1) > 1e-4)).sum() >= 5      # the motion matters
     account(f"dynamic obstacles, {name} footprint, B={B}", ocfg, (x0, xf, up, dtp), r, ref, obstacles=(no, nv, vt, rad, vel), max_rows=4)
     s.close()
+    # r03 (VERDICT r02 item 1 iii): the reference path alone converges for ~60 % of these instances (45 % before the clearance rows' slack start of 0.5);
+    # hedged by three Hermite seeds -- candidate initial trajectories, BASELINE north star -- for >= 95 %; the hedges' answers are KKT points of the same NLP
+    sc = m.BatchSolver(m.config_carlike_min_time(n, footprint_kind=kind, footprint_params=params, enable_dynamic_obstacles=True, min_obstacle_dist=dmin,
+                                                 force_inclusion_dist=0.5, cutoff_dist=2.5, max_obstacles=3, max_vertices=1, max_obstacle_rows=4,
+                                                 candidates=(0, 5, 5, 6), candidate_max_iter=(100, 100, 100, 100), candidate_param=(0.0, 2.0, 1.0, 2.0)), max_batch=B)
+    rc = sc.solve(x0, xf, up, dtp, obstacles=(no, nv, vt, rad, vel))
+    wc, _ = sc.last_candidates(B)
+    sc.close()
+    print(f"dynamic obstacles, {name} footprint: reference path alone {np.mean(r.status == 0):.3f} converged, with hedges {np.mean(rc.status == 0):.3f}; winners {np.bincount(wc + 1, minlength=5).tolist()}")
+    assert np.mean(r.status == 0) >= 0.5 and np.mean(rc.status == 0) >= 0.95
+    same0 = (wc == 0) & (r.status == 0)
+    assert (wc[r.status == 0] == 0).all() and np.array_equal(rc.x[same0], r.x[same0])          # the reference path's answer wherever it has one
+    account(f"dynamic obstacles, {name} footprint, with hedges, B={B}", ocfg, (x0, xf, up, dtp), rc, ref, obstacles=(no, nv, vt, rad, vel), max_rows=4, min_match=0.0)
 
 
 def test_rows_that_do_not_fit_are_counted(m, c_oracle):
