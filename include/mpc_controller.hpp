@@ -23,6 +23,18 @@
 
 extern "C" {
 #include "mpc_hip.h"
+
+// mpc_step_batch (all outer OCP iterations of a control cycle enqueued at once) is used when the linked C ABI has it: libmpc_hip.so does; the recording
+// stand-in ABI of the CPU tests (tests/host_harness/facade_step_host.cpp) does not, and the facade then iterates on the host as before
+#ifndef MPC_FACADE_HOST_LOOP_ONLY      // (defined by builds on a stand-in ABI that live in one process with the real library)
+extern "C" int mpc_step_batch(mpc_solver* s, int32_t B, const double* x0, const double* xf, const double* u_prev, const double* dt_prev, const double* x_init,
+                              const double* u_init, const double* dt_init, const mpc_obstacles* obstacles, int32_t outer_iterations, int32_t adapt, int32_t n_min,
+                              int32_t n_max, double dt_hyst_ratio, double* x_out, double* u_out, double* dt_out, int32_t* status, int32_t* iters, int32_t* n_grid_out)
+    __attribute__((weak));
+#define MPC_FACADE_HAS_STEP_BATCH (mpc_step_batch != nullptr)
+#else
+#define MPC_FACADE_HAS_STEP_BATCH false
+#endif
 }
 
 namespace mpc_local_planner_amd {
@@ -365,6 +377,9 @@ class Controller {
     }
     void setWarmStart(bool w) { _warm_start = w; }      // grid/warm_start (src/controller.cpp:294-296)
     void setNumOcpIterations(int n) { _num_ocp_iterations = n < 1 ? 1 : n; }      // controller/outer_ocp_iterations (src/controller.cpp:70-72)
+    // all outer iterations of a step() in one mpc_step_batch call (no host round trip between them; same results).  Off by default: the CPU tests pin the
+    // host loop against the executed reference; include/mpc_reference_binding.hpp switches it on
+    void setSingleLaunchStep(bool on) { _single_launch_step = on; }
     // The reference samples the initial state trajectory at the grid's CURRENT dt (full_discretization_grid_base_se2.cpp:61-65: precompute(getDt(), ...)), and
     // clear() does not put dt back to dt_ref (:526-536).  So on the variable grid every re-initialisation AFTER a first solve (goal jump, reset(), force_reinit_num_steps)
     // samples the plan at the LAST OPTIMISED dt while the plan's time axis still spans (n_ref - 1) dt_ref: a guess that is compressed (dt < dt_ref) or runs into the
@@ -427,7 +442,8 @@ class Controller {
         // PredictiveController::step repeats the OCP (grid update + solve) num_ocp_iterations times per control cycle
         // (controller/outer_ocp_iterations, src/controller.cpp:70-72); every repetition after the first starts from the solution just computed
         int32_t status = -1, iters = 0;
-        for (int outer = 0; outer < _num_ocp_iterations; ++outer) {
+        const bool one_call = _single_launch_step && MPC_FACADE_HAS_STEP_BATCH && _num_ocp_iterations > 1;
+        for (int outer = 0; outer < (one_call ? 1 : _num_ocp_iterations); ++outer) {
         const double* xi = nullptr; const double* ui = nullptr; const double* di = nullptr;
         if (_grid_empty) {
             _n_cur = _n_ref;
@@ -455,7 +471,25 @@ class Controller {
             if (mpc_set_grid_sizes(_h, &ng, 1) != MPC_OK) { _last_error = mpc_last_error(); return false; }
             _sizes_set = true;
         }
-        const int rc = mpc_solve_batch(_h, 1, x0, xf, _u_prev, &_dt_prev, xi, ui, di, _obst, _x.data(), _u.data(), &_dt_sol, &status, &iters);
+        int rc;
+        if (one_call) {
+            // every outer iteration in ONE call: the grid update between them (shift on the fixed grid -- towards the same x0, i.e. nothing moves --, single-step
+            // adaptation + resampling on the variable grid) runs on the device, bit for bit what the host code above does (tests/test_gpu_closed_loop.py)
+            if (_grid_adapt && _cfg.dt_free && !_sizes_set) {
+                const int32_t ng = _n_cur;
+                if (mpc_set_grid_sizes(_h, &ng, 1) != MPC_OK) { _last_error = mpc_last_error(); return false; }
+                _sizes_set = true;
+            }
+            int32_t n_after = _n_cur;
+#ifndef MPC_FACADE_HOST_LOOP_ONLY
+            rc = mpc_step_batch(_h, 1, x0, xf, _u_prev, &_dt_prev, xi, ui, di, _obst, _num_ocp_iterations, (_grid_adapt && _cfg.dt_free) ? 1 : 0, _n_min, _n_max, _dt_hyst,
+                                _x.data(), _u.data(), &_dt_sol, &status, &iters, &n_after);
+#else
+            rc = MPC_EINVAL;
+#endif
+            if (rc == MPC_OK) _n_cur = n_after;
+        } else
+            rc = mpc_solve_batch(_h, 1, x0, xf, _u_prev, &_dt_prev, xi, ui, di, _obst, _x.data(), _u.data(), &_dt_sol, &status, &iters);
         if (rc != MPC_OK) { _last_error = mpc_last_error(); return false; }
         _grid_empty = false;
         _have_solution = true;
@@ -509,7 +543,7 @@ class Controller {
     mpc_solver* _h = nullptr;
     mpc_config _cfg{};
     int _n = 0, _n_ref = 0, _n_cur = 0;
-    bool _grid_adapt = false, _sizes_set = false, _warm_start = true;
+    bool _grid_adapt = false, _sizes_set = false, _warm_start = true, _single_launch_step = false;
     int _n_max = 50, _n_min = 3;
     double _dt_hyst = 0.1;
     std::vector<double> _x, _u, _xi, _ui;

@@ -260,6 +260,24 @@ int mpc_solve_batch_device(mpc_solver* s, int32_t B,
                            double* d_x_out, double* d_u_out, double* d_dt_out,
                            int32_t* d_status, int32_t* d_iters);
 
+/* One control cycle of B planners = what Controller::step does through corbo's PredictiveController (src/controller.cpp:70-72,172): the OCP -- grid update,
+ * then solve -- is repeated controller/outer_ocp_iterations times, every repetition after the first starting from the solution just computed.  The first
+ * solve is mpc_solve_batch with the given initial guess (NULL = cold start); before each further one the grid update of mpc_grid_update_device runs on the
+ * outputs in place (fixed grid: shift towards x0, which is the same state, so nothing moves; variable grid with adapt != 0: single-step adaptation +
+ * resampling with n_min / n_max / dt_hyst_ratio).  Everything is enqueued on the solver's stream without a host round trip in between; the result is bit for
+ * bit what the separate calls give.  status / iters: those of the LAST solve (what the reference's step() returns); n_grid_out (nullable, HOST variant):
+ * the grid sizes in force after the call. */
+int mpc_step_batch(mpc_solver* s, int32_t B,
+                   const double* x0, const double* xf, const double* u_prev, const double* dt_prev,
+                   const double* x_init, const double* u_init, const double* dt_init, const mpc_obstacles* obstacles,
+                   int32_t outer_iterations, int32_t adapt, int32_t n_min, int32_t n_max, double dt_hyst_ratio,
+                   double* x_out, double* u_out, double* dt_out, int32_t* status, int32_t* iters, int32_t* n_grid_out);
+int mpc_step_batch_device(mpc_solver* s, int32_t B,
+                          const double* d_x0, const double* d_xf, const double* d_u_prev, const double* d_dt_prev,
+                          const double* d_x_init, const double* d_u_init, const double* d_dt_init, const mpc_obstacles* d_obstacles,
+                          int32_t outer_iterations, int32_t adapt, int32_t n_min, int32_t n_max, double dt_hyst_ratio,
+                          double* d_x_out, double* d_u_out, double* d_dt_out, int32_t* d_status, int32_t* d_iters);
+
 /* Per-instance grid sizes for the following mpc_solve_batch* calls (grid adaptation of the variable grid,
  * src/optimal_control/finite_differences_variable_grid_se2.cpp:99-121): instance b uses n_grid[b] grid points
  * (3 <= n_grid[b] <= cfg.n); the array layouts keep the stride cfg.n and only the first n_grid[b] rows of

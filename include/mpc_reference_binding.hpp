@@ -136,6 +136,7 @@ class Controller {
         const amd::ParamStatus st = amd::configure_from_params(_amd, src, report, caps, 0, _costmap_footprint.empty() ? nullptr : &_costmap_footprint, &_cfg, &_options);
         for (const std::string& note : report.notes) ROS_WARN_STREAM("mpc_local_planner (hip): " << note);
         if (st != amd::PARAMS_OK) { ROS_ERROR_STREAM(report.error); return false; }
+        { bool one_call = true; nh.param("mpc_hip/single_launch_step", one_call, one_call); _amd.setSingleLaunchStep(one_call); }      // all outer OCP iterations of a cycle in one mpc_step_batch call
         switch (_cfg.model) {
             case MPC_MODEL_UNICYCLE: _dynamics = std::make_shared<UnicycleModel>(); break;
             case MPC_MODEL_SIMPLE_CAR: _dynamics = std::make_shared<SimpleCarModel>(_cfg.model_params[0]); break;

@@ -20,7 +20,7 @@ HEADERS = ["mpc_solve_kernel.hpp", "mpc_core.hpp", "mpc_problem.hpp", "mpc_wave.
 
 EXPORTS = [
     "mpc_config_defaults", "mpc_create", "mpc_reset", "mpc_destroy", "mpc_solve_batch",
-    "mpc_solve_batch_device", "mpc_set_grid_sizes", "mpc_set_via_points", "mpc_set_via_points_device", "mpc_costmap_to_obstacles", "mpc_costmap_to_obstacles_device", "mpc_last_candidates", "mpc_last_rows_dropped", "mpc_check_feasibility", "mpc_check_feasibility_device", "mpc_grid_update_device", "mpc_get_grid_sizes", "mpc_synchronize", "mpc_last_kernel_ms", "mpc_last_error", "mpc_version",
+    "mpc_solve_batch_device", "mpc_step_batch", "mpc_step_batch_device", "mpc_set_grid_sizes", "mpc_set_via_points", "mpc_set_via_points_device", "mpc_costmap_to_obstacles", "mpc_costmap_to_obstacles_device", "mpc_last_candidates", "mpc_last_rows_dropped", "mpc_check_feasibility", "mpc_check_feasibility_device", "mpc_grid_update_device", "mpc_get_grid_sizes", "mpc_synchronize", "mpc_last_kernel_ms", "mpc_last_error", "mpc_version",
 ]
 
 
@@ -100,6 +100,11 @@ def load() -> C.CDLL:
     lib.mpc_solve_batch.restype = C.c_int
     lib.mpc_solve_batch_device.argtypes = sig
     lib.mpc_solve_batch_device.restype = C.c_int
+    stp = [C.c_void_p, C.c_int32] + [dp] * 7 + [C.c_void_p] + [C.c_int32] * 4 + [C.c_double] + [dp] * 5
+    lib.mpc_step_batch.argtypes = stp + [dp]
+    lib.mpc_step_batch.restype = C.c_int
+    lib.mpc_step_batch_device.argtypes = stp
+    lib.mpc_step_batch_device.restype = C.c_int
     lib.mpc_set_grid_sizes.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     lib.mpc_set_grid_sizes.restype = C.c_int
     lib.mpc_set_via_points.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]

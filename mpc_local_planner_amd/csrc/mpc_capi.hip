@@ -215,7 +215,7 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         // inputs: x0 xf u_prev dt_prev | x_init u_init dt_init | n_obstacles n_vertices vertices radius velocity (each piece 256-byte aligned)
         s->in_cap = Bm * (3 + 3 + 2 + 1) * 8 + Bm * (5 * n + 1) * 8 + (O ? Bm * 4 + Bm * O * 4 + Bm * O * V * 2 * 8 + Bm * O * 8 + Bm * O * 2 * 8 : 0) + 16 * 256;
         // outputs: x_out u_out dt_out status iters
-        s->out_cap = Bm * (5 * n + 1) * 8 + Bm * 8 + 8 * 256;
+        s->out_cap = Bm * (5 * n + 1) * 8 + Bm * 12 + 10 * 256;
         if (er == hipSuccess) er = hipHostMalloc((void**)&s->h_in, s->in_cap, hipHostMallocDefault);
         if (er == hipSuccess) er = hipHostMalloc((void**)&s->h_out, s->out_cap, hipHostMallocDefault);
         if (er == hipSuccess) er = hipMalloc((void**)&s->d_in, s->in_cap);
@@ -375,6 +375,21 @@ int mpc_solve_batch_device(mpc_solver* s, int32_t B, const double* d_x0, const d
     s->timed = true;
     s->last_status = d_status; s->last_iters = d_iters;
     return MPC_OK;
+}
+
+int mpc_step_batch_device(mpc_solver* s, int32_t B, const double* d_x0, const double* d_xf, const double* d_u_prev, const double* d_dt_prev,
+                          const double* d_x_init, const double* d_u_init, const double* d_dt_init, const mpc_obstacles* d_obstacles,
+                          int32_t outer_iterations, int32_t adapt, int32_t n_min, int32_t n_max, double dt_hyst_ratio,
+                          double* d_x_out, double* d_u_out, double* d_dt_out, int32_t* d_status, int32_t* d_iters) {
+    // PredictiveController::step repeats (grid update -> solve) outer_ocp_iterations times per control cycle (src/controller.cpp:70-72,172): every
+    // repetition after the first starts from the solution just computed, in place on the output arrays; everything is enqueued on the solver's stream
+    int rc = mpc_solve_batch_device(s, B, d_x0, d_xf, d_u_prev, d_dt_prev, d_x_init, d_u_init, d_dt_init, d_obstacles, d_x_out, d_u_out, d_dt_out, d_status, d_iters);
+    for (int it = 1; it < outer_iterations && rc == MPC_OK; ++it) {
+        rc = mpc_grid_update_device(s, B, d_x0, d_x_out, d_u_out, d_dt_out, adapt, n_min, n_max, dt_hyst_ratio);
+        if (rc == MPC_OK)
+            rc = mpc_solve_batch_device(s, B, d_x0, d_xf, d_u_prev, d_dt_prev, d_x_out, d_u_out, d_dt_out, d_obstacles, d_x_out, d_u_out, d_dt_out, d_status, d_iters);
+    }
+    return rc;
 }
 
 int mpc_last_candidates(mpc_solver* s, int32_t B, int32_t* winner, int32_t* iters_total) {
@@ -625,11 +640,13 @@ int mpc_last_kernel_ms(mpc_solver* s, float* ms) {
     return MPC_OK;
 }
 
-int mpc_solve_batch(mpc_solver* s, int32_t B, const double* x0, const double* xf, const double* u_prev, const double* dt_prev,
-                    const double* x_init, const double* u_init, const double* dt_init, const mpc_obstacles* obstacles,
-                    double* x_out, double* u_out, double* dt_out, int32_t* status, int32_t* iters) {
+// host-pointer entry of one control cycle: `outer` x (grid update -> solve) without a host round trip in between
+static int step_host(mpc_solver* s, int32_t B, const double* x0, const double* xf, const double* u_prev, const double* dt_prev,
+                     const double* x_init, const double* u_init, const double* dt_init, const mpc_obstacles* obstacles,
+                     int32_t outer, int32_t adapt, int32_t n_min, int32_t n_max, double dt_hyst_ratio,
+                     double* x_out, double* u_out, double* dt_out, int32_t* status, int32_t* iters, int32_t* n_grid_out) {
     g_err[0] = 0;
-    if (!s || !x0 || !xf || !x_out || !u_out || !dt_out) { set_err("mpc_solve_batch: null argument"); return MPC_EINVAL; }
+    if (!s || !x0 || !xf || !x_out || !u_out || !dt_out) { set_err("mpc_solve_batch / mpc_step_batch: null argument"); return MPC_EINVAL; }
     if (B <= 0) return MPC_OK;
     if (B > s->max_batch) { set_err("mpc_solve_batch: B exceeds max_batch"); return MPC_EBATCH; }
     if ((x_init != nullptr) != (u_init != nullptr) || (x_init != nullptr) != (dt_init != nullptr)) {
@@ -674,10 +691,11 @@ int mpc_solve_batch(mpc_solver* s, int32_t B, const double* x0, const double* xf
     // ---- outputs: one device block, ONE device-to-host copy
     size_t oo = 0;
     auto take = [&](size_t bytes) { size_t at = oo; oo = (oo + bytes + 255) & ~(size_t)255; return at; };
-    const size_t o_x = take(b * n * 3 * 8), o_u = take(b * n * 2 * 8), o_dt = take(b * 8), o_st = take(b * 4), o_it = take(b * 4);
-    int rc = mpc_solve_batch_device(s, B, dx0, dxf, dup, ddtp, dxi, dui, ddti, &dob, (double*)(s->d_out + o_x), (double*)(s->d_out + o_u),
-                                    (double*)(s->d_out + o_dt), (int32_t*)(s->d_out + o_st), (int32_t*)(s->d_out + o_it));
+    const size_t o_x = take(b * n * 3 * 8), o_u = take(b * n * 2 * 8), o_dt = take(b * 8), o_st = take(b * 4), o_it = take(b * 4), o_ng = take(b * 4);
+    int rc = mpc_step_batch_device(s, B, dx0, dxf, dup, ddtp, dxi, dui, ddti, &dob, outer, adapt, n_min, n_max, dt_hyst_ratio, (double*)(s->d_out + o_x),
+                                   (double*)(s->d_out + o_u), (double*)(s->d_out + o_dt), (int32_t*)(s->d_out + o_st), (int32_t*)(s->d_out + o_it));
     if (rc != MPC_OK) return rc;
+    if (n_grid_out && s->use_ngrid) HIP_TRY(hipMemcpyAsync(s->d_out + o_ng, s->d_ngrid, b * 4, hipMemcpyDeviceToDevice, q));
     HIP_TRY(hipMemcpyAsync(s->h_out, s->d_out, oo, hipMemcpyDeviceToHost, q));
     HIP_TRY(hipStreamSynchronize(q));
     memcpy(x_out, s->h_out + o_x, b * n * 3 * 8);
@@ -685,7 +703,22 @@ int mpc_solve_batch(mpc_solver* s, int32_t B, const double* x0, const double* xf
     memcpy(dt_out, s->h_out + o_dt, b * 8);
     if (status) memcpy(status, s->h_out + o_st, b * 4);
     if (iters) memcpy(iters, s->h_out + o_it, b * 4);
+    if (n_grid_out) { if (s->use_ngrid) memcpy(n_grid_out, s->h_out + o_ng, b * 4); else for (size_t i = 0; i < b; ++i) n_grid_out[i] = s->cfg.n; }
     return MPC_OK;
+}
+
+int mpc_solve_batch(mpc_solver* s, int32_t B, const double* x0, const double* xf, const double* u_prev, const double* dt_prev,
+                    const double* x_init, const double* u_init, const double* dt_init, const mpc_obstacles* obstacles,
+                    double* x_out, double* u_out, double* dt_out, int32_t* status, int32_t* iters) {
+    return step_host(s, B, x0, xf, u_prev, dt_prev, x_init, u_init, dt_init, obstacles, 1, 0, 0, 0, 0.0, x_out, u_out, dt_out, status, iters, nullptr);
+}
+
+int mpc_step_batch(mpc_solver* s, int32_t B, const double* x0, const double* xf, const double* u_prev, const double* dt_prev,
+                   const double* x_init, const double* u_init, const double* dt_init, const mpc_obstacles* obstacles,
+                   int32_t outer_iterations, int32_t adapt, int32_t n_min, int32_t n_max, double dt_hyst_ratio,
+                   double* x_out, double* u_out, double* dt_out, int32_t* status, int32_t* iters, int32_t* n_grid_out) {
+    return step_host(s, B, x0, xf, u_prev, dt_prev, x_init, u_init, dt_init, obstacles, outer_iterations, adapt, n_min, n_max, dt_hyst_ratio, x_out, u_out, dt_out, status,
+                     iters, n_grid_out);
 }
 
 }  // extern "C"

@@ -4,6 +4,7 @@
 // instantiated in the translation unit that includes this header (plain `hipcc mpc_capi.hip`, developer builds).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "../../include/mpc_hip.h"
 #include "mpc_core.hpp"
@@ -35,7 +36,7 @@ constexpr int kWinIdle = 0x7f7f7f7f;
 
 // One wavefront = one (planner instance, candidate initial trajectory); the whole working set lives in LDS (mpc_wave.hpp).
 // Grid: n_cand * B workgroups, candidate-major, so that the hardware dispatches every instance's candidate 0 before any hedge.
-template <typename T, int MODEL, int EXT>
+template <typename T, int MODEL, int EXT, bool OBST>
 __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
     mpc::Problem<T> P, mpc::WaveLayout L, int B,
     const double* __restrict__ x0, const double* __restrict__ xf, const double* __restrict__ u_prev,
@@ -72,7 +73,7 @@ __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
 #endif
         if (lane == 0) { *Ps = P; Ps->n = n; }
         __syncthreads();
-        mpc::IpmWave<T, MODEL, EXT> S(*Ps, Lv, sm, lane);
+        mpc::IpmWave<T, MODEL, EXT, OBST> S(*Ps, Lv, sm, lane);
         for (int i = 0; i < 3; ++i) { S.x0[i] = T(x0[3 * inst + i]); S.xf[i] = T(xf[3 * inst + i]); }
         S.x0[2] = mpc::normalize_theta(S.x0[2]);
         S.xf[2] = mpc::normalize_theta(S.xf[2]);
@@ -96,7 +97,7 @@ __global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
         } else {
             S.seed_start(kind, Ps->cand_param[cand]);
         }
-        if (L.M > 0) S.load_obstacles(obst.n_obstacles, obst.n_vertices, obst.vertices, obst.radius, obst.velocity, inst);
+        if (OBST && L.M > 0) S.load_obstacles(obst.n_obstacles, obst.n_vertices, obst.vertices, obst.radius, obst.velocity, inst);
         if (EXT && L.NV > 0) S.load_via_points(n_via, via, inst);
         __syncthreads();
         mpc::SolveStats<T> st = S.solve();
@@ -196,7 +197,10 @@ struct SolveLaunch {
 
 template <typename T, int MODEL>
 hipError_t launch_solve(const SolveLaunch& a, const Problem<T>& P) {
-    auto kern = a.level == 0 ? mpc_ipm_wave_kernel<T, MODEL, 0> : (a.level == 2 ? mpc_ipm_wave_kernel<T, MODEL, 2> : mpc_ipm_wave_kernel<T, MODEL, 1>);
+    // four instantiations per (arithmetic type, model): the headline level without / with clearance rows, and the two extended levels (always with)
+    static const bool force_obst = getenv("MPC_FORCE_OBST_KERNEL") != nullptr;      // developer switch (A/B of the two headline instantiations)
+    auto kern = a.level == 0 ? ((a.L.M > 0 || force_obst) ? mpc_ipm_wave_kernel<T, MODEL, 0, true> : mpc_ipm_wave_kernel<T, MODEL, 0, false>)
+                             : (a.level == 2 ? mpc_ipm_wave_kernel<T, MODEL, 2, true> : mpc_ipm_wave_kernel<T, MODEL, 1, true>);
     if (a.lds > 48u * 1024u) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.lds);
         if (e != hipSuccess) return e;

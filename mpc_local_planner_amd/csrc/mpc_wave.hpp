@@ -153,7 +153,9 @@ __device__ __forceinline__ float lane_bcast(float v, int src) {
 // EXT = false compiles the rarely used rows / objective terms (terminal l2-ball, via-points) out of the kernel: the headline
 // configurations keep their instruction count and register budget
 // EXT: 0 = headline instantiation, 1 = + the rarely used rows / terms / coupling slots, 2 = + the cost variants (off-diagonal weights, trapezoidal rule)
-template <typename T, int MODEL, int EXT = 1>
+// OBST = false compiles every clearance-row path out (solvers created without obstacles: the headline configurations): less code, and the two dozen layout
+// words of the obstacle arrays leave the scalar registers (the headline kernel spilled ~430 of them)
+template <typename T, int MODEL, int EXT = 1, bool OBST = true>
 struct IpmWave {
     const Problem<T>& P;     // lives in LDS (copied once per workgroup): wave-uniform constants are fetched with
     const WaveLayout L;      // broadcast ds_reads instead of being pinned in (and spilled from) scalar registers; the layout
@@ -193,6 +195,7 @@ struct IpmWave {
     __device__ __forceinline__ void sync() const { __syncthreads(); }
     // trig-cache words per stage: sin, cos, steering term(s); Crank-Nicolson appends sin/cos of its second evaluation angle
     static constexpr int NTRB = (MODEL == MODEL_KINEMATIC_BICYCLE || MODEL == MODEL_SIMPLE_CAR_FRONT) ? 4 : 3;
+    __device__ __forceinline__ int nM() const { return OBST ? L.M : 0; }      // clearance rows per grid point
     __device__ __forceinline__ bool fx(int i) const { return (flags >> i) & 1; }
     __device__ __forceinline__ bool dtf() const { return (flags >> 3) & 1; }
     __device__ __forceinline__ bool quad() const { return (flags >> 4) & 1; }
@@ -437,7 +440,7 @@ struct IpmWave {
     // index) -- a deviation from the reference that the caller can see: the number of rows that did not fit is returned (summed over the
     // grid points; mpc_last_rows_dropped) so that max_obstacle_rows can be raised.
     __device__ __forceinline__ int associate_obstacles() const {
-        const int n = L.n, M = L.M;
+        const int n = L.n, M = nM();
         int dropped = 0;
         for (int k = lane; k < n; k += kWave) {
             int cnt = 0;
@@ -713,11 +716,11 @@ struct IpmWave {
         const T al = trial ? alpha : T(0);
         T th = T(0), fo = T(0);
         // clearance rows (non-linear): |g(x_k) + s| with the trial slack s + alpha*ds
-        if (L.M > 0) {
+        if (nM() > 0) {
             for (int k = lane; k < n - 1; k += kWave) {
                 if (k < 1) continue;
                 const T px = xt(0, k, al), py = xt(1, k, al), pth = fpline() ? xt(2, k, al) : T(0);
-                for (int m = 0; m < L.M; ++m) {
+                for (int m = 0; m < nM(); ++m) {
                     T g, a3[3], hk, h3[3];
                     if (!obst_row3(k, m, px, py, pth, g, a3, hk, h3, d)) continue;
                     T s = F(L.OS, m, k);
@@ -781,8 +784,8 @@ struct IpmWave {
                 if (trial) s += alpha * (-(row_val(L.U, SCL(SC_D), k, q) + s) - row_jdz(k, q, dd));
                 acc.mul(s);
             }
-            if (L.M > 0 && k >= 1 && k < n - 1) {
-                for (int m = 0; m < L.M; ++m) {
+            if (nM() > 0 && k >= 1 && k < n - 1) {
+                for (int m = 0; m < nM(); ++m) {
                     if (F(L.OI, m, k) < T(0)) continue;
                     T s = F(L.OS, m, k);
                     if (trial) s += alpha * (-(F(L.OG, m, k) + s) - obst_jdz(k, m));
@@ -801,11 +804,11 @@ struct IpmWave {
     // arithmetic as eval_point() + barrier_logs() at (alpha, trial = true).
     struct TrialRegs {
         T xk[3], dxk[3], xn[3], dxn[3], u[2], du[2], s[4], ds[4];
-        T ulb[2], uub[2], dt_lb, dt_ub, Q[3], R[2], nm1;
+        T ulb[2], uub[2], dt_lb, dt_ub, nm1;      // (the quadratic weights are read from the problem record when needed: ten registers less across the line search)
         bool stage, on[4], quad, mint, dtf;
         int k;
     };
-    __device__ __forceinline__ bool trial_fast_ok() const { return L.M == 0 && L.n <= kWave && !costx(); }
+    __device__ __forceinline__ bool trial_fast_ok() const { return EXT == 0 && !(sizeof(T) == 8 && NTRB > 3) && nM() == 0 && L.n <= kWave; }      // (the extended instantiations and the fp64 bicycle / front-wheel models keep those registers for what they add: no scratch memory anywhere)
     __device__ __forceinline__ void trial_setup(TrialRegs& r, T dd) const {
         const int n = L.n, k = lane;
         const T d = SCL(SC_D);
@@ -813,7 +816,6 @@ struct IpmWave {
         r.quad = quad(); r.mint = mintime(); r.dtf = dtf(); r.nm1 = T(n - 1);
         r.dt_lb = P.dt_lb; r.dt_ub = P.dt_ub;
         for (int i = 0; i < 3; ++i) {
-            r.Q[i] = P.Q[i];
             r.xk[i] = r.dxk[i] = r.xn[i] = r.dxn[i] = T(0);
             if (r.stage) {
                 r.xk[i] = F(L.X, i, k); r.xn[i] = F(L.X, i, k + 1);
@@ -822,7 +824,7 @@ struct IpmWave {
             }
         }
         for (int j = 0; j < 2; ++j) {
-            r.R[j] = P.R[j]; r.ulb[j] = P.u_lb[j]; r.uub[j] = P.u_ub[j];
+            r.ulb[j] = P.u_lb[j]; r.uub[j] = P.u_ub[j];
             r.u[j] = r.stage ? F(L.U, j, k) : T(0); r.du[j] = r.stage ? F(L.DU, j, k) : T(0);
         }
         for (int q = 0; q < 4; ++q) {
@@ -851,7 +853,7 @@ struct IpmWave {
             th = t_abs(c0) + t_abs(c1) + t_abs(c2);
             if (r.quad) {
                 const T xd0 = x0_ - xf[0], xd1 = x1_ - xf[1], xd2 = normalize_theta(x2_ - xf[2]);
-                fo = (r.Q[0] * xd0 * xd0 + r.Q[1] * xd1 * xd1 + r.Q[2] * xd2 * xd2 + r.R[0] * v * v + r.R[1] * w * w) * (intf() ? d : T(1));
+                fo = (P.Q[0] * xd0 * xd0 + P.Q[1] * xd1 * xd1 + P.Q[2] * xd2 * xd2 + P.R[0] * v * v + P.R[1] * w * w) * (intf() ? d : T(1));
             }
             if (via()) { T vv, vg[3]; via_terms(r.k, x0_, x1_, x2_, vv, vg); fo += vv; }
             acc.mul(v - r.ulb[0]); acc.mul(r.uub[0] - v); acc.mul(w - r.ulb[1]); acc.mul(r.uub[1] - w);
@@ -935,9 +937,9 @@ struct IpmWave {
                 }
                 if (via()) { T vv; via_terms(k, F(L.X, 0, k), F(L.X, 1, k), F(L.X, 2, k), vv, gx); }
                 T osx = T(0), osy = T(0), ost = T(0);
-                if (L.M > 0 && k >= 1) {
+                if (nM() > 0 && k >= 1) {
                     const T px = F(L.X, 0, k), py = F(L.X, 1, k);
-                    for (int m = 0; m < L.M; ++m) {
+                    for (int m = 0; m < nM(); ++m) {
                         T g, a3[3], hk, h3[3], ad, hd[4];
                         if (!obst_row3(k, m, px, py, F(L.X, 2, k), g, a3, hk, h3, d, ad, hd)) continue;
                         const T ax = a3[0], ay = a3[1];
@@ -1044,7 +1046,7 @@ struct IpmWave {
         e.sum_bmult = wave_sum(sb);
         e.sum_mult = wave_sum(smult) + e.sum_bmult;
         e.theta = wave_sum(th);
-        if (L.M == 0 && cnt_bmult >= 0) { e.n_bmult = cnt_bmult; e.n_mult = cnt_mult; }      // without clearance rows the counts never change
+        if (nM() == 0 && cnt_bmult >= 0) { e.n_bmult = cnt_bmult; e.n_mult = cnt_mult; }      // without clearance rows the counts never change
         else {
             e.n_bmult = (int)wave_sum((T)nb);
             e.n_mult = (int)wave_sum((T)nm) + e.n_bmult;
@@ -1102,8 +1104,8 @@ struct IpmWave {
                 sp.gy[j] += sg * ybar; sp.gyl += sg * lim * ybar;
             }
             sp.oxx = sp.oxy = sp.oyy = sp.ogx = sp.ogy = T(0);
-            if (L.M > 0 && k >= 1 && k < n - 1) {
-                for (int m = 0; m < L.M; ++m) {
+            if (nM() > 0 && k >= 1 && k < n - 1) {
+                for (int m = 0; m < nM(); ++m) {
                     if (F(L.OI, m, k) < T(0)) continue;
                     const T s = F(L.OS, m, k), y = F(L.OY, m, k), g = F(L.OG, m, k);
                     const T ax = F(L.OAX, m, k), ay = F(L.OAY, m, k), hk = F(L.OHK, m, k);
@@ -1668,7 +1670,7 @@ struct IpmWave {
 #pragma unroll
         for (int i = 0; i < 5; ++i) M[i] = sm[a + 10 * i];
     }
-    __device__ __forceinline__ bool pit_enabled() const { return P.pit != 0 && L.n >= 40; }      // the hand-off tile (192 words) lives in DX | DU (5 n words), a saved tile pair (100 words) in 3 n words
+    __device__ __forceinline__ bool pit_enabled() const { return EXT < 2 && P.pit != 0 && L.n >= 40; }      // (EXT = 2, the cost variants: serial sweeps only -- register budget)      // the hand-off tile (192 words) lives in DX | DU (5 n words), a saved tile pair (100 words) in 3 n words
     // lane index that the optimiser must treat as unknown HERE: keeps the per-lane address arithmetic of a phase inside the phase (hoisted out of the
     // interior-point loop as loop invariants it would occupy registers for the whole solve)
     __device__ __forceinline__ int local_lane() const { int l = lane; asm volatile("" : "+v"(l)); return l; }
@@ -1852,16 +1854,15 @@ struct IpmWave {
             omp = sm[TB + 176 + c];
         }
         PIT_DBG_W("V3")
-        const CombLane cla = comb_lane(c, true, TB), clb = comb_lane(c, false, TB);
         const int lm = c < 6 ? c : 0;
         put_tile(2);
-        combine<true>(TB, pit_tile(2), cla, lm, Vp, Wp, omp, wpiv);
+        combine<true>(TB, pit_tile(2), comb_lane(c, true, TB), lm, Vp, Wp, omp, wpiv);      // (the per-lane constants are recomputed per step: cheaper than keeping them)
         PIT_DBG_W("V2")
         put_tile(1);
-        combine<false>(TB, pit_tile(1), clb, lm, Vp, Wp, omp, wpiv);
+        combine<false>(TB, pit_tile(1), comb_lane(c, false, TB), lm, Vp, Wp, omp, wpiv);
         PIT_DBG_W("V1")
         put_tile(0);
-        combine<true>(TB, pit_tile(0), cla, lm, Vp, Wp, omp, wpiv);
+        combine<true>(TB, pit_tile(0), comb_lane(c, true, TB), lm, Vp, Wp, omp, wpiv);
         PIT_DBG_W("V0")
 #ifdef MPC_PROFILE
         prof_setup += __builtin_readcyclecounter() - tp1;
@@ -2112,8 +2113,8 @@ struct IpmWave {
                 ftb(s, ds, tau, a_p);
                 ftb(y, dy, tau, a_d);
             }
-            if (L.M > 0 && k >= 1 && k < n - 1) {
-                for (int m = 0; m < L.M; ++m) {
+            if (nM() > 0 && k >= 1 && k < n - 1) {
+                for (int m = 0; m < nM(); ++m) {
                     if (F(L.OI, m, k) < T(0)) continue;
                     const T jdz = obst_jdz(k, m);
                     const T s = F(L.OS, m, k), y = F(L.OY, m, k);
@@ -2164,8 +2165,8 @@ struct IpmWave {
                 const T musn = mu * t_rcp(sn[q]);
                 yn[q] = t_min(t_max(yv, musn * (T(1) / kS)), kS * musn);
             }
-            if (L.M > 0 && k >= 1 && k < n - 1) {
-                for (int m = 0; m < L.M; ++m) {
+            if (nM() > 0 && k >= 1 && k < n - 1) {
+                for (int m = 0; m < nM(); ++m) {
                     if (F(L.OI, m, k) < T(0)) continue;
                     const T jdz = obst_jdz(k, m);
                     const T s = F(L.OS, m, k), y = F(L.OY, m, k);
@@ -2378,7 +2379,7 @@ struct IpmWave {
             for (int j = 0; j < 2; ++j) F(L.U, j, k) = push_interior(F(L.U, j, k), P.u_lb[j], P.u_ub[j]);
         if (lane == 0 && dtf()) SCL(SC_D) = push_interior(SCL(SC_D), P.dt_lb, P.dt_ub);
         sync();
-        if (L.M > 0) { rows_dropped = associate_obstacles(); sync(); }
+        if (nM() > 0) { rows_dropped = associate_obstacles(); sync(); }
         if (via()) { associate_via_points(); sync(); }
         const bool dual_ok = dual_in != nullptr && warm_guess && (int)dual_in[0] == n;       // same grid size as the solve that left the multipliers
         mu = dual_ok ? P.mu_init_dual : (warm_guess ? P.mu_init_warm : P.mu_init); rho = T(0); delta_last = T(0); fail0 = false;
@@ -2389,9 +2390,9 @@ struct IpmWave {
                 if (row_on(k, q)) { s = t_max(-row_val(L.U, d, k, q), Algo<T>::slack_push); y = mu / s; }
                 F(L.SR, q, k) = s; F(L.YR, q, k) = y;
             }
-            if (L.M > 0) {
+            if (nM() > 0) {
                 const T px = F(L.X, 0, k), py = F(L.X, 1, k);
-                for (int m = 0; m < L.M; ++m) {
+                for (int m = 0; m < nM(); ++m) {
                     T s = T(1), y = T(0), g, a3[3], hk, h3[3];
                     if (k >= 1 && k < n - 1) {
                         if (obst_row3(k, m, px, py, F(L.X, 2, k), g, a3, hk, h3, d)) { s = t_max(-g, Algo<T>::clearance_slack_push); y = mu / s; }
@@ -2477,7 +2478,13 @@ struct IpmWave {
                     rho = T(0);
                 } else break;
             }
+#ifdef MPC_ASM_MARK
+            asm volatile("; BARRIER_BEGIN");
+#endif
             MPC_TICK(1, stage_barrier_terms(); sync());
+#ifdef MPC_ASM_MARK
+            asm volatile("; BARRIER_END");
+#endif
             const T tau = t_max(Algo<T>::tau_min, T(1) - mu);
             if (mu != dc_mu) { dc_mu = mu; dc_val = nfix > 0 ? Algo<T>::delta_c * t_pow(mu, Algo<T>::kappa_c) : T(0); }   // pow() only when mu moved
             const T dc = dc_val;
@@ -2540,7 +2547,13 @@ struct IpmWave {
                         }
                     }
 #endif
+#ifdef MPC_ASM_MARK
+                    asm volatile("; POST_BEGIN");
+#endif
                     MPC_TICK(4, fw = post_pass(dd, nu, tau));
+#ifdef MPC_ASM_MARK
+                    asm volatile("; POST_END");
+#endif
                     good = fw.finite;
                     if (good) {
                         curv = -fw.hdz + fw.clam - dc * fw.nunu;
@@ -2611,7 +2624,13 @@ struct IpmWave {
             if (blockIdx.x == MPC_NANCHECK && lane == 0)
                 printf("   ls: it %d f %.6f -> %.6f theta_c %.3e alpha %.4f a_p %.4f a_d %.4f rho %.3e Dm %.4e hdz %.6e clam %.6e dz2 %.6e dphi %.6e\n", it, (double)fobj, (double)f_t, (double)th_t, (double)alpha, (double)fw.a_p, (double)fw.a_d, (double)rho, (double)Dm, (double)fw.hdz, (double)fw.clam, (double)fw.dz2, (double)fw.dphi);
 #endif
+#ifdef MPC_ASM_MARK
+            asm volatile("; ACCEPT_BEGIN");
+#endif
             MPC_TICK(7, accept(alpha, fw.a_d); sync());
+#ifdef MPC_ASM_MARK
+            asm volatile("; ACCEPT_END");
+#endif
             theta_c = th_t; fobj = f_t; logs_cur = lg_t;
             ++it;
         }

@@ -93,6 +93,20 @@ class BatchSolver:
         self._check(self._lib.mpc_reset(self._h))
 
     # ---- host buffers (numpy) ------------------------------------------------
+    def _pack_obstacles(self, obstacles, B):
+        O, V = int(self.cfg.max_obstacles), int(self.cfg.max_vertices)
+        no = np.ascontiguousarray(obstacles[0], dtype=np.int32)
+        nv = np.ascontiguousarray(obstacles[1], dtype=np.int32)
+        vv = _as_f64(obstacles[2], (B, O, V, 2))
+        rr = _as_f64(obstacles[3], (B, O)) if len(obstacles) > 3 and obstacles[3] is not None else None
+        vel = _as_f64(obstacles[4], (B, O, 2)) if len(obstacles) > 4 and obstacles[4] is not None else None
+        if no.shape != (B,) or nv.shape != (B, O):
+            raise ValueError("obstacle arrays have the wrong shape")
+        keep = (no, nv, vv, rr, vel)       # the arrays must outlive the call
+        ob = MpcObstacles(no.ctypes.data, nv.ctypes.data, vv.ctypes.data, rr.ctypes.data if rr is not None else None,
+                          vel.ctypes.data if vel is not None else None)
+        return ob, keep
+
     def solve(self, x0, xf, u_prev=None, dt_prev=None, init=None, obstacles=None) -> BatchResult:
         """One control cycle for B instances (Controller::step, src/controller.cpp:111-179).
         init = (x_init (B,n,3), u_init (B,n,2), dt_init (B,)) or None for the reference cold start.
@@ -113,25 +127,31 @@ class BatchSolver:
         do = np.empty(B)
         st = np.empty(B, dtype=np.int32)
         it = np.empty(B, dtype=np.int32)
-        ob = None
-        keep = None
-        if obstacles is not None:
-            O, V = int(self.cfg.max_obstacles), int(self.cfg.max_vertices)
-            no = np.ascontiguousarray(obstacles[0], dtype=np.int32)
-            nv = np.ascontiguousarray(obstacles[1], dtype=np.int32)
-            vv = _as_f64(obstacles[2], (B, O, V, 2))
-            rr = _as_f64(obstacles[3], (B, O)) if len(obstacles) > 3 and obstacles[3] is not None else None
-            vel = _as_f64(obstacles[4], (B, O, 2)) if len(obstacles) > 4 and obstacles[4] is not None else None
-            if no.shape != (B,) or nv.shape != (B, O):
-                raise ValueError("obstacle arrays have the wrong shape")
-            keep = (no, nv, vv, rr, vel)
-            ob = MpcObstacles(no.ctypes.data, nv.ctypes.data, vv.ctypes.data, rr.ctypes.data if rr is not None else None,
-                              vel.ctypes.data if vel is not None else None)
+        ob, keep = self._pack_obstacles(obstacles, B) if obstacles is not None else (None, None)
         rc = self._lib.mpc_solve_batch(self._h, B, _addr(x0), _addr(xf), _addr(u_prev), _addr(dt_prev), _addr(xi), _addr(ui),
                                        _addr(di), C.byref(ob) if ob is not None else None, _addr(xo), _addr(uo), _addr(do),
                                        _addr(st), _addr(it))
         self._check(rc)
         return BatchResult(xo, uo, do, st, it)
+
+    def step(self, x0, xf, u_prev=None, dt_prev=None, init=None, obstacles=None, outer_iterations=1, adapt=False, n_min=3, n_max=0, dt_hyst_ratio=0.1):
+        """One control cycle = `outer_iterations` x (grid update -> solve) in ONE call (mpc_step_batch: PredictiveController::step's outer OCP iterations,
+        src/controller.cpp:70-72,172, without a host round trip between them).  Returns (BatchResult of the last solve, grid sizes after the call)."""
+        B = int(np.asarray(x0).shape[0])
+        n = self.n
+        x0 = _as_f64(x0, (B, 3)); xf = _as_f64(xf, (B, 3))
+        u_prev = _as_f64(u_prev, (B, 2)) if u_prev is not None else None
+        dt_prev = _as_f64(dt_prev, (B,)) if dt_prev is not None else None
+        xi = ui = di = None
+        if init is not None:
+            xi, ui, di = _as_f64(init[0], (B, n, 3)), _as_f64(init[1], (B, n, 2)), _as_f64(init[2], (B,))
+        ob, keep = self._pack_obstacles(obstacles, B) if obstacles is not None else (None, None)
+        xo = np.zeros((B, n, 3)); uo = np.zeros((B, n, 2)); do = np.zeros(B); st = np.zeros(B, np.int32); it = np.zeros(B, np.int32); ng = np.zeros(B, np.int32)
+        rc = self._lib.mpc_step_batch(self._h, B, _addr(x0), _addr(xf), _addr(u_prev), _addr(dt_prev), _addr(xi), _addr(ui), _addr(di),
+                                      C.byref(ob) if ob is not None else None, int(outer_iterations), int(bool(adapt)), int(n_min), int(n_max if n_max > 0 else n),
+                                      float(dt_hyst_ratio), _addr(xo), _addr(uo), _addr(do), _addr(st), _addr(it), _addr(ng))
+        self._check(rc)
+        return BatchResult(xo, uo, do, st, it), ng
 
     # ---- device buffers (raw HBM addresses, e.g. torch tensors' data_ptr()) -----
     def solve_device(self, B: int, x0: int, xf: int, u_prev: Optional[int], dt_prev: Optional[int], x_init: Optional[int],

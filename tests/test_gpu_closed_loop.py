@@ -223,3 +223,40 @@ def test_config5_candidates_vs_oracle_rule_fp64_and_mixed(env, c_oracle):
         match, other = account(f"config 5 shape with candidates, {tag}", ocfg, inputs, r, (ox, ou, od, ost, oit))
         assert match.sum() > (0.9 if tag == "fp64" else 0.6) * B
         s.close()
+
+
+def test_step_batch_is_the_separate_calls_in_one(env):
+    """mpc_step_batch = PredictiveController::step's outer OCP iterations (src/controller.cpp:70-72,172) enqueued at once: three x (grid update -> solve)
+    of 96 car-like planners on the variable grid with adaptation give, bit for bit, what solve / grid update / solve / grid update / solve give through the
+    separate entry points -- trajectories, dt, status, iteration counts of the last solve and the adapted grid sizes."""
+    m, torch = env
+    dev = torch.device("cuda", 0)
+    B, n = 96, 30
+    x0, xf, up, dtp = m.workloads.carlike_min_time_inputs(B, seed=981, goal_range=(1.0, 4.0))
+    mk = lambda: m.BatchSolver(m.config_carlike_min_time(n), max_batch=B)
+    # one call
+    s1 = mk()
+    r1, ng1 = s1.step(x0, xf, up, dtp, outer_iterations=3, adapt=True, n_min=3, n_max=n, dt_hyst_ratio=0.1)
+    s1.close()
+    # separate calls (device entry points)
+    s2 = mk()
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d = [T(x0), T(xf), T(up), T(dtp)]
+    xo = torch.empty((B, n, 3), dtype=torch.float64, device=dev); uo = torch.empty((B, n, 2), dtype=torch.float64, device=dev)
+    do = torch.empty(B, dtype=torch.float64, device=dev); st = torch.empty(B, dtype=torch.int32, device=dev); it = torch.empty(B, dtype=torch.int32, device=dev)
+    args = (B, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr())
+    outs = (xo.data_ptr(), uo.data_ptr(), do.data_ptr(), st.data_ptr(), it.data_ptr())
+    s2.solve_device(*args, None, None, None, *outs)
+    for _ in range(2):
+        s2.grid_update_device(B, d[0].data_ptr(), xo.data_ptr(), uo.data_ptr(), do.data_ptr(), adapt=True, n_min=3, n_max=n, dt_hyst_ratio=0.1)
+        s2.solve_device(*args, xo.data_ptr(), uo.data_ptr(), do.data_ptr(), *outs)
+    s2.synchronize()
+    ng2 = s2.grid_sizes(B)
+    s2.close()
+    np.testing.assert_array_equal(ng1, ng2)
+    np.testing.assert_array_equal(r1.status, st.cpu().numpy()); np.testing.assert_array_equal(r1.iters, it.cpu().numpy())
+    np.testing.assert_array_equal(r1.dt, do.cpu().numpy())
+    for b in range(B):
+        k = int(ng1[b])
+        np.testing.assert_array_equal(r1.x[b, :k], xo[b, :k].cpu().numpy()); np.testing.assert_array_equal(r1.u[b, :k], uo[b, :k].cpu().numpy())
+    assert (ng1 != n).sum() > B // 4 and (r1.status == 0).mean() > 0.9          # the adaptation did something, the last solves converged
