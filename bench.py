@@ -5,12 +5,17 @@ One "step" = one pass of the hot path (a full batched NLP solve, cold start exac
 candidate initial trajectories of DESIGN.md section 5.4 hedging the slow instances) over one batch of synthetic planner inputs that are
 already resident in HBM.
 
-  N = 1   workload = BASELINE.json configs[1]: 1024 instances on the GPU.  The same line carries, as extra legs measured after the
-          timed region: the warm-started cycle, configs[2] (unicycle n=80, 16 polygons, B=4096), the per-GPU shares of configs[3]
-          (car-like n=50, B=4096) and configs[4] (bicycle n=120 fp32, B=1024), and the CPU baseline.
+  N = 1   workload = BASELINE.json configs[1]: 1024 instances on the GPU.  The same line carries the report on what the hedges cost in solution
+          quality (`solver.hedge_vs_reference_path`) and, as extra legs measured after the timed region: the operating point that keeps the
+          reference path's answer wherever that path converges (`reference_answer_first_caps_100`), the warm-started cycle, the per-GPU share of
+          configs[3] (car-like n=50, B=4096), configs[2] (unicycle n=80, 16 polygons, B=4096) on a placement where clearance rows bind and on one
+          where they stay inactive (with the share of instances that end with an active row), the per-GPU share of configs[4] (bicycle n=120,
+          B=1024) in MPC_MIXED -- the precision that meets the 1e-4 tolerance, hence the leg that counts -- and in plain fp32, the latency of one
+          instance at a time, and the CPU baseline.
   N > 1   workload = BASELINE.json configs[3]: 4096 instances per GPU (32768 at N=8), rank r draws its inputs from seed+r; no data-path
           collective inside the timed region.  After it, the per-rank results (status, dt, x -- device resident) are all-gathered over
-          RCCL so that every rank holds the whole job's answer; that exchange is timed separately and reported as `gather_ms`.
+          RCCL so that every rank holds the whole job's answer; that exchange is timed separately and reported as `gather_ms`.  The line
+          carries `per_gpu_reference` (the one-GPU figure of the same 4096-instance workload from the committed N = 1 line).
 
 `value` counts CONVERGED solves only (a Controller::step that returns false makes the planner reset and command zero,
 src/mpc_local_planner_ros.cpp:394-404); `value_all_solves` counts every instance.
