@@ -424,7 +424,13 @@ inline ParamStatus config_from_params(const ParamSource& p, mpc_config& c, Contr
 
 // Controller::configure(nh, ...) in one call: parameters -> mpc_config + facade options -> a configured facade.  `caps` fills in the capacities the
 // reference has no parameter for (max_obstacles, max_vertices, max_obstacle_rows, max_via_points; fields left at 0 keep their defaults).
-struct HandleCapacities { int max_obstacles = 0, max_vertices = 0, max_obstacle_rows = 0, max_via_points = 0; };
+struct HandleCapacities {
+    int max_obstacles = 0, max_vertices = 0, max_obstacle_rows = 0, max_via_points = 0;
+    // solver options the reference's parameter set has no key for (0 = the library's defaults): multipliers kept between solves (mpc_config.dual_warm_start: the grid update of a
+    // control cycle and the outer OCP iterations then start from the previous multipliers, as Ipopt does with warm_start_init_point) and the barrier starts of such solves
+    int dual_warm_start = 0;
+    double mu_init_warm = 0.0, mu_init_dual = 0.0;
+};
 inline ParamStatus configure_from_params(Controller& controller, const ParamSource& p, ParamReport& rep, const HandleCapacities& caps = HandleCapacities(),
                                          int device = 0, const std::vector<std::vector<double>>* costmap_footprint = nullptr, mpc_config* cfg_out = nullptr,
                                          ControllerOptions* options_out = nullptr) {
@@ -435,6 +441,9 @@ inline ParamStatus configure_from_params(Controller& controller, const ParamSour
     if (caps.max_obstacles > 0) { cfg.max_obstacles = caps.max_obstacles; cfg.max_vertices = caps.max_vertices > 0 ? caps.max_vertices : 1; }
     if (caps.max_obstacle_rows > 0) cfg.max_obstacle_rows = caps.max_obstacle_rows;
     if (caps.max_via_points > 0) cfg.max_via_points = caps.max_via_points;
+    if (caps.dual_warm_start) cfg.dual_warm_start = 1;
+    if (caps.mu_init_warm > 0) cfg.mu_init_warm = caps.mu_init_warm;
+    if (caps.mu_init_dual > 0) cfg.mu_init_dual = caps.mu_init_dual;
     if (cfg_out) *cfg_out = cfg;
     if (options_out) *options_out = opt;
     opt.apply(controller);                       // grid adaptation etc. BEFORE configure(): it sizes the handle for the largest grid

@@ -54,7 +54,9 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str |
     out = out or LIB_PATH                      # another `out` (+ extra_flags): an instrumented copy next to the product library (tests)
     objdir = os.path.join(CSRC, "_obj") if out == LIB_PATH else out + ".obj"
     os.makedirs(objdir, exist_ok=True)
-    base = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DMPC_SPLIT_BUILD"] + list(extra_flags)
+    # -disable-lsr: LLVM's loop strength reduction gives every LDS pointer of the (manually software-pipelined) stage loops two or three induction variables plus a
+    # re-materialised base; without it the loops keep the one pointer per stream the source has (headline kernel -3.8 %, profiles/r03_lsr_ab.log)
+    base = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-DMPC_SPLIT_BUILD", "-mllvm", "-disable-lsr"] + list(extra_flags)
     jobs = [(base + ["-c", os.path.join(CSRC, "mpc_capi.hip"), "-o", os.path.join(objdir, "mpc_capi.o")])]
     for t in ("double", "float"):
         for model in range(4):

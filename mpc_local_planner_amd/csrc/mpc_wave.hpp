@@ -49,12 +49,12 @@ struct WaveLayout {
     int OAD, OHXD, OHYD, OHDD, OHTD;              // dt parts when BOTH apply (dynamic obstacles + a turning footprint): gradient, hess [x dt, y dt, dt dt, theta dt]
     int GVEL;                                     // obstacle velocities (dynamic obstacles; 2 * OD words)
     int NV, VIA, VIDX;                            // via-points: capacity, poses (x, y, theta), attached grid point (-1 = skipped)
-    __host__ __device__ static WaveLayout make(int n, int M = 0, int O = 0, int V = 1, int ntrig = 4, int NV = 0, int MT = 0, int OD = 0, int nstg = NSTG_BASE, int MD = 0) {
-        WaveLayout L;
+    __host__ __device__ static constexpr WaveLayout make(int n, int M = 0, int O = 0, int V = 1, int ntrig = 4, int NV = 0, int MT = 0, int OD = 0, int nstg = NSTG_BASE, int MD = 0) {
+        WaveLayout L{};
         L.n = n;
         L.NS = n;
         int o = 0;
-        auto take = [&](int comps) { int b = o; o += comps * n; return b; };
+        auto take = [&o, n](int comps) constexpr { int b = o; o += comps * n; return b; };
         L.NTR = ntrig;
         L.X = take(3); L.U = take(2);
         L.LAM = take(3); L.LAMN = take(3);
@@ -78,6 +78,33 @@ struct WaveLayout {
         return L;
     }
 };
+
+// The same layout with every offset a COMPILE-TIME constant (only the instance's own grid size n stays a run-time value): the kernel instantiation for a fixed
+// stride NS, without clearance rows / via-points (IpmWave<..., NSC>).  With run-time offsets the ~45 layout words compete for the scalar registers (the headline
+// kernel spilled some 270 of them to VGPR lanes, a v_readlane per use) and every LDS access of the lane-parallel passes carries its address arithmetic; with
+// constants the offsets fold into the 16-bit immediates of the ds instructions.  Every field IS what make() returns for the same arguments (evaluated at compile time);
+// tests/test_gpu_parity.py::test_fixed_layout_kernel_equals_the_generic_kernel_bit_for_bit holds the two instantiations against each other.
+template <int NSC, int NTRIG, int NSTGW>
+struct FixedLayout {
+    int n;
+    static constexpr WaveLayout c() { return WaveLayout::make(NSC, 0, 0, 1, NTRIG, 0, 0, 0, NSTGW, 0); }
+    static constexpr int NS = NSC, NTR = NTRIG;
+    static constexpr int X = c().X, U = c().U, LAM = c().LAM, LAMN = c().LAMN, SR = c().SR, YR = c().YR, PL = c().PL, PU = c().PU, DX = c().DX, DU = c().DU, CC = c().CC,
+                         TRIG = c().TRIG, GAIN = c().GAIN, STG = c().STG, SC = c().SC, VP = c().VP, ZC = c().ZC, ZI = c().ZI, total = c().total;
+    static constexpr int M = 0, O = 0, V = 1, NV = 0;
+    static constexpr int OS = c().OS, OY = c().OY, OI = c().OI, OG = c().OG, OAX = c().OAX, OAY = c().OAY, OHK = c().OHK, GV = c().GV, GNV = c().GNV, GR = c().GR, GC = c().GC,
+                         OAT = c().OAT, OHXT = c().OHXT, OHYT = c().OHYT, OHTT = c().OHTT, OAD = c().OAD, OHXD = c().OHXD, OHYD = c().OHYD, OHDD = c().OHDD, OHTD = c().OHTD,
+                         GVEL = c().GVEL, VIA = c().VIA, VIDX = c().VIDX;
+    // does a run-time layout describe the same record?  (n and V -- the vertex capacity, unused without obstacles -- aside)
+    __host__ __device__ static bool matches(const WaveLayout& l) {
+        const WaveLayout f = c();
+        return l.NS == f.NS && l.NTR == f.NTR && l.M == 0 && l.O == 0 && l.NV == 0 && l.X == f.X && l.U == f.U && l.LAM == f.LAM && l.LAMN == f.LAMN && l.SR == f.SR && l.YR == f.YR &&
+               l.PL == f.PL && l.PU == f.PU && l.DX == f.DX && l.DU == f.DU && l.CC == f.CC && l.TRIG == f.TRIG && l.GAIN == f.GAIN && l.STG == f.STG && l.SC == f.SC && l.VP == f.VP &&
+               l.ZC == f.ZC && l.ZI == f.ZI && l.total == f.total;
+    }
+};
+template <int NSC, int NTRIG, int NSTGW> struct LayoutOf { using type = FixedLayout<NSC, NTRIG, NSTGW>; __host__ __device__ static type from(const WaveLayout& l) { return type{l.n}; } };
+template <int NTRIG, int NSTGW> struct LayoutOf<0, NTRIG, NSTGW> { using type = WaveLayout; __host__ __device__ static const WaveLayout& from(const WaveLayout& l) { return l; } };
 
 enum { SC_D = 0, SC_DT = 1, SC_DD = 2, SC_PDL = 3, SC_PDU = 4, SC_TS = 5, SC_TY = 6, SC_TG = 7, SC_TA = 8 /* 8..10 */ };
 
@@ -155,11 +182,17 @@ __device__ __forceinline__ float lane_bcast(float v, int src) {
 // EXT: 0 = headline instantiation, 1 = + the rarely used rows / terms / coupling slots, 2 = + the cost variants (off-diagonal weights, trapezoidal rule)
 // OBST = false compiles every clearance-row path out (solvers created without obstacles: the headline configurations): less code, and the two dozen layout
 // words of the obstacle arrays leave the scalar registers (the headline kernel spilled ~430 of them)
-template <typename T, int MODEL, int EXT = 1, bool OBST = true>
+// NSC > 0: the layout is a compile-time constant for the stride NS = NSC (FixedLayout; needs EXT == 0, OBST == false, no Crank-Nicolson trig words)
+template <typename T, int MODEL, int EXT = 1, bool OBST = true, int NSC = 0>
 struct IpmWave {
+    static constexpr int NSTG = EXT ? NSTG_EXT : NSTG_BASE;        // words per stage record
+    // trig-cache words per stage: sin, cos, steering term(s); Crank-Nicolson appends sin/cos of its second evaluation angle
+    static constexpr int NTRB = (MODEL == MODEL_KINEMATIC_BICYCLE || MODEL == MODEL_SIMPLE_CAR_FRONT) ? 4 : 3;
+    static_assert(NSC == 0 || (EXT == 0 && !OBST), "the fixed layout exists for the headline instantiation only");
+    using LayoutT = typename LayoutOf<NSC, NTRB, NSTG>::type;
     const Problem<T>& P;     // lives in LDS (copied once per workgroup): wave-uniform constants are fetched with
-    const WaveLayout L;      // broadcast ds_reads instead of being pinned in (and spilled from) scalar registers; the layout
-                             // (45 small ints, used by every accessor) is held by value = in scalar registers
+    const LayoutT L;         // broadcast ds_reads instead of being pinned in (and spilled from) scalar registers; the layout
+                             // (45 small ints, used by every accessor) is held by value = in scalar registers -- or is a compile-time constant (NSC > 0)
     T* sm;
     const int lane;
     T x0[3], xf[3], uprev[2], dtprev;
@@ -167,6 +200,7 @@ struct IpmWave {
     bool row0_on, fail0;
     bool warm_guess = false;     // the caller supplied an initial guess (second and later control cycles)
     mutable int cnt_mult = -1, cnt_bmult = -1;      // number of equality / bound multipliers (cached by kkt_pass)
+    mutable T inv_cnt_mult = T(1), inv_cnt_bmult = T(1);   // 1 / max(count, 1)
     int nvia = 0;   // via-points of this instance
     int flags;      // bits 0..2 xf_fixed, 3 dt_free, 4 quadratic objective, 5 has_Qf, 6..9 rate_on, 10 terminal ball, 11 via-points, 12 footprint that turns with the pose (line, two circles), 13 integral form with dt free, 14 dynamic obstacles: the problem record lives in LDS and every
                     // P.x costs a ds_read (+ wait) that the compiler cannot hoist over LDS stores; one scalar register holds the switches
@@ -181,20 +215,17 @@ struct IpmWave {
     const double* dual_in = nullptr;   // multipliers of this instance's last converged solve (handle state; dual_warm_start) or NULL
     const int* win_ptr = nullptr;
 
-    __device__ IpmWave(const Problem<T>& p, const WaveLayout& l, T* s, int ln) : P(p), L(l), sm(s), lane(ln) {}
+    __device__ IpmWave(const Problem<T>& p, const WaveLayout& l, T* s, int ln) : P(p), L(LayoutOf<NSC, NTRB, NSTG>::from(l)), sm(s), lane(ln) {}
 
     // ---- LDS accessors: component-major, stage-minor (conflict-free for lane == stage)
     __device__ __forceinline__ T& F(int base, int comp, int k) const { return sm[base + comp * L.NS + k]; }
     // stage-major records
     __device__ __forceinline__ T& G_(int i, int k) const { return sm[L.GAIN + k * NGAIN + i]; }
-    static constexpr int NSTG = EXT ? NSTG_EXT : NSTG_BASE;        // words per stage record
     static constexpr int NADDv = EXT ? (int)NADD : (int)NADD_BASE;
     __device__ __forceinline__ T& S_(int i, int k) const { return sm[L.STG + k * NSTG + i]; }
     __device__ __forceinline__ T& C_(int i, int k) const { return sm[L.CC + k * 3 + i]; }
     __device__ __forceinline__ T& SCL(int i) const { return sm[L.SC + i]; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
-    // trig-cache words per stage: sin, cos, steering term(s); Crank-Nicolson appends sin/cos of its second evaluation angle
-    static constexpr int NTRB = (MODEL == MODEL_KINEMATIC_BICYCLE || MODEL == MODEL_SIMPLE_CAR_FRONT) ? 4 : 3;
     __device__ __forceinline__ int nM() const { return OBST ? L.M : 0; }      // clearance rows per grid point
     __device__ __forceinline__ bool fx(int i) const { return (flags >> i) & 1; }
     __device__ __forceinline__ bool dtf() const { return (flags >> 3) & 1; }
@@ -253,7 +284,9 @@ struct IpmWave {
     __device__ __forceinline__ T row_val(int UB, T d, int r, int q) const {
         const int n = L.n, j = q & 1;
         T ur = r < n - 1 ? F(UB, j, r) : T(0);
-        T um = r > 0 ? F(UB, j, r - 1) : uprev[j];
+        const T up0 = uprev[0], up1 = uprev[1];      // (constant indices and a value select: a pointer select between LDS and this object would put the object into scratch memory)
+        T um = j ? up1 : up0;
+        if (r > 0) um = F(UB, j, r - 1);
         T dtp = r > 0 ? d : dtprev;
         return slot_sign<T>(q) * ((ur - um) - P.rate_lim[q] * dtp);
     }
@@ -379,7 +412,7 @@ struct IpmWave {
                 const T ax = v[2 * e], ay = v[2 * e + 1], cx = v[2 * e2], cy = v[2 * e2 + 1];
                 const T abx = cx - ax, aby = cy - ay;
                 const T sq = abx * abx + aby * aby;
-                T t = sq > T(0) ? ((px - ax) * abx + (py - ay) * aby) / sq : T(0);
+                T t = sq > T(0) ? ((px - ax) * abx + (py - ay) * aby) * t_rcp(sq) : T(0);
                 t = t_min(T(1), t_max(T(0), t));
                 const T qx = ax + t * abx, qy = ay + t * aby;
                 const T d2 = (px - qx) * (px - qx) + (py - qy) * (py - qy);
@@ -393,7 +426,7 @@ struct IpmWave {
         bool vert;
         const T best = obst_closest(px, py, j, bx, by, vert);
         const T dd = sqrt(best);
-        if (dd > T(0)) { nx = (px - bx) / dd; ny = (py - by) / dd; hk = vert ? T(1) / dd : T(0); }
+        if (dd > T(0)) { const T idd = t_rcp(dd); nx = (px - bx) * idd; ny = (py - by) * idd; hk = vert ? idd : T(0); }
         else { nx = T(0); ny = T(0); hk = T(0); }
         dist = dd - sm[L.GR + j];
     }
@@ -508,7 +541,7 @@ struct IpmWave {
             const T b0 = poly ? P.fp_poly[2 * e2] : P.fp_line[2], b1 = poly ? P.fp_poly[2 * e2 + 1] : P.fp_line[3];
             const T abx = b0 - a0, aby = b1 - a1;
             const T sq = abx * abx + aby * aby;
-            T te = sq > T(0) ? ((qx - a0) * abx + (qy - a1) * aby) / sq : T(0);
+            T te = sq > T(0) ? ((qx - a0) * abx + (qy - a1) * aby) * t_rcp(sq) : T(0);
             te = t_min(T(1), t_max(T(0), te));
             const T ex = qx - (a0 + te * abx), ey = qy - (a1 + te * aby);
             const T e2d = ex * ex + ey * ey;
@@ -520,7 +553,7 @@ struct IpmWave {
     __device__ __forceinline__ void fp_point_derivs(T s, T c, T qx, T qy, T dx, T dy, T t, T D, T a[3], T& hk, T h3[3]) const {
         T nx = T(0), ny = T(0);
         hk = T(0);
-        if (D > T(0)) { nx = dx / D; ny = dy / D; hk = (t > T(0) && t < T(1)) ? T(0) : T(1) / D; }
+        if (D > T(0)) { const T iD = t_rcp(D); nx = dx * iD; ny = dy * iD; hk = (t > T(0) && t < T(1)) ? T(0) : iD; }
         const T nw = nx * qy - ny * qx;                                   // n' dq/dtheta,  dq/dtheta = (qy, -qx)
         a[0] = c * nx - s * ny; a[1] = s * nx + c * ny; a[2] = -nw;        // -(Jq' n)
         const T hwx = hk * (qy - nx * nw), hwy = hk * (-qx - ny * nw);    // H_D dq/dtheta,  H_D = hk (I - n n')
@@ -587,7 +620,7 @@ struct IpmWave {
             best = DB;
             const T dd = sqrt(bestB);
             T nx = T(0), ny = T(0), ho = T(0);
-            if (dd > T(0)) { nx = (px + brx - bbx) / dd; ny = (py + bry - bby) / dd; ho = bvert ? T(1) / dd : T(0); }
+            if (dd > T(0)) { const T idd = t_rcp(dd); nx = (px + brx - bbx) * idd; ny = (py + bry - bby) * idd; ho = bvert ? idd : T(0); }
             const T wx = -bry, wy = brx, nw = nx * wx + ny * wy;         // w = dc/dtheta
             a[0] = -nx; a[1] = -ny; a[2] = -nw;
             hk = ho;
@@ -878,11 +911,13 @@ struct IpmWave {
     // ---------------------------------------------------------------- KKT error + stage records
     struct Err { T rd, rp, cmin, cmax, sum_mult, sum_bmult, theta; int n_mult, n_bmult; };
 
+    // Ipopt's scaled optimality error E_mu.  (reciprocals instead of IEEE divisions -- ~100 ticks each for a lone wave --: 1/count is cached with the counts,
+    // 1/s_max is a constant, the two scalings are inverted once per call)
     __device__ __forceinline__ T err_value(const Err& e, T mu_t) const {
-        T sd = t_max(Algo<T>::s_max, e.sum_mult / T(e.n_mult > 0 ? e.n_mult : 1)) / Algo<T>::s_max;
-        T sc = t_max(Algo<T>::s_max, e.sum_bmult / T(e.n_bmult > 0 ? e.n_bmult : 1)) / Algo<T>::s_max;
+        const T sd = t_max(Algo<T>::s_max, e.sum_mult * inv_cnt_mult) * (T(1) / Algo<T>::s_max);
+        const T sc = t_max(Algo<T>::s_max, e.sum_bmult * inv_cnt_bmult) * (T(1) / Algo<T>::s_max);
         T comp = e.n_bmult > 0 ? t_max(e.cmax - mu_t, mu_t - e.cmin) : T(0);
-        return t_max(e.rd / sd, t_max(e.rp, comp / sc));
+        return t_max(e.rd * t_rcp(sd), t_max(e.rp, comp * t_rcp(sc)));
     }
 
     // parallel: KKT error pieces (needs LAM of the neighbours) ; also writes the mu-independent part of STG
@@ -1051,6 +1086,7 @@ struct IpmWave {
             e.n_bmult = (int)wave_sum((T)nb);
             e.n_mult = (int)wave_sum((T)nm) + e.n_bmult;
             cnt_bmult = e.n_bmult; cnt_mult = e.n_mult;
+            inv_cnt_bmult = T(1) / T(e.n_bmult > 0 ? e.n_bmult : 1); inv_cnt_mult = T(1) / T(e.n_mult > 0 ? e.n_mult : 1);
         }
         return e;
     }
@@ -1109,8 +1145,9 @@ struct IpmWave {
                     if (F(L.OI, m, k) < T(0)) continue;
                     const T s = F(L.OS, m, k), y = F(L.OY, m, k), g = F(L.OG, m, k);
                     const T ax = F(L.OAX, m, k), ay = F(L.OAY, m, k), hk = F(L.OHK, m, k);
-                    const T sig = y / s;
-                    const T ybar = mu / s + sig * (g + s);
+                    const T is = t_rcp(s);
+                    const T sig = y * is;
+                    const T ybar = mu * is + sig * (g + s);
                     // hess(g) = -hk (I - a a')
                     sp.oxx += sig * ax * ax - y * hk * (T(1) - ax * ax);
                     sp.oxy += sig * ax * ay + y * hk * ax * ay;
@@ -1185,7 +1222,8 @@ struct IpmWave {
         if (ball()) {
             const T ts = SCL(SC_TS), tg = SCL(SC_TG);
             ty = SCL(SC_TY);
-            tsig = ty / ts; tyb = mu / ts + tsig * (tg + ts);
+            const T its = t_rcp(ts);
+            tsig = ty * its; tyb = mu * its + tsig * (tg + ts);
             ta[0] = SCL(SC_TA); ta[1] = SCL(SC_TA + 1); ta[2] = SCL(SC_TA + 2);
         }
         const T tac = c < 3 ? (c == 0 ? ta[0] : (c == 1 ? ta[1] : ta[2])) : T(0);
@@ -2001,35 +2039,37 @@ struct IpmWave {
     // ---------------------------------------------------------------- parallel post-processing of the step
     struct Fwd { T hdz, clam, dz2, dphi, a_p, a_d, dzmax, nunu; bool finite; };
 
-    __device__ __forceinline__ void ftb(T val, T dval, T tau, T& alpha) const {
-        if (dval < T(0)) { T a = -tau * val / dval; if (a < alpha) alpha = a; }
-    }
+    // fraction to the boundary: alpha = min(1, tau / max_i(-dval_i / val_i)).  The pass collects the largest ratio -dval / val (with the reciprocals of the slacks
+    // it holds anyway; one reciprocal per multiplier) and divides ONCE after the wave reduction, instead of one IEEE division per row and bound.
+    __device__ __forceinline__ void ftb_ratio(T ival, T dval, T& r) const { r = t_max(r, -dval * ival); }
+    __device__ __forceinline__ T ftb_alpha(T r, T tau) const { return r > tau ? tau / r : T(1); }
 
     __device__ __forceinline__ Fwd post_pass(T dd, const T nu[3], T tau) const {
         const int n = L.n;
         const T d = SCL(SC_D);
-        T hdz = T(0), clam = T(0), dz2 = T(0), dphi = T(0), a_p = T(1), a_d = T(1), dzmax = T(0);
-        bool fin = true;
+        T hdz = T(0), clam = T(0), dz2 = T(0), dphi = T(0), r_p = T(0), r_d = T(0), dzmax = T(0);
         if (lane == 0) {
             if (dtf()) {
                 T dl = d - P.dt_lb, du = P.dt_ub - d;
                 T pl = SCL(SC_PDL), pu = SCL(SC_PDU);
-                T gb = -mu / dl + mu / du;
+                const T idl = t_rcp(dl), idu = t_rcp(du);
+                T gb = -mu * idl + mu * idu;
                 hdz += gb * dd; dphi += gb * dd;
-                ftb(dl, dd, tau, a_p); ftb(du, -dd, tau, a_p);
-                ftb(pl, mu / dl - pl - (pl / dl) * dd, tau, a_d);
-                ftb(pu, mu / du - pu + (pu / du) * dd, tau, a_d);
+                ftb_ratio(idl, dd, r_p); ftb_ratio(idu, -dd, r_p);
+                ftb_ratio(t_rcp(pl), mu * idl - pl - (pl * idl) * dd, r_d);
+                ftb_ratio(t_rcp(pu), mu * idu - pu + (pu * idu) * dd, r_d);
                 dz2 += dd * dd; dzmax = t_max(dzmax, t_abs(dd));
             }
             if (mintime()) { hdz += T(n - 1) * dd; dphi += T(n - 1) * dd; }
             if (ball()) {
                 const T jdz = ball_jdz(), s = SCL(SC_TS), y = SCL(SC_TY), res = SCL(SC_TG) + s;
-                const T sig = y / s, ybar = mu / s + sig * res;
+                const T is = t_rcp(s);
+                const T sig = y * is, ybar = mu * is + sig * res;
                 const T ds = -res - jdz, dy = ybar + sig * jdz - y;
                 hdz += ybar * jdz;
-                dphi -= (mu / s) * ds;
-                ftb(s, ds, tau, a_p);
-                ftb(y, dy, tau, a_d);
+                dphi -= (mu * is) * ds;
+                ftb_ratio(is, ds, r_p);
+                ftb_ratio(t_rcp(y), dy, r_d);
             }
         }
         for (int k = lane; k < n; k += kWave) {
@@ -2042,15 +2082,13 @@ struct IpmWave {
                     T gbar = mu * idu - mu * idl + (quad() ? T(2) * P.R[j] * u * (intf() ? d : T(1)) : T(0));   // barrier (+ objective) gradient wrt u
                     if (costx() && quad()) gbar += T(2) * P.Ro * F(L.U, 1 - j, k) * (intf() ? d : T(1));
                     hdz += gbar * du_; dphi += gbar * du_;
-                    ftb(dl, du_, tau, a_p); ftb(du, -du_, tau, a_p);
-                    ftb(pl, mu * idl - pl - (pl * idl) * du_, tau, a_d);
-                    ftb(pu, mu * idu - pu + (pu * idu) * du_, tau, a_d);
+                    ftb_ratio(idl, du_, r_p); ftb_ratio(idu, -du_, r_p);
+                    ftb_ratio(t_rcp(pl), mu * idl - pl - (pl * idl) * du_, r_d);
+                    ftb_ratio(t_rcp(pu), mu * idu - pu + (pu * idu) * du_, r_d);
                     dz2 += du_ * du_; dzmax = t_max(dzmax, t_abs(du_));
                 }
                 for (int i = 0; i < 3; ++i) {
-                    T l = F(L.LAMN, i, k);
-                    clam += C_(i, k) * l;
-                    if (!t_finite(l)) fin = false;
+                    clam += C_(i, k) * F(L.LAMN, i, k);        // (a non-finite multiplier makes this sum non-finite: tested below)
                 }
                 if (intf()) {       // d/ddt of the integral-form stage cost
                     const T xd0 = F(L.X, 0, k) - xf[0], xd1 = F(L.X, 1, k) - xf[1], xd2 = normalize_theta(F(L.X, 2, k) - xf[2]);
@@ -2110,8 +2148,8 @@ struct IpmWave {
                 T dy = ybar + sig * jdz - y;
                 hdz += ybar * jdz;
                 dphi -= (mu * is) * ds;
-                ftb(s, ds, tau, a_p);
-                ftb(y, dy, tau, a_d);
+                ftb_ratio(is, ds, r_p);
+                ftb_ratio(t_rcp(y), dy, r_d);
             }
             if (nM() > 0 && k >= 1 && k < n - 1) {
                 for (int m = 0; m < nM(); ++m) {
@@ -2119,23 +2157,24 @@ struct IpmWave {
                     const T jdz = obst_jdz(k, m);
                     const T s = F(L.OS, m, k), y = F(L.OY, m, k);
                     const T res = F(L.OG, m, k) + s;
-                    const T sig = y / s;
-                    const T ybar = mu / s + sig * res;
+                    const T is = t_rcp(s);
+                    const T sig = y * is;
+                    const T ybar = mu * is + sig * res;
                     const T ds = -res - jdz;
                     const T dy = ybar + sig * jdz - y;
                     hdz += ybar * jdz;
-                    dphi -= (mu / s) * ds;
-                    ftb(s, ds, tau, a_p);
-                    ftb(y, dy, tau, a_d);
+                    dphi -= (mu * is) * ds;
+                    ftb_ratio(is, ds, r_p);
+                    ftb_ratio(t_rcp(y), dy, r_d);
                 }
             }
         }
         Fwd o;
         o.hdz = wave_sum(hdz); o.clam = wave_sum(clam); o.dz2 = wave_sum(dz2); o.dphi = wave_sum(dphi);
-        o.a_p = wave_min(a_p); o.a_d = wave_min(a_d); o.dzmax = wave_max(dzmax);
+        o.a_p = ftb_alpha(wave_max(r_p), tau); o.a_d = ftb_alpha(wave_max(r_d), tau); o.dzmax = wave_max(dzmax);
         o.nunu = T(0);
         for (int i = 0; i < 3; ++i) if (fx(i)) o.nunu += nu[i] * nu[i];
-        o.finite = (wave_min(fin ? T(1) : T(0)) > T(0.5)) && t_finite(o.hdz) && t_finite(o.dz2);
+        o.finite = t_finite(o.hdz) && t_finite(o.dz2) && t_finite(o.clam);
         return o;
     }
 
@@ -2171,10 +2210,12 @@ struct IpmWave {
                     const T jdz = obst_jdz(k, m);
                     const T s = F(L.OS, m, k), y = F(L.OY, m, k);
                     const T res = F(L.OG, m, k) + s;
-                    const T sig = y / s;
+                    const T is = t_rcp(s);
+                    const T sig = y * is;
                     const T so = s + alpha * (-res - jdz);
-                    T yo = y + a_d * (mu / s + sig * res + sig * jdz - y);
-                    yo = t_min(t_max(yo, mu / (kS * so)), kS * mu / so);
+                    T yo = y + a_d * (mu * is + sig * res + sig * jdz - y);
+                    const T muso = mu * t_rcp(so);
+                    yo = t_min(t_max(yo, muso * (T(1) / kS)), kS * muso);
                     F(L.OS, m, k) = so; F(L.OY, m, k) = yo;
                 }
             }
@@ -2208,18 +2249,20 @@ struct IpmWave {
             if (dtf()) {
                 T dl = d_old - P.dt_lb, du = P.dt_ub - d_old;
                 T pl = SCL(SC_PDL), pu = SCL(SC_PDU);
-                T pln = pl + a_d * (mu / dl - pl - (pl / dl) * dd);
-                T pun = pu + a_d * (mu / du - pu + (pu / du) * dd);
-                T dln = d_new - P.dt_lb, dun = P.dt_ub - d_new;
-                SCL(SC_PDL) = t_min(t_max(pln, mu / (kS * dln)), kS * mu / dln);
-                SCL(SC_PDU) = t_min(t_max(pun, mu / (kS * dun)), kS * mu / dun);
+                const T idl = t_rcp(dl), idu = t_rcp(du);
+                T pln = pl + a_d * (mu * idl - pl - (pl * idl) * dd);
+                T pun = pu + a_d * (mu * idu - pu + (pu * idu) * dd);
+                const T mdl = mu * t_rcp(d_new - P.dt_lb), mdu = mu * t_rcp(P.dt_ub - d_new);
+                SCL(SC_PDL) = t_min(t_max(pln, mdl * (T(1) / kS)), kS * mdl);
+                SCL(SC_PDU) = t_min(t_max(pun, mdu * (T(1) / kS)), kS * mdu);
             }
             SCL(SC_D) = d_new;
             if (ball()) {        // from the caches of the OLD point (value, gradient) and the step
-                const T jdz = ball_jdz(), s = SCL(SC_TS), y = SCL(SC_TY), res = SCL(SC_TG) + s, sig = y / s;
+                const T jdz = ball_jdz(), s = SCL(SC_TS), y = SCL(SC_TY), res = SCL(SC_TG) + s, is = t_rcp(s), sig = y * is;
                 const T so = s + alpha * (-res - jdz);
-                T yo = y + a_d * (mu / s + sig * res + sig * jdz - y);
-                yo = t_min(t_max(yo, mu / (kS * so)), kS * mu / so);
+                T yo = y + a_d * (mu * is + sig * res + sig * jdz - y);
+                const T muso = mu * t_rcp(so);
+                yo = t_min(t_max(yo, muso * (T(1) / kS)), kS * muso);
                 SCL(SC_TS) = so; SCL(SC_TY) = yo;
             }
         }

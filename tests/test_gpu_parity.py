@@ -433,6 +433,26 @@ def test_mixed_grid_sizes_in_one_batch(m):
     s.close()
 
 
+def test_fixed_layout_kernel_equals_the_generic_kernel_bit_for_bit(m):
+    """The fp64 headline kernel has an instantiation whose LDS layout is a compile-time constant for records of 50 grid points (mpc_wave.hpp::FixedLayout,
+    picked by launch_solve when the handle's layout matches).  Same code, same arithmetic: a handle created for n = 51 with every instance set to 50 grid
+    points runs the GENERIC kernel on the same problems and must return the same trajectories, controls, dt, statuses and iteration counts bit for bit --
+    with one candidate and with the hedged candidates of the headline run."""
+    B = 1024
+    inp = m.workloads.carlike_min_time_inputs(B, seed=20260924)
+    for kw in (dict(), dict(candidates=(0, 5, 5, 7), candidate_max_iter=(60, 45, 40, 35), candidate_param=(0.0, 2.0, 3.0, 1.5))):
+        a = m.BatchSolver(m.config_carlike_min_time(50, **kw), max_batch=B)
+        ra = a.solve(*inp)
+        a.close()
+        b = m.BatchSolver(m.config_carlike_min_time(51, **kw), max_batch=B)
+        b.set_grid_sizes(np.full(B, 50, dtype=np.int32))
+        rb = b.solve(*inp)
+        b.close()
+        assert (ra.status == 0).mean() > 0.9
+        assert np.array_equal(ra.status, rb.status) and np.array_equal(ra.iters, rb.iters) and np.array_equal(ra.dt, rb.dt)
+        assert np.array_equal(ra.x, rb.x[:, :50]) and np.array_equal(ra.u[:, :49], rb.u[:, :49])
+
+
 def test_integral_form_fixed_grid_golden(m):
     """quadratic INTEGRAL-form cost (quadratic_cost_se2.cpp:54-83) on the fixed-dt grid (weights x dt); the variable-grid case is test_integral_form_free_dt_golden."""
     g = np.load(os.path.join(GOLD, "unicycle_quadratic_integral_n20.npz"))

@@ -38,12 +38,18 @@ def test_plugin_on_hip_library_exports_the_entry_points():
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(LIB), reason="oracle/_ref/libmpc_plugin_on_hip.so is built where the reference tree is (make -C oracle ref)")
-def test_reference_plugin_drives_the_robot_with_the_gpu_solver():
+@pytest.mark.parametrize("dual_warm_start", [False, True])
+def test_reference_plugin_drives_the_robot_with_the_gpu_solver(dual_warm_start):
     """initialize() with the car-like example parameters, setPlan(), then 80 x computeVelocityCommands() in closed loop with a simple-car plant: every command comes from a
-    solve on the GPU; the robot follows the plan around the costmap's obstacles, the commands respect the control bounds, the plugin reports SUCCESS"""
+    solve on the GPU; the robot follows the plan around the costmap's obstacles, the commands respect the control bounds, the plugin reports SUCCESS.
+    dual_warm_start: the binding's optional parameter mpc_hip/dual_warm_start -- the multipliers of the last converged solve are kept in the handle, so the second and third
+    outer iteration of a cycle (and the first solve of the next cycle) start from them at a barrier of 1e-3 instead of from scratch at 0.1, as Ipopt does with
+    warm_start_init_point: same closed-loop behaviour asserted, fewer iterations per cycle (the wall time per cycle is printed)."""
     import configure_cases
     from oracle import ref_lib as RL
     prm = configure_cases.base_carlike()
+    if dual_warm_start:
+        prm["mpc_hip"] = {"dual_warm_start": True}
     prm["footprint_model"] = {"type": "line", "line_start": [0.0, 0.0], "line_end": [0.4, 0.0]}
     prm["controller"]["outer_ocp_iterations"] = 3
     rng = np.random.default_rng(11)
@@ -81,7 +87,7 @@ def test_reference_plugin_drives_the_robot_with_the_gpu_solver():
         if o["goal_reached"]:
             break
     cmds = np.array(cmds)
-    print(f"reference plugin on the GPU solver: {len(codes)} cycles, {codes.count(0)} SUCCESS, final pose {np.round(pose, 3)}, min clearance {min(clearance):.3f} m, "
+    print(f"reference plugin on the GPU solver (mpc_hip/dual_warm_start {dual_warm_start}): {len(codes)} cycles, {codes.count(0)} SUCCESS, final pose {np.round(pose, 3)}, min clearance {min(clearance):.3f} m, "
           f"max distance from the plan {max(track):.3f} m, computeVelocityCommands wall time median {1e3 * np.median(wall):.2f} ms / max {1e3 * max(wall):.2f} ms "
           f"(3 outer iterations = 3 solves per cycle, 12 point obstacles, host side = the stand-ins)")
     assert codes.count(0) >= int(0.9 * len(codes)), codes
