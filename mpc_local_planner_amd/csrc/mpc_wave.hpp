@@ -131,18 +131,19 @@ constexpr unsigned long long stage_add_row(int r, bool ext) {
 }
 
 
-// ---- wavefront reductions on the DPP path (row rotations inside each 16-lane row, then 4 v_readlane), no LDS traffic:
-//      ~25 VALU instructions per fp64 reduction instead of 12 ds_bpermute round trips.  Result is wave-uniform.
-template <int CTRL> __device__ __forceinline__ double dpp_mov(double v) {
+// ---- wavefront reductions on the DPP path, no LDS traffic: row rotations inside each 16-lane row (row_ror 8, 4, 2, 1: every lane of a row then holds the row's
+//      reduction), row_bcast:15 into rows 1 and 3, row_bcast:31 into row 3, and ONE v_readlane pair of lane 63: 20 VALU instructions per fp64 reduction, wave-uniform
+//      result.  The moves name no "old" value (an undefined register: every lane that is read later is written), which spares a copy per move; row 3 ends up with
+//      (r3 + r2) + (r1 + r0) -- the association the earlier readlane version had.
+__device__ __forceinline__ int undef_vgpr() { int x; asm volatile("" : "=v"(x)); return x; }
+template <int CTRL, int ROWS = 0xf> __device__ __forceinline__ double dpp_mov(double v) {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+    lo = __builtin_amdgcn_update_dpp(undef_vgpr(), lo, CTRL, ROWS, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(undef_vgpr(), hi, CTRL, ROWS, 0xf, false);
     return __hiloint2double(hi, lo);
 }
-template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
-    int x = __float_as_int(v);
-    x = __builtin_amdgcn_update_dpp(x, x, CTRL, 0xf, 0xf, false);
-    return __int_as_float(x);
+template <int CTRL, int ROWS = 0xf> __device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(undef_vgpr(), __float_as_int(v), CTRL, ROWS, 0xf, false));
 }
 __device__ __forceinline__ double rd_lane(double v, int src) {
     int lo = __builtin_amdgcn_readlane(__double2loint(v), src), hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
@@ -160,8 +161,9 @@ template <typename Op, typename T> __device__ __forceinline__ T wave_reduce(T v)
     v = Op::f(v, dpp_mov<0x124>(v));
     v = Op::f(v, dpp_mov<0x122>(v));
     v = Op::f(v, dpp_mov<0x121>(v));
-    const T r0 = rd_lane(v, 0), r1 = rd_lane(v, 16), r2 = rd_lane(v, 32), r3 = rd_lane(v, 48);
-    return Op::f(Op::f(r0, r1), Op::f(r2, r3));
+    v = Op::f(v, dpp_mov<0x142, 0xa>(v));      // row_bcast:15 -> rows 1, 3 (the other rows' lanes are never read again)
+    v = Op::f(v, dpp_mov<0x143, 0x8>(v));      // row_bcast:31 -> row 3
+    return rd_lane(v, 63);
 }
 template <typename T> __device__ __forceinline__ T wave_sum(T v) { return wave_reduce<OpSum>(v); }
 template <typename T> __device__ __forceinline__ T wave_min(T v) { return wave_reduce<OpMin>(v); }
@@ -1853,8 +1855,14 @@ struct IpmWave {
         load_stage(Ga, Aa);
         int j = Lm;
         for (; j >= 3; j -= 2) {
+#ifdef MPC_ASM_MARK
+            asm volatile("; PIT_LOOP_BEGIN");
+#endif
             stage(dA0, dA1, dA2, T(0), Ga, Aa, Gb, Ab);
             stage(dA0, dA1, dA2, T(0), Gb, Ab, Ga, Aa);
+#ifdef MPC_ASM_MARK
+            asm volatile("; PIT_LOOP_END");
+#endif
         }
         if (j == 2) { stage(dA0, dA1, dA2, T(0), Ga, Aa, Gb, Ab); stage(dL0, dL1, dL2, s05, Gb, Ab, Ga, Aa); }
         else stage(dL0, dL1, dL2, s05, Ga, Aa, Gb, Ab);
@@ -1882,6 +1890,9 @@ struct IpmWave {
             sync();
         };
         T Vp[6], Wp[3], omp, wpiv = T(1);
+#ifdef MPC_ASM_MARK
+        asm volatile("; PIT_COMBINE_BEGIN");
+#endif
         put_tile(3);
         {
             const int cz = (c < 6 || (c >= 8 && c < 12)) ? c : 15;         // everything else reads the idle lane's zeros
@@ -1902,6 +1913,9 @@ struct IpmWave {
         put_tile(0);
         combine<true>(TB, pit_tile(0), comb_lane(c, true, TB), lm, Vp, Wp, omp, wpiv);
         PIT_DBG_W("V0")
+#ifdef MPC_ASM_MARK
+        asm volatile("; PIT_COMBINE_END");
+#endif
 #ifdef MPC_PROFILE
         prof_setup += __builtin_readcyclecounter() - tp1;
 #endif
