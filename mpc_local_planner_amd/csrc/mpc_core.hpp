@@ -123,6 +123,13 @@ MPC_HD double t_fmin(double a, double b) { return __builtin_fmin(a, b); }   // I
 MPC_HD float t_fmin(float a, float b) { return __builtin_fminf(a, b); }
 template <typename T> MPC_HD T t_max(T a, T b) { return a > b ? a : b; }
 template <typename T> MPC_HD T t_min(T a, T b) { return a < b ? a : b; }
+// floating point: IEEE maxNum / minNum -- ONE instruction (v_max_f64) where the compare-and-select form is a compare, a wait state and two v_cndmask per fp64 value.
+// Same value for ordered operands; a NaN operand is dropped (the select form kept a NaN in b and dropped one in a): non-finite iterates are caught through the sums
+// (theta, the step norms, the multiplier sums), which propagate them.
+MPC_HD double t_max(double a, double b) { return __builtin_fmax(a, b); }
+MPC_HD double t_min(double a, double b) { return __builtin_fmin(a, b); }
+MPC_HD float t_max(float a, float b) { return __builtin_fmaxf(a, b); }
+MPC_HD float t_min(float a, float b) { return __builtin_fminf(a, b); }
 MPC_HD double t_floor(double a) { return ::floor(a); }
 MPC_HD float t_floor(float a) { return ::floorf(a); }
 MPC_HD double t_log(double a) { return ::log(a); }
