@@ -208,7 +208,11 @@ template <typename T>
 MPC_HD T normalize_theta(T th) {
     const T pi = T(3.14159265358979323846);
     if (th >= -pi && th < pi) return th;
+#if defined(__HIP_DEVICE_COMPILE__)
+    T m = t_floor(th * T(0.15915494309189533577));      // (a multiple count that is off by one at an exact multiple of 2 pi is put right by the two corrections below; no IEEE division)
+#else
     T m = t_floor(th / (T(2) * pi));
+#endif
     th = th - m * T(2) * pi;
     if (th >= pi) th -= T(2) * pi;
     if (th < -pi) th += T(2) * pi;
