@@ -75,18 +75,23 @@ def obstacle_list(n_obstacles, n_vertices, vertices, radius=None, velocity=None)
 
 
 def _one(args):
-    ocfg, x0, xf, up, dtp, x, u, dt, obst, max_rows = args
+    ocfg, x0, xf, up, dtp, x, u, dt, obst, max_rows = args[:10]
+    start_x = args[10] if len(args) > 10 else None
     if obst is None:
         return kkt_residuals(ocfg, x0, xf, up, dtp, x, u, dt)
-    # clearance rows: the association is frozen on the trajectory the solve STARTS from (the cold start), as in the product
+    # clearance rows: the association is frozen on the trajectory the solve STARTS from, as in the reference (StageInequalitySE2::update runs in the grid update, before the solve)
+    # and in the product: the reference's cold start, or -- for an answer that a candidate initial trajectory supplied -- that candidate's seed (start_x, (n, 3))
     obs = obstacle_list(*obst)
-    rel, rel_dyn = R.associate_obstacles(ocfg, R.cold_start(ocfg, x0, xf), obs, max_rows)
+    start = R.cold_start(ocfg, x0, xf) if start_x is None else R.Trajectory(np.asarray(start_x, float), np.zeros((ocfg.n - 1, 2)), float(ocfg.dt_ref))
+    rel, rel_dyn = R.associate_obstacles(ocfg, start, obs, max_rows)
     return kkt_residuals(ocfg, x0, xf, up, dtp, x, u, dt, nlp_kwargs=dict(relevant=rel, relevant_dyn=rel_dyn), inp_kwargs=dict(obstacles=obs))
 
 
-def kkt_many(ocfg, x0, xf, u_prev, dt_prev, x, u, dt, idx, workers: int = 0, obstacles=None, max_rows=None):
+def kkt_many(ocfg, x0, xf, u_prev, dt_prev, x, u, dt, idx, workers: int = 0, obstacles=None, max_rows=None, start_x=None):
     """kkt_residuals for the instances `idx` of a batch, spread over worker processes (spawned: the caller may hold a GPU context).
-    obstacles = the ABI arrays (n_obstacles (B,), n_vertices (B,O), vertices (B,O,V,2)[, radius (B,O)[, velocity (B,O,2)]])."""
+    obstacles = the ABI arrays (n_obstacles (B,), n_vertices (B,O), vertices (B,O,V,2)[, radius (B,O)[, velocity (B,O,2)]]).
+    start_x (B, n, 3) or None: the state trajectories the solves started from, where that is not the reference's cold start (candidate initial
+    trajectories): the clearance rows of an instance are the ones associated on that trajectory."""
     import multiprocessing as mp
     import os
     idx = [int(i) for i in idx]
@@ -96,7 +101,7 @@ def kkt_many(ocfg, x0, xf, u_prev, dt_prev, x, u, dt, idx, workers: int = 0, obs
         if obstacles is None:
             return None
         return tuple(None if (k >= len(obstacles) or obstacles[k] is None) else obstacles[k][i] for k in range(5))
-    jobs = [(ocfg, x0[i], xf[i], u_prev[i], float(dt_prev[i]), x[i], u[i], float(dt[i]), ob(i), max_rows) for i in idx]
+    jobs = [(ocfg, x0[i], xf[i], u_prev[i], float(dt_prev[i]), x[i], u[i], float(dt[i]), ob(i), max_rows, None if start_x is None else start_x[i]) for i in idx]
     workers = workers or max(1, min(len(jobs), (os.cpu_count() or 2) // 2, 32))
     if workers == 1 or len(jobs) < 3:
         return dict(zip(idx, map(_one, jobs)))

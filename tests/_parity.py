@@ -2,7 +2,7 @@
 import numpy as np
 
 
-def account(tag, ocfg, inputs, r, oracle_out, tol=1e-4, obstacles=None, max_rows=None, kkt_tol=1e-6, min_match=0.7):
+def account(tag, ocfg, inputs, r, oracle_out, tol=1e-4, obstacles=None, max_rows=None, kkt_tol=1e-6, min_match=0.7, start_x=None):
     """Every converged device instance is either within `tol` of the C oracle's result (same KKT point: 'match') or is shown to be a
     KKT point of the reference-form NLP on its own (oracle/kkt_check.py: feasibility, stationarity and complementarity <= kkt_tol;
     'other_kkt': a line-search tie or a regularisation decision flipped and the iterate sequences parted ways, or another candidate
@@ -19,7 +19,9 @@ def account(tag, ocfg, inputs, r, oracle_out, tol=1e-4, obstacles=None, max_rows
     conv = r.status == 0
     match = conv & (st == 0) & (err < tol)
     rest = np.nonzero(conv & ~match)[0]
-    res = KC.kkt_many(ocfg, x0, xf, up, dtp, r.x, r.u, r.dt, rest, obstacles=obstacles, max_rows=max_rows)
+    # start_x: the state trajectories the answers' solves started from where that is not the reference's cold start (results of candidate initial trajectories with
+    # clearance rows: the rows of a solve are associated on the trajectory it starts from, in the reference as in the product)
+    res = KC.kkt_many(ocfg, x0, xf, up, dtp, r.x, r.u, r.dt, rest, obstacles=obstacles, max_rows=max_rows, start_x=start_x)
     good = lambda i: KC.is_kkt_point(res[i], kkt_tol, kkt_tol, kkt_tol)
     other = [i for i in rest if good(i)]
     bad = [i for i in rest if not good(i)]
