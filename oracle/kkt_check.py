@@ -105,5 +105,19 @@ def kkt_many(ocfg, x0, xf, u_prev, dt_prev, x, u, dt, idx, workers: int = 0, obs
     workers = workers or max(1, min(len(jobs), (os.cpu_count() or 2) // 2, 32))
     if workers == 1 or len(jobs) < 3:
         return dict(zip(idx, map(_one, jobs)))
-    with mp.get_context("spawn").Pool(workers) as pool:
-        return dict(zip(idx, pool.map(_one, jobs)))
+    # one BLAS / OpenMP thread per worker: the workers inherit the environment at spawn; 32 workers with a BLAS pool of one thread per core each (256 on the GPU boxes) spend
+    # their time fighting for the cores (measured: 170 - 220 s for 60 instances instead of ~10 s)
+    keys = ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")
+    saved = {k: os.environ.get(k) for k in keys}
+    try:
+        for k in keys:
+            os.environ[k] = "1"
+        pool = mp.get_context("spawn").Pool(workers)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    with pool:
+        return dict(zip(idx, pool.map(_one, jobs, chunksize=1)))
