@@ -100,14 +100,17 @@ def test_reference_plugin_drives_the_robot_with_the_gpu_solver(dual_warm_start):
 
 @pytest.mark.gpu
 @pytest.mark.skipif(not os.path.exists(LIB), reason="oracle/_ref/libmpc_plugin_on_hip.so is built where the reference tree is (make -C oracle ref)")
+@pytest.mark.parametrize("dual_warm_start", [False, True])
 @pytest.mark.parametrize("variant", ["via_points_polygon_footprint", "diff_drive_quadratic_form", "moving_obstacle_messages", "moving_obstacle_messages_two_circles_footprint"])
-def test_reference_plugin_on_the_gpu_solver_other_configurations(variant):
+def test_reference_plugin_on_the_gpu_solver_other_configurations(variant, dual_warm_start):
     """the same closed loop with (a) the via-point objective (via-points taken from the plan every 0.6 m) and a polygon footprint, (b) a differential-drive robot with the
     quadratic-form objective on the fixed grid and a free goal, (c) obstacle messages on the "obstacles" topic with collision_avoidance/enable_dynamic_obstacles: a moving circle, a moving line and a static polygon beside the path"""
     import configure_cases
     from oracle import ref_lib as RL
     prm = configure_cases.base_carlike()
     prm["controller"]["outer_ocp_iterations"] = 2
+    if dual_warm_start:        # the binding's optional parameter: multipliers kept between the solves of the controller (same assertions on the closed loop)
+        prm["mpc_hip"] = {"dual_warm_start": True}
     car, L = True, 0.4
     msgs = None
     if variant == "via_points_polygon_footprint":
@@ -152,7 +155,7 @@ def test_reference_plugin_on_the_gpu_solver_other_configurations(variant):
         vel = np.array([v, 0.0, w])
         track.append(np.hypot(plan[:, 0] - pose[0], plan[:, 1] - pose[1]).min())
     cmds = np.array(cmds)
-    print(f"{variant}: {codes.count(0)} / {len(codes)} SUCCESS, final pose {np.round(pose, 3)}, max distance from the plan {max(track):.3f} m, via-points per cycle {min(n_via)}..{max(n_via)}")
+    print(f"{variant} (mpc_hip/dual_warm_start {dual_warm_start}): {codes.count(0)} / {len(codes)} SUCCESS, final pose {np.round(pose, 3)}, max distance from the plan {max(track):.3f} m, via-points per cycle {min(n_via)}..{max(n_via)}")
     assert codes.count(0) >= int(0.85 * len(codes)), (codes, run.log()[-3:])
     assert pose[0] > 1.5 and max(track) < 1.0, (pose, max(track))
     assert cmds[:, 0].max() <= 0.4 + 1e-6 and cmds[:, 0].min() >= -0.2 - 1e-6 and np.abs(cmds[:, 2]).max() <= (1.4 if car else 0.3) + 1e-6
