@@ -190,11 +190,12 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
                                                    cfg->footprint_kind == MPC_FOOTPRINT_POLYGON || cfg->enable_dynamic_obstacles)) ? M : 0,
                                         (O > 0 && cfg->enable_dynamic_obstacles) ? O : 0, solver_ext(s) ? mpc::NSTG_EXT : mpc::NSTG_BASE,
                                         (O > 0 && cfg->enable_dynamic_obstacles && (cfg->footprint_kind == MPC_FOOTPRINT_LINE || cfg->footprint_kind == MPC_FOOTPRINT_TWO_CIRCLES ||
-                                                                                     cfg->footprint_kind == MPC_FOOTPRINT_POLYGON)) ? M : 0);
+                                                                                     cfg->footprint_kind == MPC_FOOTPRINT_POLYGON)) ? M : 0,
+                                        cfg->precision == MPC_FP32 ? 4 : 8);      // (MPC_MIXED has no clearance rows: both of its phases see the same layout)
     }
-    s->wave_lds32 = ((((size_t)s->WL.total * 4) + 15) & ~(size_t)15) + 16 + ((sizeof(mpc::Problem<float>) + 15) & ~(size_t)15) + sizeof(mpc::WaveLayout);
+    s->wave_lds32 = ((((size_t)s->WL.total * 4) + 15) & ~(size_t)15) + 16 + ((sizeof(mpc::Problem<float>) + 15) & ~(size_t)15);
     s->wave_lds = cfg->precision == MPC_FP32 ? s->wave_lds32
-                : ((((size_t)s->WL.total * 8) + 15) & ~(size_t)15) + 16 + ((sizeof(mpc::Problem<double>) + 15) & ~(size_t)15) + sizeof(mpc::WaveLayout);
+                : ((((size_t)s->WL.total * 8) + 15) & ~(size_t)15) + 16 + ((sizeof(mpc::Problem<double>) + 15) & ~(size_t)15);
     if (s->wave_lds > 160u * 1024u) {
         set_err("mpc_create: the working set of one instance (n, max_obstacles, max_vertices, precision) does not fit in the 160 KB of LDS "
                 "of a compute unit (about n <= 215 grid points in fp64 without obstacles)");

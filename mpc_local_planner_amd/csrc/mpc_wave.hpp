@@ -49,7 +49,8 @@ struct WaveLayout {
     int OAD, OHXD, OHYD, OHDD, OHTD;              // dt parts when BOTH apply (dynamic obstacles + a turning footprint): gradient, hess [x dt, y dt, dt dt, theta dt]
     int GVEL;                                     // obstacle velocities (dynamic obstacles; 2 * OD words)
     int NV, VIA, VIDX;                            // via-points: capacity, poses (x, y, theta), attached grid point (-1 = skipped)
-    __host__ __device__ static constexpr WaveLayout make(int n, int M = 0, int O = 0, int V = 1, int ntrig = 4, int NV = 0, int MT = 0, int OD = 0, int nstg = NSTG_BASE, int MD = 0) {
+    // tsize = sizeof(T) of the kernel that uses the layout (the obstacle indices of the clearance rows are 16-bit words, M * n of them, packed into T-sized words)
+    __host__ __device__ static constexpr WaveLayout make(int n, int M = 0, int O = 0, int V = 1, int ntrig = 4, int NV = 0, int MT = 0, int OD = 0, int nstg = NSTG_BASE, int MD = 0, int tsize = 8) {
         WaveLayout L{};
         L.n = n;
         L.NS = n;
@@ -68,7 +69,9 @@ struct WaveLayout {
         L.ZC = o; o += 8;     // constants 0 0 0 0 1 0 0 0 (coefficient triples of the constant columns)
         L.ZI = o; o += 12;    // constants 0 0 0 0 0 0 1 0 0 0 0 0: the unit vector e_c (6 words) starts at ZI + 6 - c, six zeros at ZI (partitioned sweep)
         L.M = M; L.O = O; L.V = V;
-        L.OS = take(M); L.OY = take(M); L.OI = take(M); L.OG = take(M); L.OAX = take(M); L.OAY = take(M); L.OHK = take(M);
+        L.OS = take(M); L.OY = take(M);
+        L.OI = o; o += (M * n * 2 + tsize - 1) / tsize;      // uint16 per row and grid point (0xffff = no row): a quarter of a T word each -- what lets BASELINE configs[2] (n = 80, 16 polygons) keep TWO workgroups per CU
+        L.OG = take(M); L.OAX = take(M); L.OAY = take(M); L.OHK = take(M);
         L.GV = o; o += 2 * O * V; L.GNV = o; o += O; L.GR = o; o += O; L.GC = o; o += 2 * O;
         L.NV = NV; L.VIA = o; o += 3 * NV; L.VIDX = o; o += NV;
         L.OAT = take(MT); L.OHXT = take(MT); L.OHYT = take(MT); L.OHTT = take(MT);
@@ -229,6 +232,10 @@ struct IpmWave {
     __device__ __forceinline__ T& SCL(int i) const { return sm[L.SC + i]; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
     __device__ __forceinline__ int nM() const { return OBST ? L.M : 0; }      // clearance rows per grid point
+    // obstacle index of clearance row m at grid point k (-1 = no row): 16-bit words, component-major like the T arrays
+    __device__ __forceinline__ unsigned short* oi_base() const { return reinterpret_cast<unsigned short*>(sm + L.OI); }
+    __device__ __forceinline__ int oi(int m, int k) const { const unsigned v = oi_base()[m * L.NS + k]; return v == 0xffffu ? -1 : (int)v; }
+    __device__ __forceinline__ void set_oi(int m, int k, int j) const { oi_base()[m * L.NS + k] = (unsigned short)(j < 0 ? 0xffff : j); }
     __device__ __forceinline__ bool fx(int i) const { return (flags >> i) & 1; }
     __device__ __forceinline__ bool dtf() const { return (flags >> 3) & 1; }
     __device__ __forceinline__ bool quad() const { return (flags >> 4) & 1; }
@@ -479,7 +486,7 @@ struct IpmWave {
         int dropped = 0;
         for (int k = lane; k < n; k += kWave) {
             int cnt = 0;
-            for (int m = 0; m < M; ++m) F(L.OI, m, k) = T(-1);
+            for (int m = 0; m < M; ++m) set_oi(m, k, -1);
             if (k >= 1) {
                 const T px = F(L.X, 0, k), py = F(L.X, 1, k), th = F(L.X, 2, k);
                 T s, c;
@@ -487,7 +494,7 @@ struct IpmWave {
                 T lmin = T(1e30), rmin = T(1e30);
                 int lidx = -1, ridx = -1, wanted = 0;
                 if (dynobs())        // every dynamic obstacle is kept at every grid point (:99-106)
-                    for (int j = 0; j < L.O; ++j) if ((int)sm[L.GNV + j] > 0 && is_dynamic(j)) { ++wanted; if (cnt < M) { F(L.OI, cnt, k) = T(j); ++cnt; } }
+                    for (int j = 0; j < L.O; ++j) if ((int)sm[L.GNV + j] > 0 && is_dynamic(j)) { ++wanted; if (cnt < M) { set_oi(cnt, k, j); ++cnt; } }
                 const int first_forced = cnt;
                 for (int j = 0; j < L.O; ++j) {
                     if ((int)sm[L.GNV + j] <= 0) continue;
@@ -497,14 +504,14 @@ struct IpmWave {
                     else { obst_eval(px, py, j, dist, nx, ny, hk); dist -= P.fp_radius; }
                     if (dist < P.force_incl) {
                         ++wanted;
-                        if (cnt < M) { F(L.OI, cnt, k) = T(j); F(L.OG, cnt, k) = dist; ++cnt; }       // OG doubles as the distance of a kept forced row
+                        if (cnt < M) { set_oi(cnt, k, j); F(L.OG, cnt, k) = dist; ++cnt; }       // OG doubles as the distance of a kept forced row
                         else if (first_forced < M) {
                             // full: the farthest forced row kept so far gives way if this obstacle is closer (the later ones keep their order)
                             int far = first_forced;
                             for (int m = first_forced + 1; m < M; ++m) if (F(L.OG, m, k) >= F(L.OG, far, k)) far = m;
                             if (dist < F(L.OG, far, k)) {
-                                for (int m = far; m + 1 < M; ++m) { F(L.OI, m, k) = F(L.OI, m + 1, k); F(L.OG, m, k) = F(L.OG, m + 1, k); }
-                                F(L.OI, M - 1, k) = T(j); F(L.OG, M - 1, k) = dist;
+                                for (int m = far; m + 1 < M; ++m) { set_oi(m, k, oi(m + 1, k)); F(L.OG, m, k) = F(L.OG, m + 1, k); }
+                                set_oi(M - 1, k, j); F(L.OG, M - 1, k) = dist;
                             }
                         }
                         continue;
@@ -514,8 +521,8 @@ struct IpmWave {
                     if (c * sm[L.GC + 2 * j + 1] - sm[L.GC + 2 * j] * s > T(0)) { if (dist < lmin) { lmin = dist; lidx = j; } }
                     else { if (dist < rmin) { rmin = dist; ridx = j; } }
                 }
-                if (lidx >= 0) { ++wanted; if (cnt < M) { F(L.OI, cnt, k) = T(lidx); ++cnt; } }
-                if (ridx >= 0) { ++wanted; if (cnt < M) { F(L.OI, cnt, k) = T(ridx); ++cnt; } }
+                if (lidx >= 0) { ++wanted; if (cnt < M) { set_oi(cnt, k, lidx); ++cnt; } }
+                if (ridx >= 0) { ++wanted; if (cnt < M) { set_oi(cnt, k, ridx); ++cnt; } }
                 if (k < n - 1) dropped += wanted - cnt;       // the final state carries no rows (finite_differences_grid_se2.cpp:47-56)
             }
         }
@@ -676,7 +683,7 @@ struct IpmWave {
 
     // value / gradient / curvature cache of the clearance rows of grid point k at position (px,py); returns row count
     __device__ __forceinline__ bool obst_row(int k, int m, T px, T py, T& g, T& ax, T& ay, T& hk) const {
-        const int j = (int)F(L.OI, m, k);
+        const int j = oi(m, k);
         if (j < 0) return false;
         T dist, nx, ny;
         obst_eval(px, py, j, dist, nx, ny, hk);
@@ -708,7 +715,7 @@ struct IpmWave {
     __device__ __forceinline__ bool obst_row3(int k, int m, T px, T py, T th, T& g, T a[3], T& hk, T h3[3], T d, T& ad, T hd[4]) const {
         ad = T(0); hd[0] = hd[1] = hd[2] = hd[3] = T(0);
         if (dynobs()) {
-            const int j = (int)F(L.OI, m, k);
+            const int j = oi(m, k);
             if (j < 0) return false;
             if (is_dynamic(j)) {
                 if (!fpline()) { dyn_row(k, j, px, py, d, g, a, hk, h3); return true; }
@@ -725,7 +732,7 @@ struct IpmWave {
             }
         }
         if (!fpline()) { a[2] = T(0); h3[0] = h3[1] = h3[2] = T(0); return obst_row(k, m, px, py, g, a[0], a[1], hk); }
-        const int j = (int)F(L.OI, m, k);
+        const int j = oi(m, k);
         if (j < 0) return false;
         g = P.d_min - turn_eval(px, py, th, j, a, hk, h3);
         return true;
@@ -821,7 +828,7 @@ struct IpmWave {
             }
             if (nM() > 0 && k >= 1 && k < n - 1) {
                 for (int m = 0; m < nM(); ++m) {
-                    if (F(L.OI, m, k) < T(0)) continue;
+                    if (oi(m, k) < 0) continue;
                     T s = F(L.OS, m, k);
                     if (trial) s += alpha * (-(F(L.OG, m, k) + s) - obst_jdz(k, m));
                     acc.mul(s);
@@ -1144,7 +1151,7 @@ struct IpmWave {
             sp.oxx = sp.oxy = sp.oyy = sp.ogx = sp.ogy = T(0);
             if (nM() > 0 && k >= 1 && k < n - 1) {
                 for (int m = 0; m < nM(); ++m) {
-                    if (F(L.OI, m, k) < T(0)) continue;
+                    if (oi(m, k) < 0) continue;
                     const T s = F(L.OS, m, k), y = F(L.OY, m, k), g = F(L.OG, m, k);
                     const T ax = F(L.OAX, m, k), ay = F(L.OAY, m, k), hk = F(L.OHK, m, k);
                     const T is = t_rcp(s);
@@ -2167,7 +2174,7 @@ struct IpmWave {
             }
             if (nM() > 0 && k >= 1 && k < n - 1) {
                 for (int m = 0; m < nM(); ++m) {
-                    if (F(L.OI, m, k) < T(0)) continue;
+                    if (oi(m, k) < 0) continue;
                     const T jdz = obst_jdz(k, m);
                     const T s = F(L.OS, m, k), y = F(L.OY, m, k);
                     const T res = F(L.OG, m, k) + s;
@@ -2220,7 +2227,7 @@ struct IpmWave {
             }
             if (nM() > 0 && k >= 1 && k < n - 1) {
                 for (int m = 0; m < nM(); ++m) {
-                    if (F(L.OI, m, k) < T(0)) continue;
+                    if (oi(m, k) < 0) continue;
                     const T jdz = obst_jdz(k, m);
                     const T s = F(L.OS, m, k), y = F(L.OY, m, k);
                     const T res = F(L.OG, m, k) + s;
@@ -2453,7 +2460,7 @@ struct IpmWave {
                     T s = T(1), y = T(0), g, a3[3], hk, h3[3];
                     if (k >= 1 && k < n - 1) {
                         if (obst_row3(k, m, px, py, F(L.X, 2, k), g, a3, hk, h3, d)) { s = t_max(-g, Algo<T>::clearance_slack_push); y = mu / s; }
-                    } else F(L.OI, m, k) = T(-1);
+                    } else set_oi(m, k, -1);
                     F(L.OS, m, k) = s; F(L.OY, m, k) = y;
                 }
             }
