@@ -190,7 +190,7 @@ def leg_summary(leg, steps, warmup, bytes_per_solve, flops_per_iter, peak_tf, tr
     gbs = bpl / (k_ms * 1e-3) / 1e9
     tf = B * s["iters_total_mean"] * flops_per_iter / (k_ms * 1e-3) / 1e12
     return {"value": B * s["converged_frac"] * steps / elapsed, "value_all_solves": B * steps / elapsed, "unit": "solves/s", "batch": B,
-            "ms_per_step": elapsed / steps * 1e3, "solver": s,
+            "ms_per_step": elapsed / steps * 1e3, "solver": s, "lds_bytes_per_instance": leg.solver.lds_bytes(), "workgroups_per_cu": (160 * 1024) // leg.solver.lds_bytes(),
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
                          "traffic": measured_traffic(traffic_key), "kernel": "mpc_ipm_wave_kernel", "kernel_ms": k_ms,
                          "algorithmic_bytes_per_launch": bpl,
@@ -314,6 +314,7 @@ def main():
                        "candidates": {"kinds": list(kinds), "max_iter": list(caps), "param": list(pars),
                                       "rule": "lowest-index candidate that converges within its cap supplies the result (index 0 = the reference cold start)"},
                        "parallelism": f"instances sharded over {world} GPU(s), no data-path collective in the timed region",
+                       "lds_bytes_per_instance": leg.solver.lds_bytes(), "workgroups_per_cu": (160 * 1024) // leg.solver.lds_bytes(),
                        "seed": m.workloads.SEED_CONFIG2},
             "solver": dict(sstat, converged_frac_job=conv_frac_job, last_step_reproduces_the_warmup_step_bit_for_bit=reproducible),
             "roofline": {"bound": "hbm", "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",

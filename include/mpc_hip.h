@@ -358,6 +358,11 @@ int mpc_synchronize(mpc_solver* s);
  * HIP events on the solver's own stream (call after mpc_synchronize). */
 int mpc_last_kernel_ms(mpc_solver* s, float* ms);
 
+/* Dynamic LDS bytes of one workgroup of the solve kernel for this handle = the whole working set of ONE planner instance (mpc_wave.hpp::WaveLayout + the problem
+ * record).  A compute unit of the MI355X has 160 KB: 163840 / bytes workgroups (one wavefront each) are resident per CU -- 4 at BASELINE configs[1] (n = 50, fp64), 2 at
+ * configs[2] (n = 80, 16 polygons, four clearance rows per grid point), 3 in the fp32 phase of configs[4] (n = 120). */
+int mpc_lds_bytes(const mpc_solver* s, int64_t* bytes);
+
 /* Human-readable text of the last HIP/runtime error on this thread ("" if none). */
 const char* mpc_last_error(void);
 

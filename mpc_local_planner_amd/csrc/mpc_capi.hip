@@ -633,6 +633,12 @@ int mpc_synchronize(mpc_solver* s) {
     return MPC_OK;
 }
 
+int mpc_lds_bytes(const mpc_solver* s, int64_t* bytes) {
+    if (!s || !bytes) return MPC_EINVAL;
+    *bytes = (int64_t)s->wave_lds;
+    return MPC_OK;
+}
+
 int mpc_last_kernel_ms(mpc_solver* s, float* ms) {
     if (!s || !ms) return MPC_EINVAL;
     if (!s->timed) { *ms = 0.f; return MPC_OK; }

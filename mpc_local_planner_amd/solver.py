@@ -240,6 +240,12 @@ class BatchSolver:
     def synchronize(self):
         self._check(self._lib.mpc_synchronize(self._h))
 
+    def lds_bytes(self) -> int:
+        """dynamic LDS of one workgroup of the solve kernel = the working set of one instance; 163840 // lds_bytes() workgroups are resident per compute unit"""
+        b = C.c_int64(0)
+        self._check(self._lib.mpc_lds_bytes(self._h, C.byref(b)))
+        return int(b.value)
+
     def last_kernel_ms(self) -> float:
         ms = C.c_float(0)
         self._check(self._lib.mpc_last_kernel_ms(self._h, C.byref(ms)))

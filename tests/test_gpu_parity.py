@@ -433,6 +433,24 @@ def test_mixed_grid_sizes_in_one_batch(m):
     s.close()
 
 
+def test_lds_working_set_and_workgroups_per_cu_of_the_baseline_configs(m):
+    """mpc_lds_bytes: the working set of one instance = the dynamic LDS of its workgroup; what the 160 KB of a compute unit hold decides how many wavefronts a CU
+    runs: 4 at BASELINE configs[1] / [3] (n = 50, fp64), 2 at configs[2] (n = 80, 16 polygons of 6 vertices, four clearance rows per grid point: since the rows'
+    obstacle indices are 16-bit words; 1 before), 3 in plain fp32 at configs[4] (n = 120), 2 for n = 80 without obstacles."""
+    CU = 160 * 1024
+    def wgs(cfg):
+        s = m.BatchSolver(cfg, max_batch=4)
+        b = s.lds_bytes()
+        s.close()
+        return CU // b, b
+    assert wgs(m.config_carlike_min_time(50))[0] == 4
+    w3, b3 = wgs(m.config_unicycle_quadratic(80, max_obstacles=16, max_vertices=6, max_obstacle_rows=4))
+    assert w3 == 2, b3
+    assert wgs(m.config_unicycle_quadratic(80))[0] == 2
+    assert wgs(m.config_bicycle_min_time(120, precision=1, tol=1e-4))[0] == 3
+    assert wgs(m.config_bicycle_min_time(120))[0] == 1
+
+
 def test_fixed_layout_kernel_equals_the_generic_kernel_bit_for_bit(m):
     """The fp64 headline kernel has an instantiation whose LDS layout is a compile-time constant for records of 50 grid points (mpc_wave.hpp::FixedLayout,
     picked by launch_solve when the handle's layout matches).  Same code, same arithmetic: a handle created for n = 51 with every instance set to 50 grid
