@@ -37,6 +37,7 @@
  * defect), rate rows multiplied by dt_prev.
  */
 #include <math.h>
+#include <stdio.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -79,6 +80,7 @@ typedef struct oracle_config {
                                  * SolverIpopt; corbo: success iff Converged or EarlyTerminated): 0 -> Ipopt's default 1e-6, < 0 -> rule off.  Same meaning
                                  * as mpc_config.acceptable_tol (include/mpc_hip.h) */
     int32_t acceptable_iter;    /* iterations in a row at that level that end the solve with status 0: 0 -> Ipopt's default 15, < 0 -> off */
+    int32_t mu_strategy;        /* 0 adaptive (the default; see solve_one), 1 monotone Fiacco-McCormick -- mpc_config.mu_strategy */
 } oracle_config;
 static inline double acc_tol_of(const oracle_config* c) { return c->acceptable_tol > 0 ? c->acceptable_tol : (c->acceptable_tol < 0 ? 0.0 : 1e-6); }
 static inline int acc_iter_of(const oracle_config* c) { return c->acceptable_iter > 0 ? c->acceptable_iter : (c->acceptable_iter < 0 ? 0 : 15); }
@@ -252,14 +254,17 @@ typedef struct {
     int nvia; const double* via; int vidx[64];
     int rows_dropped;          /* clearance rows that did not fit into max_rows (obst_associate) */
     double* dual;              /* this instance's block of the kept multipliers or NULL */
+    int convexify;             /* this factorisation: stage blocks of the Lagrangian curvature replaced by their positive semidefinite parts */
+    int rhs_only;              /* assemble(): leave the factorised band alone, rebuild only the right-hand side / gradient pieces (they are linear in mu) */
 } work_t;
 
 static int iu(int k, int j) { return 8 * k + j; }
 static int il(int k, int a) { return 8 * k + 2 + a; }
 static int ixn(int k, int a) { return 8 * (k - 1) + 5 + a; }   /* x_k, k >= 1 */
 
-static void band_zero(work_t* w) { memset(w->AB, 0, sizeof(double) * LDAB * w->N); }
+static void band_zero(work_t* w) { if (!w->rhs_only) memset(w->AB, 0, sizeof(double) * LDAB * w->N); }
 static void band_add(work_t* w, int i, int j, double v) {
+    if (w->rhs_only) return;
     /* LAPACK band layout: A(i,j) at AB[kl+ku+i-j][j] */
     w->AB[(size_t)(KL + KU + i - j) + (size_t)LDAB * j] += v;
 }
@@ -685,7 +690,7 @@ static double barrier_logs(const work_t* w, const double* U, double D, const dou
     return a;
 }
 
-typedef struct { double rd, rp, cmin, cmax, sm, sb, theta; int nm, nb; } err_t;
+typedef struct { double rd, rp, cmin, cmax, csum, sm, sb, theta; int nm, nb; } err_t;     /* csum: sum of the nb complementarity products */
 
 static void kkt_terms(const work_t* w, const double* cc, err_t* e) {
     const oracle_config* c = w->c;
@@ -725,7 +730,7 @@ static void kkt_terms(const work_t* w, const double* cc, err_t* e) {
             const double sl = w->os[k * M + m], y = w->oy[k * M + m], res = g + sl;
             if (fabs(res) > e->rp) e->rp = fabs(res);
             e->theta += fabs(res);
-            if (sl * y < e->cmin) e->cmin = sl * y; if (sl * y > e->cmax) e->cmax = sl * y;
+            if (sl * y < e->cmin) e->cmin = sl * y; if (sl * y > e->cmax) e->cmax = sl * y; e->csum += sl * y;
             e->sb += y; e->nb += 1;
             osx += y * ax; osy += y * ay;
             if (is_dynamic(w, w->oi[k * M + m]) && fp_turns(w)) { rdd += y * ad; ost += y * a3[2]; }
@@ -746,7 +751,7 @@ static void kkt_terms(const work_t* w, const double* cc, err_t* e) {
             if (fabs(r) > e->rd) e->rd = fabs(r);
             double cl = (u - c->u_lb[j]) * pl, cu = (c->u_ub[j] - u) * pu;
             if (cl < e->cmin) e->cmin = cl; if (cu < e->cmin) e->cmin = cu;
-            if (cl > e->cmax) e->cmax = cl; if (cu > e->cmax) e->cmax = cu;
+            if (cl > e->cmax) e->cmax = cl; if (cu > e->cmax) e->cmax = cu; e->csum += cl + cu;
             e->sb += pl + pu; e->nb += 2;
         }
     }
@@ -770,7 +775,7 @@ static void kkt_terms(const work_t* w, const double* cc, err_t* e) {
             const double res = w->tg + w->ts;
             if (fabs(res) > e->rp) e->rp = fabs(res);
             e->theta += fabs(res);
-            if (w->ts * w->ty < e->cmin) e->cmin = w->ts * w->ty; if (w->ts * w->ty > e->cmax) e->cmax = w->ts * w->ty;
+            if (w->ts * w->ty < e->cmin) e->cmin = w->ts * w->ty; if (w->ts * w->ty > e->cmax) e->cmax = w->ts * w->ty; e->csum += w->ts * w->ty;
             e->sb += w->ty; e->nb += 1;
         }
     }
@@ -779,7 +784,7 @@ static void kkt_terms(const work_t* w, const double* cc, err_t* e) {
         double res = row_val_at(w, w->U, w->D, r, q) + s;
         if (fabs(res) > e->rp) e->rp = fabs(res);
         e->theta += fabs(res);
-        if (s * y < e->cmin) e->cmin = s * y; if (s * y > e->cmax) e->cmax = s * y;
+        if (s * y < e->cmin) e->cmin = s * y; if (s * y > e->cmax) e->cmax = s * y; e->csum += s * y;
         e->sb += y; e->nb += 1;
         if (r > 0) rdd -= sgn(q) * lim(w, q) * y;
     }
@@ -788,7 +793,7 @@ static void kkt_terms(const work_t* w, const double* cc, err_t* e) {
         if (fabs(rdd) > e->rd) e->rd = fabs(rdd);
         double cl = (w->D - c->dt_lb) * w->pdl, cu = (c->dt_ub - w->D) * w->pdu;
         if (cl < e->cmin) e->cmin = cl; if (cu < e->cmin) e->cmin = cu;
-        if (cl > e->cmax) e->cmax = cl; if (cu > e->cmax) e->cmax = cu;
+        if (cl > e->cmax) e->cmax = cl; if (cu > e->cmax) e->cmax = cu; e->csum += cl + cu;
         e->sb += w->pdl + w->pdu; e->nb += 2;
     }
     e->sm += e->sb; e->nm += e->nb;
@@ -832,6 +837,17 @@ static void psd_project4(stage_map_t* sm, int drop_theta) {
     sm->Hdd = R[3][3];
 }
 
+/* cheap convexification of the stage block [Hqq Hqd; Hqd' Hdd] of lam' D: every diagonal entry is raised to the sum of the absolute off-diagonal entries of
+ * its row (Gershgorin: the block becomes diagonally dominant with a non-negative diagonal, hence positive semidefinite) */
+static void gershgorin4(stage_map_t* sm, int drop_theta) {
+    double A[4][4];
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) A[i][j] = sm->Hqq[i][j]; A[i][3] = A[3][i] = sm->Hqd[i]; }
+    A[3][3] = sm->Hdd;
+    if (drop_theta) for (int j = 0; j < 4; ++j) A[0][j] = A[j][0] = 0.0;
+    for (int i = 0; i < 4; ++i) { double r = 0; for (int j = 0; j < 4; ++j) if (j != i) r += fabs(A[i][j]); if (A[i][i] < r) A[i][i] = r; }
+    for (int i = 0; i < 3; ++i) { for (int j = 0; j < 3; ++j) sm->Hqq[i][j] = A[i][j]; sm->Hqd[i] = A[i][3]; }
+    sm->Hdd = A[3][3];
+}
 static void assemble(work_t* w, const double* cc, double delta, double dc, double* Hdd, double* hd) {
     const oracle_config* c = w->c;
     int n = w->n, N = w->N;
@@ -862,7 +878,8 @@ static void assemble(work_t* w, const double* cc, double delta, double dc, doubl
             w->rhs[row] = -cc[3 * k + a];
         }
         if (k == n - 2) for (int a = 0; a < 3; ++a) if (c->xf_fixed[a]) band_add(w, il(k, a), il(k, a), -dc);
-        if (g_variant == 3 || c->hessian_mode == 1) psd_project4(&sm, qi[0] < 0);      /* stage-wise convexification of the Lagrangian curvature */
+        if (g_variant == 3 || c->hessian_mode == 1 || w->convexify == 1) psd_project4(&sm, qi[0] < 0);
+        else if (w->convexify == 2) gershgorin4(&sm, qi[0] < 0);      /* stage-wise convexification of the Lagrangian curvature */
         /* Lagrangian curvature */
         for (int j = 0; j < 3; ++j) {
             if (qi[j] < 0) continue;
@@ -992,6 +1009,208 @@ static void assemble(work_t* w, const double* cc, double delta, double dc, doubl
 
 static void ftb(double val, double dval, double tau, double* alpha) { if (dval < 0) { double a = -tau * val / dval; if (a < *alpha) *alpha = a; } }
 
+typedef struct { double hdz, dz2, dphi, a_p, a_d, dzmax, clam, nunu; } step_t;
+/* Everything that follows from a solution of the Newton system (w->rhs, w->ddt) at barrier parameter mu: primal steps, slack / multiplier steps of every
+ * inequality row, fraction-to-boundary step lengths at tau, directional derivative of the barrier function, curvature terms */
+static void derive_step(work_t* w, const double* cc, double mu, double tau, double* ds, double* dy, step_t* o) {
+    const oracle_config* c = w->c;
+    const int n = w->n;
+    /* curvature dz^T (Hc + delta I) dz = -h^T dz + c^T lam+ - dc |lam+_term|^2, with h = -(rhs of the primal rows) */
+    double clam = 0, nunu = 0, hdz = 0, dz2 = 0, dphi = 0, a_p = 1, a_d = 1, dzmax = 0;
+    /* re-assemble gradient pieces (cheap): h^T dz = gphi.dz + ybar.(Jg dz) */
+    double ddt = w->ddt;
+    if (c->dt_free) {
+        double dl = w->D - c->dt_lb, du = c->dt_ub - w->D, gb = -mu / dl + mu / du;
+        hdz += gb * ddt; dphi += gb * ddt; dz2 += ddt * ddt; if (fabs(ddt) > dzmax) dzmax = fabs(ddt);
+        ftb(dl, ddt, tau, &a_p); ftb(du, -ddt, tau, &a_p);
+        ftb(w->pdl, mu / dl - w->pdl - (w->pdl / dl) * ddt, tau, &a_d);
+        ftb(w->pdu, mu / du - w->pdu + (w->pdu / du) * ddt, tau, &a_d);
+    }
+    if (MINTIME(c)) { hdz += (n - 1) * ddt; dphi += (n - 1) * ddt; }
+    if (c->objective == 1 && c->integral) for (int k = 0; k < n; ++k) {        /* d/d dt of the integral-form stage costs */
+        double xd[3] = {w->X[3 * k] - w->xf[0], w->X[3 * k + 1] - w->xf[1], wrap(w->X[3 * k + 2] - w->xf[2])}, qx[3], sc;
+        sym3_mul(c->Q, c->Qo, xd, qx);
+        sc = state_weight(c, n, k) * (xd[0] * qx[0] + xd[1] * qx[1] + xd[2] * qx[2]);
+        if (k < n - 1) { const double v = w->U[2 * k], om = w->U[2 * k + 1]; sc += c->R[0] * v * v + c->R[1] * om * om + 2 * c->Ro * v * om; }
+        hdz += sc * ddt; dphi += sc * ddt;
+    }
+    for (int k = 0; k < n - 1; ++k) {
+        for (int j = 0; j < 2; ++j) {
+            double du_ = w->rhs[iu(k, j)], u = w->U[2 * k + j];
+            double dl = u - c->u_lb[j], du = c->u_ub[j] - u, pl = w->pl[2 * k + j], pu = w->pu[2 * k + j];
+            double gb = -mu / dl + mu / du;
+            if (c->objective == 1) gb += 2 * (c->R[j] * u + c->Ro * w->U[2 * k + 1 - j]) * (c->integral ? w->D : 1.0);
+            hdz += gb * du_; dphi += gb * du_; dz2 += du_ * du_; if (fabs(du_) > dzmax) dzmax = fabs(du_);
+            ftb(dl, du_, tau, &a_p); ftb(du, -du_, tau, &a_p);
+            ftb(pl, mu / dl - pl - (pl / dl) * du_, tau, &a_d);
+            ftb(pu, mu / du - pu + (pu / du) * du_, tau, &a_d);
+            w->dz_u[2 * k + j] = du_;
+        }
+        for (int a = 0; a < 3; ++a) {
+            double l = w->rhs[il(k, a)];
+            w->lamn[3 * k + a] = l;
+            clam += cc[3 * k + a] * l;
+            if (k == n - 2 && c->xf_fixed[a]) nunu += l * l;
+            double dx = (k + 1 < n - 1 || !c->xf_fixed[a]) ? w->rhs[ixn(k + 1, a)] : 0.0;
+            w->dz_x[3 * (k + 1) + a] = dx;
+            dz2 += dx * dx; if (fabs(dx) > dzmax) dzmax = fabs(dx);
+            {
+                double g = 0;
+                const double xd[3] = {w->X[3 * (k + 1)] - w->xf[0], w->X[3 * (k + 1) + 1] - w->xf[1], wrap(w->X[3 * (k + 1) + 2] - w->xf[2])};
+                const double ws = state_weight(c, n, k + 1);
+                double qx[3];
+                if (ws != 0.0) { sym3_mul(c->Q, c->Qo, xd, qx); g = 2 * ws * qx[a] * (c->integral ? w->D : 1.0); }
+                if (k + 1 == n - 1 && c->has_Qf && !c->xf_fixed[a]) { sym3_mul(c->Qf, c->Qfo, xd, qx); g += 2 * qx[a]; }
+                hdz += g * dx; dphi += g * dx;
+            }
+        }
+        if (c->via && k + 1 < n - 1) {        /* via-point gradient at grid point k+1 */
+            double vv, vg[3];
+            via_terms(w, k + 1, w->X[3 * (k + 1)], w->X[3 * (k + 1) + 1], w->X[3 * (k + 1) + 2], &vv, vg);
+            for (int a = 0; a < 3; ++a) { hdz += vg[a] * w->dz_x[3 * (k + 1) + a]; dphi += vg[a] * w->dz_x[3 * (k + 1) + a]; }
+        }
+    }
+    for (int r = 0; r < n; ++r) for (int q = 0; q < 4; ++q) if (row_on(w, r, q)) {
+        int j = q & 1;
+        double sg = sgn(q), L = lim(w, q);
+        double dur = r < n - 1 ? w->dz_u[2 * r + j] : 0.0, dum = r > 0 ? w->dz_u[2 * (r - 1) + j] : 0.0;
+        double jdz = sg * ((dur - dum) - (r > 0 ? L * ddt : 0.0));
+        double s = w->s[4 * r + q], y = w->y[4 * r + q], sig = y / s;
+        double res = row_val_at(w, w->U, w->D, r, q) + s, ybar = mu / s + sig * res;
+        ds[4 * r + q] = -res - jdz;
+        dy[4 * r + q] = ybar + sig * jdz - y;
+        hdz += ybar * jdz;
+        dphi -= (mu / s) * ds[4 * r + q];
+        ftb(s, ds[4 * r + q], tau, &a_p);
+        ftb(y, dy[4 * r + q], tau, &a_d);
+    }
+    for (int k = 1, M = obst_M(w); k < n - 1; ++k) for (int m = 0; m < M; ++m) {
+        if (w->oi[k * M + m] < 0) continue;
+        const int dyn_ = is_dynamic(w, w->oi[k * M + m]);
+        const double jdz = w->oax[k * M + m] * w->dz_x[3 * k] + w->oay[k * M + m] * w->dz_x[3 * k + 1] +
+                           ((dyn_ && fp_turns(w)) ? w->oat[k * M + m] * w->dz_x[3 * k + 2] + w->oad[k * M + m] * ddt
+                                                  : w->oat[k * M + m] * (dyn_ ? ddt : w->dz_x[3 * k + 2]));
+        const double sl = w->os[k * M + m], y = w->oy[k * M + m], res = w->og[k * M + m] + sl;
+        const double sig = y / sl, ybar = mu / sl + sig * res;
+        w->ods[k * M + m] = -res - jdz;
+        w->ody[k * M + m] = ybar + sig * jdz - y;
+        hdz += ybar * jdz;
+        dphi -= (mu / sl) * w->ods[k * M + m];
+        ftb(sl, w->ods[k * M + m], tau, &a_p);
+        ftb(y, w->ody[k * M + m], tau, &a_d);
+    }
+    if (ball_on(w)) {
+        double jdz = 0;
+        for (int i = 0; i < 3; ++i) if (!c->xf_fixed[i]) jdz += w->ta[i] * w->dz_x[3 * (n - 1) + i];
+        const double res = w->tg + w->ts, sig = w->ty / w->ts, ybar = mu / w->ts + sig * res;
+        w->tds = -res - jdz; w->tdy = ybar + sig * jdz - w->ty;
+        hdz += ybar * jdz;
+        dphi -= (mu / w->ts) * w->tds;
+        ftb(w->ts, w->tds, tau, &a_p);
+        ftb(w->ty, w->tdy, tau, &a_d);
+    }
+    o->hdz = hdz; o->dz2 = dz2; o->dphi = dphi; o->a_p = a_p; o->a_d = a_d; o->dzmax = dzmax; o->clam = clam; o->nunu = nunu;
+}
+
+
+/* EXPERIMENT switches (oracle_set_algo; scripts/algo_stats.py, DESIGN.md section 3 holds the measurements).  The defaults are THE algorithm -- the one
+ * oracle/ipm_dense.py and the kernel run too; everything else is Ipopt machinery that was measured on the BASELINE workloads and not adopted:
+ *   mu_oracle      0 step-length rule (the product), 1 Mehrotra's probing oracle (Ipopt mu_oracle=probing: affine-scaling solve with the same factorisation),
+ *                  2 LOQO rule (Ipopt mu_oracle=loqo)
+ *   globalization  0 l1 merit (the product), 1 Ipopt's filter (Waechter & Biegler 2006, Algorithm A) with max_soc second-order corrections
+ *   safeguard      adaptive mu: 1 = Ipopt's adaptive_mu_globalization=kkt-error (fixed-mu mode at fix_fact x the average complementarity when the error stalls)
+ *   convex_fallback  1: a factorisation that fails the curvature test at delta = 0 is repeated with the stage blocks of lam' D replaced by their positive
+ *                  semidefinite parts before any multiple of the identity is added */
+typedef struct {
+    int mu_oracle, globalization, max_soc, safeguard;
+    double sigma_max, fix_fact;
+    int convex_fallback;
+} algo_t;
+static algo_t g_algo = {0, 0, 0, 0, 100.0, 0.8, 0};
+void oracle_set_algo(int key, double v) {
+    switch (key) {
+        case 0: g_algo.mu_oracle = (int)v; break;
+        case 1: g_algo.globalization = (int)v; break;
+        case 2: g_algo.max_soc = (int)v; break;
+        case 3: g_algo.safeguard = (int)v; break;
+        case 4: g_algo.sigma_max = v; break;
+        case 5: g_algo.fix_fact = v; break;
+        case 6: g_algo.convex_fallback = (int)v; break;
+    }
+}
+
+/* sum, count, smallest of the complementarity products after a step (a_p on the slacks / box distances, a_d on the multipliers; a_p = a_d = 0: the current ones).
+ * mu enters the steps of the box multipliers only (d pl = mu/dl - pl - pl/dl du). */
+static void compl_stats(const work_t* w, const double* ds, const double* dy, double a_p, double a_d, double mu, double* sum, int* cnt, double* cmin) {
+    const oracle_config* c = w->c;
+    const int n = w->n;
+    double sm = 0, mn = 1e300; int k0 = 0;
+#define CPAIR(sv, dsv, yv, dyv) do { double p_ = ((sv) + a_p * (dsv)) * ((yv) + a_d * (dyv)); sm += p_; if (p_ < mn) mn = p_; ++k0; } while (0)
+    for (int r = 0; r < n; ++r) for (int q = 0; q < 4; ++q) if (row_on(w, r, q)) CPAIR(w->s[4 * r + q], ds[4 * r + q], w->y[4 * r + q], dy[4 * r + q]);
+    for (int k = 1, M = obst_M(w); k < n - 1; ++k) for (int m = 0; m < M; ++m) if (w->oi[k * M + m] >= 0) CPAIR(w->os[k * M + m], w->ods[k * M + m], w->oy[k * M + m], w->ody[k * M + m]);
+    if (ball_on(w)) CPAIR(w->ts, w->tds, w->ty, w->tdy);
+    for (int k = 0; k < n - 1; ++k) for (int j = 0; j < 2; ++j) {
+        const double u = w->U[2 * k + j], du_ = w->dz_u[2 * k + j], dl = u - c->u_lb[j], du = c->u_ub[j] - u, pl = w->pl[2 * k + j], pu = w->pu[2 * k + j];
+        CPAIR(dl, du_, pl, mu / dl - pl - (pl / dl) * du_);
+        CPAIR(du, -du_, pu, mu / du - pu + (pu / du) * du_);
+    }
+    if (c->dt_free) {
+        const double dl = w->D - c->dt_lb, du = c->dt_ub - w->D;
+        CPAIR(dl, w->ddt, w->pdl, mu / dl - w->pdl - (w->pdl / dl) * w->ddt);
+        CPAIR(du, -w->ddt, w->pdu, mu / du - w->pdu + (w->pdu / du) * w->ddt);
+    }
+#undef CPAIR
+    *sum = sm; *cnt = k0; *cmin = mn;
+}
+
+/* bordered solve with the factorised band: [K b; b' Hdd] [z; ddt] = [rhs; -hd]; y2 = K^-1 b is computed when *have_y2 == 0 */
+static int border_solve(work_t* w, double* y2, int* have_y2, double Hdd, double hd) {
+    const oracle_config* c = w->c;
+    const int N = w->N;
+    int good = 1;
+    band_solve(w, w->rhs);
+    double ddt = 0.0;
+    if (c->dt_free) {
+        if (!*have_y2) { memcpy(y2, w->bcol, sizeof(double) * N); band_solve(w, y2); *have_y2 = 1; }
+        double num = -hd, den = Hdd;
+        for (int i = 0; i < N; ++i) { num -= w->bcol[i] * w->rhs[i]; den -= w->bcol[i] * y2[i]; }
+        ddt = num / den;
+        if (!isfinite(ddt) || den == 0.0) good = 0;
+        else for (int i = 0; i < N; ++i) w->rhs[i] -= y2[i] * ddt;
+    }
+    w->ddt = ddt;
+    for (int i = 0; i < N && good; ++i) if (!isfinite(w->rhs[i])) good = 0;
+    return good;
+}
+
+
+/* trial point X + alpha dX (heading wrapped), U + alpha dU, D + alpha dD, slacks + alpha ds: collocation residuals cct, objective, theta and the sum of the barrier logs there */
+static void trial_point(work_t* w, double alpha, const double* ds, double* st, double* cct, double* ft, double* tht_out, double* logs) {
+    const oracle_config* c = w->c;
+    const int n = w->n;
+    for (int k = 0; k < n; ++k) for (int i = 0; i < 3; ++i) {
+        double x = w->X[3 * k + i];
+        if (k > 0 && (k < n - 1 || !c->xf_fixed[i])) { x += alpha * w->dz_x[3 * k + i]; if (i == 2) x = wrap(x); }
+        w->Xt[3 * k + i] = x;
+    }
+    for (int i = 0; i < 2 * (n - 1); ++i) w->Ut[i] = w->U[i] + alpha * w->dz_u[i];
+    w->Dt = w->D + (c->dt_free ? alpha * w->ddt : 0.0);
+    for (int i = 0; i < 4 * n; ++i) st[i] = w->s[i] + alpha * ds[i];
+    for (int i = 0, nm = n * obst_M(w); i < nm; ++i) w->ost[i] = w->oi[i] >= 0 ? w->os[i] + alpha * w->ods[i] : 1.0;
+    eval_point(w, w->Xt, w->Ut, w->Dt, cct, ft);
+    double tht = 0;
+    for (int i = 0; i < 3 * (n - 1); ++i) tht += fabs(cct[i]);
+    for (int r = 0; r < n; ++r) for (int q = 0; q < 4; ++q) if (row_on(w, r, q)) tht += fabs(row_val_at(w, w->Ut, w->Dt, r, q) + st[4 * r + q]);
+    if (obst_M(w) > 0) tht += obst_theta(w, w->Xt, w->Dt, w->ost);
+    double tlog = 0;
+    if (ball_on(w)) { double ta[3]; w->tst = w->ts + alpha * w->tds; tht += fabs(ball_eval(w, w->Xt, ta) + w->tst); tlog = log(w->tst); }
+    *tht_out = tht;
+    *logs = barrier_logs(w, w->Ut, w->Dt, st, w->ost) + tlog;
+}
+
+#define FCAP 16
+static int g_trace = 0;      /* dev: print one line per iteration (single-threaded use) */
+void oracle_set_trace(int on) { g_trace = on; }
 static long g_nfac_total = 0;
 static int g_nfac_max = 0;
 void oracle_set_variant(int v) { g_variant = v; g_nfac_total = 0; g_nfac_max = 0; }
@@ -1015,8 +1234,18 @@ static int solve_one(work_t* w, int warm) {
     double* ds = (double*)malloc(sizeof(double) * 4 * n);
     double* dy = (double*)malloc(sizeof(double) * 4 * n);
     double* y2 = (double*)malloc(sizeof(double) * N);
+    double* rhs_keep = (double*)malloc(sizeof(double) * N);
+    double* csoc = (double*)malloc(sizeof(double) * 3 * (n - 1));
+    double* ds_keep = (double*)malloc(sizeof(double) * 4 * n);
+    double* dy2 = (double*)malloc(sizeof(double) * 4 * n);
+    double fth[FCAP], fph[FCAP]; int nfilt = 0, nresto = 0; double theta0 = -1, mu_filter = -1;
+    int free_mode = 1, nrefs = 0; double refs[4];
+    const int adaptive = c->mu_strategy != 1;
+    const double sigma_min = 0.05, mu_err_floor = 1e-2, mu_max_fact = 1e3;
+    double last_alpha = 0, last_ad = 0;
+    double mu_min = 0, mu_max = 1e300;
     int status = 1, it = 0;
-    int nfac = 0, fail0_streak = 0;
+    int nfac = 0, fail0_streak = 0, seeded = 0;
     /* initial vertex values */
     if (!warm) {
         double dth = wrap(w->xf[2] - w->x0[2]);
@@ -1036,6 +1265,7 @@ static int solve_one(work_t* w, int warm) {
     {
         int any = 0;
         for (int i = 0; i < 2 * (n - 1); ++i) if (w->U[i] != 0.0) any = 1;
+        seeded = !any;
         if (!any) for (int k = 0; k < n - 1; ++k) {
             double dx = w->X[3 * (k + 1)] - w->X[3 * k], dyy = w->X[3 * (k + 1) + 1] - w->X[3 * k + 1];
             double dth = wrap(w->X[3 * (k + 1) + 2] - w->X[3 * k + 2]), th = w->X[3 * k + 2];
@@ -1051,6 +1281,20 @@ static int solve_one(work_t* w, int warm) {
             }
             om = fmin(fmax(om, c->u_lb[1]), c->u_ub[1]);
             w->U[2 * k] = v; w->U[2 * k + 1] = om;
+        }
+    }
+    if (seeded) {
+        /* ... and keeps the seeded controls inside the control-rate rows, as the reference's u = 0 start is (every row but the first): increments clamped
+         * to rate_seed_frac x the rate limits forward from u_prev, then backward from the final row (against u_ref = 0).  A seed that jumps violates the rows
+         * it crosses: their slacks start at the 1e-2 floor with a residual, and the fraction-to-boundary rule pins the first iterations. */
+        const double fr = 0.9;
+        for (int j = 0; j < 2; ++j) {
+            if (!(c->du_lb[j] > -1e29) || !(c->du_ub[j] < 1e29)) continue;
+            const double lo = c->du_lb[j] * w->D * fr, hi = c->du_ub[j] * w->D * fr;
+            if (w->dtprev != 0.0) w->U[j] = fmin(fmax(w->U[j], w->uprev[j] + c->du_lb[j] * w->dtprev * fr), w->uprev[j] + c->du_ub[j] * w->dtprev * fr);
+            for (int k = 1; k < n - 1; ++k) w->U[2 * k + j] = fmin(fmax(w->U[2 * k + j], w->U[2 * (k - 1) + j] + lo), w->U[2 * (k - 1) + j] + hi);
+            double nxt = 0.0;
+            for (int k = n - 2; k >= 0; --k) { w->U[2 * k + j] = fmin(fmax(w->U[2 * k + j], nxt - hi), nxt - lo); nxt = w->U[2 * k + j]; }
         }
     }
     for (int k = 0; k < n - 1; ++k) for (int j = 0; j < 2; ++j) {
@@ -1105,6 +1349,7 @@ static int solve_one(work_t* w, int warm) {
     const double acc_tol = acc_tol_of(c);
     const int acc_it = acc_iter_of(c);
     eval_point(w, w->X, w->U, w->D, cc, &fobj);
+    mu_min = tol / 10; mu_max = mu_max_fact * w->mu;
     while (1) {
         err_t e;
         kkt_terms(w, cc, &e);
@@ -1117,10 +1362,40 @@ static int solve_one(work_t* w, int warm) {
             if (n_acceptable >= acc_it) { status = 0; break; }
         }
         if (it >= max_iter) { status = 1; break; }
-        for (int g = 0; g < 50; ++g) {
-            double emu = err_value(&e, w->mu);
-            if (emu <= kappa_eps * w->mu && w->mu > tol / 10) { w->mu = fmax(tol / 10, fmin(kappa_mu * w->mu, pow(w->mu, theta_mu))); w->rho = 0; }
-            else break;
+        /* barrier parameter.  Monotone (oracle_config.mu_strategy = 1, Ipopt's mu_strategy monotone): Fiacco-McCormick, mu falls when the barrier
+         * subproblem is solved to kappa_eps mu.  Adaptive (the default; corbo's SolverIpopt sets mu_strategy adaptive): every iteration
+         *     mu = sigma x (average complementarity),   sigma = clamp((1 - min(alpha, alpha_dual))^3, 0.05, 1)
+         * with the step lengths the LAST iteration achieved (a full step -> the centring weight collapses, a blocked step -> mu stays: Mehrotra's
+         * sigma = (mu_aff / mu)^3 read off the step that was actually taken instead of an extra affine-scaling solve; oracle_set_algo(0, 1) runs the
+         * probing oracle itself, same statistics), never below min(mu, mu_err_floor x E_0): a barrier far below the optimality error is what stalls
+         * the non-convex instances; kept inside [tol / 10, mu_max_fact x mu_init] as Ipopt's mu_min / mu_max. */
+        int mu_chosen = 0, mu_changed = 0;
+        if (adaptive && g_algo.safeguard == 1 && free_mode) {
+            /* Ipopt adaptive_mu_globalization=kkt-error: the free mode goes on while the error is below 0.9999 x one of the last four reference values */
+            int sufficient = nrefs < 4;
+            for (int i = 0; i < nrefs && !sufficient; ++i) if (e0 <= 0.9999 * refs[i]) sufficient = 1;
+            if (sufficient) { if (nrefs < 4) refs[nrefs++] = e0; else { refs[0] = refs[1]; refs[1] = refs[2]; refs[2] = refs[3]; refs[3] = e0; } }
+            else { free_mode = 0; w->mu = fmin(fmax(g_algo.fix_fact * e.csum / e.nb, mu_min), mu_max); w->rho = 0; mu_changed = 1; }
+        }
+        if (!adaptive || !free_mode) {
+            for (int g = 0; g < 50; ++g) {
+                double emu = err_value(&e, w->mu);
+                if (emu <= kappa_eps * w->mu && w->mu > tol / 10) {
+                    if (adaptive) { free_mode = 1; nrefs = 0; break; }          /* the fixed-mu subproblem is solved: back to the free mode */
+                    w->mu = fmax(tol / 10, fmin(kappa_mu * w->mu, pow(w->mu, theta_mu))); w->rho = 0; mu_changed = 1;
+                }
+                else break;
+            }
+        }
+        if (adaptive && free_mode && g_algo.mu_oracle != 1) {
+            const double avg = e.csum / e.nb;
+            double sig;
+            if (g_algo.mu_oracle == 2) { const double xi = e.cmin / avg, t_ = fmin(0.05 * (1 - xi) / xi, 2.0); sig = 0.1 * t_ * t_ * t_; }       /* LOQO rule (experiment) */
+            else { const double a_ = 1.0 - fmin(last_alpha, last_ad); sig = it == 0 ? 1.0 : fmin(fmax(a_ * a_ * a_, sigma_min), 1.0); }
+            double mu_new = fmin(fmax(sig * avg, mu_min), mu_max);
+            mu_new = fmax(mu_new, fmin(w->mu, mu_err_floor * e0));
+            if (mu_new != w->mu) { w->mu = mu_new; w->rho = 0; mu_changed = 1; }
+            mu_chosen = 1;
         }
         double mu = w->mu, tau = fmax(tau_min, 1.0 - mu);
         double dc = nfix > 0 ? delta_c * pow(mu, kappa_c) : 0.0;
@@ -1129,125 +1404,50 @@ static int solve_one(work_t* w, int warm) {
         if (g_variant == 1 && fail0_streak >= 1 && w->delta_last > 0) delta = fmax(delta_min, kminus * w->delta_last);
         if (g_variant == 2 && fail0_streak >= 2 && w->delta_last > 0) delta = fmax(delta_min, kminus * w->delta_last);
         int started_zero = delta == 0.0;
+        w->convexify = 0;
         for (int ntry = 0; ntry <= 40; ++ntry) {
             ++nfac;
             assemble(w, cc, delta, dc, &Hdd, &hd);
             int good = band_factor(w) == 0;
             if (good) {
-                /* bordered solve: [K b; b^T Hdd] [y; ddt] = [rhs; -hd] */
-                memcpy(y2, w->bcol, sizeof(double) * N);
-                band_solve(w, w->rhs);
-                double ddt = 0.0;
-                if (c->dt_free) {
-                    band_solve(w, y2);
-                    double num = -hd, den = Hdd;
-                    for (int i = 0; i < N; ++i) { num -= w->bcol[i] * w->rhs[i]; den -= w->bcol[i] * y2[i]; }
-                    ddt = num / den;
-                    if (!isfinite(ddt) || den == 0.0) good = 0;
-                    else for (int i = 0; i < N; ++i) w->rhs[i] -= y2[i] * ddt;
+                int have_y2 = 0;
+                good = border_solve(w, y2, &have_y2, Hdd, hd);
+                if (good && adaptive && g_algo.mu_oracle == 1 && free_mode && !mu_chosen) {
+                    /* Mehrotra's probing oracle (Ipopt mu_oracle=probing): affine-scaling step (mu = 0) with the same factorisation, step to the boundary (tau = 1),
+                     * mu_aff = average complementarity there, sigma = (mu_aff / mu_cur)^3, mu = sigma mu_cur */
+                    memcpy(rhs_keep, w->rhs, sizeof(double) * N);
+                    const double ddt_keep = w->ddt, mu_keep = w->mu;
+                    double hd0, Hdd0;
+                    w->mu = 0.0; w->rhs_only = 1; assemble(w, cc, delta, dc, &Hdd0, &hd0); w->rhs_only = 0;
+                    int g2 = border_solve(w, y2, &have_y2, Hdd, hd0);
+                    if (g2) {
+                        step_t sa; double sum0, sum1, mn; int cnt;
+                        derive_step(w, cc, 0.0, 1.0, ds, dy, &sa);
+                        compl_stats(w, ds, dy, 0.0, 0.0, 0.0, &sum0, &cnt, &mn);
+                        compl_stats(w, ds, dy, sa.a_p, sa.a_d, 0.0, &sum1, &cnt, &mn);
+                        const double mu_cur = sum0 / cnt, mu_aff = sum1 / cnt;
+                        double sigma = pow(mu_aff / mu_cur, 3.0);
+                        if (!(sigma < g_algo.sigma_max)) sigma = g_algo.sigma_max;
+                        double mu_new = sigma * mu_cur;
+                        mu_new = fmin(fmax(mu_new, mu_min), mu_max);
+                        mu_new = fmax(mu_new, fmin(mu_keep, mu_err_floor * e0));
+                        if (g_trace) printf("    probing: mu_cur %.3e a_aff %.3f %.3f mu_aff %.3e sigma %.3e -> mu %.3e\n", mu_cur, sa.a_p, sa.a_d, mu_aff, sigma, mu_new);
+                        w->mu = mu = mu_new; tau = fmax(tau_min, 1.0 - mu); w->rho = 0; mu_changed = 1;
+                        w->rhs_only = 1; assemble(w, cc, delta, dc, &Hdd0, &hd); w->rhs_only = 0;
+                        good = border_solve(w, y2, &have_y2, Hdd, hd);
+                    } else { w->mu = mu_keep; memcpy(w->rhs, rhs_keep, sizeof(double) * N); w->ddt = ddt_keep; }
+                    mu_chosen = 1;
                 }
-                w->ddt = ddt;
-                for (int i = 0; i < N && good; ++i) if (!isfinite(w->rhs[i])) good = 0;
             }
             if (good) {
-                /* curvature dz^T (Hc + delta I) dz = -h^T dz + c^T lam+ - dc |lam+_term|^2, with h = -(rhs of the primal rows) */
-                double clam = 0, nunu = 0;
-                hdz = 0; dz2 = 0; dphi = 0; a_p = 1; a_d = 1; dzmax = 0;
-                /* re-assemble gradient pieces (cheap): h^T dz = gphi.dz + ybar.(Jg dz) */
-                double ddt = w->ddt;
-                if (c->dt_free) {
-                    double dl = w->D - c->dt_lb, du = c->dt_ub - w->D, gb = -mu / dl + mu / du;
-                    hdz += gb * ddt; dphi += gb * ddt; dz2 += ddt * ddt; if (fabs(ddt) > dzmax) dzmax = fabs(ddt);
-                    ftb(dl, ddt, tau, &a_p); ftb(du, -ddt, tau, &a_p);
-                    ftb(w->pdl, mu / dl - w->pdl - (w->pdl / dl) * ddt, tau, &a_d);
-                    ftb(w->pdu, mu / du - w->pdu + (w->pdu / du) * ddt, tau, &a_d);
-                }
-                if (MINTIME(c)) { hdz += (n - 1) * ddt; dphi += (n - 1) * ddt; }
-                if (c->objective == 1 && c->integral) for (int k = 0; k < n; ++k) {        /* d/d dt of the integral-form stage costs */
-                    double xd[3] = {w->X[3 * k] - w->xf[0], w->X[3 * k + 1] - w->xf[1], wrap(w->X[3 * k + 2] - w->xf[2])}, qx[3], sc;
-                    sym3_mul(c->Q, c->Qo, xd, qx);
-                    sc = state_weight(c, n, k) * (xd[0] * qx[0] + xd[1] * qx[1] + xd[2] * qx[2]);
-                    if (k < n - 1) { const double v = w->U[2 * k], om = w->U[2 * k + 1]; sc += c->R[0] * v * v + c->R[1] * om * om + 2 * c->Ro * v * om; }
-                    hdz += sc * ddt; dphi += sc * ddt;
-                }
-                for (int k = 0; k < n - 1; ++k) {
-                    for (int j = 0; j < 2; ++j) {
-                        double du_ = w->rhs[iu(k, j)], u = w->U[2 * k + j];
-                        double dl = u - c->u_lb[j], du = c->u_ub[j] - u, pl = w->pl[2 * k + j], pu = w->pu[2 * k + j];
-                        double gb = -mu / dl + mu / du;
-                        if (c->objective == 1) gb += 2 * (c->R[j] * u + c->Ro * w->U[2 * k + 1 - j]) * (c->integral ? w->D : 1.0);
-                        hdz += gb * du_; dphi += gb * du_; dz2 += du_ * du_; if (fabs(du_) > dzmax) dzmax = fabs(du_);
-                        ftb(dl, du_, tau, &a_p); ftb(du, -du_, tau, &a_p);
-                        ftb(pl, mu / dl - pl - (pl / dl) * du_, tau, &a_d);
-                        ftb(pu, mu / du - pu + (pu / du) * du_, tau, &a_d);
-                        w->dz_u[2 * k + j] = du_;
-                    }
-                    for (int a = 0; a < 3; ++a) {
-                        double l = w->rhs[il(k, a)];
-                        w->lamn[3 * k + a] = l;
-                        clam += cc[3 * k + a] * l;
-                        if (k == n - 2 && c->xf_fixed[a]) nunu += l * l;
-                        double dx = (k + 1 < n - 1 || !c->xf_fixed[a]) ? w->rhs[ixn(k + 1, a)] : 0.0;
-                        w->dz_x[3 * (k + 1) + a] = dx;
-                        dz2 += dx * dx; if (fabs(dx) > dzmax) dzmax = fabs(dx);
-                        {
-                            double g = 0;
-                            const double xd[3] = {w->X[3 * (k + 1)] - w->xf[0], w->X[3 * (k + 1) + 1] - w->xf[1], wrap(w->X[3 * (k + 1) + 2] - w->xf[2])};
-                            const double ws = state_weight(c, n, k + 1);
-                            double qx[3];
-                            if (ws != 0.0) { sym3_mul(c->Q, c->Qo, xd, qx); g = 2 * ws * qx[a] * (c->integral ? w->D : 1.0); }
-                            if (k + 1 == n - 1 && c->has_Qf && !c->xf_fixed[a]) { sym3_mul(c->Qf, c->Qfo, xd, qx); g += 2 * qx[a]; }
-                            hdz += g * dx; dphi += g * dx;
-                        }
-                    }
-                    if (c->via && k + 1 < n - 1) {        /* via-point gradient at grid point k+1 */
-                        double vv, vg[3];
-                        via_terms(w, k + 1, w->X[3 * (k + 1)], w->X[3 * (k + 1) + 1], w->X[3 * (k + 1) + 2], &vv, vg);
-                        for (int a = 0; a < 3; ++a) { hdz += vg[a] * w->dz_x[3 * (k + 1) + a]; dphi += vg[a] * w->dz_x[3 * (k + 1) + a]; }
-                    }
-                }
-                for (int r = 0; r < n; ++r) for (int q = 0; q < 4; ++q) if (row_on(w, r, q)) {
-                    int j = q & 1;
-                    double sg = sgn(q), L = lim(w, q);
-                    double dur = r < n - 1 ? w->dz_u[2 * r + j] : 0.0, dum = r > 0 ? w->dz_u[2 * (r - 1) + j] : 0.0;
-                    double jdz = sg * ((dur - dum) - (r > 0 ? L * ddt : 0.0));
-                    double s = w->s[4 * r + q], y = w->y[4 * r + q], sig = y / s;
-                    double res = row_val_at(w, w->U, w->D, r, q) + s, ybar = mu / s + sig * res;
-                    ds[4 * r + q] = -res - jdz;
-                    dy[4 * r + q] = ybar + sig * jdz - y;
-                    hdz += ybar * jdz;
-                    dphi -= (mu / s) * ds[4 * r + q];
-                    ftb(s, ds[4 * r + q], tau, &a_p);
-                    ftb(y, dy[4 * r + q], tau, &a_d);
-                }
-                for (int k = 1, M = obst_M(w); k < n - 1; ++k) for (int m = 0; m < M; ++m) {
-                    if (w->oi[k * M + m] < 0) continue;
-                    const int dyn_ = is_dynamic(w, w->oi[k * M + m]);
-                    const double jdz = w->oax[k * M + m] * w->dz_x[3 * k] + w->oay[k * M + m] * w->dz_x[3 * k + 1] +
-                                       ((dyn_ && fp_turns(w)) ? w->oat[k * M + m] * w->dz_x[3 * k + 2] + w->oad[k * M + m] * ddt
-                                                              : w->oat[k * M + m] * (dyn_ ? ddt : w->dz_x[3 * k + 2]));
-                    const double sl = w->os[k * M + m], y = w->oy[k * M + m], res = w->og[k * M + m] + sl;
-                    const double sig = y / sl, ybar = mu / sl + sig * res;
-                    w->ods[k * M + m] = -res - jdz;
-                    w->ody[k * M + m] = ybar + sig * jdz - y;
-                    hdz += ybar * jdz;
-                    dphi -= (mu / sl) * w->ods[k * M + m];
-                    ftb(sl, w->ods[k * M + m], tau, &a_p);
-                    ftb(y, w->ody[k * M + m], tau, &a_d);
-                }
-                if (ball_on(w)) {
-                    double jdz = 0;
-                    for (int i = 0; i < 3; ++i) if (!c->xf_fixed[i]) jdz += w->ta[i] * w->dz_x[3 * (n - 1) + i];
-                    const double res = w->tg + w->ts, sig = w->ty / w->ts, ybar = mu / w->ts + sig * res;
-                    w->tds = -res - jdz; w->tdy = ybar + sig * jdz - w->ty;
-                    hdz += ybar * jdz;
-                    dphi -= (mu / w->ts) * w->tds;
-                    ftb(w->ts, w->tds, tau, &a_p);
-                    ftb(w->ty, w->tdy, tau, &a_d);
-                }
+                step_t sp;
+                derive_step(w, cc, mu, tau, ds, dy, &sp);
+                hdz = sp.hdz; dz2 = sp.dz2; dphi = sp.dphi; a_p = sp.a_p; a_d = sp.a_d; dzmax = sp.dzmax;
+                const double clam = sp.clam, nunu = sp.nunu;
                 curv = -hdz + clam - dc * nunu;
                 if (isfinite(curv) && curv >= curv_kappa * dz2) { ok = 1; break; }
             }
+            if (g_algo.convex_fallback && !w->convexify) { w->convexify = g_algo.convex_fallback; continue; }
             if (delta == 0.0) delta = w->delta_last == 0.0 ? delta_first : fmax(delta_min, kminus * w->delta_last);
             else delta *= w->delta_last == 0.0 ? kplus1 : kplus;
             if (delta > delta_max) break;
@@ -1257,40 +1457,110 @@ static int solve_one(work_t* w, int warm) {
         if (started_zero) fail0_streak = delta > 0 ? fail0_streak + 1 : 0;
         else if (g_variant == 2 && (it % 4) == 3) fail0_streak = 0;   /* re-probe delta = 0 now and then */
         double theta = e.theta;
-        if (theta > 0) {
-            double sigma = curv > 0 ? 1.0 : 0.0;
-            double rt = (dphi + 0.5 * sigma * curv) / ((1.0 - rho_frac) * theta);
-            if (w->rho < rt) w->rho = rt + 1.0;
-        }
-        double phi0 = fobj - mu * (barrier_logs(w, w->U, w->D, w->s, w->os) + (ball_on(w) ? log(w->ts) : 0.0)) + w->rho * theta;
-        double Dm = dphi - w->rho * theta;
-        double alpha = a_p, ft = 0;
-        int accepted = 0;
-        for (int ls = 0; ls < max_ls; ++ls) {
-            if (ls > 0) alpha *= 0.5;
-            for (int k = 0; k < n; ++k) for (int i = 0; i < 3; ++i) {
-                double x = w->X[3 * k + i];
-                if (k > 0 && (k < n - 1 || !c->xf_fixed[i])) { x += alpha * w->dz_x[3 * k + i]; if (i == 2) x = wrap(x); }
-                w->Xt[3 * k + i] = x;
+        if (theta0 < 0) { theta0 = theta; }
+        const double theta_max = 1e4 * fmax(1.0, theta0), theta_min = 1e-4 * fmax(1.0, theta0);
+        if (mu_changed || mu != mu_filter) { nfilt = 0; mu_filter = mu; }
+        const double logs0 = barrier_logs(w, w->U, w->D, w->s, w->os) + (ball_on(w) ? log(w->ts) : 0.0);
+        double alpha = a_p, ft = 0, tht = 0;
+        int accepted = 0, ls_used = 0, soc_used = 0;
+        if (g_algo.globalization == 0) {
+            if (theta > 0) {
+                double sigma = curv > 0 ? 1.0 : 0.0;
+                double rt = (dphi + 0.5 * sigma * curv) / ((1.0 - rho_frac) * theta);
+                if (w->rho < rt) w->rho = rt + 1.0;
             }
-            for (int i = 0; i < 2 * (n - 1); ++i) w->Ut[i] = w->U[i] + alpha * w->dz_u[i];
-            w->Dt = w->D + (c->dt_free ? alpha * w->ddt : 0.0);
-            for (int i = 0; i < 4 * n; ++i) st[i] = w->s[i] + alpha * ds[i];
-            for (int i = 0, nm = n * obst_M(w); i < nm; ++i) w->ost[i] = w->oi[i] >= 0 ? w->os[i] + alpha * w->ods[i] : 1.0;
-            eval_point(w, w->Xt, w->Ut, w->Dt, cct, &ft);
-            double tht = 0;
-            for (int i = 0; i < 3 * (n - 1); ++i) tht += fabs(cct[i]);
-            for (int r = 0; r < n; ++r) for (int q = 0; q < 4; ++q) if (row_on(w, r, q)) tht += fabs(row_val_at(w, w->Ut, w->Dt, r, q) + st[4 * r + q]);
-            if (obst_M(w) > 0) tht += obst_theta(w, w->Xt, w->Dt, w->ost);
-            double tlog = 0;
-            if (ball_on(w)) { double ta[3]; w->tst = w->ts + alpha * w->tds; tht += fabs(ball_eval(w, w->Xt, ta) + w->tst); tlog = log(w->tst); }
-            double phit = ft - mu * (barrier_logs(w, w->Ut, w->Dt, st, w->ost) + tlog) + w->rho * tht;
-            if (isfinite(phit) && phit - phi0 - 10 * 2.220446049250313e-16 * fabs(phi0) <= eta * alpha * Dm) { accepted = 1; break; }
+            double phi0 = fobj - mu * logs0 + w->rho * theta;
+            double Dm = dphi - w->rho * theta;
+            for (int ls = 0; ls < max_ls; ++ls) {
+                if (ls > 0) alpha *= 0.5;
+                ls_used = ls;
+                double lg;
+                trial_point(w, alpha, ds, st, cct, &ft, &tht, &lg);
+                double phit = ft - mu * lg + w->rho * tht;
+                if (isfinite(phit) && phit - phi0 - 10 * 2.220446049250313e-16 * fabs(phi0) <= eta * alpha * Dm) { accepted = 1; break; }
+            }
+        } else {
+            /* Ipopt's filter line search (Waechter & Biegler 2006, Algorithm A, steps A-5.1 .. A-5.10) */
+            const double g_th = 1e-5, g_ph = 1e-8, s_ph = 2.3, s_th = 1.1, eta_ph = 1e-8, dlt = 1.0, g_al = 0.05, kappa_soc = 0.99;
+            const double phi_cur = fobj - mu * logs0;
+            double a_min = g_th;
+            if (dphi < 0) {
+                a_min = fmin(a_min, g_ph * theta / (-dphi));
+                if (theta <= theta_min) a_min = fmin(a_min, dlt * pow(theta, s_th) / pow(-dphi, s_ph));
+            }
+            a_min *= g_al;
+            int sw_arm = 0;
+            for (int ls = 0; ls < max_ls; ++ls) {
+                if (ls > 0) alpha *= 0.5;
+                ls_used = ls;
+                if (ls > 0 && alpha < a_min * a_p) break;
+                double lg;
+                trial_point(w, alpha, ds, st, cct, &ft, &tht, &lg);
+                double phit = ft - mu * lg;
+                int okf = isfinite(phit) && tht <= theta_max;
+                for (int f = 0; f < nfilt && okf; ++f) if (!(tht <= (1 - g_th) * fth[f] || phit <= fph[f] - g_ph * fth[f])) okf = 0;
+                const int switching = dphi < 0 && alpha * pow(-dphi, s_ph) > dlt * pow(theta, s_th);
+                const int armijo = phit - phi_cur - 10 * 2.220446049250313e-16 * fabs(phi_cur) <= eta_ph * alpha * dphi;
+                if (okf) {
+                    if (theta <= theta_min && switching) { if (armijo) { accepted = 1; sw_arm = 1; } }
+                    else if (tht <= (1 - g_th) * theta || phit <= phi_cur - g_ph * theta) accepted = 1;
+                }
+                if (accepted) break;
+                if (ls == 0 && g_algo.max_soc > 0 && tht >= theta) {
+                    /* second-order correction (A-5.5 .. A-5.9): c_soc = alpha c(x) + c(x + alpha d), same matrix */
+                    double th_old = theta, a_soc = alpha;
+                    memcpy(csoc, cc, sizeof(double) * 3 * (n - 1));
+                    memcpy(rhs_keep, w->dz_u, sizeof(double) * 2 * (n - 1)); memcpy(rhs_keep + 2 * n, w->dz_x, sizeof(double) * 3 * n);
+                    memcpy(ds_keep, ds, sizeof(double) * 4 * n);
+                    const double ddt_keep = w->ddt;
+                    for (int p_ = 0; p_ < g_algo.max_soc && !accepted; ++p_) {
+                        for (int i = 0; i < 3 * (n - 1); ++i) csoc[i] = a_soc * csoc[i] + cct[i];
+                        double Hdd0, hd1; int have = 1;
+                        w->rhs_only = 1; assemble(w, csoc, delta, dc, &Hdd0, &hd1); w->rhs_only = 0;
+                        if (!border_solve(w, y2, &have, Hdd, hd1)) break;
+                        step_t sc;
+                        derive_step(w, csoc, mu, tau, ds, dy2, &sc);
+                        a_soc = sc.a_p;
+                        double lg2, ft2, tht2;
+                        trial_point(w, a_soc, ds, st, cct, &ft2, &tht2, &lg2);
+                        double phit2 = ft2 - mu * lg2;
+                        int ok2 = isfinite(phit2) && tht2 <= theta_max;
+                        for (int f = 0; f < nfilt && ok2; ++f) if (!(tht2 <= (1 - g_th) * fth[f] || phit2 <= fph[f] - g_ph * fth[f])) ok2 = 0;
+                        const int sw2 = dphi < 0 && alpha * pow(-dphi, s_ph) > dlt * pow(theta, s_th);
+                        const int ar2 = phit2 - phi_cur - 10 * 2.220446049250313e-16 * fabs(phi_cur) <= eta_ph * alpha * dphi;
+                        if (ok2) {
+                            if (theta <= theta_min && sw2) { if (ar2) { accepted = 1; sw_arm = 1; } }
+                            else if (tht2 <= (1 - g_th) * theta || phit2 <= phi_cur - g_ph * theta) accepted = 1;
+                        }
+                        if (accepted) { ft = ft2; tht = tht2; soc_used = p_ + 1; alpha = a_soc; break; }
+                        if (tht2 > kappa_soc * th_old) break;
+                        th_old = tht2;
+                    }
+                    if (!accepted) {     /* back to the Newton step */
+                        memcpy(w->dz_u, rhs_keep, sizeof(double) * 2 * (n - 1)); memcpy(w->dz_x, rhs_keep + 2 * n, sizeof(double) * 3 * n);
+                        memcpy(ds, ds_keep, sizeof(double) * 4 * n); w->ddt = ddt_keep;
+                    }
+                }
+                if (accepted) break;
+            }
+            if (accepted && !sw_arm) {
+                if (nfilt == FCAP) { memmove(fth, fth + 1, sizeof(double) * (FCAP - 1)); memmove(fph, fph + 1, sizeof(double) * (FCAP - 1)); --nfilt; }
+                fth[nfilt] = theta; fph[nfilt] = phi_cur; ++nfilt;
+            }
+            if (!accepted) {
+                ++nresto;
+                /* no restoration phase: empty the filter and take the last trial step */
+                nfilt = 0;
+                double lg; trial_point(w, alpha, ds, st, cct, &ft, &tht, &lg);
+                if (isfinite(ft) && isfinite(lg)) accepted = 2;
+            }
         }
         /* second half (tested BEFORE the line-search failure below: Ipopt answers a failed line search at an acceptable point with success): the line search refuses every trial step, or accepts only one below 1e-6 of the fraction-to-boundary step, at a point whose
          * error is at most acceptable_tol -> the solve ends THERE (nothing is moved) with status 0 */
         if (acc_tol > 0 && (!accepted || alpha < 1e-6 * a_p) && e0 <= acc_tol) { status = 0; break; }
         if (!accepted && alpha * dzmax < 1e-14) { status = 2; break; }
+        if (g_trace) printf("%3d mu %.2e e0 %.3e th %.3e a_p %.3e alpha %.3e a_d %.3e delta %.1e rho %.2e D %.5f obj %.6f acc %d ls %d soc %d nf %d | rd %.2e rp %.2e cmin/mu %.2e cmax/mu %.2e dzmax %.2e curv %.2e\n", it, mu, e0, theta, a_p, alpha, a_d, delta, w->rho, w->D, fobj, accepted, ls_used, soc_used, nfilt, e.rd, e.rp, e.cmin / mu, e.cmax / mu, dzmax, curv);
+        last_alpha = alpha; last_ad = a_d;
         /* accept */
         const double kS = 1e10;
         for (int r = 0; r < n; ++r) for (int q = 0; q < 4; ++q) if (row_on(w, r, q)) {
@@ -1342,7 +1612,7 @@ static int solve_one(work_t* w, int warm) {
             memcpy(bpl, w->pl, sizeof(double) * 2 * (n - 1)); memcpy(bpu, w->pu, sizeof(double) * 2 * (n - 1));
         } else b[0] = 0;
     }
-    free(cc); free(cct); free(st); free(ds); free(dy); free(y2);
+    free(cc); free(cct); free(st); free(ds); free(dy); free(y2); free(rhs_keep); free(csoc); free(ds_keep); free(dy2);
 #pragma omp critical
     { g_nfac_total += nfac; if (nfac > g_nfac_max) g_nfac_max = nfac; }
     return status * 100000 + it;

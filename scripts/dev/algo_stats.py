@@ -1,0 +1,52 @@
+"""dev: convergence statistics of the C oracle's reference path (one candidate) on the BASELINE workloads.
+usage: algo_stats.py key=value ...   (oracle_set_algo keys: mu globalization soc safeguard sigma_max mu_max_fact restoration)"""
+import sys, time, os, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import numpy as np
+from oracle import c_oracle as CO, se2_nlp as R
+from mpc_local_planner_amd import workloads as W
+KEYS = dict(mu=0, glob=1, soc=2, safeguard=3, sigma_max=4, fix_fact=5, cf=6)
+
+def set_algo(args):
+    lib = CO._load()
+    for a in args:
+        k, v = a.split("=")
+        if k in KEYS:
+            lib.oracle_set_algo(C.c_int(KEYS[k]), C.c_double(float(v)))
+
+def run(name, ocfg_nlp, inputs, cap=100, obst=None, **kw):
+    oc = CO.from_nlp_config(ocfg_nlp, max_iter=cap)
+    for k, v in kw.items():
+        setattr(oc, k, v)
+    x0, xf, up, dtp = inputs[:4]
+    t = time.time()
+    if obst is not None:
+        xo, uo, do, st, it = CO.solve_batch(oc, x0, xf, up, dtp, obstacles=inputs[4], obst=obst)
+    else:
+        xo, uo, do, st, it = CO.solve_batch(oc, x0, xf, up, dtp)
+    el = time.time() - t
+    ok = st == 0
+    print(f"{name}: converged {ok.mean()*100:.2f}%  iters mean(all) {it.mean():.2f} mean(conv) {it[ok].mean():.2f} p50 {np.median(it[ok]):.0f} p90 {np.percentile(it[ok],90):.0f} p99 {np.percentile(it[ok],99):.0f}  status hist {np.bincount(st, minlength=5).tolist()}  T={do[ok].mean()*(ocfg_nlp.n-1):.4f} [{el:.1f}s]")
+    return xo, uo, do, st, it
+
+if __name__ == "__main__":
+    CO.build()
+    set_algo(sys.argv[1:])
+    B = int(os.environ.get("B", 1024))
+    kw = {}
+    for a in sys.argv[1:]:
+        k, v = a.split("=")
+        if k in ("mu_init", "tol"):
+            kw[k] = float(v)
+        if k in ("mu_strategy", "hessian_mode"):
+            kw[k] = int(v)
+    run("config2 carlike n50", R.config_carlike_min_time(50), W.carlike_min_time_inputs(B), **kw)
+    if os.environ.get("HM"):
+        run("config2 hessian_mode=1", R.config_carlike_min_time(50), W.carlike_min_time_inputs(B), hessian_mode=1)
+    if os.environ.get("ALL"):
+        run("config5 bicycle n120", R.config_bicycle_min_time(120), W.bicycle_min_time_inputs(256), **kw)
+        run("config1 unicycle n20", R.config_unicycle_quadratic(20), W.unicycle_quadratic_inputs(256), **kw)
+        c3 = R.config_unicycle_quadratic(80)
+        for lat in ((0.3, 1.5), (0.15, 0.8)):
+            inp = W.unicycle_obstacle_inputs(256, n_obst=16, max_vertices=6, lateral=lat)
+            run(f"config3 n80 polygons lateral {lat}", c3, inp, obst=CO.obst_from_nlp_config(c3, 16, 6, 4), **kw)
