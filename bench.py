@@ -5,9 +5,11 @@ One "step" = one pass of the hot path (a full batched NLP solve, cold start exac
 candidate initial trajectories of DESIGN.md section 5.4 hedging the slow instances) over one batch of synthetic planner inputs that are
 already resident in HBM.
 
-  N = 1   workload = BASELINE.json configs[1]: 1024 instances on the GPU.  The same line carries the report on what the hedges cost in solution
-          quality (`solver.hedge_vs_reference_path`) and, as extra legs measured after the timed region: the operating point that keeps the
-          reference path's answer wherever that path converges (`reference_answer_first_caps_100`), the warm-started cycle, the per-GPU share of
+  N = 1   workload = BASELINE.json configs[1]: 1024 instances on the GPU at the PARITY-PRESERVING operating point: candidate 0 (the reference's cold
+          start) runs the reference's 100 iterations, `solver.answers_equal_to_the_reference_path_alone` says for which share of the instances the
+          returned trajectory is bit for bit what the reference path alone returns (or that path fails).  Extra legs measured after the timed region:
+          the latency-tuned point with candidate 0 capped at 60 iterations and what its hedges cost in solution quality (`hedged_caps_60`), the
+          warm-started cycle, the per-GPU share of
           configs[3] (car-like n=50, B=4096), configs[2] (unicycle n=80, 16 polygons, B=4096) on a placement where clearance rows bind and on one
           where they stay inactive (with the share of instances that end with an active row), the per-GPU share of configs[4] (bicycle n=120,
           B=1024) in MPC_MIXED -- the precision that meets the 1e-4 tolerance, hence the leg that counts -- and in plain fp32, the latency of one
@@ -15,7 +17,7 @@ already resident in HBM.
   N > 1   workload = BASELINE.json configs[3]: 4096 instances per GPU (32768 at N=8), rank r draws its inputs from seed+r; no data-path
           collective inside the timed region.  After it, the per-rank results (status, dt, x -- device resident) are all-gathered over
           RCCL so that every rank holds the whole job's answer; that exchange is timed separately and reported as `gather_ms`.  The line
-          carries `per_gpu_reference` (the one-GPU figure of the same 4096-instance workload from the committed N = 1 line).
+          carries `per_gpu_reference`: rank 0 alone on the same 4096 instances, timed in the same run before the joint timed region.
 
 `value` counts CONVERGED solves only (a Controller::step that returns false makes the planner reset and command zero,
 src/mpc_local_planner_ros.cpp:394-404); `value_all_solves` counts every instance.
@@ -46,10 +48,16 @@ FP32_VECTOR_PEAK_TF = 157.3
 # its cap bounds the launch time).  Chosen with the C oracle over EIGHT seeds of the config-2 distribution (>= 99.3 % converged on each, 99.45 %
 # on average; DESIGN.md section 5.4 has the measured sweep).
 CAND_KINDS = (0, 5, 5, 7)
-CAND_CAPS = (60, 45, 40, 35)
+# HEADLINE operating point: candidate 0 -- the reference's cold start -- runs the reference's full iteration budget (100,
+# src/controller.cpp:390), so every instance the reference path solves keeps exactly that answer; the hedges only serve the rest.  The line carries
+# `solver.answers_equal_to_the_reference_path_alone` (checked against a run of the reference path alone on the same inputs).
+CAND_CAPS = (100, 45, 40, 35)
+# the latency-tuned operating point of rounds 2/3 (candidate 0 capped at 60 iterations: ~7 % of the instances get a hedge's local optimum although the
+# reference path would have converged later), reported as the leg `hedged_caps_60`
+CAND_CAPS_HEDGED = (60, 45, 40, 35)
 # at 4096 instances per GPU the launch is bound by the total work, not by its slowest instance: longer hedge caps cost nothing there and lift the converged
 # fraction (profiles/r02_candidate_sweep_B4096.log: 99.95 % instead of 99.2 % at the same 10.1 ms)
-CAND_CAPS_LARGE_BATCH = (60, 60, 50, 40)
+CAND_CAPS_LARGE_BATCH = (100, 60, 50, 40)
 CAND_PARAMS = (0.0, 2.0, 3.0, 1.5)
 CAND5_KINDS, CAND5_CAPS, CAND5_PARAMS = (0, 1, 2, 5), (60, 50, 45, 40), (0.0, 0.0, 0.0, 2.0)      # config-5 legs (bicycle, n = 120)
 
@@ -251,7 +259,19 @@ def main():
     # reference copy of the last warm-up step's results: the timed steps solve the same inputs and have to reproduce them bit for bit (the candidate
     # rule is timing independent); the LAST step is compared after the timed region
     ref_out = (leg.xo.clone(), leg.uo.clone(), leg.do.clone(), leg.st.clone(), leg.it.clone()) if args.warmup > 0 else None
+    # N > 1: the denominator for scaling efficiency is measured in THIS run -- rank 0 solves its 4096 instances alone (the other ranks wait at the
+    # barrier), same box, same clocks, same warm-up state -- before the joint timed region
+    solo_elapsed = None
     if multi:
+        dist.barrier()
+        leg.sync()
+        if rank == 0:
+            ts = time.perf_counter()
+            for _ in range(args.steps):
+                leg.step()
+                leg.solver.synchronize()
+            leg.sync()
+            solo_elapsed = time.perf_counter() - ts
         dist.barrier()
     leg.sync()
     kernel_ms = []
@@ -298,6 +318,8 @@ def main():
         bytes_per_launch = algorithmic_bytes_per_solve(n) * B
         achieved_gbs = bytes_per_launch / (k_ms * 1e-3) / 1e9
         flops_per_iter = 914.0 * (n - 1)               # SURVEY.md 8d convention
+        from mpc_local_planner_amd import _lib as mlib
+        pk64, pk32 = mlib.measured_fma_peak(local_rank, True), mlib.measured_fma_peak(local_rank, False)
         fp64_tf = B * sstat["iters_total_mean"] * flops_per_iter / (k_ms * 1e-3) / 1e12
         fp64_useful_tf = B * sstat["iters_mean"] * flops_per_iter / (k_ms * 1e-3) / 1e12
         wl = ("BASELINE.json configs[1]: carlike (Ackermann) minimum-time MPC, n=50 grid points, batch=1024 instances on 1 MI355X" if (world == 1 and B == BATCH_1GPU and n == N_GRID) else
@@ -327,52 +349,61 @@ def main():
                                        "frac": fp64_tf / FP64_VECTOR_PEAK_TF,
                                        "useful_tflops": fp64_useful_tf, "useful_frac": fp64_useful_tf / FP64_VECTOR_PEAK_TF,
                                        "flops_per_iteration": flops_per_iter,
+                                       "peak_measured_tflops": (pk64[0] if pk64 else None), "frac_of_measured_peak": (fp64_tf / pk64[0] if pk64 else None),
+                                       "fp32_peak_measured_tflops": (pk32[0] if pk32 else None),
+                                       "peak_measured_how": "csrc/mpc_ubench.hip: 8 independent v_fma_f64 (v_pk_fma_f32) chains per lane, 8 waves per SIMD on every CU, best of 3 launches of ~10 ms",
                                        "note": "frac counts the iterations of ALL candidates of an instance as work; useful_frac only those of the candidate that supplied the result"}},
         }
         if gather is not None:
             line["gather"] = gather
-        if multi:
-            # per-GPU reference of this workload (4096 instances per GPU): the config4_share_B4096 leg of the committed one-GPU line
-            ref = None
-            try:
-                ref = json.load(open(os.path.join(ROOT, "profiles", "r03_bench.json")))["legs"]["config4_share_B4096"]["value"]
-            except (OSError, ValueError, KeyError):
-                pass
-            line["per_gpu_reference"] = {"value": ref, "unit": "solves/s", "what": "legs.config4_share_B4096 of the N = 1 line in profiles/r03_bench.json: the same 4096 instances "
-                                         "per GPU on ONE MI355X -- the denominator for scaling efficiency, not the N = 1 headline (1024 instances, latency bound)"}
+        if multi and solo_elapsed is not None:
+            line["per_gpu_reference"] = {"value": B * float(ok.mean()) * args.steps / solo_elapsed, "unit": "solves/s", "ms_per_step": solo_elapsed / args.steps * 1e3,
+                                         "what": "rank 0 alone on the same %d instances, %d steps, measured in this run right before the joint timed region (the other ranks wait "
+                                                 "at a barrier): the denominator for scaling efficiency, not the N = 1 headline (1024 instances, latency bound)" % (B, args.steps)}
+
+    # ---- parity statement of the headline (every N; outside the timed region): the same inputs through the REFERENCE PATH ALONE (one candidate, the
+    # reference's 100 iterations).  An instance counts as "equal" when the reference path converges and the headline returns candidate 0's trajectory,
+    # bit for bit the reference path's, or when the reference path does not converge (then a hedge may answer).
+    st_r = dt_r = None
+    if len(kinds) > 1:
+        win_h, _ = leg.solver.last_candidates(B)
+        lr = Leg(m, torch, dev, m.config_carlike_min_time(n=n), B, m.workloads.carlike_min_time_inputs(B, seed=sharding.rank_seed(m.workloads.SEED_CONFIG2, rank)))
+        lr.step(); lr.sync()
+        dt_r = lr.do.cpu().numpy(); st_r = lr.st.cpu().numpy()
+        conv_r = lr.st == 0
+        same_traj = ((lr.xo == leg.xo).flatten(1).all(1) & (lr.uo == leg.uo).flatten(1).all(1) & (lr.do == leg.do)).cpu().numpy()
+        equal = np.where(st_r == 0, (win_h == 0) & same_traj, True)
+        if rank == 0:
+            line["solver"]["answers_equal_to_the_reference_path_alone"] = float(equal.mean())
+            line["solver"]["reference_path_alone_converged_frac"] = float((st_r == 0).mean())
+            line["solver"]["parity_note"] = ("candidate 0 = the reference's cold start with the reference's iteration budget (%d); 1.0 = every instance that path solves is answered with "
+                                             "exactly its trajectory (bit for bit), hedges answer only instances it leaves unsolved" % caps[0])
+        lr.close()
 
     # ---- extra legs (N = 1 only; after the timed region)
     if not multi and not args.no_legs:
         legs = {}
-        # what the hedges cost in solution quality: the same instances through the REFERENCE PATH ALONE (one candidate, 100
-        # iterations = the reference's solver budget); for every instance that path solves but a hedge answered in the headline run (its
-        # candidate 0 is capped at 60 iterations), objective(hedge's answer) - objective(reference path's answer), objective = (n - 1) dt
         if len(kinds) > 1:
-            win_h, _ = leg.solver.last_candidates(B)
-            dt_h = leg.do.cpu().numpy().copy(); st_h = leg.st.cpu().numpy().copy()
-            lr = Leg(m, torch, dev, m.config_carlike_min_time(n=n), B, m.workloads.carlike_min_time_inputs(B, seed=sharding.rank_seed(m.workloads.SEED_CONFIG2, rank)))
-            lr.step(); lr.sync()
-            dt_r = lr.do.cpu().numpy(); st_r = lr.st.cpu().numpy()
-            lr.close()
-            sel = (win_h > 0) & (st_h == 0) & (st_r == 0)
+            # the latency-tuned operating point of rounds 2/3: candidate 0 capped at 60 iterations.  Faster, but instances the reference path would still
+            # have solved get a hedge's answer -- a different local optimum in most of them; what that costs in solution quality is reported here:
+            # objective(hedge's answer) - objective(reference path's answer), objective = (n - 1) dt
+            capsh = CAND_CAPS_HEDGED[:len(kinds)]
+            lh = Leg(m, torch, dev, m.config_carlike_min_time(n=n, candidates=kinds, candidate_max_iter=capsh, candidate_param=pars), B,
+                     m.workloads.carlike_min_time_inputs(B, seed=sharding.rank_seed(m.workloads.SEED_CONFIG2, rank)))
+            legs["hedged_caps_60"] = leg_summary(lh, max(2, args.steps // 2), 1, algorithmic_bytes_per_solve(n), 914.0 * (n - 1), FP64_VECTOR_PEAK_TF, f"carlike_n{n}_B{B}_c{len(kinds)}")
+            legs["hedged_caps_60"]["candidate_max_iter"] = list(capsh)
+            wh, _ = lh.solver.last_candidates(B)
+            dt_h = lh.do.cpu().numpy().copy(); st_h = lh.st.cpu().numpy().copy()
+            lh.close()
+            sel = (wh > 0) & (st_h == 0) & (st_r == 0)
             dobj = (n - 1) * (dt_h[sel] - dt_r[sel])
-            line["solver"]["hedge_vs_reference_path"] = {
-                "reference_path_alone_converged_frac": float((st_r == 0).mean()),
-                "instances_answered_by_a_hedge": int((win_h > 0).sum()), "of_which_the_100_iteration_reference_path_solves": int(sel.sum()),
+            legs["hedged_caps_60"]["answers_equal_to_the_reference_path_alone"] = float(np.where(st_r == 0, wh == 0, True).mean())
+            legs["hedged_caps_60"]["hedge_vs_reference_path"] = {
+                "instances_answered_by_a_hedge": int((wh > 0).sum()), "of_which_the_100_iteration_reference_path_solves": int(sel.sum()),
                 "objective_hedge_minus_reference": ({"min": float(dobj.min()), "p10": float(np.percentile(dobj, 10)), "median": float(np.median(dobj)), "p90": float(np.percentile(dobj, 90)),
                                                      "max": float(dobj.max()), "same_within_1e-6": float((np.abs(dobj) < 1e-6).mean()), "hedge_better": float((dobj < -1e-6).mean()),
                                                      "hedge_worse": float((dobj > 1e-6).mean())} if sel.any() else None),
                 "unit": "seconds of travel time ((n-1) dt); negative = the hedge's local optimum is FASTER than the reference path's"}
-            # the other operating point: candidate 0 runs the reference's full budget, so that every instance the reference path solves keeps
-            # exactly that answer and the hedges only serve the rest
-            caps100 = (100,) + tuple(caps[1:])
-            l100 = Leg(m, torch, dev, m.config_carlike_min_time(n=n, candidates=kinds, candidate_max_iter=caps100, candidate_param=pars), B,
-                       m.workloads.carlike_min_time_inputs(B, seed=sharding.rank_seed(m.workloads.SEED_CONFIG2, rank)))
-            legs["reference_answer_first_caps_100"] = leg_summary(l100, max(2, args.steps // 2), 1, algorithmic_bytes_per_solve(n), 914.0 * (n - 1), FP64_VECTOR_PEAK_TF, f"carlike_n{n}_B{B}_c{len(kinds)}_caps100")
-            legs["reference_answer_first_caps_100"]["candidate_max_iter"] = list(caps100)
-            w100, _ = l100.solver.last_candidates(B)
-            legs["reference_answer_first_caps_100"]["answers_equal_to_the_reference_path_alone"] = float(((w100 == 0) == (st_r == 0)).mean())
-            l100.close()
         # warm start, reported separately: the plant advances one controller period (0.2 s) with u_0, the previous solution is
         # the initial guess with x0 overwritten (full_discretization_grid_base_se2.cpp:101-110; variable grid: no shifting)
         per, Lw = 0.2, float(cfg.model_params[0])

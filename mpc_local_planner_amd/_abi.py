@@ -102,7 +102,7 @@ class MpcConfig(C.Structure):
         ("hessian_mode", C.c_int32),
         ("hybrid_cost_minimum_time", C.c_int32),
         ("cost_integration", C.c_int32),
-        ("reserved", C.c_int32 * 4),
+        ("mu_strategy", C.c_int32), ("reserved", C.c_int32 * 3),
         ("Q_offdiag", C.c_double * 3),
         ("R_offdiag", C.c_double),
         ("Qf_offdiag", C.c_double * 3),

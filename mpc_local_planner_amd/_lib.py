@@ -15,6 +15,7 @@ from ._abi import MpcConfig
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libmpc_hip.so")
+UBENCH_PATH = os.path.join(CSRC, "libmpc_ubench.so")     # measurement aid of bench.py (full-occupancy FMA rate), not part of the C ABI
 SOURCES = ["mpc_capi.hip", "mpc_solve_inst.hip"]
 HEADERS = ["mpc_solve_kernel.hpp", "mpc_core.hpp", "mpc_problem.hpp", "mpc_wave.hpp", "mpc_dpp_blocks.inc", "mpc_costmap.hpp", "mpc_feasibility.hpp", "mpc_grid_update.hpp", os.path.join("..", "..", "include", "mpc_hip.h")]
 
@@ -48,6 +49,7 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str |
     Split build: the ABI + the small kernels (mpc_capi.hip) and one object per (arithmetic type, model) pair of the solve kernel
     (mpc_solve_inst.hip, three kernel instantiations each) are compiled in parallel, then linked.  A plain
     `hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared mpc_capi.hip -o libmpc_hip.so` gives the same library from one translation unit."""
+    build_ubench(force=force, verbose=verbose)
     if out is None and not force and not needs_build():
         return LIB_PATH
     from concurrent.futures import ThreadPoolExecutor
@@ -72,6 +74,30 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str |
     link = [_hipcc(), "--offload-arch=gfx950", "-fPIC", "-shared"] + [j[-1] for j in jobs] + ["-o", out]
     run(link)
     return out
+
+
+def build_ubench(force: bool = False, verbose: bool = False) -> str:
+    """csrc/mpc_ubench.hip -> csrc/libmpc_ubench.so: the FMA-rate micro-benchmark bench.py reports next to the data-sheet peaks."""
+    src = os.path.join(CSRC, "mpc_ubench.hip")
+    if force or not os.path.exists(UBENCH_PATH) or os.path.getmtime(UBENCH_PATH) < os.path.getmtime(src):
+        cmd = [_hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", src, "-o", UBENCH_PATH]
+        if verbose:
+            print(" ".join(cmd), flush=True)
+        subprocess.run(cmd, check=True, cwd=CSRC)
+    return UBENCH_PATH
+
+
+def measured_fma_peak(device: int = 0, fp64: bool = True, iters: int = 20000):
+    """(TFLOP/s, ms) of the full-occupancy v_fma_f64 / v_pk_fma_f32 loop of csrc/mpc_ubench.hip on `device`; None without the library."""
+    if not os.path.exists(UBENCH_PATH):
+        return None
+    lib = C.CDLL(UBENCH_PATH)
+    fn = lib.mpc_ubench_fma_f64 if fp64 else lib.mpc_ubench_fma_f32
+    fn.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    tf, ms = C.c_double(0.0), C.c_double(0.0)
+    if fn(device, iters, C.byref(tf), C.byref(ms)) != 0:
+        return None
+    return tf.value, ms.value
 
 
 _lib = None

@@ -65,6 +65,8 @@ struct mpc_solver {
     int32_t *d_winner, *d_iters_total;
     int32_t* d_rows_dropped;    // per instance: clearance rows that did not fit (solvers with obstacles)
     double* d_dual;             // per instance: multipliers of the last converged solve (dual_warm_start)
+    void* d_stage = nullptr;    // device staging of the host-pointer helpers (mpc_costmap_to_obstacles, mpc_check_feasibility): kept across calls, grows on demand
+    size_t stage_bytes = 0;
     int dual_words;
     int32_t* last_status;       // device pointers of the most recent solve (mpc_last_candidates without candidates)
     int32_t* last_iters;
@@ -76,6 +78,22 @@ static bool solver_ext(const mpc_solver* s) {
     const mpc::Problem<double>& P = s->P64;
     return P.ball || P.via || P.integral_form || P.dyn_obst || P.hess_mode || P.costx ||
            (P.n_obst > 0 && (P.footprint_kind == MPC_FOOTPRINT_LINE || P.footprint_kind == MPC_FOOTPRINT_TWO_CIRCLES || P.footprint_kind == MPC_FOOTPRINT_POLYGON));
+}
+
+// Device staging of the host-pointer helpers: ONE allocation kept in the handle and carved into 256-byte aligned pieces (these calls sit in a B = 1 control
+// loop next to a sub-millisecond solve; a hipMalloc / hipFree pair per temporary per call cost more than the kernels they feed).  Grows on demand, freed by mpc_destroy.
+static hipError_t stage_carve(mpc_solver* s, const size_t* sz, int count, void** out) {
+    size_t total = 0;
+    for (int i = 0; i < count; ++i) total += (sz[i] + 255) & ~(size_t)255;
+    if (total > s->stage_bytes) {
+        if (s->d_stage) { (void)hipStreamSynchronize(s->stream); (void)hipFree(s->d_stage); s->d_stage = nullptr; s->stage_bytes = 0; }
+        const hipError_t er = hipMalloc(&s->d_stage, total);
+        if (er != hipSuccess) return er;
+        s->stage_bytes = total;
+    }
+    size_t off = 0;
+    for (int i = 0; i < count; ++i) { out[i] = (char*)s->d_stage + off; off += (sz[i] + 255) & ~(size_t)255; }
+    return hipSuccess;
 }
 
 extern "C" {
@@ -282,7 +300,7 @@ void mpc_destroy(mpc_solver* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    void* bufs[] = {s->d_iters1, s->d_dual, s->d_rows_dropped, s->d_cwin, s->d_cexited, s->d_citsum, s->d_crec, s->d_winner, s->d_iters_total, s->d_nvia, s->d_via, s->d_ngrid, s->d_in, s->d_out};
+    void* bufs[] = {s->d_stage, s->d_iters1, s->d_dual, s->d_rows_dropped, s->d_cwin, s->d_cexited, s->d_citsum, s->d_crec, s->d_winner, s->d_iters_total, s->d_nvia, s->d_via, s->d_ngrid, s->d_in, s->d_out};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (s->h_in) (void)hipHostFree(s->h_in);
     if (s->h_out) (void)hipHostFree(s->h_out);
@@ -493,8 +511,7 @@ int mpc_costmap_to_obstacles(mpc_solver* s, int32_t B, const uint8_t* cost, int3
     const size_t O = s->cfg.max_obstacles, V = s->cfg.max_vertices > 0 ? s->cfg.max_vertices : 1, nb = (size_t)B;
     const size_t sz[7] = {nb * size_x * size_y, nb * 2 * 8, nb * 3 * 8, nb * 4, nb * O * 4, nb * O * V * 2 * 8, nb * 4};
     void* d[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipError_t er = hipSuccess;
-    for (int i = 0; i < 7 && er == hipSuccess; ++i) er = hipMalloc(&d[i], sz[i]);
+    hipError_t er = stage_carve(s, sz, 7, d);
     int rc = MPC_OK;
     if (er == hipSuccess) er = hipMemcpyAsync(d[0], cost, sz[0], hipMemcpyHostToDevice, s->stream);
     if (er == hipSuccess) er = hipMemcpyAsync(d[1], origin, sz[1], hipMemcpyHostToDevice, s->stream);
@@ -509,7 +526,6 @@ int mpc_costmap_to_obstacles(mpc_solver* s, int32_t B, const uint8_t* cost, int3
     if (er == hipSuccess && rc == MPC_OK) er = hipMemcpyAsync(vertices, d[5], sz[5], hipMemcpyDeviceToHost, s->stream);
     if (er == hipSuccess && rc == MPC_OK && dropped) er = hipMemcpyAsync(dropped, d[6], sz[6], hipMemcpyDeviceToHost, s->stream);
     if (er == hipSuccess) er = hipStreamSynchronize(s->stream);
-    for (int i = 0; i < 7; ++i) if (d[i]) (void)hipFree(d[i]);
     if (er != hipSuccess) { set_err("mpc_costmap_to_obstacles", er); return er == hipErrorOutOfMemory ? MPC_ENOMEM : MPC_EHIP; }
     return rc;
 }
@@ -596,8 +612,7 @@ int mpc_check_feasibility(mpc_solver* s, int32_t B, const double* x, const uint8
     const size_t nb = B, n = s->cfg.n;
     const size_t sz[4] = {nb * n * 3 * 8, nb * size_x * size_y, nb * 2 * 8, nb * 4};
     void* d[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipError_t er = hipSuccess;
-    for (int i = 0; i < 4 && er == hipSuccess; ++i) er = hipMalloc(&d[i], sz[i]);
+    hipError_t er = stage_carve(s, sz, 4, d);
     int rc = MPC_OK;
     if (er == hipSuccess) er = hipMemcpyAsync(d[0], x, sz[0], hipMemcpyHostToDevice, s->stream);
     if (er == hipSuccess) er = hipMemcpyAsync(d[1], cost, sz[1], hipMemcpyHostToDevice, s->stream);
@@ -607,7 +622,6 @@ int mpc_check_feasibility(mpc_solver* s, int32_t B, const double* x, const uint8
                                           inscribed_radius, min_resolution_collision_check_angular, look_ahead_idx, (int32_t*)d[3]);
     if (er == hipSuccess && rc == MPC_OK) er = hipMemcpyAsync(feasible, d[3], sz[3], hipMemcpyDeviceToHost, s->stream);
     if (er == hipSuccess) er = hipStreamSynchronize(s->stream);
-    for (int i = 0; i < 4; ++i) if (d[i]) (void)hipFree(d[i]);
     if (er != hipSuccess) { set_err("mpc_check_feasibility", er); return er == hipErrorOutOfMemory ? MPC_ENOMEM : MPC_EHIP; }
     return rc;
 }

@@ -92,6 +92,7 @@ struct Problem {
     int acc_iter;
     T pit_mu_min;        // ... while the barrier parameter is above this (the last iterations of a solve take the serial sweeps: see DESIGN.md)
     int pit;             // partitioned (parallel-in-time) sweeps for grids of 40 points and more (1; 0 = the serial sweeps everywhere: developer switch MPC_NO_PIT)
+    int mu_strategy;     // mpc_config.mu_strategy: 0 adaptive barrier parameter (the default), 1 monotone Fiacco-McCormick
 };
 
 // Algorithm constants (Waechter & Biegler 2006 names).  Compile-time so that they live in
@@ -107,6 +108,11 @@ template <> struct Algo<double> {
     // violated pins the fraction-to-boundary rule from the first iteration on (steps of 1e-3) and, without Ipopt's restoration phase, the solve never
     // leaves that corner: obstacles inside the clearance band converge in 81 % of the instances with 1e-2 and in 98 % with 0.5
     static constexpr double clearance_slack_push = 0.5;
+    // adaptive barrier parameter (mpc_wave.hpp::solve): sigma = clamp((1 - min(alpha, alpha_dual))^3, sigma_min, 1) from the last iteration's step lengths,
+    // mu = sigma x average complementarity, never below min(mu, mu_err_floor x E_0), inside [tol / 10, mu_max_fact x the solve's first mu]
+    static constexpr double sigma_min = 0.05, mu_err_floor = 3e-2, mu_max_fact = 1e3;
+    // control seed of a cold start: increments kept inside this fraction of the control-rate limits
+    static constexpr double rate_seed_frac = 0.9;
 };
 template <> struct Algo<float> {
     static constexpr float kappa_eps = 10, kappa_mu = 0.2f, theta_mu = 1.5f, tau_min = 0.99f, bound_push = 1e-2f, slack_push = 1e-2f;
@@ -115,6 +121,8 @@ template <> struct Algo<float> {
     static constexpr float curv_kappa = 1e-7f, s_max = 100, delta_c = 1e-5f, kappa_c = 0.25f, ls_eps = 10 * 1.1920929e-7f;
     static constexpr int max_ls = 30;
     static constexpr float clearance_slack_push = 0.5f;
+    static constexpr float sigma_min = 0.05f, mu_err_floor = 3e-2f, mu_max_fact = 1e3f;
+    static constexpr float rate_seed_frac = 0.9f;
 };
 
 MPC_HD double t_abs(double a) { return __builtin_fabs(a); }      // a source modifier on the GPU (the compare-and-select form costs 3 instructions)

@@ -918,7 +918,7 @@ struct IpmWave {
     }
 
     // ---------------------------------------------------------------- KKT error + stage records
-    struct Err { T rd, rp, cmin, cmax, sum_mult, sum_bmult, theta; int n_mult, n_bmult; };
+    struct Err { T rd, rp, cmin, cmax, csum, sum_mult, sum_bmult, theta; int n_mult, n_bmult; };     // csum: sum of the n_bmult complementarity products
 
     // Ipopt's scaled optimality error E_mu.  (reciprocals instead of IEEE divisions -- ~100 ticks each for a lone wave --: 1/count is cached with the counts,
     // 1/s_max is a constant, the two scalings are inverted once per call)
@@ -933,7 +933,7 @@ struct IpmWave {
     __device__ __forceinline__ Err kkt_pass() const {
         const int n = L.n;
         const T d = SCL(SC_D);
-        T rd = T(0), rp = T(0), cmin = T(1e30), cmax = T(0), smult = T(0), sb = T(0), th = T(0), rdd = T(0);
+        T rd = T(0), rp = T(0), cmin = T(1e30), cmax = T(0), smult = T(0), sb = T(0), th = T(0), rdd = T(0), cs = T(0);
         int nm = 0, nb = 0;
         for (int k = lane; k < n; k += kWave) {
             T rec[21];
@@ -993,7 +993,7 @@ struct IpmWave {
                         const T s = F(L.OS, m, k), y = F(L.OY, m, k);
                         const T res = g + s;
                         rp = t_max(rp, t_abs(res)); th += t_abs(res);
-                        cmin = t_min(cmin, s * y); cmax = t_max(cmax, s * y);
+                        cmin = t_min(cmin, s * y); cmax = t_max(cmax, s * y); cs += s * y;
                         sb += y; nb += 1;
                         osx += y * ax; osy += y * ay;
                         if (dynturn()) { rdd += y * ad; ost += y * a3[2]; }
@@ -1017,7 +1017,7 @@ struct IpmWave {
                     }
                     rd = t_max(rd, t_abs(r));
                     T cl = (u - P.u_lb[j]) * pl, cu = (P.u_ub[j] - u) * pu;
-                    cmin = t_min(cmin, t_min(cl, cu)); cmax = t_max(cmax, t_max(cl, cu));
+                    cmin = t_min(cmin, t_min(cl, cu)); cmax = t_max(cmax, t_max(cl, cu)); cs += cl + cu;
                     sb += pl + pu; nb += 2;
                 }
                 if (k == n - 2) {
@@ -1027,7 +1027,7 @@ struct IpmWave {
                         ty = SCL(SC_TY);
                         SCL(SC_TG) = tg; SCL(SC_TA) = ta[0]; SCL(SC_TA + 1) = ta[1]; SCL(SC_TA + 2) = ta[2];
                         rp = t_max(rp, t_abs(tg + ts)); th += t_abs(tg + ts);
-                        cmin = t_min(cmin, ts * ty); cmax = t_max(cmax, ts * ty);
+                        cmin = t_min(cmin, ts * ty); cmax = t_max(cmax, ts * ty); cs += ts * ty;
                         sb += ty; nb += 1;
                     }
                     T gext[3] = {T(0), T(0), T(0)};
@@ -1056,7 +1056,7 @@ struct IpmWave {
                 T s = F(L.SR, q, k), y = F(L.YR, q, k);
                 T res = row_val(L.U, d, k, q) + s;
                 rp = t_max(rp, t_abs(res)); th += t_abs(res);
-                cmin = t_min(cmin, s * y); cmax = t_max(cmax, s * y);
+                cmin = t_min(cmin, s * y); cmax = t_max(cmax, s * y); cs += s * y;
                 sb += y; nb += 1;
                 if (k > 0) rdd -= slot_sign<T>(q) * P.rate_lim[q] * y;
             }
@@ -1076,7 +1076,7 @@ struct IpmWave {
                 T pl = SCL(SC_PDL), pu = SCL(SC_PDU);
                 rdd += -pl + pu;
                 T cl = (d - P.dt_lb) * pl, cu = (P.dt_ub - d) * pu;
-                cmin = t_min(cmin, t_min(cl, cu)); cmax = t_max(cmax, t_max(cl, cu));
+                cmin = t_min(cmin, t_min(cl, cu)); cmax = t_max(cmax, t_max(cl, cu)); cs += cl + cu;
                 sb += pl + pu; nb += 2;
             }
         }
@@ -1087,6 +1087,7 @@ struct IpmWave {
         e.rp = wave_max(rp);
         e.cmin = wave_min(cmin);
         e.cmax = wave_max(cmax);
+        e.csum = wave_sum(cs);
         e.sum_bmult = wave_sum(sb);
         e.sum_mult = wave_sum(smult) + e.sum_bmult;
         e.theta = wave_sum(th);
@@ -2437,6 +2438,19 @@ struct IpmWave {
                 w = t_min(t_max(w, P.u_lb[1]), P.u_ub[1]);
                 F(L.U, 0, k) = v; F(L.U, 1, k) = w;
             }
+            sync();
+            // ... and keep the seeded controls inside the control-rate rows, as the reference's u = 0 start is (every row but the first): increments clamped to
+            // rate_seed_frac x the rate limits forward from u_prev, then backward from the final row (against u_ref = 0).  A seed that jumps violates the rows it
+            // crosses: their slacks start at the 1e-2 floor with a residual and the fraction-to-boundary rule pins the first iterations.  Lane j walks control j.
+            if (lane < 2 && ron(lane) && ron(2 + lane)) {
+                const int j = lane;
+                const T fr = Algo<T>::rate_seed_frac, lo = P.rate_lim[j] * d0 * fr, hi = P.rate_lim[2 + j] * d0 * fr;
+                T prev = F(L.U, j, 0);
+                if (row0_on) { const T up_ = j ? uprev[1] : uprev[0]; prev = t_min(t_max(prev, up_ + P.rate_lim[j] * dtprev * fr), up_ + P.rate_lim[2 + j] * dtprev * fr); F(L.U, j, 0) = prev; }
+                for (int k = 1; k < n - 1; ++k) { prev = t_min(t_max(F(L.U, j, k), prev + lo), prev + hi); F(L.U, j, k) = prev; }
+                T nxt = T(0);
+                for (int k = n - 2; k >= 0; --k) { nxt = t_min(t_max(F(L.U, j, k), nxt - hi), nxt - lo); F(L.U, j, k) = nxt; }
+            }
         }
         sync();
         for (int k = lane; k < n - 1; k += kWave)
@@ -2506,6 +2520,9 @@ struct IpmWave {
         const T acc_tol = P.acc_tol;
         const int acc_it = P.acc_iter;
         T e0 = T(0), logs_cur = T(0), dc_mu = T(-1), dc_val = T(0);
+        T last_alpha = T(0), last_ad = T(0);
+        bool endgame = false;
+        const T mu_max = Algo<T>::mu_max_fact * mu;
         bool have_logs = false;
 #ifdef MPC_PROFILE
         long long tk[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int nfac = 0, ntrial = 0;
@@ -2535,12 +2552,25 @@ struct IpmWave {
                 const int w = __builtin_amdgcn_readfirstlane(__hip_atomic_load(win_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 if (w < my_cand) { status = ST_SUPERSEDED; break; }
             }
-            for (int guard = 0; guard < 50; ++guard) {
-                T emu = err_value(er, mu);
-                if (emu <= Algo<T>::kappa_eps * mu && mu > P.tol / T(10)) {
-                    mu = t_max(P.tol / T(10), t_min(Algo<T>::kappa_mu * mu, t_pow(mu, Algo<T>::theta_mu)));
-                    rho = T(0);
-                } else break;
+            if (P.mu_strategy == 1 || endgame) {        // monotone Fiacco-McCormick (Ipopt's own default mu_strategy; the end game of the adaptive one)
+                for (int guard = 0; guard < 50; ++guard) {
+                    T emu = err_value(er, mu);
+                    if (emu <= Algo<T>::kappa_eps * mu && mu > P.tol / T(10)) {
+                        mu = t_max(P.tol / T(10), t_min(Algo<T>::kappa_mu * mu, t_pow(mu, Algo<T>::theta_mu)));
+                        rho = T(0);
+                    } else break;
+                }
+            } else {
+                // adaptive (the default; what corbo's SolverIpopt is believed to set): mu = sigma x the average complementarity, sigma from the step lengths the
+                // LAST iteration achieved -- Mehrotra's (mu_aff / mu)^3 read off the step that was actually taken, no second solve --, never below
+                // min(mu, mu_err_floor x E_0) (a barrier far below the optimality error is what stalls the non-convex instances), inside [tol / 10, mu_max_fact x mu_0]
+                const T avg = er.csum * inv_cnt_bmult;
+                const T a_ = T(1) - t_min(last_alpha, last_ad);
+                const T sig = it == 0 ? T(1) : t_min(t_max(a_ * a_ * a_, Algo<T>::sigma_min), T(1));
+                T mu_new = t_min(t_max(sig * avg, P.tol / T(10)), mu_max);
+                mu_new = t_max(mu_new, t_min(mu, Algo<T>::mu_err_floor * e0));
+                if (mu_new <= P.tol) { mu_new = P.tol; endgame = true; }      // end game: from mu = tol on the monotone rule takes over (tol -> tol / 10 once the barrier problem is solved to kappa_eps mu): a solve stops at a point of the central path, as with the monotone strategy
+                if (mu_new != mu) { mu = mu_new; rho = T(0); }
             }
 #ifdef MPC_ASM_MARK
             asm volatile("; BARRIER_BEGIN");
@@ -2696,6 +2726,7 @@ struct IpmWave {
             asm volatile("; ACCEPT_END");
 #endif
             theta_c = th_t; fobj = f_t; logs_cur = lg_t;
+            last_alpha = alpha; last_ad = fw.a_d;
             ++it;
         }
 #ifdef MPC_PROFILE

@@ -598,7 +598,7 @@ class SolverNlp:
 @dataclass
 class IpmOptions:
     tol: float = 1e-8
-    max_iter: int = 200
+    max_iter: int = 100                    # the reference's solver/ipopt/iterations (src/controller.cpp:390)
     mu_init: float = 0.1
     kappa_eps: float = 10.0
     kappa_mu: float = 0.2
@@ -620,9 +620,13 @@ class IpmOptions:
     max_ls: int = 30
     delta_c: float = 1e-8
     init_controls: bool = True
-    globalization: str = "filter"
+    globalization: str = "merit"           # "merit" = l1 merit backtracking (the algorithm of the product and of oracle/mpc_oracle.c) | "filter" (Ipopt's Algorithm A without SOC / restoration: experiment)
     filter_cap: int = 16
-    mu_strategy: str = "monotone"
+    mu_strategy: str = "adaptive"          # "adaptive" (the default, mpc_config.mu_strategy = MPC_MU_ADAPTIVE) | "monotone" (Fiacco-McCormick, Ipopt's own default) | "loqo" (experiment)
+    sigma_min: float = 0.05                # adaptive: sigma = clamp((1 - min(alpha, alpha_dual))^3, sigma_min, 1) from the LAST iteration's step lengths
+    mu_err_floor: float = 3e-2             # adaptive: mu never falls below min(mu, mu_err_floor * E_0)
+    mu_max_fact: float = 1e3               # adaptive: mu <= mu_max_fact * mu_init (Ipopt mu_max_fact)
+    rate_seed_frac: float = 0.9            # seeded controls keep their increments inside this fraction of the control-rate limits
     kappa_c: float = 0.25
     # Ipopt's "solved to acceptable level", which the reference's wrapper counts as success (src/controller.cpp:388-421 configures SolverIpopt; corbo
     # reports success for Converged and EarlyTerminated alike).  Two halves, both at the level `acceptable_tol` (Ipopt default 1e-6; <= 0 = off):
@@ -683,6 +687,27 @@ def controls_from_states(cfg: R.OcpConfig, init: R.Trajectory) -> R.Trajectory:
     return t
 
 
+def rate_feasible_controls(cfg: R.OcpConfig, inp: R.CycleInputs, t: R.Trajectory, frac: float) -> R.Trajectory:
+    """... and keeps the seeded controls inside the control-rate rows, as the reference's u = 0 start is (every row but the first): increments
+    clamped to `frac` x the rate limits forward from u_prev, then backward from the final row (against u_ref = 0).  A seed that jumps violates the
+    rows it crosses: their slacks start at the 1e-2 floor with a residual, and the fraction-to-boundary rule pins the first iterations."""
+    t = t.copy()
+    n = t.x.shape[0]
+    for j in range(2):
+        if not (cfg.du_lb[j] > -1e29 and cfg.du_ub[j] < 1e29):
+            continue
+        lo, hi = cfg.du_lb[j] * t.dt * frac, cfg.du_ub[j] * t.dt * frac
+        if inp.dt_prev != 0.0:
+            t.u[0, j] = min(max(t.u[0, j], inp.u_prev[j] + cfg.du_lb[j] * inp.dt_prev * frac), inp.u_prev[j] + cfg.du_ub[j] * inp.dt_prev * frac)
+        for k in range(1, n - 1):
+            t.u[k, j] = min(max(t.u[k, j], t.u[k - 1, j] + lo), t.u[k - 1, j] + hi)
+        nxt = 0.0
+        for k in range(n - 2, -1, -1):
+            t.u[k, j] = min(max(t.u[k, j], nxt - hi), nxt - lo)
+            nxt = t.u[k, j]
+    return t
+
+
 def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=None,
           opt: Optional[IpmOptions] = None, dual_start: Optional[IpmResult] = None, relevant_dyn=None) -> IpmResult:
     """dual_start: result of the previous control cycle of the same problem structure.  Its multipliers are carried over
@@ -699,7 +724,10 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
     hasU = ub < R.INF
 
     if opt.init_controls:
+        seeded = not np.any(init.u != 0.0)
         init = controls_from_states(cfg, init)
+        if seeded:
+            init = rate_feasible_controls(cfg, inp, init, opt.rate_seed_frac)
     v = nlp.to_vec(init)
     # push into the interior of the box (Ipopt bound_push / bound_frac, sec. 3.6)
     for i in range(nv):
@@ -707,7 +735,9 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
             pl = min(opt.bound_push * max(1.0, abs(lb[i])), opt.bound_push * (ub[i] - lb[i]))
             pu = min(opt.bound_push * max(1.0, abs(ub[i])), opt.bound_push * (ub[i] - lb[i]))
             v[i] = min(max(v[i], lb[i] + pl), ub[i] - pu)
-    mu = opt.mu_init
+    mu = mu0 = opt.mu_init
+    last_alpha = last_ad = 0.0
+    endgame = False
     ev = nlp.eval(v)
     push = np.full(mg, opt.slack_push)
     push[len(nlp.rate_rows):len(nlp.rate_rows) + len(nlp.obst_rows) + len(nlp.dyn_rows)] = opt.clearance_slack_push
@@ -770,7 +800,7 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
                 status = 0
                 break
         # barrier update
-        if opt.mu_strategy == "monotone":
+        if opt.mu_strategy == "monotone" or endgame:
             while True:
                 emu = kkt_err(ev, v, s, lam, y, piL, piU, mu)
                 if emu <= opt.kappa_eps * mu and mu > opt.tol / 10.0:
@@ -780,7 +810,6 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
                 else:
                     break
         else:
-            # LOQO rule (Vanderbei & Shanno 1999), as in Ipopt's mu_oracle=loqo
             comp = []
             if mg:
                 comp.append(s * y)
@@ -788,9 +817,17 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
             comp.append(((ub - v) * piU)[hasU])
             comp = np.concatenate(comp)
             avg = comp.mean()
-            xi = comp.min() / avg
-            sig = 0.1 * min(0.05 * (1 - xi) / xi, 2.0) ** 3
-            mu_new = min(max(sig * avg, opt.tol / 10.0), 1e3)
+            if opt.mu_strategy == "loqo":      # LOQO rule (Vanderbei & Shanno 1999), as in Ipopt's mu_oracle=loqo (experiment)
+                xi = comp.min() / avg
+                sig = 0.1 * min(0.05 * (1 - xi) / xi, 2.0) ** 3
+            else:
+                # adaptive (see oracle/mpc_oracle.c solve_one): Mehrotra's sigma = (mu_aff / mu)^3 read off the step the LAST iteration actually took
+                a_ = 1.0 - min(last_alpha, last_ad)
+                sig = 1.0 if it == 0 else min(max(a_ * a_ * a_, opt.sigma_min), 1.0)
+            mu_new = min(max(sig * avg, opt.tol / 10.0), opt.mu_max_fact * mu0)
+            mu_new = max(mu_new, min(mu, opt.mu_err_floor * e0))
+            if mu_new <= opt.tol:        # end game: from mu = tol on the monotone rule takes over (tol -> tol / 10 once the barrier problem is solved to kappa_eps mu)
+                mu_new, endgame = opt.tol, True
             if mu_new != mu:
                 mu = mu_new
                 rho = 0.0
@@ -956,6 +993,7 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
                 status = 2
                 break
         v, s = vt, st
+        last_alpha, last_ad = alpha, a_d
         lam = lam + alpha * (lam_new - lam)
         y = y + a_d * dy
         piL = piL + a_d * dpiL

@@ -467,6 +467,9 @@ def make_polygon_footprint(name, n=30, B=16, keep=6, M=4):
         if ref.status != 0 or ref.iters > 45:       # long runs are round-off sensitive (the device needed 88 iterations for a 58-iteration one)
             continue
         dmin = min(R.footprint_distance(cfg.footprint_kind, cfg.footprint_params, ref.traj.x[k], ob) for k in range(1, n - 1) for ob in obs)
+        if dmin < cfg.min_obstacle_dist - 1e-6:
+            continue        # the rows of a solve are those associated on the trajectory it STARTS from (stage_inequality_se2.cpp:50-162 runs in the grid update):
+                            # a single solve can end closer than d_min to an obstacle it carried no row for; the test asserts clearance to ALL obstacles
         rows.append(dict(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=dtp[i], pts=pts[i], x=ref.traj.x, u=np.vstack([ref.traj.u, ref.traj.u[-1:]]),
                          dt=ref.traj.dt, iters=ref.iters, dmin=dmin))
     np.savez_compressed(os.path.join(OUT, name + ".npz"), poly=np.array(POLY_FP), max_rows=M, **{k: np.array([r[k] for r in rows]) for k in rows[0]})

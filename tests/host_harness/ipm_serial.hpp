@@ -129,6 +129,17 @@ struct Ipm {
             M.st(L.U + 2 * k, v);
             M.st(L.U + 2 * k + 1, w);
         }
+        // rate-feasible seed (as mpc_wave.hpp::init_point): increments clamped to rate_seed_frac x the rate limits forward from u_prev, then backward from the final row
+        const T fr = Algo<T>::rate_seed_frac;
+        for (int j = 0; j < 2; ++j) {
+            if (!P.rate_on[j] || !P.rate_on[2 + j]) continue;
+            const T lo = P.rate_lim[j] * d * fr, hi = P.rate_lim[2 + j] * d * fr;
+            T prev = U(L.U, 0, j);
+            if (dtprev != T(0)) { prev = t_min(t_max(prev, uprev[j] + P.rate_lim[j] * dtprev * fr), uprev[j] + P.rate_lim[2 + j] * dtprev * fr); M.st(L.U + j, prev); }
+            for (int k = 1; k < n - 1; ++k) { prev = t_min(t_max(U(L.U, k, j), prev + lo), prev + hi); M.st(L.U + 2 * k + j, prev); }
+            T nxt = T(0);
+            for (int k = n - 2; k >= 0; --k) { nxt = t_min(t_max(U(L.U, k, j), nxt - hi), nxt - lo); M.st(L.U + 2 * k + j, nxt); }
+        }
     }
 
     MPC_HD T push_interior(T v, T lb, T ub) const {
@@ -223,7 +234,7 @@ struct Ipm {
 
     // ---------------------------------------------------------------- KKT error pass
     struct Err {
-        T rd, rp, cmin, cmax, sum_mult, sum_bmult;
+        T rd, rp, cmin, cmax, csum, sum_mult, sum_bmult;     // csum: sum of the n_bmult complementarity products
         int n_mult, n_bmult;
         T theta;   // l1 constraint violation
     };
@@ -231,7 +242,7 @@ struct Ipm {
     MPC_HD Err kkt_pass() const {
         const int n = L.n;
         Err e;
-        e.rd = T(0); e.rp = T(0); e.cmin = T(1e30); e.cmax = T(0); e.sum_mult = T(0); e.sum_bmult = T(0);
+        e.rd = T(0); e.rp = T(0); e.cmin = T(1e30); e.cmax = T(0); e.csum = T(0); e.sum_mult = T(0); e.sum_bmult = T(0);
         e.n_mult = 0; e.n_bmult = 0; e.theta = T(0);
         const T d = M.ld(L.D);
         T rd_d = (P.objective == OBJ_MIN_TIME) ? T(n - 1) : T(0);
@@ -291,6 +302,7 @@ struct Ipm {
                 T cl = (u - P.u_lb[j]) * pl, cu = (P.u_ub[j] - u) * pu;
                 e.cmin = t_min(e.cmin, t_min(cl, cu));
                 e.cmax = t_max(e.cmax, t_max(cl, cu));
+                e.csum += cl + cu;
                 e.sum_bmult += pl + pu;
                 e.n_bmult += 2;
             }
@@ -321,6 +333,7 @@ struct Ipm {
                 e.theta += t_abs(res);
                 e.cmin = t_min(e.cmin, s * y);
                 e.cmax = t_max(e.cmax, s * y);
+                e.csum += s * y;
                 e.sum_bmult += y;
                 e.n_bmult += 1;
                 if (r > 0) rd_d -= slot_sign<T>(q) * P.rate_lim[q] * y;
@@ -333,6 +346,7 @@ struct Ipm {
             T cl = (d - P.dt_lb) * pl, cu = (P.dt_ub - d) * pu;
             e.cmin = t_min(e.cmin, t_min(cl, cu));
             e.cmax = t_max(e.cmax, t_max(cl, cu));
+            e.csum += cl + cu;
             e.sum_bmult += pl + pu;
             e.n_bmult += 2;
         }
@@ -693,7 +707,9 @@ struct Ipm {
 
         int it = 0, n_acc = 0;
         int status = ST_MAX_ITER;
-        T e0 = T(0);
+        T e0 = T(0), last_alpha = T(0), last_ad = T(0);
+        bool endgame = false;
+        const T mu_max = Algo<T>::mu_max_fact * mu;
         while (true) {
             Err er = kkt_pass();
             e0 = err_value(er, T(0));
@@ -702,13 +718,24 @@ struct Ipm {
             n_acc = (P.acc_iter > 0 && e0 <= P.acc_tol) ? n_acc + 1 : 0;       // Ipopt's acceptable-level stop (counting half), as mpc_wave.hpp
             if (P.acc_iter > 0 && n_acc >= P.acc_iter) { status = ST_CONVERGED; break; }
             if (it >= P.max_iter) { status = ST_MAX_ITER; break; }
-            // monotone barrier update (Waechter & Biegler eq. 7)
-            for (int guard = 0; guard < 50; ++guard) {
-                T emu = err_value(er, mu);
-                if (emu <= Algo<T>::kappa_eps * mu && mu > P.tol / T(10)) {
-                    mu = t_max(P.tol / T(10), t_min(Algo<T>::kappa_mu * mu, t_pow(mu, Algo<T>::theta_mu)));
-                    rho = T(0);
-                } else break;
+            if (P.mu_strategy == 1 || endgame) {
+                // monotone barrier update (Waechter & Biegler eq. 7)
+                for (int guard = 0; guard < 50; ++guard) {
+                    T emu = err_value(er, mu);
+                    if (emu <= Algo<T>::kappa_eps * mu && mu > P.tol / T(10)) {
+                        mu = t_max(P.tol / T(10), t_min(Algo<T>::kappa_mu * mu, t_pow(mu, Algo<T>::theta_mu)));
+                        rho = T(0);
+                    } else break;
+                }
+            } else {
+                // adaptive barrier update, as mpc_wave.hpp::solve
+                const T avg = er.csum / T(er.n_bmult > 0 ? er.n_bmult : 1);
+                const T a_ = T(1) - t_min(last_alpha, last_ad);
+                const T sig = it == 0 ? T(1) : t_min(t_max(a_ * a_ * a_, Algo<T>::sigma_min), T(1));
+                T mu_new = t_min(t_max(sig * avg, P.tol / T(10)), mu_max);
+                mu_new = t_max(mu_new, t_min(mu, Algo<T>::mu_err_floor * e0));
+                if (mu_new <= P.tol) { mu_new = P.tol; endgame = true; }      // end game: from mu = tol on the monotone rule takes over (tol -> tol / 10 once the barrier problem is solved to kappa_eps mu): a solve stops at a point of the central path, as with the monotone strategy
+                if (mu_new != mu) { mu = mu_new; rho = T(0); }
             }
             const T tau = t_max(Algo<T>::tau_min, T(1) - mu);
             const T dc = nfix > 0 ? Algo<T>::delta_c * t_pow(mu, Algo<T>::kappa_c) : T(0);
@@ -776,6 +803,7 @@ struct Ipm {
 #endif
             accept(alpha, fw.a_d);
             theta_c = th_t; fobj = f_t; cinf = cinf_t;
+            last_alpha = alpha; last_ad = fw.a_d;
             ++it;
         }
         out.status = status;

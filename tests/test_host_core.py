@@ -22,7 +22,7 @@ GOLD = os.path.join(HERE, "golden")
 @pytest.fixture(scope="module")
 def host():
     csrc = os.path.join(HERE, "..", "mpc_local_planner_amd", "csrc")
-    deps = [SRC, os.path.join(csrc, "mpc_core.hpp"), os.path.join(csrc, "mpc_problem.hpp"), os.path.join(HERE, "..", "include", "mpc_hip.h")]
+    deps = [SRC, os.path.join(HERE, "host_harness", "ipm_serial.hpp"), os.path.join(csrc, "mpc_core.hpp"), os.path.join(csrc, "mpc_problem.hpp"), os.path.join(HERE, "..", "include", "mpc_hip.h")]
     if not os.path.exists(OUT) or os.path.getmtime(OUT) < max(os.path.getmtime(d) for d in deps):
         os.makedirs(os.path.dirname(OUT), exist_ok=True)
         subprocess.run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", SRC, "-o", OUT], check=True)
