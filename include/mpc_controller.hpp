@@ -456,7 +456,9 @@ class Controller {
             }
         } else {
             _xi = _x; _ui = _u; _dti = _dt_sol;      // previous solution = warm start (x_0 / fixed goal are overwritten by the solver)
-            if (_warm_start && !_cfg.dt_free) warm_start_shifting(_xi.data(), _ui.data(), _n_cur, x0);   // fixed grid only (…grid_base_se2.cpp:96-100)
+            // fixed grid only, and only in the FIRST outer iteration of a control cycle: the reference shifts when `new_run` (…grid_base_se2.cpp:96-100); a later repetition starts
+            // from the solution just computed as it is (a start heading outside [-pi, pi) is stored normalised: measured against it, x_0 would look 2 pi away -- ADVICE r03)
+            if (_warm_start && !_cfg.dt_free && outer == 0) warm_start_shifting(_xi.data(), _ui.data(), _n_cur, x0);
             if (_grid_adapt && _cfg.dt_free) {
                 // adaptGridTimeBasedSingleStep (src/optimal_control/finite_differences_variable_grid_se2.cpp:99-121)
                 int n_new = _n_cur;
@@ -473,8 +475,8 @@ class Controller {
         }
         int rc;
         if (one_call) {
-            // every outer iteration in ONE call: the grid update between them (shift on the fixed grid -- towards the same x0, i.e. nothing moves --, single-step
-            // adaptation + resampling on the variable grid) runs on the device, bit for bit what the host code above does (tests/test_gpu_closed_loop.py)
+            // every outer iteration in ONE call: the grid update between them (single-step adaptation + resampling on the variable grid; nothing on the fixed grid,
+            // whose shift belongs to the first outer iteration only) runs on the device, bit for bit what the host code above does (tests/test_gpu_closed_loop.py)
             if (_grid_adapt && _cfg.dt_free && !_sizes_set) {
                 const int32_t ng = _n_cur;
                 if (mpc_set_grid_sizes(_h, &ng, 1) != MPC_OK) { _last_error = mpc_last_error(); return false; }

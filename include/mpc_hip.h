@@ -273,8 +273,8 @@ int mpc_solve_batch_device(mpc_solver* s, int32_t B,
 /* One control cycle of B planners = what Controller::step does through corbo's PredictiveController (src/controller.cpp:70-72,172): the OCP -- grid update,
  * then solve -- is repeated controller/outer_ocp_iterations times, every repetition after the first starting from the solution just computed.  The first
  * solve is mpc_solve_batch with the given initial guess (NULL = cold start); before each further one the grid update of mpc_grid_update_device runs on the
- * outputs in place (fixed grid: shift towards x0, which is the same state, so nothing moves; variable grid with adapt != 0: single-step adaptation +
- * resampling with n_min / n_max / dt_hyst_ratio).  Everything is enqueued on the solver's stream without a host round trip in between; the result is bit for
+ * outputs in place on the VARIABLE grid (adapt != 0: single-step adaptation + resampling with n_min / n_max / dt_hyst_ratio); on the fixed grid nothing runs
+ * between the solves: its warm-start shift belongs to the first outer iteration of a cycle only (`new_run`, full_discretization_grid_base_se2.cpp:96-100).  Everything is enqueued on the solver's stream without a host round trip in between; the result is bit for
  * bit what the separate calls give.  status / iters: those of the LAST solve (what the reference's step() returns); n_grid_out (nullable, HOST variant):
  * the grid sizes in force after the call. */
 int mpc_step_batch(mpc_solver* s, int32_t B,

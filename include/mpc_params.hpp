@@ -339,6 +339,10 @@ inline ParamStatus config_from_params(const ParamSource& p, mpc_config& c, Contr
                 c.hessian_mode = MPC_HESSIAN_CONVEXIFIED;
                 rep.notes.push_back("hessian_approximation limited-memory -> MPC_HESSIAN_CONVEXIFIED (the positive-semidefinite part of the exact stage Hessians; no quasi-Newton update is built)");
             } else c.hessian_mode = MPC_HESSIAN_EXACT;
+        } else if (kv.first == "mu_strategy") {
+            if (kv.second == "monotone") c.mu_strategy = MPC_MU_MONOTONE;
+            else if (kv.second == "adaptive") c.mu_strategy = MPC_MU_ADAPTIVE;
+            else rep.notes.push_back("mu_strategy " + kv.second + ": unknown, the default (adaptive) is used");
         } else if (kv.first == "linear_solver") rep.notes.push_back("linear_solver " + kv.second + ": the KKT systems are solved by the stage-structured sweep of the kernel");
         else rep.notes.push_back("ipopt string option " + kv.first + ": no counterpart, ignored");
     }

@@ -36,6 +36,7 @@ MPC_EBATCH = -5
 INF = 1e30
 
 COST_LEFT_SUM, COST_TRAPEZOIDAL = 0, 1
+MU_ADAPTIVE, MU_MONOTONE = 0, 1          # enum mpc_mu_strategy
 
 CAND_REFERENCE = 0
 CAND_TRAVEL = 1
@@ -141,7 +142,7 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
                 terminal_ball_S=None, terminal_ball_gamma=1.0, vp_position_weight=1e-3, vp_orientation_weight=0.0,
                 via_points_ordered=False, max_via_points=0, footprint_params=(0.0, 0.0, 0.0, 0.0),
                 enable_dynamic_obstacles=False, footprint_vertices=(), candidates=(), candidate_max_iter=(), candidate_blend=0, dual_warm_start=False, mu_init_dual=0.0, candidate_param=(), hessian_mode=0,
-                hybrid_cost_minimum_time=False, cost_integration=COST_LEFT_SUM, acceptable_tol=0.0, acceptable_iter=0) -> MpcConfig:
+                hybrid_cost_minimum_time=False, cost_integration=COST_LEFT_SUM, acceptable_tol=0.0, acceptable_iter=0, mu_strategy=0) -> MpcConfig:
     """Q, R, Qf, terminal_ball_S: the diagonal (3 / 2 / 3 / 3 values) or the full matrix (nested 3 x 3 / 2 x 2; its symmetric part is used)."""
     c = MpcConfig()
     c.model = model
@@ -202,6 +203,7 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
     c.dual_warm_start = int(bool(dual_warm_start))
     c.mu_init_dual = float(mu_init_dual)
     c.hessian_mode = int(hessian_mode)
+    c.mu_strategy = int(mu_strategy)          # MU_ADAPTIVE (0, default) | MU_MONOTONE
     c.hybrid_cost_minimum_time = int(bool(hybrid_cost_minimum_time))
     c.cost_integration = int(cost_integration)
     c.acceptable_tol, c.acceptable_iter = float(acceptable_tol), int(acceptable_iter)      # 0 = Ipopt's defaults (1e-6, 15), negative = off

@@ -189,13 +189,17 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
     s->cfg = *cfg;
     mpc::fill_problem<double>(*cfg, s->P64);
     mpc::fill_problem<float>(*cfg, s->P32);
-    if (const char* e = getenv("MPC_NO_PIT")) { if (e[0] == '1') { s->P64.pit = 0; s->P32.pit = 0; } }      // developer switch: serial sweeps only (A/B measurements)
-    if (const char* e = getenv("MPC_PIT_MU")) { s->P64.pit_mu_min = atof(e); s->P32.pit_mu_min = (float)atof(e); }      // developer switch: threshold of the partitioned sweeps
+#ifdef MPC_DEV_SWITCHES      // developer A/B switches read from the environment: compiled out of the shipped library
+    if (const char* e = getenv("MPC_NO_PIT")) { if (e[0] == '1') { s->P64.pit = 0; s->P32.pit = 0; } }      // serial sweeps only
+    if (const char* e = getenv("MPC_PIT_MU")) { char* end = nullptr; const double v = strtod(e, &end); if (end != e && v >= 0) { s->P64.pit_mu_min = v; s->P32.pit_mu_min = (float)v; } }      // threshold of the partitioned sweeps
+#endif
     if (cfg->precision == MPC_MIXED) {
         s->P32.tol = 1e-4f; s->P32.pit_mu_min = 1e-4f;        // phase 1 stops where fp32 residuals stop making sense
         s->P64.n_cand = 1;                                   // phase 2 refines the winner
         if (!(cfg->mu_init_dual > 0)) s->P64.mu_init_dual = 1e-5;      // phase 1 ended at a barrier of ~1e-5
         s->P64.mu_init_warm = 1e-3;                          // instances phase 1 did not converge start phase 2 from its last iterate
+        s->P64.mu_strategy = 1;                              // the refinement follows the central path from mu = 1e-5 down: the monotone rule (measured: 4.2 refinement
+                                                             // iterations against 9.4 with the adaptive one, which re-derives mu from the fp32 iterate's complementarity)
         if (s->P64.max_iter > 40) s->P64.max_iter = 40;      // a refinement that needs more than that is a solve of its own (phase-1 failures would hold the launch for 100)
     }
     {
@@ -404,7 +408,9 @@ int mpc_step_batch_device(mpc_solver* s, int32_t B, const double* d_x0, const do
     // repetition after the first starts from the solution just computed, in place on the output arrays; everything is enqueued on the solver's stream
     int rc = mpc_solve_batch_device(s, B, d_x0, d_xf, d_u_prev, d_dt_prev, d_x_init, d_u_init, d_dt_init, d_obstacles, d_x_out, d_u_out, d_dt_out, d_status, d_iters);
     for (int it = 1; it < outer_iterations && rc == MPC_OK; ++it) {
-        rc = mpc_grid_update_device(s, B, d_x0, d_x_out, d_u_out, d_dt_out, adapt, n_min, n_max, dt_hyst_ratio);
+        // variable grid: single-step adaptation + resampling; fixed grid: nothing -- its warm-start shift belongs to the first outer iteration of a cycle (`new_run`,
+        // full_discretization_grid_base_se2.cpp:96-100), which is the caller's (the repetition starts from the solution just computed as it is)
+        if (s->cfg.dt_free) rc = mpc_grid_update_device(s, B, d_x0, d_x_out, d_u_out, d_dt_out, adapt, n_min, n_max, dt_hyst_ratio);
         if (rc == MPC_OK)
             rc = mpc_solve_batch_device(s, B, d_x0, d_xf, d_u_prev, d_dt_prev, d_x_out, d_u_out, d_dt_out, d_obstacles, d_x_out, d_u_out, d_dt_out, d_status, d_iters);
     }

@@ -200,13 +200,21 @@ constexpr int kFixedLayoutNS = 50;
 template <typename T, int MODEL>
 hipError_t launch_solve(const SolveLaunch& a, const Problem<T>& P) {
     // four instantiations per (arithmetic type, model): the headline level without / with clearance rows, and the two extended levels (always with)
-    static const bool force_obst = getenv("MPC_FORCE_OBST_KERNEL") != nullptr;      // developer switch (A/B of the two headline instantiations)
+#ifdef MPC_DEV_SWITCHES
+    static const bool force_obst = getenv("MPC_FORCE_OBST_KERNEL") != nullptr;      // developer switch (A/B of the two headline instantiations); not in the shipped library
+#else
+    constexpr bool force_obst = false;
+#endif
     auto kern = a.level == 0 ? ((a.L.M > 0 || force_obst) ? mpc_ipm_wave_kernel<T, MODEL, 0, true> : mpc_ipm_wave_kernel<T, MODEL, 0, false>)
                              : (a.level == 2 ? mpc_ipm_wave_kernel<T, MODEL, 2, true> : mpc_ipm_wave_kernel<T, MODEL, 1, true>);
     // fp64 headline kernel on a grid of kFixedLayoutNS points per record (the grid size of BASELINE configs[1] / [3]): the instantiation whose LDS layout is a
     // compile-time constant (mpc_wave.hpp::FixedLayout) -- same code, same results bit for bit, ~3 % fewer instructions; every other size runs the generic one
     if constexpr (sizeof(T) == 8) {
-        static const bool no_fixed = getenv("MPC_NO_FIXED_LAYOUT") != nullptr;      // developer switch (A/B)
+#ifdef MPC_DEV_SWITCHES
+        static const bool no_fixed = getenv("MPC_NO_FIXED_LAYOUT") != nullptr;      // developer switch (A/B); not in the shipped library
+#else
+        constexpr bool no_fixed = false;
+#endif
         using IW = IpmWave<T, MODEL, 0, false, kFixedLayoutNS>;
         if (a.level == 0 && a.L.M == 0 && !force_obst && !no_fixed && IW::LayoutT::matches(a.L)) kern = mpc_ipm_wave_kernel<T, MODEL, 0, false, kFixedLayoutNS>;
     }

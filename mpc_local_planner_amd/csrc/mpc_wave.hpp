@@ -1718,7 +1718,12 @@ struct IpmWave {
 #pragma unroll
         for (int i = 0; i < 5; ++i) M[i] = sm[a + 10 * i];
     }
-    __device__ __forceinline__ bool pit_enabled() const { return EXT < 2 && P.pit != 0 && L.n >= 40; }      // (EXT = 2, the cost variants: serial sweeps only -- register budget)      // the hand-off tile (192 words) lives in DX | DU (5 n words), a saved tile pair (100 words) in 3 n words
+    // (EXT = 2, the cost variants: serial sweeps only -- register budget.)  The partitioned sweep parks its tiles in live solver arrays (pit_tile): the hand-off
+    // tile (192 words) in DX | DU (5 NS words), the saved tile pairs (100 words each) in LAMN (3 NS words), the trig cache (NTR NS words) and DX.  The capacities
+    // are part of the condition, not a consequence of the grid-size threshold.  Second invariant: a saved tile overwrites the trig cache, which
+    // kkt_pass reads -- every path from a factorisation to the next kkt_pass rewrites TRIG for all k < n - 1 (eval_point / trial_eval of the accepted trial;
+    // the solve ends without another kkt_pass when no trial is evaluated).
+    __device__ __forceinline__ bool pit_enabled() const { return EXT < 2 && P.pit != 0 && L.n >= 40 && 3 * L.NS >= 100 && L.NTR * L.NS >= 100 && 5 * L.NS >= 192; }
     // lane index that the optimiser must treat as unknown HERE: keeps the per-lane address arithmetic of a phase inside the phase (hoisted out of the
     // interior-point loop as loop invariants it would occupy registers for the whole solve)
     __device__ __forceinline__ int local_lane() const { int l = lane; asm volatile("" : "+v"(l)); return l; }
@@ -2542,7 +2547,8 @@ struct IpmWave {
             asm volatile("; KKT_END");
 #endif
             e0 = err_value(er, T(0));
-            if (!t_finite(e0)) { status = ST_NUMERICAL; break; }
+            // (t_max / t_min drop a NaN operand: the maxima inside e0 cannot carry one; the sums do -- ADVICE r03)
+            if (!t_finite(e0) || !t_finite(er.theta) || !t_finite(er.sum_mult) || !t_finite(er.csum)) { status = ST_NUMERICAL; break; }
             if (e0 <= P.tol) { status = ST_CONVERGED; break; }
             // Ipopt's acceptable-level stop, counting half: acc_iter iterations in a row at the level acc_tol (mpc_config.acceptable_tol / _iter)
             n_acc = (acc_it > 0 && e0 <= acc_tol) ? n_acc + 1 : 0;
@@ -2560,13 +2566,13 @@ struct IpmWave {
                         rho = T(0);
                     } else break;
                 }
-            } else {
-                // adaptive (the default; what corbo's SolverIpopt is believed to set): mu = sigma x the average complementarity, sigma from the step lengths the
+            } else if (it > 0) {
+                // adaptive (the default; what corbo's SolverIpopt is believed to set; the first iteration keeps the start value): mu = sigma x the average complementarity, sigma from the step lengths the
                 // LAST iteration achieved -- Mehrotra's (mu_aff / mu)^3 read off the step that was actually taken, no second solve --, never below
                 // min(mu, mu_err_floor x E_0) (a barrier far below the optimality error is what stalls the non-convex instances), inside [tol / 10, mu_max_fact x mu_0]
                 const T avg = er.csum * inv_cnt_bmult;
                 const T a_ = T(1) - t_min(last_alpha, last_ad);
-                const T sig = it == 0 ? T(1) : t_min(t_max(a_ * a_ * a_, Algo<T>::sigma_min), T(1));
+                const T sig = t_min(t_max(a_ * a_ * a_, Algo<T>::sigma_min), T(1));
                 T mu_new = t_min(t_max(sig * avg, P.tol / T(10)), mu_max);
                 mu_new = t_max(mu_new, t_min(mu, Algo<T>::mu_err_floor * e0));
                 if (mu_new <= P.tol) { mu_new = P.tol; endgame = true; }      // end game: from mu = tol on the monotone rule takes over (tol -> tol / 10 once the barrier problem is solved to kappa_eps mu): a solve stops at a point of the central path, as with the monotone strategy

@@ -31,6 +31,7 @@ from . import _abi as A
 PLUGIN_NAMESPACE = "MpcLocalPlannerROS"      # move_base loads the plugin's parameters under this name (the example YAMLs' top-level key)
 FOOTPRINT_POINT, FOOTPRINT_CIRCLE, FOOTPRINT_LINE, FOOTPRINT_TWO_CIRCLES, FOOTPRINT_POLYGON = range(5)   # include/mpc_hip.h, enum mpc_footprint_kind
 HESSIAN_EXACT, HESSIAN_CONVEXIFIED = 0, 1
+MU_ADAPTIVE, MU_MONOTONE = 0, 1
 
 
 class ParamError(ValueError):
@@ -232,6 +233,11 @@ def config_from_params(params: dict, costmap_footprint=None, **sizing):
                              "no quasi-Newton update is built)")
             else:
                 kw["hessian_mode"] = HESSIAN_EXACT
+        elif k == "mu_strategy":
+            if v in ("monotone", "adaptive"):
+                kw["mu_strategy"] = MU_MONOTONE if v == "monotone" else MU_ADAPTIVE
+            else:
+                notes.append(f"mu_strategy {v}: unknown, the default (adaptive) is used")
         elif k == "linear_solver":
             notes.append(f"linear_solver {v}: the KKT systems are solved by the stage-structured sweep of the kernel")
         else:

@@ -809,7 +809,7 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
                     filt.clear()
                 else:
                     break
-        else:
+        elif it > 0:                # adaptive; the first iteration keeps the start value (mu_init, or the warm start's)
             comp = []
             if mg:
                 comp.append(s * y)
@@ -823,7 +823,7 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
             else:
                 # adaptive (see oracle/mpc_oracle.c solve_one): Mehrotra's sigma = (mu_aff / mu)^3 read off the step the LAST iteration actually took
                 a_ = 1.0 - min(last_alpha, last_ad)
-                sig = 1.0 if it == 0 else min(max(a_ * a_ * a_, opt.sigma_min), 1.0)
+                sig = min(max(a_ * a_ * a_, opt.sigma_min), 1.0)
             mu_new = min(max(sig * avg, opt.tol / 10.0), opt.mu_max_fact * mu0)
             mu_new = max(mu_new, min(mu, opt.mu_err_floor * e0))
             if mu_new <= opt.tol:        # end game: from mu = tol on the monotone rule takes over (tol -> tol / 10 once the barrier problem is solved to kappa_eps mu)

@@ -1355,7 +1355,7 @@ static int solve_one(work_t* w, int warm) {
         err_t e;
         kkt_terms(w, cc, &e);
         double e0 = err_value(&e, 0.0);
-        if (!isfinite(e0)) { status = 4; break; }
+        if (!isfinite(e0) || !isfinite(e.theta) || !isfinite(e.sm) || !isfinite(e.csum)) { status = 4; break; }
         if (e0 <= tol) { status = 0; break; }
         /* Ipopt's acceptable-level stop, first half: acceptable_iter iterations in a row with an error of at most acceptable_tol */
         if (acc_it > 0 && acc_tol > 0) {
@@ -1389,11 +1389,11 @@ static int solve_one(work_t* w, int warm) {
                 else break;
             }
         }
-        if (adaptive && free_mode && !endgame && g_algo.mu_oracle != 1) {
+        if (adaptive && free_mode && !endgame && g_algo.mu_oracle != 1 && it > 0) {      /* the first iteration keeps the start value (mu_init, or the warm start's) */
             const double avg = e.csum / e.nb;
             double sig;
             if (g_algo.mu_oracle == 2) { const double xi = e.cmin / avg, t_ = fmin(0.05 * (1 - xi) / xi, 2.0); sig = 0.1 * t_ * t_ * t_; }       /* LOQO rule (experiment) */
-            else { const double a_ = 1.0 - fmin(last_alpha, last_ad); sig = it == 0 ? 1.0 : fmin(fmax(a_ * a_ * a_, sigma_min), 1.0); }
+            else { const double a_ = 1.0 - fmin(last_alpha, last_ad); sig = fmin(fmax(a_ * a_ * a_, sigma_min), 1.0); }
             double mu_new = fmin(fmax(sig * avg, mu_min), mu_max);
             mu_new = fmax(mu_new, fmin(w->mu, mu_err_floor * e0));
             if (mu_new <= tol) { mu_new = tol; endgame = 1; }      /* end game: from mu = tol on the monotone rule takes over (tol -> tol / 10 once the barrier problem is solved to
@@ -1416,7 +1416,7 @@ static int solve_one(work_t* w, int warm) {
             if (good) {
                 int have_y2 = 0;
                 good = border_solve(w, y2, &have_y2, Hdd, hd);
-                if (good && adaptive && g_algo.mu_oracle == 1 && free_mode && !endgame && !mu_chosen) {
+                if (good && adaptive && g_algo.mu_oracle == 1 && free_mode && !endgame && !mu_chosen && it > 0) {
                     /* Mehrotra's probing oracle (Ipopt mu_oracle=probing): affine-scaling step (mu = 0) with the same factorisation, step to the boundary (tau = 1),
                      * mu_aff = average complementarity there, sigma = (mu_aff / mu_cur)^3, mu = sigma mu_cur */
                     memcpy(rhs_keep, w->rhs, sizeof(double) * N);

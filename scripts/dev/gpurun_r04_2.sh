@@ -1,0 +1,10 @@
+cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r04
+timeout 1500 python -m pytest tests -m gpu -q > gpurun_out/r04/gpu_suite_2.log 2>&1; grep -E "passed|failed|^FAILED" gpurun_out/r04/gpu_suite_2.log | tail -40
+timeout 900 python bench.py --steps 20 --warmup 3 > gpurun_out/r04/bench_2.json 2> gpurun_out/r04/bench_2.err; python - <<'PY'
+import json
+d=json.load(open('gpurun_out/r04/bench_2.json'))
+print(round(d['value']), d['ms_per_step'], d['roofline']['kernel_ms'], d['solver'].get('answers_equal_to_the_reference_path_alone'), d['solver']['converged_frac'], d['solver']['iters_mean'], d['roofline']['fp64_valu'].get('peak_measured_tflops'), d['roofline']['fp64_valu'].get('fp32_peak_measured_tflops'))
+for k,v in d['legs'].items():
+    if 'value' in v: print("   ",k, round(v['value']), round(v.get('ms_per_step',0),3), v.get('solver',{}).get('iters_mean'), v.get('solver',{}).get('converged_frac', v.get('converged_frac')))
+    else: print("   ",k,v.get('ms_p50'))
+PY

@@ -45,7 +45,7 @@ class OracleBackend:
             if cfg.objective == 2 and self._via is not None:
                 via = (self._via[0][b:b + 1], self._via[1][b:b + 1])
             xo, uo, do, st, it = CO.solve_batch(CO.from_nlp_config(ocfg, max_iter=int(cfg.max_iter), tol=float(cfg.tol), mu_init=float(cfg.mu_init), hessian_mode=int(cfg.hessian_mode),
-                                                                    acceptable_tol=float(cfg.acceptable_tol), acceptable_iter=int(cfg.acceptable_iter)),
+                                                                    acceptable_tol=float(cfg.acceptable_tol), acceptable_iter=int(cfg.acceptable_iter), mu_strategy=int(cfg.mu_strategy)),
                                                 x0[b:b + 1], xf[b:b + 1], u_prev[b:b + 1], dt_prev[b:b + 1], init=ini, obstacles=ob,
                                                 obst=CO.obst_from_nlp_config(ocfg, O, V, int(cfg.max_obstacle_rows)) if ob is not None else None, via=via)
             out.x[b, :n], out.u[b, :n], out.dt[b], out.status[b], out.iters[b] = xo[0], uo[0], do[0], st[0], it[0]

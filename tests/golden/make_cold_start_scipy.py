@@ -13,7 +13,7 @@ model has no steering authority and SLSQP's first QP is singular in the steering
 
 Stored per instance: SLSQP's x, u, dt, objective, success flag, iterations and its max constraint violation.  tests/test_oracle_solver.py
 compares the C oracle with it on the CPU, tests/test_gpu_parity.py the device.  Runtime: ~2 min (config 2) + ~25 min (config 3) on 8 cores.
-usage: python tests/golden/make_cold_start_scipy.py [2|3] [count]"""
+usage: python tests/golden/make_cold_start_scipy.py [2|3|3b|3c] [count]"""
 import multiprocessing as mp
 import os
 import sys
@@ -57,13 +57,18 @@ def solve_one(args):
 
 
 def main():
-    which = int(sys.argv[1]) if len(sys.argv) > 1 else 2
+    arg = sys.argv[1] if len(sys.argv) > 1 else "2"
+    # 3b / 3c (r04): config 3 on placements where the clearance rows BIND -- polygons 0.15 .. 0.8 m beside the start-goal line (the bench leg's
+    # placement: rows start violated by up to 5 cm) and 0.02 .. 0.6 m (polygons reach to within 2 cm of the line: rows start violated by up to 18 cm, detours)
+    lateral = {"3b": (0.15, 0.8), "3c": (0.02, 0.6)}.get(arg)
+    suffix = {"3b": "_binding", "3c": "_touching"}.get(arg, "")
+    which = int(arg[0])
     K = int(sys.argv[2]) if len(sys.argv) > 2 else 32
     if which == 2:
         x0, xf, up, dtp = W.carlike_min_time_inputs(K)
         jobs = [(2, i, x0[i], xf[i], up[i], dtp[i], None) for i in range(K)]
     else:
-        x0, xf, up, dtp, (no, nv, vt) = W.unicycle_obstacle_inputs(K, n_obst=16, max_vertices=6)
+        x0, xf, up, dtp, (no, nv, vt) = W.unicycle_obstacle_inputs(K, n_obst=16, max_vertices=6, **(dict(lateral=lateral) if lateral else {}))
         jobs = [(3, i, x0[i], xf[i], up[i], dtp[i], (no[i], nv[i], vt[i], None, None)) for i in range(K)]
     with mp.Pool(min(K, os.cpu_count() or 2)) as pool:
         out = pool.map(solve_one, jobs)
@@ -71,10 +76,10 @@ def main():
     u = np.zeros((K, n, 2))
     for i, o in enumerate(out):
         u[i, :n - 1] = o[1]; u[i, n - 1] = o[1][-1]
-    np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"cold_start_scipy_config{which}.npz"),
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"cold_start_scipy_config{which}{suffix}.npz"),
                         x=np.stack([o[0] for o in out]), u=u, dt=np.array([o[2] for o in out]), objective=np.array([o[3] for o in out]),
                         success=np.array([o[4] for o in out]), nit=np.array([o[5] for o in out]), violation=np.array([o[6] for o in out]),
-                        count=K)
+                        count=K, lateral=np.array(lateral if lateral else (0.3, 1.5)))
 
 
 if __name__ == "__main__":

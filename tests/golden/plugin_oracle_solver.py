@@ -27,7 +27,7 @@ def make(runner, cfg, iterations_out=None):
             vp = np.zeros((1, 16, 3)); vp[0, :len(via)] = via
             viap = (np.array([len(via)], np.int32), vp)
         xo, uo, do, st, it = CO.solve_batch(CO.from_nlp_config(ocfg, max_iter=int(cfg.max_iter), tol=float(cfg.tol), mu_init=float(cfg.mu_init), hessian_mode=int(cfg.hessian_mode),
-                                                                acceptable_tol=float(cfg.acceptable_tol), acceptable_iter=int(cfg.acceptable_iter)),
+                                                                acceptable_tol=float(cfg.acceptable_tol), acceptable_iter=int(cfg.acceptable_iter), mu_strategy=int(cfg.mu_strategy)),
                                             x[None, 0], goal[None], u_prev[None], np.array([dt_prev]), init=(x[None], ui, np.array([dt])),
                                             obstacles=(np.array([count], np.int32), nv, vt, rad, vel),
                                             obst=CO.obst_from_nlp_config(ocfg, MAX_OBSTACLES, MAX_VERTICES, int(cfg.max_obstacle_rows)), via=viap)

@@ -59,6 +59,59 @@ static int run_adaptive() {
     return (reached && failures <= 5 && n_first == 20 && n_min_seen <= 6) ? 0 : 1;
 }
 
+// third scenario: Controller::step with outer_ocp_iterations = 3 on the variable grid with adaptation, once with every outer iteration in ONE
+// mpc_step_batch call (grid update on the device) and once with the facade's host loop (resample_trajectory / adaptation on the host, one mpc_solve_batch per
+// outer iteration): the claim "the device grid update is bit for bit what the host code does" means identical time series, dt and grid size in every cycle
+static int run_single_launch_vs_host_loop() {
+    Controller a, b;
+    Controller* cs[2] = {&a, &b};
+    for (int i = 0; i < 2; ++i) {
+        mpc_config c;
+        mpc_config_defaults(&c);
+        c.model = MPC_MODEL_SIMPLE_CAR; c.model_params[0] = 0.4;
+        c.n = 30; c.dt_ref = 0.3; c.dt_free = 1; c.dt_lb = 0.0; c.dt_ub = 10.0;
+        c.u_lb[0] = -0.2; c.u_ub[0] = 0.4; c.u_lb[1] = -1.4; c.u_ub[1] = 1.4;
+        c.du_lb[0] = c.du_lb[1] = -0.5; c.du_ub[0] = c.du_ub[1] = 0.5;
+        if (!cs[i]->configure(c, 0)) { std::printf("configure failed: %s\n", cs[i]->lastError().c_str()); return 2; }
+        cs[i]->setGridAdaptation(true, 30, 0.1, 3);
+        cs[i]->setNumOcpIterations(3);
+        cs[i]->setSingleLaunchStep(i == 0);
+    }
+    PoseSE2 pose{0, 0, 0.3}, goal{2.5, 1.2, 0.8};
+    Twist vel;
+    const double period = 0.1;
+    TimeSeries xa, ua, xb, ub;
+    double u_prev[2] = {0, 0};
+    int compared = 0, n_changes = 0, n_last = 0;
+    for (int cyc = 0; cyc < 25; ++cyc) {
+        a.setPreviousControlInput(u_prev, cyc == 0 ? 0.0 : period);
+        b.setPreviousControlInput(u_prev, cyc == 0 ? 0.0 : period);
+        const bool oka = a.step(pose, goal, vel, period, cyc * period, ua, xa);
+        const bool okb = b.step(pose, goal, vel, period, cyc * period, ub, xb);
+        if (oka != okb || a.gridSize() != b.gridSize() || a.lastDt() != b.lastDt() || a.lastIterations() != b.lastIterations()) {
+            std::printf("single launch vs host loop: cycle %d differs: ok %d/%d n %d/%d dt %.17g/%.17g iters %d/%d\n", cyc, (int)oka, (int)okb, a.gridSize(), b.gridSize(), a.lastDt(), b.lastDt(),
+                        a.lastIterations(), b.lastIterations());
+            return 1;
+        }
+        if (!oka) { a.reset(); b.reset(); u_prev[0] = u_prev[1] = 0; continue; }
+        const int n = a.gridSize();
+        if (cyc > 0 && n != n_last) ++n_changes;
+        n_last = n;
+        for (int k = 0; k < n; ++k) {
+            for (int i = 0; i < 3; ++i) if (xa.at(k)[i] != xb.at(k)[i]) { std::printf("single launch vs host loop: cycle %d x[%d][%d] %.17g != %.17g\n", cyc, k, i, xa.at(k)[i], xb.at(k)[i]); return 1; }
+            for (int j = 0; j < 2; ++j) if (ua.at(k)[j] != ub.at(k)[j]) { std::printf("single launch vs host loop: cycle %d u[%d][%d] %.17g != %.17g\n", cyc, k, j, ua.at(k)[j], ub.at(k)[j]); return 1; }
+        }
+        ++compared;
+        const double* u0 = ua.at(0);
+        pose.x += period * u0[0] * std::cos(pose.theta);
+        pose.y += period * u0[0] * std::sin(pose.theta);
+        pose.theta = normalize_theta(pose.theta + period * u0[0] * std::tan(u0[1]) / 0.4);
+        u_prev[0] = u0[0]; u_prev[1] = u0[1];
+    }
+    std::printf("single launch vs host loop: %d cycles identical (x, u, dt, grid size, iterations), grid size changed %d times, last n %d\n", compared, n_changes, n_last);
+    return (compared >= 20 && n_changes >= 3) ? 0 : 1;
+}
+
 int main() {
     mpc_config c;
     mpc_config_defaults(&c);                 // unicycle, n=20, dt_ref=.3, variable grid, min-time, xf fixed
@@ -106,6 +159,8 @@ int main() {
     bool good = failures <= 2 && t_last < t_first && t_first > 5.385 / 0.4 - 1e-6 && pose.x > 0.5;
     const int ra = run_adaptive();
     good = good && ra == 0;
+    const int rs = run_single_launch_vs_host_loop();
+    good = good && rs == 0;
     std::printf(good ? "DEMO_OK\n" : "DEMO_FAILED\n");
     return good ? 0 : 1;
 }

@@ -713,7 +713,7 @@ struct Ipm {
         while (true) {
             Err er = kkt_pass();
             e0 = err_value(er, T(0));
-            if (!t_finite(e0)) { status = ST_NUMERICAL; break; }
+            if (!t_finite(e0) || !t_finite(er.theta) || !t_finite(er.sum_mult) || !t_finite(er.csum)) { status = ST_NUMERICAL; break; }
             if (e0 <= P.tol) { status = ST_CONVERGED; break; }
             n_acc = (P.acc_iter > 0 && e0 <= P.acc_tol) ? n_acc + 1 : 0;       // Ipopt's acceptable-level stop (counting half), as mpc_wave.hpp
             if (P.acc_iter > 0 && n_acc >= P.acc_iter) { status = ST_CONVERGED; break; }
@@ -727,11 +727,11 @@ struct Ipm {
                         rho = T(0);
                     } else break;
                 }
-            } else {
-                // adaptive barrier update, as mpc_wave.hpp::solve
+            } else if (it > 0) {
+                // adaptive barrier update, as mpc_wave.hpp::solve (the first iteration keeps the start value)
                 const T avg = er.csum / T(er.n_bmult > 0 ? er.n_bmult : 1);
                 const T a_ = T(1) - t_min(last_alpha, last_ad);
-                const T sig = it == 0 ? T(1) : t_min(t_max(a_ * a_ * a_, Algo<T>::sigma_min), T(1));
+                const T sig = t_min(t_max(a_ * a_ * a_, Algo<T>::sigma_min), T(1));
                 T mu_new = t_min(t_max(sig * avg, P.tol / T(10)), mu_max);
                 mu_new = t_max(mu_new, t_min(mu, Algo<T>::mu_err_floor * e0));
                 if (mu_new <= P.tol) { mu_new = P.tol; endgame = true; }      // end game: from mu = tol on the monotone rule takes over (tol -> tol / 10 once the barrier problem is solved to kappa_eps mu): a solve stops at a point of the central path, as with the monotone strategy

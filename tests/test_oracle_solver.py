@@ -599,7 +599,7 @@ def test_near_goal_stall_and_the_acceptable_level_stop():
     # not depend on the machine, is the one that insists on it
     assert stalled.status in (0, 1, 2) and stalled.kkt_error < 1e-4
     if stalled.status != 0:
-        assert min(h["e0"] for h in stalled.history) < 1e-7          # it had been there
+        assert min([stalled.kkt_error] + [h["e0"] for h in stalled.history]) < 1e-7          # it had been there
     assert mono_stalled.status in (0, 1) and (mono_stalled.status == 0 or (mono_stalled.iters == 100 and min(h["e0"] for h in mono_stalled.history) < 2e-8))
     assert loose.status == 0 and loose.iters <= 16
     assert stopped.status == 0 and stopped.iters <= 16 and stopped.kkt_error < 1e-7
@@ -678,3 +678,35 @@ def test_kkt_checker_takes_the_clearance_rows_of_the_trajectory_a_solve_started_
           f"cold start's rows: {len(not_cold)} (worst stationarity there {max([cold[i]['stat'] for i in not_cold], default=0):.1e})")
     assert len(ok_own) == len(conv)
     assert len(not_cold) >= 1          # the distinction is real on this workload
+
+
+def test_clearance_to_every_obstacle_needs_a_renewed_association(c_oracle):
+    """The clearance rows of ONE solve are those associated on the trajectory it starts from (StageInequalitySE2::update runs in the grid update, before the solve:
+    stage_inequality_se2.cpp:50-162) -- in the reference as here.  Measured with plain geometry (no solver quantity) on config 3 with polygons 0.15 .. 0.8 m beside the
+    path: after one solve from the cold start about one converged trajectory in five is closer than min_obstacle_dist to a polygon it carried no row for; a second solve
+    that re-associates on that solution (the next outer OCP iteration / control cycle) leaves at most a stray one, a third none.  tests/test_gpu_clearance.py asserts
+    the same through mpc_step_batch on the device."""
+    import mpc_local_planner_amd.workloads as W
+    n, B, O, V, M, dmin = 80, 96, 16, 6, 4, 0.2
+    x0, xf, up, dtp, (no, nv, verts) = W.unicycle_obstacle_inputs(B, n_obst=O, max_vertices=V, lateral=(0.15, 0.8))
+    ocfg = R.config_unicycle_quadratic(n)
+    oc, ob = c_oracle.from_nlp_config(ocfg), c_oracle.obst_from_nlp_config(ocfg, O, V, M)
+
+    def clearance(x):
+        out = np.full(B, np.inf)
+        for b in range(B):
+            p = x[b, 1:-1, :2]
+            for o in range(int(no[b])):
+                k = int(nv[b, o]); a = verts[b, o, :k]; c = np.roll(a, -1, axis=0); ab = c - a
+                t = np.clip(((p[:, None, :] - a[None]) * ab[None]).sum(-1) / (ab * ab).sum(-1)[None], 0.0, 1.0)
+                out[b] = min(out[b], float(np.sqrt(((p[:, None, :] - (a[None] + t[..., None] * ab[None])) ** 2).sum(-1)).min()))
+        return out
+    o = c_oracle.solve_batch(oc, x0, xf, up, dtp, obstacles=(no, nv, verts), obst=ob)
+    share = []
+    for rep in range(3):
+        ok = o[3] == 0
+        c = clearance(o[0])
+        share.append(float(np.mean(c[ok] >= dmin - 1e-6)))
+        assert ok.mean() >= 0.9
+        o = c_oracle.solve_batch(oc, x0, xf, up, dtp, init=(o[0], o[1], o[2]), obstacles=(no, nv, verts), obst=ob)
+    assert 0.6 < share[0] < 0.98 and share[1] >= 0.97 and share[2] == 1.0, share
