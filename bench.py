@@ -217,6 +217,7 @@ def main():
     ap.add_argument("--params", type=str, default=",".join(str(k) for k in CAND_PARAMS), help="per candidate: tangent scale of the Hermite kinds")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the extra legs (warm start, other configs)")
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the reference-path-alone run behind solver.answers_equal_to_the_reference_path_alone (profiling runs: keeps the kernel statistics of rocprofv3 to the headline launches)")
     ap.add_argument("--force-dist", action="store_true", help="developer check on a one-GPU box: take the N > 1 code path (process group, barriers, RCCL "
                     "all-gather of the results) with a world of one rank")
     args = ap.parse_args()
@@ -365,7 +366,7 @@ def main():
     # reference's 100 iterations).  An instance counts as "equal" when the reference path converges and the headline returns candidate 0's trajectory,
     # bit for bit the reference path's, or when the reference path does not converge (then a hedge may answer).
     st_r = dt_r = None
-    if len(kinds) > 1:
+    if len(kinds) > 1 and not args.no_parity_check:
         win_h, _ = leg.solver.last_candidates(B)
         lr = Leg(m, torch, dev, m.config_carlike_min_time(n=n), B, m.workloads.carlike_min_time_inputs(B, seed=sharding.rank_seed(m.workloads.SEED_CONFIG2, rank)))
         lr.step(); lr.sync()
@@ -383,7 +384,7 @@ def main():
     # ---- extra legs (N = 1 only; after the timed region)
     if not multi and not args.no_legs:
         legs = {}
-        if len(kinds) > 1:
+        if len(kinds) > 1 and st_r is not None:
             # the latency-tuned operating point of rounds 2/3: candidate 0 capped at 60 iterations.  Faster, but instances the reference path would still
             # have solved get a hedge's answer -- a different local optimum in most of them; what that costs in solution quality is reported here:
             # objective(hedge's answer) - objective(reference path's answer), objective = (n - 1) dt

@@ -2614,7 +2614,9 @@ struct IpmWave {
                     sync();
                 }
 #endif
-                if (pit && mu > P.pit_mu_min) {        // partitioned sweep; a broken-down combine pivot (or a singular stage pivot) falls back to the serial sweep
+                if (pit && mu > P.pit_mu_min) {        // partitioned sweep; a broken-down combine pivot (or a singular stage pivot) falls back to the serial sweep.  (Measured r04: with the
+                                                       // partitioned sweeps also AT mu = tol -- the first barrier problem of the adaptive rule's end game -- the EXT kernels with clearance rows converge
+                                                       // for 10 % fewer instances than the C oracle: the end game needs the serial sweeps' accuracy from mu = tol on)
                     MPC_TICK(2, good = backward_pit(delta, dc, dd, nu); sync());
                     used_pit = good;
                     if (!good) { MPC_TICK(2, good = backward_dpp(delta, dc, dd, nu); sync()); }

@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 OUT=/tmp/mpc_prof
 rm -rf $OUT; mkdir -p $OUT $R/gpurun_out/profile_summary
-CMD="python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-legs ${BENCH_EXTRA:-}"
+CMD="python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-legs --no-parity-check ${BENCH_EXTRA:-}"
 rocprofv3 --kernel-trace --stats -d $OUT/trace -o run -- $CMD > $OUT/bench_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE -d $OUT/pmc_fetch -o run -- $CMD > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE -d $OUT/pmc_write -o run -- $CMD > $OUT/pmc_write.log 2>&1

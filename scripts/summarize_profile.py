@@ -21,7 +21,7 @@ def main(src, dst, key="carlike_n50_B1024_c4"):
     out = []
     tr = os.path.join(src, "trace", "run_results.db")
     if os.path.exists(tr):
-        out.append("## rocprofv3 --kernel-trace --stats  (python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-legs)\n")
+        out.append("## rocprofv3 --kernel-trace --stats  (python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-legs --no-parity-check)\n")
         out.append("| kernel | calls | total_us | avg_us | % |\n|---|---|---|---|---|\n")
         for name, calls, tot, avg, pct in rows(tr, "select name,total_calls,total_duration,average,percentage from top_kernels")[1]:
             short = name.replace("(anonymous namespace)::", "").split("(mpc::")[0][:100]
@@ -52,7 +52,7 @@ def main(src, dst, key="carlike_n50_B1024_c4"):
         import json
         rec = {"kernel": "mpc_ipm_wave_kernel", "key": key, "fetch_size_kib": vals["FETCH_SIZE"], "write_size_kib": vals["WRITE_SIZE"],
                "bytes_per_launch": (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0,
-               "source": os.path.basename(dst) + ".md", "command": "python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-legs"}
+               "source": os.path.basename(dst) + ".md", "command": "python bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-legs --no-parity-check"}
         path = os.path.join(os.path.dirname(dst) or ".", "hbm_traffic.json")
         try:
             allrec = json.load(open(path))
