@@ -899,10 +899,11 @@ def test_candidate_initial_trajectories_best_of(m):
     s.close()
 
 
-@pytest.mark.parametrize("which", [2, 3])
+@pytest.mark.parametrize("which", [2, 3, "3b", "3c"])
 def test_device_vs_independent_sqp_from_the_cold_start(m, which):
     """SURVEY 8c level 2 on the device: scipy SLSQP on the reference-form NLP from the reference cold start (fixtures of
-    tests/golden/make_cold_start_scipy.py, 32 instances each of config 2 and config 3) against the HIP solve."""
+    tests/golden/make_cold_start_scipy.py, 32 instances each of config 2 and config 3; r04: 24 each of config 3 on the two placements where the clearance rows bind, 3b / 3c)
+    against the HIP solve."""
     from test_oracle_solver import _vs_independent_sqp
 
     def solve(ocfg, inputs, obst):
@@ -917,6 +918,10 @@ def test_device_vs_independent_sqp_from_the_cold_start(m, which):
     same, err, conv = _vs_independent_sqp(f"device vs SLSQP, config {which}", which, solve)
     if which == 3:
         assert conv.all() and same.all()
+    elif which == "3b":
+        assert conv.sum() >= len(conv) - 2 and same.sum() >= 0.8 * conv.sum()
+    elif which == "3c":
+        assert conv.sum() >= 0.3 * len(conv) and same.sum() >= 0.5 * conv.sum()
     else:
         assert conv.sum() >= 28 and same.sum() >= 14          # r04: 29 converged, 16 at SLSQP's point (r03: 30 / 14)
 

@@ -406,29 +406,32 @@ def _vs_independent_sqp(tag, which, solve):
     Returns (same mask, err)."""
     import mpc_local_planner_amd.workloads as W
     from oracle import candidates as OC, kkt_check as KC
-    g = np.load(os.path.join(GOLD, f"cold_start_scipy_config{which}.npz"))
+    suffix = {"3b": "_binding", "3c": "_touching"}.get(which, "")       # config 3 on placements where the clearance rows bind (make_cold_start_scipy.py 3b / 3c)
+    g = np.load(os.path.join(GOLD, f"cold_start_scipy_config{str(which)[0]}{suffix}.npz"))
     K = int(g["count"])
     if which == 2:
         inputs = W.carlike_min_time_inputs(K); obst = None
         ocfg = R.config_carlike_min_time(50)
     else:
-        x0, xf, up, dtp, obst = W.unicycle_obstacle_inputs(K, n_obst=16, max_vertices=6)
+        lat = tuple(float(v) for v in g["lateral"]) if "lateral" in g.files else (0.3, 1.5)
+        x0, xf, up, dtp, obst = W.unicycle_obstacle_inputs(K, n_obst=16, max_vertices=6, lateral=lat)
         inputs = (x0, xf, up, dtp)
         ocfg = R.config_unicycle_quadratic(80)
     x, u, dt, st, it = solve(ocfg, inputs, obst)
     d = x - g["x"]; d[..., 2] = OC.wrap(d[..., 2])
     err = np.abs(d).reshape(K, -1).max(1)
-    conv = st == 0
+    valid = g["violation"] < 1e-6         # (on the hardest placement SLSQP itself ends infeasible in some instances: those have no reference point)
+    conv = (st == 0) & valid
     same = conv & (err < 2e-4)            # SLSQP works with finite-difference gradients: its own accuracy is ~1e-5 .. 1e-4
     other = np.nonzero(conv & ~same)[0]
     res = KC.kkt_many(ocfg, inputs[0], inputs[1], inputs[2], inputs[3], x, u, dt, other, obstacles=obst, max_rows=4 if obst is not None else None)
     bad = [i for i in other if not KC.is_kkt_point(res[i])]
     dobj = [res[i]["objective"] - float(g["objective"][i]) for i in other]
-    print(f"[{tag}] {K} instances from the reference cold start: solver converged {int(conv.sum())}, SLSQP violation <= {g['violation'].max():.1e}; "
+    print(f"[{tag}] {K} instances from the reference cold start ({int(valid.sum())} with a feasible SLSQP result): solver converged {int(conv.sum())} of those, SLSQP violation <= {g['violation'][valid].max():.1e}; "
           f"same KKT point (<2e-4) {int(same.sum())} (median {np.median(err[same]):.1e}); different local optimum {len(other)} "
           f"(all KKT points of the reference-form NLP: {not bad}; objective solver - SLSQP: "
           + (f"min {min(dobj):+.3f} median {np.median(dobj):+.3f} max {max(dobj):+.3f}, solver better in {sum(d < 0 for d in dobj)}" if dobj else "-") + ")")
-    assert g["violation"].max() < 1e-6 and not bad
+    assert valid.sum() >= 0.5 * K and not bad
     return same, err, conv
 
 
@@ -445,6 +448,20 @@ def test_independent_sqp_from_the_cold_start_config3(c_oracle):
     start and the interior-point oracle land on the SAME point in every one of the 32 instances."""
     same, err, conv = _vs_independent_sqp("C oracle vs SLSQP, config 3", 3, _c_solve(c_oracle))
     assert conv.all() and same.all()
+
+
+@pytest.mark.parametrize("which", ["3b", "3c"])
+def test_independent_sqp_from_the_cold_start_config3_with_binding_rows(c_oracle, which):
+    """config 3 where the clearance rows BIND.  3b = the bench leg's placement (polygons 0.15 .. 0.8 m beside the start-goal line, d_min 0.2: rows start
+    violated by up to 5 cm, about half of the solutions end with an active row); 3c = polygons reaching to within 2 cm of the line (rows start violated by up to 18 cm: detours).
+    SLSQP starts at the reference's cold start with the rows associated on it, like the interior-point solve.  Every converged interior-point result is at SLSQP's point or is
+    a KKT point of the reference-form NLP in its own right (checked inside the helper); the shares are asserted as measured."""
+    same, err, conv = _vs_independent_sqp(f"C oracle vs SLSQP, config {which}", which, _c_solve(c_oracle))
+    K = len(conv)
+    if which == "3b":
+        assert conv.sum() >= K - 2 and same.sum() >= 0.8 * conv.sum()
+    else:
+        assert conv.sum() >= 0.3 * K and same.sum() >= 0.5 * conv.sum()
 
 
 def test_independent_sqp_from_the_cold_start_config2(c_oracle):
