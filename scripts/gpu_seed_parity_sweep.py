@@ -1,0 +1,34 @@
+"""Parity accounting of the headline workload on OTHER seeds than the tests use (robustness check of a round's algorithm change): device vs C oracle, reference path alone
+and with the headline's candidates (parity-preserving caps), B = 1024 each.  Every converged device result must be within 1e-4 of the oracle's or a KKT point on its own."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import numpy as np
+
+
+def main():
+    import torch
+    torch.zeros(1, device="cuda")
+    import mpc_local_planner_amd as m
+    from oracle import c_oracle as CO, se2_nlp as R, candidates as OC
+    from _parity import account
+    CO.build()
+    B, n = 1024, 50
+    ocfg = R.config_carlike_min_time(n)
+    kinds, caps, pars = (0, 5, 5, 7), (100, 45, 40, 35), (0.0, 2.0, 3.0, 1.5)
+    for seed in [int(a) for a in sys.argv[1:]] or [1, 2, 3]:
+        inputs = m.workloads.carlike_min_time_inputs(B, seed=seed)
+        s = m.BatchSolver(m.config_carlike_min_time(n), max_batch=B)
+        r = s.solve(*inputs); s.close()
+        ref = CO.solve_batch(CO.from_nlp_config(ocfg), *inputs)
+        account(f"seed {seed}: config 2, reference path", ocfg, inputs, r, ref)
+        sc = m.BatchSolver(m.config_carlike_min_time(n, candidates=kinds, candidate_max_iter=caps, candidate_param=pars), max_batch=B)
+        rc = sc.solve(*inputs); win, _ = sc.last_candidates(B); sc.close()
+        ox, ou, od, ost, oit, owin, olow, allr = OC.solve_candidates(CO, lambda cap: CO.from_nlp_config(ocfg, max_iter=cap), *inputs, kinds, caps, n, ocfg.dt_ref, params=pars)
+        print(f"seed {seed}: candidates: device converged {np.mean(rc.status == 0):.4f} oracle rule {np.mean(ost == 0):.4f} equal winners {np.mean(win == owin):.4f}; reference path's answer kept "
+              f"{np.mean(np.where(r.status == 0, (win == 0) & (np.abs(rc.x - r.x).reshape(B, -1).max(1) == 0), True)):.4f}")
+        account(f"seed {seed}: config 2 with candidates", ocfg, inputs, rc, (ox, ou, od, ost, oit))
+
+
+if __name__ == "__main__":      # (the KKT checker's worker pool spawns: the module must be importable without side effects)
+    main()
