@@ -69,7 +69,7 @@ typedef struct oracle_config {
     int32_t ball;               /* terminal l2-ball row xd' S xd - gamma <= 0 on the free final state (final_state_conditions_se2.cpp:54-64) */
     double ball_S[3], ball_gamma;
     int32_t integral;           /* quadratic objective in integral form: stage cost x dt (left sum; quadratic_cost_se2.cpp:54-83, finite_differences_grid_se2.cpp:61-75) */
-    int32_t hessian_mode;       /* 0 exact Lagrangian Hessian; 1 convexified: the stage block [Hqq Hqd; Hqd' Hdd] of lam' D is replaced by its
+    int32_t hessian_mode;       /* (2: stage-structured quasi-Newton blocks, an experiment of this file: see bfgs_update) 0 exact Lagrangian Hessian; 1 convexified: the stage block [Hqq Hqd; Hqd' Hdd] of lam' D is replaced by its
                                  * positive semidefinite part (the product's MPC_HESSIAN_CONVEXIFIED, the "reference-like" mode) */
     int32_t hybrid;             /* quadratic_form/hybrid_cost_minimum_time: + (n-1) dt (corbo::MinTimeQuadraticControls, src/controller.cpp:616-618) */
     int32_t trapezoid;          /* grid/cost_integration_method trapezoidal_rule (integral-form terms only; finite_differences_grid_se2.cpp:63-68):
@@ -254,6 +254,9 @@ typedef struct {
     int nvia; const double* via; int vidx[64];
     int rows_dropped;          /* clearance rows that did not fit into max_rows (obst_associate) */
     double* dual;              /* this instance's block of the kept multipliers or NULL */
+    double *bf, *bf_g, *bf_e;  /* hessian_mode 2 (stage-structured BFGS): per stage the 4 x 4 block over (theta, v, w, dt) as 10 words [00 01 02 11 12 22 | 03 13 23 | 33],
+                                * the gradient of lam' D_k at the point of the last update (4) and that point (4) */
+    int bf_init;
     int convexify;             /* this factorisation: stage blocks of the Lagrangian curvature replaced by their positive semidefinite parts */
     int rhs_only;              /* assemble(): leave the factorised band alone, rebuild only the right-hand side / gradient pieces (they are linear in mu) */
 } work_t;
@@ -878,6 +881,12 @@ static void assemble(work_t* w, const double* cc, double delta, double dc, doubl
             w->rhs[row] = -cc[3 * k + a];
         }
         if (k == n - 2) for (int a = 0; a < 3; ++a) if (c->xf_fixed[a]) band_add(w, il(k, a), il(k, a), -dc);
+        if (c->hessian_mode == 2) {           /* stage-structured quasi-Newton block instead of the exact curvature of lam' D_k */
+            const double* b = &w->bf[10 * k];
+            sm.Hqq[0][0] = b[0]; sm.Hqq[0][1] = sm.Hqq[1][0] = b[1]; sm.Hqq[0][2] = sm.Hqq[2][0] = b[2]; sm.Hqq[1][1] = b[3]; sm.Hqq[1][2] = sm.Hqq[2][1] = b[4]; sm.Hqq[2][2] = b[5];
+            sm.Hqd[0] = b[6]; sm.Hqd[1] = b[7]; sm.Hqd[2] = b[8]; sm.Hdd = b[9];
+            if (qi[0] < 0) { sm.Hqq[0][0] = sm.Hqq[0][1] = sm.Hqq[1][0] = sm.Hqq[0][2] = sm.Hqq[2][0] = 0; sm.Hqd[0] = 0; }      /* theta_0 is not a variable */
+        }
         if (g_variant == 3 || c->hessian_mode == 1 || w->convexify == 1) psd_project4(&sm, qi[0] < 0);
         else if (w->convexify == 2) gershgorin4(&sm, qi[0] < 0);      /* stage-wise convexification of the Lagrangian curvature */
         /* Lagrangian curvature */
@@ -1120,13 +1129,16 @@ static void derive_step(work_t* w, const double* cc, double mu, double tau, doub
  *   globalization  0 l1 merit (the product), 1 Ipopt's filter (Waechter & Biegler 2006, Algorithm A) with max_soc second-order corrections
  *   safeguard      adaptive mu: 1 = Ipopt's adaptive_mu_globalization=kkt-error (fixed-mu mode at fix_fact x the average complementarity when the error stalls)
  *   convex_fallback  1: a factorisation that fails the curvature test at delta = 0 is repeated with the stage blocks of lam' D replaced by their positive
- *                  semidefinite parts before any multiple of the identity is added */
+ *                  semidefinite parts before any multiple of the identity is added
+ *   qn_sr1         oracle_config.hessian_mode = 2 (stage-structured quasi-Newton Hessian, an experiment of this file only): 1 = symmetric rank-one element updates
+ *                  (the default of that mode), 0 = damped BFGS */
 typedef struct {
     int mu_oracle, globalization, max_soc, safeguard;
     double sigma_max, fix_fact;
     int convex_fallback;
+    int qn_sr1;
 } algo_t;
-static algo_t g_algo = {0, 0, 0, 0, 100.0, 0.8, 0};
+static algo_t g_algo = {0, 0, 0, 0, 100.0, 0.8, 0, 1};
 void oracle_set_algo(int key, double v) {
     switch (key) {
         case 0: g_algo.mu_oracle = (int)v; break;
@@ -1136,6 +1148,7 @@ void oracle_set_algo(int key, double v) {
         case 4: g_algo.sigma_max = v; break;
         case 5: g_algo.fix_fact = v; break;
         case 6: g_algo.convex_fallback = (int)v; break;
+        case 7: g_algo.qn_sr1 = (int)v; break;
     }
 }
 
@@ -1216,6 +1229,63 @@ static int g_nfac_max = 0;
 void oracle_set_variant(int v) { g_variant = v; g_nfac_total = 0; g_nfac_max = 0; }
 long oracle_nfac_total(void) { return g_nfac_total; }
 int oracle_nfac_max(void) { return g_nfac_max; }
+
+
+/* hessian_mode 2 (EXPERIMENT, this file only -- the product maps `hessian_approximation: limited-memory` to MPC_HESSIAN_CONVEXIFIED, which beats both variants below at
+ * the shipped tol 1e-4: DESIGN.md section 3.1): stage-structured (partitioned) quasi-Newton Hessian.  The Lagrangian is a sum of element functions, and the only non-linear ones are the collocation increments:
+ * L = f + sum_k lam_k' D_k(e_k) + (linear rows),  e_k = (theta_k, v_k, w_k, dt).  Each 4 x 4 element Hessian is approximated by its own damped BFGS matrix B_k
+ * (Griewank & Toint's partitioned updating; Powell's damping keeps every block positive semidefinite), which keeps the stage structure the sweeps need -- Ipopt's limited-memory
+ * matrix is sigma I + a rank-2m term that couples all stages.  Secant pair of element k after an accepted step: s = e_k+ - e_k,  y = grad_e (lam+' D_k)(e_k+) - grad_e (lam+' D_k)(e_k)
+ * (both gradients with the NEW multipliers).  B_k starts at 0: the first factorisations are regularised by delta_w like any singular Hessian.  The true element Hessian
+ * [H_qq H_qd; H_qd' 0] is indefinite whenever H_qd != 0, so a positive semidefinite BFGS block cannot approach it (measured: 32 % of config 2 converge); symmetric rank-one
+ * updates can (89 %), and the curvature test + delta_w treat the indefinite blocks as they treat the exact Hessian. */
+static void bfgs_update(work_t* w) {
+    const oracle_config* c = w->c;
+    const int n = w->n;
+    for (int k = 0; k < n - 1; ++k) {
+        const double* lam = &w->lam[3 * k];
+        stage_map_t sm;
+        stage_map(c, w->X[3 * k + 2], w->U[2 * k], w->U[2 * k + 1], w->D, NULL, &sm);
+        double* J = &w->bf_g[12 * k];           /* Jq (9, row major) and Jdt (3) at the point of the last update */
+        double* e = &w->bf_e[4 * k];
+        double* b = &w->bf[10 * k];
+        if (w->bf_init) {
+            double y[4], sv[4], B[4][4], Bs[4];
+            for (int j = 0; j < 3; ++j) y[j] = lam[0] * (sm.Jq[0][j] - J[j]) + lam[1] * (sm.Jq[1][j] - J[3 + j]) + lam[2] * (sm.Jq[2][j] - J[6 + j]);
+            y[3] = lam[0] * (sm.Jdt[0] - J[9]) + lam[1] * (sm.Jdt[1] - J[10]) + lam[2] * (sm.Jdt[2] - J[11]);
+            sv[0] = k > 0 ? wrap(w->X[3 * k + 2] - e[0]) : 0.0; sv[1] = w->U[2 * k] - e[1]; sv[2] = w->U[2 * k + 1] - e[2]; sv[3] = c->dt_free ? w->D - e[3] : 0.0;
+            if (k == 0) y[0] = 0.0;
+            if (!c->dt_free) y[3] = 0.0;
+            B[0][0] = b[0]; B[0][1] = B[1][0] = b[1]; B[0][2] = B[2][0] = b[2]; B[1][1] = b[3]; B[1][2] = B[2][1] = b[4]; B[2][2] = b[5];
+            B[0][3] = B[3][0] = b[6]; B[1][3] = B[3][1] = b[7]; B[2][3] = B[3][2] = b[8]; B[3][3] = b[9];
+            double sBs = 0, sy = 0, ss = 0, yy = 0;
+            for (int i = 0; i < 4; ++i) { Bs[i] = 0; for (int j = 0; j < 4; ++j) Bs[i] += B[i][j] * sv[j]; }
+            for (int i = 0; i < 4; ++i) { sBs += sv[i] * Bs[i]; sy += sv[i] * y[i]; ss += sv[i] * sv[i]; yy += y[i] * y[i]; }
+            if (g_algo.qn_sr1) {
+                double v[4], vs = 0, vv = 0;
+                for (int i = 0; i < 4; ++i) { v[i] = y[i] - Bs[i]; vs += v[i] * sv[i]; vv += v[i] * v[i]; }
+                if (fabs(vs) > 1e-8 * sqrt(ss * vv) && ss > 1e-24) {
+                    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) B[i][j] += v[i] * v[j] / vs;
+                    b[0] = B[0][0]; b[1] = B[0][1]; b[2] = B[0][2]; b[3] = B[1][1]; b[4] = B[1][2]; b[5] = B[2][2]; b[6] = B[0][3]; b[7] = B[1][3]; b[8] = B[2][3]; b[9] = B[3][3];
+                }
+            } else
+            if (ss > 1e-24) {
+                /* Powell's damping: r = th y + (1 - th) B s with s'r >= 0.2 s'B s */
+                double th = 1.0;
+                if (sy < 0.2 * sBs) th = 0.8 * sBs / (sBs - sy);
+                double r[4], sr = 0, rr = 0;
+                for (int i = 0; i < 4; ++i) { r[i] = th * y[i] + (1.0 - th) * Bs[i]; sr += sv[i] * r[i]; rr += r[i] * r[i]; }
+                if (sr > 1e-12 * sqrt(ss * rr) && sr > 0) {
+                    for (int i = 0; i < 4; ++i) for (int j = 0; j < 4; ++j) B[i][j] += r[i] * r[j] / sr - (sBs > 0 ? Bs[i] * Bs[j] / sBs : 0.0);
+                    b[0] = B[0][0]; b[1] = B[0][1]; b[2] = B[0][2]; b[3] = B[1][1]; b[4] = B[1][2]; b[5] = B[2][2]; b[6] = B[0][3]; b[7] = B[1][3]; b[8] = B[2][3]; b[9] = B[3][3];
+                }
+            }
+        } else for (int i = 0; i < 10; ++i) b[i] = 0.0;
+        for (int a = 0; a < 3; ++a) { for (int j = 0; j < 3; ++j) J[3 * a + j] = sm.Jq[a][j]; J[9 + a] = sm.Jdt[a]; }
+        e[0] = w->X[3 * k + 2]; e[1] = w->U[2 * k]; e[2] = w->U[2 * k + 1]; e[3] = w->D;
+    }
+    w->bf_init = 1;
+}
 
 static int solve_one(work_t* w, int warm) {
     const oracle_config* c = w->c;
@@ -1349,6 +1419,7 @@ static int solve_one(work_t* w, int warm) {
     int n_acceptable = 0;
     const double acc_tol = acc_tol_of(c);
     const int acc_it = acc_iter_of(c);
+    w->bf_init = 0;
     eval_point(w, w->X, w->U, w->D, cc, &fobj);
     mu_min = tol / 10; mu_max = mu_max_fact * w->mu;
     while (1) {
@@ -1363,6 +1434,7 @@ static int solve_one(work_t* w, int warm) {
             if (n_acceptable >= acc_it) { status = 0; break; }
         }
         if (it >= max_iter) { status = 1; break; }
+        if (c->hessian_mode == 2) bfgs_update(w);
         /* barrier parameter.  Monotone (oracle_config.mu_strategy = 1, Ipopt's mu_strategy monotone): Fiacco-McCormick, mu falls when the barrier subproblem
          * is solved to kappa_eps mu.  Adaptive (the default; what corbo's SolverIpopt is believed to set): every iteration
          *     mu = sigma x (average complementarity),   sigma = clamp((1 - min(alpha, alpha_dual))^3, 0.05, 1)
@@ -1647,6 +1719,7 @@ static work_t* work_new(const oracle_config* c) {
     w->AB = (double*)calloc((size_t)LDAB * w->N, 8); w->ipiv = (int*)calloc(w->N, sizeof(int));
     w->rhs = (double*)calloc(w->N, 8); w->bcol = (double*)calloc(w->N, 8);
     w->dz_u = (double*)calloc(2 * (n - 1), 8); w->dz_x = (double*)calloc(3 * n, 8);
+    w->bf = (double*)calloc(10 * (n - 1), 8); w->bf_g = (double*)calloc(12 * (n - 1), 8); w->bf_e = (double*)calloc(4 * (n - 1), 8);
     return w;
 }
 static void work_obst(work_t* w, const oracle_obst* ob) {       /* clearance-row storage (only when a batch has obstacles) */
@@ -1663,7 +1736,7 @@ static void work_obst(work_t* w, const oracle_obst* ob) {       /* clearance-row
 }
 static void work_free(work_t* w) {
     free(w->X); free(w->U); free(w->Xt); free(w->Ut); free(w->lam); free(w->lamn); free(w->s); free(w->y); free(w->ron);
-    free(w->pl); free(w->pu); free(w->AB); free(w->ipiv); free(w->rhs); free(w->bcol); free(w->dz_u); free(w->dz_x);
+    free(w->pl); free(w->pu); free(w->AB); free(w->ipiv); free(w->rhs); free(w->bcol); free(w->dz_u); free(w->dz_x); free(w->bf); free(w->bf_g); free(w->bf_e);
     free(w->cent); free(w->oi); free(w->os); free(w->oy); free(w->ost); free(w->ods); free(w->ody); free(w->og); free(w->oax); free(w->oay); free(w->ohk); free(w->oat); free(w->oh3); free(w->oad); free(w->ohd);
     free(w);
 }
