@@ -579,6 +579,7 @@ MPC_HD void assemble_adds(const StageParts<T>& s, const T q2[3], const T r2[2], 
 template <typename T>
 struct RicState {
     T P[6][6], p[6], S[6][3], W[3][3], om[3];
+    int neg;          // negative eigenvalues of the control pivots R_k eliminated so far (inertia of the factorisation, riccati_root)
 };
 
 template <typename T>
@@ -643,6 +644,7 @@ MPC_HD bool riccati_step(RicState<T>& V, const StageRec<T>& r, T dx, T du, T add
     T det = R00 * R11 - R01 * R01;
     T scale = t_abs(R00 * R11) + R01 * R01;
     if (!(t_abs(det) > T(1e-14) * scale) || !t_finite(det)) return false;
+    V.neg += det < T(0) ? 1 : (R00 < T(0) ? 2 : 0);      // sign changes of (1, R00, det): the negative eigenvalues of this pivot
     T id = T(1) / det;
     T Ri00 = R11 * id, Ri01 = -R01 * id, Ri11 = R00 * id;
     T (&K)[2][6] = out.K;
@@ -703,6 +705,7 @@ MPC_HD void riccati_terminal(RicState<T>& V, const Problem<T>& P_, const T xd_f[
                              const T gy[2], T gyl) {
     for (int a = 0; a < 6; ++a) { V.p[a] = T(0); for (int b = 0; b < 6; ++b) V.P[a][b] = T(0); for (int b = 0; b < 3; ++b) V.S[a][b] = T(0); }
     for (int a = 0; a < 3; ++a) { V.om[a] = T(0); for (int b = 0; b < 3; ++b) V.W[a][b] = T(0); }
+    V.neg = 0;
     for (int i = 0; i < 3; ++i) {
         if (P_.xf_fixed[i]) { V.S[i][i] = T(1); V.W[i][i] = -dc; }
         else {
@@ -734,6 +737,38 @@ MPC_HD bool riccati_root(const RicState<T>& V, const Problem<T>& P_, T& dd_out, 
             for (int b = 0; b < 3; ++b) A4[1 + a][1 + b] = P_.xf_fixed[b] ? V.W[a][b] : T(0);
             A4[1 + a][4] = -V.om[a];
         } else { A4[1 + a][1 + a] = T(1); }
+    }
+    // ---- inertia (r04): Ipopt accepts a factorisation when the KKT matrix has as many positive eigenvalues as primal variables and as many negative ones as
+    // equality rows, and raises delta_w otherwise.  By Sylvester's law the inertia is the sum over the pivot blocks of ANY symmetric block elimination (Haynsworth): the
+    // sweep eliminates, per stage, the pair (x_{k+1}, lambda_k) -- pivot [[H, -I], [-I, 0]], three positive and three negative eigenvalues whatever H is -- and the
+    // control u_k with the 2 x 2 pivot R_k (V.neg counts its negative eigenvalues); what is left is this symmetric system over (dt, nu): one negative eigenvalue per FIXED
+    // final component is what the inertia asks for.  Counted by Jacobi's signature rule -- the negative pivots of the elimination WITHOUT exchanges, order nu then dt; the
+    // rows of free components / a fixed dt are identity rows (pivot +1) -- and a vanishing pivot counts as a failed factorisation.  The test replaces the inertia-free
+    // curvature test of r01-r03, which lets Newton's iteration converge to saddle points (18 % of the config-2 answers).
+    {
+        T B4[4][4];
+        T scl = T(0);
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) { B4[a][b] = A4[(a + 1) & 3][(b + 1) & 3]; scl = t_max(scl, t_abs(B4[a][b])); }      // order nu_0 nu_1 nu_2 dt
+        int neg = V.neg, want = 0;
+        bool okp = t_finite(scl);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const T pv = B4[c][c];
+            okp = okp && (t_abs(pv) > T(1e-14) * scl);
+            neg += pv < T(0) ? 1 : 0;
+            const T ip = t_rcp(pv);
+#pragma unroll
+            for (int r = c + 1; r < 4; ++r) {
+                const T m = B4[r][c] * ip;
+#pragma unroll
+                for (int b = c + 1; b < 4; ++b) B4[r][b] -= m * B4[c][b];
+            }
+        }
+        for (int a = 0; a < 3; ++a) want += P_.xf_fixed[a] ? 1 : 0;
+        if (!okp || neg != want) return false;
     }
     // Gaussian elimination with partial pivoting, written with compile-time indices only: the pivot row is brought up by
     // compare-and-swap selects (a run-time row index would put the 4x5 tableau into scratch memory on the GPU).

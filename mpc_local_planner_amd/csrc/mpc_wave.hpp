@@ -1285,6 +1285,8 @@ struct IpmWave {
         return r;
     }
     __device__ __forceinline__ T fast_rcp(float x) const { return 1.0f / x; }
+    __device__ __forceinline__ static int sign_word(double x) { return __double2hiint(x); }      // the word that holds the sign bit
+    __device__ __forceinline__ static int sign_word(float x) { return __float_as_int(x); }
 
     // ---- register-resident backward sweep: lane c (0..11 of every 16-lane DPP row) owns COLUMN c of the value block
     //      [P | . . | p | S] (6x12) and of Hhat (8x12).  Entries of other columns are fetched with the DP-ALU DPP broadcast
@@ -1364,6 +1366,7 @@ struct IpmWave {
         const T s05 = c == 5 ? add_dd0 : (c == 8 ? add_qd0 : T(0));       // stage-0 extras of row 5
         T om = T(0), wn[3] = {T(0), T(0), T(0)};
         T worst = T(1);                                                   // min over the stages of |det R| - 1e-14 * scale
+        int negc = 0;                                                     // negative eigenvalues of the control pivots = sign changes of (1, R00, det R), summed over the stages
         auto load_stage = [&](T (&g)[3], T (&a)[8]) {                     // reads the stage the running pointers are at, then steps them
             g[0] = gp[0]; g[1] = gp[1]; g[2] = gp[2];
             gp -= gs;
@@ -1405,6 +1408,7 @@ struct IpmWave {
             const T r2 = R01 * R01;
             const T det = R00 * R11 - r2;
             worst = t_fmin(worst, t_abs(det) - T(1e-14) * (t_abs(R00 * R11) + r2));   // a NaN determinant poisons V and is caught by the root solve
+            { const int s0 = sign_word(R00), s1 = sign_word(det); negc += (int)((unsigned)s0 >> 31) + (int)((unsigned)(s0 ^ s1) >> 31); }
             const T nid = -fast_rcp(det);
             const T nRi00 = R11 * nid, Ri01 = -(R01 * nid), nRi11 = R00 * nid;  // -R^-1 = [nRi00 Ri01; Ri01 nRi11]
             const T nK0 = nRi00 * h[6] + Ri01 * h[7], nK1 = Ri01 * h[6] + nRi11 * h[7];
@@ -1449,6 +1453,7 @@ struct IpmWave {
         // row 5 of the value block, omega and the W / omega corrections are gathered with v_readlane (no LDS round trip)
         if (!(rd_lane(worst, 0) > T(0))) return false;
         RicState<T> Vr;
+        Vr.neg = __builtin_amdgcn_readlane(negc, 0);
         Vr.P[5][5] = rd_lane(V[5], 5);
         Vr.p[5] = rd_lane(V[5], 8);
         Vr.S[5][0] = rd_lane(V[5], 9); Vr.S[5][1] = rd_lane(V[5], 10); Vr.S[5][2] = rd_lane(V[5], 11);
@@ -1723,7 +1728,12 @@ struct IpmWave {
     // are part of the condition, not a consequence of the grid-size threshold.  Second invariant: a saved tile overwrites the trig cache, which
     // kkt_pass reads -- every path from a factorisation to the next kkt_pass rewrites TRIG for all k < n - 1 (eval_point / trial_eval of the accepted trial;
     // the solve ends without another kkt_pass when no trial is evaluated).
-    __device__ __forceinline__ bool pit_enabled() const { return EXT < 2 && P.pit != 0 && L.n >= 40 && 3 * L.NS >= 100 && L.NTR * L.NS >= 100 && 5 * L.NS >= 192; }
+    // r04: NOT used by the solve.  A factorisation is accepted on its INERTIA (riccati_root), which the serial sweep carries in the signs of its control pivots R_k; the
+    // segments of the partitioned sweep start from the identity border, their pivots are those of the segment's own cost-to-go, and the inertia of the whole would need the
+    // inertias of the three 12 x 12 combine blocks [[W_s, -I], [-I, P+]] on top (two symmetric 6 x 6 eliminations per combine, P+ structurally singular in the position rows).
+    // Until the combine carries that count the partitioned sweeps stay compiled out (kPartitionedSweeps); tests/test_pit_math.py keeps their algebra checked.
+    static constexpr bool kPartitionedSweeps = false;
+    __device__ __forceinline__ bool pit_enabled() const { return kPartitionedSweeps && EXT < 2 && P.pit != 0 && L.n >= 40 && 3 * L.NS >= 100 && L.NTR * L.NS >= 100 && 5 * L.NS >= 192; }
     // lane index that the optimiser must treat as unknown HERE: keeps the per-lane address arithmetic of a phase inside the phase (hoisted out of the
     // interior-point loop as loop invariants it would occupy registers for the whole solve)
     __device__ __forceinline__ int local_lane() const { int l = lane; asm volatile("" : "+v"(l)); return l; }
@@ -1935,6 +1945,7 @@ struct IpmWave {
         if (!(rd_lane(wpiv, 0) > T(1e-9))) return false;                   // a pivot of I - W P+ broke down: the caller repeats this factorisation with the serial sweep
         // ---- root: the value function at stage 0 has its P columns in lane set B (lane 15 = column 5)
         RicState<T> Vr;
+        Vr.neg = 0;                                                        // (the segments' pivots do not carry the inertia of the whole: see kPartitionedSweeps)
         Vr.P[5][5] = rd_lane(Vp[5], 15);
         Vr.p[5] = rd_lane(Vp[5], 8);
         Vr.S[5][0] = rd_lane(Vp[5], 9); Vr.S[5][1] = rd_lane(Vp[5], 10); Vr.S[5][2] = rd_lane(Vp[5], 11);
@@ -2657,9 +2668,9 @@ struct IpmWave {
                     asm volatile("; POST_END");
 #endif
                     good = fw.finite;
-                    if (good) {
+                    if (good) {      // the backward sweep has checked the inertia of this factorisation (mpc_core.hpp::riccati_root); the curvature only feeds the penalty update
                         curv = -fw.hdz + fw.clam - dc * fw.nunu;
-                        if (curv >= Algo<T>::curv_kappa * fw.dz2) { ok = true; break; }
+                        ok = true; break;
                     }
                 }
                 if (delta == T(0)) delta = (delta_last == T(0)) ? Algo<T>::delta_first : t_max(Algo<T>::delta_min, Algo<T>::kappa_minus * delta_last);

@@ -7,10 +7,12 @@ vendored, version unpinned).  This file restates Ipopt's *published* algorithm
 (Waechter & Biegler, Math. Prog. 106(1), 2006: log-barrier, primal-dual Newton
 on the perturbed KKT system, fraction-to-boundary rule, monotone
 Fiacco-McCormick barrier update, Hessian regularisation by a multiple of the
-identity) in a reduced form -- l1-merit backtracking instead of the filter, an
-inertia-free curvature test (Chiang & Zavala 2016) instead of inertia from the
-factorisation, no restoration phase -- with DENSE linear algebra (numpy.linalg)
-on the full KKT matrix.  The HIP product solves the same Newton systems with a
+identity until the KKT matrix has the inertia (n, m, 0) -- read off LAPACK's
+Bunch-Kaufman factorisation here, off the pivots of the Riccati sweep in the
+product; r01-r03 used the inertia-free curvature test of Chiang & Zavala 2016,
+which lets the iteration converge to saddle points: IpmOptions.inertia_test) in a
+reduced form -- l1-merit backtracking instead of the filter, no restoration
+phase -- with DENSE linear algebra (numpy.linalg) on the full KKT matrix.  The HIP product solves the same Newton systems with a
 stage-structured Riccati sweep; agreement of the two is the parity test.
 
 PARITY UNPINNED for the solve: no Ipopt here and no golden outputs in the reference; the
@@ -616,6 +618,7 @@ class IpmOptions:
     kappa_plus_first: float = 100.0
     kappa_minus: float = 1.0 / 3.0
     curv_kappa: float = 1e-10
+    inertia_test: str = "inertia"        # "inertia": Ipopt's test of a factorisation (nv positive, mc negative eigenvalues; r04); "curvature": the inertia-free test of r01-r03
     s_max: float = 100.0
     max_ls: int = 30
     delta_c: float = 1e-8
@@ -651,6 +654,28 @@ class IpmResult:
     history: list
     piL: Optional[np.ndarray] = None     # multipliers of the lower / upper variable bounds (for dual_start of the next cycle)
     piU: Optional[np.ndarray] = None
+
+
+def kkt_inertia(K: np.ndarray):
+    """(positive, negative) eigenvalue counts of the symmetric KKT matrix from LAPACK's Bunch-Kaufman factorisation (scipy.linalg.ldl: K = L D L' with 1 x 1 and
+    2 x 2 diagonal blocks; Sylvester's law).  A zero pivot counts for neither: the caller then sees a wrong inertia and regularises, as Ipopt does."""
+    from scipy.linalg import ldl
+    _, d, _ = ldl(K, lower=True, hermitian=True, overwrite_a=False, check_finite=False)
+    n = d.shape[0]
+    pos = neg = 0
+    i = 0
+    while i < n:
+        if i + 1 < n and d[i + 1, i] != 0.0:
+            a, b, c = d[i, i], d[i + 1, i], d[i + 1, i + 1]
+            det, tr = a * c - b * b, a + c
+            if det < 0: pos += 1; neg += 1
+            elif det > 0: pos, neg = (pos + 2, neg) if tr > 0 else (pos, neg + 2)
+            i += 2
+        else:
+            if d[i, i] > 0: pos += 1
+            elif d[i, i] < 0: neg += 1
+            i += 1
+    return pos, neg
 
 
 def controls_from_states(cfg: R.OcpConfig, init: R.Trajectory) -> R.Trajectory:
@@ -873,7 +898,11 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
             if good:
                 dz = sol[:nv]
                 curv = dz @ ((Hc + delta * np.eye(nv)) @ dz)
-                if curv >= opt.curv_kappa * (dz @ dz):
+                if opt.inertia_test == "inertia":
+                    right = kkt_inertia(K) == (nv, mc)
+                else:
+                    right = curv >= opt.curv_kappa * (dz @ dz)
+                if right:
                     ok = True
                     break
             # increase delta

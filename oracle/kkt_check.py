@@ -58,6 +58,65 @@ def kkt_residuals(ocfg, x0, xf, u_prev, dt_prev, x, u, dt, act_tol: float = 1e-1
     return {"feas": feas, "stat": stat, "comp": comp, "objective": float(nlp.objective(z)), "n_active": int(act.size + al.size + au.size)}
 
 
+def second_order(ocfg, x0, xf, u_prev, dt_prev, x, u, dt, act_tol: float = 1e-1, strong_tol: float = 1e-5, slack_tol: float = 1e-5, nlp_kwargs=None, inp_kwargs=None,
+                 fd_step: float = 1e-5, hess_step: float = 1e-4):
+    """Is a KKT point a local MINIMUM?  The reduced Hessian of the Lagrangian Z' (grad^2 L) Z on the tangent space of the active rows, by differences of the reference-form
+    NLP's functions alone (no solver quantity): multipliers from the same bounded least-squares problem as kkt_residuals; `strong` rows / bounds = multiplier > strong_tol,
+    `active` = slack < slack_tol (an interior-point result keeps slack = mu / multiplier).  Z_s = null space of the equality rows + the strong rows (the subspace of the
+    second-order SUFFICIENT condition when no row is weakly active), Z_a = null space with every active row (second-order NECESSARY condition).  grad^2 L Z by central
+    differences (hess_step) of the numeric gradient of L (fd_step) along the columns of Z.  Returns dict(dim_s, min_eig_s, dim_a, min_eig_a, n_weak): a strict local minimum
+    has min_eig_s > 0 (dim_s = 0: a vertex of the active set -- bang-bang minimum-time solutions -- min_eig = +inf)."""
+    from scipy.linalg import null_space
+    inp = R.CycleInputs(x0=np.asarray(x0, float), xf=np.asarray(xf, float), u_prev=np.asarray(u_prev, float), dt_prev=float(dt_prev), **(inp_kwargs or {}))
+    nlp = R.ReferenceNlp(ocfg, inp, **(nlp_kwargs or {}))
+    n = ocfg.n
+    z = nlp.pack(R.Trajectory(np.asarray(x, float), np.asarray(u, float)[: n - 1], float(dt)))
+    lb, ub = nlp.bounds()
+    g = nlp.inequalities(z)
+    gradf = nlp.numeric_jacobian(lambda v: np.array([nlp.objective(v)]), z, fd_step)[0]
+    Jc = nlp.numeric_jacobian(nlp.equalities, z, fd_step)
+    act = np.where(g > -act_tol)[0]
+    Jg = nlp.numeric_jacobian(nlp.inequalities, z, fd_step)[act] if act.size else np.zeros((0, z.size))
+    al = np.where(z - lb < act_tol)[0]
+    au = np.where(ub - z < act_tol)[0]
+    El = np.zeros((al.size, z.size)); El[np.arange(al.size), al] = -1.0
+    Eu = np.zeros((au.size, z.size)); Eu[np.arange(au.size), au] = 1.0
+    A = np.concatenate([Jc, Jg, El, Eu], axis=0).T
+    slack = np.concatenate([-g[act], (z - lb)[al], (ub - z)[au]])
+    me = Jc.shape[0]
+    lo = np.concatenate([np.full(me, -np.inf), np.zeros(slack.size)])
+    W = np.zeros((slack.size, lo.size)); W[np.arange(slack.size), me + np.arange(slack.size)] = np.abs(slack)
+    sol = lsq_linear(np.concatenate([A, W], axis=0), np.concatenate([-gradf, np.zeros(slack.size)]), bounds=(lo, np.full(lo.size, np.inf)), tol=1e-15, max_iter=4000, method='bvls')
+    lam, nu = sol.x[:me], sol.x[me:me + act.size]
+    mult = sol.x[me:]
+    rows = A.T[me:]
+    strong = mult > strong_tol
+    active = np.abs(slack) < slack_tol
+    # variables a fixed bound pins (start pose, a fixed goal) have lb == ub: they are in al AND au with slack 0 -- active whatever their multiplier
+    fixed = np.concatenate([np.zeros(act.size, bool), (ub - lb)[al] <= 0, (ub - lb)[au] <= 0])
+
+    def lagr(v):
+        gi = nlp.inequalities(v)
+        return np.array([nlp.objective(v) + lam @ nlp.equalities(v) + (nu @ gi[act] if act.size else 0.0)])
+
+    def reduced(sel):
+        M = np.concatenate([Jc, rows[sel | fixed]], axis=0)
+        Z = null_space(M, rcond=1e-9)
+        if Z.shape[1] == 0:
+            return 0, np.inf
+        HZ = np.zeros_like(Z)
+        for i in range(Z.shape[1]):
+            gp = nlp.numeric_jacobian(lagr, nlp.plus(z, hess_step * Z[:, i]), fd_step)[0]
+            gm = nlp.numeric_jacobian(lagr, nlp.plus(z, -hess_step * Z[:, i]), fd_step)[0]
+            HZ[:, i] = (gp - gm) / (2 * hess_step)
+        Hr = Z.T @ HZ
+        return Z.shape[1], float(np.linalg.eigvalsh(0.5 * (Hr + Hr.T)).min())
+    ds, es = reduced(strong)
+    weak = int((active & ~strong & ~fixed).sum())
+    da, ea = (ds, es) if weak == 0 else reduced(active | strong)
+    return {"dim_s": ds, "min_eig_s": es, "dim_a": da, "min_eig_a": ea, "n_weak": weak, "n_strong": int((strong & ~fixed).sum())}
+
+
 def is_kkt_point(res, feas_tol: float = 1e-6, stat_tol: float = 1e-6, comp_tol: float = 1e-6) -> bool:
     return res["feas"] <= feas_tol and res["stat"] <= stat_tol and res["comp"] <= comp_tol
 

@@ -258,6 +258,7 @@ typedef struct {
                                 * the gradient of lam' D_k at the point of the last update (4) and that point (4) */
     int bf_init;
     int convexify;             /* this factorisation: stage blocks of the Lagrangian curvature replaced by their positive semidefinite parts */
+    double *inS, *inb;         /* scratch of kkt_negative_eigenvalues */
     int rhs_only;              /* assemble(): leave the factorised band alone, rebuild only the right-hand side / gradient pieces (they are linear in mu) */
 } work_t;
 
@@ -1139,7 +1140,9 @@ typedef struct {
     int qn_sr1;
 } algo_t;
 static algo_t g_algo = {0, 0, 0, 0, 100.0, 0.8, 0, 1};
+static int g_inertia = 1;      /* 1: a factorisation is accepted when the KKT matrix has Ipopt's inertia (the algorithm); 0: the inertia-free curvature test of r01-r03 (kept for the measurements of DESIGN 3.1) */
 void oracle_set_algo(int key, double v) {
+    if (key == 9) { g_inertia = (int)v; return; }
     switch (key) {
         case 0: g_algo.mu_oracle = (int)v; break;
         case 1: g_algo.globalization = (int)v; break;
@@ -1174,6 +1177,90 @@ static void compl_stats(const work_t* w, const double* ds, const double* dy, dou
     }
 #undef CPAIR
     *sum = sm; *cnt = k0; *cmin = mn;
+}
+
+
+/* ---------------------------------------------------------------- inertia of the KKT matrix (Ipopt's test of a factorisation: n primal positive, m dual negative eigenvalues)
+ * The banded LU above pivots by rows and carries no inertia.  This pass counts the negative eigenvalues of the SAME assembled matrix [band b; b' Hdd] by a symmetric block
+ * elimination from the last stage backward -- blocks (lam_k, x_{k+1}) then u_k, k = n-2 .. 0, then dt -- with Sylvester's law: the inertia is the sum of the inertias
+ * of the pivot blocks (Haynsworth), whatever the order, as long as no pivot block is singular.  Small pivot blocks: Bunch-Parlett diagonal pivoting (1x1 / 2x2, complete pivoting). */
+static int small_inertia(double* A, int m, int* nneg) {            /* A: m x m symmetric, leading dimension 6, destroyed; returns -1 when singular */
+    int act[6], r = m, neg = 0;
+    double scale = 0;
+    for (int i = 0; i < m; ++i) { act[i] = i; for (int j = 0; j < m; ++j) if (fabs(A[6 * i + j]) > scale) scale = fabs(A[6 * i + j]); }
+    if (!(scale > 0) || !isfinite(scale)) return -1;
+    while (r > 0) {
+        double mu1 = -1, mu0 = -1; int p = 0, q0 = 0, q1 = 0;
+        for (int a = 0; a < r; ++a) {
+            const int i = act[a];
+            if (fabs(A[6 * i + i]) > mu1) { mu1 = fabs(A[6 * i + i]); p = a; }
+            for (int b = a + 1; b < r; ++b) { const int j = act[b]; if (fabs(A[6 * i + j]) > mu0) { mu0 = fabs(A[6 * i + j]); q0 = a; q1 = b; } }
+        }
+        if (!(fmax(mu0, mu1) > 0.0)) return -1;
+        if (mu1 >= 0.6404 * mu0) {
+            const int i = act[p]; const double d = A[6 * i + i];
+            if (d < 0) ++neg;
+            for (int a = 0; a < r; ++a) if (a != p) for (int b = 0; b < r; ++b) if (b != p) A[6 * act[a] + act[b]] -= A[6 * act[a] + i] * A[6 * i + act[b]] / d;
+            act[p] = act[--r];
+        } else {
+            const int i = act[q0], j = act[q1];
+            const double a11 = A[6 * i + i], a12 = A[6 * i + j], a22 = A[6 * j + j], det = a11 * a22 - a12 * a12;     /* < 0 by the choice of the pivot */
+            if (!(det < 0)) return -1;
+            ++neg;
+            for (int a = 0; a < r; ++a) if (a != q0 && a != q1) for (int b = 0; b < r; ++b) if (b != q0 && b != q1) {
+                const double ci = A[6 * act[a] + i], cj = A[6 * act[a] + j], ri = A[6 * i + act[b]], rj = A[6 * j + act[b]];
+                A[6 * act[a] + act[b]] -= (ci * (a22 * ri - a12 * rj) + cj * (-a12 * ri + a11 * rj)) / det;
+            }
+            act[q1] = act[--r];            /* q1 > q0: remove the later one first */
+            act[q0] = act[--r];
+        }
+    }
+    *nneg = neg;
+    return 0;
+}
+#define SW (2 * KL + 1)
+static int kkt_negative_eigenvalues(work_t* w, double Hdd, int* nneg_out) {       /* before band_factor (the band is factorised in place) */
+    const int N = w->N, n = w->n;
+    double* S = w->inS; double* bb = w->inb;
+    for (int i = 0; i < N; ++i) for (int d = -KL; d <= KL; ++d) {
+        const int j = i + d;
+        S[(size_t)SW * i + d + KL] = (j >= 0 && j < N) ? w->AB[(size_t)(KL + KU + i - j) + (size_t)LDAB * j] : 0.0;
+    }
+    memcpy(bb, w->bcol, sizeof(double) * N);
+    double beta = Hdd;
+    int neg = 0;
+    for (int k = n - 2; k >= 0; --k) for (int pass = 0; pass < 2; ++pass) {
+        const int b0 = pass == 0 ? 8 * k + 2 : 8 * k, m = pass == 0 ? 6 : 2, lo = b0 - KL > 0 ? b0 - KL : 0, nb = b0 - lo;
+        double M[36], Mi[36], C[6][KL + 1], X[6][KL + 1];
+        for (int i = 0; i < m; ++i) for (int j = 0; j < m; ++j) { M[6 * i + j] = S[(size_t)SW * (b0 + i) + (j - i) + KL]; Mi[6 * i + j] = M[6 * i + j]; }
+        for (int i = 0; i < m; ++i) { for (int r = 0; r < nb; ++r) { const int d = lo + r - (b0 + i); C[i][r] = d >= -KL ? S[(size_t)SW * (b0 + i) + d + KL] : 0.0; X[i][r] = C[i][r]; } C[i][nb] = bb[b0 + i]; X[i][nb] = bb[b0 + i]; }
+        int ng = 0;
+        if (small_inertia(M, m, &ng) != 0) return -1;
+        neg += ng;
+        /* X = Mi^-1 [C | b]: Gaussian elimination with partial pivoting */
+        for (int c2 = 0; c2 < m; ++c2) {
+            int pv = c2; for (int r = c2 + 1; r < m; ++r) if (fabs(Mi[6 * r + c2]) > fabs(Mi[6 * pv + c2])) pv = r;
+            if (Mi[6 * pv + c2] == 0.0) return -1;
+            if (pv != c2) { for (int j = 0; j < m; ++j) { double t = Mi[6 * pv + j]; Mi[6 * pv + j] = Mi[6 * c2 + j]; Mi[6 * c2 + j] = t; } for (int j = 0; j <= nb; ++j) { double t = X[pv][j]; X[pv][j] = X[c2][j]; X[c2][j] = t; } }
+            const double ip = 1.0 / Mi[6 * c2 + c2];
+            for (int r = 0; r < m; ++r) if (r != c2) {
+                const double f = Mi[6 * r + c2] * ip;
+                if (f == 0.0) continue;
+                for (int j = c2; j < m; ++j) Mi[6 * r + j] -= f * Mi[6 * c2 + j];
+                for (int j = 0; j <= nb; ++j) X[r][j] -= f * X[c2][j];
+            }
+        }
+        for (int i = 0; i < m; ++i) { const double ip = 1.0 / Mi[6 * i + i]; for (int j = 0; j <= nb; ++j) X[i][j] *= ip; }
+        for (int r1 = 0; r1 < nb; ++r1) {
+            for (int r2 = 0; r2 < nb; ++r2) { double a = 0; for (int i = 0; i < m; ++i) a += C[i][r1] * X[i][r2]; S[(size_t)SW * (lo + r1) + (r2 - r1) + KL] -= a; }
+            double a = 0; for (int i = 0; i < m; ++i) a += C[i][r1] * X[i][nb];
+            bb[lo + r1] -= a;
+        }
+        { double a = 0; for (int i = 0; i < m; ++i) a += C[i][nb] * X[i][nb]; beta -= a; }
+    }
+    if (w->c->dt_free) { if (!isfinite(beta) || beta == 0.0) return -1; if (beta < 0) ++neg; }
+    *nneg_out = neg;
+    return 0;
 }
 
 /* bordered solve with the factorised band: [K b; b' Hdd] [z; ddt] = [rhs; -hd]; y2 = K^-1 b is computed when *have_y2 == 0 */
@@ -1484,7 +1571,9 @@ static int solve_one(work_t* w, int warm) {
         for (int ntry = 0; ntry <= 40; ++ntry) {
             ++nfac;
             assemble(w, cc, delta, dc, &Hdd, &hd);
-            int good = band_factor(w) == 0;
+            int inertia_ok = 1;
+            if (g_inertia) { int nneg = -1; inertia_ok = kkt_negative_eigenvalues(w, Hdd, &nneg) == 0 && nneg == 3 * (n - 1); }
+            int good = inertia_ok && band_factor(w) == 0;
             if (good) {
                 int have_y2 = 0;
                 good = border_solve(w, y2, &have_y2, Hdd, hd);
@@ -1521,7 +1610,7 @@ static int solve_one(work_t* w, int warm) {
                 hdz = sp.hdz; dz2 = sp.dz2; dphi = sp.dphi; a_p = sp.a_p; a_d = sp.a_d; dzmax = sp.dzmax;
                 const double clam = sp.clam, nunu = sp.nunu;
                 curv = -hdz + clam - dc * nunu;
-                if (isfinite(curv) && curv >= curv_kappa * dz2) { ok = 1; break; }
+                if (g_inertia ? isfinite(curv) : (isfinite(curv) && curv >= curv_kappa * dz2)) { ok = 1; break; }
             }
             if (g_algo.convex_fallback && !w->convexify) { w->convexify = g_algo.convex_fallback; continue; }
             if (delta == 0.0) delta = w->delta_last == 0.0 ? delta_first : fmax(delta_min, kminus * w->delta_last);
@@ -1716,7 +1805,7 @@ static work_t* work_new(const oracle_config* c) {
     w->lam = (double*)calloc(3 * (n - 1), 8); w->lamn = (double*)calloc(3 * (n - 1), 8);
     w->s = (double*)calloc(4 * n, 8); w->y = (double*)calloc(4 * n, 8); w->ron = (int*)calloc(4 * n, sizeof(int));
     w->pl = (double*)calloc(2 * (n - 1), 8); w->pu = (double*)calloc(2 * (n - 1), 8);
-    w->AB = (double*)calloc((size_t)LDAB * w->N, 8); w->ipiv = (int*)calloc(w->N, sizeof(int));
+    w->AB = (double*)calloc((size_t)LDAB * w->N, 8); w->inS = (double*)calloc((size_t)(2 * KL + 1) * w->N, 8); w->inb = (double*)calloc(w->N, 8); w->ipiv = (int*)calloc(w->N, sizeof(int));
     w->rhs = (double*)calloc(w->N, 8); w->bcol = (double*)calloc(w->N, 8);
     w->dz_u = (double*)calloc(2 * (n - 1), 8); w->dz_x = (double*)calloc(3 * n, 8);
     w->bf = (double*)calloc(10 * (n - 1), 8); w->bf_g = (double*)calloc(12 * (n - 1), 8); w->bf_e = (double*)calloc(4 * (n - 1), 8);
@@ -1736,7 +1825,7 @@ static void work_obst(work_t* w, const oracle_obst* ob) {       /* clearance-row
 }
 static void work_free(work_t* w) {
     free(w->X); free(w->U); free(w->Xt); free(w->Ut); free(w->lam); free(w->lamn); free(w->s); free(w->y); free(w->ron);
-    free(w->pl); free(w->pu); free(w->AB); free(w->ipiv); free(w->rhs); free(w->bcol); free(w->dz_u); free(w->dz_x); free(w->bf); free(w->bf_g); free(w->bf_e);
+    free(w->pl); free(w->pu); free(w->AB); free(w->inS); free(w->inb); free(w->ipiv); free(w->rhs); free(w->bcol); free(w->dz_u); free(w->dz_x); free(w->bf); free(w->bf_g); free(w->bf_e);
     free(w->cent); free(w->oi); free(w->os); free(w->oy); free(w->ost); free(w->ods); free(w->ody); free(w->og); free(w->oax); free(w->oay); free(w->ohk); free(w->oat); free(w->oh3); free(w->oad); free(w->ohd);
     free(w);
 }

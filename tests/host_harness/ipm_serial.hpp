@@ -363,7 +363,7 @@ struct Ipm {
     }
 
     // ---------------------------------------------------------------- backward Riccati sweep
-    // returns false if a stage pivot is (numerically) singular
+    // returns false if a stage pivot is (numerically) singular or the factorisation has the wrong inertia
     MPC_HD bool backward(T delta, T dc, T& dd_out, T nu_out[3]) const {
         const int n = L.n;
         const T d = M.ld(L.D);
@@ -739,7 +739,7 @@ struct Ipm {
             }
             const T tau = t_max(Algo<T>::tau_min, T(1) - mu);
             const T dc = nfix > 0 ? Algo<T>::delta_c * t_pow(mu, Algo<T>::kappa_c) : T(0);
-            // ---- factor/solve with inertia-free regularisation
+            // ---- factor/solve, delta_w raised until the factorisation has Ipopt's inertia
             // first trial delta = 0 unless the previous iteration's delta = 0 attempt failed (then continue from the decayed value)
             T delta = (fail0 && delta_last > T(0)) ? t_max(Algo<T>::delta_min, Algo<T>::kappa_minus * delta_last) : T(0);
             const bool started_zero = delta == T(0);
@@ -752,9 +752,9 @@ struct Ipm {
                 if (good) {
                     fw = forward(dd, nu, tau, dc);
                     good = fw.finite;
-                    if (good) {
+                    if (good) {      // backward() has checked the inertia of this factorisation (mpc_core.hpp::riccati_root); the curvature only feeds the penalty update
                         curv = -fw.hdz + fw.clam - dc * fw.nunu;     // = dz^T (H + delta I) dz
-                        if (curv >= Algo<T>::curv_kappa * fw.dz2) { ok = true; break; }
+                        ok = true; break;
                     }
                 }
                 if (delta == T(0)) delta = (delta_last == T(0)) ? Algo<T>::delta_first : t_max(Algo<T>::delta_min, Algo<T>::kappa_minus * delta_last);

@@ -102,7 +102,7 @@ def test_candidate_rule_on_config2_with_the_c_oracle(c_oracle):
     assert (st == 0).mean() > 0.98 > (allr[0][3] == 0).mean()          # r04: 98.4 % with these two blended hedges (the headline's Hermite set: 99.9 %)
     ref_ok = allr[0][3] == 0
     assert (win[ref_ok] == 0).all() and np.array_equal(x[ref_ok], allr[0][0][ref_ok])
-    assert (it[st == 0] <= 60).all() and (win >= 1).mean() > 0.1
+    assert (it[st == 0] <= 60).all() and (win >= 1).mean() > 0.04          # r04 with the inertia test: the reference path alone solves 92 % within 60 iterations (84 % before), 8 % are answered by a hedge
 
 
 def test_hermite_candidates_are_smooth_curves_between_the_poses():
