@@ -99,16 +99,53 @@ def second_order(ocfg, x0, xf, u_prev, dt_prev, x, u, dt, act_tol: float = 1e-1,
         gi = nlp.inequalities(v)
         return np.array([nlp.objective(v) + lam @ nlp.equalities(v) + (nu @ gi[act] if act.size else 0.0)])
 
+    def grad_l(v):
+        return nlp.numeric_jacobian(lagr, v, fd_step)[0]
+
+    full = {}
+
+    def full_hessian():
+        """the whole Hessian of L in 16 gradient differences: a variable of grid point k meets only variables of k - 1 .. k + 1 (collocation and rate rows) and dt, so
+        variables at the same place of grid points three apart share a difference (z = [u_0 | x_k u_k, k = 1 .. n-2 | free x_{n-1} | dt], se2_nlp.ReferenceNlp.pack)"""
+        if "H" in full:
+            return full["H"]
+        nz = z.size
+        idt = nz - 1 if ocfg.dt_free else -1
+        stage = np.zeros(nz, int); place = np.zeros(nz, int)
+        for i in range(nz):
+            if i == idt: stage[i], place[i] = -10, 0
+            elif i < 2: stage[i], place[i] = 0, 3 + i
+            elif i < 2 + 5 * (n - 2): stage[i], place[i] = (i - 2) // 5 + 1, (i - 2) % 5
+            else: stage[i], place[i] = n - 1, i - (2 + 5 * (n - 2))
+        H = np.zeros((nz, nz))
+        for pl in range(5):
+            for md in range(3):
+                cols = [i for i in range(nz) if i != idt and place[i] == pl and stage[i] % 3 == md]
+                if not cols:
+                    continue
+                e = np.zeros(nz); e[cols] = hess_step
+                d = (grad_l(nlp.plus(z, e)) - grad_l(nlp.plus(z, -e))) / (2 * hess_step)
+                for c in cols:
+                    r = np.nonzero((np.abs(stage - stage[c]) <= 1) & (np.arange(nz) != idt))[0]
+                    H[r, c] = d[r]
+        if idt >= 0:
+            e = np.zeros(nz); e[idt] = hess_step
+            d = (grad_l(nlp.plus(z, e)) - grad_l(nlp.plus(z, -e))) / (2 * hess_step)
+            H[:, idt] = d; H[idt, :] = d
+        full["H"] = 0.5 * (H + H.T)
+        return full["H"]
+
     def reduced(sel):
         M = np.concatenate([Jc, rows[sel | fixed]], axis=0)
         Z = null_space(M, rcond=1e-9)
         if Z.shape[1] == 0:
             return 0, np.inf
-        HZ = np.zeros_like(Z)
-        for i in range(Z.shape[1]):
-            gp = nlp.numeric_jacobian(lagr, nlp.plus(z, hess_step * Z[:, i]), fd_step)[0]
-            gm = nlp.numeric_jacobian(lagr, nlp.plus(z, -hess_step * Z[:, i]), fd_step)[0]
-            HZ[:, i] = (gp - gm) / (2 * hess_step)
+        if Z.shape[1] > 16 and not nlp_kwargs:          # (clearance rows couple nothing new, but keep the plain differences for them)
+            HZ = full_hessian() @ Z
+        else:
+            HZ = np.zeros_like(Z)
+            for i in range(Z.shape[1]):
+                HZ[:, i] = (grad_l(nlp.plus(z, hess_step * Z[:, i])) - grad_l(nlp.plus(z, -hess_step * Z[:, i]))) / (2 * hess_step)
         Hr = Z.T @ HZ
         return Z.shape[1], float(np.linalg.eigvalsh(0.5 * (Hr + Hr.T)).min())
     ds, es = reduced(strong)
@@ -180,3 +217,35 @@ def kkt_many(ocfg, x0, xf, u_prev, dt_prev, x, u, dt, idx, workers: int = 0, obs
                 os.environ[k] = v
     with pool:
         return dict(zip(idx, pool.map(_one, jobs, chunksize=1)))
+
+
+def _one_so(args):
+    ocfg, x0, xf, up, dtp, x, u, dt = args
+    return second_order(ocfg, x0, xf, up, dtp, x, u, dt)
+
+
+def second_order_many(ocfg, x0, xf, u_prev, dt_prev, x, u, dt, idx, workers: int = 0):
+    """second_order for the instances `idx` of a batch (no clearance rows), spread over spawned worker processes like kkt_many"""
+    import multiprocessing as mp
+    import os
+    idx = [int(i) for i in idx]
+    if not idx:
+        return {}
+    jobs = [(ocfg, x0[i], xf[i], u_prev[i], float(dt_prev[i]), x[i], u[i], float(dt[i])) for i in idx]
+    workers = workers or max(1, min(len(jobs), (os.cpu_count() or 2) // 2, 32))
+    if workers == 1 or len(jobs) < 3:
+        return dict(zip(idx, map(_one_so, jobs)))
+    keys = ("OMP_NUM_THREADS", "OPENBLAS_NUM_THREADS", "MKL_NUM_THREADS")
+    saved = {k: os.environ.get(k) for k in keys}
+    try:
+        for k in keys:
+            os.environ[k] = "1"
+        pool = mp.get_context("spawn").Pool(workers)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+    with pool:
+        return dict(zip(idx, pool.map(_one_so, jobs, chunksize=1)))

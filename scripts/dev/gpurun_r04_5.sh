@@ -1,6 +1,3 @@
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/r04
-bash scripts/profile.sh r04_wave_kernel_caps100 carlike_n50_B1024_c4 > gpurun_out/r04/profile_caps100.log 2>&1; cp gpurun_out/profile_summary/bench_under_rocprof.json gpurun_out/r04/bench_under_rocprof_caps100.json
-BENCH_EXTRA="--caps 60,45,40,35" bash scripts/profile.sh r04_wave_kernel_caps60 carlike_n50_B1024_c4_caps60 > gpurun_out/r04/profile_caps60.log 2>&1; cp gpurun_out/profile_summary/bench_under_rocprof.json gpurun_out/r04/bench_under_rocprof_caps60.json
-BENCH_EXTRA="--batch 4096" bash scripts/profile.sh r04_wave_kernel_B4096 carlike_n50_B4096_c4 > gpurun_out/r04/profile_B4096.log 2>&1; cp gpurun_out/profile_summary/bench_under_rocprof.json gpurun_out/r04/bench_under_rocprof_B4096.json
-python scripts/gpu_batch_sweep.py > gpurun_out/r04/batch_sweep_caps60.log 2>&1
-ls gpurun_out/profile_summary; tail -9 gpurun_out/r04/batch_sweep_caps60.log
+timeout 900 python -m pytest tests -m gpu -q -s > gpurun_out/r04/gpu_suite_10.log 2>&1; grep -E "passed|failed|^FAILED|^E   " gpurun_out/r04/gpu_suite_10.log | cut -c1-300 | tail -40
+timeout 600 python bench.py > gpurun_out/r04/bench_10.json 2> gpurun_out/r04/bench_10.err; tail -c 6000 gpurun_out/r04/bench_10.json; tail -5 gpurun_out/r04/bench_10.err

@@ -136,7 +136,7 @@ def test_candidates_full_batch_winners_vs_oracle_rule(m, c_oracle):
     dobj = (n - 1) * (r.dt[sel] - r100.dt[sel])
     print(f"[hedges vs the reference path alone] {int(sel.sum())} instances answered by a hedge although the 100-iteration reference path solves them: objective difference "
           f"median {np.median(dobj):+.3f} s, p10 {np.percentile(dobj, 10):+.3f}, p90 {np.percentile(dobj, 90):+.3f}, max {dobj.max():+.3f}; better {np.mean(dobj < -1e-6):.2f} same {np.mean(np.abs(dobj) < 1e-6):.2f} worse {np.mean(dobj > 1e-6):.2f}")
-    assert sel.sum() >= 50 and np.median(dobj) <= 1e-9 and np.mean(dobj > 1e-6) < 0.15
+    assert sel.sum() >= 30 and np.median(dobj) <= 1e-9 and np.mean(dobj > 1e-6) < 0.15          # r04 with the inertia test: 43 such instances (100 before: the reference path needs fewer iterations)
     _account("config 2 with candidates, B=1024", ocfg, inputs, r, (ox, ou, od, ost, oit))
     s.close()
 
@@ -943,3 +943,29 @@ def test_terminal_cost_with_minimum_time_objective_vs_c_oracle(m, c_oracle):
     assert (r.status == 0).mean() > 0.9 and match.sum() > 0.85 * B
     assert np.abs(r.x[:, -1] - inputs[1]).max(1)[r.status == 0].max() > 0.05      # the terminal cost is live: the final state is not the goal
     s.close()
+
+
+def test_device_answers_are_local_minima(m):
+    """r04: the kernel accepts a factorisation on its inertia (signs of the Riccati sweep's control pivots + the (dt, nu) root system, mpc_core.hpp::riccati_root) -- Ipopt's test.
+    Checked on the device's own answers with nothing of any solver: the reduced Hessian of the Lagrangian of the reference-form NLP on the tangent space of the active rows
+    (oracle/kkt_check.py::second_order, differences of the NLP's functions) has no negative eigenvalue at any of 24 converged answers of the headline workload -- reference
+    path and hedges alike.  (With the inertia-free curvature test of r01-r03 about one converged answer in five was a saddle point:
+    tests/test_oracle_solver.py::test_converged_answers_are_local_minima_and_the_curvature_test_s_were_not.)"""
+    from oracle import kkt_check as KC
+    from mpc_local_planner_amd import _abi as A
+    B, n = 96, 50
+    _, ocfg = _cases(m)["carlike_min_time_n50"]
+    x0, xf, up, dtp = m.workloads.carlike_min_time_inputs(B)
+    s = m.BatchSolver(m.config_carlike_min_time(n, candidates=(A.CAND_REFERENCE, A.CAND_HERMITE_FF, A.CAND_HERMITE_FF, A.CAND_HERMITE_FR), candidate_max_iter=(100, 45, 40, 35),
+                                                candidate_param=(0.0, 2.0, 3.0, 1.5)), max_batch=B)
+    r = s.solve(x0, xf, up, dtp)
+    win, _ = s.last_candidates(B)
+    s.close()
+    ok = np.nonzero(r.status == 0)[0]
+    hedged = [i for i in ok if win[i] > 0][:6]
+    pick = sorted(set(hedged) | set(ok[:24 - len(hedged)].tolist()))
+    so = KC.second_order_many(ocfg, x0, xf, up, dtp, r.x, r.u, r.dt, pick)
+    eig = np.array([so[i]["min_eig_s"] for i in pick])
+    print(f"[second-order check of device answers] {len(pick)} converged answers ({len(hedged)} supplied by a hedge): tangent-space dimensions {sorted(so[i]['dim_s'] for i in pick)}, "
+          f"smallest eigenvalue of the reduced Hessian {np.min(eig):.2e} (vertices of the active set count as +inf), weakly active rows {max(so[i]['n_weak'] for i in pick)}")
+    assert len(pick) >= 20 and (eig > -1e-6).all()

@@ -8,6 +8,7 @@ from scipy.optimize import minimize
 
 from oracle import se2_nlp as R
 from oracle import ipm_dense as I
+from oracle import kkt_check as K
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 OCFG = {
@@ -762,3 +763,33 @@ def test_stage_structured_quasi_newton_hessian_experiment(c_oracle):
     both = (a[3] == 0) & (b[3] == 0)
     same = np.abs(a[0] - b[0]).reshape(B, -1).max(1)[both] < 1e-2
     assert same.mean() > 0.5
+
+
+def test_converged_answers_are_local_minima_and_the_curvature_test_s_were_not(c_oracle):
+    """r04: what `converged` means.  oracle/kkt_check.py::second_order measures, with differences of the reference-form NLP's functions only, the smallest eigenvalue of the
+    Lagrangian's Hessian on the tangent space of the active rows of a KKT point.  With the inertia-free curvature test of r01-r03 (oracle_set_algo(9, 0)) the Newton iteration
+    converges to SADDLE points -- a feasible direction of negative curvature, verified by moving along it in DESIGN section 3.2 -- for about one converged config-2 answer in
+    five; with Ipopt's inertia test (the algorithm since r04: delta_w is raised until the KKT matrix has n positive and m negative eigenvalues) every converged answer of the
+    sample is a minimum, in fewer iterations."""
+    import ctypes as C
+    import mpc_local_planner_amd.workloads as W
+    B, n = 10, 50
+    ocfg = R.config_carlike_min_time(n)
+    pick = [0, 4, 11, 15, 24, 30, 1, 2, 3, 5]          # of the 96-instance draw: six of the 17 saddle points the curvature test returns there, four others
+    x0, xf, up, dtp = (a[pick] for a in W.carlike_min_time_inputs(96))
+    lib = c_oracle._load()
+    out = {}
+    for mode in (0, 1):
+        lib.oracle_set_algo(C.c_int(9), C.c_double(mode))
+        try:
+            x, u, dt, st, it = c_oracle.solve_batch(c_oracle.from_nlp_config(ocfg), x0, xf, up, dtp)
+        finally:
+            lib.oracle_set_algo(C.c_int(9), C.c_double(1))
+        so = K.second_order_many(ocfg, x0, xf, up, dtp, x, u, dt, np.nonzero(st == 0)[0])
+        eig = np.array([r["min_eig_s"] for r in so.values()])
+        out[mode] = (int((st == 0).sum()), float(it.mean()), eig, [r["n_weak"] for r in so.values()])
+        print(f"inertia test {mode}: converged {out[mode][0]} / {B}, mean iterations {out[mode][1]:.1f}, smallest reduced-Hessian eigenvalues {np.sort(eig)[:5].round(4).tolist()}, "
+              f"saddle points {(eig < -1e-6).sum()}")
+    assert (out[0][2] < -1e-3).sum() >= 2                     # the curvature test's answers: saddle points among them
+    assert (out[1][2] > -1e-6).all() and max(out[1][3]) == 0   # the inertia test's: minima (no weakly active row blurs the statement)
+    assert out[1][0] >= out[0][0] and out[1][1] < out[0][1]
