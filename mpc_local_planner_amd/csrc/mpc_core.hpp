@@ -723,7 +723,8 @@ MPC_HD void riccati_terminal(RicState<T>& V, const Problem<T>& P_, const T xd_f[
 }
 
 template <typename T>
-MPC_HD bool riccati_root(const RicState<T>& V, const Problem<T>& P_, T& dd_out, T nu_out[3]) {
+// returns 1: solved, the factorisation has the right inertia; -1: wrong inertia (the caller raises delta_w); 0: a pivot broke down / non-finite values
+MPC_HD int riccati_root(const RicState<T>& V, const Problem<T>& P_, T& dd_out, T nu_out[3]) {
     T A4[4][5];
     for (int a = 0; a < 4; ++a) for (int b = 0; b < 5; ++b) A4[a][b] = T(0);
     if (P_.dt_free) {
@@ -768,7 +769,8 @@ MPC_HD bool riccati_root(const RicState<T>& V, const Problem<T>& P_, T& dd_out, 
             }
         }
         for (int a = 0; a < 3; ++a) want += P_.xf_fixed[a] ? 1 : 0;
-        if (!okp || neg != want) return false;
+        if (!okp) return 0;
+        if (neg != want) return -1;
     }
     // Gaussian elimination with partial pivoting, written with compile-time indices only: the pivot row is brought up by
     // compare-and-swap selects (a run-time row index would put the 4x5 tableau into scratch memory on the GPU).
@@ -793,7 +795,7 @@ MPC_HD bool riccati_root(const RicState<T>& V, const Problem<T>& P_, T& dd_out, 
             for (int b = c; b < 5; ++b) A4[r][b] -= m * A4[c][b];
         }
     }
-    if (!ok) return false;
+    if (!ok) return 0;
     T sol[4];
 #pragma unroll
     for (int c = 3; c >= 0; --c) {
@@ -804,7 +806,7 @@ MPC_HD bool riccati_root(const RicState<T>& V, const Problem<T>& P_, T& dd_out, 
     }
     dd_out = sol[0];
     nu_out[0] = sol[1]; nu_out[1] = sol[2]; nu_out[2] = sol[3];
-    return t_finite(sol[0]) && t_finite(sol[1]) && t_finite(sol[2]) && t_finite(sol[3]);
+    return (t_finite(sol[0]) && t_finite(sol[1]) && t_finite(sol[2]) && t_finite(sol[3])) ? 1 : 0;
 }
 
 // rate-row slot helpers: q in 0..3 -> component j, sign sg

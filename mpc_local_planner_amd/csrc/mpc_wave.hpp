@@ -1478,7 +1478,7 @@ struct IpmWave {
 #endif
 #ifdef MPC_NANCHECK
         {
-            const bool okr = riccati_root(Vr, P, dd_out, nu_out);
+            const bool okr = riccati_root(Vr, P, dd_out, nu_out) > 0;
             if (blockIdx.x == MPC_NANCHECK && lane == 0)
                 printf("  root: ok %d worst %g P55 %g p5 %g S5 %g %g %g om %g %g %g W %g %g %g %g %g %g\n", (int)okr, (double)rd_lane(worst, 0), (double)Vr.P[5][5], (double)Vr.p[5],
                        (double)Vr.S[5][0], (double)Vr.S[5][1], (double)Vr.S[5][2], (double)Vr.om[0], (double)Vr.om[1], (double)Vr.om[2],
@@ -1486,7 +1486,7 @@ struct IpmWave {
             return okr;
         }
 #endif
-        return riccati_root(Vr, P, dd_out, nu_out);
+        return riccati_root(Vr, P, dd_out, nu_out) > 0;
     }
 
     // inclusive suffix sum over the wave (lane i gets sum_{j >= i} v_j): Hillis-Steele inside each 16-lane row with DPP row
@@ -1728,20 +1728,86 @@ struct IpmWave {
     // are part of the condition, not a consequence of the grid-size threshold.  Second invariant: a saved tile overwrites the trig cache, which
     // kkt_pass reads -- every path from a factorisation to the next kkt_pass rewrites TRIG for all k < n - 1 (eval_point / trial_eval of the accepted trial;
     // the solve ends without another kkt_pass when no trial is evaluated).
-    // r04: NOT used by the solve.  A factorisation is accepted on its INERTIA (riccati_root), which the serial sweep carries in the signs of its control pivots R_k; the
-    // segments of the partitioned sweep start from the identity border, their pivots are those of the segment's own cost-to-go, and the inertia of the whole would need the
-    // inertias of the three 12 x 12 combine blocks [[W_s, -I], [-I, P+]] on top (two symmetric 6 x 6 eliminations per combine, P+ structurally singular in the position rows).
-    // Until the combine carries that count the partitioned sweeps stay compiled out (kPartitionedSweeps); tests/test_pit_math.py keeps their algebra checked.
-    static constexpr bool kPartitionedSweeps = false;
+    // r04, inertia: a factorisation is accepted when the KKT matrix has Ipopt's inertia (riccati_root).  The serial sweep reads it off the signs of its control pivots R_k.  Here
+    // every row counts the negative eigenvalues of the pivots of ITS segment (those of the segment's own cost-to-go from the identity border, not the serial ones), and
+    // every combine eliminates the pair (costate, state) at a boundary: the block [[W, -I], [-I, P+]] over the five components that have a costate column has the inertia
+    // In(W) + In(P+ - W^-1) (Haynsworth), five negative eigenvalues when all is well -- pit_block_inertia() returns the excess.  The sum of all of it plus the root system's
+    // count is the matrix's, whatever the elimination order (Sylvester); tests/test_pit_math.py::test_inertia_of_the_kkt_matrix_from_the_sweeps holds both counts to the
+    // eigenvalues of the dense matrix, including the cases where a negative pivot in one place is made up for in another.
+    // Kernels WITH clearance-row code take the serial sweeps (r04, measured on the MI355X with the inertia test in both: car-like minimum time against point obstacles, line /
+    // polygon / two-circle footprints, 192 instances -- serial sweeps 179 / 163 / 175 converged, each of them at the C oracle's trajectory (oracle: 180 / 163 / 175);
+    // partitioned sweeps 172 / 147 / 163, the converged ones still at the oracle's trajectory: rows that are active late in a solve put 1e8-sized entries into the
+    // position block of the value functions and the combines' I - W P+ loses the last digits the end game needs).
+    static constexpr bool kPartitionedSweeps = !OBST;
     __device__ __forceinline__ bool pit_enabled() const { return kPartitionedSweeps && EXT < 2 && P.pit != 0 && L.n >= 40 && 3 * L.NS >= 100 && L.NTR * L.NS >= 100 && 5 * L.NS >= 192; }
     // lane index that the optimiser must treat as unknown HERE: keeps the per-lane address arithmetic of a phase inside the phase (hoisted out of the
     // interior-point loop as loop invariants it would occupy registers for the whole solve)
     __device__ __forceinline__ int local_lane() const { int l = lane; asm volatile("" : "+v"(l)); return l; }
+    // excess of negative eigenvalues of a combine's pivot block: n-(W) + n-(P+ - W^-1) - 5, by Jacobi's signature rule (negative pivots of the elimination without exchanges).
+    // W (the element's, 5 x 5, in the hand-off tile) is swept in place -- the symmetric sweep operator leaves -W^-1 and shows the same pivots as the elimination --, then
+    // G = P+ + (-W^-1) is eliminated.  Wave-uniform arithmetic on values read with uniform LDS addresses / v_readlane: ~330 instructions per combine against the ~4 k a
+    // partitioned factorisation saves.  ok = false when a pivot vanishes (the caller then repeats the factorisation with the serial sweep).
+    template <bool LP_A>
+    __device__ __forceinline__ int pit_block_inertia(const int TB, const T (&Vp)[6], bool& ok) const {
+        const int TW = TB + 96;
+        T w[5][5], g[5][5];
+        T scl = T(0);
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+#pragma unroll
+            for (int b = a; b < 5; ++b) {
+                const T x = T(0.5) * (T(sm[TW + 16 * a + 9 + b]) + T(sm[TW + 16 * b + 9 + a]));
+                w[a][b] = x; w[b][a] = x; scl = t_max(scl, t_abs(x));
+                const T y = T(0.5) * (rd_lane(Vp[a], LP_A ? b : (b < 2 ? 6 + b : 10 + b)) + rd_lane(Vp[b], LP_A ? a : (a < 2 ? 6 + a : 10 + a)));
+                g[a][b] = y; g[b][a] = y;
+            }
+        int neg = -5;
+        bool okp = t_finite(scl) && scl > T(0);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {                 // sweep on pivot k: afterwards w = -(W^-1) restricted appropriately; the pivot is the Schur complement's diagonal
+            const T d = w[k][k];
+            okp = okp && (t_abs(d) > T(1e-13) * scl);
+            neg += d < T(0) ? 1 : 0;
+            const T id = t_rcp(d);
+            T col[5];
+#pragma unroll
+            for (int i = 0; i < 5; ++i) col[i] = w[i][k];
+#pragma unroll
+            for (int i = 0; i < 5; ++i)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) if (i != k && j != k) w[i][j] -= col[i] * col[j] * id;
+#pragma unroll
+            for (int i = 0; i < 5; ++i) if (i != k) { w[i][k] = col[i] * id; w[k][i] = col[i] * id; }
+            w[k][k] = -id;
+        }
+        T gs = T(0);
+#pragma unroll
+        for (int a = 0; a < 5; ++a)
+#pragma unroll
+            for (int b = 0; b < 5; ++b) { g[a][b] += w[a][b]; gs = t_max(gs, t_abs(g[a][b])); }
+        okp = okp && t_finite(gs) && gs > T(0);
+#pragma unroll
+        for (int k = 0; k < 5; ++k) {
+            const T d = g[k][k];
+            okp = okp && (t_abs(d) > T(1e-13) * gs);
+            neg += d < T(0) ? 1 : 0;
+            const T id = t_rcp(d);
+#pragma unroll
+            for (int i = k + 1; i < 5; ++i) {
+                const T m = g[i][k] * id;
+#pragma unroll
+                for (int j = i; j < 5; ++j) { g[i][j] -= m * g[k][j]; g[j][i] = g[i][j]; }
+            }
+        }
+        ok = ok && okp;
+        return neg;
+    }
     // one combine step.  LP_A: the value function's P+ columns sit in lane set A (then the result's sit in B), else the other way round.
     // In: Vp / Wp / omp = value function at the segment's end, the element's tile in LDS at TB.  Out: the same registers = value function at the
     // segment's start; the eliminated tile and the old value function go to `save` for the forward pass; wpiv = min |pivot| so far.
     template <bool LP_A>
-    __device__ __forceinline__ void combine(const int TB, const int save, const CombLane& cl, const int lm, T (&Vp)[6], T (&Wp)[3], T& omp, T& wpiv) const {
+    __device__ __forceinline__ void combine(const int TB, const int save, const CombLane& cl, const int lm, T (&Vp)[6], T (&Wp)[3], T& omp, T& wpiv, int& inert, bool& iok) const {
+        inert += pit_block_inertia<LP_A>(TB, Vp, iok);        // first: nothing of the combine is live yet
         const int TW = TB + 96;
         T Wt[5], WV[5], A[6], U[6], St[6], Ra[6];
 #pragma unroll
@@ -1773,7 +1839,7 @@ struct IpmWave {
 #else
 #define PIT_DBG_W(tag)
 #endif
-    __device__ __forceinline__ bool backward_pit(T delta, T dc, T& dd_out, T nu_out[3]) const {
+    __device__ __forceinline__ int backward_pit(T delta, T dc, T& dd_out, T nu_out[3]) const {
         const int n = L.n, N = n - 1, Lm = N >> 2, rem = N - 4 * Lm;
         const T d = SCL(SC_D);
         const int ZC = L.ZC;
@@ -1824,6 +1890,7 @@ struct IpmWave {
         const T s05 = row == 0 ? (c == 5 ? add_dd0 : (c == 8 ? add_qd0 : T(0))) : T(0);
         const T dL0 = row == 0 ? T(0) : dA0, dL1 = row == 0 ? T(0) : dA1, dL2 = row == 0 ? T(0) : dA2;
         T worst = T(1);
+        int negc = 0, negc_rem = 0;                                       // negative eigenvalues of the control pivots: this row's segment / the leftover stages all rows sweep together
         auto load_stage = [&](T (&g)[3], T (&a)[8]) {
             g[0] = gp[0]; g[1] = gp[1]; g[2] = gp[2];
             gp -= gs;
@@ -1845,6 +1912,7 @@ struct IpmWave {
             const T r2 = R01 * R01;
             const T det = R00 * R11 - r2;
             worst = t_fmin(worst, t_abs(det) - T(1e-14) * (t_abs(R00 * R11) + r2));
+            { const int s0 = sign_word(R00), s1 = sign_word(det); negc += (int)((unsigned)s0 >> 31) + (int)((unsigned)(s0 ^ s1) >> 31); }
             const T nid = -fast_rcp(det);
             const T nRi00 = R11 * nid, Ri01 = -(R01 * nid), nRi11 = R00 * nid;
             const T nK0 = nRi00 * h[6] + Ri01 * h[7], nK1 = Ri01 * h[6] + nRi11 * h[7];
@@ -1865,6 +1933,7 @@ struct IpmWave {
             if (rem > 1) stage(dA0, dA1, dA2, T(0), Gb, Ab, Ga, Aa);
             if (rem > 2) stage(dA0, dA1, dA2, T(0), Ga, Aa, Gb, Ab);
         }
+        negc_rem = negc; negc = 0;
         // ---- rows 0..2 start their segments from the identity border
         if (row < 3) {
 #pragma unroll
@@ -1891,7 +1960,7 @@ struct IpmWave {
         else stage(dL0, dL1, dL2, s05, Ga, Aa, Gb, Ab);
         {
             const T w4 = t_fmin(t_fmin(rd_lane(worst, 0), rd_lane(worst, 16)), t_fmin(rd_lane(worst, 32), rd_lane(worst, 48)));
-            if (!(w4 > T(0))) return false;
+            if (!(w4 > T(0))) return 0;
         }
 #ifdef MPC_PROFILE
         const long long tp1 = __builtin_readcyclecounter();
@@ -1913,6 +1982,8 @@ struct IpmWave {
             sync();
         };
         T Vp[6], Wp[3], omp, wpiv = T(1);
+        int inert = __builtin_amdgcn_readlane(negc_rem, 0) + __builtin_amdgcn_readlane(negc, 0) + __builtin_amdgcn_readlane(negc, 16) + __builtin_amdgcn_readlane(negc, 32) + __builtin_amdgcn_readlane(negc, 48);
+        bool iok = true;
 #ifdef MPC_ASM_MARK
         asm volatile("; PIT_COMBINE_BEGIN");
 #endif
@@ -1928,13 +1999,13 @@ struct IpmWave {
         PIT_DBG_W("V3")
         const int lm = c < 6 ? c : 0;
         put_tile(2);
-        combine<true>(TB, pit_tile(2), comb_lane(c, true, TB), lm, Vp, Wp, omp, wpiv);      // (the per-lane constants are recomputed per step: cheaper than keeping them)
+        combine<true>(TB, pit_tile(2), comb_lane(c, true, TB), lm, Vp, Wp, omp, wpiv, inert, iok);      // (the per-lane constants are recomputed per step: cheaper than keeping them)
         PIT_DBG_W("V2")
         put_tile(1);
-        combine<false>(TB, pit_tile(1), comb_lane(c, false, TB), lm, Vp, Wp, omp, wpiv);
+        combine<false>(TB, pit_tile(1), comb_lane(c, false, TB), lm, Vp, Wp, omp, wpiv, inert, iok);
         PIT_DBG_W("V1")
         put_tile(0);
-        combine<true>(TB, pit_tile(0), comb_lane(c, true, TB), lm, Vp, Wp, omp, wpiv);
+        combine<true>(TB, pit_tile(0), comb_lane(c, true, TB), lm, Vp, Wp, omp, wpiv, inert, iok);
         PIT_DBG_W("V0")
 #ifdef MPC_ASM_MARK
         asm volatile("; PIT_COMBINE_END");
@@ -1942,10 +2013,10 @@ struct IpmWave {
 #ifdef MPC_PROFILE
         prof_setup += __builtin_readcyclecounter() - tp1;
 #endif
-        if (!(rd_lane(wpiv, 0) > T(1e-9))) return false;                   // a pivot of I - W P+ broke down: the caller repeats this factorisation with the serial sweep
+        if (!(rd_lane(wpiv, 0) > T(1e-9)) || !iok) return 0;           // a pivot of I - W P+ (or of the inertia count) broke down: the caller repeats this factorisation with the serial sweep
         // ---- root: the value function at stage 0 has its P columns in lane set B (lane 15 = column 5)
         RicState<T> Vr;
-        Vr.neg = 0;                                                        // (the segments' pivots do not carry the inertia of the whole: see kPartitionedSweeps)
+        Vr.neg = inert;                                                    // segments' control pivots + the excess of the three combine blocks (pit_block_inertia)
         Vr.P[5][5] = rd_lane(Vp[5], 15);
         Vr.p[5] = rd_lane(Vp[5], 8);
         Vr.S[5][0] = rd_lane(Vp[5], 9); Vr.S[5][1] = rd_lane(Vp[5], 10); Vr.S[5][2] = rd_lane(Vp[5], 11);
@@ -1965,7 +2036,7 @@ struct IpmWave {
                    (double)Vr.S[5][0], (double)Vr.S[5][1], (double)Vr.S[5][2], (double)Vr.om[0], (double)Vr.om[1], (double)Vr.om[2],
                    (double)Vr.W[0][0], (double)Vr.W[0][1], (double)Vr.W[0][2], (double)Vr.W[1][1], (double)Vr.W[1][2], (double)Vr.W[2][2]);
 #endif
-        return riccati_root(Vr, P, dd_out, nu_out);
+        return riccati_root(Vr, P, dd_out, nu_out);       // 1 good, -1 wrong inertia (no point in repeating the sweep), 0 breakdown
     }
 
     __device__ __forceinline__ void forward_pit(T dd, const T nu[3], T delta) const {
@@ -2609,7 +2680,8 @@ struct IpmWave {
 #ifdef MPC_PIT_CHECK     // developer aid: both sweeps on the same factorisation; blocks below MPC_PIT_CHECK report every factorisation on which the two differ
                 if (pit && (int)blockIdx.x < MPC_PIT_CHECK) {
                     T dd1 = T(0), nu1[3] = {T(0), T(0), T(0)}, dd2 = T(0), nu2[3] = {T(0), T(0), T(0)};
-                    const bool g1 = backward_pit(delta, dc, dd1, nu1); sync();
+                    const int g1c = backward_pit(delta, dc, dd1, nu1); sync();
+                    const bool g1 = g1c > 0;
                     if (g1) { forward_pit(dd1, nu1, delta); sync(); }
                     T keepx = T(0), keepu = T(0), keepl = T(0);
                     const int kk = lane < L.n - 1 ? lane : 0;
@@ -2620,17 +2692,18 @@ struct IpmWave {
                     const T ex = wave_max(t_abs(keepx - F(L.DX, 2, kk))), eu = wave_max(t_abs(keepu - F(L.DU, 1, kk))), el = wave_max(t_abs(keepl - F(L.LAMN, 2, kk)));
                     const T sx = wave_max(t_abs(F(L.DX, 2, kk))), su = wave_max(t_abs(F(L.DU, 1, kk))), sl = wave_max(t_abs(F(L.LAMN, 2, kk)));
                     if (lane == 0 && (g1 != g2 || ex > T(1e-7) * (sx + T(1e-3)) || eu > T(1e-7) * (su + T(1e-3)) || el > T(1e-7) * (sl + T(1e-3))))
-                        printf("blk %d it %d try %d delta %.2e mu %.1e: pit ok %d serial ok %d | dd %.9e vs %.9e | max diff dx %.2e (of %.2e) du %.2e (of %.2e) lam %.2e (of %.2e)\n", (int)blockIdx.x, it, ntry, (double)delta, (double)mu,
-                               (int)g1, (int)g2, (double)dd1, (double)dd2, (double)ex, (double)sx, (double)eu, (double)su, (double)el, (double)sl);
+                        printf("blk %d it %d try %d delta %.2e mu %.1e: pit ok %d (code %d) serial ok %d | dd %.9e vs %.9e | max diff dx %.2e (of %.2e) du %.2e (of %.2e) lam %.2e (of %.2e)\n", (int)blockIdx.x, it, ntry, (double)delta, (double)mu,
+                               (int)g1, g1c, (int)g2, (double)dd1, (double)dd2, (double)ex, (double)sx, (double)eu, (double)su, (double)el, (double)sl);
                     sync();
                 }
 #endif
                 if (pit && mu > P.pit_mu_min) {        // partitioned sweep; a broken-down combine pivot (or a singular stage pivot) falls back to the serial sweep.  (Measured r04: with the
                                                        // partitioned sweeps also AT mu = tol -- the first barrier problem of the adaptive rule's end game -- the EXT kernels with clearance rows converge
                                                        // for 10 % fewer instances than the C oracle: the end game needs the serial sweeps' accuracy from mu = tol on)
-                    MPC_TICK(2, good = backward_pit(delta, dc, dd, nu); sync());
-                    used_pit = good;
-                    if (!good) { MPC_TICK(2, good = backward_dpp(delta, dc, dd, nu); sync()); }
+                    int gp_;
+                    MPC_TICK(2, gp_ = backward_pit(delta, dc, dd, nu); sync());
+                    good = used_pit = gp_ > 0;
+                    if (gp_ == 0) { MPC_TICK(2, good = backward_dpp(delta, dc, dd, nu); sync()); }
                 } else { MPC_TICK(2, good = backward_dpp(delta, dc, dd, nu); sync()); }
 #ifdef MPC_PROFILE
                 ++nfac;

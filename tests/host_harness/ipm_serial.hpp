@@ -427,7 +427,7 @@ struct Ipm {
             M.st(gb + 12, g.kap[0]); M.st(gb + 13, g.kap[1]);
             for (int a = 0; a < 2; ++a) for (int b = 0; b < 3; ++b) M.st(gb + 14 + 3 * a + b, g.Kn[a][b]);
         }
-        return riccati_root(V, P, dd_out, nu_out);
+        return riccati_root(V, P, dd_out, nu_out) > 0;
     }
 
     // condensed barrier terms of the rate rows of index r (lim = 0 for r = 0: dt_prev is a constant there)

@@ -41,7 +41,7 @@ def random_lq(rng, N, nfix=3, convex=True):
     return st, (PN, pN, SN, WN, omN)
 
 
-def dense_solve(st, term):
+def dense_solve(st, term, want_kkt=False):
     """variables: xi_0[5] (= ddt; the other five components of xi_0 are fixed to 0), u_0, xi_1, u_1, ..., xi_N, then lam_1..lam_N (dynamics), nu"""
     N = len(st); PN, pN, SN, WN, omN = term; m = SN.shape[1]
     nz = 1 + 2 * N + 6 * N; ne = 6 * N + m
@@ -74,6 +74,8 @@ def dense_solve(st, term):
         K[nz + 6 * N + j, xs] = SN[:, j]; K[xs, nz + 6 * N + j] = SN[:, j]
         K[nz + 6 * N + j, nz + 6 * N + j] = WN[j, j]
         r[nz + 6 * N + j] = -omN[j]
+    if want_kkt:
+        return K, nz, ne
     sol = np.linalg.solve(K, r)
     xi = np.zeros((N + 1, 6)); xi[0, 5] = sol[0]
     for k in range(1, N + 1):
@@ -167,3 +169,84 @@ def test_partitioned_sweep_equals_serial_sweep_equals_dense_solve(N, convex):
         xs, us = forward(st[b[s]:b[s + 1]], seg[s][1], xb[s], nu2 if s == 3 else lam[s + 1])
         xi_p[b[s]:b[s + 1] + 1] = xs; u_p[b[s]:b[s + 1]] = us
     assert np.abs(xi_p - xi_d).max() < 1e-7 * scale and np.abs(u_p - u_d).max() < 1e-7 * scale
+
+
+# ---------------------------------------------------------------- inertia (r04)
+def neg_pivots(A):
+    """negative eigenvalues of a symmetric matrix by Jacobi's signature rule: the negative pivots of the elimination without exchanges (None when a pivot vanishes)"""
+    A = np.array(A, float); n = A.shape[0]; neg = 0
+    scale = np.abs(A).max()
+    for c in range(n):
+        pv = A[c, c]
+        if not abs(pv) > 1e-13 * scale:
+            return None
+        neg += pv < 0
+        A[c + 1:, c:] -= np.outer(A[c + 1:, c] / pv, A[c, c:])
+    return neg
+
+
+def backward_neg(st, V):
+    """backward() + the negative eigenvalues of the control pivots R_k it eliminates"""
+    P, p, S, W, om = [a.copy() for a in V]
+    neg = 0
+    for (F, c, H, h) in reversed(st):
+        Hh = H + F.T @ P @ F
+        Sh = F.T @ S
+        R = Hh[6:, 6:]
+        det = R[0, 0] * R[1, 1] - R[0, 1] ** 2
+        neg += 1 if det < 0 else (2 if R[0, 0] < 0 else 0)
+        Ri = np.linalg.inv(R)
+        K, Kn = Ri @ Hh[6:, :6], Ri @ Sh[6:]
+        P = Hh[:6, :6] - Hh[:6, 6:] @ K
+        S = Sh[:6] - Hh[:6, 6:] @ Kn
+        W = W - Sh[6:].T @ Kn
+    return (P, p, S, W, om), neg
+
+
+def root_neg(V, m):
+    P, p, S, W, om = V
+    A = np.zeros((1 + m, 1 + m))
+    A[1:, 1:] = W; A[0, 0] = P[5, 5]; A[0, 1:] = S[5]; A[1:, 0] = S[5]
+    order = list(range(1, 1 + m)) + [0]                      # nu first, then dt (mpc_core.hpp::riccati_root)
+    return neg_pivots(A[np.ix_(order, order)])
+
+
+@pytest.mark.parametrize("N,seed", [(49, 1), (49, 2), (49, 3), (30, 4), (119, 5), (12, 6), (49, 7), (49, 8)])
+def test_inertia_of_the_kkt_matrix_from_the_sweeps(N, seed):
+    """Ipopt accepts a factorisation when the KKT matrix has one negative eigenvalue per equality row.  SERIAL sweep: the count is the sum over the stages of the negative
+    eigenvalues of the control pivots R_k plus those of the (dt, nu) root system (every eliminated pair (xi_{k+1}, lambda_k) contributes six positive and six negative
+    ones whatever the curvature; Haynsworth's inertia additivity) -- what mpc_core.hpp::riccati_step / riccati_root count.  PARTITIONED sweep: a mid-segment's pivots are those of
+    its own cost-to-go from the identity border, and every combine eliminates the pair (lambda_b, xi_b) at a boundary: the block [[W, -I], [-I, P+]] over the five components
+    that have a costate column (the dt component passes through) has the inertia In(W) + In(P+ - W^-1).  Both counts equal the dense matrix's on random LQ problems, convex and
+    not (where the count is wrong both say by how much)."""
+    rng = np.random.default_rng(100 + seed)
+    st, term = random_lq(rng, N, convex=False)
+    # more or less curvature removed: from the right inertia to several negative directions
+    shift = [0.0, 0.3, 0.8, 1.5, 0.0, 0.5, 2.5, 0.1][seed - 1]
+    st = [(F, c, H - shift * np.diag([0, 0, 1, 0, 0, 0, 1, 1.0]), h) for (F, c, H, h) in st]
+    K, nz, ne = dense_solve(st, term, want_kkt=True)
+    ev = np.linalg.eigvalsh(K)
+    dense_extra = int((ev < 0).sum()) - ne                  # negative eigenvalues beyond the one per equality row
+    assert np.abs(ev).min() > 1e-10
+    # serial
+    V0, neg = backward_neg(st, term)
+    serial_extra = neg + root_neg(V0, 3) - 3
+    assert serial_extra == dense_extra
+    # partitioned
+    b = [0] + [round(N * s / 4) for s in (1, 2, 3)] + [N]
+    I6 = (np.zeros((6, 6)), np.zeros(6), np.eye(6), np.zeros((6, 6)), np.zeros(6))
+    seg = [backward_neg(st[b[s]:b[s + 1]], term if s == 3 else I6) for s in range(4)]
+    total = sum(sg[1] for sg in seg)
+    V = seg[3][0]
+    for s in (2, 1, 0):
+        W5, P5 = seg[s][0][3][:5, :5], V[0][:5, :5]
+        nw, ng = neg_pivots(W5), neg_pivots(P5 - np.linalg.inv(W5))
+        assert nw is not None and ng is not None
+        total += nw + ng - 5
+        V, _ = combine(seg[s][0], V)
+    pit_extra = total + root_neg(V, 3) - 3
+    assert pit_extra == dense_extra
+    if seed == 1:
+        assert dense_extra == 0
+    if seed in (3, 4, 7):
+        assert dense_extra > 0
