@@ -79,7 +79,7 @@ enum mpc_candidate_kind {
 enum mpc_cost_integration { MPC_COST_LEFT_SUM = 0, MPC_COST_TRAPEZOIDAL = 1 };
 
 enum mpc_hessian_mode {
-    MPC_HESSIAN_EXACT = 0,            /* exact Lagrangian Hessian (analytic) + inertia-free regularisation: the default */
+    MPC_HESSIAN_EXACT = 0,            /* exact Lagrangian Hessian (analytic), delta_w raised until the factorisation has the inertia (n, m, 0) (Ipopt's test): the default */
     MPC_HESSIAN_CONVEXIFIED = 1       /* every stage block of the constraint curvature lam' D over (theta, v, w, dt) replaced by its positive semidefinite
                                        * part: hardly any regularisation retries (1.03 instead of 1.2 factorisations per iteration) but linear instead of
                                        * quadratic local convergence.  With tol = 1e-4 this is the "reference-like" setting: the car-like example runs

@@ -871,7 +871,7 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
         Hc = W + np.diag(SigZ) + Jg.T @ (SigS[:, None] * Jg)
         rhs1 = -(gphi + Jg.T @ ybar)
         rhs = np.concatenate([rhs1, -c])
-        # regularisation loop with inertia-free curvature test
+        # regularisation loop: delta_w until the test of the factorisation holds (opt.inertia_test)
         # first trial: delta = 0, unless the previous iteration's delta = 0 attempt already failed (then continue from the
         # decayed previous regularisation; it decays by kappa_minus per iteration, so it fades out on its own)
         delta = 0.0

@@ -1325,7 +1325,7 @@ int oracle_nfac_max(void) { return g_nfac_max; }
  * matrix is sigma I + a rank-2m term that couples all stages.  Secant pair of element k after an accepted step: s = e_k+ - e_k,  y = grad_e (lam+' D_k)(e_k+) - grad_e (lam+' D_k)(e_k)
  * (both gradients with the NEW multipliers).  B_k starts at 0: the first factorisations are regularised by delta_w like any singular Hessian.  The true element Hessian
  * [H_qq H_qd; H_qd' 0] is indefinite whenever H_qd != 0, so a positive semidefinite BFGS block cannot approach it (measured: 32 % of config 2 converge); symmetric rank-one
- * updates can (89 %), and the curvature test + delta_w treat the indefinite blocks as they treat the exact Hessian. */
+ * updates can (89 % under the curvature test of r01-r03; under the inertia test their factorisations drown in delta_w: 15 %), and delta_w treats the indefinite blocks as it treats the exact Hessian. */
 static void bfgs_update(work_t* w) {
     const oracle_config* c = w->c;
     const int n = w->n;
