@@ -101,7 +101,8 @@ enum mpc_status {                     /* per-instance result; 0 == what corbo re
     MPC_MAX_ITER = 1,
     MPC_LINESEARCH_FAILED = 2,
     MPC_LINSOLVE_FAILED = 3,
-    MPC_NUMERICAL_ERROR = 4
+    MPC_NUMERICAL_ERROR = 4,
+    MPC_TIME_LIMIT = 5                /* mpc_config.max_time_us ran out (Ipopt: Maximum_CpuTime_Exceeded; a failure for the reference's wrapper) */
 };
 
 enum mpc_error {
@@ -208,7 +209,11 @@ typedef struct mpc_config {
      * NO_VALID_CMD).  The headline workloads are untouched by it (bit-identical trajectories / iteration counts). */
     double  acceptable_tol;           /* solver/ipopt/ipopt_numeric_options/acceptable_tol: 0 -> Ipopt's default 1e-6, < 0 -> rule off */
     int32_t acceptable_iter;          /* .../ipopt_integer_options/acceptable_iter: 0 -> Ipopt's default 15, < 0 -> counting half off */
-    int32_t reserved2;
+    /* solver/ipopt/max_cpu_time (src/controller.cpp:395-397 -> SolverIpopt::setMaxCpuTime): wall-clock budget of ONE solve in microseconds, measured on the device from
+     * the moment the solve's wavefront starts (every candidate initial trajectory has its own); tested once per interior-point iteration, so a solve overruns by at most one
+     * iteration (~45 us at n = 50).  0 = no limit (the reference's default -1).  A solve that runs out ends with MPC_TIME_LIMIT and returns its last iterate.  By nature the one
+     * setting whose results depend on the machine's load; everything stays bit-reproducible with 0. */
+    int32_t max_time_us;
 } mpc_config;
 
 /* Obstacles of a batch (teb_local_planner ObstContainer of every instance, flattened; borrowed for the call).

@@ -313,8 +313,10 @@ inline ParamStatus config_from_params(const ParamSource& p, mpc_config& c, Contr
     if (solver == "lsq_lm") return missing("solver/type lsq_lm: the Levenberg-Marquardt least-squares solver is outside this path (SURVEY.md section 8: out of scope)");
     if (solver != "ipopt") return reject("Unknown solver type '" + solver + "' specified.");
     c.max_iter = p.param("solver/ipopt/iterations", 100);
-    if (p.param("solver/ipopt/max_cpu_time", -1.0) > 0)
-        rep.notes.push_back("solver/ipopt/max_cpu_time has no counterpart: a launch is bounded by max_iter (and by the candidates' iteration caps)");
+    {   // :395-397 -> mpc_config.max_time_us (per solve, on the device's clock)
+        const double t = p.param("solver/ipopt/max_cpu_time", -1.0);
+        c.max_time_us = t > 0 ? (int32_t)(t * 1e6 + 0.5) : 0;
+    }
     std::map<std::string, double> numeric; std::map<std::string, std::string> strings; std::map<std::string, int> integers;
     p.get("solver/ipopt/ipopt_numeric_options", numeric);
     {

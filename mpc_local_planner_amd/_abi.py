@@ -24,7 +24,7 @@ FP64 = 0
 FP32 = 1
 MIXED = 2
 
-STATUS_NAMES = {0: "converged", 1: "max_iter", 2: "linesearch_failed", 3: "linsolve_failed", 4: "numerical_error"}
+STATUS_NAMES = {0: "converged", 1: "max_iter", 2: "linesearch_failed", 3: "linsolve_failed", 4: "numerical_error", 5: "time_limit"}
 
 MPC_OK = 0
 MPC_EINVAL = -1
@@ -110,7 +110,7 @@ class MpcConfig(C.Structure):
         ("terminal_ball_S_offdiag", C.c_double * 3),
         ("acceptable_tol", C.c_double),
         ("acceptable_iter", C.c_int32),
-        ("reserved2", C.c_int32),
+        ("max_time_us", C.c_int32),
     ]
 
 
@@ -142,7 +142,7 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
                 terminal_ball_S=None, terminal_ball_gamma=1.0, vp_position_weight=1e-3, vp_orientation_weight=0.0,
                 via_points_ordered=False, max_via_points=0, footprint_params=(0.0, 0.0, 0.0, 0.0),
                 enable_dynamic_obstacles=False, footprint_vertices=(), candidates=(), candidate_max_iter=(), candidate_blend=0, dual_warm_start=False, mu_init_dual=0.0, candidate_param=(), hessian_mode=0,
-                hybrid_cost_minimum_time=False, cost_integration=COST_LEFT_SUM, acceptable_tol=0.0, acceptable_iter=0, mu_strategy=0) -> MpcConfig:
+                hybrid_cost_minimum_time=False, cost_integration=COST_LEFT_SUM, acceptable_tol=0.0, acceptable_iter=0, mu_strategy=0, max_cpu_time=0.0) -> MpcConfig:
     """Q, R, Qf, terminal_ball_S: the diagonal (3 / 2 / 3 / 3 values) or the full matrix (nested 3 x 3 / 2 x 2; its symmetric part is used)."""
     c = MpcConfig()
     c.model = model
@@ -207,6 +207,7 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
     c.hybrid_cost_minimum_time = int(bool(hybrid_cost_minimum_time))
     c.cost_integration = int(cost_integration)
     c.acceptable_tol, c.acceptable_iter = float(acceptable_tol), int(acceptable_iter)      # 0 = Ipopt's defaults (1e-6, 15), negative = off
+    c.max_time_us = int(round(max_cpu_time * 1e6)) if max_cpu_time and max_cpu_time > 0 else 0      # solver/ipopt/max_cpu_time (seconds; <= 0 = none)
     return c
 
 

@@ -44,6 +44,7 @@ constexpr int ST_MAX_ITER = 1;
 constexpr int ST_LINESEARCH = 2;
 constexpr int ST_LINSOLVE = 3;
 constexpr int ST_NUMERICAL = 4;
+constexpr int ST_TIME_LIMIT = 5;      // MPC_TIME_LIMIT
 constexpr int ST_SUPERSEDED = 5;     // internal: a candidate stopped because a higher-priority candidate of its instance converged (never returned)
 
 // Problem description in device-friendly form (passed by value as a kernel argument).
@@ -93,6 +94,7 @@ struct Problem {
     T pit_mu_min;        // ... while the barrier parameter is above this (the last iterations of a solve take the serial sweeps: see DESIGN.md)
     int pit;             // partitioned (parallel-in-time) sweeps for grids of 40 points and more (1; 0 = the serial sweeps everywhere: developer switch MPC_NO_PIT)
     int mu_strategy;     // mpc_config.mu_strategy: 0 adaptive barrier parameter (the default), 1 monotone Fiacco-McCormick
+    long long max_ticks; // mpc_config.max_time_us in ticks of the device's constant 100 MHz clock (wall_clock64); 0 = no limit
 };
 
 // Algorithm constants (Waechter & Biegler 2006 names).  Compile-time so that they live in

@@ -95,6 +95,7 @@ inline void fill_problem(const mpc_config& c, mpc::Problem<T>& P) {
                                // relative, which is plenty while the steps are large and stalls the last digits of the KKT error (measured: DESIGN.md)
     P.acc_tol = T(c.acceptable_tol > 0 ? c.acceptable_tol : (c.acceptable_tol < 0 ? 0.0 : 1e-6));
     P.acc_iter = c.acceptable_iter > 0 ? c.acceptable_iter : (c.acceptable_iter < 0 ? 0 : 15);
+    P.max_ticks = c.max_time_us > 0 ? 100ll * c.max_time_us : 0ll;
     P.mu_strategy = c.mu_strategy == MPC_MU_MONOTONE ? 1 : 0;
     P.costx = (P.trapz || P.Ro != T(0)) ? 1 : 0;
     for (int i = 0; i < 3; ++i) if (P.Qo[i] != T(0) || P.Qfo[i] != T(0) || (P.ball && P.So[i] != T(0))) P.costx = 1;

@@ -2604,6 +2604,7 @@ struct IpmWave {
         eval_point(SCL(SC_D), theta_c, fobj);
         sync();
         int it = 0, status = ST_MAX_ITER, n_acc = 0;
+        const long long t_start = P.max_ticks > 0 ? (long long)wall_clock64() : 0ll;      // mpc_config.max_time_us: this solve's own clock
         const T acc_tol = P.acc_tol;
         const int acc_it = P.acc_iter;
         T e0 = T(0), logs_cur = T(0), dc_mu = T(-1), dc_val = T(0);
@@ -2636,6 +2637,7 @@ struct IpmWave {
             n_acc = (acc_it > 0 && e0 <= acc_tol) ? n_acc + 1 : 0;
             if (acc_it > 0 && n_acc >= acc_it) { status = ST_CONVERGED; break; }
             if (it >= iter_cap) { status = ST_MAX_ITER; break; }
+            if (P.max_ticks > 0 && (long long)wall_clock64() - t_start > P.max_ticks) { status = ST_TIME_LIMIT; break; }
             if (win_ptr) {      // hedged candidate: one L2 read per iteration (all lanes, same word)
                 const int w = __builtin_amdgcn_readfirstlane(__hip_atomic_load(win_ptr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
                 if (w < my_cand) { status = ST_SUPERSEDED; break; }

@@ -201,8 +201,8 @@ def config_from_params(params: dict, costmap_footprint=None, **sizing):
     if solver != "ipopt":
         raise ParamError(f"Unknown solver type '{solver}' specified.")                        # :477
     kw["max_iter"] = p.get("solver/ipopt/iterations", 100)
-    if p.get("solver/ipopt/max_cpu_time", -1.0) > 0:
-        notes.append("solver/ipopt/max_cpu_time has no counterpart: a launch is bounded by max_iter (and by the candidates' iteration caps)")
+    if p.get("solver/ipopt/max_cpu_time", -1.0) > 0:                                         # :395-397 -> mpc_config.max_time_us (per solve, on the device's clock)
+        kw["max_cpu_time"] = float(p.get("solver/ipopt/max_cpu_time", -1.0))
     numeric = p.get("solver/ipopt/ipopt_numeric_options", {}) or {}
     strings = p.get("solver/ipopt/ipopt_string_options", {}) or {}
     integers = p.get("solver/ipopt/ipopt_integer_options", {}) or {}

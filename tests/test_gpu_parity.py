@@ -969,3 +969,25 @@ def test_device_answers_are_local_minima(m):
     print(f"[second-order check of device answers] {len(pick)} converged answers ({len(hedged)} supplied by a hedge): tangent-space dimensions {sorted(so[i]['dim_s'] for i in pick)}, "
           f"smallest eigenvalue of the reduced Hessian {np.min(eig):.2e} (vertices of the active set count as +inf), weakly active rows {max(so[i]['n_weak'] for i in pick)}")
     assert len(pick) >= 20 and (eig > -1e-6).all()
+
+
+def test_time_limit_per_solve(m):
+    """solver/ipopt/max_cpu_time (src/controller.cpp:395-397 -> SolverIpopt::setMaxCpuTime) = mpc_config.max_time_us, a budget per solve on the device's clock: a generous budget
+    changes nothing, bit for bit; a budget of 200 us ends every solve that is not done by then with MPC_TIME_LIMIT after a handful of iterations (one iteration ~45 us), the rest
+    converged as before; the reference's wrapper counts MPC_TIME_LIMIT as a failed solve like any other status but 0."""
+    from mpc_local_planner_amd import _abi as A
+    B, n = 256, 50
+    x0, xf, up, dtp = m.workloads.carlike_min_time_inputs(B)
+    out = {}
+    for tag, t in (("none", 0.0), ("1 s", 1.0), ("200 us", 200e-6)):
+        s = m.BatchSolver(m.config_carlike_min_time(n, max_cpu_time=t), max_batch=B)
+        out[tag] = s.solve(x0, xf, up, dtp)
+        s.close()
+    a, b, c = out["none"], out["1 s"], out["200 us"]
+    assert np.array_equal(a.status, b.status) and np.array_equal(a.iters, b.iters) and np.array_equal(a.x, b.x) and np.array_equal(a.dt, b.dt)
+    lim = c.status == 5
+    print(f"[time limit 200 us] {int(lim.sum())} of {B} solves ran out of time after {c.iters[lim].min()} .. {c.iters[lim].max()} iterations; {(c.status == 0).sum()} converged inside the budget")
+    assert A.STATUS_NAMES[5] == "time_limit" and lim.sum() >= 0.9 * B and c.iters[lim].max() <= 12 and c.iters[lim].min() >= 1
+    assert set(np.unique(c.status)) <= {0, 5}
+    done = c.status == 0
+    assert np.array_equal(c.x[done], a.x[done]) and (a.status[done] == 0).all()

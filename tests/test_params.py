@@ -105,8 +105,9 @@ def test_yaml_in_the_reference_layout(tmp_path):
     assert ctrl["force_reinit_new_goal_angular"] == 0.5 * math.pi and ctrl["force_reinit_num_steps"] == 5
     assert ctrl["prefer_x_feedback"] and ctrl["publish_ocp_results"] and not ctrl["print_cpu_time"] and ctrl["allow_init_with_backward_motion"]
     text = " | ".join(notes)
-    for word in ("max_vel_x_backwards", "max_cpu_time", "linear_solver", "limited-memory", "print_level"):
+    for word in ("max_vel_x_backwards", "linear_solver", "limited-memory", "print_level"):
         assert word in text
+    assert cfg.max_time_us == 100000 and "max_cpu_time" not in text          # solver/ipopt/max_cpu_time 0.1 s -> mpc_config.max_time_us (r04)
     # the library accepts what the loader produced (mpc_create validates without touching a GPU until it allocates; here: field ranges only)
     assert 3 <= cfg.n <= 4096 and cfg.dt_ref > 0
 
@@ -294,7 +295,7 @@ def _cpp_config(cpp, tree, costmap_footprint=None):
 
 SCALARS = ["model", "n", "dt_ref", "dt_free", "dt_lb", "dt_ub", "collocation", "objective", "integral_form", "has_Qf", "max_iter", "tol", "mu_init", "precision",
            "min_obstacle_dist", "force_inclusion_dist", "cutoff_dist", "footprint_kind", "footprint_radius", "footprint_n_vertices", "max_obstacles", "max_vertices",
-           "max_obstacle_rows", "terminal_ball", "enable_dynamic_obstacles", "hessian_mode", "via_points_ordered", "n_candidates", "dual_warm_start", "hybrid_cost_minimum_time", "cost_integration", "R_offdiag"]
+           "max_obstacle_rows", "terminal_ball", "enable_dynamic_obstacles", "hessian_mode", "via_points_ordered", "n_candidates", "dual_warm_start", "hybrid_cost_minimum_time", "cost_integration", "R_offdiag", "acceptable_tol", "acceptable_iter", "mu_strategy", "max_time_us"]
 ARRAYS = ["model_params", "xf_fixed", "Q", "R", "Qf", "u_lb", "u_ub", "du_lb", "du_ub", "terminal_ball_S", "footprint_params", "footprint_vertices", "Q_offdiag", "Qf_offdiag",
           "terminal_ball_S_offdiag"]
 
