@@ -163,6 +163,15 @@ MPC_HD double t_rcp(double x) {
 #endif
 }
 MPC_HD float t_rcp(float x) { return 1.0f / x; }
+// hardware reciprocal seed alone (~1e-8 relative in fp64; callers add the Newton steps they need)
+MPC_HD double t_rcp_approx(double x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcp(x);
+#else
+    return 1.0 / x;
+#endif
+}
+MPC_HD float t_rcp_approx(float x) { return 1.0f / x; }
 // ---- fp64 sine / cosine / tangent for the arguments this solver produces (angles wrapped to [-pi, pi), steering angles
 //      inside their box): Cody-Waite reduction by pi/2 (two FMAs, exact for the quadrant counts that occur) and the classic
 //      degree-13/14 minimax kernels on [-pi/4, pi/4] (Sun fdlibm coefficients).  ~40 instructions instead of the several hundred

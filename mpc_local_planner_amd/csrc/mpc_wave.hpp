@@ -1745,58 +1745,58 @@ struct IpmWave {
     __device__ __forceinline__ int local_lane() const { int l = lane; asm volatile("" : "+v"(l)); return l; }
     // excess of negative eigenvalues of a combine's pivot block: n-(W) + n-(P+ - W^-1) - 5, by Jacobi's signature rule (negative pivots of the elimination without exchanges).
     // W (the element's, 5 x 5, in the hand-off tile) is swept in place -- the symmetric sweep operator leaves -W^-1 and shows the same pivots as the elimination --, then
-    // G = P+ + (-W^-1) is eliminated.  Wave-uniform arithmetic on values read with uniform LDS addresses / v_readlane: ~330 instructions per combine against the ~4 k a
-    // partitioned factorisation saves.  ok = false when a pivot vanishes (the caller then repeats the factorisation with the serial sweep).
+    // G = P+ + (-W^-1) is eliminated.  Wave-uniform arithmetic on the upper triangles, values read with uniform LDS addresses / v_readlane: a few hundred instructions per
+    // combine against the ~4 k a partitioned factorisation saves.  ok = false when a pivot vanishes (the caller then repeats the factorisation with the serial sweep).
     template <bool LP_A>
     __device__ __forceinline__ int pit_block_inertia(const int TB, const T (&Vp)[6], bool& ok) const {
         const int TW = TB + 96;
-        T w[5][5], g[5][5];
+        // upper triangles, index u(a, b) = a (9 - a) / 2 + b for a <= b (compile-time after unrolling); one reciprocal Newton step is plenty for the signs
+        T w[15], g[15];
         T scl = T(0);
 #pragma unroll
         for (int a = 0; a < 5; ++a)
 #pragma unroll
             for (int b = a; b < 5; ++b) {
-                const T x = T(0.5) * (T(sm[TW + 16 * a + 9 + b]) + T(sm[TW + 16 * b + 9 + a]));
-                w[a][b] = x; w[b][a] = x; scl = t_max(scl, t_abs(x));
-                const T y = T(0.5) * (rd_lane(Vp[a], LP_A ? b : (b < 2 ? 6 + b : 10 + b)) + rd_lane(Vp[b], LP_A ? a : (a < 2 ? 6 + a : 10 + a)));
-                g[a][b] = y; g[b][a] = y;
+                const int u = a * (9 - a) / 2 + b;
+                w[u] = T(sm[TW + 16 * a + 9 + b]);                                        // W[a][b] lives in lane 9 + b as wn[a] (the asymmetry of the accumulated tile is rounding)
+                scl = t_max(scl, t_abs(w[u]));
+                g[u] = rd_lane(Vp[a], LP_A ? b : (b < 2 ? 6 + b : 10 + b));
             }
+        auto rcp1 = [](T x) { T r = t_rcp_approx(x); return r + r * (T(1) - x * r); };
         int neg = -5;
         bool okp = t_finite(scl) && scl > T(0);
 #pragma unroll
-        for (int k = 0; k < 5; ++k) {                 // sweep on pivot k: afterwards w = -(W^-1) restricted appropriately; the pivot is the Schur complement's diagonal
-            const T d = w[k][k];
+        for (int k = 0; k < 5; ++k) {                 // symmetric sweep on pivot k: the pivot is the diagonal of the Schur complement; after five sweeps w = -W^-1
+            const T d = w[k * (9 - k) / 2 + k];
             okp = okp && (t_abs(d) > T(1e-13) * scl);
             neg += d < T(0) ? 1 : 0;
-            const T id = t_rcp(d);
-            T col[5];
+            const T id = rcp1(d);
+            T col[5], tc[5];
 #pragma unroll
-            for (int i = 0; i < 5; ++i) col[i] = w[i][k];
+            for (int i = 0; i < 5; ++i) { col[i] = i <= k ? w[i * (9 - i) / 2 + k] : w[k * (9 - k) / 2 + i]; tc[i] = col[i] * id; }
 #pragma unroll
             for (int i = 0; i < 5; ++i)
 #pragma unroll
-                for (int j = 0; j < 5; ++j) if (i != k && j != k) w[i][j] -= col[i] * col[j] * id;
+                for (int j = i; j < 5; ++j) if (i != k && j != k) w[i * (9 - i) / 2 + j] -= tc[i] * col[j];
 #pragma unroll
-            for (int i = 0; i < 5; ++i) if (i != k) { w[i][k] = col[i] * id; w[k][i] = col[i] * id; }
-            w[k][k] = -id;
+            for (int i = 0; i < 5; ++i) if (i != k) { if (i < k) w[i * (9 - i) / 2 + k] = tc[i]; else w[k * (9 - k) / 2 + i] = tc[i]; }
+            w[k * (9 - k) / 2 + k] = -id;
         }
         T gs = T(0);
 #pragma unroll
-        for (int a = 0; a < 5; ++a)
-#pragma unroll
-            for (int b = 0; b < 5; ++b) { g[a][b] += w[a][b]; gs = t_max(gs, t_abs(g[a][b])); }
+        for (int u = 0; u < 15; ++u) { g[u] += w[u]; gs = t_max(gs, t_abs(g[u])); }
         okp = okp && t_finite(gs) && gs > T(0);
 #pragma unroll
         for (int k = 0; k < 5; ++k) {
-            const T d = g[k][k];
+            const T d = g[k * (9 - k) / 2 + k];
             okp = okp && (t_abs(d) > T(1e-13) * gs);
             neg += d < T(0) ? 1 : 0;
-            const T id = t_rcp(d);
+            const T id = rcp1(d);
 #pragma unroll
             for (int i = k + 1; i < 5; ++i) {
-                const T m = g[i][k] * id;
+                const T m = g[k * (9 - k) / 2 + i] * id;
 #pragma unroll
-                for (int j = i; j < 5; ++j) { g[i][j] -= m * g[k][j]; g[j][i] = g[i][j]; }
+                for (int j = i; j < 5; ++j) g[i * (9 - i) / 2 + j] -= m * g[k * (9 - k) / 2 + j];
             }
         }
         ok = ok && okp;
