@@ -91,8 +91,7 @@ inline void fill_problem(const mpc_config& c, mpc::Problem<T>& P) {
         for (int i = 0; i < 3; ++i) P.Qf[i] = T(0);
     }
     P.pit = 1;
-    P.pit_mu_min = P.tol;      // the final barrier subproblems (mu <= tol) are solved with the serial sweeps: the partitioned sweeps' steps are accurate to ~1e-7
-                               // relative, which is plenty while the steps are large and stalls the last digits of the KKT error (measured: DESIGN.md)
+    P.pit_mu_min = P.tol > T(1e-6) ? P.tol : T(1e-6);      // the barrier subproblems below max(tol, 1e-6) are solved with the serial sweeps (measured: mpc_wave.hpp, pit_floor)
     P.acc_tol = T(c.acceptable_tol > 0 ? c.acceptable_tol : (c.acceptable_tol < 0 ? 0.0 : 1e-6));
     P.acc_iter = c.acceptable_iter > 0 ? c.acceptable_iter : (c.acceptable_iter < 0 ? 0 : 15);
     P.max_ticks = c.max_time_us > 0 ? 100ll * c.max_time_us : 0ll;

@@ -1734,11 +1734,14 @@ struct IpmWave {
     // In(W) + In(P+ - W^-1) (Haynsworth), five negative eigenvalues when all is well -- pit_block_inertia() returns the excess.  The sum of all of it plus the root system's
     // count is the matrix's, whatever the elimination order (Sylvester); tests/test_pit_math.py::test_inertia_of_the_kkt_matrix_from_the_sweeps holds both counts to the
     // eigenvalues of the dense matrix, including the cases where a negative pivot in one place is made up for in another.
-    // Kernels WITH clearance-row code take the serial sweeps (r04, measured on the MI355X with the inertia test in both: car-like minimum time against point obstacles, line /
-    // polygon / two-circle footprints, 192 instances -- serial sweeps 179 / 163 / 175 converged, each of them at the C oracle's trajectory (oracle: 180 / 163 / 175);
-    // partitioned sweeps 172 / 147 / 163, the converged ones still at the oracle's trajectory: rows that are active late in a solve put 1e8-sized entries into the
-    // position block of the value functions and the combines' I - W P+ loses the last digits the end game needs).
-    static constexpr bool kPartitionedSweeps = !OBST;
+    // Where the serial sweeps take over (r04, measured on the MI355X with the inertia test in both, scripts/dev/pit_*_sweep.py): the combines' I - W P+ is eliminated without
+    // exchanges and loses the last digits the end game needs.  Headline kernel, three seeds x 1024 cold starts: partitioned sweeps down to mu = tol = 1e-8 converge 990 / 980 / 989
+    // instances, down to 1e-6 992 / 985 / 998 -- exactly the serial sweeps' counts and iteration numbers, at the same kernel time.  Kernels with clearance rows (active rows put
+    // 1e8-sized entries into the position block of the value functions): car-like footprints x 192 instances 172 / 147 / 163 with the partitioned sweeps down to 1e-8,
+    // 179 / 163 / 175 = the serial sweeps' from 1e-6 up; config 3 at 4096 instances 4004 (1e-8), 4015 (1e-6), 4016 = serial (1e-4) at 21.5 ms against 23.8 ms serial.
+    // So: partitioned while mu > max(tol, 1e-6) (Problem::pit_mu_min), max(tol, 1e-4) in the kernels with clearance rows (pit_floor()).
+    static constexpr bool kPartitionedSweeps = true;
+    __device__ __forceinline__ T pit_floor() const { return OBST ? t_max(P.pit_mu_min, T(1e-4)) : P.pit_mu_min; }
     __device__ __forceinline__ bool pit_enabled() const { return kPartitionedSweeps && EXT < 2 && P.pit != 0 && L.n >= 40 && 3 * L.NS >= 100 && L.NTR * L.NS >= 100 && 5 * L.NS >= 192; }
     // lane index that the optimiser must treat as unknown HERE: keeps the per-lane address arithmetic of a phase inside the phase (hoisted out of the
     // interior-point loop as loop invariants it would occupy registers for the whole solve)
@@ -2699,9 +2702,7 @@ struct IpmWave {
                     sync();
                 }
 #endif
-                if (pit && mu > P.pit_mu_min) {        // partitioned sweep; a broken-down combine pivot (or a singular stage pivot) falls back to the serial sweep.  (Measured r04: with the
-                                                       // partitioned sweeps also AT mu = tol -- the first barrier problem of the adaptive rule's end game -- the EXT kernels with clearance rows converge
-                                                       // for 10 % fewer instances than the C oracle: the end game needs the serial sweeps' accuracy from mu = tol on)
+                if (pit && mu > pit_floor()) {        // partitioned sweep; a broken-down combine pivot (or a singular stage pivot) falls back to the serial sweep; below pit_floor() the end game takes the serial sweeps
                     int gp_;
                     MPC_TICK(2, gp_ = backward_pit(delta, dc, dd, nu); sync());
                     good = used_pit = gp_ > 0;
