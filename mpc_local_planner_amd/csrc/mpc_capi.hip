@@ -129,7 +129,7 @@ void mpc_config_defaults(mpc_config* c) {
 }
 
 const char* mpc_last_error(void) { return g_err; }
-int32_t mpc_version(void) { return 300; }      // 0.3.0: mpc_config grew (acceptable_tol / acceptable_iter)
+int32_t mpc_version(void) { return 400; }      // 0.4.0: mpc_config.mu_strategy / max_time_us took reserved words (same size), MPC_TIME_LIMIT; a solve accepts factorisations on their inertia
 // history: 0.2.0: mpc_config grew (candidates, kept multipliers, hessian_mode), new entry points; 0.2.1: cost variants (off-diagonal weights, trapezoidal rule, hybrid cost)
 
 #ifdef MPC_PROFILE
