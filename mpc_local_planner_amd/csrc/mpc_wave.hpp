@@ -14,6 +14,8 @@
 //       backward Riccati sweep over the augmented stage state (x_k, u_{k-1}, dt): lane c owns column c of the
 //       value block and of the stage Hessian (backward_dpp); forward state recurrence: lane c owns component c
 //       of (dx, du) (forward_states); the costate (multiplier) recurrence is two wave suffix scans.
+//       The backward sweep also counts the negative eigenvalues of its pivots: a factorisation is accepted on its inertia, as Ipopt does it (mpc_core.hpp::riccati_root).
+//   partitioned over the four 16-lane DPP rows (four time segments at once, backward_pit / forward_pit) while the barrier parameter is above pit_floor().
 // The arithmetic is the same as mpc_core.hpp (lane-per-instance variant); see that file for the
 // reference citations of every formula.
 #pragma once

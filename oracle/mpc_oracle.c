@@ -9,6 +9,8 @@
  * solve by a general BANDED LU with partial pivoting on the stage-interleaved KKT matrix plus a
  * bordered (Schur) step for the global dt column -- i.e. linear algebra that shares nothing
  * with the product's Riccati sweep.
+ * A factorisation is accepted on its INERTIA (Ipopt's test, r04): the LU carries none, so a second pass counts the negative eigenvalues of the same assembled matrix by a
+ * symmetric block elimination (kkt_negative_eigenvalues); oracle/ipm_dense.py reads the same count off LAPACK's Bunch-Kaufman factorisation, the product off its sweeps' pivots.
  *
  * PARITY: the reference ships no golden outputs and Ipopt/corbo are not vendored, so the SOLVE (the iterates, the point a non-convex problem converges to) is unpinned.
  * The NLP pieces are pinned where the reference's own code could be compiled and executed (oracle/_ref): this file follows oracle/se2_nlp.py, which is held to the recorded
