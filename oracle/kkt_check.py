@@ -26,17 +26,12 @@ from scipy.optimize import lsq_linear
 from . import se2_nlp as R
 
 
-def kkt_residuals(ocfg, x0, xf, u_prev, dt_prev, x, u, dt, act_tol: float = 1e-1, nlp_kwargs=None, inp_kwargs=None, fd_step: float = 1e-5):
-    """x (n,3), u (n,2) or (n-1,2) (a duplicated last control is dropped), dt.  Returns dict(feas, stat, objective, n_active)."""
-    inp = R.CycleInputs(x0=np.asarray(x0, float), xf=np.asarray(xf, float), u_prev=np.asarray(u_prev, float), dt_prev=float(dt_prev), **(inp_kwargs or {}))
-    nlp = R.ReferenceNlp(ocfg, inp, **(nlp_kwargs or {}))
-    n = ocfg.n
-    u = np.asarray(u, float)[: n - 1]
-    z = nlp.pack(R.Trajectory(np.asarray(x, float), u, float(dt)))
+def _active_set_and_multipliers(nlp, z, act_tol, fd_step):
+    """the bounded least-squares problem both checkers share: numeric gradients of the reference-form NLP at z, the nearly active rows / bounds, and the multipliers
+    (lambda free; nu, pi_l, pi_u >= 0) that minimise the stationarity residual with the complementarity products as extra rows"""
     lb, ub = nlp.bounds()
     c = nlp.equalities(z)
     g = nlp.inequalities(z)
-    feas = max(float(np.abs(c).max(initial=0.0)), float(g.max(initial=0.0)), float((lb - z).max(initial=0.0)), float((z - ub).max(initial=0.0)))
     gradf = nlp.numeric_jacobian(lambda v: np.array([nlp.objective(v)]), z, fd_step)[0]
     Jc = nlp.numeric_jacobian(nlp.equalities, z, fd_step)
     act = np.where(g > -act_tol)[0]
@@ -53,8 +48,22 @@ def kkt_residuals(ocfg, x0, xf, u_prev, dt_prev, x, u, dt, act_tol: float = 1e-1
     W = np.zeros((slack.size, lo.size)); W[np.arange(slack.size), Jc.shape[0] + np.arange(slack.size)] = np.abs(slack)
     sol = lsq_linear(np.concatenate([A, W], axis=0), np.concatenate([-gradf, np.zeros(slack.size)]), bounds=(lo, np.full(lo.size, np.inf)),
                      tol=1e-15, max_iter=4000, method='bvls')
-    stat = float(np.abs(A @ sol.x + gradf).max())
-    comp = float((sol.x[Jc.shape[0]:] * np.abs(slack)).max(initial=0.0))
+    return dict(lb=lb, ub=ub, c=c, g=g, gradf=gradf, Jc=Jc, act=act, al=al, au=au, A=A, slack=slack, mult=sol.x)
+
+
+def kkt_residuals(ocfg, x0, xf, u_prev, dt_prev, x, u, dt, act_tol: float = 1e-1, nlp_kwargs=None, inp_kwargs=None, fd_step: float = 1e-5):
+    """x (n,3), u (n,2) or (n-1,2) (a duplicated last control is dropped), dt.  Returns dict(feas, stat, objective, n_active)."""
+    inp = R.CycleInputs(x0=np.asarray(x0, float), xf=np.asarray(xf, float), u_prev=np.asarray(u_prev, float), dt_prev=float(dt_prev), **(inp_kwargs or {}))
+    nlp = R.ReferenceNlp(ocfg, inp, **(nlp_kwargs or {}))
+    n = ocfg.n
+    u = np.asarray(u, float)[: n - 1]
+    z = nlp.pack(R.Trajectory(np.asarray(x, float), u, float(dt)))
+    q = _active_set_and_multipliers(nlp, z, act_tol, fd_step)
+    lb, ub, c, g, A, slack, me = q["lb"], q["ub"], q["c"], q["g"], q["A"], q["slack"], q["Jc"].shape[0]
+    feas = max(float(np.abs(c).max(initial=0.0)), float(g.max(initial=0.0)), float((lb - z).max(initial=0.0)), float((z - ub).max(initial=0.0)))
+    stat = float(np.abs(A @ q["mult"] + q["gradf"]).max())
+    comp = float((q["mult"][me:] * np.abs(slack)).max(initial=0.0))
+    act, al, au = q["act"], q["al"], q["au"]
     return {"feas": feas, "stat": stat, "comp": comp, "objective": float(nlp.objective(z)), "n_active": int(act.size + al.size + au.size)}
 
 
@@ -71,24 +80,11 @@ def second_order(ocfg, x0, xf, u_prev, dt_prev, x, u, dt, act_tol: float = 1e-1,
     nlp = R.ReferenceNlp(ocfg, inp, **(nlp_kwargs or {}))
     n = ocfg.n
     z = nlp.pack(R.Trajectory(np.asarray(x, float), np.asarray(u, float)[: n - 1], float(dt)))
-    lb, ub = nlp.bounds()
-    g = nlp.inequalities(z)
-    gradf = nlp.numeric_jacobian(lambda v: np.array([nlp.objective(v)]), z, fd_step)[0]
-    Jc = nlp.numeric_jacobian(nlp.equalities, z, fd_step)
-    act = np.where(g > -act_tol)[0]
-    Jg = nlp.numeric_jacobian(nlp.inequalities, z, fd_step)[act] if act.size else np.zeros((0, z.size))
-    al = np.where(z - lb < act_tol)[0]
-    au = np.where(ub - z < act_tol)[0]
-    El = np.zeros((al.size, z.size)); El[np.arange(al.size), al] = -1.0
-    Eu = np.zeros((au.size, z.size)); Eu[np.arange(au.size), au] = 1.0
-    A = np.concatenate([Jc, Jg, El, Eu], axis=0).T
-    slack = np.concatenate([-g[act], (z - lb)[al], (ub - z)[au]])
+    q = _active_set_and_multipliers(nlp, z, act_tol, fd_step)
+    lb, ub, Jc, act, al, au, A, slack = q["lb"], q["ub"], q["Jc"], q["act"], q["al"], q["au"], q["A"], q["slack"]
     me = Jc.shape[0]
-    lo = np.concatenate([np.full(me, -np.inf), np.zeros(slack.size)])
-    W = np.zeros((slack.size, lo.size)); W[np.arange(slack.size), me + np.arange(slack.size)] = np.abs(slack)
-    sol = lsq_linear(np.concatenate([A, W], axis=0), np.concatenate([-gradf, np.zeros(slack.size)]), bounds=(lo, np.full(lo.size, np.inf)), tol=1e-15, max_iter=4000, method='bvls')
-    lam, nu = sol.x[:me], sol.x[me:me + act.size]
-    mult = sol.x[me:]
+    lam, nu = q["mult"][:me], q["mult"][me:me + act.size]
+    mult = q["mult"][me:]
     rows = A.T[me:]
     strong = mult > strong_tol
     active = np.abs(slack) < slack_tol
