@@ -820,6 +820,57 @@ MPC_HD int riccati_root(const RicState<T>& V, const Problem<T>& P_, T& dd_out, T
     return (t_finite(sol[0]) && t_finite(sol[1]) && t_finite(sol[2]) && t_finite(sol[3])) ? 1 : 0;
 }
 
+// Excess of negative eigenvalues of the pivot block of a combine step of the partitioned sweep (mpc_wave.hpp::backward_pit): n-(W) + n-(P+ - W^-1) - 5 for symmetric 5 x 5
+// matrices given by their upper triangles, index u(a, b) = a (9 - a) / 2 + b for a <= b.  The block [[W, -I], [-I, P+]] over the five components with a costate column has the
+// inertia In(W) + In(P+ - W^-1) (Haynsworth), five negative eigenvalues when all is well.  Jacobi's signature rule: the negative eigenvalues of a symmetric matrix are the negative
+// pivots of its elimination without exchanges.  W is swept in place -- the symmetric sweep operator shows the same pivots as the elimination and leaves -W^-1 --, then
+// g = P+ + (-W^-1) is eliminated.  One Newton step per reciprocal is plenty for signs.  ok = false when a pivot vanishes (both arrays are destroyed).
+template <typename T>
+MPC_HD int pit_block_inertia_tri(T (&w)[15], T (&g)[15], bool& ok) {
+    T scl = T(0);
+#pragma unroll
+    for (int u = 0; u < 15; ++u) scl = t_max(scl, t_abs(w[u]));
+    auto rcp1 = [](T x) { T r = t_rcp_approx(x); return r + r * (T(1) - x * r); };
+    int neg = -5;
+    bool okp = t_finite(scl) && scl > T(0);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {                 // symmetric sweep on pivot k: the pivot is the diagonal of the Schur complement; after five sweeps w = -W^-1
+        const T d = w[k * (9 - k) / 2 + k];
+        okp = okp && (t_abs(d) > T(1e-13) * scl);
+        neg += d < T(0) ? 1 : 0;
+        const T id = rcp1(d);
+        T col[5], tc[5];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) { col[i] = i <= k ? w[i * (9 - i) / 2 + k] : w[k * (9 - k) / 2 + i]; tc[i] = col[i] * id; }
+#pragma unroll
+        for (int i = 0; i < 5; ++i)
+#pragma unroll
+            for (int j = i; j < 5; ++j) if (i != k && j != k) w[i * (9 - i) / 2 + j] -= tc[i] * col[j];
+#pragma unroll
+        for (int i = 0; i < 5; ++i) if (i != k) { if (i < k) w[i * (9 - i) / 2 + k] = tc[i]; else w[k * (9 - k) / 2 + i] = tc[i]; }
+        w[k * (9 - k) / 2 + k] = -id;
+    }
+    T gs = T(0);
+#pragma unroll
+    for (int u = 0; u < 15; ++u) { g[u] += w[u]; gs = t_max(gs, t_abs(g[u])); }
+    okp = okp && t_finite(gs) && gs > T(0);
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+        const T d = g[k * (9 - k) / 2 + k];
+        okp = okp && (t_abs(d) > T(1e-13) * gs);
+        neg += d < T(0) ? 1 : 0;
+        const T id = rcp1(d);
+#pragma unroll
+        for (int i = k + 1; i < 5; ++i) {
+            const T m = g[k * (9 - k) / 2 + i] * id;
+#pragma unroll
+            for (int j = i; j < 5; ++j) g[i * (9 - i) / 2 + j] -= m * g[k * (9 - k) / 2 + j];
+        }
+    }
+    ok = ok && okp;
+    return neg;
+}
+
 // rate-row slot helpers: q in 0..3 -> component j, sign sg
 MPC_HD int slot_comp(int q) { return q & 1; }
 template <typename T> MPC_HD T slot_sign(int q) { return q < 2 ? T(-1) : T(1); }

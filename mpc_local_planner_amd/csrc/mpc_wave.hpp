@@ -1755,57 +1755,16 @@ struct IpmWave {
     template <bool LP_A>
     __device__ __forceinline__ int pit_block_inertia(const int TB, const T (&Vp)[6], bool& ok) const {
         const int TW = TB + 96;
-        // upper triangles, index u(a, b) = a (9 - a) / 2 + b for a <= b (compile-time after unrolling); one reciprocal Newton step is plenty for the signs
-        T w[15], g[15];
-        T scl = T(0);
+        T w[15], g[15];                               // upper triangles (mpc_core.hpp::pit_block_inertia_tri has the arithmetic, compiled for the host by the tests)
 #pragma unroll
         for (int a = 0; a < 5; ++a)
 #pragma unroll
             for (int b = a; b < 5; ++b) {
                 const int u = a * (9 - a) / 2 + b;
                 w[u] = T(sm[TW + 16 * a + 9 + b]);                                        // W[a][b] lives in lane 9 + b as wn[a] (the asymmetry of the accumulated tile is rounding)
-                scl = t_max(scl, t_abs(w[u]));
                 g[u] = rd_lane(Vp[a], LP_A ? b : (b < 2 ? 6 + b : 10 + b));
             }
-        auto rcp1 = [](T x) { T r = t_rcp_approx(x); return r + r * (T(1) - x * r); };
-        int neg = -5;
-        bool okp = t_finite(scl) && scl > T(0);
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {                 // symmetric sweep on pivot k: the pivot is the diagonal of the Schur complement; after five sweeps w = -W^-1
-            const T d = w[k * (9 - k) / 2 + k];
-            okp = okp && (t_abs(d) > T(1e-13) * scl);
-            neg += d < T(0) ? 1 : 0;
-            const T id = rcp1(d);
-            T col[5], tc[5];
-#pragma unroll
-            for (int i = 0; i < 5; ++i) { col[i] = i <= k ? w[i * (9 - i) / 2 + k] : w[k * (9 - k) / 2 + i]; tc[i] = col[i] * id; }
-#pragma unroll
-            for (int i = 0; i < 5; ++i)
-#pragma unroll
-                for (int j = i; j < 5; ++j) if (i != k && j != k) w[i * (9 - i) / 2 + j] -= tc[i] * col[j];
-#pragma unroll
-            for (int i = 0; i < 5; ++i) if (i != k) { if (i < k) w[i * (9 - i) / 2 + k] = tc[i]; else w[k * (9 - k) / 2 + i] = tc[i]; }
-            w[k * (9 - k) / 2 + k] = -id;
-        }
-        T gs = T(0);
-#pragma unroll
-        for (int u = 0; u < 15; ++u) { g[u] += w[u]; gs = t_max(gs, t_abs(g[u])); }
-        okp = okp && t_finite(gs) && gs > T(0);
-#pragma unroll
-        for (int k = 0; k < 5; ++k) {
-            const T d = g[k * (9 - k) / 2 + k];
-            okp = okp && (t_abs(d) > T(1e-13) * gs);
-            neg += d < T(0) ? 1 : 0;
-            const T id = rcp1(d);
-#pragma unroll
-            for (int i = k + 1; i < 5; ++i) {
-                const T m = g[k * (9 - k) / 2 + i] * id;
-#pragma unroll
-                for (int j = i; j < 5; ++j) g[i * (9 - i) / 2 + j] -= m * g[k * (9 - k) / 2 + j];
-            }
-        }
-        ok = ok && okp;
-        return neg;
+        return pit_block_inertia_tri(w, g, ok);
     }
     // one combine step.  LP_A: the value function's P+ columns sit in lane set A (then the result's sit in B), else the other way round.
     // In: Vp / Wp / omp = value function at the segment's end, the element's tile in LDS at TB.  Out: the same registers = value function at the

@@ -97,3 +97,14 @@ extern "C" void hostdbg_colloc(const mpc_config* cfg, int count, const double* x
     }
 }
 extern "C" double hostdbg_normalize_theta(double th) { return mpc::normalize_theta(th); }
+
+
+// mpc_core.hpp::pit_block_inertia_tri on the host (tests/test_pit_math.py): full symmetric 5 x 5 matrices in, excess of negative eigenvalues out (ok = 0 when a pivot vanished)
+extern "C" int host_pit_block_inertia(const double* W, const double* P, int* ok_out) {
+    double w[15], g[15];
+    for (int a = 0; a < 5; ++a) for (int b = a; b < 5; ++b) { w[a * (9 - a) / 2 + b] = W[5 * a + b]; g[a * (9 - a) / 2 + b] = P[5 * a + b]; }
+    bool ok = true;
+    const int r = mpc::pit_block_inertia_tri(w, g, ok);
+    *ok_out = ok ? 1 : 0;
+    return r;
+}

@@ -159,3 +159,28 @@ def test_device_core_on_host_closed_loop_golden(host):
     assert (st == 0).all()
     assert np.abs(xo - g["x"]).max() < 1e-6 and np.abs(uo - g["u"]).max() < 1e-6
     assert (np.abs(it - g["iters"]) <= 2).all()
+
+
+def test_inertia_count_of_a_combine_block_on_the_host(host):
+    """mpc_core.hpp::pit_block_inertia_tri -- the arithmetic the partitioned sweep's combine runs on the device to count the negative eigenvalues of its pivot block --
+    compiled for the host: n-(W) + n-(P - W^-1) - 5 against numpy's eigenvalues on random symmetric pairs, definite and not; a vanishing pivot is reported, not guessed."""
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    host.host_pit_block_inertia.restype = C.c_int
+    ok = C.c_int(0)
+    seen = set()
+    for t in range(400):
+        A = rng.normal(size=(5, 5)); W = A + A.T
+        if t % 3 == 0:
+            W = -(A @ A.T) - 0.05 * np.eye(5)               # the usual case: W negative definite
+        B = rng.normal(size=(5, 5)); P = B + B.T
+        if t % 5 == 0:
+            P[:2, :] = 0.0; P[:, :2] = 0.0                      # no curvature in the position rows (minimum time without clearance rows)
+        r = host.host_pit_block_inertia(np.ascontiguousarray(W).ctypes.data_as(C.c_void_p), np.ascontiguousarray(P).ctypes.data_as(C.c_void_p), C.byref(ok))
+        want = int((np.linalg.eigvalsh(W) < 0).sum() + (np.linalg.eigvalsh(P - np.linalg.inv(W)) < 0).sum()) - 5
+        assert ok.value == 1 and r == want, (t, r, want)
+        seen.add(want)
+    assert {0, 1, 2}.issubset(seen) and min(seen) < 0
+    Z = np.zeros((5, 5)); Z[0, 1] = Z[1, 0] = 1.0            # zero leading pivot
+    host.host_pit_block_inertia(Z.ctypes.data_as(C.c_void_p), np.eye(5).ctypes.data_as(C.c_void_p), C.byref(ok))
+    assert ok.value == 0
