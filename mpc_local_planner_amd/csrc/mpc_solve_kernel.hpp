@@ -37,7 +37,11 @@ constexpr int kWinIdle = 0x7f7f7f7f;
 // One wavefront = one (planner instance, candidate initial trajectory); the whole working set lives in LDS (mpc_wave.hpp).
 // Grid: n_cand * B workgroups, candidate-major, so that the hardware dispatches every instance's candidate 0 before any hedge.
 template <typename T, int MODEL, int EXT, bool OBST, int NSC = 0>
-__global__ __launch_bounds__(mpc::kWave) void mpc_ipm_wave_kernel(
+__global__ __launch_bounds__(mpc::kWave)
+#ifdef MPC_WAVES_PER_EU      // developer experiment (scripts/dev/occupancy_probe.py): cap the register budget so that this many waves fit a SIMD
+__attribute__((amdgpu_waves_per_eu(MPC_WAVES_PER_EU, MPC_WAVES_PER_EU)))
+#endif
+void mpc_ipm_wave_kernel(
     mpc::Problem<T> P, mpc::WaveLayout L, int B,
     const double* __restrict__ x0, const double* __restrict__ xf, const double* __restrict__ u_prev,
     const double* __restrict__ dt_prev, const double* __restrict__ x_init, const double* __restrict__ u_init,
