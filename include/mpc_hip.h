@@ -87,6 +87,13 @@ enum mpc_hessian_mode {
                                        * work well with the carlike model" (cfg/carlike/mpc_local_planner_params.yaml:91-95). */
 };
 
+enum mpc_stage_data {                 /* mpc_config.stage_data */
+    MPC_STAGE_AUTO = 0,               /* decided per handle and precision at mpc_create: global memory exactly when the smaller LDS record puts more workgroups on a CU */
+    MPC_STAGE_LDS = 1,                /* the whole working set of an instance in LDS (97 words per grid point) */
+    MPC_STAGE_GLOBAL = 2              /* stage records and gains in a per-workgroup block of global memory (L2 / Infinity-Cache resident), 34 words per grid point in LDS;
+                                       * headline kernel level only (mpc_create refuses it for the extended terms) */
+};
+
 enum mpc_mu_strategy {
     MPC_MU_ADAPTIVE = 0,              /* the default (corbo's SolverIpopt is believed to set mu_strategy adaptive): every iteration
                                        * mu = sigma x (average complementarity), sigma = clamp((1 - min(alpha, alpha_dual))^3, 0.05, 1) from the step lengths the
@@ -191,7 +198,10 @@ typedef struct mpc_config {
                                        * integrated (integral_form = 1): trapezoidal = 0.5 dt (l(x_k, u_k) + l(x_{k+1}, u_k)) per interval
                                        * (corbo::TrapezoidalIntegralCostEdge, finite_differences_grid_se2.cpp:63-68) */
     int32_t mu_strategy;              /* solver/ipopt/ipopt_string_options/mu_strategy: MPC_MU_ADAPTIVE (0, the default) | MPC_MU_MONOTONE */
-    int32_t reserved[3];
+    int32_t stage_data;               /* where a solve keeps its factorisation data (stage records + Riccati gains, 63 of the 97 words per grid point): MPC_STAGE_AUTO (0: global
+                                       * memory exactly when that puts more workgroups on a compute unit -- long horizons, clearance rows), MPC_STAGE_LDS, MPC_STAGE_GLOBAL.
+                                       * Results are bit-identical either way; no counterpart in the reference (its solver's working memory is Ipopt's) */
+    int32_t reserved[2];
     /* full weight matrices (state_weights / control_weights / final_state_weights / weight_matrix given as n x n lists, column major,
      * src/controller.cpp:565-573,580-588,656-664,690-698): Q, R, Qf, terminal_ball_S above hold the DIAGONALS, these the off-diagonal terms
      * (0,1), (0,2), (1,2) of the symmetric parts (x' W x only sees (W + W') / 2); all zero = diagonal weights */

@@ -315,7 +315,8 @@ inline ParamStatus config_from_params(const ParamSource& p, mpc_config& c, Contr
     c.max_iter = p.param("solver/ipopt/iterations", 100);
     {   // :395-397 -> mpc_config.max_time_us (per solve, on the device's clock)
         const double t = p.param("solver/ipopt/max_cpu_time", -1.0);
-        c.max_time_us = t > 0 ? (int32_t)(t * 1e6 + 0.5) : 0;
+        // (a budget beyond the int32 range of microseconds -- ~2147 s, e.g. `max_cpu_time: 1e9` for "none" -- is no budget: 0)
+        c.max_time_us = (t > 0 && t * 1e6 + 0.5 < 2147483647.0) ? (int32_t)(t * 1e6 + 0.5) : 0;
     }
     std::map<std::string, double> numeric; std::map<std::string, std::string> strings; std::map<std::string, int> integers;
     p.get("solver/ipopt/ipopt_numeric_options", numeric);

@@ -49,7 +49,11 @@ def build(force: bool = False, verbose: bool = False, extra_flags=(), out: str |
     Split build: the ABI + the small kernels (mpc_capi.hip) and one object per (arithmetic type, model) pair of the solve kernel
     (mpc_solve_inst.hip, three kernel instantiations each) are compiled in parallel, then linked.  A plain
     `hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared mpc_capi.hip -o libmpc_hip.so` gives the same library from one translation unit."""
-    build_ubench(force=force, verbose=verbose)
+    if out is None:      # the measurement-only micro-benchmark rides along with the product library, but never stands in its way (ADVICE r04)
+        try:
+            build_ubench(force=force, verbose=verbose)
+        except (OSError, RuntimeError, subprocess.CalledProcessError) as e:
+            print(f"mpc_local_planner_amd: libmpc_ubench.so not built ({e}); bench.py will report the data-sheet peaks only")
     if out is None and not force and not needs_build():
         return LIB_PATH
     from concurrent.futures import ThreadPoolExecutor

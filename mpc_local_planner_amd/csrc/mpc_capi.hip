@@ -39,7 +39,10 @@ struct mpc_solver {
     mpc_config cfg;
     mpc::Problem<double> P64;
     mpc::Problem<float> P32;
-    mpc::WaveLayout WL;
+    mpc::WaveLayout WL;         // everything in LDS
+    mpc::WaveLayout WLg;        // factorisation data (GAIN, STG) in global memory (mpc_wave.hpp::GlobalStage): the LDS record is a third
+    bool gs64, gs32;            // which of the two the fp64 / fp32 launches of this handle use (mpc_config.stage_data; MPC_STAGE_AUTO: the one that puts more workgroups on a CU)
+    void* d_gstage;             // the workgroups' blocks of factorisation data (max_batch x candidates x WLg.GSW words), NULL when neither precision uses them
     size_t wave_lds;            // dynamic LDS of the kernel instantiation of cfg.precision (MPC_MIXED: the fp64 one, the larger)
     size_t wave_lds32;          // MPC_MIXED: dynamic LDS of the fp32 phase
     int32_t* d_iters1;          // MPC_MIXED: iterations of the fp32 phase
@@ -169,6 +172,8 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
     if (cfg->precision == MPC_MIXED && (cfg->max_obstacles > 0 || cfg->objective == MPC_OBJ_MIN_TIME_VIA_POINTS)) {
         set_err("mpc_create: MPC_MIXED is implemented for problems without clearance rows and via-points (their association would be redone by the refinement phase)"); return MPC_EINVAL; }
     if (cfg->hessian_mode != MPC_HESSIAN_EXACT && cfg->hessian_mode != MPC_HESSIAN_CONVEXIFIED) { set_err("mpc_create: unknown hessian_mode"); return MPC_EINVAL; }
+    if (cfg->mu_strategy != MPC_MU_ADAPTIVE && cfg->mu_strategy != MPC_MU_MONOTONE) { set_err("mpc_create: unknown mu_strategy"); return MPC_EINVAL; }
+    if (cfg->max_time_us < 0) { set_err("mpc_create: max_time_us must be >= 0 (0 = no budget)"); return MPC_EINVAL; }
     if (cfg->n_candidates < 0 || cfg->n_candidates > MPC_MAX_CANDIDATES) { set_err("mpc_create: n_candidates must be in [0, MPC_MAX_CANDIDATES]"); return MPC_EINVAL; }
     for (int k = 0; k < cfg->n_candidates; ++k)
         if (cfg->candidate_kind[k] < MPC_CAND_REFERENCE || cfg->candidate_kind[k] > MPC_CAND_HERMITE_RF || cfg->candidate_max_iter[k] < 0) {
@@ -207,20 +212,48 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         const int M = O > 0 ? (cfg->max_obstacle_rows > 0 ? cfg->max_obstacle_rows : 4) : 0;
         const int ntrig = ((cfg->model == MPC_MODEL_KINEMATIC_BICYCLE || cfg->model == MPC_MODEL_SIMPLE_CAR_FRONT) ? 4 : 3) +
                           (cfg->collocation == MPC_COLLOC_CRANK_NICOLSON ? 2 : 0);
-        s->WL = mpc::WaveLayout::make(cfg->n, M, O, cfg->max_vertices > 0 ? cfg->max_vertices : 1, ntrig, s->P64.n_via,
-                                        (O > 0 && (cfg->footprint_kind == MPC_FOOTPRINT_LINE || cfg->footprint_kind == MPC_FOOTPRINT_TWO_CIRCLES ||
-                                                   cfg->footprint_kind == MPC_FOOTPRINT_POLYGON || cfg->enable_dynamic_obstacles)) ? M : 0,
-                                        (O > 0 && cfg->enable_dynamic_obstacles) ? O : 0, solver_ext(s) ? mpc::NSTG_EXT : mpc::NSTG_BASE,
-                                        (O > 0 && cfg->enable_dynamic_obstacles && (cfg->footprint_kind == MPC_FOOTPRINT_LINE || cfg->footprint_kind == MPC_FOOTPRINT_TWO_CIRCLES ||
-                                                                                     cfg->footprint_kind == MPC_FOOTPRINT_POLYGON)) ? M : 0,
-                                        cfg->precision == MPC_FP32 ? 4 : 8);      // (MPC_MIXED has no clearance rows: both of its phases see the same layout)
+        auto layout = [&](bool gs) {
+            return mpc::WaveLayout::make(cfg->n, M, O, cfg->max_vertices > 0 ? cfg->max_vertices : 1, ntrig, s->P64.n_via,
+                                         (O > 0 && (cfg->footprint_kind == MPC_FOOTPRINT_LINE || cfg->footprint_kind == MPC_FOOTPRINT_TWO_CIRCLES ||
+                                                    cfg->footprint_kind == MPC_FOOTPRINT_POLYGON || cfg->enable_dynamic_obstacles)) ? M : 0,
+                                         (O > 0 && cfg->enable_dynamic_obstacles) ? O : 0, solver_ext(s) ? mpc::NSTG_EXT : mpc::NSTG_BASE,
+                                         (O > 0 && cfg->enable_dynamic_obstacles && (cfg->footprint_kind == MPC_FOOTPRINT_LINE || cfg->footprint_kind == MPC_FOOTPRINT_TWO_CIRCLES ||
+                                                                                      cfg->footprint_kind == MPC_FOOTPRINT_POLYGON)) ? M : 0,
+                                         cfg->precision == MPC_FP32 ? 4 : 8, gs);      // (MPC_MIXED has no clearance rows: both of its phases see the same layout)
+        };
+        s->WL = layout(false);
+        s->WLg = layout(true);
     }
-    s->wave_lds32 = ((((size_t)s->WL.total * 4) + 15) & ~(size_t)15) + 16 + ((sizeof(mpc::Problem<float>) + 15) & ~(size_t)15);
-    s->wave_lds = cfg->precision == MPC_FP32 ? s->wave_lds32
-                : ((((size_t)s->WL.total * 8) + 15) & ~(size_t)15) + 16 + ((sizeof(mpc::Problem<double>) + 15) & ~(size_t)15);
+    auto lds_of = [](const mpc::WaveLayout& L, size_t tsize, size_t psize) { return ((((size_t)L.total * tsize) + 15) & ~(size_t)15) + 16 + ((psize + 15) & ~(size_t)15); };
+    // Where the factorisation data lives, per precision.  The register file holds these kernels at one wave per SIMD, so a CU has room for four workgroups; an LDS record
+    // that fits fewer than four times leaves SIMDs without a wave.  Measured on the MI355X (profiles/r05_stage_data_probe.log): the global-memory form costs 5 % per
+    // solve at n = 80 / 120 and 19 % at n = 50 when both forms hold the same number of waves, and pays x2.0 - x2.6 at n = 120 in fp64 (1 -> 4 workgroups per CU), x1.15 at
+    // n = 80 with 16 polygons (2 -> 3).  MPC_STAGE_AUTO therefore takes it for fp64 when the LDS form leaves at least HALF of a CU's SIMDs empty and the global form fills
+    // more of them; fp32 keeps everything in LDS (3 -> 4 workgroups per CU at n = 120 measured 2 % slower; and the compiler contracts / packs the fp32 lane-parallel
+    // passes differently around global loads, so the two forms agree to rounding there, not bit for bit as in fp64).  The extended kernel levels exist in the LDS form only.
+    {
+        const bool can_gs = !solver_ext(s);
+        auto per_cu = [](size_t lds) { const size_t k = (160u * 1024u) / lds; return k > 4 ? (size_t)4 : k; };
+        auto choose = [&](size_t tsize, size_t psize) {
+            if (!can_gs || cfg->stage_data == MPC_STAGE_LDS) return false;
+            if (cfg->stage_data == MPC_STAGE_GLOBAL) return true;
+            const size_t a = lds_of(s->WL, tsize, psize), g = lds_of(s->WLg, tsize, psize);
+            if (a > 160u * 1024u) return g <= 160u * 1024u;           // only the global form fits at all
+            return tsize == 8 && per_cu(a) <= 2 && per_cu(g) > per_cu(a);
+        };
+        if (cfg->stage_data != MPC_STAGE_AUTO && cfg->stage_data != MPC_STAGE_LDS && cfg->stage_data != MPC_STAGE_GLOBAL) { set_err("mpc_create: unknown stage_data"); delete s; return MPC_EINVAL; }
+        if (cfg->stage_data == MPC_STAGE_GLOBAL && !can_gs) {
+            set_err("mpc_create: MPC_STAGE_GLOBAL exists for the headline kernel level only (no terminal ball, via-points, turning footprints, dynamic obstacles, convexified Hessian, cost variants)");
+            delete s; return MPC_EINVAL; }
+        s->gs32 = cfg->precision != MPC_FP64 && choose(4, sizeof(mpc::Problem<float>));
+        // (the refinement phase of MPC_MIXED -- one candidate, a handful of iterations -- measured faster in the LDS form: 9.0 against 9.4 ms for both phases at n = 120, B = 1024)
+        s->gs64 = cfg->precision != MPC_FP32 && (cfg->precision != MPC_MIXED || cfg->stage_data == MPC_STAGE_GLOBAL) && choose(8, sizeof(mpc::Problem<double>));
+    }
+    s->wave_lds32 = lds_of(s->gs32 ? s->WLg : s->WL, 4, sizeof(mpc::Problem<float>));
+    s->wave_lds = cfg->precision == MPC_FP32 ? s->wave_lds32 : lds_of(s->gs64 ? s->WLg : s->WL, 8, sizeof(mpc::Problem<double>));
     if (s->wave_lds > 160u * 1024u) {
         set_err("mpc_create: the working set of one instance (n, max_obstacles, max_vertices, precision) does not fit in the 160 KB of LDS "
-                "of a compute unit (about n <= 215 grid points in fp64 without obstacles)");
+                "of a compute unit (about n <= 215 grid points in fp64 without obstacles; n <= 590 with the factorisation data in global memory, which the extended kernel levels do not have)");
         delete s;
         return MPC_EINVAL;
     }
@@ -257,6 +290,11 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         if (er == hipSuccess) er = hipMemset(s->d_rows_dropped, 0, Bm * 4);
     }
     if (cfg->precision == MPC_MIXED && er == hipSuccess) er = hipMalloc((void**)&s->d_iters1, Bm * 4);
+    if (s->gs32 || s->gs64) {      // one block of factorisation data per workgroup of the largest launch (stale contents are never read: every word is written before it is read within a solve)
+        const size_t g32 = s->gs32 ? Bm * (size_t)(s->P32.n_cand > 1 ? s->P32.n_cand : 1) * (size_t)s->WLg.GSW * 4 : 0;
+        const size_t g64 = s->gs64 ? Bm * (size_t)(s->P64.n_cand > 1 ? s->P64.n_cand : 1) * (size_t)s->WLg.GSW * 8 : 0;
+        if (er == hipSuccess) er = hipMalloc(&s->d_gstage, g32 > g64 ? g32 : g64);
+    }
     if (cfg->dual_warm_start || cfg->precision == MPC_MIXED) {
         s->dual_words = mpc::IpmWave<double, 0, 0>::dual_words(s->WL.NS);
         if (er == hipSuccess) er = hipMalloc((void**)&s->d_dual, Bm * (size_t)s->dual_words * 8);
@@ -304,7 +342,7 @@ void mpc_destroy(mpc_solver* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    void* bufs[] = {s->d_stage, s->d_iters1, s->d_dual, s->d_rows_dropped, s->d_cwin, s->d_cexited, s->d_citsum, s->d_crec, s->d_winner, s->d_iters_total, s->d_nvia, s->d_via, s->d_ngrid, s->d_in, s->d_out};
+    void* bufs[] = {s->d_gstage, s->d_stage, s->d_iters1, s->d_dual, s->d_rows_dropped, s->d_cwin, s->d_cexited, s->d_citsum, s->d_crec, s->d_winner, s->d_iters_total, s->d_nvia, s->d_via, s->d_ngrid, s->d_in, s->d_out};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (s->h_in) (void)hipHostFree(s->h_in);
     if (s->h_out) (void)hipHostFree(s->h_out);
@@ -328,7 +366,9 @@ static hipError_t launch_model(mpc_solver* s, const mpc::Problem<T>& P, int B, c
     a.level = !solver_ext(s) ? 0 : (s->P64.costx ? 2 : 1);
     a.lds = sizeof(T) == 4 ? s->wave_lds32 : s->wave_lds;
     a.stream = s->stream;
-    a.L = s->WL; a.B = B;
+    const bool gs = sizeof(T) == 4 ? s->gs32 : s->gs64;
+    a.L = gs ? s->WLg : s->WL; a.B = B;
+    a.gstage = gs ? s->d_gstage : nullptr;
     a.x0 = x0; a.xf = xf; a.u_prev = up; a.dt_prev = dtp; a.x_init = xi; a.u_init = ui; a.dt_init = dti; a.obst = ob;
     a.n_grid = s->use_ngrid ? s->d_ngrid : nullptr; a.n_via = s->p_nvia; a.via = s->p_via;
     // kept multipliers: a launch starts from them under dual_warm_start; in MPC_MIXED without it the block is only the hand-off from the fp32 phase

@@ -45,7 +45,9 @@ constexpr int ST_LINESEARCH = 2;
 constexpr int ST_LINSOLVE = 3;
 constexpr int ST_NUMERICAL = 4;
 constexpr int ST_TIME_LIMIT = 5;      // MPC_TIME_LIMIT
-constexpr int ST_SUPERSEDED = 5;     // internal: a candidate stopped because a higher-priority candidate of its instance converged (never returned)
+constexpr int ST_SUPERSEDED = 1000;  // internal: a candidate stopped because a higher-priority candidate of its instance converged (never returned; outside the range of enum mpc_status)
+static_assert(ST_SUPERSEDED != ST_CONVERGED && ST_SUPERSEDED != ST_MAX_ITER && ST_SUPERSEDED != ST_LINESEARCH && ST_SUPERSEDED != ST_LINSOLVE && ST_SUPERSEDED != ST_NUMERICAL &&
+              ST_SUPERSEDED != ST_TIME_LIMIT, "the internal status must differ from every status a caller can see");
 
 // Problem description in device-friendly form (passed by value as a kernel argument).
 template <typename T>

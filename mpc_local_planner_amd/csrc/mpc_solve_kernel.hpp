@@ -36,7 +36,7 @@ constexpr int kWinIdle = 0x7f7f7f7f;
 
 // One wavefront = one (planner instance, candidate initial trajectory); the whole working set lives in LDS (mpc_wave.hpp).
 // Grid: n_cand * B workgroups, candidate-major, so that the hardware dispatches every instance's candidate 0 before any hedge.
-template <typename T, int MODEL, int EXT, bool OBST, int NSC = 0>
+template <typename T, int MODEL, int EXT, bool OBST, int NSC = 0, bool GS = false>
 __global__ __launch_bounds__(mpc::kWave)
 #ifdef MPC_WAVES_PER_EU      // developer experiment (scripts/dev/occupancy_probe.py): cap the register budget so that this many waves fit a SIMD
 __attribute__((amdgpu_waves_per_eu(MPC_WAVES_PER_EU, MPC_WAVES_PER_EU)))
@@ -47,7 +47,7 @@ void mpc_ipm_wave_kernel(
     const double* __restrict__ dt_prev, const double* __restrict__ x_init, const double* __restrict__ u_init,
     const double* __restrict__ dt_init, mpc_obstacles obst, const int32_t* __restrict__ n_grid, const int32_t* __restrict__ n_via,
     const double* __restrict__ via, CandCtl cc, const int32_t* __restrict__ iters_add, double* __restrict__ x_out,
-    double* __restrict__ u_out, double* __restrict__ dt_out, int32_t* __restrict__ status, int32_t* __restrict__ iters) {
+    double* __restrict__ u_out, double* __restrict__ dt_out, int32_t* __restrict__ status, int32_t* __restrict__ iters, void* gstage) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mpc_smem[];
     T* sm = reinterpret_cast<T*>(mpc_smem);
     // problem record at the end of the dynamic LDS block (16-byte aligned); the layout stays in scalar registers
@@ -77,7 +77,8 @@ void mpc_ipm_wave_kernel(
 #endif
         if (lane == 0) { *Ps = P; Ps->n = n; }
         __syncthreads();
-        mpc::IpmWave<T, MODEL, EXT, OBST, NSC> S(*Ps, Lv, sm, lane);
+        mpc::IpmWave<T, MODEL, EXT, OBST, NSC, GS> S(*Ps, Lv, sm, lane);
+        if constexpr (GS) S.gmb = reinterpret_cast<T*>(gstage) + (size_t)blockIdx.x * (size_t)L.GSW;      // this workgroup's block of factorisation data (GlobalStage)
         for (int i = 0; i < 3; ++i) { S.x0[i] = T(x0[3 * inst + i]); S.xf[i] = T(xf[3 * inst + i]); }
         S.x0[2] = mpc::normalize_theta(S.x0[2]);
         S.xf[2] = mpc::normalize_theta(S.xf[2]);
@@ -197,6 +198,7 @@ struct SolveLaunch {
     const int32_t* iters_add;
     double *x_out, *u_out, *dt_out;
     int32_t *status, *iters;
+    void* gstage;               // L.GSW > 0: the workgroups' blocks of factorisation data in global memory (grid x L.GSW words of T), else NULL
 };
 
 constexpr int kFixedLayoutNS = 50;
@@ -211,6 +213,11 @@ hipError_t launch_solve(const SolveLaunch& a, const Problem<T>& P) {
 #endif
     auto kern = a.level == 0 ? ((a.L.M > 0 || force_obst) ? mpc_ipm_wave_kernel<T, MODEL, 0, true> : mpc_ipm_wave_kernel<T, MODEL, 0, false>)
                              : (a.level == 2 ? mpc_ipm_wave_kernel<T, MODEL, 2, true> : mpc_ipm_wave_kernel<T, MODEL, 1, true>);
+    // factorisation data in global memory (WaveLayout::GSW > 0; mpc_capi.hip decides per handle and precision): the headline level's two instantiations exist in that form
+    if (a.L.GSW > 0) {
+        if (a.level != 0 || !a.gstage) return hipErrorInvalidConfiguration;
+        kern = (a.L.M > 0 || force_obst) ? mpc_ipm_wave_kernel<T, MODEL, 0, true, 0, true> : mpc_ipm_wave_kernel<T, MODEL, 0, false, 0, true>;
+    }
     // fp64 headline kernel on a grid of kFixedLayoutNS points per record (the grid size of BASELINE configs[1] / [3]): the instantiation whose LDS layout is a
     // compile-time constant (mpc_wave.hpp::FixedLayout) -- same code, same results bit for bit, ~3 % fewer instructions; every other size runs the generic one
     if constexpr (sizeof(T) == 8) {
@@ -220,14 +227,14 @@ hipError_t launch_solve(const SolveLaunch& a, const Problem<T>& P) {
         constexpr bool no_fixed = false;
 #endif
         using IW = IpmWave<T, MODEL, 0, false, kFixedLayoutNS>;
-        if (a.level == 0 && a.L.M == 0 && !force_obst && !no_fixed && IW::LayoutT::matches(a.L)) kern = mpc_ipm_wave_kernel<T, MODEL, 0, false, kFixedLayoutNS>;
+        if (a.level == 0 && a.L.M == 0 && a.L.GSW == 0 && !force_obst && !no_fixed && IW::LayoutT::matches(a.L)) kern = mpc_ipm_wave_kernel<T, MODEL, 0, false, kFixedLayoutNS>;
     }
     if (a.lds > 48u * 1024u) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.lds);
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)a.B * (unsigned)(P.n_cand > 1 ? P.n_cand : 1)), dim3(kWave), a.lds, a.stream, P, a.L, a.B, a.x0, a.xf, a.u_prev, a.dt_prev,
-                       a.x_init, a.u_init, a.dt_init, a.obst, a.n_grid, a.n_via, a.via, a.cc, a.iters_add, a.x_out, a.u_out, a.dt_out, a.status, a.iters);
+                       a.x_init, a.u_init, a.dt_init, a.obst, a.n_grid, a.n_via, a.via, a.cc, a.iters_add, a.x_out, a.u_out, a.dt_out, a.status, a.iters, a.gstage);
     return hipSuccess;
 }
 

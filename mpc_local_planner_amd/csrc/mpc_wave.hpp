@@ -20,6 +20,7 @@
 // reference citations of every formula.
 #pragma once
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include "mpc_core.hpp"
 #include "mpc_dpp_blocks.inc"
@@ -39,6 +40,21 @@ constexpr int NGAIN = 24;  // negated gains: nK0(6) nkappa0 nKnu0(5) | nK1(6) nk
                            // costate of (x, u_prev); the serial sweep and the last segment use the first 3 = the fixed goal components)
 constexpr int NGH = NGAIN / 2;
 
+// Factorisation data in global memory (IpmWave<..., GS = true>): what the Riccati sweeps stream through -- the stage records STG, the gains GAIN, and copies of
+// the little else their running pointers touch (the constant triples ZC, the residuals c_k, the folded residuals c^_k, a dummy store target) -- sits in ONE block of
+// global memory per workgroup, stage-major exactly like the LDS arrays it replaces, so that the sweeps' pointer arithmetic is the same in both storage classes.
+// The LDS record shrinks from 97 to 34 words per grid point (n = 120 in fp64: 95 KB -> 33 KB, four workgroups per CU instead of one); the block is written and
+// re-read by the same CU within one interior-point iteration (L2 / Infinity-Cache resident: 63 n words per resident wave).  Word offsets inside the block:
+struct GlobalStage {
+    static constexpr int ZC = 0;          // 8 words: constants 0 0 0 0 1 0 0 0
+    static constexpr int VP = 8;          // 16 words: dummy store targets of the idle lanes
+    static constexpr int CC = 32;         // 3 NS words, stage-major: c_k (copy of the LDS array, written by kkt_pass)
+    __host__ __device__ static constexpr int CH(int ns) { return CC + 3 * ns; }            // 3 NS words, component-major: c^_k = c_k + f_k dd (forward sweeps)
+    __host__ __device__ static constexpr int GAIN(int ns) { return CC + 6 * ns; }          // NGAIN NS words, stage-major
+    __host__ __device__ static constexpr int STG(int ns) { return CC + (6 + NGAIN) * ns; }    // nstg NS words, stage-major
+    __host__ __device__ static constexpr int words(int ns, int nstg) { return ((STG(ns) + nstg * ns + 15) / 16) * 16; }     // (128-byte multiple in fp64)
+};
+
 struct WaveLayout {
     int n, NS;
     int NTR;                                      // trig-cache words per stage (3, or 4 for the bicycle / front-wheel car; +2 for Crank-Nicolson)
@@ -51,8 +67,9 @@ struct WaveLayout {
     int OAD, OHXD, OHYD, OHDD, OHTD;              // dt parts when BOTH apply (dynamic obstacles + a turning footprint): gradient, hess [x dt, y dt, dt dt, theta dt]
     int GVEL;                                     // obstacle velocities (dynamic obstacles; 2 * OD words)
     int NV, VIA, VIDX;                            // via-points: capacity, poses (x, y, theta), attached grid point (-1 = skipped)
+    int GSW;                                      // > 0: the factorisation data (GAIN, STG) lives in a block of GSW words of GLOBAL memory per workgroup instead of LDS (IpmWave<..., GS = true>; GlobalStage below)
     // tsize = sizeof(T) of the kernel that uses the layout (the obstacle indices of the clearance rows are 16-bit words, M * n of them, packed into T-sized words)
-    __host__ __device__ static constexpr WaveLayout make(int n, int M = 0, int O = 0, int V = 1, int ntrig = 4, int NV = 0, int MT = 0, int OD = 0, int nstg = NSTG_BASE, int MD = 0, int tsize = 8) {
+    __host__ __device__ static constexpr WaveLayout make(int n, int M = 0, int O = 0, int V = 1, int ntrig = 4, int NV = 0, int MT = 0, int OD = 0, int nstg = NSTG_BASE, int MD = 0, int tsize = 8, bool gs = false) {
         WaveLayout L{};
         L.n = n;
         L.NS = n;
@@ -65,7 +82,8 @@ struct WaveLayout {
         L.PL = take(2); L.PU = take(2);
         L.DX = take(3); L.DU = take(2);
         L.CC = take(3); L.TRIG = take(ntrig);
-        L.GAIN = take(NGAIN); L.STG = take(nstg);
+        L.GAIN = take(gs ? 0 : NGAIN); L.STG = take(gs ? 0 : nstg);
+        L.GSW = gs ? GlobalStage::words(n, nstg) : 0;
         L.SC = o; o += 16;    // scalars: D, DT, DD, PDL, PDU | terminal-ball row: slack, multiplier, cached value and gradient
         L.VP = o; o += 16;    // dummy store targets of the idle lanes in the sweeps
         L.ZC = o; o += 8;     // constants 0 0 0 0 1 0 0 0 (coefficient triples of the constant columns)
@@ -190,17 +208,20 @@ __device__ __forceinline__ float lane_bcast(float v, int src) {
 // OBST = false compiles every clearance-row path out (solvers created without obstacles: the headline configurations): less code, and the two dozen layout
 // words of the obstacle arrays leave the scalar registers (the headline kernel spilled ~430 of them)
 // NSC > 0: the layout is a compile-time constant for the stride NS = NSC (FixedLayout; needs EXT == 0, OBST == false, no Crank-Nicolson trig words)
-template <typename T, int MODEL, int EXT = 1, bool OBST = true, int NSC = 0>
+// GS: the factorisation data (STG, GAIN) in global memory instead of LDS (GlobalStage): same arithmetic, same results bit for bit, a third of the LDS record
+template <typename T, int MODEL, int EXT = 1, bool OBST = true, int NSC = 0, bool GS = false>
 struct IpmWave {
     static constexpr int NSTG = EXT ? NSTG_EXT : NSTG_BASE;        // words per stage record
     // trig-cache words per stage: sin, cos, steering term(s); Crank-Nicolson appends sin/cos of its second evaluation angle
     static constexpr int NTRB = (MODEL == MODEL_KINEMATIC_BICYCLE || MODEL == MODEL_SIMPLE_CAR_FRONT) ? 4 : 3;
     static_assert(NSC == 0 || (EXT == 0 && !OBST), "the fixed layout exists for the headline instantiation only");
+    static_assert(!GS || NSC == 0, "the fixed layout keeps its factorisation data in LDS");
     using LayoutT = typename LayoutOf<NSC, NTRB, NSTG>::type;
     const Problem<T>& P;     // lives in LDS (copied once per workgroup): wave-uniform constants are fetched with
     const LayoutT L;         // broadcast ds_reads instead of being pinned in (and spilled from) scalar registers; the layout
                              // (45 small ints, used by every accessor) is held by value = in scalar registers -- or is a compile-time constant (NSC > 0)
     T* sm;
+    T* gmb = nullptr;        // GS: this workgroup's block of global memory (GlobalStage), wave-uniform
     const int lane;
     T x0[3], xf[3], uprev[2], dtprev;
     T mu, rho, delta_last;
@@ -227,10 +248,18 @@ struct IpmWave {
     // ---- LDS accessors: component-major, stage-minor (conflict-free for lane == stage)
     __device__ __forceinline__ T& F(int base, int comp, int k) const { return sm[base + comp * L.NS + k]; }
     // stage-major records
-    __device__ __forceinline__ T& G_(int i, int k) const { return sm[L.GAIN + k * NGAIN + i]; }
+    // (GS: the same records in the workgroup's global block -- byte offsets are formed in 32 bits and zero-extended, so that the accesses compile to
+    //  global_load / global_store with the block's base in a scalar register pair and constant parts in the immediate offset)
+    typedef __attribute__((address_space(1))) T GlbT;
+    typedef __attribute__((address_space(1))) char GlbC;
+    using SwT = std::conditional_t<GS, GlbT, T>;                         // a word of the sweeps' storage class
+    __device__ __forceinline__ GlbT& gw(unsigned word) const { return *(GlbT*)((GlbC*)gmb + (size_t)(word * (unsigned)sizeof(T))); }
+    __device__ __forceinline__ SwT& G_(int i, int k) const { if constexpr (GS) return gw((unsigned)(GlobalStage::GAIN(L.NS) + k * NGAIN + i)); else return sm[L.GAIN + k * NGAIN + i]; }
     static constexpr int NADDv = EXT ? (int)NADD : (int)NADD_BASE;
-    __device__ __forceinline__ T& S_(int i, int k) const { return sm[L.STG + k * NSTG + i]; }
+    __device__ __forceinline__ SwT& S_(int i, int k) const { if constexpr (GS) return gw((unsigned)(GlobalStage::STG(L.NS) + k * NSTG + i)); else return sm[L.STG + k * NSTG + i]; }
     __device__ __forceinline__ T& C_(int i, int k) const { return sm[L.CC + k * 3 + i]; }
+    // c^_k = c_k + f_k dd, what the forward sweeps read (component-major): parked in LAMN, or (GS) in the global block
+    __device__ __forceinline__ SwT& CH_(int i, int k) const { if constexpr (GS) return gw((unsigned)(GlobalStage::CH(L.NS) + i * L.NS + k)); else return sm[L.LAMN + i * L.NS + k]; }
     __device__ __forceinline__ T& SCL(int i) const { return sm[L.SC + i]; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
     __device__ __forceinline__ int nM() const { return OBST ? L.M : 0; }      // clearance rows per grid point
@@ -275,6 +304,22 @@ struct IpmWave {
     // explicit LDS pointers for the running-pointer loops (address-space inference gives up on per-lane selected pointers)
     typedef __attribute__((address_space(3))) T LdsT;
     __device__ __forceinline__ LdsT* lds(int word) const { return (LdsT*)sm + word; }
+    // ---- running pointers of the sweeps, in the sweeps' storage class: an LDS pointer, or (GS) a BYTE offset into the workgroup's global block.  W_*(): where the
+    //      regions the sweeps stream through start (word index in that storage class); sw_step(): a stride in the units such a pointer advances by
+    using SwRef = std::conditional_t<GS, unsigned, LdsT*>;
+    using SwCRef = std::conditional_t<GS, unsigned, const LdsT*>;
+    __device__ __forceinline__ int W_ZC() const { if constexpr (GS) return GlobalStage::ZC; else return L.ZC; }
+    __device__ __forceinline__ int W_VP() const { if constexpr (GS) return GlobalStage::VP; else return L.VP; }
+    __device__ __forceinline__ int W_CC() const { if constexpr (GS) return GlobalStage::CC; else return L.CC; }
+    __device__ __forceinline__ int W_CH() const { if constexpr (GS) return GlobalStage::CH(L.NS); else return L.LAMN; }      // c^_k of the forward sweeps (LDS: parked in LAMN)
+    __device__ __forceinline__ int W_GAIN() const { if constexpr (GS) return GlobalStage::GAIN(L.NS); else return L.GAIN; }
+    __device__ __forceinline__ int W_STG() const { if constexpr (GS) return GlobalStage::STG(L.NS); else return L.STG; }
+    __device__ __forceinline__ SwRef sw(int word) const { if constexpr (GS) return (unsigned)word * (unsigned)sizeof(T); else return lds(word); }
+    __device__ __forceinline__ static constexpr int sw_step(int words) { return GS ? words * (int)sizeof(T) : words; }
+    // word i (a compile-time constant at every call site) behind a running pointer / the word `step` pointer units behind it
+    __device__ __forceinline__ T sw_ld(SwCRef p, int i = 0) const { if constexpr (GS) return *(const GlbT*)((const GlbC*)gmb + (size_t)p + (size_t)(i * (int)sizeof(T))); else return p[i]; }
+    __device__ __forceinline__ T sw_ld_at(SwCRef p, int step) const { if constexpr (GS) return *(const GlbT*)((const GlbC*)gmb + (size_t)(p + (unsigned)step)); else return p[step]; }
+    __device__ __forceinline__ void sw_st(SwRef p, int i, T v) const { if constexpr (GS) *(GlbT*)((GlbC*)gmb + (size_t)p + (size_t)(i * (int)sizeof(T))) = v; else p[i] = v; }
 
     // trial point z + alpha*dz, evaluated on the fly (no trial copy in LDS)
     // (alpha == 0 must not touch the step arrays: they are unwritten before the first factorisation, and 0 * garbage can be NaN)
@@ -1063,6 +1108,7 @@ struct IpmWave {
                 if (k > 0) rdd -= slot_sign<T>(q) * P.rate_lim[q] * y;
             }
             if (k < n - 1) {
+                if constexpr (GS) { for (int i = 0; i < 3; ++i) gw((unsigned)(GlobalStage::CC + 3 * k + i)) = C_(i, k); }      // c_k where the sweeps' pointers live
                 S_(0, k) = rec[0]; S_(1, k) = rec[1]; S_(2, k) = T(1);                 // column 2 of Ghat: (a0, a1, 1)
                 S_(3, k) = rec[2]; S_(4, k) = rec[3]; S_(5, k) = rec[4];
                 for (int a = 0; a < 3; ++a) { S_(6 + a, k) = rec[5 + a]; S_(9 + a, k) = rec[8 + a]; }   // Bx column-major
@@ -1322,27 +1368,28 @@ struct IpmWave {
 #endif
         const int n = L.n;
         const T d = SCL(SC_D);
-        const int ZC = L.ZC;                            // constants 0 0 0 0 1 0 0 0 (written once per solve): (0,0,0) @0, (0,1,0) @3, (1,0,0) @4
+        const int ZC = W_ZC();                          // constants 0 0 0 0 1 0 0 0 (written once per solve): (0,0,0) @0, (0,1,0) @3, (1,0,0) @4
         const int c = lane & 15;                    // column owned by this lane (12..15 idle: they carry zeros)
         const bool act = c < 12;
         // coefficient triple of column c: three consecutive words, running pointer (stride 0 for the constant triples).
         // kind: 0 (0,0,0)  1 (1,0,0)  2 (0,1,0)  3 (a0,a1,1)  4 f  5 Bx[:,0]  6 Bx[:,1]  7 c_k   -- columns 0..11, 3 bits each
         constexpr unsigned long long KIND = 1ull | (2ull << 3) | (3ull << 6) | (4ull << 15) | (5ull << 18) | (6ull << 21) | (7ull << 24);
         const int kind = act ? (int)((KIND >> (3 * c)) & 7) : 0;
-        const int gb = kind < 3 ? ZC + (kind == 1 ? 4 : (kind == 2 ? 3 : 0)) : (kind < 7 ? L.STG + 3 * (kind - 3) : L.CC);
-        const int gs = kind < 3 ? 0 : (kind < 7 ? NSTG : 3);
-        const LdsT* gp = lds(gb + (n - 2) * gs);
-        const LdsT* ap[8];
+        const int gb = kind < 3 ? ZC + (kind == 1 ? 4 : (kind == 2 ? 3 : 0)) : (kind < 7 ? W_STG() + 3 * (kind - 3) : W_CC());
+        const int gsw = kind < 3 ? 0 : (kind < 7 ? NSTG : 3);
+        const int gs = sw_step(gsw);
+        SwCRef gp = sw(gb + (n - 2) * gsw);
+        SwCRef ap[8];
         int as_[8];
         constexpr unsigned long long rows[8] = {stage_add_row(0, EXT), stage_add_row(1, EXT), stage_add_row(2, EXT), stage_add_row(3, EXT),
                                                 stage_add_row(4, EXT), stage_add_row(5, EXT), stage_add_row(6, EXT), stage_add_row(7, EXT)};
         const int sh = act ? 5 * c : 60;               // idle lanes: shift the row word out (slot -1)
-        const int abase = L.STG + RA - 1 + (n - 2) * NSTG;
+        const int abase = W_STG() + RA - 1 + (n - 2) * NSTG;
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
             const int slot1 = (int)((rows[r] >> sh) & 31);       // slot + 1, 0 = structurally zero
-            as_[r] = slot1 ? NSTG : 0;
-            ap[r] = lds(slot1 ? abase + slot1 : ZC);
+            as_[r] = sw_step(slot1 ? NSTG : 0);
+            ap[r] = sw(slot1 ? abase + slot1 : ZC);
         }
         const T ec = (c == 5 || (c >= 8 && c < 12)) ? T(1) : T(0);       // own column enters T1 (dt, p, S)
         const T E3 = c == 6 ? T(1) : T(0), E4 = c == 7 ? T(1) : T(0);     // the u columns pick up the u_prev columns of V+
@@ -1351,12 +1398,12 @@ struct IpmWave {
         // negated gains go to GAIN as [nK0 (cols 0..5) | nkappa0 | nKnu0 (3 of 5) | nK1 ... ] : g1 = g0 + NGH; idle lanes hit a dummy pair
         const bool wrG = lane < 12 && c != 6 && c != 7;
         const int g0 = c < 6 ? c : (c == 8 ? 6 : 7 + (c - 9));
-        LdsT* kp = lds(wrG ? L.GAIN + g0 + (n - 2) * NGAIN : L.VP);      // idle lanes: dummy pair in the scratch area
-        const int ks = wrG ? NGAIN : 0;
+        SwRef kp = sw(wrG ? W_GAIN() + g0 + (n - 2) * NGAIN : W_VP());      // idle lanes: dummy pair in the scratch area
+        const int ks = sw_step(wrG ? NGAIN : 0);
         // ---- terminal value function, straight into the owning lanes' registers (rows 3..5: the u_prev / dt entries of the
         //      final rate rows = the A slots (i, c) of stage n-1 for c in {3, 4, 5, 8})
         T V[6];
-        terminal_value(V, c, delta, d, ap[3][as_[3]], ap[4][as_[4]], ap[5][as_[5]]);       // rows 3..5: one stage above the running pointers
+        terminal_value(V, c, delta, d, sw_ld_at(ap[3], as_[3]), sw_ld_at(ap[4], as_[4]), sw_ld_at(ap[5], as_[5]));       // rows 3..5: one stage above the running pointers
         T add_dd0 = T(0), add_qd0 = T(0);
         if (mintime()) add_qd0 += T(n - 1);
         if (dtf()) {
@@ -1370,10 +1417,10 @@ struct IpmWave {
         T worst = T(1);                                                   // min over the stages of |det R| - 1e-14 * scale
         int negc = 0;                                                     // negative eigenvalues of the control pivots = sign changes of (1, R00, det R), summed over the stages
         auto load_stage = [&](T (&g)[3], T (&a)[8]) {                     // reads the stage the running pointers are at, then steps them
-            g[0] = gp[0]; g[1] = gp[1]; g[2] = gp[2];
+            g[0] = sw_ld(gp, 0); g[1] = sw_ld(gp, 1); g[2] = sw_ld(gp, 2);
             gp -= gs;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) { a[r] = *ap[r]; ap[r] -= as_[r]; }
+            for (int r = 0; r < 8; ++r) { a[r] = sw_ld(ap[r]); ap[r] -= as_[r]; }
         };
         auto stage = [&](T dk0, T dk1, T dk2, T s5, T (&G)[3], T (&A)[8], T (&Gn)[3], T (&An)[8]) {
             load_stage(Gn, An);                                           // prefetch of the next stage (k - 1)
@@ -1414,7 +1461,7 @@ struct IpmWave {
             const T nid = -fast_rcp(det);
             const T nRi00 = R11 * nid, Ri01 = -(R01 * nid), nRi11 = R00 * nid;  // -R^-1 = [nRi00 Ri01; Ri01 nRi11]
             const T nK0 = nRi00 * h[6] + Ri01 * h[7], nK1 = Ri01 * h[6] + nRi11 * h[7];
-            kp[0] = nK0; kp[NGH] = nK1;
+            sw_st(kp, 0, nK0); sw_st(kp, NGH, nK1);
             kp -= ks;
             // W[a][b] -= Su[:,a]' Knu[:,b] in lane 9+b, omega[a] -= Su[:,a]' kappa in lane 8 (Su[j][a] = Hhat[6+j][9+a]);
             // V = Hhat_xx + Hhat_xu nK   (row i of Hhat[:,6:8] = lane i's Hhat[6:8][.])
@@ -1523,7 +1570,7 @@ struct IpmWave {
         for (int k = lane; k < n - 1; k += kWave) {
             for (int a = 0; a < 2; ++a)
                 G_(NGH * a + 6, k) += G_(NGH * a + 7, k) * nu[0] + G_(NGH * a + 8, k) * nu[1] + G_(NGH * a + 9, k) * nu[2] + G_(NGH * a + 5, k) * dd;
-            for (int i = 0; i < 3; ++i) F(L.LAMN, i, k) = C_(i, k) + S_(3 + i, k) * dd;
+            for (int i = 0; i < 3; ++i) CH_(i, k) = C_(i, k) + S_(3 + i, k) * dd;
         }
         if (lane == 0) { SCL(SC_DD) = dd; F(L.DX, 0, 0) = T(0); F(L.DX, 1, 0) = T(0); F(L.DX, 2, 0) = T(0); }
         sync();
@@ -1533,31 +1580,31 @@ struct IpmWave {
         //      i.e. 7 DPP-broadcast FMAs; the 8 per-lane coefficients are prefetched one stage ahead through running pointers.
         {
             const int c = lane & 15;
-            const int ZC = L.ZC;
+            const int ZC = W_ZC();
             int qw[8], qs[8];        // word index and stride of: cst, q0..q4, b0, b1
 #pragma unroll
             for (int j = 0; j < 8; ++j) { qw[j] = ZC; qs[j] = 0; }
             if (c < 3) {
-                qw[0] = L.LAMN + c * L.NS; qs[0] = 1;
+                qw[0] = W_CH() + c * L.NS; qs[0] = 1;
                 qw[1 + c] = ZC + 4;                                          // xi[c] itself
-                if (c < 2) { qw[3] = L.STG + c; qs[3] = NSTG; }              // a_c * xi[2]
-                qw[6] = L.STG + 6 + c; qs[6] = NSTG;
-                qw[7] = L.STG + 9 + c; qs[7] = NSTG;
+                if (c < 2) { qw[3] = W_STG() + c; qs[3] = NSTG; }            // a_c * xi[2]
+                qw[6] = W_STG() + 6 + c; qs[6] = NSTG;
+                qw[7] = W_STG() + 9 + c; qs[7] = NSTG;
             } else if (c < 5) {
                 const int a = c - 3;
-                qw[0] = L.GAIN + NGH * a + 6; qs[0] = NGAIN;
+                qw[0] = W_GAIN() + NGH * a + 6; qs[0] = NGAIN;
 #pragma unroll
-                for (int j = 0; j < 5; ++j) { qw[1 + j] = L.GAIN + NGH * a + j; qs[1 + j] = NGAIN; }
+                for (int j = 0; j < 5; ++j) { qw[1 + j] = W_GAIN() + NGH * a + j; qs[1 + j] = NGAIN; }
             }
-            const LdsT* qp[8];
+            SwCRef qp[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) qp[j] = lds(qw[j]);
+            for (int j = 0; j < 8; ++j) { qp[j] = sw(qw[j]); qs[j] = sw_step(qs[j]); }
             // where the result goes: dx_{k+1}[c] / du_k[c-3]; idle lanes write a dummy word of the sweep scratch
             LdsT* op = lds(c < 3 ? L.DX + c * L.NS + 1 : (c < 5 ? L.DU + (c - 3) * L.NS : L.VP + 12));
             const int os = c < 5 ? 1 : 0;
             auto load_q = [&](T (&q)[8]) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { q[j] = *qp[j]; qp[j] += qs[j]; }
+                for (int j = 0; j < 8; ++j) { q[j] = sw_ld(qp[j]); qp[j] += qs[j]; }
             };
             T xi = T(0);
             auto stage = [&](T (&q)[8], T (&qn)[8]) {
@@ -1806,35 +1853,36 @@ struct IpmWave {
     __device__ __forceinline__ int backward_pit(T delta, T dc, T& dd_out, T nu_out[3]) const {
         const int n = L.n, N = n - 1, Lm = N >> 2, rem = N - 4 * Lm;
         const T d = SCL(SC_D);
-        const int ZC = L.ZC;
+        const int ZC = W_ZC();
         const int ll = local_lane();
         const int c = ll & 15, row = ll >> 4;
         // columns: 0..5 P, 6 7 the u columns of Hhat, 8 p, 9..13 border (row 3: 9..11 = the fixed goal components), 14 the dt border column, 15 idle
         constexpr unsigned long long KIND = 1ull | (2ull << 3) | (3ull << 6) | (4ull << 15) | (5ull << 18) | (6ull << 21) | (7ull << 24);
         const int kind = c < 12 ? (int)((KIND >> (3 * c)) & 7) : 0;
-        const int gb = kind < 3 ? ZC + (kind == 1 ? 4 : (kind == 2 ? 3 : 0)) : (kind < 7 ? L.STG + 3 * (kind - 3) : L.CC);
-        const int gs = kind < 3 ? 0 : (kind < 7 ? NSTG : 3);
+        const int gb = kind < 3 ? ZC + (kind == 1 ? 4 : (kind == 2 ? 3 : 0)) : (kind < 7 ? W_STG() + 3 * (kind - 3) : W_CC());
+        const int gsw = kind < 3 ? 0 : (kind < 7 ? NSTG : 3);
+        const int gs = sw_step(gsw);
         constexpr unsigned long long rows[8] = {stage_add_row(0, EXT), stage_add_row(1, EXT), stage_add_row(2, EXT), stage_add_row(3, EXT),
                                                 stage_add_row(4, EXT), stage_add_row(5, EXT), stage_add_row(6, EXT), stage_add_row(7, EXT)};
         const int sh = c < 12 ? 5 * c : 60;
         int slot1[8], as_[8];
 #pragma unroll
-        for (int r = 0; r < 8; ++r) { slot1[r] = (int)((rows[r] >> sh) & 31); as_[r] = slot1[r] ? NSTG : 0; }
+        for (int r = 0; r < 8; ++r) { slot1[r] = (int)((rows[r] >> sh) & 31); as_[r] = sw_step(slot1[r] ? NSTG : 0); }
         const T ec = (c == 5 || (c >= 8 && c < 15)) ? T(1) : T(0);
         const T E3 = c == 6 ? T(1) : T(0), E4 = c == 7 ? T(1) : T(0);
         const T dA0 = c == 0 ? delta : T(0), dA1 = c == 1 ? delta : T(0), dA2 = c == 2 ? delta : T(0);
         const T dA6 = c == 6 ? delta : T(0), dA7 = c == 7 ? delta : T(0);
         const bool wrG = c < 14 && c != 6 && c != 7;                       // every row stores the gains of its own stages
         const int g0 = c < 6 ? c : (c == 8 ? 6 : 7 + (c - 9));
-        const LdsT* gp;
-        const LdsT* ap[8];
-        LdsT* kp;
-        const int ks = wrG ? NGAIN : 0;
+        SwCRef gp;
+        SwCRef ap[8];
+        SwRef kp;
+        const int ks = sw_step(wrG ? NGAIN : 0);
         auto point_at = [&](int k) {                                      // running pointers at stage k (per lane)
-            gp = lds(gb + k * gs);
+            gp = sw(gb + k * gsw);
 #pragma unroll
-            for (int r = 0; r < 8; ++r) ap[r] = lds(slot1[r] ? L.STG + RA - 1 + slot1[r] + k * NSTG : ZC);
-            kp = lds(wrG ? L.GAIN + g0 + k * NGAIN : L.VP);
+            for (int r = 0; r < 8; ++r) ap[r] = sw(slot1[r] ? W_STG() + RA - 1 + slot1[r] + k * NSTG : ZC);
+            kp = sw(wrG ? W_GAIN() + g0 + k * NGAIN : W_VP());
         };
         T V[6], wn[5] = {T(0), T(0), T(0), T(0), T(0)}, om = T(0);
         {
@@ -1856,10 +1904,10 @@ struct IpmWave {
         T worst = T(1);
         int negc = 0, negc_rem = 0;                                       // negative eigenvalues of the control pivots: this row's segment / the leftover stages all rows sweep together
         auto load_stage = [&](T (&g)[3], T (&a)[8]) {
-            g[0] = gp[0]; g[1] = gp[1]; g[2] = gp[2];
+            g[0] = sw_ld(gp, 0); g[1] = sw_ld(gp, 1); g[2] = sw_ld(gp, 2);
             gp -= gs;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) { a[r] = *ap[r]; ap[r] -= as_[r]; }
+            for (int r = 0; r < 8; ++r) { a[r] = sw_ld(ap[r]); ap[r] -= as_[r]; }
         };
         auto stage = [&](T dk0, T dk1, T dk2, T s5, T (&G)[3], T (&A)[8], T (&Gn)[3], T (&An)[8]) {
             load_stage(Gn, An);
@@ -1880,7 +1928,7 @@ struct IpmWave {
             const T nid = -fast_rcp(det);
             const T nRi00 = R11 * nid, Ri01 = -(R01 * nid), nRi11 = R00 * nid;
             const T nK0 = nRi00 * h[6] + Ri01 * h[7], nK1 = Ri01 * h[6] + nRi11 * h[7];
-            kp[0] = nK0; kp[NGH] = nK1;
+            sw_st(kp, 0, nK0); sw_st(kp, NGH, nK1);
             kp -= ks;
             V[0] = h[0]; V[1] = h[1]; V[2] = h[2]; V[3] = h[3]; V[4] = h[4]; V[5] = h[5];
             MPC_DPP_BLOCK_V5
@@ -2048,36 +2096,36 @@ struct IpmWave {
             for (int a = 0; a < 2; ++a)
                 G_(NGH * a + 6, k) += G_(NGH * a + 7, k) * m5[0] + G_(NGH * a + 8, k) * m5[1] + G_(NGH * a + 9, k) * m5[2] + G_(NGH * a + 10, k) * m5[3] + G_(NGH * a + 11, k) * m5[4] +
                                       G_(NGH * a + 5, k) * dd;
-            for (int i = 0; i < 3; ++i) F(L.LAMN, i, k) = C_(i, k) + S_(3 + i, k) * dd;
+            for (int i = 0; i < 3; ++i) CH_(i, k) = C_(i, k) + S_(3 + i, k) * dd;
         }
         if (lane == 0) { SCL(SC_DD) = dd; F(L.DX, 0, 0) = T(0); F(L.DX, 1, 0) = T(0); F(L.DX, 2, 0) = T(0); }
         sync();
         // ---- the four segments at once: row s carries (dx, du_prev) through its stages, starting from its boundary state
         {
-            const int ZC = L.ZC, k0 = row * Lm;
+            const int ZC = W_ZC(), k0 = row * Lm;
             int qw[8], qs[8];
 #pragma unroll
             for (int j = 0; j < 8; ++j) { qw[j] = ZC; qs[j] = 0; }
             if (c < 3) {
-                qw[0] = L.LAMN + c * L.NS; qs[0] = 1;
+                qw[0] = W_CH() + c * L.NS; qs[0] = 1;
                 qw[1 + c] = ZC + 4;
-                if (c < 2) { qw[3] = L.STG + c; qs[3] = NSTG; }
-                qw[6] = L.STG + 6 + c; qs[6] = NSTG;
-                qw[7] = L.STG + 9 + c; qs[7] = NSTG;
+                if (c < 2) { qw[3] = W_STG() + c; qs[3] = NSTG; }
+                qw[6] = W_STG() + 6 + c; qs[6] = NSTG;
+                qw[7] = W_STG() + 9 + c; qs[7] = NSTG;
             } else if (c < 5) {
                 const int a = c - 3;
-                qw[0] = L.GAIN + NGH * a + 6; qs[0] = NGAIN;
+                qw[0] = W_GAIN() + NGH * a + 6; qs[0] = NGAIN;
 #pragma unroll
-                for (int j = 0; j < 5; ++j) { qw[1 + j] = L.GAIN + NGH * a + j; qs[1 + j] = NGAIN; }
+                for (int j = 0; j < 5; ++j) { qw[1 + j] = W_GAIN() + NGH * a + j; qs[1 + j] = NGAIN; }
             }
-            const LdsT* qp[8];
+            SwCRef qp[8];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) qp[j] = lds(qw[j] + qs[j] * k0);
+            for (int j = 0; j < 8; ++j) { qp[j] = sw(qw[j] + qs[j] * k0); qs[j] = sw_step(qs[j]); }
             int os = c < 5 ? 1 : 0;
             LdsT* op = lds((c < 3 ? L.DX + c * L.NS + 1 : (c < 5 ? L.DU + (c - 3) * L.NS : L.VP + 12)) + os * k0);
             auto load_q = [&](T (&q)[8]) {
 #pragma unroll
-                for (int j = 0; j < 8; ++j) { q[j] = *qp[j]; qp[j] += qs[j]; }
+                for (int j = 0; j < 8; ++j) { q[j] = sw_ld(qp[j]); qp[j] += qs[j]; }
             };
             T xi = xi_row;
             auto stage = [&](T (&q)[8], T (&qn)[8]) {
@@ -2561,6 +2609,7 @@ struct IpmWave {
         row0_on = dtprev != T(0);
         if (iter_cap <= 0) iter_cap = P.max_iter;
         if (lane < 8) sm[L.ZC + lane] = lane == 4 ? T(1) : T(0);      // constant coefficient triples of the sweeps
+        if constexpr (GS) { if (lane < 8) gw((unsigned)(GlobalStage::ZC + lane)) = lane == 4 ? T(1) : T(0); }      // ... and their copy where the sweeps' pointers live
         if (lane < 12) sm[L.ZI + lane] = lane == 6 ? T(1) : T(0);     // unit vectors / zeros of the partitioned sweep's combine step
         const bool pit = pit_enabled();
         init_point();

@@ -434,21 +434,32 @@ def test_mixed_grid_sizes_in_one_batch(m):
 
 
 def test_lds_working_set_and_workgroups_per_cu_of_the_baseline_configs(m):
-    """mpc_lds_bytes: the working set of one instance = the dynamic LDS of its workgroup; what the 160 KB of a compute unit hold decides how many wavefronts a CU
-    runs: 4 at BASELINE configs[1] / [3] (n = 50, fp64), 2 at configs[2] (n = 80, 16 polygons of 6 vertices, four clearance rows per grid point: since the rows'
-    obstacle indices are 16-bit words; 1 before), 3 in plain fp32 at configs[4] (n = 120), 2 for n = 80 without obstacles."""
+    """mpc_lds_bytes: the working set of one instance in LDS = the dynamic LDS of its workgroup; what the 160 KB of a compute unit hold decides how many wavefronts a
+    CU runs (four at most: the register file holds the kernel at one wave per SIMD).  Everything in LDS (MPC_STAGE_LDS, rounds 1-4): 4 at BASELINE configs[1] / [3]
+    (n = 50, fp64), 2 at configs[2] (n = 80, 16 polygons of 6 vertices, four clearance rows per grid point), 3 in plain fp32 at configs[4] (n = 120), 1 in fp64 there.
+    r05, MPC_STAGE_AUTO: with the factorisation data in global memory where the LDS form leaves half of the SIMDs empty, 3 at configs[2] and 4 at n = 120 in fp64;
+    the headline grid, fp32 and the refinement phase of MPC_MIXED keep the LDS form."""
+    from mpc_local_planner_amd import _abi as A
     CU = 160 * 1024
     def wgs(cfg):
         s = m.BatchSolver(cfg, max_batch=4)
         b = s.lds_bytes()
         s.close()
-        return CU // b, b
-    assert wgs(m.config_carlike_min_time(50))[0] == 4
-    w3, b3 = wgs(m.config_unicycle_quadratic(80, max_obstacles=16, max_vertices=6, max_obstacle_rows=4))
+        return min(4, CU // b), b
+    lds = dict(stage_data=A.STAGE_LDS)
+    assert wgs(m.config_carlike_min_time(50))[0] == 4 and wgs(m.config_carlike_min_time(50))[1] == wgs(m.config_carlike_min_time(50, **lds))[1]
+    w3, b3 = wgs(m.config_unicycle_quadratic(80, max_obstacles=16, max_vertices=6, max_obstacle_rows=4, **lds))
     assert w3 == 2, b3
-    assert wgs(m.config_unicycle_quadratic(80))[0] == 2
+    w3, b3 = wgs(m.config_unicycle_quadratic(80, max_obstacles=16, max_vertices=6, max_obstacle_rows=4))
+    assert w3 == 3, b3
+    assert wgs(m.config_unicycle_quadratic(80, **lds))[0] == 2 and wgs(m.config_unicycle_quadratic(80))[0] == 4
     assert wgs(m.config_bicycle_min_time(120, precision=1, tol=1e-4))[0] == 3
-    assert wgs(m.config_bicycle_min_time(120))[0] == 1
+    assert wgs(m.config_bicycle_min_time(120, **lds))[0] == 1 and wgs(m.config_bicycle_min_time(120))[0] == 4
+    assert wgs(m.config_bicycle_min_time(120, precision=A.MIXED))[0] == 1          # the short refinement phase measured faster in the LDS form
+    # grids beyond the LDS form's ~215 points exist in the global form
+    assert wgs(m.config_bicycle_min_time(300))[0] == 1
+    with pytest.raises(Exception):
+        m.BatchSolver(m.config_bicycle_min_time(300, **lds), max_batch=4)
 
 
 def test_fixed_layout_kernel_equals_the_generic_kernel_bit_for_bit(m):
@@ -469,6 +480,65 @@ def test_fixed_layout_kernel_equals_the_generic_kernel_bit_for_bit(m):
         assert (ra.status == 0).mean() > 0.9
         assert np.array_equal(ra.status, rb.status) and np.array_equal(ra.iters, rb.iters) and np.array_equal(ra.dt, rb.dt)
         assert np.array_equal(ra.x, rb.x[:, :50]) and np.array_equal(ra.u[:, :49], rb.u[:, :49])
+
+
+@pytest.mark.parametrize("case", ["bicycle_n120_fp64_candidates", "bicycle_n120_mixed", "unicycle_n80_polygons", "carlike_n50_candidates", "carlike_n30_ragged_fp32"])
+def test_factorisation_data_in_global_memory_equals_lds_bit_for_bit(m, case):
+    """mpc_config.stage_data: the stage records and Riccati gains of a solve (63 of the 97 words per grid point) live in LDS or in a per-workgroup block of
+    global memory (mpc_wave.hpp::GlobalStage; what MPC_STAGE_AUTO picks when the smaller LDS record puts more workgroups on a CU: n = 120 in fp64 1 -> 4,
+    n = 80 with 16 polygons 2 -> 3).  Same arithmetic on the same numbers: trajectories, controls, dt, statuses and iteration counts must be equal bit for bit,
+    in every precision, with candidates, with clearance rows, and on ragged grids -- and MPC_STAGE_AUTO must be one of the two."""
+    from mpc_local_planner_amd import _abi as A
+    obstacles, sizes = None, None
+    if case == "bicycle_n120_fp64_candidates":
+        B, mk = 512, lambda **k: m.config_bicycle_min_time(120, candidates=(0, 1, 2, 5), candidate_max_iter=(60, 50, 45, 40), candidate_param=(0.0, 0.0, 0.0, 2.0), **k)
+        inp = m.workloads.bicycle_min_time_inputs(B)
+    elif case == "bicycle_n120_mixed":
+        B, mk = 512, lambda **k: m.config_bicycle_min_time(120, precision=A.MIXED, candidates=(0, 1, 2, 5), candidate_max_iter=(60, 50, 45, 40), candidate_param=(0.0, 0.0, 0.0, 2.0), **k)
+        inp = m.workloads.bicycle_min_time_inputs(B)
+    elif case == "unicycle_n80_polygons":
+        B, O, V = 512, 16, 6
+        x0, xf, up, dtp, obstacles = m.workloads.unicycle_obstacle_inputs(B, n_obst=O, max_vertices=V, lateral=(0.15, 0.8))
+        inp = (x0, xf, up, dtp)
+        mk = lambda **k: m.config_unicycle_quadratic(80, max_obstacles=O, max_vertices=V, max_obstacle_rows=4, max_iter=60, **k)
+    elif case == "carlike_n50_candidates":
+        B, mk = 1024, lambda **k: m.config_carlike_min_time(50, candidates=(0, 5, 5, 7), candidate_max_iter=(60, 45, 40, 35), candidate_param=(0.0, 2.0, 3.0, 1.5), **k)
+        inp = m.workloads.carlike_min_time_inputs(B, seed=20260924)
+    else:
+        B, mk = 256, lambda **k: m.config_carlike_min_time(30, precision=A.FP32, tol=1e-4, **k)
+        inp = m.workloads.carlike_min_time_inputs(B, seed=5)
+        sizes = (12 + np.arange(B) % 19).astype(np.int32)          # grids of 12 .. 30 points in one batch (serial sweeps below 40 points)
+    res, lds = {}, {}
+    for mode in (A.STAGE_LDS, A.STAGE_GLOBAL, A.STAGE_AUTO):
+        s = m.BatchSolver(mk(stage_data=mode), max_batch=B)
+        if sizes is not None:
+            s.set_grid_sizes(sizes)
+        res[mode] = s.solve(*inp, obstacles=obstacles)
+        lds[mode] = s.lds_bytes()
+        s.close()
+    a, g, auto = res[A.STAGE_LDS], res[A.STAGE_GLOBAL], res[A.STAGE_AUTO]
+    assert (a.status == 0).mean() > 0.7
+    fp32_phase = case in ("bicycle_n120_mixed", "carlike_n30_ragged_fp32")
+    for f in ("status", "iters", "dt", "x", "u"):
+        # fp64: bit for bit.  An fp32 (phase) in the global form agrees to rounding only: the compiler contracts / packs the fp32 lane-parallel passes differently around
+        # global loads (each form is deterministic run to run; MPC_STAGE_AUTO never takes the global form in fp32)
+        if not fp32_phase:
+            assert np.array_equal(getattr(a, f), getattr(g, f)), f
+        assert np.array_equal(getattr(a, f), getattr(auto, f)), f
+    if fp32_phase:
+        both = (a.status == 0) & (g.status == 0) & (a.iters == g.iters)
+        assert abs((a.status == 0).mean() - (g.status == 0).mean()) < 0.02 and both.mean() > 0.5
+        assert np.median(np.abs(a.x - g.x).reshape(B, -1).max(1)[both]) < (1e-6 if case == "bicycle_n120_mixed" else 1e-3)
+    assert lds[A.STAGE_GLOBAL] < 0.55 * lds[A.STAGE_LDS]
+    # what MPC_STAGE_AUTO picks in fp64: the global form where the LDS form leaves at least half of a CU's SIMDs empty and the global form fills more (four workgroups
+    # per CU at most: one wave per SIMD); fp32 keeps everything in LDS.  mpc_lds_bytes reports the fp64 kernel's record (MPC_MIXED: the refinement phase's)
+    per_cu = lambda b: min(4, (160 * 1024) // b)
+    want_global = case not in ("carlike_n30_ragged_fp32", "bicycle_n120_mixed") and per_cu(lds[A.STAGE_LDS]) <= 2 and per_cu(lds[A.STAGE_GLOBAL]) > per_cu(lds[A.STAGE_LDS])
+    assert lds[A.STAGE_AUTO] == (lds[A.STAGE_GLOBAL] if want_global else lds[A.STAGE_LDS])
+    if case in ("bicycle_n120_fp64_candidates", "unicycle_n80_polygons"):
+        assert lds[A.STAGE_AUTO] == lds[A.STAGE_GLOBAL] and per_cu(lds[A.STAGE_AUTO]) >= 3
+    if case == "carlike_n50_candidates":
+        assert lds[A.STAGE_AUTO] == lds[A.STAGE_LDS]           # the headline grid keeps everything in LDS
 
 
 def test_integral_form_fixed_grid_golden(m):
