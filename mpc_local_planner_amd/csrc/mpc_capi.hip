@@ -42,7 +42,9 @@ struct mpc_solver {
     mpc::WaveLayout WL;         // everything in LDS
     mpc::WaveLayout WLg;        // factorisation data (GAIN, STG) in global memory (mpc_wave.hpp::GlobalStage): the LDS record is a third
     bool gs64, gs32;            // which of the two the fp64 / fp32 launches of this handle use (mpc_config.stage_data; MPC_STAGE_AUTO: the one that puts more workgroups on a CU)
-    void* d_gstage;             // the workgroups' blocks of factorisation data (max_batch x candidates x WLg.GSW words), NULL when neither precision uses them
+    void* d_gstage;             // n_gslots blocks of factorisation data (WLg.GSW words each), NULL when neither precision uses them
+    int* d_gslots;              // [n_gslots] claim words of the blocks (0 = free)
+    int n_gslots;
     size_t wave_lds;            // dynamic LDS of the kernel instantiation of cfg.precision (MPC_MIXED: the fp64 one, the larger)
     size_t wave_lds32;          // MPC_MIXED: dynamic LDS of the fp32 phase
     int32_t* d_iters1;          // MPC_MIXED: iterations of the fp32 phase
@@ -290,10 +292,20 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         if (er == hipSuccess) er = hipMemset(s->d_rows_dropped, 0, Bm * 4);
     }
     if (cfg->precision == MPC_MIXED && er == hipSuccess) er = hipMalloc((void**)&s->d_iters1, Bm * 4);
-    if (s->gs32 || s->gs64) {      // one block of factorisation data per workgroup of the largest launch (stale contents are never read: every word is written before it is read within a solve)
-        const size_t g32 = s->gs32 ? Bm * (size_t)(s->P32.n_cand > 1 ? s->P32.n_cand : 1) * (size_t)s->WLg.GSW * 4 : 0;
-        const size_t g64 = s->gs64 ? Bm * (size_t)(s->P64.n_cand > 1 ? s->P64.n_cand : 1) * (size_t)s->WLg.GSW * 8 : 0;
-        if (er == hipSuccess) er = hipMalloc(&s->d_gstage, g32 > g64 ? g32 : g64);
+    if (s->gs32 || s->gs64) {
+        // blocks of factorisation data, a pool per XCD (mpc_solve_kernel.hpp): per XCD as many as the whole device has CUs -- an XCD has an eighth of them and a CU holds at
+        // most 8 of these one-wave workgroups (2 per SIMD under the register budget of any build), so a pool can never run dry --, never more than the largest launch has
+        // workgroups.  Stale contents are never read: every word is written before it is read within a solve.
+        hipDeviceProp_t prop;
+        if (er == hipSuccess) er = hipGetDeviceProperties(&prop, device);
+        const size_t c32 = (cfg->precision != MPC_FP64 && s->P32.n_cand > 1) ? (size_t)s->P32.n_cand : 1, c64 = (cfg->precision != MPC_FP32 && s->P64.n_cand > 1) ? (size_t)s->P64.n_cand : 1;
+        const size_t grid = Bm * (c32 > c64 ? c32 : c64);
+        size_t per_xcd = er == hipSuccess ? (size_t)prop.multiProcessorCount : 256;
+        if (per_xcd > grid) per_xcd = grid;
+        s->n_gslots = (int)per_xcd;
+        if (er == hipSuccess) er = hipMalloc(&s->d_gstage, 8 * per_xcd * (size_t)s->WLg.GSW * (s->gs64 ? 8 : 4));
+        if (er == hipSuccess) er = hipMalloc((void**)&s->d_gslots, 8 * per_xcd * 4);
+        if (er == hipSuccess) er = hipMemset(s->d_gslots, 0, 8 * per_xcd * 4);
     }
     if (cfg->dual_warm_start || cfg->precision == MPC_MIXED) {
         s->dual_words = mpc::IpmWave<double, 0, 0>::dual_words(s->WL.NS);
@@ -329,6 +341,7 @@ int mpc_reset(mpc_solver* s) {
     HIP_TRY(hipSetDevice(s->device));
     HIP_TRY(hipStreamSynchronize(s->stream));
     if (s->d_dual) HIP_TRY(hipMemset(s->d_dual, 0, (size_t)s->max_batch * s->dual_words * 8));      // forget the multipliers
+    if (s->d_gslots) HIP_TRY(hipMemset(s->d_gslots, 0, 8 * (size_t)s->n_gslots * 4));                      // claim words of the factorisation-data blocks (self-restoring unless a launch was aborted)
     if (s->d_cwin) {      // candidate bookkeeping back to idle (it is self-restoring unless a launch was aborted)
         HIP_TRY(hipMemset(s->d_cwin, 0x7f, (size_t)s->max_batch * 4));
         HIP_TRY(hipMemset(s->d_cexited, 0, (size_t)s->max_batch * 4));
@@ -342,7 +355,7 @@ void mpc_destroy(mpc_solver* s) {
     if (!s) return;
     (void)hipSetDevice(s->device);
     if (s->stream) (void)hipStreamSynchronize(s->stream);
-    void* bufs[] = {s->d_gstage, s->d_stage, s->d_iters1, s->d_dual, s->d_rows_dropped, s->d_cwin, s->d_cexited, s->d_citsum, s->d_crec, s->d_winner, s->d_iters_total, s->d_nvia, s->d_via, s->d_ngrid, s->d_in, s->d_out};
+    void* bufs[] = {s->d_gslots, s->d_gstage, s->d_stage, s->d_iters1, s->d_dual, s->d_rows_dropped, s->d_cwin, s->d_cexited, s->d_citsum, s->d_crec, s->d_winner, s->d_iters_total, s->d_nvia, s->d_via, s->d_ngrid, s->d_in, s->d_out};
     for (void* b : bufs) if (b) (void)hipFree(b);
     if (s->h_in) (void)hipHostFree(s->h_in);
     if (s->h_out) (void)hipHostFree(s->h_out);
@@ -368,7 +381,7 @@ static hipError_t launch_model(mpc_solver* s, const mpc::Problem<T>& P, int B, c
     a.stream = s->stream;
     const bool gs = sizeof(T) == 4 ? s->gs32 : s->gs64;
     a.L = gs ? s->WLg : s->WL; a.B = B;
-    a.gstage = gs ? s->d_gstage : nullptr;
+    a.gstage = gs ? s->d_gstage : nullptr; a.gslots = s->d_gslots; a.n_gslots = s->n_gslots;
     a.x0 = x0; a.xf = xf; a.u_prev = up; a.dt_prev = dtp; a.x_init = xi; a.u_init = ui; a.dt_init = dti; a.obst = ob;
     a.n_grid = s->use_ngrid ? s->d_ngrid : nullptr; a.n_via = s->p_nvia; a.via = s->p_via;
     // kept multipliers: a launch starts from them under dual_warm_start; in MPC_MIXED without it the block is only the hand-off from the fp32 phase

@@ -47,7 +47,7 @@ void mpc_ipm_wave_kernel(
     const double* __restrict__ dt_prev, const double* __restrict__ x_init, const double* __restrict__ u_init,
     const double* __restrict__ dt_init, mpc_obstacles obst, const int32_t* __restrict__ n_grid, const int32_t* __restrict__ n_via,
     const double* __restrict__ via, CandCtl cc, const int32_t* __restrict__ iters_add, double* __restrict__ x_out,
-    double* __restrict__ u_out, double* __restrict__ dt_out, int32_t* __restrict__ status, int32_t* __restrict__ iters, void* gstage) {
+    double* __restrict__ u_out, double* __restrict__ dt_out, int32_t* __restrict__ status, int32_t* __restrict__ iters, void* gstage, int* __restrict__ gslots, int n_gslots) {
     extern __shared__ __attribute__((aligned(16))) unsigned char mpc_smem[];
     T* sm = reinterpret_cast<T*>(mpc_smem);
     // problem record at the end of the dynamic LDS block (16-byte aligned); the layout stays in scalar registers
@@ -78,7 +78,24 @@ void mpc_ipm_wave_kernel(
         if (lane == 0) { *Ps = P; Ps->n = n; }
         __syncthreads();
         mpc::IpmWave<T, MODEL, EXT, OBST, NSC, GS> S(*Ps, Lv, sm, lane);
-        if constexpr (GS) S.gmb = reinterpret_cast<T*>(gstage) + (size_t)blockIdx.x * (size_t)L.GSW;      // this workgroup's block of factorisation data (GlobalStage)
+        int gslot = -1;
+        if constexpr (GS) {
+            // this workgroup's block of factorisation data (GlobalStage): one of the n_gslots blocks OF ITS XCD, claimed for the lifetime of the workgroup.  Per XCD because
+            // the eight L2s are not coherent with each other inside a launch: a block that only ever moves through ONE L2 needs no cache maintenance, a block that changed
+            // XCDs could be clobbered by the write-back of the previous owner's dirty lines.  There are more blocks per XCD than workgroups it can hold at once
+            // (mpc_capi.hip), so the probe ends after a step or two.  What it buys over a block per workgroup of the GRID: the memory a launch touches is resident waves
+            // x 63 n words (62 MB at n = 120 in fp64 on 256 CUs) whatever the batch -- inside the 256 MB Infinity Cache -- instead of batch x candidates x 63 n words
+            // (2 GB at 8192 x 4).
+            if (lane == 0) {
+                const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u;          // HW_REG_XCC_ID (id 20), bits 3:0
+                const unsigned base = xcc * (unsigned)n_gslots;
+                unsigned g = ((unsigned)blockIdx.x * 2654435761u) % (unsigned)n_gslots;
+                while (atomicCAS(gslots + base + g, 0, 1) != 0) g = g + 1 == (unsigned)n_gslots ? 0u : g + 1;
+                gslot = (int)(base + g);
+            }
+            gslot = __builtin_amdgcn_readfirstlane(gslot);
+            S.gmb = reinterpret_cast<T*>(gstage) + (size_t)gslot * (size_t)L.GSW;
+        }
         for (int i = 0; i < 3; ++i) { S.x0[i] = T(x0[3 * inst + i]); S.xf[i] = T(xf[3 * inst + i]); }
         S.x0[2] = mpc::normalize_theta(S.x0[2]);
         S.xf[2] = mpc::normalize_theta(S.xf[2]);
@@ -107,6 +124,7 @@ void mpc_ipm_wave_kernel(
         __syncthreads();
         mpc::SolveStats<T> st = S.solve();
         __syncthreads();
+        if constexpr (GS) { if (lane == 0) __hip_atomic_store(gslots + gslot, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }      // (every access of the block happened before the barrier)
         st_status = st.status; st_iters = st.iters;
         if (cc.rows_dropped && cand == 0 && lane == 0) cc.rows_dropped[inst] = S.rows_dropped;
         if (cand == 0) {
@@ -198,7 +216,9 @@ struct SolveLaunch {
     const int32_t* iters_add;
     double *x_out, *u_out, *dt_out;
     int32_t *status, *iters;
-    void* gstage;               // L.GSW > 0: the workgroups' blocks of factorisation data in global memory (grid x L.GSW words of T), else NULL
+    void* gstage;               // L.GSW > 0: 8 x n_gslots blocks of factorisation data in global memory (L.GSW words of T each; n_gslots per XCD), claimed by the workgroups through `gslots`; else NULL
+    int* gslots;                // [8][n_gslots] 0 = free, 1 = taken (all 0 between launches)
+    int n_gslots;
 };
 
 constexpr int kFixedLayoutNS = 50;
@@ -234,7 +254,7 @@ hipError_t launch_solve(const SolveLaunch& a, const Problem<T>& P) {
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(kern, dim3((unsigned)a.B * (unsigned)(P.n_cand > 1 ? P.n_cand : 1)), dim3(kWave), a.lds, a.stream, P, a.L, a.B, a.x0, a.xf, a.u_prev, a.dt_prev,
-                       a.x_init, a.u_init, a.dt_init, a.obst, a.n_grid, a.n_via, a.via, a.cc, a.iters_add, a.x_out, a.u_out, a.dt_out, a.status, a.iters, a.gstage);
+                       a.x_init, a.u_init, a.dt_init, a.obst, a.n_grid, a.n_via, a.via, a.cc, a.iters_add, a.x_out, a.u_out, a.dt_out, a.status, a.iters, a.gstage, a.gslots, a.n_gslots);
     return hipSuccess;
 }
 

@@ -52,7 +52,9 @@ struct GlobalStage {
     __host__ __device__ static constexpr int CH(int ns) { return CC + 3 * ns; }            // 3 NS words, component-major: c^_k = c_k + f_k dd (forward sweeps)
     __host__ __device__ static constexpr int GAIN(int ns) { return CC + 6 * ns; }          // NGAIN NS words, stage-major
     __host__ __device__ static constexpr int STG(int ns) { return CC + (6 + NGAIN) * ns; }    // nstg NS words, stage-major
-    __host__ __device__ static constexpr int words(int ns, int nstg) { return ((STG(ns) + nstg * ns + 15) / 16) * 16; }     // (128-byte multiple in fp64)
+    __host__ __device__ static constexpr int OBC(int ns, int nstg) { return STG(ns) + nstg * ns; }   // 4 M NS words, component-major [OG | OAX | OAY | OHK][m][k]: the clearance rows' cached value,
+                                                                                                     // gradient and curvature (touched by the lane-parallel passes only: coalesced)
+    __host__ __device__ static constexpr int words(int ns, int nstg, int M) { return ((OBC(ns, nstg) + 4 * M * ns + 15) / 16) * 16; }     // (128-byte multiple in fp64)
 };
 
 struct WaveLayout {
@@ -83,7 +85,7 @@ struct WaveLayout {
         L.DX = take(3); L.DU = take(2);
         L.CC = take(3); L.TRIG = take(ntrig);
         L.GAIN = take(gs ? 0 : NGAIN); L.STG = take(gs ? 0 : nstg);
-        L.GSW = gs ? GlobalStage::words(n, nstg) : 0;
+        L.GSW = gs ? GlobalStage::words(n, nstg, M) : 0;
         L.SC = o; o += 16;    // scalars: D, DT, DD, PDL, PDU | terminal-ball row: slack, multiplier, cached value and gradient
         L.VP = o; o += 16;    // dummy store targets of the idle lanes in the sweeps
         L.ZC = o; o += 8;     // constants 0 0 0 0 1 0 0 0 (coefficient triples of the constant columns)
@@ -91,7 +93,7 @@ struct WaveLayout {
         L.M = M; L.O = O; L.V = V;
         L.OS = take(M); L.OY = take(M);
         L.OI = o; o += (M * n * 2 + tsize - 1) / tsize;      // uint16 per row and grid point (0xffff = no row): a quarter of a T word each -- what lets BASELINE configs[2] (n = 80, 16 polygons) keep TWO workgroups per CU
-        L.OG = take(M); L.OAX = take(M); L.OAY = take(M); L.OHK = take(M);
+        L.OG = take(gs ? 0 : M); L.OAX = take(gs ? 0 : M); L.OAY = take(gs ? 0 : M); L.OHK = take(gs ? 0 : M);      // (gs: the cached row values / gradients / curvatures live in the global block too)
         L.GV = o; o += 2 * O * V; L.GNV = o; o += O; L.GR = o; o += O; L.GC = o; o += 2 * O;
         L.NV = NV; L.VIA = o; o += 3 * NV; L.VIDX = o; o += NV;
         L.OAT = take(MT); L.OHXT = take(MT); L.OHYT = take(MT); L.OHTT = take(MT);
@@ -258,6 +260,10 @@ struct IpmWave {
     static constexpr int NADDv = EXT ? (int)NADD : (int)NADD_BASE;
     __device__ __forceinline__ SwT& S_(int i, int k) const { if constexpr (GS) return gw((unsigned)(GlobalStage::STG(L.NS) + k * NSTG + i)); else return sm[L.STG + k * NSTG + i]; }
     __device__ __forceinline__ T& C_(int i, int k) const { return sm[L.CC + k * 3 + i]; }
+    // cached value (0), gradient (1, 2) and curvature (3) of clearance row m at grid point k: written by kkt_pass, read by the other lane-parallel passes
+    __device__ __forceinline__ SwT& OB_(int which, int m, int k) const {
+        if constexpr (GS) return gw((unsigned)(GlobalStage::OBC(L.NS, NSTG) + (which * L.M + m) * L.NS + k)); else return sm[(which == 0 ? L.OG : (which == 1 ? L.OAX : (which == 2 ? L.OAY : L.OHK))) + m * L.NS + k];
+    }
     // c^_k = c_k + f_k dd, what the forward sweeps read (component-major): parked in LAMN, or (GS) in the global block
     __device__ __forceinline__ SwT& CH_(int i, int k) const { if constexpr (GS) return gw((unsigned)(GlobalStage::CH(L.NS) + i * L.NS + k)); else return sm[L.LAMN + i * L.NS + k]; }
     __device__ __forceinline__ T& SCL(int i) const { return sm[L.SC + i]; }
@@ -551,14 +557,14 @@ struct IpmWave {
                     else { obst_eval(px, py, j, dist, nx, ny, hk); dist -= P.fp_radius; }
                     if (dist < P.force_incl) {
                         ++wanted;
-                        if (cnt < M) { set_oi(cnt, k, j); F(L.OG, cnt, k) = dist; ++cnt; }       // OG doubles as the distance of a kept forced row
+                        if (cnt < M) { set_oi(cnt, k, j); OB_(0, cnt, k) = dist; ++cnt; }       // OG doubles as the distance of a kept forced row
                         else if (first_forced < M) {
                             // full: the farthest forced row kept so far gives way if this obstacle is closer (the later ones keep their order)
                             int far = first_forced;
-                            for (int m = first_forced + 1; m < M; ++m) if (F(L.OG, m, k) >= F(L.OG, far, k)) far = m;
-                            if (dist < F(L.OG, far, k)) {
-                                for (int m = far; m + 1 < M; ++m) { set_oi(m, k, oi(m + 1, k)); F(L.OG, m, k) = F(L.OG, m + 1, k); }
-                                set_oi(M - 1, k, j); F(L.OG, M - 1, k) = dist;
+                            for (int m = first_forced + 1; m < M; ++m) if (OB_(0, m, k) >= OB_(0, far, k)) far = m;
+                            if (dist < OB_(0, far, k)) {
+                                for (int m = far; m + 1 < M; ++m) { set_oi(m, k, oi(m + 1, k)); OB_(0, m, k) = OB_(0, m + 1, k); }
+                                set_oi(M - 1, k, j); OB_(0, M - 1, k) = dist;
                             }
                         }
                         continue;
@@ -791,7 +797,7 @@ struct IpmWave {
     __device__ __forceinline__ bool dynturn() const { return fpline() && dynobs(); }
     // a' dz of row (k, m) from the cached gradient
     __device__ __forceinline__ T obst_jdz(int k, int m) const {
-        T j = F(L.OAX, m, k) * F(L.DX, 0, k) + F(L.OAY, m, k) * F(L.DX, 1, k);
+        T j = OB_(1, m, k) * F(L.DX, 0, k) + OB_(2, m, k) * F(L.DX, 1, k);
         if (fpline()) j += F(L.OAT, m, k) * F(L.DX, 2, k);
         if (dynturn()) j += F(L.OAD, m, k) * SCL(SC_DD);
         else if (dynobs()) j += F(L.OAT, m, k) * SCL(SC_DD);
@@ -813,7 +819,7 @@ struct IpmWave {
                     T g, a3[3], hk, h3[3];
                     if (!obst_row3(k, m, px, py, pth, g, a3, hk, h3, d)) continue;
                     T s = F(L.OS, m, k);
-                    if (trial) s += alpha * (-(F(L.OG, m, k) + s) - obst_jdz(k, m));
+                    if (trial) s += alpha * (-(OB_(0, m, k) + s) - obst_jdz(k, m));
                     th += t_abs(g + s);
                 }
             }
@@ -877,7 +883,7 @@ struct IpmWave {
                 for (int m = 0; m < nM(); ++m) {
                     if (oi(m, k) < 0) continue;
                     T s = F(L.OS, m, k);
-                    if (trial) s += alpha * (-(F(L.OG, m, k) + s) - obst_jdz(k, m));
+                    if (trial) s += alpha * (-(OB_(0, m, k) + s) - obst_jdz(k, m));
                     acc.mul(s);
                 }
             }
@@ -897,7 +903,7 @@ struct IpmWave {
         bool stage, on[4], quad, mint, dtf;
         int k;
     };
-    __device__ __forceinline__ bool trial_fast_ok() const { return EXT == 0 && !(sizeof(T) == 8 && NTRB > 3) && nM() == 0 && L.n <= kWave; }      // (the extended instantiations and the fp64 bicycle / front-wheel models keep those registers for what they add: no scratch memory anywhere)
+    __device__ __forceinline__ bool trial_fast_ok() const { return EXT == 0 && !GS && !(sizeof(T) == 8 && NTRB > 3) && nM() == 0 && L.n <= kWave; }      // (the extended instantiations and the fp64 bicycle / front-wheel models keep those registers for what they add: no scratch memory anywhere)
     __device__ __forceinline__ void trial_setup(TrialRegs& r, T dd) const {
         const int n = L.n, k = lane;
         const T d = SCL(SC_D);
@@ -1034,7 +1040,7 @@ struct IpmWave {
                         T g, a3[3], hk, h3[3], ad, hd[4];
                         if (!obst_row3(k, m, px, py, F(L.X, 2, k), g, a3, hk, h3, d, ad, hd)) continue;
                         const T ax = a3[0], ay = a3[1];
-                        F(L.OG, m, k) = g; F(L.OAX, m, k) = ax; F(L.OAY, m, k) = ay; F(L.OHK, m, k) = hk;
+                        OB_(0, m, k) = g; OB_(1, m, k) = ax; OB_(2, m, k) = ay; OB_(3, m, k) = hk;
                         if (fpline() || dynobs()) { F(L.OAT, m, k) = a3[2]; F(L.OHXT, m, k) = h3[0]; F(L.OHYT, m, k) = h3[1]; F(L.OHTT, m, k) = h3[2]; }
                         if (dynturn()) { F(L.OAD, m, k) = ad; F(L.OHXD, m, k) = hd[0]; F(L.OHYD, m, k) = hd[1]; F(L.OHDD, m, k) = hd[2]; F(L.OHTD, m, k) = hd[3]; }
                         const T s = F(L.OS, m, k), y = F(L.OY, m, k);
@@ -1201,8 +1207,8 @@ struct IpmWave {
             if (nM() > 0 && k >= 1 && k < n - 1) {
                 for (int m = 0; m < nM(); ++m) {
                     if (oi(m, k) < 0) continue;
-                    const T s = F(L.OS, m, k), y = F(L.OY, m, k), g = F(L.OG, m, k);
-                    const T ax = F(L.OAX, m, k), ay = F(L.OAY, m, k), hk = F(L.OHK, m, k);
+                    const T s = F(L.OS, m, k), y = F(L.OY, m, k), g = OB_(0, m, k);
+                    const T ax = OB_(1, m, k), ay = OB_(2, m, k), hk = OB_(3, m, k);
                     const T is = t_rcp(s);
                     const T sig = y * is;
                     const T ybar = mu * is + sig * (g + s);
@@ -2277,7 +2283,7 @@ struct IpmWave {
                     if (oi(m, k) < 0) continue;
                     const T jdz = obst_jdz(k, m);
                     const T s = F(L.OS, m, k), y = F(L.OY, m, k);
-                    const T res = F(L.OG, m, k) + s;
+                    const T res = OB_(0, m, k) + s;
                     const T is = t_rcp(s);
                     const T sig = y * is;
                     const T ybar = mu * is + sig * res;
@@ -2330,7 +2336,7 @@ struct IpmWave {
                     if (oi(m, k) < 0) continue;
                     const T jdz = obst_jdz(k, m);
                     const T s = F(L.OS, m, k), y = F(L.OY, m, k);
-                    const T res = F(L.OG, m, k) + s;
+                    const T res = OB_(0, m, k) + s;
                     const T is = t_rcp(s);
                     const T sig = y * is;
                     const T so = s + alpha * (-res - jdz);

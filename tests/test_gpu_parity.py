@@ -451,7 +451,7 @@ def test_lds_working_set_and_workgroups_per_cu_of_the_baseline_configs(m):
     w3, b3 = wgs(m.config_unicycle_quadratic(80, max_obstacles=16, max_vertices=6, max_obstacle_rows=4, **lds))
     assert w3 == 2, b3
     w3, b3 = wgs(m.config_unicycle_quadratic(80, max_obstacles=16, max_vertices=6, max_obstacle_rows=4))
-    assert w3 == 3, b3
+    assert w3 == 4, b3
     assert wgs(m.config_unicycle_quadratic(80, **lds))[0] == 2 and wgs(m.config_unicycle_quadratic(80))[0] == 4
     assert wgs(m.config_bicycle_min_time(120, precision=1, tol=1e-4))[0] == 3
     assert wgs(m.config_bicycle_min_time(120, **lds))[0] == 1 and wgs(m.config_bicycle_min_time(120))[0] == 4
