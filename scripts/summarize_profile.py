@@ -63,6 +63,27 @@ def main(src, dst, key="carlike_n50_B1024_c4"):
         allrec[key] = rec
         json.dump(allrec, open(path, "w"), indent=1)
         out.append(f"\nHBM traffic per launch = 2 x FETCH_SIZE + WRITE_SIZE = {rec['bytes_per_launch'] / 1e6:.2f} MB\n")
+    # every PMC mean of the solve kernel, per workload key: what bench.py's roofline line reads next to the live numbers (profiles/pmc_counters.json)
+    allc = {}
+    for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+        db = os.path.join(d, "run_results.db")
+        if os.path.exists(db):
+            for name, mean in rows(db, "select counter_name, avg(value) from counters_collection where kernel_name like '%mpc_ipm%' group by counter_name")[1]:
+                allc[name] = mean
+    tr = os.path.join(src, "trace", "run_results.db")
+    if os.path.exists(tr):
+        r = rows(tr, "select avg(duration), count(*), max(lds_size), max(vgpr_count), max(accum_vgpr_count) from kernels where name like '%mpc_ipm%'")[1]
+        if r and r[0][0]:
+            allc["kernel_avg_ns"], allc["dispatches"], allc["lds_bytes"] = r[0][0], r[0][1], r[0][2]
+    if allc:
+        import json
+        path = os.path.join(os.path.dirname(dst) or ".", "pmc_counters.json")
+        try:
+            store = json.load(open(path))
+        except (OSError, ValueError):
+            store = {}
+        store[key] = dict(allc, source=os.path.basename(dst) + ".md")
+        json.dump(store, open(path, "w"), indent=1, sort_keys=True)
     open(dst + ".md", "w").write("".join(out))
     print("".join(out))
 
