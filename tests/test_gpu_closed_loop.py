@@ -221,7 +221,9 @@ def test_config5_candidates_vs_oracle_rule_fp64_and_mixed(env, c_oracle):
         if tag == "fp64":
             assert np.mean(win == owin) > 0.95
         match, other = account(f"config 5 shape with candidates, {tag}", ocfg, inputs, r, (ox, ou, od, ost, oit))
-        assert match.sum() > (0.9 if tag == "fp64" else 0.6) * B
+        # fp64 is the precision of the bench leg that counts for BASELINE configs[4] (r05: affordable since the factorisation data left LDS): >= 95 % of the 1024
+        # answers within 1e-4 of the oracle rule's (measured 1022).  MPC_MIXED keeps its 60 % floor (833: the fp32 phase picks another basin in ~19 %).
+        assert match.sum() > (0.95 if tag == "fp64" else 0.6) * B
         s.close()
 
 
