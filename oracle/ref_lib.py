@@ -101,6 +101,39 @@ def normalize_theta(th):
     return np.array([lib.ref_normalize_theta(float(t)) for t in np.atleast_1d(th)])
 
 
+def vertex_plus(values, inc, per_component=False):
+    """VectorVertexSE2::plus on `count` vertices (vector_vertex_se2.h:79-96): values, inc [count][dim] -> values after the retraction"""
+    v, d = np.ascontiguousarray(values, float), np.ascontiguousarray(inc, float)
+    out = np.empty_like(v)
+    fn = load().ref_vertex_plus_idx if per_component else load().ref_vertex_plus
+    fn(C.c_int(v.shape[0]), C.c_int(v.shape[1]), _p(v), _p(d), _p(out))
+    return out
+
+
+def vertex_plus_unfixed(values, fixed, inc_unfixed):
+    """PartiallyFixedVectorVertexSE2::plusUnfixed (vector_vertex_se2.h:240-251): -> (values after, getDimensionUnfixed())"""
+    v, f, d = np.ascontiguousarray(values, float), np.ascontiguousarray(fixed, np.int32), np.ascontiguousarray(inc_unfixed, float)
+    out = np.empty_like(v)
+    nu = load().ref_vertex_plus_unfixed(C.c_int(v.size), _p(v), _p(f), _p(d), _p(out))
+    return out, int(nu)
+
+
+def vertex_set(data):
+    """setData per component / set(values, lb, ub) (vector_vertex_se2.h:98-118): -> (values after setData, values after set)"""
+    d = np.ascontiguousarray(data, float)
+    a, b = np.empty_like(d), np.empty_like(d)
+    load().ref_vertex_set(C.c_int(d.size), _p(d), _p(a), _p(b))
+    return a, b
+
+
+def vertex_bound_counts(lb, ub, fixed):
+    """getNumberFinite{Lower,Upper,}Bounds(false / true) of the partially fixed vertex (vector_vertex_se2.h:262-311)"""
+    l, u, f = np.ascontiguousarray(lb, float), np.ascontiguousarray(ub, float), np.ascontiguousarray(fixed, np.int32)
+    out = np.zeros(6, np.int32)
+    load().ref_vertex_bound_counts(C.c_int(l.size), _p(l), _p(u), _p(f), _p(out))
+    return out
+
+
 def interpolate_angle(a1, a2, f):
     lib = load()
     return np.array([lib.ref_interpolate_angle(float(a), float(b), float(c)) for a, b, c in zip(a1, a2, f)])

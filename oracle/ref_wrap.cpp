@@ -4,6 +4,7 @@
 //   include/mpc_local_planner/utils/math_utils.h                          normalize_theta, interpolate_angle, average_angles   (self-contained)
 //   include/mpc_local_planner/systems/{unicycle_robot,simple_car,kinematic_bicycle_model}.h      the four robot models' dynamics()
 //   include/mpc_local_planner/optimal_control/fd_collocation_se2.h        forward / midpoint / Crank-Nicolson collocation rows on SE(2)
+//   include/mpc_local_planner/optimal_control/vector_vertex_se2.h         the vertex classes of the state variables: plus / plusUnfixed / setData / set (r05): oracle/ref_wrap_vertex.cpp
 //   src/optimal_control/stage_inequality_se2.cpp (+ its header)           obstacle association, clearance rows, control-rate rows: oracle/ref_wrap_rows.cpp
 //   src/optimal_control/min_time_via_points_cost.cpp (+ its header)       via-point association and cost terms, time term: oracle/ref_wrap_rows.cpp
 //   src/optimal_control/full_discretization_grid_base_se2.cpp, finite_differences_variable_grid_se2.cpp (+ headers), src/utils/time_series_se2.cpp

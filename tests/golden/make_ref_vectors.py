@@ -4,6 +4,7 @@ stand-in) -- on seeded inputs and records what it gives.  /root/reference does n
 tree is (deterministic: a second run rewrites identical files).   usage: python tests/golden/make_ref_vectors.py
 
   ref_models_collocation.npz     math_utils.h, the four robot models, the three SE(2) collocation rules
+  ref_vertex.npz                 vector_vertex_se2.h: the retraction of the state vertices (plus / plusUnfixed / setData / set), bound counts
   ref_stage_inequality.npz       StageInequalitySE2: obstacle association, clearance rows of point obstacles, control-rate rows
   ref_via_points.npz             MinTimeViaPointsCost: association, terms, time term
   ref_grid.npz                   the grid classes and TimeSeriesSE2: cold start, nearest state, warm-start cycle, resampling, adaptation, closest pose, time series
@@ -58,6 +59,32 @@ def main():
             out[f"manifold_collocation_model{mid}_method{method}"] = RL.collocation(method, mid, par, x1, u, x2m, dt)
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_models_collocation.npz"), **out)
     print("written", len(out), "arrays")
+    # ---- the reference's own vertex classes (include/mpc_local_planner/optimal_control/vector_vertex_se2.h, executed since r05: SURVEY.md 8 row a15): the retraction
+    #      x (+) inc of a state vertex with the heading at and around +-pi, the partially fixed vertex (final state with fixed components), setData / set, the bound counts
+    rng = np.random.default_rng(20260925)
+    V = 400
+    vals = np.stack([rng.uniform(-5, 5, V), rng.uniform(-5, 5, V), rng.uniform(-np.pi, np.pi, V)], axis=1)
+    incs = np.stack([rng.normal(0, 1, V), rng.normal(0, 1, V), rng.normal(0, 2.5, V)], axis=1)
+    edge = np.array([np.pi, -np.pi, np.nextafter(np.pi, 0), np.nextafter(-np.pi, 0), np.pi - 1e-16, 0.0, 3.0, -3.0])
+    vals[:64, 2] = np.repeat(edge, 8)
+    incs[:64, 2] = np.tile(np.array([0.0, 1e-17, -1e-17, 1e-9, -1e-9, np.pi, -np.pi, 2 * np.pi]), 8)
+    vx = dict(values=vals, inc=incs, plus=RL.vertex_plus(vals, incs), plus_per_component=RL.vertex_plus(vals, incs, per_component=True))
+    vals5 = np.concatenate([vals, rng.uniform(-1, 1, (V, 2))], axis=1); incs5 = np.concatenate([incs, rng.normal(0, 1, (V, 2))], axis=1)
+    vx.update(values5=vals5, inc5=incs5, plus5=RL.vertex_plus(vals5, incs5))       # dimension > 3: the tail is plain reals (vector_vertex_se2.h:92)
+    fixed = np.array([[a, b, c] for a in (0, 1) for b in (0, 1) for c in (0, 1)], dtype=np.int32)
+    pf_out, pf_nu = [], []
+    for i in range(V):
+        fx = fixed[i % 8]
+        o, nu = RL.vertex_plus_unfixed(vals[i], fx, incs[i][fx == 0])
+        pf_out.append(o); pf_nu.append(nu)
+    vx.update(fixed=fixed, plus_unfixed=np.array(pf_out), dim_unfixed=np.array(pf_nu))
+    sd = [RL.vertex_set(vals[i] + np.array([0.0, 0.0, 4.0])) for i in range(64)]
+    vx.update(set_data=np.array([a for a, b in sd]), set_values=np.array([b for a, b in sd]))
+    inf = RL.corbo_inf()
+    lb = np.array([-inf, -1.0, -inf]); ub = np.array([inf, 1.0, 2.0])
+    vx.update(bound_lb=lb, bound_ub=ub, bound_counts=np.array([RL.vertex_bound_counts(lb, ub, fx) for fx in fixed]))
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_vertex.npz"), **vx)
+    print("written", len(vx), "vertex arrays")
     # ---- the reference's StageInequalitySE2 (src/optimal_control/stage_inequality_se2.cpp): association of every grid point, clearance rows of static and
     #      moving POINT obstacles for the point footprint, control-rate rows -> tests/golden/ref_stage_inequality.npz
     rng = np.random.default_rng(20260926)

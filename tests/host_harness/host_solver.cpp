@@ -97,6 +97,17 @@ extern "C" void hostdbg_colloc(const mpc_config* cfg, int count, const double* x
     }
 }
 extern "C" double hostdbg_normalize_theta(double th) { return mpc::normalize_theta(th); }
+// the accept step of the kernel on ONE state vertex, as mpc_wave.hpp::xt / accept() write it: x + alpha dx per component, the heading wrapped (SURVEY.md 8 row a15:
+// VectorVertexSE2::plus, include/mpc_local_planner/optimal_control/vector_vertex_se2.h:79-96 -- tests/test_reference_pinned.py holds this to the executed reference)
+extern "C" void hostdbg_retract(int count, const double* x, const double* dx, double alpha, double* out) {
+    for (int i = 0; i < count; ++i)
+        for (int a = 0; a < 3; ++a) {
+            double v = x[3 * i + a];
+            v += alpha * dx[3 * i + a];
+            if (a == 2) v = mpc::normalize_theta(v);
+            out[3 * i + a] = v;
+        }
+}
 
 
 // mpc_core.hpp::pit_block_inertia_tri on the host (tests/test_pit_math.py): full symmetric 5 x 5 matrices in, excess of negative eigenvalues out (ok = 0 when a pivot vanished)

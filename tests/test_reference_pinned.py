@@ -65,6 +65,52 @@ def test_kernel_core_angle_wrap_reproduces_the_reference(host):
     assert np.array_equal(ours, G["normalize_theta"])
 
 
+VX = np.load(os.path.join(HERE, "golden", "ref_vertex.npz"))
+
+
+def test_vertex_retraction_reproduces_the_reference_s_vertex_classes(host):
+    """SURVEY.md 8 row a15, pinned to EXECUTED reference code since r05: include/mpc_local_planner/optimal_control/vector_vertex_se2.h compiles as it is against the
+    corbo vertex interface of oracle/ref_stubs/ (no stand-in shadows it any more) and its plus / plusUnfixed / setData / set were recorded on 400 vertices, 64 of them
+    with the heading at +-pi, one ulp inside, and increments of 0, +-1e-17, +-1e-9, +-pi, 2 pi.  Held to the recording, bit for bit: the numpy oracle's retraction
+    (se2_nlp.ReferenceNlp.plus / ipm_dense retract: z + dz, heading wrapped), the candidates' wrap, and the host build of the kernel core's accept step
+    (x += alpha dx; heading = normalize_theta, mpc_wave.hpp::xt / accept) at alpha = 1."""
+    v, d = VX["values"], VX["inc"]
+    ours = v + d
+    ours[:, 2] = [R.normalize_theta(t) for t in ours[:, 2]]
+    assert np.array_equal(ours, VX["plus"]) and np.array_equal(VX["plus"], VX["plus_per_component"])
+    assert ((VX["plus"][:, 2] >= -np.pi) & (VX["plus"][:, 2] < np.pi)).all()
+    from oracle import candidates as OC
+    assert np.array_equal(OC.wrap(v[:, 2] + d[:, 2]), VX["plus"][:, 2])
+    # dimension 5: the tail behind the pose is plain reals
+    o5 = VX["values5"] + VX["inc5"]; o5[:, 2] = [R.normalize_theta(t) for t in o5[:, 2]]
+    assert np.array_equal(o5, VX["plus5"])
+    # the kernel core's accept step
+    out = np.empty_like(v)
+    host.hostdbg_retract.restype = None
+    host.hostdbg_retract(C.c_int(v.shape[0]), np.ascontiguousarray(v).ctypes.data_as(C.c_void_p), np.ascontiguousarray(d).ctypes.data_as(C.c_void_p), C.c_double(1.0),
+                         out.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(out, VX["plus"])
+    # partially fixed vertex (the final state with fixed goal components): only the free components move, the increment carries one entry per free component
+    for i in range(v.shape[0]):
+        fx = VX["fixed"][i % 8].astype(bool)
+        want = v[i].copy()
+        want[~fx] += d[i][~fx]
+        if not fx[2]:
+            want[2] = R.normalize_theta(want[2])
+        assert np.array_equal(want, VX["plus_unfixed"][i]) and VX["dim_unfixed"][i] == int((~fx).sum())
+    # setData / set wrap the heading they are given
+    raw = v[:64] + np.array([0.0, 0.0, 4.0])
+    want = raw.copy(); want[:, 2] = [R.normalize_theta(t) for t in raw[:, 2]]
+    assert np.array_equal(want, VX["set_data"]) and np.array_equal(want, VX["set_values"])
+    # finite bounds: [lower, upper, any] over all components, then over the unfixed ones (what the NLP's bound multipliers are counted from)
+    lb, ub = VX["bound_lb"], VX["bound_ub"]
+    inf = 2e30
+    for fx, got in zip(VX["fixed"].astype(bool), VX["bound_counts"]):
+        allc = [int((lb > -inf).sum()), int((ub < inf).sum()), int(((lb > -inf) | (ub < inf)).sum())]
+        free = [int(((lb > -inf) & ~fx).sum()), int(((ub < inf) & ~fx).sum()), int((((lb > -inf) | (ub < inf)) & ~fx).sum())] if (~fx).any() else allc
+        assert list(got) == allc + free, (fx, got)
+
+
 @pytest.mark.parametrize("model", sorted(MODELS))
 @pytest.mark.parametrize("method", [0, 1, 2])
 def test_kernel_core_collocation_rows_reproduce_the_reference_on_the_heading_manifold(host, model, method):
@@ -605,6 +651,11 @@ def test_recorded_vectors_are_what_the_compiled_reference_gives_today():
             ctl = RL.RefController(params)
             assert ctl.dump() == rec[name]["built"], name
             ctl.close()
+    assert np.array_equal(RL.vertex_plus(VX["values"], VX["inc"]), VX["plus"]) and np.array_equal(RL.vertex_plus(VX["values5"], VX["inc5"]), VX["plus5"])
+    for i in range(0, 400, 37):
+        fx = VX["fixed"][i % 8]
+        o, nu = RL.vertex_plus_unfixed(VX["values"][i], fx, VX["inc"][i][fx == 0])
+        assert np.array_equal(o, VX["plus_unfixed"][i]) and nu == VX["dim_unfixed"][i]
     for i in range(0, GR["n"].shape[0], 7):
         n, x, u, dt = _traj(i)
         assert RL.grid_find_nearest_state(x, u, dt, GR["query"][i]) == GR["nearest"][i]
