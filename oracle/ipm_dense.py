@@ -639,6 +639,14 @@ class IpmOptions:
     # Same rule, same defaults in oracle/mpc_oracle.c (oracle_config.acceptable_tol / _iter) and in the kernel (mpc_config.acceptable_tol / _iter).
     acceptable_tol: float = 1e-6
     acceptable_iter: int = 15
+    # Restoration for clearance rows that jam (r05; same rule and constants in oracle/mpc_oracle.c::solve_one and in the kernel, mpc_wave.hpp::solve): after
+    # `elastic_trigger` iterations in a row whose fraction-to-boundary limit on the primal step is below `elastic_ap` while the infeasibility is still at least
+    # `elastic_prog` x its value at the start of the streak, the clearance rows become elastic for the rest of the solve: g + s - e = 0, e >= 0, + elastic_rho e in
+    # the objective (the exact l1 penalty of the row's violation).  e counts as primal infeasibility, so the solve can only end with e <= tol.  elastic_rho = 0: off.
+    elastic_rho: float = 1000.0
+    elastic_ap: float = 5e-2
+    elastic_prog: float = 0.7
+    elastic_trigger: int = 3
     verbose: bool = False
 
 
@@ -788,33 +796,57 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
     status = 1
     it = 0
     n_acceptable = 0
+    # elastic clearance rows (restoration): e is zero outside the mode and on every other row
+    cl = np.zeros(mg, dtype=bool)
+    cl[len(nlp.rate_rows):len(nlp.rate_rows) + len(nlp.obst_rows) + len(nlp.dyn_rows)] = True
+    el = np.zeros(mg)
+    erho = 0.0
+    jam_streak, jam_theta0 = 0, 0.0
 
     def kkt_err(ev, v, s, lam, y, piL, piU, mu_t):
         rd = ev["gf"] + ev["Jc"].T @ lam + ev["Jg"].T @ y - piL + piU
-        rp = max(np.abs(ev["c"]).max(initial=0.0), np.abs(ev["g"] + s).max(initial=0.0))
+        rp = max(np.abs(ev["c"]).max(initial=0.0), np.abs(ev["g"] + s - el).max(initial=0.0), el.max(initial=0.0))
         comp = 0.0
         if mg:
             comp = max(comp, np.abs(s * y - mu_t).max())
+        if erho > 0 and cl.any():
+            comp = max(comp, np.abs(el[cl] * (erho - y[cl]) - mu_t).max())
         if hasL.any():
             comp = max(comp, np.abs((v - lb)[hasL] * piL[hasL] - mu_t).max())
         if hasU.any():
             comp = max(comp, np.abs((ub - v)[hasU] * piU[hasU] - mu_t).max())
-        nm = mc + mg + hasL.sum() + hasU.sum()
-        sd = max(opt.s_max, (np.abs(lam).sum() + np.abs(y).sum() + piL.sum() + piU.sum()) / max(nm, 1)) / opt.s_max
-        nz = mg + hasL.sum() + hasU.sum()
-        sc = max(opt.s_max, (np.abs(y).sum() + piL.sum() + piU.sum()) / max(nz, 1)) / opt.s_max
+        ne = int(cl.sum()) if erho > 0 else 0
+        we = float((erho - y[cl]).sum()) if erho > 0 else 0.0          # the elastic variables' own multipliers, rho - y
+        nm = mc + mg + hasL.sum() + hasU.sum() + ne
+        sd = max(opt.s_max, (np.abs(lam).sum() + np.abs(y).sum() + piL.sum() + piU.sum() + we) / max(nm, 1)) / opt.s_max
+        nz = mg + hasL.sum() + hasU.sum() + ne
+        sc = max(opt.s_max, (np.abs(y).sum() + piL.sum() + piU.sum() + we) / max(nz, 1)) / opt.s_max
         return max(np.abs(rd).max() / sd, rp, comp / sc)
 
-    def barrier_obj(f, v, s, mu):
+    def barrier_obj(f, v, s, mu, e_=None):
         val = f
         if mg:
             val -= mu * np.log(s).sum()
+        if erho > 0 and cl.any():
+            ee = el if e_ is None else e_
+            val += erho * ee[cl].sum() - mu * np.log(ee[cl]).sum()
         val -= mu * np.log((v - lb)[hasL]).sum()
         val -= mu * np.log((ub - v)[hasU]).sum()
         return val
 
     while it < opt.max_iter:
         ev = nlp.eval(v, lam, y, want_hess=True)
+        if erho == 0 and opt.elastic_rho > 0 and opt.elastic_trigger > 0 and cl.any() and jam_streak >= opt.elastic_trigger and \
+                np.abs(ev["c"]).sum() + np.abs(ev["g"] + s).sum() >= opt.elastic_prog * jam_theta0:
+            # enter the restoration mode at this point: every clearance row is satisfied again (e takes up the violation, the slack goes back to its start rule)
+            erho = opt.elastic_rho
+            gcl = ev["g"][cl]
+            s[cl] = np.maximum(np.maximum(-gcl, opt.clearance_slack_push), s[cl])
+            el[cl] = np.maximum(gcl + s[cl], mu / erho)
+            y[cl] = np.maximum(np.minimum(y[cl], 0.5 * erho), mu / s[cl])
+            rho = 0.0
+            jam_streak = 0
+            ev = nlp.eval(v, lam, y, want_hess=True)
         e0 = kkt_err(ev, v, s, lam, y, piL, piU, 0.0)
         if e0 <= opt.tol:
             status = 0
@@ -838,6 +870,8 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
             comp = []
             if mg:
                 comp.append(s * y)
+            if erho > 0 and cl.any():
+                comp.append(el[cl] * (erho - y[cl]))
             comp.append(((v - lb) * piL)[hasL])
             comp.append(((ub - v) * piU)[hasU])
             comp = np.concatenate(comp)
@@ -865,9 +899,14 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
         SigS = y / s
         # gradient of the barrier function wrt z (no multipliers of c, g)
         gphi = gf - np.where(hasL, mu / dL, 0.0) + np.where(hasU, mu / dU, 0.0)
-        rg = g + s
+        rg = g + s - el
         # condensed rhs: y+ = mu/s + SigS*(g+s) + SigS*Jg dz
         ybar = mu / s + SigS * rg
+        if erho > 0 and cl.any():      # elastic rows, (s, e) condensed together: sigma = 1 / (s / y + e / (rho - y)), ybar = y + sigma (res + mu / y - s - mu / (rho - y) + e)
+            wv = erho - y[cl]
+            SigS = SigS.copy()
+            SigS[cl] = 1.0 / (s[cl] / y[cl] + el[cl] / wv)
+            ybar[cl] = y[cl] + SigS[cl] * (rg[cl] + mu / y[cl] - s[cl] - mu / wv + el[cl])
         Hc = W + np.diag(SigZ) + Jg.T @ (SigS[:, None] * Jg)
         rhs1 = -(gphi + Jg.T @ ybar)
         rhs = np.concatenate([rhs1, -c])
@@ -924,6 +963,11 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
         ds = -rg - Jg @ dz
         y_new = ybar + SigS * (Jg @ dz)
         dy = y_new - y
+        de = np.zeros(mg)
+        if erho > 0 and cl.any():
+            wv = erho - y[cl]
+            ds[cl] = mu / y[cl] - s[cl] - (s[cl] / y[cl]) * dy[cl]
+            de[cl] = mu / wv - el[cl] + (el[cl] / wv) * dy[cl]
         dpiL = np.where(hasL, mu / dL - piL - (piL / dL) * dz, 0.0)
         dpiU = np.where(hasU, mu / dU - piU + (piU / dU) * dz, 0.0)
 
@@ -943,6 +987,9 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
         a_d = 1.0
         if mg:
             a_d = min(a_d, max_step(y, dy, tau))
+        if erho > 0 and cl.any():
+            a_p = min(a_p, max_step(el[cl], de[cl], tau))
+            a_d = min(a_d, max_step(erho - y[cl], -dy[cl], tau))
         if hasL.any():
             a_d = min(a_d, max_step(piL[hasL], dpiL[hasL], tau))
         if hasU.any():
@@ -950,7 +997,17 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
 
         theta = np.abs(c).sum() + np.abs(rg).sum()
         dphi = gphi @ dz - (mu / s) @ ds if mg else gphi @ dz
+        if erho > 0 and cl.any():
+            dphi += (erho - mu / el[cl]) @ de[cl]
         phi_cur = barrier_obj(ev["f"], v, s, mu)
+        if erho == 0 and opt.elastic_rho > 0 and opt.elastic_trigger > 0 and cl.any():      # the restoration trigger's streak (see IpmOptions.elastic_*)
+            rp_now = max(np.abs(c).max(initial=0.0), np.abs(rg).max(initial=0.0))
+            if a_p < opt.elastic_ap and rp_now > 1e-3:
+                if jam_streak == 0:
+                    jam_theta0 = theta
+                jam_streak += 1
+            else:
+                jam_streak = 0
         if theta0 is None:
             theta0 = theta
             theta_max = 1e4 * max(1.0, theta0)
@@ -971,9 +1028,10 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
                     alpha *= 0.5
                 vt = nlp.retract(v, alpha * dz)
                 st = s + alpha * ds
+                et = el + alpha * de
                 evt = nlp.eval(vt)
-                tht = np.abs(evt["c"]).sum() + np.abs(evt["g"] + st).sum()
-                phit = barrier_obj(evt["f"], vt, st, mu) + rho * tht
+                tht = np.abs(evt["c"]).sum() + np.abs(evt["g"] + st - et).sum()
+                phit = barrier_obj(evt["f"], vt, st, mu, et) + rho * tht
                 if np.isfinite(phit) and phit - phi0 - 10 * 2.220446049250313e-16 * abs(phi0) <= opt.eta_armijo * alpha * D:
                     accepted = True
                     break
@@ -1022,6 +1080,8 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
                 status = 2
                 break
         v, s = vt, st
+        if erho > 0:
+            el = el + alpha * de
         last_alpha, last_ad = alpha, a_d
         lam = lam + alpha * (lam_new - lam)
         y = y + a_d * dy
@@ -1031,6 +1091,8 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
         kS = 1e10
         if mg:
             y = np.minimum(np.maximum(y, mu / (kS * s)), kS * mu / s)
+        if erho > 0 and cl.any():      # the same safeguards for e and its multiplier rho - y
+            y[cl] = np.minimum(np.maximum(y[cl], erho - kS * mu / el[cl]), erho - mu / (kS * el[cl]))
         dLn = np.where(hasL, v - lb, 1.0)
         dUn = np.where(hasU, ub - v, 1.0)
         piL = np.where(hasL, np.minimum(np.maximum(piL, mu / (kS * dLn)), kS * mu / dLn), 0.0)

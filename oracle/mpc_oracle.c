@@ -246,6 +246,8 @@ typedef struct {
     double* cent;             /* O*2 centroids */
     int* oi;                  /* n*M obstacle index or -1 */
     double *os, *oy, *ost, *ods, *ody;   /* n*M slack, multiplier, trial slack, steps */
+    double *oe, *oet, *ode;              /* n*M elastic variable of the clearance rows (g + s - e = 0, e >= 0, cost rho e), its trial value and step; all zero unless elastic */
+    double erho;                         /* > 0: the clearance rows are elastic with this penalty */
     double *og, *oax, *oay, *ohk;        /* n*M cached value, gradient (= -unit normal), curvature 1/|p-q| (0 on an edge interior) */
     double *oad, *ohd;                   /* dt parts (n*M, 4*n*M) of a dynamic obstacle's row when the footprint turns with the pose */
     double *oat, *oh3;                   /* third-variable parts of the rows: gradient entry n*M and Hessian entries 3*n*M -- heading for the
@@ -591,7 +593,7 @@ static double obst_theta(const work_t* w, const double* X, double D, const doubl
     double th = 0;
     for (int k = 1; k < n - 1; ++k) for (int m = 0; m < M; ++m) {
         double g, a[3], hk, h3[3];
-        if (obst_row3(w, k, m, X[3 * k], X[3 * k + 1], X[3 * k + 2], D, &g, a, &hk, h3)) th += fabs(g + sl[k * M + m]);
+        if (obst_row3(w, k, m, X[3 * k], X[3 * k + 1], X[3 * k + 2], D, &g, a, &hk, h3)) th += fabs(g + sl[k * M + m] - (sl == w->ost ? w->oet[k * M + m] : w->oe[k * M + m]));
     }
     return th;
 }
@@ -692,7 +694,10 @@ static double barrier_logs(const work_t* w, const double* U, double D, const dou
     for (int k = 0; k < n - 1; ++k) for (int j = 0; j < 2; ++j) a += log(U[2 * k + j] - c->u_lb[j]) + log(c->u_ub[j] - U[2 * k + j]);
     if (c->dt_free) a += log(D - c->dt_lb) + log(c->dt_ub - D);
     for (int r = 0; r < n; ++r) for (int q = 0; q < 4; ++q) if (row_on(w, r, q)) a += log(s[4 * r + q]);
-    for (int k = 1, M = obst_M(w); k < n - 1; ++k) for (int m = 0; m < M; ++m) if (w->oi[k * M + m] >= 0) a += log(os[k * M + m]);
+    for (int k = 1, M = obst_M(w); k < n - 1; ++k) for (int m = 0; m < M; ++m) if (w->oi[k * M + m] >= 0) {
+        a += log(os[k * M + m]);
+        if (w->erho > 0) a += log(os == w->ost ? w->oet[k * M + m] : w->oe[k * M + m]);
+    }
     return a;
 }
 
@@ -733,11 +738,17 @@ static void kkt_terms(const work_t* w, const double* cc, err_t* e) {
             wm->og[k * M + m] = g; wm->oax[k * M + m] = ax; wm->oay[k * M + m] = ay; wm->ohk[k * M + m] = hk;
             wm->oat[k * M + m] = a3[2]; for (int i = 0; i < 3; ++i) wm->oh3[3 * (k * M + m) + i] = h3[i];
             wm->oad[k * M + m] = ad; for (int i = 0; i < 4; ++i) wm->ohd[4 * (k * M + m) + i] = hd[i];
-            const double sl = w->os[k * M + m], y = w->oy[k * M + m], res = g + sl;
+            const double sl = w->os[k * M + m], y = w->oy[k * M + m], res = g + sl - w->oe[k * M + m];
             if (fabs(res) > e->rp) e->rp = fabs(res);
             e->theta += fabs(res);
             if (sl * y < e->cmin) e->cmin = sl * y; if (sl * y > e->cmax) e->cmax = sl * y; e->csum += sl * y;
             e->sb += y; e->nb += 1;
+            if (w->erho > 0) {      /* the elastic variable's own complementarity, e (rho - y); a solve may only end with e negligible: it counts as infeasibility of the ORIGINAL row */
+                const double ce = w->oe[k * M + m] * (w->erho - y);
+                if (ce < e->cmin) e->cmin = ce; if (ce > e->cmax) e->cmax = ce; e->csum += ce;
+                e->sb += w->erho - y; e->nb += 1;
+                if (w->oe[k * M + m] > e->rp) e->rp = w->oe[k * M + m];
+            }
             osx += y * ax; osy += y * ay;
             if (is_dynamic(w, w->oi[k * M + m]) && fp_turns(w)) { rdd += y * ad; ost += y * a3[2]; }
             else if (is_dynamic(w, w->oi[k * M + m])) rdd += y * a3[2]; else ost += y * a3[2];
@@ -939,7 +950,11 @@ static void assemble(work_t* w, const double* cc, double delta, double dc, doubl
             if (w->oi[k * M + m] < 0) continue;
             const double sl = w->os[k * M + m], y = w->oy[k * M + m], g = w->og[k * M + m];
             const double ax = w->oax[k * M + m], ay = w->oay[k * M + m], hk = w->ohk[k * M + m];
-            const double sig = y / sl, ybar = mu / sl + sig * (g + sl);
+            double sig = y / sl, ybar = mu / sl + sig * (g + sl);
+            if (w->erho > 0) {      /* elastic row, (s, e) condensed: sigma = 1 / (s / y + e / (rho - y)), ybar = y + sigma (res + mu / y - s - mu / (rho - y) + e) */
+                const double ee = w->oe[k * M + m], wv = w->erho - y;
+                sig = 1.0 / (sl / y + ee / wv); ybar = y + sig * ((g + sl - ee) + mu / y - sl - mu / wv + ee);
+            }
             band_add(w, ixn(k, 0), ixn(k, 0), sig * ax * ax - y * hk * (1.0 - ax * ax));
             sym_add(w, ixn(k, 0), ixn(k, 1), sig * ax * ay + y * hk * ax * ay);
             band_add(w, ixn(k, 1), ixn(k, 1), sig * ay * ay - y * hk * (1.0 - ay * ay));
@@ -1102,7 +1117,21 @@ static void derive_step(work_t* w, const double* cc, double mu, double tau, doub
         const double jdz = w->oax[k * M + m] * w->dz_x[3 * k] + w->oay[k * M + m] * w->dz_x[3 * k + 1] +
                            ((dyn_ && fp_turns(w)) ? w->oat[k * M + m] * w->dz_x[3 * k + 2] + w->oad[k * M + m] * ddt
                                                   : w->oat[k * M + m] * (dyn_ ? ddt : w->dz_x[3 * k + 2]));
-        const double sl = w->os[k * M + m], y = w->oy[k * M + m], res = w->og[k * M + m] + sl;
+        const double sl = w->os[k * M + m], y = w->oy[k * M + m];
+        if (w->erho > 0) {
+            const double ee = w->oe[k * M + m], wv = w->erho - y, res = w->og[k * M + m] + sl - ee;
+            const double sig = 1.0 / (sl / y + ee / wv), ybar = y + sig * (res + mu / y - sl - mu / wv + ee);
+            const double dyv = ybar + sig * jdz - y;
+            w->ody[k * M + m] = dyv;
+            w->ods[k * M + m] = mu / y - sl - (sl / y) * dyv;
+            w->ode[k * M + m] = mu / wv - ee + (ee / wv) * dyv;
+            hdz += ybar * jdz;
+            dphi += -(mu / sl) * w->ods[k * M + m] - (mu / ee) * w->ode[k * M + m] + w->erho * w->ode[k * M + m];
+            ftb(sl, w->ods[k * M + m], tau, &a_p); ftb(ee, w->ode[k * M + m], tau, &a_p);
+            ftb(y, dyv, tau, &a_d); ftb(wv, -dyv, tau, &a_d);
+            continue;
+        }
+        const double res = w->og[k * M + m] + sl;
         const double sig = y / sl, ybar = mu / sl + sig * res;
         w->ods[k * M + m] = -res - jdz;
         w->ody[k * M + m] = ybar + sig * jdz - y;
@@ -1140,8 +1169,12 @@ typedef struct {
     double sigma_max, fix_fact;
     int convex_fallback;
     int qn_sr1;
+    double elastic_rho;      /* > 0: clearance rows elastic from the start of a solve (g + s - e = 0, e >= 0, + rho e in the objective): experiment for VERDICT r04 item 3 */
+    double elastic_ap;       /* the step length below which an iteration counts as jammed */
+    double elastic_prog;     /* ... and the streak only triggers when the infeasibility is still above this share of its value at the streak's start */
+    int elastic_trigger;     /* with elastic_rho > 0: 0 = from the start, k > 0 = entered after k iterations in a row whose fraction-to-boundary step is below 1e-2 while a row is violated */
 } algo_t;
-static algo_t g_algo = {0, 0, 0, 0, 100.0, 0.8, 0, 1};
+static algo_t g_algo = {0, 0, 0, 0, 100.0, 0.8, 0, 1, 1000.0, 5e-2, 0.7, 3};
 static int g_inertia = 1;      /* 1: a factorisation is accepted when the KKT matrix has Ipopt's inertia (the algorithm); 0: the inertia-free curvature test of r01-r03 (kept for the measurements of DESIGN 3.1) */
 void oracle_set_algo(int key, double v) {
     if (key == 9) { g_inertia = (int)v; return; }
@@ -1154,6 +1187,10 @@ void oracle_set_algo(int key, double v) {
         case 5: g_algo.fix_fact = v; break;
         case 6: g_algo.convex_fallback = (int)v; break;
         case 7: g_algo.qn_sr1 = (int)v; break;
+        case 10: g_algo.elastic_rho = v; break;
+        case 11: g_algo.elastic_trigger = (int)v; break;
+        case 12: g_algo.elastic_ap = v; break;
+        case 13: g_algo.elastic_prog = v; break;
     }
 }
 
@@ -1300,6 +1337,7 @@ static void trial_point(work_t* w, double alpha, const double* ds, double* st, d
     for (int i = 0; i < 4 * n; ++i) st[i] = w->s[i] + alpha * ds[i];
     for (int i = 0, nm = n * obst_M(w); i < nm; ++i) w->ost[i] = w->oi[i] >= 0 ? w->os[i] + alpha * w->ods[i] : 1.0;
     eval_point(w, w->Xt, w->Ut, w->Dt, cct, ft);
+    if (w->erho > 0) for (int i = 0, nm = n * obst_M(w); i < nm; ++i) { w->oet[i] = w->oi[i] >= 0 ? w->oe[i] + alpha * w->ode[i] : 0.0; if (w->oi[i] >= 0 && i >= obst_M(w) && i < (n - 1) * obst_M(w)) *ft += w->erho * w->oet[i]; }
     double tht = 0;
     for (int i = 0; i < 3 * (n - 1); ++i) tht += fabs(cct[i]);
     for (int r = 0; r < n; ++r) for (int q = 0; q < 4; ++q) if (row_on(w, r, q)) tht += fabs(row_val_at(w, w->Ut, w->Dt, r, q) + st[4 * r + q]);
@@ -1490,8 +1528,11 @@ static int solve_one(work_t* w, int warm) {
             w->os[k * M + m] = 1.0; w->oy[k * M + m] = 0.0; w->ods[k * M + m] = 0.0; w->ody[k * M + m] = 0.0;
             if (k >= 1 && k < n - 1 && obst_row3(w, k, m, w->X[3 * k], w->X[3 * k + 1], w->X[3 * k + 2], w->D, &g, a3, &hk, h3)) {
                 w->os[k * M + m] = fmax(-g, clearance_slack_push); w->oy[k * M + m] = w->mu / w->os[k * M + m];
+                w->oe[k * M + m] = 0.0; w->ode[k * M + m] = 0.0; w->oet[k * M + m] = 0.0;
+                if (g_algo.elastic_rho > 0 && g_algo.elastic_trigger == 0) w->oe[k * M + m] = fmax(g + w->os[k * M + m], w->mu / g_algo.elastic_rho);      /* the row starts satisfied: g + s - e = 0 */
             } else w->oi[k * M + m] = -1;
         }
+        w->erho = (g_algo.elastic_rho > 0 && g_algo.elastic_trigger == 0) ? g_algo.elastic_rho : 0.0;
     }
     if (ball_on(w)) { double ta[3]; w->ts = fmax(-ball_eval(w, w->X, ta), slack_push); w->ty = w->mu / w->ts; w->tds = w->tdy = 0; }
     w->pdl = c->dt_free ? w->mu / (w->D - c->dt_lb) : 0.0;
@@ -1510,10 +1551,32 @@ static int solve_one(work_t* w, int warm) {
     const int acc_it = acc_iter_of(c);
     w->bf_init = 0;
     eval_point(w, w->X, w->U, w->D, cc, &fobj);
+    if (w->erho > 0) for (int k = 1, M = obst_M(w); k < n - 1; ++k) for (int m = 0; m < M; ++m) if (w->oi[k * M + m] >= 0) fobj += w->erho * w->oe[k * M + m];
     mu_min = tol / 10; mu_max = mu_max_fact * w->mu;
+    int jam_streak = 0; double jam_theta0 = 0;
     while (1) {
         err_t e;
         kkt_terms(w, cc, &e);
+        /* RESTORATION for clearance rows that jam (r05; Ipopt leaves such points to its restoration phase, src/controller.cpp:388-421 hands the NLP to Ipopt).  A row that
+         * starts violated pulls its slack to the boundary within a few iterations; from then on the fraction-to-boundary rule admits steps of 1e-3 and the infeasibility
+         * stays where it is.  Detected as elastic_trigger iterations in a row with a primal step limit below elastic_ap while the infeasibility has not fallen below
+         * elastic_prog x its value at the start of the streak.  From there on the clearance rows are ELASTIC -- g + s - e = 0, e >= 0, + rho e in the objective, the exact
+         * l1 penalty of the row's violation --: every row is satisfied again at once (e takes up the violation, the slack goes back to its start rule), nothing has to
+         * cross a bound, and rho pushes e to zero as the trajectory moves out of the band.  (s, e) are condensed together: sigma = 1 / (s / y + e / (rho - y)).  The mode
+         * stays on until the solve ends; e counts as primal infeasibility, so a solve can only end with e <= tol: the answer is a KKT point of the reference's NLP. */
+        if (w->erho == 0 && obst_M(w) > 0 && g_algo.elastic_rho > 0 && g_algo.elastic_trigger > 0 && jam_streak >= g_algo.elastic_trigger && e.theta >= g_algo.elastic_prog * jam_theta0) {
+            w->erho = g_algo.elastic_rho;
+            for (int k = 1, M = obst_M(w); k < n - 1; ++k) for (int m = 0; m < M; ++m) if (w->oi[k * M + m] >= 0) {
+                const double g = w->og[k * M + m];
+                w->os[k * M + m] = fmax(fmax(-g, clearance_slack_push), w->os[k * M + m]);
+                w->oe[k * M + m] = fmax(g + w->os[k * M + m], w->mu / w->erho);
+                w->oy[k * M + m] = fmax(fmin(w->oy[k * M + m], 0.5 * w->erho), w->mu / w->os[k * M + m]);
+                fobj += w->erho * w->oe[k * M + m];
+            }
+            w->rho = 0;
+            jam_streak = 0;
+            kkt_terms(w, cc, &e);
+        }
         double e0 = err_value(&e, 0.0);
         if (!isfinite(e0) || !isfinite(e.theta) || !isfinite(e.sm) || !isfinite(e.csum)) { status = 4; break; }
         if (e0 <= tol) { status = 0; break; }
@@ -1728,6 +1791,10 @@ static int solve_one(work_t* w, int warm) {
         if (!accepted && alpha * dzmax < 1e-14) { status = 2; break; }
         if (g_trace) printf("%3d mu %.2e e0 %.3e th %.3e a_p %.3e alpha %.3e a_d %.3e delta %.1e rho %.2e D %.5f obj %.6f acc %d ls %d soc %d nf %d | rd %.2e rp %.2e cmin/mu %.2e cmax/mu %.2e dzmax %.2e curv %.2e\n", it, mu, e0, theta, a_p, alpha, a_d, delta, w->rho, w->D, fobj, accepted, ls_used, soc_used, nfilt, e.rd, e.rp, e.cmin / mu, e.cmax / mu, dzmax, curv);
         last_alpha = alpha; last_ad = a_d;
+        /* (experiment) the restoration trigger: the fraction-to-boundary rule has held the primal step below 1e-2 for elastic_trigger iterations in a row while rows are infeasible */
+        if (g_algo.elastic_rho > 0 && g_algo.elastic_trigger > 0 && w->erho == 0 && obst_M(w) > 0) {
+            if (a_p < g_algo.elastic_ap && e.rp > 1e-3) { if (jam_streak == 0) jam_theta0 = e.theta; ++jam_streak; } else jam_streak = 0;
+        }
         /* accept */
         const double kS = 1e10;
         for (int r = 0; r < n; ++r) for (int q = 0; q < 4; ++q) if (row_on(w, r, q)) {
@@ -1739,6 +1806,11 @@ static int solve_one(work_t* w, int warm) {
             const double sn = w->ost[k * M + m];
             double yn = w->oy[k * M + m] + a_d * w->ody[k * M + m];
             yn = fmin(fmax(yn, mu / (kS * sn)), kS * mu / sn);
+            if (w->erho > 0) {      /* e and its multiplier rho - y: the same safeguards */
+                const double en = w->oet[k * M + m];
+                yn = fmin(fmax(yn, w->erho - kS * mu / en), w->erho - mu / (kS * en));
+                w->oe[k * M + m] = en;
+            }
             w->os[k * M + m] = sn; w->oy[k * M + m] = yn;
         }
         for (int k = 0; k < n - 1; ++k) {
@@ -1820,6 +1892,7 @@ static void work_obst(work_t* w, const oracle_obst* ob) {       /* clearance-row
     w->oi = (int*)calloc((size_t)n * M, sizeof(int));
     w->os = (double*)calloc((size_t)n * M, 8); w->oy = (double*)calloc((size_t)n * M, 8); w->ost = (double*)calloc((size_t)n * M, 8);
     w->ods = (double*)calloc((size_t)n * M, 8); w->ody = (double*)calloc((size_t)n * M, 8);
+    w->oe = (double*)calloc((size_t)n * M + 1, 8); w->oet = (double*)calloc((size_t)n * M + 1, 8); w->ode = (double*)calloc((size_t)n * M + 1, 8); w->erho = 0;
     w->og = (double*)calloc((size_t)n * M, 8); w->oax = (double*)calloc((size_t)n * M, 8); w->oay = (double*)calloc((size_t)n * M, 8);
     w->ohk = (double*)calloc((size_t)n * M, 8);
     w->oat = (double*)calloc((size_t)n * M, 8); w->oh3 = (double*)calloc((size_t)3 * n * M, 8);
@@ -1828,7 +1901,7 @@ static void work_obst(work_t* w, const oracle_obst* ob) {       /* clearance-row
 static void work_free(work_t* w) {
     free(w->X); free(w->U); free(w->Xt); free(w->Ut); free(w->lam); free(w->lamn); free(w->s); free(w->y); free(w->ron);
     free(w->pl); free(w->pu); free(w->AB); free(w->inS); free(w->inb); free(w->ipiv); free(w->rhs); free(w->bcol); free(w->dz_u); free(w->dz_x); free(w->bf); free(w->bf_g); free(w->bf_e);
-    free(w->cent); free(w->oi); free(w->os); free(w->oy); free(w->ost); free(w->ods); free(w->ody); free(w->og); free(w->oax); free(w->oay); free(w->ohk); free(w->oat); free(w->oh3); free(w->oad); free(w->ohd);
+    free(w->oe); free(w->oet); free(w->ode); free(w->cent); free(w->oi); free(w->os); free(w->oy); free(w->ost); free(w->ods); free(w->ody); free(w->og); free(w->oax); free(w->oay); free(w->ohk); free(w->oat); free(w->oh3); free(w->oad); free(w->ohd);
     free(w);
 }
 

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from oracle import c_oracle as CO, se2_nlp as R
 from mpc_local_planner_amd import workloads as W
-KEYS = dict(mu=0, glob=1, soc=2, safeguard=3, sigma_max=4, fix_fact=5, cf=6, sr1=7, sreset=8, inertia=9)
+KEYS = dict(mu=0, glob=1, soc=2, safeguard=3, sigma_max=4, fix_fact=5, cf=6, sr1=7, sreset=8, inertia=9, elastic=10, etrig=11)
 
 def set_algo(args):
     lib = CO._load()

@@ -333,6 +333,21 @@ def test_cpp_controller_facade_closed_loop(m, tmp_path):
     assert r.returncode == 0 and "DEMO_OK" in r.stdout, r.stdout + r.stderr
 
 
+def test_two_handles_shard_a_batch_like_two_gpus(m, tmp_path):
+    """examples/two_handles_shard.cpp: the multi-GPU split from a C++ host through the C ABI alone -- one handle per device (device 1 when the box has one, else both on
+    device 0), one host thread per handle, contiguous ragged shards of one batch with hedged candidates -- returns bit for bit what ONE handle returns for the
+    whole batch.  No scaling curve is claimed from it."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "mpc_local_planner_amd", "csrc")
+    exe = str(tmp_path / "two_handles_shard")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", os.path.join(root, "examples", "two_handles_shard.cpp"), "-L" + libdir, "-lmpc_hip",
+                    "-Wl,-rpath," + libdir, "-o", exe], check=True)
+    r = subprocess.run([exe, "600"], capture_output=True, text=True, timeout=300)
+    print(r.stdout)
+    assert r.returncode == 0 and "SHARD_OK" in r.stdout, r.stdout + r.stderr
+
+
 def test_no_uninitialised_lds_reads(m, tmp_path):
     """Instrumented build (-DMPC_POISON_LDS fills the whole LDS working set with NaN before the solve): every golden
     fixture must still be reproduced, i.e. the solver never consumes an LDS word it has not written (regression test
