@@ -292,8 +292,8 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         if (er == hipSuccess) er = hipMemset(s->d_rows_dropped, 0, Bm * 4);
     }
     if (cfg->precision == MPC_MIXED && er == hipSuccess) er = hipMalloc((void**)&s->d_iters1, Bm * 4);
-    if (s->gs32 || s->gs64) {
-        // blocks of factorisation data, a pool per XCD (mpc_solve_kernel.hpp): per XCD as many as the whole device has CUs -- an XCD has an eighth of them and a CU holds at
+    if (s->gs32 || s->gs64 || s->WL.GSW > 0) {
+        // blocks of factorisation data / of the clearance rows' elastic arrays (every layout with clearance rows has one, WaveLayout::GSW), a pool per XCD (mpc_solve_kernel.hpp): per XCD as many as the whole device has CUs -- an XCD has an eighth of them and a CU holds at
         // most 8 of these one-wave workgroups (2 per SIMD under the register budget of any build), so a pool can never run dry --, never more than the largest launch has
         // workgroups.  Stale contents are never read: every word is written before it is read within a solve.
         hipDeviceProp_t prop;
@@ -303,7 +303,8 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         size_t per_xcd = er == hipSuccess ? (size_t)prop.multiProcessorCount : 256;
         if (per_xcd > grid) per_xcd = grid;
         s->n_gslots = (int)per_xcd;
-        if (er == hipSuccess) er = hipMalloc(&s->d_gstage, 8 * per_xcd * (size_t)s->WLg.GSW * (s->gs64 ? 8 : 4));
+        const size_t blk64 = cfg->precision != MPC_FP32 ? (size_t)(s->gs64 ? s->WLg.GSW : s->WL.GSW) * 8 : 0, blk32 = cfg->precision != MPC_FP64 ? (size_t)(s->gs32 ? s->WLg.GSW : s->WL.GSW) * 4 : 0;
+        if (er == hipSuccess) er = hipMalloc(&s->d_gstage, 8 * per_xcd * (blk64 > blk32 ? blk64 : blk32));
         if (er == hipSuccess) er = hipMalloc((void**)&s->d_gslots, 8 * per_xcd * 4);
         if (er == hipSuccess) er = hipMemset(s->d_gslots, 0, 8 * per_xcd * 4);
     }
@@ -381,7 +382,7 @@ static hipError_t launch_model(mpc_solver* s, const mpc::Problem<T>& P, int B, c
     a.stream = s->stream;
     const bool gs = sizeof(T) == 4 ? s->gs32 : s->gs64;
     a.L = gs ? s->WLg : s->WL; a.B = B;
-    a.gstage = gs ? s->d_gstage : nullptr; a.gslots = s->d_gslots; a.n_gslots = s->n_gslots;
+    a.gstage = s->d_gstage; a.gslots = s->d_gslots; a.n_gslots = s->n_gslots;
     a.x0 = x0; a.xf = xf; a.u_prev = up; a.dt_prev = dtp; a.x_init = xi; a.u_init = ui; a.dt_init = dti; a.obst = ob;
     a.n_grid = s->use_ngrid ? s->d_ngrid : nullptr; a.n_via = s->p_nvia; a.via = s->p_via;
     // kept multipliers: a launch starts from them under dual_warm_start; in MPC_MIXED without it the block is only the hand-off from the fp32 phase

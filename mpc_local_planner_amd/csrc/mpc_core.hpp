@@ -112,6 +112,10 @@ template <> struct Algo<double> {
     // violated pins the fraction-to-boundary rule from the first iteration on (steps of 1e-3) and, without Ipopt's restoration phase, the solve never
     // leaves that corner: obstacles inside the clearance band converge in 81 % of the instances with 1e-2 and in 98 % with 0.5
     static constexpr double clearance_slack_push = 0.5;
+    // restoration for clearance rows that jam (mpc_wave.hpp::solve; same constants in the two CPU restatements the tests check against): penalty of the elastic variables, the
+    // primal step limit below which an iteration counts as jammed, the share of the streak's initial infeasibility that has to be left, the length of the streak
+    static constexpr double elastic_rho = 1000.0, elastic_ap = 5e-2, elastic_prog = 0.8;
+    static constexpr int elastic_trigger = 5;
     // adaptive barrier parameter (mpc_wave.hpp::solve): sigma = clamp((1 - min(alpha, alpha_dual))^3, sigma_min, 1) from the last iteration's step lengths,
     // mu = sigma x average complementarity, never below min(mu, mu_err_floor x E_0), inside [tol / 10, mu_max_fact x the solve's first mu]
     static constexpr double sigma_min = 0.05, mu_err_floor = 3e-2, mu_max_fact = 1e3;
@@ -125,6 +129,8 @@ template <> struct Algo<float> {
     static constexpr float curv_kappa = 1e-7f, s_max = 100, delta_c = 1e-5f, kappa_c = 0.25f, ls_eps = 10 * 1.1920929e-7f;
     static constexpr int max_ls = 30;
     static constexpr float clearance_slack_push = 0.5f;
+    static constexpr float elastic_rho = 1000.0f, elastic_ap = 5e-2f, elastic_prog = 0.8f;
+    static constexpr int elastic_trigger = 5;
     static constexpr float sigma_min = 0.05f, mu_err_floor = 3e-2f, mu_max_fact = 1e3f;
     static constexpr float rate_seed_frac = 0.9f;
 };

@@ -79,7 +79,7 @@ void mpc_ipm_wave_kernel(
         __syncthreads();
         mpc::IpmWave<T, MODEL, EXT, OBST, NSC, GS> S(*Ps, Lv, sm, lane);
         int gslot = -1;
-        if constexpr (GS) {
+        if (GS || (OBST && L.GSW > 0)) {
             // this workgroup's block of factorisation data (GlobalStage): one of the n_gslots blocks OF ITS XCD, claimed for the lifetime of the workgroup.  Per XCD because
             // the eight L2s are not coherent with each other inside a launch: a block that only ever moves through ONE L2 needs no cache maintenance, a block that changed
             // XCDs could be clobbered by the write-back of the previous owner's dirty lines.  There are more blocks per XCD than workgroups it can hold at once
@@ -124,7 +124,7 @@ void mpc_ipm_wave_kernel(
         __syncthreads();
         mpc::SolveStats<T> st = S.solve();
         __syncthreads();
-        if constexpr (GS) { if (lane == 0) __hip_atomic_store(gslots + gslot, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }      // (every access of the block happened before the barrier)
+        if (GS || (OBST && L.GSW > 0)) { if (lane == 0) __hip_atomic_store(gslots + gslot, 0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT); }      // (every access of the block happened before the barrier)
         st_status = st.status; st_iters = st.iters;
         if (cc.rows_dropped && cand == 0 && lane == 0) cc.rows_dropped[inst] = S.rows_dropped;
         if (cand == 0) {
@@ -233,9 +233,10 @@ hipError_t launch_solve(const SolveLaunch& a, const Problem<T>& P) {
 #endif
     auto kern = a.level == 0 ? ((a.L.M > 0 || force_obst) ? mpc_ipm_wave_kernel<T, MODEL, 0, true> : mpc_ipm_wave_kernel<T, MODEL, 0, false>)
                              : (a.level == 2 ? mpc_ipm_wave_kernel<T, MODEL, 2, true> : mpc_ipm_wave_kernel<T, MODEL, 1, true>);
-    // factorisation data in global memory (WaveLayout::GSW > 0; mpc_capi.hip decides per handle and precision): the headline level's two instantiations exist in that form
-    if (a.L.GSW > 0) {
-        if (a.level != 0 || !a.gstage) return hipErrorInvalidConfiguration;
+    // factorisation data in global memory (WaveLayout::GSF; mpc_capi.hip decides per handle and precision): the headline level's two instantiations exist in that form
+    if (a.L.GSW > 0 && !a.gstage) return hipErrorInvalidConfiguration;
+    if (a.L.GSF) {
+        if (a.level != 0) return hipErrorInvalidConfiguration;
         kern = (a.L.M > 0 || force_obst) ? mpc_ipm_wave_kernel<T, MODEL, 0, true, 0, true> : mpc_ipm_wave_kernel<T, MODEL, 0, false, 0, true>;
     }
     // fp64 headline kernel on a grid of kFixedLayoutNS points per record (the grid size of BASELINE configs[1] / [3]): the instantiation whose LDS layout is a
@@ -247,7 +248,7 @@ hipError_t launch_solve(const SolveLaunch& a, const Problem<T>& P) {
         constexpr bool no_fixed = false;
 #endif
         using IW = IpmWave<T, MODEL, 0, false, kFixedLayoutNS>;
-        if (a.level == 0 && a.L.M == 0 && a.L.GSW == 0 && !force_obst && !no_fixed && IW::LayoutT::matches(a.L)) kern = mpc_ipm_wave_kernel<T, MODEL, 0, false, kFixedLayoutNS>;
+        if (a.level == 0 && a.L.M == 0 && a.L.GSF == 0 && !force_obst && !no_fixed && IW::LayoutT::matches(a.L)) kern = mpc_ipm_wave_kernel<T, MODEL, 0, false, kFixedLayoutNS>;
     }
     if (a.lds > 48u * 1024u) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.lds);

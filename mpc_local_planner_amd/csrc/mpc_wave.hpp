@@ -54,7 +54,13 @@ struct GlobalStage {
     __host__ __device__ static constexpr int STG(int ns) { return CC + (6 + NGAIN) * ns; }    // nstg NS words, stage-major
     __host__ __device__ static constexpr int OBC(int ns, int nstg) { return STG(ns) + nstg * ns; }   // 4 M NS words, component-major [OG | OAX | OAY | OHK][m][k]: the clearance rows' cached value,
                                                                                                      // gradient and curvature (touched by the lane-parallel passes only: coalesced)
-    __host__ __device__ static constexpr int words(int ns, int nstg, int M) { return ((OBC(ns, nstg) + 4 * M * ns + 15) / 16) * 16; }     // (128-byte multiple in fp64)
+    __host__ __device__ static constexpr int OEL(int ns, int nstg, int M) { return OBC(ns, nstg) + 4 * M * ns; }   // 2 M NS words [OE | ODE][m][k]: the elastic variables of the clearance rows and
+                                                                                                     // their steps (restoration mode, IpmWave::solve)
+    __host__ __device__ static constexpr int words(int ns, int nstg, int M) { return ((OEL(ns, nstg, M) + 2 * M * ns + 15) / 16) * 16; }     // (128-byte multiple in fp64)
+    // a layout that keeps its factorisation data in LDS still has a block when it has clearance rows: the elastic arrays alone (touched by the lane-parallel passes only, and
+    // only in the restoration mode: not worth 2 M words of LDS per grid point)
+    static constexpr int OEL_ONLY = 16;
+    __host__ __device__ static constexpr int words_elastic_only(int ns, int M) { return ((OEL_ONLY + 2 * M * ns + 15) / 16) * 16; }
 };
 
 struct WaveLayout {
@@ -69,7 +75,9 @@ struct WaveLayout {
     int OAD, OHXD, OHYD, OHDD, OHTD;              // dt parts when BOTH apply (dynamic obstacles + a turning footprint): gradient, hess [x dt, y dt, dt dt, theta dt]
     int GVEL;                                     // obstacle velocities (dynamic obstacles; 2 * OD words)
     int NV, VIA, VIDX;                            // via-points: capacity, poses (x, y, theta), attached grid point (-1 = skipped)
-    int GSW;                                      // > 0: the factorisation data (GAIN, STG) lives in a block of GSW words of GLOBAL memory per workgroup instead of LDS (IpmWave<..., GS = true>; GlobalStage below)
+    int GSW;                                      // > 0: the workgroup has a block of GSW words of GLOBAL memory (GlobalStage): the elastic arrays of the clearance rows, and with GSF the factorisation data
+    int GSF;                                      // 1: the factorisation data (GAIN, STG) and the clearance rows' caches live in that block instead of LDS (IpmWave<..., GS = true>)
+    int OEB;                                      // word offset of the elastic arrays [OE | ODE] inside the block
     // tsize = sizeof(T) of the kernel that uses the layout (the obstacle indices of the clearance rows are 16-bit words, M * n of them, packed into T-sized words)
     __host__ __device__ static constexpr WaveLayout make(int n, int M = 0, int O = 0, int V = 1, int ntrig = 4, int NV = 0, int MT = 0, int OD = 0, int nstg = NSTG_BASE, int MD = 0, int tsize = 8, bool gs = false) {
         WaveLayout L{};
@@ -85,7 +93,9 @@ struct WaveLayout {
         L.DX = take(3); L.DU = take(2);
         L.CC = take(3); L.TRIG = take(ntrig);
         L.GAIN = take(gs ? 0 : NGAIN); L.STG = take(gs ? 0 : nstg);
-        L.GSW = gs ? GlobalStage::words(n, nstg, M) : 0;
+        L.GSW = gs ? GlobalStage::words(n, nstg, M) : (M > 0 ? GlobalStage::words_elastic_only(n, M) : 0);
+        L.GSF = gs ? 1 : 0;
+        L.OEB = gs ? GlobalStage::OEL(n, nstg, M) : GlobalStage::OEL_ONLY;
         L.SC = o; o += 16;    // scalars: D, DT, DD, PDL, PDU | terminal-ball row: slack, multiplier, cached value and gradient
         L.VP = o; o += 16;    // dummy store targets of the idle lanes in the sweeps
         L.ZC = o; o += 8;     // constants 0 0 0 0 1 0 0 0 (coefficient triples of the constant columns)
@@ -116,7 +126,7 @@ struct FixedLayout {
     static constexpr int NS = NSC, NTR = NTRIG;
     static constexpr int X = c().X, U = c().U, LAM = c().LAM, LAMN = c().LAMN, SR = c().SR, YR = c().YR, PL = c().PL, PU = c().PU, DX = c().DX, DU = c().DU, CC = c().CC,
                          TRIG = c().TRIG, GAIN = c().GAIN, STG = c().STG, SC = c().SC, VP = c().VP, ZC = c().ZC, ZI = c().ZI, total = c().total;
-    static constexpr int M = 0, O = 0, V = 1, NV = 0;
+    static constexpr int M = 0, O = 0, V = 1, NV = 0, GSW = 0, GSF = 0, OEB = 0;
     static constexpr int OS = c().OS, OY = c().OY, OI = c().OI, OG = c().OG, OAX = c().OAX, OAY = c().OAY, OHK = c().OHK, GV = c().GV, GNV = c().GNV, GR = c().GR, GC = c().GC,
                          OAT = c().OAT, OHXT = c().OHXT, OHYT = c().OHYT, OHTT = c().OHTT, OAD = c().OAD, OHXD = c().OHXD, OHYD = c().OHYD, OHDD = c().OHDD, OHTD = c().OHTD,
                          GVEL = c().GVEL, VIA = c().VIA, VIDX = c().VIDX;
@@ -227,6 +237,7 @@ struct IpmWave {
     const int lane;
     T x0[3], xf[3], uprev[2], dtprev;
     T mu, rho, delta_last;
+    T erho = T(0);           // > 0: the clearance rows are elastic with this penalty (restoration mode, see solve()); wave-uniform
     bool row0_on, fail0;
     bool warm_guess = false;     // the caller supplied an initial guess (second and later control cycles)
     mutable int cnt_mult = -1, cnt_bmult = -1;      // number of equality / bound multipliers (cached by kkt_pass)
@@ -264,6 +275,8 @@ struct IpmWave {
     __device__ __forceinline__ SwT& OB_(int which, int m, int k) const {
         if constexpr (GS) return gw((unsigned)(GlobalStage::OBC(L.NS, NSTG) + (which * L.M + m) * L.NS + k)); else return sm[(which == 0 ? L.OG : (which == 1 ? L.OAX : (which == 2 ? L.OAY : L.OHK))) + m * L.NS + k];
     }
+    // elastic variable e (0) and its step de (1) of clearance row m at grid point k (restoration mode): always in the workgroup's global block
+    __device__ __forceinline__ GlbT& OE_(int which, int m, int k) const { return gw((unsigned)(L.OEB + (which * L.M + m) * L.NS + k)); }
     // c^_k = c_k + f_k dd, what the forward sweeps read (component-major): parked in LAMN, or (GS) in the global block
     __device__ __forceinline__ SwT& CH_(int i, int k) const { if constexpr (GS) return gw((unsigned)(GlobalStage::CH(L.NS) + i * L.NS + k)); else return sm[L.LAMN + i * L.NS + k]; }
     __device__ __forceinline__ T& SCL(int i) const { return sm[L.SC + i]; }
@@ -795,6 +808,22 @@ struct IpmWave {
         return obst_row3(k, m, px, py, th, g, a, hk, h3, d, ad, hd);
     }
     __device__ __forceinline__ bool dynturn() const { return fpline() && dynobs(); }
+    // restoration mode, one clearance row g + s - e = 0 with (s, e) condensed together (derivation: DESIGN.md section 3.3):
+    //     sigma = 1 / (s / y + e / (rho - y)),   ybar = y + sigma (res + mu / y - s - mu / (rho - y) + e),   res = g + s - e
+    __device__ __forceinline__ void elastic_condense(T s, T y, T g, T ee, T& sig, T& ybar) const {
+        const T iy = t_rcp(y), iw = t_rcp(erho - y);
+        sig = t_rcp(s * iy + ee * iw);
+        ybar = y + sig * ((g + s - ee) + mu * iy - s - mu * iw + ee);
+    }
+    // ... and the steps of its slack, elastic variable and multiplier for a' dz = jdz
+    __device__ __forceinline__ void elastic_steps(T s, T y, T g, T ee, T jdz, T& ds, T& de, T& dy, T& ybar) const {
+        T sig;
+        elastic_condense(s, y, g, ee, sig, ybar);
+        dy = ybar + sig * jdz - y;
+        const T iy = t_rcp(y), iw = t_rcp(erho - y);
+        ds = mu * iy - s - (s * iy) * dy;
+        de = mu * iw - ee + (ee * iw) * dy;
+    }
     // a' dz of row (k, m) from the cached gradient
     __device__ __forceinline__ T obst_jdz(int k, int m) const {
         T j = OB_(1, m, k) * F(L.DX, 0, k) + OB_(2, m, k) * F(L.DX, 1, k);
@@ -819,6 +848,14 @@ struct IpmWave {
                     T g, a3[3], hk, h3[3];
                     if (!obst_row3(k, m, px, py, pth, g, a3, hk, h3, d)) continue;
                     T s = F(L.OS, m, k);
+                    if (erho > T(0)) {      // restoration mode: g + s - e with the trial values of both, + rho e in the objective
+                        const T ee = OE_(0, m, k), de = trial ? T(OE_(1, m, k)) : T(0);
+                        if (trial) s += alpha * (-(OB_(0, m, k) + s - ee) - obst_jdz(k, m) + de);
+                        const T et = ee + (trial ? alpha * de : T(0));
+                        th += t_abs(g + s - et);
+                        fo += erho * et;
+                        continue;
+                    }
                     if (trial) s += alpha * (-(OB_(0, m, k) + s) - obst_jdz(k, m));
                     th += t_abs(g + s);
                 }
@@ -883,6 +920,12 @@ struct IpmWave {
                 for (int m = 0; m < nM(); ++m) {
                     if (oi(m, k) < 0) continue;
                     T s = F(L.OS, m, k);
+                    if (erho > T(0)) {
+                        const T ee = OE_(0, m, k), de = trial ? T(OE_(1, m, k)) : T(0);
+                        if (trial) s += alpha * (-(OB_(0, m, k) + s - ee) - obst_jdz(k, m) + de);
+                        acc.mul(s); acc.mul(ee + (trial ? alpha * de : T(0)));
+                        continue;
+                    }
                     if (trial) s += alpha * (-(OB_(0, m, k) + s) - obst_jdz(k, m));
                     acc.mul(s);
                 }
@@ -903,7 +946,7 @@ struct IpmWave {
         bool stage, on[4], quad, mint, dtf;
         int k;
     };
-    __device__ __forceinline__ bool trial_fast_ok() const { return EXT == 0 && !GS && !(sizeof(T) == 8 && NTRB > 3) && nM() == 0 && L.n <= kWave; }      // (the extended instantiations and the fp64 bicycle / front-wheel models keep those registers for what they add: no scratch memory anywhere)
+    __device__ __forceinline__ bool trial_fast_ok() const { return EXT == 0 && !GS && !OBST && !(sizeof(T) == 8 && NTRB > 3) && L.n <= kWave; }      // (a kernel with clearance-row code only runs for handles that have rows)      // (the extended instantiations and the fp64 bicycle / front-wheel models keep those registers for what they add: no scratch memory anywhere)
     __device__ __forceinline__ void trial_setup(TrialRegs& r, T dd) const {
         const int n = L.n, k = lane;
         const T d = SCL(SC_D);
@@ -1044,10 +1087,17 @@ struct IpmWave {
                         if (fpline() || dynobs()) { F(L.OAT, m, k) = a3[2]; F(L.OHXT, m, k) = h3[0]; F(L.OHYT, m, k) = h3[1]; F(L.OHTT, m, k) = h3[2]; }
                         if (dynturn()) { F(L.OAD, m, k) = ad; F(L.OHXD, m, k) = hd[0]; F(L.OHYD, m, k) = hd[1]; F(L.OHDD, m, k) = hd[2]; F(L.OHTD, m, k) = hd[3]; }
                         const T s = F(L.OS, m, k), y = F(L.OY, m, k);
-                        const T res = g + s;
+                        const T ee = erho > T(0) ? T(OE_(0, m, k)) : T(0);            // restoration mode: the row reads g + s - e = 0
+                        const T res = g + s - ee;
                         rp = t_max(rp, t_abs(res)); th += t_abs(res);
                         cmin = t_min(cmin, s * y); cmax = t_max(cmax, s * y); cs += s * y;
                         sb += y; nb += 1;
+                        if (erho > T(0)) {      // the elastic variable's own complementarity, e (rho - y); e itself counts as infeasibility of the ORIGINAL row
+                            const T ce = ee * (erho - y);
+                            cmin = t_min(cmin, ce); cmax = t_max(cmax, ce); cs += ce;
+                            sb += erho - y; nb += 1;
+                            rp = t_max(rp, ee);
+                        }
                         osx += y * ax; osy += y * ay;
                         if (dynturn()) { rdd += y * ad; ost += y * a3[2]; }
                         else if (dynobs()) rdd += y * a3[2]; else ost += y * a3[2];
@@ -1210,8 +1260,9 @@ struct IpmWave {
                     const T s = F(L.OS, m, k), y = F(L.OY, m, k), g = OB_(0, m, k);
                     const T ax = OB_(1, m, k), ay = OB_(2, m, k), hk = OB_(3, m, k);
                     const T is = t_rcp(s);
-                    const T sig = y * is;
-                    const T ybar = mu * is + sig * (g + s);
+                    T sig = y * is;
+                    T ybar = mu * is + sig * (g + s);
+                    if (erho > T(0)) elastic_condense(s, y, g, T(OE_(0, m, k)), sig, ybar);
                     // hess(g) = -hk (I - a a')
                     sp.oxx += sig * ax * ax - y * hk * (T(1) - ax * ax);
                     sp.oxy += sig * ax * ay + y * hk * ax * ay;
@@ -2283,6 +2334,17 @@ struct IpmWave {
                     if (oi(m, k) < 0) continue;
                     const T jdz = obst_jdz(k, m);
                     const T s = F(L.OS, m, k), y = F(L.OY, m, k);
+                    if (erho > T(0)) {      // restoration mode: elastic row; the step of e is kept for the trials and the accept pass
+                        const T ee = OE_(0, m, k);
+                        T ds, de, dy, ybar;
+                        elastic_steps(s, y, OB_(0, m, k), ee, jdz, ds, de, dy, ybar);
+                        OE_(1, m, k) = de;
+                        hdz += ybar * jdz;
+                        dphi += -(mu * t_rcp(s)) * ds - (mu * t_rcp(ee)) * de + erho * de;
+                        ftb_ratio(t_rcp(s), ds, r_p); ftb_ratio(t_rcp(ee), de, r_p);
+                        ftb_ratio(t_rcp(y), dy, r_d); ftb_ratio(t_rcp(erho - y), -dy, r_d);
+                        continue;
+                    }
                     const T res = OB_(0, m, k) + s;
                     const T is = t_rcp(s);
                     const T sig = y * is;
@@ -2339,6 +2401,18 @@ struct IpmWave {
                     const T res = OB_(0, m, k) + s;
                     const T is = t_rcp(s);
                     const T sig = y * is;
+                    if (erho > T(0)) {      // restoration mode: slack, elastic variable and multiplier of the elastic row; the same safeguards for e and its multiplier rho - y
+                        const T ee = OE_(0, m, k);
+                        T ds, de, dy, ybar;
+                        elastic_steps(s, y, OB_(0, m, k), ee, jdz, ds, de, dy, ybar);
+                        const T so = s + alpha * ds, eo = ee + alpha * de;
+                        T yo = y + a_d * dy;
+                        const T muso = mu * t_rcp(so), mueo = mu * t_rcp(eo);
+                        yo = t_min(t_max(yo, muso * (T(1) / kS)), kS * muso);
+                        yo = t_min(t_max(yo, erho - kS * mueo), erho - mueo * (T(1) / kS));
+                        F(L.OS, m, k) = so; F(L.OY, m, k) = yo; OE_(0, m, k) = eo;
+                        continue;
+                    }
                     const T so = s + alpha * (-res - jdz);
                     T yo = y + a_d * (mu * is + sig * res + sig * jdz - y);
                     const T muso = mu * t_rcp(so);
@@ -2606,6 +2680,28 @@ struct IpmWave {
     }
 
     // ---------------------------------------------------------------- driver (all lanes, uniform control flow)
+    // enters the restoration mode at the current point (the caches of kkt_pass hold the rows' values there); returns what the objective gains: rho x sum of e
+    __device__ __forceinline__ T enter_restoration() {
+        const int n = L.n;
+        erho = Algo<T>::elastic_rho;
+        T esum = T(0);
+        for (int k = lane; k < n - 1; k += kWave) {
+            if (k < 1) continue;
+            for (int m = 0; m < nM(); ++m) {
+                if (oi(m, k) < 0) continue;
+                const T g = OB_(0, m, k);
+                const T s = t_max(t_max(-g, Algo<T>::clearance_slack_push), F(L.OS, m, k));
+                const T ee = t_max(g + s, mu / erho);
+                const T y = t_max(t_min(F(L.OY, m, k), T(0.5) * erho), mu / s);
+                F(L.OS, m, k) = s; F(L.OY, m, k) = y; OE_(0, m, k) = ee; OE_(1, m, k) = T(0);
+                esum += ee;
+            }
+        }
+        esum = wave_sum(esum);
+        sync();
+        return erho * esum;
+    }
+
     __device__ __forceinline__ SolveStats<T> solve() {
         SolveStats<T> out;
         flags = (P.xf_fixed[0] ? 1 : 0) | (P.xf_fixed[1] ? 2 : 0) | (P.xf_fixed[2] ? 4 : 0) | (P.dt_free ? 8 : 0) | (P.objective == OBJ_QUADRATIC ? 16 : 0) |
@@ -2628,6 +2724,8 @@ struct IpmWave {
         const int acc_it = P.acc_iter;
         T e0 = T(0), logs_cur = T(0), dc_mu = T(-1), dc_val = T(0);
         T last_alpha = T(0), last_ad = T(0);
+        int jam_streak = 0;
+        T jam_theta0 = T(0);
         bool endgame = false;
         const T mu_max = Algo<T>::mu_max_fact * mu;
         bool have_logs = false;
@@ -2648,6 +2746,20 @@ struct IpmWave {
 #ifdef MPC_ASM_MARK
             asm volatile("; KKT_END");
 #endif
+            if constexpr (OBST) {
+                // RESTORATION for clearance rows that jam (r05; what Ipopt leaves to its restoration phase -- src/controller.cpp:388-421 hands the NLP to Ipopt; restated in
+                // the CPU restatements the tests check against; DESIGN.md section 3.3 has the derivation).  A row that starts violated pulls its slack to the boundary within a
+                // few iterations; from then on the fraction-to-boundary rule admits steps of 1e-3 and the infeasibility stays where it is.  Detected as elastic_trigger
+                // iterations in a row with a primal step limit below elastic_ap while the infeasibility has not fallen below elastic_prog x its value at the start of the
+                // streak.  From there on the clearance rows are ELASTIC: g + s - e = 0, e >= 0, + rho e in the objective (the exact l1 penalty of the row's violation).
+                // Every row is satisfied again at once -- e takes up the violation, the slack goes back to its start rule --, and rho pushes e to zero as the trajectory
+                // moves out of the band.  The mode stays on until the solve ends; e counts as primal infeasibility (kkt_pass), so a solve can only end with e <= tol.
+                if (nM() > 0 && erho == T(0) && jam_streak >= Algo<T>::elastic_trigger && er.theta >= Algo<T>::elastic_prog * jam_theta0) {
+                    fobj += enter_restoration();
+                    rho = T(0); have_logs = false; jam_streak = 0;
+                    er = kkt_pass();
+                }
+            }
             e0 = err_value(er, T(0));
             // (t_max / t_min drop a NaN operand: the maxima inside e0 cannot carry one; the sums do -- ADVICE r03)
             if (!t_finite(e0) || !t_finite(er.theta) || !t_finite(er.sum_mult) || !t_finite(er.csum)) { status = ST_NUMERICAL; break; }
@@ -2770,6 +2882,12 @@ struct IpmWave {
                 if (delta > Algo<T>::delta_max) break;
             }
             if (!ok) { status = ST_LINSOLVE; break; }
+            if constexpr (OBST) {      // the restoration trigger's streak
+                if (nM() > 0 && erho == T(0)) {
+                    if (fw.a_p < Algo<T>::elastic_ap && er.rp > T(1e-3)) { if (jam_streak == 0) jam_theta0 = er.theta; ++jam_streak; }
+                    else jam_streak = 0;
+                }
+            }
             if (delta > T(0)) delta_last = delta;
             if (started_zero) fail0 = delta > T(0);
             const T theta = er.theta;

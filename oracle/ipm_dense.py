@@ -645,8 +645,8 @@ class IpmOptions:
     # the objective (the exact l1 penalty of the row's violation).  e counts as primal infeasibility, so the solve can only end with e <= tol.  elastic_rho = 0: off.
     elastic_rho: float = 1000.0
     elastic_ap: float = 5e-2
-    elastic_prog: float = 0.7
-    elastic_trigger: int = 3
+    elastic_prog: float = 0.8
+    elastic_trigger: int = 5
     verbose: bool = False
 
 

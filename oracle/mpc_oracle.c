@@ -1174,7 +1174,7 @@ typedef struct {
     double elastic_prog;     /* ... and the streak only triggers when the infeasibility is still above this share of its value at the streak's start */
     int elastic_trigger;     /* with elastic_rho > 0: 0 = from the start, k > 0 = entered after k iterations in a row whose fraction-to-boundary step is below 1e-2 while a row is violated */
 } algo_t;
-static algo_t g_algo = {0, 0, 0, 0, 100.0, 0.8, 0, 1, 1000.0, 5e-2, 0.7, 3};
+static algo_t g_algo = {0, 0, 0, 0, 100.0, 0.8, 0, 1, 1000.0, 5e-2, 0.8, 5};
 static int g_inertia = 1;      /* 1: a factorisation is accepted when the KKT matrix has Ipopt's inertia (the algorithm); 0: the inertia-free curvature test of r01-r03 (kept for the measurements of DESIGN 3.1) */
 void oracle_set_algo(int key, double v) {
     if (key == 9) { g_inertia = (int)v; return; }

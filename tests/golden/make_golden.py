@@ -333,6 +333,8 @@ def make_line_footprint(name, n=30, B=16, keep=6, M=4):
         if ref.status != 0 or ref.iters > 60:
             continue
         dmin = min(R.footprint_distance(cfg.footprint_kind, cfg.footprint_params, ref.traj.x[k], ob) for k in range(1, n - 1) for ob in obs)
+        if dmin < cfg.min_obstacle_dist - 1e-6:
+            continue      # an answer that passes an obstacle its grid point carried no row for (the association is frozen on the start trajectory, in the reference as here): not a fixture
         rows.append(dict(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=dtp[i], pts=pts[i], x=ref.traj.x, u=np.vstack([ref.traj.u, ref.traj.u[-1:]]),
                          dt=ref.traj.dt, iters=ref.iters, dmin=dmin))
     np.savez_compressed(os.path.join(OUT, name + ".npz"), line=np.array(LINE_FP), max_rows=M, **{k: np.array([r[k] for r in rows]) for k in rows[0]})
@@ -408,7 +410,7 @@ if __name__ == "__main__" and "--integral-free" in sys.argv:
     make_integral_free_dt("unicycle_quadratic_integral_free_dt_n20")
 
 
-def make_dynamic_obstacles(name, n=30, B=12, keep=6, M=4, O=3):
+def make_dynamic_obstacles(name, n=30, B=16, keep=6, M=4, O=3):
     """a22: dynamic obstacles (stage_inequality_se2.cpp:99-106,177-189) in the car-like min-time problem: a circular obstacle that crosses the
     path with constant velocity (its row at grid point k is evaluated at the predicted position for t = k dt, so the row depends on dt)
     and a static point obstacle.  Every kept instance is re-checked in the reference-form rows (ReferenceNlp with relevant_dyn)."""
@@ -436,6 +438,8 @@ def make_dynamic_obstacles(name, n=30, B=12, keep=6, M=4, O=3):
         z = nlp.pack(ref.traj)
         assert np.abs(nlp.equalities(z)).max() < 1e-7 and nlp.inequalities(z).max() < 1e-7
         dmin = min(R.footprint_distance(cfg.footprint_kind, cfg.footprint_params, ref.traj.x[k], obs[0], k * ref.traj.dt) for k in range(1, n - 1))
+        if abs(dmin - cfg.min_obstacle_dist) > 1e-5:
+            continue      # the fixture is about answers on which the moving obstacle's row BINDS (tests/test_gpu_parity.py::test_dynamic_obstacles_golden checks exactly that)
         rows.append(dict(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=dtp[i], n_obstacles=2, n_vertices=np.array([1, 1, 0]), vertices=verts, radius=rad,
                          velocity=vel, x=ref.traj.x, u=np.vstack([ref.traj.u, ref.traj.u[-1:]]), dt=ref.traj.dt, iters=ref.iters, dmin=dmin))
     np.savez_compressed(os.path.join(OUT, name + ".npz"), max_rows=M, **{k: np.array([r[k] for r in rows]) for k in rows[0]})
