@@ -17,7 +17,7 @@ CSRC = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC, "libmpc_hip.so")
 UBENCH_PATH = os.path.join(CSRC, "libmpc_ubench.so")     # measurement aid of bench.py (full-occupancy FMA rate), not part of the C ABI
 SOURCES = ["mpc_capi.hip", "mpc_solve_inst.hip"]
-HEADERS = ["mpc_solve_kernel.hpp", "mpc_core.hpp", "mpc_problem.hpp", "mpc_wave.hpp", "mpc_wave_layout.hpp", "mpc_wave_rows.inc", "mpc_wave_passes.inc", "mpc_wave_sweeps.inc", "mpc_wave_pit.inc",
+HEADERS = ["mpc_solve_kernel.hpp", "mpc_core.hpp", "mpc_problem.hpp", "mpc_wave.hpp", "mpc_wave_layout.hpp", "mpc_wave_debug.hpp", "mpc_wave_rows.inc", "mpc_wave_passes.inc", "mpc_wave_sweeps.inc", "mpc_wave_pit.inc",
            "mpc_wave_step.inc", "mpc_wave_solve.inc", "mpc_dpp_blocks.inc", "mpc_costmap.hpp", "mpc_feasibility.hpp", "mpc_grid_update.hpp", os.path.join("..", "..", "include", "mpc_hip.h")]
 
 EXPORTS = [

@@ -40,6 +40,7 @@ __device__ long long g_mpc_prof[4096][16];
 #endif
 
 #include "mpc_wave_layout.hpp"
+#include "mpc_wave_debug.hpp"
 
 namespace mpc {
 
