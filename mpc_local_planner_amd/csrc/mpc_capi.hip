@@ -304,7 +304,7 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         if (per_xcd > grid) per_xcd = grid;
         s->n_gslots = (int)per_xcd;
         const size_t blk64 = cfg->precision != MPC_FP32 ? (size_t)(s->gs64 ? s->WLg.GSW : s->WL.GSW) * 8 : 0, blk32 = cfg->precision != MPC_FP64 ? (size_t)(s->gs32 ? s->WLg.GSW : s->WL.GSW) * 4 : 0;
-        if (er == hipSuccess) er = hipMalloc(&s->d_gstage, 8 * per_xcd * (blk64 > blk32 ? blk64 : blk32));
+        if (er == hipSuccess) er = hipMalloc(&s->d_gstage, 8 * per_xcd * (blk64 > blk32 ? blk64 : blk32) + (size_t)mpc::GlobalStage::kPrefetchPad * 8);
         if (er == hipSuccess) er = hipMalloc((void**)&s->d_gslots, 8 * per_xcd * 4);
         if (er == hipSuccess) er = hipMemset(s->d_gslots, 0, 8 * per_xcd * 4);
     }

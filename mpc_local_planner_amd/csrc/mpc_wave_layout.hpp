@@ -33,6 +33,7 @@ struct GlobalStage {
     __host__ __device__ static constexpr int OEL(int ns, int nstg, int M) { return OBC(ns, nstg) + 4 * M * ns; }   // 2 M NS words [OE | ODE][m][k]: the elastic variables of the clearance rows and
                                                                                                      // their steps (restoration mode, IpmWave::solve)
     __host__ __device__ static constexpr int words(int ns, int nstg, int M) { return ((OEL(ns, nstg, M) + 2 * M * ns + 15) / 16) * 16; }     // (128-byte multiple in fp64)
+    static constexpr int kPrefetchPad = 256;      // words behind the LAST block of the allocation: the forward sweeps prefetch up to three stages past a record's end (values never used)
     // a layout that keeps its factorisation data in LDS still has a block when it has clearance rows: the elastic arrays alone (touched by the lane-parallel passes only, and
     // only in the restoration mode: not worth 2 M words of LDS per grid point)
     static constexpr int OEL_ONLY = 16;
