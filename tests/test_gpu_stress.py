@@ -59,6 +59,51 @@ def test_candidate_results_are_bit_identical_over_200_launches_at_B32768(m):
     s.close()
 
 
+def test_global_form_blocks_are_claimed_and_released_without_a_trace_over_40_launches(m):
+    """The global form of the factorisation data (mpc_config.stage_data) hands every workgroup a block of global memory claimed from the pool of ITS XCD
+    (mpc_solve_kernel.hpp: HW_REG_XCC_ID + a CAS probe) -- 2048 blocks for 16384 workgroups per launch here, so every block changes hands about eight times per launch, in an
+    order that differs from launch to launch.  A block that moved between XCDs, a claim that two workgroups won, or a stale word that some path consumed would show up as
+    a difference: 40 launches of the config-5 shape (n = 120, fp64, four candidates, B = 4096) and 10 of config 3 (n = 80, 16 polygons, B = 4096) are compared bit for
+    bit with launch 0 on the device, and launch 0 with the LDS form.  (SLOW_TIER)"""
+    import torch
+    from mpc_local_planner_amd import _abi as A
+    dev = torch.device("cuda", 0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    C5 = dict(candidates=(0, 1, 2, 5), candidate_max_iter=(60, 50, 45, 40), candidate_param=(0.0, 0.0, 0.0, 2.0))
+    B = 4096
+    x0, xf, up, dtp, obs = m.workloads.unicycle_obstacle_inputs(B, n_obst=16, max_vertices=6, lateral=(0.15, 0.8))
+    cases = [("config 5 shape", 120, 40, lambda **k: m.config_bicycle_min_time(120, **C5, **k), m.workloads.bicycle_min_time_inputs(B), None),
+             ("config 3", 80, 10, lambda **k: m.config_unicycle_quadratic(80, max_obstacles=16, max_vertices=6, max_obstacle_rows=4, max_iter=60, **k), (x0, xf, up, dtp), obs)]
+    for tag, n, launches, mk, inp, ob in cases:
+        d_in = [t(a) for a in inp]
+        d_ob = None if ob is None else [t(a) for a in ob]
+        obp = None if ob is None else tuple(a.data_ptr() for a in d_ob)
+        out = lambda: dict(x=torch.full((B, n, 3), float("nan"), dtype=torch.float64, device=dev), u=torch.full((B, n, 2), float("nan"), dtype=torch.float64, device=dev),
+                           dt=torch.full((B,), float("nan"), dtype=torch.float64, device=dev), st=torch.full((B,), -7, dtype=torch.int32, device=dev),
+                           it=torch.full((B,), -7, dtype=torch.int32, device=dev))
+
+        def launch(s, o):
+            s.solve_device(B, d_in[0].data_ptr(), d_in[1].data_ptr(), d_in[2].data_ptr(), d_in[3].data_ptr(), None, None, None,
+                           o["x"].data_ptr(), o["u"].data_ptr(), o["dt"].data_ptr(), o["st"].data_ptr(), o["it"].data_ptr(), obstacles=obp)
+            s.synchronize()
+        sl = m.BatchSolver(mk(stage_data=A.STAGE_LDS), max_batch=B)
+        lds = out(); launch(sl, lds); sl.close()
+        s = m.BatchSolver(mk(), max_batch=B)                      # MPC_STAGE_AUTO: the global form on both workloads
+        assert s.lds_bytes() < 45000
+        ref = out(); launch(s, ref)
+        assert (ref["st"] == 0).float().mean().item() > 0.95 and not torch.isnan(ref["x"]).any()
+        assert all(torch.equal(ref[k], lds[k]) for k in ref), tag
+        bad = []
+        for k in range(1, launches):
+            o = out(); launch(s, o)
+            diffs = {name: int((o[name] != ref[name]).sum().item()) for name in ref}
+            if any(diffs.values()):
+                bad.append((k, diffs))
+        print(f"[global-form blocks, {tag}] B = {B}, {launches} launches: {len(bad)} differ from launch 0" + (f": {bad[:5]}" if bad else ""))
+        assert not bad, bad[:5]
+        s.close()
+
+
 def test_rccl_all_gather_of_device_resident_results_with_a_world_of_one_rank(m):
     """bench.py's N > 1 path on a one-GPU box: `nccl` (= RCCL) process group, a solve of the shard, all_gather of status / dt / x where they live
     (HBM to HBM), the own shard found in the gathered arrays."""
