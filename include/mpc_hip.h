@@ -251,7 +251,8 @@ void mpc_config_defaults(mpc_config* cfg);
 int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_solver** out);
 
 /* Replaces Controller::reset (controller.h:104): waits for the stream and returns the handle's per-instance state (candidate
- * bookkeeping, the duals kept for warm starts) to its initial values. */
+ * bookkeeping, the duals kept for warm starts, the claim words of the factorisation-data blocks of mpc_config.stage_data) to its initial values -- all of it restores
+ * itself at the end of every launch, so this only matters after a launch that was aborted. */
 int mpc_reset(mpc_solver* s);
 
 void mpc_destroy(mpc_solver* s);
@@ -383,9 +384,11 @@ int mpc_synchronize(mpc_solver* s);
  * HIP events on the solver's own stream (call after mpc_synchronize). */
 int mpc_last_kernel_ms(mpc_solver* s, float* ms);
 
-/* Dynamic LDS bytes of one workgroup of the solve kernel for this handle = the whole working set of ONE planner instance (mpc_wave.hpp::WaveLayout + the problem
- * record).  A compute unit of the MI355X has 160 KB: 163840 / bytes workgroups (one wavefront each) are resident per CU -- 4 at BASELINE configs[1] (n = 50, fp64), 2 at
- * configs[2] (n = 80, 16 polygons, four clearance rows per grid point), 3 in the fp32 phase of configs[4] (n = 120). */
+/* Dynamic LDS bytes of one workgroup of the solve kernel for this handle = the working set of ONE planner instance that lives in LDS (mpc_wave_layout.hpp::WaveLayout + the
+ * problem record; with mpc_config.stage_data in the global form the factorisation data is not part of it).  A compute unit of the MI355X has 160 KB and its register file
+ * holds four of these one-wave workgroups: min(4, 163840 / bytes) are resident per CU -- 4 at BASELINE configs[1] (n = 50, fp64: 40 128 B), 4 at configs[2] (n = 80, 16 polygons,
+ * four clearance rows per grid point: 30 896 B in the global form MPC_STAGE_AUTO picks; 81 456 B = 2 per CU in the LDS form), 4 at configs[4]'s shape in fp64 (n = 120: 34 928 B;
+ * 95 408 B = 1 in the LDS form), 3 in fp32 there (47 792 B, LDS form).  MPC_MIXED reports its fp64 phase. */
 int mpc_lds_bytes(const mpc_solver* s, int64_t* bytes);
 
 /* Human-readable text of the last HIP/runtime error on this thread ("" if none). */
