@@ -13,7 +13,8 @@
 // Differences a maintainer should know (all reported, none silent):
 //   * footprint_model/type costmap_2d: teb's PolygonRobotFootprint has no accessor for its vertices, so the model object handed to configure() cannot be read
 //     back; call setCostmapFootprint(costmap_ros->getRobotFootprint()) before configure(), otherwise the point model is used and a warning is logged;
-//   * (optional: mpc_hip/dual_warm_start, mpc_hip/mu_init_warm, mpc_hip/mu_init_dual -- multipliers kept between solves, barrier start of warm-started solves)
+//   * (optional: mpc_hip/dual_warm_start, mpc_hip/mu_init_warm, mpc_hip/mu_init_dual -- multipliers kept between solves, barrier start of warm-started solves;
+//      mpc_hip/stage_data = auto | lds | global -- where a solve keeps its factorisation data, mpc_config.stage_data)
 //   * the handle's capacities come from extra parameters, mpc_hip/max_obstacles (default 256), mpc_hip/max_vertices (default 8) and mpc_hip/max_obstacle_rows (clearance rows
 //     per grid point, default 4; the reference has no cap -- a warning says how many rows of a cycle did not fit); when a cycle has more obstacles than max_obstacles, the nearest
 //     ones to the robot are kept and a warning is logged; a polygon with more vertices than max_vertices is an error (step fails);
@@ -134,6 +135,7 @@ class Controller {
         { bool dual = false; nh.param("mpc_hip/dual_warm_start", dual, dual); caps.dual_warm_start = dual ? 1 : 0; }
         nh.param("mpc_hip/mu_init_warm", caps.mu_init_warm, caps.mu_init_warm);
         nh.param("mpc_hip/mu_init_dual", caps.mu_init_dual, caps.mu_init_dual);
+        { std::string sd = "auto"; nh.param("mpc_hip/stage_data", sd, sd); caps.stage_data = sd == "lds" ? MPC_STAGE_LDS : (sd == "global" ? MPC_STAGE_GLOBAL : MPC_STAGE_AUTO); }
         amd::ParamReport report;
         _amd.setInitialPlanEstimateOrientation(_initial_plan_estimate_orientation);
         std::string type; if (nh.getParam("footprint_model/type", type) && type == "costmap_2d" && _costmap_footprint.empty())

@@ -134,7 +134,7 @@ void mpc_config_defaults(mpc_config* c) {
 }
 
 const char* mpc_last_error(void) { return g_err; }
-int32_t mpc_version(void) { return 400; }      // 0.4.0: mpc_config.mu_strategy / max_time_us took reserved words (same size), MPC_TIME_LIMIT; a solve accepts factorisations on their inertia
+int32_t mpc_version(void) { return 500; }      // 0.5.0: mpc_config.stage_data took a reserved word (same size); a solve restores clearance rows that jam.  0.4.0: mpc_config.mu_strategy / max_time_us took reserved words (same size), MPC_TIME_LIMIT; a solve accepts factorisations on their inertia
 // history: 0.2.0: mpc_config grew (candidates, kept multipliers, hessian_mode), new entry points; 0.2.1: cost variants (off-diagonal weights, trapezoidal rule, hybrid cost)
 
 #ifdef MPC_PROFILE
@@ -300,7 +300,8 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         if (er == hipSuccess) er = hipGetDeviceProperties(&prop, device);
         const size_t c32 = (cfg->precision != MPC_FP64 && s->P32.n_cand > 1) ? (size_t)s->P32.n_cand : 1, c64 = (cfg->precision != MPC_FP32 && s->P64.n_cand > 1) ? (size_t)s->P64.n_cand : 1;
         const size_t grid = Bm * (c32 > c64 ? c32 : c64);
-        size_t per_xcd = er == hipSuccess ? (size_t)prop.multiProcessorCount : 256;
+        // (at least 256: in a partitioned mode the device is ONE XCD with 32 CUs, which still holds 32 x 8 workgroups)
+        size_t per_xcd = er == hipSuccess && prop.multiProcessorCount > 256 ? (size_t)prop.multiProcessorCount : 256;
         if (per_xcd > grid) per_xcd = grid;
         s->n_gslots = (int)per_xcd;
         const size_t blk64 = cfg->precision != MPC_FP32 ? (size_t)(s->gs64 ? s->WLg.GSW : s->WL.GSW) * 8 : 0, blk32 = cfg->precision != MPC_FP64 ? (size_t)(s->gs32 ? s->WLg.GSW : s->WL.GSW) * 4 : 0;
