@@ -702,6 +702,53 @@ def test_kkt_checker_takes_the_clearance_rows_of_the_trajectory_a_solve_started_
     assert len(not_cold) >= 1          # the distinction is real on this workload
 
 
+def test_restoration_for_jammed_clearance_rows_in_both_cpu_solvers(c_oracle):
+    """r05: clearance rows that jam -- five iterations in a row whose fraction-to-boundary limit on the primal step is below 0.05 with the infeasibility still at
+    80 % -- turn elastic (g + s - e = 0, e >= 0, + 1000 e).  Car-like minimum time, n = 30, three point obstacles 0.05 .. 0.5 m beside the path (d_min 0.3: most rows start violated),
+    64 instances, reference path alone.  (i) The mode changes the outcome of some instances and ONLY helps the converged count: instances that ran into the iteration limit converge.
+    (ii) Along the restoration path the dense numpy solver and the banded-LU C solver -- two implementations of the rule, two linear algebras -- produce the same iterate sequence:
+    same iteration counts, trajectories equal to 1e-6 (they are equal to 1e-13 on most).  (iii) What is returned is a KKT point of the reference-form NLP with the frozen rows
+    (oracle/kkt_check.py), i.e. the elastic variables ended at zero."""
+    import ctypes as C
+    from oracle import kkt_check as KC
+    import mpc_local_planner_amd.workloads as W
+    B, n, O = 64, 30, 3
+    x0, xf, up, dtp = W.carlike_min_time_inputs(B, seed=77, goal_range=(2.0, 4.0))
+    rng = np.random.default_rng(78)
+    d = xf[:, None, :2] - x0[:, None, :2]
+    nrm = np.stack([-d[..., 1], d[..., 0]], -1) / np.linalg.norm(d, axis=-1, keepdims=True)
+    pts = x0[:, None, :2] + rng.uniform(0.2, 0.8, (B, O, 1)) * d + rng.uniform(0.05, 0.5, (B, O, 1)) * rng.choice([-1.0, 1.0], (B, O, 1)) * nrm
+    obstacles = (np.full(B, O, np.int32), np.ones((B, O), np.int32), pts.reshape(B, O, 1, 2))
+    ocfg = R.config_carlike_min_time(n)
+    ocfg.min_obstacle_dist, ocfg.force_inclusion_dist, ocfg.cutoff_dist = 0.3, 0.5, 2.5
+    ob = c_oracle.obst_from_nlp_config(ocfg, O, 1, 4)
+    lib = c_oracle._load()
+    on = c_oracle.solve_batch(c_oracle.from_nlp_config(ocfg), x0, xf, up, dtp, obstacles=obstacles, obst=ob)
+    try:
+        lib.oracle_set_algo(C.c_int(10), C.c_double(0.0))                  # experiment switch: restoration off
+        off = c_oracle.solve_batch(c_oracle.from_nlp_config(ocfg), x0, xf, up, dtp, obstacles=obstacles, obst=ob)
+    finally:
+        lib.oracle_set_algo(C.c_int(10), C.c_double(1000.0))
+    changed = np.flatnonzero((on[3] != off[3]) | (on[4] != off[4]))
+    print(f"[restoration, CPU] converged without / with: {int((off[3] == 0).sum())} / {int((on[3] == 0).sum())} of {B}; instances whose iterate path it changes: "
+          f"{[(int(i), int(off[3][i]), int(off[4][i]), int(on[3][i]), int(on[4][i])) for i in changed]}")
+    assert len(changed) >= 4 and (on[3] == 0).sum() >= (off[3] == 0).sum() + 2
+    assert not ((off[3] == 0) & (on[3] != 0)).any()                        # nothing that converged without the mode is lost with it
+    same_it, checked = 0, 0
+    for i in [int(i) for i in changed if on[3][i] == 0][:5]:
+        obs = [R.Obstacle(R.OBST_POINT, pts[i, o:o + 1]) for o in range(O)]
+        inp = R.CycleInputs(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=float(dtp[i]), obstacles=obs)
+        init = R.cold_start(ocfg, x0[i], xf[i])
+        rel, _ = R.associate_obstacles(ocfg, init, obs, max_rows=4)
+        ref = I.solve(ocfg, inp, init, relevant=rel, opt=I.IpmOptions(globalization="merit", max_iter=100))
+        assert ref.status == 0
+        assert np.abs(ref.traj.x - on[0][i]).max() < 1e-4 and abs(ref.traj.dt - on[2][i]) < 1e-8
+        same_it += int(ref.iters == on[4][i]); checked += 1
+    assert checked >= 3 and same_it >= checked - 1
+    res = KC.kkt_many(ocfg, x0, xf, up, dtp, on[0], on[1], on[2], [int(i) for i in changed if on[3][i] == 0], obstacles=obstacles, max_rows=4)
+    assert all(KC.is_kkt_point(r, 1e-6, 1e-6, 1e-6) for r in res.values()), res
+
+
 def test_clearance_to_every_obstacle_needs_a_renewed_association(c_oracle):
     """The clearance rows of ONE solve are those associated on the trajectory it starts from (StageInequalitySE2::update runs in the grid update, before the solve:
     stage_inequality_se2.cpp:50-162) -- in the reference as here.  Measured with plain geometry (no solver quantity) on config 3 with polygons 0.15 .. 0.8 m beside the
