@@ -615,6 +615,52 @@ def test_long_horizon_bicycle_vs_c_oracle(m, c_oracle):
     s.close()
 
 
+def test_restoration_on_the_device_follows_the_c_oracle(m, c_oracle):
+    """r05 (DESIGN.md 3.3): the workload of tests/test_oracle_solver.py::test_restoration_for_jammed_clearance_rows_in_both_cpu_solvers (car-like minimum time, n = 30, three
+    point obstacles 0.05 .. 0.5 m beside the path, d_min 0.3, reference path alone) on the device, in the LDS form and -- forced -- in the global form: the instances whose iterate
+    path the restoration mode changes are known from the C oracle (its experiment switch turns the mode off); on those, and on the whole batch, the device returns the C oracle's
+    statuses, its trajectories and (within a few) its iteration counts.  The workload also guards the pivot test of the root system (mpc_core.hpp::riccati_root): measured against the
+    largest entry of the system instead of the pivot's own row, it ended 6 of these 64 solves with MPC_LINSOLVE in their last iterations (r05)."""
+    import ctypes as C
+    from oracle import se2_nlp as R
+    from mpc_local_planner_amd import _abi as A
+    B, n, O = 64, 30, 3
+    x0, xf, up, dtp = m.workloads.carlike_min_time_inputs(B, seed=77, goal_range=(2.0, 4.0))
+    rng = np.random.default_rng(78)
+    d = xf[:, None, :2] - x0[:, None, :2]
+    nrm = np.stack([-d[..., 1], d[..., 0]], -1) / np.linalg.norm(d, axis=-1, keepdims=True)
+    pts = x0[:, None, :2] + rng.uniform(0.2, 0.8, (B, O, 1)) * d + rng.uniform(0.05, 0.5, (B, O, 1)) * rng.choice([-1.0, 1.0], (B, O, 1)) * nrm
+    obstacles = (np.full(B, O, np.int32), np.ones((B, O), np.int32), pts.reshape(B, O, 1, 2))
+    ocfg = R.config_carlike_min_time(n)
+    ocfg.min_obstacle_dist, ocfg.force_inclusion_dist, ocfg.cutoff_dist = 0.3, 0.5, 2.5
+    ob = c_oracle.obst_from_nlp_config(ocfg, O, 1, 4)
+    lib = c_oracle._load()
+    on = c_oracle.solve_batch(c_oracle.from_nlp_config(ocfg), x0, xf, up, dtp, obstacles=obstacles, obst=ob)
+    try:
+        lib.oracle_set_algo(C.c_int(10), C.c_double(0.0))
+        off = c_oracle.solve_batch(c_oracle.from_nlp_config(ocfg), x0, xf, up, dtp, obstacles=obstacles, obst=ob)
+    finally:
+        lib.oracle_set_algo(C.c_int(10), C.c_double(1000.0))
+    changed = (on[3] != off[3]) | (on[4] != off[4])
+    assert changed.sum() >= 4
+    for mode in (A.STAGE_AUTO, A.STAGE_GLOBAL):
+        s = m.BatchSolver(m.config_carlike_min_time(n, min_obstacle_dist=0.3, force_inclusion_dist=0.5, cutoff_dist=2.5, max_obstacles=O, max_vertices=1, max_obstacle_rows=4,
+                                                    stage_data=mode), max_batch=B)
+        r = s.solve(x0, xf, up, dtp, obstacles=obstacles)
+        s.close()
+        both = (r.status == 0) & (on[3] == 0)
+        err = np.abs(r.x - on[0]).reshape(B, -1).max(1)
+        print(f"[restoration on the device, stage_data {mode}] converged device / oracle {int((r.status == 0).sum())} / {int((on[3] == 0).sum())} (oracle without the mode: {int((off[3] == 0).sum())}); "
+              f"on the {int(changed.sum())} instances the mode changes: same status {int((r.status[changed] == on[3][changed]).sum())}, same iterations {int((r.iters[changed] == on[4][changed]).sum())}, "
+              f"max |x - oracle| {err[changed & both].max():.1e}")
+        assert (r.status == on[3]).mean() >= 0.97 and (r.status[changed] == on[3][changed]).sum() >= changed.sum() - 1
+        # iteration counts: the end game of these solves is badly scaled (active rows: dt-dt entries of 1e11 in the value function), the last digits of the optimality error
+        # differ between the sweeps and the banded LU and with them the iteration in which it passes tol -- a handful of instances end one to four iterations apart
+        assert (np.abs(r.iters - on[4])[both] <= 4).mean() >= 0.95 and (r.iters == on[4])[both].mean() >= 0.8
+        same = both & (r.iters == on[4])
+        assert np.median(err[both]) < 1e-9 and (err[same] < 1e-5).sum() >= same.sum() - 2 and (err[both] < 1e-3).sum() >= both.sum() - 1
+
+
 def test_active_clearance_rows_vs_c_oracle(m, c_oracle):
     """Obstacles INSIDE the clearance band (workload lateral=(0.15, 0.8): the rows start violated and about a quarter of the instances
     end with binding clearance constraints).  The device must converge on the same instances as the C oracle and land on the same
@@ -975,7 +1021,7 @@ def test_candidate_initial_trajectories_best_of(m):
     s = m.BatchSolver(m.config_carlike_min_time(50), max_batch=2 * B)
     best, win, allr = K.solve_best_of(s, x0, xf, up, dtp, guesses=("cold", "travel"))
     cold_ok = allr.status[:B] == 0
-    assert (best.status == 0).mean() >= 0.97 and (best.status == 0).mean() >= cold_ok.mean() + 0.02
+    assert (best.status == 0).mean() >= 0.97 and (best.status == 0).sum() >= min(B, cold_ok.sum() + 3)      # the C solver's cold start: 251 of these 256
     assert (best.status[cold_ok] == 0).all() and (best.dt[cold_ok] <= allr.dt[:B][cold_ok] + 1e-12).all()
     single = s.solve(x0, xf, up, dtp)                                   # the device-side cold start is the same guess
     same = cold_ok & (single.status == 0)
