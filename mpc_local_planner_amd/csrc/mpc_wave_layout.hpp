@@ -17,23 +17,29 @@ constexpr int NGAIN = 24;  // negated gains: nK0(6) nkappa0 nKnu0(5) | nK1(6) nk
 constexpr int NGH = NGAIN / 2;
 
 // Factorisation data in global memory (IpmWave<..., GS = true>): what the Riccati sweeps stream through -- the stage records STG, the gains GAIN, and copies of
-// the little else their running pointers touch (the constant triples ZC, the residuals c_k, the folded residuals c^_k, a dummy store target) -- sits in ONE block of
-// global memory per workgroup, stage-major exactly like the LDS arrays it replaces, so that the sweeps' pointer arithmetic is the same in both storage classes.
-// The LDS record shrinks from 97 to 34 words per grid point (n = 120 in fp64: 95 KB -> 33 KB, four workgroups per CU instead of one); the block is written and
-// re-read by the same CU within one interior-point iteration (L2 / Infinity-Cache resident: 63 n words per resident wave).  Word offsets inside the block:
+// the little else their running pointers touch (the constant triples, the residuals c_k, the folded residuals c^_k) -- sits in ONE block of global memory per
+// workgroup.  The LDS record shrinks from 97 to 34 words per grid point (n = 120 in fp64: 95 KB -> 33 KB, four workgroups per CU instead of one); the block is
+// written and re-read by the same CU within one interior-point iteration (L2 / Infinity-Cache resident).
+// Layout inside the block: COMPONENT-major rows of `pitch` words (entry i of every stage adjacent; the LDS arrays these replace are stage-major).  The lane-parallel
+// passes (lane = stage) then read and write whole cache lines -- stage-major records put every lane of a load into a line of its own, 16 x the bytes through the
+// L1 -- and a lane of a serial sweep streams along one row, 16 stages per line.  The pitch leaves at least 16 spare columns behind the n stages: the sweeps' idle
+// lanes store there, and the prefetches that run a few stages past either end of a row land there (or in the previous row's spare columns).  Word offsets:
 struct GlobalStage {
-    static constexpr int ZC = 0;          // 8 words: constants 0 0 0 0 1 0 0 0
-    static constexpr int VP = 8;          // 16 words: dummy store targets of the idle lanes
-    static constexpr int CC = 32;         // 3 NS words, stage-major: c_k (copy of the LDS array, written by kkt_pass)
-    __host__ __device__ static constexpr int CH(int ns) { return CC + 3 * ns; }            // 3 NS words, component-major: c^_k = c_k + f_k dd (forward sweeps)
-    __host__ __device__ static constexpr int GAIN(int ns) { return CC + 6 * ns; }          // NGAIN NS words, stage-major
-    __host__ __device__ static constexpr int STG(int ns) { return CC + (6 + NGAIN) * ns; }    // nstg NS words, stage-major
-    __host__ __device__ static constexpr int OBC(int ns, int nstg) { return STG(ns) + nstg * ns; }   // 4 M NS words, component-major [OG | OAX | OAY | OHK][m][k]: the clearance rows' cached value,
-                                                                                                     // gradient and curvature (touched by the lane-parallel passes only: coalesced)
+    __host__ __device__ static constexpr int pitch(int ns) { return (ns / 16 + 2) * 16; }      // a multiple of 16 words: rows start on a cache line
+    static constexpr int ZC = 0;          // 8 words: constants 0 0 0 0 1 0 0 0 (single words read with stride 0)
+    static constexpr int VP = 8;          // 16 words: unused (kept so that the rows start at word 32)
+    static constexpr int Z3 = 32;         // 3 rows: the constant coefficient triples of the backward sweeps as COLUMNS -- column 0 (0,0,0), column 1 (1,0,0), column 2 (0,1,0)
+    __host__ __device__ static constexpr int CC(int ns) { return Z3 + 3 * pitch(ns); }            // 3 rows: c_k (copy of the LDS array, written by kkt_pass)
+    __host__ __device__ static constexpr int CH(int ns) { return CC(ns) + 3 * pitch(ns); }        // 3 rows: c^_k = c_k + f_k dd (forward sweeps)
+    __host__ __device__ static constexpr int GAIN(int ns) { return CH(ns) + 3 * pitch(ns); }      // NGAIN (ns + 1) words (+ padding to a line), STAGE-major: the gains are written by the sweeps, 24 adjacent words per stage
+                                                                                                  // (as rows every stage of a sweep would store into 20 lines); the record behind the last stage is the idle lanes' store target
+    __host__ __device__ static constexpr int STG(int ns) { return GAIN(ns) + ((NGAIN * (ns + 1) + 15) / 16) * 16; }    // nstg rows
+    __host__ __device__ static constexpr int OBC(int ns, int nstg) { return STG(ns) + nstg * pitch(ns); }   // 4 M NS words [OG | OAX | OAY | OHK][m][k]: the clearance rows' cached value,
+                                                                                                     // gradient and curvature (touched by the lane-parallel passes only)
     __host__ __device__ static constexpr int OEL(int ns, int nstg, int M) { return OBC(ns, nstg) + 4 * M * ns; }   // 2 M NS words [OE | ODE][m][k]: the elastic variables of the clearance rows and
                                                                                                      // their steps (restoration mode, IpmWave::solve)
     __host__ __device__ static constexpr int words(int ns, int nstg, int M) { return ((OEL(ns, nstg, M) + 2 * M * ns + 15) / 16) * 16; }     // (128-byte multiple in fp64)
-    static constexpr int kPrefetchPad = 256;      // words behind the LAST block of the allocation: the forward sweeps prefetch up to three stages past a record's end (values never used)
+    static constexpr int kPrefetchPad = 256;      // words behind the LAST block of the allocation (slack for reads past a block's last row; values never used)
     // a layout that keeps its factorisation data in LDS still has a block when it has clearance rows: the elastic arrays alone (touched by the lane-parallel passes only, and
     // only in the restoration mode: not worth 2 M words of LDS per grid point)
     static constexpr int OEL_ONLY = 16;
