@@ -53,6 +53,7 @@ struct WaveLayout {
     int M, O, V;                                  // clearance rows per grid point, obstacles, vertices per obstacle
     int OS, OY, OI, OG, OAX, OAY, OHK;            // per-row slack, multiplier, obstacle index, cached g, gradient, curvature
     int GV, GNV, GR, GC;                          // obstacle geometry: vertices, vertex counts, radii, centroids
+    int GE;                                       // edge table (V >= 2): 3 words per edge (b - a, 1 / |b - a|^2), computed once per solve by load_obstacles
     int OAT, OHXT, OHYT, OHTT;                    // third-variable parts of the clearance rows: heading (footprints that turn with the pose) or
                                                   // dt (dynamic obstacles); MT = M when either is configured, else 0 words
     int OAD, OHXD, OHYD, OHDD, OHTD;              // dt parts when BOTH apply (dynamic obstacles + a turning footprint): gradient, hess [x dt, y dt, dt dt, theta dt]
@@ -88,6 +89,7 @@ struct WaveLayout {
         L.OI = o; o += (M * n * 2 + tsize - 1) / tsize;      // uint16 per row and grid point (0xffff = no row): a quarter of a T word each -- what lets BASELINE configs[2] (n = 80, 16 polygons) keep TWO workgroups per CU
         L.OG = take(gs ? 0 : M); L.OAX = take(gs ? 0 : M); L.OAY = take(gs ? 0 : M); L.OHK = take(gs ? 0 : M);      // (gs: the cached row values / gradients / curvatures live in the global block too)
         L.GV = o; o += 2 * O * V; L.GNV = o; o += O; L.GR = o; o += O; L.GC = o; o += 2 * O;
+        L.GE = o; o += V >= 2 ? 3 * O * V : 0;
         L.NV = NV; L.VIA = o; o += 3 * NV; L.VIDX = o; o += NV;
         L.OAT = take(MT); L.OHXT = take(MT); L.OHYT = take(MT); L.OHTT = take(MT);
         L.OAD = take(MD); L.OHXD = take(MD); L.OHYD = take(MD); L.OHDD = take(MD); L.OHTD = take(MD);
@@ -110,7 +112,7 @@ struct FixedLayout {
     static constexpr int X = c().X, U = c().U, LAM = c().LAM, LAMN = c().LAMN, SR = c().SR, YR = c().YR, PL = c().PL, PU = c().PU, DX = c().DX, DU = c().DU, CC = c().CC,
                          TRIG = c().TRIG, GAIN = c().GAIN, STG = c().STG, SC = c().SC, VP = c().VP, ZC = c().ZC, ZI = c().ZI, total = c().total;
     static constexpr int M = 0, O = 0, V = 1, NV = 0, GSW = 0, GSF = 0, OEB = 0;
-    static constexpr int OS = c().OS, OY = c().OY, OI = c().OI, OG = c().OG, OAX = c().OAX, OAY = c().OAY, OHK = c().OHK, GV = c().GV, GNV = c().GNV, GR = c().GR, GC = c().GC,
+    static constexpr int OS = c().OS, OY = c().OY, OI = c().OI, OG = c().OG, OAX = c().OAX, OAY = c().OAY, OHK = c().OHK, GV = c().GV, GNV = c().GNV, GR = c().GR, GC = c().GC, GE = c().GE,
                          OAT = c().OAT, OHXT = c().OHXT, OHYT = c().OHYT, OHTT = c().OHTT, OAD = c().OAD, OHXD = c().OHXD, OHYD = c().OHYD, OHDD = c().OHDD, OHTD = c().OHTD,
                          GVEL = c().GVEL, VIA = c().VIA, VIDX = c().VIDX;
     // does a run-time layout describe the same record?  (n and V -- the vertex capacity, unused without obstacles -- aside)

@@ -451,8 +451,8 @@ def test_mixed_grid_sizes_in_one_batch(m):
 def test_lds_working_set_and_workgroups_per_cu_of_the_baseline_configs(m):
     """mpc_lds_bytes: the working set of one instance in LDS = the dynamic LDS of its workgroup; what the 160 KB of a compute unit hold decides how many wavefronts a
     CU runs (four at most: the register file holds the kernel at one wave per SIMD).  Everything in LDS (MPC_STAGE_LDS, rounds 1-4): 4 at BASELINE configs[1] / [3]
-    (n = 50, fp64), 2 at configs[2] (n = 80, 16 polygons of 6 vertices, four clearance rows per grid point), 3 in plain fp32 at configs[4] (n = 120), 1 in fp64 there.
-    r05, MPC_STAGE_AUTO: with the factorisation data in global memory where the LDS form leaves half of the SIMDs empty, 3 at configs[2] and 4 at n = 120 in fp64;
+    (n = 50, fp64), 2 at configs[2] until r05 and 1 since (n = 80, 16 polygons of 6 vertices, four clearance rows per grid point), 3 in plain fp32 at configs[4] (n = 120), 1 in fp64 there.
+    r05, MPC_STAGE_AUTO: with the factorisation data in global memory where the LDS form leaves half of the SIMDs empty, 4 at configs[2] and 4 at n = 120 in fp64;
     the headline grid, fp32 and the refinement phase of MPC_MIXED keep the LDS form."""
     from mpc_local_planner_amd import _abi as A
     CU = 160 * 1024
@@ -464,7 +464,7 @@ def test_lds_working_set_and_workgroups_per_cu_of_the_baseline_configs(m):
     lds = dict(stage_data=A.STAGE_LDS)
     assert wgs(m.config_carlike_min_time(50))[0] == 4 and wgs(m.config_carlike_min_time(50))[1] == wgs(m.config_carlike_min_time(50, **lds))[1]
     w3, b3 = wgs(m.config_unicycle_quadratic(80, max_obstacles=16, max_vertices=6, max_obstacle_rows=4, **lds))
-    assert w3 == 2, b3
+    assert w3 == 1 and b3 < 84 * 1024, b3          # (2 until the edge table of the polygon distances -- 2.3 KB -- went in: 81 456 B were 464 B short of the limit for two)
     w3, b3 = wgs(m.config_unicycle_quadratic(80, max_obstacles=16, max_vertices=6, max_obstacle_rows=4))
     assert w3 == 4, b3
     assert wgs(m.config_unicycle_quadratic(80, **lds))[0] == 2 and wgs(m.config_unicycle_quadratic(80))[0] == 4
