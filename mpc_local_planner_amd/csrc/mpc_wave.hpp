@@ -76,6 +76,7 @@ struct IpmWave {
     int flags;      // bits 0..2 xf_fixed, 3 dt_free, 4 quadratic objective, 5 has_Qf, 6..9 rate_on, 10 terminal ball, 11 via-points, 12 footprint that turns with the pose (line, two circles), 13 integral form with dt free, 14 dynamic obstacles: the problem record lives in LDS and every
                     // P.x costs a ds_read (+ wait) that the compiler cannot hoist over LDS stores; one scalar register holds the switches
 #ifdef MPC_PROFILE
+    mutable long long prof_mult = 0;
     mutable long long prof_loop = 0, prof_setup = 0, prof_fwd_loop = 0;    // ticks inside the backward stage loop / before it / inside the forward loop
 #endif
     int nfix;

@@ -24,7 +24,7 @@
             long long* o = g_mpc_prof[blockIdx.x]; \
             o[0] = __builtin_readcyclecounter() - t_begin; o[1] = wall_clock64() - w_begin; o[2] = it; o[3] = nfac; o[4] = ntrial; \
             for (int i = 0; i < 8; ++i) o[5 + i] = tk[i]; \
-            o[13] = prof_loop; o[14] = prof_setup; o[15] = prof_fwd_loop; \
+            o[13] = prof_loop; o[14] = prof_setup; o[15] = prof_fwd_loop; if (prof_mult) o[10] = prof_mult;      /* (-DMPC_PROFILE_MULT: the multiplier recurrence instead of logs0) */ \
         }
 #else
 #define MPC_PROFILE_BEGIN
