@@ -497,6 +497,29 @@ def test_fixed_layout_kernel_equals_the_generic_kernel_bit_for_bit(m):
         assert np.array_equal(ra.x, rb.x[:, :50]) and np.array_equal(ra.u[:, :49], rb.u[:, :49])
 
 
+def test_global_form_equals_lds_form_over_the_grid_sizes(m):
+    """The global block's rows have a pitch of (n / 16 + 2) x 16 words, the sweeps' prefetches run into the spare columns, the partitioned sweeps start at 40 grid points and a
+    ragged batch uses less than a row: fp64 results of the two forms bit for bit over grid sizes on either side of every such boundary (scripts/dev/gs_sweep.py is the longer list)."""
+    from mpc_local_planner_amd import _abi as A
+    B = 32
+    def both(mk, inp, n_grid=None, **kw):
+        out = []
+        for mode in (A.STAGE_LDS, A.STAGE_GLOBAL):
+            s = m.BatchSolver(mk(mode), max_batch=B)
+            if n_grid is not None: s.set_grid_sizes(n_grid)
+            out.append(s.solve(*inp, **kw)); s.close()
+        for f in ("x", "u", "dt", "status", "iters"):
+            assert np.array_equal(getattr(out[0], f), getattr(out[1], f), equal_nan=True), f
+        assert (out[0].status == 0).mean() > 0.7
+    for n in (12, 39, 40, 48, 49, 64, 65, 128, 129, 200):
+        both(lambda mode: m.config_carlike_min_time(n, stage_data=mode), m.workloads.carlike_min_time_inputs(B, seed=n))
+    for n in (30, 64, 100):
+        x0, xf, up, dtp, obstacles = m.workloads.unicycle_obstacle_inputs(B, n_obst=8, max_vertices=5, lateral=(0.15, 0.8))
+        both(lambda mode: m.config_unicycle_quadratic(n, max_obstacles=8, max_vertices=5, max_obstacle_rows=3, max_iter=60, stage_data=mode), (x0, xf, up, dtp), obstacles=obstacles)
+    ng = np.random.default_rng(90).integers(8, 91, B).astype(np.int32)
+    both(lambda mode: m.config_bicycle_min_time(90, stage_data=mode), m.workloads.bicycle_min_time_inputs(B), n_grid=ng)
+
+
 @pytest.mark.parametrize("case", ["bicycle_n120_fp64_candidates", "bicycle_n120_mixed", "unicycle_n80_polygons", "carlike_n50_candidates", "carlike_n30_ragged_fp32"])
 def test_factorisation_data_in_global_memory_equals_lds_bit_for_bit(m, case):
     """mpc_config.stage_data: the stage records and Riccati gains of a solve (63 of the 97 words per grid point) live in LDS or in a per-workgroup block of
