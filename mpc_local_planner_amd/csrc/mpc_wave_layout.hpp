@@ -46,6 +46,18 @@ struct GlobalStage {
     __host__ __device__ static constexpr int words_elastic_only(int ns, int M) { return ((OEL_ONLY + 2 * M * ns + 15) / 16) * 16; }
 };
 
+// (compile-time checks of the block's layout for the grid sizes on either side of a pitch boundary: rows start on a cache line, at least 16 spare columns behind the stages, the
+//  regions follow each other without overlap, the spare gain record and the obstacle arrays fit)
+constexpr bool global_stage_ok(int ns, int nstg, int M) {
+    using G = GlobalStage;
+    return G::pitch(ns) % 16 == 0 && G::pitch(ns) >= ns + 16 && G::Z3 >= G::VP + 16 && G::CC(ns) == G::Z3 + 3 * G::pitch(ns) && G::CH(ns) == G::CC(ns) + 3 * G::pitch(ns) &&
+           G::GAIN(ns) == G::CH(ns) + 3 * G::pitch(ns) && G::STG(ns) >= G::GAIN(ns) + NGAIN * (ns + 1) && G::STG(ns) % 16 == 0 && G::OBC(ns, nstg) == G::STG(ns) + nstg * G::pitch(ns) &&
+           G::OEL(ns, nstg, M) == G::OBC(ns, nstg) + 4 * M * ns && G::words(ns, nstg, M) >= G::OEL(ns, nstg, M) + 2 * M * ns && G::words(ns, nstg, M) % 16 == 0;
+}
+static_assert(global_stage_ok(3, NSTG_BASE, 0) && global_stage_ok(15, NSTG_BASE, 4) && global_stage_ok(16, NSTG_BASE, 4) && global_stage_ok(17, NSTG_BASE, 0) && global_stage_ok(50, NSTG_BASE, 0) &&
+              global_stage_ok(80, NSTG_BASE, 4) && global_stage_ok(120, NSTG_BASE, 0) && global_stage_ok(127, NSTG_EXT, 8) && global_stage_ok(128, NSTG_EXT, 8) && global_stage_ok(590, NSTG_BASE, 0),
+              "GlobalStage: a region overlaps its neighbour or a row does not start on a cache line");
+
 struct WaveLayout {
     int n, NS;
     int NTR;                                      // trig-cache words per stage (3, or 4 for the bicycle / front-wheel car; +2 for Crank-Nicolson)
