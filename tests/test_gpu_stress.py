@@ -36,6 +36,7 @@ def test_candidate_results_are_bit_identical_over_200_launches_at_B32768(m):
                       it=torch.full((B,), -7, dtype=torch.int32, device=dev))
 
     def launch(o):
+        torch.cuda.current_stream().synchronize()      # the fills of `o` run on torch's stream, the solve on the handle's own (non-blocking) one: without this a late fill can overwrite what the solve wrote
         s.solve_device(B, d_in[0].data_ptr(), d_in[1].data_ptr(), d_in[2].data_ptr(), d_in[3].data_ptr(), None, None, None,
                        o["x"].data_ptr(), o["u"].data_ptr(), o["dt"].data_ptr(), o["st"].data_ptr(), o["it"].data_ptr())
         s.synchronize()
@@ -83,6 +84,7 @@ def test_global_form_blocks_are_claimed_and_released_without_a_trace_over_40_lau
                            it=torch.full((B,), -7, dtype=torch.int32, device=dev))
 
         def launch(s, o):
+            torch.cuda.current_stream().synchronize()      # the fills of `o` run on torch's stream, the solve on the handle's own (non-blocking) one: without this a late fill can overwrite what the solve wrote
             s.solve_device(B, d_in[0].data_ptr(), d_in[1].data_ptr(), d_in[2].data_ptr(), d_in[3].data_ptr(), None, None, None,
                            o["x"].data_ptr(), o["u"].data_ptr(), o["dt"].data_ptr(), o["st"].data_ptr(), o["it"].data_ptr(), obstacles=obp)
             s.synchronize()
