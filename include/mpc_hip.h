@@ -278,7 +278,10 @@ int mpc_solve_batch(mpc_solver* s, int32_t B,
                     int32_t* status, int32_t* iters);
 
 /* Same contract with DEVICE pointers (HBM-resident inputs/outputs), asynchronous on the
- * solver's stream; pair with mpc_synchronize.  This is what bench.py times. */
+ * solver's stream; pair with mpc_synchronize.  This is what bench.py times.
+ * The solver's stream is a NON-BLOCKING one (hipStreamNonBlocking): it is not ordered against the null stream or any
+ * other stream of the caller.  Work of the caller that produces the inputs -- or still writes the output buffers, e.g. a
+ * fill enqueued on another stream -- has to be complete (stream / event synchronised) before this call. */
 int mpc_solve_batch_device(mpc_solver* s, int32_t B,
                            const double* d_x0, const double* d_xf, const double* d_u_prev, const double* d_dt_prev,
                            const double* d_x_init, const double* d_u_init, const double* d_dt_init,
