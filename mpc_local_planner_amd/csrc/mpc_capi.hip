@@ -306,6 +306,8 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         s->n_gslots = (int)per_xcd;
         const size_t blk64 = cfg->precision != MPC_FP32 ? (size_t)(s->gs64 ? s->WLg.GSW : s->WL.GSW) * 8 : 0, blk32 = cfg->precision != MPC_FP64 ? (size_t)(s->gs32 ? s->WLg.GSW : s->WL.GSW) * 4 : 0;
         if (er == hipSuccess) er = hipMalloc(&s->d_gstage, 8 * per_xcd * (blk64 > blk32 ? blk64 : blk32) + (size_t)mpc::GlobalStage::kPrefetchPad * 8);
+        // developer check (scripts/dev/gs_sweep.py under MPC_POISON_GSTAGE=1): every word of the pool starts as a NaN pattern, so a word that some path consumes before writing it shows up in the results
+        if (er == hipSuccess) { if (const char* e = getenv("MPC_POISON_GSTAGE")) { if (e[0] == '1') er = hipMemset(s->d_gstage, 0xFF, 8 * per_xcd * (blk64 > blk32 ? blk64 : blk32) + (size_t)mpc::GlobalStage::kPrefetchPad * 8); } }
         if (er == hipSuccess) er = hipMalloc((void**)&s->d_gslots, 8 * per_xcd * 4);
         if (er == hipSuccess) er = hipMemset(s->d_gslots, 0, 8 * per_xcd * 4);
     }

@@ -1,5 +1,5 @@
 """developer check (GPU): global form == LDS form bit for bit (fp64) over a sweep of grid sizes around the row pitch's / the partitioned sweeps' boundaries, with and without
-clearance rows, and with ragged grids"""
+clearance rows, and with ragged grids.  Under MPC_POISON_GSTAGE=1 the pool of global blocks starts as NaN patterns: a word consumed before it is written would show up here."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
