@@ -92,16 +92,19 @@ struct IpmWave {
     // ---- LDS accessors: component-major, stage-minor (conflict-free for lane == stage)
     __device__ __forceinline__ T& F(int base, int comp, int k) const { return sm[base + comp * L.NS + k]; }
     // stage records: stage-major in LDS
-    // (GS: the same records in the workgroup's global block, COMPONENT-major rows of gpitch() words (GlobalStage) -- byte offsets are formed in 32 bits and
+    // (GS: the same records in the workgroup's global block, in tiles of four stages (GlobalStage) -- byte offsets are formed in 32 bits and
     //  zero-extended, so that the accesses compile to global_load / global_store with the block's base in a scalar register pair)
     typedef __attribute__((address_space(1))) T GlbT;
     typedef __attribute__((address_space(1))) char GlbC;
     using SwT = std::conditional_t<GS, GlbT, T>;                         // a word of the sweeps' storage class
     __device__ __forceinline__ GlbT& gw(unsigned word) const { return *(GlbT*)((GlbC*)gmb + (size_t)(word * (unsigned)sizeof(T))); }
-    __device__ __forceinline__ int gpitch() const { return GlobalStage::pitch(L.NS); }
-    __device__ __forceinline__ SwT& G_(int i, int k) const { if constexpr (GS) return gw((unsigned)(GlobalStage::GAIN(L.NS) + k * NGAIN + i)); else return sm[L.GAIN + k * NGAIN + i]; }
+    // entry e of stage k's tile slot (GlobalStage): [0, NSTG) the stage record, then c_k, c^_k, the constants 0 0 0 1 0 0
+    static constexpr int TE_CC = NSTG, TE_CH = NSTG + 3, TE_Z = NSTG + 6, TNT = GlobalStage::nt(NSTG);
+    __device__ __forceinline__ int tile_k(int k) const { return GlobalStage::TILE(L.NS) + ((k + GlobalStage::kGuard) >> 2) * (4 * TNT) + ((k + GlobalStage::kGuard) & 3); }      // word of entry 0 of stage k
+    __device__ __forceinline__ GlbT& TL_(int e, int k) const { return gw((unsigned)(tile_k(k) + 4 * e)); }
+    __device__ __forceinline__ SwT& G_(int i, int k) const { if constexpr (GS) return gw((unsigned)(GlobalStage::GAIN + k * NGAIN + i)); else return sm[L.GAIN + k * NGAIN + i]; }
     static constexpr int NADDv = EXT ? (int)NADD : (int)NADD_BASE;
-    __device__ __forceinline__ SwT& S_(int i, int k) const { if constexpr (GS) return gw((unsigned)(GlobalStage::STG(L.NS) + i * gpitch() + k)); else return sm[L.STG + k * NSTG + i]; }
+    __device__ __forceinline__ SwT& S_(int i, int k) const { if constexpr (GS) return TL_(i, k); else return sm[L.STG + k * NSTG + i]; }
     __device__ __forceinline__ T& C_(int i, int k) const { return sm[L.CC + k * 3 + i]; }
     // cached value (0), gradient (1, 2) and curvature (3) of clearance row m at grid point k: written by kkt_pass, read by the other lane-parallel passes
     __device__ __forceinline__ SwT& OB_(int which, int m, int k) const {
@@ -110,7 +113,7 @@ struct IpmWave {
     // elastic variable e (0) and its step de (1) of clearance row m at grid point k (restoration mode): always in the workgroup's global block
     __device__ __forceinline__ GlbT& OE_(int which, int m, int k) const { return gw((unsigned)(L.OEB + (which * L.M + m) * L.NS + k)); }
     // c^_k = c_k + f_k dd, what the forward sweeps read (component-major): parked in LAMN, or (GS) in the global block
-    __device__ __forceinline__ SwT& CH_(int i, int k) const { if constexpr (GS) return gw((unsigned)(GlobalStage::CH(L.NS) + i * gpitch() + k)); else return sm[L.LAMN + i * L.NS + k]; }
+    __device__ __forceinline__ SwT& CH_(int i, int k) const { if constexpr (GS) return TL_(TE_CH + i, k); else return sm[L.LAMN + i * L.NS + k]; }
     __device__ __forceinline__ T& SCL(int i) const { return sm[L.SC + i]; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
     __device__ __forceinline__ int nM() const { return OBST ? L.M : 0; }      // clearance rows per grid point
@@ -160,23 +163,25 @@ struct IpmWave {
     using SwRef = std::conditional_t<GS, unsigned, LdsT*>;
     using SwCRef = std::conditional_t<GS, unsigned, const LdsT*>;
     __device__ __forceinline__ int W_ZC() const { if constexpr (GS) return GlobalStage::ZC; else return L.ZC; }
-    // entry i of stage 0's record and the distance between stages, for the records the sweeps stream through (LDS: stage-major, entries adjacent; GS: rows)
-    __device__ __forceinline__ int STG_W(int i) const { if constexpr (GS) return GlobalStage::STG(L.NS) + i * gpitch(); else return L.STG + i; }
-    __device__ __forceinline__ int GAIN_W(int i) const { if constexpr (GS) return GlobalStage::GAIN(L.NS) + i; else return L.GAIN + i; }      // (stage-major in both)
-    __device__ __forceinline__ int CC_W(int i) const { if constexpr (GS) return GlobalStage::CC(L.NS) + i * gpitch(); else return L.CC + i; }
-    __device__ __forceinline__ int CH_W(int i) const { if constexpr (GS) return GlobalStage::CH(L.NS) + i * gpitch(); else return L.LAMN + i * L.NS; }      // c^_k of the forward sweeps (LDS: parked in LAMN, component-major)
-    static constexpr int STG_S = GS ? 1 : NSTG, GAIN_S = NGAIN, CC_S = GS ? 1 : 3;
-    // constant coefficient triple of the backward sweeps (read with stride 0): kind 0 (0,0,0)  1 (1,0,0)  2 (0,1,0)
-    __device__ __forceinline__ int ZT_W(int kind) const { if constexpr (GS) return GlobalStage::Z3 + kind; else return L.ZC + (kind == 1 ? 4 : (kind == 2 ? 3 : 0)); }
+    // LDS form: entry i of stage 0's record and the distance between stages, for the arrays the sweeps stream through.  (GS: the gains alike -- stage-major in both forms --; the
+    // stage records, c_k, c^_k and the constant triples are entries of a stage's tile slot, addressed as tile_k(k) + 4 e)
+    __device__ __forceinline__ int STG_W(int i) const { return L.STG + i; }
+    __device__ __forceinline__ int GAIN_W(int i) const { if constexpr (GS) return GlobalStage::GAIN + i; else return L.GAIN + i; }
+    __device__ __forceinline__ int CC_W(int i) const { return L.CC + i; }
+    __device__ __forceinline__ int CH_W(int i) const { return L.LAMN + i * L.NS; }      // c^_k of the forward sweeps (LDS form: parked in LAMN, component-major)
+    static constexpr int STG_S = NSTG, GAIN_S = NGAIN, CC_S = 3;
+    // constant coefficient triple of the backward sweeps (LDS form, read with stride 0): kind 0 (0,0,0)  1 (1,0,0)  2 (0,1,0); in the tile slot's constants 0 0 0 1 0 0 the same triples start at entries 0, 3, 2
+    __device__ __forceinline__ int ZT_W(int kind) const { return L.ZC + (kind == 1 ? 4 : (kind == 2 ? 3 : 0)); }
+    __device__ __forceinline__ static constexpr int zt_entry(int kind) { return TE_Z + (kind == 1 ? 3 : (kind == 2 ? 2 : 0)); }
     // where the idle lanes of a gain store go: the record behind the last stage / the sweep scratch
-    __device__ __forceinline__ int GAIN_DUMMY_W() const { if constexpr (GS) return GlobalStage::GAIN(L.NS) + L.NS * NGAIN; else return L.VP; }
+    __device__ __forceinline__ int GAIN_DUMMY_W() const { if constexpr (GS) return GlobalStage::GAIN + L.NS * NGAIN; else return L.VP; }
+    // a word of the global block at a byte offset that is the sum of a (wave-uniform or per-row) stage part and a per-lane entry part
+    __device__ __forceinline__ T gld(unsigned stage_bytes, unsigned lane_bytes) const { return *(const GlbT*)((const GlbC*)gmb + (size_t)stage_bytes + (size_t)lane_bytes); }
     __device__ __forceinline__ SwRef sw(int word) const { if constexpr (GS) return (unsigned)word * (unsigned)sizeof(T); else return lds(word); }
     __device__ __forceinline__ static constexpr int sw_step(int words) { return GS ? words * (int)sizeof(T) : words; }
     // word i (a compile-time constant at every call site) behind a running pointer / the word `step` pointer units behind it / entry i of the record the pointer is in
     __device__ __forceinline__ T sw_ld(SwCRef p, int i = 0) const { if constexpr (GS) return *(const GlbT*)((const GlbC*)gmb + (size_t)p + (size_t)(i * (int)sizeof(T))); else return p[i]; }
     __device__ __forceinline__ T sw_ld_at(SwCRef p, int step) const { if constexpr (GS) return *(const GlbT*)((const GlbC*)gmb + (size_t)(p + (unsigned)step)); else return p[step]; }
-    __device__ __forceinline__ T sw_ld_e(SwCRef p, int i) const { if constexpr (GS) return *(const GlbT*)((const GlbC*)gmb + (size_t)((unsigned)(i * gpitch()) * (unsigned)sizeof(T)) + (size_t)p); else return p[i]; }
-    __device__ __forceinline__ void sw_st_e(SwRef p, int i, T v) const { if constexpr (GS) *(GlbT*)((GlbC*)gmb + (size_t)((unsigned)(i * gpitch()) * (unsigned)sizeof(T)) + (size_t)p) = v; else p[i] = v; }
     __device__ __forceinline__ void sw_st(SwRef p, int i, T v) const { if constexpr (GS) *(GlbT*)((GlbC*)gmb + (size_t)p + (size_t)(i * (int)sizeof(T))) = v; else p[i] = v; }
 
     // trial point z + alpha*dz, evaluated on the fly (no trial copy in LDS)

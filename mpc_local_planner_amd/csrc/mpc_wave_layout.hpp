@@ -20,21 +20,24 @@ constexpr int NGH = NGAIN / 2;
 // the little else their running pointers touch (the constant triples, the residuals c_k, the folded residuals c^_k) -- sits in ONE block of global memory per
 // workgroup.  The LDS record shrinks from 97 to 34 words per grid point (n = 120 in fp64: 95 KB -> 33 KB, four workgroups per CU instead of one); the block is
 // written and re-read by the same CU within one interior-point iteration (L2 / Infinity-Cache resident).
-// Layout inside the block: COMPONENT-major rows of `pitch` words (entry i of every stage adjacent; the LDS arrays these replace are stage-major).  The lane-parallel
-// passes (lane = stage) then read and write whole cache lines -- stage-major records put every lane of a load into a line of its own, 16 x the bytes through the
-// L1 -- and a lane of a serial sweep streams along one row, 16 stages per line.  The pitch leaves at least 16 spare columns behind the n stages: the sweeps' idle
-// lanes store there, and the prefetches that run a few stages past either end of a row land there (or in the previous row's spare columns).  Word offsets:
+// Layout inside the block.  The vector-memory path of a CU charges an instruction per DISTINCT cache line it touches, and four resident waves share it
+// (scripts/ubench/vmem_lines.hip).  A lane-parallel pass has lane = stage: stage-major records put every lane of a load or store into a line of its own (64 per
+// instruction); a sweep has lane = entry: component-major rows put every lane into a row of its own (12 per instruction, 48 in the partitioned sweeps).  The stage
+// records therefore live in TILES of four stages, interleaved word by word: entry e of stage k is word 4 e + (k mod 4) of tile k / 4.  A pass touches 16 lines per
+// instruction (four lanes share 32 bytes), a sweep three or four, reused for four stages.  A stage's tile slot carries, behind the record, the copy of c_k, c^_k
+// and the constants 0 0 0 1 0 0 (the sweeps' constant coefficient triples are entries of the slot like everything else they read: every running pointer of a lane
+// moves through the tiles the same way).  One guard tile in front of stage 0 and the tiles behind stage n - 1 take the prefetches that run past either end.
+// The gains stay STAGE-major, 24 adjacent words per stage: the sweeps WRITE them (as rows a stage stored into 20 lines).  Word offsets:
 struct GlobalStage {
-    __host__ __device__ static constexpr int pitch(int ns) { return (ns / 16 + 2) * 16; }      // a multiple of 16 words: rows start on a cache line
-    static constexpr int ZC = 0;          // 8 words: constants 0 0 0 0 1 0 0 0 (single words read with stride 0)
-    static constexpr int VP = 8;          // 16 words: unused (kept so that the rows start at word 32)
-    static constexpr int Z3 = 32;         // 3 rows: the constant coefficient triples of the backward sweeps as COLUMNS -- column 0 (0,0,0), column 1 (1,0,0), column 2 (0,1,0)
-    __host__ __device__ static constexpr int CC(int ns) { return Z3 + 3 * pitch(ns); }            // 3 rows: c_k (copy of the LDS array, written by kkt_pass)
-    __host__ __device__ static constexpr int CH(int ns) { return CC(ns) + 3 * pitch(ns); }        // 3 rows: c^_k = c_k + f_k dd (forward sweeps)
-    __host__ __device__ static constexpr int GAIN(int ns) { return CH(ns) + 3 * pitch(ns); }      // NGAIN (ns + 1) words (+ padding to a line), STAGE-major: the gains are written by the sweeps, 24 adjacent words per stage
-                                                                                                  // (as rows every stage of a sweep would store into 20 lines); the record behind the last stage is the idle lanes' store target
-    __host__ __device__ static constexpr int STG(int ns) { return GAIN(ns) + ((NGAIN * (ns + 1) + 15) / 16) * 16; }    // nstg rows
-    __host__ __device__ static constexpr int OBC(int ns, int nstg) { return STG(ns) + nstg * pitch(ns); }   // 4 M NS words [OG | OAX | OAY | OHK][m][k]: the clearance rows' cached value,
+    static constexpr int ZC = 0;          // 8 words: constants 0 0 0 0 1 0 0 0 (single words read with stride 0 by the forward sweeps)
+    static constexpr int GAIN = 32;       // NGAIN (ns + 1) words, stage-major; the record behind the last stage is the idle lanes' store target
+    static constexpr int kGuard = 4;      // stages in front of stage 0 (one tile)
+    // entries of a stage's slot: [0, nstg) the record | c_k (3) | c^_k (3) | 0 0 0 1 0 0 | padding to a multiple of four
+    __host__ __device__ static constexpr int nt(int nstg) { return ((nstg + 12 + 3) / 4) * 4; }
+    __host__ __device__ static constexpr int tiles(int ns) { return (ns + kGuard + 4 + 3) / 4; }                      // stages -4 .. ns + 3
+    __host__ __device__ static constexpr int TILE(int ns) { return GAIN + ((NGAIN * (ns + 1) + 15) / 16) * 16; }
+    __host__ __device__ static constexpr int tile_k(int nstg, int k) { return ((k + kGuard) >> 2) * (4 * nt(nstg)) + ((k + kGuard) & 3); }      // + 4 e: entry e of stage k, relative to TILE
+    __host__ __device__ static constexpr int OBC(int ns, int nstg) { return TILE(ns) + tiles(ns) * 4 * nt(nstg); }   // 4 M NS words [OG | OAX | OAY | OHK][m][k]: the clearance rows' cached value,
                                                                                                      // gradient and curvature (touched by the lane-parallel passes only)
     __host__ __device__ static constexpr int OEL(int ns, int nstg, int M) { return OBC(ns, nstg) + 4 * M * ns; }   // 2 M NS words [OE | ODE][m][k]: the elastic variables of the clearance rows and
                                                                                                      // their steps (restoration mode, IpmWave::solve)
@@ -46,17 +49,18 @@ struct GlobalStage {
     __host__ __device__ static constexpr int words_elastic_only(int ns, int M) { return ((OEL_ONLY + 2 * M * ns + 15) / 16) * 16; }
 };
 
-// (compile-time checks of the block's layout for the grid sizes on either side of a pitch boundary: rows start on a cache line, at least 16 spare columns behind the stages, the
-//  regions follow each other without overlap, the spare gain record and the obstacle arrays fit)
+// (compile-time checks of the block's layout: the tiles start on a cache line and hold a whole number of lines, the regions follow each other without overlap, the
+//  spare gain record, the guard tile and the tiles behind the last stage exist, the obstacle arrays fit)
 constexpr bool global_stage_ok(int ns, int nstg, int M) {
     using G = GlobalStage;
-    return G::pitch(ns) % 16 == 0 && G::pitch(ns) >= ns + 16 && G::Z3 >= G::VP + 16 && G::CC(ns) == G::Z3 + 3 * G::pitch(ns) && G::CH(ns) == G::CC(ns) + 3 * G::pitch(ns) &&
-           G::GAIN(ns) == G::CH(ns) + 3 * G::pitch(ns) && G::STG(ns) >= G::GAIN(ns) + NGAIN * (ns + 1) && G::STG(ns) % 16 == 0 && G::OBC(ns, nstg) == G::STG(ns) + nstg * G::pitch(ns) &&
-           G::OEL(ns, nstg, M) == G::OBC(ns, nstg) + 4 * M * ns && G::words(ns, nstg, M) >= G::OEL(ns, nstg, M) + 2 * M * ns && G::words(ns, nstg, M) % 16 == 0;
+    return G::nt(nstg) % 4 == 0 && G::nt(nstg) >= nstg + 12 && G::TILE(ns) % 16 == 0 && G::TILE(ns) >= G::GAIN + NGAIN * (ns + 1) && (4 * G::nt(nstg)) % 16 == 0 &&
+           G::tile_k(nstg, -G::kGuard) == 0 && G::tile_k(nstg, ns + 3) + 4 * (G::nt(nstg) - 1) < G::tiles(ns) * 4 * G::nt(nstg) &&
+           G::OBC(ns, nstg) == G::TILE(ns) + G::tiles(ns) * 4 * G::nt(nstg) && G::OEL(ns, nstg, M) == G::OBC(ns, nstg) + 4 * M * ns &&
+           G::words(ns, nstg, M) >= G::OEL(ns, nstg, M) + 2 * M * ns && G::words(ns, nstg, M) % 16 == 0;
 }
 static_assert(global_stage_ok(3, NSTG_BASE, 0) && global_stage_ok(15, NSTG_BASE, 4) && global_stage_ok(16, NSTG_BASE, 4) && global_stage_ok(17, NSTG_BASE, 0) && global_stage_ok(50, NSTG_BASE, 0) &&
               global_stage_ok(80, NSTG_BASE, 4) && global_stage_ok(120, NSTG_BASE, 0) && global_stage_ok(127, NSTG_EXT, 8) && global_stage_ok(128, NSTG_EXT, 8) && global_stage_ok(590, NSTG_BASE, 0),
-              "GlobalStage: a region overlaps its neighbour or a row does not start on a cache line");
+              "GlobalStage: a region overlaps its neighbour or a tile does not start on a cache line");
 
 struct WaveLayout {
     int n, NS;
