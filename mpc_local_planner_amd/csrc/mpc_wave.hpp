@@ -98,8 +98,8 @@ struct IpmWave {
     typedef __attribute__((address_space(1))) char GlbC;
     using SwT = std::conditional_t<GS, GlbT, T>;                         // a word of the sweeps' storage class
     __device__ __forceinline__ GlbT& gw(unsigned word) const { return *(GlbT*)((GlbC*)gmb + (size_t)(word * (unsigned)sizeof(T))); }
-    // entry e of stage k's tile slot (GlobalStage): [0, NSTG) the stage record, then c_k, c^_k, the constants 0 0 0 1 0 0
-    static constexpr int TE_CC = NSTG, TE_CH = NSTG + 3, TE_Z = NSTG + 6, TNT = GlobalStage::nt(NSTG);
+    // entry e of stage k's tile slot (GlobalStage): [0, NSTG) the stage record, then c_k, the constants 0 0 0 1 0 0
+    static constexpr int TE_CC = NSTG, TE_Z = NSTG + 3, TNT = GlobalStage::nt(NSTG);
     __device__ __forceinline__ int tile_k(int k) const { return GlobalStage::TILE(L.NS) + ((k + GlobalStage::kGuard) >> 2) * (4 * TNT) + ((k + GlobalStage::kGuard) & 3); }      // word of entry 0 of stage k
     __device__ __forceinline__ GlbT& TL_(int e, int k) const { return gw((unsigned)(tile_k(k) + 4 * e)); }
     __device__ __forceinline__ SwT& G_(int i, int k) const { if constexpr (GS) return gw((unsigned)(GlobalStage::GAIN + k * NGAIN + i)); else return sm[L.GAIN + k * NGAIN + i]; }
@@ -112,8 +112,8 @@ struct IpmWave {
     }
     // elastic variable e (0) and its step de (1) of clearance row m at grid point k (restoration mode): always in the workgroup's global block
     __device__ __forceinline__ GlbT& OE_(int which, int m, int k) const { return gw((unsigned)(L.OEB + (which * L.M + m) * L.NS + k)); }
-    // c^_k = c_k + f_k dd, what the forward sweeps read (component-major): parked in LAMN, or (GS) in the global block
-    __device__ __forceinline__ SwT& CH_(int i, int k) const { if constexpr (GS) return TL_(TE_CH + i, k); else return sm[L.LAMN + i * L.NS + k]; }
+    // c^_k = c_k + f_k dd, what the forward sweeps read (component-major): parked in LAMN in both forms
+    __device__ __forceinline__ T& CH_(int i, int k) const { return sm[L.LAMN + i * L.NS + k]; }
     __device__ __forceinline__ T& SCL(int i) const { return sm[L.SC + i]; }
     __device__ __forceinline__ void sync() const { __syncthreads(); }
     __device__ __forceinline__ int nM() const { return OBST ? L.M : 0; }      // clearance rows per grid point

@@ -24,7 +24,7 @@ constexpr int NGH = NGAIN / 2;
 // (scripts/ubench/vmem_lines.hip).  A lane-parallel pass has lane = stage: stage-major records put every lane of a load or store into a line of its own (64 per
 // instruction); a sweep has lane = entry: component-major rows put every lane into a row of its own (12 per instruction, 48 in the partitioned sweeps).  The stage
 // records therefore live in TILES of four stages, interleaved word by word: entry e of stage k is word 4 e + (k mod 4) of tile k / 4.  A pass touches 16 lines per
-// instruction (four lanes share 32 bytes), a sweep three or four, reused for four stages.  A stage's tile slot carries, behind the record, the copy of c_k, c^_k
+// instruction (four lanes share 32 bytes), a sweep three or four, reused for four stages.  A stage's tile slot carries, behind the record, the copy of c_k
 // and the constants 0 0 0 1 0 0 (the sweeps' constant coefficient triples are entries of the slot like everything else they read: every running pointer of a lane
 // moves through the tiles the same way).  One guard tile in front of stage 0 and the tiles behind stage n - 1 take the prefetches that run past either end.
 // The gains stay STAGE-major, 24 adjacent words per stage: the sweeps WRITE them (as rows a stage stored into 20 lines).  Word offsets:
@@ -32,8 +32,8 @@ struct GlobalStage {
     static constexpr int ZC = 0;          // 8 words: constants 0 0 0 0 1 0 0 0 (single words read with stride 0 by the forward sweeps)
     static constexpr int GAIN = 32;       // NGAIN (ns + 1) words, stage-major; the record behind the last stage is the idle lanes' store target
     static constexpr int kGuard = 4;      // stages in front of stage 0 (one tile)
-    // entries of a stage's slot: [0, nstg) the record | c_k (3) | c^_k (3) | 0 0 0 1 0 0 | padding to a multiple of four
-    __host__ __device__ static constexpr int nt(int nstg) { return ((nstg + 12 + 3) / 4) * 4; }
+    // entries of a stage's slot: [0, nstg) the record | c_k (3) | 0 0 0 1 0 0 | padding to a multiple of four  (c^_k, the forward sweeps' constant term, is in LDS in both forms)
+    __host__ __device__ static constexpr int nt(int nstg) { return ((nstg + 9 + 3) / 4) * 4; }
     __host__ __device__ static constexpr int tiles(int ns) { return (ns + kGuard + 4 + 3) / 4; }                      // stages -4 .. ns + 3
     __host__ __device__ static constexpr int TILE(int ns) { return GAIN + ((NGAIN * (ns + 1) + 15) / 16) * 16; }
     __host__ __device__ static constexpr int tile_k(int nstg, int k) { return ((k + kGuard) >> 2) * (4 * nt(nstg)) + ((k + kGuard) & 3); }      // + 4 e: entry e of stage k, relative to TILE
@@ -53,7 +53,7 @@ struct GlobalStage {
 //  spare gain record, the guard tile and the tiles behind the last stage exist, the obstacle arrays fit)
 constexpr bool global_stage_ok(int ns, int nstg, int M) {
     using G = GlobalStage;
-    return G::nt(nstg) % 4 == 0 && G::nt(nstg) >= nstg + 12 && G::TILE(ns) % 16 == 0 && G::TILE(ns) >= G::GAIN + NGAIN * (ns + 1) && (4 * G::nt(nstg)) % 16 == 0 &&
+    return G::nt(nstg) % 4 == 0 && G::nt(nstg) >= nstg + 9 && G::TILE(ns) % 16 == 0 && G::TILE(ns) >= G::GAIN + NGAIN * (ns + 1) && (4 * G::nt(nstg)) % 16 == 0 &&
            G::tile_k(nstg, -G::kGuard) == 0 && G::tile_k(nstg, ns + 3) + 4 * (G::nt(nstg) - 1) < G::tiles(ns) * 4 * G::nt(nstg) &&
            G::OBC(ns, nstg) == G::TILE(ns) + G::tiles(ns) * 4 * G::nt(nstg) && G::OEL(ns, nstg, M) == G::OBC(ns, nstg) + 4 * M * ns &&
            G::words(ns, nstg, M) >= G::OEL(ns, nstg, M) + 2 * M * ns && G::words(ns, nstg, M) % 16 == 0;
