@@ -200,7 +200,8 @@ typedef struct mpc_config {
     int32_t mu_strategy;              /* solver/ipopt/ipopt_string_options/mu_strategy: MPC_MU_ADAPTIVE (0, the default) | MPC_MU_MONOTONE */
     int32_t stage_data;               /* where a solve keeps its factorisation data (stage records + Riccati gains, 63 of the 97 words per grid point): MPC_STAGE_AUTO (0: global
                                        * memory exactly when that puts more workgroups on a compute unit -- long horizons, clearance rows), MPC_STAGE_LDS, MPC_STAGE_GLOBAL.
-                                       * Results are bit-identical either way; no counterpart in the reference (its solver's working memory is Ipopt's) */
+                                       * Results are bit-identical either way in fp64 (in fp32 the two forms agree to rounding); no counterpart in the reference (its solver's
+                                       * working memory is Ipopt's) */
     int32_t reserved[2];
     /* full weight matrices (state_weights / control_weights / final_state_weights / weight_matrix given as n x n lists, column major,
      * src/controller.cpp:565-573,580-588,656-664,690-698): Q, R, Qf, terminal_ball_S above hold the DIAGONALS, these the off-diagonal terms
@@ -390,8 +391,8 @@ int mpc_last_kernel_ms(mpc_solver* s, float* ms);
 /* Dynamic LDS bytes of one workgroup of the solve kernel for this handle = the working set of ONE planner instance that lives in LDS (mpc_wave_layout.hpp::WaveLayout + the
  * problem record; with mpc_config.stage_data in the global form the factorisation data is not part of it).  A compute unit of the MI355X has 160 KB and its register file
  * holds four of these one-wave workgroups: min(4, 163840 / bytes) are resident per CU -- 4 at BASELINE configs[1] (n = 50, fp64: 40 128 B), 4 at configs[2] (n = 80, 16 polygons,
- * four clearance rows per grid point: 30 896 B in the global form MPC_STAGE_AUTO picks; 81 456 B = 2 per CU in the LDS form), 4 at configs[4]'s shape in fp64 (n = 120: 34 928 B;
- * 95 408 B = 1 in the LDS form), 3 in fp32 there (47 792 B, LDS form).  MPC_MIXED reports its fp64 phase. */
+ * four clearance rows per grid point: 33 200 B in the global form MPC_STAGE_AUTO picks; 83 760 B = 1 per CU in the LDS form), 4 at configs[4]'s shape in fp64 (n = 120: 34 928 B;
+ * 95 408 B = 1 in the LDS form) and in fp32 (17 552 B in the global form; 47 792 B = 3 in the LDS form).  MPC_MIXED reports its fp64 phase. */
 int mpc_lds_bytes(const mpc_solver* s, int64_t* bytes);
 
 /* Human-readable text of the last HIP/runtime error on this thread ("" if none). */

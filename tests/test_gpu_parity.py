@@ -468,7 +468,7 @@ def test_lds_working_set_and_workgroups_per_cu_of_the_baseline_configs(m):
     w3, b3 = wgs(m.config_unicycle_quadratic(80, max_obstacles=16, max_vertices=6, max_obstacle_rows=4))
     assert w3 == 4, b3
     assert wgs(m.config_unicycle_quadratic(80, **lds))[0] == 2 and wgs(m.config_unicycle_quadratic(80))[0] == 4
-    assert wgs(m.config_bicycle_min_time(120, precision=1, tol=1e-4))[0] == 3
+    assert wgs(m.config_bicycle_min_time(120, precision=1, tol=1e-4, **lds))[0] == 3 and wgs(m.config_bicycle_min_time(120, precision=1, tol=1e-4))[0] == 4      # plain fp32: the global form from three per CU on
     assert wgs(m.config_bicycle_min_time(120, **lds))[0] == 1 and wgs(m.config_bicycle_min_time(120))[0] == 4
     assert wgs(m.config_bicycle_min_time(120, precision=A.MIXED))[0] == 1          # the short refinement phase measured faster in the LDS form
     # grids beyond the LDS form's ~215 points exist in the global form
@@ -569,7 +569,7 @@ def test_factorisation_data_in_global_memory_equals_lds_bit_for_bit(m, case):
         assert np.median(np.abs(a.x - g.x).reshape(B, -1).max(1)[both]) < (1e-6 if case == "bicycle_n120_mixed" else 1e-3)
     assert lds[A.STAGE_GLOBAL] < 0.55 * lds[A.STAGE_LDS]
     # what MPC_STAGE_AUTO picks in fp64: the global form where the LDS form leaves at least half of a CU's SIMDs empty and the global form fills more (four workgroups
-    # per CU at most: one wave per SIMD); fp32 keeps everything in LDS.  mpc_lds_bytes reports the fp64 kernel's record (MPC_MIXED: the refinement phase's)
+    # per CU at most: one wave per SIMD); plain fp32 takes the global form from three per CU on (the ragged n = 30 case here has four), the fp32 phase of MPC_MIXED keeps the LDS form.  mpc_lds_bytes reports the fp64 kernel's record (MPC_MIXED: the refinement phase's)
     per_cu = lambda b: min(4, (160 * 1024) // b)
     want_global = case not in ("carlike_n30_ragged_fp32", "bicycle_n120_mixed") and per_cu(lds[A.STAGE_LDS]) <= 2 and per_cu(lds[A.STAGE_GLOBAL]) > per_cu(lds[A.STAGE_LDS])
     assert lds[A.STAGE_AUTO] == (lds[A.STAGE_GLOBAL] if want_global else lds[A.STAGE_LDS])
