@@ -439,6 +439,7 @@ struct HandleCapacities {
     int dual_warm_start = 0;
     double mu_init_warm = 0.0, mu_init_dual = 0.0;
     int stage_data = 0;      // mpc_config.stage_data: MPC_STAGE_AUTO (0) / MPC_STAGE_LDS / MPC_STAGE_GLOBAL
+    int two_wave_min_batch = 0;      // mpc_config.two_wave_min_batch (0: the library's default)
 };
 inline ParamStatus configure_from_params(Controller& controller, const ParamSource& p, ParamReport& rep, const HandleCapacities& caps = HandleCapacities(),
                                          int device = 0, const std::vector<std::vector<double>>* costmap_footprint = nullptr, mpc_config* cfg_out = nullptr,
@@ -454,6 +455,7 @@ inline ParamStatus configure_from_params(Controller& controller, const ParamSour
     if (caps.mu_init_warm > 0) cfg.mu_init_warm = caps.mu_init_warm;
     if (caps.mu_init_dual > 0) cfg.mu_init_dual = caps.mu_init_dual;
     cfg.stage_data = caps.stage_data;
+    cfg.two_wave_min_batch = caps.two_wave_min_batch;
     if (cfg_out) *cfg_out = cfg;
     if (options_out) *options_out = opt;
     opt.apply(controller);                       // grid adaptation etc. BEFORE configure(): it sizes the handle for the largest grid

@@ -136,6 +136,7 @@ class Controller {
         nh.param("mpc_hip/mu_init_warm", caps.mu_init_warm, caps.mu_init_warm);
         nh.param("mpc_hip/mu_init_dual", caps.mu_init_dual, caps.mu_init_dual);
         { std::string sd = "auto"; nh.param("mpc_hip/stage_data", sd, sd); caps.stage_data = sd == "lds" ? MPC_STAGE_LDS : (sd == "global" ? MPC_STAGE_GLOBAL : MPC_STAGE_AUTO); }
+        nh.param("mpc_hip/two_wave_min_batch", caps.two_wave_min_batch, caps.two_wave_min_batch);
         amd::ParamReport report;
         _amd.setInitialPlanEstimateOrientation(_initial_plan_estimate_orientation);
         std::string type; if (nh.getParam("footprint_model/type", type) && type == "costmap_2d" && _costmap_footprint.empty())

@@ -41,6 +41,10 @@ struct mpc_solver {
     mpc::Problem<float> P32;
     mpc::WaveLayout WL;         // everything in LDS
     mpc::WaveLayout WLg;        // factorisation data (GAIN, STG) in global memory (mpc_wave.hpp::GlobalStage): the LDS record is a third
+    bool w2_gs;                 // (developer builds) the two-wave kernel in the global form
+    bool w2_ok;                 // fp64 launches with more instances than the device has SIMDs may take the two-waves-per-SIMD kernel (global form, <= 256 registers): decided per launch (launch_model)
+    size_t wave_lds_w2;         // its dynamic LDS
+    int w2_min_batch;           // from this many instances per launch on
     bool gs64, gs32;            // which of the two the fp64 / fp32 launches of this handle use (mpc_config.stage_data; MPC_STAGE_AUTO: the one that puts more workgroups on a CU)
     void* d_gstage;             // n_gslots blocks of factorisation data (WLg.GSW words each), NULL when neither precision uses them
     int* d_gslots;              // [n_gslots] claim words of the blocks (0 = free)
@@ -134,7 +138,7 @@ void mpc_config_defaults(mpc_config* c) {
 }
 
 const char* mpc_last_error(void) { return g_err; }
-int32_t mpc_version(void) { return 500; }      // 0.5.0: mpc_config.stage_data took a reserved word (same size); a solve restores clearance rows that jam.  0.4.0: mpc_config.mu_strategy / max_time_us took reserved words (same size), MPC_TIME_LIMIT; a solve accepts factorisations on their inertia
+int32_t mpc_version(void) { return 600; }      // 0.6.0: mpc_config.two_wave_min_batch took a reserved word (same size).  0.5.0: mpc_config.stage_data took a reserved word (same size); a solve restores clearance rows that jam.  0.4.0: mpc_config.mu_strategy / max_time_us took reserved words (same size), MPC_TIME_LIMIT; a solve accepts factorisations on their inertia
 // history: 0.2.0: mpc_config grew (candidates, kept multipliers, hessian_mode), new entry points; 0.2.1: cost variants (off-diagonal weights, trapezoidal rule, hybrid cost)
 
 #ifdef MPC_PROFILE
@@ -253,6 +257,24 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         // (the refinement phase of MPC_MIXED -- one candidate, a handful of iterations -- measured faster in the LDS form: 9.0 against 9.4 ms for both phases at n = 120, B = 1024)
         s->gs64 = cfg->precision != MPC_FP32 && (cfg->precision != MPC_MIXED || cfg->stage_data == MPC_STAGE_GLOBAL) && choose(8, sizeof(mpc::Problem<double>));
     }
+    // Two waves per SIMD (mpc_solve_kernel.hpp, W2): the fp64 headline level without clearance rows, when the LDS record fits eight times into a CU (everything in LDS: about
+    // n <= 24 grid points -- the grid sizes of the reference's shipped parameter files).  A launch takes it when it has at least w2_min_batch instances (the device then has waves
+    // waiting for a SIMD, and a second resident wave fills the issue slots the first leaves idle); below that a launch lasts as long as its slowest wave, which runs fastest
+    // alone.  Same arithmetic on the same numbers: results bit for bit those of the one-wave kernels.  (With the factorisation data in global memory the second wave buys
+    // nothing -- measured at n = 50, profiles/r06_w2_probe.log: the form's cost is the CU's vector-memory path, which eight waves share --, so grids whose LDS form does not fit
+    // eight times keep the one-wave kernels.)
+    s->w2_gs = false;
+    s->wave_lds_w2 = lds_of(s->WL, 8, sizeof(mpc::Problem<double>));
+    s->w2_ok = cfg->precision == MPC_FP64 && cfg->stage_data == MPC_STAGE_AUTO && !solver_ext(s) && cfg->max_obstacles <= 0 && s->wave_lds_w2 <= (160u * 1024u) / 8u;
+    s->w2_min_batch = cfg->two_wave_min_batch > 0 ? cfg->two_wave_min_batch : (cfg->n_candidates > 1 ? 32768 : 8192);      // (hedged launches: x1.02 - 1.05 at 32768 instances, below 1 before)
+    if (cfg->two_wave_min_batch < 0) s->w2_ok = false;
+#ifdef MPC_DEV_SWITCHES
+    if (const char* e = getenv("MPC_W2_GS")) {      // developer A/B: the two-wave kernel in the global form where the LDS form does not fit eight times
+        if (e[0] == '1' && !s->w2_ok && cfg->two_wave_min_batch >= 0 && cfg->precision == MPC_FP64 && cfg->stage_data == MPC_STAGE_AUTO && !solver_ext(s) && cfg->max_obstacles <= 0 && lds_of(s->WLg, 8, sizeof(mpc::Problem<double>)) <= (160u * 1024u) / 8u) {
+            s->w2_gs = true; s->w2_ok = true; s->wave_lds_w2 = lds_of(s->WLg, 8, sizeof(mpc::Problem<double>));
+        }
+    }
+#endif
     s->wave_lds32 = lds_of(s->gs32 ? s->WLg : s->WL, 4, sizeof(mpc::Problem<float>));
     s->wave_lds = cfg->precision == MPC_FP32 ? s->wave_lds32 : lds_of(s->gs64 ? s->WLg : s->WL, 8, sizeof(mpc::Problem<double>));
     if (s->wave_lds > 160u * 1024u) {
@@ -294,7 +316,7 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         if (er == hipSuccess) er = hipMemset(s->d_rows_dropped, 0, Bm * 4);
     }
     if (cfg->precision == MPC_MIXED && er == hipSuccess) er = hipMalloc((void**)&s->d_iters1, Bm * 4);
-    if (s->gs32 || s->gs64 || s->WL.GSW > 0) {
+    if (s->gs32 || s->gs64 || s->w2_gs || s->WL.GSW > 0) {
         // blocks of factorisation data / of the clearance rows' elastic arrays (every layout with clearance rows has one, WaveLayout::GSW), a pool per XCD (mpc_solve_kernel.hpp): per XCD as many as the whole device has CUs -- an XCD has an eighth of them and a CU holds at
         // most 8 of these one-wave workgroups (2 per SIMD under the register budget of any build), so a pool can never run dry --, never more than the largest launch has
         // workgroups.  Stale contents are never read: every word is written before it is read within a solve.
@@ -304,9 +326,10 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         const size_t grid = Bm * (c32 > c64 ? c32 : c64);
         // (at least 256: in a partitioned mode the device is ONE XCD with 32 CUs, which still holds 32 x 8 workgroups)
         size_t per_xcd = er == hipSuccess && prop.multiProcessorCount > 256 ? (size_t)prop.multiProcessorCount : 256;
+        if (s->w2_gs) per_xcd *= 2;      // eight resident workgroups per CU fill a pool of 256 to the last block; twice that keeps the claim probes short
         if (per_xcd > grid) per_xcd = grid;
         s->n_gslots = (int)per_xcd;
-        const size_t blk64 = cfg->precision != MPC_FP32 ? (size_t)(s->gs64 ? s->WLg.GSW : s->WL.GSW) * 8 : 0, blk32 = cfg->precision != MPC_FP64 ? (size_t)(s->gs32 ? s->WLg.GSW : s->WL.GSW) * 4 : 0;
+        const size_t blk64 = cfg->precision != MPC_FP32 ? (size_t)((s->gs64 || s->w2_gs) ? s->WLg.GSW : s->WL.GSW) * 8 : 0, blk32 = cfg->precision != MPC_FP64 ? (size_t)(s->gs32 ? s->WLg.GSW : s->WL.GSW) * 4 : 0;
         if (er == hipSuccess) er = hipMalloc(&s->d_gstage, 8 * per_xcd * (blk64 > blk32 ? blk64 : blk32) + (size_t)mpc::GlobalStage::kPrefetchPad * 8);
         // developer check (scripts/dev/gs_sweep.py under MPC_POISON_GSTAGE=1): every word of the pool starts as a NaN pattern, so a word that some path consumes before writing it shows up in the results
         if (er == hipSuccess) { if (const char* e = getenv("MPC_POISON_GSTAGE")) { if (e[0] == '1') er = hipMemset(s->d_gstage, 0xFF, 8 * per_xcd * (blk64 > blk32 ? blk64 : blk32) + (size_t)mpc::GlobalStage::kPrefetchPad * 8); } }
@@ -385,7 +408,9 @@ static hipError_t launch_model(mpc_solver* s, const mpc::Problem<T>& P, int B, c
     a.level = !solver_ext(s) ? 0 : (s->P64.costx ? 2 : 1);
     a.lds = sizeof(T) == 4 ? s->wave_lds32 : s->wave_lds;
     a.stream = s->stream;
-    const bool gs = sizeof(T) == 4 ? s->gs32 : s->gs64;
+    a.w2 = sizeof(T) == 8 && s->w2_ok && B >= s->w2_min_batch;
+    if (a.w2) a.lds = s->wave_lds_w2;
+    const bool gs = a.w2 ? s->w2_gs : (sizeof(T) == 4 ? s->gs32 : s->gs64);
     a.L = gs ? s->WLg : s->WL; a.B = B;
     a.gstage = s->d_gstage; a.gslots = s->d_gslots; a.n_gslots = s->n_gslots;
     a.x0 = x0; a.xf = xf; a.u_prev = up; a.dt_prev = dtp; a.x_init = xi; a.u_init = ui; a.dt_init = dti; a.obst = ob;

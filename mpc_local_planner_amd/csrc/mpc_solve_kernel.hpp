@@ -36,11 +36,11 @@ constexpr int kWinIdle = 0x7f7f7f7f;
 
 // One wavefront = one (planner instance, candidate initial trajectory); the whole working set lives in LDS (mpc_wave.hpp).
 // Grid: n_cand * B workgroups, candidate-major, so that the hardware dispatches every instance's candidate 0 before any hedge.
-template <typename T, int MODEL, int EXT, bool OBST, int NSC = 0, bool GS = false>
+// W2: the variant for TWO waves per SIMD (throughput regime: more instances than SIMDs): at most 256 registers, every phase of an iteration on a lane index of its own
+// (IpmWave::local_lane: no per-lane address arithmetic survives from one phase into the next), line-search trials on the generic path.  Same arithmetic, same results bit for bit.
+template <typename T, int MODEL, int EXT, bool OBST, int NSC = 0, bool GS = false, bool W2 = false>
 __global__ __launch_bounds__(mpc::kWave)
-#ifdef MPC_WAVES_PER_EU      // developer experiment (scripts/dev/occupancy_probe.py): cap the register budget so that this many waves fit a SIMD
-__attribute__((amdgpu_waves_per_eu(MPC_WAVES_PER_EU, MPC_WAVES_PER_EU)))
-#endif
+__attribute__((amdgpu_waves_per_eu(W2 ? 2 : 1)))
 void mpc_ipm_wave_kernel(
     mpc::Problem<T> P, mpc::WaveLayout L, int B,
     const double* __restrict__ x0, const double* __restrict__ xf, const double* __restrict__ u_prev,
@@ -77,7 +77,7 @@ void mpc_ipm_wave_kernel(
 #endif
         if (lane == 0) { *Ps = P; Ps->n = n; }
         __syncthreads();
-        mpc::IpmWave<T, MODEL, EXT, OBST, NSC, GS> S(*Ps, Lv, sm, lane);
+        mpc::IpmWave<T, MODEL, EXT, OBST, NSC, GS, W2> S(*Ps, Lv, sm, lane);
         int gslot = -1;
         if (GS || (OBST && L.GSW > 0)) {
             // this workgroup's block of factorisation data (GlobalStage): one of the n_gslots blocks OF ITS XCD, claimed for the lifetime of the workgroup.  Per XCD because
@@ -219,6 +219,7 @@ struct SolveLaunch {
     void* gstage;               // L.GSW > 0: 8 x n_gslots blocks of factorisation data in global memory (L.GSW words of T each; n_gslots per XCD), claimed by the workgroups through `gslots`; else NULL
     int* gslots;                // [8][n_gslots] 0 = free, 1 = taken (all 0 between launches)
     int n_gslots;
+    bool w2;                    // the two-waves-per-SIMD kernel (fp64, level 0, no clearance rows, L.GSF: mpc_capi.hip decides per launch)
 };
 
 constexpr int kFixedLayoutNS = 50;
@@ -249,6 +250,17 @@ hipError_t launch_solve(const SolveLaunch& a, const Problem<T>& P) {
 #endif
         using IW = IpmWave<T, MODEL, 0, false, kFixedLayoutNS>;
         if (a.level == 0 && a.L.M == 0 && a.L.GSF == 0 && !force_obst && !no_fixed && IW::LayoutT::matches(a.L)) kern = mpc_ipm_wave_kernel<T, MODEL, 0, false, kFixedLayoutNS>;
+    }
+    if constexpr (sizeof(T) == 8) {
+        if (a.w2) {
+            if (a.level != 0 || a.L.M > 0) return hipErrorInvalidConfiguration;
+#ifdef MPC_DEV_SWITCHES
+            kern = a.L.GSF ? mpc_ipm_wave_kernel<T, MODEL, 0, false, 0, true, true> : mpc_ipm_wave_kernel<T, MODEL, 0, false, 0, false, true>;
+#else
+            if (a.L.GSF) return hipErrorInvalidConfiguration;
+            kern = mpc_ipm_wave_kernel<T, MODEL, 0, false, 0, false, true>;
+#endif
+        }
     }
     if (a.lds > 48u * 1024u) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.lds);

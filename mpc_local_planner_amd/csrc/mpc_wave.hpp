@@ -51,7 +51,7 @@ namespace mpc {
 // words of the obstacle arrays leave the scalar registers (the headline kernel spilled ~430 of them)
 // NSC > 0: the layout is a compile-time constant for the stride NS = NSC (FixedLayout; needs EXT == 0, OBST == false, no Crank-Nicolson trig words)
 // GS: the factorisation data (STG, GAIN) in global memory instead of LDS (GlobalStage): same arithmetic, same results bit for bit, a third of the LDS record
-template <typename T, int MODEL, int EXT = 1, bool OBST = true, int NSC = 0, bool GS = false>
+template <typename T, int MODEL, int EXT = 1, bool OBST = true, int NSC = 0, bool GS = false, bool W2 = false>
 struct IpmWave {
     static constexpr int NSTG = EXT ? NSTG_EXT : NSTG_BASE;        // words per stage record
     // trig-cache words per stage: sin, cos, steering term(s); Crank-Nicolson appends sin/cos of its second evaluation angle
@@ -222,12 +222,19 @@ struct IpmWave {
         return t_min(t_max(v, lb + pl), ub - pu);
     }
 
+    // lane index that the optimiser must treat as unknown HERE: keeps the per-lane address arithmetic of a phase inside the phase (hoisted out of the
+    // interior-point loop as loop invariants it would occupy registers for the whole solve)
+    __device__ __forceinline__ int local_lane() const { int l = lane; asm volatile("" : "+v"(l)); return l; }
+    // MPC_PHASE_LANE opens every phase of an iteration: in the two-waves-per-SIMD kernels (W2: 256 registers) the phase works on such a lane index of its own
+#define MPC_PHASE_LANE const int lane = W2 ? this->local_lane() : this->lane; (void)lane;
+
 #include "mpc_wave_rows.inc"
 #include "mpc_wave_passes.inc"
 #include "mpc_wave_sweeps.inc"
 #include "mpc_wave_pit.inc"
 #include "mpc_wave_step.inc"
 #include "mpc_wave_solve.inc"
+#undef MPC_PHASE_LANE
 };
 
 }  // namespace mpc

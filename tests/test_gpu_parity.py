@@ -520,6 +520,31 @@ def test_global_form_equals_lds_form_over_the_grid_sizes(m):
     both(lambda mode: m.config_bicycle_min_time(90, stage_data=mode), m.workloads.bicycle_min_time_inputs(B), n_grid=ng)
 
 
+def test_two_waves_per_simd_kernel_equals_the_one_wave_kernels_bit_for_bit(m):
+    """mpc_config.two_wave_min_batch: launches of at least that many instances take the kernel variant for two resident waves per SIMD (<= 256 registers, every phase of an
+    iteration on a lane index of its own, generic line-search trials; exists where the LDS record fits eight times into a CU: n <= 24 in fp64).  Same arithmetic on the same
+    numbers: trajectories, controls, dt, statuses and iteration counts bit for bit those of the one-wave kernels -- every model, with candidates, on a ragged batch; and a
+    grid whose record does not fit eight times ignores the setting."""
+    B = 192
+    def both(mk, inp, n_grid=None):
+        out = []
+        for w2 in (-1, 1):
+            s = m.BatchSolver(mk(two_wave_min_batch=w2), max_batch=B)
+            if n_grid is not None: s.set_grid_sizes(n_grid)
+            out.append(s.solve(*inp)); s.close()
+        for f in ("x", "u", "dt", "status", "iters"):
+            assert np.array_equal(getattr(out[0], f), getattr(out[1], f), equal_nan=True), f
+        assert (out[0].status == 0).mean() > 0.7
+    cand = dict(candidates=(0, 5, 5, 7), candidate_max_iter=(100, 45, 40, 35), candidate_param=(0.0, 2.0, 3.0, 1.5))
+    for n in (12, 20, 24):
+        both(lambda **k: m.config_carlike_min_time(n, **k), m.workloads.carlike_min_time_inputs(B, seed=n, goal_range=(0.5, 2.5)))
+        both(lambda **k: m.config_carlike_min_time(n, **cand, **k), m.workloads.carlike_min_time_inputs(B, seed=100 + n, goal_range=(0.5, 2.5)))
+    both(lambda **k: m.config_unicycle_quadratic(20, **k), m.workloads.carlike_min_time_inputs(B, seed=3, goal_range=(0.5, 1.5)))
+    both(lambda **k: m.config_bicycle_min_time(24, **k), m.workloads.bicycle_min_time_inputs(B, goal_range=(1.0, 5.0)))
+    both(lambda **k: m.config_carlike_min_time(24, **k), m.workloads.carlike_min_time_inputs(B, seed=9, goal_range=(0.5, 2.5)), n_grid=(8 + np.arange(B) % 17).astype(np.int32))
+    both(lambda **k: m.config_carlike_min_time(50, **k), m.workloads.carlike_min_time_inputs(B, seed=50))      # 40 KB record: one wave per SIMD whatever the setting
+
+
 @pytest.mark.parametrize("case", ["bicycle_n120_fp64_candidates", "bicycle_n120_mixed", "unicycle_n80_polygons", "carlike_n50_candidates", "carlike_n30_ragged_fp32"])
 def test_factorisation_data_in_global_memory_equals_lds_bit_for_bit(m, case):
     """mpc_config.stage_data: the stage records and Riccati gains of a solve (63 of the 97 words per grid point) live in LDS or in a per-workgroup block of
