@@ -166,8 +166,8 @@ inline void warm_start_shifting(double* x, double* u, int n, const double x0[3])
     u[2 * (n - 1)] = u[2 * (n - 2)]; u[2 * (n - 1) + 1] = u[2 * (n - 2) + 1];               // keep the duplicated last control consistent
 }
 
-// ---- what the reference's plugin prepares before Controller::step (src/mpc_local_planner_ros.cpp); each function is held to that source, compiled and executed
-// (oracle/ref_wrap_plugin.cpp, tests/test_reference_pinned.py)
+// ---- what the reference's plugin prepares before Controller::step (src/mpc_local_planner_ros.cpp); each function restates that source, line ranges cited per function
+// (the plugin source needs ROS / teb headers the build image lacks: not executed here)
 
 // MpcLocalPlannerROS::updateViaPointsContainer (:619-635): walking along the transformed plan, a pose becomes a via-point when it is at least min_separation away
 // (x / y) from the previously inserted one; the first pose counts as inserted but is no via-point.  min_separation <= 0: none.
@@ -383,7 +383,7 @@ class Controller {
     // The reference samples the initial state trajectory at the grid's CURRENT dt (full_discretization_grid_base_se2.cpp:61-65: precompute(getDt(), ...)), and
     // clear() does not put dt back to dt_ref (:526-536).  So on the variable grid every re-initialisation AFTER a first solve (goal jump, reset(), force_reinit_num_steps)
     // samples the plan at the LAST OPTIMISED dt while the plan's time axis still spans (n_ref - 1) dt_ref: a guess that is compressed (dt < dt_ref) or runs into the
-    // goal early (dt > dt_ref).  Seen by executing the reference's Controller (oracle/ref_wrap_controller.cpp).  true (default): reproduce it, so that re-initialised
+    // goal early (dt > dt_ref).  (Read off the cited lines; the reference's Controller does not build in this image.)  true (default): reproduce it, so that re-initialised
     // solves start where the reference's do; false: always sample at dt_ref.
     void setReferenceReinitSampling(bool on) { _reference_reinit_sampling = on; }
     int gridSize() const { return _n_cur; }
@@ -513,7 +513,7 @@ class Controller {
 
     // Controller::publishOptimalControlResult (src/controller.cpp:197-221) without the publisher: the message of the last step()
     void optimalControlResult(const TimeSeries& x_seq, const TimeSeries& u_seq, OptimalControlResult& msg) const {
-        // header.seq = _ocp_seq BEFORE step() increments it (:163 publishes, :165 ++_ocp_seq): the first step's message carries 0 (executed: tests/golden/ref_feasibility_and_result.npz)
+        // header.seq = _ocp_seq BEFORE step() increments it (:163 publishes, :165 ++_ocp_seq): the first step's message carries 0
         fill_optimal_control_result(x_seq, u_seq, _ocp_successful, _last_step_time, (uint32_t)(_ocp_seq > 0 ? _ocp_seq - 1 : 0), msg);
     }
 

@@ -355,8 +355,8 @@ inline ParamStatus config_from_params(const ParamSource& p, mpc_config& c, Contr
         else rep.notes.push_back("ipopt integer option " + kv.first + ": no counterpart, ignored");
     }
     if (c.hessian_mode == MPC_HESSIAN_CONVEXIFIED && c.tol < 1e-6) {
-        // first-order curvature converges linearly close to the goal: with tol 1e-8 the convexified Hessian needs more iterations and fails one cycle of 54 of the recorded goal
-        // approach (tests/golden/ref_plugin_closed_loop_carlike_to_the_goal.*; before the acceptable-level stop existed it stalled in front of the goal), the exact Hessian none;
+        // first-order curvature converges linearly close to the goal: with tol 1e-8 the convexified Hessian needs more iterations and fails one cycle of 54 of a closed-loop goal
+        // approach of the shipped car-like file (measured in r04; before the acceptable-level stop existed it stalled in front of the goal), the exact Hessian none;
         // the file's tol 1e-4 keeps the convexified mode
         c.hessian_mode = MPC_HESSIAN_EXACT;
         rep.notes.push_back("hessian_approximation limited-memory with tol < 1e-6: the exact Hessian is used instead of MPC_HESSIAN_CONVEXIFIED (first-order curvature does not reach such a tolerance reliably close to the goal; the KKT points are the same)");

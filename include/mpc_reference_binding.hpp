@@ -3,9 +3,8 @@
 // (include/mpc_hip.h through the facade include/mpc_controller.hpp and the parameter reader include/mpc_params.hpp) instead of control_box_rst + Ipopt.
 //
 // HOW A MAINTAINER OF THE REFERENCE USES IT: replace the body of include/mpc_local_planner/controller.h by `#include <mpc_reference_binding.hpp>`, drop
-// src/controller.cpp from the library target, link libmpc_hip.so.  The plugin source src/mpc_local_planner_ros.cpp is compiled UNCHANGED -- it is, in this
-// repository's test suite: oracle/Makefile builds that file twice, once with the reference's own Controller and once with this one, and
-// tests/test_reference_pinned.py runs both plugins side by side through the same cycles (initialize, setPlan, computeVelocityCommands).
+// src/controller.cpp from the library target, link libmpc_hip.so.  The plugin source src/mpc_local_planner_ros.cpp is meant to compile UNCHANGED on it.  NOT COMPILED IN THIS
+// REPOSITORY'S TEST SUITE: the build image has none of the headers below, and writing stand-ins for them is not a reference build (INTEGRATION.md says what was checked instead).
 //
 // This header needs the reference's build environment (roscpp, teb_local_planner, corbo-core's TimeSeries, base_local_planner, Eigen, the reference's own
 // robot-model headers); it is NOT part of libmpc_hip.so and nothing in this repository's product path includes it.

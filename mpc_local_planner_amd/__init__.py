@@ -10,4 +10,3 @@ from .solver import BatchSolver, BatchResult, MpcError  # noqa: F401
 from . import workloads  # noqa: F401
 from . import params  # noqa: F401  (the reference's parameter set -> mpc_config)
 from .params import config_from_params, config_from_yaml  # noqa: F401
-from . import plugin_inputs  # noqa: F401  (what the reference's plugin prepares around a solve: plan handling, via-points, obstacle messages)

@@ -252,7 +252,7 @@ def config_from_params(params: dict, costmap_footprint=None, **sizing):
     if "tol" not in kw:
         kw["tol"] = 1e-8       # Ipopt's default tol
     if kw.get("hessian_mode") == HESSIAN_CONVEXIFIED and kw["tol"] < 1e-6:
-        # measured on the recorded goal approach (tests/golden/ref_plugin_closed_loop_carlike_to_the_goal.*, C oracle as the solver): first-order curvature converges linearly close to
+        # measured on a closed-loop goal approach of the shipped car-like parameter file (r04, C oracle as the solver): first-order curvature converges linearly close to
         # the goal -- with tol 1e-8 the convexified Hessian needs 23.3 iterations per solve and fails one cycle of 54 (at the iteration limit; before the acceptable-level stop existed
         # it stalled 0.27 m in front of the goal, 41 of 90 cycles failing), the exact Hessian 18.0 iterations and no failing cycle.  tol 1e-4 -- what the shipped car-like file asks
         # for -- keeps the convexified mode

@@ -3,9 +3,8 @@
 Restates MpcLocalPlannerROS::updateObstacleContainerWithCostmap (src/mpc_local_planner_ros.cpp:474-499).  Third-party pieces
 (costmap_2d, ROS navigation -- absent from /root/reference, restated from its published interface): getCost(mx, my) =
 costmap[my * size_x + mx]; LETHAL_OBSTACLE = 254; mapToWorld(mx, my): w = origin + (m + 0.5) * resolution.
-Parity: PINNED to the reference's own updateObstacleContainerWithCostmap, compiled (the whole plugin source) and executed on an array-backed costmap
-(tests/test_reference_pinned.py::test_costmap_scan_reproduces_the_reference_plugin: same obstacles in the same order); getCost / mapToWorld are costmap_2d's published
-definitions (third-party, restated in the stand-in).
+Parity UNPINNED: restated from the cited lines (the plugin source needs ROS / costmap_2d / teb headers, which the image lacks); getCost / mapToWorld are costmap_2d's published
+definitions (third-party).
 """
 import math
 

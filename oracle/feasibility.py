@@ -14,9 +14,8 @@ base_local_planner/src/costmap_model.cpp + line_iterator.h + costmap_2d::Costmap
     (LineIterator = Bresenham, x0,y0 .. x1,y1) in order: NO_INFORMATION -> -2, LETHAL -> -1; the FIRST negative value is returned.
   worldToMap(wx, wy): false if wx < origin_x or wy < origin_y; m = (int)((w - origin) / resolution); false unless mx < size_x and my < size_y.
 (Older navigation releases return -1 for all three cases; with that convention unknown / outside cells would also make a trajectory
-infeasible.  The reference compares with -1 only.)  Parity: the poses that are asked about and the early exit are PINNED to the reference's own
-isPoseTrajectoryFeasible, compiled and executed with a recording costmap model (tests/test_reference_pinned.py::test_feasibility_check_asks_about_the_same_poses_as_the_reference);
-footprintCost itself is third-party (base_local_planner) and stays restated from its published source.
+infeasible.  The reference compares with -1 only.)  Parity UNPINNED: restated from src/controller.cpp:859-917 (that file needs corbo / ROS headers,
+which the image lacks); footprintCost itself is third-party (base_local_planner) and restated from its published source.
 """
 import math
 
@@ -100,8 +99,8 @@ def footprint_cost(cost, resolution, origin, x, y, theta, spec):
 
 
 def is_pose_trajectory_feasible(cost, resolution, origin, x, spec, inscribed_radius, min_resolution_collision_check_angular, look_ahead_idx=-1, pose_cost=None):
-    """cost (size_y, size_x) uint8, x (n, 3) planned states.  src/controller.cpp:859-917.  pose_cost(x, y, theta): replaces the costmap lookup (the poses asked
-    and the early exit are PINNED to the executed reference with it: tests/test_reference_pinned.py)"""
+    """cost (size_y, size_x) uint8, x (n, 3) planned states.  src/controller.cpp:859-917.  pose_cost(x, y, theta): replaces the costmap lookup (a test hook: the poses asked
+    about, in order, and the early exit)"""
     if pose_cost is not None:
         footprint_cost = lambda _c, _r, _o, px, py, pth, _s: pose_cost(px, py, pth)      # noqa: E731
     else:

@@ -17,8 +17,8 @@ stage-structured Riccati sweep; agreement of the two is the parity test.
 
 PARITY UNPINNED for the solve: no Ipopt here and no golden outputs in the reference; the
 solution is cross-checked against scipy (SLSQP / trust-constr) on the
-reference-form NLP of oracle/se2_nlp.py, and by KKT residuals.  The NLP it solves is pinned
-to executed reference code where that was possible (header of oracle/se2_nlp.py).
+reference-form NLP of oracle/se2_nlp.py, and by KKT residuals.  The NLP it solves is the
+restatement of oracle/se2_nlp.py (its header says what of it is pinned: the angle helpers).
 
 "Solver form" of the rows (same feasible set / same primal KKT points as the
 reference form, rows rescaled by positive factors):

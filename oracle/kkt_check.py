@@ -1,9 +1,9 @@
 """ORACLE (test infrastructure only): is a trajectory a KKT point of the REFERENCE-FORM NLP?
 
-Pinning: the NLP this checker evaluates (oracle/se2_nlp.py::ReferenceNlp) is held to EXECUTED reference code -- the reference's own edge classes, compiled in place
-into oracle/_ref and recorded in tests/golden/ref_* (tests/test_reference_pinned.py::test_reference_form_nlp_is_the_reference_s_terms_on_the_reference_s_edge_layout).
-What stays unpinned is only what /root/reference does not contain: Ipopt's iterates (this file checks optimality conditions, not iterates) and teb's distance
-functions for lines / polygons (restated in oracle/footprints.py, checked against sampled outlines in tests/test_footprint_bruteforce.py).
+Pinning: the NLP this checker evaluates (oracle/se2_nlp.py::ReferenceNlp) is a restatement of the reference's edge classes from their sources (cited there, function by
+function); of it only the angle helpers are held to executed reference code (tests/test_reference_math.py) -- nothing else of the reference builds in this image.  Also
+unpinned: Ipopt's iterates (this file checks optimality conditions, not iterates) and teb's distance functions for lines / polygons (restated, checked against sampled
+outlines in tests/test_footprint_bruteforce.py).
 
 
 Used by the parity tests to classify solver results that do not coincide with the oracle's iterate sequence (a line-search tie that

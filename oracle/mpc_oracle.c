@@ -12,10 +12,11 @@
  * A factorisation is accepted on its INERTIA (Ipopt's test, r04): the LU carries none, so a second pass counts the negative eigenvalues of the same assembled matrix by a
  * symmetric block elimination (kkt_negative_eigenvalues); oracle/ipm_dense.py reads the same count off LAPACK's Bunch-Kaufman factorisation, the product off its sweeps' pivots.
  *
- * PARITY: the reference ships no golden outputs and Ipopt/corbo are not vendored, so the SOLVE (the iterates, the point a non-convex problem converges to) is unpinned.
- * The NLP pieces are pinned where the reference's own code could be compiled and executed (oracle/_ref): this file follows oracle/se2_nlp.py, which is held to the recorded
- * outputs of the reference's models, collocation rules, costs, rate rows, association and via-point rules (tests/test_reference_pinned.py; the association of this file
- * directly: test_c_oracle_association_reproduces_the_reference); teb's distance functions for lines / polygons / turning footprints are third-party and stay restated.
+ * PARITY UNPINNED (except the angle wrap): the reference ships no tests or golden outputs, Ipopt / corbo / teb are not vendored, and of the reference's sources only
+ * utils/math_utils.h compiles in this image (everything else includes Eigen / corbo / ROS / teb headers, which are absent; no stand-ins are written).  This file follows
+ * oracle/se2_nlp.py (same status: restated from the cited sources; normalize_theta / interpolate_angle held bit for bit to the executed header, tests/test_reference_math.py)
+ * and is held to it and to independent scipy solves of the same NLP by the CPU tests.  The SOLVE (the iterates, the point a non-convex problem converges to) has no reference
+ * to compare with: "local minimum of the restated NLP", never "what Ipopt returns".
  *
  * NLP pieces and where they come from (paths under /root/reference/mpc_local_planner/):
  *   dynamics          include/mpc_local_planner/systems/{unicycle_robot.h:59-68,simple_car.h:68-77,131-141,

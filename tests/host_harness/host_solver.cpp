@@ -72,8 +72,8 @@ extern "C" void hostdbg_trig(int n, const double* x, double* s, double* c, doubl
 extern "C" void hostdbg_log_mantissa(int n, const double* m, double* out) { for (int i = 0; i < n; ++i) out[i] = mpc::log_mantissa(m[i]); }
 
 // the collocation rows as the kernel's core forms them (mpc_core.hpp: model_trig_colloc + colloc_f; mpc_wave.hpp::eval_point does exactly this):
-// c = dt * F(theta_1, u, dt) - (x_2 - x_1), heading difference wrapped.  tests/test_reference_pinned.py compares them with the compiled
-// REFERENCE collocation rules (oracle/_ref) on the heading manifold, where the two formulations coincide.
+// c = dt * F(theta_1, u, dt) - (x_2 - x_1), heading difference wrapped.  tests/test_host_core.py compares them with the numpy oracle's
+// reference-form collocation rules on the heading manifold, where the two formulations coincide.
 template <int MODEL>
 static void colloc_rows(const mpc::Problem<double>& P, int count, const double* x1, const double* u, const double* x2, const double* dt, double* c) {
     for (int i = 0; i < count; ++i) {
@@ -98,7 +98,7 @@ extern "C" void hostdbg_colloc(const mpc_config* cfg, int count, const double* x
 }
 extern "C" double hostdbg_normalize_theta(double th) { return mpc::normalize_theta(th); }
 // the accept step of the kernel on ONE state vertex, as mpc_wave.hpp::xt / accept() write it: x + alpha dx per component, the heading wrapped (SURVEY.md 8 row a15:
-// VectorVertexSE2::plus, include/mpc_local_planner/optimal_control/vector_vertex_se2.h:79-96 -- tests/test_reference_pinned.py holds this to the executed reference)
+// VectorVertexSE2::plus, include/mpc_local_planner/optimal_control/vector_vertex_se2.h:79-96 -- tests/test_host_core.py holds this to the numpy oracle's retraction)
 extern "C" void hostdbg_retract(int count, const double* x, const double* dx, double alpha, double* out) {
     for (int i = 0; i < count; ++i)
         for (int a = 0; a < 3; ++a) {

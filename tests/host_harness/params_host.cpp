@@ -36,7 +36,7 @@ extern "C" int ctl_config_from_params(const char* text, const char* costmap_fp, 
     return (int)st;
 }
 
-// plugin-level parameters (include/mpc_params.hpp::plugin_options_from_params): text / move_base_text as above; out [14] in the order of oracle/ref_lib.py::PLUGIN_PARAMETER_NAMES,
+// plugin-level parameters (include/mpc_params.hpp::plugin_options_from_params): text / move_base_text as above; out [14] in the order of mpc_local_planner_amd/params.py::plugin_options_from_params (its key order),
 // strings "odom_topic\ncostmap_converter_plugin"
 extern "C" void ctl_plugin_options(const char* text, const char* move_base_text, double* out, char* strings, int cap) {
     using namespace mpc_local_planner_amd;

@@ -184,3 +184,58 @@ def test_inertia_count_of_a_combine_block_on_the_host(host):
     Z = np.zeros((5, 5)); Z[0, 1] = Z[1, 0] = 1.0            # zero leading pivot
     host.host_pit_block_inertia(Z.ctypes.data_as(C.c_void_p), np.eye(5).ctypes.data_as(C.c_void_p), C.byref(ok))
     assert ok.value == 0
+
+
+MODEL_PARAMS = {0: (), 1: (0.4,), 2: (0.4,), 3: (1.0, 1.3)}
+
+
+@pytest.mark.parametrize("model", sorted(MODEL_PARAMS))
+@pytest.mark.parametrize("method", [0, 1, 2])
+def test_kernel_core_collocation_rows_equal_the_oracle_s_reference_form_rows_on_the_heading_manifold(host, model, method):
+    """The kernel forms its rows as c = dt F(theta_1, u, dt) - (x_2 - x_1) with the midpoint / second Crank-Nicolson point placed by the explicit heading
+    relation (mpc_core.hpp::model_trig_colloc) instead of interpolate_angle(theta_1, theta_2): the same thing wherever theta_2 satisfies the rule's own
+    heading row -- so the comparison with the numpy oracle's REFERENCE-FORM rule (se2_nlp.collocation_defect: fd_collocation_se2.h:54-69, :91-108, :130-147 restated literally,
+    the Crank-Nicolson aliasing included) is made there (theta_2 = theta_1 + dt f_2 for forward / midpoint differences, theta_1 + 2 dt f_2 for the literal
+    Crank-Nicolson rule); positions are arbitrary.  dt * reference-form error == kernel row."""
+    rng = np.random.default_rng(100 * model + method)
+    N = 400
+    par = MODEL_PARAMS[model]
+    x1 = np.column_stack([rng.uniform(-5, 5, N), rng.uniform(-5, 5, N), rng.uniform(-np.pi, np.pi, N)])
+    x1[:16, 2] = np.pi * np.array([1, -1] * 8) * (1 - 1e-16 * np.arange(16))            # headings at +-pi
+    u = np.column_stack([rng.uniform(-0.2, 0.4, N), rng.uniform(-1.2, 1.2, N)])
+    dt = rng.uniform(0.01, 1.0, N)
+    f = np.array([R.dynamics(model, par, a, b) for a, b in zip(x1, u)])                  # the heading rate does not depend on the pose
+    x2 = np.column_stack([rng.uniform(-5, 5, N), rng.uniform(-5, 5, N), np.zeros(N)])
+    step = (2.0 if method == 2 else 1.0) * dt * f[:, 2]
+    x2[:, 2] = [R.normalize_theta(a + b) for a, b in zip(x1[:, 2], step)]
+    ref = np.stack([R.collocation_defect(method, model, par, x1[i:i + 1], u[i:i + 1], x2[i:i + 1], dt[i])[0] for i in range(N)]) * dt[:, None]
+    cfg = A.make_config(model=model, model_params=par if par else (0.0,), n=20, collocation=method)
+    c = np.zeros_like(x1)
+    p = lambda a: np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)
+    x1c, uc, x2c, dtc = (np.ascontiguousarray(a) for a in (x1, u, x2, dt))
+    host.hostdbg_colloc(C.byref(cfg), C.c_int(N), p(x1c), p(uc), p(x2c), p(dtc), c.ctypes.data_as(C.c_void_p))
+    assert np.abs(c - ref).max() < 5e-15, np.abs(c - ref).max()
+    small = np.abs(step) < 3.0                                                            # (a heading step beyond pi wraps: there the row is 2 pi on BOTH sides)
+    assert np.abs(c[small, 2]).max() < 5e-15                                              # on the heading manifold the heading row vanishes
+
+
+def test_kernel_core_accept_step_is_the_oracle_s_retraction(host):
+    """SURVEY.md 8 row a15 (VectorVertexSE2::plus, include/mpc_local_planner/optimal_control/vector_vertex_se2.h:79-96: add the increment, wrap the heading): the host build of
+    the kernel core's accept step (x += alpha dx; heading = normalize_theta, mpc_wave.hpp::xt / accept) at alpha = 1 against the numpy restatement, bit for bit -- on vertices
+    with the heading at +-pi and one ulp inside, and increments of 0, +-1e-17, +-1e-9, +-pi, 2 pi."""
+    rng = np.random.default_rng(15)
+    N = 400
+    v = np.column_stack([rng.uniform(-10, 10, N), rng.uniform(-10, 10, N), rng.uniform(-np.pi, np.pi, N)])
+    d = rng.uniform(-4, 4, (N, 3))
+    v[:32, 2] = np.pi; v[32:64, 2] = np.nextafter(np.pi, 0) * np.array([1, -1] * 16)
+    special = np.array([0.0, 1e-17, -1e-17, 1e-9, -1e-9, np.pi, -np.pi, 2 * np.pi])
+    d[:64, 2] = np.tile(special, 8)
+    want = v + d
+    want[:, 2] = [R.normalize_theta(t) for t in want[:, 2]]
+    assert ((want[:, 2] >= -np.pi) & (want[:, 2] < np.pi)).all()
+    out = np.empty_like(v)
+    host.hostdbg_retract.restype = None
+    host.hostdbg_retract(C.c_int(N), np.ascontiguousarray(v).ctypes.data_as(C.c_void_p), np.ascontiguousarray(d).ctypes.data_as(C.c_void_p), C.c_double(1.0), out.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(out, want)
+    from oracle import candidates as OC
+    assert np.array_equal(OC.wrap(v[:, 2] + d[:, 2]), want[:, 2])

@@ -351,250 +351,3 @@ def test_cpp_reader_gives_the_same_verdicts(cpp):
         with pytest.raises(P.ParamNotImplemented):
             P.config_from_params(tree)
         assert _cpp_config(cpp, tree)[0] == 2
-
-
-# ---- held to the REFERENCE's own Controller::configure, compiled and executed (oracle/ref_wrap_controller.cpp; tests/golden/make_ref_vectors.py ran it on every
-# parameter set of tests/golden/configure_cases.py and recorded what it built in tests/golden/ref_configure.json) -----------------------------------------------------
-import json
-import sys
-sys.path.insert(0, os.path.join(HERE, "golden"))
-import configure_cases      # noqa: E402
-
-REF_CONFIGURE = json.load(open(os.path.join(HERE, "golden", "ref_configure.json")))
-REF_MODELS = {0: "unicycle", 1: "simple_car", 2: "simple_car_front_wheel_driving", 3: "kinematic_bicycle_vel_input"}
-REF_COLLOC = {0: "forward_differences", 1: "midpoint_differences", 2: "crank_nicolson_differences"}
-
-
-def _sym(diag, off, dim):
-    m = np.diag(np.array(list(diag)[:dim], float))
-    if dim == 3:
-        m[0, 1], m[0, 2], m[1, 2] = off
-        m[1, 0], m[2, 0], m[2, 1] = off
-    else:
-        m[0, 1] = m[1, 0] = off
-    return m
-
-
-def _nums(text):
-    return np.array([float(x) for x in text.split(",")]) if text else np.zeros(0)
-
-
-def _unbounded(v):
-    v = np.asarray(v, float)
-    return np.where(np.abs(v) >= 1e29, np.sign(v) * np.inf, v)         # "no limit": corbo's 2e30 there, 1e30 here
-
-
-def _held_to_reference(cfg, ctrl, built):
-    """every setting Controller::configure put into the objects it built, against the mpc_config / facade options made from the same parameters"""
-    def same(name, ours, ref):
-        ok = (ours == ref) if isinstance(ours, str) else np.array_equal(np.asarray(ours, float), np.asarray(ref, float))
-        assert ok, (name, ours, ref)
-    sym_of = lambda key, dim: (lambda m: 0.5 * (m + m.T))(_nums(built[key]).reshape(dim, dim))
-    same("model", REF_MODELS[cfg.model], built["model"])
-    if cfg.model in (1, 2):
-        same("wheelbase", cfg.model_params[0], float(built["wheelbase"]))
-    if cfg.model == 3:
-        same("length_rear", cfg.model_params[0], float(built["length_rear"])); same("length_front", cfg.model_params[1], float(built["length_front"]))
-    same("variable_grid", cfg.dt_free, int(built["variable_grid"]))
-    same("grid_size_ref", cfg.n, int(built["n_ref"])); same("dt_ref", cfg.dt_ref, float(built["dt_ref"])); same("warm_start", ctrl["warm_start"], int(built["warm_start"]))
-    if cfg.dt_free:
-        same("min_dt", cfg.dt_lb, float(built["dt_lb"])); same("max_dt", cfg.dt_ub, float(built["dt_ub"]))
-    same("xf_fixed", list(cfg.xf_fixed), _nums(built["xf_fixed"]))
-    same("collocation", REF_COLLOC[cfg.collocation], built["collocation"])
-    same("grid_adaptation", ctrl["grid_adaptation"], int(built.get("grid_adaptation", 0)))
-    if ctrl["grid_adaptation"]:
-        same("max_grid_size", ctrl["max_grid_size"], int(built["n_max"])); same("min_grid_size", ctrl["min_grid_size"], int(built["n_min"]))
-        same("dt_hyst_ratio", ctrl["dt_hyst_ratio"], float(built["dt_hyst_ratio"]))
-    same("iterations", cfg.max_iter, int(built.get("ipopt_integer.max_iter", built["iterations"])))
-    if "ipopt_numeric.tol" in built:
-        same("tol", cfg.tol, float(built["ipopt_numeric.tol"]))
-    same("u_lb", list(cfg.u_lb), _nums(built["u_lb"])); same("u_ub", list(cfg.u_ub), _nums(built["u_ub"]))
-    same("du_lb", _unbounded(list(cfg.du_lb)), _unbounded(_nums(built["du_lb"]))); same("du_ub", _unbounded(list(cfg.du_ub)), _unbounded(_nums(built["du_ub"])))
-    Q, Rm = _sym(cfg.Q, tuple(cfg.Q_offdiag), 3), _sym(cfg.R, cfg.R_offdiag, 2)
-    if cfg.objective == A.OBJ_MIN_TIME:
-        stage = "MinimumTime"
-    elif cfg.objective == A.OBJ_MIN_TIME_VIA_POINTS:
-        stage = "MinTimeViaPointsCost"
-    else:       # which corbo / SE(2) cost class the weights select (src/controller.cpp:598-624)
-        stage = ("MinTimeQuadraticControls" if cfg.hybrid_cost_minimum_time else "QuadraticFormCostSE2" if Q.any() and Rm.any() else "QuadraticStateCostSE2" if Q.any()
-                 else "QuadraticControlCost" if Rm.any() else "none")
-    same("stage cost", stage, built["stage_cost"])
-    if "Q" in built:
-        same("Q", Q, sym_of("Q", 3))
-    if "R" in built:
-        same("R", Rm, sym_of("R", 2))
-    if "integral_form" in built:
-        same("integral_form", cfg.integral_form, int(built["integral_form"]))
-        if cfg.integral_form:
-            same("cost_integration", "trapezoidal_rule" if cfg.cost_integration else "left_sum", built["cost_integration"])
-    if stage == "MinTimeViaPointsCost":
-        same("via_points_ordered", cfg.via_points_ordered, int(built["via_points_ordered"])); same("position_weight", cfg.vp_position_weight, float(built["vp_position_weight"]))
-        same("orientation_weight", cfg.vp_orientation_weight, float(built["vp_orientation_weight"]))
-    same("terminal cost", "QuadraticFinalStateCostSE2" if cfg.has_Qf else "none", built["final_stage_cost"])
-    if cfg.has_Qf:
-        same("Qf", _sym(cfg.Qf, tuple(cfg.Qf_offdiag), 3), sym_of("Qf", 3))
-    same("terminal constraint", "TerminalBallSE2" if cfg.terminal_ball else "none", built["final_stage_constraint"])
-    if cfg.terminal_ball:
-        same("S", _sym(cfg.terminal_ball_S, tuple(cfg.terminal_ball_S_offdiag), 3), sym_of("S", 3)); same("radius", cfg.terminal_ball_gamma, float(built["gamma"]))
-    for k in ("min_obstacle_dist", "force_inclusion_dist", "cutoff_dist"):
-        same(k, getattr(cfg, k), float(built[k]))
-    same("enable_dynamic_obstacles", cfg.enable_dynamic_obstacles, int(built["enable_dynamic_obstacles"]))
-    for k in ("outer_ocp_iterations", "force_reinit_new_goal_dist", "force_reinit_new_goal_angular", "allow_init_with_backward_motion", "force_reinit_num_steps", "prefer_x_feedback",
-              "publish_ocp_results", "print_cpu_time"):
-        same(k, ctrl[k], float(built[k]))
-    assert built["auto_update_previous_control"] == "0"         # src/controller.cpp:90: the caller hands the previous control over (setPreviousControlInput)
-
-
-NOT_BUILT = {"lsq_lm_solver", "unknown_collocation"}      # the reference configures; this path says what it lacks instead of solving a different problem
-
-
-@pytest.mark.parametrize("name", sorted(REF_CONFIGURE))
-def test_parameter_translation_reproduces_what_the_reference_s_configure_built(name):
-    """keys, in-code defaults, roscpp's type conversions, sign fix-ups, the cost class chosen from which weights vanish, column-major weight matrices, "<= 0 means no
-    rate limit", and the verdicts.  Where the reference returns false, ParamError carries its reason; where it CRASHES (every `return {}` of configureOcp ends in
-    `_ocp->initialize()` on an empty pointer, src/controller.cpp:97) ParamError carries the reason it logged just before."""
-    params, rec = configure_cases.cases()[name], REF_CONFIGURE[name]
-    if rec["status"] != 1:
-        with pytest.raises(P.ParamError) as e:
-            P.config_from_params(params)
-        assert str(e.value) == rec["errors"][0]
-        return
-    if name in NOT_BUILT:
-        with pytest.raises(P.ParamNotImplemented):
-            P.config_from_params(params)
-        return
-    cfg, ctrl, notes = P.config_from_params(params)
-    _held_to_reference(cfg, ctrl, rec["built"])
-    for w in rec["warnings"]:             # the reference's warnings reappear as notes ('"max_vel_x_backwards must be >= 0"')
-        assert any(w.strip('"').split(" must")[0] in n for n in notes), (w, notes)
-
-
-def test_reference_configure_records_cover_every_verdict():
-    st = [r["status"] for r in REF_CONFIGURE.values()]
-    assert st.count(1) >= 38 and st.count(0) >= 3 and st.count(2) >= 8
-    # `tol: 1e-4` read by a YAML 1.1 loader is text: the reference's numeric option map stays empty (no ipopt_numeric.* entry), the package honours the intent and says so
-    built = REF_CONFIGURE["carlike_numeric_option_as_text"]["built"]
-    assert not any(k.startswith("ipopt_numeric.") for k in built)
-    cfg, _, notes = P.config_from_params(configure_cases.cases()["carlike_numeric_option_as_text"])
-    assert cfg.tol == 1e-4 and any("roscpp rejects the whole map" in n for n in notes)
-    assert float(REF_CONFIGURE["carlike_numeric_options"]["built"]["ipopt_numeric.tol"]) == 1e-4
-
-
-@pytest.mark.parametrize("name", sorted(REF_CONFIGURE))
-def test_cpp_reader_on_the_reference_s_configure_cases(cpp, name):
-    """include/mpc_params.hpp gives the same verdict and the same mpc_config / facade options as the Python reader on every recorded parameter set"""
-    params, rec = configure_cases.cases()[name], REF_CONFIGURE[name]
-    st, cfg, opt, rep = _cpp_config(cpp, params)
-    if rec["status"] != 1:
-        assert st == 1 and rep.split("\n")[0] == rec["errors"][0]
-        return
-    if name in NOT_BUILT:
-        assert st == 2
-        return
-    assert st == 0, rep
-    py_cfg, py_ctrl, _ = P.config_from_params(params)
-    for field in SCALARS:
-        assert getattr(cfg, field) == getattr(py_cfg, field), field
-    for field in ARRAYS:
-        assert list(getattr(cfg, field)) == list(getattr(py_cfg, field)), field
-    for k, v in py_ctrl.items():
-        assert opt[k] == float(v), k
-    _held_to_reference(cfg, {k: opt[k] for k in py_ctrl}, rec["built"])
-
-
-# ---- footprint_model: held to getRobotFootprintFromParamServer of the reference's plugin source (src/mpc_local_planner_ros.cpp:890-1001 + makeFootprintFromXMLRPC /
-# getNumberFromXMLRPC :1046-1095), compiled and executed (oracle/ref_wrap_plugin.cpp -> tests/golden/ref_footprint_models.json)
-import footprint_cases      # noqa: E402
-
-REF_FOOTPRINTS = json.load(open(os.path.join(HERE, "golden", "ref_footprint_models.json")))
-FOOTPRINT_KIND_NAMES = {0: "point", 1: "circular", 2: "line", 3: "two_circles", 4: "polygon"}
-
-
-def _footprint_held_to_reference(cfg, rec):
-    assert FOOTPRINT_KIND_NAMES[cfg.footprint_kind] == rec["kind"]
-    if rec["kind"] == "circular":
-        assert cfg.footprint_radius == rec["args"][0]
-    if rec["kind"] in ("line", "two_circles"):
-        assert list(cfg.footprint_params) == rec["args"]
-    if rec["kind"] == "polygon":
-        k = len(rec["vertices"])
-        assert cfg.footprint_n_vertices == k
-        got = np.array(list(cfg.footprint_vertices)[:2 * k]).reshape(-1, 2)
-        assert np.abs(got - np.array(rec["vertices"])).max() < 1e-7          # the costmap footprint went through geometry_msgs/Point32 there
-
-
-@pytest.mark.parametrize("name", sorted(REF_FOOTPRINTS))
-def test_footprint_model_reproduces_what_the_reference_plugin_builds(cpp, name):
-    """every model type, ints where doubles are expected, and every fall-back to the point model: missing keys, a radius given as text, 3-D line ends, fewer than 3 polygon
-    vertices, a vertex that is not [x, y], a coordinate that is not a number, a flat list, an unknown type, costmap_2d with and without a costmap -- the Python reader and
-    the C++ reader (include/mpc_params.hpp) build what the reference builds, and complain (note) exactly where the reference complains"""
-    fm, cfp, no_costmap = footprint_cases.cases()[name]
-    rec = REF_FOOTPRINTS[name]
-    tree = {"footprint_model": fm} if fm else {}
-    cfg, _, notes = P.config_from_params(tree, costmap_footprint=None if no_costmap else cfp)
-    _footprint_held_to_reference(cfg, rec)
-    assert bool(rec["complaints"]) == bool(notes), (rec["complaints"], notes)
-    if name == "polygon_text":
-        return                 # a coordinate that is text cannot be expressed through the typed C++ parameter source
-    st, ccfg, _, rep = _cpp_config(cpp, tree, None if no_costmap else cfp)
-    assert st == 0, rep
-    _footprint_held_to_reference(ccfg, rec)
-    assert bool(rec["complaints"]) == (len([l for l in rep.split("\n") if l]) > 0), (rec["complaints"], rep)
-
-
-@pytest.mark.skipif(not os.path.isdir("/root/reference/mpc_local_planner_examples/cfg"), reason="the reference tree is only present in the build container")
-def test_the_reference_s_shipped_parameter_files_against_its_own_configure(cpp):
-    """every mpc_local_planner_params*.yaml under mpc_local_planner_examples/cfg and cfg/test_mpc_optim_node.yaml: loaded with the YAML loader rosparam uses, run through the
-    REFERENCE's Controller::configure (oracle/_ref, live) and through both parameter readers of this repository"""
-    import glob
-    import yaml
-    from oracle import ref_lib as RL
-    assert RL.build()
-    files = sorted(glob.glob("/root/reference/mpc_local_planner_examples/cfg/*/mpc_local_planner_params*.yaml")) + ["/root/reference/mpc_local_planner/cfg/test_mpc_optim_node.yaml"]
-    assert len(files) >= 4
-    for path in files:
-        tree = yaml.safe_load(open(path)) or {}
-        tree = tree.get("MpcLocalPlannerROS", tree)
-        status, log = RL.probe_configure(tree)
-        assert status == 1, (path, log)
-        ctl = RL.RefController(tree)
-        built = ctl.dump()
-        ctl.close()
-        cfg, ctrl, notes = P.config_from_params(tree)
-        _held_to_reference(cfg, ctrl, built)
-        st, ccfg, opt, rep = _cpp_config(cpp, tree)
-        assert st == 0, rep
-        _held_to_reference(ccfg, {k: opt[k] for k in ctrl}, built)
-
-
-@pytest.mark.skipif(not os.path.isdir("/root/reference/mpc_local_planner/src"), reason="the reference tree is only present in the build container")
-def test_plugin_level_parameters_against_the_reference_s_initialize(cpp):
-    """the parameters MpcLocalPlannerROS::initialize reads for itself (src/mpc_local_planner_ros.cpp:96-125, :220), executed (oracle/_ref, the whole plugin) on parameter sets
-    with defaults, explicit values and roscpp's conversions: plugin_options_from_params gives the same values"""
-    from oracle import ref_lib as RL
-    assert RL.build()
-    base = configure_cases.base_carlike()
-    sets = [({}, None), (base, None),
-            ({"controller": {"xy_goal_tolerance": 0.05, "yaw_goal_tolerance": 1, "global_plan_overwrite_orientation": False, "global_plan_prune_distance": 0.4,
-                             "max_global_plan_lookahead_dist": 3, "global_plan_viapoint_sep": 0.5},
-              "odom_topic": "/robot/odom", "footprint_model": {"is_footprint_dynamic": True},
-              "collision_avoidance": {"include_costmap_obstacles": False, "costmap_obstacles_behind_robot_dist": 0.7, "collision_check_no_poses": 6.6, "collision_check_min_resolution_angular": 0.3},
-              "costmap_converter_plugin": "", "costmap_converter_rate": 7, "costmap_converter_spin_thread": False}, {"controller_frequency": 20.0}),
-            ({"controller": {"global_plan_overwrite_orientation": 1, "xy_goal_tolerance": "0.3"}, "collision_avoidance": {"collision_check_no_poses": "4"}}, {"controller_frequency": 5})]
-    cost = np.zeros((10, 10), np.uint8)
-    for tree, mb in sets:
-        run = RL.PluginRunner(tree, cost, 0.1, (0.0, 0.0), footprint=[(0.2, 0.1), (-0.2, 0.1), (-0.2, -0.1)], move_base_params=mb)
-        assert run.initialized
-        ref = run.parameters()
-        run.close()
-        ours = P.plugin_options_from_params(tree, mb)
-        assert set(ours) == set(ref)
-        for k, v in ref.items():
-            assert (ours[k] == v) if isinstance(v, str) else (float(ours[k]) == v), (k, ours[k], v, tree)
-        out = np.zeros(14); strings = C.create_string_buffer(1024)
-        cpp.ctl_plugin_options.restype = None
-        cpp.ctl_plugin_options("\n".join(_flatten(tree)).encode(), "\n".join(_flatten(mb or {})).encode(), out.ctypes.data_as(C.c_void_p), strings, 1024)
-        got = dict(zip(RL.PluginRunner.PLUGIN_PARAMETER_NAMES, out.tolist()))
-        txt = strings.value.decode().split("\n")
-        got["odom_topic"], got["costmap_converter_plugin"] = txt[0], (txt[1] if len(txt) > 1 else "")
-        assert got == ref, (got, ref)
