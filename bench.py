@@ -503,7 +503,7 @@ def main():
             l3.close()
         # configs[4] share: kinematic bicycle, n = 120, fp32, 1024 per GPU
         n5, B5 = 120, 1024
-        # candidate set chosen ON THE DEVICE in fp32 (scripts/gpu_candidate_sweep_config5.py, profiles/r02_candidate_sweep_config5.log): the reference cold
+        # candidate set chosen ON THE DEVICE in fp32 (tests/tools/gpu_candidate_sweep_config5.py, profiles/r02_candidate_sweep_config5.log): the reference cold
         # start, then the reference's own no-initial-plan guess (heading = direction of travel), its reverse-driving twin and one Hermite seed.  On these
         # 5-40 m problems the reference cold start alone converges for 72 %, this set for 99.8 % (6 draws: see the log); the headline's Hermite set at
         # caps 100, which this leg ran before, reached 97.9 % in 20 ms.

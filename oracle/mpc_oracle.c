@@ -1155,7 +1155,7 @@ static void derive_step(work_t* w, const double* cc, double mu, double tau, doub
 }
 
 
-/* EXPERIMENT switches (oracle_set_algo; scripts/algo_stats.py, DESIGN.md section 3 holds the measurements).  The defaults are THE algorithm -- the one
+/* EXPERIMENT switches (oracle_set_algo; tests/tools/algo_stats.py, DESIGN.md section 3 holds the measurements).  The defaults are THE algorithm -- the one
  * oracle/ipm_dense.py and the kernel run too; everything else is Ipopt machinery that was measured on the BASELINE workloads and not adopted:
  *   mu_oracle      0 step-length rule (the product), 1 Mehrotra's probing oracle (Ipopt mu_oracle=probing: affine-scaling solve with the same factorisation),
  *                  2 LOQO rule (Ipopt mu_oracle=loqo)

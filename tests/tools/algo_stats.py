@@ -1,7 +1,7 @@
 """Convergence statistics of the C oracle's reference path (one candidate, 100 iterations) on the BASELINE workloads, with the experiment switches of oracle_set_algo
 usage: algo_stats.py key=value ...   (oracle_set_algo keys: mu globalization soc safeguard sigma_max mu_max_fact restoration)"""
 import sys, time, os, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle import c_oracle as CO, se2_nlp as R
 from mpc_local_planner_amd import workloads as W

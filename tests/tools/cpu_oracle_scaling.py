@@ -1,6 +1,6 @@
 """Throughput of the C oracle (the CPU baseline of bench.py) versus the number of OpenMP threads on this host."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from oracle import c_oracle as CO, se2_nlp as R
 import mpc_local_planner_amd.workloads as W

@@ -1,5 +1,5 @@
 """C oracle, reference path alone, on the clearance-row workloads -- with the experiment switches of oracle_set_algo (elastic=<rho> etrig=<k>)
-usage: python scripts/dev/elastic_stats.py [elastic=1000] [etrig=3] [B=128]"""
+usage: python tests/tools/dev/elastic_stats.py [elastic=1000] [etrig=3] [B=128]"""
 import sys, os, time, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))

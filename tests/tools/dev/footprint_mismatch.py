@@ -1,5 +1,5 @@
 """developer script (GPU): the instances of the turning-footprint workloads of tests/test_gpu_ext_rows.py where device and C oracle end with different statuses or iteration counts.
-The oracle's results are computed on the CPU beforehand (`python scripts/dev/footprint_mismatch.py cpu`) and kept next to this file."""
+The oracle's results are computed on the CPU beforehand (`python tests/tools/dev/footprint_mismatch.py cpu`) and kept next to this file."""
 import os, sys
 import numpy as np
 R_ = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

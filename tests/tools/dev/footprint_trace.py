@@ -1,6 +1,6 @@
-"""developer script: per-iteration trace of ONE instance of a workload of scripts/dev/footprint_mismatch.py
-    python scripts/dev/footprint_trace.py cpu "static line" 102      -- the C oracle's (oracle_set_trace)
-    MPC_HIP_LIB=<a -DMPC_NANCHECK=102 single-TU build> python scripts/dev/footprint_trace.py gpu "static line" 102"""
+"""developer script: per-iteration trace of ONE instance of a workload of tests/tools/dev/footprint_mismatch.py
+    python tests/tools/dev/footprint_trace.py cpu "static line" 102      -- the C oracle's (oracle_set_trace)
+    MPC_HIP_LIB=<a -DMPC_NANCHECK=102 single-TU build> python tests/tools/dev/footprint_trace.py gpu "static line" 102"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))

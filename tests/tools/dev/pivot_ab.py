@@ -1,4 +1,4 @@
-"""developer script: statuses / iteration counts of the one-candidate config-2 batch against the C solver's (computed on the CPU beforehand: python scripts/dev/pivot_ab.py cpu)"""
+"""developer script: statuses / iteration counts of the one-candidate config-2 batch against the C solver's (computed on the CPU beforehand: python tests/tools/dev/pivot_ab.py cpu)"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))

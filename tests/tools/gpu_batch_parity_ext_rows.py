@@ -1,10 +1,10 @@
 """Batch-scale device-vs-C-oracle parity for the rows that live in the EXT kernel instantiation (terminal ball, integral form with dt free,
 line / polygon / two-circle footprints, dynamic obstacles).  Written after round 1's GPU minutes were spent: run it on an MI355X
-(`gpurun -- python scripts/gpu_batch_parity_ext_rows.py`) and turn the printed statistics into `-m gpu` tests with thresholds.
+(`gpurun -- python tests/tools/gpu_batch_parity_ext_rows.py`) and turn the printed statistics into `-m gpu` tests with thresholds.
 The C oracle is pinned to the numpy fixtures for every one of these rows (tests/test_oracle_solver.py)."""
 import copy, os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import mpc_local_planner_amd as m
 from oracle import c_oracle as CO, se2_nlp as R
 from mpc_local_planner_amd import workloads as W

@@ -5,7 +5,7 @@ import json, os, sys
 import numpy as np
 import torch
 torch.zeros(1, device="cuda")
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import mpc_local_planner_amd as m
 
 B, n = int(sys.argv[1]) if len(sys.argv) > 1 else 1024, 120

@@ -1,11 +1,11 @@
 #!/usr/bin/env python
 """Developer script (GPU box): candidate initial trajectories on the device vs the same rule on the C oracle, config 2.
-usage: python scripts/gpu_candidates.py [B] [caps e.g. 60,60,60]"""
+usage: python tests/tools/gpu_candidates.py [B] [caps e.g. 60,60,60]"""
 import json, os, sys, time
 import numpy as np
 import torch
 torch.cuda.init(); torch.zeros(1, device='cuda')      # torch's HIP runtime first (bench.py order)
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import mpc_local_planner_amd as m
 from mpc_local_planner_amd import _abi as A
 from oracle import c_oracle as CO, se2_nlp as R, candidates as OC

@@ -1,6 +1,6 @@
 """First-light GPU check: parity vs the numpy oracle on a few instances + B=1024 timing."""
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import mpc_local_planner_amd as m
 from oracle import se2_nlp as R, ipm_dense as I

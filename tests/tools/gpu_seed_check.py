@@ -4,7 +4,7 @@ import os, sys
 import numpy as np
 import torch
 torch.zeros(1, device="cuda")
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import mpc_local_planner_amd as m
 B, n = 1024, 50
 s = m.BatchSolver(m.config_carlike_min_time(n, candidates=(0, 5, 5, 7), candidate_max_iter=(60, 45, 40, 35), candidate_param=(0.0, 2.0, 3.0, 1.5)), max_batch=B)

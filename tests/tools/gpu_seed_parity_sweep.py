@@ -1,8 +1,8 @@
 """Parity accounting of the headline workload on OTHER seeds than the tests use (robustness check of a round's algorithm change): device vs C oracle, reference path alone
 and with the headline's candidates (parity-preserving caps), B = 1024 each.  Every converged device result must be within 1e-4 of the oracle's or a KKT point on its own."""
 import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 
 
