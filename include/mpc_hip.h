@@ -88,7 +88,10 @@ enum mpc_hessian_mode {
 };
 
 enum mpc_stage_data {                 /* mpc_config.stage_data */
-    MPC_STAGE_AUTO = 0,               /* decided per handle and precision at mpc_create: global memory exactly when the smaller LDS record puts more workgroups on a CU */
+    MPC_STAGE_AUTO = 0,               /* decided per handle and precision at mpc_create.  fp64: global memory when the LDS form leaves at least half of a CU's SIMDs without a wave and
+                                       * the global form fills more of them (bit-identical results either way).  Plain fp32: already when the LDS form leaves one of four empty --
+                                       * there the two forms agree to rounding only, so an fp32 handle reproduces itself run to run but not the results of library versions
+                                       * before 0.5.0 (which kept fp32 in LDS).  Both phases of MPC_MIXED keep the LDS form */
     MPC_STAGE_LDS = 1,                /* the whole working set of an instance in LDS (97 words per grid point) */
     MPC_STAGE_GLOBAL = 2              /* stage records and gains in a per-workgroup block of global memory (L2 / Infinity-Cache resident), 34 words per grid point in LDS;
                                        * headline kernel level only (mpc_create refuses it for the extended terms) */
@@ -253,7 +256,10 @@ void mpc_config_defaults(mpc_config* cfg);
 
 /* Create a solver for one (model, objective, n, flags) tuple on HIP device `device`
  * with room for `max_batch` instances.  Fails with MPC_ENODEV when no GPU is present:
- * there is NO CPU fallback.  Replaces Controller::configure (include/.../controller.h:61-62). */
+ * there is NO CPU fallback.  Replaces Controller::configure (include/.../controller.h:61-62).
+ * Device memory of a handle besides the per-instance inputs / outputs: with the factorisation data in global memory (mpc_config.stage_data; also every handle with
+ * clearance rows, for their elastic arrays) a pool of blocks per XCD -- 8 pools x 2 x (resident workgroups per CU, from the occupancy API) x (CUs of an XCD) blocks of
+ * ~63 n words: 150 MB at n = 120 in fp64 on an MI355X, independent of max_batch; fleets with several such handles add it up. */
 int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_solver** out);
 
 /* Replaces Controller::reset (controller.h:104): waits for the stream and returns the handle's per-instance state (candidate

@@ -89,6 +89,28 @@ static bool solver_ext(const mpc_solver* s) {
            (P.n_obst > 0 && (P.footprint_kind == MPC_FOOTPRINT_LINE || P.footprint_kind == MPC_FOOTPRINT_TWO_CIRCLES || P.footprint_kind == MPC_FOOTPRINT_POLYGON));
 }
 
+// which XCC ids the device's workgroups run on (bit i of *mask: some workgroup saw HW_REG_XCC_ID & 7 == i): 8 bits on an MI355X, 1 in a partitioned mode
+namespace mpc {
+__global__ void xcc_probe_kernel(unsigned* mask) {
+    if (threadIdx.x == 0) atomicOr(mask, 1u << ((unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 7u));
+}
+}  // namespace mpc
+// resident workgroups per CU of the solve kernel a launch record selects (per precision and model: the instantiations live in mpc_solve_inst.hip)
+static hipError_t pool_kernel_occupancy(bool f32, int model, const mpc::SolveLaunch& a, int* out) {
+#ifdef MPC_DEV_ONE_MODEL
+    (void)model; return f32 ? hipErrorInvalidConfiguration : mpc::solve_occupancy<double, MPC_DEV_ONE_MODEL>(a, out);
+#else
+#define MPC_OCC(M) (f32 ? mpc::solve_occupancy<float, M>(a, out) : mpc::solve_occupancy<double, M>(a, out))
+    switch (model) {
+        case MPC_MODEL_UNICYCLE: return MPC_OCC(mpc::MODEL_UNICYCLE);
+        case MPC_MODEL_SIMPLE_CAR: return MPC_OCC(mpc::MODEL_SIMPLE_CAR);
+        case MPC_MODEL_SIMPLE_CAR_FRONT: return MPC_OCC(mpc::MODEL_SIMPLE_CAR_FRONT);
+        default: return MPC_OCC(mpc::MODEL_KINEMATIC_BICYCLE);
+    }
+#undef MPC_OCC
+#endif
+}
+
 // Device staging of the host-pointer helpers: ONE allocation kept in the handle and carved into 256-byte aligned pieces (these calls sit in a B = 1 control
 // loop next to a sub-millisecond solve; a hipMalloc / hipFree pair per temporary per call cost more than the kernels they feed).  Grows on demand, freed by mpc_destroy.
 static hipError_t stage_carve(mpc_solver* s, const size_t* sz, int count, void** out) {
@@ -231,12 +253,14 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         s->WLg = layout(true);
     }
     auto lds_of = [](const mpc::WaveLayout& L, size_t tsize, size_t psize) { return ((((size_t)L.total * tsize) + 15) & ~(size_t)15) + 16 + ((psize + 15) & ~(size_t)15); };
-    // Where the factorisation data lives, per precision.  The register file holds these kernels at one wave per SIMD, so a CU has room for four workgroups; an LDS record
-    // that fits fewer than four times leaves SIMDs without a wave.  Measured on the MI355X (profiles/r05_stage_data_probe.log): the global-memory form costs 5 % per
-    // solve at n = 80 / 120 and 19 % at n = 50 when both forms hold the same number of waves, and pays x2.0 - x2.6 at n = 120 in fp64 (1 -> 4 workgroups per CU), x1.15 at
-    // n = 80 with 16 polygons (2 -> 3).  MPC_STAGE_AUTO therefore takes it for fp64 when the LDS form leaves at least HALF of a CU's SIMDs empty and the global form fills
-    // more of them; fp32 keeps everything in LDS (3 -> 4 workgroups per CU at n = 120 measured 2 % slower; and the compiler contracts / packs the fp32 lane-parallel
-    // passes differently around global loads, so the two forms agree to rounding there, not bit for bit as in fp64).  The extended kernel levels exist in the LDS form only.
+    // Where the factorisation data lives, per precision (MPC_STAGE_AUTO).  The register file holds these kernels at one wave per SIMD, so a CU has room for four workgroups; an
+    // LDS record that fits fewer than four times leaves SIMDs without a wave.  Measured on the MI355X (profiles/r05_stage_data_probe.log): at EQUAL residency the global form
+    // costs 24 % per iteration at n = 50 and ~5 % at n = 80 / 120; it pays x2.2 - x2.8 at n = 120 in fp64 (1 -> 4 workgroups per CU) and x1.3 - x1.5 from residency alone at n = 80
+    // with 16 polygons.  The rule, stated once (also in include/mpc_hip.h): fp64 takes the global form when the LDS form leaves at least HALF of a CU's SIMDs empty and the global
+    // form fills more of them; plain fp32 already when the LDS form leaves ONE of four empty (n = 120: 7.06 -> 6.43 ms since the block is laid out in tiles) -- in fp32 the two
+    // forms agree to rounding, not bit for bit (the compiler contracts / packs the fp32 lane-parallel passes differently around global loads), so an fp32 handle under
+    // MPC_STAGE_AUTO reproduces itself run to run but not the results of builds before 0.5.0; both phases of MPC_MIXED keep the LDS form.  The extended kernel levels exist in
+    // the LDS form only.
     {
         const bool can_gs = !solver_ext(s);
         auto per_cu = [](size_t lds) { const size_t k = (160u * 1024u) / lds; return k > 4 ? (size_t)4 : k; };
@@ -324,10 +348,34 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         if (er == hipSuccess) er = hipGetDeviceProperties(&prop, device);
         const size_t c32 = (cfg->precision != MPC_FP64 && s->P32.n_cand > 1) ? (size_t)s->P32.n_cand : 1, c64 = (cfg->precision != MPC_FP32 && s->P64.n_cand > 1) ? (size_t)s->P64.n_cand : 1;
         const size_t grid = Bm * (c32 > c64 ? c32 : c64);
-        // (at least 256: in a partitioned mode the device is ONE XCD with 32 CUs, which still holds 32 x 8 workgroups)
-        size_t per_xcd = er == hipSuccess && prop.multiProcessorCount > 256 ? (size_t)prop.multiProcessorCount : 256;
-        if (s->w2_gs) per_xcd *= 2;      // eight resident workgroups per CU fill a pool of 256 to the last block; twice that keeps the claim probes short
-        if (per_xcd > grid) per_xcd = grid;
+        // Pool size per XCD = twice what ONE XCD can hold at once, from the runtime: workgroups per CU of the kernel that uses the pool (occupancy API: registers,
+        // LDS, one-wave workgroups) x the CUs of an XCD (the device's CUs / the number of distinct XCC ids a probe launch sees: 8 on an MI355X, 1 in a partitioned mode).  A
+        // pool can then never run dry, and the factor two keeps the claim probe of mpc_solve_kernel.hpp at a step or two when every CU is full.  Never more than the largest
+        // launch has workgroups.  Memory: 8 pools x per_xcd x block bytes (MI355X, n = 120 in fp64: 8 x 256 x 73 KB = 150 MB per handle; include/mpc_hip.h, mpc_create).
+        size_t per_cu = 8;      // (two one-wave workgroups per SIMD: the upper limit of any build)
+        int n_xcc = 1;
+        if (er == hipSuccess) {
+            int occ = 0;
+            mpc::SolveLaunch a{};
+            a.level = !solver_ext(s) ? 0 : (s->P64.costx ? 2 : 1);
+            const bool f32 = cfg->precision == MPC_FP32;
+            a.w2 = !f32 && s->w2_gs;
+            const bool gsf = f32 ? s->gs32 : (s->gs64 || s->w2_gs);
+            a.L = gsf ? s->WLg : s->WL;
+            a.lds = f32 ? s->wave_lds32 : (s->w2_gs ? s->wave_lds_w2 : s->wave_lds);
+            if (pool_kernel_occupancy(f32, cfg->model, a, &occ) == hipSuccess && occ > 0) per_cu = (size_t)occ;
+            unsigned* d_mask = nullptr; unsigned h_mask = 0;
+            if (hipMalloc((void**)&d_mask, 4) == hipSuccess) {
+                if (hipMemset(d_mask, 0, 4) == hipSuccess) {
+                    hipLaunchKernelGGL(mpc::xcc_probe_kernel, dim3(16u * (unsigned)prop.multiProcessorCount), dim3(64), 0, 0, d_mask);
+                    if (hipMemcpy(&h_mask, d_mask, 4, hipMemcpyDeviceToHost) == hipSuccess && h_mask) n_xcc = __builtin_popcount(h_mask & 0xffu);
+                }
+                (void)hipFree(d_mask);
+            }
+        }
+        const size_t cus_per_xcd = ((size_t)prop.multiProcessorCount + (size_t)n_xcc - 1) / (size_t)n_xcc;
+        size_t per_xcd = er == hipSuccess ? 2 * per_cu * cus_per_xcd : 512;
+        if (per_xcd < 64) per_xcd = 64;
         s->n_gslots = (int)per_xcd;
         const size_t blk64 = cfg->precision != MPC_FP32 ? (size_t)((s->gs64 || s->w2_gs) ? s->WLg.GSW : s->WL.GSW) * 8 : 0, blk32 = cfg->precision != MPC_FP64 ? (size_t)(s->gs32 ? s->WLg.GSW : s->WL.GSW) * 4 : 0;
         if (er == hipSuccess) er = hipMalloc(&s->d_gstage, 8 * per_xcd * (blk64 > blk32 ? blk64 : blk32) + (size_t)mpc::GlobalStage::kPrefetchPad * 8);

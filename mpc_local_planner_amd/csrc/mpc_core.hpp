@@ -789,6 +789,7 @@ MPC_HD int riccati_root(const RicState<T>& V, const Problem<T>& P_, T& dd_out, T
             okp = okp && (t_abs(pv) > T(1e-14) * rs) && (rs > T(0));
             neg += pv < T(0) ? 1 : 0;
             const T ip = t_rcp(pv);
+            okp = okp && t_finite(ip);      // (a denormal pivot whose reciprocal overflows passes the row-relative test when its row holds nothing else: ADVICE r05)
 #pragma unroll
             for (int r = c + 1; r < 4; ++r) {
                 const T m = B4[r][c] * ip;

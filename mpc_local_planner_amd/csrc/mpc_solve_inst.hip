@@ -8,4 +8,5 @@
 
 namespace mpc {
 template hipError_t launch_solve<MPC_INST_T, MPC_INST_MODEL>(const SolveLaunch&, const Problem<MPC_INST_T>&);
+template hipError_t solve_occupancy<MPC_INST_T, MPC_INST_MODEL>(const SolveLaunch&, int*);
 }

@@ -224,8 +224,10 @@ struct SolveLaunch {
 
 constexpr int kFixedLayoutNS = 50;
 
+// the kernel instantiation that serves a launch record (nullptr + an error for a combination that does not exist)
 template <typename T, int MODEL>
-hipError_t launch_solve(const SolveLaunch& a, const Problem<T>& P) {
+auto select_kernel(const SolveLaunch& a, hipError_t& err) -> decltype(&mpc_ipm_wave_kernel<T, MODEL, 0, true>) {
+    err = hipSuccess;
     // four instantiations per (arithmetic type, model): the headline level without / with clearance rows, and the two extended levels (always with)
 #ifdef MPC_DEV_SWITCHES
     static const bool force_obst = getenv("MPC_FORCE_OBST_KERNEL") != nullptr;      // developer switch (A/B of the two headline instantiations); not in the shipped library
@@ -235,9 +237,8 @@ hipError_t launch_solve(const SolveLaunch& a, const Problem<T>& P) {
     auto kern = a.level == 0 ? ((a.L.M > 0 || force_obst) ? mpc_ipm_wave_kernel<T, MODEL, 0, true> : mpc_ipm_wave_kernel<T, MODEL, 0, false>)
                              : (a.level == 2 ? mpc_ipm_wave_kernel<T, MODEL, 2, true> : mpc_ipm_wave_kernel<T, MODEL, 1, true>);
     // factorisation data in global memory (WaveLayout::GSF; mpc_capi.hip decides per handle and precision): the headline level's two instantiations exist in that form
-    if (a.L.GSW > 0 && !a.gstage) return hipErrorInvalidConfiguration;
     if (a.L.GSF) {
-        if (a.level != 0) return hipErrorInvalidConfiguration;
+        if (a.level != 0) { err = hipErrorInvalidConfiguration; return nullptr; }
         kern = (a.L.M > 0 || force_obst) ? mpc_ipm_wave_kernel<T, MODEL, 0, true, 0, true> : mpc_ipm_wave_kernel<T, MODEL, 0, false, 0, true>;
     }
     // fp64 headline kernel on a grid of kFixedLayoutNS points per record (the grid size of BASELINE configs[1] / [3]): the instantiation whose LDS layout is a
@@ -253,15 +254,24 @@ hipError_t launch_solve(const SolveLaunch& a, const Problem<T>& P) {
     }
     if constexpr (sizeof(T) == 8) {
         if (a.w2) {
-            if (a.level != 0 || a.L.M > 0) return hipErrorInvalidConfiguration;
+            if (a.level != 0 || a.L.M > 0) { err = hipErrorInvalidConfiguration; return nullptr; }
 #ifdef MPC_DEV_SWITCHES
             kern = a.L.GSF ? mpc_ipm_wave_kernel<T, MODEL, 0, false, 0, true, true> : mpc_ipm_wave_kernel<T, MODEL, 0, false, 0, false, true>;
 #else
-            if (a.L.GSF) return hipErrorInvalidConfiguration;
+            if (a.L.GSF) { err = hipErrorInvalidConfiguration; return nullptr; }
             kern = mpc_ipm_wave_kernel<T, MODEL, 0, false, 0, false, true>;
 #endif
         }
     }
+    return kern;
+}
+
+template <typename T, int MODEL>
+hipError_t launch_solve(const SolveLaunch& a, const Problem<T>& P) {
+    if (a.L.GSW > 0 && !a.gstage) return hipErrorInvalidConfiguration;
+    hipError_t err;
+    auto kern = select_kernel<T, MODEL>(a, err);
+    if (!kern) return err;
     if (a.lds > 48u * 1024u) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.lds);
         if (e != hipSuccess) return e;
@@ -271,8 +281,21 @@ hipError_t launch_solve(const SolveLaunch& a, const Problem<T>& P) {
     return hipSuccess;
 }
 
+// resident one-wave workgroups per CU of the kernel that serves a launch record (registers, LDS): what sizes the per-XCD block pools (mpc_capi.hip)
+template <typename T, int MODEL>
+hipError_t solve_occupancy(const SolveLaunch& a, int* out) {
+    hipError_t err;
+    auto kern = select_kernel<T, MODEL>(a, err);
+    if (!kern) return err;
+    if (a.lds > 48u * 1024u) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)a.lds);
+        if (e != hipSuccess) return e;
+    }
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(out, kern, kWave, a.lds);
+}
+
 #if defined(MPC_SPLIT_BUILD) && !defined(MPC_SOLVE_INST)
-#define MPC_EXTERN_LAUNCH(T, M) extern template hipError_t launch_solve<T, M>(const SolveLaunch&, const Problem<T>&);
+#define MPC_EXTERN_LAUNCH(T, M) extern template hipError_t launch_solve<T, M>(const SolveLaunch&, const Problem<T>&); extern template hipError_t solve_occupancy<T, M>(const SolveLaunch&, int*);
 MPC_EXTERN_LAUNCH(double, 0) MPC_EXTERN_LAUNCH(double, 1) MPC_EXTERN_LAUNCH(double, 2) MPC_EXTERN_LAUNCH(double, 3)
 MPC_EXTERN_LAUNCH(float, 0) MPC_EXTERN_LAUNCH(float, 1) MPC_EXTERN_LAUNCH(float, 2) MPC_EXTERN_LAUNCH(float, 3)
 #undef MPC_EXTERN_LAUNCH
