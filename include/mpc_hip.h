@@ -406,6 +406,11 @@ int mpc_last_kernel_ms(mpc_solver* s, float* ms);
  * 95 408 B = 1 in the LDS form) and in fp32 (17 552 B in the global form; 47 792 B = 3 in the LDS form).  MPC_MIXED reports its fp64 phase. */
 int mpc_lds_bytes(const mpc_solver* s, int64_t* bytes);
 
+/* What a launch of B instances on this handle occupies, from the runtime's occupancy calculation on the kernel instantiation such a launch selects (registers, LDS, one-wave
+ * workgroups): resident workgroups per compute unit (4 = one wave per SIMD; 8 with the two-waves-per-SIMD kernel of mpc_config.two_wave_min_batch) and the dynamic LDS of one of
+ * them.  MPC_MIXED reports its fp64 phase.  Measurement aid (bench.py reports it next to the throughput); no counterpart in the reference. */
+int mpc_occupancy(mpc_solver* s, int32_t B, int32_t* workgroups_per_cu, int64_t* lds_bytes);
+
 /* Human-readable text of the last HIP/runtime error on this thread ("" if none). */
 const char* mpc_last_error(void);
 

@@ -22,7 +22,7 @@ HEADERS = ["mpc_solve_kernel.hpp", "mpc_core.hpp", "mpc_problem.hpp", "mpc_wave.
 
 EXPORTS = [
     "mpc_config_defaults", "mpc_create", "mpc_reset", "mpc_destroy", "mpc_solve_batch",
-    "mpc_solve_batch_device", "mpc_step_batch", "mpc_step_batch_device", "mpc_set_grid_sizes", "mpc_set_via_points", "mpc_set_via_points_device", "mpc_costmap_to_obstacles", "mpc_costmap_to_obstacles_device", "mpc_last_candidates", "mpc_last_rows_dropped", "mpc_check_feasibility", "mpc_check_feasibility_device", "mpc_grid_update_device", "mpc_get_grid_sizes", "mpc_synchronize", "mpc_last_kernel_ms", "mpc_lds_bytes", "mpc_last_error", "mpc_version",
+    "mpc_solve_batch_device", "mpc_step_batch", "mpc_step_batch_device", "mpc_set_grid_sizes", "mpc_set_via_points", "mpc_set_via_points_device", "mpc_costmap_to_obstacles", "mpc_costmap_to_obstacles_device", "mpc_last_candidates", "mpc_last_rows_dropped", "mpc_check_feasibility", "mpc_check_feasibility_device", "mpc_grid_update_device", "mpc_get_grid_sizes", "mpc_synchronize", "mpc_last_kernel_ms", "mpc_lds_bytes", "mpc_occupancy", "mpc_last_error", "mpc_version",
 ]
 
 
@@ -168,6 +168,8 @@ def load() -> C.CDLL:
     lib.mpc_last_kernel_ms.restype = C.c_int
     lib.mpc_lds_bytes.argtypes = [C.c_void_p, C.POINTER(C.c_int64)]
     lib.mpc_lds_bytes.restype = C.c_int
+    lib.mpc_occupancy.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+    lib.mpc_occupancy.restype = C.c_int
     lib.mpc_last_error.argtypes = []
     lib.mpc_last_error.restype = C.c_char_p
     lib.mpc_version.argtypes = []

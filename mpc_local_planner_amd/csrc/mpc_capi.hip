@@ -791,6 +791,24 @@ int mpc_lds_bytes(const mpc_solver* s, int64_t* bytes) {
     return MPC_OK;
 }
 
+int mpc_occupancy(mpc_solver* s, int32_t B, int32_t* workgroups_per_cu, int64_t* lds_bytes) {
+    if (!s || !workgroups_per_cu || B <= 0) return MPC_EINVAL;
+    g_err[0] = 0;
+    HIP_TRY(hipSetDevice(s->device));
+    const bool f32 = s->cfg.precision == MPC_FP32;
+    mpc::SolveLaunch a{};
+    a.level = !solver_ext(s) ? 0 : (s->P64.costx ? 2 : 1);
+    a.w2 = !f32 && s->w2_ok && B >= s->w2_min_batch;
+    const bool gs = a.w2 ? s->w2_gs : (f32 ? s->gs32 : s->gs64);
+    a.L = gs ? s->WLg : s->WL;
+    a.lds = f32 ? s->wave_lds32 : (a.w2 ? s->wave_lds_w2 : s->wave_lds);
+    int occ = 0;
+    HIP_TRY(pool_kernel_occupancy(f32, s->cfg.model, a, &occ));
+    *workgroups_per_cu = occ;
+    if (lds_bytes) *lds_bytes = (int64_t)a.lds;
+    return MPC_OK;
+}
+
 int mpc_last_kernel_ms(mpc_solver* s, float* ms) {
     if (!s || !ms) return MPC_EINVAL;
     if (!s->timed) { *ms = 0.f; return MPC_OK; }

@@ -52,3 +52,63 @@ def max_over_ranks(value: float, device=None) -> float:
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def run_sharded_job(leg, steps: int, warmup: int, rank: int, world: int, total: int, device=None, solo_reference: bool = True, force_gather: bool = False):
+    """The N > 1 protocol of bench.py, as ONE function (bench.py calls it on the GPU legs over RCCL; tests/test_multi_gpu_cpu.py drives the same code under gloo with a CPU
+    stand-in for the leg): `total` independent planner instances are partitioned over `world` ranks (shard_range: contiguous, sizes differ by at most one), every rank owns
+    `leg` = its shard's solver + resident inputs / outputs.  No collective touches the data path.
+      1. `warmup` untimed steps; 2. (solo_reference) rank 0 alone runs `steps` steps while the others wait at a barrier: the per-GPU denominator for scaling efficiency,
+      measured in the same process state; 3. barrier, EXACTLY `steps` timed steps (each ends when its results are available: leg.step_wait()), barrier; the job's time is the
+      MAXIMUM over the ranks; 4. outside the timed region, every rank receives the whole job's status / dt / x by all_gather (ragged shards padded) and checks that its own
+      slice of the gathered arrays is what it computed.
+    leg: .step_wait() (one step, returns when its results are available), .sync() (everything queued is done), .results() -> (status, dt, x) arrays or tensors of this rank's
+    shard.  Returns a dict: elapsed (max over ranks, seconds), solo_elapsed (rank 0, or None), converged_total, shard (lo, hi), gather_ms, gathered (status, dt, x)."""
+    import time
+    import torch.distributed as dist
+    multi = dist.is_initialized() and (world > 1 or force_gather)
+    lo, hi = shard_range(total, world, rank)
+    for _ in range(warmup):
+        leg.step_wait()
+    leg.sync()
+    solo_elapsed = None
+    if multi and solo_reference:
+        dist.barrier()
+        leg.sync()
+        if rank == 0:
+            ts = time.perf_counter()
+            for _ in range(steps):
+                leg.step_wait()
+            leg.sync()
+            solo_elapsed = time.perf_counter() - ts
+        dist.barrier()
+    leg.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        leg.step_wait()
+    leg.sync()
+    if multi:
+        dist.barrier()
+    leg.sync()
+    elapsed = max_over_ranks(time.perf_counter() - t0, device=device)
+    st, dt, x = leg.results()
+    assert st.shape[0] == hi - lo, (st.shape, lo, hi)
+    out = {"elapsed": elapsed, "solo_elapsed": solo_elapsed, "shard": (lo, hi), "gather_ms": None, "gathered": None}
+    is_np = isinstance(st, np.ndarray)
+    n_conv = int((st == 0).sum()) if is_np else int((st == 0).sum().item())
+    if multi:
+        tg = time.perf_counter()
+        g_st = gather_results(st, world, total, device=device, force=force_gather)
+        g_dt = gather_results(dt, world, total, device=device, force=force_gather)
+        g_x = gather_results(x, world, total, device=device, force=force_gather)
+        if not is_np and g_x.is_cuda:
+            import torch
+            torch.cuda.synchronize()
+        out["gather_ms"] = (time.perf_counter() - tg) * 1e3
+        eq = (lambda a, b: np.array_equal(a, b)) if is_np else (lambda a, b: bool((a == b).all().item()))
+        assert g_st.shape[0] == total and g_dt.shape[0] == total and g_x.shape[0] == total
+        assert eq(g_st[lo:hi], st) and eq(g_x[lo:hi], x) and eq(g_dt[lo:hi], dt), "a rank's own slice of the gathered results differs from what it computed"
+        n_conv = int((g_st == 0).sum()) if is_np else int((g_st == 0).sum().item())
+        out["gathered"] = (g_st, g_dt, g_x)
+    out["converged_total"] = n_conv
+    return out

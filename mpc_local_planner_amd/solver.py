@@ -246,6 +246,12 @@ class BatchSolver:
         self._check(self._lib.mpc_lds_bytes(self._h, C.byref(b)))
         return int(b.value)
 
+    def occupancy(self, B: int):
+        """(resident workgroups per compute unit, dynamic LDS bytes of one) of the kernel a launch of B instances selects, from the runtime's occupancy calculation"""
+        w, b = C.c_int32(0), C.c_int64(0)
+        self._check(self._lib.mpc_occupancy(self._h, int(B), C.byref(w), C.byref(b)))
+        return int(w.value), int(b.value)
+
     def last_kernel_ms(self) -> float:
         ms = C.c_float(0)
         self._check(self._lib.mpc_last_kernel_ms(self._h, C.byref(ms)))
