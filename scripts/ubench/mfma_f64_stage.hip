@@ -138,17 +138,18 @@ template <int MODE> __global__ __launch_bounds__(64) void k(double* out, long lo
     if (lane == 0) ticks[blockIdx.x] = t1 - t0;
 }
 
-template <int MODE> void run(const char* name, int blocks, int per_iter) {
+template <int MODE> void run(const char* name, int blocks, int per_iter, size_t lds = 39 * 1024, int waves_per_simd = 1) {
     double* out; long long* ticks;
     hipMalloc(&out, blocks * 64 * sizeof(double)); hipMalloc(&ticks, blocks * sizeof(long long));
     hipMemset(out, 0, blocks * 64 * sizeof(double));
-    const int iters = 2000; const size_t lds = 39 * 1024;
+    const int iters = 2000;
     k<MODE><<<blocks, 64, lds>>>(out, ticks, 10);
     k<MODE><<<blocks, 64, lds>>>(out, ticks, iters);
     hipDeviceSynchronize();
     std::vector<long long> h(blocks); hipMemcpy(h.data(), ticks, blocks * sizeof(long long), hipMemcpyDeviceToHost);
     double mean = 0; for (auto t : h) mean += t; mean /= blocks;
-    printf("%-78s blocks=%5d  ticks per %s %8.1f\n", name, blocks, per_iter == 1 ? "stage      " : "instruction", mean / iters / per_iter);
+    if (waves_per_simd > 1) printf("%-78s blocks=%5d  %d waves per SIMD: ticks per stage of ONE wave %8.1f = %8.1f per stage and SIMD\n", name, blocks, waves_per_simd, mean / iters / per_iter, mean / iters / per_iter / waves_per_simd);
+    else printf("%-78s blocks=%5d  ticks per %s %8.1f\n", name, blocks, per_iter == 1 ? "stage      " : "instruction", mean / iters / per_iter);
     hipFree(out); hipFree(ticks);
 }
 int main() {
@@ -160,4 +161,9 @@ int main() {
         run<4>("backward-sweep stage on v_mfma_f64_4x4x4f64 (10 MFMAs + 5 lane permutations + pivot + gains)", blocks, 1);
         run<5>("backward-sweep stage as shipped (T1+H+R+V DPP blocks, 75 DPP FMAs + ~25)", blocks, 1);
     }
+    // r06: the same two stages with TWO waves per SIMD -- 16 KB of LDS per one-wave workgroup, 2048 workgroups = eight per CU -- so that the second wave can
+    // hide the ds_bpermute round trips and the MFMA -> VALU hand-offs of the first.  A wave's own clock then runs longer per stage; what counts is ticks per stage and SIMD.
+    run<4>("backward-sweep stage on v_mfma_f64_4x4x4f64 (10 MFMAs + 5 lane permutations + pivot + gains)", 2048, 1, 16 * 1024, 2);
+    run<5>("backward-sweep stage as shipped (T1+H+R+V DPP blocks, 75 DPP FMAs + ~25)", 2048, 1, 16 * 1024, 2);
+    run<1>("v_mfma_f64_4x4x4f64, 4 independent accumulators", 2048, 64, 16 * 1024, 2);
 }

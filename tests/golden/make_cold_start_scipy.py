@@ -4,6 +4,7 @@ with the interior-point implementations of this repository) on the REFERENCE-FOR
 reference's cold start -- not from anybody's answer (level 2).
 
   config 2   car-like minimum time, n = 50, the first 32 instances of the SURVEY 8d distribution
+  config 5   (shape of BASELINE configs[4]) kinematic bicycle minimum time, n = 120, the first 8 instances of workloads.bicycle_min_time_inputs (r06)
   config 3   unicycle quadratic form, n = 80, 16 polygon obstacles, the first 32 instances of workloads.unicycle_obstacle_inputs
              (association frozen on the cold start, max 4 rows per grid point, as the batched solvers do)
 
@@ -13,7 +14,8 @@ model has no steering authority and SLSQP's first QP is singular in the steering
 
 Stored per instance: SLSQP's x, u, dt, objective, success flag, iterations and its max constraint violation.  tests/test_oracle_solver.py
 compares the C oracle with it on the CPU, tests/test_gpu_parity.py the device.  Runtime: ~2 min (config 2) + ~25 min (config 3) on 8 cores.
-usage: python tests/golden/make_cold_start_scipy.py [2|3|3b|3c] [count]"""
+usage: python tests/golden/make_cold_start_scipy.py [2|3|3b|3c|5] [count]"""
+import json
 import multiprocessing as mp
 import os
 import sys
@@ -33,6 +35,10 @@ def solve_one(args):
     t0 = time.time()
     if cfgname == 2:
         ocfg = R.config_carlike_min_time(50)
+        inp = R.CycleInputs(x0=x0, xf=xf, u_prev=up, dt_prev=float(dtp))
+        nlp = R.ReferenceNlp(ocfg, inp)
+    elif cfgname == 5:
+        ocfg = R.config_bicycle_min_time(120)
         inp = R.CycleInputs(x0=x0, xf=xf, u_prev=up, dt_prev=float(dtp))
         nlp = R.ReferenceNlp(ocfg, inp)
     else:
@@ -67,19 +73,25 @@ def main():
     if which == 2:
         x0, xf, up, dtp = W.carlike_min_time_inputs(K)
         jobs = [(2, i, x0[i], xf[i], up[i], dtp[i], None) for i in range(K)]
+    elif which == 5:          # (r06) config-5 shape: kinematic bicycle, n = 120, goals 5 .. 40 m; ~1.5 min per instance, so 8 instances by default
+        K = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+        x0, xf, up, dtp = W.bicycle_min_time_inputs(K)
+        jobs = [(5, i, x0[i], xf[i], up[i], dtp[i], None) for i in range(K)]
     else:
         x0, xf, up, dtp, (no, nv, vt) = W.unicycle_obstacle_inputs(K, n_obst=16, max_vertices=6, **(dict(lateral=lateral) if lateral else {}))
         jobs = [(3, i, x0[i], xf[i], up[i], dtp[i], (no[i], nv[i], vt[i], None, None)) for i in range(K)]
     with mp.Pool(min(K, os.cpu_count() or 2)) as pool:
         out = pool.map(solve_one, jobs)
-    n = 50 if which == 2 else 80
+    n = {2: 50, 5: 120}.get(which, 80)
     u = np.zeros((K, n, 2))
     for i, o in enumerate(out):
         u[i, :n - 1] = o[1]; u[i, n - 1] = o[1][-1]
     np.savez_compressed(os.path.join(ROOT, "tests", "golden", f"cold_start_scipy_config{which}{suffix}.npz"),
                         x=np.stack([o[0] for o in out]), u=u, dt=np.array([o[2] for o in out]), objective=np.array([o[3] for o in out]),
                         success=np.array([o[4] for o in out]), nit=np.array([o[5] for o in out]), violation=np.array([o[6] for o in out]),
-                        count=K, lateral=np.array(lateral if lateral else (0.3, 1.5)))
+                        count=K, lateral=np.array(lateral if lateral else (0.3, 1.5)),
+                        generator=json.dumps(dict(script="tests/golden/make_cold_start_scipy.py", solver="scipy.optimize.minimize(method='SLSQP', maxiter=600, ftol=1e-12) on oracle/se2_nlp.py::ReferenceNlp",
+                                                  start="reference cold start, controls seeded from the state guess (oracle/ipm_dense.py::controls_from_states)"), sort_keys=True))
 
 
 if __name__ == "__main__":

@@ -2,6 +2,7 @@
 the one part of the reference that compiles in this image from its own sources (oracle/ref_math.cpp, `make -C oracle ref`).  Run where /root/reference exists:
     python tests/golden/make_ref_math_vectors.py
 The GPU box has no reference tree: the device tests compare against these vectors."""
+import json
 import os
 import sys
 
@@ -32,7 +33,8 @@ if __name__ == "__main__":
     dt, ds = RM.distance_points2d(v1, v2)
     out = dict(theta=theta, normalize_theta=RM.normalize_theta(theta), a1=a1, a2=a2, factor=factor, interpolate_angle=RM.interpolate_angle(a1, a2, factor),
                v1=v1, v2=v2, cross2d=RM.cross2d(v1, v2), distance_templated=dt, distance_scalar=ds,
-               average_angles=np.array([RM.average_angles(s) for s in sets]), n_sets=np.array(len(sets)))
+               average_angles=np.array([RM.average_angles(s) for s in sets]), n_sets=np.array(len(sets)),
+               generator=json.dumps(dict(script="tests/golden/make_ref_math_vectors.py", source="/root/reference/mpc_local_planner/include/mpc_local_planner/utils/math_utils.h compiled by oracle/ref_math.cpp (g++ -O2 -ffp-contract=off)")))
     for i, s in enumerate(sets):
         out[f"set{i}"] = s
     np.savez(os.path.join(ROOT, "tests", "golden", "ref_math_utils.npz"), **out)

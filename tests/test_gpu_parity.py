@@ -46,6 +46,26 @@ def test_gpu_reproduces_golden_fixtures(m, name):
     s.close()
 
 
+@pytest.mark.parametrize("name", ["carlike_min_time_n20_monotone", "unicycle_quadratic_n20_monotone"])
+def test_gpu_reproduces_the_fixtures_of_the_other_barrier_rule(m, name):
+    """tests/golden/*_monotone.npz are made with mu_strategy = monotone (Fiacco-McCormick) instead of the adaptive rule of every other fixture: the device under
+    MPC_MU_MONOTONE reproduces them at 1e-6 with the oracle's iteration counts; the device's DEFAULT (adaptive) solves end at the same minimum within the scatter
+    tests/test_oracle_solver.py::test_answers_under_the_other_barrier_rule documents (states within 1e-4, same travel time)."""
+    from mpc_local_planner_amd import _abi as A
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    mk = m.config_carlike_min_time if name.startswith("carlike") else m.config_unicycle_quadratic
+    B = g["x0"].shape[0]
+    s = m.BatchSolver(mk(20, mu_strategy=A.MU_MONOTONE), max_batch=B)
+    r = s.solve(g["x0"], g["xf"], g["u_prev"], g["dt_prev"]); s.close()
+    assert (r.status == 0).all() and np.abs(r.x - g["x"]).max() < 1e-6 and np.abs(r.u - g["u"]).max() < 1e-6 and np.abs(r.dt - g["dt"]).max() < 1e-8
+    assert np.abs(r.iters - g["iters"]).max() <= 2
+    s = m.BatchSolver(mk(20), max_batch=B)
+    a = s.solve(g["x0"], g["xf"], g["u_prev"], g["dt_prev"]); s.close()
+    assert (a.status == 0).all() and np.abs(a.x - g["x"]).max() < 1e-4 and np.abs(a.u - g["u"]).max() < 3e-4
+    if name.startswith("carlike"):
+        assert np.abs(a.dt - g["dt"]).max() < 1e-7 * np.abs(g["dt"]).max()
+
+
 def _feasibility(R, ocfg, x0, xf, up, dtp, res, i):
     inp = R.CycleInputs(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=float(dtp[i]))
     nlp = R.ReferenceNlp(ocfg, inp)

@@ -95,6 +95,52 @@ def test_numpy_ipm_reproduces_golden(name):
         assert abs(res.traj.dt - g["dt"][i]) < 1e-8
 
 
+def test_every_solver_fixture_records_how_it_was_made():
+    """ every tests/golden/*.npz carries a `generator` entry: the script, the function, and for the interior-point fixtures the full option set
+    (oracle/ipm_dense.py::IpmOptions) it was solved with"""
+    import glob
+    import json
+    files = sorted(glob.glob(os.path.join(GOLD, "*.npz")))
+    assert len(files) >= 30
+    for path in files:
+        g = np.load(path)
+        assert "generator" in g.files, path
+        rec = json.loads(str(g["generator"]))
+        assert rec["script"].startswith("tests/golden/make_") and os.path.exists(os.path.join(os.path.dirname(GOLD), "..", rec["script"])), (path, rec.get("script"))
+        if rec["script"].endswith("make_golden.py"):
+            assert rec["ipm_options"]["mu_strategy"] in ("adaptive", "monotone") and rec["ipm_options"]["tol"] == 1e-8, path
+
+
+MONOTONE = {"carlike_min_time_n20_monotone": lambda: R.config_carlike_min_time(20), "unicycle_quadratic_n20_monotone": lambda: R.config_unicycle_quadratic(20)}
+
+
+@pytest.mark.parametrize("name", sorted(MONOTONE))
+def test_answers_under_the_other_barrier_rule(name, c_oracle):
+    """(VERDICT r05 item 7 / ADVICE r04 item 4) One fixture set is made with mu_strategy = MONOTONE (Fiacco-McCormick, Ipopt's own default) instead of the adaptive rule every
+    other fixture and every default solve uses.  (1) Under the monotone rule the numpy oracle and the C oracle reproduce it at 1e-6 (they follow the same iterate sequence:
+    1e-12).  (2) The ADAPTIVE solvers, from the same start, end at the same minimum -- the objective agrees to 1e-7 relative -- but NOT at the same point to 1e-6 everywhere:
+    minimum-time and effort-weighted optima have flat directions (controls sliding along weakly active rate rows), and two interior-point runs that stop at E_0 <= 1e-8 on
+    different central paths sit up to 1e-4 apart in the controls, 2e-5 in the states (measured: 9 of 12 car-like and 3 of 8 unicycle instances within 1e-6, all states
+    within 1e-4 = the tolerance BASELINE.json states).  That scatter is what "within 1e-4 of the Ipopt reference" can mean at best for these NLPs."""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    cfg = MONOTONE[name]()
+    B = g["x0"].shape[0]
+    xo, uo, do, st, it = c_oracle.solve_batch(c_oracle.from_nlp_config(cfg, mu_strategy=1), g["x0"], g["xf"], g["u_prev"], g["dt_prev"])
+    assert (st == 0).all() and np.abs(xo - g["x"]).max() < 1e-6 and np.abs(uo - g["u"]).max() < 1e-6 and np.abs(do - g["dt"]).max() < 1e-8 and np.abs(it - g["iters"]).max() <= 1
+    for i in range(2):
+        inp = R.CycleInputs(x0=g["x0"][i], xf=g["xf"][i], u_prev=g["u_prev"][i], dt_prev=float(g["dt_prev"][i]))
+        res = I.solve(cfg, inp, R.cold_start(cfg, g["x0"][i], g["xf"][i]), opt=I.IpmOptions(globalization="merit", max_iter=100, mu_strategy="monotone"))
+        assert res.status == 0 and np.abs(res.traj.x - g["x"][i]).max() < 1e-6 and np.abs(res.traj.u - g["u"][i, :-1]).max() < 1e-6
+    xa, ua, da, sa, ia = c_oracle.solve_batch(c_oracle.from_nlp_config(cfg), g["x0"], g["xf"], g["u_prev"], g["dt_prev"])      # the default: adaptive
+    assert (sa == 0).all()
+    ex = np.abs(xa - g["x"]).reshape(B, -1).max(1); eu = np.abs(ua - g["u"]).reshape(B, -1).max(1)
+    assert ex.max() < 1e-4 and eu.max() < 3e-4, (ex.max(), eu.max())
+    assert np.mean(np.maximum(ex, eu) < 1e-6) >= 0.3 and np.median(ex) < 2e-6
+    if cfg.dt_free:
+        assert np.abs(da - g["dt"]).max() < 1e-7 * np.abs(g["dt"]).max()          # same travel time
+    print(f"[barrier rule, {name}] adaptive vs monotone answers: within 1e-6 {int(np.sum(np.maximum(ex, eu) < 1e-6))} of {B}, max state difference {ex.max():.1e}, max control difference {eu.max():.1e}")
+
+
 @pytest.mark.parametrize("name", sorted(OCFG))
 def test_c_oracle_reproduces_golden(name, c_oracle):
     g = np.load(os.path.join(GOLD, name + ".npz"))
