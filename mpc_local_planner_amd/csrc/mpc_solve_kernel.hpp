@@ -257,6 +257,10 @@ auto select_kernel(const SolveLaunch& a, hipError_t& err) -> decltype(&mpc_ipm_w
             if (a.level != 0 || a.L.M > 0) { err = hipErrorInvalidConfiguration; return nullptr; }
 #ifdef MPC_DEV_SWITCHES
             kern = a.L.GSF ? mpc_ipm_wave_kernel<T, MODEL, 0, false, 0, true, true> : mpc_ipm_wave_kernel<T, MODEL, 0, false, 0, false, true>;
+            {      // developer A/B: the 256-register variant of the fixed-layout kernel (one wave per SIMD all the same: its record is 40 KB)
+                using IW = IpmWave<T, MODEL, 0, false, kFixedLayoutNS>;
+                if (!a.L.GSF && IW::LayoutT::matches(a.L)) kern = mpc_ipm_wave_kernel<T, MODEL, 0, false, kFixedLayoutNS, false, true>;
+            }
 #else
             if (a.L.GSF) { err = hipErrorInvalidConfiguration; return nullptr; }
             kern = mpc_ipm_wave_kernel<T, MODEL, 0, false, 0, false, true>;

@@ -227,6 +227,23 @@ struct IpmWave {
     __device__ __forceinline__ int local_lane() const { int l = lane; asm volatile("" : "+v"(l)); return l; }
     // MPC_PHASE_LANE opens every phase of an iteration: in the two-waves-per-SIMD kernels (W2: 256 registers) the phase works on such a lane index of its own
 #define MPC_PHASE_LANE const int lane = W2 ? this->local_lane() : this->lane; (void)lane;
+    // A wave-uniform fp64 value that lives across phases of an iteration occupies TWO vector registers in every lane; read back through v_readfirstlane it is a scalar register
+    // pair (which the compiler parks in a lane of a spill register when it runs out: 1/32 of the space), and the phases in between have the vector registers for themselves.
+    // The 256-register kernels (W2) do that with the solve loop's scalars -- some sixty of them: barrier parameter, penalty, step data, the KKT error's pieces --, which is where
+    // their scratch traffic came from (profiles/r06_wave_kernel_n20_two_waves.md).  Pure copies: results unchanged.
+    static constexpr bool kUniformScalars = W2
+#ifdef MPC_UNIFORM_SCALARS_ALL      // developer A/B: the same in the one-wave kernels
+        || true
+#endif
+        ;
+    __device__ __forceinline__ static double uni_(double v) { return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v))); }
+    __device__ __forceinline__ static float uni_(float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+    // pow() of the device library is some 300 instructions and three dozen fp64 literals; inlined at its two (rarely executed) call sites of the solve loop the compiler
+    // materialises those literals ONCE in front of the loop and -- in the 256-register kernels -- spills them to scratch for the whole solve.  There it is a call.
+    __device__ __attribute__((noinline)) static T pow_cold(T a, T b) { return t_pow(a, b); }
+    __device__ __forceinline__ static T pow_(T a, T b) { if constexpr (W2) return pow_cold(a, b); else return t_pow(a, b); }
+    __device__ __forceinline__ static void U(T& v) { if constexpr (kUniformScalars) v = uni_(v); }
+    template <typename... Ts> __device__ __forceinline__ static void U(T& v, Ts&... rest) { U(v); U(rest...); }
 
 #include "mpc_wave_rows.inc"
 #include "mpc_wave_passes.inc"

@@ -1,5 +1,5 @@
 """One workload, a few launches of the solve kernel: the command rocprofv3 wraps for the per-leg profiles (scripts/profile_cmd.sh).
-    python scripts/gpu_solve_once.py <config5_fp64|config5_fp64_lds|config3|config3_lds|config4|headline> [launches]"""
+    python scripts/gpu_solve_once.py <config5_fp64|config5_fp64_lds|config3|config3_lds|config4|headline|n20_one_wave|n20_two_waves> [launches]"""
 import os
 import sys
 
@@ -24,6 +24,10 @@ elif what == "config3":
     x0, xf, up, dtp, obstacles = m.workloads.unicycle_obstacle_inputs(B, n_obst=16, max_vertices=6, lateral=(0.15, 0.8))
     inp = (x0, xf, up, dtp)
     cfg = m.config_unicycle_quadratic(80, max_obstacles=16, max_vertices=6, max_obstacle_rows=4, max_iter=60, stage_data=mode)
+elif what in ("n20_one_wave", "n20_two_waves"):      # the reference's shipped grid size at saturation, reference path alone: one wave per SIMD against mpc_config.two_wave_min_batch's kernel
+    B = 32768
+    cfg = m.config_carlike_min_time(20, two_wave_min_batch=-1 if what == "n20_one_wave" else 0)
+    inp = m.workloads.carlike_min_time_inputs(B, goal_range=(1.0, 2.4))
 elif what == "config4":
     B = 4096
     cfg = m.config_carlike_min_time(50, candidates=(0, 5, 5, 7), candidate_max_iter=(100, 60, 50, 40), candidate_param=(0.0, 2.0, 3.0, 1.5), stage_data=mode)

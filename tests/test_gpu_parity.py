@@ -66,6 +66,21 @@ def test_gpu_reproduces_the_fixtures_of_the_other_barrier_rule(m, name):
         assert np.abs(a.dt - g["dt"]).max() < 1e-7 * np.abs(g["dt"]).max()
 
 
+def test_config5_shape_vs_slsqp_on_the_device(m):
+    """tests/golden/cold_start_scipy_config5.npz: scipy SLSQP on the reference-form NLP of the config-5 shape (bicycle, n = 120), from the reference's cold start.  The device's
+    reference path ends at SLSQP's point on at least 5 of the 6 instances SLSQP solves (headings modulo 2 pi; tests/test_oracle_solver.py::test_config5_shape_vs_slsqp has the
+    same comparison for the C oracle)."""
+    g = np.load(os.path.join(GOLD, "cold_start_scipy_config5.npz"))
+    K = int(g["count"])
+    s = m.BatchSolver(m.config_bicycle_min_time(120), max_batch=K)
+    r = s.solve(*m.workloads.bicycle_min_time_inputs(K)); s.close()
+    d = r.x - g["x"]
+    d[..., 2] = (d[..., 2] + np.pi) % (2 * np.pi) - np.pi
+    same = (np.abs(d).reshape(K, -1).max(1) < 1e-5) & (r.status == 0) & g["success"].astype(bool)
+    assert same.sum() >= 5 and (r.status == 0).sum() >= 7
+    assert np.abs(119 * r.dt[same] - g["objective"][same]).max() < 1e-5
+
+
 def _feasibility(R, ocfg, x0, xf, up, dtp, res, i):
     inp = R.CycleInputs(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=float(dtp[i]))
     nlp = R.ReferenceNlp(ocfg, inp)

@@ -886,3 +886,34 @@ def test_converged_answers_are_local_minima_and_the_curvature_test_s_were_not(c_
     assert (out[0][2] < -1e-3).sum() >= 2                     # the curvature test's answers: saddle points among them
     assert (out[1][2] > -1e-6).all() and max(out[1][3]) == 0   # the inertia test's: minima (no weakly active row blurs the statement)
     assert out[1][0] >= out[0][0] and out[1][1] < out[0][1]
+
+
+def _same_point_mod_2pi(xa, xb, tol):
+    d = xa - xb
+    d[..., 2] = (d[..., 2] + np.pi) % (2 * np.pi) - np.pi          # SLSQP does not wrap headings: compare them modulo 2 pi
+    return np.abs(d).reshape(d.shape[0], -1).max(1) < tol
+
+
+def test_config5_shape_vs_slsqp(c_oracle):
+    """ The config-5 SHAPE (kinematic bicycle, n = 120, goals 5 .. 40 m) against an independent solver from the same cold start:
+    tests/golden/cold_start_scipy_config5.npz (scipy SLSQP on the reference-form NLP, 8 instances, ~1-10 min each).  SLSQP succeeds on 6 of 8; the C oracle's reference path
+    converges on all 8; on 5 of SLSQP's 6 the two end at the SAME point (headings modulo 2 pi, 1e-5), the sixth is another local minimum of this multi-modal NLP (travel time
+    179.65 s against SLSQP's 165.53 s); where SLSQP gives up, the interior-point answer is feasible with a lower travel time than SLSQP's last iterate."""
+    from mpc_local_planner_amd import workloads as W
+    g = np.load(os.path.join(GOLD, "cold_start_scipy_config5.npz"))
+    K = int(g["count"])
+    x0, xf, up, dtp = W.bicycle_min_time_inputs(K)
+    cfg = R.config_bicycle_min_time(120)
+    xo, uo, do, st, it = c_oracle.solve_batch(c_oracle.from_nlp_config(cfg, max_iter=100), x0, xf, up, dtp)
+    ok = g["success"].astype(bool)
+    assert ok.sum() >= 6 and (st == 0).sum() >= 7
+    same = _same_point_mod_2pi(xo, g["x"], 1e-5) & (st == 0) & ok
+    obj = (cfg.n - 1) * do
+    print(f"[config-5 shape vs SLSQP] SLSQP succeeded on {int(ok.sum())} of {K}; the C oracle converged on {int((st == 0).sum())}; same point (headings mod 2 pi) on {int(same.sum())} of SLSQP's; "
+          f"travel time oracle - SLSQP where both have an answer: {np.round((obj - g['objective'])[ok & (st == 0)], 4).tolist()}")
+    assert same.sum() >= 5
+    assert np.abs(obj[same] - g["objective"][same]).max() < 1e-5
+    both = ok & (st == 0) & ~same
+    assert (g["violation"][ok] < 1e-8).all()
+    for i in np.where(~ok & (st == 0))[0]:          # SLSQP gave up: our answer must at least be feasible and not worse than where SLSQP stopped
+        assert obj[i] < g["objective"][i] + 1e-6
