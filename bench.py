@@ -528,6 +528,25 @@ def main():
         legs["config5_share_bicycle_n120_fp32_B1024"]["parity"] = "plain fp32 does NOT meet the 1e-4 tolerance against the fp64 result (DESIGN.md section 6); reported because BASELINE configs[4] names fp32"
         legs["config5_share_bicycle_n120_fp32_B1024"]["kernel_ms"] = legs["config5_share_bicycle_n120_fp32_B1024"].pop("roofline")["kernel_ms"]
         l5.close()
+        # (r06) an EXTENDED kernel level on a grid whose LDS record fits once per CU: car-like minimum time, n = 80, the shipped car-like file's line footprint, three obstacles beside
+        # the path of which one crosses it (stage_inequality_se2.cpp:164-189).  The factorisation data in the global block (MPC_STAGE_AUTO) against everything in LDS.
+        from mpc_local_planner_amd import _abi as mabi
+        nE, BE = 80, 1024
+        x0e, xfe, upe, dtpe, obe = m.workloads.carlike_moving_obstacle_inputs(BE)
+        ext = {}
+        for tag, mode in (("lds_form", mabi.STAGE_LDS), ("auto", mabi.STAGE_AUTO)):
+            le = Leg(m, torch, dev, m.config_carlike_min_time(nE, footprint_kind=2,      # MPC_FOOTPRINT_LINE
+                                                            footprint_params=(0.0, 0.0, 0.4, 0.0), enable_dynamic_obstacles=True,
+                                                            min_obstacle_dist=0.27, force_inclusion_dist=0.5, cutoff_dist=2.5, max_obstacles=3, max_vertices=1, max_obstacle_rows=4, stage_data=mode),
+                     BE, (x0e, xfe, upe, dtpe), obstacles=obe)
+            el, kms = le.timed(max(2, args.steps // 2), 1)
+            se, oke = le.stats()
+            ext[tag] = {"value": BE * float(oke.mean()) * max(2, args.steps // 2) / el, "unit": "solves/s", "kernel_ms": kms, "converged_frac": float(oke.mean()), "iters_mean": se["iters_mean"],
+                        "workgroups_per_cu": workgroups_per_cu(le.solver, BE), "lds_bytes_per_instance": le.solver.occupancy(BE)[1], "checksum_dt": float(le.do.sum().item())}
+            le.close()
+        ext["same_answers"] = bool(ext["lds_form"]["checksum_dt"] == ext["auto"]["checksum_dt"])
+        ext["what"] = "car-like minimum time, n = 80, line footprint, 3 obstacles of which one moves across the path, 1024 instances, reference path alone (extended kernel level 1)"
+        legs["carlike_n80_line_footprint_moving_obstacle_B1024"] = ext
         # the reference's shipped grid size (grid_size_ref 20 in every example parameter file) at saturation: one wave per SIMD against the two-waves-per-SIMD kernel that
         # mpc_config.two_wave_min_batch selects for launches this large (its 15.6 KB record fits eight times into a CU); the reference path alone, same answers bit for bit
         n20, B20 = 20, 32768

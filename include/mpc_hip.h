@@ -94,7 +94,7 @@ enum mpc_stage_data {                 /* mpc_config.stage_data */
                                        * before 0.5.0 (which kept fp32 in LDS).  Both phases of MPC_MIXED keep the LDS form */
     MPC_STAGE_LDS = 1,                /* the whole working set of an instance in LDS (97 words per grid point) */
     MPC_STAGE_GLOBAL = 2              /* stage records and gains in a per-workgroup block of global memory (L2 / Infinity-Cache resident), 34 words per grid point in LDS;
-                                       * headline kernel level only (mpc_create refuses it for the extended terms) */
+                                       * every kernel level (r06: the extended terms too -- terminal ball, via-points, turning footprints, dynamic obstacles, cost variants) */
 };
 
 enum mpc_mu_strategy {

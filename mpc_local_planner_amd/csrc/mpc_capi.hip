@@ -259,10 +259,9 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
     // with 16 polygons.  The rule, stated once (also in include/mpc_hip.h): fp64 takes the global form when the LDS form leaves at least HALF of a CU's SIMDs empty and the global
     // form fills more of them; plain fp32 already when the LDS form leaves ONE of four empty (n = 120: 7.06 -> 6.43 ms since the block is laid out in tiles) -- in fp32 the two
     // forms agree to rounding, not bit for bit (the compiler contracts / packs the fp32 lane-parallel passes differently around global loads), so an fp32 handle under
-    // MPC_STAGE_AUTO reproduces itself run to run but not the results of builds before 0.5.0; both phases of MPC_MIXED keep the LDS form.  The extended kernel levels exist in
-    // the LDS form only.
+    // MPC_STAGE_AUTO reproduces itself run to run but not the results of builds before 0.5.0; both phases of MPC_MIXED keep the LDS form.  Every kernel level exists in both forms (r06: the extended levels too).
     {
-        const bool can_gs = !solver_ext(s);
+        const bool can_gs = true;      // (r06: every kernel level exists in the global form)
         auto per_cu = [](size_t lds) { const size_t k = (160u * 1024u) / lds; return k > 4 ? (size_t)4 : k; };
         auto choose = [&](size_t tsize, size_t psize) {
             if (!can_gs || cfg->stage_data == MPC_STAGE_LDS) return false;
@@ -274,9 +273,6 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
             return per_cu(a) <= ((tsize == 4 && cfg->precision == MPC_FP32) ? 3u : 2u) && per_cu(g) > per_cu(a);
         };
         if (cfg->stage_data != MPC_STAGE_AUTO && cfg->stage_data != MPC_STAGE_LDS && cfg->stage_data != MPC_STAGE_GLOBAL) { set_err("mpc_create: unknown stage_data"); delete s; return MPC_EINVAL; }
-        if (cfg->stage_data == MPC_STAGE_GLOBAL && !can_gs) {
-            set_err("mpc_create: MPC_STAGE_GLOBAL exists for the headline kernel level only (no terminal ball, via-points, turning footprints, dynamic obstacles, convexified Hessian, cost variants)");
-            delete s; return MPC_EINVAL; }
         s->gs32 = cfg->precision != MPC_FP64 && choose(4, sizeof(mpc::Problem<float>));
         // (the refinement phase of MPC_MIXED -- one candidate, a handful of iterations -- measured faster in the LDS form: 9.0 against 9.4 ms for both phases at n = 120, B = 1024)
         s->gs64 = cfg->precision != MPC_FP32 && (cfg->precision != MPC_MIXED || cfg->stage_data == MPC_STAGE_GLOBAL) && choose(8, sizeof(mpc::Problem<double>));
@@ -306,7 +302,7 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
     s->wave_lds = cfg->precision == MPC_FP32 ? s->wave_lds32 : lds_of(s->gs64 ? s->WLg : s->WL, 8, sizeof(mpc::Problem<double>));
     if (s->wave_lds > 160u * 1024u) {
         set_err("mpc_create: the working set of one instance (n, max_obstacles, max_vertices, precision) does not fit in the 160 KB of LDS "
-                "of a compute unit (about n <= 215 grid points in fp64 without obstacles; n <= 590 with the factorisation data in global memory, which the extended kernel levels do not have)");
+                "of a compute unit (about n <= 215 grid points in fp64 without obstacles; n <= 590 with the factorisation data in global memory)");
         delete s;
         return MPC_EINVAL;
     }

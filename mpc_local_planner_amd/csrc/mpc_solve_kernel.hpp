@@ -236,10 +236,10 @@ auto select_kernel(const SolveLaunch& a, hipError_t& err) -> decltype(&mpc_ipm_w
 #endif
     auto kern = a.level == 0 ? ((a.L.M > 0 || force_obst) ? mpc_ipm_wave_kernel<T, MODEL, 0, true> : mpc_ipm_wave_kernel<T, MODEL, 0, false>)
                              : (a.level == 2 ? mpc_ipm_wave_kernel<T, MODEL, 2, true> : mpc_ipm_wave_kernel<T, MODEL, 1, true>);
-    // factorisation data in global memory (WaveLayout::GSF; mpc_capi.hip decides per handle and precision): the headline level's two instantiations exist in that form
-    if (a.L.GSF) {
-        if (a.level != 0) { err = hipErrorInvalidConfiguration; return nullptr; }
-        kern = (a.L.M > 0 || force_obst) ? mpc_ipm_wave_kernel<T, MODEL, 0, true, 0, true> : mpc_ipm_wave_kernel<T, MODEL, 0, false, 0, true>;
+    // factorisation data in global memory (WaveLayout::GSF; mpc_capi.hip decides per handle and precision)
+    if (a.L.GSF) {      // (r06: the extended levels too -- turning footprints, moving obstacles, cost variants at grid sizes whose LDS record fits fewer than four times)
+        kern = a.level == 0 ? ((a.L.M > 0 || force_obst) ? mpc_ipm_wave_kernel<T, MODEL, 0, true, 0, true> : mpc_ipm_wave_kernel<T, MODEL, 0, false, 0, true>)
+                            : (a.level == 2 ? mpc_ipm_wave_kernel<T, MODEL, 2, true, 0, true> : mpc_ipm_wave_kernel<T, MODEL, 1, true, 0, true>);
     }
     // fp64 headline kernel on a grid of kFixedLayoutNS points per record (the grid size of BASELINE configs[1] / [3]): the instantiation whose LDS layout is a
     // compile-time constant (mpc_wave.hpp::FixedLayout) -- same code, same results bit for bit, ~3 % fewer instructions; every other size runs the generic one

@@ -85,3 +85,18 @@ def unicycle_obstacle_inputs(batch: int, seed: int = SEED_CONFIG3, n_obst: int =
             verts[b, o, :k, 1] = c[1] + rad * np.sin(ang)
     no = np.full(batch, n_obst, dtype=np.int32)
     return x0, xf, np.zeros((batch, 2)), np.full(batch, 0.2), (no, nv, verts)
+
+
+def carlike_moving_obstacle_inputs(batch: int, seed: int = 951, goal_range=(3.0, 8.0), n_obst: int = 3):
+    """car-like minimum time with clearance rows of a footprint that turns with the pose: `n_obst` point obstacles 0.6 .. 1.1 m beside the start-goal line, the first of them a
+    circle of radius 0.15 m that crosses the path at 0.12 m/s (stage_inequality_se2.cpp:177-189: the row at grid point k is evaluated against the obstacle moved by k dt v).
+    Returns x0, xf, u_prev, dt_prev, (n_obstacles, n_vertices, vertices, radius, velocity)."""
+    x0, xf, up, dtp = carlike_min_time_inputs(batch, seed=seed, goal_range=goal_range)
+    rng = np.random.default_rng(seed + 1)
+    d = xf[:, None, :2] - x0[:, None, :2]
+    nrm = np.stack([-d[..., 1], d[..., 0]], -1) / np.linalg.norm(d, axis=-1, keepdims=True)
+    pts = x0[:, None, :2] + rng.uniform(0.2, 0.8, (batch, n_obst, 1)) * d + rng.uniform(0.6, 1.1, (batch, n_obst, 1)) * rng.choice([-1.0, 1.0], (batch, n_obst, 1)) * nrm
+    vt = pts.reshape(batch, n_obst, 1, 2)
+    rad = np.zeros((batch, n_obst)); vel = np.zeros((batch, n_obst, 2))
+    vt[:, 0, 0] = x0[:, :2] + 0.5 * d[:, 0] + 1.2 * nrm[:, 0]; rad[:, 0] = 0.15; vel[:, 0] = -0.12 * nrm[:, 0]
+    return x0, xf, up, dtp, (np.full(batch, n_obst, np.int32), np.ones((batch, n_obst), np.int32), vt, rad, vel)

@@ -467,3 +467,62 @@ def test_solver_from_a_parameter_file_of_the_reference(m, tmp_path):
     dth = np.arctan2(np.sin(r.x[ok, last, 2] - xf[ok, 2]), np.cos(r.x[ok, last, 2] - xf[ok, 2]))
     assert (0.5 * dth ** 2 <= 0.2 + 1e-6).all()
     s.close()
+
+
+@pytest.mark.parametrize("case", ["line_footprint_moving_obstacle_n80", "polygon_footprint_n64", "full_weight_matrices_n70", "terminal_ball_n70", "via_points_n60"])
+def test_extended_levels_in_the_global_form_equal_the_lds_form_bit_for_bit(m, case):
+    """(r06) mpc_config.stage_data for the EXTENDED kernel levels: turning footprints, moving obstacles, terminal ball, via-points and the cost variants exist
+    in the global form of the factorisation data too (stage_inequality_se2.cpp:164-189 with a line / polygon footprint at n >= 60 used to run two workgroups per CU).  Same
+    arithmetic on the same numbers: trajectories, controls, dt, statuses and iteration counts bit for bit, and MPC_STAGE_AUTO takes the global form where it puts more workgroups
+    on a CU."""
+    from mpc_local_planner_amd import _abi as A
+    obstacles, via = None, None
+    if case == "line_footprint_moving_obstacle_n80":
+        B, n = 128, 80
+        kind, params, dmin = FOOTPRINTS["line"]
+        x0, xf, up, dtp, obstacles = m.workloads.carlike_moving_obstacle_inputs(B)          # (the workload of bench.py's leg carlike_n80_line_footprint_moving_obstacle)
+        mk = lambda **k: m.config_carlike_min_time(n, footprint_kind=kind, footprint_params=params, enable_dynamic_obstacles=True, min_obstacle_dist=dmin, force_inclusion_dist=0.5,
+                                                   cutoff_dist=2.5, max_obstacles=3, max_vertices=1, max_obstacle_rows=4, **k)
+    elif case == "polygon_footprint_n64":
+        B, n = 128, 64
+        kind, params, dmin = FOOTPRINTS["polygon"]
+        x0, xf, up, dtp = m.workloads.carlike_min_time_inputs(B, seed=953, goal_range=(2.0, 6.0))
+        obstacles = point_obstacles(x0, xf, 954)
+        mk = lambda **k: m.config_carlike_min_time(n, footprint_kind=kind, footprint_vertices=params, min_obstacle_dist=dmin, force_inclusion_dist=0.5, cutoff_dist=2.5, max_obstacles=4,
+                                                   max_vertices=1, max_obstacle_rows=4, **k)
+    elif case == "full_weight_matrices_n70":      # the "full_weights" variant of test_cost_variants_vs_c_oracle (level 2: serial sweeps only), on a grid of 70 points
+        B, n = 128, 70
+        x0, xf, up, dtp = m.workloads.unicycle_quadratic_inputs(B, seed=11)
+        mk = lambda **k: m.config_unicycle_quadratic(n, **DEVICE_COST_VARIANTS["full_weights"], **k)
+    elif case == "terminal_ball_n70":             # the workload of test_terminal_ball_batch_vs_c_oracle on 70 points (level 1)
+        B, n = 128, 70
+        x0, xf, up, dtp = m.workloads.unicycle_quadratic_inputs(B, seed=904, goal_range=(0.8, 1.3))
+        mk = lambda **k: m.config_unicycle_quadratic(n, Q=(0.2, 0.2, 0.02), R=(1.0, 0.5), Qf=None, terminal_ball_S=(1.0, 1.0, 0.01), terminal_ball_gamma=0.02, **k)
+    else:
+        B, n = 128, 60
+        x0, xf, up, dtp = m.workloads.carlike_min_time_inputs(B, seed=957, goal_range=(2.0, 6.0))
+        rng = np.random.default_rng(958)
+        VP = 3
+        t = np.sort(rng.uniform(0.2, 0.8, (B, VP)), axis=1)
+        vp = np.zeros((B, VP, 3))
+        vp[..., :2] = x0[:, None, :2] + t[..., None] * (xf[:, None, :2] - x0[:, None, :2]) + rng.normal(0, 0.15, (B, VP, 2))
+        via = (np.full(B, VP, np.int32), vp)
+        mk = lambda **k: m.config_carlike_min_time(n, objective=m.OBJ_MIN_TIME_VIA_POINTS, vp_position_weight=0.5, max_via_points=VP, **k)
+    res, lds = {}, {}
+    for mode in (A.STAGE_LDS, A.STAGE_GLOBAL, A.STAGE_AUTO):
+        s = m.BatchSolver(mk(stage_data=mode), max_batch=B)
+        if via is not None:
+            s.set_via_points(*via)
+        res[mode] = s.solve(x0, xf, up, dtp, obstacles=obstacles)
+        lds[mode] = s.lds_bytes()
+        s.close()
+    a, g, auto = res[A.STAGE_LDS], res[A.STAGE_GLOBAL], res[A.STAGE_AUTO]
+    assert (a.status == 0).mean() > 0.5, (a.status == 0).mean()
+    for f in ("status", "iters", "dt", "x", "u"):
+        assert np.array_equal(getattr(a, f), getattr(g, f), equal_nan=True), (case, f)
+        assert np.array_equal(getattr(a, f), getattr(auto, f), equal_nan=True), (case, f)
+    per_cu = lambda b: min(4, (160 * 1024) // b)
+    assert lds[A.STAGE_GLOBAL] < lds[A.STAGE_LDS]
+    print(f"[extended levels, {case}] LDS form {lds[A.STAGE_LDS]} B = {per_cu(lds[A.STAGE_LDS])} per CU, global form {lds[A.STAGE_GLOBAL]} B = {per_cu(lds[A.STAGE_GLOBAL])} per CU, AUTO takes {lds[A.STAGE_AUTO]} B; converged {(a.status == 0).mean():.3f}")
+    if per_cu(lds[A.STAGE_LDS]) <= 2 and per_cu(lds[A.STAGE_GLOBAL]) > per_cu(lds[A.STAGE_LDS]):
+        assert lds[A.STAGE_AUTO] == lds[A.STAGE_GLOBAL]
