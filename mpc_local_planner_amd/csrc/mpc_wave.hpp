@@ -110,6 +110,15 @@ struct IpmWave {
     __device__ __forceinline__ SwT& OB_(int which, int m, int k) const {
         if constexpr (GS) return gw((unsigned)(GlobalStage::OBC(L.NS, NSTG) + (which * L.M + m) * L.NS + k)); else return sm[(which == 0 ? L.OG : (which == 1 ? L.OAX : (which == 2 ? L.OAY : L.OHK))) + m * L.NS + k];
     }
+    // third-variable caches of clearance row m at grid point k -- which: 0 OAT (gradient part), 1 OHXT 2 OHYT 3 OHTT (curvature parts) of the heading (footprints that turn with the
+    // pose) or of dt (dynamic obstacles); 4 OAD 5 OHXD 6 OHYD 7 OHDD 8 OHTD the dt parts when both apply.  LDS arrays, or (GS, r06) regions of the workgroup's global block
+    __device__ __forceinline__ SwT& OX_(int which, int m, int k) const {
+        if constexpr (GS) return gw((unsigned)(L.OXB + ((which < 4 ? which * L.MT : 4 * L.MT + (which - 4) * L.MD) + m) * L.NS + k));
+        else {
+            const int base = which == 0 ? L.OAT : (which == 1 ? L.OHXT : (which == 2 ? L.OHYT : (which == 3 ? L.OHTT : (which == 4 ? L.OAD : (which == 5 ? L.OHXD : (which == 6 ? L.OHYD : (which == 7 ? L.OHDD : L.OHTD)))))));
+            return sm[base + m * L.NS + k];
+        }
+    }
     // elastic variable e (0) and its step de (1) of clearance row m at grid point k (restoration mode): always in the workgroup's global block
     __device__ __forceinline__ GlbT& OE_(int which, int m, int k) const { return gw((unsigned)(L.OEB + (which * L.M + m) * L.NS + k)); }
     // c^_k = c_k + f_k dd, what the forward sweeps read (component-major): parked in LAMN in both forms

@@ -78,6 +78,9 @@ struct WaveLayout {
     int GSW;                                      // > 0: the workgroup has a block of GSW words of GLOBAL memory (GlobalStage): the elastic arrays of the clearance rows, and with GSF the factorisation data
     int GSF;                                      // 1: the factorisation data (GAIN, STG) and the clearance rows' caches live in that block instead of LDS (IpmWave<..., GS = true>)
     int OEB;                                      // word offset of the elastic arrays [OE | ODE] inside the block
+    int MT, MD;                                   // rows per grid point that carry a third-variable part (heading or dt) / a second one (dt next to the heading)
+    int OXB;                                      // GSF: word offset of the rows' third-variable caches [OAT | OHXT | OHYT | OHTT][MT][NS] + [OAD | OHXD | OHYD | OHDD | OHTD][MD][NS] inside the block
+                                                  // (r06: written by kkt_pass, read by lane-parallel passes only -- like OG / OAX / OAY / OHK, they leave LDS in the global form)
     // tsize = sizeof(T) of the kernel that uses the layout (the obstacle indices of the clearance rows are 16-bit words, M * n of them, packed into T-sized words)
     __host__ __device__ static constexpr WaveLayout make(int n, int M = 0, int O = 0, int V = 1, int ntrig = 4, int NV = 0, int MT = 0, int OD = 0, int nstg = NSTG_BASE, int MD = 0, int tsize = 8, bool gs = false) {
         WaveLayout L{};
@@ -93,9 +96,11 @@ struct WaveLayout {
         L.DX = take(3); L.DU = take(2);
         L.CC = take(3); L.TRIG = take(ntrig);
         L.GAIN = take(gs ? 0 : NGAIN); L.STG = take(gs ? 0 : nstg);
-        L.GSW = gs ? GlobalStage::words(n, nstg, M) : (M > 0 ? GlobalStage::words_elastic_only(n, M) : 0);
+        L.GSW = gs ? GlobalStage::words(n, nstg, M) + (((4 * MT + 5 * MD) * n + 15) / 16) * 16 : (M > 0 ? GlobalStage::words_elastic_only(n, M) : 0);
         L.GSF = gs ? 1 : 0;
         L.OEB = gs ? GlobalStage::OEL(n, nstg, M) : GlobalStage::OEL_ONLY;
+        L.MT = MT; L.MD = MD;
+        L.OXB = gs ? GlobalStage::words(n, nstg, M) : 0;
         L.SC = o; o += 16;    // scalars: D, DT, DD, PDL, PDU | terminal-ball row: slack, multiplier, cached value and gradient
         L.VP = o; o += 16;    // dummy store targets of the idle lanes in the sweeps
         L.ZC = o; o += 8;     // constants 0 0 0 0 1 0 0 0 (coefficient triples of the constant columns)
@@ -107,8 +112,8 @@ struct WaveLayout {
         L.GV = o; o += 2 * O * V; L.GNV = o; o += O; L.GR = o; o += O; L.GC = o; o += 2 * O;
         L.GE = o; o += V >= 2 ? 3 * O * V : 0;
         L.NV = NV; L.VIA = o; o += 3 * NV; L.VIDX = o; o += NV;
-        L.OAT = take(MT); L.OHXT = take(MT); L.OHYT = take(MT); L.OHTT = take(MT);
-        L.OAD = take(MD); L.OHXD = take(MD); L.OHYD = take(MD); L.OHDD = take(MD); L.OHTD = take(MD);
+        L.OAT = take(gs ? 0 : MT); L.OHXT = take(gs ? 0 : MT); L.OHYT = take(gs ? 0 : MT); L.OHTT = take(gs ? 0 : MT);
+        L.OAD = take(gs ? 0 : MD); L.OHXD = take(gs ? 0 : MD); L.OHYD = take(gs ? 0 : MD); L.OHDD = take(gs ? 0 : MD); L.OHTD = take(gs ? 0 : MD);
         L.GVEL = o; o += 2 * OD;
         L.total = o;
         return L;
@@ -127,7 +132,7 @@ struct FixedLayout {
     static constexpr int NS = NSC, NTR = NTRIG;
     static constexpr int X = c().X, U = c().U, LAM = c().LAM, LAMN = c().LAMN, SR = c().SR, YR = c().YR, PL = c().PL, PU = c().PU, DX = c().DX, DU = c().DU, CC = c().CC,
                          TRIG = c().TRIG, GAIN = c().GAIN, STG = c().STG, SC = c().SC, VP = c().VP, ZC = c().ZC, ZI = c().ZI, total = c().total;
-    static constexpr int M = 0, O = 0, V = 1, NV = 0, GSW = 0, GSF = 0, OEB = 0;
+    static constexpr int M = 0, O = 0, V = 1, NV = 0, GSW = 0, GSF = 0, OEB = 0, MT = 0, MD = 0, OXB = 0;
     static constexpr int OS = c().OS, OY = c().OY, OI = c().OI, OG = c().OG, OAX = c().OAX, OAY = c().OAY, OHK = c().OHK, GV = c().GV, GNV = c().GNV, GR = c().GR, GC = c().GC, GE = c().GE,
                          OAT = c().OAT, OHXT = c().OHXT, OHYT = c().OHYT, OHTT = c().OHTT, OAD = c().OAD, OHXD = c().OHXD, OHYD = c().OHYD, OHDD = c().OHDD, OHTD = c().OHTD,
                          GVEL = c().GVEL, VIA = c().VIA, VIDX = c().VIDX;
