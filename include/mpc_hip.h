@@ -205,12 +205,11 @@ typedef struct mpc_config {
                                        * memory exactly when that puts more workgroups on a compute unit -- long horizons, clearance rows), MPC_STAGE_LDS, MPC_STAGE_GLOBAL.
                                        * Results are bit-identical either way in fp64 (in fp32 the two forms agree to rounding); no counterpart in the reference (its solver's
                                        * working memory is Ipopt's) */
-    int32_t two_wave_min_batch;       /* launches with at least this many instances run the kernel variant for TWO resident waves per SIMD (<= 256 registers; fp64, headline kernel
-                                       * level without clearance rows, and only where the LDS record fits eight times into a compute unit: about n <= 24 grid points -- the grid
-                                       * sizes of the reference's shipped parameter files).  0 -> the default 8192 (measured on the MI355X: the second wave pays from about 4096
-                                       * instances on -- x1.16-1.20 at 8192, x1.46 at 32768 for a single candidate, x1.10-1.14 / x1.28-1.32 with hedged candidates; a small launch
-                                       * lasts as long as its slowest wave, which runs fastest alone: x0.8 at 1024); negative -> never.  Results are bit-identical either way.
-                                       * No counterpart in the reference */
+    int32_t two_wave_min_batch;       /* launches with at least this many instances run the kernel variant for TWO resident waves per SIMD (236 registers, no scratch; fp64, headline
+                                       * kernel level without clearance rows, and only where the LDS record fits eight times into a compute unit: about n <= 24 grid points -- the
+                                       * grid sizes of the reference's shipped parameter files).  0 -> the default 8192 (measured on the MI355X: x1.14-1.27 there, x1.4-1.6 at 32768
+                                       * instances; at 4096 x1.10-1.15 for n = 20 / 24 but x0.73 for n = 12; a small launch lasts as long as its slowest wave, which runs fastest
+                                       * alone: x0.85 at 1024); negative -> never.  Results are bit-identical either way.  No counterpart in the reference */
     int32_t reserved[1];
     /* full weight matrices (state_weights / control_weights / final_state_weights / weight_matrix given as n x n lists, column major,
      * src/controller.cpp:565-573,580-588,656-664,690-698): Q, R, Qf, terminal_ball_S above hold the DIAGONALS, these the off-diagonal terms

@@ -556,8 +556,9 @@ def test_global_form_equals_lds_form_over_the_grid_sizes(m):
 
 
 def test_two_waves_per_simd_kernel_equals_the_one_wave_kernels_bit_for_bit(m):
-    """mpc_config.two_wave_min_batch: launches of at least that many instances take the kernel variant for two resident waves per SIMD (<= 256 registers, every phase of an
-    iteration on a lane index of its own, generic line-search trials; exists where the LDS record fits eight times into a CU: n <= 24 in fp64).  Same arithmetic on the same
+    """mpc_config.two_wave_min_batch: launches of at least that many instances take the kernel variant for two resident waves per SIMD (236 registers, no scratch: every phase of an
+    iteration on a lane index of its own, the solve loop's uniform scalars in scalar registers, generic line-search trials, no partitioned sweeps; exists where the LDS record fits
+    eight times into a CU: n <= 24 in fp64).  Same arithmetic on the same
     numbers: trajectories, controls, dt, statuses and iteration counts bit for bit those of the one-wave kernels -- every model, with candidates, on a ragged batch; and a
     grid whose record does not fit eight times ignores the setting."""
     B = 192
