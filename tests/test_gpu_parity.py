@@ -579,6 +579,18 @@ def test_two_waves_per_simd_kernel_equals_the_one_wave_kernels_bit_for_bit(m):
     both(lambda **k: m.config_bicycle_min_time(24, **k), m.workloads.bicycle_min_time_inputs(B, goal_range=(1.0, 5.0)))
     both(lambda **k: m.config_carlike_min_time(24, **k), m.workloads.carlike_min_time_inputs(B, seed=9, goal_range=(0.5, 2.5)), n_grid=(8 + np.arange(B) % 17).astype(np.int32))
     both(lambda **k: m.config_carlike_min_time(50, **k), m.workloads.carlike_min_time_inputs(B, seed=50))      # 40 KB record: one wave per SIMD whatever the setting
+    # a warm-started second cycle from kept multipliers (dual_warm_start: the kernel's other entry into the solve loop) and a per-solve time budget
+    inp = m.workloads.carlike_min_time_inputs(B, seed=77, goal_range=(0.5, 2.5))
+    out = []
+    for w2 in (-1, 1):
+        s = m.BatchSolver(m.config_carlike_min_time(20, two_wave_min_batch=w2, mu_init_warm=1e-2, dual_warm_start=True, mu_init_dual=1e-3), max_batch=B)
+        r1 = s.solve(*inp)
+        x1 = inp[0].copy(); x1[:, :2] += 0.02
+        r2 = s.solve(x1, inp[1], r1.u[:, 0].copy(), inp[3], init=(r1.x.copy(), r1.u.copy(), r1.dt.copy()))
+        out.append((r1, r2)); s.close()
+    for f in ("x", "u", "dt", "status", "iters"):
+        assert np.array_equal(getattr(out[0][0], f), getattr(out[1][0], f), equal_nan=True) and np.array_equal(getattr(out[0][1], f), getattr(out[1][1], f), equal_nan=True), f
+    assert (out[0][1].status == 0).mean() > 0.7 and out[0][1].iters.mean() < out[0][0].iters.mean()
 
 
 @pytest.mark.parametrize("case", ["bicycle_n120_fp64_candidates", "bicycle_n120_mixed", "unicycle_n80_polygons", "carlike_n50_candidates", "carlike_n30_ragged_fp32"])
