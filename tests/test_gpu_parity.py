@@ -593,6 +593,25 @@ def test_two_waves_per_simd_kernel_equals_the_one_wave_kernels_bit_for_bit(m):
     assert (out[0][1].status == 0).mean() > 0.7 and out[0][1].iters.mean() < out[0][0].iters.mean()
 
 
+def test_occupancy_reported_by_the_runtime(m):
+    """mpc_occupancy: resident one-wave workgroups per CU of the kernel instantiation a launch of B instances selects, from hipOccupancyMaxActiveBlocksPerMultiprocessor (registers,
+    LDS) -- what bench.py reports as workgroups_per_cu / waves_per_simd and what sizes the per-XCD block pools"""
+    s = m.BatchSolver(m.config_carlike_min_time(50), max_batch=64)
+    assert s.occupancy(64) == (4, s.lds_bytes()) and s.lds_bytes() == 40128          # BASELINE configs[1]: one wave per SIMD, 40 KB record
+    s.close()
+    s = m.BatchSolver(m.config_carlike_min_time(20), max_batch=8192)
+    w_small, lds_small = s.occupancy(1024)
+    w_large, lds_large = s.occupancy(8192)
+    assert (w_small, w_large) == (4, 8) and lds_small == lds_large == s.lds_bytes()   # the two-waves-per-SIMD kernel from the default threshold on
+    s.close()
+    s = m.BatchSolver(m.config_carlike_min_time(20, two_wave_min_batch=-1), max_batch=8192)
+    assert s.occupancy(8192)[0] == 4
+    s.close()
+    s = m.BatchSolver(m.config_bicycle_min_time(120), max_batch=64)
+    assert s.occupancy(64)[0] == 4 and s.lds_bytes() < 40960                          # BASELINE configs[4] shape in fp64: the global form, four per CU
+    s.close()
+
+
 @pytest.mark.parametrize("case", ["bicycle_n120_fp64_candidates", "bicycle_n120_mixed", "unicycle_n80_polygons", "carlike_n50_candidates", "carlike_n30_ragged_fp32"])
 def test_factorisation_data_in_global_memory_equals_lds_bit_for_bit(m, case):
     """mpc_config.stage_data: the stage records and Riccati gains of a solve (63 of the 97 words per grid point) live in LDS or in a per-workgroup block of
