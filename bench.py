@@ -581,6 +581,19 @@ def main():
                                                 "converged_frac": 0.5 * (sa["converged_frac"] + sb_["converged_frac"]),
                                                 "what": "two handles, two streams, one 1024-instance batch each, both launched before either is waited for; same candidates / caps as the headline"}
         la.close(); lb.close()
+        # the same 1024-instance batch through the HOST-pointer entry of the boundary (mpc_solve_batch: one pinned staging copy each way + one H2D + one D2H per call): the
+        # PCIe-inclusive rate, reported next to `value` (which is measured with the inputs resident in HBM) and never in its place
+        sh = m.BatchSolver(cfg, max_batch=B, device=local_rank)
+        hin = m.workloads.carlike_min_time_inputs(B, seed=sharding.rank_seed(m.workloads.SEED_CONFIG2, rank))
+        rh = sh.solve(*hin)
+        th = time.perf_counter()
+        kh = max(2, args.steps // 2)
+        for _ in range(kh):
+            rh = sh.solve(*hin)
+        th = time.perf_counter() - th
+        sh.close()
+        legs["host_pointer_entry_B1024"] = {"value": B * float(np.mean(rh.status == 0)) * kh / th, "unit": "solves/s", "ms_per_step": th / kh * 1e3,
+                                            "what": "mpc_solve_batch with host buffers in and out (inputs 72 B, outputs ~2 KB per instance; staging + H2D + kernel + D2H, synchronous)"}
         # B = 1: what ONE move_base instance pays per control cycle -- Controller::step through the host-pointer entry (PCIe and launch included),
         # 256 different config-2 instances solved one at a time, cold start with the headline's candidates (all of them run concurrently here)
         s1 = m.BatchSolver(cfg, max_batch=1, device=local_rank)
