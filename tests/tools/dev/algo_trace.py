@@ -1,6 +1,6 @@
 import sys, os, ctypes as C
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))      # tests/tools: algo_stats.py
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import numpy as np
 from oracle import c_oracle as CO, se2_nlp as R
 from mpc_local_planner_amd import workloads as W

@@ -1,6 +1,6 @@
 import sys, os, numpy as np, ctypes as C
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", ".."))
 from oracle import se2_nlp as R, c_oracle as CO, kkt_check as KC
 import mpc_local_planner_amd.workloads as W
 from test_gpu_ext_rows import point_obstacles, FOOTPRINTS

@@ -2,8 +2,8 @@
 (oracle/kkt_check.py is the checker only) and of the same candidates solved as (capped reference, that candidate) pairs"""
 import os, sys
 import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import torch
 torch.zeros(1, device="cuda")
 import mpc_local_planner_amd as m

@@ -1,8 +1,8 @@
 """C oracle, reference path alone, on the clearance-row workloads -- with the experiment switches of oracle_set_algo (elastic=<rho> etrig=<k>)
 usage: python tests/tools/dev/elastic_stats.py [elastic=1000] [etrig=3] [B=128]"""
 import sys, os, time, ctypes as C
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import numpy as np
 from oracle import c_oracle as CO, se2_nlp as R
 from mpc_local_planner_amd import workloads as W

@@ -2,7 +2,7 @@
 The oracle's results are computed on the CPU beforehand (`python tests/tools/dev/footprint_mismatch.py cpu`) and kept next to this file."""
 import os, sys
 import numpy as np
-R_ = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+R_ = os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, R_); sys.path.insert(0, os.path.join(R_, "tests"))
 import mpc_local_planner_amd as m
 F = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_footprint_mismatch_oracle.npz")

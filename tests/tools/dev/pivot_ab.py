@@ -1,7 +1,7 @@
 """developer script: statuses / iteration counts of the one-candidate config-2 batch against the C solver's (computed on the CPU beforehand: python tests/tools/dev/pivot_ab.py cpu)"""
 import os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 import mpc_local_planner_amd as m
 F = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_pivot_ab_oracle.npz")
 B = 1024

@@ -1,5 +1,5 @@
 import sys, os, numpy as np, ctypes as C
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", ".."))
 import torch
 import mpc_local_planner_amd as m
 from mpc_local_planner_amd import _abi as A
