@@ -25,7 +25,7 @@ class OracleConfig(C.Structure):
         ("hessian_mode", C.c_int32),
         ("hybrid", C.c_int32), ("trapezoid", C.c_int32),
         ("Qo", C.c_double * 3), ("Ro", C.c_double), ("Qfo", C.c_double * 3), ("So", C.c_double * 3),
-        ("acceptable_tol", C.c_double), ("acceptable_iter", C.c_int32), ("mu_strategy", C.c_int32),
+        ("acceptable_tol", C.c_double), ("acceptable_iter", C.c_int32), ("mu_strategy", C.c_int32), ("line_search", C.c_int32),
     ]
 
 
@@ -50,7 +50,10 @@ def _load():
     return _lib
 
 
-def from_nlp_config(cfg, max_iter=100, tol=1e-8, mu_init=0.1, hessian_mode=0, acceptable_tol=0.0, acceptable_iter=0, mu_strategy=0) -> OracleConfig:
+LINE_SEARCH_DEFAULT = 1      # 0 filter, 1 l1 merit (mpc_config.line_search)
+
+
+def from_nlp_config(cfg, max_iter=100, tol=1e-8, mu_init=0.1, hessian_mode=0, acceptable_tol=0.0, acceptable_iter=0, mu_strategy=0, line_search=None) -> OracleConfig:
     """oracle.se2_nlp.OcpConfig -> OracleConfig.  acceptable_tol / acceptable_iter: Ipopt's acceptable-level stop (0 = its defaults 1e-6 / 15,
     negative = off), the same fields as mpc_config's."""
     o = OracleConfig()
@@ -81,6 +84,7 @@ def from_nlp_config(cfg, max_iter=100, tol=1e-8, mu_init=0.1, hessian_mode=0, ac
     o.hessian_mode = int(hessian_mode)
     o.acceptable_tol, o.acceptable_iter = float(acceptable_tol), int(acceptable_iter)
     o.mu_strategy = int(mu_strategy)      # 0 adaptive (default), 1 monotone
+    o.line_search = int(LINE_SEARCH_DEFAULT if line_search is None else line_search)      # 0 filter, 1 l1 merit
     o.collocation = int(getattr(cfg, "collocation", 0))
     o.integral = int(bool(getattr(cfg, "integral_form", False)) and cfg.objective == 1)
     if getattr(cfg, "terminal_ball_S", None) is not None:

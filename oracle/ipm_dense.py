@@ -791,6 +791,7 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
     fail0 = False
     theta0 = None
     filt = []
+    mu_filter = -1.0
     nrest = 0
     history = []
     status = 1
@@ -845,6 +846,7 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
             el[cl] = np.maximum(gcl + s[cl], mu / erho)
             y[cl] = np.maximum(np.minimum(y[cl], 0.5 * erho), mu / s[cl])
             rho = 0.0
+            filt.clear()          # the objective changed: the filter's pairs are of another barrier function
             jam_streak = 0
             ev = nlp.eval(v, lam, y, want_hess=True)
         e0 = kkt_err(ev, v, s, lam, y, piL, piU, 0.0)
@@ -1036,40 +1038,70 @@ def solve(cfg: R.OcpConfig, inp: R.CycleInputs, init: R.Trajectory, relevant=Non
                     accepted = True
                     break
         else:
-            # Ipopt filter line search (Waechter & Biegler 2006, Alg. A, steps A-5.*), no SOC / restoration
-            g_th, g_ph, s_ph, s_th, eta_ph, dlt = 1e-5, 1e-5, 2.3, 1.1, 1e-8, 1.0
+            # Ipopt's filter line search (Waechter & Biegler 2006, Algorithm A, steps A-5.1 .. A-5.10) with Ipopt's default constants; no second-order correction, no
+            # restoration phase: when every trial step is refused the filter is emptied and the shortest trial step taken.  Identical, statement by statement, in
+            # oracle/mpc_oracle.c (solve_one), the kernel (mpc_wave_solve.inc) and tests/host_harness/ipm_serial.hpp.  The filter holds the (theta, phi) of the iterates
+            # whose step was accepted by the sufficient-decrease rule (not by the switching / Armijo rule); its margins are applied when a trial is checked.
+            g_th, g_ph, s_ph, s_th, eta_ph, dlt, g_al = 1e-5, 1e-8, 2.3, 1.1, 1e-8, 1.0, 0.05
+            if mu != mu_filter:
+                filt.clear()
+                mu_filter = mu
+            p_ph = (-dphi) ** s_ph if dphi < 0 else 0.0
+            p_th = theta ** s_th
+            a_min = g_th
+            if dphi < 0:
+                a_min = min(a_min, g_ph * theta / (-dphi))
+                if theta <= theta_min:
+                    a_min = min(a_min, dlt * p_th / p_ph)
+            a_min *= g_al
+            sw_arm = False
+            evaluated = False
             for ls in range(opt.max_ls):
+                if ls > 0:
+                    alpha *= 0.5
+                if ls > 0 and alpha < a_min * a_p:
+                    evaluated = False
+                    break
                 vt = nlp.retract(v, alpha * dz)
                 st = s + alpha * ds
+                et = el + alpha * de
                 evt = nlp.eval(vt)
-                tht = np.abs(evt["c"]).sum() + np.abs(evt["g"] + st).sum()
-                phit = barrier_obj(evt["f"], vt, st, mu)
+                evaluated = True
+                tht = np.abs(evt["c"]).sum() + np.abs(evt["g"] + st - et).sum()
+                phit = barrier_obj(evt["f"], vt, st, mu, et)
                 ok_t = np.isfinite(phit) and tht <= theta_max
                 if ok_t:
                     for (fth, fph) in filt:
-                        if not (tht < fth or phit < fph):
+                        if not (tht <= (1 - g_th) * fth or phit <= fph - g_ph * fth):
                             ok_t = False
                             break
-                switching = dphi < 0 and alpha * (-dphi) ** s_ph > dlt * theta ** s_th
-                armijo = phit <= phi_cur + eta_ph * alpha * dphi
+                switching = dphi < 0 and alpha * p_ph > dlt * p_th
+                armijo = phit - phi_cur - 10 * 2.220446049250313e-16 * abs(phi_cur) <= eta_ph * alpha * dphi
                 if ok_t:
                     if theta <= theta_min and switching:
                         if armijo:
                             accepted = True
-                    else:
-                        if tht <= (1 - g_th) * theta or phit <= phi_cur - g_ph * theta:
-                            accepted = True
+                            sw_arm = True
+                    elif tht <= (1 - g_th) * theta or phit <= phi_cur - g_ph * theta:
+                        accepted = True
                 if accepted:
-                    if not (switching and armijo):
-                        filt.append(((1 - g_th) * theta, phi_cur - g_ph * theta))
-                        if len(filt) > opt.filter_cap:
-                            filt.pop(0)
                     break
-                alpha *= 0.5
+            if accepted and not sw_arm:
+                if len(filt) == opt.filter_cap:
+                    filt.pop(0)
+                filt.append((theta, phi_cur))
             if not accepted:
-                # no restoration phase: clear the filter and take the shortest trial step
+                # no restoration phase: empty the filter and take the last (shortest) trial step
                 filt.clear()
                 nrest += 1
+                if not evaluated:
+                    vt = nlp.retract(v, alpha * dz)
+                    st = s + alpha * ds
+                    et = el + alpha * de
+                    evt = nlp.eval(vt)
+                    phit = barrier_obj(evt["f"], vt, st, mu, et)
+                if np.isfinite(phit):
+                    accepted = True
         if opt.acceptable_tol > 0 and (not accepted or alpha < 1e-6 * a_p) and e0 <= opt.acceptable_tol:
             # nothing is moved (neither the point nor the multipliers): the next iteration would compute the same step and refuse it again.
             # Tested before the line-search failure: Ipopt answers a failed line search at an acceptable point with success.

@@ -84,6 +84,8 @@ typedef struct oracle_config {
                                  * as mpc_config.acceptable_tol (include/mpc_hip.h) */
     int32_t acceptable_iter;    /* iterations in a row at that level that end the solve with status 0: 0 -> Ipopt's default 15, < 0 -> off */
     int32_t mu_strategy;        /* 0 adaptive (the default; see solve_one), 1 monotone Fiacco-McCormick -- mpc_config.mu_strategy */
+    int32_t line_search;        /* 0 Ipopt's filter line search (Waechter & Biegler 2006, Algorithm A; no second-order correction, no restoration phase: when every trial step is
+                                 * refused the filter is emptied and the shortest trial step taken), 1 l1-merit backtracking (the globalisation of rounds 1-5) -- mpc_config.line_search */
 } oracle_config;
 static inline double acc_tol_of(const oracle_config* c) { return c->acceptable_tol > 0 ? c->acceptable_tol : (c->acceptable_tol < 0 ? 0.0 : 1e-6); }
 static inline int acc_iter_of(const oracle_config* c) { return c->acceptable_iter > 0 ? c->acceptable_iter : (c->acceptable_iter < 0 ? 0 : 15); }
@@ -1175,10 +1177,14 @@ typedef struct {
     double elastic_prog;     /* ... and the streak only triggers when the infeasibility is still above this share of its value at the streak's start */
     int elastic_trigger;     /* with elastic_rho > 0: 0 = from the start, k > 0 = entered after k iterations in a row whose fraction-to-boundary step is below 1e-2 while a row is violated */
 } algo_t;
-static algo_t g_algo = {0, 0, 0, 0, 100.0, 0.8, 0, 1, 1000.0, 5e-2, 0.8, 5};
+static algo_t g_algo = {0, -1, 0, 0, 100.0, 0.8, 0, 1, 1000.0, 5e-2, 0.8, 5};      /* globalization -1: what oracle_config.line_search says; 0 / 1 force the merit / the filter (experiments) */
 static int g_inertia = 1;      /* 1: a factorisation is accepted when the KKT matrix has Ipopt's inertia (the algorithm); 0: the inertia-free curvature test of r01-r03 (kept for the measurements of DESIGN 3.1) */
+static int g_rho_mode = 0;          /* EXPERIMENT (r06): 0 = the algorithm (the l1 penalty only grows between barrier updates), 1 = recomputed every iteration, 2 = may decay by g_rho_decay per iteration */
+static double g_rho_decay = 0.5;
 void oracle_set_algo(int key, double v) {
     if (key == 9) { g_inertia = (int)v; return; }
+    if (key == 14) { g_rho_mode = (int)v; return; }
+    if (key == 15) { g_rho_decay = v; return; }
     switch (key) {
         case 0: g_algo.mu_oracle = (int)v; break;
         case 1: g_algo.globalization = (int)v; break;
@@ -1575,6 +1581,7 @@ static int solve_one(work_t* w, int warm) {
                 fobj += w->erho * w->oe[k * M + m];
             }
             w->rho = 0;
+            nfilt = 0;           /* the objective changed: the filter's pairs are of another barrier function */
             jam_streak = 0;
             kkt_terms(w, cc, &e);
         }
@@ -1694,11 +1701,13 @@ static int solve_one(work_t* w, int warm) {
         const double logs0 = barrier_logs(w, w->U, w->D, w->s, w->os) + (ball_on(w) ? log(w->ts) : 0.0);
         double alpha = a_p, ft = 0, tht = 0;
         int accepted = 0, ls_used = 0, soc_used = 0;
-        if (g_algo.globalization == 0) {
+        if ((g_algo.globalization < 0 ? (c->line_search == 1 ? 0 : 1) : g_algo.globalization) == 0) {
             if (theta > 0) {
                 double sigma = curv > 0 ? 1.0 : 0.0;
                 double rt = (dphi + 0.5 * sigma * curv) / ((1.0 - rho_frac) * theta);
-                if (w->rho < rt) w->rho = rt + 1.0;
+                if (g_rho_mode == 1) w->rho = fmax(rt + 1.0, 1.0);                          /* experiment: the smallest penalty that makes this step a descent direction, every iteration */
+                else if (g_rho_mode == 2) w->rho = fmax(rt + 1.0, fmax(g_rho_decay * w->rho, 1.0));      /* experiment: the penalty may fall by a factor per iteration */
+                else if (w->rho < rt) w->rho = rt + 1.0;
             }
             double phi0 = fobj - mu * logs0 + w->rho * theta;
             double Dm = dphi - w->rho * theta;
