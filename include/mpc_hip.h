@@ -106,6 +106,16 @@ enum mpc_mu_strategy {
     MPC_MU_MONOTONE = 1               /* Fiacco-McCormick: mu falls (x 0.2 / ^1.5) when the barrier subproblem is solved to 10 mu -- Ipopt's own default mu_strategy */
 };
 
+enum mpc_line_search {                /* the globalisation of the interior-point iteration (Ipopt option line_search_method; solver/ipopt/ipopt_string_options, src/controller.cpp:407-418) */
+    MPC_LS_DEFAULT = 0,               /* the library's default: see mpc_problem.hpp (fill_problem) and DESIGN.md section 3 */
+    MPC_LS_MERIT = 1,                 /* backtracking on the l1 merit function f - mu sum log + rho theta with Ipopt's penalty-parameter rule (the globalisation of rounds 1-5) */
+    MPC_LS_FILTER = 2                 /* Ipopt's own default: the filter line search of Waechter & Biegler (2006), Algorithm A, with its published constants (gamma_theta 1e-5,
+                                       * gamma_phi 1e-8, s_phi 2.3, s_theta 1.1, eta_phi 1e-8, delta 1, gamma_alpha 0.05, theta_max / theta_min = 1e4 / 1e-4 x max(1, theta_0));
+                                       * the filter holds the last 16 (theta, phi) pairs of the current barrier problem and is emptied when mu changes.  Not restated: the
+                                       * second-order correction, and the restoration phase -- when every trial step is refused the filter is emptied and the shortest trial
+                                       * step taken (clearance rows have their own restoration) */
+};
+
 enum mpc_status {                     /* per-instance result; 0 == what corbo reports as Converged */
     MPC_CONVERGED = 0,
     MPC_MAX_ITER = 1,
@@ -210,7 +220,7 @@ typedef struct mpc_config {
                                        * grid sizes of the reference's shipped parameter files).  0 -> the default 8192 (measured on the MI355X: x1.14-1.27 there, x1.4-1.6 at 32768
                                        * instances; at 4096 x1.10-1.15 for n = 20 / 24 but x0.73 for n = 12; a small launch lasts as long as its slowest wave, which runs fastest
                                        * alone: x0.85 at 1024); negative -> never.  Results are bit-identical either way.  No counterpart in the reference */
-    int32_t reserved[1];
+    int32_t line_search;              /* enum mpc_line_search (solver/ipopt/ipopt_string_options/line_search_method) */
     /* full weight matrices (state_weights / control_weights / final_state_weights / weight_matrix given as n x n lists, column major,
      * src/controller.cpp:565-573,580-588,656-664,690-698): Q, R, Qf, terminal_ball_S above hold the DIAGONALS, these the off-diagonal terms
      * (0,1), (0,2), (1,2) of the symmetric parts (x' W x only sees (W + W') / 2); all zero = diagonal weights */

@@ -346,6 +346,10 @@ inline ParamStatus config_from_params(const ParamSource& p, mpc_config& c, Contr
             if (kv.second == "monotone") c.mu_strategy = MPC_MU_MONOTONE;
             else if (kv.second == "adaptive") c.mu_strategy = MPC_MU_ADAPTIVE;
             else rep.notes.push_back("mu_strategy " + kv.second + ": unknown, the default (adaptive) is used");
+        } else if (kv.first == "line_search_method") {      // Ipopt: filter (its default) | cg-penalty | penalty
+            if (kv.second == "filter") c.line_search = MPC_LS_FILTER;
+            else if (kv.second == "penalty" || kv.second == "cg-penalty") { c.line_search = MPC_LS_MERIT; rep.notes.push_back("line_search_method " + kv.second + " -> MPC_LS_MERIT (backtracking on the l1 merit function with Ipopt's penalty rule)"); }
+            else rep.notes.push_back("line_search_method " + kv.second + ": unknown, the library's default is used");
         } else if (kv.first == "linear_solver") rep.notes.push_back("linear_solver " + kv.second + ": the KKT systems are solved by the stage-structured sweep of the kernel");
         else rep.notes.push_back("ipopt string option " + kv.first + ": no counterpart, ignored");
     }

@@ -37,6 +37,7 @@ INF = 1e30
 
 COST_LEFT_SUM, COST_TRAPEZOIDAL = 0, 1
 MU_ADAPTIVE, MU_MONOTONE = 0, 1          # enum mpc_mu_strategy
+LS_DEFAULT, LS_MERIT, LS_FILTER = 0, 1, 2   # enum mpc_line_search
 STAGE_AUTO, STAGE_LDS, STAGE_GLOBAL = 0, 1, 2      # enum mpc_stage_data: where a solve keeps its factorisation data
 
 CAND_REFERENCE = 0
@@ -104,7 +105,7 @@ class MpcConfig(C.Structure):
         ("hessian_mode", C.c_int32),
         ("hybrid_cost_minimum_time", C.c_int32),
         ("cost_integration", C.c_int32),
-        ("mu_strategy", C.c_int32), ("stage_data", C.c_int32), ("two_wave_min_batch", C.c_int32), ("reserved", C.c_int32 * 1),
+        ("mu_strategy", C.c_int32), ("stage_data", C.c_int32), ("two_wave_min_batch", C.c_int32), ("line_search", C.c_int32),
         ("Q_offdiag", C.c_double * 3),
         ("R_offdiag", C.c_double),
         ("Qf_offdiag", C.c_double * 3),
@@ -143,7 +144,7 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
                 terminal_ball_S=None, terminal_ball_gamma=1.0, vp_position_weight=1e-3, vp_orientation_weight=0.0,
                 via_points_ordered=False, max_via_points=0, footprint_params=(0.0, 0.0, 0.0, 0.0),
                 enable_dynamic_obstacles=False, footprint_vertices=(), candidates=(), candidate_max_iter=(), candidate_blend=0, dual_warm_start=False, mu_init_dual=0.0, candidate_param=(), hessian_mode=0,
-                hybrid_cost_minimum_time=False, cost_integration=COST_LEFT_SUM, acceptable_tol=0.0, acceptable_iter=0, mu_strategy=0, max_cpu_time=0.0, stage_data=STAGE_AUTO, two_wave_min_batch=0) -> MpcConfig:
+                hybrid_cost_minimum_time=False, cost_integration=COST_LEFT_SUM, acceptable_tol=0.0, acceptable_iter=0, mu_strategy=0, max_cpu_time=0.0, stage_data=STAGE_AUTO, two_wave_min_batch=0, line_search=LS_DEFAULT) -> MpcConfig:
     """Q, R, Qf, terminal_ball_S: the diagonal (3 / 2 / 3 / 3 values) or the full matrix (nested 3 x 3 / 2 x 2; its symmetric part is used)."""
     c = MpcConfig()
     c.model = model
@@ -206,6 +207,7 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
     c.hessian_mode = int(hessian_mode)
     c.mu_strategy = int(mu_strategy)          # MU_ADAPTIVE (0, default) | MU_MONOTONE
     c.stage_data = int(stage_data)            # STAGE_AUTO (0, default) | STAGE_LDS | STAGE_GLOBAL
+    c.line_search = int(line_search)          # LS_DEFAULT (0) | LS_MERIT | LS_FILTER
     c.two_wave_min_batch = int(two_wave_min_batch)      # 0: the default threshold (8192 instances per launch), negative: never the two-waves-per-SIMD kernel
     c.hybrid_cost_minimum_time = int(bool(hybrid_cost_minimum_time))
     c.cost_integration = int(cost_integration)

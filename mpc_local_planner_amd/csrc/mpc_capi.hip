@@ -160,7 +160,7 @@ void mpc_config_defaults(mpc_config* c) {
 }
 
 const char* mpc_last_error(void) { return g_err; }
-int32_t mpc_version(void) { return 600; }      // 0.6.0: mpc_config.two_wave_min_batch took a reserved word (same size).  0.5.0: mpc_config.stage_data took a reserved word (same size); a solve restores clearance rows that jam.  0.4.0: mpc_config.mu_strategy / max_time_us took reserved words (same size), MPC_TIME_LIMIT; a solve accepts factorisations on their inertia
+int32_t mpc_version(void) { return 600; }      // 0.6.0: mpc_config.two_wave_min_batch and mpc_config.line_search took the last reserved words (same size).  0.5.0: mpc_config.stage_data took a reserved word (same size); a solve restores clearance rows that jam.  0.4.0: mpc_config.mu_strategy / max_time_us took reserved words (same size), MPC_TIME_LIMIT; a solve accepts factorisations on their inertia
 // history: 0.2.0: mpc_config grew (candidates, kept multipliers, hessian_mode), new entry points; 0.2.1: cost variants (off-diagonal weights, trapezoidal rule, hybrid cost)
 
 #ifdef MPC_PROFILE
@@ -201,6 +201,7 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
         set_err("mpc_create: MPC_MIXED is implemented for problems without clearance rows and via-points (their association would be redone by the refinement phase)"); return MPC_EINVAL; }
     if (cfg->hessian_mode != MPC_HESSIAN_EXACT && cfg->hessian_mode != MPC_HESSIAN_CONVEXIFIED) { set_err("mpc_create: unknown hessian_mode"); return MPC_EINVAL; }
     if (cfg->mu_strategy != MPC_MU_ADAPTIVE && cfg->mu_strategy != MPC_MU_MONOTONE) { set_err("mpc_create: unknown mu_strategy"); return MPC_EINVAL; }
+    if (cfg->line_search != MPC_LS_DEFAULT && cfg->line_search != MPC_LS_MERIT && cfg->line_search != MPC_LS_FILTER) { set_err("mpc_create: unknown line_search"); return MPC_EINVAL; }
     if (cfg->max_time_us < 0) { set_err("mpc_create: max_time_us must be >= 0 (0 = no budget)"); return MPC_EINVAL; }
     if (cfg->n_candidates < 0 || cfg->n_candidates > MPC_MAX_CANDIDATES) { set_err("mpc_create: n_candidates must be in [0, MPC_MAX_CANDIDATES]"); return MPC_EINVAL; }
     for (int k = 0; k < cfg->n_candidates; ++k)

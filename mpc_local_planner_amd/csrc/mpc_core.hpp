@@ -96,6 +96,7 @@ struct Problem {
     T pit_mu_min;        // ... while the barrier parameter is above this (the last iterations of a solve take the serial sweeps: see DESIGN.md)
     int pit;             // partitioned (parallel-in-time) sweeps for grids of 40 points and more (1; 0 = the serial sweeps everywhere: developer switch MPC_NO_PIT)
     int mu_strategy;     // mpc_config.mu_strategy: 0 adaptive barrier parameter (the default), 1 monotone Fiacco-McCormick
+    int line_search;     // mpc_config.line_search resolved: 0 l1 merit, 1 Ipopt's filter line search
     long long max_ticks; // mpc_config.max_time_us in ticks of the device's constant 100 MHz clock (wall_clock64); 0 = no limit
 };
 
@@ -111,6 +112,9 @@ template <> struct Algo<double> {
     static constexpr double kappa_plus = 8, kappa_plus_first = 100, kappa_minus = 1.0 / 3.0;
     static constexpr double curv_kappa = 1e-10, s_max = 100, delta_c = 1e-8, kappa_c = 0.25, ls_eps = 10 * 2.220446049250313e-16;
     static constexpr int max_ls = 30;
+    // Ipopt's filter line search (Waechter & Biegler 2006, Algorithm A; the constants of section 3.4 / Ipopt's defaults)
+    static constexpr double flt_gth = 1e-5, flt_gph = 1e-8, flt_sph = 2.3, flt_sth = 1.1, flt_eta = 1e-8, flt_delta = 1.0, flt_gal = 0.05, flt_thmax = 1e4, flt_thmin = 1e-4;
+    static constexpr int flt_cap = 16;
     // initial slack of a CLEARANCE row: max(-g, 0.5) (metres of clearance) instead of the 1e-2 of the linear rows.  With 1e-2 a row that starts active or
     // violated pins the fraction-to-boundary rule from the first iteration on (steps of 1e-3) and, without Ipopt's restoration phase, the solve never
     // leaves that corner: obstacles inside the clearance band converge in 81 % of the instances with 1e-2 and in 98 % with 0.5
@@ -131,6 +135,8 @@ template <> struct Algo<float> {
     static constexpr float kappa_plus = 8, kappa_plus_first = 100, kappa_minus = 1.0f / 3.0f;
     static constexpr float curv_kappa = 1e-7f, s_max = 100, delta_c = 1e-5f, kappa_c = 0.25f, ls_eps = 10 * 1.1920929e-7f;
     static constexpr int max_ls = 30;
+    static constexpr float flt_gth = 1e-5f, flt_gph = 1e-8f, flt_sph = 2.3f, flt_sth = 1.1f, flt_eta = 1e-8f, flt_delta = 1.0f, flt_gal = 0.05f, flt_thmax = 1e4f, flt_thmin = 1e-4f;
+    static constexpr int flt_cap = 16;
     static constexpr float clearance_slack_push = 0.5f;
     static constexpr float elastic_rho = 1000.0f, elastic_ap = 5e-2f, elastic_prog = 0.8f;
     static constexpr int elastic_trigger = MPC_ELASTIC_TRIGGER;

@@ -6,6 +6,9 @@
 
 namespace mpc {
 
+// what mpc_config.line_search = MPC_LS_DEFAULT means: 0 the l1 merit, 1 Ipopt's filter
+constexpr int kDefaultLineSearch = 0;
+
 template <typename T>
 inline void fill_problem(const mpc_config& c, mpc::Problem<T>& P) {
     P.model = c.model;
@@ -96,6 +99,7 @@ inline void fill_problem(const mpc_config& c, mpc::Problem<T>& P) {
     P.acc_iter = c.acceptable_iter > 0 ? c.acceptable_iter : (c.acceptable_iter < 0 ? 0 : 15);
     P.max_ticks = c.max_time_us > 0 ? 100ll * c.max_time_us : 0ll;
     P.mu_strategy = c.mu_strategy == MPC_MU_MONOTONE ? 1 : 0;
+    P.line_search = c.line_search == MPC_LS_DEFAULT ? kDefaultLineSearch : (c.line_search == MPC_LS_FILTER ? 1 : 0);
     P.costx = (P.trapz || P.Ro != T(0)) ? 1 : 0;
     for (int i = 0; i < 3; ++i) if (P.Qo[i] != T(0) || P.Qfo[i] != T(0) || (P.ball && P.So[i] != T(0))) P.costx = 1;
 }

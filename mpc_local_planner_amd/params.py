@@ -32,6 +32,7 @@ PLUGIN_NAMESPACE = "MpcLocalPlannerROS"      # move_base loads the plugin's para
 FOOTPRINT_POINT, FOOTPRINT_CIRCLE, FOOTPRINT_LINE, FOOTPRINT_TWO_CIRCLES, FOOTPRINT_POLYGON = range(5)   # include/mpc_hip.h, enum mpc_footprint_kind
 HESSIAN_EXACT, HESSIAN_CONVEXIFIED = 0, 1
 MU_ADAPTIVE, MU_MONOTONE = 0, 1
+LS_DEFAULT, LS_MERIT, LS_FILTER = 0, 1, 2      # enum mpc_line_search
 
 
 class ParamError(ValueError):
@@ -238,6 +239,14 @@ def config_from_params(params: dict, costmap_footprint=None, **sizing):
                 kw["mu_strategy"] = MU_MONOTONE if v == "monotone" else MU_ADAPTIVE
             else:
                 notes.append(f"mu_strategy {v}: unknown, the default (adaptive) is used")
+        elif k == "line_search_method":      # Ipopt: filter (its default) | cg-penalty | penalty
+            if v == "filter":
+                kw["line_search"] = LS_FILTER
+            elif v in ("penalty", "cg-penalty"):
+                kw["line_search"] = LS_MERIT
+                notes.append(f"line_search_method {v} -> MPC_LS_MERIT (backtracking on the l1 merit function with Ipopt's penalty rule)")
+            else:
+                notes.append(f"line_search_method {v}: unknown, the library's default is used")
         elif k == "linear_solver":
             notes.append(f"linear_solver {v}: the KKT systems are solved by the stage-structured sweep of the kernel")
         else:

@@ -50,7 +50,7 @@ def _load():
     return _lib
 
 
-LINE_SEARCH_DEFAULT = 1      # 0 filter, 1 l1 merit (mpc_config.line_search)
+LINE_SEARCH_DEFAULT = 0      # 0 l1 merit, 1 Ipopt's filter (what mpc_config.line_search = MPC_LS_DEFAULT resolves to in the library: mpc_problem.hpp)
 
 
 def from_nlp_config(cfg, max_iter=100, tol=1e-8, mu_init=0.1, hessian_mode=0, acceptable_tol=0.0, acceptable_iter=0, mu_strategy=0, line_search=None) -> OracleConfig:
@@ -84,7 +84,7 @@ def from_nlp_config(cfg, max_iter=100, tol=1e-8, mu_init=0.1, hessian_mode=0, ac
     o.hessian_mode = int(hessian_mode)
     o.acceptable_tol, o.acceptable_iter = float(acceptable_tol), int(acceptable_iter)
     o.mu_strategy = int(mu_strategy)      # 0 adaptive (default), 1 monotone
-    o.line_search = int(LINE_SEARCH_DEFAULT if line_search is None else line_search)      # 0 filter, 1 l1 merit
+    o.line_search = int(LINE_SEARCH_DEFAULT if line_search is None else line_search)      # 0 l1 merit, 1 filter
     o.collocation = int(getattr(cfg, "collocation", 0))
     o.integral = int(bool(getattr(cfg, "integral_form", False)) and cfg.objective == 1)
     if getattr(cfg, "terminal_ball_S", None) is not None:

@@ -84,8 +84,8 @@ typedef struct oracle_config {
                                  * as mpc_config.acceptable_tol (include/mpc_hip.h) */
     int32_t acceptable_iter;    /* iterations in a row at that level that end the solve with status 0: 0 -> Ipopt's default 15, < 0 -> off */
     int32_t mu_strategy;        /* 0 adaptive (the default; see solve_one), 1 monotone Fiacco-McCormick -- mpc_config.mu_strategy */
-    int32_t line_search;        /* 0 Ipopt's filter line search (Waechter & Biegler 2006, Algorithm A; no second-order correction, no restoration phase: when every trial step is
-                                 * refused the filter is emptied and the shortest trial step taken), 1 l1-merit backtracking (the globalisation of rounds 1-5) -- mpc_config.line_search */
+    int32_t line_search;        /* mpc_config.line_search: 0 l1-merit backtracking (the globalisation of rounds 1-5, the default), 1 Ipopt's filter line search (Waechter & Biegler
+                                 * 2006, Algorithm A; no second-order correction, no restoration phase: when every trial step is refused the filter is emptied and the shortest trial step taken) */
 } oracle_config;
 static inline double acc_tol_of(const oracle_config* c) { return c->acceptable_tol > 0 ? c->acceptable_tol : (c->acceptable_tol < 0 ? 0.0 : 1e-6); }
 static inline int acc_iter_of(const oracle_config* c) { return c->acceptable_iter > 0 ? c->acceptable_iter : (c->acceptable_iter < 0 ? 0 : 15); }
@@ -1701,7 +1701,7 @@ static int solve_one(work_t* w, int warm) {
         const double logs0 = barrier_logs(w, w->U, w->D, w->s, w->os) + (ball_on(w) ? log(w->ts) : 0.0);
         double alpha = a_p, ft = 0, tht = 0;
         int accepted = 0, ls_used = 0, soc_used = 0;
-        if ((g_algo.globalization < 0 ? (c->line_search == 1 ? 0 : 1) : g_algo.globalization) == 0) {
+        if ((g_algo.globalization < 0 ? (c->line_search == 1 ? 1 : 0) : g_algo.globalization) == 0) {
             if (theta > 0) {
                 double sigma = curv > 0 ? 1.0 : 0.0;
                 double rt = (dphi + 0.5 * sigma * curv) / ((1.0 - rho_frac) * theta);

@@ -706,6 +706,8 @@ struct Ipm {
         eval_point(L.X, L.U, L.D, L.TRIG, L.CC, theta_c, fobj, cinf);
 
         int it = 0, n_acc = 0;
+        T f_th[Algo<T>::flt_cap], f_ph[Algo<T>::flt_cap], theta0 = T(-1), mu_filter = T(-1);      // Ipopt's filter (mpc_config.line_search): a ring of (theta, phi) pairs
+        int nfilt = 0, fpos = 0;
         int status = ST_MAX_ITER;
         T e0 = T(0), last_alpha = T(0), last_ad = T(0);
         bool endgame = false;
@@ -764,27 +766,64 @@ struct Ipm {
             if (!ok) { status = ST_LINSOLVE; break; }
             if (delta > T(0)) delta_last = delta;
             if (started_zero) fail0 = delta > T(0);
-            // ---- l1 merit, backtracking
+            // ---- l1 merit backtracking, or Ipopt's filter line search (mpc_config.line_search; the statements of mpc_wave_solve.inc)
+            const bool filter = P.line_search == 1;
             const T theta = er.theta;
-            if (theta > T(0)) {
+            if (!filter && theta > T(0)) {
                 T sigma = curv > T(0) ? T(1) : T(0);
                 T rho_trial = (fw.dphi + T(0.5) * sigma * curv) / ((T(1) - Algo<T>::rho_frac) * theta);
                 if (rho < rho_trial) rho = rho_trial + T(1);
             }
-            const T phi0 = fobj - mu * barrier_logs(L.U, L.D, T(0), false) + rho * theta;
-            const T Dm = fw.dphi - rho * theta;
+            const T rho_ls = filter ? T(0) : rho;
+            const T phi0 = fobj - mu * barrier_logs(L.U, L.D, T(0), false) + rho_ls * theta;
+            const T Dm = fw.dphi - rho_ls * theta;
             const T theta_rows = theta - theta_c;      // linear rows: scales with (1 - alpha)
             T alpha = fw.a_p;
-            bool accepted = false;
-            T th_t = T(0), f_t = T(0), cinf_t = T(0);
+            T a_min = T(0), p_ph = T(0), p_th = T(0), theta_max = T(0), theta_min = T(0);
+            if (filter) {
+                if (theta0 < T(0)) theta0 = theta;
+                if (mu != mu_filter) { nfilt = 0; fpos = 0; mu_filter = mu; }
+                theta_max = Algo<T>::flt_thmax * t_max(T(1), theta0); theta_min = Algo<T>::flt_thmin * t_max(T(1), theta0);
+                a_min = Algo<T>::flt_gth;
+                if (fw.dphi < T(0)) {
+                    p_ph = t_pow(-fw.dphi, Algo<T>::flt_sph); p_th = t_pow(theta, Algo<T>::flt_sth);
+                    a_min = t_min(a_min, Algo<T>::flt_gph * theta / (-fw.dphi));
+                    if (theta <= theta_min) a_min = t_min(a_min, Algo<T>::flt_delta * p_th / p_ph);
+                }
+                a_min = a_min * Algo<T>::flt_gal * fw.a_p;
+            }
+            bool accepted = false, sw_arm = false;
+            T th_t = T(0), f_t = T(0), cinf_t = T(0), lg_t = T(0);
             for (int ls = 0; ls < Algo<T>::max_ls; ++ls) {
                 if (ls > 0) alpha *= T(0.5);
+                const bool below = filter && ls > 0 && alpha < a_min;
                 make_trial(alpha);
                 eval_point(L.XT, L.UT, L.DT, L.TRIG, L.CC, th_t, f_t, cinf_t);   // overwrites the caches of the current point
                 T tht = th_t + (T(1) - alpha) * theta_rows;
-                T phit = f_t - mu * barrier_logs(L.UT, L.DT, alpha, true) + rho * tht;
-                // round-off relaxed Armijo test (Waechter & Biegler 2006, sec. 3.3: 10*eps_mach*|phi|)
-                if (t_finite(phit) && phit - phi0 - Algo<T>::ls_eps * t_abs(phi0) <= Algo<T>::eta_armijo * alpha * Dm) { accepted = true; break; }
+                lg_t = barrier_logs(L.UT, L.DT, alpha, true);
+                T phit = f_t - mu * lg_t + rho_ls * tht;
+                if (!filter) {
+                    // round-off relaxed Armijo test (Waechter & Biegler 2006, sec. 3.3: 10*eps_mach*|phi|)
+                    if (t_finite(phit) && phit - phi0 - Algo<T>::ls_eps * t_abs(phi0) <= Algo<T>::eta_armijo * alpha * Dm) { accepted = true; break; }
+                } else {
+                    if (below) break;
+                    bool okf = t_finite(phit) && tht <= theta_max;
+                    for (int f = 0; f < nfilt && okf; ++f) if (!(tht <= (T(1) - Algo<T>::flt_gth) * f_th[f] || phit <= f_ph[f] - Algo<T>::flt_gph * f_th[f])) okf = false;
+                    if (okf) {
+                        const bool switching = fw.dphi < T(0) && alpha * p_ph > Algo<T>::flt_delta * p_th;
+                        if (theta <= theta_min && switching) {
+                            if (phit - phi0 - Algo<T>::ls_eps * t_abs(phi0) <= Algo<T>::flt_eta * alpha * fw.dphi) { accepted = true; sw_arm = true; }
+                        } else if (tht <= (T(1) - Algo<T>::flt_gth) * theta || phit <= phi0 - Algo<T>::flt_gph * theta) accepted = true;
+                    }
+                    if (accepted) break;
+                }
+            }
+            if (filter) {
+                if (accepted && !sw_arm) {
+                    f_th[fpos] = theta; f_ph[fpos] = phi0;
+                    fpos = (fpos + 1) & (Algo<T>::flt_cap - 1); nfilt = nfilt < Algo<T>::flt_cap ? nfilt + 1 : Algo<T>::flt_cap;
+                }
+                if (!accepted) { nfilt = 0; fpos = 0; accepted = t_finite(f_t) && t_finite(lg_t); }
             }
             if (P.acc_tol > T(0) && (!accepted || alpha < T(1e-6) * fw.a_p) && e0 <= P.acc_tol) {      // refused-step half of the acceptable-level stop
                 eval_point(L.X, L.U, L.D, L.TRIG, L.CC, theta_c, fobj, cinf);

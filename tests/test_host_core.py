@@ -77,6 +77,27 @@ def test_device_core_matches_c_oracle_on_a_batch(host, c_oracle):
     assert np.median(err[both]) < 1e-9
 
 
+@pytest.mark.parametrize("name,n,B", [("carlike_min_time_n20", 30, 48), ("unicycle_quadratic_n20", 20, 24), ("bicycle_min_time_n30", 30, 24)])
+def test_device_core_filter_line_search_follows_the_c_oracle(host, c_oracle, name, n, B):
+    """mpc_config.line_search = MPC_LS_FILTER (Ipopt's filter line search, Waechter & Biegler 2006 Algorithm A without second-order correction): the kernel's statements
+    (tests/host_harness/ipm_serial.hpp carries the ones of mpc_wave_solve.inc) against the C oracle's (oracle_config.line_search = 1): same statuses, the same iteration
+    counts on nearly every instance, the same trajectories; and the filter is a DIFFERENT iteration from the l1 merit on some of these instances."""
+    mk = {"carlike_min_time_n20": (A.config_carlike_min_time, R.config_carlike_min_time, lambda: W.carlike_min_time_inputs(B, seed=11, goal_range=(1.0, 4.0))),
+          "unicycle_quadratic_n20": (A.config_unicycle_quadratic, R.config_unicycle_quadratic, lambda: W.unicycle_quadratic_inputs(B, seed=12)),
+          "bicycle_min_time_n30": (A.config_bicycle_min_time, R.config_bicycle_min_time, lambda: W.bicycle_min_time_inputs(B, seed=13, goal_range=(1.0, 5.0)))}[name]
+    x0, xf, up, dtp = mk[2]()
+    a = host_solve(host, mk[0](n, line_search=A.LS_FILTER), x0, xf, up, dtp)
+    am = host_solve(host, mk[0](n, line_search=A.LS_MERIT), x0, xf, up, dtp)
+    b = c_oracle.solve_batch(c_oracle.from_nlp_config(mk[1](n), line_search=1), x0, xf, up, dtp)
+    both = (a[3] == 0) & (b[3] == 0)
+    assert (a[3] == b[3]).mean() >= 0.95 and both.sum() >= 0.8 * B
+    err = np.maximum(np.abs(a[0] - b[0]).reshape(B, -1).max(1), np.abs(a[1] - b[1]).reshape(B, -1).max(1))
+    assert (a[4] == b[4])[both].mean() >= 0.9
+    assert (err[both] < 1e-6).mean() >= 0.9 and np.median(err[both]) < 1e-9
+    if name != "unicycle_quadratic_n20":
+        assert (a[4] != am[4]).any()
+
+
 def test_device_core_fp32_is_close_to_fp64(host):
     n = 20
     x0, xf, up, dtp = W.carlike_min_time_inputs(16, seed=12, goal_range=(1.0, 2.5))

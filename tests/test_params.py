@@ -295,7 +295,7 @@ def _cpp_config(cpp, tree, costmap_footprint=None):
 
 SCALARS = ["model", "n", "dt_ref", "dt_free", "dt_lb", "dt_ub", "collocation", "objective", "integral_form", "has_Qf", "max_iter", "tol", "mu_init", "precision",
            "min_obstacle_dist", "force_inclusion_dist", "cutoff_dist", "footprint_kind", "footprint_radius", "footprint_n_vertices", "max_obstacles", "max_vertices",
-           "max_obstacle_rows", "terminal_ball", "enable_dynamic_obstacles", "hessian_mode", "via_points_ordered", "n_candidates", "dual_warm_start", "hybrid_cost_minimum_time", "cost_integration", "R_offdiag", "acceptable_tol", "acceptable_iter", "mu_strategy", "max_time_us"]
+           "max_obstacle_rows", "terminal_ball", "enable_dynamic_obstacles", "hessian_mode", "via_points_ordered", "n_candidates", "dual_warm_start", "hybrid_cost_minimum_time", "cost_integration", "R_offdiag", "acceptable_tol", "acceptable_iter", "mu_strategy", "max_time_us", "line_search"]
 ARRAYS = ["model_params", "xf_fixed", "Q", "R", "Qf", "u_lb", "u_ub", "du_lb", "du_ub", "terminal_ball_S", "footprint_params", "footprint_vertices", "Q_offdiag", "Qf_offdiag",
           "terminal_ball_S_offdiag"]
 
@@ -311,7 +311,9 @@ def test_cpp_reader_agrees_with_the_python_reader(cpp, tmp_path):
                "grid": {"variable_grid": {"enable": False}, "xf_fixed": [False, False, True], "grid_size_ref": 33}}, None),
              ({"planning": {"objective": {"type": "minimum_time_via_points", "minimum_time_via_points": {"position_weight": 10.5, "via_points_ordered": True}}},
                "footprint_model": {"type": "two_circles", "front_offset": 0.2, "front_radius": 0.25, "rear_offset": 0.1, "rear_radius": 0.2},
-               "solver": {"ipopt": {"iterations": 55, "ipopt_numeric_options": {"tol": 1e-5, "mu_init": 0.05, "acceptable_tol": 1e-3}, "ipopt_integer_options": {"max_iter": 70}}}}, None),
+               "solver": {"ipopt": {"iterations": 55, "ipopt_numeric_options": {"tol": 1e-5, "mu_init": 0.05, "acceptable_tol": 1e-3}, "ipopt_integer_options": {"max_iter": 70},
+                                    "ipopt_string_options": {"line_search_method": "filter"}}}}, None),
+             ({"solver": {"ipopt": {"ipopt_string_options": {"line_search_method": "cg-penalty", "mu_strategy": "monotone"}}}}, None),
              ({"planning": {"objective": {"type": "quadratic_form", "quadratic_form": {"state_weights": [1, 0.5, 0, 0.3, 2, 0, 0, 0.2, 3.0], "control_weights": [1, 0.1, 0.3, 2.0], "integral_form": True}},
                             "terminal_cost": {"type": "quadratic", "quadratic": {"final_state_weights": [5, 1, 0, 1, 6, 0.5, 0, 0.5, 7.0]}},
                             "terminal_constraint": {"type": "l2_ball", "l2_ball": {"weight_matrix": [1, 0.2, 0, 0.2, 1, 0, 0, 0, 0.5], "radius": 0.4}}},
