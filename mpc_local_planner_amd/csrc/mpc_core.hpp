@@ -93,10 +93,10 @@ struct Problem {
     // Ipopt's acceptable-level stop (mpc_config.acceptable_tol / acceptable_iter): level (0 = rule off) and iterations in a row (0 = counting half off)
     T acc_tol;
     int acc_iter;
+    int line_search;     // mpc_config.line_search resolved: 0 l1 merit, 1 Ipopt's filter line search (sits in the padding after acc_iter in the fp64 form)
     T pit_mu_min;        // ... while the barrier parameter is above this (the last iterations of a solve take the serial sweeps: see DESIGN.md)
     int pit;             // partitioned (parallel-in-time) sweeps for grids of 40 points and more (1; 0 = the serial sweeps everywhere: developer switch MPC_NO_PIT)
     int mu_strategy;     // mpc_config.mu_strategy: 0 adaptive barrier parameter (the default), 1 monotone Fiacco-McCormick
-    int line_search;     // mpc_config.line_search resolved: 0 l1 merit, 1 Ipopt's filter line search
     long long max_ticks; // mpc_config.max_time_us in ticks of the device's constant 100 MHz clock (wall_clock64); 0 = no limit
 };
 

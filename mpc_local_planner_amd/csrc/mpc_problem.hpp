@@ -7,7 +7,7 @@
 namespace mpc {
 
 // what mpc_config.line_search = MPC_LS_DEFAULT means: 0 the l1 merit, 1 Ipopt's filter
-constexpr int kDefaultLineSearch = 0;
+constexpr int kDefaultLineSearch = 1;
 
 template <typename T>
 inline void fill_problem(const mpc_config& c, mpc::Problem<T>& P) {

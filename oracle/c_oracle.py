@@ -50,7 +50,7 @@ def _load():
     return _lib
 
 
-LINE_SEARCH_DEFAULT = 0      # 0 l1 merit, 1 Ipopt's filter (what mpc_config.line_search = MPC_LS_DEFAULT resolves to in the library: mpc_problem.hpp)
+LINE_SEARCH_DEFAULT = 1      # 0 l1 merit, 1 Ipopt's filter (what mpc_config.line_search = MPC_LS_DEFAULT resolves to in the library: mpc_problem.hpp)
 
 
 def from_nlp_config(cfg, max_iter=100, tol=1e-8, mu_init=0.1, hessian_mode=0, acceptable_tol=0.0, acceptable_iter=0, mu_strategy=0, line_search=None) -> OracleConfig:

@@ -623,7 +623,7 @@ class IpmOptions:
     max_ls: int = 30
     delta_c: float = 1e-8
     init_controls: bool = True
-    globalization: str = "merit"           # "merit" = l1 merit backtracking (the algorithm of the product and of oracle/mpc_oracle.c) | "filter" (Ipopt's Algorithm A without SOC / restoration: experiment)
+    globalization: str = "filter"          # "filter" = Ipopt's filter line search (Waechter & Biegler 2006, Algorithm A, no second-order correction; the default of the product, of oracle/mpc_oracle.c and of Ipopt) | "merit" = l1-merit backtracking (mpc_config.line_search = MPC_LS_MERIT, the globalisation of rounds 1-5)
     filter_cap: int = 16
     mu_strategy: str = "adaptive"          # "adaptive" (the default, mpc_config.mu_strategy = MPC_MU_ADAPTIVE) | "monotone" (Fiacco-McCormick, Ipopt's own default) | "loqo" (experiment)
     sigma_min: float = 0.05                # adaptive: sigma = clamp((1 - min(alpha, alpha_dual))^3, sigma_min, 1) from the LAST iteration's step lengths

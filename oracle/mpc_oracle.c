@@ -84,7 +84,7 @@ typedef struct oracle_config {
                                  * as mpc_config.acceptable_tol (include/mpc_hip.h) */
     int32_t acceptable_iter;    /* iterations in a row at that level that end the solve with status 0: 0 -> Ipopt's default 15, < 0 -> off */
     int32_t mu_strategy;        /* 0 adaptive (the default; see solve_one), 1 monotone Fiacco-McCormick -- mpc_config.mu_strategy */
-    int32_t line_search;        /* mpc_config.line_search: 0 l1-merit backtracking (the globalisation of rounds 1-5, the default), 1 Ipopt's filter line search (Waechter & Biegler
+    int32_t line_search;        /* mpc_config.line_search: 0 l1-merit backtracking (the globalisation of rounds 1-5), 1 Ipopt's filter line search (Waechter & Biegler
                                  * 2006, Algorithm A; no second-order correction, no restoration phase: when every trial step is refused the filter is emptied and the shortest trial step taken) */
 } oracle_config;
 static inline double acc_tol_of(const oracle_config* c) { return c->acceptable_tol > 0 ? c->acceptable_tol : (c->acceptable_tol < 0 ? 0.0 : 1e-6); }

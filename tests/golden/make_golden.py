@@ -29,7 +29,7 @@ def make(name, cfg, inputs, keep):
         if st[i] != 0:
             continue
         inp = R.CycleInputs(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=float(dtp[i]))
-        ref = I.solve(cfg, inp, R.cold_start(cfg, x0[i], xf[i]), opt=I.IpmOptions(globalization="merit", max_iter=100))
+        ref = I.solve(cfg, inp, R.cold_start(cfg, x0[i], xf[i]), opt=I.IpmOptions(max_iter=100))
         if ref.status != 0 or ref.iters > 45:
             continue        # long runs are round-off sensitive (a flipped line-search tie changes the local minimum)
         err = max(np.abs(ref.traj.x - xo[i]).max(), np.abs(ref.traj.u - uo[i, :-1]).max(), abs(ref.traj.dt - do[i]))
@@ -54,7 +54,7 @@ def make_obstacles(name, n=30, B=10, O=6, V=6, M=4, keep=6):
         inp = R.CycleInputs(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=float(dtp[i]), obstacles=obs)
         init = R.cold_start(cfg, x0[i], xf[i])
         rel, _ = R.associate_obstacles(cfg, init, obs, max_rows=M)
-        ref = I.solve(cfg, inp, init, relevant=rel, opt=I.IpmOptions(globalization="merit", max_iter=100))
+        ref = I.solve(cfg, inp, init, relevant=rel, opt=I.IpmOptions(max_iter=100))
         if ref.status != 0:
             continue
         sel.append(i); X.append(ref.traj.x); U.append(np.vstack([ref.traj.u, ref.traj.u[-1:]])); D.append(ref.traj.dt); IT.append(ref.iters)
@@ -65,7 +65,7 @@ def make_obstacles(name, n=30, B=10, O=6, V=6, M=4, keep=6):
     print(name, "kept", len(sel), "iters", IT)
 
 
-if __name__ == "__main__" and "--monotone" not in sys.argv and "--stamp" not in sys.argv and "--warm" not in sys.argv and "--integral" not in sys.argv and "--closed-loop" not in sys.argv and "--config3" not in sys.argv and "--midpoint" not in sys.argv and "--cn" not in sys.argv and "--ball" not in sys.argv and "--via" not in sys.argv and "--line" not in sys.argv and "--two" not in sys.argv and "--integral-free" not in sys.argv and "--dynamic" not in sys.argv and "--polygon" not in sys.argv:
+if __name__ == "__main__" and "--monotone" not in sys.argv and "--merit" not in sys.argv and "--stamp" not in sys.argv and "--warm" not in sys.argv and "--integral" not in sys.argv and "--closed-loop" not in sys.argv and "--config3" not in sys.argv and "--midpoint" not in sys.argv and "--cn" not in sys.argv and "--ball" not in sys.argv and "--via" not in sys.argv and "--line" not in sys.argv and "--two" not in sys.argv and "--integral-free" not in sys.argv and "--dynamic" not in sys.argv and "--polygon" not in sys.argv:
     make_obstacles("unicycle_quadratic_obstacles_n30")
     make("carlike_min_time_n50", R.config_carlike_min_time(50), W.carlike_min_time_inputs(32, seed=101), keep=8)
     make("carlike_min_time_n20", R.config_carlike_min_time(20), W.carlike_min_time_inputs(32, seed=102, goal_range=(1.0, 2.5)), keep=8)
@@ -91,7 +91,7 @@ def make_warm(name, n=20, keep=6):
         init = R.Trajectory(prev.x.copy(), prev.u.copy(), prev.dt)
         init.x[0] = x1
         inp = R.CycleInputs(x0=x1, xf=g["xf"][i], u_prev=u0, dt_prev=per)
-        ref = I.solve(cfg, inp, init, opt=I.IpmOptions(globalization="merit", max_iter=100))
+        ref = I.solve(cfg, inp, init, opt=I.IpmOptions(max_iter=100))
         if ref.status != 0 or ref.iters > 45:
             continue
         rows.append(dict(x0=x1, xf=g["xf"][i], u_prev=u0, dt_prev=per, x_init=init.x, u_init=np.vstack([init.u, init.u[-1:]]), dt_init=init.dt,
@@ -114,7 +114,7 @@ def make_integral(name, n=20, keep=6):
         if len(rows) >= keep:
             break
         inp = R.CycleInputs(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=float(dtp[i]))
-        ref = I.solve(cfg, inp, R.cold_start(cfg, x0[i], xf[i]), opt=I.IpmOptions(globalization="merit", max_iter=100))
+        ref = I.solve(cfg, inp, R.cold_start(cfg, x0[i], xf[i]), opt=I.IpmOptions(max_iter=100))
         if ref.status != 0 or ref.iters > 45:
             continue
         rows.append(dict(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=dtp[i], x=ref.traj.x, u=np.vstack([ref.traj.u, ref.traj.u[-1:]]), dt=ref.traj.dt, iters=ref.iters))
@@ -142,7 +142,7 @@ def make_closed_loop(name, n=20, cycles=40):
             init = R.cold_start(cfg, x0, xf)
         else:
             init = R.new_run_overwrite(cfg, R.warm_start_shifting(prev, x0), x0, xf)
-        ref = I.solve(cfg, inp, init, opt=I.IpmOptions(globalization="merit", max_iter=100))
+        ref = I.solve(cfg, inp, init, opt=I.IpmOptions(max_iter=100))
         assert ref.status == 0, (c, ref.status)
         rows.append(dict(x0=x0.copy(), xf=xf.copy(), u_prev=up.copy(), dt_prev=per, x_init=init.x.copy(), u_init=np.vstack([init.u, init.u[-1:]]),
                          dt_init=init.dt, x=ref.traj.x, u=np.vstack([ref.traj.u, ref.traj.u[-1:]]), dt=ref.traj.dt, iters=ref.iters))
@@ -172,7 +172,7 @@ def make_midpoint(name, cfg, inputs, keep=6):
         if len(rows) >= keep:
             break
         inp = R.CycleInputs(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=float(dtp[i]))
-        ref = I.solve(cfg, inp, R.cold_start(cfg, x0[i], xf[i]), opt=I.IpmOptions(globalization="merit", max_iter=100))
+        ref = I.solve(cfg, inp, R.cold_start(cfg, x0[i], xf[i]), opt=I.IpmOptions(max_iter=100))
         if ref.status != 0 or ref.iters > 45:
             continue
         nlp = R.ReferenceNlp(cfg, inp)
@@ -225,10 +225,10 @@ def make_terminal_ball(name, n=20, B=16, keep=6):
             break
         inp = R.CycleInputs(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=float(dtp[i]))
         cfg = ball_config(n, False)
-        free = I.solve(cfg, inp, R.cold_start(cfg, x0[i], xf[i]), opt=I.IpmOptions(globalization="merit", max_iter=100))
+        free = I.solve(cfg, inp, R.cold_start(cfg, x0[i], xf[i]), opt=I.IpmOptions(max_iter=100))
         xd = free.traj.x[-1] - xf[i]; xd[2] = R.normalize_theta(xd[2])
         cfg = ball_config(n, True)
-        ref = I.solve(cfg, inp, R.cold_start(cfg, x0[i], xf[i]), opt=I.IpmOptions(globalization="merit", max_iter=100))
+        ref = I.solve(cfg, inp, R.cold_start(cfg, x0[i], xf[i]), opt=I.IpmOptions(max_iter=100))
         if free.status != 0 or float(xd @ (BALL_S * xd)) < 2 * BALL_GAMMA or ref.status != 0 or ref.iters > 45:
             continue
         nlp = R.ReferenceNlp(cfg, inp)
@@ -273,14 +273,14 @@ def make_via(name, ordered, wo, nvp, near_start, n=30, B=24, keep=6, VP=4):
         inp = R.CycleInputs(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=float(dtp[i]), via_points=vps)
         init = R.cold_start(cfg, x0[i], xf[i])
         idx = R.associate_via_points(cfg, init.x, vps)
-        ref = I.solve(cfg, inp, init, opt=I.IpmOptions(globalization="merit", max_iter=100))
+        ref = I.solve(cfg, inp, init, opt=I.IpmOptions(max_iter=100))
         if ref.status != 0 or ref.iters > 45:
             continue
         # keep only instances whose iterate path is stable under round-off: these problems are flat around the solution (a KKT error of
         # 1e-9 leaves ~1e-5 of play in the states), so two implementations agree to 1e-6 only where a 1e-12 perturbation of the data
         # does not move the point where the iteration stops
         inp2 = R.CycleInputs(x0=x0[i], xf=xf[i] * (1 + 1e-12), u_prev=up[i], dt_prev=float(dtp[i]), via_points=vps * (1 - 1e-12))
-        pert = I.solve(cfg, inp2, R.cold_start(cfg, x0[i], inp2.xf), opt=I.IpmOptions(globalization="merit", max_iter=100))
+        pert = I.solve(cfg, inp2, R.cold_start(cfg, x0[i], inp2.xf), opt=I.IpmOptions(max_iter=100))
         if pert.iters != ref.iters or np.abs(pert.traj.x - ref.traj.x).max() > 1e-8 or np.abs(pert.traj.u - ref.traj.u).max() > 1e-8:
             continue
         nlp = R.ReferenceNlp(cfg, inp, via_idx=idx)
@@ -329,7 +329,7 @@ def make_line_footprint(name, n=30, B=16, keep=6, M=4):
         inp = R.CycleInputs(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=float(dtp[i]), obstacles=obs)
         init = R.cold_start(cfg, x0[i], xf[i])
         rel, _ = R.associate_obstacles(cfg, init, obs, max_rows=M)
-        ref = I.solve(cfg, inp, init, relevant=rel, opt=I.IpmOptions(globalization="merit", max_iter=100))
+        ref = I.solve(cfg, inp, init, relevant=rel, opt=I.IpmOptions(max_iter=100))
         if ref.status != 0 or ref.iters > 60:
             continue
         dmin = min(R.footprint_distance(cfg.footprint_kind, cfg.footprint_params, ref.traj.x[k], ob) for k in range(1, n - 1) for ob in obs)
@@ -361,7 +361,7 @@ def make_two_circles(name, n=30, B=12, O=6, V=6, M=4, keep=6):
         inp = R.CycleInputs(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=float(dtp[i]), obstacles=obs)
         init = R.cold_start(cfg, x0[i], xf[i])
         rel, _ = R.associate_obstacles(cfg, init, obs, max_rows=M)
-        ref = I.solve(cfg, inp, init, relevant=rel, opt=I.IpmOptions(globalization="merit", max_iter=100))
+        ref = I.solve(cfg, inp, init, relevant=rel, opt=I.IpmOptions(max_iter=100))
         if ref.status != 0 or ref.iters > 60:
             continue
         dmin = min(R.footprint_distance(cfg.footprint_kind, cfg.footprint_params, ref.traj.x[k], ob) for k in range(1, n - 1) for ob in obs)
@@ -392,9 +392,9 @@ def make_integral_free_dt(name, n=20, B=16, keep=6):
         if len(rows) >= keep:
             break
         inp = R.CycleInputs(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=float(dtp[i]))
-        ref = I.solve(cfg, inp, R.cold_start(cfg, x0[i], xf[i]), opt=I.IpmOptions(globalization="merit", max_iter=100))
+        ref = I.solve(cfg, inp, R.cold_start(cfg, x0[i], xf[i]), opt=I.IpmOptions(max_iter=100))
         inp2 = R.CycleInputs(x0=x0[i], xf=xf[i] * (1 + 1e-12), u_prev=up[i], dt_prev=float(dtp[i]))
-        pert = I.solve(cfg, inp2, R.cold_start(cfg, x0[i], inp2.xf), opt=I.IpmOptions(globalization="merit", max_iter=100))
+        pert = I.solve(cfg, inp2, R.cold_start(cfg, x0[i], inp2.xf), opt=I.IpmOptions(max_iter=100))
         if ref.status != 0 or ref.iters > 60 or pert.iters != ref.iters or np.abs(pert.traj.x - ref.traj.x).max() > 1e-8:
             continue
         nlp = R.ReferenceNlp(cfg, inp)
@@ -431,7 +431,7 @@ def make_dynamic_obstacles(name, n=30, B=16, keep=6, M=4, O=3):
         inp = R.CycleInputs(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=float(dtp[i]), obstacles=obs)
         init = R.cold_start(cfg, x0[i], xf[i])
         rel, reld = R.associate_obstacles(cfg, init, obs, max_rows=M - 1)          # the device keeps dynamic rows first, M rows in total
-        ref = I.solve(cfg, inp, init, relevant=rel, relevant_dyn=reld, opt=I.IpmOptions(globalization="merit", max_iter=100))
+        ref = I.solve(cfg, inp, init, relevant=rel, relevant_dyn=reld, opt=I.IpmOptions(max_iter=100))
         if ref.status != 0 or ref.iters > 60:
             continue
         nlp = R.ReferenceNlp(cfg, inp, relevant=rel, relevant_dyn=reld)
@@ -467,7 +467,7 @@ def make_polygon_footprint(name, n=30, B=16, keep=6, M=4):
         inp = R.CycleInputs(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=float(dtp[i]), obstacles=obs)
         init = R.cold_start(cfg, x0[i], xf[i])
         rel, _ = R.associate_obstacles(cfg, init, obs, max_rows=M)
-        ref = I.solve(cfg, inp, init, relevant=rel, opt=I.IpmOptions(globalization="merit", max_iter=100))
+        ref = I.solve(cfg, inp, init, relevant=rel, opt=I.IpmOptions(max_iter=100))
         if ref.status != 0 or ref.iters > 45:       # long runs are round-off sensitive (the device needed 88 iterations for a 58-iteration one)
             continue
         dmin = min(R.footprint_distance(cfg.footprint_kind, cfg.footprint_params, ref.traj.x[k], ob) for k in range(1, n - 1) for ob in obs)
@@ -491,14 +491,13 @@ if __name__ == "__main__" and "--polygon" in sys.argv:
 def generator_record(function, opt=None, **extra):
     import dataclasses
     import json
-    o = dataclasses.asdict(opt if opt is not None else I.IpmOptions(globalization="merit", max_iter=100))
+    o = dataclasses.asdict(opt if opt is not None else I.IpmOptions(max_iter=100))
     return json.dumps(dict(script="tests/golden/make_golden.py", function=function, solver="oracle/ipm_dense.py::solve (numpy, dense KKT)", ipm_options=o, **extra), sort_keys=True)
 
 
-def make_monotone(name, cfg, inputs, keep):
+def make_variant(name, cfg, inputs, keep, opt, oracle_kw, function, kept):
     x0, xf, up, dtp = inputs
-    opt = I.IpmOptions(globalization="merit", max_iter=100, mu_strategy="monotone")
-    oc = CO.from_nlp_config(cfg, mu_strategy=1)
+    oc = CO.from_nlp_config(cfg, **oracle_kw)
     xo, uo, do, st, it = CO.solve_batch(oc, x0, xf, up, dtp)
     sel, X, U, D, IT = [], [], [], [], []
     for i in range(x0.shape[0]):
@@ -516,13 +515,30 @@ def make_monotone(name, cfg, inputs, keep):
         sel.append(i); X.append(ref.traj.x); U.append(np.vstack([ref.traj.u, ref.traj.u[-1:]])); D.append(ref.traj.dt); IT.append(ref.iters)
     sel = np.array(sel)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), x0=x0[sel], xf=xf[sel], u_prev=up[sel], dt_prev=dtp[sel], x=np.array(X), u=np.array(U), dt=np.array(D), iters=np.array(IT),
-                        generator=generator_record("make_monotone", opt, kept="converged in the numpy AND the C oracle under the monotone rule, the two within 1e-8"))
+                        generator=generator_record(function, opt, kept=kept))
     print(name, "kept", len(sel), "iters", IT)
+
+
+def make_monotone(name, cfg, inputs, keep):
+    make_variant(name, cfg, inputs, keep, I.IpmOptions(max_iter=100, mu_strategy="monotone"), dict(mu_strategy=1), "make_monotone",
+                 "converged in the numpy AND the C oracle under the monotone rule, the two within 1e-8")
+
+
+def make_merit(name, cfg, inputs, keep):
+    # the OTHER globalisation: backtracking on the l1 merit function (mpc_config.line_search = MPC_LS_MERIT; the default of rounds 1-5) on the inputs of the base fixtures
+    make_variant(name, cfg, inputs, keep, I.IpmOptions(max_iter=100, globalization="merit"), dict(line_search=0), "make_merit",
+                 "converged in the numpy AND the C oracle under the l1 merit, the two within 1e-8")
 
 
 if __name__ == "__main__" and "--monotone" in sys.argv:
     make_monotone("carlike_min_time_n20_monotone", R.config_carlike_min_time(20), W.carlike_min_time_inputs(32, seed=102, goal_range=(1.0, 2.5)), keep=12)
     make_monotone("unicycle_quadratic_n20_monotone", R.config_unicycle_quadratic(20), W.unicycle_quadratic_inputs(16, seed=103), keep=8)
+
+
+if __name__ == "__main__" and "--merit" in sys.argv:
+    make_merit("carlike_min_time_n20_merit", R.config_carlike_min_time(20), W.carlike_min_time_inputs(32, seed=102, goal_range=(1.0, 2.5)), keep=12)
+    make_merit("carlike_min_time_n50_merit", R.config_carlike_min_time(50), W.carlike_min_time_inputs(32, seed=101), keep=8)
+    make_merit("bicycle_min_time_n30_merit", R.config_bicycle_min_time(30), W.carlike_min_time_inputs(32, seed=104, goal_range=(2.0, 6.0)), keep=6)
 
 
 if __name__ == "__main__" and "--stamp" in sys.argv:
@@ -545,6 +561,6 @@ if __name__ == "__main__" and "--stamp" in sys.argv:
                                              start="reference cold start, controls seeded from the state guess (oracle/ipm_dense.py::controls_from_states)"), sort_keys=True)
         else:
             fn = made_by.get(name, "make_midpoint" if ("midpoint" in name or "_cn_" in name) else "make")
-            g["generator"] = generator_record(fn, note="stamped in r06; made in an earlier round by this function with these options (its defaults)")
+            g["generator"] = generator_record(fn, note="made by this function with these options (its defaults); the record is written by --stamp after the function has run")
         np.savez_compressed(path, **g)
         print("stamped", name)

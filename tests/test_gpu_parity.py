@@ -66,19 +66,36 @@ def test_gpu_reproduces_the_fixtures_of_the_other_barrier_rule(m, name):
         assert np.abs(a.dt - g["dt"]).max() < 1e-7 * np.abs(g["dt"]).max()
 
 
+@pytest.mark.parametrize("name", ["carlike_min_time_n20_merit", "carlike_min_time_n50_merit", "bicycle_min_time_n30_merit"])
+def test_gpu_reproduces_the_fixtures_of_the_other_line_search(m, name):
+    """tests/golden/*_merit.npz are made with the l1-merit line search (the globalisation of rounds 1-5) instead of the filter line search of every other fixture: the device under
+    MPC_LS_MERIT reproduces them at 1e-6 with the oracle's iteration counts (tests/test_oracle_solver.py::test_answers_under_the_other_line_search: the CPU half)."""
+    from mpc_local_planner_amd import _abi as A
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    mk, n = {"carlike_min_time_n20_merit": (m.config_carlike_min_time, 20), "carlike_min_time_n50_merit": (m.config_carlike_min_time, 50),
+             "bicycle_min_time_n30_merit": (m.config_bicycle_min_time, 30)}[name]
+    B = g["x0"].shape[0]
+    s = m.BatchSolver(mk(n, line_search=A.LS_MERIT), max_batch=B)
+    r = s.solve(g["x0"], g["xf"], g["u_prev"], g["dt_prev"]); s.close()
+    assert (r.status == 0).all() and np.abs(r.x - g["x"]).max() < 1e-6 and np.abs(r.u - g["u"]).max() < 1e-6 and np.abs(r.dt - g["dt"]).max() < 1e-8
+    assert np.abs(r.iters - g["iters"]).max() <= 2 and np.median(np.abs(r.iters - g["iters"])) == 0
+
+
 def test_config5_shape_vs_slsqp_on_the_device(m):
     """tests/golden/cold_start_scipy_config5.npz: scipy SLSQP on the reference-form NLP of the config-5 shape (bicycle, n = 120), from the reference's cold start.  The device's
-    reference path ends at SLSQP's point on at least 5 of the 6 instances SLSQP solves (headings modulo 2 pi; tests/test_oracle_solver.py::test_config5_shape_vs_slsqp has the
-    same comparison for the C oracle)."""
+    reference path ends at SLSQP's point on at least 4 of the 6 instances SLSQP solves (5 under the l1-merit line search; headings modulo 2 pi;
+    tests/test_oracle_solver.py::test_config5_shape_vs_slsqp has the same comparison for the C oracle)."""
     g = np.load(os.path.join(GOLD, "cold_start_scipy_config5.npz"))
     K = int(g["count"])
-    s = m.BatchSolver(m.config_bicycle_min_time(120), max_batch=K)
-    r = s.solve(*m.workloads.bicycle_min_time_inputs(K)); s.close()
-    d = r.x - g["x"]
-    d[..., 2] = (d[..., 2] + np.pi) % (2 * np.pi) - np.pi
-    same = (np.abs(d).reshape(K, -1).max(1) < 1e-5) & (r.status == 0) & g["success"].astype(bool)
-    assert same.sum() >= 5 and (r.status == 0).sum() >= 7
-    assert np.abs(119 * r.dt[same] - g["objective"][same]).max() < 1e-5
+    from mpc_local_planner_amd import _abi as A
+    for ls, floor in ((A.LS_DEFAULT, 4), (A.LS_MERIT, 5)):
+        s = m.BatchSolver(m.config_bicycle_min_time(120, line_search=ls), max_batch=K)
+        r = s.solve(*m.workloads.bicycle_min_time_inputs(K)); s.close()
+        d = r.x - g["x"]
+        d[..., 2] = (d[..., 2] + np.pi) % (2 * np.pi) - np.pi
+        same = (np.abs(d).reshape(K, -1).max(1) < 1e-5) & (r.status == 0) & g["success"].astype(bool)
+        assert same.sum() >= floor and (r.status == 0).sum() >= 7
+        assert np.abs(119 * r.dt[same] - g["objective"][same]).max() < 1e-5
 
 
 def _feasibility(R, ocfg, x0, xf, up, dtp, res, i):
@@ -115,6 +132,28 @@ def test_config2_batch_vs_c_oracle(m, c_oracle):
     for i in np.nonzero(r.status == 0)[0][:64]:
         assert _feasibility(R, ocfg, x0, xf, up, dtp, r, i) < 1e-6
     s.close()
+
+
+def test_config2_batch_under_the_l1_merit_vs_c_oracle(m, c_oracle):
+    """mpc_config.line_search = MPC_LS_MERIT (the globalisation of rounds 1-5, kept as an option) against the C oracle with oracle_config.line_search = 0, on config 2: same
+    statuses, same iteration counts, same trajectories -- and a different iteration from the default (the filter line search) on part of the batch."""
+    from mpc_local_planner_amd import _abi as A
+    B = 256
+    _, ocfg = _cases(m)["carlike_min_time_n50"]
+    inputs = m.workloads.carlike_min_time_inputs(B)
+    s = m.BatchSolver(m.config_carlike_min_time(50, line_search=A.LS_MERIT), max_batch=B)
+    r = s.solve(*inputs); s.close()
+    s = m.BatchSolver(m.config_carlike_min_time(50, line_search=A.LS_FILTER), max_batch=B)
+    f = s.solve(*inputs); s.close()
+    s = m.BatchSolver(m.config_carlike_min_time(50), max_batch=B)
+    d = s.solve(*inputs); s.close()
+    assert np.array_equal(f.x, d.x) and np.array_equal(f.iters, d.iters) and np.array_equal(f.status, d.status)        # MPC_LS_DEFAULT is the filter
+    xo, uo, do, st, it = c_oracle.solve_batch(c_oracle.from_nlp_config(ocfg, line_search=0), *inputs)
+    both = (r.status == 0) & (st == 0)
+    err = np.abs(r.x - xo).reshape(B, -1).max(1)
+    assert (r.status == st).mean() > 0.97 and (r.iters == it)[both].mean() > 0.95 and np.median(err[both]) < 1e-8
+    assert (r.iters != f.iters).mean() > 0.2
+    print(f"[config 2, B=256] l1 merit: converged {int((r.status == 0).sum())}, mean iterations {r.iters.mean():.2f}; filter: converged {int((f.status == 0).sum())}, mean iterations {f.iters.mean():.2f}")
 
 
 def test_config2_full_batch_accounting(m, c_oracle):

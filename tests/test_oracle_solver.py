@@ -20,7 +20,7 @@ OCFG = {
 
 
 def _ipm(cfg, inp, **kw):
-    return I.solve(cfg, inp, R.cold_start(cfg, inp.x0, inp.xf), opt=I.IpmOptions(globalization="merit", max_iter=100, **kw))
+    return I.solve(cfg, inp, R.cold_start(cfg, inp.x0, inp.xf), opt=I.IpmOptions(max_iter=100, **kw))
 
 
 def _slsqp_polish(cfg, inp, traj):
@@ -111,6 +111,34 @@ def test_every_solver_fixture_records_how_it_was_made():
             assert rec["ipm_options"]["mu_strategy"] in ("adaptive", "monotone") and rec["ipm_options"]["tol"] == 1e-8, path
 
 
+MERIT = {"carlike_min_time_n20_merit": lambda: R.config_carlike_min_time(20), "carlike_min_time_n50_merit": lambda: R.config_carlike_min_time(50),
+         "bicycle_min_time_n30_merit": lambda: R.config_bicycle_min_time(30)}
+
+
+@pytest.mark.parametrize("name", sorted(MERIT))
+def test_answers_under_the_other_line_search(name, c_oracle):
+    """tests/golden/*_merit.npz are made with the l1-MERIT line search (oracle_config.line_search = 0 / IpmOptions.globalization = "merit" / MPC_LS_MERIT: the globalisation of
+    rounds 1-5) on the inputs of the base fixtures.  (1) Under the merit the C oracle and the numpy oracle reproduce them (same iterate sequence).  (2) The default solvers (Ipopt's
+    filter line search) end, from the same start, at the same minimum on most instances -- same travel time to 1e-7 relative, states within 1e-4 --; where they do not, both
+    answers are local minima of a multi-modal NLP (another travel time), which the test counts instead of hiding."""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    cfg = MERIT[name]()
+    B = g["x0"].shape[0]
+    xo, uo, do, st, it = c_oracle.solve_batch(c_oracle.from_nlp_config(cfg, line_search=0), g["x0"], g["xf"], g["u_prev"], g["dt_prev"])
+    assert (st == 0).all() and np.abs(xo - g["x"]).max() < 1e-6 and np.abs(uo - g["u"]).max() < 1e-6 and np.abs(do - g["dt"]).max() < 1e-8 and np.abs(it - g["iters"]).max() <= 1
+    for i in range(2):
+        inp = R.CycleInputs(x0=g["x0"][i], xf=g["xf"][i], u_prev=g["u_prev"][i], dt_prev=float(g["dt_prev"][i]))
+        res = I.solve(cfg, inp, R.cold_start(cfg, g["x0"][i], g["xf"][i]), opt=I.IpmOptions(max_iter=100, globalization="merit"))
+        assert res.status == 0 and np.abs(res.traj.x - g["x"][i]).max() < 1e-6 and res.iters == g["iters"][i]
+    xa, ua, da, sa, ia = c_oracle.solve_batch(c_oracle.from_nlp_config(cfg), g["x0"], g["xf"], g["u_prev"], g["dt_prev"])      # the default: filter
+    assert (sa == 0).all()
+    same_T = np.abs(da - g["dt"]) < 1e-7 * np.abs(g["dt"])
+    ex = np.abs(xa - g["x"]).reshape(B, -1).max(1)
+    print(f"[{name}] filter vs merit answers: same travel time on {int(same_T.sum())} of {B}, max |x| difference there {ex[same_T].max():.1e}; iterations merit {g['iters'].tolist()} filter {ia.tolist()}")
+    assert same_T.sum() >= B - 1 and ex[same_T].max() < 1e-4
+    assert (ia != g["iters"]).any()              # the two line searches are different iterations
+
+
 MONOTONE = {"carlike_min_time_n20_monotone": lambda: R.config_carlike_min_time(20), "unicycle_quadratic_n20_monotone": lambda: R.config_unicycle_quadratic(20)}
 
 
@@ -129,7 +157,7 @@ def test_answers_under_the_other_barrier_rule(name, c_oracle):
     assert (st == 0).all() and np.abs(xo - g["x"]).max() < 1e-6 and np.abs(uo - g["u"]).max() < 1e-6 and np.abs(do - g["dt"]).max() < 1e-8 and np.abs(it - g["iters"]).max() <= 1
     for i in range(2):
         inp = R.CycleInputs(x0=g["x0"][i], xf=g["xf"][i], u_prev=g["u_prev"][i], dt_prev=float(g["dt_prev"][i]))
-        res = I.solve(cfg, inp, R.cold_start(cfg, g["x0"][i], g["xf"][i]), opt=I.IpmOptions(globalization="merit", max_iter=100, mu_strategy="monotone"))
+        res = I.solve(cfg, inp, R.cold_start(cfg, g["x0"][i], g["xf"][i]), opt=I.IpmOptions(max_iter=100, mu_strategy="monotone"))
         assert res.status == 0 and np.abs(res.traj.x - g["x"][i]).max() < 1e-6 and np.abs(res.traj.u - g["u"][i, :-1]).max() < 1e-6
     xa, ua, da, sa, ia = c_oracle.solve_batch(c_oracle.from_nlp_config(cfg), g["x0"], g["xf"], g["u_prev"], g["dt_prev"])      # the default: adaptive
     assert (sa == 0).all()
@@ -191,7 +219,7 @@ def test_numpy_ipm_with_obstacle_rows_reproduces_golden_and_keeps_clearance():
         init = R.cold_start(cfg, inp.x0, inp.xf)
         rel, _ = R.associate_obstacles(cfg, init, obs, max_rows=M)
         assert max(len(q) for q in rel) <= M and rel[0] == []
-        res = I.solve(cfg, inp, init, relevant=rel, opt=I.IpmOptions(globalization="merit", max_iter=100))
+        res = I.solve(cfg, inp, init, relevant=rel, opt=I.IpmOptions(max_iter=100))
         assert res.status == 0
         assert np.abs(res.traj.x - g["x"][i]).max() < 1e-6
         # reference-form rows: d_min - dist <= 0 for every associated obstacle
@@ -208,7 +236,7 @@ def test_dual_start_lands_on_the_same_solution():
     cfg = R.config_carlike_min_time(20)
     i, per = 3, 0.2
     inp = R.CycleInputs(x0=g["x0"][i], xf=g["xf"][i], u_prev=g["u_prev"][i], dt_prev=float(g["dt_prev"][i]))
-    r1 = I.solve(cfg, inp, R.cold_start(cfg, inp.x0, inp.xf), opt=I.IpmOptions(globalization="merit", max_iter=100))
+    r1 = I.solve(cfg, inp, R.cold_start(cfg, inp.x0, inp.xf), opt=I.IpmOptions(max_iter=100))
     assert r1.status == 0 and r1.piL is not None
     u0 = r1.traj.u[0]
     x1 = inp.x0 + per * R.dynamics(cfg.model, cfg.model_params, inp.x0, u0)
@@ -216,7 +244,7 @@ def test_dual_start_lands_on_the_same_solution():
     init = R.Trajectory(r1.traj.x.copy(), r1.traj.u.copy(), r1.traj.dt)
     init.x[0] = x1
     inp2 = R.CycleInputs(x0=x1, xf=g["xf"][i], u_prev=u0, dt_prev=per)
-    opt = I.IpmOptions(globalization="merit", max_iter=100, mu_init=1e-3)
+    opt = I.IpmOptions(max_iter=100, mu_init=1e-3)
     a = I.solve(cfg, inp2, init, opt=opt)
     b = I.solve(cfg, inp2, init, opt=opt, dual_start=r1)
     assert a.status == 0 and b.status == 0
@@ -290,7 +318,7 @@ def test_numpy_oracle_reproduces_via_point_and_terminal_ball_goldens(name):
             vps = g["via"][i, :int(g["n_via"][i])]
             inp = R.CycleInputs(x0=g["x0"][i], xf=g["xf"][i], u_prev=g["u_prev"][i], dt_prev=float(g["dt_prev"][i]), via_points=vps)
             assert R.associate_via_points(cfg, R.cold_start(cfg, g["x0"][i], g["xf"][i]).x, vps) == list(g["idx"][i, :len(vps)])
-        r = I.solve(cfg, inp, R.cold_start(cfg, g["x0"][i], g["xf"][i]), opt=I.IpmOptions(globalization="merit", max_iter=100))
+        r = I.solve(cfg, inp, R.cold_start(cfg, g["x0"][i], g["xf"][i]), opt=I.IpmOptions(max_iter=100))
         assert r.status == 0 and r.iters == g["iters"][i]
         assert np.abs(r.traj.x - g["x"][i]).max() < 1e-9 and abs(r.traj.dt - g["dt"][i]) < 1e-10
 
@@ -542,7 +570,7 @@ def test_numpy_and_c_oracle_agree_on_unfiltered_config2_instances(c_oracle):
     hard = parted = 0
     for i in pick:
         inp = R.CycleInputs(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=float(dtp[i]))
-        r = I.solve(ocfg, inp, R.cold_start(ocfg, x0[i], xf[i]), opt=I.IpmOptions(globalization="merit", max_iter=100))
+        r = I.solve(ocfg, inp, R.cold_start(ocfg, x0[i], xf[i]), opt=I.IpmOptions(max_iter=100))
         if r.status != o[3][i]:
             assert o[4][i] > 45 or r.iters > 45, (i, r.status, o[3][i])      # a slow run may end on either side of the cap
             parted += 1
@@ -655,14 +683,16 @@ def test_near_goal_stall_and_the_acceptable_level_stop():
     WITHOUT Ipopt's acceptable-level stop the solve stands at 6e-8 after 13 iterations (1.2e-8 after 15 with the monotone barrier rule): the terminal rows'
     dual regularisation leaves a residual the Newton step cannot remove, the merit function's predicted decrease counts on removing it, and the line search
     refuses what follows -- the solve ends in a line-search failure (monotone rule: at max_iter).  At tol 1e-5 it converges; with the stop (the default of all
-    three solvers: IpmOptions.acceptable_tol / oracle_config / mpc_config) it ends at that 13th iterate with status 0, and the answers agree to 5e-6."""
+    three solvers: IpmOptions.acceptable_tol / oracle_config / mpc_config) it ends at that 13th iterate with status 0, and the answers agree to 5e-6.
+    This is the l1-MERIT line search (mpc_config.line_search = MPC_LS_MERIT, the default of rounds 1-5); the filter line search (the default since r06) does not
+    stall here: it reaches tol 1e-8 with the stop switched off (last lines)."""
     cfg = R.config_carlike_min_time(4)
     inp = R.CycleInputs(x0=np.array([1.836, 0.676, 0.366]), xf=np.array([2.087, 0.769, 0.2927]), u_prev=np.array([0.4, 0.0]), dt_prev=0.1)
-    stalled = _ipm(cfg, inp, acceptable_tol=0.0)
-    loose = _ipm(cfg, inp, tol=1e-5)
-    stopped = _ipm(cfg, inp)
-    mono = _ipm(cfg, inp, mu_strategy="monotone")
-    mono_stalled = _ipm(cfg, inp, mu_strategy="monotone", acceptable_tol=0.0)
+    stalled = _ipm(cfg, inp, acceptable_tol=0.0, globalization="merit")
+    loose = _ipm(cfg, inp, tol=1e-5, globalization="merit")
+    stopped = _ipm(cfg, inp, globalization="merit")
+    mono = _ipm(cfg, inp, mu_strategy="monotone", globalization="merit")
+    mono_stalled = _ipm(cfg, inp, mu_strategy="monotone", acceptable_tol=0.0, globalization="merit")
     # the stall sits at the rounding level of the merit function: on this container's BLAS it is there; the C solver's test below, whose arithmetic does
     # not depend on the machine, is the one that insists on it
     assert stalled.status in (0, 1, 2) and stalled.kkt_error < 1e-4
@@ -677,28 +707,32 @@ def test_near_goal_stall_and_the_acceptable_level_stop():
         assert np.abs(stopped.traj.u - other.traj.u).max() < 5e-6
         assert abs(stopped.traj.dt - other.traj.dt) < 5e-6
     # Ipopt's defaults
-    assert I.IpmOptions().acceptable_tol == 1e-6 and I.IpmOptions().acceptable_iter == 15
+    assert I.IpmOptions().acceptable_tol == 1e-6 and I.IpmOptions().acceptable_iter == 15 and I.IpmOptions().globalization == "filter"
+    filt = _ipm(cfg, inp, acceptable_tol=0.0)
+    assert filt.status == 0 and filt.iters <= 20 and filt.kkt_error <= 1e-8 and np.abs(filt.traj.x - stopped.traj.x).max() < 5e-6
 
 
 def test_near_goal_stall_in_the_c_solver_and_its_acceptable_level_stop(c_oracle):
-    """The same instance in the C solver: no success with the rule switched off (acceptable_tol < 0), 13 iterations with it (the default), same point
-    as numpy; and the headline workload is untouched by the rule: bit-identical trajectories, statuses and iteration counts on 256 cold starts."""
+    """The same instance in the C solver under the l1 merit (oracle_config.line_search = 0): no success with the rule switched off (acceptable_tol < 0), 13 iterations with
+    it (the default), same point as numpy; under the filter (the default line search) the instance converges to tol without the rule; and the headline workload is untouched by the rule: bit-identical trajectories, statuses and iteration counts on 256 cold starts."""
     cfg = R.config_carlike_min_time(4)
     x0, xf = np.array([[1.836, 0.676, 0.366]]), np.array([[2.087, 0.769, 0.2927]])
     up, dtp = np.array([[0.4, 0.0]]), np.array([0.1])
-    off = c_oracle.from_nlp_config(cfg, max_iter=100, tol=1e-8, acceptable_tol=-1.0)
-    on = c_oracle.from_nlp_config(cfg, max_iter=100, tol=1e-8)
-    ref = _ipm(cfg, R.CycleInputs(x0=x0[0], xf=xf[0], u_prev=up[0], dt_prev=0.1))
+    off = c_oracle.from_nlp_config(cfg, max_iter=100, tol=1e-8, acceptable_tol=-1.0, line_search=0)
+    on = c_oracle.from_nlp_config(cfg, max_iter=100, tol=1e-8, line_search=0)
+    ref = _ipm(cfg, R.CycleInputs(x0=x0[0], xf=xf[0], u_prev=up[0], dt_prev=0.1), globalization="merit")
     r = c_oracle.solve_batch(off, x0, xf, up, dtp, nthreads=1)
     assert r[3][0] == 2 and r[4][0] <= 20           # line search failure at the stall (adaptive barrier rule, the default)
-    r = c_oracle.solve_batch(c_oracle.from_nlp_config(cfg, max_iter=100, tol=1e-8, acceptable_tol=-1.0, mu_strategy=1), x0, xf, up, dtp, nthreads=1)
+    r = c_oracle.solve_batch(c_oracle.from_nlp_config(cfg, max_iter=100, tol=1e-8, acceptable_tol=-1.0, mu_strategy=1, line_search=0), x0, xf, up, dtp, nthreads=1)
     assert r[3][0] == 1 and r[4][0] == 100          # the monotone rule creeps on to max_iter
     r = c_oracle.solve_batch(on, x0, xf, up, dtp, nthreads=1)
     assert r[3][0] == 0 and r[4][0] == ref.iters
     assert np.abs(r[0][0] - ref.traj.x).max() < 1e-7 and np.abs(r[1][0][:3] - ref.traj.u).max() < 1e-7 and abs(r[2][0] - ref.traj.dt) < 1e-7
     # a looser level with the counting half: the run ends early, by whichever rule fires first
-    r = c_oracle.solve_batch(c_oracle.from_nlp_config(cfg, max_iter=100, tol=1e-8, acceptable_tol=1e-5, acceptable_iter=15), x0, xf, up, dtp, nthreads=1)
+    r = c_oracle.solve_batch(c_oracle.from_nlp_config(cfg, max_iter=100, tol=1e-8, acceptable_tol=1e-5, acceptable_iter=15, line_search=0), x0, xf, up, dtp, nthreads=1)
     assert r[3][0] == 0 and r[4][0] <= 30
+    r = c_oracle.solve_batch(c_oracle.from_nlp_config(cfg, max_iter=100, tol=1e-8, acceptable_tol=-1.0), x0, xf, up, dtp, nthreads=1)
+    assert r[3][0] == 0 and r[4][0] <= 20           # the filter line search: no stall
     # headline workload (config 2): the rule changes nothing
     from mpc_local_planner_amd import workloads as W
     cfg2 = R.config_carlike_min_time(50)
@@ -748,13 +782,17 @@ def test_kkt_checker_takes_the_clearance_rows_of_the_trajectory_a_solve_started_
     assert len(not_cold) >= 1          # the distinction is real on this workload
 
 
-def test_restoration_for_jammed_clearance_rows_in_both_cpu_solvers(c_oracle):
+@pytest.mark.parametrize("ls", ["filter", "merit"])
+def test_restoration_for_jammed_clearance_rows_in_both_cpu_solvers(c_oracle, ls):
     """r05: clearance rows that jam -- five iterations in a row whose fraction-to-boundary limit on the primal step is below 0.05 with the infeasibility still at
     80 % -- turn elastic (g + s - e = 0, e >= 0, + 1000 e).  Car-like minimum time, n = 30, three point obstacles 0.05 .. 0.5 m beside the path (d_min 0.3: most rows start violated),
     64 instances, reference path alone.  (i) The mode changes the outcome of some instances and ONLY helps the converged count: instances that ran into the iteration limit converge.
     (ii) Along the restoration path the dense numpy solver and the banded-LU C solver -- two implementations of the rule, two linear algebras -- produce the same iterate sequence:
     same iteration counts, trajectories equal to 1e-6 (they are equal to 1e-13 on most).  (iii) What is returned is a KKT point of the reference-form NLP with the frozen rows
-    (oracle/kkt_check.py), i.e. the elastic variables ended at zero."""
+    (oracle/kkt_check.py), i.e. the elastic variables ended at zero.
+    (i) is the statement for the l1-merit line search the mode was built under (r05).  Under the filter line search (the default since r06) this small workload converges 63 of 64
+    either way (one instance each way ends at the iteration limit); what the mode is worth there shows on the harder workloads (moving obstacle + polygon footprint: 58 % without,
+    93 % with) -- here the filter half checks (ii) and (iii) and that the converged count does not fall."""
     import ctypes as C
     from oracle import kkt_check as KC
     import mpc_local_planner_amd.workloads as W
@@ -769,24 +807,28 @@ def test_restoration_for_jammed_clearance_rows_in_both_cpu_solvers(c_oracle):
     ocfg.min_obstacle_dist, ocfg.force_inclusion_dist, ocfg.cutoff_dist = 0.3, 0.5, 2.5
     ob = c_oracle.obst_from_nlp_config(ocfg, O, 1, 4)
     lib = c_oracle._load()
-    on = c_oracle.solve_batch(c_oracle.from_nlp_config(ocfg), x0, xf, up, dtp, obstacles=obstacles, obst=ob)
+    on = c_oracle.solve_batch(c_oracle.from_nlp_config(ocfg, line_search=0 if ls == "merit" else 1), x0, xf, up, dtp, obstacles=obstacles, obst=ob)
     try:
         lib.oracle_set_algo(C.c_int(10), C.c_double(0.0))                  # experiment switch: restoration off
-        off = c_oracle.solve_batch(c_oracle.from_nlp_config(ocfg), x0, xf, up, dtp, obstacles=obstacles, obst=ob)
+        off = c_oracle.solve_batch(c_oracle.from_nlp_config(ocfg, line_search=0 if ls == "merit" else 1), x0, xf, up, dtp, obstacles=obstacles, obst=ob)
     finally:
         lib.oracle_set_algo(C.c_int(10), C.c_double(1000.0))
     changed = np.flatnonzero((on[3] != off[3]) | (on[4] != off[4]))
-    print(f"[restoration, CPU] converged without / with: {int((off[3] == 0).sum())} / {int((on[3] == 0).sum())} of {B}; instances whose iterate path it changes: "
+    print(f"[restoration, CPU, {ls}] converged without / with: {int((off[3] == 0).sum())} / {int((on[3] == 0).sum())} of {B}; instances whose iterate path it changes: "
           f"{[(int(i), int(off[3][i]), int(off[4][i]), int(on[3][i]), int(on[4][i])) for i in changed]}")
-    assert len(changed) >= 4 and (on[3] == 0).sum() >= (off[3] == 0).sum() + 2
-    assert not ((off[3] == 0) & (on[3] != 0)).any()                        # nothing that converged without the mode is lost with it
+    assert len(changed) >= 4
+    if ls == "merit":
+        assert (on[3] == 0).sum() >= (off[3] == 0).sum() + 2
+        assert not ((off[3] == 0) & (on[3] != 0)).any()                    # nothing that converged without the mode is lost with it
+    else:
+        assert (on[3] == 0).sum() >= (off[3] == 0).sum() and (on[3] == 0).sum() >= B - 1
     same_it, checked = 0, 0
     for i in [int(i) for i in changed if on[3][i] == 0][:5]:
         obs = [R.Obstacle(R.OBST_POINT, pts[i, o:o + 1]) for o in range(O)]
         inp = R.CycleInputs(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=float(dtp[i]), obstacles=obs)
         init = R.cold_start(ocfg, x0[i], xf[i])
         rel, _ = R.associate_obstacles(ocfg, init, obs, max_rows=4)
-        ref = I.solve(ocfg, inp, init, relevant=rel, opt=I.IpmOptions(globalization="merit", max_iter=100))
+        ref = I.solve(ocfg, inp, init, relevant=rel, opt=I.IpmOptions(max_iter=100, globalization=ls))
         assert ref.status == 0
         assert np.abs(ref.traj.x - on[0][i]).max() < 1e-4 and abs(ref.traj.dt - on[2][i]) < 1e-8
         same_it += int(ref.iters == on[4][i]); checked += 1
@@ -897,8 +939,9 @@ def _same_point_mod_2pi(xa, xb, tol):
 def test_config5_shape_vs_slsqp(c_oracle):
     """ The config-5 SHAPE (kinematic bicycle, n = 120, goals 5 .. 40 m) against an independent solver from the same cold start:
     tests/golden/cold_start_scipy_config5.npz (scipy SLSQP on the reference-form NLP, 8 instances, ~1-10 min each).  SLSQP succeeds on 6 of 8; the C oracle's reference path
-    converges on all 8; on 5 of SLSQP's 6 the two end at the SAME point (headings modulo 2 pi, 1e-5), the sixth is another local minimum of this multi-modal NLP (travel time
-    179.65 s against SLSQP's 165.53 s); where SLSQP gives up, the interior-point answer is feasible with a lower travel time than SLSQP's last iterate."""
+    converges on all 8; on 4 of SLSQP's 6 the two end at the SAME point (headings modulo 2 pi, 1e-5; 5 of 6 under the l1-merit line search, checked too), the others are other
+    local minima of this multi-modal NLP (travel times 12 ms and 14.1 s above SLSQP's); where SLSQP gives up, the interior-point answer is feasible with a lower travel time than
+    SLSQP's last iterate."""
     from mpc_local_planner_amd import workloads as W
     g = np.load(os.path.join(GOLD, "cold_start_scipy_config5.npz"))
     K = int(g["count"])
@@ -911,8 +954,10 @@ def test_config5_shape_vs_slsqp(c_oracle):
     obj = (cfg.n - 1) * do
     print(f"[config-5 shape vs SLSQP] SLSQP succeeded on {int(ok.sum())} of {K}; the C oracle converged on {int((st == 0).sum())}; same point (headings mod 2 pi) on {int(same.sum())} of SLSQP's; "
           f"travel time oracle - SLSQP where both have an answer: {np.round((obj - g['objective'])[ok & (st == 0)], 4).tolist()}")
-    assert same.sum() >= 5
+    assert same.sum() >= 4
     assert np.abs(obj[same] - g["objective"][same]).max() < 1e-5
+    xm, _, dm, stm, _ = c_oracle.solve_batch(c_oracle.from_nlp_config(cfg, max_iter=100, line_search=0), x0, xf, up, dtp)
+    assert (_same_point_mod_2pi(xm, g["x"], 1e-5) & (stm == 0) & ok).sum() >= 5
     both = ok & (st == 0) & ~same
     assert (g["violation"][ok] < 1e-8).all()
     for i in np.where(~ok & (st == 0))[0]:          # SLSQP gave up: our answer must at least be feasible and not worse than where SLSQP stopped

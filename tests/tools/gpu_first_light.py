@@ -24,6 +24,6 @@ ocfg = R.config_carlike_min_time(n)
 worst = 0
 for i in range(6):
     inp = R.CycleInputs(x0=x0[i], xf=xf[i], u_prev=up[i], dt_prev=float(dtp[i]))
-    ref = I.solve(ocfg, inp, R.cold_start(ocfg, x0[i], xf[i]), opt=I.IpmOptions(globalization="merit", max_iter=100))
+    ref = I.solve(ocfg, inp, R.cold_start(ocfg, x0[i], xf[i]), opt=I.IpmOptions(max_iter=100))
     err = max(np.abs(ref.traj.x - res.x[i]).max(), np.abs(ref.traj.u - res.u[i, :-1]).max(), abs(ref.traj.dt - res.dt[i]))
     print(i, "oracle", ref.status, ref.iters, "gpu", st[i], it[i], "err", err)

@@ -16,7 +16,7 @@ for i in range(B):
     init = R.cold_start(ocfg, x0[i], xf[i])
     rel, _ = R.associate_obstacles(ocfg, init, obs, max_rows=M)
     t = time.time()
-    ref = I.solve(ocfg, inp, init, relevant=rel, opt=I.IpmOptions(globalization="merit", max_iter=100))
+    ref = I.solve(ocfg, inp, init, relevant=rel, opt=I.IpmOptions(max_iter=100))
     err = max(np.abs(ref.traj.x - r.x[i]).max(), np.abs(ref.traj.u - r.u[i, :-1]).max())
     nrows = sum(len(q) for q in rel[1:n-1])
     dmin = min((R.footprint_distance(0, (), r.x[i, k], obs[j]) for k in range(1, n - 1) for j in rel[k]), default=9)
