@@ -786,9 +786,11 @@ struct Ipm {
                 theta_max = Algo<T>::flt_thmax * t_max(T(1), theta0); theta_min = Algo<T>::flt_thmin * t_max(T(1), theta0);
                 a_min = Algo<T>::flt_gth;
                 if (fw.dphi < T(0)) {
-                    p_ph = t_pow(-fw.dphi, Algo<T>::flt_sph); p_th = t_pow(theta, Algo<T>::flt_sth);
                     a_min = t_min(a_min, Algo<T>::flt_gph * theta / (-fw.dphi));
-                    if (theta <= theta_min) a_min = t_min(a_min, Algo<T>::flt_delta * p_th / p_ph);
+                    if (theta <= theta_min) {      // (the powers are only consulted at such a point)
+                        p_ph = t_pow(-fw.dphi, Algo<T>::flt_sph); p_th = t_pow(theta, Algo<T>::flt_sth);
+                        a_min = t_min(a_min, Algo<T>::flt_delta * p_th / p_ph);
+                    }
                 }
                 a_min = a_min * Algo<T>::flt_gal * fw.a_p;
             }
