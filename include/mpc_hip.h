@@ -107,7 +107,7 @@ enum mpc_mu_strategy {
 };
 
 enum mpc_line_search {                /* the globalisation of the interior-point iteration (Ipopt option line_search_method; solver/ipopt/ipopt_string_options, src/controller.cpp:407-418) */
-    MPC_LS_DEFAULT = 0,               /* the library's default: see mpc_problem.hpp (fill_problem) and DESIGN.md section 3 */
+    MPC_LS_DEFAULT = 0,               /* the library's default: MPC_LS_FILTER since 0.6.0 (mpc_problem.hpp::kDefaultLineSearch; DESIGN.md section 3.1a has the measurements) */
     MPC_LS_MERIT = 1,                 /* backtracking on the l1 merit function f - mu sum log + rho theta with Ipopt's penalty-parameter rule (the globalisation of rounds 1-5) */
     MPC_LS_FILTER = 2                 /* Ipopt's own default: the filter line search of Waechter & Biegler (2006), Algorithm A, with its published constants (gamma_theta 1e-5,
                                        * gamma_phi 1e-8, s_phi 2.3, s_theta 1.1, eta_phi 1e-8, delta 1, gamma_alpha 0.05, theta_max / theta_min = 1e4 / 1e-4 x max(1, theta_0));
@@ -217,9 +217,9 @@ typedef struct mpc_config {
                                        * working memory is Ipopt's) */
     int32_t two_wave_min_batch;       /* launches with at least this many instances run the kernel variant for TWO resident waves per SIMD (236 registers, no scratch; fp64, headline
                                        * kernel level without clearance rows, and only where the LDS record fits eight times into a compute unit: about n <= 24 grid points -- the
-                                       * grid sizes of the reference's shipped parameter files).  0 -> the default 8192 (measured on the MI355X: x1.14-1.27 there, x1.4-1.6 at 32768
-                                       * instances; at 4096 x1.10-1.15 for n = 20 / 24 but x0.73 for n = 12; a small launch lasts as long as its slowest wave, which runs fastest
-                                       * alone: x0.85 at 1024); negative -> never.  Results are bit-identical either way.  No counterpart in the reference */
+                                       * grid sizes of the reference's shipped parameter files).  0 -> the default 4096 (measured on the MI355X for n = 12 / 20 / 24: x1.03 / x1.0 / x1.3 there, x1.06 / x1.4 / x1.37
+                                       * at 8192, x1.46 / x1.64 / x1.6 at 32768 instances; below the threshold n = 12 loses -- x0.83 at 2048 -- and n = 20 / 24 gain x1.13 / x1.29: a small
+                                       * launch lasts as long as its slowest wave, which runs fastest alone); negative -> never.  Results are bit-identical either way.  No counterpart in the reference */
     int32_t line_search;              /* enum mpc_line_search (solver/ipopt/ipopt_string_options/line_search_method) */
     /* full weight matrices (state_weights / control_weights / final_state_weights / weight_matrix given as n x n lists, column major,
      * src/controller.cpp:565-573,580-588,656-664,690-698): Q, R, Qf, terminal_ball_S above hold the DIAGONALS, these the off-diagonal terms

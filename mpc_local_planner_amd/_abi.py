@@ -208,7 +208,7 @@ def make_config(model=MODEL_UNICYCLE, model_params=(0.5, 1.0), n=20, dt_ref=0.3,
     c.mu_strategy = int(mu_strategy)          # MU_ADAPTIVE (0, default) | MU_MONOTONE
     c.stage_data = int(stage_data)            # STAGE_AUTO (0, default) | STAGE_LDS | STAGE_GLOBAL
     c.line_search = int(line_search)          # LS_DEFAULT (0) | LS_MERIT | LS_FILTER
-    c.two_wave_min_batch = int(two_wave_min_batch)      # 0: the default threshold (8192 instances per launch), negative: never the two-waves-per-SIMD kernel
+    c.two_wave_min_batch = int(two_wave_min_batch)      # 0: the default threshold (4096 instances per launch), negative: never the two-waves-per-SIMD kernel
     c.hybrid_cost_minimum_time = int(bool(hybrid_cost_minimum_time))
     c.cost_integration = int(cost_integration)
     c.acceptable_tol, c.acceptable_iter = float(acceptable_tol), int(acceptable_iter)      # 0 = Ipopt's defaults (1e-6, 15), negative = off

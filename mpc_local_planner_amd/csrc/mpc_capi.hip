@@ -287,7 +287,7 @@ int mpc_create(const mpc_config* cfg, int32_t max_batch, int32_t device, mpc_sol
     s->w2_gs = false;
     s->wave_lds_w2 = lds_of(s->WL, 8, sizeof(mpc::Problem<double>));
     s->w2_ok = cfg->precision == MPC_FP64 && cfg->stage_data == MPC_STAGE_AUTO && !solver_ext(s) && cfg->max_obstacles <= 0 && s->wave_lds_w2 <= (160u * 1024u) / 8u;
-    s->w2_min_batch = cfg->two_wave_min_batch > 0 ? cfg->two_wave_min_batch : 8192;      // (measured, profiles/r06_w2_probe.log: x1.14-1.27 there, x1.4-1.6 at 32768; at 4096 x1.10-1.15 for n = 20 / 24 but x0.73 for n = 12; x0.85 at 1024)
+    s->w2_min_batch = cfg->two_wave_min_batch > 0 ? cfg->two_wave_min_batch : 4096;      // (measured under the filter line search, profiles/r06_w2_probe.log, n = 12 / 20 / 24: x1.03 / x1.00-1.02 / x1.30-1.34 there, x1.06 / x1.4 / x1.37 at 8192, x1.46 / x1.64 / x1.6 at 32768; below: x0.83 / x1.13 / x1.29 at 2048, x0.81 / x1.02 / x1.02 at 1024 -- a small launch lasts as long as its slowest wave, which runs fastest alone)
     if (cfg->two_wave_min_batch < 0) s->w2_ok = false;
 #ifdef MPC_DEV_SWITCHES
     if (const char* e = getenv("MPC_W2_FORCE")) {      // developer A/B: the 256-register kernel variant whatever the record's size (LDS form)

@@ -11,8 +11,9 @@ identity until the KKT matrix has the inertia (n, m, 0) -- read off LAPACK's
 Bunch-Kaufman factorisation here, off the pivots of the Riccati sweep in the
 product; r01-r03 used the inertia-free curvature test of Chiang & Zavala 2016,
 which lets the iteration converge to saddle points: IpmOptions.inertia_test) in a
-reduced form -- l1-merit backtracking instead of the filter, no restoration
-phase -- with DENSE linear algebra (numpy.linalg) on the full KKT matrix.  The HIP product solves the same Newton systems with a
+reduced form -- the filter line search without second-order corrections (r06;
+IpmOptions.globalization = "merit": the l1-merit backtracking of rounds 1-5), no restoration
+phase (a refused line search empties the filter and takes the shortest trial step) -- with DENSE linear algebra (numpy.linalg) on the full KKT matrix.  The HIP product solves the same Newton systems with a
 stage-structured Riccati sweep; agreement of the two is the parity test.
 
 PARITY UNPINNED for the solve: no Ipopt here and no golden outputs in the reference; the

@@ -1161,7 +1161,9 @@ static void derive_step(work_t* w, const double* cc, double mu, double tau, doub
  * oracle/ipm_dense.py and the kernel run too; everything else is Ipopt machinery that was measured on the BASELINE workloads and not adopted:
  *   mu_oracle      0 step-length rule (the product), 1 Mehrotra's probing oracle (Ipopt mu_oracle=probing: affine-scaling solve with the same factorisation),
  *                  2 LOQO rule (Ipopt mu_oracle=loqo)
- *   globalization  0 l1 merit (the product), 1 Ipopt's filter (Waechter & Biegler 2006, Algorithm A) with max_soc second-order corrections
+ *   globalization  -1 what oracle_config.line_search says (the default; the product: the filter without second-order corrections); forced: 0 l1 merit, 1 Ipopt's filter
+ *                  (Waechter & Biegler 2006, Algorithm A) with max_soc second-order corrections
+ *   rho_mode       (keys 14 / 15, l1 merit only) 1 the smallest admissible penalty every iteration, 2 the penalty may fall by rho_decay per iteration: measured in r06, not adopted
  *   safeguard      adaptive mu: 1 = Ipopt's adaptive_mu_globalization=kkt-error (fixed-mu mode at fix_fact x the average complementarity when the error stalls)
  *   convex_fallback  1: a factorisation that fails the curvature test at delta = 0 is repeated with the stage blocks of lam' D replaced by their positive
  *                  semidefinite parts before any multiple of the identity is added

@@ -642,6 +642,7 @@ def test_occupancy_reported_by_the_runtime(m):
     w_small, lds_small = s.occupancy(1024)
     w_large, lds_large = s.occupancy(8192)
     assert (w_small, w_large) == (4, 8) and lds_small == lds_large == s.lds_bytes()   # the two-waves-per-SIMD kernel from the default threshold on
+    assert s.occupancy(4096)[0] == 8 and s.occupancy(4095)[0] == 4                     # ... which is 4096 instances per launch
     s.close()
     s = m.BatchSolver(m.config_carlike_min_time(20, two_wave_min_batch=-1), max_batch=8192)
     assert s.occupancy(8192)[0] == 4
