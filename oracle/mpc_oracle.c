@@ -1360,6 +1360,10 @@ static void trial_point(work_t* w, double alpha, const double* ds, double* st, d
 #define FCAP 16
 static int g_trace = 0;      /* dev: print one line per iteration (single-threaded use) */
 void oracle_set_trace(int on) { g_trace = on; }
+/* developer counters over all solves since the last reset (tests/tools/dev): [0] iterations, [1] trial points, [2] line searches that refused every trial step, [3] trial points of those */
+static long long g_cnt[4];
+void oracle_counters(long long* out, int reset) { for (int i = 0; i < 4; ++i) { out[i] = g_cnt[i]; if (reset) g_cnt[i] = 0; } }
+#define CNT(i, v) do { _Pragma("omp atomic") g_cnt[i] += (v); } while (0)
 static long g_nfac_total = 0;
 static int g_nfac_max = 0;
 void oracle_set_variant(int v) { g_variant = v; g_nfac_total = 0; g_nfac_max = 0; }
@@ -1717,7 +1721,7 @@ static int solve_one(work_t* w, int warm) {
                 if (ls > 0) alpha *= 0.5;
                 ls_used = ls;
                 double lg;
-                trial_point(w, alpha, ds, st, cct, &ft, &tht, &lg);
+                trial_point(w, alpha, ds, st, cct, &ft, &tht, &lg); CNT(1, 1);
                 double phit = ft - mu * lg + w->rho * tht;
                 if (isfinite(phit) && phit - phi0 - 10 * 2.220446049250313e-16 * fabs(phi0) <= eta * alpha * Dm) { accepted = 1; break; }
             }
@@ -1737,7 +1741,7 @@ static int solve_one(work_t* w, int warm) {
                 ls_used = ls;
                 if (ls > 0 && alpha < a_min * a_p) break;
                 double lg;
-                trial_point(w, alpha, ds, st, cct, &ft, &tht, &lg);
+                trial_point(w, alpha, ds, st, cct, &ft, &tht, &lg); CNT(1, 1);
                 double phit = ft - mu * lg;
                 int okf = isfinite(phit) && tht <= theta_max;
                 for (int f = 0; f < nfilt && okf; ++f) if (!(tht <= (1 - g_th) * fth[f] || phit <= fph[f] - g_ph * fth[f])) okf = 0;
@@ -1790,7 +1794,7 @@ static int solve_one(work_t* w, int warm) {
                 fth[nfilt] = theta; fph[nfilt] = phi_cur; ++nfilt;
             }
             if (!accepted) {
-                ++nresto;
+                ++nresto; CNT(2, 1); CNT(3, ls_used + 1);
                 /* no restoration phase: empty the filter and take the last trial step */
                 nfilt = 0;
                 double lg; trial_point(w, alpha, ds, st, cct, &ft, &tht, &lg);
@@ -1802,7 +1806,7 @@ static int solve_one(work_t* w, int warm) {
         if (acc_tol > 0 && (!accepted || alpha < 1e-6 * a_p) && e0 <= acc_tol) { status = 0; break; }
         if (!accepted && alpha * dzmax < 1e-14) { status = 2; break; }
         if (g_trace) printf("%3d mu %.2e e0 %.3e th %.3e a_p %.3e alpha %.3e a_d %.3e delta %.1e rho %.2e D %.5f obj %.6f acc %d ls %d soc %d nf %d | rd %.2e rp %.2e cmin/mu %.2e cmax/mu %.2e dzmax %.2e curv %.2e\n", it, mu, e0, theta, a_p, alpha, a_d, delta, w->rho, w->D, fobj, accepted, ls_used, soc_used, nfilt, e.rd, e.rp, e.cmin / mu, e.cmax / mu, dzmax, curv);
-        last_alpha = alpha; last_ad = a_d;
+        last_alpha = alpha; last_ad = a_d; CNT(0, 1);
         /* (experiment) the restoration trigger: the fraction-to-boundary rule has held the primal step below 1e-2 for elastic_trigger iterations in a row while rows are infeasible */
         if (g_algo.elastic_rho > 0 && g_algo.elastic_trigger > 0 && w->erho == 0 && obst_M(w) > 0) {
             if (a_p < g_algo.elastic_ap && e.rp > 1e-3) { if (jam_streak == 0) jam_theta0 = e.theta; ++jam_streak; } else jam_streak = 0;
