@@ -513,6 +513,18 @@ def main():
                                                                    "candidate rule on these 1024 instances is asserted >= 0.95 by tests/test_gpu_closed_loop.py::test_config5_candidates_vs_oracle_rule_fp64_and_mixed (GPUTEST); "
                                                                    "the leg that counts for BASELINE configs[4]")
         l5d.close()
+        if len(kinds) > 1:
+            # the same leg at the PARITY-PRESERVING operating point of the headline: candidate 0 -- the reference's cold start -- runs the reference's 100 iterations, so every instance
+            # that path solves within the reference's budget is answered by it (lowest converged index wins); the hedges keep their caps.  The launch lasts as long as 100 iterations of a wave.
+            caps100 = (100,) + tuple(CAND5_CAPS[1:])
+            l5p = Leg(m, torch, dev, m.config_bicycle_min_time(n5, precision=0, candidates=CAND5_KINDS, candidate_max_iter=caps100, candidate_param=CAND5_PARAMS), B5, m.workloads.bicycle_min_time_inputs(B5))
+            el, kms = l5p.timed(max(2, args.steps // 2), 1)
+            s5, _ = l5p.stats()
+            legs["config5_share_bicycle_n120_fp64_B1024_reference_path_at_100_iterations"] = {
+                "value": B5 * s5["converged_frac"] * max(2, args.steps // 2) / el, "unit": "solves/s", "batch": B5, "ms_per_step": el / max(2, args.steps // 2) * 1e3, "kernel_ms": kms,
+                "caps": list(caps100), "solver": s5, "answered_by_the_reference_path": s5["winner_histogram"][1] / B5,
+                "what": "the fp64 leg above with candidate 0 at the reference's iteration budget instead of 60: the share of answers that are the reference path's own rises, the launch lasts 100 iterations"}
+            l5p.close()
         c5m = m.config_bicycle_min_time(n5, precision=2, **c5kw)
         l5m = Leg(m, torch, dev, c5m, B5, m.workloads.bicycle_min_time_inputs(B5))
         legs["config5_share_bicycle_n120_mixed_B1024"] = leg_summary(l5m, max(2, args.steps // 2), 1, algorithmic_bytes_per_solve(n5, 8), f5, FP32_VECTOR_PEAK_TF, "bicycle_n120_mixed_B1024")
