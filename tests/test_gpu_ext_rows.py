@@ -64,9 +64,12 @@ def test_heading_dependent_footprints_batch_vs_c_oracle(m, c_oracle, name):
     s.close()
 
 
-def test_dynamic_obstacles_batch_vs_c_oracle(m, c_oracle):
-    """a22: one moving circle crossing the path + static points, car-like n = 50 (rows at t = k dt, dt in gradient and Hessian)."""
+@pytest.mark.parametrize("ls", ["filter", "merit"])
+def test_dynamic_obstacles_batch_vs_c_oracle(m, c_oracle, ls):
+    """a22: one moving circle crossing the path + static points, car-like n = 50 (rows at t = k dt, dt in gradient and Hessian); under the default line search (filter) and
+    under MPC_LS_MERIT (the extended kernel level's l1-merit path)."""
     from oracle import se2_nlp as R
+    from mpc_local_planner_amd import _abi as A
     B, n = 192, 50
     x0, xf, up, dtp = m.workloads.carlike_min_time_inputs(B, seed=901, goal_range=(2.0, 5.0))
     no, nv, vt = point_obstacles(x0, xf, 903, n_obst=3, lo=0.5, hi=1.0)
@@ -77,11 +80,11 @@ def test_dynamic_obstacles_batch_vs_c_oracle(m, c_oracle):
     ocfg = R.config_carlike_min_time(n)
     ocfg.enable_dynamic_obstacles, ocfg.min_obstacle_dist, ocfg.force_inclusion_dist, ocfg.cutoff_dist = True, 0.3, 0.5, 2.5
     s = m.BatchSolver(m.config_carlike_min_time(n, enable_dynamic_obstacles=True, min_obstacle_dist=0.3, force_inclusion_dist=0.5, cutoff_dist=2.5,
-                                                max_obstacles=3, max_vertices=1, max_obstacle_rows=4), max_batch=B)
+                                                max_obstacles=3, max_vertices=1, max_obstacle_rows=4, line_search=A.LS_MERIT if ls == "merit" else A.LS_DEFAULT), max_batch=B)
     r = s.solve(x0, xf, up, dtp, obstacles=(no, nv, vt, rad, vel))
-    ref = c_oracle.solve_batch(c_oracle.from_nlp_config(ocfg), x0, xf, up, dtp, obstacles=(no, nv, vt, rad, vel), obst=c_oracle.obst_from_nlp_config(ocfg, 3, 1, 4))
+    ref = c_oracle.solve_batch(c_oracle.from_nlp_config(ocfg, line_search=0 if ls == "merit" else 1), x0, xf, up, dtp, obstacles=(no, nv, vt, rad, vel), obst=c_oracle.obst_from_nlp_config(ocfg, 3, 1, 4))
     _summary(r, ref, B)
-    account(f"dynamic obstacles, B={B}", ocfg, (x0, xf, up, dtp), r, ref, obstacles=(no, nv, vt, rad, vel), max_rows=4)
+    account(f"dynamic obstacles, {ls} line search, B={B}", ocfg, (x0, xf, up, dtp), r, ref, obstacles=(no, nv, vt, rad, vel), max_rows=4)
     s.close()
 
 

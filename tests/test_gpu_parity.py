@@ -770,12 +770,14 @@ def test_long_horizon_bicycle_vs_c_oracle(m, c_oracle):
     s.close()
 
 
-def test_restoration_on_the_device_follows_the_c_oracle(m, c_oracle):
+@pytest.mark.parametrize("ls", ["filter", "merit"])
+def test_restoration_on_the_device_follows_the_c_oracle(m, c_oracle, ls):
     """r05 (DESIGN.md 3.3): the workload of tests/test_oracle_solver.py::test_restoration_for_jammed_clearance_rows_in_both_cpu_solvers (car-like minimum time, n = 30, three
     point obstacles 0.05 .. 0.5 m beside the path, d_min 0.3, reference path alone) on the device, in the LDS form and -- forced -- in the global form: the instances whose iterate
     path the restoration mode changes are known from the C oracle (its experiment switch turns the mode off); on those, and on the whole batch, the device returns the C oracle's
     statuses, its trajectories and (within a few) its iteration counts.  The workload also guards the pivot test of the root system (mpc_core.hpp::riccati_root): measured against the
-    largest entry of the system instead of the pivot's own row, it ended 6 of these 64 solves with MPC_LINSOLVE in their last iterations (r05)."""
+    largest entry of the system instead of the pivot's own row, it ended 6 of these 64 solves with MPC_LINSOLVE in their last iterations (r05).  Under both line searches (r06): the
+    restoration entry resets the filter / the l1 penalty."""
     import ctypes as C
     from oracle import se2_nlp as R
     from mpc_local_planner_amd import _abi as A
@@ -790,22 +792,22 @@ def test_restoration_on_the_device_follows_the_c_oracle(m, c_oracle):
     ocfg.min_obstacle_dist, ocfg.force_inclusion_dist, ocfg.cutoff_dist = 0.3, 0.5, 2.5
     ob = c_oracle.obst_from_nlp_config(ocfg, O, 1, 4)
     lib = c_oracle._load()
-    on = c_oracle.solve_batch(c_oracle.from_nlp_config(ocfg), x0, xf, up, dtp, obstacles=obstacles, obst=ob)
+    on = c_oracle.solve_batch(c_oracle.from_nlp_config(ocfg, line_search=0 if ls == "merit" else 1), x0, xf, up, dtp, obstacles=obstacles, obst=ob)
     try:
         lib.oracle_set_algo(C.c_int(10), C.c_double(0.0))
-        off = c_oracle.solve_batch(c_oracle.from_nlp_config(ocfg), x0, xf, up, dtp, obstacles=obstacles, obst=ob)
+        off = c_oracle.solve_batch(c_oracle.from_nlp_config(ocfg, line_search=0 if ls == "merit" else 1), x0, xf, up, dtp, obstacles=obstacles, obst=ob)
     finally:
         lib.oracle_set_algo(C.c_int(10), C.c_double(1000.0))
     changed = (on[3] != off[3]) | (on[4] != off[4])
     assert changed.sum() >= 4
     for mode in (A.STAGE_AUTO, A.STAGE_GLOBAL):
         s = m.BatchSolver(m.config_carlike_min_time(n, min_obstacle_dist=0.3, force_inclusion_dist=0.5, cutoff_dist=2.5, max_obstacles=O, max_vertices=1, max_obstacle_rows=4,
-                                                    stage_data=mode), max_batch=B)
+                                                    stage_data=mode, line_search=A.LS_MERIT if ls == "merit" else A.LS_DEFAULT), max_batch=B)
         r = s.solve(x0, xf, up, dtp, obstacles=obstacles)
         s.close()
         both = (r.status == 0) & (on[3] == 0)
         err = np.abs(r.x - on[0]).reshape(B, -1).max(1)
-        print(f"[restoration on the device, stage_data {mode}] converged device / oracle {int((r.status == 0).sum())} / {int((on[3] == 0).sum())} (oracle without the mode: {int((off[3] == 0).sum())}); "
+        print(f"[restoration on the device, {ls} line search, stage_data {mode}] converged device / oracle {int((r.status == 0).sum())} / {int((on[3] == 0).sum())} (oracle without the mode: {int((off[3] == 0).sum())}); "
               f"on the {int(changed.sum())} instances the mode changes: same status {int((r.status[changed] == on[3][changed]).sum())}, same iterations {int((r.iters[changed] == on[4][changed]).sum())}, "
               f"max |x - oracle| {err[changed & both].max():.1e}")
         assert (r.status == on[3]).mean() >= 0.97 and (r.status[changed] == on[3][changed]).sum() >= changed.sum() - 1

@@ -96,6 +96,11 @@ def test_device_core_filter_line_search_follows_the_c_oracle(host, c_oracle, nam
     assert (err[both] < 1e-6).mean() >= 0.9 and np.median(err[both]) < 1e-9
     if name != "unicycle_quadratic_n20":
         assert (a[4] != am[4]).any()
+    # ... and the l1 merit (MPC_LS_MERIT) against the C oracle's (oracle_config.line_search = 0)
+    bm = c_oracle.solve_batch(c_oracle.from_nlp_config(mk[1](n), line_search=0), x0, xf, up, dtp)
+    both = (am[3] == 0) & (bm[3] == 0)
+    errm = np.abs(am[0] - bm[0]).reshape(B, -1).max(1)
+    assert (am[3] == bm[3]).mean() >= 0.95 and (am[4] == bm[4])[both].mean() >= 0.9 and np.median(errm[both]) < 1e-9
 
 
 def test_device_core_fp32_is_close_to_fp64(host):
