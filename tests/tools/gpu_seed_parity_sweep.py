@@ -28,6 +28,21 @@ def main():
         print(f"seed {seed}: candidates: device converged {np.mean(rc.status == 0):.4f} oracle rule {np.mean(ost == 0):.4f} equal winners {np.mean(win == owin):.4f}; reference path's answer kept "
               f"{np.mean(np.where(r.status == 0, (win == 0) & (np.abs(rc.x - r.x).reshape(B, -1).max(1) == 0), True)):.4f}")
         account(f"seed {seed}: config 2 with candidates", ocfg, inputs, rc, (ox, ou, od, ost, oit))
+        if os.environ.get("OTHER_CONFIGS", "1") != "0":
+            # the config-5 shape (bicycle, n = 120, global form) and the config-3 shape (unicycle, n = 80, 16 polygons, rows binding) on the same seeds, reference path alone
+            B5 = 512
+            o5 = R.config_bicycle_min_time(120)
+            in5 = m.workloads.bicycle_min_time_inputs(B5, seed=seed)
+            s5 = m.BatchSolver(m.config_bicycle_min_time(120), max_batch=B5)
+            r5 = s5.solve(*in5); s5.close()
+            account(f"seed {seed}: config-5 shape, reference path", o5, in5, r5, CO.solve_batch(CO.from_nlp_config(o5), *in5), min_match=0.9)
+            B3, O, V, M = 512, 16, 6, 4
+            x0, xf, up, dtp, obs = m.workloads.unicycle_obstacle_inputs(B3, seed=seed, n_obst=O, max_vertices=V, lateral=(0.15, 0.8))
+            o3 = R.config_unicycle_quadratic(80)
+            s3 = m.BatchSolver(m.config_unicycle_quadratic(80, max_obstacles=O, max_vertices=V, max_obstacle_rows=M), max_batch=B3)
+            r3 = s3.solve(x0, xf, up, dtp, obstacles=obs); s3.close()
+            account(f"seed {seed}: config-3 shape (rows binding), reference path", o3, (x0, xf, up, dtp), r3,
+                    CO.solve_batch(CO.from_nlp_config(o3), x0, xf, up, dtp, obstacles=obs, obst=CO.obst_from_nlp_config(o3, O, V, M)), obstacles=obs, max_rows=M, min_match=0.9)
 
 
 if __name__ == "__main__":      # (the KKT checker's worker pool spawns: the module must be importable without side effects)
